@@ -1,0 +1,776 @@
+/*
+ * oracle/ilupp_oracle.c -- CPU restatement of the ilupp hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain C99, single-threaded, written from the behavioural spec of the reference (file:line cited
+ * per function, paths relative to /root/reference/src/ilupp unless noted).  Operation ORDER follows
+ * the reference exactly so that results are bit-identical on x86-64 without FMA contraction
+ * (compile with -O2 -ffp-contract=off; see oracle/Makefile).
+ *
+ * Parity PINNED by tests/test_oracle_golden.py against golden vectors emitted by the reference
+ * itself (tests/golden/make_golden.py via oracle/_ref).
+ *
+ * Nothing in the product path (ilupp_amd/, include/) may link, load or call this file.
+ */
+#include "ilupp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+static void mat_init(orc_mat *M, orc_int n, orc_int cap, int is_csr)
+{
+    M->n = n;
+    M->nnz = 0;
+    M->is_csr = is_csr;
+    M->ptr = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));   /* reformat zero-fills pointer (:2531-2540) */
+    M->idx = (orc_int *)malloc(sizeof(orc_int) * (size_t)(cap > 0 ? cap : 1));
+    M->val = (double *)malloc(sizeof(double) * (size_t)(cap > 0 ? cap : 1));
+}
+
+void orc_free_mat(orc_mat *M)
+{
+    if (!M) return;
+    free(M->ptr); free(M->idx); free(M->val);
+    M->ptr = M->idx = NULL; M->val = NULL; M->n = M->nnz = 0;
+}
+
+static void mat_swap(orc_mat *A, orc_mat *B)   /* matrix_sparse::interchange, sparse_implementation.h:3475-3484 */
+{
+    orc_mat t = *A; *A = *B; *B = t;
+}
+
+/* matrix_sparse::compress(threshold), sparse_implementation.h:3696-3722: keep |x| > thr, exact size. */
+static void mat_compress(orc_mat *M, double thr)
+{
+    orc_int counter = 0, i, j, start = 0;
+    for (i = 0; i < M->n; ++i) {
+        orc_int end = M->ptr[i + 1];
+        for (j = start; j < end; ++j) {
+            if (fabs(M->val[j]) > thr) {
+                M->val[counter] = M->val[j];
+                M->idx[counter] = M->idx[j];
+                counter++;
+            }
+        }
+        start = end;
+        M->ptr[i + 1] = counter;
+    }
+    M->nnz = counter;
+    M->idx = (orc_int *)realloc(M->idx, sizeof(orc_int) * (size_t)(counter > 0 ? counter : 1));
+    M->val = (double *)realloc(M->val, sizeof(double) * (size_t)(counter > 0 ? counter : 1));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ILU(0)                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* sparse_vec_update, ILU0.hpp:8-23: two-pointer merge, update only above column k. */
+static void sparse_vec_update(orc_int l1, orc_int u1, orc_int l2, orc_int u2, orc_int k, double l_ik,
+                              const orc_int *indices, double *data_U)
+{
+    while (l1 < u1 && l2 < u2) {
+        if (indices[l1] == indices[l2]) {
+            if (indices[l1] > k)
+                data_U[l1] -= l_ik * data_U[l2];
+            l1++; l2++;
+        } else if (indices[l1] < indices[l2])
+            l1++;
+        else
+            l2++;
+    }
+}
+
+int orc_ilu0(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_mat *L, orc_mat *U)
+{
+    /* compute_ilu0, ILU0.hpp:26-66 */
+    const orc_int nnz = ptr[n];
+    double *LU = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+    double *diag_U = (double *)malloc(sizeof(double) * (size_t)n);
+    orc_int diag_idx = 0, nnzL = 0, nnzU = 0, i, kk;
+
+    for (i = 0; i < n; ++i) {
+        for (kk = ptr[i]; kk < ptr[i + 1]; ++kk) {
+            LU[kk] = val[kk];
+            if (idx[kk] == i) diag_idx = kk;
+            if (idx[kk] <= i) ++nnzL;
+            if (idx[kk] >= i) ++nnzU;
+        }
+        for (kk = ptr[i]; kk < ptr[i + 1]; ++kk) {
+            const orc_int k = idx[kk];
+            double L_ik;
+            if (k >= i) continue;
+            L_ik = LU[kk] / diag_U[k];
+            sparse_vec_update(ptr[i], ptr[i + 1], ptr[k], ptr[k + 1], k, L_ik, idx, LU);
+            LU[kk] = L_ik;
+        }
+        diag_U[i] = LU[diag_idx];
+    }
+
+    /* split, ILU0.hpp:79-98: L = strict lower + unit diagonal LAST; U = diagonal first + upper */
+    mat_init(L, n, nnzL, 1);
+    mat_init(U, n, nnzU, 1);
+    {
+        orc_int iL = 0, iU = 0, k;
+        for (i = 0; i < n; ++i) {
+            for (k = ptr[i]; k < ptr[i + 1]; ++k) {
+                const orc_int j = idx[k];
+                if (j < i) { L->idx[iL] = j; L->val[iL++] = LU[k]; }
+                else       { U->idx[iU] = j; U->val[iU++] = LU[k]; }
+            }
+            L->idx[iL] = i; L->val[iL++] = 1.0;
+            L->ptr[i + 1] = iL;
+            U->ptr[i + 1] = iU;
+        }
+        L->nnz = iL; U->nnz = iU;
+    }
+    free(LU); free(diag_U);
+
+    if (!is_csr) {   /* ILU0.hpp:100-105: we decomposed A^T; swap roles and relabel */
+        mat_swap(L, U);
+        L->is_csr = 0;
+        U->is_csr = 0;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* std::sort as shipped by libstdc++ (bits/stl_algo.h:1855-1957, bits/stl_heap.h), restated    */
+/* for "slot ids ordered by DEcreasing |key|" -- the comparator of dropping.hpp:25-26.         */
+/* Needed because the kept set under magnitude ties is defined by this exact algorithm.        */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct { const double *key; } abs_desc_cmp;
+#define CMP(a, b) (fabs(c->key[(a)]) > fabs(c->key[(b)]))
+
+static void s_unguarded_linear_insert(orc_int *last, const abs_desc_cmp *c)
+{
+    orc_int v = *last;
+    orc_int *next = last - 1;
+    while (CMP(v, *next)) { *last = *next; last = next; --next; }
+    *last = v;
+}
+
+static void s_insertion_sort(orc_int *first, orc_int *last, const abs_desc_cmp *c)
+{
+    orc_int *i;
+    if (first == last) return;
+    for (i = first + 1; i != last; ++i) {
+        if (CMP(*i, *first)) {
+            orc_int v = *i;
+            memmove(first + 1, first, sizeof(orc_int) * (size_t)(i - first));
+            *first = v;
+        } else
+            s_unguarded_linear_insert(i, c);
+    }
+}
+
+static void s_push_heap(orc_int *first, long hole, long top, orc_int v, const abs_desc_cmp *c)
+{
+    long parent = (hole - 1) / 2;
+    while (hole > top && CMP(first[parent], v)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = v;
+}
+
+static void s_adjust_heap(orc_int *first, long hole, long len, orc_int v, const abs_desc_cmp *c)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (CMP(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    s_push_heap(first, hole, top, v, c);
+}
+
+static void s_heapsort(orc_int *first, orc_int *last, const abs_desc_cmp *c)
+{
+    /* __partial_sort(first, last, last): __heap_select == __make_heap here, then __sort_heap */
+    long len = last - first, parent;
+    if (len >= 2) {
+        parent = (len - 2) / 2;
+        for (;;) {
+            orc_int v = first[parent];
+            s_adjust_heap(first, parent, len, v, c);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    while (last - first > 1) {
+        orc_int v;
+        --last;
+        v = *last;
+        *last = *first;
+        s_adjust_heap(first, 0, last - first, v, c);
+    }
+}
+
+static void s_move_median_to_first(orc_int *result, orc_int *a, orc_int *b, orc_int *cc, const abs_desc_cmp *c)
+{
+#define SWAP(p, q) do { orc_int t_ = *(p); *(p) = *(q); *(q) = t_; } while (0)
+    if (CMP(*a, *b)) {
+        if (CMP(*b, *cc)) SWAP(result, b);
+        else if (CMP(*a, *cc)) SWAP(result, cc);
+        else SWAP(result, a);
+    } else if (CMP(*a, *cc)) SWAP(result, a);
+    else if (CMP(*b, *cc)) SWAP(result, cc);
+    else SWAP(result, b);
+}
+
+static orc_int *s_unguarded_partition(orc_int *first, orc_int *last, orc_int *pivot, const abs_desc_cmp *c)
+{
+    for (;;) {
+        while (CMP(*first, *pivot)) ++first;
+        --last;
+        while (CMP(*pivot, *last)) --last;
+        if (!(first < last)) return first;
+        SWAP(first, last);
+        ++first;
+    }
+}
+
+static void s_introsort_loop(orc_int *first, orc_int *last, long depth, const abs_desc_cmp *c)
+{
+    while (last - first > 16) {
+        orc_int *mid, *cut;
+        if (depth == 0) { s_heapsort(first, last, c); return; }
+        --depth;
+        mid = first + (last - first) / 2;
+        s_move_median_to_first(first, first + 1, mid, last - 1, c);
+        cut = s_unguarded_partition(first + 1, last, first, c);
+        s_introsort_loop(cut, last, depth, c);
+        last = cut;
+    }
+}
+
+void orc_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key)
+{
+    abs_desc_cmp cmp, *c = &cmp;
+    orc_int *first = list, *last = list + len;
+    long lg = 0, m = len;
+    cmp.key = key;
+    if (len <= 0) return;
+    while (m > 1) { m >>= 1; ++lg; }          /* std::__lg */
+    s_introsort_loop(first, last, 2 * lg, c);
+    if (last - first > 16) {                  /* __final_insertion_sort */
+        orc_int *i;
+        s_insertion_sort(first, first + 16, c);
+        for (i = first + 16; i != last; ++i) s_unguarded_linear_insert(i, c);
+    } else
+        s_insertion_sort(first, last, c);
+}
+#undef CMP
+#undef SWAP
+
+static int cmp_slot_by_index(const void *a, const void *b, void *ctx)
+{
+    const orc_int *wp = (const orc_int *)ctx;
+    orc_int ia = wp[*(const orc_int *)a], ib = wp[*(const orc_int *)b];
+    return (ia > ib) - (ia < ib);
+}
+
+/* sort kept slots by column index; keys are unique among kept slots (dead slots carry 0 and are
+ * never kept), so any correct sort reproduces dropping.hpp:32-33. */
+static void sort_slots_by_index(orc_int *list, orc_int len, const orc_int *wpointer)
+{
+    orc_int i;
+    /* plain insertion sort for short lists, qsort_r otherwise */
+    if (len <= 32) {
+        for (i = 1; i < len; ++i) {
+            orc_int v = list[i], j = i - 1;
+            while (j >= 0 && wpointer[list[j]] > wpointer[v]) { list[j + 1] = list[j]; --j; }
+            list[j + 1] = v;
+        }
+    } else {
+        qsort_r(list, (size_t)len, sizeof(orc_int), cmp_slot_by_index, (void *)wpointer);
+    }
+}
+
+/* threshold_and_drop, dropping.hpp:8-34 */
+orc_int orc_threshold_and_drop(const double *wdata, const orc_int *wpointer, orc_int wnnz,
+                               orc_int *list, orc_int n, double tau, orc_int from, orc_int to)
+{
+    orc_int len = 0, x;
+    double z = 0.0, norm;
+    if (n <= 0) return 0;
+
+    /* vector_sparse_dynamic::norm2(begin,end), sparse_implementation.h:1087-1093: insertion order */
+    for (x = 0; x < wnnz; ++x)
+        if (from <= wpointer[x] && wpointer[x] < to)
+            z += wdata[x] * wdata[x];
+    norm = sqrt(z);
+
+    for (x = 0; x < wnnz; ++x) {
+        const orc_int i = wpointer[x];
+        if (from <= i && i < to && fabs(wdata[x]) > norm * tau)
+            list[len++] = x;
+    }
+    if (len > n) {
+        orc_sort_slots_by_abs_desc(list, len, wdata);
+        len = n;
+    }
+    sort_slots_by_index(list, len, wpointer);
+    return len;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* working row: vector_sparse_dynamic / vector_sparse_ordered (sparse.h:169-323,               */
+/* sparse_implementation.h:950-1093)                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    orc_int size, nnz;
+    double *data;        /* slot -> value */
+    orc_int *occupancy;  /* index -> slot or -1 */
+    orc_int *pointer;    /* slot -> index (insertion order) */
+    orc_int *heap;       /* ordered variant: binary min-heap of slots keyed by pointer[slot] */
+    orc_int heap_len;
+    int ordered;
+} wvec;
+
+static void wv_init(wvec *w, orc_int m, int ordered)
+{
+    orc_int i;
+    w->size = m; w->nnz = 0; w->ordered = ordered; w->heap_len = 0;
+    /* a slot list can outgrow m only through dead slots (zero_set then re-insert); the reference
+     * would write out of bounds there, we give headroom instead */
+    w->data = (double *)malloc(sizeof(double) * (size_t)(2 * (size_t)m + 16));
+    w->pointer = (orc_int *)malloc(sizeof(orc_int) * (size_t)(2 * (size_t)m + 16));
+    w->occupancy = (orc_int *)malloc(sizeof(orc_int) * (size_t)(m > 0 ? m : 1));
+    w->heap = ordered ? (orc_int *)malloc(sizeof(orc_int) * (size_t)(2 * (size_t)m + 16)) : NULL;
+    for (i = 0; i < m; ++i) w->occupancy[i] = -1;
+}
+
+static void wv_free(wvec *w)
+{
+    free(w->data); free(w->pointer); free(w->occupancy); free(w->heap);
+}
+
+static void wv_heap_push(wvec *w, orc_int slot)
+{
+    /* std::push_heap with comparator "pointer[x] > pointer[y]" => min-heap on index.  Pop order
+     * among equal indices is irrelevant: the only duplicates are dead slots holding 0, which the
+     * ILUT loop skips (ILUT.hpp:239-240). */
+    orc_int hole = w->heap_len++;
+    while (hole > 0) {
+        orc_int parent = (hole - 1) / 2;
+        if (w->pointer[w->heap[parent]] > w->pointer[slot]) {
+            w->heap[hole] = w->heap[parent];
+            hole = parent;
+        } else break;
+    }
+    w->heap[hole] = slot;
+}
+
+static orc_int wv_pop_next_index(wvec *w)   /* sparse.h:313-322 */
+{
+    orc_int top, last, hole, len;
+    if (w->heap_len == 0) return -1;
+    top = w->heap[0];
+    last = w->heap[--w->heap_len];
+    len = w->heap_len;
+    hole = 0;
+    for (;;) {
+        orc_int child = 2 * hole + 1;
+        if (child >= len) break;
+        if (child + 1 < len && w->pointer[w->heap[child + 1]] < w->pointer[w->heap[child]]) child++;
+        if (w->pointer[w->heap[child]] < w->pointer[last]) {
+            w->heap[hole] = w->heap[child];
+            hole = child;
+        } else break;
+    }
+    if (len > 0) w->heap[hole] = last;
+    return top;
+}
+
+/* operator[] (insert-on-miss), sparse_implementation.h:980-994 / sparse.h:298-311; returns slot */
+static orc_int wv_slot(wvec *w, orc_int j)
+{
+    if (w->occupancy[j] < 0) {
+        w->occupancy[j] = w->nnz;
+        w->pointer[w->nnz] = j;
+        w->data[w->nnz] = 0.0;
+        w->nnz++;
+        if (w->ordered) wv_heap_push(w, w->nnz - 1);
+    }
+    return w->occupancy[j];
+}
+
+static void wv_zero_set_index(wvec *w, orc_int j)   /* sparse_implementation.h:1010-1021 */
+{
+    if (w->occupancy[j] >= 0) {
+        w->data[w->occupancy[j]] = 0.0;
+        w->occupancy[j] = -1;
+    }
+}
+
+static void wv_zero_reset(wvec *w)   /* sparse_implementation.h:1036-1040 */
+{
+    orc_int i;
+    for (i = 0; i < w->nnz; ++i) w->occupancy[w->pointer[i]] = -1;
+    w->nnz = 0;
+    w->heap_len = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ILUT (heap variant)                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+static void mat_reserve(orc_mat *M, orc_int need, orc_int *cap)
+{
+    if (need > *cap) {
+        orc_int nc = *cap < 1024 ? 1024 : *cap;
+        while (nc < need) nc = nc + nc / 2 + 16;
+        M->idx = (orc_int *)realloc(M->idx, sizeof(orc_int) * (size_t)nc);
+        M->val = (double *)realloc(M->val, sizeof(double) * (size_t)nc);
+        *cap = nc;
+    }
+}
+
+int orc_ilut(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_int max_fill_in, double threshold, orc_mat *L, orc_mat *U, orc_int *err_row)
+{
+    /* ILUT_heap, ILUT.hpp:199-278.  The reference pre-reserves p(p+1)/2+(n-p)p entries in int32
+     * arithmetic (:214, overflows for large n*p); the restatement grows its arrays instead and so
+     * never raises "insufficient memory reserved" -- documented deviation, SURVEY appendix item 12. */
+    wvec w;
+    orc_int *list_L, *list_U;
+    orc_int i, k, x, capL = 0, capU = 0;
+    int rc = ORC_OK;
+
+    if (max_fill_in < 1) max_fill_in = 1;
+    if (max_fill_in > n) max_fill_in = n;
+
+    wv_init(&w, n, 1);
+    list_L = (orc_int *)malloc(sizeof(orc_int) * (size_t)(2 * (size_t)n + 16));
+    list_U = (orc_int *)malloc(sizeof(orc_int) * (size_t)(2 * (size_t)n + 16));
+    mat_init(L, n, 1, 1);
+    mat_init(U, n, 1, 1);
+    capL = capU = 1;
+
+    for (i = 0; i < n; ++i) {
+        double norm_wL = 0.0;
+        orc_int nL, nU, kk, j, s;
+
+        /* (2.) scatter the row, norm of the strictly-lower part in CSR order (:222-231) */
+        for (k = ptr[i]; k < ptr[i + 1]; ++k) {
+            s = wv_slot(&w, idx[k]);
+            w.data[s] = val[k];
+            if (idx[k] < i) norm_wL += val[k] * val[k];
+        }
+        norm_wL = sqrt(norm_wL);
+
+        /* (3.-9.) eliminate in ascending column order (:234-255) */
+        for (x = wv_pop_next_index(&w); x >= 0; x = wv_pop_next_index(&w)) {
+            double wk;
+            k = w.pointer[x];
+            if (k >= i) break;
+            if (w.data[x] == 0.0) continue;
+            if (fabs(w.data[x]) < threshold * norm_wL) {
+                wv_zero_set_index(&w, k);
+            } else {
+                w.data[x] /= U->val[U->ptr[k]];
+                wk = w.data[x];
+                for (j = U->ptr[k] + 1; j < U->ptr[k + 1]; j++) {
+                    s = wv_slot(&w, U->idx[j]);
+                    w.data[s] -= wk * U->val[j];
+                }
+            }
+        }
+
+        /* (10.) dropping (:259,261) */
+        nL = orc_threshold_and_drop(w.data, w.pointer, w.nnz, list_L, max_fill_in - 1, threshold, 0, i);
+        nU = orc_threshold_and_drop(w.data, w.pointer, w.nnz, list_U, max_fill_in - 1, threshold, i + 1, n);
+
+        /* (11.) L row = kept entries then (i, 1.0)  (append_row_with_suffix :3212-3230) */
+        kk = L->ptr[i];
+        mat_reserve(L, kk + nL + 1, &capL);
+        for (j = 0; j < nL; ++j) { L->val[kk] = w.data[list_L[j]]; L->idx[kk++] = w.pointer[list_L[j]]; }
+        L->val[kk] = 1.0; L->idx[kk++] = i;
+        L->ptr[i + 1] = kk;
+
+        /* (12.) U row = (i, w[i]) then kept entries (append_row_with_prefix :3190-3210);
+         * w[i] inserts a zero slot when the row has no diagonal */
+        s = wv_slot(&w, i);
+        kk = U->ptr[i];
+        mat_reserve(U, kk + nU + 1, &capU);
+        U->val[kk] = w.data[s]; U->idx[kk++] = i;
+        for (j = 0; j < nU; ++j) { U->val[kk] = w.data[list_U[j]]; U->idx[kk++] = w.pointer[list_U[j]]; }
+        U->ptr[i + 1] = kk;
+
+        if (U->val[U->ptr[i]] == 0.0) {      /* :269-270 */
+            if (err_row) *err_row = i;
+            rc = ORC_ERR_ZERO_PIVOT;
+            break;
+        }
+        wv_zero_reset(&w);
+    }
+    wv_free(&w); free(list_L); free(list_U);
+    if (rc != ORC_OK) { orc_free_mat(L); orc_free_mat(U); return rc; }
+
+    L->nnz = L->ptr[n]; U->nnz = U->ptr[n];
+    mat_compress(L, 0.0);   /* :275-276 */
+    mat_compress(U, 0.0);
+
+    if (!is_csr) {   /* binding.cpp:440-444 / preconditioner_implementation.h:999-1001 */
+        mat_swap(L, U);
+        L->is_csr = 0;
+        U->is_csr = 0;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* IChol(0)                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* natural_triangular_part(increasing), sparse_implementation.h:2568-2592 (orientation-agnostic) */
+static void natural_triangular_part(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val,
+                                    int increasing, orc_mat *T, int is_csr)
+{
+    orc_int i, k, cur = 0;
+    mat_init(T, n, ptr[n], is_csr);
+    for (i = 0; i < n; ++i) {
+        for (k = ptr[i]; k < ptr[i + 1]; ++k) {
+            const orc_int j = idx[k];
+            if ((increasing && j <= i) || (!increasing && j >= i)) {
+                T->idx[cur] = j;
+                T->val[cur++] = val[k];
+            }
+        }
+        T->ptr[i + 1] = cur;
+    }
+    T->nnz = cur;
+}
+
+/* sparse_dot_product, IChol.hpp:16-28 */
+static double sparse_dot_product(orc_int l1, orc_int u1, orc_int l2, orc_int u2, const orc_int *indices, const double *data)
+{
+    double result = 0.0;
+    while (l1 < u1 && l2 < u2) {
+        if (indices[l1] == indices[l2]) {
+            result += data[l1] * data[l2];
+            l1++; l2++;
+        } else if (indices[l1] < indices[l2])
+            l1++;
+        else
+            l2++;
+    }
+    return result;
+}
+
+int orc_ichol0(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+               orc_mat *L)
+{
+    /* IChol0, IChol.hpp:63-73: lower part in major order (j <= i), relabelled ROW */
+    orc_int i, k;
+    double *nd;
+    (void)is_csr;
+    natural_triangular_part(n, ptr, idx, val, 1, L, 1);
+    nd = (double *)malloc(sizeof(double) * (size_t)(L->nnz > 0 ? L->nnz : 1));
+
+    /* compute_ichol0, IChol.hpp:33-59 */
+    for (i = 0; i < n; ++i) {
+        for (k = L->ptr[i]; k < L->ptr[i + 1]; ++k) {
+            const orc_int j = L->idx[k];
+            const double dp = sparse_dot_product(L->ptr[i], L->ptr[i + 1] - 1, L->ptr[j], L->ptr[j + 1] - 1, L->idx, nd);
+            const double A_ij = L->val[k];
+            if (j < i) {
+                const double L_jj = nd[L->ptr[j + 1] - 1];
+                nd[k] = (A_ij - dp) / L_jj;
+            } else if (j == i)
+                nd[k] = sqrt(A_ij - dp);
+            else { free(nd); orc_free_mat(L); return ORC_ERR_NOT_TRIANGULAR; }
+        }
+    }
+    memcpy(L->val, nd, sizeof(double) * (size_t)L->nnz);
+    free(nd);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ICholT                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* update_triangular_fields, ILUC.hpp:37-63 */
+static void update_triangular_fields(orc_int k, const orc_int *pointer, const orc_int *indices, orc_int *list, orc_int *first)
+{
+    orc_int h, i, j;
+    for (h = list[k]; h != -1; h = list[h]) first[h] += 1;
+    first[k] = pointer[k] + 1;
+    h = list[k];
+    if (pointer[k] + 1 < pointer[k + 1]) {
+        j = indices[pointer[k] + 1];
+        list[k] = list[j];
+        list[j] = k;
+    }
+    while (h != -1) {
+        i = h;
+        h = list[i];
+        if (first[i] < pointer[i + 1]) {
+            j = indices[first[i]];
+            list[i] = list[j];
+            list[j] = i;
+        }
+    }
+}
+
+int orc_icholt(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+               orc_int add_fill_in, double threshold, orc_mat *L)
+{
+    /* ICholT, IChol.hpp:158-164: keep j >= i in major order, relabel as CSC lower triangle */
+    orc_mat A;
+    const orc_int m = n;
+    orc_int reserved, j, x, k;
+    orc_int *firstL, *listL, *listw;
+    double *D;
+    wvec w;
+    int rc = ORC_OK;
+    (void)is_csr;
+
+    natural_triangular_part(n, ptr, idx, val, 0, &A, 0);
+
+    /* ICholT_tri, IChol.hpp:78-155 */
+    {
+        long a = (long)A.nnz + (long)(add_fill_in > 0 ? add_fill_in : 0) * (long)m;   /* :85-87 (int32 in the reference) */
+        long b = (long)((double)A.nnz * 10.0);
+        long r = a < b ? a : b;
+        reserved = (orc_int)r;
+    }
+    firstL = (orc_int *)malloc(sizeof(orc_int) * (size_t)(m > 0 ? m : 1));
+    listL = (orc_int *)malloc(sizeof(orc_int) * (size_t)(m > 0 ? m : 1));
+    listw = (orc_int *)malloc(sizeof(orc_int) * (size_t)(2 * (size_t)m + 16));
+    D = (double *)calloc((size_t)(m > 0 ? m : 1), sizeof(double));
+    for (j = 0; j < m; ++j) { listL[j] = -1; firstL[j] = 0; }   /* std::vector<Integer>(m) zero-inits firstL */
+    mat_init(L, m, reserved, 0);
+    wv_init(&w, m, 0);
+
+    for (j = 0; j < m; ++j) {
+        double L_jj;
+        orc_int s, col_len, nkeep, kk;
+
+        if (A.ptr[j] >= A.ptr[j + 1] || A.idx[A.ptr[j]] != j) { rc = ORC_ERR_NOT_TRIANGULAR; break; }   /* :105-107 */
+
+        wv_zero_reset(&w);
+        for (x = A.ptr[j]; x < A.ptr[j + 1]; ++x) {
+            s = wv_slot(&w, A.idx[x]);
+            w.data[s] = A.val[x];
+        }
+        D[j] += A.val[A.ptr[j]];
+        L_jj = sqrt(D[j]);
+        w.data[wv_slot(&w, j)] = L_jj;
+
+        for (k = listL[j]; k != -1; k = listL[k]) {   /* :120-132, linked-list order */
+            const double L_jk = L->val[firstL[k]];
+            x = firstL[k];
+            if (L->idx[x] == j) ++x;
+            for (; x < L->ptr[k + 1]; ++x) {
+                s = wv_slot(&w, L->idx[x]);
+                w.data[s] -= L->val[x] * L_jk;
+            }
+        }
+
+        for (x = 0; x < w.nnz; ++x) {   /* :135-141 */
+            const orc_int i = w.pointer[x];
+            if (i > j) {
+                w.data[x] /= L_jj;
+                D[i] -= w.data[x] * w.data[x];
+            }
+        }
+
+        col_len = A.ptr[j + 1] - A.ptr[j];
+        nkeep = orc_threshold_and_drop(w.data, w.pointer, w.nnz, listw, col_len + add_fill_in, threshold, j, m);
+
+        /* append_row, sparse_implementation.h:3170-3186 */
+        kk = L->ptr[j];
+        if (kk + nkeep > reserved) { rc = ORC_ERR_MEMORY; break; }
+        for (x = 0; x < nkeep; ++x) { L->val[kk] = w.data[listw[x]]; L->idx[kk++] = w.pointer[listw[x]]; }
+        L->ptr[j + 1] = kk;
+
+        update_triangular_fields(j, L->ptr, L->idx, listL, firstL);
+    }
+
+    wv_free(&w); free(firstL); free(listL); free(listw); free(D);
+    orc_free_mat(&A);
+    if (rc != ORC_OK) { orc_free_mat(L); return rc; }
+    L->nnz = L->ptr[m];
+    mat_compress(L, -1.0);   /* :153 */
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* triangular solves + apply                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_trisolve(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+                  int form, int use, double *x)
+{
+    /* matrix_sparse::triangular_solve, sparse_implementation.h:4040-4087 */
+    orc_int j, k;
+    const int row = is_csr != 0;
+    if ((form == ORC_LOWER && row && use == ORC_ID) || (form == ORC_UPPER && !row && use == ORC_TRANSPOSE)) {
+        for (k = 0; k < n; k++) {                                   /* T1: forward gather, diagonal last */
+            for (j = ptr[k]; j < ptr[k + 1] - 1; j++) x[k] -= val[j] * x[idx[j]];
+            x[k] /= val[ptr[k + 1] - 1];
+        }
+        return;
+    }
+    if ((form == ORC_LOWER && !row && use == ORC_ID) || (form == ORC_UPPER && row && use == ORC_TRANSPOSE)) {
+        for (k = 0; k < n; k++) {                                   /* T2: forward scatter, diagonal first */
+            x[k] /= val[ptr[k]];
+            for (j = ptr[k] + 1; j < ptr[k + 1]; j++) x[idx[j]] -= val[j] * x[k];
+        }
+        return;
+    }
+    if ((form == ORC_UPPER && row && use == ORC_ID) || (form == ORC_LOWER && !row && use == ORC_TRANSPOSE)) {
+        for (k = n - 1; k >= 0; k--) {                              /* T3: backward gather, diagonal first */
+            for (j = ptr[k] + 1; j < ptr[k + 1]; j++) x[k] -= val[j] * x[idx[j]];
+            x[k] /= val[ptr[k]];
+        }
+        return;
+    }
+    for (k = n - 1; k >= 0; k--) {                                  /* T4: backward scatter, diagonal last */
+        x[k] /= val[ptr[k + 1] - 1];
+        for (j = ptr[k]; j < ptr[k + 1] - 1; j++) x[idx[j]] -= val[j] * x[k];
+    }
+}
+
+void orc_apply_lu(const orc_mat *L, const orc_mat *U, int use, double *x)
+{
+    /* split_preconditioner::apply_preconditioner_only, preconditioner_implementation.h:103-111 */
+    if (use == ORC_ID) {
+        orc_trisolve(L->n, L->ptr, L->idx, L->val, L->is_csr, ORC_LOWER, ORC_ID, x);
+        orc_trisolve(U->n, U->ptr, U->idx, U->val, U->is_csr, ORC_UPPER, ORC_ID, x);
+    } else {
+        orc_trisolve(U->n, U->ptr, U->idx, U->val, U->is_csr, ORC_UPPER, ORC_TRANSPOSE, x);
+        orc_trisolve(L->n, L->ptr, L->idx, L->val, L->is_csr, ORC_LOWER, ORC_TRANSPOSE, x);
+    }
+}
+
+void orc_apply_llt(const orc_mat *L, int use, double *x)
+{
+    /* :381-394: left = solve(LOWER, use), right = solve(LOWER, other_usage(use)) */
+    if (use == ORC_ID) {
+        orc_trisolve(L->n, L->ptr, L->idx, L->val, L->is_csr, ORC_LOWER, ORC_ID, x);
+        orc_trisolve(L->n, L->ptr, L->idx, L->val, L->is_csr, ORC_LOWER, ORC_TRANSPOSE, x);
+    } else {
+        /* TRANSPOSE: right first with other_usage(TRANSPOSE)=ID, then left with TRANSPOSE */
+        orc_trisolve(L->n, L->ptr, L->idx, L->val, L->is_csr, ORC_LOWER, ORC_ID, x);
+        orc_trisolve(L->n, L->ptr, L->idx, L->val, L->is_csr, ORC_LOWER, ORC_TRANSPOSE, x);
+    }
+}

@@ -1,0 +1,87 @@
+/*
+ * oracle/ilupp_oracle.h -- CPU restatement of the ilupp hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle: a plain-C, single-threaded restatement of the reference's
+ * algorithms, operation for operation.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; the product (ilupp_amd) never does.
+ *
+ * Parity is PINNED: tests/test_oracle_golden.py checks every function here bit-for-bit against
+ * golden vectors produced by the reference itself (oracle/_ref, built from /root/reference by
+ * oracle/Makefile; generator tests/golden/make_golden.py).
+ *
+ * All matrices are compressed sparse (CSR or CSC), int32 indices, fp64 values
+ * (reference: declarations.h:49-58).
+ */
+#ifndef ILUPP_ORACLE_H
+#define ILUPP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t orc_int;
+
+/* A compressed sparse matrix; arrays are malloc()ed by the oracle and released with orc_free_mat. */
+typedef struct {
+    orc_int n;        /* square dimension */
+    orc_int nnz;      /* = ptr[n] */
+    orc_int *ptr;     /* n+1 */
+    orc_int *idx;     /* nnz */
+    double  *val;     /* nnz */
+    int      is_csr;  /* 1 = ROW orientation, 0 = COLUMN */
+} orc_mat;
+
+enum { ORC_LOWER = 0, ORC_UPPER = 1 };
+enum { ORC_ID = 0, ORC_TRANSPOSE = 1 };
+
+/* error codes */
+enum {
+    ORC_OK = 0,
+    ORC_ERR_ZERO_PIVOT = 1,      /* ILUT.hpp:269-270; *err_row receives the row */
+    ORC_ERR_NOT_TRIANGULAR = 2,  /* IChol.hpp:54-55, :105-107 */
+    ORC_ERR_MEMORY = 3           /* sparse_implementation.h:3178-3179 ("insufficient memory reserved") */
+};
+
+void orc_free_mat(orc_mat *M);
+
+/* ILU0.hpp:69-106 (compute_ilu0 :26-66, sparse_vec_update :8-23). */
+int orc_ilu0(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_mat *L, orc_mat *U);
+
+/* ILUT.hpp:199-278 (ILUT_heap) + orientation handling of binding.cpp:432-447 /
+ * preconditioner_implementation.h:992-1011; dropping.hpp:8-34. */
+int orc_ilut(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_int max_fill_in, double threshold, orc_mat *L, orc_mat *U, orc_int *err_row);
+
+/* IChol.hpp:63-73 (compute_ichol0 :33-59). */
+int orc_ichol0(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+               orc_mat *L);
+
+/* IChol.hpp:158-164 -> ICholT_tri :78-155. */
+int orc_icholt(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+               orc_int add_fill_in, double threshold, orc_mat *L);
+
+/* sparse_implementation.h:4040-4087: in-place triangular solve, loop chosen by (form, orientation, use). */
+void orc_trisolve(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+                  int form, int use, double *x);
+
+/* preconditioner_implementation.h:103-111 + :321-334: LU apply (ID: L then U; TRANSPOSE: U^T then L^T). */
+void orc_apply_lu(const orc_mat *L, const orc_mat *U, int use, double *x);
+
+/* preconditioner_implementation.h:103-111 + :381-394: LL^T apply. */
+void orc_apply_llt(const orc_mat *L, int use, double *x);
+
+/* libstdc++ std::sort restated (bits/stl_algo.h:1855-1957), exposed for its own unit test:
+ * sorts slot ids `list[0..len)` by DEcreasing |key[slot]|. */
+void orc_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key);
+
+/* dropping.hpp:8-34 on raw working-row arrays; returns the number of kept slots written to `list`. */
+orc_int orc_threshold_and_drop(const double *wdata, const orc_int *wpointer, orc_int wnnz,
+                               orc_int *list, orc_int n, double tau, orc_int from, orc_int to);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,249 @@
+"""oracle/oracle.py -- ctypes front-end to the parity oracle.  TEST INFRASTRUCTURE ONLY.
+
+Loads ``oracle/liborc.so`` (plain-C restatement, prefix ``orc_``) and, when present,
+``oracle/_ref/libilupp_ref.so`` (the real reference behind the same C ABI, prefix ``ref_``).
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import
+this module; the product package ``ilupp_amd`` never does.
+
+Every function takes/returns plain numpy arrays:  a matrix is ``(data, indices, indptr, is_csr)``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+LOWER, UPPER = 0, 1
+ID, TRANSPOSE = 0, 1
+
+OK, ERR_ZERO_PIVOT, ERR_NOT_TRIANGULAR, ERR_MEMORY = 0, 1, 2, 3
+
+
+class _Mat(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("nnz", ctypes.c_int32),
+                ("ptr", ctypes.POINTER(ctypes.c_int32)), ("idx", ctypes.POINTER(ctypes.c_int32)),
+                ("val", ctypes.POINTER(ctypes.c_double)), ("is_csr", ctypes.c_int)]
+
+
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_F64P = ctypes.POINTER(ctypes.c_double)
+
+
+def _p_i32(a):
+    return a.ctypes.data_as(_I32P)
+
+
+def _p_f64(a):
+    return a.ctypes.data_as(_F64P)
+
+
+def build(ref=False):
+    """(Re)build liborc.so, and _ref/libilupp_ref.so when ``ref`` and /root/reference exist."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+    if ref and os.path.isdir("/root/reference/src/ilupp"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code, row=-1):
+        self.code, self.row = code, row
+        msg = {ERR_ZERO_PIVOT: "ILUT_heap: encountered zero pivot in row %d" % row,
+               ERR_NOT_TRIANGULAR: "matrix not in triangular form",
+               ERR_MEMORY: "append_row: insufficient memory reserved"}.get(code, "error %d" % code)
+        super().__init__(msg)
+
+
+class _Lib:
+    """One of the two libraries behind the common ABI."""
+
+    def __init__(self, path, prefix):
+        self.path, self.prefix = path, prefix
+        self.lib = ctypes.CDLL(path)
+        f = self._f
+        mat_in = [ctypes.c_int32, _I32P, _I32P, _F64P, ctypes.c_int]
+        f("ilu0").argtypes = mat_in + [ctypes.POINTER(_Mat), ctypes.POINTER(_Mat)]
+        f("ilut").argtypes = mat_in + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_Mat),
+                                       ctypes.POINTER(_Mat), _I32P]
+        f("ichol0").argtypes = mat_in + [ctypes.POINTER(_Mat)]
+        f("icholt").argtypes = mat_in + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_Mat)]
+        f("trisolve").argtypes = mat_in + [ctypes.c_int, ctypes.c_int, _F64P]
+        f("trisolve").restype = None
+        f("apply_lu").argtypes = [ctypes.POINTER(_Mat), ctypes.POINTER(_Mat), ctypes.c_int, _F64P]
+        f("apply_lu").restype = None
+        f("apply_llt").argtypes = [ctypes.POINTER(_Mat), ctypes.c_int, _F64P]
+        f("apply_llt").restype = None
+        f("free_mat").argtypes = [ctypes.POINTER(_Mat)]
+        f("free_mat").restype = None
+        f("sort_slots_by_abs_desc").argtypes = [_I32P, ctypes.c_int32, _F64P]
+        f("sort_slots_by_abs_desc").restype = None
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    # -- helpers ----------------------------------------------------------------------------
+    @staticmethod
+    def _in(A):
+        data, indices, indptr, is_csr = A
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        n = indptr.shape[0] - 1
+        return (n, _p_i32(indptr), _p_i32(indices), _p_f64(data), int(bool(is_csr))), (data, indices, indptr)
+
+    def _out(self, m):
+        n, nnz = m.n, m.nnz
+        ptr = np.ctypeslib.as_array(m.ptr, shape=(n + 1,)).copy()
+        idx = np.ctypeslib.as_array(m.idx, shape=(max(nnz, 1),))[:nnz].copy()
+        val = np.ctypeslib.as_array(m.val, shape=(max(nnz, 1),))[:nnz].copy()
+        is_csr = bool(m.is_csr)
+        self._f("free_mat")(ctypes.byref(m))
+        return (val, idx, ptr, is_csr)
+
+    @staticmethod
+    def _as_mat(M, keep):
+        data, indices, indptr, is_csr = M
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        keep.extend([data, indices, indptr])
+        m = _Mat()
+        m.n = indptr.shape[0] - 1
+        m.nnz = int(indptr[-1])
+        m.ptr, m.idx, m.val = _p_i32(indptr), _p_i32(indices), _p_f64(data)
+        m.is_csr = int(bool(is_csr))
+        return m
+
+    # -- factorisations ---------------------------------------------------------------------
+    def ilu0(self, A):
+        args, keep = self._in(A)
+        L, U = _Mat(), _Mat()
+        rc = self._f("ilu0")(*args, ctypes.byref(L), ctypes.byref(U))
+        if rc:
+            raise OracleError(rc)
+        return self._out(L), self._out(U)
+
+    def ilut(self, A, fill_in=100, threshold=0.1):
+        args, keep = self._in(A)
+        L, U = _Mat(), _Mat()
+        row = ctypes.c_int32(-1)
+        rc = self._f("ilut")(*args, int(fill_in), float(threshold), ctypes.byref(L), ctypes.byref(U),
+                             ctypes.byref(row))
+        if rc:
+            raise OracleError(rc, row.value)
+        return self._out(L), self._out(U)
+
+    def ichol0(self, A):
+        args, keep = self._in(A)
+        L = _Mat()
+        rc = self._f("ichol0")(*args, ctypes.byref(L))
+        if rc:
+            raise OracleError(rc)
+        return self._out(L)
+
+    def icholt(self, A, add_fill_in=0, threshold=0.0):
+        args, keep = self._in(A)
+        L = _Mat()
+        rc = self._f("icholt")(*args, int(add_fill_in), float(threshold), ctypes.byref(L))
+        if rc:
+            raise OracleError(rc)
+        return self._out(L)
+
+    # -- solves -----------------------------------------------------------------------------
+    def trisolve(self, M, form, use, x):
+        args, keep = self._in(M)
+        x = np.array(x, dtype=np.float64, copy=True).ravel()
+        self._f("trisolve")(*args, int(form), int(use), _p_f64(x))
+        return x
+
+    def apply_lu(self, L, U, x, use=ID):
+        keep = []
+        Lm, Um = self._as_mat(L, keep), self._as_mat(U, keep)
+        x = np.array(x, dtype=np.float64, copy=True).ravel()
+        self._f("apply_lu")(ctypes.byref(Lm), ctypes.byref(Um), int(use), _p_f64(x))
+        return x
+
+    def apply_llt(self, L, x, use=ID):
+        keep = []
+        Lm = self._as_mat(L, keep)
+        x = np.array(x, dtype=np.float64, copy=True).ravel()
+        self._f("apply_llt")(ctypes.byref(Lm), int(use), _p_f64(x))
+        return x
+
+    def sort_slots_by_abs_desc(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.float64)
+        lst = np.arange(keys.shape[0], dtype=np.int32)
+        self._f("sort_slots_by_abs_desc")(_p_i32(lst), lst.shape[0], _p_f64(keys))
+        return lst
+
+
+_orc = None
+_ref = None
+
+
+def orc():
+    """The plain-C restatement (always available; built on demand)."""
+    global _orc
+    if _orc is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        _orc = _Lib(path, "orc_")
+    return _orc
+
+
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libilupp_ref.so"))
+
+
+def ref():
+    """The real reference behind the same ABI (only where oracle/_ref was built)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libilupp_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/_ref/libilupp_ref.so not built (needs /root/reference: make -C oracle ref)")
+        _ref = _Lib(path, "ref_")
+        lib = _ref.lib
+        mat_in = [ctypes.c_int32, _I32P, _I32P, _F64P, ctypes.c_int]
+        lib.ref_total_nnz_lu_generic.argtypes = [ctypes.POINTER(_Mat), ctypes.POINTER(_Mat)]
+        lib.ref_total_nnz_lu_generic.restype = ctypes.c_int32
+        lib.ref_total_nnz_ilut.argtypes = mat_in + [ctypes.c_int32, ctypes.c_double]
+        lib.ref_total_nnz_ilut.restype = ctypes.c_int32
+        lib.ref_ilut_precond_apply.argtypes = mat_in + [ctypes.c_int32, ctypes.c_double, ctypes.c_int, _F64P]
+    return _ref
+
+
+def ref_total_nnz_ilut(A, fill_in, threshold):
+    r = ref()
+    args, keep = r._in(A)
+    return int(r.lib.ref_total_nnz_ilut(*args, int(fill_in), float(threshold)))
+
+
+def ref_ilut_precond_apply(A, fill_in, threshold, x, use=ID):
+    r = ref()
+    args, keep = r._in(A)
+    x = np.array(x, dtype=np.float64, copy=True).ravel()
+    rc = r.lib.ref_ilut_precond_apply(*args, int(fill_in), float(threshold), int(use), _p_f64(x))
+    if rc:
+        raise OracleError(rc)
+    return x
+
+
+def as_scipy(M):
+    """(data, indices, indptr, is_csr) -> scipy matrix (test convenience)."""
+    import scipy.sparse as sp
+    data, indices, indptr, is_csr = M
+    n = indptr.shape[0] - 1
+    cls = sp.csr_matrix if is_csr else sp.csc_matrix
+    return cls((data, indices, indptr), shape=(n, n))
+
+
+def from_scipy(A):
+    """scipy csr/csc -> (data, indices, indptr, is_csr) with sorted int32 indices."""
+    import scipy.sparse as sp
+    A = A.copy()
+    A.sort_indices()
+    return (A.data.astype(np.float64), A.indices.astype(np.int32), A.indptr.astype(np.int32),
+            isinstance(A, sp.csr_matrix))

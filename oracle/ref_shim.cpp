@@ -1,0 +1,186 @@
+/*
+ * oracle/ref_shim.cpp -- C-ABI shim over the REAL reference (c-f-h/ilupp), TEST INFRASTRUCTURE ONLY.
+ *
+ * Compiled by oracle/Makefile against the reference headers where they lie (-I/root/reference/src);
+ * no reference source is copied into this repository.  The resulting oracle/_ref/libilupp_ref.so is
+ * used (1) to pin oracle/ilupp_oracle.c, (2) to emit tests/golden/*.npz, (3) as the "reference" CPU
+ * baseline of bench.py.  It calls exactly the functions the reference's own binding calls
+ * (src/binding.cpp:366-447) and the same preconditioner classes for apply (binding.cpp:237-254).
+ *
+ * The exported signatures are identical to oracle/ilupp_oracle.h (prefix ref_ instead of orc_).
+ */
+#include "ilupp/iluplusplus_interface.cpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "ilupp_oracle.h"
+
+using namespace iluplusplus;
+
+namespace {
+
+void export_mat(const matrix &M, orc_mat *out)
+{
+    const Integer n = M.rows();
+    const Integer nnz = M.actual_non_zeroes();
+    out->n = n;
+    out->nnz = nnz;
+    out->is_csr = (M.orient() == ROW) ? 1 : 0;
+    out->ptr = (orc_int *)std::malloc(sizeof(orc_int) * (size_t)(n + 1));
+    out->idx = (orc_int *)std::malloc(sizeof(orc_int) * (size_t)(nnz > 0 ? nnz : 1));
+    out->val = (double *)std::malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+    for (Integer i = 0; i <= n; ++i) out->ptr[i] = M.read_pointer(i);
+    for (Integer i = 0; i < nnz; ++i) { out->idx[i] = M.read_index(i); out->val[i] = M.read_data(i); }
+}
+
+matrix view(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr)
+{
+    return matrix(const_cast<double *>(val), const_cast<Integer *>(idx), const_cast<Integer *>(ptr),
+                  n, n, is_csr ? ROW : COLUMN, true);
+}
+
+}  // namespace
+
+extern "C" {
+
+void ref_free_mat(orc_mat *M)
+{
+    if (!M) return;
+    std::free(M->ptr); std::free(M->idx); std::free(M->val);
+    M->ptr = M->idx = nullptr; M->val = nullptr;
+}
+
+int ref_ilu0(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_mat *Lo, orc_mat *Uo)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    matrix L, U;
+    ILU0(A, L, U);                                   // binding.cpp:421-430
+    export_mat(L, Lo); export_mat(U, Uo);
+    return ORC_OK;
+}
+
+int ref_ilut(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_int max_fill_in, double threshold, orc_mat *Lo, orc_mat *Uo, orc_int *err_row)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    matrix L, U;
+    Real time;
+    try {
+        ILUT_heap(A, L, U, max_fill_in, threshold, time);   // binding.cpp:432-447
+    } catch (const std::runtime_error &e) {
+        const char *p = std::strstr(e.what(), "row ");
+        if (err_row) *err_row = p ? (orc_int)std::atoi(p + 4) : -1;
+        return ORC_ERR_ZERO_PIVOT;
+    }
+    if (!is_csr) {
+        L.interchange(U);
+        L.transpose_in_place();
+        U.transpose_in_place();
+    }
+    export_mat(L, Lo); export_mat(U, Uo);
+    return ORC_OK;
+}
+
+int ref_ichol0(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, orc_mat *Lo)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    try {
+        matrix L = IChol0(A);                        // binding.cpp:399-408
+        export_mat(L, Lo);
+    } catch (const std::logic_error &) {
+        return ORC_ERR_NOT_TRIANGULAR;
+    }
+    return ORC_OK;
+}
+
+int ref_icholt(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+               orc_int add_fill_in, double threshold, orc_mat *Lo)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    try {
+        matrix L = ICholT(A, add_fill_in, threshold);   // binding.cpp:410-419
+        export_mat(L, Lo);
+    } catch (const std::logic_error &) {
+        return ORC_ERR_NOT_TRIANGULAR;
+    } catch (const std::runtime_error &) {
+        return ORC_ERR_MEMORY;
+    }
+    return ORC_OK;
+}
+
+void ref_trisolve(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+                  int form, int use, double *x)
+{
+    matrix M = view(n, ptr, idx, val, is_csr);
+    vector v(n, x, true);
+    M.triangular_solve(form == ORC_LOWER ? LOWER_TRIANGULAR : UPPER_TRIANGULAR,
+                       use == ORC_ID ? ID : TRANSPOSE, v);
+}
+
+/* apply through the reference's own preconditioner classes, as binding.cpp:237-254 does */
+void ref_apply_lu(const orc_mat *L, const orc_mat *U, int use, double *x)
+{
+    matrix Lm = view(L->n, L->ptr, L->idx, L->val, L->is_csr);
+    matrix Um = view(U->n, U->ptr, U->idx, U->val, U->is_csr);
+    matrix Lc(Lm), Uc(Um);
+    indirect_split_triangular_preconditioner<Real, matrix, vector> P(std::move(Lc), LOWER_TRIANGULAR, std::move(Uc), UPPER_TRIANGULAR);
+    vector v(L->n, x, true);
+    P.apply_preconditioner_only(use == ORC_ID ? ID : TRANSPOSE, v);
+}
+
+void ref_apply_llt(const orc_mat *L, int use, double *x)
+{
+    matrix Lm = view(L->n, L->ptr, L->idx, L->val, L->is_csr);
+    matrix Lc(Lm);
+    indirect_split_triangular_symmetric_preconditioner<Real, matrix, vector> P(std::move(Lc), LOWER_TRIANGULAR);
+    vector v(L->n, x, true);
+    P.apply_preconditioner_only(use == ORC_ID ? ID : TRANSPOSE, v);
+}
+
+/* total_nnz conventions as the Python-visible objects report them */
+orc_int ref_total_nnz_lu_generic(const orc_mat *L, const orc_mat *U)
+{
+    matrix Lm = view(L->n, L->ptr, L->idx, L->val, L->is_csr);
+    matrix Um = view(U->n, U->ptr, U->idx, U->val, U->is_csr);
+    matrix Lc(Lm), Uc(Um);
+    indirect_split_triangular_preconditioner<Real, matrix, vector> P(std::move(Lc), LOWER_TRIANGULAR, std::move(Uc), UPPER_TRIANGULAR);
+    return P.total_nnz();
+}
+
+orc_int ref_total_nnz_ilut(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+                           orc_int max_fill_in, double threshold)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    try {
+        ILUTPreconditioner<Real, matrix, vector> P(A, max_fill_in, threshold);
+        return P.total_nnz();
+    } catch (...) {
+        return -1;
+    }
+}
+
+/* full ILUT preconditioner path (ctor + apply), preconditioner_implementation.h:992-1011 */
+int ref_ilut_precond_apply(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+                           orc_int max_fill_in, double threshold, int use, double *x)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    try {
+        ILUTPreconditioner<Real, matrix, vector> P(A, max_fill_in, threshold);
+        vector v(n, x, true);
+        P.apply_preconditioner_only(use == ORC_ID ? ID : TRANSPOSE, v);
+    } catch (...) {
+        return ORC_ERR_ZERO_PIVOT;
+    }
+    return ORC_OK;
+}
+
+/* libstdc++'s own std::sort with the comparator of dropping.hpp:25-26, to pin orc_sort_slots_by_abs_desc */
+void ref_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key)
+{
+    std::sort(list, list + len, [&](orc_int x, orc_int y) { return std::abs(key[x]) > std::abs(key[y]); });
+}
+
+}  // extern "C"
