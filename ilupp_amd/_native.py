@@ -1,0 +1,299 @@
+"""ctypes binding of include/ilupp_hip.h (the C ABI of the MI355X engine).
+
+This module plays the role of the reference's compiled extension ``ilupp._ilupp``
+(src/binding.cpp): same function names, positional signatures, return kinds and exception
+types/messages for the hot-path subset.  There is NO CPU fallback: if the HIP library is missing
+or no GPU is visible, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libilupp_hip.so")
+
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_F64P = ctypes.POINTER(ctypes.c_double)
+_VP = ctypes.c_void_p
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("analysis_ms", ctypes.c_float), ("numeric_ms", ctypes.c_float),
+                ("last_apply_ms", ctypes.c_float), ("numeric_kernel_ms", ctypes.c_float),
+                ("lsolve_kernel_ms", ctypes.c_float), ("usolve_kernel_ms", ctypes.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libilupp_hip.so (built in-tree by `make -C ilupp_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("ilupp_amd: %s not found -- build the HIP extension first "
+                          "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+                          % _LIB_PATH)
+    L = ctypes.CDLL(_LIB_PATH)
+    L.ilupp_hip_index_size.restype = ctypes.c_int
+    L.ilupp_hip_last_error.restype = ctypes.c_char_p
+    L.ilupp_hip_set_device.argtypes = [ctypes.c_int]
+    L.ilupp_hip_device_count.restype = ctypes.c_int
+    mat_host = [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int]
+    L.ilupp_hip_ilu0_create.argtypes = mat_host + [ctypes.POINTER(_VP)]
+    L.ilupp_hip_ilu0_create_device.argtypes = mat_host + [ctypes.POINTER(_VP)]
+    L.ilupp_hip_ilu0_refactor_device.argtypes = [_VP, _VP, _VP, _VP]
+    L.ilupp_hip_ilut_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_ichol0_create.argtypes = mat_host + [ctypes.POINTER(_VP)]
+    L.ilupp_hip_icholt_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_destroy.argtypes = [_VP]
+    L.ilupp_hip_destroy.restype = None
+    L.ilupp_hip_apply.argtypes = [_VP, _VP, ctypes.c_int64]
+    L.ilupp_hip_apply_trans.argtypes = [_VP, _VP, ctypes.c_int64]
+    L.ilupp_hip_apply_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    L.ilupp_hip_sync.argtypes = [_VP]
+    L.ilupp_hip_total_nnz.argtypes = [_VP]
+    L.ilupp_hip_total_nnz.restype = ctypes.c_int64
+    for name in ("memory_used_calculations", "memory_allocated_calculations", "memory"):
+        f = getattr(L, "ilupp_hip_" + name)
+        f.argtypes = [_VP]
+        f.restype = ctypes.c_double
+    L.ilupp_hip_exists.argtypes = [_VP]
+    L.ilupp_hip_special_info.argtypes = [_VP]
+    L.ilupp_hip_special_info.restype = ctypes.c_char_p
+    L.ilupp_hip_print_info.argtypes = [_VP]
+    L.ilupp_hip_print_info.restype = None
+    L.ilupp_hip_dimension.argtypes = [_VP]
+    L.ilupp_hip_dimension.restype = ctypes.c_int32
+    L.ilupp_hip_num_factors.argtypes = [_VP]
+    L.ilupp_hip_factor_info.argtypes = [_VP, ctypes.c_int, _I32P, _I32P, ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_int)]
+    L.ilupp_hip_factor_copy.argtypes = [_VP, ctypes.c_int, _VP, _VP, _VP]
+    L.ilupp_hip_factor_device_ptrs.argtypes = [_VP, ctypes.c_int, ctypes.POINTER(_VP), ctypes.POINTER(_VP),
+                                               ctypes.POINTER(_VP)]
+    L.ilupp_hip_get_timings.argtypes = [_VP, ctypes.POINTER(Timings)]
+    _lib = L
+    return L
+
+
+# names every symbol include/ilupp_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ilupp_hip_index_size", "ilupp_hip_last_error", "ilupp_hip_set_device", "ilupp_hip_device_count",
+    "ilupp_hip_ilu0_create", "ilupp_hip_ilu0_create_device", "ilupp_hip_ilut_create",
+    "ilupp_hip_ichol0_create", "ilupp_hip_icholt_create", "ilupp_hip_destroy",
+    "ilupp_hip_apply", "ilupp_hip_apply_trans", "ilupp_hip_apply_device", "ilupp_hip_total_nnz",
+    "ilupp_hip_memory_used_calculations", "ilupp_hip_memory_allocated_calculations", "ilupp_hip_memory",
+    "ilupp_hip_exists", "ilupp_hip_special_info", "ilupp_hip_print_info", "ilupp_hip_dimension",
+    "ilupp_hip_num_factors", "ilupp_hip_factor_info", "ilupp_hip_factor_copy",
+    "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
+    "ilupp_hip_sync",
+]
+
+
+def index_size():
+    """binding.cpp:279"""
+    return lib().ilupp_hip_index_size()
+
+
+def _raise(rc):
+    msg = lib().ilupp_hip_last_error().decode()
+    if rc == -8:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)          # pybind11 maps std::exception -> RuntimeError
+
+
+# ---- buffer validation: the checks of make_matrix / make_vector (binding.cpp:33-98) ----------------
+def _check_1d_contiguous(a, name):
+    mv = memoryview(a)
+    if mv.ndim != 1:
+        raise RuntimeError("Expected 1D array for %s!" % name)
+    if mv.strides[0] != mv.itemsize:
+        raise RuntimeError("Expected contiguous array for %s!" % name)
+    return mv
+
+
+def _check_real(a, name):
+    mv = _check_1d_contiguous(a, name)
+    if mv.format != "d":
+        raise RuntimeError("Expected d (d) array for %s, got %s!" % (name, mv.format))
+    return mv
+
+
+def _check_int(a, name):
+    mv = _check_1d_contiguous(a, name)
+    if not (len(mv.format) == 1 and mv.format in "ilq" and mv.itemsize == 4):
+        raise RuntimeError("Expected integer type with length 4 for %s, got %s!" % (name, mv.format))
+    return mv
+
+
+def _matrix_args(A_data, A_indices, A_indptr, is_csr):
+    d = _check_real(A_data, "A_data")
+    i = _check_int(A_indices, "A_indices")
+    p = _check_int(A_indptr, "A_indptr")
+    if p.shape[0] <= 1:
+        raise RuntimeError("matrix has size 0!")
+    if i.shape[0] != d.shape[0]:
+        raise RuntimeError("indices and data should have the same size!")
+    n = p.shape[0] - 1
+    da = np.frombuffer(d, dtype=np.float64) if d.shape[0] else np.zeros(0)
+    ia = np.frombuffer(i, dtype=np.int32) if i.shape[0] else np.zeros(0, dtype=np.int32)
+    pa = np.frombuffer(p, dtype=np.int32)
+    return (da.ctypes.data, ia.ctypes.data, pa.ctypes.data, n, 1 if is_csr else 0), (da, ia, pa)
+
+
+class Preconditioner:
+    """Native preconditioner object: the members of wrapPreconditioner<P> (binding.cpp:233-264)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.ilupp_hip_destroy(h)
+
+    def _vec(self, x):
+        mv = _check_real(x, "b")
+        if mv.readonly:
+            raise RuntimeError("b must be writable")
+        return np.frombuffer(mv, dtype=np.float64)
+
+    def apply(self, x):
+        a = self._vec(x)
+        if a.shape[0] != lib().ilupp_hip_dimension(self._h):
+            raise RuntimeError("vector has wrong size for preconditioner!")
+        rc = lib().ilupp_hip_apply(self._h, a.ctypes.data, a.shape[0])
+        if rc:
+            _raise(rc)
+
+    def apply_trans(self, x):
+        a = self._vec(x)
+        if a.shape[0] != lib().ilupp_hip_dimension(self._h):
+            raise RuntimeError("vector has wrong size for preconditioner!")
+        rc = lib().ilupp_hip_apply_trans(self._h, a.ctypes.data, a.shape[0])
+        if rc:
+            _raise(rc)
+
+    def apply_device(self, dptr, n, transpose=False, sync=True):
+        """apply on a device pointer (int address in this GPU's HBM)"""
+        rc = lib().ilupp_hip_apply_device(self._h, dptr, n, 1 if transpose else 0, 1 if sync else 0)
+        if rc:
+            _raise(rc)
+
+    def sync(self):
+        rc = lib().ilupp_hip_sync(self._h)
+        if rc:
+            _raise(rc)
+
+    def refactor_device(self, d_data, d_indices, d_indptr):
+        rc = lib().ilupp_hip_ilu0_refactor_device(self._h, d_data, d_indices, d_indptr)
+        if rc:
+            _raise(rc)
+
+    @property
+    def total_nnz(self):
+        return int(lib().ilupp_hip_total_nnz(self._h))
+
+    @property
+    def memory_used_calculations(self):
+        return lib().ilupp_hip_memory_used_calculations(self._h)
+
+    @property
+    def memory_allocated_calculations(self):
+        return lib().ilupp_hip_memory_allocated_calculations(self._h)
+
+    @property
+    def memory(self):
+        return lib().ilupp_hip_memory(self._h)
+
+    @property
+    def exists(self):
+        return bool(lib().ilupp_hip_exists(self._h))
+
+    @property
+    def special_info(self):
+        return lib().ilupp_hip_special_info(self._h).decode()
+
+    def print_info(self):
+        lib().ilupp_hip_print_info(self._h)
+
+    def factors_info(self):
+        """list of (data, indices, indptr, is_csr, rows, cols), as wrap_matrix builds (binding.cpp:118-133)"""
+        out = []
+        L = lib()
+        for k in range(L.ilupp_hip_num_factors(self._h)):
+            rows, cols = ctypes.c_int32(), ctypes.c_int32()
+            nnz, is_csr = ctypes.c_int64(), ctypes.c_int()
+            rc = L.ilupp_hip_factor_info(self._h, k, ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(nnz),
+                                         ctypes.byref(is_csr))
+            if rc:
+                _raise(rc)
+            data = np.empty(nnz.value, dtype=np.float64)
+            indices = np.empty(nnz.value, dtype=np.int32)
+            indptr = np.empty(rows.value + 1, dtype=np.int32)
+            rc = L.ilupp_hip_factor_copy(self._h, k, data.ctypes.data, indices.ctypes.data, indptr.ctypes.data)
+            if rc:
+                _raise(rc)
+            out.append((data, indices, indptr, bool(is_csr.value), rows.value, cols.value))
+        return out
+
+    def timings(self):
+        t = Timings()
+        lib().ilupp_hip_get_timings(self._h, ctypes.byref(t))
+        return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+
+def _create(fn, A_data, A_indices, A_indptr, is_csr, *extra):
+    args, keep = _matrix_args(A_data, A_indices, A_indptr, is_csr)
+    h = _VP()
+    rc = fn(*args, *extra, ctypes.byref(h))
+    if rc:
+        _raise(rc)
+    return Preconditioner(h)
+
+
+# ---- factories, binding.cpp:299-310, 366-397 ------------------------------------------------------
+def ILU0Preconditioner(A_data, A_indices, A_indptr, is_csr):
+    return _create(lib().ilupp_hip_ilu0_create, A_data, A_indices, A_indptr, is_csr)
+
+
+def ILU0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr):
+    """ILU(0) of a matrix already resident in HBM (device pointers as ints)."""
+    h = _VP()
+    rc = lib().ilupp_hip_ilu0_create_device(d_data, d_indices, d_indptr, n, 1 if is_csr else 0, ctypes.byref(h))
+    if rc:
+        _raise(rc)
+    return Preconditioner(h)
+
+
+def ILUTPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, threshold):
+    return _create(lib().ilupp_hip_ilut_create, A_data, A_indices, A_indptr, is_csr,
+                   ctypes.c_int32(int(max_fill_in)), ctypes.c_double(float(threshold)))
+
+
+def IChol0Preconditioner(A_data, A_indices, A_indptr, is_csr):
+    return _create(lib().ilupp_hip_ichol0_create, A_data, A_indices, A_indptr, is_csr)
+
+
+def ICholTPreconditioner(A_data, A_indices, A_indptr, is_csr, add_fill_in, threshold):
+    return _create(lib().ilupp_hip_icholt_create, A_data, A_indices, A_indptr, is_csr,
+                   ctypes.c_int32(int(add_fill_in)), ctypes.c_double(float(threshold)))
+
+
+# ---- stand-alone factor functions, binding.cpp:399-447 ----------------------------------------------
+def ilu0(A_data, A_indices, A_indptr, is_csr):
+    return tuple(ILU0Preconditioner(A_data, A_indices, A_indptr, is_csr).factors_info())
+
+
+def ilut(A_data, A_indices, A_indptr, is_csr, fill_in, threshold):
+    return tuple(ILUTPreconditioner(A_data, A_indices, A_indptr, is_csr, fill_in, threshold).factors_info())
+
+
+def ichol0(A_data, A_indices, A_indptr, is_csr):
+    return IChol0Preconditioner(A_data, A_indices, A_indptr, is_csr).factors_info()[0]
+
+
+def icholt(A_data, A_indices, A_indptr, is_csr, add_fill_in, threshold):
+    return ICholTPreconditioner(A_data, A_indices, A_indptr, is_csr, add_fill_in, threshold).factors_info()[0]

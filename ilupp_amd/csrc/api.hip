@@ -1,0 +1,464 @@
+// ilupp_amd/csrc/api.hip -- the C ABI (include/ilupp_hip.h): object lifetime, dispatch of apply()
+// to the sweep kernels, factor egress.  Mirrors the reference's binding layer (src/binding.cpp) and
+// L2 dispatch (preconditioner_implementation.h:103-111, :321-334, :381-394).
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace ilupp {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+void DevMat::release()
+{
+    if (owns) {
+        if (ptr) (void)hipFree(ptr);
+        if (idx) (void)hipFree(idx);
+        if (val) (void)hipFree(val);
+    }
+    ptr = idx = nullptr; val = nullptr; nnz = 0;
+}
+void Schedule::release()
+{
+    if (start) (void)hipFree(start);
+    start = nullptr; nb = 0;
+}
+
+static int report(const HipError &e)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) in %s at %s:%d", (int)e.code, hipGetErrorString(e.code), e.what, e.file, e.line);
+    set_error(buf);
+    return ILUPP_ERR_HIP;
+}
+
+}  // namespace ilupp
+
+using namespace ilupp;
+
+enum { KIND_LU = 0, KIND_LLT = 1 };
+enum { NNZ_GENERIC_LU = 0, NNZ_ILUT = 1, NNZ_LLT = 2 };
+
+struct ilupp_precond {
+    int kind = KIND_LU;
+    int nnz_mode = NNZ_GENERIC_LU;
+    int32_t n = 0;
+    bool input_csc = false;      // factors were computed on the row-major view M = A^T
+    // LU: row-major factors of M.  LLT: Lc = the factor in its stored major order, `llt_diag_last`
+    DevMat Lc, Uc;
+    bool llt_diag_last = true;
+    DevMat LcT, UcT;             // transposed storage, built on first use
+    bool haveT = false;
+    Schedule sA, sL, sU, sUT, sLT;   // factor sweep; fwd(Lc); bwd(Uc); fwd(UcT); bwd(LcT)
+    int32_t max_row_len = 0;
+    double *work = nullptr;      // n, all-sentinel between applies
+    double *xdev = nullptr;      // n, staging for host-vector apply
+    int32_t *done = nullptr;     // n
+    int32_t *ctrl = nullptr;     // 16 ints: [0] err, [1] ilu0 ticket (+ its err in [2]) , [4],[5] solve tickets
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    ilupp_timings tm = {0, 0, 0, 0, 0, 0};
+    bool apply_events_valid = false;
+    int max_lanes = 65536;
+};
+
+namespace {
+
+void destroy_obj(ilupp_precond *p)
+{
+    if (!p) return;
+    p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
+    p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
+    if (p->work) (void)hipFree(p->work);
+    if (p->xdev) (void)hipFree(p->xdev);
+    if (p->done) (void)hipFree(p->done);
+    if (p->ctrl) (void)hipFree(p->ctrl);
+    for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+ilupp_precond *new_obj(int32_t n)
+{
+    ilupp_precond *p = new ilupp_precond();
+    p->n = n;
+    ILUPP_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    for (auto &e : p->ev) ILUPP_HIP(hipEventCreate(&e));
+    ILUPP_HIP(hipMalloc(&p->work, sizeof(double) * (size_t)n));
+    ILUPP_HIP(hipMalloc(&p->done, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(hipMalloc(&p->ctrl, 64));
+    fill_u64(p->stream, reinterpret_cast<unsigned long long *>(p->work), n, kSentinel);
+    p->max_lanes = device_cu_count() * kThreads;
+    return p;
+}
+
+int validate(const int32_t *indptr, int32_t n)
+{
+    if (n <= 0 || indptr == nullptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }   // binding.cpp:80-81
+    return ILUPP_OK;
+}
+
+// ILU(0) of the row-major view held in A (device).  Fills p->Lc/Uc, schedules and timings.
+int ilu0_factor(ilupp_precond *p, const DevMat &A)
+{
+    hipStream_t st = p->stream;
+    hipEvent_t a0 = p->ev[0], a1 = p->ev[1], a2 = p->ev[2];
+    ILUPP_HIP(hipEventRecord(a0, st));
+    int32_t missing = -1;
+    int rc = ilu0_symbolic(st, A, &p->Lc, &p->Uc, &missing);
+    if (rc == ILUPP_ERR_NO_DIAGONAL) {
+        set_error("ILU0: structurally missing diagonal entry in row " + std::to_string(missing));
+        return rc;
+    }
+    if (rc) return rc;
+    // one pass over A's pattern gives the factor-sweep schedule; L shares A's forward cuts and U its
+    // backward cuts (same strictly-lower / strictly-upper patterns)
+    count_cuts_and_schedule(st, A.n, A.ptr, A.idx, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
+    ILUPP_HIP(hipEventRecord(a1, st));
+    float kms = 0.f;
+    rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
+    ILUPP_HIP(hipEventRecord(a2, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
+    p->tm.numeric_kernel_ms = kms;
+    if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out (invalid structure?)");
+    return rc;
+}
+
+void ensure_transposed(ilupp_precond *p)
+{
+    if (p->haveT) return;
+    hipStream_t st = p->stream;
+    if (p->kind == KIND_LU) {
+        transpose_storage(st, p->Uc, &p->UcT);      // lower, diagonal last
+        transpose_storage(st, p->Lc, &p->LcT);      // upper, diagonal first
+        count_cuts_and_schedule(st, p->n, p->UcT.ptr, p->UcT.idx, p->max_lanes, &p->sUT, nullptr, nullptr);
+        count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, nullptr);
+    } else {
+        transpose_storage(st, p->Lc, &p->LcT);
+        if (p->llt_diag_last)   // Lc row-major lower (IChol0): LcT is upper, diagonal first -> backward sweep
+            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, nullptr);
+        else                    // Lc column-major lower (ICholT): LcT is its row-major form, diagonal last -> forward
+            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, &p->sLT, nullptr, nullptr);
+    }
+    p->haveT = true;
+}
+
+// apply on a device vector; `transpose` as in apply_preconditioner_only(use, y)
+int apply_dev(ilupp_precond *p, double *x, int transpose)
+{
+    hipStream_t st = p->stream;
+    ILUPP_HIP(hipMemsetAsync(p->ctrl, 0, 64, st));
+    int32_t *err = p->ctrl, *t1 = p->ctrl + 4, *t2 = p->ctrl + 5;
+    double *y = p->work;
+    if (p->kind == KIND_LU) {
+        // solve with M (= A for CSR input): fwd(Lc) then bwd(Uc)      [CSR/ID, CSC/TRANSPOSE]
+        // solve with M^T:                   fwd(Uc^T) then bwd_desc(Lc^T)  [CSR/TRANSPOSE, CSC/ID]
+        const bool with_MT = (transpose != 0) != p->input_csc;
+        if (!with_MT) {
+            // L has A's strictly-lower pattern, hence A's forward cuts: the factor-sweep schedule serves it
+            const Schedule &sl = p->sL.start ? p->sL : p->sA;
+            ILUPP_HIP(hipEventRecord(p->ev[0], st));
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, sl, x, y, t1, err);
+            ILUPP_HIP(hipEventRecord(p->ev[1], st));
+            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, y, x, t2, err);
+            ILUPP_HIP(hipEventRecord(p->ev[2], st));
+        } else {
+            ensure_transposed(p);
+            ILUPP_HIP(hipEventRecord(p->ev[0], st));
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, x, y, t1, err);
+            ILUPP_HIP(hipEventRecord(p->ev[1], st));
+            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, y, x, t2, err);
+            ILUPP_HIP(hipEventRecord(p->ev[2], st));
+        }
+    } else {
+        // LL^T: apply == apply_trans (preconditioner_implementation.h:381-394)
+        ensure_transposed(p);
+        ILUPP_HIP(hipEventRecord(p->ev[0], st));
+        if (p->llt_diag_last) {       // IChol0: T1(L) then T4(L)
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, x, y, t1, err);
+            ILUPP_HIP(hipEventRecord(p->ev[1], st));
+            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, y, x, t2, err);
+        } else {                      // ICholT: T2(L) then T3(L)
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, x, y, t1, err);
+            ILUPP_HIP(hipEventRecord(p->ev[1], st));
+            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, y, x, t2, err);
+        }
+        ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    }
+    p->apply_events_valid = true;
+    return ILUPP_OK;
+}
+
+int finish_apply(ilupp_precond *p)
+{
+    int32_t err = 0;
+    ILUPP_HIP(hipMemcpyAsync(&err, p->ctrl, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
+    ILUPP_HIP(hipStreamSynchronize(p->stream));
+    if (p->apply_events_valid) {
+        ILUPP_HIP(hipEventElapsedTime(&p->tm.lsolve_kernel_ms, p->ev[0], p->ev[1]));
+        ILUPP_HIP(hipEventElapsedTime(&p->tm.usolve_kernel_ms, p->ev[1], p->ev[2]));
+        ILUPP_HIP(hipEventElapsedTime(&p->tm.last_apply_ms, p->ev[0], p->ev[2]));
+    }
+    if (err) {
+        // a sweep gave up: restore the all-sentinel invariant of the work vector
+        fill_u64(p->stream, reinterpret_cast<unsigned long long *>(p->work), p->n, kSentinel);
+        ILUPP_HIP(hipStreamSynchronize(p->stream));
+        set_error("triangular solve: dependency wait timed out (factor not triangular?)");
+        return ILUPP_ERR_TIMEOUT;
+    }
+    return ILUPP_OK;
+}
+
+int ilu0_create_common(const DevMat &A, int is_csr, ilupp_precond **out)
+{
+    ilupp_precond *p = new_obj(A.n);
+    p->kind = KIND_LU;
+    p->nnz_mode = NNZ_GENERIC_LU;
+    p->input_csc = !is_csr;
+    int rc = ilu0_factor(p, A);
+    if (rc) { destroy_obj(p); return rc; }
+    *out = p;
+    return ILUPP_OK;
+}
+
+}  // namespace
+
+#define API_TRY try {
+#define API_CATCH                                                          \
+    } catch (const ilupp::HipError &e) { return ilupp::report(e); }        \
+    catch (const std::bad_alloc &) { ilupp::set_error("out of host memory"); return ILUPP_ERR_MEMORY; }
+
+extern "C" {
+
+int ilupp_hip_index_size(void) { return (int)sizeof(int32_t); }
+
+const char *ilupp_hip_last_error(void) { return ilupp::g_last_error.c_str(); }
+
+int ilupp_hip_set_device(int device)
+{
+    API_TRY
+    ILUPP_HIP(hipSetDevice(device));
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int ilupp_hip_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int ilupp_hip_ilu0_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                          int32_t n, int is_csr, ilupp_precond **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(hipMalloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(hipMalloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    rc = ilu0_create_common(A, is_csr, out);
+    A.release();
+    return rc;
+    API_CATCH
+}
+
+int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                 int32_t n, int is_csr, ilupp_precond **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+    int32_t nnz32 = 0;
+    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    DevMat A;
+    A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
+    A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+    return ilu0_create_common(A, is_csr, out);
+    API_CATCH
+}
+
+int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices, const int32_t *d_indptr)
+{
+    API_TRY
+    if (!p || p->kind != KIND_LU) { set_error("not an ILU(0) object"); return ILUPP_ERR_INVALID; }
+    DevMat A;
+    A.n = p->n; A.is_csr = true; A.owns = false;
+    A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+    hipStream_t st = p->stream;
+    ILUPP_HIP(hipEventRecord(p->ev[1], st));
+    float kms = 0.f;
+    int rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
+    ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));
+    p->tm.numeric_kernel_ms = kms;
+    p->apply_events_valid = false;
+    if (p->haveT) { p->LcT.release(); p->UcT.release(); p->sUT.release(); p->sLT.release(); p->haveT = false; }
+    if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out");
+    return rc;
+    API_CATCH
+}
+
+int ilupp_hip_ilut_create(const double *, const int32_t *, const int32_t *, int32_t, int, int32_t, double, ilupp_precond **out)
+{
+    if (out) *out = nullptr;
+    set_error("ILUT: HIP path not built yet");
+    return ILUPP_ERR_UNSUPPORTED;
+}
+int ilupp_hip_ichol0_create(const double *, const int32_t *, const int32_t *, int32_t, int, ilupp_precond **out)
+{
+    if (out) *out = nullptr;
+    set_error("IChol0: HIP path not built yet");
+    return ILUPP_ERR_UNSUPPORTED;
+}
+int ilupp_hip_icholt_create(const double *, const int32_t *, const int32_t *, int32_t, int, int32_t, double, ilupp_precond **out)
+{
+    if (out) *out = nullptr;
+    set_error("ICholT: HIP path not built yet");
+    return ILUPP_ERR_UNSUPPORTED;
+}
+
+void ilupp_hip_destroy(ilupp_precond *p) { destroy_obj(p); }
+
+int ilupp_hip_apply_device(ilupp_precond *p, double *d_x, int64_t len, int transpose, int sync)
+{
+    API_TRY
+    if (!p) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    if (len != p->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }   // binding.cpp:241-242
+    int rc = apply_dev(p, d_x, transpose);
+    if (rc) return rc;
+    if (sync) return finish_apply(p);
+    return ILUPP_OK;
+    API_CATCH
+}
+
+static int apply_host(ilupp_precond *p, double *x, int64_t len, int transpose)
+{
+    API_TRY
+    if (!p) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    if (len != p->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }
+    if (!p->xdev) ILUPP_HIP(hipMalloc(&p->xdev, sizeof(double) * (size_t)p->n));
+    ILUPP_HIP(hipMemcpyAsync(p->xdev, x, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
+    int rc = apply_dev(p, p->xdev, transpose);
+    if (rc) return rc;
+    rc = finish_apply(p);
+    if (rc) return rc;
+    ILUPP_HIP(hipMemcpy(x, p->xdev, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToHost));
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int ilupp_hip_apply(ilupp_precond *p, double *x, int64_t len) { return apply_host(p, x, len, 0); }
+int ilupp_hip_apply_trans(ilupp_precond *p, double *x, int64_t len) { return apply_host(p, x, len, 1); }
+
+int64_t ilupp_hip_total_nnz(const ilupp_precond *p)
+{
+    if (!p) return 0;
+    switch (p->nnz_mode) {
+    case NNZ_ILUT: return p->Lc.nnz - p->n + p->Uc.nnz;    // preconditioner_implementation.h:1035-1039
+    case NNZ_LLT: return p->Lc.nnz;                        // preconditioner.h:246-247
+    default: return p->Lc.nnz + p->Uc.nnz;                 // preconditioner.h:208-209
+    }
+}
+double ilupp_hip_memory_used_calculations(const ilupp_precond *) { return 0.0; }        // preconditioner.h:65
+double ilupp_hip_memory_allocated_calculations(const ilupp_precond *) { return 0.0; }
+double ilupp_hip_memory(const ilupp_precond *) { return 0.0; }                          // preconditioner.h:113
+int ilupp_hip_exists(const ilupp_precond *p) { return p ? 1 : 0; }
+const char *ilupp_hip_special_info(const ilupp_precond *) { return ""; }
+int32_t ilupp_hip_dimension(const ilupp_precond *p) { return p ? p->n : 0; }
+
+int ilupp_hip_num_factors(const ilupp_precond *p) { return p ? (p->kind == KIND_LU ? 2 : 1) : 0; }
+
+// which factor the caller sees as #which: CSR input -> [L, U] = [Lc, Uc];
+// CSC input -> L.interchange(U) + relabel (ILU0.hpp:100-105) -> [Uc as csc, Lc as csc]
+static const DevMat *exposed(const ilupp_precond *p, int which, bool *is_csr)
+{
+    if (!p || which < 0 || which >= ilupp_hip_num_factors(p)) return nullptr;
+    if (p->kind == KIND_LLT) { *is_csr = p->Lc.is_csr; return &p->Lc; }
+    if (!p->input_csc) { *is_csr = true; return which == 0 ? &p->Lc : &p->Uc; }
+    *is_csr = false;
+    return which == 0 ? &p->Uc : &p->Lc;
+}
+
+int ilupp_hip_factor_info(const ilupp_precond *p, int which, int32_t *rows, int32_t *cols, int64_t *nnz, int *is_csr)
+{
+    bool csr = true;
+    const DevMat *M = exposed(p, which, &csr);
+    if (!M) { set_error("no such factor"); return ILUPP_ERR_INVALID; }
+    if (rows) *rows = p->n;
+    if (cols) *cols = p->n;
+    if (nnz) *nnz = M->nnz;
+    if (is_csr) *is_csr = csr ? 1 : 0;
+    return ILUPP_OK;
+}
+
+int ilupp_hip_factor_copy(const ilupp_precond *p, int which, double *data, int32_t *indices, int32_t *indptr)
+{
+    API_TRY
+    bool csr = true;
+    const DevMat *M = exposed(p, which, &csr);
+    if (!M) { set_error("no such factor"); return ILUPP_ERR_INVALID; }
+    ILUPP_HIP(hipStreamSynchronize(p->stream));
+    ILUPP_HIP(hipMemcpy(indptr, M->ptr, sizeof(int32_t) * (size_t)(p->n + 1), hipMemcpyDeviceToHost));
+    if (M->nnz > 0) {
+        ILUPP_HIP(hipMemcpy(indices, M->idx, sizeof(int32_t) * (size_t)M->nnz, hipMemcpyDeviceToHost));
+        ILUPP_HIP(hipMemcpy(data, M->val, sizeof(double) * (size_t)M->nnz, hipMemcpyDeviceToHost));
+    }
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double **d_data,
+                                 const int32_t **d_indices, const int32_t **d_indptr)
+{
+    bool csr = true;
+    const DevMat *M = exposed(p, which, &csr);
+    if (!M) { set_error("no such factor"); return ILUPP_ERR_INVALID; }
+    if (d_data) *d_data = M->val;
+    if (d_indices) *d_indices = M->idx;
+    if (d_indptr) *d_indptr = M->ptr;
+    return ILUPP_OK;
+}
+
+void ilupp_hip_print_info(const ilupp_precond *p)
+{
+    if (!p) return;
+    // the reference prints both matrices in full (preconditioner_implementation.h:360-366); we print the summary
+    printf("The left matrix of the preconditioner: %d x %d, nnz=%lld\n", p->n, p->n, (long long)p->Lc.nnz);
+    if (p->kind == KIND_LU)
+        printf("The right matrix of the preconditioner: %d x %d, nnz=%lld\n", p->n, p->n, (long long)p->Uc.nnz);
+}
+
+int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t)
+{
+    if (!p || !t) return ILUPP_ERR_INVALID;
+    *t = p->tm;
+    return ILUPP_OK;
+}
+
+int ilupp_hip_sync(ilupp_precond *p)
+{
+    API_TRY
+    if (!p) return ILUPP_ERR_INVALID;
+    return finish_apply(p);
+    API_CATCH
+}
+
+}  // extern "C"

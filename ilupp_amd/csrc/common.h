@@ -1,0 +1,107 @@
+// ilupp_amd/csrc/common.h -- shared host/device helpers of the MI355X ILU engine (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/ilupp_hip.h"
+
+namespace ilupp {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const std::string &msg);
+struct HipError { hipError_t code; const char *what; const char *file; int line; };
+
+#define ILUPP_HIP(expr)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) throw ilupp::HipError{e_, #expr, __FILE__, __LINE__};          \
+    } while (0)
+
+// ---- device containers ----------------------------------------------------------------------
+// A compressed sparse matrix resident in HBM.  `is_csr` is only the LABEL handed back to the
+// caller (reference: matrix_sparse::orientation); kernels always see "major slices".
+struct DevMat {
+    int32_t n = 0;
+    int64_t nnz = 0;
+    int32_t *ptr = nullptr;   // n+1
+    int32_t *idx = nullptr;   // nnz
+    double *val = nullptr;    // nnz
+    bool is_csr = true;
+    bool owns = true;
+    void release();
+};
+
+// Row-block schedule of one sweep direction: lane s of the persistent grid owns rows
+// [start[b], start[b+1]) with b = s (forward) or nb-1-s (backward).
+struct Schedule {
+    int32_t nb = 0;
+    int32_t *start = nullptr;   // nb+1, ascending
+    void release();
+};
+
+// Sentinel that marks "not yet computed" in solve vectors (data-is-flag hand-off, see sptrsv.hip).
+// A quiet NaN with a payload no arithmetic produces (hardware NaNs are canonical 0x7FF8000000000000).
+static constexpr unsigned long long kSentinel = 0x7FF85EEDC0DE0001ull;
+static constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
+
+// persistent-grid geometry: one 256-thread workgroup per CU
+static constexpr int kThreads = 256;
+
+// ---- device helpers -------------------------------------------------------------------------
+#if defined(__HIPCC__)
+// agent-scope relaxed accesses: global_load/store ... sc1 (bypass the per-CU L1, coherent across XCDs)
+__device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent_f64(const double *p)
+{
+    return __longlong_as_double((long long)ld_agent_u64(reinterpret_cast<const unsigned long long *>(p)));
+}
+__device__ __forceinline__ void st_agent_f64(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_u64(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent_i32(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_i32(int *p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// compiler-only ordering point: keeps payload loads below the poll that guards them
+__device__ __forceinline__ void order_after_poll() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+// every store of this wave has left the CU before the flag that publishes them
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
+// ---- kernels' host entry points (one per .hip file) -------------------------------------------
+struct Ilu0Plan;   // symbolic result, see ilu0.hip
+
+// symbolic.hip
+int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
+                            int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
+void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
+void fill_u64(hipStream_t st, unsigned long long *p, int64_t count, unsigned long long v);
+int device_cu_count();
+
+// ilu0.hip
+int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag);
+int ilu0_numeric(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
+                 int32_t max_row_len, int32_t *d_done, int32_t *d_ctrl, float *kernel_ms);
+
+// sptrsv.hip
+enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRST_DESC = 2 };
+int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, double *rhs_and_reset,
+           double *out, int32_t *d_ticket, int32_t *d_err);
+
+}  // namespace ilupp

@@ -1,0 +1,211 @@
+// ilupp_amd/csrc/symbolic.hip -- pattern analysis shared by all sweeps (gfx950).
+//
+//  * row-block schedule: the persistent sweeps (ilu0.hip, sptrsv.hip) give every lane a contiguous
+//    block of rows that it processes strictly in order, so a dependency on the lane's own previous
+//    row never leaves the lane.  Blocks are cut only where row r does NOT depend on row r-1
+//    (forward) / row r-1 does NOT depend on row r (backward): a chain r-1 -> r -> r+1 ... is serial
+//    work anyway, and cutting inside it would serialise two lanes.  On a lexicographic grid the
+//    chains are the x-lines.
+//  * transposed storage for the scatter-form solves of the reference
+//    (sparse_implementation.h:4055-4065, :4075-4084), built with a stable radix sort.
+//
+// Everything here is streaming integer work: coalesced loads, HBM-bound, no MFMA.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace ilupp {
+
+int device_cu_count()
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ILUPP_HIP(hipGetDevice(&dev));
+    ILUPP_HIP(hipGetDeviceProperties(&prop, dev));
+    return prop.multiProcessorCount;
+}
+
+__global__ void k_fill_u64(unsigned long long *p, int64_t count, unsigned long long v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) p[i] = v;
+}
+
+void fill_u64(hipStream_t st, unsigned long long *p, int64_t count, unsigned long long v)
+{
+    if (count <= 0) return;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)blocks), dim3(256), 0, st, p, count, v);
+}
+
+// first position in [lo,hi) with idx[pos] >= key
+__device__ __forceinline__ int lower_bound_dev(const int32_t *idx, int lo, int hi, int key)
+{
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (idx[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// cutf[r] = 1 iff row r has no entry in column r-1  (a forward block may start at r)
+// cutb[r] = 1 iff row r-1 has no entry in column r  (a backward block may end just above r-1 ... i.e. cut between r-1 and r)
+// stats[0] += #forward cuts, stats[1] += #backward cuts, stats[2] = max row length
+__global__ void k_row_cuts(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                           uint8_t *__restrict__ cutf, uint8_t *__restrict__ cutb, int32_t *__restrict__ stats)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int cf = 0, cb = 0, len = 0;
+    if (r < n) {
+        const int lo = ptr[r], hi = ptr[r + 1];
+        len = hi - lo;
+        int pos = lower_bound_dev(idx, lo, hi, r - 1);
+        bool has_prev = false, has_next = false;
+        for (int q = pos; q < hi && q < pos + 3; ++q) {
+            const int c = idx[q];
+            has_prev |= (c == r - 1);
+            has_next |= (c == r + 1);
+        }
+        cf = (r == 0) ? 1 : (has_prev ? 0 : 1);
+        cutf[r] = (uint8_t)cf;
+        if (r + 1 < n) { cb = has_next ? 0 : 1; cutb[r + 1] = (uint8_t)cb; }
+        if (r == 0) { cutb[0] = 1; cb += 1; }
+    }
+    // wave-level reduction, one atomic per wave
+    const unsigned long long mf = __ballot(cf), mb = __ballot(cb);
+    int mx = len;
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) {
+        // cb may be 2 for r == 0 (cutb[0] and cutb[1]); count it exactly
+        atomicAdd(&stats[0], __popcll(mf));
+        atomicAdd(&stats[1], __popcll(mb));
+        atomicMax(&stats[2], mx);
+    }
+}
+
+// start[b] = first allowed cut in the nominal cell [b*B, (b+1)*B), or the cell's end if the cell
+// lies inside one long chain (the chain is then split at a cell border: correct, merely serial).
+__global__ void k_block_starts(int32_t n, int32_t B, int32_t nb, const uint8_t *__restrict__ cut, int32_t *__restrict__ start)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    if (b == nb) { start[nb] = n; return; }
+    if (b == 0) { start[0] = 0; return; }
+    const int64_t lo = (int64_t)b * B;
+    int64_t hi = lo + B;
+    if (hi > n) hi = n;
+    int64_t s = hi;
+    for (int64_t p = lo; p < hi; ++p)
+        if (cut[p]) { s = p; break; }
+    start[b] = (int32_t)s;
+}
+
+static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t ncuts, int max_lanes, Schedule *sch)
+{
+    // rows per lane: at least n/max_lanes, and about one chain when chains are long
+    int64_t B = ((int64_t)n + max_lanes - 1) / max_lanes;
+    int64_t chain = ncuts > 0 ? ((int64_t)n + ncuts - 1) / ncuts : n;
+    if (chain > B) B = chain;
+    if (B < 1) B = 1;
+    int64_t nb = ((int64_t)n + B - 1) / B;
+    sch->nb = (int32_t)nb;
+    ILUPP_HIP(hipMalloc(&sch->start, sizeof(int32_t) * (size_t)(nb + 1)));
+    hipLaunchKernelGGL(k_block_starts, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st,
+                       n, (int32_t)B, (int32_t)nb, cut, sch->start);
+}
+
+int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
+                            int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len)
+{
+    uint8_t *cutf = nullptr, *cutb = nullptr;
+    int32_t *stats = nullptr;
+    ILUPP_HIP(hipMalloc(&cutf, (size_t)n + 1));
+    ILUPP_HIP(hipMalloc(&cutb, (size_t)n + 1));
+    ILUPP_HIP(hipMalloc(&stats, sizeof(int32_t) * 4));
+    ILUPP_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * 4, st));
+    hipLaunchKernelGGL(k_row_cuts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ptr, idx, cutf, cutb, stats);
+    int32_t h[4];
+    ILUPP_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    if (max_row_len) *max_row_len = h[2];
+    if (fwd) make_schedule(st, n, cutf, h[0], max_lanes, fwd);
+    if (bwd) make_schedule(st, n, cutb, h[1], max_lanes, bwd);
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipFree(cutf));
+    ILUPP_HIP(hipFree(cutb));
+    ILUPP_HIP(hipFree(stats));
+    return ILUPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transposed storage: (ptr, idx, val) of A  ->  the same arrays of A^T, entries of each new major
+// slice in ascending order of the old major index (stable sort by column).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_expand_rows(int32_t n, const int32_t *__restrict__ ptr, int32_t *__restrict__ rowid, int32_t *__restrict__ seq)
+{
+    // one wave per 64 rows would be enough; rows are short, so thread-per-row with a short loop
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int q = ptr[r]; q < ptr[r + 1]; ++q) { rowid[q] = r; seq[q] = q; }
+}
+
+__global__ void k_gather_transposed(int64_t nnz, const int32_t *__restrict__ perm, const int32_t *__restrict__ rowid,
+                                    const double *__restrict__ val, int32_t *__restrict__ tidx, double *__restrict__ tval)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < nnz; e += stride) {
+        const int p = perm[e];
+        tidx[e] = rowid[p];
+        tval[e] = val[p];
+    }
+}
+
+__global__ void k_ptr_from_sorted(int32_t n, int64_t nnz, const int32_t *__restrict__ sorted_cols, int32_t *__restrict__ tptr)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n) return;
+    // first position with sorted_cols[pos] >= c
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (sorted_cols[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    tptr[c] = (int32_t)lo;
+}
+
+void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
+{
+    const int32_t n = A.n;
+    const int64_t nnz = A.nnz;
+    T->n = n; T->nnz = nnz; T->is_csr = !A.is_csr; T->owns = true;
+    ILUPP_HIP(hipMalloc(&T->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(hipMalloc(&T->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMalloc(&T->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    int32_t *rowid, *seq, *keys_out, *perm;
+    const size_t eb = sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1);
+    ILUPP_HIP(hipMalloc(&rowid, eb));
+    ILUPP_HIP(hipMalloc(&seq, eb));
+    ILUPP_HIP(hipMalloc(&keys_out, eb));
+    ILUPP_HIP(hipMalloc(&perm, eb));
+    hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, rowid, seq);
+    size_t tmp_bytes = 0;
+    int end_bit = 1;
+    while ((1ll << end_bit) < (long long)n && end_bit < 31) ++end_bit;
+    ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.idx, keys_out, seq, perm, (int)nnz, 0, end_bit, st));
+    void *tmp = nullptr;
+    ILUPP_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, A.idx, keys_out, seq, perm, (int)nnz, 0, end_bit, st));
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_gather_transposed, dim3((unsigned)blocks), dim3(256), 0, st, nnz, perm, rowid, A.val, T->idx, T->val);
+    hipLaunchKernelGGL(k_ptr_from_sorted, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, n, nnz, keys_out, T->ptr);
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipFree(tmp));
+    ILUPP_HIP(hipFree(rowid)); ILUPP_HIP(hipFree(seq)); ILUPP_HIP(hipFree(keys_out)); ILUPP_HIP(hipFree(perm));
+}
+
+}  // namespace ilupp

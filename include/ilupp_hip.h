@@ -1,0 +1,137 @@
+/*
+ * include/ilupp_hip.h -- C ABI of the MI355X-native incomplete-factorisation engine.
+ *
+ * Drop-in boundary for the hot path of c-f-h/ilupp: every entry point below
+ * replaces one definition of the reference's pybind11 translation unit src/binding.cpp (cited per
+ * function, paths relative to /root/reference).  Plain pointers and sizes only; no torch, numpy or
+ * pybind types.  Indices are int32 (the reference's default `Integer`, declarations.h:49-53), values
+ * fp64.
+ *
+ * All functions return ILUPP_OK (0) or a negative ilupp_status; ilupp_hip_last_error() gives the
+ * message the reference would have thrown (same wording where the reference has one).
+ *
+ * Host-pointer entry points borrow the caller's buffers for the duration of the call only
+ * (binding.cpp:85-89: non-owning views).  `_device` variants take pointers that already live in this
+ * GPU's HBM; they are what bench.py times.
+ */
+#ifndef ILUPP_HIP_H
+#define ILUPP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ilupp_precond ilupp_precond;   /* opaque; owns the factors in HBM */
+
+typedef enum {
+    ILUPP_OK = 0,
+    ILUPP_ERR_INVALID = -1,        /* bad argument (binding.cpp:77-83 "matrix has size 0!", size mismatch) */
+    ILUPP_ERR_WRONG_SIZE = -2,     /* binding.cpp:241-242 "vector has wrong size for preconditioner!" */
+    ILUPP_ERR_ZERO_PIVOT = -3,     /* ILUT.hpp:269-270 "ILUT_heap: encountered zero pivot in row N" */
+    ILUPP_ERR_NOT_TRIANGULAR = -4, /* IChol.hpp:54-55,105-107 */
+    ILUPP_ERR_NO_DIAGONAL = -5,    /* ILU(0): structurally missing diagonal (reference: undefined behaviour, ILU0.hpp:39-40,64) */
+    ILUPP_ERR_HIP = -6,            /* HIP runtime failure */
+    ILUPP_ERR_TIMEOUT = -7,        /* dependency wait exceeded its bound (cyclic/invalid structure) */
+    ILUPP_ERR_UNSUPPORTED = -8,    /* path not built yet in this round */
+    ILUPP_ERR_MEMORY = -9          /* sparse_implementation.h:3178-3179 "insufficient memory reserved" */
+} ilupp_status;
+
+/* binding.cpp:279  m.def("index_size") -> sizeof(Integer) */
+int ilupp_hip_index_size(void);
+
+/* message of the last failure on this thread ("" if none) */
+const char *ilupp_hip_last_error(void);
+
+/* device selection (default 0); one HIP stream per preconditioner object */
+int ilupp_hip_set_device(int device);
+int ilupp_hip_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Factories.  (data, indices, indptr, is_csr) exactly as the reference's make_matrix receives them
+ * (binding.cpp:68-90): n = len(indptr)-1, nnz = indptr[n]; column indices sorted ascending per row
+ * (the Python wrapper guarantees it, ilupp/__init__.py:70).
+ * ------------------------------------------------------------------------------------------- */
+
+/* binding.cpp:366-375  ILU0Preconditioner(data, indices, indptr, is_csr) -> GenericLUPreconditioner
+ * (ILU0.hpp:69-106) */
+int ilupp_hip_ilu0_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                          int32_t n, int is_csr, ilupp_precond **out);
+int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                 int32_t n, int is_csr, ilupp_precond **out);
+
+/* binding.cpp:299-310  ILUTPreconditioner.__init__(..., max_fill_in, threshold)  (ILUT.hpp:199-278) */
+int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                          int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out);
+
+/* binding.cpp:377-386  IChol0Preconditioner(...) -> GenericLLTPreconditioner (IChol.hpp:63-73) */
+int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                            int32_t n, int is_csr, ilupp_precond **out);
+
+/* binding.cpp:388-397  ICholTPreconditioner(..., add_fill_in, threshold) (IChol.hpp:158-164) */
+int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                            int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out);
+
+void ilupp_hip_destroy(ilupp_precond *p);
+
+/* ---------------------------------------------------------------------------------------------
+ * Preconditioner object members (binding.cpp:233-264, wrapPreconditioner<P>)
+ * ------------------------------------------------------------------------------------------- */
+
+/* binding.cpp:237-245 apply(x): in place on a contiguous fp64 buffer of length `len` */
+int ilupp_hip_apply(ilupp_precond *p, double *x, int64_t len);
+/* binding.cpp:246-254 apply_trans(x) */
+int ilupp_hip_apply_trans(ilupp_precond *p, double *x, int64_t len);
+/* the same on a vector that already lives in HBM (asynchronous on the object's stream unless sync!=0) */
+int ilupp_hip_apply_device(ilupp_precond *p, double *d_x, int64_t len, int transpose, int sync);
+
+/* binding.cpp:255  total_nnz  (conventions per class) */
+int64_t ilupp_hip_total_nnz(const ilupp_precond *p);
+/* binding.cpp:257-261 */
+double ilupp_hip_memory_used_calculations(const ilupp_precond *p);
+double ilupp_hip_memory_allocated_calculations(const ilupp_precond *p);
+double ilupp_hip_memory(const ilupp_precond *p);
+int ilupp_hip_exists(const ilupp_precond *p);
+const char *ilupp_hip_special_info(const ilupp_precond *p);
+/* binding.cpp:262 print_info() */
+void ilupp_hip_print_info(const ilupp_precond *p);
+/* pre_image_dimension(), used by the size check binding.cpp:241 */
+int32_t ilupp_hip_dimension(const ilupp_precond *p);
+
+/* ---------------------------------------------------------------------------------------------
+ * Factor egress (binding.cpp:118-175 wrap_matrix / wrap_all_factor_matrices -> factors_info()).
+ * LU objects expose [L, U], LL^T objects [L].
+ * ------------------------------------------------------------------------------------------- */
+int ilupp_hip_num_factors(const ilupp_precond *p);
+int ilupp_hip_factor_info(const ilupp_precond *p, int which, int32_t *rows, int32_t *cols,
+                          int64_t *nnz, int *is_csr);
+/* copies the factor into caller-allocated host arrays of nnz / nnz / rows+1 elements */
+int ilupp_hip_factor_copy(const ilupp_precond *p, int which, double *data, int32_t *indices, int32_t *indptr);
+/* device pointers of a factor (valid while p lives); for GPU-resident callers */
+int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double **d_data,
+                                 const int32_t **d_indices, const int32_t **d_indptr);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hooks used by bench.py (not part of the reference's surface).
+ * Times are GPU milliseconds from hipEvents recorded on the object's stream.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float analysis_ms;   /* symbolic pass: diagonal positions, L/U pattern split, row scheduling */
+    float numeric_ms;    /* numeric factorisation kernel(s) */
+    float last_apply_ms; /* most recent apply / apply_trans on device data */
+    float numeric_kernel_ms;  /* the dominant numeric kernel alone */
+    float lsolve_kernel_ms;   /* forward-solve kernel of the last apply */
+    float usolve_kernel_ms;   /* backward-solve kernel of the last apply */
+} ilupp_timings;
+int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t);
+/* redo the numeric phase on (possibly new) values with the SAME pattern (buffers reused); times it */
+int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices,
+                                   const int32_t *d_indptr);
+/* wait for asynchronous applies (ilupp_hip_apply_device with sync=0) and report their status */
+int ilupp_hip_sync(ilupp_precond *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
