@@ -1,6 +1,7 @@
 // ilupp_amd/csrc/api.hip -- the C ABI (include/ilupp_hip.h): object lifetime, dispatch of apply()
 // to the sweep kernels, factor egress.  Mirrors the reference's binding layer (src/binding.cpp) and
 // L2 dispatch (preconditioner_implementation.h:103-111, :321-334, :381-394).
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -25,7 +26,17 @@ void DevMat::release()
 void Schedule::release()
 {
     if (start) (void)hipFree(start);
-    start = nullptr; nb = 0;
+    if (slot2blk) (void)hipFree(slot2blk);
+    if (blk2slot) (void)hipFree(blk2slot);
+    if (sfirst) (void)hipFree(sfirst);
+    if (scount) (void)hipFree(scount);
+    start = slot2blk = blk2slot = sfirst = scount = nullptr; nb = 0; nslots = 0;
+}
+void Ilu0Program::release()
+{
+    if (prow) (void)hipFree(prow);
+    if (prog) (void)hipFree(prog);
+    prow = prog = nullptr; nwords = 0;
 }
 
 static int report(const HipError &e)
@@ -54,7 +65,12 @@ struct ilupp_precond {
     DevMat LcT, UcT;             // transposed storage, built on first use
     bool haveT = false;
     Schedule sA, sL, sU, sUT, sLT;   // factor sweep; fwd(Lc); bwd(Uc); fwd(UcT); bwd(LcT)
+    Ilu0Program prog;                // ILU(0) update program for sA (empty -> generic kernel)
+    int32_t *prog_f3 = nullptr;      // fixed-size program (short-row matrices): loader/consumer kernel
+    bool compact = false;            // descriptors/program usable (block size and grid within the encoding)
+    int32_t *dL = nullptr, *dU = nullptr, *dUT = nullptr, *dLT = nullptr;   // solve descriptors
     int32_t max_row_len = 0;
+    int32_t max_len_T = 0;       // longest major slice of the transposed storages
     double *work = nullptr;      // n, all-sentinel between applies
     double *xdev = nullptr;      // n, staging for host-vector apply
     int32_t *done = nullptr;     // n
@@ -68,11 +84,16 @@ struct ilupp_precond {
 
 namespace {
 
+bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <= (1 << 17); }
+
 void destroy_obj(ilupp_precond *p)
 {
     if (!p) return;
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
+    p->prog.release();
+    if (p->prog_f3) (void)hipFree(p->prog_f3);
+    for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)hipFree(d);
     if (p->work) (void)hipFree(p->work);
     if (p->xdev) (void)hipFree(p->xdev);
     if (p->done) (void)hipFree(p->done);
@@ -118,9 +139,24 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     // one pass over A's pattern gives the factor-sweep schedule; L shares A's forward cuts and U its
     // backward cuts (same strictly-lower / strictly-upper patterns)
     count_cuts_and_schedule(st, A.n, A.ptr, A.idx, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
+    build_slot_tables(st, &p->sA, true);
+    build_slot_tables(st, &p->sU, false);
+    p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
+    bool have_prog = false;
+    if (p->compact) {
+        static const bool allow_lc = getenv("ILUPP_FACTOR_V2") == nullptr;
+        if (!(allow_lc && A.nnz >= 16 && build_ilu0_program_f3(st, A, p->Uc, p->sA, &p->prog_f3)))
+            have_prog = build_ilu0_program(st, A, p->Uc, p->sA, &p->prog);
+        make_desc(st, p->Lc, p->sA, &p->dL);
+        make_desc(st, p->Uc, p->sU, &p->dU);
+    }
     ILUPP_HIP(hipEventRecord(a1, st));
     float kms = 0.f;
-    rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
+    rc = ILUPP_ERR_UNSUPPORTED;
+    if (p->prog_f3) rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, &kms);
+    else if (have_prog) rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, &kms);
+    if (rc == ILUPP_ERR_UNSUPPORTED)
+        rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
     ILUPP_HIP(hipEventRecord(a2, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
@@ -137,18 +173,27 @@ void ensure_transposed(ilupp_precond *p)
     if (p->kind == KIND_LU) {
         transpose_storage(st, p->Uc, &p->UcT);      // lower, diagonal last
         transpose_storage(st, p->Lc, &p->LcT);      // upper, diagonal first
-        count_cuts_and_schedule(st, p->n, p->UcT.ptr, p->UcT.idx, p->max_lanes, &p->sUT, nullptr, nullptr);
-        count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, nullptr);
+        int32_t m1 = 0, m2 = 0;
+        count_cuts_and_schedule(st, p->n, p->UcT.ptr, p->UcT.idx, p->max_lanes, &p->sUT, nullptr, &m1);
+        count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, &m2);
+        p->max_len_T = m1 > m2 ? m1 : m2;
+        build_slot_tables(st, &p->sUT, true);
+        build_slot_tables(st, &p->sLT, false);
+        if (schedule_is_compact(p->sUT) && schedule_is_compact(p->sLT)) {
+            make_desc(st, p->UcT, p->sUT, &p->dUT);
+            make_desc(st, p->LcT, p->sLT, &p->dLT);
+        }
     } else {
         transpose_storage(st, p->Lc, &p->LcT);
         if (p->llt_diag_last)   // Lc row-major lower (IChol0): LcT is upper, diagonal first -> backward sweep
-            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, nullptr);
+            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, &p->max_len_T);
         else                    // Lc column-major lower (ICholT): LcT is its row-major form, diagonal last -> forward
-            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, &p->sLT, nullptr, nullptr);
+            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, &p->sLT, nullptr, &p->max_len_T);
     }
     p->haveT = true;
 }
 
+#define MAXLEN_OF(M) ((&(M) == &p->LcT || &(M) == &p->UcT) ? p->max_len_T : p->max_row_len)
 // apply on a device vector; `transpose` as in apply_preconditioner_only(use, y)
 int apply_dev(ilupp_precond *p, double *x, int transpose)
 {
@@ -164,16 +209,16 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             // L has A's strictly-lower pattern, hence A's forward cuts: the factor-sweep schedule serves it
             const Schedule &sl = p->sL.start ? p->sL : p->sA;
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, sl, x, y, t1, err);
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, y, x, t2, err);
+            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), y, x, t2, err);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         } else {
             ensure_transposed(p);
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, x, y, t1, err);
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, y, x, t2, err);
+            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), y, x, t2, err);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         }
     } else {
@@ -181,13 +226,13 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
         ensure_transposed(p);
         ILUPP_HIP(hipEventRecord(p->ev[0], st));
         if (p->llt_diag_last) {       // IChol0: T1(L) then T4(L)
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, x, y, t1, err);
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, y, x, t2, err);
+            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), y, x, t2, err);
         } else {                      // ICholT: T2(L) then T3(L)
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, x, y, t1, err);
+            sptrsv(st, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, y, x, t2, err);
+            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), y, x, t2, err);
         }
         ILUPP_HIP(hipEventRecord(p->ev[2], st));
     }
@@ -304,13 +349,22 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     hipStream_t st = p->stream;
     ILUPP_HIP(hipEventRecord(p->ev[1], st));
     float kms = 0.f;
-    int rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
+    int rc = ILUPP_ERR_UNSUPPORTED;
+    if (p->prog_f3) rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, &kms);
+    else if (p->prog.prog) rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, &kms);
+    if (rc == ILUPP_ERR_UNSUPPORTED)
+        rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
     ILUPP_HIP(hipStreamSynchronize(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));
     p->tm.numeric_kernel_ms = kms;
     p->apply_events_valid = false;
-    if (p->haveT) { p->LcT.release(); p->UcT.release(); p->sUT.release(); p->sLT.release(); p->haveT = false; }
+    if (p->haveT) {
+        p->LcT.release(); p->UcT.release(); p->sUT.release(); p->sLT.release();
+        if (p->dUT) (void)hipFree(p->dUT);
+        if (p->dLT) (void)hipFree(p->dLT);
+        p->dUT = p->dLT = nullptr; p->haveT = false;
+    }
     if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out");
     return rc;
     API_CATCH

@@ -37,8 +37,26 @@ struct DevMat {
 // Row-block schedule of one sweep direction: lane s of the persistent grid owns rows
 // [start[b], start[b+1]) with b = s (forward) or nb-1-s (backward).
 struct Schedule {
-    int32_t nb = 0;
+    int32_t nb = 0;             // number of row blocks
+    int32_t B = 1;              // nominal rows per block (start[b] lies in [b*B, (b+1)*B])
     int32_t *start = nullptr;   // nb+1, ascending
+    // placement of blocks on the persistent grid (schedule.hip); slot = workgroup*256 + lane
+    bool fwd = true;
+    int32_t nslots = 0;
+    int32_t *slot2blk = nullptr;   // nslots, -1 = idle lane
+    int32_t *blk2slot = nullptr;   // nb
+    int32_t *sfirst = nullptr;     // nslots: first row of the slot in processing order
+    int32_t *scount = nullptr;     // nslots: number of rows of the slot
+    void release();
+};
+
+// ILU(0) update program (schedule.hip)
+struct Ilu0Program {
+    int32_t *prow = nullptr;    // n+1 word offsets
+    int32_t *prog = nullptr;    // nwords
+    int64_t nwords = 0;
+    int32_t max_words = 0;      // longest record
+    int32_t max_ulen = 0;       // longest U row (diagonal included)
     void release();
 };
 
@@ -85,7 +103,6 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 #endif
 
 // ---- kernels' host entry points (one per .hip file) -------------------------------------------
-struct Ilu0Plan;   // symbolic result, see ilu0.hip
 
 // symbolic.hip
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
@@ -94,14 +111,24 @@ void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
 void fill_u64(hipStream_t st, unsigned long long *p, int64_t count, unsigned long long v);
 int device_cu_count();
 
+// schedule.hip
+void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd);
+void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc);
+bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, Ilu0Program *P);
+bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, int32_t **prog_out);
+int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd, const int32_t *prog_f3,
+                    int32_t *d_ctrl, float *kernel_ms);
+
 // ilu0.hip
+int ilu0_numeric_program(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
+                         const Ilu0Program &P, int32_t max_row_len, int32_t *d_ctrl, float *kernel_ms);
 int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag);
 int ilu0_numeric(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
                  int32_t max_row_len, int32_t *d_done, int32_t *d_ctrl, float *kernel_ms);
 
 // sptrsv.hip
 enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRST_DESC = 2 };
-int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, double *rhs_and_reset,
-           double *out, int32_t *d_ticket, int32_t *d_err);
+int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
+           int32_t max_row_len, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
 }  // namespace ilupp

@@ -198,6 +198,524 @@ k_ilu0_numeric(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aid
 #undef W
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// numeric, program-driven: the production kernel
+// ---------------------------------------------------------------------------------------------
+// Same dataflow as above, but
+//  * the eliminations of a row come from the precomputed update program (schedule.hip): no merge
+//    loop, no index loads, every address known up front;
+//  * a finished U row is handed to consumers of the SAME workgroup through an LDS ring
+//    (ring slot = kloc mod D, seqlock-style tag), which costs ~100 cycles instead of a trip through
+//    the memory fabric; this covers the lane's own previous row and its neighbours in the block grid;
+//  * every U value is its own flag for consumers in OTHER workgroups: U.val starts as all-sentinel,
+//    a value is stored once with a write-through (sc1) store, readers poll with sc1 loads until it
+//    is not the sentinel.  No flag array, no store drain, no fence.
+// LDS per workgroup: working rows maxlen*256*8 B, ring D*maxu*256*8 B, tags D*256*4 B.
+template <int D>
+__global__ void __launch_bounds__(kThreads)
+k_ilu0_numeric_prog(const double *__restrict__ Aval, const int32_t *__restrict__ Aptr,
+                    const int32_t *__restrict__ Lptr, double *__restrict__ Lval,
+                    const int32_t *__restrict__ Uptr, double *Uval,
+                    const int32_t *__restrict__ prow, const int32_t *__restrict__ prog,
+                    int32_t nslots_used, const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount,
+                    int32_t maxlen, int32_t maxu, int32_t *ctrl)
+{
+    // all LDS in the dynamic region so its base stays 16-byte aligned (cdna_hip_programming.md G17)
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    double *w = lds;                                                  // [maxlen][256]
+    volatile double *uring = lds + (size_t)maxlen * kThreads;        // [D][maxu][256]
+    volatile int *tag = reinterpret_cast<volatile int *>(lds + (size_t)(maxlen + D * maxu) * kThreads);   // [D][256]
+    volatile unsigned *wg_ticket = reinterpret_cast<volatile unsigned *>(tag + D * kThreads);
+    if (tid == 0) *wg_ticket = (unsigned)atomicAdd(&ctrl[0], 1);
+    for (int s = 0; s < D; ++s) tag[s * kThreads + tid] = -1;
+    __syncthreads();
+    const unsigned wg = *wg_ticket;
+    const int myslot = (int)(wg * kThreads + tid);
+
+    int cnt = 0, r = 0;
+    if (myslot < nslots_used) { cnt = scount[myslot]; r = sfirst[myslot]; }
+    bool active = cnt > 0;
+    int rloc = 0;
+    int a0 = 0, l0 = 0, u0 = 0, po = 0;
+    if (active) { a0 = Aptr[r]; l0 = Lptr[r]; u0 = Uptr[r]; po = prow[r]; }
+    bool need_init = true;
+    int len = 0, cl = 0, e = 0, pe = 0;
+    unsigned spins = 0;
+
+#define W(q) w[(q) * kThreads + tid]
+    for (;;) {
+        if (!__any(active)) break;
+        bool progressed = false;
+        if (active) {
+            if (need_init) {
+                const int hdr = prog[po];
+                len = hdr & 0xffff;
+                cl = (int)((unsigned)hdr >> 16);
+                for (int q = 0; q < len; ++q) W(q) = Aval[a0 + q];
+                e = 0;
+                pe = po + 1;
+                need_init = false;
+                progressed = true;
+            }
+            while (e < cl) {
+                const int piv_pos = prog[pe];
+                const int kloc = prog[pe + 1];
+                const unsigned meta = (unsigned)prog[pe + 2];
+                const int nm = (int)(meta & 255u);
+                const unsigned oslot = meta >> 8;
+                bool from_memory = true;
+                if ((oslot >> 8) == wg) {
+                    const int lane = (int)(oslot & 255u);
+                    const int s = kloc & (D - 1);
+                    const int t1 = tag[s * kThreads + lane];
+                    if (t1 == kloc) {
+                        const double piv = uring[(size_t)(s * maxu) * kThreads + lane];
+                        const double l_ik = W(e) / piv;
+                        for (int m = 0; m < nm; ++m) {
+                            const unsigned mw = (unsigned)prog[pe + 3 + m];
+                            const int off = (int)(mw & 0xffffu), pp = (int)(mw >> 16);
+                            const double u_kj = uring[(size_t)(s * maxu + off) * kThreads + lane];
+                            const double prod = l_ik * u_kj;
+                            W(pp) = W(pp) - prod;
+                        }
+                        const int t2 = tag[s * kThreads + lane];
+                        if (t2 != kloc) { need_init = true; break; }   // ring slot recycled under us: redo the row
+                        W(e) = l_ik;
+                        from_memory = false;
+                    } else if (t1 < kloc) {
+                        break;                                           // producer not there yet
+                    }                                                    // else: slot already recycled -> memory
+                }
+                if (from_memory) {
+                    const double piv = ld_agent_f64(&Uval[piv_pos]);
+                    if ((unsigned long long)__double_as_longlong(piv) == kSentinel) break;
+                    bool ok = true;
+                    for (int m = 0; m < nm; ++m) {
+                        const int off = (int)((unsigned)prog[pe + 3 + m] & 0xffffu);
+                        const unsigned long long b = ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Uval[piv_pos + off]));
+                        ok = ok && (b != kSentinel);
+                    }
+                    if (!ok) break;
+                    const double l_ik = W(e) / piv;
+                    for (int m = 0; m < nm; ++m) {
+                        const unsigned mw = (unsigned)prog[pe + 3 + m];
+                        const int off = (int)(mw & 0xffffu), pp = (int)(mw >> 16);
+                        const double u_kj = ld_agent_f64(&Uval[piv_pos + off]);   // final once not the sentinel
+                        const double prod = l_ik * u_kj;
+                        W(pp) = W(pp) - prod;
+                    }
+                    W(e) = l_ik;
+                }
+                pe += 3 + nm;
+                ++e;
+                progressed = true;
+            }
+            if (!need_init && e == cl) {
+                for (int q = 0; q < cl; ++q) Lval[l0 + q] = W(q);
+                const int s = rloc & (D - 1);
+                tag[s * kThreads + tid] = -1;
+                for (int q = cl; q < len; ++q) {
+                    double v = W(q);
+                    if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN);
+                    uring[(size_t)(s * maxu + (q - cl)) * kThreads + tid] = v;
+                    st_agent_f64(&Uval[u0 + q - cl], v);
+                }
+                tag[s * kThreads + tid] = rloc;
+                a0 += len;
+                l0 += cl + 1;
+                u0 += len - cl;
+                po = pe;
+                ++rloc;
+                ++r;
+                need_init = true;
+                active = rloc < cnt;
+                progressed = true;
+            } else if (need_init) {
+                progressed = true;   // row restart counts as activity
+            }
+        }
+        if (__any(progressed)) {
+            spins = 0;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) {
+                if ((tid & 63) == 0) atomicExch(&ctrl[1], 1);
+                break;
+            }
+        }
+    }
+#undef W
+}
+
+int ilu0_numeric_program(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
+                         const Ilu0Program &P, int32_t max_row_len, int32_t *d_ctrl, float *kernel_ms)
+{
+    ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
+    fill_u64(st, reinterpret_cast<unsigned long long *>(U->val), U->nnz, kSentinel);
+    const unsigned grid = (unsigned)(fwd.nslots / kThreads);
+    int maxlen = max_row_len < 1 ? 1 : max_row_len;
+    int maxu = P.max_ulen < 1 ? 1 : P.max_ulen;
+    // ring depth: as deep as LDS allows (a consumer that finds its slot recycled falls back to memory)
+    const size_t budget = 144 * 1024;
+    int D = 4;
+    auto need = [&](int d) { return (size_t)(maxlen + d * maxu) * kThreads * sizeof(double) + (size_t)d * kThreads * sizeof(int) + 16; };
+    while (D > 1 && need(D) > budget) D >>= 1;
+    if (need(D) > budget) return ILUPP_ERR_UNSUPPORTED;
+    const size_t ldsb = need(D);
+    hipEvent_t e0, e1;
+    ILUPP_HIP(hipEventCreate(&e0));
+    ILUPP_HIP(hipEventCreate(&e1));
+    ILUPP_HIP(hipEventRecord(e0, st));
+#define LAUNCHP(DD)                                                                                              \
+    do {                                                                                                         \
+        ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_numeric_prog<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+        hipLaunchKernelGGL((k_ilu0_numeric_prog<DD>), dim3(grid), dim3(kThreads), ldsb, st, A.val, A.ptr, L->ptr, L->val, \
+                           U->ptr, U->val, P.prow, P.prog, fwd.nslots, fwd.sfirst, fwd.scount, maxlen, maxu, d_ctrl); \
+    } while (0)
+    if (D == 4) LAUNCHP(4); else if (D == 2) LAUNCHP(2); else LAUNCHP(1);
+#undef LAUNCHP
+    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipGetLastError());
+    int32_t ctrl[4];
+    ILUPP_HIP(hipMemcpyAsync(ctrl, d_ctrl, 16, hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    ILUPP_HIP(hipEventDestroy(e0));
+    ILUPP_HIP(hipEventDestroy(e1));
+    if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
+    return ILUPP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// numeric, loader/consumer: the production kernel for short-row matrices (F3 program)
+// ---------------------------------------------------------------------------------------------
+// Same roles as the solve kernel (sptrsv.hip): waves 4-7 stream each consumer lane's fixed-size update
+// records and A values into per-lane LDS rings a few rows ahead; waves 0-3 read LDS only and need two
+// dependent LDS round trips per row (round 1: hand-shake words + record + A values; round 2: the ring
+// entries of every pivot and matched U value the row needs).  A finished U row is published as one
+// 16-byte {tag,value} LDS entry per value (each entry validates itself: no seqlock) and stored
+// write-through to HBM, where consumers of other workgroups poll it (data-is-flag on U.val).
+struct __attribute__((aligned(8))) D2f { double v[2]; };
+struct __attribute__((aligned(16))) I4f { int v[4]; };
+typedef int v4i_f __attribute__((ext_vector_type(4)));
+
+static constexpr int kPR = 4, kPQ = 2;      // program ring (records) / refill quantum
+static constexpr int kAW = 16, kAQ = 8;     // A-value ring / refill quantum
+static constexpr int kUD = 4;               // depth of the U-row hand-off ring (rows per lane)
+static constexpr size_t kIluLcLds = (size_t)kThreads * (kPR * 12 * 4 + kAW * 8 + kUD * 4 * 16 + 5 * 4) + 16;
+
+// the working row lives in eight NAMED scalars (w0..w7): an indexable aggregate gets demoted to scratch memory
+#define SEL8(i) ((i) == 0 ? w0 : (i) == 1 ? w1 : (i) == 2 ? w2 : (i) == 3 ? w3 : (i) == 4 ? w4 : (i) == 5 ? w5 : (i) == 6 ? w6 : w7)
+#define PUT8(i, nv)                                                                                         \
+    do {                                                                                                    \
+        const int i_ = (i); const double nv_ = (nv);                                                        \
+        w0 = i_ == 0 ? nv_ : w0; w1 = i_ == 1 ? nv_ : w1; w2 = i_ == 2 ? nv_ : w2; w3 = i_ == 3 ? nv_ : w3; \
+        w4 = i_ == 4 ? nv_ : w4; w5 = i_ == 5 ? nv_ : w5; w6 = i_ == 6 ? nv_ : w6; w7 = i_ == 7 ? nv_ : w7; \
+    } while (0)
+
+__global__ void __launch_bounds__(2 * kThreads)
+k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__restrict__ Aptr,
+                  const int32_t *__restrict__ Lptr, double *__restrict__ Lval,
+                  const int32_t *__restrict__ Uptr, double *Uval, long nnzU,
+                  const int32_t *__restrict__ prog, int32_t n,
+                  int32_t nslots_used, const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount,
+                  int32_t *ctrl)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x & (kThreads - 1);
+    const bool is_loader = threadIdx.x >= kThreads;
+    double *sA = reinterpret_cast<double *>(smem);                                 // [kAW][256]
+    v4i_f *ur = reinterpret_cast<v4i_f *>(sA + kAW * kThreads);                    // [kUD][4][256] {tag,-,lo,hi}
+    int *sprog = reinterpret_cast<int *>(ur + kUD * 4 * kThreads);                 // [kPR*12][256]
+    int *p_avail = sprog + kPR * 12 * kThreads;                                    // [256] each
+    int *a_avail = p_avail + kThreads;
+    int *p_cons = a_avail + kThreads;
+    int *a_cons = p_cons + kThreads;
+    int *fin = a_cons + kThreads;
+    unsigned *wg_ticket = reinterpret_cast<unsigned *>(fin + kThreads);
+    if (threadIdx.x == 0) *wg_ticket = (unsigned)atomicAdd(&ctrl[0], 1);
+    __syncthreads();
+    const unsigned wg = *wg_ticket;
+    const unsigned myslot = wg * kThreads + tid;
+
+#define PW(row, k) sprog[((((row) & (kPR - 1)) * 12) + (k)) * kThreads + tid]
+#define RA(i) sA[((i) & (kAW - 1)) * kThreads + tid]
+
+    int cnt = 0, r0 = 0;
+    if ((int)myslot < nslots_used) { cnt = scount[myslot]; r0 = sfirst[myslot]; }
+    int a00 = 0, l00 = 0, u00 = 0;
+    if (cnt > 0) { a00 = Aptr[r0]; l00 = Lptr[r0]; u00 = Uptr[r0]; }
+    if (!is_loader) {
+#pragma unroll
+        for (int s = 0; s < kUD * 4; ++s) { v4i_f e; e.x = -1; e.y = 0; e.z = 0; e.w = 0; ur[s * kThreads + tid] = e; }
+        p_avail[tid] = r0; a_avail[tid] = a00;
+        p_cons[tid] = r0;  a_cons[tid] = a00;
+        fin[tid] = cnt > 0 ? 0 : 1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+
+    if (is_loader) {
+        // ------------------------------------------------------------------ loader
+        int p_next = r0, a_next = a00;
+        bool live = cnt > 0;
+        unsigned idle = 0;
+        for (;;) {
+            if (!__any(live)) break;
+            asm volatile("" ::: "memory");
+            bool did = false;
+            if (live) {
+                if (fin[tid]) {
+                    live = false;
+                } else {
+                    const int pc = p_cons[tid], ac = a_cons[tid];
+                    const bool want_p = (p_next + kPQ <= pc + kPR);
+                    const bool want_a = (a_next + kAQ <= ac + kAW);
+                    I4f tp[kPQ * 3];
+                    D2f ta[kAQ / 2];
+                    long ba[kAQ / 2];
+                    if (want_p) {
+#pragma unroll
+                        for (int q = 0; q < kPQ; ++q) {
+                            const long row = (p_next + q < n) ? (p_next + q) : (n - 1);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) tp[q * 3 + c] = *reinterpret_cast<const I4f *>(prog + row * 12 + 4 * c);
+                        }
+                    }
+                    if (want_a) {
+#pragma unroll
+                        for (int q = 0; q < kAQ / 2; ++q) {
+                            long b = (long)a_next + 2 * q;
+                            b = b < 0 ? 0 : (b > nnzA - 2 ? nnzA - 2 : b);
+                            ba[q] = b;
+                            ta[q] = *reinterpret_cast<const D2f *>(Aval + b);
+                        }
+                    }
+                    if (want_p) {
+#pragma unroll
+                        for (int q = 0; q < kPQ; ++q)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) PW(p_next + q, 4 * c + k) = tp[q * 3 + c].v[k];
+                        p_next += kPQ;
+                        asm volatile("" ::: "memory");
+                        p_avail[tid] = p_next;
+                        did = true;
+                    }
+                    if (want_a) {
+#pragma unroll
+                        for (int q = 0; q < kAQ / 2; ++q)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) RA((int)ba[q] + k) = ta[q].v[k];
+                        a_next += kAQ;
+                        asm volatile("" ::: "memory");
+                        a_avail[tid] = a_next;
+                        did = true;
+                    }
+                }
+            }
+            if (__any(did)) {
+                idle = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+                if (++idle > kSpinLimit) break;
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    int r = r0, rloc = 0;
+    int a0 = a00, l0 = l00, u0 = u00;
+    bool active = cnt > 0;
+    int phase = 0;
+    int pw[12];
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0, w7 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pw[k] = 0;
+    int len = 0, cl = 0, nmt = 0;
+    unsigned spins = 0;
+
+    for (;;) {
+        if (!__any(active)) break;
+        asm volatile("" ::: "memory");
+        bool progressed = false;
+        if (active) {
+            if (phase == 0) {
+                // round 1
+                const int pa = p_avail[tid], aa = a_avail[tid];
+                asm volatile("" ::: "memory");      // hand-shake words are read BEFORE the data they guard
+#pragma unroll
+                for (int k = 0; k < 12; ++k) pw[k] = PW(r, k);
+                w0 = RA(a0); w1 = RA(a0 + 1); w2 = RA(a0 + 2); w3 = RA(a0 + 3);
+                w4 = RA(a0 + 4); w5 = RA(a0 + 5); w6 = RA(a0 + 6); w7 = RA(a0 + 7);
+                asm volatile("" ::: "memory");      // ... and the data BEFORE the words that release its slots
+                if (r < pa) {
+                    len = pw[0] & 255; cl = (pw[0] >> 8) & 255; nmt = (pw[0] >> 16) & 255;
+                    p_cons[tid] = r;
+                    a_cons[tid] = a0;
+                    if (a0 + len <= aa) { phase = 1; progressed = true; }
+                }
+            }
+            if (phase == 1) {
+                // round 2: every pivot / matched value this row needs, from the ring of its producer
+                int dlane[3], dkl[3]; bool dinwg[3];
+                v4i_f pe[3], me[5];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const unsigned kd = (unsigned)pw[1 + 2 * e];
+                    const unsigned oslot = kd >> 15;
+                    dkl[e] = (int)(kd & 0x7fffu);
+                    dlane[e] = (int)(oslot & 255u);
+                    dinwg[e] = (oslot >> 8) == wg;
+                    pe[e] = ur[((dkl[e] & (kUD - 1)) * 4) * kThreads + dlane[e]];
+                }
+                int me_e[5], me_off[5], me_pp[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    const unsigned mw = (unsigned)pw[7 + m];
+                    me_e[m] = (int)(mw & 3u); me_off[m] = (int)((mw >> 2) & 255u); me_pp[m] = (int)((mw >> 10) & 255u);
+                    const int ln = me_e[m] == 0 ? dlane[0] : (me_e[m] == 1 ? dlane[1] : dlane[2]);
+                    const int kl = me_e[m] == 0 ? dkl[0] : (me_e[m] == 1 ? dkl[1] : dkl[2]);
+                    me[m] = ur[((kl & (kUD - 1)) * 4 + (me_off[m] & 3)) * kThreads + ln];
+                }
+                bool ready = true, use_mem = false;
+                double piv[3] = {1.0, 1.0, 1.0}, um[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                bool dmem[3] = {false, false, false};
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    if (e < cl) {
+                        if (dinwg[e] && pe[e].x <= dkl[e]) {
+                            if (pe[e].x == dkl[e]) piv[e] = __hiloint2double(pe[e].w, pe[e].z);
+                            else ready = false;                       // producer not there yet
+                        } else { dmem[e] = true; use_mem = true; }      // other workgroup, or ring slot recycled
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    if (m < nmt) {
+                        const int e = me_e[m];
+                        const bool mm = e == 0 ? dmem[0] : (e == 1 ? dmem[1] : dmem[2]);
+                        const int kl = e == 0 ? dkl[0] : (e == 1 ? dkl[1] : dkl[2]);
+                        if (!mm) {
+                            if (me[m].x == kl) um[m] = __hiloint2double(me[m].w, me[m].z);
+                            else if (me[m].x < kl) ready = false;
+                            else { use_mem = true; }                    // recycled between the two reads: take it from memory
+                        }
+                    }
+                }
+                if (ready && use_mem) {
+                    // values that live only in HBM: write-through stored by their producer, each its own flag
+                    unsigned long long bp[3] = {0, 0, 0}, bm[5] = {0, 0, 0, 0, 0};
+                    bool needm[5];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (e < cl && dmem[e]) bp[e] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pw[2 + 2 * e]));
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) {
+                        const int e = me_e[m];
+                        const bool mm = e == 0 ? dmem[0] : (e == 1 ? dmem[1] : dmem[2]);
+                        const int kl = e == 0 ? dkl[0] : (e == 1 ? dkl[1] : dkl[2]);
+                        needm[m] = (m < nmt) && (mm || me[m].x > kl);
+                        const int pv = e == 0 ? pw[2] : (e == 1 ? pw[4] : pw[6]);
+                        if (needm[m]) bm[m] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pv + me_off[m]));
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (e < cl && dmem[e]) { if (bp[e] == kSentinel) ready = false; else piv[e] = __longlong_as_double((long long)bp[e]); }
+#pragma unroll
+                    for (int m = 0; m < 5; ++m)
+                        if (needm[m]) { if (bm[m] == kSentinel) ready = false; else um[m] = __longlong_as_double((long long)bm[m]); }
+                }
+                if (ready) {
+                    // eliminations in ascending k, matches of each in ascending column (reference merge order)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        if (e < cl) {
+                            const double l_ik = SEL8(e) / piv[e];
+#pragma unroll
+                            for (int m = 0; m < 5; ++m) {
+                                if (m < nmt && me_e[m] == e) {
+                                    const double prod = l_ik * um[m];
+                                    const double nv = SEL8(me_pp[m]) - prod;
+                                    PUT8(me_pp[m], nv);
+                                }
+                            }
+                            PUT8(e, l_ik);
+                        }
+                    }
+                    if (0 < cl) Lval[l0] = w0;
+                    if (1 < cl) Lval[l0 + 1] = w1;
+                    if (2 < cl) Lval[l0 + 2] = w2;
+                    const int ulen = len - cl;
+                    const int s = rloc & (kUD - 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q < ulen) {
+                            double v = SEL8(cl + q);
+                            if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN);
+                            v4i_f e; e.x = rloc; e.y = 0; e.z = __double2loint(v); e.w = __double2hiint(v);
+                            ur[(s * 4 + q) * kThreads + tid] = e;
+                            st_agent_f64(&Uval[u0 + q], v);
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    a0 += len; l0 += cl + 1; u0 += ulen;
+                    ++r; ++rloc;
+                    phase = 0;
+                    active = rloc < cnt;
+                    if (!active) fin[tid] = 1;
+                    progressed = true;
+                }
+            }
+        }
+        if (__any(progressed)) {
+            spins = 0;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) {
+                if ((tid & 63) == 0) atomicExch(&ctrl[1], 1);
+                fin[tid] = 1;
+                break;
+            }
+        }
+    }
+#undef PW
+#undef RA
+#undef SEL8
+#undef PUT8
+}
+
+int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd, const int32_t *prog_f3,
+                    int32_t *d_ctrl, float *kernel_ms)
+{
+    ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
+    fill_u64(st, reinterpret_cast<unsigned long long *>(U->val), U->nnz, kSentinel);
+    const unsigned grid = (unsigned)(fwd.nslots / kThreads);
+    hipEvent_t e0, e1;
+    ILUPP_HIP(hipEventCreate(&e0));
+    ILUPP_HIP(hipEventCreate(&e1));
+    ILUPP_HIP(hipEventRecord(e0, st));
+    ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_numeric_lc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIluLcLds));
+    hipLaunchKernelGGL(k_ilu0_numeric_lc, dim3(grid), dim3(2 * kThreads), kIluLcLds, st, A.val, (long)A.nnz, A.ptr,
+                       L->ptr, L->val, U->ptr, U->val, (long)U->nnz, prog_f3, A.n, fwd.nslots, fwd.sfirst, fwd.scount, d_ctrl);
+    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipGetLastError());
+    int32_t ctrl[4];
+    ILUPP_HIP(hipMemcpyAsync(ctrl, d_ctrl, 16, hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    ILUPP_HIP(hipEventDestroy(e0));
+    ILUPP_HIP(hipEventDestroy(e1));
+    if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
+    return ILUPP_OK;
+}
+
 int ilu0_numeric(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
                  int32_t max_row_len, int32_t *d_done, int32_t *d_ctrl, float *kernel_ms)
 {

@@ -1,0 +1,289 @@
+// ilupp_amd/csrc/schedule.hip -- static products of the analysis phase that the persistent sweeps
+// stream instead of chasing pointers (gfx950).
+//
+//  * slot tables: which row block every lane (slot = workgroup*256 + lane) of the persistent grid owns;
+//  * solve descriptors: one int32 per stored entry of a triangular factor, replacing the column index
+//    in the sweep: (owner slot << 15 | position of the wanted row in its owner's processing order), so
+//    a consumer knows at once whether its producer sits in the same workgroup (LDS ring) or not;
+//  * ILU(0) update program: per row, the list of eliminations and, for each, where the pivot row's
+//    matching entries live -- the symbolic half of sparse_vec_update (reference ILU0.hpp:8-23) done
+//    once, so the numeric kernel has no merge loop and no dependent index loads.
+//
+// All of it is integer streaming work with thread-per-row kernels over independent rows.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace ilupp {
+
+// block that owns row c:  start[b] <= c < start[b+1]
+__device__ __forceinline__ int block_of(int c, int B, int nb, const int32_t *__restrict__ start)
+{
+    int b = c / B;
+    if (b >= nb) b = nb - 1;
+    while (c < start[b]) --b;
+    while (c >= start[b + 1]) ++b;
+    return b;
+}
+
+__global__ void k_slot_tables(int32_t nb, int32_t nslots, int fwd, const int32_t *__restrict__ start,
+                              int32_t *__restrict__ slot2blk, int32_t *__restrict__ blk2slot,
+                              int32_t *__restrict__ sfirst, int32_t *__restrict__ scount)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    // identity placement: forward sweeps hand block s to slot s, backward sweeps block nb-1-s
+    const int b = (s < nb) ? (fwd ? s : nb - 1 - s) : -1;
+    slot2blk[s] = b;
+    if (b >= 0) {
+        blk2slot[b] = s;
+        const int lo = start[b], hi = start[b + 1];
+        sfirst[s] = fwd ? lo : hi - 1;       // first row in processing order
+        scount[s] = hi - lo;
+    } else {
+        sfirst[s] = 0;
+        scount[s] = 0;
+    }
+}
+
+void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
+{
+    sch->fwd = fwd;
+    sch->nslots = ((sch->nb + kThreads - 1) / kThreads) * kThreads;
+    const size_t bytes = sizeof(int32_t) * (size_t)sch->nslots;
+    ILUPP_HIP(hipMalloc(&sch->slot2blk, bytes));
+    ILUPP_HIP(hipMalloc(&sch->blk2slot, sizeof(int32_t) * (size_t)(sch->nb > 0 ? sch->nb : 1)));
+    ILUPP_HIP(hipMalloc(&sch->sfirst, bytes));
+    ILUPP_HIP(hipMalloc(&sch->scount, bytes));
+    hipLaunchKernelGGL(k_slot_tables, dim3((unsigned)(sch->nslots / kThreads)), dim3(kThreads), 0, st,
+                       sch->nb, sch->nslots, fwd ? 1 : 0, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount);
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve descriptors
+// ---------------------------------------------------------------------------------------------
+// desc = owner_slot << 15 | kloc, kloc = index of row c in its owner's processing order.
+__global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                            int32_t B, int32_t nb, int fwd, const int32_t *__restrict__ start,
+                            const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int q = ptr[r]; q < ptr[r + 1]; ++q) {
+        const int c = idx[q];
+        if (c == r) { desc[q] = 0; continue; }
+        const int b = block_of(c, B, nb, start);
+        const int kloc = fwd ? (c - start[b]) : (start[b + 1] - 1 - c);
+        desc[q] = (blk2slot[b] << 15) | kloc;
+    }
+}
+
+void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc)
+{
+    ILUPP_HIP(hipMalloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
+    hipLaunchKernelGGL(k_make_desc, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, st, M.n, M.ptr, M.idx,
+                       sch.B, sch.nb, sch.fwd ? 1 : 0, sch.start, sch.blk2slot, *desc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ILU(0) update program
+// ---------------------------------------------------------------------------------------------
+// record of row r (32-bit words):
+//   [ len | cl << 16 ]
+//   per strictly-lower entry e (ascending column k):
+//       [ piv_pos ]                 index of U row k's diagonal in U.val
+//       [ kloc ]                    row k's index in its owner's processing order
+//       [ oslot << 8 | nm ]         owner slot, number of matches
+//       nm x [ off | pp << 16 ]     U row k's entry piv_pos+off updates working-row position pp
+// stats: [0] max words per row, [1] max U-row length, [2] limit violations
+template <bool WRITE>
+__global__ void k_ilu0_program(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx,
+                               const int32_t *__restrict__ Uptr, int32_t B, int32_t nb,
+                               const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
+                               int32_t *__restrict__ nwords, const int32_t *__restrict__ prow,
+                               int32_t *__restrict__ prog, int32_t *__restrict__ stats)
+{
+    const int rr = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = rr < n;
+    const int r = in_range ? rr : n - 1;          // out-of-range threads shadow the last row and write nothing
+    const int a0 = Aptr[r], a1 = Aptr[r + 1];
+    const int len = a1 - a0;
+    int cl = 0;
+    while (cl < len && Aidx[a0 + cl] < r) ++cl;
+    int w = 0, bad = 0;
+    if (WRITE && !in_range) return;
+    int32_t *out = WRITE ? prog + prow[r] : nullptr;
+    if (WRITE) out[0] = len | (cl << 16);
+    w = 1;
+    if (len >= 65536) bad = 1;
+    for (int e = 0; e < cl; ++e) {
+        const int k = Aidx[a0 + e];
+        const int k0 = Aptr[k], k1 = Aptr[k + 1];
+        // first entry of row k with column > k; the diagonal sits just before it
+        int ku = k0;
+        while (ku < k1 && Aidx[ku] <= k) ++ku;
+        const int kd = ku - 1;      // position of (k,k) in A's row k (presence checked by the count pass)
+        int nm = 0, pp = e + 1;
+        for (int j = ku; j < k1; ++j) {
+            const int m = Aidx[j];
+            while (pp < len && Aidx[a0 + pp] < m) ++pp;
+            if (pp >= len) break;
+            if (Aidx[a0 + pp] == m) {
+                if (WRITE) out[w + 3 + nm] = (j - kd) | (pp << 16);
+                ++nm; ++pp;
+            }
+        }
+        if (nm > 255 || (k1 - kd) >= 65536) bad = 1;
+        if (WRITE) {
+            const int b = block_of(k, B, nb, start);
+            const int oslot = blk2slot[b];
+            out[w] = Uptr[k];
+            out[w + 1] = k - start[b];
+            out[w + 2] = (oslot << 8) | (nm & 255);
+        }
+        w += 3 + nm;
+    }
+    if (!WRITE) {
+        if (in_range) nwords[r] = w;
+        // U-row length of this row (diagonal + strictly upper); statistics leave through LDS, one set of
+        // atomics per workgroup
+        const int ulen = len - cl;
+        __shared__ int red[3];
+        if (threadIdx.x < 3) red[threadIdx.x] = 0;
+        __syncthreads();
+        int mw = w, mu = ulen;
+        for (int off = 32; off > 0; off >>= 1) { mw = max(mw, __shfl_xor(mw, off)); mu = max(mu, __shfl_xor(mu, off)); }
+        const unsigned long long anybad = __ballot(bad);
+        if ((threadIdx.x & 63) == 0) { atomicMax(&red[0], mw); atomicMax(&red[1], mu); if (anybad) atomicAdd(&red[2], 1); }
+        __syncthreads();
+        if (threadIdx.x == 0) { atomicMax(&stats[0], red[0]); atomicMax(&stats[1], red[1]); if (red[2]) atomicAdd(&stats[2], 1); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed-size update program "F3" for short-row matrices (<= 3 eliminations, <= 5 matches, <= 8 entries per row,
+// U rows of <= 4 entries): 12 words per row, built in ONE pass with no scan, streamed by the loader waves
+// of k_ilu0_numeric_lc.  The 5- and 7-point stencils fit; anything else takes the variable-length program.
+//   w0      len | cl << 8 | nmt << 16
+//   w1+2e   dep e: owner_slot << 15 | kloc          (same encoding as a solve descriptor)
+//   w2+2e   dep e: piv_pos (index of U row k's diagonal in U.val)
+//   w7+m    match m: e | off << 2 | pp << 10        (matches grouped by e, ascending; U entry piv_pos+off updates w[pp])
+__global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx,
+                                  const int32_t *__restrict__ Uptr, int32_t B, int32_t nb,
+                                  const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
+                                  int32_t *__restrict__ prog, int32_t *__restrict__ ineligible)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int a0 = Aptr[r], a1 = Aptr[r + 1];
+    const int len = a1 - a0;
+    int cl = 0;
+    while (cl < len && Aidx[a0 + cl] < r) ++cl;
+    bool bad = (len > 8) || (cl > 3) || (len - cl > 4);
+    int words[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) words[k] = 0;
+    int nmt = 0;
+    if (!bad) {
+        for (int e = 0; e < cl; ++e) {
+            const int k = Aidx[a0 + e];
+            const int k0 = Aptr[k], k1 = Aptr[k + 1];
+            int ku = k0;
+            while (ku < k1 && Aidx[ku] <= k) ++ku;
+            const int kd = ku - 1;
+            if (k1 - kd > 4) bad = true;                 // U row of k longer than the LDS ring entry
+            int pp = e + 1;
+            for (int j = ku; j < k1; ++j) {
+                const int m = Aidx[j];
+                while (pp < len && Aidx[a0 + pp] < m) ++pp;
+                if (pp >= len) break;
+                if (Aidx[a0 + pp] == m) {
+                    if (nmt < 5) {
+                        const int mw = e | ((j - kd) << 2) | (pp << 10);
+                        // static slots only (no private-memory array indexing)
+                        if (nmt == 0) words[7] = mw; else if (nmt == 1) words[8] = mw; else if (nmt == 2) words[9] = mw;
+                        else if (nmt == 3) words[10] = mw; else words[11] = mw;
+                    }
+                    ++nmt; ++pp;
+                }
+            }
+            const int b = block_of(k, B, nb, start);
+            const int kd_word = (blk2slot[b] << 15) | (k - start[b]);
+            const int pv = Uptr[k];
+            if (e == 0) { words[1] = kd_word; words[2] = pv; }
+            else if (e == 1) { words[3] = kd_word; words[4] = pv; }
+            else { words[5] = kd_word; words[6] = pv; }
+        }
+        if (nmt > 5) bad = true;
+    }
+    words[0] = len | (cl << 8) | ((nmt > 5 ? 5 : nmt) << 16);
+    int4 *out = reinterpret_cast<int4 *>(prog + (size_t)r * 12);
+    out[0] = make_int4(words[0], words[1], words[2], words[3]);
+    out[1] = make_int4(words[4], words[5], words[6], words[7]);
+    out[2] = make_int4(words[8], words[9], words[10], words[11]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicExch(ineligible, 1);
+}
+
+// F3 program; returns false (and frees it) when some row does not fit the fixed record
+bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, int32_t **prog_out)
+{
+    const int32_t n = A.n;
+    if (sch.B > 32768 || sch.nslots > (1 << 17)) return false;
+    int32_t *prog = nullptr, *flag = nullptr;
+    ILUPP_HIP(hipMalloc(&prog, sizeof(int32_t) * 12 * (size_t)n + 64));
+    ILUPP_HIP(hipMalloc(&flag, 16));
+    ILUPP_HIP(hipMemsetAsync(flag, 0, 16, st));
+    hipLaunchKernelGGL(k_ilu0_program_f3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr,
+                       sch.B, sch.nb, sch.start, sch.blk2slot, prog, flag);
+    int32_t h = 0;
+    ILUPP_HIP(hipMemcpyAsync(&h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipFree(flag));
+    if (h != 0) { ILUPP_HIP(hipFree(prog)); return false; }
+    *prog_out = prog;
+    return true;
+}
+
+// builds the program for schedule `sch` (forward); returns false if the compact encoding cannot
+// represent this matrix (then the generic kernel of ilu0.hip is used instead)
+bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, Ilu0Program *P)
+{
+    const int32_t n = A.n;
+    int32_t *nwords = nullptr, *stats = nullptr;
+    ILUPP_HIP(hipMalloc(&nwords, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(hipMalloc(&stats, 16));
+    ILUPP_HIP(hipMemsetAsync(stats, 0, 16, st));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL((k_ilu0_program<false>), dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr, sch.B, sch.nb,
+                       sch.start, sch.blk2slot, nwords, (const int32_t *)nullptr, (int32_t *)nullptr, stats);
+    ILUPP_HIP(hipMalloc(&P->prow, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(hipMemsetAsync(P->prow, 0, sizeof(int32_t), st));
+    // 64-bit total first: the compact program indexes words with int32
+    size_t tmp_bytes = 0;
+    ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, nwords, P->prow + 1, n, st));
+    void *tmp = nullptr;
+    ILUPP_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, nwords, P->prow + 1, n, st));
+    int32_t h[4], total = 0;
+    ILUPP_HIP(hipMemcpyAsync(h, stats, 16, hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipMemcpyAsync(&total, P->prow + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipFree(tmp));
+    P->max_words = h[0];
+    P->max_ulen = h[1];
+    const bool ok = (h[2] == 0) && total > 0 && sch.B <= 32768 && sch.nslots <= (1 << 17);
+    if (!ok) {
+        ILUPP_HIP(hipFree(nwords)); ILUPP_HIP(hipFree(stats));
+        ILUPP_HIP(hipFree(P->prow)); P->prow = nullptr;
+        return false;
+    }
+    P->nwords = total;
+    ILUPP_HIP(hipMalloc(&P->prog, sizeof(int32_t) * (size_t)total));
+    hipLaunchKernelGGL((k_ilu0_program<true>), dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr, sch.B, sch.nb,
+                       sch.start, sch.blk2slot, nwords, P->prow, P->prog, stats);
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipFree(nwords)); ILUPP_HIP(hipFree(stats));
+    return true;
+}
+
+}  // namespace ilupp

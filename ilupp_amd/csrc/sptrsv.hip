@@ -19,6 +19,8 @@
 // sentinel.  No flag array, no fences, no grid barrier.  The right-hand side is read once per row
 // and immediately overwritten with the sentinel, which makes that buffer the ready-made output of
 // the next sweep: L-solve  x -> y,  U-solve  y -> x  leaves the result in place in x and y reset.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ilupp {
@@ -107,10 +109,503 @@ k_sptrsv(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const
     }
 }
 
-int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, double *rhs_and_reset,
-           double *out, int32_t *d_ticket, int32_t *d_err)
+
+// ---------------------------------------------------------------------------------------------
+// descriptor-driven sweep: the production kernel
+// ---------------------------------------------------------------------------------------------
+// Same arithmetic; the column index of every stored entry is replaced by its solve descriptor
+// (schedule.hip), so a lane knows without any lookup whether the unknown it needs is produced by
+// its own workgroup.  If so it comes through an LDS ring (slot = kloc mod D, seqlock tag), ~100
+// cycles; otherwise through the data-is-flag poll on the output vector in HBM.
+static constexpr int kXRing = 8;
+
+template <int KIND>
+__global__ void __launch_bounds__(kThreads)
+k_sptrsv_desc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, const double *__restrict__ val,
+              double *rhs, double *out, int32_t nslots_used, const int32_t *__restrict__ sfirst,
+              const int32_t *__restrict__ scount, int32_t *ticket, int32_t *err)
+{
+    constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
+    constexpr bool DESC = (KIND == SWEEP_BWD_FIRST_DESC);
+    constexpr int D = kXRing;
+    __shared__ __attribute__((aligned(16))) double xring_s[D * kThreads];
+    __shared__ int tag_s[D * kThreads];
+    __shared__ unsigned wg_ticket;
+    volatile double *xring = xring_s;
+    volatile int *tag = tag_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) wg_ticket = (unsigned)atomicAdd(ticket, 1);
+    for (int s = 0; s < D; ++s) tag[s * kThreads + tid] = -1;
+    __syncthreads();
+    const unsigned wg = wg_ticket;
+    const unsigned myslot = wg * kThreads + tid;
+
+    int cnt = 0, r = 0;
+    if ((int)myslot < nslots_used) { cnt = scount[myslot]; r = sfirst[myslot]; }
+    constexpr int dir = FWD ? 1 : -1;
+    bool active = cnt > 0;
+    bool need_init = true;
+    int rloc = 0;
+    int j = 0, jend = 0, dpos = 0;
+    double acc = 0.0, prev_val = 0.0;
+    unsigned spins = 0;
+    const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(out);
+
+    for (;;) {
+        if (!__any(active)) break;
+        bool progressed = false;
+        if (active) {
+            if (need_init) {
+                const int lo = ptr[r], hi = ptr[r + 1];
+                acc = rhs[r];
+                reinterpret_cast<unsigned long long *>(rhs)[r] = kSentinel;
+                if (FWD)       { j = lo;     jend = hi - 1; dpos = hi - 1; }
+                else if (!DESC){ j = lo + 1; jend = hi;     dpos = lo; }
+                else           { j = hi - 1; jend = lo;     dpos = lo; }
+                need_init = false;
+                progressed = true;
+            }
+            while (j != jend) {
+                const unsigned d = (unsigned)desc[j];
+                const unsigned oslot = d >> 15;
+                const int kl = (int)(d & 0x7fffu);
+                double xc;
+                bool have = false;
+                if (oslot == myslot && kl == rloc - 1) {
+                    xc = prev_val;                                   // own previous row
+                    have = true;
+                } else if ((oslot >> 8) == wg) {
+                    const int lane = (int)(oslot & 255u);
+                    const int s = kl & (D - 1);
+                    const int t1 = tag[s * kThreads + lane];
+                    if (t1 == kl) {
+                        xc = xring[s * kThreads + lane];
+                        have = (tag[s * kThreads + lane] == kl);     // slot not recycled while we read
+                    } else if (t1 < kl) {
+                        break;                                       // producer not there yet
+                    }
+                }
+                if (!have) {
+                    const int c = sfirst[oslot] + dir * kl;
+                    const unsigned long long bits = ld_agent_u64(outb + c);
+                    if (bits == kSentinel) break;
+                    xc = __longlong_as_double((long long)bits);
+                }
+                const double prod = val[j] * xc;
+                acc = acc - prod;
+                j += DESC ? -1 : 1;
+                progressed = true;
+            }
+            if (j == jend) {
+                acc = acc / val[dpos];
+                if (acc != acc) acc = __longlong_as_double((long long)kCanonNaN);
+                const int s = rloc & (D - 1);
+                tag[s * kThreads + tid] = -1;
+                xring[s * kThreads + tid] = acc;
+                tag[s * kThreads + tid] = rloc;
+                st_agent_f64(out + r, acc);
+                prev_val = acc;
+                r += dir;
+                ++rloc;
+                need_init = true;
+                active = rloc < cnt;
+                progressed = true;
+            }
+        }
+        if (__any(progressed)) {
+            spins = 0;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSolveSpinLimit) {
+                if ((tid & 63) == 0) atomicExch(err, 1);
+                break;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// loader/consumer sweep: the production solve kernel for short-row factors
+// ---------------------------------------------------------------------------------------------
+// The sweeps are latency-bound: ~22 k independent rows per dependency level over 256 CUs leave each
+// CU a few waves, and gfx950 returns a wave's vector-memory operations IN ORDER (one vmcnt queue), so
+// a wave that prefetches cannot also poll cheaply.  The workgroup therefore splits roles:
+//   * waves 4-7 are LOADERS: loader lane t streams the four input streams of consumer lane t (row
+//     pointers, right-hand side, descriptors, values; all contiguous because the lane owns consecutive
+//     rows) a few rows ahead with independent 16-byte loads and drops them into per-lane LDS rings
+//     ([slot][lane] layout: the bank depends on the lane only, so any per-lane offset is conflict-free);
+//     only loaders ever wait on HBM latency;
+//   * waves 0-3 are CONSUMERS: they read LDS only.  Unknowns produced in the same workgroup arrive
+//     through a 16-byte {tag,x} LDS ring entry (one ds_read_b128); unknowns produced elsewhere are
+//     polled in HBM (data-is-flag), four consecutive ones per trip; results leave by write-through stores.
+struct __attribute__((aligned(4))) I4u { int v[4]; };
+struct __attribute__((aligned(8))) D2u { double v[2]; };
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Branch-free window loads: a 16-byte load whose base is clamped into the array; the elements are
+// dropped at their TRUE absolute ring positions (clamp_base(...) + k), so array ends need neither
+// padding nor a scalar fallback (a fallback branch would make hipcc wait for every load in turn).
+__device__ __forceinline__ long clamp_base(long i, long n, int w) { return i < 0 ? 0 : (i > n - w ? n - w : i); }
+
+static constexpr int kEW = 32, kEQ = 8;    // entry ring / refill quantum (descriptors, values)
+static constexpr int kRW = 8, kRQ = 4;     // row ring / refill quantum (row pointers, right-hand side)
+static constexpr int kXD = 4;              // depth of the {tag,x} hand-off ring
+static constexpr int kEC = 4;              // external unknowns fetched per trip
+static constexpr int kLcThreads = 2 * kThreads;
+static constexpr size_t kLcLds = (size_t)kThreads * (kEW * 4 + kEW * 8 + kRW * 4 + kRW * 8 + kXD * 16 + kEC * 8 + 5 * 4) + 16;
+
+template <int KIND>
+__global__ void __launch_bounds__(kLcThreads)
+k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, const double *__restrict__ val,
+            int32_t n, long nnz, double *rhs, double *out, int32_t nslots_used,
+            const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount, int32_t *ticket, int32_t *err)
+{
+    constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
+    constexpr bool DESC = (KIND == SWEEP_BWD_FIRST_DESC);
+    constexpr int DR = FWD ? 1 : -1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x & (kThreads - 1);        // consumer lane / client lane
+    const bool is_loader = threadIdx.x >= kThreads;
+    // carve (every offset a multiple of 16)
+    double *sval = reinterpret_cast<double *>(smem);                         // [kEW][256]
+    double *srhs = sval + kEW * kThreads;                                    // [kRW][256]
+    double *secv = srhs + kRW * kThreads;                                    // [kEC][256]
+    v4i *xr = reinterpret_cast<v4i *>(secv + kEC * kThreads);                // [kXD][256] {tag,-,x.lo,x.hi}
+    int *sdesc = reinterpret_cast<int *>(xr + kXD * kThreads);               // [kEW][256]
+    int *sptr = sdesc + kEW * kThreads;                                      // [kRW][256]
+    // hand-shake words (plain LDS accesses; ordering comes from the in-order LDS queue of each wave plus
+    // the compiler barriers below -- volatile would demote them to flat, system-scope accesses)
+    int *e_avail = sptr + kRW * kThreads;                                    // [256] each
+    int *r_avail = e_avail + kThreads;
+    int *e_cons = r_avail + kThreads;
+    int *r_cons = e_cons + kThreads;
+    int *fin = r_cons + kThreads;
+    unsigned *wg_ticket = reinterpret_cast<unsigned *>(fin + kThreads);
+    if (threadIdx.x == 0) *wg_ticket = (unsigned)atomicAdd(ticket, 1);
+    __syncthreads();
+    const unsigned wg = *wg_ticket;
+    const unsigned myslot = wg * kThreads + tid;
+
+#define RD(i) sdesc[((i) & (kEW - 1)) * kThreads + tid]
+#define RV(i) sval[((i) & (kEW - 1)) * kThreads + tid]
+#define RP(i) sptr[((i) & (kRW - 1)) * kThreads + tid]
+#define RR(i) srhs[((i) & (kRW - 1)) * kThreads + tid]
+
+    int cnt = 0, r0 = 0;
+    if ((int)myslot < nslots_used) { cnt = scount[myslot]; r0 = sfirst[myslot]; }
+    int bound0 = 0;          // FWD: start of the first row; BWD: end of the first row
+    if (cnt > 0) bound0 = FWD ? ptr[r0] : ptr[r0 + 1];
+    if (!is_loader) {
+        for (int s = 0; s < kXD; ++s) { v4i e; e.x = -1; e.y = 0; e.z = 0; e.w = 0; xr[s * kThreads + tid] = e; }
+        e_avail[tid] = bound0; r_avail[tid] = FWD ? r0 : r0 + 1;
+        e_cons[tid] = bound0;  r_cons[tid] = r0;
+        fin[tid] = cnt > 0 ? 0 : 1;
+    }
+    // retire the set-up loads with a wait hipcc can see: a load still pending at the loop header would
+    // make it re-wait (vmcnt(0), i.e. also for our own write-through stores) on every round
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+
+    if (is_loader) {
+        // ------------------------------------------------------------------ loader
+        int e_next = bound0;                 // FWD: next entry to load; BWD: one past the next quantum
+        int r_next = FWD ? r0 : r0 + 1;      // FWD: next row to load;   BWD: one past the next quantum
+        bool live = cnt > 0;
+        unsigned idle = 0;
+        for (;;) {
+            if (!__any(live)) break;
+            asm volatile("" ::: "memory");
+            bool did = false;
+            if (live) {
+                if (fin[tid]) {
+                    live = false;
+                } else {
+                    const int ec = e_cons[tid], rc = r_cons[tid];
+                    const bool want_e = FWD ? (e_next + kEQ <= ec + kEW) : (e_next - kEQ >= ec - kEW);
+                    const bool want_r = FWD ? (r_next + kRQ <= rc + kRW) : (r_next - kRQ >= rc + 1 - kRW);
+                    if (want_e) {
+                        const int base = FWD ? e_next : e_next - kEQ;
+                        long bd[kEQ / 4], bv[kEQ / 2];
+                        I4u td[kEQ / 4];
+                        D2u tv[kEQ / 2];
+#pragma unroll
+                        for (int q = 0; q < kEQ / 4; ++q) { bd[q] = clamp_base((long)base + 4 * q, nnz, 4); td[q] = *reinterpret_cast<const I4u *>(desc + bd[q]); }
+#pragma unroll
+                        for (int q = 0; q < kEQ / 2; ++q) { bv[q] = clamp_base((long)base + 2 * q, nnz, 2); tv[q] = *reinterpret_cast<const D2u *>(val + bv[q]); }
+#pragma unroll
+                        for (int q = 0; q < kEQ / 4; ++q)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) RD((int)bd[q] + k) = td[q].v[k];
+#pragma unroll
+                        for (int q = 0; q < kEQ / 2; ++q)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) RV((int)bv[q] + k) = tv[q].v[k];
+                        e_next += FWD ? kEQ : -kEQ;
+                        asm volatile("" ::: "memory");
+                        e_avail[tid] = e_next;
+                        did = true;
+                    }
+                    if (want_r) {
+                        const int base = FWD ? r_next : r_next - kRQ;
+                        const long bp = clamp_base((long)base + (FWD ? 1 : 0), (long)n + 1, 4);
+                        const I4u tp = *reinterpret_cast<const I4u *>(ptr + bp);
+                        long br[kRQ / 2];
+                        D2u tr[kRQ / 2];
+#pragma unroll
+                        for (int q = 0; q < kRQ / 2; ++q) { br[q] = clamp_base((long)base + 2 * q, n, 2); tr[q] = *reinterpret_cast<const D2u *>(rhs + br[q]); }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) RP((int)bp - (FWD ? 1 : 0) + k) = tp.v[k];
+#pragma unroll
+                        for (int q = 0; q < kRQ / 2; ++q)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) RR((int)br[q] + k) = tr[q].v[k];
+                        r_next += FWD ? kRQ : -kRQ;
+                        asm volatile("" ::: "memory");
+                        r_avail[tid] = r_next;
+                        did = true;
+                    }
+                }
+            }
+            if (__any(did)) {
+                idle = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+                if (++idle > kSolveSpinLimit) break;     // consumers report the time-out
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    // A row costs TWO dependent LDS round trips when it has at most 4 stored entries (the 5-/7-point
+    // factors): round 1 reads the hand-shake words, the row pointer, the right-hand side and -- from the
+    // already known row start -- four descriptor/value pairs speculatively; round 2 reads the {tag,x}
+    // ring entries of all its in-workgroup dependencies at once.  Longer rows take the entry loop.
+    int r = r0;
+    bool active = cnt > 0;
+    int rloc = 0;
+    int bound = bound0;
+    int phase = 0;            // 0: fetch the row; 1: short row, waiting for dependencies; 2: long row, entry loop
+    int j = 0, jend = 0, dpos = 0, lo = 0, hi = 0, len = 0;
+    int ed[4] = {0, 0, 0, 0};
+    double ev[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc = 0.0, prev_val = 0.0;
+    unsigned ec_oslot = 0xffffffffu; int ec_kl0 = 0, ec_cnt = 0, ec_first = 0;
+    unsigned spins = 0;
+    const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(out);
+
+    // external unknown (other workgroup): cached batch of kEC consecutive ones, else one poll trip
+    auto external = [&](unsigned oslot, int kl, double &xc) -> bool {
+        if (oslot == ec_oslot && kl >= ec_kl0 && kl < ec_kl0 + ec_cnt) {
+            xc = secv[(kl - ec_kl0) * kThreads + tid];
+            return true;
+        }
+        if (oslot != ec_oslot) { ec_first = sfirst[oslot]; ec_oslot = oslot; ec_cnt = 0; __builtin_amdgcn_s_waitcnt(0x0F70); }
+        const int c = ec_first + DR * kl;
+        unsigned long long b[kEC];
+#pragma unroll
+        for (int q = 0; q < kEC; ++q) {
+            const int cq = c + DR * q;
+            b[q] = ld_agent_u64(outb + (cq < 0 ? 0 : (cq >= n ? n - 1 : cq)));
+        }
+        // retire the polls HERE: otherwise hipcc parks a vmcnt(0) at the join, where it would also wait
+        // for the previous row's write-through store on every row
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (b[0] == kSentinel) { ec_cnt = 0; return false; }
+        int got = 1;
+#pragma unroll
+        for (int q = 1; q < kEC; ++q) got += (got == q && b[q] != kSentinel && c + DR * q >= 0 && c + DR * q < n) ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < kEC; ++q) secv[q * kThreads + tid] = __longlong_as_double((long long)b[q]);
+        ec_kl0 = kl; ec_cnt = got;
+        xc = __longlong_as_double((long long)b[0]);
+        return true;
+    };
+    auto publish = [&](double x) {
+        if (x != x) x = __longlong_as_double((long long)kCanonNaN);
+        v4i e;
+        e.x = rloc; e.y = 0; e.z = __double2loint(x); e.w = __double2hiint(x);
+        xr[(rloc & (kXD - 1)) * kThreads + tid] = e;                  // one ds_write_b128
+        asm volatile("" ::: "memory");
+        st_agent_f64(out + r, x);
+        prev_val = x;
+        bound = FWD ? hi : lo;
+        r += DR;
+        ++rloc;
+        phase = 0;
+        active = rloc < cnt;
+        if (!active) fin[tid] = 1;
+    };
+
+    for (;;) {
+        if (!__any(active)) break;
+        asm volatile("" ::: "memory");     // LDS written by other waves is re-read every round
+        bool progressed = false;
+        if (active) {
+            if (phase == 0) {
+                // round 1: everything addressable from registers, issued together
+                const int ebase = FWD ? bound : bound - 4;
+                const int ra = r_avail[tid];
+                const int ea = e_avail[tid];
+                asm volatile("" ::: "memory");      // hand-shake words are read BEFORE the data they guard
+                const int pr = RP(r);
+                const double rr = RR(r);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ed[k] = RD(ebase + k); ev[k] = RV(ebase + k); }
+                asm volatile("" ::: "memory");      // ... and the data BEFORE the words that release its slots
+                if (FWD ? (r < ra) : (r >= ra)) {
+                    if (FWD) { lo = bound; hi = pr; } else { hi = bound; lo = pr; }
+                    r_cons[tid] = r;
+                    e_cons[tid] = FWD ? lo : hi;
+                    if (FWD ? (hi <= ea) : (lo >= ea)) {
+                        len = hi - lo;
+                        acc = rr;
+                        reinterpret_cast<unsigned long long *>(rhs)[r] = kSentinel;
+                        if (len <= 4) {
+                            phase = 1;
+                        } else {
+                            if (FWD)        { j = lo;     jend = hi - 1; dpos = hi - 1; }
+                            else if (!DESC) { j = lo + 1; jend = hi;     dpos = lo; }
+                            else            { j = hi - 1; jend = lo;     dpos = lo; }
+                            phase = 2;
+                        }
+                        progressed = true;
+                    }
+                }
+            }
+            if (phase == 1) {
+                // register slots of the row: FWD [0,len) with the diagonal last, BWD [4-len,4) with the diagonal first
+                const int first = FWD ? 0 : 4 - len;
+                const int dslot = FWD ? len - 1 : first;
+                // round 2: ring entries of all in-workgroup dependencies at once
+                v4i re[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned d = (unsigned)ed[k];
+                    const int lane = (int)((d >> 15) & 255u);
+                    re[k] = xr[((int)(d & 0x7fffu) & (kXD - 1)) * kThreads + lane];
+                }
+                bool ready = true;
+                double xs[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool isdep = FWD ? (k < len - 1) : (k > first);
+                    if (isdep && ready) {
+                        const unsigned d = (unsigned)ed[k];
+                        const unsigned oslot = d >> 15;
+                        const int kl = (int)(d & 0x7fffu);
+                        if (oslot == myslot && kl == rloc - 1) {
+                            xs[k] = prev_val;
+                        } else if ((oslot >> 8) == wg && re[k].x <= kl) {
+                            if (re[k].x == kl) xs[k] = __hiloint2double(re[k].w, re[k].z);
+                            else ready = false;                                  // producer not there yet
+                        } else {
+                            double xc = 0.0;
+                            if (external(oslot, kl, xc)) xs[k] = xc; else ready = false;
+                        }
+                    }
+                }
+                if (ready) {
+                    // sequential accumulation in stored order (reference loop order), diagonal by position
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = DESC ? 3 - kk : kk;
+                        const bool isdep = FWD ? (k < len - 1) : (k > first);
+                        if (isdep) { const double prod = ev[k] * xs[k]; acc = acc - prod; }
+                    }
+                    double dv = ev[0];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) dv = (k == dslot) ? ev[k] : dv;
+                    publish(acc / dv);
+                    progressed = true;
+                }
+            } else if (phase == 2) {
+                while (j != jend) {
+                    const unsigned d = (unsigned)RD(j);
+                    const unsigned oslot = d >> 15;
+                    const int kl = (int)(d & 0x7fffu);
+                    double xc = 0.0;
+                    bool have = false;
+                    if (oslot == myslot && kl == rloc - 1) {
+                        xc = prev_val;
+                        have = true;
+                    } else if ((oslot >> 8) == wg) {
+                        const int lane = (int)(oslot & 255u);
+                        const v4i e = xr[(kl & (kXD - 1)) * kThreads + lane];
+                        if (e.x == kl) {
+                            xc = __hiloint2double(e.w, e.z);
+                            have = true;
+                        } else if (e.x < kl) {
+                            break;
+                        }
+                    }
+                    if (!have && !external(oslot, kl, xc)) break;
+                    const double prod = RV(j) * xc;
+                    acc = acc - prod;
+                    j += DESC ? -1 : 1;
+                    progressed = true;
+                }
+                if (j == jend) {
+                    publish(acc / RV(dpos));
+                    progressed = true;
+                }
+            }
+        }
+        if (__any(progressed)) {
+            spins = 0;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSolveSpinLimit) {
+                if ((tid & 63) == 0) atomicExch(err, 1);
+                fin[tid] = 1;
+                break;
+            }
+        }
+    }
+#undef RD
+#undef RV
+#undef RP
+#undef RR
+}
+
+int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
+           int32_t max_row_len, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err)
 {
     // *d_ticket must be zero on entry (the caller zeroes the whole control block once per apply)
+    if (desc) {
+        const unsigned grid = (unsigned)(sch.nslots / kThreads);
+        static const bool allow_lc = getenv("ILUPP_SOLVE_V2") == nullptr;
+        // rows must fit the entry ring with room for the refill quantum; tiny systems keep the simple kernel
+        if (allow_lc && max_row_len > 0 && max_row_len <= kEW - 2 * kEQ && M.nnz >= 16 && M.n >= 8) {
+#define LAUNCHS(K)                                                                                           \
+            do {                                                                                             \
+                ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lc<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLcLds)); \
+                hipLaunchKernelGGL((k_sptrsv_lc<K>), dim3(grid), dim3(kLcThreads), kLcLds, st, M.ptr, desc, M.val, M.n, (long)M.nnz, \
+                                   rhs_and_reset, out, sch.nslots, sch.sfirst, sch.scount, d_ticket, d_err);  \
+            } while (0)
+            switch (kind) {
+            case SWEEP_FWD_LAST_ASC: LAUNCHS(SWEEP_FWD_LAST_ASC); break;
+            case SWEEP_BWD_FIRST_ASC: LAUNCHS(SWEEP_BWD_FIRST_ASC); break;
+            default: LAUNCHS(SWEEP_BWD_FIRST_DESC); break;
+            }
+#undef LAUNCHS
+            ILUPP_HIP(hipGetLastError());
+            return ILUPP_OK;
+        }
+#define LAUNCHD(K)                                                                                           \
+        hipLaunchKernelGGL((k_sptrsv_desc<K>), dim3(grid), dim3(kThreads), 0, st, M.ptr, desc, M.val, rhs_and_reset, out, \
+                           sch.nslots, sch.sfirst, sch.scount, d_ticket, d_err)
+        switch (kind) {
+        case SWEEP_FWD_LAST_ASC: LAUNCHD(SWEEP_FWD_LAST_ASC); break;
+        case SWEEP_BWD_FIRST_ASC: LAUNCHD(SWEEP_BWD_FIRST_ASC); break;
+        default: LAUNCHD(SWEEP_BWD_FIRST_DESC); break;
+        }
+#undef LAUNCHD
+        ILUPP_HIP(hipGetLastError());
+        return ILUPP_OK;
+    }
+    // generic kernel (no descriptors: block size or grid beyond the compact encoding)
     const unsigned grid = (unsigned)((sch.nb + kThreads - 1) / kThreads);
     switch (kind) {
     case SWEEP_FWD_LAST_ASC:

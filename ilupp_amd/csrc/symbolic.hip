@@ -56,33 +56,32 @@ __device__ __forceinline__ int lower_bound_dev(const int32_t *idx, int lo, int h
 __global__ void k_row_cuts(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                            uint8_t *__restrict__ cutf, uint8_t *__restrict__ cutb, int32_t *__restrict__ stats)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    int cf = 0, cb = 0, len = 0;
-    if (r < n) {
+    // grid-stride with per-thread partial sums and ONE set of atomics per workgroup: three words shared by
+    // a quarter of a million waves would serialise in L2
+    int nf = 0, nbk = 0, mx = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const int lo = ptr[r], hi = ptr[r + 1];
-        len = hi - lo;
-        int pos = lower_bound_dev(idx, lo, hi, r - 1);
+        mx = max(mx, hi - lo);
+        const int pos = lower_bound_dev(idx, lo, hi, r - 1);
         bool has_prev = false, has_next = false;
         for (int q = pos; q < hi && q < pos + 3; ++q) {
             const int c = idx[q];
             has_prev |= (c == r - 1);
             has_next |= (c == r + 1);
         }
-        cf = (r == 0) ? 1 : (has_prev ? 0 : 1);
+        const int cf = (r == 0) ? 1 : (has_prev ? 0 : 1);
         cutf[r] = (uint8_t)cf;
-        if (r + 1 < n) { cb = has_next ? 0 : 1; cutb[r + 1] = (uint8_t)cb; }
-        if (r == 0) { cutb[0] = 1; cb += 1; }
+        nf += cf;
+        if (r + 1 < n) { const int cb = has_next ? 0 : 1; cutb[r + 1] = (uint8_t)cb; nbk += cb; }
+        if (r == 0) { cutb[0] = 1; nbk += 1; }
     }
-    // wave-level reduction, one atomic per wave
-    const unsigned long long mf = __ballot(cf), mb = __ballot(cb);
-    int mx = len;
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0) {
-        // cb may be 2 for r == 0 (cutb[0] and cutb[1]); count it exactly
-        atomicAdd(&stats[0], __popcll(mf));
-        atomicAdd(&stats[1], __popcll(mb));
-        atomicMax(&stats[2], mx);
-    }
+    __shared__ int red[3];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) { nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&stats[0], red[0]); atomicAdd(&stats[1], red[1]); atomicMax(&stats[2], red[2]); }
 }
 
 // start[b] = first allowed cut in the nominal cell [b*B, (b+1)*B), or the cell's end if the cell
@@ -111,6 +110,7 @@ static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t
     if (B < 1) B = 1;
     int64_t nb = ((int64_t)n + B - 1) / B;
     sch->nb = (int32_t)nb;
+    sch->B = (int32_t)B;
     ILUPP_HIP(hipMalloc(&sch->start, sizeof(int32_t) * (size_t)(nb + 1)));
     hipLaunchKernelGGL(k_block_starts, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st,
                        n, (int32_t)B, (int32_t)nb, cut, sch->start);
@@ -125,7 +125,11 @@ int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const
     ILUPP_HIP(hipMalloc(&cutb, (size_t)n + 1));
     ILUPP_HIP(hipMalloc(&stats, sizeof(int32_t) * 4));
     ILUPP_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * 4, st));
-    hipLaunchKernelGGL(k_row_cuts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ptr, idx, cutf, cutb, stats);
+    {
+        unsigned gb = (unsigned)((n + 255) / 256);
+        if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL(k_row_cuts, dim3(gb), dim3(256), 0, st, n, ptr, idx, cutf, cutb, stats);
+    }
     int32_t h[4];
     ILUPP_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
