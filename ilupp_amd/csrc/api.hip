@@ -139,6 +139,9 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     // one pass over A's pattern gives the factor-sweep schedule; L shares A's forward cuts and U its
     // backward cuts (same strictly-lower / strictly-upper patterns)
     count_cuts_and_schedule(st, A.n, A.ptr, A.idx, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
+    const int max_wgs = p->max_lanes / kThreads;
+    choose_tiling(st, A.n, A.ptr, A.idx, &p->sA, true, max_wgs);
+    choose_tiling(st, A.n, A.ptr, A.idx, &p->sU, false, max_wgs);
     build_slot_tables(st, &p->sA, true);
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
@@ -177,6 +180,8 @@ void ensure_transposed(ilupp_precond *p)
         count_cuts_and_schedule(st, p->n, p->UcT.ptr, p->UcT.idx, p->max_lanes, &p->sUT, nullptr, &m1);
         count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, &m2);
         p->max_len_T = m1 > m2 ? m1 : m2;
+        choose_tiling(st, p->n, p->UcT.ptr, p->UcT.idx, &p->sUT, true, p->max_lanes / kThreads);
+        choose_tiling(st, p->n, p->LcT.ptr, p->LcT.idx, &p->sLT, false, p->max_lanes / kThreads);
         build_slot_tables(st, &p->sUT, true);
         build_slot_tables(st, &p->sLT, false);
         if (schedule_is_compact(p->sUT) && schedule_is_compact(p->sLT)) {

@@ -47,6 +47,8 @@ struct Schedule {
     int32_t *blk2slot = nullptr;   // nb
     int32_t *sfirst = nullptr;     // nslots: first row of the slot in processing order
     int32_t *scount = nullptr;     // nslots: number of rows of the slot
+    // 2-D tiling of the block grid (0 = identity placement): block b = (b % s2, b / s2), a workgroup owns ty x tz blocks
+    int32_t tile_s2 = 0, tile_ty = 0, tile_tz = 0;
     void release();
 };
 
@@ -112,6 +114,7 @@ void fill_u64(hipStream_t st, unsigned long long *p, int64_t count, unsigned lon
 int device_cu_count();
 
 // schedule.hip
+void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, Schedule *sch, bool fwd, int max_wgs);
 void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd);
 void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc);
 bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, Ilu0Program *P);

@@ -10,6 +10,11 @@
 //    once, so the numeric kernel has no merge loop and no dependent index loads.
 //
 // All of it is integer streaming work with thread-per-row kernels over independent rows.
+#include <stdlib.h>
+
+#include <utility>
+#include <vector>
+
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -26,14 +31,33 @@ __device__ __forceinline__ int block_of(int c, int B, int nb, const int32_t *__r
     return b;
 }
 
-__global__ void k_slot_tables(int32_t nb, int32_t nslots, int fwd, const int32_t *__restrict__ start,
+// Placement of row blocks on the persistent grid.
+//  identity: slot s owns block s (in sweep order).
+//  tiled:    the blocks form a 2-D grid (b % s2, b / s2) -- on a lexicographic 3-D mesh: (y, z) of the
+//            x-line -- and a workgroup owns a ty x tz patch of it, so that both neighbour dependencies of
+//            a block stay inside the workgroup (LDS hand-off) except on two faces of the patch.  A
+//            dependency path then crosses O(sqrt(#workgroups)) workgroup borders instead of O(#workgroups).
+struct Tiling { int s2, ty, tz, NY, nb; };
+
+__device__ __forceinline__ int tiled_block_of(int slot, const Tiling &t)
+{
+    const int T = slot / kThreads, lane = slot % kThreads;
+    const int by = (T % t.NY) * t.ty + lane % t.ty;
+    const int bz = (T / t.NY) * t.tz + lane / t.ty;
+    if (by >= t.s2 || lane / t.ty >= t.tz) return -1;
+    const long bs = (long)bz * t.s2 + by;
+    return bs < t.nb ? (int)bs : -1;
+}
+
+__global__ void k_slot_tables(int32_t nb, int32_t nslots, int fwd, Tiling til, const int32_t *__restrict__ start,
                               int32_t *__restrict__ slot2blk, int32_t *__restrict__ blk2slot,
                               int32_t *__restrict__ sfirst, int32_t *__restrict__ scount)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
-    // identity placement: forward sweeps hand block s to slot s, backward sweeps block nb-1-s
-    const int b = (s < nb) ? (fwd ? s : nb - 1 - s) : -1;
+    // block index in SWEEP order (forward: b, backward: nb-1-b)
+    int bs = (til.s2 > 0) ? tiled_block_of(s, til) : (s < nb ? s : -1);
+    const int b = bs < 0 ? -1 : (fwd ? bs : nb - 1 - bs);
     slot2blk[s] = b;
     if (b >= 0) {
         blk2slot[b] = s;
@@ -49,14 +73,94 @@ __global__ void k_slot_tables(int32_t nb, int32_t nslots, int fwd, const int32_t
 void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
 {
     sch->fwd = fwd;
-    sch->nslots = ((sch->nb + kThreads - 1) / kThreads) * kThreads;
+    Tiling til = {0, 0, 0, 0, sch->nb};
+    if (sch->tile_s2 > 0) {
+        til.s2 = sch->tile_s2; til.ty = sch->tile_ty; til.tz = sch->tile_tz;
+        til.NY = (til.s2 + til.ty - 1) / til.ty;
+        const int nbz = (sch->nb + til.s2 - 1) / til.s2;
+        const int NZ = (nbz + til.tz - 1) / til.tz;
+        sch->nslots = til.NY * NZ * kThreads;
+    } else {
+        sch->nslots = ((sch->nb + kThreads - 1) / kThreads) * kThreads;
+    }
     const size_t bytes = sizeof(int32_t) * (size_t)sch->nslots;
     ILUPP_HIP(hipMalloc(&sch->slot2blk, bytes));
     ILUPP_HIP(hipMalloc(&sch->blk2slot, sizeof(int32_t) * (size_t)(sch->nb > 0 ? sch->nb : 1)));
     ILUPP_HIP(hipMalloc(&sch->sfirst, bytes));
     ILUPP_HIP(hipMalloc(&sch->scount, bytes));
     hipLaunchKernelGGL(k_slot_tables, dim3((unsigned)(sch->nslots / kThreads)), dim3(kThreads), 0, st,
-                       sch->nb, sch->nslots, fwd ? 1 : 0, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount);
+                       sch->nb, sch->nslots, fwd ? 1 : 0, til, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount);
+}
+
+// block-level dependency offsets of a sample of blocks (middle row of each sampled block)
+__global__ void k_sample_block_offsets(int32_t nsamp, int32_t stride, int32_t B, int32_t nb, int fwd,
+                                       const int32_t *__restrict__ start, const int32_t *__restrict__ ptr,
+                                       const int32_t *__restrict__ idx, int32_t *__restrict__ offs)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsamp) return;
+    const int b = (int)(((long)s * stride) % nb);
+    int32_t *o = offs + (size_t)s * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = 0;
+    if (start[b + 1] <= start[b]) return;
+    const int r = start[b] + (start[b + 1] - start[b]) / 2;
+    int w = 0;
+    for (int q = ptr[r]; q < ptr[r + 1] && w < 8; ++q) {
+        const int c = idx[q];
+        if (fwd ? (c >= r) : (c <= r)) continue;
+        const int d = fwd ? (b - block_of(c, B, nb, start)) : (block_of(c, B, nb, start) - b);
+        if (d > 0) o[w++] = d;
+    }
+}
+
+// Decide whether the block grid has the (1, s2) dependency structure of a lexicographic mesh and pick
+// the patch shape.  Purely a placement (performance) decision: any placement is correct.
+void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, Schedule *sch, bool fwd, int max_wgs)
+{
+    (void)n;
+    sch->tile_s2 = sch->tile_ty = sch->tile_tz = 0;
+    static const bool off = getenv("ILUPP_NO_TILES") != nullptr;
+    if (off || sch->nb < 2 * kThreads) return;
+    const int nsamp = sch->nb < 2048 ? sch->nb : 2048;
+    const int stride = sch->nb / nsamp > 0 ? sch->nb / nsamp : 1;
+    int32_t *d_offs = nullptr;
+    ILUPP_HIP(hipMalloc(&d_offs, sizeof(int32_t) * 8 * (size_t)nsamp));
+    hipLaunchKernelGGL(k_sample_block_offsets, dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, nsamp, stride,
+                       sch->B, sch->nb, fwd ? 1 : 0, sch->start, ptr, idx, d_offs);
+    std::vector<int32_t> h((size_t)nsamp * 8);
+    ILUPP_HIP(hipMemcpyAsync(h.data(), d_offs, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipFree(d_offs));
+    // most frequent offset > 1
+    std::vector<std::pair<int, int>> cnt;   // (offset, count), tiny
+    int has1 = 0, nonempty = 0;
+    for (int s = 0; s < nsamp; ++s) {
+        bool any = false;
+        for (int k = 0; k < 8; ++k) {
+            const int d = h[(size_t)s * 8 + k];
+            if (d <= 0) continue;
+            any = true;
+            if (d == 1) { ++has1; continue; }
+            bool found = false;
+            for (auto &pr : cnt) if (pr.first == d) { ++pr.second; found = true; break; }
+            if (!found && cnt.size() < 64) cnt.push_back({d, 1});
+        }
+        nonempty += any ? 1 : 0;
+    }
+    int s2 = 0, best = 0;
+    for (auto &pr : cnt) if (pr.second > best) { best = pr.second; s2 = pr.first; }
+    if (nonempty == 0 || s2 < 4 || best * 2 < nonempty || has1 * 2 < nonempty) return;
+    const int nbz = (sch->nb + s2 - 1) / s2;
+    // patch shape ty x tz = 256, as square as the grid allows
+    int ty = 16, tz = 16;
+    while (ty > s2 && ty > 1) { ty >>= 1; tz <<= 1; }
+    while (tz > nbz && tz > 1) { tz >>= 1; ty <<= 1; }
+    if (ty > s2 || ty * tz != kThreads) return;
+    const int NY = (s2 + ty - 1) / ty, NZ = (nbz + tz - 1) / tz;
+    // every workgroup must be resident at once (a patch may wait on a higher-numbered patch)
+    if ((long)NY * NZ > max_wgs) return;
+    sch->tile_s2 = s2; sch->tile_ty = ty; sch->tile_tz = tz;
 }
 
 // ---------------------------------------------------------------------------------------------
