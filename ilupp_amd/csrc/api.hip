@@ -4,7 +4,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -17,26 +20,92 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 void DevMat::release()
 {
     if (owns) {
-        if (ptr) (void)hipFree(ptr);
-        if (idx) (void)hipFree(idx);
-        if (val) (void)hipFree(val);
+        if (ptr) (void)pool_free(ptr);
+        if (idx) (void)pool_free(idx);
+        if (val) (void)pool_free(val);
     }
     ptr = idx = nullptr; val = nullptr; nnz = 0;
 }
 void Schedule::release()
 {
-    if (start) (void)hipFree(start);
-    if (slot2blk) (void)hipFree(slot2blk);
-    if (blk2slot) (void)hipFree(blk2slot);
-    if (sfirst) (void)hipFree(sfirst);
-    if (scount) (void)hipFree(scount);
+    if (start) (void)pool_free(start);
+    if (slot2blk) (void)pool_free(slot2blk);
+    if (blk2slot) (void)pool_free(blk2slot);
+    if (sfirst) (void)pool_free(sfirst);
+    if (scount) (void)pool_free(scount);
     start = slot2blk = blk2slot = sfirst = scount = nullptr; nb = 0; nslots = 0;
 }
 void Ilu0Program::release()
 {
-    if (prow) (void)hipFree(prow);
-    if (prog) (void)hipFree(prog);
+    if (prow) (void)pool_free(prow);
+    if (prog) (void)pool_free(prog);
     prow = prog = nullptr; nwords = 0;
+}
+
+// ---- pooled device memory ---------------------------------------------------------------------
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;     // size -> block
+    std::unordered_map<void *, size_t> live;       // block -> size
+    size_t cached = 0;
+    static constexpr size_t kMaxCached = 24ull << 30;   // of 288 GB HBM
+} g_pool;
+}  // namespace
+
+hipError_t pool_malloc(void **p, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.free_blocks.find(bytes);
+        if (it != g_pool.free_blocks.end()) {
+            *p = it->second;
+            g_pool.free_blocks.erase(it);
+            g_pool.cached -= bytes;
+            g_pool.live[*p] = bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = ::hipMalloc(p, bytes);
+    if (e != hipSuccess) {          // out of memory: give the cache back and retry once
+        pool_trim();
+        (void)hipGetLastError();
+        e = ::hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        g_pool.live[*p] = bytes;
+    }
+    return e;
+}
+
+hipError_t pool_free(void *p)
+{
+    if (!p) return hipSuccess;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.live.find(p);
+        if (it == g_pool.live.end()) return ::hipFree(p);
+        bytes = it->second;
+        g_pool.live.erase(it);
+        if (g_pool.cached + bytes <= Pool::kMaxCached) {
+            g_pool.free_blocks.emplace(bytes, p);
+            g_pool.cached += bytes;
+            return hipSuccess;
+        }
+    }
+    return ::hipFree(p);
+}
+
+void pool_trim()
+{
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto &kv : g_pool.free_blocks) (void)::hipFree(kv.second);
+    g_pool.free_blocks.clear();
+    g_pool.cached = 0;
 }
 
 static int report(const HipError &e)
@@ -89,15 +158,16 @@ bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <=
 void destroy_obj(ilupp_precond *p)
 {
     if (!p) return;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);   // pooled blocks may be handed out again at once
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
     p->prog.release();
-    if (p->prog_f3) (void)hipFree(p->prog_f3);
-    for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)hipFree(d);
-    if (p->work) (void)hipFree(p->work);
-    if (p->xdev) (void)hipFree(p->xdev);
-    if (p->done) (void)hipFree(p->done);
-    if (p->ctrl) (void)hipFree(p->ctrl);
+    if (p->prog_f3) (void)pool_free(p->prog_f3);
+    for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)pool_free(d);
+    if (p->work) (void)pool_free(p->work);
+    if (p->xdev) (void)pool_free(p->xdev);
+    if (p->done) (void)pool_free(p->done);
+    if (p->ctrl) (void)pool_free(p->ctrl);
     for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -109,9 +179,9 @@ ilupp_precond *new_obj(int32_t n)
     p->n = n;
     ILUPP_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     for (auto &e : p->ev) ILUPP_HIP(hipEventCreate(&e));
-    ILUPP_HIP(hipMalloc(&p->work, sizeof(double) * (size_t)n));
-    ILUPP_HIP(hipMalloc(&p->done, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(hipMalloc(&p->ctrl, 64));
+    ILUPP_HIP(pool_malloc(&p->work, sizeof(double) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&p->done, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&p->ctrl, 64));
     fill_u64(p->stream, reinterpret_cast<unsigned long long *>(p->work), n, kSentinel);
     p->max_lanes = device_cu_count() * kThreads;
     return p;
@@ -316,9 +386,9 @@ int ilupp_hip_ilu0_create(const double *data, const int32_t *indices, const int3
     const int64_t nnz = indptr[n];
     DevMat A;
     A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
-    ILUPP_HIP(hipMalloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(hipMalloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-    ILUPP_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
     ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
@@ -366,8 +436,8 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     p->apply_events_valid = false;
     if (p->haveT) {
         p->LcT.release(); p->UcT.release(); p->sUT.release(); p->sLT.release();
-        if (p->dUT) (void)hipFree(p->dUT);
-        if (p->dLT) (void)hipFree(p->dLT);
+        if (p->dUT) (void)pool_free(p->dUT);
+        if (p->dLT) (void)pool_free(p->dLT);
         p->dUT = p->dLT = nullptr; p->haveT = false;
     }
     if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out");
@@ -413,7 +483,7 @@ static int apply_host(ilupp_precond *p, double *x, int64_t len, int transpose)
     API_TRY
     if (!p) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
     if (len != p->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }
-    if (!p->xdev) ILUPP_HIP(hipMalloc(&p->xdev, sizeof(double) * (size_t)p->n));
+    if (!p->xdev) ILUPP_HIP(pool_malloc(&p->xdev, sizeof(double) * (size_t)p->n));
     ILUPP_HIP(hipMemcpyAsync(p->xdev, x, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
     int rc = apply_dev(p, p->xdev, transpose);
     if (rc) return rc;
@@ -509,6 +579,13 @@ int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t)
 {
     if (!p || !t) return ILUPP_ERR_INVALID;
     *t = p->tm;
+    return ILUPP_OK;
+}
+
+int ilupp_hip_debug_ctrl(ilupp_precond *p, int32_t *out16)
+{
+    if (!p || !out16) return ILUPP_ERR_INVALID;
+    if (hipMemcpy(out16, p->ctrl, 64, hipMemcpyDeviceToHost) != hipSuccess) return ILUPP_ERR_HIP;
     return ILUPP_OK;
 }
 

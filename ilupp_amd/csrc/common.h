@@ -20,6 +20,15 @@ struct HipError { hipError_t code; const char *what; const char *file; int line;
         if (e_ != hipSuccess) throw ilupp::HipError{e_, #expr, __FILE__, __LINE__};          \
     } while (0)
 
+// ---- pooled device memory ---------------------------------------------------------------------
+// hipMalloc/hipFree of multi-GB buffers cost milliseconds and serialise the device; a factorisation
+// that is repeated (time stepping, refactorisation, the benchmark loop) asks for the same sizes every
+// time, so freed blocks are kept in a size-keyed pool (bounded) and handed out again.
+hipError_t pool_malloc(void **p, size_t bytes);
+hipError_t pool_free(void *p);
+void pool_trim();
+template <class T> inline hipError_t pool_malloc(T **p, size_t bytes) { return pool_malloc(reinterpret_cast<void **>(p), bytes); }
+
 // ---- device containers ----------------------------------------------------------------------
 // A compressed sparse matrix resident in HBM.  `is_csr` is only the LABEL handed back to the
 // caller (reference: matrix_sparse::orientation); kernels always see "major slices".

@@ -68,23 +68,23 @@ int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t
 {
     const int32_t n = A.n;
     int32_t *lrow, *urow, *missing;
-    ILUPP_HIP(hipMalloc(&lrow, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(hipMalloc(&urow, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(hipMalloc(&missing, sizeof(int32_t)));
+    ILUPP_HIP(pool_malloc(&lrow, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&urow, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&missing, sizeof(int32_t)));
     const int32_t big = 0x7fffffff;
     ILUPP_HIP(hipMemcpyAsync(missing, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
     const unsigned gb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_ilu0_count, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, lrow, urow, missing);
 
     L->n = U->n = n; L->is_csr = U->is_csr = true; L->owns = U->owns = true;
-    ILUPP_HIP(hipMalloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(hipMalloc(&U->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&U->ptr, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(hipMemsetAsync(L->ptr, 0, sizeof(int32_t), st));
     ILUPP_HIP(hipMemsetAsync(U->ptr, 0, sizeof(int32_t), st));
     size_t tmp_bytes = 0;
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, lrow, L->ptr + 1, n, st));
     void *tmp = nullptr;
-    ILUPP_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, lrow, L->ptr + 1, n, st));
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, urow, U->ptr + 1, n, st));
     int32_t tot[2], miss;
@@ -92,13 +92,13 @@ int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t
     ILUPP_HIP(hipMemcpyAsync(&tot[1], U->ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipMemcpyAsync(&miss, missing, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(hipFree(tmp)); ILUPP_HIP(hipFree(lrow)); ILUPP_HIP(hipFree(urow)); ILUPP_HIP(hipFree(missing));
+    ILUPP_HIP(pool_free(tmp)); ILUPP_HIP(pool_free(lrow)); ILUPP_HIP(pool_free(urow)); ILUPP_HIP(pool_free(missing));
     if (first_missing_diag) *first_missing_diag = (miss == big) ? -1 : miss;
     L->nnz = tot[0]; U->nnz = tot[1];
-    ILUPP_HIP(hipMalloc(&L->idx, sizeof(int32_t) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
-    ILUPP_HIP(hipMalloc(&L->val, sizeof(double) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
-    ILUPP_HIP(hipMalloc(&U->idx, sizeof(int32_t) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
-    ILUPP_HIP(hipMalloc(&U->val, sizeof(double) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
+    ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
+    ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
+    ILUPP_HIP(pool_malloc(&U->idx, sizeof(int32_t) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
+    ILUPP_HIP(pool_malloc(&U->val, sizeof(double) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
     if (miss != big) return ILUPP_ERR_NO_DIAGONAL;
     hipLaunchKernelGGL(k_ilu0_pattern, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, L->ptr, U->ptr, L->idx, L->val, U->idx);
     return ILUPP_OK;
@@ -736,7 +736,7 @@ int ilu0_numeric(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Sc
     else if (max_row_len <= 32) LAUNCH(32, false, 32 * kThreads * sizeof(double));
     else if (max_row_len <= 64) LAUNCH(64, false, 64 * kThreads * sizeof(double));
     else {
-        ILUPP_HIP(hipMalloc(&wscratch, sizeof(double) * (size_t)grid * kThreads * (size_t)max_row_len));
+        ILUPP_HIP(pool_malloc(&wscratch, sizeof(double) * (size_t)grid * kThreads * (size_t)max_row_len));
         LAUNCH(1, true, 0);
     }
 #undef LAUNCH
@@ -748,7 +748,7 @@ int ilu0_numeric(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Sc
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
     ILUPP_HIP(hipEventDestroy(e0));
     ILUPP_HIP(hipEventDestroy(e1));
-    if (wscratch) ILUPP_HIP(hipFree(wscratch));
+    if (wscratch) ILUPP_HIP(pool_free(wscratch));
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
     return ILUPP_OK;
 }

@@ -84,10 +84,10 @@ void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
         sch->nslots = ((sch->nb + kThreads - 1) / kThreads) * kThreads;
     }
     const size_t bytes = sizeof(int32_t) * (size_t)sch->nslots;
-    ILUPP_HIP(hipMalloc(&sch->slot2blk, bytes));
-    ILUPP_HIP(hipMalloc(&sch->blk2slot, sizeof(int32_t) * (size_t)(sch->nb > 0 ? sch->nb : 1)));
-    ILUPP_HIP(hipMalloc(&sch->sfirst, bytes));
-    ILUPP_HIP(hipMalloc(&sch->scount, bytes));
+    ILUPP_HIP(pool_malloc(&sch->slot2blk, bytes));
+    ILUPP_HIP(pool_malloc(&sch->blk2slot, sizeof(int32_t) * (size_t)(sch->nb > 0 ? sch->nb : 1)));
+    ILUPP_HIP(pool_malloc(&sch->sfirst, bytes));
+    ILUPP_HIP(pool_malloc(&sch->scount, bytes));
     hipLaunchKernelGGL(k_slot_tables, dim3((unsigned)(sch->nslots / kThreads)), dim3(kThreads), 0, st,
                        sch->nb, sch->nslots, fwd ? 1 : 0, til, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount);
 }
@@ -125,13 +125,13 @@ void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t 
     const int nsamp = sch->nb < 2048 ? sch->nb : 2048;
     const int stride = sch->nb / nsamp > 0 ? sch->nb / nsamp : 1;
     int32_t *d_offs = nullptr;
-    ILUPP_HIP(hipMalloc(&d_offs, sizeof(int32_t) * 8 * (size_t)nsamp));
+    ILUPP_HIP(pool_malloc(&d_offs, sizeof(int32_t) * 8 * (size_t)nsamp));
     hipLaunchKernelGGL(k_sample_block_offsets, dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, nsamp, stride,
                        sch->B, sch->nb, fwd ? 1 : 0, sch->start, ptr, idx, d_offs);
     std::vector<int32_t> h((size_t)nsamp * 8);
     ILUPP_HIP(hipMemcpyAsync(h.data(), d_offs, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(hipFree(d_offs));
+    ILUPP_HIP(pool_free(d_offs));
     // most frequent offset > 1
     std::vector<std::pair<int, int>> cnt;   // (offset, count), tiny
     int has1 = 0, nonempty = 0;
@@ -166,7 +166,7 @@ void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t 
 // ---------------------------------------------------------------------------------------------
 // solve descriptors
 // ---------------------------------------------------------------------------------------------
-// desc = owner_slot << 15 | kloc, kloc = index of row c in its owner's processing order.
+// desc = owner_slot << 15 | kloc, kloc = index of row c in its owner's processing order; -1 on the diagonal.
 __global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                             int32_t B, int32_t nb, int fwd, const int32_t *__restrict__ start,
                             const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc)
@@ -175,7 +175,7 @@ __global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const in
     if (r >= n) return;
     for (int q = ptr[r]; q < ptr[r + 1]; ++q) {
         const int c = idx[q];
-        if (c == r) { desc[q] = 0; continue; }
+        if (c == r) { desc[q] = -1; continue; }     // diagonal marker: also delimits the rows of the stream
         const int b = block_of(c, B, nb, start);
         const int kloc = fwd ? (c - start[b]) : (start[b + 1] - 1 - c);
         desc[q] = (blk2slot[b] << 15) | kloc;
@@ -184,7 +184,7 @@ __global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const in
 
 void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc)
 {
-    ILUPP_HIP(hipMalloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
+    ILUPP_HIP(pool_malloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
     hipLaunchKernelGGL(k_make_desc, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, st, M.n, M.ptr, M.idx,
                        sch.B, sch.nb, sch.fwd ? 1 : 0, sch.start, sch.blk2slot, *desc);
 }
@@ -334,16 +334,16 @@ bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, con
     const int32_t n = A.n;
     if (sch.B > 32768 || sch.nslots > (1 << 17)) return false;
     int32_t *prog = nullptr, *flag = nullptr;
-    ILUPP_HIP(hipMalloc(&prog, sizeof(int32_t) * 12 * (size_t)n + 64));
-    ILUPP_HIP(hipMalloc(&flag, 16));
+    ILUPP_HIP(pool_malloc(&prog, sizeof(int32_t) * 12 * (size_t)n + 64));
+    ILUPP_HIP(pool_malloc(&flag, 16));
     ILUPP_HIP(hipMemsetAsync(flag, 0, 16, st));
     hipLaunchKernelGGL(k_ilu0_program_f3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr,
                        sch.B, sch.nb, sch.start, sch.blk2slot, prog, flag);
     int32_t h = 0;
     ILUPP_HIP(hipMemcpyAsync(&h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(hipFree(flag));
-    if (h != 0) { ILUPP_HIP(hipFree(prog)); return false; }
+    ILUPP_HIP(pool_free(flag));
+    if (h != 0) { ILUPP_HIP(pool_free(prog)); return false; }
     *prog_out = prog;
     return true;
 }
@@ -354,39 +354,39 @@ bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const 
 {
     const int32_t n = A.n;
     int32_t *nwords = nullptr, *stats = nullptr;
-    ILUPP_HIP(hipMalloc(&nwords, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(hipMalloc(&stats, 16));
+    ILUPP_HIP(pool_malloc(&nwords, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&stats, 16));
     ILUPP_HIP(hipMemsetAsync(stats, 0, 16, st));
     const unsigned gb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL((k_ilu0_program<false>), dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr, sch.B, sch.nb,
                        sch.start, sch.blk2slot, nwords, (const int32_t *)nullptr, (int32_t *)nullptr, stats);
-    ILUPP_HIP(hipMalloc(&P->prow, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&P->prow, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(hipMemsetAsync(P->prow, 0, sizeof(int32_t), st));
     // 64-bit total first: the compact program indexes words with int32
     size_t tmp_bytes = 0;
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, nwords, P->prow + 1, n, st));
     void *tmp = nullptr;
-    ILUPP_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, nwords, P->prow + 1, n, st));
     int32_t h[4], total = 0;
     ILUPP_HIP(hipMemcpyAsync(h, stats, 16, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipMemcpyAsync(&total, P->prow + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(hipFree(tmp));
+    ILUPP_HIP(pool_free(tmp));
     P->max_words = h[0];
     P->max_ulen = h[1];
     const bool ok = (h[2] == 0) && total > 0 && sch.B <= 32768 && sch.nslots <= (1 << 17);
     if (!ok) {
-        ILUPP_HIP(hipFree(nwords)); ILUPP_HIP(hipFree(stats));
-        ILUPP_HIP(hipFree(P->prow)); P->prow = nullptr;
+        ILUPP_HIP(pool_free(nwords)); ILUPP_HIP(pool_free(stats));
+        ILUPP_HIP(pool_free(P->prow)); P->prow = nullptr;
         return false;
     }
     P->nwords = total;
-    ILUPP_HIP(hipMalloc(&P->prog, sizeof(int32_t) * (size_t)total));
+    ILUPP_HIP(pool_malloc(&P->prog, sizeof(int32_t) * (size_t)total));
     hipLaunchKernelGGL((k_ilu0_program<true>), dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr, sch.B, sch.nb,
                        sch.start, sch.blk2slot, nwords, P->prow, P->prog, stats);
     ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(hipFree(nwords)); ILUPP_HIP(hipFree(stats));
+    ILUPP_HIP(pool_free(nwords)); ILUPP_HIP(pool_free(stats));
     return true;
 }
 

@@ -248,12 +248,13 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // padding nor a scalar fallback (a fallback branch would make hipcc wait for every load in turn).
 __device__ __forceinline__ long clamp_base(long i, long n, int w) { return i < 0 ? 0 : (i > n - w ? n - w : i); }
 
-static constexpr int kEW = 32, kEQ = 8;    // entry ring / refill quantum (descriptors, values)
-static constexpr int kRW = 8, kRQ = 4;     // row ring / refill quantum (row pointers, right-hand side)
+static constexpr int kEW = 32, kEQ = 8, kENQ = 3;   // entry ring / refill quantum / quanta per loader round
+static constexpr int kRW = 16, kRQ = 4, kRNQ = 3;   // right-hand-side ring / quantum / quanta per round
 static constexpr int kXD = 4;              // depth of the {tag,x} hand-off ring
 static constexpr int kEC = 4;              // external unknowns fetched per trip
 static constexpr int kLcThreads = 2 * kThreads;
-static constexpr size_t kLcLds = (size_t)kThreads * (kEW * 4 + kEW * 8 + kRW * 4 + kRW * 8 + kXD * 16 + kEC * 8 + 5 * 4) + 16;
+static constexpr size_t kLcLds = (size_t)kThreads * (kEW * 4 + kEW * 8 + kRW * 8 + kXD * 16 + kEC * 8 + 5 * 4) + 16;
+static constexpr int kDiag = -1;           // descriptor of a diagonal entry (schedule.hip); delimits rows in the stream
 
 template <int KIND>
 __global__ void __launch_bounds__(kLcThreads)
@@ -273,10 +274,9 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     double *secv = srhs + kRW * kThreads;                                    // [kEC][256]
     v4i *xr = reinterpret_cast<v4i *>(secv + kEC * kThreads);                // [kXD][256] {tag,-,x.lo,x.hi}
     int *sdesc = reinterpret_cast<int *>(xr + kXD * kThreads);               // [kEW][256]
-    int *sptr = sdesc + kEW * kThreads;                                      // [kRW][256]
     // hand-shake words (plain LDS accesses; ordering comes from the in-order LDS queue of each wave plus
-    // the compiler barriers below -- volatile would demote them to flat, system-scope accesses)
-    int *e_avail = sptr + kRW * kThreads;                                    // [256] each
+    // compiler barriers -- volatile would demote them to flat, system-scope accesses)
+    int *e_avail = sdesc + kEW * kThreads;                                   // [256] each
     int *r_avail = e_avail + kThreads;
     int *e_cons = r_avail + kThreads;
     int *r_cons = e_cons + kThreads;
@@ -289,7 +289,6 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
 
 #define RD(i) sdesc[((i) & (kEW - 1)) * kThreads + tid]
 #define RV(i) sval[((i) & (kEW - 1)) * kThreads + tid]
-#define RP(i) sptr[((i) & (kRW - 1)) * kThreads + tid]
 #define RR(i) srhs[((i) & (kRW - 1)) * kThreads + tid]
 
     int cnt = 0, r0 = 0;
@@ -309,6 +308,8 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
 
     if (is_loader) {
         // ------------------------------------------------------------------ loader
+        // every round: issue ALL quanta the rings have room for (independent 16-byte loads), one wait,
+        // drop them into LDS, publish.  Only this wave ever waits on HBM latency.
         int e_next = bound0;                 // FWD: next entry to load; BWD: one past the next quantum
         int r_next = FWD ? r0 : r0 + 1;      // FWD: next row to load;   BWD: one past the next quantum
         bool live = cnt > 0;
@@ -322,49 +323,61 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                     live = false;
                 } else {
                     const int ec = e_cons[tid], rc = r_cons[tid];
-                    const bool want_e = FWD ? (e_next + kEQ <= ec + kEW) : (e_next - kEQ >= ec - kEW);
-                    const bool want_r = FWD ? (r_next + kRQ <= rc + kRW) : (r_next - kRQ >= rc + 1 - kRW);
-                    if (want_e) {
-                        const int base = FWD ? e_next : e_next - kEQ;
-                        long bd[kEQ / 4], bv[kEQ / 2];
-                        I4u td[kEQ / 4];
-                        D2u tv[kEQ / 2];
+                    bool te[kENQ], tr[kRNQ];
+                    long bd[kENQ][kEQ / 4], bv[kENQ][kEQ / 2], br[kRNQ][kRQ / 2];
+                    I4u td[kENQ][kEQ / 4];
+                    D2u tv[kENQ][kEQ / 2], tw[kRNQ][kRQ / 2];
 #pragma unroll
-                        for (int q = 0; q < kEQ / 4; ++q) { bd[q] = clamp_base((long)base + 4 * q, nnz, 4); td[q] = *reinterpret_cast<const I4u *>(desc + bd[q]); }
+                    for (int u = 0; u < kENQ; ++u) {
+                        const int en = e_next + (FWD ? u * kEQ : -u * kEQ);
+                        te[u] = FWD ? (en + kEQ <= ec + kEW) : (en - kEQ >= ec - kEW);
+                        const int base = FWD ? en : en - kEQ;
+                        if (te[u]) {
 #pragma unroll
-                        for (int q = 0; q < kEQ / 2; ++q) { bv[q] = clamp_base((long)base + 2 * q, nnz, 2); tv[q] = *reinterpret_cast<const D2u *>(val + bv[q]); }
+                            for (int q = 0; q < kEQ / 4; ++q) { bd[u][q] = clamp_base((long)base + 4 * q, nnz, 4); td[u][q] = *reinterpret_cast<const I4u *>(desc + bd[u][q]); }
 #pragma unroll
-                        for (int q = 0; q < kEQ / 4; ++q)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) RD((int)bd[q] + k) = td[q].v[k];
-#pragma unroll
-                        for (int q = 0; q < kEQ / 2; ++q)
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) RV((int)bv[q] + k) = tv[q].v[k];
-                        e_next += FWD ? kEQ : -kEQ;
-                        asm volatile("" ::: "memory");
-                        e_avail[tid] = e_next;
-                        did = true;
+                            for (int q = 0; q < kEQ / 2; ++q) { bv[u][q] = clamp_base((long)base + 2 * q, nnz, 2); tv[u][q] = *reinterpret_cast<const D2u *>(val + bv[u][q]); }
+                        }
                     }
-                    if (want_r) {
-                        const int base = FWD ? r_next : r_next - kRQ;
-                        const long bp = clamp_base((long)base + (FWD ? 1 : 0), (long)n + 1, 4);
-                        const I4u tp = *reinterpret_cast<const I4u *>(ptr + bp);
-                        long br[kRQ / 2];
-                        D2u tr[kRQ / 2];
 #pragma unroll
-                        for (int q = 0; q < kRQ / 2; ++q) { br[q] = clamp_base((long)base + 2 * q, n, 2); tr[q] = *reinterpret_cast<const D2u *>(rhs + br[q]); }
+                    for (int u = 0; u < kRNQ; ++u) {
+                        const int rn = r_next + (FWD ? u * kRQ : -u * kRQ);
+                        tr[u] = FWD ? (rn + kRQ <= rc + kRW) : (rn - kRQ >= rc + 1 - kRW);
+                        const int base = FWD ? rn : rn - kRQ;
+                        if (tr[u]) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) RP((int)bp - (FWD ? 1 : 0) + k) = tp.v[k];
-#pragma unroll
-                        for (int q = 0; q < kRQ / 2; ++q)
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) RR((int)br[q] + k) = tr[q].v[k];
-                        r_next += FWD ? kRQ : -kRQ;
-                        asm volatile("" ::: "memory");
-                        r_avail[tid] = r_next;
-                        did = true;
+                            for (int q = 0; q < kRQ / 2; ++q) { br[u][q] = clamp_base((long)base + 2 * q, n, 2); tw[u][q] = *reinterpret_cast<const D2u *>(rhs + br[u][q]); }
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < kENQ; ++u) {
+                        if (te[u]) {
+#pragma unroll
+                            for (int q = 0; q < kEQ / 4; ++q)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) RD((int)bd[u][q] + k) = td[u][q].v[k];
+#pragma unroll
+                            for (int q = 0; q < kEQ / 2; ++q)
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) RV((int)bv[u][q] + k) = tv[u][q].v[k];
+                            e_next += FWD ? kEQ : -kEQ;
+                            did = true;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kRNQ; ++u) {
+                        if (tr[u]) {
+#pragma unroll
+                            for (int q = 0; q < kRQ / 2; ++q)
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) RR((int)br[u][q] + k) = tw[u][q].v[k];
+                            r_next += FWD ? kRQ : -kRQ;
+                            did = true;
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    e_avail[tid] = e_next;
+                    r_avail[tid] = r_next;
                 }
             }
             if (__any(did)) {
@@ -379,9 +392,10 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
 
     // ---------------------------------------------------------------------- consumer
     // A row costs TWO dependent LDS round trips when it has at most 4 stored entries (the 5-/7-point
-    // factors): round 1 reads the hand-shake words, the row pointer, the right-hand side and -- from the
-    // already known row start -- four descriptor/value pairs speculatively; round 2 reads the {tag,x}
-    // ring entries of all its in-workgroup dependencies at once.  Longer rows take the entry loop.
+    // factors): round 1 reads the hand-shake words, the right-hand side and -- from the already known row
+    // start -- four descriptor/value pairs speculatively (the diagonal's marker descriptor delimits the
+    // row, so no row-pointer stream exists); round 2 reads the {tag,x} ring entries of all its
+    // in-workgroup dependencies at once.  Longer rows take the entry loop.
     int r = r0;
     bool active = cnt > 0;
     int rloc = 0;
@@ -393,6 +407,7 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     double acc = 0.0, prev_val = 0.0;
     unsigned ec_oslot = 0xffffffffu; int ec_kl0 = 0, ec_cnt = 0, ec_first = 0;
     unsigned spins = 0;
+    unsigned dbg_iters = 0, dbg_prog = 0;
     const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(out);
 
     // external unknown (other workgroup): cached batch of kEC consecutive ones, else one poll trip
@@ -449,25 +464,34 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                 const int ra = r_avail[tid];
                 const int ea = e_avail[tid];
                 asm volatile("" ::: "memory");      // hand-shake words are read BEFORE the data they guard
-                const int pr = RP(r);
                 const double rr = RR(r);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { ed[k] = RD(ebase + k); ev[k] = RV(ebase + k); }
                 asm volatile("" ::: "memory");      // ... and the data BEFORE the words that release its slots
                 if (FWD ? (r < ra) : (r >= ra)) {
-                    if (FWD) { lo = bound; hi = pr; } else { hi = bound; lo = pr; }
-                    r_cons[tid] = r;
-                    e_cons[tid] = FWD ? lo : hi;
-                    if (FWD ? (hi <= ea) : (lo >= ea)) {
-                        len = hi - lo;
+                    // locate the diagonal marker among the entries that are really loaded
+                    int dk = -1;
+                    if (FWD) {
+#pragma unroll
+                        for (int k = 3; k >= 0; --k) if (ed[k] == kDiag && ebase + k < ea) dk = k;      // first marker
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (ed[k] == kDiag && ebase + k >= ea) dk = k;     // nearest marker below hi
+                    }
+                    const bool all4 = FWD ? (ebase + 4 <= ea) : (ebase >= ea);
+                    if (dk >= 0 || all4) {
+                        r_cons[tid] = r;
+                        e_cons[tid] = bound;
                         acc = rr;
                         reinterpret_cast<unsigned long long *>(rhs)[r] = kSentinel;
-                        if (len <= 4) {
+                        if (dk >= 0) {
+                            if (FWD) { lo = bound; len = dk + 1; hi = lo + len; }
+                            else     { hi = bound; len = 4 - dk; lo = hi - len; }
                             phase = 1;
                         } else {
-                            if (FWD)        { j = lo;     jend = hi - 1; dpos = hi - 1; }
-                            else if (!DESC) { j = lo + 1; jend = hi;     dpos = lo; }
-                            else            { j = hi - 1; jend = lo;     dpos = lo; }
+                            // long row: entry loop.  FWD walks up to the marker; BWD first finds the marker below
+                            if (FWD) { lo = bound; j = lo; }
+                            else     { hi = bound; j = hi - 1; lo = -1; }
                             phase = 2;
                         }
                         progressed = true;
@@ -521,37 +545,60 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                     progressed = true;
                 }
             } else if (phase == 2) {
-                while (j != jend) {
-                    const unsigned d = (unsigned)RD(j);
-                    const unsigned oslot = d >> 15;
-                    const int kl = (int)(d & 0x7fffu);
-                    double xc = 0.0;
-                    bool have = false;
-                    if (oslot == myslot && kl == rloc - 1) {
-                        xc = prev_val;
-                        have = true;
-                    } else if ((oslot >> 8) == wg) {
-                        const int lane = (int)(oslot & 255u);
-                        const v4i e = xr[(kl & (kXD - 1)) * kThreads + lane];
-                        if (e.x == kl) {
-                            xc = __hiloint2double(e.w, e.z);
-                            have = true;
-                        } else if (e.x < kl) {
-                            break;
-                        }
+                const int ea = e_avail[tid];
+                asm volatile("" ::: "memory");
+                if (!FWD && lo < 0) {
+                    // BWD: find the row start (the marker) before any arithmetic when entries go ascending
+                    while (j >= ea && RD(j) != kDiag) --j;
+                    if (j >= ea) {
+                        lo = j;
+                        if (DESC) { j = hi - 1; jend = lo; } else { j = lo + 1; jend = hi; }
+                        dpos = lo;
+                        progressed = true;
+                    } else {
+                        j = hi - 1;      // marker not loaded yet: rescan next round
                     }
-                    if (!have && !external(oslot, kl, xc)) break;
-                    const double prod = RV(j) * xc;
-                    acc = acc - prod;
-                    j += DESC ? -1 : 1;
-                    progressed = true;
                 }
-                if (j == jend) {
-                    publish(acc / RV(dpos));
-                    progressed = true;
+                if (FWD || lo >= 0) {
+                    for (;;) {
+                        if (FWD) {
+                            if (j >= ea) break;                               // not loaded yet
+                            if (RD(j) == kDiag) { dpos = j; hi = j + 1; jend = j; break; }
+                        } else if (j == jend) break;
+                        const unsigned d = (unsigned)RD(j);
+                        const unsigned oslot = d >> 15;
+                        const int kl = (int)(d & 0x7fffu);
+                        double xc = 0.0;
+                        bool have = false;
+                        if (oslot == myslot && kl == rloc - 1) {
+                            xc = prev_val;
+                            have = true;
+                        } else if ((oslot >> 8) == wg) {
+                            const int lane = (int)(oslot & 255u);
+                            const v4i e = xr[(kl & (kXD - 1)) * kThreads + lane];
+                            if (e.x == kl) {
+                                xc = __hiloint2double(e.w, e.z);
+                                have = true;
+                            } else if (e.x < kl) {
+                                break;
+                            }
+                        }
+                        if (!have && !external(oslot, kl, xc)) break;
+                        const double prod = RV(j) * xc;
+                        acc = acc - prod;
+                        j += DESC ? -1 : 1;
+                        progressed = true;
+                    }
+                    const bool at_end = FWD ? (j < ea && RD(j) == kDiag) : (j == jend);
+                    if (at_end) {
+                        publish(acc / RV(dpos));
+                        progressed = true;
+                    }
                 }
             }
         }
+        ++dbg_iters;
+        dbg_prog += progressed ? 1u : 0u;
         if (__any(progressed)) {
             spins = 0;
         } else {
@@ -563,9 +610,12 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
             }
         }
     }
+    if (wg == 0 && (tid == 0 || tid == 17 || tid == 255)) {   // diagnostic words (ignored by the host unless asked)
+        const int w = tid == 0 ? 0 : (tid == 17 ? 1 : 2);
+        err[8 + w] = (int)dbg_iters; err[11 + w] = (int)dbg_prog;
+    }
 #undef RD
 #undef RV
-#undef RP
 #undef RR
 }
 

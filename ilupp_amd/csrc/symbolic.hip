@@ -111,7 +111,7 @@ static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t
     int64_t nb = ((int64_t)n + B - 1) / B;
     sch->nb = (int32_t)nb;
     sch->B = (int32_t)B;
-    ILUPP_HIP(hipMalloc(&sch->start, sizeof(int32_t) * (size_t)(nb + 1)));
+    ILUPP_HIP(pool_malloc(&sch->start, sizeof(int32_t) * (size_t)(nb + 1)));
     hipLaunchKernelGGL(k_block_starts, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st,
                        n, (int32_t)B, (int32_t)nb, cut, sch->start);
 }
@@ -121,9 +121,9 @@ int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const
 {
     uint8_t *cutf = nullptr, *cutb = nullptr;
     int32_t *stats = nullptr;
-    ILUPP_HIP(hipMalloc(&cutf, (size_t)n + 1));
-    ILUPP_HIP(hipMalloc(&cutb, (size_t)n + 1));
-    ILUPP_HIP(hipMalloc(&stats, sizeof(int32_t) * 4));
+    ILUPP_HIP(pool_malloc(&cutf, (size_t)n + 1));
+    ILUPP_HIP(pool_malloc(&cutb, (size_t)n + 1));
+    ILUPP_HIP(pool_malloc(&stats, sizeof(int32_t) * 4));
     ILUPP_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * 4, st));
     {
         unsigned gb = (unsigned)((n + 255) / 256);
@@ -137,9 +137,9 @@ int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const
     if (fwd) make_schedule(st, n, cutf, h[0], max_lanes, fwd);
     if (bwd) make_schedule(st, n, cutb, h[1], max_lanes, bwd);
     ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(hipFree(cutf));
-    ILUPP_HIP(hipFree(cutb));
-    ILUPP_HIP(hipFree(stats));
+    ILUPP_HIP(pool_free(cutf));
+    ILUPP_HIP(pool_free(cutb));
+    ILUPP_HIP(pool_free(stats));
     return ILUPP_OK;
 }
 
@@ -185,22 +185,22 @@ void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
     const int32_t n = A.n;
     const int64_t nnz = A.nnz;
     T->n = n; T->nnz = nnz; T->is_csr = !A.is_csr; T->owns = true;
-    ILUPP_HIP(hipMalloc(&T->ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(hipMalloc(&T->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-    ILUPP_HIP(hipMalloc(&T->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&T->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&T->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&T->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
     int32_t *rowid, *seq, *keys_out, *perm;
     const size_t eb = sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1);
-    ILUPP_HIP(hipMalloc(&rowid, eb));
-    ILUPP_HIP(hipMalloc(&seq, eb));
-    ILUPP_HIP(hipMalloc(&keys_out, eb));
-    ILUPP_HIP(hipMalloc(&perm, eb));
+    ILUPP_HIP(pool_malloc(&rowid, eb));
+    ILUPP_HIP(pool_malloc(&seq, eb));
+    ILUPP_HIP(pool_malloc(&keys_out, eb));
+    ILUPP_HIP(pool_malloc(&perm, eb));
     hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, rowid, seq);
     size_t tmp_bytes = 0;
     int end_bit = 1;
     while ((1ll << end_bit) < (long long)n && end_bit < 31) ++end_bit;
     ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.idx, keys_out, seq, perm, (int)nnz, 0, end_bit, st));
     void *tmp = nullptr;
-    ILUPP_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
     ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, A.idx, keys_out, seq, perm, (int)nnz, 0, end_bit, st));
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -208,8 +208,8 @@ void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
     hipLaunchKernelGGL(k_gather_transposed, dim3((unsigned)blocks), dim3(256), 0, st, nnz, perm, rowid, A.val, T->idx, T->val);
     hipLaunchKernelGGL(k_ptr_from_sorted, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, n, nnz, keys_out, T->ptr);
     ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(hipFree(tmp));
-    ILUPP_HIP(hipFree(rowid)); ILUPP_HIP(hipFree(seq)); ILUPP_HIP(hipFree(keys_out)); ILUPP_HIP(hipFree(perm));
+    ILUPP_HIP(pool_free(tmp));
+    ILUPP_HIP(pool_free(rowid)); ILUPP_HIP(pool_free(seq)); ILUPP_HIP(pool_free(keys_out)); ILUPP_HIP(pool_free(perm));
 }
 
 }  // namespace ilupp
