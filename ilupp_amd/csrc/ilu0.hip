@@ -402,10 +402,10 @@ struct __attribute__((aligned(8))) D2f { double v[2]; };
 struct __attribute__((aligned(16))) I4f { int v[4]; };
 typedef int v4i_f __attribute__((ext_vector_type(4)));
 
-static constexpr int kPR = 4, kPQ = 2;      // program ring (records) / refill quantum
-static constexpr int kAW = 16, kAQ = 8;     // A-value ring / refill quantum
-static constexpr int kUD = 4;               // depth of the U-row hand-off ring (rows per lane)
-static constexpr size_t kIluLcLds = (size_t)kThreads * (kPR * 12 * 4 + kAW * 8 + kUD * 4 * 16 + 5 * 4) + 16;
+static constexpr int kPR = 6, kPQ = 2, kPNQ = 2;   // program ring (8-word records; not a power of two) / quantum / quanta per round
+static constexpr int kAW = 32, kAQ = 8, kANQ = 3;  // A-value ring / quantum / quanta per loader round
+static constexpr int kUD = 2;               // depth of the U-row hand-off ring (rows per lane)
+static constexpr size_t kIluLcLds = (size_t)kThreads * (kPR * 8 * 4 + kAW * 8 + kUD * 4 * 16 + 5 * 4) + 16;
 
 // the working row lives in eight NAMED scalars (w0..w7): an indexable aggregate gets demoted to scratch memory
 #define SEL8(i) ((i) == 0 ? w0 : (i) == 1 ? w1 : (i) == 2 ? w2 : (i) == 3 ? w3 : (i) == 4 ? w4 : (i) == 5 ? w5 : (i) == 6 ? w6 : w7)
@@ -429,8 +429,8 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
     const bool is_loader = threadIdx.x >= kThreads;
     double *sA = reinterpret_cast<double *>(smem);                                 // [kAW][256]
     v4i_f *ur = reinterpret_cast<v4i_f *>(sA + kAW * kThreads);                    // [kUD][4][256] {tag,-,lo,hi}
-    int *sprog = reinterpret_cast<int *>(ur + kUD * 4 * kThreads);                 // [kPR*12][256]
-    int *p_avail = sprog + kPR * 12 * kThreads;                                    // [256] each
+    int *sprog = reinterpret_cast<int *>(ur + kUD * 4 * kThreads);                 // [kPR*8][256]
+    int *p_avail = sprog + kPR * 8 * kThreads;                                     // [256] each
     int *a_avail = p_avail + kThreads;
     int *p_cons = a_avail + kThreads;
     int *a_cons = p_cons + kThreads;
@@ -441,7 +441,7 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
     const unsigned wg = *wg_ticket;
     const unsigned myslot = wg * kThreads + tid;
 
-#define PW(row, k) sprog[((((row) & (kPR - 1)) * 12) + (k)) * kThreads + tid]
+#define PW(row, k) sprog[((((row) % kPR) * 8) + (k)) * kThreads + tid]
 #define RA(i) sA[((i) & (kAW - 1)) * kThreads + tid]
 
     int cnt = 0, r0 = 0;
@@ -460,6 +460,7 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
 
     if (is_loader) {
         // ------------------------------------------------------------------ loader
+        // every round: issue ALL quanta the rings have room for, one wait, drop them into LDS, publish
         int p_next = r0, a_next = a00;
         bool live = cnt > 0;
         unsigned idle = 0;
@@ -472,50 +473,62 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                     live = false;
                 } else {
                     const int pc = p_cons[tid], ac = a_cons[tid];
-                    const bool want_p = (p_next + kPQ <= pc + kPR);
-                    const bool want_a = (a_next + kAQ <= ac + kAW);
-                    I4f tp[kPQ * 3];
-                    D2f ta[kAQ / 2];
-                    long ba[kAQ / 2];
-                    if (want_p) {
+                    bool tp[kPNQ], ta[kANQ];
+                    I4f vp[kPNQ][kPQ * 2];
+                    D2f va[kANQ][kAQ / 2];
+                    long ba[kANQ][kAQ / 2];
 #pragma unroll
-                        for (int q = 0; q < kPQ; ++q) {
-                            const long row = (p_next + q < n) ? (p_next + q) : (n - 1);
+                    for (int u = 0; u < kPNQ; ++u) {
+                        const int pn = p_next + u * kPQ;
+                        tp[u] = (pn + kPQ <= pc + kPR);
+                        if (tp[u]) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) tp[q * 3 + c] = *reinterpret_cast<const I4f *>(prog + row * 12 + 4 * c);
+                            for (int q = 0; q < kPQ; ++q) {
+                                const long row = (pn + q < n) ? (pn + q) : (n - 1);
+                                vp[u][2 * q] = *reinterpret_cast<const I4f *>(prog + row * 8);
+                                vp[u][2 * q + 1] = *reinterpret_cast<const I4f *>(prog + row * 8 + 4);
+                            }
                         }
                     }
-                    if (want_a) {
 #pragma unroll
-                        for (int q = 0; q < kAQ / 2; ++q) {
-                            long b = (long)a_next + 2 * q;
-                            b = b < 0 ? 0 : (b > nnzA - 2 ? nnzA - 2 : b);
-                            ba[q] = b;
-                            ta[q] = *reinterpret_cast<const D2f *>(Aval + b);
+                    for (int u = 0; u < kANQ; ++u) {
+                        const int an = a_next + u * kAQ;
+                        ta[u] = (an + kAQ <= ac + kAW);
+                        if (ta[u]) {
+#pragma unroll
+                            for (int q = 0; q < kAQ / 2; ++q) {
+                                long b = (long)an + 2 * q;
+                                b = b < 0 ? 0 : (b > nnzA - 2 ? nnzA - 2 : b);
+                                ba[u][q] = b;
+                                va[u][q] = *reinterpret_cast<const D2f *>(Aval + b);
+                            }
                         }
                     }
-                    if (want_p) {
 #pragma unroll
-                        for (int q = 0; q < kPQ; ++q)
+                    for (int u = 0; u < kPNQ; ++u) {
+                        if (tp[u]) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c)
+                            for (int q = 0; q < kPQ; ++q)
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) PW(p_next + q, 4 * c + k) = tp[q * 3 + c].v[k];
-                        p_next += kPQ;
-                        asm volatile("" ::: "memory");
-                        p_avail[tid] = p_next;
-                        did = true;
+                                for (int k = 0; k < 8; ++k) PW(p_next + q, k) = vp[u][2 * q + (k >> 2)].v[k & 3];
+                            p_next += kPQ;
+                            did = true;
+                        }
                     }
-                    if (want_a) {
 #pragma unroll
-                        for (int q = 0; q < kAQ / 2; ++q)
+                    for (int u = 0; u < kANQ; ++u) {
+                        if (ta[u]) {
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) RA((int)ba[q] + k) = ta[q].v[k];
-                        a_next += kAQ;
-                        asm volatile("" ::: "memory");
-                        a_avail[tid] = a_next;
-                        did = true;
+                            for (int q = 0; q < kAQ / 2; ++q)
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) RA((int)ba[u][q] + k) = va[u][q].v[k];
+                            a_next += kAQ;
+                            did = true;
+                        }
                     }
+                    asm volatile("" ::: "memory");
+                    p_avail[tid] = p_next;
+                    a_avail[tid] = a_next;
                 }
             }
             if (__any(did)) {
@@ -533,10 +546,10 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
     int a0 = a00, l0 = l00, u0 = u00;
     bool active = cnt > 0;
     int phase = 0;
-    int pw[12];
+    int pw[8];
     double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0, w7 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) pw[k] = 0;
+    for (int k = 0; k < 8; ++k) pw[k] = 0;
     int len = 0, cl = 0, nmt = 0;
     unsigned spins = 0;
 
@@ -550,12 +563,12 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                 const int pa = p_avail[tid], aa = a_avail[tid];
                 asm volatile("" ::: "memory");      // hand-shake words are read BEFORE the data they guard
 #pragma unroll
-                for (int k = 0; k < 12; ++k) pw[k] = PW(r, k);
+                for (int k = 0; k < 8; ++k) pw[k] = PW(r, k);
                 w0 = RA(a0); w1 = RA(a0 + 1); w2 = RA(a0 + 2); w3 = RA(a0 + 3);
                 w4 = RA(a0 + 4); w5 = RA(a0 + 5); w6 = RA(a0 + 6); w7 = RA(a0 + 7);
                 asm volatile("" ::: "memory");      // ... and the data BEFORE the words that release its slots
                 if (r < pa) {
-                    len = pw[0] & 255; cl = (pw[0] >> 8) & 255; nmt = (pw[0] >> 16) & 255;
+                    len = pw[0] & 15; cl = (pw[0] >> 4) & 3; nmt = (pw[0] >> 6) & 7;
                     p_cons[tid] = r;
                     a_cons[tid] = a0;
                     if (a0 + len <= aa) { phase = 1; progressed = true; }
@@ -567,7 +580,7 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                 v4i_f pe[3], me[5];
 #pragma unroll
                 for (int e = 0; e < 3; ++e) {
-                    const unsigned kd = (unsigned)pw[1 + 2 * e];
+                    const unsigned kd = (unsigned)pw[2 + 2 * e];
                     const unsigned oslot = kd >> 15;
                     dkl[e] = (int)(kd & 0x7fffu);
                     dlane[e] = (int)(oslot & 255u);
@@ -577,8 +590,8 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                 int me_e[5], me_off[5], me_pp[5];
 #pragma unroll
                 for (int m = 0; m < 5; ++m) {
-                    const unsigned mw = (unsigned)pw[7 + m];
-                    me_e[m] = (int)(mw & 3u); me_off[m] = (int)((mw >> 2) & 255u); me_pp[m] = (int)((mw >> 10) & 255u);
+                    const unsigned mw = m < 3 ? ((unsigned)pw[0] >> (9 + 7 * m)) & 127u : ((unsigned)pw[1] >> (7 * (m - 3))) & 127u;
+                    me_e[m] = (int)(mw & 3u); me_off[m] = (int)((mw >> 2) & 3u); me_pp[m] = (int)((mw >> 4) & 7u);
                     const int ln = me_e[m] == 0 ? dlane[0] : (me_e[m] == 1 ? dlane[1] : dlane[2]);
                     const int kl = me_e[m] == 0 ? dkl[0] : (me_e[m] == 1 ? dkl[1] : dkl[2]);
                     me[m] = ur[((kl & (kUD - 1)) * 4 + (me_off[m] & 3)) * kThreads + ln];
@@ -614,14 +627,14 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                     bool needm[5];
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
-                        if (e < cl && dmem[e]) bp[e] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pw[2 + 2 * e]));
+                        if (e < cl && dmem[e]) bp[e] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pw[3 + 2 * e]));
 #pragma unroll
                     for (int m = 0; m < 5; ++m) {
                         const int e = me_e[m];
                         const bool mm = e == 0 ? dmem[0] : (e == 1 ? dmem[1] : dmem[2]);
                         const int kl = e == 0 ? dkl[0] : (e == 1 ? dkl[1] : dkl[2]);
                         needm[m] = (m < nmt) && (mm || me[m].x > kl);
-                        const int pv = e == 0 ? pw[2] : (e == 1 ? pw[4] : pw[6]);
+                        const int pv = e == 0 ? pw[3] : (e == 1 ? pw[5] : pw[7]);
                         if (needm[m]) bm[m] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pv + me_off[m]));
                     }
                     __builtin_amdgcn_s_waitcnt(0x0F70);

@@ -266,12 +266,13 @@ __global__ void k_ilu0_program(int32_t n, const int32_t *__restrict__ Aptr, cons
 
 // ---------------------------------------------------------------------------------------------
 // fixed-size update program "F3" for short-row matrices (<= 3 eliminations, <= 5 matches, <= 8 entries per row,
-// U rows of <= 4 entries): 12 words per row, built in ONE pass with no scan, streamed by the loader waves
+// U rows of <= 4 entries): 8 words (32 B) per row, built in ONE pass with no scan, streamed by the loader waves
 // of k_ilu0_numeric_lc.  The 5- and 7-point stencils fit; anything else takes the variable-length program.
-//   w0      len | cl << 8 | nmt << 16
-//   w1+2e   dep e: owner_slot << 15 | kloc          (same encoding as a solve descriptor)
-//   w2+2e   dep e: piv_pos (index of U row k's diagonal in U.val)
-//   w7+m    match m: e | off << 2 | pp << 10        (matches grouped by e, ascending; U entry piv_pos+off updates w[pp])
+//   w0      len (4b) | cl (2b) << 4 | nmt (3b) << 6 | m0 << 9 | m1 << 16 | m2 << 23
+//   w1      m3 | m4 << 7                      match m = e (2b) | off (2b) << 2 | pp (3b) << 4
+//   w2+2e   dep e: owner_slot << 15 | kloc    (same encoding as a solve descriptor)
+//   w3+2e   dep e: piv_pos (index of U row k's diagonal in U.val)
+// matches are grouped by e, ascending column: U entry piv_pos+off of dep e updates working-row position pp
 __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx,
                                   const int32_t *__restrict__ Uptr, int32_t B, int32_t nb,
                                   const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
@@ -284,9 +285,8 @@ __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, c
     int cl = 0;
     while (cl < len && Aidx[a0 + cl] < r) ++cl;
     bool bad = (len > 8) || (cl > 3) || (len - cl > 4);
-    int words[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) words[k] = 0;
+    int d0 = 0, p0 = 0, d1 = 0, p1 = 0, d2 = 0, p2 = 0;
+    unsigned long long mbits = 0;      // 5 x 7 bits
     int nmt = 0;
     if (!bad) {
         for (int e = 0; e < cl; ++e) {
@@ -302,29 +302,24 @@ __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, c
                 while (pp < len && Aidx[a0 + pp] < m) ++pp;
                 if (pp >= len) break;
                 if (Aidx[a0 + pp] == m) {
-                    if (nmt < 5) {
-                        const int mw = e | ((j - kd) << 2) | (pp << 10);
-                        // static slots only (no private-memory array indexing)
-                        if (nmt == 0) words[7] = mw; else if (nmt == 1) words[8] = mw; else if (nmt == 2) words[9] = mw;
-                        else if (nmt == 3) words[10] = mw; else words[11] = mw;
-                    }
+                    if (nmt < 5) mbits |= (unsigned long long)(e | (((j - kd) & 3) << 2) | ((pp & 7) << 4)) << (7 * nmt);
                     ++nmt; ++pp;
                 }
             }
             const int b = block_of(k, B, nb, start);
             const int kd_word = (blk2slot[b] << 15) | (k - start[b]);
             const int pv = Uptr[k];
-            if (e == 0) { words[1] = kd_word; words[2] = pv; }
-            else if (e == 1) { words[3] = kd_word; words[4] = pv; }
-            else { words[5] = kd_word; words[6] = pv; }
+            if (e == 0) { d0 = kd_word; p0 = pv; }
+            else if (e == 1) { d1 = kd_word; p1 = pv; }
+            else { d2 = kd_word; p2 = pv; }
         }
         if (nmt > 5) bad = true;
     }
-    words[0] = len | (cl << 8) | ((nmt > 5 ? 5 : nmt) << 16);
-    int4 *out = reinterpret_cast<int4 *>(prog + (size_t)r * 12);
-    out[0] = make_int4(words[0], words[1], words[2], words[3]);
-    out[1] = make_int4(words[4], words[5], words[6], words[7]);
-    out[2] = make_int4(words[8], words[9], words[10], words[11]);
+    const int w0 = (len & 15) | ((cl & 3) << 4) | (((nmt > 5 ? 5 : nmt) & 7) << 6) | (int)((mbits & 0x1FFFFFull) << 9);
+    const int w1 = (int)((mbits >> 21) & 0x3FFFull);
+    int4 *out = reinterpret_cast<int4 *>(prog + (size_t)r * 8);
+    out[0] = make_int4(w0, w1, d0, p0);
+    out[1] = make_int4(d1, p1, d2, p2);
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicExch(ineligible, 1);
 }
 
@@ -334,7 +329,7 @@ bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, con
     const int32_t n = A.n;
     if (sch.B > 32768 || sch.nslots > (1 << 17)) return false;
     int32_t *prog = nullptr, *flag = nullptr;
-    ILUPP_HIP(pool_malloc(&prog, sizeof(int32_t) * 12 * (size_t)n + 64));
+    ILUPP_HIP(pool_malloc(&prog, sizeof(int32_t) * 8 * (size_t)n + 64));
     ILUPP_HIP(pool_malloc(&flag, 16));
     ILUPP_HIP(hipMemsetAsync(flag, 0, 16, st));
     hipLaunchKernelGGL(k_ilu0_program_f3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr,

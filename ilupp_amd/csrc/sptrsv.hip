@@ -407,7 +407,7 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     double acc = 0.0, prev_val = 0.0;
     unsigned ec_oslot = 0xffffffffu; int ec_kl0 = 0, ec_cnt = 0, ec_first = 0;
     unsigned spins = 0;
-    unsigned dbg_iters = 0, dbg_prog = 0;
+    unsigned dbg_iters = 0, dbg_prog = 0, dbg_wdata = 0, dbg_wdep = 0;
     const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(out);
 
     // external unknown (other workgroup): cached batch of kEC consecutive ones, else one poll trip
@@ -599,6 +599,7 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
         }
         ++dbg_iters;
         dbg_prog += progressed ? 1u : 0u;
+        if (active && !progressed) { if (phase == 0) ++dbg_wdata; else ++dbg_wdep; }
         if (__any(progressed)) {
             spins = 0;
         } else {
@@ -612,7 +613,7 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     }
     if (wg == 0 && (tid == 0 || tid == 17 || tid == 255)) {   // diagnostic words (ignored by the host unless asked)
         const int w = tid == 0 ? 0 : (tid == 17 ? 1 : 2);
-        err[8 + w] = (int)dbg_iters; err[11 + w] = (int)dbg_prog;
+        err[8 + w] = (int)dbg_iters; err[11 + w] = (int)(dbg_wdata + dbg_wdep); (void)dbg_prog;
     }
 #undef RD
 #undef RV

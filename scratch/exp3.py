@@ -15,4 +15,4 @@ for shape in ((256,16,16),(256,256,1)):
     t=P.pr.timings()
     out=np.zeros(16,dtype=np.int32)
     L.ilupp_hip_debug_ctrl(P.pr._h, out.ctypes.data)
-    print(shape,'L ms %.3f U ms %.3f'%(t['lsolve_kernel_ms'],t['usolve_kernel_ms']),'ctrl',out[8:14])
+    print(shape,'L ms %.3f U ms %.3f'%(t['lsolve_kernel_ms'],t['usolve_kernel_ms']),'wdata',out[4:7],'iters',out[8:11],'wdep',out[11:14])
