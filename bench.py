@@ -39,9 +39,28 @@ def algorithmic_bytes(n, nnz):
     return factor, apply_
 
 
+def measured_traffic(kernel, g):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*_pmc_hbm.json, collected with
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs of this same command).  gfx950
+    correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports one half of the loaded bytes, WRITE_SIZE
+    is taken as reported; both counters are in KiB.  Only valid for the 256^3 workload it was measured on."""
+    import glob
+    if g != 256:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]["ilupp::" + kernel]
+        return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(g, want_ref=True):
     """The reference's own C++ path (oracle/_ref, kind "reference") or the plain-C restatement
-    (kind "port") on ONE host core: ILU(0) factor + one apply on the same workload shape."""
+    (kind "port") on ONE host core (the reference is single-threaded): ILU(0) factor + one apply on the
+    same workload shape.  Bounded: one pass over the workload (about 10-15 s at 256^3)."""
     import matgen
     from oracle import oracle as O
     kind = "reference" if (want_ref and O.ref_available()) else "port"
@@ -53,9 +72,14 @@ def cpu_baseline(g, want_ref=True):
     t1 = time.perf_counter()
     x = lib.apply_lu(L, U, np.ones(n), O.ID)
     t2 = time.perf_counter()
+    try:
+        cpu = open("/proc/cpuinfo").read().split("model name")[1].split(":")[1].split("\n")[0].strip()
+    except Exception:
+        cpu = "unknown"
     return {"value": nnz / (t2 - t0), "unit": "nnz/s", "cores": 1, "kind": kind,
-            "sample": "full workload once: 3-D 7-pt Poisson %d^3 (n=%d, nnz=%d), factor %.3f s + apply %.3f s "
-                      "(includes the wrapper's copy-out of L/U)" % (g, n, nnz, t1 - t0, t2 - t1),
+            "sample": "the full workload once: 3-D 7-pt Poisson %d^3 (n=%d, nnz=%d); factor %.3f s + apply %.3f s "
+                      "through the C-ABI wrapper (includes copying L/U out and in); host CPU: %s, %d cores present"
+                      % (g, n, nnz, t1 - t0, t2 - t1, cpu, os.cpu_count() or 0),
             "factor_s": t1 - t0, "apply_s": t2 - t1, "checksum": float(np.sum(x))}
 
 
@@ -107,7 +131,7 @@ def main():
         torch.cuda.synchronize()
 
     P = None
-    fac_ms, num_ms, ana_ms, app_ms, ls_ms, us_ms = [], [], [], [], [], []
+    fac_ms, num_ms, ana_ms, app_ms, ls_ms, us_ms, knum_ms = [], [], [], [], [], [], []
 
     def step(record):
         nonlocal P
@@ -120,6 +144,7 @@ def main():
             t = P.timings()
             ana_ms.append(t["analysis_ms"]); num_ms.append(t["numeric_ms"]); fac_ms.append(t["analysis_ms"] + t["numeric_ms"])
             app_ms.append(t["last_apply_ms"]); ls_ms.append(t["lsolve_kernel_ms"]); us_ms.append(t["usolve_kernel_ms"])
+            knum_ms.append(t["numeric_kernel_ms"])
 
     for _ in range(args.warmup):
         step(False)
@@ -140,8 +165,11 @@ def main():
     if rank == 0:
         fb, ab = algorithmic_bytes(n, nnz)
         med = lambda v: float(np.median(v)) if v else 0.0
-        k_num = med(num_ms)          # numeric factor kernel (HIP events on the library's stream)
+        k_num = med(knum_ms)         # numeric factor kernel alone (HIP events on the library's stream)
         gpu_ms = med(fac_ms) + med(app_ms)
+        reuse_ms = med(num_ms) + med(app_ms)
+        # dominant kernel = the numeric factorisation sweep; its algorithmic bytes = the factor bytes of
+        # read A once + write L and U once
         out = {
             "metric": "ILU(0) factor+apply nnz/s, 3-D 7-pt Poisson fp64",
             "value": world * nnz / (wall / args.steps),
@@ -154,18 +182,23 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "C2: ILU(0) factor + one L/U apply, 3-D 7-point Poisson %d^3 CSR (n=%d, nnz=%d), fp64/int32" % (g, n, nnz),
-                       "parallelism": "1 matrix per GPU" if world > 1 else "single GPU",
-                       "step": "symbolic + schedule + numeric factor + L-solve + U-solve, inputs resident in HBM"},
+                       "parallelism": "1 matrix per GPU, no data-path collective" if world > 1 else "single GPU",
+                       "step": "full ILU0Preconditioner construction (pattern analysis + row scheduling + numeric factorisation) "
+                               "+ one apply, A and x resident in HBM; wall clock over all steps"},
             "gpu_ms": {"analysis": med(ana_ms), "numeric": med(num_ms), "factor": med(fac_ms), "apply": med(app_ms),
-                       "lsolve": med(ls_ms), "usolve": med(us_ms), "factor_plus_apply": gpu_ms},
+                       "lsolve": med(ls_ms), "usolve": med(us_ms), "factor_plus_apply": gpu_ms,
+                       "numeric_kernel": k_num},
             "gpu_event_value_nnz_per_s": nnz / (gpu_ms * 1e-3) if gpu_ms > 0 else None,
+            "pattern_reuse_value_nnz_per_s": nnz / (reuse_ms * 1e-3) if reuse_ms > 0 else None,
             "hbm_fraction_factor_plus_apply": ((fb + ab) / (gpu_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gpu_ms > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "k_ilu0_numeric",
+            "hbm_fraction_pattern_reuse": ((fb + ab) / (reuse_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if reuse_ms > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": "k_ilu0_numeric_lc",
                          "achieved": (fb / (k_num * 1e-3) / 1e9) if k_num > 0 else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (fb / (k_num * 1e-3) / 1e9) / HBM_PEAK_GBS if k_num > 0 else None,
-                         "traffic": None,
-                         "algorithmic_bytes_per_launch": fb},
+                         "traffic": measured_traffic("k_ilu0_numeric_lc", g),
+                         "algorithmic_bytes_per_launch": fb,
+                         "avg_launch_ms": k_num},
             "checksum": checksum,
         }
         if not args.no_cpu and world == 1:
