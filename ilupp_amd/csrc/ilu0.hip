@@ -407,13 +407,14 @@ static constexpr int kAW = 32, kAQ = 8, kANQ = 3;  // A-value ring / quantum / q
 static constexpr int kUD = 2;               // depth of the U-row hand-off ring (rows per lane)
 static constexpr size_t kIluLcLds = (size_t)kThreads * (kPR * 8 * 4 + kAW * 8 + kUD * 4 * 16 + 5 * 4) + 16;
 
-// the working row lives in eight NAMED scalars (w0..w7): an indexable aggregate gets demoted to scratch memory
-#define SEL8(i) ((i) == 0 ? w0 : (i) == 1 ? w1 : (i) == 2 ? w2 : (i) == 3 ? w3 : (i) == 4 ? w4 : (i) == 5 ? w5 : (i) == 6 ? w6 : w7)
-#define PUT8(i, nv)                                                                                         \
+// the working row lives in seven NAMED scalars w0..w6 (an indexable aggregate gets demoted to scratch memory),
+// diagonal-aligned: w3 is the diagonal, w0..w2 the (right-aligned) eliminations, w4..w6 the upper entries
+#define SEL7(i) ((i) == 0 ? w0 : (i) == 1 ? w1 : (i) == 2 ? w2 : (i) == 3 ? w3 : (i) == 4 ? w4 : (i) == 5 ? w5 : w6)
+#define PUT7(i, nv)                                                                                         \
     do {                                                                                                    \
         const int i_ = (i); const double nv_ = (nv);                                                        \
         w0 = i_ == 0 ? nv_ : w0; w1 = i_ == 1 ? nv_ : w1; w2 = i_ == 2 ? nv_ : w2; w3 = i_ == 3 ? nv_ : w3; \
-        w4 = i_ == 4 ? nv_ : w4; w5 = i_ == 5 ? nv_ : w5; w6 = i_ == 6 ? nv_ : w6; w7 = i_ == 7 ? nv_ : w7; \
+        w4 = i_ == 4 ? nv_ : w4; w5 = i_ == 5 ? nv_ : w5; w6 = i_ == 6 ? nv_ : w6;                          \
     } while (0)
 
 __global__ void __launch_bounds__(2 * kThreads)
@@ -547,7 +548,6 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
     bool active = cnt > 0;
     int phase = 0;
     int pw[8];
-    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0, w7 = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) pw[k] = 0;
     int len = 0, cl = 0, nmt = 0;
@@ -559,13 +559,11 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
         bool progressed = false;
         if (active) {
             if (phase == 0) {
-                // round 1
+                // round 1: hand-shake words + the row's record
                 const int pa = p_avail[tid], aa = a_avail[tid];
                 asm volatile("" ::: "memory");      // hand-shake words are read BEFORE the data they guard
 #pragma unroll
                 for (int k = 0; k < 8; ++k) pw[k] = PW(r, k);
-                w0 = RA(a0); w1 = RA(a0 + 1); w2 = RA(a0 + 2); w3 = RA(a0 + 3);
-                w4 = RA(a0 + 4); w5 = RA(a0 + 5); w6 = RA(a0 + 6); w7 = RA(a0 + 7);
                 asm volatile("" ::: "memory");      // ... and the data BEFORE the words that release its slots
                 if (r < pa) {
                     len = pw[0] & 15; cl = (pw[0] >> 4) & 3; nmt = (pw[0] >> 6) & 7;
@@ -575,45 +573,48 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                 }
             }
             if (phase == 1) {
-                // round 2: every pivot / matched value this row needs, from the ring of its producer
+                // round 2: the aligned working row and every pivot / matched value the row needs
+                const int ab = a0 + cl - 3;
+                double w0 = RA(ab), w1 = RA(ab + 1), w2 = RA(ab + 2), w3 = RA(ab + 3), w4 = RA(ab + 4), w5 = RA(ab + 5), w6 = RA(ab + 6);
                 int dlane[3], dkl[3]; bool dinwg[3];
                 v4i_f pe[3], me[5];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    const unsigned kd = (unsigned)pw[2 + 2 * e];
+                for (int sl = 0; sl < 3; ++sl) {
+                    const unsigned kd = (unsigned)pw[2 + 2 * sl];
                     const unsigned oslot = kd >> 15;
-                    dkl[e] = (int)(kd & 0x7fffu);
-                    dlane[e] = (int)(oslot & 255u);
-                    dinwg[e] = (oslot >> 8) == wg;
-                    pe[e] = ur[((dkl[e] & (kUD - 1)) * 4) * kThreads + dlane[e]];
+                    dkl[sl] = (int)(kd & 0x7fffu);
+                    dlane[sl] = (int)(oslot & 255u);
+                    dinwg[sl] = (oslot >> 8) == wg;
+                    pe[sl] = ur[((dkl[sl] & (kUD - 1)) * 4) * kThreads + dlane[sl]];
                 }
-                int me_e[5], me_off[5], me_pp[5];
+                int me_s[5], me_off[5], me_pp[5];
 #pragma unroll
                 for (int m = 0; m < 5; ++m) {
                     const unsigned mw = m < 3 ? ((unsigned)pw[0] >> (9 + 7 * m)) & 127u : ((unsigned)pw[1] >> (7 * (m - 3))) & 127u;
-                    me_e[m] = (int)(mw & 3u); me_off[m] = (int)((mw >> 2) & 3u); me_pp[m] = (int)((mw >> 4) & 7u);
-                    const int ln = me_e[m] == 0 ? dlane[0] : (me_e[m] == 1 ? dlane[1] : dlane[2]);
-                    const int kl = me_e[m] == 0 ? dkl[0] : (me_e[m] == 1 ? dkl[1] : dkl[2]);
-                    me[m] = ur[((kl & (kUD - 1)) * 4 + (me_off[m] & 3)) * kThreads + ln];
+                    me_s[m] = (int)(mw & 3u); me_off[m] = (int)((mw >> 2) & 3u); me_pp[m] = (int)((mw >> 4) & 7u);
+                    const int ln = me_s[m] == 0 ? dlane[0] : (me_s[m] == 1 ? dlane[1] : dlane[2]);
+                    const int kl = me_s[m] == 0 ? dkl[0] : (me_s[m] == 1 ? dkl[1] : dkl[2]);
+                    me[m] = ur[((kl & (kUD - 1)) * 4 + me_off[m]) * kThreads + ln];
                 }
+                const int s0 = 3 - cl;            // first used dep slot
                 bool ready = true, use_mem = false;
                 double piv[3] = {1.0, 1.0, 1.0}, um[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
                 bool dmem[3] = {false, false, false};
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    if (e < cl) {
-                        if (dinwg[e] && pe[e].x <= dkl[e]) {
-                            if (pe[e].x == dkl[e]) piv[e] = __hiloint2double(pe[e].w, pe[e].z);
+                for (int sl = 0; sl < 3; ++sl) {
+                    if (sl >= s0) {
+                        if (dinwg[sl] && pe[sl].x <= dkl[sl]) {
+                            if (pe[sl].x == dkl[sl]) piv[sl] = __hiloint2double(pe[sl].w, pe[sl].z);
                             else ready = false;                       // producer not there yet
-                        } else { dmem[e] = true; use_mem = true; }      // other workgroup, or ring slot recycled
+                        } else { dmem[sl] = true; use_mem = true; }     // other workgroup, or ring slot recycled
                     }
                 }
 #pragma unroll
                 for (int m = 0; m < 5; ++m) {
                     if (m < nmt) {
-                        const int e = me_e[m];
-                        const bool mm = e == 0 ? dmem[0] : (e == 1 ? dmem[1] : dmem[2]);
-                        const int kl = e == 0 ? dkl[0] : (e == 1 ? dkl[1] : dkl[2]);
+                        const int sl = me_s[m];
+                        const bool mm = sl == 0 ? dmem[0] : (sl == 1 ? dmem[1] : dmem[2]);
+                        const int kl = sl == 0 ? dkl[0] : (sl == 1 ? dkl[1] : dkl[2]);
                         if (!mm) {
                             if (me[m].x == kl) um[m] = __hiloint2double(me[m].w, me[m].z);
                             else if (me[m].x < kl) ready = false;
@@ -626,57 +627,62 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                     unsigned long long bp[3] = {0, 0, 0}, bm[5] = {0, 0, 0, 0, 0};
                     bool needm[5];
 #pragma unroll
-                    for (int e = 0; e < 3; ++e)
-                        if (e < cl && dmem[e]) bp[e] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pw[3 + 2 * e]));
+                    for (int sl = 0; sl < 3; ++sl)
+                        if (sl >= s0 && dmem[sl]) bp[sl] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pw[3 + 2 * sl]));
 #pragma unroll
                     for (int m = 0; m < 5; ++m) {
-                        const int e = me_e[m];
-                        const bool mm = e == 0 ? dmem[0] : (e == 1 ? dmem[1] : dmem[2]);
-                        const int kl = e == 0 ? dkl[0] : (e == 1 ? dkl[1] : dkl[2]);
+                        const int sl = me_s[m];
+                        const bool mm = sl == 0 ? dmem[0] : (sl == 1 ? dmem[1] : dmem[2]);
+                        const int kl = sl == 0 ? dkl[0] : (sl == 1 ? dkl[1] : dkl[2]);
                         needm[m] = (m < nmt) && (mm || me[m].x > kl);
-                        const int pv = e == 0 ? pw[3] : (e == 1 ? pw[5] : pw[7]);
+                        const int pv = sl == 0 ? pw[3] : (sl == 1 ? pw[5] : pw[7]);
                         if (needm[m]) bm[m] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(Uval + pv + me_off[m]));
                     }
                     __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
-                    for (int e = 0; e < 3; ++e)
-                        if (e < cl && dmem[e]) { if (bp[e] == kSentinel) ready = false; else piv[e] = __longlong_as_double((long long)bp[e]); }
+                    for (int sl = 0; sl < 3; ++sl)
+                        if (sl >= s0 && dmem[sl]) { if (bp[sl] == kSentinel) ready = false; else piv[sl] = __longlong_as_double((long long)bp[sl]); }
 #pragma unroll
                     for (int m = 0; m < 5; ++m)
                         if (needm[m]) { if (bm[m] == kSentinel) ready = false; else um[m] = __longlong_as_double((long long)bm[m]); }
                 }
                 if (ready) {
-                    // eliminations in ascending k, matches of each in ascending column (reference merge order)
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) {
-                        if (e < cl) {
-                            const double l_ik = SEL8(e) / piv[e];
-#pragma unroll
-                            for (int m = 0; m < 5; ++m) {
-                                if (m < nmt && me_e[m] == e) {
-                                    const double prod = l_ik * um[m];
-                                    const double nv = SEL8(me_pp[m]) - prod;
-                                    PUT8(me_pp[m], nv);
-                                }
-                            }
-                            PUT8(e, l_ik);
-                        }
+                    // eliminations in ascending k (= ascending slot), matches of each in ascending column
+                    // (reference merge order, ILU0.hpp:8-23, :47-62); every position is a fixed register
+#define ELIM(SL, WS)                                                                                       \
+                    if (SL >= s0) {                                                                         \
+                        const double l_ik = WS / piv[SL];                                                   \
+                        _Pragma("unroll") for (int m = 0; m < 5; ++m) {                                     \
+                            if (m < nmt && me_s[m] == SL) {                                                 \
+                                const double prod = l_ik * um[m];                                           \
+                                if (me_pp[m] == 3) { w3 = w3 - prod; }                                      \
+                                else { const double nv = SEL7(me_pp[m]) - prod; PUT7(me_pp[m], nv); }       \
+                            }                                                                               \
+                        }                                                                                   \
+                        WS = l_ik;                                                                          \
                     }
-                    if (0 < cl) Lval[l0] = w0;
-                    if (1 < cl) Lval[l0 + 1] = w1;
-                    if (2 < cl) Lval[l0 + 2] = w2;
+                    ELIM(0, w0)
+                    ELIM(1, w1)
+                    ELIM(2, w2)
+#undef ELIM
+                    if (0 >= s0) Lval[l0 + 0 - s0] = w0;
+                    if (1 >= s0) Lval[l0 + 1 - s0] = w1;
+                    if (2 >= s0) Lval[l0 + 2 - s0] = w2;
                     const int ulen = len - cl;
-                    const int s = rloc & (kUD - 1);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (q < ulen) {
-                            double v = SEL8(cl + q);
-                            if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN);
-                            v4i_f e; e.x = rloc; e.y = 0; e.z = __double2loint(v); e.w = __double2hiint(v);
-                            ur[(s * 4 + q) * kThreads + tid] = e;
-                            st_agent_f64(&Uval[u0 + q], v);
-                        }
+                    const int sr = rloc & (kUD - 1);
+#define PUBLISH(Q, WQ)                                                                                     \
+                    if (Q < ulen) {                                                                         \
+                        double v = WQ;                                                                      \
+                        if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN); \
+                        v4i_f e; e.x = rloc; e.y = 0; e.z = __double2loint(v); e.w = __double2hiint(v);      \
+                        ur[(sr * 4 + Q) * kThreads + tid] = e;                                              \
+                        st_agent_f64(&Uval[u0 + Q], v);                                                     \
                     }
+                    PUBLISH(0, w3)
+                    PUBLISH(1, w4)
+                    PUBLISH(2, w5)
+                    PUBLISH(3, w6)
+#undef PUBLISH
                     asm volatile("" ::: "memory");
                     a0 += len; l0 += cl + 1; u0 += ulen;
                     ++r; ++rloc;
@@ -700,8 +706,8 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
     }
 #undef PW
 #undef RA
-#undef SEL8
-#undef PUT8
+#undef SEL7
+#undef PUT7
 }
 
 int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd, const int32_t *prog_f3,

@@ -268,11 +268,16 @@ __global__ void k_ilu0_program(int32_t n, const int32_t *__restrict__ Aptr, cons
 // fixed-size update program "F3" for short-row matrices (<= 3 eliminations, <= 5 matches, <= 8 entries per row,
 // U rows of <= 4 entries): 8 words (32 B) per row, built in ONE pass with no scan, streamed by the loader waves
 // of k_ilu0_numeric_lc.  The 5- and 7-point stencils fit; anything else takes the variable-length program.
+//
+// The working row is DIAGONAL-ALIGNED: its diagonal sits at position 3, the cl eliminations right-aligned in
+// positions 3-cl..2, the strictly-upper entries in 4..6.  Every position the kernel touches is then a fixed
+// register (dep slot s <-> position s), whatever the row's shape.
 //   w0      len (4b) | cl (2b) << 4 | nmt (3b) << 6 | m0 << 9 | m1 << 16 | m2 << 23
-//   w1      m3 | m4 << 7                      match m = e (2b) | off (2b) << 2 | pp (3b) << 4
-//   w2+2e   dep e: owner_slot << 15 | kloc    (same encoding as a solve descriptor)
-//   w3+2e   dep e: piv_pos (index of U row k's diagonal in U.val)
-// matches are grouped by e, ascending column: U entry piv_pos+off of dep e updates working-row position pp
+//   w1      m3 | m4 << 7                      match m = s (2b) | off (2b) << 2 | pp (3b) << 4   (pp: aligned position)
+//   w2+2s   dep slot s: owner_slot << 15 | kloc    (same encoding as a solve descriptor); slots < 3-cl unused
+//   w3+2s   dep slot s: piv_pos (index of U row k's diagonal in U.val)
+// matches are grouped by s ascending (= ascending k), ascending column inside: U entry piv_pos+off of dep s
+// updates aligned position pp
 __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx,
                                   const int32_t *__restrict__ Uptr, int32_t B, int32_t nb,
                                   const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
@@ -284,12 +289,13 @@ __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, c
     const int len = a1 - a0;
     int cl = 0;
     while (cl < len && Aidx[a0 + cl] < r) ++cl;
-    bool bad = (len > 8) || (cl > 3) || (len - cl > 4);
+    bool bad = (len > 7) || (cl > 3) || (len - cl > 4);
     int d0 = 0, p0 = 0, d1 = 0, p1 = 0, d2 = 0, p2 = 0;
     unsigned long long mbits = 0;      // 5 x 7 bits
     int nmt = 0;
     if (!bad) {
         for (int e = 0; e < cl; ++e) {
+            const int sl = e + 3 - cl;                    // right-aligned dep slot
             const int k = Aidx[a0 + e];
             const int k0 = Aptr[k], k1 = Aptr[k + 1];
             int ku = k0;
@@ -302,15 +308,15 @@ __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, c
                 while (pp < len && Aidx[a0 + pp] < m) ++pp;
                 if (pp >= len) break;
                 if (Aidx[a0 + pp] == m) {
-                    if (nmt < 5) mbits |= (unsigned long long)(e | (((j - kd) & 3) << 2) | ((pp & 7) << 4)) << (7 * nmt);
+                    if (nmt < 5) mbits |= (unsigned long long)(sl | (((j - kd) & 3) << 2) | (((pp - cl + 3) & 7) << 4)) << (7 * nmt);
                     ++nmt; ++pp;
                 }
             }
             const int b = block_of(k, B, nb, start);
             const int kd_word = (blk2slot[b] << 15) | (k - start[b]);
             const int pv = Uptr[k];
-            if (e == 0) { d0 = kd_word; p0 = pv; }
-            else if (e == 1) { d1 = kd_word; p1 = pv; }
+            if (sl == 0) { d0 = kd_word; p0 = pv; }
+            else if (sl == 1) { d1 = kd_word; p1 = pv; }
             else { d2 = kd_word; p2 = pv; }
         }
         if (nmt > 5) bad = true;
