@@ -649,6 +649,15 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                 if (ready) {
                     // eliminations in ascending k (= ascending slot), matches of each in ascending column
                     // (reference merge order, ILU0.hpp:8-23, :47-62); every position is a fixed register
+                    if ((pw[0] >> 30) & 1) {
+                        // simple row: match m belongs to slot s0+m and lands on the diagonal
+                        const double u0v = s0 == 0 ? um[0] : 0.0;
+                        const double u1v = s0 == 0 ? um[1] : (s0 == 1 ? um[0] : 0.0);
+                        const double u2v = s0 == 0 ? um[2] : (s0 == 1 ? um[1] : (s0 == 2 ? um[0] : 0.0));
+                        if (0 >= s0) { const double l = w0 / piv[0]; const double pr = l * u0v; w3 = w3 - pr; w0 = l; }
+                        if (1 >= s0) { const double l = w1 / piv[1]; const double pr = l * u1v; w3 = w3 - pr; w1 = l; }
+                        if (2 >= s0) { const double l = w2 / piv[2]; const double pr = l * u2v; w3 = w3 - pr; w2 = l; }
+                    } else {
 #define ELIM(SL, WS)                                                                                       \
                     if (SL >= s0) {                                                                         \
                         const double l_ik = WS / piv[SL];                                                   \
@@ -665,6 +674,7 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                     ELIM(1, w1)
                     ELIM(2, w2)
 #undef ELIM
+                    }
                     if (0 >= s0) Lval[l0 + 0 - s0] = w0;
                     if (1 >= s0) Lval[l0 + 1 - s0] = w1;
                     if (2 >= s0) Lval[l0 + 2 - s0] = w2;

@@ -321,7 +321,15 @@ __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, c
         }
         if (nmt > 5) bad = true;
     }
-    const int w0 = (len & 15) | ((cl & 3) << 4) | (((nmt > 5 ? 5 : nmt) & 7) << 6) | (int)((mbits & 0x1FFFFFull) << 9);
+    // "simple" rows (bit 30): every elimination has exactly one match and it lands on the diagonal -- the shape of
+    // every interior row of a 5-/7-point stencil; the kernel then runs a straight-line path
+    bool simple = !bad && nmt == cl;
+    for (int m = 0; m < 3 && simple; ++m)
+        if (m < nmt) {
+            const int mw = (int)((mbits >> (7 * m)) & 127);
+            simple = ((mw & 3) == m + 3 - cl) && (((mw >> 4) & 7) == 3);
+        }
+    const int w0 = (len & 15) | ((cl & 3) << 4) | (((nmt > 5 ? 5 : nmt) & 7) << 6) | (int)((mbits & 0x1FFFFFull) << 9) | (simple ? (1 << 30) : 0);
     const int w1 = (int)((mbits >> 21) & 0x3FFFull);
     int4 *out = reinterpret_cast<int4 *>(prog + (size_t)r * 8);
     out[0] = make_int4(w0, w1, d0, p0);

@@ -613,7 +613,7 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     }
     if (wg == 0 && (tid == 0 || tid == 17 || tid == 255)) {   // diagnostic words (ignored by the host unless asked)
         const int w = tid == 0 ? 0 : (tid == 17 ? 1 : 2);
-        err[8 + w] = (int)dbg_iters; err[11 + w] = (int)(dbg_wdata + dbg_wdep); (void)dbg_prog;
+        err[8 + w] = (int)dbg_iters; err[11 + w] = (int)dbg_wdata; if (w > 0) err[13 + w] = (int)dbg_wdep; (void)dbg_prog;
     }
 #undef RD
 #undef RV
