@@ -260,10 +260,14 @@ void ensure_transposed(ilupp_precond *p)
         }
     } else {
         transpose_storage(st, p->Lc, &p->LcT);
-        if (p->llt_diag_last)   // Lc row-major lower (IChol0): LcT is upper, diagonal first -> backward sweep
-            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, &p->max_len_T);
-        else                    // Lc column-major lower (ICholT): LcT is its row-major form, diagonal last -> forward
-            count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, &p->sLT, nullptr, &p->max_len_T);
+        // Lc row-major lower (IChol0): LcT is upper with the diagonal first -> backward sweep;
+        // Lc column-major lower (ICholT): LcT is its row-major form with the diagonal last -> forward sweep
+        const bool t_fwd = !p->llt_diag_last;
+        if (t_fwd) count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, &p->sLT, nullptr, &p->max_len_T);
+        else       count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, nullptr, &p->sLT, &p->max_len_T);
+        choose_tiling(st, p->n, p->LcT.ptr, p->LcT.idx, &p->sLT, t_fwd, p->max_lanes / kThreads);
+        build_slot_tables(st, &p->sLT, t_fwd);
+        if (schedule_is_compact(p->sLT)) make_desc(st, p->LcT, p->sLT, &p->dLT);
     }
     p->haveT = true;
 }
@@ -451,11 +455,61 @@ int ilupp_hip_ilut_create(const double *, const int32_t *, const int32_t *, int3
     set_error("ILUT: HIP path not built yet");
     return ILUPP_ERR_UNSUPPORTED;
 }
-int ilupp_hip_ichol0_create(const double *, const int32_t *, const int32_t *, int32_t, int, ilupp_precond **out)
+int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                            int32_t n, int is_csr, ilupp_precond **out)
 {
-    if (out) *out = nullptr;
-    set_error("IChol0: HIP path not built yet");
-    return ILUPP_ERR_UNSUPPORTED;
+    API_TRY
+    (void)is_csr;     // IChol0 keeps idx <= major in either orientation and labels the result ROW (IChol.hpp:63-68)
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    ilupp_precond *p = new_obj(n);
+    p->kind = KIND_LLT;
+    p->nnz_mode = NNZ_LLT;
+    p->llt_diag_last = true;
+    hipStream_t st = p->stream;
+    ILUPP_HIP(hipEventRecord(p->ev[0], st));
+    int32_t missing = -1;
+    rc = triangular_part(st, A, true, &p->Lc, &missing);
+    ILUPP_HIP(hipStreamSynchronize(st));
+    A.release();
+    if (rc == ILUPP_ERR_NO_DIAGONAL) {
+        set_error("IChol0: structurally missing diagonal entry in row " + std::to_string(missing));
+        destroy_obj(p);
+        return rc;
+    }
+    p->Lc.is_csr = true;
+    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, &p->sL, nullptr, &p->max_row_len);
+    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, true, p->max_lanes / kThreads);
+    build_slot_tables(st, &p->sL, true);
+    p->compact = schedule_is_compact(p->sL);
+    if (p->compact) make_desc(st, p->Lc, p->sL, &p->dL);
+    ILUPP_HIP(hipEventRecord(p->ev[1], st));
+    float kms = 0.f;
+    rc = ichol0_numeric(st, &p->Lc, p->sL, p->max_row_len, p->done, p->ctrl, &kms);
+    ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[0], p->ev[1]));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));
+    p->tm.numeric_kernel_ms = kms;
+    if (rc) {
+        if (rc == ILUPP_ERR_TIMEOUT) set_error("IChol0: dependency wait timed out");
+        destroy_obj(p);
+        return rc;
+    }
+    *out = p;
+    return ILUPP_OK;
+    API_CATCH
 }
 int ilupp_hip_icholt_create(const double *, const int32_t *, const int32_t *, int32_t, int, int32_t, double, ilupp_precond **out)
 {

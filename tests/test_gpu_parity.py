@@ -201,7 +201,7 @@ def test_unbuilt_paths_fail_loudly():
     import ilupp_amd as ilupp
     d, i, p = matgen.poisson2d(5)
     A = sp.csr_matrix((d, i, p), shape=(25, 25))
-    for ctor in (ilupp.ILUTPreconditioner, ilupp.IChol0Preconditioner, ilupp.ICholTPreconditioner):
+    for ctor in (ilupp.ILUTPreconditioner, ilupp.ICholTPreconditioner):
         try:
             ctor(A)
         except NotImplementedError:
@@ -228,3 +228,78 @@ def test_full_size_properties_128():
     assert np.linalg.norm(LU @ x - b) <= 1e-12 * np.linalg.norm(b) * 50
     xt = b.copy(); P.apply_trans(xt)
     assert np.linalg.norm(LU.T @ xt - b) <= 1e-12 * np.linalg.norm(b) * 50
+
+
+# ------------------------------------------------------------------------------------------------
+# IChol(0)  (SURVEY section 8a, A9): factor bit-exact, LL^T apply == apply_trans
+# ------------------------------------------------------------------------------------------------
+def _check_ichol0(z, key, S):
+    import ilupp_amd as ilupp
+    A = _scipy(S)
+    n = A.shape[0]
+    b = G.rhs(n)
+    P = ilupp.IChol0Preconditioner(A)
+    (Lm,) = P.factors()
+    L = _fac(Lm)
+    if G.has_mat(z, key + "/ichol0_L"):
+        Lg = G.get_mat(z, key + "/ichol0_L")
+        assert G.mat_close(L, Lg, RTOL)
+        assert G.mat_equal(L, Lg)
+    x = b.copy(); P.apply(x)
+    xt = b.copy(); P.apply_trans(xt)
+    assert np.array_equal(x, z[key + "/ichol0_apply"], equal_nan=True)
+    assert np.array_equal(xt, z[key + "/ichol0_apply_trans"], equal_nan=True)
+    assert P.total_nnz == L[2][-1]
+    L2 = ilupp.ichol0(A)
+    assert G.mat_equal(_fac(L2), L)
+    return P
+
+
+@pytest.mark.parametrize("name", ["laplace", "laplace2d", "random"])
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_ichol0_reference_test_matrices(name, fmt):
+    z = G.load("reftests.npz")
+    key = "%s_%s" % (name, fmt)
+    P = _check_ichol0(z, key, G.get_mat(z, key + "/S"))
+    n = P.shape[0]
+    assert repr(P) == "<%dx%d IChol0Preconditioner with nnz=%d, dtype=float64>" % (n, n, P.total_nnz)
+
+
+@pytest.mark.parametrize("name", sorted(G.CONFIG_CASES))
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_ichol0_config_shaped(name, fmt):
+    z = G.load("configs.npz")
+    _, S = G.config_inputs(name, fmt)
+    _check_ichol0(z, "%s_%s" % (name, fmt), S)
+
+
+def test_reference_unit_tests_ichol0():
+    """test/tests.py:286-306 for IChol0: one-step solve on the 1-D Laplacian, L L^T = A, total_nnz = 2n-1"""
+    import ilupp_amd as ilupp
+    n = 50
+    d, i, p = matgen.laplace1d(n)
+    for fmt in ("csr", "csc"):
+        A = sp.csr_matrix((d, i, p), shape=(n, n)).asformat(fmt)
+        X = np.linspace(0, 1, n + 2)[1:-1]
+        x_exact = X * (1 - X) / 2
+        P = ilupp.IChol0Preconditioner(A)
+        x = np.ones(n); P.apply(x)
+        assert np.allclose(x, x_exact)
+        assert np.allclose(P.T @ (A.T @ x_exact), x_exact)
+        (L,) = P.factors()
+        assert np.allclose(A.toarray(), L.dot(L.T).toarray())
+        assert P.total_nnz == 2 * n - 1
+
+
+def test_ichol0_medium_digests():
+    import ilupp_amd as ilupp
+    dg = G.load("digests.json")
+    for name, gen in (("poisson2d_200", lambda: matgen.poisson2d(200)), ("poisson3d_64", lambda: matgen.poisson3d(64))):
+        e = dg[name]
+        d, i, p = gen()
+        n = p.shape[0] - 1
+        P = ilupp.IChol0Preconditioner(sp.csr_matrix((d, i, p), shape=(n, n)))
+        (L,) = P.factors()
+        assert G.digest_of(_fac(L)) == e["ichol0_L"]
+        x = np.ones(n); P.apply(x)
+        assert G.sha(x) == e["ichol0_apply_ones"]
