@@ -449,12 +449,66 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     API_CATCH
 }
 
-int ilupp_hip_ilut_create(const double *, const int32_t *, const int32_t *, int32_t, int, int32_t, double, ilupp_precond **out)
+int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                          int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
-    if (out) *out = nullptr;
-    set_error("ILUT: HIP path not built yet");
-    return ILUPP_ERR_UNSUPPORTED;
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    ilupp_precond *p = new_obj(n);
+    p->kind = KIND_LU;
+    p->nnz_mode = NNZ_ILUT;
+    p->input_csc = !is_csr;      // CSC: factor the row-major view A^T, swap roles on egress (preconditioner_implementation.h:999-1001)
+    hipStream_t st = p->stream;
+    ILUPP_HIP(hipEventRecord(p->ev[0], st));
+    int32_t err_row = -1;
+    float kms = 0.f;
+    rc = ilut_factor(st, A, max_fill_in, threshold, &p->Lc, &p->Uc, &err_row, &kms);
+    ILUPP_HIP(hipEventRecord(p->ev[1], st));
+    A.release();
+    if (rc) {
+        if (rc == ILUPP_ERR_ZERO_PIVOT) set_error("ILUT_heap: encountered zero pivot in row " + std::to_string(err_row));   // ILUT.hpp:269-270
+        else if (rc == ILUPP_ERR_TIMEOUT) set_error("ILUT: dependency wait timed out");
+        else set_error("ILUT: working row overflow");
+        destroy_obj(p);
+        return rc;
+    }
+    // solve schedules from the factors' own patterns
+    int32_t m1 = 0, m2 = 0;
+    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, &p->sL, nullptr, &m1);
+    count_cuts_and_schedule(st, n, p->Uc.ptr, p->Uc.idx, p->max_lanes, nullptr, &p->sU, &m2);
+    p->max_row_len = m1 > m2 ? m1 : m2;
+    const int max_wgs = p->max_lanes / kThreads;
+    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, true, max_wgs);
+    choose_tiling(st, n, p->Uc.ptr, p->Uc.idx, &p->sU, false, max_wgs);
+    build_slot_tables(st, &p->sL, true);
+    build_slot_tables(st, &p->sU, false);
+    p->compact = schedule_is_compact(p->sL) && schedule_is_compact(p->sU);
+    if (p->compact) {
+        make_desc(st, p->Lc, p->sL, &p->dL);
+        make_desc(st, p->Uc, p->sU, &p->dU);
+    }
+    ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
+    p->tm.numeric_kernel_ms = kms;
+    *out = p;
+    return ILUPP_OK;
+    API_CATCH
 }
+
 int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const int32_t *indptr,
                             int32_t n, int is_csr, ilupp_precond **out)
 {

@@ -143,6 +143,10 @@ int triangular_part(hipStream_t st, const DevMat &A, bool lower, DevMat *T, int3
 int ichol0_numeric(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t max_row_len, int32_t *d_done, int32_t *d_ctrl,
                    float *kernel_ms);
 
+// ilut.hip
+int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U,
+                int32_t *err_row, float *kernel_ms);
+
 // sptrsv.hip
 enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRST_DESC = 2 };
 int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
