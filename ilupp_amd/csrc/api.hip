@@ -565,11 +565,62 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
     return ILUPP_OK;
     API_CATCH
 }
-int ilupp_hip_icholt_create(const double *, const int32_t *, const int32_t *, int32_t, int, int32_t, double, ilupp_precond **out)
+int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                            int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out)
 {
-    if (out) *out = nullptr;
-    set_error("ICholT: HIP path not built yet");
-    return ILUPP_ERR_UNSUPPORTED;
+    API_TRY
+    (void)is_csr;     // ICholT keeps idx >= major in either orientation and labels the result COLUMN (IChol.hpp:158-164)
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    ilupp_precond *p = new_obj(n);
+    p->kind = KIND_LLT;
+    p->nnz_mode = NNZ_LLT;
+    p->llt_diag_last = false;
+    hipStream_t st = p->stream;
+    ILUPP_HIP(hipEventRecord(p->ev[0], st));
+    DevMat T;
+    int32_t missing = -1;
+    rc = triangular_part(st, A, false, &T, &missing);        // natural_triangular_part(false): keep idx >= major
+    ILUPP_HIP(hipStreamSynchronize(st));
+    A.release();
+    float kms = 0.f;
+    // a missing diagonal is caught by the reference inside the column loop (IChol.hpp:105-107); same error here
+    rc = icholt_factor(st, T, add_fill_in, threshold, &p->Lc, &kms);
+    T.release();
+    ILUPP_HIP(hipEventRecord(p->ev[1], st));
+    if (rc) {
+        if (rc == ILUPP_ERR_NOT_TRIANGULAR) set_error("ICholT: A must be in triangular form with no zeros on the diagonal");
+        else set_error("append_row: insufficient memory reserved");
+        destroy_obj(p);
+        return rc;
+    }
+    // Lc = CSC lower, diagonal first.  Its arrays read as CSR are L^T (upper, diagonal first): backward sweep.
+    int32_t m1 = 0;
+    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);
+    p->max_row_len = m1;
+    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, false, p->max_lanes / kThreads);
+    build_slot_tables(st, &p->sL, false);
+    p->compact = schedule_is_compact(p->sL);
+    if (p->compact) make_desc(st, p->Lc, p->sL, &p->dL);
+    ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
+    p->tm.numeric_kernel_ms = kms;
+    *out = p;
+    return ILUPP_OK;
+    API_CATCH
 }
 
 void ilupp_hip_destroy(ilupp_precond *p) { destroy_obj(p); }

@@ -143,6 +143,8 @@ int triangular_part(hipStream_t st, const DevMat &A, bool lower, DevMat *T, int3
 int ichol0_numeric(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t max_row_len, int32_t *d_done, int32_t *d_ctrl,
                    float *kernel_ms);
 
+int icholt_factor(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms);
+
 // ilut.hip
 int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U,
                 int32_t *err_row, float *kernel_ms);

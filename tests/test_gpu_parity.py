@@ -197,17 +197,6 @@ def test_missing_diagonal_is_reported():
         ilupp.ILU0Preconditioner(A)
 
 
-def test_unbuilt_paths_fail_loudly():
-    import ilupp_amd as ilupp
-    d, i, p = matgen.poisson2d(5)
-    A = sp.csr_matrix((d, i, p), shape=(25, 25))
-    for ctor in (ilupp.ICholTPreconditioner,):
-        try:
-            ctor(A)
-        except NotImplementedError:
-            pass   # acceptable until the HIP path exists; never a silent CPU fallback
-
-
 def test_full_size_properties_128():
     """size-independent properties at a size the oracle does not need to touch: L*U reproduces A on
     A's pattern (ILU(0) defining property), apply solves (LU)x=b, transposed apply solves (LU)^T x=b"""
@@ -409,3 +398,85 @@ def test_ilut_medium_digests():
         assert G.digest_of(U) == e["ilut_%d_%g_U" % (pp, t)]
         x = np.ones(50000); P.apply(x)
         assert G.sha(x) == e["ilut_%d_%g_apply_ones" % (pp, t)]
+
+
+# ------------------------------------------------------------------------------------------------
+# ICholT: CSC lower factor, diagonal first; apply == apply_trans
+# ------------------------------------------------------------------------------------------------
+def _check_icholt(z, key, S, params, with_apply=True):
+    import ilupp_amd as ilupp
+    A = _scipy(S)
+    n = A.shape[0]
+    b = G.rhs(n)
+    for (a, t) in params:
+        tag = "icholt_%d_%g" % (a, t)
+        P = ilupp.ICholTPreconditioner(A, add_fill_in=a, threshold=t)
+        (Lm,) = P.factors()
+        L = _fac(Lm)
+        Lg = G.get_mat(z, key + "/" + tag + "_L")
+        assert not L[3]                     # csc for either input orientation
+        assert G.mat_close(L, Lg, RTOL), tag
+        assert G.mat_equal(L, Lg), tag
+        if with_apply:
+            x = b.copy(); P.apply(x)
+            assert np.array_equal(x, z[key + "/" + tag + "_apply"], equal_nan=True), tag
+            xt = b.copy(); P.apply_trans(xt)
+            assert np.array_equal(xt, x, equal_nan=True), tag       # LL^T: apply_trans == apply
+        assert P.total_nnz == L[2][-1]
+        L2 = ilupp.icholt(A, add_fill_in=a, threshold=t)
+        assert G.mat_equal(_fac(L2), L)
+
+
+@pytest.mark.parametrize("name", ["laplace", "laplace2d", "random"])
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_icholt_reference_test_matrices(name, fmt):
+    z = G.load("reftests.npz")
+    key = "%s_%s" % (name, fmt)
+    _check_icholt(z, key, G.get_mat(z, key + "/S"), ((0, 0.0), (5, 1e-3)))
+
+
+@pytest.mark.parametrize("name", sorted(G.CONFIG_CASES))
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_icholt_config_shaped(name, fmt):
+    z = G.load("configs.npz")
+    _, S = G.config_inputs(name, fmt)
+    _check_icholt(z, "%s_%s" % (name, fmt), S, G.ICHOLT)
+
+
+def test_icholt_topk_ties_and_unit_tests():
+    import ilupp_amd as ilupp
+    z = G.load("edges.npz")
+    d, i, p = matgen.poisson3d(12)
+    S = matgen.symmetrize(d, i, p) + (True,)
+    for (a, t) in ((5, 1e-3), (3, 0.0), (12, 0.0)):
+        L = ilupp.icholt(_scipy(S), add_fill_in=a, threshold=t)
+        assert G.mat_equal(_fac(L), G.get_mat(z, "ties/icholt_%d_%g_L" % (a, t)))
+    # test/tests.py:286-306 for ICholT on the 1-D Laplacian
+    n = 50
+    d, i, p = matgen.laplace1d(n)
+    for fmt in ("csr", "csc"):
+        A = sp.csr_matrix((d, i, p), shape=(n, n)).asformat(fmt)
+        X = np.linspace(0, 1, n + 2)[1:-1]
+        x_exact = X * (1 - X) / 2
+        P = ilupp.ICholTPreconditioner(A)
+        x = np.ones(n); P.apply(x)
+        assert np.allclose(x, x_exact)
+        assert np.allclose(P.T @ (A.T @ x_exact), x_exact)
+        (L,) = P.factors()
+        assert np.allclose(A.toarray(), L.dot(L.T).toarray())
+        assert P.total_nnz == 2 * n - 1
+        assert repr(P) == "<%dx%d ICholTPreconditioner with nnz=%d, dtype=float64>" % (n, n, P.total_nnz)
+
+
+def test_icholt_medium_digests():
+    import ilupp_amd as ilupp
+    dg = G.load("digests.json")
+    e = dg["poisson2d_200"]
+    d, i, p = matgen.poisson2d(200)
+    A = sp.csr_matrix((d, i, p), shape=(40000, 40000))
+    for (a, t) in ((0, 0.0), (5, 1e-3)):
+        P = ilupp.ICholTPreconditioner(A, add_fill_in=a, threshold=t)
+        (L,) = P.factors()
+        assert G.digest_of(_fac(L)) == e["icholt_%d_%g_L" % (a, t)]
+        x = np.ones(40000); P.apply(x)
+        assert G.sha(x) == e["icholt_%d_%g_apply_ones" % (a, t)]
