@@ -33,7 +33,8 @@ void Schedule::release()
     if (blk2slot) (void)pool_free(blk2slot);
     if (sfirst) (void)pool_free(sfirst);
     if (scount) (void)pool_free(scount);
-    start = slot2blk = blk2slot = sfirst = scount = nullptr; nb = 0; nslots = 0;
+    if (exported) (void)pool_free(exported);
+    start = slot2blk = blk2slot = sfirst = scount = exported = nullptr; nb = 0; nslots = 0;
 }
 void Ilu0Program::release()
 {

@@ -56,6 +56,7 @@ struct Schedule {
     int32_t *blk2slot = nullptr;   // nb
     int32_t *sfirst = nullptr;     // nslots: first row of the slot in processing order
     int32_t *scount = nullptr;     // nslots: number of rows of the slot
+    int32_t *exported = nullptr;   // nslots: 1 if some OTHER workgroup reads this slot's results (filled by make_desc / the program builder)
     // 2-D tiling of the block grid (0 = identity placement): block b = (b % s2, b / s2), a workgroup owns ty x tz blocks
     int32_t tile_s2 = 0, tile_ty = 0, tile_tz = 0;
     void release();

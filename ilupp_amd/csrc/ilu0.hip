@@ -423,7 +423,7 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                   const int32_t *__restrict__ Uptr, double *Uval, long nnzU,
                   const int32_t *__restrict__ prog, int32_t n,
                   int32_t nslots_used, const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount,
-                  int32_t *ctrl)
+                  const int32_t *__restrict__ exported, int32_t *ctrl)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x & (kThreads - 1);
@@ -446,7 +446,8 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
 #define RA(i) sA[((i) & (kAW - 1)) * kThreads + tid]
 
     int cnt = 0, r0 = 0;
-    if ((int)myslot < nslots_used) { cnt = scount[myslot]; r0 = sfirst[myslot]; }
+    bool exports = true;          // U rows read by another workgroup must leave the XCD (write-through); the rest may stay in L2
+    if ((int)myslot < nslots_used) { cnt = scount[myslot]; r0 = sfirst[myslot]; exports = exported[myslot] != 0; }
     int a00 = 0, l00 = 0, u00 = 0;
     if (cnt > 0) { a00 = Aptr[r0]; l00 = Lptr[r0]; u00 = Uptr[r0]; }
     if (!is_loader) {
@@ -686,7 +687,7 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                         if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN); \
                         v4i_f e; e.x = rloc; e.y = 0; e.z = __double2loint(v); e.w = __double2hiint(v);      \
                         ur[(sr * 4 + Q) * kThreads + tid] = e;                                              \
-                        st_agent_f64(&Uval[u0 + Q], v);                                                     \
+                        if (exports) st_agent_f64(&Uval[u0 + Q], v); else Uval[u0 + Q] = v;                 \
                     }
                     PUBLISH(0, w3)
                     PUBLISH(1, w4)
@@ -732,7 +733,7 @@ int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const
     ILUPP_HIP(hipEventRecord(e0, st));
     ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_numeric_lc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIluLcLds));
     hipLaunchKernelGGL(k_ilu0_numeric_lc, dim3(grid), dim3(2 * kThreads), kIluLcLds, st, A.val, (long)A.nnz, A.ptr,
-                       L->ptr, L->val, U->ptr, U->val, (long)U->nnz, prog_f3, A.n, fwd.nslots, fwd.sfirst, fwd.scount, d_ctrl);
+                       L->ptr, L->val, U->ptr, U->val, (long)U->nnz, prog_f3, A.n, fwd.nslots, fwd.sfirst, fwd.scount, fwd.exported, d_ctrl);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t ctrl[4];

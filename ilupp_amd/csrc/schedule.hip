@@ -88,6 +88,8 @@ void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
     ILUPP_HIP(pool_malloc(&sch->blk2slot, sizeof(int32_t) * (size_t)(sch->nb > 0 ? sch->nb : 1)));
     ILUPP_HIP(pool_malloc(&sch->sfirst, bytes));
     ILUPP_HIP(pool_malloc(&sch->scount, bytes));
+    ILUPP_HIP(pool_malloc(&sch->exported, bytes));
+    ILUPP_HIP(hipMemsetAsync(sch->exported, 0, bytes, st));
     hipLaunchKernelGGL(k_slot_tables, dim3((unsigned)(sch->nslots / kThreads)), dim3(kThreads), 0, st,
                        sch->nb, sch->nslots, fwd ? 1 : 0, til, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount);
 }
@@ -169,16 +171,19 @@ void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t 
 // desc = owner_slot << 15 | kloc, kloc = index of row c in its owner's processing order; -1 on the diagonal.
 __global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                             int32_t B, int32_t nb, int fwd, const int32_t *__restrict__ start,
-                            const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc)
+                            const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc, int32_t *__restrict__ exported)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    const int mywg = blk2slot[block_of(r, B, nb, start)] >> 8;
     for (int q = ptr[r]; q < ptr[r + 1]; ++q) {
         const int c = idx[q];
         if (c == r) { desc[q] = -1; continue; }     // diagonal marker: also delimits the rows of the stream
         const int b = block_of(c, B, nb, start);
         const int kloc = fwd ? (c - start[b]) : (start[b + 1] - 1 - c);
-        desc[q] = (blk2slot[b] << 15) | kloc;
+        const int oslot = blk2slot[b];
+        desc[q] = (oslot << 15) | kloc;
+        if ((oslot >> 8) != mywg) exported[oslot] = 1;     // read across a workgroup border: must be stored write-through
     }
 }
 
@@ -186,7 +191,7 @@ void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **d
 {
     ILUPP_HIP(pool_malloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
     hipLaunchKernelGGL(k_make_desc, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, st, M.n, M.ptr, M.idx,
-                       sch.B, sch.nb, sch.fwd ? 1 : 0, sch.start, sch.blk2slot, *desc);
+                       sch.B, sch.nb, sch.fwd ? 1 : 0, sch.start, sch.blk2slot, *desc, sch.exported);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,10 +286,11 @@ __global__ void k_ilu0_program(int32_t n, const int32_t *__restrict__ Aptr, cons
 __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx,
                                   const int32_t *__restrict__ Uptr, int32_t B, int32_t nb,
                                   const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
-                                  int32_t *__restrict__ prog, int32_t *__restrict__ ineligible)
+                                  int32_t *__restrict__ prog, int32_t *__restrict__ ineligible, int32_t *__restrict__ exported)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    const int mywg = blk2slot[block_of(r, B, nb, start)] >> 8;
     const int a0 = Aptr[r], a1 = Aptr[r + 1];
     const int len = a1 - a0;
     int cl = 0;
@@ -314,6 +320,7 @@ __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, c
             }
             const int b = block_of(k, B, nb, start);
             const int kd_word = (blk2slot[b] << 15) | (k - start[b]);
+            if ((blk2slot[b] >> 8) != mywg) exported[blk2slot[b]] = 1;
             const int pv = Uptr[k];
             if (sl == 0) { d0 = kd_word; p0 = pv; }
             else if (sl == 1) { d1 = kd_word; p1 = pv; }
@@ -347,7 +354,7 @@ bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, con
     ILUPP_HIP(pool_malloc(&flag, 16));
     ILUPP_HIP(hipMemsetAsync(flag, 0, 16, st));
     hipLaunchKernelGGL(k_ilu0_program_f3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr,
-                       sch.B, sch.nb, sch.start, sch.blk2slot, prog, flag);
+                       sch.B, sch.nb, sch.start, sch.blk2slot, prog, flag, sch.exported);
     int32_t h = 0;
     ILUPP_HIP(hipMemcpyAsync(&h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));

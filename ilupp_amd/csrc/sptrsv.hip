@@ -260,7 +260,8 @@ template <int KIND>
 __global__ void __launch_bounds__(kLcThreads)
 k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, const double *__restrict__ val,
             int32_t n, long nnz, double *rhs, double *out, int32_t nslots_used,
-            const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount, int32_t *ticket, int32_t *err)
+            const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount,
+            const int32_t *__restrict__ exported, int32_t *ticket, int32_t *err)
 {
     constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
     constexpr bool DESC = (KIND == SWEEP_BWD_FIRST_DESC);
@@ -292,7 +293,8 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
 #define RR(i) srhs[((i) & (kRW - 1)) * kThreads + tid]
 
     int cnt = 0, r0 = 0;
-    if ((int)myslot < nslots_used) { cnt = scount[myslot]; r0 = sfirst[myslot]; }
+    bool exports = true;          // results read by another workgroup must leave the XCD (write-through); the rest may stay in L2
+    if ((int)myslot < nslots_used) { cnt = scount[myslot]; r0 = sfirst[myslot]; exports = exported[myslot] != 0; }
     int bound0 = 0;          // FWD: start of the first row; BWD: end of the first row
     if (cnt > 0) bound0 = FWD ? ptr[r0] : ptr[r0 + 1];
     if (!is_loader) {
@@ -443,7 +445,7 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
         e.x = rloc; e.y = 0; e.z = __double2loint(x); e.w = __double2hiint(x);
         xr[(rloc & (kXD - 1)) * kThreads + tid] = e;                  // one ds_write_b128
         asm volatile("" ::: "memory");
-        st_agent_f64(out + r, x);
+        if (exports) st_agent_f64(out + r, x); else out[r] = x;
         prev_val = x;
         bound = FWD ? hi : lo;
         r += DR;
@@ -633,7 +635,7 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
             do {                                                                                             \
                 ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lc<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLcLds)); \
                 hipLaunchKernelGGL((k_sptrsv_lc<K>), dim3(grid), dim3(kLcThreads), kLcLds, st, M.ptr, desc, M.val, M.n, (long)M.nnz, \
-                                   rhs_and_reset, out, sch.nslots, sch.sfirst, sch.scount, d_ticket, d_err);  \
+                                   rhs_and_reset, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, d_ticket, d_err);  \
             } while (0)
             switch (kind) {
             case SWEEP_FWD_LAST_ASC: LAUNCHS(SWEEP_FWD_LAST_ASC); break;
