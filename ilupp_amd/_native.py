@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libilupp_hip.so")
+_LIB_PATH = os.environ.get("ILUPP_HIP_LIBRARY") or os.path.join(_HERE, "libilupp_hip.so")
 
 _I32P = ctypes.POINTER(ctypes.c_int32)
 _F64P = ctypes.POINTER(ctypes.c_double)

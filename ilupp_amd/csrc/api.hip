@@ -34,7 +34,8 @@ void Schedule::release()
     if (sfirst) (void)pool_free(sfirst);
     if (scount) (void)pool_free(scount);
     if (exported) (void)pool_free(exported);
-    start = slot2blk = blk2slot = sfirst = scount = exported = nullptr; nb = 0; nslots = 0;
+    if (gtab) (void)pool_free(gtab);
+    start = slot2blk = blk2slot = sfirst = scount = exported = gtab = nullptr; nb = 0; nslots = 0;
 }
 void Ilu0Program::release()
 {
@@ -154,7 +155,7 @@ struct ilupp_precond {
 
 namespace {
 
-bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <= (1 << 17); }
+bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <= kGhostBase; }
 
 void destroy_obj(ilupp_precond *p)
 {

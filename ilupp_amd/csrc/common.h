@@ -57,10 +57,15 @@ struct Schedule {
     int32_t *sfirst = nullptr;     // nslots: first row of the slot in processing order
     int32_t *scount = nullptr;     // nslots: number of rows of the slot
     int32_t *exported = nullptr;   // nslots: 1 if some OTHER workgroup reads this slot's results (filled by make_desc / the program builder)
+    int32_t *gtab = nullptr;       // nslots/256 x kGhosts: foreign producer slots a workgroup imports through ghost lanes (-1 = free)
     // 2-D tiling of the block grid (0 = identity placement): block b = (b % s2, b / s2), a workgroup owns ty x tz blocks
     int32_t tile_s2 = 0, tile_ty = 0, tile_tz = 0;
     void release();
 };
+
+// Descriptor owner fields >= kGhostBase name ghost lane (owner - kGhostBase) of the reading workgroup.
+static constexpr int kGhosts = 64;
+static constexpr int kGhostBase = (1 << 17) - kGhosts;
 
 // ILU(0) update program (schedule.hip)
 struct Ilu0Program {

@@ -90,6 +90,8 @@ void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
     ILUPP_HIP(pool_malloc(&sch->scount, bytes));
     ILUPP_HIP(pool_malloc(&sch->exported, bytes));
     ILUPP_HIP(hipMemsetAsync(sch->exported, 0, bytes, st));
+    const size_t gbytes = sizeof(int32_t) * (size_t)(sch->nslots / kThreads) * kGhosts;
+    ILUPP_HIP(pool_malloc(&sch->gtab, gbytes));
     hipLaunchKernelGGL(k_slot_tables, dim3((unsigned)(sch->nslots / kThreads)), dim3(kThreads), 0, st,
                        sch->nb, sch->nslots, fwd ? 1 : 0, til, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount);
 }
@@ -169,9 +171,45 @@ void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t 
 // solve descriptors
 // ---------------------------------------------------------------------------------------------
 // desc = owner_slot << 15 | kloc, kloc = index of row c in its owner's processing order; -1 on the diagonal.
+// Import table of a workgroup: the foreign producer slots its lanes read from, found on a sample of each
+// lane's rows (first, middle, last -- the lanes of a mesh-like matrix read the same neighbours in every
+// row).  Purely a fast path: a producer that is not in the table is polled directly by its consumer.
+__global__ void __launch_bounds__(kThreads)
+k_ghost_table(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t B, int32_t nb,
+              const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot, int fwd,
+              const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount, int32_t *__restrict__ gtab)
+{
+    __shared__ int tab[kGhosts];
+    const int wg = blockIdx.x, t = threadIdx.x;
+    if (t < kGhosts) tab[t] = -1;
+    __syncthreads();
+    const int slot = wg * kThreads + t;
+    const int cnt = scount[slot], first = sfirst[slot];
+    const int dr = fwd ? 1 : -1;
+    for (int sample = 0; sample < 3 && cnt > 0; ++sample) {
+        const int k = sample == 0 ? 0 : (sample == 1 ? cnt / 2 : cnt - 1);
+        if (sample > 0 && k == (sample == 1 ? 0 : cnt / 2)) continue;
+        const int r = first + dr * k;
+        for (int q = ptr[r]; q < ptr[r + 1]; ++q) {
+            const int c = idx[q];
+            if (c == r) continue;
+            const int oslot = blk2slot[block_of(c, B, nb, start)];
+            if ((oslot >> 8) == wg) continue;
+            unsigned h = ((unsigned)oslot * 0x9E3779B1u) >> 26;
+            for (int probe = 0; probe < kGhosts; ++probe, h = (h + 1) & (kGhosts - 1)) {
+                const int cur = atomicCAS(&tab[h], -1, oslot);
+                if (cur == -1 || cur == oslot) break;
+            }
+        }
+    }
+    __syncthreads();
+    if (t < kGhosts) gtab[(size_t)wg * kGhosts + t] = tab[t];
+}
+
 __global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                             int32_t B, int32_t nb, int fwd, const int32_t *__restrict__ start,
-                            const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc, int32_t *__restrict__ exported)
+                            const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc, int32_t *__restrict__ exported,
+                            const int32_t *__restrict__ gtab)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -181,17 +219,32 @@ __global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const in
         if (c == r) { desc[q] = -1; continue; }     // diagonal marker: also delimits the rows of the stream
         const int b = block_of(c, B, nb, start);
         const int kloc = fwd ? (c - start[b]) : (start[b + 1] - 1 - c);
-        const int oslot = blk2slot[b];
+        int oslot = blk2slot[b];
+        if ((oslot >> 8) != mywg) {
+            exported[oslot] = 1;     // read across a workgroup border: must be stored write-through
+            // a producer listed in the import table is named by its ghost lane (sptrsv.hip)
+            if (gtab && kloc < 0x7fff) {
+                const int32_t *tab = gtab + (size_t)mywg * kGhosts;
+                unsigned h = ((unsigned)oslot * 0x9E3779B1u) >> 26;
+                for (int probe = 0; probe < kGhosts; ++probe, h = (h + 1) & (kGhosts - 1)) {
+                    const int cur = tab[h];
+                    if (cur == oslot) { oslot = kGhostBase + (int)h; break; }
+                    if (cur == -1) break;
+                }
+            }
+        }
         desc[q] = (oslot << 15) | kloc;
-        if ((oslot >> 8) != mywg) exported[oslot] = 1;     // read across a workgroup border: must be stored write-through
     }
 }
 
 void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc)
 {
     ILUPP_HIP(pool_malloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
+    if (sch.gtab)
+        hipLaunchKernelGGL(k_ghost_table, dim3((unsigned)(sch.nslots / kThreads)), dim3(kThreads), 0, st, M.ptr, M.idx,
+                           sch.B, sch.nb, sch.start, sch.blk2slot, sch.fwd ? 1 : 0, sch.sfirst, sch.scount, sch.gtab);
     hipLaunchKernelGGL(k_make_desc, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, st, M.n, M.ptr, M.idx,
-                       sch.B, sch.nb, sch.fwd ? 1 : 0, sch.start, sch.blk2slot, *desc, sch.exported);
+                       sch.B, sch.nb, sch.fwd ? 1 : 0, sch.start, sch.blk2slot, *desc, sch.exported, sch.gtab);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -348,7 +401,7 @@ __global__ void k_ilu0_program_f3(int32_t n, const int32_t *__restrict__ Aptr, c
 bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, int32_t **prog_out)
 {
     const int32_t n = A.n;
-    if (sch.B > 32768 || sch.nslots > (1 << 17)) return false;
+    if (sch.B > 32768 || sch.nslots > kGhostBase) return false;
     int32_t *prog = nullptr, *flag = nullptr;
     ILUPP_HIP(pool_malloc(&prog, sizeof(int32_t) * 8 * (size_t)n + 64));
     ILUPP_HIP(pool_malloc(&flag, 16));
@@ -391,7 +444,7 @@ bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const 
     ILUPP_HIP(pool_free(tmp));
     P->max_words = h[0];
     P->max_ulen = h[1];
-    const bool ok = (h[2] == 0) && total > 0 && sch.B <= 32768 && sch.nslots <= (1 << 17);
+    const bool ok = (h[2] == 0) && total > 0 && sch.B <= 32768 && sch.nslots <= kGhostBase;
     if (!ok) {
         ILUPP_HIP(pool_free(nwords)); ILUPP_HIP(pool_free(stats));
         ILUPP_HIP(pool_free(P->prow)); P->prow = nullptr;

@@ -19,6 +19,7 @@
 // sentinel.  No flag array, no fences, no grid barrier.  The right-hand side is read once per row
 // and immediately overwritten with the sentinel, which makes that buffer the ready-made output of
 // the next sweep: L-solve  x -> y,  U-solve  y -> x  leaves the result in place in x and y reset.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -123,7 +124,7 @@ template <int KIND>
 __global__ void __launch_bounds__(kThreads)
 k_sptrsv_desc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, const double *__restrict__ val,
               double *rhs, double *out, int32_t nslots_used, const int32_t *__restrict__ sfirst,
-              const int32_t *__restrict__ scount, int32_t *ticket, int32_t *err)
+              const int32_t *__restrict__ scount, const int32_t *__restrict__ gtab, int32_t *ticket, int32_t *err)
 {
     constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
     constexpr bool DESC = (KIND == SWEEP_BWD_FIRST_DESC);
@@ -186,7 +187,9 @@ k_sptrsv_desc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc,
                     }
                 }
                 if (!have) {
-                    const int c = sfirst[oslot] + dir * kl;
+                    // a ghost owner names an entry of this workgroup's import table (schedule.hip)
+                    const unsigned os = oslot >= (unsigned)kGhostBase ? (unsigned)gtab[wg * kGhosts + (oslot & (kGhosts - 1))] : oslot;
+                    const int c = sfirst[os] + dir * kl;
                     const unsigned long long bits = ld_agent_u64(outb + c);
                     if (bits == kSentinel) break;
                     xc = __longlong_as_double((long long)bits);
@@ -237,8 +240,12 @@ k_sptrsv_desc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc,
 //     ([slot][lane] layout: the bank depends on the lane only, so any per-lane offset is conflict-free);
 //     only loaders ever wait on HBM latency;
 //   * waves 0-3 are CONSUMERS: they read LDS only.  Unknowns produced in the same workgroup arrive
-//     through a 16-byte {tag,x} LDS ring entry (one ds_read_b128); unknowns produced elsewhere are
-//     polled in HBM (data-is-flag), four consecutive ones per trip; results leave by write-through stores.
+//     through a 16-byte {tag,x} LDS ring entry (one ds_read_b128); results leave by write-through stores;
+//   * wave 8 is the IMPORTER: lane g follows one foreign producer lane (a "ghost", schedule.hip gtab): it
+//     polls that lane's unknowns in HBM (data-is-flag) a few rows ahead of their consumer and drops them
+//     into a ghost {tag,x} ring, so a consumer reads a foreign unknown exactly like a local one and never
+//     waits on a memory round trip (a poll by one lane stalls all 64 lanes of its wave).  The ghost ring is
+//     only a fast path: an entry that is late or already recycled is fetched by the consumer itself.
 struct __attribute__((aligned(4))) I4u { int v[4]; };
 struct __attribute__((aligned(8))) D2u { double v[2]; };
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -252,23 +259,39 @@ static constexpr int kEW = 32, kEQ = 8, kENQ = 3;   // entry ring / refill quant
 static constexpr int kRW = 16, kRQ = 4, kRNQ = 3;   // right-hand-side ring / quantum / quanta per round
 static constexpr int kXD = 4;              // depth of the {tag,x} hand-off ring
 static constexpr int kEC = 4;              // external unknowns fetched per trip
-static constexpr int kLcThreads = 2 * kThreads;
-static constexpr size_t kLcLds = (size_t)kThreads * (kEW * 4 + kEW * 8 + kRW * 8 + kXD * 16 + kEC * 8 + 5 * 4) + 16;
+static constexpr int kGD = 8;              // depth of a ghost ring (overlays the external cache: kGD*kGhosts*16 == kEC*256*8)
+static constexpr int kIB = 4;              // unknowns an importer lane polls per trip
+#ifndef GP
+#define GP 256
+#endif
+static constexpr int kGhostPatience = GP;  // rounds a consumer waits for a ghost entry before polling itself
+static constexpr int kLcThreads = 2 * kThreads + 64;
+static constexpr size_t kLcLds = (size_t)kThreads * (kEW * 4 + kEW * 8 + kRW * 8 + kXD * 16 + kEC * 8 + 5 * 4) + 2 * kGhosts * 4 + 32;
+static_assert(kGD * kGhosts * 16 == kEC * kThreads * 8, "ghost rings overlay the external cache");
 static constexpr int kDiag = -1;           // descriptor of a diagonal entry (schedule.hip); delimits rows in the stream
+
+#ifdef ILUPP_TIMELINE
+__device__ unsigned long long *g_timeline = nullptr;     // diagnostics build only: 8 words per workgroup
+#define TL(i) do { if (tl) tl[(size_t)wg * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define TL(i) do { } while (0)
+#endif
 
 template <int KIND>
 __global__ void __launch_bounds__(kLcThreads)
 k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, const double *__restrict__ val,
             int32_t n, long nnz, double *rhs, double *out, int32_t nslots_used,
             const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount,
-            const int32_t *__restrict__ exported, int32_t *ticket, int32_t *err)
+            const int32_t *__restrict__ exported, const int32_t *__restrict__ gtab, int32_t *ticket, int32_t *err)
 {
     constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
     constexpr bool DESC = (KIND == SWEEP_BWD_FIRST_DESC);
     constexpr int DR = FWD ? 1 : -1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x & (kThreads - 1);        // consumer lane / client lane
-    const bool is_loader = threadIdx.x >= kThreads;
+    const bool is_consumer = threadIdx.x < kThreads;
+    const bool is_loader = !is_consumer && threadIdx.x < 2 * kThreads;
+    const bool is_importer = threadIdx.x >= 2 * kThreads;
     // carve (every offset a multiple of 16)
     double *sval = reinterpret_cast<double *>(smem);                         // [kEW][256]
     double *srhs = sval + kEW * kThreads;                                    // [kRW][256]
@@ -282,11 +305,19 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     int *e_cons = r_avail + kThreads;
     int *r_cons = e_cons + kThreads;
     int *fin = r_cons + kThreads;
-    unsigned *wg_ticket = reinterpret_cast<unsigned *>(fin + kThreads);
+    int *gfirst = fin + kThreads;                                            // [kGhosts] first row of the ghost's producer
+    int *gack = gfirst + kGhosts;                                            // [kGhosts] oldest entry still wanted by the consumer
+    int *hasg = gack + kGhosts;                                              // workgroup imports through ghosts
+    unsigned *wg_ticket = reinterpret_cast<unsigned *>(hasg + 4);
+    v4i *gr = reinterpret_cast<v4i *>(secv);                                 // [kGD][kGhosts] {tag,-,x.lo,x.hi}, ghost mode only
     if (threadIdx.x == 0) *wg_ticket = (unsigned)atomicAdd(ticket, 1);
     __syncthreads();
     const unsigned wg = *wg_ticket;
     const unsigned myslot = wg * kThreads + tid;
+#ifdef ILUPP_TIMELINE
+    unsigned long long *const tl = g_timeline;
+#endif
+    if (threadIdx.x == 0) TL(0);
 
 #define RD(i) sdesc[((i) & (kEW - 1)) * kThreads + tid]
 #define RV(i) sval[((i) & (kEW - 1)) * kThreads + tid]
@@ -297,7 +328,17 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     if ((int)myslot < nslots_used) { cnt = scount[myslot]; r0 = sfirst[myslot]; exports = exported[myslot] != 0; }
     int bound0 = 0;          // FWD: start of the first row; BWD: end of the first row
     if (cnt > 0) bound0 = FWD ? ptr[r0] : ptr[r0 + 1];
-    if (!is_loader) {
+    int g_first = 0, g_cnt = 0;
+    if (is_importer) {
+        const int g = threadIdx.x - 2 * kThreads;
+        const int os = gtab ? gtab[(size_t)wg * kGhosts + g] : -1;
+        if (os >= 0) { g_first = sfirst[os]; g_cnt = scount[os]; }
+        const bool any = __any(os >= 0);
+        if (g == 0) *hasg = any ? 1 : 0;
+        if (any) for (int s = 0; s < kGD; ++s) { v4i e; e.x = -1; e.y = 0; e.z = 0; e.w = 0; gr[s * kGhosts + g] = e; }
+        gfirst[g] = g_first; gack[g] = 0;
+    }
+    if (is_consumer) {
         for (int s = 0; s < kXD; ++s) { v4i e; e.x = -1; e.y = 0; e.z = 0; e.w = 0; xr[s * kThreads + tid] = e; }
         e_avail[tid] = bound0; r_avail[tid] = FWD ? r0 : r0 + 1;
         e_cons[tid] = bound0;  r_cons[tid] = r0;
@@ -392,6 +433,57 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
         return;
     }
 
+    const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(out);
+    if (is_importer) {
+        // ---------------------------------------------------------------- importer
+        if (!*hasg) return;
+        const int g = threadIdx.x - 2 * kThreads;
+        int next = 0;
+        unsigned idle = 0;
+        for (;;) {
+            asm volatile("" ::: "memory");
+            const v4i f = reinterpret_cast<const v4i *>(fin)[g];
+            if (__all((f.x & f.y & f.z & f.w) != 0)) break;             // every consumer lane is done
+            bool did = false;
+            if (next < g_cnt) {
+                const int ack = gack[g];
+                if (ack > next) next = ack;                              // the consumer fetched those itself
+                int nb = g_cnt - next;
+                nb = nb < kIB ? nb : kIB;
+                nb = nb < ack + kGD - next ? nb : ack + kGD - next;      // entry k recycles the slot of k-kGD
+                if (nb > 0) {
+                    unsigned long long b[kIB];
+#pragma unroll
+                    for (int q = 0; q < kIB; ++q) {
+                        const int cq = g_first + DR * (next + q);
+                        b[q] = ld_agent_u64(outb + (cq < 0 ? 0 : (cq >= n ? n - 1 : cq)));
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    int got = 0;
+#pragma unroll
+                    for (int q = 0; q < kIB; ++q) got += (got == q && q < nb && b[q] != kSentinel) ? 1 : 0;
+#pragma unroll
+                    for (int q = 0; q < kIB; ++q) {
+                        if (q < got) {
+                            v4i e;
+                            e.x = next + q; e.y = 0; e.z = (int)(unsigned)b[q]; e.w = (int)(unsigned)(b[q] >> 32);
+                            gr[((next + q) & (kGD - 1)) * kGhosts + g] = e;
+                        }
+                    }
+                    next += got;
+                    did = got > 0;
+                }
+            }
+            if (__any(did)) {
+                idle = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+                if (++idle > kSolveSpinLimit) break;
+            }
+        }
+        return;
+    }
+
     // ---------------------------------------------------------------------- consumer
     // A row costs TWO dependent LDS round trips when it has at most 4 stored entries (the 5-/7-point
     // factors): round 1 reads the hand-shake words, the right-hand side and -- from the already known row
@@ -409,11 +501,22 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
     double acc = 0.0, prev_val = 0.0;
     unsigned ec_oslot = 0xffffffffu; int ec_kl0 = 0, ec_cnt = 0, ec_first = 0;
     unsigned spins = 0;
-    unsigned dbg_iters = 0, dbg_prog = 0, dbg_wdata = 0, dbg_wdep = 0;
-    const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(out);
+    int stall = 0;                         // rounds the current row has been waiting for its dependencies
+    int gpat = kGhostPatience;
+    const bool ghost_mode = *hasg != 0;    // the external cache's LDS then belongs to the ghost rings
 
     // external unknown (other workgroup): cached batch of kEC consecutive ones, else one poll trip
+    auto poll_one = [&](int c, double &xc) -> bool {
+        const unsigned long long b = ld_agent_u64(outb + c);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        xc = __longlong_as_double((long long)b);
+        return b != kSentinel;
+    };
     auto external = [&](unsigned oslot, int kl, double &xc) -> bool {
+        if (ghost_mode) {
+            if (oslot != ec_oslot) { ec_first = sfirst[oslot]; ec_oslot = oslot; __builtin_amdgcn_s_waitcnt(0x0F70); }
+            return poll_one(ec_first + DR * kl, xc);
+        }
         if (oslot == ec_oslot && kl >= ec_kl0 && kl < ec_kl0 + ec_cnt) {
             xc = secv[(kl - ec_kl0) * kThreads + tid];
             return true;
@@ -439,18 +542,45 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
         xc = __longlong_as_double((long long)b[0]);
         return true;
     };
+    // unknown kl of ghost lane g; e is its ring entry read this round
+    auto ghost = [&](int g, int kl, const v4i &e, double &xc) -> bool {
+        bool have = false;
+        if (e.x == kl) {
+            xc = __hiloint2double(e.w, e.z);
+            have = true;
+        } else if (e.x > kl || stall > gpat) {
+            // recycled before we came, or nothing arrived for a long time: fetch it here
+            have = poll_one(gfirst[g] + DR * kl, xc);
+            if (e.x < kl) { if (have) gpat = 0; else stall = 0; }     // the ring failed us once: stop relying on it
+        }
+        gack[g] = kl;              // entries older than the one we want may be recycled; the importer skips to it
+        return have;
+    };
     auto publish = [&](double x) {
         if (x != x) x = __longlong_as_double((long long)kCanonNaN);
         v4i e;
         e.x = rloc; e.y = 0; e.z = __double2loint(x); e.w = __double2hiint(x);
         xr[(rloc & (kXD - 1)) * kThreads + tid] = e;                  // one ds_write_b128
         asm volatile("" ::: "memory");
+#ifdef EXP_NOSTORE
+        if (exports) st_agent_f64(out + r, x);
+#else
         if (exports) st_agent_f64(out + r, x); else out[r] = x;
+#endif
+#ifdef ILUPP_TIMELINE
+        if (rloc == 0 || rloc == cnt - 1 || rloc == cnt / 2) {
+            if (tid == 0) { if (rloc == 0) TL(1); else if (rloc == cnt - 1) TL(2); else TL(7); }
+            if (tid == 255) { if (rloc == 0) TL(3); if (rloc == cnt - 1) TL(4); }
+            if (tid == 15 && rloc == 0) TL(5);
+            if (tid == 240 && rloc == 0) TL(6);
+        }
+#endif
         prev_val = x;
         bound = FWD ? hi : lo;
         r += DR;
         ++rloc;
         phase = 0;
+        stall = 0;
         active = rloc < cnt;
         if (!active) fin[tid] = 1;
     };
@@ -485,7 +615,9 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                         r_cons[tid] = r;
                         e_cons[tid] = bound;
                         acc = rr;
+#ifndef EXP_NORESET
                         reinterpret_cast<unsigned long long *>(rhs)[r] = kSentinel;
+#endif
                         if (dk >= 0) {
                             if (FWD) { lo = bound; len = dk + 1; hi = lo + len; }
                             else     { hi = bound; len = 4 - dk; lo = hi - len; }
@@ -509,8 +641,13 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const unsigned d = (unsigned)ed[k];
-                    const int lane = (int)((d >> 15) & 255u);
-                    re[k] = xr[((int)(d & 0x7fffu) & (kXD - 1)) * kThreads + lane];
+                    const int kl = (int)(d & 0x7fffu);
+                    const unsigned os = d >> 15;
+                    // one ds_read_b128 either way: the ghost rings sit kEC*kThreads*8 bytes below xr
+                    const int at = os >= (unsigned)kGhostBase
+                        ? -(kEC * kThreads * 8 / 16) + (kl & (kGD - 1)) * kGhosts + (int)(os & (kGhosts - 1))
+                        : (kl & (kXD - 1)) * kThreads + (int)(os & 255u);
+                    re[k] = xr[at];
                 }
                 bool ready = true;
                 double xs[4] = {0.0, 0.0, 0.0, 0.0};
@@ -523,6 +660,9 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                         const int kl = (int)(d & 0x7fffu);
                         if (oslot == myslot && kl == rloc - 1) {
                             xs[k] = prev_val;
+                        } else if (oslot >= (unsigned)kGhostBase) {
+                            double xc = 0.0;
+                            if (ghost((int)(oslot & (kGhosts - 1)), kl, re[k], xc)) xs[k] = xc; else ready = false;
                         } else if ((oslot >> 8) == wg && re[k].x <= kl) {
                             if (re[k].x == kl) xs[k] = __hiloint2double(re[k].w, re[k].z);
                             else ready = false;                                  // producer not there yet
@@ -545,6 +685,8 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                     for (int k = 1; k < 4; ++k) dv = (k == dslot) ? ev[k] : dv;
                     publish(acc / dv);
                     progressed = true;
+                } else {
+                    ++stall;
                 }
             } else if (phase == 2) {
                 const int ea = e_avail[tid];
@@ -575,6 +717,11 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                         if (oslot == myslot && kl == rloc - 1) {
                             xc = prev_val;
                             have = true;
+                        } else if (oslot >= (unsigned)kGhostBase) {
+                            const int g = (int)(oslot & (kGhosts - 1));
+                            const v4i e = gr[(kl & (kGD - 1)) * kGhosts + g];
+                            if (!ghost(g, kl, e, xc)) { ++stall; break; }
+                            have = true;
                         } else if ((oslot >> 8) == wg) {
                             const int lane = (int)(oslot & 255u);
                             const v4i e = xr[(kl & (kXD - 1)) * kThreads + lane];
@@ -599,9 +746,6 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                 }
             }
         }
-        ++dbg_iters;
-        dbg_prog += progressed ? 1u : 0u;
-        if (active && !progressed) { if (phase == 0) ++dbg_wdata; else ++dbg_wdep; }
         if (__any(progressed)) {
             spins = 0;
         } else {
@@ -612,10 +756,6 @@ k_sptrsv_lc(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, c
                 break;
             }
         }
-    }
-    if (wg == 0 && (tid == 0 || tid == 17 || tid == 255)) {   // diagnostic words (ignored by the host unless asked)
-        const int w = tid == 0 ? 0 : (tid == 17 ? 1 : 2);
-        err[8 + w] = (int)dbg_iters; err[11 + w] = (int)dbg_wdata; if (w > 0) err[13 + w] = (int)dbg_wdep; (void)dbg_prog;
     }
 #undef RD
 #undef RV
@@ -635,20 +775,38 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
             do {                                                                                             \
                 ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lc<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLcLds)); \
                 hipLaunchKernelGGL((k_sptrsv_lc<K>), dim3(grid), dim3(kLcThreads), kLcLds, st, M.ptr, desc, M.val, M.n, (long)M.nnz, \
-                                   rhs_and_reset, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, d_ticket, d_err);  \
+                                   rhs_and_reset, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, sch.gtab, d_ticket, d_err);  \
             } while (0)
+#ifdef ILUPP_TIMELINE
+            static unsigned long long *d_tl = nullptr;
+            if (!d_tl) {
+                ILUPP_HIP(hipMalloc(&d_tl, 8 * 8 * 4096));
+                ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &d_tl, sizeof(d_tl)));
+            }
+            ILUPP_HIP(hipMemsetAsync(d_tl, 0, 8 * 8 * 4096, st));
+#endif
             switch (kind) {
             case SWEEP_FWD_LAST_ASC: LAUNCHS(SWEEP_FWD_LAST_ASC); break;
             case SWEEP_BWD_FIRST_ASC: LAUNCHS(SWEEP_BWD_FIRST_ASC); break;
             default: LAUNCHS(SWEEP_BWD_FIRST_DESC); break;
             }
 #undef LAUNCHS
+#ifdef ILUPP_TIMELINE
+            if (grid <= 4096) {
+                static unsigned long long h_tl[8 * 4096];
+                ILUPP_HIP(hipStreamSynchronize(st));
+                ILUPP_HIP(hipMemcpy(h_tl, d_tl, 8 * 8 * (size_t)grid, hipMemcpyDeviceToHost));
+                char name[64];
+                snprintf(name, sizeof name, "/tmp/timeline_%d.bin", (int)kind);
+                if (FILE *f = fopen(name, "wb")) { fwrite(h_tl, 8, 8 * (size_t)grid, f); fclose(f); }
+            }
+#endif
             ILUPP_HIP(hipGetLastError());
             return ILUPP_OK;
         }
 #define LAUNCHD(K)                                                                                           \
         hipLaunchKernelGGL((k_sptrsv_desc<K>), dim3(grid), dim3(kThreads), 0, st, M.ptr, desc, M.val, rhs_and_reset, out, \
-                           sch.nslots, sch.sfirst, sch.scount, d_ticket, d_err)
+                           sch.nslots, sch.sfirst, sch.scount, sch.gtab, d_ticket, d_err)
         switch (kind) {
         case SWEEP_FWD_LAST_ASC: LAUNCHD(SWEEP_FWD_LAST_ASC); break;
         case SWEEP_BWD_FIRST_ASC: LAUNCHD(SWEEP_BWD_FIRST_ASC); break;

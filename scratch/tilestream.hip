@@ -1,0 +1,47 @@
+// Microbenchmark: lane-private streams with the solve kernel's placement (16x16 patches of lines) vs linear placement.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ long line_of(int wg, int t, int mode) {
+    if (mode == 0) return (long)wg * 256 + t;                 // linear: a workgroup owns 256 consecutive lines
+    const int ty = wg & 15, tz = wg >> 4, ly = t & 15, lz = t >> 4;
+    return (long)(tz * 16 + lz) * 256 + ty * 16 + ly;         // 16x16 patch of the 256x256 line grid
+}
+
+// per lane and step: 16 B of desc (4 entries), 32 B of val, 8 B rhs read, 8 B out write  (one L-solve row)
+__global__ __launch_bounds__(256) void k_rows(const int4 *__restrict__ desc, const double2 *__restrict__ val,
+                                               const double *__restrict__ rhs, double *__restrict__ out, int rows, int mode, int wr) {
+    const long line = line_of(blockIdx.x, threadIdx.x, mode);
+    const int4 *d = desc + line * rows;
+    const double2 *v = val + line * rows * 2;
+    const double *b = rhs + line * rows;
+    double *o = out + line * rows;
+    double acc = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        const int4 dd = d[r];
+        const double2 v0 = v[2 * r], v1 = v[2 * r + 1];
+        acc += b[r] + v0.x * dd.x + v0.y * dd.y + v1.x * dd.z + v1.y * dd.w;
+        if (wr) o[r] = acc;
+    }
+    if (!wr && acc == 1.2345) o[0] = acc;
+}
+
+int main() {
+    const int rows = 256; const long lines = 65536;
+    int4 *desc; double2 *val; double *rhs, *out;
+    CK(hipMalloc(&desc, lines * rows * 16)); CK(hipMalloc(&val, lines * rows * 32)); CK(hipMalloc(&rhs, lines * rows * 8)); CK(hipMalloc(&out, lines * rows * 8));
+    CK(hipMemset(desc, 0, lines * rows * 16)); CK(hipMemset(val, 0, lines * rows * 32)); CK(hipMemset(rhs, 0, lines * rows * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int wr = 0; wr < 2; ++wr)
+        for (int mode = 0; mode < 2; ++mode) {
+            k_rows<<<256, 256>>>(desc, val, rhs, out, rows, mode, wr); CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0)); for (int it = 0; it < 3; ++it) k_rows<<<256, 256>>>(desc, val, rhs, out, rows, mode, wr);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+            const double bytes = (double)lines * rows * (16 + 32 + 8 + (wr ? 8 : 0));
+            printf("%s placement, %s: %.3f ms  %.1f GB/s  (%.2f us per row-step)\n", mode ? "patch " : "linear", wr ? "read+write" : "read only ", ms, bytes / ms * 1e-6, ms * 1e3 / rows);
+        }
+    return 0;
+}
