@@ -140,6 +140,7 @@ struct ilupp_precond {
     int32_t *prog_f3 = nullptr;      // fixed-size program (short-row matrices): loader/consumer kernel
     bool compact = false;            // descriptors/program usable (block size and grid within the encoding)
     int32_t *dL = nullptr, *dU = nullptr, *dUT = nullptr, *dLT = nullptr;   // solve descriptors
+    PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
     int32_t max_row_len = 0;
     int32_t max_len_T = 0;       // longest major slice of the transposed storages
     double *work = nullptr;      // n, all-sentinel between applies
@@ -164,6 +165,7 @@ void destroy_obj(ilupp_precond *p)
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
     p->prog.release();
+    p->pkL.release(); p->pkU.release();
     if (p->prog_f3) (void)pool_free(p->prog_f3);
     for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)pool_free(d);
     if (p->work) (void)pool_free(p->work);
@@ -224,6 +226,8 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
             have_prog = build_ilu0_program(st, A, p->Uc, p->sA, &p->prog);
         make_desc(st, p->Lc, p->sA, &p->dL);
         make_desc(st, p->Uc, p->sU, &p->dU);
+        lm_prepare(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, p->max_row_len, &p->pkL);
+        lm_prepare(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, p->max_row_len, &p->pkU);
     }
     ILUPP_HIP(hipEventRecord(a1, st));
     float kms = 0.f;
@@ -232,8 +236,12 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     else if (have_prog) rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, &kms);
     if (rc == ILUPP_ERR_UNSUPPORTED)
         rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
+    lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL);
+    lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU);
     ILUPP_HIP(hipEventRecord(a2, st));
     ILUPP_HIP(hipStreamSynchronize(st));
+    lm_finish(st, &p->pkL);
+    lm_finish(st, &p->pkU);
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
     p->tm.numeric_kernel_ms = kms;
@@ -275,6 +283,20 @@ void ensure_transposed(ilupp_precond *p)
 }
 
 #define MAXLEN_OF(M) ((&(M) == &p->LcT || &(M) == &p->UcT) ? p->max_len_T : p->max_row_len)
+
+// one sweep: the packed kernel when the factor has a verified level-major form, else the CSR kernels.  Either way
+// the right-hand side buffer is all-sentinel afterwards (the CSR kernels reset it row by row).
+static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, int32_t maxlen,
+                 const PackedSweep *ps, double *rhs, double *out, int32_t *ticket, int32_t *err)
+{
+    if (ps && ps->valid) {
+        int rc = sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err);
+        if (rc) return rc;
+        fill_u64(p->stream, reinterpret_cast<unsigned long long *>(rhs), p->n, kSentinel);
+        return ILUPP_OK;
+    }
+    return sptrsv(p->stream, kind, M, sch, desc, maxlen, rhs, out, ticket, err);
+}
 // apply on a device vector; `transpose` as in apply_preconditioner_only(use, y)
 int apply_dev(ilupp_precond *p, double *x, int transpose)
 {
@@ -290,9 +312,9 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             // L has A's strictly-lower pattern, hence A's forward cuts: the factor-sweep schedule serves it
             const Schedule &sl = p->sL.start ? p->sL : p->sA;
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), x, y, t1, err);
+            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), &p->pkL, x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), y, x, t2, err);
+            sweep(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), &p->pkU, y, x, t2, err);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         } else {
             ensure_transposed(p);
@@ -435,6 +457,9 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     else if (p->prog.prog) rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, &kms);
     if (rc == ILUPP_ERR_UNSUPPORTED)
         rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
+    // same pattern, hence same (already verified) record structure: only the records are rewritten
+    if (p->pkL.valid) lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL);
+    if (p->pkU.valid) lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
     ILUPP_HIP(hipStreamSynchronize(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));

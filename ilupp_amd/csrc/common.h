@@ -67,6 +67,21 @@ struct Schedule {
 static constexpr int kGhosts = 64;
 static constexpr int kGhostBase = (1 << 17) - kGhosts;
 
+// Level-major packed form of one triangular sweep (sptrsv_lm.hip); short-row factors only.
+struct PackedSweep {
+    bool built = false;         // structure (skews, chunk table, storage) exists
+    bool valid = false;         // records written and verified: the packed kernel may run
+    int kind = 0;               // SweepKind the records were ordered for
+    int32_t nwg = 0;
+    int32_t *skew = nullptr;    // nslots: step offset of each lane
+    int32_t *wtab = nullptr;    // nwg*4 x {first chunk, first step, chunks, -}
+    int32_t *flags = nullptr;   // [0] rejected, [1] total chunks, [2] longest wave
+    void *pk = nullptr;         // chunks x 3072 bytes
+    int64_t nchunks = 0;
+    int32_t max_chunks = 0;
+    void release();
+};
+
 // ILU(0) update program (schedule.hip)
 struct Ilu0Program {
     int32_t *prow = nullptr;    // n+1 word offsets
@@ -159,5 +174,13 @@ int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double thr
 enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRST_DESC = 2 };
 int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
            int32_t max_row_len, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
+
+// sptrsv_lm.hip
+bool lm_prepare(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
+                int32_t max_row_len, PackedSweep *ps);
+void lm_pack(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, PackedSweep *ps);
+bool lm_finish(hipStream_t st, PackedSweep *ps);
+int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
+              int32_t *d_ticket, int32_t *d_err);
 
 }  // namespace ilupp
