@@ -197,6 +197,31 @@ int validate(const int32_t *indptr, int32_t n)
     return ILUPP_OK;
 }
 
+// numeric phase with whatever machinery the analysis could set up; leaves the sweep records' values in place
+static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, float *kms)
+{
+    hipStream_t st = p->stream;
+    int rc = ILUPP_ERR_UNSUPPORTED;
+    bool direct = false;
+    if (p->prog_f3) {
+        // letting this kernel scatter the sweep records itself costs more than the separate value pass
+        static const bool allow_direct = getenv("ILUPP_DIRECT_PACK") != nullptr;
+        direct = allow_direct && p->pkL.valid && p->pkU.valid && p->pkU.linked;
+        rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, kms, direct ? &p->pkL : nullptr, direct ? &p->pkU : nullptr);
+    } else if (have_prog) {
+        rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, kms);
+    }
+    if (rc == ILUPP_ERR_UNSUPPORTED) {
+        direct = false;
+        rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, kms);
+    }
+    if (!direct && p->pkL.valid && p->pkU.valid) {
+        lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL, 2);
+        lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU, 2);
+    }
+    return rc;
+}
+
 // ILU(0) of the row-major view held in A (device).  Fills p->Lc/Uc, schedules and timings.
 int ilu0_factor(ilupp_precond *p, const DevMat &A)
 {
@@ -226,22 +251,23 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
             have_prog = build_ilu0_program(st, A, p->Uc, p->sA, &p->prog);
         make_desc(st, p->Lc, p->sA, &p->dL);
         make_desc(st, p->Uc, p->sU, &p->dU);
-        lm_prepare(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, p->max_row_len, &p->pkL);
-        lm_prepare(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, p->max_row_len, &p->pkU);
+        // level-major sweep records: structure and pattern half now, values from the factor kernel
+        if (lm_prepare(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, p->max_row_len, &p->pkL) &&
+            lm_prepare(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, p->max_row_len, &p->pkU)) {
+            lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL, 1);
+            lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU, 1);
+            lm_link_factor(st, p->sA, p->sU, &p->pkU);
+            lm_finish(st, &p->pkL);
+            lm_finish(st, &p->pkU);
+        }
+        if (!(p->pkL.valid && p->pkU.valid)) { p->pkL.release(); p->pkU.release(); }
     }
     ILUPP_HIP(hipEventRecord(a1, st));
     float kms = 0.f;
     rc = ILUPP_ERR_UNSUPPORTED;
-    if (p->prog_f3) rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, &kms);
-    else if (have_prog) rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, &kms);
-    if (rc == ILUPP_ERR_UNSUPPORTED)
-        rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
-    lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL);
-    lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU);
+    rc = ilu0_numeric_any(p, A, have_prog, &kms);
     ILUPP_HIP(hipEventRecord(a2, st));
     ILUPP_HIP(hipStreamSynchronize(st));
-    lm_finish(st, &p->pkL);
-    lm_finish(st, &p->pkU);
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
     p->tm.numeric_kernel_ms = kms;
@@ -452,14 +478,7 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     hipStream_t st = p->stream;
     ILUPP_HIP(hipEventRecord(p->ev[1], st));
     float kms = 0.f;
-    int rc = ILUPP_ERR_UNSUPPORTED;
-    if (p->prog_f3) rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, &kms);
-    else if (p->prog.prog) rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, &kms);
-    if (rc == ILUPP_ERR_UNSUPPORTED)
-        rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, &kms);
-    // same pattern, hence same (already verified) record structure: only the records are rewritten
-    if (p->pkL.valid) lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL);
-    if (p->pkU.valid) lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU);
+    int rc = ilu0_numeric_any(p, A, p->prog.prog != nullptr, &kms);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
     ILUPP_HIP(hipStreamSynchronize(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));

@@ -77,6 +77,8 @@ struct PackedSweep {
     int32_t *wtab = nullptr;    // nwg*4 x {first chunk, first step, chunks, -}
     int32_t *flags = nullptr;   // [0] rejected, [1] total chunks, [2] longest wave
     void *pk = nullptr;         // chunks x 3072 bytes
+    int32_t *uslot = nullptr;   // (backward sweep) slot of this schedule that owns the rows of each forward-schedule slot
+    bool linked = false;        // uslot complete: the factor kernel can address this sweep's records
     int64_t nchunks = 0;
     int32_t max_chunks = 0;
     void release();
@@ -128,6 +130,16 @@ __device__ __forceinline__ void st_agent_i32(int *p, int v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// block that owns row c:  start[b] <= c < start[b+1]
+__device__ __forceinline__ int block_of(int c, int B, int nb, const int32_t *__restrict__ start)
+{
+    int b = c / B;
+    if (b >= nb) b = nb - 1;
+    while (c < start[b]) --b;
+    while (c >= start[b + 1]) ++b;
+    return b;
+}
+
 // compiler-only ordering point: keeps payload loads below the poll that guards them
 __device__ __forceinline__ void order_after_poll() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 // every store of this wave has left the CU before the flag that publishes them
@@ -150,7 +162,7 @@ void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **d
 bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, Ilu0Program *P);
 bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, int32_t **prog_out);
 int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd, const int32_t *prog_f3,
-                    int32_t *d_ctrl, float *kernel_ms);
+                    int32_t *d_ctrl, float *kernel_ms, const PackedSweep *pl = nullptr, const PackedSweep *pu = nullptr);
 
 // ilu0.hip
 int ilu0_numeric_program(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
@@ -178,7 +190,8 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
 // sptrsv_lm.hip
 bool lm_prepare(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
                 int32_t max_row_len, PackedSweep *ps);
-void lm_pack(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, PackedSweep *ps);
+void lm_pack(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, PackedSweep *ps, int what);
+void lm_link_factor(hipStream_t st, const Schedule &fwd, const Schedule &bwd, PackedSweep *ps_u);
 bool lm_finish(hipStream_t st, PackedSweep *ps);
 int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
               int32_t *d_ticket, int32_t *d_err);

@@ -417,13 +417,19 @@ static constexpr size_t kIluLcLds = (size_t)kThreads * (kPR * 8 * 4 + kAW * 8 + 
         w4 = i_ == 4 ? nv_ : w4; w5 = i_ == 5 ? nv_ : w5; w6 = i_ == 6 ? nv_ : w6;                          \
     } while (0)
 
+typedef double v2d_f __attribute__((ext_vector_type(2)));
+struct PackedOut {                    // where the factor kernel drops the values of the level-major sweep records (null: nowhere)
+    v2d_f *pkL; const int32_t *wtabL; const int32_t *skewL;
+    v2d_f *pkU; const int32_t *wtabU; const int32_t *skewU; const int32_t *uslot;
+};
+
 __global__ void __launch_bounds__(2 * kThreads)
 k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__restrict__ Aptr,
                   const int32_t *__restrict__ Lptr, double *__restrict__ Lval,
                   const int32_t *__restrict__ Uptr, double *Uval, long nnzU,
                   const int32_t *__restrict__ prog, int32_t n,
                   int32_t nslots_used, const int32_t *__restrict__ sfirst, const int32_t *__restrict__ scount,
-                  const int32_t *__restrict__ exported, int32_t *ctrl)
+                  const int32_t *__restrict__ exported, int32_t *ctrl, PackedOut po)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x & (kThreads - 1);
@@ -547,6 +553,16 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
     int r = r0, rloc = 0;
     int a0 = a00, l0 = l00, u0 = u00;
     bool active = cnt > 0;
+    // level-major records of the two sweeps (sptrsv_lm.hip): this lane's rows sit 192 sixteen-byte units apart,
+    // ascending in the forward sweep's storage and descending in the backward sweep's
+    long lp = 0, up = 0;
+    if (po.pkL && cnt > 0) {
+        const int w = (int)(myslot >> 6);
+        lp = ((long)po.wtabL[w * 4] + (po.skewL[myslot] - po.wtabL[w * 4 + 1])) * 192 + 64 + (tid & 63);
+        const int su = po.uslot[myslot];
+        const int wu = su >> 6;
+        up = ((long)po.wtabU[wu * 4] + (cnt - 1 + po.skewU[su] - po.wtabU[wu * 4 + 1])) * 192 + 64 + (su & 63);
+    }
     int phase = 0;
     int pw[8];
 #pragma unroll
@@ -680,11 +696,25 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
                     if (1 >= s0) Lval[l0 + 1 - s0] = w1;
                     if (2 >= s0) Lval[l0 + 2 - s0] = w2;
                     const int ulen = len - cl;
+                    // never store the sentinel's bit pattern
+                    if ((unsigned long long)__double_as_longlong(w3) == kSentinel) w3 = __longlong_as_double((long long)kCanonNaN);
+                    if ((unsigned long long)__double_as_longlong(w4) == kSentinel) w4 = __longlong_as_double((long long)kCanonNaN);
+                    if ((unsigned long long)__double_as_longlong(w5) == kSentinel) w5 = __longlong_as_double((long long)kCanonNaN);
+                    if ((unsigned long long)__double_as_longlong(w6) == kSentinel) w6 = __longlong_as_double((long long)kCanonNaN);
+                    if (po.pkL) {
+                        // L record: eliminations in stored order, unit diagonal; U record: strictly-upper entries, then the pivot
+                        v2d_f la, lb, ua, ub;
+                        la.x = s0 == 0 ? w0 : (s0 == 1 ? w1 : w2); la.y = s0 == 0 ? w1 : w2;
+                        lb.x = w2; lb.y = 1.0;
+                        ua.x = w4; ua.y = w5; ub.x = w6; ub.y = w3;
+                        po.pkL[lp] = la; po.pkL[lp + 64] = lb;
+                        po.pkU[up] = ua; po.pkU[up + 64] = ub;
+                        lp += 192; up -= 192;
+                    }
                     const int sr = rloc & (kUD - 1);
 #define PUBLISH(Q, WQ)                                                                                     \
                     if (Q < ulen) {                                                                         \
-                        double v = WQ;                                                                      \
-                        if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN); \
+                        const double v = WQ;                                                                \
                         v4i_f e; e.x = rloc; e.y = 0; e.z = __double2loint(v); e.w = __double2hiint(v);      \
                         ur[(sr * 4 + Q) * kThreads + tid] = e;                                              \
                         if (exports) st_agent_f64(&Uval[u0 + Q], v); else Uval[u0 + Q] = v;                 \
@@ -722,8 +752,13 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
 }
 
 int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd, const int32_t *prog_f3,
-                    int32_t *d_ctrl, float *kernel_ms)
+                    int32_t *d_ctrl, float *kernel_ms, const PackedSweep *pl, const PackedSweep *pu)
 {
+    PackedOut po = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (pl && pu && pl->built && pu->built && pu->uslot) {
+        po.pkL = reinterpret_cast<v2d_f *>(pl->pk); po.wtabL = pl->wtab; po.skewL = pl->skew;
+        po.pkU = reinterpret_cast<v2d_f *>(pu->pk); po.wtabU = pu->wtab; po.skewU = pu->skew; po.uslot = pu->uslot;
+    }
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
     fill_u64(st, reinterpret_cast<unsigned long long *>(U->val), U->nnz, kSentinel);
     const unsigned grid = (unsigned)(fwd.nslots / kThreads);
@@ -733,7 +768,7 @@ int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const
     ILUPP_HIP(hipEventRecord(e0, st));
     ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_numeric_lc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIluLcLds));
     hipLaunchKernelGGL(k_ilu0_numeric_lc, dim3(grid), dim3(2 * kThreads), kIluLcLds, st, A.val, (long)A.nnz, A.ptr,
-                       L->ptr, L->val, U->ptr, U->val, (long)U->nnz, prog_f3, A.n, fwd.nslots, fwd.sfirst, fwd.scount, fwd.exported, d_ctrl);
+                       L->ptr, L->val, U->ptr, U->val, (long)U->nnz, prog_f3, A.n, fwd.nslots, fwd.sfirst, fwd.scount, fwd.exported, d_ctrl, po);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t ctrl[4];

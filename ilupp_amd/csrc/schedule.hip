@@ -21,16 +21,6 @@
 
 namespace ilupp {
 
-// block that owns row c:  start[b] <= c < start[b+1]
-__device__ __forceinline__ int block_of(int c, int B, int nb, const int32_t *__restrict__ start)
-{
-    int b = c / B;
-    if (b >= nb) b = nb - 1;
-    while (c < start[b]) --b;
-    while (c >= start[b + 1]) ++b;
-    return b;
-}
-
 // Placement of row blocks on the persistent grid.
 //  identity: slot s owns block s (in sweep order).
 //  tiled:    the blocks form a 2-D grid (b % s2, b / s2) -- on a lexicographic 3-D mesh: (y, z) of the

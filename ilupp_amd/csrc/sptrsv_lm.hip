@@ -41,7 +41,8 @@ void PackedSweep::release()
     if (wtab) (void)pool_free(wtab);
     if (flags) (void)pool_free(flags);
     if (pk) (void)pool_free(pk);
-    skew = wtab = flags = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false;
+    if (uslot) (void)pool_free(uslot);
+    skew = wtab = flags = uslot = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false; linked = false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -120,7 +121,8 @@ k_lm_scan(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ flag
 // ---------------------------------------------------------------------------------------------
 // records
 // ---------------------------------------------------------------------------------------------
-template <int KIND>
+// WHAT: bit 0 = the pattern half of every record ({d0,d1,d2,flags}, with the liveness checks), bit 1 = the values
+template <int KIND, int WHAT>
 __global__ void __launch_bounds__(512)
 k_lm_pack(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, const double *__restrict__ val,
           const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
@@ -146,12 +148,13 @@ k_lm_pack(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, con
         const int r = sfirst[slot] + DR * k;
         const int q0 = ptr[r], q1 = ptr[r + 1];
         const int nd = q1 - q0 - 1;                    // dependencies (the host admits rows of at most 4 entries)
-        v[3] = val[FWD ? q1 - 1 : q0];
+        if (WHAT & 2) v[3] = val[FWD ? q1 - 1 : q0];
         for (int j = 0; j < 3; ++j) {
             if (j < nd) {
                 const int q = FWD ? q0 + j : (DESC ? q1 - 1 - j : q0 + 1 + j);
+                if (WHAT & 2) v[j] = val[q];
+                if (!(WHAT & 1)) continue;
                 int dd = desc[q];
-                v[j] = val[q];
                 const unsigned os = (unsigned)dd >> 15;
                 const int kl = dd & 0x7fff;
                 if ((int)os == slot && kl == k - 1) {
@@ -171,12 +174,36 @@ k_lm_pack(const int32_t *__restrict__ ptr, const int32_t *__restrict__ desc, con
     }
     if (bad) atomicOr(&flags[0], 2);
     v4i *p = pk + ((size_t)base + c) * 192 + L;
-    v4i rec; rec.x = d[0]; rec.y = d[1]; rec.z = d[2]; rec.w = valid ? 1 : 0;
-    p[0] = rec;
-    v2d a; a.x = v[0]; a.y = v[1];
-    v2d b; b.x = v[2]; b.y = v[3];
-    reinterpret_cast<v2d *>(p)[64] = a;
-    reinterpret_cast<v2d *>(p)[128] = b;
+    if (WHAT & 1) {
+        v4i rec; rec.x = d[0]; rec.y = d[1]; rec.z = d[2]; rec.w = valid ? 1 : 0;
+        p[0] = rec;
+    }
+    if (WHAT & 2) {
+        v2d a; a.x = v[0]; a.y = v[1];
+        v2d b; b.x = v[2]; b.y = v[3];
+        reinterpret_cast<v2d *>(p)[64] = a;
+        reinterpret_cast<v2d *>(p)[128] = b;
+    }
+}
+
+// slot of the backward schedule that owns the same rows as each slot of the forward schedule; flags[3] is set
+// when some forward chain is not also a backward chain (then the factor kernel cannot address the U records)
+__global__ void k_lm_uslot(int32_t nslots, const int32_t *__restrict__ slot2blkA, const int32_t *__restrict__ startA,
+                           const int32_t *__restrict__ startU, int32_t nbU, const int32_t *__restrict__ blk2slotU,
+                           int32_t BU, int32_t *__restrict__ uslot, int32_t *__restrict__ flags)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    const int b = slot2blkA[s];
+    int us = -1;
+    if (b >= 0) {
+        const int lo = startA[b], hi = startA[b + 1];
+        if (hi > lo) {
+            const int bu = block_of(lo, BU, nbU, startU);
+            if (startU[bu] == lo && startU[bu + 1] == hi) us = blk2slotU[bu]; else atomicOr(&flags[3], 1);
+        }
+    }
+    uslot[s] = us;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -273,7 +300,11 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
                     int r = r0 + DR * k;
                     r = (k >= 0 && k < cnt) ? r : r0;
                     r = r < 0 ? 0 : (r >= n ? n - 1 : r);
+#ifdef EXP_LM_NORHS
+                    rr[u] = 1.0 + r;
+#else
                     rr[u] = rhs[r];
+#endif
                 }
             }
 #pragma unroll
@@ -433,7 +464,11 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
                 e.x = k; e.y = 0; e.z = __double2loint(x); e.w = __double2hiint(x);
                 xr[(k & (kXD8 - 1)) * kThreads + tid] = e;
                 const int r = r0 + DR * k;
+#ifdef EXP_LM_NOSTORE
+                if (exports) st_agent_f64(out + r, x);
+#else
                 if (exports) st_agent_f64(out + r, x); else out[r] = x;
+#endif
                 prev_val = x;
                 done = true;
             }
@@ -512,33 +547,46 @@ bool lm_prepare(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule 
     return true;
 }
 
-void lm_pack(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, PackedSweep *ps)
+void lm_pack(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, PackedSweep *ps, int what)
 {
     if (!ps->built) return;
     const dim3 grid((unsigned)(ps->nwg * 4), (unsigned)((ps->max_chunks + 7) / 8));
-#define PACK(K) hipLaunchKernelGGL((k_lm_pack<K>), grid, dim3(512), 0, st, M.ptr, desc, M.val, ps->wtab, ps->skew, sch.sfirst, \
-                                   sch.scount, sch.gtab, reinterpret_cast<v4i *>(ps->pk), ps->flags)
+#define PACK(K, W) hipLaunchKernelGGL((k_lm_pack<K, W>), grid, dim3(512), 0, st, M.ptr, desc, M.val, ps->wtab, ps->skew, sch.sfirst, \
+                                      sch.scount, sch.gtab, reinterpret_cast<v4i *>(ps->pk), ps->flags)
+#define PACKW(K) do { if (what == 1) PACK(K, 1); else if (what == 2) PACK(K, 2); else PACK(K, 3); } while (0)
     switch (kind) {
-    case SWEEP_FWD_LAST_ASC: PACK(SWEEP_FWD_LAST_ASC); break;
-    case SWEEP_BWD_FIRST_ASC: PACK(SWEEP_BWD_FIRST_ASC); break;
-    default: PACK(SWEEP_BWD_FIRST_DESC); break;
+    case SWEEP_FWD_LAST_ASC: PACKW(SWEEP_FWD_LAST_ASC); break;
+    case SWEEP_BWD_FIRST_ASC: PACKW(SWEEP_BWD_FIRST_ASC); break;
+    default: PACKW(SWEEP_BWD_FIRST_DESC); break;
     }
+#undef PACKW
 #undef PACK
     ILUPP_HIP(hipGetLastError());
     ps->kind = (int)kind;
+}
+
+// can the factor kernel (forward schedule fwd) write the records of the backward sweep ps_u (schedule bwd) itself?
+// Builds the slot map it needs; the answer is in flags[3] of ps_u, read by lm_finish.
+void lm_link_factor(hipStream_t st, const Schedule &fwd, const Schedule &bwd, PackedSweep *ps_u)
+{
+    if (!ps_u->built) return;
+    ILUPP_HIP(pool_malloc(&ps_u->uslot, sizeof(int32_t) * (size_t)fwd.nslots));
+    hipLaunchKernelGGL(k_lm_uslot, dim3((unsigned)((fwd.nslots + 255) / 256)), dim3(256), 0, st, fwd.nslots, fwd.slot2blk, fwd.start,
+                       bwd.start, bwd.nb, bwd.blk2slot, bwd.B, ps_u->uslot, ps_u->flags);
 }
 
 // after the stream has been synchronised: did the records pass the liveness checks?
 bool lm_finish(hipStream_t st, PackedSweep *ps)
 {
     if (!ps->built) return false;
-    int32_t h = 0;
-    ILUPP_HIP(hipMemcpyAsync(&h, ps->flags, sizeof(h), hipMemcpyDeviceToHost, st));
+    int32_t h[4] = {0, 0, 0, 0};
+    ILUPP_HIP(hipMemcpyAsync(h, ps->flags, sizeof(h), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[ilupp] packed sweep kind %d: flags %d, %lld chunks\n", ps->kind, h, (long long)ps->nchunks);
-    if (h != 0) { ps->release(); return false; }
+    if (dbg) fprintf(stderr, "[ilupp] packed sweep kind %d: flags %d/%d, %lld chunks\n", ps->kind, h[0], h[3], (long long)ps->nchunks);
+    if (h[0] != 0) { ps->release(); return false; }
     ps->valid = true;
+    ps->linked = ps->uslot != nullptr && h[3] == 0;
     return true;
 }
 
