@@ -141,6 +141,8 @@ struct ilupp_precond {
     bool compact = false;            // descriptors/program usable (block size and grid within the encoding)
     int32_t *dL = nullptr, *dU = nullptr, *dUT = nullptr, *dLT = nullptr;   // solve descriptors
     PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
+    FactorLM flm;                    // level-major factor kernel state (then Lc.val / Uc.val are filled on demand)
+    bool csr_vals = true;            // Lc.val / Uc.val hold the factor values
     int32_t max_row_len = 0;
     int32_t max_len_T = 0;       // longest major slice of the transposed storages
     double *work = nullptr;      // n, all-sentinel between applies
@@ -165,7 +167,7 @@ void destroy_obj(ilupp_precond *p)
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
     p->prog.release();
-    p->pkL.release(); p->pkU.release();
+    p->pkL.release(); p->pkU.release(); p->flm.release();
     if (p->prog_f3) (void)pool_free(p->prog_f3);
     for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)pool_free(d);
     if (p->work) (void)pool_free(p->work);
@@ -203,6 +205,12 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
     hipStream_t st = p->stream;
     int rc = ILUPP_ERR_UNSUPPORTED;
     bool direct = false;
+    if (p->flm.built) {
+        rc = ilu0_numeric_lm(st, A, p->sA, p->prog_f3, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms);
+        p->csr_vals = false;
+        return rc;
+    }
+    p->csr_vals = true;
     if (p->prog_f3) {
         // letting this kernel scatter the sweep records itself costs more than the separate value pass
         static const bool allow_direct = getenv("ILUPP_DIRECT_PACK") != nullptr;
@@ -261,6 +269,7 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
             lm_finish(st, &p->pkU);
         }
         if (!(p->pkL.valid && p->pkU.valid)) { p->pkL.release(); p->pkU.release(); }
+        else flm_prepare(st, A, p->sA, p->prog_f3, &p->pkL, &p->pkU, &p->flm);
     }
     ILUPP_HIP(hipEventRecord(a1, st));
     float kms = 0.f;
@@ -275,9 +284,20 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     return rc;
 }
 
+// the CSR value arrays of the factors, when the level-major factor kernel left them unwritten
+void ensure_csr_values(ilupp_precond *p)
+{
+    if (p->csr_vals) return;
+    lm_unpack(p->stream, p->Lc, p->sA, p->pkL);
+    lm_unpack(p->stream, p->Uc, p->sU, p->pkU);
+    ILUPP_HIP(hipStreamSynchronize(p->stream));
+    p->csr_vals = true;
+}
+
 void ensure_transposed(ilupp_precond *p)
 {
     if (p->haveT) return;
+    ensure_csr_values(p);
     hipStream_t st = p->stream;
     if (p->kind == KIND_LU) {
         transpose_storage(st, p->Uc, &p->UcT);      // lower, diagonal last
@@ -749,6 +769,7 @@ int ilupp_hip_factor_copy(const ilupp_precond *p, int which, double *data, int32
     bool csr = true;
     const DevMat *M = exposed(p, which, &csr);
     if (!M) { set_error("no such factor"); return ILUPP_ERR_INVALID; }
+    ensure_csr_values(const_cast<ilupp_precond *>(p));
     ILUPP_HIP(hipStreamSynchronize(p->stream));
     ILUPP_HIP(hipMemcpy(indptr, M->ptr, sizeof(int32_t) * (size_t)(p->n + 1), hipMemcpyDeviceToHost));
     if (M->nnz > 0) {
@@ -765,6 +786,7 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
     bool csr = true;
     const DevMat *M = exposed(p, which, &csr);
     if (!M) { set_error("no such factor"); return ILUPP_ERR_INVALID; }
+    try { ensure_csr_values(const_cast<ilupp_precond *>(p)); } catch (const ilupp::HipError &e) { return ilupp::report(e); }
     if (d_data) *d_data = M->val;
     if (d_indices) *d_indices = M->idx;
     if (d_indptr) *d_indptr = M->ptr;

@@ -84,6 +84,16 @@ struct PackedSweep {
     void release();
 };
 
+// Level-major factor kernel (ilu0_lm.hip): what it needs beyond the two sweeps' structures
+struct FactorLM {
+    bool built = false;
+    void *pkA = nullptr;            // chunks x 4096 bytes: rows of A (diagonal-aligned) + program header words
+    int32_t *xbase = nullptr;       // nslots: first exchange row of a slot whose U rows other workgroups read, else -1
+    double *xch = nullptr;          // exchange rows x 4 doubles (write-through, sentinel = not yet)
+    long long *xcount = nullptr;    // device: doubles of xch in use
+    void release();
+};
+
 // ILU(0) update program (schedule.hip)
 struct Ilu0Program {
     int32_t *prow = nullptr;    // n+1 word offsets
@@ -195,5 +205,12 @@ void lm_link_factor(hipStream_t st, const Schedule &fwd, const Schedule &bwd, Pa
 bool lm_finish(hipStream_t st, PackedSweep *ps);
 int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
               int32_t *d_ticket, int32_t *d_err);
+
+// ilu0_lm.hip
+bool flm_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, const int32_t *prog_f3, PackedSweep *pl,
+                 const PackedSweep *pu, FactorLM *f);
+int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, const int32_t *prog_f3, PackedSweep *pl,
+                    PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms);
+void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
 
 }  // namespace ilupp
