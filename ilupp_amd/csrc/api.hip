@@ -206,7 +206,7 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
     int rc = ILUPP_ERR_UNSUPPORTED;
     bool direct = false;
     if (p->flm.built) {
-        rc = ilu0_numeric_lm(st, A, p->sA, p->prog_f3, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms);
+        rc = ilu0_numeric_lm(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms);
         p->csr_vals = false;
         return rc;
     }
@@ -253,23 +253,22 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
     bool have_prog = false;
-    if (p->compact) {
+    if (p->compact && !lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm)) {
+        // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels
         static const bool allow_lc = getenv("ILUPP_FACTOR_V2") == nullptr;
         if (!(allow_lc && A.nnz >= 16 && build_ilu0_program_f3(st, A, p->Uc, p->sA, &p->prog_f3)))
             have_prog = build_ilu0_program(st, A, p->Uc, p->sA, &p->prog);
         make_desc(st, p->Lc, p->sA, &p->dL);
         make_desc(st, p->Uc, p->sU, &p->dU);
-        // level-major sweep records: structure and pattern half now, values from the factor kernel
+        // the sweeps may still have a level-major form (records from the descriptors, values by a pass after the factor kernel)
         if (lm_prepare(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, p->max_row_len, &p->pkL) &&
             lm_prepare(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, p->max_row_len, &p->pkU)) {
             lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL, 1);
             lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU, 1);
-            lm_link_factor(st, p->sA, p->sU, &p->pkU);
             lm_finish(st, &p->pkL);
             lm_finish(st, &p->pkU);
         }
         if (!(p->pkL.valid && p->pkU.valid)) { p->pkL.release(); p->pkU.release(); }
-        else flm_prepare(st, A, p->sA, p->prog_f3, &p->pkL, &p->pkU, &p->flm);
     }
     ILUPP_HIP(hipEventRecord(a1, st));
     float kms = 0.f;

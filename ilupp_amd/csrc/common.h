@@ -87,7 +87,7 @@ struct PackedSweep {
 // Level-major factor kernel (ilu0_lm.hip): what it needs beyond the two sweeps' structures
 struct FactorLM {
     bool built = false;
-    void *pkA = nullptr;            // chunks x 4096 bytes: rows of A (diagonal-aligned) + program header words
+    void *pkA = nullptr;            // chunks x 5120 bytes: rows of A (diagonal-aligned), program header, decoded dependencies
     int32_t *xbase = nullptr;       // nslots: first exchange row of a slot whose U rows other workgroups read, else -1
     double *xch = nullptr;          // exchange rows x 4 doubles (write-through, sentinel = not yet)
     long long *xcount = nullptr;    // device: doubles of xch in use
@@ -207,10 +207,11 @@ int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err);
 
 // ilu0_lm.hip
-bool flm_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, const int32_t *prog_f3, PackedSweep *pl,
-                 const PackedSweep *pu, FactorLM *f);
-int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, const int32_t *prog_f3, PackedSweep *pl,
+int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl,
                     PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms);
+// records_lm.hip
+bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
+                     PackedSweep *pu, FactorLM *f);
 void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
 
 }  // namespace ilupp

@@ -8,9 +8,9 @@
 // the value halves of the two sweeps' records.  Nothing is written to the CSR value arrays; they are filled
 // on demand (lm_unpack) when a caller asks for the factors.
 //
-//   input per (chunk, lane)    {d0,d1,d2,valid} from the forward sweep's record (who produces the U rows this
-//                              row eliminates with), and 64 bytes {a0..a6 | w0,w1}: the row of A, diagonal-aligned
-//                              (diagonal at a3), and the two header words of its F3 program
+//   input per (chunk, lane)    80 bytes: {a0..a6 | w0,w1}: the row of A, diagonal-aligned (diagonal at a3), and the
+//                              two header words of its F3 program; {dep0,dep1,dep2,hdr}: who produces the U rows the
+//                              row eliminates with, already decoded into hand-off ring addresses and tags
 //   output per (chunk, lane)   L record values {l0,l1},{l2,1.0} -- one coalesced 2 KB store per wave and step --
 //                              and U record values {u1,u2},{u3,u0} at the row's place in the backward sweep
 //   hand-off inside a workgroup   48-byte LDS ring entries {tag,-,u0},{u1,u2},{u3,-}
@@ -28,9 +28,8 @@ namespace ilupp {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-static constexpr int kNoDep = -1;
-static constexpr int kOwnPrev = -3;
 static constexpr unsigned kFlmSpinLimit = 1u << 22;
+// hand-off ring: [4][3][256] own entries, then [4][3][kGhosts] ghost entries (addresses precomputed by records_lm.hip)
 
 void FactorLM::release()
 {
@@ -42,79 +41,41 @@ void FactorLM::release()
 }
 
 // ---------------------------------------------------------------------------------------------
-// analysis side
+// per-factorisation helpers
 // ---------------------------------------------------------------------------------------------
-__global__ void k_flm_xrows(int32_t nslots, const int32_t *__restrict__ exported, const int32_t *__restrict__ scount,
-                            int32_t *__restrict__ rows)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nslots) rows[s] = exported[s] ? scount[s] : 0;
-}
-__global__ void k_flm_xbase(int32_t nslots, const int32_t *__restrict__ exported, const int32_t *__restrict__ scount,
-                            int32_t *__restrict__ xbase, long long *__restrict__ xcount)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nslots) return;
-    const int b = xbase[s];
-    if (s == nslots - 1) *xcount = ((long long)b + (exported[s] ? scount[s] : 0)) * 4;     // doubles in use
-    if (!exported[s]) xbase[s] = -1;
-}
 __global__ void k_flm_fill(unsigned long long *__restrict__ p, const long long *__restrict__ count, unsigned long long v)
 {
     const long long n = *count;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// WHAT 1: header words of every record (from the F3 program) + eligibility of the step structure for the factor
-// kernel (every in-workgroup dependency exactly one step back, so the 4-deep hand-off ring cannot be lapped);
-// WHAT 2: the rows of A, diagonal-aligned
-template <int WHAT>
+// the rows of A, diagonal-aligned, into the factor records (whose header words the analysis wrote: records_lm.hip)
 __global__ void __launch_bounds__(512)
-k_flm_pack(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval, const int32_t *__restrict__ prog,
-           const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
-           const int32_t *__restrict__ scount, const v4i *__restrict__ pkL, v4i *__restrict__ pkA, int32_t *__restrict__ flags)
+k_flm_pack_a(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval,
+             const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
+             const int32_t *__restrict__ scount, v4i *__restrict__ pkA)
 {
     const int w = blockIdx.x;
     const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
     const int L = threadIdx.x & 63;
     const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
     if (c >= nch) return;
-    const int wg = w >> 2;
-    const int slot = wg * kThreads + (w & 3) * 64 + L;
-    const int tau = tmin + c;
-    const int k = tau - skew[slot];
+    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
+    const int k = tmin + c - skew[slot];
     const bool valid = k >= 0 && k < scount[slot];
-    const int r = valid ? sfirst[slot] + k : 0;
-    v4i *p = pkA + ((size_t)base + c) * 256 + L;
-    if (WHAT == 1) {
-        int w0 = 0, w1 = 0;
-        if (valid) {
-            w0 = prog[(size_t)r * 8]; w1 = prog[(size_t)r * 8 + 1];
-            const v4i rec = pkL[((size_t)base + c) * 192 + L];
-            const int dd[3] = {rec.x, rec.y, rec.z};
-            int bad = 0;
-            for (int j = 0; j < 3; ++j) {
-                const unsigned os = (unsigned)dd[j] >> 15;
-                if (dd[j] == kNoDep || dd[j] == kOwnPrev || os >= (unsigned)kGhostBase || (int)(os >> 8) != wg) continue;
-                if ((dd[j] & 0x7fff) + skew[os] != tau - 1) bad = 1;
-            }
-            if (bad) atomicOr(&flags[4], 1);
-        }
-        int *q = reinterpret_cast<int *>(p + 192);
-        q[2] = w0; q[3] = w1;
-    } else {
-        double a[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (valid) {
-            const int w0 = prog[(size_t)r * 8];
-            const int len = w0 & 15, cl = (w0 >> 4) & 3;
-            const int a0 = Aptr[r];
-            for (int j = 0; j < 7; ++j) { const int e = j - (3 - cl); if (e >= 0 && e < len) a[j] = Aval[a0 + e]; }
-        }
-        v2d x; x.x = a[0]; x.y = a[1]; reinterpret_cast<v2d *>(p)[0] = x;
-        x.x = a[2]; x.y = a[3]; reinterpret_cast<v2d *>(p)[64] = x;
-        x.x = a[4]; x.y = a[5]; reinterpret_cast<v2d *>(p)[128] = x;
-        reinterpret_cast<double *>(p + 192)[0] = a[6];
+    v4i *p = pkA + ((size_t)base + c) * 320 + L;
+    double a[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (valid) {
+        const int r = sfirst[slot] + k;
+        const int w0 = reinterpret_cast<const int *>(p + 192)[2];
+        const int len = w0 & 15, cl = (w0 >> 4) & 3;
+        const int a0 = Aptr[r];
+        for (int j = 0; j < 7; ++j) { const int e = j - (3 - cl); if (e >= 0 && e < len) a[j] = Aval[a0 + e]; }
     }
+    v2d x; x.x = a[0]; x.y = a[1]; reinterpret_cast<v2d *>(p)[0] = x;
+    x.x = a[2]; x.y = a[3]; reinterpret_cast<v2d *>(p)[64] = x;
+    x.x = a[4]; x.y = a[5]; reinterpret_cast<v2d *>(p)[128] = x;
+    reinterpret_cast<double *>(p + 192)[0] = a[6];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,8 +155,7 @@ k_ilu0_lm(FlmArgs A)
         // every round: the chunks the ring has room for (five coalesced 1 KB loads each) and, on the importer lanes,
         // the next exchange rows of their ghosts; one wait; everything into LDS
         const int L = tid & 63;
-        const v4i *pd = A.pkL_in + (size_t)base * 192 + L;
-        const v4i *pa = A.pkA + (size_t)base * 256 + L;
+        const v4i *pa = A.pkA + (size_t)base * 320 + L;
         int c_next = 0, next = 0;
         unsigned idle = 0;
         for (;;) {
@@ -224,8 +184,8 @@ k_ilu0_lm(FlmArgs A)
             for (int u = 0; u < kLF; ++u) {
                 if (u < room) {
                     const size_t o = (size_t)(c_next + u);
-                    d[u] = pd[o * 192];
-                    a0[u] = pa[o * 256]; a1[u] = pa[o * 256 + 64]; a2[u] = pa[o * 256 + 128]; a3[u] = pa[o * 256 + 192];
+                    d[u] = pa[o * 320 + 256];
+                    a0[u] = pa[o * 320]; a1[u] = pa[o * 320 + 64]; a2[u] = pa[o * 320 + 128]; a3[u] = pa[o * 320 + 192];
                 }
             }
             if (nb > 0) {
@@ -313,43 +273,45 @@ k_ilu0_lm(FlmArgs A)
         if (dead) break;
         if ((tid & 63) == 0) cons[wv] = c + 1;
         const int k = tau - sk;
-        const bool valid = rec.w != 0;
+        const int hdr = rec.w;
+        const bool valid = (hdr & 1) != 0;
         double w0 = __hiloint2double(r0.y, r0.x), w1 = __hiloint2double(r0.w, r0.z), w2 = __hiloint2double(r1.y, r1.x),
                w3 = __hiloint2double(r1.w, r1.z), w4 = __hiloint2double(r2.y, r2.x), w5 = __hiloint2double(r2.w, r2.z),
                w6 = __hiloint2double(r3.y, r3.x);
         const int pw0 = r3.z, pw1 = r3.w;
-        const int len = pw0 & 15, cl = (pw0 >> 4) & 3, nmt = (pw0 >> 6) & 7;
+        const int cl = (hdr >> 7) & 3, ulen = (hdr >> 9) & 7, nmt = (hdr >> 13) & 7;
         const int s0 = 3 - cl;
-        const int ulen = len - cl;
-        // dependency slot sl (right-aligned, as in the program) <- record slot sl - s0
-        int dsl[3];
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            const int j = sl - s0;
-            dsl[sl] = (valid && j >= 0) ? (j == 0 ? rec.x : (j == 1 ? rec.y : rec.z)) : kNoDep;
-        }
-        int at[3], kl[3];
+        // dependency slots (right-aligned, as in the program), decoded when the records were built:
+        // kind 0 none, 1 the lane's own previous row, 2 hand-off ring (address | tag << 12 | off << 27 | ghost << 29), 3 exchange buffer
+        const int dw[3] = {rec.x, rec.y, rec.z};
+        int at[3], kl[3], off[3];
         int need = 0, ringm = 0, ghostm = 0, ownm = 0;
 #pragma unroll
         for (int sl = 0; sl < 3; ++sl) {
-            const unsigned d = (unsigned)dsl[sl];
-            const unsigned os = d >> 15;
-            const int kk = (int)(d & 0x7fffu);
-            const bool real = dsl[sl] != kNoDep && dsl[sl] != kOwnPrev;
-            const bool isg = os >= (unsigned)kGhostBase;
-            const bool ring = real && (isg || (os >> 8) == wg);
-            at[sl] = !ring ? 0 : isg ? kUF * 3 * kThreads + (kk & (kUF - 1)) * 3 * kGhosts + (int)(os & (kGhosts - 1))
-                                     : (kk & (kUF - 1)) * 3 * kThreads + (int)(os & 255u);
-            kl[sl] = ring ? kk : -2;
-            if (real) need |= 1 << sl;
+            const int kind = (hdr >> (1 + 2 * sl)) & 3;
+            const bool ring = kind == 2;
+            at[sl] = ring ? (dw[sl] & 0xfff) : 0;
+            kl[sl] = ring ? ((dw[sl] >> 12) & 0x7fff) : -2;
+            off[sl] = (dw[sl] >> 27) & 3;
+            if (kind >= 2) need |= 1 << sl;
             if (ring) ringm |= 1 << sl;
-            if (ring && isg) { ghostm |= 1 << sl; gack[os & (kGhosts - 1)] = kk; }
-            if (dsl[sl] == kOwnPrev) ownm |= 1 << sl;
+            if (ring && ((dw[sl] >> 29) & 1)) { ghostm |= 1 << sl; gack[dw[sl] & (kGhosts - 1)] = kl[sl]; }
+            if (kind == 1) ownm |= 1 << sl;
         }
         bool done = !valid;
         int stall = 0;
         spins = 0;
 
+#ifdef EXP_FLM_NOL
+#define FLM_STORE_L() do { } while (0)
+#else
+#define FLM_STORE_L() do { lout[(size_t)c * 192] = la_; lout[(size_t)c * 192 + 64] = lb_; } while (0)
+#endif
+#ifdef EXP_FLM_NOU
+#define FLM_STORE_U() do { (void)uo_; } while (0)
+#else
+#define FLM_STORE_U() do { uo_[0] = ua_; uo_[64] = ub_; } while (0)
+#endif
         // results of a finished row: hand-off entry (value words first, the tag word last), exchange row, the two
         // sweeps' records (eliminations in stored order + unit diagonal; strictly-upper entries + pivot)
 #define FLM_PUBLISH()                                                                                                  \
@@ -377,25 +339,22 @@ k_ilu0_lm(FlmArgs A)
             la_.x = s0 == 0 ? w0 : (s0 == 1 ? w1 : w2); la_.y = s0 == 0 ? w1 : w2;                                     \
             lb_.x = w2; lb_.y = 1.0;                                                                                   \
             ua_.x = w4; ua_.y = w5; ub_.x = w6; ub_.y = w3;                                                            \
-            lout[(size_t)c * 192] = la_; lout[(size_t)c * 192 + 64] = lb_;                                             \
+            FLM_STORE_L();                                                                                             \
             v2d *uo_ = A.pkU_out + (up0 - 192 * (long)k);                                                              \
-            uo_[0] = ua_; uo_[64] = ub_;                                                                               \
+            FLM_STORE_U();                                                                                             \
             pu0 = w3; pu1 = w4; pu2 = w5; pu3 = w6;                                                                    \
             done = true;                                                                                               \
         } while (0)
 
         // ---- fast path: every row of the wave is "simple" (each elimination has one match, on the diagonal --
         // all rows of a 5-/7-point stencil) and reads rings only.  Per round: 3 tag/pivot words + 3 match words.
-        const bool simple = ((pw0 >> 30) & 1) != 0;
+        const bool simple = ((hdr >> 12) & 1) != 0;
         bool generic = !__all(!valid || (simple && (need & ~ringm) == 0));
         if (!generic) {
             // match m belongs to slot s0 + m; the word that holds U entry `off` of that slot's row
-            int off[3], mat[3];
+            int mat[3];
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) {
-                const int m = sl - s0;
-                const unsigned mw = m < 0 ? 0u : ((unsigned)pw0 >> (9 + 7 * m)) & 127u;
-                off[sl] = (int)((mw >> 2) & 3u);
                 const bool g = ((ghostm >> sl) & 1) != 0;
                 mat[sl] = ((ringm >> sl) & 1) ? at[sl] + (off[sl] == 3 ? 2 : 1) * (g ? kGhosts : kThreads) : 0;
             }
@@ -525,10 +484,9 @@ k_ilu0_lm(FlmArgs A)
 #pragma unroll
                     for (int sl = 0; sl < 3; ++sl) {
                         if (slow & (1 << sl)) {
-                            const unsigned d = (unsigned)dsl[sl];
-                            const unsigned os = d >> 15;
-                            const int kk = (int)(d & 0x7fffu);
-                            const int prod = os >= (unsigned)kGhostBase ? A.gtab[(size_t)wg * kGhosts + (os & (kGhosts - 1))] : (int)os;
+                            const bool isg = ((ghostm >> sl) & 1) != 0;
+                            const int kk = isg ? kl[sl] : (dw[sl] & 0x7fff);
+                            const int prod = isg ? A.gtab[(size_t)wg * kGhosts + (dw[sl] & (kGhosts - 1))] : (int)((unsigned)dw[sl] >> 15);
                             const int pxb = A.xbase[prod];
                             __builtin_amdgcn_s_waitcnt(0x0F70);
                             unsigned long long b[4];
@@ -536,7 +494,7 @@ k_ilu0_lm(FlmArgs A)
                             for (int e = 0; e < 4; ++e) b[e] = ld_agent_u64(xchb + ((size_t)(pxb < 0 ? 0 : pxb) + kk) * 4 + e);
                             __builtin_amdgcn_s_waitcnt(0x0F70);
                             const bool have = pxb >= 0 && b[0] != kSentinel && b[1] != kSentinel && b[2] != kSentinel && b[3] != kSentinel;
-                            if (os >= (unsigned)kGhostBase) {
+                            if (isg) {
                                 const int tag = sl == 0 ? p0.x : (sl == 1 ? p1.x : p2.x);
                                 if (tag < kk) { if (have) gpat = 0; else stall = 0; }
                             }
@@ -556,6 +514,8 @@ k_ilu0_lm(FlmArgs A)
             }
         }
 #undef FLM_PUBLISH
+#undef FLM_STORE_L
+#undef FLM_STORE_U
         asm volatile("" ::: "memory");
         if ((tid & 63) == 0) wdone[wv] = tau;
     }
@@ -611,52 +571,15 @@ void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const Packe
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-// analysis: exchange-row table, storage, header words.  pl/pu: the verified, linked sweep structures.
-bool flm_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, const int32_t *prog_f3, PackedSweep *pl,
-                 const PackedSweep *pu, FactorLM *f)
-{
-    f->release();
-    static const bool off = getenv("ILUPP_NO_PACKED_FACTOR") != nullptr;
-    if (off || !prog_f3 || !pl->valid || !pu->valid || !pu->linked) return false;
-    const int nslots = fwd.nslots;
-    ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots));
-    ILUPP_HIP(pool_malloc(&f->xcount, 64));
-    int32_t *rows = nullptr;
-    ILUPP_HIP(pool_malloc(&rows, sizeof(int32_t) * (size_t)nslots));
-    const unsigned gb = (unsigned)((nslots + 255) / 256);
-    hipLaunchKernelGGL(k_flm_xrows, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, rows);
-    size_t tb = 0;
-    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rows, f->xbase, nslots, st));
-    void *tmp = nullptr;
-    ILUPP_HIP(pool_malloc(&tmp, tb));
-    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, rows, f->xbase, nslots, st));
-    hipLaunchKernelGGL(k_flm_xbase, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, f->xbase, f->xcount);
-    ILUPP_HIP(pool_malloc(&f->xch, sizeof(double) * 4 * (size_t)A.n + 64));       // upper bound; only *xcount doubles are used
-    ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
-    const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
-    hipLaunchKernelGGL((k_flm_pack<1>), grid, dim3(512), 0, st, A.ptr, A.val, prog_f3, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
-                       reinterpret_cast<const v4i *>(pl->pk), reinterpret_cast<v4i *>(f->pkA), pl->flags);
-    int32_t h[8];
-    ILUPP_HIP(hipMemcpyAsync(h, pl->flags, sizeof(h), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(pool_free(rows));
-    ILUPP_HIP(pool_free(tmp));
-    static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[ilupp] packed factor: step structure %s\n", h[4] ? "rejected" : "accepted");
-    if (h[4] != 0) { f->release(); return false; }
-    f->built = true;
-    return true;
-}
-
-int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, const int32_t *prog_f3, PackedSweep *pl,
+int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl,
                     PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms)
 {
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
     hipLaunchKernelGGL(k_flm_fill, dim3(512), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
                        reinterpret_cast<const long long *>(f->xcount), kSentinel);
     const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
-    hipLaunchKernelGGL((k_flm_pack<2>), grid, dim3(512), 0, st, A.ptr, A.val, prog_f3, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
-                       reinterpret_cast<const v4i *>(pl->pk), reinterpret_cast<v4i *>(f->pkA), pl->flags);
+    hipLaunchKernelGGL(k_flm_pack_a, grid, dim3(512), 0, st, A.ptr, A.val, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
+                       reinterpret_cast<v4i *>(f->pkA));
     FlmArgs a;
     a.pkL_in = reinterpret_cast<const v4i *>(pl->pk); a.pkL_out = reinterpret_cast<v2d *>(pl->pk);
     a.pkA = reinterpret_cast<const v4i *>(f->pkA);
