@@ -55,14 +55,15 @@ k_flm_pack_a(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval,
              const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
              const int32_t *__restrict__ scount, v4i *__restrict__ pkA)
 {
+    // a block owns the 64 lanes of one wave x 8 consecutive rows of each (8 lanes x 8 rows per wave: the loads of a
+    // wave touch 8 contiguous pieces of A, its stores diagonals of 8 neighbouring places)
     const int w = blockIdx.x;
-    const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
-    const int L = threadIdx.x & 63;
-    const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
-    if (c >= nch) return;
+    const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
+    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
     const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
-    const int k = tmin + c - skew[slot];
-    const bool valid = k >= 0 && k < scount[slot];
+    const bool valid = k < scount[slot];
+    if (!valid) return;
+    const int base = wtab[(size_t)w * 4], c = k + skew[slot] - wtab[(size_t)w * 4 + 1];
     v4i *p = pkA + ((size_t)base + c) * 320 + L;
     double a[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (valid) {
@@ -577,8 +578,8 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
     hipLaunchKernelGGL(k_flm_fill, dim3(512), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
                        reinterpret_cast<const long long *>(f->xcount), kSentinel);
-    const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
-    hipLaunchKernelGGL(k_flm_pack_a, grid, dim3(512), 0, st, A.ptr, A.val, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
+    const dim3 gridr((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));   // every lane has at most max_chunks rows
+    hipLaunchKernelGGL(k_flm_pack_a, gridr, dim3(512), 0, st, A.ptr, A.val, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
                        reinterpret_cast<v4i *>(f->pkA));
     FlmArgs a;
     a.pkL_in = reinterpret_cast<const v4i *>(pl->pk); a.pkL_out = reinterpret_cast<v2d *>(pl->pk);

@@ -30,6 +30,29 @@ static constexpr int kOwnPrev = -3;
 static constexpr int kMaxSkewA = 30000;
 static constexpr int kFlmGhostBaseA = 4 * 3 * kThreads;      // = kFlmGhostBase of ilu0_lm.hip
 
+// The (at most 8) column indices of a short row in registers: two 16-byte loads instead of a load per entry.
+// Entries beyond `len` are set to INT_MAX so that comparisons need no length checks.
+struct __attribute__((aligned(4))) I4a { int v[4]; };
+struct Row8 { int c[8]; };
+__device__ __forceinline__ Row8 load_row8(const int32_t *__restrict__ idx, int q0, int len, int64_t nnz)
+{
+    Row8 r;
+    if ((int64_t)q0 + 8 <= nnz) {
+        const I4a lo = *reinterpret_cast<const I4a *>(idx + q0);
+        const I4a hi = *reinterpret_cast<const I4a *>(idx + q0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r.c[i] = lo.v[i]; r.c[4 + i] = hi.v[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.c[i] = (int64_t)q0 + i < nnz ? idx[q0 + i] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.c[i] = i < len ? r.c[i] : 0x7fffffff;
+    return r;
+}
+#define ROW8_AT(R, I) ((I) == 0 ? (R).c[0] : (I) == 1 ? (R).c[1] : (I) == 2 ? (R).c[2] : (I) == 3 ? (R).c[3] : \
+                       (I) == 4 ? (R).c[4] : (I) == 5 ? (R).c[5] : (I) == 6 ? (R).c[6] : (R).c[7])
+
 // Import table from one triangle of A (tri = +1: columns below the diagonal, -1: above); see k_ghost_table
 __global__ void __launch_bounds__(kThreads)
 k_ghost_table_tri(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t B, int32_t nb,
@@ -138,21 +161,23 @@ k_lm_scan_a(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ fl
 // ---------------------------------------------------------------------------------------------
 // flags[0] |= 2 : a row or dependency the level-major kernels cannot take; flags[4] |= 1 : step structure unfit
 // for the factor kernel (an in-workgroup dependency that is not exactly one step back)
-// One thread per ROW (consecutive threads read consecutive rows: the pattern loads coalesce); the records are
-// scattered to their (chunk, lane) places, k_pad_records marks the places no row lands on.
-__global__ void __launch_bounds__(256)
-k_fwd_records(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int32_t B, int32_t nb,
+// A block owns the 64 lanes of one wave x 8 consecutive rows of each; inside a wave 8 lanes x 8 rows, so a load
+// instruction touches 8 short contiguous segments of A and a store instruction lands on diagonals of 8 neighbouring
+// places (the skew of neighbouring lanes differs by one step).  k_pad_records marks the places no row lands on.
+__global__ void __launch_bounds__(512)
+k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int64_t nnz, int32_t B, int32_t nb,
               const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
-              const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew,
-              const int32_t *__restrict__ gtab, int32_t *__restrict__ exported,
+              const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
+              const int32_t *__restrict__ scount, const int32_t *__restrict__ gtab, int32_t *__restrict__ exported,
               v4i *__restrict__ pkL, v4i *__restrict__ pkA, int32_t *__restrict__ flags)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int myb = block_of(r, B, nb, start);
-    const int slot = blk2slot[myb];
-    const int wg = slot >> 8, w = slot >> 6, L = slot & 63;
-    const int k = r - start[myb];
+    const int w = blockIdx.x;
+    const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
+    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
+    const int wg = w >> 2;
+    const int slot = wg * kThreads + (w & 3) * 64 + L;
+    if (k >= scount[slot]) return;
+    const int r = sfirst[slot] + k;
     const int tau = k + skew[slot];
     const int base = wtab[(size_t)w * 4], c = tau - wtab[(size_t)w * 4 + 1];
     v4i lrec; lrec.x = kNoDep; lrec.y = kNoDep; lrec.z = kNoDep; lrec.w = 0;
@@ -161,32 +186,43 @@ k_fwd_records(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__rest
     {
         const int a0 = Aptr[r], a1 = Aptr[r + 1];
         const int len = a1 - a0;
+        const Row8 own = load_row8(Aidx, a0, len > 8 ? 8 : len, nnz);
         int cl = 0;
-        while (cl < len && cl < 4 && Aidx[a0 + cl] < r) ++cl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cl += own.c[i] < r ? 1 : 0;
         int bad = (len > 7 || cl > 3 || len - cl > 4 || len - cl < 1) ? 1 : 0;
         int badf = 0;
         unsigned long long mbits = 0;
         int nmt = 0, kinds = 0;
         int sd[3] = {kNoDep, kNoDep, kNoDep}, word[3] = {0, 0, 0};
         if (!bad) {
-            for (int e = 0; e < cl; ++e) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if (e >= cl) continue;
                 const int sl = e + 3 - cl;                    // right-aligned dependency slot of the program
-                const int kc = Aidx[a0 + e];
-                // matches of U row kc against the rest of this row (merge order of the reference)
+                const int kc = own.c[e];
+                // matches of U row kc against the rest of this row (merge order of the reference): the U entries in
+                // ascending column, each looked up among this row's columns
                 const int k0 = Aptr[kc], k1 = Aptr[kc + 1];
-                int ku = k0;
-                while (ku < k1 && Aidx[ku] <= kc) ++ku;
-                const int kd = ku - 1;
-                if (k1 - kd > 4) bad = 1;                    // U row longer than a hand-off entry
-                int pp = e + 1, first_off = 0, nm_e = 0;
-                for (int j = ku; j < k1; ++j) {
-                    const int m = Aidx[j];
-                    while (pp < len && Aidx[a0 + pp] < m) ++pp;
-                    if (pp >= len) break;
-                    if (Aidx[a0 + pp] == m) {
-                        if (nmt < 5) mbits |= (unsigned long long)(sl | (((j - kd) & 3) << 2) | (((pp - cl + 3) & 7) << 4)) << (7 * nmt);
-                        if (nm_e == 0) first_off = (j - kd) & 3;
-                        ++nmt; ++nm_e; ++pp;
+                const int klen = k1 - k0;
+                const Row8 dep = load_row8(Aidx, k0, klen > 8 ? 8 : klen, nnz);
+                int kd = 0;                                   // position of U row kc's diagonal in its row of A
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kd += dep.c[i] < kc ? 1 : 0;
+                if (klen > 8 || klen - kd > 4) bad = 1;       // U row longer than a hand-off entry
+                int first_off = 0, nm_e = 0;
+#pragma unroll
+                for (int off = 1; off < 4; ++off) {
+                    if (kd + off < klen) {
+                        const int m = ROW8_AT(dep, kd + off);
+                        int pp = 0, found = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { pp += own.c[i] < m ? 1 : 0; found |= own.c[i] == m ? 1 : 0; }
+                        if (found) {
+                            if (nmt < 5) mbits |= (unsigned long long)(sl | (off << 2) | (((pp - cl + 3) & 7) << 4)) << (7 * nmt);
+                            if (nm_e == 0) first_off = off;
+                            ++nmt; ++nm_e;
+                        }
                     }
                 }
                 // who produces U row kc
@@ -254,31 +290,37 @@ k_fwd_records(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__rest
 // ---------------------------------------------------------------------------------------------
 // backward pass: the U sweep reads, in stored order, the entries right of the diagonal (SWEEP_BWD_FIRST_ASC)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_bwd_records(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int32_t B, int32_t nb,
+__global__ void __launch_bounds__(512)
+k_bwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int64_t nnz, int32_t B, int32_t nb,
               const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
-              const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew,
-              const int32_t *__restrict__ gtab, int32_t *__restrict__ exported,
+              const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
+              const int32_t *__restrict__ scount, const int32_t *__restrict__ gtab, int32_t *__restrict__ exported,
               v4i *__restrict__ pkU, int32_t *__restrict__ flags)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int myb = block_of(r, B, nb, start);
-    const int slot = blk2slot[myb];
-    const int wg = slot >> 8, w = slot >> 6, L = slot & 63;
-    const int k = start[myb + 1] - 1 - r;
+    const int w = blockIdx.x;
+    const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
+    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
+    const int wg = w >> 2;
+    const int slot = wg * kThreads + (w & 3) * 64 + L;
+    if (k >= scount[slot]) return;
+    const int r = sfirst[slot] - k;
     const int tau = k + skew[slot];
     const int base = wtab[(size_t)w * 4], c = tau - wtab[(size_t)w * 4 + 1];
     v4i rec; rec.x = kNoDep; rec.y = kNoDep; rec.z = kNoDep; rec.w = 0;
     {
         const int a0 = Aptr[r], a1 = Aptr[r + 1];
-        int qd = a0;
-        while (qd < a1 && Aidx[qd] < r) ++qd;              // the diagonal (its presence was checked by the count pass)
-        const int nd = a1 - qd - 1;
-        int bad = (nd > 3 || nd < 0) ? 1 : 0;
+        const int len = a1 - a0;
+        const Row8 own = load_row8(Aidx, a0, len > 8 ? 8 : len, nnz);
+        int qd = 0;                                         // the diagonal (its presence was checked by the count pass)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qd += own.c[i] < r ? 1 : 0;
+        const int nd = len - qd - 1;
+        int bad = (nd > 3 || nd < 0 || len > 8) ? 1 : 0;
         int sd[3] = {kNoDep, kNoDep, kNoDep};
-        for (int j = 0; j < 3 && j < nd; ++j) {
-            const int kc = Aidx[qd + 1 + j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= nd) continue;
+            const int kc = ROW8_AT(own, qd + 1 + j);
             const int b = block_of(kc, B, nb, start);
             const int oslot = blk2slot[b];
             const int kloc = start[b + 1] - 1 - kc;
@@ -403,16 +445,18 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
         hipLaunchKernelGGL(k_pad_records, grid, dim3(512), 0, st, pl->wtab, pl->skew, fwd.scount, reinterpret_cast<v4i *>(pl->pk),
                            reinterpret_cast<v4i *>(f->pkA));
-        hipLaunchKernelGGL(k_fwd_records, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.ptr, A.idx, fwd.B, fwd.nb,
-                           fwd.start, fwd.blk2slot, pl->wtab, pl->skew, fwd.gtab, fwd.exported, reinterpret_cast<v4i *>(pl->pk),
+        const dim3 gridr((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));   // every lane has at most max_chunks rows
+        hipLaunchKernelGGL(k_fwd_records, gridr, dim3(512), 0, st, A.ptr, A.idx, (int64_t)A.nnz, fwd.B, fwd.nb, fwd.start, fwd.blk2slot, pl->wtab,
+                           pl->skew, fwd.sfirst, fwd.scount, fwd.gtab, fwd.exported, reinterpret_cast<v4i *>(pl->pk),
                            reinterpret_cast<v4i *>(f->pkA), pl->flags);
     }
     {
         const dim3 grid((unsigned)(pu->nwg * 4), (unsigned)((pu->max_chunks + 7) / 8));
         hipLaunchKernelGGL(k_pad_records, grid, dim3(512), 0, st, pu->wtab, pu->skew, bwd.scount, reinterpret_cast<v4i *>(pu->pk),
                            static_cast<v4i *>(nullptr));
-        hipLaunchKernelGGL(k_bwd_records, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.ptr, A.idx, bwd.B, bwd.nb,
-                           bwd.start, bwd.blk2slot, pu->wtab, pu->skew, bwd.gtab, bwd.exported, reinterpret_cast<v4i *>(pu->pk), pu->flags);
+        const dim3 gridr((unsigned)(pu->nwg * 4), (unsigned)((pu->max_chunks + 7) / 8));
+        hipLaunchKernelGGL(k_bwd_records, gridr, dim3(512), 0, st, A.ptr, A.idx, (int64_t)A.nnz, bwd.B, bwd.nb, bwd.start, bwd.blk2slot, pu->wtab,
+                           pu->skew, bwd.sfirst, bwd.scount, bwd.gtab, bwd.exported, reinterpret_cast<v4i *>(pu->pk), pu->flags);
     }
     lm_link_factor(st, fwd, bwd, pu);
     // exchange rows of the exported forward slots
