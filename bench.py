@@ -192,11 +192,11 @@ def main():
             "pattern_reuse_value_nnz_per_s": nnz / (reuse_ms * 1e-3) if reuse_ms > 0 else None,
             "hbm_fraction_factor_plus_apply": ((fb + ab) / (gpu_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gpu_ms > 0 else None,
             "hbm_fraction_pattern_reuse": ((fb + ab) / (reuse_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if reuse_ms > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "k_ilu0_numeric_lc",
+            "roofline": {"bound": "hbm", "kernel": "k_ilu0_lm",
                          "achieved": (fb / (k_num * 1e-3) / 1e9) if k_num > 0 else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (fb / (k_num * 1e-3) / 1e9) / HBM_PEAK_GBS if k_num > 0 else None,
-                         "traffic": measured_traffic("k_ilu0_numeric_lc", g),
+                         "traffic": measured_traffic("k_ilu0_lm", g),
                          "algorithmic_bytes_per_launch": fb,
                          "avg_launch_ms": k_num},
             "checksum": checksum,

@@ -808,12 +808,6 @@ int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t)
     return ILUPP_OK;
 }
 
-int ilupp_hip_debug_ctrl(ilupp_precond *p, int32_t *out16)
-{
-    if (!p || !out16) return ILUPP_ERR_INVALID;
-    if (hipMemcpy(out16, p->ctrl, 64, hipMemcpyDeviceToHost) != hipSuccess) return ILUPP_ERR_HIP;
-    return ILUPP_OK;
-}
 
 int ilupp_hip_sync(ilupp_precond *p)
 {

@@ -50,8 +50,9 @@ __global__ void k_flm_fill(unsigned long long *__restrict__ p, const long long *
 }
 
 // the rows of A, diagonal-aligned, into the factor records (whose header words the analysis wrote: records_lm.hip)
+struct __attribute__((aligned(8))) D2a { double v[2]; };
 __global__ void __launch_bounds__(512)
-k_flm_pack_a(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval,
+k_flm_pack_a(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval, int64_t nnz,
              const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
              const int32_t *__restrict__ scount, v4i *__restrict__ pkA)
 {
@@ -71,7 +72,22 @@ k_flm_pack_a(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval,
         const int w0 = reinterpret_cast<const int *>(p + 192)[2];
         const int len = w0 & 15, cl = (w0 >> 4) & 3;
         const int a0 = Aptr[r];
-        for (int j = 0; j < 7; ++j) { const int e = j - (3 - cl); if (e >= 0 && e < len) a[j] = Aval[a0 + e]; }
+        // the row's (at most 7) values with four 16-byte loads, then shifted into diagonal-aligned position
+        double v[8];
+        if ((int64_t)a0 + 8 <= nnz) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const D2a t = *reinterpret_cast<const D2a *>(Aval + a0 + 2 * i); v[2 * i] = t.v[0]; v[2 * i + 1] = t.v[1]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (int64_t)a0 + i < nnz ? Aval[a0 + i] : 0.0;
+        }
+        const int sh = 3 - cl;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int e = j - sh;
+            const double x = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : e == 3 ? v[3] : e == 4 ? v[4] : e == 5 ? v[5] : v[6];
+            a[j] = (e >= 0 && e < len) ? x : 0.0;
+        }
     }
     v2d x; x.x = a[0]; x.y = a[1]; reinterpret_cast<v2d *>(p)[0] = x;
     x.x = a[2]; x.y = a[3]; reinterpret_cast<v2d *>(p)[64] = x;
@@ -579,7 +595,7 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     hipLaunchKernelGGL(k_flm_fill, dim3(512), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
                        reinterpret_cast<const long long *>(f->xcount), kSentinel);
     const dim3 gridr((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));   // every lane has at most max_chunks rows
-    hipLaunchKernelGGL(k_flm_pack_a, gridr, dim3(512), 0, st, A.ptr, A.val, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
+    hipLaunchKernelGGL(k_flm_pack_a, gridr, dim3(512), 0, st, A.ptr, A.val, (int64_t)A.nnz, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
                        reinterpret_cast<v4i *>(f->pkA));
     FlmArgs a;
     a.pkL_in = reinterpret_cast<const v4i *>(pl->pk); a.pkL_out = reinterpret_cast<v2d *>(pl->pk);
