@@ -332,10 +332,11 @@ void ensure_transposed(ilupp_precond *p)
 // one sweep: the packed kernel when the factor has a verified level-major form, else the CSR kernels.  Either way
 // the right-hand side buffer is all-sentinel afterwards (the CSR kernels reset it row by row).
 static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, int32_t maxlen,
-                 const PackedSweep *ps, double *rhs, double *out, int32_t *ticket, int32_t *err)
+                 const PackedSweep *ps, double *rhs, double *out, int32_t *ticket, int32_t *err,
+                 double *ypk_out = nullptr, const double *ypk_in = nullptr, const int32_t *ysrc = nullptr)
 {
     if (ps && ps->valid) {
-        int rc = sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err);
+        int rc = sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc);
         if (rc) return rc;
         fill_u64(p->stream, reinterpret_cast<unsigned long long *>(rhs), p->n, kSentinel);
         return ILUPP_OK;
@@ -357,9 +358,13 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             // L has A's strictly-lower pattern, hence A's forward cuts: the factor-sweep schedule serves it
             const Schedule &sl = p->sL.start ? p->sL : p->sA;
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), &p->pkL, x, y, t1, err);
+            // with the level-major factor path (every in-workgroup dependency one step back) the intermediate vector
+            // travels level-major between the two sweeps; y then only carries the values other workgroups poll
+            const bool ylm = p->flm.built && p->pkL.valid && p->pkU.valid && p->pkL.ybuf && p->pkU.ysrc;
+            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), &p->pkL, x, y, t1, err, ylm ? p->pkL.ybuf : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sweep(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), &p->pkU, y, x, t2, err);
+            sweep(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), &p->pkU, y, x, t2, err, nullptr,
+                  ylm ? p->pkL.ybuf : nullptr, ylm ? p->pkU.ysrc : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         } else {
             ensure_transposed(p);

@@ -79,6 +79,8 @@ struct PackedSweep {
     void *pk = nullptr;         // chunks x 3072 bytes
     int32_t *uslot = nullptr;   // (backward sweep) slot of this schedule that owns the rows of each forward-schedule slot
     bool linked = false;        // uslot complete: the factor kernel can address this sweep's records
+    double *ybuf = nullptr;     // (forward sweep) its unknowns in level-major order, 64 per chunk
+    int32_t *ysrc = nullptr;    // (backward sweep) per slot: where its first row's right-hand side sits in the forward sweep's ybuf
     int64_t nchunks = 0;
     int32_t max_chunks = 0;
     void release();
@@ -204,7 +206,9 @@ void lm_pack(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sc
 void lm_link_factor(hipStream_t st, const Schedule &fwd, const Schedule &bwd, PackedSweep *ps_u);
 bool lm_finish(hipStream_t st, PackedSweep *ps);
 int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
-              int32_t *d_ticket, int32_t *d_err);
+              int32_t *d_ticket, int32_t *d_err, double *ypk_out = nullptr, const double *ypk_in = nullptr,
+              const int32_t *ysrc = nullptr);
+void lm_link_y(hipStream_t st, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu);
 
 // ilu0_lm.hip
 int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl,

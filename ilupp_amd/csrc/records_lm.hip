@@ -459,6 +459,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
                            pu->skew, bwd.sfirst, bwd.scount, bwd.gtab, bwd.exported, reinterpret_cast<v4i *>(pu->pk), pu->flags);
     }
     lm_link_factor(st, fwd, bwd, pu);
+    lm_link_y(st, fwd, pl, pu);
     // exchange rows of the exported forward slots
     const int nslots = fwd.nslots;
     ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots));

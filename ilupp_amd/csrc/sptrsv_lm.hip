@@ -42,6 +42,9 @@ void PackedSweep::release()
     if (flags) (void)pool_free(flags);
     if (pk) (void)pool_free(pk);
     if (uslot) (void)pool_free(uslot);
+    if (ysrc) (void)pool_free(ysrc);
+    if (ybuf) (void)pool_free(ybuf);
+    ysrc = nullptr; ybuf = nullptr;
     skew = wtab = flags = uslot = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false; linked = false;
 }
 
@@ -206,6 +209,20 @@ __global__ void k_lm_uslot(int32_t nslots, const int32_t *__restrict__ slot2blkA
     uslot[s] = us;
 }
 
+// where the backward sweep finds, in the forward sweep's level-major vector, the right-hand side of each of its
+// slots' FIRST row (its later rows sit 64 doubles further down each): the forward slot f of the same rows has its
+// last row at chunk  cnt-1 + skew(f) - tmin(wave of f)
+__global__ void k_lm_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, const int32_t *__restrict__ scount,
+                          const int32_t *__restrict__ wtabL, const int32_t *__restrict__ skewL, int32_t *__restrict__ ysrc)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nslots) return;
+    const int su = uslot[f];
+    if (su < 0) return;
+    const int w = f >> 6;
+    ysrc[su] = (wtabL[(size_t)w * 4] + (scount[f] - 1 + skewL[f] - wtabL[(size_t)w * 4 + 1])) * 64 + (f & 63);
+}
+
 // ---------------------------------------------------------------------------------------------
 // the sweep
 // ---------------------------------------------------------------------------------------------
@@ -226,8 +243,12 @@ __global__ void __launch_bounds__(kLmThreads)
 k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, int32_t n,
             const double *__restrict__ rhs, double *out, int32_t nslots_used, const int32_t *__restrict__ sfirst,
             const int32_t *__restrict__ scount, const int32_t *__restrict__ exported, const int32_t *__restrict__ gtab,
+            double *__restrict__ ypk_out, const double *__restrict__ ypk_in, const int32_t *__restrict__ ysrc,
             int32_t *ticket, int32_t *err)
 {
+    // ypk_out: the unknowns are (also) stored level-major, next to their record -- one coalesced 512-byte store per wave
+    // and step -- and only exported lanes write the natural-order vector; ypk_in/ysrc: the right-hand side is read from
+    // such a vector written by the sweep of the opposite direction (lm_link_y), instead of the natural-order one
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ring slot q: [desc 256 x 16][v01 256 x 16][v23 256 x 16][rhs 256 x 8]
     v4i *xr = reinterpret_cast<v4i *>(smem + kCD * kChunkLds);                 // [kXD8][256] {tag,-,x.lo,x.hi}
@@ -276,6 +297,7 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
         // ------------------------------------------------------------------ loader
         const int L = tid & 63;
         const v4i *p = pk + (size_t)base * 192 + L;
+        const long ysrc0 = (ypk_in && cnt > 0) ? (long)ysrc[myslot] : 0;
         int c_next = 0;
         unsigned idle = 0;
         while (c_next < nch) {
@@ -300,11 +322,7 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
                     int r = r0 + DR * k;
                     r = (k >= 0 && k < cnt) ? r : r0;
                     r = r < 0 ? 0 : (r >= n ? n - 1 : r);
-#ifdef EXP_LM_NORHS
-                    rr[u] = 1.0 + r;
-#else
-                    rr[u] = rhs[r];
-#endif
+                    rr[u] = ypk_in ? ypk_in[(k >= 0 && k < cnt) ? (size_t)(ysrc0 - 64 * (long)k) : 0] : rhs[r];
                 }
             }
 #pragma unroll
@@ -464,11 +482,12 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
                 e.x = k; e.y = 0; e.z = __double2loint(x); e.w = __double2hiint(x);
                 xr[(k & (kXD8 - 1)) * kThreads + tid] = e;
                 const int r = r0 + DR * k;
-#ifdef EXP_LM_NOSTORE
-                if (exports) st_agent_f64(out + r, x);
-#else
-                if (exports) st_agent_f64(out + r, x); else out[r] = x;
-#endif
+                if (ypk_out) {
+                    ypk_out[((size_t)base + c) * 64 + (tid & 63)] = x;
+                    if (exports) st_agent_f64(out + r, x);
+                } else {
+                    if (exports) st_agent_f64(out + r, x); else out[r] = x;
+                }
                 prev_val = x;
                 done = true;
             }
@@ -590,18 +609,29 @@ bool lm_finish(hipStream_t st, PackedSweep *ps)
     return true;
 }
 
+// the forward sweep pl may hand its result to the backward sweep pu level-major (pu linked to pl's schedule)
+void lm_link_y(hipStream_t st, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu)
+{
+    if (!pl->built || !pu->built || !pu->uslot) return;
+    ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)pl->nchunks));
+    ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)fwd.nslots));
+    ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)fwd.nslots, st));
+    hipLaunchKernelGGL(k_lm_ysrc, dim3((unsigned)((fwd.nslots + 255) / 256)), dim3(256), 0, st, fwd.nslots, pu->uslot, fwd.scount,
+                       pl->wtab, pl->skew, pu->ysrc);
+}
+
 int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
-              int32_t *d_ticket, int32_t *d_err)
+              int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
     const unsigned grid = (unsigned)ps.nwg;
     if (ps.kind == (int)SWEEP_FWD_LAST_ASC) {
         ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
         hipLaunchKernelGGL((k_sptrsv_lm<1>), dim3(grid), dim3(kLmThreads), kLmLds, st, reinterpret_cast<const v4i *>(ps.pk), ps.wtab,
-                           ps.skew, n, rhs, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, sch.gtab, d_ticket, d_err);
+                           ps.skew, n, rhs, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, sch.gtab, ypk_out, ypk_in, ysrc, d_ticket, d_err);
     } else {
         ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
         hipLaunchKernelGGL((k_sptrsv_lm<-1>), dim3(grid), dim3(kLmThreads), kLmLds, st, reinterpret_cast<const v4i *>(ps.pk), ps.wtab,
-                           ps.skew, n, rhs, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, sch.gtab, d_ticket, d_err);
+                           ps.skew, n, rhs, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, sch.gtab, ypk_out, ypk_in, ysrc, d_ticket, d_err);
     }
     ILUPP_HIP(hipGetLastError());
     return ILUPP_OK;
