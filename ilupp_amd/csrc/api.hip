@@ -253,7 +253,9 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
     bool have_prog = false;
-    if (p->compact && !lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm)) {
+    const bool lm = p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
+    if (!lm) ilu0_unit_diagonal(st, &p->Lc);        // the CSR-streaming factor kernels write the eliminations only
+    if (p->compact && !lm) {
         // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels
         static const bool allow_lc = getenv("ILUPP_FACTOR_V2") == nullptr;
         if (!(allow_lc && A.nnz >= 16 && build_ilu0_program_f3(st, A, p->Uc, p->sA, &p->prog_f3)))

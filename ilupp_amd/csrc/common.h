@@ -152,6 +152,29 @@ __device__ __forceinline__ int block_of(int c, int B, int nb, const int32_t *__r
     return b;
 }
 
+// The (at most 8) column indices of a short row in registers: two 16-byte loads instead of a load per entry.
+// Entries beyond `len` are set to INT_MAX so that comparisons need no length checks.
+struct __attribute__((aligned(4))) I4a { int v[4]; };
+struct Row8 { int c[8]; };
+__device__ __forceinline__ Row8 load_row8(const int32_t *__restrict__ idx, int q0, int len, int64_t nnz)
+{
+    Row8 r;
+    if ((int64_t)q0 + 8 <= nnz) {
+        const I4a lo = *reinterpret_cast<const I4a *>(idx + q0);
+        const I4a hi = *reinterpret_cast<const I4a *>(idx + q0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r.c[i] = lo.v[i]; r.c[4 + i] = hi.v[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.c[i] = (int64_t)q0 + i < nnz ? idx[q0 + i] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.c[i] = i < len ? r.c[i] : 0x7fffffff;
+    return r;
+}
+#define ROW8_AT(R, I) ((I) == 0 ? (R).c[0] : (I) == 1 ? (R).c[1] : (I) == 2 ? (R).c[2] : (I) == 3 ? (R).c[3] : \
+                       (I) == 4 ? (R).c[4] : (I) == 5 ? (R).c[5] : (I) == 6 ? (R).c[6] : (R).c[7])
+
 // compiler-only ordering point: keeps payload loads below the poll that guards them
 __device__ __forceinline__ void order_after_poll() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 // every store of this wave has left the CU before the flag that publishes them
@@ -179,6 +202,7 @@ int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const
 // ilu0.hip
 int ilu0_numeric_program(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
                          const Ilu0Program &P, int32_t max_row_len, int32_t *d_ctrl, float *kernel_ms);
+void ilu0_unit_diagonal(hipStream_t st, DevMat *L);
 int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag);
 int ilu0_numeric(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
                  int32_t max_row_len, int32_t *d_done, int32_t *d_ctrl, float *kernel_ms);

@@ -48,20 +48,43 @@ __global__ void k_ilu0_count(int32_t n, const int32_t *__restrict__ ptr, const i
     if (ceq == 0) atomicMin(missing, r);
 }
 
-__global__ void k_ilu0_pattern(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+__global__ void k_ilu0_pattern(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int64_t nnz,
                                const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Uptr,
-                               int32_t *__restrict__ Lidx, double *__restrict__ Lval, int32_t *__restrict__ Uidx)
+                               int32_t *__restrict__ Lidx, int32_t *__restrict__ Uidx)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int lo = ptr[r], hi = ptr[r + 1];
     int l = Lptr[r], u = Uptr[r];
+    if (hi - lo <= 8) {
+        // short row: two 16-byte loads, everything else in registers
+        const Row8 row = load_row8(idx, lo, hi - lo, nnz);
+        int cl = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cl += row.c[i] < r ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < hi - lo) { if (i < cl) Lidx[l + i] = row.c[i]; else Uidx[u + i - cl] = row.c[i]; }
+        }
+        Lidx[l + cl] = r;
+        return;
+    }
     for (int q = lo; q < hi; ++q) {
         const int c = idx[q];
         if (c < r) Lidx[l++] = c; else Uidx[u++] = c;
     }
     Lidx[l] = r;
-    Lval[l] = 1.0;
+}
+
+// the unit diagonal of L (ILU0.hpp:93), for the kernels that write the eliminations only
+__global__ void k_unit_diag(int32_t n, const int32_t *__restrict__ Lptr, double *__restrict__ Lval)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) Lval[Lptr[r + 1] - 1] = 1.0;
+}
+void ilu0_unit_diagonal(hipStream_t st, DevMat *L)
+{
+    hipLaunchKernelGGL(k_unit_diag, dim3((unsigned)((L->n + 255) / 256)), dim3(256), 0, st, L->n, L->ptr, L->val);
 }
 
 int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag)
@@ -100,7 +123,7 @@ int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t
     ILUPP_HIP(pool_malloc(&U->idx, sizeof(int32_t) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
     ILUPP_HIP(pool_malloc(&U->val, sizeof(double) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
     if (miss != big) return ILUPP_ERR_NO_DIAGONAL;
-    hipLaunchKernelGGL(k_ilu0_pattern, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, L->ptr, U->ptr, L->idx, L->val, U->idx);
+    hipLaunchKernelGGL(k_ilu0_pattern, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz, L->ptr, U->ptr, L->idx, U->idx);
     return ILUPP_OK;
 }
 

@@ -30,29 +30,6 @@ static constexpr int kOwnPrev = -3;
 static constexpr int kMaxSkewA = 30000;
 static constexpr int kFlmGhostBaseA = 4 * 3 * kThreads;      // = kFlmGhostBase of ilu0_lm.hip
 
-// The (at most 8) column indices of a short row in registers: two 16-byte loads instead of a load per entry.
-// Entries beyond `len` are set to INT_MAX so that comparisons need no length checks.
-struct __attribute__((aligned(4))) I4a { int v[4]; };
-struct Row8 { int c[8]; };
-__device__ __forceinline__ Row8 load_row8(const int32_t *__restrict__ idx, int q0, int len, int64_t nnz)
-{
-    Row8 r;
-    if ((int64_t)q0 + 8 <= nnz) {
-        const I4a lo = *reinterpret_cast<const I4a *>(idx + q0);
-        const I4a hi = *reinterpret_cast<const I4a *>(idx + q0 + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { r.c[i] = lo.v[i]; r.c[4 + i] = hi.v[i]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r.c[i] = (int64_t)q0 + i < nnz ? idx[q0 + i] : 0;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.c[i] = i < len ? r.c[i] : 0x7fffffff;
-    return r;
-}
-#define ROW8_AT(R, I) ((I) == 0 ? (R).c[0] : (I) == 1 ? (R).c[1] : (I) == 2 ? (R).c[2] : (I) == 3 ? (R).c[3] : \
-                       (I) == 4 ? (R).c[4] : (I) == 5 ? (R).c[5] : (I) == 6 ? (R).c[6] : (R).c[7])
-
 // Import table from one triangle of A (tri = +1: columns below the diagonal, -1: above); see k_ghost_table
 __global__ void __launch_bounds__(kThreads)
 k_ghost_table_tri(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t B, int32_t nb,
