@@ -89,6 +89,7 @@ struct PackedSweep {
 // Level-major factor kernel (ilu0_lm.hip): what it needs beyond the two sweeps' structures
 struct FactorLM {
     bool built = false;
+    bool values_packed = false;     // the factor records already hold the values of the matrix about to be factored
     void *pkA = nullptr;            // chunks x 5120 bytes: rows of A (diagonal-aligned), program header, decoded dependencies
     int32_t *xbase = nullptr;       // nslots: first exchange row of a slot whose U rows other workgroups read, else -1
     double *xch = nullptr;          // exchange rows x 4 doubles (write-through, sentinel = not yet)

@@ -37,7 +37,7 @@ void FactorLM::release()
     if (xbase) (void)pool_free(xbase);
     if (xch) (void)pool_free(xch);
     if (xcount) (void)pool_free(xcount);
-    pkA = nullptr; xbase = nullptr; xch = nullptr; xcount = nullptr; built = false;
+    pkA = nullptr; xbase = nullptr; xch = nullptr; xcount = nullptr; built = false; values_packed = false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -595,8 +595,10 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     hipLaunchKernelGGL(k_flm_fill, dim3(512), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
                        reinterpret_cast<const long long *>(f->xcount), kSentinel);
     const dim3 gridr((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));   // every lane has at most max_chunks rows
-    hipLaunchKernelGGL(k_flm_pack_a, gridr, dim3(512), 0, st, A.ptr, A.val, (int64_t)A.nnz, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
-                       reinterpret_cast<v4i *>(f->pkA));
+    if (!f->values_packed)
+        hipLaunchKernelGGL(k_flm_pack_a, gridr, dim3(512), 0, st, A.ptr, A.val, (int64_t)A.nnz, pl->wtab, pl->skew, fwd.sfirst, fwd.scount,
+                           reinterpret_cast<v4i *>(f->pkA));
+    f->values_packed = false;
     FlmArgs a;
     a.pkL_in = reinterpret_cast<const v4i *>(pl->pk); a.pkL_out = reinterpret_cast<v2d *>(pl->pk);
     a.pkA = reinterpret_cast<const v4i *>(f->pkA);

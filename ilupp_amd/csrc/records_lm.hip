@@ -29,6 +29,7 @@ static constexpr int kNoDep = -1;
 static constexpr int kOwnPrev = -3;
 static constexpr int kMaxSkewA = 30000;
 static constexpr int kFlmGhostBaseA = 4 * 3 * kThreads;      // = kFlmGhostBase of ilu0_lm.hip
+struct __attribute__((aligned(8))) D2r { double v[2]; };
 
 // Import table from one triangle of A (tri = +1: columns below the diagonal, -1: above); see k_ghost_table
 __global__ void __launch_bounds__(kThreads)
@@ -142,7 +143,7 @@ k_lm_scan_a(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ fl
 // instruction touches 8 short contiguous segments of A and a store instruction lands on diagonals of 8 neighbouring
 // places (the skew of neighbouring lanes differs by one step).  k_pad_records marks the places no row lands on.
 __global__ void __launch_bounds__(512)
-k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int64_t nnz, int32_t B, int32_t nb,
+k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval, int64_t nnz, int32_t B, int32_t nb,
               const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
               const int32_t *__restrict__ wtab, const int32_t *__restrict__ skew, const int32_t *__restrict__ sfirst,
               const int32_t *__restrict__ scount, const int32_t *__restrict__ gtab, int32_t *__restrict__ exported,
@@ -262,6 +263,33 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
     int *q = reinterpret_cast<int *>(p + 192);
     q[2] = w0; q[3] = w1;
     p[256] = dec;
+    if (Aval) {
+        // the values of this factorisation right away (k_flm_pack_a does the same for a later one on the same pattern):
+        // the row of A, diagonal-aligned
+        const int len = w0 & 15, cl = (w0 >> 4) & 3;
+        const int a0 = Aptr[r];
+        double v[8];
+        if ((int64_t)a0 + 8 <= nnz) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const D2r t = *reinterpret_cast<const D2r *>(Aval + a0 + 2 * i); v[2 * i] = t.v[0]; v[2 * i + 1] = t.v[1]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (int64_t)a0 + i < nnz ? Aval[a0 + i] : 0.0;
+        }
+        const int sh = 3 - cl;
+        double a[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int e = j - sh;
+            const double x = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : e == 3 ? v[3] : e == 4 ? v[4] : e == 5 ? v[5] : v[6];
+            a[j] = (e >= 0 && e < len) ? x : 0.0;
+        }
+        typedef double v2dr __attribute__((ext_vector_type(2)));
+        v2dr x; x.x = a[0]; x.y = a[1]; reinterpret_cast<v2dr *>(p)[0] = x;
+        x.x = a[2]; x.y = a[3]; reinterpret_cast<v2dr *>(p)[64] = x;
+        x.x = a[4]; x.y = a[5]; reinterpret_cast<v2dr *>(p)[128] = x;
+        reinterpret_cast<double *>(p + 192)[0] = a[6];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,7 +451,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         hipLaunchKernelGGL(k_pad_records, grid, dim3(512), 0, st, pl->wtab, pl->skew, fwd.scount, reinterpret_cast<v4i *>(pl->pk),
                            reinterpret_cast<v4i *>(f->pkA));
         const dim3 gridr((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));   // every lane has at most max_chunks rows
-        hipLaunchKernelGGL(k_fwd_records, gridr, dim3(512), 0, st, A.ptr, A.idx, (int64_t)A.nnz, fwd.B, fwd.nb, fwd.start, fwd.blk2slot, pl->wtab,
+        hipLaunchKernelGGL(k_fwd_records, gridr, dim3(512), 0, st, A.ptr, A.idx, A.val, (int64_t)A.nnz, fwd.B, fwd.nb, fwd.start, fwd.blk2slot, pl->wtab,
                            pl->skew, fwd.sfirst, fwd.scount, fwd.gtab, fwd.exported, reinterpret_cast<v4i *>(pl->pk),
                            reinterpret_cast<v4i *>(f->pkA), pl->flags);
     }
@@ -463,6 +491,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     pl->valid = pu->valid = true;
     pu->linked = true;
     f->built = true;
+    f->values_packed = A.val != nullptr;
     return true;
 }
 
