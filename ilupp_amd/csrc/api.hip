@@ -237,18 +237,16 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     hipEvent_t a0 = p->ev[0], a1 = p->ev[1], a2 = p->ev[2];
     ILUPP_HIP(hipEventRecord(a0, st));
     int32_t missing = -1;
-    int rc = ilu0_symbolic(st, A, &p->Lc, &p->Uc, &missing);
+    // one pass over A's pattern: row counts of L and U, diagonal check, and the factor-sweep schedules (L shares A's
+    // forward cuts and U its backward cuts: same strictly-lower / strictly-upper patterns)
+    int rc = ilu0_symbolic_and_schedule(st, A, &p->Lc, &p->Uc, &missing, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
     if (rc == ILUPP_ERR_NO_DIAGONAL) {
         set_error("ILU0: structurally missing diagonal entry in row " + std::to_string(missing));
         return rc;
     }
     if (rc) return rc;
-    // one pass over A's pattern gives the factor-sweep schedule; L shares A's forward cuts and U its
-    // backward cuts (same strictly-lower / strictly-upper patterns)
-    count_cuts_and_schedule(st, A.n, A.ptr, A.idx, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
     const int max_wgs = p->max_lanes / kThreads;
-    choose_tiling(st, A.n, A.ptr, A.idx, &p->sA, true, max_wgs);
-    choose_tiling(st, A.n, A.ptr, A.idx, &p->sU, false, max_wgs);
+    choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
     build_slot_tables(st, &p->sA, true);
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);

@@ -185,6 +185,8 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 // ---- kernels' host entry points (one per .hip file) -------------------------------------------
 
 // symbolic.hip
+int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag,
+                               int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
@@ -193,6 +195,7 @@ int device_cu_count();
 
 // schedule.hip
 void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, Schedule *sch, bool fwd, int max_wgs);
+void choose_tiling_pair(hipStream_t st, const int32_t *ptr, const int32_t *idx, Schedule *fwd, Schedule *bwd, int max_wgs);
 void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd);
 void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc);
 bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, Ilu0Program *P);

@@ -110,22 +110,26 @@ __global__ void k_sample_block_offsets(int32_t nsamp, int32_t stride, int32_t B,
 
 // Decide whether the block grid has the (1, s2) dependency structure of a lexicographic mesh and pick
 // the patch shape.  Purely a placement (performance) decision: any placement is correct.
-void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, Schedule *sch, bool fwd, int max_wgs)
+static bool tiling_wanted(const Schedule *sch)
 {
-    (void)n;
-    sch->tile_s2 = sch->tile_ty = sch->tile_tz = 0;
     static const bool off = getenv("ILUPP_NO_TILES") != nullptr;
-    if (off || sch->nb < 2 * kThreads) return;
+    return !off && sch->nb >= 2 * kThreads;
+}
+static int32_t *tiling_sample(hipStream_t st, const int32_t *ptr, const int32_t *idx, const Schedule *sch, bool fwd, std::vector<int32_t> *h)
+{
     const int nsamp = sch->nb < 2048 ? sch->nb : 2048;
     const int stride = sch->nb / nsamp > 0 ? sch->nb / nsamp : 1;
     int32_t *d_offs = nullptr;
     ILUPP_HIP(pool_malloc(&d_offs, sizeof(int32_t) * 8 * (size_t)nsamp));
     hipLaunchKernelGGL(k_sample_block_offsets, dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, nsamp, stride,
                        sch->B, sch->nb, fwd ? 1 : 0, sch->start, ptr, idx, d_offs);
-    std::vector<int32_t> h((size_t)nsamp * 8);
-    ILUPP_HIP(hipMemcpyAsync(h.data(), d_offs, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(pool_free(d_offs));
+    h->resize((size_t)nsamp * 8);
+    ILUPP_HIP(hipMemcpyAsync(h->data(), d_offs, sizeof(int32_t) * h->size(), hipMemcpyDeviceToHost, st));
+    return d_offs;
+}
+static void tiling_decide(const std::vector<int32_t> &h, Schedule *sch, int max_wgs)
+{
+    const int nsamp = (int)(h.size() / 8);
     // most frequent offset > 1
     std::vector<std::pair<int, int>> cnt;   // (offset, count), tiny
     int has1 = 0, nonempty = 0;
@@ -155,6 +159,32 @@ void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t 
     // every workgroup must be resident at once (a patch may wait on a higher-numbered patch)
     if ((long)NY * NZ > max_wgs) return;
     sch->tile_s2 = s2; sch->tile_ty = ty; sch->tile_tz = tz;
+}
+
+void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, Schedule *sch, bool fwd, int max_wgs)
+{
+    (void)n;
+    sch->tile_s2 = sch->tile_ty = sch->tile_tz = 0;
+    if (!tiling_wanted(sch)) return;
+    std::vector<int32_t> h;
+    int32_t *d = tiling_sample(st, ptr, idx, sch, fwd, &h);
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(pool_free(d));
+    tiling_decide(h, sch, max_wgs);
+}
+
+// forward and backward schedule of the same matrix with one host round trip
+void choose_tiling_pair(hipStream_t st, const int32_t *ptr, const int32_t *idx, Schedule *fwd, Schedule *bwd, int max_wgs)
+{
+    fwd->tile_s2 = fwd->tile_ty = fwd->tile_tz = 0;
+    bwd->tile_s2 = bwd->tile_ty = bwd->tile_tz = 0;
+    std::vector<int32_t> hf, hb;
+    int32_t *df = tiling_wanted(fwd) ? tiling_sample(st, ptr, idx, fwd, true, &hf) : nullptr;
+    int32_t *db = tiling_wanted(bwd) ? tiling_sample(st, ptr, idx, bwd, false, &hb) : nullptr;
+    if (!df && !db) return;
+    ILUPP_HIP(hipStreamSynchronize(st));
+    if (df) { ILUPP_HIP(pool_free(df)); tiling_decide(hf, fwd, max_wgs); }
+    if (db) { ILUPP_HIP(pool_free(db)); tiling_decide(hb, bwd, max_wgs); }
 }
 
 // ---------------------------------------------------------------------------------------------

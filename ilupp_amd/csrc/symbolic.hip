@@ -116,6 +116,133 @@ static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t
                        n, (int32_t)B, (int32_t)nb, cut, sch->start);
 }
 
+// ILU(0) analysis, first pass over A's pattern: everything k_row_cuts finds plus the row counts of L (lrow[r] =
+// strictly-lower entries + unit diagonal, ILU0.hpp:93) and the first row without a diagonal entry.
+// stats[3] = min row with no diagonal (INT_MAX when none)
+__global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int64_t nnz,
+                                  uint8_t *__restrict__ cutf, uint8_t *__restrict__ cutb, int32_t *__restrict__ lrow,
+                                  int32_t *__restrict__ stats)
+{
+    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int lo = ptr[r], hi = ptr[r + 1];
+        mx = max(mx, hi - lo);
+        int cl = 0;
+        bool has_prev = false, has_next = false, has_diag = false;
+        if (hi - lo <= 8) {
+            const Row8 row = load_row8(idx, lo, hi - lo, nnz);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cl += row.c[i] < r ? 1 : 0;
+                has_prev |= row.c[i] == r - 1; has_next |= row.c[i] == r + 1; has_diag |= row.c[i] == r;
+            }
+        } else {
+            for (int q = lo; q < hi; ++q) {
+                const int c = idx[q];
+                cl += c < r ? 1 : 0;
+                has_prev |= c == r - 1; has_next |= c == r + 1; has_diag |= c == r;
+            }
+        }
+        lrow[r] = cl + 1;
+        if (!has_diag) miss = min(miss, r);
+        const int cf = (r == 0) ? 1 : (has_prev ? 0 : 1);
+        cutf[r] = (uint8_t)cf;
+        nf += cf;
+        if (r + 1 < n) { const int cb = has_next ? 0 : 1; cutb[r + 1] = (uint8_t)cb; nbk += cb; }
+        if (r == 0) { cutb[0] = 1; nbk += 1; }
+    }
+    __shared__ int red[4];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0;
+    if (threadIdx.x == 3) red[3] = 0x7fffffff;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); miss = min(miss, __shfl_xor(miss, off));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&stats[0], red[0]); atomicAdd(&stats[1], red[1]); atomicMax(&stats[2], red[2]); atomicMin(&stats[3], red[3]); }
+}
+
+// L/U patterns from the row pointers of L alone: Uptr[r] = Aptr[r] - (Lptr[r] - r)
+__global__ void k_ilu0_pattern2(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int64_t nnz,
+                                const int32_t *__restrict__ Lptr, int32_t *__restrict__ Uptr,
+                                int32_t *__restrict__ Lidx, int32_t *__restrict__ Uidx)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int lo = ptr[r], hi = ptr[r + 1];
+    int l = Lptr[r], u = lo - (l - r);
+    Uptr[r] = u;
+    if (r == n - 1) Uptr[n] = hi - (Lptr[n] - n);
+    if (hi - lo <= 8) {
+        const Row8 row = load_row8(idx, lo, hi - lo, nnz);
+        int cl = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cl += row.c[i] < r ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < hi - lo) { if (i < cl) Lidx[l + i] = row.c[i]; else Uidx[u + i - cl] = row.c[i]; }
+        }
+        Lidx[l + cl] = r;
+        return;
+    }
+    for (int q = lo; q < hi; ++q) {
+        const int c = idx[q];
+        if (c < r) Lidx[l++] = c; else Uidx[u++] = c;
+    }
+    Lidx[l] = r;
+}
+
+// ILU(0): symbolic factorisation (ilu0_symbolic) and both sweep schedules (count_cuts_and_schedule) with ONE pass over
+// the pattern for the counts, one scan and one host round trip
+int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag,
+                               int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len)
+{
+    const int32_t n = A.n;
+    uint8_t *cutf = nullptr, *cutb = nullptr;
+    int32_t *stats = nullptr, *lrow = nullptr;
+    ILUPP_HIP(pool_malloc(&cutf, (size_t)n + 1));
+    ILUPP_HIP(pool_malloc(&cutb, (size_t)n + 1));
+    ILUPP_HIP(pool_malloc(&lrow, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&stats, sizeof(int32_t) * 4));
+    const int32_t init[4] = {0, 0, 0, 0x7fffffff};
+    ILUPP_HIP(hipMemcpyAsync(stats, init, sizeof(init), hipMemcpyHostToDevice, st));
+    unsigned gb = (unsigned)((n + 255) / 256);
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_row_cuts_counts, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz, cutf, cutb, lrow, stats);
+    L->n = U->n = n; L->is_csr = U->is_csr = true; L->owns = U->owns = true;
+    ILUPP_HIP(pool_malloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&U->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(hipMemsetAsync(L->ptr, 0, sizeof(int32_t), st));
+    size_t tmp_bytes = 0;
+    ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, lrow, L->ptr + 1, n, st));
+    void *tmp = nullptr;
+    ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, lrow, L->ptr + 1, n, st));
+    int32_t h[4], nnzl = 0;
+    ILUPP_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipMemcpyAsync(&nnzl, L->ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(pool_free(tmp)); ILUPP_HIP(pool_free(lrow)); ILUPP_HIP(pool_free(stats));
+    if (max_row_len) *max_row_len = h[2];
+    if (first_missing_diag) *first_missing_diag = (h[3] == 0x7fffffff) ? -1 : h[3];
+    L->nnz = nnzl;
+    U->nnz = A.nnz - ((int64_t)nnzl - n);
+    ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
+    ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
+    ILUPP_HIP(pool_malloc(&U->idx, sizeof(int32_t) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
+    ILUPP_HIP(pool_malloc(&U->val, sizeof(double) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
+    if (h[3] != 0x7fffffff) { ILUPP_HIP(pool_free(cutf)); ILUPP_HIP(pool_free(cutb)); return ILUPP_ERR_NO_DIAGONAL; }
+    hipLaunchKernelGGL(k_ilu0_pattern2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz,
+                       L->ptr, U->ptr, L->idx, U->idx);
+    make_schedule(st, n, cutf, h[0], max_lanes, fwd);
+    make_schedule(st, n, cutb, h[1], max_lanes, bwd);
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(pool_free(cutf));
+    ILUPP_HIP(pool_free(cutb));
+    return ILUPP_OK;
+}
+
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len)
 {
