@@ -143,6 +143,7 @@ struct ilupp_precond {
     PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
     FactorLM flm;                    // level-major factor kernel state (then Lc.val / Uc.val are filled on demand)
     bool csr_vals = true;            // Lc.val / Uc.val hold the factor values
+    int64_t nnzA = 0;                // stored entries of the factored matrix (same pattern on a numeric re-factorisation)
     int32_t max_row_len = 0;
     int32_t max_len_T = 0;       // longest major slice of the transposed storages
     double *work = nullptr;      // n, all-sentinel between applies
@@ -235,6 +236,7 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
 {
     hipStream_t st = p->stream;
     hipEvent_t a0 = p->ev[0], a1 = p->ev[1], a2 = p->ev[2];
+    p->nnzA = A.nnz;
     ILUPP_HIP(hipEventRecord(a0, st));
     int32_t missing = -1;
     // one pass over A's pattern: row counts of L and U, diagonal check, and the factor-sweep schedules (L shares A's
@@ -497,7 +499,7 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     API_TRY
     if (!p || p->kind != KIND_LU) { set_error("not an ILU(0) object"); return ILUPP_ERR_INVALID; }
     DevMat A;
-    A.n = p->n; A.is_csr = true; A.owns = false;
+    A.n = p->n; A.is_csr = true; A.owns = false; A.nnz = p->nnzA;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
     hipStream_t st = p->stream;
     ILUPP_HIP(hipEventRecord(p->ev[1], st));

@@ -207,7 +207,6 @@ int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const
 int ilu0_numeric_program(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
                          const Ilu0Program &P, int32_t max_row_len, int32_t *d_ctrl, float *kernel_ms);
 void ilu0_unit_diagonal(hipStream_t st, DevMat *L);
-int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag);
 int ilu0_numeric(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd,
                  int32_t max_row_len, int32_t *d_done, int32_t *d_ctrl, float *kernel_ms);
 

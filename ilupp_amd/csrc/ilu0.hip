@@ -31,51 +31,6 @@ namespace ilupp {
 // ---------------------------------------------------------------------------------------------
 // symbolic
 // ---------------------------------------------------------------------------------------------
-__global__ void k_ilu0_count(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-                             int32_t *__restrict__ lrow, int32_t *__restrict__ urow, int32_t *__restrict__ missing)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int lo = ptr[r], hi = ptr[r + 1];
-    int cl = 0, ceq = 0;
-    for (int q = lo; q < hi; ++q) {
-        const int c = idx[q];
-        cl += (c < r);
-        ceq += (c == r);
-    }
-    lrow[r] = cl + 1;                 // + unit diagonal (ILU0.hpp:93)
-    urow[r] = (hi - lo) - cl;         // entries with column >= r (ILU0.hpp:43)
-    if (ceq == 0) atomicMin(missing, r);
-}
-
-__global__ void k_ilu0_pattern(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int64_t nnz,
-                               const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Uptr,
-                               int32_t *__restrict__ Lidx, int32_t *__restrict__ Uidx)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int lo = ptr[r], hi = ptr[r + 1];
-    int l = Lptr[r], u = Uptr[r];
-    if (hi - lo <= 8) {
-        // short row: two 16-byte loads, everything else in registers
-        const Row8 row = load_row8(idx, lo, hi - lo, nnz);
-        int cl = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cl += row.c[i] < r ? 1 : 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < hi - lo) { if (i < cl) Lidx[l + i] = row.c[i]; else Uidx[u + i - cl] = row.c[i]; }
-        }
-        Lidx[l + cl] = r;
-        return;
-    }
-    for (int q = lo; q < hi; ++q) {
-        const int c = idx[q];
-        if (c < r) Lidx[l++] = c; else Uidx[u++] = c;
-    }
-    Lidx[l] = r;
-}
-
 // the unit diagonal of L (ILU0.hpp:93), for the kernels that write the eliminations only
 __global__ void k_unit_diag(int32_t n, const int32_t *__restrict__ Lptr, double *__restrict__ Lval)
 {
@@ -85,46 +40,6 @@ __global__ void k_unit_diag(int32_t n, const int32_t *__restrict__ Lptr, double 
 void ilu0_unit_diagonal(hipStream_t st, DevMat *L)
 {
     hipLaunchKernelGGL(k_unit_diag, dim3((unsigned)((L->n + 255) / 256)), dim3(256), 0, st, L->n, L->ptr, L->val);
-}
-
-int ilu0_symbolic(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag)
-{
-    const int32_t n = A.n;
-    int32_t *lrow, *urow, *missing;
-    ILUPP_HIP(pool_malloc(&lrow, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(pool_malloc(&urow, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(pool_malloc(&missing, sizeof(int32_t)));
-    const int32_t big = 0x7fffffff;
-    ILUPP_HIP(hipMemcpyAsync(missing, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_ilu0_count, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, lrow, urow, missing);
-
-    L->n = U->n = n; L->is_csr = U->is_csr = true; L->owns = U->owns = true;
-    ILUPP_HIP(pool_malloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(pool_malloc(&U->ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(hipMemsetAsync(L->ptr, 0, sizeof(int32_t), st));
-    ILUPP_HIP(hipMemsetAsync(U->ptr, 0, sizeof(int32_t), st));
-    size_t tmp_bytes = 0;
-    ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, lrow, L->ptr + 1, n, st));
-    void *tmp = nullptr;
-    ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
-    ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, lrow, L->ptr + 1, n, st));
-    ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, urow, U->ptr + 1, n, st));
-    int32_t tot[2], miss;
-    ILUPP_HIP(hipMemcpyAsync(&tot[0], L->ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipMemcpyAsync(&tot[1], U->ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipMemcpyAsync(&miss, missing, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
-    ILUPP_HIP(pool_free(tmp)); ILUPP_HIP(pool_free(lrow)); ILUPP_HIP(pool_free(urow)); ILUPP_HIP(pool_free(missing));
-    if (first_missing_diag) *first_missing_diag = (miss == big) ? -1 : miss;
-    L->nnz = tot[0]; U->nnz = tot[1];
-    ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
-    ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
-    ILUPP_HIP(pool_malloc(&U->idx, sizeof(int32_t) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
-    ILUPP_HIP(pool_malloc(&U->val, sizeof(double) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
-    if (miss != big) return ILUPP_ERR_NO_DIAGONAL;
-    hipLaunchKernelGGL(k_ilu0_pattern, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz, L->ptr, U->ptr, L->idx, U->idx);
-    return ILUPP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -193,7 +193,7 @@ __global__ void k_ilu0_pattern2(int32_t n, const int32_t *__restrict__ ptr, cons
     Lidx[l] = r;
 }
 
-// ILU(0): symbolic factorisation (ilu0_symbolic) and both sweep schedules (count_cuts_and_schedule) with ONE pass over
+// ILU(0): symbolic factorisation (L/U patterns, ILU0.hpp:85-98) and both sweep schedules with ONE pass over
 // the pattern for the counts, one scan and one host round trip
 int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag,
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len)

@@ -143,6 +143,82 @@ def test_ilu0_medium_digests():
     assert G.sha(x) == e["ilu0_apply_ones"]
 
 
+_VARIANT_SCRIPT = r"""
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, scipy.sparse as sp
+import golden_util as G, matgen
+import ilupp_amd as ilupp
+dg = G.load("digests.json")
+for name, gen in (("poisson2d_200", lambda: matgen.poisson2d(200)), ("poisson3d_64", lambda: matgen.poisson3d(64))):
+    e = dg[name]
+    d, i, p = gen()
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    P = ilupp.ILU0Preconditioner(A)
+    x = np.ones(n); P.apply(x)
+    assert G.sha(x) == e["ilu0_apply_ones"], name
+    L, U = [(F.data, F.indices, F.indptr, isinstance(F, sp.csr_matrix)) for F in P.factors()]
+    assert G.digest_of(L) == e["ilu0_L"] and G.digest_of(U) == e["ilu0_U"], name
+    x = np.ones(n); P.apply(x)
+    assert G.sha(x) == e["ilu0_apply_ones"], name
+    xt = np.ones(n); P.apply_trans(xt)
+    assert G.sha(xt) == e["ilu0_apply_trans_ones"], name
+print("variant ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"ILUPP_CLASSIC_ANALYSIS": "1"}, {"ILUPP_NO_PACKED": "1"}, {"ILUPP_NO_TILES": "1"}],
+                         ids=["csr_factor_kernel_packed_sweeps", "csr_streaming_kernels_only", "identity_placement"])
+def test_ilu0_fallback_kernel_generations(env):
+    """the short-row matrices normally take the level-major kernels; the CSR-streaming generation (what any
+    matrix the level-major analysis rejects runs on) must give the same bits.  The switches are read once
+    per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _VARIANT_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")}
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_ilu0_poisson128_bitexact_and_refactor():
+    """128^3 (64 patches of 16x16 lines, level-major kernels): factors and apply bit-identical to the C restatement
+    of the reference; a second numeric factorisation on the same pattern (other values) as well"""
+    from oracle import oracle as O
+    from ilupp_amd import _native
+    import torch
+    g = 128
+    d, i, p = matgen.poisson3d(g)
+    n = p.shape[0] - 1
+    orc = O.orc()
+    Lo, Uo = orc.ilu0((d, i, p, True))
+    xo = orc.apply_lu(Lo, Uo, np.ones(n), O.ID)
+    dev = torch.device("cuda", 0)
+    td, ti, tp = (torch.from_numpy(a).to(dev) for a in (d, i, p))
+    P = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True)
+    tx = torch.ones(n, dtype=torch.float64, device=dev)
+    P.apply_device(tx.data_ptr(), n, transpose=False, sync=True)
+    assert np.array_equal(tx.cpu().numpy(), xo)
+    (Ld, Li, Lp, _, _, _), (Ud, Ui, Up, _, _, _) = P.factors_info()
+    assert np.array_equal(Li, Lo[1]) and np.array_equal(Lp, Lo[2]) and np.array_equal(Ld, Lo[0])
+    assert np.array_equal(Ui, Uo[1]) and np.array_equal(Up, Uo[2]) and np.array_equal(Ud, Uo[0])
+    # same pattern, new values
+    d2 = d * (1.0 + 0.25 * np.cos(np.arange(d.shape[0], dtype=np.float64)))
+    d2[d > 0] = d[d > 0] * 1.5
+    td2 = torch.from_numpy(d2).to(dev)
+    P.refactor_device(td2.data_ptr(), ti.data_ptr(), tp.data_ptr())
+    L2, U2 = orc.ilu0((d2, i, p, True))
+    x2 = orc.apply_lu(L2, U2, np.ones(n), O.ID)
+    tx.fill_(1.0)
+    P.apply_device(tx.data_ptr(), n, transpose=False, sync=True)
+    assert np.array_equal(tx.cpu().numpy(), x2)
+    (Ld, _, _, _, _, _), (Ud, _, _, _, _, _) = P.factors_info()
+    assert np.array_equal(Ld, L2[0]) and np.array_equal(Ud, U2[0])
+
+
 @pytest.mark.parametrize("case", ["rand_k7", "rand_k30_long_rows", "rand_dense_rows", "grid_ragged"])
 def test_ilu0_vs_oracle_seeded(case):
     """fresh seeded inputs against the pinned CPU oracle, incl. rows longer than the LDS working row"""
