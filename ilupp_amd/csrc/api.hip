@@ -151,13 +151,17 @@ struct ilupp_precond {
     int32_t *done = nullptr;     // n
     int32_t *ctrl = nullptr;     // 16 ints: [0] err, [1] ilu0 ticket (+ its err in [2]) , [4],[5] solve tickets
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4],[5]: around the factor kernel
+    int device = 0;
     ilupp_timings tm = {0, 0, 0, 0, 0, 0};
     bool apply_events_valid = false;
     int max_lanes = 65536;
 };
 
 namespace {
+
+struct QueuePack { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int device = 0; };
+struct QueuePool { std::mutex mu; std::vector<QueuePack> free_list; } g_queues;
 
 bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <= kGhostBase; }
 
@@ -175,8 +179,13 @@ void destroy_obj(ilupp_precond *p)
     if (p->xdev) (void)pool_free(p->xdev);
     if (p->done) (void)pool_free(p->done);
     if (p->ctrl) (void)pool_free(p->ctrl);
-    for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    // streams and events are recycled: creating them costs more than a small kernel
+    if (p->stream) {
+        std::lock_guard<std::mutex> lk(g_queues.mu);
+        QueuePack q; q.stream = p->stream; q.device = p->device;
+        for (int k = 0; k < 6; ++k) q.ev[k] = p->ev[k];
+        g_queues.free_list.push_back(q);
+    }
     delete p;
 }
 
@@ -184,8 +193,21 @@ ilupp_precond *new_obj(int32_t n)
 {
     ilupp_precond *p = new ilupp_precond();
     p->n = n;
-    ILUPP_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    for (auto &e : p->ev) ILUPP_HIP(hipEventCreate(&e));
+    ILUPP_HIP(hipGetDevice(&p->device));
+    {
+        std::lock_guard<std::mutex> lk(g_queues.mu);
+        for (size_t k = 0; k < g_queues.free_list.size(); ++k)
+            if (g_queues.free_list[k].device == p->device) {
+                p->stream = g_queues.free_list[k].stream;
+                for (int e = 0; e < 6; ++e) p->ev[e] = g_queues.free_list[k].ev[e];
+                g_queues.free_list.erase(g_queues.free_list.begin() + (long)k);
+                break;
+            }
+    }
+    if (!p->stream) {
+        ILUPP_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        for (auto &e : p->ev) ILUPP_HIP(hipEventCreate(&e));
+    }
     ILUPP_HIP(pool_malloc(&p->work, sizeof(double) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->done, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->ctrl, 64));
@@ -207,7 +229,7 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
     int rc = ILUPP_ERR_UNSUPPORTED;
     bool direct = false;
     if (p->flm.built) {
-        rc = ilu0_numeric_lm(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms);
+        rc = ilu0_numeric_lm(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5]);
         p->csr_vals = false;
         return rc;
     }

@@ -239,7 +239,7 @@ void lm_link_y(hipStream_t st, const Schedule &fwd, PackedSweep *pl, PackedSweep
 
 // ilu0_lm.hip
 int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl,
-                    PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms);
+                    PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1);
 // records_lm.hip
 bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
                      PackedSweep *pu, FactorLM *f);

@@ -589,7 +589,7 @@ void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const Packe
 // host
 // ---------------------------------------------------------------------------------------------
 int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl,
-                    PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms)
+                    PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1)
 {
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
     hipLaunchKernelGGL(k_flm_fill, dim3(512), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
@@ -606,11 +606,12 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     a.wtabL = pl->wtab; a.skewL = pl->skew; a.wtabU = pu->wtab; a.skewU = pu->skew; a.uslot = pu->uslot;
     a.sfirst = fwd.sfirst; a.scount = fwd.scount; a.exported = fwd.exported; a.gtab = fwd.gtab; a.xbase = f->xbase;
     a.xch = f->xch; a.nslots_used = fwd.nslots; a.ctrl = d_ctrl;
-    hipEvent_t e0, e1;
-    ILUPP_HIP(hipEventCreate(&e0));
-    ILUPP_HIP(hipEventCreate(&e1));
     ILUPP_HIP(hipEventRecord(e0, st));
-    ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlmLds));
+    static bool attr_set = false;
+    if (!attr_set) {
+        ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlmLds));
+        attr_set = true;
+    }
     hipLaunchKernelGGL(k_ilu0_lm, dim3((unsigned)pl->nwg), dim3(kFlmThreads), kFlmLds, st, a);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
@@ -618,8 +619,6 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     ILUPP_HIP(hipMemcpyAsync(ctrl, d_ctrl, 16, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
-    ILUPP_HIP(hipEventDestroy(e0));
-    ILUPP_HIP(hipEventDestroy(e1));
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
     return ILUPP_OK;
 }

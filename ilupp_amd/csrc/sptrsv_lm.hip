@@ -624,12 +624,16 @@ int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
     const unsigned grid = (unsigned)ps.nwg;
-    if (ps.kind == (int)SWEEP_FWD_LAST_ASC) {
+    static bool attr_set = false;
+    if (!attr_set) {
         ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
+        ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
+        attr_set = true;
+    }
+    if (ps.kind == (int)SWEEP_FWD_LAST_ASC) {
         hipLaunchKernelGGL((k_sptrsv_lm<1>), dim3(grid), dim3(kLmThreads), kLmLds, st, reinterpret_cast<const v4i *>(ps.pk), ps.wtab,
                            ps.skew, n, rhs, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, sch.gtab, ypk_out, ypk_in, ysrc, d_ticket, d_err);
     } else {
-        ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
         hipLaunchKernelGGL((k_sptrsv_lm<-1>), dim3(grid), dim3(kLmThreads), kLmLds, st, reinterpret_cast<const v4i *>(ps.pk), ps.wtab,
                            ps.skew, n, rhs, out, sch.nslots, sch.sfirst, sch.scount, sch.exported, sch.gtab, ypk_out, ypk_in, ysrc, d_ticket, d_err);
     }
