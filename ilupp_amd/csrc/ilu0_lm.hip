@@ -109,6 +109,10 @@ static constexpr size_t kChunkF = (size_t)kThreads * 80;                        
 static constexpr size_t kFlmLds = kCF * kChunkF + (size_t)kUF * 3 * kThreads * 16 + (size_t)kUF * 3 * kGhosts * 16 + (12 + kGhosts + 8) * 4;
 static constexpr int kDoneF = 0x7fffffff;
 
+// the record streams are read once and written once: keep them out of the way of the data that is re-used
+#define FLM_LD(p) __builtin_nontemporal_load(p)
+#define FLM_ST(p, v) __builtin_nontemporal_store(v, p)
+
 struct FlmArgs {
     const v4i *pkL_in; v2d *pkL_out;          // forward sweep records: pattern half read, value halves written
     const v4i *pkA;
@@ -201,8 +205,8 @@ k_ilu0_lm(FlmArgs A)
             for (int u = 0; u < kLF; ++u) {
                 if (u < room) {
                     const size_t o = (size_t)(c_next + u);
-                    d[u] = pa[o * 320 + 256];
-                    a0[u] = pa[o * 320]; a1[u] = pa[o * 320 + 64]; a2[u] = pa[o * 320 + 128]; a3[u] = pa[o * 320 + 192];
+                    d[u] = FLM_LD(pa + o * 320 + 256);
+                    a0[u] = FLM_LD(pa + o * 320); a1[u] = FLM_LD(pa + o * 320 + 64); a2[u] = FLM_LD(pa + o * 320 + 128); a3[u] = FLM_LD(pa + o * 320 + 192);
                 }
             }
             if (nb > 0) {
@@ -322,12 +326,12 @@ k_ilu0_lm(FlmArgs A)
 #ifdef EXP_FLM_NOL
 #define FLM_STORE_L() do { } while (0)
 #else
-#define FLM_STORE_L() do { lout[(size_t)c * 192] = la_; lout[(size_t)c * 192 + 64] = lb_; } while (0)
+#define FLM_STORE_L() do { FLM_ST(lout + (size_t)c * 192, la_); FLM_ST(lout + (size_t)c * 192 + 64, lb_); } while (0)
 #endif
 #ifdef EXP_FLM_NOU
 #define FLM_STORE_U() do { (void)uo_; } while (0)
 #else
-#define FLM_STORE_U() do { uo_[0] = ua_; uo_[64] = ub_; } while (0)
+#define FLM_STORE_U() do { FLM_ST(uo_, ua_); FLM_ST(uo_ + 64, ub_); } while (0)
 #endif
         // results of a finished row: hand-off entry (value words first, the tag word last), exchange row, the two
         // sweeps' records (eliminations in stored order + unit diagonal; strictly-upper entries + pivot)

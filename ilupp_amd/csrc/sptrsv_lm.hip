@@ -317,7 +317,8 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
             for (int u = 0; u < kLB; ++u) {
                 if (u < room) {
                     const size_t o = (size_t)(c_next + u) * 192;
-                    d[u] = p[o]; a[u] = p[o + 64]; b[u] = p[o + 128];
+                    // read once: streaming loads
+                    d[u] = __builtin_nontemporal_load(p + o); a[u] = __builtin_nontemporal_load(p + o + 64); b[u] = __builtin_nontemporal_load(p + o + 128);
                     const int k = tmin + c_next + u - sk;
                     int r = r0 + DR * k;
                     r = (k >= 0 && k < cnt) ? r : r0;
