@@ -258,11 +258,11 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
         dec.x = word[0]; dec.y = word[1]; dec.z = word[2];
         dec.w = 1 | (kinds << 1) | (cl << 7) | ((len - cl) << 9) | ((simple ? 1 : 0) << 12) | ((nmt > 5 ? 5 : nmt) << 13);
     }
-    pkL[((size_t)base + c) * 192 + L] = lrec;
+    __builtin_nontemporal_store(lrec, pkL + ((size_t)base + c) * 192 + L);
     v4i *p = pkA + ((size_t)base + c) * 320 + L;
     int *q = reinterpret_cast<int *>(p + 192);
     q[2] = w0; q[3] = w1;
-    p[256] = dec;
+    __builtin_nontemporal_store(dec, p + 256);
     if (Aval) {
         // the values of this factorisation right away (k_flm_pack_a does the same for a later one on the same pattern):
         // the row of A, diagonal-aligned
@@ -285,9 +285,9 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
             a[j] = (e >= 0 && e < len) ? x : 0.0;
         }
         typedef double v2dr __attribute__((ext_vector_type(2)));
-        v2dr x; x.x = a[0]; x.y = a[1]; reinterpret_cast<v2dr *>(p)[0] = x;
-        x.x = a[2]; x.y = a[3]; reinterpret_cast<v2dr *>(p)[64] = x;
-        x.x = a[4]; x.y = a[5]; reinterpret_cast<v2dr *>(p)[128] = x;
+        v2dr x; x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, reinterpret_cast<v2dr *>(p));
+        x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, reinterpret_cast<v2dr *>(p) + 64);
+        x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, reinterpret_cast<v2dr *>(p) + 128);
         reinterpret_cast<double *>(p + 192)[0] = a[6];
     }
 }
@@ -353,7 +353,7 @@ k_bwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
         if (bad) atomicOr(&flags[0], 2);
         rec.x = sd[0]; rec.y = sd[1]; rec.z = sd[2]; rec.w = 1;
     }
-    pkU[((size_t)base + c) * 192 + L] = rec;
+    __builtin_nontemporal_store(rec, pkU + ((size_t)base + c) * 192 + L);
 }
 
 // places of the chunks that hold no row: valid = 0 in every pattern word

@@ -484,7 +484,7 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
                 xr[(k & (kXD8 - 1)) * kThreads + tid] = e;
                 const int r = r0 + DR * k;
                 if (ypk_out) {
-                    ypk_out[((size_t)base + c) * 64 + (tid & 63)] = x;
+                    __builtin_nontemporal_store(x, ypk_out + ((size_t)base + c) * 64 + (tid & 63));
                     if (exports) st_agent_f64(out + r, x);
                 } else {
                     if (exports) st_agent_f64(out + r, x); else out[r] = x;
