@@ -20,9 +20,14 @@
 //     arrays stay bit-exact even on structured grids where ties do occur;
 //   * rows go to fixed-pitch slabs (p entries per row), a compaction pass drops exact zeros like compress(0.0).
 //
-// Correctness-first kernel: one lane of the wave executes the row (the algorithm is a chain of dependent
-// pointer operations); the other lanes idle.  Vectorising the U-row AXPY and the candidate scans over the wave
-// is the next step for this path.
+// The row algorithm is a chain of dependent pointer operations: the 64 lanes of the wave run it redundantly with
+// wave-uniform control flow, and fetch the U rows it eliminates with cooperatively (one memory round trip per row
+// instead of one per entry).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -207,9 +212,18 @@ __device__ int threshold_and_drop_dev(const double *sdata, const int32_t *sptr, 
     return len;
 }
 
-static constexpr unsigned kIlutSpinLimit = 1u << 24;
+#ifndef ILUT_SPIN
+#define ILUT_SPIN (1u << 24)
+#endif
+static constexpr unsigned kIlutSpinLimit = ILUT_SPIN;
 
 // ctrl: [0] next row, [1] error/timeout, [2] smallest row with a zero pivot (init INT_MAX)
+// The working row (slots, heap, candidate lists) and its occupancy map live in LDS -- a hash table instead of the
+// dense array -- as long as the row holds at most kIlutLdsCap entries; a row that outgrows LDS is started over with
+// the wave's global-memory working row (dense occupancy array).
+static constexpr int kIlutLdsCap = 1024;
+static constexpr int kIlutHash = 2048;
+
 __global__ void __launch_bounds__(64)
 k_ilut_rows(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
             int32_t p, double tau, IlutWork wk,
@@ -219,40 +233,87 @@ k_ilut_rows(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restri
 {
     const int lane = threadIdx.x;
     const size_t w = blockIdx.x;
-    int32_t *occ = wk.occ + w * (size_t)n;
-    double *sdata = wk.sdata + w * (size_t)wk.cap;
-    int32_t *sptr = wk.sptr + w * (size_t)wk.cap;
-    int32_t *heap = wk.heap + w * (size_t)wk.cap;
-    int32_t *listL = wk.listL + w * (size_t)wk.cap;
-    int32_t *listU = wk.listU + w * (size_t)wk.cap;
+    __shared__ double l_sdata[kIlutLdsCap];
+    __shared__ int32_t l_sptr[kIlutLdsCap], l_heap[kIlutLdsCap], l_listL[kIlutLdsCap], l_listU[kIlutLdsCap];
+    __shared__ int32_t h_key[kIlutHash], h_slot[kIlutHash];
+    for (int q = lane; q < kIlutHash; q += 64) h_key[q] = -1;
+    // row k of U as the wave fetched it (one round trip for the whole row instead of one per entry)
+    __shared__ int32_t u_idx[64];
+    __shared__ double u_val[64];
 
     for (;;) {
         int i = 0;
         if (lane == 0) i = atomicAdd(&ctrl[0], 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= n) break;
-        if (lane == 0) {
-            int wnnz = 0, hlen = 0;
-            bool overflow = false;
-            // insert-on-miss accessor (sparse.h:298-311): returns the slot of column j
-            auto slot_of = [&](int j) -> int {
-                int s = occ[j];
-                if (s < 0) {
-                    if (wnnz >= wk.cap) { overflow = true; return 0; }
-                    s = wnnz++;
-                    occ[j] = s;
-                    sptr[s] = j;
-                    sdata[s] = 0.0;
-                    // push_heap (min-heap on column index)
-                    int hole = hlen++;
-                    while (hole > 0) {
-                        const int parent = (hole - 1) / 2;
-                        if (sptr[heap[parent]] > j) { heap[hole] = heap[parent]; hole = parent; } else break;
-                    }
-                    heap[hole] = s;
+        // the row is a chain of dependent pointer operations: all 64 lanes execute it redundantly (identical values,
+        // wave-uniform control flow -- a lane-0-only region with breaks defeats hipcc's loop structurizer), and share
+        // the memory round trips where a whole U row is fetched.
+        // the working row starts in LDS and moves to the wave's global-memory arrays if it outgrows them
+        bool in_lds = true;
+        int32_t *occ = wk.occ + w * (size_t)n;
+        double *sdata = l_sdata;
+        int32_t *sptr = l_sptr, *heap = l_heap, *listL = l_listL, *listU = l_listU;
+        int cap = kIlutLdsCap;
+        // occupancy map: column -> slot (or -1).  Open-addressing hash in LDS (erased keys keep their place with
+        // slot -1: a column is never touched again after its elimination, ILUT.hpp:234-255), or the dense array
+        auto occ_get = [&](int j) -> int {
+            if (!in_lds) return occ[j];
+            unsigned h = ((unsigned)j * 0x9E3779B1u) >> 21;
+            for (;;) {
+                const int kk = h_key[h];
+                if (kk == j) return h_slot[h];
+                if (kk == -1) return -1;
+                h = (h + 1) & (kIlutHash - 1);
+            }
+        };
+        auto occ_put = [&](int j, int sl) {
+            if (!in_lds) { occ[j] = sl; return; }
+            unsigned h = ((unsigned)j * 0x9E3779B1u) >> 21;
+            for (;;) {
+                const int kk = h_key[h];
+                if (kk == j || kk == -1) { h_key[h] = j; h_slot[h] = sl; return; }
+                h = (h + 1) & (kIlutHash - 1);
+            }
+        };
+        int wnnz = 0, hlen = 0;
+        bool overflow = false;
+        // LDS working row full: continue in global memory (all lanes copy; the values are identical in every lane)
+        auto migrate = [&]() {
+            double *g_sdata = wk.sdata + w * (size_t)wk.cap;
+            int32_t *g_sptr = wk.sptr + w * (size_t)wk.cap, *g_heap = wk.heap + w * (size_t)wk.cap;
+            for (int q = lane; q < wnnz; q += 64) { g_sdata[q] = l_sdata[q]; g_sptr[q] = l_sptr[q]; }
+            for (int q = lane; q < hlen; q += 64) g_heap[q] = l_heap[q];
+            for (int q = lane; q < kIlutHash; q += 64) { const int kk = h_key[q]; if (kk != -1) { occ[kk] = h_slot[q]; h_key[q] = -1; } }
+            __builtin_amdgcn_s_waitcnt(0);          // the wave reads these arrays right away
+            sdata = g_sdata; sptr = g_sptr; heap = g_heap;
+            listL = wk.listL + w * (size_t)wk.cap; listU = wk.listU + w * (size_t)wk.cap;
+            cap = wk.cap;
+            in_lds = false;
+        };
+        // insert-on-miss accessor (sparse.h:298-311): returns the slot of column j
+        auto slot_of = [&](int j) -> int {
+            int s = occ_get(j);
+            if (s < 0) {
+                if (wnnz >= cap) {
+                    if (in_lds) migrate(); else { overflow = true; return 0; }
                 }
-                return s;
-            };
+                s = wnnz++;
+                occ_put(j, s);
+                sptr[s] = j;
+                sdata[s] = 0.0;
+                // push_heap (min-heap on column index)
+                int hole = hlen++;
+                while (hole > 0) {
+                    const int parent = (hole - 1) / 2;
+                    if (sptr[heap[parent]] > j) { heap[hole] = heap[parent]; hole = parent; } else break;
+                }
+                heap[hole] = s;
+            }
+            return s;
+        };
+        double thr1 = 0.0;
+        {
             // (2.) scatter the row, norm of the strictly-lower part in CSR order (ILUT.hpp:222-231)
             double norm_wL = 0.0;
             for (int k = Aptr[i]; k < Aptr[i + 1]; ++k) {
@@ -262,12 +323,17 @@ k_ilut_rows(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restri
                 if (c < i) { const double sq = v * v; norm_wL = norm_wL + sq; }
             }
             norm_wL = sqrt(norm_wL);
-            const double thr1 = tau * norm_wL;
-            // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
-            bool timed_out = false;
-            while (hlen > 0) {
+            thr1 = tau * norm_wL;
+        }
+        // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
+        bool timed_out = false;
+        for (;;) {
+            int act = 0;            // 0: done with the eliminations, 1: next heap entry, 2: eliminate with row k of U
+            int k = 0, x = 0;
+            double wkv = 0.0;
+            if (hlen > 0) {
                 // pop_next_index (sparse.h:313-322)
-                const int x = heap[0];
+                x = heap[0];
                 const int lastv = heap[--hlen];
                 if (hlen > 0) {
                     int hole = 0;
@@ -279,33 +345,50 @@ k_ilut_rows(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restri
                     }
                     heap[hole] = lastv;
                 }
-                const int k = sptr[x];
-                if (k >= i) break;
-                const double wkv = sdata[x];
-                if (wkv == 0.0) continue;                       // stale heap entry (ILUT.hpp:239-240)
-                if (fabs(wkv) < thr1) {                          // stage-1 drop, before dividing (ILUT.hpp:244-245)
-                    if (occ[k] >= 0) { sdata[occ[k]] = 0.0; occ[k] = -1; }     // zero_set(k)
-                } else {
-                    // row k of U must be complete
-                    unsigned spins = 0;
-                    while (ld_agent_i32(&done[k]) == 0) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > kIlutSpinLimit) { timed_out = true; break; }
-                    }
-                    if (timed_out) break;
-                    order_after_poll();
-                    const size_t ub = (size_t)k * p;
-                    const int ul = ld_agent_i32(&Ulen[k]);
-                    const double m = wkv / ld_agent_f64(&Urow_val[ub]);          // w[k] /= U[k,k]  (diag first)
-                    sdata[x] = m;
-                    for (int j = 1; j < ul; ++j) {                               // w -= w[k] * U[k, j>k]
-                        const int c = ld_agent_i32(&Urow_idx[ub + j]);
-                        const double pr = m * ld_agent_f64(&Urow_val[ub + j]);
-                        const int s = slot_of(c);
-                        sdata[s] = sdata[s] - pr;
+                k = sptr[x];
+                if (k < i) {
+                    wkv = sdata[x];
+                    if (wkv == 0.0) {
+                        act = 1;                                     // stale heap entry (ILUT.hpp:239-240)
+                    } else if (fabs(wkv) < thr1) {                   // stage-1 drop, before dividing (ILUT.hpp:244-245)
+                        { const int so = occ_get(k); if (so >= 0) { sdata[so] = 0.0; occ_put(k, -1); } }     // zero_set(k)
+                        act = 1;
+                    } else {
+                        act = 2;
                     }
                 }
             }
+            act = __builtin_amdgcn_readfirstlane(act);       // (already uniform; keeps the branches scalar)
+            if (act == 0 || overflow) break;
+            if (act == 1) continue;
+            k = __builtin_amdgcn_readfirstlane(k);
+            // row k of U must be complete
+            unsigned spins = 0;
+            while (ld_agent_i32(&done[k]) == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kIlutSpinLimit) { timed_out = true; break; }
+            }
+            if (timed_out) break;
+            order_after_poll();
+            const size_t ub = (size_t)k * p;
+            const int ul = ld_agent_i32(&Ulen[k]);
+            double m = 0.0;
+            for (int base = 0; base < ul; base += 64) {
+                const int q = base + lane;
+                if (q < ul) { u_idx[lane] = ld_agent_i32(&Urow_idx[ub + q]); u_val[lane] = ld_agent_f64(&Urow_val[ub + q]); }
+                {
+                    const int cntq = ul - base < 64 ? ul - base : 64;
+                    int j = 0;
+                    if (base == 0) { m = wkv / u_val[0]; sdata[x] = m; j = 1; }      // w[k] /= U[k,k]  (diag first)
+                    for (; j < cntq; ++j) {                                            // w -= w[k] * U[k, j>k]
+                        const double pr = m * u_val[j];
+                        const int s2 = slot_of(u_idx[j]);
+                        sdata[s2] = sdata[s2] - pr;
+                    }
+                }
+            }
+        }
+        {
             // (10.) dropping (ILUT.hpp:259,261)
             const int nL = threshold_and_drop_dev(sdata, sptr, wnnz, listL, p - 1, tau, 0, i);
             const int nU = threshold_and_drop_dev(sdata, sptr, wnnz, listU, p - 1, tau, i + 1, n);
@@ -319,12 +402,13 @@ k_ilut_rows(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restri
             st_agent_i32(&Urow_idx[lb], i); st_agent_f64(&Urow_val[lb], piv);
             for (int q = 0; q < nU; ++q) { st_agent_i32(&Urow_idx[lb + 1 + q], sptr[listU[q]]); st_agent_f64(&Urow_val[lb + 1 + q], sdata[listU[q]]); }
             st_agent_i32(&Ulen[i], nU + 1);
-            if (piv == 0.0) atomicMin(&ctrl[2], i);        // ILUT.hpp:269-270 (reported after the sweep)
-            if (timed_out || overflow) atomicExch(&ctrl[1], overflow ? 2 : 1);
+            if (lane == 0 && piv == 0.0) atomicMin(&ctrl[2], i);        // ILUT.hpp:269-270 (reported after the sweep)
+            if (lane == 0 && (timed_out || overflow)) atomicExch(&ctrl[1], overflow ? 2 : 1);
             drain_stores();
             st_agent_i32(&done[i], 1);
             // (13.) zero_reset (sparse_implementation.h:1036-1040)
-            for (int q = 0; q < wnnz; ++q) occ[sptr[q]] = -1;
+            if (in_lds) { for (int q = lane; q < kIlutHash; q += 64) h_key[q] = -1; }
+            else { for (int q = lane; q < wnnz; q += 64) occ[sptr[q]] = -1; __builtin_amdgcn_s_waitcnt(0); }
         }
     }
 }
@@ -383,20 +467,6 @@ int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double thr
     int32_t p = max_fill_in;
     if (p < 1) p = 1;
     if (p > n) p = n;                                           // ILUT.hpp:211-212
-    // resident waves: bounded by the device and by 48 GB of working-row storage
-    int workers = device_cu_count() * 8;
-    const size_t per_worker = (size_t)n * 4 + (size_t)(n + 16) * (8 + 4 * 4);
-    while (workers > 1 && (size_t)workers * per_worker > (48ull << 30)) workers >>= 1;
-    if (workers > n) workers = n;
-    IlutWork wk;
-    wk.cap = n + 16;
-    ILUPP_HIP(pool_malloc(&wk.occ, sizeof(int32_t) * (size_t)workers * n));
-    ILUPP_HIP(pool_malloc(&wk.sdata, sizeof(double) * (size_t)workers * wk.cap));
-    ILUPP_HIP(pool_malloc(&wk.sptr, sizeof(int32_t) * (size_t)workers * wk.cap));
-    ILUPP_HIP(pool_malloc(&wk.heap, sizeof(int32_t) * (size_t)workers * wk.cap));
-    ILUPP_HIP(pool_malloc(&wk.listL, sizeof(int32_t) * (size_t)workers * wk.cap));
-    ILUPP_HIP(pool_malloc(&wk.listU, sizeof(int32_t) * (size_t)workers * wk.cap));
-    ILUPP_HIP(hipMemsetAsync(wk.occ, 0xff, sizeof(int32_t) * (size_t)workers * n, st));
     int32_t *Lri, *Uri, *Llen, *Ulen, *done, *ctrl;
     double *Lrv, *Urv;
     const size_t slab = (size_t)n * p;
@@ -408,18 +478,33 @@ int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double thr
     ILUPP_HIP(pool_malloc(&Ulen, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&done, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&ctrl, 16));
-    ILUPP_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * (size_t)n, st));
-    const int32_t init[4] = {0, 0, 0x7fffffff, 0};
-    ILUPP_HIP(hipMemcpyAsync(ctrl, init, 16, hipMemcpyHostToDevice, st));
+    IlutWork wk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    int32_t h[4] = {0, 0, 0, 0};
     hipEvent_t e0, e1;
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
+    // resident waves: 4 per CU (LDS working rows), bounded by 48 GB of global working-row storage for the rows that
+    // outgrow LDS (one dense occupancy array per wave -- 288 GB of HBM buys what the CPU code does with a single array)
+    int workers = device_cu_count() * 4;
+    const size_t per_worker = (size_t)n * 4 + (size_t)(n + 16) * (8 + 4 * 4);
+    while (workers > 1 && (size_t)workers * per_worker > (48ull << 30)) workers >>= 1;
+    if (workers > n) workers = n;
+    wk.cap = n + 16;
+    ILUPP_HIP(pool_malloc(&wk.occ, sizeof(int32_t) * (size_t)workers * n));
+    ILUPP_HIP(pool_malloc(&wk.sdata, sizeof(double) * (size_t)workers * wk.cap));
+    ILUPP_HIP(pool_malloc(&wk.sptr, sizeof(int32_t) * (size_t)workers * wk.cap));
+    ILUPP_HIP(pool_malloc(&wk.heap, sizeof(int32_t) * (size_t)workers * wk.cap));
+    ILUPP_HIP(pool_malloc(&wk.listL, sizeof(int32_t) * (size_t)workers * wk.cap));
+    ILUPP_HIP(pool_malloc(&wk.listU, sizeof(int32_t) * (size_t)workers * wk.cap));
+    ILUPP_HIP(hipMemsetAsync(wk.occ, 0xff, sizeof(int32_t) * (size_t)workers * n, st));
+    ILUPP_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * (size_t)n, st));
+    const int32_t init[4] = {0, 0, 0x7fffffff, 0};
+    ILUPP_HIP(hipMemcpyAsync(ctrl, init, 16, hipMemcpyHostToDevice, st));
     ILUPP_HIP(hipEventRecord(e0, st));
     hipLaunchKernelGGL(k_ilut_rows, dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, wk,
                        Lri, Lrv, Llen, Uri, Urv, Ulen, done, ctrl);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
-    int32_t h[4];
     ILUPP_HIP(hipMemcpyAsync(h, ctrl, 16, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
