@@ -219,7 +219,8 @@ def test_ilu0_poisson128_bitexact_and_refactor():
     assert np.array_equal(Ld, L2[0]) and np.array_equal(Ud, U2[0])
 
 
-@pytest.mark.parametrize("case", ["rand_k7", "rand_k30_long_rows", "rand_dense_rows", "grid_ragged"])
+@pytest.mark.parametrize("case", ["rand_k7", "rand_k30_long_rows", "rand_dense_rows", "grid_ragged",
+                                  "grid_ragged_patches", "grid_2d_ragged", "grid_perturbed_values"])
 def test_ilu0_vs_oracle_seeded(case):
     """fresh seeded inputs against the pinned CPU oracle, incl. rows longer than the LDS working row"""
     import ilupp_amd as ilupp
@@ -231,6 +232,14 @@ def test_ilu0_vs_oracle_seeded(case):
         d, i, p = matgen.random_dd(1500, 30, 40.0, 11)
     elif case == "rand_dense_rows":
         d, i, p = matgen.random_dd(400, 90, 120.0, 13)        # > 64 entries per row: global working row
+    elif case == "grid_ragged_patches":
+        d, i, p = matgen.poisson3d(70, 45, 37)       # level-major kernels, patches cut by the grid's edges
+    elif case == "grid_2d_ragged":
+        d, i, p = matgen.poisson2d(301, 173) if matgen.poisson2d.__code__.co_argcount > 1 else matgen.poisson2d(301)
+    elif case == "grid_perturbed_values":
+        d, i, p = matgen.poisson3d(40, 40, 40)
+        d = d * (1.0 + 0.3 * np.sin(np.arange(d.shape[0], dtype=np.float64) * 0.37))
+        d[d > 0] += 2.0
     else:
         d, i, p = matgen.poisson3d(9, 4, 11)
     n = p.shape[0] - 1
