@@ -98,8 +98,11 @@ k_flm_pack_a(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval, 
 // ---------------------------------------------------------------------------------------------
 // the factor kernel
 // ---------------------------------------------------------------------------------------------
+#ifndef KLF
+#define KLF 3
+#endif
 static constexpr int kCF = 4;               // chunk ring depth
-static constexpr int kLF = 2;               // chunks a loader fetches per round
+static constexpr int kLF = KLF;               // chunks a loader fetches per round
 static constexpr int kUF = 4;               // U-row hand-off ring depth (rows per lane)
 static constexpr int kBackF = 2;            // a wave runs at most this many steps ahead of the slowest wave of its workgroup
 static constexpr int kIF = 2;               // rows an importer lane polls per trip
@@ -112,6 +115,10 @@ static constexpr int kDoneF = 0x7fffffff;
 // the record streams are read once and written once: keep them out of the way of the data that is re-used
 #define FLM_LD(p) __builtin_nontemporal_load(p)
 #define FLM_ST(p, v) __builtin_nontemporal_store(v, p)
+
+#ifdef ILUPP_TIMELINE
+__device__ unsigned long long *g_flm_timeline = nullptr;     // diagnostics build only: 8 words per workgroup
+#endif
 
 struct FlmArgs {
     const v4i *pkL_in; v2d *pkL_out;          // forward sweep records: pattern half read, value halves written
@@ -275,7 +282,15 @@ k_ilu0_lm(FlmArgs A)
     }
     v2d *lout = A.pkL_out + (size_t)base * 192 + 64 + (tid & 63);
 
+#ifdef ILUPP_TIMELINE
+    unsigned long long *const tl = g_flm_timeline;
+    if (tl && tid == 0) tl[(size_t)wg * 8] = wall_clock64();
+#endif
     for (int c = 0; c < nch && !dead; ++c) {
+#ifdef ILUPP_TIMELINE
+        if (tl && (tid & 63) == 0 && (c == 0 || c == nch / 2 || c == nch - 1))
+            tl[(size_t)wg * 8 + 1 + (wv == 0 ? 0 : 3) + (c == 0 ? 0 : (c == nch - 1 ? 2 : 1))] = wall_clock64();
+#endif
         const int tau = tmin + c;
         const v4i *q = reinterpret_cast<const v4i *>(smem + (size_t)(c & (kCF - 1)) * kChunkF);
         v4i rec, r0, r1, r2, r3;
@@ -610,6 +625,14 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     a.wtabL = pl->wtab; a.skewL = pl->skew; a.wtabU = pu->wtab; a.skewU = pu->skew; a.uslot = pu->uslot;
     a.sfirst = fwd.sfirst; a.scount = fwd.scount; a.exported = fwd.exported; a.gtab = fwd.gtab; a.xbase = f->xbase;
     a.xch = f->xch; a.nslots_used = fwd.nslots; a.ctrl = d_ctrl;
+#ifdef ILUPP_TIMELINE
+    static unsigned long long *d_tl = nullptr;
+    if (!d_tl) {
+        ILUPP_HIP(hipMalloc(&d_tl, 8 * 8 * 4096));
+        ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_flm_timeline), &d_tl, sizeof(d_tl)));
+    }
+    ILUPP_HIP(hipMemsetAsync(d_tl, 0, 8 * 8 * 4096, st));
+#endif
     ILUPP_HIP(hipEventRecord(e0, st));
     static bool attr_set = false;
     if (!attr_set) {
@@ -623,6 +646,13 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     ILUPP_HIP(hipMemcpyAsync(ctrl, d_ctrl, 16, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+#ifdef ILUPP_TIMELINE
+    if (pl->nwg <= 4096) {
+        static unsigned long long h_tl[8 * 4096];
+        ILUPP_HIP(hipMemcpy(h_tl, d_tl, 8 * 8 * (size_t)pl->nwg, hipMemcpyDeviceToHost));
+        if (FILE *ftl = fopen("/tmp/timeline_factor.bin", "wb")) { fwrite(h_tl, 8, 8 * (size_t)pl->nwg, ftl); fclose(ftl); }
+    }
+#endif
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
     return ILUPP_OK;
 }

@@ -226,8 +226,11 @@ __global__ void k_lm_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, con
 // ---------------------------------------------------------------------------------------------
 // the sweep
 // ---------------------------------------------------------------------------------------------
+#ifndef KLB
+#define KLB 3
+#endif
 static constexpr int kCD = 8;              // chunk ring depth
-static constexpr int kLB = 2;              // chunks a loader fetches per round
+static constexpr int kLB = KLB;              // chunks a loader fetches per round
 static constexpr int kXD8 = 8;             // {tag,x} hand-off ring depth
 static constexpr int kGD8 = 8;             // ghost ring depth
 static constexpr int kIB4 = 4;             // unknowns an importer lane polls per trip
