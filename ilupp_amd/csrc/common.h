@@ -86,6 +86,14 @@ struct PackedSweep {
     void release();
 };
 
+// Hand-off rings of the level-major factor kernel (their addresses are baked into the factor records, records_lm.hip):
+// own U rows kFlmUF deep (slot = row index modulo kFlmUF; a wave runs at most kFlmUF-2 steps ahead of the slowest wave
+// of its workgroup), ghost U rows kFlmGF deep
+static constexpr int kFlmUF = 4;
+static constexpr int kFlmGF = 4;
+static constexpr int kFlmGhostBase = kFlmUF * 3 * 256;
+static_assert(kFlmGhostBase + kFlmGF * 3 * 64 <= 4096, "ring addresses are 12-bit fields of the factor records");
+
 // Level-major factor kernel (ilu0_lm.hip): what it needs beyond the two sweeps' structures
 struct FactorLM {
     bool built = false;

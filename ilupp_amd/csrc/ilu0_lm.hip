@@ -101,15 +101,16 @@ k_flm_pack_a(const int32_t *__restrict__ Aptr, const double *__restrict__ Aval, 
 #ifndef KLF
 #define KLF 3
 #endif
-static constexpr int kCF = 4;               // chunk ring depth
+static constexpr int kCF = 4;               // chunk ring depth (not a power of two: slots are taken modulo)
 static constexpr int kLF = KLF;               // chunks a loader fetches per round
-static constexpr int kUF = 4;               // U-row hand-off ring depth (rows per lane)
-static constexpr int kBackF = 2;            // a wave runs at most this many steps ahead of the slowest wave of its workgroup
+static constexpr int kUF = kFlmUF;          // own U-row hand-off ring depth (rows per lane)
+static constexpr int kGF = kFlmGF;          // ghost U-row ring depth
+static constexpr int kBackF = kFlmUF - 2;   // a wave runs at most this many steps ahead of the slowest wave of its workgroup
 static constexpr int kIF = 2;               // rows an importer lane polls per trip
 static constexpr int kPatienceF = 256;
 static constexpr int kFlmThreads = 2 * kThreads;   // 4 consumer waves + 4 loader waves (16 lanes of each loader double as importers)
 static constexpr size_t kChunkF = (size_t)kThreads * 80;                                  // desc + 4 x 16 B of A / header
-static constexpr size_t kFlmLds = kCF * kChunkF + (size_t)kUF * 3 * kThreads * 16 + (size_t)kUF * 3 * kGhosts * 16 + (12 + kGhosts + 8) * 4;
+static constexpr size_t kFlmLds = kCF * kChunkF + (size_t)kUF * 3 * kThreads * 16 + (size_t)kGF * 3 * kGhosts * 16 + (12 + kGhosts + 8) * 4;
 static constexpr int kDoneF = 0x7fffffff;
 
 // the record streams are read once and written once: keep them out of the way of the data that is re-used
@@ -136,8 +137,8 @@ k_ilu0_lm(FlmArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v4i *ur = reinterpret_cast<v4i *>(smem + kCF * kChunkF);            // [kUF][3][256]: {tag,-,u0} {u1,u2} {u3,-}
-    v4i *gur = ur + kUF * 3 * kThreads;                                  // [kUF][3][kGhosts]
-    int *avail = reinterpret_cast<int *>(gur + kUF * 3 * kGhosts);       // [4]
+    v4i *gur = ur + kUF * 3 * kThreads;                                  // [kGF][3][kGhosts]
+    int *avail = reinterpret_cast<int *>(gur + kGF * 3 * kGhosts);       // [4]
     int *cons = avail + 4;                                               // [4]
     int *wdone = cons + 4;                                               // [4]
     int *gack = wdone + 4;                                               // [kGhosts]
@@ -167,7 +168,7 @@ k_ilu0_lm(FlmArgs A)
     if (is_importer) {
         const int os = A.gtab[(size_t)wg * kGhosts + gid];
         if (os >= 0) { g_xb = A.xbase[os]; g_cnt = g_xb >= 0 ? A.scount[os] : 0; }
-        for (int s = 0; s < kUF * 3; ++s) { v4i e; e.x = -1; e.y = 0; e.z = 0; e.w = 0; gur[s * kGhosts + gid] = e; }
+        for (int s = 0; s < kGF * 3; ++s) { v4i e; e.x = -1; e.y = 0; e.z = 0; e.w = 0; gur[s * kGhosts + gid] = e; }
         gack[gid] = 0;
     }
     if (is_consumer) {
@@ -199,7 +200,7 @@ k_ilu0_lm(FlmArgs A)
                 if (ack > next) next = ack;
                 nb = g_cnt - next;
                 nb = nb < kIF ? nb : kIF;
-                nb = nb < ack + kUF - next ? nb : ack + kUF - next;
+                nb = nb < ack + kGF - next ? nb : ack + kGF - next;
             }
             if (room <= 0 && !__any(nb > 0)) {
                 __builtin_amdgcn_s_sleep(2);
@@ -228,7 +229,7 @@ k_ilu0_lm(FlmArgs A)
 #pragma unroll
             for (int u = 0; u < kLF; ++u) {
                 if (u < room) {
-                    v4i *q = reinterpret_cast<v4i *>(smem + (size_t)((c_next + u) & (kCF - 1)) * kChunkF);
+                    v4i *q = reinterpret_cast<v4i *>(smem + (size_t)((c_next + u) % kCF) * kChunkF);
                     q[tid] = d[u]; q[kThreads + tid] = a0[u]; q[2 * kThreads + tid] = a1[u];
                     q[3 * kThreads + tid] = a2[u]; q[4 * kThreads + tid] = a3[u];
                 }
@@ -243,7 +244,7 @@ k_ilu0_lm(FlmArgs A)
 #pragma unroll
                 for (int q = 0; q < kIF; ++q) {
                     if (q < got) {
-                        v4i *e = gur + (size_t)((next + q) & (kUF - 1)) * 3 * kGhosts + gid;
+                        v4i *e = gur + (size_t)((next + q) & (kGF - 1)) * 3 * kGhosts + gid;
                         v4i w1, w2, w0;
                         w1.x = (int)(unsigned)b[q][1]; w1.y = (int)(unsigned)(b[q][1] >> 32); w1.z = (int)(unsigned)b[q][2]; w1.w = (int)(unsigned)(b[q][2] >> 32);
                         w2.x = (int)(unsigned)b[q][3]; w2.y = (int)(unsigned)(b[q][3] >> 32); w2.z = 0; w2.w = 0;
@@ -292,7 +293,7 @@ k_ilu0_lm(FlmArgs A)
             tl[(size_t)wg * 8 + 1 + (wv == 0 ? 0 : 3) + (c == 0 ? 0 : (c == nch - 1 ? 2 : 1))] = wall_clock64();
 #endif
         const int tau = tmin + c;
-        const v4i *q = reinterpret_cast<const v4i *>(smem + (size_t)(c & (kCF - 1)) * kChunkF);
+        const v4i *q = reinterpret_cast<const v4i *>(smem + (size_t)(c % kCF) * kChunkF);
         v4i rec, r0, r1, r2, r3;
         unsigned spins = 0;
         for (;;) {
@@ -359,7 +360,7 @@ k_ilu0_lm(FlmArgs A)
             if (ulen < 2) w4 = 0.0;                                                                                    \
             if (ulen < 3) w5 = 0.0;                                                                                    \
             if (ulen < 4) w6 = 0.0;                                                                                    \
-            v4i *e_ = ur + (size_t)(k & (kUF - 1)) * 3 * kThreads + tid;                                               \
+            v4i *e_ = ur + (size_t)(k % kUF) * 3 * kThreads + tid;                                                     \
             v4i e1_, e2_, e0_;                                                                                         \
             e1_.x = __double2loint(w4); e1_.y = __double2hiint(w4); e1_.z = __double2loint(w5); e1_.w = __double2hiint(w5); \
             e2_.x = __double2loint(w6); e2_.y = __double2hiint(w6); e2_.z = 0; e2_.w = 0;                              \

@@ -28,7 +28,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 static constexpr int kNoDep = -1;
 static constexpr int kOwnPrev = -3;
 static constexpr int kMaxSkewA = 30000;
-static constexpr int kFlmGhostBaseA = 4 * 3 * kThreads;      // = kFlmGhostBase of ilu0_lm.hip
 struct __attribute__((aligned(8))) D2r { double v[2]; };
 
 // Import table from one triangle of A (tri = +1: columns below the diagonal, -1: above); see k_ghost_table
@@ -214,9 +213,9 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
                 } else if ((oslot >> 8) == wg) {
                     const int td = kloc + skew[oslot];
                     if (td > tau) bad = 1;                    // the sweep would wait for a later step of its own workgroup
-                    if (td != tau - 1) badf = 1;              // the factor kernel's 4-deep hand-off ring must not be lapped
+                    if (td != tau - 1) badf = 1;              // the factor kernel's short hand-off ring must not be lapped
                     sd[e] = (oslot << 15) | kloc;
-                    word[sl] = ((kloc & 3) * 3 * kThreads + (oslot & 255)) | (kloc << 12) | (first_off << 27);
+                    word[sl] = ((kloc % kFlmUF) * 3 * kThreads + (oslot & 255)) | (kloc << 12) | (first_off << 27);
                     kinds |= 2 << (2 * sl);
                 } else {
                     exported[oslot] = 1;                      // read across a workgroup border: stored write-through / exchanged
@@ -233,7 +232,7 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
                     }
                     if (g >= 0) {
                         sd[e] = ((kGhostBase + g) << 15) | kloc;
-                        word[sl] = (kFlmGhostBaseA + (kloc & 3) * 3 * kGhosts + g) | (kloc << 12) | (first_off << 27) | (1 << 29);
+                        word[sl] = (kFlmGhostBase + (kloc & (kFlmGF - 1)) * 3 * kGhosts + g) | (kloc << 12) | (first_off << 27) | (1 << 29);
                         kinds |= 2 << (2 * sl);
                     } else {
                         sd[e] = (oslot << 15) | kloc;
