@@ -141,6 +141,8 @@ struct ilupp_precond {
     bool compact = false;            // descriptors/program usable (block size and grid within the encoding)
     int32_t *dL = nullptr, *dU = nullptr, *dUT = nullptr, *dLT = nullptr;   // solve descriptors
     PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
+    PackedSweep pkUT, pkLT;          // ... of the transposed storages
+    bool pack_tried[4] = {false, false, false, false};   // Lc, Uc, UcT, LcT: packing from the descriptors was attempted
     FactorLM flm;                    // level-major factor kernel state (then Lc.val / Uc.val are filled on demand)
     bool csr_vals = true;            // Lc.val / Uc.val hold the factor values
     int64_t nnzA = 0;                // stored entries of the factored matrix (same pattern on a numeric re-factorisation)
@@ -172,7 +174,7 @@ void destroy_obj(ilupp_precond *p)
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
     p->prog.release();
-    p->pkL.release(); p->pkU.release(); p->flm.release();
+    p->pkL.release(); p->pkU.release(); p->pkUT.release(); p->pkLT.release(); p->flm.release();
     if (p->prog_f3) (void)pool_free(p->prog_f3);
     for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)pool_free(d);
     if (p->work) (void)pool_free(p->work);
@@ -355,6 +357,21 @@ void ensure_transposed(ilupp_precond *p)
 
 // one sweep: the packed kernel when the factor has a verified level-major form, else the CSR kernels.  Either way
 // the right-hand side buffer is all-sentinel afterwards (the CSR kernels reset it row by row).
+// level-major records of a sweep straight from its CSR arrays and descriptors (any object whose rows are short enough:
+// transposed ILU(0) factors, IChol(0)); tried once, on first use
+static const PackedSweep *packed(ilupp_precond *p, int which, SweepKind kind, const DevMat &M, const Schedule &sch,
+                                 const int32_t *desc, int32_t maxlen, PackedSweep *ps)
+{
+    if (!ps->valid && !p->pack_tried[which] && desc) {
+        if (lm_prepare(p->stream, kind, M, sch, desc, maxlen, ps)) {
+            lm_pack(p->stream, kind, M, sch, desc, ps, 3);
+            lm_finish(p->stream, ps);
+        }
+    }
+    p->pack_tried[which] = true;
+    return ps->valid ? ps : nullptr;
+}
+
 static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc, int32_t maxlen,
                  const PackedSweep *ps, double *rhs, double *out, int32_t *ticket, int32_t *err,
                  double *ypk_out = nullptr, const double *ypk_in = nullptr, const int32_t *ysrc = nullptr)
@@ -385,31 +402,41 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             // with the level-major factor path (every in-workgroup dependency one step back) the intermediate vector
             // travels level-major between the two sweeps; y then only carries the values other workgroups poll
             const bool ylm = p->flm.built && p->pkL.valid && p->pkU.valid && p->pkL.ybuf && p->pkU.ysrc;
-            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), &p->pkL, x, y, t1, err, ylm ? p->pkL.ybuf : nullptr);
+            const PackedSweep *p1 = packed(p, 0, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
+            const PackedSweep *p2 = packed(p, 1, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), &p->pkU);
+            ILUPP_HIP(hipEventRecord(p->ev[0], st));
+            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), p1, x, y, t1, err, ylm ? p->pkL.ybuf : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sweep(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), &p->pkU, y, x, t2, err, nullptr,
+            sweep(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), p2, y, x, t2, err, nullptr,
                   ylm ? p->pkL.ybuf : nullptr, ylm ? p->pkU.ysrc : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         } else {
             ensure_transposed(p);
+            const PackedSweep *p1 = packed(p, 2, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), &p->pkUT);
+            const PackedSweep *p2 = packed(p, 3, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), &p->pkLT);
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), x, y, t1, err);
+            sweep(p, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), p1, x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), y, x, t2, err);
+            sweep(p, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p2, y, x, t2, err);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         }
     } else {
         // LL^T: apply == apply_trans (preconditioner_implementation.h:381-394)
         ensure_transposed(p);
-        ILUPP_HIP(hipEventRecord(p->ev[0], st));
         if (p->llt_diag_last) {       // IChol0: T1(L) then T4(L)
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), x, y, t1, err);
+            const PackedSweep *p1 = packed(p, 0, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
+            const PackedSweep *p2 = packed(p, 3, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), &p->pkLT);
+            ILUPP_HIP(hipEventRecord(p->ev[0], st));
+            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), p1, x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), y, x, t2, err);
+            sweep(p, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p2, y, x, t2, err);
         } else {                      // ICholT: T2(L) then T3(L)
-            sptrsv(st, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), x, y, t1, err);
+            const PackedSweep *p1 = packed(p, 3, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), &p->pkLT);
+            const PackedSweep *p2 = packed(p, 0, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
+            ILUPP_HIP(hipEventRecord(p->ev[0], st));
+            sweep(p, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p1, x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sptrsv(st, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), y, x, t2, err);
+            sweep(p, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), p2, y, x, t2, err);
         }
         ILUPP_HIP(hipEventRecord(p->ev[2], st));
     }
@@ -537,6 +564,7 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
         if (p->dUT) (void)pool_free(p->dUT);
         if (p->dLT) (void)pool_free(p->dLT);
         p->dUT = p->dLT = nullptr; p->haveT = false;
+        p->pkUT.release(); p->pkLT.release(); p->pack_tried[2] = p->pack_tried[3] = false;
     }
     if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out");
     return rc;
