@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include "stdsort.h"
 
 namespace ilupp {
 
@@ -213,111 +214,13 @@ int ichol0_numeric(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t max_r
 // Left-looking by columns.  Two things in the reference make the column order matter for the BITS of the
 // result, not just for correctness: (1) column j subtracts the contributing columns k in the order of a linked
 // list that is re-threaded after every column (ILUC.hpp:37-63), (2) every column j updates the running diagonal
-// D[i] of ALL rows i > j of its PRE-drop working column (IChol.hpp:135-141), so the value of D[i] seen by
-// column i depends on the order in which all earlier columns -- including entries that are dropped afterwards --
-// reached it.  Which columns touch a row is therefore not known before they have run.  This first GPU version
-// keeps the reference's order outright: one wave walks the columns in sequence (one lane executes the pointer
-// chasing; the data never leaves HBM/L2).  It is a correctness-first, drop-in path, not yet a fast one; a
-// dataflow version needs a symbolic bound on the pre-drop patterns.
+// D[i] of ALL rows i > j of its PRE-drop working column (IChol.hpp:135-141).  The dataflow kernel in
+// icholt_df.hip reproduces both in parallel and is what normally runs.  The kernel below is the reference loop
+// verbatim on one lane: the fallback for what the dataflow kernel's LDS capacities do not cover (very long
+// working columns, a dropped diagonal, add_fill_in < 0), and the A/B check of the dataflow kernel
+// (ILUPP_ICHOLT_SEQUENTIAL=1).
 namespace ilupp {
 
-struct AbsDescC {
-    const double *key;
-    __device__ __forceinline__ bool operator()(int a, int b) const { return fabs(key[a]) > fabs(key[b]); }
-};
-// the same libstdc++ std::sort restatement as ilut.hip (kept local: separate translation units)
-__device__ void c_unguarded_linear_insert(int *last, const AbsDescC &c)
-{
-    const int v = *last;
-    int *next = last - 1;
-    while (c(v, *next)) { *last = *next; last = next; --next; }
-    *last = v;
-}
-__device__ void c_insertion_sort(int *first, int *last, const AbsDescC &c)
-{
-    if (first == last) return;
-    for (int *i = first + 1; i != last; ++i) {
-        if (c(*i, *first)) {
-            const int v = *i;
-            for (int *q = i; q != first; --q) *q = *(q - 1);
-            *first = v;
-        } else
-            c_unguarded_linear_insert(i, c);
-    }
-}
-__device__ void c_push_heap(int *first, long hole, long top, int v, const AbsDescC &c)
-{
-    long parent = (hole - 1) / 2;
-    while (hole > top && c(first[parent], v)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
-    first[hole] = v;
-}
-__device__ void c_adjust_heap(int *first, long hole, long len, int v, const AbsDescC &c)
-{
-    const long top = hole;
-    long child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        if (c(first[child], first[child - 1])) child--;
-        first[hole] = first[child];
-        hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); first[hole] = first[child - 1]; hole = child - 1; }
-    c_push_heap(first, hole, top, v, c);
-}
-__device__ void c_heapsort(int *first, int *last, const AbsDescC &c)
-{
-    const long len = last - first;
-    if (len >= 2) {
-        long parent = (len - 2) / 2;
-        for (;;) { const int v = first[parent]; c_adjust_heap(first, parent, len, v, c); if (parent == 0) break; parent--; }
-    }
-    while (last - first > 1) { --last; const int v = *last; *last = *first; c_adjust_heap(first, 0, last - first, v, c); }
-}
-__device__ void c_sort_slots_by_abs_desc(int *list, int len, const double *key)
-{
-    AbsDescC c{key};
-    if (len <= 0) return;
-    int *first = list, *last = list + len;
-    long lg = 0, m = len;
-    while (m > 1) { m >>= 1; ++lg; }
-    struct Frame { int *first, *last; long depth; };
-    Frame stack[64];
-    int sp = 0;
-    stack[sp++] = Frame{first, last, 2 * lg};
-    while (sp > 0) {
-        Frame f = stack[--sp];
-        int *fl = f.last;
-        long depth = f.depth;
-        while (fl - f.first > 16) {
-            if (depth == 0) { c_heapsort(f.first, fl, c); break; }
-            --depth;
-            int *mid = f.first + (fl - f.first) / 2;
-            int *a = f.first + 1, *b = mid, *cc = fl - 1, *res = f.first, *pick;
-            if (c(*a, *b)) { if (c(*b, *cc)) pick = b; else if (c(*a, *cc)) pick = cc; else pick = a; }
-            else if (c(*a, *cc)) pick = a;
-            else if (c(*b, *cc)) pick = cc;
-            else pick = b;
-            { const int t = *res; *res = *pick; *pick = t; }
-            int *lo = f.first + 1, *hi = fl;
-            const int *pivot = f.first;
-            for (;;) {
-                while (c(*lo, *pivot)) ++lo;
-                --hi;
-                while (c(*pivot, *hi)) --hi;
-                if (!(lo < hi)) break;
-                const int t = *lo; *lo = *hi; *hi = t;
-                ++lo;
-            }
-            if (sp < 64) stack[sp++] = Frame{lo, fl, depth};
-            fl = lo;
-        }
-    }
-    if (last - first > 16) {
-        c_insertion_sort(first, first + 16, c);
-        for (int *i = first + 16; i != last; ++i) c_unguarded_linear_insert(i, c);
-    } else
-        c_insertion_sort(first, last, c);
-}
 
 // ctrl: [0] status (0 ok, 2 not triangular, 3 insufficient memory reserved), [1] final nnz
 __global__ void __launch_bounds__(64)
@@ -427,6 +330,11 @@ __global__ void k_fill_i32(int32_t *p, long count, int32_t v)
 int icholt_factor(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms)
 {
     const int32_t m = Atri.n;
+    const char *force_seq = getenv("ILUPP_ICHOLT_SEQUENTIAL");
+    if (!(force_seq && force_seq[0] == '1')) {
+        const int rc_df = icholt_factor_df(st, Atri, add_fill_in, threshold, L, kernel_ms);
+        if (rc_df != 1) return rc_df;          // 1 = outside the dataflow kernel's capacities
+    }
     long a = (long)Atri.nnz + (long)(add_fill_in > 0 ? add_fill_in : 0) * (long)m;     // IChol.hpp:85-87
     long b = (long)((double)Atri.nnz * 10.0);
     long reserved = a < b ? a : b;

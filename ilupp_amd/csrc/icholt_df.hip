@@ -1,0 +1,437 @@
+// ilupp_amd/csrc/icholt_df.hip -- ICholT (reference IChol.hpp:78-164, ILUC.hpp:31-63, dropping.hpp:8-34) as a
+// DATAFLOW computation over columns for gfx950: one wave per column, columns start as soon as everything that
+// reaches them has finished, bit-identical to the reference's strictly sequential column loop.
+//
+// Why this is not a level schedule.  The pattern of L depends on the values (top-k by magnitude, threshold), and a
+// column j is reached not only by the columns stored in row j but by every column whose PRE-drop working column
+// had row j (they all update the running diagonal D[j], IChol.hpp:135-141).  Nothing of this is known ahead.  What
+// IS known: every reach of column k on row i (k < i) has a cause that is visible earlier --
+//     (a) A(i,k) != 0, or
+//     (b) some finished column k' stores both rows k and i (k' < k < i): then column k will pull the tail of
+//         column k' and create/update its slot for row i (IChol.hpp:120-132).
+// So every row carries a counter `pending[i]` of announced-but-not-yet-executed reaches: it starts at the number of
+// entries left of the diagonal in row i of A (a); a finishing column k' adds, for every stored row i, the number of
+// stored rows between k' and i (b), and takes off one per entry it scattered/updated itself.  An unannounced reach
+// always has an announced, unfinished ancestor, so the counter reaches zero exactly once: when every column that
+// reaches i has finished.  That column then goes to the ready queue.  No symbolic bound, no speculation.
+//
+// Order-dependent arithmetic, reproduced exactly:
+//   * D[j] = ((0 - w_{k1,j}^2) - w_{k2,j}^2 ...) + A_jj in ascending column order: every reach leaves a 32-byte
+//     TOUCH record {k, value, ...} in row j's record list (dropped entries too); column j sorts them by k and sums.
+//   * The contributing columns are subtracted in the order of the reference's re-threaded linked list
+//     (ILUC.hpp:37-63: a column moves from the list of row t to the head of the list of its next stored row when
+//     column t has been processed; t itself is pushed first).  Traversal of list j = columns ordered by
+//     (previous stored row t DESCENDING, then REVERSE of their order in list t, t itself last).  Column t writes the
+//     position (`seq`) of each of its contributors into the touch record of that contributor's next stored row, so
+//     column j orders its contributors by (t desc, seq desc) -- no list is ever built.
+//   * The working column: slots in insertion order (A's column, then new rows in the order the contributors'
+//     tails bring them), every slot accumulated sequentially over the contributors, separate multiply/subtract;
+//     2-norm summed in slot order; candidates |w| > norm*tau; top-k by magnitude with std::sort's semantics (the
+//     kept SET only depends on the sort algorithm if the k-th and (k+1)-th magnitudes are equal: then one lane runs
+//     the libstdc++ algorithm, otherwise a parallel ranking); kept entries by increasing row.
+//
+// Columns land in fixed slabs (capacity = column length of A + add_fill_in, the top-k budget, IChol.hpp:144-145);
+// a compaction pass produces the CSC arrays.  Anything outside the kernel's LDS capacities (very long working
+// columns, more than T reaches per row, a dropped diagonal, add_fill_in < 0) makes the caller fall back to the
+// sequential kernel in ichol.hip, which is the reference loop verbatim.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "stdsort.h"
+
+namespace ilupp {
+
+static constexpr int kCtNE = 512;     // entries gathered per column: A's column + the contributors' tails
+static constexpr int kCtNS = 256;     // slots of the working column
+static constexpr int kCtTmax = 128;   // touch records per row (run-time T <= this)
+static constexpr int kCtQTail = 32;   // ctrl word of the ready queue's tail (own cache line)
+static constexpr unsigned kCtSpinLimit = 1u << 22;
+
+// ctrl: [0] next ticket, [2] error (1 = capacity exceeded -> sequential fallback, 2 = timeout), [3] malformed column,
+//       [32] ready-queue tail
+__global__ void k_ict_prep(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int32_t add,
+                           int32_t *__restrict__ cap, int32_t *pending, int32_t *ctrl)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int c0 = Aptr[j], c1 = Aptr[j + 1];
+    if (c0 >= c1 || Aidx[c0] != j) { atomicMin(&ctrl[3], j); cap[j] = 0; return; }     // IChol.hpp:105-107
+    cap[j] = (c1 - c0) + add;
+    for (int x = c0 + 1; x < c1; ++x) atomicAdd(&pending[Aidx[x]], 1);
+}
+
+__global__ void k_ict_seed(int32_t m, const int32_t *__restrict__ pending, int32_t *rq, int32_t *ctrl)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    if (pending[j] == 0) rq[atomicAdd(&ctrl[kCtQTail], 1)] = j;
+}
+
+__device__ __forceinline__ unsigned long long pack2(int lo, int hi)
+{
+    return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
+}
+
+__global__ void __launch_bounds__(64)
+k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
+            int32_t add, double tau, int32_t T, const int32_t *__restrict__ Loff,
+            int32_t *Lidx, double *Lval, int32_t *Llen,
+            int32_t *cnt, unsigned long long *rec, int32_t *pending, int32_t *rq, int32_t *ctrl)
+{
+    __shared__ int erow[kCtNE], eslot[kCtNE];
+    __shared__ double eval[kCtNE];
+    __shared__ int srow[kCtNS], scnt[kCtNS], srank[kCtNS], sridx[kCtNS], cand[kCtNS], crank[kCtNS], keptslot[kCtNS];
+    __shared__ double sval[kCtNS];
+    __shared__ int tk[kCtTmax], tx[kCtTmax], tt[kCtTmax], trem[kCtTmax], tnxt[kCtTmax], tseq[kCtTmax];
+    __shared__ double tv[kCtTmax], ordv[kCtTmax];
+    __shared__ int cx[kCtTmax], crem[kCtTmax], cbase[kCtTmax + 1], cnxt[kCtTmax];
+    __shared__ double cv[kCtTmax];
+    __shared__ double tie_mag[2];
+
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#define CT_FAIL(code) do { if (lane == 0) atomicCAS(&ctrl[2], 0, (code)); return; } while (0)
+
+    for (;;) {
+        int tkt = 0;
+        if (lane == 0) tkt = atomicAdd(&ctrl[0], 1);
+        tkt = __builtin_amdgcn_readfirstlane(tkt);
+        if (tkt >= m) break;
+        int j;
+        unsigned spins = 0;
+        for (;;) {
+            j = ld_agent_i32(&rq[tkt]);
+            if (j >= 0) break;
+            if ((++spins & 63u) == 0) {
+                if (ld_agent_i32(&ctrl[2]) != 0) return;
+                if (spins > kCtSpinLimit) CT_FAIL(2);
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        j = __builtin_amdgcn_readfirstlane(j);
+
+        const int c0 = __builtin_amdgcn_readfirstlane(Aptr[j]);
+        const int clen = __builtin_amdgcn_readfirstlane(Aptr[j + 1]) - c0;
+        const int capj = clen + add;
+        const int loff = __builtin_amdgcn_readfirstlane(Loff[j]);
+        const int nt = __builtin_amdgcn_readfirstlane(ld_agent_i32(&cnt[j]));
+        if (clen > kCtNS || nt > T) CT_FAIL(1);
+
+        // ---- the column of A (slots 0..clen-1, IChol.hpp:110-112) and the touch records of row j ----
+        for (int e = lane; e < clen; e += 64) { erow[e] = Aidx[c0 + e]; eval[e] = Aval[c0 + e]; eslot[e] = e; srow[e] = erow[e]; }
+        for (int q = lane; q < nt; q += 64) {
+            const unsigned long long *r = rec + ((size_t)j * T + q) * 4;
+            const unsigned long long w0 = ld_agent_u64(r), w1 = ld_agent_u64(r + 1), w2 = ld_agent_u64(r + 2), w3 = ld_agent_u64(r + 3);
+            tk[q] = (int)(unsigned)w0; tx[q] = (int)(unsigned)(w0 >> 32);
+            tt[q] = (int)(unsigned)w1; trem[q] = (int)(unsigned)(w1 >> 32);
+            tv[q] = __longlong_as_double((long long)w2);
+            tnxt[q] = (int)(unsigned)w3; tseq[q] = (int)(unsigned)(w3 >> 32);
+        }
+        __syncthreads();
+
+        // ---- D[j]: the squares of all reaches in ascending column order, then + A_jj  (:115, :139) ----
+        int nc = 0;
+        for (int q = lane; q < nt; q += 64) {
+            const int kq = tk[q];
+            int r = 0;
+            for (int q2 = 0; q2 < nt; ++q2) r += (tk[q2] < kq) ? 1 : 0;
+            ordv[r] = tv[q];
+        }
+        for (int q2 = 0; q2 < nt; ++q2) nc += (tx[q2] >= 0) ? 1 : 0;
+        nc = __builtin_amdgcn_readfirstlane(nc);
+        __syncthreads();
+        double D = 0.0;
+        for (int r = 0; r < nt; ++r) { const double v = ordv[r]; const double sq = v * v; D = D - sq; }
+        D = D + eval[0];
+        const double Ljj = sqrt(D);                                                  // :116
+
+        // ---- contributors in the reference's linked-list order: (previous stored row desc, seq desc) ----
+        for (int q = lane; q < nt; q += 64) {
+            if (tx[q] < 0) continue;
+            const int t0 = tt[q], s0 = tseq[q];
+            int p = 0;
+            for (int q2 = 0; q2 < nt; ++q2) {
+                if (tx[q2] < 0) continue;
+                const int t2 = tt[q2], s2 = tseq[q2];
+                p += (t2 > t0 || (t2 == t0 && s2 > s0)) ? 1 : 0;
+            }
+            cx[p] = tx[q]; crem[p] = trem[q]; cv[p] = tv[q]; cnxt[p] = tnxt[q];
+        }
+        __syncthreads();
+        for (int p = lane; p < nc; p += 64)
+            if (cnxt[p] >= 0) st_agent_i32(reinterpret_cast<int *>(rec + (size_t)cnxt[p] * 4 + 3) + 1, p + 1);
+        if (lane == 0) {
+            int s = 0;
+            for (int p = 0; p < nc; ++p) { cbase[p] = s; s += crem[p]; }
+            cbase[nc] = s;
+        }
+        __syncthreads();
+        const int net = __builtin_amdgcn_readfirstlane(cbase[nc]);
+        const int ne = clen + net;
+        if (ne > kCtNE) CT_FAIL(1);
+
+        // ---- tails of the contributing columns: entry e = (row, L_ik * L_jk)  (:122-131) ----
+        for (int e = lane; e < net; e += 64) {
+            int p = 0;
+            while (cbase[p + 1] <= e) ++p;
+            const int xx = cx[p] + 1 + (e - cbase[p]);
+            const int row = ld_agent_i32(&Lidx[xx]);
+            const double lv = ld_agent_f64(&Lval[xx]);
+            erow[clen + e] = row;
+            eval[clen + e] = lv * cv[p];
+        }
+        __syncthreads();
+
+        // ---- slots in insertion order: a row's slot is created by its first occurrence ----
+        int ns = clen;
+        for (int base = clen; base < ne; base += 64) {
+            const int e = base + lane;
+            bool first = false;
+            int fo = e;
+            if (e < ne) {
+                const int r = erow[e];
+                for (int e2 = 0; e2 < e; ++e2) if (erow[e2] == r) { fo = e2; break; }
+                first = fo == e;
+            }
+            const unsigned long long mask = __ballot(first);
+            if (e < ne) {
+                if (first) {
+                    const int s = ns + __popcll(mask & lt_mask);
+                    eslot[e] = s;
+                    if (s < kCtNS) srow[s] = erow[e];
+                } else
+                    eslot[e] = -1 - fo;
+            }
+            ns += __popcll(mask);
+        }
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        if (ns > kCtNS) CT_FAIL(1);
+        __syncthreads();
+        for (int e = clen + lane; e < ne; e += 64) { const int s = eslot[e]; if (s < 0) { const int s1 = eslot[-1 - s]; eslot[e] = s1; } }
+        __syncthreads();
+
+        // ---- accumulate every slot sequentially over the entries, scale by 1/L_jj  (:126-131, :135-141) ----
+        for (int s = lane; s < ns; s += 64) {
+            double v = s < clen ? eval[s] : 0.0;
+            int c = s < clen ? 1 : 0;
+            if (s == 0) v = Ljj;                                                   // :117
+            for (int e = clen; e < ne; ++e) if (eslot[e] == s) { v = v - eval[e]; ++c; }
+            if (s > 0) v = v / Ljj;
+            sval[s] = v; scnt[s] = c; srank[s] = -1;
+        }
+        __syncthreads();
+
+        // ---- threshold_and_drop(w, list, capj, tau, j, m)  (dropping.hpp:8-34) ----
+        double z = 0.0;
+        for (int s = 0; s < ns; ++s) { const double v = sval[s]; const double sq = v * v; z = z + sq; }
+        const double thr = sqrt(z) * tau;
+        int ncand = 0;
+        for (int base = 0; base < ns; base += 64) {
+            const int s = base + lane;
+            const bool is = s < ns && fabs(sval[s]) > thr;
+            const unsigned long long mask = __ballot(is);
+            if (is) cand[ncand + __popcll(mask & lt_mask)] = s;
+            ncand += __popcll(mask);
+        }
+        ncand = __builtin_amdgcn_readfirstlane(ncand);
+        __syncthreads();
+        int nk = ncand;
+        if (ncand > capj) {
+            nk = capj;
+            for (int c = lane; c < ncand; c += 64) {
+                const double a = fabs(sval[cand[c]]);
+                int r = 0;
+                for (int c2 = 0; c2 < ncand; ++c2) { const double a2 = fabs(sval[cand[c2]]); r += (a2 > a || (a2 == a && c2 < c)) ? 1 : 0; }
+                crank[c] = r;
+                if (r == capj - 1) tie_mag[0] = a;
+                if (r == capj) tie_mag[1] = a;
+            }
+            __syncthreads();
+            const bool tie = __builtin_amdgcn_readfirstlane((ncand > 16 && tie_mag[0] == tie_mag[1]) ? 1 : 0) != 0;
+            if (tie) {
+                // equal magnitudes across the cut: the kept set is whatever libstdc++'s introsort leaves in front
+                if (lane == 0) {
+                    c_sort_slots_by_abs_desc(cand, ncand, sval);
+                    for (int c = 0; c < capj; ++c) srank[cand[c]] = 0;
+                }
+            } else {
+                for (int c = lane; c < ncand; c += 64) if (crank[c] < capj) srank[cand[c]] = 0;
+            }
+        } else {
+            for (int c = lane; c < ncand; c += 64) srank[cand[c]] = 0;
+        }
+        __syncthreads();
+        // kept entries by increasing row (dropping.hpp:32-33); srank = position in the stored column
+        for (int s = lane; s < ns; s += 64) {
+            if (srank[s] < 0) continue;
+            const int r0 = srow[s];
+            int r = 0;
+            for (int s2 = 0; s2 < ns; ++s2) r += (srank[s2] >= 0 && srow[s2] < r0) ? 1 : 0;
+            crank[s] = r;                       // (crank is free again)
+            keptslot[r] = s;
+        }
+        __syncthreads();
+        for (int s = lane; s < ns; s += 64) if (srank[s] >= 0) srank[s] = crank[s];
+        __syncthreads();
+        // the reference assumes the diagonal leads the stored column (firstL = pointer+1, ILUC.hpp:43); a dropped
+        // diagonal (NaN column, tiny budget) is left to the sequential kernel
+        if (nk < 1 || __builtin_amdgcn_readfirstlane(srank[0]) != 0) CT_FAIL(1);
+
+        // ---- append  (sparse_implementation.h:3170-3186) ----
+        for (int s = lane; s < ns; s += 64)
+            if (srank[s] >= 0) { st_agent_i32(&Lidx[loff + srank[s]], srow[s]); st_agent_f64(&Lval[loff + srank[s]], sval[s]); }
+        if (lane == 0) Llen[j] = nk;
+
+        // ---- one touch record per sub-diagonal slot, in the record list of its row ----
+        bool ovf = false;
+        for (int s = 1 + lane; s < ns; s += 64) {
+            const int i = srow[s];
+            const int pos = atomicAdd(&cnt[i], 1);
+            if (pos >= T) ovf = true;
+            sridx[s] = i * T + pos;
+        }
+        if (__ballot(ovf) != 0ull) CT_FAIL(1);
+        __syncthreads();
+        for (int s = 1 + lane; s < ns; s += 64) {
+            const int r = srank[s];
+            const bool stored = r >= 0;
+            const int x = stored ? loff + r : -1;
+            const int tprev = stored ? srow[keptslot[r - 1]] : -1;
+            const int rem = stored ? nk - 1 - r : 0;
+            const int nxt = (stored && r + 1 < nk) ? sridx[keptslot[r + 1]] : -1;
+            unsigned long long *rp = rec + (size_t)sridx[s] * 4;
+            st_agent_u64(rp, pack2(j, x));
+            st_agent_u64(rp + 1, pack2(tprev, rem));
+            st_agent_u64(rp + 2, (unsigned long long)__double_as_longlong(sval[s]));
+            st_agent_u64(rp + 3, pack2(nxt, 0));
+        }
+        drain_stores();
+        // ---- announce / discharge reaches; rows whose last reach this was become ready ----
+        for (int s = 1 + lane; s < ns; s += 64) {
+            const int i = srow[s];
+            const int r = srank[s];
+            const int delta = (r >= 0 ? r - 1 : 0) - scnt[s];
+            if (delta != 0) {
+                const int nv = atomicAdd(&pending[i], delta) + delta;
+                if (nv == 0) { const int pos = atomicAdd(&ctrl[kCtQTail], 1); st_agent_i32(&rq[pos], i); }
+            }
+        }
+        __syncthreads();
+    }
+#undef CT_FAIL
+}
+
+__global__ void k_ict_compact(int32_t m, const int32_t *__restrict__ Loff, const int32_t *__restrict__ Llen,
+                              const int32_t *__restrict__ Lptr, const int32_t *__restrict__ sidx, const double *__restrict__ sval,
+                              int32_t *__restrict__ oidx, double *__restrict__ oval)
+{
+    const int j = blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
+    if (j >= m) return;
+    const int src = Loff[j], dst = Lptr[j], len = Llen[j];
+    for (int q = threadIdx.x % 8; q < len; q += 8) { oidx[dst + q] = sidx[src + q]; oval[dst + q] = sval[src + q]; }
+}
+
+// returns ILUPP_OK / an error of the reference / +1 = "not handled here, run the sequential kernel"
+int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms)
+{
+    const int32_t m = Atri.n;
+    if (add_fill_in < 0 || m < 1) return 1;
+    const long slab = (long)Atri.nnz + (long)add_fill_in * (long)m;
+    if (slab > 0x7fffffffL) return 1;
+    long a = slab;                                                      // IChol.hpp:85-87
+    long b = (long)((double)Atri.nnz * 10.0);
+    long reserved = a < b ? a : b;
+    if (reserved > 0x7fffffffL) reserved = 0x7fffffffL;
+
+    // touch-record capacity per row: the number of reaches of a row is about the length of a pre-drop column
+    const long avg = Atri.nnz / m + 1;
+    int T = 16;
+    while (T < 4 * (avg + add_fill_in) && T < kCtTmax) T *= 2;
+    while (T > 16 && ((long)m * T > 0x7fffffffL || (size_t)m * T * 32 > ((size_t)96 << 30))) T /= 2;
+    if ((long)m * T > 0x7fffffffL) return 1;
+
+    int32_t *cap, *Loff, *Lidx, *Llen, *cnt, *pending, *rq, *ctrl, *Lptr;
+    double *Lval;
+    unsigned long long *rec;
+    ILUPP_HIP(pool_malloc(&cap, sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(pool_malloc(&Loff, sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(pool_malloc(&Llen, sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(pool_malloc(&Lptr, sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(pool_malloc(&Lidx, sizeof(int32_t) * (size_t)(slab > 0 ? slab : 1)));
+    ILUPP_HIP(pool_malloc(&Lval, sizeof(double) * (size_t)(slab > 0 ? slab : 1)));
+    ILUPP_HIP(pool_malloc(&cnt, sizeof(int32_t) * (size_t)m));
+    ILUPP_HIP(pool_malloc(&pending, sizeof(int32_t) * (size_t)m));
+    ILUPP_HIP(pool_malloc(&rq, sizeof(int32_t) * (size_t)m));
+    ILUPP_HIP(pool_malloc(&ctrl, 256));
+    if (pool_malloc(&rec, (size_t)m * T * 32) != hipSuccess) {
+        (void)hipGetLastError();
+        for (void *q : {(void *)cap, (void *)Loff, (void *)Llen, (void *)Lptr, (void *)Lidx, (void *)Lval, (void *)cnt, (void *)pending,
+                        (void *)rq, (void *)ctrl})
+            ILUPP_HIP(pool_free(q));
+        return 1;
+    }
+    ILUPP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)m, st));
+    ILUPP_HIP(hipMemsetAsync(pending, 0, sizeof(int32_t) * (size_t)m, st));
+    ILUPP_HIP(hipMemsetAsync(Llen, 0, sizeof(int32_t) * (size_t)(m + 1), st));
+    ILUPP_HIP(hipMemsetAsync(rq, 0xff, sizeof(int32_t) * (size_t)m, st));
+    ILUPP_HIP(hipMemsetAsync(ctrl, 0, 256, st));
+    const int32_t big = 0x7fffffff;
+    ILUPP_HIP(hipMemcpyAsync(ctrl + 3, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const int gb = (m + 255) / 256;
+    hipLaunchKernelGGL(k_ict_prep, dim3(gb), dim3(256), 0, st, m, Atri.ptr, Atri.idx, add_fill_in, cap, pending, ctrl);
+    {
+        size_t tb = 0;
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cap, Loff, m, st));
+        void *tmp;
+        ILUPP_HIP(pool_malloc(&tmp, tb > 0 ? tb : 1));
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cap, Loff, m, st));
+        ILUPP_HIP(pool_free(tmp));
+    }
+    hipLaunchKernelGGL(k_ict_seed, dim3(gb), dim3(256), 0, st, m, pending, rq, ctrl);
+    hipEvent_t e0, e1;
+    ILUPP_HIP(hipEventCreate(&e0));
+    ILUPP_HIP(hipEventCreate(&e1));
+    ILUPP_HIP(hipEventRecord(e0, st));
+    int waves = device_cu_count() * 6;
+    if (waves > m) waves = m;
+    hipLaunchKernelGGL(k_icholt_df, dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in, threshold, T, Loff,
+                       Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
+    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipGetLastError());
+    int32_t h[4];
+    ILUPP_HIP(hipMemcpyAsync(h, ctrl, 16, hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    ILUPP_HIP(hipEventDestroy(e0));
+    ILUPP_HIP(hipEventDestroy(e1));
+    int rc = ILUPP_OK;
+    if (h[3] != big) rc = ILUPP_ERR_NOT_TRIANGULAR;
+    else if (h[2] != 0) rc = 1;
+    if (rc == ILUPP_OK) {
+        size_t tb = 0;
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, Llen, Lptr, m + 1, st));
+        void *tmp;
+        ILUPP_HIP(pool_malloc(&tmp, tb > 0 ? tb : 1));
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, Llen, Lptr, m + 1, st));
+        ILUPP_HIP(pool_free(tmp));
+        int32_t nnz = 0;
+        ILUPP_HIP(hipMemcpyAsync(&nnz, Lptr + m, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        if ((long)nnz > reserved) rc = ILUPP_ERR_MEMORY;             // append_row's capacity check, :3178-3179
+        else {
+            L->n = m; L->nnz = nnz; L->is_csr = false; L->owns = true;
+            L->ptr = Lptr;
+            ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+            ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+            hipLaunchKernelGGL(k_ict_compact, dim3((m + 31) / 32), dim3(256), 0, st, m, Loff, Llen, Lptr, Lidx, Lval, L->idx, L->val);
+            ILUPP_HIP(hipStreamSynchronize(st));
+        }
+    }
+    if (rc != ILUPP_OK) ILUPP_HIP(pool_free(Lptr));
+    for (void *q : {(void *)cap, (void *)Loff, (void *)Llen, (void *)Lidx, (void *)Lval, (void *)cnt, (void *)pending, (void *)rq,
+                    (void *)ctrl, (void *)rec})
+        ILUPP_HIP(pool_free(q));
+    return rc;
+}
+
+}  // namespace ilupp
