@@ -231,6 +231,10 @@ int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, do
 int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U,
                 int32_t *err_row, float *kernel_ms);
 
+// ilut_wp.hip (returns 1 when a row is outside its capacities: the caller runs k_ilut_rows)
+int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
+                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms);
+
 // sptrsv.hip
 enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRST_DESC = 2 };
 int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,

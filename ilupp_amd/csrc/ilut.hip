@@ -478,6 +478,29 @@ int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double thr
     ILUPP_HIP(pool_malloc(&Ulen, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&done, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&ctrl, 16));
+    // the wave-parallel kernel (ilut_wp.hip) first; k_ilut_rows below is the any-capacity fallback and the A/B check
+    // (ILUPP_ILUT_SEQUENTIAL=1)
+    {
+        const char *force_seq = getenv("ILUPP_ILUT_SEQUENTIAL");
+        if (!(force_seq && force_seq[0] == '1')) {
+            const int rw = ilut_rows_wp(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
+            if (rw != 1) {
+                int32_t hw[4] = {0, 0, 0, 0};
+                ILUPP_HIP(hipMemcpyAsync(hw, ctrl, 16, hipMemcpyDeviceToHost, st));
+                ILUPP_HIP(hipStreamSynchronize(st));
+                int rc = rw;
+                if (rc == ILUPP_OK && hw[2] != 0x7fffffff) { rc = ILUPP_ERR_ZERO_PIVOT; if (err_row) *err_row = hw[2]; }
+                if (rc == ILUPP_OK) {
+                    compact_slab(st, n, p, Llen, Lri, Lrv, L);
+                    compact_slab(st, n, p, Ulen, Uri, Urv, U);
+                    ILUPP_HIP(hipStreamSynchronize(st));
+                }
+                for (void *q : {(void *)Lri, (void *)Uri, (void *)Lrv, (void *)Urv, (void *)Llen, (void *)Ulen, (void *)done, (void *)ctrl})
+                    ILUPP_HIP(pool_free(q));
+                return rc;
+            }
+        }
+    }
     IlutWork wk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     int32_t h[4] = {0, 0, 0, 0};
     hipEvent_t e0, e1;

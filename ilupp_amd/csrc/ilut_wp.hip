@@ -1,0 +1,429 @@
+// ilupp_amd/csrc/ilut_wp.hip -- ILUT(p, tau) rows computed by a whole wave (gfx950).
+//
+// Same function as k_ilut_rows in ilut.hip (reference ILUT_heap, ILUT.hpp:199-278; threshold_and_drop,
+// dropping.hpp:8-34) and the same claiming discipline -- every wave takes the next row from an atomic counter, so a
+// row only waits on rows claimed earlier -- but the row itself is no longer the reference's pointer chasing executed
+// redundantly by 64 lanes.  The working row is kept as three insertion-ordered pieces, which is all the reference's
+// results depend on (its 2-norms and candidate lists run over the slots of one index range in insertion order,
+// sparse_implementation.h:1087-1093, dropping.hpp:14-21):
+//   * POOL: entries left of the diagonal that have not been eliminated yet {column, value, seq}; seq numbers the
+//     left-part insertions (A's entries in CSR order, then fill in creation order);
+//   * KEPT: the multipliers {column, w_k / U_kk, seq} of the eliminated columns; entries removed by the stage-1
+//     drop (ILUT.hpp:244-245) or found exactly zero (:239-240) are simply forgotten -- the reference leaves a zero
+//     slot behind, which adds 0.0 to the norm and can never be a candidate (strict >);
+//   * U slots: the entries right of the diagonal in insertion order (they are never removed); the diagonal is a scalar.
+// What the reference does with a binary heap -- "next column in ascending order" -- is a wave-wide minimum over the
+// pool (DPP reduction); what it does with an n-long occupancy array -- "slot of column c" -- is a wave-wide search of
+// the pool and the U slots for the (sorted) columns of the U row being subtracted, every match updated by the lane
+// that found it, the misses appended in row order (= the reference's insertion order) by ballot/prefix-sum.
+// A finished U row is fetched in ONE memory round trip: rows live in fixed-pitch slabs initialised to sentinels
+// (index -1, value kSentinel, length 0); the writer stores every datum write-through, the reader validates every
+// datum it needs and retries otherwise (write-once data: a set of individually fresh values is consistent).
+// Dropping: norm in insertion order, candidates by strict >, the p-1 largest by repeated wave-wide maximum with
+// (magnitude desc, position asc) order -- equal to std::sort's result unless the cut falls between equal magnitudes
+// among more than 16 candidates; then one lane runs libstdc++'s algorithm (stdsort.h) on the candidate list.
+// The pieces live in LDS; a row that outgrows them is started over with the wave's global-memory arrays (sc1
+// accesses, 64 K entries); a row that outgrows those makes the host fall back to k_ilut_rows.
+#include "common.h"
+#include "stdsort.h"
+
+namespace ilupp {
+
+static constexpr int kWpCapU = 2048, kWpCapL = 768, kWpCapK = 512, kWpSel = 512;
+static constexpr int kWpGCapU = 1 << 16, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;
+#ifndef ILUT_SPIN
+#define ILUT_SPIN (1u << 24)
+#endif
+
+struct WpArrays {
+    int *ucol; double *uval; int capU;
+    int *lcol; double *lval; int *lseq; int capL;
+    int *kcol; double *kval; int *kseq; int capK;
+};
+
+// accessors of the working-row pieces: LDS (plain) or the wave's global arrays (agent scope: never through the L1)
+template <bool G> struct WpAcc {
+    static __device__ __forceinline__ int ldi(const int *p) { if constexpr (G) return ld_agent_i32(p); else return *p; }
+    static __device__ __forceinline__ double ldd(const double *p) { if constexpr (G) return ld_agent_f64(p); else return *p; }
+    static __device__ __forceinline__ void sti(int *p, int v) { if constexpr (G) st_agent_i32(p, v); else *p = v; }
+    static __device__ __forceinline__ void std_(double *p, double v) { if constexpr (G) st_agent_f64(p, v); else *p = v; }
+    // cross-lane hand-over inside the wave: LDS is in order per wave; global stores must have landed
+    static __device__ __forceinline__ void sync() { if constexpr (G) __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
+};
+
+template <int CTRL, int RM, int BM> __device__ __forceinline__ unsigned wp_dpp(unsigned identity, unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, RM, BM, false);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = min(v, wp_dpp<0x111, 0xf, 0xf>(~0u, v));    // row_shr:1
+    v = min(v, wp_dpp<0x112, 0xf, 0xf>(~0u, v));    // row_shr:2
+    v = min(v, wp_dpp<0x114, 0xf, 0xe>(~0u, v));    // row_shr:4
+    v = min(v, wp_dpp<0x118, 0xf, 0xc>(~0u, v));    // row_shr:8
+    v = min(v, wp_dpp<0x142, 0xa, 0xf>(~0u, v));    // row_bcast:15
+    v = min(v, wp_dpp<0x143, 0xc, 0xf>(~0u, v));    // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    v = max(v, wp_dpp<0x111, 0xf, 0xf>(0u, v));
+    v = max(v, wp_dpp<0x112, 0xf, 0xf>(0u, v));
+    v = max(v, wp_dpp<0x114, 0xf, 0xe>(0u, v));
+    v = max(v, wp_dpp<0x118, 0xf, 0xc>(0u, v));
+    v = max(v, wp_dpp<0x142, 0xa, 0xf>(0u, v));
+    v = max(v, wp_dpp<0x143, 0xc, 0xf>(0u, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+    const unsigned h = (unsigned)(v >> 32);
+    const unsigned gh = wave_max_u32(h);
+    const unsigned gl = wave_max_u32(h == gh ? (unsigned)v : 0u);
+    return ((unsigned long long)gh << 32) | gl;
+}
+__device__ __forceinline__ double wave_bcast_f64(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// threshold_and_drop over one piece (dropping.hpp:8-34): cols/vals[0..cnt) in insertion order; writes the kept entries
+// by increasing column to out_idx/out_val (STORE_AGENT: write-through, sentinel-safe) and returns their number
+template <bool G, bool STORE_AGENT>
+__device__ __forceinline__ int wp_select(const int lane, const int *cols, const double *vals, const int cnt, const int nkeep,
+                                         const double tau, int *selq, int *gscratch, int *out_idx, double *out_val)
+{
+    using A = WpAcc<G>;
+    if (nkeep <= 0) return 0;                                                 // dropping.hpp:11-12
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    double z = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < cnt; ++q) { const double v = A::ldd(&vals[q]); const double sq = v * v; z = z + sq; }
+    const double thr = sqrt(z) * tau;
+    int ncand = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int q = base + lane;
+        const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
+        ncand += __popcll(__ballot(is));
+    }
+    int nsel;
+    if (ncand <= nkeep) {
+        nsel = 0;
+        for (int base = 0; base < cnt; base += 64) {
+            const int q = base + lane;
+            const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
+            const unsigned long long m = __ballot(is);
+            if (is) selq[nsel + __popcll(m & lt)] = q;
+            nsel += __popcll(m);
+        }
+    } else {
+        unsigned long long pm = ~0ull;
+        int pp = -1;
+        bool tie = false;
+        for (int t = 0; t <= nkeep; ++t) {          // the extra round finds the first entry NOT kept (tie test)
+            unsigned long long bm = 0ull;
+            unsigned bq = 0x7fffffffu;
+            for (int q = lane; q < cnt; q += 64) {
+                const double a = fabs(A::ldd(&vals[q]));
+                if (!(a > thr)) continue;
+                const unsigned long long mb = (unsigned long long)__double_as_longlong(a);
+                const bool after = mb < pm || (mb == pm && q > pp);
+                if (after && mb > bm) { bm = mb; bq = (unsigned)q; }
+            }
+            const unsigned long long gm = wave_max_u64(bm);
+            const unsigned gq = wave_min_u32(bm == gm ? bq : 0x7fffffffu);
+            if (t < nkeep) { if (lane == 0) selq[t] = (int)gq; }
+            else tie = gm == pm;
+            pm = gm; pp = (int)gq;
+        }
+        nsel = nkeep;
+        if (tie && ncand > 16) {
+            // equal magnitudes across the cut: the kept set is what libstdc++'s introsort leaves in front (stdsort.h)
+            int c = 0;
+            for (int base = 0; base < cnt; base += 64) {
+                const int q = base + lane;
+                const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
+                const unsigned long long m = __ballot(is);
+                if (is) st_agent_i32(&gscratch[c + __popcll(m & lt)], q);
+                c += __popcll(m);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane == 0) {
+                c_sort_slots_by_abs_desc(gscratch, ncand, vals);
+                for (int t = 0; t < nkeep; ++t) selq[t] = gscratch[t];
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // by increasing column (dropping.hpp:32-33; unique keys)
+    for (int t = lane; t < nsel; t += 64) {
+        const int q = selq[t];
+        const int c = A::ldi(&cols[q]);
+        int r = 0;
+        for (int t2 = 0; t2 < nsel; ++t2) r += (A::ldi(&cols[selq[t2]]) < c) ? 1 : 0;
+        double v = A::ldd(&vals[q]);
+        if constexpr (STORE_AGENT) {
+            if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN);
+            st_agent_f64(&out_val[r], v);
+            st_agent_i32(&out_idx[r], c);
+        } else {
+            out_val[r] = v;
+            out_idx[r] = c;
+        }
+    }
+    return nsel;
+}
+
+// one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout
+template <bool G>
+__device__ __forceinline__ int wp_row(const int lane, const int i, const int n, const int p, const double tau,
+                                      const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
+                                      int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
+                                      int32_t *Urow_idx, double *Urow_val, int32_t *Ulen,
+                                      const WpArrays w, int *bcol, double *bpr, int *bfound, int *selq, int *gscratch, int32_t *ctrl)
+{
+    using A = WpAcc<G>;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nL = 0, nU = 0, nK = 0, seq = 0;
+    double wdiag = 0.0;
+    // (2.) scatter the row (ILUT.hpp:222-231)
+    const int a0 = Aptr[i], a1 = Aptr[i + 1];
+    for (int base = a0; base < a1; base += 64) {
+        const int q = base + lane;
+        const bool valid = q < a1;
+        const int c = valid ? Aidx[q] : 0x7fffffff;
+        const double v = valid ? Aval[q] : 0.0;
+        const bool isL = valid && c < i, isU = valid && c > i, isD = valid && c == i;
+        const unsigned long long mL = __ballot(isL), mU = __ballot(isU), mD = __ballot(isD);
+        if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) return 1;
+        if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
+        if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], v); }
+        if (mD != 0ull) wdiag = wave_bcast_f64(v, __ffsll((long long)mD) - 1);
+        nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
+    }
+    A::sync();
+    double thr1;
+    {
+        double z = 0.0;
+        for (int q = 0; q < nL; ++q) { const double v = A::ldd(&w.lval[q]); const double sq = v * v; z = z + sq; }
+        thr1 = tau * sqrt(z);
+    }
+    // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
+    for (;;) {
+        unsigned best = 0x7fffffffu;
+        int bq = -1;
+        for (int q = lane; q < nL; q += 64) { const unsigned c = (unsigned)A::ldi(&w.lcol[q]); if (c < best) { best = c; bq = q; } }
+        const unsigned g = wave_min_u32(best);
+        if (g == 0x7fffffffu) break;
+        const unsigned long long who = __ballot(best == g);
+        const int qs = __builtin_amdgcn_readlane(bq, __ffsll((long long)who) - 1);
+        const int k = (int)g;
+        const double wkv = A::ldd(&w.lval[qs]);
+        const int sk = A::ldi(&w.lseq[qs]);
+        const int last = nL - 1;
+        int mc = 0, ms = 0; double mv = 0.0;
+        if (qs != last) { mc = A::ldi(&w.lcol[last]); mv = A::ldd(&w.lval[last]); ms = A::ldi(&w.lseq[last]); }
+        A::sync();
+        if (lane == 0 && qs != last) { A::sti(&w.lcol[qs], mc); A::std_(&w.lval[qs], mv); A::sti(&w.lseq[qs], ms); }
+        nL = last;
+        A::sync();
+        if (wkv == 0.0) continue;                                            // ILUT.hpp:239-240
+        if (fabs(wkv) < thr1) continue;                                      // stage-1 drop, :244-245
+        // row k of U, validated against the sentinels
+        const size_t ub = (size_t)k * p;
+        int ul, c0;
+        unsigned long long v0;
+        unsigned spins = 0;
+        for (;;) {
+            ul = ld_agent_i32(&Ulen[k]);
+            const bool mine = lane < p;
+            c0 = mine ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
+            v0 = mine ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
+            const bool bad = ul <= 0 || (lane < ul && (c0 < 0 || v0 == kSentinel));
+            if (__ballot(bad) == 0ull) break;
+            if (++spins > ILUT_SPIN) return 2;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        ul = __builtin_amdgcn_readfirstlane(ul);
+        const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
+        const double m = wkv / ud;                                           // :249
+        if (nK >= w.capK) return 1;
+        if (lane == 0) { A::sti(&w.kcol[nK], k); A::std_(&w.kval[nK], m); A::sti(&w.kseq[nK], sk); }
+        ++nK;
+        for (int base = 0; base < ul; base += 64) {                          // w -= m * U[k, j>k]  (:252-253)
+            const int j = base + lane;
+            int c = c0;
+            unsigned long long vb = v0;
+            if (base > 0) {
+                unsigned sp2 = 0;
+                for (;;) {
+                    c = j < ul ? ld_agent_i32(&Urow_idx[ub + j]) : 0;
+                    vb = j < ul ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + j])) : 0ull;
+                    const bool bad = j < ul && (c < 0 || vb == kSentinel);
+                    if (__ballot(bad) == 0ull) break;
+                    if (++sp2 > ILUT_SPIN) return 2;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const bool valid = j < ul && j >= 1;
+            const double pr = m * __longlong_as_double((long long)vb);
+            const int cnt = ul - base < 64 ? ul - base : 64;
+            bcol[lane] = j < ul ? c : 0x7fffffff;
+            bpr[lane] = pr;
+            bfound[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            const int bmin = bcol[0], bmax = bcol[cnt - 1];
+            for (int q = lane; q < nL; q += 64) {
+                const int c2 = A::ldi(&w.lcol[q]);
+                if (c2 >= bmin && c2 <= bmax) {
+                    int lo = 0, hi = cnt - 1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (bcol[mid] < c2) lo = mid + 1; else hi = mid; }
+                    if (bcol[lo] == c2) { const double o = A::ldd(&w.lval[q]); A::std_(&w.lval[q], o - bpr[lo]); bfound[lo] = 1; }
+                }
+            }
+            for (int q = lane; q < nU; q += 64) {
+                const int c2 = A::ldi(&w.ucol[q]);
+                if (c2 >= bmin && c2 <= bmax) {
+                    int lo = 0, hi = cnt - 1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (bcol[mid] < c2) lo = mid + 1; else hi = mid; }
+                    if (bcol[lo] == c2) { const double o = A::ldd(&w.uval[q]); A::std_(&w.uval[q], o - bpr[lo]); bfound[lo] = 1; }
+                }
+            }
+            const unsigned long long md = __ballot(valid && c == i);
+            if (md != 0ull) wdiag = wdiag - wave_bcast_f64(pr, __ffsll((long long)md) - 1);
+            A::sync();
+            const bool nf = valid && c != i && bfound[lane] == 0;
+            const bool isL = nf && c < i, isU = nf && c > i;
+            const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
+            if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) return 1;
+            if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], 0.0 - pr); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
+            if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
+            nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
+            A::sync();
+        }
+    }
+    // (10.) dropping (ILUT.hpp:259,261): the multipliers back in insertion order, then both pieces
+    for (int q = lane; q < nK; q += 64) {
+        const int s = A::ldi(&w.kseq[q]);
+        int r = 0;
+        for (int q2 = 0; q2 < nK; ++q2) r += (A::ldi(&w.kseq[q2]) < s) ? 1 : 0;
+        A::sti(&w.lcol[r], A::ldi(&w.kcol[q]));
+        A::std_(&w.lval[r], A::ldd(&w.kval[q]));
+    }
+    A::sync();
+    const size_t lb = (size_t)i * p;
+    // (11.) L row = kept entries then (i, 1.0)
+    const int nLk = wp_select<G, false>(lane, w.lcol, w.lval, nK, p - 1, tau, selq, gscratch, Lrow_idx + lb, Lrow_val + lb);
+    if (lane == 0) { Lrow_idx[lb + nLk] = i; Lrow_val[lb + nLk] = 1.0; Llen[i] = nLk + 1; }
+    A::sync();
+    // (12.) U row = (i, w[i]) then kept entries; every datum write-through, the length last is not required
+    const int nUk = wp_select<G, true>(lane, w.ucol, w.uval, nU, p - 1, tau, selq, gscratch, Urow_idx + lb + 1, Urow_val + lb + 1);
+    if (lane == 0) {
+        double piv = wdiag;
+        if (piv == 0.0) atomicMin(&ctrl[2], i);                                  // ILUT.hpp:269-270 (reported after the sweep)
+        if ((unsigned long long)__double_as_longlong(piv) == kSentinel) piv = __longlong_as_double((long long)kCanonNaN);
+        st_agent_f64(&Urow_val[lb], piv);
+        st_agent_i32(&Urow_idx[lb], i);
+        st_agent_i32(&Ulen[i], nUk + 1);
+    }
+    A::sync();
+    return 0;
+}
+
+// ctrl: [0] next row, [1] error (1 timeout, 3 capacity -> the host runs k_ilut_rows instead), [2] smallest row with a zero pivot
+__global__ void __launch_bounds__(64)
+k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
+               int32_t p, double tau, WpArrays gw, int *gscratch_all,
+               int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
+               int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl)
+{
+    __shared__ int s_ucol[kWpCapU], s_lcol[kWpCapL], s_lseq[kWpCapL], s_kcol[kWpCapK], s_kseq[kWpCapK], s_selq[kWpSel];
+    __shared__ double s_uval[kWpCapU], s_lval[kWpCapL], s_kval[kWpCapK];
+    __shared__ int bcol[64], bfound[64];
+    __shared__ double bpr[64];
+    const int lane = threadIdx.x;
+    const size_t wv = blockIdx.x;
+    const WpArrays lw = {s_ucol, s_uval, kWpCapU, s_lcol, s_lval, s_lseq, kWpCapL, s_kcol, s_kval, s_kseq, kWpCapK};
+    WpArrays g = gw;
+    g.ucol += wv * (size_t)gw.capU; g.uval += wv * (size_t)gw.capU;
+    g.lcol += wv * (size_t)gw.capL; g.lval += wv * (size_t)gw.capL; g.lseq += wv * (size_t)gw.capL;
+    g.kcol += wv * (size_t)gw.capK; g.kval += wv * (size_t)gw.capK; g.kseq += wv * (size_t)gw.capK;
+    int *gscratch = gscratch_all + wv * (size_t)gw.capU;
+    for (;;) {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(&ctrl[0], 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= n) break;
+        int rc = wp_row<false>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+                               lw, bcol, bpr, bfound, s_selq, gscratch, ctrl);
+        rc = __builtin_amdgcn_readfirstlane(rc);
+        if (rc == 1) {
+            rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+                              g, bcol, bpr, bfound, s_selq, gscratch, ctrl);
+            rc = __builtin_amdgcn_readfirstlane(rc);
+        }
+        if (rc != 0) {
+            // give up: publish a poisoned row so that nobody waits for it, and report
+            if (lane == 0) {
+                atomicMax(&ctrl[1], rc == 1 ? 3 : 1);
+                st_agent_f64(&Urow_val[(size_t)i * p], 1.0);
+                st_agent_i32(&Urow_idx[(size_t)i * p], i);
+                st_agent_i32(&Ulen[i], 1);
+                Llen[i] = 0;
+            }
+        }
+    }
+}
+
+// returns 0 = rows computed (ctrl holds zero-pivot info), 1 = not handled (run k_ilut_rows), ILUPP_ERR_TIMEOUT
+int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
+                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms)
+{
+    const int32_t n = A.n;
+    if (p - 1 >= kWpSel) return 1;
+    const size_t slab = (size_t)n * p;
+    int workers = device_cu_count() * 3;
+    if (workers > n) workers = n;
+    WpArrays g = {nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
+    int *gscratch = nullptr;
+    ILUPP_HIP(pool_malloc(&g.ucol, sizeof(int) * (size_t)workers * g.capU));
+    ILUPP_HIP(pool_malloc(&g.uval, sizeof(double) * (size_t)workers * g.capU));
+    ILUPP_HIP(pool_malloc(&g.lcol, sizeof(int) * (size_t)workers * g.capL));
+    ILUPP_HIP(pool_malloc(&g.lval, sizeof(double) * (size_t)workers * g.capL));
+    ILUPP_HIP(pool_malloc(&g.lseq, sizeof(int) * (size_t)workers * g.capL));
+    ILUPP_HIP(pool_malloc(&g.kcol, sizeof(int) * (size_t)workers * g.capK));
+    ILUPP_HIP(pool_malloc(&g.kval, sizeof(double) * (size_t)workers * g.capK));
+    ILUPP_HIP(pool_malloc(&g.kseq, sizeof(int) * (size_t)workers * g.capK));
+    ILUPP_HIP(pool_malloc(&gscratch, sizeof(int) * (size_t)workers * g.capU));
+    ILUPP_HIP(hipMemsetAsync(Uri, 0xff, sizeof(int32_t) * slab, st));
+    fill_u64(st, reinterpret_cast<unsigned long long *>(Urv), (int64_t)slab, kSentinel);
+    ILUPP_HIP(hipMemsetAsync(Ulen, 0, sizeof(int32_t) * (size_t)n, st));
+    const int32_t init[4] = {0, 0, 0x7fffffff, 0};
+    ILUPP_HIP(hipMemcpyAsync(ctrl, init, 16, hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1;
+    ILUPP_HIP(hipEventCreate(&e0));
+    ILUPP_HIP(hipEventCreate(&e1));
+    ILUPP_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_ilut_rows_wp, dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
+                       Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipGetLastError());
+    int32_t h[4];
+    ILUPP_HIP(hipMemcpyAsync(h, ctrl, 16, hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    ILUPP_HIP(hipEventDestroy(e0));
+    ILUPP_HIP(hipEventDestroy(e1));
+    for (void *q : {(void *)g.ucol, (void *)g.uval, (void *)g.lcol, (void *)g.lval, (void *)g.lseq, (void *)g.kcol, (void *)g.kval,
+                    (void *)g.kseq, (void *)gscratch})
+        ILUPP_HIP(pool_free(q));
+    if (h[1] == 3) return 1;
+    if (h[1] == 1) return ILUPP_ERR_TIMEOUT;
+    return 0;
+}
+
+}  // namespace ilupp
