@@ -22,17 +22,28 @@
 // Dropping: norm in insertion order, candidates by strict >, the p-1 largest by repeated wave-wide maximum with
 // (magnitude desc, position asc) order -- equal to std::sort's result unless the cut falls between equal magnitudes
 // among more than 16 candidates; then one lane runs libstdc++'s algorithm (stdsort.h) on the candidate list.
-// The pieces live in LDS; a row that outgrows them is started over with the wave's global-memory arrays (sc1
-// accesses, 64 K entries); a row that outgrows those makes the host fall back to k_ilut_rows.
+// The pieces live in LDS; a row that outgrows them is started over with the wave's global-memory arrays (64 K
+// entries, private to the wave); a row that outgrows those makes the host fall back to k_ilut_rows.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "stdsort.h"
 
 namespace ilupp {
 
-static constexpr int kWpCapU = 2048, kWpCapL = 768, kWpCapK = 512, kWpSel = 512;
+static constexpr int kWpCapU = 1536, kWpCapL = 1408, kWpCapK = 512, kWpSel = 512;
 static constexpr int kWpGCapU = 1 << 16, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;
 #ifndef ILUT_SPIN
 #define ILUT_SPIN (1u << 24)
+#endif
+
+#ifdef ILUT_PROFILE
+#define WP_T(var) const long long var = clock64()
+#define WP_ACC(slot, t0, t1) do { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + (slot), (unsigned long long)((t1) - (t0))); } while (0)
+#else
+#define WP_T(var)
+#define WP_ACC(slot, t0, t1)
 #endif
 
 struct WpArrays {
@@ -41,12 +52,13 @@ struct WpArrays {
     int *kcol; double *kval; int *kseq; int capK;
 };
 
-// accessors of the working-row pieces: LDS (plain) or the wave's global arrays (agent scope: never through the L1)
+// accessors of the working-row pieces: LDS, or the wave's PRIVATE global arrays.  Those are only ever touched by this
+// wave (one CU, one L1), so plain accesses are coherent once the stores have been acknowledged (s_waitcnt in sync()).
 template <bool G> struct WpAcc {
-    static __device__ __forceinline__ int ldi(const int *p) { if constexpr (G) return ld_agent_i32(p); else return *p; }
-    static __device__ __forceinline__ double ldd(const double *p) { if constexpr (G) return ld_agent_f64(p); else return *p; }
-    static __device__ __forceinline__ void sti(int *p, int v) { if constexpr (G) st_agent_i32(p, v); else *p = v; }
-    static __device__ __forceinline__ void std_(double *p, double v) { if constexpr (G) st_agent_f64(p, v); else *p = v; }
+    static __device__ __forceinline__ int ldi(const int *p) { return *p; }
+    static __device__ __forceinline__ double ldd(const double *p) { return *p; }
+    static __device__ __forceinline__ void sti(int *p, int v) { *p = v; }
+    static __device__ __forceinline__ void std_(double *p, double v) { *p = v; }
     // cross-lane hand-over inside the wave: LDS is in order per wave; global stores must have landed
     static __device__ __forceinline__ void sync() { if constexpr (G) __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
 };
@@ -146,11 +158,10 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
                 const int q = base + lane;
                 const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
                 const unsigned long long m = __ballot(is);
-                if (is) st_agent_i32(&gscratch[c + __popcll(m & lt)], q);
+                if (is) gscratch[c + __popcll(m & lt)] = q;
                 c += __popcll(m);
             }
             __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (lane == 0) {
                 c_sort_slots_by_abs_desc(gscratch, ncand, vals);
                 for (int t = 0; t < nkeep; ++t) selq[t] = gscratch[t];
@@ -199,7 +210,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double v = valid ? Aval[q] : 0.0;
         const bool isL = valid && c < i, isU = valid && c > i, isD = valid && c == i;
         const unsigned long long mL = __ballot(isL), mU = __ballot(isU), mD = __ballot(isD);
-        if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) return 1;
+        if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
         if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
         if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], v); }
         if (mD != 0ull) wdiag = wave_bcast_f64(v, __ffsll((long long)mD) - 1);
@@ -214,6 +225,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     }
     // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
     for (;;) {
+        WP_T(tp0);
         unsigned best = 0x7fffffffu;
         int bq = -1;
         for (int q = lane; q < nL; q += 64) { const unsigned c = (unsigned)A::ldi(&w.lcol[q]); if (c < best) { best = c; bq = q; } }
@@ -234,6 +246,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         if (wkv == 0.0) continue;                                            // ILUT.hpp:239-240
         if (fabs(wkv) < thr1) continue;                                      // stage-1 drop, :244-245
         // row k of U, validated against the sentinels
+        WP_T(tp1); WP_ACC(0, tp0, tp1);
         const size_t ub = (size_t)k * p;
         int ul, c0;
         unsigned long long v0;
@@ -249,9 +262,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             __builtin_amdgcn_s_sleep(1);
         }
         ul = __builtin_amdgcn_readfirstlane(ul);
+        WP_T(tp2); WP_ACC(1, tp1, tp2);
         const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
         const double m = wkv / ud;                                           // :249
-        if (nK >= w.capK) return 1;
+        if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); return 1; }
         if (lane == 0) { A::sti(&w.kcol[nK], k); A::std_(&w.kval[nK], m); A::sti(&w.kseq[nK], sk); }
         ++nK;
         for (int base = 0; base < ul; base += 64) {                          // w -= m * U[k, j>k]  (:252-253)
@@ -299,13 +313,15 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             const bool nf = valid && c != i && bfound[lane] == 0;
             const bool isL = nf && c < i, isU = nf && c > i;
             const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
-            if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) return 1;
+            if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
             if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], 0.0 - pr); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
         }
+        WP_T(tp3); WP_ACC(2, tp2, tp3);
     }
+    WP_T(tq0);
     // (10.) dropping (ILUT.hpp:259,261): the multipliers back in insertion order, then both pieces
     for (int q = lane; q < nK; q += 64) {
         const int s = A::ldi(&w.kseq[q]);
@@ -331,6 +347,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         st_agent_i32(&Ulen[i], nUk + 1);
     }
     A::sync();
+    WP_T(tq1); WP_ACC(3, tq0, tq1);
     return 0;
 }
 
@@ -362,6 +379,7 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
                                lw, bcol, bpr, bfound, s_selq, gscratch, ctrl);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc == 1) {
+            if (lane == 0) atomicAdd(&ctrl[3], 1);          // statistics: rows that went to the global-memory pieces
             rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
                               g, bcol, bpr, bfound, s_selq, gscratch, ctrl);
             rc = __builtin_amdgcn_readfirstlane(rc);
@@ -402,8 +420,8 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     ILUPP_HIP(hipMemsetAsync(Uri, 0xff, sizeof(int32_t) * slab, st));
     fill_u64(st, reinterpret_cast<unsigned long long *>(Urv), (int64_t)slab, kSentinel);
     ILUPP_HIP(hipMemsetAsync(Ulen, 0, sizeof(int32_t) * (size_t)n, st));
-    const int32_t init[4] = {0, 0, 0x7fffffff, 0};
-    ILUPP_HIP(hipMemcpyAsync(ctrl, init, 16, hipMemcpyHostToDevice, st));
+    const int32_t init[16] = {0, 0, 0x7fffffff, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ILUPP_HIP(hipMemcpyAsync(ctrl, init, 64, hipMemcpyHostToDevice, st));
     hipEvent_t e0, e1;
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
@@ -412,8 +430,8 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
                        Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
-    int32_t h[4];
-    ILUPP_HIP(hipMemcpyAsync(h, ctrl, 16, hipMemcpyDeviceToHost, st));
+    int32_t h[8];
+    ILUPP_HIP(hipMemcpyAsync(h, ctrl, 32, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
     ILUPP_HIP(hipEventDestroy(e0));
@@ -421,6 +439,15 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     for (void *q : {(void *)g.ucol, (void *)g.uval, (void *)g.lcol, (void *)g.lval, (void *)g.lseq, (void *)g.kcol, (void *)g.kval,
                     (void *)g.kseq, (void *)gscratch})
         ILUPP_HIP(pool_free(q));
+#ifdef ILUT_PROFILE
+    {
+        unsigned long long t[4];
+        ILUPP_HIP(hipMemcpy(t, ctrl + 8, 32, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ilupp] ilut_wp cycles (sum over waves, M): pops+drops %.1f  fetch %.1f  update %.1f  dropping %.1f\n",
+                t[0] * 1e-6, t[1] * 1e-6, t[2] * 1e-6, t[3] * 1e-6);
+    }
+#endif
+    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: %d of %d rows outgrew LDS (pool %d, U slots %d, kept %d), status %d, kernel %.3f ms\n", h[3], n, h[4], h[5], h[6], h[1], kernel_ms ? *kernel_ms : 0.f);
     if (h[1] == 3) return 1;
     if (h[1] == 1) return ILUPP_ERR_TIMEOUT;
     return 0;

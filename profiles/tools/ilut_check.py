@@ -1,5 +1,5 @@
 # ILUT wave-parallel kernel: bit-exact comparison with the reference (oracle/_ref when present, else the C restatement)
-# and timings.  usage: python profiles/tools/ilut_check.py [n_random ...]
+# and timings.  usage: python profiles/tools/ilut_check.py [--grids g1,g2] [n_random ...]
 import os, sys, time, numpy as np, scipy.sparse as sp
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import matgen
@@ -27,8 +27,12 @@ def check(name, d, i, p, fill, tau, compare=True):
         msg += '   %s (1 core) %.3f s   bit-exact=%s' % (kind, tc, eq(L, Lo) and eq(U, Uo))
     print(msg, flush=True)
 
-args = [int(s) for s in sys.argv[1:]] or [2000, 50000]
-for g in (8, 16, 32):
+grids = (8, 16, 32)
+argv = sys.argv[1:]
+if argv and argv[0] == '--grids':
+    grids = tuple(int(x) for x in argv[1].split(',') if x); argv = argv[2:]
+args = [int(s) for s in argv] or [2000, 50000]
+for g in grids:
     d, i, p = matgen.poisson3d(g)
     for fill, tau in ((10, 1e-4), (5, 0.1), (100, 0.0)):
         if fill == 100 and g > 16: continue
