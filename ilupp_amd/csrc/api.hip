@@ -154,6 +154,8 @@ struct ilupp_precond {
     int32_t *ctrl = nullptr;     // 16 ints: [0] err, [1] ilu0 ticket (+ its err in [2]) , [4],[5] solve tickets
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4],[5]: around the factor kernel
+    hipStream_t side = nullptr;                       // work that overlaps the persistent factor kernel
+    hipEvent_t sev[2] = {nullptr, nullptr};           // fork / join of the side stream
     int device = 0;
     ilupp_timings tm = {0, 0, 0, 0, 0, 0};
     bool apply_events_valid = false;
@@ -162,7 +164,7 @@ struct ilupp_precond {
 
 namespace {
 
-struct QueuePack { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int device = 0; };
+struct QueuePack { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipStream_t side = nullptr; hipEvent_t sev[2] = {nullptr, nullptr}; int device = 0; };
 struct QueuePool { std::mutex mu; std::vector<QueuePack> free_list; } g_queues;
 
 bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <= kGhostBase; }
@@ -171,6 +173,7 @@ void destroy_obj(ilupp_precond *p)
 {
     if (!p) return;
     if (p->stream) (void)hipStreamSynchronize(p->stream);   // pooled blocks may be handed out again at once
+    if (p->side) (void)hipStreamSynchronize(p->side);
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
     p->prog.release();
@@ -186,6 +189,7 @@ void destroy_obj(ilupp_precond *p)
         std::lock_guard<std::mutex> lk(g_queues.mu);
         QueuePack q; q.stream = p->stream; q.device = p->device;
         for (int k = 0; k < 6; ++k) q.ev[k] = p->ev[k];
+        q.side = p->side; q.sev[0] = p->sev[0]; q.sev[1] = p->sev[1];
         g_queues.free_list.push_back(q);
     }
     delete p;
@@ -202,6 +206,7 @@ ilupp_precond *new_obj(int32_t n)
             if (g_queues.free_list[k].device == p->device) {
                 p->stream = g_queues.free_list[k].stream;
                 for (int e = 0; e < 6; ++e) p->ev[e] = g_queues.free_list[k].ev[e];
+                p->side = g_queues.free_list[k].side; p->sev[0] = g_queues.free_list[k].sev[0]; p->sev[1] = g_queues.free_list[k].sev[1];
                 g_queues.free_list.erase(g_queues.free_list.begin() + (long)k);
                 break;
             }
@@ -209,6 +214,8 @@ ilupp_precond *new_obj(int32_t n)
     if (!p->stream) {
         ILUPP_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         for (auto &e : p->ev) ILUPP_HIP(hipEventCreate(&e));
+        ILUPP_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        for (auto &e : p->sev) ILUPP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     ILUPP_HIP(pool_malloc(&p->work, sizeof(double) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->done, sizeof(int32_t) * (size_t)n));
@@ -278,6 +285,12 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
     bool have_prog = false;
     const bool lm = p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
+    // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
+    // transposed solves): the pass runs on the side stream next to the persistent factor kernel, which is bound by
+    // dependency latency and leaves most of the memory system idle.
+    static const bool no_overlap = getenv("ILUPP_OVERLAP_PATTERNS") == nullptr;   // measured: the overlap costs the factor kernel more (2.0 -> 2.5 ms) than the pass takes (0.28 ms)
+    const bool patterns_aside = lm && !no_overlap;
+    if (!patterns_aside) ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
     if (!lm) ilu0_unit_diagonal(st, &p->Lc);        // the CSR-streaming factor kernels write the eliminations only
     if (p->compact && !lm) {
         // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels
@@ -297,9 +310,16 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
         if (!(p->pkL.valid && p->pkU.valid)) { p->pkL.release(); p->pkU.release(); }
     }
     ILUPP_HIP(hipEventRecord(a1, st));
+    if (patterns_aside) {
+        ILUPP_HIP(hipEventRecord(p->sev[0], st));
+        ILUPP_HIP(hipStreamWaitEvent(p->side, p->sev[0], 0));
+        ilu0_write_patterns(p->side, A, &p->Lc, &p->Uc);
+        ILUPP_HIP(hipEventRecord(p->sev[1], p->side));
+    }
     float kms = 0.f;
     rc = ILUPP_ERR_UNSUPPORTED;
     rc = ilu0_numeric_any(p, A, have_prog, &kms);
+    if (patterns_aside) ILUPP_HIP(hipStreamWaitEvent(st, p->sev[1], 0));
     ILUPP_HIP(hipEventRecord(a2, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));

@@ -259,10 +259,11 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
     }
     __builtin_nontemporal_store(lrec, pkL + ((size_t)base + c) * 192 + L);
     v4i *p = pkA + ((size_t)base + c) * 320 + L;
-    int *q = reinterpret_cast<int *>(p + 192);
-    q[2] = w0; q[3] = w1;
     __builtin_nontemporal_store(dec, p + 256);
-    if (Aval) {
+    if (!Aval) {
+        int *q = reinterpret_cast<int *>(p + 192);
+        q[2] = w0; q[3] = w1;
+    } else {
         // the values of this factorisation right away (k_flm_pack_a does the same for a later one on the same pattern):
         // the row of A, diagonal-aligned
         const int len = w0 & 15, cl = (w0 >> 4) & 3;
@@ -287,7 +288,10 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
         v2dr x; x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, reinterpret_cast<v2dr *>(p));
         x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, reinterpret_cast<v2dr *>(p) + 64);
         x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, reinterpret_cast<v2dr *>(p) + 128);
-        reinterpret_cast<double *>(p + 192)[0] = a[6];
+        // {a6 | w0, w1} as ONE 16-byte store: two 8-byte halves written at different times make every line of this
+        // piece a partial write (read-modify-write in the memory system)
+        v4i last; last.x = __double2loint(a[6]); last.y = __double2hiint(a[6]); last.z = w0; last.w = w1;
+        __builtin_nontemporal_store(last, p + 192);
     }
 }
 

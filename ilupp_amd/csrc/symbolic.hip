@@ -233,14 +233,23 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
     ILUPP_HIP(pool_malloc(&U->idx, sizeof(int32_t) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
     ILUPP_HIP(pool_malloc(&U->val, sizeof(double) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
     if (h[3] != 0x7fffffff) { ILUPP_HIP(pool_free(cutf)); ILUPP_HIP(pool_free(cutb)); return ILUPP_ERR_NO_DIAGONAL; }
-    hipLaunchKernelGGL(k_ilu0_pattern2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz,
-                       L->ptr, U->ptr, L->idx, U->idx);
+    // (the CSR patterns of L and U themselves are written by ilu0_write_patterns: nothing of the factorisation or of the
+    // solves reads them when the level-major kernels run, so the caller overlaps that pass with the factor kernel)
     make_schedule(st, n, cutf, h[0], max_lanes, fwd);
     make_schedule(st, n, cutb, h[1], max_lanes, bwd);
     ILUPP_HIP(hipStreamSynchronize(st));
     ILUPP_HIP(pool_free(cutf));
     ILUPP_HIP(pool_free(cutb));
     return ILUPP_OK;
+}
+
+// the split of A's pattern into the patterns of L (unit diagonal appended last) and U (diagonal first), ILU0.hpp:85-98;
+// needs L->ptr from ilu0_symbolic_and_schedule
+void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U)
+{
+    const int32_t n = A.n;
+    hipLaunchKernelGGL(k_ilu0_pattern2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz,
+                       L->ptr, U->ptr, L->idx, U->idx);
 }
 
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
