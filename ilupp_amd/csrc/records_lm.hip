@@ -28,6 +28,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 static constexpr int kNoDep = -1;
 static constexpr int kOwnPrev = -3;
 static constexpr int kMaxSkewA = 30000;
+#ifndef REC_ROWS
+#define REC_ROWS 1
+#endif
+static constexpr int kRecRows = REC_ROWS;     // groups of 8 rows a block of the record kernels walks per lane (measured: 4 is slower, 3.05 vs 2.57 ms analysis)
 struct __attribute__((aligned(8))) D2r { double v[2]; };
 
 // Import table from one triangle of A (tri = +1: columns below the diagonal, -1: above); see k_ghost_table
@@ -150,10 +154,13 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
 {
     const int w = blockIdx.x;
     const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
-    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
     const int wg = w >> 2;
     const int slot = wg * kThreads + (w & 3) * 64 + L;
-    if (k >= scount[slot]) return;
+    // kRecRows consecutive groups of 8 rows per lane and block: the pieces of A a lane reads (28 + 56 bytes per row) are
+    // then long enough that the 128-byte lines at their ends are fetched once, not once per neighbouring block
+    for (int jj = 0; jj < kRecRows; ++jj) {
+    const int k = (blockIdx.y * kRecRows + jj) * 8 + ((threadIdx.x >> 3) & 7);
+    if (k >= scount[slot]) continue;
     const int r = sfirst[slot] + k;
     const int tau = k + skew[slot];
     const int base = wtab[(size_t)w * 4], c = tau - wtab[(size_t)w * 4 + 1];
@@ -293,6 +300,7 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
         v4i last; last.x = __double2loint(a[6]); last.y = __double2hiint(a[6]); last.z = w0; last.w = w1;
         __builtin_nontemporal_store(last, p + 192);
     }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -307,10 +315,11 @@ k_bwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
 {
     const int w = blockIdx.x;
     const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
-    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
     const int wg = w >> 2;
     const int slot = wg * kThreads + (w & 3) * 64 + L;
-    if (k >= scount[slot]) return;
+    for (int jj = 0; jj < kRecRows; ++jj) {
+    const int k = (blockIdx.y * kRecRows + jj) * 8 + ((threadIdx.x >> 3) & 7);
+    if (k >= scount[slot]) continue;
     const int r = sfirst[slot] - k;
     const int tau = k + skew[slot];
     const int base = wtab[(size_t)w * 4], c = tau - wtab[(size_t)w * 4 + 1];
@@ -357,6 +366,7 @@ k_bwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
         rec.x = sd[0]; rec.y = sd[1]; rec.z = sd[2]; rec.w = 1;
     }
     __builtin_nontemporal_store(rec, pkU + ((size_t)base + c) * 192 + L);
+    }
 }
 
 // places of the chunks that hold no row: valid = 0 in every pattern word
@@ -453,7 +463,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
         hipLaunchKernelGGL(k_pad_records, grid, dim3(512), 0, st, pl->wtab, pl->skew, fwd.scount, reinterpret_cast<v4i *>(pl->pk),
                            reinterpret_cast<v4i *>(f->pkA));
-        const dim3 gridr((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));   // every lane has at most max_chunks rows
+        const dim3 gridr((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 8 * kRecRows - 1) / (8 * kRecRows)));   // every lane has at most max_chunks rows
         hipLaunchKernelGGL(k_fwd_records, gridr, dim3(512), 0, st, A.ptr, A.idx, A.val, (int64_t)A.nnz, fwd.B, fwd.nb, fwd.start, fwd.blk2slot, pl->wtab,
                            pl->skew, fwd.sfirst, fwd.scount, fwd.gtab, fwd.exported, reinterpret_cast<v4i *>(pl->pk),
                            reinterpret_cast<v4i *>(f->pkA), pl->flags);
@@ -462,7 +472,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         const dim3 grid((unsigned)(pu->nwg * 4), (unsigned)((pu->max_chunks + 7) / 8));
         hipLaunchKernelGGL(k_pad_records, grid, dim3(512), 0, st, pu->wtab, pu->skew, bwd.scount, reinterpret_cast<v4i *>(pu->pk),
                            static_cast<v4i *>(nullptr));
-        const dim3 gridr((unsigned)(pu->nwg * 4), (unsigned)((pu->max_chunks + 7) / 8));
+        const dim3 gridr((unsigned)(pu->nwg * 4), (unsigned)((pu->max_chunks + 8 * kRecRows - 1) / (8 * kRecRows)));
         hipLaunchKernelGGL(k_bwd_records, gridr, dim3(512), 0, st, A.ptr, A.idx, (int64_t)A.nnz, bwd.B, bwd.nb, bwd.start, bwd.blk2slot, pu->wtab,
                            pu->skew, bwd.sfirst, bwd.scount, bwd.gtab, bwd.exported, reinterpret_cast<v4i *>(pu->pk), pu->flags);
     }
