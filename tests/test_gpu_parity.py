@@ -565,3 +565,130 @@ def test_icholt_medium_digests():
         assert G.digest_of(_fac(L)) == e["icholt_%d_%g_L" % (a, t)]
         x = np.ones(40000); P.apply(x)
         assert G.sha(x) == e["icholt_%d_%g_apply_ones" % (a, t)]
+
+
+# ---------------------------------------------------------------------------------------------
+# the dataflow ICholT kernel (icholt_df.hip) and the wave-parallel ILUT kernel (ilut_wp.hip): fresh seeded inputs against
+# the pinned oracle, the sequential kernels as A/B, and the capacity fall-backs
+# ---------------------------------------------------------------------------------------------
+def _spd_from(d, i, p, shift):
+    ds, is_, ps = matgen.symmetrize(d, i, p)
+    n = ps.shape[0] - 1
+    S = sp.csr_matrix((ds, is_, ps), shape=(n, n)) + shift * sp.identity(n, format="csr")
+    S = S.tocsr(); S.sort_indices()
+    return S.data.astype(np.float64), S.indices.astype(np.int32), S.indptr.astype(np.int32)
+
+
+def _with_env(name, value, f):
+    import os
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return f()
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+
+
+@pytest.mark.parametrize("case", ["grid_40", "grid_ragged", "rand_spd", "rand_spd_dense_rows", "chain"])
+def test_icholt_dataflow_vs_oracle_seeded(case):
+    """value-dependent patterns, reaches from dropped entries, linked-list order, ties: bit-exact against the oracle, for
+    both kernels (dataflow = default, sequential = ILUPP_ICHOLT_SEQUENTIAL=1) and both input orientations"""
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    orc = O.orc()
+    if case == "grid_40":
+        d, i, p = matgen.poisson3d(40)
+        params = ((0, 0.0), (5, 1e-3), (2, 0.05), (12, 1e-5))
+    elif case == "grid_ragged":
+        d, i, p = matgen.poisson3d(23, 9, 31)
+        params = ((0, 0.0), (3, 1e-2), (7, 0.0))
+    elif case == "rand_spd":
+        d, i, p = _spd_from(*matgen.random_dd(4000, 9, 0.0, 21), 12.0)
+        params = ((0, 0.0), (4, 1e-3), (10, 1e-6))
+    elif case == "rand_spd_dense_rows":
+        d, i, p = _spd_from(*matgen.random_dd(600, 40, 0.0, 5), 60.0)       # long working columns: capacity fall-back
+        params = ((0, 0.0), (30, 1e-8))
+    else:
+        d, i, p = matgen.laplace1d(3000)
+        params = ((0, 0.0), (2, 0.0))
+    n = p.shape[0] - 1
+    b = G.rhs(n)
+    for fmt in ("csr", "csc"):
+        M = (d, i, p, True) if fmt == "csr" else matgen.to_csc(d, i, p) + (False,)
+        for a, t in params:
+            Lo = orc.icholt(M, a, t)
+            P = ilupp.ICholTPreconditioner(_scipy(M), add_fill_in=a, threshold=t)
+            L, = P.factors()
+            assert G.mat_equal(_fac(L), Lo), (case, fmt, a, t)
+            x = b.copy(); P.apply(x)
+            assert np.array_equal(x, orc.apply_llt(Lo, b, O.ID), equal_nan=True)
+            if fmt == "csr":
+                Ps = _with_env("ILUPP_ICHOLT_SEQUENTIAL", "1",
+                               lambda: ilupp.ICholTPreconditioner(_scipy(M), add_fill_in=a, threshold=t))
+                Ls, = Ps.factors()
+                assert G.mat_equal(_fac(Ls), Lo), (case, "sequential", a, t)
+
+
+@pytest.mark.parametrize("case", ["grid_24", "rand_20k", "rand_long_rows", "wide_budget", "budget_one"])
+def test_ilut_wave_kernel_vs_oracle_seeded(case):
+    """pool/kept/U-slot working row, validated U-row fetches, top-k with ties, rows that outgrow LDS, U rows longer than one
+    wave (fill_in > 64): bit-exact against the oracle for both kernels (wave-parallel = default, ILUPP_ILUT_SEQUENTIAL=1)"""
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    orc = O.orc()
+    if case == "grid_24":
+        d, i, p = matgen.poisson3d(24)
+        params = ((10, 1e-4), (5, 0.1), (30, 0.0))
+    elif case == "rand_20k":
+        d, i, p = matgen.random_dd(20000, 19, 25.0, 99)      # some rows outgrow the LDS pieces
+        params = ((10, 1e-4), (3, 1e-2))
+    elif case == "rand_long_rows":
+        d, i, p = matgen.random_dd(500, 90, 120.0, 13)
+        params = ((20, 1e-6), (100, 0.0))
+    elif case == "wide_budget":
+        d, i, p = matgen.poisson3d(12)
+        params = ((100, 0.0), (200, 1e-12))                  # U rows of more than 64 entries
+    else:
+        d, i, p = matgen.poisson3d(10)
+        params = ((1, 0.1), (2, 0.0))
+    n = p.shape[0] - 1
+    b = G.rhs(n)
+    for fmt in ("csr", "csc"):
+        M = (d, i, p, True) if fmt == "csr" else matgen.to_csc(d, i, p) + (False,)
+        for fill, t in params:
+            Lo, Uo = orc.ilut(M, fill, t)
+            P = ilupp.ILUTPreconditioner(_scipy(M), fill_in=fill, threshold=t)
+            L, U = [_fac(F) for F in P.factors()]
+            assert G.mat_equal(L, Lo) and G.mat_equal(U, Uo), (case, fmt, fill, t)
+            x = b.copy(); P.apply(x)
+            assert np.array_equal(x, orc.apply_lu(Lo, Uo, b, O.ID), equal_nan=True)
+            if fmt == "csr":
+                Ps = _with_env("ILUPP_ILUT_SEQUENTIAL", "1", lambda: ilupp.ILUTPreconditioner(_scipy(M), fill_in=fill, threshold=t))
+                Ls, Us = [_fac(F) for F in Ps.factors()]
+                assert G.mat_equal(Ls, Lo) and G.mat_equal(Us, Uo), (case, "sequential", fill, t)
+
+
+def test_icholt_full_size_properties_128():
+    """128^3 (2.1 M columns): the dataflow kernel against the reference's own C++ when it travelled (oracle/_ref), else
+    the C restatement; plus L L^T = A on A's pattern for the no-fill variant's kept entries"""
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    ref = O.ref() if O.ref_available() else O.orc()
+    d, i, p = matgen.poisson3d(128)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    for a, t in ((0, 0.0), (5, 1e-3)):
+        P = ilupp.ICholTPreconditioner(A, add_fill_in=a, threshold=t)
+        L, = P.factors()
+        Lo = ref.icholt((d, i, p, True), a, t)
+        assert G.mat_equal(_fac(L), Lo), (a, t)
+        assert P.total_nnz == L.nnz
+    # apply == apply_trans for LL^T objects (preconditioner_implementation.h:381-394), both equal to the oracle's two sweeps
+    b = np.ones(n)
+    x = b.copy(); P.apply(x)
+    xt = b.copy(); P.apply_trans(xt)
+    assert np.array_equal(x, xt)
+    assert np.array_equal(x, O.orc().apply_llt(Lo, b, O.ID))
