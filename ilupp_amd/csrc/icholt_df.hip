@@ -41,14 +41,20 @@
 
 namespace ilupp {
 
-static constexpr int kCtNE = 512;     // entries gathered per column: A's column + the contributors' tails
-static constexpr int kCtNS = 256;     // slots of the working column
-static constexpr int kCtTmax = 128;   // touch records per row (run-time T <= this)
-static constexpr int kCtQTail = 32;   // ctrl word of the ready queue's tail (own cache line)
+// LDS capacities come in two classes (template parameters of the kernel): NE = entries gathered per column (A's column +
+// the contributors' tails), NS = slots of the working column, TM = touch records per row.  The small class keeps 12 waves
+// per CU resident (the kernel is bound by the latency of its ~8 dependent memory round trips per column, so resident waves
+// are throughput); a factorisation that exceeds it is run again with the large class, then by the sequential kernel.
+static constexpr int kCtTmax = 128;   // touch records per row, large class (run-time T <= this)
+static constexpr int kCtTsmall = 64;
+// ready queues: kCtQ of them, column i goes to queue i % kCtQ (so the number of entries a queue will ever get is known:
+// a worker whose ticket lies beyond it is done), wave w serves queue w % kCtQ.  One queue would put two atomics per
+// column on two addresses -- 33 M same-address atomics at 256^3, which alone take longer than the factorisation.
+static constexpr int kCtQ = 64;     // at most; fewer when there are fewer waves than that (every queue needs a worker)
+static constexpr int kCtQBase = 64;   // ctrl word of queue 0's head; queue q: head at kCtQBase + 64 q, tail 32 words later
 static constexpr unsigned kCtSpinLimit = 1u << 22;
 
-// ctrl: [0] next ticket, [2] error (1 = capacity exceeded -> sequential fallback, 2 = timeout), [3] malformed column,
-//       [32] ready-queue tail
+// ctrl: [2] error (1 = capacity exceeded -> sequential fallback, 2 = timeout), [3] malformed column, then the queues' heads/tails
 __global__ void k_ict_prep(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int32_t add,
                            int32_t *__restrict__ cap, int32_t *pending, int32_t *ctrl)
 {
@@ -60,11 +66,15 @@ __global__ void k_ict_prep(int32_t m, const int32_t *__restrict__ Aptr, const in
     for (int x = c0 + 1; x < c1; ++x) atomicAdd(&pending[Aidx[x]], 1);
 }
 
-__global__ void k_ict_seed(int32_t m, const int32_t *__restrict__ pending, int32_t *rq, int32_t *ctrl)
+__global__ void k_ict_seed(int32_t m, int32_t nq, const int32_t *__restrict__ pending, int32_t *rq, int32_t *ctrl)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    if (pending[j] == 0) rq[atomicAdd(&ctrl[kCtQTail], 1)] = j;
+    if (pending[j] == 0) {
+        const int q = j % nq;
+        const int qcap = (m + nq - 1) / nq;
+        rq[(size_t)q * qcap + atomicAdd(&ctrl[kCtQBase + 64 * q + 32], 1)] = j;
+    }
 }
 
 __device__ __forceinline__ unsigned long long pack2(int lo, int hi)
@@ -72,9 +82,10 @@ __device__ __forceinline__ unsigned long long pack2(int lo, int hi)
     return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
 }
 
+template <int kCtNE, int kCtNS, int kCtTM>
 __global__ void __launch_bounds__(64)
 k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
-            int32_t add, double tau, int32_t T, const int32_t *__restrict__ Loff,
+            int32_t add, double tau, int32_t T, int32_t nq, const int32_t *__restrict__ Loff,
             int32_t *Lidx, double *Lval, int32_t *Llen,
             int32_t *cnt, unsigned long long *rec, int32_t *pending, int32_t *rq, int32_t *ctrl)
 {
@@ -82,25 +93,30 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
     __shared__ double eval[kCtNE];
     __shared__ int srow[kCtNS], scnt[kCtNS], srank[kCtNS], sridx[kCtNS], cand[kCtNS], crank[kCtNS], keptslot[kCtNS];
     __shared__ double sval[kCtNS];
-    __shared__ int tk[kCtTmax], tx[kCtTmax], tt[kCtTmax], trem[kCtTmax], tnxt[kCtTmax], tseq[kCtTmax];
-    __shared__ double tv[kCtTmax], ordv[kCtTmax];
-    __shared__ int cx[kCtTmax], crem[kCtTmax], cbase[kCtTmax + 1], cnxt[kCtTmax];
-    __shared__ double cv[kCtTmax];
+    __shared__ int tk[kCtTM], tx[kCtTM], tt[kCtTM], trem[kCtTM], tnxt[kCtTM], tseq[kCtTM];
+    __shared__ double tv[kCtTM], ordv[kCtTM];
+    __shared__ int cx[kCtTM], crem[kCtTM], cbase[kCtTM + 1], cnxt[kCtTM];
+    __shared__ double cv[kCtTM];
     __shared__ double tie_mag[2];
 
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #define CT_FAIL(code) do { if (lane == 0) atomicCAS(&ctrl[2], 0, (code)); return; } while (0)
 
+    const int myq = (int)(blockIdx.x % nq);
+    const int qcap = (m + nq - 1) / nq;
+    const int qtotal = (m - myq + nq - 1) / nq;              // columns i = myq (mod nq) below m
+    int32_t *const qhead = &ctrl[kCtQBase + 64 * myq];
+    const int32_t *const myrq = rq + (size_t)myq * qcap;
     for (;;) {
         int tkt = 0;
-        if (lane == 0) tkt = atomicAdd(&ctrl[0], 1);
+        if (lane == 0) tkt = atomicAdd(qhead, 1);
         tkt = __builtin_amdgcn_readfirstlane(tkt);
-        if (tkt >= m) break;
+        if (tkt >= qtotal) break;
         int j;
         unsigned spins = 0;
         for (;;) {
-            j = ld_agent_i32(&rq[tkt]);
+            j = ld_agent_i32(&myrq[tkt]);
             if (j >= 0) break;
             if ((++spins & 63u) == 0) {
                 if (ld_agent_i32(&ctrl[2]) != 0) return;
@@ -115,7 +131,7 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         const int capj = clen + add;
         const int loff = __builtin_amdgcn_readfirstlane(Loff[j]);
         const int nt = __builtin_amdgcn_readfirstlane(ld_agent_i32(&cnt[j]));
-        if (clen > kCtNS || nt > T) CT_FAIL(1);
+        if (clen > kCtNS || nt > T || nt > kCtTM) CT_FAIL(1);
 
         // ---- the column of A (slots 0..clen-1, IChol.hpp:110-112) and the touch records of row j ----
         for (int e = lane; e < clen; e += 64) { erow[e] = Aidx[c0 + e]; eval[e] = Aval[c0 + e]; eslot[e] = e; srow[e] = erow[e]; }
@@ -311,9 +327,12 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
             const int i = srow[s];
             const int r = srank[s];
             const int delta = (r >= 0 ? r - 1 : 0) - scnt[s];
-            if (delta != 0) {
-                const int nv = atomicAdd(&pending[i], delta) + delta;
-                if (nv == 0) { const int pos = atomicAdd(&ctrl[kCtQTail], 1); st_agent_i32(&rq[pos], i); }
+            bool ready = false;
+            if (delta != 0) ready = atomicAdd(&pending[i], delta) + delta == 0;
+            if (ready) {
+                const int q = i % nq;
+                const int pos = atomicAdd(&ctrl[kCtQBase + 64 * q + 32], 1);
+                st_agent_i32(&rq[(size_t)q * qcap + pos], i);
             }
         }
         __syncthreads();
@@ -331,8 +350,9 @@ __global__ void k_ict_compact(int32_t m, const int32_t *__restrict__ Loff, const
     for (int q = threadIdx.x % 8; q < len; q += 8) { oidx[dst + q] = sidx[src + q]; oval[dst + q] = sval[src + q]; }
 }
 
-// returns ILUPP_OK / an error of the reference / +1 = "not handled here, run the sequential kernel"
-int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms)
+// one attempt with one capacity class; returns ILUPP_OK / an error of the reference / +1 = "outside this class"
+static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms,
+                          bool small)
 {
     const int32_t m = Atri.n;
     if (add_fill_in < 0 || m < 1) return 1;
@@ -347,6 +367,7 @@ int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, do
     const long avg = Atri.nnz / m + 1;
     int T = 16;
     while (T < 4 * (avg + add_fill_in) && T < kCtTmax) T *= 2;
+    if (small && T > kCtTsmall) return 1;
     while (T > 16 && ((long)m * T > 0x7fffffffL || (size_t)m * T * 32 > ((size_t)96 << 30))) T /= 2;
     if ((long)m * T > 0x7fffffffL) return 1;
 
@@ -361,8 +382,10 @@ int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, do
     ILUPP_HIP(pool_malloc(&Lval, sizeof(double) * (size_t)(slab > 0 ? slab : 1)));
     ILUPP_HIP(pool_malloc(&cnt, sizeof(int32_t) * (size_t)m));
     ILUPP_HIP(pool_malloc(&pending, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&rq, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&ctrl, 256));
+    const size_t rq_len = (size_t)kCtQ * (size_t)((m + kCtQ - 1) / kCtQ) + (size_t)m;   // (nq <= kCtQ queues of ceil(m / nq) entries)
+    ILUPP_HIP(pool_malloc(&rq, sizeof(int32_t) * rq_len));
+    const size_t ctrl_bytes = sizeof(int32_t) * (size_t)(kCtQBase + 64 * kCtQ);
+    ILUPP_HIP(pool_malloc(&ctrl, ctrl_bytes));
     if (pool_malloc(&rec, (size_t)m * T * 32) != hipSuccess) {
         (void)hipGetLastError();
         for (void *q : {(void *)cap, (void *)Loff, (void *)Llen, (void *)Lptr, (void *)Lidx, (void *)Lval, (void *)cnt, (void *)pending,
@@ -373,10 +396,13 @@ int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, do
     ILUPP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)m, st));
     ILUPP_HIP(hipMemsetAsync(pending, 0, sizeof(int32_t) * (size_t)m, st));
     ILUPP_HIP(hipMemsetAsync(Llen, 0, sizeof(int32_t) * (size_t)(m + 1), st));
-    ILUPP_HIP(hipMemsetAsync(rq, 0xff, sizeof(int32_t) * (size_t)m, st));
-    ILUPP_HIP(hipMemsetAsync(ctrl, 0, 256, st));
+    ILUPP_HIP(hipMemsetAsync(rq, 0xff, sizeof(int32_t) * rq_len, st));
+    ILUPP_HIP(hipMemsetAsync(ctrl, 0, ctrl_bytes, st));
     const int32_t big = 0x7fffffff;
     ILUPP_HIP(hipMemcpyAsync(ctrl + 3, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    int waves = device_cu_count() * (small ? 12 : 3);
+    if (waves > m) waves = m;
+    const int nq = waves < kCtQ ? waves : kCtQ;
     const int gb = (m + 255) / 256;
     hipLaunchKernelGGL(k_ict_prep, dim3(gb), dim3(256), 0, st, m, Atri.ptr, Atri.idx, add_fill_in, cap, pending, ctrl);
     {
@@ -387,15 +413,17 @@ int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, do
         ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cap, Loff, m, st));
         ILUPP_HIP(pool_free(tmp));
     }
-    hipLaunchKernelGGL(k_ict_seed, dim3(gb), dim3(256), 0, st, m, pending, rq, ctrl);
+    hipLaunchKernelGGL(k_ict_seed, dim3(gb), dim3(256), 0, st, m, nq, pending, rq, ctrl);
     hipEvent_t e0, e1;
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
     ILUPP_HIP(hipEventRecord(e0, st));
-    int waves = device_cu_count() * 6;
-    if (waves > m) waves = m;
-    hipLaunchKernelGGL(k_icholt_df, dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in, threshold, T, Loff,
-                       Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
+    if (small)
+        hipLaunchKernelGGL((k_icholt_df<256, 128, kCtTsmall>), dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in,
+                           threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
+    else
+        hipLaunchKernelGGL((k_icholt_df<1024, 512, kCtTmax>), dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in,
+                           threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t h[4];
@@ -431,6 +459,14 @@ int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, do
     for (void *q : {(void *)cap, (void *)Loff, (void *)Llen, (void *)Lidx, (void *)Lval, (void *)cnt, (void *)pending, (void *)rq,
                     (void *)ctrl, (void *)rec})
         ILUPP_HIP(pool_free(q));
+    return rc;
+}
+
+// returns ILUPP_OK / an error of the reference / +1 = "not handled here, run the sequential kernel"
+int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms)
+{
+    int rc = icholt_attempt(st, Atri, add_fill_in, threshold, L, kernel_ms, true);
+    if (rc == 1) rc = icholt_attempt(st, Atri, add_fill_in, threshold, L, kernel_ms, false);
     return rc;
 }
 

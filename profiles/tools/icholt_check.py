@@ -17,7 +17,10 @@ def check(name, d, i, p, a, tau, compare=True):
     tg, P = t(lambda: ilupp.ICholTPreconditioner(A, add_fill_in=a, threshold=tau))
     tg2, P = t(lambda: ilupp.ICholTPreconditioner(A, add_fill_in=a, threshold=tau))
     L, = P.factors()
-    msg = '%s ICholT(%d,%g) n=%d nnz(L)=%d: GPU %.4f s (2nd %.4f s)' % (name, a, tau, n, L.nnz, tg, tg2)
+    k2 = P.pr.timings()['numeric_kernel_ms']
+    tg3, P = t(lambda: ilupp.ICholTPreconditioner(A, add_fill_in=a, threshold=tau))
+    k3 = P.pr.timings()['numeric_kernel_ms']
+    msg = '%s ICholT(%d,%g) n=%d nnz(L)=%d: GPU %.4f s (2nd %.4f s, kernel %.1f ms; 3rd %.4f s, kernel %.1f ms)' % (name, a, tau, n, L.nnz, tg, tg2, k2, tg3, k3)
     if compare:
         tc, Lo = t(lambda: ref.icholt((d, i, p, True), a, tau))
         ok = (np.array_equal(L.indptr, Lo[2]) and np.array_equal(L.indices, Lo[1])
