@@ -236,9 +236,14 @@ static constexpr int kGD8 = 8;             // ghost ring depth
 static constexpr int kIB4 = 4;             // unknowns an importer lane polls per trip
 static constexpr int kBack = 4;            // a wave runs at most this many steps ahead of the slowest wave of its workgroup
 static constexpr int kPatience = 256;
-static constexpr int kLmThreads = 2 * kThreads + 64;
+#ifndef LM_LOADER_SETS
+#define LM_LOADER_SETS 1
+#endif
+static constexpr int kLS = LM_LOADER_SETS;   // loader waves per consumer wave (measured: 2 changes nothing, the sweeps are not loader-bound): set s fetches the chunks c = s (mod kLS), so that
+                                              // kLS fetch rounds are in flight per consumer wave even when each round tops up one chunk
+static constexpr int kLmThreads = 2 * kThreads + 64 + (kLS - 1) * kThreads;
 static constexpr size_t kChunkLds = (size_t)kThreads * (16 + 16 + 16 + 8);           // one ring slot: desc, v01, v23, rhs
-static constexpr size_t kLmLds = kCD * kChunkLds + (size_t)kXD8 * kThreads * 16 + (size_t)kGD8 * kGhosts * 16 + (12 + 2 * kGhosts + 8) * 4;
+static constexpr size_t kLmLds = kCD * kChunkLds + (size_t)kXD8 * kThreads * 16 + (size_t)kGD8 * kGhosts * 16 + (16 + 2 * kGhosts + 8) * 4;
 static constexpr int kDone = 0x7fffffff;
 
 template <int DR>
@@ -256,8 +261,8 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
     // ring slot q: [desc 256 x 16][v01 256 x 16][v23 256 x 16][rhs 256 x 8]
     v4i *xr = reinterpret_cast<v4i *>(smem + kCD * kChunkLds);                 // [kXD8][256] {tag,-,x.lo,x.hi}
     v4i *gr = xr + kXD8 * kThreads;                                            // [kGD8][kGhosts]
-    int *avail = reinterpret_cast<int *>(gr + kGD8 * kGhosts);                 // [4] chunks loaded per wave
-    int *cons = avail + 4;                                                     // [4] chunks taken by the consumer wave
+    int *avail = reinterpret_cast<int *>(gr + kGD8 * kGhosts);                 // [2][4] per loader set and wave: first chunk of the set not yet loaded
+    int *cons = avail + 8;                                                     // [4] chunks taken by the consumer wave
     int *wdone = cons + 4;                                                     // [4] last completed step (absolute), kDone when finished
     int *gfirst = wdone + 4;                                                   // [kGhosts]
     int *gack = gfirst + kGhosts;                                              // [kGhosts]
@@ -268,7 +273,8 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
     const unsigned wg = *wg_ticket;
     const int tid = threadIdx.x & (kThreads - 1);
     const bool is_consumer = threadIdx.x < kThreads;
-    const bool is_loader = !is_consumer && threadIdx.x < 2 * kThreads;
+    const bool is_loader = !is_consumer && (threadIdx.x < 2 * kThreads || threadIdx.x >= 2 * kThreads + 64);
+    const int lset = threadIdx.x >= 2 * kThreads + 64 ? 1 + (int)(threadIdx.x - (2 * kThreads + 64)) / kThreads : 0;   // loader set
     const int wv = tid >> 6;                                    // consumer wave / the wave a loader serves
     const unsigned myslot = wg * kThreads + tid;
 
@@ -291,7 +297,7 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
     }
     if (is_consumer) {
         for (int s = 0; s < kXD8; ++s) { v4i e; e.x = -1; e.y = 0; e.z = 0; e.w = 0; xr[s * kThreads + tid] = e; }
-        if ((tid & 63) == 0) { avail[wv] = 0; cons[wv] = 0; wdone[wv] = nch > 0 ? tmin - 1 : kDone; }
+        if ((tid & 63) == 0) { avail[wv] = 0; avail[4 + wv] = 1; cons[wv] = 0; wdone[wv] = nch > 0 ? tmin - 1 : kDone; }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
@@ -301,12 +307,13 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
         const int L = tid & 63;
         const v4i *p = pk + (size_t)base * 192 + L;
         const long ysrc0 = (ypk_in && cnt > 0) ? (long)ysrc[myslot] : 0;
-        int c_next = 0;
+        int c_next = lset;
         unsigned idle = 0;
         while (c_next < nch) {
             asm volatile("" ::: "memory");
-            int room = cons[wv] + kCD - c_next;
-            room = room < nch - c_next ? room : nch - c_next;
+            int lim = cons[wv] + kCD;
+            lim = lim < nch ? lim : nch;
+            int room = (lim - c_next + kLS - 1) / kLS;              // chunks of this set in [c_next, lim)
             room = __builtin_amdgcn_readfirstlane(room);
             if (room <= 0) {
                 __builtin_amdgcn_s_sleep(2);
@@ -319,10 +326,11 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
 #pragma unroll
             for (int u = 0; u < kLB; ++u) {
                 if (u < room) {
-                    const size_t o = (size_t)(c_next + u) * 192;
+                    const int cu = c_next + kLS * u;
+                    const size_t o = (size_t)cu * 192;
                     // read once: streaming loads
                     d[u] = __builtin_nontemporal_load(p + o); a[u] = __builtin_nontemporal_load(p + o + 64); b[u] = __builtin_nontemporal_load(p + o + 128);
-                    const int k = tmin + c_next + u - sk;
+                    const int k = tmin + cu - sk;
                     int r = r0 + DR * k;
                     r = (k >= 0 && k < cnt) ? r : r0;
                     r = r < 0 ? 0 : (r >= n ? n - 1 : r);
@@ -332,16 +340,16 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
 #pragma unroll
             for (int u = 0; u < kLB; ++u) {
                 if (u < room) {
-                    unsigned char *q = smem + (size_t)((c_next + u) & (kCD - 1)) * kChunkLds;
+                    unsigned char *q = smem + (size_t)((c_next + kLS * u) & (kCD - 1)) * kChunkLds;
                     reinterpret_cast<v4i *>(q)[tid] = d[u];
                     reinterpret_cast<v4i *>(q + kThreads * 16)[tid] = a[u];
                     reinterpret_cast<v4i *>(q + kThreads * 32)[tid] = b[u];
                     reinterpret_cast<double *>(q + kThreads * 48)[tid] = rr[u];
                 }
             }
-            c_next += room < kLB ? room : kLB;
+            c_next += kLS * (room < kLB ? room : kLB);
             asm volatile("" ::: "memory");
-            if (L == 0) avail[wv] = c_next;
+            if (L == 0) avail[4 * lset + wv] = c_next;
         }
         return;
     }
@@ -424,7 +432,7 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
         unsigned spins = 0;
         for (;;) {
             asm volatile("" ::: "memory");
-            const int av = avail[wv];
+            const int av = avail[4 * (kLS > 1 ? (c % kLS) : 0) + wv];
             const v4i wd = *wdone4;
             asm volatile("" ::: "memory");
             rec = reinterpret_cast<const v4i *>(q)[tid];
