@@ -172,7 +172,7 @@ bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <=
 void destroy_obj(ilupp_precond *p)
 {
     if (!p) return;
-    if (p->stream) (void)hipStreamSynchronize(p->stream);   // pooled blocks may be handed out again at once
+    if (p->stream) (void)stream_sync(p->stream);   // pooled blocks may be handed out again at once
     if (p->side) (void)hipStreamSynchronize(p->side);
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
@@ -321,7 +321,7 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     rc = ilu0_numeric_any(p, A, have_prog, &kms);
     if (patterns_aside) ILUPP_HIP(hipStreamWaitEvent(st, p->sev[1], 0));
     ILUPP_HIP(hipEventRecord(a2, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
     p->tm.numeric_kernel_ms = kms;
@@ -335,7 +335,7 @@ void ensure_csr_values(ilupp_precond *p)
     if (p->csr_vals) return;
     lm_unpack(p->stream, p->Lc, p->sA, p->pkL);
     lm_unpack(p->stream, p->Uc, p->sU, p->pkU);
-    ILUPP_HIP(hipStreamSynchronize(p->stream));
+    ILUPP_HIP(stream_sync(p->stream));
     p->csr_vals = true;
 }
 
@@ -467,8 +467,8 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
 int finish_apply(ilupp_precond *p)
 {
     int32_t err = 0;
-    ILUPP_HIP(hipMemcpyAsync(&err, p->ctrl, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
-    ILUPP_HIP(hipStreamSynchronize(p->stream));
+    ILUPP_HIP(d2h_async(p->stream, &err, p->ctrl, sizeof(int32_t)));
+    ILUPP_HIP(stream_sync(p->stream));
     if (p->apply_events_valid) {
         ILUPP_HIP(hipEventElapsedTime(&p->tm.lsolve_kernel_ms, p->ev[0], p->ev[1]));
         ILUPP_HIP(hipEventElapsedTime(&p->tm.usolve_kernel_ms, p->ev[1], p->ev[2]));
@@ -477,7 +477,7 @@ int finish_apply(ilupp_precond *p)
     if (err) {
         // a sweep gave up: restore the all-sentinel invariant of the work vector
         fill_u64(p->stream, reinterpret_cast<unsigned long long *>(p->work), p->n, kSentinel);
-        ILUPP_HIP(hipStreamSynchronize(p->stream));
+        ILUPP_HIP(stream_sync(p->stream));
         set_error("triangular solve: dependency wait timed out (factor not triangular?)");
         return ILUPP_ERR_TIMEOUT;
     }
@@ -500,8 +500,8 @@ int ilu0_create_common(const DevMat &A, int is_csr, ilupp_precond **out)
 
 #define API_TRY try {
 #define API_CATCH                                                          \
-    } catch (const ilupp::HipError &e) { return ilupp::report(e); }        \
-    catch (const std::bad_alloc &) { ilupp::set_error("out of host memory"); return ILUPP_ERR_MEMORY; }
+    } catch (const ilupp::HipError &e) { ilupp::d2h_cancel_all(); return ilupp::report(e); }        \
+    catch (const std::bad_alloc &) { ilupp::d2h_cancel_all(); ilupp::set_error("out of host memory"); return ILUPP_ERR_MEMORY; }
 
 extern "C" {
 
@@ -575,7 +575,7 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     float kms = 0.f;
     int rc = ilu0_numeric_any(p, A, p->prog.prog != nullptr, &kms);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));
     p->tm.numeric_kernel_ms = kms;
     p->apply_events_valid = false;
@@ -642,7 +642,7 @@ int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int3
         make_desc(st, p->Uc, p->sU, &p->dU);
     }
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
     p->tm.numeric_kernel_ms = kms;
@@ -677,7 +677,7 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
     ILUPP_HIP(hipEventRecord(p->ev[0], st));
     int32_t missing = -1;
     rc = triangular_part(st, A, true, &p->Lc, &missing);
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     A.release();
     if (rc == ILUPP_ERR_NO_DIAGONAL) {
         set_error("IChol0: structurally missing diagonal entry in row " + std::to_string(missing));
@@ -694,7 +694,7 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
     float kms = 0.f;
     rc = ichol0_numeric(st, &p->Lc, p->sL, p->max_row_len, p->done, p->ctrl, &kms);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[0], p->ev[1]));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));
     p->tm.numeric_kernel_ms = kms;
@@ -734,7 +734,7 @@ int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const in
     DevMat T;
     int32_t missing = -1;
     rc = triangular_part(st, A, false, &T, &missing);        // natural_triangular_part(false): keep idx >= major
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     A.release();
     float kms = 0.f;
     // a missing diagonal is caught by the reference inside the column loop (IChol.hpp:105-107); same error here
@@ -756,7 +756,7 @@ int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const in
     p->compact = schedule_is_compact(p->sL);
     if (p->compact) make_desc(st, p->Lc, p->sL, &p->dL);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
     p->tm.numeric_kernel_ms = kms;
@@ -846,7 +846,7 @@ int ilupp_hip_factor_copy(const ilupp_precond *p, int which, double *data, int32
     const DevMat *M = exposed(p, which, &csr);
     if (!M) { set_error("no such factor"); return ILUPP_ERR_INVALID; }
     ensure_csr_values(const_cast<ilupp_precond *>(p));
-    ILUPP_HIP(hipStreamSynchronize(p->stream));
+    ILUPP_HIP(stream_sync(p->stream));
     ILUPP_HIP(hipMemcpy(indptr, M->ptr, sizeof(int32_t) * (size_t)(p->n + 1), hipMemcpyDeviceToHost));
     if (M->nnz > 0) {
         ILUPP_HIP(hipMemcpy(indices, M->idx, sizeof(int32_t) * (size_t)M->nnz, hipMemcpyDeviceToHost));

@@ -644,8 +644,8 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t ctrl[4];
-    ILUPP_HIP(hipMemcpyAsync(ctrl, d_ctrl, 16, hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, 16));
+    ILUPP_HIP(stream_sync(st));
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
 #ifdef ILUPP_TIMELINE
     if (pl->nwg <= 4096) {

@@ -444,9 +444,9 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     structure_launch(st, A, fwd, +1, pl);
     structure_launch(st, A, bwd, -1, pu);
     int32_t hl[4], hu[4];
-    ILUPP_HIP(hipMemcpyAsync(hl, pl->flags, sizeof(hl), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipMemcpyAsync(hu, pu->flags, sizeof(hu), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
+    ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
+    ILUPP_HIP(stream_sync(st));
     const int64_t lim = 2 * (int64_t)A.n + 64 * 4 * (int64_t)pl->nwg;
     if (hl[0] || hu[0] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim) {
         if (dbg) fprintf(stderr, "[ilupp] level-major analysis: structure rejected (%d %d, %d %d chunks)\n", hl[0], hu[0], hl[1], hu[1]);
@@ -494,9 +494,9 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     hipLaunchKernelGGL(k_flm_xbase_a, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, f->xbase, f->xcount);
     ILUPP_HIP(pool_malloc(&f->xch, sizeof(double) * 4 * (size_t)A.n + 64));
     int32_t gl[8], gu[8];
-    ILUPP_HIP(hipMemcpyAsync(gl, pl->flags, sizeof(gl), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipMemcpyAsync(gu, pu->flags, sizeof(gu), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, gl, pl->flags, sizeof(gl)));
+    ILUPP_HIP(d2h_async(st, gu, pu->flags, sizeof(gu)));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(rows));
     ILUPP_HIP(pool_free(tmp));
     if (dbg) fprintf(stderr, "[ilupp] level-major analysis: flags fwd %d/%d bwd %d link %d, %d+%d chunks\n", gl[0], gl[4], gu[0], gu[3], hl[1], hu[1]);

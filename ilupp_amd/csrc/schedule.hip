@@ -124,7 +124,7 @@ static int32_t *tiling_sample(hipStream_t st, const int32_t *ptr, const int32_t 
     hipLaunchKernelGGL(k_sample_block_offsets, dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, nsamp, stride,
                        sch->B, sch->nb, fwd ? 1 : 0, sch->start, ptr, idx, d_offs);
     h->resize((size_t)nsamp * 8);
-    ILUPP_HIP(hipMemcpyAsync(h->data(), d_offs, sizeof(int32_t) * h->size(), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(d2h_async(st, h->data(), d_offs, sizeof(int32_t) * h->size()));
     return d_offs;
 }
 static void tiling_decide(const std::vector<int32_t> &h, Schedule *sch, int max_wgs)
@@ -168,7 +168,7 @@ void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t 
     if (!tiling_wanted(sch)) return;
     std::vector<int32_t> h;
     int32_t *d = tiling_sample(st, ptr, idx, sch, fwd, &h);
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(d));
     tiling_decide(h, sch, max_wgs);
 }
@@ -182,7 +182,7 @@ void choose_tiling_pair(hipStream_t st, const int32_t *ptr, const int32_t *idx, 
     int32_t *df = tiling_wanted(fwd) ? tiling_sample(st, ptr, idx, fwd, true, &hf) : nullptr;
     int32_t *db = tiling_wanted(bwd) ? tiling_sample(st, ptr, idx, bwd, false, &hb) : nullptr;
     if (!df && !db) return;
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     if (df) { ILUPP_HIP(pool_free(df)); tiling_decide(hf, fwd, max_wgs); }
     if (db) { ILUPP_HIP(pool_free(db)); tiling_decide(hb, bwd, max_wgs); }
 }
@@ -429,8 +429,8 @@ bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, con
     hipLaunchKernelGGL(k_ilu0_program_f3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr,
                        sch.B, sch.nb, sch.start, sch.blk2slot, prog, flag, sch.exported);
     int32_t h = 0;
-    ILUPP_HIP(hipMemcpyAsync(&h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, &h, flag, sizeof(int32_t)));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(flag));
     if (h != 0) { ILUPP_HIP(pool_free(prog)); return false; }
     *prog_out = prog;
@@ -458,9 +458,9 @@ bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const 
     ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, nwords, P->prow + 1, n, st));
     int32_t h[4], total = 0;
-    ILUPP_HIP(hipMemcpyAsync(h, stats, 16, hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipMemcpyAsync(&total, P->prow + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, h, stats, 16));
+    ILUPP_HIP(d2h_async(st, &total, P->prow + n, sizeof(int32_t)));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(tmp));
     P->max_words = h[0];
     P->max_ulen = h[1];
@@ -474,7 +474,7 @@ bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const 
     ILUPP_HIP(pool_malloc(&P->prog, sizeof(int32_t) * (size_t)total));
     hipLaunchKernelGGL((k_ilu0_program<true>), dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, U.ptr, sch.B, sch.nb,
                        sch.start, sch.blk2slot, nwords, P->prow, P->prog, stats);
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(nwords)); ILUPP_HIP(pool_free(stats));
     return true;
 }

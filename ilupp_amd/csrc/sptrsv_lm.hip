@@ -566,8 +566,8 @@ bool lm_prepare(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule 
                        ps->skew, ps->wtab, ps->flags);
     hipLaunchKernelGGL(k_lm_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, ps->wtab, ps->flags);
     int32_t h[4] = {0, 0, 0, 0};
-    ILUPP_HIP(hipMemcpyAsync(h, ps->flags, sizeof(h), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, h, ps->flags, sizeof(h)));
+    ILUPP_HIP(stream_sync(st));
     // give up on irregular structures: skews ran away, or the padding would outweigh the gain
     const int64_t rows_padded = (int64_t)h[1] * 64;
     if (h[0] != 0 || h[1] <= 0 || rows_padded > 2 * (int64_t)M.n + 64 * 4 * (int64_t)nwg) { ps->release(); return false; }
@@ -611,8 +611,8 @@ bool lm_finish(hipStream_t st, PackedSweep *ps)
 {
     if (!ps->built) return false;
     int32_t h[4] = {0, 0, 0, 0};
-    ILUPP_HIP(hipMemcpyAsync(h, ps->flags, sizeof(h), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, h, ps->flags, sizeof(h)));
+    ILUPP_HIP(stream_sync(st));
     static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[ilupp] packed sweep kind %d: flags %d/%d, %lld chunks\n", ps->kind, h[0], h[3], (long long)ps->nchunks);
     if (h[0] != 0) { ps->release(); return false; }

@@ -10,11 +10,76 @@
 //    (sparse_implementation.h:4055-4065, :4075-4084), built with a stable radix sort.
 //
 // Everything here is streaming integer work: coalesced loads, HBM-bound, no MFMA.
+#include <string.h>
+
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
 
 namespace ilupp {
+
+// ---------------------------------------------------------------------------------------------
+// small device-to-host read-backs (flags, counts) without a copy command: a one-block kernel writes the words into a
+// pinned, device-mapped staging buffer of the stream; stream_sync() hands them to their destinations.  A
+// hipMemcpyAsync to pageable memory costs 40-50 us of idle stream per read-back on this stack (copy command + staging),
+// and the ILU(0) analysis has half a dozen of them.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Staging { char *host = nullptr; char *dev = nullptr; size_t used = 0; struct Item { void *dst; size_t off, bytes; }; std::vector<Item> pending; };
+std::mutex g_stage_mu;
+std::unordered_map<hipStream_t, Staging> g_stage;
+constexpr size_t kStageBytes = 65536;
+}
+__global__ void k_copy_words(const int *__restrict__ src, int *__restrict__ dst, int nwords)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nwords) dst[i] = src[i];
+}
+hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t bytes)
+{
+    static const bool off = getenv("ILUPP_NO_MAPPED_READBACK") != nullptr;
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    Staging &s = g_stage[st];
+    if (!off && !s.host) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, kStageBytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            s.host = static_cast<char *>(h); s.dev = static_cast<char *>(d);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (off || !s.host || (bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(dev_src) & 3) != 0 || s.used + bytes > kStageBytes)
+        return hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st);
+    const int nwords = (int)(bytes / 4);
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, static_cast<const int *>(dev_src),
+                       reinterpret_cast<int *>(s.dev + s.used), nwords);
+    s.pending.push_back({host_dst, s.used, bytes});
+    s.used += (bytes + 15) & ~(size_t)15;
+    return hipGetLastError();
+}
+// after a failure: destinations of read-backs still pending may be gone (stack variables of the frames that threw)
+void d2h_cancel_all()
+{
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    for (auto &kv : g_stage) { kv.second.pending.clear(); kv.second.used = 0; }
+}
+hipError_t stream_sync(hipStream_t st)
+{
+    const hipError_t e = hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    auto it = g_stage.find(st);
+    if (it != g_stage.end()) {
+        Staging &s = it->second;
+        if (e == hipSuccess) for (const auto &p : s.pending) memcpy(p.dst, s.host + p.off, p.bytes);
+        s.pending.clear();
+        s.used = 0;
+    }
+    return e;
+}
 
 int device_cu_count()
 {
@@ -160,7 +225,28 @@ __global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, co
     }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); }
     __syncthreads();
-    if (threadIdx.x == 0) { atomicAdd(&stats[0], red[0]); atomicAdd(&stats[1], red[1]); atomicMax(&stats[2], red[2]); atomicMin(&stats[3], red[3]); }
+    // per-block partial results; k_reduce_stats folds them (same-address atomics cost ~10 ns each on this chip: four per
+    // block were 0.16 of this kernel's 0.26 ms at 4096 blocks, and 1.2 ms at 32768)
+    if (threadIdx.x == 0) { int *o = stats + 4 + 4 * blockIdx.x; o[0] = red[0]; o[1] = red[1]; o[2] = red[2]; o[3] = red[3]; }
+}
+
+__global__ void k_reduce_stats(int nblocks, int32_t *stats)
+{
+    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        const int *o = stats + 4 + 4 * b;
+        nf += o[0]; nbk += o[1]; mx = max(mx, o[2]); miss = min(miss, o[3]);
+    }
+    __shared__ int red[4];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0;
+    if (threadIdx.x == 3) red[3] = 0x7fffffff;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); miss = min(miss, __shfl_xor(miss, off));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); }
+    __syncthreads();
+    if (threadIdx.x == 0) { stats[0] = red[0]; stats[1] = red[1]; stats[2] = red[2]; stats[3] = red[3]; }
 }
 
 // L/U patterns from the row pointers of L alone: Uptr[r] = Aptr[r] - (Lptr[r] - r)
@@ -204,12 +290,11 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
     ILUPP_HIP(pool_malloc(&cutf, (size_t)n + 1));
     ILUPP_HIP(pool_malloc(&cutb, (size_t)n + 1));
     ILUPP_HIP(pool_malloc(&lrow, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(pool_malloc(&stats, sizeof(int32_t) * 4));
-    const int32_t init[4] = {0, 0, 0, 0x7fffffff};
-    ILUPP_HIP(hipMemcpyAsync(stats, init, sizeof(init), hipMemcpyHostToDevice, st));
     unsigned gb = (unsigned)((n + 255) / 256);
-    if (gb > 4096) gb = 4096;
+    if (gb > 16384) gb = 16384;
+    ILUPP_HIP(pool_malloc(&stats, sizeof(int32_t) * (4 + 4 * (size_t)gb)));
     hipLaunchKernelGGL(k_row_cuts_counts, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz, cutf, cutb, lrow, stats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(1024), 0, st, (int)gb, stats);
     L->n = U->n = n; L->is_csr = U->is_csr = true; L->owns = U->owns = true;
     ILUPP_HIP(pool_malloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(pool_malloc(&U->ptr, sizeof(int32_t) * (size_t)(n + 1)));
@@ -220,9 +305,9 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
     ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, lrow, L->ptr + 1, n, st));
     int32_t h[4], nnzl = 0;
-    ILUPP_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipMemcpyAsync(&nnzl, L->ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, h, stats, sizeof(h)));
+    ILUPP_HIP(d2h_async(st, &nnzl, L->ptr + n, sizeof(int32_t)));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(tmp)); ILUPP_HIP(pool_free(lrow)); ILUPP_HIP(pool_free(stats));
     if (max_row_len) *max_row_len = h[2];
     if (first_missing_diag) *first_missing_diag = (h[3] == 0x7fffffff) ? -1 : h[3];
@@ -237,7 +322,7 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
     // solves reads them when the level-major kernels run, so the caller overlaps that pass with the factor kernel)
     make_schedule(st, n, cutf, h[0], max_lanes, fwd);
     make_schedule(st, n, cutb, h[1], max_lanes, bwd);
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(cutf));
     ILUPP_HIP(pool_free(cutb));
     return ILUPP_OK;
@@ -267,12 +352,12 @@ int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const
         hipLaunchKernelGGL(k_row_cuts, dim3(gb), dim3(256), 0, st, n, ptr, idx, cutf, cutb, stats);
     }
     int32_t h[4];
-    ILUPP_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(d2h_async(st, h, stats, sizeof(h)));
+    ILUPP_HIP(stream_sync(st));
     if (max_row_len) *max_row_len = h[2];
     if (fwd) make_schedule(st, n, cutf, h[0], max_lanes, fwd);
     if (bwd) make_schedule(st, n, cutb, h[1], max_lanes, bwd);
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(cutf));
     ILUPP_HIP(pool_free(cutb));
     ILUPP_HIP(pool_free(stats));
@@ -343,7 +428,7 @@ void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_gather_transposed, dim3((unsigned)blocks), dim3(256), 0, st, nnz, perm, rowid, A.val, T->idx, T->val);
     hipLaunchKernelGGL(k_ptr_from_sorted, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, n, nnz, keys_out, T->ptr);
-    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(tmp));
     ILUPP_HIP(pool_free(rowid)); ILUPP_HIP(pool_free(seq)); ILUPP_HIP(pool_free(keys_out)); ILUPP_HIP(pool_free(perm));
 }
