@@ -182,6 +182,9 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
         if (!bad) {
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
+#ifdef EXP_REC_NODEP
+                continue;
+#endif
                 if (e >= cl) continue;
                 const int sl = e + 3 - cl;                    // right-aligned dependency slot of the program
                 const int kc = own.c[e];
@@ -267,7 +270,11 @@ k_fwd_records(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx
     __builtin_nontemporal_store(lrec, pkL + ((size_t)base + c) * 192 + L);
     v4i *p = pkA + ((size_t)base + c) * 320 + L;
     __builtin_nontemporal_store(dec, p + 256);
+#ifdef EXP_REC_NOVAL
+    if (true) {
+#else
     if (!Aval) {
+#endif
         int *q = reinterpret_cast<int *>(p + 192);
         q[2] = w0; q[3] = w1;
     } else {
