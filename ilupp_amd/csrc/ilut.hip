@@ -477,7 +477,7 @@ int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double thr
     ILUPP_HIP(pool_malloc(&Llen, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&Ulen, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&done, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(pool_malloc(&ctrl, 64));
+    ILUPP_HIP(pool_malloc(&ctrl, 256));
     // the wave-parallel kernel (ilut_wp.hip) first; k_ilut_rows below is the any-capacity fallback and the A/B check
     // (ILUPP_ILUT_SEQUENTIAL=1)
     {

@@ -261,6 +261,9 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             if (++spins > ILUT_SPIN) return 2;
             __builtin_amdgcn_s_sleep(1);
         }
+#ifdef ILUT_PROFILE
+        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + 4, (unsigned long long)spins); atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + 5, 1ull); }
+#endif
         ul = __builtin_amdgcn_readfirstlane(ul);
         WP_T(tp2); WP_ACC(1, tp1, tp2);
         const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
@@ -291,6 +294,36 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             bfound[lane] = 0;
             __builtin_amdgcn_wave_barrier();
             const int bmin = bcol[0], bmax = bcol[cnt - 1];
+            if (cnt <= 16) {
+                // the usual case (p <= 16): the U row's columns sit in 16 scalars and every slot is compared against all of
+                // them -- a binary search per slot is a chain of dependent LDS reads that the whole wave pays for as soon
+                // as one lane's slot lies in [bmin, bmax], i.e. always (it was 5-6 us per U row, 3/4 of a row's time)
+                int bc[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) bc[jj] = __builtin_amdgcn_readfirstlane(jj < cnt ? bcol[jj] : -1);
+#define WP_MATCH(c2, m) do { _Pragma("unroll") for (int jj = 0; jj < 16; ++jj) m = (c2) == bc[jj] ? jj : m; } while (0)
+                for (int q = lane; q < nL; q += 128) {
+                    const int q1 = q + 64;
+                    const int ca = A::ldi(&w.lcol[q]);
+                    const int cb = q1 < nL ? A::ldi(&w.lcol[q1]) : -2;
+                    int ma = -1, mb = -1;
+                    WP_MATCH(ca, ma);
+                    WP_MATCH(cb, mb);
+                    if (ma >= 0) { const double o = A::ldd(&w.lval[q]); A::std_(&w.lval[q], o - bpr[ma]); bfound[ma] = 1; }
+                    if (mb >= 0) { const double o = A::ldd(&w.lval[q1]); A::std_(&w.lval[q1], o - bpr[mb]); bfound[mb] = 1; }
+                }
+                for (int q = lane; q < nU; q += 128) {
+                    const int q1 = q + 64;
+                    const int ca = A::ldi(&w.ucol[q]);
+                    const int cb = q1 < nU ? A::ldi(&w.ucol[q1]) : -2;
+                    int ma = -1, mb = -1;
+                    WP_MATCH(ca, ma);
+                    WP_MATCH(cb, mb);
+                    if (ma >= 0) { const double o = A::ldd(&w.uval[q]); A::std_(&w.uval[q], o - bpr[ma]); bfound[ma] = 1; }
+                    if (mb >= 0) { const double o = A::ldd(&w.uval[q1]); A::std_(&w.uval[q1], o - bpr[mb]); bfound[mb] = 1; }
+                }
+#undef WP_MATCH
+            } else {
             for (int q = lane; q < nL; q += 64) {
                 const int c2 = A::ldi(&w.lcol[q]);
                 if (c2 >= bmin && c2 <= bmax) {
@@ -307,6 +340,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                     if (bcol[lo] == c2) { const double o = A::ldd(&w.uval[q]); A::std_(&w.uval[q], o - bpr[lo]); bfound[lo] = 1; }
                 }
             }
+            }
+            WP_T(ts1);
             const unsigned long long md = __ballot(valid && c == i);
             if (md != 0ull) wdiag = wdiag - wave_bcast_f64(pr, __ffsll((long long)md) - 1);
             A::sync();
@@ -318,6 +353,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
+            WP_T(ts2); WP_ACC(6, ts1, ts2);
         }
         WP_T(tp3); WP_ACC(2, tp2, tp3);
     }
@@ -405,6 +441,7 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     if (p - 1 >= kWpSel) return 1;
     const size_t slab = (size_t)n * p;
     int workers = device_cu_count() * 3;
+    if (const char *e = getenv("ILUPP_ILUT_WAVES")) { const int v = atoi(e); if (v > 0 && v < workers) workers = v; }     // experiments
     if (workers > n) workers = n;
     WpArrays g = {nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
     int *gscratch = nullptr;
@@ -420,8 +457,8 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     ILUPP_HIP(hipMemsetAsync(Uri, 0xff, sizeof(int32_t) * slab, st));
     fill_u64(st, reinterpret_cast<unsigned long long *>(Urv), (int64_t)slab, kSentinel);
     ILUPP_HIP(hipMemsetAsync(Ulen, 0, sizeof(int32_t) * (size_t)n, st));
-    const int32_t init[16] = {0, 0, 0x7fffffff, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    ILUPP_HIP(hipMemcpyAsync(ctrl, init, 64, hipMemcpyHostToDevice, st));
+    const int32_t init[32] = {0, 0, 0x7fffffff};
+    ILUPP_HIP(hipMemcpyAsync(ctrl, init, 128, hipMemcpyHostToDevice, st));
     hipEvent_t e0, e1;
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
@@ -441,10 +478,10 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         ILUPP_HIP(pool_free(q));
 #ifdef ILUT_PROFILE
     {
-        unsigned long long t[4];
-        ILUPP_HIP(hipMemcpy(t, ctrl + 8, 32, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ilupp] ilut_wp cycles (sum over waves, M): pops+drops %.1f  fetch %.1f  update %.1f  dropping %.1f\n",
-                t[0] * 1e-6, t[1] * 1e-6, t[2] * 1e-6, t[3] * 1e-6);
+        unsigned long long t[8];
+        ILUPP_HIP(hipMemcpy(t, ctrl + 8, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ilupp] ilut_wp cycles (sum over waves, M): pops+drops %.1f  fetch %.1f  update %.1f (of which append %.1f)  dropping %.1f;  %llu fetches, %llu retries\n",
+                t[0] * 1e-6, t[1] * 1e-6, t[2] * 1e-6, t[6] * 1e-6, t[3] * 1e-6, t[5], t[4]);
     }
 #endif
     if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: %d of %d rows outgrew LDS (pool %d, U slots %d, kept %d), status %d, kernel %.3f ms\n", h[3], n, h[4], h[5], h[6], h[1], kernel_ms ? *kernel_ms : 0.f);
