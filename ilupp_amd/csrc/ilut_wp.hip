@@ -32,8 +32,10 @@
 
 namespace ilupp {
 
-static constexpr int kWpCapU = 1536, kWpCapL = 1408, kWpCapK = 512, kWpSel = 512;
-static constexpr int kWpGCapU = 1 << 16, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;
+static constexpr int kWpCapU = 1536, kWpCapL = 1536, kWpSel = 256;      // (the KEPT list is append-only until the end: it lives in global memory)
+static constexpr int kWpHashLds = 4096;                       // cells of the U-slot hash table in LDS (2 bytes each)
+static constexpr int kWpGCapU = 65534, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;      // (U slot ids + 1 fit the table's 16-bit cells)
+static constexpr int kWpHashG = 1 << 17;
 #ifndef ILUT_SPIN
 #define ILUT_SPIN (1u << 24)
 #endif
@@ -47,9 +49,10 @@ static constexpr int kWpGCapU = 1 << 16, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;
 #endif
 
 struct WpArrays {
+    unsigned short *uh; int hmask;           // column -> U slot + 1 (0 = empty), open addressing; all cells 0 between rows
     int *ucol; double *uval; int capU;
-    int *lcol; double *lval; int *lseq; int capL;
-    int *kcol; double *kval; int *kseq; int capK;
+    int *lcol; double *lval; unsigned short *lseq; int capL;      // (seq < 65536: it counts the left-part insertions of one row)
+    int *kcol; double *kval; unsigned short *kseq; int capK;
 };
 
 // accessors of the working-row pieces: LDS, or the wave's PRIVATE global arrays.  Those are only ever touched by this
@@ -59,6 +62,8 @@ template <bool G> struct WpAcc {
     static __device__ __forceinline__ double ldd(const double *p) { return *p; }
     static __device__ __forceinline__ void sti(int *p, int v) { *p = v; }
     static __device__ __forceinline__ void std_(double *p, double v) { *p = v; }
+    static __device__ __forceinline__ int ldi(const unsigned short *p) { return (int)*p; }
+    static __device__ __forceinline__ void sti(unsigned short *p, int v) { *p = (unsigned short)v; }
     // cross-lane hand-over inside the wave: LDS is in order per wave; global stores must have landed
     static __device__ __forceinline__ void sync() { if constexpr (G) __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
 };
@@ -189,6 +194,26 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
     return nsel;
 }
 
+// U-slot hash: what the reference does with its n-long occupancy array (sparse_implementation.h:987-993)
+__device__ __forceinline__ unsigned wp_hash(int c, int hmask) { return (((unsigned)c * 0x9E3779B1u) >> 12) & (unsigned)hmask; }
+template <bool G>
+__device__ __forceinline__ int wp_uh_find(const WpArrays &w, int c)
+{
+    unsigned h = wp_hash(c, w.hmask);
+    for (;;) {
+        const unsigned e = w.uh[h];
+        if (e == 0u) return -1;
+        if (WpAcc<G>::ldi(&w.ucol[e - 1]) == c) return (int)e - 1;
+        h = (h + 1) & (unsigned)w.hmask;
+    }
+}
+__device__ __forceinline__ void wp_uh_insert(const WpArrays &w, int c, int slot)      // one lane at a time
+{
+    unsigned h = wp_hash(c, w.hmask);
+    while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask;
+    w.uh[h] = (unsigned short)(slot + 1);
+}
+
 // one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout
 template <bool G>
 __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, const int p, const double tau,
@@ -201,6 +226,12 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nL = 0, nU = 0, nK = 0, seq = 0;
     double wdiag = 0.0;
+    // the U-slot hash starts empty
+    {
+        unsigned long long *t64 = reinterpret_cast<unsigned long long *>(w.uh);
+        for (int q = lane; q < (w.hmask + 1) / 4; q += 64) t64[q] = 0ull;
+        A::sync();
+    }
     // (2.) scatter the row (ILUT.hpp:222-231)
     const int a0 = Aptr[i], a1 = Aptr[i + 1];
     for (int base = a0; base < a1; base += 64) {
@@ -210,9 +241,14 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double v = valid ? Aval[q] : 0.0;
         const bool isL = valid && c < i, isU = valid && c > i, isD = valid && c == i;
         const unsigned long long mL = __ballot(isL), mU = __ballot(isU), mD = __ballot(isD);
+        if (seq + __popcll(mL) > 65535) return 1;
         if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
         if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
         if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], v); }
+        for (unsigned long long mm = mU; mm != 0ull; mm &= mm - 1ull) {
+            if (lane == __ffsll((long long)mm) - 1) wp_uh_insert(w, c, nU + __popcll(mU & lt));
+            A::sync();
+        }
         if (mD != 0ull) wdiag = wave_bcast_f64(v, __ffsll((long long)mD) - 1);
         nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
     }
@@ -269,7 +305,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
         const double m = wkv / ud;                                           // :249
         if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); return 1; }
-        if (lane == 0) { A::sti(&w.kcol[nK], k); A::std_(&w.kval[nK], m); A::sti(&w.kseq[nK], sk); }
+        if (lane == 0) { w.kcol[nK] = k; w.kval[nK] = m; w.kseq[nK] = (unsigned short)sk; }
         ++nK;
         for (int base = 0; base < ul; base += 64) {                          // w -= m * U[k, j>k]  (:252-253)
             const int j = base + lane;
@@ -312,16 +348,6 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                     if (ma >= 0) { const double o = A::ldd(&w.lval[q]); A::std_(&w.lval[q], o - bpr[ma]); bfound[ma] = 1; }
                     if (mb >= 0) { const double o = A::ldd(&w.lval[q1]); A::std_(&w.lval[q1], o - bpr[mb]); bfound[mb] = 1; }
                 }
-                for (int q = lane; q < nU; q += 128) {
-                    const int q1 = q + 64;
-                    const int ca = A::ldi(&w.ucol[q]);
-                    const int cb = q1 < nU ? A::ldi(&w.ucol[q1]) : -2;
-                    int ma = -1, mb = -1;
-                    WP_MATCH(ca, ma);
-                    WP_MATCH(cb, mb);
-                    if (ma >= 0) { const double o = A::ldd(&w.uval[q]); A::std_(&w.uval[q], o - bpr[ma]); bfound[ma] = 1; }
-                    if (mb >= 0) { const double o = A::ldd(&w.uval[q1]); A::std_(&w.uval[q1], o - bpr[mb]); bfound[mb] = 1; }
-                }
 #undef WP_MATCH
             } else {
             for (int q = lane; q < nL; q += 64) {
@@ -332,25 +358,28 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                     if (bcol[lo] == c2) { const double o = A::ldd(&w.lval[q]); A::std_(&w.lval[q], o - bpr[lo]); bfound[lo] = 1; }
                 }
             }
-            for (int q = lane; q < nU; q += 64) {
-                const int c2 = A::ldi(&w.ucol[q]);
-                if (c2 >= bmin && c2 <= bmax) {
-                    int lo = 0, hi = cnt - 1;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (bcol[mid] < c2) lo = mid + 1; else hi = mid; }
-                    if (bcol[lo] == c2) { const double o = A::ldd(&w.uval[q]); A::std_(&w.uval[q], o - bpr[lo]); bfound[lo] = 1; }
-                }
             }
+            // right of the diagonal: the entry's own lane looks its column up in the hash (the reference's occupancy[] access)
+            bool ufound = false;
+            if (valid && c > i) {
+                const int us = wp_uh_find<G>(w, c);
+                if (us >= 0) { const double o = A::ldd(&w.uval[us]); A::std_(&w.uval[us], o - pr); ufound = true; }
             }
             WP_T(ts1);
             const unsigned long long md = __ballot(valid && c == i);
             if (md != 0ull) wdiag = wdiag - wave_bcast_f64(pr, __ffsll((long long)md) - 1);
             A::sync();
-            const bool nf = valid && c != i && bfound[lane] == 0;
+            const bool nf = valid && c != i && (c < i ? bfound[lane] == 0 : !ufound);
             const bool isL = nf && c < i, isU = nf && c > i;
             const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
+            if (seq + __popcll(mL) > 65535) return 1;
             if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
             if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], 0.0 - pr); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
+            for (unsigned long long mm = mU; mm != 0ull; mm &= mm - 1ull) {
+                if (lane == __ffsll((long long)mm) - 1) wp_uh_insert(w, c, nU + __popcll(mU & lt));
+                A::sync();
+            }
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
             WP_T(ts2); WP_ACC(6, ts1, ts2);
@@ -358,13 +387,18 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         WP_T(tp3); WP_ACC(2, tp2, tp3);
     }
     WP_T(tq0);
-    // (10.) dropping (ILUT.hpp:259,261): the multipliers back in insertion order, then both pieces
+    // (10.) dropping (ILUT.hpp:259,261): the multipliers back in insertion order (the pool is empty now: its arrays take
+    // them), then both pieces
+    if (nK > w.capL) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); return 1; }
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int q = lane; q < nK; q += 64) A::sti(&w.lseq[q], (int)w.kseq[q]);
+    A::sync();
     for (int q = lane; q < nK; q += 64) {
-        const int s = A::ldi(&w.kseq[q]);
+        const int s = A::ldi(&w.lseq[q]);
         int r = 0;
-        for (int q2 = 0; q2 < nK; ++q2) r += (A::ldi(&w.kseq[q2]) < s) ? 1 : 0;
-        A::sti(&w.lcol[r], A::ldi(&w.kcol[q]));
-        A::std_(&w.lval[r], A::ldd(&w.kval[q]));
+        for (int q2 = 0; q2 < nK; ++q2) r += (A::ldi(&w.lseq[q2]) < s) ? 1 : 0;
+        A::sti(&w.lcol[r], w.kcol[q]);
+        A::std_(&w.lval[r], w.kval[q]);
     }
     A::sync();
     const size_t lb = (size_t)i * p;
@@ -394,18 +428,21 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
                int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
                int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl)
 {
-    __shared__ int s_ucol[kWpCapU], s_lcol[kWpCapL], s_lseq[kWpCapL], s_kcol[kWpCapK], s_kseq[kWpCapK], s_selq[kWpSel];
-    __shared__ double s_uval[kWpCapU], s_lval[kWpCapL], s_kval[kWpCapK];
+    __shared__ int s_ucol[kWpCapU], s_lcol[kWpCapL], s_selq[kWpSel];
+    __shared__ unsigned short s_lseq[kWpCapL];
+    __shared__ double s_uval[kWpCapU], s_lval[kWpCapL];
     __shared__ int bcol[64], bfound[64];
     __shared__ double bpr[64];
+    __shared__ __attribute__((aligned(16))) unsigned short s_uh[kWpHashLds];
     const int lane = threadIdx.x;
     const size_t wv = blockIdx.x;
-    const WpArrays lw = {s_ucol, s_uval, kWpCapU, s_lcol, s_lval, s_lseq, kWpCapL, s_kcol, s_kval, s_kseq, kWpCapK};
     WpArrays g = gw;
+    g.uh += wv * (size_t)kWpHashG;
     g.ucol += wv * (size_t)gw.capU; g.uval += wv * (size_t)gw.capU;
     g.lcol += wv * (size_t)gw.capL; g.lval += wv * (size_t)gw.capL; g.lseq += wv * (size_t)gw.capL;
     g.kcol += wv * (size_t)gw.capK; g.kval += wv * (size_t)gw.capK; g.kseq += wv * (size_t)gw.capK;
     int *gscratch = gscratch_all + wv * (size_t)gw.capU;
+    const WpArrays lw = {s_uh, kWpHashLds - 1, s_ucol, s_uval, kWpCapU, s_lcol, s_lval, s_lseq, kWpCapL, g.kcol, g.kval, g.kseq, gw.capK};
     for (;;) {
         int i = 0;
         if (lane == 0) i = atomicAdd(&ctrl[0], 1);
@@ -443,16 +480,17 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     int workers = device_cu_count() * 3;
     if (const char *e = getenv("ILUPP_ILUT_WAVES")) { const int v = atoi(e); if (v > 0 && v < workers) workers = v; }     // experiments
     if (workers > n) workers = n;
-    WpArrays g = {nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
+    WpArrays g = {nullptr, kWpHashG - 1, nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
+    ILUPP_HIP(pool_malloc(&g.uh, sizeof(unsigned short) * (size_t)workers * kWpHashG));
     int *gscratch = nullptr;
     ILUPP_HIP(pool_malloc(&g.ucol, sizeof(int) * (size_t)workers * g.capU));
     ILUPP_HIP(pool_malloc(&g.uval, sizeof(double) * (size_t)workers * g.capU));
     ILUPP_HIP(pool_malloc(&g.lcol, sizeof(int) * (size_t)workers * g.capL));
     ILUPP_HIP(pool_malloc(&g.lval, sizeof(double) * (size_t)workers * g.capL));
-    ILUPP_HIP(pool_malloc(&g.lseq, sizeof(int) * (size_t)workers * g.capL));
+    ILUPP_HIP(pool_malloc(&g.lseq, sizeof(unsigned short) * (size_t)workers * g.capL));
     ILUPP_HIP(pool_malloc(&g.kcol, sizeof(int) * (size_t)workers * g.capK));
     ILUPP_HIP(pool_malloc(&g.kval, sizeof(double) * (size_t)workers * g.capK));
-    ILUPP_HIP(pool_malloc(&g.kseq, sizeof(int) * (size_t)workers * g.capK));
+    ILUPP_HIP(pool_malloc(&g.kseq, sizeof(unsigned short) * (size_t)workers * g.capK));
     ILUPP_HIP(pool_malloc(&gscratch, sizeof(int) * (size_t)workers * g.capU));
     ILUPP_HIP(hipMemsetAsync(Uri, 0xff, sizeof(int32_t) * slab, st));
     fill_u64(st, reinterpret_cast<unsigned long long *>(Urv), (int64_t)slab, kSentinel);
@@ -473,7 +511,7 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
     ILUPP_HIP(hipEventDestroy(e0));
     ILUPP_HIP(hipEventDestroy(e1));
-    for (void *q : {(void *)g.ucol, (void *)g.uval, (void *)g.lcol, (void *)g.lval, (void *)g.lseq, (void *)g.kcol, (void *)g.kval,
+    for (void *q : {(void *)g.uh, (void *)g.ucol, (void *)g.uval, (void *)g.lcol, (void *)g.lval, (void *)g.lseq, (void *)g.kcol, (void *)g.kval,
                     (void *)g.kseq, (void *)gscratch})
         ILUPP_HIP(pool_free(q));
 #ifdef ILUT_PROFILE
