@@ -207,11 +207,24 @@ __device__ __forceinline__ int wp_uh_find(const WpArrays &w, int c)
         h = (h + 1) & (unsigned)w.hmask;
     }
 }
-__device__ __forceinline__ void wp_uh_insert(const WpArrays &w, int c, int slot)      // one lane at a time
+// all lanes with `mine` insert their (distinct) columns at once: everybody walks to an empty cell and writes; where two
+// lanes picked the same cell one of the writes survives, the other lane sees a foreign value and walks on
+template <bool G>
+__device__ __forceinline__ void wp_uh_insert_all(const WpArrays &w, bool mine, int c, int slot)
 {
     unsigned h = wp_hash(c, w.hmask);
-    while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask;
-    w.uh[h] = (unsigned short)(slot + 1);
+    bool pending = mine;
+    while (__ballot(pending) != 0ull) {
+        if (pending) {
+            while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask;
+            w.uh[h] = (unsigned short)(slot + 1);
+        }
+        WpAcc<G>::sync();
+        if (pending) {
+            if (w.uh[h] == (unsigned short)(slot + 1)) pending = false;
+            else h = (h + 1) & (unsigned)w.hmask;
+        }
+    }
 }
 
 // one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout
@@ -245,10 +258,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
         if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
         if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], v); }
-        for (unsigned long long mm = mU; mm != 0ull; mm &= mm - 1ull) {
-            if (lane == __ffsll((long long)mm) - 1) wp_uh_insert(w, c, nU + __popcll(mU & lt));
-            A::sync();
-        }
+        A::sync();
+        wp_uh_insert_all<G>(w, isU, c, nU + __popcll(mU & lt));
         if (mD != 0ull) wdiag = wave_bcast_f64(v, __ffsll((long long)mD) - 1);
         nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
     }
@@ -376,10 +387,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
             if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], 0.0 - pr); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
-            for (unsigned long long mm = mU; mm != 0ull; mm &= mm - 1ull) {
-                if (lane == __ffsll((long long)mm) - 1) wp_uh_insert(w, c, nU + __popcll(mU & lt));
-                A::sync();
-            }
+            A::sync();
+            wp_uh_insert_all<G>(w, isU, c, nU + __popcll(mU & lt));
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
             WP_T(ts2); WP_ACC(6, ts1, ts2);
