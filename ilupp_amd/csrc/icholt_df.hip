@@ -41,12 +41,12 @@
 
 namespace ilupp {
 
-// LDS capacities come in two classes (template parameters of the kernel): NE = entries gathered per column (A's column +
-// the contributors' tails), NS = slots of the working column, TM = touch records per row.  The small class keeps 12 waves
-// per CU resident (the kernel is bound by the latency of its ~8 dependent memory round trips per column, so resident waves
+// LDS capacities come in three classes (template parameters of the kernel): NE = entries gathered per column (A's column +
+// the contributors' tails), NS = slots of the working column, TM = touch records per row.  The tiny class keeps 24 waves per CU resident, the small one 12 (the kernel is bound by the latency of its ~8 dependent memory round trips per column, so resident waves
 // are throughput); a factorisation that exceeds it is run again with the large class, then by the sequential kernel.
 static constexpr int kCtTmax = 128;   // touch records per row, large class (run-time T <= this)
 static constexpr int kCtTsmall = 64;
+static constexpr int kCtTtiny = 32;
 // ready queues: kCtQ of them, column i goes to queue i % kCtQ (so the number of entries a queue will ever get is known:
 // a worker whose ticket lies beyond it is done), wave w serves queue w % kCtQ.  One queue would put two atomics per
 // column on two addresses -- 33 M same-address atomics at 256^3, which alone take longer than the factorisation.
@@ -352,8 +352,9 @@ __global__ void k_ict_compact(int32_t m, const int32_t *__restrict__ Loff, const
 
 // one attempt with one capacity class; returns ILUPP_OK / an error of the reference / +1 = "outside this class"
 static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms,
-                          bool small)
+                          int cls)          // capacity class: 0 tiny (24 waves per CU), 1 small (12), 2 large (3)
 {
+    const bool small = cls <= 1;
     const int32_t m = Atri.n;
     if (add_fill_in < 0 || m < 1) return 1;
     const long slab = (long)Atri.nnz + (long)add_fill_in * (long)m;
@@ -367,7 +368,8 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     const long avg = Atri.nnz / m + 1;
     int T = 16;
     while (T < 4 * (avg + add_fill_in) && T < kCtTmax) T *= 2;
-    if (small && T > kCtTsmall) return 1;
+    if (cls == 1 && T > kCtTsmall) return 1;
+    if (cls == 0 && T > kCtTtiny) return 1;
     while (T > 16 && ((long)m * T > 0x7fffffffL || (size_t)m * T * 32 > ((size_t)96 << 30))) T /= 2;
     if ((long)m * T > 0x7fffffffL) return 1;
 
@@ -400,7 +402,7 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, ctrl_bytes, st));
     const int32_t big = 0x7fffffff;
     ILUPP_HIP(hipMemcpyAsync(ctrl + 3, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    int waves = device_cu_count() * (small ? 12 : 3);
+    int waves = device_cu_count() * (cls == 0 ? 24 : (cls == 1 ? 12 : 3));
     if (waves > m) waves = m;
     const int nq = waves < kCtQ ? waves : kCtQ;
     const int gb = (m + 255) / 256;
@@ -418,7 +420,10 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
     ILUPP_HIP(hipEventRecord(e0, st));
-    if (small)
+    if (cls == 0)
+        hipLaunchKernelGGL((k_icholt_df<128, 64, kCtTtiny>), dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in,
+                           threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
+    else if (small)
         hipLaunchKernelGGL((k_icholt_df<256, 128, kCtTsmall>), dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in,
                            threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
     else
@@ -465,8 +470,8 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
 // returns ILUPP_OK / an error of the reference / +1 = "not handled here, run the sequential kernel"
 int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms)
 {
-    int rc = icholt_attempt(st, Atri, add_fill_in, threshold, L, kernel_ms, true);
-    if (rc == 1) rc = icholt_attempt(st, Atri, add_fill_in, threshold, L, kernel_ms, false);
+    int rc = 1;
+    for (int cls = 0; cls < 3 && rc == 1; ++cls) rc = icholt_attempt(st, Atri, add_fill_in, threshold, L, kernel_ms, cls);
     return rc;
 }
 
