@@ -229,12 +229,21 @@ __global__ void k_lm_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, con
 #ifndef KLB
 #define KLB 3
 #endif
-static constexpr int kCD = 8;              // chunk ring depth
+#ifndef LM_CD
+#define LM_CD 8
+#endif
+#ifndef LM_XD
+#define LM_XD 8
+#endif
+#ifndef LM_BACK
+#define LM_BACK 4
+#endif
+static constexpr int kCD = LM_CD;              // chunk ring depth
 static constexpr int kLB = KLB;              // chunks a loader fetches per round
-static constexpr int kXD8 = 8;             // {tag,x} hand-off ring depth
+static constexpr int kXD8 = LM_XD;             // {tag,x} hand-off ring depth
 static constexpr int kGD8 = 8;             // ghost ring depth
 static constexpr int kIB4 = 4;             // unknowns an importer lane polls per trip
-static constexpr int kBack = 4;            // a wave runs at most this many steps ahead of the slowest wave of its workgroup
+static constexpr int kBack = LM_BACK;            // a wave runs at most this many steps ahead of the slowest wave of its workgroup
 static constexpr int kPatience = 256;
 #ifndef LM_LOADER_SETS
 #define LM_LOADER_SETS 1
