@@ -692,3 +692,19 @@ def test_icholt_full_size_properties_128():
     xt = b.copy(); P.apply_trans(xt)
     assert np.array_equal(x, xt)
     assert np.array_equal(x, O.orc().apply_llt(Lo, b, O.ID))
+
+
+def test_icholt_config_c4_full_size():
+    """BASELINE config C4 at its full size (256^3, 16.8 M columns, ICholT(0, 0)): bit-identical to the reference's own C++
+    when it travelled (oracle/_ref), else to the C restatement"""
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    ref = O.ref() if O.ref_available() else O.orc()
+    d, i, p = matgen.poisson3d(256)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    P = ilupp.ICholTPreconditioner(A)
+    L, = P.factors()
+    Lo = ref.icholt((d, i, p, True), 0, 0.0)
+    assert G.mat_equal(_fac(L), Lo)
+    assert P.total_nnz == L.nnz == 66912256
