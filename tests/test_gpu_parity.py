@@ -708,3 +708,10 @@ def test_icholt_config_c4_full_size():
     Lo = ref.icholt((d, i, p, True), 0, 0.0)
     assert G.mat_equal(_fac(L), Lo)
     assert P.total_nnz == L.nnz == 66912256
+
+
+def test_fuzz_new_kernels():
+    """60 random matrices x both orientations x random parameters (budgets 1..100, thresholds 0..0.3, equal magnitudes at the
+    top-k cut, indefinite matrices with NaN columns) through ILUT and ICholT: everything bit-identical to the oracle"""
+    import fuzz_util
+    assert fuzz_util.run(60, first_seed=1000, verbose=False) == 0
