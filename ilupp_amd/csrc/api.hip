@@ -151,6 +151,7 @@ struct ilupp_precond {
     double *work = nullptr;      // n, all-sentinel between applies
     double *xdev = nullptr;      // n, staging for host-vector apply
     int32_t *done = nullptr;     // n
+    int32_t *iota = nullptr;     // n + 1: the one-row-per-lane schedule of the row-parallel sweep (built on first use)
     int32_t *ctrl = nullptr;     // 16 ints: [0] err, [1] ilu0 ticket (+ its err in [2]) , [4],[5] solve tickets
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4],[5]: around the factor kernel
@@ -183,6 +184,7 @@ void destroy_obj(ilupp_precond *p)
     if (p->work) (void)pool_free(p->work);
     if (p->xdev) (void)pool_free(p->xdev);
     if (p->done) (void)pool_free(p->done);
+    if (p->iota) (void)pool_free(p->iota);
     if (p->ctrl) (void)pool_free(p->ctrl);
     // streams and events are recycled: creating them costs more than a small kernel
     if (p->stream) {
@@ -401,6 +403,22 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
         if (rc) return rc;
         fill_u64(p->stream, reinterpret_cast<unsigned long long *>(rhs), p->n, kSentinel);
         return ILUPP_OK;
+    }
+    // Rows too long for the level-major records (ILUT factors, ICholT with fill): one lane per ROW instead of one lane per
+    // block of consecutive rows.  With blocks, a row waits for everything its lane has to do before it, and the factors of
+    // a random matrix have no chains that would make blocks pay: BASELINE config C3's apply took 70 + 186 ms, more than the
+    // reference needs on one core.
+    static const bool blocks_only = getenv("ILUPP_SPTRSV_BLOCKS") != nullptr;
+    if (!blocks_only && M.nnz > 4 * (int64_t)M.n && M.n >= 1024) {
+        if (!p->iota) {
+            ILUPP_HIP(pool_malloc(&p->iota, sizeof(int32_t) * ((size_t)p->n + 1)));
+            iota_i32(p->stream, p->iota, (int64_t)p->n + 1);
+        }
+        Schedule rows;
+        rows.nb = M.n; rows.B = 1; rows.start = p->iota;
+        const int rc = sptrsv(p->stream, kind, M, rows, nullptr, maxlen, rhs, out, ticket, err);
+        rows.start = nullptr;
+        return rc;
     }
     return sptrsv(p->stream, kind, M, sch, desc, maxlen, rhs, out, ticket, err);
 }

@@ -201,6 +201,7 @@ int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
 void fill_u64(hipStream_t st, unsigned long long *p, int64_t count, unsigned long long v);
 int device_cu_count();
+void iota_i32(hipStream_t st, int32_t *p, int64_t count);
 hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t bytes);   // small read-back, visible after stream_sync()
 hipError_t stream_sync(hipStream_t st);
 void d2h_cancel_all();

@@ -81,6 +81,20 @@ hipError_t stream_sync(hipStream_t st)
     return e;
 }
 
+__global__ void k_iota_i32(int32_t *p, int64_t count)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) p[i] = (int32_t)i;
+}
+void iota_i32(hipStream_t st, int32_t *p, int64_t count)
+{
+    unsigned gb = (unsigned)((count + 255) / 256);
+    if (gb > 4096) gb = 4096;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_iota_i32, dim3(gb), dim3(256), 0, st, p, count);
+}
+
 int device_cu_count()
 {
     int dev = 0;

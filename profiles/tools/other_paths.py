@@ -17,7 +17,9 @@ def kms(P):
     return P.pr.timings()['numeric_kernel_ms']
 
 def line(name, tg, P, tc=None):
-    s = '%-58s GPU %.3f s (kernel %.1f ms)' % (name, tg, kms(P))
+    x = np.ones(P.shape[0]); P.apply(x); x[:] = 1.0; P.apply(x)          # second apply: transposed storages / records exist
+    tm = P.pr.timings()
+    s = '%-58s GPU %.3f s (kernel %.1f ms; apply %.2f + %.2f ms)' % (name, tg, kms(P), tm['lsolve_kernel_ms'], tm['usolve_kernel_ms'])
     if tc is not None:
         s += '   %s, 1 core: %.3f s  -> x%.1f' % (kind, tc, tc / tg)
     print(s, flush=True)
