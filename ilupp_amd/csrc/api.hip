@@ -410,6 +410,8 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
     // reference needs on one core.
     static const bool blocks_only = getenv("ILUPP_SPTRSV_BLOCKS") != nullptr;
     if (!blocks_only && M.nnz > 4 * (int64_t)M.n && M.n >= 1024) {
+        static const bool no_shuffle = getenv("ILUPP_SPTRSV_ROWS_V1") != nullptr;      // (A/B: the generic kernel on one-row blocks)
+        if (!no_shuffle) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
         if (!p->iota) {
             ILUPP_HIP(pool_malloc(&p->iota, sizeof(int32_t) * ((size_t)p->n + 1)));
             iota_i32(p->stream, p->iota, (int64_t)p->n + 1);
