@@ -113,31 +113,42 @@ k_sptrsv(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const
 
 // ---------------------------------------------------------------------------------------------
 // one lane per ROW (factors whose rows are too long for the level-major records and have no chains worth a lane:
-// ILUT factors, ICholT with fill).  A wave holds 64 consecutive rows of the sweep; a dependency on a row of the same
-// wave is taken from that lane's register (ballot of the finished lanes + shuffle) instead of through memory: on
-// mesh-like factors consecutive rows ARE a chain, and a link through the write-through store / cache-bypassing poll
-// costs ~3 us, a link through the shuffle ~0.1 us.  Everything else as in k_sptrsv: sequential accumulation in stored
-// order, diagonal by position, data-is-flag on the output vector, block ids from an atomic ticket.
+// ILUT factors, ICholT with fill).  A workgroup holds kRowsBlock consecutive rows of the sweep; a dependency on a row of
+// the same workgroup is read from an LDS copy of the workgroup's unknowns (sentinel = not yet) instead of through
+// memory: on mesh-like factors consecutive rows ARE a chain and the next grid line is a few hundred rows away; a link
+// through the write-through store / cache-bypassing poll costs ~3 us, a link through LDS ~0.1 us.  Everything else as in
+// k_sptrsv: sequential accumulation in stored order, diagonal by position, data-is-flag on the output vector, block
+// ids from an atomic ticket (a row only polls rows of earlier tickets or earlier lanes of its own workgroup).
 // ---------------------------------------------------------------------------------------------
+#ifndef ROWS_W
+#define ROWS_W 8
+#endif
+#ifndef ROWS_BLOCK
+#define ROWS_BLOCK 1024
+#endif
+static constexpr int kRowsBlock = ROWS_BLOCK;
+
 template <int KIND>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kRowsBlock)
 k_sptrsv_rows(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const double *__restrict__ val,
               double *rhs, double *out, int32_t *ticket, int32_t *err)
 {
     constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
     constexpr bool DESC = (KIND == SWEEP_BWD_FIRST_DESC);
     constexpr int dj = DESC ? -1 : 1;
-    constexpr int W = 8;                                             // dependencies fetched per round trip
+    constexpr int W = ROWS_W;                                        // dependencies fetched per round trip
     __shared__ unsigned wg_ticket;
+    __shared__ unsigned long long xs[kRowsBlock];                    // this workgroup's unknowns, sentinel = not yet
     if (threadIdx.x == 0) wg_ticket = (unsigned)atomicAdd(ticket, 1);
+    xs[threadIdx.x] = kSentinel;
     __syncthreads();
-    const int64_t t = (int64_t)wg_ticket * kThreads + threadIdx.x;
-    const int64_t t0 = t - (threadIdx.x & 63);                       // position of the wave's first row in sweep order
+    const int64_t tb = (int64_t)wg_ticket * kRowsBlock;              // position of the workgroup's first row in sweep order
+    const int64_t t = tb + threadIdx.x;
     bool active = t < n;
     const int r = active ? (FWD ? (int)t : (int)(n - 1 - t)) : 0;
-    const int row0 = FWD ? (int)t0 : (int)(n - 1 - t0);             // (outside [0, n) only for inactive lanes)
+    const long row0 = FWD ? (long)tb : (long)n - 1 - (long)tb;       // row at position tb
     int j = 0, jend = 0;
-    double acc = 0.0, dv = 1.0, myx = 0.0;
+    double acc = 0.0, dv = 1.0;
     if (active) {
         const int lo = ptr[r], hi = ptr[r + 1];
         acc = rhs[r];
@@ -161,8 +172,7 @@ k_sptrsv_rows(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restr
     for (int u = 0; u < W; ++u) { wc[u] = -1; wv[u] = 0.0; wb[u] = kSentinel; }
     unsigned spins = 0;
     for (;;) {
-        const unsigned long long donemask = __ballot(!active);
-        if (donemask == ~0ull) break;
+        if (__ballot(active) == 0ull) break;
         bool progressed = false;
         if (active && cur == wn && j != jend) {
             const int left = DESC ? j - jend : jend - j;
@@ -172,32 +182,25 @@ k_sptrsv_rows(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restr
             for (int u = 0; u < W; ++u) if (u < wn) { wc[u] = idx[j + u * dj]; wv[u] = val[j + u * dj]; }
 #pragma unroll
             for (int u = 0; u < W; ++u) {
-                const int li_u = FWD ? wc[u] - row0 : row0 - wc[u];
-                wb[u] = (u < wn && (unsigned)li_u >= 64u) ? ld_agent_u64(outb + wc[u]) : kSentinel;
+                const long lb_u = FWD ? (long)wc[u] - row0 : row0 - (long)wc[u];
+                wb[u] = (u < wn && (unsigned long)lb_u >= (unsigned long)kRowsBlock) ? ld_agent_u64(outb + wc[u]) : kSentinel;
             }
             progressed = true;
         }
-        const bool want = active && cur < wn;
-        int c = -1; double v = 0.0; unsigned long long b = kSentinel;
-#pragma unroll
-        for (int u = 0; u < W; ++u) if (cur == u) { c = wc[u]; v = wv[u]; b = wb[u]; }
-        if (!want) c = -1;
-        const int li = FWD ? c - row0 : row0 - c;                     // lane that owns row c, if it is in this wave
-        const bool inwave = want && (unsigned)li < 64u;
-        const double xin = __shfl(myx, inwave ? li : 0);
         if (active) {
-            if (want) {
-                bool have;
-                double xc = xin;
-                if (inwave) {
-                    have = ((donemask >> li) & 1ull) != 0ull;
-                } else {
-                    if (b == kSentinel) b = ld_agent_u64(outb + c);   // was not there when the window was fetched: poll this one only
-                    have = b != kSentinel;
-                    xc = __longlong_as_double((long long)b);
+            if (cur < wn) {
+                int c = -1; double v = 0.0; unsigned long long b = kSentinel;
+#pragma unroll
+                for (int u = 0; u < W; ++u) if (cur == u) { c = wc[u]; v = wv[u]; b = wb[u]; }
+                const long lb = FWD ? (long)c - row0 : row0 - (long)c;   // place of row c in this workgroup, if it is one of ours
+                if ((unsigned long)lb < (unsigned long)kRowsBlock) {
+                    asm volatile("" ::: "memory");
+                    b = xs[lb];
+                } else if (b == kSentinel) {
+                    b = ld_agent_u64(outb + c);                        // was not there when the window was fetched: poll this one only
                 }
-                if (have) {
-                    const double prod = v * xc;
+                if (b != kSentinel) {
+                    const double prod = v * __longlong_as_double((long long)b);
                     acc = acc - prod;                       // x[k] -= data[j]*x[indices[j]]  (:4049, :4070)
                     j += dj;
                     ++cur;
@@ -208,7 +211,8 @@ k_sptrsv_rows(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restr
                 double x = acc / dv;                        // x[k] /= diagonal (by position)  (:4051, :4072)
                 if (x != x) x = __longlong_as_double((long long)kCanonNaN);   // never store the sentinel
                 st_agent_f64(out + r, x);
-                myx = x;
+                xs[threadIdx.x] = (unsigned long long)__double_as_longlong(x);
+                asm volatile("" ::: "memory");
                 active = false;
                 progressed = true;
             }
@@ -952,16 +956,16 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
 
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err)
 {
-    const unsigned grid = (unsigned)((M.n + kThreads - 1) / kThreads);
+    const unsigned grid = (unsigned)((M.n + kRowsBlock - 1) / kRowsBlock);
     switch (kind) {
     case SWEEP_FWD_LAST_ASC:
-        hipLaunchKernelGGL((k_sptrsv_rows<SWEEP_FWD_LAST_ASC>), dim3(grid), dim3(kThreads), 0, st, M.n, M.ptr, M.idx, M.val, rhs_and_reset, out, d_ticket, d_err);
+        hipLaunchKernelGGL((k_sptrsv_rows<SWEEP_FWD_LAST_ASC>), dim3(grid), dim3(kRowsBlock), 0, st, M.n, M.ptr, M.idx, M.val, rhs_and_reset, out, d_ticket, d_err);
         break;
     case SWEEP_BWD_FIRST_ASC:
-        hipLaunchKernelGGL((k_sptrsv_rows<SWEEP_BWD_FIRST_ASC>), dim3(grid), dim3(kThreads), 0, st, M.n, M.ptr, M.idx, M.val, rhs_and_reset, out, d_ticket, d_err);
+        hipLaunchKernelGGL((k_sptrsv_rows<SWEEP_BWD_FIRST_ASC>), dim3(grid), dim3(kRowsBlock), 0, st, M.n, M.ptr, M.idx, M.val, rhs_and_reset, out, d_ticket, d_err);
         break;
     default:
-        hipLaunchKernelGGL((k_sptrsv_rows<SWEEP_BWD_FIRST_DESC>), dim3(grid), dim3(kThreads), 0, st, M.n, M.ptr, M.idx, M.val, rhs_and_reset, out, d_ticket, d_err);
+        hipLaunchKernelGGL((k_sptrsv_rows<SWEEP_BWD_FIRST_DESC>), dim3(grid), dim3(kRowsBlock), 0, st, M.n, M.ptr, M.idx, M.val, rhs_and_reset, out, d_ticket, d_err);
         break;
     }
     ILUPP_HIP(hipGetLastError());
