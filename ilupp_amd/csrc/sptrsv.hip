@@ -189,22 +189,48 @@ k_sptrsv_rows(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restr
         }
         if (active) {
             if (cur < wn) {
-                int c = -1; double v = 0.0; unsigned long long b = kSentinel;
+                // everything of the window that is there, in stored order, in this round: after a blocker has arrived (in a
+                // backward sweep in ascending order that is the FIRST entry: the chain neighbour) the rest must not cost one
+                // round each -- the rounds of a chain add up
+                // (sweeps that meet their nearest dependency LAST -- forward, or backward in descending order -- take one entry
+                // per round: the heavier round costs them more than it saves)
+                constexpr bool MULTI = (KIND == SWEEP_BWD_FIRST_ASC);
+                asm volatile("" ::: "memory");
+                if constexpr (MULTI) {
+                    bool stop = false;
 #pragma unroll
-                for (int u = 0; u < W; ++u) if (cur == u) { c = wc[u]; v = wv[u]; b = wb[u]; }
-                const long lb = FWD ? (long)c - row0 : row0 - (long)c;   // place of row c in this workgroup, if it is one of ours
-                if ((unsigned long)lb < (unsigned long)kRowsBlock) {
-                    asm volatile("" ::: "memory");
-                    b = xs[lb];
-                } else if (b == kSentinel) {
-                    b = ld_agent_u64(outb + c);                        // was not there when the window was fetched: poll this one only
-                }
-                if (b != kSentinel) {
-                    const double prod = v * __longlong_as_double((long long)b);
-                    acc = acc - prod;                       // x[k] -= data[j]*x[indices[j]]  (:4049, :4070)
-                    j += dj;
-                    ++cur;
-                    progressed = true;
+                    for (int u = 0; u < W; ++u) {
+                        if (!stop && u >= cur && u < wn) {
+                            const int c = wc[u];
+                            const long lb = FWD ? (long)c - row0 : row0 - (long)c;   // place of row c in this workgroup, if it is one of ours
+                            unsigned long long b = wb[u];
+                            if ((unsigned long)lb < (unsigned long)kRowsBlock) b = xs[lb];
+                            else if (b == kSentinel) b = ld_agent_u64(outb + c);       // was not there when the window was fetched: poll this one only
+                            if (b != kSentinel) {
+                                const double prod = wv[u] * __longlong_as_double((long long)b);
+                                acc = acc - prod;               // x[k] -= data[j]*x[indices[j]]  (:4049, :4070)
+                                j += dj;
+                                ++cur;
+                                progressed = true;
+                            } else {
+                                stop = true;
+                            }
+                        }
+                    }
+                } else {
+                    int c = -1; double v = 0.0; unsigned long long b = kSentinel;
+#pragma unroll
+                    for (int u = 0; u < W; ++u) if (cur == u) { c = wc[u]; v = wv[u]; b = wb[u]; }
+                    const long lb = FWD ? (long)c - row0 : row0 - (long)c;
+                    if ((unsigned long)lb < (unsigned long)kRowsBlock) b = xs[lb];
+                    else if (b == kSentinel) b = ld_agent_u64(outb + c);
+                    if (b != kSentinel) {
+                        const double prod = v * __longlong_as_double((long long)b);
+                        acc = acc - prod;                       // x[k] -= data[j]*x[indices[j]]  (:4049, :4070)
+                        j += dj;
+                        ++cur;
+                        progressed = true;
+                    }
                 }
             }
             if (j == jend) {
