@@ -186,7 +186,12 @@ static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t
     int64_t B = ((int64_t)n + max_lanes - 1) / max_lanes;
     int64_t chain = ncuts > 0 ? ((int64_t)n + ncuts - 1) / ncuts : n;
     if (chain > B) B = chain;
+    // no chains to speak of (rows rarely depend on their predecessor: random matrices): one row per lane.  A lane that owns
+    // a block of unrelated rows makes each of them wait for everything before it in the block (ILU(0) numeric on a random
+    // matrix with n = 1e6: 48.7 ms with 15 rows per lane, 3.3 ms with one)
+    if (chain <= 4) B = 1;
     if (B < 1) B = 1;
+    if (const char *e = getenv("ILUPP_SCHEDULE_B")) { const int v = atoi(e); if (v > 0) B = v; }      // experiments
     int64_t nb = ((int64_t)n + B - 1) / B;
     sch->nb = (int32_t)nb;
     sch->B = (int32_t)B;
