@@ -23,6 +23,10 @@
 
 #include "common.h"
 
+#ifndef IMPORT_SLEEP
+#define IMPORT_SLEEP 1
+#endif
+
 namespace ilupp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -262,7 +266,7 @@ k_ilu0_lm(FlmArgs A)
             if (__any(did)) {
                 idle = 0;
             } else {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(IMPORT_SLEEP);
                 if (++idle > kFlmSpinLimit) break;
             }
         }

@@ -25,6 +25,10 @@
 
 #include "common.h"
 
+#ifndef IMPORT_SLEEP
+#define IMPORT_SLEEP 1
+#endif
+
 namespace ilupp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -406,7 +410,7 @@ k_sptrsv_lm(const v4i *__restrict__ pk, const int32_t *__restrict__ wtab, const 
             if (__any(did)) {
                 idle = 0;
             } else {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(IMPORT_SLEEP);
                 if (++idle > kLmSpinLimit) break;
             }
         }
