@@ -151,6 +151,7 @@ struct ilupp_precond {
     double *work = nullptr;      // n, all-sentinel between applies
     double *xdev = nullptr;      // n, staging for host-vector apply
     int32_t *done = nullptr;     // n
+    bool degenerate = false;     // a factor has a major slice without entries (NaN columns of an indefinite ICholT): guarded sweeps only
     int32_t *iota = nullptr;     // n + 1: the one-row-per-lane schedule of the row-parallel sweep (built on first use)
     int32_t *ctrl = nullptr;     // 16 ints: [0] err, [1] ilu0 ticket (+ its err in [2]) , [4],[5] solve tickets
     hipStream_t stream = nullptr;
@@ -363,6 +364,7 @@ void ensure_transposed(ilupp_precond *p)
         }
     } else {
         transpose_storage(st, p->Lc, &p->LcT);
+        if (min_row_len(st, p->n, p->LcT.ptr, p->LcT.idx, p->llt_diag_last ? 1 : 2) == 0) p->degenerate = true;
         // Lc row-major lower (IChol0): LcT is upper with the diagonal first -> backward sweep;
         // Lc column-major lower (ICholT): LcT is its row-major form with the diagonal last -> forward sweep
         const bool t_fwd = !p->llt_diag_last;
@@ -384,7 +386,7 @@ void ensure_transposed(ilupp_precond *p)
 static const PackedSweep *packed(ilupp_precond *p, int which, SweepKind kind, const DevMat &M, const Schedule &sch,
                                  const int32_t *desc, int32_t maxlen, PackedSweep *ps)
 {
-    if (!ps->valid && !p->pack_tried[which] && desc) {
+    if (!ps->valid && !p->pack_tried[which] && desc && !p->degenerate) {
         if (lm_prepare(p->stream, kind, M, sch, desc, maxlen, ps)) {
             lm_pack(p->stream, kind, M, sch, desc, ps, 3);
             lm_finish(p->stream, ps);
@@ -398,6 +400,7 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
                  const PackedSweep *ps, double *rhs, double *out, int32_t *ticket, int32_t *err,
                  double *ypk_out = nullptr, const double *ypk_in = nullptr, const int32_t *ysrc = nullptr)
 {
+    if (p->degenerate) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
     if (ps && ps->valid) {
         int rc = sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc);
         if (rc) return rc;
@@ -462,6 +465,15 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
         }
     } else {
         // LL^T: apply == apply_trans (preconditioner_implementation.h:381-394)
+        if (p->degenerate && !p->llt_diag_last) {
+            // misplaced or missing diagonals (indefinite matrix): the reference's positional loops, verbatim
+            ILUPP_HIP(hipEventRecord(p->ev[0], st));
+            llt_apply_positional(st, p->Lc, x);
+            ILUPP_HIP(hipEventRecord(p->ev[1], st));
+            ILUPP_HIP(hipEventRecord(p->ev[2], st));
+            p->apply_events_valid = true;
+            return ILUPP_OK;
+        }
         ensure_transposed(p);
         if (p->llt_diag_last) {       // IChol0: T1(L) then T4(L)
             const PackedSweep *p1 = packed(p, 0, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
@@ -767,6 +779,7 @@ int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const in
         destroy_obj(p);
         return rc;
     }
+    p->degenerate = min_row_len(st, n, p->Lc.ptr, p->Lc.idx, 1) == 0;      // (column-major lower: diagonal first)
     // Lc = CSC lower, diagonal first.  Its arrays read as CSR are L^T (upper, diagonal first): backward sweep.
     int32_t m1 = 0;
     count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);

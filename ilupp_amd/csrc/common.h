@@ -201,6 +201,7 @@ int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
 void fill_u64(hipStream_t st, unsigned long long *p, int64_t count, unsigned long long v);
 int device_cu_count();
+int32_t min_row_len(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, int diag_at);
 void iota_i32(hipStream_t st, int32_t *p, int64_t count);
 hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t bytes);   // small read-back, visible after stream_sync()
 hipError_t stream_sync(hipStream_t st);
@@ -245,6 +246,7 @@ enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRS
 int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
            int32_t max_row_len, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
+void llt_apply_positional(hipStream_t st, const DevMat &Lc, double *x);
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
 // sptrsv_lm.hip

@@ -95,6 +95,36 @@ void iota_i32(hipStream_t st, int32_t *p, int64_t count)
     hipLaunchKernelGGL(k_iota_i32, dim3(gb), dim3(256), 0, st, p, count);
 }
 
+__global__ void k_min_row_len(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int diag_at, int32_t *out)
+{
+    int m = 0x7fffffff;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int lo = ptr[r], hi = ptr[r + 1];
+        int len = hi - lo;
+        // the entry at the diagonal's POSITION is not the diagonal (it was dropped): counts like an empty slice
+        if (len > 0 && diag_at == 1 && idx[lo] != r) len = 0;
+        if (len > 0 && diag_at == 2 && idx[hi - 1] != r) len = 0;
+        m = min(m, len);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMin(out, m);
+}
+// length of the shortest major slice; 0 also when a slice does not have its diagonal where the solves take it from
+// (diag_at: 1 first, 2 last, 0 not checked).  0 = only the guarded, purely positional row-parallel sweep may run on the factor.
+int32_t min_row_len(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, int diag_at)
+{
+    int32_t *d = nullptr, h = 0x7fffffff;
+    ILUPP_HIP(pool_malloc(&d, sizeof(int32_t)));
+    ILUPP_HIP(hipMemcpyAsync(d, &h, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    unsigned gb = (unsigned)((n + 255) / 256);
+    if (gb > 1024) gb = 1024;
+    hipLaunchKernelGGL(k_min_row_len, dim3(gb), dim3(256), 0, st, n, ptr, idx, diag_at, d);
+    ILUPP_HIP(hipMemcpyAsync(&h, d, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    ILUPP_HIP(pool_free(d));
+    return h;
+}
+
 int device_cu_count()
 {
     int dev = 0;

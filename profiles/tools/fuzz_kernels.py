@@ -3,4 +3,5 @@
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import fuzz_util
-sys.exit(1 if fuzz_util.run(int(sys.argv[1]) if len(sys.argv) > 1 else 150) else 0)
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+sys.exit(1 if fuzz_util.run(int(sys.argv[1]) if len(sys.argv) > 1 else 150, first_seed=first, verbose=2 if len(sys.argv) > 3 else True) else 0)

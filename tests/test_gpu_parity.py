@@ -665,6 +665,8 @@ def test_ilut_wave_kernel_vs_oracle_seeded(case):
             assert G.mat_equal(L, Lo) and G.mat_equal(U, Uo), (case, fmt, fill, t)
             x = b.copy(); P.apply(x)
             assert np.array_equal(x, orc.apply_lu(Lo, Uo, b, O.ID), equal_nan=True)
+            xt = b.copy(); P.apply_trans(xt)              # (rows > 4 entries: the row-parallel sweep kernel, all three sweep kinds)
+            assert np.array_equal(xt, orc.apply_lu(Lo, Uo, b, O.TRANSPOSE), equal_nan=True)
             if fmt == "csr":
                 Ps = _with_env("ILUPP_ILUT_SEQUENTIAL", "1", lambda: ilupp.ILUTPreconditioner(_scipy(M), fill_in=fill, threshold=t))
                 Ls, Us = [_fac(F) for F in Ps.factors()]
