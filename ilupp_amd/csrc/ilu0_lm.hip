@@ -403,7 +403,13 @@ k_ilu0_lm(FlmArgs A)
                 asm volatile("" ::: "memory");
                 const v4i p0 = ur[at[0]], p1 = ur[at[1]], p2 = ur[at[2]];
                 asm volatile("" ::: "memory");                           // tag words before the value words they guard
+#ifdef EXP_FLM_CONST_U
+                // experiment only (valid for matrices whose off-diagonals are all -1, e.g. the 7-point Poisson matrix): how much of
+                // the step is the second half of the hand-off (the matched U entries)?
+                v4i m0, m1, m2; m0.x = 0; m0.y = (int)0xBFF00000; m0.z = 0; m0.w = (int)0xBFF00000; m1 = m0; m2 = m0;
+#else
                 const v4i m0 = ur[mat[0]], m1 = ur[mat[1]], m2 = ur[mat[2]];
+#endif
                 asm volatile("" ::: "memory");
                 const int hit = (p0.x == kl[0] ? 1 : 0) | (p1.x == kl[1] ? 2 : 0) | (p2.x == kl[2] ? 4 : 0);
                 if (!done && (need & ~hit) == 0) {
