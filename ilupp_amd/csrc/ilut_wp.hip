@@ -8,14 +8,17 @@
 // sparse_implementation.h:1087-1093, dropping.hpp:14-21):
 //   * POOL: entries left of the diagonal that have not been eliminated yet {column, value, seq}; seq numbers the
 //     left-part insertions (A's entries in CSR order, then fill in creation order);
-//   * KEPT: the multipliers {column, w_k / U_kk, seq} of the eliminated columns; entries removed by the stage-1
-//     drop (ILUT.hpp:244-245) or found exactly zero (:239-240) are simply forgotten -- the reference leaves a zero
-//     slot behind, which adds 0.0 to the norm and can never be a candidate (strict >);
-//   * U slots: the entries right of the diagonal in insertion order (they are never removed); the diagonal is a scalar.
+//   * KEPT: the multipliers {column, w_k / U_kk, seq} of the eliminated columns (append-only until the row ends: kept in
+//     global memory); entries removed by the stage-1 drop (ILUT.hpp:244-245) or found exactly zero (:239-240) are simply
+//     forgotten -- the reference leaves a zero slot behind, which adds 0.0 to the norm and can never be a candidate (strict >);
+//   * U slots: the entries right of the diagonal in insertion order (they are never removed) with a hash table
+//     column -> slot, the stand-in for the reference's n-long occupancy array; the diagonal is a scalar.
 // What the reference does with a binary heap -- "next column in ascending order" -- is a wave-wide minimum over the
-// pool (DPP reduction); what it does with an n-long occupancy array -- "slot of column c" -- is a wave-wide search of
-// the pool and the U slots for the (sorted) columns of the U row being subtracted, every match updated by the lane
-// that found it, the misses appended in row order (= the reference's insertion order) by ballot/prefix-sum.
+// pool (DPP reduction).  Subtracting a U row: its (<= 16) columns go into scalars and every pool entry is compared against
+// all of them (a binary search per entry is a chain of dependent LDS reads that the whole wave pays for as soon as one
+// lane needs it: it was 3/4 of a row's time); the entries right of the diagonal look their column up in the hash, each on
+// its own lane; the misses are appended in row order (= the reference's insertion order) by ballot/prefix-sum and enter
+// the hash all at once.
 // A finished U row is fetched in ONE memory round trip: rows live in fixed-pitch slabs initialised to sentinels
 // (index -1, value kSentinel, length 0); the writer stores every datum write-through, the reader validates every
 // datum it needs and retries otherwise (write-once data: a set of individually fresh values is consistent).
