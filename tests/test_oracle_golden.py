@@ -144,3 +144,55 @@ def test_oracle_vs_reference_live():
     for n in (17, 33, 100, 1000):
         k = rng.integers(0, 5, n).astype(np.float64)
         assert np.array_equal(orc.sort_slots_by_abs_desc(k), ref.sort_slots_by_abs_desc(k))
+
+
+def test_restatement_vs_reference_on_fuzz_matrices():
+    """the matrices of the GPU fuzz (tests/fuzz_util.py: ties, budgets 1..100, indefinite matrices whose ICholT factors lose
+    diagonals or whole columns) through the C restatement and through the reference's own C++: factors and applies identical,
+    so the fuzz's oracle is pinned on these inputs too.  Needs oracle/_ref (built from /root/reference where that exists)."""
+    from oracle import oracle as O
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built")
+    import scipy.sparse as sp
+    orc, ref = O.orc(), O.ref()
+    nseeds = 120
+    bad = 0; deg = 0; tot = 0
+    for seed in range(2000, 2000 + nseeds):
+        rng = np.random.default_rng(seed)
+        n = int(rng.choice([1, 2, 3, 7, 20, 64, 65, 150, 400, 1500, 2500]))
+        dens = float(rng.choice([0.5, 2.0, 5.0, 12.0])) / max(n, 1)
+        R = sp.random(n, n, density=min(1.0, dens), random_state=rng, format='csr')
+        if rng.random() < 0.3:
+            R.data = np.round(R.data * 4) / 4
+        A = (R + sp.identity(n) * float(rng.choice([1.0, 4.0, 25.0]))).tocsr(); A.sort_indices()
+        S = ((A + A.T) * 0.5 + sp.identity(n) * float(rng.choice([2.0, 2.0, 0.0, -3.0]))).tocsr(); S.sort_indices()
+        for fmt in ('csr', 'csc'):
+            Af = A if fmt == 'csr' else A.tocsc(); Sf = S if fmt == 'csr' else S.tocsc()
+            Af.sort_indices(); Sf.sort_indices()
+            Mi = (Af.data.astype(np.float64), Af.indices.astype(np.int32), Af.indptr.astype(np.int32), fmt == 'csr')
+            Ms = (Sf.data.astype(np.float64), Sf.indices.astype(np.int32), Sf.indptr.astype(np.int32), fmt == 'csr')
+            fill = int(rng.choice([1, 2, 3, 5, 10, 17, 70, 100])); tau = float(rng.choice([0.0, 1e-6, 1e-3, 0.05, 0.3]))
+            add = int(rng.choice([0, 1, 2, 5, 9, 40])); tau2 = float(rng.choice([0.0, 1e-6, 1e-3, 0.05, 0.3]))
+            b = np.cos(np.arange(n, dtype=np.float64)) + 1.5
+            tot += 1
+            try:
+                Lo, Uo = orc.ilut(Mi, fill, tau); e1 = None
+            except O.OracleError as e: e1 = e
+            try:
+                Lr, Ur = ref.ilut(Mi, fill, tau); e2 = None
+            except O.OracleError as e: e2 = e
+            if (e1 is None) != (e2 is None): bad += 1; print('ILUT error mismatch', seed, fmt)
+            elif e1 is None:
+                ok = all(np.array_equal(a, c, equal_nan=True) for a, c in zip(Lo[:3] + Uo[:3], Lr[:3] + Ur[:3]))
+                ok = ok and np.array_equal(orc.apply_lu(Lo, Uo, b, O.TRANSPOSE), ref.apply_lu(Lr, Ur, b, O.TRANSPOSE), equal_nan=True)
+                if not ok: bad += 1; print('ILUT mismatch', seed, fmt)
+            Lo = orc.icholt(Ms, add, tau2); Lr = ref.icholt(Ms, add, tau2)
+            ok = all(np.array_equal(a, c, equal_nan=True) for a, c in zip(Lo[:3], Lr[:3]))
+            d = bool(np.any(np.diff(Lo[2]) == 0)) or any(Lo[1][Lo[2][j]] != j for j in range(n) if Lo[2][j+1] > Lo[2][j])
+            deg += d
+            trailing_empty = n > 0 and Lo[2][-1] == Lo[2][-2]
+            if ok and not trailing_empty:
+                ok = np.array_equal(orc.apply_llt(Lo, b, O.ID), ref.apply_llt(Lr, b, O.ID), equal_nan=True)
+            if not ok: bad += 1; print('ICHOLT mismatch', seed, fmt, 'degenerate', d)
+    assert bad == 0
+    assert deg > 0            # the degenerate cases are in the sample
