@@ -71,10 +71,16 @@ __global__ __launch_bounds__(256) void k_tilesolve(const double *__restrict__ re
             if (z > 0) { const double pr = a0.x * xz; acc = acc - pr; }
             if (y > 0) { const double pr = a0.y * xy; acc = acc - pr; }
             if (k > 0) { const double pr = b0.x * prev; acc = acc - pr; }
+#ifdef NO_DIV
+            x = acc * b0.y;          // (experiment: the share of the division in a level)
+#else
             x = acc / b0.y;
+#endif
         }
         prev = x;
+#ifndef NO_STORE
         __builtin_nontemporal_store(x, o + (size_t)tau * 64);
+#endif
         if (zl == 3) xs[w][tau & (kDepth - 1)][y] = x;
         asm volatile("" ::: "memory");
         if (lane == 0) wstep[w] = tau;
