@@ -166,6 +166,23 @@ def main():
     P.apply_device(tx.data_ptr(), n, transpose=False, sync=True)
     checksum = float(tx.sum().item())
 
+    # what this box's HBM gives a plain device-to-device copy (read + written bytes), next to the 8 TB/s spec peak
+    copy_gbs = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 27, dtype=torch.float64, device=dev)      # 1 GiB
+            dst = torch.empty_like(src)
+            src.fill_(1.0); dst.copy_(src); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbs = 5 * 2.0 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            copy_gbs = None
+
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
@@ -208,7 +225,9 @@ def main():
                          "frac": (fb / (k_num * 1e-3) / 1e9) / HBM_PEAK_GBS if k_num > 0 else None,
                          "traffic": measured_traffic("k_ilu0_lm", g),
                          "algorithmic_bytes_per_launch": fb,
-                         "avg_launch_ms": k_num},
+                         "avg_launch_ms": k_num,
+                         "copy_GBs_measured": copy_gbs,
+                         "frac_of_measured_copy": ((fb / (k_num * 1e-3) / 1e9) / copy_gbs) if (k_num > 0 and copy_gbs) else None},
             "checksum": checksum,
         }
         if not args.no_cpu and world == 1:
