@@ -241,7 +241,8 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
     int rc = ILUPP_ERR_UNSUPPORTED;
     bool direct = false;
     if (p->flm.built) {
-        rc = ilu0_numeric_lm(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5]);
+        rc = p->flm.stat ? ilu0_numeric_st(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5])
+                         : ilu0_numeric_lm(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5]);
         p->csr_vals = false;
         return rc;
     }
@@ -287,7 +288,9 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
     bool have_prog = false;
-    const bool lm = p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
+    // static form first (lane tables, values-only records: st.hip), then the record-decoding level-major form
+    const bool lm = p->compact && (st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm) ||
+                                   lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm));
     // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
     // transposed solves): the pass runs on the side stream next to the persistent factor kernel, which is bound by
     // dependency latency and leaves most of the memory system idle.
@@ -336,8 +339,13 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
 void ensure_csr_values(ilupp_precond *p)
 {
     if (p->csr_vals) return;
-    lm_unpack(p->stream, p->Lc, p->sA, p->pkL);
-    lm_unpack(p->stream, p->Uc, p->sU, p->pkU);
+    if (p->pkL.stat) {
+        st_unpack(p->stream, p->Lc, p->sA, p->pkL);
+        st_unpack(p->stream, p->Uc, p->sU, p->pkU);
+    } else {
+        lm_unpack(p->stream, p->Lc, p->sA, p->pkL);
+        lm_unpack(p->stream, p->Uc, p->sU, p->pkU);
+    }
     ILUPP_HIP(stream_sync(p->stream));
     p->csr_vals = true;
 }
@@ -402,7 +410,8 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
 {
     if (p->degenerate) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
     if (ps && ps->valid) {
-        int rc = sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc);
+        int rc = ps->stat ? sptrsv_st(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc)
+                          : sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc);
         if (rc) return rc;
         fill_u64(p->stream, reinterpret_cast<unsigned long long *>(rhs), p->n, kSentinel);
         return ILUPP_OK;

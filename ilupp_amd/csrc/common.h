@@ -83,8 +83,17 @@ struct PackedSweep {
     int32_t *ysrc = nullptr;    // (backward sweep) per slot: where its first row's right-hand side sits in the forward sweep's ybuf
     int64_t nchunks = 0;
     int32_t max_chunks = 0;
+    // static form (st.hip): every lane's dependency structure is the same for all of its rows and sits in a lane
+    // table; the records then hold values only (2 KB per chunk, absent entries = kAbsent)
+    bool stat = false;
+    int32_t *ltab = nullptr;    // nslots x kStTab ints
     void release();
 };
+
+// lane table of the static level-major kernels (st.hip), one entry of kStTab ints per slot
+static constexpr int kStTab = 32;
+enum { ST_FIRST = 0, ST_CNT = 1, ST_SKEW = 2, ST_ND = 3, ST_OFF = 4, ST_SRC = 7, ST_BLK = 10, ST_KAP = 13, ST_MPOS = 16, ST_DT = 17 };
+enum { ST_NONE = 0, ST_OWN = 1, ST_LOCAL = 2, ST_GHOST = 3 };     // low two bits of a source word; the producer slot above them
 
 // Hand-off rings of the level-major factor kernel (their addresses are baked into the factor records, records_lm.hip):
 // own U rows kFlmUF deep (slot = row index modulo kFlmUF; a wave runs at most kFlmUF-2 steps ahead of the slowest wave
@@ -102,6 +111,7 @@ struct FactorLM {
     int32_t *xbase = nullptr;       // nslots: first exchange row of a slot whose U rows other workgroups read, else -1
     double *xch = nullptr;          // exchange rows x 4 doubles (write-through, sentinel = not yet)
     long long *xcount = nullptr;    // device: doubles of xch in use
+    bool stat = false;              // static form (st.hip): pkA holds 4 KB chunks {a0..a6, mask}
     void release();
 };
 
@@ -119,6 +129,8 @@ struct Ilu0Program {
 // A quiet NaN with a payload no arithmetic produces (hardware NaNs are canonical 0x7FF8000000000000).
 static constexpr unsigned long long kSentinel = 0x7FF85EEDC0DE0001ull;
 static constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
+// "no such entry" in the value records and hand-off entries of the static level-major kernels (st.hip)
+static constexpr unsigned long long kAbsent = 0x7FF85EEDC0DE0002ull;
 
 // persistent-grid geometry: one 256-thread workgroup per CU
 static constexpr int kThreads = 256;
@@ -267,5 +279,14 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
 bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
                      PackedSweep *pu, FactorLM *f);
 void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
+// st.hip
+bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
+                     PackedSweep *pu, FactorLM *f);
+int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, FactorLM *f,
+                    int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1);
+int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
+              int32_t *d_ticket, int32_t *d_err, double *ypk_out = nullptr, const double *ypk_in = nullptr,
+              const int32_t *ysrc = nullptr);
+void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
 
 }  // namespace ilupp

@@ -48,7 +48,8 @@ void PackedSweep::release()
     if (uslot) (void)pool_free(uslot);
     if (ysrc) (void)pool_free(ysrc);
     if (ybuf) (void)pool_free(ybuf);
-    ysrc = nullptr; ybuf = nullptr;
+    if (ltab) (void)pool_free(ltab);
+    ysrc = nullptr; ybuf = nullptr; ltab = nullptr; stat = false;
     skew = wtab = flags = uslot = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false; linked = false;
 }
 
