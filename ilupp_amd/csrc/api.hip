@@ -295,8 +295,10 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     // transposed solves): the pass runs on the side stream next to the persistent factor kernel, which is bound by
     // dependency latency and leaves most of the memory system idle.
     static const bool no_overlap = getenv("ILUPP_OVERLAP_PATTERNS") == nullptr;   // measured: the overlap costs the factor kernel more (2.0 -> 2.5 ms) than the pass takes (0.28 ms)
-    const bool patterns_aside = lm && !no_overlap;
-    if (!patterns_aside) ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
+    const bool patterns_aside = lm && !no_overlap && !p->flm.stat;
+    // (static form: only U's row pointers now; the column indices come out of the records together with the values)
+    if (p->flm.stat) ilu0_write_uptr(st, A, &p->Lc, &p->Uc);
+    else if (!patterns_aside) ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
     if (!lm) ilu0_unit_diagonal(st, &p->Lc);        // the CSR-streaming factor kernels write the eliminations only
     if (p->compact && !lm) {
         // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels

@@ -87,12 +87,14 @@ struct PackedSweep {
     // table; the records then hold values only (2 KB per chunk, absent entries = kAbsent)
     bool stat = false;
     int32_t *ltab = nullptr;    // nslots x kStTab ints
+    double *dump = nullptr;     // where the stores of lanes without a row go
     void release();
 };
 
 // lane table of the static level-major kernels (st.hip), one entry of kStTab ints per slot
 static constexpr int kStTab = 32;
-enum { ST_FIRST = 0, ST_CNT = 1, ST_SKEW = 2, ST_ND = 3, ST_OFF = 4, ST_SRC = 7, ST_BLK = 10, ST_KAP = 13, ST_MPOS = 16, ST_DT = 17 };
+enum { ST_FIRST = 0, ST_CNT = 1, ST_SKEW = 2, ST_ND = 3, ST_OFF = 4, ST_SRC = 7, ST_KLO = 10, ST_KAP = 13, ST_UP0 = 16, ST_DT = 17,
+       ST_KHI = 20, ST_SCAT = 23 };
 enum { ST_NONE = 0, ST_OWN = 1, ST_LOCAL = 2, ST_GHOST = 3 };     // low two bits of a source word; the producer slot above them
 
 // Hand-off rings of the level-major factor kernel (their addresses are baked into the factor records, records_lm.hip):
@@ -208,6 +210,7 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag,
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
+void ilu0_write_uptr(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);

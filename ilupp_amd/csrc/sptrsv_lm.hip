@@ -49,6 +49,8 @@ void PackedSweep::release()
     if (ysrc) (void)pool_free(ysrc);
     if (ybuf) (void)pool_free(ybuf);
     if (ltab) (void)pool_free(ltab);
+    if (dump) (void)pool_free(dump);
+    dump = nullptr;
     ysrc = nullptr; ybuf = nullptr; ltab = nullptr; stat = false;
     skew = wtab = flags = uslot = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false; linked = false;
 }

@@ -8,18 +8,26 @@
 //   * the analysis proves, for EVERY row, that the lane's rows all look alike: the columns of row r are r + o for offsets o
 //     out of a per-lane template of at most 3 offsets left and 3 right of the diagonal, each offset always produced by the
 //     same lane (own previous row / a lane of the workgroup a fixed number of steps back / a lane of an earlier workgroup),
-//     and every elimination matches the eliminated row on its diagonal only ("simple" rows: all 5-/7-point stencils; then the
-//     strictly-upper part of U is A's and the only recurrence is the one of the pivots).  What varies from row to row is
-//     which template entries exist (domain boundaries): one mask byte per row, stored with the row's values of A;
-//   * the consumer therefore has no record decode, no tags and no polling inside a workgroup: the lane table sits in
-//     registers, finished unknowns / U rows go into LDS arrays indexed by (step mod 8, lane), and ONE s_barrier per step
-//     orders them (4 waves per workgroup, nothing else resident: no loader waves, no importer wave);
-//   * the streams are read by the consuming lane itself, kStD steps ahead, into a rotating register file (fully unrolled
-//     loop), level-major and coalesced: factor kernel 64 B in (a0..a6, mask) and 2 x 32 B out per row, sweeps 32 B + rhs in;
-//   * values of earlier workgroups (tile borders) are polled kStD steps ahead by the border lanes themselves
-//     (write-through stores / cache-bypassing loads, the data is the flag); a value that is not there when its step
-//     comes is polled again, which makes the tile fall back behind its producers by just the latency it needs.
+//     and every elimination meets the eliminated row on its diagonal only ("simple" rows: all 5-/7-point stencils).
+//     Which template entries a row has (domain boundaries) is in the data: an entry that does not exist is kAbsent;
+//   * for such rows the strictly-upper part of U is A's and l_ik = a_ik / u_kk with a_ik untouched: the ONLY recurrence of
+//     the factorisation is the one of the pivots,  u_ii = a_ii - sum_k (a_ik / u_kk) * a_ki .  So the pass that brings A
+//     into level-major order (k_st_rows) writes the off-diagonals of U itself and hands every row the transposed entries
+//     a_ki it needs (each row scatters its upper entries into the records of the rows they meet), and the factor kernel
+//     is left with what the L sweep does: one value per row handed from lane to lane;
+//   * the consumer has no record decode, no tags and no polling inside a workgroup: the lane table sits in registers,
+//     finished values go into ONE LDS array indexed by (step mod 8, lane) -- kept twice, 8 steps apart, so that every read
+//     address is a lane constant plus an immediate -- and ONE s_barrier per step orders them (4 waves per workgroup,
+//     nothing else resident: no loader waves, no importer wave);
+//   * the streams are read by the consuming lane itself, 8 steps ahead, into a rotating register file (fully unrolled
+//     loop), level-major and coalesced.  vmcnt retires loads and stores in issue order and hipcc only counts the
+//     operations it is certain of, so EVERY memory operation of a step is unconditional (lanes or waves without a row
+//     are redirected to a dump location): the waits then leave the whole read-ahead in flight;
+//   * values of earlier workgroups (tile borders) are polled 4 steps ahead by the border lanes themselves (write-through
+//     stores / cache-bypassing loads, the data is the flag); a value that is not there when its step comes is polled
+//     again, which makes the tile fall back behind its producers by just the latency it needs.
 //
+// A step is bound by instruction issue (one wave per SIMD): everything that can be a lane constant is one.
 // Everything the proof rejects runs on the record-decoding kernels (records_lm.hip) or the CSR kernels (any matrix).
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,20 +43,25 @@ namespace ilupp {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-static constexpr int kStH = 8;                 // steps of hand-off history kept in LDS
-#ifndef ST_D
-#define ST_D 8
-#endif
-static constexpr int kStD = ST_D;              // steps the streams are read ahead (rotating registers)
-#ifndef ST_P
-#define ST_P 4
-#endif
-static constexpr int kStP = ST_P;              // steps ahead the values of earlier workgroups are polled (at most 2 such dependencies per lane)
-static_assert(kStD % kStP == 0, "the poll ring is indexed by the unrolled step");
+static constexpr int kStH = 8;                 // steps of hand-off history kept in LDS = steps the streams are read ahead
+static constexpr int kStP = 4;                 // steps ahead the values of earlier workgroups are polled (at most 2 per lane)
 static constexpr int kStMaxSkew = 30000;
 static constexpr unsigned kStSpinLimit = 1u << 21;
+static constexpr int64_t kStMaxChunks = 1 << 21;      // record offsets are 32-bit byte offsets
 
 struct __attribute__((aligned(8))) D2s { double v[2]; };
+
+__global__ void k_lm_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, const int32_t *__restrict__ scount,
+                          const int32_t *__restrict__ wtabL, const int32_t *__restrict__ skewL, int32_t *__restrict__ ysrc);   // sptrsv_lm.hip
+
+__device__ __forceinline__ unsigned long long st_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ double st_dbl(unsigned long long b) { return __longlong_as_double((long long)b); }
+// a value that enters the records must not look like one of the two markers
+__device__ __forceinline__ double st_clean(double x)
+{
+    const unsigned long long b = st_bits(x);
+    return (b == kSentinel || b == kAbsent) ? st_dbl(kCanonNaN) : x;
+}
 
 // ---------------------------------------------------------------------------------------------
 // analysis 1: lane templates.  TRI = +1: the entries left of the diagonal (forward schedule), -1: right (backward)
@@ -106,21 +119,35 @@ k_st_template(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, 
             ++nd;
         }
     }
+    if (nd == 3 && (s0 & 3) == ST_GHOST && (s1 & 3) == ST_GHOST && (s2 & 3) == ST_GHOST) bad = 1;   // the poll ring holds two
     int32_t *T = ltab + (size_t)slot * kStTab;
     T[ST_FIRST] = first; T[ST_CNT] = cnt; T[ST_SKEW] = 0; T[ST_ND] = nd;
-    T[ST_OFF] = o0; T[ST_OFF + 1] = o1; T[ST_OFF + 2] = o2;
-    T[ST_SRC] = nd > 0 ? s0 : 0; T[ST_SRC + 1] = nd > 1 ? s1 : 0; T[ST_SRC + 2] = nd > 2 ? s2 : 0;
-    T[ST_BLK] = b0; T[ST_BLK + 1] = b1; T[ST_BLK + 2] = b2;
-    T[ST_KAP] = k0; T[ST_KAP + 1] = k1; T[ST_KAP + 2] = k2;
-    T[ST_MPOS] = 0x3f; T[ST_DT] = 1; T[ST_DT + 1] = 1; T[ST_DT + 2] = 1;
-    if (nd == 3 && (s0 & 3) == ST_GHOST && (s1 & 3) == ST_GHOST && (s2 & 3) == ST_GHOST) bad = 1;   // the poll ring holds two
+    const int oo[3] = {o0, o1, o2}, ss[3] = {s0, s1, s2}, bb[3] = {b0, b1, b2}, kk[3] = {k0, k1, k2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const bool in = j < nd;
+        T[ST_OFF + j] = in ? oo[j] : 0;
+        T[ST_SRC + j] = in ? ss[j] : 0;
+        T[ST_KAP + j] = in ? kk[j] : 0;
+        T[ST_DT + j] = 1;
+        T[ST_SCAT + j] = -1;
+        // the rows k of this lane whose entry at this offset lies where the template says (own chain: all but the first)
+        int klo = 0, khi = 0;
+        if (in) {
+            if ((ss[j] & 3) == ST_OWN) { klo = 1; khi = cnt; }
+            else if (TRI > 0) { klo = start[bb[j]] - first - oo[j]; khi = start[bb[j] + 1] - first - oo[j]; }
+            else { klo = first + oo[j] - start[bb[j] + 1] + 1; khi = first + oo[j] - start[bb[j]] + 1; }
+        }
+        T[ST_KLO + j] = klo; T[ST_KHI + j] = khi;
+    }
+    T[ST_UP0] = 0;
     if (bad) atomicOr(&flags[0], 2);
 }
 
 // ---------------------------------------------------------------------------------------------
-// analysis 2: skews (longest-path fixpoint over the workgroup's in-workgroup dependencies, now exact: the templates
-// hold for every row), steps back of every in-workgroup dependency, chunk range of each wave; FWD: where each
-// elimination's pivot row holds the entry that meets this row's diagonal, and the proof that it meets nothing else
+// analysis 2: skews (longest-path fixpoint over the workgroup's in-workgroup dependencies, exact: the templates hold
+// for every row), steps back of every in-workgroup dependency, chunk range of each wave; FWD: the proof that each
+// elimination meets the eliminated row on its diagonal only
 // ---------------------------------------------------------------------------------------------
 template <bool FWD>
 __global__ void __launch_bounds__(kThreads)
@@ -176,7 +203,6 @@ k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const 
     }
     if (FWD && cnt > 0) {
         const int su = uslot[slot];
-        int mpw = 0;
         if (su < 0) {
             bad = 1;
         } else {
@@ -186,11 +212,8 @@ k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const 
             const int ml[3] = {T[ST_OFF], T[ST_OFF + 1], T[ST_OFF + 2]};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                int mp = 3;
                 if (j < nd) {
-                    const int sw = T[ST_SRC + j];
-                    const int ps = sw >> 2;
-                    const int pu = uslot[ps];
+                    const int pu = uslot[T[ST_SRC + j] >> 2];
                     if (pu < 0) {
                         bad = 1;
                     } else {
@@ -200,9 +223,7 @@ k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const 
                         for (int p = 0; p < 3; ++p) {
                             if (p < np) {
                                 const int m = ml[j] + TP[ST_OFF + p];       // column of the pivot row's entry, relative to this row
-                                if (m == 0) {
-                                    mp = p;
-                                } else {
+                                if (m != 0) {
                                     // a match off the diagonal would change an L or U entry of this row: not a "simple" row
 #pragma unroll
                                     for (int q = 0; q < 3; ++q) {
@@ -214,10 +235,8 @@ k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const 
                         }
                     }
                 }
-                mpw |= mp << (2 * j);
             }
         }
-        T[ST_MPOS] = mpw;
     }
     if (bad) atomicOr(&flags[0], 4);
 }
@@ -244,123 +263,168 @@ k_st_scan(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ flag
     for (int i = t * per; i < (t + 1) * per && i < nwaves; ++i) { wtab[(size_t)i * 4] = run; run += wtab[(size_t)i * 4 + 2]; }
 }
 
+__global__ void k_st_inv(int32_t nslots, const int32_t *__restrict__ uslot, int32_t *__restrict__ inv)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < nslots && uslot[f] >= 0) inv[uslot[f]] = f;
+}
+
+// analysis 3 (forward lanes, after the chunk tables): where the lane's rows sit in the backward sweep's records, and
+// where each of their upper entries a(r, r+o) goes: into the record of row r+o, as the transposed entry of that row's
+// elimination with row r.  Both are "position of row 0 of the lane" + a fixed stride per row.
+// ... and everything the rows pass needs about a lane in one 128-byte record (rtab):
+//   {first, cnt, skew, nL} {oL0, oL1, oL2, nU} {oU0, oU1, oU2, up0} {kloL x3, -} {khiL x3, -} {kloU x3, -} {khiU x3, -} {scat x3, -}
+__global__ void k_st_scat(int32_t nslots, int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB,
+                          const int32_t *__restrict__ uslot, const int32_t *__restrict__ inv,
+                          const int32_t *__restrict__ wtabF, const int32_t *__restrict__ wtabU, int32_t *__restrict__ rtab,
+                          int32_t *__restrict__ flags)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nslots) return;
+    int32_t *T = ltabF + (size_t)f * kStTab;
+    int32_t *R = rtab + (size_t)f * 32;
+    const int cnt = T[ST_CNT];
+    R[0] = T[ST_FIRST]; R[1] = cnt; R[2] = T[ST_SKEW]; R[3] = T[ST_ND];
+    if (cnt <= 0) return;
+    const int su = uslot[f];
+    if (su < 0) { atomicOr(&flags[0], 16); return; }
+    const int32_t *TB = ltabB + (size_t)su * kStTab;
+    const int wu = su >> 6;
+    // 16-byte units; row k of the lane: - 128 k
+    T[ST_UP0] = (wtabU[wu * 4] + (cnt - 1 + TB[ST_SKEW] - wtabU[wu * 4 + 1])) * 128 + (su & 63);
+    const int nu = TB[ST_ND];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int sc = -1;
+        if (p < nu) {
+            const int cs = inv[TB[ST_SRC + p] >> 2];                 // forward slot of the chain that holds rows r + o
+            if (cs < 0) {
+                atomicOr(&flags[0], 16);
+            } else {
+                const int32_t *TC = ltabF + (size_t)cs * kStTab;
+                const int o = TB[ST_OFF + p];
+                int jc = -1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < TC[ST_ND] && TC[ST_OFF + j] == -o) jc = j;
+                if (jc >= 0) {
+                    const int kc = T[ST_FIRST] + o - TC[ST_FIRST];               // index of row r + o in its chain, for row 0 of this lane
+                    const int cw = cs >> 6;
+                    const int chunk0 = wtabF[cw * 4] + (kc + TC[ST_SKEW] - wtabF[cw * 4 + 1]);
+                    // 8-byte units: piece 2 + jc/2 of the chunk, half jc%2; row k of the lane: + 512 k
+                    sc = (chunk0 * 256 + (2 + (jc >> 1)) * 64 + (cs & 63)) * 2 + (jc & 1);
+                }
+            }
+        }
+        T[ST_SCAT + p] = sc;
+        R[28 + p] = sc;
+        R[4 + p] = T[ST_OFF + p]; R[8 + p] = TB[ST_OFF + p];
+        R[12 + p] = T[ST_KLO + p]; R[16 + p] = T[ST_KHI + p];
+        R[20 + p] = TB[ST_KLO + p]; R[24 + p] = TB[ST_KHI + p];
+    }
+    R[7] = nu; R[11] = T[ST_UP0];
+}
+
+// the transposed-entry halves of the factor records start out as "no such entry"
+__global__ void k_st_prefill(int64_t nchunks, v2d *__restrict__ pkA)
+{
+    const int64_t total = nchunks * 128;
+    v2d a; a.x = st_dbl(kAbsent); a.y = st_dbl(kAbsent);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(a, pkA + (i >> 7) * 256 + 128 + (i & 127));
+}
+
 // ---------------------------------------------------------------------------------------------
-// analysis 3: the proof, row by row, and the factor kernel's input: per (chunk, lane) 64 bytes
-//   {a0,a1} {a2,a3} {a4,a5} {a6, mask}: the row of A by template position (a0..a2 left of the diagonal, a3 the
-//   diagonal, a4..a6 right of it), mask bit j = position present (bit 3 = the row exists)
+// analysis 4: the proof, row by row, and the factor kernel's input.  Per (chunk, lane) 64 bytes
+//   {a0,a1} {a2,a3} {t0,t1} {t2,a6}: a0..a2 the entries left of the diagonal by template position, a3 the diagonal,
+//   t_j = a(k_j, r) the transposed entry of elimination j (written by row k_j, below), a6 the last upper entry;
+// the off-diagonal part {a4,a5} of the row of U goes straight into the backward sweep's record.
 // A block owns the 64 lanes of one wave x 8 consecutive rows of each; inside a wave 8 lanes x 8 rows, so a load
 // instruction touches 8 contiguous segments of A and a store instruction 8 neighbouring places of 8 chunks.
-// VALUES: 0 = pattern only (masks), 1 = pattern and values, 2 = values only (masks exist: numeric re-factorisation)
 // ---------------------------------------------------------------------------------------------
-template <int VALUES>
 __global__ void __launch_bounds__(512)
 k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval, int64_t nnz,
-          const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot,
-          const int32_t *__restrict__ wtab, const int32_t *__restrict__ startF, const int32_t *__restrict__ startB,
-          v4i *__restrict__ pkA, int32_t *__restrict__ flags)
+          const int32_t *__restrict__ rtab, const int32_t *__restrict__ wtab, v2d *__restrict__ pkA, v2d *__restrict__ pkU,
+          int32_t *__restrict__ flags)
 {
     const int w = blockIdx.x;
     const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
     const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
-    const int32_t *T = ltabF + (size_t)slot * kStTab;
-    const int cnt = T[ST_CNT];
+    const v4i *R = reinterpret_cast<const v4i *>(rtab + (size_t)slot * 32);
+    const v4i t0 = R[0];                                                 // first, cnt, skew, nL
+    const int cnt = t0.y;
     const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
     if (k >= cnt) return;
-    const int r = T[ST_FIRST] + k;
-    const int c = k + T[ST_SKEW] - wtab[(size_t)w * 4 + 1];
-    v4i *p = pkA + ((size_t)wtab[(size_t)w * 4] + c) * 256 + L;
+    const v4i t1 = R[1], t2 = R[2];                                      // oL x3, nU | oU x3, up0
+    const int r = t0.x + k;
+    const int c = k + t0.z - wtab[(size_t)w * 4 + 1];
+    v2d *p = pkA + ((size_t)wtab[(size_t)w * 4] + c) * 256 + L;
     const int a0 = Aptr[r];
+    const int len = Aptr[r + 1] - a0;
     double v[8];
-    if (VALUES != 0) {
-        if ((int64_t)a0 + 8 <= nnz) {
+    if ((int64_t)a0 + 8 <= nnz) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const D2s x = *reinterpret_cast<const D2s *>(Aval + a0 + 2 * i); v[2 * i] = x.v[0]; v[2 * i + 1] = x.v[1]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (int64_t)a0 + i < nnz ? Aval[a0 + i] : 0.0;
-        }
+        for (int i = 0; i < 4; ++i) { const D2s x = *reinterpret_cast<const D2s *>(Aval + a0 + 2 * i); v[2 * i] = x.v[0]; v[2 * i + 1] = x.v[1]; }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.0;
+        for (int i = 0; i < 8; ++i) v[i] = (int64_t)a0 + i < nnz ? Aval[a0 + i] : 0.0;
     }
-    double a[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int bad = (len > 7 || len < 1) ? 1 : 0;
+    const int ndF = t0.w, ndB = t1.w;
+    const int oF[3] = {t1.x, t1.y, t1.z};
+    const int oB[3] = {t2.x, t2.y, t2.z};
+    const Row8 own = load_row8(Aidx, a0, len > 8 ? 8 : len, nnz);
+    const double absent = st_dbl(kAbsent);
+    double a[7] = {absent, absent, absent, absent, absent, absent, absent};
     int mask = 0;
-    if (VALUES == 2) {
-        mask = reinterpret_cast<const int *>(p + 192)[2];
-        int pos = 0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            if (mask & (1 << j)) {
-                a[j] = pos == 0 ? v[0] : pos == 1 ? v[1] : pos == 2 ? v[2] : pos == 3 ? v[3] : pos == 4 ? v[4] : pos == 5 ? v[5] : v[6];
-                ++pos;
-            }
-        }
-    } else {
-        const int len = Aptr[r + 1] - a0;
-        const int su = uslot[slot];
-        int bad = (len > 7 || len < 1 || su < 0) ? 1 : 0;
-        const int32_t *TB = ltabB + (size_t)(su < 0 ? 0 : su) * kStTab;
-        const int ndF = T[ST_ND], ndB = TB[ST_ND];
-        const int oF[3] = {T[ST_OFF], T[ST_OFF + 1], T[ST_OFF + 2]};
-        const int oB[3] = {TB[ST_OFF], TB[ST_OFF + 1], TB[ST_OFF + 2]};
-        const Row8 own = load_row8(Aidx, a0, len > 8 ? 8 : len, nnz);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const bool in = i < len;
-            const int o = in ? own.c[i] - r : 0x40000000;
-            bool hit = false;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const bool h = in && o < 0 && j < ndF && o == oF[j];
-                if (h) { a[j] = v[i]; mask |= 1 << j; }
-                hit |= h;
-            }
-            {
-                const bool h = in && o == 0;
-                if (h) { a[3] = v[i]; mask |= 8; }
-                hit |= h;
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const bool h = in && o > 0 && q < ndB && o == oB[q];
-                if (h) { a[4 + q] = v[i]; mask |= 16 << q; }
-                hit |= h;
-            }
-            if (in && !hit) bad = 1;                            // a column outside the lane's template
-        }
-        if (!(mask & 8)) bad = 1;
-        // every entry is produced where the template says: own chain, or the recorded block of the other lane
+    for (int i = 0; i < 7; ++i) {
+        const bool in = i < len;
+        const int o = in ? own.c[i] - r : 0x40000000;
+        const double vi = st_clean(v[i]);
+        bool hit = false;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            if (mask & (1 << j)) {
-                const int col = r + oF[j];
-                if ((T[ST_SRC + j] & 3) == ST_OWN) {
-                    if (k == 0) bad = 1;
-                } else {
-                    const int b = T[ST_BLK + j];
-                    if (col < startF[b] || col >= startF[b + 1]) bad = 1;
-                }
-            }
-            if (mask & (16 << j)) {
-                const int col = r + oB[j];
-                if ((TB[ST_SRC + j] & 3) == ST_OWN) {
-                    if (k == cnt - 1) bad = 1;
-                } else {
-                    const int b = TB[ST_BLK + j];
-                    if (col < startB[b] || col >= startB[b + 1]) bad = 1;
-                }
-            }
+            const bool h = in && j < ndF && o == oF[j];
+            if (h) { a[j] = vi; mask |= 1 << j; }
+            hit |= h;
         }
-        if (bad) atomicOr(&flags[0], 8);
+        {
+            const bool h = in && o == 0;
+            if (h) { a[3] = vi; mask |= 8; }
+            hit |= h;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const bool h = in && q < ndB && o == oB[q];
+            if (h) { a[4 + q] = vi; mask |= 16 << q; }
+            hit |= h;
+        }
+        if (in && !hit) bad = 1;                            // a column outside the lane's template
     }
+    if (!(mask & 8)) bad = 1;
+    // every entry is produced where the template says
+    const v4i klF = R[3], khF = R[4], klB = R[5], khB = R[6], sc = R[7];
+    const int kb = cnt - 1 - k;                             // the row's index in the backward schedule
+    const int kl[3] = {klF.x, klF.y, klF.z}, kh[3] = {khF.x, khF.y, khF.z};
+    const int bl[3] = {klB.x, klB.y, klB.z}, bh[3] = {khB.x, khB.y, khB.z};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if ((mask & (1 << j)) && (k < kl[j] || k >= kh[j])) bad = 1;
+        if ((mask & (16 << j)) && (kb < bl[j] || kb >= bh[j])) bad = 1;
+    }
+    if (bad) { atomicOr(&flags[0], 8); return; }
     v2d x;
-    if (VALUES != 0) {
-        x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, reinterpret_cast<v2d *>(p));
-        x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, reinterpret_cast<v2d *>(p) + 64);
-        x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, reinterpret_cast<v2d *>(p) + 128);
-    }
-    v4i last; last.x = __double2loint(a[6]); last.y = __double2hiint(a[6]); last.z = mask; last.w = 0;
-    __builtin_nontemporal_store(last, p + 192);
+    x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, p);
+    x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, p + 64);
+    reinterpret_cast<double *>(p + 192)[1] = a[6];
+    x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((long)t2.w - 128 * (long)k));
+    // the upper entries, to the rows they meet
+    double *pd = reinterpret_cast<double *>(pkA);
+    const int scs[3] = {sc.x, sc.y, sc.z};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if ((mask & (16 << q)) && scs[q] >= 0) pd[(long)scs[q] + 512 * (long)k] = a[4 + q];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -369,67 +433,82 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
 // ---------------------------------------------------------------------------------------------
 #define ST_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-__device__ __forceinline__ unsigned long long st_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
-__device__ __forceinline__ double st_dbl(unsigned long long b) { return __longlong_as_double((long long)b); }
-// a value about to be published must not look like one of the two markers
-__device__ __forceinline__ double st_clean(double x)
+__device__ __forceinline__ double st_lds(const unsigned char *base, unsigned off) { return *reinterpret_cast<const double *>(base + off); }
+__device__ __forceinline__ int st_med3(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// lane constants of the hand-off: LDS read address of each dependency (the value of `dt` steps ago of lane `u`, in the
+// copy 8 slots up: slot index = step%8 + 8 - dt stays inside [1, 15] with the step's immediate), which dependencies
+// come from an earlier workgroup and which of the two poll registers holds them
+struct StLane {
+    int first, cnt, sk;
+    unsigned va[3];
+    bool isg[3], g1[3];
+    int ng;
+};
+__device__ __forceinline__ StLane st_lane(const int32_t *T, int t)
 {
-    const unsigned long long b = st_bits(x);
-    return (b == kSentinel || b == kAbsent) ? st_dbl(kCanonNaN) : x;
+    StLane s;
+    s.first = T[ST_FIRST]; s.cnt = T[ST_CNT]; s.sk = T[ST_SKEW];
+    const int nd = T[ST_ND];
+    s.ng = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int sw = T[ST_SRC + j];
+        const int ty = (j < nd && s.cnt > 0) ? (sw & 3) : ST_NONE;
+        const int u = ty == ST_LOCAL ? ((sw >> 2) & 255) : t;
+        const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;              // (own previous row: lane t, one step back)
+        s.va[j] = (unsigned)(((kStH - dt) * kThreads + u) * 8);
+        s.isg[j] = ty == ST_GHOST;
+        s.g1[j] = s.isg[j] && s.ng > 0;
+        s.ng += s.isg[j] ? 1 : 0;
+    }
+    return s;
 }
 
+#ifdef ST_STAMP
+// diagnostics build only: cycles of the first wave of the LAST workgroup, summed over its steps, per segment of a step
+__device__ unsigned long long g_st_stamp[32];
+#define ST_T(i) do { if (stamp_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_[i] += n_ - last_; last_ = __builtin_amdgcn_s_memtime(); } } while (0)
+#define ST_T_DECL(cond) const bool stamp_on = (cond); unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_amdgcn_s_memtime(); unsigned long long nst_ = 0
+#define ST_T_END(off) do { if (stamp_on && ln == 0) { for (int i_ = 0; i_ < 8; ++i_) g_st_stamp[(off) + i_] = acc_[i_]; g_st_stamp[(off) + 8] = nst_; } } while (0)
+#else
+#define ST_T(i) do { } while (0)
+#define ST_T_DECL(cond) do { } while (0)
+#define ST_T_END(off) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
-// the factor kernel
+// the factor kernel: pivots only
 // ---------------------------------------------------------------------------------------------
 struct StFArgs {
     const int32_t *ltab, *wtab;               // forward schedule
-    const v2d *pkA;                           // 4 x 64 x 16 B per chunk
-    v2d *pkL, *pkU;                           // 2 x 64 x 16 B per chunk: {l0,l1}{l2,1} / {u1,u2}{u3,u0}
-    const int32_t *wtabU, *skewU, *uslot;
+    const v2d *pkA;                           // 4 x 64 x 16 B per chunk: {a0,a1}{a2,a3}{t0,t1}{t2,a6}
+    v2d *pkL, *pkU;                           // 2 x 64 x 16 B per chunk: {l0,l1}{l2,1} / {u1,u2}{u3,u0}; one spare chunk at the end each
+    int32_t nchL, nchU;                       // index of the first spare chunk (one per wave)
     const int32_t *xbase;                     // per slot: first exchange row, -1 = nobody outside the workgroup reads it
-    const long long *xcount;                  // doubles of xch in use
+    const long long *xcount;                  // exchange rows in use (the one after them is the dump)
     double *xch;
     int32_t *ctrl;                            // [0] ticket, [1] error
 };
-static constexpr size_t kStFLds = (size_t)4 * kStH * kThreads * sizeof(double);
 
 __global__ void __launch_bounds__(kThreads)
 k_ilu0_st(StFArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *UH = reinterpret_cast<double *>(smem);               // [4][kStH][256]: u0 (pivot), u1, u2, u3 of finished rows
+    __shared__ __attribute__((aligned(16))) unsigned char xh[2 * kStH * kThreads * 8];      // pivots of finished rows: [16][256], slots s and s+8 alike
     __shared__ unsigned s_ticket;
     if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
     __syncthreads();
     const int wg = (int)s_ticket;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
-    const int slot = wg * kThreads + t;
-    const int32_t *T = A.ltab + (size_t)slot * kStTab;
-    const int first = T[ST_FIRST], cnt = T[ST_CNT], sk = T[ST_SKEW], nd = T[ST_ND];
-    (void)first;
-    const long xrows = (long)(A.xcount[0] / 4);
-    int ty[3], ix[3], dt[3], mp[3], gi[3];
-    long gxr[2] = {0, 0};
-    int gmo[2] = {1, 1};
-    int ng = 0;
+    const int32_t *T = A.ltab + (size_t)(wg * kThreads + t) * kStTab;
+    const StLane S = st_lane(T, t);
+    const int cnt = S.cnt, sk = S.sk;
+    const int xdump = (int)A.xcount[0];                                 // exchange rows: one double each
+    int gx0 = xdump, gx1 = xdump;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int sw = T[ST_SRC + j];
-        ty[j] = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
-        ix[j] = ty[j] == ST_LOCAL ? ((sw >> 2) & 255) : t;
-        dt[j] = ty[j] == ST_LOCAL ? T[ST_DT + j] : 1;
-        const int m = (T[ST_MPOS] >> (2 * j)) & 3;
-        mp[j] = m;
-        gi[j] = 0;
-        if (ty[j] == ST_GHOST) {
-            const long g = (long)A.xbase[sw >> 2] + T[ST_KAP + j];
-            const int mo_ = 1 + (m < 3 ? m : 0);
-            if (ng == 0) { gxr[0] = g; gmo[0] = mo_; } else { gxr[1] = g; gmo[1] = mo_; }
-            gi[j] = ng < 1 ? 0 : 1;
-            ++ng;
-        }
-    }
-    const bool wave_ghost = __any(ng > 0);
+    for (int j = 0; j < 3; ++j)
+        if (S.isg[j]) { const int g = A.xbase[T[ST_SRC + j] >> 2] + T[ST_KAP + j]; if (S.g1[j]) gx1 = g; else gx0 = g; }
+    const bool wave_ghost = __any(S.ng > 0);
     const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
     const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
               nchw = __builtin_amdgcn_readfirstlane(wt[2]);
@@ -442,171 +521,171 @@ k_ilu0_st(StFArgs A)
     }
     tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
     if (thi <= tlo) return;
-    const int nsteps = ((thi - tlo + kStD - 1) / kStD) * kStD;
-    // this lane's rows in the backward sweep's records: one chunk (128 sixteen-byte units) apart, descending
-    long up0 = 0;
-    if (cnt > 0) {
-        const int su = A.uslot[slot];
-        const int wu = su >> 6;
-        up0 = ((long)A.wtabU[wu * 4] + (cnt - 1 + A.skewU[su] - A.wtabU[wu * 4 + 1])) * 128 + (su & 63);
-    }
-    const int xb = cnt > 0 ? A.xbase[slot] : -1;
+    tlo &= ~(kStH - 1);                                                 // step % 8 = position in the unrolled loop
+    const int xb = cnt > 0 ? A.xbase[wg * kThreads + t] : -1;
     const bool exports = xb >= 0;
     const unsigned long long *xchb = reinterpret_cast<const unsigned long long *>(A.xch);
-    const v2d *pa = A.pkA + (size_t)(nchw > 0 ? base : 0) * 256 + ln;
-    v2d *lout = A.pkL + (size_t)base * 128 + ln;
+    const unsigned char *pa = reinterpret_cast<const unsigned char *>(A.pkA) + (size_t)(nchw > 0 ? base : 0) * 4096;
+    unsigned char *pl = reinterpret_cast<unsigned char *>(A.pkL);
+    unsigned char *pu = reinterpret_cast<unsigned char *>(A.pkU);
+    const unsigned lo16 = (unsigned)ln * 16u;
     const int cmax = nchw > 0 ? nchw - 1 : 0;
+    // dump places: one spare chunk per wave behind the records (a place shared by all waves would be a hot spot)
+    const int wglob = wg * 4 + wv;
+    const unsigned udump = (unsigned)(A.nchU + wglob) * 2048u + lo16;
+    const int ldump = A.nchL + wglob;
+    const bool wave_exports = __any(xb >= 0);
+    const int up0 = T[ST_UP0];
 
-    v2d ra[kStD][4];
-    unsigned long long gq[kStP][2][2];            // [ring][dependency][pivot, matching entry]
-    const int mo[3] = {1 + (mp[0] < 3 ? mp[0] : 0), 1 + (mp[1] < 3 ? mp[1] : 0), 1 + (mp[2] < 3 ? mp[2] : 0)};
+    v2d ra[kStH][4];
+    unsigned long long gq[kStP][2];
 
 #define STF_LOAD(u, tp)                                                                                              \
     do {                                                                                                             \
-        int cw_ = (tp) - tminw; cw_ = cw_ < 0 ? 0 : (cw_ > cmax ? cmax : cw_);                                      \
-        const v2d *q_ = pa + (size_t)cw_ * 256;                                                                      \
-        ra[u][0] = __builtin_nontemporal_load(q_); ra[u][1] = __builtin_nontemporal_load(q_ + 64);                   \
-        ra[u][2] = __builtin_nontemporal_load(q_ + 128); ra[u][3] = __builtin_nontemporal_load(q_ + 192);            \
+        const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                              \
+        const unsigned char *q_ = pa + (size_t)cw_ * 4096;                                                           \
+        ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                             \
+        ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                      \
+        ra[u][2] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 2048));                      \
+        ra[u][3] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 3072));                      \
     } while (0)
-#define STF_POLL(g, tp)                                                                                              \
+#define STF_POLL(g, kq)                                                                                              \
     do {                                                                                                             \
-        if (wave_ghost) {                                                                                            \
-            int kp_ = (tp) - sk; kp_ = kp_ < 0 ? 0 : (kp_ >= cnt ? cnt - 1 : kp_);                                   \
-            _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                                       \
-                if (e_ < ng) {                                                                                       \
-                    long row_ = gxr[e_] + kp_; row_ = row_ < 0 ? 0 : (row_ >= xrows ? xrows - 1 : row_);             \
-                    gq[g][e_][0] = ld_agent_u64(xchb + row_ * 4);                                                    \
-                    gq[g][e_][1] = ld_agent_u64(xchb + row_ * 4 + gmo[e_]);                                          \
-                }                                                                                                    \
-            }                                                                                                        \
-        }                                                                                                            \
+        if (S.ng > 0) gq[g][0] = ld_agent_u64(xchb + st_med3(gx0 + (kq), 0, xdump));                                 \
+        if (S.ng > 1) gq[g][1] = ld_agent_u64(xchb + st_med3(gx1 + (kq), 0, xdump));                                 \
     } while (0)
 
-#pragma unroll
-    for (int g = 0; g < kStP; ++g) {
-        gq[g][0][0] = kSentinel; gq[g][0][1] = kSentinel; gq[g][1][0] = kSentinel; gq[g][1][1] = kSentinel;
-        STF_POLL(g, tlo + g);
-        asm volatile("" ::: "memory");
-    }
     // in step order (a compiler barrier after each): the waits of the loop are derived from the oldest position a
     // register's load can have, and the scheduler is free to turn an unordered prologue upside down
 #pragma unroll
-    for (int u = 0; u < kStD; ++u) { STF_LOAD(u, tlo + u); asm volatile("" ::: "memory"); }
-    double pu0 = 0.0, pu1 = 0.0, pu2 = 0.0, pu3 = 0.0;          // U row of the lane's previous row
+    for (int g = 0; g < kStP; ++g) { gq[g][0] = kSentinel; gq[g][1] = kSentinel; STF_POLL(g, tlo + g - sk); asm volatile("" ::: "memory"); }
+    // ... and with the stores a step of the loop has, to the dump places: hipcc takes, for every wait, the smaller of
+    // the operation counts behind the load on the two ways into the loop body
+    const double absent = st_dbl(kAbsent);
+#pragma unroll
+    for (int u = 0; u < kStH; ++u) {
+        STF_LOAD(u, tlo + u);
+        v2d z; z.x = absent; z.y = absent;
+        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16));
+        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16 + 1024));
+        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pu + udump));
+        asm volatile("" ::: "memory");
+    }
     bool dead = false;
+    ST_T_DECL(wv == 0 && wg == (int)gridDim.x - 1);
 
-    for (int tb = 0; tb < nsteps; tb += kStD) {
+    for (int tb = tlo; tb < thi; tb += kStH) {
+        const int kb = tb - sk;
 #pragma unroll
-        for (int u = 0; u < kStD; ++u) {
-            const int tau = tlo + tb + u;
-            const int k = tau - sk;
+        for (int u = 0; u < kStH; ++u) {
+            const int k = kb + u;
             const bool valid = (unsigned)k < (unsigned)cnt;
+#ifdef ST_STAMP
+            ++nst_;
+#endif
+            ST_T(0);
             const v2d r0 = ra[u][0], r1 = ra[u][1], r2 = ra[u][2], r3 = ra[u][3];
-            // (both halves of the mask word are used on purpose: a dead quarter of a 16-byte load is a free register to
-            // the allocator, and a temporary placed there has to wait for that load -- a load of a LATER step)
-            const int mask = valid ? ((int)(unsigned)st_bits(r3.y) | (int)(unsigned)(st_bits(r3.y) >> 32)) : 0;
+            const double av[3] = {r0.x, r0.y, r1.x}, at[3] = {r2.x, r2.y, r3.x};
+            bool pj[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pj[j] = valid && st_bits(av[j]) != kAbsent;
             ST_BARRIER();
-            // in-workgroup hand-off: pivot and the one matching entry of each eliminated row, kStH steps of history
-            double piv[3], um[3];
+            ST_T(1);
+            double piv[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int at = ((tau - dt[j]) & (kStH - 1)) * kThreads + ix[j];
-                piv[j] = UH[at];
-                um[j] = UH[mo[j] * kStH * kThreads + at];
-            }
+            for (int j = 0; j < 3; ++j) piv[j] = st_lds(xh, S.va[j] + (unsigned)u * (kThreads * 8));
+#ifdef ST_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            ST_T(2);
+            if (wave_ghost) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (ty[j] == ST_OWN) { piv[j] = pu0; um[j] = mo[j] == 1 ? pu1 : (mo[j] == 2 ? pu2 : pu3); }
-                if (ty[j] == ST_GHOST) {
-                    piv[j] = st_dbl(gi[j] == 0 ? gq[u % kStP][0][0] : gq[u % kStP][1][0]);
-                    um[j] = st_dbl(gi[j] == 0 ? gq[u % kStP][0][1] : gq[u % kStP][1][1]);
-                }
-            }
-            if (wave_ghost && !dead) {
-                // rows of earlier workgroups that had not arrived when they were asked for: ask again
-                unsigned spins = 0;
-                for (;;) {
-                    bool miss = false;
+                for (int j = 0; j < 3; ++j)
+                    if (S.isg[j]) piv[j] = st_dbl(S.g1[j] ? gq[u % kStP][1] : gq[u % kStP][0]);
+                if (!dead) {
+                    // pivots of earlier workgroups that had not arrived when they were asked for: ask again
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool miss = false;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (ty[j] == ST_GHOST && (mask & (1 << j)) && (st_bits(piv[j]) == kSentinel || st_bits(um[j]) == kSentinel)) miss = true;
-                    if (!__any(miss)) break;
-                    if (miss) {
+                        for (int j = 0; j < 3; ++j)
+                            if (S.isg[j] && pj[j] && st_bits(piv[j]) == kSentinel) miss = true;
+                        if (!__any(miss)) break;
+                        if (miss) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            if (ty[j] == ST_GHOST && (mask & (1 << j))) {
-                                long row = (gi[j] == 0 ? gxr[0] : gxr[1]) + k; row = row < 0 ? 0 : (row >= xrows ? xrows - 1 : row);
-                                piv[j] = st_dbl(ld_agent_u64(xchb + row * 4));
-                                um[j] = st_dbl(ld_agent_u64(xchb + row * 4 + mo[j]));
-                            }
+                            for (int j = 0; j < 3; ++j)
+                                if (S.isg[j] && pj[j]) piv[j] = st_dbl(ld_agent_u64(xchb + st_med3((S.g1[j] ? gx1 : gx0) + k, 0, xdump)));
+                        }
+                        // retired HERE: a load pending at the join below would make hipcc wait for vmcnt(0) -- the whole
+                        // read-ahead -- on every step, also on those that never come through this loop
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 255u) == 0) {
+                            if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);
+                            const int e = ld_agent_i32(&A.ctrl[1]);
+                            __builtin_amdgcn_s_waitcnt(0x0F70);
+                            if (spins > kStSpinLimit || e != 0) { dead = true; break; }
                         }
                     }
-                    // retired HERE: a load pending at the join below would make hipcc wait for vmcnt(0) -- the whole
-                    // read-ahead -- on every step, also on those that never come through this loop
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 255u) == 0) {
-                        if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);
-                        const int e = ld_agent_i32(&A.ctrl[1]);
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        if (spins > kStSpinLimit || e != 0) { dead = true; break; }
-                    }
                 }
             }
-            double w0 = r0.x, w1 = r0.y, w2 = r1.x, w3 = r1.y;
-            const double w4 = r2.x, w5 = r2.y, w6 = r3.x;
-            // eliminations in ascending column; each meets this row on the diagonal only (ILU0.hpp:8-23, :47-62)
-            if (mask & 1) { const double l = w0 / piv[0]; if (mp[0] < 3 && st_bits(um[0]) != kAbsent) { const double pr = l * um[0]; w3 = w3 - pr; } w0 = l; }
-            if (mask & 2) { const double l = w1 / piv[1]; if (mp[1] < 3 && st_bits(um[1]) != kAbsent) { const double pr = l * um[1]; w3 = w3 - pr; } w1 = l; }
-            if (mask & 4) { const double l = w2 / piv[2]; if (mp[2] < 3 && st_bits(um[2]) != kAbsent) { const double pr = l * um[2]; w3 = w3 - pr; } w2 = l; }
-            const double absent = st_dbl(kAbsent);
-            const double u0 = st_clean(w3);
-            const double u1 = (mask & 16) ? st_clean(w4) : absent;
-            const double u2 = (mask & 32) ? st_clean(w5) : absent;
-            const double u3 = (mask & 64) ? st_clean(w6) : absent;
-            {
-                const int at = (tau & (kStH - 1)) * kThreads + t;
-                UH[at] = u0; UH[kStH * kThreads + at] = u1; UH[2 * kStH * kThreads + at] = u2; UH[3 * kStH * kThreads + at] = u3;
+            ST_T(3);
+            // u_ii = a_ii - sum (a_ik / u_kk) a_ki, eliminations in ascending k (ILU0.hpp:47-62 for rows whose eliminations
+            // meet them on the diagonal only)
+            double w3 = r1.y;
+            double l[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                l[j] = av[j] / piv[j];
+                const double pr = l[j] * at[j];
+                const double nw = w3 - pr;
+                w3 = (pj[j] && st_bits(at[j]) != kAbsent) ? nw : w3;
             }
-            if (exports && valid) {
-                double *xr = A.xch + ((size_t)xb + k) * 4;
-                st_agent_f64(xr, u0); st_agent_f64(xr + 1, u1); st_agent_f64(xr + 2, u2); st_agent_f64(xr + 3, u3);
-            }
-            const int cw = tau - tminw;
-#ifndef EXP_ST_NOSTORE
-            if ((unsigned)cw < (unsigned)nchw) {
-                v2d la, lb;
-                la.x = (mask & 1) ? st_clean(w0) : absent; la.y = (mask & 2) ? st_clean(w1) : absent;
-                lb.x = (mask & 4) ? st_clean(w2) : absent; lb.y = 1.0;
-                v2d *o = lout + (size_t)cw * 128;
-                __builtin_nontemporal_store(la, o); __builtin_nontemporal_store(lb, o + 64);
-            }
-            if (valid) {
-                v2d ua, ub;
-                ua.x = u1; ua.y = u2; ub.x = u3; ub.y = u0;
-                v2d *o = A.pkU + (up0 - 128 * (long)k);
-                __builtin_nontemporal_store(ua, o); __builtin_nontemporal_store(ub, o + 64);
-            }
+#ifdef ST_STAMP
+            asm volatile("" :: "v"(w3));
 #endif
-            if (valid) { pu0 = u0; pu1 = u1; pu2 = u2; pu3 = u3; }
-            STF_LOAD(u, tau + kStD);
-            STF_POLL(u % kStP, tau + kStP);
+            ST_T(4);
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)u * (kThreads * 8)) = w3;
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u + kStH) * (kThreads * 8)) = w3;
+            // pivots that other workgroups read: write-through (the one store of a step that hipcc cannot count on)
+            if (wave_exports) { if (exports && valid) st_agent_f64(A.xch + (xb + k), w3); }
+            // the record stores happen on every step (lanes / waves without a row store to their dump place)
+            {
+                const int cw = tb + u - tminw;
+                unsigned char *o = pl + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048;
+                v2d la, lb;
+                la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
+                lb.x = pj[2] ? l[2] : absent; lb.y = 1.0;
+                __builtin_nontemporal_store(la, reinterpret_cast<v2d *>(o + lo16));
+                __builtin_nontemporal_store(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
+            }
+            {
+                v2d ub; ub.x = r3.y; ub.y = w3;
+                const unsigned uo = valid ? (unsigned)(up0 - 128 * k) * 16u + 1024u : udump;
+                __builtin_nontemporal_store(ub, reinterpret_cast<v2d *>(pu + uo));
+            }
+            ST_T(5);
+            STF_LOAD(u, tb + u + kStH);
+            if (wave_ghost) STF_POLL(u % kStP, k + kStP);
+            ST_T(6);
         }
     }
 #undef STF_LOAD
 #undef STF_POLL
+    ST_T_END(0);
     if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
 }
 
 // ---------------------------------------------------------------------------------------------
-// the sweeps.  DR = +1 forward (rows ascending), -1 backward
+// the sweeps.  DR = +1 forward (rows ascending; the diagonal of L is 1: no division), -1 backward
 // ---------------------------------------------------------------------------------------------
 struct StSArgs {
     const v2d *pk;                            // 2 x 64 x 16 B per chunk: {v0,v1}{v2,vdiag}, dependencies in accumulation order
     const int32_t *ltab, *wtab;
-    int32_t n;
+    int32_t n, nchY;                          // nchY: the first spare chunk of ypk_out (one per wave)
     const double *rhs;
     double *out;
+    double *dump;
     const int32_t *exported;
     double *ypk_out;                          // the unknowns level-major, 64 per chunk (then only exported lanes write `out`)
     const double *ypk_in;                     // right-hand side from such a vector written by the opposite sweep
@@ -614,11 +693,11 @@ struct StSArgs {
     int32_t *ticket, *err;
 };
 
-template <int DR>
+template <int DR, bool YOUT, bool YIN>
 __global__ void __launch_bounds__(kThreads)
 k_sptrsv_st(StSArgs A)
 {
-    __shared__ double XH[kStH * kThreads];
+    __shared__ __attribute__((aligned(16))) unsigned char xh[2 * kStH * kThreads * 8];
     __shared__ unsigned s_ticket;
     if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(A.ticket, 1);
     __syncthreads();
@@ -626,25 +705,14 @@ k_sptrsv_st(StSArgs A)
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
     const int slot = wg * kThreads + t;
     const int32_t *T = A.ltab + (size_t)slot * kStTab;
-    const int first = T[ST_FIRST], cnt = T[ST_CNT], sk = T[ST_SKEW], nd = T[ST_ND];
-    int ty[3], ix[3], dt[3], goff[3], gi[3];
-    int go2[2] = {0, 0};
-    int ng = 0;
+    const StLane S = st_lane(T, t);
+    const int cnt = S.cnt, sk = S.sk, first = S.first;
+    const int n = A.n;
+    int go0 = 0, go1 = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int sw = T[ST_SRC + j];
-        ty[j] = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
-        ix[j] = ty[j] == ST_LOCAL ? ((sw >> 2) & 255) : t;
-        dt[j] = ty[j] == ST_LOCAL ? T[ST_DT + j] : 1;
-        goff[j] = T[ST_OFF + j];
-        gi[j] = 0;
-        if (ty[j] == ST_GHOST) {
-            if (ng == 0) go2[0] = goff[j]; else go2[1] = goff[j];
-            gi[j] = ng < 1 ? 0 : 1;
-            ++ng;
-        }
-    }
-    const bool wave_ghost = __any(ng > 0);
+    for (int j = 0; j < 3; ++j)
+        if (S.isg[j]) { if (S.g1[j]) go1 = T[ST_OFF + j]; else go0 = T[ST_OFF + j]; }
+    const bool wave_ghost = __any(S.ng > 0);
     const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
     const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
               nchw = __builtin_amdgcn_readfirstlane(wt[2]);
@@ -657,127 +725,145 @@ k_sptrsv_st(StSArgs A)
     }
     tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
     if (thi <= tlo) return;
-    const int nsteps = ((thi - tlo + kStD - 1) / kStD) * kStD;
+    tlo &= ~(kStH - 1);
     const bool exports = cnt > 0 && A.exported[slot] != 0;
-    const long ysrc0 = (A.ypk_in && cnt > 0) ? (long)A.ysrc[slot] : 0;
+    const bool wave_exports = __any(exports);
+    double *const mydump = A.dump + slot;                               // a dump place per lane (a shared one would be a hot spot)
+    const int ydump = A.nchY + wg * 4 + wv;                             // ... and a spare chunk per wave
+    const int ysrc0 = (YIN && cnt > 0) ? A.ysrc[slot] : 0;
     const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(A.out);
-    const v2d *pr = A.pk + (size_t)(nchw > 0 ? base : 0) * 128 + ln;
-    double *yo = A.ypk_out ? A.ypk_out + (size_t)base * 64 + ln : nullptr;
+    const unsigned char *pr = reinterpret_cast<const unsigned char *>(A.pk) + (size_t)(nchw > 0 ? base : 0) * 2048;
+    unsigned char *py = reinterpret_cast<unsigned char *>(A.ypk_out);
+    const unsigned lo16 = (unsigned)ln * 16u, lo8 = (unsigned)ln * 8u;
     const int cmax = nchw > 0 ? nchw - 1 : 0;
-    const int n = A.n;
 
-    v2d ra[kStD][2];
-    double rr[kStD];
+    v2d ra[kStH][2];
+    double rr[kStH];
     unsigned long long gq[kStP][2];
 
-#define STS_LOAD(u, tp)                                                                                              \
+#define STS_LOAD(u, tp, kq)                                                                                          \
     do {                                                                                                             \
-        int cw_ = (tp) - tminw; cw_ = cw_ < 0 ? 0 : (cw_ > cmax ? cmax : cw_);                                      \
-        const v2d *q_ = pr + (size_t)cw_ * 128;                                                                      \
-        ra[u][0] = __builtin_nontemporal_load(q_); ra[u][1] = __builtin_nontemporal_load(q_ + 64);                   \
-        const int kq_ = (tp) - sk;                                                                                   \
-        const bool in_ = (unsigned)kq_ < (unsigned)cnt;                                                              \
-        int row_ = first + DR * (in_ ? kq_ : 0); row_ = row_ < 0 ? 0 : (row_ >= n ? n - 1 : row_);                   \
-        rr[u] = A.ypk_in ? A.ypk_in[in_ ? (size_t)(ysrc0 - 64 * (long)kq_) : 0] : A.rhs[row_];                       \
+        const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                              \
+        const unsigned char *q_ = pr + (size_t)cw_ * 2048;                                                           \
+        ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                             \
+        ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                      \
+        const int kc_ = st_med3((kq), 0, cnt > 0 ? cnt - 1 : 0);                                                     \
+        rr[u] = YIN ? A.ypk_in[ysrc0 - 64 * kc_] : A.rhs[st_med3(first + DR * kc_, 0, n - 1)];                        \
     } while (0)
-#define STS_POLL(g, tp)                                                                                              \
+#define STS_POLL(g, kq)                                                                                              \
     do {                                                                                                             \
-        if (wave_ghost) {                                                                                            \
-            const int kq_ = (tp) - sk;                                                                               \
-            const bool in_ = (unsigned)kq_ < (unsigned)cnt;                                                          \
-            const int row_ = first + DR * (in_ ? kq_ : 0);                                                           \
-            _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                                       \
-                if (e_ < ng) {                                                                                       \
-                    int c_ = row_ + go2[e_]; c_ = c_ < 0 ? 0 : (c_ >= n ? n - 1 : c_);                               \
-                    gq[g][e_] = ld_agent_u64(outb + c_);                                                             \
-                }                                                                                                    \
-            }                                                                                                        \
-        }                                                                                                            \
+        const int row_ = first + DR * (kq);                                                                          \
+        if (S.ng > 0) gq[g][0] = ld_agent_u64(outb + st_med3(row_ + go0, 0, n - 1));                                 \
+        if (S.ng > 1) gq[g][1] = ld_agent_u64(outb + st_med3(row_ + go1, 0, n - 1));                                 \
     } while (0)
 
 #pragma unroll
-    for (int g = 0; g < kStP; ++g) {
-        gq[g][0] = kSentinel; gq[g][1] = kSentinel;
-        STS_POLL(g, tlo + g);
+    for (int g = 0; g < kStP; ++g) { gq[g][0] = kSentinel; gq[g][1] = kSentinel; STS_POLL(g, tlo + g - sk); asm volatile("" ::: "memory"); }
+#pragma unroll
+    for (int u = 0; u < kStH; ++u) {
+        STS_LOAD(u, tlo + u, tlo + u - sk);
+        // (the stores of a step, to the dump places: see k_ilu0_st)
+        if (YOUT) __builtin_nontemporal_store(0.0, reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8));
+        else *mydump = 0.0;
         asm volatile("" ::: "memory");
     }
-#pragma unroll
-    for (int u = 0; u < kStD; ++u) { STS_LOAD(u, tlo + u); asm volatile("" ::: "memory"); }
-    double prev = 0.0;
     bool dead = false;
+    ST_T_DECL(wv == 0 && wg == (int)gridDim.x - 1);
 
-    for (int tb = 0; tb < nsteps; tb += kStD) {
+    for (int tb = tlo; tb < thi; tb += kStH) {
+        const int kb = tb - sk;
 #pragma unroll
-        for (int u = 0; u < kStD; ++u) {
-            const int tau = tlo + tb + u;
-            const int k = tau - sk;
+        for (int u = 0; u < kStH; ++u) {
+            const int k = kb + u;
             const bool valid = (unsigned)k < (unsigned)cnt;
             const int r = first + DR * k;
+#ifdef ST_STAMP
+            ++nst_;
+#endif
+            ST_T(0);
             const v2d va = ra[u][0], vb = ra[u][1];
             const double v[3] = {va.x, va.y, vb.x};
-            bool pres[3];
+            bool pj[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) pres[j] = valid && ty[j] != ST_NONE && st_bits(v[j]) != kAbsent;
+            for (int j = 0; j < 3; ++j) pj[j] = valid && st_bits(v[j]) != kAbsent;
+            // (the forward sweep does not divide: the diagonal is used HERE so that its register stays taken until this
+            // step -- a dead quarter of a 16-byte load is a free register to the allocator, and whatever it puts there has
+            // to wait for that load, a load of a later step)
+            if (DR > 0) pj[2] = pj[2] && st_bits(vb.y) != kAbsent;
             ST_BARRIER();
+            ST_T(1);
             double xs[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) xs[j] = XH[((tau - dt[j]) & (kStH - 1)) * kThreads + ix[j]];
+            for (int j = 0; j < 3; ++j) xs[j] = st_lds(xh, S.va[j] + (unsigned)u * (kThreads * 8));
+#ifdef ST_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            ST_T(2);
+            if (wave_ghost) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (ty[j] == ST_OWN) xs[j] = prev;
-                if (ty[j] == ST_GHOST) xs[j] = st_dbl(gi[j] == 0 ? gq[u % kStP][0] : gq[u % kStP][1]);
-            }
-            if (wave_ghost && !dead) {
-                unsigned spins = 0;
-                for (;;) {
-                    bool miss = false;
+                for (int j = 0; j < 3; ++j)
+                    if (S.isg[j]) xs[j] = st_dbl(S.g1[j] ? gq[u % kStP][1] : gq[u % kStP][0]);
+                if (!dead) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool miss = false;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (ty[j] == ST_GHOST && pres[j] && st_bits(xs[j]) == kSentinel) miss = true;
-                    if (!__any(miss)) break;
-                    if (miss) {
+                        for (int j = 0; j < 3; ++j)
+                            if (S.isg[j] && pj[j] && st_bits(xs[j]) == kSentinel) miss = true;
+                        if (!__any(miss)) break;
+                        if (miss) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            if (ty[j] == ST_GHOST && pres[j]) {
-                                int c = r + goff[j]; c = c < 0 ? 0 : (c >= n ? n - 1 : c);
-                                xs[j] = st_dbl(ld_agent_u64(outb + c));
-                            }
+                            for (int j = 0; j < 3; ++j)
+                                if (S.isg[j] && pj[j]) xs[j] = st_dbl(ld_agent_u64(outb + st_med3(r + (S.g1[j] ? go1 : go0), 0, n - 1)));
                         }
-                    }
-                    __builtin_amdgcn_s_waitcnt(0x0F70);      // retired here, not at the join (see k_ilu0_st)
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 255u) == 0) {
-                        if (spins > kStSpinLimit) atomicExch(A.err, 1);
-                        const int e = ld_agent_i32(A.err);
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        if (spins > kStSpinLimit || e != 0) { dead = true; break; }
+                        __builtin_amdgcn_s_waitcnt(0x0F70);      // retired here, not at the join (see k_ilu0_st)
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 255u) == 0) {
+                            if (spins > kStSpinLimit) atomicExch(A.err, 1);
+                            const int e = ld_agent_i32(A.err);
+                            __builtin_amdgcn_s_waitcnt(0x0F70);
+                            if (spins > kStSpinLimit || e != 0) { dead = true; break; }
+                        }
                     }
                 }
             }
-            // sequential accumulation in stored order, division by the diagonal even when it is 1 (a quotient by 1.0 is
-            // the dividend, bit for bit: the L sweep skips the divider)
+            ST_T(3);
+            // sequential accumulation in stored order; the division by a diagonal of 1.0 would return the dividend
             double acc = rr[u];
-            if (pres[0]) { const double p = v[0] * xs[0]; acc = acc - p; }
-            if (pres[1]) { const double p = v[1] * xs[1]; acc = acc - p; }
-            if (pres[2]) { const double p = v[2] * xs[2]; acc = acc - p; }
-            double x = acc;
-            if (__any(valid && vb.y != 1.0)) x = acc / vb.y;
-            if (x != x) x = st_dbl(kCanonNaN);
-            XH[(tau & (kStH - 1)) * kThreads + t] = x;
-            const int cw = tau - tminw;
-            if (yo) {
-                if ((unsigned)cw < (unsigned)nchw) __builtin_nontemporal_store(x, yo + (size_t)cw * 64);
-                if (exports && valid) st_agent_f64(A.out + r, x);
-            } else if (valid) {
-                if (exports) st_agent_f64(A.out + r, x); else A.out[r] = x;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double p = v[j] * xs[j];
+                const double na = acc - p;
+                acc = pj[j] ? na : acc;
             }
-            if (valid) prev = x;
-            STS_LOAD(u, tau + kStD);
-            STS_POLL(u % kStP, tau + kStP);
+            double x = DR > 0 ? acc : acc / vb.y;
+            if (x != x) x = st_dbl(kCanonNaN);
+#ifdef ST_STAMP
+            asm volatile("" :: "v"(x));
+#endif
+            ST_T(4);
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)u * (kThreads * 8)) = x;
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u + kStH) * (kThreads * 8)) = x;
+            // the stream store happens on every step (lanes / waves without a row store to their dump place); unknowns that
+            // other workgroups read: write-through (the one store of a step that hipcc cannot count on)
+            if (YOUT) {
+                const int cw = tb + u - tminw;
+                unsigned char *o = py + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ydump) * 512;
+                __builtin_nontemporal_store(x, reinterpret_cast<double *>(o + lo8));
+            } else {
+                double *o = (valid && !exports) ? A.out + r : mydump;
+                *o = x;
+            }
+            if (wave_exports) { if (exports && valid) st_agent_f64(A.out + r, x); }
+            ST_T(5);
+            STS_LOAD(u, tb + u + kStH, k + kStH);
+            if (wave_ghost) STS_POLL(u % kStP, k + kStP);
+            ST_T(6);
         }
     }
 #undef STS_LOAD
 #undef STS_POLL
+    ST_T_END(DR > 0 ? 10 : 20);
     if (dead && ln == 0) atomicExch(A.err, 1);
 }
 
@@ -786,7 +872,7 @@ k_sptrsv_st(StSArgs A)
 // ---------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ void __launch_bounds__(512)
-k_st_unpack(const int32_t *__restrict__ ptr, double *__restrict__ val, const int32_t *__restrict__ wtab,
+k_st_unpack(const int32_t *__restrict__ ptr, int32_t *__restrict__ idx, double *__restrict__ val, const int32_t *__restrict__ wtab,
             const int32_t *__restrict__ ltab, const v2d *__restrict__ pk)
 {
     constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
@@ -806,10 +892,11 @@ k_st_unpack(const int32_t *__restrict__ ptr, double *__restrict__ val, const int
     const v2d a = p[0], b = p[64];
     const double v[3] = {a.x, a.y, b.x};
     val[FWD ? q1 - 1 : q0] = b.y;
+    idx[FWD ? q1 - 1 : q0] = r;
     int q = FWD ? q0 : q0 + 1;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-        if (st_bits(v[j]) != kAbsent && q < (FWD ? q1 - 1 : q1)) val[q++] = v[j];
+        if (st_bits(v[j]) != kAbsent && q < (FWD ? q1 - 1 : q1)) { val[q] = v[j]; idx[q] = r + T[ST_OFF + j]; ++q; }
 }
 
 void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps)
@@ -817,10 +904,10 @@ void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const Packe
     (void)sch;
     const dim3 grid((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 7) / 8));
     if ((SweepKind)ps.kind == SWEEP_FWD_LAST_ASC)
-        hipLaunchKernelGGL((k_st_unpack<SWEEP_FWD_LAST_ASC>), grid, dim3(512), 0, st, M.ptr, M.val, ps.wtab, ps.ltab,
+        hipLaunchKernelGGL((k_st_unpack<SWEEP_FWD_LAST_ASC>), grid, dim3(512), 0, st, M.ptr, M.idx, M.val, ps.wtab, ps.ltab,
                            reinterpret_cast<const v2d *>(ps.pk));
     else
-        hipLaunchKernelGGL((k_st_unpack<SWEEP_BWD_FIRST_ASC>), grid, dim3(512), 0, st, M.ptr, M.val, ps.wtab, ps.ltab,
+        hipLaunchKernelGGL((k_st_unpack<SWEEP_BWD_FIRST_ASC>), grid, dim3(512), 0, st, M.ptr, M.idx, M.val, ps.wtab, ps.ltab,
                            reinterpret_cast<const v2d *>(ps.pk));
     ILUPP_HIP(hipGetLastError());
 }
@@ -840,12 +927,12 @@ __global__ void k_st_xbase(int32_t nslots, const int32_t *__restrict__ exported,
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
     const int b = xbase[s];
-    if (s == nslots - 1) *xcount = ((long long)b + (exported[s] ? scount[s] : 0)) * 4;
+    if (s == nslots - 1) *xcount = (long long)b + (exported[s] ? scount[s] : 0);
     if (!exported[s]) xbase[s] = -1;
 }
 __global__ void k_st_fill(unsigned long long *__restrict__ p, const long long *__restrict__ count, unsigned long long v)
 {
-    const long long n = *count;
+    const long long n = *count + 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
 
@@ -857,7 +944,16 @@ static void st_structure(hipStream_t st, const Schedule &sch, PackedSweep *ps, i
     ILUPP_HIP(pool_malloc(&ps->skew, sizeof(int32_t) * (size_t)sch.nslots));
     ILUPP_HIP(pool_malloc(&ps->wtab, sizeof(int32_t) * 16 * (size_t)ps->nwg));
     ILUPP_HIP(pool_malloc(&ps->flags, 64));
+    ILUPP_HIP(pool_malloc(&ps->dump, sizeof(double) * (size_t)sch.nslots));
     ILUPP_HIP(hipMemsetAsync(ps->flags, 0, 64, st));
+}
+
+static void st_pack_values(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, FactorLM *f)
+{
+    hipLaunchKernelGGL(k_st_prefill, dim3(2048), dim3(256), 0, st, (int64_t)pl->nchunks, reinterpret_cast<v2d *>(f->pkA));
+    const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));        // every lane has at most max_chunks rows
+    hipLaunchKernelGGL(k_st_rows, grid, dim3(512), 0, st, A.ptr, A.idx, A.val, (int64_t)A.nnz, f->xbase + pl->nwg * kThreads,
+                       pl->wtab, reinterpret_cast<v2d *>(f->pkA), reinterpret_cast<v2d *>(pu->pk), pl->flags);
 }
 
 // The whole static analysis of an ILU(0): true when the factor kernel and both sweeps can run from lane tables
@@ -871,6 +967,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
     if (off || A.nnz > 7 * (int64_t)A.n || A.nnz < 16 || fwd.nslots < kThreads || fwd.nslots != bwd.nslots || !A.val) return false;
     const int nwg = fwd.nslots / kThreads;
+    const int nslots = fwd.nslots;
     st_structure(st, fwd, pl, (int)SWEEP_FWD_LAST_ASC);
     st_structure(st, bwd, pu, (int)SWEEP_BWD_FIRST_ASC);
     hipLaunchKernelGGL((k_st_template<1>), dim3((unsigned)nwg), dim3(kThreads), 0, st, A.ptr, A.idx, fwd.B, fwd.nb, fwd.start,
@@ -885,35 +982,18 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
                        static_cast<const int32_t *>(nullptr), pu->skew, pu->wtab, pu->flags);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pu->wtab, pu->flags);
-    int32_t hl[4], hu[4];
-    ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
-    ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
-    ILUPP_HIP(stream_sync(st));
-    const int64_t lim = 2 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;
-    if (hl[0] || hu[0] || hu[3] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim) {
-        if (dbg) fprintf(stderr, "[ilupp] static analysis: structure rejected (flags %d %d link %d, %d %d chunks)\n", hl[0], hu[0], hu[3], hl[1], hu[1]);
-        pl->release(); pu->release();
-        return false;
-    }
-    pl->nchunks = hl[1]; pl->max_chunks = hl[2];
-    pu->nchunks = hu[1]; pu->max_chunks = hu[2];
-    ILUPP_HIP(pool_malloc(&pl->pk, (size_t)pl->nchunks * 2048));
-    ILUPP_HIP(pool_malloc(&pu->pk, (size_t)pu->nchunks * 2048));
-    ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
-    pl->built = true;
-    {
-        const dim3 grid((unsigned)(nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));        // every lane has at most max_chunks rows
-        hipLaunchKernelGGL((k_st_rows<1>), grid, dim3(512), 0, st, A.ptr, A.idx, A.val, (int64_t)A.nnz, pl->ltab, pu->ltab, pu->uslot,
-                           pl->wtab, fwd.start, bwd.start, reinterpret_cast<v4i *>(f->pkA), pl->flags);
-    }
-    lm_link_y(st, fwd, pl, pu);
-    // exchange rows of the forward lanes that other workgroups read
-    const int nslots = fwd.nslots;
-    ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots));
+    int32_t *inv = nullptr;
+    ILUPP_HIP(pool_malloc(&inv, sizeof(int32_t) * (size_t)nslots));
+    ILUPP_HIP(hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)nslots, st));
+    const unsigned gb = (unsigned)((nslots + 255) / 256);
+    hipLaunchKernelGGL(k_st_inv, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv);
+    // exchange rows (one pivot each) of the forward lanes that other workgroups read; behind them the rows pass' lane records
+    ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots * 33));
+    hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
+                       f->xbase + nslots, pl->flags);
     ILUPP_HIP(pool_malloc(&f->xcount, 64));
     int32_t *rows = nullptr;
     ILUPP_HIP(pool_malloc(&rows, sizeof(int32_t) * (size_t)nslots));
-    const unsigned gb = (unsigned)((nslots + 255) / 256);
     hipLaunchKernelGGL(k_st_xrows, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, rows);
     size_t tb = 0;
     ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rows, f->xbase, nslots, st));
@@ -921,12 +1001,35 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&tmp, tb));
     ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, rows, f->xbase, nslots, st));
     hipLaunchKernelGGL(k_st_xbase, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, f->xbase, f->xcount);
-    ILUPP_HIP(pool_malloc(&f->xch, sizeof(double) * 4 * (size_t)A.n + 64));
+    int32_t hl[4], hu[4];
+    ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
+    ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(rows)); ILUPP_HIP(pool_free(tmp));
+    const int64_t lim = 2 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;
+    if (hl[0] || hu[0] || hu[3] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim ||
+        hl[1] + 4 * nwg >= kStMaxChunks || hu[1] + 4 * nwg >= kStMaxChunks) {
+        if (dbg) fprintf(stderr, "[ilupp] static analysis: structure rejected (flags %d %d link %d, %d %d chunks)\n", hl[0], hu[0], hu[3], hl[1], hu[1]);
+        pl->release(); pu->release(); f->release();
+        return false;
+    }
+    pl->nchunks = hl[1]; pl->max_chunks = hl[2];
+    pu->nchunks = hu[1]; pu->max_chunks = hu[2];
+    // one spare chunk per wave each: where waves / lanes without a row at a step store
+    ILUPP_HIP(pool_malloc(&pl->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));
+    ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pu->nchunks + 4 * nwg) * 2048));
+    ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
+    ILUPP_HIP(pool_malloc(&f->xch, sizeof(double) * ((size_t)A.n + 16)));
+    pl->built = true;
+    st_pack_values(st, A, pl, pu, f);
+    // the intermediate vector of an apply travels level-major from the L sweep to the U sweep
+    ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
+    ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
+    ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)nslots, st));
+    hipLaunchKernelGGL(k_lm_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
     int32_t gl[4];
     ILUPP_HIP(d2h_async(st, gl, pl->flags, sizeof(gl)));
     ILUPP_HIP(stream_sync(st));
-    ILUPP_HIP(pool_free(rows));
-    ILUPP_HIP(pool_free(tmp));
     if (dbg) fprintf(stderr, "[ilupp] static analysis: row flags %d, %d+%d chunks\n", gl[0], hl[1], hu[1]);
     if (gl[0]) { pl->release(); pu->release(); f->release(); return false; }
     pl->valid = pu->valid = true;
@@ -941,35 +1044,33 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
 int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, FactorLM *f,
                     int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1)
 {
+    (void)fwd;
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
-    hipLaunchKernelGGL(k_st_fill, dim3(512), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
+    hipLaunchKernelGGL(k_st_fill, dim3(256), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
                        reinterpret_cast<const long long *>(f->xcount), kSentinel);
-    if (!f->values_packed) {
-        const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
-        hipLaunchKernelGGL((k_st_rows<2>), grid, dim3(512), 0, st, A.ptr, A.idx, A.val, (int64_t)A.nnz, pl->ltab, pu->ltab, pu->uslot,
-                           pl->wtab, fwd.start, fwd.start, reinterpret_cast<v4i *>(f->pkA), pl->flags);
+    const bool repack = !f->values_packed;
+    if (repack) {
+        // new values on the same pattern: the rows pass once more (it re-proves what it relies on)
+        ILUPP_HIP(hipMemsetAsync(pl->flags, 0, 4, st));
+        st_pack_values(st, A, pl, pu, f);
     }
     f->values_packed = false;
     StFArgs a;
     a.ltab = pl->ltab; a.wtab = pl->wtab;
     a.pkA = reinterpret_cast<const v2d *>(f->pkA);
     a.pkL = reinterpret_cast<v2d *>(pl->pk); a.pkU = reinterpret_cast<v2d *>(pu->pk);
-    a.wtabU = pu->wtab; a.skewU = pu->skew; a.uslot = pu->uslot;
+    a.nchL = (int32_t)pl->nchunks; a.nchU = (int32_t)pu->nchunks;
     a.xbase = f->xbase; a.xcount = f->xcount; a.xch = f->xch; a.ctrl = d_ctrl;
     ILUPP_HIP(hipEventRecord(e0, st));
-    static std::once_flag once[16];
-    int dev = 0;
-    ILUPP_HIP(hipGetDevice(&dev));
-    std::call_once(once[dev & 15], [] {
-        ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStFLds));
-    });
-    hipLaunchKernelGGL(k_ilu0_st, dim3((unsigned)pl->nwg), dim3(kThreads), kStFLds, st, a);
+    hipLaunchKernelGGL(k_ilu0_st, dim3((unsigned)pl->nwg), dim3(kThreads), 0, st, a);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
-    int32_t ctrl[4];
+    int32_t ctrl[4], fl[4] = {0, 0, 0, 0};
     ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, 16));
+    if (repack) ILUPP_HIP(d2h_async(st, fl, pl->flags, 16));
     ILUPP_HIP(stream_sync(st));
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    if (fl[0] != 0) { set_error("ILU0: the matrix handed to the numeric re-factorisation does not have the analysed pattern"); return ILUPP_ERR_INVALID; }
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
     return ILUPP_OK;
 }
@@ -978,14 +1079,31 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
     StSArgs a;
-    a.pk = reinterpret_cast<const v2d *>(ps.pk); a.ltab = ps.ltab; a.wtab = ps.wtab; a.n = n; a.rhs = rhs; a.out = out;
+    a.pk = reinterpret_cast<const v2d *>(ps.pk); a.ltab = ps.ltab; a.wtab = ps.wtab; a.n = n; a.nchY = (int32_t)ps.nchunks;
+    a.rhs = rhs; a.out = out; a.dump = ps.dump;
     a.exported = sch.exported; a.ypk_out = ypk_out; a.ypk_in = ypk_in; a.ysrc = ysrc; a.ticket = d_ticket; a.err = d_err;
-    if (ps.kind == (int)SWEEP_FWD_LAST_ASC)
-        hipLaunchKernelGGL((k_sptrsv_st<1>), dim3((unsigned)ps.nwg), dim3(kThreads), 0, st, a);
-    else
-        hipLaunchKernelGGL((k_sptrsv_st<-1>), dim3((unsigned)ps.nwg), dim3(kThreads), 0, st, a);
+    const dim3 grid((unsigned)ps.nwg), block(kThreads);
+    if (ps.kind == (int)SWEEP_FWD_LAST_ASC) {
+        if (ypk_out) hipLaunchKernelGGL((k_sptrsv_st<1, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_sptrsv_st<1, false, false>), grid, block, 0, st, a);
+    } else {
+        if (ypk_in) hipLaunchKernelGGL((k_sptrsv_st<-1, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_sptrsv_st<-1, false, false>), grid, block, 0, st, a);
+    }
     ILUPP_HIP(hipGetLastError());
     return ILUPP_OK;
 }
 
+#ifdef ST_STAMP
+void st_read_stamps(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_stamp), sizeof(unsigned long long) * 32)); }
+#endif
+
 }  // namespace ilupp
+
+#ifdef ST_STAMP
+extern "C" int ilupp_hip_debug_stamps(unsigned long long *out)
+{
+    try { ilupp::st_read_stamps(out); } catch (...) { return -1; }
+    return 0;
+}
+#endif

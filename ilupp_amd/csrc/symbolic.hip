@@ -386,6 +386,18 @@ void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U)
                        L->ptr, U->ptr, L->idx, U->idx);
 }
 
+// only the row pointers of U (the static level-major path writes the column indices of L and U together with their
+// values, from its records, when somebody asks for the factors)
+__global__ void k_ilu0_uptr(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ Lptr, int32_t *__restrict__ Uptr)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n) Uptr[r] = ptr[r] - (Lptr[r] - r);
+}
+void ilu0_write_uptr(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U)
+{
+    hipLaunchKernelGGL(k_ilu0_uptr, dim3((unsigned)((A.n + 256) / 256)), dim3(256), 0, st, A.n, A.ptr, L->ptr, U->ptr);
+}
+
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len)
 {
