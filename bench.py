@@ -5,20 +5,28 @@ Metric: ILU(0) factor + one L/U apply on the 3-D 7-point Poisson 256^3 CSR matri
 int32 indices), reported as nnz(A)/s, with the achieved fraction of the HBM roofline for the
 dominant kernel and the reference's own CPU path timed beside it.
 
-A "step" = one complete ILU(0) factorisation of the device-resident CSR matrix (symbolic pattern
-split + row scheduling + numeric factorisation) followed by one apply() on a device-resident
-vector, i.e. exactly what `P = ilupp.ILU0Preconditioner(A); P.apply(x)` does, with A and x already
-in HBM when the timed region starts.
+A "step" = one complete ILU(0) factorisation of the device-resident CSR matrix (pattern analysis
++ row scheduling + numeric factorisation) followed by one apply() on a device-resident vector,
+i.e. exactly what `P = ilupp.ILU0Preconditioner(A); P.apply(x)` does, with A and x already in HBM
+when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu] [--config C2|C3|C4]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the path does not shard (a single
-factorisation is one dependency chain), so every rank factors its own matrix of the batch
-(weak scaling, no data-path collective; RCCL only for the barrier / max-over-ranks timing).
+N > 1: the path does not shard (a single factorisation is one dependency chain), so every rank
+factors its own matrix of a batch (weak scaling, no data-path collective; RCCL only for the barrier,
+the max-over-ranks time and one gather of per-matrix records).  Launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU);
+run without a launcher, `--gpus N` starts that launcher itself -- before anything touches the GPU.
+
+--config C3 / C4 add the other BASELINE configs as extra keys of the same JSON line ("extra"):
+ILUT(10, 1e-4) on the random diagonally dominant matrix with n = 1e6, ICholT(0, 0) on the 256^3 matrix
+(bytes = read A + write the factors actually produced).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,6 +38,10 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+# kernel that dominates the numeric factorisation, per construction path (ilupp_hip_path)
+FACTOR_KERNEL = {"ilu0:static-level-major": "k_ilu0_st", "ilu0:level-major": "k_ilu0_lm",
+                 "ilu0:csr-program": "k_ilu0_numeric_lc", "ilu0:csr": "k_ilu0_numeric"}
 
 
 def algorithmic_bytes(n, nnz):
@@ -47,20 +59,19 @@ def measured_traffic(kernel, g):
     import glob
     if g != 256:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["kernels"]["ilupp::" + kernel]
-        return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")), reverse=True):
+        try:
+            k = json.load(open(f))["kernels"]["ilupp::" + kernel]
+            return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(g, want_ref=True):
-    """The reference's own C++ path (oracle/_ref, kind "reference") or the plain-C restatement
-    (kind "port") on ONE host core (the reference is single-threaded): ILU(0) factor + one apply on the
-    same workload shape.  Bounded: one pass over the workload (about 10-15 s at 256^3)."""
+    """The reference's own C++ path (oracle/_ref, kind "reference") or the plain-C restatement (kind "port") on
+    ONE host core (the reference is single-threaded): ILU(0) factor + one apply (the two triangular solves, no
+    copies) on the same workload.  Bounded: one pass over the workload.  Returns the record and apply(ones)."""
     import matgen
     from oracle import oracle as O
     kind = "reference" if (want_ref and O.ref_available()) else "port"
@@ -70,17 +81,84 @@ def cpu_baseline(g, want_ref=True):
     t0 = time.perf_counter()
     L, U = lib.ilu0((d, i, p, True))
     t1 = time.perf_counter()
-    x = lib.apply_lu(L, U, np.ones(n), O.ID)
+    # preconditioner_implementation.h:321-334: L.triangular_solve(LOWER) then U.triangular_solve(UPPER), in place
+    x = np.ones(n)
+    x = lib.trisolve(L, O.LOWER, O.ID, x)
+    x = lib.trisolve(U, O.UPPER, O.ID, x)
     t2 = time.perf_counter()
+    x2 = lib.apply_lu(L, U, np.ones(n), O.ID)          # through the preconditioner object: copies L and U first
+    t3 = time.perf_counter()
     try:
         cpu = open("/proc/cpuinfo").read().split("model name")[1].split(":")[1].split("\n")[0].strip()
     except Exception:
         cpu = "unknown"
-    return {"value": nnz / (t2 - t0), "unit": "nnz/s", "cores": 1, "kind": kind,
-            "sample": "the full workload once: 3-D 7-pt Poisson %d^3 (n=%d, nnz=%d); factor %.3f s + apply %.3f s "
-                      "through the C-ABI wrapper (includes copying L/U out and in); host CPU: %s, %d cores present"
-                      % (g, n, nnz, t1 - t0, t2 - t1, cpu, os.cpu_count() or 0),
-            "factor_s": t1 - t0, "apply_s": t2 - t1, "checksum": float(np.sum(x))}
+    rec = {"value": nnz / (t2 - t0), "unit": "nnz/s", "cores": 1, "kind": kind,
+           "sample": "the full workload once: 3-D 7-pt Poisson %d^3 (n=%d, nnz=%d); factor %.3f s + apply %.3f s (two "
+                     "triangular solves in place); host CPU: %s, %d cores present" % (g, n, nnz, t1 - t0, t2 - t1, cpu, os.cpu_count() or 0),
+           "factor_s": t1 - t0, "apply_s": t2 - t1, "apply_with_copies_s": t3 - t2,
+           "checksum": float(np.sum(x)), "apply_paths_agree": bool(np.array_equal(x, x2))}
+    return rec, x
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start `torch.distributed.run` as a child (nothing here has touched the GPU)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def batch_matrix(g, member):
+    """matrix `member` of the batch: the 7-point matrix with its diagonal shifted by 0.01 * member"""
+    import matgen
+    d, i, p = matgen.poisson3d(g)
+    if member:
+        d = d + np.where(d > 0, 0.01 * member, 0.0)
+    return d, i, p
+
+
+def extra_config(name, dev, steps):
+    """C3 / C4 on device-resident inputs: seconds, factor bytes (read A + write the factors produced), GB/s"""
+    import torch
+    import matgen
+    from ilupp_amd import _native
+    if name == "C3":
+        d, i, p = matgen.random_dd(1000000, 19, 25.0, 12345)
+        make = lambda a: _native.ILUTPreconditioner_device(*a, True, 10, 1e-4)
+        what = "C3: ILUTPreconditioner(fill_in=10, threshold=1e-4), random diagonally dominant CSR n=1e6"
+    else:
+        d, i, p = matgen.poisson3d(256)
+        make = lambda a: _native.ICholTPreconditioner_device(*a, True, 0, 0.0)
+        what = "C4: ICholTPreconditioner(add_fill_in=0, threshold=0), 3-D 7-point Laplacian 256^3"
+    n, nnz = p.shape[0] - 1, int(p[-1])
+    td, ti, tp = (torch.from_numpy(a).to(dev) for a in (d, i, p))
+    x = torch.ones(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    args = (td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n)
+    walls, kms, apps = [], [], []
+    nnz_out = 0
+    for rep in range(max(2, steps)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        P = make(args)
+        t1 = time.perf_counter()
+        P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+        t = P.timings()
+        nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
+        if rep:
+            walls.append(t1 - t0); kms.append(t["numeric_kernel_ms"]); apps.append(t["last_apply_ms"])
+        x.fill_(1.0)
+        P = None
+    nf = 2 if name == "C3" else 1
+    fbytes = (12 * nnz + 4 * (n + 1)) + (12 * nnz_out + 4 * (n + 1) * nf)
+    sec = float(np.median(walls))
+    return {"workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
+            "numeric_kernel_ms": float(np.median(kms)), "apply_ms": float(np.median(apps)),
+            "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
+            "hbm_fraction": fbytes / sec / 1e9 / HBM_PEAK_GBS}
 
 
 def main():
@@ -92,15 +170,23 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4"],
+                    help="extra BASELINE configs measured after the headline one (C2 is always the bench line)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import matgen
     from ilupp_amd import _native
+    from ilupp_amd.batched import run_batch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -114,10 +200,8 @@ def main():
     assert rc == 0
 
     g = args.grid
-    d, i, p = matgen.poisson3d(g)
-    # batched case: rank r factors its own matrix of the batch (distinct diagonal shift)
-    if world > 1:
-        d = d + np.where(d > 0, 0.01 * rank, 0.0)
+    # batched case: rank r factors matrix r of the batch
+    d, i, p = batch_matrix(g, rank if world > 1 else 0)
     n, nnz = p.shape[0] - 1, int(p[-1])
     td = torch.from_numpy(d).to(dev)
     ti = torch.from_numpy(i).to(dev)
@@ -135,12 +219,11 @@ def main():
 
     P = None
     fac_ms, num_ms, ana_ms, app_ms, ls_ms, us_ms, knum_ms = [], [], [], [], [], [], []
-
     nstep = 0
 
     def step(record):
         nonlocal P, nstep
-        P = None      # release the previous factorisation first (its buffers go back to the HIP allocator)
+        P = None      # release the previous factorisation first (its buffers go back to the allocator)
         P = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True)
         tx = txs[nstep % nrhs]
         nstep += 1
@@ -159,12 +242,14 @@ def main():
         step(True)
     barrier()
     wall = time.perf_counter() - t0
-    # checksum of apply(ones) with the last factorisation (untimed; compared with the CPU baseline's)
+    path = P.path()
+    # apply(ones) with the last factorisation (untimed): compared, as an array, with the CPU leg's
     tx = txs[0]
     tx.fill_(1.0)
     torch.cuda.synchronize()
     P.apply_device(tx.data_ptr(), n, transpose=False, sync=True)
-    checksum = float(tx.sum().item())
+    x_gpu = tx.cpu().numpy()
+    checksum = float(x_gpu.sum())
 
     # what this box's HBM gives a plain device-to-device copy (read + written bytes), next to the 8 TB/s spec peak
     copy_gbs = None
@@ -189,12 +274,36 @@ def main():
     wall = float(wall_t.item())
     ms_per_step = 1e3 * wall / args.steps
 
+    # the batch through the driver of the N > 1 path (ilupp_amd/batched.py): one record per matrix, gathered on
+    # every rank; rank 0 then factors every matrix itself and demands byte-identical outputs
+    batch = None
+    if world > 1:
+        def work(member):
+            dm, im, pm = batch_matrix(g, member)
+            a = [torch.from_numpy(v).to(dev) for v in (dm, im, pm)]
+            xb = torch.ones(n, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Pm = _native.ILU0Preconditioner_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), n, True)
+            Pm.apply_device(xb.data_ptr(), n, transpose=False, sync=True)
+            ms = 1e3 * (time.perf_counter() - t0)
+            nl, nu = (f[0].shape[0] for f in Pm.factors_info()) if g <= 64 else (0, 0)
+            return (member, int(nl), int(nu), int(Pm.total_nnz), hashlib.sha256(xb.cpu().numpy().tobytes()).hexdigest(), ms)
+        recs = run_batch(world, work)
+        if rank == 0:
+            solo = [work(m) for m in range(world)]
+            same = all(a[:5] == b[:5] for a, b in zip(recs, solo))
+            batch = {"records": [{"matrix": r[0], "total_nnz": r[3], "sha256_apply": r[4][:16], "ms": r[5]} for r in recs],
+                     "identical_to_single_rank": bool(same)}
+            assert same, "batched outputs differ from the single-rank run"
+
     if rank == 0:
         fb, ab = algorithmic_bytes(n, nnz)
         med = lambda v: float(np.median(v)) if v else 0.0
         k_num = med(knum_ms)         # numeric factor kernel alone (HIP events on the library's stream)
         gpu_ms = med(fac_ms) + med(app_ms)
         reuse_ms = med(num_ms) + med(app_ms)
+        kernel = FACTOR_KERNEL.get(path, path)
         # dominant kernel = the numeric factorisation sweep; its algorithmic bytes = the factor bytes of
         # read A once + write L and U once
         out = {
@@ -211,7 +320,8 @@ def main():
             "config": {"workload": "C2: ILU(0) factor + one L/U apply, 3-D 7-point Poisson %d^3 CSR (n=%d, nnz=%d), fp64/int32" % (g, n, nnz),
                        "parallelism": "1 matrix per GPU, no data-path collective" if world > 1 else "single GPU",
                        "step": "full ILU0Preconditioner construction (pattern analysis + row scheduling + numeric factorisation) "
-                               "+ one apply, A and x resident in HBM; wall clock over all steps"},
+                               "+ one apply, A and x resident in HBM; wall clock over all steps",
+                       "path": path},
             "gpu_ms": {"analysis": med(ana_ms), "numeric": med(num_ms), "factor": med(fac_ms), "apply": med(app_ms),
                        "lsolve": med(ls_ms), "usolve": med(us_ms), "factor_plus_apply": gpu_ms,
                        "numeric_kernel": k_num},
@@ -219,21 +329,38 @@ def main():
             "pattern_reuse_value_nnz_per_s": nnz / (reuse_ms * 1e-3) if reuse_ms > 0 else None,
             "hbm_fraction_factor_plus_apply": ((fb + ab) / (gpu_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gpu_ms > 0 else None,
             "hbm_fraction_pattern_reuse": ((fb + ab) / (reuse_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if reuse_ms > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "k_ilu0_lm",
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": (fb / (k_num * 1e-3) / 1e9) if k_num > 0 else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (fb / (k_num * 1e-3) / 1e9) / HBM_PEAK_GBS if k_num > 0 else None,
-                         "traffic": measured_traffic("k_ilu0_lm", g),
+                         "traffic": measured_traffic(kernel, g),
                          "algorithmic_bytes_per_launch": fb,
                          "avg_launch_ms": k_num,
                          "copy_GBs_measured": copy_gbs,
                          "frac_of_measured_copy": ((fb / (k_num * 1e-3) / 1e9) / copy_gbs) if (k_num > 0 and copy_gbs) else None},
             "checksum": checksum,
         }
+        if batch is not None:
+            out["batch"] = batch
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_grid or g)
+            cg = args.cpu_grid or g
+            rec, x_cpu = cpu_baseline(cg)
+            out["cpu_baseline"] = rec
+            if cg == g:
+                # bit-for-bit: the kernels follow the reference's operation order without FMA contraction
+                out["parity"] = {"apply_ones_equal": bool(np.array_equal(x_gpu, x_cpu, equal_nan=True)),
+                                 "max_rel_diff": float(np.max(np.abs(x_gpu - x_cpu) / np.maximum(np.abs(x_cpu), 1e-300)))}
+                assert out["parity"]["max_rel_diff"] <= 1e-12, "GPU apply(ones) differs from the CPU baseline"
         else:
             out["cpu_baseline"] = None
+        extra = {}
+        for cfg in args.config:
+            if cfg in ("C3", "C4") and world == 1:
+                del_txs = txs[:]        # free the headline workload first
+                txs.clear(); del del_txs
+                extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

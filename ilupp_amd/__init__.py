@@ -1,87 +1,91 @@
-"""ilupp_amd -- MI355X-native incomplete LU / incomplete Cholesky preconditioners.
+"""ilupp_amd -- incomplete LU / incomplete Cholesky preconditioners on MI355X.
 
-Drop-in for the hot path of c-f-h/ilupp: the same Python surface as the reference's
-``ilupp/__init__.py`` (class names, argument names and defaults, LinearOperator protocol,
-``apply``/``apply_trans`` in place, ``factors()``, ``total_nnz``, ``repr``, exception types), with the
-factorisation and the L/U triangular solves running as hand-written HIP kernels on the GPU through
-the C ABI in ``include/ilupp_hip.h``.  There is no CPU fallback.
+A drop-in for the hot path of c-f-h/ilupp behind that package's Python surface: the preconditioner classes are
+scipy ``LinearOperator``s built from a square scipy CSR/CSC matrix, ``P @ x`` / ``P.T @ x`` / in-place
+``apply`` / ``apply_trans`` run the triangular solves, ``factors()`` hands the factors back as scipy matrices.
+What the reference does in C++ on one core (src/ilupp via src/binding.cpp) runs here as hand-written HIP kernels
+through the C ABI of ``include/ilupp_hip.h``; there is no CPU fallback.
 
     import ilupp_amd as ilupp
-    P = ilupp.ILU0Preconditioner(A)          # scipy CSR/CSC in
-    y = P @ x                                # or P.apply(x) in place, P.T @ x
+    P = ilupp.ILU0Preconditioner(A)
+    y = P @ x
+
+Observable behaviour kept from the reference (ilupp/__init__.py): class and function names, argument names and
+defaults, ``A.sort_indices()`` on the caller's matrix, exception types, ``total_nnz`` conventions, ``repr``.
 """
+import collections
+
 import numpy as np
-import scipy.sparse
-import scipy.sparse.linalg
+import scipy.sparse as _sp
+from scipy.sparse.linalg import LinearOperator as _LinearOperator
 
-from . import _native as _ilupp
+from . import _native
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
-_index_size = _ilupp.index_size()        # 4: int32 build (reference default, declarations.h:49-53)
-if _index_size == 4:
-    _index_dtype = np.dtype(np.int32)
-elif _index_size == 8:
-    _index_dtype = np.dtype(np.int64)
-else:
-    raise RuntimeError('invalid index type size %d' % _index_size)
+# index width of the compiled engine (the reference's `Integer`; binding.cpp:279)
+_INDEX_DTYPES = {4: np.dtype(np.int32), 8: np.dtype(np.int64)}
+try:
+    _INDEX = _INDEX_DTYPES[_native.index_size()]
+except KeyError:
+    raise RuntimeError("invalid index type size %d" % _native.index_size())
 
-
-def _upcast_indices(idx):
-    """Same contract as the reference (ilupp/__init__.py:38-53): smaller ints are widened, larger
-    ones are refused rather than silently truncated."""
-    sz, target_sz = idx.dtype.itemsize, _index_size
-    if sz == target_sz:
-        return idx
-    elif sz < target_sz:
-        return idx.astype(_index_dtype)
-    else:
-        raise TypeError(
-            'Index array has %d bytes per index, but the library '
-            'is compiled for %d bytes per index. Downcasting might '
-            'lead to integer overflow. Please compile ilupp with a '
-            'larger index type if you need to use very large matrices.'
-            % (sz, target_sz))
+_Borrowed = collections.namedtuple("_Borrowed", "data indices indptr is_csr")
 
 
-def _matrix_fields(A):
-    """(data, indices, indptr, is_csr) of a square scipy CSR/CSC matrix; sorts A's indices IN PLACE
-    exactly like the reference does (ilupp/__init__.py:55-71)."""
-    if isinstance(A, scipy.sparse.csr_matrix):
-        is_csr = True
-    elif isinstance(A, scipy.sparse.csc_matrix):
-        is_csr = False
+def _engine_indices(a):
+    """an index array in the engine's width: narrower ones are widened, wider ones refused (never truncated)"""
+    if a.dtype.itemsize > _INDEX.itemsize:
+        raise TypeError("the matrix uses %d-byte indices but this build of the engine works with %d-byte ones; "
+                        "narrowing them could overflow" % (a.dtype.itemsize, _INDEX.itemsize))
+    return a if a.dtype.itemsize == _INDEX.itemsize else a.astype(_INDEX)
+
+
+def _borrow(A):
+    """the buffers of a square CSR/CSC matrix as the engine wants them; sorts A's indices in place like the reference"""
+    if isinstance(A, _sp.csr_matrix):
+        row_major = True
+    elif isinstance(A, _sp.csc_matrix):
+        row_major = False
     else:
         raise TypeError("A must be a csr_matrix or a csc_matrix")
-    if A.shape[0] != A.shape[1]:
+    rows, cols = A.shape
+    if rows != cols:
         raise ValueError("A must be a square matrix!")
     A.sort_indices()
-    return A.data, _upcast_indices(A.indices), _upcast_indices(A.indptr), is_csr
+    return _Borrowed(A.data, _engine_indices(A.indices), _engine_indices(A.indptr), row_major)
 
 
-def _matrix_from_info(data, indices, indptr, is_csr, rows, cols):
-    """ilupp/__init__.py:73-82"""
-    if is_csr:
-        A = scipy.sparse.csr_matrix((data, indices, indptr), shape=(rows, cols), copy=False)
-    else:
-        A = scipy.sparse.csc_matrix((data, indices, indptr), shape=(rows, cols), copy=False)
-    A.has_sorted_indices = True
-    return A
+def _as_scipy(info):
+    """one entry of factors_info() -> scipy matrix sharing the arrays"""
+    data, indices, indptr, row_major, rows, cols = info
+    kind = _sp.csr_matrix if row_major else _sp.csc_matrix
+    M = kind((data, indices, indptr), shape=(rows, cols), copy=False)
+    M.has_sorted_indices = True
+    return M
 
 
-class _BaseWrapper(scipy.sparse.linalg.LinearOperator):
-    """Members common to all preconditioners (reference: ilupp/__init__.py:122-168)."""
+class _HipPreconditioner(_LinearOperator):
+    """A factorisation held in HBM, seen as a linear operator.  `pr` is the native object (the role of the
+    reference's pybind11 preconditioner objects)."""
+
+    def __init__(self, A, make):
+        self.pr = make(_borrow(A))
+        super().__init__(dtype=A.dtype, shape=A.shape)
+
+    # -- LinearOperator protocol: out-of-place, so that P @ x, P.dot(x), P.T @ x and scipy's solvers work
+    def _solve_copy(self, x, solve):
+        y = np.array(x, copy=True).ravel()
+        solve(y)
+        return y
 
     def _matvec(self, x):
-        y = x.copy().ravel()
-        self.pr.apply(y)
-        return y
+        return self._solve_copy(x, self.pr.apply)
 
     def _rmatvec(self, x):
-        y = x.copy().ravel()
-        self.pr.apply_trans(y)
-        return y
+        return self._solve_copy(x, self.pr.apply_trans)
 
+    # -- the reference's in-place members
     def apply(self, x):
         """Apply the preconditioner to the vector `x` in-place."""
         self.pr.apply(x.ravel())
@@ -96,71 +100,59 @@ class _BaseWrapper(scipy.sparse.linalg.LinearOperator):
         return self.pr.total_nnz
 
     def factors(self):
-        """Return all matrix factors (usually (L,U) or just (L,)) as a list of sparse matrices."""
-        return [_matrix_from_info(*info) for info in self.pr.factors_info()]
+        """All matrix factors ((L, U) or just (L,)) as a list of sparse matrices."""
+        return [_as_scipy(f) for f in self.pr.factors_info()]
 
     def __repr__(self):
-        M, N = self.shape
-        if self.dtype is None:
-            dt = 'unspecified dtype'
-        else:
-            dt = 'dtype=' + str(self.dtype)
-        return '<%dx%d %s with nnz=%d, %s>' % (M, N, self.__class__.__name__, self.total_nnz, dt)
+        rows, cols = self.shape
+        what = "unspecified dtype" if self.dtype is None else "dtype=%s" % (self.dtype,)
+        return "<%dx%d %s with nnz=%d, %s>" % (rows, cols, type(self).__name__, self.total_nnz, what)
 
 
-class ILUTPreconditioner(_BaseWrapper):
-    """ILUT (Saad) preconditioner: ``fill_in`` nonzeros per row of L/U, relative ``threshold``.
-    Reference: ilupp/__init__.py:205-216."""
+class ILUTPreconditioner(_HipPreconditioner):
+    """ILUT (Saad): at most `fill_in` entries per row of L and of U, relative drop `threshold`."""
 
     def __init__(self, A, fill_in=100, threshold=0.1):
-        Ad, Ai, Ap, Ao = _matrix_fields(A)
-        self.pr = _ilupp.ILUTPreconditioner(Ad, Ai, Ap, Ao, fill_in, threshold)
-        scipy.sparse.linalg.LinearOperator.__init__(self, shape=A.shape, dtype=A.dtype)
+        super().__init__(A, lambda m: _native.ILUTPreconditioner(*m, fill_in, threshold))
 
 
-class ILU0Preconditioner(_BaseWrapper):
-    """ILU(0) preconditioner (no fill-in).  Reference: ilupp/__init__.py:272-281."""
+class ILU0Preconditioner(_HipPreconditioner):
+    """ILU(0): incomplete LU in the pattern of A."""
 
     def __init__(self, A):
-        Ad, Ai, Ap, Ao = _matrix_fields(A)
-        self.pr = _ilupp.ILU0Preconditioner(Ad, Ai, Ap, Ao)
-        scipy.sparse.linalg.LinearOperator.__init__(self, shape=A.shape, dtype=A.dtype)
+        super().__init__(A, lambda m: _native.ILU0Preconditioner(*m))
 
 
-class IChol0Preconditioner(_BaseWrapper):
-    """IChol(0) preconditioner for a symmetric positive definite matrix.  Reference: :283-293."""
+class IChol0Preconditioner(_HipPreconditioner):
+    """IChol(0) of a symmetric positive definite matrix, in the pattern of its lower triangle."""
 
     def __init__(self, A):
-        Ad, Ai, Ap, Ao = _matrix_fields(A)
-        self.pr = _ilupp.IChol0Preconditioner(Ad, Ai, Ap, Ao)
-        scipy.sparse.linalg.LinearOperator.__init__(self, shape=A.shape, dtype=A.dtype)
+        super().__init__(A, lambda m: _native.IChol0Preconditioner(*m))
 
 
-class ICholTPreconditioner(_BaseWrapper):
-    """Incomplete Cholesky with ``add_fill_in`` extra nonzeros per column and relative ``threshold``
-    (Lin-More for threshold=0).  Reference: ilupp/__init__.py:295-310."""
+class ICholTPreconditioner(_HipPreconditioner):
+    """Incomplete Cholesky with `add_fill_in` extra entries per column and relative drop `threshold`."""
 
     def __init__(self, A, add_fill_in=0, threshold=0.0):
-        Ad, Ai, Ap, Ao = _matrix_fields(A)
-        self.pr = _ilupp.ICholTPreconditioner(Ad, Ai, Ap, Ao, add_fill_in, threshold)
-        scipy.sparse.linalg.LinearOperator.__init__(self, shape=A.shape, dtype=A.dtype)
+        super().__init__(A, lambda m: _native.ICholTPreconditioner(*m, add_fill_in, threshold))
 
 
+# ---- stand-alone factor functions ---------------------------------------------------------------
 def ichol0(A):
-    """L factor of an incomplete Cholesky decomposition without fill-in (reference :314-316)."""
-    return _matrix_from_info(*_ilupp.ichol0(*_matrix_fields(A)))
+    """L of an incomplete Cholesky decomposition without fill-in."""
+    return _as_scipy(_native.ichol0(*_borrow(A)))
 
 
 def icholt(A, add_fill_in=0, threshold=0.0):
-    """L factor of an incomplete Cholesky decomposition with thresholding (reference :318-320)."""
-    return _matrix_from_info(*_ilupp.icholt(*_matrix_fields(A), add_fill_in, threshold))
+    """L of an incomplete Cholesky decomposition with thresholding."""
+    return _as_scipy(_native.icholt(*_borrow(A), add_fill_in, threshold))
 
 
 def ilu0(A):
-    """(L, U) factors of an incomplete LU decomposition without fill-in (reference :322-324)."""
-    return tuple(_matrix_from_info(*mtx) for mtx in _ilupp.ilu0(*_matrix_fields(A)))
+    """(L, U) of an incomplete LU decomposition without fill-in."""
+    return tuple(_as_scipy(f) for f in _native.ilu0(*_borrow(A)))
 
 
 def ilut(A, fill_in=100, threshold=0.1):
-    """(L, U) factors of an incomplete LU decomposition with thresholding (reference :326-328)."""
-    return tuple(_matrix_from_info(*mtx) for mtx in _ilupp.ilut(*_matrix_fields(A), fill_in, threshold))
+    """(L, U) of an incomplete LU decomposition with thresholding."""
+    return tuple(_as_scipy(f) for f in _native.ilut(*_borrow(A), fill_in, threshold))

@@ -48,6 +48,12 @@ def lib():
     L.ilupp_hip_ilut_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
     L.ilupp_hip_ichol0_create.argtypes = mat_host + [ctypes.POINTER(_VP)]
     L.ilupp_hip_icholt_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_ilut_create_device.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_ichol0_create_device.argtypes = mat_host + [ctypes.POINTER(_VP)]
+    L.ilupp_hip_icholt_create_device.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_set_caller_stream.argtypes = [_VP, ctypes.c_int]
+    L.ilupp_hip_path.argtypes = [_VP]
+    L.ilupp_hip_path.restype = ctypes.c_char_p
     L.ilupp_hip_destroy.argtypes = [_VP]
     L.ilupp_hip_destroy.restype = None
     L.ilupp_hip_apply.argtypes = [_VP, _VP, ctypes.c_int64]
@@ -88,7 +94,8 @@ ABI_SYMBOLS = [
     "ilupp_hip_exists", "ilupp_hip_special_info", "ilupp_hip_print_info", "ilupp_hip_dimension",
     "ilupp_hip_num_factors", "ilupp_hip_factor_info", "ilupp_hip_factor_copy",
     "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
-    "ilupp_hip_sync",
+    "ilupp_hip_sync", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
+    "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path",
 ]
 
 
@@ -239,6 +246,18 @@ class Preconditioner:
             out.append((data, indices, indptr, bool(is_csr.value), rows.value, cols.value))
         return out
 
+    def path(self):
+        """which kernel family built this object (measurement hook)"""
+        return lib().ilupp_hip_path(self._h).decode()
+
+    def factor_device_ptrs(self, which):
+        """(data, indices, indptr) device addresses of factor `which` (valid while the object lives)"""
+        d, i, p = _VP(), _VP(), _VP()
+        rc = lib().ilupp_hip_factor_device_ptrs(self._h, which, ctypes.byref(d), ctypes.byref(i), ctypes.byref(p))
+        if rc:
+            _raise(rc)
+        return d.value, i.value, p.value
+
     def timings(self):
         t = Timings()
         lib().ilupp_hip_get_timings(self._h, ctypes.byref(t))
@@ -266,6 +285,34 @@ def ILU0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr):
     if rc:
         _raise(rc)
     return Preconditioner(h)
+
+
+def _create_device(fn, d_data, d_indices, d_indptr, n, is_csr, *extra):
+    h = _VP()
+    rc = fn(d_data, d_indices, d_indptr, n, 1 if is_csr else 0, *extra, ctypes.byref(h))
+    if rc:
+        _raise(rc)
+    return Preconditioner(h)
+
+
+def ILUTPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, max_fill_in, threshold):
+    return _create_device(lib().ilupp_hip_ilut_create_device, d_data, d_indices, d_indptr, n, is_csr,
+                          ctypes.c_int32(int(max_fill_in)), ctypes.c_double(float(threshold)))
+
+
+def IChol0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr):
+    return _create_device(lib().ilupp_hip_ichol0_create_device, d_data, d_indices, d_indptr, n, is_csr)
+
+
+def ICholTPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, add_fill_in, threshold):
+    return _create_device(lib().ilupp_hip_icholt_create_device, d_data, d_indices, d_indptr, n, is_csr,
+                          ctypes.c_int32(int(add_fill_in)), ctypes.c_double(float(threshold)))
+
+
+def set_caller_stream(stream_handle, enable=True):
+    """order the *_device entry points of this thread after / before `stream_handle` (a hipStream_t as int; 0 = the
+    legacy default stream); see include/ilupp_hip.h"""
+    lib().ilupp_hip_set_caller_stream(_VP(stream_handle or 0), 1 if enable else 0)
 
 
 def ILUTPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, threshold):

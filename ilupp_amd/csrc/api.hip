@@ -48,8 +48,8 @@ void Ilu0Program::release()
 namespace {
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;     // size -> block
-    std::unordered_map<void *, size_t> live;       // block -> size
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;     // (device, size) -> block
+    std::unordered_map<void *, std::pair<int, size_t>> live;       // block -> (device, size)
     size_t cached = 0;
     static constexpr size_t kMaxCached = 24ull << 30;   // of 288 GB HBM
 } g_pool;
@@ -59,14 +59,16 @@ hipError_t pool_malloc(void **p, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~(size_t)255;
+    int dev = 0;
+    (void)hipGetDevice(&dev);                      // a cached block is only ever handed back on the GPU it lives on
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        auto it = g_pool.free_blocks.find(bytes);
+        auto it = g_pool.free_blocks.find({dev, bytes});
         if (it != g_pool.free_blocks.end()) {
             *p = it->second;
             g_pool.free_blocks.erase(it);
             g_pool.cached -= bytes;
-            g_pool.live[*p] = bytes;
+            g_pool.live[*p] = {dev, bytes};
             return hipSuccess;
         }
     }
@@ -78,7 +80,7 @@ hipError_t pool_malloc(void **p, size_t bytes)
     }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        g_pool.live[*p] = bytes;
+        g_pool.live[*p] = {dev, bytes};
     }
     return e;
 }
@@ -86,16 +88,15 @@ hipError_t pool_malloc(void **p, size_t bytes)
 hipError_t pool_free(void *p)
 {
     if (!p) return hipSuccess;
-    size_t bytes = 0;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
         auto it = g_pool.live.find(p);
         if (it == g_pool.live.end()) return ::hipFree(p);
-        bytes = it->second;
+        const std::pair<int, size_t> key = it->second;
         g_pool.live.erase(it);
-        if (g_pool.cached + bytes <= Pool::kMaxCached) {
-            g_pool.free_blocks.emplace(bytes, p);
-            g_pool.cached += bytes;
+        if (g_pool.cached + key.second <= Pool::kMaxCached) {
+            g_pool.free_blocks.emplace(key, p);
+            g_pool.cached += key.second;
             return hipSuccess;
         }
     }
@@ -108,6 +109,24 @@ void pool_trim()
     for (auto &kv : g_pool.free_blocks) (void)::hipFree(kv.second);
     g_pool.free_blocks.clear();
     g_pool.cached = 0;
+}
+
+// Ordering against the caller's own HIP stream (device-pointer entry points): when set for this thread, every *_device
+// call first makes the object's queue wait for the work already submitted to that stream (the producer of the matrix /
+// the vector), and an asynchronous apply makes that stream wait for the result.
+static thread_local hipStream_t g_caller_stream = nullptr;
+static thread_local bool g_caller_stream_set = false;
+static void order_after_caller(hipStream_t st, hipEvent_t ev)
+{
+    if (!g_caller_stream_set) return;
+    ILUPP_HIP(hipEventRecord(ev, g_caller_stream));
+    ILUPP_HIP(hipStreamWaitEvent(st, ev, 0));
+}
+static void order_caller_after(hipStream_t st, hipEvent_t ev)
+{
+    if (!g_caller_stream_set) return;
+    ILUPP_HIP(hipEventRecord(ev, st));
+    ILUPP_HIP(hipStreamWaitEvent(g_caller_stream, ev, 0));
 }
 
 static int report(const HipError &e)
@@ -220,6 +239,7 @@ ilupp_precond *new_obj(int32_t n)
         ILUPP_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         for (auto &e : p->sev) ILUPP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    order_after_caller(p->stream, p->sev[0]);        // (the matrix a *_create_device call is about to read)
     ILUPP_HIP(pool_malloc(&p->work, sizeof(double) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->done, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->ctrl, 64));
@@ -259,9 +279,11 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
         direct = false;
         rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, kms);
     }
-    if (!direct && p->pkL.valid && p->pkU.valid) {
-        lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sA, p->dL, &p->pkL, 2);
-        lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU, 2);
+    // the level-major sweeps of this object keep their own copy of the values: every one that exists gets the new ones
+    // (they are built independently, on first use, so one may exist without the other)
+    if (!direct) {
+        if (p->pkL.valid && !p->pkL.stat) lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sL.start ? p->sL : p->sA, p->dL, &p->pkL, 2);
+        if (p->pkU.valid && !p->pkU.stat) lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU, 2);
     }
     return rc;
 }
@@ -439,9 +461,11 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
     return sptrsv(p->stream, kind, M, sch, desc, maxlen, rhs, out, ticket, err);
 }
 // apply on a device vector; `transpose` as in apply_preconditioner_only(use, y)
+#define SWEEP_OR_RETURN(...) do { const int rc_ = sweep(__VA_ARGS__); if (rc_) return rc_; } while (0)
 int apply_dev(ilupp_precond *p, double *x, int transpose)
 {
     hipStream_t st = p->stream;
+    order_after_caller(st, p->sev[0]);
     ILUPP_HIP(hipMemsetAsync(p->ctrl, 0, 64, st));
     int32_t *err = p->ctrl, *t1 = p->ctrl + 4, *t2 = p->ctrl + 5;
     double *y = p->work;
@@ -459,9 +483,9 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             const PackedSweep *p1 = packed(p, 0, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
             const PackedSweep *p2 = packed(p, 1, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), &p->pkU);
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), p1, x, y, t1, err, ylm ? p->pkL.ybuf : nullptr);
+            SWEEP_OR_RETURN(p, SWEEP_FWD_LAST_ASC, p->Lc, sl, p->dL, MAXLEN_OF(p->Lc), p1, x, y, t1, err, ylm ? p->pkL.ybuf : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sweep(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), p2, y, x, t2, err, nullptr,
+            SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), p2, y, x, t2, err, nullptr,
                   ylm ? p->pkL.ybuf : nullptr, ylm ? p->pkU.ysrc : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         } else {
@@ -469,9 +493,9 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             const PackedSweep *p1 = packed(p, 2, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), &p->pkUT);
             const PackedSweep *p2 = packed(p, 3, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), &p->pkLT);
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sweep(p, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), p1, x, y, t1, err);
+            SWEEP_OR_RETURN(p, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), p1, x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sweep(p, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p2, y, x, t2, err);
+            SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p2, y, x, t2, err);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         }
     } else {
@@ -490,16 +514,16 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             const PackedSweep *p1 = packed(p, 0, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
             const PackedSweep *p2 = packed(p, 3, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), &p->pkLT);
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sweep(p, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), p1, x, y, t1, err);
+            SWEEP_OR_RETURN(p, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), p1, x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sweep(p, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p2, y, x, t2, err);
+            SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p2, y, x, t2, err);
         } else {                      // ICholT: T2(L) then T3(L)
             const PackedSweep *p1 = packed(p, 3, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), &p->pkLT);
             const PackedSweep *p2 = packed(p, 0, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            sweep(p, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p1, x, y, t1, err);
+            SWEEP_OR_RETURN(p, SWEEP_FWD_LAST_ASC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p1, x, y, t1, err);
             ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            sweep(p, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), p2, y, x, t2, err);
+            SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), p2, y, x, t2, err);
         }
         ILUPP_HIP(hipEventRecord(p->ev[2], st));
     }
@@ -609,7 +633,15 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
 int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices, const int32_t *d_indptr)
 {
     API_TRY
-    if (!p || p->kind != KIND_LU) { set_error("not an ILU(0) object"); return ILUPP_ERR_INVALID; }
+    if (!p || p->kind != KIND_LU || p->nnz_mode != NNZ_GENERIC_LU || p->sA.nb <= 0) { set_error("not an ILU(0) object"); return ILUPP_ERR_INVALID; }
+    order_after_caller(p->stream, p->sev[0]);
+    {
+        // same pattern as the analysed one: at least the same number of stored entries
+        int32_t nnz32 = -1;
+        ILUPP_HIP(hipMemcpyAsync(&nnz32, d_indptr + p->n, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
+        ILUPP_HIP(hipStreamSynchronize(p->stream));
+        if ((int64_t)nnz32 != p->nnzA) { set_error("ILU0 refactor: the matrix does not have the analysed pattern"); return ILUPP_ERR_INVALID; }
+    }
     DevMat A;
     A.n = p->n; A.is_csr = true; A.owns = false; A.nnz = p->nnzA;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
@@ -634,23 +666,13 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     API_CATCH
 }
 
-int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int32_t *indptr,
-                          int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
+}  // extern "C"
+
+static int ilut_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
-    API_TRY
-    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
-    *out = nullptr;
-    int rc = validate(indptr, n);
-    if (rc) return rc;
-    const int64_t nnz = indptr[n];
-    DevMat A;
-    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
-    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
-    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
-    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
-    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    int rc = ILUPP_OK;
+    const int64_t nnz = A.nnz;
+    (void)nnz; (void)is_csr;
     ilupp_precond *p = new_obj(n);
     p->kind = KIND_LU;
     p->nnz_mode = NNZ_ILUT;
@@ -691,14 +713,14 @@ int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int3
     p->tm.numeric_kernel_ms = kms;
     *out = p;
     return ILUPP_OK;
-    API_CATCH
 }
 
-int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const int32_t *indptr,
-                            int32_t n, int is_csr, ilupp_precond **out)
+extern "C" {
+
+int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int32_t *indptr,
+        int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
     API_TRY
-    (void)is_csr;     // IChol0 keeps idx <= major in either orientation and labels the result ROW (IChol.hpp:63-68)
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);
@@ -712,6 +734,36 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
     ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    rc = ilut_create_common(A, n, is_csr, max_fill_in, threshold, out);
+    A.release();
+    return rc;
+    API_CATCH
+}
+
+/* the same on a matrix that already lives in HBM (borrowed for the call) */
+int ilupp_hip_ilut_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+        int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+    int32_t nnz32 = 0;
+    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    DevMat A;
+    A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
+    A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+    return ilut_create_common(A, n, is_csr, max_fill_in, threshold, out);
+    API_CATCH
+}
+
+}  // extern "C"
+
+static int ichol0_create_common(DevMat &A, int32_t n, int is_csr, ilupp_precond **out)
+{
+    int rc = ILUPP_OK;
+    const int64_t nnz = A.nnz;
+    (void)nnz; (void)is_csr;
     ilupp_precond *p = new_obj(n);
     p->kind = KIND_LLT;
     p->nnz_mode = NNZ_LLT;
@@ -748,13 +800,15 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
     }
     *out = p;
     return ILUPP_OK;
-    API_CATCH
 }
-int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const int32_t *indptr,
-                            int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out)
+
+extern "C" {
+
+int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const int32_t *indptr,
+        int32_t n, int is_csr, ilupp_precond **out)
 {
     API_TRY
-    (void)is_csr;     // ICholT keeps idx >= major in either orientation and labels the result COLUMN (IChol.hpp:158-164)
+    (void)is_csr;     // IChol0 keeps idx <= major in either orientation and labels the result ROW (IChol.hpp:63-68)
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);
@@ -768,6 +822,34 @@ int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const in
     ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    rc = ichol0_create_common(A, n, is_csr, out);
+    A.release();
+    return rc;
+    API_CATCH
+}
+
+int ilupp_hip_ichol0_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+        int32_t n, int is_csr, ilupp_precond **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+    int32_t nnz32 = 0;
+    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    DevMat A;
+    A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
+    A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+    return ichol0_create_common(A, n, is_csr, out);
+    API_CATCH
+}
+}  // extern "C"
+
+static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out)
+{
+    int rc = ILUPP_OK;
+    const int64_t nnz = A.nnz;
+    (void)nnz; (void)is_csr;
     ilupp_precond *p = new_obj(n);
     p->kind = KIND_LLT;
     p->nnz_mode = NNZ_LLT;
@@ -806,6 +888,47 @@ int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const in
     p->tm.numeric_kernel_ms = kms;
     *out = p;
     return ILUPP_OK;
+}
+
+extern "C" {
+
+int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const int32_t *indptr,
+        int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out)
+{
+    API_TRY
+    (void)is_csr;     // ICholT keeps idx >= major in either orientation and labels the result COLUMN (IChol.hpp:158-164)
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    rc = icholt_create_common(A, n, is_csr, add_fill_in, threshold, out);
+    A.release();
+    return rc;
+    API_CATCH
+}
+
+int ilupp_hip_icholt_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+        int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+    int32_t nnz32 = 0;
+    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    DevMat A;
+    A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
+    A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+    return icholt_create_common(A, n, is_csr, add_fill_in, threshold, out);
     API_CATCH
 }
 
@@ -819,8 +942,27 @@ int ilupp_hip_apply_device(ilupp_precond *p, double *d_x, int64_t len, int trans
     int rc = apply_dev(p, d_x, transpose);
     if (rc) return rc;
     if (sync) return finish_apply(p);
+    order_caller_after(p->stream, p->sev[1]);
     return ILUPP_OK;
     API_CATCH
+}
+
+int ilupp_hip_set_caller_stream(void *hip_stream, int enable)
+{
+    g_caller_stream = static_cast<hipStream_t>(hip_stream);
+    g_caller_stream_set = enable != 0;
+    return ILUPP_OK;
+}
+
+const char *ilupp_hip_path(const ilupp_precond *p)
+{
+    if (!p) return "";
+    if (p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU) {
+        if (p->flm.built) return p->flm.stat ? "ilu0:static-level-major" : "ilu0:level-major";
+        return p->prog_f3 ? "ilu0:csr-program" : "ilu0:csr";
+    }
+    if (p->kind == KIND_LU) return "ilut";
+    return p->llt_diag_last ? "ichol0" : "icholt";
 }
 
 static int apply_host(ilupp_precond *p, double *x, int64_t len, int transpose)

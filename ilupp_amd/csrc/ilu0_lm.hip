@@ -19,6 +19,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -645,10 +647,14 @@ int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     ILUPP_HIP(hipMemsetAsync(d_tl, 0, 8 * 8 * 4096, st));
 #endif
     ILUPP_HIP(hipEventRecord(e0, st));
-    static bool attr_set = false;
-    if (!attr_set) {
-        ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlmLds));
-        attr_set = true;
+    {
+        // once per device (the attribute is a property of the function on a device)
+        static std::once_flag once[64];
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlmLds));
+        });
     }
     hipLaunchKernelGGL(k_ilu0_lm, dim3((unsigned)pl->nwg), dim3(kFlmThreads), kFlmLds, st, a);
     ILUPP_HIP(hipEventRecord(e1, st));

@@ -23,6 +23,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 #ifndef IMPORT_SLEEP
@@ -652,11 +654,14 @@ int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
     const unsigned grid = (unsigned)ps.nwg;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
-        ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
-        attr_set = true;
+    {
+        static std::once_flag once[64];      // once per device
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lm<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLds));
+        });
     }
     if (ps.kind == (int)SWEEP_FWD_LAST_ASC) {
         hipLaunchKernelGGL((k_sptrsv_lm<1>), dim3(grid), dim3(kLmThreads), kLmLds, st, reinterpret_cast<const v4i *>(ps.pk), ps.wtab,

@@ -377,10 +377,16 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
     const double absent = st_dbl(kAbsent);
     double a[7] = {absent, absent, absent, absent, absent, absent, absent};
     int mask = 0;
+    // the row is sorted: cl entries left of the diagonal, the diagonal, the rest right of it; each side is matched
+    // against its own side of the template only
+    int cl = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const bool in = i < len;
-        const int o = in ? own.c[i] - r : 0x40000000;
+    for (int i = 0; i < 7; ++i) cl += own.c[i] < r ? 1 : 0;
+    if (cl > 3 || len - cl - 1 > 3 || len - cl - 1 < 0) bad = 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const bool in = i < cl;
+        const int o = own.c[i] - r;
         const double vi = st_clean(v[i]);
         bool hit = false;
 #pragma unroll
@@ -389,18 +395,27 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
             if (h) { a[j] = vi; mask |= 1 << j; }
             hit |= h;
         }
-        {
-            const bool h = in && o == 0;
-            if (h) { a[3] = vi; mask |= 8; }
-            hit |= h;
-        }
+        if (in && !hit) bad = 1;                            // a column outside the lane's template
+    }
+    {
+        const int cd = cl == 0 ? own.c[0] : cl == 1 ? own.c[1] : cl == 2 ? own.c[2] : own.c[3];
+        const double vd = cl == 0 ? v[0] : cl == 1 ? v[1] : cl == 2 ? v[2] : v[3];
+        if (cd == r) { a[3] = st_clean(vd); mask |= 8; }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const bool in = cl + 1 + u < len;
+        const int cu = cl == 0 ? own.c[1 + u] : cl == 1 ? own.c[2 + u] : cl == 2 ? own.c[3 + u] : own.c[4 + u];
+        const double vu = st_clean(cl == 0 ? v[1 + u] : cl == 1 ? v[2 + u] : cl == 2 ? v[3 + u] : v[4 + u]);
+        const int o = cu - r;
+        bool hit = false;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const bool h = in && q < ndB && o == oB[q];
-            if (h) { a[4 + q] = vi; mask |= 16 << q; }
+            if (h) { a[4 + q] = vu; mask |= 16 << q; }
             hit |= h;
         }
-        if (in && !hit) bad = 1;                            // a column outside the lane's template
+        if (in && !hit) bad = 1;
     }
     if (!(mask & 8)) bad = 1;
     // every entry is produced where the template says
@@ -417,14 +432,20 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
     v2d x;
     x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, p);
     x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, p + 64);
+#ifndef EXP_ROWS_NOA6
     reinterpret_cast<double *>(p + 192)[1] = a[6];
+#endif
+#ifndef EXP_ROWS_NOU
     x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((long)t2.w - 128 * (long)k));
+#endif
     // the upper entries, to the rows they meet
     double *pd = reinterpret_cast<double *>(pkA);
     const int scs[3] = {sc.x, sc.y, sc.z};
+#ifndef EXP_ROWS_NOSCAT
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         if ((mask & (16 << q)) && scs[q] >= 0) pd[(long)scs[q] + 512 * (long)k] = a[4 + q];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

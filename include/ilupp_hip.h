@@ -73,6 +73,15 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
 int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const int32_t *indptr,
                             int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out);
 
+/* The three above on a matrix that already lives in this GPU's HBM (borrowed for the duration of the call): what a
+ * GPU-resident caller -- and bench.py's C3/C4 legs -- use, as ilupp_hip_ilu0_create_device does for ILU(0). */
+int ilupp_hip_ilut_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                 int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out);
+int ilupp_hip_ichol0_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                   int32_t n, int is_csr, ilupp_precond **out);
+int ilupp_hip_icholt_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                   int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out);
+
 void ilupp_hip_destroy(ilupp_precond *p);
 
 /* ---------------------------------------------------------------------------------------------
@@ -85,6 +94,14 @@ int ilupp_hip_apply(ilupp_precond *p, double *x, int64_t len);
 int ilupp_hip_apply_trans(ilupp_precond *p, double *x, int64_t len);
 /* the same on a vector that already lives in HBM (asynchronous on the object's stream unless sync!=0) */
 int ilupp_hip_apply_device(ilupp_precond *p, double *d_x, int64_t len, int transpose, int sync);
+
+/* Stream ordering of the device-pointer entry points (*_create_device, ilupp_hip_ilu0_refactor_device,
+ * ilupp_hip_apply_device).  Every object works on a private non-blocking HIP stream.  By default the caller must
+ * have synchronised the producer of the device buffers before the call, and a call with sync=0 must be followed by
+ * ilupp_hip_sync() before the result is read.  With a caller stream set for the calling thread (enable != 0;
+ * hip_stream = the caller's hipStream_t, NULL = the legacy default stream), every such call is ordered after the work
+ * already submitted to that stream, and an asynchronous apply makes that stream wait for the result. */
+int ilupp_hip_set_caller_stream(void *hip_stream, int enable);
 
 /* binding.cpp:255  total_nnz  (conventions per class) */
 int64_t ilupp_hip_total_nnz(const ilupp_precond *p);
@@ -125,6 +142,9 @@ typedef struct {
     float usolve_kernel_ms;   /* backward-solve kernel of the last apply */
 } ilupp_timings;
 int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t);
+/* which kernel family built this object ("ilu0:static-level-major", "ilu0:level-major", "ilu0:csr-program", "ilu0:csr",
+ * "ilut", "ichol0", "icholt"): bench.py names the kernel its roofline line is about */
+const char *ilupp_hip_path(const ilupp_precond *p);
 /* redo the numeric phase on (possibly new) values with the SAME pattern (buffers reused); times it */
 int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices,
                                    const int32_t *d_indptr);

@@ -55,7 +55,7 @@ def test_input_validation_types():
     B = sp.eye(4, format="csr")
     B.indices = B.indices.astype(np.int64)
     B.indptr = B.indptr.astype(np.int64)
-    with pytest.raises(TypeError, match="8 bytes per index"):
+    with pytest.raises(TypeError, match="8-byte indices"):
         ilupp.ILU0Preconditioner(B)
     C = sp.eye(4, format="csr", dtype=np.float32)
     with pytest.raises(RuntimeError, match=r"Expected d \(d\) array for A_data, got f!"):

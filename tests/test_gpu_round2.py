@@ -1,0 +1,345 @@
+"""GPU tests added in round 2 (run with -m gpu on an MI355X), all through the C ABI:
+
+* the headline config C2 (256^3) and C3 (n = 1e6) at FULL size, array-compared with the reference's own C++ (oracle/_ref,
+  when it travelled) or its C restatement;
+* the static level-major path (st.hip) on meshes it accepts and on matrices it must hand to the other generations;
+* device-resident constructors of ILUT / IChol0 / ICholT, caller-stream ordering, numeric re-factorisation on every
+  kernel generation, error paths, the batched multi-GPU driver.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import golden_util as G
+import matgen
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle():
+    from oracle import oracle as O
+    return O, (O.ref() if O.ref_available() else O.orc())
+
+
+def _dev(*arrays):
+    import torch
+    dev = torch.device("cuda", 0)
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrays]
+
+
+def _ptrs(ts):
+    return [t.data_ptr() for t in ts]
+
+
+def test_ilu0_config_c2_full_size():
+    """BASELINE config C2 at its full size (256^3 7-point Poisson): L, U (indices and values) and apply(ones) are
+    array-equal to the reference; the construction took the static level-major path"""
+    import torch
+    from ilupp_amd import _native
+    O, ref = _oracle()
+    d, i, p = matgen.poisson3d(256)
+    n = p.shape[0] - 1
+    t = _dev(d, i, p)
+    torch.cuda.synchronize()
+    P = _native.ILU0Preconditioner_device(*_ptrs(t), n, True)
+    assert P.path() == "ilu0:static-level-major"
+    x = torch.ones(n, dtype=torch.float64, device=t[0].device)
+    torch.cuda.synchronize()
+    P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+    Lo, Uo = ref.ilu0((d, i, p, True))
+    xo = ref.trisolve(Uo, O.UPPER, O.ID, ref.trisolve(Lo, O.LOWER, O.ID, np.ones(n)))
+    assert np.array_equal(x.cpu().numpy(), xo)
+    (Ld, Li, Lp, Lcsr, _, _), (Ud, Ui, Up, Ucsr, _, _) = P.factors_info()
+    assert Lcsr and Ucsr and Li.dtype == np.int32
+    assert np.array_equal(Lp, Lo[2]) and np.array_equal(Li, Lo[1]) and np.array_equal(Ld, Lo[0])
+    assert np.array_equal(Up, Uo[2]) and np.array_equal(Ui, Uo[1]) and np.array_equal(Ud, Uo[0])
+    assert P.total_nnz == 2 * 66912256
+    # the transposed solves on the same object (transposed storages built from the unpacked factors)
+    x.fill_(1.0)
+    torch.cuda.synchronize()
+    P.apply_device(x.data_ptr(), n, transpose=True, sync=True)
+    xt = ref.trisolve(Lo, O.LOWER, O.TRANSPOSE, ref.trisolve(Uo, O.UPPER, O.TRANSPOSE, np.ones(n)))
+    assert np.array_equal(x.cpu().numpy(), xt)
+
+
+def test_ilut_config_c3_full_size():
+    """BASELINE config C3 at its full size (random diagonally dominant, n = 1e6, nnz = 2e7, ILUT(10, 1e-4)) against the
+    reference (about a minute of CPU): L and U array-equal, through the device-resident constructor"""
+    import torch
+    from ilupp_amd import _native
+    O, ref = _oracle()
+    n = 1000000
+    d, i, p = matgen.random_dd(n, 19, 25.0, 12345)
+    t = _dev(d, i, p)
+    torch.cuda.synchronize()
+    P = _native.ILUTPreconditioner_device(*_ptrs(t), n, True, 10, 1e-4)
+    L, U = P.factors_info()
+    Lo, Uo = ref.ilut((d, i, p, True), 10, 1e-4)
+    assert np.array_equal(L[2], Lo[2]) and np.array_equal(L[1], Lo[1]) and np.array_equal(L[0], Lo[0])
+    assert np.array_equal(U[2], Uo[2]) and np.array_equal(U[1], Uo[1]) and np.array_equal(U[0], Uo[0])
+    b = G.rhs(n)
+    x = torch.from_numpy(b.copy()).to(t[0].device)
+    torch.cuda.synchronize()
+    P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+    assert np.array_equal(x.cpu().numpy(), O.orc().apply_lu(Lo, Uo, b, O.ID))
+
+
+@pytest.mark.parametrize("shape", [(40, 40, 40), (64, 24, 16), (17, 33, 65), (300, 300)])
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_static_path_meshes(shape, fmt):
+    """meshes of several aspect ratios (lines longer / shorter than a 16 x 16 patch of lines, 2-D): bit-exact, and where
+    the static analysis accepts the structure the static kernels ran"""
+    import ilupp_amd as ilupp
+    O, ref = _oracle()
+    d, i, p = matgen.poisson3d(*shape) if len(shape) == 3 else matgen.poisson2d(*shape)
+    n = p.shape[0] - 1
+    # nonsymmetric values on the symmetric pattern (the transposed entries really are other numbers)
+    rng = np.random.default_rng(7)
+    d = d * (1.0 + 0.3 * rng.random(d.shape[0]))
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    A = A if fmt == "csr" else A.tocsc()
+    P = ilupp.ILU0Preconditioner(A)
+    Lo, Uo = ref.ilu0((A.data, A.indices, A.indptr, fmt == "csr"))
+    L, U = P.factors()
+    assert G.mat_equal((L.data, L.indices, L.indptr, fmt == "csr"), Lo) and G.mat_equal((U.data, U.indices, U.indptr, fmt == "csr"), Uo)
+    b = G.rhs(n)
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, O.ID))
+    xt = b.copy(); P.apply_trans(xt)
+    assert np.array_equal(xt, O.orc().apply_lu(Lo, Uo, b, O.TRANSPOSE))
+
+
+def _mesh_with_holes(g, seed):
+    """7-point mesh with random points removed (rows/columns deleted): chains of irregular length, templates that do not hold"""
+    d, i, p = matgen.poisson3d(g)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    keep = np.random.default_rng(seed).random(n) > 0.03
+    idx = np.flatnonzero(keep)
+    B = A[idx][:, idx].tocsr()
+    B.sort_indices()
+    return B
+
+
+@pytest.mark.parametrize("case", ["holes", "nonsym_pattern", "wide_rows"])
+def test_static_path_rejects_and_falls_back(case):
+    """structures outside the static form (irregular chains, a structurally nonsymmetric stencil, 9-point rows) take the
+    other kernel generations and stay bit-exact"""
+    import ilupp_amd as ilupp
+    O, ref = _oracle()
+    if case == "holes":
+        A = _mesh_with_holes(32, 5)
+    elif case == "nonsym_pattern":
+        d, i, p = matgen.poisson3d(32)
+        n = p.shape[0] - 1
+        A = sp.csr_matrix((d, i, p), shape=(n, n)).tolil()
+        rng = np.random.default_rng(11)
+        for r in rng.integers(40, n - 40, size=400):         # drop some upper entries only
+            if A[r, r + 1] != 0:
+                A[r, r + 1] = 0
+        A = A.tocsr(); A.eliminate_zeros(); A.sort_indices()
+    else:
+        g = 96
+        T = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(g, g))
+        E = sp.diags([1.0, 1.0, 1.0], [-1, 0, 1], shape=(g, g))
+        A = (sp.kron(sp.identity(g), T) + sp.kron(T, sp.identity(g)) - 0.1 * sp.kron(E, E)).tocsr()
+        A.sort_indices()
+    n = A.shape[0]
+    P = ilupp.ILU0Preconditioner(A)
+    Lo, Uo = ref.ilu0((A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32), True))
+    L, U = P.factors()
+    assert G.mat_equal((L.data, L.indices, L.indptr, True), Lo) and G.mat_equal((U.data, U.indices, U.indptr, True), Uo)
+    b = G.rhs(n)
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, O.ID))
+
+
+def test_device_constructors_match_host_constructors():
+    """ILUT / IChol0 / ICholT from device-resident inputs (include/ilupp_hip.h *_create_device) = the host-pointer ones"""
+    import torch
+    from ilupp_amd import _native
+    d, i, p = matgen.random_dd(20000, 12, 25.0, 99)
+    n = p.shape[0] - 1
+    t = _dev(d, i, p)
+    torch.cuda.synchronize()
+    a = _native.ILUTPreconditioner_device(*_ptrs(t), n, True, 8, 1e-3).factors_info()
+    b = _native.ILUTPreconditioner(d, i, p, True, 8, 1e-3).factors_info()
+    for fa, fb in zip(a, b):
+        assert all(np.array_equal(u, v) for u, v in zip(fa[:3], fb[:3]))
+    ds, is_, ps = matgen.poisson3d(20)
+    ns = ps.shape[0] - 1
+    ts = _dev(ds, is_, ps)
+    torch.cuda.synchronize()
+    for dev_fn, host_fn, extra in ((_native.IChol0Preconditioner_device, _native.IChol0Preconditioner, ()),
+                                   (_native.ICholTPreconditioner_device, _native.ICholTPreconditioner, (3, 1e-3))):
+        fa = dev_fn(*_ptrs(ts), ns, True, *extra)
+        fb = host_fn(ds, is_, ps, True, *extra)
+        assert all(np.array_equal(u, v) for u, v in zip(fa.factors_info()[0][:3], fb.factors_info()[0][:3]))
+        x = torch.ones(ns, dtype=torch.float64, device=ts[0].device)
+        torch.cuda.synchronize()
+        fa.apply_device(x.data_ptr(), ns, transpose=False, sync=True)
+        y = np.ones(ns); fb.apply(y)
+        assert np.array_equal(x.cpu().numpy(), y)
+
+
+def test_caller_stream_ordering():
+    """with the caller's stream registered, producer work queued on it is seen by create / apply without a host
+    synchronisation, and an asynchronous apply's result is ordered before the caller's next work on that stream"""
+    import torch
+    from ilupp_amd import _native
+    O, ref = _oracle()
+    d, i, p = matgen.poisson3d(48)
+    n = p.shape[0] - 1
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(device=dev)
+    _native.set_caller_stream(s.cuda_stream, True)
+    try:
+        with torch.cuda.stream(s):
+            td = torch.from_numpy(d).to(dev, non_blocking=True) * 1.0          # produced on s
+            ti = torch.from_numpy(i).to(dev); tp = torch.from_numpy(p).to(dev)
+            P = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True)
+            x = torch.zeros(n, dtype=torch.float64, device=dev)
+            x += 1.0                                                            # producer of x on s, no sync
+            P.apply_device(x.data_ptr(), n, transpose=False, sync=False)
+            y = x * 2.0                                                         # consumer on s, no sync
+        s.synchronize()
+        P.sync()
+    finally:
+        _native.set_caller_stream(0, False)
+    Lo, Uo = ref.ilu0((d, i, p, True))
+    xo = O.orc().apply_lu(Lo, Uo, np.ones(n), O.ID)
+    assert np.array_equal(x.cpu().numpy(), xo) and np.array_equal(y.cpu().numpy(), 2.0 * xo)
+
+
+_REFACTOR_SCRIPT = r'''
+import sys
+sys.path[:0] = [%(root)r, %(tests)r]
+import numpy as np, torch
+import matgen
+from oracle import oracle as O
+from ilupp_amd import _native
+dev = torch.device("cuda", 0)
+def check(d, i, p, tag):
+    n = p.shape[0] - 1
+    t = [torch.from_numpy(a).to(dev) for a in (d, i, p)]
+    torch.cuda.synchronize()
+    P = _native.ILU0Preconditioner_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, True)
+    x = torch.ones(n, dtype=torch.float64, device=dev); torch.cuda.synchronize()
+    P.apply_device(x.data_ptr(), n, transpose=False, sync=True)          # builds whatever sweep forms this object has
+    d2 = d * (1.0 + 0.25 * np.cos(np.arange(d.shape[0], dtype=np.float64)))
+    t2 = torch.from_numpy(d2).to(dev); torch.cuda.synchronize()
+    P.refactor_device(t2.data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+    L2, U2 = O.orc().ilu0((d2, i, p, True))
+    for tr in (False, True):
+        x.fill_(1.0); torch.cuda.synchronize()
+        P.apply_device(x.data_ptr(), n, transpose=tr, sync=True)
+        assert np.array_equal(x.cpu().numpy(), O.orc().apply_lu(L2, U2, np.ones(n), O.TRANSPOSE if tr else O.ID)), (tag, tr)
+    F = P.factors_info()
+    assert np.array_equal(F[0][0], L2[0]) and np.array_equal(F[1][0], U2[0]), tag
+    print("ok", tag, P.path())
+check(*matgen.poisson3d(40), "mesh")
+# short L rows, long U rows: only one of the two sweeps has a level-major form
+n = 6000
+rng = np.random.default_rng(3)
+rows, cols, vals = [], [], []
+for r in range(n):
+    cs = {r}
+    if r > 0: cs.add(r - 1)
+    if r > 70: cs.add(r - 64)
+    for c in rng.integers(r + 1, min(n, r + 400), size=6) if r + 1 < n else []:
+        cs.add(int(c))
+    for c in sorted(cs):
+        rows.append(r); cols.append(c); vals.append(20.0 if c == r else -rng.random())
+import scipy.sparse as sp
+A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)); A.sort_indices()
+check(A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32), "short_L_long_U")
+print("refactor ok")
+'''
+
+
+@pytest.mark.parametrize("env", [{}, {"ILUPP_NO_STATIC": "1"}, {"ILUPP_CLASSIC_ANALYSIS": "1"}, {"ILUPP_NO_PACKED": "1"}],
+                         ids=["static", "level_major_records", "csr_program_packed_sweeps", "csr_only"])
+def test_refactor_on_every_generation(env):
+    """numeric re-factorisation (same pattern, new values) followed by apply / apply_trans / factors() on every kernel
+    generation, incl. an object of which only one sweep has a level-major form (stale packed values)"""
+    code = _REFACTOR_SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "refactor ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_refactor_rejects_other_objects_and_patterns():
+    import torch
+    from ilupp_amd import _native
+    d, i, p = matgen.poisson3d(16)
+    n = p.shape[0] - 1
+    t = _dev(d, i, p)
+    torch.cuda.synchronize()
+    T = _native.ILUTPreconditioner_device(*_ptrs(t), n, True, 5, 0.1)
+    with pytest.raises(RuntimeError, match="not an ILU\\(0\\) object"):
+        T.refactor_device(*_ptrs(t))
+    P = _native.ILU0Preconditioner_device(*_ptrs(t), n, True)
+    A2 = sp.csr_matrix((d, i, p), shape=(n, n)).tolil()
+    A2[5, 6] = 0.0                                   # one stored entry fewer behind the same object
+    A2 = A2.tocsr(); A2.eliminate_zeros(); A2.sort_indices()
+    t2 = _dev(A2.data, A2.indices.astype(np.int32), A2.indptr.astype(np.int32))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="analysed pattern"):
+        P.refactor_device(*_ptrs(t2))
+
+
+def test_error_paths_of_the_reference():
+    """IChol.hpp:105-107 "must be in triangular form" (a zero on the diagonal position) and
+    sparse_implementation.h:3178-3179 "insufficient memory reserved" do not exist for valid inputs; what can be provoked:
+    a structurally missing diagonal in ICholT's input"""
+    import ilupp_amd as ilupp
+    n = 50
+    A = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n)).tolil()
+    A[10, 10] = 0.0
+    A = A.tocsr(); A.eliminate_zeros(); A.sort_indices()
+    with pytest.raises(RuntimeError, match="triangular form"):
+        ilupp.ICholTPreconditioner(A)
+    with pytest.raises(RuntimeError, match="missing diagonal"):
+        ilupp.ILU0Preconditioner(A)
+
+
+_BATCH_SCRIPT = r'''
+import json, os, subprocess, sys
+root = %(root)r
+r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "48", "--no-cpu"],
+                   capture_output=True, text=True, timeout=600, cwd=root)
+line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+assert r.returncode == 0 and line, r.stdout + r.stderr
+out = json.loads(line[-1])
+assert out["n_gpus"] == 2 and out["batch"]["identical_to_single_rank"] and len(out["batch"]["records"]) == 2
+print("batch ok")
+'''
+
+
+def test_batched_two_gpus():
+    """the N > 1 path on the HIP kernels: bench.py --gpus 2 spawns one rank per GPU, every rank factors its own matrix of the
+    batch through ilupp_amd.batched.run_batch, outputs byte-identical to the single-rank run (skipped with < 2 GPUs)"""
+    from ilupp_amd import _native
+    if _native.lib().ilupp_hip_device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    r = subprocess.run([sys.executable, "-c", _BATCH_SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "batch ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_single_gpu_line():
+    """bench.py's contract on a small grid: one JSON line with roofline, cpu_baseline and an ARRAY parity verdict"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "48"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout + r.stderr
+    out = json.loads(line[-1])
+    assert out["n_gpus"] == 1 and out["parity"]["apply_ones_equal"] is True
+    assert out["roofline"]["kernel"] == "k_ilu0_st" and out["roofline"]["frac"] > 0
+    assert out["cpu_baseline"]["kind"] in ("reference", "port") and out["cpu_baseline"]["apply_paths_agree"]
