@@ -52,6 +52,7 @@ def lib():
     L.ilupp_hip_ichol0_create_device.argtypes = mat_host + [ctypes.POINTER(_VP)]
     L.ilupp_hip_icholt_create_device.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
     L.ilupp_hip_set_caller_stream.argtypes = [_VP, ctypes.c_int]
+    L.ilupp_hip_spmv_device.argtypes = [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP, _VP, _VP]
     L.ilupp_hip_path.argtypes = [_VP]
     L.ilupp_hip_path.restype = ctypes.c_char_p
     L.ilupp_hip_destroy.argtypes = [_VP]
@@ -95,7 +96,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_num_factors", "ilupp_hip_factor_info", "ilupp_hip_factor_copy",
     "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
     "ilupp_hip_sync", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
-    "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path",
+    "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_spmv_device",
 ]
 
 

@@ -1,0 +1,113 @@
+"""GPU-resident Krylov building blocks: the preconditioners of this package and a CSR
+operator that work on torch tensors living in HBM, so that an iteration of CG / BiCGstab / GMRES never crosses PCIe.
+
+    import torch, ilupp_amd.device as ild
+    A = ild.DeviceCSR.from_scipy(A_scipy)                  # one H2D copy
+    M = ild.DevicePreconditioner("ICholT", A, add_fill_in=0, threshold=0.0)
+    x = ild.cg(A, b, M, maxiter=50)                        # b, x: torch.float64 tensors on the GPU
+
+Everything is ordered on torch's current stream (ilupp_hip_set_caller_stream): no host synchronisation per call.
+The reference's counterpart is the loop of iterative_solvers_implementation.h:385-530 around
+matrix_sparse::matrix_vector_multiplication (sparse_implementation.h:2733-2760) and apply_preconditioner_only.
+"""
+import torch
+
+from . import _native
+
+_FACTORIES = {
+    "ILU0": (_native.ILU0Preconditioner_device, ()),
+    "ILUT": (_native.ILUTPreconditioner_device, ("fill_in", "threshold")),
+    "IChol0": (_native.IChol0Preconditioner_device, ()),
+    "ICholT": (_native.ICholTPreconditioner_device, ("add_fill_in", "threshold")),
+}
+_DEFAULTS = {"ILUT": {"fill_in": 100, "threshold": 0.1}, "ICholT": {"add_fill_in": 0, "threshold": 0.0}}
+
+
+def _on_current_stream():
+    _native.set_caller_stream(torch.cuda.current_stream().cuda_stream, True)
+
+
+class DeviceCSR:
+    """a square CSR matrix in HBM (fp64 values, int32 indices) with a bit-exact matvec"""
+
+    def __init__(self, data, indices, indptr):
+        assert data.is_cuda and data.dtype == torch.float64 and indices.dtype == torch.int32 and indptr.dtype == torch.int32
+        self.data, self.indices, self.indptr = data.contiguous(), indices.contiguous(), indptr.contiguous()
+        self.n = indptr.numel() - 1
+        self.nnz = data.numel()
+        self.shape = (self.n, self.n)
+
+    @classmethod
+    def from_scipy(cls, A, device=None):
+        import numpy as np
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        return cls(torch.from_numpy(np.ascontiguousarray(A.data, dtype=np.float64)).to(dev),
+                   torch.from_numpy(A.indices.astype(np.int32)).to(dev), torch.from_numpy(A.indptr.astype(np.int32)).to(dev))
+
+    def matvec(self, x, out=None):
+        y = torch.empty_like(x) if out is None else out
+        rc = _native.lib().ilupp_hip_spmv_device(self.data.data_ptr(), self.indices.data_ptr(), self.indptr.data_ptr(), self.n,
+                                                 self.nnz, x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc:
+            _native._raise(rc)
+        return y
+
+    __matmul__ = matvec
+
+
+class DevicePreconditioner:
+    """ILU0 / ILUT / IChol0 / ICholT of a DeviceCSR, applied to device tensors in place or out of place"""
+
+    def __init__(self, kind, A, **params):
+        make, names = _FACTORIES[kind]
+        p = dict(_DEFAULTS.get(kind, {}))
+        p.update(params)
+        _on_current_stream()
+        self.pr = make(A.data.data_ptr(), A.indices.data_ptr(), A.indptr.data_ptr(), A.n, True, *[p[k] for k in names])
+        self.n = A.n
+        self.shape = A.shape
+
+    def apply_(self, x, transpose=False):
+        """in place on a contiguous fp64 device tensor; asynchronous, ordered on torch's current stream"""
+        assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous() and x.numel() == self.n
+        _on_current_stream()
+        self.pr.apply_device(x.data_ptr(), self.n, transpose=transpose, sync=False)
+        return x
+
+    def matvec(self, x):
+        return self.apply_(x.clone())
+
+    __matmul__ = matvec
+
+    def sync(self):
+        self.pr.sync()
+
+
+def cg(A, b, M=None, x0=None, maxiter=100, rtol=0.0, check_every=0):
+    """preconditioned conjugate gradients on device tensors.  No host round trip per iteration: the scalars stay 0-dim
+    device tensors; the residual is only looked at every `check_every` iterations (0 = never: run maxiter iterations)."""
+    x = torch.zeros_like(b) if x0 is None else x0.clone()
+    r = b - A.matvec(x) if x0 is not None else b.clone()
+    z = M.matvec(r) if M is not None else r.clone()
+    p = z.clone()
+    rz = torch.dot(r, z)
+    bnorm = torch.linalg.vector_norm(b)
+    Ap = torch.empty_like(b)
+    for it in range(maxiter):
+        A.matvec(p, out=Ap)
+        alpha = rz / torch.dot(p, Ap)
+        x.add_(p * alpha)
+        r.sub_(Ap * alpha)
+        if check_every and (it + 1) % check_every == 0 and rtol > 0.0:
+            if float(torch.linalg.vector_norm(r) / bnorm) <= rtol:      # the only device-to-host read
+                break
+        z = M.matvec(r) if M is not None else r
+        rz_new = torch.dot(r, z)
+        p = z + p * (rz_new / rz)
+        rz = rz_new
+    if M is not None:
+        M.sync()
+    return x

@@ -103,6 +103,12 @@ int ilupp_hip_apply_device(ilupp_precond *p, double *d_x, int64_t len, int trans
  * already submitted to that stream, and an asynchronous apply makes that stream wait for the result. */
 int ilupp_hip_set_caller_stream(void *hip_stream, int enable);
 
+/* y = A x for a CSR matrix in HBM (row-major storage read as given; for a CSC matrix this is A^T x), on the caller's
+ * stream: with ilupp_hip_apply_device the two halves of a GPU-resident Krylov iteration.  One lane per row, accumulation in
+ * stored order from 0 (reference: sparse_implementation.h:2733-2760, ROW/ID branch) -- bit-identical to the reference. */
+int ilupp_hip_spmv_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr, int32_t n, int64_t nnz,
+                          const double *d_x, double *d_y, void *hip_stream);
+
 /* binding.cpp:255  total_nnz  (conventions per class) */
 int64_t ilupp_hip_total_nnz(const ilupp_precond *p);
 /* binding.cpp:257-261 */
