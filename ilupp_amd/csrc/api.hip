@@ -868,7 +868,10 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
     ILUPP_HIP(hipEventRecord(p->ev[1], st));
     if (rc) {
         if (rc == ILUPP_ERR_NOT_TRIANGULAR) set_error("ICholT: A must be in triangular form with no zeros on the diagonal");
-        else set_error("append_row: insufficient memory reserved");
+        else if (rc == ILUPP_ERR_NOT_SPD) set_error("ICholT: a column lost its diagonal entry (the matrix is not positive definite, or the "
+                                                         "fill budget is below one entry per column); the reference returns a NaN-filled factor here");
+        else if (rc == ILUPP_ERR_TIMEOUT) set_error("ICholT: dependency wait timed out");
+        else set_error("append_row: insufficient memory reserved (or a working column beyond the kernel's largest capacity class)");
         destroy_obj(p);
         return rc;
     }

@@ -16,7 +16,6 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
-#include "stdsort.h"
 
 namespace ilupp {
 
@@ -215,109 +214,10 @@ int ichol0_numeric(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t max_r
 // result, not just for correctness: (1) column j subtracts the contributing columns k in the order of a linked
 // list that is re-threaded after every column (ILUC.hpp:37-63), (2) every column j updates the running diagonal
 // D[i] of ALL rows i > j of its PRE-drop working column (IChol.hpp:135-141).  The dataflow kernel in
-// icholt_df.hip reproduces both in parallel and is what normally runs.  The kernel below is the reference loop
-// verbatim on one lane: the fallback for what the dataflow kernel's LDS capacities do not cover (very long
-// working columns, a dropped diagonal, add_fill_in < 0), and the A/B check of the dataflow kernel
-// (ILUPP_ICHOLT_SEQUENTIAL=1).
+// icholt_df.hip reproduces both in parallel (its largest capacity class gives one wave the whole LDS of a CU); this
+// file only holds the entry point.
 namespace ilupp {
 
-
-// ctrl: [0] status (0 ok, 2 not triangular, 3 insufficient memory reserved), [1] final nnz
-__global__ void __launch_bounds__(64)
-k_icholt_columns(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
-                 int32_t add_fill_in, double tau, int32_t reserved,
-                 int32_t *Lptr, int32_t *Lidx, double *Lval,
-                 int32_t *occ, double *sdata, int32_t *sptr, int32_t *listw, int32_t *firstL, int32_t *listL, double *D,
-                 int32_t *ctrl)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Lptr[0] = 0;
-    int status = 0;
-    int wnnz = 0;
-    for (int j = 0; j < m; ++j) {
-        const int c0 = Aptr[j], c1 = Aptr[j + 1];
-        if (c0 >= c1 || Aidx[c0] != j) { status = 2; break; }                 // IChol.hpp:105-107
-        // w.zero_reset(); scatter the lower column of A  (:110-112)
-        for (int q = 0; q < wnnz; ++q) occ[sptr[q]] = -1;
-        wnnz = 0;
-        auto slot_of = [&](int i) -> int {
-            int s = occ[i];
-            if (s < 0) { s = wnnz++; occ[i] = s; sptr[s] = i; sdata[s] = 0.0; }
-            return s;
-        };
-        for (int x = c0; x < c1; ++x) sdata[slot_of(Aidx[x])] = Aval[x];
-        D[j] = D[j] + Aval[c0];                                                // :115
-        const double L_jj = sqrt(D[j]);
-        sdata[slot_of(j)] = L_jj;
-        // subtract the contributing columns in linked-list order  (:120-132)
-        for (int k = listL[j]; k != -1; k = listL[k]) {
-            const double L_jk = Lval[firstL[k]];
-            int x = firstL[k];
-            if (Lidx[x] == j) ++x;
-            const int xe = Lptr[k + 1];
-            for (; x < xe; ++x) {
-                const int s = slot_of(Lidx[x]);
-                const double pr = Lval[x] * L_jk;
-                sdata[s] = sdata[s] - pr;
-            }
-        }
-        // scale the sub-diagonal part and update the running diagonals BEFORE dropping  (:135-141)
-        for (int x = 0; x < wnnz; ++x) {
-            const int i = sptr[x];
-            if (i > j) {
-                const double v = sdata[x] / L_jj;
-                sdata[x] = v;
-                const double sq = v * v;
-                D[i] = D[i] - sq;
-            }
-        }
-        // threshold_and_drop(w, listw, col_len + add_fill_in, tau, j, m)  (:144-145, dropping.hpp:8-34)
-        const int nkeep_max = (c1 - c0) + add_fill_in;
-        int len = 0;
-        if (nkeep_max > 0) {
-            double z = 0.0;
-            for (int x = 0; x < wnnz; ++x) { const int i = sptr[x]; if (j <= i && i < m) { const double sq = sdata[x] * sdata[x]; z = z + sq; } }
-            const double thr = sqrt(z) * tau;
-            for (int x = 0; x < wnnz; ++x) { const int i = sptr[x]; if (j <= i && i < m && fabs(sdata[x]) > thr) listw[len++] = x; }
-            if (len > nkeep_max) { c_sort_slots_by_abs_desc(listw, len, sdata); len = nkeep_max; }
-            for (int gap = len / 2; gap > 0; gap = (gap == 2) ? 1 : (int)(gap / 2.2)) {     // by increasing row index (unique keys)
-                for (int a = gap; a < len; ++a) {
-                    const int v = listw[a];
-                    int b = a;
-                    while (b >= gap && sptr[listw[b - gap]] > sptr[v]) { listw[b] = listw[b - gap]; b -= gap; }
-                    listw[b] = v;
-                }
-            }
-        }
-        // append_row (sparse_implementation.h:3170-3186)
-        int kk = Lptr[j];
-        if ((long)kk + len > (long)reserved) { status = 3; break; }
-        for (int q = 0; q < len; ++q) { Lval[kk] = sdata[listw[q]]; Lidx[kk++] = sptr[listw[q]]; }
-        Lptr[j + 1] = kk;
-        // update_triangular_fields(j, ...)  (ILUC.hpp:37-63)
-        {
-            for (int h = listL[j]; h != -1; h = listL[h]) firstL[h] += 1;
-            firstL[j] = Lptr[j] + 1;
-            int h = listL[j];
-            if (Lptr[j] + 1 < Lptr[j + 1]) {
-                const int jj = Lidx[Lptr[j] + 1];
-                listL[j] = listL[jj];
-                listL[jj] = j;
-            }
-            while (h != -1) {
-                const int i = h;
-                h = listL[i];
-                if (firstL[i] < Lptr[i + 1]) {
-                    const int jj = Lidx[firstL[i]];
-                    listL[i] = listL[jj];
-                    listL[jj] = i;
-                }
-            }
-        }
-    }
-    ctrl[0] = status;
-    ctrl[1] = status == 0 ? Lptr[m] : 0;
-}
 
 __global__ void k_fill_i32(int32_t *p, long count, int32_t v)
 {
@@ -329,69 +229,8 @@ __global__ void k_fill_i32(int32_t *p, long count, int32_t v)
 // A_tri: lower triangle by columns (CSC of A's lower part, diagonal first).  L comes back CSC-labelled.
 int icholt_factor(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms)
 {
-    const int32_t m = Atri.n;
-    const char *force_seq = getenv("ILUPP_ICHOLT_SEQUENTIAL");
-    if (!(force_seq && force_seq[0] == '1')) {
-        const int rc_df = icholt_factor_df(st, Atri, add_fill_in, threshold, L, kernel_ms);
-        if (rc_df != 1) return rc_df;          // 1 = outside the dataflow kernel's capacities
-    }
-    long a = (long)Atri.nnz + (long)(add_fill_in > 0 ? add_fill_in : 0) * (long)m;     // IChol.hpp:85-87
-    long b = (long)((double)Atri.nnz * 10.0);
-    long reserved = a < b ? a : b;
-    if (reserved < 1) reserved = 1;
-    if (reserved > 0x7fffffffL) reserved = 0x7fffffffL;
-    int32_t *Lptr, *Lidx, *occ, *sptr, *listw, *firstL, *listL, *ctrl;
-    double *Lval, *sdata, *D;
-    ILUPP_HIP(pool_malloc(&Lptr, sizeof(int32_t) * (size_t)(m + 1)));
-    ILUPP_HIP(pool_malloc(&Lidx, sizeof(int32_t) * (size_t)reserved));
-    ILUPP_HIP(pool_malloc(&Lval, sizeof(double) * (size_t)reserved));
-    ILUPP_HIP(pool_malloc(&occ, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&sptr, sizeof(int32_t) * (size_t)(m + 16)));
-    ILUPP_HIP(pool_malloc(&sdata, sizeof(double) * (size_t)(m + 16)));
-    ILUPP_HIP(pool_malloc(&listw, sizeof(int32_t) * (size_t)(m + 16)));
-    ILUPP_HIP(pool_malloc(&firstL, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&listL, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&D, sizeof(double) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&ctrl, 16));
-    ILUPP_HIP(hipMemsetAsync(occ, 0xff, sizeof(int32_t) * (size_t)m, st));
-    ILUPP_HIP(hipMemsetAsync(listL, 0xff, sizeof(int32_t) * (size_t)m, st));
-    ILUPP_HIP(hipMemsetAsync(firstL, 0, sizeof(int32_t) * (size_t)m, st));
-    ILUPP_HIP(hipMemsetAsync(D, 0, sizeof(double) * (size_t)m, st));
-    ILUPP_HIP(hipMemsetAsync(ctrl, 0, 16, st));
-    hipEvent_t e0, e1;
-    ILUPP_HIP(hipEventCreate(&e0));
-    ILUPP_HIP(hipEventCreate(&e1));
-    ILUPP_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(k_icholt_columns, dim3(1), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in, threshold,
-                       (int32_t)reserved, Lptr, Lidx, Lval, occ, sdata, sptr, listw, firstL, listL, D, ctrl);
-    ILUPP_HIP(hipEventRecord(e1, st));
-    ILUPP_HIP(hipGetLastError());
-    int32_t h[4];
-    ILUPP_HIP(hipMemcpyAsync(h, ctrl, 16, hipMemcpyDeviceToHost, st));
-    ILUPP_HIP(hipStreamSynchronize(st));
-    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
-    ILUPP_HIP(hipEventDestroy(e0));
-    ILUPP_HIP(hipEventDestroy(e1));
-    int rc = ILUPP_OK;
-    if (h[0] == 2) rc = ILUPP_ERR_NOT_TRIANGULAR;
-    else if (h[0] == 3) rc = ILUPP_ERR_MEMORY;
-    if (rc == ILUPP_OK) {
-        // compress(-1.0) keeps every entry and shrinks the arrays to their exact size (IChol.hpp:153)
-        const int32_t nnz = h[1];
-        L->n = m; L->nnz = nnz; L->is_csr = false; L->owns = true;
-        L->ptr = Lptr;
-        ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-        ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
-        ILUPP_HIP(hipMemcpyAsync(L->idx, Lidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, st));
-        ILUPP_HIP(hipMemcpyAsync(L->val, Lval, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, st));
-        ILUPP_HIP(hipStreamSynchronize(st));
-    } else {
-        ILUPP_HIP(pool_free(Lptr));
-    }
-    for (void *q : {(void *)Lidx, (void *)Lval, (void *)occ, (void *)sptr, (void *)sdata, (void *)listw, (void *)firstL,
-                    (void *)listL, (void *)D, (void *)ctrl})
-        ILUPP_HIP(pool_free(q));
-    return rc;
+    const int rc = icholt_factor_df(st, Atri, add_fill_in, threshold, L, kernel_ms);
+    return rc == 1 ? ILUPP_ERR_MEMORY : rc;      // (1 = a working column that does not fit the largest capacity class)
 }
 
 }  // namespace ilupp

@@ -31,9 +31,16 @@
 //     the libstdc++ algorithm, otherwise a parallel ranking); kept entries by increasing row.
 //
 // Columns land in fixed slabs (capacity = column length of A + add_fill_in, the top-k budget, IChol.hpp:144-145);
-// a compaction pass produces the CSC arrays.  Anything outside the kernel's LDS capacities (very long working
-// columns, more than T reaches per row, a dropped diagonal, add_fill_in < 0) makes the caller fall back to the
-// sequential kernel in ichol.hip, which is the reference loop verbatim.
+// a compaction pass produces the CSC arrays.  Whatever exceeds the static LDS capacity classes (long working columns, many
+// reaches per row) runs in the largest class: the same kernel with one wave per CU, working columns of up to 2048 rows in LDS,
+// the gathered entries (up to 262144 per column) and the touch records of a row (up to 65536) in global memory; beyond that
+// the factorisation is refused.
+// A column that loses its diagonal (indefinite input: the pivot's square root is NaN; a negative add_fill_in that leaves a
+// budget below 1) is an error here ("not positive definite"), where the reference silently returns a NaN-filled factor.
+#include <stdlib.h>
+
+#include <mutex>
+
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -62,7 +69,7 @@ __global__ void k_ict_prep(int32_t m, const int32_t *__restrict__ Aptr, const in
     if (j >= m) return;
     const int c0 = Aptr[j], c1 = Aptr[j + 1];
     if (c0 >= c1 || Aidx[c0] != j) { atomicMin(&ctrl[3], j); cap[j] = 0; return; }     // IChol.hpp:105-107
-    cap[j] = (c1 - c0) + add;
+    cap[j] = (c1 - c0) + add > 0 ? (c1 - c0) + add : 0;
     for (int x = c0 + 1; x < c1; ++x) atomicAdd(&pending[Aidx[x]], 1);
 }
 
@@ -77,27 +84,62 @@ __global__ void k_ict_seed(int32_t m, int32_t nq, const int32_t *__restrict__ pe
     }
 }
 
+// largest class: bytes of the entry / slot arrays (dynamic LDS) and of one wave's touch arrays (global workspace)
+__host__ __device__ inline size_t ict_lds_bytes(int ns) { return ((size_t)ns * (36 + 16) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t ict_touch_bytes(int tm) { return ((size_t)tm * 64 + 4 + 63) & ~(size_t)63; }
+
 __device__ __forceinline__ unsigned long long pack2(int lo, int hi)
 {
     return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
 }
 
-template <int kCtNE, int kCtNS, int kCtTM>
+// kGlobal: the largest class, one wave per CU.  Entry and slot arrays are carved out of one dynamic LDS allocation of (almost)
+// the whole 160 KB of a CU, the touch arrays live in a per-wave slice of global memory, sizes (gNE, gNS, gTM) are run-time
+// values -- same code, same order of operations; what the static classes cannot hold (long working columns, rows reached
+// by many columns) runs here instead of on a one-lane loop.
+template <int kLdsNE, int kLdsNS, int kLdsTM, bool kGlobal>
 __global__ void __launch_bounds__(64)
 k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
             int32_t add, double tau, int32_t T, int32_t nq, const int32_t *__restrict__ Loff,
             int32_t *Lidx, double *Lval, int32_t *Llen,
-            int32_t *cnt, unsigned long long *rec, int32_t *pending, int32_t *rq, int32_t *ctrl)
+            int32_t *cnt, unsigned long long *rec, int32_t *pending, int32_t *rq, int32_t *ctrl,
+            unsigned char *gws, int32_t gNE, int32_t gNS, int32_t gTM)
 {
-    __shared__ int erow[kCtNE], eslot[kCtNE];
-    __shared__ double eval[kCtNE];
-    __shared__ int srow[kCtNS], scnt[kCtNS], srank[kCtNS], sridx[kCtNS], cand[kCtNS], crank[kCtNS], keptslot[kCtNS];
-    __shared__ double sval[kCtNS];
-    __shared__ int tk[kCtTM], tx[kCtTM], tt[kCtTM], trem[kCtTM], tnxt[kCtTM], tseq[kCtTM];
-    __shared__ double tv[kCtTM], ordv[kCtTM];
-    __shared__ int cx[kCtTM], crem[kCtTM], cbase[kCtTM + 1], cnxt[kCtTM];
-    __shared__ double cv[kCtTM];
+    __shared__ int s_erow[kLdsNE], s_eslot[kLdsNE];
+    __shared__ double s_eval[kLdsNE];
+    __shared__ int s_srow[kLdsNS], s_scnt[kLdsNS], s_srank[kLdsNS], s_sridx[kLdsNS], s_cand[kLdsNS], s_crank[kLdsNS], s_keptslot[kLdsNS];
+    __shared__ double s_sval[kLdsNS];
+    __shared__ int s_hslot[4 * kLdsNS];
+    __shared__ int s_tk[kLdsTM], s_tx[kLdsTM], s_tt[kLdsTM], s_trem[kLdsTM], s_tnxt[kLdsTM], s_tseq[kLdsTM];
+    __shared__ double s_tv[kLdsTM], s_ordv[kLdsTM];
+    __shared__ int s_cx[kLdsTM], s_crem[kLdsTM], s_cbase[kLdsTM + 1], s_cnxt[kLdsTM];
+    __shared__ double s_cv[kLdsTM];
     __shared__ double tie_mag[2];
+    const int kCtNE = kGlobal ? gNE : kLdsNE, kCtNS = kGlobal ? gNS : kLdsNS, kCtTM = kGlobal ? gTM : kLdsTM;
+    int *erow = s_erow, *eslot = s_eslot, *srow = s_srow, *scnt = s_scnt, *srank = s_srank, *sridx = s_sridx, *cand = s_cand,
+        *crank = s_crank, *keptslot = s_keptslot, *tk = s_tk, *tx = s_tx, *tt = s_tt, *trem = s_trem, *tnxt = s_tnxt, *tseq = s_tseq,
+        *cx = s_cx, *crem = s_crem, *cbase = s_cbase, *cnxt = s_cnxt, *hslot = s_hslot;
+    double *eval = s_eval, *sval = s_sval, *tv = s_tv, *ordv = s_ordv, *cv = s_cv;
+    if (kGlobal) {
+        // slots and their hash: dynamic LDS (doubles first); gathered entries and the touch records of the row: this wave's
+        // slices of a global workspace (streamed / read one element at a time on all lanes -- broadcast loads that pipeline --
+        // and their number grows with the matrix: a row of a matrix with much fill is reached by hundreds of columns)
+        extern __shared__ __attribute__((aligned(16))) unsigned char ict_dyn[];
+        double *d = reinterpret_cast<double *>(ict_dyn);
+        sval = d; d += gNS;
+        int *q = reinterpret_cast<int *>(d);
+        srow = q; q += gNS; scnt = q; q += gNS; srank = q; q += gNS; sridx = q; q += gNS; cand = q; q += gNS; crank = q; q += gNS; keptslot = q; q += gNS;
+        hslot = q; q += 4 * gNS;
+        // gathered entries: behind this wave's touch arrays in the global workspace
+        double *ge = reinterpret_cast<double *>(gws + (size_t)gridDim.x * ict_touch_bytes(gTM) + (size_t)blockIdx.x * ((size_t)gNE * 16));
+        eval = ge; ge += gNE;
+        erow = reinterpret_cast<int *>(ge); eslot = erow + gNE;
+        double *gd = reinterpret_cast<double *>(gws + (size_t)blockIdx.x * ict_touch_bytes(gTM));
+        tv = gd; gd += gTM; ordv = gd; gd += gTM; cv = gd; gd += gTM;
+        int *gq = reinterpret_cast<int *>(gd);
+        tk = gq; gq += gTM; tx = gq; gq += gTM; tt = gq; gq += gTM; trem = gq; gq += gTM; tnxt = gq; gq += gTM; tseq = gq; gq += gTM;
+        cx = gq; gq += gTM; crem = gq; gq += gTM; cbase = gq; gq += gTM + 1; cnxt = gq; gq += gTM;
+    }
 
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -198,43 +240,72 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         }
         __syncthreads();
 
-        // ---- slots in insertion order: a row's slot is created by its first occurrence ----
+        // ---- slots in insertion order: a row's slot is created by its first occurrence (hash: row -> slot + 1) ----
+        const unsigned hmask = (unsigned)(4 * kCtNS - 1);
+        for (int h = lane; h < 4 * kCtNS; h += 64) hslot[h] = 0;
+        __syncthreads();
+        for (int e = lane; e < clen; e += 64) {                        // A's column: distinct rows, slots 0..clen-1
+            unsigned h = ((unsigned)erow[e] * 0x9E3779B1u) >> 7;
+            for (;;) { h &= hmask; if (atomicCAS(&hslot[h], 0, e + 1) == 0) break; ++h; }
+        }
+        __syncthreads();
         int ns = clen;
         for (int base = clen; base < ne; base += 64) {
             const int e = base + lane;
-            bool first = false;
-            int fo = e;
-            if (e < ne) {
-                const int r = erow[e];
-                for (int e2 = 0; e2 < e; ++e2) if (erow[e2] == r) { fo = e2; break; }
-                first = fo == e;
+            const bool act = e < ne;
+            const int r = act ? erow[e] : -1;
+            int sl = -1;
+            if (act) {
+                unsigned h = ((unsigned)r * 0x9E3779B1u) >> 7;
+                for (;;) { h &= hmask; const int v = hslot[h]; if (v == 0) break; if (srow[v - 1] == r) { sl = v - 1; break; } ++h; }
             }
-            const unsigned long long mask = __ballot(first);
-            if (e < ne) {
-                if (first) {
-                    const int s = ns + __popcll(mask & lt_mask);
-                    eslot[e] = s;
-                    if (s < kCtNS) srow[s] = erow[e];
-                } else
-                    eslot[e] = -1 - fo;
+            // rows this batch sees for the first time, in lane order; equal rows share the slot their first lane creates
+            bool need = act && sl < 0;
+            unsigned long long todo = __ballot(need);
+            while (todo != 0ull) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int lr = __shfl(r, leader);
+                const bool same = need && r == lr;
+                if (same) { sl = ns; need = false; }
+                if (lane == leader && ns < kCtNS) {
+                    srow[ns] = lr;
+                    unsigned h = ((unsigned)lr * 0x9E3779B1u) >> 7;
+                    for (;;) { h &= hmask; if (hslot[h] == 0) { hslot[h] = ns + 1; break; } ++h; }
+                }
+                ++ns;
+                todo &= ~__ballot(same);
+                __syncthreads();
             }
-            ns += __popcll(mask);
+            if (act) eslot[e] = sl;
+            if (ns > kCtNS) break;
         }
         ns = __builtin_amdgcn_readfirstlane(ns);
         if (ns > kCtNS) CT_FAIL(1);
         __syncthreads();
-        for (int e = clen + lane; e < ne; e += 64) { const int s = eslot[e]; if (s < 0) { const int s1 = eslot[-1 - s]; eslot[e] = s1; } }
-        __syncthreads();
 
         // ---- accumulate every slot sequentially over the entries, scale by 1/L_jj  (:126-131, :135-141) ----
-        for (int s = lane; s < ns; s += 64) {
-            double v = s < clen ? eval[s] : 0.0;
-            int c = s < clen ? 1 : 0;
-            if (s == 0) v = Ljj;                                                   // :117
-            for (int e = clen; e < ne; ++e) if (eslot[e] == s) { v = v - eval[e]; ++c; }
-            if (s > 0) v = v / Ljj;
-            sval[s] = v; scnt[s] = c; srank[s] = -1;
+        // batches of 64 entries in order; inside a batch the entries of one slot go one after the other, lowest lane first
+        for (int sl = lane; sl < ns; sl += 64) {
+            sval[sl] = sl == 0 ? Ljj : (sl < clen ? eval[sl] : 0.0);                // :117
+            scnt[sl] = sl < clen ? 1 : 0; srank[sl] = -1; crank[sl] = 64;
         }
+        __syncthreads();
+        for (int base = clen; base < ne; base += 64) {
+            const int e = base + lane;
+            bool rem = e < ne;
+            const int sl = rem ? eslot[e] : 0;
+            const double ev = rem ? eval[e] : 0.0;
+            while (__ballot(rem) != 0ull) {
+                if (rem) atomicMin(&crank[sl], lane);
+                __syncthreads();
+                const bool go = rem && crank[sl] == lane;
+                if (go) { sval[sl] = sval[sl] - ev; scnt[sl] += 1; }
+                __syncthreads();
+                if (go) { crank[sl] = 64; rem = false; }
+                __syncthreads();
+            }
+        }
+        for (int sl = 1 + lane; sl < ns; sl += 64) sval[sl] = sval[sl] / Ljj;
         __syncthreads();
 
         // ---- threshold_and_drop(w, list, capj, tau, j, m)  (dropping.hpp:8-34) ----
@@ -289,9 +360,10 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         __syncthreads();
         for (int s = lane; s < ns; s += 64) if (srank[s] >= 0) srank[s] = crank[s];
         __syncthreads();
-        // the reference assumes the diagonal leads the stored column (firstL = pointer+1, ILUC.hpp:43); a dropped
-        // diagonal (NaN column, tiny budget) is left to the sequential kernel
-        if (nk < 1 || __builtin_amdgcn_readfirstlane(srank[0]) != 0) CT_FAIL(1);
+        // the reference assumes the diagonal leads the stored column (firstL = pointer+1, ILUC.hpp:43).  A column that lost
+        // it (the pivot became negative: NaN column; a budget too small to keep it) is reported: the reference goes on and
+        // returns a factor full of NaN / with misplaced "diagonals" for such an input
+        if (nk < 1 || __builtin_amdgcn_readfirstlane(srank[0]) != 0) CT_FAIL(3);
 
         // ---- append  (sparse_implementation.h:3170-3186) ----
         for (int s = lane; s < ns; s += 64)
@@ -356,8 +428,8 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
 {
     const bool small = cls <= 1;
     const int32_t m = Atri.n;
-    if (add_fill_in < 0 || m < 1) return 1;
-    const long slab = (long)Atri.nnz + (long)add_fill_in * (long)m;
+    if (m < 1) return 1;
+    const long slab = (long)Atri.nnz + (long)(add_fill_in > 0 ? add_fill_in : 0) * (long)m;
     if (slab > 0x7fffffffL) return 1;
     long a = slab;                                                      // IChol.hpp:85-87
     long b = (long)((double)Atri.nnz * 10.0);
@@ -367,7 +439,10 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     // touch-record capacity per row: the number of reaches of a row is about the length of a pre-drop column
     const long avg = Atri.nnz / m + 1;
     int T = 16;
-    while (T < 4 * (avg + add_fill_in) && T < kCtTmax) T *= 2;
+    const int Tlimit = cls == 3 ? (1 << 16) : kCtTmax;
+    while (T < 4 * (avg + (add_fill_in > 0 ? add_fill_in : 0)) && T < Tlimit) T *= 2;
+    // largest class: as many touch records per row as the matrix can need (every column may reach a row), within 8 GB
+    if (cls == 3) { while (T < Tlimit && T < m && (size_t)m * T * 2 * 32 <= ((size_t)8 << 30)) T *= 2; }
     if (cls == 1 && T > kCtTsmall) return 1;
     if (cls == 0 && T > kCtTtiny) return 1;
     while (T > 16 && ((long)m * T > 0x7fffffffL || (size_t)m * T * 32 > ((size_t)96 << 30))) T /= 2;
@@ -404,6 +479,23 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     ILUPP_HIP(hipMemcpyAsync(ctrl + 3, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
     int waves = device_cu_count() * (cls == 0 ? 24 : (cls == 1 ? 12 : 3));
     if (waves > m) waves = m;
+    // largest class: one wave per CU, working arrays in a dynamic LDS allocation
+    unsigned char *gws = nullptr;
+    int gNE = 0, gNS = 0, gTM = 0;
+    size_t dyn_bytes = 0;
+    if (cls == 3) {
+        gTM = T; gNS = 2048; gNE = 1 << 18;
+        dyn_bytes = ict_lds_bytes(gNS);
+        waves = device_cu_count();
+        if (waves > m) waves = m;
+        ILUPP_HIP(pool_malloc(&gws, (ict_touch_bytes(gTM) + (size_t)gNE * 16) * (size_t)waves));
+        static std::once_flag once[64];
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_icholt_df<1, 1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        });
+    }
     const int nq = waves < kCtQ ? waves : kCtQ;
     const int gb = (m + 255) / 256;
     hipLaunchKernelGGL(k_ict_prep, dim3(gb), dim3(256), 0, st, m, Atri.ptr, Atri.idx, add_fill_in, cap, pending, ctrl);
@@ -420,15 +512,16 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
     ILUPP_HIP(hipEventRecord(e0, st));
+#define ICT_ARGS m, Atri.ptr, Atri.idx, Atri.val, add_fill_in, threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl, gws, gNE, gNS, gTM
     if (cls == 0)
-        hipLaunchKernelGGL((k_icholt_df<128, 64, kCtTtiny>), dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in,
-                           threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
+        hipLaunchKernelGGL((k_icholt_df<128, 64, kCtTtiny, false>), dim3(waves), dim3(64), 0, st, ICT_ARGS);
     else if (small)
-        hipLaunchKernelGGL((k_icholt_df<256, 128, kCtTsmall>), dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in,
-                           threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
+        hipLaunchKernelGGL((k_icholt_df<256, 128, kCtTsmall, false>), dim3(waves), dim3(64), 0, st, ICT_ARGS);
+    else if (cls == 2)
+        hipLaunchKernelGGL((k_icholt_df<1024, 512, kCtTmax, false>), dim3(waves), dim3(64), 0, st, ICT_ARGS);
     else
-        hipLaunchKernelGGL((k_icholt_df<1024, 512, kCtTmax>), dim3(waves), dim3(64), 0, st, m, Atri.ptr, Atri.idx, Atri.val, add_fill_in,
-                           threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl);
+        hipLaunchKernelGGL((k_icholt_df<1, 1, 1, true>), dim3(waves), dim3(64), dyn_bytes, st, ICT_ARGS);
+#undef ICT_ARGS
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t h[4];
@@ -438,7 +531,10 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     ILUPP_HIP(hipEventDestroy(e0));
     ILUPP_HIP(hipEventDestroy(e1));
     int rc = ILUPP_OK;
+    if (gws) ILUPP_HIP(pool_free(gws));
     if (h[3] != big) rc = ILUPP_ERR_NOT_TRIANGULAR;
+    else if (h[2] == 3) rc = ILUPP_ERR_NOT_SPD;          // a column lost its diagonal: not positive definite (or a budget below 1)
+    else if (h[2] == 2) rc = ILUPP_ERR_TIMEOUT;
     else if (h[2] != 0) rc = 1;
     if (rc == ILUPP_OK) {
         size_t tb = 0;
@@ -467,11 +563,14 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     return rc;
 }
 
-// returns ILUPP_OK / an error of the reference / +1 = "not handled here, run the sequential kernel"
+// returns ILUPP_OK / an error; the capacity classes are tried from the one with the most resident waves to the one that
+// takes the whole LDS of a CU per wave; +1 when a working column does not fit even there
 int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms)
 {
     int rc = 1;
-    for (int cls = 0; cls < 3 && rc == 1; ++cls) rc = icholt_attempt(st, Atri, add_fill_in, threshold, L, kernel_ms, cls);
+    const char *force = getenv("ILUPP_ICHOLT_CLASS");                  // tests: start with a given class
+    const int first = force ? atoi(force) : 0;
+    for (int cls = first; cls < 4 && rc == 1; ++cls) rc = icholt_attempt(st, Atri, add_fill_in, threshold, L, kernel_ms, cls);
     return rc;
 }
 

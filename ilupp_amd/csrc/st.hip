@@ -44,7 +44,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 static constexpr int kStH = 8;                 // steps of hand-off history kept in LDS = steps the streams are read ahead
-static constexpr int kStP = 4;                 // steps ahead the values of earlier workgroups are polled (at most 2 per lane)
+#ifndef ST_P
+#define ST_P 4
+#endif
+static constexpr int kStP = ST_P;                 // steps ahead the values of earlier workgroups are polled (at most 2 per lane)
 static constexpr int kStMaxSkew = 30000;
 static constexpr unsigned kStSpinLimit = 1u << 21;
 static constexpr int64_t kStMaxChunks = 1 << 21;      // record offsets are 32-bit byte offsets
@@ -489,6 +492,7 @@ __device__ __forceinline__ StLane st_lane(const int32_t *T, int t)
 #ifdef ST_STAMP
 // diagnostics build only: cycles of the first wave of the LAST workgroup, summed over its steps, per segment of a step
 __device__ unsigned long long g_st_stamp[32];
+__device__ unsigned long long g_st_tl[4096 * 4];     // per workgroup of the forward sweep: entry, first row done, last row done, exit (100 MHz)
 #define ST_T(i) do { if (stamp_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_[i] += n_ - last_; last_ = __builtin_amdgcn_s_memtime(); } } while (0)
 #define ST_T_DECL(cond) const bool stamp_on = (cond); unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_amdgcn_s_memtime(); unsigned long long nst_ = 0
 #define ST_T_END(off) do { if (stamp_on && ln == 0) { for (int i_ = 0; i_ < 8; ++i_) g_st_stamp[(off) + i_] = acc_[i_]; g_st_stamp[(off) + 8] = nst_; } } while (0)
@@ -790,6 +794,9 @@ k_sptrsv_st(StSArgs A)
     }
     bool dead = false;
     ST_T_DECL(wv == 0 && wg == (int)gridDim.x - 1);
+#ifdef ST_STAMP
+    if (DR > 0 && t == 0 && wg < 4096) g_st_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int tb = tlo; tb < thi; tb += kStH) {
         const int kb = tb - sk;
@@ -798,6 +805,10 @@ k_sptrsv_st(StSArgs A)
             const int k = kb + u;
             const bool valid = (unsigned)k < (unsigned)cnt;
             const int r = first + DR * k;
+#ifdef ST_STAMP
+            if (DR > 0 && t == 0 && wg < 4096 && k == 1) g_st_tl[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            if (DR > 0 && t == 255 && wg < 4096 && k == cnt - 1) g_st_tl[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef ST_STAMP
             ++nst_;
 #endif
@@ -885,6 +896,9 @@ k_sptrsv_st(StSArgs A)
 #undef STS_LOAD
 #undef STS_POLL
     ST_T_END(DR > 0 ? 10 : 20);
+#ifdef ST_STAMP
+    if (DR > 0 && t == 0 && wg < 4096) g_st_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (dead && ln == 0) atomicExch(A.err, 1);
 }
 
@@ -1117,6 +1131,7 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
 
 #ifdef ST_STAMP
 void st_read_stamps(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_stamp), sizeof(unsigned long long) * 32)); }
+void st_read_tl(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_tl), sizeof(unsigned long long) * 4096 * 4)); }
 #endif
 
 }  // namespace ilupp
@@ -1125,6 +1140,11 @@ void st_read_stamps(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out
 extern "C" int ilupp_hip_debug_stamps(unsigned long long *out)
 {
     try { ilupp::st_read_stamps(out); } catch (...) { return -1; }
+    return 0;
+}
+extern "C" int ilupp_hip_debug_timeline(unsigned long long *out)
+{
+    try { ilupp::st_read_tl(out); } catch (...) { return -1; }
     return 0;
 }
 #endif

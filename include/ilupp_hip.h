@@ -35,7 +35,9 @@ typedef enum {
     ILUPP_ERR_HIP = -6,            /* HIP runtime failure */
     ILUPP_ERR_TIMEOUT = -7,        /* dependency wait exceeded its bound (cyclic/invalid structure) */
     ILUPP_ERR_UNSUPPORTED = -8,    /* path not built yet in this round */
-    ILUPP_ERR_MEMORY = -9          /* sparse_implementation.h:3178-3179 "insufficient memory reserved" */
+    ILUPP_ERR_MEMORY = -9,         /* sparse_implementation.h:3178-3179 "insufficient memory reserved" */
+    ILUPP_ERR_NOT_SPD = -10        /* ICholT: a column lost its diagonal (indefinite input / budget below one entry); the reference
+                                      returns a NaN-filled factor for such input (IChol.hpp:115-117 has no positivity check) */
 } ilupp_status;
 
 /* binding.cpp:279  m.def("index_size") -> sizeof(Integer) */

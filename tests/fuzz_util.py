@@ -50,20 +50,25 @@ def run(nseeds, first_seed=0, verbose=True):
                 bad += 1; print('ILUT MISMATCH seed', seed, fmt, n, fill, tau, flush=True)
             add = int(rng.choice([0, 1, 2, 5, 9, 40])); tau = float(rng.choice([0.0, 1e-6, 1e-3, 0.05, 0.3]))
             Lo = orc.icholt(Ms, add, tau)
-            P = ilupp.ICholTPreconditioner(Sf.copy(), add_fill_in=add, threshold=tau)
+            # a column of the reference's factor that does not start with its diagonal (dropped, or the whole column empty: the
+            # pivot's square root was NaN) = indefinite input or a budget below one entry: the engine reports it instead of
+            # returning the reference's NaN-filled factor (deviations)
+            lens = np.diff(Lo[2])
+            lost = bool(np.any(lens == 0)) or bool(np.any(Lo[1][Lo[2][:-1][lens > 0]] != np.arange(n)[lens > 0]))
+            try:
+                P = ilupp.ICholTPreconditioner(Sf.copy(), add_fill_in=add, threshold=tau)
+            except RuntimeError as e:
+                if not (lost and 'lost its diagonal' in str(e)):
+                    bad += 1; print('ICHOLT UNEXPECTED ERROR seed', seed, fmt, n, add, tau, e, flush=True)
+                continue
+            if lost:
+                bad += 1; print('ICHOLT MISSING ERROR seed', seed, fmt, n, add, tau, flush=True)
+                continue
             L, = P.factors()
             b = np.cos(np.arange(n, dtype=np.float64)) + 1.5
-            x = b.copy()
-            try:
-                P.apply(x)
-            except RuntimeError as e:
-                bad += 1; print('ICHOLT APPLY ERROR seed', seed, fmt, n, add, tau, 'empty cols', int(np.sum(np.diff(Lo[2]) == 0)), 'nan', int(np.isnan(Lo[0]).sum()), e, flush=True)
-                continue
-            # (dropped diagonals and empty columns -- indefinite matrices -- go through the reference's positional loops verbatim; only an
-            # empty LAST column makes the reference read out of bounds: not compared)
-            degenerate = bool(Lo[2][-1] == Lo[2][-2]) if n > 0 else False      # (only a trailing empty column: that read is out of bounds)
+            x = b.copy(); P.apply(x)
             if not (np.array_equal(L.indptr, Lo[2]) and np.array_equal(L.indices, Lo[1]) and np.array_equal(L.data, Lo[0], equal_nan=True)
-                    and (degenerate or np.array_equal(x, orc.apply_llt(Lo, b, O.ID), equal_nan=True))):
+                    and np.array_equal(x, orc.apply_llt(Lo, b, O.ID), equal_nan=True)):
                 bad += 1; print('ICHOLT MISMATCH seed', seed, fmt, n, add, tau, flush=True)
     if verbose:
         print('fuzz: %d seeds, %d mismatches' % (nseeds, bad))

@@ -595,7 +595,7 @@ def _with_env(name, value, f):
 @pytest.mark.parametrize("case", ["grid_40", "grid_ragged", "rand_spd", "rand_spd_dense_rows", "chain"])
 def test_icholt_dataflow_vs_oracle_seeded(case):
     """value-dependent patterns, reaches from dropped entries, linked-list order, ties: bit-exact against the oracle, for
-    both kernels (dataflow = default, sequential = ILUPP_ICHOLT_SEQUENTIAL=1) and both input orientations"""
+    the LDS capacity classes and the largest capacity class (ILUPP_ICHOLT_CLASS=3) and both input orientations"""
     import ilupp_amd as ilupp
     from oracle import oracle as O
     orc = O.orc()
@@ -626,10 +626,11 @@ def test_icholt_dataflow_vs_oracle_seeded(case):
             x = b.copy(); P.apply(x)
             assert np.array_equal(x, orc.apply_llt(Lo, b, O.ID), equal_nan=True)
             if fmt == "csr":
-                Ps = _with_env("ILUPP_ICHOLT_SEQUENTIAL", "1",
+                # the largest capacity class of the same kernel (one wave per CU, the whole LDS for its working arrays)
+                Ps = _with_env("ILUPP_ICHOLT_CLASS", "3",
                                lambda: ilupp.ICholTPreconditioner(_scipy(M), add_fill_in=a, threshold=t))
                 Ls, = Ps.factors()
-                assert G.mat_equal(_fac(Ls), Lo), (case, "sequential", a, t)
+                assert G.mat_equal(_fac(Ls), Lo), (case, "largest capacity class", a, t)
 
 
 @pytest.mark.parametrize("case", ["grid_24", "rand_20k", "rand_long_rows", "wide_budget", "budget_one"])
