@@ -500,15 +500,6 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
         }
     } else {
         // LL^T: apply == apply_trans (preconditioner_implementation.h:381-394)
-        if (p->degenerate && !p->llt_diag_last) {
-            // misplaced or missing diagonals (indefinite matrix): the reference's positional loops, verbatim
-            ILUPP_HIP(hipEventRecord(p->ev[0], st));
-            llt_apply_positional(st, p->Lc, x);
-            ILUPP_HIP(hipEventRecord(p->ev[1], st));
-            ILUPP_HIP(hipEventRecord(p->ev[2], st));
-            p->apply_events_valid = true;
-            return ILUPP_OK;
-        }
         ensure_transposed(p);
         if (p->llt_diag_last) {       // IChol0: T1(L) then T4(L)
             const PackedSweep *p1 = packed(p, 0, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), &p->pkL);

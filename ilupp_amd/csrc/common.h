@@ -261,7 +261,6 @@ enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRS
 int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
            int32_t max_row_len, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
-void llt_apply_positional(hipStream_t st, const DevMat &Lc, double *x);
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
 // sptrsv_lm.hip

@@ -982,36 +982,6 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
     return ILUPP_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// L L^T apply of a factor whose diagonals are not where the solves take them from (ICholT of an indefinite matrix: a
-// diagonal that was dropped, a column that lost all its entries).  The reference's loops are purely positional
-// (sparse_implementation.h:4059-4063 forward scatter, :4069-4072 backward gather on the column-major factor), and what
-// they compute then depends on that -- so this is those two loops verbatim, on one lane.  Garbage in, the reference's
-// garbage out; nothing here is fast and nothing needs to be.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_llt_apply_positional(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-                                       const double *__restrict__ val, int64_t nnz, double *x)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const double qnan = __longlong_as_double((long long)kCanonNaN);
-    for (int k = 0; k < n; ++k) {                                   // T2: x_k /= d_first; x[idx_j] -= d_j * x_k
-        const double d = ptr[k] < nnz ? val[ptr[k]] : qnan;          // (the reference reads past the end here)
-        const double xk = x[k] / d;
-        x[k] = xk;
-        for (int j = ptr[k] + 1; j < ptr[k + 1]; ++j) { const double prod = val[j] * xk; x[idx[j]] = x[idx[j]] - prod; }
-    }
-    for (int k = n - 1; k >= 0; --k) {                              // T3: x_k -= sum d_j x[idx_j] (j > first); x_k /= d_first
-        double xk = x[k];
-        for (int j = ptr[k] + 1; j < ptr[k + 1]; ++j) { const double prod = val[j] * x[idx[j]]; xk = xk - prod; }
-        const double d = ptr[k] < nnz ? val[ptr[k]] : qnan;
-        x[k] = xk / d;
-    }
-}
-void llt_apply_positional(hipStream_t st, const DevMat &Lc, double *x)
-{
-    hipLaunchKernelGGL(k_llt_apply_positional, dim3(1), dim3(64), 0, st, Lc.n, Lc.ptr, Lc.idx, Lc.val, (int64_t)Lc.nnz, x);
-}
-
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err)
 {
     const unsigned grid = (unsigned)((M.n + kRowsBlock - 1) / kRowsBlock);
