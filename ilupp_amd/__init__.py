@@ -19,9 +19,19 @@ import numpy as np
 import scipy.sparse as _sp
 from scipy.sparse.linalg import LinearOperator as _LinearOperator
 
+import os as _os
+
 from . import _native
 
 __version__ = "0.2.0"
+
+# Which binding of the C ABI builds the objects: the ctypes one (`_native`, default: it also carries the device-pointer entry
+# points) or the compiled pybind11 shim (`_ilupp_hip`, ilupp_amd/csrc/pybind_module.cpp: the module a maintainer of the reference
+# would ship in place of `ilupp._ilupp`).  Same factory signatures, same object members.
+if _os.environ.get("ILUPP_AMD_BINDING", "ctypes") == "pybind":
+    from . import _ilupp_hip as _backend
+else:
+    _backend = _native
 
 # index width of the compiled engine (the reference's `Integer`; binding.cpp:279)
 _INDEX_DTYPES = {4: np.dtype(np.int32), 8: np.dtype(np.int64)}
@@ -113,46 +123,46 @@ class ILUTPreconditioner(_HipPreconditioner):
     """ILUT (Saad): at most `fill_in` entries per row of L and of U, relative drop `threshold`."""
 
     def __init__(self, A, fill_in=100, threshold=0.1):
-        super().__init__(A, lambda m: _native.ILUTPreconditioner(*m, fill_in, threshold))
+        super().__init__(A, lambda m: _backend.ILUTPreconditioner(*m, fill_in, threshold))
 
 
 class ILU0Preconditioner(_HipPreconditioner):
     """ILU(0): incomplete LU in the pattern of A."""
 
     def __init__(self, A):
-        super().__init__(A, lambda m: _native.ILU0Preconditioner(*m))
+        super().__init__(A, lambda m: _backend.ILU0Preconditioner(*m))
 
 
 class IChol0Preconditioner(_HipPreconditioner):
     """IChol(0) of a symmetric positive definite matrix, in the pattern of its lower triangle."""
 
     def __init__(self, A):
-        super().__init__(A, lambda m: _native.IChol0Preconditioner(*m))
+        super().__init__(A, lambda m: _backend.IChol0Preconditioner(*m))
 
 
 class ICholTPreconditioner(_HipPreconditioner):
     """Incomplete Cholesky with `add_fill_in` extra entries per column and relative drop `threshold`."""
 
     def __init__(self, A, add_fill_in=0, threshold=0.0):
-        super().__init__(A, lambda m: _native.ICholTPreconditioner(*m, add_fill_in, threshold))
+        super().__init__(A, lambda m: _backend.ICholTPreconditioner(*m, add_fill_in, threshold))
 
 
 # ---- stand-alone factor functions ---------------------------------------------------------------
 def ichol0(A):
     """L of an incomplete Cholesky decomposition without fill-in."""
-    return _as_scipy(_native.ichol0(*_borrow(A)))
+    return _as_scipy(_backend.ichol0(*_borrow(A)))
 
 
 def icholt(A, add_fill_in=0, threshold=0.0):
     """L of an incomplete Cholesky decomposition with thresholding."""
-    return _as_scipy(_native.icholt(*_borrow(A), add_fill_in, threshold))
+    return _as_scipy(_backend.icholt(*_borrow(A), add_fill_in, threshold))
 
 
 def ilu0(A):
     """(L, U) of an incomplete LU decomposition without fill-in."""
-    return tuple(_as_scipy(f) for f in _native.ilu0(*_borrow(A)))
+    return tuple(_as_scipy(f) for f in _backend.ilu0(*_borrow(A)))
 
 
 def ilut(A, fill_in=100, threshold=0.1):
     """(L, U) of an incomplete LU decomposition with thresholding."""
-    return tuple(_as_scipy(f) for f in _native.ilut(*_borrow(A), fill_in, threshold))
+    return tuple(_as_scipy(f) for f in _backend.ilut(*_borrow(A), fill_in, threshold))

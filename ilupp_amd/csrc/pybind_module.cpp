@@ -1,0 +1,174 @@
+// ilupp_amd/csrc/pybind_module.cpp -- the pybind11 shim over the C ABI (include/ilupp_hip.h): a compiled module with the
+// surface of the reference's `ilupp._ilupp` for the hot path (src/binding.cpp:233-264 object members, :279 index_size,
+// :299-310 ILUTPreconditioner, :366-397 the ILU0 / IChol0 / ICholT factories, :399-447 the stand-alone factor functions).
+// Host code only: buffer checks, GIL handling, numpy egress; all arithmetic happens behind the C ABI on the GPU.
+//   g++ -O2 -shared -fPIC $(python3 -m pybind11 --includes) pybind_module.cpp -L.. -lilupp_hip -Wl,-rpath,'$ORIGIN'
+//       -o ../_ilupp_hip$(python3-config --extension-suffix)
+#include <pybind11/pybind11.h>
+#include <pybind11/numpy.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/ilupp_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+[[noreturn]] void fail(int) { throw std::runtime_error(ilupp_hip_last_error()); }       // pybind11: std::exception -> RuntimeError
+inline void ok(int rc) { if (rc) fail(rc); }
+
+// what make_matrix / make_vector demand of a buffer (binding.cpp:33-98), with the reference's messages
+py::buffer_info flat(const py::buffer &b, const char *name)
+{
+    py::buffer_info info = b.request();
+    if (info.ndim != 1) throw std::runtime_error(std::string("Expected 1D array for ") + name + "!");
+    if (info.strides[0] != info.itemsize) throw std::runtime_error(std::string("Expected contiguous array for ") + name + "!");
+    return info;
+}
+py::buffer_info reals(const py::buffer &b, const char *name)
+{
+    py::buffer_info info = flat(b, name);
+    if (info.format != py::format_descriptor<double>::format())
+        throw std::runtime_error(std::string("Expected d (d) array for ") + name + ", got " + info.format + "!");
+    return info;
+}
+py::buffer_info ints(const py::buffer &b, const char *name)
+{
+    py::buffer_info info = flat(b, name);
+    const bool integral = info.format.size() == 1 && std::string("ilq").find(info.format[0]) != std::string::npos;
+    if (!integral || info.itemsize != (py::ssize_t)sizeof(int32_t))
+        throw std::runtime_error(std::string("Expected integer type with length 4 for ") + name + ", got " + info.format + "!");
+    return info;
+}
+
+struct Csr { const double *val; const int32_t *idx, *ptr; int32_t n; int row_major; };
+Csr borrow(const py::buffer &data, const py::buffer &indices, const py::buffer &indptr, bool is_csr)
+{
+    const py::buffer_info d = reals(data, "A_data"), i = ints(indices, "A_indices"), p = ints(indptr, "A_indptr");
+    if (p.shape[0] <= 1) throw std::runtime_error("matrix has size 0!");
+    if (i.shape[0] != d.shape[0]) throw std::runtime_error("indices and data should have the same size!");
+    return Csr{static_cast<const double *>(d.ptr), static_cast<const int32_t *>(i.ptr), static_cast<const int32_t *>(p.ptr),
+               (int32_t)(p.shape[0] - 1), is_csr ? 1 : 0};
+}
+
+// a factorisation in HBM; LU and LLT are distinct Python classes like the reference's Generic*Preconditioner
+struct Factorisation {
+    ilupp_precond *h = nullptr;
+    Factorisation() = default;
+    Factorisation(const Factorisation &) = delete;
+    Factorisation(Factorisation &&o) noexcept : h(o.h) { o.h = nullptr; }
+    ~Factorisation() { if (h) ilupp_hip_destroy(h); }
+};
+struct LU : Factorisation { using Factorisation::Factorisation; };
+struct LLT : Factorisation { using Factorisation::Factorisation; };
+struct ILUT : Factorisation { using Factorisation::Factorisation; };
+
+template <class Make>
+ilupp_precond *build(Make make)
+{
+    ilupp_precond *h = nullptr;
+    int rc;
+    {
+        py::gil_scoped_release release;              // factorisation runs without the GIL (binding.cpp:371)
+        rc = make(&h);
+    }
+    ok(rc);
+    return h;
+}
+
+py::list egress(const Factorisation &f)
+{
+    py::list out;
+    const int nf = ilupp_hip_num_factors(f.h);
+    for (int k = 0; k < nf; ++k) {
+        int32_t rows = 0, cols = 0; int64_t nnz = 0; int row_major = 1;
+        ok(ilupp_hip_factor_info(f.h, k, &rows, &cols, &nnz, &row_major));
+        py::array_t<double> data(nnz);
+        py::array_t<int32_t> indices(nnz), indptr(rows + 1);
+        ok(ilupp_hip_factor_copy(f.h, k, data.mutable_data(), indices.mutable_data(), indptr.mutable_data()));
+        out.append(py::make_tuple(data, indices, indptr, row_major != 0, rows, cols));
+    }
+    return out;
+}
+
+void solve_in_place(const Factorisation &f, const py::buffer &x, bool transposed)
+{
+    py::buffer_info v = reals(x, "b");
+    if (v.readonly) throw std::runtime_error("b must be writable");
+    if (v.shape[0] != ilupp_hip_dimension(f.h)) throw std::runtime_error("vector has wrong size for preconditioner!");
+    ok(transposed ? ilupp_hip_apply_trans(f.h, static_cast<double *>(v.ptr), v.shape[0])
+                  : ilupp_hip_apply(f.h, static_cast<double *>(v.ptr), v.shape[0]));       // GIL held, as binding.cpp:237-254
+}
+
+template <class T>
+py::class_<T> members(py::module_ &m, const char *name)
+{
+    return py::class_<T>(m, name)
+        .def("apply", [](const T &f, py::buffer x) { solve_in_place(f, x, false); })
+        .def("apply_trans", [](const T &f, py::buffer x) { solve_in_place(f, x, true); })
+        .def_property_readonly("total_nnz", [](const T &f) { return ilupp_hip_total_nnz(f.h); })
+        .def("factors_info", [](const T &f) { return egress(f); })
+        .def_property_readonly("memory_used_calculations", [](const T &f) { return ilupp_hip_memory_used_calculations(f.h); })
+        .def_property_readonly("memory_allocated_calculations", [](const T &f) { return ilupp_hip_memory_allocated_calculations(f.h); })
+        .def_property_readonly("memory", [](const T &f) { return ilupp_hip_memory(f.h); })
+        .def_property_readonly("exists", [](const T &f) { return ilupp_hip_exists(f.h) != 0; })
+        .def_property_readonly("special_info", [](const T &f) { return std::string(ilupp_hip_special_info(f.h)); })
+        .def("print_info", [](const T &f) { ilupp_hip_print_info(f.h); });
+}
+
+template <class T> T adopt(ilupp_precond *h) { T t; t.h = h; return t; }
+
+}  // namespace
+
+PYBIND11_MODULE(_ilupp_hip, m)
+{
+    m.doc() = "MI355X backend of the ilupp preconditioners (pybind11 shim over the C ABI of include/ilupp_hip.h)";
+    m.def("index_size", []() { return ilupp_hip_index_size(); });
+    m.def("device_count", []() { return ilupp_hip_device_count(); });
+
+    members<LU>(m, "GenericLUPreconditioner");
+    members<LLT>(m, "GenericLLTPreconditioner");
+    members<ILUT>(m, "ILUTPreconditioner")
+        .def(py::init([](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t max_fill_in, double threshold) {
+            const Csr a = borrow(data, indices, indptr, is_csr);
+            return adopt<ILUT>(build([&](ilupp_precond **h) { return ilupp_hip_ilut_create(a.val, a.idx, a.ptr, a.n, a.row_major, max_fill_in, threshold, h); }));
+        }));
+
+    m.def("ILU0Preconditioner", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr) {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        return adopt<LU>(build([&](ilupp_precond **h) { return ilupp_hip_ilu0_create(a.val, a.idx, a.ptr, a.n, a.row_major, h); }));
+    });
+    m.def("IChol0Preconditioner", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr) {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        return adopt<LLT>(build([&](ilupp_precond **h) { return ilupp_hip_ichol0_create(a.val, a.idx, a.ptr, a.n, a.row_major, h); }));
+    });
+    m.def("ICholTPreconditioner", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t add_fill_in, double threshold) {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        return adopt<LLT>(build([&](ilupp_precond **h) { return ilupp_hip_icholt_create(a.val, a.idx, a.ptr, a.n, a.row_major, add_fill_in, threshold, h); }));
+    });
+
+    // stand-alone factor functions: build, hand the factors out, drop the object
+    m.def("ilu0", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr) {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        const LU f = adopt<LU>(build([&](ilupp_precond **h) { return ilupp_hip_ilu0_create(a.val, a.idx, a.ptr, a.n, a.row_major, h); }));
+        return py::tuple(egress(f));
+    });
+    m.def("ilut", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t fill_in, double threshold) {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        const ILUT f = adopt<ILUT>(build([&](ilupp_precond **h) { return ilupp_hip_ilut_create(a.val, a.idx, a.ptr, a.n, a.row_major, fill_in, threshold, h); }));
+        return py::tuple(egress(f));
+    });
+    m.def("ichol0", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr) -> py::object {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        const LLT f = adopt<LLT>(build([&](ilupp_precond **h) { return ilupp_hip_ichol0_create(a.val, a.idx, a.ptr, a.n, a.row_major, h); }));
+        return py::object(egress(f)[0]);
+    });
+    m.def("icholt", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t add_fill_in, double threshold) -> py::object {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        const LLT f = adopt<LLT>(build([&](ilupp_precond **h) { return ilupp_hip_icholt_create(a.val, a.idx, a.ptr, a.n, a.row_major, add_fill_in, threshold, h); }));
+        return py::object(egress(f)[0]);
+    });
+}

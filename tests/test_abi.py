@@ -69,3 +69,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower().replace("no cpu fallback", ""), f
+
+
+def test_pybind11_shim_surface_and_validation():
+    """the compiled pybind11 shim over the C ABI (ilupp_amd/csrc/pybind_module.cpp): the names of the reference's `_ilupp`
+    for this path, and the buffer checks of binding.cpp:33-98 with the reference's messages (raised before any GPU call)"""
+    from ilupp_amd import _ilupp_hip as m
+    for name in ("index_size", "ILU0Preconditioner", "IChol0Preconditioner", "ICholTPreconditioner", "ILUTPreconditioner",
+                 "GenericLUPreconditioner", "GenericLLTPreconditioner", "ilu0", "ilut", "ichol0", "icholt"):
+        assert hasattr(m, name), name
+    assert m.index_size() == 4
+    for member in ("apply", "apply_trans", "total_nnz", "factors_info", "memory_used_calculations",
+                   "memory_allocated_calculations", "memory", "exists", "special_info", "print_info"):
+        assert hasattr(m.GenericLUPreconditioner, member) and hasattr(m.ILUTPreconditioner, member), member
+    d, i, p = np.ones(3), np.arange(3, dtype=np.int32), np.arange(4, dtype=np.int32)
+    with pytest.raises(RuntimeError, match=r"Expected d \(d\) array for A_data, got f!"):
+        m.ILU0Preconditioner(d.astype(np.float32), i, p, True)
+    with pytest.raises(RuntimeError, match="Expected integer type with length 4 for A_indices"):
+        m.ILU0Preconditioner(d, i.astype(np.int64), p, True)
+    with pytest.raises(RuntimeError, match="matrix has size 0!"):
+        m.ILU0Preconditioner(d[:0], i[:0], p[:1], True)
+    with pytest.raises(RuntimeError, match="Expected 1D array"):
+        m.ILU0Preconditioner(np.ones((2, 2)), i, p, True)

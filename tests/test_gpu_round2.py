@@ -391,3 +391,50 @@ def test_device_resident_cg_matches_host_iterates():
     # and it converges: 60 iterations bring the residual down by 1e8
     xs = ild.cg(Ad, torch.from_numpy(b).cuda(), M, maxiter=60).cpu().numpy()
     assert np.linalg.norm(b - A @ xs) <= 1e-8 * np.linalg.norm(b)
+
+
+_PYBIND_SCRIPT = r'''
+import sys
+sys.path[:0] = [%(root)r, %(tests)r]
+import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
+import golden_util as G, matgen
+import ilupp_amd as ilupp
+from oracle import oracle as O
+assert ilupp._backend.__name__.endswith("_ilupp_hip")
+d, i, p = matgen.poisson3d(20)
+n = p.shape[0] - 1
+for fmt in ("csr", "csc"):
+    A = sp.csr_matrix((d, i, p), shape=(n, n)).asformat(fmt)
+    M = (A.data, A.indices, A.indptr, fmt == "csr")
+    P = ilupp.ILU0Preconditioner(A)
+    Lo, Uo = O.orc().ilu0(M)
+    L, U = P.factors()
+    assert G.mat_equal((L.data, L.indices, L.indptr, fmt == "csr"), Lo) and G.mat_equal((U.data, U.indices, U.indptr, fmt == "csr"), Uo)
+    b = G.rhs(n)
+    assert np.array_equal(P @ b, O.orc().apply_lu(Lo, Uo, b, O.ID)) and np.array_equal(P.T @ b, O.orc().apply_lu(Lo, Uo, b, O.TRANSPOSE))
+    assert repr(P) == "<%%dx%%d ILU0Preconditioner with nnz=%%d, dtype=float64>" %% (n, n, P.total_nnz)
+    T = ilupp.ILUTPreconditioner(A, fill_in=5, threshold=0.1)
+    Lt, Ut = O.orc().ilut(M, 5, 0.1)
+    Lg, Ug = T.factors()
+    assert G.mat_equal((Lg.data, Lg.indices, Lg.indptr, fmt == "csr"), Lt) and G.mat_equal((Ug.data, Ug.indices, Ug.indptr, fmt == "csr"), Ut)
+    C = ilupp.ICholTPreconditioner(A, add_fill_in=2, threshold=1e-3)
+    Lc, = C.factors()
+    assert G.mat_equal((Lc.data, Lc.indices, Lc.indptr, False), O.orc().icholt(M, 2, 1e-3))
+    assert G.mat_equal(tuple(getattr(ilupp.ichol0(A), k) for k in ("data", "indices", "indptr")) + (True,), O.orc().ichol0(M))
+    x, info = spla.gmres(A, b, M=P, atol=1e-10)
+    assert info == 0
+try:
+    P.apply(np.ones(n + 1))
+    raise SystemExit("no size check")
+except RuntimeError as e:
+    assert "wrong size" in str(e)
+print("pybind ok")
+'''
+
+
+def test_pybind11_shim_end_to_end():
+    """the whole Python surface on top of the compiled pybind11 shim instead of ctypes (ILUPP_AMD_BINDING=pybind)"""
+    code = _PYBIND_SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    e = dict(os.environ); e["ILUPP_AMD_BINDING"] = "pybind"
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "pybind ok" in r.stdout, r.stdout + r.stderr
