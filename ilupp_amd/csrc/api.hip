@@ -434,8 +434,9 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
 {
     if (p->degenerate) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
     if (ps && ps->valid) {
-        int rc = ps->stat ? sptrsv_st(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc)
-                          : sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc);
+        // (the static sweeps exchange through a buffer of their own: `out` needs no sentinels before and `rhs` none after)
+        if (ps->stat) return sptrsv_st(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc);
+        int rc = sptrsv_lm(p->stream, *ps, sch, p->n, rhs, out, ticket, err, ypk_out, ypk_in, ysrc);
         if (rc) return rc;
         fill_u64(p->stream, reinterpret_cast<unsigned long long *>(rhs), p->n, kSentinel);
         return ILUPP_OK;

@@ -88,6 +88,13 @@ struct PackedSweep {
     bool stat = false;
     int32_t *ltab = nullptr;    // nslots x kStTab ints
     double *dump = nullptr;     // where the stores of lanes without a row go
+    double *xlm = nullptr;      // (forward sweep) the right-hand side in this sweep's level-major order, 64 per chunk
+    int64_t y_chunks = 0;       // (forward sweep) chunks of the backward sweep, in whose order the intermediate vector is stored
+    // exchange between workgroups of a static schedule, step-major: workgroup w's exported lanes (ordinal xe[slot], xw[4w] of
+    // them rounded up to 16) store the value of step s at xch[xw[4w+3] + (s - xw[4w+1]) * xw[4w] + xe]
+    int32_t *xe = nullptr, *xw = nullptr;
+    double *xch = nullptr;
+    int64_t xch_len = 0;
     void release();
 };
 

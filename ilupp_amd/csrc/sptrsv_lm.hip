@@ -52,7 +52,11 @@ void PackedSweep::release()
     if (ybuf) (void)pool_free(ybuf);
     if (ltab) (void)pool_free(ltab);
     if (dump) (void)pool_free(dump);
-    dump = nullptr;
+    if (xlm) (void)pool_free(xlm);
+    if (xe) (void)pool_free(xe);
+    if (xw) (void)pool_free(xw);
+    if (xch) (void)pool_free(xch);
+    dump = nullptr; xlm = nullptr; y_chunks = 0; xe = xw = nullptr; xch = nullptr; xch_len = 0;
     ysrc = nullptr; ybuf = nullptr; ltab = nullptr; stat = false;
     skew = wtab = flags = uslot = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false; linked = false;
 }

@@ -489,6 +489,12 @@ __device__ __forceinline__ StLane st_lane(const int32_t *T, int t)
     return s;
 }
 
+#ifndef ST_STAMP_WG
+#define ST_STAMP_WG -1
+#endif
+#ifndef ST_STAMP_WV
+#define ST_STAMP_WV 0
+#endif
 #ifdef ST_STAMP
 // diagnostics build only: cycles of the first wave of the LAST workgroup, summed over its steps, per segment of a step
 __device__ unsigned long long g_st_stamp[32];
@@ -597,7 +603,7 @@ k_ilu0_st(StFArgs A)
         asm volatile("" ::: "memory");
     }
     bool dead = false;
-    ST_T_DECL(wv == 0 && wg == (int)gridDim.x - 1);
+    ST_T_DECL(wv == ST_STAMP_WV && wg == (ST_STAMP_WG < 0 ? (int)gridDim.x - 1 : ST_STAMP_WG));
 
     for (int tb = tlo; tb < thi; tb += kStH) {
         const int kb = tb - sk;
@@ -702,119 +708,117 @@ k_ilu0_st(StFArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// the sweeps.  DR = +1 forward (rows ascending; the diagonal of L is 1: no division), -1 backward
+// the sweeps.  DR = +1 forward (rows ascending; the diagonal of L is 1: no division), -1 backward.
+// Vectors travel level-major too: a lane reading / writing its own natural-order element is one cache line per lane and
+// instruction -- 64 lines per wave instruction -- and that alone was half of a forward step and a third of a backward one
+// (single tile, 400 steps: 204 us with the natural-order right-hand side, 101 without; backward 195 -> 124 without the
+// natural-order store).  So k_st_gather brings the right-hand side into the forward sweep's order first, the forward sweep
+// stores the intermediate vector in the BACKWARD sweep's order (each lane knows where its rows sit there), the backward sweep
+// reads and overwrites it in place, and k_st_scatter takes the result back to natural order.  Natural-order stores are left
+// for the lanes other workgroups read (write-through, the data is the flag).
 // ---------------------------------------------------------------------------------------------
 struct StSArgs {
     const v2d *pk;                            // 2 x 64 x 16 B per chunk: {v0,v1}{v2,vdiag}, dependencies in accumulation order
     const int32_t *ltab, *wtab;
-    int32_t n, nchY;                          // nchY: the first spare chunk of ypk_out (one per wave)
-    const double *rhs;
-    double *out;
-    double *dump;
-    const int32_t *exported;
-    double *ypk_out;                          // the unknowns level-major, 64 per chunk (then only exported lanes write `out`)
-    const double *ypk_in;                     // right-hand side from such a vector written by the opposite sweep
-    const int32_t *ysrc;
+    int32_t n, nchY;                          // nchY: first spare chunk (one per wave) of ylm
+    const double *xlm;                        // forward: right-hand side, level-major in this sweep's order
+    double *ylm;                              // the intermediate vector / the result, level-major in the backward sweep's order
+    const int32_t *xe, *xw;                   // the exchange between workgroups (PackedSweep::xe, xw, xch): all-sentinel before the sweep
+    double *xch;
     int32_t *ticket, *err;
 };
 
-template <int DR, bool YOUT, bool YIN>
-__global__ void __launch_bounds__(kThreads)
-k_sptrsv_st(StSArgs A)
+// Who does what in a workgroup of a sweep: waves 0-3 are the 256 lanes of the schedule, wave 4 is the COURIER.  Unknowns of
+// earlier workgroups ("ghosts") used to be polled, tested and selected by the lanes that need them; that code was 150 of the 200
+// instructions of a step in a wave that has such lanes (a wave64 instruction is 4 cycles: 0.2 us per step, and with the barrier
+// the whole workgroup runs at the pace of that wave) -- a workgroup behind a border ran at half the speed of one without, whatever
+// the poll distance or the kind of load.  Now the courier polls (kStP steps ahead, one (lane, dependency) pair per courier lane,
+// at most 64 per workgroup -- the analysis checks), waits for values not there yet, and puts them into the hand-off array as the
+// values of 64 more lanes "of this step"; to the lanes of the schedule a ghost is just another LDS read at a constant address.
+#ifndef ST_CSLEEP
+#define ST_CSLEEP 1
+#endif
+#ifndef ST_SOLO
+#define ST_SOLO (48 * 1024)
+#endif
+static constexpr int kStSoloLds = ST_SOLO;      // dynamic LDS nobody uses: > 80 KB per workgroup in total
+#ifndef ST_RA
+#define ST_RA 8
+#endif
+static constexpr int kStRA = ST_RA;            // steps the streams of a sweep are read ahead (a multiple of kStH)
+static constexpr int kStRow = kThreads + 64;     // doubles per slot of the hand-off array: the lanes, then the courier's pairs
+static constexpr int kStWgThreads = kThreads + 64;
+
+struct StPair { int idx0, stride, sk, klo, khi; };   // the value of step s is xch[idx0 + s * stride]; the lane's skew; the k = s - sk that have it
+
+// EX: some lane's unknowns are read by later workgroups (a template parameter, not a branch: hipcc's waitcnt pass only counts the
+// memory operations it is sure were issued, so a store inside a branch makes every later wait of a wave that does execute it
+// stricter than meant by one)
+template <int DR, bool EX>
+__device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *xh, const int wg, const unsigned *va, const int tlo, const int thi)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char xh[2 * kStH * kThreads * 8];
-    __shared__ unsigned s_ticket;
-    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(A.ticket, 1);
-    __syncthreads();
-    const int wg = (int)s_ticket;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
     const int slot = wg * kThreads + t;
     const int32_t *T = A.ltab + (size_t)slot * kStTab;
-    const StLane S = st_lane(T, t);
-    const int cnt = S.cnt, sk = S.sk, first = S.first;
-    const int n = A.n;
-    int go0 = 0, go1 = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (S.isg[j]) { if (S.g1[j]) go1 = T[ST_OFF + j]; else go0 = T[ST_OFF + j]; }
-    const bool wave_ghost = __any(S.ng > 0);
+    const int cnt = T[ST_CNT], sk = T[ST_SKEW];
     const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
     const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
               nchw = __builtin_amdgcn_readfirstlane(wt[2]);
-    int tlo = 0x7fffffff, thi = -0x7fffffff;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int32_t *w4 = A.wtab + (size_t)(wg * 4 + q) * 4;
-        const int a = w4[1], b = w4[2];
-        if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
-    }
-    tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
-    if (thi <= tlo) return;
-    tlo &= ~(kStH - 1);
-    const bool exports = cnt > 0 && A.exported[slot] != 0;
-    const bool wave_exports = __any(exports);
-    double *const mydump = A.dump + slot;                               // a dump place per lane (a shared one would be a hot spot)
-    const int ydump = A.nchY + wg * 4 + wv;                             // ... and a spare chunk per wave
-    const int ysrc0 = (YIN && cnt > 0) ? A.ysrc[slot] : 0;
-    const unsigned long long *outb = reinterpret_cast<const unsigned long long *>(A.out);
+    const int xe = A.xe[slot];
+    const bool exports = cnt > 0 && xe >= 0;
+    const int xE = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
+    const int xoff = A.xw[wg * 4 + 3] - A.xw[wg * 4 + 1] * xE + xe;          // + step * xE: where this lane's value of a step goes
     const unsigned char *pr = reinterpret_cast<const unsigned char *>(A.pk) + (size_t)(nchw > 0 ? base : 0) * 2048;
-    unsigned char *py = reinterpret_cast<unsigned char *>(A.ypk_out);
+    // forward: the right-hand side from xlm, chunk by chunk; backward: from ylm at this sweep's own chunks
+    const unsigned char *prr = reinterpret_cast<const unsigned char *>(DR > 0 ? A.xlm : A.ylm) + (size_t)(nchw > 0 ? base : 0) * 512;
+    unsigned char *py = reinterpret_cast<unsigned char *>(A.ylm);
     const unsigned lo16 = (unsigned)ln * 16u, lo8 = (unsigned)ln * 8u;
     const int cmax = nchw > 0 ? nchw - 1 : 0;
+    const int ydump = A.nchY + wg * 4 + wv;                             // spare chunk of this wave (a shared one would be a hot spot)
+    // forward: where the lane's row 0 sits in the backward sweep's order (8-byte units; row k: - 64 k)
+    const int up0 = T[ST_UP0];
+    const int ypos0 = DR > 0 ? (up0 >> 7) * 64 + (up0 & 127) : 0;
 
-    v2d ra[kStH][2];
-    double rr[kStH];
-    unsigned long long gq[kStP][2];
+    v2d ra[kStRA][2];
+    double rr[kStRA];
 
-#define STS_LOAD(u, tp, kq)                                                                                          \
+#define STS_LOAD(u, tp)                                                                                              \
     do {                                                                                                             \
         const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                              \
         const unsigned char *q_ = pr + (size_t)cw_ * 2048;                                                           \
         ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                             \
         ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                      \
-        const int kc_ = st_med3((kq), 0, cnt > 0 ? cnt - 1 : 0);                                                     \
-        rr[u] = YIN ? A.ypk_in[ysrc0 - 64 * kc_] : A.rhs[st_med3(first + DR * kc_, 0, n - 1)];                        \
-    } while (0)
-#define STS_POLL(g, kq)                                                                                              \
-    do {                                                                                                             \
-        const int row_ = first + DR * (kq);                                                                          \
-        if (S.ng > 0) gq[g][0] = ld_agent_u64(outb + st_med3(row_ + go0, 0, n - 1));                                 \
-        if (S.ng > 1) gq[g][1] = ld_agent_u64(outb + st_med3(row_ + go1, 0, n - 1));                                 \
+        rr[u] = __builtin_nontemporal_load(reinterpret_cast<const double *>(prr + (size_t)cw_ * 512 + lo8));         \
     } while (0)
 
 #pragma unroll
-    for (int g = 0; g < kStP; ++g) { gq[g][0] = kSentinel; gq[g][1] = kSentinel; STS_POLL(g, tlo + g - sk); asm volatile("" ::: "memory"); }
-#pragma unroll
-    for (int u = 0; u < kStH; ++u) {
-        STS_LOAD(u, tlo + u, tlo + u - sk);
-        // (the stores of a step, to the dump places: see k_ilu0_st)
-        if (YOUT) __builtin_nontemporal_store(0.0, reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8));
-        else *mydump = 0.0;
+    for (int u = 0; u < kStRA; ++u) {
+        STS_LOAD(u, tlo + u);
+        // (the stores of a step, to the dump places: the waitcnt pass takes the minimum over the way into the loop and its back
+        // edge, so the way in has to look like a pass of the loop -- see k_ilu0_st)
+        __builtin_nontemporal_store(0.0, reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8));
+        if (EX) st_agent_f64(reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8), 0.0);
         asm volatile("" ::: "memory");
     }
-    bool dead = false;
-    ST_T_DECL(wv == 0 && wg == (int)gridDim.x - 1);
+    ST_T_DECL(wv == ST_STAMP_WV && wg == (ST_STAMP_WG < 0 ? (int)gridDim.x - 1 : ST_STAMP_WG));
 #ifdef ST_STAMP
     if (DR > 0 && t == 0 && wg < 4096) g_st_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    for (int tb = tlo; tb < thi; tb += kStH) {
+    for (int tb = tlo; tb < thi; tb += kStRA) {
         const int kb = tb - sk;
 #pragma unroll
-        for (int u = 0; u < kStH; ++u) {
+        for (int u = 0; u < kStRA; ++u) {
             const int k = kb + u;
             const bool valid = (unsigned)k < (unsigned)cnt;
-            const int r = first + DR * k;
 #ifdef ST_STAMP
             if (DR > 0 && t == 0 && wg < 4096 && k == 1) g_st_tl[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
             if (DR > 0 && t == 255 && wg < 4096 && k == cnt - 1) g_st_tl[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef ST_STAMP
             ++nst_;
 #endif
             ST_T(0);
-            const v2d va = ra[u][0], vb = ra[u][1];
-            const double v[3] = {va.x, va.y, vb.x};
+            const v2d va_ = ra[u][0], vb = ra[u][1];
+            const double v[3] = {va_.x, va_.y, vb.x};
             bool pj[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) pj[j] = valid && st_bits(v[j]) != kAbsent;
@@ -826,39 +830,11 @@ k_sptrsv_st(StSArgs A)
             ST_T(1);
             double xs[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) xs[j] = st_lds(xh, S.va[j] + (unsigned)u * (kThreads * 8));
+            for (int j = 0; j < 3; ++j) xs[j] = st_lds(xh, va[j] + (unsigned)(u % kStH) * (kStRow * 8));
 #ifdef ST_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             ST_T(2);
-            if (wave_ghost) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (S.isg[j]) xs[j] = st_dbl(S.g1[j] ? gq[u % kStP][1] : gq[u % kStP][0]);
-                if (!dead) {
-                    unsigned spins = 0;
-                    for (;;) {
-                        bool miss = false;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            if (S.isg[j] && pj[j] && st_bits(xs[j]) == kSentinel) miss = true;
-                        if (!__any(miss)) break;
-                        if (miss) {
-#pragma unroll
-                            for (int j = 0; j < 3; ++j)
-                                if (S.isg[j] && pj[j]) xs[j] = st_dbl(ld_agent_u64(outb + st_med3(r + (S.g1[j] ? go1 : go0), 0, n - 1)));
-                        }
-                        __builtin_amdgcn_s_waitcnt(0x0F70);      // retired here, not at the join (see k_ilu0_st)
-                        __builtin_amdgcn_s_sleep(1);
-                        if ((++spins & 255u) == 0) {
-                            if (spins > kStSpinLimit) atomicExch(A.err, 1);
-                            const int e = ld_agent_i32(A.err);
-                            __builtin_amdgcn_s_waitcnt(0x0F70);
-                            if (spins > kStSpinLimit || e != 0) { dead = true; break; }
-                        }
-                    }
-                }
-            }
             ST_T(3);
             // sequential accumulation in stored order; the division by a diagonal of 1.0 would return the dividend
             double acc = rr[u];
@@ -874,32 +850,183 @@ k_sptrsv_st(StSArgs A)
             asm volatile("" :: "v"(x));
 #endif
             ST_T(4);
-            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)u * (kThreads * 8)) = x;
-            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u + kStH) * (kThreads * 8)) = x;
-            // the stream store happens on every step (lanes / waves without a row store to their dump place); unknowns that
-            // other workgroups read: write-through (the one store of a step that hipcc cannot count on)
-            if (YOUT) {
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u % kStH) * (kStRow * 8)) = x;
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u % kStH + kStH) * (kStRow * 8)) = x;
+            // the stream store happens on every step (lanes / waves without a row store to the wave's spare chunk); unknowns
+            // that other workgroups read: also to the natural-order vector, write-through
+            if (DR > 0) {
+                const unsigned yo = valid ? (unsigned)(ypos0 - 64 * k) * 8u : (unsigned)ydump * 512u + lo8;
+                __builtin_nontemporal_store(x, reinterpret_cast<double *>(py + yo));
+            } else {
                 const int cw = tb + u - tminw;
                 unsigned char *o = py + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ydump) * 512;
                 __builtin_nontemporal_store(x, reinterpret_cast<double *>(o + lo8));
-            } else {
-                double *o = (valid && !exports) ? A.out + r : mydump;
-                *o = x;
             }
-            if (wave_exports) { if (exports && valid) st_agent_f64(A.out + r, x); }
+            if (EX) st_agent_f64((exports && valid) ? A.xch + (xoff + (tb + u) * xE) : reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8), x);
             ST_T(5);
-            STS_LOAD(u, tb + u + kStH, k + kStH);
-            if (wave_ghost) STS_POLL(u % kStP, k + kStP);
+            STS_LOAD(u, tb + u + kStRA);
             ST_T(6);
         }
     }
 #undef STS_LOAD
-#undef STS_POLL
     ST_T_END(DR > 0 ? 10 : 20);
 #ifdef ST_STAMP
     if (DR > 0 && t == 0 && wg < 4096) g_st_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (dead && ln == 0) atomicExch(A.err, 1);
+}
+
+// the courier of a sweep: lane p serves pair p.  src: the exchange the producers write through to (all-sentinel before the
+// sweep); a pair's value for step s is element idx0 + s stride, wanted for klo <= s - sk < khi.
+template <int DR>
+__device__ __forceinline__ void st_sweep_courier(const unsigned long long *src, const unsigned long long *idle, unsigned char *xh, const StPair P,
+                                                 const int tlo, const int thi, int32_t *err)
+{
+    const int ln = threadIdx.x & 63;
+    const unsigned span = (unsigned)(P.khi - P.klo);
+    unsigned long long gq[kStP];
+#define STC_ADDR(k_) ((unsigned)((k_) - P.klo) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
+#pragma unroll
+    for (int g = 0; g < kStP; ++g) { gq[g] = ld_agent_u64(STC_ADDR(tlo + g - P.sk)); asm volatile("" ::: "memory"); }
+    bool dead = false;
+    for (int tb = tlo; tb < thi; tb += kStRA) {
+#pragma unroll
+        for (int u = 0; u < kStRA; ++u) {
+            const int k = tb + u - P.sk;
+            const bool need = (unsigned)(k - P.klo) < span;
+            unsigned long long v = gq[u % kStP];
+            if (!dead) {
+                unsigned spins = 0;
+                while (__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0) {
+                    if (need && v == kSentinel) v = ld_agent_u64(STC_ADDR(k));
+                    __builtin_amdgcn_s_waitcnt(0x0F70);          // retired here, not at the join after the loop
+                    __builtin_amdgcn_s_sleep(ST_CSLEEP);
+                    if ((++spins & 255u) == 0) {
+                        if (spins > kStSpinLimit) atomicExch(err, 1);
+                        const int e = ld_agent_i32(err);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (spins > kStSpinLimit || e != 0) { dead = true; break; }
+                    }
+                }
+            }
+            *reinterpret_cast<unsigned long long *>(xh + (unsigned)(kThreads + ln) * 8 + (unsigned)(u % kStH + kStH) * (kStRow * 8)) = v;
+            gq[u % kStP] = ld_agent_u64(STC_ADDR(k + kStP));
+            ST_BARRIER();
+        }
+    }
+#undef STC_ADDR
+    if (dead && ln == 0) atomicExch(err, 1);
+}
+
+// The pairs of a workgroup, numbered: lane t's ghost dependency j gets the next free index p, its descriptor goes to pairs[p],
+// and the lane reads it like any hand-off value: slot "this step", lane 256 + p.  Returns the dependency's LDS read address.
+// (called by the 256 lanes of the schedule; s_cnt[4]: scratch; *s_total: the number of pairs)
+__device__ __forceinline__ void st_number_pairs(const int32_t *T, const int t, const bool isg[3], const int idx0[3], const int stride[3],
+                                                unsigned va[3], StPair *pairs, int *s_cnt, int *s_total)
+{
+    const int wv = t >> 6;
+    unsigned long long bal[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bal[j] = __builtin_amdgcn_ballot_w64(isg[j]);
+    const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]);
+    if ((t & 63) == 0) s_cnt[wv] = mine;
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < wv; ++q) before += s_cnt[q];
+    if (t == 0) *s_total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (isg[j]) {
+            const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
+            if (p < 64) {
+                StPair d;
+                d.idx0 = idx0[j]; d.stride = stride[j]; d.sk = T[ST_SKEW];
+                d.klo = max(T[ST_KLO + j], 0); d.khi = max(min(T[ST_KHI + j], T[ST_CNT]), d.klo);
+                pairs[p] = d;
+            }
+            va[j] = (unsigned)((kStH * kStRow + kThreads + min(p, 63)) * 8);
+        }
+        before += __popcll(bal[j]);
+    }
+}
+
+template <int DR>
+__global__ void __launch_bounds__(kStWgThreads)
+k_sptrsv_st(StSArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char xh[2 * kStH * kStRow * 8];
+    __shared__ StPair s_pairs[64];
+    __shared__ int s_cnt[4], s_total;
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(A.ticket, 1);
+    __syncthreads();
+    const int wg = (int)s_ticket;
+    const int t = threadIdx.x;
+    int tlo = 0x7fffffff, thi = -0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t *w4 = A.wtab + (size_t)(wg * 4 + q) * 4;
+        const int a = w4[1], b = w4[2];
+        if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
+    }
+    tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
+    if (thi <= tlo) return;
+    tlo &= ~(kStRA - 1);
+    if (t < 64) { StPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.klo = 0; z.khi = 0; s_pairs[t] = z; }
+    if (t < kThreads) {
+        const int slot = wg * kThreads + t;
+        const int32_t *T = A.ltab + (size_t)slot * kStTab;
+        const int nd = T[ST_ND], cnt = T[ST_CNT];
+        bool isg[3]; int idx0[3], stride[3]; unsigned va[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int sw = T[ST_SRC + j];
+            const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
+            const int u = ty == ST_LOCAL ? ((sw >> 2) & 255) : t;
+            const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;          // (own previous row: lane t, one step back)
+            va[j] = (unsigned)(((kStH - dt) * kStRow + u) * 8);
+            isg[j] = ty == ST_GHOST;
+            idx0[j] = 0; stride[j] = 0;
+            if (isg[j]) {
+                // the producer lane's value of ITS step s' = k' + skew' with k' = k + T[ST_KAP + j], k = s - skew
+                const int os = sw >> 2, pw = os >> 8;
+                const int E = A.xw[pw * 4];
+                stride[j] = E;
+                idx0[j] = A.xw[pw * 4 + 3] + (T[ST_KAP + j] + A.ltab[(size_t)os * kStTab + ST_SKEW] - T[ST_SKEW] - A.xw[pw * 4 + 1]) * E + A.xe[os];
+            }
+        }
+        __syncthreads();                                              // (s_pairs zeroed)
+        st_number_pairs(T, t, isg, idx0, stride, va, s_pairs, s_cnt, &s_total);
+        __syncthreads();
+        if (t == 0 && s_total > 64) atomicExch(A.err, 1);             // (the analysis does not let such a schedule through)
+        const bool wave_exports = __any(cnt > 0 && A.xe[slot] >= 0);
+        // (every wave passes the same number of barriers whichever variant it runs)
+        if (wave_exports) st_sweep_wave<DR, true>(A, xh, wg, va, tlo, thi); else st_sweep_wave<DR, false>(A, xh, wg, va, tlo, thi);
+    } else {
+        __syncthreads();
+        __syncthreads();                                              // (the one inside st_number_pairs)
+        __syncthreads();
+        const StPair P = s_pairs[t - kThreads];
+        // (a poll nobody needs goes to a place of this workgroup's own: the same address for the whole chip would be a hot spot)
+        const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
+        st_sweep_courier<DR>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, A.err);
+    }
+}
+
+// natural order <-> level-major order of a sweep (64 per chunk).  A block owns the 64 lanes of one wave x 8 consecutive rows of
+// each; inside a wave 8 lanes x 8 rows: both sides move 64-byte pieces.  TO_LM: xlm <- x; else x <- xlm.
+template <int DR, bool TO_LM>
+__global__ void __launch_bounds__(512)
+k_st_vec(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, double *__restrict__ nat, double *__restrict__ lm)
+{
+    const int w = blockIdx.x;
+    const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
+    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
+    const v4i t0 = *reinterpret_cast<const v4i *>(ltab + (size_t)slot * kStTab);          // first, cnt, skew, nd
+    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
+    if (k >= t0.y) return;
+    const size_t at = ((size_t)wtab[(size_t)w * 4] + (k + t0.z - wtab[(size_t)w * 4 + 1])) * 64 + L;
+    const int r = t0.x + DR * k;
+    if (TO_LM) lm[at] = nat[r]; else nat[r] = lm[at];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -950,6 +1077,42 @@ void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const Packe
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
+// the step-major exchange of a schedule: ordinals of the exported lanes of each workgroup, the workgroup's row length and steps
+static constexpr int kStXAlign = 16;          // first step of a workgroup's exchange rows: its first step rounded down to this
+__global__ void __launch_bounds__(kThreads)
+k_st_xch_layout(const int32_t *__restrict__ exported, const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab,
+                int32_t *__restrict__ xe, int32_t *__restrict__ xw, int32_t *__restrict__ xsz)
+{
+    __shared__ int s_cnt[4];
+    const int wg = blockIdx.x, t = threadIdx.x, wv = t >> 6;
+    const int slot = wg * kThreads + t;
+    const bool ex = ltab[(size_t)slot * kStTab + ST_CNT] > 0 && exported[slot] != 0;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(ex);
+    if ((t & 63) == 0) s_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < wv; ++q) before += s_cnt[q];
+    xe[slot] = ex ? before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0)) : -1;
+    if (t == 0) {
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const int E = (total + 15) & ~15;
+        int tlo = 0x7fffffff, thi = -0x7fffffff;
+        for (int q = 0; q < 4; ++q) {
+            const int a = wtab[(size_t)(wg * 4 + q) * 4 + 1], b = wtab[(size_t)(wg * 4 + q) * 4 + 2];
+            if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
+        }
+        if (thi <= tlo) { tlo = 0; thi = 0; }
+        tlo &= ~(kStXAlign - 1);
+        xw[wg * 4 + 0] = E; xw[wg * 4 + 1] = tlo; xw[wg * 4 + 2] = thi - tlo; xw[wg * 4 + 3] = 0;
+        xsz[wg] = E * (thi - tlo);
+    }
+}
+__global__ void k_st_xch_rows(int32_t nwg, const int32_t *__restrict__ xoff, int32_t *__restrict__ xw)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwg) xw[w * 4 + 3] = xoff[w];
+}
+
 __global__ void k_st_xrows(int32_t nslots, const int32_t *__restrict__ exported, const int32_t *__restrict__ scount,
                            int32_t *__restrict__ rows)
 {
@@ -1036,6 +1199,31 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&tmp, tb));
     ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, rows, f->xbase, nslots, st));
     hipLaunchKernelGGL(k_st_xbase, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, f->xbase, f->xcount);
+    int32_t xtot[2][2];
+    {
+        int32_t *xsz = nullptr, *xoff = nullptr;
+        ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 2));
+        xoff = xsz + nwg;
+        PackedSweep *pp[2] = {pl, pu};
+        const Schedule *ss[2] = {&fwd, &bwd};
+        for (int d = 0; d < 2; ++d) {
+            ILUPP_HIP(pool_malloc(&pp[d]->xe, sizeof(int32_t) * (size_t)nslots));
+            ILUPP_HIP(pool_malloc(&pp[d]->xw, sizeof(int32_t) * (size_t)nwg * 4));
+            hipLaunchKernelGGL(k_st_xch_layout, dim3((unsigned)nwg), dim3(kThreads), 0, st, ss[d]->exported, pp[d]->ltab, pp[d]->wtab,
+                               pp[d]->xe, pp[d]->xw, xsz);
+            size_t tb2 = 0;
+            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, xsz, xoff, nwg, st));
+            void *tmp2 = nullptr;
+            ILUPP_HIP(pool_malloc(&tmp2, tb2));
+            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, xsz, xoff, nwg, st));
+            hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, xoff, pp[d]->xw);
+            ILUPP_HIP(d2h_async(st, &xtot[d][0], xoff + (nwg - 1), sizeof(int32_t)));
+            ILUPP_HIP(d2h_async(st, &xtot[d][1], xsz + (nwg - 1), sizeof(int32_t)));
+            ILUPP_HIP(stream_sync(st));
+            ILUPP_HIP(pool_free(tmp2));
+        }
+        ILUPP_HIP(pool_free(xsz));
+    }
     int32_t hl[4], hu[4];
     ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
     ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
@@ -1057,8 +1245,14 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&f->xch, sizeof(double) * ((size_t)A.n + 16)));
     pl->built = true;
     st_pack_values(st, A, pl, pu, f);
-    // the intermediate vector of an apply travels level-major from the L sweep to the U sweep
-    ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
+    // vectors travel level-major: the right-hand side in the L sweep's order, the intermediate vector and the result in the U sweep's
+    ILUPP_HIP(pool_malloc(&pl->xlm, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
+    ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pu->nchunks + 4 * nwg)));
+    pl->y_chunks = pu->nchunks;
+    pl->xch_len = (int64_t)xtot[0][0] + xtot[0][1] + 64;
+    pu->xch_len = (int64_t)xtot[1][0] + xtot[1][1] + 64;
+    ILUPP_HIP(pool_malloc(&pl->xch, sizeof(double) * (size_t)pl->xch_len));
+    ILUPP_HIP(pool_malloc(&pu->xch, sizeof(double) * (size_t)pu->xch_len));
     ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
     ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)nslots, st));
     hipLaunchKernelGGL(k_lm_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
@@ -1110,20 +1304,42 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     return ILUPP_OK;
 }
 
+// One sweep of an apply.  Forward: `rhs` (natural order) -> the intermediate vector in `ylm` (= the forward sweep's ybuf, in the
+// BACKWARD sweep's level-major order); backward: `ylm` -> the result in `out` (natural order).  `out` also is where the values
+// other workgroups poll are stored (all-sentinel before the sweep).
 int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
               int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
+    (void)ysrc;
+    const bool fwd = ps.kind == (int)SWEEP_FWD_LAST_ASC;
+    double *ylm = fwd ? ypk_out : const_cast<double *>(ypk_in);
+    if (!ylm) { set_error("static sweep without its level-major vector"); return ILUPP_ERR_INVALID; }
+    const dim3 gridv((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 7) / 8));
     StSArgs a;
-    a.pk = reinterpret_cast<const v2d *>(ps.pk); a.ltab = ps.ltab; a.wtab = ps.wtab; a.n = n; a.nchY = (int32_t)ps.nchunks;
-    a.rhs = rhs; a.out = out; a.dump = ps.dump;
-    a.exported = sch.exported; a.ypk_out = ypk_out; a.ypk_in = ypk_in; a.ysrc = ysrc; a.ticket = d_ticket; a.err = d_err;
-    const dim3 grid((unsigned)ps.nwg), block(kThreads);
-    if (ps.kind == (int)SWEEP_FWD_LAST_ASC) {
-        if (ypk_out) hipLaunchKernelGGL((k_sptrsv_st<1, true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_sptrsv_st<1, false, false>), grid, block, 0, st, a);
+    a.pk = reinterpret_cast<const v2d *>(ps.pk); a.ltab = ps.ltab; a.wtab = ps.wtab; a.n = n;
+    a.nchY = (int32_t)(fwd ? ps.y_chunks : ps.nchunks);
+    a.xlm = ps.xlm; a.ylm = ylm;
+    a.xe = ps.xe; a.xw = ps.xw; a.xch = ps.xch; a.ticket = d_ticket; a.err = d_err;
+    fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
+    const dim3 grid((unsigned)ps.nwg);
+    // one workgroup per CU: with 40 KB of LDS three would fit, and the dispatcher does put several on one CU while others stay
+    // empty; the steps of two schedules on the same four SIMDs take turns.  The unused dynamic LDS makes the workgroup too big
+    // for a neighbour.
+    {
+        static std::once_flag once[64];      // once per device
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+        });
+    }
+    if (fwd) {
+        hipLaunchKernelGGL((k_st_vec<1, true>), gridv, dim3(512), 0, st, ps.ltab, ps.wtab, const_cast<double *>(rhs), ps.xlm);
+        hipLaunchKernelGGL((k_sptrsv_st<1>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
-        if (ypk_in) hipLaunchKernelGGL((k_sptrsv_st<-1, false, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_sptrsv_st<-1, false, false>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((k_sptrsv_st<-1>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        hipLaunchKernelGGL((k_st_vec<-1, false>), gridv, dim3(512), 0, st, ps.ltab, ps.wtab, out, ylm);
     }
     ILUPP_HIP(hipGetLastError());
     return ILUPP_OK;

@@ -8,6 +8,6 @@ python3 - "$f" "$1" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 print("==", sys.argv[2])
-for r in rows[:int(9)]:
+for r in rows[:int(16)]:
     print("%-44s calls %4s avg %10.1f us" % (r["Name"].split("(")[0][-44:], r["Calls"], float(r["AverageNs"])/1e3))
 PY

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timings of the ILU(0) construction + apply on a 7-point mesh, device-resident, for one or more builds of the library.
-usage: st_time.py GRID [lib.so ...]      (no lib: the in-tree one)"""
+usage: st_time.py GRID|NX,NY,NZ [lib.so ...]      (no lib: the in-tree one)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 2 and sys.argv[2] != "--child":
@@ -12,8 +12,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch, time
 import matgen
 from ilupp_amd import _native
-g = int(sys.argv[1]); tag = sys.argv[3] if len(sys.argv) > 3 else "in-tree"
-d, i, p = matgen.poisson3d(g)
+dims = [int(v) for v in sys.argv[1].split(",")]; g = dims[0]; tag = sys.argv[3] if len(sys.argv) > 3 else "in-tree"
+d, i, p = matgen.poisson3d(*dims)
 n = p.shape[0] - 1
 dev = torch.device("cuda", 0)
 td, ti, tp = (torch.from_numpy(a).to(dev) for a in (d, i, p))

@@ -7,8 +7,10 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import matgen
 from ilupp_amd import _native
-g = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-d, i, p = matgen.poisson3d(g)
+dims = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "128").split(",")]
+dims = dims * 3 if len(dims) == 1 else dims
+g = dims[0]
+d, i, p = matgen.poisson3d(*dims)
 n = p.shape[0] - 1
 dev = torch.device("cuda", 0)
 td, ti, tp = (torch.from_numpy(a).to(dev) for a in (d, i, p))
@@ -20,13 +22,16 @@ for rep in range(3):
 t = P.timings()
 buf = (ctypes.c_ulonglong * (4096 * 4))()
 assert _native.lib().ilupp_hip_debug_timeline(buf) == 0
-T = g // 16
-a = np.array(buf[:T * T * 4], dtype=np.float64).reshape(T * T, 4)
+Ty, Tz = dims[1] // 16, dims[2] // 16
+T = Ty
+a = np.array(buf[:Ty * Tz * 4], dtype=np.float64).reshape(Ty * Tz, 4)
 t0 = a[:, 0].min()
 a = (a - t0) / 100.0      # us
-print("lsolve kernel %.1f us; tiles %d x %d; per tile: entry / first row / last row / exit (us)" % (1e3 * t["lsolve_kernel_ms"], T, T))
-for z in range(T):
-    print("  ".join("%6.1f %6.1f" % (a[z * T + y, 1], a[z * T + y, 2]) for y in range(T)))
+print("lsolve sweep %.1f us; tiles %d x %d; per tile: entry / first row / last row / exit (us)" % (1e3 * t["lsolve_kernel_ms"], T, T))
+for z in range(Tz):
+    print("  ".join("%6.1f %6.1f" % (a[z * Ty + y, 1], a[z * Ty + y, 2]) for y in range(Ty)))
+if Ty != Tz:
+    sys.exit(0)
 diag = [a[k * T + k] for k in range(T)]
 print("diagonal tiles (k,k): first-row times", " ".join("%.1f" % v[1] for v in diag))
 print("  first-row deltas along the diagonal:", " ".join("%.1f" % (diag[k + 1][1] - diag[k][1]) for k in range(T - 1)))
