@@ -460,35 +460,6 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
 __device__ __forceinline__ double st_lds(const unsigned char *base, unsigned off) { return *reinterpret_cast<const double *>(base + off); }
 __device__ __forceinline__ int st_med3(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// lane constants of the hand-off: LDS read address of each dependency (the value of `dt` steps ago of lane `u`, in the
-// copy 8 slots up: slot index = step%8 + 8 - dt stays inside [1, 15] with the step's immediate), which dependencies
-// come from an earlier workgroup and which of the two poll registers holds them
-struct StLane {
-    int first, cnt, sk;
-    unsigned va[3];
-    bool isg[3], g1[3];
-    int ng;
-};
-__device__ __forceinline__ StLane st_lane(const int32_t *T, int t)
-{
-    StLane s;
-    s.first = T[ST_FIRST]; s.cnt = T[ST_CNT]; s.sk = T[ST_SKEW];
-    const int nd = T[ST_ND];
-    s.ng = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int sw = T[ST_SRC + j];
-        const int ty = (j < nd && s.cnt > 0) ? (sw & 3) : ST_NONE;
-        const int u = ty == ST_LOCAL ? ((sw >> 2) & 255) : t;
-        const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;              // (own previous row: lane t, one step back)
-        s.va[j] = (unsigned)(((kStH - dt) * kThreads + u) * 8);
-        s.isg[j] = ty == ST_GHOST;
-        s.g1[j] = s.isg[j] && s.ng > 0;
-        s.ng += s.isg[j] ? 1 : 0;
-    }
-    return s;
-}
-
 #ifndef ST_STAMP_WG
 #define ST_STAMP_WG -1
 #endif
@@ -507,205 +478,6 @@ __device__ unsigned long long g_st_tl[4096 * 4];     // per workgroup of the for
 #define ST_T_DECL(cond) do { } while (0)
 #define ST_T_END(off) do { } while (0)
 #endif
-
-// ---------------------------------------------------------------------------------------------
-// the factor kernel: pivots only
-// ---------------------------------------------------------------------------------------------
-struct StFArgs {
-    const int32_t *ltab, *wtab;               // forward schedule
-    const v2d *pkA;                           // 4 x 64 x 16 B per chunk: {a0,a1}{a2,a3}{t0,t1}{t2,a6}
-    v2d *pkL, *pkU;                           // 2 x 64 x 16 B per chunk: {l0,l1}{l2,1} / {u1,u2}{u3,u0}; one spare chunk at the end each
-    int32_t nchL, nchU;                       // index of the first spare chunk (one per wave)
-    const int32_t *xbase;                     // per slot: first exchange row, -1 = nobody outside the workgroup reads it
-    const long long *xcount;                  // exchange rows in use (the one after them is the dump)
-    double *xch;
-    int32_t *ctrl;                            // [0] ticket, [1] error
-};
-
-__global__ void __launch_bounds__(kThreads)
-k_ilu0_st(StFArgs A)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char xh[2 * kStH * kThreads * 8];      // pivots of finished rows: [16][256], slots s and s+8 alike
-    __shared__ unsigned s_ticket;
-    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
-    __syncthreads();
-    const int wg = (int)s_ticket;
-    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
-    const int32_t *T = A.ltab + (size_t)(wg * kThreads + t) * kStTab;
-    const StLane S = st_lane(T, t);
-    const int cnt = S.cnt, sk = S.sk;
-    const int xdump = (int)A.xcount[0];                                 // exchange rows: one double each
-    int gx0 = xdump, gx1 = xdump;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (S.isg[j]) { const int g = A.xbase[T[ST_SRC + j] >> 2] + T[ST_KAP + j]; if (S.g1[j]) gx1 = g; else gx0 = g; }
-    const bool wave_ghost = __any(S.ng > 0);
-    const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
-    const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
-              nchw = __builtin_amdgcn_readfirstlane(wt[2]);
-    int tlo = 0x7fffffff, thi = -0x7fffffff;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int32_t *w4 = A.wtab + (size_t)(wg * 4 + q) * 4;
-        const int a = w4[1], b = w4[2];
-        if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
-    }
-    tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
-    if (thi <= tlo) return;
-    tlo &= ~(kStH - 1);                                                 // step % 8 = position in the unrolled loop
-    const int xb = cnt > 0 ? A.xbase[wg * kThreads + t] : -1;
-    const bool exports = xb >= 0;
-    const unsigned long long *xchb = reinterpret_cast<const unsigned long long *>(A.xch);
-    const unsigned char *pa = reinterpret_cast<const unsigned char *>(A.pkA) + (size_t)(nchw > 0 ? base : 0) * 4096;
-    unsigned char *pl = reinterpret_cast<unsigned char *>(A.pkL);
-    unsigned char *pu = reinterpret_cast<unsigned char *>(A.pkU);
-    const unsigned lo16 = (unsigned)ln * 16u;
-    const int cmax = nchw > 0 ? nchw - 1 : 0;
-    // dump places: one spare chunk per wave behind the records (a place shared by all waves would be a hot spot)
-    const int wglob = wg * 4 + wv;
-    const unsigned udump = (unsigned)(A.nchU + wglob) * 2048u + lo16;
-    const int ldump = A.nchL + wglob;
-    const bool wave_exports = __any(xb >= 0);
-    const int up0 = T[ST_UP0];
-
-    v2d ra[kStH][4];
-    unsigned long long gq[kStP][2];
-
-#define STF_LOAD(u, tp)                                                                                              \
-    do {                                                                                                             \
-        const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                              \
-        const unsigned char *q_ = pa + (size_t)cw_ * 4096;                                                           \
-        ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                             \
-        ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                      \
-        ra[u][2] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 2048));                      \
-        ra[u][3] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 3072));                      \
-    } while (0)
-#define STF_POLL(g, kq)                                                                                              \
-    do {                                                                                                             \
-        if (S.ng > 0) gq[g][0] = ld_agent_u64(xchb + st_med3(gx0 + (kq), 0, xdump));                                 \
-        if (S.ng > 1) gq[g][1] = ld_agent_u64(xchb + st_med3(gx1 + (kq), 0, xdump));                                 \
-    } while (0)
-
-    // in step order (a compiler barrier after each): the waits of the loop are derived from the oldest position a
-    // register's load can have, and the scheduler is free to turn an unordered prologue upside down
-#pragma unroll
-    for (int g = 0; g < kStP; ++g) { gq[g][0] = kSentinel; gq[g][1] = kSentinel; STF_POLL(g, tlo + g - sk); asm volatile("" ::: "memory"); }
-    // ... and with the stores a step of the loop has, to the dump places: hipcc takes, for every wait, the smaller of
-    // the operation counts behind the load on the two ways into the loop body
-    const double absent = st_dbl(kAbsent);
-#pragma unroll
-    for (int u = 0; u < kStH; ++u) {
-        STF_LOAD(u, tlo + u);
-        v2d z; z.x = absent; z.y = absent;
-        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16));
-        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16 + 1024));
-        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pu + udump));
-        asm volatile("" ::: "memory");
-    }
-    bool dead = false;
-    ST_T_DECL(wv == ST_STAMP_WV && wg == (ST_STAMP_WG < 0 ? (int)gridDim.x - 1 : ST_STAMP_WG));
-
-    for (int tb = tlo; tb < thi; tb += kStH) {
-        const int kb = tb - sk;
-#pragma unroll
-        for (int u = 0; u < kStH; ++u) {
-            const int k = kb + u;
-            const bool valid = (unsigned)k < (unsigned)cnt;
-#ifdef ST_STAMP
-            ++nst_;
-#endif
-            ST_T(0);
-            const v2d r0 = ra[u][0], r1 = ra[u][1], r2 = ra[u][2], r3 = ra[u][3];
-            const double av[3] = {r0.x, r0.y, r1.x}, at[3] = {r2.x, r2.y, r3.x};
-            bool pj[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) pj[j] = valid && st_bits(av[j]) != kAbsent;
-            ST_BARRIER();
-            ST_T(1);
-            double piv[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) piv[j] = st_lds(xh, S.va[j] + (unsigned)u * (kThreads * 8));
-#ifdef ST_STAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            ST_T(2);
-            if (wave_ghost) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (S.isg[j]) piv[j] = st_dbl(S.g1[j] ? gq[u % kStP][1] : gq[u % kStP][0]);
-                if (!dead) {
-                    // pivots of earlier workgroups that had not arrived when they were asked for: ask again
-                    unsigned spins = 0;
-                    for (;;) {
-                        bool miss = false;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            if (S.isg[j] && pj[j] && st_bits(piv[j]) == kSentinel) miss = true;
-                        if (!__any(miss)) break;
-                        if (miss) {
-#pragma unroll
-                            for (int j = 0; j < 3; ++j)
-                                if (S.isg[j] && pj[j]) piv[j] = st_dbl(ld_agent_u64(xchb + st_med3((S.g1[j] ? gx1 : gx0) + k, 0, xdump)));
-                        }
-                        // retired HERE: a load pending at the join below would make hipcc wait for vmcnt(0) -- the whole
-                        // read-ahead -- on every step, also on those that never come through this loop
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        __builtin_amdgcn_s_sleep(1);
-                        if ((++spins & 255u) == 0) {
-                            if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);
-                            const int e = ld_agent_i32(&A.ctrl[1]);
-                            __builtin_amdgcn_s_waitcnt(0x0F70);
-                            if (spins > kStSpinLimit || e != 0) { dead = true; break; }
-                        }
-                    }
-                }
-            }
-            ST_T(3);
-            // u_ii = a_ii - sum (a_ik / u_kk) a_ki, eliminations in ascending k (ILU0.hpp:47-62 for rows whose eliminations
-            // meet them on the diagonal only)
-            double w3 = r1.y;
-            double l[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                l[j] = av[j] / piv[j];
-                const double pr = l[j] * at[j];
-                const double nw = w3 - pr;
-                w3 = (pj[j] && st_bits(at[j]) != kAbsent) ? nw : w3;
-            }
-#ifdef ST_STAMP
-            asm volatile("" :: "v"(w3));
-#endif
-            ST_T(4);
-            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)u * (kThreads * 8)) = w3;
-            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u + kStH) * (kThreads * 8)) = w3;
-            // pivots that other workgroups read: write-through (the one store of a step that hipcc cannot count on)
-            if (wave_exports) { if (exports && valid) st_agent_f64(A.xch + (xb + k), w3); }
-            // the record stores happen on every step (lanes / waves without a row store to their dump place)
-            {
-                const int cw = tb + u - tminw;
-                unsigned char *o = pl + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048;
-                v2d la, lb;
-                la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
-                lb.x = pj[2] ? l[2] : absent; lb.y = 1.0;
-                __builtin_nontemporal_store(la, reinterpret_cast<v2d *>(o + lo16));
-                __builtin_nontemporal_store(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
-            }
-            {
-                v2d ub; ub.x = r3.y; ub.y = w3;
-                const unsigned uo = valid ? (unsigned)(up0 - 128 * k) * 16u + 1024u : udump;
-                __builtin_nontemporal_store(ub, reinterpret_cast<v2d *>(pu + uo));
-            }
-            ST_T(5);
-            STF_LOAD(u, tb + u + kStH);
-            if (wave_ghost) STF_POLL(u % kStP, k + kStP);
-            ST_T(6);
-        }
-    }
-#undef STF_LOAD
-#undef STF_POLL
-    ST_T_END(0);
-    if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
-}
 
 // ---------------------------------------------------------------------------------------------
 // the sweeps.  DR = +1 forward (rows ascending; the diagonal of L is 1: no division), -1 backward.
@@ -877,8 +649,8 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
 
 // the courier of a sweep: lane p serves pair p.  src: the exchange the producers write through to (all-sentinel before the
 // sweep); a pair's value for step s is element idx0 + s stride, wanted for klo <= s - sk < khi.
-template <int DR>
-__device__ __forceinline__ void st_sweep_courier(const unsigned long long *src, const unsigned long long *idle, unsigned char *xh, const StPair P,
+template <int RA>
+__device__ __forceinline__ void st_courier(const unsigned long long *src, const unsigned long long *idle, unsigned char *xh, const StPair P,
                                                  const int tlo, const int thi, int32_t *err)
 {
     const int ln = threadIdx.x & 63;
@@ -888,9 +660,9 @@ __device__ __forceinline__ void st_sweep_courier(const unsigned long long *src, 
 #pragma unroll
     for (int g = 0; g < kStP; ++g) { gq[g] = ld_agent_u64(STC_ADDR(tlo + g - P.sk)); asm volatile("" ::: "memory"); }
     bool dead = false;
-    for (int tb = tlo; tb < thi; tb += kStRA) {
+    for (int tb = tlo; tb < thi; tb += RA) {
 #pragma unroll
-        for (int u = 0; u < kStRA; ++u) {
+        for (int u = 0; u < RA; ++u) {
             const int k = tb + u - P.sk;
             const bool need = (unsigned)(k - P.klo) < span;
             unsigned long long v = gq[u % kStP];
@@ -915,6 +687,32 @@ __device__ __forceinline__ void st_sweep_courier(const unsigned long long *src, 
     }
 #undef STC_ADDR
     if (dead && ln == 0) atomicExch(err, 1);
+}
+
+// where a lane's dependencies come from: the LDS read address of each (the value of `dt` steps ago of lane `u`, in the copy 8
+// slots up: slot index = step % 8 + 8 - dt stays inside [1, 15] with the step's immediate), and for those of earlier workgroups
+// where in the exchange the producer lane's value of step s = 0 would be and how far apart steps are
+__device__ __forceinline__ void st_lane_sources(const int32_t *T, const int t, const int32_t *ltab, const int32_t *xe, const int32_t *xw,
+                                                bool isg[3], int idx0[3], int stride[3], unsigned va[3])
+{
+    const int nd = T[ST_ND], cnt = T[ST_CNT];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int sw = T[ST_SRC + j];
+        const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
+        const int u = ty == ST_LOCAL ? ((sw >> 2) & 255) : t;
+        const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;          // (own previous row: lane t, one step back)
+        va[j] = (unsigned)(((kStH - dt) * kStRow + u) * 8);
+        isg[j] = ty == ST_GHOST;
+        idx0[j] = 0; stride[j] = 0;
+        if (isg[j]) {
+            // the producer lane's value of ITS step s' = k' + skew' with k' = k + T[ST_KAP + j], k = s - skew
+            const int os = sw >> 2, pw = os >> 8;
+            const int E = xw[pw * 4];
+            stride[j] = E;
+            idx0[j] = xw[pw * 4 + 3] + (T[ST_KAP + j] + ltab[(size_t)os * kStTab + ST_SKEW] - T[ST_SKEW] - xw[pw * 4 + 1]) * E + xe[os];
+        }
+    }
 }
 
 // The pairs of a workgroup, numbered: lane t's ghost dependency j gets the next free index p, its descriptor goes to pairs[p],
@@ -975,25 +773,9 @@ k_sptrsv_st(StSArgs A)
     if (t < kThreads) {
         const int slot = wg * kThreads + t;
         const int32_t *T = A.ltab + (size_t)slot * kStTab;
-        const int nd = T[ST_ND], cnt = T[ST_CNT];
+        const int cnt = T[ST_CNT];
         bool isg[3]; int idx0[3], stride[3]; unsigned va[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int sw = T[ST_SRC + j];
-            const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
-            const int u = ty == ST_LOCAL ? ((sw >> 2) & 255) : t;
-            const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;          // (own previous row: lane t, one step back)
-            va[j] = (unsigned)(((kStH - dt) * kStRow + u) * 8);
-            isg[j] = ty == ST_GHOST;
-            idx0[j] = 0; stride[j] = 0;
-            if (isg[j]) {
-                // the producer lane's value of ITS step s' = k' + skew' with k' = k + T[ST_KAP + j], k = s - skew
-                const int os = sw >> 2, pw = os >> 8;
-                const int E = A.xw[pw * 4];
-                stride[j] = E;
-                idx0[j] = A.xw[pw * 4 + 3] + (T[ST_KAP + j] + A.ltab[(size_t)os * kStTab + ST_SKEW] - T[ST_SKEW] - A.xw[pw * 4 + 1]) * E + A.xe[os];
-            }
-        }
+        st_lane_sources(T, t, A.ltab, A.xe, A.xw, isg, idx0, stride, va);
         __syncthreads();                                              // (s_pairs zeroed)
         st_number_pairs(T, t, isg, idx0, stride, va, s_pairs, s_cnt, &s_total);
         __syncthreads();
@@ -1008,7 +790,186 @@ k_sptrsv_st(StSArgs A)
         const StPair P = s_pairs[t - kThreads];
         // (a poll nobody needs goes to a place of this workgroup's own: the same address for the whole chip would be a hot spot)
         const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
-        st_sweep_courier<DR>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, A.err);
+        st_courier<kStRA>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, A.err);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the factor kernel: pivots only
+// ---------------------------------------------------------------------------------------------
+struct StFArgs {
+    const int32_t *ltab, *wtab;               // forward schedule
+    const v2d *pkA;                           // 4 x 64 x 16 B per chunk: {a0,a1}{a2,a3}{t0,t1}{t2,a6}
+    v2d *pkL, *pkU;                           // 2 x 64 x 16 B per chunk: {l0,l1}{l2,1} / {u1,u2}{u3,u0}; one spare chunk at the end each
+    int32_t nchL, nchU;                       // index of the first spare chunk (one per wave)
+    const int32_t *xe, *xw;                   // the forward schedule's exchange between workgroups (PackedSweep::xe, xw, xch),
+    double *xch;                              // all-sentinel before the kernel: pivots of exported lanes
+    int32_t *ctrl;                            // [0] ticket, [1] error
+};
+
+// the 256 lanes of the schedule (the courier wave brings the pivots of earlier workgroups: see the sweeps)
+template <bool EX>
+__device__ __forceinline__ void st_factor_wave(const StFArgs &A, unsigned char *xh, const int wg, const unsigned *va, const int tlo, const int thi)
+{
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    const int slot = wg * kThreads + t;
+    const int32_t *T = A.ltab + (size_t)slot * kStTab;
+    const int cnt = T[ST_CNT], sk = T[ST_SKEW];
+    const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
+    const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
+              nchw = __builtin_amdgcn_readfirstlane(wt[2]);
+    const int xe = A.xe[slot];
+    const bool exports = cnt > 0 && xe >= 0;
+    const int xE = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
+    const int xoff = A.xw[wg * 4 + 3] - A.xw[wg * 4 + 1] * xE + xe;          // + step * xE: where this lane's pivot of a step goes
+    const unsigned char *pa = reinterpret_cast<const unsigned char *>(A.pkA) + (size_t)(nchw > 0 ? base : 0) * 4096;
+    unsigned char *pl = reinterpret_cast<unsigned char *>(A.pkL);
+    unsigned char *pu = reinterpret_cast<unsigned char *>(A.pkU);
+    const unsigned lo16 = (unsigned)ln * 16u;
+    const int cmax = nchw > 0 ? nchw - 1 : 0;
+    // dump places: one spare chunk per wave behind the records (a place shared by all waves would be a hot spot)
+    const int wglob = wg * 4 + wv;
+    const unsigned udump = (unsigned)(A.nchU + wglob) * 2048u + lo16;
+    const int ldump = A.nchL + wglob;
+    const int up0 = T[ST_UP0];
+
+    v2d ra[kStH][4];
+
+#define STF_LOAD(u, tp)                                                                                              \
+    do {                                                                                                             \
+        const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                              \
+        const unsigned char *q_ = pa + (size_t)cw_ * 4096;                                                           \
+        ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                             \
+        ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                      \
+        ra[u][2] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 2048));                      \
+        ra[u][3] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 3072));                      \
+    } while (0)
+
+    // the way into the loop in step order (a compiler barrier after each) and with the stores a step of the loop has, to the
+    // dump places: the waits of the loop are derived from the oldest position a register's load can have, hipcc takes the
+    // smaller of the operation counts behind the load on the two ways into the loop body, and the scheduler is free to turn an
+    // unordered prologue upside down
+    const double absent = st_dbl(kAbsent);
+#pragma unroll
+    for (int u = 0; u < kStH; ++u) {
+        STF_LOAD(u, tlo + u);
+        v2d z; z.x = absent; z.y = absent;
+        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16));
+        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16 + 1024));
+        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pu + udump));
+        if (EX) st_agent_f64(reinterpret_cast<double *>(pu + udump), absent);
+        asm volatile("" ::: "memory");
+    }
+    ST_T_DECL(wv == ST_STAMP_WV && wg == (ST_STAMP_WG < 0 ? (int)gridDim.x - 1 : ST_STAMP_WG));
+
+    for (int tb = tlo; tb < thi; tb += kStH) {
+        const int kb = tb - sk;
+#pragma unroll
+        for (int u = 0; u < kStH; ++u) {
+            const int k = kb + u;
+            const bool valid = (unsigned)k < (unsigned)cnt;
+#ifdef ST_STAMP
+            ++nst_;
+#endif
+            ST_T(0);
+            const v2d r0 = ra[u][0], r1 = ra[u][1], r2 = ra[u][2], r3 = ra[u][3];
+            const double av[3] = {r0.x, r0.y, r1.x}, at[3] = {r2.x, r2.y, r3.x};
+            bool pj[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pj[j] = valid && st_bits(av[j]) != kAbsent;
+            ST_BARRIER();
+            ST_T(1);
+            double piv[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) piv[j] = st_lds(xh, va[j] + (unsigned)u * (kStRow * 8));
+#ifdef ST_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            ST_T(2);
+            ST_T(3);
+            // u_ii = a_ii - sum (a_ik / u_kk) a_ki, eliminations in ascending k (ILU0.hpp:47-62 for rows whose eliminations
+            // meet them on the diagonal only)
+            double w3 = r1.y;
+            double l[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                l[j] = av[j] / piv[j];
+                const double pr = l[j] * at[j];
+                const double nw = w3 - pr;
+                w3 = (pj[j] && st_bits(at[j]) != kAbsent) ? nw : w3;
+            }
+#ifdef ST_STAMP
+            asm volatile("" :: "v"(w3));
+#endif
+            ST_T(4);
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)u * (kStRow * 8)) = w3;
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u + kStH) * (kStRow * 8)) = w3;
+            // pivots that other workgroups read: write-through, to the exchange
+            if (EX) st_agent_f64((exports && valid) ? A.xch + (xoff + (tb + u) * xE) : reinterpret_cast<double *>(pu + udump), w3);
+            // the record stores happen on every step (lanes / waves without a row store to their dump place)
+            {
+                const int cw = tb + u - tminw;
+                unsigned char *o = pl + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048;
+                v2d la, lb;
+                la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
+                lb.x = pj[2] ? l[2] : absent; lb.y = 1.0;
+                __builtin_nontemporal_store(la, reinterpret_cast<v2d *>(o + lo16));
+                __builtin_nontemporal_store(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
+            }
+            {
+                v2d ub; ub.x = r3.y; ub.y = w3;
+                const unsigned uo = valid ? (unsigned)(up0 - 128 * k) * 16u + 1024u : udump;
+                __builtin_nontemporal_store(ub, reinterpret_cast<v2d *>(pu + uo));
+            }
+            ST_T(5);
+            STF_LOAD(u, tb + u + kStH);
+            ST_T(6);
+        }
+    }
+#undef STF_LOAD
+    ST_T_END(0);
+}
+
+__global__ void __launch_bounds__(kStWgThreads)
+k_ilu0_st(StFArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char xh[2 * kStH * kStRow * 8];      // pivots of finished rows: [16][320], slots s and s+8 alike
+    __shared__ StPair s_pairs[64];
+    __shared__ int s_cnt[4], s_total;
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
+    __syncthreads();
+    const int wg = (int)s_ticket;
+    const int t = threadIdx.x;
+    int tlo = 0x7fffffff, thi = -0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t *w4 = A.wtab + (size_t)(wg * 4 + q) * 4;
+        const int a = w4[1], b = w4[2];
+        if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
+    }
+    tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
+    if (thi <= tlo) return;
+    tlo &= ~(kStH - 1);                                                 // step % 8 = position in the unrolled loop
+    if (t < 64) { StPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.klo = 0; z.khi = 0; s_pairs[t] = z; }
+    if (t < kThreads) {
+        const int slot = wg * kThreads + t;
+        const int32_t *T = A.ltab + (size_t)slot * kStTab;
+        bool isg[3]; int idx0[3], stride[3]; unsigned va[3];
+        st_lane_sources(T, t, A.ltab, A.xe, A.xw, isg, idx0, stride, va);
+        __syncthreads();                                              // (s_pairs zeroed)
+        st_number_pairs(T, t, isg, idx0, stride, va, s_pairs, s_cnt, &s_total);
+        __syncthreads();
+        if (t == 0 && s_total > 64) atomicExch(&A.ctrl[1], 1);        // (the analysis does not let such a schedule through)
+        const bool wave_exports = __any(T[ST_CNT] > 0 && A.xe[slot] >= 0);
+        if (wave_exports) st_factor_wave<true>(A, xh, wg, va, tlo, thi); else st_factor_wave<false>(A, xh, wg, va, tlo, thi);
+    } else {
+        __syncthreads();
+        __syncthreads();                                              // (the one inside st_number_pairs)
+        __syncthreads();
+        const StPair P = s_pairs[t - kThreads];
+        const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
+        st_courier<kStH>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, &A.ctrl[1]);
     }
 }
 
@@ -1113,27 +1074,6 @@ __global__ void k_st_xch_rows(int32_t nwg, const int32_t *__restrict__ xoff, int
     if (w < nwg) xw[w * 4 + 3] = xoff[w];
 }
 
-__global__ void k_st_xrows(int32_t nslots, const int32_t *__restrict__ exported, const int32_t *__restrict__ scount,
-                           int32_t *__restrict__ rows)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nslots) rows[s] = exported[s] ? scount[s] : 0;
-}
-__global__ void k_st_xbase(int32_t nslots, const int32_t *__restrict__ exported, const int32_t *__restrict__ scount,
-                           int32_t *__restrict__ xbase, long long *__restrict__ xcount)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nslots) return;
-    const int b = xbase[s];
-    if (s == nslots - 1) *xcount = (long long)b + (exported[s] ? scount[s] : 0);
-    if (!exported[s]) xbase[s] = -1;
-}
-__global__ void k_st_fill(unsigned long long *__restrict__ p, const long long *__restrict__ count, unsigned long long v)
-{
-    const long long n = *count + 8;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
-}
-
 static void st_structure(hipStream_t st, const Schedule &sch, PackedSweep *ps, int kind)
 {
     ps->nwg = sch.nslots / kThreads;
@@ -1185,20 +1125,10 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)nslots, st));
     const unsigned gb = (unsigned)((nslots + 255) / 256);
     hipLaunchKernelGGL(k_st_inv, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv);
-    // exchange rows (one pivot each) of the forward lanes that other workgroups read; behind them the rows pass' lane records
+    // the rows pass' lane records (behind nslots unused ints)
     ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots * 33));
     hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
                        f->xbase + nslots, pl->flags);
-    ILUPP_HIP(pool_malloc(&f->xcount, 64));
-    int32_t *rows = nullptr;
-    ILUPP_HIP(pool_malloc(&rows, sizeof(int32_t) * (size_t)nslots));
-    hipLaunchKernelGGL(k_st_xrows, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, rows);
-    size_t tb = 0;
-    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rows, f->xbase, nslots, st));
-    void *tmp = nullptr;
-    ILUPP_HIP(pool_malloc(&tmp, tb));
-    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, rows, f->xbase, nslots, st));
-    hipLaunchKernelGGL(k_st_xbase, dim3(gb), dim3(256), 0, st, nslots, fwd.exported, fwd.scount, f->xbase, f->xcount);
     int32_t xtot[2][2];
     {
         int32_t *xsz = nullptr, *xoff = nullptr;
@@ -1228,7 +1158,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
     ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
     ILUPP_HIP(stream_sync(st));
-    ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(rows)); ILUPP_HIP(pool_free(tmp));
+    ILUPP_HIP(pool_free(inv));
     const int64_t lim = 2 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;
     if (hl[0] || hu[0] || hu[3] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim ||
         hl[1] + 4 * nwg >= kStMaxChunks || hu[1] + 4 * nwg >= kStMaxChunks) {
@@ -1242,7 +1172,6 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&pl->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));
     ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pu->nchunks + 4 * nwg) * 2048));
     ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
-    ILUPP_HIP(pool_malloc(&f->xch, sizeof(double) * ((size_t)A.n + 16)));
     pl->built = true;
     st_pack_values(st, A, pl, pu, f);
     // vectors travel level-major: the right-hand side in the L sweep's order, the intermediate vector and the result in the U sweep's
@@ -1275,8 +1204,7 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
 {
     (void)fwd;
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
-    hipLaunchKernelGGL(k_st_fill, dim3(256), dim3(256), 0, st, reinterpret_cast<unsigned long long *>(f->xch),
-                       reinterpret_cast<const long long *>(f->xcount), kSentinel);
+    fill_u64(st, reinterpret_cast<unsigned long long *>(pl->xch), pl->xch_len, kSentinel);
     const bool repack = !f->values_packed;
     if (repack) {
         // new values on the same pattern: the rows pass once more (it re-proves what it relies on)
@@ -1289,9 +1217,9 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     a.pkA = reinterpret_cast<const v2d *>(f->pkA);
     a.pkL = reinterpret_cast<v2d *>(pl->pk); a.pkU = reinterpret_cast<v2d *>(pu->pk);
     a.nchL = (int32_t)pl->nchunks; a.nchU = (int32_t)pu->nchunks;
-    a.xbase = f->xbase; a.xcount = f->xcount; a.xch = f->xch; a.ctrl = d_ctrl;
+    a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
     ILUPP_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(k_ilu0_st, dim3((unsigned)pl->nwg), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(k_ilu0_st, dim3((unsigned)pl->nwg), dim3(kStWgThreads), 0, st, a);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t ctrl[4], fl[4] = {0, 0, 0, 0};
