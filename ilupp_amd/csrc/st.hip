@@ -320,7 +320,14 @@ __global__ void k_st_scat(int32_t nslots, int32_t *__restrict__ ltabF, const int
             }
         }
         T[ST_SCAT + p] = sc;
-        R[28 + p] = sc;
+        {
+            // the forward dependency p's producer lane, when it is one of the 64 lanes of the same wave: lane | (k' - k + 128) << 8
+            const int sw = T[ST_SRC + p];
+            const int ty = p < T[ST_ND] ? (sw & 3) : ST_NONE;
+            const int os = sw >> 2;
+            R[28 + p] = ((ty == ST_OWN || ty == ST_LOCAL) && (os >> 6) == (f >> 6) && T[ST_KAP + p] > -128 && T[ST_KAP + p] < 128)
+                            ? ((os & 63) | ((T[ST_KAP + p] + 128) << 8)) : -1;
+        }
         R[4 + p] = T[ST_OFF + p]; R[8 + p] = TB[ST_OFF + p];
         R[12 + p] = T[ST_KLO + p]; R[16 + p] = T[ST_KHI + p];
         R[20 + p] = TB[ST_KLO + p]; R[24 + p] = TB[ST_KHI + p];
@@ -328,127 +335,209 @@ __global__ void k_st_scat(int32_t nslots, int32_t *__restrict__ ltabF, const int
     R[7] = nu; R[11] = T[ST_UP0];
 }
 
-// the transposed-entry halves of the factor records start out as "no such entry"
-__global__ void k_st_prefill(int64_t nchunks, v2d *__restrict__ pkA)
-{
-    const int64_t total = nchunks * 128;
-    v2d a; a.x = st_dbl(kAbsent); a.y = st_dbl(kAbsent);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        __builtin_nontemporal_store(a, pkA + (i >> 7) * 256 + 128 + (i & 127));
-}
-
 // ---------------------------------------------------------------------------------------------
 // analysis 4: the proof, row by row, and the factor kernel's input.  Per (chunk, lane) 64 bytes
 //   {a0,a1} {a2,a3} {t0,t1} {t2,a6}: a0..a2 the entries left of the diagonal by template position, a3 the diagonal,
-//   t_j = a(k_j, r) the transposed entry of elimination j (written by row k_j, below), a6 the last upper entry;
+//   t_j = a(k_j, r) the transposed entry of elimination j (fetched from row k_j), a6 the last upper entry;
 // the off-diagonal part {a4,a5} of the row of U goes straight into the backward sweep's record.
 // A block owns the 64 lanes of one wave x 8 consecutive rows of each; inside a wave 8 lanes x 8 rows, so a load
 // instruction touches 8 contiguous segments of A and a store instruction 8 neighbouring places of 8 chunks.
 // ---------------------------------------------------------------------------------------------
+// One row of A -> the ten doubles of its records {a0,a1} {a2,a3} {t0,t1} {t2,a6} {a4,a5}.  The row's entries come from LDS (the
+// lane's span), the transposed entries t_j = a(c_j, r) of the pivot rows c_j = r + oF[j] from LDS too when the pivot row is a
+// row of this block, else from A.
+struct StSpan { const double *v; const int *c; int len; };                 // a row: values, columns, entries
+__device__ __forceinline__ int st_row_find(const StSpan &s, int col)
+{
+    int at = -1;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) at = (i < s.len && s.c[i] == col) ? i : at;
+    return at;
+}
+
+// A block owns 8 consecutive rows (k0 .. k0+7) of each of the 64 lanes of a wave.  The vector-memory pipe takes about one cycle
+// per 64-byte piece an instruction touches, whatever it returns, and a row-per-thread read of A (56-byte rows, 16 bytes per
+// instruction) touches 64 pieces per instruction: the kernel was bound by that pipe (1.1 ms on 256^3, 26 % of the wave cycles
+// stalled at issue, 76 cycles per vector-memory instruction and CU).  So the 9 rows a lane contributes (one before the eight:
+// the pivot row of the first) are read as ONE contiguous run, 8 threads x 16 bytes per instruction, into LDS, and the rows
+// and most of the pivot rows are picked from there.
+#ifndef EXP_ROWS_NOSTORE
+#define EXP_ROWS_NOSTORE 0
+#endif
+#ifndef EXP_ROWS_NOGATHER
+#define EXP_ROWS_NOGATHER 0
+#endif
+#ifndef EXP_ROWS_NOU
+#define EXP_ROWS_NOU 0
+#endif
+static constexpr int kStSpanMax = 64;            // entries of a lane's run (9 rows of at most 7)
 __global__ void __launch_bounds__(512)
 k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval, int64_t nnz,
           const int32_t *__restrict__ rtab, const int32_t *__restrict__ wtab, v2d *__restrict__ pkA, v2d *__restrict__ pkU,
-          int32_t *__restrict__ flags)
+          int32_t *__restrict__ flags, int32_t groups)
 {
-    const int w = blockIdx.x;
-    const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
-    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
-    const v4i *R = reinterpret_cast<const v4i *>(rtab + (size_t)slot * 32);
-    const v4i t0 = R[0];                                                 // first, cnt, skew, nL
-    const int cnt = t0.y;
-    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
-    if (k >= cnt) return;
-    const v4i t1 = R[1], t2 = R[2];                                      // oL x3, nU | oU x3, up0
-    const int r = t0.x + k;
-    const int c = k + t0.z - wtab[(size_t)w * 4 + 1];
-    v2d *p = pkA + ((size_t)wtab[(size_t)w * 4] + c) * 256 + L;
-    const int a0 = Aptr[r];
-    const int len = Aptr[r + 1] - a0;
-    double v[8];
-    if ((int64_t)a0 + 8 <= nnz) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const D2s x = *reinterpret_cast<const D2s *>(Aval + a0 + 2 * i); v[2 * i] = x.v[0]; v[2 * i + 1] = x.v[1]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (int64_t)a0 + i < nnz ? Aval[a0 + i] : 0.0;
+    __shared__ double sv[64][kStSpanMax + 1];
+    __shared__ int si[64][kStSpanMax + 1];
+    __shared__ int rp[64][12];                   // row pointers of rows k0-1 .. k0+8 (the last: the end of row k0+7); -1: no such row
+    __shared__ int slo[64], sfirst[64];
+    const int w = blockIdx.x / groups;
+    const int k0 = (blockIdx.x % groups) * 8;
+    const int t = threadIdx.x;
+    const int slot0 = (w >> 2) * kThreads + (w & 3) * 64;
+    for (int q = t; q < 64 * 10; q += 512) {
+        const int l = q / 10, i = q % 10;
+        const v4i h = *reinterpret_cast<const v4i *>(rtab + (size_t)(slot0 + l) * 32);      // first, cnt, skew, nL
+        const int kr = k0 - 1 + i;
+        rp[l][i] = (kr >= 0 && kr <= h.y && k0 < h.y) ? Aptr[h.x + kr] : -1;
+        if (i == 0) sfirst[l] = h.x;
     }
-    int bad = (len > 7 || len < 1) ? 1 : 0;
-    const int ndF = t0.w, ndB = t1.w;
-    const int oF[3] = {t1.x, t1.y, t1.z};
-    const int oB[3] = {t2.x, t2.y, t2.z};
-    const Row8 own = load_row8(Aidx, a0, len > 8 ? 8 : len, nnz);
-    const double absent = st_dbl(kAbsent);
-    double a[7] = {absent, absent, absent, absent, absent, absent, absent};
-    int mask = 0;
-    // the row is sorted: cl entries left of the diagonal, the diagonal, the rest right of it; each side is matched
-    // against its own side of the template only
-    int cl = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) cl += own.c[i] < r ? 1 : 0;
-    if (cl > 3 || len - cl - 1 > 3 || len - cl - 1 < 0) bad = 1;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const bool in = i < cl;
-        const int o = own.c[i] - r;
-        const double vi = st_clean(v[i]);
-        bool hit = false;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const bool h = in && j < ndF && o == oF[j];
-            if (h) { a[j] = vi; mask |= 1 << j; }
-            hit |= h;
-        }
-        if (in && !hit) bad = 1;                            // a column outside the lane's template
-    }
+    __syncthreads();
+    const int l = t >> 3, sub = t & 7;
+    int bad = 0;
     {
-        const int cd = cl == 0 ? own.c[0] : cl == 1 ? own.c[1] : cl == 2 ? own.c[2] : own.c[3];
-        const double vd = cl == 0 ? v[0] : cl == 1 ? v[1] : cl == 2 ? v[2] : v[3];
-        if (cd == r) { a[3] = st_clean(vd); mask |= 8; }
-    }
+        // the lane's run: from its first row here to the end of its last
+        int lo = rp[l][0] >= 0 ? rp[l][0] : rp[l][1], hi = -1;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const bool in = cl + 1 + u < len;
-        const int cu = cl == 0 ? own.c[1 + u] : cl == 1 ? own.c[2 + u] : cl == 2 ? own.c[3 + u] : own.c[4 + u];
-        const double vu = st_clean(cl == 0 ? v[1 + u] : cl == 1 ? v[2 + u] : cl == 2 ? v[3 + u] : v[4 + u]);
-        const int o = cu - r;
-        bool hit = false;
+        for (int i = 1; i < 10; ++i) hi = rp[l][i] >= 0 ? rp[l][i] : hi;
+        const int len = lo >= 0 ? hi - lo : 0;
+        if (len > kStSpanMax) bad = 1;
+        if (sub == 0) slo[l] = lo;
+        if (!bad) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const bool h = in && q < ndB && o == oB[q];
-            if (h) { a[4 + q] = vu; mask |= 16 << q; }
-            hit |= h;
+            for (int it = 0; it < 4; ++it) {
+                const int e = (it * 8 + sub) * 2;
+                if (e + 1 < len) { const D2s x = *reinterpret_cast<const D2s *>(Aval + lo + e); sv[l][e] = x.v[0]; sv[l][e + 1] = x.v[1]; }
+                else if (e < len) sv[l][e] = Aval[lo + e];
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = (it * 8 + sub) * 4;
+                if (e + 3 < len) {
+                    const I4a x = *reinterpret_cast<const I4a *>(Aidx + lo + e);
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) si[l][e + z] = x.v[z];
+                } else {
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) if (e + z < len) si[l][e + z] = Aidx[lo + e + z];
+                }
+            }
         }
-        if (in && !hit) bad = 1;
     }
-    if (!(mask & 8)) bad = 1;
-    // every entry is produced where the template says
-    const v4i klF = R[3], khF = R[4], klB = R[5], khB = R[6], sc = R[7];
-    const int kb = cnt - 1 - k;                             // the row's index in the backward schedule
-    const int kl[3] = {klF.x, klF.y, klF.z}, kh[3] = {khF.x, khF.y, khF.z};
-    const int bl[3] = {klB.x, klB.y, klB.z}, bh[3] = {khB.x, khB.y, khB.z};
+    __syncthreads();
+    // the row of this thread: lane l, k = k0 + sub
+    const v4i *R = reinterpret_cast<const v4i *>(rtab + (size_t)(slot0 + l) * 32);
+    const v4i t0 = R[0];
+    const int cnt = t0.y, k = k0 + sub;
+    if (k < cnt && !bad) {
+        const v4i t1 = R[1], t2 = R[2];                                      // oL x3, nU | oU x3, up0
+        const int r = t0.x + k;
+        const int b = rp[l][sub + 1] - slo[l];
+        const int len = rp[l][sub + 2] - rp[l][sub + 1];
+        if (len > 7 || len < 1) bad = 1;
+        const int ndF = t0.w, ndB = t1.w;
+        const int oF[3] = {t1.x, t1.y, t1.z};
+        const int oB[3] = {t2.x, t2.y, t2.z};
+        const double absent = st_dbl(kAbsent);
+        double a[7] = {absent, absent, absent, absent, absent, absent, absent};
+        double tj[3] = {absent, absent, absent};
+        int mask = 0;
+        if (!bad) {
+            // the row is sorted: cl entries left of the diagonal, the diagonal, the rest right of it; each side is matched against
+            // its own side of the template only
+            int cc[7]; double v[7];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if ((mask & (1 << j)) && (k < kl[j] || k >= kh[j])) bad = 1;
-        if ((mask & (16 << j)) && (kb < bl[j] || kb >= bh[j])) bad = 1;
+            for (int i = 0; i < 7; ++i) { cc[i] = i < len ? si[l][b + i] : 0x7fffffff; v[i] = i < len ? st_clean(sv[l][b + i]) : 0.0; }
+            int cl = 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) cl += cc[i] < r ? 1 : 0;
+            if (cl > 3 || len - cl - 1 > 3 || len - cl - 1 < 0) bad = 1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const bool in = i < cl;
+                const int o = cc[i] - r;
+                bool hit = false;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const bool h = in && j < ndF && o == oF[j];
+                    if (h) { a[j] = v[i]; mask |= 1 << j; }
+                    hit |= h;
+                }
+                if (in && !hit) bad = 1;                            // a column outside the lane's template
+            }
+            {
+                const int cd = cl == 0 ? cc[0] : cl == 1 ? cc[1] : cl == 2 ? cc[2] : cc[3];
+                const double vd = cl == 0 ? v[0] : cl == 1 ? v[1] : cl == 2 ? v[2] : v[3];
+                if (cd == r) { a[3] = vd; mask |= 8; }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool in = cl + 1 + u < len;
+                const int cu = cl == 0 ? cc[1 + u] : cl == 1 ? cc[2 + u] : cl == 2 ? cc[3 + u] : cc[4 + u];
+                const double vu = cl == 0 ? v[1 + u] : cl == 1 ? v[2 + u] : cl == 2 ? v[3 + u] : v[4 + u];
+                const int o = cu - r;
+                bool hit = false;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const bool h = in && q < ndB && o == oB[q];
+                    if (h) { a[4 + q] = vu; mask |= 16 << q; }
+                    hit |= h;
+                }
+                if (in && !hit) bad = 1;
+            }
+            if (!(mask & 8)) bad = 1;
+            // every entry is produced where the template says
+            const v4i klF = R[3], khF = R[4], klB = R[5], khB = R[6], src = R[7];
+            const int kb = cnt - 1 - k;                             // the row's index in the backward schedule
+            const int kl[3] = {klF.x, klF.y, klF.z}, kh[3] = {khF.x, khF.y, khF.z};
+            const int bl[3] = {klB.x, klB.y, klB.z}, bh[3] = {khB.x, khB.y, khB.z};
+            const int sr[3] = {src.x, src.y, src.z};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if ((mask & (1 << j)) && (k < kl[j] || k >= kh[j])) bad = 1;
+                if ((mask & (16 << j)) && (kb < bl[j] || kb >= bh[j])) bad = 1;
+            }
+            // t_j = a(c_j, r): from the pivot row c_j = r + oF[j] (gathered, not scattered by the row that owns it: a scattered
+            // 8-byte store is a read-modify-write of a memory burst, and the records would have to be pre-filled)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (!bad && (mask & (1 << j))) {
+                    const int c = r + oF[j];
+                    bool done = false;
+                    if (sr[j] >= 0) {
+                        const int lp = sr[j] & 63, ip = k + ((sr[j] >> 8) - 128) - (k0 - 1);       // lane and row slot of the pivot row
+                        if (ip >= 0 && ip <= 8 && rp[lp][ip] >= 0 && rp[lp][ip + 1] >= 0 && sfirst[lp] + (k0 - 1 + ip) == c) {
+                            const int bp = rp[lp][ip] - slo[lp];
+                            StSpan sp; sp.v = &sv[lp][bp]; sp.c = &si[lp][bp]; sp.len = min(rp[lp][ip + 1] - rp[lp][ip], 7);
+                            const int at = st_row_find(sp, r);
+                            if (at >= 0) tj[j] = st_clean(sp.v[at]);
+                            done = true;
+                        }
+                    }
+                    if (!done && !EXP_ROWS_NOGATHER) {
+                        const int b0 = Aptr[c];
+                        const int bl_ = Aptr[c + 1] - b0;
+                        const Row8 rc = load_row8(Aidx, b0, bl_ > 8 ? 8 : bl_, nnz);
+                        int at_ = -1;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) at_ = rc.c[i] == r ? i : at_;
+                        if (at_ >= 0) tj[j] = st_clean(Aval[b0 + at_]);
+                    }
+                }
+            }
+        }
+        if (EXP_ROWS_NOSTORE) { if (a[0] + a[1] + a[2] + a[3] + tj[0] + tj[1] + tj[2] + a[6] + a[4] + a[5] == 1.2345) flags[2] = 1; }
+        else if (!bad) {
+            const int c = k + t0.z - wtab[(size_t)w * 4 + 1];
+            v2d *p = pkA + ((size_t)wtab[(size_t)w * 4] + c) * 256 + l;
+            v2d x;
+            x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, p);
+            x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, p + 64);
+            x.x = tj[0]; x.y = tj[1]; __builtin_nontemporal_store(x, p + 128);
+            x.x = tj[2]; x.y = a[6]; __builtin_nontemporal_store(x, p + 192);
+            if (!EXP_ROWS_NOU) { x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((long)t2.w - 128 * (long)k)); }
+        }
     }
-    if (bad) { atomicOr(&flags[0], 8); return; }
-    v2d x;
-    x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, p);
-    x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, p + 64);
-#ifndef EXP_ROWS_NOA6
-    reinterpret_cast<double *>(p + 192)[1] = a[6];
-#endif
-#ifndef EXP_ROWS_NOU
-    x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((long)t2.w - 128 * (long)k));
-#endif
-    // the upper entries, to the rows they meet
-    double *pd = reinterpret_cast<double *>(pkA);
-    const int scs[3] = {sc.x, sc.y, sc.z};
-#ifndef EXP_ROWS_NOSCAT
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-        if ((mask & (16 << q)) && scs[q] >= 0) pd[(long)scs[q] + 512 * (long)k] = a[4 + q];
-#endif
+    if (bad) atomicOr(&flags[0], 8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1088,10 +1177,10 @@ static void st_structure(hipStream_t st, const Schedule &sch, PackedSweep *ps, i
 
 static void st_pack_values(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, FactorLM *f)
 {
-    hipLaunchKernelGGL(k_st_prefill, dim3(2048), dim3(256), 0, st, (int64_t)pl->nchunks, reinterpret_cast<v2d *>(f->pkA));
-    const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));        // every lane has at most max_chunks rows
-    hipLaunchKernelGGL(k_st_rows, grid, dim3(512), 0, st, A.ptr, A.idx, A.val, (int64_t)A.nnz, f->xbase + pl->nwg * kThreads,
-                       pl->wtab, reinterpret_cast<v2d *>(f->pkA), reinterpret_cast<v2d *>(pu->pk), pl->flags);
+    const int groups = (int)((pl->max_chunks + 7) / 8);                                     // every lane has at most max_chunks rows
+    hipLaunchKernelGGL(k_st_rows, dim3((unsigned)(pl->nwg * 4 * groups)), dim3(512), 0, st, A.ptr, A.idx, A.val, (int64_t)A.nnz,
+                       f->xbase + pl->nwg * kThreads, pl->wtab, reinterpret_cast<v2d *>(f->pkA), reinterpret_cast<v2d *>(pu->pk),
+                       pl->flags, groups);
 }
 
 // The whole static analysis of an ILU(0): true when the factor kernel and both sweeps can run from lane tables
@@ -1129,36 +1218,34 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots * 33));
     hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
                        f->xbase + nslots, pl->flags);
+    // the exchange layouts of both schedules; their sizes come back with the flags (one wait for all)
     int32_t xtot[2][2];
+    int32_t *xsz = nullptr;
+    void *tmp2 = nullptr;
     {
-        int32_t *xsz = nullptr, *xoff = nullptr;
-        ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 2));
-        xoff = xsz + nwg;
+        ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 4));
         PackedSweep *pp[2] = {pl, pu};
         const Schedule *ss[2] = {&fwd, &bwd};
+        size_t tb2 = 0;
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, xsz, xsz + nwg, nwg, st));
+        ILUPP_HIP(pool_malloc(&tmp2, tb2));
         for (int d = 0; d < 2; ++d) {
+            int32_t *sz = xsz + 2 * d * nwg, *off = sz + nwg;
             ILUPP_HIP(pool_malloc(&pp[d]->xe, sizeof(int32_t) * (size_t)nslots));
             ILUPP_HIP(pool_malloc(&pp[d]->xw, sizeof(int32_t) * (size_t)nwg * 4));
             hipLaunchKernelGGL(k_st_xch_layout, dim3((unsigned)nwg), dim3(kThreads), 0, st, ss[d]->exported, pp[d]->ltab, pp[d]->wtab,
-                               pp[d]->xe, pp[d]->xw, xsz);
-            size_t tb2 = 0;
-            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, xsz, xoff, nwg, st));
-            void *tmp2 = nullptr;
-            ILUPP_HIP(pool_malloc(&tmp2, tb2));
-            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, xsz, xoff, nwg, st));
-            hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, xoff, pp[d]->xw);
-            ILUPP_HIP(d2h_async(st, &xtot[d][0], xoff + (nwg - 1), sizeof(int32_t)));
-            ILUPP_HIP(d2h_async(st, &xtot[d][1], xsz + (nwg - 1), sizeof(int32_t)));
-            ILUPP_HIP(stream_sync(st));
-            ILUPP_HIP(pool_free(tmp2));
+                               pp[d]->xe, pp[d]->xw, sz);
+            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, sz, off, nwg, st));
+            hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, off, pp[d]->xw);
+            ILUPP_HIP(d2h_async(st, &xtot[d][0], off + (nwg - 1), sizeof(int32_t)));
+            ILUPP_HIP(d2h_async(st, &xtot[d][1], sz + (nwg - 1), sizeof(int32_t)));
         }
-        ILUPP_HIP(pool_free(xsz));
     }
     int32_t hl[4], hu[4];
     ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
     ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
     ILUPP_HIP(stream_sync(st));
-    ILUPP_HIP(pool_free(inv));
+    ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(xsz)); ILUPP_HIP(pool_free(tmp2));
     const int64_t lim = 2 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;
     if (hl[0] || hu[0] || hu[3] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim ||
         hl[1] + 4 * nwg >= kStMaxChunks || hu[1] + 4 * nwg >= kStMaxChunks) {
