@@ -534,7 +534,7 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
             x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, p + 64);
             x.x = tj[0]; x.y = tj[1]; __builtin_nontemporal_store(x, p + 128);
             x.x = tj[2]; x.y = a[6]; __builtin_nontemporal_store(x, p + 192);
-            if (!EXP_ROWS_NOU) { x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((long)t2.w - 128 * (long)k)); }
+            if (!EXP_ROWS_NOU) { x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((size_t)wtab[(size_t)w * 4] + c) * 128 + l); }
         }
     }
     if (bad) atomicOr(&flags[0], 8);
@@ -582,8 +582,10 @@ struct StSArgs {
     const v2d *pk;                            // 2 x 64 x 16 B per chunk: {v0,v1}{v2,vdiag}, dependencies in accumulation order
     const int32_t *ltab, *wtab;
     int32_t n, nchY;                          // nchY: first spare chunk (one per wave) of ylm
-    const double *xlm;                        // forward: right-hand side, level-major in this sweep's order
-    double *ylm;                              // the intermediate vector / the result, level-major in the backward sweep's order
+    double *xlm;                              // level-major in the FORWARD sweep's order: the right-hand side, overwritten with the intermediate vector
+    double *ylm;                              // level-major in the backward sweep's order: the result
+    const int32_t *ysrc;                      // backward: where in xlm the lane's row 0 is (row k: - 64 k)
+    int32_t xlm_chunks;                       // chunks of xlm (and of the backward sweep's records)
     const int32_t *xe, *xw;                   // the exchange between workgroups (PackedSweep::xe, xw, xch): all-sentinel before the sweep
     double *xch;
     int32_t *ticket, *err;
@@ -629,27 +631,37 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
     const bool exports = cnt > 0 && xe >= 0;
     const int xE = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
     const int xoff = A.xw[wg * 4 + 3] - A.xw[wg * 4 + 1] * xE + xe;          // + step * xE: where this lane's value of a step goes
-    const unsigned char *pr = reinterpret_cast<const unsigned char *>(A.pk) + (size_t)(nchw > 0 ? base : 0) * 2048;
-    // forward: the right-hand side from xlm, chunk by chunk; backward: from ylm at this sweep's own chunks
-    const unsigned char *prr = reinterpret_cast<const unsigned char *>(DR > 0 ? A.xlm : A.ylm) + (size_t)(nchw > 0 ? base : 0) * 512;
-    unsigned char *py = reinterpret_cast<unsigned char *>(A.ylm);
+    const unsigned char *pr = reinterpret_cast<const unsigned char *>(A.pk) + (DR > 0 ? (size_t)(nchw > 0 ? base : 0) * 2048 : (size_t)0);
+    // forward: the right-hand side from xlm, chunk by chunk, and the intermediate vector back into the same place (a store
+    // in another order -- the backward sweep's -- would be 64 partial writes per instruction: lanes in descending address
+    // order do not merge; it cost the forward sweep 130 us on 256^3); backward: from xlm lane by lane (a load does not care)
+    const unsigned char *prr = reinterpret_cast<const unsigned char *>(A.xlm) + (DR > 0 ? (size_t)(nchw > 0 ? base : 0) * 512 : (size_t)0);
+    unsigned char *py = reinterpret_cast<unsigned char *>(DR > 0 ? A.xlm : A.ylm);
+    // (the backward sweep's records too are stored in the forward order: the factor kernel writes them)
+    const int ysrc_ = DR > 0 ? 0 : A.ysrc[slot];
+    const int ychunk0 = (ysrc_ >> 6) + sk;                               // chunk of step 0 (step s: - s)
+    const unsigned ylane16 = (unsigned)(ysrc_ & 63) * 16u;
     const unsigned lo16 = (unsigned)ln * 16u, lo8 = (unsigned)ln * 8u;
     const int cmax = nchw > 0 ? nchw - 1 : 0;
     const int ydump = A.nchY + wg * 4 + wv;                             // spare chunk of this wave (a shared one would be a hot spot)
-    // forward: where the lane's row 0 sits in the backward sweep's order (8-byte units; row k: - 64 k)
-    const int up0 = T[ST_UP0];
-    const int ypos0 = DR > 0 ? (up0 >> 7) * 64 + (up0 & 127) : 0;
-
     v2d ra[kStRA][2];
     double rr[kStRA];
 
 #define STS_LOAD(u, tp)                                                                                              \
     do {                                                                                                             \
-        const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                              \
-        const unsigned char *q_ = pr + (size_t)cw_ * 2048;                                                           \
-        ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                             \
-        ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                      \
-        rr[u] = __builtin_nontemporal_load(reinterpret_cast<const double *>(prr + (size_t)cw_ * 512 + lo8));         \
+        if (DR > 0) {                                                                                                \
+            const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                          \
+            const unsigned char *q_ = pr + (size_t)cw_ * 2048;                                                       \
+            ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                         \
+            ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                  \
+            rr[u] = __builtin_nontemporal_load(reinterpret_cast<const double *>(prr + (size_t)cw_ * 512 + lo8));     \
+        } else {                                                                                                     \
+            const unsigned ch_ = (unsigned)st_med3(ychunk0 - (tp), 0, A.xlm_chunks - 1);                             \
+            const unsigned char *q_ = pr + ch_ * 2048u + ylane16;                                                    \
+            ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_));                                \
+            ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + 1024));                         \
+            rr[u] = __builtin_nontemporal_load(reinterpret_cast<const double *>(prr + ch_ * 512u + (ylane16 >> 1))); \
+        }                                                                                                            \
     } while (0)
 
 #pragma unroll
@@ -715,10 +727,7 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
             *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u % kStH + kStH) * (kStRow * 8)) = x;
             // the stream store happens on every step (lanes / waves without a row store to the wave's spare chunk); unknowns
             // that other workgroups read: also to the natural-order vector, write-through
-            if (DR > 0) {
-                const unsigned yo = valid ? (unsigned)(ypos0 - 64 * k) * 8u : (unsigned)ydump * 512u + lo8;
-                __builtin_nontemporal_store(x, reinterpret_cast<double *>(py + yo));
-            } else {
+            {
                 const int cw = tb + u - tminw;
                 unsigned char *o = py + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ydump) * 512;
                 __builtin_nontemporal_store(x, reinterpret_cast<double *>(o + lo8));
@@ -889,8 +898,8 @@ k_sptrsv_st(StSArgs A)
 struct StFArgs {
     const int32_t *ltab, *wtab;               // forward schedule
     const v2d *pkA;                           // 4 x 64 x 16 B per chunk: {a0,a1}{a2,a3}{t0,t1}{t2,a6}
-    v2d *pkL, *pkU;                           // 2 x 64 x 16 B per chunk: {l0,l1}{l2,1} / {u1,u2}{u3,u0}; one spare chunk at the end each
-    int32_t nchL, nchU;                       // index of the first spare chunk (one per wave)
+    v2d *pkL, *pkU;                           // 2 x 64 x 16 B per chunk: {l0,l1}{l2,1} / {u1,u2}{u3,u0}, BOTH in the forward schedule's order
+    int32_t nchL;                             // index of the first spare chunk (one per wave)
     const int32_t *xe, *xw;                   // the forward schedule's exchange between workgroups (PackedSweep::xe, xw, xch),
     double *xch;                              // all-sentinel before the kernel: pivots of exported lanes
     int32_t *ctrl;                            // [0] ticket, [1] error
@@ -918,9 +927,8 @@ __device__ __forceinline__ void st_factor_wave(const StFArgs &A, unsigned char *
     const int cmax = nchw > 0 ? nchw - 1 : 0;
     // dump places: one spare chunk per wave behind the records (a place shared by all waves would be a hot spot)
     const int wglob = wg * 4 + wv;
-    const unsigned udump = (unsigned)(A.nchU + wglob) * 2048u + lo16;
+    const unsigned udump = (unsigned)(A.nchL + wglob) * 2048u + lo16;
     const int ldump = A.nchL + wglob;
-    const int up0 = T[ST_UP0];
 
     v2d ra[kStH][4];
 
@@ -996,8 +1004,8 @@ __device__ __forceinline__ void st_factor_wave(const StFArgs &A, unsigned char *
             // pivots that other workgroups read: write-through, to the exchange
             if (EX) st_agent_f64((exports && valid) ? A.xch + (xoff + (tb + u) * xE) : reinterpret_cast<double *>(pu + udump), w3);
             // the record stores happen on every step (lanes / waves without a row store to their dump place)
+            const int cw = tb + u - tminw;
             {
-                const int cw = tb + u - tminw;
                 unsigned char *o = pl + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048;
                 v2d la, lb;
                 la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
@@ -1007,8 +1015,7 @@ __device__ __forceinline__ void st_factor_wave(const StFArgs &A, unsigned char *
             }
             {
                 v2d ub; ub.x = r3.y; ub.y = w3;
-                const unsigned uo = valid ? (unsigned)(up0 - 128 * k) * 16u + 1024u : udump;
-                __builtin_nontemporal_store(ub, reinterpret_cast<v2d *>(pu + uo));
+                __builtin_nontemporal_store(ub, reinterpret_cast<v2d *>(pu + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048 + 1024 + lo16));
             }
             ST_T(5);
             STF_LOAD(u, tb + u + kStH);
@@ -1062,30 +1069,43 @@ k_ilu0_st(StFArgs A)
     }
 }
 
-// natural order <-> level-major order of a sweep (64 per chunk).  A block owns the 64 lanes of one wave x 8 consecutive rows of
-// each; inside a wave 8 lanes x 8 rows: both sides move 64-byte pieces.  TO_LM: xlm <- x; else x <- xlm.
-template <int DR, bool TO_LM>
+// natural order -> level-major order of the forward sweep (64 per chunk).  A wave writes one chunk (512 contiguous bytes: an
+// 8-byte store per lane into 64 different chunks would be 64 partial writes) and a block 32 consecutive chunks of its wave, so
+// what a lane reads -- 8 bytes of its run per chunk -- comes from the same two cache lines 32 times.
 __global__ void __launch_bounds__(512)
-k_st_vec(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, double *__restrict__ nat, double *__restrict__ lm)
+k_st_gather(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, const double *__restrict__ nat, double *__restrict__ lm)
 {
     const int w = blockIdx.x;
-    const int L = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
+    const int L = threadIdx.x & 63;
     const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
     const v4i t0 = *reinterpret_cast<const v4i *>(ltab + (size_t)slot * kStTab);          // first, cnt, skew, nd
-    const int k = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7);
+    const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = blockIdx.y * 32 + it * 8 + (threadIdx.x >> 6);
+        const int k = c + tmin - t0.z;
+        if (c < nch && k >= 0 && k < t0.y) lm[((size_t)base + c) * 64 + L] = nat[t0.x + k];
+    }
+}
+// level-major order of the backward sweep -> natural order.  Here the natural-order side is the one written: a wave takes 4
+// lanes x 16 consecutive rows of each (128 contiguous bytes per lane and instruction).
+__global__ void __launch_bounds__(512)
+k_st_scatter(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, double *__restrict__ nat, const double *__restrict__ lm)
+{
+    const int w = blockIdx.x >> 1;
+    const int L = (blockIdx.x & 1) * 32 + (threadIdx.x >> 6) * 4 + (threadIdx.x & 3);
+    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
+    const v4i t0 = *reinterpret_cast<const v4i *>(ltab + (size_t)slot * kStTab);          // first, cnt, skew, nd
+    const int k = blockIdx.y * 16 + 15 - ((threadIdx.x >> 2) & 15);                        // (rows descend along a backward lane)
     if (k >= t0.y) return;
     const size_t at = ((size_t)wtab[(size_t)w * 4] + (k + t0.z - wtab[(size_t)w * 4 + 1])) * 64 + L;
-    const int r = t0.x + DR * k;
-    if (TO_LM) lm[at] = nat[r]; else nat[r] = lm[at];
+    nat[t0.x - k] = lm[at];
 }
 
-// ---------------------------------------------------------------------------------------------
-// CSR values on demand
-// ---------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ void __launch_bounds__(512)
 k_st_unpack(const int32_t *__restrict__ ptr, int32_t *__restrict__ idx, double *__restrict__ val, const int32_t *__restrict__ wtab,
-            const int32_t *__restrict__ ltab, const v2d *__restrict__ pk)
+            const int32_t *__restrict__ ltab, const v2d *__restrict__ pk, const int32_t *__restrict__ ysrc)
 {
     constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
     constexpr int DR = FWD ? 1 : -1;
@@ -1100,7 +1120,9 @@ k_st_unpack(const int32_t *__restrict__ ptr, int32_t *__restrict__ idx, double *
     if (k < 0 || k >= T[ST_CNT]) return;
     const int r = T[ST_FIRST] + DR * k;
     const int q0 = ptr[r], q1 = ptr[r + 1];
-    const v2d *p = pk + ((size_t)base + c) * 128 + L;
+    // (the backward sweep's records are stored in the forward schedule's order: ysrc = chunk * 64 + lane of the lane's row 0)
+    const int pos = FWD ? 0 : ysrc[slot] - 64 * k;
+    const v2d *p = FWD ? pk + ((size_t)base + c) * 128 + L : pk + (size_t)(pos >> 6) * 128 + (pos & 63);
     const v2d a = p[0], b = p[64];
     const double v[3] = {a.x, a.y, b.x};
     val[FWD ? q1 - 1 : q0] = b.y;
@@ -1117,10 +1139,10 @@ void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const Packe
     const dim3 grid((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 7) / 8));
     if ((SweepKind)ps.kind == SWEEP_FWD_LAST_ASC)
         hipLaunchKernelGGL((k_st_unpack<SWEEP_FWD_LAST_ASC>), grid, dim3(512), 0, st, M.ptr, M.idx, M.val, ps.wtab, ps.ltab,
-                           reinterpret_cast<const v2d *>(ps.pk));
+                           reinterpret_cast<const v2d *>(ps.pk), static_cast<const int32_t *>(nullptr));
     else
         hipLaunchKernelGGL((k_st_unpack<SWEEP_BWD_FIRST_ASC>), grid, dim3(512), 0, st, M.ptr, M.idx, M.val, ps.wtab, ps.ltab,
-                           reinterpret_cast<const v2d *>(ps.pk));
+                           reinterpret_cast<const v2d *>(ps.pk), ps.ysrc);
     ILUPP_HIP(hipGetLastError());
 }
 
@@ -1257,14 +1279,15 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     pu->nchunks = hu[1]; pu->max_chunks = hu[2];
     // one spare chunk per wave each: where waves / lanes without a row at a step store
     ILUPP_HIP(pool_malloc(&pl->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));
-    ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pu->nchunks + 4 * nwg) * 2048));
+    ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));      // (the forward schedule's order: see k_sptrsv_st)
     ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
     pl->built = true;
     st_pack_values(st, A, pl, pu, f);
-    // vectors travel level-major: the right-hand side in the L sweep's order, the intermediate vector and the result in the U sweep's
-    ILUPP_HIP(pool_malloc(&pl->xlm, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
-    ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pu->nchunks + 4 * nwg)));
-    pl->y_chunks = pu->nchunks;
+    // vectors travel level-major: the right-hand side and the intermediate vector in the L sweep's order (pl->ybuf, in place), the
+    // result in the U sweep's (pu->xlm)
+    ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
+    ILUPP_HIP(pool_malloc(&pu->xlm, sizeof(double) * 64 * (size_t)(pu->nchunks + 4 * nwg)));
+    pu->y_chunks = pl->nchunks + 4 * nwg;
     pl->xch_len = (int64_t)xtot[0][0] + xtot[0][1] + 64;
     pu->xch_len = (int64_t)xtot[1][0] + xtot[1][1] + 64;
     ILUPP_HIP(pool_malloc(&pl->xch, sizeof(double) * (size_t)pl->xch_len));
@@ -1303,7 +1326,7 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     a.ltab = pl->ltab; a.wtab = pl->wtab;
     a.pkA = reinterpret_cast<const v2d *>(f->pkA);
     a.pkL = reinterpret_cast<v2d *>(pl->pk); a.pkU = reinterpret_cast<v2d *>(pu->pk);
-    a.nchL = (int32_t)pl->nchunks; a.nchU = (int32_t)pu->nchunks;
+    a.nchL = (int32_t)pl->nchunks;
     a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
     ILUPP_HIP(hipEventRecord(e0, st));
     hipLaunchKernelGGL(k_ilu0_st, dim3((unsigned)pl->nwg), dim3(kStWgThreads), 0, st, a);
@@ -1319,21 +1342,20 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     return ILUPP_OK;
 }
 
-// One sweep of an apply.  Forward: `rhs` (natural order) -> the intermediate vector in `ylm` (= the forward sweep's ybuf, in the
-// BACKWARD sweep's level-major order); backward: `ylm` -> the result in `out` (natural order).  `out` also is where the values
-// other workgroups poll are stored (all-sentinel before the sweep).
+// One sweep of an apply.  Forward: `rhs` (natural order) -> the intermediate vector in `ypk_out` (the forward sweep's ybuf, in the
+// forward sweep's level-major order); backward: `ypk_in` (the same buffer) -> the result in `out` (natural order).
 int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
               int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
-    (void)ysrc;
+    (void)sch;
     const bool fwd = ps.kind == (int)SWEEP_FWD_LAST_ASC;
-    double *ylm = fwd ? ypk_out : const_cast<double *>(ypk_in);
-    if (!ylm) { set_error("static sweep without its level-major vector"); return ILUPP_ERR_INVALID; }
-    const dim3 gridv((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 7) / 8));
+    double *lml = fwd ? ypk_out : const_cast<double *>(ypk_in);        // level-major, forward order
+    if (!lml || (!fwd && (!ysrc || !ps.xlm))) { set_error("static sweep without its level-major vector"); return ILUPP_ERR_INVALID; }
     StSArgs a;
     a.pk = reinterpret_cast<const v2d *>(ps.pk); a.ltab = ps.ltab; a.wtab = ps.wtab; a.n = n;
-    a.nchY = (int32_t)(fwd ? ps.y_chunks : ps.nchunks);
-    a.xlm = ps.xlm; a.ylm = ylm;
+    a.nchY = (int32_t)ps.nchunks;
+    a.xlm = lml; a.ylm = fwd ? nullptr : ps.xlm;
+    a.ysrc = ysrc; a.xlm_chunks = (int32_t)(fwd ? ps.nchunks : ps.y_chunks);
     a.xe = ps.xe; a.xw = ps.xw; a.xch = ps.xch; a.ticket = d_ticket; a.err = d_err;
     fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
     const dim3 grid((unsigned)ps.nwg);
@@ -1350,11 +1372,12 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
         });
     }
     if (fwd) {
-        hipLaunchKernelGGL((k_st_vec<1, true>), gridv, dim3(512), 0, st, ps.ltab, ps.wtab, const_cast<double *>(rhs), ps.xlm);
+        hipLaunchKernelGGL(k_st_gather, dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab, rhs, lml);
         hipLaunchKernelGGL((k_sptrsv_st<1>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
         hipLaunchKernelGGL((k_sptrsv_st<-1>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
-        hipLaunchKernelGGL((k_st_vec<-1, false>), gridv, dim3(512), 0, st, ps.ltab, ps.wtab, out, ylm);
+        hipLaunchKernelGGL(k_st_scatter, dim3((unsigned)(ps.nwg * 8), (unsigned)((ps.max_chunks + 15) / 16)), dim3(512), 0, st, ps.ltab, ps.wtab, out,
+                           static_cast<const double *>(ps.xlm));
     }
     ILUPP_HIP(hipGetLastError());
     return ILUPP_OK;
