@@ -343,15 +343,22 @@ __global__ void k_st_scat(int32_t nslots, int32_t *__restrict__ ltabF, const int
 // A block owns the 64 lanes of one wave x 8 consecutive rows of each; inside a wave 8 lanes x 8 rows, so a load
 // instruction touches 8 contiguous segments of A and a store instruction 8 neighbouring places of 8 chunks.
 // ---------------------------------------------------------------------------------------------
+// workgroup id -> position in the work list such that each of the 8 XCDs (workgroup id modulo 8) gets a contiguous eighth
+__device__ __forceinline__ int st_xcd_order(int b, int n)
+{
+    const int per = n >> 3, x = b & 7, q = b >> 3;
+    return q < per ? x * per + q : b;                  // (the tail n % 8 stays where it is)
+}
+
 // One row of A -> the ten doubles of its records {a0,a1} {a2,a3} {t0,t1} {t2,a6} {a4,a5}.  The row's entries come from LDS (the
 // lane's span), the transposed entries t_j = a(c_j, r) of the pivot rows c_j = r + oF[j] from LDS too when the pivot row is a
 // row of this block, else from A.
-struct StSpan { const double *v; const int *c; int len; };                 // a row: values, columns, entries
+struct StSpan { const double *v; const int *c; int len, room; };           // a row: values, columns, entries; readable places from c
 __device__ __forceinline__ int st_row_find(const StSpan &s, int col)
 {
     int at = -1;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) at = (i < s.len && s.c[i] == col) ? i : at;
+    for (int i = 0; i < 7; ++i) { const int ci = s.c[min(i, s.room)]; at = (i < s.len && ci == col) ? i : at; }
     return at;
 }
 
@@ -380,8 +387,11 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
     __shared__ int si[64][kStSpanMax + 1];
     __shared__ int rp[64][12];                   // row pointers of rows k0-1 .. k0+8 (the last: the end of row k0+7); -1: no such row
     __shared__ int slo[64], sfirst[64];
-    const int w = blockIdx.x / groups;
-    const int k0 = (blockIdx.x % groups) * 8;
+    // consecutive workgroups go to different XCDs, each with its own L2: hand every XCD a contiguous range of (wave, rows), so
+    // that the cache lines two neighbouring runs share are fetched once
+    const int bid = st_xcd_order(blockIdx.x, gridDim.x);
+    const int w = bid / groups;
+    const int k0 = (bid % groups) * 8;
     const int t = threadIdx.x;
     const int slot0 = (w >> 2) * kThreads + (w & 3) * 64;
     for (int q = t; q < 64 * 10; q += 512) {
@@ -446,7 +456,12 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
             // its own side of the template only
             int cc[7]; double v[7];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { cc[i] = i < len ? si[l][b + i] : 0x7fffffff; v[i] = i < len ? st_clean(sv[l][b + i]) : 0.0; }
+            // (unconditional reads at clamped places, then a select: a read under a condition is a branch around it)
+            for (int i = 0; i < 7; ++i) {
+                const int e = min(b + i, kStSpanMax);
+                const int ci = si[l][e]; const double vi = sv[l][e];
+                cc[i] = i < len ? ci : 0x7fffffff; v[i] = i < len ? st_clean(vi) : 0.0;
+            }
             int cl = 0;
 #pragma unroll
             for (int i = 0; i < 7; ++i) cl += cc[i] < r ? 1 : 0;
@@ -507,7 +522,7 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
                         const int lp = sr[j] & 63, ip = k + ((sr[j] >> 8) - 128) - (k0 - 1);       // lane and row slot of the pivot row
                         if (ip >= 0 && ip <= 8 && rp[lp][ip] >= 0 && rp[lp][ip + 1] >= 0 && sfirst[lp] + (k0 - 1 + ip) == c) {
                             const int bp = rp[lp][ip] - slo[lp];
-                            StSpan sp; sp.v = &sv[lp][bp]; sp.c = &si[lp][bp]; sp.len = min(rp[lp][ip + 1] - rp[lp][ip], 7);
+                            StSpan sp; sp.v = &sv[lp][bp]; sp.c = &si[lp][bp]; sp.len = min(rp[lp][ip + 1] - rp[lp][ip], 7); sp.room = kStSpanMax - bp;
                             const int at = st_row_find(sp, r);
                             if (at >= 0) tj[j] = st_clean(sp.v[at]);
                             done = true;
