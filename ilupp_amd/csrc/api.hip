@@ -158,6 +158,7 @@ struct ilupp_precond {
     Ilu0Program prog;                // ILU(0) update program for sA (empty -> generic kernel)
     int32_t *prog_f3 = nullptr;      // fixed-size program (short-row matrices): loader/consumer kernel
     bool compact = false;            // descriptors/program usable (block size and grid within the encoding)
+    bool no_static_T = false;        // the static form's transposed records were tried and declined
     int32_t *dL = nullptr, *dU = nullptr, *dUT = nullptr, *dLT = nullptr;   // solve descriptors
     PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
     PackedSweep pkUT, pkLT;          // ... of the transposed storages
@@ -298,21 +299,38 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     int32_t missing = -1;
     // one pass over A's pattern: row counts of L and U, diagonal check, and the factor-sweep schedules (L shares A's
     // forward cuts and U its backward cuts: same strictly-lower / strictly-upper patterns)
-    int rc = ilu0_symbolic_and_schedule(st, A, &p->Lc, &p->Uc, &missing, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
+    // The static kernels take workgroups in ticket order and only ever wait for lower tickets, so they do not need the whole
+    // schedule resident at once: they get one lane per chain however many chains there are (a 288^3 mesh has 82 944 lines for
+    // the 65 536 lanes of the chip).  The older generations poll any workgroup and need co-residency: if the static analysis
+    // declines such a schedule, it is rebuilt for the resident lanes below.
+    const int lanes_static = 1 << 24;
+    int rc = ilu0_symbolic_and_schedule(st, A, &p->Lc, &p->Uc, &missing, lanes_static, &p->sA, &p->sU, &p->max_row_len);
     if (rc == ILUPP_ERR_NO_DIAGONAL) {
         set_error("ILU0: structurally missing diagonal entry in row " + std::to_string(missing));
         return rc;
     }
     if (rc) return rc;
     const int max_wgs = p->max_lanes / kThreads;
-    choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
+    choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, lanes_static / kThreads);
     build_slot_tables(st, &p->sA, true);
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
     bool have_prog = false;
     // static form first (lane tables, values-only records: st.hip), then the record-decoding level-major form
-    const bool lm = p->compact && (st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm) ||
-                                   lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm));
+    // (the static form has no descriptor words: no limit on block size or number of slots)
+    bool lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
+    if (!lm) {
+        if (p->sA.nslots > p->max_lanes || p->sU.nslots > p->max_lanes) {
+            p->sA.release(); p->sU.release();
+            rc = count_cuts_and_schedule(st, A.n, A.ptr, A.idx, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
+            if (rc) return rc;
+            choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
+            build_slot_tables(st, &p->sA, true);
+            build_slot_tables(st, &p->sU, false);
+            p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
+        }
+        lm = p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
+    }
     // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
     // transposed solves): the pass runs on the side stream next to the persistent factor kernel, which is bound by
     // dependency latency and leaves most of the memory system idle.
@@ -489,6 +507,14 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), p2, y, x, t2, err, nullptr,
                   ylm ? p->pkL.ybuf : nullptr, ylm ? p->pkU.ysrc : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
+        } else if (p->flm.stat && p->pkL.stat && p->pkU.stat && !p->no_static_T &&
+                   (st_build_transposed(st, p->sA, p->n, p->flm, &p->pkL, &p->pkU, p->Lc.nnz - p->n, p->Uc.nnz - p->n) || (p->no_static_T = true, false))) {
+            // static form: the same two sweep kernels on records of U^T and L^T
+            ILUPP_HIP(hipEventRecord(p->ev[0], st));
+            { const int rc_ = sptrsv_st_T(st, p->pkL, p->n, x, y, t1, err, p->pkL.ybuf, nullptr); if (rc_) return rc_; }
+            ILUPP_HIP(hipEventRecord(p->ev[1], st));
+            { const int rc_ = sptrsv_st_T(st, p->pkU, p->n, y, x, t2, err, p->pkL.ybuf, p->pkU.ysrc); if (rc_) return rc_; }
+            ILUPP_HIP(hipEventRecord(p->ev[2], st));
         } else {
             ensure_transposed(p);
             const PackedSweep *p1 = packed(p, 2, SWEEP_FWD_LAST_ASC, p->UcT, p->sUT, p->dUT, MAXLEN_OF(p->UcT), &p->pkUT);
@@ -646,6 +672,7 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[1], p->ev[2]));
     p->tm.numeric_kernel_ms = kms;
     p->apply_events_valid = false;
+    st_drop_transposed(&p->pkL, &p->pkU);
     if (p->haveT) {
         p->LcT.release(); p->UcT.release(); p->sUT.release(); p->sLT.release();
         if (p->dUT) (void)pool_free(p->dUT);

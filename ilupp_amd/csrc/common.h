@@ -95,6 +95,9 @@ struct PackedSweep {
     int32_t *xe = nullptr, *xw = nullptr;
     double *xch = nullptr;
     int64_t xch_len = 0;
+    // records of the TRANSPOSED factor for this sweep's schedule (static form; built on the first transposed apply, dropped
+    // by a re-factorisation): forward schedule: U^T (diagonal u_rr), backward schedule: L^T (diagonal 1)
+    unsigned char *pkT = nullptr;
     void release();
 };
 
@@ -297,5 +300,11 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err, double *ypk_out = nullptr, const double *ypk_in = nullptr,
               const int32_t *ysrc = nullptr);
 void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
+// static form, transposed apply: records of U^T / L^T from those of L and U (false: the pattern is not symmetric enough)
+bool st_build_transposed(hipStream_t st, const Schedule &fwd, int32_t n, const FactorLM &f, PackedSweep *pl, PackedSweep *pu,
+                         int64_t offdiagL, int64_t offdiagU);
+void st_drop_transposed(PackedSweep *pl, PackedSweep *pu);
+int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rhs, double *out, int32_t *d_ticket, int32_t *d_err,
+                double *lml, const int32_t *ysrc);
 
 }  // namespace ilupp

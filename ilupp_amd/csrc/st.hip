@@ -632,7 +632,7 @@ struct StPair { int idx0, stride, sk, klo, khi; };   // the value of step s is x
 // EX: some lane's unknowns are read by later workgroups (a template parameter, not a branch: hipcc's waitcnt pass only counts the
 // memory operations it is sure were issued, so a store inside a branch makes every later wait of a wave that does execute it
 // stricter than meant by one)
-template <int DR, bool EX>
+template <int DR, bool EX, bool TR>
 __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *xh, const int wg, const unsigned *va, const int tlo, const int thi)
 {
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
@@ -713,7 +713,7 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
             // (the forward sweep does not divide: the diagonal is used HERE so that its register stays taken until this
             // step -- a dead quarter of a 16-byte load is a free register to the allocator, and whatever it puts there has
             // to wait for that load, a load of a later step)
-            if (DR > 0) pj[2] = pj[2] && st_bits(vb.y) != kAbsent;
+            if (DR > 0 && !TR) pj[2] = pj[2] && st_bits(vb.y) != kAbsent;
             ST_BARRIER();
             ST_T(1);
             double xs[3];
@@ -725,14 +725,17 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
             ST_T(2);
             ST_T(3);
             // sequential accumulation in stored order; the division by a diagonal of 1.0 would return the dividend
+            // (transposed factors: U^T forward with its diagonal; L^T backward in DESCENDING column order -- the reference walks
+            // the columns of a row-stored L from the last to the first, sparse_implementation.h:4040-4087)
             double acc = rr[u];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int jj = 0; jj < 3; ++jj) {
+                const int j = (TR && DR < 0) ? 2 - jj : jj;
                 const double p = v[j] * xs[j];
                 const double na = acc - p;
                 acc = pj[j] ? na : acc;
             }
-            double x = DR > 0 ? acc : acc / vb.y;
+            double x = (DR > 0 && !TR) ? acc : acc / vb.y;
             if (x != x) x = st_dbl(kCanonNaN);
 #ifdef ST_STAMP
             asm volatile("" :: "v"(x));
@@ -860,7 +863,7 @@ __device__ __forceinline__ void st_number_pairs(const int32_t *T, const int t, c
     }
 }
 
-template <int DR>
+template <int DR, bool TR>
 __global__ void __launch_bounds__(kStWgThreads)
 k_sptrsv_st(StSArgs A)
 {
@@ -895,7 +898,7 @@ k_sptrsv_st(StSArgs A)
         if (t == 0 && s_total > 64) atomicExch(A.err, 1);             // (the analysis does not let such a schedule through)
         const bool wave_exports = __any(cnt > 0 && A.xe[slot] >= 0);
         // (every wave passes the same number of barriers whichever variant it runs)
-        if (wave_exports) st_sweep_wave<DR, true>(A, xh, wg, va, tlo, thi); else st_sweep_wave<DR, false>(A, xh, wg, va, tlo, thi);
+        if (wave_exports) st_sweep_wave<DR, true, TR>(A, xh, wg, va, tlo, thi); else st_sweep_wave<DR, false, TR>(A, xh, wg, va, tlo, thi);
     } else {
         __syncthreads();
         __syncthreads();                                              // (the one inside st_number_pairs)
@@ -1168,12 +1171,19 @@ void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const Packe
 static constexpr int kStXAlign = 16;          // first step of a workgroup's exchange rows: its first step rounded down to this
 __global__ void __launch_bounds__(kThreads)
 k_st_xch_layout(const int32_t *__restrict__ exported, const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab,
-                int32_t *__restrict__ xe, int32_t *__restrict__ xw, int32_t *__restrict__ xsz)
+                int32_t *__restrict__ xe, int32_t *__restrict__ xw, int32_t *__restrict__ xsz, int32_t *__restrict__ flags)
 {
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[4], s_pairs;
     const int wg = blockIdx.x, t = threadIdx.x, wv = t >> 6;
     const int slot = wg * kThreads + t;
-    const bool ex = ltab[(size_t)slot * kStTab + ST_CNT] > 0 && exported[slot] != 0;
+    const int32_t *T = ltab + (size_t)slot * kStTab;
+    const bool ex = T[ST_CNT] > 0 && exported[slot] != 0;
+    // the courier wave of the kernels serves at most 64 (lane, dependency) pairs that come from earlier workgroups
+    if (t == 0) s_pairs = 0;
+    __syncthreads();
+    int ng = 0;
+    for (int j = 0; j < 3; ++j) ng += (j < T[ST_ND] && T[ST_CNT] > 0 && (T[ST_SRC + j] & 3) == ST_GHOST) ? 1 : 0;
+    if (ng) atomicAdd(&s_pairs, ng);
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(ex);
     if ((t & 63) == 0) s_cnt[wv] = __popcll(bal);
     __syncthreads();
@@ -1192,6 +1202,7 @@ k_st_xch_layout(const int32_t *__restrict__ exported, const int32_t *__restrict_
         tlo &= ~(kStXAlign - 1);
         xw[wg * 4 + 0] = E; xw[wg * 4 + 1] = tlo; xw[wg * 4 + 2] = thi - tlo; xw[wg * 4 + 3] = 0;
         xsz[wg] = E * (thi - tlo);
+        if (s_pairs > 64) atomicOr(&flags[0], 32);
     }
 }
 __global__ void k_st_xch_rows(int32_t nwg, const int32_t *__restrict__ xoff, int32_t *__restrict__ xw)
@@ -1271,7 +1282,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
             ILUPP_HIP(pool_malloc(&pp[d]->xe, sizeof(int32_t) * (size_t)nslots));
             ILUPP_HIP(pool_malloc(&pp[d]->xw, sizeof(int32_t) * (size_t)nwg * 4));
             hipLaunchKernelGGL(k_st_xch_layout, dim3((unsigned)nwg), dim3(kThreads), 0, st, ss[d]->exported, pp[d]->ltab, pp[d]->wtab,
-                               pp[d]->xe, pp[d]->xw, sz);
+                               pp[d]->xe, pp[d]->xw, sz, pp[d]->flags);
             ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, sz, off, nwg, st));
             hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, off, pp[d]->xw);
             ILUPP_HIP(d2h_async(st, &xtot[d][0], off + (nwg - 1), sizeof(int32_t)));
@@ -1382,15 +1393,159 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
         int dev = 0;
         ILUPP_HIP(hipGetDevice(&dev));
         std::call_once(once[dev & 63], [] {
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<-1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
         });
     }
     if (fwd) {
         hipLaunchKernelGGL(k_st_gather, dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab, rhs, lml);
-        hipLaunchKernelGGL((k_sptrsv_st<1>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        hipLaunchKernelGGL((k_sptrsv_st<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
-        hipLaunchKernelGGL((k_sptrsv_st<-1>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        hipLaunchKernelGGL((k_sptrsv_st<-1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        hipLaunchKernelGGL(k_st_scatter, dim3((unsigned)(ps.nwg * 8), (unsigned)((ps.max_chunks + 15) / 16)), dim3(512), 0, st, ps.ltab, ps.wtab, out,
+                           static_cast<const double *>(ps.xlm));
+    }
+    ILUPP_HIP(hipGetLastError());
+    return ILUPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transposed apply on the static form: records of U^T (forward schedule) and L^T (backward schedule) from those of L and U.
+// Row r of U^T has u(k, r) for the rows k = r + oF[j] of r's lower template, row r of L^T has l(k, r) for k = r + oB[q]; the
+// entry sits in row k's record at the template position whose offset is the opposite one.  Every row is found through the
+// forward schedule (block -> slot -> chunk); both outputs are stored in the forward order (as pkL / pkU are).
+// count[0], count[1]: entries placed (the host compares them with the factors' entry counts: a pattern whose transposed
+// rows do not fit the lanes' templates keeps the generic transposed solves).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+k_st_transpose(const int32_t *__restrict__ rtab, const int32_t *__restrict__ wtab, int32_t n, int32_t B, int32_t nb,
+               const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot,
+               const v2d *__restrict__ pkL, const v2d *__restrict__ pkU, v2d *__restrict__ pkUT, v2d *__restrict__ pkLT,
+               unsigned long long *__restrict__ count)
+{
+    const int w = blockIdx.x;
+    const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
+    const int L = threadIdx.x & 63;
+    const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
+    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
+    const v4i *R = reinterpret_cast<const v4i *>(rtab + (size_t)slot * 32);
+    const v4i t0 = R[0], t1 = R[1], t2 = R[2];                           // first, cnt, skew, nL | oL x3, nU | oU x3, -
+    const int k = tmin + c - t0.z;
+    const bool live = c < nch && k >= 0 && k < t0.y;                     // (no early exit: the wave sums its counts below)
+    const int r = t0.x + k;
+    const double absent = st_dbl(kAbsent);
+    const v2d *own = pkU + ((size_t)base + (live ? c : 0)) * 128 + L;
+    double ut[3] = {absent, absent, absent}, lt[3] = {absent, absent, absent};
+    const int oF[3] = {t1.x, t1.y, t1.z}, oB[3] = {t2.x, t2.y, t2.z};
+    int nu = 0, nl = 0;
+    // an entry only counts where the lane's template names the right producer for it (the rows k of R[3..6]); one that does
+    // not is not placed, the totals then differ from the factors' and the host keeps the generic transposed solves
+    const v4i klF = R[3], khF = R[4], klB = R[5], khB = R[6];
+    const int klo[2][3] = {{klF.x, klF.y, klF.z}, {klB.x, klB.y, klB.z}}, khi[2][3] = {{khF.x, khF.y, khF.z}, {khB.x, khB.y, khB.z}};
+    const int kside[2] = {k, t0.y - 1 - k};
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int o = side == 0 ? oF[j] : oB[j];
+            if (!live || j >= (side == 0 ? t0.w : t1.w)) continue;
+            const int kr = r + o;
+            if (kr < 0 || kr >= n) continue;
+            const int b = block_of(kr, B, nb, start);
+            const int ps = blk2slot[b];
+            const v4i *P = reinterpret_cast<const v4i *>(rtab + (size_t)ps * 32);
+            const v4i p0 = P[0], p1 = P[1], p2 = P[2];
+            const int kk = kr - p0.x;
+            if (kk < 0 || kk >= p0.y) continue;
+            const int pw = ps >> 6;
+            const size_t at = ((size_t)wtab[(size_t)pw * 4] + (kk + p0.z - wtab[(size_t)pw * 4 + 1])) * 128 + (ps & 63);
+            // the producer row's template position with the opposite offset: its upper side for U^T, its lower side for L^T
+            const int po[3] = {side == 0 ? p2.x : p1.x, side == 0 ? p2.y : p1.y, side == 0 ? p2.z : p1.z};
+            const int pn = side == 0 ? p1.w : p0.w;
+            const v2d *src = (side == 0 ? pkU : pkL) + at;
+            const v2d a = src[0], bq = src[64];
+            const double pv[3] = {a.x, a.y, bq.x};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < pn && po[q] == -o && st_bits(pv[q]) != kAbsent && kside[side] >= klo[side][j] && kside[side] < khi[side][j]) {
+                    if (side == 0) { ut[j] = pv[q]; ++nu; } else { lt[j] = pv[q]; ++nl; }
+                }
+        }
+    }
+    if (live) {
+    v2d x;
+    v2d *pu_ = pkUT + ((size_t)base + c) * 128 + L;
+    x.x = ut[0]; x.y = ut[1]; __builtin_nontemporal_store(x, pu_);
+    x.x = ut[2]; x.y = own[64].y; __builtin_nontemporal_store(x, pu_ + 64);            // diagonal of U
+    v2d *pl_ = pkLT + ((size_t)base + c) * 128 + L;
+    x.x = lt[0]; x.y = lt[1]; __builtin_nontemporal_store(x, pl_);
+    x.x = lt[2]; x.y = 1.0; __builtin_nontemporal_store(x, pl_ + 64);
+    }
+    // (per-wave partial sums: one atomic per wave and side)
+    for (int off = 32; off > 0; off >>= 1) { nu += __shfl_xor(nu, off); nl += __shfl_xor(nl, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&count[0], (unsigned long long)nu); atomicAdd(&count[1], (unsigned long long)nl); }
+}
+
+void st_drop_transposed(PackedSweep *pl, PackedSweep *pu)
+{
+    if (pl->pkT) { (void)pool_free(pl->pkT); pl->pkT = nullptr; }
+    if (pu->pkT) { (void)pool_free(pu->pkT); pu->pkT = nullptr; }
+}
+
+bool st_build_transposed(hipStream_t st, const Schedule &fwd, int32_t n, const FactorLM &f, PackedSweep *pl, PackedSweep *pu,
+                         int64_t offdiagL, int64_t offdiagU)
+{
+    const int32_t *rtab = f.xbase + (size_t)pl->nwg * kThreads;
+    if (pl->pkT && pu->pkT) return true;
+    st_drop_transposed(pl, pu);
+    const size_t bytes = (size_t)(pl->nchunks + 4 * pl->nwg) * 2048;
+    unsigned long long *cnt = nullptr;
+    ILUPP_HIP(pool_malloc(&pl->pkT, bytes));
+    ILUPP_HIP(pool_malloc(&pu->pkT, bytes));
+    ILUPP_HIP(pool_malloc(&cnt, 16));
+    ILUPP_HIP(hipMemsetAsync(cnt, 0, 16, st));
+    const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
+    hipLaunchKernelGGL(k_st_transpose, grid, dim3(512), 0, st, rtab, pl->wtab, n, fwd.B, fwd.nb,
+                       fwd.start, fwd.blk2slot, reinterpret_cast<const v2d *>(pl->pk), reinterpret_cast<const v2d *>(pu->pk),
+                       reinterpret_cast<v2d *>(pl->pkT), reinterpret_cast<v2d *>(pu->pkT), cnt);
+    unsigned long long h[2] = {0, 0};
+    ILUPP_HIP(d2h_async(st, h, cnt, 16));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(cnt));
+    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] static transposed records: %lld of %lld entries of U, %lld of %lld of L\n", (long long)h[0],
+                                       (long long)offdiagU, (long long)h[1], (long long)offdiagL);
+    if ((int64_t)h[0] != offdiagU || (int64_t)h[1] != offdiagL) { st_drop_transposed(pl, pu); return false; }
+    return true;
+}
+
+// a sweep of the transposed apply: forward with U^T (pl's schedule and pkT), backward with L^T (pu's)
+int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rhs, double *out, int32_t *d_ticket, int32_t *d_err,
+                double *lml, const int32_t *ysrc)
+{
+    const bool fwd = ps.kind == (int)SWEEP_FWD_LAST_ASC;
+    if (!lml || !ps.pkT || (!fwd && (!ysrc || !ps.xlm))) { set_error("static transposed sweep without its records"); return ILUPP_ERR_INVALID; }
+    StSArgs a;
+    a.pk = reinterpret_cast<const v2d *>(ps.pkT); a.ltab = ps.ltab; a.wtab = ps.wtab; a.n = n;
+    a.nchY = (int32_t)ps.nchunks;
+    a.xlm = lml; a.ylm = fwd ? nullptr : ps.xlm;
+    a.ysrc = ysrc; a.xlm_chunks = (int32_t)(fwd ? ps.nchunks : ps.y_chunks);
+    a.xe = ps.xe; a.xw = ps.xw; a.xch = ps.xch; a.ticket = d_ticket; a.err = d_err;
+    fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
+    const dim3 grid((unsigned)ps.nwg);
+    {
+        static std::once_flag once[64];      // once per device
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+        });
+    }
+    if (fwd) {
+        hipLaunchKernelGGL(k_st_gather, dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab, rhs, lml);
+        hipLaunchKernelGGL((k_sptrsv_st<1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+    } else {
+        hipLaunchKernelGGL((k_sptrsv_st<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
         hipLaunchKernelGGL(k_st_scatter, dim3((unsigned)(ps.nwg * 8), (unsigned)((ps.max_chunks + 15) / 16)), dim3(512), 0, st, ps.ltab, ps.wtab, out,
                            static_cast<const double *>(ps.xlm));
     }

@@ -115,6 +115,31 @@ def test_static_path_meshes(shape, fmt):
     assert np.array_equal(xt, O.orc().apply_lu(Lo, Uo, b, O.TRANSPOSE))
 
 
+def test_static_path_more_lines_than_lanes():
+    """a mesh with more lines (90 000) than the chip has lanes (65 536): one lane per line all the same -- the static kernels take
+    workgroups in ticket order and only wait for lower tickets, so the schedule need not be resident at once (before: blocks
+    that straddled lines, 600x slower at 260^3, a time-out at 288^3) -- and a grid of more than 131 008 slots (the older
+    generations' descriptor limit)"""
+    import ilupp_amd as ilupp
+    O, ref = _oracle()
+    for shape in ((64, 300, 300), (48, 272, 500)):
+        d, i, p = matgen.poisson3d(*shape)
+        n = p.shape[0] - 1
+        rng = np.random.default_rng(11)
+        d = d * (1.0 + 0.3 * rng.random(d.shape[0]))
+        A = sp.csr_matrix((d, i, p), shape=(n, n))
+        P = ilupp.ILU0Preconditioner(A)
+        assert P.pr.path() == "ilu0:static-level-major"
+        Lo, Uo = ref.ilu0((A.data, A.indices, A.indptr, True))
+        L, U = P.factors()
+        assert G.mat_equal((L.data, L.indices, L.indptr, True), Lo) and G.mat_equal((U.data, U.indices, U.indptr, True), Uo)
+        b = G.rhs(n)
+        x = b.copy(); P.apply(x)
+        assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, O.ID))
+        xt = b.copy(); P.apply_trans(xt)
+        assert np.array_equal(xt, O.orc().apply_lu(Lo, Uo, b, O.TRANSPOSE))
+
+
 def _mesh_with_holes(g, seed):
     """7-point mesh with random points removed (rows/columns deleted): chains of irregular length, templates that do not hold"""
     d, i, p = matgen.poisson3d(g)
