@@ -1294,7 +1294,9 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
     ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(xsz)); ILUPP_HIP(pool_free(tmp2));
-    const int64_t lim = 2 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;
+    // row slots of the chunks against rows: lines of 8 rows in a 16 x 16 patch (30 steps of skew) are 4.75 slots per row, and
+    // still 400 times faster than what the other generations make of 90 000 such lines
+    const int64_t lim = 6 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;
     if (hl[0] || hu[0] || hu[3] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim ||
         hl[1] + 4 * nwg >= kStMaxChunks || hu[1] + 4 * nwg >= kStMaxChunks) {
         if (dbg) fprintf(stderr, "[ilupp] static analysis: structure rejected (flags %d %d link %d, %d %d chunks)\n", hl[0], hu[0], hu[3], hl[1], hu[1]);
