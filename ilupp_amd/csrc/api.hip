@@ -172,12 +172,10 @@ struct ilupp_precond {
     double *xdev = nullptr;      // n, staging for host-vector apply
     int32_t *done = nullptr;     // n
     bool degenerate = false;     // a factor has a major slice without entries (NaN columns of an indefinite ICholT): guarded sweeps only
-    int32_t *iota = nullptr;     // n + 1: the one-row-per-lane schedule of the row-parallel sweep (built on first use)
     int32_t *ctrl = nullptr;     // 16 ints: [0] err, [1] ilu0 ticket (+ its err in [2]) , [4],[5] solve tickets
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4],[5]: around the factor kernel
-    hipStream_t side = nullptr;                       // work that overlaps the persistent factor kernel
-    hipEvent_t sev[2] = {nullptr, nullptr};           // fork / join of the side stream
+    hipEvent_t sev[2] = {nullptr, nullptr};           // ordering against the caller's stream
     int device = 0;
     ilupp_timings tm = {0, 0, 0, 0, 0, 0};
     bool apply_events_valid = false;
@@ -186,7 +184,7 @@ struct ilupp_precond {
 
 namespace {
 
-struct QueuePack { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipStream_t side = nullptr; hipEvent_t sev[2] = {nullptr, nullptr}; int device = 0; };
+struct QueuePack { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t sev[2] = {nullptr, nullptr}; int device = 0; };
 struct QueuePool { std::mutex mu; std::vector<QueuePack> free_list; } g_queues;
 
 bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <= kGhostBase; }
@@ -195,7 +193,6 @@ void destroy_obj(ilupp_precond *p)
 {
     if (!p) return;
     if (p->stream) (void)stream_sync(p->stream);   // pooled blocks may be handed out again at once
-    if (p->side) (void)hipStreamSynchronize(p->side);
     p->Lc.release(); p->Uc.release(); p->LcT.release(); p->UcT.release();
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
     p->prog.release();
@@ -205,14 +202,13 @@ void destroy_obj(ilupp_precond *p)
     if (p->work) (void)pool_free(p->work);
     if (p->xdev) (void)pool_free(p->xdev);
     if (p->done) (void)pool_free(p->done);
-    if (p->iota) (void)pool_free(p->iota);
     if (p->ctrl) (void)pool_free(p->ctrl);
     // streams and events are recycled: creating them costs more than a small kernel
     if (p->stream) {
         std::lock_guard<std::mutex> lk(g_queues.mu);
         QueuePack q; q.stream = p->stream; q.device = p->device;
         for (int k = 0; k < 6; ++k) q.ev[k] = p->ev[k];
-        q.side = p->side; q.sev[0] = p->sev[0]; q.sev[1] = p->sev[1];
+        q.sev[0] = p->sev[0]; q.sev[1] = p->sev[1];
         g_queues.free_list.push_back(q);
     }
     delete p;
@@ -229,7 +225,7 @@ ilupp_precond *new_obj(int32_t n)
             if (g_queues.free_list[k].device == p->device) {
                 p->stream = g_queues.free_list[k].stream;
                 for (int e = 0; e < 6; ++e) p->ev[e] = g_queues.free_list[k].ev[e];
-                p->side = g_queues.free_list[k].side; p->sev[0] = g_queues.free_list[k].sev[0]; p->sev[1] = g_queues.free_list[k].sev[1];
+                p->sev[0] = g_queues.free_list[k].sev[0]; p->sev[1] = g_queues.free_list[k].sev[1];
                 g_queues.free_list.erase(g_queues.free_list.begin() + (long)k);
                 break;
             }
@@ -237,7 +233,6 @@ ilupp_precond *new_obj(int32_t n)
     if (!p->stream) {
         ILUPP_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         for (auto &e : p->ev) ILUPP_HIP(hipEventCreate(&e));
-        ILUPP_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         for (auto &e : p->sev) ILUPP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     order_after_caller(p->stream, p->sev[0]);        // (the matrix a *_create_device call is about to read)
@@ -260,7 +255,6 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
 {
     hipStream_t st = p->stream;
     int rc = ILUPP_ERR_UNSUPPORTED;
-    bool direct = false;
     if (p->flm.built) {
         rc = p->flm.stat ? ilu0_numeric_st(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5])
                          : ilu0_numeric_lm(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5]);
@@ -269,23 +263,18 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
     }
     p->csr_vals = true;
     if (p->prog_f3) {
-        // letting this kernel scatter the sweep records itself costs more than the separate value pass
-        static const bool allow_direct = getenv("ILUPP_DIRECT_PACK") != nullptr;
-        direct = allow_direct && p->pkL.valid && p->pkU.valid && p->pkU.linked;
-        rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, kms, direct ? &p->pkL : nullptr, direct ? &p->pkU : nullptr);
+        // (letting this kernel scatter the sweep records itself cost more than the separate value pass below)
+        rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, kms, nullptr, nullptr);
     } else if (have_prog) {
         rc = ilu0_numeric_program(st, A, &p->Lc, &p->Uc, p->sA, p->prog, p->max_row_len, p->ctrl, kms);
     }
     if (rc == ILUPP_ERR_UNSUPPORTED) {
-        direct = false;
         rc = ilu0_numeric(st, A, &p->Lc, &p->Uc, p->sA, p->max_row_len, p->done, p->ctrl, kms);
     }
     // the level-major sweeps of this object keep their own copy of the values: every one that exists gets the new ones
     // (they are built independently, on first use, so one may exist without the other)
-    if (!direct) {
-        if (p->pkL.valid && !p->pkL.stat) lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sL.start ? p->sL : p->sA, p->dL, &p->pkL, 2);
-        if (p->pkU.valid && !p->pkU.stat) lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU, 2);
-    }
+    if (p->pkL.valid && !p->pkL.stat) lm_pack(st, SWEEP_FWD_LAST_ASC, p->Lc, p->sL.start ? p->sL : p->sA, p->dL, &p->pkL, 2);
+    if (p->pkU.valid && !p->pkU.stat) lm_pack(st, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, &p->pkU, 2);
     return rc;
 }
 
@@ -332,18 +321,15 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
         lm = p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
     }
     // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
-    // transposed solves): the pass runs on the side stream next to the persistent factor kernel, which is bound by
-    // dependency latency and leaves most of the memory system idle.
-    static const bool no_overlap = getenv("ILUPP_OVERLAP_PATTERNS") == nullptr;   // measured: the overlap costs the factor kernel more (2.0 -> 2.5 ms) than the pass takes (0.28 ms)
-    const bool patterns_aside = lm && !no_overlap && !p->flm.stat;
-    // (static form: only U's row pointers now; the column indices come out of the records together with the values)
+    // transposed solves).  (Running this pass on a side stream next to the factor kernel cost the kernel more -- 2.0 -> 2.5 ms
+    // -- than the pass takes, 0.28 ms.)  Static form: only U's row pointers; the column indices come out of the records
+    // together with the values.
     if (p->flm.stat) ilu0_write_uptr(st, A, &p->Lc, &p->Uc);
-    else if (!patterns_aside) ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
+    else ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
     if (!lm) ilu0_unit_diagonal(st, &p->Lc);        // the CSR-streaming factor kernels write the eliminations only
     if (p->compact && !lm) {
         // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels
-        static const bool allow_lc = getenv("ILUPP_FACTOR_V2") == nullptr;
-        if (!(allow_lc && A.nnz >= 16 && build_ilu0_program_f3(st, A, p->Uc, p->sA, &p->prog_f3)))
+        if (!(A.nnz >= 16 && build_ilu0_program_f3(st, A, p->Uc, p->sA, &p->prog_f3)))
             have_prog = build_ilu0_program(st, A, p->Uc, p->sA, &p->prog);
         make_desc(st, p->Lc, p->sA, &p->dL);
         make_desc(st, p->Uc, p->sU, &p->dU);
@@ -358,16 +344,8 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
         if (!(p->pkL.valid && p->pkU.valid)) { p->pkL.release(); p->pkU.release(); }
     }
     ILUPP_HIP(hipEventRecord(a1, st));
-    if (patterns_aside) {
-        ILUPP_HIP(hipEventRecord(p->sev[0], st));
-        ILUPP_HIP(hipStreamWaitEvent(p->side, p->sev[0], 0));
-        ilu0_write_patterns(p->side, A, &p->Lc, &p->Uc);
-        ILUPP_HIP(hipEventRecord(p->sev[1], p->side));
-    }
     float kms = 0.f;
-    rc = ILUPP_ERR_UNSUPPORTED;
     rc = ilu0_numeric_any(p, A, have_prog, &kms);
-    if (patterns_aside) ILUPP_HIP(hipStreamWaitEvent(st, p->sev[1], 0));
     ILUPP_HIP(hipEventRecord(a2, st));
     ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
@@ -463,20 +441,7 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
     // block of consecutive rows.  With blocks, a row waits for everything its lane has to do before it, and the factors of
     // a random matrix have no chains that would make blocks pay: BASELINE config C3's apply took 70 + 186 ms, more than the
     // reference needs on one core.
-    static const bool blocks_only = getenv("ILUPP_SPTRSV_BLOCKS") != nullptr;
-    if (!blocks_only && M.nnz > 4 * (int64_t)M.n && M.n >= 1024) {
-        static const bool no_shuffle = getenv("ILUPP_SPTRSV_ROWS_V1") != nullptr;      // (A/B: the generic kernel on one-row blocks)
-        if (!no_shuffle) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
-        if (!p->iota) {
-            ILUPP_HIP(pool_malloc(&p->iota, sizeof(int32_t) * ((size_t)p->n + 1)));
-            iota_i32(p->stream, p->iota, (int64_t)p->n + 1);
-        }
-        Schedule rows;
-        rows.nb = M.n; rows.B = 1; rows.start = p->iota;
-        const int rc = sptrsv(p->stream, kind, M, rows, nullptr, maxlen, rhs, out, ticket, err);
-        rows.start = nullptr;
-        return rc;
-    }
+    if (M.nnz > 4 * (int64_t)M.n && M.n >= 1024) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
     return sptrsv(p->stream, kind, M, sch, desc, maxlen, rhs, out, ticket, err);
 }
 // apply on a device vector; `transpose` as in apply_preconditioner_only(use, y)

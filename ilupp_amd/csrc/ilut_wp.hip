@@ -490,7 +490,6 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     if (p - 1 >= kWpSel) return 1;
     const size_t slab = (size_t)n * p;
     int workers = device_cu_count() * 3;
-    if (const char *e = getenv("ILUPP_ILUT_WAVES")) { const int v = atoi(e); if (v > 0 && v < workers) workers = v; }     // experiments
     if (workers > n) workers = n;
     WpArrays g = {nullptr, kWpHashG - 1, nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
     ILUPP_HIP(pool_malloc(&g.uh, sizeof(unsigned short) * (size_t)workers * kWpHashG));

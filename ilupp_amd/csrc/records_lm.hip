@@ -442,7 +442,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
                      PackedSweep *pu, FactorLM *f)
 {
     pl->release(); pu->release(); f->release();
-    static const bool off = getenv("ILUPP_NO_PACKED") != nullptr || getenv("ILUPP_NO_PACKED_FACTOR") != nullptr ||
+    static const bool off = getenv("ILUPP_NO_PACKED") != nullptr ||
                             getenv("ILUPP_CLASSIC_ANALYSIS") != nullptr;
     static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
     // rows of at most 7 entries (checked per row by the passes; nnz <= 7n is the cheap necessary condition)

@@ -914,9 +914,8 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
     // *d_ticket must be zero on entry (the caller zeroes the whole control block once per apply)
     if (desc) {
         const unsigned grid = (unsigned)(sch.nslots / kThreads);
-        static const bool allow_lc = getenv("ILUPP_SOLVE_V2") == nullptr;
         // rows must fit the entry ring with room for the refill quantum; tiny systems keep the simple kernel
-        if (allow_lc && max_row_len > 0 && max_row_len <= kEW - 2 * kEQ && M.nnz >= 16 && M.n >= 8) {
+        if (max_row_len > 0 && max_row_len <= kEW - 2 * kEQ && M.nnz >= 16 && M.n >= 8) {
 #define LAUNCHS(K)                                                                                           \
             do {                                                                                             \
                 ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_lc<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLcLds)); \

@@ -1237,7 +1237,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
                      PackedSweep *pu, FactorLM *f)
 {
     pl->release(); pu->release(); f->release();
-    static const bool off = getenv("ILUPP_NO_PACKED") != nullptr || getenv("ILUPP_NO_PACKED_FACTOR") != nullptr ||
+    static const bool off = getenv("ILUPP_NO_PACKED") != nullptr ||
                             getenv("ILUPP_CLASSIC_ANALYSIS") != nullptr || getenv("ILUPP_NO_STATIC") != nullptr;
     static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
     if (off || A.nnz > 7 * (int64_t)A.n || A.nnz < 16 || fwd.nslots < kThreads || fwd.nslots != bwd.nslots || !A.val) return false;

@@ -41,10 +41,9 @@ __global__ void k_copy_words(const int *__restrict__ src, int *__restrict__ dst,
 }
 hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t bytes)
 {
-    static const bool off = getenv("ILUPP_NO_MAPPED_READBACK") != nullptr;
     std::lock_guard<std::mutex> lk(g_stage_mu);
     Staging &s = g_stage[st];
-    if (!off && !s.host) {
+    if (!s.host) {
         void *h = nullptr, *d = nullptr;
         if (hipHostMalloc(&h, kStageBytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
             s.host = static_cast<char *>(h); s.dev = static_cast<char *>(d);
@@ -52,7 +51,7 @@ hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t
             (void)hipGetLastError();
         }
     }
-    if (off || !s.host || (bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(dev_src) & 3) != 0 || s.used + bytes > kStageBytes)
+    if (!s.host || (bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(dev_src) & 3) != 0 || s.used + bytes > kStageBytes)
         return hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st);
     const int nwords = (int)(bytes / 4);
     hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, static_cast<const int *>(dev_src),
@@ -221,7 +220,6 @@ static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t
     // matrix with n = 1e6: 48.7 ms with 15 rows per lane, 3.3 ms with one)
     if (chain <= 4) B = 1;
     if (B < 1) B = 1;
-    if (const char *e = getenv("ILUPP_SCHEDULE_B")) { const int v = atoi(e); if (v > 0) B = v; }      // experiments
     int64_t nb = ((int64_t)n + B - 1) / B;
     sch->nb = (int32_t)nb;
     sch->B = (int32_t)B;
