@@ -321,11 +321,14 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
         lm = p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
     }
     // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
-    // transposed solves).  (Running this pass on a side stream next to the factor kernel cost the kernel more -- 2.0 -> 2.5 ms
-    // -- than the pass takes, 0.28 ms.)  Static form: only U's row pointers; the column indices come out of the records
-    // together with the values.
-    if (p->flm.stat) ilu0_write_uptr(st, A, &p->Lc, &p->Uc);
-    else ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
+    // generic transposed solves).  (Running this pass on a side stream next to the factor kernel cost the kernel more --
+    // 2.0 -> 2.5 ms -- than the pass takes, 0.28 ms.)  Static form: nothing here; row pointers, column indices and values all
+    // come out of the records when somebody asks (ensure_csr_values).
+    if (!p->flm.stat) {
+        rc = ilu0_csr_ptrs(st, A, &p->Lc, &p->Uc);
+        if (rc) return rc;
+        ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
+    }
     if (!lm) ilu0_unit_diagonal(st, &p->Lc);        // the CSR-streaming factor kernels write the eliminations only
     if (p->compact && !lm) {
         // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels
@@ -360,6 +363,7 @@ void ensure_csr_values(ilupp_precond *p)
 {
     if (p->csr_vals) return;
     if (p->pkL.stat) {
+        if (!p->Lc.ptr) (void)st_make_csr(p->stream, p->n, p->pkL, p->pkU, &p->Lc, &p->Uc);      // (throws on a HIP error)
         st_unpack(p->stream, p->Lc, p->sA, p->pkL);
         st_unpack(p->stream, p->Uc, p->sU, p->pkU);
     } else {
@@ -444,6 +448,15 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
     if (M.nnz > 4 * (int64_t)M.n && M.n >= 1024) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
     return sptrsv(p->stream, kind, M, sch, desc, maxlen, rhs, out, ticket, err);
 }
+// static form: records of U^T and L^T exist (built on first use; a pattern they cannot express is remembered)
+static bool static_transposed_ready(ilupp_precond *p)
+{
+    if (!(p->flm.stat && p->pkL.stat && p->pkU.stat) || p->no_static_T) return false;
+    if (st_build_transposed(p->stream, p->sA, p->n, p->flm, &p->pkL, &p->pkU, p->Lc.nnz - p->n, p->Uc.nnz - p->n)) return true;
+    p->no_static_T = true;
+    return false;
+}
+
 // apply on a device vector; `transpose` as in apply_preconditioner_only(use, y)
 #define SWEEP_OR_RETURN(...) do { const int rc_ = sweep(__VA_ARGS__); if (rc_) return rc_; } while (0)
 int apply_dev(ilupp_precond *p, double *x, int transpose)
@@ -472,8 +485,7 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), p2, y, x, t2, err, nullptr,
                   ylm ? p->pkL.ybuf : nullptr, ylm ? p->pkU.ysrc : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
-        } else if (p->flm.stat && p->pkL.stat && p->pkU.stat && !p->no_static_T &&
-                   (st_build_transposed(st, p->sA, p->n, p->flm, &p->pkL, &p->pkU, p->Lc.nnz - p->n, p->Uc.nnz - p->n) || (p->no_static_T = true, false))) {
+        } else if (static_transposed_ready(p)) {
             // static form: the same two sweep kernels on records of U^T and L^T
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
             { const int rc_ = sptrsv_st_T(st, p->pkL, p->n, x, y, t1, err, p->pkL.ybuf, nullptr); if (rc_) return rc_; }

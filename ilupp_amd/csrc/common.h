@@ -220,7 +220,9 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag,
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
-void ilu0_write_uptr(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
+int ilu0_csr_ptrs(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
+int csr_ptrs_from_counts(hipStream_t st, int32_t n, int32_t *counts, DevMat *M);
+int st_make_csr(hipStream_t st, int32_t n, const PackedSweep &pl, const PackedSweep &pu, DevMat *L, DevMat *U);
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);

@@ -1151,6 +1151,50 @@ k_st_unpack(const int32_t *__restrict__ ptr, int32_t *__restrict__ idx, double *
         if (st_bits(v[j]) != kAbsent && q < (FWD ? q1 - 1 : q1)) { val[q] = v[j]; idx[q] = r + T[ST_OFF + j]; ++q; }
 }
 
+// entries per row of a factor, from its records (the CSR row pointers of the static form are made when somebody asks for them)
+template <int KIND>
+__global__ void __launch_bounds__(512)
+k_st_rowcounts(int32_t *__restrict__ cnt, const int32_t *__restrict__ wtab, const int32_t *__restrict__ ltab, const v2d *__restrict__ pk,
+               const int32_t *__restrict__ ysrc)
+{
+    constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
+    constexpr int DR = FWD ? 1 : -1;
+    const int w = blockIdx.x;
+    const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
+    const int L = threadIdx.x & 63;
+    const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
+    if (c >= nch) return;
+    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
+    const int32_t *T = ltab + (size_t)slot * kStTab;
+    const int k = tmin + c - T[ST_SKEW];
+    if (k < 0 || k >= T[ST_CNT]) return;
+    const int pos = FWD ? 0 : ysrc[slot] - 64 * k;
+    const v2d *p = FWD ? pk + ((size_t)base + c) * 128 + L : pk + (size_t)(pos >> 6) * 128 + (pos & 63);
+    const v2d a = p[0], b = p[64];
+    cnt[T[ST_FIRST] + DR * k] = 1 + (st_bits(a.x) != kAbsent ? 1 : 0) + (st_bits(a.y) != kAbsent ? 1 : 0) + (st_bits(b.x) != kAbsent ? 1 : 0);
+}
+
+int st_make_csr(hipStream_t st, int32_t n, const PackedSweep &pl, const PackedSweep &pu, DevMat *L, DevMat *U)
+{
+    int32_t *cnt = nullptr;
+    ILUPP_HIP(pool_malloc(&cnt, sizeof(int32_t) * (size_t)n));
+    for (int d = 0; d < 2; ++d) {
+        const PackedSweep &ps = d == 0 ? pl : pu;
+        DevMat *M = d == 0 ? L : U;
+        const dim3 grid((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 7) / 8));
+        if (d == 0)
+            hipLaunchKernelGGL((k_st_rowcounts<SWEEP_FWD_LAST_ASC>), grid, dim3(512), 0, st, cnt, ps.wtab, ps.ltab,
+                               reinterpret_cast<const v2d *>(ps.pk), static_cast<const int32_t *>(nullptr));
+        else
+            hipLaunchKernelGGL((k_st_rowcounts<SWEEP_BWD_FIRST_ASC>), grid, dim3(512), 0, st, cnt, ps.wtab, ps.ltab,
+                               reinterpret_cast<const v2d *>(ps.pk), ps.ysrc);
+        const int rc = csr_ptrs_from_counts(st, n, cnt, M);
+        if (rc) { (void)pool_free(cnt); return rc; }
+    }
+    ILUPP_HIP(pool_free(cnt));
+    return ILUPP_OK;
+}
+
 void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps)
 {
     (void)sch;
@@ -1298,7 +1342,9 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     // still 400 times faster than what the other generations make of 90 000 such lines
     const int64_t lim = 6 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;
     if (hl[0] || hu[0] || hu[3] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim ||
-        hl[1] + 4 * nwg >= kStMaxChunks || hu[1] + 4 * nwg >= kStMaxChunks) {
+        hl[1] + 4 * nwg >= kStMaxChunks || hu[1] + 4 * nwg >= kStMaxChunks ||
+        // (the exchange layout is indexed with 32 bits: at most 256 exported lanes x the steps of a workgroup, each)
+        (int64_t)nwg * kThreads * ((int64_t)(hl[2] > hu[2] ? hl[2] : hu[2]) + 2 * kStXAlign) > 0x7fffffffLL) {
         if (dbg) fprintf(stderr, "[ilupp] static analysis: structure rejected (flags %d %d link %d, %d %d chunks)\n", hl[0], hu[0], hu[3], hl[1], hu[1]);
         pl->release(); pu->release(); f->release();
         return false;

@@ -235,7 +235,7 @@ __global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, co
                                   uint8_t *__restrict__ cutf, uint8_t *__restrict__ cutb, int32_t *__restrict__ lrow,
                                   int32_t *__restrict__ stats)
 {
-    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff;
+    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff, nl = 0;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const int lo = ptr[r], hi = ptr[r + 1];
         mx = max(mx, hi - lo);
@@ -255,7 +255,8 @@ __global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, co
                 has_prev |= c == r - 1; has_next |= c == r + 1; has_diag |= c == r;
             }
         }
-        lrow[r] = cl + 1;
+        if (lrow) lrow[r] = cl + 1;
+        nl += cl + 1;
         if (!has_diag) miss = min(miss, r);
         const int cf = (r == 0) ? 1 : (has_prev ? 0 : 1);
         cutf[r] = (uint8_t)cf;
@@ -263,37 +264,43 @@ __global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, co
         if (r + 1 < n) { const int cb = has_next ? 0 : 1; cutb[r + 1] = (uint8_t)cb; nbk += cb; }
         if (r == 0) { cutb[0] = 1; nbk += 1; }
     }
-    __shared__ int red[4];
+    __shared__ int red[5];
     if (threadIdx.x < 3) red[threadIdx.x] = 0;
     if (threadIdx.x == 3) red[3] = 0x7fffffff;
+    if (threadIdx.x == 4) red[4] = 0;
     __syncthreads();
     for (int off = 32; off > 0; off >>= 1) {
-        nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); miss = min(miss, __shfl_xor(miss, off));
+        nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); miss = min(miss, __shfl_xor(miss, off)); nl += __shfl_xor(nl, off);
     }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); atomicAdd(&red[4], nl); }
     __syncthreads();
     // per-block partial results; k_reduce_stats folds them (same-address atomics cost ~10 ns each on this chip: four per
     // block were 0.16 of this kernel's 0.26 ms at 4096 blocks, and 1.2 ms at 32768)
-    if (threadIdx.x == 0) { int *o = stats + 4 + 4 * blockIdx.x; o[0] = red[0]; o[1] = red[1]; o[2] = red[2]; o[3] = red[3]; }
+    if (threadIdx.x == 0) { int *o = stats + 8 + 8 * blockIdx.x; o[0] = red[0]; o[1] = red[1]; o[2] = red[2]; o[3] = red[3]; o[4] = red[4]; }
 }
 
 __global__ void k_reduce_stats(int nblocks, int32_t *stats)
 {
     int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff;
+    long long nl = 0;
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-        const int *o = stats + 4 + 4 * b;
-        nf += o[0]; nbk += o[1]; mx = max(mx, o[2]); miss = min(miss, o[3]);
+        const int *o = stats + 8 + 8 * b;
+        nf += o[0]; nbk += o[1]; mx = max(mx, o[2]); miss = min(miss, o[3]); nl += o[4];
     }
     __shared__ int red[4];
+    __shared__ unsigned long long rl;
     if (threadIdx.x < 3) red[threadIdx.x] = 0;
     if (threadIdx.x == 3) red[3] = 0x7fffffff;
+    if (threadIdx.x == 4) rl = 0;
     __syncthreads();
     for (int off = 32; off > 0; off >>= 1) {
         nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); miss = min(miss, __shfl_xor(miss, off));
+        nl += __shfl_xor(nl, off);
     }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); atomicAdd(&rl, (unsigned long long)nl); }
     __syncthreads();
-    if (threadIdx.x == 0) { stats[0] = red[0]; stats[1] = red[1]; stats[2] = red[2]; stats[3] = red[3]; }
+    // stats[4..5]: entries of L (strictly lower + unit diagonal), 64 bits
+    if (threadIdx.x == 0) { stats[0] = red[0]; stats[1] = red[1]; stats[2] = red[2]; stats[3] = red[3]; *reinterpret_cast<unsigned long long *>(stats + 4) = rl; }
 }
 
 // L/U patterns from the row pointers of L alone: Uptr[r] = Aptr[r] - (Lptr[r] - r)
@@ -331,47 +338,76 @@ __global__ void k_ilu0_pattern2(int32_t n, const int32_t *__restrict__ ptr, cons
 int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag,
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len)
 {
+    // (the CSR row pointers and index arrays of L and U are NOT made here: the static level-major kernels never read them --
+    // st_make_csr builds them from the records when somebody asks for the factors -- and the other generations call
+    // ilu0_csr_ptrs below once the static analysis has declined the matrix)
     const int32_t n = A.n;
     uint8_t *cutf = nullptr, *cutb = nullptr;
-    int32_t *stats = nullptr, *lrow = nullptr;
+    int32_t *stats = nullptr;
     ILUPP_HIP(pool_malloc(&cutf, (size_t)n + 1));
     ILUPP_HIP(pool_malloc(&cutb, (size_t)n + 1));
-    ILUPP_HIP(pool_malloc(&lrow, sizeof(int32_t) * (size_t)n));
     unsigned gb = (unsigned)((n + 255) / 256);
     if (gb > 16384) gb = 16384;
-    ILUPP_HIP(pool_malloc(&stats, sizeof(int32_t) * (4 + 4 * (size_t)gb)));
-    hipLaunchKernelGGL(k_row_cuts_counts, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz, cutf, cutb, lrow, stats);
+    ILUPP_HIP(pool_malloc(&stats, sizeof(int32_t) * (8 + 8 * (size_t)gb)));
+    hipLaunchKernelGGL(k_row_cuts_counts, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz, cutf, cutb,
+                       static_cast<int32_t *>(nullptr), stats);
     hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(1024), 0, st, (int)gb, stats);
     L->n = U->n = n; L->is_csr = U->is_csr = true; L->owns = U->owns = true;
+    int32_t h[6];
+    ILUPP_HIP(d2h_async(st, h, stats, sizeof(h)));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(stats));
+    if (max_row_len) *max_row_len = h[2];
+    if (first_missing_diag) *first_missing_diag = (h[3] == 0x7fffffff) ? -1 : h[3];
+    long long nnzl = 0;
+    memcpy(&nnzl, h + 4, sizeof(nnzl));
+    L->nnz = nnzl;
+    U->nnz = A.nnz - (nnzl - n);
+    if (h[3] != 0x7fffffff) { ILUPP_HIP(pool_free(cutf)); ILUPP_HIP(pool_free(cutb)); return ILUPP_ERR_NO_DIAGONAL; }
+    make_schedule(st, n, cutf, h[0], max_lanes, fwd);
+    make_schedule(st, n, cutb, h[1], max_lanes, bwd);
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(cutf));
+    ILUPP_HIP(pool_free(cutb));
+    return ILUPP_OK;
+}
+
+// row pointers of L (strictly-lower entries + unit diagonal, ILU0.hpp:93) and U, and room for their entries
+__global__ void k_ilu0_lrow(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t *__restrict__ lrow)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int cl = 0;
+    for (int q = ptr[r]; q < ptr[r + 1]; ++q) cl += idx[q] < r ? 1 : 0;
+    lrow[r] = cl + 1;
+}
+int csr_ptrs_from_counts(hipStream_t st, int32_t n, int32_t *lrow, DevMat *L)
+{
     ILUPP_HIP(pool_malloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(pool_malloc(&U->ptr, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(hipMemsetAsync(L->ptr, 0, sizeof(int32_t), st));
     size_t tmp_bytes = 0;
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, lrow, L->ptr + 1, n, st));
     void *tmp = nullptr;
     ILUPP_HIP(pool_malloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
     ILUPP_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, lrow, L->ptr + 1, n, st));
-    int32_t h[4], nnzl = 0;
-    ILUPP_HIP(d2h_async(st, h, stats, sizeof(h)));
-    ILUPP_HIP(d2h_async(st, &nnzl, L->ptr + n, sizeof(int32_t)));
     ILUPP_HIP(stream_sync(st));
-    ILUPP_HIP(pool_free(tmp)); ILUPP_HIP(pool_free(lrow)); ILUPP_HIP(pool_free(stats));
-    if (max_row_len) *max_row_len = h[2];
-    if (first_missing_diag) *first_missing_diag = (h[3] == 0x7fffffff) ? -1 : h[3];
-    L->nnz = nnzl;
-    U->nnz = A.nnz - ((int64_t)nnzl - n);
+    ILUPP_HIP(pool_free(tmp));
     ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
     ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)(L->nnz > 0 ? L->nnz : 1)));
+    return ILUPP_OK;
+}
+int ilu0_csr_ptrs(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U)
+{
+    const int32_t n = A.n;
+    int32_t *lrow = nullptr;
+    ILUPP_HIP(pool_malloc(&lrow, sizeof(int32_t) * (size_t)n));
+    hipLaunchKernelGGL(k_ilu0_lrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, lrow);
+    int rc = csr_ptrs_from_counts(st, n, lrow, L);
+    ILUPP_HIP(pool_free(lrow));
+    if (rc) return rc;
+    ILUPP_HIP(pool_malloc(&U->ptr, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(pool_malloc(&U->idx, sizeof(int32_t) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
     ILUPP_HIP(pool_malloc(&U->val, sizeof(double) * (size_t)(U->nnz > 0 ? U->nnz : 1)));
-    if (h[3] != 0x7fffffff) { ILUPP_HIP(pool_free(cutf)); ILUPP_HIP(pool_free(cutb)); return ILUPP_ERR_NO_DIAGONAL; }
-    // (the CSR patterns of L and U themselves are written by ilu0_write_patterns: nothing of the factorisation or of the
-    // solves reads them when the level-major kernels run, so the caller overlaps that pass with the factor kernel)
-    make_schedule(st, n, cutf, h[0], max_lanes, fwd);
-    make_schedule(st, n, cutb, h[1], max_lanes, bwd);
-    ILUPP_HIP(stream_sync(st));
-    ILUPP_HIP(pool_free(cutf));
-    ILUPP_HIP(pool_free(cutb));
     return ILUPP_OK;
 }
 
@@ -382,18 +418,6 @@ void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U)
     const int32_t n = A.n;
     hipLaunchKernelGGL(k_ilu0_pattern2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz,
                        L->ptr, U->ptr, L->idx, U->idx);
-}
-
-// only the row pointers of U (the static level-major path writes the column indices of L and U together with their
-// values, from its records, when somebody asks for the factors)
-__global__ void k_ilu0_uptr(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ Lptr, int32_t *__restrict__ Uptr)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r <= n) Uptr[r] = ptr[r] - (Lptr[r] - r);
-}
-void ilu0_write_uptr(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U)
-{
-    hipLaunchKernelGGL(k_ilu0_uptr, dim3((unsigned)((A.n + 256) / 256)), dim3(256), 0, st, A.n, A.ptr, L->ptr, U->ptr);
 }
 
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
