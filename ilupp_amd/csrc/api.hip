@@ -240,7 +240,12 @@ ilupp_precond *new_obj(int32_t n)
     ILUPP_HIP(pool_malloc(&p->done, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->ctrl, 64));
     fill_u64(p->stream, reinterpret_cast<unsigned long long *>(p->work), n, kSentinel);
-    p->max_lanes = device_cu_count() * kThreads;
+    // Lanes a schedule may spread over.  NOT the lanes of the chip: every kernel takes its workgroup id from a ticket counter
+    // and only waits for rows of lower tickets, which have started by then, so a grid larger than the chip makes progress;
+    // what matters is that a lane's block of rows is one dependency chain (a mesh line).  With the chip's 65 536 lanes as the
+    // limit, a 288^3 mesh (82 944 lines) got blocks of 365 rows that straddled lines, every lane waited for its predecessor
+    // to finish, and the sweeps ran into their spin limits.
+    p->max_lanes = 1 << 24;
     return p;
 }
 
@@ -288,38 +293,22 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     int32_t missing = -1;
     // one pass over A's pattern: row counts of L and U, diagonal check, and the factor-sweep schedules (L shares A's
     // forward cuts and U its backward cuts: same strictly-lower / strictly-upper patterns)
-    // The static kernels take workgroups in ticket order and only ever wait for lower tickets, so they do not need the whole
-    // schedule resident at once: they get one lane per chain however many chains there are (a 288^3 mesh has 82 944 lines for
-    // the 65 536 lanes of the chip).  The older generations poll any workgroup and need co-residency: if the static analysis
-    // declines such a schedule, it is rebuilt for the resident lanes below.
-    const int lanes_static = 1 << 24;
-    int rc = ilu0_symbolic_and_schedule(st, A, &p->Lc, &p->Uc, &missing, lanes_static, &p->sA, &p->sU, &p->max_row_len);
+    int rc = ilu0_symbolic_and_schedule(st, A, &p->Lc, &p->Uc, &missing, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
     if (rc == ILUPP_ERR_NO_DIAGONAL) {
         set_error("ILU0: structurally missing diagonal entry in row " + std::to_string(missing));
         return rc;
     }
     if (rc) return rc;
     const int max_wgs = p->max_lanes / kThreads;
-    choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, lanes_static / kThreads);
+    choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
     build_slot_tables(st, &p->sA, true);
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
     bool have_prog = false;
-    // static form first (lane tables, values-only records: st.hip), then the record-decoding level-major form
-    // (the static form has no descriptor words: no limit on block size or number of slots)
-    bool lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
-    if (!lm) {
-        if (p->sA.nslots > p->max_lanes || p->sU.nslots > p->max_lanes) {
-            p->sA.release(); p->sU.release();
-            rc = count_cuts_and_schedule(st, A.n, A.ptr, A.idx, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
-            if (rc) return rc;
-            choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
-            build_slot_tables(st, &p->sA, true);
-            build_slot_tables(st, &p->sU, false);
-            p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
-        }
-        lm = p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
-    }
+    // static form first (lane tables, values-only records: st.hip; no descriptor words, hence no limit on block size or number
+    // of slots), then the record-decoding level-major form
+    const bool lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm) ||
+                    (p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm));
     // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
     // generic transposed solves).  (Running this pass on a side stream next to the factor kernel cost the kernel more --
     // 2.0 -> 2.5 ms -- than the pass takes, 0.28 ms.)  Static form: nothing here; row pointers, column indices and values all

@@ -140,6 +140,53 @@ def test_static_path_more_lines_than_lanes():
         assert np.array_equal(xt, O.orc().apply_lu(Lo, Uo, b, O.TRANSPOSE))
 
 
+def test_more_lines_than_lanes_other_kernels(monkeypatch):
+    """the same kind of mesh (78 400 lines) through IChol0, ICholT(0, 0) and the record-decoding generation of ILU(0): array-equal
+    to the reference.  (With the chip's 65 536 lanes as the limit of a schedule, blocks straddled lines and these ran into their
+    spin limits from 288^3 on: every kernel takes tickets and only waits for lower ones, so the limit never was one.)"""
+    import ilupp_amd as ilupp
+    O, ref = _oracle()
+    d, i, p = matgen.poisson3d(48, 280, 280)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    b = G.rhs(n)
+    P = ilupp.IChol0Preconditioner(A)
+    Lo = ref.ichol0((A.data, A.indices, A.indptr, True))
+    (L,) = P.factors()
+    assert G.mat_equal((L.data, L.indices, L.indptr, isinstance(L, sp.csr_matrix)), Lo)
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, O.orc().apply_llt(Lo, b, O.ID))
+    del P
+    P = ilupp.ICholTPreconditioner(A, add_fill_in=0, threshold=0.0)
+    Lo = ref.icholt((A.data, A.indices, A.indptr, True), 0, 0.0)
+    (L,) = P.factors()
+    assert G.mat_equal((L.data, L.indices, L.indptr, isinstance(L, sp.csr_matrix)), Lo)
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, O.orc().apply_llt(Lo, b, O.ID))
+    del P
+    monkeypatch.setenv("ILUPP_NO_STATIC", "1")
+    code = """
+import sys, numpy as np, scipy.sparse as sp
+sys.path[:0] = [%r, %r]
+import matgen, golden_util as G, ilupp_amd as ilupp
+from oracle import oracle as O
+d, i, p = matgen.poisson3d(48, 280, 280)
+n = p.shape[0] - 1
+A = sp.csr_matrix((d, i, p), shape=(n, n))
+P = ilupp.ILU0Preconditioner(A)
+assert P.pr.path() != "ilu0:static-level-major", P.pr.path()
+ref = O.ref() if O.ref_available() else O.orc()
+Lo, Uo = ref.ilu0((A.data, A.indices, A.indptr, True))
+b = G.rhs(n)
+for use, f in ((O.ID, P.apply), (O.TRANSPOSE, P.apply_trans)):
+    x = b.copy(); f(x)
+    assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, use))
+print("ok", P.pr.path())
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def _mesh_with_holes(g, seed):
     """7-point mesh with random points removed (rows/columns deleted): chains of irregular length, templates that do not hold"""
     d, i, p = matgen.poisson3d(g)
