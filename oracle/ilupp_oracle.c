@@ -714,6 +714,118 @@ int orc_icholt(orc_int n, const orc_int *ptr, const orc_int *idx, const double *
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* ILUC (Crout ILU, Li/Saad/Chow)                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* initialize_sparse_matrix_fields, ILUC.hpp:74-84: list[i] chains the rows whose first unprocessed entry lies in
+ * the same column; head[j] is the first row of column j's chain */
+static void initialize_sparse_matrix_fields(orc_int n, const orc_int *pointer, const orc_int *indices, orc_int *list, orc_int *head,
+                                            orc_int *first)
+{
+    orc_int k;
+    for (k = 0; k < n; ++k) head[k] = -1;
+    for (k = 0; k < n; ++k) {
+        first[k] = pointer[k];
+        if (pointer[k] < pointer[k + 1]) { list[k] = head[indices[pointer[k]]]; head[indices[pointer[k]]] = k; }
+    }
+}
+
+/* update_sparse_matrix_fields, ILUC.hpp:86-101 */
+static void update_sparse_matrix_fields(orc_int k, const orc_int *pointer, const orc_int *indices, orc_int *list, orc_int *head,
+                                        orc_int *first)
+{
+    orc_int h, i;
+    for (h = head[k]; h != -1; h = list[h]) first[h] += 1;
+    h = head[k];
+    while (h != -1) {
+        i = h;
+        h = list[i];
+        if (first[i] < pointer[i + 1]) { list[i] = head[indices[first[i]]]; head[indices[first[i]]] = i; }
+    }
+}
+
+/* append_row_with_prefix, sparse_implementation.h:3189-3208 */
+static int append_with_prefix(orc_mat *M, orc_int reserved, orc_int i, const wvec *w, const orc_int *list, orc_int len, double prefix)
+{
+    orc_int kk = M->ptr[i], x;
+    if ((long)kk + (long)len + 1 > (long)reserved) return ORC_ERR_MEMORY;
+    M->val[kk] = prefix; M->idx[kk++] = i;
+    for (x = 0; x < len; ++x) { M->val[kk] = w->data[list[x]]; M->idx[kk++] = w->pointer[list[x]]; }
+    M->ptr[i + 1] = kk;
+    return ORC_OK;
+}
+
+int orc_iluc(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_int max_fill_in, double threshold, orc_mat *Lout, orc_mat *Uout, orc_int *err_row)
+{
+    /* ILUC2, ILUC.hpp:112-207, on the major-order view of the arrays (for a COLUMN matrix: of A^T); orientation of the results
+     * and their interchange for COLUMN input: binding.cpp:449-460 */
+    const orc_int m = n;
+    orc_int k, j, h, x, reserved;
+    orc_int *firstU, *listU, *firstL, *listL, *listA, *headA, *firstA, *listw, *listz;
+    wvec z, w;
+    orc_mat L, U;
+    int rc = ORC_OK;
+    long nnzA = ptr[n];
+    {
+        /* :120 (Integer arithmetic in the reference; the product is taken in 64 bits here) */
+        long a = (long)max_fill_in * (long)n, b = (long)(10.0 * (double)nnzA);
+        long r = a < b ? a : b;
+        reserved = (orc_int)(r > 0 ? r : 0);
+    }
+    if (err_row) *err_row = -1;
+    firstU = (orc_int *)calloc((size_t)m + 1, sizeof(orc_int)); listU = (orc_int *)malloc(sizeof(orc_int) * ((size_t)m + 1));
+    firstL = (orc_int *)calloc((size_t)m + 1, sizeof(orc_int)); listL = (orc_int *)malloc(sizeof(orc_int) * ((size_t)m + 1));
+    listA = (orc_int *)calloc((size_t)m + 1, sizeof(orc_int)); headA = (orc_int *)malloc(sizeof(orc_int) * ((size_t)m + 1));
+    firstA = (orc_int *)calloc((size_t)m + 1, sizeof(orc_int));
+    listw = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)m + 16)); listz = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)m + 16));
+    mat_init(&L, m, reserved > 0 ? reserved : 1, !is_csr);       /* other_orientation(A.orientation), :129 */
+    mat_init(&U, m, reserved > 0 ? reserved : 1, is_csr);
+    wv_init(&z, n, 0); wv_init(&w, m, 0);
+    if (max_fill_in < 1) max_fill_in = 1;                        /* :133 (after the reservation) */
+    initialize_sparse_matrix_fields(m, ptr, idx, listA, headA, firstA);
+    for (k = 0; k < m; ++k) { listL[k] = -1; listU[k] = -1; }
+
+    for (k = 0; k < m; ++k) {
+        orc_int nw, nz;
+        double U_kk;
+        wv_zero_reset(&z);                                        /* (2.) */
+        for (j = firstA[k]; j < ptr[k + 1]; ++j) z.data[wv_slot(&z, idx[j])] = val[j];
+        for (h = listL[k]; h != -1; h = listL[h]) {               /* (3.)-(5.) */
+            const double L_kh = L.val[firstL[h]];
+            for (j = firstU[h]; j < U.ptr[h + 1]; ++j) { x = wv_slot(&z, U.idx[j]); z.data[x] -= L_kh * U.val[j]; }
+        }
+        wv_zero_reset(&w);                                        /* (6.) */
+        for (h = headA[k]; h != -1; h = listA[h])
+            if (h > k) w.data[wv_slot(&w, h)] = val[firstA[h]];
+        for (h = listU[k]; h != -1; h = listU[h]) {               /* (7.)-(9.) */
+            const double U_hk = U.val[firstU[h]];
+            for (j = firstL[h]; j < L.ptr[h + 1]; ++j) { x = wv_slot(&w, L.idx[j]); w.data[x] -= U_hk * L.val[j]; }
+        }
+        if (z.occupancy[k] < 0) { rc = ORC_ERR_ZERO_PIVOT; if (err_row) *err_row = k; break; }    /* :174-175 */
+        nw = orc_threshold_and_drop(w.data, w.pointer, w.nnz, listw, max_fill_in - 1, threshold, k + 1, m);   /* (10.) */
+        nz = orc_threshold_and_drop(z.data, z.pointer, z.nnz, listz, max_fill_in - 1, threshold, k + 1, n);   /* (11.) */
+        rc = append_with_prefix(&U, reserved, k, &z, listz, nz, z.data[z.occupancy[k]]);                         /* (12.) */
+        if (rc) break;
+        U_kk = U.val[U.ptr[k]];
+        for (x = 0; x < nw; ++x) w.data[listw[x]] /= U_kk;                                                       /* (13.) */
+        rc = append_with_prefix(&L, reserved, k, &w, listw, nw, 1.0);
+        if (rc) break;
+        update_sparse_matrix_fields(k, ptr, idx, listA, headA, firstA);
+        update_triangular_fields(k, L.ptr, L.idx, listL, firstL);
+        update_triangular_fields(k, U.ptr, U.idx, listU, firstU);
+    }
+    wv_free(&z); wv_free(&w);
+    free(firstU); free(listU); free(firstL); free(listL); free(listA); free(headA); free(firstA); free(listw); free(listz);
+    if (rc != ORC_OK) { orc_free_mat(&L); orc_free_mat(&U); return rc; }
+    L.nnz = L.ptr[m]; U.nnz = U.ptr[m];
+    mat_compress(&L, -1.0); mat_compress(&U, -1.0);               /* :205-206 */
+    if (is_csr) { *Lout = L; *Uout = U; }
+    else { *Lout = U; *Uout = L; }                                /* binding.cpp:456-457 */
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* triangular solves + apply                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -63,6 +63,12 @@ int orc_ichol0(orc_int n, const orc_int *ptr, const orc_int *idx, const double *
 int orc_icholt(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
                orc_int add_fill_in, double threshold, orc_mat *L);
 
+/* ILUC.hpp:112-207 (ILUC2) with the helpers :31-101; results as binding.cpp:449-460 returns them: the first factor is
+ * stored column-wise (is_csr = 0: for ROW input L with its unit diagonal first in every column, for COLUMN input U), the second
+ * row-wise. */
+int orc_iluc(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_int max_fill_in, double threshold, orc_mat *L, orc_mat *U, orc_int *err_row);
+
 /* sparse_implementation.h:4040-4087: in-place triangular solve, loop chosen by (form, orientation, use). */
 void orc_trisolve(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
                   int form, int use, double *x);

@@ -66,6 +66,8 @@ class _Lib:
         f("ilu0").argtypes = mat_in + [ctypes.POINTER(_Mat), ctypes.POINTER(_Mat)]
         f("ilut").argtypes = mat_in + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_Mat),
                                        ctypes.POINTER(_Mat), _I32P]
+        f("iluc").argtypes = mat_in + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_Mat),
+                                       ctypes.POINTER(_Mat), _I32P]
         f("ichol0").argtypes = mat_in + [ctypes.POINTER(_Mat)]
         f("icholt").argtypes = mat_in + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_Mat)]
         f("trisolve").argtypes = mat_in + [ctypes.c_int, ctypes.c_int, _F64P]
@@ -129,6 +131,17 @@ class _Lib:
         L, U = _Mat(), _Mat()
         row = ctypes.c_int32(-1)
         rc = self._f("ilut")(*args, int(fill_in), float(threshold), ctypes.byref(L), ctypes.byref(U),
+                             ctypes.byref(row))
+        if rc:
+            raise OracleError(rc, row.value)
+        return self._out(L), self._out(U)
+
+    def iluc(self, A, fill_in=100, threshold=0.1):
+        """(first, second) as ilupp.iluc returns them: ILUC.hpp:112-207, binding.cpp:449-460"""
+        args, keep = self._in(A)
+        L, U = _Mat(), _Mat()
+        row = ctypes.c_int32(-1)
+        rc = self._f("iluc")(*args, int(fill_in), float(threshold), ctypes.byref(L), ctypes.byref(U),
                              ctypes.byref(row))
         if rc:
             raise OracleError(rc, row.value)

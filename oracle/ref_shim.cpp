@@ -111,6 +111,24 @@ int ref_icholt(orc_int n, const orc_int *ptr, const orc_int *idx, const double *
     return ORC_OK;
 }
 
+int ref_iluc(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+             orc_int max_fill_in, double threshold, orc_mat *Lo, orc_mat *Uo, orc_int *err_row)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    matrix L, U;
+    if (err_row) *err_row = -1;
+    try {
+        ILUC2(A, L, U, max_fill_in, threshold);     // binding.cpp:449-460
+    } catch (const std::runtime_error &e) {
+        const char *p = std::strstr(e.what(), "k=");
+        if (p) { if (err_row) *err_row = (orc_int)std::atoi(p + 2); return ORC_ERR_ZERO_PIVOT; }
+        return ORC_ERR_MEMORY;                      // "append_row_with_prefix: insufficient memory reserved"
+    }
+    if (!is_csr) L.interchange(U);
+    export_mat(L, Lo); export_mat(U, Uo);
+    return ORC_OK;
+}
+
 void ref_trisolve(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
                   int form, int use, double *x)
 {
