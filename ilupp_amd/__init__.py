@@ -126,6 +126,13 @@ class ILUTPreconditioner(_HipPreconditioner):
         super().__init__(A, lambda m: _backend.ILUTPreconditioner(*m, fill_in, threshold))
 
 
+class ILUCPreconditioner(_HipPreconditioner):
+    """ILUC, the Crout ILU of Li, Saad and Chow: at most `fill_in` entries per column of L and row of U, relative drop `threshold`."""
+
+    def __init__(self, A, fill_in=100, threshold=0.1):
+        super().__init__(A, lambda m: _backend.ILUCPreconditioner(*m, fill_in, threshold))
+
+
 class ILU0Preconditioner(_HipPreconditioner):
     """ILU(0): incomplete LU in the pattern of A."""
 
@@ -166,3 +173,8 @@ def ilu0(A):
 def ilut(A, fill_in=100, threshold=0.1):
     """(L, U) of an incomplete LU decomposition with thresholding."""
     return tuple(_as_scipy(f) for f in _backend.ilut(*_borrow(A), fill_in, threshold))
+
+
+def iluc(A, fill_in=100, threshold=0.1):
+    """(L, U) of an incomplete Crout LU decomposition with thresholding."""
+    return tuple(_as_scipy(f) for f in _backend.iluc(*_borrow(A), fill_in, threshold))

@@ -46,6 +46,8 @@ def lib():
     L.ilupp_hip_ilu0_create_device.argtypes = mat_host + [ctypes.POINTER(_VP)]
     L.ilupp_hip_ilu0_refactor_device.argtypes = [_VP, _VP, _VP, _VP]
     L.ilupp_hip_ilut_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_iluc_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_iluc_create_device.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
     L.ilupp_hip_ichol0_create.argtypes = mat_host + [ctypes.POINTER(_VP)]
     L.ilupp_hip_icholt_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
     L.ilupp_hip_ilut_create_device.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
@@ -97,6 +99,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
     "ilupp_hip_sync", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
     "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_spmv_device",
+    "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
 ]
 
 
@@ -301,6 +304,11 @@ def ILUTPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, max_fill_i
                           ctypes.c_int32(int(max_fill_in)), ctypes.c_double(float(threshold)))
 
 
+def ILUCPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, max_fill_in, threshold):
+    return _create_device(lib().ilupp_hip_iluc_create_device, d_data, d_indices, d_indptr, n, is_csr,
+                          ctypes.c_int32(int(max_fill_in)), ctypes.c_double(float(threshold)))
+
+
 def IChol0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr):
     return _create_device(lib().ilupp_hip_ichol0_create_device, d_data, d_indices, d_indptr, n, is_csr)
 
@@ -321,6 +329,12 @@ def ILUTPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, thresho
                    ctypes.c_int32(int(max_fill_in)), ctypes.c_double(float(threshold)))
 
 
+def ILUCPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, threshold):
+    """binding.cpp:329-340"""
+    return _create(lib().ilupp_hip_iluc_create, A_data, A_indices, A_indptr, is_csr,
+                   ctypes.c_int32(int(max_fill_in)), ctypes.c_double(float(threshold)))
+
+
 def IChol0Preconditioner(A_data, A_indices, A_indptr, is_csr):
     return _create(lib().ilupp_hip_ichol0_create, A_data, A_indices, A_indptr, is_csr)
 
@@ -337,6 +351,11 @@ def ilu0(A_data, A_indices, A_indptr, is_csr):
 
 def ilut(A_data, A_indices, A_indptr, is_csr, fill_in, threshold):
     return tuple(ILUTPreconditioner(A_data, A_indices, A_indptr, is_csr, fill_in, threshold).factors_info())
+
+
+def iluc(A_data, A_indices, A_indptr, is_csr, fill_in, threshold):
+    """binding.cpp:449-460"""
+    return tuple(ILUCPreconditioner(A_data, A_indices, A_indptr, is_csr, fill_in, threshold).factors_info())
 
 
 def ichol0(A_data, A_indices, A_indptr, is_csr):

@@ -141,7 +141,7 @@ static int report(const HipError &e)
 
 using namespace ilupp;
 
-enum { KIND_LU = 0, KIND_LLT = 1 };
+enum { KIND_LU = 0, KIND_LLT = 1, KIND_UTU = 2 };     // UTU (ILUC): two factors whose arrays both read as an upper CSR matrix, diagonal first
 enum { NNZ_GENERIC_LU = 0, NNZ_ILUT = 1, NNZ_LLT = 2 };
 
 struct ilupp_precond {
@@ -383,6 +383,20 @@ void ensure_transposed(ilupp_precond *p)
             make_desc(st, p->UcT, p->sUT, &p->dUT);
             make_desc(st, p->LcT, p->sLT, &p->dLT);
         }
+    } else if (p->kind == KIND_UTU) {
+        // both transposes are row-major lower matrices with the diagonal last: forward sweeps
+        transpose_storage(st, p->Lc, &p->LcT);
+        transpose_storage(st, p->Uc, &p->UcT);
+        int32_t m1 = 0, m2 = 0;
+        count_cuts_and_schedule(st, p->n, p->LcT.ptr, p->LcT.idx, p->max_lanes, &p->sLT, nullptr, &m1);
+        count_cuts_and_schedule(st, p->n, p->UcT.ptr, p->UcT.idx, p->max_lanes, &p->sUT, nullptr, &m2);
+        p->max_len_T = m1 > m2 ? m1 : m2;
+        choose_tiling(st, p->n, p->LcT.ptr, p->LcT.idx, &p->sLT, true, p->max_lanes / kThreads);
+        choose_tiling(st, p->n, p->UcT.ptr, p->UcT.idx, &p->sUT, true, p->max_lanes / kThreads);
+        build_slot_tables(st, &p->sLT, true);
+        build_slot_tables(st, &p->sUT, true);
+        if (schedule_is_compact(p->sLT)) make_desc(st, p->LcT, p->sLT, &p->dLT);
+        if (schedule_is_compact(p->sUT)) make_desc(st, p->UcT, p->sUT, &p->dUT);
     } else {
         transpose_storage(st, p->Lc, &p->LcT);
         if (min_row_len(st, p->n, p->LcT.ptr, p->LcT.idx, p->llt_diag_last ? 1 : 2) == 0) p->degenerate = true;
@@ -491,6 +505,24 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), p2, y, x, t2, err);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
         }
+    } else if (p->kind == KIND_UTU) {
+        // ILUC (preconditioner_implementation.h:940-958 + :103-111): the left factor is stored column-wise, the right one row-wise,
+        // i.e. both array triples read as upper CSR matrices with the diagonal first (F1 = left^T, F2 = right).
+        //   ID:        T2(left)  = forward sweep over F1^T,  then T3(right) = backward sweep over F2
+        //   TRANSPOSE: T2(right^T) = forward sweep over F2^T, then T3(left^T) = backward sweep over F1
+        ensure_transposed(p);
+        const bool tr = transpose != 0;
+        const DevMat &Mf = tr ? p->UcT : p->LcT;
+        const DevMat &Mb = tr ? p->Lc : p->Uc;
+        const Schedule &sf = tr ? p->sUT : p->sLT, &sb = tr ? p->sL : p->sU;
+        const int32_t *df = tr ? p->dUT : p->dLT, *db = tr ? p->dL : p->dU;
+        const PackedSweep *p1 = packed(p, tr ? 2 : 3, SWEEP_FWD_LAST_ASC, Mf, sf, df, MAXLEN_OF(Mf), tr ? &p->pkUT : &p->pkLT);
+        const PackedSweep *p2 = packed(p, tr ? 0 : 1, SWEEP_BWD_FIRST_ASC, Mb, sb, db, MAXLEN_OF(Mb), tr ? &p->pkL : &p->pkU);
+        ILUPP_HIP(hipEventRecord(p->ev[0], st));
+        SWEEP_OR_RETURN(p, SWEEP_FWD_LAST_ASC, Mf, sf, df, MAXLEN_OF(Mf), p1, x, y, t1, err);
+        ILUPP_HIP(hipEventRecord(p->ev[1], st));
+        SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_ASC, Mb, sb, db, MAXLEN_OF(Mb), p2, y, x, t2, err);
+        ILUPP_HIP(hipEventRecord(p->ev[2], st));
     } else {
         // LL^T: apply == apply_trans (preconditioner_implementation.h:381-394)
         ensure_transposed(p);
@@ -653,6 +685,54 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
 
 }  // extern "C"
 
+// ILUC: A = the major-order view (CSR arrays of the input, whatever its orientation: ILUC2 works on dim_along_orientation)
+static int iluc_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
+{
+    ilupp_precond *p = new_obj(n);
+    p->kind = KIND_UTU;
+    p->nnz_mode = NNZ_GENERIC_LU;
+    p->input_csc = !is_csr;
+    hipStream_t st = p->stream;
+    ILUPP_HIP(hipEventRecord(p->ev[0], st));
+    int32_t err_row = -1;
+    float kms = 0.f;
+    DevMat Lcol, Urow;             // L by columns (unit diagonal first), U by rows (pivot first)
+    int rc = iluc_factor(st, A, max_fill_in, threshold, &Lcol, &Urow, &err_row, &kms);
+    ILUPP_HIP(hipEventRecord(p->ev[1], st));
+    A.release();
+    if (rc) {
+        if (rc == ILUPP_ERR_ZERO_PIVOT) set_error("ILUC2: zero pivot on diagonal, k=" + std::to_string(err_row));               // ILUC.hpp:174-175
+        else if (rc == ILUPP_ERR_MEMORY) set_error("append_row_with_prefix: insufficient memory reserved");                       // sparse_implementation.h:3196-3197
+        else if (rc == ILUPP_ERR_TIMEOUT) set_error("ILUC: dependency wait timed out");
+        destroy_obj(p);
+        return rc;
+    }
+    // ROW input: left = L (columns), right = U (rows); COLUMN input: ILUC2(A, right, left): left = U of the view, right = L of the
+    // view (preconditioner_implementation.h:940-951) -- and iluc() interchanges the same way (binding.cpp:456-457)
+    if (is_csr) { p->Lc = Lcol; p->Uc = Urow; } else { p->Lc = Urow; p->Uc = Lcol; }
+    Lcol.owns = Urow.owns = false;
+    int32_t m1 = 0, m2 = 0;
+    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);
+    count_cuts_and_schedule(st, n, p->Uc.ptr, p->Uc.idx, p->max_lanes, nullptr, &p->sU, &m2);
+    p->max_row_len = m1 > m2 ? m1 : m2;
+    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, false, p->max_lanes / kThreads);
+    choose_tiling(st, n, p->Uc.ptr, p->Uc.idx, &p->sU, false, p->max_lanes / kThreads);
+    build_slot_tables(st, &p->sL, false);
+    build_slot_tables(st, &p->sU, false);
+    p->compact = schedule_is_compact(p->sL) && schedule_is_compact(p->sU);
+    if (p->compact) {
+        make_desc(st, p->Lc, p->sL, &p->dL);
+        make_desc(st, p->Uc, p->sU, &p->dU);
+    }
+    ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
+    p->tm.numeric_kernel_ms = kms;
+    *out = p;
+    return ILUPP_OK;
+}
+
 static int ilut_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
     int rc = ILUPP_OK;
@@ -739,6 +819,46 @@ int ilupp_hip_ilut_create_device(const double *d_data, const int32_t *d_indices,
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
     return ilut_create_common(A, n, is_csr, max_fill_in, threshold, out);
+    API_CATCH
+}
+
+/* binding.cpp:329-340 ILUCPreconditioner(A, max_fill_in, threshold): Crout ILU (Li, Saad, Chow), ILUC.hpp:112-207 */
+int ilupp_hip_iluc_create(const double *data, const int32_t *indices, const int32_t *indptr,
+        int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    rc = iluc_create_common(A, n, is_csr, max_fill_in, threshold, out);
+    A.release();
+    return rc;
+    API_CATCH
+}
+
+int ilupp_hip_iluc_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+        int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+    int32_t nnz32 = 0;
+    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    DevMat A;
+    A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
+    A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+    return iluc_create_common(A, n, is_csr, max_fill_in, threshold, out);
     API_CATCH
 }
 
@@ -950,6 +1070,7 @@ const char *ilupp_hip_path(const ilupp_precond *p)
         return p->prog_f3 ? "ilu0:csr-program" : "ilu0:csr";
     }
     if (p->kind == KIND_LU) return "ilut";
+    if (p->kind == KIND_UTU) return "iluc";
     return p->llt_diag_last ? "ichol0" : "icholt";
 }
 
@@ -988,7 +1109,7 @@ int ilupp_hip_exists(const ilupp_precond *p) { return p ? 1 : 0; }
 const char *ilupp_hip_special_info(const ilupp_precond *) { return ""; }
 int32_t ilupp_hip_dimension(const ilupp_precond *p) { return p ? p->n : 0; }
 
-int ilupp_hip_num_factors(const ilupp_precond *p) { return p ? (p->kind == KIND_LU ? 2 : 1) : 0; }
+int ilupp_hip_num_factors(const ilupp_precond *p) { return p ? (p->kind == KIND_LLT ? 1 : 2) : 0; }
 
 // which factor the caller sees as #which: CSR input -> [L, U] = [Lc, Uc];
 // CSC input -> L.interchange(U) + relabel (ILU0.hpp:100-105) -> [Uc as csc, Lc as csc]
@@ -996,6 +1117,7 @@ static const DevMat *exposed(const ilupp_precond *p, int which, bool *is_csr)
 {
     if (!p || which < 0 || which >= ilupp_hip_num_factors(p)) return nullptr;
     if (p->kind == KIND_LLT) { *is_csr = p->Lc.is_csr; return &p->Lc; }
+    if (p->kind == KIND_UTU) { *is_csr = which != 0; return which == 0 ? &p->Lc : &p->Uc; }     // binding.cpp:449-460: column-wise, row-wise
     if (!p->input_csc) { *is_csr = true; return which == 0 ? &p->Lc : &p->Uc; }
     *is_csr = false;
     return which == 0 ? &p->Uc : &p->Lc;
@@ -1048,7 +1170,7 @@ void ilupp_hip_print_info(const ilupp_precond *p)
     if (!p) return;
     // the reference prints both matrices in full (preconditioner_implementation.h:360-366); we print the summary
     printf("The left matrix of the preconditioner: %d x %d, nnz=%lld\n", p->n, p->n, (long long)p->Lc.nnz);
-    if (p->kind == KIND_LU)
+    if (p->kind != KIND_LLT)
         printf("The right matrix of the preconditioner: %d x %d, nnz=%lld\n", p->n, p->n, (long long)p->Uc.nnz);
 }
 

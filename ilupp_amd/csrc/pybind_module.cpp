@@ -65,6 +65,7 @@ struct Factorisation {
 struct LU : Factorisation { using Factorisation::Factorisation; };
 struct LLT : Factorisation { using Factorisation::Factorisation; };
 struct ILUT : Factorisation { using Factorisation::Factorisation; };
+struct ILUC : Factorisation { using Factorisation::Factorisation; };
 
 template <class Make>
 ilupp_precond *build(Make make)
@@ -137,6 +138,12 @@ PYBIND11_MODULE(_ilupp_hip, m)
             return adopt<ILUT>(build([&](ilupp_precond **h) { return ilupp_hip_ilut_create(a.val, a.idx, a.ptr, a.n, a.row_major, max_fill_in, threshold, h); }));
         }));
 
+    members<ILUC>(m, "ILUCPreconditioner")
+        .def(py::init([](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t max_fill_in, double threshold) {
+            const Csr a = borrow(data, indices, indptr, is_csr);
+            return adopt<ILUC>(build([&](ilupp_precond **h) { return ilupp_hip_iluc_create(a.val, a.idx, a.ptr, a.n, a.row_major, max_fill_in, threshold, h); }));
+        }));
+
     m.def("ILU0Preconditioner", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr) {
         const Csr a = borrow(data, indices, indptr, is_csr);
         return adopt<LU>(build([&](ilupp_precond **h) { return ilupp_hip_ilu0_create(a.val, a.idx, a.ptr, a.n, a.row_major, h); }));
@@ -159,6 +166,11 @@ PYBIND11_MODULE(_ilupp_hip, m)
     m.def("ilut", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t fill_in, double threshold) {
         const Csr a = borrow(data, indices, indptr, is_csr);
         const ILUT f = adopt<ILUT>(build([&](ilupp_precond **h) { return ilupp_hip_ilut_create(a.val, a.idx, a.ptr, a.n, a.row_major, fill_in, threshold, h); }));
+        return py::tuple(egress(f));
+    });
+    m.def("iluc", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t fill_in, double threshold) {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        const ILUC f = adopt<ILUC>(build([&](ilupp_precond **h) { return ilupp_hip_iluc_create(a.val, a.idx, a.ptr, a.n, a.row_major, fill_in, threshold, h); }));
         return py::tuple(egress(f));
     });
     m.def("ichol0", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr) -> py::object {

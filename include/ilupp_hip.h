@@ -75,6 +75,16 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
 int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const int32_t *indptr,
                             int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out);
 
+/* SURVEY 8(f1).  binding.cpp:329-340  ILUCPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, threshold)
+ * -> preconditioner_implementation.h:940-958 -> ILUC2, ILUC.hpp:112-207 (Crout ILU of Li, Saad, Chow; dropping.hpp:8-34).
+ * Two factors: #0 stored column-wise, #1 row-wise (binding.cpp:449-460: for COLUMN input the two are interchanged).
+ * Errors: ILUPP_ERR_ZERO_PIVOT ("ILUC2: zero pivot on diagonal, k=..."), ILUPP_ERR_MEMORY (the reference's reservation of
+ * min(max_fill_in n, 10 nnz) entries per factor exceeded).  The _device form borrows a matrix in HBM. */
+int ilupp_hip_iluc_create(const double *data, const int32_t *indices, const int32_t *indptr,
+                          int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out);
+int ilupp_hip_iluc_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                 int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out);
+
 /* The three above on a matrix that already lives in this GPU's HBM (borrowed for the duration of the call): what a
  * GPU-resident caller -- and bench.py's C3/C4 legs -- use, as ilupp_hip_ilu0_create_device does for ILU(0). */
 int ilupp_hip_ilut_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
