@@ -246,17 +246,17 @@ k_iluc_df(IlucArgs A)
                 }
                 first = __builtin_amdgcn_readfirstlane(first);
                 na = r1 - first;
-                if (na > kNS) CU_FAIL(1);
+                if (na > kNS) CU_FAIL(11);
                 for (int e = lane; e < na; e += 64) { erow[e] = A.idx[first + e]; eval[e] = A.val[first + e]; eslot[e] = e; srow[e] = erow[e]; }
             } else {
                 const int b = __builtin_amdgcn_readfirstlane(A.colptr[k]);
                 na = __builtin_amdgcn_readfirstlane(A.colptr[k + 1]) - b;
-                if (na > kNS) CU_FAIL(1);
+                if (na > kNS) CU_FAIL(11);
                 for (int e = lane; e < na; e += 64) { const int q = A.colord[b + e]; erow[e] = A.rowof[q]; eval[e] = A.val[q]; eslot[e] = e; srow[e] = erow[e]; }
             }
             // ---- the touch records of this kind ----
             const int nt = __builtin_amdgcn_readfirstlane(ld_agent_i32(Z ? &A.cntL[k] : &A.cntU[k]));
-            if (nt > T || nt > kTM) CU_FAIL(1);
+            if (nt > T || nt > kTM) CU_FAIL(12);
             const unsigned long long *recs = (Z ? A.recL : A.recU) + (size_t)k * T * 4;
             for (int q = lane; q < nt; q += 64) {
                 const unsigned long long *r = recs + (size_t)q * 4;
@@ -288,7 +288,7 @@ k_iluc_df(IlucArgs A)
             CU_SYNC();
             const int net = __builtin_amdgcn_readfirstlane(cbase[nt]);
             const int ne = na + net;
-            if (ne > kNE) CU_FAIL(1);
+            if (ne > kNE) CU_FAIL(13);
             // ---- tails: z takes u(h, j >= k) * l(k,h) from the contributor's U row, w takes l(i > k, h) * u(h,k) from its L column ----
             {
                 const int32_t *Oidx = Z ? A.Uidx : A.Lidx;
@@ -341,7 +341,7 @@ k_iluc_df(IlucArgs A)
                 if (ns > kNS) break;
             }
             ns = __builtin_amdgcn_readfirstlane(ns);
-            if (ns > kNS) CU_FAIL(1);
+            if (ns > kNS) CU_FAIL(14);
             CU_SYNC();
             // ---- accumulate every slot sequentially over the entries (batches of 64 in order, inside a batch lowest lane first) ----
             for (int sl = lane; sl < ns; sl += 64) {
@@ -475,7 +475,7 @@ k_iluc_df(IlucArgs A)
                     if (pos >= T) ovf = true;
                     zridx[r] = j * T + pos;
                 }
-                if (__ballot(ovf) != 0ull) CU_FAIL(1);
+                if (__ballot(ovf) != 0ull) CU_FAIL(15);
                 CU_SYNC();
                 // kind L, stored row i at position r: the step of row i will take the tail u(k, j >= i) of THIS step's U row
                 for (int r = 1 + lane; r <= nkw; r += 64) {
@@ -591,7 +591,8 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     const long avg = Av.nnz / m + 1;
     int T = 16;
     const int Tlimit = cls == 0 ? 32 : (cls == 1 ? 64 : (cls == 2 ? 128 : 4096));
-    while (T < 2 * (avg + fill) && T < Tlimit) T *= 2;
+    (void)avg;
+    T = Tlimit < 4096 ? Tlimit : 16;           // as many touch records per step as the class can read (a row of L may be reached by many)
     if (cls == 3) { while (T < Tlimit && T < m) T *= 2; }                  // (a row of L can be reached by every earlier step)
     while (T > 16 && ((long)m * T > 0x7fffffffL || (size_t)m * T * 64 > ((size_t)64 << 30))) T /= 2;
     if ((long)m * T > 0x7fffffffL || (size_t)m * T * 64 > ((size_t)64 << 30)) return 1;
@@ -678,11 +679,14 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     ILUPP_HIP(hipMemcpyAsync(h, ctrl, 16, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    float ms = 0.f;
+    ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
     ILUPP_HIP(hipEventDestroy(e0));
     ILUPP_HIP(hipEventDestroy(e1));
+    if (getenv("ILUPP_DEBUG")) { fprintf(stderr, "[ilupp] iluc: class %d, T %d, waves %d: status %d, %.1f ms\n", cls, T, waves, h[2], ms); }
     int rc = ILUPP_OK;
     if (h[2] == 2) rc = ILUPP_ERR_TIMEOUT;
-    else if (h[2] != 0) rc = 1;
+    else if (h[2] != 0) rc = 1;                        // 11..15: which capacity (A's part, touch records read, entries, slots, touch records written)
     else if (h[3] != big) { rc = ILUPP_ERR_ZERO_PIVOT; if (err_row) *err_row = h[3]; }
     if (rc == ILUPP_OK) {
         DevMat *out[2] = {L, U};
@@ -723,7 +727,12 @@ int iluc_factor(hipStream_t st, const DevMat &Av, int32_t max_fill_in, double th
                 float *kernel_ms)
 {
     int rc = 1;
-    for (int cls = 0; cls < 4 && rc == 1; ++cls) rc = iluc_attempt(st, Av, max_fill_in, threshold, L, U, err_row, kernel_ms, cls);
+    // where to start: a working row gathers about (entries of A's row + fill) tails of up to fill entries; an attempt in a class
+    // that turns out too small costs the time until the first step that does not fit
+    const long fill = max_fill_in < 1 ? 1 : max_fill_in;
+    const long est = (Av.nnz / (Av.n > 0 ? Av.n : 1) / 2 + 1 + fill) * fill;
+    const int first = est <= 192 ? 0 : (est <= 640 ? 1 : 2);
+    for (int cls = first; cls < 4 && rc == 1; ++cls) rc = iluc_attempt(st, Av, max_fill_in, threshold, L, U, err_row, kernel_ms, cls);
     if (rc == 1) { set_error("ILUC: a working row does not fit the largest capacity class"); rc = ILUPP_ERR_UNSUPPORTED; }
     return rc;
 }
