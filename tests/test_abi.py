@@ -76,12 +76,12 @@ def test_pybind11_shim_surface_and_validation():
     for this path, and the buffer checks of binding.cpp:33-98 with the reference's messages (raised before any GPU call)"""
     from ilupp_amd import _ilupp_hip as m
     for name in ("index_size", "ILU0Preconditioner", "IChol0Preconditioner", "ICholTPreconditioner", "ILUTPreconditioner",
-                 "GenericLUPreconditioner", "GenericLLTPreconditioner", "ilu0", "ilut", "ichol0", "icholt"):
+                 "ILUCPreconditioner", "GenericLUPreconditioner", "GenericLLTPreconditioner", "ilu0", "ilut", "iluc", "ichol0", "icholt"):
         assert hasattr(m, name), name
     assert m.index_size() == 4
     for member in ("apply", "apply_trans", "total_nnz", "factors_info", "memory_used_calculations",
                    "memory_allocated_calculations", "memory", "exists", "special_info", "print_info"):
-        assert hasattr(m.GenericLUPreconditioner, member) and hasattr(m.ILUTPreconditioner, member), member
+        assert hasattr(m.GenericLUPreconditioner, member) and hasattr(m.ILUTPreconditioner, member) and hasattr(m.ILUCPreconditioner, member), member
     d, i, p = np.ones(3), np.arange(3, dtype=np.int32), np.arange(4, dtype=np.int32)
     with pytest.raises(RuntimeError, match=r"Expected d \(d\) array for A_data, got f!"):
         m.ILU0Preconditioner(d.astype(np.float32), i, p, True)

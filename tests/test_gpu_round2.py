@@ -489,6 +489,11 @@ for fmt in ("csr", "csc"):
     Lt, Ut = O.orc().ilut(M, 5, 0.1)
     Lg, Ug = T.factors()
     assert G.mat_equal((Lg.data, Lg.indices, Lg.indptr, fmt == "csr"), Lt) and G.mat_equal((Ug.data, Ug.indices, Ug.indptr, fmt == "csr"), Ut)
+    Q = ilupp.ILUCPreconditioner(A, fill_in=5, threshold=0.1)
+    Lq, Uq = O.orc().iluc(M, 5, 0.1)
+    Lh, Uh = Q.factors()
+    assert G.mat_equal((Lh.data, Lh.indices, Lh.indptr, False), Lq) and G.mat_equal((Uh.data, Uh.indices, Uh.indptr, True), Uq)
+    assert np.array_equal(Q @ b, O.orc().apply_lu(Lq, Uq, b, O.ID)) and np.array_equal(Q.T @ b, O.orc().apply_lu(Lq, Uq, b, O.TRANSPOSE))
     C = ilupp.ICholTPreconditioner(A, add_fill_in=2, threshold=1e-3)
     Lc, = C.factors()
     assert G.mat_equal((Lc.data, Lc.indices, Lc.indptr, False), O.orc().icholt(M, 2, 1e-3))
