@@ -588,9 +588,9 @@ __device__ unsigned long long g_st_tl[4096 * 4];     // per workgroup of the for
 // Vectors travel level-major too: a lane reading / writing its own natural-order element is one cache line per lane and
 // instruction -- 64 lines per wave instruction -- and that alone was half of a forward step and a third of a backward one
 // (single tile, 400 steps: 204 us with the natural-order right-hand side, 101 without; backward 195 -> 124 without the
-// natural-order store).  So k_st_gather brings the right-hand side into the forward sweep's order first, the forward sweep
+// natural-order store).  So k_st_vec brings the right-hand side into the forward sweep's order first, the forward sweep
 // stores the intermediate vector in the BACKWARD sweep's order (each lane knows where its rows sit there), the backward sweep
-// reads and overwrites it in place, and k_st_scatter takes the result back to natural order.  Natural-order stores are left
+// reads and overwrites it in place, and k_st_vec takes the result back to natural order.  Natural-order stores are left
 // for the lanes other workgroups read (write-through, the data is the flag).
 // ---------------------------------------------------------------------------------------------
 struct StSArgs {
@@ -1087,37 +1087,52 @@ k_ilu0_st(StFArgs A)
     }
 }
 
-// natural order -> level-major order of the forward sweep (64 per chunk).  A wave writes one chunk (512 contiguous bytes: an
-// 8-byte store per lane into 64 different chunks would be 64 partial writes) and a block 32 consecutive chunks of its wave, so
-// what a lane reads -- 8 bytes of its run per chunk -- comes from the same two cache lines 32 times.
+// natural order <-> level-major order of a sweep (64 per chunk), both sides coalesced through an LDS tile of 32 chunks x 64 lanes:
+// the natural-order side is touched as one contiguous run of 32 elements per lane (8 threads x 32 B), the level-major side as whole
+// chunks (a wave per chunk: 512 contiguous bytes).  Which element of a lane sits in a chunk depends on the lane's skew:
+// k = chunk + tmin - skew; DR = +1: the lane's rows ascend with k (forward schedule), -1: they descend (backward schedule).
+template <int DR, bool TO_LM>
 __global__ void __launch_bounds__(512)
-k_st_gather(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, const double *__restrict__ nat, double *__restrict__ lm)
+k_st_vec(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, double *__restrict__ nat, double *__restrict__ lm)
 {
+    __shared__ double tile[32][65];
     const int w = blockIdx.x;
-    const int L = threadIdx.x & 63;
-    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
-    const v4i t0 = *reinterpret_cast<const v4i *>(ltab + (size_t)slot * kStTab);          // first, cnt, skew, nd
     const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
+    const int c0 = blockIdx.y * 32;
+    if (c0 >= nch) return;
+    const int t = threadIdx.x;
+    // natural-order role: lane l, elements j = sub*4 .. sub*4+3 of its run (chunk c0 + j)
+    const int l = t >> 3, sub = t & 7;
+    const v4i t0 = *reinterpret_cast<const v4i *>(ltab + (size_t)((w >> 2) * kThreads + (w & 3) * 64 + l) * kStTab);      // first, cnt, skew, nd
+    // level-major role: chunk c0 + (t >> 6) + 8 i, lane t & 63
+    const int ll = t & 63, cw = t >> 6;
+    if (TO_LM) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int c = blockIdx.y * 32 + it * 8 + (threadIdx.x >> 6);
-        const int k = c + tmin - t0.z;
-        if (c < nch && k >= 0 && k < t0.y) lm[((size_t)base + c) * 64 + L] = nat[t0.x + k];
+        for (int q = 0; q < 4; ++q) {
+            const int j = sub * 4 + q;
+            const int k = c0 + j + tmin - t0.z;
+            tile[j][l] = (k >= 0 && k < t0.y) ? nat[t0.x + DR * k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = cw + 8 * i;
+            if (c0 + j < nch) lm[((size_t)base + c0 + j) * 64 + ll] = tile[j][ll];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = cw + 8 * i;
+            tile[j][ll] = (c0 + j < nch) ? lm[((size_t)base + c0 + j) * 64 + ll] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = sub * 4 + q;
+            const int k = c0 + j + tmin - t0.z;
+            if (k >= 0 && k < t0.y && c0 + j < nch) nat[t0.x + DR * k] = tile[j][l];
+        }
     }
-}
-// level-major order of the backward sweep -> natural order.  Here the natural-order side is the one written: a wave takes 4
-// lanes x 16 consecutive rows of each (128 contiguous bytes per lane and instruction).
-__global__ void __launch_bounds__(512)
-k_st_scatter(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, double *__restrict__ nat, const double *__restrict__ lm)
-{
-    const int w = blockIdx.x >> 1;
-    const int L = (blockIdx.x & 1) * 32 + (threadIdx.x >> 6) * 4 + (threadIdx.x & 3);
-    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
-    const v4i t0 = *reinterpret_cast<const v4i *>(ltab + (size_t)slot * kStTab);          // first, cnt, skew, nd
-    const int k = blockIdx.y * 16 + 15 - ((threadIdx.x >> 2) & 15);                        // (rows descend along a backward lane)
-    if (k >= t0.y) return;
-    const size_t at = ((size_t)wtab[(size_t)w * 4] + (k + t0.z - wtab[(size_t)w * 4 + 1])) * 64 + L;
-    nat[t0.x - k] = lm[at];
 }
 
 template <int KIND>
@@ -1446,12 +1461,13 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
         });
     }
     if (fwd) {
-        hipLaunchKernelGGL(k_st_gather, dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab, rhs, lml);
+        hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+                           const_cast<double *>(rhs), lml);
         hipLaunchKernelGGL((k_sptrsv_st<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
         hipLaunchKernelGGL((k_sptrsv_st<-1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
-        hipLaunchKernelGGL(k_st_scatter, dim3((unsigned)(ps.nwg * 8), (unsigned)((ps.max_chunks + 15) / 16)), dim3(512), 0, st, ps.ltab, ps.wtab, out,
-                           static_cast<const double *>(ps.xlm));
+        hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+                           out, ps.xlm);
     }
     ILUPP_HIP(hipGetLastError());
     return ILUPP_OK;
@@ -1590,12 +1606,13 @@ int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *
         });
     }
     if (fwd) {
-        hipLaunchKernelGGL(k_st_gather, dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab, rhs, lml);
+        hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+                           const_cast<double *>(rhs), lml);
         hipLaunchKernelGGL((k_sptrsv_st<1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
         hipLaunchKernelGGL((k_sptrsv_st<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
-        hipLaunchKernelGGL(k_st_scatter, dim3((unsigned)(ps.nwg * 8), (unsigned)((ps.max_chunks + 15) / 16)), dim3(512), 0, st, ps.ltab, ps.wtab, out,
-                           static_cast<const double *>(ps.xlm));
+        hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+                           out, ps.xlm);
     }
     ILUPP_HIP(hipGetLastError());
     return ILUPP_OK;
