@@ -575,7 +575,7 @@ __global__ void k_iluc_compact(int32_t m, int32_t cap, const int32_t *__restrict
 
 // one attempt with one capacity class; ILUPP_OK / an error of the reference / +1 = "outside this class"
 static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U, int32_t *err_row,
-                        float *kernel_ms, int cls)
+                        float *kernel_ms, int cls, int *which_capacity)
 {
     const int32_t m = Av.n;
     if (m < 1) return 1;
@@ -590,10 +590,10 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     if ((long)m * cap > 0x7fffffffL) return 1;
     const long avg = Av.nnz / m + 1;
     int T = 16;
-    const int Tlimit = cls == 0 ? 32 : (cls == 1 ? 64 : (cls == 2 ? 128 : 4096));
+    const int Tlimit = cls == 0 ? 32 : (cls == 1 ? 64 : (cls == 2 ? 128 : (cls == 3 ? 512 : 4096)));
     (void)avg;
     T = Tlimit < 4096 ? Tlimit : 16;           // as many touch records per step as the class can read (a row of L may be reached by many)
-    if (cls == 3) { while (T < Tlimit && T < m) T *= 2; }                  // (a row of L can be reached by every earlier step)
+    if (cls == 4) { while (T < Tlimit && T < m) T *= 2; }                  // (a row of L can be reached by every earlier step)
     while (T > 16 && ((long)m * T > 0x7fffffffL || (size_t)m * T * 64 > ((size_t)64 << 30))) T /= 2;
     if ((long)m * T > 0x7fffffffL || (size_t)m * T * 64 > ((size_t)64 << 30)) return 1;
 
@@ -647,11 +647,11 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     }
     hipLaunchKernelGGL(k_iluc_colfill, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, colptr, fillc, colpos);
     hipLaunchKernelGGL(k_iluc_colorder, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, rowof, colptr, colpos, colord);
-    int waves = device_cu_count() * (cls == 0 ? 16 : (cls == 1 ? 8 : (cls == 2 ? 2 : 4)));
+    int waves = device_cu_count() * (cls == 0 ? 16 : (cls == 1 ? 8 : (cls == 2 ? 2 : (cls == 3 ? 2 : 4))));
     if (waves > m) waves = m;
     unsigned char *gws = nullptr;
     int gNE = 0, gNS = 0, gTM = 0;
-    if (cls == 3) {
+    if (cls == 4) {
         gTM = T; gNS = 1024; while (gNS < m + 1 && gNS < 16384) gNS *= 2;       // (a power of two: the slot hash masks with 4 gNS - 1)
         gNE = 1 << 19;
         while (gNE > 4096 && (size_t)waves * iluc_ws_bytes(gNE, gNS, gTM) > ((size_t)16 << 30)) gNE /= 2;
@@ -672,6 +672,7 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     if (cls == 0) hipLaunchKernelGGL((k_iluc_df<256, 128, 32, false>), dim3(waves), dim3(64), 0, st, a);
     else if (cls == 1) hipLaunchKernelGGL((k_iluc_df<768, 256, 64, false>), dim3(waves), dim3(64), 0, st, a);
     else if (cls == 2) hipLaunchKernelGGL((k_iluc_df<1024, 512, 128, false>), dim3(waves), dim3(64), 0, st, a);
+    else if (cls == 3) hipLaunchKernelGGL((k_iluc_df<960, 256, 512, false>), dim3(waves), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_iluc_df<1, 1, 1, true>), dim3(waves), dim3(64), 0, st, a);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
@@ -686,7 +687,7 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     if (getenv("ILUPP_DEBUG")) { fprintf(stderr, "[ilupp] iluc: class %d, T %d, waves %d: status %d, %.1f ms\n", cls, T, waves, h[2], ms); }
     int rc = ILUPP_OK;
     if (h[2] == 2) rc = ILUPP_ERR_TIMEOUT;
-    else if (h[2] != 0) rc = 1;                        // 11..15: which capacity (A's part, touch records read, entries, slots, touch records written)
+    else if (h[2] != 0) { rc = 1; if (which_capacity) *which_capacity = h[2]; }      // 11..15: which capacity (A's part, touch records read, entries, slots, touch records written)
     else if (h[3] != big) { rc = ILUPP_ERR_ZERO_PIVOT; if (err_row) *err_row = h[3]; }
     if (rc == ILUPP_OK) {
         DevMat *out[2] = {L, U};
@@ -732,7 +733,13 @@ int iluc_factor(hipStream_t st, const DevMat &Av, int32_t max_fill_in, double th
     const long fill = max_fill_in < 1 ? 1 : max_fill_in;
     const long est = (Av.nnz / (Av.n > 0 ? Av.n : 1) / 2 + 1 + fill) * fill;
     const int first = est <= 192 ? 0 : (est <= 640 ? 1 : 2);
-    for (int cls = first; cls < 4 && rc == 1; ++cls) rc = iluc_attempt(st, Av, max_fill_in, threshold, L, U, err_row, kernel_ms, cls);
+    for (int cls = first; cls < 5 && rc == 1; ++cls) {
+        int which = 0;
+        rc = iluc_attempt(st, Av, max_fill_in, threshold, L, U, err_row, kernel_ms, cls, &which);
+        // a step reached by more stored entries than the class has touch records: the next class has only twice as many, the
+        // one after it 512 (a matrix with a few heavily reached rows would fail there again, after a longer run)
+        if (rc == 1 && (which == 12 || which == 15) && cls < 2) cls = 2;
+    }
     if (rc == 1) { set_error("ILUC: a working row does not fit the largest capacity class"); rc = ILUPP_ERR_UNSUPPORTED; }
     return rc;
 }
