@@ -368,15 +368,6 @@ __device__ __forceinline__ int st_row_find(const StSpan &s, int col)
 // stalled at issue, 76 cycles per vector-memory instruction and CU).  So the 9 rows a lane contributes (one before the eight:
 // the pivot row of the first) are read as ONE contiguous run, 8 threads x 16 bytes per instruction, into LDS, and the rows
 // and most of the pivot rows are picked from there.
-#ifndef EXP_ROWS_NOSTORE
-#define EXP_ROWS_NOSTORE 0
-#endif
-#ifndef EXP_ROWS_NOGATHER
-#define EXP_ROWS_NOGATHER 0
-#endif
-#ifndef EXP_ROWS_NOU
-#define EXP_ROWS_NOU 0
-#endif
 static constexpr int kStSpanMax = 64;            // entries of a lane's run (9 rows of at most 7)
 __global__ void __launch_bounds__(512)
 k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval, int64_t nnz,
@@ -528,7 +519,7 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
                             done = true;
                         }
                     }
-                    if (!done && !EXP_ROWS_NOGATHER) {
+                    if (!done) {
                         const int b0 = Aptr[c];
                         const int bl_ = Aptr[c + 1] - b0;
                         const Row8 rc = load_row8(Aidx, b0, bl_ > 8 ? 8 : bl_, nnz);
@@ -540,8 +531,7 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
                 }
             }
         }
-        if (EXP_ROWS_NOSTORE) { if (a[0] + a[1] + a[2] + a[3] + tj[0] + tj[1] + tj[2] + a[6] + a[4] + a[5] == 1.2345) flags[2] = 1; }
-        else if (!bad) {
+        if (!bad) {
             const int c = k + t0.z - wtab[(size_t)w * 4 + 1];
             v2d *p = pkA + ((size_t)wtab[(size_t)w * 4] + c) * 256 + l;
             v2d x;
@@ -549,7 +539,7 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
             x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, p + 64);
             x.x = tj[0]; x.y = tj[1]; __builtin_nontemporal_store(x, p + 128);
             x.x = tj[2]; x.y = a[6]; __builtin_nontemporal_store(x, p + 192);
-            if (!EXP_ROWS_NOU) { x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((size_t)wtab[(size_t)w * 4] + c) * 128 + l); }
+            x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((size_t)wtab[(size_t)w * 4] + c) * 128 + l);
         }
     }
     if (bad) atomicOr(&flags[0], 8);
