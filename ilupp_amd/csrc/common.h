@@ -175,6 +175,26 @@ __device__ __forceinline__ void st_agent_i32(int *p, int v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a 32-byte record with two 16-byte agent-scope accesses instead of four 8-byte ones (the dataflow kernels of ICholT / ILUC are
+// bound by the number of small memory operations; a record is only read after the counter that publishes it)
+struct Rec32 { unsigned long long w[4]; };
+__device__ __forceinline__ Rec32 ld_agent_rec32(const unsigned long long *p)
+{
+    typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+    v2u a, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+    Rec32 r; r.w[0] = a.x; r.w[1] = a.y; r.w[2] = b.x; r.w[3] = b.y;
+    return r;
+}
+__device__ __forceinline__ void st_agent_rec32(unsigned long long *p, unsigned long long w0, unsigned long long w1, unsigned long long w2,
+                                               unsigned long long w3)
+{
+    typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+    v2u a, b;
+    a.x = w0; a.y = w1; b.x = w2; b.y = w3;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(p), "v"(a), "v"(b) : "memory");
+}
 // block that owns row c:  start[b] <= c < start[b+1]
 __device__ __forceinline__ int block_of(int c, int B, int nb, const int32_t *__restrict__ start)
 {

@@ -178,8 +178,8 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         // ---- the column of A (slots 0..clen-1, IChol.hpp:110-112) and the touch records of row j ----
         for (int e = lane; e < clen; e += 64) { erow[e] = Aidx[c0 + e]; eval[e] = Aval[c0 + e]; eslot[e] = e; srow[e] = erow[e]; }
         for (int q = lane; q < nt; q += 64) {
-            const unsigned long long *r = rec + ((size_t)j * T + q) * 4;
-            const unsigned long long w0 = ld_agent_u64(r), w1 = ld_agent_u64(r + 1), w2 = ld_agent_u64(r + 2), w3 = ld_agent_u64(r + 3);
+            const Rec32 rr = ld_agent_rec32(rec + ((size_t)j * T + q) * 4);
+            const unsigned long long w0 = rr.w[0], w1 = rr.w[1], w2 = rr.w[2], w3 = rr.w[3];
             tk[q] = (int)(unsigned)w0; tx[q] = (int)(unsigned)(w0 >> 32);
             tt[q] = (int)(unsigned)w1; trem[q] = (int)(unsigned)(w1 >> 32);
             tv[q] = __longlong_as_double((long long)w2);
@@ -388,10 +388,7 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
             const int rem = stored ? nk - 1 - r : 0;
             const int nxt = (stored && r + 1 < nk) ? sridx[keptslot[r + 1]] : -1;
             unsigned long long *rp = rec + (size_t)sridx[s] * 4;
-            st_agent_u64(rp, pack2(j, x));
-            st_agent_u64(rp + 1, pack2(tprev, rem));
-            st_agent_u64(rp + 2, (unsigned long long)__double_as_longlong(sval[s]));
-            st_agent_u64(rp + 3, pack2(nxt, 0));
+            st_agent_rec32(rp, pack2(j, x), pack2(tprev, rem), (unsigned long long)__double_as_longlong(sval[s]), pack2(nxt, 0));
         }
         drain_stores();
         // ---- announce / discharge reaches; rows whose last reach this was become ready ----

@@ -259,8 +259,8 @@ k_iluc_df(IlucArgs A)
             if (nt > T || nt > kTM) CU_FAIL(12);
             const unsigned long long *recs = (Z ? A.recL : A.recU) + (size_t)k * T * 4;
             for (int q = lane; q < nt; q += 64) {
-                const unsigned long long *r = recs + (size_t)q * 4;
-                const unsigned long long w0 = ld_agent_u64(r), w1 = ld_agent_u64(r + 1), w2 = ld_agent_u64(r + 2), w3 = ld_agent_u64(r + 3);
+                const Rec32 rr = ld_agent_rec32(recs + (size_t)q * 4);
+                const unsigned long long w0 = rr.w[0], w1 = rr.w[1], w2 = rr.w[2], w3 = rr.w[3];
                 tx[q] = (int)(unsigned)(w0 >> 32);
                 tt[q] = (int)(unsigned)w1; trem[q] = (int)(unsigned)(w1 >> 32);
                 tv[q] = __longlong_as_double((long long)w2);
@@ -486,10 +486,8 @@ k_iluc_df(IlucArgs A)
                     const int tprev = r > 1 ? srow[keptslot[r - 1]] : k;
                     const int nxt = r < nkw ? sridx[r + 1] : -1;
                     unsigned long long *rp = A.recL + (size_t)sridx[r] * 4;
-                    st_agent_u64(rp, cu_pack2(k, (int)(off + lb)));
-                    st_agent_u64(rp + 1, cu_pack2(tprev, nkz + 1 - lb));
-                    st_agent_u64(rp + 2, (unsigned long long)__double_as_longlong(sval[s]));
-                    st_agent_u64(rp + 3, cu_pack2(nxt, 0));
+                    st_agent_rec32(rp, cu_pack2(k, (int)(off + lb)), cu_pack2(tprev, nkz + 1 - lb), (unsigned long long)__double_as_longlong(sval[s]),
+                                   cu_pack2(nxt, 0));
                 }
                 // kind U, stored column j at position r: the step of column j will take the tail l(i > j, k) of THIS step's L column
                 for (int r = 1 + lane; r <= nkz; r += 64) {
@@ -499,10 +497,8 @@ k_iluc_df(IlucArgs A)
                     const int tprev = r > 1 ? zkept[r - 1] : k;
                     const int nxt = r < nkz ? zridx[r + 1] : -1;
                     unsigned long long *rp = A.recU + (size_t)zridx[r] * 4;
-                    st_agent_u64(rp, cu_pack2(k, (int)(off + ub)));
-                    st_agent_u64(rp + 1, cu_pack2(tprev, nkw + 1 - ub));
-                    st_agent_u64(rp + 2, (unsigned long long)__double_as_longlong(zkv[r]));
-                    st_agent_u64(rp + 3, cu_pack2(nxt, 0));
+                    st_agent_rec32(rp, cu_pack2(k, (int)(off + ub)), cu_pack2(tprev, nkw + 1 - ub), (unsigned long long)__double_as_longlong(zkv[r]),
+                                   cu_pack2(nxt, 0));
                 }
                 drain_stores();
                 // announcements first: x in R gets the kept columns below x, x in C the kept rows below x
