@@ -43,6 +43,7 @@ namespace ilupp {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+#define ST_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
 static constexpr int kStH = 8;                 // steps of hand-off history kept in LDS = steps the streams are read ahead
 #ifndef ST_P
 #define ST_P 4
@@ -368,6 +369,9 @@ __device__ __forceinline__ int st_row_find(const StSpan &s, int col)
 // stalled at issue, 76 cycles per vector-memory instruction and CU).  So the 9 rows a lane contributes (one before the eight:
 // the pivot row of the first) are read as ONE contiguous run, 8 threads x 16 bytes per instruction, into LDS, and the rows
 // and most of the pivot rows are picked from there.
+// (plain stores, not streaming ones: a wave holds its LDS and its slot until its stores are acknowledged, and the L2 acknowledges
+// a write-back store sooner -- 1.13 -> 0.93 ms in an A/B on the same box; the sweeps' and the factor kernel's stores showed no such gain)
+#define ST_ROWS_STORE(v, p) (*(p) = (v))
 static constexpr int kStSpanMax = 64;            // entries of a lane's run (9 rows of at most 7)
 __global__ void __launch_bounds__(512)
 k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval, int64_t nnz,
@@ -535,11 +539,11 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
             const int c = k + t0.z - wtab[(size_t)w * 4 + 1];
             v2d *p = pkA + ((size_t)wtab[(size_t)w * 4] + c) * 256 + l;
             v2d x;
-            x.x = a[0]; x.y = a[1]; __builtin_nontemporal_store(x, p);
-            x.x = a[2]; x.y = a[3]; __builtin_nontemporal_store(x, p + 64);
-            x.x = tj[0]; x.y = tj[1]; __builtin_nontemporal_store(x, p + 128);
-            x.x = tj[2]; x.y = a[6]; __builtin_nontemporal_store(x, p + 192);
-            x.x = a[4]; x.y = a[5]; __builtin_nontemporal_store(x, pkU + ((size_t)wtab[(size_t)w * 4] + c) * 128 + l);
+            x.x = a[0]; x.y = a[1]; ST_ROWS_STORE(x, p);
+            x.x = a[2]; x.y = a[3]; ST_ROWS_STORE(x, p + 64);
+            x.x = tj[0]; x.y = tj[1]; ST_ROWS_STORE(x, p + 128);
+            x.x = tj[2]; x.y = a[6]; ST_ROWS_STORE(x, p + 192);
+            x.x = a[4]; x.y = a[5]; ST_ROWS_STORE(x, pkU + ((size_t)wtab[(size_t)w * 4] + c) * 128 + l);
         }
     }
     if (bad) atomicOr(&flags[0], 8);
@@ -674,7 +678,7 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
         STS_LOAD(u, tlo + u);
         // (the stores of a step, to the dump places: the waitcnt pass takes the minimum over the way into the loop and its back
         // edge, so the way in has to look like a pass of the loop -- see k_ilu0_st)
-        __builtin_nontemporal_store(0.0, reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8));
+        ST_STREAM_STORE(0.0, reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8));
         if (EX) st_agent_f64(reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8), 0.0);
         asm volatile("" ::: "memory");
     }
@@ -738,7 +742,7 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
             {
                 const int cw = tb + u - tminw;
                 unsigned char *o = py + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ydump) * 512;
-                __builtin_nontemporal_store(x, reinterpret_cast<double *>(o + lo8));
+                ST_STREAM_STORE(x, reinterpret_cast<double *>(o + lo8));
             }
             if (EX) st_agent_f64((exports && valid) ? A.xch + (xoff + (tb + u) * xE) : reinterpret_cast<double *>(py + (size_t)ydump * 512 + lo8), x);
             ST_T(5);
@@ -959,9 +963,9 @@ __device__ __forceinline__ void st_factor_wave(const StFArgs &A, unsigned char *
     for (int u = 0; u < kStH; ++u) {
         STF_LOAD(u, tlo + u);
         v2d z; z.x = absent; z.y = absent;
-        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16));
-        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16 + 1024));
-        __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(pu + udump));
+        ST_STREAM_STORE(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16));
+        ST_STREAM_STORE(z, reinterpret_cast<v2d *>(pl + (size_t)ldump * 2048 + lo16 + 1024));
+        ST_STREAM_STORE(z, reinterpret_cast<v2d *>(pu + udump));
         if (EX) st_agent_f64(reinterpret_cast<double *>(pu + udump), absent);
         asm volatile("" ::: "memory");
     }
@@ -1018,12 +1022,12 @@ __device__ __forceinline__ void st_factor_wave(const StFArgs &A, unsigned char *
                 v2d la, lb;
                 la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
                 lb.x = pj[2] ? l[2] : absent; lb.y = 1.0;
-                __builtin_nontemporal_store(la, reinterpret_cast<v2d *>(o + lo16));
-                __builtin_nontemporal_store(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
+                ST_STREAM_STORE(la, reinterpret_cast<v2d *>(o + lo16));
+                ST_STREAM_STORE(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
             }
             {
                 v2d ub; ub.x = r3.y; ub.y = w3;
-                __builtin_nontemporal_store(ub, reinterpret_cast<v2d *>(pu + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048 + 1024 + lo16));
+                ST_STREAM_STORE(ub, reinterpret_cast<v2d *>(pu + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048 + 1024 + lo16));
             }
             ST_T(5);
             STF_LOAD(u, tb + u + kStH);
@@ -1529,11 +1533,11 @@ k_st_transpose(const int32_t *__restrict__ rtab, const int32_t *__restrict__ wta
     if (live) {
     v2d x;
     v2d *pu_ = pkUT + ((size_t)base + c) * 128 + L;
-    x.x = ut[0]; x.y = ut[1]; __builtin_nontemporal_store(x, pu_);
-    x.x = ut[2]; x.y = own[64].y; __builtin_nontemporal_store(x, pu_ + 64);            // diagonal of U
+    x.x = ut[0]; x.y = ut[1]; ST_STREAM_STORE(x, pu_);
+    x.x = ut[2]; x.y = own[64].y; ST_STREAM_STORE(x, pu_ + 64);            // diagonal of U
     v2d *pl_ = pkLT + ((size_t)base + c) * 128 + L;
-    x.x = lt[0]; x.y = lt[1]; __builtin_nontemporal_store(x, pl_);
-    x.x = lt[2]; x.y = 1.0; __builtin_nontemporal_store(x, pl_ + 64);
+    x.x = lt[0]; x.y = lt[1]; ST_STREAM_STORE(x, pl_);
+    x.x = lt[2]; x.y = 1.0; ST_STREAM_STORE(x, pl_ + 64);
     }
     // (per-wave partial sums: one atomic per wave and side)
     for (int off = 32; off > 0; off >>= 1) { nu += __shfl_xor(nu, off); nl += __shfl_xor(nl, off); }
