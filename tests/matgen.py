@@ -119,3 +119,36 @@ def symmetrize(data, indices, indptr):
     S = ((A + A.T) / 2).tocsr()
     S.sort_indices()
     return S.data.astype(np.float64), S.indices.astype(np.int32), S.indptr.astype(np.int32)
+
+
+def box_stencil(dims, diag=None):
+    """full (2 radius-1 box) stencil on a lexicographic grid: 9-point in 2-D, 27-point in 3-D; diagonally dominant, nonsymmetric values"""
+    dims = tuple(int(d) for d in dims)
+    n = int(np.prod(dims))
+    nd = len(dims)
+    strides = [1]
+    for d in dims[:-1]:
+        strides.append(strides[-1] * d)
+    ii = np.arange(n, dtype=np.int64)
+    coords, rem = [], ii
+    for d in dims:
+        coords.append(rem % d); rem = rem // d
+    offs, valid = [], []
+    for delta in np.ndindex(*([3] * nd)):
+        dl = [v - 1 for v in delta][::-1]                      # slowest dimension first => ascending column order
+        o = sum(dl[nd - 1 - a] * strides[a] for a in range(nd))
+        ok = np.ones(n, dtype=bool)
+        for a in range(nd):
+            c = coords[a] + dl[nd - 1 - a]
+            ok &= (c >= 0) & (c < dims[a])
+        offs.append(o); valid.append(ok)
+    order = np.argsort(offs)
+    offs = [offs[k] for k in order]; valid = np.stack([valid[k] for k in order], axis=1)
+    counts = valid.sum(axis=1)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    cols = (ii[:, None] + np.asarray(offs, dtype=np.int64)[None, :])[valid]
+    w = float(3 ** nd) if diag is None else float(diag)
+    base = np.where(np.asarray(offs) == 0, w, -1.0 + 0.1 * np.sin(np.arange(len(offs))))
+    vals = np.broadcast_to(base[None, :], valid.shape)[valid]
+    return np.ascontiguousarray(vals, dtype=np.float64), cols.astype(np.int32), indptr.astype(np.int32)
