@@ -396,8 +396,11 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
         rp[l][i] = (kr >= 0 && kr <= h.y && k0 < h.y) ? Aptr[h.x + kr] : -1;
         if (i == 0) sfirst[l] = h.x;
     }
-    __syncthreads();
+    // (the lane record of this thread's row: asked for here, used after the two barriers below -- one round trip less in the chain)
     const int l = t >> 3, sub = t & 7;
+    const v4i *R = reinterpret_cast<const v4i *>(rtab + (size_t)(slot0 + l) * 32);
+    const v4i t0 = R[0], t1 = R[1], t2 = R[2], klF = R[3], khF = R[4], klB = R[5], khB = R[6], src = R[7];
+    __syncthreads();
     int bad = 0;
     {
         // the lane's run: from its first row here to the end of its last
@@ -430,11 +433,8 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
     }
     __syncthreads();
     // the row of this thread: lane l, k = k0 + sub
-    const v4i *R = reinterpret_cast<const v4i *>(rtab + (size_t)(slot0 + l) * 32);
-    const v4i t0 = R[0];
     const int cnt = t0.y, k = k0 + sub;
     if (k < cnt && !bad) {
-        const v4i t1 = R[1], t2 = R[2];                                      // oL x3, nU | oU x3, up0
         const int r = t0.x + k;
         const int b = rp[l][sub + 1] - slo[l];
         const int len = rp[l][sub + 2] - rp[l][sub + 1];
@@ -496,7 +496,6 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
             }
             if (!(mask & 8)) bad = 1;
             // every entry is produced where the template says
-            const v4i klF = R[3], khF = R[4], klB = R[5], khB = R[6], src = R[7];
             const int kb = cnt - 1 - k;                             // the row's index in the backward schedule
             const int kl[3] = {klF.x, klF.y, klF.z}, kh[3] = {khF.x, khF.y, khF.z};
             const int bl[3] = {klB.x, klB.y, klB.z}, bh[3] = {khB.x, khB.y, khB.z};
