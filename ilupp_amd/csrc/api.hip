@@ -159,6 +159,7 @@ struct ilupp_precond {
     int32_t *prog_f3 = nullptr;      // fixed-size program (short-row matrices): loader/consumer kernel
     bool compact = false;            // descriptors/program usable (block size and grid within the encoding)
     bool no_static_T = false;        // the static form's transposed records were tried and declined
+    bool pair_tried = false;         // static sweeps for the stored factor pair (LL^T objects) were tried
     int32_t *dL = nullptr, *dU = nullptr, *dUT = nullptr, *dLT = nullptr;   // solve descriptors
     PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
     PackedSweep pkUT, pkLT;          // ... of the transposed storages
@@ -526,6 +527,28 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
     } else {
         // LL^T: apply == apply_trans (preconditioner_implementation.h:381-394)
         ensure_transposed(p);
+        // stencil-like factors (IChol0, ICholT without fill on a mesh): the static sweep kernels on the factor's own values
+        {
+            const bool dl = p->llt_diag_last;
+            PackedSweep *pf = dl ? &p->pkL : &p->pkLT, *pb = dl ? &p->pkLT : &p->pkL;
+            if (!p->pair_tried && !p->degenerate) {
+                p->pair_tried = true;
+                // IChol0: forward over L (row-major, diagonal last), backward over its transposed copy in DESCENDING column order (T4);
+                // ICholT: forward over the row-major copy of L, backward over L's own column-major arrays (T3)
+                const bool ok = dl ? st_analyse_pair(st, p->n, p->Lc, p->LcT, p->sL, p->sLT, pf, pb, true)
+                                   : st_analyse_pair(st, p->n, p->LcT, p->Lc, p->sLT, p->sL, pf, pb, false);
+                if (ok) p->pack_tried[0] = p->pack_tried[3] = true;
+            }
+            if (pf->valid && pf->pair && pb->valid && pb->pair) {
+                ILUPP_HIP(hipEventRecord(p->ev[0], st));
+                { const int rc_ = sptrsv_st(st, *pf, dl ? p->sL : p->sLT, p->n, x, y, t1, err, pf->ybuf, nullptr, nullptr); if (rc_) return rc_; }
+                ILUPP_HIP(hipEventRecord(p->ev[1], st));
+                { const int rc_ = sptrsv_st(st, *pb, dl ? p->sLT : p->sL, p->n, y, x, t2, err, nullptr, pf->ybuf, pb->ysrc); if (rc_) return rc_; }
+                ILUPP_HIP(hipEventRecord(p->ev[2], st));
+                p->apply_events_valid = true;
+                return ILUPP_OK;
+            }
+        }
         if (p->llt_diag_last) {       // IChol0: T1(L) then T4(L)
             const PackedSweep *p1 = packed(p, 0, SWEEP_FWD_LAST_ASC, p->Lc, p->sL, p->dL, MAXLEN_OF(p->Lc), &p->pkL);
             const PackedSweep *p2 = packed(p, 3, SWEEP_BWD_FIRST_DESC, p->LcT, p->sLT, p->dLT, MAXLEN_OF(p->LcT), &p->pkLT);

@@ -98,6 +98,9 @@ struct PackedSweep {
     // records of the TRANSPOSED factor for this sweep's schedule (static form; built on the first transposed apply, dropped
     // by a re-factorisation): forward schedule: U^T (diagonal u_rr), backward schedule: L^T (diagonal 1)
     unsigned char *pkT = nullptr;
+    // static sweeps made from a pair of stored triangular factors (st_analyse_pair): the forward sweep divides by its stored
+    // diagonal; the backward sweep accumulates in descending column order when `desc` (a row-stored lower factor used transposed)
+    bool pair = false, desc = false;
     void release();
 };
 
@@ -325,6 +328,10 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err, double *ypk_out = nullptr, const double *ypk_in = nullptr,
               const int32_t *ysrc = nullptr);
 void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
+// static sweeps for a pair of stored factors: Lrow = row-major lower, diagonal last; Urow = row-major upper, diagonal first; both
+// with at most 3 entries per row besides the diagonal (false: the structure does not fit; pl, pu released)
+bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat &Urow, const Schedule &fwd, const Schedule &bwd,
+                     PackedSweep *pl, PackedSweep *pu, bool bwd_desc);
 // static form, transposed apply: records of U^T / L^T from those of L and U (false: the pattern is not symmetric enough)
 bool st_build_transposed(hipStream_t st, const Schedule &fwd, int32_t n, const FactorLM &f, PackedSweep *pl, PackedSweep *pu,
                          int64_t offdiagL, int64_t offdiagU);

@@ -57,7 +57,7 @@ void PackedSweep::release()
     if (xw) (void)pool_free(xw);
     if (xch) (void)pool_free(xch);
     if (pkT) (void)pool_free(pkT);
-    pkT = nullptr;
+    pkT = nullptr; pair = false; desc = false;
     dump = nullptr; xlm = nullptr; y_chunks = 0; xe = xw = nullptr; xch = nullptr; xch_len = 0;
     ysrc = nullptr; ybuf = nullptr; ltab = nullptr; stat = false;
     skew = wtab = flags = uslot = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false; linked = false;

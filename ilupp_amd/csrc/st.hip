@@ -1424,6 +1424,17 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
     return ILUPP_OK;
 }
 
+static void st_solo_attr_T()
+{
+    static std::once_flag once[64];      // once per device
+    int dev = 0;
+    ILUPP_HIP(hipGetDevice(&dev));
+    std::call_once(once[dev & 63], [] {
+        ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+        ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+    });
+}
+
 // One sweep of an apply.  Forward: `rhs` (natural order) -> the intermediate vector in `ypk_out` (the forward sweep's ybuf, in the
 // forward sweep's level-major order); backward: `ypk_in` (the same buffer) -> the result in `out` (natural order).
 int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
@@ -1453,17 +1464,170 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<-1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
         });
     }
+    if (ps.pair) st_solo_attr_T();
     if (fwd) {
         hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
                            const_cast<double *>(rhs), lml);
-        hipLaunchKernelGGL((k_sptrsv_st<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        // (a pair of stored factors: the forward factor has a diagonal of its own)
+        if (ps.pair) hipLaunchKernelGGL((k_sptrsv_st<1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        else hipLaunchKernelGGL((k_sptrsv_st<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
-        hipLaunchKernelGGL((k_sptrsv_st<-1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        if (ps.pair && ps.desc) hipLaunchKernelGGL((k_sptrsv_st<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        else hipLaunchKernelGGL((k_sptrsv_st<-1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
         hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
                            out, ps.xlm);
     }
     ILUPP_HIP(hipGetLastError());
     return ILUPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// static sweeps for a pair of STORED factors (IChol0, ICholT without fill, ILU(0) of a matrix whose factorisation took another
+// generation): the same lane templates, skews, chunk tables and exchange as for ILU(0), proven on the factors' own patterns; the
+// records are the factors' values.  One thread per (forward lane, row): the row of the forward factor (diagonal last) and the row
+// of the backward factor (diagonal first), each entry matched against the lane's template and its range of rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+k_st_pack_pair(const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lidx, const double *__restrict__ Lval,
+               const int32_t *__restrict__ Uptr, const int32_t *__restrict__ Uidx, const double *__restrict__ Uval,
+               const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot,
+               const int32_t *__restrict__ wtab, v2d *__restrict__ pkL, v2d *__restrict__ pkU, int32_t *__restrict__ flags)
+{
+    const int w = blockIdx.x;
+    const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
+    const int L = threadIdx.x & 63;
+    const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
+    if (c >= nch) return;
+    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
+    const int32_t *T = ltabF + (size_t)slot * kStTab;
+    const int k = tmin + c - T[ST_SKEW];
+    const int cnt = T[ST_CNT];
+    if (k < 0 || k >= cnt) return;
+    const int su = uslot[slot];
+    if (su < 0) { atomicOr(&flags[0], 64); return; }
+    const int32_t *TB = ltabB + (size_t)su * kStTab;
+    const int r = T[ST_FIRST] + k;
+    const double absent = st_dbl(kAbsent);
+    double lv[3] = {absent, absent, absent}, uv[3] = {absent, absent, absent};
+    int bad = 0;
+    const int q0 = Lptr[r], q1 = Lptr[r + 1];
+    if (q1 - q0 < 1 || q1 - q0 > 4 || Lidx[q1 - 1] != r) bad = 1;
+    for (int q = q0; q < q1 - 1 && !bad; ++q) {
+        const int o = Lidx[q] - r;
+        int hit = -1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (j < T[ST_ND] && T[ST_OFF + j] == o) hit = j;
+        if (hit < 0 || k < T[ST_KLO + hit] || k >= T[ST_KHI + hit]) bad = 1; else lv[hit] = st_clean(Lval[q]);
+    }
+    const int p0 = Uptr[r], p1 = Uptr[r + 1];
+    const int kb = cnt - 1 - k;
+    if (p1 - p0 < 1 || p1 - p0 > 4 || Uidx[p0] != r) bad = 1;
+    for (int q = p0 + 1; q < p1 && !bad; ++q) {
+        const int o = Uidx[q] - r;
+        int hit = -1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (j < TB[ST_ND] && TB[ST_OFF + j] == o) hit = j;
+        if (hit < 0 || kb < TB[ST_KLO + hit] || kb >= TB[ST_KHI + hit]) bad = 1; else uv[hit] = st_clean(Uval[q]);
+    }
+    if (bad) { atomicOr(&flags[0], 8); return; }
+    v2d x;
+    v2d *pl_ = pkL + ((size_t)base + c) * 128 + L;
+    x.x = lv[0]; x.y = lv[1]; pl_[0] = x;
+    x.x = lv[2]; x.y = st_clean(Lval[q1 - 1]); pl_[64] = x;
+    v2d *pu_ = pkU + ((size_t)base + c) * 128 + L;
+    x.x = uv[0]; x.y = uv[1]; pu_[0] = x;
+    x.x = uv[2]; x.y = st_clean(Uval[p0]); pu_[64] = x;
+}
+
+bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat &Urow, const Schedule &fwd, const Schedule &bwd,
+                     PackedSweep *pl, PackedSweep *pu, bool bwd_desc)
+{
+    pl->release(); pu->release();
+    static const bool off = getenv("ILUPP_NO_PACKED") != nullptr || getenv("ILUPP_NO_STATIC") != nullptr;
+    static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
+    if (off || Lrow.nnz > 4 * (int64_t)n || Urow.nnz > 4 * (int64_t)n || n < 16 || fwd.nslots < kThreads || fwd.nslots != bwd.nslots ||
+        !Lrow.val || !Urow.val || !fwd.exported || !bwd.exported)
+        return false;
+    const int nwg = fwd.nslots / kThreads;
+    const int nslots = fwd.nslots;
+    st_structure(st, fwd, pl, (int)SWEEP_FWD_LAST_ASC);
+    st_structure(st, bwd, pu, (int)SWEEP_BWD_FIRST_ASC);
+    hipLaunchKernelGGL((k_st_template<1>), dim3((unsigned)nwg), dim3(kThreads), 0, st, Lrow.ptr, Lrow.idx, fwd.B, fwd.nb, fwd.start,
+                       fwd.blk2slot, fwd.sfirst, fwd.scount, fwd.exported, pl->ltab, pl->flags);
+    hipLaunchKernelGGL((k_st_template<-1>), dim3((unsigned)nwg), dim3(kThreads), 0, st, Urow.ptr, Urow.idx, bwd.B, bwd.nb, bwd.start,
+                       bwd.blk2slot, bwd.sfirst, bwd.scount, bwd.exported, pu->ltab, pu->flags);
+    pu->built = true;
+    lm_link_factor(st, fwd, bwd, pu);
+    hipLaunchKernelGGL((k_st_link<false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, pl->ltab, static_cast<const int32_t *>(nullptr),
+                       static_cast<const int32_t *>(nullptr), pl->skew, pl->wtab, pl->flags);
+    hipLaunchKernelGGL((k_st_link<false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, pu->ltab, static_cast<const int32_t *>(nullptr),
+                       static_cast<const int32_t *>(nullptr), pu->skew, pu->wtab, pu->flags);
+    hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags);
+    hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pu->wtab, pu->flags);
+    int32_t xtot[2][2];
+    int32_t *xsz = nullptr;
+    void *tmp2 = nullptr;
+    {
+        ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 4));
+        PackedSweep *pp[2] = {pl, pu};
+        const Schedule *ss[2] = {&fwd, &bwd};
+        size_t tb2 = 0;
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, xsz, xsz + nwg, nwg, st));
+        ILUPP_HIP(pool_malloc(&tmp2, tb2));
+        for (int d = 0; d < 2; ++d) {
+            int32_t *sz = xsz + 2 * d * nwg, *offp = sz + nwg;
+            ILUPP_HIP(pool_malloc(&pp[d]->xe, sizeof(int32_t) * (size_t)nslots));
+            ILUPP_HIP(pool_malloc(&pp[d]->xw, sizeof(int32_t) * (size_t)nwg * 4));
+            hipLaunchKernelGGL(k_st_xch_layout, dim3((unsigned)nwg), dim3(kThreads), 0, st, ss[d]->exported, pp[d]->ltab, pp[d]->wtab,
+                               pp[d]->xe, pp[d]->xw, sz, pp[d]->flags);
+            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, sz, offp, nwg, st));
+            hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, offp, pp[d]->xw);
+            ILUPP_HIP(d2h_async(st, &xtot[d][0], offp + (nwg - 1), sizeof(int32_t)));
+            ILUPP_HIP(d2h_async(st, &xtot[d][1], sz + (nwg - 1), sizeof(int32_t)));
+        }
+    }
+    int32_t hl[4], hu[4];
+    ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
+    ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(xsz)); ILUPP_HIP(pool_free(tmp2));
+    const int64_t lim = 6 * (int64_t)n + 64 * 4 * (int64_t)nwg;
+    if (hl[0] || hu[0] || hu[3] || hl[1] <= 0 || hu[1] <= 0 || (int64_t)hl[1] * 64 > lim || (int64_t)hu[1] * 64 > lim ||
+        hl[1] + 4 * nwg >= kStMaxChunks || hu[1] + 4 * nwg >= kStMaxChunks ||
+        (int64_t)nwg * kThreads * ((int64_t)(hl[2] > hu[2] ? hl[2] : hu[2]) + 2 * kStXAlign) > 0x7fffffffLL) {
+        if (dbg) fprintf(stderr, "[ilupp] static sweeps of a factor pair: structure rejected (flags %d %d link %d, %d %d chunks)\n", hl[0], hu[0], hu[3], hl[1], hu[1]);
+        pl->release(); pu->release();
+        return false;
+    }
+    pl->nchunks = hl[1]; pl->max_chunks = hl[2];
+    pu->nchunks = hu[1]; pu->max_chunks = hu[2];
+    ILUPP_HIP(pool_malloc(&pl->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));
+    ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));      // (both in the forward schedule's order)
+    pl->built = true;
+    hipLaunchKernelGGL(k_st_pack_pair, dim3((unsigned)(nwg * 4), (unsigned)((pl->max_chunks + 7) / 8)), dim3(512), 0, st, Lrow.ptr, Lrow.idx,
+                       Lrow.val, Urow.ptr, Urow.idx, Urow.val, pl->ltab, pu->ltab, pu->uslot, pl->wtab, reinterpret_cast<v2d *>(pl->pk),
+                       reinterpret_cast<v2d *>(pu->pk), pl->flags);
+    ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
+    ILUPP_HIP(pool_malloc(&pu->xlm, sizeof(double) * 64 * (size_t)(pu->nchunks + 4 * nwg)));
+    pu->y_chunks = pl->nchunks + 4 * nwg;
+    pl->xch_len = (int64_t)xtot[0][0] + xtot[0][1] + 64;
+    pu->xch_len = (int64_t)xtot[1][0] + xtot[1][1] + 64;
+    ILUPP_HIP(pool_malloc(&pl->xch, sizeof(double) * (size_t)pl->xch_len));
+    ILUPP_HIP(pool_malloc(&pu->xch, sizeof(double) * (size_t)pu->xch_len));
+    ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
+    ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)nslots, st));
+    hipLaunchKernelGGL(k_lm_ysrc, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, pu->uslot, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
+    int32_t gl[4];
+    ILUPP_HIP(d2h_async(st, gl, pl->flags, sizeof(gl)));
+    ILUPP_HIP(stream_sync(st));
+    if (dbg) fprintf(stderr, "[ilupp] static sweeps of a factor pair: row flags %d, %d+%d chunks\n", gl[0], hl[1], hu[1]);
+    if (gl[0]) { pl->release(); pu->release(); return false; }
+    pl->valid = pu->valid = true;
+    pl->stat = pu->stat = true;
+    pl->pair = pu->pair = true;
+    pu->desc = bwd_desc;
+    pu->linked = true;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1589,15 +1753,7 @@ int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *
     a.xe = ps.xe; a.xw = ps.xw; a.xch = ps.xch; a.ticket = d_ticket; a.err = d_err;
     fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
     const dim3 grid((unsigned)ps.nwg);
-    {
-        static std::once_flag once[64];      // once per device
-        int dev = 0;
-        ILUPP_HIP(hipGetDevice(&dev));
-        std::call_once(once[dev & 63], [] {
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_st<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
-        });
-    }
+    st_solo_attr_T();
     if (fwd) {
         hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
                            const_cast<double *>(rhs), lml);
