@@ -45,10 +45,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define ST_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
 static constexpr int kStH = 8;                 // steps of hand-off history kept in LDS = steps the streams are read ahead
-#ifndef ST_P
-#define ST_P 4
-#endif
-static constexpr int kStP = ST_P;                 // steps ahead the values of earlier workgroups are polled (at most 2 per lane)
+static constexpr int kStPF = 8, kStPS = 2;   // steps ahead the courier polls the values of earlier workgroups: factor kernel, sweeps (measured: +-4 %)
 static constexpr int kStMaxSkew = 30000;
 static constexpr unsigned kStSpinLimit = 1u << 21;
 static constexpr int64_t kStMaxChunks = 1 << 21;      // record offsets are 32-bit byte offsets
@@ -603,7 +600,7 @@ struct StSArgs {
 // earlier workgroups ("ghosts") used to be polled, tested and selected by the lanes that need them; that code was 150 of the 200
 // instructions of a step in a wave that has such lanes (a wave64 instruction is 4 cycles: 0.2 us per step, and with the barrier
 // the whole workgroup runs at the pace of that wave) -- a workgroup behind a border ran at half the speed of one without, whatever
-// the poll distance or the kind of load.  Now the courier polls (kStP steps ahead, one (lane, dependency) pair per courier lane,
+// the poll distance or the kind of load.  Now the courier polls (kStPF / kStPS steps ahead, one (lane, dependency) pair per courier lane,
 // at most 64 per workgroup -- the analysis checks), waits for values not there yet, and puts them into the hand-off array as the
 // values of 64 more lanes "of this step"; to the lanes of the schedule a ghost is just another LDS read at a constant address.
 #ifndef ST_CSLEEP
@@ -614,7 +611,7 @@ struct StSArgs {
 #endif
 static constexpr int kStSoloLds = ST_SOLO;      // dynamic LDS nobody uses: > 80 KB per workgroup in total
 #ifndef ST_RA
-#define ST_RA 8
+#define ST_RA 16
 #endif
 static constexpr int kStRA = ST_RA;            // steps the streams of a sweep are read ahead (a multiple of kStH)
 static constexpr int kStRow = kThreads + 64;     // doubles per slot of the hand-off array: the lanes, then the courier's pairs
@@ -758,23 +755,23 @@ __device__ __forceinline__ void st_sweep_wave(const StSArgs &A, unsigned char *x
 
 // the courier of a sweep: lane p serves pair p.  src: the exchange the producers write through to (all-sentinel before the
 // sweep); a pair's value for step s is element idx0 + s stride, wanted for klo <= s - sk < khi.
-template <int RA>
+template <int RA, int NP>
 __device__ __forceinline__ void st_courier(const unsigned long long *src, const unsigned long long *idle, unsigned char *xh, const StPair P,
                                                  const int tlo, const int thi, int32_t *err)
 {
     const int ln = threadIdx.x & 63;
     const unsigned span = (unsigned)(P.khi - P.klo);
-    unsigned long long gq[kStP];
+    unsigned long long gq[NP];
 #define STC_ADDR(k_) ((unsigned)((k_) - P.klo) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
 #pragma unroll
-    for (int g = 0; g < kStP; ++g) { gq[g] = ld_agent_u64(STC_ADDR(tlo + g - P.sk)); asm volatile("" ::: "memory"); }
+    for (int g = 0; g < NP; ++g) { gq[g] = ld_agent_u64(STC_ADDR(tlo + g - P.sk)); asm volatile("" ::: "memory"); }
     bool dead = false;
     for (int tb = tlo; tb < thi; tb += RA) {
 #pragma unroll
         for (int u = 0; u < RA; ++u) {
             const int k = tb + u - P.sk;
             const bool need = (unsigned)(k - P.klo) < span;
-            unsigned long long v = gq[u % kStP];
+            unsigned long long v = gq[u % NP];
             if (!dead) {
                 unsigned spins = 0;
                 while (__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0) {
@@ -790,7 +787,7 @@ __device__ __forceinline__ void st_courier(const unsigned long long *src, const 
                 }
             }
             *reinterpret_cast<unsigned long long *>(xh + (unsigned)(kThreads + ln) * 8 + (unsigned)(u % kStH + kStH) * (kStRow * 8)) = v;
-            gq[u % kStP] = ld_agent_u64(STC_ADDR(k + kStP));
+            gq[u % NP] = ld_agent_u64(STC_ADDR(k + NP));
             ST_BARRIER();
         }
     }
@@ -899,7 +896,7 @@ k_sptrsv_st(StSArgs A)
         const StPair P = s_pairs[t - kThreads];
         // (a poll nobody needs goes to a place of this workgroup's own: the same address for the whole chip would be a hot spot)
         const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
-        st_courier<kStRA>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, A.err);
+        st_courier<kStRA, kStPS>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, A.err);
     }
 }
 
@@ -1076,7 +1073,7 @@ k_ilu0_st(StFArgs A)
         __syncthreads();
         const StPair P = s_pairs[t - kThreads];
         const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
-        st_courier<kStH>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, &A.ctrl[1]);
+        st_courier<kStH, kStPF>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, &A.ctrl[1]);
     }
 }
 
