@@ -25,6 +25,20 @@ class Timings(ctypes.Structure):
 
 
 _lib = None
+_lib_gil = None
+
+
+def _lib_holding_gil():
+    """the same library through ctypes.PyDLL: calls made through it keep the GIL, as the reference's `apply` / `apply_trans` do
+    (binding.cpp:237-254 has no gil_scoped_release; the factorisations release it, :299-397)"""
+    global _lib_gil
+    if _lib_gil is None:
+        lib()
+        G = ctypes.PyDLL(_LIB_PATH)
+        G.ilupp_hip_apply.argtypes = [_VP, _VP, ctypes.c_int64]
+        G.ilupp_hip_apply_trans.argtypes = [_VP, _VP, ctypes.c_int64]
+        _lib_gil = G
+    return _lib_gil
 
 
 def lib():
@@ -175,7 +189,7 @@ class Preconditioner:
         a = self._vec(x)
         if a.shape[0] != lib().ilupp_hip_dimension(self._h):
             raise RuntimeError("vector has wrong size for preconditioner!")
-        rc = lib().ilupp_hip_apply(self._h, a.ctypes.data, a.shape[0])
+        rc = _lib_holding_gil().ilupp_hip_apply(self._h, a.ctypes.data, a.shape[0])
         if rc:
             _raise(rc)
 
@@ -183,7 +197,7 @@ class Preconditioner:
         a = self._vec(x)
         if a.shape[0] != lib().ilupp_hip_dimension(self._h):
             raise RuntimeError("vector has wrong size for preconditioner!")
-        rc = lib().ilupp_hip_apply_trans(self._h, a.ctypes.data, a.shape[0])
+        rc = _lib_holding_gil().ilupp_hip_apply_trans(self._h, a.ctypes.data, a.shape[0])
         if rc:
             _raise(rc)
 
