@@ -164,6 +164,7 @@ struct ilupp_precond {
     PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
     PackedSweep pkUT, pkLT;          // ... of the transposed storages
     bool pack_tried[4] = {false, false, false, false};   // Lc, Uc, UcT, LcT: packing from the descriptors was attempted
+    LevelSweep lvl[4];               // Lc, Uc, UcT, LcT in level order (long-row factors), built on first use
     FactorLM flm;                    // level-major factor kernel state (then Lc.val / Uc.val are filled on demand)
     bool csr_vals = true;            // Lc.val / Uc.val hold the factor values
     int64_t nnzA = 0;                // stored entries of the factored matrix (same pattern on a numeric re-factorisation)
@@ -198,6 +199,7 @@ void destroy_obj(ilupp_precond *p)
     p->sA.release(); p->sL.release(); p->sU.release(); p->sUT.release(); p->sLT.release();
     p->prog.release();
     p->pkL.release(); p->pkU.release(); p->pkUT.release(); p->pkLT.release(); p->flm.release();
+    for (auto &l : p->lvl) l.release();
     if (p->prog_f3) (void)pool_free(p->prog_f3);
     for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)pool_free(d);
     if (p->work) (void)pool_free(p->work);
@@ -449,7 +451,17 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
     // block of consecutive rows.  With blocks, a row waits for everything its lane has to do before it, and the factors of
     // a random matrix have no chains that would make blocks pay: BASELINE config C3's apply took 70 + 186 ms, more than the
     // reference needs on one core.
-    if (M.nnz > 4 * (int64_t)M.n && M.n >= 1024) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
+    if (M.nnz > 4 * (int64_t)M.n && M.n >= 1024) {
+        // ... and the rows in level order (sptrsv_lvl.hip; renumbered copy of the factor, built at the first sweep): in natural
+        // order only the rows inside the window of resident tickets can run, on a mesh a few grid lines
+        LevelSweep *ls = &M == &p->Lc ? &p->lvl[0] : &M == &p->Uc ? &p->lvl[1] : &M == &p->UcT ? &p->lvl[2] : &M == &p->LcT ? &p->lvl[3] : nullptr;
+        if (ls && !ls->tried) {
+            if (&M == &p->Lc || &M == &p->Uc) ensure_csr_values(p);
+            lvl_build(p->stream, kind, M, ls);
+        }
+        if (ls && ls->valid) return sptrsv_lvl(p->stream, *ls, rhs, out, ticket, err);
+        return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
+    }
     return sptrsv(p->stream, kind, M, sch, desc, maxlen, rhs, out, ticket, err);
 }
 // static form: records of U^T and L^T exist (built on first use; a pattern they cannot express is remembered)
@@ -694,6 +706,7 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
     p->tm.numeric_kernel_ms = kms;
     p->apply_events_valid = false;
     st_drop_transposed(&p->pkL, &p->pkU);
+    for (auto &l : p->lvl) l.release();            // (copies of the old values)
     if (p->haveT) {
         p->LcT.release(); p->UcT.release(); p->sUT.release(); p->sLT.release();
         if (p->dUT) (void)pool_free(p->dUT);

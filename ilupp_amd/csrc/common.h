@@ -67,6 +67,17 @@ struct Schedule {
 static constexpr int kGhosts = 64;
 static constexpr int kGhostBase = (1 << 17) - kGhosts;
 
+// One triangular factor renumbered in level order for the one-lane-per-row sweep (sptrsv_lvl.hip): rows sorted by
+// (level, row), columns rewritten to positions, each row = off-diagonal entries in application order + diagonal.
+struct LevelSweep {
+    bool tried = false, valid = false;
+    int32_t n = 0, nlevels = 0;
+    int w = 8, block = 1024;                                    // window and block size of the sweep kernel
+    int32_t *ptr = nullptr, *idx = nullptr, *perm = nullptr;    // n+1, nnz, n (position -> row)
+    double *val = nullptr, *xp = nullptr;                       // nnz; n unknowns in position order (what the rows poll)
+    void release();
+};
+
 // Level-major packed form of one triangular sweep (sptrsv_lm.hip); short-row factors only.
 struct PackedSweep {
     bool built = false;         // structure (skews, chunk table, storage) exists
@@ -300,6 +311,10 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
            int32_t max_row_len, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
+
+// sptrsv_lvl.hip
+bool lvl_build(hipStream_t st, SweepKind kind, const DevMat &M, LevelSweep *ls);
+int sptrsv_lvl(hipStream_t st, const LevelSweep &ls, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
 // sptrsv_lm.hip
 bool lm_prepare(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, const int32_t *desc,
