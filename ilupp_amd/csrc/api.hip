@@ -165,6 +165,8 @@ struct ilupp_precond {
     PackedSweep pkUT, pkLT;          // ... of the transposed storages
     bool pack_tried[4] = {false, false, false, false};   // Lc, Uc, UcT, LcT: packing from the descriptors was attempted
     LevelSweep lvl[4];               // Lc, Uc, UcT, LcT in level order (long-row factors), built on first use
+    int32_t *fperm = nullptr;        // ILU(0) of a long-row matrix: its rows in level order (ilu0_lvl.hip), also the forward sweep's order
+    int32_t fperm_levels = 0;
     FactorLM flm;                    // level-major factor kernel state (then Lc.val / Uc.val are filled on demand)
     bool csr_vals = true;            // Lc.val / Uc.val hold the factor values
     int64_t nnzA = 0;                // stored entries of the factored matrix (same pattern on a numeric re-factorisation)
@@ -200,6 +202,7 @@ void destroy_obj(ilupp_precond *p)
     p->prog.release();
     p->pkL.release(); p->pkU.release(); p->pkUT.release(); p->pkLT.release(); p->flm.release();
     for (auto &l : p->lvl) l.release();
+    if (p->fperm) (void)pool_free(p->fperm);
     if (p->prog_f3) (void)pool_free(p->prog_f3);
     for (int32_t *d : {p->dL, p->dU, p->dUT, p->dLT}) if (d) (void)pool_free(d);
     if (p->work) (void)pool_free(p->work);
@@ -270,7 +273,9 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
         return rc;
     }
     p->csr_vals = true;
-    if (p->prog_f3) {
+    if (p->fperm) {
+        rc = ilu0_numeric_lvl(st, A, &p->Lc, &p->Uc, p->fperm, p->ctrl, kms);
+    } else if (p->prog_f3) {
         // (letting this kernel scatter the sweep records itself cost more than the separate value pass below)
         rc = ilu0_numeric_lc(st, A, &p->Lc, &p->Uc, p->sA, p->prog_f3, p->ctrl, kms, nullptr, nullptr);
     } else if (have_prog) {
@@ -322,7 +327,11 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
         ilu0_write_patterns(st, A, &p->Lc, &p->Uc);
     }
     if (!lm) ilu0_unit_diagonal(st, &p->Lc);        // the CSR-streaming factor kernels write the eliminations only
-    if (p->compact && !lm) {
+    // rows too long for the level-major forms (9-point, 27-point stencils ...): one wave per row, rows in level order (ilu0_lvl.hip);
+    // the sweeps of such factors are the level-ordered ones as well (sptrsv_lvl.hip), nothing below is needed
+    const bool by_level = !lm && A.nnz > 8 * (int64_t)A.n && p->max_row_len <= 64 && A.n >= 1024 &&
+                          lvl_order(st, 2, A.n, A.nnz, A.ptr, A.idx, p->sA, &p->fperm, &p->fperm_levels);
+    if (p->compact && !lm && !by_level) {
         // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels
         if (!(A.nnz >= 16 && build_ilu0_program_f3(st, A, p->Uc, p->sA, &p->prog_f3)))
             have_prog = build_ilu0_program(st, A, p->Uc, p->sA, &p->prog);
@@ -457,7 +466,8 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
         LevelSweep *ls = &M == &p->Lc ? &p->lvl[0] : &M == &p->Uc ? &p->lvl[1] : &M == &p->UcT ? &p->lvl[2] : &M == &p->LcT ? &p->lvl[3] : nullptr;
         if (ls && !ls->tried) {
             if (&M == &p->Lc || &M == &p->Uc) ensure_csr_values(p);
-            lvl_build(p->stream, kind, M, ls);
+            const bool reuse = &M == &p->Lc && p->fperm && kind == SWEEP_FWD_LAST_ASC;      // L's rows depend on each other as A's lower part does
+            lvl_build(p->stream, kind, M, sch, ls, reuse ? p->fperm : nullptr, reuse ? p->fperm_levels : 0);
         }
         if (ls && ls->valid) return sptrsv_lvl(p->stream, *ls, rhs, out, ticket, err);
         return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
@@ -1103,6 +1113,7 @@ const char *ilupp_hip_path(const ilupp_precond *p)
     if (!p) return "";
     if (p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU) {
         if (p->flm.built) return p->flm.stat ? "ilu0:static-level-major" : "ilu0:level-major";
+        if (p->fperm) return "ilu0:level-order";
         return p->prog_f3 ? "ilu0:csr-program" : "ilu0:csr";
     }
     if (p->kind == KIND_LU) return "ilut";

@@ -313,7 +313,11 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
 // sptrsv_lvl.hip
-bool lvl_build(hipStream_t st, SweepKind kind, const DevMat &M, LevelSweep *ls);
+bool lvl_order(hipStream_t st, int mode, int32_t n, int64_t nnz, const int32_t *ptr, const int32_t *idx, const Schedule &sch,
+               int32_t **perm_out, int32_t *nlevels);
+bool lvl_build(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, LevelSweep *ls, const int32_t *perm_given = nullptr,
+               int32_t nlevels_given = 0);
+int ilu0_numeric_lvl(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const int32_t *perm, int32_t *d_ctrl, float *kernel_ms);
 int sptrsv_lvl(hipStream_t st, const LevelSweep &ls, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 
 // sptrsv_lm.hip

@@ -18,7 +18,11 @@
 
 namespace ilupp {
 
-static constexpr int kLvBlock = 1024;           // (the level pass; the sweep kernel has two block sizes)
+#ifndef LV_BLOCK
+#define LV_BLOCK 64
+#endif
+static constexpr int kLvBlock = LV_BLOCK;       // lanes of a workgroup of the level pass
+static constexpr int kLvRing = 16;              // levels a lane of the level pass keeps in LDS for its neighbours (a power of two)
 static constexpr unsigned kLvSpinLimit = 1u << 22;
 
 void LevelSweep::release()
@@ -31,54 +35,140 @@ void LevelSweep::release()
 // ---------------------------------------------------------------------------------------------
 // levels: natural order, one lane per row, data-is-flag on lev[] (-1 = not yet)
 // ---------------------------------------------------------------------------------------------
-template <bool FWD>
+// MODE 0: lower factor (diagonal last), 1: upper factor (diagonal first, rows walked backwards), 2: the part left of the diagonal
+// of a general matrix with sorted rows (= the dependencies of its ILU(0) rows).
+// A lane walks one BLOCK of the sweep's schedule (schedule.hip: consecutive rows that form a chain, on a mesh a grid line), the
+// level of its previous row in a register.  With one row per lane the rows that can run are those of the mesh lines inside the
+// window of resident lanes (2048 x 2048, 9-point: 256 of 2048 lines, 25 ms; 4096 x 4096: 190 ms); with a lane per line every line
+// is resident, and the 64 lanes of a wave are 64 neighbouring lines, each a step or two behind the one before.  (Sixteen
+// consecutive rows per lane instead: the lanes of a wave are then pieces of ONE line and run one after the other, 1.5 s.)
+// A row costs its lane one round trip (the levels it reads) and not three: the row pointers are read three rows ahead and the
+// column indices of the next row while the current one waits.
+template <int MODE, int W>
 __global__ void __launch_bounds__(kLvBlock)
-k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t *lev, int32_t *ticket, int32_t *err)
+k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t nb, const int32_t *__restrict__ start,
+             int32_t B, int32_t *lev, int32_t *ticket, int32_t *err)
 {
-    constexpr int W = 8;
+    constexpr bool FWD = MODE != 1;
+    constexpr int dir = FWD ? 1 : -1;
+    constexpr int D = kLvRing;
+    // the last D levels of every lane, {row, level} in slot row % D: what the neighbouring lines read (a link through memory costs
+    // ~3 us, and on a mesh every row hangs on the line before it: 9 us per row, 56 ms for 2048 x 2048, without this)
+    extern __shared__ unsigned long long lv_ring[];
     __shared__ unsigned wg_ticket;
-    __shared__ int ls[kLvBlock];
     if (threadIdx.x == 0) wg_ticket = (unsigned)atomicAdd(ticket, 1);
-    ls[threadIdx.x] = -1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) lv_ring[d * kLvBlock + threadIdx.x] = FWD ? 0xffffffff00000000ull : 0x7fffffff00000000ull;
     __syncthreads();
+    volatile unsigned long long *ring = lv_ring;
     const int64_t tb = (int64_t)wg_ticket * kLvBlock;
-    const int64_t t = tb + threadIdx.x;
-    bool active = t < n;
-    const int r = active ? (FWD ? (int)t : (int)(n - 1 - t)) : 0;
-    const long row0 = FWD ? (long)tb : (long)n - 1 - (long)tb;
-    int j = 0, jend = 0, mx = 0;
+    const int64_t q = tb + threadIdx.x;
+    bool active = q < nb;
+    int r = 0, cnt = 0, r0 = 0;
     if (active) {
-        const int lo = ptr[r], hi = ptr[r + 1];
-        if (hi > lo) { j = FWD ? lo : lo + 1; jend = FWD ? hi - 1 : hi; }
+        const int b = FWD ? (int)q : (int)(nb - 1 - q);
+        const int s0 = start[b], s1 = start[b + 1];
+        r0 = FWD ? s0 : s1 - 1;
+        cnt = s1 - s0;
+        active = cnt > 0;
     }
-    volatile int *lsv = ls;
+    r = r0;
+    // boundary k of the lane: row k (the k-th it walks) lies between boundary k and boundary k + 1
+#define LV_BOUND(k) ptr[FWD ? r0 + ((k) < cnt ? (k) : cnt) : r0 + 1 - ((k) < cnt ? (k) : cnt)]
+#define LV_RANGE(ea, eb, j0, j1)                                                                                   \
+    do {                                                                                                           \
+        const int lo_ = FWD ? (ea) : (eb), hi_ = FWD ? (eb) : (ea);                                                \
+        j0 = lo_; j1 = lo_;                                                                                        \
+        if (hi_ > lo_) { j0 = MODE == 1 ? lo_ + 1 : lo_; j1 = MODE == 0 ? hi_ - 1 : hi_; }                         \
+    } while (0)
+    // lane of this workgroup that walks row c, or -1
+#define LV_OWNER(c, out)                                                                                           \
+    do {                                                                                                           \
+        const int bb_ = block_of((c), B, nb, start);                                                                \
+        const int64_t ql_ = (FWD ? (int64_t)bb_ : (int64_t)(nb - 1 - bb_)) - tb;                                   \
+        out = (ql_ >= 0 && ql_ < kLvBlock) ? (int)ql_ : -1;                                                        \
+    } while (0)
+    int e0 = 0, e1 = 0, e2 = 0, e3 = 0, k = 0;
+    int j = 0, jend = 0, mx = 0, rprev = -1, mprev = 0;
+    int wc[W], nw[W], wo[W], no[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) { wc[u] = 0; nw[u] = 0; wo[u] = -1; no[u] = -1; }
+    if (active) {
+        e0 = LV_BOUND(0); e1 = LV_BOUND(1); e2 = LV_BOUND(2); e3 = LV_BOUND(3);
+        LV_RANGE(e0, e1, j, jend);
+        int n0, n1;
+        LV_RANGE(e1, e2, n0, n1);
+#pragma unroll
+        for (int u = 0; u < W; ++u) { wc[u] = j + u < jend ? idx[j + u] : 0; nw[u] = n0 + u < n1 ? idx[n0 + u] : 0; }
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            wo[u] = -1; no[u] = -1;
+            if (j + u < jend) LV_OWNER(wc[u], wo[u]);
+            if (n0 + u < n1) LV_OWNER(nw[u], no[u]);
+        }
+    }
+    int wbase = j;                                  // entry the window starts at
     unsigned spins = 0;
     for (;;) {
         if (__ballot(active) == 0ull) break;
         bool progressed = false;
         if (active) {
-            int wc[W], wl[W];
-            const int left = jend - j;
-            const int wn = left < W ? left : W;
+            if (j - wbase >= W && j < jend) {       // a row with more entries than the window: the next piece (not read ahead)
+                wbase = j;
 #pragma unroll
-            for (int u = 0; u < W; ++u) wc[u] = u < wn ? idx[j + u] : 0;
+                for (int u = 0; u < W; ++u) wc[u] = j + u < jend ? idx[j + u] : 0;
 #pragma unroll
-            for (int u = 0; u < W; ++u) {
-                const long lb = FWD ? (long)wc[u] - row0 : row0 - (long)wc[u];
-                wl[u] = u >= wn ? -1 : ((unsigned long)lb < (unsigned long)kLvBlock ? lsv[lb] : ld_agent_i32(lev + wc[u]));
+                for (int u = 0; u < W; ++u) { wo[u] = -1; if (j + u < jend) LV_OWNER(wc[u], wo[u]); }
+                progressed = true;
             }
-            bool stop = false;
+            const int off = j - wbase;
+            int wl[W];
 #pragma unroll
             for (int u = 0; u < W; ++u) {
-                if (!stop && u < wn) {
-                    if (wl[u] >= 0) { mx = wl[u] + 1 > mx ? wl[u] + 1 : mx; ++j; progressed = true; }
+                const bool in = u >= off && wbase + u < jend;
+                const bool beyond = MODE == 2 && wc[u] >= r;         // (sorted rows: the part left of the diagonal ends here)
+                int v = -1;
+                if (in && !beyond) {
+                    if (wc[u] == rprev) {
+                        v = mprev;
+                    } else if (wo[u] >= 0) {
+                        const unsigned long long e = ring[(wc[u] & (D - 1)) * kLvBlock + wo[u]];
+                        const int tag = (int)(e >> 32);
+                        if (tag == wc[u]) v = (int)(unsigned)e;
+                        else if (FWD ? tag > wc[u] : tag < wc[u]) v = ld_agent_i32(lev + wc[u]);    // the lane is more than D rows past it
+                    } else {
+                        v = ld_agent_i32(lev + wc[u]);
+                    }
+                }
+                wl[u] = !in ? -1 : (beyond ? -2 : v);
+            }
+            bool stop = false, rowdone = false;
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                if (!stop && u >= off && wbase + u < jend) {
+                    if (wl[u] == -2) { rowdone = true; stop = true; }
+                    else if (wl[u] >= 0) { mx = wl[u] + 1 > mx ? wl[u] + 1 : mx; ++j; progressed = true; }
                     else stop = true;
                 }
             }
-            if (j == jend) {
+            if (j == jend || rowdone) {
                 st_agent_i32(lev + r, mx);
-                lsv[threadIdx.x] = mx;
-                active = false;
+                ring[(r & (D - 1)) * kLvBlock + threadIdx.x] = ((unsigned long long)(unsigned)r << 32) | (unsigned long long)(unsigned)mx;
+                rprev = r; mprev = mx;
+                ++k;
+                active = k < cnt;
+                r += dir;
+                // the next row becomes the current one; the row after it is fetched (its pointers are already here)
+                e0 = e1; e1 = e2; e2 = e3;
+                LV_RANGE(e0, e1, j, jend);
+                wbase = j; mx = 0;
+                int n0, n1;
+                LV_RANGE(e1, e2, n0, n1);
+#pragma unroll
+                for (int u = 0; u < W; ++u) { wc[u] = nw[u]; wo[u] = no[u]; nw[u] = (active && n0 + u < n1) ? idx[n0 + u] : 0; }
+#pragma unroll
+                for (int u = 0; u < W; ++u) { no[u] = -1; if (active && n0 + u < n1) LV_OWNER(nw[u], no[u]); }
+                if (active) e3 = LV_BOUND(k + 3);
                 progressed = true;
             }
         }
@@ -92,6 +182,9 @@ k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restri
             }
         }
     }
+#undef LV_BOUND
+#undef LV_RANGE
+#undef LV_OWNER
 }
 
 // position of every row, length of every row in position order
@@ -236,85 +329,117 @@ k_sptrsv_lvl(int32_t n, const int32_t *__restrict__ ptrp, const int32_t *__restr
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-bool lvl_build(hipStream_t st, SweepKind kind, const DevMat &M, LevelSweep *ls)
+// rows of a triangular pattern (or of the lower part of a general one, mode 2) sorted by (level, row): perm[position] = row
+bool lvl_order(hipStream_t st, int mode, int32_t n, int64_t nnz, const int32_t *ptr, const int32_t *idx, const Schedule &sch,
+               int32_t **perm_out, int32_t *nlevels)
 {
-    static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
-    ls->release();
-    ls->tried = true;
-    const int32_t n = M.n;
-    if (n < 1024 || !M.ptr || !M.idx || !M.val || M.nnz >= 0x7fffffffLL) return false;
-    const bool fwd = kind == SWEEP_FWD_LAST_ASC;
-    const unsigned grid = (unsigned)((n + kLvBlock - 1) / kLvBlock);
-    int32_t *lev = nullptr, *lev2 = nullptr, *iota = nullptr, *pos = nullptr, *ctl = nullptr, *plen = nullptr;
+    *perm_out = nullptr;
+    if (sch.nb <= 0 || !sch.start || sch.fwd != (mode != 1)) return false;
+    const unsigned grid = (unsigned)((sch.nb + kLvBlock - 1) / kLvBlock);
+    constexpr int kLvLds = kLvRing * kLvBlock * (int)sizeof(unsigned long long);
+    static_assert(kLvLds <= 65536, "the level pass relies on the default limit of dynamic LDS");
+    int32_t *lev = nullptr, *lev2 = nullptr, *iota = nullptr, *ctl = nullptr, *perm = nullptr;
     void *tmp = nullptr;
     ILUPP_HIP(pool_malloc(&lev, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&lev2, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&iota, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(pool_malloc(&pos, sizeof(int32_t) * (size_t)n));
-    ILUPP_HIP(pool_malloc(&plen, sizeof(int32_t) * ((size_t)n + 1)));
     ILUPP_HIP(pool_malloc(&ctl, 64));
-    ILUPP_HIP(pool_malloc(&ls->perm, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&perm, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(hipMemsetAsync(lev, 0xff, sizeof(int32_t) * (size_t)n, st));
     ILUPP_HIP(hipMemsetAsync(ctl, 0, 64, st));
-    if (fwd) hipLaunchKernelGGL((k_lvl_levels<true>), dim3(grid), dim3(kLvBlock), 0, st, n, M.ptr, M.idx, lev, ctl, ctl + 1);
-    else     hipLaunchKernelGGL((k_lvl_levels<false>), dim3(grid), dim3(kLvBlock), 0, st, n, M.ptr, M.idx, lev, ctl, ctl + 1);
-    size_t b1 = 0, b2 = 0, b3 = 0;
+    // window = the entries an average row of the part has (every trip of the wait loop handles a whole window)
+    const double per_row = mode == 2 ? 0.5 * ((double)nnz / (double)n - 1.0) : (double)nnz / (double)n - 1.0;
+    const int w = per_row <= 4.5 ? 4 : (per_row <= 8.5 ? 8 : 16);
+#define LV_LAUNCH(M, WW)                                                                                                        \
+    hipLaunchKernelGGL((k_lvl_levels<M, WW>), dim3(grid), dim3(kLvBlock), kLvLds, st, n, ptr, idx, sch.nb, sch.start, sch.B, lev, ctl, ctl + 1)
+#define LV_LAUNCH_W(M) do { if (w == 4) LV_LAUNCH(M, 4); else if (w == 8) LV_LAUNCH(M, 8); else LV_LAUNCH(M, 16); } while (0)
+    if (mode == 0) LV_LAUNCH_W(0); else if (mode == 1) LV_LAUNCH_W(1); else LV_LAUNCH_W(2);
+#undef LV_LAUNCH_W
+#undef LV_LAUNCH
+    size_t b1 = 0, b2 = 0;
     ILUPP_HIP(hipcub::DeviceReduce::Max(nullptr, b1, lev, ctl + 2, n, st));
-    ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, lev, lev2, iota, ls->perm, n, 0, 32, st));
-    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b3, plen, plen, n + 1, st));
-    const size_t tb = b1 > b2 ? (b1 > b3 ? b1 : b3) : (b2 > b3 ? b2 : b3);
+    ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, lev, lev2, iota, perm, n, 0, 32, st));
+    const size_t tb = b1 > b2 ? b1 : b2;
     ILUPP_HIP(pool_malloc(&tmp, tb));
     size_t bb = tb;
     ILUPP_HIP(hipcub::DeviceReduce::Max(tmp, bb, lev, ctl + 2, n, st));
     int32_t h[4] = {0, 1, 0, 0};
     ILUPP_HIP(d2h_async(st, h, ctl, sizeof(h)));
     ILUPP_HIP(stream_sync(st));
-    bool ok = h[1] == 0 && h[2] >= 0;
+    const bool ok = h[1] == 0 && h[2] >= 0;
     if (ok) {
         int bits = 1;
         while (bits < 31 && (1 << bits) <= h[2]) ++bits;
         iota_i32(st, iota, n);
         bb = tb;
-        ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bb, lev, lev2, iota, ls->perm, n, 0, bits, st));
-        hipLaunchKernelGGL(k_lvl_pos, dim3((unsigned)(((int64_t)n + 1 + 255) / 256)), dim3(256), 0, st, n, ls->perm, M.ptr, pos, plen);
-        ILUPP_HIP(pool_malloc(&ls->ptr, sizeof(int32_t) * ((size_t)n + 1)));
-        bb = tb;
-        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bb, plen, ls->ptr, n + 1, st));
-        ILUPP_HIP(pool_malloc(&ls->idx, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
-        ILUPP_HIP(pool_malloc(&ls->val, sizeof(double) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
-        ILUPP_HIP(pool_malloc(&ls->xp, sizeof(double) * (size_t)n));
-        const dim3 g((unsigned)((n + 255) / 256)), b(256);
-        switch (kind) {
-        case SWEEP_FWD_LAST_ASC:
-            hipLaunchKernelGGL((k_lvl_fill<SWEEP_FWD_LAST_ASC>), g, b, 0, st, n, ls->perm, pos, M.ptr, M.idx, M.val, ls->ptr, ls->idx, ls->val, ctl + 3);
-            break;
-        case SWEEP_BWD_FIRST_ASC:
-            hipLaunchKernelGGL((k_lvl_fill<SWEEP_BWD_FIRST_ASC>), g, b, 0, st, n, ls->perm, pos, M.ptr, M.idx, M.val, ls->ptr, ls->idx, ls->val, ctl + 3);
-            break;
-        default:
-            hipLaunchKernelGGL((k_lvl_fill<SWEEP_BWD_FIRST_DESC>), g, b, 0, st, n, ls->perm, pos, M.ptr, M.idx, M.val, ls->ptr, ls->idx, ls->val, ctl + 3);
-            break;
-        }
-        ILUPP_HIP(d2h_async(st, h, ctl, sizeof(h)));
-        ILUPP_HIP(stream_sync(st));
-        ok = h[3] == 0;
+        ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bb, lev, lev2, iota, perm, n, 0, bits, st));
+        ILUPP_HIP(stream_sync(st));                      // (the scratch goes back to the pool)
     }
-    if (dbg) fprintf(stderr, "[ilupp] level order of a factor (kind %d, n %d, %.1f entries per row): %s, %d levels\n", (int)kind, n, (double)M.nnz / n, ok ? "built" : "declined", h[2] + 1);
-    for (void *q : {(void *)lev, (void *)lev2, (void *)iota, (void *)pos, (void *)plen, (void *)ctl, tmp}) if (q) (void)pool_free(q);
+    for (void *q : {(void *)lev, (void *)lev2, (void *)iota, (void *)ctl, tmp}) if (q) (void)pool_free(q);
+    if (!ok) { (void)pool_free(perm); return false; }
+    *perm_out = perm;
+    *nlevels = h[2] + 1;
+    return true;
+}
+
+// perm_given (with its number of levels): an order somebody has already computed for this pattern (the ILU(0) factor kernel's for L)
+bool lvl_build(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch, LevelSweep *ls, const int32_t *perm_given,
+               int32_t nlevels_given)
+{
+    static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
+    ls->release();
+    ls->tried = true;
+    const int32_t n = M.n;
+    if (n < 1024 || !M.ptr || !M.idx || !M.val || M.nnz >= 0x7fffffffLL) return false;
+    int32_t nlev = nlevels_given;
+    if (perm_given) {
+        ILUPP_HIP(pool_malloc(&ls->perm, sizeof(int32_t) * (size_t)n));
+        ILUPP_HIP(hipMemcpyAsync(ls->perm, perm_given, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    } else if (!lvl_order(st, kind == SWEEP_FWD_LAST_ASC ? 0 : 1, n, M.nnz, M.ptr, M.idx, sch, &ls->perm, &nlev)) {
+        if (dbg) fprintf(stderr, "[ilupp] level order of a factor (kind %d, n %d): declined\n", (int)kind, n);
+        return false;
+    }
+    int32_t *pos = nullptr, *plen = nullptr, *ctl = nullptr;
+    void *tmp = nullptr;
+    ILUPP_HIP(pool_malloc(&pos, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&plen, sizeof(int32_t) * ((size_t)n + 1)));
+    ILUPP_HIP(pool_malloc(&ctl, 64));
+    ILUPP_HIP(hipMemsetAsync(ctl, 0, 64, st));
+    size_t tb = 0;
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, plen, plen, n + 1, st));
+    ILUPP_HIP(pool_malloc(&tmp, tb));
+    hipLaunchKernelGGL(k_lvl_pos, dim3((unsigned)(((int64_t)n + 1 + 255) / 256)), dim3(256), 0, st, n, ls->perm, M.ptr, pos, plen);
+    ILUPP_HIP(pool_malloc(&ls->ptr, sizeof(int32_t) * ((size_t)n + 1)));
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, plen, ls->ptr, n + 1, st));
+    ILUPP_HIP(pool_malloc(&ls->idx, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
+    ILUPP_HIP(pool_malloc(&ls->val, sizeof(double) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
+    ILUPP_HIP(pool_malloc(&ls->xp, sizeof(double) * (size_t)n));
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    switch (kind) {
+    case SWEEP_FWD_LAST_ASC:
+        hipLaunchKernelGGL((k_lvl_fill<SWEEP_FWD_LAST_ASC>), g, b, 0, st, n, ls->perm, pos, M.ptr, M.idx, M.val, ls->ptr, ls->idx, ls->val, ctl + 3);
+        break;
+    case SWEEP_BWD_FIRST_ASC:
+        hipLaunchKernelGGL((k_lvl_fill<SWEEP_BWD_FIRST_ASC>), g, b, 0, st, n, ls->perm, pos, M.ptr, M.idx, M.val, ls->ptr, ls->idx, ls->val, ctl + 3);
+        break;
+    default:
+        hipLaunchKernelGGL((k_lvl_fill<SWEEP_BWD_FIRST_DESC>), g, b, 0, st, n, ls->perm, pos, M.ptr, M.idx, M.val, ls->ptr, ls->idx, ls->val, ctl + 3);
+        break;
+    }
+    int32_t h[4] = {0, 0, 0, 1};
+    ILUPP_HIP(d2h_async(st, h, ctl, sizeof(h)));
+    ILUPP_HIP(stream_sync(st));
+    const bool ok = h[3] == 0;
+    if (dbg) fprintf(stderr, "[ilupp] level order of a factor (kind %d, n %d, %.1f entries per row): %s, %d levels\n", (int)kind, n, (double)M.nnz / n, ok ? "built" : "declined", nlev);
+    for (void *q : {(void *)pos, (void *)plen, (void *)ctl, tmp}) if (q) (void)pool_free(q);
     if (!ok) { ls->release(); ls->tried = true; return false; }
     ls->n = n;
-    ls->nlevels = h[2] + 1;
+    ls->nlevels = nlev;
     // window = the off-diagonal entries of an average row (a wider one makes every trip of the wait loop longer: 9-point, 4 entries:
     // 23 ms with 8, 34 ms with 16; a narrower one costs a round trip per refill: 27-point, 13 entries: 12 ms with 8, 7.5 ms with 16)
     const double offd = (double)M.nnz / (double)n - 1.0;
     ls->w = offd <= 4.5 ? 4 : (offd <= 8.5 ? 8 : 16);
     ls->block = (int64_t)n / ls->nlevels < 4096 ? 256 : 1024;
-#ifdef LV_FORCE_W
-    ls->w = LV_FORCE_W;
-#endif
-#ifdef LV_FORCE_BLOCK
-    ls->block = LV_FORCE_BLOCK;
-#endif
     ls->valid = true;
     return true;
 }
