@@ -10,7 +10,7 @@ A "step" = one complete ILU(0) factorisation of the device-resident CSR matrix (
 i.e. exactly what `P = ilupp.ILU0Preconditioner(A); P.apply(x)` does, with A and x already in HBM
 when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu] [--config C2|C3|C4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu] [--config C2|C3|C4|S27|S9]
 
 N > 1: the path does not shard (a single factorisation is one dependency chain), so every rank
 factors its own matrix of a batch (weak scaling, no data-path collective; RCCL only for the barrier,
@@ -20,7 +20,9 @@ run without a launcher, `--gpus N` starts that launcher itself -- before anythin
 
 --config C3 / C4 add the other BASELINE configs as extra keys of the same JSON line ("extra"):
 ILUT(10, 1e-4) on the random diagonally dominant matrix with n = 1e6, ICholT(0, 0) on the 256^3 matrix
-(bytes = read A + write the factors actually produced).
+(bytes = read A + write the factors actually produced).  --config S27 / S9: ILU(0) beyond 7-point rows (27-point box
+stencil 128^3, 9-point 2048^2: the level-ordered kernels), same keys.  first_apply_ms: the apply right after construction (it may
+build what the sweeps need); apply_ms: the apply after that.
 """
 import argparse
 import hashlib
@@ -129,6 +131,12 @@ def extra_config(name, dev, steps):
         d, i, p = matgen.random_dd(1000000, 19, 25.0, 12345)
         make = lambda a: _native.ILUTPreconditioner_device(*a, True, 10, 1e-4)
         what = "C3: ILUTPreconditioner(fill_in=10, threshold=1e-4), random diagonally dominant CSR n=1e6"
+    elif name in ("S27", "S9"):
+        # ILU(0) beyond the 7-point rows of the headline: box stencils (eliminations meet off-diagonal entries)
+        dims = (128, 128, 128) if name == "S27" else (2048, 2048)
+        d, i, p = matgen.box_stencil(dims)
+        make = lambda a: _native.ILU0Preconditioner_device(*a, True)
+        what = "%s: ILU0Preconditioner, %d-point box stencil %s CSR" % (name, 3 ** len(dims), "x".join(map(str, dims)))
     else:
         d, i, p = matgen.poisson3d(256)
         make = lambda a: _native.ICholTPreconditioner_device(*a, True, 0, 0.0)
@@ -138,7 +146,7 @@ def extra_config(name, dev, steps):
     x = torch.ones(n, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     args = (td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n)
-    walls, kms, apps = [], [], []
+    walls, kms, apps, firsts = [], [], [], []
     nnz_out = 0
     for rep in range(max(2, steps)):
         torch.cuda.synchronize()
@@ -146,17 +154,22 @@ def extra_config(name, dev, steps):
         P = make(args)
         t1 = time.perf_counter()
         P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+        first = P.timings()["last_apply_ms"]
+        # the first apply of a long-row factor renumbers it by dependency level (sptrsv_lvl.hip) and the first apply of an LL^T object
+        # builds its static sweep records; both are reported: "first_apply_ms" and the steady-state "apply_ms" of a Krylov iteration
+        x.fill_(1.0)
+        P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
         t = P.timings()
         nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
         if rep:
-            walls.append(t1 - t0); kms.append(t["numeric_kernel_ms"]); apps.append(t["last_apply_ms"])
+            walls.append(t1 - t0); kms.append(t["numeric_kernel_ms"]); apps.append(t["last_apply_ms"]); firsts.append(first)
         x.fill_(1.0)
         P = None
-    nf = 2 if name == "C3" else 1
+    nf = 1 if name == "C4" else 2
     fbytes = (12 * nnz + 4 * (n + 1)) + (12 * nnz_out + 4 * (n + 1) * nf)
     sec = float(np.median(walls))
     return {"workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
-            "numeric_kernel_ms": float(np.median(kms)), "apply_ms": float(np.median(apps)),
+            "numeric_kernel_ms": float(np.median(kms)), "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
             "hbm_fraction": fbytes / sec / 1e9 / HBM_PEAK_GBS}
 
@@ -170,7 +183,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4"],
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "S27", "S9"],
                     help="extra BASELINE configs measured after the headline one (C2 is always the bench line)")
     args = ap.parse_args()
 
@@ -355,7 +368,7 @@ def main():
             out["cpu_baseline"] = None
         extra = {}
         for cfg in args.config:
-            if cfg in ("C3", "C4") and world == 1:
+            if cfg in ("C3", "C4", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))

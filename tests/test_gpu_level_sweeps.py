@@ -119,3 +119,29 @@ def test_refactor_drops_the_renumbered_copy():
     for use, f in ((O.ID, P.apply), (O.TRANSPOSE, P.apply_trans)):
         x = b.copy(); f(x)
         assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, use))
+
+
+def test_ilu0_27_point_96_cubed():
+    """ILU(0) on a 27-point 96^3 matrix (n = 884 736, 23 M entries; eliminations meet off-diagonal entries: the general merge of
+    ILU0.hpp:8-23) through the device-resident constructor: L, U, apply and apply_trans array-equal to the reference"""
+    import torch
+    from ilupp_amd import _native
+    O, ref = _oracle()
+    d, i, p = matgen.box_stencil((96, 96, 96))
+    n = p.shape[0] - 1
+    dev = torch.device("cuda", 0)
+    td, ti, tp = (torch.from_numpy(a).to(dev) for a in (d, i, p))
+    torch.cuda.synchronize()
+    P = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True)
+    assert P.path() == "ilu0:level-order"
+    Lo, Uo = ref.ilu0((d, i, p, True))
+    L, U = P.factors_info()
+    assert G.mat_equal(tuple(L[:4]), Lo) and G.mat_equal(tuple(U[:4]), Uo)
+    b = G.rhs(n)
+    for use in (O.ID, O.TRANSPOSE):
+        want = O.orc().apply_lu(Lo, Uo, b, use)
+        for rep in range(2):
+            x = torch.from_numpy(b.copy()).to(dev)
+            torch.cuda.synchronize()
+            P.apply_device(x.data_ptr(), n, transpose=(use == O.TRANSPOSE), sync=True)
+            assert np.array_equal(x.cpu().numpy(), want), (use, rep)
