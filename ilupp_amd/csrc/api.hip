@@ -160,6 +160,7 @@ struct ilupp_precond {
     bool compact = false;            // descriptors/program usable (block size and grid within the encoding)
     bool no_static_T = false;        // the static form's transposed records were tried and declined
     bool pair_tried = false;         // static sweeps for the stored factor pair (LL^T objects) were tried
+    bool chol_static = false;        // IChol(0) was computed by the static-form kernel (st.hip)
     int32_t *dL = nullptr, *dU = nullptr, *dUT = nullptr, *dLT = nullptr;   // solve descriptors
     PackedSweep pkL, pkU;            // level-major packed sweeps of Lc / Uc (short-row factors)
     PackedSweep pkUT, pkLT;          // ... of the transposed storages
@@ -938,7 +939,10 @@ static int ichol0_create_common(DevMat &A, int32_t n, int is_csr, ilupp_precond 
     if (p->compact) make_desc(st, p->Lc, p->sL, &p->dL);
     ILUPP_HIP(hipEventRecord(p->ev[1], st));
     float kms = 0.f;
-    rc = ichol0_numeric(st, &p->Lc, p->sL, p->max_row_len, p->done, p->ctrl, &kms);
+    // stencil-like lower triangles whose rows are "simple" (5-/7-point): the static form (st.hip); everything else: the dataflow kernel over chains
+    p->chol_static = ichol0_numeric_st(st, &p->Lc, p->sL, p->ctrl, &kms, &rc);
+    if (!p->chol_static)
+        rc = ichol0_numeric(st, &p->Lc, p->sL, p->max_row_len, p->done, p->ctrl, &kms);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
     ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[0], p->ev[1]));
@@ -1118,7 +1122,7 @@ const char *ilupp_hip_path(const ilupp_precond *p)
     }
     if (p->kind == KIND_LU) return "ilut";
     if (p->kind == KIND_UTU) return "iluc";
-    return p->llt_diag_last ? "ichol0" : "icholt";
+    return p->llt_diag_last ? (p->chol_static ? "ichol0:static-level-major" : "ichol0") : "icholt";
 }
 
 static int apply_host(ilupp_precond *p, double *x, int64_t len, int transpose)

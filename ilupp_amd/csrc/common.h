@@ -347,6 +347,7 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err, double *ypk_out = nullptr, const double *ypk_in = nullptr,
               const int32_t *ysrc = nullptr);
 void st_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
+bool ichol0_numeric_st(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t *d_ctrl, float *kernel_ms, int *rc_out);
 // static sweeps for a pair of stored factors: Lrow = row-major lower, diagonal last; Urow = row-major upper, diagonal first; both
 // with at most 3 entries per row besides the diagonal (false: the structure does not fit; pl, pu released)
 bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat &Urow, const Schedule &fwd, const Schedule &bwd,

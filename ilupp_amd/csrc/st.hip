@@ -1034,8 +1034,11 @@ __device__ __forceinline__ void st_factor_wave(const StFArgs &A, unsigned char *
     ST_T_END(0);
 }
 
-__global__ void __launch_bounds__(kStWgThreads)
-k_ilu0_st(StFArgs A)
+template <bool EX>
+__device__ __forceinline__ void st_chol_wave(const StFArgs &A, unsigned char *xh, const int wg, const unsigned *va, const int tlo, const int thi);
+
+template <bool CHOL>
+__device__ __forceinline__ void st_factor_body(const StFArgs &A)
 {
     __shared__ __attribute__((aligned(16))) unsigned char xh[2 * kStH * kStRow * 8];      // pivots of finished rows: [16][320], slots s and s+8 alike
     __shared__ StPair s_pairs[64];
@@ -1066,7 +1069,8 @@ k_ilu0_st(StFArgs A)
         __syncthreads();
         if (t == 0 && s_total > 64) atomicExch(&A.ctrl[1], 1);        // (the analysis does not let such a schedule through)
         const bool wave_exports = __any(T[ST_CNT] > 0 && A.xe[slot] >= 0);
-        if (wave_exports) st_factor_wave<true>(A, xh, wg, va, tlo, thi); else st_factor_wave<false>(A, xh, wg, va, tlo, thi);
+        if (CHOL) { if (wave_exports) st_chol_wave<true>(A, xh, wg, va, tlo, thi); else st_chol_wave<false>(A, xh, wg, va, tlo, thi); }
+        else      { if (wave_exports) st_factor_wave<true>(A, xh, wg, va, tlo, thi); else st_factor_wave<false>(A, xh, wg, va, tlo, thi); }
     } else {
         __syncthreads();
         __syncthreads();                                              // (the one inside st_number_pairs)
@@ -1075,6 +1079,171 @@ k_ilu0_st(StFArgs A)
         const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
         st_courier<kStH, kStPF>(reinterpret_cast<const unsigned long long *>(A.xch), idle, xh, P, tlo, thi, &A.ctrl[1]);
     }
+}
+
+__global__ void __launch_bounds__(kStWgThreads)
+k_ilu0_st(StFArgs A)
+{
+    st_factor_body<false>(A);
+}
+
+// ---------------------------------------------------------------------------------------------
+// IChol(0) on the static form (IChol.hpp:33-59 for rows whose dot products with earlier rows are all empty: the "simple" rows of a
+// 5-/7-point stencil's lower triangle, proven lane by lane in k_st_chol_check): l_ij = a_ij / l_jj, l_ii = sqrt(a_ii - sum_j l_ij^2),
+// the sum in ascending column order starting from 0.0 as sparse_dot_product does (IChol.hpp:16-28).  Same machinery as the ILU(0)
+// kernel -- lane tables, one barrier per step, hand-off array in LDS (here the finished diagonal l_ii), courier wave, exchange --
+// on records {a0,a1}{a2,a_ii} that are overwritten in place by {l0,l1}{l2,l_ii} (a chunk is read eight steps before it is written).
+// ---------------------------------------------------------------------------------------------
+template <bool EX>
+__device__ __forceinline__ void st_chol_wave(const StFArgs &A, unsigned char *xh, const int wg, const unsigned *va, const int tlo, const int thi)
+{
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    const int slot = wg * kThreads + t;
+    const int32_t *T = A.ltab + (size_t)slot * kStTab;
+    const int cnt = T[ST_CNT], sk = T[ST_SKEW];
+    const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
+    const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
+              nchw = __builtin_amdgcn_readfirstlane(wt[2]);
+    const int xe = A.xe[slot];
+    const bool exports = cnt > 0 && xe >= 0;
+    const int xE = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
+    const int xoff = A.xw[wg * 4 + 3] - A.xw[wg * 4 + 1] * xE + xe;
+    unsigned char *pk = reinterpret_cast<unsigned char *>(A.pkL);
+    const unsigned char *pa = pk + (size_t)(nchw > 0 ? base : 0) * 2048;
+    const unsigned lo16 = (unsigned)ln * 16u;
+    const int cmax = nchw > 0 ? nchw - 1 : 0;
+    const int ldump = A.nchL + wg * 4 + wv;                       // one spare chunk per wave behind the records
+    double *xdump = reinterpret_cast<double *>(pk + (size_t)ldump * 2048 + lo16);
+
+    v2d ra[kStH][2];
+#define STC_LOAD(u, tp)                                                                                              \
+    do {                                                                                                             \
+        const int cw_ = st_med3((tp) - tminw, 0, cmax);                                                              \
+        const unsigned char *q_ = pa + (size_t)cw_ * 2048;                                                           \
+        ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16));                             \
+        ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(q_ + lo16 + 1024));                      \
+    } while (0)
+    const double absent = st_dbl(kAbsent);
+    // (the way into the loop in step order with the stores a step has: see st_factor_wave)
+#pragma unroll
+    for (int u = 0; u < kStH; ++u) {
+        STC_LOAD(u, tlo + u);
+        v2d z; z.x = absent; z.y = absent;
+        ST_STREAM_STORE(z, reinterpret_cast<v2d *>(pk + (size_t)ldump * 2048 + lo16));
+        ST_STREAM_STORE(z, reinterpret_cast<v2d *>(pk + (size_t)ldump * 2048 + lo16 + 1024));
+        if (EX) st_agent_f64(xdump, absent);
+        asm volatile("" ::: "memory");
+    }
+    for (int tb = tlo; tb < thi; tb += kStH) {
+        const int kb = tb - sk;
+#pragma unroll
+        for (int u = 0; u < kStH; ++u) {
+            const int k = kb + u;
+            const bool valid = (unsigned)k < (unsigned)cnt;
+            const v2d r0 = ra[u][0], r1 = ra[u][1];
+            const double av[3] = {r0.x, r0.y, r1.x};
+            bool pj[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pj[j] = valid && st_bits(av[j]) != kAbsent;
+            ST_BARRIER();
+            double piv[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) piv[j] = st_lds(xh, va[j] + (unsigned)u * (kStRow * 8));
+            double l[3];
+            double z = 0.0;                                               // sparse_dot_product of the row with itself (IChol.hpp:16-28)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                l[j] = av[j] / piv[j];                                    // (A_ij - 0.0) / L_jj  (IChol.hpp:49-51)
+                const double sq = l[j] * l[j];
+                const double nz = z + sq;
+                z = pj[j] ? nz : z;
+            }
+            const double d = sqrt(r1.y - z);                              // IChol.hpp:52-53
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)u * (kStRow * 8)) = d;
+            *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u + kStH) * (kStRow * 8)) = d;
+            if (EX) st_agent_f64((exports && valid) ? A.xch + (xoff + (tb + u) * xE) : xdump, d);
+            const int cw = tb + u - tminw;
+            {
+                unsigned char *o = pk + (size_t)((unsigned)cw < (unsigned)nchw ? base + cw : ldump) * 2048;
+                v2d la, lb;
+                la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
+                lb.x = pj[2] ? l[2] : absent; lb.y = d;
+                ST_STREAM_STORE(la, reinterpret_cast<v2d *>(o + lo16));
+                ST_STREAM_STORE(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
+            }
+            STC_LOAD(u, tb + u + kStH);
+        }
+    }
+#undef STC_LOAD
+}
+
+__global__ void __launch_bounds__(kStWgThreads)
+k_ichol0_st(StFArgs A)
+{
+    st_factor_body<true>(A);
+}
+
+// the proof: no row of a lane shares a column left of the diagonal with a row it divides by (then every dot product of
+// IChol.hpp:47 with an earlier row is empty).  Offsets of the lane and of each of its dependencies' lanes, from the lane tables.
+__global__ void __launch_bounds__(kThreads)
+k_st_chol_check(const int32_t *__restrict__ ltab, int32_t *__restrict__ flags)
+{
+    const int slot = blockIdx.x * kThreads + threadIdx.x;
+    const int32_t *T = ltab + (size_t)slot * kStTab;
+    const int cnt = T[ST_CNT], nd = T[ST_ND];
+    if (cnt <= 0) return;
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < nd) {
+            const int32_t *TP = ltab + (size_t)(T[ST_SRC + j] >> 2) * kStTab;
+            const int np = TP[ST_ND];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (p < np) {
+                    const int m = T[ST_OFF + j] + TP[ST_OFF + p];        // a column of the dependency's row, relative to this row
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) if (q < nd && m == T[ST_OFF + q]) bad = 1;
+                }
+            }
+        }
+    }
+    if (bad) atomicOr(&flags[0], 4);
+}
+
+// lower rows (diagonal last) -> records {a0,a1}{a2,a_ii}, every entry matched against its lane's template and range of rows
+__global__ void __launch_bounds__(512)
+k_st_pack_lower(const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lidx, const double *__restrict__ Lval,
+                const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, v2d *__restrict__ pk, int32_t *__restrict__ flags)
+{
+    const int w = blockIdx.x;
+    const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
+    const int L = threadIdx.x & 63;
+    const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
+    if (c >= nch) return;
+    const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
+    const int32_t *T = ltab + (size_t)slot * kStTab;
+    const int k = tmin + c - T[ST_SKEW];
+    const int cnt = T[ST_CNT];
+    const double absent = st_dbl(kAbsent);
+    v2d *o = pk + ((size_t)base + c) * 128 + L;
+    v2d x;
+    if (k < 0 || k >= cnt) { x.x = absent; x.y = absent; o[0] = x; o[64] = x; return; }
+    const int r = T[ST_FIRST] + k;
+    double lv[3] = {absent, absent, absent};
+    int bad = 0;
+    const int q0 = Lptr[r], q1 = Lptr[r + 1];
+    if (q1 - q0 < 1 || q1 - q0 > 4 || Lidx[q1 - 1] != r) bad = 1;
+    for (int q = q0; q < q1 - 1 && !bad; ++q) {
+        const int off = Lidx[q] - r;
+        int hit = -1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (j < T[ST_ND] && T[ST_OFF + j] == off) hit = j;
+        if (hit < 0 || k < T[ST_KLO + hit] || k >= T[ST_KHI + hit]) bad = 1; else lv[hit] = st_clean(Lval[q]);
+    }
+    if (bad) { atomicOr(&flags[0], 8); return; }
+    x.x = lv[0]; x.y = lv[1]; o[0] = x;
+    x.x = lv[2]; x.y = st_clean(Lval[q1 - 1]); o[64] = x;
 }
 
 // natural order <-> level-major order of a sweep (64 per chunk), both sides coalesced through an LDS tile of 32 chunks x 64 lanes:
@@ -1624,6 +1793,96 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
     pl->pair = pu->pair = true;
     pu->desc = bwd_desc;
     pu->linked = true;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// IChol(0), numeric phase on the static form.  L: on entry the lower triangle of A (rows, diagonal last), on exit the factor
+// (values in place, pattern unchanged).  false = this matrix is not one for the static form (nothing has been touched).
+// ---------------------------------------------------------------------------------------------
+bool ichol0_numeric_st(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t *d_ctrl, float *kernel_ms, int *rc_out)
+{
+    static const bool off = getenv("ILUPP_NO_PACKED") != nullptr || getenv("ILUPP_NO_STATIC") != nullptr;
+    static const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
+    const int32_t n = L->n;
+    *rc_out = ILUPP_OK;
+    if (off || L->nnz > 4 * (int64_t)n || n < 16 || fwd.nslots < kThreads || !L->val || !fwd.exported) return false;
+    const int nwg = fwd.nslots / kThreads;
+    const int nslots = fwd.nslots;
+    PackedSweep ps;
+    st_structure(st, fwd, &ps, (int)SWEEP_FWD_LAST_ASC);
+    hipLaunchKernelGGL((k_st_template<1>), dim3((unsigned)nwg), dim3(kThreads), 0, st, L->ptr, L->idx, fwd.B, fwd.nb, fwd.start,
+                       fwd.blk2slot, fwd.sfirst, fwd.scount, fwd.exported, ps.ltab, ps.flags);
+    hipLaunchKernelGGL((k_st_link<false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, ps.ltab, static_cast<const int32_t *>(nullptr),
+                       static_cast<const int32_t *>(nullptr), ps.skew, ps.wtab, ps.flags);
+    hipLaunchKernelGGL(k_st_chol_check, dim3((unsigned)nwg), dim3(kThreads), 0, st, ps.ltab, ps.flags);
+    hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, ps.wtab, ps.flags);
+    int32_t *xsz = nullptr;
+    void *tmp2 = nullptr;
+    size_t tb2 = 0;
+    int32_t xtot[2] = {0, 0};
+    ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 2));
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, xsz, xsz + nwg, nwg, st));
+    ILUPP_HIP(pool_malloc(&tmp2, tb2));
+    ILUPP_HIP(pool_malloc(&ps.xe, sizeof(int32_t) * (size_t)nslots));
+    ILUPP_HIP(pool_malloc(&ps.xw, sizeof(int32_t) * (size_t)nwg * 4));
+    hipLaunchKernelGGL(k_st_xch_layout, dim3((unsigned)nwg), dim3(kThreads), 0, st, fwd.exported, ps.ltab, ps.wtab, ps.xe, ps.xw, xsz, ps.flags);
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, xsz, xsz + nwg, nwg, st));
+    hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, xsz + nwg, ps.xw);
+    ILUPP_HIP(d2h_async(st, &xtot[0], xsz + nwg + (nwg - 1), sizeof(int32_t)));
+    ILUPP_HIP(d2h_async(st, &xtot[1], xsz + (nwg - 1), sizeof(int32_t)));
+    int32_t hl[4];
+    ILUPP_HIP(d2h_async(st, hl, ps.flags, sizeof(hl)));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(xsz)); ILUPP_HIP(pool_free(tmp2));
+    const int64_t lim = 6 * (int64_t)n + 64 * 4 * (int64_t)nwg;
+    if (hl[0] || hl[1] <= 0 || (int64_t)hl[1] * 64 > lim || hl[1] + 4 * nwg >= kStMaxChunks ||
+        (int64_t)nwg * kThreads * ((int64_t)hl[2] + 2 * kStXAlign) > 0x7fffffffLL) {
+        if (dbg) fprintf(stderr, "[ilupp] IChol0 static form: structure rejected (flags %d, %d chunks)\n", hl[0], hl[1]);
+        ps.release();
+        return false;
+    }
+    ps.nchunks = hl[1]; ps.max_chunks = hl[2];
+    ILUPP_HIP(pool_malloc(&ps.pk, (size_t)(ps.nchunks + 4 * nwg) * 2048));
+    ps.built = true;
+    hipLaunchKernelGGL(k_st_pack_lower, dim3((unsigned)(nwg * 4), (unsigned)((ps.max_chunks + 7) / 8)), dim3(512), 0, st, L->ptr, L->idx, L->val,
+                       ps.ltab, ps.wtab, reinterpret_cast<v2d *>(ps.pk), ps.flags);
+    ps.xch_len = (int64_t)xtot[0] + xtot[1] + 64;
+    ILUPP_HIP(pool_malloc(&ps.xch, sizeof(double) * (size_t)ps.xch_len));
+    fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
+    int32_t gl[4];
+    ILUPP_HIP(d2h_async(st, gl, ps.flags, sizeof(gl)));
+    ILUPP_HIP(stream_sync(st));
+    if (gl[0]) {
+        if (dbg) fprintf(stderr, "[ilupp] IChol0 static form: row flags %d\n", gl[0]);
+        ps.release();
+        return false;
+    }
+    ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
+    StFArgs a;
+    a.ltab = ps.ltab; a.wtab = ps.wtab;
+    a.pkA = reinterpret_cast<const v2d *>(ps.pk);
+    a.pkL = reinterpret_cast<v2d *>(ps.pk); a.pkU = nullptr;
+    a.nchL = (int32_t)ps.nchunks;
+    a.xe = ps.xe; a.xw = ps.xw; a.xch = ps.xch; a.ctrl = d_ctrl;
+    hipEvent_t e0, e1;
+    ILUPP_HIP(hipEventCreate(&e0));
+    ILUPP_HIP(hipEventCreate(&e1));
+    ILUPP_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_ichol0_st, dim3((unsigned)nwg), dim3(kStWgThreads), 0, st, a);
+    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipGetLastError());
+    ps.valid = true; ps.stat = true;
+    st_unpack(st, *L, fwd, ps);
+    int32_t ctrl[4] = {0, 0, 0, 0};
+    ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, 16));
+    ILUPP_HIP(stream_sync(st));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    ILUPP_HIP(hipEventDestroy(e0));
+    ILUPP_HIP(hipEventDestroy(e1));
+    if (dbg) fprintf(stderr, "[ilupp] IChol0 static form: %d chunks, kernel %.3f ms, status %d\n", hl[1], kernel_ms ? *kernel_ms : 0.f, ctrl[1]);
+    ps.release();
+    if (ctrl[1] != 0) *rc_out = ILUPP_ERR_TIMEOUT;
     return true;
 }
 
