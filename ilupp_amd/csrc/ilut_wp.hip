@@ -35,8 +35,13 @@
 
 namespace ilupp {
 
-static constexpr int kWpCapU = 1536, kWpCapL = 1536, kWpSel = 256;      // (the KEPT list is append-only until the end: it lives in global memory)
-static constexpr int kWpHashLds = 4096;                       // cells of the U-slot hash table in LDS (2 bytes each)
+// LDS pieces of a wave (pool, U slots, hash cells) in two sizes.  What decides the kernel's time is how many waves a CU holds: it is
+// bound by the chains of dependent memory operations of each row, and the time goes like 1 / waves up to about 20 waves per CU.
+// With pieces of 1 536 entries (49 KB, 3 waves per CU) C3 took 1.12 s and 1 % of its rows started over in global memory; with 128
+// entries (6 KB, 20 waves per CU) 74 % of the rows start over (early: the pieces fill within the first eliminations) and it takes
+// 0.63 s.  Rows of a factorisation with a large fill budget (p > 32; 48^3 mesh, ILUT(100, 1e-3): ~110 entries per row) get
+// 256 entries and 14 waves per CU (65 ms against 230 ms with 128 and 155 ms with 1 536).
+static constexpr int kWpSel = 256;      // (the KEPT list is append-only until the end: it lives in global memory)
 static constexpr int kWpGCapU = 65534, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;      // (U slot ids + 1 fit the table's 16-bit cells)
 static constexpr int kWpHashG = 1 << 17;
 #ifndef ILUT_SPIN
@@ -434,12 +439,14 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
 }
 
 // ctrl: [0] next row, [1] error (1 timeout, 3 capacity -> the host runs k_ilut_rows instead), [2] smallest row with a zero pivot
+template <int kWpCapU, int kWpHashLds>
 __global__ void __launch_bounds__(64)
 k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                int32_t p, double tau, WpArrays gw, int *gscratch_all,
                int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
                int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl)
 {
+    constexpr int kWpCapL = kWpCapU;
     __shared__ int s_ucol[kWpCapU], s_lcol[kWpCapL], s_selq[kWpSel];
     __shared__ unsigned short s_lseq[kWpCapL];
     __shared__ double s_uval[kWpCapU], s_lval[kWpCapL];
@@ -489,7 +496,8 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     const int32_t n = A.n;
     if (p - 1 >= kWpSel) return 1;
     const size_t slab = (size_t)n * p;
-    int workers = device_cu_count() * 3;
+    const bool small_pieces = p <= 32;
+    int workers = device_cu_count() * (small_pieces ? 20 : 14);
     if (workers > n) workers = n;
     WpArrays g = {nullptr, kWpHashG - 1, nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
     ILUPP_HIP(pool_malloc(&g.uh, sizeof(unsigned short) * (size_t)workers * kWpHashG));
@@ -512,8 +520,12 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
     ILUPP_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(k_ilut_rows_wp, dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                       Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+    if (small_pieces)
+        hipLaunchKernelGGL((k_ilut_rows_wp<128, 512>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
+                           Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+    else
+        hipLaunchKernelGGL((k_ilut_rows_wp<256, 1024>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
+                           Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t h[8];
