@@ -39,6 +39,13 @@
 #include "common.h"
 #include "stdsort.h"
 
+#ifndef ILUC_W4
+#define ILUC_W4 4
+#endif
+#ifndef ILUC_WSGB
+#define ILUC_WSGB 16
+#endif
+
 namespace ilupp {
 
 static constexpr int kCuQ = 64;           // ready queues (step i goes to queue i % nq)
@@ -643,14 +650,14 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     }
     hipLaunchKernelGGL(k_iluc_colfill, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, colptr, fillc, colpos);
     hipLaunchKernelGGL(k_iluc_colorder, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, rowof, colptr, colpos, colord);
-    int waves = device_cu_count() * (cls == 0 ? 16 : (cls == 1 ? 8 : (cls == 2 ? 2 : (cls == 3 ? 2 : 4))));
+    int waves = device_cu_count() * (cls == 0 ? 16 : (cls == 1 ? 8 : (cls == 2 ? 2 : (cls == 3 ? 2 : ILUC_W4))));
     if (waves > m) waves = m;
     unsigned char *gws = nullptr;
     int gNE = 0, gNS = 0, gTM = 0;
     if (cls == 4) {
         gTM = T; gNS = 1024; while (gNS < m + 1 && gNS < 16384) gNS *= 2;       // (a power of two: the slot hash masks with 4 gNS - 1)
         gNE = 1 << 19;
-        while (gNE > 4096 && (size_t)waves * iluc_ws_bytes(gNE, gNS, gTM) > ((size_t)16 << 30)) gNE /= 2;
+        while (gNE > 4096 && (size_t)waves * iluc_ws_bytes(gNE, gNS, gTM) > ((size_t)ILUC_WSGB << 30)) gNE /= 2;
         ILUPP_HIP(pool_malloc(&gws, (size_t)waves * iluc_ws_bytes(gNE, gNS, gTM)));
     }
     const int nq = waves < kCuQ ? waves : kCuQ;
@@ -728,7 +735,11 @@ int iluc_factor(hipStream_t st, const DevMat &Av, int32_t max_fill_in, double th
     // that turns out too small costs the time until the first step that does not fit
     const long fill = max_fill_in < 1 ? 1 : max_fill_in;
     const long est = (Av.nnz / (Av.n > 0 ? Av.n : 1) / 2 + 1 + fill) * fill;
+#ifdef ILUC_FIRST
+    const int first = ILUC_FIRST;
+#else
     const int first = est <= 192 ? 0 : (est <= 640 ? 1 : 2);
+#endif
     for (int cls = first; cls < 5 && rc == 1; ++cls) {
         int which = 0;
         rc = iluc_attempt(st, Av, max_fill_in, threshold, L, U, err_row, kernel_ms, cls, &which);
