@@ -77,6 +77,7 @@ def lib():
     L.ilupp_hip_apply_trans.argtypes = [_VP, _VP, ctypes.c_int64]
     L.ilupp_hip_apply_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     L.ilupp_hip_sync.argtypes = [_VP]
+    L.ilupp_hip_release_cached_memory.argtypes = []
     L.ilupp_hip_total_nnz.argtypes = [_VP]
     L.ilupp_hip_total_nnz.restype = ctypes.c_int64
     for name in ("memory_used_calculations", "memory_allocated_calculations", "memory"):
@@ -111,7 +112,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_exists", "ilupp_hip_special_info", "ilupp_hip_print_info", "ilupp_hip_dimension",
     "ilupp_hip_num_factors", "ilupp_hip_factor_info", "ilupp_hip_factor_copy",
     "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
-    "ilupp_hip_sync", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
+    "ilupp_hip_sync", "ilupp_hip_release_cached_memory", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
     "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_spmv_device",
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
 ]
@@ -330,6 +331,13 @@ def IChol0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr):
 def ICholTPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, add_fill_in, threshold):
     return _create_device(lib().ilupp_hip_icholt_create_device, d_data, d_indices, d_indptr, n, is_csr,
                           ctypes.c_int32(int(add_fill_in)), ctypes.c_double(float(threshold)))
+
+
+def release_cached_memory():
+    """hand the device buffers the library keeps for the next construction back to the driver"""
+    rc = lib().ilupp_hip_release_cached_memory()
+    if rc:
+        _raise(rc)
 
 
 def set_caller_stream(stream_handle, enable=True):

@@ -1233,6 +1233,14 @@ int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t)
 }
 
 
+int ilupp_hip_release_cached_memory(void)
+{
+    API_TRY
+    pool_trim();
+    return ILUPP_OK;
+    API_CATCH
+}
+
 int ilupp_hip_sync(ilupp_precond *p)
 {
     API_TRY

@@ -168,6 +168,10 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
                                    const int32_t *d_indptr);
 /* wait for asynchronous applies (ilupp_hip_apply_device with sync=0) and report their status */
 int ilupp_hip_sync(ilupp_precond *p);
+/* The library keeps freed device buffers (up to 96 GB per process) for the next construction: a factorisation that is repeated asks
+ * for the same sizes again and hipMalloc / hipFree of multi-GB buffers cost more than the kernels.  This hands them back to the
+ * driver (no counterpart in binding.cpp: the reference's buffers are host memory). */
+int ilupp_hip_release_cached_memory(void);
 
 #ifdef __cplusplus
 }
