@@ -81,18 +81,23 @@ k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restri
         j0 = lo_; j1 = lo_;                                                                                        \
         if (hi_ > lo_) { j0 = MODE == 1 ? lo_ + 1 : lo_; j1 = MODE == 0 ? hi_ - 1 : hi_; }                         \
     } while (0)
-    // lane of this workgroup that walks row c, or -1
-#define LV_OWNER(c, out)                                                                                           \
+    // lane of this workgroup that walks row c (or -1), and the rows [rlo, rhi) of that lane's block.  Looked up when a row becomes the
+    // current one (its columns were fetched a row earlier), and only when the column has left the block its window position pointed
+    // into for the previous row: on a mesh that is once per line, not a division and two dependent loads per entry and row.
+#define LV_OWNER(c, out, rlo, rhi)                                                                                 \
     do {                                                                                                           \
-        const int bb_ = block_of((c), B, nb, start);                                                                \
-        const int64_t ql_ = (FWD ? (int64_t)bb_ : (int64_t)(nb - 1 - bb_)) - tb;                                   \
-        out = (ql_ >= 0 && ql_ < kLvBlock) ? (int)ql_ : -1;                                                        \
+        if (!((c) >= (rlo) && (c) < (rhi))) {                                                                      \
+            const int bb_ = block_of((c), B, nb, start);                                                            \
+            rlo = start[bb_]; rhi = start[bb_ + 1];                                                                \
+            const int64_t ql_ = (FWD ? (int64_t)bb_ : (int64_t)(nb - 1 - bb_)) - tb;                               \
+            out = (ql_ >= 0 && ql_ < kLvBlock) ? (int)ql_ : -1;                                                    \
+        }                                                                                                          \
     } while (0)
     int e0 = 0, e1 = 0, e2 = 0, e3 = 0, k = 0;
     int j = 0, jend = 0, mx = 0, rprev = -1, mprev = 0;
-    int wc[W], nw[W], wo[W], no[W];
+    int wc[W], nw[W], wo[W], clo[W], chi[W];
 #pragma unroll
-    for (int u = 0; u < W; ++u) { wc[u] = 0; nw[u] = 0; wo[u] = -1; no[u] = -1; }
+    for (int u = 0; u < W; ++u) { wc[u] = 0; nw[u] = 0; wo[u] = -1; clo[u] = 0; chi[u] = 0; }
     if (active) {
         e0 = LV_BOUND(0); e1 = LV_BOUND(1); e2 = LV_BOUND(2); e3 = LV_BOUND(3);
         LV_RANGE(e0, e1, j, jend);
@@ -101,11 +106,8 @@ k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restri
 #pragma unroll
         for (int u = 0; u < W; ++u) { wc[u] = j + u < jend ? idx[j + u] : 0; nw[u] = n0 + u < n1 ? idx[n0 + u] : 0; }
 #pragma unroll
-        for (int u = 0; u < W; ++u) {
-            wo[u] = -1; no[u] = -1;
-            if (j + u < jend) LV_OWNER(wc[u], wo[u]);
-            if (n0 + u < n1) LV_OWNER(nw[u], no[u]);
-        }
+        for (int u = 0; u < W; ++u)
+            if (j + u < jend && !(MODE == 2 && wc[u] >= r)) LV_OWNER(wc[u], wo[u], clo[u], chi[u]);
     }
     int wbase = j;                                  // entry the window starts at
     unsigned spins = 0;
@@ -118,7 +120,8 @@ k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restri
 #pragma unroll
                 for (int u = 0; u < W; ++u) wc[u] = j + u < jend ? idx[j + u] : 0;
 #pragma unroll
-                for (int u = 0; u < W; ++u) { wo[u] = -1; if (j + u < jend) LV_OWNER(wc[u], wo[u]); }
+                for (int u = 0; u < W; ++u)
+                    if (j + u < jend && !(MODE == 2 && wc[u] >= r)) LV_OWNER(wc[u], wo[u], clo[u], chi[u]);
                 progressed = true;
             }
             const int off = j - wbase;
@@ -165,9 +168,12 @@ k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restri
                 int n0, n1;
                 LV_RANGE(e1, e2, n0, n1);
 #pragma unroll
-                for (int u = 0; u < W; ++u) { wc[u] = nw[u]; wo[u] = no[u]; nw[u] = (active && n0 + u < n1) ? idx[n0 + u] : 0; }
+                for (int u = 0; u < W; ++u) wc[u] = nw[u];
 #pragma unroll
-                for (int u = 0; u < W; ++u) { no[u] = -1; if (active && n0 + u < n1) LV_OWNER(nw[u], no[u]); }
+                for (int u = 0; u < W; ++u)
+                    if (active && j + u < jend && !(MODE == 2 && wc[u] >= r)) LV_OWNER(wc[u], wo[u], clo[u], chi[u]);
+#pragma unroll
+                for (int u = 0; u < W; ++u) nw[u] = (active && n0 + u < n1) ? idx[n0 + u] : 0;
                 if (active) e3 = LV_BOUND(k + 3);
                 progressed = true;
             }
