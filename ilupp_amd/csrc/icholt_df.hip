@@ -44,6 +44,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include <vector>
 #include "stdsort.h"
 
 namespace ilupp {
@@ -61,7 +62,7 @@ static constexpr int kCtQ = 64;     // at most; fewer when there are fewer waves
 static constexpr int kCtQBase = 64;   // ctrl word of queue 0's head; queue q: head at kCtQBase + 64 q, tail 32 words later
 static constexpr unsigned kCtSpinLimit = 1u << 22;
 
-// ctrl: [2] error (1 = capacity exceeded -> sequential fallback, 2 = timeout), [3] malformed column, then the queues' heads/tails
+// ctrl: [2] error (1 = capacity exceeded -> next class, 2 = timeout), [3] malformed column, [4] finished columns (progress), then the queues' heads/tails
 __global__ void k_ict_prep(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int32_t add,
                            int32_t *__restrict__ cap, int32_t *pending, int32_t *ctrl)
 {
@@ -157,12 +158,18 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         if (tkt >= qtotal) break;
         int j;
         unsigned spins = 0;
+        int last_done = -1;
         for (;;) {
             j = ld_agent_i32(&myrq[tkt]);
             if (j >= 0) break;
             if ((++spins & 63u) == 0) {
                 if (ld_agent_i32(&ctrl[2]) != 0) return;
-                if (spins > kCtSpinLimit) CT_FAIL(2);
+                // the limit is on the time WITHOUT PROGRESS anywhere (ctrl[4] counts finished columns): the last columns of a small
+                // dense-ish matrix with a large fill budget are reached by a thousand earlier ones each and form a chain -- a hundred
+                // of them took longer than a fixed limit on the wait (found by profiles/tools/fuzz_kernels.py, seed 1245)
+                const int done = ld_agent_i32(&ctrl[4]);
+                if (done != last_done) { last_done = done; spins = 0; }
+                else if (spins > kCtSpinLimit) CT_FAIL(2);
             }
             __builtin_amdgcn_s_sleep(4);
         }
@@ -368,7 +375,7 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         // ---- append  (sparse_implementation.h:3170-3186) ----
         for (int s = lane; s < ns; s += 64)
             if (srank[s] >= 0) { st_agent_i32(&Lidx[loff + srank[s]], srow[s]); st_agent_f64(&Lval[loff + srank[s]], sval[s]); }
-        if (lane == 0) Llen[j] = nk;
+        if (lane == 0) { Llen[j] = nk; atomicAdd(&ctrl[4], 1); }
 
         // ---- one touch record per sub-diagonal slot, in the record list of its row ----
         bool ovf = false;
@@ -529,6 +536,17 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     ILUPP_HIP(hipEventDestroy(e1));
     int rc = ILUPP_OK;
     if (gws) ILUPP_HIP(pool_free(gws));
+    if (h[2] == 2 && getenv("ILUPP_DEBUG")) {
+        std::vector<int32_t> hp(m), hl(m + 1), hc(m);
+        ILUPP_HIP(hipMemcpy(hp.data(), pending, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+        ILUPP_HIP(hipMemcpy(hl.data(), Llen, sizeof(int32_t) * (size_t)(m + 1), hipMemcpyDeviceToHost));
+        ILUPP_HIP(hipMemcpy(hc.data(), cnt, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+        int unfinished = 0, firstu = -1, negp = 0;
+        for (int j = 0; j < m; ++j) { if (hl[j] == 0) { ++unfinished; if (firstu < 0) firstu = j; } if (hp[j] < 0) ++negp; }
+        fprintf(stderr, "[ilupp] icholt timeout: class %d, T %d, waves %d, nq %d: %d of %d columns unfinished, first %d (pending %d, touch records %d), %d negative counters\n",
+                cls, T, waves, nq, unfinished, m, firstu, firstu >= 0 ? hp[firstu] : 0, firstu >= 0 ? hc[firstu] : 0, negp);
+        for (int j = firstu; j >= 0 && j < m && j < firstu + 6; ++j) fprintf(stderr, "   col %d: len %d pending %d cnt %d\n", j, hl[j], hp[j], hc[j]);
+    }
     if (h[3] != big) rc = ILUPP_ERR_NOT_TRIANGULAR;
     else if (h[2] == 3) rc = ILUPP_ERR_NOT_SPD;          // a column lost its diagonal: not positive definite (or a budget below 1)
     else if (h[2] == 2) rc = ILUPP_ERR_TIMEOUT;
