@@ -375,7 +375,10 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         // ---- append  (sparse_implementation.h:3170-3186) ----
         for (int s = lane; s < ns; s += 64)
             if (srank[s] >= 0) { st_agent_i32(&Lidx[loff + srank[s]], srow[s]); st_agent_f64(&Lval[loff + srank[s]], sval[s]); }
-        if (lane == 0) { Llen[j] = nk; atomicAdd(&ctrl[4], 1); }
+        if (lane == 0) {
+            Llen[j] = nk;
+            if (nt > 64 || (j & 255) == 0) atomicAdd(&ctrl[4], 1);    // progress mark (not from every column: one address; the slow columns are those with many records)
+        }
 
         // ---- one touch record per sub-diagonal slot, in the record list of its row ----
         bool ovf = false;

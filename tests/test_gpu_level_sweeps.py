@@ -145,3 +145,9 @@ def test_ilu0_27_point_96_cubed():
             torch.cuda.synchronize()
             P.apply_device(x.data_ptr(), n, transpose=(use == O.TRANSPOSE), sync=True)
             assert np.array_equal(x.cpu().numpy(), want), (use, rep)
+
+
+def test_fuzz_level_order():
+    """random matrices (5 to 40 entries per row, some with a band: chains) through ILU(0), IChol0 and ILUC and their applies"""
+    import fuzz_lvl
+    assert fuzz_lvl.run(6, first_seed=0, verbose=False) == 0
