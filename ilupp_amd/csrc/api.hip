@@ -51,9 +51,7 @@ struct Pool {
     std::multimap<std::pair<int, size_t>, std::pair<void *, size_t>> free_blocks;     // (device, size) -> (block, age stamp)
     std::unordered_map<void *, std::pair<int, size_t>> live;       // block -> (device, size)
     size_t cached = 0;
-    size_t gen = 0;                                                 // counts created objects: a cached block that was not asked for again
-                                                                    // while the next kKeepGens objects were built goes back to the driver
-    static constexpr size_t kKeepGens = 2;
+    size_t gen = 0;
     static constexpr size_t kMaxCached = 96ull << 30;   // of 288 GB HBM (ILUC on a 256^3 mesh holds 2 x 17 GB of touch records per attempt: with 24 GB they went back to the driver every time, 0.96 s of its 1.25 s)
 } g_pool;
 }  // namespace
@@ -112,24 +110,6 @@ void pool_trim()
     for (auto &kv : g_pool.free_blocks) (void)::hipFree(kv.second.first);
     g_pool.free_blocks.clear();
     g_pool.cached = 0;
-}
-
-// called when an object is created (never during process teardown): blocks nobody has asked for since kKeepGens objects ago are given back (a loop that
-// builds the same kind of object again and again keeps its blocks; the 11 GB of ILUT work arrays do not outlive the ILUT objects by much)
-static void pool_age()
-{
-    std::lock_guard<std::mutex> lk(g_pool.mu);
-    ++g_pool.gen;
-    if ((g_pool.gen & 3) != 0) return;                 // (a look at the list every fourth object is often enough)
-    for (auto it = g_pool.free_blocks.begin(); it != g_pool.free_blocks.end();) {
-        if (it->second.second + Pool::kKeepGens < g_pool.gen) {
-            (void)::hipFree(it->second.first);
-            g_pool.cached -= it->first.second;
-            it = g_pool.free_blocks.erase(it);
-        } else {
-            ++it;
-        }
-    }
 }
 
 // Ordering against the caller's own HIP stream (device-pointer entry points): when set for this thread, every *_device
@@ -244,7 +224,6 @@ void destroy_obj(ilupp_precond *p)
 
 ilupp_precond *new_obj(int32_t n)
 {
-    pool_age();
     ilupp_precond *p = new ilupp_precond();
     p->n = n;
     ILUPP_HIP(hipGetDevice(&p->device));
