@@ -92,7 +92,15 @@ hipError_t pool_free(void *p)
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
         auto it = g_pool.live.find(p);
-        if (it == g_pool.live.end()) return ::hipFree(p);
+        if (it == g_pool.live.end()) {
+            // not a block the pool has handed out.  One that already sits in the kept list (freed twice) must not go back to the driver
+            for (auto &kv : g_pool.free_blocks)
+                if (kv.second.first == p) {
+                    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] pool: block of %zu bytes freed twice\n", kv.first.second);
+                    return hipSuccess;
+                }
+            return ::hipFree(p);
+        }
         const std::pair<int, size_t> key = it->second;
         g_pool.live.erase(it);
         if (g_pool.cached + key.second <= Pool::kMaxCached) {
