@@ -1125,7 +1125,7 @@ const char *ilupp_hip_path(const ilupp_precond *p)
 {
     if (!p) return "";
     if (p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU) {
-        if (p->flm.built) return p->flm.stat ? "ilu0:static-level-major" : "ilu0:level-major";
+        if (p->flm.built) return p->flm.stat ? (p->flm.direct ? "ilu0:static-direct" : "ilu0:static-level-major") : "ilu0:level-major";
         if (p->fperm) return "ilu0:level-order";
         return p->prog_f3 ? "ilu0:csr-program" : "ilu0:csr";
     }

@@ -138,6 +138,7 @@ struct FactorLM {
     double *xch = nullptr;          // exchange rows x 4 doubles (write-through, sentinel = not yet)
     long long *xcount = nullptr;    // device: doubles of xch in use
     bool stat = false;              // static form (st.hip): pkA holds 4 KB chunks {a0..a6, mask}
+    bool direct = false;            // static form fed from A's CSR values (st_direct.hip): no pkA at all
     void release();
 };
 

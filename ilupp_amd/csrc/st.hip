@@ -36,33 +36,12 @@
 
 #include <hipcub/hipcub.hpp>
 
-#include "common.h"
+#include "st_common.h"
 
 namespace ilupp {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-#define ST_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
-static constexpr int kStH = 8;                 // steps of hand-off history kept in LDS = steps the streams are read ahead
-static constexpr int kStPF = 8, kStPS = 2;   // steps ahead the courier polls the values of earlier workgroups: factor kernel, sweeps (measured: +-4 %)
-static constexpr int kStMaxSkew = 30000;
-static constexpr unsigned kStSpinLimit = 1u << 21;
-static constexpr int64_t kStMaxChunks = 1 << 21;      // record offsets are 32-bit byte offsets
-
-struct __attribute__((aligned(8))) D2s { double v[2]; };
-
 __global__ void k_lm_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, const int32_t *__restrict__ scount,
                           const int32_t *__restrict__ wtabL, const int32_t *__restrict__ skewL, int32_t *__restrict__ ysrc);   // sptrsv_lm.hip
-
-__device__ __forceinline__ unsigned long long st_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
-__device__ __forceinline__ double st_dbl(unsigned long long b) { return __longlong_as_double((long long)b); }
-// a value that enters the records must not look like one of the two markers
-__device__ __forceinline__ double st_clean(double x)
-{
-    const unsigned long long b = st_bits(x);
-    return (b == kSentinel || b == kAbsent) ? st_dbl(kCanonNaN) : x;
-}
 
 // ---------------------------------------------------------------------------------------------
 // analysis 1: lane templates.  TRI = +1: the entries left of the diagonal (forward schedule), -1: right (backward)
@@ -544,15 +523,6 @@ k_st_rows(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, co
     }
     if (bad) atomicOr(&flags[0], 8);
 }
-
-// ---------------------------------------------------------------------------------------------
-// the barrier of a step: this wave's LDS writes of the previous step have landed, then everybody's have
-// (NOT __syncthreads(): that would also drain the global loads in flight, i.e. the read-ahead)
-// ---------------------------------------------------------------------------------------------
-#define ST_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-__device__ __forceinline__ double st_lds(const unsigned char *base, unsigned off) { return *reinterpret_cast<const double *>(base + off); }
-__device__ __forceinline__ int st_med3(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 #ifndef ST_STAMP_WG
 #define ST_STAMP_WG -1
@@ -1528,9 +1498,14 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     // one spare chunk per wave each: where waves / lanes without a row at a step store
     ILUPP_HIP(pool_malloc(&pl->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));
     ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));      // (the forward schedule's order: see k_sptrsv_st)
-    ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
     pl->built = true;
-    st_pack_values(st, A, pl, pu, f);
+    // the factor kernel that reads A's values where they lie (st_direct.hip) when the lanes are uniform enough (its checks run
+    // here, their verdict comes back with the last wait below), else factor records made by the rows pass
+    const bool try_direct = st_direct_prepare(st, A, fwd, pl, pu, pl->flags + 8);
+    if (!try_direct) {
+        ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
+        st_pack_values(st, A, pl, pu, f);
+    }
     // vectors travel level-major: the right-hand side and the intermediate vector in the L sweep's order (pl->ybuf, in place), the
     // result in the U sweep's (pu->xlm)
     ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
@@ -1543,10 +1518,19 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
     ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)nslots, st));
     hipLaunchKernelGGL(k_lm_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
-    int32_t gl[4];
+    int32_t gl[4], dfl = 0;
     ILUPP_HIP(d2h_async(st, gl, pl->flags, sizeof(gl)));
+    if (try_direct) ILUPP_HIP(d2h_async(st, &dfl, pl->flags + 8, sizeof(dfl)));
     ILUPP_HIP(stream_sync(st));
-    if (dbg) fprintf(stderr, "[ilupp] static analysis: row flags %d, %d+%d chunks\n", gl[0], hl[1], hu[1]);
+    if (try_direct && dfl != 0) {
+        if (dbg) fprintf(stderr, "[ilupp] static analysis: lanes not uniform (flags %d): factor records\n", dfl);
+        ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
+        st_pack_values(st, A, pl, pu, f);
+        ILUPP_HIP(d2h_async(st, gl, pl->flags, sizeof(gl)));
+        ILUPP_HIP(stream_sync(st));
+    }
+    f->direct = try_direct && dfl == 0;
+    if (dbg) fprintf(stderr, "[ilupp] static analysis: row flags %d, %d+%d chunks%s\n", gl[0], hl[1], hu[1], f->direct ? ", direct feed" : "");
     if (gl[0]) { pl->release(); pu->release(); f->release(); return false; }
     pl->valid = pu->valid = true;
     pl->stat = pu->stat = true;
@@ -1561,6 +1545,7 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
                     int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1)
 {
     (void)fwd;
+    if (f->direct) return ilu0_numeric_sd(st, A, pl, pu, d_ctrl, kernel_ms, e0, e1);
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
     fill_u64(st, reinterpret_cast<unsigned long long *>(pl->xch), pl->xch_len, kSentinel);
     const bool repack = !f->values_packed;

@@ -1,0 +1,567 @@
+// ilupp_amd/csrc/st_direct.hip -- ILU(0) on the static level-major form, fed from A's CSR values directly (gfx950).
+//
+// st.hip's factor kernel reads level-major factor records that a rows pass (k_st_rows) makes from A: A -> records -> kernel is
+// 5.75 GB of traffic for 3.21 GB of work, and the rows pass is the longest kernel of a construction.  Here the records are gone.
+// What makes that possible is a stronger statement about the lanes than st.hip's (proven row by row, pattern only: k_sd_proof):
+//
+//   a lane's rows (a chain of consecutive rows, CSR rows first .. first+cnt-1) ALL have exactly the lane's template entries --
+//   except that the own-chain entries are missing where the chain ends (column r-1 in the lane's first row, r+1 in its last).
+//
+// Then a lane's part of A's value array is ONE contiguous stream with a fixed pitch of m entries per row (one entry less in the
+// first row), nothing about a row has to be looked up, and the column indices are never read again:
+//
+//   * PRODUCER waves (3 per workgroup) copy, for every lane and every block of two steps, the 128 bytes of A.val that hold the
+//     lane's two rows -- 8 threads x 16 bytes per lane, aligned pieces, through a register file that holds the pieces of the next
+//     4 blocks (the read-ahead) -- verbatim into an LDS ring of two blocks;
+//   * the CONSUMER lanes (4 waves, one row per lane and step, as in st.hip) read their row from the ring at lane-constant
+//     addresses: entries left of the diagonal from the row's start, the diagonal and the entries right of it from the diagonal's
+//     place (the two rows at a chain's ends shift one of the two by one entry);
+//   * the transposed entry a(k,r) an elimination needs (ILU0.hpp:8-23 on such rows: u_rr -= (a_rk / u_kk) a_kr) is an entry RIGHT
+//     of the diagonal of the pivot row k, i.e. something the lane of row k has in its registers when it finishes u_kk: the hand-off
+//     array in LDS carries pairs {u_kk, a(k, k+o)} (one per entry right of the diagonal) instead of u_kk alone, and a dependency is
+//     ONE 16-byte LDS read.  For pivot rows of earlier workgroups the courier wave reads a(k,r) from A itself (it polls the pivot
+//     a few steps ahead anyway);
+//   * the kernel writes the complete records of both sweeps (l_rk and 1; A's entries right of the diagonal and u_rr).
+//
+// Per row: 56 B of A read, 64 B of records written -- the algorithmic traffic of SURVEY section 8(d) without the column indices.
+// Arithmetic, order of operations and the records' formats are st.hip's (bit-identical results; tests A/B the two).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "st_common.h"
+
+namespace ilupp {
+
+static constexpr int kSdH = 4;                                     // hand-off slots: an in-workgroup dependency lies at most kSdH-1 steps back
+static constexpr int kSdHoLane = 48;                               // bytes per lane and slot: three pairs {pivot, entry right of the diagonal}
+static constexpr int kSdHoRow = kThreads * kSdHoLane + 64 * 16;    // a slot: the lanes' pairs, then the courier's
+static constexpr int kSdPitch = 136;                               // bytes of a lane's piece of a block (128 loaded; 17 x 8: conflict-free 8-byte reads)
+static constexpr int kSdRing = kThreads * kSdPitch;                // a block of two steps
+static constexpr int kSdProd = 3;                                  // producer waves
+static constexpr int kSdPer = 11;                                  // groups of 8 lanes per producer wave (3 x 11 x 8 >= 256)
+static constexpr int kSdRA = 4;                                    // blocks the producers read ahead
+static constexpr int kSdThreads = kThreads + 64 + 64 * kSdProd;
+static constexpr int kSdLds = 2 * kSdRing + kSdH * kSdHoRow;
+static constexpr unsigned kSdOob = 0xfffffff0u;                    // a buffer offset beyond any array: the load returns zeros and touches nothing
+static_assert(kSdProd * kSdPer * 8 >= kThreads, "every lane needs a producer");
+static_assert(kSdHoRow % 16 == 0 && kSdRing % 8 == 0, "alignment of the LDS regions");
+
+struct SdArgs {
+    const int32_t *ltab, *wtab;               // forward schedule
+    const double *val;                        // A's values, the pointer rounded down to 16 bytes
+    uint32_t val_bytes;                       // bytes readable from there
+    int32_t val_shift;                        // what the rounding took off (0 or 8)
+    v2d *pkL, *pkU;                           // 2 x 64 x 16 B per chunk: {l0,l1}{l2,1} / {u1,u2}{u3,u0}, both in the forward schedule's order
+    const int32_t *xe, *xw;                   // the forward schedule's exchange between workgroups: pivots of exported lanes
+    double *xch;
+    int32_t *ctrl;                            // [0] ticket, [1] error
+};
+
+// a (lane, dependency) pair whose pivot row belongs to an earlier workgroup: the pivot of the consumer's row k is element
+// idx0 + (k + sk) * stride of the exchange; the transposed entry is 8 bytes at at0 + k * atm (- sh in the producer's last row)
+struct SdPair { int idx0, stride, sk, cnt; unsigned at0; int atm, klast, sh, hasT; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sd_rsrc(const SdArgs &A)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.val), 0, (int)A.val_bytes, 0x00020000);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the 256 lanes of the schedule
+// ---------------------------------------------------------------------------------------------
+template <bool EX>
+__device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds, const int wg, const unsigned (&R)[3][kSdH], const bool (&hasT)[3],
+                                            const int tlo, const int thi)
+{
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    const int slot = wg * kThreads + t;
+    const int32_t *T = A.ltab + (size_t)slot * kStTab;
+    const int cnt = T[ST_CNT], sk = T[ST_SKEW], nd = T[ST_ND], fl = T[ST_DFL], p0 = T[ST_P0];
+    const int ndU = fl & 3, ownL = (fl >> 2) & 1, ownU = (fl >> 3) & 1, m = fl >> 4;
+    const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
+    const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
+              nchw = __builtin_amdgcn_readfirstlane(wt[2]);
+    const int xe = A.xe[slot];
+    const bool exports = cnt > 0 && xe >= 0;
+    const int xE = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
+    const int xoff = A.xw[wg * 4 + 3] - A.xw[wg * 4 + 1] * xE + xe;          // + step * xE: where this lane's pivot of a step goes
+    unsigned char *pl = reinterpret_cast<unsigned char *>(A.pkL);
+    unsigned char *pu = reinterpret_cast<unsigned char *>(A.pkU);
+    const unsigned lo16 = (unsigned)ln * 16u;
+    // where the lane's rows sit in its piece of a block: the piece starts at the 16-byte boundary at or below the (virtual) start
+    // of the block's first row; row start of the second row: 8 m further
+    const unsigned Cu = 8u * (unsigned)(p0 - ownL - sk * m) + (unsigned)A.val_shift;
+    const unsigned rowA = (unsigned)t * kSdPitch + (Cu & 15u);
+    const unsigned aL_[2] = {rowA, rowA + 8u * (unsigned)m};                             // entries left of the diagonal: + 8 j
+    const unsigned aD_[2] = {rowA + 8u * (unsigned)nd, rowA + 8u * (unsigned)(m + nd)};  // the diagonal; right of it: + 8 (1 + q)
+    const int k0L = ownL ? 0 : -1;                          // the row without its own-chain entry on the left / on the right
+    const int kEU = ownU ? cnt - 1 : -1;
+    const unsigned hoW = 2u * kSdRing + (unsigned)t * kSdHoLane;
+    const bool inL[3] = {0 < nd, 1 < nd, 2 < nd}, inU[3] = {0 < ndU, 1 < ndU, 2 < ndU};
+    const bool lastL[3] = {nd == 1, nd == 2, nd == 3};
+    const double absent = st_dbl(kAbsent);
+
+    for (int tb = tlo; tb < thi; tb += 8) {
+        const int kb = tb - sk;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = kb + u;
+            const bool valid = (unsigned)k < (unsigned)cnt;
+            const unsigned par = (unsigned)((u >> 1) & 1) * kSdRing;
+            const bool c0 = k == k0L, cE = k == kEU;
+            const unsigned aL = aL_[u & 1] + (c0 ? 8u : 0u);
+            const unsigned aU = aD_[u & 1] - (cE ? 8u : 0u);
+            ST_BARRIER();
+            double av[3], up[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) av[j] = st_lds(lds, aL + par + 8u * j);
+            double d = st_lds(lds, aD_[u & 1] + par);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) up[q] = st_lds(lds, aU + par + 8u + 8u * q);
+            v2d P[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) P[j] = *reinterpret_cast<const v2d *>(lds + R[j][u % kSdH]);
+            bool pj[3], pq[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pj[j] = valid && inL[j] && !(lastL[j] && c0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pq[q] = valid && inU[q] && !(q == 0 && cE);
+            // values that look like one of the two markers (NaNs with a payload no arithmetic makes) are canonicalised, as the
+            // rows pass of st.hip does
+            {
+                bool nan = d != d;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) nan = nan || av[j] != av[j] || up[j] != up[j];
+                if (__any(nan)) {
+                    d = st_clean(d);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { av[j] = st_clean(av[j]); up[j] = st_clean(up[j]); }
+                }
+            }
+            // u_ii = a_ii - sum (a_ik / u_kk) a_ki, eliminations in ascending k (ILU0.hpp:47-62 for rows whose eliminations
+            // meet them on the diagonal only)
+            double w3 = d;
+            double l[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                l[j] = av[j] / P[j].x;
+                const double pr = l[j] * P[j].y;
+                const double nw = w3 - pr;
+                w3 = (pj[j] && hasT[j]) ? nw : w3;
+            }
+            {
+                const unsigned long long wb = st_bits(w3);
+                if (wb == kSentinel || wb == kAbsent) w3 = st_dbl(kCanonNaN);
+            }
+            // hand-off: the pivot with each entry right of the diagonal
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                v2d h; h.x = w3; h.y = up[q];
+                *reinterpret_cast<v2d *>(lds + hoW + (unsigned)(u % kSdH) * kSdHoRow + 16u * q) = h;
+            }
+            // pivots that other workgroups read: write-through, to the exchange
+            if (EX) { if (exports && valid) st_agent_f64(A.xch + (xoff + (tb + u) * xE), w3); }
+            const int cw = tb + u - tminw;
+            if (valid && (unsigned)cw < (unsigned)nchw) {
+                unsigned char *o = pl + (size_t)(base + cw) * 2048;
+                v2d la, lb;
+                la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
+                lb.x = pj[2] ? l[2] : absent; lb.y = 1.0;
+                ST_STREAM_STORE(la, reinterpret_cast<v2d *>(o + lo16));
+                ST_STREAM_STORE(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
+                unsigned char *ou = pu + (size_t)(base + cw) * 2048;
+                v2d ua, ub;
+                ua.x = pq[0] ? up[0] : absent; ua.y = pq[1] ? up[1] : absent;
+                ub.x = pq[2] ? up[2] : absent; ub.y = w3;
+                ST_STREAM_STORE(ua, reinterpret_cast<v2d *>(ou + lo16));
+                ST_STREAM_STORE(ub, reinterpret_cast<v2d *>(ou + lo16 + 1024));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the courier: lane p brings pair p -- the pivot from the exchange (polled kStPF steps ahead; all-sentinel before the kernel), the
+// transposed entry from A -- into the hand-off slot of the step that needs it
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sd_courier(const SdArgs &A, const unsigned long long *idle, unsigned char *lds, const SdPair P,
+                                           const int tlo, const int thi)
+{
+    constexpr int NP = kStPF;
+    const int ln = threadIdx.x & 63;
+    const __amdgpu_buffer_rsrc_t rs = sd_rsrc(A);
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.xch);
+    const unsigned span = (unsigned)P.cnt;
+    unsigned long long gq[NP];
+    double ga[NP];
+#define SDC_ADDR(k_) ((unsigned)(k_) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
+#define SDC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : kSdOob)
+#define SDC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, SDC_AT(k_), 0, 0))
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        gq[g] = ld_agent_u64(SDC_ADDR(tlo + g - P.sk));
+        ga[g] = SDC_LDAT(tlo + g - P.sk);
+        asm volatile("" ::: "memory");
+    }
+    bool dead = false;
+    for (int tb = tlo; tb < thi; tb += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = tb + u - P.sk;
+            const bool need = (unsigned)k < span;
+            unsigned long long v = gq[u % NP];
+            if (!dead) {
+                unsigned spins = 0;
+                while (__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0) {
+                    if (need && v == kSentinel) v = ld_agent_u64(SDC_ADDR(k));
+                    __builtin_amdgcn_s_waitcnt(0x0F70);          // retired here, not at the join after the loop
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0) {
+                        if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);
+                        const int e = ld_agent_i32(&A.ctrl[1]);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (spins > kStSpinLimit || e != 0) { dead = true; break; }
+                    }
+                }
+            }
+            v2d h; h.x = st_dbl(v); h.y = st_clean(ga[u % NP]);
+            *reinterpret_cast<v2d *>(lds + 2u * kSdRing + (unsigned)(u % kSdH) * kSdHoRow + (unsigned)kThreads * kSdHoLane + (unsigned)ln * 16u) = h;
+            gq[u % NP] = ld_agent_u64(SDC_ADDR(k + NP));
+            ga[u % NP] = SDC_LDAT(k + NP);
+            ST_BARRIER();
+        }
+    }
+#undef SDC_ADDR
+#undef SDC_AT
+#undef SDC_LDAT
+    if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a producer wave: 8 threads per lane, 16 bytes each; kSdPer groups of 8 lanes per wave
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sd_producer(const SdArgs &A, unsigned char *lds, const int wg, const int pw, const int tlo, const int thi)
+{
+    const int ln = threadIdx.x & 63, sub = ln & 7, lg = ln >> 3;
+    const __amdgpu_buffer_rsrc_t rs = sd_rsrc(A);
+    unsigned g[kSdPer], S[kSdPer];
+    const int b0 = tlo >> 1;
+#pragma unroll
+    for (int i = 0; i < kSdPer; ++i) {
+        const int l = (pw * kSdPer + i) * 8 + lg;
+        const bool live = l < kThreads;
+        const int32_t *T = A.ltab + (size_t)(wg * kThreads + (live ? l : 0)) * kStTab;
+        const int cnt = T[ST_CNT], sk = T[ST_SKEW], fl = T[ST_DFL], p0 = T[ST_P0];
+        const int ownL = (fl >> 2) & 1, m = fl >> 4;
+        const unsigned Cu = 8u * (unsigned)(p0 - ownL - sk * m) + (unsigned)A.val_shift;
+        const bool on = live && cnt > 0;
+        S[i] = on ? 16u * (unsigned)m : 0u;
+        g[i] = on ? (Cu & ~15u) + (unsigned)b0 * S[i] + 16u * (unsigned)sub : kSdOob;
+    }
+    const unsigned dst = (unsigned)(pw * kSdPer * 8 + lg) * kSdPitch + 16u * (unsigned)sub;      // group i: + i * 8 * kSdPitch
+    v4u ra[kSdRA][kSdPer];
+#define SDP_LOAD(rb)                                                                       \
+    do {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < kSdPer; ++i) {                               \
+            ra[rb][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, g[i], 0, 0);             \
+            g[i] += S[i];                                                                  \
+        }                                                                                  \
+    } while (0)
+#define SDP_WRITE(rb, parity)                                                              \
+    do {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < kSdPer; ++i) {                               \
+            if ((pw * kSdPer + i) * 8 < kThreads) {                                        \
+                unsigned char *o_ = lds + dst + (unsigned)i * (8u * kSdPitch) + (unsigned)(parity) * kSdRing; \
+                typedef unsigned long long u64_;                                           \
+                const v4u x_ = ra[rb][i];                                                  \
+                reinterpret_cast<u64_ *>(o_)[0] = ((u64_)x_.y << 32) | x_.x;               \
+                reinterpret_cast<u64_ *>(o_)[1] = ((u64_)x_.w << 32) | x_.z;               \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
+    // the first kSdRA blocks; block b0 (b0 is a multiple of 4: the steps of a trip of the loops are 8) goes to the ring at once
+#pragma unroll
+    for (int rb = 0; rb < kSdRA; ++rb) { SDP_LOAD(rb); asm volatile("" ::: "memory"); }
+    SDP_WRITE(0, 0);
+    SDP_LOAD(0);
+    for (int tb = tlo; tb < thi; tb += 8) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            ST_BARRIER();                                       // the consumers read block tb/2 + bb now; the one before it is free
+            SDP_WRITE((bb + 1) & 3, (bb + 1) & 1);
+            SDP_LOAD((bb + 1) & 3);
+            ST_BARRIER();
+        }
+    }
+#undef SDP_LOAD
+#undef SDP_WRITE
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kSdThreads)
+k_ilu0_sd(SdArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ SdPair s_pairs[64];
+    __shared__ int s_cnt[4], s_total;
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
+    __syncthreads();
+    const int wg = (int)s_ticket;
+    const int t = threadIdx.x;
+    int tlo = 0x7fffffff, thi = -0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t *w4 = A.wtab + (size_t)(wg * 4 + q) * 4;
+        const int a = w4[1], b = w4[2];
+        if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
+    }
+    tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
+    if (thi <= tlo) return;
+    tlo &= ~7;                                                        // step % 8 = position in the unrolled loops
+    if (t < 64) { SdPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; s_pairs[t] = z; }
+    if (t < kThreads) {
+        const int slot = wg * kThreads + t;
+        const int32_t *T = A.ltab + (size_t)slot * kStTab;
+        const int nd = T[ST_ND], cnt = T[ST_CNT];
+        // where each dependency's pair {pivot, transposed entry} is read: the hand-off entry of the producer lane dt steps back
+        // (slot (step - dt) mod kSdH: one address per residue of the step), or the courier's entry of this step
+        unsigned R[3][kSdH];
+        bool hasT[3], isg[3];
+        SdPair gp[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int sw = T[ST_SRC + j];
+            const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
+            const int q = (ty != ST_NONE) ? T[ST_Q + j] : -1;
+            hasT[j] = q >= 0;
+            const int qq = q < 0 ? 0 : q;
+            const int os = sw >> 2;
+            const int lane = ty == ST_LOCAL ? (os & 255) : t;
+            const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;
+            isg[j] = ty == ST_GHOST;
+#pragma unroll
+            for (int i = 0; i < kSdH; ++i)
+                R[j][i] = 2u * kSdRing + (unsigned)((i - dt) & (kSdH - 1)) * kSdHoRow + (unsigned)lane * kSdHoLane + 16u * (unsigned)qq;
+            SdPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0;
+            if (isg[j]) {
+                const int pw = os >> 8;
+                const int32_t *TP = A.ltab + (size_t)os * kStTab;
+                const int E = A.xw[pw * 4];
+                const int kap = T[ST_KAP + j];
+                d.stride = E;
+                d.idx0 = A.xw[pw * 4 + 3] + (kap + TP[ST_SKEW] - T[ST_SKEW] - A.xw[pw * 4 + 1]) * E + A.xe[os];
+                const int flp = TP[ST_DFL];
+                const int mp = flp >> 4;
+                d.hasT = hasT[j] ? 1 : 0;
+                d.atm = 8 * mp;
+                d.at0 = (unsigned)A.val_shift + 8u * (unsigned)(TP[ST_P0] - ((flp >> 2) & 1) + TP[ST_ND] + 1 + qq + kap * mp);
+                d.klast = TP[ST_CNT] - 1 - kap;
+                d.sh = 8 * ((flp >> 3) & 1);
+            }
+            gp[j] = d;
+        }
+        __syncthreads();                                              // (s_pairs zeroed)
+        // the pairs of the workgroup, numbered
+        {
+            const int wv = t >> 6;
+            unsigned long long bal[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bal[j] = __builtin_amdgcn_ballot_w64(isg[j]);
+            const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]);
+            if ((t & 63) == 0) s_cnt[wv] = mine;
+            __syncthreads();
+            int before = 0;
+            for (int q = 0; q < wv; ++q) before += s_cnt[q];
+            if (t == 0) s_total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (isg[j]) {
+                    const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
+                    if (p < 64) s_pairs[p] = gp[j];
+#pragma unroll
+                    for (int i = 0; i < kSdH; ++i)
+                        R[j][i] = 2u * kSdRing + (unsigned)i * kSdHoRow + (unsigned)kThreads * kSdHoLane + (unsigned)min(p, 63) * 16u;
+                }
+                before += __popcll(bal[j]);
+            }
+        }
+        __syncthreads();
+        if (t == 0 && s_total > 64) atomicExch(&A.ctrl[1], 1);        // (the analysis does not let such a schedule through)
+        const bool wave_exports = __any(cnt > 0 && A.xe[slot] >= 0);
+        if (wave_exports) sd_consumer<true>(A, lds, wg, R, hasT, tlo, thi); else sd_consumer<false>(A, lds, wg, R, hasT, tlo, thi);
+    } else if (t < kThreads + 64) {
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        const SdPair P = s_pairs[t - kThreads];
+        // (a poll nobody needs goes to a place of this workgroup's own: the same address for the whole chip would be a hot spot)
+        const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
+        sd_courier(A, idle, lds, P, tlo, thi);
+    } else {
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        sd_producer(A, lds, wg, (t - kThreads - 64) >> 6, tlo, thi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// analysis: the lane fields the kernel needs, and the statement about the lanes it relies on (lane level)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sd_tab(int32_t nslots, int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot,
+                         const int32_t *__restrict__ Aptr, int32_t *__restrict__ dflags)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nslots) return;
+    int32_t *T = ltabF + (size_t)f * kStTab;
+    const int cnt = T[ST_CNT], nd = T[ST_ND];
+    T[ST_P0] = 0; T[ST_DFL] = 0; T[ST_Q] = -1; T[ST_Q + 1] = -1; T[ST_Q + 2] = -1;
+    if (cnt <= 0) return;
+    int bad = 0;
+    const int su = uslot[f];
+    if (su < 0) { atomicOr(dflags, 1); return; }
+    const int32_t *TB = ltabB + (size_t)su * kStTab;
+    const int ndU = TB[ST_ND];
+    if (TB[ST_CNT] != cnt) bad = 1;
+    int ownL = 0, ownU = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < nd) {
+            const int ty = T[ST_SRC + j] & 3;
+            if (ty == ST_OWN) {
+                // the own-chain entry: column r - 1, the last one left of the diagonal
+                if (j != nd - 1 || T[ST_OFF + j] != -1) bad = 1;
+                ownL = 1;
+            } else {
+                // every row of the lane has the entry, and its producer is where the template says
+                if (T[ST_KLO + j] > 0 || T[ST_KHI + j] < cnt) bad = 1;
+                if (ty == ST_LOCAL && (T[ST_DT + j] < 1 || T[ST_DT + j] > kSdH - 1)) bad = 1;
+            }
+        }
+        if (j < ndU) {
+            const int ty = TB[ST_SRC + j] & 3;
+            if (ty == ST_OWN) {
+                if (j != 0 || TB[ST_OFF + j] != 1) bad = 1;
+                ownU = 1;
+            } else {
+                if (TB[ST_KLO + j] > 0 || TB[ST_KHI + j] < cnt) bad = 1;
+            }
+        }
+    }
+    // the transposed entry of dependency j: the entry of the pivot row's right side whose offset is the opposite one
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int q = -1;
+        if (j < nd) {
+            const int os = T[ST_SRC + j] >> 2;
+            const int pu = uslot[os];
+            if (pu < 0) {
+                bad = 1;
+            } else {
+                const int32_t *TP = ltabB + (size_t)pu * kStTab;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) if (p < TP[ST_ND] && TP[ST_OFF + p] == -T[ST_OFF + j]) q = p;
+            }
+        }
+        T[ST_Q + j] = q;
+    }
+    T[ST_P0] = Aptr[T[ST_FIRST]];
+    T[ST_DFL] = ndU | (ownL << 2) | (ownU << 3) | ((nd + 1 + ndU) << 4);
+    if (bad) atomicOr(dflags, 2);
+}
+
+// the statement, row by row (pattern only): row k of a lane starts at p0 + k m (- 1 behind the first row when the chain entry
+// exists), and its columns are the template's -- r + oL, r, r + oU -- without r - 1 in the first row and r + 1 in the last
+__global__ void __launch_bounds__(256)
+k_sd_proof(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, int64_t nnz, int32_t B, int32_t nb,
+           const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot, const int32_t *__restrict__ ltabF,
+           const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot, int32_t *__restrict__ dflags)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int b = block_of(r, B, nb, start);
+    const int f = blk2slot[b];
+    const int32_t *T = ltabF + (size_t)f * kStTab;
+    const int su = uslot[f];
+    if (su < 0) { atomicOr(dflags, 1); return; }
+    const int32_t *TB = ltabB + (size_t)su * kStTab;
+    const v4i t0 = *reinterpret_cast<const v4i *>(T);                 // first, cnt, skew, nd
+    const int k = r - t0.x, cnt = t0.y, nd = t0.w;
+    const int fl = T[ST_DFL], p0 = T[ST_P0];
+    const int ndU = fl & 3, ownL = (fl >> 2) & 1, ownU = (fl >> 3) & 1, m = fl >> 4;
+    int bad = (k < 0 || k >= cnt) ? 1 : 0;
+    const int q0 = Aptr[r], q1 = Aptr[r + 1];
+    const int noL = (ownL && k == 0) ? 1 : 0, noU = (ownU && k == cnt - 1) ? 1 : 0;
+    if (q0 != p0 + k * m - ((ownL && k > 0) ? 1 : 0)) bad = 1;
+    if (q1 - q0 != m - noL - noU) bad = 1;
+    if (!bad) {
+        const Row8 rc = load_row8(Aidx, q0, q1 - q0, nnz);
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < nd && !(noL && j == nd - 1)) { if (ROW8_AT(rc, e) != r + T[ST_OFF + j]) bad = 1; ++e; }
+        if (ROW8_AT(rc, e) != r) bad = 1;
+        ++e;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < ndU && !(noU && q == 0)) { if (ROW8_AT(rc, e) != r + TB[ST_OFF + q]) bad = 1; ++e; }
+    }
+    if (bad) atomicOr(dflags, 4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+// Launches the two checks; dflags (device, one int, zeroed here) is non-zero afterwards when the matrix is not one for this kernel.
+bool st_direct_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, int32_t *dflags)
+{
+    static const bool off = getenv("ILUPP_NO_DIRECT") != nullptr;
+    // (the producers address A's values with 32-bit byte offsets)
+    if (off || !A.val || (A.nnz + 4) * 8 >= 0x7fffffffLL) return false;
+    const int nslots = fwd.nslots;
+    ILUPP_HIP(hipMemsetAsync(dflags, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_sd_tab, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, A.ptr, dflags);
+    hipLaunchKernelGGL(k_sd_proof, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.ptr, A.idx, (int64_t)A.nnz, fwd.B, fwd.nb,
+                       fwd.start, fwd.blk2slot, pl->ltab, pu->ltab, pu->uslot, dflags);
+    return true;
+}
+
+int ilu0_numeric_sd(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,
+                    hipEvent_t e0, hipEvent_t e1)
+{
+    {
+        static std::once_flag once[64];      // once per device
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_sd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSdLds));
+        });
+    }
+    ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
+    fill_u64(st, reinterpret_cast<unsigned long long *>(pl->xch), pl->xch_len, kSentinel);
+    SdArgs a;
+    a.ltab = pl->ltab; a.wtab = pl->wtab;
+    const uintptr_t vp = reinterpret_cast<uintptr_t>(A.val);
+    a.val = reinterpret_cast<const double *>(vp & ~(uintptr_t)15);
+    a.val_shift = (int32_t)(vp & 15);
+    a.val_bytes = (uint32_t)(A.nnz * 8 + a.val_shift);
+    a.pkL = reinterpret_cast<v2d *>(pl->pk); a.pkU = reinterpret_cast<v2d *>(pu->pk);
+    a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
+    ILUPP_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_ilu0_sd, dim3((unsigned)pl->nwg), dim3(kSdThreads), kSdLds, st, a);
+    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipGetLastError());
+    int32_t ctrl[4];
+    ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, 16));
+    ILUPP_HIP(stream_sync(st));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
+    return ILUPP_OK;
+}
+
+}  // namespace ilupp

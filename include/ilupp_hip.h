@@ -160,8 +160,8 @@ typedef struct {
     float usolve_kernel_ms;   /* backward-solve kernel of the last apply */
 } ilupp_timings;
 int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t);
-/* which kernel family built this object ("ilu0:static-level-major", "ilu0:level-major", "ilu0:csr-program", "ilu0:csr",
- * "ilut", "ichol0", "icholt"): bench.py names the kernel its roofline line is about */
+/* which kernel family built this object ("ilu0:static-direct", "ilu0:static-level-major", "ilu0:level-major", "ilu0:level-order",
+ * "ilu0:csr-program", "ilu0:csr", "ilut", "ichol0", "icholt"): bench.py names the kernel its roofline line is about */
 const char *ilupp_hip_path(const ilupp_precond *p);
 /* redo the numeric phase on (possibly new) values with the SAME pattern (buffers reused); times it */
 int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices,

@@ -48,7 +48,7 @@ def test_ilu0_config_c2_full_size():
     t = _dev(d, i, p)
     torch.cuda.synchronize()
     P = _native.ILU0Preconditioner_device(*_ptrs(t), n, True)
-    assert P.path() == "ilu0:static-level-major"
+    assert P.path() == "ilu0:static-direct"
     x = torch.ones(n, dtype=torch.float64, device=t[0].device)
     torch.cuda.synchronize()
     P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
@@ -129,7 +129,7 @@ def test_static_path_more_lines_than_lanes():
         d = d * (1.0 + 0.3 * rng.random(d.shape[0]))
         A = sp.csr_matrix((d, i, p), shape=(n, n))
         P = ilupp.ILU0Preconditioner(A)
-        assert P.pr.path() == "ilu0:static-level-major"
+        assert P.pr.path().startswith("ilu0:static-")
         Lo, Uo = ref.ilu0((A.data, A.indices, A.indptr, True))
         L, U = P.factors()
         assert G.mat_equal((L.data, L.indices, L.indptr, True), Lo) and G.mat_equal((U.data, U.indices, U.indptr, True), Uo)
@@ -174,7 +174,7 @@ d, i, p = matgen.poisson3d(48, 280, 280)
 n = p.shape[0] - 1
 A = sp.csr_matrix((d, i, p), shape=(n, n))
 P = ilupp.ILU0Preconditioner(A)
-assert P.pr.path() != "ilu0:static-level-major", P.pr.path()
+assert not P.pr.path().startswith("ilu0:static-"), P.pr.path()
 ref = O.ref() if O.ref_available() else O.orc()
 Lo, Uo = ref.ilu0((A.data, A.indices, A.indptr, True))
 b = G.rhs(n)
