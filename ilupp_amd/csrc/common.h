@@ -60,6 +60,7 @@ struct Schedule {
     int32_t *gtab = nullptr;       // nslots/256 x kGhosts: foreign producer slots a workgroup imports through ghost lanes (-1 = free)
     // 2-D tiling of the block grid (0 = identity placement): block b = (b % s2, b / s2), a workgroup owns ty x tz blocks
     int32_t tile_s2 = 0, tile_ty = 0, tile_tz = 0;
+    bool chains = false;           // every block is exactly one chain of rows and the rows of every chain are alike (symbolic.hip: rows_alike)
     void release();
 };
 

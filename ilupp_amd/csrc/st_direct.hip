@@ -32,6 +32,15 @@
 
 #include "st_common.h"
 
+#ifdef SD_PLAIN_STORE
+#define SD_STORE(v, p) (*(p) = (v))
+#else
+#define SD_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
+#ifndef SD_CSLEEP
+#define SD_CSLEEP 1
+#endif
 namespace ilupp {
 
 static constexpr int kSdH = 4;                                     // hand-off slots: an in-workgroup dependency lies at most kSdH-1 steps back
@@ -47,6 +56,21 @@ static constexpr int kSdLds = 2 * kSdRing + kSdH * kSdHoRow;
 static constexpr unsigned kSdOob = 0xfffffff0u;                    // a buffer offset beyond any array: the load returns zeros and touches nothing
 static_assert(kSdProd * kSdPer * 8 >= kThreads, "every lane needs a producer");
 static_assert(kSdHoRow % 16 == 0 && kSdRing % 8 == 0, "alignment of the LDS regions");
+
+#ifdef SD_STAMP
+// diagnostics build only: 100 MHz ticks of one consumer wave ([0..7]) and one producer wave ([16..23]) of workgroup SD_STAMP_WG, per segment of a step
+__device__ unsigned long long g_sd_stamp[32];
+#ifndef SD_STAMP_WG
+#define SD_STAMP_WG 120
+#endif
+#define SD_T(i) do { if (stamp_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_[i] += n_ - last_; last_ = n_; } } while (0)
+#define SD_T_DECL(cond) const bool stamp_on = (cond); unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_amdgcn_s_memtime(); unsigned long long nst_ = 0
+#define SD_T_END(off) do { if (stamp_on && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) g_sd_stamp[(off) + i_] = acc_[i_]; g_sd_stamp[(off) + 6] = nst_; } } while (0)
+#else
+#define SD_T(i) do { } while (0)
+#define SD_T_DECL(cond) do { } while (0)
+#define SD_T_END(off) do { } while (0)
+#endif
 
 struct SdArgs {
     const int32_t *ltab, *wtab;               // forward schedule
@@ -103,17 +127,35 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
     const bool lastL[3] = {nd == 1, nd == 2, nd == 3};
     const double absent = st_dbl(kAbsent);
 
+    SD_T_DECL(wv == 0 && wg == SD_STAMP_WG);
+    // the record stores of a step are issued during the NEXT step, one at a time between its divisions: the path from the registers
+    // to the memory pipeline takes 16 bytes per cycle and CU -- 64 cycles per 16-byte store instruction, 1024 per step for the
+    // workgroup's 16 KB -- and four stores back to back at the end of a step left every wave waiting at issue for most of that time
+    v2d s_la, s_lb, s_ua, s_ub;
+    s_la.x = s_la.y = s_lb.x = s_lb.y = s_ua.x = s_ua.y = s_ub.x = s_ub.y = 0.0;
+    bool s_ok = false;
+    unsigned char *s_o = pl, *s_ou = pu;
+#define SD_FLUSH(which) do { if (s_ok) { \
+        if (which == 0) SD_STORE(s_la, reinterpret_cast<v2d *>(s_o + lo16)); \
+        if (which == 1) SD_STORE(s_lb, reinterpret_cast<v2d *>(s_o + lo16 + 1024)); \
+        if (which == 2) SD_STORE(s_ua, reinterpret_cast<v2d *>(s_ou + lo16)); \
+        if (which == 3) SD_STORE(s_ub, reinterpret_cast<v2d *>(s_ou + lo16 + 1024)); } } while (0)
     for (int tb = tlo; tb < thi; tb += 8) {
         const int kb = tb - sk;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int k = kb + u;
             const bool valid = (unsigned)k < (unsigned)cnt;
+#ifdef SD_STAMP
+            ++nst_;
+#endif
+            SD_T(0);
             const unsigned par = (unsigned)((u >> 1) & 1) * kSdRing;
             const bool c0 = k == k0L, cE = k == kEU;
             const unsigned aL = aL_[u & 1] + (c0 ? 8u : 0u);
             const unsigned aU = aD_[u & 1] - (cE ? 8u : 0u);
             ST_BARRIER();
+            SD_T(1);
             double av[3], up[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) av[j] = st_lds(lds, aL + par + 8u * j);
@@ -123,6 +165,13 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             v2d P[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) P[j] = *reinterpret_cast<const v2d *>(lds + R[j][u % kSdH]);
+#ifdef SD_SPREAD
+            SD_FLUSH(0);
+#endif
+#ifdef SD_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            SD_T(2);
             bool pj[3], pq[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) pj[j] = valid && inL[j] && !(lastL[j] && c0);
@@ -134,7 +183,11 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
                 bool nan = d != d;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) nan = nan || av[j] != av[j] || up[j] != up[j];
+#ifdef SD_NONAN
+                if (false) {
+#else
                 if (__any(nan)) {
+#endif
                     d = st_clean(d);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { av[j] = st_clean(av[j]); up[j] = st_clean(up[j]); }
@@ -150,11 +203,19 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
                 const double pr = l[j] * P[j].y;
                 const double nw = w3 - pr;
                 w3 = (pj[j] && hasT[j]) ? nw : w3;
+#ifdef SD_SPREAD
+                asm volatile("" : "+v"(w3) :: "memory");
+                SD_FLUSH(j + 1);
+#endif
             }
             {
                 const unsigned long long wb = st_bits(w3);
                 if (wb == kSentinel || wb == kAbsent) w3 = st_dbl(kCanonNaN);
             }
+#ifdef SD_STAMP
+            asm volatile("" :: "v"(w3));
+#endif
+            SD_T(3);
             // hand-off: the pivot with each entry right of the diagonal
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -164,22 +225,46 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             // pivots that other workgroups read: write-through, to the exchange
             if (EX) { if (exports && valid) st_agent_f64(A.xch + (xoff + (tb + u) * xE), w3); }
             const int cw = tb + u - tminw;
+#ifdef SD_SPREAD
+            s_ok = valid && (unsigned)cw < (unsigned)nchw;
+            s_o = pl + (size_t)(base + cw) * 2048; s_ou = pu + (size_t)(base + cw) * 2048;
+            s_la.x = pj[0] ? l[0] : absent; s_la.y = pj[1] ? l[1] : absent;
+            s_lb.x = pj[2] ? l[2] : absent; s_lb.y = 1.0;
+            s_ua.x = pq[0] ? up[0] : absent; s_ua.y = pq[1] ? up[1] : absent;
+            s_ub.x = pq[2] ? up[2] : absent; s_ub.y = w3;
+            if (false) {
+#elif defined(SD_NOSTORE)
+            if (valid && (unsigned)cw < (unsigned)nchw && w3 == 1.2345e-300) {
+#else
             if (valid && (unsigned)cw < (unsigned)nchw) {
+#endif
                 unsigned char *o = pl + (size_t)(base + cw) * 2048;
                 v2d la, lb;
                 la.x = pj[0] ? l[0] : absent; la.y = pj[1] ? l[1] : absent;
                 lb.x = pj[2] ? l[2] : absent; lb.y = 1.0;
-                ST_STREAM_STORE(la, reinterpret_cast<v2d *>(o + lo16));
-                ST_STREAM_STORE(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
+                SD_STORE(la, reinterpret_cast<v2d *>(o + lo16));
+                SD_STORE(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
                 unsigned char *ou = pu + (size_t)(base + cw) * 2048;
+#ifndef SD_HALF_STORE
                 v2d ua, ub;
                 ua.x = pq[0] ? up[0] : absent; ua.y = pq[1] ? up[1] : absent;
                 ub.x = pq[2] ? up[2] : absent; ub.y = w3;
-                ST_STREAM_STORE(ua, reinterpret_cast<v2d *>(ou + lo16));
-                ST_STREAM_STORE(ub, reinterpret_cast<v2d *>(ou + lo16 + 1024));
+                SD_STORE(ua, reinterpret_cast<v2d *>(ou + lo16));
+                SD_STORE(ub, reinterpret_cast<v2d *>(ou + lo16 + 1024));
+#endif
             }
+            SD_T(4);
         }
     }
+#ifdef SD_SPREAD
+    SD_FLUSH(0); SD_FLUSH(1); SD_FLUSH(2); SD_FLUSH(3);
+#endif
+#undef SD_FLUSH
+    SD_T_END(0);
+#ifdef SD_STAMP
+    if (t == 0 && wg == (int)gridDim.x - 1) { g_sd_stamp[10] = __builtin_amdgcn_s_memtime(); g_sd_stamp[11] = __builtin_amdgcn_s_memrealtime(); }
+    if (t == 0 && wg == 0) { g_sd_stamp[12] = __builtin_amdgcn_s_memtime(); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -217,7 +302,7 @@ __device__ __forceinline__ void sd_courier(const SdArgs &A, const unsigned long 
                 while (__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0) {
                     if (need && v == kSentinel) v = ld_agent_u64(SDC_ADDR(k));
                     __builtin_amdgcn_s_waitcnt(0x0F70);          // retired here, not at the join after the loop
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(SD_CSLEEP);
                     if ((++spins & 255u) == 0) {
                         if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);
                         const int e = ld_agent_i32(&A.ctrl[1]);
@@ -259,6 +344,9 @@ __device__ __forceinline__ void sd_producer(const SdArgs &A, unsigned char *lds,
         const bool on = live && cnt > 0;
         S[i] = on ? 16u * (unsigned)m : 0u;
         g[i] = on ? (Cu & ~15u) + (unsigned)b0 * S[i] + 16u * (unsigned)sub : kSdOob;
+#ifdef SD_NOLOAD
+        g[i] = kSdOob; S[i] = 0;
+#endif
     }
     const unsigned dst = (unsigned)(pw * kSdPer * 8 + lg) * kSdPitch + 16u * (unsigned)sub;      // group i: + i * 8 * kSdPitch
     v4u ra[kSdRA][kSdPer];
@@ -286,15 +374,26 @@ __device__ __forceinline__ void sd_producer(const SdArgs &A, unsigned char *lds,
     for (int rb = 0; rb < kSdRA; ++rb) { SDP_LOAD(rb); asm volatile("" ::: "memory"); }
     SDP_WRITE(0, 0);
     SDP_LOAD(0);
+    SD_T_DECL(pw == 0 && wg == SD_STAMP_WG);
     for (int tb = tlo; tb < thi; tb += 8) {
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
+            SD_T(0);
             ST_BARRIER();                                       // the consumers read block tb/2 + bb now; the one before it is free
+            SD_T(1);
+#ifdef SD_STAMP
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kSdRA - 1) * kSdPer) : "memory");
+            ++nst_;
+#endif
+            SD_T(2);
             SDP_WRITE((bb + 1) & 3, (bb + 1) & 1);
             SDP_LOAD((bb + 1) & 3);
+            SD_T(3);
             ST_BARRIER();
+            SD_T(4);
         }
     }
+    SD_T_END(16);
 #undef SDP_LOAD
 #undef SDP_WRITE
 }
@@ -313,6 +412,9 @@ k_ilu0_sd(SdArgs A)
     __syncthreads();
     const int wg = (int)s_ticket;
     const int t = threadIdx.x;
+#ifdef SD_STAMP
+    if (t == 0 && wg == 0) { g_sd_stamp[8] = __builtin_amdgcn_s_memtime(); g_sd_stamp[9] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     int tlo = 0x7fffffff, thi = -0x7fffffff;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -517,17 +619,22 @@ k_sd_proof(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restric
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-// Launches the two checks; dflags (device, one int, zeroed here) is non-zero afterwards when the matrix is not one for this kernel.
+// The checks of the premise.  Row level: every block of the schedule is one whole chain and the rows of every chain are alike
+// (found by the first pass over the pattern, symbolic.hip: Schedule::chains) -- then the lane templates, taken from three sampled
+// rows, hold for every row.  Lane level: k_sd_tab, launched here; dflags (device, one int, zeroed here) is non-zero afterwards
+// when the matrix is not one for this kernel.  ILUPP_SD_VERIFY=1 also runs the row-by-row statement (k_sd_proof).
 bool st_direct_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, int32_t *dflags)
 {
     static const bool off = getenv("ILUPP_NO_DIRECT") != nullptr;
+    static const bool verify = getenv("ILUPP_SD_VERIFY") != nullptr;
     // (the producers address A's values with 32-bit byte offsets)
-    if (off || !A.val || (A.nnz + 4) * 8 >= 0x7fffffffLL) return false;
+    if (off || !fwd.chains || !A.val || (A.nnz + 4) * 8 >= 0x7fffffffLL) return false;
     const int nslots = fwd.nslots;
     ILUPP_HIP(hipMemsetAsync(dflags, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_sd_tab, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, A.ptr, dflags);
-    hipLaunchKernelGGL(k_sd_proof, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.ptr, A.idx, (int64_t)A.nnz, fwd.B, fwd.nb,
-                       fwd.start, fwd.blk2slot, pl->ltab, pu->ltab, pu->uslot, dflags);
+    if (verify)
+        hipLaunchKernelGGL(k_sd_proof, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.ptr, A.idx, (int64_t)A.nnz, fwd.B, fwd.nb,
+                           fwd.start, fwd.blk2slot, pl->ltab, pu->ltab, pu->uslot, dflags);
     return true;
 }
 
@@ -564,4 +671,16 @@ int ilu0_numeric_sd(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     return ILUPP_OK;
 }
 
+#ifdef SD_STAMP
+void sd_read_stamps(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sd_stamp), sizeof(unsigned long long) * 32)); }
+#endif
+
 }  // namespace ilupp
+
+#ifdef SD_STAMP
+extern "C" int ilupp_hip_debug_sd_stamps(unsigned long long *out)
+{
+    try { ilupp::sd_read_stamps(out); } catch (...) { return -1; }
+    return 0;
+}
+#endif

@@ -194,13 +194,17 @@ __global__ void k_row_cuts(int32_t n, const int32_t *__restrict__ ptr, const int
 
 // start[b] = first allowed cut in the nominal cell [b*B, (b+1)*B), or the cell's end if the cell
 // lies inside one long chain (the chain is then split at a cell border: correct, merely serial).
-__global__ void k_block_starts(int32_t n, int32_t B, int32_t nb, const uint8_t *__restrict__ cut, int32_t *__restrict__ start)
+__global__ void k_block_starts(int32_t n, int32_t B, int32_t nb, const uint8_t *__restrict__ cut, int32_t *__restrict__ start,
+                               int32_t *__restrict__ ragged)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
     if (b == nb) { start[nb] = n; return; }
-    if (b == 0) { start[0] = 0; return; }
     const int64_t lo = (int64_t)b * B;
+    // *ragged: some nominal cell does not begin with the start of a chain (with as many chains as cells -- the host knows both
+    // numbers -- every block is then exactly one chain)
+    if (ragged && !cut[lo]) *ragged = 1;
+    if (b == 0) { start[0] = 0; return; }
     int64_t hi = lo + B;
     if (hi > n) hi = n;
     int64_t s = hi;
@@ -209,7 +213,7 @@ __global__ void k_block_starts(int32_t n, int32_t B, int32_t nb, const uint8_t *
     start[b] = (int32_t)s;
 }
 
-static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t ncuts, int max_lanes, Schedule *sch)
+static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t ncuts, int max_lanes, Schedule *sch, int32_t *ragged = nullptr)
 {
     // rows per lane: at least n/max_lanes, and about one chain when chains are long
     int64_t B = ((int64_t)n + max_lanes - 1) / max_lanes;
@@ -225,24 +229,66 @@ static void make_schedule(hipStream_t st, int32_t n, const uint8_t *cut, int32_t
     sch->B = (int32_t)B;
     ILUPP_HIP(pool_malloc(&sch->start, sizeof(int32_t) * (size_t)(nb + 1)));
     hipLaunchKernelGGL(k_block_starts, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st,
-                       n, (int32_t)B, (int32_t)nb, cut, sch->start);
+                       n, (int32_t)B, (int32_t)nb, cut, sch->start, ragged);
 }
 
 // ILU(0) analysis, first pass over A's pattern: everything k_row_cuts finds plus the row counts of L (lrow[r] =
 // strictly-lower entries + unit diagonal, ILU0.hpp:93) and the first row without a diagonal entry.
 // stats[3] = min row with no diagonal (INT_MAX when none)
+// side entries of a row: everything but the diagonal and the two links of its chain (columns r - 1, r + 1).  Rows r - 1 and r of one
+// chain are ALIKE when their side entries have the same offsets from the diagonal, row r - 1 has column r, and both fit 8 entries.
+// (the light form of st_direct.hip's statement about lanes: with every chain alike and every lane exactly one chain, the lane
+// templates that k_st_template takes from three sampled rows hold for all rows)
+__device__ __forceinline__ bool rows_alike(const Row8 &cur, int r, int len, const Row8 &prv, int plen)
+{
+    if (len > 8 || plen > 8) return false;
+    // entry i of a row: left of the diagonal block {r-1, r, r+1} the side entries sit at the front, right of it at the back
+    int cl = 0, pl = 0, hp = 0, hn = 0, php = 0, phn = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        cl += cur.c[i] < r - 1 ? 1 : 0; pl += prv.c[i] < r - 2 ? 1 : 0;
+        hp |= cur.c[i] == r - 1; hn |= cur.c[i] == r + 1; php |= prv.c[i] == r - 2; phn |= prv.c[i] == r;
+    }
+    if (!phn) return false;                                             // (r, r-1) stored without (r-1, r)
+    const int us = cl + 1 + hp + hn, ups = pl + 1 + php + phn;          // first side entry right of the diagonal
+    if (cl != pl || len - us != plen - ups) return false;
+    bool ok = true;
+    if (us == ups) {
+        // same places in both rows (the rule inside a chain): entry by entry, row r - 1 shifted by one column
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool side = i < cl || (i >= us && i < len);
+            ok = ok && (!side || cur.c[i] == prv.c[i] + 1);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ok = ok && (i >= cl || cur.c[i] == prv.c[i] + 1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int a = us + i, b = ups + i;
+            if (a < len) ok = ok && ROW8_AT(cur, a > 7 ? 7 : a) == ROW8_AT(prv, b > 7 ? 7 : b) + 1;
+        }
+    }
+    return ok;
+}
+
 __global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int64_t nnz,
                                   uint8_t *__restrict__ cutf, uint8_t *__restrict__ cutb, int32_t *__restrict__ lrow,
                                   int32_t *__restrict__ stats)
 {
-    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff, nl = 0;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const int lo = ptr[r], hi = ptr[r + 1];
+    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff, nl = 0, nun = 0;
+    for (int r0 = blockIdx.x * blockDim.x; r0 < n; r0 += gridDim.x * blockDim.x) {
+        const int r = r0 + (int)threadIdx.x;
+        const bool live = r < n;
+        const int lo = live ? ptr[r] : 0, hi = live ? ptr[r + 1] : 0;
         mx = max(mx, hi - lo);
         int cl = 0;
         bool has_prev = false, has_next = false, has_diag = false;
-        if (hi - lo <= 8) {
-            const Row8 row = load_row8(idx, lo, hi - lo, nnz);
+        Row8 row;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row.c[i] = 0x7fffffff;
+        if (live && hi - lo <= 8) {
+            row = load_row8(idx, lo, hi - lo, nnz);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 cl += row.c[i] < r ? 1 : 0;
@@ -255,52 +301,74 @@ __global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, co
                 has_prev |= c == r - 1; has_next |= c == r + 1; has_diag |= c == r;
             }
         }
-        if (lrow) lrow[r] = cl + 1;
-        nl += cl + 1;
-        if (!has_diag) miss = min(miss, r);
-        const int cf = (r == 0) ? 1 : (has_prev ? 0 : 1);
-        cutf[r] = (uint8_t)cf;
-        nf += cf;
-        if (r + 1 < n) { const int cb = has_next ? 0 : 1; cutb[r + 1] = (uint8_t)cb; nbk += cb; }
-        if (r == 0) { cutb[0] = 1; nbk += 1; }
+        // the row before, from the lane before (the first lane of a wave reads it)
+        Row8 prv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) prv.c[i] = __shfl_up(row.c[i], 1);
+        int plen = __shfl_up(hi - lo, 1);
+        if ((threadIdx.x & 63) == 0 && live && r > 0) {
+            const int plo = ptr[r - 1];
+            plen = lo - plo;
+            if (plen <= 8) prv = load_row8(idx, plo, plen, nnz);
+        }
+        if (live) {
+            if (has_prev && !rows_alike(row, r, hi - lo, prv, plen)) ++nun;
+            if (!has_prev && r > 0 && plen <= 8) {
+                // a chain starts here: the row before must not point at this one either
+                bool phn = false;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) phn |= prv.c[i] == r;
+                if (phn) ++nun;
+            }
+            if (lrow) lrow[r] = cl + 1;
+            nl += cl + 1;
+            if (!has_diag) miss = min(miss, r);
+            const int cf = (r == 0) ? 1 : (has_prev ? 0 : 1);
+            cutf[r] = (uint8_t)cf;
+            nf += cf;
+            if (r + 1 < n) { const int cb = has_next ? 0 : 1; cutb[r + 1] = (uint8_t)cb; nbk += cb; }
+            if (r == 0) { cutb[0] = 1; nbk += 1; }
+        }
     }
-    __shared__ int red[5];
+    __shared__ int red[6];
     if (threadIdx.x < 3) red[threadIdx.x] = 0;
     if (threadIdx.x == 3) red[3] = 0x7fffffff;
     if (threadIdx.x == 4) red[4] = 0;
+    if (threadIdx.x == 5) red[5] = 0;
     __syncthreads();
     for (int off = 32; off > 0; off >>= 1) {
         nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); miss = min(miss, __shfl_xor(miss, off)); nl += __shfl_xor(nl, off);
+        nun += __shfl_xor(nun, off);
     }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); atomicAdd(&red[4], nl); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); atomicAdd(&red[4], nl); atomicAdd(&red[5], nun); }
     __syncthreads();
     // per-block partial results; k_reduce_stats folds them (same-address atomics cost ~10 ns each on this chip: four per
     // block were 0.16 of this kernel's 0.26 ms at 4096 blocks, and 1.2 ms at 32768)
-    if (threadIdx.x == 0) { int *o = stats + 8 + 8 * blockIdx.x; o[0] = red[0]; o[1] = red[1]; o[2] = red[2]; o[3] = red[3]; o[4] = red[4]; }
+    if (threadIdx.x == 0) { int *o = stats + 8 + 8 * blockIdx.x; o[0] = red[0]; o[1] = red[1]; o[2] = red[2]; o[3] = red[3]; o[4] = red[4]; o[5] = red[5] > 0 ? 1 : 0; }
 }
 
 __global__ void k_reduce_stats(int nblocks, int32_t *stats)
 {
-    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff;
+    int nf = 0, nbk = 0, mx = 0, miss = 0x7fffffff, nun = 0;
     long long nl = 0;
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
         const int *o = stats + 8 + 8 * b;
-        nf += o[0]; nbk += o[1]; mx = max(mx, o[2]); miss = min(miss, o[3]); nl += o[4];
+        nf += o[0]; nbk += o[1]; mx = max(mx, o[2]); miss = min(miss, o[3]); nl += o[4]; nun += o[5];
     }
-    __shared__ int red[4];
+    __shared__ int red[5];
     __shared__ unsigned long long rl;
     if (threadIdx.x < 3) red[threadIdx.x] = 0;
     if (threadIdx.x == 3) red[3] = 0x7fffffff;
-    if (threadIdx.x == 4) rl = 0;
+    if (threadIdx.x == 4) { rl = 0; red[4] = 0; }
     __syncthreads();
     for (int off = 32; off > 0; off >>= 1) {
         nf += __shfl_xor(nf, off); nbk += __shfl_xor(nbk, off); mx = max(mx, __shfl_xor(mx, off)); miss = min(miss, __shfl_xor(miss, off));
-        nl += __shfl_xor(nl, off);
+        nl += __shfl_xor(nl, off); nun += __shfl_xor(nun, off);
     }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); atomicAdd(&rl, (unsigned long long)nl); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nf); atomicAdd(&red[1], nbk); atomicMax(&red[2], mx); atomicMin(&red[3], miss); atomicAdd(&rl, (unsigned long long)nl); atomicAdd(&red[4], nun); }
     __syncthreads();
-    // stats[4..5]: entries of L (strictly lower + unit diagonal), 64 bits
-    if (threadIdx.x == 0) { stats[0] = red[0]; stats[1] = red[1]; stats[2] = red[2]; stats[3] = red[3]; *reinterpret_cast<unsigned long long *>(stats + 4) = rl; }
+    // stats[4..5]: entries of L (strictly lower + unit diagonal), 64 bits; stats[6]: blocks of rows with a chain that is not alike
+    if (threadIdx.x == 0) { stats[0] = red[0]; stats[1] = red[1]; stats[2] = red[2]; stats[3] = red[3]; *reinterpret_cast<unsigned long long *>(stats + 4) = rl; stats[6] = red[4]; stats[7] = 0; }
 }
 
 // L/U patterns from the row pointers of L alone: Uptr[r] = Aptr[r] - (Lptr[r] - r)
@@ -353,22 +421,26 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
                        static_cast<int32_t *>(nullptr), stats);
     hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(1024), 0, st, (int)gb, stats);
     L->n = U->n = n; L->is_csr = U->is_csr = true; L->owns = U->owns = true;
-    int32_t h[6];
+    int32_t h[8];
     ILUPP_HIP(d2h_async(st, h, stats, sizeof(h)));
     ILUPP_HIP(stream_sync(st));
-    ILUPP_HIP(pool_free(stats));
     if (max_row_len) *max_row_len = h[2];
     if (first_missing_diag) *first_missing_diag = (h[3] == 0x7fffffff) ? -1 : h[3];
     long long nnzl = 0;
     memcpy(&nnzl, h + 4, sizeof(nnzl));
     L->nnz = nnzl;
     U->nnz = A.nnz - (nnzl - n);
-    if (h[3] != 0x7fffffff) { ILUPP_HIP(pool_free(cutf)); ILUPP_HIP(pool_free(cutb)); return ILUPP_ERR_NO_DIAGONAL; }
-    make_schedule(st, n, cutf, h[0], max_lanes, fwd);
-    make_schedule(st, n, cutb, h[1], max_lanes, bwd);
+    if (h[3] != 0x7fffffff) { ILUPP_HIP(pool_free(cutf)); ILUPP_HIP(pool_free(cutb)); ILUPP_HIP(pool_free(stats)); return ILUPP_ERR_NO_DIAGONAL; }
+    make_schedule(st, n, cutf, h[0], max_lanes, fwd, stats + 7);
+    make_schedule(st, n, cutb, h[1], max_lanes, bwd, stats + 7);
+    int32_t ragged = 1;
+    ILUPP_HIP(d2h_async(st, &ragged, stats + 7, sizeof(ragged)));
     ILUPP_HIP(stream_sync(st));
+    // every lane one whole chain, all chains alike (st_direct.hip's premise, in its light form)
+    fwd->chains = bwd->chains = h[6] == 0 && ragged == 0 && h[0] == fwd->nb && h[1] == bwd->nb;
     ILUPP_HIP(pool_free(cutf));
     ILUPP_HIP(pool_free(cutb));
+    ILUPP_HIP(pool_free(stats));
     return ILUPP_OK;
 }
 
