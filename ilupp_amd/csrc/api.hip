@@ -138,6 +138,20 @@ static void order_caller_after(hipStream_t st, hipEvent_t ev)
     ILUPP_HIP(hipStreamWaitEvent(g_caller_stream, ev, 0));
 }
 
+// indptr[n] of a device-resident matrix.  Ordered after the work the caller has submitted to its stream when one is set (the
+// producer of the arrays: a blocking copy on the null stream does not wait for a non-blocking stream)
+static int32_t read_device_nnz(const int32_t *d_indptr, int32_t n)
+{
+    int32_t v = 0;
+    if (g_caller_stream_set) {
+        ILUPP_HIP(hipMemcpyAsync(&v, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, g_caller_stream));
+        ILUPP_HIP(hipStreamSynchronize(g_caller_stream));
+    } else {
+        ILUPP_HIP(hipMemcpy(&v, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return v;
+}
+
 static int report(const HipError &e)
 {
     char buf[512];
@@ -182,7 +196,8 @@ struct ilupp_precond {
     int64_t nnzA = 0;                // stored entries of the factored matrix (same pattern on a numeric re-factorisation)
     int32_t max_row_len = 0;
     int32_t max_len_T = 0;       // longest major slice of the transposed storages
-    double *work = nullptr;      // n, all-sentinel between applies
+    double *work = nullptr;      // n, all-sentinel between applies of the record-decoding / CSR sweeps (filled when the first of them runs)
+    bool work_clean = false;
     double *xdev = nullptr;      // n, staging for host-vector apply
     int32_t *done = nullptr;     // n
     bool degenerate = false;     // a factor has a major slice without entries (NaN columns of an indefinite ICholT): guarded sweeps only
@@ -255,7 +270,6 @@ ilupp_precond *new_obj(int32_t n)
     ILUPP_HIP(pool_malloc(&p->work, sizeof(double) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->done, sizeof(int32_t) * (size_t)n));
     ILUPP_HIP(pool_malloc(&p->ctrl, 64));
-    fill_u64(p->stream, reinterpret_cast<unsigned long long *>(p->work), n, kSentinel);
     // Lanes a schedule may spread over.  NOT the lanes of the chip: every kernel takes its workgroup id from a ticket counter
     // and only waits for rows of lower tickets, which have started by then, so a grid larger than the chip makes progress;
     // what matters is that a lane's block of rows is one dependency chain (a mesh line).  With the chip's 65 536 lanes as the
@@ -457,6 +471,12 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
                  const PackedSweep *ps, double *rhs, double *out, int32_t *ticket, int32_t *err,
                  double *ypk_out = nullptr, const double *ypk_in = nullptr, const int32_t *ysrc = nullptr)
 {
+    // every sweep but the static ones hands its unknowns over through `out` (the data is the flag): all-sentinel before it runs.
+    // The static sweeps never touch the work vector, so an object that only ever runs them never pays for the fill.
+    if (!(ps && ps->valid && ps->stat && !p->degenerate) && !p->work_clean) {
+        fill_u64(p->stream, reinterpret_cast<unsigned long long *>(p->work), p->n, kSentinel);
+        p->work_clean = true;
+    }
     if (p->degenerate) return sptrsv_rows(p->stream, kind, M, rhs, out, ticket, err);
     if (ps && ps->valid) {
         // (the static sweeps exchange through a buffer of their own: `out` needs no sentinels before and `rhs` none after)
@@ -692,8 +712,7 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
-    int32_t nnz32 = 0;
-    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t nnz32 = read_device_nnz(d_indptr, n);
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
@@ -869,8 +888,7 @@ int ilupp_hip_ilut_create_device(const double *d_data, const int32_t *d_indices,
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
-    int32_t nnz32 = 0;
-    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t nnz32 = read_device_nnz(d_indptr, n);
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
@@ -909,8 +927,7 @@ int ilupp_hip_iluc_create_device(const double *d_data, const int32_t *d_indices,
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
-    int32_t nnz32 = 0;
-    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t nnz32 = read_device_nnz(d_indptr, n);
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
@@ -999,8 +1016,7 @@ int ilupp_hip_ichol0_create_device(const double *d_data, const int32_t *d_indice
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
-    int32_t nnz32 = 0;
-    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t nnz32 = read_device_nnz(d_indptr, n);
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
@@ -1090,8 +1106,7 @@ int ilupp_hip_icholt_create_device(const double *d_data, const int32_t *d_indice
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
-    int32_t nnz32 = 0;
-    ILUPP_HIP(hipMemcpy(&nnz32, d_indptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t nnz32 = read_device_nnz(d_indptr, n);
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);

@@ -267,6 +267,8 @@ int device_cu_count();
 int32_t min_row_len(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, int diag_at);
 void iota_i32(hipStream_t st, int32_t *p, int64_t count);
 hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t bytes);   // small read-back, visible after stream_sync()
+struct D2HItem { void *dst; const void *src; size_t bytes; };
+hipError_t d2h_async_many(hipStream_t st, const D2HItem *items, int n);   // up to 8 read-backs with one launch
 hipError_t stream_sync(hipStream_t st);
 void d2h_cancel_all();
 

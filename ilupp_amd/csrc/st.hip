@@ -47,11 +47,11 @@ __global__ void k_lm_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, con
 // analysis 1: lane templates.  TRI = +1: the entries left of the diagonal (forward schedule), -1: right (backward)
 // ---------------------------------------------------------------------------------------------
 template <int TRI>
-__global__ void __launch_bounds__(kThreads)
-k_st_template(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t B, int32_t nb,
-              const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot, const int32_t *__restrict__ sfirst,
-              const int32_t *__restrict__ scount, int32_t *__restrict__ exported, int32_t *__restrict__ ltab,
-              int32_t *__restrict__ flags)
+__device__ __forceinline__ void
+st_template_body(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t B, int32_t nb,
+                 const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot, const int32_t *__restrict__ sfirst,
+                 const int32_t *__restrict__ scount, int32_t *__restrict__ exported, int32_t *__restrict__ ltab,
+                 int32_t *__restrict__ flags)
 {
     const int wg = blockIdx.x, t = threadIdx.x;
     const int slot = wg * kThreads + t;
@@ -124,17 +124,35 @@ k_st_template(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, 
     if (bad) atomicOr(&flags[0], 2);
 }
 
+template <int TRI>
+__global__ void __launch_bounds__(kThreads)
+k_st_template(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t B, int32_t nb,
+              const int32_t *__restrict__ start, const int32_t *__restrict__ blk2slot, const int32_t *__restrict__ sfirst,
+              const int32_t *__restrict__ scount, int32_t *__restrict__ exported, int32_t *__restrict__ ltab,
+              int32_t *__restrict__ flags)
+{
+    st_template_body<TRI>(ptr, idx, B, nb, start, blk2slot, sfirst, scount, exported, ltab, flags);
+}
+// both schedules of a matrix with one launch (blockIdx.y: 0 forward, 1 backward; a launch of 256 small workgroups is 25 us of
+// dependent loads whatever it does)
+struct StTplArgs { int32_t B, nb; const int32_t *start, *blk2slot, *sfirst, *scount; int32_t *exported, *ltab, *flags; };
+__global__ void __launch_bounds__(kThreads)
+k_st_template_pair(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, StTplArgs f, StTplArgs b)
+{
+    if (blockIdx.y == 0) st_template_body<1>(ptr, idx, f.B, f.nb, f.start, f.blk2slot, f.sfirst, f.scount, f.exported, f.ltab, f.flags);
+    else st_template_body<-1>(ptr, idx, b.B, b.nb, b.start, b.blk2slot, b.sfirst, b.scount, b.exported, b.ltab, b.flags);
+}
+
 // ---------------------------------------------------------------------------------------------
 // analysis 2: skews (longest-path fixpoint over the workgroup's in-workgroup dependencies, exact: the templates hold
 // for every row), steps back of every in-workgroup dependency, chunk range of each wave; FWD: the proof that each
 // elimination meets the eliminated row on its diagonal only
 // ---------------------------------------------------------------------------------------------
 template <bool FWD>
-__global__ void __launch_bounds__(kThreads)
-k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const int32_t *__restrict__ uslot,
-          int32_t *__restrict__ skew, int32_t *__restrict__ wtab, int32_t *__restrict__ flags)
+__device__ __forceinline__ void
+st_link_body(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const int32_t *__restrict__ uslot,
+             int32_t *__restrict__ skew, int32_t *__restrict__ wtab, int32_t *__restrict__ flags, int *s)
 {
-    __shared__ int s[kThreads];
     const int wg = blockIdx.x, t = threadIdx.x;
     const int slot = wg * kThreads + t;
     int32_t *T = ltab + (size_t)slot * kStTab;
@@ -221,6 +239,25 @@ k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const 
     if (bad) atomicOr(&flags[0], 4);
 }
 
+template <bool FWD>
+__global__ void __launch_bounds__(kThreads)
+k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const int32_t *__restrict__ uslot,
+          int32_t *__restrict__ skew, int32_t *__restrict__ wtab, int32_t *__restrict__ flags)
+{
+    __shared__ int s[kThreads];
+    st_link_body<FWD>(ltab, ltab_u, uslot, skew, wtab, flags, s);
+}
+// both schedules of an ILU(0) with one launch (blockIdx.y: 0 forward with the proof about the eliminations, 1 backward)
+__global__ void __launch_bounds__(kThreads)
+k_st_link_pair(int32_t *__restrict__ ltabF, int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot, int32_t *__restrict__ skewF,
+               int32_t *__restrict__ skewB, int32_t *__restrict__ wtabF, int32_t *__restrict__ wtabB, int32_t *__restrict__ flagsF,
+               int32_t *__restrict__ flagsB)
+{
+    __shared__ int s[kThreads];
+    if (blockIdx.y == 0) st_link_body<true>(ltabF, ltabB, uslot, skewF, wtabF, flagsF, s);
+    else st_link_body<false>(ltabB, nullptr, nullptr, skewB, wtabB, flagsB, s);
+}
+
 // exclusive scan of the waves' chunk counts (one block); flags[1] = total, flags[2] = longest wave
 __global__ void __launch_bounds__(kThreads)
 k_st_scan(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ flags)
@@ -257,10 +294,12 @@ __global__ void k_st_inv(int32_t nslots, const int32_t *__restrict__ uslot, int3
 __global__ void k_st_scat(int32_t nslots, int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB,
                           const int32_t *__restrict__ uslot, const int32_t *__restrict__ inv,
                           const int32_t *__restrict__ wtabF, const int32_t *__restrict__ wtabU, int32_t *__restrict__ rtab,
-                          int32_t *__restrict__ flags)
+                          int32_t *__restrict__ flags, const int32_t *__restrict__ Aptr, int32_t *__restrict__ dflags)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nslots) return;
+    // (the direct-feed factor kernel's lane fields and lane-level checks: st_direct.hip)
+    if (dflags) sd_tab_lane(f, ltabF, ltabB, uslot, Aptr, dflags);
     int32_t *T = ltabF + (size_t)f * kStTab;
     int32_t *R = rtab + (size_t)f * 32;
     const int cnt = T[ST_CNT];
@@ -1433,16 +1472,18 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     const int nslots = fwd.nslots;
     st_structure(st, fwd, pl, (int)SWEEP_FWD_LAST_ASC);
     st_structure(st, bwd, pu, (int)SWEEP_BWD_FIRST_ASC);
-    hipLaunchKernelGGL((k_st_template<1>), dim3((unsigned)nwg), dim3(kThreads), 0, st, A.ptr, A.idx, fwd.B, fwd.nb, fwd.start,
-                       fwd.blk2slot, fwd.sfirst, fwd.scount, fwd.exported, pl->ltab, pl->flags);
-    hipLaunchKernelGGL((k_st_template<-1>), dim3((unsigned)nwg), dim3(kThreads), 0, st, A.ptr, A.idx, bwd.B, bwd.nb, bwd.start,
-                       bwd.blk2slot, bwd.sfirst, bwd.scount, bwd.exported, pu->ltab, pu->flags);
+    {
+        StTplArgs tf, tb;
+        tf.B = fwd.B; tf.nb = fwd.nb; tf.start = fwd.start; tf.blk2slot = fwd.blk2slot; tf.sfirst = fwd.sfirst; tf.scount = fwd.scount;
+        tf.exported = fwd.exported; tf.ltab = pl->ltab; tf.flags = pl->flags;
+        tb.B = bwd.B; tb.nb = bwd.nb; tb.start = bwd.start; tb.blk2slot = bwd.blk2slot; tb.sfirst = bwd.sfirst; tb.scount = bwd.scount;
+        tb.exported = bwd.exported; tb.ltab = pu->ltab; tb.flags = pu->flags;
+        hipLaunchKernelGGL(k_st_template_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, A.ptr, A.idx, tf, tb);
+    }
     pu->built = true;
     lm_link_factor(st, fwd, bwd, pu);                   // forward slot -> backward slot of the same chain (flags[3] when there is none)
-    hipLaunchKernelGGL((k_st_link<true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew,
-                       pl->wtab, pl->flags);
-    hipLaunchKernelGGL((k_st_link<false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, pu->ltab, static_cast<const int32_t *>(nullptr),
-                       static_cast<const int32_t *>(nullptr), pu->skew, pu->wtab, pu->flags);
+    hipLaunchKernelGGL(k_st_link_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew, pu->skew,
+                       pl->wtab, pu->wtab, pl->flags, pu->flags);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pu->wtab, pu->flags);
     int32_t *inv = nullptr;
@@ -1450,14 +1491,21 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)nslots, st));
     const unsigned gb = (unsigned)((nslots + 255) / 256);
     hipLaunchKernelGGL(k_st_inv, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv);
-    // the rows pass' lane records (behind nslots unused ints)
+    // the rows pass' lane records (behind nslots unused ints); with them the lane fields and lane-level checks of the factor kernel
+    // that reads A's values where they lie (st_direct.hip; its verdict: pl->flags[8])
+    const bool try_direct = st_direct_prepare(st, A, fwd, pl->flags + 8);
     ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots * 33));
     hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
-                       f->xbase + nslots, pl->flags);
+                       f->xbase + nslots, pl->flags, A.ptr, try_direct ? pl->flags + 8 : static_cast<int32_t *>(nullptr));
+    if (try_direct) st_direct_verify(st, A, fwd, pl, pu, pl->flags + 8);
+    ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
+    ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)nslots, st));
+    hipLaunchKernelGGL(k_lm_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
     // the exchange layouts of both schedules; their sizes come back with the flags (one wait for all)
     int32_t xtot[2][2];
     int32_t *xsz = nullptr;
     void *tmp2 = nullptr;
+    int32_t hl[12], hu[4];
     {
         ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 4));
         PackedSweep *pp[2] = {pl, pu};
@@ -1465,6 +1513,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         size_t tb2 = 0;
         ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, xsz, xsz + nwg, nwg, st));
         ILUPP_HIP(pool_malloc(&tmp2, tb2));
+        D2HItem items[6];
         for (int d = 0; d < 2; ++d) {
             int32_t *sz = xsz + 2 * d * nwg, *off = sz + nwg;
             ILUPP_HIP(pool_malloc(&pp[d]->xe, sizeof(int32_t) * (size_t)nslots));
@@ -1473,13 +1522,13 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
                                pp[d]->xe, pp[d]->xw, sz, pp[d]->flags);
             ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, sz, off, nwg, st));
             hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, off, pp[d]->xw);
-            ILUPP_HIP(d2h_async(st, &xtot[d][0], off + (nwg - 1), sizeof(int32_t)));
-            ILUPP_HIP(d2h_async(st, &xtot[d][1], sz + (nwg - 1), sizeof(int32_t)));
+            items[2 * d] = {&xtot[d][0], off + (nwg - 1), sizeof(int32_t)};
+            items[2 * d + 1] = {&xtot[d][1], sz + (nwg - 1), sizeof(int32_t)};
         }
+        items[4] = {hl, pl->flags, sizeof(hl)};
+        items[5] = {hu, pu->flags, sizeof(hu)};
+        ILUPP_HIP(d2h_async_many(st, items, 6));
     }
-    int32_t hl[4], hu[4];
-    ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
-    ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
     ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(xsz)); ILUPP_HIP(pool_free(tmp2));
     // row slots of the chunks against rows: lines of 8 rows in a 16 x 16 patch (30 steps of skew) are 4.75 slots per row, and
@@ -1499,13 +1548,6 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&pl->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));
     ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));      // (the forward schedule's order: see k_sptrsv_st)
     pl->built = true;
-    // the factor kernel that reads A's values where they lie (st_direct.hip) when the lanes are uniform enough (its checks run
-    // here, their verdict comes back with the last wait below), else factor records made by the rows pass
-    const bool try_direct = st_direct_prepare(st, A, fwd, pl, pu, pl->flags + 8);
-    if (!try_direct) {
-        ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
-        st_pack_values(st, A, pl, pu, f);
-    }
     // vectors travel level-major: the right-hand side and the intermediate vector in the L sweep's order (pl->ybuf, in place), the
     // result in the U sweep's (pu->xlm)
     ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
@@ -1515,29 +1557,26 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     pu->xch_len = (int64_t)xtot[1][0] + xtot[1][1] + 64;
     ILUPP_HIP(pool_malloc(&pl->xch, sizeof(double) * (size_t)pl->xch_len));
     ILUPP_HIP(pool_malloc(&pu->xch, sizeof(double) * (size_t)pu->xch_len));
-    ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
-    ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)nslots, st));
-    hipLaunchKernelGGL(k_lm_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
-    int32_t gl[4], dfl = 0;
-    ILUPP_HIP(d2h_async(st, gl, pl->flags, sizeof(gl)));
-    if (try_direct) ILUPP_HIP(d2h_async(st, &dfl, pl->flags + 8, sizeof(dfl)));
-    ILUPP_HIP(stream_sync(st));
-    if (try_direct && dfl != 0) {
-        if (dbg) fprintf(stderr, "[ilupp] static analysis: lanes not uniform (flags %d): factor records\n", dfl);
+    f->direct = try_direct && hl[8] == 0;
+    if (!f->direct) {
+        // lanes not uniform enough for the direct feed: factor records made by the rows pass (it proves what they rely on, row by row)
+        if (dbg && try_direct) fprintf(stderr, "[ilupp] static analysis: lanes not uniform (flags %d): factor records\n", hl[8]);
         ILUPP_HIP(pool_malloc(&f->pkA, (size_t)pl->nchunks * 4096));
         st_pack_values(st, A, pl, pu, f);
+        int32_t gl[4];
         ILUPP_HIP(d2h_async(st, gl, pl->flags, sizeof(gl)));
         ILUPP_HIP(stream_sync(st));
+        if (dbg) fprintf(stderr, "[ilupp] static analysis: row flags %d, %d+%d chunks\n", gl[0], hl[1], hu[1]);
+        if (gl[0]) { pl->release(); pu->release(); f->release(); return false; }
+    } else if (dbg) {
+        fprintf(stderr, "[ilupp] static analysis: %d+%d chunks, direct feed\n", hl[1], hu[1]);
     }
-    f->direct = try_direct && dfl == 0;
-    if (dbg) fprintf(stderr, "[ilupp] static analysis: row flags %d, %d+%d chunks%s\n", gl[0], hl[1], hu[1], f->direct ? ", direct feed" : "");
-    if (gl[0]) { pl->release(); pu->release(); f->release(); return false; }
     pl->valid = pu->valid = true;
     pl->stat = pu->stat = true;
     pu->linked = true;
     f->built = true;
     f->stat = true;
-    f->values_packed = true;
+    f->values_packed = !f->direct;
     return true;
 }
 

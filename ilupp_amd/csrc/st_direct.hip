@@ -32,18 +32,14 @@
 
 #include "st_common.h"
 
-#ifdef SD_PLAIN_STORE
-#define SD_STORE(v, p) (*(p) = (v))
-#else
 #define SD_STORE(v, p) __builtin_nontemporal_store(v, p)
-#endif
 
 #ifndef SD_CSLEEP
 #define SD_CSLEEP 1
 #endif
 namespace ilupp {
 
-static constexpr int kSdH = 4;                                     // hand-off slots: an in-workgroup dependency lies at most kSdH-1 steps back
+static constexpr int kSdH = kSdHist;                                     // hand-off slots: an in-workgroup dependency lies at most kSdH-1 steps back
 static constexpr int kSdHoLane = 48;                               // bytes per lane and slot: three pairs {pivot, entry right of the diagonal}
 static constexpr int kSdHoRow = kThreads * kSdHoLane + 64 * 16;    // a slot: the lanes' pairs, then the courier's
 static constexpr int kSdPitch = 136;                               // bytes of a lane's piece of a block (128 loaded; 17 x 8: conflict-free 8-byte reads)
@@ -128,18 +124,6 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
     const double absent = st_dbl(kAbsent);
 
     SD_T_DECL(wv == 0 && wg == SD_STAMP_WG);
-    // the record stores of a step are issued during the NEXT step, one at a time between its divisions: the path from the registers
-    // to the memory pipeline takes 16 bytes per cycle and CU -- 64 cycles per 16-byte store instruction, 1024 per step for the
-    // workgroup's 16 KB -- and four stores back to back at the end of a step left every wave waiting at issue for most of that time
-    v2d s_la, s_lb, s_ua, s_ub;
-    s_la.x = s_la.y = s_lb.x = s_lb.y = s_ua.x = s_ua.y = s_ub.x = s_ub.y = 0.0;
-    bool s_ok = false;
-    unsigned char *s_o = pl, *s_ou = pu;
-#define SD_FLUSH(which) do { if (s_ok) { \
-        if (which == 0) SD_STORE(s_la, reinterpret_cast<v2d *>(s_o + lo16)); \
-        if (which == 1) SD_STORE(s_lb, reinterpret_cast<v2d *>(s_o + lo16 + 1024)); \
-        if (which == 2) SD_STORE(s_ua, reinterpret_cast<v2d *>(s_ou + lo16)); \
-        if (which == 3) SD_STORE(s_ub, reinterpret_cast<v2d *>(s_ou + lo16 + 1024)); } } while (0)
     for (int tb = tlo; tb < thi; tb += 8) {
         const int kb = tb - sk;
 #pragma unroll
@@ -165,9 +149,6 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             v2d P[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) P[j] = *reinterpret_cast<const v2d *>(lds + R[j][u % kSdH]);
-#ifdef SD_SPREAD
-            SD_FLUSH(0);
-#endif
 #ifdef SD_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -183,11 +164,7 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
                 bool nan = d != d;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) nan = nan || av[j] != av[j] || up[j] != up[j];
-#ifdef SD_NONAN
-                if (false) {
-#else
                 if (__any(nan)) {
-#endif
                     d = st_clean(d);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { av[j] = st_clean(av[j]); up[j] = st_clean(up[j]); }
@@ -203,10 +180,6 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
                 const double pr = l[j] * P[j].y;
                 const double nw = w3 - pr;
                 w3 = (pj[j] && hasT[j]) ? nw : w3;
-#ifdef SD_SPREAD
-                asm volatile("" : "+v"(w3) :: "memory");
-                SD_FLUSH(j + 1);
-#endif
             }
             {
                 const unsigned long long wb = st_bits(w3);
@@ -225,15 +198,7 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             // pivots that other workgroups read: write-through, to the exchange
             if (EX) { if (exports && valid) st_agent_f64(A.xch + (xoff + (tb + u) * xE), w3); }
             const int cw = tb + u - tminw;
-#ifdef SD_SPREAD
-            s_ok = valid && (unsigned)cw < (unsigned)nchw;
-            s_o = pl + (size_t)(base + cw) * 2048; s_ou = pu + (size_t)(base + cw) * 2048;
-            s_la.x = pj[0] ? l[0] : absent; s_la.y = pj[1] ? l[1] : absent;
-            s_lb.x = pj[2] ? l[2] : absent; s_lb.y = 1.0;
-            s_ua.x = pq[0] ? up[0] : absent; s_ua.y = pq[1] ? up[1] : absent;
-            s_ub.x = pq[2] ? up[2] : absent; s_ub.y = w3;
-            if (false) {
-#elif defined(SD_NOSTORE)
+#ifdef SD_NOSTORE
             if (valid && (unsigned)cw < (unsigned)nchw && w3 == 1.2345e-300) {
 #else
             if (valid && (unsigned)cw < (unsigned)nchw) {
@@ -245,21 +210,15 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
                 SD_STORE(la, reinterpret_cast<v2d *>(o + lo16));
                 SD_STORE(lb, reinterpret_cast<v2d *>(o + lo16 + 1024));
                 unsigned char *ou = pu + (size_t)(base + cw) * 2048;
-#ifndef SD_HALF_STORE
                 v2d ua, ub;
                 ua.x = pq[0] ? up[0] : absent; ua.y = pq[1] ? up[1] : absent;
                 ub.x = pq[2] ? up[2] : absent; ub.y = w3;
                 SD_STORE(ua, reinterpret_cast<v2d *>(ou + lo16));
                 SD_STORE(ub, reinterpret_cast<v2d *>(ou + lo16 + 1024));
-#endif
             }
             SD_T(4);
         }
     }
-#ifdef SD_SPREAD
-    SD_FLUSH(0); SD_FLUSH(1); SD_FLUSH(2); SD_FLUSH(3);
-#endif
-#undef SD_FLUSH
     SD_T_END(0);
 #ifdef SD_STAMP
     if (t == 0 && wg == (int)gridDim.x - 1) { g_sd_stamp[10] = __builtin_amdgcn_s_memtime(); g_sd_stamp[11] = __builtin_amdgcn_s_memrealtime(); }
@@ -515,68 +474,6 @@ k_ilu0_sd(SdArgs A)
 // ---------------------------------------------------------------------------------------------
 // analysis: the lane fields the kernel needs, and the statement about the lanes it relies on (lane level)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_sd_tab(int32_t nslots, int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot,
-                         const int32_t *__restrict__ Aptr, int32_t *__restrict__ dflags)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nslots) return;
-    int32_t *T = ltabF + (size_t)f * kStTab;
-    const int cnt = T[ST_CNT], nd = T[ST_ND];
-    T[ST_P0] = 0; T[ST_DFL] = 0; T[ST_Q] = -1; T[ST_Q + 1] = -1; T[ST_Q + 2] = -1;
-    if (cnt <= 0) return;
-    int bad = 0;
-    const int su = uslot[f];
-    if (su < 0) { atomicOr(dflags, 1); return; }
-    const int32_t *TB = ltabB + (size_t)su * kStTab;
-    const int ndU = TB[ST_ND];
-    if (TB[ST_CNT] != cnt) bad = 1;
-    int ownL = 0, ownU = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (j < nd) {
-            const int ty = T[ST_SRC + j] & 3;
-            if (ty == ST_OWN) {
-                // the own-chain entry: column r - 1, the last one left of the diagonal
-                if (j != nd - 1 || T[ST_OFF + j] != -1) bad = 1;
-                ownL = 1;
-            } else {
-                // every row of the lane has the entry, and its producer is where the template says
-                if (T[ST_KLO + j] > 0 || T[ST_KHI + j] < cnt) bad = 1;
-                if (ty == ST_LOCAL && (T[ST_DT + j] < 1 || T[ST_DT + j] > kSdH - 1)) bad = 1;
-            }
-        }
-        if (j < ndU) {
-            const int ty = TB[ST_SRC + j] & 3;
-            if (ty == ST_OWN) {
-                if (j != 0 || TB[ST_OFF + j] != 1) bad = 1;
-                ownU = 1;
-            } else {
-                if (TB[ST_KLO + j] > 0 || TB[ST_KHI + j] < cnt) bad = 1;
-            }
-        }
-    }
-    // the transposed entry of dependency j: the entry of the pivot row's right side whose offset is the opposite one
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        int q = -1;
-        if (j < nd) {
-            const int os = T[ST_SRC + j] >> 2;
-            const int pu = uslot[os];
-            if (pu < 0) {
-                bad = 1;
-            } else {
-                const int32_t *TP = ltabB + (size_t)pu * kStTab;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) if (p < TP[ST_ND] && TP[ST_OFF + p] == -T[ST_OFF + j]) q = p;
-            }
-        }
-        T[ST_Q + j] = q;
-    }
-    T[ST_P0] = Aptr[T[ST_FIRST]];
-    T[ST_DFL] = ndU | (ownL << 2) | (ownU << 3) | ((nd + 1 + ndU) << 4);
-    if (bad) atomicOr(dflags, 2);
-}
-
 // the statement, row by row (pattern only): row k of a lane starts at p0 + k m (- 1 behind the first row when the chain entry
 // exists), and its columns are the template's -- r + oL, r, r + oU -- without r - 1 in the first row and r + 1 in the last
 __global__ void __launch_bounds__(256)
@@ -621,21 +518,23 @@ k_sd_proof(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restric
 // ---------------------------------------------------------------------------------------------
 // The checks of the premise.  Row level: every block of the schedule is one whole chain and the rows of every chain are alike
 // (found by the first pass over the pattern, symbolic.hip: Schedule::chains) -- then the lane templates, taken from three sampled
-// rows, hold for every row.  Lane level: k_sd_tab, launched here; dflags (device, one int, zeroed here) is non-zero afterwards
-// when the matrix is not one for this kernel.  ILUPP_SD_VERIFY=1 also runs the row-by-row statement (k_sd_proof).
-bool st_direct_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, int32_t *dflags)
+// rows, hold for every row.  Lane level: sd_tab_lane (st_common.h; run by k_st_scat); dflags (device, one int, zeroed by the caller)
+// is non-zero afterwards when the matrix is not one for this kernel.  ILUPP_SD_VERIFY=1 also runs the row-by-row statement (k_sd_proof).
+bool st_direct_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, int32_t *dflags)
 {
     static const bool off = getenv("ILUPP_NO_DIRECT") != nullptr;
-    static const bool verify = getenv("ILUPP_SD_VERIFY") != nullptr;
     // (the producers address A's values with 32-bit byte offsets)
     if (off || !fwd.chains || !A.val || (A.nnz + 4) * 8 >= 0x7fffffffLL) return false;
-    const int nslots = fwd.nslots;
     ILUPP_HIP(hipMemsetAsync(dflags, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_sd_tab, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, A.ptr, dflags);
-    if (verify)
-        hipLaunchKernelGGL(k_sd_proof, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.ptr, A.idx, (int64_t)A.nnz, fwd.B, fwd.nb,
-                           fwd.start, fwd.blk2slot, pl->ltab, pu->ltab, pu->uslot, dflags);
     return true;
+}
+// (tests, ILUPP_SD_VERIFY=1: the row-by-row statement next to the light one; after k_st_scat has made the lane fields)
+void st_direct_verify(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, int32_t *dflags)
+{
+    static const bool verify = getenv("ILUPP_SD_VERIFY") != nullptr;
+    if (!verify) return;
+    hipLaunchKernelGGL(k_sd_proof, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.ptr, A.idx, (int64_t)A.nnz, fwd.B, fwd.nb,
+                       fwd.start, fwd.blk2slot, pl->ltab, pu->ltab, pu->uslot, dflags);
 }
 
 int ilu0_numeric_sd(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,

@@ -60,6 +60,43 @@ hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t
     s.used += (bytes + 15) & ~(size_t)15;
     return hipGetLastError();
 }
+// several read-backs with ONE launch (a launch costs about 4 us of stream time; an analysis has a dozen read-backs)
+struct CopyList { const int *src[8]; int off[8]; int words[8]; int n; };
+__global__ void k_copy_words_many(CopyList L, int *__restrict__ dst)
+{
+    for (int e = 0; e < L.n; ++e)
+        for (int i = threadIdx.x; i < L.words[e]; i += blockDim.x) dst[L.off[e] + i] = L.src[e][i];
+}
+hipError_t d2h_async_many(hipStream_t st, const D2HItem *items, int n)
+{
+    bool fits = n <= 8;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        Staging &s = g_stage[st];
+        size_t need = 0;
+        for (int e = 0; e < n && fits; ++e) {
+            if ((items[e].bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(items[e].src) & 3) != 0) fits = false;
+            need += (items[e].bytes + 15) & ~(size_t)15;
+        }
+        if (!s.host || s.used + need > kStageBytes) fits = false;
+        if (fits) {
+            CopyList L;
+            L.n = n;
+            for (int e = 0; e < n; ++e) {
+                L.src[e] = static_cast<const int *>(items[e].src); L.off[e] = (int)(s.used / 4); L.words[e] = (int)(items[e].bytes / 4);
+                s.pending.push_back({items[e].dst, s.used, items[e].bytes});
+                s.used += (items[e].bytes + 15) & ~(size_t)15;
+            }
+            hipLaunchKernelGGL(k_copy_words_many, dim3(1), dim3(64), 0, st, L, reinterpret_cast<int *>(s.dev));
+            return hipGetLastError();
+        }
+    }
+    for (int e = 0; e < n; ++e) {
+        const hipError_t err = d2h_async(st, items[e].dst, items[e].src, items[e].bytes);
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
+}
 // after a failure: destinations of read-backs still pending may be gone (stack variables of the frames that threw)
 void d2h_cancel_all()
 {
@@ -302,10 +339,11 @@ __global__ void k_row_cuts_counts(int32_t n, const int32_t *__restrict__ ptr, co
             }
         }
         // the row before, from the lane before (the first lane of a wave reads it)
+        // (DPP wave shift: one VALU instruction each; __shfl_up goes through the LDS crossbar)
         Row8 prv;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) prv.c[i] = __shfl_up(row.c[i], 1);
-        int plen = __shfl_up(hi - lo, 1);
+        for (int i = 0; i < 8; ++i) prv.c[i] = __builtin_amdgcn_update_dpp(0, row.c[i], 0x138, 0xf, 0xf, false);
+        int plen = __builtin_amdgcn_update_dpp(0, hi - lo, 0x138, 0xf, 0xf, false);
         if ((threadIdx.x & 63) == 0 && live && r > 0) {
             const int plo = ptr[r - 1];
             plen = lo - plo;
