@@ -10,7 +10,7 @@ A "step" = one complete ILU(0) factorisation of the device-resident CSR matrix (
 i.e. exactly what `P = ilupp.ILU0Preconditioner(A); P.apply(x)` does, with A and x already in HBM
 when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu] [--config C2|C3|C4|S27|S9]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu] [--no-extra] [--config C3|C4|ILUC|S27|S9]
 
 N > 1: the path does not shard (a single factorisation is one dependency chain), so every rank
 factors its own matrix of a batch (weak scaling, no data-path collective; RCCL only for the barrier,
@@ -18,6 +18,8 @@ the max-over-ranks time and one gather of per-matrix records).  Launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU);
 run without a launcher, `--gpus N` starts that launcher itself -- before anything touches the GPU.
 
+The default run (one GPU) also measures C3, C4 and one ILUC config after the headline one (about 20 s; --no-extra skips them)
+and a re-factorisation with new values on the analysed pattern ("refactor").
 --config C3 / C4 add the other BASELINE configs as extra keys of the same JSON line ("extra"):
 ILUT(10, 1e-4) on the random diagonally dominant matrix with n = 1e6, ICholT(0, 0) on the 256^3 matrix
 (bytes = read A + write the factors actually produced).  --config S27 / S9: ILU(0) beyond 7-point rows (27-point box
@@ -63,8 +65,12 @@ def measured_traffic(kernel, g):
         return None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")), reverse=True):
         try:
-            k = json.load(open(f))["kernels"]["ilupp::" + kernel]
-            return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
+            ks = json.load(open(f))["kernels"]
+            for name, k in ks.items():
+                if name.split("(")[0].split("<")[0].split("::")[-1] == kernel.split("<")[0]:
+                    if "<" in kernel and kernel not in name:
+                        continue
+                    return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
         except Exception:
             continue
     return None
@@ -131,6 +137,10 @@ def extra_config(name, dev, steps):
         d, i, p = matgen.random_dd(1000000, 19, 25.0, 12345)
         make = lambda a: _native.ILUTPreconditioner_device(*a, True, 10, 1e-4)
         what = "C3: ILUTPreconditioner(fill_in=10, threshold=1e-4), random diagonally dominant CSR n=1e6"
+    elif name == "ILUC":
+        d, i, p = matgen.poisson3d(128)
+        make = lambda a: _native.ILUCPreconditioner_device(*a, True, 8, 1e-2)
+        what = "ILUC: ILUCPreconditioner(fill_in=8, threshold=1e-2), 3-D 7-point Laplacian 128^3"
     elif name in ("S27", "S9"):
         # ILU(0) beyond the 7-point rows of the headline: box stencils (eliminations meet off-diagonal entries)
         dims = (128, 128, 128) if name == "S27" else (2048, 2048)
@@ -183,8 +193,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "S27", "S9"],
-                    help="extra BASELINE configs measured after the headline one (C2 is always the bench line)")
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "ILUC", "S27", "S9"],
+                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, ILUC)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, ILUC) and the refactor loop")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -256,6 +267,31 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     path = P.path()
+    # numeric re-factorisation with NEW values on the analysed pattern + one apply (what a time-stepping caller pays per step),
+    # timed the same way: ilupp_hip_ilu0_refactor_device reads the new value array where it lies
+    refac = None
+    if not args.no_extra and world == 1:
+        td2 = td * 1.0009765625
+        torch.cuda.synchronize()
+        rn, ra = [], []
+        for _ in range(2):
+            P.refactor_device(td2.data_ptr(), ti.data_ptr(), tp.data_ptr())
+        k = max(3, min(args.steps, 10))
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for it in range(k):
+            P.refactor_device((td2 if it % 2 == 0 else td).data_ptr(), ti.data_ptr(), tp.data_ptr())
+            tx = txs[it % nrhs]
+            P.apply_device(tx.data_ptr(), n, transpose=False, sync=True)
+            t = P.timings()
+            rn.append(t["numeric_ms"]); ra.append(t["last_apply_ms"])
+        torch.cuda.synchronize()
+        rwall = (time.perf_counter() - r0) / k
+        refac = {"ms_per_step": 1e3 * rwall, "steps": k, "numeric_ms": float(np.median(rn)), "apply_ms": float(np.median(ra)),
+                 "what": "ilupp_hip_ilu0_refactor_device (new values, analysed pattern) + one apply, wall clock per step"}
+        # leave the object with the original values (the checksum below is of A itself)
+        P.refactor_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr())
+        del td2
     # apply(ones) with the last factorisation (untimed): compared, as an array, with the CPU leg's
     tx = txs[0]
     tx.fill_(1.0)
@@ -315,10 +351,19 @@ def main():
         med = lambda v: float(np.median(v)) if v else 0.0
         k_num = med(knum_ms)         # numeric factor kernel alone (HIP events on the library's stream)
         gpu_ms = med(fac_ms) + med(app_ms)
-        reuse_ms = med(num_ms) + med(app_ms)
         kernel = FACTOR_KERNEL.get(path, path)
-        # dominant kernel = the numeric factorisation sweep; its algorithmic bytes = the factor bytes of
-        # read A once + write L and U once
+        # dominant kernel = the numeric factorisation sweep (the longest kernel of the step); its algorithmic bytes = the
+        # factor bytes of SURVEY.md section 8(d): read A once + write L and U once
+        step_s = wall / args.steps
+        phases = [
+            {"name": kernel, "what": "numeric factorisation kernel", "ms": k_num, "algorithmic_bytes": fb, "traffic": measured_traffic(kernel, g)},
+            {"name": "analysis (k_row_cuts_counts + lane tables, ~20 launches)", "what": "pattern analysis and schedule, whole phase",
+             "ms": med(ana_ms), "algorithmic_bytes": None, "traffic": measured_traffic("k_row_cuts_counts", g)},
+            {"name": "k_st_vec<1, true> + k_sptrsv_st<1, false>", "what": "L solve, whole phase", "ms": med(ls_ms),
+             "algorithmic_bytes": ab // 2, "traffic": measured_traffic("k_sptrsv_st<1, false>", g)},
+            {"name": "k_sptrsv_st<-1, false> + k_st_vec<-1, false>", "what": "U solve, whole phase", "ms": med(us_ms),
+             "algorithmic_bytes": ab - ab // 2, "traffic": measured_traffic("k_sptrsv_st<-1, false>", g)},
+        ]
         out = {
             "metric": "ILU(0) factor+apply nnz/s, 3-D 7-pt Poisson fp64",
             "value": world * nnz / (wall / args.steps),
@@ -339,9 +384,7 @@ def main():
                        "lsolve": med(ls_ms), "usolve": med(us_ms), "factor_plus_apply": gpu_ms,
                        "numeric_kernel": k_num},
             "gpu_event_value_nnz_per_s": nnz / (gpu_ms * 1e-3) if gpu_ms > 0 else None,
-            "pattern_reuse_value_nnz_per_s": nnz / (reuse_ms * 1e-3) if reuse_ms > 0 else None,
             "hbm_fraction_factor_plus_apply": ((fb + ab) / (gpu_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gpu_ms > 0 else None,
-            "hbm_fraction_pattern_reuse": ((fb + ab) / (reuse_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if reuse_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": (fb / (k_num * 1e-3) / 1e9) if k_num > 0 else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -349,10 +392,18 @@ def main():
                          "traffic": measured_traffic(kernel, g),
                          "algorithmic_bytes_per_launch": fb,
                          "avg_launch_ms": k_num,
+                         # the whole step against the roofline: factor + apply bytes of section 8(d) over the wall clock of a step
+                         "step_frac": ((fb + ab) / step_s / 1e9) / HBM_PEAK_GBS,
+                         "step_algorithmic_bytes": fb + ab,
+                         "phases": phases,
                          "copy_GBs_measured": copy_gbs,
                          "frac_of_measured_copy": ((fb / (k_num * 1e-3) / 1e9) / copy_gbs) if (k_num > 0 and copy_gbs) else None},
             "checksum": checksum,
         }
+        if refac is not None:
+            refac["hbm_fraction"] = ((fb + ab) / (refac["ms_per_step"] * 1e-3) / 1e9) / HBM_PEAK_GBS
+            refac["value_nnz_per_s"] = nnz / (refac["ms_per_step"] * 1e-3)
+            out["refactor"] = refac
         if batch is not None:
             out["batch"] = batch
         if not args.no_cpu and world == 1:
@@ -367,8 +418,11 @@ def main():
         else:
             out["cpu_baseline"] = None
         extra = {}
-        for cfg in args.config:
-            if cfg in ("C3", "C4", "S27", "S9") and world == 1:
+        cfgs = list(args.config)
+        if not args.no_extra and world == 1:
+            cfgs = [c for c in ("C3", "C4", "ILUC") if c not in cfgs] + cfgs
+        for cfg in cfgs:
+            if cfg in ("C3", "C4", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))

@@ -78,6 +78,11 @@ def lib():
     L.ilupp_hip_apply_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     L.ilupp_hip_sync.argtypes = [_VP]
     L.ilupp_hip_release_cached_memory.argtypes = []
+    L.ilupp_hip_set_cache_limit.argtypes = [ctypes.c_ulonglong]
+    L.ilupp_hip_cached_bytes.argtypes = []
+    L.ilupp_hip_cached_bytes.restype = ctypes.c_ulonglong
+    L.ilupp_hip_live_blocks.argtypes = []
+    L.ilupp_hip_live_blocks.restype = ctypes.c_ulonglong
     L.ilupp_hip_total_nnz.argtypes = [_VP]
     L.ilupp_hip_total_nnz.restype = ctypes.c_int64
     for name in ("memory_used_calculations", "memory_allocated_calculations", "memory"):
@@ -112,7 +117,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_exists", "ilupp_hip_special_info", "ilupp_hip_print_info", "ilupp_hip_dimension",
     "ilupp_hip_num_factors", "ilupp_hip_factor_info", "ilupp_hip_factor_copy",
     "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
-    "ilupp_hip_sync", "ilupp_hip_release_cached_memory", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
+    "ilupp_hip_sync", "ilupp_hip_release_cached_memory", "ilupp_hip_set_cache_limit", "ilupp_hip_cached_bytes", "ilupp_hip_live_blocks", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
     "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_spmv_device",
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
 ]
@@ -331,6 +336,21 @@ def IChol0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr):
 def ICholTPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, add_fill_in, threshold):
     return _create_device(lib().ilupp_hip_icholt_create_device, d_data, d_indices, d_indptr, n, is_csr,
                           ctypes.c_int32(int(add_fill_in)), ctypes.c_double(float(threshold)))
+
+
+def set_cache_limit(nbytes):
+    """limit (bytes) of the device buffers kept for the next construction (include/ilupp_hip.h: ilupp_hip_set_cache_limit)"""
+    rc = lib().ilupp_hip_set_cache_limit(ctypes.c_ulonglong(int(nbytes)))
+    if rc:
+        _raise(rc)
+
+
+def cached_bytes():
+    return int(lib().ilupp_hip_cached_bytes())
+
+
+def live_blocks():
+    return int(lib().ilupp_hip_live_blocks())
 
 
 def release_cached_memory():

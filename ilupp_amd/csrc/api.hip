@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "pool.h"
 
 namespace ilupp {
 
@@ -44,81 +45,52 @@ void Ilu0Program::release()
     prow = prog = nullptr; nwords = 0;
 }
 
-// ---- pooled device memory ---------------------------------------------------------------------
+// ---- pooled device memory (pool.h) ------------------------------------------------------------
 namespace {
-struct Pool {
-    std::mutex mu;
-    std::multimap<std::pair<int, size_t>, std::pair<void *, size_t>> free_blocks;     // (device, size) -> (block, age stamp)
-    std::unordered_map<void *, std::pair<int, size_t>> live;       // block -> (device, size)
-    size_t cached = 0;
-    size_t gen = 0;
-    static constexpr size_t kMaxCached = 96ull << 30;   // of 288 GB HBM (ILUC on a 256^3 mesh holds 2 x 17 GB of touch records per attempt: with 24 GB they went back to the driver every time, 0.96 s of its 1.25 s)
-} g_pool;
+int be_alloc(void **p, size_t bytes)
+{
+    const hipError_t e = ::hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return (int)e;
+}
+int be_release(void *p) { return (int)::hipFree(p); }
+int be_device() { int dev = 0; (void)hipGetDevice(&dev); return dev; }      // a kept block is only ever handed back on the GPU it lives on
+size_t default_cache_limit()
+{
+    // ILUC on a 256^3 mesh keeps 2 x 17 GB of touch records per attempt (with 24 GB they went back to the driver every time, 0.96 s
+    // of its 1.25 s); a process that shares the GPU lowers the limit (ilupp_hip_set_cache_limit, ILUPP_CACHE_LIMIT_MB)
+    const char *s = getenv("ILUPP_CACHE_LIMIT_MB");
+    if (s && *s) return (size_t)strtoull(s, nullptr, 10) << 20;
+    return (size_t)48 << 30;
+}
+BlockPool &pool()
+{
+    static BlockPool g(PoolBackend{be_alloc, be_release, be_device}, default_cache_limit());
+    return g;
+}
 }  // namespace
 
 hipError_t pool_malloc(void **p, size_t bytes)
 {
-    if (bytes == 0) bytes = 16;
-    bytes = (bytes + 255) & ~(size_t)255;
-    int dev = 0;
-    (void)hipGetDevice(&dev);                      // a cached block is only ever handed back on the GPU it lives on
-    {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        auto it = g_pool.free_blocks.find({dev, bytes});
-        if (it != g_pool.free_blocks.end()) {
-            *p = it->second.first;
-            g_pool.free_blocks.erase(it);
-            g_pool.cached -= bytes;
-            g_pool.live[*p] = {dev, bytes};
-            return hipSuccess;
-        }
-    }
-    hipError_t e = ::hipMalloc(p, bytes);
-    if (e != hipSuccess) {          // out of memory: give the cache back and retry once
-        pool_trim();
-        (void)hipGetLastError();
-        e = ::hipMalloc(p, bytes);
-    }
-    if (e == hipSuccess) {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        g_pool.live[*p] = {dev, bytes};
-    }
-    return e;
+    const int e = pool().acquire(p, bytes);
+    return e == 0 ? hipSuccess : (hipError_t)e;
 }
 
 hipError_t pool_free(void *p)
 {
-    if (!p) return hipSuccess;
-    {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        auto it = g_pool.live.find(p);
-        if (it == g_pool.live.end()) {
-            // not a block the pool has handed out.  One that already sits in the kept list (freed twice) must not go back to the driver
-            for (auto &kv : g_pool.free_blocks)
-                if (kv.second.first == p) {
-                    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] pool: block of %zu bytes freed twice\n", kv.first.second);
-                    return hipSuccess;
-                }
-            return ::hipFree(p);
-        }
-        const std::pair<int, size_t> key = it->second;
-        g_pool.live.erase(it);
-        if (g_pool.cached + key.second <= Pool::kMaxCached) {
-            g_pool.free_blocks.emplace(key, std::make_pair(p, g_pool.gen));
-            g_pool.cached += key.second;
-            return hipSuccess;
-        }
+    const int e = pool().release(p);
+    if (e == BlockPool::kNotLive) {
+        // never ignored: a block freed twice may meanwhile belong to somebody else
+        set_error("internal error: a device block was released that the pool had not handed out (double release?)");
+        return hipErrorInvalidValue;
     }
-    return ::hipFree(p);
+    return e == 0 ? hipSuccess : hipErrorUnknown;
 }
 
-void pool_trim()
-{
-    std::lock_guard<std::mutex> lk(g_pool.mu);
-    for (auto &kv : g_pool.free_blocks) (void)::hipFree(kv.second.first);
-    g_pool.free_blocks.clear();
-    g_pool.cached = 0;
-}
+void pool_trim() { pool().trim(); }
+void pool_set_limit(size_t bytes) { pool().set_limit(bytes); }
+size_t pool_cached_bytes() { return pool().cached(); }
+size_t pool_live_blocks() { return pool().live_blocks(); }
 
 // Ordering against the caller's own HIP stream (device-pointer entry points): when set for this thread, every *_device
 // call first makes the object's queue wait for the work already submitted to that stream (the producer of the matrix /
@@ -1264,6 +1236,16 @@ int ilupp_hip_release_cached_memory(void)
     return ILUPP_OK;
     API_CATCH
 }
+
+int ilupp_hip_set_cache_limit(unsigned long long bytes)
+{
+    API_TRY
+    pool_set_limit((size_t)bytes);
+    return ILUPP_OK;
+    API_CATCH
+}
+unsigned long long ilupp_hip_cached_bytes(void) { return (unsigned long long)pool_cached_bytes(); }
+unsigned long long ilupp_hip_live_blocks(void) { return (unsigned long long)pool_live_blocks(); }
 
 int ilupp_hip_sync(ilupp_precond *p)
 {

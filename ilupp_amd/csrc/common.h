@@ -27,6 +27,21 @@ struct HipError { hipError_t code; const char *what; const char *file; int line;
 hipError_t pool_malloc(void **p, size_t bytes);
 hipError_t pool_free(void *p);
 void pool_trim();
+void pool_set_limit(size_t bytes);
+size_t pool_cached_bytes();
+size_t pool_live_blocks();
+// a block that goes back to the pool when the scope ends (work arrays of a factorisation attempt: an ILUPP_HIP that throws in the
+// middle of one would otherwise leak all of them)
+struct PoolBlock {
+    void *p = nullptr;
+    PoolBlock() {}
+    PoolBlock(const PoolBlock &) = delete;
+    PoolBlock &operator=(const PoolBlock &) = delete;
+    ~PoolBlock() { if (p) (void)pool_free(p); }
+    hipError_t alloc(size_t bytes) { if (p) { (void)pool_free(p); p = nullptr; } return pool_malloc(&p, bytes); }
+    void *release() { void *q = p; p = nullptr; return q; }                  // the caller takes the block over
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
 template <class T> inline hipError_t pool_malloc(T **p, size_t bytes) { return pool_malloc(reinterpret_cast<void **>(p), bytes); }
 
 // ---- device containers ----------------------------------------------------------------------

@@ -1266,41 +1266,56 @@ k_st_vec(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, dou
     __shared__ double tile[32][65];
     const int w = blockIdx.x;
     const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
-    const int c0 = blockIdx.y * 32;
-    if (c0 >= nch) return;
     const int t = threadIdx.x;
     // natural-order role: lane l, elements j = sub*4 .. sub*4+3 of its run (chunk c0 + j)
     const int l = t >> 3, sub = t & 7;
     const v4i t0 = *reinterpret_cast<const v4i *>(ltab + (size_t)((w >> 2) * kThreads + (w & 3) * 64 + l) * kStTab);      // first, cnt, skew, nd
     // level-major role: chunk c0 + (t >> 6) + 8 i, lane t & 63
     const int ll = t & 63, cw = t >> 6;
-    if (TO_LM) {
+    // a block takes every gridDim.y-th group of 32 chunks of its wave; the loads of the next group are in flight while this one
+    // is stored (a block per group was 9 000 short-lived blocks, each a chain of table -> loads -> LDS -> stores: 2.7 TB/s)
+    double v[4];
+#define STV_LOAD(c0_)                                                                                   \
+    do {                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+            if (TO_LM) {                                                                                \
+                const int j = sub * 4 + q;                                                              \
+                const int k = (c0_) + j + tmin - t0.z;                                                  \
+                v[q] = (k >= 0 && k < t0.y) ? nat[t0.x + DR * k] : 0.0;                                 \
+            } else {                                                                                    \
+                const int j = cw + 8 * q;                                                               \
+                v[q] = ((c0_) + j < nch) ? lm[((size_t)base + (c0_) + j) * 64 + ll] : 0.0;              \
+            }                                                                                           \
+        }                                                                                               \
+    } while (0)
+    int c0 = blockIdx.y * 32;
+    if (c0 >= nch) return;
+    STV_LOAD(c0);
+    for (; c0 < nch; c0 += gridDim.y * 32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int j = sub * 4 + q;
-            const int k = c0 + j + tmin - t0.z;
-            tile[j][l] = (k >= 0 && k < t0.y) ? nat[t0.x + DR * k] : 0.0;
+            if (TO_LM) tile[sub * 4 + q][l] = v[q]; else tile[cw + 8 * q][ll] = v[q];
         }
         __syncthreads();
+        const int cn = c0 + gridDim.y * 32;
+        double o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = cw + 8 * i;
-            if (c0 + j < nch) lm[((size_t)base + c0 + j) * 64 + ll] = tile[j][ll];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = cw + 8 * i;
-            tile[j][ll] = (c0 + j < nch) ? lm[((size_t)base + c0 + j) * 64 + ll] : 0.0;
-        }
-        __syncthreads();
+        for (int q = 0; q < 4; ++q) o[q] = TO_LM ? tile[cw + 8 * q][ll] : tile[sub * 4 + q][l];
+        if (cn < nch) STV_LOAD(cn);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int j = sub * 4 + q;
-            const int k = c0 + j + tmin - t0.z;
-            if (k >= 0 && k < t0.y && c0 + j < nch) nat[t0.x + DR * k] = tile[j][l];
+            if (TO_LM) {
+                const int j = cw + 8 * q;
+                if (c0 + j < nch) lm[((size_t)base + c0 + j) * 64 + ll] = o[q];
+            } else {
+                const int j = sub * 4 + q;
+                const int k = c0 + j + tmin - t0.z;
+                if (k >= 0 && k < t0.y && c0 + j < nch) nat[t0.x + DR * k] = o[q];
+            }
         }
+        __syncthreads();
     }
+#undef STV_LOAD
 }
 
 template <int KIND>
@@ -1625,6 +1640,8 @@ static void st_solo_attr_T()
     });
 }
 
+static inline int st_vec_groups(int max_chunks) { const int g = (max_chunks + 31) / 32; return g < 3 ? (g < 1 ? 1 : g) : 3; }
+
 // One sweep of an apply.  Forward: `rhs` (natural order) -> the intermediate vector in `ypk_out` (the forward sweep's ybuf, in the
 // forward sweep's level-major order); backward: `ypk_in` (the same buffer) -> the result in `out` (natural order).
 int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
@@ -1656,7 +1673,7 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
     }
     if (ps.pair) st_solo_attr_T();
     if (fwd) {
-        hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+        hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)st_vec_groups(ps.max_chunks)), dim3(512), 0, st, ps.ltab, ps.wtab,
                            const_cast<double *>(rhs), lml);
         // (a pair of stored factors: the forward factor has a diagonal of its own)
         if (ps.pair) hipLaunchKernelGGL((k_sptrsv_st<1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
@@ -1664,7 +1681,7 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
     } else {
         if (ps.pair && ps.desc) hipLaunchKernelGGL((k_sptrsv_st<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
         else hipLaunchKernelGGL((k_sptrsv_st<-1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
-        hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+        hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)st_vec_groups(ps.max_chunks)), dim3(512), 0, st, ps.ltab, ps.wtab,
                            out, ps.xlm);
     }
     ILUPP_HIP(hipGetLastError());
@@ -2035,12 +2052,12 @@ int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *
     const dim3 grid((unsigned)ps.nwg);
     st_solo_attr_T();
     if (fwd) {
-        hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+        hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)st_vec_groups(ps.max_chunks)), dim3(512), 0, st, ps.ltab, ps.wtab,
                            const_cast<double *>(rhs), lml);
         hipLaunchKernelGGL((k_sptrsv_st<1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
         hipLaunchKernelGGL((k_sptrsv_st<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
-        hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)((ps.max_chunks + 31) / 32)), dim3(512), 0, st, ps.ltab, ps.wtab,
+        hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)st_vec_groups(ps.max_chunks)), dim3(512), 0, st, ps.ltab, ps.wtab,
                            out, ps.xlm);
     }
     ILUPP_HIP(hipGetLastError());

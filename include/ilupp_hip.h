@@ -168,10 +168,16 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
                                    const int32_t *d_indptr);
 /* wait for asynchronous applies (ilupp_hip_apply_device with sync=0) and report their status */
 int ilupp_hip_sync(ilupp_precond *p);
-/* The library keeps freed device buffers (up to 96 GB per process) for the next construction: a factorisation that is repeated asks
- * for the same sizes again and hipMalloc / hipFree of multi-GB buffers cost more than the kernels.  This hands them back to the
- * driver (no counterpart in binding.cpp: the reference's buffers are host memory). */
+/* The library keeps freed device buffers (up to a limit, the oldest go first) for the next construction: a factorisation that is
+ * repeated asks for the same sizes again and hipMalloc / hipFree of multi-GB buffers cost more than the kernels.  This hands them
+ * back to the driver (no counterpart in binding.cpp: the reference's buffers are host memory). */
 int ilupp_hip_release_cached_memory(void);
+/* the limit of that cache in bytes (default 48 GiB, or ILUPP_CACHE_LIMIT_MB; 0 = keep nothing); blocks over the new limit are
+ * handed back at once.  A process that shares the GPU with other allocators sets this before its first factorisation. */
+int ilupp_hip_set_cache_limit(unsigned long long bytes);
+/* bytes currently kept in the cache / blocks currently handed out (diagnostics; a leak shows as blocks that never come back) */
+unsigned long long ilupp_hip_cached_bytes(void);
+unsigned long long ilupp_hip_live_blocks(void);
 
 #ifdef __cplusplus
 }

@@ -407,13 +407,14 @@ def test_batched_two_gpus():
 def test_bench_single_gpu_line():
     """bench.py's contract on a small grid: one JSON line with roofline, cpu_baseline and an ARRAY parity verdict"""
     import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "48"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "48", "--no-extra"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and line, r.stdout + r.stderr
     out = json.loads(line[-1])
     assert out["n_gpus"] == 1 and out["parity"]["apply_ones_equal"] is True
-    assert out["roofline"]["kernel"] == "k_ilu0_st" and out["roofline"]["frac"] > 0
+    assert out["roofline"]["kernel"] == "k_ilu0_sd" and out["roofline"]["frac"] > 0 and out["roofline"]["step_frac"] > 0
+    assert [ph["name"] for ph in out["roofline"]["phases"]][0] == "k_ilu0_sd"
     assert out["cpu_baseline"]["kind"] in ("reference", "port") and out["cpu_baseline"]["apply_paths_agree"]
 
 
