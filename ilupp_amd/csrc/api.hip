@@ -735,7 +735,9 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
 // ILUC: A = the major-order view (CSR arrays of the input, whatever its orientation: ILUC2 works on dim_along_orientation)
 static int iluc_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
-    ilupp_precond *p = new_obj(n);
+    // (guards: an ILUPP_HIP that throws below must leave neither the object nor the factors behind)
+    struct ObjGuard { ilupp_precond *p; ~ObjGuard() { if (p) destroy_obj(p); } } og{new_obj(n)};
+    ilupp_precond *p = og.p;
     p->kind = KIND_UTU;
     p->nnz_mode = NNZ_GENERIC_LU;
     p->input_csc = !is_csr;
@@ -743,7 +745,8 @@ static int iluc_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill
     ILUPP_HIP(hipEventRecord(p->ev[0], st));
     int32_t err_row = -1;
     float kms = 0.f;
-    DevMat Lcol, Urow;             // L by columns (unit diagonal first), U by rows (pivot first)
+    struct MatGuard { DevMat m; ~MatGuard() { m.release(); } } gl, gu;
+    DevMat &Lcol = gl.m, &Urow = gu.m;             // L by columns (unit diagonal first), U by rows (pivot first)
     int rc = iluc_factor(st, A, max_fill_in, threshold, &Lcol, &Urow, &err_row, &kms);
     ILUPP_HIP(hipEventRecord(p->ev[1], st));
     A.release();
@@ -751,13 +754,12 @@ static int iluc_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill
         if (rc == ILUPP_ERR_ZERO_PIVOT) set_error("ILUC2: zero pivot on diagonal, k=" + std::to_string(err_row));               // ILUC.hpp:174-175
         else if (rc == ILUPP_ERR_MEMORY) set_error("append_row_with_prefix: insufficient memory reserved");                       // sparse_implementation.h:3196-3197
         else if (rc == ILUPP_ERR_TIMEOUT) set_error("ILUC: dependency wait timed out");
-        destroy_obj(p);
         return rc;
     }
     // ROW input: left = L (columns), right = U (rows); COLUMN input: ILUC2(A, right, left): left = U of the view, right = L of the
     // view (preconditioner_implementation.h:940-951) -- and iluc() interchanges the same way (binding.cpp:456-457)
     if (is_csr) { p->Lc = Lcol; p->Uc = Urow; } else { p->Lc = Urow; p->Uc = Lcol; }
-    Lcol.owns = Urow.owns = false;
+    Lcol.ptr = Lcol.idx = nullptr; Lcol.val = nullptr; Urow.ptr = Urow.idx = nullptr; Urow.val = nullptr;      // (the object owns them now)
     int32_t m1 = 0, m2 = 0;
     count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);
     count_cuts_and_schedule(st, n, p->Uc.ptr, p->Uc.idx, p->max_lanes, nullptr, &p->sU, &m2);
@@ -777,6 +779,7 @@ static int iluc_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
     p->tm.numeric_kernel_ms = kms;
     *out = p;
+    og.p = nullptr;
     return ILUPP_OK;
 }
 

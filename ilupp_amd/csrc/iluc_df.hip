@@ -600,31 +600,37 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     while (T > 16 && ((long)m * T > 0x7fffffffL || (size_t)m * T * 64 > ((size_t)64 << 30))) T /= 2;
     if ((long)m * T > 0x7fffffffL || (size_t)m * T * 64 > ((size_t)64 << 30)) return 1;
 
-    int32_t *pending, *colcnt, *colptr, *colpos, *colord, *rowof, *fillc, *Uidx, *Lidx, *Ulen, *Llen, *cntL, *cntU, *rq, *ctrl;
-    double *Uval, *Lval;
-    unsigned long long *recL, *recU;
+    // (work arrays in holders that give them back when the scope ends: an ILUPP_HIP that throws in the middle must not leak them)
+    PoolBlock b_pending, b_colcnt, b_colptr, b_fillc, b_colpos, b_colord, b_rowof, b_Uidx, b_Lidx, b_Uval, b_Lval, b_Ulen, b_Llen, b_cntL,
+              b_cntU, b_recL, b_recU, b_rq, b_ctrl, b_gws;
     const size_t slab = (size_t)m * cap;
-    ILUPP_HIP(pool_malloc(&pending, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&colcnt, sizeof(int32_t) * (size_t)(m + 1)));
-    ILUPP_HIP(pool_malloc(&colptr, sizeof(int32_t) * (size_t)(m + 1)));
-    ILUPP_HIP(pool_malloc(&fillc, sizeof(int32_t) * (size_t)(m + 1)));
-    ILUPP_HIP(pool_malloc(&colpos, sizeof(int32_t) * (size_t)(Av.nnz > 0 ? Av.nnz : 1)));
-    ILUPP_HIP(pool_malloc(&colord, sizeof(int32_t) * (size_t)(Av.nnz > 0 ? Av.nnz : 1)));
-    ILUPP_HIP(pool_malloc(&rowof, sizeof(int32_t) * (size_t)(Av.nnz > 0 ? Av.nnz : 1)));
-    ILUPP_HIP(pool_malloc(&Uidx, sizeof(int32_t) * slab));
-    ILUPP_HIP(pool_malloc(&Lidx, sizeof(int32_t) * slab));
-    ILUPP_HIP(pool_malloc(&Uval, sizeof(double) * slab));
-    ILUPP_HIP(pool_malloc(&Lval, sizeof(double) * slab));
-    ILUPP_HIP(pool_malloc(&Ulen, sizeof(int32_t) * (size_t)(m + 1)));
-    ILUPP_HIP(pool_malloc(&Llen, sizeof(int32_t) * (size_t)(m + 1)));
-    ILUPP_HIP(pool_malloc(&cntL, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&cntU, sizeof(int32_t) * (size_t)m));
-    ILUPP_HIP(pool_malloc(&recL, (size_t)m * T * 32));
-    ILUPP_HIP(pool_malloc(&recU, (size_t)m * T * 32));
+    ILUPP_HIP(b_pending.alloc(sizeof(int32_t) * (size_t)m));
+    ILUPP_HIP(b_colcnt.alloc(sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(b_colptr.alloc(sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(b_fillc.alloc(sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(b_colpos.alloc(sizeof(int32_t) * (size_t)(Av.nnz > 0 ? Av.nnz : 1)));
+    ILUPP_HIP(b_colord.alloc(sizeof(int32_t) * (size_t)(Av.nnz > 0 ? Av.nnz : 1)));
+    ILUPP_HIP(b_rowof.alloc(sizeof(int32_t) * (size_t)(Av.nnz > 0 ? Av.nnz : 1)));
+    ILUPP_HIP(b_Uidx.alloc(sizeof(int32_t) * slab));
+    ILUPP_HIP(b_Lidx.alloc(sizeof(int32_t) * slab));
+    ILUPP_HIP(b_Uval.alloc(sizeof(double) * slab));
+    ILUPP_HIP(b_Lval.alloc(sizeof(double) * slab));
+    ILUPP_HIP(b_Ulen.alloc(sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(b_Llen.alloc(sizeof(int32_t) * (size_t)(m + 1)));
+    ILUPP_HIP(b_cntL.alloc(sizeof(int32_t) * (size_t)m));
+    ILUPP_HIP(b_cntU.alloc(sizeof(int32_t) * (size_t)m));
+    ILUPP_HIP(b_recL.alloc((size_t)m * T * 32));
+    ILUPP_HIP(b_recU.alloc((size_t)m * T * 32));
     const size_t rq_len = (size_t)kCuQ * (size_t)((m + kCuQ - 1) / kCuQ) + (size_t)m;
-    ILUPP_HIP(pool_malloc(&rq, sizeof(int32_t) * rq_len));
+    ILUPP_HIP(b_rq.alloc(sizeof(int32_t) * rq_len));
     const size_t ctrl_bytes = sizeof(int32_t) * (size_t)(kCuQBase + 64 * kCuQ);
-    ILUPP_HIP(pool_malloc(&ctrl, ctrl_bytes));
+    ILUPP_HIP(b_ctrl.alloc(ctrl_bytes));
+    int32_t *pending = b_pending.as<int32_t>(), *colcnt = b_colcnt.as<int32_t>(), *colptr = b_colptr.as<int32_t>(), *fillc = b_fillc.as<int32_t>(),
+            *colpos = b_colpos.as<int32_t>(), *colord = b_colord.as<int32_t>(), *rowof = b_rowof.as<int32_t>(), *Uidx = b_Uidx.as<int32_t>(),
+            *Lidx = b_Lidx.as<int32_t>(), *Ulen = b_Ulen.as<int32_t>(), *Llen = b_Llen.as<int32_t>(), *cntL = b_cntL.as<int32_t>(),
+            *cntU = b_cntU.as<int32_t>(), *rq = b_rq.as<int32_t>(), *ctrl = b_ctrl.as<int32_t>();
+    double *Uval = b_Uval.as<double>(), *Lval = b_Lval.as<double>();
+    unsigned long long *recL = b_recL.as<unsigned long long>(), *recU = b_recU.as<unsigned long long>();
     ILUPP_HIP(hipMemsetAsync(pending, 0, sizeof(int32_t) * (size_t)m, st));
     ILUPP_HIP(hipMemsetAsync(colcnt, 0, sizeof(int32_t) * (size_t)(m + 1), st));
     ILUPP_HIP(hipMemsetAsync(fillc, 0, sizeof(int32_t) * (size_t)(m + 1), st));
@@ -642,11 +648,10 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     {
         size_t tb = 0;
         ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, colcnt, colptr, m + 1, st));
-        void *tmp;
-        ILUPP_HIP(pool_malloc(&tmp, tb > 0 ? tb : 1));
-        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, colcnt, colptr, m + 1, st));
+        PoolBlock tmp;
+        ILUPP_HIP(tmp.alloc(tb > 0 ? tb : 1));
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, colcnt, colptr, m + 1, st));
         ILUPP_HIP(hipStreamSynchronize(st));
-        ILUPP_HIP(pool_free(tmp));
     }
     hipLaunchKernelGGL(k_iluc_colfill, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, colptr, fillc, colpos);
     hipLaunchKernelGGL(k_iluc_colorder, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, rowof, colptr, colpos, colord);
@@ -658,7 +663,8 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
         gTM = T; gNS = 1024; while (gNS < m + 1 && gNS < 16384) gNS *= 2;       // (a power of two: the slot hash masks with 4 gNS - 1)
         gNE = 1 << 19;
         while (gNE > 4096 && (size_t)waves * iluc_ws_bytes(gNE, gNS, gTM) > ((size_t)ILUC_WSGB << 30)) gNE /= 2;
-        ILUPP_HIP(pool_malloc(&gws, (size_t)waves * iluc_ws_bytes(gNE, gNS, gTM)));
+        ILUPP_HIP(b_gws.alloc((size_t)waves * iluc_ws_bytes(gNE, gNS, gTM)));
+        gws = b_gws.as<unsigned char>();
     }
     const int nq = waves < kCuQ ? waves : kCuQ;
     hipLaunchKernelGGL(k_iluc_seed, dim3(gb), dim3(256), 0, st, m, nq, pending, rq, ctrl);
@@ -668,9 +674,10 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     a.p = fill - 1; a.cap = cap; a.tau = threshold; a.T = T; a.nq = nq;
     a.Uidx = Uidx; a.Lidx = Lidx; a.Ulen = Ulen; a.Llen = Llen; a.Uval = Uval; a.Lval = Lval;
     a.cntL = cntL; a.cntU = cntU; a.recL = recL; a.recU = recU; a.pending = pending; a.rq = rq; a.ctrl = ctrl;
-    hipEvent_t e0, e1;
-    ILUPP_HIP(hipEventCreate(&e0));
-    ILUPP_HIP(hipEventCreate(&e1));
+    struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
+    ILUPP_HIP(hipEventCreate(&ev.a));
+    ILUPP_HIP(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     ILUPP_HIP(hipEventRecord(e0, st));
     if (cls == 0) hipLaunchKernelGGL((k_iluc_df<256, 128, 32, false>), dim3(waves), dim3(64), 0, st, a);
     else if (cls == 1) hipLaunchKernelGGL((k_iluc_df<768, 256, 64, false>), dim3(waves), dim3(64), 0, st, a);
@@ -685,8 +692,6 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
     float ms = 0.f;
     ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    ILUPP_HIP(hipEventDestroy(e0));
-    ILUPP_HIP(hipEventDestroy(e1));
     if (getenv("ILUPP_DEBUG")) { fprintf(stderr, "[ilupp] iluc: class %d, T %d, waves %d: status %d, %.1f ms\n", cls, T, waves, h[2], ms); }
     int rc = ILUPP_OK;
     if (h[2] == 2) rc = ILUPP_ERR_TIMEOUT;
@@ -701,13 +706,12 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
             ILUPP_HIP(pool_malloc(&M->ptr, sizeof(int32_t) * (size_t)(m + 1)));
             size_t tb = 0;
             ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, lens[d], M->ptr, m + 1, st));
-            void *tmp;
-            ILUPP_HIP(pool_malloc(&tmp, tb > 0 ? tb : 1));
-            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, lens[d], M->ptr, m + 1, st));
+            PoolBlock tmp;
+            ILUPP_HIP(tmp.alloc(tb > 0 ? tb : 1));
+            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, lens[d], M->ptr, m + 1, st));
             int32_t nnz = 0;
             ILUPP_HIP(hipMemcpyAsync(&nnz, M->ptr + m, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             ILUPP_HIP(hipStreamSynchronize(st));
-            ILUPP_HIP(pool_free(tmp));
             if ((long)nnz > reserved_l) { rc = ILUPP_ERR_MEMORY; break; }     // append_row_with_prefix's check, :3196-3197
             M->n = m; M->nnz = nnz; M->is_csr = true; M->owns = true;
             ILUPP_HIP(pool_malloc(&M->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
@@ -717,11 +721,7 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
         ILUPP_HIP(hipStreamSynchronize(st));
         if (rc != ILUPP_OK) { L->release(); U->release(); }
     }
-    if (gws) ILUPP_HIP(pool_free(gws));
-    for (void *q : {(void *)pending, (void *)colcnt, (void *)colptr, (void *)fillc, (void *)colpos, (void *)colord, (void *)rowof, (void *)Uidx,
-                    (void *)Lidx, (void *)Uval, (void *)Lval, (void *)Ulen, (void *)Llen, (void *)cntL, (void *)cntU, (void *)recL, (void *)recU,
-                    (void *)rq, (void *)ctrl})
-        ILUPP_HIP(pool_free(q));
+    // (the holders give the work arrays back)
     return rc;
 }
 

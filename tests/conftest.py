@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# a release of a device block that the library's pool has not handed out (a double release) is fatal in the tests (pool.h)
+os.environ.setdefault("ILUPP_POOL_STRICT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
