@@ -1023,8 +1023,11 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
     ILUPP_HIP(hipEventRecord(p->ev[1], st));
     if (rc) {
         if (rc == ILUPP_ERR_NOT_TRIANGULAR) set_error("ICholT: A must be in triangular form with no zeros on the diagonal");
-        else if (rc == ILUPP_ERR_NOT_SPD) set_error("ICholT: a column lost its diagonal entry (the matrix is not positive definite, or the "
-                                                         "fill budget is below one entry per column); the reference returns a NaN-filled factor here");
+        else if (rc == ILUPP_ERR_NOT_SPD) set_error("ICholT: the pivot of a column is NaN (the matrix is not positive definite); "
+                                                         "the reference returns a NaN-filled factor here");
+        else if (rc == ILUPP_ERR_DIAG_DROPPED) set_error("ICholT: the diagonal entry of a column was dropped by the threshold or the fill budget "
+                                                              "(threshold too large / budget too small for this matrix); the reference keeps such a "
+                                                              "factor and divides by the column's first stored entry, this build does not support it");
         else if (rc == ILUPP_ERR_TIMEOUT) set_error("ICholT: dependency wait timed out");
         else set_error("append_row: insufficient memory reserved (or a working column beyond the kernel's largest capacity class)");
         destroy_obj(p);

@@ -320,7 +320,7 @@ int iluc_factor(hipStream_t st, const DevMat &Av, int32_t max_fill_in, double th
 int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U,
                 int32_t *err_row, float *kernel_ms);
 
-// ilut_wp.hip (returns 1 when a row is outside its capacities: the caller runs k_ilut_rows)
+// ilut_wp.hip (returns 1 when a row fits no capacity class, not even the largest: the matrix is too wide for the memory budget)
 int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
                  int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms);
 

@@ -370,7 +370,11 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         // the reference assumes the diagonal leads the stored column (firstL = pointer+1, ILUC.hpp:43).  A column that lost
         // it (the pivot became negative: NaN column; a budget too small to keep it) is reported: the reference goes on and
         // returns a factor full of NaN / with misplaced "diagonals" for such an input
-        if (nk < 1 || __builtin_amdgcn_readfirstlane(srank[0]) != 0) CT_FAIL(3);
+        //   3: the pivot is NaN (the matrix is not positive definite); 4: a finite pivot that the threshold or the top-k budget dropped
+        if (nk < 1 || __builtin_amdgcn_readfirstlane(srank[0]) != 0) {
+            const double piv = sval[0];
+            CT_FAIL(piv != piv ? 3 : 4);
+        }
 
         // ---- append  (sparse_implementation.h:3170-3186) ----
         for (int s = lane; s < ns; s += 64)
@@ -551,7 +555,8 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
         for (int j = firstu; j >= 0 && j < m && j < firstu + 6; ++j) fprintf(stderr, "   col %d: len %d pending %d cnt %d\n", j, hl[j], hp[j], hc[j]);
     }
     if (h[3] != big) rc = ILUPP_ERR_NOT_TRIANGULAR;
-    else if (h[2] == 3) rc = ILUPP_ERR_NOT_SPD;          // a column lost its diagonal: not positive definite (or a budget below 1)
+    else if (h[2] == 3) rc = ILUPP_ERR_NOT_SPD;          // a column lost its diagonal: the pivot is NaN (not positive definite)
+    else if (h[2] == 4) rc = ILUPP_ERR_DIAG_DROPPED;     // ... a finite pivot dropped by the threshold / the budget
     else if (h[2] == 2) rc = ILUPP_ERR_TIMEOUT;
     else if (h[2] != 0) rc = 1;
     if (rc == ILUPP_OK) {
@@ -560,10 +565,10 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
         void *tmp;
         ILUPP_HIP(pool_malloc(&tmp, tb > 0 ? tb : 1));
         ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, Llen, Lptr, m + 1, st));
-        ILUPP_HIP(pool_free(tmp));
         int32_t nnz = 0;
         ILUPP_HIP(hipMemcpyAsync(&nnz, Lptr + m, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
+        ILUPP_HIP(pool_free(tmp));                   // (after the wait: the pool knows nothing of streams)
         if ((long)nnz > reserved) rc = ILUPP_ERR_MEMORY;             // append_row's capacity check, :3178-3179
         else {
             L->n = m; L->nnz = nnz; L->is_csr = false; L->owns = true;

@@ -696,7 +696,24 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
     int rc = ILUPP_OK;
     if (h[2] == 2) rc = ILUPP_ERR_TIMEOUT;
     else if (h[2] != 0) { rc = 1; if (which_capacity) *which_capacity = h[2]; }      // 11..15: which capacity (A's part, touch records read, entries, slots, touch records written)
-    else if (h[3] != big) { rc = ILUPP_ERR_ZERO_PIVOT; if (err_row) *err_row = h[3]; }
+    else if (h[3] != big) {
+        // the reference's loop fails at the FIRST step that fails: a step k checks its pivot (ILUC.hpp:174-175), then appends the row of
+        // U and the column of L (their reservation checks, sparse_implementation.h:3196-3197).  So the zero pivot of step h[3] is
+        // what it reports -- unless the entries of an earlier step already exceeded the reservation
+        rc = ILUPP_ERR_ZERO_PIVOT; if (err_row) *err_row = h[3];
+        for (int d = 0; d < 2 && h[3] > 0; ++d) {
+            PoolBlock pre, tmp;
+            ILUPP_HIP(pre.alloc(sizeof(int32_t) * (size_t)(m + 1)));
+            size_t tb = 0;
+            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d == 0 ? Ulen : Llen, pre.as<int32_t>(), m + 1, st));
+            ILUPP_HIP(tmp.alloc(tb > 0 ? tb : 1));
+            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, d == 0 ? Ulen : Llen, pre.as<int32_t>(), m + 1, st));
+            int32_t upto = 0;
+            ILUPP_HIP(hipMemcpyAsync(&upto, pre.as<int32_t>() + h[3], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            ILUPP_HIP(hipStreamSynchronize(st));
+            if ((long)upto > reserved_l) { rc = ILUPP_ERR_MEMORY; break; }
+        }
+    }
     if (rc == ILUPP_OK) {
         DevMat *out[2] = {L, U};
         int32_t *lens[2] = {Llen, Ulen}, *sidx[2] = {Lidx, Uidx};

@@ -1,9 +1,7 @@
 // ilupp_amd/csrc/ilut_wp.hip -- ILUT(p, tau) rows computed by a whole wave (gfx950).
 //
-// Same function as k_ilut_rows in ilut.hip (reference ILUT_heap, ILUT.hpp:199-278; threshold_and_drop,
-// dropping.hpp:8-34) and the same claiming discipline -- every wave takes the next row from an atomic counter, so a
-// row only waits on rows claimed earlier -- but the row itself is no longer the reference's pointer chasing executed
-// redundantly by 64 lanes.  The working row is kept as three insertion-ordered pieces, which is all the reference's
+// Reference ILUT_heap, ILUT.hpp:199-278; threshold_and_drop, dropping.hpp:8-34.  Every wave takes the next row from an atomic
+// counter, so a row only waits on rows claimed earlier.  The working row is kept as three insertion-ordered pieces, which is all the reference's
 // results depend on (its 2-norms and candidate lists run over the slots of one index range in insertion order,
 // sparse_implementation.h:1087-1093, dropping.hpp:14-21):
 //   * POOL: entries left of the diagonal that have not been eliminated yet {column, value, seq}; seq numbers the
@@ -26,7 +24,8 @@
 // (magnitude desc, position asc) order -- equal to std::sort's result unless the cut falls between equal magnitudes
 // among more than 16 candidates; then one lane runs libstdc++'s algorithm (stdsort.h) on the candidate list.
 // The pieces live in LDS; a row that outgrows them is started over with the wave's global-memory arrays (64 K
-// entries, private to the wave); a row that outgrows those makes the host fall back to k_ilut_rows.
+// entries, private to the wave); a row that outgrows those, or a fill budget beyond the LDS selection queue, makes the host run
+// the whole factorisation in the largest capacity class (k_ilut_rows_wp_big: pieces as long as the matrix is wide, on fewer waves).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -56,12 +55,17 @@ static constexpr int kWpHashG = 1 << 17;
 #define WP_ACC(slot, t0, t1)
 #endif
 
-struct WpArrays {
-    unsigned short *uh; int hmask;           // column -> U slot + 1 (0 = empty), open addressing; all cells 0 between rows
+// IdT: the type of a U-slot id and of a left-part sequence number: 16 bits for the LDS pieces and the 64 K global pieces, 32 bits
+// for the largest capacity class (pieces as long as the matrix is wide)
+template <typename IdT> struct WpArraysT {
+    IdT *uh; int hmask;                      // column -> U slot + 1 (0 = empty), open addressing; all cells 0 between rows
     int *ucol; double *uval; int capU;
-    int *lcol; double *lval; unsigned short *lseq; int capL;      // (seq < 65536: it counts the left-part insertions of one row)
-    int *kcol; double *kval; unsigned short *kseq; int capK;
+    int *lcol; double *lval; IdT *lseq; int capL;      // (seq counts the left-part insertions of one row)
+    int *kcol; double *kval; IdT *kseq; int capK;
 };
+typedef WpArraysT<unsigned short> WpArrays;
+template <typename IdT> struct WpIdMax { static constexpr int value = 65535; };
+template <> struct WpIdMax<unsigned int> { static constexpr int value = 0x7ffffff0; };
 
 // accessors of the working-row pieces: LDS, or the wave's PRIVATE global arrays.  Those are only ever touched by this
 // wave (one CU, one L1), so plain accesses are coherent once the stores have been acknowledged (s_waitcnt in sync()).
@@ -72,6 +76,8 @@ template <bool G> struct WpAcc {
     static __device__ __forceinline__ void std_(double *p, double v) { *p = v; }
     static __device__ __forceinline__ int ldi(const unsigned short *p) { return (int)*p; }
     static __device__ __forceinline__ void sti(unsigned short *p, int v) { *p = (unsigned short)v; }
+    static __device__ __forceinline__ int ldi(const unsigned int *p) { return (int)*p; }
+    static __device__ __forceinline__ void sti(unsigned int *p, int v) { *p = (unsigned int)v; }
     // cross-lane hand-over inside the wave: LDS is in order per wave; global stores must have landed
     static __device__ __forceinline__ void sync() { if constexpr (G) __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
 };
@@ -116,7 +122,8 @@ __device__ __forceinline__ double wave_bcast_f64(double v, int src)
 
 // threshold_and_drop over one piece (dropping.hpp:8-34): cols/vals[0..cnt) in insertion order; writes the kept entries
 // by increasing column to out_idx/out_val (STORE_AGENT: write-through, sentinel-safe) and returns their number
-template <bool G, bool STORE_AGENT>
+// (SELG: the selection queue lives in global memory too -- budgets beyond kWpSel: hand-overs between lanes wait for the stores)
+template <bool G, bool STORE_AGENT, bool SELG = false>
 __device__ __forceinline__ int wp_select(const int lane, const int *cols, const double *vals, const int cnt, const int nkeep,
                                          const double tau, int *selq, int *gscratch, int *out_idx, double *out_val)
 {
@@ -182,6 +189,7 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
             __builtin_amdgcn_s_waitcnt(0);
         }
     }
+    if constexpr (SELG) __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     // by increasing column (dropping.hpp:32-33; unique keys)
     for (int t = lane; t < nsel; t += 64) {
@@ -204,8 +212,8 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
 
 // U-slot hash: what the reference does with its n-long occupancy array (sparse_implementation.h:987-993)
 __device__ __forceinline__ unsigned wp_hash(int c, int hmask) { return (((unsigned)c * 0x9E3779B1u) >> 12) & (unsigned)hmask; }
-template <bool G>
-__device__ __forceinline__ int wp_uh_find(const WpArrays &w, int c)
+template <bool G, typename IdT>
+__device__ __forceinline__ int wp_uh_find(const WpArraysT<IdT> &w, int c)
 {
     unsigned h = wp_hash(c, w.hmask);
     for (;;) {
@@ -217,31 +225,31 @@ __device__ __forceinline__ int wp_uh_find(const WpArrays &w, int c)
 }
 // all lanes with `mine` insert their (distinct) columns at once: everybody walks to an empty cell and writes; where two
 // lanes picked the same cell one of the writes survives, the other lane sees a foreign value and walks on
-template <bool G>
-__device__ __forceinline__ void wp_uh_insert_all(const WpArrays &w, bool mine, int c, int slot)
+template <bool G, typename IdT>
+__device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool mine, int c, int slot)
 {
     unsigned h = wp_hash(c, w.hmask);
     bool pending = mine;
     while (__ballot(pending) != 0ull) {
         if (pending) {
             while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask;
-            w.uh[h] = (unsigned short)(slot + 1);
+            w.uh[h] = (IdT)(slot + 1);
         }
         WpAcc<G>::sync();
         if (pending) {
-            if (w.uh[h] == (unsigned short)(slot + 1)) pending = false;
+            if (w.uh[h] == (IdT)(slot + 1)) pending = false;
             else h = (h + 1) & (unsigned)w.hmask;
         }
     }
 }
 
 // one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout
-template <bool G>
+template <bool G, typename IdT = unsigned short, bool SELG = false>
 __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, const int p, const double tau,
                                       const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                                       int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
                                       int32_t *Urow_idx, double *Urow_val, int32_t *Ulen,
-                                      const WpArrays w, int *bcol, double *bpr, int *bfound, int *selq, int *gscratch, int32_t *ctrl)
+                                      const WpArraysT<IdT> w, int *bcol, double *bpr, int *bfound, int *selq, int *gscratch, int32_t *ctrl)
 {
     using A = WpAcc<G>;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -250,7 +258,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     // the U-slot hash starts empty
     {
         unsigned long long *t64 = reinterpret_cast<unsigned long long *>(w.uh);
-        for (int q = lane; q < (w.hmask + 1) / 4; q += 64) t64[q] = 0ull;
+        for (int q = lane; q < (int)((size_t)(w.hmask + 1) * sizeof(IdT) / 8); q += 64) t64[q] = 0ull;
         A::sync();
     }
     // (2.) scatter the row (ILUT.hpp:222-231)
@@ -262,12 +270,12 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double v = valid ? Aval[q] : 0.0;
         const bool isL = valid && c < i, isU = valid && c > i, isD = valid && c == i;
         const unsigned long long mL = __ballot(isL), mU = __ballot(isU), mD = __ballot(isD);
-        if (seq + __popcll(mL) > 65535) return 1;
+        if (seq + __popcll(mL) > WpIdMax<IdT>::value) return 1;
         if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
         if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
         if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], v); }
         A::sync();
-        wp_uh_insert_all<G>(w, isU, c, nU + __popcll(mU & lt));
+        wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt));
         if (mD != 0ull) wdiag = wave_bcast_f64(v, __ffsll((long long)mD) - 1);
         nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
     }
@@ -324,7 +332,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
         const double m = wkv / ud;                                           // :249
         if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); return 1; }
-        if (lane == 0) { w.kcol[nK] = k; w.kval[nK] = m; w.kseq[nK] = (unsigned short)sk; }
+        if (lane == 0) { w.kcol[nK] = k; w.kval[nK] = m; w.kseq[nK] = (IdT)sk; }
         ++nK;
         for (int base = 0; base < ul; base += 64) {                          // w -= m * U[k, j>k]  (:252-253)
             const int j = base + lane;
@@ -381,7 +389,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             // right of the diagonal: the entry's own lane looks its column up in the hash (the reference's occupancy[] access)
             bool ufound = false;
             if (valid && c > i) {
-                const int us = wp_uh_find<G>(w, c);
+                const int us = wp_uh_find<G, IdT>(w, c);
                 if (us >= 0) { const double o = A::ldd(&w.uval[us]); A::std_(&w.uval[us], o - pr); ufound = true; }
             }
             WP_T(ts1);
@@ -391,12 +399,12 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             const bool nf = valid && c != i && (c < i ? bfound[lane] == 0 : !ufound);
             const bool isL = nf && c < i, isU = nf && c > i;
             const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
-            if (seq + __popcll(mL) > 65535) return 1;
+            if (seq + __popcll(mL) > WpIdMax<IdT>::value) return 1;
             if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
             if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], 0.0 - pr); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
             A::sync();
-            wp_uh_insert_all<G>(w, isU, c, nU + __popcll(mU & lt));
+            wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt));
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
             WP_T(ts2); WP_ACC(6, ts1, ts2);
@@ -420,11 +428,11 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     A::sync();
     const size_t lb = (size_t)i * p;
     // (11.) L row = kept entries then (i, 1.0)
-    const int nLk = wp_select<G, false>(lane, w.lcol, w.lval, nK, p - 1, tau, selq, gscratch, Lrow_idx + lb, Lrow_val + lb);
+    const int nLk = wp_select<G, false, SELG>(lane, w.lcol, w.lval, nK, p - 1, tau, selq, gscratch, Lrow_idx + lb, Lrow_val + lb);
     if (lane == 0) { Lrow_idx[lb + nLk] = i; Lrow_val[lb + nLk] = 1.0; Llen[i] = nLk + 1; }
     A::sync();
     // (12.) U row = (i, w[i]) then kept entries; every datum write-through, the length last is not required
-    const int nUk = wp_select<G, true>(lane, w.ucol, w.uval, nU, p - 1, tau, selq, gscratch, Urow_idx + lb + 1, Urow_val + lb + 1);
+    const int nUk = wp_select<G, true, SELG>(lane, w.ucol, w.uval, nU, p - 1, tau, selq, gscratch, Urow_idx + lb + 1, Urow_val + lb + 1);
     if (lane == 0) {
         double piv = wdiag;
         if (piv == 0.0) atomicMin(&ctrl[2], i);                                  // ILUT.hpp:269-270 (reported after the sweep)
@@ -438,7 +446,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     return 0;
 }
 
-// ctrl: [0] next row, [1] error (1 timeout, 3 capacity -> the host runs k_ilut_rows instead), [2] smallest row with a zero pivot
+// ctrl: [0] next row, [1] error (1 timeout, 3 capacity -> the host runs the largest capacity class), [2] smallest row with a zero pivot
 template <int kWpCapU, int kWpHashLds>
 __global__ void __launch_bounds__(64)
 k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
@@ -489,54 +497,152 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
     }
 }
 
-// returns 0 = rows computed (ctrl holds zero-pivot info), 1 = not handled (run k_ilut_rows), ILUPP_ERR_TIMEOUT
-int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
-                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms)
+// the largest capacity class: every piece as long as the matrix is wide, 32-bit slot ids and sequence numbers, the selection
+// queue in global memory too (budgets beyond kWpSel) -- rows of any length and any fill budget, on a few waves
+__global__ void __launch_bounds__(64)
+k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
+                   int32_t p, double tau, WpArraysT<unsigned int> gw, int *gscratch_all, int *selq_all,
+                   int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
+                   int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl)
 {
-    const int32_t n = A.n;
-    if (p - 1 >= kWpSel) return 1;
-    const size_t slab = (size_t)n * p;
-    const bool small_pieces = p <= 32;
-    int workers = device_cu_count() * (small_pieces ? 20 : 14);
-    if (workers > n) workers = n;
-    WpArrays g = {nullptr, kWpHashG - 1, nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
-    ILUPP_HIP(pool_malloc(&g.uh, sizeof(unsigned short) * (size_t)workers * kWpHashG));
-    int *gscratch = nullptr;
-    ILUPP_HIP(pool_malloc(&g.ucol, sizeof(int) * (size_t)workers * g.capU));
-    ILUPP_HIP(pool_malloc(&g.uval, sizeof(double) * (size_t)workers * g.capU));
-    ILUPP_HIP(pool_malloc(&g.lcol, sizeof(int) * (size_t)workers * g.capL));
-    ILUPP_HIP(pool_malloc(&g.lval, sizeof(double) * (size_t)workers * g.capL));
-    ILUPP_HIP(pool_malloc(&g.lseq, sizeof(unsigned short) * (size_t)workers * g.capL));
-    ILUPP_HIP(pool_malloc(&g.kcol, sizeof(int) * (size_t)workers * g.capK));
-    ILUPP_HIP(pool_malloc(&g.kval, sizeof(double) * (size_t)workers * g.capK));
-    ILUPP_HIP(pool_malloc(&g.kseq, sizeof(unsigned short) * (size_t)workers * g.capK));
-    ILUPP_HIP(pool_malloc(&gscratch, sizeof(int) * (size_t)workers * g.capU));
+    __shared__ int bcol[64], bfound[64];
+    __shared__ double bpr[64];
+    const int lane = threadIdx.x;
+    const size_t wv = blockIdx.x;
+    WpArraysT<unsigned int> g = gw;
+    g.uh += wv * (size_t)(gw.hmask + 1);
+    g.ucol += wv * (size_t)gw.capU; g.uval += wv * (size_t)gw.capU;
+    g.lcol += wv * (size_t)gw.capL; g.lval += wv * (size_t)gw.capL; g.lseq += wv * (size_t)gw.capL;
+    g.kcol += wv * (size_t)gw.capK; g.kval += wv * (size_t)gw.capK; g.kseq += wv * (size_t)gw.capK;
+    int *gscratch = gscratch_all + wv * (size_t)gw.capU;
+    int *selq = selq_all + wv * (size_t)(p + 1);
+    for (;;) {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(&ctrl[0], 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= n) break;
+        int rc = wp_row<true, unsigned int, true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+                                                  g, bcol, bpr, bfound, selq, gscratch, ctrl);
+        rc = __builtin_amdgcn_readfirstlane(rc);
+        if (rc != 0) {
+            // give up: publish a poisoned row so that nobody waits for it, and report
+            if (lane == 0) {
+                atomicMax(&ctrl[1], rc == 1 ? 3 : 1);
+                st_agent_f64(&Urow_val[(size_t)i * p], 1.0);
+                st_agent_i32(&Urow_idx[(size_t)i * p], i);
+                st_agent_i32(&Ulen[i], 1);
+                Llen[i] = 0;
+            }
+        }
+    }
+}
+
+static void wp_init_slabs(hipStream_t st, int32_t n, size_t slab, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl)
+{
     ILUPP_HIP(hipMemsetAsync(Uri, 0xff, sizeof(int32_t) * slab, st));
     fill_u64(st, reinterpret_cast<unsigned long long *>(Urv), (int64_t)slab, kSentinel);
     ILUPP_HIP(hipMemsetAsync(Ulen, 0, sizeof(int32_t) * (size_t)n, st));
     const int32_t init[32] = {0, 0, 0x7fffffff};
     ILUPP_HIP(hipMemcpyAsync(ctrl, init, 128, hipMemcpyHostToDevice, st));
-    hipEvent_t e0, e1;
-    ILUPP_HIP(hipEventCreate(&e0));
-    ILUPP_HIP(hipEventCreate(&e1));
-    ILUPP_HIP(hipEventRecord(e0, st));
-    if (small_pieces)
-        hipLaunchKernelGGL((k_ilut_rows_wp<128, 512>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                           Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
-    else
-        hipLaunchKernelGGL((k_ilut_rows_wp<256, 1024>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                           Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
-    ILUPP_HIP(hipEventRecord(e1, st));
+}
+struct WpEvents { hipEvent_t a = nullptr, b = nullptr; ~WpEvents() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } };
+
+// 0 = rows computed, 1 = not even this class has room (a matrix too wide for the memory budget), ILUPP_ERR_TIMEOUT
+static int ilut_rows_wp_big(hipStream_t st, const DevMat &A, int32_t p, double threshold,
+                            int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms)
+{
+    const int32_t n = A.n;
+    const size_t slab = (size_t)n * p;
+    const int cap = n + 64;
+    size_t hashN = 1024;
+    while (hashN < 2 * (size_t)cap) hashN *= 2;
+    const size_t per_wave = hashN * 4 + (size_t)cap * (12 + 16 + 16 + 4) + (size_t)(p + 1) * 4;
+    int workers = device_cu_count() * 4;
+    while (workers > 1 && (size_t)workers * per_wave > ((size_t)16 << 30)) workers >>= 1;
+    if ((size_t)workers * per_wave > ((size_t)64 << 30)) return 1;
+    if (workers > n) workers = n;
+    WpArraysT<unsigned int> g = {nullptr, (int)hashN - 1, nullptr, nullptr, cap, nullptr, nullptr, nullptr, cap, nullptr, nullptr, nullptr, cap};
+    PoolBlock b_uh, b_ucol, b_uval, b_lcol, b_lval, b_lseq, b_kcol, b_kval, b_kseq, b_scr, b_selq;
+    ILUPP_HIP(b_uh.alloc(sizeof(unsigned int) * (size_t)workers * hashN));
+    ILUPP_HIP(b_ucol.alloc(sizeof(int) * (size_t)workers * cap));
+    ILUPP_HIP(b_uval.alloc(sizeof(double) * (size_t)workers * cap));
+    ILUPP_HIP(b_lcol.alloc(sizeof(int) * (size_t)workers * cap));
+    ILUPP_HIP(b_lval.alloc(sizeof(double) * (size_t)workers * cap));
+    ILUPP_HIP(b_lseq.alloc(sizeof(unsigned int) * (size_t)workers * cap));
+    ILUPP_HIP(b_kcol.alloc(sizeof(int) * (size_t)workers * cap));
+    ILUPP_HIP(b_kval.alloc(sizeof(double) * (size_t)workers * cap));
+    ILUPP_HIP(b_kseq.alloc(sizeof(unsigned int) * (size_t)workers * cap));
+    ILUPP_HIP(b_scr.alloc(sizeof(int) * (size_t)workers * cap));
+    ILUPP_HIP(b_selq.alloc(sizeof(int) * (size_t)workers * (size_t)(p + 1)));
+    g.uh = b_uh.as<unsigned int>(); g.ucol = b_ucol.as<int>(); g.uval = b_uval.as<double>();
+    g.lcol = b_lcol.as<int>(); g.lval = b_lval.as<double>(); g.lseq = b_lseq.as<unsigned int>();
+    g.kcol = b_kcol.as<int>(); g.kval = b_kval.as<double>(); g.kseq = b_kseq.as<unsigned int>();
+    wp_init_slabs(st, n, slab, Uri, Urv, Ulen, ctrl);
+    WpEvents ev;
+    ILUPP_HIP(hipEventCreate(&ev.a));
+    ILUPP_HIP(hipEventCreate(&ev.b));
+    ILUPP_HIP(hipEventRecord(ev.a, st));
+    hipLaunchKernelGGL(k_ilut_rows_wp_big, dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, b_scr.as<int>(),
+                       b_selq.as<int>(), Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+    ILUPP_HIP(hipEventRecord(ev.b, st));
     ILUPP_HIP(hipGetLastError());
     int32_t h[8];
     ILUPP_HIP(hipMemcpyAsync(h, ctrl, 32, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
-    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
-    ILUPP_HIP(hipEventDestroy(e0));
-    ILUPP_HIP(hipEventDestroy(e1));
-    for (void *q : {(void *)g.uh, (void *)g.ucol, (void *)g.uval, (void *)g.lcol, (void *)g.lval, (void *)g.lseq, (void *)g.kcol, (void *)g.kval,
-                    (void *)g.kseq, (void *)gscratch})
-        ILUPP_HIP(pool_free(q));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, ev.a, ev.b));
+    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: largest capacity class, %d waves, status %d, kernel %.3f ms\n", workers, h[1], kernel_ms ? *kernel_ms : 0.f);
+    if (h[1] == 3) return 1;
+    if (h[1] == 1) return ILUPP_ERR_TIMEOUT;
+    return 0;
+}
+
+// returns 0 = rows computed (ctrl holds zero-pivot info), 1 = a row that fits no capacity class, ILUPP_ERR_TIMEOUT
+int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
+                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms)
+{
+    const int32_t n = A.n;
+    const bool force_big = getenv("ILUPP_ILUT_BIG") != nullptr;                // (tests: A/B of the capacity classes)
+    // fill budgets beyond the LDS selection queue: the largest class at once
+    if (p - 1 >= kWpSel || force_big) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
+    const size_t slab = (size_t)n * p;
+    const bool small_pieces = p <= 32;
+    int workers = device_cu_count() * (small_pieces ? 20 : 14);
+    if (workers > n) workers = n;
+    WpArrays g = {nullptr, kWpHashG - 1, nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
+    int32_t h[8];
+    {
+        PoolBlock b_uh, b_ucol, b_uval, b_lcol, b_lval, b_lseq, b_kcol, b_kval, b_kseq, b_scr;
+        ILUPP_HIP(b_uh.alloc(sizeof(unsigned short) * (size_t)workers * kWpHashG));
+        ILUPP_HIP(b_ucol.alloc(sizeof(int) * (size_t)workers * g.capU));
+        ILUPP_HIP(b_uval.alloc(sizeof(double) * (size_t)workers * g.capU));
+        ILUPP_HIP(b_lcol.alloc(sizeof(int) * (size_t)workers * g.capL));
+        ILUPP_HIP(b_lval.alloc(sizeof(double) * (size_t)workers * g.capL));
+        ILUPP_HIP(b_lseq.alloc(sizeof(unsigned short) * (size_t)workers * g.capL));
+        ILUPP_HIP(b_kcol.alloc(sizeof(int) * (size_t)workers * g.capK));
+        ILUPP_HIP(b_kval.alloc(sizeof(double) * (size_t)workers * g.capK));
+        ILUPP_HIP(b_kseq.alloc(sizeof(unsigned short) * (size_t)workers * g.capK));
+        ILUPP_HIP(b_scr.alloc(sizeof(int) * (size_t)workers * g.capU));
+        g.uh = b_uh.as<unsigned short>(); g.ucol = b_ucol.as<int>(); g.uval = b_uval.as<double>();
+        g.lcol = b_lcol.as<int>(); g.lval = b_lval.as<double>(); g.lseq = b_lseq.as<unsigned short>();
+        g.kcol = b_kcol.as<int>(); g.kval = b_kval.as<double>(); g.kseq = b_kseq.as<unsigned short>();
+        int *gscratch = b_scr.as<int>();
+        wp_init_slabs(st, n, slab, Uri, Urv, Ulen, ctrl);
+        WpEvents ev;
+        ILUPP_HIP(hipEventCreate(&ev.a));
+        ILUPP_HIP(hipEventCreate(&ev.b));
+        ILUPP_HIP(hipEventRecord(ev.a, st));
+        if (small_pieces)
+            hipLaunchKernelGGL((k_ilut_rows_wp<128, 512>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+        else
+            hipLaunchKernelGGL((k_ilut_rows_wp<256, 1024>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+        ILUPP_HIP(hipEventRecord(ev.b, st));
+        ILUPP_HIP(hipGetLastError());
+        ILUPP_HIP(hipMemcpyAsync(h, ctrl, 32, hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, ev.a, ev.b));
+    }
 #ifdef ILUT_PROFILE
     {
         unsigned long long t[8];
@@ -546,7 +652,8 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     }
 #endif
     if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: %d of %d rows outgrew LDS (pool %d, U slots %d, kept %d), status %d, kernel %.3f ms\n", h[3], n, h[4], h[5], h[6], h[1], kernel_ms ? *kernel_ms : 0.f);
-    if (h[1] == 3) return 1;
+    // a row that outgrew the 64 K pieces: the whole factorisation once more in the largest class
+    if (h[1] == 3) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
     if (h[1] == 1) return ILUPP_ERR_TIMEOUT;
     return 0;
 }

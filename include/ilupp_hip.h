@@ -36,8 +36,11 @@ typedef enum {
     ILUPP_ERR_TIMEOUT = -7,        /* dependency wait exceeded its bound (cyclic/invalid structure) */
     ILUPP_ERR_UNSUPPORTED = -8,    /* path not built yet in this round */
     ILUPP_ERR_MEMORY = -9,         /* sparse_implementation.h:3178-3179 "insufficient memory reserved" */
-    ILUPP_ERR_NOT_SPD = -10        /* ICholT: a column lost its diagonal (indefinite input / budget below one entry); the reference
+    ILUPP_ERR_NOT_SPD = -10,       /* ICholT: the pivot of a column is NaN (the matrix is not positive definite); the reference
                                       returns a NaN-filled factor for such input (IChol.hpp:115-117 has no positivity check) */
+    ILUPP_ERR_DIAG_DROPPED = -11   /* ICholT: a finite pivot was dropped by the threshold or the top-k budget (dropping.hpp:8-34 does not
+                                      protect it).  The reference keeps such a factor and solves with whatever entry comes first in
+                                      the column; this build reports it instead (documented deviation) */
 } ilupp_status;
 
 /* binding.cpp:279  m.def("index_size") -> sizeof(Integer) */

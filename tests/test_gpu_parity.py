@@ -633,10 +633,11 @@ def test_icholt_dataflow_vs_oracle_seeded(case):
                 assert G.mat_equal(_fac(Ls), Lo), (case, "largest capacity class", a, t)
 
 
-@pytest.mark.parametrize("case", ["grid_24", "rand_20k", "rand_long_rows", "wide_budget", "budget_one"])
+@pytest.mark.parametrize("case", ["grid_24", "rand_20k", "rand_long_rows", "wide_budget", "huge_budget", "budget_one"])
 def test_ilut_wave_kernel_vs_oracle_seeded(case):
     """pool/kept/U-slot working row, validated U-row fetches, top-k with ties, rows that outgrow LDS, U rows longer than one
-    wave (fill_in > 64): bit-exact against the oracle for both kernels (wave-parallel = default, ILUPP_ILUT_SEQUENTIAL=1)"""
+    wave (fill_in > 64), fill budgets beyond the LDS selection queue (fill_in > 256: the largest capacity class): bit-exact
+    against the oracle in the default classes and in the largest one (ILUPP_ILUT_BIG=1)"""
     import ilupp_amd as ilupp
     from oracle import oracle as O
     orc = O.orc()
@@ -652,6 +653,9 @@ def test_ilut_wave_kernel_vs_oracle_seeded(case):
     elif case == "wide_budget":
         d, i, p = matgen.poisson3d(12)
         params = ((100, 0.0), (200, 1e-12))                  # U rows of more than 64 entries
+    elif case == "huge_budget":
+        d, i, p = matgen.poisson3d(9)
+        params = ((300, 0.0), (729, 0.0))                    # budgets beyond kWpSel: exact LU in the largest capacity class
     else:
         d, i, p = matgen.poisson3d(10)
         params = ((1, 0.1), (2, 0.0))
@@ -669,9 +673,9 @@ def test_ilut_wave_kernel_vs_oracle_seeded(case):
             xt = b.copy(); P.apply_trans(xt)              # (rows > 4 entries: the row-parallel sweep kernel, all three sweep kinds)
             assert np.array_equal(xt, orc.apply_lu(Lo, Uo, b, O.TRANSPOSE), equal_nan=True)
             if fmt == "csr":
-                Ps = _with_env("ILUPP_ILUT_SEQUENTIAL", "1", lambda: ilupp.ILUTPreconditioner(_scipy(M), fill_in=fill, threshold=t))
+                Ps = _with_env("ILUPP_ILUT_BIG", "1", lambda: ilupp.ILUTPreconditioner(_scipy(M), fill_in=fill, threshold=t))
                 Ls, Us = [_fac(F) for F in Ps.factors()]
-                assert G.mat_equal(Ls, Lo) and G.mat_equal(Us, Uo), (case, "sequential", fill, t)
+                assert G.mat_equal(Ls, Lo) and G.mat_equal(Us, Uo), (case, "largest capacity class", fill, t)
 
 
 def test_icholt_full_size_properties_128():
