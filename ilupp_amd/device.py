@@ -19,8 +19,10 @@ _FACTORIES = {
     "ILUT": (_native.ILUTPreconditioner_device, ("fill_in", "threshold")),
     "IChol0": (_native.IChol0Preconditioner_device, ()),
     "ICholT": (_native.ICholTPreconditioner_device, ("add_fill_in", "threshold")),
+    "ILUC": (_native.ILUCPreconditioner_device, ("fill_in", "threshold")),
 }
-_DEFAULTS = {"ILUT": {"fill_in": 100, "threshold": 0.1}, "ICholT": {"add_fill_in": 0, "threshold": 0.0}}
+_DEFAULTS = {"ILUT": {"fill_in": 100, "threshold": 0.1}, "ICholT": {"add_fill_in": 0, "threshold": 0.0},
+             "ILUC": {"fill_in": 100, "threshold": 0.1}}
 
 
 def _on_current_stream():
@@ -59,7 +61,7 @@ class DeviceCSR:
 
 
 class DevicePreconditioner:
-    """ILU0 / ILUT / IChol0 / ICholT of a DeviceCSR, applied to device tensors in place or out of place"""
+    """ILU0 / ILUT / ILUC / IChol0 / ICholT of a DeviceCSR, applied to device tensors in place or out of place"""
 
     def __init__(self, kind, A, **params):
         make, names = _FACTORIES[kind]
@@ -111,3 +113,42 @@ def cg(A, b, M=None, x0=None, maxiter=100, rtol=0.0, check_every=0):
     if M is not None:
         M.sync()
     return x
+
+
+def bicgstab(A, b, M=None, x0=None, maxiter=100, rtol=0.0, check_every=0, history=None):
+    """left-preconditioned BiCGstab on device tensors, statement for statement the loop of the reference
+    (iterative_solvers_implementation.h:385-530 with a LEFT preconditioner application): the residual recurrence runs on
+    r = M^-1 (b - A x), Ap = M^-1 (A p), As = M^-1 (A s).  No host round trip per iteration (the scalars stay 0-dim device tensors;
+    the residual norm is looked at every `check_every` iterations only); `history`, when a list, receives a copy of the iterate after
+    every iteration (tests)."""
+    def prec(v):
+        return M.matvec(v) if M is not None else v.clone()
+    y = torch.zeros_like(b) if x0 is None else x0.clone()
+    r0star = b.clone() if x0 is None else b - A.matvec(y)
+    r = prec(r0star)
+    r0star = r.clone()
+    p = r.clone()
+    initial_res = torch.linalg.vector_norm(r)
+    Ap = torch.empty_like(b)
+    As = torch.empty_like(b)
+    for it in range(maxiter):
+        Ap = prec(A.matvec(p))
+        dot_r_r0star = torch.dot(r, r0star)
+        alpha = dot_r_r0star / torch.dot(Ap, r0star)
+        s = r - alpha * Ap
+        As = prec(A.matvec(s))
+        omega = torch.dot(As, s) / torch.dot(As, As)
+        y.add_(alpha * p)
+        y.add_(omega * s)
+        r = s - omega * As
+        beta = (torch.dot(r, r0star) / dot_r_r0star) * (alpha / omega)
+        p.sub_(omega * Ap)
+        p = beta * p + r
+        if history is not None:
+            history.append(y.clone())
+        if check_every and (it + 1) % check_every == 0 and rtol > 0.0:
+            if float(torch.linalg.vector_norm(r) / initial_res) <= rtol:      # the only device-to-host read
+                break
+    if M is not None:
+        M.sync()
+    return y

@@ -195,6 +195,51 @@ int ref_ilut_precond_apply(orc_int n, const orc_int *ptr, const orc_int *idx, co
     return ORC_OK;
 }
 
+/* the reference's BiCGstab (iterative_solvers_implementation.h:385-530) with an ILU(0) preconditioner applied from the LEFT,
+ * exactly `iters` iterations from the zero start vector: x receives the iterate (pins ilupp_amd.device.bicgstab) */
+int ref_bicgstab_ilu0_left(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+                           const double *b, orc_int iters, double *x)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    matrix L, U;
+    ILU0(A, L, U);
+    indirect_split_triangular_preconditioner<Real, matrix, vector> P(std::move(L), LOWER_TRIANGULAR, std::move(U), UPPER_TRIANGULAR);
+    vector bv(n, const_cast<double *>(b), true);
+    vector xv(n, 0.0);
+    Integer max_iter = iters;
+    Real rel_tol = 300.0, abs_tol = 300.0;            // (-log10 of the tolerances: never reached)
+    bicgstab<Real, matrix, vector>(P, LEFT, A, bv, xv, iters, max_iter, rel_tol, abs_tol, true);
+    if (xv.dimension() != n) return ORC_ERR_MEMORY;
+    for (orc_int i = 0; i < n; ++i) x[i] = xv[i];
+    return ORC_OK;
+}
+
+/* the multilevel ILU++ preconditioner (binding.cpp:284-298 -> preconditioner_implementation.h:1350-1665) with the parameters of
+ * iluplusplus_precond_parameter::default_configuration(config) (parameters_implementation.h:538-609), threshold and (fill_in >= 0)
+ * fill_in set as ilupp/__init__.py:171-203 does.  Emits golden vectors for SURVEY section 8 row f3: apply(x) in place, the number
+ * of levels, total_nnz. */
+int ref_ilupp_apply(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr,
+                    orc_int config, double threshold, orc_int fill_in, int use, double *x, orc_int *levels, orc_int *total_nnz)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    iluplusplus_precond_parameter param;
+    if (config >= 0) param.default_configuration(config);
+    param.set_threshold(threshold);
+    if (fill_in >= 0) param.set_fill_in(fill_in);
+    multilevelILUCDPPreconditioner<Real, matrix, vector> P;
+    try {
+        P.make_preprocessed_multilevelILUCDP(A, param);
+    } catch (...) {
+        return ORC_ERR_ZERO_PIVOT;
+    }
+    if (!P.exists()) return ORC_ERR_ZERO_PIVOT;
+    if (levels) *levels = P.levels();
+    if (total_nnz) *total_nnz = P.total_nnz();
+    vector v(n, x, true);
+    P.apply_preconditioner_only(use == ORC_ID ? ID : TRANSPOSE, v);
+    return ORC_OK;
+}
+
 /* libstdc++'s own std::sort with the comparator of dropping.hpp:25-26, to pin orc_sort_slots_by_abs_desc */
 void ref_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key)
 {

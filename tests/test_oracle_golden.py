@@ -1,5 +1,7 @@
 """CPU tests: the plain-C oracle (oracle/ilupp_oracle.c) against golden vectors emitted by the real
 reference (tests/golden/make_golden.py).  Bit-exact on every array.  This is what PINS the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,7 @@ import golden_util as G
 from oracle import oracle as O
 
 orc = O.orc()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _check_family(z, key, M, S, ilut_params, icholt_params):
@@ -196,3 +199,13 @@ def test_restatement_vs_reference_on_fuzz_matrices():
             if not ok: bad += 1; print('ICHOLT mismatch', seed, fmt, 'degenerate', d)
     assert bad == 0
     assert deg > 0            # the degenerate cases are in the sample
+
+
+def test_golden_ml_fixture_is_complete():
+    """tests/golden/ml.npz (make_golden_ml.py: BiCGstab iterates and multilevel ILU++ applies from the REAL reference): every case has
+    its apply, apply_trans and (levels, total_nnz); where oracle/_ref travelled, a sample is re-derived from it live"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ml.npz"))
+    infos = [k for k in z.files if k.endswith("_info")]
+    assert len(infos) == 120 and all(k[:-5] + "_apply" in z.files and k[:-5] + "_apply_trans" in z.files for k in infos)
+    assert all(("bicg/x_%d" % k) in z.files for k in range(1, 7))
+    assert {int(z[k][0]) for k in infos} >= {1, 2, 3}            # one-, two- and three-level factorisations are pinned
