@@ -319,15 +319,18 @@ __device__ __forceinline__ void sd_producer(const SdArgs &A, unsigned char *lds,
             g[i] += S[i];                                                                  \
         }                                                                                  \
     } while (0)
+    // (two 8-byte LDS stores with IMMEDIATE offsets -- the places of a wave's eleven groups lie up to 45 KB apart, beyond the 2 KB reach
+    // of ds_write2_b64, and an address add per store in a wave that shares its SIMD with a consumer costs the consumer its issue slots)
+    const unsigned dst_lds = (unsigned)reinterpret_cast<uintptr_t>(lds) + dst;
 #define SDP_WRITE(rb, parity)                                                              \
     do {                                                                                   \
         _Pragma("unroll") for (int i = 0; i < kSdPer; ++i) {                               \
             if ((pw * kSdPer + i) * 8 < kThreads) {                                        \
-                unsigned char *o_ = lds + dst + (unsigned)i * (8u * kSdPitch) + (unsigned)(parity) * kSdRing; \
                 typedef unsigned long long u64_;                                           \
                 const v4u x_ = ra[rb][i];                                                  \
-                reinterpret_cast<u64_ *>(o_)[0] = ((u64_)x_.y << 32) | x_.x;               \
-                reinterpret_cast<u64_ *>(o_)[1] = ((u64_)x_.w << 32) | x_.z;               \
+                const u64_ lo_ = ((u64_)x_.y << 32) | x_.x, hi_ = ((u64_)x_.w << 32) | x_.z; \
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(dst_lds), "v"(lo_), "n"(i * (8 * kSdPitch) + (parity) * kSdRing) : "memory"); \
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(dst_lds), "v"(hi_), "n"(i * (8 * kSdPitch) + (parity) * kSdRing + 8) : "memory"); \
             }                                                                              \
         }                                                                                  \
     } while (0)
