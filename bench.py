@@ -67,9 +67,7 @@ def measured_traffic(kernel, g):
         try:
             ks = json.load(open(f))["kernels"]
             for name, k in ks.items():
-                if name.split("(")[0].split("<")[0].split("::")[-1] == kernel.split("<")[0]:
-                    if "<" in kernel and kernel not in name:
-                        continue
+                if name.replace("ilupp::", "") == kernel:
                     return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
         except Exception:
             continue

@@ -23,7 +23,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")            # (template arguments kept: the L and the U sweep are two kernels)
         key = (k, r["Dispatch_Id"])
         disp[key] += float(r["Counter_Value"])
         name[key] = k
@@ -42,10 +42,10 @@ def main():
             continue
         kernels[k] = {"FETCH_SIZE_KiB_avg_per_launch": fe.get(k, (0.0, 0))[0], "WRITE_SIZE_KiB_avg_per_launch": wr.get(k, (0.0, 0))[0],
                       "launches_fetch": fe.get(k, (0.0, 0))[1], "launches_write": wr.get(k, (0.0, 0))[1]}
-    json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu",
+    json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extra",
                "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in kernels.items():
-        print("%-32s fetch %10.1f MiB  write %10.1f MiB  (hbm bytes %.3f GB)" % (
+        print("%-52s fetch %10.1f MiB  write %10.1f MiB  (hbm bytes %.3f GB)" % (
             k, v["FETCH_SIZE_KiB_avg_per_launch"] / 1024, v["WRITE_SIZE_KiB_avg_per_launch"] / 1024,
             (2 * v["FETCH_SIZE_KiB_avg_per_launch"] + v["WRITE_SIZE_KiB_avg_per_launch"]) * 1024 / 1e9))
 
