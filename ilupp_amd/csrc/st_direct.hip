@@ -17,10 +17,13 @@
 //     addresses: entries left of the diagonal from the row's start, the diagonal and the entries right of it from the diagonal's
 //     place (the two rows at a chain's ends shift one of the two by one entry);
 //   * the transposed entry a(k,r) an elimination needs (ILU0.hpp:8-23 on such rows: u_rr -= (a_rk / u_kk) a_kr) is an entry RIGHT
-//     of the diagonal of the pivot row k, i.e. something the lane of row k has in its registers when it finishes u_kk: the hand-off
-//     array in LDS carries pairs {u_kk, a(k, k+o)} (one per entry right of the diagonal) instead of u_kk alone, and a dependency is
-//     ONE 16-byte LDS read.  For pivot rows of earlier workgroups the courier wave reads a(k,r) from A itself (it polls the pivot
-//     a few steps ahead anyway);
+//     of the diagonal of the pivot row k, i.e. something the lane of row k knows as soon as it has read its row: the hand-off
+//     array in LDS carries, next to the pivots, every row's three entries right of the diagonal.  For pivot rows of earlier
+//     workgroups the courier wave reads a(k,r) from A itself (it polls the pivot a few steps ahead anyway);
+//   * behind the barrier of a step a lane reads its (at most three) PIVOTS and nothing else: its own row and the transposed entries
+//     were read during the step before (the row's piece of the ring is complete one step early; the entries right of the diagonal
+//     are handed over as soon as their row has been read, a step before its pivot exists).  The chain of a step is then
+//     barrier -> three 8-byte LDS reads -> three divisions -> one 8-byte LDS write;
 //   * the kernel writes the complete records of both sweeps (l_rk and 1; A's entries right of the diagonal and u_rr).
 //
 // Per row: 56 B of A read, 64 B of records written -- the algorithmic traffic of SURVEY section 8(d) without the column indices.
@@ -39,9 +42,10 @@
 #endif
 namespace ilupp {
 
-static constexpr int kSdH = kSdHist;                                     // hand-off slots: an in-workgroup dependency lies at most kSdH-1 steps back
-static constexpr int kSdHoLane = 48;                               // bytes per lane and slot: three pairs {pivot, entry right of the diagonal}
-static constexpr int kSdHoRow = kThreads * kSdHoLane + 64 * 16;    // a slot: the lanes' pairs, then the courier's
+static constexpr int kSdH = kSdHist;                               // hand-off slots: an in-workgroup dependency lies at most kSdH-1 steps back
+static constexpr int kSdHoU = (kThreads + 64) * 8;                 // a slot, first part: the lanes' pivots, then the courier's
+static constexpr int kSdHoAt = 24;                                 // second part, bytes per lane: its row's three entries right of the diagonal
+static constexpr int kSdHoRow = kSdHoU + kThreads * kSdHoAt + 64 * 8;      // ... then the courier's transposed entries
 static constexpr int kSdPitch = 136;                               // bytes of a lane's piece of a block (128 loaded; 17 x 8: conflict-free 8-byte reads)
 static constexpr int kSdRing = kThreads * kSdPitch;                // a block of two steps
 static constexpr int kSdProd = 3;                                  // producer waves
@@ -51,7 +55,8 @@ static constexpr int kSdThreads = kThreads + 64 + 64 * kSdProd;
 static constexpr int kSdLds = 2 * kSdRing + kSdH * kSdHoRow;
 static constexpr unsigned kSdOob = 0xfffffff0u;                    // a buffer offset beyond any array: the load returns zeros and touches nothing
 static_assert(kSdProd * kSdPer * 8 >= kThreads, "every lane needs a producer");
-static_assert(kSdHoRow % 16 == 0 && kSdRing % 8 == 0, "alignment of the LDS regions");
+static_assert(kSdHoRow % 8 == 0 && kSdRing % 8 == 0, "alignment of the LDS regions");
+static constexpr unsigned kSdHo = 2u * kSdRing;                    // where the hand-off slots begin
 
 #ifdef SD_STAMP
 // diagnostics build only: 100 MHz ticks of one consumer wave ([0..7]) and one producer wave ([16..23]) of workgroup SD_STAMP_WG, per segment of a step
@@ -92,8 +97,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sd_rsrc(const SdArgs &A)
 // the 256 lanes of the schedule
 // ---------------------------------------------------------------------------------------------
 template <bool EX>
-__device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds, const int wg, const unsigned (&R)[3][kSdH], const bool (&hasT)[3],
-                                            const int tlo, const int thi)
+__device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds, const int wg, const unsigned (&Ru)[3][kSdH], const unsigned (&Rt)[3][kSdH],
+                                            const bool (&hasT)[3], const int tlo, const int thi)
 {
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
     const int slot = wg * kThreads + t;
@@ -118,11 +123,39 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
     const unsigned aD_[2] = {rowA + 8u * (unsigned)nd, rowA + 8u * (unsigned)(m + nd)};  // the diagonal; right of it: + 8 (1 + q)
     const int k0L = ownL ? 0 : -1;                          // the row without its own-chain entry on the left / on the right
     const int kEU = ownU ? cnt - 1 : -1;
-    const unsigned hoW = 2u * kSdRing + (unsigned)t * kSdHoLane;
+    const unsigned hoU = kSdHo + (unsigned)t * 8u;                                        // this lane's pivot: + slot * kSdHoRow
+    const unsigned hoA = kSdHo + kSdHoU + (unsigned)t * kSdHoAt;                          // ... its entries right of the diagonal
     const bool inL[3] = {0 < nd, 1 < nd, 2 < nd}, inU[3] = {0 < ndU, 1 < ndU, 2 < ndU};
     const bool lastL[3] = {nd == 1, nd == 2, nd == 3};
     const double absent = st_dbl(kAbsent);
 
+    // the row of a step (its seven values and the transposed entries of its eliminations) is read during the step BEFORE
+    double nav[3], nd_, nup[3], nat[3];
+#define SD_PREREAD(k_, ui_, par_, ri_)                                                                  \
+    do {                                                                                                \
+        const unsigned aLn_ = aL_[ui_] + ((k_) == k0L ? 8u : 0u), aUn_ = aD_[ui_] - ((k_) == kEU ? 8u : 0u); \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) nav[j] = st_lds(lds, aLn_ + (par_) + 8u * j);     \
+        nd_ = st_lds(lds, aD_[ui_] + (par_));                                                           \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) nup[q] = st_lds(lds, aUn_ + (par_) + 8u + 8u * q); \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) nat[j] = st_lds(lds, Rt[j][ri_]);                  \
+    } while (0)
+    // values that look like one of the two markers (NaNs with a payload no arithmetic makes) are canonicalised, as the rows pass of
+    // st.hip does; then the entries right of the diagonal go to the hand-off slot of their step
+#define SD_CLEAN_AND_HAND(ri_)                                                                          \
+    do {                                                                                                \
+        bool nan_ = nd_ != nd_;                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) nan_ = nan_ || nav[j] != nav[j] || nup[j] != nup[j] || nat[j] != nat[j]; \
+        if (__any(nan_)) {                                                                              \
+            nd_ = st_clean(nd_);                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j) { nav[j] = st_clean(nav[j]); nup[j] = st_clean(nup[j]); nat[j] = st_clean(nat[j]); } \
+        }                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                   \
+            *reinterpret_cast<double *>(lds + hoA + (unsigned)(ri_) * kSdHoRow + 8u * q) = nup[q];      \
+    } while (0)
+
+    ST_BARRIER();                                           // (the producers' first block and the courier's first entries are in place)
+    SD_PREREAD(tlo - sk, 0, 0u, 0);
+    SD_CLEAN_AND_HAND(0);
     SD_T_DECL(wv == 0 && wg == SD_STAMP_WG);
     for (int tb = tlo; tb < thi; tb += 8) {
         const int kb = tb - sk;
@@ -134,23 +167,20 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             ++nst_;
 #endif
             SD_T(0);
-            const unsigned par = (unsigned)((u >> 1) & 1) * kSdRing;
             const bool c0 = k == k0L, cE = k == kEU;
-            const unsigned aL = aL_[u & 1] + (c0 ? 8u : 0u);
-            const unsigned aU = aD_[u & 1] - (cE ? 8u : 0u);
+            double av[3], up[3], at[3];
+            const double d = nd_;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { av[j] = nav[j]; up[j] = nup[j]; at[j] = nat[j]; }
             ST_BARRIER();
             SD_T(1);
-            double av[3], up[3];
+            // the pivots: what the step waits for.  Behind them, in flight while the divisions run, the row of the next step
+            double piv[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) av[j] = st_lds(lds, aL + par + 8u * j);
-            double d = st_lds(lds, aD_[u & 1] + par);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) up[q] = st_lds(lds, aU + par + 8u + 8u * q);
-            v2d P[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) P[j] = *reinterpret_cast<const v2d *>(lds + R[j][u % kSdH]);
+            for (int j = 0; j < 3; ++j) piv[j] = st_lds(lds, Ru[j][u % kSdH]);
+            SD_PREREAD(k + 1, (u + 1) & 1, (unsigned)(((u + 1) >> 1) & 1) * kSdRing, (u + 1) % kSdH);
 #ifdef SD_STAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
 #endif
             SD_T(2);
             bool pj[3], pq[3];
@@ -158,26 +188,14 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             for (int j = 0; j < 3; ++j) pj[j] = valid && inL[j] && !(lastL[j] && c0);
 #pragma unroll
             for (int q = 0; q < 3; ++q) pq[q] = valid && inU[q] && !(q == 0 && cE);
-            // values that look like one of the two markers (NaNs with a payload no arithmetic makes) are canonicalised, as the
-            // rows pass of st.hip does
-            {
-                bool nan = d != d;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) nan = nan || av[j] != av[j] || up[j] != up[j];
-                if (__any(nan)) {
-                    d = st_clean(d);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { av[j] = st_clean(av[j]); up[j] = st_clean(up[j]); }
-                }
-            }
             // u_ii = a_ii - sum (a_ik / u_kk) a_ki, eliminations in ascending k (ILU0.hpp:47-62 for rows whose eliminations
             // meet them on the diagonal only)
             double w3 = d;
             double l[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                l[j] = av[j] / P[j].x;
-                const double pr = l[j] * P[j].y;
+                l[j] = av[j] / piv[j];
+                const double pr = l[j] * at[j];
                 const double nw = w3 - pr;
                 w3 = (pj[j] && hasT[j]) ? nw : w3;
             }
@@ -189,14 +207,11 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             asm volatile("" :: "v"(w3));
 #endif
             SD_T(3);
-            // hand-off: the pivot with each entry right of the diagonal
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                v2d h; h.x = w3; h.y = up[q];
-                *reinterpret_cast<v2d *>(lds + hoW + (unsigned)(u % kSdH) * kSdHoRow + 16u * q) = h;
-            }
+            *reinterpret_cast<double *>(lds + hoU + (unsigned)(u % kSdH) * kSdHoRow) = w3;
             // pivots that other workgroups read: write-through, to the exchange
             if (EX) { if (exports && valid) st_agent_f64(A.xch + (xoff + (tb + u) * xE), w3); }
+            // (everything below is off the chain of the step)
+            SD_CLEAN_AND_HAND((u + 1) % kSdH);
             const int cw = tb + u - tminw;
 #ifdef SD_NOSTORE
             if (valid && (unsigned)cw < (unsigned)nchw && w3 == 1.2345e-300) {
@@ -219,6 +234,8 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
             SD_T(4);
         }
     }
+#undef SD_PREREAD
+#undef SD_CLEAN_AND_HAND
     SD_T_END(0);
 #ifdef SD_STAMP
     if (t == 0 && wg == (int)gridDim.x - 1) { g_sd_stamp[10] = __builtin_amdgcn_s_memtime(); g_sd_stamp[11] = __builtin_amdgcn_s_memrealtime(); }
@@ -227,8 +244,9 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
 }
 
 // ---------------------------------------------------------------------------------------------
-// the courier: lane p brings pair p -- the pivot from the exchange (polled kStPF steps ahead; all-sentinel before the kernel), the
-// transposed entry from A -- into the hand-off slot of the step that needs it
+// the courier: lane p brings pair p -- the pivot of a step from the exchange (polled kStPF steps ahead; all-sentinel before the
+// kernel) into the hand-off slot of that step, the transposed entry from A into the slot of its step one step EARLY (the lanes
+// read their transposed entries during the step before)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sd_courier(const SdArgs &A, const unsigned long long *idle, unsigned char *lds, const SdPair P,
                                            const int tlo, const int thi)
@@ -238,8 +256,10 @@ __device__ __forceinline__ void sd_courier(const SdArgs &A, const unsigned long 
     const __amdgpu_buffer_rsrc_t rs = sd_rsrc(A);
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.xch);
     const unsigned span = (unsigned)P.cnt;
+    const unsigned hoU = kSdHo + (unsigned)(kThreads + ln) * 8u;
+    const unsigned hoA = kSdHo + kSdHoU + (unsigned)kThreads * kSdHoAt + (unsigned)ln * 8u;
     unsigned long long gq[NP];
-    double ga[NP];
+    double ga[NP];                                        // ga[s % NP]: the transposed entry of step s
 #define SDC_ADDR(k_) ((unsigned)(k_) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
 #define SDC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : kSdOob)
 #define SDC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, SDC_AT(k_), 0, 0))
@@ -249,6 +269,10 @@ __device__ __forceinline__ void sd_courier(const SdArgs &A, const unsigned long 
         ga[g] = SDC_LDAT(tlo + g - P.sk);
         asm volatile("" ::: "memory");
     }
+    // the transposed entry of the first step, before anybody reads it
+    *reinterpret_cast<double *>(lds + hoA) = st_clean(ga[0]);
+    ga[0] = SDC_LDAT(tlo + NP - P.sk);
+    ST_BARRIER();
     bool dead = false;
     for (int tb = tlo; tb < thi; tb += 8) {
 #pragma unroll
@@ -270,10 +294,10 @@ __device__ __forceinline__ void sd_courier(const SdArgs &A, const unsigned long 
                     }
                 }
             }
-            v2d h; h.x = st_dbl(v); h.y = st_clean(ga[u % NP]);
-            *reinterpret_cast<v2d *>(lds + 2u * kSdRing + (unsigned)(u % kSdH) * kSdHoRow + (unsigned)kThreads * kSdHoLane + (unsigned)ln * 16u) = h;
+            *reinterpret_cast<unsigned long long *>(lds + hoU + (unsigned)(u % kSdH) * kSdHoRow) = v;
+            *reinterpret_cast<double *>(lds + hoA + (unsigned)((u + 1) % kSdH) * kSdHoRow) = st_clean(ga[(u + 1) % NP]);
             gq[u % NP] = ld_agent_u64(SDC_ADDR(k + NP));
-            ga[u % NP] = SDC_LDAT(k + NP);
+            ga[(u + 1) % NP] = SDC_LDAT(k + 1 + NP);
             ST_BARRIER();
         }
     }
@@ -339,6 +363,7 @@ __device__ __forceinline__ void sd_producer(const SdArgs &A, unsigned char *lds,
     for (int rb = 0; rb < kSdRA; ++rb) { SDP_LOAD(rb); asm volatile("" ::: "memory"); }
     SDP_WRITE(0, 0);
     SDP_LOAD(0);
+    ST_BARRIER();                                           // (the lanes read their first row behind this one)
     SD_T_DECL(pw == 0 && wg == SD_STAMP_WG);
     for (int tb = tlo; tb < thi; tb += 8) {
 #pragma unroll
@@ -395,9 +420,10 @@ k_ilu0_sd(SdArgs A)
         const int slot = wg * kThreads + t;
         const int32_t *T = A.ltab + (size_t)slot * kStTab;
         const int nd = T[ST_ND], cnt = T[ST_CNT];
-        // where each dependency's pair {pivot, transposed entry} is read: the hand-off entry of the producer lane dt steps back
-        // (slot (step - dt) mod kSdH: one address per residue of the step), or the courier's entry of this step
-        unsigned R[3][kSdH];
+        // where each dependency's pivot is read -- the hand-off slot of the producer lane's step, dt steps back: one address per
+        // residue of the step -- and where its transposed entry is (the producer row's q-th entry right of the diagonal, in the slot of
+        // that row's step), or the courier's places of this step
+        unsigned Ru[3][kSdH], Rt[3][kSdH];
         bool hasT[3], isg[3];
         SdPair gp[3];
 #pragma unroll
@@ -412,8 +438,11 @@ k_ilu0_sd(SdArgs A)
             const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;
             isg[j] = ty == ST_GHOST;
 #pragma unroll
-            for (int i = 0; i < kSdH; ++i)
-                R[j][i] = 2u * kSdRing + (unsigned)((i - dt) & (kSdH - 1)) * kSdHoRow + (unsigned)lane * kSdHoLane + 16u * (unsigned)qq;
+            for (int i = 0; i < kSdH; ++i) {
+                const unsigned sl = kSdHo + (unsigned)((i - dt) & (kSdH - 1)) * kSdHoRow;
+                Ru[j][i] = sl + (unsigned)lane * 8u;
+                Rt[j][i] = sl + kSdHoU + (unsigned)lane * kSdHoAt + 8u * (unsigned)qq;
+            }
             SdPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0;
             if (isg[j]) {
                 const int pw = os >> 8;
@@ -451,8 +480,10 @@ k_ilu0_sd(SdArgs A)
                     const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
                     if (p < 64) s_pairs[p] = gp[j];
 #pragma unroll
-                    for (int i = 0; i < kSdH; ++i)
-                        R[j][i] = 2u * kSdRing + (unsigned)i * kSdHoRow + (unsigned)kThreads * kSdHoLane + (unsigned)min(p, 63) * 16u;
+                    for (int i = 0; i < kSdH; ++i) {
+                        Ru[j][i] = kSdHo + (unsigned)i * kSdHoRow + (unsigned)(kThreads + min(p, 63)) * 8u;
+                        Rt[j][i] = kSdHo + (unsigned)i * kSdHoRow + kSdHoU + (unsigned)kThreads * kSdHoAt + (unsigned)min(p, 63) * 8u;
+                    }
                 }
                 before += __popcll(bal[j]);
             }
@@ -460,7 +491,7 @@ k_ilu0_sd(SdArgs A)
         __syncthreads();
         if (t == 0 && s_total > 64) atomicExch(&A.ctrl[1], 1);        // (the analysis does not let such a schedule through)
         const bool wave_exports = __any(cnt > 0 && A.xe[slot] >= 0);
-        if (wave_exports) sd_consumer<true>(A, lds, wg, R, hasT, tlo, thi); else sd_consumer<false>(A, lds, wg, R, hasT, tlo, thi);
+        if (wave_exports) sd_consumer<true>(A, lds, wg, Ru, Rt, hasT, tlo, thi); else sd_consumer<false>(A, lds, wg, Ru, Rt, hasT, tlo, thi);
     } else if (t < kThreads + 64) {
         __syncthreads();
         __syncthreads();
