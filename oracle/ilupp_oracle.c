@@ -886,3 +886,551 @@ void orc_apply_llt(const orc_mat *L, int use, double *x)
         orc_trisolve(L->n, L->ptr, L->idx, L->val, L->is_csr, ORC_LOWER, ORC_TRANSPOSE, x);
     }
 }
+
+/* ========================================================================================== */
+/* Multilevel ILU++ without pivoting: SURVEY section 8(f) rank 3, the precon_parameter 10     */
+/* family (parameters_implementation.h:927-934: PERMUTE_ROWS 0, TOTAL_PIV 0, piv_tol 0,       */
+/* SMALL_PIVOT_TERMINATES) = multilevelILUCDPPreconditioner::make_preprocessed_multilevelILUCDP */
+/* (preconditioner_implementation.h:1350-1665) over matrix_sparse::partialILUC                 */
+/* (ILUCDP.hpp:1405-2231) with the preprocessing of matrix_sparse::preprocess                  */
+/* (sparse_implementation.h:5214-5460) and the apply of :433-488.                              */
+/* Knobs outside that family (pivoting, inverse / weighted / positional dropping, improved     */
+/* Schur complement, bounded fill) are NOT restated: orc_ml_create refuses them.               */
+/* ========================================================================================== */
+
+struct orc_ml_level {
+    orc_int n;
+    orc_mat L, U;                 /* Precond_left (COLUMN, 1 first), Precond_right (ROW, 1 first) */
+    double *D;                    /* Precond_middle: 1 / pivot */
+    orc_int *perm_rows, *perm_cols, *inv_perm_rows, *inv_perm_cols;
+    double *D_l, *D_r;
+    orc_int zero_pivots;
+};
+
+struct orc_ml {
+    orc_int n;
+    int nlevels;
+    struct orc_ml_level *lev;
+};
+
+static void mat_copy(orc_mat *dst, const orc_mat *src)
+{
+    mat_init(dst, src->n, src->nnz, src->is_csr);
+    memcpy(dst->ptr, src->ptr, sizeof(orc_int) * ((size_t)src->n + 1));
+    memcpy(dst->idx, src->idx, sizeof(orc_int) * (size_t)src->nnz);
+    memcpy(dst->val, src->val, sizeof(double) * (size_t)src->nnz);
+    dst->nnz = src->nnz;
+}
+
+/* matrix_sparse::change_orientation, sparse_implementation.h:2543-2566: same matrix, other storage order */
+static void mat_change_orientation(const orc_mat *A, orc_mat *B)
+{
+    orc_int i, j, *counter;
+    const orc_int n = A->n, nnz = A->ptr[n];
+    mat_init(B, n, nnz, !A->is_csr);
+    for (i = 0; i < nnz; ++i) B->ptr[1 + A->idx[i]]++;
+    for (i = 1; i <= n; ++i) B->ptr[i] += B->ptr[i - 1];
+    counter = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));
+    for (i = 0; i < n; ++i)
+        for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
+            const orc_int l = A->idx[j], k = B->ptr[l] + counter[l];
+            B->val[k] = A->val[j]; B->idx[k] = i; counter[l]++;
+        }
+    free(counter);
+    B->nnz = nnz;
+}
+
+/* vector_dense<T>::quicksort(index_list&, left, right), sparse_implementation.h:471-505: the reference's own (unstable) quicksort
+ * on the values, the list follows -- the order of equal values is part of the PQ permutation */
+static void vec_quicksort(double *data, orc_int *list, orc_int left, orc_int right)
+{
+    orc_int i, j;
+    double m;
+    if (left < right) {
+        m = data[left]; i = left; j = right;
+        while (i <= j) {
+            while (data[i] < m) i++;
+            while (data[j] > m) j--;
+            if (i <= j) {
+                const double t = data[i]; const orc_int u = list[i];
+                data[i] = data[j]; data[j] = t; list[i] = list[j]; list[j] = u;
+                i++; j--;
+            }
+        }
+        vec_quicksort(data, list, left, j);
+        vec_quicksort(data, list, i, right);
+    }
+}
+
+/* matrix_sparse::normal_order, :3381-3405: every row by increasing index (the indices of a row are distinct) */
+static int cmp_idx_pair(const void *a, const void *b)
+{
+    const orc_int x = *(const orc_int *)a, y = *(const orc_int *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+static void mat_normal_order(orc_mat *M)
+{
+    orc_int k, j, maxlen = 0;
+    struct pr { orc_int idx; orc_int pos; } *buf;
+    double *tmp;
+    for (k = 0; k < M->n; ++k) if (M->ptr[k + 1] - M->ptr[k] > maxlen) maxlen = M->ptr[k + 1] - M->ptr[k];
+    buf = (struct pr *)malloc(sizeof(struct pr) * (size_t)(maxlen > 0 ? maxlen : 1));
+    tmp = (double *)malloc(sizeof(double) * (size_t)(maxlen > 0 ? maxlen : 1));
+    for (k = 0; k < M->n; ++k) {
+        const orc_int b = M->ptr[k], len = M->ptr[k + 1] - b;
+        for (j = 0; j < len; ++j) { buf[j].idx = M->idx[b + j]; buf[j].pos = j; tmp[j] = M->val[b + j]; }
+        qsort(buf, (size_t)len, sizeof(struct pr), cmp_idx_pair);
+        for (j = 0; j < len; ++j) { M->idx[b + j] = buf[j].idx; M->val[b + j] = tmp[buf[j].pos]; }
+    }
+    free(buf); free(tmp);
+}
+
+/* matrix_sparse::permute(p1,p2,ip1,ip2) for a ROW matrix, :5570-5573 -> permute_along_with_perm_and_against_orientation_with_invperm
+ * :5533-5548: new row i = old row perm_along[i], every column index c becomes invperm_against[c], rows re-sorted */
+static void mat_permute_rows_cols(orc_mat *A, const orc_int *perm_along, const orc_int *invperm_against)
+{
+    orc_mat H;
+    orc_int i, j, counter = 0;
+    mat_init(&H, A->n, A->nnz, A->is_csr);
+    for (i = 0; i < A->n; ++i) {
+        H.ptr[i] = counter;
+        for (j = A->ptr[perm_along[i]]; j < A->ptr[perm_along[i] + 1]; ++j) {
+            H.val[counter] = A->val[j];
+            H.idx[counter] = invperm_against[A->idx[j]];
+            counter++;
+        }
+    }
+    H.ptr[A->n] = counter;
+    H.nnz = counter;
+    mat_normal_order(&H);
+    orc_free_mat(A);
+    *A = H;
+}
+
+static void perm_invert(orc_int *inv, const orc_int *perm, orc_int n)      /* index_list::invert, :6140-6144 */
+{
+    orc_int i;
+    for (i = 0; i < n; ++i) inv[perm[i]] = i;
+}
+static void perm_compose_right(orc_int *P, const orc_int *Q, orc_int n)    /* P := P o Q: P[i] = P[Q[i]], :6165-6183 */
+{
+    orc_int i, *H = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1));
+    for (i = 0; i < n; ++i) H[i] = P[Q[i]];
+    memcpy(P, H, sizeof(orc_int) * (size_t)n);
+    free(H);
+}
+static void vec_permute(double *x, const orc_int *perm, orc_int n)          /* vector_dense::permute(perm), :590-597 */
+{
+    orc_int i;
+    double *H = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (i = 0; i < n; ++i) H[i] = x[perm[i]];
+    memcpy(x, H, sizeof(double) * (size_t)n);
+    free(H);
+}
+
+/* matrix_sparse::ddPQ(P, Q, tau), :4571-4635 (Saad's greedy PQ ordering); P, Q are the INVERSE permutations */
+static orc_int mat_ddPQ(const orc_mat *A, orc_int *P, orc_int *Q, double tau)
+{
+    const orc_int n = A->n;
+    orc_int j, k, count, Qcount, pos;
+    orc_int *I = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1));
+    orc_int *J = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1));
+    orc_int *J2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1));
+    double *W = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (k = 0; k < n; ++k) { P[k] = -1; Q[k] = -1; I[k] = k; }
+    for (k = 0; k < n; ++k) {
+        double current_max = 0.0, divisor;
+        W[k] = 0.0; J[k] = 0;
+        for (j = A->ptr[k]; j < A->ptr[k + 1]; ++j) {
+            W[k] += fabs(A->val[j]);
+            if (fabs(A->val[j]) > current_max) { current_max = fabs(A->val[j]); J[k] = A->idx[j]; }
+        }
+        divisor = W[k] * (double)(A->ptr[k + 1] - A->ptr[k]);
+        if (divisor == 0.0) W[k] = 0.0;
+        else W[k] = -current_max / divisor;
+    }
+    vec_quicksort(W, I, 0, n - 1);
+    for (k = 0; k < n; ++k) J2[k] = J[I[k]];                                   /* permute_vec(J, I) */
+    count = -1;
+    for (k = 0; k < n; ++k)
+        if (P[I[k]] == -1 && Q[J2[k]] == -1 && -W[k] >= tau) { count++; P[I[k]] = count; Q[J2[k]] = count; }
+    pos = Qcount = count;
+    for (k = 0; k < n; ++k) if (P[k] < 0) { count++; P[k] = count; }
+    for (k = 0; k < n; ++k) if (Q[k] < 0) { Qcount++; Q[k] = Qcount; }
+    free(I); free(J); free(J2); free(W);
+    return pos + 1;
+}
+
+/* matrix_sparse::preprocess, :5214-5460, for the steps of orc_ml_params.preprocessing; A is ROW storage and is replaced by the
+ * preprocessed matrix.  P, Q, invP, invQ, Drow, Dcol: n each. */
+static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_int *Q, orc_int *invP, orc_int *invQ, double *Drow,
+                          double *Dcol, orc_int *bad_at)
+{
+    const orc_int n = A->n;
+    orc_int i, j;
+    int s;
+    double *D = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    orc_int *p1 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1)), *p2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1)),
+            *ip1 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1)), *ip2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1));
+    int rc = ORC_OK;
+    *bad_at = n;
+    for (i = 0; i < n; ++i) { P[i] = Q[i] = invP[i] = invQ[i] = i; Drow[i] = 1.0; Dcol[i] = 1.0; }
+    for (s = 0; s < IP->n_preprocessing && rc == ORC_OK; ++s) {
+        switch (IP->preprocessing[s]) {
+        case ORC_PRE_NORMALIZE_COLUMNS:                                        /* :5241-5246, normalize_columns :3306-3309 */
+            for (i = 0; i < n; ++i) D[i] = 0.0;
+            for (j = 0; j < A->ptr[n]; ++j) D[A->idx[j]] += A->val[j] * A->val[j];       /* norm2_of_dim1, :820-833 */
+            for (i = 0; i < n; ++i) D[i] = sqrt(D[i]);
+            for (j = 0; j < A->ptr[n]; ++j) A->val[j] /= D[A->idx[j]];                   /* inverse_scale(COLUMN), :3279-3282 */
+            vec_permute(D, invQ, n);
+            for (i = 0; i < n; ++i) Dcol[i] *= D[i];
+            *bad_at = n;
+            break;
+        case ORC_PRE_NORMALIZE_ROWS:                                           /* :5247-5252 */
+            for (i = 0; i < n; ++i) {
+                D[i] = 0.0;
+                for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) D[i] += A->val[j] * A->val[j];
+            }
+            for (i = 0; i < n; ++i) D[i] = sqrt(D[i]);
+            for (i = 0; i < n; ++i)
+                for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) A->val[j] /= D[i];
+            vec_permute(D, invP, n);
+            for (i = 0; i < n; ++i) Drow[i] *= D[i];
+            *bad_at = n;
+            break;
+        case ORC_PRE_PQ_ORDERING:                                              /* :5264-5275 */
+            *bad_at = mat_ddPQ(A, ip1, ip2, IP->pq_threshold);
+            perm_invert(p1, ip1, n);
+            perm_invert(p2, ip2, n);
+            mat_permute_rows_cols(A, p1, ip2);
+            perm_compose_right(P, p1, n);
+            perm_compose_right(Q, p2, n);
+            perm_invert(invP, P, n);
+            perm_invert(invQ, Q, n);
+            break;
+        default:
+            rc = ORC_ERR_UNSUPPORTED;
+        }
+    }
+    free(D); free(p1); free(p2); free(ip1); free(ip2);
+    return rc;
+}
+
+/* vector_sparse_dynamic::take_single_weight_largest_elements_by_abs_value_with_threshold, :1360-1415, WEIGHTED_DROPPING branch with
+ * n >= the number of candidates (MAX_FILLIN_IS_INF): the indices in [from, to) whose weight * |value| >= tau, ascending */
+static orc_int take_single_weight(const wvec *v, orc_int *list, double weight, double tau, orc_int from, orc_int to)
+{
+    orc_int i, cnt = 0;
+    for (i = 0; i < v->nnz; ++i) {
+        const double product = weight * fabs(v->data[i]);
+        if (from <= v->pointer[i] && v->pointer[i] < to && product >= tau) list[cnt++] = v->pointer[i];
+    }
+    qsort(list, (size_t)cnt, sizeof(orc_int), cmp_idx_pair);
+    return cnt;
+}
+
+/* vector_sparse_dynamic::take_largest_elements_by_abs_value_with_threshold, :1322-1357, with n >= the number of candidates */
+static orc_int take_largest(const wvec *v, orc_int *list, double tau, orc_int from, orc_int to)
+{
+    orc_int i, cnt = 0;
+    double z = 0.0, norm;
+    for (i = 0; i < v->nnz; ++i)
+        if (from <= v->pointer[i] && v->pointer[i] < to) z += v->data[i] * v->data[i];
+    norm = sqrt(z);
+    for (i = 0; i < v->nnz; ++i)
+        if (from <= v->pointer[i] && v->pointer[i] < to && fabs(v->data[i]) > norm * tau) list[cnt++] = v->pointer[i];
+    qsort(list, (size_t)cnt, sizeof(orc_int), cmp_idx_pair);
+    return cnt;
+}
+
+static double wv_norm1(const wvec *v)                                         /* :1074-1078 */
+{
+    double z = 0.0;
+    orc_int i;
+    for (i = 0; i < v->nnz; ++i) z += fabs(v->data[i]);
+    return z;
+}
+
+/* matrix_sparse::partialILUC, ILUCDP.hpp:1405-2231, for the precon_parameter 10 family: err-prop dropping (weight of a row of U = the
+ * 1-norm of the scaled column of L and vice versa), DROP_TYPE 0, no improved Schur complement, unbounded fill, the level ends at
+ * the first pivot smaller than MIN_PIVOT.  L: COLUMN, U: ROW (both with the 1 first), Dinv, Anew: the Schur complement (ROW). */
+static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_finish, double threshold, orc_mat *L, orc_mat *U,
+                        double *Dinv, orc_mat *Anew, orc_int *zero_pivots)
+{
+    const orc_int n = Arow->n;
+    const orc_int *ptr = Arow->ptr, *idx = Arow->idx;
+    const double *val = Arow->val;
+    orc_int k, j, h, x, capL, capU, capA = 0;
+    orc_int last_row_to_eliminate = n - 1, n_Anew = 0;
+    int eliminate = 1;
+    double pivot = 0.0;
+    orc_int *firstU, *listU, *firstL, *listL, *listA, *headA, *firstA, *list_L, *list_U;
+    wvec z, w;
+    *zero_pivots = 0;
+    capL = capU = ptr[n] + n + 16;
+    mat_init(L, n, capL, 0);
+    mat_init(U, n, capU, 1);
+    mat_init(Anew, 0, 1, 1);
+    for (k = 0; k < n; ++k) Dinv[k] = 1.0;
+    firstU = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int)); listU = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    firstL = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int)); listL = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    listA = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int)); headA = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    firstA = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));
+    list_L = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16)); list_U = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16));
+    wv_init(&z, n, 0); wv_init(&w, n, 0);
+    initialize_sparse_matrix_fields(n, ptr, idx, listA, headA, firstA);
+    for (k = 0; k < n; ++k) { listL[k] = -1; listU[k] = -1; }
+
+    for (k = 0; k < n; ++k) {
+        orc_int nL = 0, nU;
+        double weightL, weightU;
+        wv_zero_reset(&z);                                                     /* (2.) :1575-1583 */
+        for (j = firstA[k]; j < ptr[k + 1]; ++j) z.data[wv_slot(&z, idx[j])] = val[j];
+        for (h = listL[k]; h != -1; h = listL[h]) {                            /* (3.) :1589-1602 */
+            for (j = firstU[h]; j < U->ptr[h + 1]; ++j) {
+                x = wv_slot(&z, U->idx[j]);
+                z.data[x] -= L->val[firstL[h]] / Dinv[h] * U->val[j];
+            }
+        }
+        /* the level ends at a small pivot, :1619-1636 (z[k] inserts the slot if the diagonal is missing) */
+        if (eliminate && !force_finish && (double)k > IP->min_elim_factor * (double)n && IP->small_pivot_terminates
+            && fabs(z.data[wv_slot(&z, k)]) < IP->min_pivot) {
+            eliminate = 0;
+            threshold *= IP->threshold_shift_schur;
+            last_row_to_eliminate = k - 1;
+            n_Anew = n - k;
+            orc_free_mat(Anew);
+            capA = ptr[n] + 16;
+            mat_init(Anew, n_Anew, capA, 1);
+        }
+        if (eliminate) {                                                       /* :1637-1642 */
+            x = wv_slot(&z, k);
+            pivot = z.data[x];
+            Dinv[k] = 1.0 / z.data[x];
+            for (j = 0; j < z.nnz; ++j) z.data[j] *= Dinv[k];
+            z.data[wv_slot(&z, k)] = 0.0;
+        }
+        wv_zero_reset(&w);                                                     /* (8.) :1651-1675 */
+        if (eliminate) {
+            for (h = headA[k]; h != -1; h = listA[h])
+                if (h > k) w.data[wv_slot(&w, h)] = val[firstA[h]];
+            for (h = listU[k]; h != -1; h = listU[h]) {
+                for (j = firstL[h]; j < L->ptr[h + 1]; ++j) {
+                    x = wv_slot(&w, L->idx[j]);
+                    w.data[x] -= U->val[firstU[h]] / Dinv[h] * L->val[j];
+                }
+            }
+        }
+        for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* w.scale(Dinv[k]), :1676 */
+        /* dropping, :1716-1764 */
+        if (!eliminate) {
+            nU = take_largest(&z, list_U, threshold, last_row_to_eliminate + 1, n);
+        } else {
+            const double e = 1.0 * wv_norm1(&w);                              /* WEIGHT_ERR_PROP_DROP * w.norm1() */
+            weightU = 0.0 < e ? e : 0.0;                                       /* combine: std::max(NEUTRAL_ELEMENT, .) */
+            nU = take_single_weight(&z, list_U, weightU, threshold, k + 1, n);
+        }
+        /* update U or Anew, :1769-1850 */
+        if (eliminate) {
+            mat_reserve(U, U->ptr[k] + nU + 1, &capU);
+            U->val[U->ptr[k]] = 1.0; U->idx[U->ptr[k]] = k;
+            for (j = 0; j < nU; ++j) { U->val[U->ptr[k] + j + 1] = z.data[z.occupancy[list_U[j]]]; U->idx[U->ptr[k] + j + 1] = list_U[j]; }
+            U->ptr[k + 1] = U->ptr[k] + nU + 1;
+            if (pivot == 0.0) { (*zero_pivots)++; Dinv[k] = 1.0; }
+        } else {
+            const orc_int k_Anew = k - last_row_to_eliminate - 1;
+            mat_reserve(U, U->ptr[k] + 1, &capU);
+            mat_reserve(Anew, Anew->ptr[k_Anew] + nU, &capA);
+            U->val[U->ptr[k]] = 1.0; Dinv[k] = 1.0; U->idx[U->ptr[k]] = k;
+            U->ptr[k + 1] = U->ptr[k] + 1;
+            for (j = 0; j < nU; ++j) { Anew->val[Anew->ptr[k_Anew] + j] = z.data[z.occupancy[list_U[j]]]; Anew->idx[Anew->ptr[k_Anew] + j] = list_U[j]; }
+            Anew->ptr[k_Anew + 1] = Anew->ptr[k_Anew] + nU;
+        }
+        /* (12.) L, :1855-1975 */
+        if (eliminate) {
+            const double e = 1.0 * wv_norm1(&z);
+            weightL = 0.0 < e ? e : 0.0;
+            nL = take_single_weight(&w, list_L, weightL, threshold, k + 1, n);
+            mat_reserve(L, L->ptr[k] + nL + 1, &capL);
+            L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = k;
+            for (j = 0; j < nL; ++j) { L->val[L->ptr[k] + j + 1] = w.data[w.occupancy[list_L[j]]]; L->idx[L->ptr[k] + j + 1] = list_L[j]; }
+            L->ptr[k + 1] = L->ptr[k] + nL + 1;
+        } else {
+            mat_reserve(L, L->ptr[k] + 1, &capL);
+            L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = k;
+            L->ptr[k + 1] = L->ptr[k] + 1;
+        }
+        if (eliminate) {                                                       /* :1977-1983 */
+            update_sparse_matrix_fields(k, ptr, idx, listA, headA, firstA);
+            update_triangular_fields(k, U->ptr, U->idx, listU, firstU);
+        }
+        update_triangular_fields(k, L->ptr, L->idx, listL, firstL);
+    }
+    L->nnz = L->ptr[n]; U->nnz = U->ptr[n];
+    mat_compress(L, 0.0);                                                      /* compress(), :2053-2054 */
+    mat_compress(U, 0.0);
+    if (eliminate) {                                                           /* :2055 */
+        orc_free_mat(Anew);
+        mat_init(Anew, 0, 1, 1);
+    } else {
+        Anew->nnz = Anew->ptr[n_Anew];
+        if (Anew->nnz > 0) {                                                   /* :2057-2065 */
+            mat_compress(Anew, 0.0);
+            for (j = 0; j < Anew->nnz; ++j) Anew->idx[j] -= last_row_to_eliminate + 1;
+            mat_normal_order(Anew);
+        }
+    }
+    wv_free(&z); wv_free(&w);
+    free(firstU); free(listU); free(firstL); free(listL); free(listA); free(headA); free(firstA); free(list_L); free(list_U);
+    return ORC_OK;
+}
+
+static void ml_level_free(struct orc_ml_level *l)
+{
+    orc_free_mat(&l->L); orc_free_mat(&l->U);
+    free(l->D); free(l->perm_rows); free(l->perm_cols); free(l->inv_perm_rows); free(l->inv_perm_cols); free(l->D_l); free(l->D_r);
+}
+
+void orc_ml_free(orc_ml *P)
+{
+    int i;
+    if (!P) return;
+    for (i = 0; i < P->nlevels; ++i) ml_level_free(&P->lev[i]);
+    free(P->lev);
+    free(P);
+}
+
+void orc_ml_default_params(orc_ml_params *p)       /* default_parameters (:430-501) + init case 10 (:927-934) + set_PQ */
+{
+    memset(p, 0, sizeof(*p));
+    p->threshold = 0.0;
+    p->n_preprocessing = 3;
+    p->preprocessing[0] = ORC_PRE_NORMALIZE_COLUMNS; p->preprocessing[1] = ORC_PRE_NORMALIZE_ROWS; p->preprocessing[2] = ORC_PRE_PQ_ORDERING;
+    p->pq_threshold = 0.0;
+    p->max_levels = 100;
+    p->min_ml_size = 0;
+    p->small_pivot_terminates = 1;
+    p->min_pivot = 1e-2;
+    p->min_elim_factor = 0.0;
+    p->threshold_shift_schur = 0.0;
+    p->vary_threshold_factor = 1.0;
+    p->use_final_threshold = 0;
+    p->final_threshold = 0.0;
+}
+
+/* make_preprocessed_multilevelILUCDP, preconditioner_implementation.h:1350-1665, use_ILUC branch */
+int orc_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, const orc_ml_params *IP, orc_ml **out)
+{
+    orc_ml *P;
+    orc_mat Ak, Anext, view;
+    double tau = IP->threshold;
+    orc_int matrix_size, nonzeroes;
+    int cap = IP->max_levels > 0 ? IP->max_levels + 1 : 1;
+    *out = NULL;
+    view.n = n; view.nnz = ptr[n]; view.ptr = (orc_int *)ptr; view.idx = (orc_int *)idx; view.val = (double *)val; view.is_csr = is_csr;
+    if (is_csr) mat_copy(&Ak, &view);
+    else mat_change_orientation(&view, &Ak);                                   /* :1388-1391 */
+    P = (orc_ml *)calloc(1, sizeof(orc_ml));
+    P->n = n;
+    P->lev = (struct orc_ml_level *)calloc((size_t)cap, sizeof(struct orc_ml_level));
+    matrix_size = Ak.n; nonzeroes = Ak.ptr[Ak.n];
+    for (;;) {
+        const int in_loop = matrix_size > IP->min_ml_size && P->nlevels < IP->max_levels - 1 && nonzeroes > 0;     /* :1405 */
+        struct orc_ml_level *l;
+        orc_int bad_at, m;
+        int rc;
+        if (!in_loop && !(matrix_size > 0)) break;                             /* :1550 */
+        l = &P->lev[P->nlevels];
+        m = Ak.n;
+        l->n = m;
+        l->perm_rows = (orc_int *)malloc(sizeof(orc_int) * (size_t)m); l->perm_cols = (orc_int *)malloc(sizeof(orc_int) * (size_t)m);
+        l->inv_perm_rows = (orc_int *)malloc(sizeof(orc_int) * (size_t)m); l->inv_perm_cols = (orc_int *)malloc(sizeof(orc_int) * (size_t)m);
+        l->D_l = (double *)malloc(sizeof(double) * (size_t)m); l->D_r = (double *)malloc(sizeof(double) * (size_t)m);
+        l->D = (double *)malloc(sizeof(double) * (size_t)m);
+        rc = mat_preprocess(&Ak, IP, l->perm_rows, l->perm_cols, l->inv_perm_rows, l->inv_perm_cols, l->D_l, l->D_r, &bad_at);
+        if (rc != ORC_OK) { P->nlevels++; orc_free_mat(&Ak); orc_ml_free(P); return rc; }
+        if (!in_loop && IP->use_final_threshold) tau *= IP->final_threshold;   /* :1580-1581 */
+        rc = partial_iluc(&Ak, IP, in_loop ? 0 : 1, tau, &l->L, &l->U, l->D, &Anext, &l->zero_pivots);
+        P->nlevels++;
+        if (rc != ORC_OK) { orc_free_mat(&Ak); orc_free_mat(&Anext); orc_ml_free(P); return rc; }
+        orc_free_mat(&Ak);
+        Ak = Anext;                                                            /* :1532 */
+        if (!in_loop) break;
+        matrix_size = Ak.n; nonzeroes = Ak.n > 0 ? Ak.ptr[Ak.n] : 0;
+        tau *= IP->vary_threshold_factor;
+    }
+    orc_free_mat(&Ak);
+    *out = P;
+    return ORC_OK;
+}
+
+int orc_ml_levels(const orc_ml *P) { return P->nlevels; }
+
+orc_int orc_ml_total_nnz(const orc_ml *P)          /* preconditioner.h:312, preconditioner_implementation.h:551-569 */
+{
+    orc_int sum = 0;
+    int k;
+    for (k = 0; k < P->nlevels; ++k) sum += (P->lev[k].L.nnz - P->lev[k].n) + (P->lev[k].U.nnz - P->lev[k].n) + P->lev[k].n;
+    return sum;
+}
+
+int orc_ml_level(const orc_ml *P, int k, orc_ml_level_view *v)
+{
+    const struct orc_ml_level *l;
+    if (k < 0 || k >= P->nlevels) return ORC_ERR_UNSUPPORTED;
+    l = &P->lev[k];
+    v->n = l->n; v->L = l->L; v->U = l->U; v->D = l->D; v->perm_rows = l->perm_rows; v->perm_cols = l->perm_cols;
+    v->inv_perm_rows = l->inv_perm_rows; v->inv_perm_cols = l->inv_perm_cols; v->D_l = l->D_l; v->D_r = l->D_r; v->zero_pivots = l->zero_pivots;
+    return ORC_OK;
+}
+
+/* triangular_solve_with_smaller_matrix (+ _permute_first / _permute_last), sparse_implementation.h:4096-4165: the four loops of
+ * orc_trisolve on the LAST m entries of x */
+static void tail_permute(double *x, orc_int off, orc_int m, const orc_int *perm)
+{
+    orc_int i;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    for (i = 0; i < m; ++i) w[i] = x[off + i];
+    for (i = 0; i < m; ++i) x[off + i] = w[perm[i]];
+    free(w);
+}
+
+void orc_ml_apply(const orc_ml *P, int use, double *x)   /* apply_preconditioner_only :103-111 with left :441-453, right :468-486 */
+{
+    int i;
+    orc_int j;
+    const orc_int n = P->n;
+    if (use == ORC_ID) {
+        for (i = 0; i < P->nlevels; ++i) {
+            const struct orc_ml_level *l = &P->lev[i];
+            const orc_int off = n - l->n;
+            for (j = 0; j < l->n; ++j) x[off + j] /= l->D_l[j];
+            tail_permute(x, off, l->n, l->perm_rows);
+            orc_trisolve(l->n, l->L.ptr, l->L.idx, l->L.val, 0, ORC_LOWER, ORC_ID, x + off);
+        }
+        for (i = P->nlevels - 1; i >= 0; --i) {
+            const struct orc_ml_level *l = &P->lev[i];
+            const orc_int off = n - l->n;
+            for (j = 0; j < l->n; ++j) x[off + j] *= l->D[j];
+            orc_trisolve(l->n, l->U.ptr, l->U.idx, l->U.val, 1, ORC_UPPER, ORC_ID, x + off);
+            tail_permute(x, off, l->n, l->inv_perm_cols);
+            for (j = 0; j < l->n; ++j) x[off + j] /= l->D_r[j];
+        }
+    } else {
+        for (i = 0; i < P->nlevels; ++i) {
+            const struct orc_ml_level *l = &P->lev[i];
+            const orc_int off = n - l->n;
+            for (j = 0; j < l->n; ++j) x[off + j] /= l->D_r[j];
+            tail_permute(x, off, l->n, l->perm_cols);
+            orc_trisolve(l->n, l->U.ptr, l->U.idx, l->U.val, 1, ORC_UPPER, ORC_TRANSPOSE, x + off);
+            for (j = 0; j < l->n; ++j) x[off + j] *= l->D[j];
+        }
+        for (i = P->nlevels - 1; i >= 0; --i) {
+            const struct orc_ml_level *l = &P->lev[i];
+            const orc_int off = n - l->n;
+            orc_trisolve(l->n, l->L.ptr, l->L.idx, l->L.val, 0, ORC_LOWER, ORC_TRANSPOSE, x + off);
+            tail_permute(x, off, l->n, l->inv_perm_rows);
+            for (j = 0; j < l->n; ++j) x[off + j] /= l->D_l[j];
+        }
+    }
+}

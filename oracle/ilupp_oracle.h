@@ -41,7 +41,8 @@ enum {
     ORC_OK = 0,
     ORC_ERR_ZERO_PIVOT = 1,      /* ILUT.hpp:269-270; *err_row receives the row */
     ORC_ERR_NOT_TRIANGULAR = 2,  /* IChol.hpp:54-55, :105-107 */
-    ORC_ERR_MEMORY = 3           /* sparse_implementation.h:3178-3179 ("insufficient memory reserved") */
+    ORC_ERR_MEMORY = 3,          /* sparse_implementation.h:3178-3179 ("insufficient memory reserved") */
+    ORC_ERR_UNSUPPORTED = 4      /* a knob of the multilevel preconditioner that is not restated */
 };
 
 void orc_free_mat(orc_mat *M);
@@ -86,6 +87,51 @@ void orc_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key);
 /* dropping.hpp:8-34 on raw working-row arrays; returns the number of kept slots written to `list`. */
 orc_int orc_threshold_and_drop(const double *wdata, const orc_int *wpointer, orc_int wnnz,
                                orc_int *list, orc_int n, double tau, orc_int from, orc_int to);
+
+/* ---- multilevel ILU++ without pivoting (the precon_parameter 10 family): preconditioner_implementation.h:1350-1665 over
+ * ILUCDP.hpp:1405-2231, preprocessing sparse_implementation.h:5214-5460, apply preconditioner_implementation.h:433-488 ---- */
+enum {                                   /* steps of a preprocessing_sequence (orderings.h:27-63) that are restated */
+    ORC_PRE_NORMALIZE_COLUMNS = 1,
+    ORC_PRE_NORMALIZE_ROWS = 2,
+    ORC_PRE_PQ_ORDERING = 3,
+    ORC_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,
+    ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5
+};
+
+typedef struct {
+    double threshold;                    /* tau of the first level */
+    int n_preprocessing;
+    int preprocessing[8];
+    double pq_threshold;                 /* PQ_THRESHOLD */
+    int max_levels;                      /* MAX_LEVELS */
+    orc_int min_ml_size;                 /* MIN_ML_SIZE */
+    int small_pivot_terminates;          /* SMALL_PIVOT_TERMINATES */
+    double min_pivot;                    /* MIN_PIVOT */
+    double min_elim_factor;              /* MIN_ELIM_FACTOR */
+    double threshold_shift_schur;        /* THRESHOLD_SHIFT_SCHUR */
+    double vary_threshold_factor;        /* VARY_THRESHOLD_FACTOR */
+    int use_final_threshold;             /* USE_FINAL_THRESHOLD */
+    double final_threshold;              /* FINAL_THRESHOLD */
+} orc_ml_params;
+
+typedef struct orc_ml orc_ml;
+
+typedef struct {                         /* one level, borrowed from the object */
+    orc_int n;
+    orc_mat L, U;
+    const double *D;
+    const orc_int *perm_rows, *perm_cols, *inv_perm_rows, *inv_perm_cols;
+    const double *D_l, *D_r;
+    orc_int zero_pivots;
+} orc_ml_level_view;
+
+void orc_ml_default_params(orc_ml_params *p);      /* default_configuration(1): NORMALIZE_COLUMNS, NORMALIZE_ROWS, PQ + precon_parameter 10 */
+int orc_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, const orc_ml_params *IP, orc_ml **out);
+int orc_ml_levels(const orc_ml *P);
+orc_int orc_ml_total_nnz(const orc_ml *P);
+int orc_ml_level(const orc_ml *P, int k, orc_ml_level_view *v);
+void orc_ml_apply(const orc_ml *P, int use, double *x);
+void orc_ml_free(orc_ml *P);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,88 @@ class _Mat(ctypes.Structure):
 _I32P = ctypes.POINTER(ctypes.c_int32)
 _F64P = ctypes.POINTER(ctypes.c_double)
 
+# steps of a preprocessing sequence (ilupp_oracle.h)
+PRE_NORMALIZE_COLUMNS, PRE_NORMALIZE_ROWS, PRE_PQ_ORDERING, PRE_MAX_WEIGHTED_MATCHING_ORDERING, PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 1, 2, 3, 4, 5
+ERR_UNSUPPORTED = 4
+
+
+class MLParams(ctypes.Structure):
+    """orc_ml_params: the knobs of the multilevel preconditioner without pivoting (precon_parameter 10 family)"""
+    _fields_ = [("threshold", ctypes.c_double), ("n_preprocessing", ctypes.c_int), ("preprocessing", ctypes.c_int * 8),
+                ("pq_threshold", ctypes.c_double), ("max_levels", ctypes.c_int), ("min_ml_size", ctypes.c_int32),
+                ("small_pivot_terminates", ctypes.c_int), ("min_pivot", ctypes.c_double), ("min_elim_factor", ctypes.c_double),
+                ("threshold_shift_schur", ctypes.c_double), ("vary_threshold_factor", ctypes.c_double),
+                ("use_final_threshold", ctypes.c_int), ("final_threshold", ctypes.c_double)]
+
+
+class _MLView(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("L", _Mat), ("U", _Mat), ("D", _F64P), ("perm_rows", _I32P), ("perm_cols", _I32P),
+                ("inv_perm_rows", _I32P), ("inv_perm_cols", _I32P), ("D_l", _F64P), ("D_r", _F64P), ("zero_pivots", ctypes.c_int32)]
+
+
+def ml_params(threshold=0.0, preprocessing=(PRE_NORMALIZE_COLUMNS, PRE_NORMALIZE_ROWS, PRE_PQ_ORDERING), **kw):
+    """default_configuration(1) (NORMALIZE_COLUMNS, NORMALIZE_ROWS, PQ + precon_parameter 10) with single knobs changed"""
+    p = MLParams()
+    orc().lib.orc_ml_default_params(ctypes.byref(p))
+    p.threshold = threshold
+    p.n_preprocessing = len(preprocessing)
+    for i, s in enumerate(preprocessing):
+        p.preprocessing[i] = s
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class ML:
+    """a multilevel preconditioner object of either library"""
+
+    def __init__(self, lib, A, params):
+        self.libobj = lib
+        self.lib = lib.lib
+        self.pre = lib.prefix
+        args, self._keep = lib._in(A)
+        self.h = ctypes.c_void_p()
+        rc = getattr(self.lib, self.pre + "ml_create")(*args, ctypes.byref(params), ctypes.byref(self.h))
+        if rc:
+            raise OracleError(rc)
+        self.n = args[0]
+
+    def levels(self):
+        return int(getattr(self.lib, self.pre + "ml_levels")(self.h))
+
+    def total_nnz(self):
+        return int(getattr(self.lib, self.pre + "ml_total_nnz")(self.h))
+
+    def level(self, k):
+        v = _MLView()
+        rc = getattr(self.lib, self.pre + "ml_level")(self.h, int(k), ctypes.byref(v))
+        if rc:
+            raise OracleError(rc)
+        n = v.n
+
+        def mat(m):
+            nnz = m.nnz
+            return (np.ctypeslib.as_array(m.val, shape=(max(nnz, 1),))[:nnz].copy(), np.ctypeslib.as_array(m.idx, shape=(max(nnz, 1),))[:nnz].copy(),
+                    np.ctypeslib.as_array(m.ptr, shape=(n + 1,)).copy(), bool(m.is_csr))
+
+        def vec(p):
+            return np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].copy()
+        return {"n": n, "L": mat(v.L), "U": mat(v.U), "D": vec(v.D), "perm_rows": vec(v.perm_rows), "perm_cols": vec(v.perm_cols),
+                "inv_perm_rows": vec(v.inv_perm_rows), "inv_perm_cols": vec(v.inv_perm_cols), "D_l": vec(v.D_l), "D_r": vec(v.D_r),
+                "zero_pivots": int(v.zero_pivots)}
+
+    def apply(self, x, use=ID):
+        x = np.array(x, dtype=np.float64, copy=True).ravel()
+        getattr(self.lib, self.pre + "ml_apply")(self.h, int(use), _p_f64(x))
+        return x
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and self.h:
+            getattr(self.lib, self.pre + "ml_free")(self.h)
+            self.h = None
+
 
 def _p_i32(a):
     return a.ctypes.data_as(_I32P)
@@ -80,6 +162,19 @@ class _Lib:
         f("free_mat").restype = None
         f("sort_slots_by_abs_desc").argtypes = [_I32P, ctypes.c_int32, _F64P]
         f("sort_slots_by_abs_desc").restype = None
+        f("ml_create").argtypes = mat_in + [ctypes.POINTER(MLParams), ctypes.POINTER(ctypes.c_void_p)]
+        f("ml_levels").argtypes = [ctypes.c_void_p]
+        f("ml_total_nnz").argtypes = [ctypes.c_void_p]
+        f("ml_total_nnz").restype = ctypes.c_int32
+        f("ml_level").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(_MLView)]
+        f("ml_apply").argtypes = [ctypes.c_void_p, ctypes.c_int, _F64P]
+        f("ml_apply").restype = None
+        f("ml_free").argtypes = [ctypes.c_void_p]
+        f("ml_free").restype = None
+
+    def ml(self, A, params):
+        """multilevel ILU++ without pivoting: an ML object (levels, total_nnz, level(k), apply)"""
+        return ML(self, A, params)
 
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)

@@ -240,6 +240,106 @@ int ref_ilupp_apply(orc_int n, const orc_int *ptr, const orc_int *idx, const dou
     return ORC_OK;
 }
 
+
+/* ---- the multilevel preconditioner of binding.cpp:284-298 behind the orc_ml_* ABI (prefix ref_): parameters = default_parameters
+ * + init(sequence, 10) (parameters_implementation.h:832-934) with the knobs of orc_ml_params set through the reference's own setters ---- */
+struct ref_ml {
+    multilevelILUCDPPreconditioner<Real, matrix, vector> P;
+    orc_int n;
+    std::vector<orc_mat> Ls, Us;
+    std::vector<std::vector<double>> D, Dl, Dr;
+    std::vector<std::vector<orc_int>> pr, pc, ipr, ipc;
+};
+
+int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, const orc_ml_params *IP, ref_ml **out)
+{
+    *out = nullptr;
+    matrix A = view(n, ptr, idx, val, is_csr);
+    preprocessing_sequence seq;
+    seq.resize(IP->n_preprocessing);
+    for (int i = 0; i < IP->n_preprocessing; ++i) {
+        switch (IP->preprocessing[i]) {
+        case ORC_PRE_NORMALIZE_COLUMNS: seq.set(i) = NORMALIZE_COLUMNS; break;
+        case ORC_PRE_NORMALIZE_ROWS: seq.set(i) = NORMALIZE_ROWS; break;
+        case ORC_PRE_PQ_ORDERING: seq.set(i) = PQ_ORDERING; break;
+        case ORC_PRE_MAX_WEIGHTED_MATCHING_ORDERING: seq.set(i) = MAX_WEIGHTED_MATCHING_ORDERING; break;
+        case ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM: seq.set(i) = DD_SYMM_MOVE_CORNER_ORDERING_IM; break;
+        default: return ORC_ERR_UNSUPPORTED;
+        }
+    }
+    iluplusplus_precond_parameter param;
+    param.init(seq, 10, "");
+    param.set_threshold(IP->threshold);
+    param.set_PQ_THRESHOLD(IP->pq_threshold);
+    param.set_MAX_LEVELS(IP->max_levels);
+    param.set_MIN_ML_SIZE(IP->min_ml_size);
+    param.set_SMALL_PIVOT_TERMINATES(IP->small_pivot_terminates != 0);
+    param.set_MIN_PIVOT(IP->min_pivot);
+    param.set_MIN_ELIM_FACTOR(IP->min_elim_factor);
+    param.set_THRESHOLD_SHIFT_SCHUR(IP->threshold_shift_schur);
+    param.set_VARY_THRESHOLD_FACTOR(IP->vary_threshold_factor);
+    param.set_USE_FINAL_THRESHOLD(IP->use_final_threshold != 0);
+    param.set_FINAL_THRESHOLD(IP->final_threshold);
+    ref_ml *R = new ref_ml;
+    R->n = n;
+    try {
+        R->P.make_preprocessed_multilevelILUCDP(A, param);
+    } catch (...) {
+        delete R;
+        return ORC_ERR_ZERO_PIVOT;
+    }
+    if (!R->P.exists()) { delete R; return ORC_ERR_ZERO_PIVOT; }
+    const int nl = R->P.levels();
+    R->Ls.resize(nl); R->Us.resize(nl); R->D.resize(nl); R->Dl.resize(nl); R->Dr.resize(nl);
+    R->pr.resize(nl); R->pc.resize(nl); R->ipr.resize(nl); R->ipc.resize(nl);
+    for (int k = 0; k < nl; ++k) {
+        export_mat(R->P.extract_left_matrix(k), &R->Ls[k]);
+        export_mat(R->P.extract_right_matrix(k), &R->Us[k]);
+        const vector &d = R->P.extract_middle_matrix(k);
+        const Integer m = d.dimension();
+        R->D[k].resize(m); R->Dl[k].resize(m); R->Dr[k].resize(m); R->pr[k].resize(m); R->pc[k].resize(m); R->ipr[k].resize(m); R->ipc[k].resize(m);
+        for (Integer i = 0; i < m; ++i) {
+            R->D[k][i] = d[i];
+            R->Dl[k][i] = R->P.extract_left_scaling(k)[i];
+            R->Dr[k][i] = R->P.extract_right_scaling(k)[i];
+            R->pr[k][i] = R->P.extract_permutation_rows(k)[i];
+            R->pc[k][i] = R->P.extract_permutation_columns(k)[i];
+            R->ipr[k][i] = R->P.extract_inverse_permutation_rows(k)[i];
+            R->ipc[k][i] = R->P.extract_inverse_permutation_columns(k)[i];
+        }
+    }
+    *out = R;
+    return ORC_OK;
+}
+
+int ref_ml_levels(const ref_ml *R) { return R->P.levels(); }
+orc_int ref_ml_total_nnz(const ref_ml *R) { return R->P.total_nnz(); }
+
+int ref_ml_level(const ref_ml *R, int k, orc_ml_level_view *v)
+{
+    if (k < 0 || k >= R->P.levels()) return ORC_ERR_UNSUPPORTED;
+    v->n = (orc_int)R->D[k].size();
+    v->L = R->Ls[k]; v->U = R->Us[k]; v->D = R->D[k].data();
+    v->perm_rows = R->pr[k].data(); v->perm_cols = R->pc[k].data(); v->inv_perm_rows = R->ipr[k].data(); v->inv_perm_cols = R->ipc[k].data();
+    v->D_l = R->Dl[k].data(); v->D_r = R->Dr[k].data();
+    v->zero_pivots = R->P.zero_pivots_encountered(k);
+    return ORC_OK;
+}
+
+void ref_ml_apply(const ref_ml *R, int use, double *x)
+{
+    vector v(R->n, x, true);
+    R->P.apply_preconditioner_only(use == ORC_ID ? ID : TRANSPOSE, v);
+}
+
+void ref_ml_free(ref_ml *R)
+{
+    if (!R) return;
+    for (auto &m : R->Ls) ref_free_mat(&m);
+    for (auto &m : R->Us) ref_free_mat(&m);
+    delete R;
+}
+
 /* libstdc++'s own std::sort with the comparator of dropping.hpp:25-26, to pin orc_sort_slots_by_abs_desc */
 void ref_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key)
 {
