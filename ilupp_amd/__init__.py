@@ -22,6 +22,7 @@ from scipy.sparse.linalg import LinearOperator as _LinearOperator
 import os as _os
 
 from . import _native
+from .params import iluplusplus_precond_parameter, preprocessing_sequence  # noqa: F401  (reference: ilupp/__init__.py:27-28)
 
 __version__ = "0.2.0"
 
@@ -117,6 +118,40 @@ class _HipPreconditioner(_LinearOperator):
         rows, cols = self.shape
         what = "unspecified dtype" if self.dtype is None else "dtype=%s" % (self.dtype,)
         return "<%dx%d %s with nnz=%d, %s>" % (rows, cols, type(self).__name__, self.total_nnz, what)
+
+
+class ILUppPreconditioner(_HipPreconditioner):
+    """A multilevel ILU++ preconditioner (reference: ilupp/__init__.py:171-203 over binding.cpp:284-298).
+
+    Args:
+        A: a sparse matrix in CSR or CSC format
+        threshold: the threshold parameter for ILU++; entries with relative magnitude less than this are dropped
+        fill_in: the fill_in parameter for the ILU++ preconditioner
+        params: an instance of :class:`iluplusplus_precond_parameter`; if passed, overrides fill_in and threshold
+
+    The engine has the family WITHOUT pivoting (``params.default_configuration(1)``: normalisation + PQ ordering, factorisation
+    preset 10).  Default-constructed parameters select the reference's pivoting factorisation, which is not built: the call then
+    raises NotImplementedError -- nothing is replaced behind the caller's back."""
+
+    def __init__(self, A, threshold=1.0, fill_in=None, params=None):
+        if params is None:
+            params = iluplusplus_precond_parameter()
+            params.threshold = threshold
+            if fill_in is not None:
+                params.fill_in = fill_in
+        super().__init__(A, lambda m: _native.MultilevelILUCDPPreconditioner(*m, params))
+
+    @property
+    def memory(self):
+        return self.pr.memory
+
+    @property
+    def memory_used_calculations(self):
+        return self.pr.memory_used_calculations
+
+    @property
+    def memory_allocated_calculations(self):
+        return self.pr.memory_allocated_calculations
 
 
 class ILUTPreconditioner(_HipPreconditioner):

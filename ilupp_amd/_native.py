@@ -24,6 +24,15 @@ class Timings(ctypes.Structure):
                 ("lsolve_kernel_ms", ctypes.c_float), ("usolve_kernel_ms", ctypes.c_float)]
 
 
+class MLParams(ctypes.Structure):
+    """ilupp_ml_params of include/ilupp_hip.h"""
+    _fields_ = [("threshold", ctypes.c_double), ("n_preprocessing", ctypes.c_int32), ("preprocessing", ctypes.c_int32 * 8),
+                ("pq_threshold", ctypes.c_double), ("max_levels", ctypes.c_int32), ("min_ml_size", ctypes.c_int32),
+                ("small_pivot_terminates", ctypes.c_int32), ("min_pivot", ctypes.c_double), ("min_elim_factor", ctypes.c_double),
+                ("threshold_shift_schur", ctypes.c_double), ("vary_threshold_factor", ctypes.c_double),
+                ("use_final_threshold", ctypes.c_int32), ("final_threshold", ctypes.c_double)]
+
+
 _lib = None
 _lib_gil = None
 
@@ -37,6 +46,7 @@ def _lib_holding_gil():
         G = ctypes.PyDLL(_LIB_PATH)
         G.ilupp_hip_apply.argtypes = [_VP, _VP, ctypes.c_int64]
         G.ilupp_hip_apply_trans.argtypes = [_VP, _VP, ctypes.c_int64]
+        G.ilupp_hip_ml_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
         _lib_gil = G
     return _lib_gil
 
@@ -103,6 +113,22 @@ def lib():
     L.ilupp_hip_factor_device_ptrs.argtypes = [_VP, ctypes.c_int, ctypes.POINTER(_VP), ctypes.POINTER(_VP),
                                                ctypes.POINTER(_VP)]
     L.ilupp_hip_get_timings.argtypes = [_VP, ctypes.POINTER(Timings)]
+    L.ilupp_hip_ml_default_params.argtypes = [ctypes.POINTER(MLParams)]
+    L.ilupp_hip_ml_default_params.restype = None
+    L.ilupp_hip_ml_create.argtypes = mat_host + [ctypes.POINTER(MLParams), ctypes.POINTER(_VP)]
+    L.ilupp_hip_ml_create_device.argtypes = mat_host + [ctypes.POINTER(MLParams), ctypes.POINTER(_VP)]
+    L.ilupp_hip_ml_destroy.argtypes = [_VP]
+    L.ilupp_hip_ml_destroy.restype = None
+    L.ilupp_hip_ml_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
+    L.ilupp_hip_ml_apply_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    L.ilupp_hip_ml_sync.argtypes = [_VP]
+    L.ilupp_hip_ml_levels.argtypes = [_VP]
+    L.ilupp_hip_ml_levels.restype = ctypes.c_int32
+    L.ilupp_hip_ml_total_nnz.argtypes = [_VP]
+    L.ilupp_hip_ml_total_nnz.restype = ctypes.c_int64
+    L.ilupp_hip_ml_level_info.argtypes = [_VP, ctypes.c_int32, _I32P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    L.ilupp_hip_ml_level_copy.argtypes = [_VP, ctypes.c_int32] + [_VP] * 13
+    L.ilupp_hip_ml_timings.argtypes = [_VP, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     _lib = L
     return L
 
@@ -120,6 +146,9 @@ ABI_SYMBOLS = [
     "ilupp_hip_sync", "ilupp_hip_release_cached_memory", "ilupp_hip_set_cache_limit", "ilupp_hip_cached_bytes", "ilupp_hip_live_blocks", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
     "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_spmv_device",
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
+    "ilupp_hip_ml_default_params", "ilupp_hip_ml_create", "ilupp_hip_ml_create_device", "ilupp_hip_ml_destroy", "ilupp_hip_ml_apply",
+    "ilupp_hip_ml_apply_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
+    "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings",
 ]
 
 
@@ -286,6 +315,113 @@ class Preconditioner:
         t = Timings()
         lib().ilupp_hip_get_timings(self._h, ctypes.byref(t))
         return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+
+class MultilevelPreconditioner:
+    """Native multilevel ILU++ object: the members wrapPreconditioner<_MultilevelILUCDPPreconditioner> gives it (binding.cpp:233-264,
+    :284-298), plus the levels for tests and measurements."""
+
+    def __init__(self, handle, n):
+        self._h = handle
+        self._n = n
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.ilupp_hip_ml_destroy(h)
+
+    def _apply(self, x, transpose):
+        mv = _check_real(x, "b")
+        if mv.readonly:
+            raise RuntimeError("b must be writable")
+        a = np.frombuffer(mv, dtype=np.float64)
+        if a.shape[0] != self._n:
+            raise RuntimeError("vector has wrong size for preconditioner!")
+        rc = _lib_holding_gil().ilupp_hip_ml_apply(self._h, a.ctypes.data, a.shape[0], transpose)
+        if rc:
+            _raise(rc)
+
+    def apply(self, x):
+        self._apply(x, 0)
+
+    def apply_trans(self, x):
+        self._apply(x, 1)
+
+    def apply_device(self, dptr, n, transpose=False, sync=True):
+        rc = lib().ilupp_hip_ml_apply_device(self._h, dptr, n, 1 if transpose else 0, 1 if sync else 0)
+        if rc:
+            _raise(rc)
+
+    def sync(self):
+        rc = lib().ilupp_hip_ml_sync(self._h)
+        if rc:
+            _raise(rc)
+
+    @property
+    def total_nnz(self):
+        return int(lib().ilupp_hip_ml_total_nnz(self._h))
+
+    # (preconditioner.h:65, :113: bookkeeping of host allocations in the reference; nothing of the kind lives on the host here)
+    memory_used_calculations = 0.0
+    memory_allocated_calculations = 0.0
+    memory = 0.0
+    exists = True
+    special_info = ""
+
+    def factors_info(self):
+        """binding.cpp:158-163: "not implemented" for the multilevel class -- an empty list"""
+        return []
+
+    def print_info(self):
+        print("A multilevel incomplete LU factorisation: %d levels, %d entries" % (self.levels(), self.total_nnz))
+
+    def levels(self):
+        return int(lib().ilupp_hip_ml_levels(self._h))
+
+    def level(self, k):
+        """level k as a dict: L (by columns), U (by rows) as (data, indices, indptr), D, the permutations, the scalings"""
+        L = lib()
+        n, nl, nu = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        rc = L.ilupp_hip_ml_level_info(self._h, k, ctypes.byref(n), ctypes.byref(nl), ctypes.byref(nu))
+        if rc:
+            _raise(rc)
+        n, nl, nu = n.value, nl.value, nu.value
+        out = {"n": n,
+               "L": (np.empty(nl), np.empty(nl, dtype=np.int32), np.empty(n + 1, dtype=np.int32)),
+               "U": (np.empty(nu), np.empty(nu, dtype=np.int32), np.empty(n + 1, dtype=np.int32)),
+               "D": np.empty(n), "perm_rows": np.empty(n, dtype=np.int32), "perm_cols": np.empty(n, dtype=np.int32),
+               "inv_perm_rows": np.empty(n, dtype=np.int32), "inv_perm_cols": np.empty(n, dtype=np.int32), "D_l": np.empty(n), "D_r": np.empty(n)}
+        ptrs = [a.ctypes.data for a in out["L"]] + [a.ctypes.data for a in out["U"]] + [
+            out[k2].ctypes.data for k2 in ("D", "perm_rows", "perm_cols", "inv_perm_rows", "inv_perm_cols", "D_l", "D_r")]
+        rc = L.ilupp_hip_ml_level_copy(self._h, k, *ptrs)
+        if rc:
+            _raise(rc)
+        return out
+
+    def timings(self):
+        a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        lib().ilupp_hip_ml_timings(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return {"construct_ms": a.value, "kernel_ms": b.value, "last_apply_ms": c.value}
+
+
+def MultilevelILUCDPPreconditioner(A_data, A_indices, A_indptr, is_csr, param):
+    """binding.cpp:284-298; `param`: an iluplusplus_precond_parameter (ilupp_amd.params) or an MLParams block"""
+    p = param if isinstance(param, MLParams) else param._to_ml_params()
+    args, keep = _matrix_args(A_data, A_indices, A_indptr, is_csr)
+    h = _VP()
+    rc = lib().ilupp_hip_ml_create(*args, ctypes.byref(p), ctypes.byref(h))
+    if rc:
+        _raise(rc)
+    return MultilevelPreconditioner(h, args[3])
+
+
+def MultilevelILUCDPPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, param):
+    p = param if isinstance(param, MLParams) else param._to_ml_params()
+    h = _VP()
+    rc = lib().ilupp_hip_ml_create_device(d_data, d_indices, d_indptr, n, 1 if is_csr else 0, ctypes.byref(p), ctypes.byref(h))
+    if rc:
+        _raise(rc)
+    return MultilevelPreconditioner(h, n)
 
 
 def _create(fn, A_data, A_indices, A_indptr, is_csr, *extra):

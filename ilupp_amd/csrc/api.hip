@@ -181,6 +181,7 @@ struct ilupp_precond {
     ilupp_timings tm = {0, 0, 0, 0, 0, 0};
     bool apply_events_valid = false;
     int max_lanes = 65536;
+    bool borrowed_queue = false; // stream and events belong to another object (the levels of a multilevel preconditioner share one)
 };
 
 namespace {
@@ -207,7 +208,7 @@ void destroy_obj(ilupp_precond *p)
     if (p->done) (void)pool_free(p->done);
     if (p->ctrl) (void)pool_free(p->ctrl);
     // streams and events are recycled: creating them costs more than a small kernel
-    if (p->stream) {
+    if (p->stream && !p->borrowed_queue) {
         std::lock_guard<std::mutex> lk(g_queues.mu);
         QueuePack q; q.stream = p->stream; q.device = p->device;
         for (int k = 0; k < 6; ++k) q.ev[k] = p->ev[k];
@@ -733,6 +734,27 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
 }  // extern "C"
 
 // ILUC: A = the major-order view (CSR arrays of the input, whatever its orientation: ILUC2 works on dim_along_orientation)
+// the sweeps of an object whose two factors both read as upper CSR matrices with the diagonal first (ILUC; a level of the multilevel
+// preconditioner): backward schedules and descriptors of the stored arrays (the forward sweeps run on transposed copies, built on first use)
+static void utu_analyse(ilupp_precond *p)
+{
+    hipStream_t st = p->stream;
+    const int32_t n = p->n;
+    int32_t m1 = 0, m2 = 0;
+    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);
+    count_cuts_and_schedule(st, n, p->Uc.ptr, p->Uc.idx, p->max_lanes, nullptr, &p->sU, &m2);
+    p->max_row_len = m1 > m2 ? m1 : m2;
+    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, false, p->max_lanes / kThreads);
+    choose_tiling(st, n, p->Uc.ptr, p->Uc.idx, &p->sU, false, p->max_lanes / kThreads);
+    build_slot_tables(st, &p->sL, false);
+    build_slot_tables(st, &p->sU, false);
+    p->compact = schedule_is_compact(p->sL) && schedule_is_compact(p->sU);
+    if (p->compact) {
+        make_desc(st, p->Lc, p->sL, &p->dL);
+        make_desc(st, p->Uc, p->sU, &p->dU);
+    }
+}
+
 static int iluc_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
     // (guards: an ILUPP_HIP that throws below must leave neither the object nor the factors behind)
@@ -760,19 +782,7 @@ static int iluc_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill
     // view (preconditioner_implementation.h:940-951) -- and iluc() interchanges the same way (binding.cpp:456-457)
     if (is_csr) { p->Lc = Lcol; p->Uc = Urow; } else { p->Lc = Urow; p->Uc = Lcol; }
     Lcol.ptr = Lcol.idx = nullptr; Lcol.val = nullptr; Urow.ptr = Urow.idx = nullptr; Urow.val = nullptr;      // (the object owns them now)
-    int32_t m1 = 0, m2 = 0;
-    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);
-    count_cuts_and_schedule(st, n, p->Uc.ptr, p->Uc.idx, p->max_lanes, nullptr, &p->sU, &m2);
-    p->max_row_len = m1 > m2 ? m1 : m2;
-    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, false, p->max_lanes / kThreads);
-    choose_tiling(st, n, p->Uc.ptr, p->Uc.idx, &p->sU, false, p->max_lanes / kThreads);
-    build_slot_tables(st, &p->sL, false);
-    build_slot_tables(st, &p->sU, false);
-    p->compact = schedule_is_compact(p->sL) && schedule_is_compact(p->sU);
-    if (p->compact) {
-        make_desc(st, p->Lc, p->sL, &p->dL);
-        make_desc(st, p->Uc, p->sU, &p->dU);
-    }
+    utu_analyse(p);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
     ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
@@ -1259,6 +1269,317 @@ int ilupp_hip_sync(ilupp_precond *p)
     if (!p) return ILUPP_ERR_INVALID;
     return finish_apply(p);
     API_CATCH
+}
+
+}  // extern "C"
+
+// ================================================================================================================================
+// the multilevel ILU++ preconditioner without pivoting (include/ilupp_hip.h: ilupp_hip_ml_*).  Levels from ml.hip /
+// piluc_df.hip; every level's two factors are an object of the ILUC kind (left by columns, right by rows, both unit), whose sweep
+// kernels the apply borrows one half at a time: preconditioner_implementation.h:441-453 (left: all levels upwards) and :468-486
+// (right: all levels downwards), each on the LAST n_level entries of the vector (sparse_implementation.h:4096-4165).
+// ================================================================================================================================
+struct ilupp_ml {
+    int32_t n = 0;
+    std::vector<MlLevelDev> dev;              // per level: scalings, permutations, the middle diagonal (the factors move into `obj`)
+    std::vector<ilupp_precond *> obj;         // per level: the sweeps of its two factors
+    double *buf = nullptr;                    // n: what a sweep reads
+    double *xdev = nullptr;                   // n: staging of host vectors
+    float construct_ms = 0.f, kernel_ms = 0.f, last_apply_ms = 0.f;
+};
+
+namespace {
+
+void ml_destroy(ilupp_ml *m)
+{
+    if (!m) return;
+    // (the first level owns the stream the others borrow: it goes last)
+    for (size_t k = m->obj.size(); k-- > 0;) if (m->obj[k]) destroy_obj(m->obj[k]);
+    for (auto &l : m->dev) l.release();
+    if (m->buf) (void)pool_free(m->buf);
+    if (m->xdev) (void)pool_free(m->xdev);
+    delete m;
+}
+
+// one half of the ILUC-kind apply (apply_dev, KIND_UTU): forward = the T2 loop (left factor, or right^T), backward = the T3 loop
+int utu_half(ilupp_precond *p, bool forward, bool tr, double *rhs, double *out, int32_t *ticket)
+{
+    ensure_transposed(p);
+    int32_t *err = p->ctrl;
+    if (forward) {
+        const DevMat &Mf = tr ? p->UcT : p->LcT;
+        const Schedule &sf = tr ? p->sUT : p->sLT;
+        const int32_t *df = tr ? p->dUT : p->dLT;
+        const PackedSweep *p1 = packed(p, tr ? 2 : 3, SWEEP_FWD_LAST_ASC, Mf, sf, df, MAXLEN_OF(Mf), tr ? &p->pkUT : &p->pkLT);
+        return sweep(p, SWEEP_FWD_LAST_ASC, Mf, sf, df, MAXLEN_OF(Mf), p1, rhs, out, ticket, err);
+    }
+    const DevMat &Mb = tr ? p->Lc : p->Uc;
+    const Schedule &sb = tr ? p->sL : p->sU;
+    const int32_t *db = tr ? p->dL : p->dU;
+    const PackedSweep *p2 = packed(p, tr ? 0 : 1, SWEEP_BWD_FIRST_ASC, Mb, sb, db, MAXLEN_OF(Mb), tr ? &p->pkL : &p->pkU);
+    return sweep(p, SWEEP_BWD_FIRST_ASC, Mb, sb, db, MAXLEN_OF(Mb), p2, rhs, out, ticket, err);
+}
+
+int ml_apply_dev(ilupp_ml *m, double *x, int transpose)
+{
+    ilupp_precond *p0 = m->obj[0];
+    hipStream_t st = p0->stream;
+    order_after_caller(st, p0->sev[0]);
+    const int nl = (int)m->obj.size();
+    for (int i = 0; i < nl; ++i) ILUPP_HIP(hipMemsetAsync(m->obj[(size_t)i]->ctrl, 0, 64, st));
+    ILUPP_HIP(hipEventRecord(p0->ev[0], st));
+    const bool tr = transpose != 0;
+    // first pass upwards through the levels, second pass downwards (:103-111 with :441-453, :468-486)
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int s = 0; s < nl; ++s) {
+            const int i = pass == 0 ? s : nl - 1 - s;
+            ilupp_precond *p = m->obj[(size_t)i];
+            const MlLevelDev &l = m->dev[(size_t)i];
+            double *xt = x + (m->n - l.n);
+            int rc = ILUPP_OK;
+            if (!tr && pass == 0) {            // left, ID: x /= D_l; permute_first(perm_rows); T2(L)
+                ml_scale_perm(st, l.n, xt, l.Dl, l.pr, m->buf);
+                rc = utu_half(p, true, false, m->buf, p->work, p->ctrl + 4);
+                if (!rc) ml_take(st, l.n, p->work, nullptr, xt);
+            } else if (!tr) {                  // right, ID: x *= D; T3(U); permute_last(inverse_perm_columns); x /= D_r
+                ml_scale(st, l.n, xt, l.D, m->buf);
+                rc = utu_half(p, false, false, m->buf, p->work, p->ctrl + 5);
+                if (!rc) {
+                    ml_perm_scale(st, l.n, p->work, l.ipc, l.Dr, xt);
+                    fill_u64(st, reinterpret_cast<unsigned long long *>(p->work), l.n, kSentinel);
+                }
+            } else if (pass == 0) {            // right, TRANSPOSE: x /= D_r; permute_first(perm_columns); T2(U^T); x *= D
+                ml_scale_perm(st, l.n, xt, l.Dr, l.pc, m->buf);
+                rc = utu_half(p, true, true, m->buf, p->work, p->ctrl + 4);
+                if (!rc) ml_take(st, l.n, p->work, l.D, xt);
+            } else {                           // left, TRANSPOSE: T3(L^T); permute_last(inverse_perm_rows); x /= D_l
+                ILUPP_HIP(hipMemcpyAsync(m->buf, xt, sizeof(double) * (size_t)l.n, hipMemcpyDeviceToDevice, st));
+                rc = utu_half(p, false, true, m->buf, p->work, p->ctrl + 5);
+                if (!rc) {
+                    ml_perm_scale(st, l.n, p->work, l.ipr, l.Dl, xt);
+                    fill_u64(st, reinterpret_cast<unsigned long long *>(p->work), l.n, kSentinel);
+                }
+            }
+            if (rc) return rc;
+        }
+    }
+    ILUPP_HIP(hipEventRecord(p0->ev[2], st));
+    return ILUPP_OK;
+}
+
+int ml_finish_apply(ilupp_ml *m)
+{
+    ilupp_precond *p0 = m->obj[0];
+    const int nl = (int)m->obj.size();
+    std::vector<int32_t> err((size_t)nl, 0);
+    for (int i = 0; i < nl; ++i) ILUPP_HIP(hipMemcpyAsync(&err[(size_t)i], m->obj[(size_t)i]->ctrl, sizeof(int32_t), hipMemcpyDeviceToHost, p0->stream));
+    ILUPP_HIP(stream_sync(p0->stream));
+    ILUPP_HIP(hipEventElapsedTime(&m->last_apply_ms, p0->ev[0], p0->ev[2]));
+    for (int i = 0; i < nl; ++i)
+        if (err[(size_t)i]) {
+            for (int j = 0; j < nl; ++j) fill_u64(p0->stream, reinterpret_cast<unsigned long long *>(m->obj[(size_t)j]->work), m->obj[(size_t)j]->n, kSentinel);
+            ILUPP_HIP(stream_sync(p0->stream));
+            set_error("triangular solve: dependency wait timed out (factor not triangular?)");
+            return ILUPP_ERR_TIMEOUT;
+        }
+    return ILUPP_OK;
+}
+
+int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
+{
+    MlParams P;
+    P.threshold = ip->threshold;
+    P.n_pre = ip->n_preprocessing;
+    if (P.n_pre < 0 || P.n_pre > 8) { set_error("ILU++: at most 8 preprocessing steps"); return ILUPP_ERR_INVALID; }
+    for (int i = 0; i < P.n_pre; ++i) P.pre[i] = ip->preprocessing[i];
+    P.pq_threshold = ip->pq_threshold; P.max_levels = ip->max_levels; P.min_ml_size = ip->min_ml_size;
+    P.pil.small_pivot_terminates = ip->small_pivot_terminates != 0; P.pil.min_pivot = ip->min_pivot; P.pil.min_elim_factor = ip->min_elim_factor;
+    P.pil.threshold_shift_schur = ip->threshold_shift_schur; P.vary_threshold_factor = ip->vary_threshold_factor;
+    P.use_final_threshold = ip->use_final_threshold != 0; P.final_threshold = ip->final_threshold;
+    struct MlGuard { ilupp_ml *m; ~MlGuard() { if (m) ml_destroy(m); } } g{new ilupp_ml()};
+    ilupp_ml *m = g.m;
+    m->n = A.n;
+    // the first level's object owns the stream everything runs on
+    ilupp_precond *p0 = new_obj(A.n);
+    m->obj.push_back(p0);
+    hipStream_t st = p0->stream;
+    ILUPP_HIP(hipEventRecord(p0->ev[0], st));
+    int rc = ml_build(st, A, P, &m->dev, &m->kernel_ms);
+    if (rc) return rc;
+    ILUPP_HIP(pool_malloc(&m->buf, sizeof(double) * (size_t)A.n));
+    for (size_t k = 0; k < m->dev.size(); ++k) {
+        MlLevelDev &l = m->dev[k];
+        ilupp_precond *p = p0;
+        if (k > 0) {
+            p = new_obj(l.n);
+            m->obj.push_back(p);
+            {   // its own queue back to the pool: the level works on the first level's
+                std::lock_guard<std::mutex> lk(g_queues.mu);
+                QueuePack q; q.stream = p->stream; q.device = p->device;
+                for (int e = 0; e < 6; ++e) q.ev[e] = p->ev[e];
+                q.sev[0] = p->sev[0]; q.sev[1] = p->sev[1];
+                g_queues.free_list.push_back(q);
+            }
+            p->stream = st;
+            for (int e = 0; e < 6; ++e) p->ev[e] = p0->ev[e];
+            p->sev[0] = p0->sev[0]; p->sev[1] = p0->sev[1];
+            p->borrowed_queue = true;
+        }
+        p->kind = KIND_UTU; p->nnz_mode = NNZ_GENERIC_LU; p->input_csc = false;
+        p->Lc = l.L; p->Uc = l.U;
+        l.L = DevMat(); l.U = DevMat();                        // (the object owns the arrays now)
+        utu_analyse(p);
+    }
+    ILUPP_HIP(hipEventRecord(p0->ev[1], st));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(hipEventElapsedTime(&m->construct_ms, p0->ev[0], p0->ev[1]));
+    *out = m;
+    g.m = nullptr;
+    return ILUPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ilupp_hip_ml_default_params(ilupp_ml_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->threshold = 0.0;
+    p->n_preprocessing = 3;
+    p->preprocessing[0] = ILUPP_PRE_NORMALIZE_COLUMNS; p->preprocessing[1] = ILUPP_PRE_NORMALIZE_ROWS; p->preprocessing[2] = ILUPP_PRE_PQ_ORDERING;
+    p->pq_threshold = 0.0; p->max_levels = 100; p->min_ml_size = 0;
+    p->small_pivot_terminates = 1; p->min_pivot = 1e-2; p->min_elim_factor = 0.0; p->threshold_shift_schur = 0.0;
+    p->vary_threshold_factor = 1.0; p->use_final_threshold = 0; p->final_threshold = 0.0;
+}
+
+int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const ilupp_ml_params *params,
+                        ilupp_ml **out)
+{
+    API_TRY
+    if (!out || !params) { set_error("null argument"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    struct MatGuard { DevMat m; ~MatGuard() { m.release(); } } ga;
+    DevMat &A = ga.m;
+    A.n = n; A.nnz = nnz; A.is_csr = is_csr != 0; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    return ml_create_common(A, params, out);
+    API_CATCH
+}
+
+int ilupp_hip_ml_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr, int32_t n, int is_csr,
+                               const ilupp_ml_params *params, ilupp_ml **out)
+{
+    API_TRY
+    if (!out || !params) { set_error("null argument"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+    DevMat A;
+    A.n = n; A.nnz = read_device_nnz(d_indptr, n); A.is_csr = is_csr != 0; A.owns = false;
+    A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+    return ml_create_common(A, params, out);
+    API_CATCH
+}
+
+void ilupp_hip_ml_destroy(ilupp_ml *p)
+{
+    try { ml_destroy(p); } catch (...) {}
+}
+
+int ilupp_hip_ml_apply_device(ilupp_ml *m, double *d_x, int64_t len, int transpose, int sync)
+{
+    API_TRY
+    if (!m) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    if (len != m->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }
+    int rc = ml_apply_dev(m, d_x, transpose);
+    if (rc) return rc;
+    if (sync) return ml_finish_apply(m);
+    order_caller_after(m->obj[0]->stream, m->obj[0]->sev[1]);
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int ilupp_hip_ml_apply(ilupp_ml *m, double *x, int64_t len, int transpose)
+{
+    API_TRY
+    if (!m) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    if (len != m->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }
+    if (!m->xdev) ILUPP_HIP(pool_malloc(&m->xdev, sizeof(double) * (size_t)m->n));
+    ILUPP_HIP(hipMemcpyAsync(m->xdev, x, sizeof(double) * (size_t)m->n, hipMemcpyHostToDevice, m->obj[0]->stream));
+    int rc = ml_apply_dev(m, m->xdev, transpose);
+    if (rc) return rc;
+    rc = ml_finish_apply(m);
+    if (rc) return rc;
+    ILUPP_HIP(hipMemcpy(x, m->xdev, sizeof(double) * (size_t)m->n, hipMemcpyDeviceToHost));
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int ilupp_hip_ml_sync(ilupp_ml *m)
+{
+    API_TRY
+    if (!m) return ILUPP_ERR_INVALID;
+    return ml_finish_apply(m);
+    API_CATCH
+}
+
+int32_t ilupp_hip_ml_levels(const ilupp_ml *m) { return m ? (int32_t)m->obj.size() : 0; }
+
+int64_t ilupp_hip_ml_total_nnz(const ilupp_ml *m)          // preconditioner.h:312 with preconditioner_implementation.h:551-569
+{
+    if (!m) return 0;
+    int64_t sum = 0;
+    for (const ilupp_precond *p : m->obj) sum += (p->Lc.nnz - p->n) + (p->Uc.nnz - p->n) + p->n;
+    return sum;
+}
+
+int ilupp_hip_ml_level_info(const ilupp_ml *m, int32_t level, int32_t *n, int64_t *nnz_left, int64_t *nnz_right)
+{
+    if (!m || level < 0 || level >= (int32_t)m->obj.size()) { set_error("no such level"); return ILUPP_ERR_INVALID; }
+    const ilupp_precond *p = m->obj[(size_t)level];
+    if (n) *n = p->n;
+    if (nnz_left) *nnz_left = p->Lc.nnz;
+    if (nnz_right) *nnz_right = p->Uc.nnz;
+    return ILUPP_OK;
+}
+
+int ilupp_hip_ml_level_copy(const ilupp_ml *m, int32_t level, double *l_data, int32_t *l_indices, int32_t *l_indptr, double *u_data, int32_t *u_indices,
+                            int32_t *u_indptr, double *middle, int32_t *perm_rows, int32_t *perm_cols, int32_t *inv_perm_rows, int32_t *inv_perm_cols,
+                            double *d_left, double *d_right)
+{
+    API_TRY
+    if (!m || level < 0 || level >= (int32_t)m->obj.size()) { set_error("no such level"); return ILUPP_ERR_INVALID; }
+    const ilupp_precond *p = m->obj[(size_t)level];
+    const MlLevelDev &l = m->dev[(size_t)level];
+    ILUPP_HIP(stream_sync(p->stream));
+    const size_t n = (size_t)p->n;
+    auto get = [](void *dst, const void *src, size_t bytes) { if (dst && bytes) ILUPP_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); };
+    get(l_data, p->Lc.val, sizeof(double) * (size_t)p->Lc.nnz); get(l_indices, p->Lc.idx, sizeof(int32_t) * (size_t)p->Lc.nnz); get(l_indptr, p->Lc.ptr, sizeof(int32_t) * (n + 1));
+    get(u_data, p->Uc.val, sizeof(double) * (size_t)p->Uc.nnz); get(u_indices, p->Uc.idx, sizeof(int32_t) * (size_t)p->Uc.nnz); get(u_indptr, p->Uc.ptr, sizeof(int32_t) * (n + 1));
+    get(middle, l.D, sizeof(double) * n);
+    get(perm_rows, l.pr, sizeof(int32_t) * n); get(perm_cols, l.pc, sizeof(int32_t) * n);
+    get(inv_perm_rows, l.ipr, sizeof(int32_t) * n); get(inv_perm_cols, l.ipc, sizeof(int32_t) * n);
+    get(d_left, l.Dl, sizeof(double) * n); get(d_right, l.Dr, sizeof(double) * n);
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int ilupp_hip_ml_timings(const ilupp_ml *m, float *construct_ms, float *kernel_ms, float *last_apply_ms)
+{
+    if (!m) return ILUPP_ERR_INVALID;
+    if (construct_ms) *construct_ms = m->construct_ms;
+    if (kernel_ms) *kernel_ms = m->kernel_ms;
+    if (last_apply_ms) *last_apply_ms = m->last_apply_ms;
+    return ILUPP_OK;
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/ilupp_hip.h"
 
@@ -315,6 +316,44 @@ int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, do
 // iluc_df.hip: Crout ILU on the major-order view; L by columns (arrays = CSR of L^T, 1 first), U by rows (pivot first)
 int iluc_factor(hipStream_t st, const DevMat &Av, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U, int32_t *err_row,
                 float *kernel_ms);
+
+// piluc_df.hip: one level of the multilevel preconditioner without pivoting (reference partialILUC, ILUCDP.hpp:1405-2231)
+struct PilucParams {
+    double min_pivot = 1e-2;              // MIN_PIVOT
+    bool small_pivot_terminates = true;   // SMALL_PIVOT_TERMINATES
+    double min_elim_factor = 0.0;         // MIN_ELIM_FACTOR
+    double threshold_shift_schur = 0.0;   // THRESHOLD_SHIFT_SCHUR
+};
+int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv, DevMat *Anew,
+                int32_t *kterm, float *kernel_ms);
+
+// ml.hip: the multilevel preconditioner built from such levels (reference preconditioner_implementation.h:1350-1665, :433-488)
+enum { ML_PRE_NORMALIZE_COLUMNS = 1, ML_PRE_NORMALIZE_ROWS = 2, ML_PRE_PQ_ORDERING = 3 };    // = ILUPP_PRE_* of include/ilupp_hip.h
+struct MlParams {
+    double threshold = 0.0;
+    int n_pre = 0;
+    int pre[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double pq_threshold = 0.0;            // PQ_THRESHOLD
+    int max_levels = 100;                 // MAX_LEVELS
+    int32_t min_ml_size = 0;              // MIN_ML_SIZE
+    PilucParams pil;
+    double vary_threshold_factor = 1.0;   // VARY_THRESHOLD_FACTOR
+    bool use_final_threshold = false;     // USE_FINAL_THRESHOLD
+    double final_threshold = 0.0;         // FINAL_THRESHOLD
+};
+struct MlLevelDev {
+    int32_t n = 0;
+    DevMat L, U;                          // Precond_left (by columns, the 1 first), Precond_right (by rows, the 1 first)
+    double *D = nullptr;                  // Precond_middle
+    double *Dl = nullptr, *Dr = nullptr;  // D_l, D_r
+    int32_t *pr = nullptr, *pc = nullptr, *ipr = nullptr, *ipc = nullptr;   // permutation_rows / _columns and their inverses
+    void release();
+};
+int ml_build(hipStream_t st, const DevMat &A, const MlParams &IP, std::vector<MlLevelDev> *levels, float *kernel_ms);
+void ml_scale_perm(hipStream_t st, int32_t n, const double *x, const double *D, const int32_t *perm, double *out);
+void ml_take(hipStream_t st, int32_t n, double *w, const double *D, double *x);
+void ml_scale(hipStream_t st, int32_t n, const double *x, const double *D, double *out);
+void ml_perm_scale(hipStream_t st, int32_t n, const double *w, const int32_t *perm, const double *D, double *x);
 
 // ilut.hip
 int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U,

@@ -37,6 +37,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include "iluc_common.h"
 #include "stdsort.h"
 
 #ifndef ILUC_W4
@@ -47,10 +48,6 @@
 #endif
 
 namespace ilupp {
-
-static constexpr int kCuQ = 64;           // ready queues (step i goes to queue i % nq)
-static constexpr int kCuQBase = 64;       // ctrl word of queue 0's head; queue q: head at kCuQBase + 64 q, tail 32 words later
-static constexpr unsigned kCuSpinLimit = 1u << 22;
 
 // ctrl: [2] error (1 = capacity exceeded -> next class, 2 = timeout), [3] smallest step without a pivot, [4] finished steps, then the queues
 // pending[x]: entries of A left of the diagonal in row x and above it in column x
@@ -129,10 +126,6 @@ __global__ void k_iluc_seed(int32_t m, int32_t nq, const int32_t *__restrict__ p
     }
 }
 
-__device__ __forceinline__ unsigned long long cu_pack2(int lo, int hi)
-{
-    return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
-}
 
 // bytes of one wave's working arrays in the global class
 __host__ __device__ inline size_t iluc_ws_bytes(int ne, int ns, int tm)

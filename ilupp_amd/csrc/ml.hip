@@ -1,0 +1,364 @@
+// ilupp_amd/csrc/ml.hip -- the multilevel ILU++ preconditioner without pivoting (the precon_parameter 10
+// family of the reference): the loop over the levels of multilevelILUCDPPreconditioner::make_preprocessed_multilevelILUCDP
+// (preconditioner_implementation.h:1350-1665, use_ILUC branch) with the preprocessing of matrix_sparse::preprocess
+// (sparse_implementation.h:5214-5460) around piluc_level (piluc_df.hip), and the vector kernels of the multilevel apply (:433-488).
+//
+// Where things run.  The matrix of every level stays in HBM from the input to the last Schur complement: normalisation (column and
+// row 2-norms, summed in the reference's storage order), scaling, the application of the permutations, the factorisation, the Schur
+// complement.  The ORDER decisions of the PQ preprocessing are taken on the host: the candidate weights and columns are computed on
+// the device (one sequential sum per row), then n weights go to the host, where the reference's own unstable quicksort
+// (sparse_implementation.h:471-505 -- the order of equal weights is part of the result) and the greedy selection (:4611-4634), both
+// sequential by definition, produce the two permutations, which go back as 2 n integers.
+#include <stdlib.h>
+
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "iluc_common.h"
+
+namespace ilupp {
+
+// ---------------------------------------------- normalisation ----------------------------------------------
+// vector_dense::norm2_of_dim1 along the storage order (sparse_implementation.h:820-833) + inverse_scale (:3271-3282), rows of a ROW matrix
+__global__ void k_ml_row_norms_scale(int32_t n, const int32_t *__restrict__ ptr, double *__restrict__ val, double *__restrict__ D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int j = ptr[i]; j < ptr[i + 1]; ++j) { const double sq = val[j] * val[j]; s = s + sq; }
+    const double d = sqrt(s);
+    D[i] = d;
+    for (int j = ptr[i]; j < ptr[i + 1]; ++j) val[j] = val[j] / d;
+}
+// ... and columns: the entries of a column in the order of the storage = by increasing row = the order of the transposed storage
+__global__ void k_ml_col_norms(int32_t n, const int32_t *__restrict__ tptr, const double *__restrict__ tval, double *__restrict__ D)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    double s = 0.0;
+    for (int j = tptr[c]; j < tptr[c + 1]; ++j) { const double sq = tval[j] * tval[j]; s = s + sq; }
+    D[c] = sqrt(s);
+}
+__global__ void k_ml_col_scale(int64_t nnz, const int32_t *__restrict__ idx, double *__restrict__ val, const double *__restrict__ D)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nnz) val[j] = val[j] / D[idx[j]];
+}
+// Dtot[i] *= D[inv[i]]   (D.permute(inv); Dtot.multiply(D), :5243-5244 / :5249-5250)
+__global__ void k_ml_fold_scaling(int32_t n, double *__restrict__ Dtot, const double *__restrict__ D, const int32_t *__restrict__ inv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Dtot[i] = Dtot[i] * D[inv ? inv[i] : i];
+}
+__global__ void k_ml_fill_f64(int32_t n, double *p, double v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------- PQ ordering ----------------------------------------------
+// Algorithm 3.1 of matrix_sparse::ddPQ (:4584-4606): per row the column of the largest magnitude (the first of equals) and the
+// weight  - max / (|row|_1 * entries)
+__global__ void k_ml_pq_candidates(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                   double *__restrict__ W, int32_t *__restrict__ J)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double current_max = 0.0, w = 0.0;
+    int jk = 0;
+    for (int j = ptr[k]; j < ptr[k + 1]; ++j) {
+        const double a = fabs(val[j]);
+        w = w + a;
+        if (a > current_max) { current_max = a; jk = idx[j]; }
+    }
+    const double divisor = w * (double)(ptr[k + 1] - ptr[k]);
+    W[k] = divisor == 0.0 ? 0.0 : -current_max / divisor;
+    J[k] = jk;
+}
+
+// vector_dense<T>::quicksort(index_list&, left, right), :471-505
+static void ref_quicksort(double *data, int32_t *list, long left, long right)
+{
+    while (left < right) {
+        const double m = data[left];
+        long i = left, j = right;
+        while (i <= j) {
+            while (data[i] < m) i++;
+            while (data[j] > m) j--;
+            if (i <= j) {
+                const double t = data[i]; data[i] = data[j]; data[j] = t;
+                const int32_t u = list[i]; list[i] = list[j]; list[j] = u;
+                i++; j--;
+            }
+        }
+        // (the same two sub-ranges as the reference's two recursive calls; the smaller one by recursion, the larger by the loop: the
+        // ranges are disjoint, so the order in which they are sorted does not matter, and the stack stays logarithmic)
+        if (j - left < right - i) { ref_quicksort(data, list, left, j); left = i; }
+        else { ref_quicksort(data, list, i, right); right = j; }
+    }
+}
+
+// the greedy selection (:4608-4634): ip (rows) and iq (columns) are the INVERSE permutations; returns the size of the leading block
+static int32_t pq_select(int32_t n, std::vector<double> &W, const std::vector<int32_t> &J, double tau, std::vector<int32_t> &ip, std::vector<int32_t> &iq)
+{
+    std::vector<int32_t> I((size_t)n);
+    for (int32_t k = 0; k < n; ++k) I[(size_t)k] = k;
+    ip.assign((size_t)n, -1); iq.assign((size_t)n, -1);
+    if (n > 0) ref_quicksort(W.data(), I.data(), 0, (long)n - 1);
+    int32_t count = -1;
+    for (int32_t k = 0; k < n; ++k) {
+        const int32_t r = I[(size_t)k], c = J[(size_t)r];
+        if (ip[(size_t)r] == -1 && iq[(size_t)c] == -1 && -W[(size_t)k] >= tau) { count++; ip[(size_t)r] = count; iq[(size_t)c] = count; }
+    }
+    const int32_t pos = count;
+    int32_t qcount = count;
+    for (int32_t k = 0; k < n; ++k) if (ip[(size_t)k] < 0) { count++; ip[(size_t)k] = count; }
+    for (int32_t k = 0; k < n; ++k) if (iq[(size_t)k] < 0) { qcount++; iq[(size_t)k] = qcount; }
+    return pos + 1;
+}
+
+// ---------------------------------------------- applying permutations to the matrix ----------------------------------------------
+// matrix_sparse::permute(p1, p2, ip1, ip2) on a ROW matrix (:5570-5573 -> :5533-5548): new row i = old row p1[i], a column index c
+// becomes ip2[c], the rows by increasing index again.  Keys (new row, new column) sorted as 64-bit integers carry the values along.
+__global__ void k_ml_perm_lengths(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ p1, int32_t *__restrict__ len)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    len[i] = i < n ? ptr[p1[i] + 1] - ptr[p1[i]] : 0;
+}
+__global__ void k_ml_perm_keys(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const int32_t *__restrict__ ip1,
+                               const int32_t *__restrict__ ip2, unsigned long long *__restrict__ keys)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;      // old row
+    if (r >= n) return;
+    const unsigned long long hi = (unsigned long long)(unsigned)ip1[r] << 32;
+    for (int j = ptr[r]; j < ptr[r + 1]; ++j) keys[j] = hi | (unsigned)ip2[idx[j]];
+}
+__global__ void k_ml_keys_low(int64_t nnz, const unsigned long long *__restrict__ keys, int32_t *__restrict__ idx)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nnz) idx[j] = (int32_t)(unsigned)keys[j];
+}
+
+static int scan_i32(hipStream_t st, const int32_t *in, int32_t *out, int count)
+{
+    size_t tb = 0;
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, count, st));
+    PoolBlock tmp;
+    ILUPP_HIP(tmp.alloc(tb > 0 ? tb : 1));
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, count, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    return ILUPP_OK;
+}
+
+// A (ROW storage, owned) := P A Q with the rows re-sorted
+static int permute_matrix(hipStream_t st, DevMat *A, const int32_t *d_p1, const int32_t *d_ip1, const int32_t *d_ip2)
+{
+    const int32_t n = A->n;
+    const int64_t nnz = A->nnz;
+    PoolBlock b_len, b_k0, b_k1, b_v1, b_tmp;
+    int32_t *nptr = nullptr;
+    ILUPP_HIP(b_len.alloc(sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&nptr, sizeof(int32_t) * (size_t)(n + 1)));
+    hipLaunchKernelGGL(k_ml_perm_lengths, dim3((n + 256) / 256), dim3(256), 0, st, n, A->ptr, d_p1, b_len.as<int32_t>());
+    { const int rc = scan_i32(st, b_len.as<int32_t>(), nptr, n + 1); if (rc) { (void)pool_free(nptr); return rc; } }
+    if (nnz > 0) {
+        ILUPP_HIP(b_k0.alloc(sizeof(unsigned long long) * (size_t)nnz));
+        ILUPP_HIP(b_k1.alloc(sizeof(unsigned long long) * (size_t)nnz));
+        ILUPP_HIP(b_v1.alloc(sizeof(double) * (size_t)nnz));
+        hipLaunchKernelGGL(k_ml_perm_keys, dim3((n + 255) / 256), dim3(256), 0, st, n, A->ptr, A->idx, d_ip1, d_ip2, b_k0.as<unsigned long long>());
+        size_t tb = 0;
+        ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b_k0.as<unsigned long long>(), b_k1.as<unsigned long long>(), A->val, b_v1.as<double>(),
+                                                     (int)nnz, 0, 64, st));
+        ILUPP_HIP(b_tmp.alloc(tb > 0 ? tb : 1));
+        ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_k0.as<unsigned long long>(), b_k1.as<unsigned long long>(), A->val, b_v1.as<double>(),
+                                                     (int)nnz, 0, 64, st));
+        hipLaunchKernelGGL(k_ml_keys_low, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, b_k1.as<unsigned long long>(), A->idx);
+        ILUPP_HIP(hipMemcpyAsync(A->val, b_v1.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, st));
+    }
+    ILUPP_HIP(hipStreamSynchronize(st));
+    (void)pool_free(A->ptr);
+    A->ptr = nptr;
+    return ILUPP_OK;
+}
+
+static void upload_i32(hipStream_t st, int32_t *dst, const std::vector<int32_t> &src)
+{
+    if (!src.empty()) ILUPP_HIP(hipMemcpyAsync(dst, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, st));
+}
+
+// matrix_sparse::preprocess (:5214-5460) for the steps this build has; A: ROW storage, replaced by the preprocessed matrix.
+// P, Q, invP, invQ: host; Drow, Dcol: device, n doubles each.
+static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::vector<int32_t> &P, std::vector<int32_t> &Q, std::vector<int32_t> &invP,
+                            std::vector<int32_t> &invQ, double *Drow, double *Dcol)
+{
+    const int32_t n = A->n;
+    const int gb = (n + 255) / 256;
+    P.resize((size_t)n); Q.resize((size_t)n); invP.resize((size_t)n); invQ.resize((size_t)n);
+    for (int32_t i = 0; i < n; ++i) P[(size_t)i] = Q[(size_t)i] = invP[(size_t)i] = invQ[(size_t)i] = i;
+    bool permuted_rows = false, permuted_cols = false;
+    hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Drow, 1.0);
+    hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Dcol, 1.0);
+    PoolBlock b_D, b_inv;
+    ILUPP_HIP(b_D.alloc(sizeof(double) * (size_t)n));
+    ILUPP_HIP(b_inv.alloc(sizeof(int32_t) * (size_t)n));
+    for (int s = 0; s < IP.n_pre; ++s) {
+        switch (IP.pre[s]) {
+        case ML_PRE_NORMALIZE_COLUMNS: {                                       // :5241-5246
+            DevMat T;
+            transpose_storage(st, *A, &T);                                     // (column-major copy: the entries of a column by increasing row)
+            hipLaunchKernelGGL(k_ml_col_norms, dim3(gb), dim3(256), 0, st, n, T.ptr, T.val, b_D.as<double>());
+            if (A->nnz > 0)
+                hipLaunchKernelGGL(k_ml_col_scale, dim3((unsigned)((A->nnz + 255) / 256)), dim3(256), 0, st, A->nnz, A->idx, A->val, b_D.as<double>());
+            const int32_t *inv = nullptr;
+            if (permuted_cols) { upload_i32(st, b_inv.as<int32_t>(), invQ); inv = b_inv.as<int32_t>(); }
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Dcol, b_D.as<double>(), inv);
+            ILUPP_HIP(hipStreamSynchronize(st));
+            T.release();
+            break;
+        }
+        case ML_PRE_NORMALIZE_ROWS: {                                          // :5247-5252
+            hipLaunchKernelGGL(k_ml_row_norms_scale, dim3(gb), dim3(256), 0, st, n, A->ptr, A->val, b_D.as<double>());
+            const int32_t *inv = nullptr;
+            if (permuted_rows) { upload_i32(st, b_inv.as<int32_t>(), invP); inv = b_inv.as<int32_t>(); }
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), inv);
+            ILUPP_HIP(hipStreamSynchronize(st));
+            break;
+        }
+        case ML_PRE_PQ_ORDERING: {                                             // :5264-5275
+            PoolBlock b_J, b_p1, b_ip1, b_ip2;
+            ILUPP_HIP(b_J.alloc(sizeof(int32_t) * (size_t)n));
+            hipLaunchKernelGGL(k_ml_pq_candidates, dim3(gb), dim3(256), 0, st, n, A->ptr, A->idx, A->val, b_D.as<double>(), b_J.as<int32_t>());
+            std::vector<double> W((size_t)n);
+            std::vector<int32_t> J((size_t)n), ip1, ip2, p1((size_t)n), p2((size_t)n);
+            ILUPP_HIP(hipMemcpyAsync(W.data(), b_D.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+            ILUPP_HIP(hipMemcpyAsync(J.data(), b_J.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+            ILUPP_HIP(hipStreamSynchronize(st));
+            (void)pq_select(n, W, J, IP.pq_threshold, ip1, ip2);
+            for (int32_t i = 0; i < n; ++i) { p1[(size_t)ip1[(size_t)i]] = i; p2[(size_t)ip2[(size_t)i]] = i; }
+            ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(b_ip1.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(b_ip2.alloc(sizeof(int32_t) * (size_t)n));
+            upload_i32(st, b_p1.as<int32_t>(), p1); upload_i32(st, b_ip1.as<int32_t>(), ip1); upload_i32(st, b_ip2.as<int32_t>(), ip2);
+            { const int rc = permute_matrix(st, A, b_p1.as<int32_t>(), b_ip1.as<int32_t>(), b_ip2.as<int32_t>()); if (rc) return rc; }
+            // P.compose_right(p1): P[i] = P[p1[i]]; the same for Q; then the inverses (:5269-5272)
+            std::vector<int32_t> H((size_t)n);
+            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = P[(size_t)p1[(size_t)i]];
+            P.swap(H);
+            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = Q[(size_t)p2[(size_t)i]];
+            Q.swap(H);
+            for (int32_t i = 0; i < n; ++i) { invP[(size_t)P[(size_t)i]] = i; invQ[(size_t)Q[(size_t)i]] = i; }
+            permuted_rows = permuted_cols = true;
+            break;
+        }
+        default:
+            set_error("ILU++ preprocessing step " + std::to_string(IP.pre[s]) + " is not built yet (available: NORMALIZE_COLUMNS, NORMALIZE_ROWS, PQ_ORDERING)");
+            return ILUPP_ERR_UNSUPPORTED;
+        }
+    }
+    return ILUPP_OK;
+}
+
+void MlLevelDev::release()
+{
+    L.release(); U.release();
+    for (double *p : {D, Dl, Dr}) if (p) (void)pool_free(p);
+    for (int32_t *p : {pr, pc, ipr, ipc}) if (p) (void)pool_free(p);
+    D = Dl = Dr = nullptr; pr = pc = ipr = ipc = nullptr;
+}
+
+// make_preprocessed_multilevelILUCDP (preconditioner_implementation.h:1350-1665), use_ILUC branch.  A: the input in either storage.
+int ml_build(hipStream_t st, const DevMat &A, const MlParams &IP, std::vector<MlLevelDev> *levels, float *kernel_ms)
+{
+    DevMat Ak;                                                                 // the matrix of the current level, ROW storage, owned
+    if (A.is_csr) {
+        Ak.n = A.n; Ak.nnz = A.nnz; Ak.is_csr = true; Ak.owns = true;
+        ILUPP_HIP(pool_malloc(&Ak.ptr, sizeof(int32_t) * (size_t)(A.n + 1)));
+        ILUPP_HIP(pool_malloc(&Ak.idx, sizeof(int32_t) * (size_t)(A.nnz > 0 ? A.nnz : 1)));
+        ILUPP_HIP(pool_malloc(&Ak.val, sizeof(double) * (size_t)(A.nnz > 0 ? A.nnz : 1)));
+        ILUPP_HIP(hipMemcpyAsync(Ak.ptr, A.ptr, sizeof(int32_t) * (size_t)(A.n + 1), hipMemcpyDeviceToDevice, st));
+        if (A.nnz > 0) {
+            ILUPP_HIP(hipMemcpyAsync(Ak.idx, A.idx, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
+            ILUPP_HIP(hipMemcpyAsync(Ak.val, A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
+        }
+    } else {
+        transpose_storage(st, A, &Ak);                                         // change_orientation(), :1388-1391
+        Ak.is_csr = true;
+    }
+    struct Guard { DevMat *m; std::vector<MlLevelDev> *lv; bool ok = false; ~Guard() { m->release(); if (!ok) { for (auto &l : *lv) l.release(); lv->clear(); } } } guard{&Ak, levels};
+    double tau = IP.threshold;
+    int32_t matrix_size = Ak.n;
+    int64_t nonzeroes = Ak.nnz;
+    int nlev = 0;
+    for (;;) {
+        const bool in_loop = matrix_size > IP.min_ml_size && nlev < IP.max_levels - 1 && nonzeroes > 0;     // :1405
+        if (!in_loop && !(matrix_size > 0)) break;                                                           // :1550
+        const int32_t m = Ak.n;
+        levels->emplace_back();
+        MlLevelDev &l = levels->back();
+        l.n = m;
+        ILUPP_HIP(pool_malloc(&l.Dl, sizeof(double) * (size_t)m));
+        ILUPP_HIP(pool_malloc(&l.Dr, sizeof(double) * (size_t)m));
+        std::vector<int32_t> P, Q, invP, invQ;
+        { const int rc = preprocess_level(st, &Ak, IP, P, Q, invP, invQ, l.Dl, l.Dr); if (rc) return rc; }
+        for (int32_t **d : {&l.pr, &l.pc, &l.ipr, &l.ipc}) ILUPP_HIP(pool_malloc(d, sizeof(int32_t) * (size_t)m));
+        upload_i32(st, l.pr, P); upload_i32(st, l.pc, Q); upload_i32(st, l.ipr, invP); upload_i32(st, l.ipc, invQ);
+        ILUPP_HIP(hipStreamSynchronize(st));
+        if (!in_loop && IP.use_final_threshold) tau *= IP.final_threshold;     // :1580-1581
+        DevMat Anext;
+        int32_t kterm = m;
+        const int rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+        if (rc) { Anext.release(); return rc; }
+        ++nlev;
+        Ak.release();
+        Ak = Anext;                                                            // :1532
+        Ak.owns = true;
+        if (!in_loop) break;
+        matrix_size = Ak.n; nonzeroes = Ak.nnz;
+        tau *= IP.vary_threshold_factor;
+    }
+    guard.ok = true;
+    return ILUPP_OK;
+}
+
+// ---------------------------------------------- the vector kernels of the apply (:441-486) ----------------------------------------------
+// out[i] = x[perm[i]] / D[perm[i]]         inverse_scale_at_end + permute_first (sparse_implementation.h:170-176, :4142-4153)
+__global__ void k_ml_scale_perm(int32_t n, const double *__restrict__ x, const double *__restrict__ D, const int32_t *__restrict__ perm, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int s = perm[i]; out[i] = x[s] / D[s]; }
+}
+// x[i] = w[i] (* D[i]); w[i] = the sweeps' "not yet" mark again
+__global__ void k_ml_take(int32_t n, double *__restrict__ w, const double *__restrict__ D, double *__restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = w[i];
+    x[i] = D ? v * D[i] : v;
+    reinterpret_cast<unsigned long long *>(w)[i] = kSentinel;
+}
+// out[i] = x[i] * D[i]                      scale_at_end (:153-159)
+__global__ void k_ml_scale(int32_t n, const double *__restrict__ x, const double *__restrict__ D, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * D[i];
+}
+// x[i] = w[perm[i]] / D[i]                  permute_last + inverse_scale_at_end (:4156-4165, :170-176)
+__global__ void k_ml_perm_scale(int32_t n, const double *__restrict__ w, const int32_t *__restrict__ perm, const double *__restrict__ D, double *__restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = w[perm[i]] / D[i];
+}
+
+void ml_scale_perm(hipStream_t st, int32_t n, const double *x, const double *D, const int32_t *perm, double *out)
+{ hipLaunchKernelGGL(k_ml_scale_perm, dim3((n + 255) / 256), dim3(256), 0, st, n, x, D, perm, out); }
+void ml_take(hipStream_t st, int32_t n, double *w, const double *D, double *x)
+{ hipLaunchKernelGGL(k_ml_take, dim3((n + 255) / 256), dim3(256), 0, st, n, w, D, x); }
+void ml_scale(hipStream_t st, int32_t n, const double *x, const double *D, double *out)
+{ hipLaunchKernelGGL(k_ml_scale, dim3((n + 255) / 256), dim3(256), 0, st, n, x, D, out); }
+void ml_perm_scale(hipStream_t st, int32_t n, const double *w, const int32_t *perm, const double *D, double *x)
+{ hipLaunchKernelGGL(k_ml_perm_scale, dim3((n + 255) / 256), dim3(256), 0, st, n, w, perm, D, x); }
+
+}  // namespace ilupp

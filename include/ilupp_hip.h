@@ -38,6 +38,7 @@ typedef enum {
     ILUPP_ERR_MEMORY = -9,         /* sparse_implementation.h:3178-3179 "insufficient memory reserved" */
     ILUPP_ERR_NOT_SPD = -10,       /* ICholT: the pivot of a column is NaN (the matrix is not positive definite); the reference
                                       returns a NaN-filled factor for such input (IChol.hpp:115-117 has no positivity check) */
+    ILUPP_ERR_INTERNAL = -12,      /* an invariant of this build does not hold (a bug here, never a property of the input) */
     ILUPP_ERR_DIAG_DROPPED = -11   /* ICholT: a finite pivot was dropped by the threshold or the top-k budget (dropping.hpp:8-34 does not
                                       protect it).  The reference keeps such a factor and solves with whatever entry comes first in
                                       the column; this build reports it instead (documented deviation) */
@@ -149,6 +150,65 @@ int ilupp_hip_factor_copy(const ilupp_precond *p, int which, double *data, int32
 /* device pointers of a factor (valid while p lives); for GPU-resident callers */
 int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double **d_data,
                                  const int32_t **d_indices, const int32_t **d_indptr);
+
+/* ---------------------------------------------------------------------------------------------
+ * the multilevel ILU++ preconditioner, binding.cpp:284-298
+ *   MultilevelILUCDPPreconditioner(A_data, A_indices, A_indptr, is_csr, iluplusplus_precond_parameter)
+ *   -> multilevelILUCDPPreconditioner::make_preprocessed_multilevelILUCDP (preconditioner_implementation.h:1350-1665),
+ *      apply :433-488, total_nnz preconditioner.h:312.
+ * Built: the family WITHOUT pivoting (use_ILUC, :1385-1390: PERMUTE_ROWS 0, TOTAL_PIV 0, piv_tol 0 -- precon_parameter 10 of
+ * parameters_implementation.h:927-934, e.g. default_configuration(1)) over matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) with
+ * error-propagation dropping, unbounded fill, levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
+ * PQ_ORDERING (sparse_implementation.h:5214-5275).  Every other parameter combination -- the pivoting factorisation partialILUCDP of
+ * the default-constructed parameters among them -- is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ilupp_ml ilupp_ml;
+
+enum {                               /* preprocessing_type values (orderings.h) this build has */
+    ILUPP_PRE_NORMALIZE_COLUMNS = 1,
+    ILUPP_PRE_NORMALIZE_ROWS = 2,
+    ILUPP_PRE_PQ_ORDERING = 3
+};
+
+typedef struct {                     /* the fields of iluplusplus_precond_parameter (parameters.h:120-235) the built family reads */
+    double threshold;                /* threshold */
+    int32_t n_preprocessing;         /* PREPROCESSING: number of steps, */
+    int32_t preprocessing[8];        /*                the steps (ILUPP_PRE_*) */
+    double pq_threshold;             /* PQ_THRESHOLD */
+    int32_t max_levels;              /* MAX_LEVELS */
+    int32_t min_ml_size;             /* MIN_ML_SIZE */
+    int32_t small_pivot_terminates;  /* SMALL_PIVOT_TERMINATES */
+    double min_pivot;                /* MIN_PIVOT */
+    double min_elim_factor;          /* MIN_ELIM_FACTOR */
+    double threshold_shift_schur;    /* THRESHOLD_SHIFT_SCHUR */
+    double vary_threshold_factor;    /* VARY_THRESHOLD_FACTOR */
+    int32_t use_final_threshold;     /* USE_FINAL_THRESHOLD */
+    double final_threshold;          /* FINAL_THRESHOLD */
+} ilupp_ml_params;
+
+/* default_configuration(1) (parameters_implementation.h:546-549: set_PQ + precon_parameter 10) with threshold 0 */
+void ilupp_hip_ml_default_params(ilupp_ml_params *p);
+int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr,
+                        const ilupp_ml_params *params, ilupp_ml **out);
+int ilupp_hip_ml_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr, int32_t n, int is_csr,
+                               const ilupp_ml_params *params, ilupp_ml **out);
+void ilupp_hip_ml_destroy(ilupp_ml *p);
+/* binding.cpp:237-254 apply / apply_trans, in place on a host vector; the _device form on a vector in HBM (sync as above) */
+int ilupp_hip_ml_apply(ilupp_ml *p, double *x, int64_t len, int transpose);
+int ilupp_hip_ml_apply_device(ilupp_ml *p, double *d_x, int64_t len, int transpose, int sync);
+int ilupp_hip_ml_sync(ilupp_ml *p);
+/* levels() (preconditioner.h:298), total_nnz (:312), dim(k) */
+int32_t ilupp_hip_ml_levels(const ilupp_ml *p);
+int64_t ilupp_hip_ml_total_nnz(const ilupp_ml *p);
+/* one level (extract_left_matrix(k) ... extract_right_scaling(k), preconditioner.h:288-296): sizes, then copies to host buffers
+ * (any pointer may be NULL): L by columns, U by rows (data / indices of nnz entries, indptr of n + 1), the middle diagonal,
+ * the four permutations and the two scalings, n entries each */
+int ilupp_hip_ml_level_info(const ilupp_ml *p, int32_t level, int32_t *n, int64_t *nnz_left, int64_t *nnz_right);
+int ilupp_hip_ml_level_copy(const ilupp_ml *p, int32_t level, double *l_data, int32_t *l_indices, int32_t *l_indptr, double *u_data,
+                            int32_t *u_indices, int32_t *u_indptr, double *middle, int32_t *perm_rows, int32_t *perm_cols,
+                            int32_t *inv_perm_rows, int32_t *inv_perm_cols, double *d_left, double *d_right);
+/* GPU milliseconds of the construction (whole, and the factorisation kernels alone) and of the last apply */
+int ilupp_hip_ml_timings(const ilupp_ml *p, float *construct_ms, float *kernel_ms, float *last_apply_ms);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement hooks used by bench.py (not part of the reference's surface).
