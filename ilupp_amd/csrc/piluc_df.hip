@@ -257,9 +257,11 @@ k_piluc_df(PilucArgs A)
                 }
             }
             PU_SYNC();
-            // ---- slots in insertion order (hash: index -> slot + 1) ----
-            const unsigned hmask = (unsigned)(4 * kNS - 1);
-            for (int h = lane; h < 4 * kNS; h += 64) hslot[h] = 0;
+            // ---- slots in insertion order (hash: index -> slot + 1; the table only as large as this step's entries need) ----
+            int hsize = 64;
+            while (hsize < 2 * (ne + 1) && hsize < 4 * kNS) hsize *= 2;
+            const unsigned hmask = (unsigned)(hsize - 1);
+            for (int h = lane; h < hsize; h += 64) hslot[h] = 0;
             PU_SYNC();
             for (int e = lane; e < na; e += 64) {
                 unsigned h = ((unsigned)erow[e] * 0x9E3779B1u) >> 7;
@@ -622,7 +624,7 @@ static void launch_class(int cls, int waves, hipStream_t st, const PilucArgs &a)
 
 // one attempt with one capacity class and one store size; ILUPP_OK / an error / +1 = "outside this class" / +2 = "stores too small"
 static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv_out,
-                         DevMat *Anew, int32_t *kterm_out, float *kernel_ms, int cls, long store, int *which_capacity)
+                         DevMat *Anew, int32_t *kterm_out, float *kernel_ms, int cls, long store, int gns, int *which_capacity)
 {
     const int32_t m = Av.n;
     int T = cls == 0 ? 32 : (cls == 1 ? 64 : (cls == 2 ? 128 : (cls == 3 ? 512 : 16)));
@@ -683,8 +685,10 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
     if (waves > m) waves = m;
     int gNE = 0, gNS = 0, gTM = 0;
     if (cls == 4) {
-        gTM = T; gNS = 1024; while (gNS < m + 1 && gNS < 32768) gNS *= 2;       // (a power of two: the slot hash masks with 4 gNS - 1)
-        gNE = 1 << 20;
+        gTM = T; gNS = gns;                                                     // (a power of two: the slot hash masks with a power of two <= 4 gNS)
+        gNE = 32 * gNS;
+        if (gNE > (1 << 22)) gNE = 1 << 22;
+        while (waves > 64 && (size_t)waves * piluc_ws_bytes(gNE, gNS, gTM) > ((size_t)PILUC_WSGB << 30)) waves /= 2;
         while (gNE > 4096 && (size_t)waves * piluc_ws_bytes(gNE, gNS, gTM) > ((size_t)PILUC_WSGB << 30)) gNE /= 2;
         ILUPP_HIP(b_gws.alloc((size_t)waves * piluc_ws_bytes(gNE, gNS, gTM)));
     }
@@ -718,8 +722,14 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
     ILUPP_HIP(hipMemcpyAsync(h, ctrl, 32, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[ilupp] piluc: n %d class %d T %d waves %d store %ld: status %d kterm %d finished %d left %d cursors %d %d\n", m, cls, T, waves, store,
-                     h[2], h[3], h[4], h[5], h[6], h[7]);
+    if (dbg) {
+        float ms = 0.f;
+        ILUPP_HIP(hipEventRecord(ev.b, st));
+        ILUPP_HIP(hipEventSynchronize(ev.b));
+        ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+        fprintf(stderr, "[ilupp] piluc: n %d class %d (slots %d) T %d waves %d store %ld: status %d kterm %d finished %d left %d cursors %d %d, %.1f ms\n", m, cls,
+                cls == 4 ? gNS : 0, T, waves, store, h[2], h[3], h[4], h[5], h[6], h[7], ms);
+    }
     if (h[2] == 2) return ILUPP_ERR_TIMEOUT;
     if (h[2] == 16) return 2;
     if (h[2] != 0) { if (which_capacity) *which_capacity = h[2]; return 1; }
@@ -815,13 +825,25 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
         cls = avg * avg <= 64 ? 0 : (avg * avg <= 256 ? 1 : 2);
     }
     int rc = 1;
+    int gns = 2048;
     while (rc == 1 || rc == 2) {
         int which = 0;
         L->release(); U->release(); Anew->release();
-        rc = piluc_attempt(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms, cls, store, &which);
+        rc = piluc_attempt(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms, cls, store, gns, &which);
         if (rc == 1) {
-            if (cls >= 4) { set_error("partialILUC: a working row does not fit the largest capacity class"); rc = ILUPP_ERR_UNSUPPORTED; break; }
-            cls = ((which == 12 || which == 15) && cls < 2) ? 2 : cls + 1;
+            const bool records = which == 12 || which == 15;          // more touch records per step than the class holds
+            if (cls < 4) {
+                // (class 3 has the records of many steps but no more entries or slots than class 2)
+                cls = records ? (cls < 2 ? 2 : cls + 1) : (cls < 2 ? cls + 1 : 4);
+            } else if (records) {
+                set_error("partialILUC: a step is reached by more than 4096 stored entries");
+                rc = ILUPP_ERR_UNSUPPORTED;
+            } else if (gns >= (1 << 20) || gns > 2 * (long)Av.n) {
+                set_error("partialILUC: a working row does not fit the largest capacity class");
+                rc = ILUPP_ERR_UNSUPPORTED;
+            } else {
+                gns *= 4;
+            }
         } else if (rc == 2) {
             if (store >= 0x7ffffff0L) { set_error("partialILUC: the factors of a level exceed 2^31 entries"); rc = ILUPP_ERR_MEMORY; break; }
             store *= 2;

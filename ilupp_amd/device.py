@@ -20,6 +20,7 @@ _FACTORIES = {
     "IChol0": (_native.IChol0Preconditioner_device, ()),
     "ICholT": (_native.ICholTPreconditioner_device, ("add_fill_in", "threshold")),
     "ILUC": (_native.ILUCPreconditioner_device, ("fill_in", "threshold")),
+    "ILUpp": (_native.MultilevelILUCDPPreconditioner_device, ("params",)),     # params: an iluplusplus_precond_parameter (no default: see ILUppPreconditioner)
 }
 _DEFAULTS = {"ILUT": {"fill_in": 100, "threshold": 0.1}, "ICholT": {"add_fill_in": 0, "threshold": 0.0},
              "ILUC": {"fill_in": 100, "threshold": 0.1}}
@@ -61,7 +62,7 @@ class DeviceCSR:
 
 
 class DevicePreconditioner:
-    """ILU0 / ILUT / ILUC / IChol0 / ICholT of a DeviceCSR, applied to device tensors in place or out of place"""
+    """ILU0 / ILUT / ILUC / IChol0 / ICholT / multilevel ILU++ of a DeviceCSR, applied to device tensors in place or out of place"""
 
     def __init__(self, kind, A, **params):
         make, names = _FACTORIES[kind]

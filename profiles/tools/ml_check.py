@@ -1,6 +1,7 @@
 """GPU check of the multilevel ILU++ preconditioner against the oracle, level by level (development tool; the tests proper are
 tests/test_gpu_ml.py).   python profiles/tools/ml_check.py [--big]"""
-import sys, os, time
+import sys, os, time, faulthandler
+faulthandler.dump_traceback_later(int(os.environ.get("DUMP_AFTER", "600")), exit=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, scipy.sparse as sp
@@ -68,10 +69,20 @@ for thr in (0.0, 0.01, 0.1):
 if "--big" in sys.argv:
     for n, k in ((20000, 6), (100000, 8)):
         M = sp.csr_matrix(matgen.random_dd(n, k=k), shape=(n, n))
-        for thr in (0.1, 0.01):
+        for thr in (1e-3, 1e-4):
             allok &= check(M, params(thr), "rdd n=%d thr %g" % (n, thr))
     d, i, pp = matgen.poisson3d(40, 40, 40); A = sp.csr_matrix((d, i, pp))
-    allok &= check(A, params(0.05), "p3d 40^3 thr 0.05")
-    R = (sp.random(100000, 100000, density=6e-5, random_state=np.random.default_rng(7), format='csr') + sp.eye(100000) * 0.3).tocsr()
-    allok &= check(R, params(0.05), "rand 1e5 weak diag thr 0.05")
+    for thr in (0.05, 0.01):
+        allok &= check(A, params(thr), "p3d 40^3 thr %g" % thr)
+    d, i, pp = matgen.poisson3d(30, 30, 30); n = pp.shape[0] - 1
+    A = (sp.csr_matrix((d, i, pp), shape=(n, n)) + 0.8 * sp.diags([np.ones(n - 1)], [1], shape=(n, n))).tocsr()
+    allok &= check(A, params(0.005), "convdiff 30^3 thr 0.005")
+    allok &= check(A.tocsc(), params(0.02), "convdiff 30^3 csc thr 0.02")
+    R = (sp.random(2000, 2000, density=0.004, random_state=np.random.default_rng(7), format='csr') + sp.eye(2000) * 0.3).tocsr()
+    allok &= check(R, params(0.05), "weak diagonal n=2000 thr 0.05 (26 levels)")
+    M = sp.csr_matrix(matgen.random_dd(20000, k=8, diag=2.0), shape=(20000, 20000))
+    allok &= check(M, params(1e-2), "rdd diag 2 n=20000 thr 0.01")
+if "--huge" in sys.argv:
+    M = sp.csr_matrix(matgen.random_dd(1000000, k=8), shape=(1000000, 1000000))
+    allok &= check(M, params(1e-3), "rdd n=1e6 thr 1e-3")
 print("ALL OK" if allok else "SOME FAILED")

@@ -1,0 +1,84 @@
+"""The cases of the multilevel ILU++ tests (preset 10 family): shared by the generator of the golden
+vectors (tests/golden/make_golden_ml10.py), the CPU test of the oracle and the GPU parity test.
+
+A case = (name, matrix builder, parameter changes on top of default_configuration(1)); the matrices are the reference's own test
+matrices (test/tests.py:9-36) and config-shaped small ones, each as CSR and CSC."""
+import numpy as np
+import scipy.sparse as sp
+
+import matgen
+
+PRE = {"NORMALIZE_COLUMNS": 1, "NORMALIZE_ROWS": 2, "PQ_ORDERING": 3}
+
+
+def laplace_matrix(n):
+    return sp.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr") * (n + 1) ** 2
+
+
+def laplace2d_matrix(n_total):
+    n = int(np.sqrt(n_total))
+    A, I = laplace_matrix(n), sp.eye(n)
+    return (sp.kron(A, I) + sp.kron(I, A)).tocsr()
+
+
+def weak_random(n, density, diag, seed):
+    """a random matrix with a weak diagonal: small pivots end levels, the Schur complements fill (stored in the fixture as arrays:
+    scipy's sampler is version dependent)"""
+    return (sp.random(n, n, density=density, random_state=np.random.default_rng(seed), format="csr") + sp.eye(n) * diag).tocsr()
+
+
+def matrices():
+    d, i, p = matgen.poisson3d(6, 7, 5)
+    yield "p3d_6_7_5", sp.csr_matrix((d, i, p), shape=(210, 210))
+    yield "laplace2d_400", laplace2d_matrix(400)
+    yield "rdd_300", sp.csr_matrix(matgen.random_dd(300, k=7, diag=3.0), shape=(300, 300))
+    yield "weak_300", weak_random(300, 0.03, 0.5, 5)
+    yield "weak_120", weak_random(120, 0.05, 0.2, 11)
+    yield "weak_200", weak_random(200, 0.04, 0.05, 23)
+
+
+# parameter sets: (tag, threshold, preprocessing, other knobs by the reference's names)
+PARAMS = [
+    ("t0", 0.0, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {}),
+    ("t0.01", 0.01, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {}),
+    ("t0.1", 0.1, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {}),
+    ("t1", 1.0, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {}),
+    ("t0.1_nopre", 0.1, (), {}),
+    ("t0.1_norm", 0.1, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS"), {}),
+    ("t0.1_rows_first", 0.1, ("NORMALIZE_ROWS", "PQ_ORDERING", "NORMALIZE_COLUMNS"), {}),
+    ("t0.05_maxlev3", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"MAX_LEVELS": 3}),
+    ("t0.05_shift", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"THRESHOLD_SHIFT_SCHUR": 1e-3, "MIN_PIVOT": 0.1}),
+    ("t0.05_pq0.3", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"PQ_THRESHOLD": 0.3, "MIN_ELIM_FACTOR": 0.25}),
+    ("t0.02_vary", 0.02, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"VARY_THRESHOLD_FACTOR": 2.0, "USE_FINAL_THRESHOLD": True, "FINAL_THRESHOLD": 0.5}),
+    ("t0.05_noterm", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"SMALL_PIVOT_TERMINATES": False}),
+]
+
+_ORC_FIELDS = {"MAX_LEVELS": "max_levels", "THRESHOLD_SHIFT_SCHUR": "threshold_shift_schur", "MIN_PIVOT": "min_pivot", "PQ_THRESHOLD": "pq_threshold",
+               "MIN_ELIM_FACTOR": "min_elim_factor", "VARY_THRESHOLD_FACTOR": "vary_threshold_factor", "USE_FINAL_THRESHOLD": "use_final_threshold",
+               "FINAL_THRESHOLD": "final_threshold", "SMALL_PIVOT_TERMINATES": "small_pivot_terminates", "MIN_ML_SIZE": "min_ml_size"}
+
+
+def oracle_params(O, thr, pre, knobs):
+    """the parameter block of oracle/ilupp_oracle.h for a case"""
+    return O.ml_params(thr, preprocessing=tuple(PRE[s] for s in pre), **{_ORC_FIELDS[k]: (int(v) if isinstance(v, bool) else v) for k, v in knobs.items()})
+
+
+def engine_params(ilupp, thr, pre, knobs):
+    """the reference-style parameter object of ilupp_amd for a case"""
+    p = ilupp.iluplusplus_precond_parameter()
+    p.default_configuration(1)
+    p.threshold = thr
+    p.PREPROCESSING = ilupp.preprocessing_sequence(pre)
+    for k, v in knobs.items():
+        setattr(p, k, v)
+    return p
+
+
+def rhs(n):
+    return 1.0 + (np.arange(n, dtype=np.float64) % 17) / 16.0 - (np.arange(n, dtype=np.float64) % 5) / 8.0
+
+
+def level_arrays(lv):
+    """a level (dict from oracle.ML.level or ilupp_amd._native.MultilevelPreconditioner.level) as a flat list of arrays"""
+    return [np.asarray(lv["L"][0]), np.asarray(lv["L"][1]), np.asarray(lv["L"][2]), np.asarray(lv["U"][0]), np.asarray(lv["U"][1]), np.asarray(lv["U"][2]),
+            lv["D"], lv["perm_rows"], lv["perm_cols"], lv["inv_perm_rows"], lv["inv_perm_cols"], lv["D_l"], lv["D_r"]]

@@ -1,0 +1,170 @@
+"""GPU parity tests of SURVEY section 8(f) rank 3: the multilevel ILU++ preconditioner without pivoting (ilupp_amd/csrc/piluc_df.hip,
+ml.hip; reference preconditioner_implementation.h:1350-1665 over ILUCDP.hpp:1405-2231, apply :433-488).
+
+Everything is compared bit for bit -- the bar of this package for all its factorisations; the 1e-12 of the north star is implied:
+* against the golden vectors of the REAL reference (tests/golden/ml10.npz): levels, sizes, total_nnz, every level's factors, middle
+  diagonal, permutations and scalings (sha256), apply and apply_trans, CSR and CSC input, twelve parameter sets;
+* against the oracle on larger matrices (n up to 10^5: fill, levels ended by small pivots, Schur complements), and at n = 10^6 through
+  the class API;
+* the Python class (ilupp/__init__.py:171-203): LinearOperator protocol, total_nnz, repr, factors() == [] (binding.cpp:158-163),
+  the refusal of the pivoting family, a vector of the wrong size;
+* the device-pointer entry points, and BiCGstab on the GPU preconditioned with the multilevel object.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import matgen
+import ml_cases as C
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _digest(arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+def _native_ml(M, params):
+    from ilupp_amd import _native
+    M = M.copy()
+    M.sort_indices()
+    return _native.MultilevelILUCDPPreconditioner(M.data, M.indices.astype(np.int32), M.indptr.astype(np.int32), sp.isspmatrix_csr(M), params)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+@pytest.mark.parametrize("name", [n for n, _ in C.matrices()])
+def test_against_reference_vectors(name, fmt):
+    import ilupp_amd as ilupp
+    gold = np.load(os.path.join(HERE, "golden", "ml10.npz"))
+    key = "%s_%s" % (name, fmt)
+    kind = sp.csr_matrix if fmt == "csr" else sp.csc_matrix
+    n = gold[key + "/indptr"].shape[0] - 1
+    M = kind((gold[key + "/data"], gold[key + "/indices"], gold[key + "/indptr"]), shape=(n, n))
+    b = C.rhs(n)
+    for tag, thr, pre, knobs in C.PARAMS:
+        k2 = "%s/%s" % (key, tag)
+        P = _native_ml(M, C.engine_params(ilupp, thr, pre, knobs))
+        info = gold[k2 + "/info"]
+        assert P.levels() == info[0] and P.total_nnz == info[1], k2
+        for k in range(P.levels()):
+            lv = P.level(k)
+            assert lv["n"] == info[2 + k], (k2, k)
+            assert np.array_equal(_digest(C.level_arrays(lv)), gold[k2 + "/levels_sha"][k]), (k2, k)
+        x = b.copy(); P.apply(x)
+        assert np.array_equal(x, gold[k2 + "/apply"], equal_nan=True), k2
+        x = b.copy(); P.apply_trans(x)
+        assert np.array_equal(x, gold[k2 + "/apply_trans"], equal_nan=True), k2
+
+
+def _against_oracle(M, params_tuple):
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    thr, pre, knobs = params_tuple
+    M = M.copy(); M.sort_indices()
+    a = (M.data, M.indices.astype(np.int32), M.indptr.astype(np.int32), sp.isspmatrix_csr(M))
+    Q = O.orc().ml(a, C.oracle_params(O, thr, pre, knobs))
+    P = _native_ml(M, C.engine_params(ilupp, thr, pre, knobs))
+    assert P.levels() == Q.levels() and P.total_nnz == Q.total_nnz()
+    for k in range(Q.levels()):
+        for x, y in zip(C.level_arrays(P.level(k)), C.level_arrays(Q.level(k))):
+            assert x.shape == y.shape and np.array_equal(x, y, equal_nan=True), k
+    b = C.rhs(M.shape[0])
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, Q.apply(b), equal_nan=True)
+    x = b.copy(); P.apply_trans(x)
+    assert np.array_equal(x, Q.apply(b, O.TRANSPOSE), equal_nan=True)
+    return Q.levels()
+
+
+PQ = ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING")
+
+
+def test_larger_matrices_against_oracle():
+    """fill (threshold 1e-3 .. 1e-4 on diagonally dominant random rows), mesh matrices symmetric and with convection, CSC input"""
+    for n, k in ((20000, 6), (100000, 8)):
+        M = sp.csr_matrix(matgen.random_dd(n, k=k), shape=(n, n))
+        for thr in (1e-3, 1e-4):
+            assert _against_oracle(M, (thr, PQ, {})) == 1
+    d, i, p = matgen.poisson3d(40, 40, 40)
+    A = sp.csr_matrix((d, i, p))
+    for thr in (0.05, 0.01):
+        _against_oracle(A, (thr, PQ, {}))
+    d, i, p = matgen.poisson3d(30, 30, 30)
+    n = p.shape[0] - 1
+    A = (sp.csr_matrix((d, i, p), shape=(n, n)) + 0.8 * sp.diags([np.ones(n - 1)], [1], shape=(n, n))).tocsr()
+    _against_oracle(A, (0.005, PQ, {}))
+    _against_oracle(A.tocsc(), (0.02, PQ, {}))
+
+
+def test_many_levels_against_oracle():
+    """weak diagonals: levels ended by small pivots one after the other, Schur complements that fill"""
+    A = C.weak_random(700, 0.01, 0.3, 7)
+    assert _against_oracle(A, (0.05, PQ, {})) >= 8
+    assert _against_oracle(A.tocsc(), (0.2, PQ, {"THRESHOLD_SHIFT_SCHUR": 1e-2})) >= 3
+    # a structurally missing diagonal is a pivot 0: level 0 ends at once (k > 0), the last level takes it as a "zero pivot"
+    B = A.tolil(); B[5, 5] = 0.0; B[40, 40] = 0.0; B = B.tocsr(); B.eliminate_zeros()
+    _against_oracle(B, (0.1, (), {}))
+    _against_oracle(B, (0.1, (), {"SMALL_PIVOT_TERMINATES": False}))
+
+
+def test_class_api():
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    n = 1000000
+    A = sp.csr_matrix(matgen.random_dd(n, k=8), shape=(n, n))          # BASELINE config C5's shape: unsymmetric, n = 10^6
+    A.indices = A.indices.astype(np.int32); A.indptr = A.indptr.astype(np.int32)
+    params = ilupp.iluplusplus_precond_parameter()
+    params.default_configuration(1)
+    params.threshold = 1e-3
+    P = ilupp.ILUppPreconditioner(A, params=params)
+    Q = O.orc().ml((A.data, A.indices, A.indptr, True), O.ml_params(1e-3))
+    assert P.total_nnz == Q.total_nnz() and P.pr.levels() == Q.levels()
+    assert repr(P) == "<%dx%d ILUppPreconditioner with nnz=%d, dtype=float64>" % (n, n, Q.total_nnz())
+    assert P.factors() == [] and P.memory == 0.0
+    b = C.rhs(n)
+    want = Q.apply(b)
+    assert np.array_equal(P @ b, want) and np.array_equal(P.dot(b), want)
+    assert np.array_equal(P.T @ b, Q.apply(b, O.TRANSPOSE))
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, want)
+    X = np.stack([b, 2 * b], axis=1)
+    assert (P @ X).shape == (n, 2) and np.array_equal((P @ X)[:, 0], want)
+    with pytest.raises(RuntimeError, match="vector has wrong size for preconditioner!"):
+        P.pr.apply(np.ones(n - 1))
+    with pytest.raises(NotImplementedError, match="partialILUCDP"):
+        ilupp.ILUppPreconditioner(A, threshold=0.1)
+
+
+def test_device_entry_points_and_bicgstab():
+    """the matrix and the vectors stay in HBM: construction from device pointers, apply on a device vector, and the reference's
+    solver loop (BiCGstab, iterative_solvers_implementation.h:385-530) with the multilevel object as its preconditioner"""
+    import torch
+    import ilupp_amd as ilupp
+    import ilupp_amd.device as ild
+    from oracle import oracle as O
+    d, i, p = matgen.poisson3d(24, 20, 22)
+    n = p.shape[0] - 1
+    A = (sp.csr_matrix((d, i, p), shape=(n, n)) + 0.5 * sp.diags([np.ones(n - 1)], [1], shape=(n, n))).tocsr()
+    A.sort_indices()
+    params = ilupp.iluplusplus_precond_parameter()
+    params.default_configuration(1)
+    params.threshold = 0.02
+    dA = ild.DeviceCSR.from_scipy(A)
+    M = ild.DevicePreconditioner("ILUpp", dA, params=params)
+    Q = O.orc().ml((A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32), True), O.ml_params(0.02))
+    b = C.rhs(n)
+    tb = torch.from_numpy(b).cuda()
+    assert np.array_equal((M @ tb).cpu().numpy(), Q.apply(b))
+    tx = tb.clone(); M.apply_(tx, transpose=True); M.sync()
+    assert np.array_equal(tx.cpu().numpy(), Q.apply(b, O.TRANSPOSE))
+    x = ild.bicgstab(dA, tb, M, maxiter=25)
+    r = b - A @ x.cpu().numpy()
+    assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b)

@@ -1,0 +1,153 @@
+"""CPU tests of SURVEY section 8(f) rank 3, the multilevel ILU++ preconditioner without pivoting (precon_parameter 10 family):
+
+* the oracle's restatement (oracle/ilupp_oracle.c: orc_ml_*, of preconditioner_implementation.h:1350-1665 over ILUCDP.hpp:1405-2231)
+  against the golden vectors the REAL reference emitted (tests/golden/ml10.npz from tests/golden/make_golden_ml10.py): number and
+  sizes of the levels, total_nnz, every level's factors / diagonal / permutations / scalings (sha256), apply and apply_trans -- bit for bit;
+* where oracle/_ref is present (the build container), the same comparison live on further matrices;
+* the parameter objects of the package (ilupp_amd/params.py against parameters_implementation.h:430-609, :872-934) and the refusal
+  of everything outside the built family -- no GPU involved.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import ml_cases as C
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "ml10.npz")
+
+
+def _digest(arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _keys(gold):
+    return sorted({k.rsplit("/", 1)[0] for k in gold.files if k.endswith("/info")})
+
+
+def test_fixture_is_complete(gold):
+    names = [n for n, _ in C.matrices()]
+    assert len(_keys(gold)) == len(names) * 2 * len(C.PARAMS)
+    multi = sum(1 for k in _keys(gold) if gold[k + "/info"][0] > 1)
+    assert multi >= 25, "the fixture must hold cases with several levels"
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+@pytest.mark.parametrize("name", [n for n, _ in C.matrices()])
+def test_oracle_against_reference_vectors(gold, name, fmt):
+    key = "%s_%s" % (name, fmt)
+    a = (gold[key + "/data"], gold[key + "/indices"], gold[key + "/indptr"], fmt == "csr")
+    n = a[2].shape[0] - 1
+    b = C.rhs(n)
+    for tag, thr, pre, knobs in C.PARAMS:
+        k2 = "%s/%s" % (key, tag)
+        P = O.orc().ml(a, C.oracle_params(O, thr, pre, knobs))
+        info = gold[k2 + "/info"]
+        assert P.levels() == info[0] and P.total_nnz() == info[1], k2
+        assert [P.level(k)["n"] for k in range(P.levels())] == list(info[2:]), k2
+        for k in range(P.levels()):
+            assert np.array_equal(_digest(C.level_arrays(P.level(k))), gold[k2 + "/levels_sha"][k]), (k2, k)
+        assert np.array_equal(P.apply(b), gold[k2 + "/apply"], equal_nan=True), k2
+        assert np.array_equal(P.apply(b, O.TRANSPOSE), gold[k2 + "/apply_trans"], equal_nan=True), k2
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_against_reference_live():
+    rng = np.random.default_rng(17)
+    for n, dens, dg in ((80, 0.08, 0.1), (500, 0.01, 0.4), (900, 0.006, 1.5)):
+        A = (sp.random(n, n, density=dens, random_state=rng, format="csr") + sp.eye(n) * dg).tocsr()
+        for fmt in ("csr", "csc"):
+            a = O.from_scipy(A.asformat(fmt))
+            for thr in (0.0, 0.03, 0.3):
+                p = O.ml_params(thr)
+                R, P = O.ref().ml(a, p), O.orc().ml(a, p)
+                assert R.levels() == P.levels() and R.total_nnz() == P.total_nnz()
+                for k in range(R.levels()):
+                    for x, y in zip(C.level_arrays(R.level(k)), C.level_arrays(P.level(k))):
+                        assert np.array_equal(x, y, equal_nan=True)
+                b = C.rhs(n)
+                assert np.array_equal(R.apply(b), P.apply(b), equal_nan=True)
+                assert np.array_equal(R.apply(b, O.TRANSPOSE), P.apply(b, O.TRANSPOSE), equal_nan=True)
+
+
+def test_oracle_refuses_unknown_preprocessing():
+    A = sp.eye(5, format="csr")
+    with pytest.raises(O.OracleError):
+        O.orc().ml(O.from_scipy(A), O.ml_params(0.1, preprocessing=(4,)))      # MAX_WEIGHTED_MATCHING_ORDERING: not restated
+
+
+# ---- the parameter objects (no GPU) -------------------------------------------------------------------------------------------
+def test_default_parameters_and_presets():
+    import ilupp_amd as ilupp
+    p = ilupp.iluplusplus_precond_parameter()
+    # default_parameters(), parameters_implementation.h:430-501
+    assert (p.fill_in, p.threshold, p.piv_tol, p.PRECON_PARAMETER, p.MAX_LEVELS, p.PERMUTE_ROWS, p.TOTAL_PIV) == (10000, 0.0, 1.0, 0, 100, 3, 1)
+    assert p.MAX_FILLIN_IS_INF and p.USE_ERR_PROP_DROPPING and not p.SMALL_PIVOT_TERMINATES and p.MIN_PIVOT == 1e-2 and p.MEM_FACTOR == 3.0
+    assert p.PREPROCESSING.to_names() == ["NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"]
+    p.default_configuration(1)                      # :546-549 + init case 10 (:927-934)
+    assert (p.PRECON_PARAMETER, p.PERMUTE_ROWS, p.TOTAL_PIV, p.piv_tol, p.MIN_ELIM_FACTOR) == (10, 0, 0, 0.0, 0.0) and p.SMALL_PIVOT_TERMINATES
+    assert p.PREPROCESSING.to_names() == ["NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"]
+    p.default_configuration(11)
+    assert p.PRECON_PARAMETER == 10 and p.PREPROCESSING.to_names() == ["MAX_WEIGHTED_MATCHING_ORDERING", "DD_SYMM_MOVE_CORNER_ORDERING_IM"]
+    p.default_configuration(1001)                   # :580-583 + init case 1010 (:1592-1601)
+    assert (p.PRECON_PARAMETER, p.THRESHOLD_SHIFT_SCHUR, p.MAX_FILLIN_IS_INF, p.fill_in) == (1010, 1e-3, False, 500)
+    p.default_configuration(10)
+    assert p.PRECON_PARAMETER == 0 and p.PERMUTE_ROWS == 3 and p.PREPROCESSING.to_names() == ["MAX_WEIGHTED_MATCHING_ORDERING"]
+    with pytest.raises(NotImplementedError):
+        p.default_configuration(-4)
+    p.PREPROCESSING.set_normalize()
+    assert p.PREPROCESSING.to_names() == ["NORMALIZE_COLUMNS", "NORMALIZE_ROWS"]
+    p.PREPROCESSING.set_none()
+    assert p.PREPROCESSING.to_names() == []
+
+
+def test_parameter_block_of_the_built_family():
+    import ilupp_amd as ilupp
+    p = ilupp.iluplusplus_precond_parameter()
+    p.default_configuration(1)
+    p.threshold = 0.25
+    p.MIN_PIVOT = 0.05
+    p.MAX_LEVELS = 7
+    b = p._to_ml_params()
+    assert (b.threshold, b.n_preprocessing, list(b.preprocessing)[:3], b.max_levels, b.min_pivot, b.small_pivot_terminates) == (0.25, 3, [1, 2, 3], 7, 0.05, 1)
+    assert (b.min_elim_factor, b.threshold_shift_schur, b.vary_threshold_factor, b.use_final_threshold) == (0.0, 0.0, 1.0, 0)
+
+
+def test_everything_outside_the_built_family_is_refused():
+    """no silent substitution: the pivoting factorisation of the default parameters, other dropping rules, bounded fill, preprocessing
+    steps without a kernel -- each raises NotImplementedError before anything runs"""
+    import ilupp_amd as ilupp
+
+    def refused(change):
+        p = ilupp.iluplusplus_precond_parameter()
+        p.default_configuration(1)
+        change(p)
+        with pytest.raises(NotImplementedError):
+            p._to_ml_params()
+    with pytest.raises(NotImplementedError, match="pivoting"):
+        ilupp.iluplusplus_precond_parameter()._to_ml_params()
+    refused(lambda p: setattr(p, "piv_tol", 0.5))
+    refused(lambda p: setattr(p, "PERMUTE_ROWS", 3))
+    refused(lambda p: p.use_only_inverse_dropping())
+    refused(lambda p: setattr(p, "MAX_FILLIN_IS_INF", False))
+    refused(lambda p: setattr(p, "SCHUR_COMPLEMENT", 1))
+    refused(lambda p: setattr(p, "DROP_TYPE_L", 1))
+    refused(lambda p: p.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING())
+    refused(lambda p: setattr(p, "EXTERNAL_FINAL_ROW", True))
+    refused(lambda p: setattr(p, "PRECON_PARAMETER", -1))
+    # ... and through the class: default-constructed parameters (ilupp/__init__.py:186-190) select the pivoting factorisation
+    A = sp.eye(4, format="csr")
+    with pytest.raises(NotImplementedError, match="partialILUCDP"):
+        ilupp.ILUppPreconditioner(A)
