@@ -107,8 +107,8 @@ def test_larger_matrices_against_oracle():
 def test_many_levels_against_oracle():
     """weak diagonals: levels ended by small pivots one after the other, Schur complements that fill"""
     A = C.weak_random(700, 0.01, 0.3, 7)
-    assert _against_oracle(A, (0.05, PQ, {})) >= 8
-    assert _against_oracle(A.tocsc(), (0.2, PQ, {"THRESHOLD_SHIFT_SCHUR": 1e-2})) >= 3
+    assert _against_oracle(A, (0.05, PQ, {})) >= 5
+    assert _against_oracle(A.tocsc(), (0.2, PQ, {"THRESHOLD_SHIFT_SCHUR": 1e-2})) >= 2
     # a structurally missing diagonal is a pivot 0: level 0 ends at once (k > 0), the last level takes it as a "zero pivot"
     B = A.tolil(); B[5, 5] = 0.0; B[40, 40] = 0.0; B = B.tocsr(); B.eliminate_zeros()
     _against_oracle(B, (0.1, (), {}))
