@@ -139,6 +139,17 @@ def extra_config(name, dev, steps):
         d, i, p = matgen.poisson3d(128)
         make = lambda a: _native.ILUCPreconditioner_device(*a, True, 8, 1e-2)
         what = "ILUC: ILUCPreconditioner(fill_in=8, threshold=1e-2), 3-D 7-point Laplacian 128^3"
+    elif name == "C5":
+        # BASELINE config 5's shape (unsymmetric CSR, n = 1e6) with the multilevel preconditioner this build has: default_configuration(1)
+        # = normalisation + PQ ordering + the factorisation WITHOUT pivoting (preset 10).  BASELINE names default_configuration(10),
+        # whose factorisation pivots (partialILUCDP): not built, and not substituted -- the line says which one ran.
+        import ilupp_amd as ilupp
+        d, i, p = matgen.random_dd(1000000, 8, 25.0, 12345)
+        prm = ilupp.iluplusplus_precond_parameter()
+        prm.default_configuration(1)
+        prm.threshold = 1e-3
+        make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
+        what = "C5: ILUppPreconditioner(default_configuration(1): NORMALIZE_COLUMNS+NORMALIZE_ROWS+PQ_ORDERING, preset 10 without pivoting, threshold=1e-3), random unsymmetric CSR n=1e6"
     elif name in ("S27", "S9"):
         # ILU(0) beyond the 7-point rows of the headline: box stencils (eliminations meet off-diagonal entries)
         dims = (128, 128, 128) if name == "S27" else (2048, 2048)
@@ -169,6 +180,10 @@ def extra_config(name, dev, steps):
         P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
         t = P.timings()
         nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
+        if name == "C5":
+            t["numeric_kernel_ms"] = t["kernel_ms"]
+            levels = P.levels()
+            nnz_out = sum(sum(P.level_sizes(k)[1:]) for k in range(levels))      # both unit diagonals stored, per level
         if rep:
             walls.append(t1 - t0); kms.append(t["numeric_kernel_ms"]); apps.append(t["last_apply_ms"]); firsts.append(first)
         x.fill_(1.0)
@@ -176,7 +191,8 @@ def extra_config(name, dev, steps):
     nf = 1 if name == "C4" else 2
     fbytes = (12 * nnz + 4 * (n + 1)) + (12 * nnz_out + 4 * (n + 1) * nf)
     sec = float(np.median(walls))
-    return {"workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
+    more = {"levels": int(levels)} if name == "C5" else {}
+    return {**more, "workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
             "numeric_kernel_ms": float(np.median(kms)), "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
             "hbm_fraction": fbytes / sec / 1e9 / HBM_PEAK_GBS}
@@ -191,9 +207,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "ILUC", "S27", "S9"],
-                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, ILUC)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, ILUC) and the refactor loop")
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "ILUC", "S27", "S9"],
+                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, ILUC)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, C5, ILUC) and the refactor loop")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -344,6 +360,40 @@ def main():
                      "identical_to_single_rank": bool(same)}
             assert same, "batched outputs differ from the single-rank run"
 
+    # BASELINE config 5 the same way: `world` unsymmetric matrices of n = 1e6 (seeds 12345 + member), one multilevel ILU++ preconditioner
+    # (default_configuration(1), threshold 1e-3: the family without pivoting) + one apply each, sharded over the ranks
+    batch_ml = None
+    if world > 1:
+        import matgen
+        import ilupp_amd as ilupp
+        prm = ilupp.iluplusplus_precond_parameter()
+        prm.default_configuration(1)
+        prm.threshold = 1e-3
+        nml = 1000000
+
+        def work_ml(member):
+            dm, im, pm = matgen.random_dd(nml, 8, 25.0, 12345 + member)
+            a = [torch.from_numpy(v).to(dev) for v in (dm, im, pm)]
+            xb = torch.ones(nml, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Pm = _native.MultilevelILUCDPPreconditioner_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), nml, True, prm)
+            Pm.apply_device(xb.data_ptr(), nml, transpose=False, sync=True)
+            ms = 1e3 * (time.perf_counter() - t0)
+            return (member, int(Pm.levels()), int(Pm.total_nnz), hashlib.sha256(xb.cpu().numpy().tobytes()).hexdigest(), ms)
+        barrier()
+        b0 = time.perf_counter()
+        recs = run_batch(world, work_ml)
+        barrier()
+        bwall = time.perf_counter() - b0
+        if rank == 0:
+            solo = [work_ml(m) for m in range(world)]
+            same = all(a[:4] == b[:4] for a, b in zip(recs, solo))
+            batch_ml = {"what": "C5 batch: ILUppPreconditioner(default_configuration(1), threshold=1e-3) + apply on %d unsymmetric matrices n=1e6, one per rank" % world,
+                        "records": [{"matrix": r[0], "levels": r[1], "total_nnz": r[2], "sha256_apply": r[3][:16], "ms": r[4]} for r in recs],
+                        "wall_s_incl_matrix_generation": bwall, "identical_to_single_rank": bool(same)}
+            assert same, "batched multilevel outputs differ from the single-rank run"
+
     if rank == 0:
         fb, ab = algorithmic_bytes(n, nnz)
         med = lambda v: float(np.median(v)) if v else 0.0
@@ -404,6 +454,8 @@ def main():
             out["refactor"] = refac
         if batch is not None:
             out["batch"] = batch
+        if batch_ml is not None:
+            out["batch_ml"] = batch_ml
         if not args.no_cpu and world == 1:
             cg = args.cpu_grid or g
             rec, x_cpu = cpu_baseline(cg)
@@ -418,9 +470,9 @@ def main():
         extra = {}
         cfgs = list(args.config)
         if not args.no_extra and world == 1:
-            cfgs = [c for c in ("C3", "C4", "ILUC") if c not in cfgs] + cfgs
+            cfgs = [c for c in ("C3", "C4", "C5", "ILUC") if c not in cfgs] + cfgs
         for cfg in cfgs:
-            if cfg in ("C3", "C4", "ILUC", "S27", "S9") and world == 1:
+            if cfg in ("C3", "C4", "C5", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))

@@ -121,6 +121,7 @@ def lib():
     L.ilupp_hip_ml_destroy.restype = None
     L.ilupp_hip_ml_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
     L.ilupp_hip_ml_apply_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    L.ilupp_hip_ml_apply_part_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.ilupp_hip_ml_sync.argtypes = [_VP]
     L.ilupp_hip_ml_levels.argtypes = [_VP]
     L.ilupp_hip_ml_levels.restype = ctypes.c_int32
@@ -147,7 +148,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_spmv_device",
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
     "ilupp_hip_ml_default_params", "ilupp_hip_ml_create", "ilupp_hip_ml_create_device", "ilupp_hip_ml_destroy", "ilupp_hip_ml_apply",
-    "ilupp_hip_ml_apply_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
+    "ilupp_hip_ml_apply_device", "ilupp_hip_ml_apply_part_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
     "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings",
 ]
 
@@ -352,6 +353,12 @@ class MultilevelPreconditioner:
         if rc:
             _raise(rc)
 
+    def apply_part_device(self, dptr, n, left, transpose=False, sync=True):
+        """the left (left=True) or right half of the split preconditioner on a device pointer"""
+        rc = lib().ilupp_hip_ml_apply_part_device(self._h, dptr, n, 1 if transpose else 0, 1 if left else 0, 1 if sync else 0)
+        if rc:
+            _raise(rc)
+
     def sync(self):
         rc = lib().ilupp_hip_ml_sync(self._h)
         if rc:
@@ -377,6 +384,14 @@ class MultilevelPreconditioner:
 
     def levels(self):
         return int(lib().ilupp_hip_ml_levels(self._h))
+
+    def level_sizes(self, k):
+        """(n, stored entries of the left factor, of the right factor) of level k"""
+        n, nl, nu = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        rc = lib().ilupp_hip_ml_level_info(self._h, k, ctypes.byref(n), ctypes.byref(nl), ctypes.byref(nu))
+        if rc:
+            _raise(rc)
+        return n.value, nl.value, nu.value
 
     def level(self, k):
         """level k as a dict: L (by columns), U (by rows) as (data, indices, indptr), D, the permutations, the scalings"""

@@ -1320,7 +1320,7 @@ int utu_half(ilupp_precond *p, bool forward, bool tr, double *rhs, double *out, 
     return sweep(p, SWEEP_BWD_FIRST_ASC, Mb, sb, db, MAXLEN_OF(Mb), p2, rhs, out, ticket, err);
 }
 
-int ml_apply_dev(ilupp_ml *m, double *x, int transpose)
+int ml_apply_dev(ilupp_ml *m, double *x, int transpose, int part = 0)       // part: 0 = both passes, 1 = the first only, 2 = the second only
 {
     ilupp_precond *p0 = m->obj[0];
     hipStream_t st = p0->stream;
@@ -1331,6 +1331,7 @@ int ml_apply_dev(ilupp_ml *m, double *x, int transpose)
     const bool tr = transpose != 0;
     // first pass upwards through the levels, second pass downwards (:103-111 with :441-453, :468-486)
     for (int pass = 0; pass < 2; ++pass) {
+        if (part != 0 && part != pass + 1) continue;
         for (int s = 0; s < nl; ++s) {
             const int i = pass == 0 ? s : nl - 1 - s;
             ilupp_precond *p = m->obj[(size_t)i];
@@ -1501,6 +1502,21 @@ int ilupp_hip_ml_apply_device(ilupp_ml *m, double *d_x, int64_t len, int transpo
     if (!m) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
     if (len != m->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }
     int rc = ml_apply_dev(m, d_x, transpose);
+    if (rc) return rc;
+    if (sync) return ml_finish_apply(m);
+    order_caller_after(m->obj[0]->stream, m->obj[0]->sev[1]);
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int ilupp_hip_ml_apply_part_device(ilupp_ml *m, double *d_x, int64_t len, int transpose, int left, int sync)
+{
+    API_TRY
+    if (!m) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    if (len != m->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }
+    // ID: the left part is the first pass (upwards through the levels), the right part the second; TRANSPOSE: right^T first, then left^T
+    const int part = (left != 0) == (transpose == 0) ? 1 : 2;
+    int rc = ml_apply_dev(m, d_x, transpose, part);
     if (rc) return rc;
     if (sync) return ml_finish_apply(m);
     order_caller_after(m->obj[0]->stream, m->obj[0]->sev[1]);

@@ -85,6 +85,13 @@ class DevicePreconditioner:
 
     __matmul__ = matvec
 
+    def apply_part_(self, x, left, transpose=False):
+        """the left or the right half of a split preconditioner in place (multilevel ILU++ objects only)"""
+        assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous() and x.numel() == self.n
+        _on_current_stream()
+        self.pr.apply_part_device(x.data_ptr(), self.n, left, transpose=transpose, sync=False)
+        return x
+
     def sync(self):
         self.pr.sync()
 
@@ -153,3 +160,38 @@ def bicgstab(A, b, M=None, x0=None, maxiter=100, rtol=0.0, check_every=0, histor
     if M is not None:
         M.sync()
     return y
+
+
+def bicgstab_split(A, b, M, min_iter=1, max_iter=500, rtol=1e-4, atol=1e-4):
+    """BiCGstab with SPLIT preconditioning as the reference's `solve` runs it (solving_routines_implementation.h:81 ->
+    iterative_solvers_implementation.h:385-530 from the zero vector): r = L' b, Ap = L'(A(R' p)), x = R' y at the end; the loop goes on
+    while (res / initial_res > rtol or res > atol) and iter < max_iter, or iter < min_iter -- the residual is looked at after every
+    iteration, as there.  Returns (x, iterations, res / initial_res, res).  M: a DevicePreconditioner of the "ILUpp" kind."""
+    def pmv(v):
+        w = M.apply_part_(v.clone(), left=False)
+        return M.apply_part_(A.matvec(w), left=True)
+    r = M.apply_part_(b.clone(), left=True)
+    r0star = r.clone()
+    p = r.clone()
+    y = torch.zeros_like(b)
+    initial_res = float(torch.linalg.vector_norm(r))
+    res = initial_res
+    it = 0
+    while (((res / initial_res > rtol) or res > atol) and it < max_iter) or it < min_iter:
+        it += 1
+        Ap = pmv(p)
+        dot_r_r0star = torch.dot(r, r0star)
+        alpha = dot_r_r0star / torch.dot(Ap, r0star)
+        s = r - alpha * Ap
+        As = pmv(s)
+        omega = torch.dot(As, s) / torch.dot(As, As)
+        y.add_(alpha * p)
+        y.add_(omega * s)
+        r = s - omega * As
+        beta = (torch.dot(r, r0star) / dot_r_r0star) * (alpha / omega)
+        p.sub_(omega * Ap)
+        p = beta * p + r
+        res = float(torch.linalg.vector_norm(r))
+    x = M.apply_part_(y, left=False)
+    M.sync()
+    return x, it, res / initial_res, res

@@ -196,6 +196,9 @@ void ilupp_hip_ml_destroy(ilupp_ml *p);
 /* binding.cpp:237-254 apply / apply_trans, in place on a host vector; the _device form on a vector in HBM (sync as above) */
 int ilupp_hip_ml_apply(ilupp_ml *p, double *x, int64_t len, int transpose);
 int ilupp_hip_ml_apply_device(ilupp_ml *p, double *d_x, int64_t len, int transpose, int sync);
+/* one half of the split preconditioner on a vector in HBM: apply_preconditioner_left / _right (preconditioner_implementation.h:441-453,
+ * :468-486), what the reference's solver loop uses with SPLIT preconditioning (solving_routines_implementation.h:81); left != 0: the left part */
+int ilupp_hip_ml_apply_part_device(ilupp_ml *p, double *d_x, int64_t len, int transpose, int left, int sync);
 int ilupp_hip_ml_sync(ilupp_ml *p);
 /* levels() (preconditioner.h:298), total_nnz (:312), dim(k) */
 int32_t ilupp_hip_ml_levels(const ilupp_ml *p);

@@ -168,3 +168,30 @@ def test_device_entry_points_and_bicgstab():
     x = ild.bicgstab(dA, tb, M, maxiter=25)
     r = b - A @ x.cpu().numpy()
     assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b)
+
+
+def test_solve_like_the_reference_tests():
+    """ilupp.solve (ilupp/__init__.py:85-119): the reference's own tests of it (test/tests.py:344-383) with parameters of the built
+    family -- x_exact recovered to np.allclose, convergence info returned, "did not converge" raised"""
+    import ilupp_amd as ilupp
+    A = C.laplace2d_matrix(900)
+    n = A.shape[0]
+    x_exact = np.random.default_rng(3).random(n)
+    b = A @ x_exact
+    for fmt in ("csr", "csc"):
+        param = ilupp.iluplusplus_precond_parameter()
+        param.default_configuration(1)
+        param.threshold = 1e-2
+        x, info = ilupp.solve(A.asformat(fmt), b, atol=1e-8, rtol=1e-8, params=param, info=True)
+        assert np.allclose(x_exact, x)
+        assert 1 <= info[0] <= 60 and info[1] < 1e-8 and info[2] < 1e-8
+    A = sp.csr_matrix(matgen.random_dd(50, k=5, diag=10.0), shape=(50, 50))
+    x_exact = np.linspace(1.0, 2.0, 50)
+    param = ilupp.iluplusplus_precond_parameter()
+    param.default_configuration(1)
+    param.threshold = 0.1
+    assert np.allclose(ilupp.solve(A, A @ x_exact, atol=1e-8, params=param), x_exact)
+    with pytest.raises(RuntimeError, match="did not converge"):
+        ilupp.solve(C.laplace2d_matrix(900), np.ones(900), atol=1e-14, rtol=1e-14, max_iter=2, params=param)
+    with pytest.raises(NotImplementedError):
+        ilupp.solve(A, A @ x_exact)                 # default-constructed parameters: the pivoting factorisation
