@@ -73,6 +73,33 @@ struct PilucArgs {
     int32_t *pending, *rq, *ctrl;
 };
 
+// bitonic sort of N (a power of two) 64-bit keys by one wave, ascending; the array in LDS or, for the global class, in the wave's slice
+// of global memory
+template <bool kGlobal>
+__device__ __forceinline__ void wave_sort_u64(unsigned long long *a, int N, int lane)
+{
+    for (int k2 = 2; k2 <= N; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < N; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = a[i], y = a[l];
+                    const bool up = (i & k2) == 0;
+                    if ((x > y) == up) { a[i] = y; a[l] = x; }
+                }
+            }
+            if (kGlobal) __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+}
+// first position p in [lo, hi] (1-based list `slots`, keys key[slots[p]]) whose key is >= v; hi + 1 if none
+__device__ __forceinline__ int lower_pos(const int *slots, const int *key, int lo, int hi, int v)
+{
+    int a = lo, b = hi + 1;
+    while (a < b) { const int mid = (a + b) >> 1; if (key[slots[mid]] < v) a = mid + 1; else b = mid; }
+    return a;
+}
+
 template <int kLNE, int kLNS, int kLTM, bool kGlobal>
 __global__ void __launch_bounds__(64)
 k_piluc_df(PilucArgs A)
@@ -209,11 +236,27 @@ k_piluc_df(PilucArgs A)
             if (nt > kTM) PU_FAIL(12);
             PU_SYNC();
             // ---- contributors in the reference's linked-list order: (previous stored index desc, seq desc) ----
-            for (int q = lane; q < nt; q += 64) {
-                const int t0 = tt[q], s0 = tseq[q];
-                int p = 0;
-                for (int q2 = 0; q2 < nt; ++q2) { const int t2 = tt[q2], s2 = tseq[q2]; p += (t2 > t0 || (t2 == t0 && s2 > s0)) ? 1 : 0; }
-                cx[p] = tx[q]; crem[p] = trem[q]; cv[p] = tv[q]; cnxt[p] = tnxt[q]; cw[p] = tw[q];
+            if (nt <= 64) {
+                for (int q = lane; q < nt; q += 64) {
+                    const int t0 = tt[q], s0 = tseq[q];
+                    int p = 0;
+                    for (int q2 = 0; q2 < nt; ++q2) { const int t2 = tt[q2], s2 = tseq[q2]; p += (t2 > t0 || (t2 == t0 && s2 > s0)) ? 1 : 0; }
+                    cx[p] = tx[q]; crem[p] = trem[q]; cv[p] = tv[q]; cnxt[p] = tnxt[q]; cw[p] = tw[q];
+                }
+            } else {
+                // many contributors: sort the keys (t descending, seq descending; q rides in the low bits) -- scratch behind A's part of the entries
+                unsigned long long *keys = reinterpret_cast<unsigned long long *>(eval + kNS);
+                int N = 64;
+                while (N < nt) N *= 2;
+                for (int q = lane; q < N; q += 64)
+                    keys[q] = q < nt ? (((unsigned long long)(unsigned)(0x7fffffff - tt[q]) << 32) | ((unsigned long long)(unsigned)(0xfffff - tseq[q]) << 12) | (unsigned)q)
+                                     : ~0ull;
+                PU_SYNC();
+                wave_sort_u64<kGlobal>(keys, N, lane);
+                for (int p = lane; p < nt; p += 64) {
+                    const int q = (int)(keys[p] & 0xfffull);
+                    cx[p] = tx[q]; crem[p] = trem[q]; cv[p] = tv[q]; cnxt[p] = tnxt[q]; cw[p] = tw[q];
+                }
             }
             PU_SYNC();
             {
@@ -234,10 +277,17 @@ k_piluc_df(PilucArgs A)
                 }
                 PU_SYNC();
             }
-            if (lane == 0) {
-                int s = 0;
-                for (int p = 0; p < nt; ++p) { cbase[p] = s; s += crem[p]; }
-                cbase[nt] = s;
+            {
+                int run = 0;
+                for (int base = 0; base < nt; base += 64) {
+                    const int p = base + lane;
+                    const int v = p < nt ? crem[p] : 0;
+                    int incl = v;
+                    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+                    if (p < nt) cbase[p] = run + incl - v;
+                    run += __shfl(incl, 63);
+                }
+                if (lane == 0) cbase[nt] = run;
             }
             PU_SYNC();
             const int net = __builtin_amdgcn_readfirstlane(cbase[nt]);
@@ -278,22 +328,33 @@ k_piluc_df(PilucArgs A)
                     unsigned h = ((unsigned)r * 0x9E3779B1u) >> 7;
                     for (;;) { h &= hmask; const int v = hslot[h]; if (v == 0) break; if (srow[v - 1] == r) { sl = v - 1; break; } ++h; }
                 }
-                bool need = act && sl < 0;
-                unsigned long long todo = __ballot(need);
-                while (todo != 0ull) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const int lr = __shfl(r, leader);
-                    const bool same = need && r == lr;
-                    if (same) { sl = ns; need = false; }
-                    if (lane == leader && ns < kNS) {
-                        srow[ns] = lr;
-                        unsigned h = ((unsigned)lr * 0x9E3779B1u) >> 7;
-                        for (;;) { h &= hmask; if (hslot[h] == 0) { hslot[h] = ns + 1; break; } ++h; }
+                // the new indices of this batch, numbered in the order of their first entries: every lane that needs a slot claims the
+                // hash position of its index (or finds the lane that did), the groups are ranked by their lowest lanes
+                const bool need = act && sl < 0;
+                int owner = lane, hpos = -1;
+                if (lane < 64) crank[lane] = 64;
+                PU_SYNC();
+                if (need) {
+                    unsigned h = ((unsigned)r * 0x9E3779B1u) >> 7;
+                    for (;;) {
+                        h &= hmask;
+                        int v = hslot[h];
+                        if (v == 0) {
+                            v = atomicCAS(&hslot[h], 0, -(lane + 1));
+                            if (v == 0) { hpos = (int)h; break; }
+                        }
+                        if (v < 0 && erow[base + (-v - 1)] == r) { owner = -v - 1; break; }
+                        ++h;
                     }
-                    ++ns;
-                    todo &= ~__ballot(same);
-                    PU_SYNC();
+                    atomicMin(&crank[owner], lane);
                 }
+                PU_SYNC();
+                const int gfirst = need ? crank[owner] : 64;
+                const unsigned long long firsts = __ballot(need && gfirst == lane);
+                if (need) sl = ns + __popcll(firsts & ((1ull << gfirst) - 1ull));
+                if (hpos >= 0) { hslot[hpos] = sl + 1; if (sl < kNS) srow[sl] = r; }
+                ns += __popcll(firsts);
+                PU_SYNC();
                 if (act) eslot[e] = sl;
                 if (ns > kNS) break;
             }
@@ -336,12 +397,22 @@ k_piluc_df(PilucArgs A)
                 if (lane == 0) pos = atomicAdd(&A.ctrl[6], nk);
                 pos = __builtin_amdgcn_readfirstlane(pos);
                 if (pos < 0 || (long)pos + nk > (long)A.capS) PU_FAIL(16);
-                for (int s = lane; s < ns; s += 64) {
-                    if (srank[s] < 0) continue;
-                    const int r0 = srow[s];
-                    int r = 0;
-                    for (int s2 = 0; s2 < ns; ++s2) r += (srank[s2] >= 0 && srow[s2] < r0) ? 1 : 0;
-                    A.Sidx[pos + r] = r0; A.Sval[pos + r] = sval[s];
+                if (ns <= 128) {
+                    for (int s = lane; s < ns; s += 64) {
+                        if (srank[s] < 0) continue;
+                        const int r0 = srow[s];
+                        int r = 0;
+                        for (int s2 = 0; s2 < ns; ++s2) r += (srank[s2] >= 0 && srow[s2] < r0) ? 1 : 0;
+                        A.Sidx[pos + r] = r0; A.Sval[pos + r] = sval[s];
+                    }
+                } else {
+                    unsigned long long *keys = reinterpret_cast<unsigned long long *>(eval);
+                    int N = 64;
+                    while (N < ns) N *= 2;
+                    for (int s = lane; s < N; s += 64) keys[s] = (s < ns && srank[s] >= 0) ? (((unsigned long long)(unsigned)srow[s] << 32) | (unsigned)s) : ~0ull;
+                    PU_SYNC();
+                    wave_sort_u64<kGlobal>(keys, N, lane);
+                    for (int r = lane; r < nk; r += 64) { const int s = (int)(unsigned)keys[r]; A.Sidx[pos + r] = srow[s]; A.Sval[pos + r] = sval[s]; }
                 }
                 if (lane == 0) { A.Sstart[k - kterm] = pos; A.Slen[k - kterm] = nk; }
                 // the chains this row handed on: their next rows may go
@@ -401,19 +472,40 @@ k_piluc_df(PilucArgs A)
                 for (int base = 0; base < nzs; base += 64) { const int s = base + lane; nkz += __popcll(__ballot(s < nzs && (zcnt[s] & 0x40000000))); }
                 for (int base = 0; base < ns; base += 64) { const int s = base + lane; nkw += __popcll(__ballot(s < ns && srank[s] >= 0)); }
                 nkz = __builtin_amdgcn_readfirstlane(nkz); nkw = __builtin_amdgcn_readfirstlane(nkw);
-                for (int s = lane; s < nzs; s += 64) {
-                    if (!(zcnt[s] & 0x40000000)) continue;
-                    const int c0 = zcol[s];
-                    int r = 0;
-                    for (int s2 = 0; s2 < nzs; ++s2) r += ((zcnt[s2] & 0x40000000) && zcol[s2] < c0) ? 1 : 0;
-                    zkept[r + 1] = s;
+                if (nzs <= 128) {
+                    for (int s = lane; s < nzs; s += 64) {
+                        if (!(zcnt[s] & 0x40000000)) continue;
+                        const int c0 = zcol[s];
+                        int r = 0;
+                        for (int s2 = 0; s2 < nzs; ++s2) r += ((zcnt[s2] & 0x40000000) && zcol[s2] < c0) ? 1 : 0;
+                        zkept[r + 1] = s;
+                    }
+                } else {
+                    unsigned long long *keys = reinterpret_cast<unsigned long long *>(eval);
+                    int N = 64;
+                    while (N < nzs) N *= 2;
+                    for (int s = lane; s < N; s += 64) keys[s] = (s < nzs && (zcnt[s] & 0x40000000)) ? (((unsigned long long)(unsigned)zcol[s] << 32) | (unsigned)s) : ~0ull;
+                    PU_SYNC();
+                    wave_sort_u64<kGlobal>(keys, N, lane);
+                    for (int r = lane; r < nkz; r += 64) zkept[r + 1] = (int)(unsigned)keys[r];
+                    PU_SYNC();
                 }
-                for (int s = lane; s < ns; s += 64) {
-                    if (srank[s] < 0) continue;
-                    const int r0 = srow[s];
-                    int r = 0;
-                    for (int s2 = 0; s2 < ns; ++s2) r += (srank[s2] >= 0 && srow[s2] < r0) ? 1 : 0;
-                    keptslot[r + 1] = s;
+                if (ns <= 128) {
+                    for (int s = lane; s < ns; s += 64) {
+                        if (srank[s] < 0) continue;
+                        const int r0 = srow[s];
+                        int r = 0;
+                        for (int s2 = 0; s2 < ns; ++s2) r += (srank[s2] >= 0 && srow[s2] < r0) ? 1 : 0;
+                        keptslot[r + 1] = s;
+                    }
+                } else {
+                    unsigned long long *keys = reinterpret_cast<unsigned long long *>(eval);
+                    int N = 64;
+                    while (N < ns) N *= 2;
+                    for (int s = lane; s < N; s += 64) keys[s] = (s < ns && srank[s] >= 0) ? (((unsigned long long)(unsigned)srow[s] << 32) | (unsigned)s) : ~0ull;
+                    PU_SYNC();
+                    wave_sort_u64<kGlobal>(keys, N, lane);
+                    for (int r = lane; r < nkw; r += 64) keptslot[r + 1] = (int)(unsigned)keys[r];
                 }
                 PU_SYNC();
                 // ---- the stores: row k of U = (k, 1), kept entries; column k of L likewise (:1779-1785, :1951-1958) ----
@@ -450,8 +542,7 @@ k_piluc_df(PilucArgs A)
                 for (int r = 1 + lane; r <= nkw; r += 64) {
                     const int s = keptslot[r];
                     const int i = srow[s];
-                    int lb = 1;
-                    while (lb <= nkz && zcol[zkept[lb]] < i) ++lb;                       // first kept column >= i
+                    const int lb = lower_pos(zkept, zcol, 1, nkz, i);                    // first kept column >= i
                     const int tprev = r > 1 ? srow[keptslot[r - 1]] : k;
                     const int nxt = r < nkw ? sridx[r + 1] : -1;
                     const double mult = sval[s] / dinv_store;
@@ -462,8 +553,7 @@ k_piluc_df(PilucArgs A)
                 for (int r = 1 + lane; r <= nkz; r += 64) {
                     const int s = zkept[r];
                     const int j = zcol[s];
-                    int ub = 1;
-                    while (ub <= nkw && srow[keptslot[ub]] < j) ++ub;                    // first kept row >= j
+                    const int ub = lower_pos(keptslot, srow, 1, nkw, j);                 // first kept row >= j
                     const int tprev = r > 1 ? zcol[zkept[r - 1]] : k;
                     const int nxt = r < nkz ? zridx[r + 1] : -1;
                     const double mult = zval[s] / dinv_store;
@@ -474,14 +564,12 @@ k_piluc_df(PilucArgs A)
                 // announcements first: x in R gets the kept columns below x, x in C the kept rows below x
                 for (int r = 1 + lane; r <= nkw; r += 64) {
                     const int i = srow[keptslot[r]];
-                    int c = 0;
-                    while (c < nkz && zcol[zkept[c + 1]] < i) ++c;
+                    const int c = lower_pos(zkept, zcol, 1, nkz, i) - 1;                 // kept columns below i
                     if (c) atomicAdd(&A.pending[i], c);
                 }
                 for (int r = 1 + lane; r <= nkz; r += 64) {
                     const int j = zcol[zkept[r]];
-                    int c = 0;
-                    while (c < nkw && srow[keptslot[c + 1]] < j) ++c;
+                    const int c = lower_pos(keptslot, srow, 1, nkw, j) - 1;              // kept rows below j
                     if (c) atomicAdd(&A.pending[j], c);
                 }
                 // ... and every stored row (column) but the first waits for the step of the one before it in this column (row), which
