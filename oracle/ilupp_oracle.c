@@ -1061,6 +1061,324 @@ static orc_int mat_ddPQ(const orc_mat *A, orc_int *P, orc_int *Q, double tau)
     return pos + 1;
 }
 
+/* ---- maximum-weight perfect matching with scalings: find_pmwm, pmwm_implementation.h:385-537 (class sapTree :37-383) ---- */
+typedef struct { orc_int index; double value, weight; } pm_dist;
+/* std::priority_queue<dist, vector<dist>, greater<dist>> = libstdc++'s push_heap / pop_heap (bits/stl_heap.h) with comp(a, b) = a.value > b.value */
+static void pm_push_heap(pm_dist *first, long hole, long top, pm_dist v)
+{
+    long parent = (hole - 1) / 2;
+    while (hole > top && first[parent].value > v.value) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = v;
+}
+static void pm_adjust_heap(pm_dist *first, long hole, long len, pm_dist v)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (first[child].value > first[child - 1].value) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    pm_push_heap(first, hole, top, v);
+}
+typedef struct { pm_dist *a; long len, cap; } pm_queue;
+static void pmq_push(pm_queue *q, pm_dist v)
+{
+    if (q->len == q->cap) { q->cap = q->cap ? 2 * q->cap : 64; q->a = (pm_dist *)realloc(q->a, sizeof(pm_dist) * (size_t)q->cap); }
+    q->len++;
+    pm_push_heap(q->a, q->len - 1, 0, v);
+}
+static void pmq_pop(pm_queue *q)
+{
+    if (q->len > 1) {
+        const pm_dist v = q->a[q->len - 1];
+        q->a[q->len - 1] = q->a[0];
+        pm_adjust_heap(q->a, 0, q->len - 1, v);
+    }
+    q->len--;
+}
+
+static int mat_pmwm(const orc_mat *A, orc_int *mate_row, orc_int *mate_col, double *inv_row, double *inv_col)
+{
+    const orc_int dim = A->n, nz = A->ptr[A->n];
+    const orc_int *ptr = A->ptr, *idx = A->idx;
+    orc_int i, row, col, r, s;
+    int ok = 1;
+    double *u = (double *)calloc((size_t)dim + 1, sizeof(double)), *v = (double *)calloc((size_t)dim + 1, sizeof(double));
+    double *comp = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1)), *amax = (double *)calloc((size_t)dim + 1, sizeof(double));
+    orc_int *row_pointer = (orc_int *)calloc((size_t)dim + 1, sizeof(orc_int));
+    double *cand_weights = (double *)calloc((size_t)dim + 1, sizeof(double)), *weights = (double *)calloc((size_t)dim + 1, sizeof(double));
+    wvec checked, rdist;
+    pm_queue q = {NULL, 0, 0};
+    wv_init(&checked, dim, 0); wv_init(&rdist, dim, 0);
+    for (i = 0; i < dim; ++i) { mate_row[i] = -1; mate_col[i] = -1; inv_row[i] = 0.0; inv_col[i] = 0.0; }
+    /* transform_and_copy_data, :362-372 */
+    for (row = 0; row < dim; ++row)
+        for (i = ptr[row]; i < ptr[row + 1]; ++i) if (amax[row] < fabs(A->val[i])) amax[row] = fabs(A->val[i]);
+    for (row = 0; row < dim; ++row)
+        for (i = ptr[row]; i < ptr[row + 1]; ++i) comp[i] = log(amax[row] / fabs(A->val[i]));
+    /* dual_initialization, :171-200 */
+    for (i = 0; i < dim; ++i) { v[i] = -1; u[i] = -1; }
+    for (i = 0; i < nz; ++i) { col = idx[i]; if (v[col] > comp[i] || v[col] == -1) v[col] = comp[i]; }
+    for (row = 0; row < dim; ++row)
+        for (i = ptr[row]; i < ptr[row + 1]; ++i)
+            if (u[row] > comp[i] - v[idx[i]] || u[row] == -1) u[row] = comp[i] - v[idx[i]];
+    /* matching_initialization, :203-250 */
+    for (row = 0; row < dim; ++row)
+        for (i = ptr[row]; i < ptr[row + 1]; ++i) {
+            col = idx[i];
+            if (mate_col[col] == -1 && (comp[i] - u[row] - v[col] == 0)) { mate_row[row] = col; mate_col[col] = row; weights[col] = comp[i]; break; }
+        }
+    for (row = 0; row < dim; ++row) {
+        if (mate_row[row] != -1) continue;
+        for (i = ptr[row]; i < ptr[row + 1]; ++i) {
+            col = idx[i];
+            if (mate_col[col] != -1 && (comp[i] - u[row] - v[col] == 0)) {
+                const orc_int row_new = mate_col[col];
+                orc_int j;
+                for (j = ptr[row_new]; j < ptr[row_new + 1]; ++j) {
+                    const orc_int col_new = idx[j];
+                    if (mate_col[col_new] == -1 && (comp[j] - u[row_new] - v[col_new] == 0)) {
+                        mate_row[row] = col; mate_col[col] = row;
+                        mate_row[row_new] = col_new; mate_col[col_new] = row_new;
+                        weights[col_new] = comp[j]; weights[col] = comp[i];
+                        break;
+                    }
+                }
+            }
+            if (mate_row[row] != -1) break;
+        }
+    }
+    for (r = 0; r < dim && ok; ++r) {
+        orc_int isap = -1, jsap = -1, j, k;
+        double lsap = -1, lsp = 0;
+        if (mate_row[r] != -1) continue;
+        /* reset(r), :133-141 */
+        q.len = 0;
+        wv_zero_reset(&checked); wv_zero_reset(&rdist);
+        /* find_sap, :287-355 */
+        i = r;
+        for (;;) {
+            orc_int d;
+            pm_dist md;
+            orc_int j_min;
+            for (d = ptr[i]; d < ptr[i + 1]; ++d) {
+                j = idx[d];
+                if (checked.occupancy[j] < 0) {
+                    const double weight = comp[d];
+                    const double dnew = lsp + weight - u[i] - v[j];
+                    if (lsap == -1 || dnew < lsap) {
+                        if (mate_col[j] == -1) { lsap = dnew; cand_weights[j] = weight; jsap = j; isap = i; }
+                        else if (rdist.occupancy[j] < 0 || dnew < rdist.data[rdist.occupancy[j]]) {
+                            pm_dist t;
+                            rdist.data[wv_slot(&rdist, j)] = dnew;
+                            row_pointer[mate_col[j]] = i;
+                            t.index = j; t.value = dnew; t.weight = weight;
+                            pmq_push(&q, t);
+                        }
+                    }
+                }
+            }
+            if (q.len == 0) break;
+            do { md = q.a[0]; j_min = md.index; pmq_pop(&q); } while (checked.occupancy[j_min] >= 0 && q.len != 0);
+            if (q.len == 0 && checked.occupancy[j_min] >= 0) break;
+            lsp = md.value;
+            if (lsap != -1 && lsap <= lsp) break;
+            cand_weights[j_min] = md.weight;
+            checked.data[wv_slot(&checked, j_min)] = 1;
+            i = mate_col[j_min];
+        }
+        if (lsap == -1 || jsap == -1) { ok = 0; break; }                        /* :460-471: no perfect matching */
+        /* augment(mate_row, mate_col, isap, jsap), :144-168 */
+        i = isap; j = jsap;
+        mate_col[j] = i;
+        while (i != r) {
+            weights[j] = cand_weights[j];
+            k = mate_row[i];
+            mate_row[i] = j;
+            j = k;
+            i = row_pointer[i];
+            mate_col[j] = i;
+        }
+        mate_row[r] = j;
+        weights[j] = cand_weights[j];
+        /* dual_update, :253-284 */
+        for (s = 0; s < checked.nnz; ++s) { col = checked.pointer[s]; v[col] = v[col] + rdist.data[wv_slot(&rdist, col)] - lsap; }
+        i = isap; j = jsap;
+        while (i != r) {
+            checked.data[wv_slot(&checked, j)] = 0;
+            u[i] = weights[j] - v[j];
+            i = row_pointer[i]; j = mate_row[i];
+        }
+        checked.data[wv_slot(&checked, j)] = 0; u[r] = weights[j] - v[j];
+        for (s = 0; s < checked.nnz; ++s) { col = checked.pointer[s]; u[mate_col[col]] = weights[col] - v[col]; }
+    }
+    if (!ok) {
+        for (s = 0; s < dim; ++s) { inv_row[s] = 1.0; inv_col[s] = 1.0; mate_row[s] = s; mate_col[s] = s; }
+    } else {
+        for (s = 0; s < dim; ++s) { inv_row[s] = amax[s] / exp(u[s]); inv_col[s] = exp(-v[s]); }                 /* :512-515 */
+    }
+    wv_free(&checked); wv_free(&rdist); free(q.a);
+    free(u); free(v); free(comp); free(amax); free(row_pointer); free(cand_weights); free(weights);
+    return ok;
+}
+
+/* ---- sorted_vector (arrays_implementation.h:43-155): a std::multimap<Real, Integer> -- equal keys in insertion order -- as a binary
+ * heap on (key, insertion number) with entries that are left behind when an index is re-inserted or removed ---- */
+typedef struct { double key; long seq; orc_int idx; } sv_ent;
+typedef struct { sv_ent *a; long len, cap, counter; long *cur; double *key; char *used; orc_int n; } sorted_vec;
+static int sv_less(const sv_ent *x, const sv_ent *y) { return x->key < y->key || (x->key == y->key && x->seq < y->seq); }
+static void sv_push(sorted_vec *w, sv_ent e)
+{
+    long h;
+    if (w->len == w->cap) { w->cap = w->cap ? 2 * w->cap : 64; w->a = (sv_ent *)realloc(w->a, sizeof(sv_ent) * (size_t)w->cap); }
+    h = w->len++;
+    while (h > 0 && sv_less(&e, &w->a[(h - 1) / 2])) { w->a[h] = w->a[(h - 1) / 2]; h = (h - 1) / 2; }
+    w->a[h] = e;
+}
+static void sv_pop(sorted_vec *w)
+{
+    sv_ent e = w->a[--w->len];
+    long h = 0;
+    for (;;) {
+        long c = 2 * h + 1;
+        if (c >= w->len) break;
+        if (c + 1 < w->len && sv_less(&w->a[c + 1], &w->a[c])) c++;
+        if (!sv_less(&w->a[c], &e)) break;
+        w->a[h] = w->a[c]; h = c;
+    }
+    if (w->len > 0) w->a[h] = e;
+}
+static void sv_insert(sorted_vec *w, orc_int pos, double val)
+{
+    sv_ent e;
+    e.key = val; e.seq = ++w->counter; e.idx = pos;
+    w->cur[pos] = e.seq; w->key[pos] = val; w->used[pos] = 1;
+    sv_push(w, e);
+}
+static void sv_resize(sorted_vec *w, orc_int n)
+{
+    orc_int k;
+    w->len = 0;
+    for (k = 0; k < n; ++k) sv_insert(w, k, 0.0);
+}
+static void sv_init(sorted_vec *w, orc_int n)
+{
+    memset(w, 0, sizeof(*w));
+    w->n = n;
+    w->cur = (long *)calloc((size_t)n + 1, sizeof(long)); w->key = (double *)calloc((size_t)n + 1, sizeof(double)); w->used = (char *)calloc((size_t)n + 1, 1);
+    sv_resize(w, n);
+}
+static void sv_free(sorted_vec *w) { free(w->a); free(w->cur); free(w->key); free(w->used); }
+static orc_int sv_index_min(sorted_vec *w)
+{
+    while (w->len > 0 && !(w->used[w->a[0].idx] && w->cur[w->a[0].idx] == w->a[0].seq)) sv_pop(w);
+    return w->len > 0 ? w->a[0].idx : -1;
+}
+static void sv_remove(sorted_vec *w, orc_int k) { w->used[k] = 0; }
+static void sv_remove_min(sorted_vec *w) { const orc_int k = sv_index_min(w); if (k >= 0) { w->used[k] = 0; sv_pop(w); } }
+static void sv_add(sorted_vec *w, orc_int pos, double val) { sv_insert(w, pos, val + (w->used[pos] ? w->key[pos] : 0.0)); }
+
+/* matrix_sparse::diagonally_dominant_symmetric_move_to_corner_improved, sparse_implementation.h:4967-5036 (ROW matrix).
+ * Returns 0 when the first phase rejects an index: the reference then re-uses its sorted_vector through resize() (:5014), which
+ * refills the multimap but leaves the `used` flags of the first phase (arrays_implementation.h:55-63: vector<bool>::resize keeps
+ * existing elements) -- remove() and add() no longer erase, index_min() returns the refilled zero entries in index order, and the
+ * result is not a permutation (indices repeat); what follows is undefined (the reference aborts on some inputs).  Nothing to pin. */
+static int mat_dd_move_corner(const orc_mat *M, orc_int *P)
+{
+    const orc_int n = M->n;
+    const orc_int *ptr = M->ptr, *idx = M->idx;
+    const double *val = M->val;
+    orc_int i, j, counter = 0;
+    orc_mat T;
+    sorted_vec w;
+    orc_int *unused = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));
+    double *row_gap = (double *)malloc(sizeof(double) * ((size_t)n + 1)), *col_gap = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    for (i = 0; i < n; ++i) { row_gap[i] = 2.0; col_gap[i] = 2.0; P[i] = i; }
+    sv_init(&w, n);
+    mat_change_orientation(M, &T);
+    for (i = 0; i < n; ++i) {
+        const orc_int cur = sv_index_min(&w);
+        int acceptable = (row_gap[cur] >= 0) && (col_gap[cur] >= 0);
+        j = ptr[cur];
+        while (acceptable && j < ptr[cur + 1]) {
+            if (unused[idx[j]] == 1) acceptable = acceptable && (fabs(val[j]) <= col_gap[idx[j]]);
+            j++;
+        }
+        j = T.ptr[cur];
+        while (acceptable && j < T.ptr[cur + 1]) {
+            if (unused[T.idx[j]] == 1) acceptable = acceptable && (fabs(T.val[j]) <= row_gap[T.idx[j]]);
+            j++;
+        }
+        if (acceptable) {
+            P[counter] = cur;
+            sv_remove_min(&w);
+            unused[cur] = 1;
+            for (j = ptr[cur]; j < ptr[cur + 1]; ++j) {
+                if (unused[idx[j]] == 0) sv_add(&w, idx[j], fabs(val[j]));
+                col_gap[idx[j]] -= fabs(val[j]);
+            }
+            for (j = T.ptr[cur]; j < T.ptr[cur + 1]; ++j) {
+                if (unused[T.idx[j]] == 0) sv_add(&w, T.idx[j], fabs(T.val[j]));
+                row_gap[T.idx[j]] -= fabs(T.val[j]);
+            }
+            counter++;
+        } else {
+            unused[cur] = -1;
+            sv_remove_min(&w);
+        }
+    }
+    if (counter < n) { sv_free(&w); orc_free_mat(&T); free(unused); free(row_gap); free(col_gap); return 0; }
+    /* the rejected indices, :5013-5035 (with a working container; never reached, see above) */
+    sv_resize(&w, n);
+    for (i = 0; i < counter; ++i) sv_remove(&w, P[i]);
+    for (i = 0; i < n; ++i)
+        if (unused[i] == -1) {
+            for (j = ptr[i]; j < ptr[i + 1]; ++j) if (unused[idx[j]] != -1) sv_add(&w, i, fabs(val[j]));
+            for (j = T.ptr[i]; j < T.ptr[i + 1]; ++j) if (unused[T.idx[j]] != -1) sv_add(&w, i, fabs(T.val[j]));
+        }
+    for (i = counter; i < n; ++i) {
+        P[i] = sv_index_min(&w);
+        sv_remove_min(&w);
+        unused[P[i]] = 0;
+        for (j = ptr[P[i]]; j < ptr[P[i] + 1]; ++j) if (unused[idx[j]] == -1) sv_add(&w, idx[j], fabs(val[j]));
+        for (j = T.ptr[P[i]]; j < T.ptr[P[i] + 1]; ++j) if (unused[T.idx[j]] == -1) sv_add(&w, T.idx[j], fabs(T.val[j]));
+    }
+    sv_free(&w); orc_free_mat(&T); free(unused); free(row_gap); free(col_gap);
+    return 1;
+}
+
+/* vector_dense<Integer>::quicksort(index_list&, left, right): the same algorithm as vec_quicksort on integer data (column_perm,
+ * pmwm_implementation.h:539-560) */
+static void ivec_quicksort(orc_int *data, orc_int *list, orc_int left, orc_int right)
+{
+    orc_int i, j, m;
+    if (left < right) {
+        m = data[left]; i = left; j = right;
+        while (i <= j) {
+            while (data[i] < m) i++;
+            while (data[j] > m) j--;
+            if (i <= j) {
+                const orc_int t = data[i], u = list[i];
+                data[i] = data[j]; data[j] = t; list[i] = list[j]; list[j] = u;
+                i++; j--;
+            }
+        }
+        ivec_quicksort(data, list, left, j);
+        ivec_quicksort(data, list, i, right);
+    }
+}
+
 /* matrix_sparse::preprocess, :5214-5460, for the steps of orc_ml_params.preprocessing; A is ROW storage and is replaced by the
  * preprocessed matrix.  P, Q, invP, invQ, Drow, Dcol: n each. */
 static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_int *Q, orc_int *invP, orc_int *invQ, double *Drow,
@@ -1108,6 +1426,59 @@ static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_i
             perm_invert(invP, P, n);
             perm_invert(invQ, Q, n);
             break;
+        case ORC_PRE_MAX_WEIGHTED_MATCHING_ORDERING: {                         /* :5276-5292 */
+            double *D2 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+            (void)mat_pmwm(A, ip1, p1, D, D2);                                 /* maximal_weight_inverse_scales(p1, D1, D2): find_pmwm(A, invP, P, D1, D2), :5731-5734 */
+            for (i = 0; i < n; ++i)
+                for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) A->val[j] /= D[i];                    /* inverse_scale(D1, ROW) */
+            for (j = 0; j < A->ptr[n]; ++j) A->val[j] /= D2[A->idx[j]];                           /* inverse_scale(D2, COLUMN) */
+            for (i = 0; i < n; ++i) ip2[i] = i;
+            mat_permute_rows_cols(A, p1, ip2);                                                    /* permute(p1, ROW), :5520-5522, :5463-5478 */
+            vec_permute(D, invP, n);
+            for (i = 0; i < n; ++i) Drow[i] *= D[i];
+            vec_permute(D2, invQ, n);
+            for (i = 0; i < n; ++i) Dcol[i] *= D2[i];
+            perm_compose_right(P, p1, n);
+            perm_invert(invP, P, n);
+            free(D2);
+            *bad_at = n;
+            break;
+        }
+        case ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM:                          /* :5441-5450 */
+            if (!mat_dd_move_corner(A, p1)) { rc = ORC_ERR_UNSUPPORTED; break; }
+            perm_invert(ip1, p1, n);
+            mat_permute_rows_cols(A, p1, ip1);                                 /* permute(p1, p1), :5564-5568 -> :5550-5561 */
+            perm_compose_right(P, p1, n);
+            perm_compose_right(Q, p1, n);
+            perm_invert(invP, P, n);
+            perm_invert(invQ, Q, n);
+            *bad_at = n;
+            break;
+        case ORC_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING:                            /* :5309-5314, unit_or_zero_diagonal :5172-5178 */
+            for (i = 0; i < n; ++i) {
+                D[i] = 1.0;
+                for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) if (A->idx[j] == i && A->val[j] != 0.0) D[i] = A->val[j];
+            }
+            for (i = 0; i < n; ++i)
+                for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) A->val[j] /= D[i];
+            for (i = 0; i < n; ++i) Drow[i] *= D[i];
+            *bad_at = n;
+            break;
+        case ORC_PRE_SPARSE_FIRST_ORDERING: {                                  /* :5293-5299, column_perm pmwm_implementation.h:539-560 */
+            orc_int *cnt = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));
+            for (j = 0; j < A->ptr[n]; ++j) cnt[A->idx[j]]++;
+            for (i = 0; i < n; ++i) p2[i] = i;
+            ivec_quicksort(cnt, p2, 0, n - 1);
+            if (n > 0 && cnt[0] == 0) for (i = 0; i < n; ++i) p2[i] = i;       /* an empty column: fill_identity */
+            free(cnt);
+            perm_invert(ip2, p2, n);
+            for (i = 0; i < n; ++i) p1[i] = i;
+            mat_permute_rows_cols(A, p1, ip2);                                 /* permute(p2, COLUMN): indices relabelled by the inverse, rows re-sorted, :5497-5512 */
+            perm_compose_right(Q, p2, n);
+            perm_invert(invQ, Q, n);
+            *bad_at = n;
+            break;
+        }
         default:
             rc = ORC_ERR_UNSUPPORTED;
         }

@@ -95,7 +95,9 @@ enum {                                   /* steps of a preprocessing_sequence (o
     ORC_PRE_NORMALIZE_ROWS = 2,
     ORC_PRE_PQ_ORDERING = 3,
     ORC_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,
-    ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5
+    ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5,
+    ORC_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6,
+    ORC_PRE_SPARSE_FIRST_ORDERING = 7
 };
 
 typedef struct {
