@@ -139,6 +139,17 @@ def extra_config(name, dev, steps):
         d, i, p = matgen.poisson3d(128)
         make = lambda a: _native.ILUCPreconditioner_device(*a, True, 8, 1e-2)
         what = "ILUC: ILUCPreconditioner(fill_in=8, threshold=1e-2), 3-D 7-point Laplacian 128^3"
+    elif name == "C5M":
+        # the same matrix with the I-matrix preprocessing BASELINE's default_configuration(10) names: maximum-weight matching (permutation
+        # and scalings from the host's augmenting-path search, applied on the device) + the factorisation without pivoting
+        import ilupp_amd as ilupp
+        d, i, p = matgen.random_dd(1000000, 8, 25.0, 12345)
+        prm = ilupp.iluplusplus_precond_parameter()
+        prm.default_configuration(1)
+        prm.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING()
+        prm.threshold = 1e-3
+        make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
+        what = "C5M: ILUppPreconditioner(MAX_WEIGHTED_MATCHING_ORDERING, preset 10 without pivoting, threshold=1e-3), random unsymmetric CSR n=1e6 (matching on one host core)"
     elif name == "C5":
         # BASELINE config 5's shape (unsymmetric CSR, n = 1e6) with the multilevel preconditioner this build has: default_configuration(1)
         # = normalisation + PQ ordering + the factorisation WITHOUT pivoting (preset 10).  BASELINE names default_configuration(10),
@@ -180,7 +191,7 @@ def extra_config(name, dev, steps):
         P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
         t = P.timings()
         nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
-        if name == "C5":
+        if name in ("C5", "C5M"):
             t["numeric_kernel_ms"] = t["kernel_ms"]
             levels = P.levels()
             nnz_out = sum(sum(P.level_sizes(k)[1:]) for k in range(levels))      # both unit diagonals stored, per level
@@ -191,7 +202,7 @@ def extra_config(name, dev, steps):
     nf = 1 if name == "C4" else 2
     fbytes = (12 * nnz + 4 * (n + 1)) + (12 * nnz_out + 4 * (n + 1) * nf)
     sec = float(np.median(walls))
-    more = {"levels": int(levels)} if name == "C5" else {}
+    more = {"levels": int(levels)} if name in ("C5", "C5M") else {}
     return {**more, "workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
             "numeric_kernel_ms": float(np.median(kms)), "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
@@ -207,8 +218,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "ILUC", "S27", "S9"],
-                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, ILUC)")
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "ILUC", "S27", "S9"],
+                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, C5M, ILUC)")
     ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, C5, ILUC) and the refactor loop")
     args = ap.parse_args()
 
@@ -470,9 +481,9 @@ def main():
         extra = {}
         cfgs = list(args.config)
         if not args.no_extra and world == 1:
-            cfgs = [c for c in ("C3", "C4", "C5", "ILUC") if c not in cfgs] + cfgs
+            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "ILUC") if c not in cfgs] + cfgs
         for cfg in cfgs:
-            if cfg in ("C3", "C4", "C5", "ILUC", "S27", "S9") and world == 1:
+            if cfg in ("C3", "C4", "C5", "C5M", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))

@@ -328,7 +328,8 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
                 int32_t *kterm, float *kernel_ms);
 
 // ml.hip: the multilevel preconditioner built from such levels (reference preconditioner_implementation.h:1350-1665, :433-488)
-enum { ML_PRE_NORMALIZE_COLUMNS = 1, ML_PRE_NORMALIZE_ROWS = 2, ML_PRE_PQ_ORDERING = 3 };    // = ILUPP_PRE_* of include/ilupp_hip.h
+enum { ML_PRE_NORMALIZE_COLUMNS = 1, ML_PRE_NORMALIZE_ROWS = 2, ML_PRE_PQ_ORDERING = 3, ML_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,
+       ML_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5, ML_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6, ML_PRE_SPARSE_FIRST_ORDERING = 7 };    // = ILUPP_PRE_* of include/ilupp_hip.h
 struct MlParams {
     double threshold = 0.0;
     int n_pre = 0;

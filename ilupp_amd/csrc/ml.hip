@@ -20,6 +20,13 @@
 
 namespace ilupp {
 
+// ml_order.hip (host): the sequential ordering algorithms
+bool pmwm_host(int32_t n, const int32_t *ptr, const int32_t *idx, const double *val, std::vector<int32_t> &mate_col, std::vector<double> &inv_row,
+               std::vector<double> &inv_col);
+bool dd_move_corner_host(int32_t n, const int32_t *ptr, const int32_t *idx, const double *val, const int32_t *tptr, const int32_t *tidx, const double *tval,
+                         std::vector<int32_t> &P);
+void sparse_first_host(int32_t n, std::vector<int32_t> &counts, std::vector<int32_t> &p2);
+
 // ---------------------------------------------- normalisation ----------------------------------------------
 // vector_dense::norm2_of_dim1 along the storage order (sparse_implementation.h:820-833) + inverse_scale (:3271-3282), rows of a ROW matrix
 __global__ void k_ml_row_norms_scale(int32_t n, const int32_t *__restrict__ ptr, double *__restrict__ val, double *__restrict__ D)
@@ -56,6 +63,30 @@ __global__ void k_ml_fill_f64(int32_t n, double *p, double v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+}
+
+// rows divided by D (inverse_scale(D, ROW), sparse_implementation.h:3271-3278)
+__global__ void k_ml_row_scale(int32_t n, const int32_t *__restrict__ ptr, double *__restrict__ val, const double *__restrict__ D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = D[i];
+    for (int j = ptr[i]; j < ptr[i + 1]; ++j) val[j] = val[j] / d;
+}
+// unit_or_zero_diagonal (:5172-5178) + inverse_scale(D, ROW): D[i] = the stored diagonal entry if it is not zero, else 1
+__global__ void k_ml_unit_diag_scale(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, double *__restrict__ val, double *__restrict__ D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d = 1.0;
+    for (int j = ptr[i]; j < ptr[i + 1]; ++j) if (idx[j] == i && val[j] != 0.0) d = val[j];
+    D[i] = d;
+    for (int j = ptr[i]; j < ptr[i + 1]; ++j) val[j] = val[j] / d;
+}
+__global__ void k_ml_col_counts(int64_t nnz, const int32_t *__restrict__ idx, int32_t *__restrict__ cnt)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nnz) atomicAdd(&cnt[idx[j]], 1);
 }
 
 // ---------------------------------------------- PQ ordering ----------------------------------------------
@@ -253,8 +284,112 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             permuted_rows = permuted_cols = true;
             break;
         }
+        case ML_PRE_MAX_WEIGHTED_MATCHING_ORDERING: {                         // :5276-5292
+            // the matching is a sequential augmenting-path algorithm: the level's matrix goes to the host once, a permutation and two
+            // scalings come back; scaling and permuting the matrix happen on the device
+            const int64_t nnz = A->nnz;
+            std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), p1, ip1((size_t)n), ident((size_t)n);
+            std::vector<double> hv((size_t)(nnz > 0 ? nnz : 1)), D1, D2;
+            ILUPP_HIP(hipMemcpyAsync(hp.data(), A->ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+            if (nnz > 0) {
+                ILUPP_HIP(hipMemcpyAsync(hi.data(), A->idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+                ILUPP_HIP(hipMemcpyAsync(hv.data(), A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+            }
+            ILUPP_HIP(hipStreamSynchronize(st));
+            (void)pmwm_host(n, hp.data(), hi.data(), hv.data(), p1, D1, D2);
+            for (int32_t i = 0; i < n; ++i) { ip1[(size_t)p1[(size_t)i]] = i; ident[(size_t)i] = i; }
+            PoolBlock b_D2, b_p1, b_ip1, b_id;
+            ILUPP_HIP(b_D2.alloc(sizeof(double) * (size_t)n));
+            ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(b_ip1.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(b_id.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(hipMemcpyAsync(b_D.p, D1.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+            ILUPP_HIP(hipMemcpyAsync(b_D2.p, D2.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+            upload_i32(st, b_p1.as<int32_t>(), p1); upload_i32(st, b_ip1.as<int32_t>(), ip1); upload_i32(st, b_id.as<int32_t>(), ident);
+            hipLaunchKernelGGL(k_ml_row_scale, dim3(gb), dim3(256), 0, st, n, A->ptr, A->val, b_D.as<double>());           // inverse_scale(D1, ROW)
+            if (nnz > 0)
+                hipLaunchKernelGGL(k_ml_col_scale, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, A->idx, A->val, b_D2.as<double>());   // (D2, COLUMN)
+            { const int rc = permute_matrix(st, A, b_p1.as<int32_t>(), b_ip1.as<int32_t>(), b_id.as<int32_t>()); if (rc) return rc; }   // permute(p1, ROW)
+            const int32_t *inv = nullptr;
+            if (permuted_rows) { upload_i32(st, b_inv.as<int32_t>(), invP); inv = b_inv.as<int32_t>(); }
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), inv);
+            ILUPP_HIP(hipStreamSynchronize(st));
+            inv = nullptr;
+            if (permuted_cols) { upload_i32(st, b_inv.as<int32_t>(), invQ); inv = b_inv.as<int32_t>(); }
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Dcol, b_D2.as<double>(), inv);
+            ILUPP_HIP(hipStreamSynchronize(st));
+            std::vector<int32_t> H((size_t)n);
+            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = P[(size_t)p1[(size_t)i]];                     // P.compose_right(p1); invP.invert(P)
+            P.swap(H);
+            for (int32_t i = 0; i < n; ++i) invP[(size_t)P[(size_t)i]] = i;
+            permuted_rows = true;
+            break;
+        }
+        case ML_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING:                             // :5309-5314 (Drow.multiply(D1) without a permutation, as there)
+            hipLaunchKernelGGL(k_ml_unit_diag_scale, dim3(gb), dim3(256), 0, st, n, A->ptr, A->idx, A->val, b_D.as<double>());
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), (const int32_t *)nullptr);
+            ILUPP_HIP(hipStreamSynchronize(st));
+            break;
+        case ML_PRE_SPARSE_FIRST_ORDERING: {                                   // :5293-5299
+            PoolBlock b_cnt, b_id, b_ip2;
+            ILUPP_HIP(b_cnt.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(hipMemsetAsync(b_cnt.p, 0, sizeof(int32_t) * (size_t)n, st));
+            if (A->nnz > 0)
+                hipLaunchKernelGGL(k_ml_col_counts, dim3((unsigned)((A->nnz + 255) / 256)), dim3(256), 0, st, A->nnz, A->idx, b_cnt.as<int32_t>());
+            std::vector<int32_t> cnt((size_t)n), p2, ip2((size_t)n), ident((size_t)n);
+            ILUPP_HIP(hipMemcpyAsync(cnt.data(), b_cnt.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+            ILUPP_HIP(hipStreamSynchronize(st));
+            sparse_first_host(n, cnt, p2);
+            for (int32_t i = 0; i < n; ++i) { ip2[(size_t)p2[(size_t)i]] = i; ident[(size_t)i] = i; }
+            ILUPP_HIP(b_id.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(b_ip2.alloc(sizeof(int32_t) * (size_t)n));
+            upload_i32(st, b_id.as<int32_t>(), ident); upload_i32(st, b_ip2.as<int32_t>(), ip2);
+            { const int rc = permute_matrix(st, A, b_id.as<int32_t>(), b_id.as<int32_t>(), b_ip2.as<int32_t>()); if (rc) return rc; }   // permute(p2, COLUMN)
+            std::vector<int32_t> H((size_t)n);
+            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = Q[(size_t)p2[(size_t)i]];
+            Q.swap(H);
+            for (int32_t i = 0; i < n; ++i) invQ[(size_t)Q[(size_t)i]] = i;
+            permuted_cols = true;
+            break;
+        }
+        case ML_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM: {                         // :5441-5450
+            const int64_t nnz = A->nnz;
+            DevMat T;
+            transpose_storage(st, *A, &T);
+            std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), tp((size_t)n + 1), ti((size_t)(nnz > 0 ? nnz : 1)), p1, ip1((size_t)n);
+            std::vector<double> hv((size_t)(nnz > 0 ? nnz : 1)), tv((size_t)(nnz > 0 ? nnz : 1));
+            ILUPP_HIP(hipMemcpyAsync(hp.data(), A->ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+            ILUPP_HIP(hipMemcpyAsync(tp.data(), T.ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+            if (nnz > 0) {
+                ILUPP_HIP(hipMemcpyAsync(hi.data(), A->idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+                ILUPP_HIP(hipMemcpyAsync(hv.data(), A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+                ILUPP_HIP(hipMemcpyAsync(ti.data(), T.idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+                ILUPP_HIP(hipMemcpyAsync(tv.data(), T.val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+            }
+            ILUPP_HIP(hipStreamSynchronize(st));
+            T.release();
+            if (!dd_move_corner_host(n, hp.data(), hi.data(), hv.data(), tp.data(), ti.data(), tv.data(), p1)) {
+                set_error("DD_SYMM_MOVE_CORNER_ORDERING_IM: the ordering rejects an index of this matrix, and the reference's result is then undefined (it refills its "
+                          "container with stale flags, sparse_implementation.h:5014 / arrays_implementation.h:55-63, and returns indices that repeat): refused");
+                return ILUPP_ERR_UNSUPPORTED;
+            }
+            for (int32_t i = 0; i < n; ++i) ip1[(size_t)p1[(size_t)i]] = i;
+            PoolBlock b_p1, b_ip1;
+            ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
+            ILUPP_HIP(b_ip1.alloc(sizeof(int32_t) * (size_t)n));
+            upload_i32(st, b_p1.as<int32_t>(), p1); upload_i32(st, b_ip1.as<int32_t>(), ip1);
+            { const int rc = permute_matrix(st, A, b_p1.as<int32_t>(), b_ip1.as<int32_t>(), b_ip1.as<int32_t>()); if (rc) return rc; }     // permute(p1, p1)
+            std::vector<int32_t> H((size_t)n);
+            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = P[(size_t)p1[(size_t)i]];
+            P.swap(H);
+            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = Q[(size_t)p1[(size_t)i]];
+            Q.swap(H);
+            for (int32_t i = 0; i < n; ++i) { invP[(size_t)P[(size_t)i]] = i; invQ[(size_t)Q[(size_t)i]] = i; }
+            permuted_rows = permuted_cols = true;
+            break;
+        }
         default:
-            set_error("ILU++ preprocessing step " + std::to_string(IP.pre[s]) + " is not built yet (available: NORMALIZE_COLUMNS, NORMALIZE_ROWS, PQ_ORDERING)");
+            set_error("ILU++ preprocessing step " + std::to_string(IP.pre[s]) + " is not built");
             return ILUPP_ERR_UNSUPPORTED;
         }
     }

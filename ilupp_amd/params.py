@@ -9,7 +9,8 @@ preconditioner is constructed (``_to_ml_params``): a parameter set it cannot hon
 from . import _native
 
 # preprocessing_type names (functions_implementation.h:94-127) the engine has kernels for -> ILUPP_PRE_* of include/ilupp_hip.h
-_BUILT_STEPS = {"NORMALIZE_COLUMNS": 1, "NORMALIZE_ROWS": 2, "PQ_ORDERING": 3}
+_BUILT_STEPS = {"NORMALIZE_COLUMNS": 1, "NORMALIZE_ROWS": 2, "PQ_ORDERING": 3, "MAX_WEIGHTED_MATCHING_ORDERING": 4,
+                "DD_SYMM_MOVE_CORNER_ORDERING_IM": 5, "UNIT_OR_ZERO_DIAGONAL_SCALING": 6, "SPARSE_FIRST_ORDERING": 7}
 
 
 class preprocessing_sequence(list):

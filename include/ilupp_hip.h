@@ -159,7 +159,8 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
  * Built: the family WITHOUT pivoting (use_ILUC, :1385-1390: PERMUTE_ROWS 0, TOTAL_PIV 0, piv_tol 0 -- precon_parameter 10 of
  * parameters_implementation.h:927-934, e.g. default_configuration(1)) over matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) with
  * error-propagation dropping, unbounded fill, levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
- * PQ_ORDERING (sparse_implementation.h:5214-5275).  Every other parameter combination -- the pivoting factorisation partialILUCDP of
+ * PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING, DD_SYMM_MOVE_CORNER_ORDERING_IM
+ * (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter combination -- the pivoting factorisation partialILUCDP of
  * the default-constructed parameters among them -- is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ilupp_ml ilupp_ml;
@@ -167,7 +168,11 @@ typedef struct ilupp_ml ilupp_ml;
 enum {                               /* preprocessing_type values (orderings.h) this build has */
     ILUPP_PRE_NORMALIZE_COLUMNS = 1,
     ILUPP_PRE_NORMALIZE_ROWS = 2,
-    ILUPP_PRE_PQ_ORDERING = 3
+    ILUPP_PRE_PQ_ORDERING = 3,
+    ILUPP_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,     /* the matching itself runs on the host (sequential augmenting paths) */
+    ILUPP_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5,    /* refused for matrices on which the reference's own result is undefined */
+    ILUPP_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6,
+    ILUPP_PRE_SPARSE_FIRST_ORDERING = 7
 };
 
 typedef struct {                     /* the fields of iluplusplus_precond_parameter (parameters.h:120-235) the built family reads */

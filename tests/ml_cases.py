@@ -8,7 +8,8 @@ import scipy.sparse as sp
 
 import matgen
 
-PRE = {"NORMALIZE_COLUMNS": 1, "NORMALIZE_ROWS": 2, "PQ_ORDERING": 3}
+PRE = {"NORMALIZE_COLUMNS": 1, "NORMALIZE_ROWS": 2, "PQ_ORDERING": 3, "MAX_WEIGHTED_MATCHING_ORDERING": 4, "DD_SYMM_MOVE_CORNER_ORDERING_IM": 5,
+       "UNIT_OR_ZERO_DIAGONAL_SCALING": 6, "SPARSE_FIRST_ORDERING": 7}
 
 
 def laplace_matrix(n):
@@ -27,7 +28,14 @@ def weak_random(n, density, diag, seed):
     return (sp.random(n, n, density=density, random_state=np.random.default_rng(seed), format="csr") + sp.eye(n) * diag).tocsr()
 
 
+def offdiag_random(n, seed):
+    """large entries off the diagonal, none on it: the matching has to permute"""
+    R = weak_random(n, 0.02, 0.0, seed)
+    return (R + sp.diags([np.full(n - 1, 3.0)], [1], shape=(n, n)) + sp.diags([np.full(1, 2.5)], [-(n - 1)], shape=(n, n))).tocsr()
+
+
 def matrices():
+    yield "offdiag_150", offdiag_random(150, 3)
     d, i, p = matgen.poisson3d(6, 7, 5)
     yield "p3d_6_7_5", sp.csr_matrix((d, i, p), shape=(210, 210))
     yield "laplace2d_400", laplace2d_matrix(400)
@@ -51,6 +59,16 @@ PARAMS = [
     ("t0.05_pq0.3", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"PQ_THRESHOLD": 0.3, "MIN_ELIM_FACTOR": 0.25}),
     ("t0.02_vary", 0.02, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"VARY_THRESHOLD_FACTOR": 2.0, "USE_FINAL_THRESHOLD": True, "FINAL_THRESHOLD": 0.5}),
     ("t0.05_noterm", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"SMALL_PIVOT_TERMINATES": False}),
+    # maximum-weight matching (the I-matrix preprocessing of default_configuration(10 .. 13)) and what is combined with it
+    ("t0.05_mwm", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING",), {}),
+    ("t0_mwm", 0.0, ("MAX_WEIGHTED_MATCHING_ORDERING",), {}),
+    ("t0.05_norm_mwm", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "MAX_WEIGHTED_MATCHING_ORDERING"), {}),
+    ("t0.05_sf_mwm", 0.05, ("SPARSE_FIRST_ORDERING", "MAX_WEIGHTED_MATCHING_ORDERING"), {}),
+    ("t0.05_mwm_unit", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "UNIT_OR_ZERO_DIAGONAL_SCALING"), {}),
+    ("t0.05_mwm_pq", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "PQ_ORDERING"), {}),
+    # default_configuration(11): where the move-to-corner ordering rejects an index the reference's result is undefined:
+    # the oracle and the engine refuse, and the fixture records that
+    ("t0.05_mwm_dd", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "DD_SYMM_MOVE_CORNER_ORDERING_IM"), {}),
 ]
 
 _ORC_FIELDS = {"MAX_LEVELS": "max_levels", "THRESHOLD_SHIFT_SCHUR": "threshold_shift_schur", "MIN_PIVOT": "min_pivot", "PQ_THRESHOLD": "pq_threshold",
