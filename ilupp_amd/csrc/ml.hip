@@ -230,6 +230,12 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
     P.resize((size_t)n); Q.resize((size_t)n); invP.resize((size_t)n); invQ.resize((size_t)n);
     for (int32_t i = 0; i < n; ++i) P[(size_t)i] = Q[(size_t)i] = invP[(size_t)i] = invQ[(size_t)i] = i;
     bool permuted_rows = false, permuted_cols = false;
+    // The reference keeps ONE set of work permutations for all steps of a preprocess() call (sparse_implementation.h:5217-5218) and two
+    // steps only resize them (std::vector::resize keeps existing elements): after a step that filled p1 the matching starts with every
+    // column "matched", finds no augmenting path and returns the identity with unit scalings (pmwm_implementation.h:411, :460-471);
+    // a second PQ step finds everything "taken" and returns the first one's permutations again (:4580-4581, :4613).  Kept as it behaves.
+    bool p1_filled = false;
+    std::vector<int32_t> pq_ip1, pq_ip2;
     hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Drow, 1.0);
     hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Dcol, 1.0);
     PoolBlock b_D, b_inv;
@@ -267,7 +273,9 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             ILUPP_HIP(hipMemcpyAsync(W.data(), b_D.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
             ILUPP_HIP(hipMemcpyAsync(J.data(), b_J.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
             ILUPP_HIP(hipStreamSynchronize(st));
-            (void)pq_select(n, W, J, IP.pq_threshold, ip1, ip2);
+            if (pq_ip1.empty()) { (void)pq_select(n, W, J, IP.pq_threshold, ip1, ip2); pq_ip1 = ip1; pq_ip2 = ip2; }
+            else { ip1 = pq_ip1; ip2 = pq_ip2; }
+            p1_filled = true;
             for (int32_t i = 0; i < n; ++i) { p1[(size_t)ip1[(size_t)i]] = i; p2[(size_t)ip2[(size_t)i]] = i; }
             ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
             ILUPP_HIP(b_ip1.alloc(sizeof(int32_t) * (size_t)n));
@@ -296,7 +304,9 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
                 ILUPP_HIP(hipMemcpyAsync(hv.data(), A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
             }
             ILUPP_HIP(hipStreamSynchronize(st));
-            (void)pmwm_host(n, hp.data(), hi.data(), hv.data(), p1, D1, D2);
+            if (!p1_filled) (void)pmwm_host(n, hp.data(), hi.data(), hv.data(), p1, D1, D2);
+            else { p1.resize((size_t)n); for (int32_t i = 0; i < n; ++i) p1[(size_t)i] = i; D1.assign((size_t)n, 1.0); D2.assign((size_t)n, 1.0); }
+            p1_filled = true;
             for (int32_t i = 0; i < n; ++i) { ip1[(size_t)p1[(size_t)i]] = i; ident[(size_t)i] = i; }
             PoolBlock b_D2, b_p1, b_ip1, b_id;
             ILUPP_HIP(b_D2.alloc(sizeof(double) * (size_t)n));
@@ -373,6 +383,7 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
                           "container with stale flags, sparse_implementation.h:5014 / arrays_implementation.h:55-63, and returns indices that repeat): refused");
                 return ILUPP_ERR_UNSUPPORTED;
             }
+            p1_filled = true;
             for (int32_t i = 0; i < n; ++i) ip1[(size_t)p1[(size_t)i]] = i;
             PoolBlock b_p1, b_ip1;
             ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));

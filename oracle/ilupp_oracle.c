@@ -1391,6 +1391,12 @@ static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_i
     orc_int *p1 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1)), *p2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1)),
             *ip1 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1)), *ip2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1));
     int rc = ORC_OK;
+    /* preprocess() keeps ONE set of work permutations p1, p2, ip1, ip2 for all steps of a call (:5217-5218), and two of the steps only
+     * resize them without re-initialising (std::vector::resize keeps existing elements): after a step that filled p1, find_pmwm starts with
+     * every column "matched" (mate_col = p1, pmwm_implementation.h:411), finds no augmenting path and returns the identity with unit
+     * scalings (:460-471); after a PQ step, a second one finds every row and column "taken" (:4580-4581, :4613) and returns the same
+     * permutations again.  Reproduced as the reference behaves. */
+    int p1_filled = 0, ip_filled = 0;
     *bad_at = n;
     for (i = 0; i < n; ++i) { P[i] = Q[i] = invP[i] = invQ[i] = i; Drow[i] = 1.0; Dcol[i] = 1.0; }
     for (s = 0; s < IP->n_preprocessing && rc == ORC_OK; ++s) {
@@ -1417,7 +1423,9 @@ static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_i
             *bad_at = n;
             break;
         case ORC_PRE_PQ_ORDERING:                                              /* :5264-5275 */
-            *bad_at = mat_ddPQ(A, ip1, ip2, IP->pq_threshold);
+            if (!ip_filled) *bad_at = mat_ddPQ(A, ip1, ip2, IP->pq_threshold);
+            else *bad_at = 0;                                                  /* count = -1: pos + 1 */
+            ip_filled = 1; p1_filled = 1;
             perm_invert(p1, ip1, n);
             perm_invert(p2, ip2, n);
             mat_permute_rows_cols(A, p1, ip2);
@@ -1428,7 +1436,14 @@ static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_i
             break;
         case ORC_PRE_MAX_WEIGHTED_MATCHING_ORDERING: {                         /* :5276-5292 */
             double *D2 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-            (void)mat_pmwm(A, ip1, p1, D, D2);                                 /* maximal_weight_inverse_scales(p1, D1, D2): find_pmwm(A, invP, P, D1, D2), :5731-5734 */
+            if (!p1_filled) {
+                orc_int *mr = (orc_int *)malloc(sizeof(orc_int) * (size_t)(n > 0 ? n : 1));
+                (void)mat_pmwm(A, mr, p1, D, D2);                              /* maximal_weight_inverse_scales(p1, D1, D2): find_pmwm(A, invP, P, D1, D2), :5731-5734 */
+                free(mr);
+            } else {
+                for (i = 0; i < n; ++i) { p1[i] = i; D[i] = 1.0; D2[i] = 1.0; }
+            }
+            p1_filled = 1;
             for (i = 0; i < n; ++i)
                 for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) A->val[j] /= D[i];                    /* inverse_scale(D1, ROW) */
             for (j = 0; j < A->ptr[n]; ++j) A->val[j] /= D2[A->idx[j]];                           /* inverse_scale(D2, COLUMN) */
@@ -1446,6 +1461,7 @@ static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_i
         }
         case ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM:                          /* :5441-5450 */
             if (!mat_dd_move_corner(A, p1)) { rc = ORC_ERR_UNSUPPORTED; break; }
+            p1_filled = 1;
             perm_invert(ip1, p1, n);
             mat_permute_rows_cols(A, p1, ip1);                                 /* permute(p1, p1), :5564-5568 -> :5550-5561 */
             perm_compose_right(P, p1, n);

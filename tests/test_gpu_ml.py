@@ -236,3 +236,15 @@ def test_matching_preprocessing_against_oracle():
     S[:, 7] = 0
     S = S.tocsr(); S.eliminate_zeros()
     _against_oracle(S, (0.05, MWM, {}))
+
+
+def test_fuzz_against_oracle():
+    """random small matrices of all kinds (missing diagonals, wild magnitudes, empty-ish rows, 1 x 1 ... 350 x 350) with random
+    preprocessing sequences and knobs (tests/fuzz_ml.py): every level and both applies bit for bit, NaNs and infinities included"""
+    import fuzz_ml
+    for seed in range(120):
+        A, params = fuzz_ml.case(seed)
+        try:
+            _against_oracle(A, params)
+        except AssertionError as e:
+            raise AssertionError("fuzz case %d: %s" % (seed, e))

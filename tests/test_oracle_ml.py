@@ -88,6 +88,24 @@ def test_oracle_against_reference_live():
                 assert np.array_equal(R.apply(b, O.TRANSPOSE), P.apply(b, O.TRANSPOSE), equal_nan=True)
 
 
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_against_reference_fuzz():
+    """random small matrices of all kinds with random parameter sets (tests/fuzz_ml.py): every level and both applies, bit for bit"""
+    import fuzz_ml
+    for seed in range(150):
+        A, (thr, pre, knobs) = fuzz_ml.case(seed)
+        a = O.from_scipy(A)
+        p = C.oracle_params(O, thr, pre, knobs)
+        R, P = O.ref().ml(a, p), O.orc().ml(a, p)
+        assert R.levels() == P.levels() and R.total_nnz() == P.total_nnz(), seed
+        for k in range(R.levels()):
+            for x, y in zip(C.level_arrays(R.level(k)), C.level_arrays(P.level(k))):
+                assert x.shape == y.shape and np.array_equal(x, y, equal_nan=True), (seed, k)
+        b = C.rhs(A.shape[0])
+        assert np.array_equal(R.apply(b), P.apply(b), equal_nan=True), seed
+        assert np.array_equal(R.apply(b, O.TRANSPOSE), P.apply(b, O.TRANSPOSE), equal_nan=True), seed
+
+
 def test_oracle_refuses_unknown_preprocessing():
     A = sp.eye(5, format="csr")
     with pytest.raises(O.OracleError):
