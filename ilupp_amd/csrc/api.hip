@@ -1397,6 +1397,7 @@ int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
     P.pil.small_pivot_terminates = ip->small_pivot_terminates != 0; P.pil.min_pivot = ip->min_pivot; P.pil.min_elim_factor = ip->min_elim_factor;
     P.pil.threshold_shift_schur = ip->threshold_shift_schur; P.vary_threshold_factor = ip->vary_threshold_factor;
     P.use_final_threshold = ip->use_final_threshold != 0; P.final_threshold = ip->final_threshold;
+    P.pil.max_fill_in = ip->max_fill_in > 0 ? ip->max_fill_in : 0;
     struct MlGuard { ilupp_ml *m; ~MlGuard() { if (m) ml_destroy(m); } } g{new ilupp_ml()};
     ilupp_ml *m = g.m;
     m->n = A.n;
@@ -1453,6 +1454,7 @@ void ilupp_hip_ml_default_params(ilupp_ml_params *p)
     p->pq_threshold = 0.0; p->max_levels = 100; p->min_ml_size = 0;
     p->small_pivot_terminates = 1; p->min_pivot = 1e-2; p->min_elim_factor = 0.0; p->threshold_shift_schur = 0.0;
     p->vary_threshold_factor = 1.0; p->use_final_threshold = 0; p->final_threshold = 0.0;
+    p->max_fill_in = 0;
 }
 
 int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const ilupp_ml_params *params,

@@ -323,6 +323,7 @@ struct PilucParams {
     bool small_pivot_terminates = true;   // SMALL_PIVOT_TERMINATES
     double min_elim_factor = 0.0;         // MIN_ELIM_FACTOR
     double threshold_shift_schur = 0.0;   // THRESHOLD_SHIFT_SCHUR
+    int32_t max_fill_in = 0;              // 0: MAX_FILLIN_IS_INF; else fill_in
 };
 int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv, DevMat *Anew,
                 int32_t *kterm, float *kernel_ms);

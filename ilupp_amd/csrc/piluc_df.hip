@@ -57,6 +57,7 @@ struct PilucArgs {
     double tau;                               // dropping threshold of this launch
     double min_pivot;
     int32_t park_from;                        // steps k > park_from may end the level (0x7fffffff: none may)
+    int32_t budget;                           // entries a row of U / a column of L may keep besides the 1 (max_fill_in - 1); Schur mode: entries of a row (max_fill_in)
     int32_t schur, kterm;                     // Schur mode: rows kterm.. of the Schur complement
     int32_t T, nq;
     int32_t *Uidx, *Lidx;                     // the stores: a row of U = (k, 1) then the kept entries by increasing index; same for L
@@ -92,6 +93,40 @@ __device__ __forceinline__ void wave_sort_u64(unsigned long long *a, int N, int 
             __syncthreads();
         }
 }
+// vector_dense<T>::sort(list, left, right, m), sparse_implementation.h:507-563: the selection algorithm the reference uses when a row has more
+// candidates than it may keep -- afterwards the m largest keys stand at the end; which of several equal keys do is defined by this algorithm,
+// so it runs as written, on one lane (rows that exceed a bounded fill are rare)
+__device__ void select_largest(double *data, int *list, int left, int right, int m)
+{
+    const int k = right - m + 1;
+#define PSW(x, y) do { const double t_ = data[x]; const int u_ = list[x]; data[x] = data[y]; data[y] = t_; list[x] = list[y]; list[y] = u_; } while (0)
+    for (;;) {
+        if (right <= left + 1) {
+            if (right == left + 1 && data[right] < data[left]) PSW(left, right);
+            break;
+        }
+        const int mid = (left + right) / 2;
+        PSW(mid, left + 1);
+        if (data[left] > data[right]) PSW(left, right);
+        if (data[left + 1] > data[right]) PSW(left + 1, right);
+        if (data[left] > data[left + 1]) PSW(left, left + 1);
+        int i = left + 1, j = right;
+        const double a = data[left + 1];
+        const int a_list = list[left + 1];
+        for (;;) {
+            do i++; while (data[i] < a);
+            do j--; while (data[j] > a);
+            if (j < i) break;
+            PSW(i, j);
+        }
+        data[left + 1] = data[j]; list[left + 1] = list[j];
+        data[j] = a; list[j] = a_list;
+        if (j >= k) right = j - 1;
+        if (j <= k) left = i;
+    }
+#undef PSW
+}
+
 // first position p in [lo, hi] (1-based list `slots`, keys key[slots[p]]) whose key is >= v; hi + 1 if none
 __device__ __forceinline__ int lower_pos(const int *slots, const int *key, int lo, int hi, int v)
 {
@@ -393,6 +428,18 @@ k_piluc_df(PilucArgs A)
                 int nk = 0;
                 for (int base = 0; base < ns; base += 64) { const int s = base + lane; nk += __popcll(__ballot(s < ns && srank[s] >= 0)); }
                 nk = __builtin_amdgcn_readfirstlane(nk);
+                if (nk > A.budget) {
+                    // more than max_fill_in candidates: the largest by the reference's selection (:1341-1350)
+                    if (lane == 0) {
+                        int *ids = erow;
+                        int c = 0;
+                        for (int s = 0; s < ns; ++s) if (srank[s] >= 0) { eval[c] = fabs(sval[s]); ids[c] = s; ++c; }
+                        if (A.budget > 0) select_largest(eval, ids, 0, c - 1, A.budget);
+                        for (int q = 0; q < c - A.budget; ++q) srank[ids[q]] = -1;
+                    }
+                    nk = A.budget;
+                    PU_SYNC();
+                }
                 int pos = 0;
                 if (lane == 0) pos = atomicAdd(&A.ctrl[6], nk);
                 pos = __builtin_amdgcn_readfirstlane(pos);
@@ -472,6 +519,27 @@ k_piluc_df(PilucArgs A)
                 for (int base = 0; base < nzs; base += 64) { const int s = base + lane; nkz += __popcll(__ballot(s < nzs && (zcnt[s] & 0x40000000))); }
                 for (int base = 0; base < ns; base += 64) { const int s = base + lane; nkw += __popcll(__ballot(s < ns && srank[s] >= 0)); }
                 nkz = __builtin_amdgcn_readfirstlane(nkz); nkw = __builtin_amdgcn_readfirstlane(nkw);
+                if (nkz > A.budget || nkw > A.budget) {
+                    // bounded fill: the max_fill_in - 1 largest products by the reference's selection (:1398-1405), candidates in slot order
+                    if (lane == 0) {
+                        int *ids = erow;
+                        if (nkz > A.budget) {
+                            int c = 0;
+                            for (int s = 0; s < nzs; ++s) if (zcnt[s] & 0x40000000) { eval[c] = weightU * fabs(zval[s]); ids[c] = s; ++c; }
+                            if (A.budget > 0) select_largest(eval, ids, 0, c - 1, A.budget);
+                            for (int q = 0; q < c - A.budget; ++q) zcnt[ids[q]] &= 0x3fffffff;
+                        }
+                        if (nkw > A.budget) {
+                            int c = 0;
+                            for (int s = 0; s < ns; ++s) if (srank[s] >= 0) { eval[c] = weightL * fabs(sval[s]); ids[c] = s; ++c; }
+                            if (A.budget > 0) select_largest(eval, ids, 0, c - 1, A.budget);
+                            for (int q = 0; q < c - A.budget; ++q) srank[ids[q]] = -1;
+                        }
+                    }
+                    if (nkz > A.budget) nkz = A.budget;
+                    if (nkw > A.budget) nkw = A.budget;
+                    PU_SYNC();
+                }
                 if (nzs <= 128) {
                     for (int s = lane; s < nzs; s += 64) {
                         if (!(zcnt[s] & 0x40000000)) continue;
@@ -793,6 +861,10 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
         const double x = P.min_elim_factor * (double)m;
         a.park_from = x < 0.0 ? -1 : (x >= 2147483647.0 ? big : (int32_t)x);
     }
+    int32_t max_fill = P.max_fill_in > 0 ? P.max_fill_in : m;             // ILUCDP.hpp:1440-1447: MAX_FILLIN_IS_INF => n; clamped to [1, n]
+    if (max_fill < 1) max_fill = 1;
+    if (max_fill > m) max_fill = m;
+    a.budget = max_fill - 1;
     a.schur = 0; a.kterm = big; a.T = T; a.nq = nq;
     a.Uidx = b_Uidx.as<int32_t>(); a.Lidx = b_Lidx.as<int32_t>(); a.Uval = b_Uval.as<double>(); a.Lval = b_Lval.as<double>();
     a.capU = (int32_t)store; a.capL = (int32_t)store;
@@ -841,6 +913,7 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
         hipLaunchKernelGGL(k_piluc_schur_seed, dim3(gs), dim3(256), 0, st, m, kterm, nq, b_pendS.as<int32_t>(), rq, ctrl);
         PilucArgs s = a;
         s.schur = 1; s.kterm = kterm; s.tau = tau * P.threshold_shift_schur;              // threshold *= threshold_Schur_factor, :1622
+        s.budget = max_fill;                                                              // take_largest(..., max_fill_in, ...), :1717
         s.pending = b_pendS.as<int32_t>();
         s.Sidx = b_Sidx.as<int32_t>(); s.Sval = b_Sval.as<double>(); s.capS = (int32_t)capS; s.Sstart = b_Sstart.as<int32_t>(); s.Slen = b_Slen.as<int32_t>();
         launch_class(cls, waves, st, s);

@@ -193,7 +193,7 @@ class iluplusplus_precond_parameter:
                               "USE_WEIGHTED_DROPPING2", "USE_ERR_PROP_DROPPING2", "USE_PIVOT_DROPPING") if getattr(self, k)]
         if others or not self.USE_ERR_PROP_DROPPING:
             refuse("dropping by " + (", ".join(others) or "no rule"))
-        checks = [("MAX_FILLIN_IS_INF", True), ("DROP_TYPE_L", 0), ("DROP_TYPE_U", 0), ("SCHUR_COMPLEMENT", 0), ("EXTERNAL_FINAL_ROW", False),
+        checks = [("DROP_TYPE_L", 0), ("DROP_TYPE_U", 0), ("SCHUR_COMPLEMENT", 0), ("EXTERNAL_FINAL_ROW", False),
                   ("REQUIRE_ZERO_SCHUR", False), ("USE_THRES_ZERO_SCHUR", False), ("WEIGHTED_DROPPING", True), ("SUM_DROPPING", False),
                   ("COMBINE_FACTOR", 0), ("NEUTRAL_ELEMENT", 0.0), ("WEIGHT_ERR_PROP_DROP", 1.0), ("SCALE_WEIGHT_INVDIAG", False),
                   ("SCALE_WGT_MAXINVDIAG", False), ("USE_POS_COMPRESS", False)]
@@ -226,4 +226,5 @@ class iluplusplus_precond_parameter:
         p.vary_threshold_factor = float(self.VARY_THRESHOLD_FACTOR)
         p.use_final_threshold = 1 if self.USE_FINAL_THRESHOLD else 0
         p.final_threshold = float(self.FINAL_THRESHOLD)
+        p.max_fill_in = 0 if self.MAX_FILLIN_IS_INF else max(1, int(self.fill_in))      # partialILUC :1440-1447 (clamped to the level's size there)
         return p

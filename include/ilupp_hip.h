@@ -158,7 +158,7 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
  *      apply :433-488, total_nnz preconditioner.h:312.
  * Built: the family WITHOUT pivoting (use_ILUC, :1385-1390: PERMUTE_ROWS 0, TOTAL_PIV 0, piv_tol 0 -- precon_parameter 10 of
  * parameters_implementation.h:927-934, e.g. default_configuration(1)) over matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) with
- * error-propagation dropping, unbounded fill, levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
+ * error-propagation dropping, unbounded or bounded fill (presets 10 and 1010), levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
  * PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING, DD_SYMM_MOVE_CORNER_ORDERING_IM
  * (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter combination -- the pivoting factorisation partialILUCDP of
  * the default-constructed parameters among them -- is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
@@ -189,6 +189,7 @@ typedef struct {                     /* the fields of iluplusplus_precond_parame
     double vary_threshold_factor;    /* VARY_THRESHOLD_FACTOR */
     int32_t use_final_threshold;     /* USE_FINAL_THRESHOLD */
     double final_threshold;          /* FINAL_THRESHOLD */
+    int32_t max_fill_in;             /* 0: MAX_FILLIN_IS_INF; else fill_in (entries a row of U / a column of L may have, the 1 included) */
 } ilupp_ml_params;
 
 /* default_configuration(1) (parameters_implementation.h:546-549: set_PQ + precon_parameter 10) with threshold 0 */

@@ -1503,30 +1503,82 @@ static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_i
     return rc;
 }
 
-/* vector_sparse_dynamic::take_single_weight_largest_elements_by_abs_value_with_threshold, :1360-1415, WEIGHTED_DROPPING branch with
- * n >= the number of candidates (MAX_FILLIN_IS_INF): the indices in [from, to) whose weight * |value| >= tau, ascending */
-static orc_int take_single_weight(const wvec *v, orc_int *list, double weight, double tau, orc_int from, orc_int to)
+/* vector_dense<T>::sort(list, left, right, m), sparse_implementation.h:507-563: partitions so that the m largest values stand at the end
+ * (the selection algorithm of Numerical Recipes; which of several equal values end up there is defined by it); the list follows */
+static void vec_select_largest(double *data, orc_int *list, orc_int left, orc_int right, orc_int m)
 {
-    orc_int i, cnt = 0;
-    for (i = 0; i < v->nnz; ++i) {
-        const double product = weight * fabs(v->data[i]);
-        if (from <= v->pointer[i] && v->pointer[i] < to && product >= tau) list[cnt++] = v->pointer[i];
+    orc_int i, j, mid, a_list;
+    const orc_int k = right - m + 1;
+#define SW(x, y) do { const double t_ = data[x]; const orc_int u_ = list[x]; data[x] = data[y]; data[y] = t_; list[x] = list[y]; list[y] = u_; } while (0)
+    for (;;) {
+        if (right <= left + 1) {
+            if (right == left + 1 && data[right] < data[left]) SW(left, right);
+            break;
+        } else {
+            double a;
+            mid = (left + right) / 2;
+            SW(mid, left + 1);
+            if (data[left] > data[right]) SW(left, right);
+            if (data[left + 1] > data[right]) SW(left + 1, right);
+            if (data[left] > data[left + 1]) SW(left, left + 1);
+            i = left + 1; j = right;
+            a = data[left + 1]; a_list = list[left + 1];
+            for (;;) {
+                do i++; while (data[i] < a);
+                do j--; while (data[j] > a);
+                if (j < i) break;
+                SW(i, j);
+            }
+            data[left + 1] = data[j]; list[left + 1] = list[j];
+            data[j] = a; list[j] = a_list;
+            if (j >= k) right = j - 1;
+            if (j <= k) left = i;
+        }
+    }
+#undef SW
+}
+
+/* the common tail of the two selections below: more candidates than n => the n largest (by vec_select_largest), then by index */
+static orc_int keep_largest_sorted(double *key, orc_int *list, orc_int cnt, orc_int n)
+{
+    if (cnt > n) {
+        const orc_int offset = cnt - n;
+        vec_select_largest(key, list, 0, cnt - 1, n);
+        memmove(list, list + offset, sizeof(orc_int) * (size_t)n);
+        cnt = n;
     }
     qsort(list, (size_t)cnt, sizeof(orc_int), cmp_idx_pair);
     return cnt;
 }
 
-/* vector_sparse_dynamic::take_largest_elements_by_abs_value_with_threshold, :1322-1357, with n >= the number of candidates */
-static orc_int take_largest(const wvec *v, orc_int *list, double tau, orc_int from, orc_int to)
+/* vector_sparse_dynamic::take_single_weight_largest_elements_by_abs_value_with_threshold, :1360-1415, WEIGHTED_DROPPING branch: the indices
+ * in [from, to) whose weight * |value| >= tau -- at most n of them, the largest products --, ascending */
+static orc_int take_single_weight(const wvec *v, orc_int *list, double weight, orc_int n, double tau, orc_int from, orc_int to)
+{
+    orc_int i, cnt = 0;
+    double *key = (double *)malloc(sizeof(double) * (size_t)(v->nnz > 0 ? v->nnz : 1));
+    for (i = 0; i < v->nnz; ++i) {
+        const double product = weight * fabs(v->data[i]);
+        if (from <= v->pointer[i] && v->pointer[i] < to && product >= tau) { key[cnt] = product; list[cnt++] = v->pointer[i]; }
+    }
+    cnt = keep_largest_sorted(key, list, cnt, n);
+    free(key);
+    return cnt;
+}
+
+/* vector_sparse_dynamic::take_largest_elements_by_abs_value_with_threshold, :1322-1357 */
+static orc_int take_largest(const wvec *v, orc_int *list, orc_int n, double tau, orc_int from, orc_int to)
 {
     orc_int i, cnt = 0;
     double z = 0.0, norm;
+    double *key = (double *)malloc(sizeof(double) * (size_t)(v->nnz > 0 ? v->nnz : 1));
     for (i = 0; i < v->nnz; ++i)
         if (from <= v->pointer[i] && v->pointer[i] < to) z += v->data[i] * v->data[i];
     norm = sqrt(z);
     for (i = 0; i < v->nnz; ++i)
-        if (from <= v->pointer[i] && v->pointer[i] < to && fabs(v->data[i]) > norm * tau) list[cnt++] = v->pointer[i];
-    qsort(list, (size_t)cnt, sizeof(orc_int), cmp_idx_pair);
+        if (from <= v->pointer[i] && v->pointer[i] < to && fabs(v->data[i]) > norm * tau) { key[cnt] = fabs(v->data[i]); list[cnt++] = v->pointer[i]; }
+    cnt = keep_largest_sorted(key, list, cnt, n);
+    free(key);
     return cnt;
 }
 
@@ -1549,10 +1601,13 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
     const double *val = Arow->val;
     orc_int k, j, h, x, capL, capU, capA = 0;
     orc_int last_row_to_eliminate = n - 1, n_Anew = 0;
+    orc_int max_fill_in = IP->max_fill_in > 0 ? IP->max_fill_in : n;       /* :1440-1447: MAX_FILLIN_IS_INF => n; clamped to [1, n] */
     int eliminate = 1;
     double pivot = 0.0;
     orc_int *firstU, *listU, *firstL, *listL, *listA, *headA, *firstA, *list_L, *list_U;
     wvec z, w;
+    if (max_fill_in < 1) max_fill_in = 1;
+    if (max_fill_in > n) max_fill_in = n;
     *zero_pivots = 0;
     capL = capU = ptr[n] + n + 16;
     mat_init(L, n, capL, 0);
@@ -1611,11 +1666,11 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* w.scale(Dinv[k]), :1676 */
         /* dropping, :1716-1764 */
         if (!eliminate) {
-            nU = take_largest(&z, list_U, threshold, last_row_to_eliminate + 1, n);
+            nU = take_largest(&z, list_U, max_fill_in, threshold, last_row_to_eliminate + 1, n);
         } else {
             const double e = 1.0 * wv_norm1(&w);                              /* WEIGHT_ERR_PROP_DROP * w.norm1() */
             weightU = 0.0 < e ? e : 0.0;                                       /* combine: std::max(NEUTRAL_ELEMENT, .) */
-            nU = take_single_weight(&z, list_U, weightU, threshold, k + 1, n);
+            nU = take_single_weight(&z, list_U, weightU, max_fill_in - 1, threshold, k + 1, n);
         }
         /* update U or Anew, :1769-1850 */
         if (eliminate) {
@@ -1637,7 +1692,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         if (eliminate) {
             const double e = 1.0 * wv_norm1(&z);
             weightL = 0.0 < e ? e : 0.0;
-            nL = take_single_weight(&w, list_L, weightL, threshold, k + 1, n);
+            nL = take_single_weight(&w, list_L, weightL, max_fill_in - 1, threshold, k + 1, n);
             mat_reserve(L, L->ptr[k] + nL + 1, &capL);
             L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = k;
             for (j = 0; j < nL; ++j) { L->val[L->ptr[k] + j + 1] = w.data[w.occupancy[list_L[j]]]; L->idx[L->ptr[k] + j + 1] = list_L[j]; }
@@ -1703,6 +1758,7 @@ void orc_ml_default_params(orc_ml_params *p)       /* default_parameters (:430-5
     p->vary_threshold_factor = 1.0;
     p->use_final_threshold = 0;
     p->final_threshold = 0.0;
+    p->max_fill_in = 0;
 }
 
 /* make_preprocessed_multilevelILUCDP, preconditioner_implementation.h:1350-1665, use_ILUC branch */

@@ -114,6 +114,7 @@ typedef struct {
     double vary_threshold_factor;        /* VARY_THRESHOLD_FACTOR */
     int use_final_threshold;             /* USE_FINAL_THRESHOLD */
     double final_threshold;              /* FINAL_THRESHOLD */
+    orc_int max_fill_in;                 /* 0: MAX_FILLIN_IS_INF; else fill_in (entries a row of U / a column of L may have, the 1 included) */
 } orc_ml_params;
 
 typedef struct orc_ml orc_ml;

@@ -41,7 +41,7 @@ class MLParams(ctypes.Structure):
                 ("pq_threshold", ctypes.c_double), ("max_levels", ctypes.c_int), ("min_ml_size", ctypes.c_int32),
                 ("small_pivot_terminates", ctypes.c_int), ("min_pivot", ctypes.c_double), ("min_elim_factor", ctypes.c_double),
                 ("threshold_shift_schur", ctypes.c_double), ("vary_threshold_factor", ctypes.c_double),
-                ("use_final_threshold", ctypes.c_int), ("final_threshold", ctypes.c_double)]
+                ("use_final_threshold", ctypes.c_int), ("final_threshold", ctypes.c_double), ("max_fill_in", ctypes.c_int32)]
 
 
 class _MLView(ctypes.Structure):

@@ -282,6 +282,7 @@ int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
     param.set_VARY_THRESHOLD_FACTOR(IP->vary_threshold_factor);
     param.set_USE_FINAL_THRESHOLD(IP->use_final_threshold != 0);
     param.set_FINAL_THRESHOLD(IP->final_threshold);
+    if (IP->max_fill_in > 0) { param.set_MAX_FILLIN_IS_INF(false); param.set_fill_in(IP->max_fill_in); }
     ref_ml *R = new ref_ml;
     R->n = n;
     try {

@@ -48,4 +48,6 @@ def case(seed):
         knobs["SMALL_PIVOT_TERMINATES"] = False
     if rng.random() < 0.2:
         knobs["MIN_ELIM_FACTOR"] = float(rng.choice([0.1, 0.5]))
+    if rng.random() < 0.3:
+        knobs["fill_in"] = int(rng.choice([1, 2, 3, 6, 15]))
     return A, (thr, pre, knobs)

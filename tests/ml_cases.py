@@ -66,6 +66,12 @@ PARAMS = [
     ("t0.05_sf_mwm", 0.05, ("SPARSE_FIRST_ORDERING", "MAX_WEIGHTED_MATCHING_ORDERING"), {}),
     ("t0.05_mwm_unit", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "UNIT_OR_ZERO_DIAGONAL_SCALING"), {}),
     ("t0.05_mwm_pq", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "PQ_ORDERING"), {}),
+    # bounded fill (presets 1000+: MAX_FILLIN_IS_INF false): at most fill_in entries per row of U / column of L, the largest by the
+    # reference's own selection algorithm; THRESHOLD_SHIFT_SCHUR as in preset 1010
+    ("t0_fill4", 0.0, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"fill_in": 4}),
+    ("t0.02_fill7_shift", 0.02, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"fill_in": 7, "THRESHOLD_SHIFT_SCHUR": 1e-3}),
+    ("t0.01_fill1", 0.01, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"fill_in": 1}),
+    ("t0_mwm_fill12", 0.0, ("MAX_WEIGHTED_MATCHING_ORDERING",), {"fill_in": 12, "THRESHOLD_SHIFT_SCHUR": 1e-3}),
     # default_configuration(11): where the move-to-corner ordering rejects an index the reference's result is undefined:
     # the oracle and the engine refuse, and the fixture records that
     ("t0.05_mwm_dd", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "DD_SYMM_MOVE_CORNER_ORDERING_IM"), {}),
@@ -73,7 +79,8 @@ PARAMS = [
 
 _ORC_FIELDS = {"MAX_LEVELS": "max_levels", "THRESHOLD_SHIFT_SCHUR": "threshold_shift_schur", "MIN_PIVOT": "min_pivot", "PQ_THRESHOLD": "pq_threshold",
                "MIN_ELIM_FACTOR": "min_elim_factor", "VARY_THRESHOLD_FACTOR": "vary_threshold_factor", "USE_FINAL_THRESHOLD": "use_final_threshold",
-               "FINAL_THRESHOLD": "final_threshold", "SMALL_PIVOT_TERMINATES": "small_pivot_terminates", "MIN_ML_SIZE": "min_ml_size"}
+               "FINAL_THRESHOLD": "final_threshold", "SMALL_PIVOT_TERMINATES": "small_pivot_terminates", "MIN_ML_SIZE": "min_ml_size",
+               "fill_in": "max_fill_in"}
 
 
 def oracle_params(O, thr, pre, knobs):
@@ -89,6 +96,8 @@ def engine_params(ilupp, thr, pre, knobs):
     p.PREPROCESSING = ilupp.preprocessing_sequence(pre)
     for k, v in knobs.items():
         setattr(p, k, v)
+    if "fill_in" in knobs:
+        p.MAX_FILLIN_IS_INF = False
     return p
 
 

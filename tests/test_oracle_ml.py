@@ -127,6 +127,8 @@ def test_default_parameters_and_presets():
     assert p.PRECON_PARAMETER == 10 and p.PREPROCESSING.to_names() == ["MAX_WEIGHTED_MATCHING_ORDERING", "DD_SYMM_MOVE_CORNER_ORDERING_IM"]
     p.default_configuration(1001)                   # :580-583 + init case 1010 (:1592-1601)
     assert (p.PRECON_PARAMETER, p.THRESHOLD_SHIFT_SCHUR, p.MAX_FILLIN_IS_INF, p.fill_in) == (1010, 1e-3, False, 500)
+    b = p._to_ml_params()                           # the bounded-fill family is built
+    assert (b.max_fill_in, b.threshold_shift_schur) == (500, 1e-3)
     p.default_configuration(10)
     assert p.PRECON_PARAMETER == 0 and p.PERMUTE_ROWS == 3 and p.PREPROCESSING.to_names() == ["MAX_WEIGHTED_MATCHING_ORDERING"]
     with pytest.raises(NotImplementedError):
@@ -165,7 +167,6 @@ def test_everything_outside_the_built_family_is_refused():
     refused(lambda p: setattr(p, "piv_tol", 0.5))
     refused(lambda p: setattr(p, "PERMUTE_ROWS", 3))
     refused(lambda p: p.use_only_inverse_dropping())
-    refused(lambda p: setattr(p, "MAX_FILLIN_IS_INF", False))
     refused(lambda p: setattr(p, "SCHUR_COMPLEMENT", 1))
     refused(lambda p: setattr(p, "DROP_TYPE_L", 1))
     refused(lambda p: p.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ())
