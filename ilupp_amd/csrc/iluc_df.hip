@@ -549,7 +549,8 @@ k_iluc_df(IlucArgs A)
                         }
                     }
                 }
-                if (lane == 0) atomicAdd(&A.ctrl[4], 1);
+                // progress mark for the waiters' time-out (not from every step: one address that a million steps update is a bottleneck of its own)
+                if (lane == 0 && ((k & 255) == 0 || ne > 2048)) atomicAdd(&A.ctrl[4], 1);
                 CU_SYNC();
             }
         }

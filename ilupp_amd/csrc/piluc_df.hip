@@ -37,8 +37,12 @@
 
 namespace ilupp {
 
-// ctrl: [2] error (11..17 = a capacity, 2 = timeout), [3] smallest parked step, [4] finished steps, [5] steps queued or running,
-//       [6] cursor of the U store (Schur mode: of the store of the Schur rows), [7] cursor of the L store, then the queues
+// ctrl: [2] error (11..17 = a capacity, 2 = timeout), [3] smallest parked step, [4] finished steps (every wave adds its count when it leaves),
+//       [6] cursor of the U store (Schur mode: of the store of the Schur rows), [7] cursor of the L store -- both moved a CHUNK at a time, a wave
+//       appends its rows to its own chunk --, [9] progress mark, then the queues: queue q has its head at kCuQBase + 64 q, its tail 32 words later
+//       and, 48 words later, a 64-bit word {pushes so far : steps queued or running}.
+// One address that every step updates is a bottleneck of its own (a million steps, 100+ ms, whatever the number of waves): hence the chunks, the
+// per-queue counts and the sparse progress mark.
 __host__ __device__ inline size_t piluc_ws_bytes(int ne, int ns, int tm)
 {
     const size_t dbl = (size_t)ne + 2 * (size_t)ns + 2 * (size_t)tm;
@@ -63,6 +67,7 @@ struct PilucArgs {
     int32_t *Uidx, *Lidx;                     // the stores: a row of U = (k, 1) then the kept entries by increasing index; same for L
     double *Uval, *Lval;
     int32_t capU, capL;
+    int32_t chunk;                            // entries a wave takes from a store at a time
     int32_t *Ustart, *Ulen, *Lstart, *Llen;   // per step (Schur mode: Ustart / Ulen of the steps below kterm are read)
     double *Dinv;
     int32_t *Sidx;                            // Schur mode: store of the Schur rows (column indices as in the level's matrix)
@@ -179,10 +184,13 @@ k_piluc_df(PilucArgs A)
     // (one wave per block: __syncthreads() orders LDS; with the arrays in global memory the wave's stores must have landed too)
 #define PU_SYNC() do { if (kGlobal) __builtin_amdgcn_s_waitcnt(0); __syncthreads(); } while (0)
     // a step that is done (finished, parked or dropped): one less queued or running -- after everything it pushed
-#define PU_RETIRE() do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) atomicAdd(&A.ctrl[5], -1); } while (0)
-#define PU_PUSH(x_) do { const int xq_ = (x_) % nq; atomicAdd(&A.ctrl[5], 1); const int pos_ = atomicAdd(&A.ctrl[kCuQBase + 64 * xq_ + 32], 1); \
+#define PU_OUT(q_) reinterpret_cast<unsigned long long *>(&A.ctrl[kCuQBase + 64 * (q_) + 48])
+#define PU_RETIRE() do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) atomicAdd(PU_OUT(k % nq), ~0ull); } while (0)
+#define PU_PUSH(x_) do { const int xq_ = (x_) % nq; atomicAdd(PU_OUT(xq_), (1ull << 32) + 1ull); const int pos_ = atomicAdd(&A.ctrl[kCuQBase + 64 * xq_ + 32], 1); \
                          st_agent_i32(&A.rq[(size_t)xq_ * qcap + pos_], (x_)); } while (0)
 
+    int ndone = 0;                           // steps this wave finished
+    int uoff = 0, uend = 0, loff = 0, lend = 0;      // the wave's chunks of the two stores
     const int myq = (int)(blockIdx.x % nq);
     const int qcap = (m + nq - 1) / nq;
     const int qtotal = (m - myq + nq - 1) / nq;
@@ -201,13 +209,27 @@ k_piluc_df(PilucArgs A)
             if (k >= 0) break;
             if ((++spins & 63u) == 0) {
                 if (ld_agent_i32(&A.ctrl[2]) != 0) return;
-                // nothing queued or running anywhere: whoever could have filled this slot is gone (a step retires after its pushes)
-                if (ld_agent_i32(&A.ctrl[5]) == 0) {
-                    k = ld_agent_i32(&myrq[tkt]);
-                    if (k >= 0) break;
-                    return;
+                // nothing queued or running anywhere: whoever could have filled this slot is gone (a step retires after its pushes).  The
+                // counts are per queue; two looks with no push in between (the push counters) make the sum a consistent one
+                {
+                    unsigned long long first = 1ull, again = 1ull;
+                    for (int look = 0; look < 2; ++look) {
+                        const unsigned long long w = lane < nq ? __hip_atomic_load(PU_OUT(lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                        unsigned long long busy = __ballot((unsigned)w != 0u) != 0ull ? 1ull : 0ull;
+                        unsigned long long pushes = w >> 32;
+                        for (int off = 32; off > 0; off >>= 1) pushes += __shfl_xor(pushes, off);
+                        const unsigned long long v = (pushes << 1) | busy;
+                        if (look == 0) first = v; else again = v;
+                        if (busy) break;
+                    }
+                    if ((first & 1ull) == 0ull && first == again) {
+                        k = ld_agent_i32(&myrq[tkt]);
+                        if (k >= 0) break;
+                        if (lane == 0 && ndone) atomicAdd(&A.ctrl[4], ndone);
+                        return;
+                    }
                 }
-                const int done = ld_agent_i32(&A.ctrl[4]);
+                const int done = ld_agent_i32(&A.ctrl[9]);
                 if (done != seen) { seen = done; spins = 0; }
                 if (spins > kCuSpinLimit) PU_FAIL(2);
             }
@@ -440,10 +462,16 @@ k_piluc_df(PilucArgs A)
                     nk = A.budget;
                     PU_SYNC();
                 }
-                int pos = 0;
-                if (lane == 0) pos = atomicAdd(&A.ctrl[6], nk);
-                pos = __builtin_amdgcn_readfirstlane(pos);
-                if (pos < 0 || (long)pos + nk > (long)A.capS) PU_FAIL(16);
+                if (uoff + nk > uend) {
+                    const int take = nk > A.chunk ? nk : A.chunk;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&A.ctrl[6], take);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base < 0 || (long)base + take > (long)A.capS) PU_FAIL(16);
+                    uoff = base; uend = base + take;
+                }
+                const int pos = uoff;
+                uoff += nk;
                 if (ns <= 128) {
                     for (int s = lane; s < ns; s += 64) {
                         if (srank[s] < 0) continue;
@@ -471,7 +499,8 @@ k_piluc_df(PilucArgs A)
                     const int x = nx / T;
                     if (atomicAdd(&A.pending[x], -1) - 1 == 0) PU_PUSH(x);
                 }
-                if (lane == 0) atomicAdd(&A.ctrl[4], 1);
+                ++ndone;
+                if (lane == 0 && ((k & 255) == 0 || ne > 2048)) atomicAdd(&A.ctrl[9], 1);      // progress mark
                 PU_SYNC();
                 break;
             }
@@ -577,10 +606,24 @@ k_piluc_df(PilucArgs A)
                 }
                 PU_SYNC();
                 // ---- the stores: row k of U = (k, 1), kept entries; column k of L likewise (:1779-1785, :1951-1958) ----
-                int posU = 0, posL = 0;
-                if (lane == 0) { posU = atomicAdd(&A.ctrl[6], nkz + 1); posL = atomicAdd(&A.ctrl[7], nkw + 1); }
-                posU = __builtin_amdgcn_readfirstlane(posU); posL = __builtin_amdgcn_readfirstlane(posL);
-                if (posU < 0 || (long)posU + nkz + 1 > (long)A.capU || posL < 0 || (long)posL + nkw + 1 > (long)A.capL) PU_FAIL(16);
+                if (uoff + nkz + 1 > uend) {
+                    const int take = nkz + 1 > A.chunk ? nkz + 1 : A.chunk;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&A.ctrl[6], take);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base < 0 || (long)base + take > (long)A.capU) PU_FAIL(16);
+                    uoff = base; uend = base + take;
+                }
+                if (loff + nkw + 1 > lend) {
+                    const int take = nkw + 1 > A.chunk ? nkw + 1 : A.chunk;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&A.ctrl[7], take);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base < 0 || (long)base + take > (long)A.capL) PU_FAIL(16);
+                    loff = base; lend = base + take;
+                }
+                const int posU = uoff, posL = loff;
+                uoff += nkz + 1; loff += nkw + 1;
                 if (lane == 0) {
                     st_agent_i32(&A.Uidx[posU], k); st_agent_f64(&A.Uval[posU], 1.0);
                     st_agent_i32(&A.Lidx[posL], k); st_agent_f64(&A.Lval[posL], 1.0);
@@ -667,16 +710,19 @@ k_piluc_df(PilucArgs A)
                         if (atomicAdd(&A.pending[x], -d) - d == 0) PU_PUSH(x);
                     }
                 }
-                if (lane == 0) atomicAdd(&A.ctrl[4], 1);
+                ++ndone;
+                if (lane == 0 && ((k & 255) == 0 || ne > 2048)) atomicAdd(&A.ctrl[9], 1);      // progress mark
                 PU_SYNC();
             }
         }
         (void)parked;
         PU_RETIRE();
     }
+    if (lane == 0 && ndone) atomicAdd(&A.ctrl[4], ndone);
 #undef PU_FAIL
 #undef PU_SYNC
 #undef PU_RETIRE
+#undef PU_OUT
 #undef PU_PUSH
 }
 
@@ -702,14 +748,14 @@ __global__ void k_piluc_schur_seed(int32_t n, int32_t kterm, int32_t nq, const i
     if (pendS[k] == 0) {
         const int q = k % nq;
         const int qcap = (n + nq - 1) / nq;
-        atomicAdd(&ctrl[5], 1);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ctrl[kCuQBase + 64 * q + 48]), (1ull << 32) + 1ull);
         rq[(size_t)q * qcap + atomicAdd(&ctrl[kCuQBase + 64 * q + 32], 1)] = k;
     }
 }
-__global__ void k_piluc_count_seeds(int32_t m, const int32_t *__restrict__ pending, int32_t *ctrl)
+__global__ void k_piluc_count_seeds(int32_t m, int32_t nq, const int32_t *__restrict__ pending, int32_t *ctrl)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m && pending[j] == 0) atomicAdd(&ctrl[5], 1);
+    if (j < m && pending[j] == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&ctrl[kCuQBase + 64 * (j % nq) + 48]), (1ull << 32) + 1ull);
 }
 
 // ---- the factors as the reference returns them: steps below kterm from the stores, (k, 1) for the others; compress() (:2053-2054,
@@ -849,7 +895,7 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
         ILUPP_HIP(b_gws.alloc((size_t)waves * piluc_ws_bytes(gNE, gNS, gTM)));
     }
     const int nq = waves < kCuQ ? waves : kCuQ;
-    hipLaunchKernelGGL(k_piluc_count_seeds, dim3(gb), dim3(256), 0, st, m, pending, ctrl);
+    hipLaunchKernelGGL(k_piluc_count_seeds, dim3(gb), dim3(256), 0, st, m, nq, pending, ctrl);
     hipLaunchKernelGGL(k_iluc_seed, dim3(gb), dim3(256), 0, st, m, nq, pending, rq, ctrl);
     PilucArgs a;
     a.gws = b_gws.as<unsigned char>(); a.gNE = gNE; a.gNS = gNS; a.gTM = gTM;
@@ -868,6 +914,10 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
     a.schur = 0; a.kterm = big; a.T = T; a.nq = nq;
     a.Uidx = b_Uidx.as<int32_t>(); a.Lidx = b_Lidx.as<int32_t>(); a.Uval = b_Uval.as<double>(); a.Lval = b_Lval.as<double>();
     a.capU = (int32_t)store; a.capL = (int32_t)store;
+    {
+        long c = store / (4L * waves);                      // (the waves' open chunks together: at most a quarter of a store)
+        a.chunk = (int32_t)(c < 16 ? 16 : (c > 4096 ? 4096 : c));
+    }
     a.Ustart = b_Ustart.as<int32_t>(); a.Ulen = b_Ulen.as<int32_t>(); a.Lstart = b_Lstart.as<int32_t>(); a.Llen = b_Llen.as<int32_t>();
     a.Dinv = b_dinv.as<double>();
     a.Sidx = nullptr; a.Sval = nullptr; a.capS = 0; a.Sstart = nullptr; a.Slen = nullptr;
@@ -984,6 +1034,7 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
     {
         const long avg = Av.nnz / Av.n + 1;
         cls = avg * avg <= 64 ? 0 : (avg * avg <= 256 ? 1 : 2);
+        if (const char *e = getenv("ILUPP_PILUC_CLASS")) cls = atoi(e) < 0 ? 0 : (atoi(e) > 4 ? 4 : atoi(e));     // (experiments)
     }
     int rc = 1;
     int gns = 2048;
