@@ -5,12 +5,14 @@
 //
 // Where things run.  The matrix of every level stays in HBM from the input to the last Schur complement: normalisation (column and
 // row 2-norms, summed in the reference's storage order), scaling, the application of the permutations, the factorisation, the Schur
-// complement.  The ORDER decisions of the PQ preprocessing are taken on the host: the candidate weights and columns are computed on
-// the device (one sequential sum per row), then n weights go to the host, where the reference's own unstable quicksort
-// (sparse_implementation.h:471-505 -- the order of equal weights is part of the result) and the greedy selection (:4611-4634), both
-// sequential by definition, produce the two permutations, which go back as 2 n integers.
+// complement.  PQ ordering: the candidate weights and columns are computed on the device (one sequential sum per row) and sorted there
+// when all weights are distinct (the order is then unique); with equal weights the order among them is what the reference's own unstable
+// quicksort (sparse_implementation.h:471-505) leaves, and that algorithm runs on the host on n weights.  The greedy selection
+// (:4611-4634) is sequential by definition: it walks the sorted candidates on the host and the two permutations go back as 2 n
+// integers.  The matching (MAX_WEIGHTED_MATCHING_ORDERING) and the move-to-corner ordering are sequential algorithms too (ml_order.hip).
 #include <stdlib.h>
 
+#include <chrono>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
@@ -131,13 +133,21 @@ static void ref_quicksort(double *data, int32_t *list, long left, long right)
     }
 }
 
-// the greedy selection (:4608-4634): ip (rows) and iq (columns) are the INVERSE permutations; returns the size of the leading block
-static int32_t pq_select(int32_t n, std::vector<double> &W, const std::vector<int32_t> &J, double tau, std::vector<int32_t> &ip, std::vector<int32_t> &iq)
+// are two neighbours of the sorted weights equal (or is one a NaN)?  Then the order the reference's quicksort leaves them in is its own
+__global__ void k_ml_sorted_ties(int32_t n, const double *__restrict__ w, int32_t *flag)
 {
-    std::vector<int32_t> I((size_t)n);
-    for (int32_t k = 0; k < n; ++k) I[(size_t)k] = k;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = w[i];
+    if (a != a || (i + 1 < n && !(a < w[i + 1]))) *flag = 1;
+}
+
+// the greedy selection (:4608-4634) over the candidates in sorted order (W ascending, I = their rows): ip (rows) and iq (columns) are the
+// INVERSE permutations; returns the size of the leading block
+static int32_t pq_select(int32_t n, const std::vector<double> &W, const std::vector<int32_t> &I, const std::vector<int32_t> &J, double tau,
+                         std::vector<int32_t> &ip, std::vector<int32_t> &iq)
+{
     ip.assign((size_t)n, -1); iq.assign((size_t)n, -1);
-    if (n > 0) ref_quicksort(W.data(), I.data(), 0, (long)n - 1);
     int32_t count = -1;
     for (int32_t k = 0; k < n; ++k) {
         const int32_t r = I[(size_t)k], c = J[(size_t)r];
@@ -241,7 +251,13 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
     PoolBlock b_D, b_inv;
     ILUPP_HIP(b_D.alloc(sizeof(double) * (size_t)n));
     ILUPP_HIP(b_inv.alloc(sizeof(int32_t) * (size_t)n));
+    const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
     for (int s = 0; s < IP.n_pre; ++s) {
+        struct StepTimer {
+            bool on; int step; std::chrono::steady_clock::time_point t0; hipStream_t st;
+            ~StepTimer() { if (on) { (void)hipStreamSynchronize(st); fprintf(stderr, "[ilupp] ml: preprocessing step %d: %.2f ms\n", step,
+                                                                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } }
+        } timer{dbg, IP.pre[s], std::chrono::steady_clock::now(), st};
         switch (IP.pre[s]) {
         case ML_PRE_NORMALIZE_COLUMNS: {                                       // :5241-5246
             DevMat T;
@@ -269,12 +285,41 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             ILUPP_HIP(b_J.alloc(sizeof(int32_t) * (size_t)n));
             hipLaunchKernelGGL(k_ml_pq_candidates, dim3(gb), dim3(256), 0, st, n, A->ptr, A->idx, A->val, b_D.as<double>(), b_J.as<int32_t>());
             std::vector<double> W((size_t)n);
-            std::vector<int32_t> J((size_t)n), ip1, ip2, p1((size_t)n), p2((size_t)n);
-            ILUPP_HIP(hipMemcpyAsync(W.data(), b_D.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-            ILUPP_HIP(hipMemcpyAsync(J.data(), b_J.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-            ILUPP_HIP(hipStreamSynchronize(st));
-            if (pq_ip1.empty()) { (void)pq_select(n, W, J, IP.pq_threshold, ip1, ip2); pq_ip1 = ip1; pq_ip2 = ip2; }
-            else { ip1 = pq_ip1; ip2 = pq_ip2; }
+            std::vector<int32_t> J((size_t)n), I((size_t)n), ip1, ip2, p1((size_t)n), p2((size_t)n);
+            if (pq_ip1.empty()) {
+                // The candidates by increasing weight.  With all weights distinct the order is unique: a radix sort on the device, and only the
+                // sorted rows travel.  With equal weights (every interior row of a stencil matrix has the same) the order among them is whatever the
+                // reference's unstable quicksort (sparse_implementation.h:471-505) leaves -- then that algorithm runs, on the host.
+                PoolBlock b_W2, b_I, b_I2, b_flag, b_tmp;
+                ILUPP_HIP(b_W2.alloc(sizeof(double) * (size_t)n));
+                ILUPP_HIP(b_I.alloc(sizeof(int32_t) * (size_t)n));
+                ILUPP_HIP(b_I2.alloc(sizeof(int32_t) * (size_t)n));
+                ILUPP_HIP(b_flag.alloc(64));
+                ILUPP_HIP(hipMemsetAsync(b_flag.p, 0, 64, st));
+                iota_i32(st, b_I.as<int32_t>(), n);
+                size_t tb = 0;
+                ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b_D.as<double>(), b_W2.as<double>(), b_I.as<int32_t>(), b_I2.as<int32_t>(), n, 0, 64, st));
+                ILUPP_HIP(b_tmp.alloc(tb > 0 ? tb : 1));
+                ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_D.as<double>(), b_W2.as<double>(), b_I.as<int32_t>(), b_I2.as<int32_t>(), n, 0, 64, st));
+                hipLaunchKernelGGL(k_ml_sorted_ties, dim3(gb), dim3(256), 0, st, n, b_W2.as<double>(), b_flag.as<int32_t>());
+                int32_t ties = 0;
+                ILUPP_HIP(hipMemcpyAsync(&ties, b_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                ILUPP_HIP(hipMemcpyAsync(J.data(), b_J.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+                ILUPP_HIP(hipStreamSynchronize(st));
+                if (!ties) {
+                    ILUPP_HIP(hipMemcpyAsync(W.data(), b_W2.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+                    ILUPP_HIP(hipMemcpyAsync(I.data(), b_I2.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+                    ILUPP_HIP(hipStreamSynchronize(st));
+                } else {
+                    ILUPP_HIP(hipMemcpyAsync(W.data(), b_D.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+                    ILUPP_HIP(hipStreamSynchronize(st));
+                    for (int32_t k = 0; k < n; ++k) I[(size_t)k] = k;
+                    if (n > 0) ref_quicksort(W.data(), I.data(), 0, (long)n - 1);
+                }
+                if (dbg) fprintf(stderr, "[ilupp] ml: PQ candidates sorted %s\n", ties ? "on the host (equal weights)" : "on the device");
+                (void)pq_select(n, W, I, J, IP.pq_threshold, ip1, ip2);
+                pq_ip1 = ip1; pq_ip2 = ip2;
+            } else { ip1 = pq_ip1; ip2 = pq_ip2; }
             p1_filled = true;
             for (int32_t i = 0; i < n; ++i) { p1[(size_t)ip1[(size_t)i]] = i; p2[(size_t)ip2[(size_t)i]] = i; }
             ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
@@ -455,7 +500,10 @@ int ml_build(hipStream_t st, const DevMat &A, const MlParams &IP, std::vector<Ml
         if (!in_loop && IP.use_final_threshold) tau *= IP.final_threshold;     // :1580-1581
         DevMat Anext;
         int32_t kterm = m;
+        const auto tl0 = std::chrono::steady_clock::now();
         const int rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ml: level %d (n %d): factorisation %.2f ms\n", nlev, m,
+                                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
         if (rc) { Anext.release(); return rc; }
         ++nlev;
         Ak.release();
