@@ -126,6 +126,27 @@ def batch_matrix(g, member):
     return d, i, p
 
 
+def ml_batch_member(dev, member, n=1000000):
+    """matrix `member` of the C5 batch (unsymmetric random CSR, seed 12345 + member) through the multilevel preconditioner
+    (default_configuration(1), threshold 1e-3) + one apply: (member, levels, total_nnz, sha256 of apply(ones), ms)"""
+    import torch
+    import matgen
+    import ilupp_amd as ilupp
+    from ilupp_amd import _native
+    prm = ilupp.iluplusplus_precond_parameter()
+    prm.default_configuration(1)
+    prm.threshold = 1e-3
+    dm, im, pm = matgen.random_dd(n, 8, 25.0, 12345 + member)
+    a = [torch.from_numpy(v).to(dev) for v in (dm, im, pm)]
+    xb = torch.ones(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Pm = _native.MultilevelILUCDPPreconditioner_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), n, True, prm)
+    Pm.apply_device(xb.data_ptr(), n, transpose=False, sync=True)
+    ms = 1e3 * (time.perf_counter() - t0)
+    return (member, int(Pm.levels()), int(Pm.total_nnz), hashlib.sha256(xb.cpu().numpy().tobytes()).hexdigest(), ms)
+
+
 def extra_config(name, dev, steps):
     """C3 / C4 on device-resident inputs: seconds, factor bytes (read A + write the factors produced), GB/s"""
     import torch
@@ -240,8 +261,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # BENCH_SHARE_GPU=1 (tests only): all ranks on GPU 0 with the gloo backend -- the N > 1 code path of this file on a one-GPU box
+        # (RCCL refuses two ranks on one device); the measured path is one rank per GPU over RCCL
+        share = os.environ.get("BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if share else "nccl")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -375,23 +401,8 @@ def main():
     # (default_configuration(1), threshold 1e-3: the family without pivoting) + one apply each, sharded over the ranks
     batch_ml = None
     if world > 1:
-        import matgen
-        import ilupp_amd as ilupp
-        prm = ilupp.iluplusplus_precond_parameter()
-        prm.default_configuration(1)
-        prm.threshold = 1e-3
-        nml = 1000000
-
         def work_ml(member):
-            dm, im, pm = matgen.random_dd(nml, 8, 25.0, 12345 + member)
-            a = [torch.from_numpy(v).to(dev) for v in (dm, im, pm)]
-            xb = torch.ones(nml, dtype=torch.float64, device=dev)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            Pm = _native.MultilevelILUCDPPreconditioner_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), nml, True, prm)
-            Pm.apply_device(xb.data_ptr(), nml, transpose=False, sync=True)
-            ms = 1e3 * (time.perf_counter() - t0)
-            return (member, int(Pm.levels()), int(Pm.total_nnz), hashlib.sha256(xb.cpu().numpy().tobytes()).hexdigest(), ms)
+            return ml_batch_member(dev, member)
         barrier()
         b0 = time.perf_counter()
         recs = run_batch(world, work_ml)

@@ -248,3 +248,23 @@ def test_fuzz_against_oracle():
             _against_oracle(A, params)
         except AssertionError as e:
             raise AssertionError("fuzz case %d: %s" % (seed, e))
+
+
+def test_bench_batch_member():
+    """the unit of bench.py's multi-GPU C5 batch (`batch_ml`: one matrix per rank through ilupp_amd.batched.run_batch) on one GPU: the record
+    is reproducible (what the bench asserts between the sharded and the single-rank run) and agrees with the oracle"""
+    import sys
+    import torch
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from ilupp_amd.batched import run_batch
+    dev = torch.device("cuda", 0)
+    recs = run_batch(2, lambda m: bench.ml_batch_member(dev, m, n=200000))
+    again = [bench.ml_batch_member(dev, m, n=200000) for m in range(2)]
+    assert [r[:4] for r in recs] == [r[:4] for r in again] and recs[0][3] != recs[1][3]
+    d, i, p = matgen.random_dd(200000, 8, 25.0, 12345)
+    Q = O.orc().ml((d, i, p, True), O.ml_params(1e-3))
+    import hashlib
+    assert recs[0][1] == Q.levels() and recs[0][2] == Q.total_nnz()
+    assert recs[0][3] == hashlib.sha256(Q.apply(np.ones(200000)).tobytes()).hexdigest()

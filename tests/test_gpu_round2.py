@@ -404,6 +404,23 @@ def test_batched_two_gpus():
     assert r.returncode == 0 and "batch ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 code path where only one GPU is visible: two ranks share GPU 0 over gloo (BENCH_SHARE_GPU=1; the measured runs use
+    one rank per GPU over RCCL): both batches -- ILU(0) on shifted meshes, the multilevel preconditioner on n = 10^6 matrices -- gathered
+    through run_batch and byte-identical to rank 0's own single-rank run, one JSON line with the whole-job value"""
+    import json
+    e = dict(os.environ, BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "48", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(line) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(line[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["batch"]["identical_to_single_rank"] and len(out["batch"]["records"]) == 2
+    assert out["batch_ml"]["identical_to_single_rank"] and [x["matrix"] for x in out["batch_ml"]["records"]] == [0, 1]
+    assert out["batch_ml"]["records"][0]["sha256_apply"] != out["batch_ml"]["records"][1]["sha256_apply"]
+
+
 def test_bench_single_gpu_line():
     """bench.py's contract on a small grid: one JSON line with roofline, cpu_baseline and an ARRAY parity verdict"""
     import json
