@@ -139,7 +139,7 @@ class ILUppPreconditioner(_HipPreconditioner):
             params.threshold = threshold
             if fill_in is not None:
                 params.fill_in = fill_in
-        super().__init__(A, lambda m: _native.MultilevelILUCDPPreconditioner(*m, params))
+        super().__init__(A, lambda m: _backend.MultilevelILUCDPPreconditioner(*m, params))
 
     @property
     def memory(self):

@@ -516,6 +516,18 @@ for fmt in ("csr", "csc"):
     Lc, = C.factors()
     assert G.mat_equal((Lc.data, Lc.indices, Lc.indptr, False), O.orc().icholt(M, 2, 1e-3))
     assert G.mat_equal(tuple(getattr(ilupp.ichol0(A), k) for k in ("data", "indices", "indptr")) + (True,), O.orc().ichol0(M))
+    # the multilevel class of the shim (binding.cpp:284-298)
+    prm = ilupp.iluplusplus_precond_parameter(); prm.default_configuration(1); prm.threshold = 0.02
+    ML = ilupp.ILUppPreconditioner(A, params=prm)
+    assert type(ML.pr).__module__.endswith("_ilupp_hip") and ML.factors() == []
+    Qm = O.orc().ml(M, O.ml_params(0.02))
+    assert ML.total_nnz == Qm.total_nnz() and ML.pr.levels() == Qm.levels()
+    assert np.array_equal(ML @ b, Qm.apply(b)) and np.array_equal(ML.T @ b, Qm.apply(b, O.TRANSPOSE))
+    try:
+        ilupp.ILUppPreconditioner(A)
+        raise SystemExit("the pivoting family was not refused")
+    except NotImplementedError:
+        pass
     x, info = spla.gmres(A, b, M=P, atol=1e-10)
     assert info == 0
 try:
