@@ -1033,7 +1033,9 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
     int cls = 0;
     {
         const long avg = Av.nnz / Av.n + 1;
-        cls = avg * avg <= 64 ? 0 : (avg * avg <= 256 ? 1 : 2);
+        // the kernel's time goes like 1 / (resident waves) -- a step is a few dozen dependent memory round trips -- and the smallest class has
+        // the most waves (C5: 9 / 19 / 38 ms in classes 0 / 1 / 2); an attempt in a class that turns out too small costs at most its own short run
+        cls = avg <= 16 ? 0 : (avg <= 40 ? 1 : 2);
         if (const char *e = getenv("ILUPP_PILUC_CLASS")) cls = atoi(e) < 0 ? 0 : (atoi(e) > 4 ? 4 : atoi(e));     // (experiments)
     }
     int rc = 1;
