@@ -30,7 +30,11 @@ class MLParams(ctypes.Structure):
                 ("pq_threshold", ctypes.c_double), ("max_levels", ctypes.c_int32), ("min_ml_size", ctypes.c_int32),
                 ("small_pivot_terminates", ctypes.c_int32), ("min_pivot", ctypes.c_double), ("min_elim_factor", ctypes.c_double),
                 ("threshold_shift_schur", ctypes.c_double), ("vary_threshold_factor", ctypes.c_double),
-                ("use_final_threshold", ctypes.c_int32), ("final_threshold", ctypes.c_double), ("max_fill_in", ctypes.c_int32)]
+                ("use_final_threshold", ctypes.c_int32), ("final_threshold", ctypes.c_double), ("max_fill_in", ctypes.c_int32),
+                ("drop_rules", ctypes.c_int32), ("weight_standard_drop", ctypes.c_double), ("weight_standard_drop2", ctypes.c_double),
+                ("weight_err_prop_drop", ctypes.c_double), ("weight_err_prop_drop2", ctypes.c_double), ("weight_pivot_drop", ctypes.c_double),
+                ("combine_factor", ctypes.c_int32), ("neutral_element", ctypes.c_double), ("min_weight", ctypes.c_double),
+                ("scale_weight_invdiag", ctypes.c_int32)]
 
 
 _lib = None

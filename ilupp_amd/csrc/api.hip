@@ -1398,6 +1398,11 @@ int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
     P.pil.threshold_shift_schur = ip->threshold_shift_schur; P.vary_threshold_factor = ip->vary_threshold_factor;
     P.use_final_threshold = ip->use_final_threshold != 0; P.final_threshold = ip->final_threshold;
     P.pil.max_fill_in = ip->max_fill_in > 0 ? ip->max_fill_in : 0;
+    P.pil.rules = ip->drop_rules; P.pil.combine = ip->combine_factor; P.pil.scale_invdiag = ip->scale_weight_invdiag != 0;
+    P.pil.wgt[0] = ip->weight_standard_drop; P.pil.wgt[1] = ip->weight_standard_drop2; P.pil.wgt[2] = ip->weight_err_prop_drop;
+    P.pil.wgt[3] = ip->weight_err_prop_drop2; P.pil.wgt[4] = ip->weight_pivot_drop;
+    P.pil.neutral = ip->neutral_element; P.pil.min_weight = ip->min_weight;
+    if ((P.pil.rules & ~31) != 0) { set_error("ILU++: unknown dropping rule"); return ILUPP_ERR_INVALID; }
     struct MlGuard { ilupp_ml *m; ~MlGuard() { if (m) ml_destroy(m); } } g{new ilupp_ml()};
     ilupp_ml *m = g.m;
     m->n = A.n;
@@ -1455,6 +1460,9 @@ void ilupp_hip_ml_default_params(ilupp_ml_params *p)
     p->small_pivot_terminates = 1; p->min_pivot = 1e-2; p->min_elim_factor = 0.0; p->threshold_shift_schur = 0.0;
     p->vary_threshold_factor = 1.0; p->use_final_threshold = 0; p->final_threshold = 0.0;
     p->max_fill_in = 0;
+    p->drop_rules = ILUPP_DROP_ERR_PROP;
+    p->weight_standard_drop = p->weight_standard_drop2 = p->weight_err_prop_drop = p->weight_err_prop_drop2 = p->weight_pivot_drop = 1.0;
+    p->combine_factor = 0; p->neutral_element = 0.0; p->min_weight = 1.0; p->scale_weight_invdiag = 0;
 }
 
 int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const ilupp_ml_params *params,

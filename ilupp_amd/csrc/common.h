@@ -324,7 +324,13 @@ struct PilucParams {
     double min_elim_factor = 0.0;         // MIN_ELIM_FACTOR
     double threshold_shift_schur = 0.0;   // THRESHOLD_SHIFT_SCHUR
     int32_t max_fill_in = 0;              // 0: MAX_FILLIN_IS_INF; else fill_in
+    int32_t rules = 4;                    // PILUC_DROP_*: which rules make up the weight of a row (default: error propagation)
+    int32_t combine = 0;                  // COMBINE_FACTOR
+    bool scale_invdiag = false;           // SCALE_WEIGHT_INVDIAG
+    double wgt[5] = {1.0, 1.0, 1.0, 1.0, 1.0};   // WEIGHT_STANDARD_DROP, _DROP2, WEIGHT_ERR_PROP_DROP, _DROP2, WEIGHT_PIVOT_DROP
+    double neutral = 0.0, min_weight = 1.0;      // NEUTRAL_ELEMENT, MIN_WEIGHT
 };
+enum { PILUC_DROP_STANDARD = 1, PILUC_DROP_STANDARD2 = 2, PILUC_DROP_ERR_PROP = 4, PILUC_DROP_ERR_PROP2 = 8, PILUC_DROP_PIVOT = 16 };   // = ILUPP_DROP_*
 int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv, DevMat *Anew,
                 int32_t *kterm, float *kernel_ms);
 

@@ -61,6 +61,9 @@ struct PilucArgs {
     double tau;                               // dropping threshold of this launch
     double min_pivot;
     int32_t park_from;                        // steps k > park_from may end the level (0x7fffffff: none may)
+    int32_t rules, combine, scale_invdiag;    // the dropping rules that make up a row's weight (PILUC_DROP_*), COMBINE_FACTOR, SCALE_WEIGHT_INVDIAG
+    double wgt[5];                            // WEIGHT_STANDARD_DROP, _DROP2, WEIGHT_ERR_PROP_DROP, _DROP2, WEIGHT_PIVOT_DROP
+    double neutral, min_weight;               // NEUTRAL_ELEMENT, MIN_WEIGHT
     int32_t budget;                           // entries a row of U / a column of L may keep besides the 1 (max_fill_in - 1); Schur mode: entries of a row (max_fill_in)
     int32_t schur, kterm;                     // Schur mode: rows kterm.. of the Schur complement
     int32_t T, nq;
@@ -130,6 +133,28 @@ __device__ void select_largest(double *data, int *list, int left, int right, int
         if (j <= k) left = i;
     }
 #undef PSW
+}
+
+// the weight of a row of U / a column of L (ILUCDP.hpp:1719-1728, :1896-1906; combine(): parameters_implementation.h:526-534 with std::max):
+// n2own = 2-norm of the vector that is dropped, n1other = 1-norm of the other factor's vector, dinv = Dinv[k] of that moment
+__device__ __forceinline__ double piluc_weight(const PilucArgs &A, double n2own, double n1other, double dinv)
+{
+    double w = A.neutral;
+    auto comb = [&](double x, double y) {
+        switch (A.combine) {
+        case 1: return x + y;
+        case 2: return x * y;
+        case 3: { const double m = x < y ? y : x; return A.min_weight < m ? m : A.min_weight; }
+        default: return x < y ? y : x;
+        }
+    };
+    if (A.rules & PILUC_DROP_STANDARD) { const double norm = n2own == 0.0 ? 1e-16 : n2own; w = comb(w, A.wgt[0] / norm); }
+    if (A.rules & PILUC_DROP_STANDARD2) w = comb(w, A.wgt[1]);
+    if (A.rules & PILUC_DROP_ERR_PROP) w = comb(w, A.wgt[2] * n1other);
+    if (A.rules & PILUC_DROP_ERR_PROP2) w = comb(w, A.wgt[3] * n1other / fabs(dinv));
+    if (A.rules & PILUC_DROP_PIVOT) w = comb(w, A.wgt[4] * fabs(dinv));
+    if (A.scale_invdiag) w = w * fabs(dinv);
+    return w;
 }
 
 // first position p in [lo, hi] (1-based list `slots`, keys key[slots[p]]) whose key is >= v; hi + 1 if none
@@ -536,10 +561,17 @@ k_piluc_df(PilucArgs A)
                 // ================= both working vectors are known: norms, dropping, the stores, touch records, counters =================
                 for (int s = lane; s < ns; s += 64) sval[s] = sval[s] * dinv;                               // w.scale(Dinv[k]), :1676
                 PU_SYNC();
-                double n1w = 0.0, n1z = 0.0;                                                                   // vector_sparse_dynamic::norm1, in slot order
-                for (int s = 0; s < ns; ++s) n1w = n1w + fabs(sval[s]);
-                for (int s = 0; s < nzs; ++s) n1z = n1z + fabs(zval[s]);
-                const double weightU = 0.0 < n1w ? n1w : 0.0, weightL = 0.0 < n1z ? n1z : 0.0;               // combine(): std::max(NEUTRAL_ELEMENT, .)
+                double n1w = 0.0, n1z = 0.0, n2w = 0.0, n2z = 0.0;                                             // vector_sparse_dynamic::norm1 / norm2, in slot order
+                if (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) {
+                    for (int s = 0; s < ns; ++s) n1w = n1w + fabs(sval[s]);
+                    for (int s = 0; s < nzs; ++s) n1z = n1z + fabs(zval[s]);
+                }
+                if (A.rules & PILUC_DROP_STANDARD) {
+                    for (int s = 0; s < ns; ++s) { const double sq = sval[s] * sval[s]; n2w = n2w + sq; }
+                    for (int s = 0; s < nzs; ++s) { const double sq = zval[s] * zval[s]; n2z = n2z + sq; }
+                    n2w = sqrt(n2w); n2z = sqrt(n2z);
+                }
+                const double weightU = piluc_weight(A, n2z, n1w, dinv), weightL = piluc_weight(A, n2w, n1z, dinv_store);
                 // kept slots (index in [k+1, n), weight * |v| >= tau), by increasing index
                 for (int s = lane; s < nzs; s += 64) { const double pr = weightU * fabs(zval[s]); zcnt[s] = (zcnt[s] & 0x3fffffff) | ((zcol[s] > k && pr >= A.tau) ? 0x40000000 : 0); }
                 for (int s = lane; s < ns; s += 64) { const double pr = weightL * fabs(sval[s]); srank[s] = (srow[s] > k && pr >= A.tau) ? 0 : -1; }
@@ -907,6 +939,9 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
         const double x = P.min_elim_factor * (double)m;
         a.park_from = x < 0.0 ? -1 : (x >= 2147483647.0 ? big : (int32_t)x);
     }
+    a.rules = P.rules; a.combine = P.combine; a.scale_invdiag = P.scale_invdiag ? 1 : 0;
+    for (int q = 0; q < 5; ++q) a.wgt[q] = P.wgt[q];
+    a.neutral = P.neutral; a.min_weight = P.min_weight;
     int32_t max_fill = P.max_fill_in > 0 ? P.max_fill_in : m;             // ILUCDP.hpp:1440-1447: MAX_FILLIN_IS_INF => n; clamped to [1, n]
     if (max_fill < 1) max_fill = 1;
     if (max_fill > m) max_fill = m;

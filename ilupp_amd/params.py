@@ -189,13 +189,16 @@ class iluplusplus_precond_parameter:
         if not self._uses_partial_iluc():
             refuse("the pivoting factorisation partialILUCDP that these parameters select (the default-constructed "
                    "parameters do: PERMUTE_ROWS %d, TOTAL_PIV %d, piv_tol %g)" % (self.PERMUTE_ROWS, self.TOTAL_PIV, self.piv_tol))
-        others = [k for k in ("USE_STANDARD_DROPPING", "USE_STANDARD_DROPPING2", "USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING",
-                              "USE_WEIGHTED_DROPPING2", "USE_ERR_PROP_DROPPING2", "USE_PIVOT_DROPPING") if getattr(self, k)]
-        if others or not self.USE_ERR_PROP_DROPPING:
-            refuse("dropping by " + (", ".join(others) or "no rule"))
+        seq_rules = [k for k in ("USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2") if getattr(self, k)]
+        if seq_rules:
+            refuse("dropping by " + ", ".join(seq_rules) + " (these rules accumulate estimates over the steps in their sequential order)")
+        rules = 0
+        for bit, k in ((1, "USE_STANDARD_DROPPING"), (2, "USE_STANDARD_DROPPING2"), (4, "USE_ERR_PROP_DROPPING"), (8, "USE_ERR_PROP_DROPPING2"),
+                       (16, "USE_PIVOT_DROPPING")):
+            if getattr(self, k):
+                rules |= bit
         checks = [("DROP_TYPE_L", 0), ("DROP_TYPE_U", 0), ("SCHUR_COMPLEMENT", 0), ("EXTERNAL_FINAL_ROW", False),
                   ("REQUIRE_ZERO_SCHUR", False), ("USE_THRES_ZERO_SCHUR", False), ("WEIGHTED_DROPPING", True), ("SUM_DROPPING", False),
-                  ("COMBINE_FACTOR", 0), ("NEUTRAL_ELEMENT", 0.0), ("WEIGHT_ERR_PROP_DROP", 1.0), ("SCALE_WEIGHT_INVDIAG", False),
                   ("SCALE_WGT_MAXINVDIAG", False), ("USE_POS_COMPRESS", False)]
         for name, want in checks:
             if getattr(self, name) != want:
@@ -227,4 +230,11 @@ class iluplusplus_precond_parameter:
         p.use_final_threshold = 1 if self.USE_FINAL_THRESHOLD else 0
         p.final_threshold = float(self.FINAL_THRESHOLD)
         p.max_fill_in = 0 if self.MAX_FILLIN_IS_INF else max(1, int(self.fill_in))      # partialILUC :1440-1447 (clamped to the level's size there)
+        p.drop_rules = rules
+        p.weight_standard_drop, p.weight_standard_drop2 = float(self.WEIGHT_STANDARD_DROP), float(self.WEIGHT_STANDARD_DROP2)
+        p.weight_err_prop_drop, p.weight_err_prop_drop2 = float(self.WEIGHT_ERR_PROP_DROP), float(self.WEIGHT_ERR_PROP_DROP2)
+        p.weight_pivot_drop = float(self.WEIGHT_PIVOT_DROP)
+        p.combine_factor = int(self.COMBINE_FACTOR) if int(self.COMBINE_FACTOR) in (0, 1, 2, 3) else 0       # combine(): default branch = max
+        p.neutral_element, p.min_weight = float(self.NEUTRAL_ELEMENT), float(self.MIN_WEIGHT)
+        p.scale_weight_invdiag = 1 if self.SCALE_WEIGHT_INVDIAG else 0
         return p

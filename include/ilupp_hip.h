@@ -158,7 +158,8 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
  *      apply :433-488, total_nnz preconditioner.h:312.
  * Built: the family WITHOUT pivoting (use_ILUC, :1385-1390: PERMUTE_ROWS 0, TOTAL_PIV 0, piv_tol 0 -- precon_parameter 10 of
  * parameters_implementation.h:927-934, e.g. default_configuration(1)) over matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) with
- * error-propagation dropping, unbounded or bounded fill (presets 10 and 1010), levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
+ * dropping by the combined weight of the standard / error-propagation / pivot rules (presets 10, 13, 1010, 1013; the inverse-based and
+ * weighted rules accumulate over the steps in their sequential order and are not built), unbounded or bounded fill, levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
  * PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING, DD_SYMM_MOVE_CORNER_ORDERING_IM
  * (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter combination -- the pivoting factorisation partialILUCDP of
  * the default-constructed parameters among them -- is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
@@ -175,6 +176,8 @@ enum {                               /* preprocessing_type values (orderings.h) 
     ILUPP_PRE_SPARSE_FIRST_ORDERING = 7
 };
 
+enum { ILUPP_DROP_STANDARD = 1, ILUPP_DROP_STANDARD2 = 2, ILUPP_DROP_ERR_PROP = 4, ILUPP_DROP_ERR_PROP2 = 8, ILUPP_DROP_PIVOT = 16 };
+
 typedef struct {                     /* the fields of iluplusplus_precond_parameter (parameters.h:120-235) the built family reads */
     double threshold;                /* threshold */
     int32_t n_preprocessing;         /* PREPROCESSING: number of steps, */
@@ -190,6 +193,11 @@ typedef struct {                     /* the fields of iluplusplus_precond_parame
     int32_t use_final_threshold;     /* USE_FINAL_THRESHOLD */
     double final_threshold;          /* FINAL_THRESHOLD */
     int32_t max_fill_in;             /* 0: MAX_FILLIN_IS_INF; else fill_in (entries a row of U / a column of L may have, the 1 included) */
+    int32_t drop_rules;              /* ILUPP_DROP_*: USE_STANDARD_DROPPING, _DROPPING2, USE_ERR_PROP_DROPPING, _DROPPING2, USE_PIVOT_DROPPING */
+    double weight_standard_drop, weight_standard_drop2, weight_err_prop_drop, weight_err_prop_drop2, weight_pivot_drop;   /* WEIGHT_* */
+    int32_t combine_factor;          /* COMBINE_FACTOR */
+    double neutral_element, min_weight;   /* NEUTRAL_ELEMENT, MIN_WEIGHT */
+    int32_t scale_weight_invdiag;    /* SCALE_WEIGHT_INVDIAG */
 } ilupp_ml_params;
 
 /* default_configuration(1) (parameters_implementation.h:546-549: set_PQ + precon_parameter 10) with threshold 0 */

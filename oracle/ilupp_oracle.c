@@ -1590,6 +1590,39 @@ static double wv_norm1(const wvec *v)                                         /*
     return z;
 }
 
+static double wv_norm2(const wvec *v)                                         /* :1080-1085 */
+{
+    double z = 0.0;
+    orc_int i;
+    for (i = 0; i < v->nnz; ++i) z += v->data[i] * v->data[i];
+    return sqrt(z);
+}
+
+/* iluplusplus_precond_parameter::combine, parameters_implementation.h:526-534 (max is std::max) */
+static double ml_combine(const orc_ml_params *IP, double x, double y)
+{
+    switch (IP->combine_factor) {
+    case 1: return x + y;
+    case 2: return x * y;
+    case 3: { const double m = x < y ? y : x; return IP->min_weight < m ? m : IP->min_weight; }
+    default: return x < y ? y : x;
+    }
+}
+
+/* the weight of a row of U (or column of L) for take_single_weight, ILUCDP.hpp:1719-1728 / :1896-1906: `own` is the vector that is dropped,
+ * `other` the one of the other factor, dinv the Dinv[k] of that moment */
+static double ml_weight(const orc_ml_params *IP, const wvec *own, const wvec *other, double dinv)
+{
+    double w = IP->neutral_element;
+    if (IP->drop_rules & ORC_DROP_STANDARD) { double norm = wv_norm2(own); if (norm == 0.0) norm = 1e-16; w = ml_combine(IP, w, IP->weight_standard_drop / norm); }
+    if (IP->drop_rules & ORC_DROP_STANDARD2) w = ml_combine(IP, w, IP->weight_standard_drop2);
+    if (IP->drop_rules & ORC_DROP_ERR_PROP) w = ml_combine(IP, w, IP->weight_err_prop_drop * wv_norm1(other));
+    if (IP->drop_rules & ORC_DROP_ERR_PROP2) w = ml_combine(IP, w, IP->weight_err_prop_drop2 * wv_norm1(other) / fabs(dinv));
+    if (IP->drop_rules & ORC_DROP_PIVOT) w = ml_combine(IP, w, IP->weight_pivot_drop * fabs(dinv));
+    if (IP->scale_weight_invdiag) w *= fabs(dinv);
+    return w;
+}
+
 /* matrix_sparse::partialILUC, ILUCDP.hpp:1405-2231, for the precon_parameter 10 family: err-prop dropping (weight of a row of U = the
  * 1-norm of the scaled column of L and vice versa), DROP_TYPE 0, no improved Schur complement, unbounded fill, the level ends at
  * the first pivot smaller than MIN_PIVOT.  L: COLUMN, U: ROW (both with the 1 first), Dinv, Anew: the Schur complement (ROW). */
@@ -1668,8 +1701,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         if (!eliminate) {
             nU = take_largest(&z, list_U, max_fill_in, threshold, last_row_to_eliminate + 1, n);
         } else {
-            const double e = 1.0 * wv_norm1(&w);                              /* WEIGHT_ERR_PROP_DROP * w.norm1() */
-            weightU = 0.0 < e ? e : 0.0;                                       /* combine: std::max(NEUTRAL_ELEMENT, .) */
+            weightU = ml_weight(IP, &z, &w, Dinv[k]);
             nU = take_single_weight(&z, list_U, weightU, max_fill_in - 1, threshold, k + 1, n);
         }
         /* update U or Anew, :1769-1850 */
@@ -1690,8 +1722,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         }
         /* (12.) L, :1855-1975 */
         if (eliminate) {
-            const double e = 1.0 * wv_norm1(&z);
-            weightL = 0.0 < e ? e : 0.0;
+            weightL = ml_weight(IP, &w, &z, Dinv[k]);                          /* (Dinv[k] after the zero-pivot reset of :1786-1792) */
             nL = take_single_weight(&w, list_L, weightL, max_fill_in - 1, threshold, k + 1, n);
             mat_reserve(L, L->ptr[k] + nL + 1, &capL);
             L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = k;
@@ -1759,6 +1790,12 @@ void orc_ml_default_params(orc_ml_params *p)       /* default_parameters (:430-5
     p->use_final_threshold = 0;
     p->final_threshold = 0.0;
     p->max_fill_in = 0;
+    p->drop_rules = ORC_DROP_ERR_PROP;
+    p->weight_standard_drop = p->weight_standard_drop2 = p->weight_err_prop_drop = p->weight_err_prop_drop2 = p->weight_pivot_drop = 1.0;
+    p->combine_factor = 0;
+    p->neutral_element = 0.0;
+    p->min_weight = 1.0;
+    p->scale_weight_invdiag = 0;
 }
 
 /* make_preprocessed_multilevelILUCDP, preconditioner_implementation.h:1350-1665, use_ILUC branch */

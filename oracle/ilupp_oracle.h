@@ -100,6 +100,8 @@ enum {                                   /* steps of a preprocessing_sequence (o
     ORC_PRE_SPARSE_FIRST_ORDERING = 7
 };
 
+enum { ORC_DROP_STANDARD = 1, ORC_DROP_STANDARD2 = 2, ORC_DROP_ERR_PROP = 4, ORC_DROP_ERR_PROP2 = 8, ORC_DROP_PIVOT = 16 };
+
 typedef struct {
     double threshold;                    /* tau of the first level */
     int n_preprocessing;
@@ -115,6 +117,11 @@ typedef struct {
     int use_final_threshold;             /* USE_FINAL_THRESHOLD */
     double final_threshold;              /* FINAL_THRESHOLD */
     orc_int max_fill_in;                 /* 0: MAX_FILLIN_IS_INF; else fill_in (entries a row of U / a column of L may have, the 1 included) */
+    int drop_rules;                      /* ORC_DROP_*: USE_STANDARD_DROPPING, _DROPPING2, USE_ERR_PROP_DROPPING, _DROPPING2, USE_PIVOT_DROPPING */
+    double weight_standard_drop, weight_standard_drop2, weight_err_prop_drop, weight_err_prop_drop2, weight_pivot_drop;   /* WEIGHT_* */
+    int combine_factor;                  /* COMBINE_FACTOR */
+    double neutral_element, min_weight;  /* NEUTRAL_ELEMENT, MIN_WEIGHT */
+    int scale_weight_invdiag;            /* SCALE_WEIGHT_INVDIAG */
 } orc_ml_params;
 
 typedef struct orc_ml orc_ml;

@@ -31,6 +31,7 @@ _I32P = ctypes.POINTER(ctypes.c_int32)
 _F64P = ctypes.POINTER(ctypes.c_double)
 
 # steps of a preprocessing sequence (ilupp_oracle.h)
+DROP_STANDARD, DROP_STANDARD2, DROP_ERR_PROP, DROP_ERR_PROP2, DROP_PIVOT = 1, 2, 4, 8, 16
 PRE_NORMALIZE_COLUMNS, PRE_NORMALIZE_ROWS, PRE_PQ_ORDERING, PRE_MAX_WEIGHTED_MATCHING_ORDERING, PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 1, 2, 3, 4, 5
 ERR_UNSUPPORTED = 4
 
@@ -41,7 +42,11 @@ class MLParams(ctypes.Structure):
                 ("pq_threshold", ctypes.c_double), ("max_levels", ctypes.c_int), ("min_ml_size", ctypes.c_int32),
                 ("small_pivot_terminates", ctypes.c_int), ("min_pivot", ctypes.c_double), ("min_elim_factor", ctypes.c_double),
                 ("threshold_shift_schur", ctypes.c_double), ("vary_threshold_factor", ctypes.c_double),
-                ("use_final_threshold", ctypes.c_int), ("final_threshold", ctypes.c_double), ("max_fill_in", ctypes.c_int32)]
+                ("use_final_threshold", ctypes.c_int), ("final_threshold", ctypes.c_double), ("max_fill_in", ctypes.c_int32),
+                ("drop_rules", ctypes.c_int), ("weight_standard_drop", ctypes.c_double), ("weight_standard_drop2", ctypes.c_double),
+                ("weight_err_prop_drop", ctypes.c_double), ("weight_err_prop_drop2", ctypes.c_double), ("weight_pivot_drop", ctypes.c_double),
+                ("combine_factor", ctypes.c_int), ("neutral_element", ctypes.c_double), ("min_weight", ctypes.c_double),
+                ("scale_weight_invdiag", ctypes.c_int)]
 
 
 class _MLView(ctypes.Structure):

@@ -283,6 +283,16 @@ int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
     param.set_USE_FINAL_THRESHOLD(IP->use_final_threshold != 0);
     param.set_FINAL_THRESHOLD(IP->final_threshold);
     if (IP->max_fill_in > 0) { param.set_MAX_FILLIN_IS_INF(false); param.set_fill_in(IP->max_fill_in); }
+    param.set_USE_STANDARD_DROPPING((IP->drop_rules & ORC_DROP_STANDARD) != 0);
+    param.set_USE_STANDARD_DROPPING2((IP->drop_rules & ORC_DROP_STANDARD2) != 0);
+    param.set_USE_ERR_PROP_DROPPING((IP->drop_rules & ORC_DROP_ERR_PROP) != 0);
+    param.set_USE_ERR_PROP_DROPPING2((IP->drop_rules & ORC_DROP_ERR_PROP2) != 0);
+    param.set_USE_PIVOT_DROPPING((IP->drop_rules & ORC_DROP_PIVOT) != 0);
+    param.set_WEIGHT_STANDARD_DROP(IP->weight_standard_drop); param.set_WEIGHT_STANDARD_DROP2(IP->weight_standard_drop2);
+    param.set_WEIGHT_ERR_PROP_DROP(IP->weight_err_prop_drop); param.set_WEIGHT_ERR_PROP_DROP2(IP->weight_err_prop_drop2);
+    param.set_WEIGHT_PIVOT_DROP(IP->weight_pivot_drop);
+    param.set_COMBINE_FACTOR(IP->combine_factor); param.set_NEUTRAL_ELEMENT(IP->neutral_element); param.set_MIN_WEIGHT(IP->min_weight);
+    param.set_SCALE_WEIGHT_INVDIAG(IP->scale_weight_invdiag != 0);
     ref_ml *R = new ref_ml;
     R->n = n;
     try {

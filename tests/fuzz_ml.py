@@ -50,4 +50,14 @@ def case(seed):
         knobs["MIN_ELIM_FACTOR"] = float(rng.choice([0.1, 0.5]))
     if rng.random() < 0.3:
         knobs["fill_in"] = int(rng.choice([1, 2, 3, 6, 15]))
+    if rng.random() < 0.35:                                     # other dropping rules, combined at random
+        for name in ("USE_STANDARD_DROPPING", "USE_STANDARD_DROPPING2", "USE_ERR_PROP_DROPPING", "USE_ERR_PROP_DROPPING2", "USE_PIVOT_DROPPING"):
+            knobs[name] = bool(rng.random() < 0.4)
+        knobs["COMBINE_FACTOR"] = int(rng.integers(0, 4))
+        if rng.random() < 0.5:
+            knobs["NEUTRAL_ELEMENT"] = float(rng.choice([0.0, 0.5, 1.0]))
+            knobs["WEIGHT_STANDARD_DROP"] = float(rng.choice([0.2, 1.0, 3.0]))
+            knobs["WEIGHT_PIVOT_DROP"] = float(rng.choice([0.1, 1.0]))
+        if rng.random() < 0.3:
+            knobs["SCALE_WEIGHT_INVDIAG"] = True
     return A, (thr, pre, knobs)

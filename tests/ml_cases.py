@@ -72,6 +72,14 @@ PARAMS = [
     ("t0.02_fill7_shift", 0.02, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"fill_in": 7, "THRESHOLD_SHIFT_SCHUR": 1e-3}),
     ("t0.01_fill1", 0.01, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"fill_in": 1}),
     ("t0_mwm_fill12", 0.0, ("MAX_WEIGHTED_MATCHING_ORDERING",), {"fill_in": 12, "THRESHOLD_SHIFT_SCHUR": 1e-3}),
+    # the other dropping rules that are local to a step: dual threshold (preset 13), pivot, the second error-propagation rule; combined by
+    # maximum, sum, product (COMBINE_FACTOR), weights and neutral element changed
+    ("t0.05_std", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"USE_STANDARD_DROPPING": True, "USE_ERR_PROP_DROPPING": False}),
+    ("t0.05_std_err_sum", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"USE_STANDARD_DROPPING": True, "COMBINE_FACTOR": 1, "WEIGHT_STANDARD_DROP": 0.3}),
+    ("t0.05_piv_err2_prod", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING",), {"USE_PIVOT_DROPPING": True, "USE_ERR_PROP_DROPPING2": True, "USE_ERR_PROP_DROPPING": False,
+                                                                          "COMBINE_FACTOR": 2, "NEUTRAL_ELEMENT": 1.0, "WEIGHT_PIVOT_DROP": 0.5}),
+    ("t0.1_std2_minw_invdiag", 0.1, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"USE_STANDARD_DROPPING2": True, "COMBINE_FACTOR": 3, "MIN_WEIGHT": 0.5,
+                                                                                              "SCALE_WEIGHT_INVDIAG": True}),
     # default_configuration(11): where the move-to-corner ordering rejects an index the reference's result is undefined:
     # the oracle and the engine refuse, and the fixture records that
     ("t0.05_mwm_dd", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "DD_SYMM_MOVE_CORNER_ORDERING_IM"), {}),
@@ -80,12 +88,20 @@ PARAMS = [
 _ORC_FIELDS = {"MAX_LEVELS": "max_levels", "THRESHOLD_SHIFT_SCHUR": "threshold_shift_schur", "MIN_PIVOT": "min_pivot", "PQ_THRESHOLD": "pq_threshold",
                "MIN_ELIM_FACTOR": "min_elim_factor", "VARY_THRESHOLD_FACTOR": "vary_threshold_factor", "USE_FINAL_THRESHOLD": "use_final_threshold",
                "FINAL_THRESHOLD": "final_threshold", "SMALL_PIVOT_TERMINATES": "small_pivot_terminates", "MIN_ML_SIZE": "min_ml_size",
-               "fill_in": "max_fill_in"}
+               "fill_in": "max_fill_in", "WEIGHT_STANDARD_DROP": "weight_standard_drop", "WEIGHT_STANDARD_DROP2": "weight_standard_drop2",
+               "WEIGHT_ERR_PROP_DROP": "weight_err_prop_drop", "WEIGHT_ERR_PROP_DROP2": "weight_err_prop_drop2", "WEIGHT_PIVOT_DROP": "weight_pivot_drop",
+               "COMBINE_FACTOR": "combine_factor", "NEUTRAL_ELEMENT": "neutral_element", "MIN_WEIGHT": "min_weight", "SCALE_WEIGHT_INVDIAG": "scale_weight_invdiag"}
+
+
+_RULES = (("USE_STANDARD_DROPPING", 1, False), ("USE_STANDARD_DROPPING2", 2, False), ("USE_ERR_PROP_DROPPING", 4, True), ("USE_ERR_PROP_DROPPING2", 8, False),
+          ("USE_PIVOT_DROPPING", 16, False))
 
 
 def oracle_params(O, thr, pre, knobs):
     """the parameter block of oracle/ilupp_oracle.h for a case"""
-    return O.ml_params(thr, preprocessing=tuple(PRE[s] for s in pre), **{_ORC_FIELDS[k]: (int(v) if isinstance(v, bool) else v) for k, v in knobs.items()})
+    kw = {_ORC_FIELDS[k]: (int(v) if isinstance(v, bool) else v) for k, v in knobs.items() if k in _ORC_FIELDS}
+    kw["drop_rules"] = sum(bit for name, bit, default in _RULES if knobs.get(name, default))
+    return O.ml_params(thr, preprocessing=tuple(PRE[s] for s in pre), **kw)
 
 
 def engine_params(ilupp, thr, pre, knobs):

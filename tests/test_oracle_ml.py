@@ -129,6 +129,8 @@ def test_default_parameters_and_presets():
     assert (p.PRECON_PARAMETER, p.THRESHOLD_SHIFT_SCHUR, p.MAX_FILLIN_IS_INF, p.fill_in) == (1010, 1e-3, False, 500)
     b = p._to_ml_params()                           # the bounded-fill family is built
     assert (b.max_fill_in, b.threshold_shift_schur) == (500, 1e-3)
+    p.init(ilupp.preprocessing_sequence(["PQ_ORDERING"]), 13)       # dual threshold dropping (:951-959): built
+    assert p.USE_STANDARD_DROPPING and not p.USE_ERR_PROP_DROPPING and p._to_ml_params().drop_rules == 1
     p.default_configuration(10)
     assert p.PRECON_PARAMETER == 0 and p.PERMUTE_ROWS == 3 and p.PREPROCESSING.to_names() == ["MAX_WEIGHTED_MATCHING_ORDERING"]
     with pytest.raises(NotImplementedError):
@@ -167,6 +169,8 @@ def test_everything_outside_the_built_family_is_refused():
     refused(lambda p: setattr(p, "piv_tol", 0.5))
     refused(lambda p: setattr(p, "PERMUTE_ROWS", 3))
     refused(lambda p: p.use_only_inverse_dropping())
+    refused(lambda p: setattr(p, "USE_WEIGHTED_DROPPING", True))
+    refused(lambda p: setattr(p, "SCALE_WGT_MAXINVDIAG", True))
     refused(lambda p: setattr(p, "SCHUR_COMPLEMENT", 1))
     refused(lambda p: setattr(p, "DROP_TYPE_L", 1))
     refused(lambda p: p.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ())
