@@ -1301,11 +1301,18 @@ void ml_destroy(ilupp_ml *m)
     delete m;
 }
 
+static bool getenv_small_off() { static const bool off = getenv("ILUPP_NO_SMALL_SWEEPS") != nullptr; return off; }
+
 // one half of the ILUC-kind apply (apply_dev, KIND_UTU): forward = the T2 loop (left factor, or right^T), backward = the T3 loop
 int utu_half(ilupp_precond *p, bool forward, bool tr, double *rhs, double *out, int32_t *ticket)
 {
     ensure_transposed(p);
     int32_t *err = p->ctrl;
+    // small levels (the later, denser ones): one workgroup with the unknowns in LDS instead of a chain of hops through memory
+    if (p->n <= kSmallSweepMax && !getenv_small_off()) {
+        const DevMat &M = forward ? (tr ? p->UcT : p->LcT) : (tr ? p->Lc : p->Uc);
+        return sptrsv_small(p->stream, forward ? SWEEP_FWD_LAST_ASC : SWEEP_BWD_FIRST_ASC, M, rhs, out);
+    }
     if (forward) {
         const DevMat &Mf = tr ? p->UcT : p->LcT;
         const Schedule &sf = tr ? p->sUT : p->sLT;

@@ -25,6 +25,9 @@ __global__ void k_iluc_colfill(int32_t n, const int32_t *__restrict__ ptr, const
 __global__ void k_iluc_colorder(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const int32_t *__restrict__ rowof,
                                 const int32_t *__restrict__ colptr, const int32_t *__restrict__ colpos, int32_t *__restrict__ colord);
 __global__ void k_iluc_rowof(int32_t n, const int32_t *__restrict__ ptr, int32_t *__restrict__ rowof);
+// ... for every column: by k_iluc_colorder where columns are short, by the sequential threading itself (host, pattern only) where they are long
+int iluc_column_order(hipStream_t st, int32_t m, const DevMat &Av, const int32_t *colcnt, const int32_t *colptr, int32_t *fillc, int32_t *colpos,
+                      const int32_t *rowof, int32_t *colord);
 // the steps nothing reaches go to the ready queues
 __global__ void k_iluc_seed(int32_t m, int32_t nq, const int32_t *__restrict__ pending, int32_t *rq, int32_t *ctrl);
 

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
@@ -108,6 +109,65 @@ __global__ void k_iluc_colorder(int32_t n, const int32_t *__restrict__ ptr, cons
         colord[b + rank] = q1;
     }
 }
+// sum over the columns of (entries below the diagonal)^2: what k_iluc_colorder's pairwise ranking costs at least
+__global__ void k_iluc_colorder_cost(int32_t n, const int32_t *__restrict__ colcnt, unsigned long long *cost)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = c < n ? (unsigned long long)colcnt[c] * (unsigned long long)colcnt[c] : 0ull;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(cost, v);
+}
+
+// The order in which the reference walks column k of A (ILUC.hpp:74-101) for every k, into colord (CSR positions): the pairwise ranking of
+// k_iluc_colorder where columns are short (sparse matrices: every column on its own, in parallel); where they are long -- a dense Schur
+// complement of a multilevel factorisation: 549 rows took 11 s that way, the comparison of two rows walks back along everything they
+// share -- the threading of the lists itself, which is sequential but linear in the entries, on the host (pattern only; such matrices are small).
+// colptr must hold the exclusive scan of colcnt (both from k_iluc_prep); colpos is scratch.
+int iluc_column_order(hipStream_t st, int32_t m, const DevMat &Av, const int32_t *colcnt, const int32_t *colptr, int32_t *fillc, int32_t *colpos,
+                      const int32_t *rowof, int32_t *colord)
+{
+    const int gb = (m + 255) / 256;
+    PoolBlock b_cost;
+    ILUPP_HIP(b_cost.alloc(64));
+    ILUPP_HIP(hipMemsetAsync(b_cost.p, 0, 64, st));
+    hipLaunchKernelGGL(k_iluc_colorder_cost, dim3(gb), dim3(256), 0, st, m, colcnt, b_cost.as<unsigned long long>());
+    unsigned long long cost = 0;
+    ILUPP_HIP(hipMemcpyAsync(&cost, b_cost.p, sizeof(cost), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    const int64_t nnz = Av.nnz;
+    if (cost <= 64ull * (unsigned long long)(nnz > 0 ? nnz : 1) + 1000000ull || nnz > 200000000) {
+        hipLaunchKernelGGL(k_iluc_colfill, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, colptr, fillc, colpos);
+        hipLaunchKernelGGL(k_iluc_colorder, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, rowof, colptr, colpos, colord);
+        return ILUPP_OK;
+    }
+    std::vector<int32_t> ptr((size_t)m + 1), idx((size_t)(nnz > 0 ? nnz : 1)), cp((size_t)m + 1), ord((size_t)(nnz > 0 ? nnz : 1)), first((size_t)m), list((size_t)m, -1),
+                         head((size_t)m, -1), fill((size_t)m, 0);
+    ILUPP_HIP(hipMemcpyAsync(ptr.data(), Av.ptr, sizeof(int32_t) * (size_t)(m + 1), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipMemcpyAsync(cp.data(), colptr, sizeof(int32_t) * (size_t)(m + 1), hipMemcpyDeviceToHost, st));
+    if (nnz > 0) ILUPP_HIP(hipMemcpyAsync(idx.data(), Av.idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    // initialize_sparse_matrix_fields (ILUC.hpp:74-84), then for every k: the walk of chain k, and update_sparse_matrix_fields (:86-101)
+    for (int32_t k = 0; k < m; ++k) {
+        first[(size_t)k] = ptr[(size_t)k];
+        if (ptr[(size_t)k] < ptr[(size_t)k + 1]) { const int32_t c = idx[(size_t)ptr[(size_t)k]]; list[(size_t)k] = head[(size_t)c]; head[(size_t)c] = k; }
+    }
+    for (int32_t k = 0; k < m; ++k) {
+        for (int32_t h = head[(size_t)k]; h != -1; h = list[(size_t)h])
+            if (h > k) ord[(size_t)cp[(size_t)k] + (size_t)fill[(size_t)k]++] = first[(size_t)h];
+        for (int32_t h = head[(size_t)k]; h != -1; h = list[(size_t)h]) first[(size_t)h] += 1;
+        int32_t h = head[(size_t)k];
+        while (h != -1) {
+            const int32_t i = h;
+            h = list[(size_t)i];
+            if (first[(size_t)i] < ptr[(size_t)i + 1]) { const int32_t c = idx[(size_t)first[(size_t)i]]; list[(size_t)i] = head[(size_t)c]; head[(size_t)c] = i; }
+        }
+    }
+    const size_t nsub = (size_t)cp[(size_t)m];
+    if (nsub) ILUPP_HIP(hipMemcpyAsync(colord, ord.data(), sizeof(int32_t) * nsub, hipMemcpyHostToDevice, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    return ILUPP_OK;
+}
+
 __global__ void k_iluc_rowof(int32_t n, const int32_t *__restrict__ ptr, int32_t *__restrict__ rowof)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,11 +498,12 @@ k_iluc_df(IlucArgs A)
             if (Z) {
                 // ---- row k of U: the pivot, then the kept entries (append_row_with_prefix, sparse_implementation.h:3189-3208) ----
                 const size_t off = (size_t)k * A.cap;
-                if (!nopivot) {
-                    if (lane == 0) { st_agent_i32(&A.Uidx[off], k); st_agent_f64(&A.Uval[off], ukk); }
-                    for (int s = lane; s < ns; s += 64)
-                        if (srank[s] >= 0) { st_agent_i32(&A.Uidx[off + srank[s]], srow[s]); st_agent_f64(&A.Uval[off + srank[s]], sval[s]); }
-                }
+                // (also for a step without a pivot, with its stand-in: the steps it reaches go on -- only the error is reported in the end -- and
+                // must read a row that was written.  They used to read whatever the slab held: zeros in fresh memory, the indices of an older
+                // factorisation in a block the pool handed out again -- the memory fault behind round 2's abort in the error-path tests)
+                if (lane == 0) { st_agent_i32(&A.Uidx[off], k); st_agent_f64(&A.Uval[off], ukk); }
+                for (int s = lane; s < ns; s += 64)
+                    if (srank[s] >= 0) { st_agent_i32(&A.Uidx[off + srank[s]], srow[s]); st_agent_f64(&A.Uval[off + srank[s]], sval[s]); }
                 if (lane == 0) A.Ulen[k] = nk + 1;
                 nkz = nk; nzs = ns;
                 for (int s = lane; s < ns; s += 64) { zcol[s] = srow[s]; zcnt[s] = s == dslot ? 0 : scnt[s]; }
@@ -647,8 +708,7 @@ static int iluc_attempt(hipStream_t st, const DevMat &Av, int32_t max_fill_in, d
         ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, colcnt, colptr, m + 1, st));
         ILUPP_HIP(hipStreamSynchronize(st));
     }
-    hipLaunchKernelGGL(k_iluc_colfill, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, colptr, fillc, colpos);
-    hipLaunchKernelGGL(k_iluc_colorder, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, rowof, colptr, colpos, colord);
+    { const int rc = iluc_column_order(st, m, Av, colcnt, colptr, fillc, colpos, rowof, colord); if (rc) return rc; }
     int waves = device_cu_count() * (cls == 0 ? 16 : (cls == 1 ? 8 : (cls == 2 ? 2 : (cls == 3 ? 2 : ILUC_W4))));
     if (waves > m) waves = m;
     unsigned char *gws = nullptr;

@@ -26,6 +26,8 @@
 //     the touch records of the steps below kterm, tails = the part of their U rows right of kterm.
 #include <stdlib.h>
 
+#include <chrono>
+
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -180,13 +182,13 @@ k_piluc_df(PilucArgs A)
     __shared__ double s_cv[kLTM];
     // the row of U waits (scaled, not dropped yet) until the column of L is known: its slots, how often each was announced, then its
     // kept slots by increasing index and where their touch records went
-    __shared__ int s_zcol[kLNS], s_zcnt[kLNS], s_zkept[kLNS + 1], s_zridx[kLNS + 1], s_znx[kLTM];
+    __shared__ int s_zcol[kLNS], s_zcnt[kLNS], s_zkept[kLNS + 1], s_zridx[kLNS + 1];
     __shared__ double s_zval[kLNS];
     const int kNE = kGlobal ? A.gNE : kLNE, kNS = kGlobal ? A.gNS : kLNS, kTM = kGlobal ? A.gTM : kLTM;
     int *erow = s_erow, *eslot = s_eslot, *srow = s_srow, *scnt = s_scnt, *srank = s_srank, *sridx = s_sridx, *crank = s_crank,
         *keptslot = s_keptslot, *hslot = s_hslot, *tx = s_tx, *tt = s_tt, *trem = s_trem, *tnxt = s_tnxt, *tseq = s_tseq, *tw = s_tw,
         *cx = s_cx, *crem = s_crem, *cbase = s_cbase, *cnxt = s_cnxt, *cw = s_cw, *zcol = s_zcol, *zcnt = s_zcnt, *zkept = s_zkept,
-        *zridx = s_zridx, *znx = s_znx;
+        *zridx = s_zridx;
     double *eval = s_eval, *sval = s_sval, *tv = s_tv, *cv = s_cv, *zval = s_zval;
     if (kGlobal) {
         double *d = reinterpret_cast<double *>(A.gws + (size_t)blockIdx.x * piluc_ws_bytes(A.gNE, A.gNS, A.gTM));
@@ -197,7 +199,7 @@ k_piluc_df(PilucArgs A)
         hslot = q; q += 4 * kNS;
         tx = q; q += kTM; tt = q; q += kTM; trem = q; q += kTM; tnxt = q; q += kTM; tseq = q; q += kTM; tw = q; q += kTM;
         cx = q; q += kTM; crem = q; q += kTM; cbase = q; q += kTM + 1; cnxt = q; q += kTM; cw = q; q += kTM;
-        zcol = q; q += kNS; zcnt = q; q += kNS; zkept = q; q += kNS + 1; zridx = q; q += kNS + 1; znx = q; q += kTM;
+        zcol = q; q += kNS; zcnt = q; q += kNS; zkept = q; q += kNS + 1; zridx = q; q += kNS + 1;
     }
 
     const int lane = threadIdx.x;
@@ -264,7 +266,7 @@ k_piluc_df(PilucArgs A)
         // above a parked step: the level has ended before this one
         if (!schur && k > __builtin_amdgcn_readfirstlane(ld_agent_i32(&A.ctrl[3]))) { PU_RETIRE(); continue; }
 
-        int nzs = 0, nzt = 0;           // z: slots, contributors
+        int nzs = 0;                    // z: slots
         int dslot = -1;
         double dinv = 1.0, dinv_store = 1.0;
         bool parked = false;
@@ -342,10 +344,20 @@ k_piluc_df(PilucArgs A)
             }
             PU_SYNC();
             {
-                // the chains go on to the contributors' next stored indices: tell those records where the chain stood in THIS list
+                // the chains go on to the contributors' next stored indices: tell those records where the chain stood in THIS list, and let
+                // their steps go as far as this hand-over is concerned -- at once: the order is all they need from here, and rows of a dense
+                // Schur complement, each handing every chain to the next, would otherwise run strictly one after the other
                 unsigned long long *rb = Z ? A.recL : A.recU;
                 for (int p = lane; p < nt; p += 64)
                     if (cnxt[p] >= 0) st_agent_i32(reinterpret_cast<int *>(rb + (size_t)cnxt[p] * 4 + 3) + 1, p + 1);
+                drain_stores();
+                PU_SYNC();
+                for (int p = lane; p < nt; p += 64) {
+                    const int nx = cnxt[p];
+                    if (nx < 0) continue;
+                    const int x = nx / T;
+                    if (atomicAdd(&A.pending[x], -1) - 1 == 0) PU_PUSH(x);
+                }
             }
             if (schur) {
                 // the tails of the Schur rows: the part of the contributor's U row right of kterm (firstU stands there since the last
@@ -515,15 +527,6 @@ k_piluc_df(PilucArgs A)
                     for (int r = lane; r < nk; r += 64) { const int s = (int)(unsigned)keys[r]; A.Sidx[pos + r] = srow[s]; A.Sval[pos + r] = sval[s]; }
                 }
                 if (lane == 0) { A.Sstart[k - kterm] = pos; A.Slen[k - kterm] = nk; }
-                // the chains this row handed on: their next rows may go
-                __builtin_amdgcn_s_waitcnt(0);
-                PU_SYNC();
-                for (int q = lane; q < nt; q += 64) {
-                    const int nx = cnxt[q];
-                    if (nx < 0) continue;
-                    const int x = nx / T;
-                    if (atomicAdd(&A.pending[x], -1) - 1 == 0) PU_PUSH(x);
-                }
                 ++ndone;
                 if (lane == 0 && ((k & 255) == 0 || ne > 2048)) atomicAdd(&A.ctrl[9], 1);      // progress mark
                 PU_SYNC();
@@ -554,8 +557,7 @@ k_piluc_df(PilucArgs A)
                 dinv_store = piv == 0.0 ? 1.0 : dinv;                    // "zero pivot: setting diagonal to 1" (:1786-1792) -- for everyone after this step
                 PU_SYNC();
                 for (int s = lane; s < ns; s += 64) { const double v = sval[s] * dinv; zval[s] = s == dslot ? 0.0 : v; zcol[s] = srow[s]; zcnt[s] = s == dslot ? 0 : scnt[s]; }
-                nzs = ns; nzt = nt;
-                for (int q = lane; q < nt; q += 64) znx[q] = cnxt[q];
+                nzs = ns;
                 PU_SYNC();
             } else {
                 // ================= both working vectors are known: norms, dropping, the stores, touch records, counters =================
@@ -721,16 +723,6 @@ k_piluc_df(PilucArgs A)
                 for (int r = 2 + lane; r <= nkz; r += 64) atomicAdd(&A.pending[zcol[zkept[r]]], 1);
                 __builtin_amdgcn_s_waitcnt(0);
                 PU_SYNC();
-                // the chains this step handed on (seq written above, drained): their next steps may go
-                for (int half2 = 0; half2 < 2; ++half2) {
-                    const int cn = half2 == 0 ? nt : nzt;
-                    for (int q = lane; q < cn; q += 64) {
-                        const int nx = half2 == 0 ? cnxt[q] : znx[q];
-                        if (nx < 0) continue;
-                        const int x = nx / T;
-                        if (atomicAdd(&A.pending[x], -1) - 1 == 0) PU_PUSH(x);
-                    }
-                }
                 // then what this step decided: every slot of w and of z, as many times as it was announced (the slots of index k
                 // themselves are this step's own business)
                 for (int half2 = 0; half2 < 2; ++half2) {
@@ -847,6 +839,18 @@ static int scan_i32(hipStream_t st, const int32_t *in, int32_t *out, int count)
     return ILUPP_OK;
 }
 
+struct HostLap {                               // wall-clock laps of an attempt (ILUPP_DEBUG)
+    bool on; std::chrono::steady_clock::time_point t;
+    explicit HostLap(bool o) : on(o), t(std::chrono::steady_clock::now()) {}
+    void lap(hipStream_t st, const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(st);
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ilupp] piluc:   %-28s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 static void launch_class(int cls, int waves, hipStream_t st, const PilucArgs &a)
 {
     if (cls == 0) hipLaunchKernelGGL((k_piluc_df<256, 128, 32, false>), dim3(waves), dim3(64), 0, st, a);
@@ -858,7 +862,7 @@ static void launch_class(int cls, int waves, hipStream_t st, const PilucArgs &a)
 
 // one attempt with one capacity class and one store size; ILUPP_OK / an error / +1 = "outside this class" / +2 = "stores too small"
 static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv_out,
-                         DevMat *Anew, int32_t *kterm_out, float *kernel_ms, int cls, long store, int gns, int *which_capacity)
+                         DevMat *Anew, int32_t *kterm_out, float *kernel_ms, int cls, long store, int gns, long gne, int *which_capacity)
 {
     const int32_t m = Av.n;
     int T = cls == 0 ? 32 : (cls == 1 ? 64 : (cls == 2 ? 128 : (cls == 3 ? 512 : 16)));
@@ -867,6 +871,7 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
     if ((long)m * T > 0x7fffffffL) return 1;
     if (store > 0x7ffffff0L) store = 0x7ffffff0L;
 
+    HostLap laps(getenv("ILUPP_DEBUG") != nullptr && getenv("ILUPP_PILUC_LAPS") != nullptr);
     PoolBlock b_pending, b_colcnt, b_colptr, b_fillc, b_colpos, b_colord, b_rowof, b_Uidx, b_Lidx, b_Uval, b_Lval, b_Ustart, b_Ulen, b_Lstart, b_Llen,
               b_cntL, b_cntU, b_recL, b_recU, b_rq, b_ctrl, b_gws, b_dinv;
     const size_t nz = (size_t)(Av.nnz > 0 ? Av.nnz : 1);
@@ -909,23 +914,24 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, ctrl_bytes, st));
     const int32_t big = 0x7fffffff;
     ILUPP_HIP(hipMemcpyAsync(ctrl + 3, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    laps.lap(st, "allocations, memsets");
     const int gb = (m + 255) / 256;
     hipLaunchKernelGGL(k_iluc_prep, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, pending, colcnt);
     hipLaunchKernelGGL(k_iluc_rowof, dim3(gb), dim3(256), 0, st, m, Av.ptr, rowof);
     { const int rc = scan_i32(st, colcnt, colptr, m + 1); if (rc) return rc; }
-    hipLaunchKernelGGL(k_iluc_colfill, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, colptr, fillc, colpos);
-    hipLaunchKernelGGL(k_iluc_colorder, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, rowof, colptr, colpos, colord);
+    { const int rc = iluc_column_order(st, m, Av, colcnt, colptr, fillc, colpos, rowof, colord); if (rc) return rc; }
     int waves = device_cu_count() * (cls == 0 ? 16 : (cls == 1 ? 8 : (cls == 2 ? 2 : (cls == 3 ? 2 : 4))));
     if (waves > m) waves = m;
     int gNE = 0, gNS = 0, gTM = 0;
     if (cls == 4) {
         gTM = T; gNS = gns;                                                     // (a power of two: the slot hash masks with a power of two <= 4 gNS)
-        gNE = 32 * gNS;
-        if (gNE > (1 << 22)) gNE = 1 << 22;
-        while (waves > 64 && (size_t)waves * piluc_ws_bytes(gNE, gNS, gTM) > ((size_t)PILUC_WSGB << 30)) waves /= 2;
-        while (gNE > 4096 && (size_t)waves * piluc_ws_bytes(gNE, gNS, gTM) > ((size_t)PILUC_WSGB << 30)) gNE /= 2;
+        gNE = (int)(gne > (1L << 26) ? (1L << 26) : gne);
+        if (gNE < 2 * gNS) gNE = 2 * gNS;                        // (scratch of the sorts lies behind the first gNS entries)
+        while (waves > 16 && (size_t)waves * piluc_ws_bytes(gNE, gNS, gTM) > ((size_t)PILUC_WSGB << 30)) waves /= 2;
+        if ((size_t)waves * piluc_ws_bytes(gNE, gNS, gTM) > ((size_t)PILUC_WSGB << 30)) return ILUPP_ERR_UNSUPPORTED;
         ILUPP_HIP(b_gws.alloc((size_t)waves * piluc_ws_bytes(gNE, gNS, gTM)));
     }
+    laps.lap(st, "column order of A, work space");
     const int nq = waves < kCuQ ? waves : kCuQ;
     hipLaunchKernelGGL(k_piluc_count_seeds, dim3(gb), dim3(256), 0, st, m, nq, pending, ctrl);
     hipLaunchKernelGGL(k_iluc_seed, dim3(gb), dim3(256), 0, st, m, nq, pending, rq, ctrl);
@@ -966,6 +972,7 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
     int32_t h[8];
     ILUPP_HIP(hipMemcpyAsync(h, ctrl, 32, hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
+    laps.lap(st, "elimination kernel");
     const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
     if (dbg) {
         float ms = 0.f;
@@ -1011,6 +1018,7 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
         if (h[2] != 0) { if (which_capacity) *which_capacity = h[2]; return 1; }
         if (h[4] != nS) { set_error("partialILUC: Schur rows left unprocessed"); return ILUPP_ERR_INTERNAL; }
     }
+    laps.lap(st, "Schur complement");
     ILUPP_HIP(hipEventRecord(ev.b, st));
     // ---- the reference's arrays ----
     PoolBlock b_cnt, b_err;
@@ -1052,6 +1060,7 @@ static int piluc_attempt(hipStream_t st, const DevMat &Av, const PilucParams &P,
                            b_Sidx.as<int32_t>(), b_Sval.as<double>(), Anew->ptr, Anew->idx, Anew->val);
     }
     ILUPP_HIP(hipStreamSynchronize(st));
+    laps.lap(st, "factors as CSR arrays");
     if (kernel_ms) { float ms = 0.f; ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b)); *kernel_ms += ms; }
     *Dinv_out = b_dinv.as<double>();
     b_dinv.p = nullptr;                                   // (the caller owns it now)
@@ -1075,10 +1084,11 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
     }
     int rc = 1;
     int gns = 2048;
+    long gne = 65536;
     while (rc == 1 || rc == 2) {
         int which = 0;
         L->release(); U->release(); Anew->release();
-        rc = piluc_attempt(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms, cls, store, gns, &which);
+        rc = piluc_attempt(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms, cls, store, gns, gne, &which);
         if (rc == 1) {
             const bool records = which == 12 || which == 15;          // more touch records per step than the class holds
             if (cls < 4) {
@@ -1087,15 +1097,18 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
             } else if (records) {
                 set_error("partialILUC: a step is reached by more than 4096 stored entries");
                 rc = ILUPP_ERR_UNSUPPORTED;
-            } else if (gns >= (1 << 20) || gns > 2 * (long)Av.n) {
-                set_error("partialILUC: a working row does not fit the largest capacity class");
-                rc = ILUPP_ERR_UNSUPPORTED;
-            } else {
-                gns *= 4;
+            } else if (which == 13) {                                  // the entries of a working row: at most (contributors) x (row length)
+                if (gne >= (1L << 26)) { set_error("partialILUC: a working row gathers more than 2^26 entries"); rc = ILUPP_ERR_UNSUPPORTED; }
+                else gne *= 4;
+            } else {                                                   // its slots: at most n + 1
+                if (gns > 2 * (long)Av.n + 2) { set_error("partialILUC: a working row does not fit the largest capacity class"); rc = ILUPP_ERR_UNSUPPORTED; }
+                else { gns *= 4; if (gne < 8L * gns) gne = 8L * gns; }
             }
         } else if (rc == 2) {
             if (store >= 0x7ffffff0L) { set_error("partialILUC: the factors of a level exceed 2^31 entries"); rc = ILUPP_ERR_MEMORY; break; }
             store *= 2;
+        } else if (rc == ILUPP_ERR_UNSUPPORTED) {
+            set_error("partialILUC: the working arrays of the largest capacity class exceed the memory set aside for them");
         }
     }
     if (rc != ILUPP_OK) { L->release(); U->release(); Anew->release(); }

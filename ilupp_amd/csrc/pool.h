@@ -42,11 +42,24 @@ public:
     }
     ~BlockPool() { trim(); }
 
-    // a block of at least `bytes` (rounded up to 256): a kept one of the same device and size, else a new one
-    int acquire(void **p, size_t bytes)
+    // the size a request is served with: multiples of 256 bytes; from 1 MiB on, one of eight sizes per power of two (at most 12.5 % more) --
+    // requests that differ a little (the levels of a multilevel factorisation, each a bit smaller than the one before) then meet the
+    // same kept blocks instead of sending a GB-sized block back to the driver and asking it for another one
+    static size_t bucket(size_t bytes)
     {
         if (bytes == 0) bytes = 16;
         bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes < ((size_t)1 << 20)) return bytes;
+        int k = 0;
+        while (((size_t)2 << k) <= bytes) ++k;                  // 2^k <= bytes < 2^(k+1)
+        const size_t step = (size_t)1 << (k - 3);
+        return (bytes + step - 1) & ~(step - 1);
+    }
+
+    // a block of at least `bytes`: a kept one of the same device and bucket, else a new one
+    int acquire(void **p, size_t bytes)
+    {
+        bytes = bucket(bytes);
         const int dev = be_.device();
         {
             std::lock_guard<std::mutex> lk(mu_);

@@ -18,3 +18,7 @@ p = ilupp.iluplusplus_precond_parameter(); p.default_configuration(1); p.thresho
 t0 = time.time()
 G = _native.MultilevelILUCDPPreconditioner(A.data, A.indices, A.indptr, True, p)
 print("created %.2fs" % (time.time() - t0), G.levels(), G.total_nnz, G.timings(), flush=True)
+b = np.ones(A.shape[0])
+for rep in range(3):
+    x = b.copy(); t0 = time.time(); G.apply(x); print("apply %.2f ms wall" % (1e3 * (time.time() - t0)), G.timings()["last_apply_ms"], flush=True)
+x = b.copy(); G.apply_trans(x); print("apply_trans", G.timings()["last_apply_ms"], flush=True)

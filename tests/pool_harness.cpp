@@ -90,6 +90,15 @@ int main(int argc, char **argv)
         CHECK(P.acquire(&x, 6 << 20) == 0 && P.cached() == 0);
         CHECK(P.release(x) == 0);
         g_budget = (size_t)1 << 40;
+        // sizes from 1 MiB on are served from eight buckets per power of two: a slightly smaller request meets the kept block
+        CHECK(BlockPool::bucket(1000) == 1024 && BlockPool::bucket((1 << 20) + 1) == (1 << 20) + (1 << 17) && BlockPool::bucket(6 << 20) == (6 << 20));
+        CHECK(BlockPool::bucket(((size_t)937 << 20) + 12345) == ((size_t)960 << 20));
+        {
+            void *y = nullptr, *z = nullptr;
+            CHECK(P.acquire(&y, (5 << 20) - 4096) == 0 && P.release(y) == 0);
+            CHECK(P.acquire(&z, (5 << 20) - 300000) == 0 && z == y && P.release(z) == 0);
+            P.trim();
+        }
         // random traffic
         std::mt19937 rng(7);
         std::vector<std::pair<void *, size_t>> held;
