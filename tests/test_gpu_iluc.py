@@ -104,3 +104,20 @@ def test_medium_against_the_oracle(case):
             assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, O.ID))
             xt = b.copy(); P.apply_trans(xt)
             assert np.array_equal(xt, O.orc().apply_lu(Lo, Uo, b, O.TRANSPOSE))
+
+
+def test_error_path_on_reused_slabs():
+    """the step without a pivot writes its row of U: the steps it reaches read that row, not what an older factorisation left in a slab the
+    pool hands out again (round 2's abort in this file: a GPU memory fault that depended on what the pool had kept).  A factorisation of
+    the same shape with large indices runs first, is released, and its blocks come back for the error case"""
+    import ilupp_amd as ilupp
+    z = G.load("iluc.npz")
+    M = G.get_mat(z, "edge_nopivot/A")
+    n = M[2].shape[0] - 1
+    rng = np.random.default_rng(2)
+    for _ in range(3):
+        B = (sp.random(n, n, density=min(1.0, 6.0 / n), random_state=rng, format="csr") + sp.eye(n) * 4.0).tocsr()
+        B.sort_indices()
+        P = ilupp.ILUCPreconditioner(B, fill_in=5, threshold=0.1)
+        del P
+        check(z, "edge_nopivot", M, ((5, 0.1),))
