@@ -168,6 +168,28 @@ class ILUCPreconditioner(_HipPreconditioner):
         super().__init__(A, lambda m: _backend.ILUCPreconditioner(*m, fill_in, threshold))
 
 
+class _NotBuilt(_LinearOperator):
+    """a class of the reference this package has no engine for yet: constructing it says so (nothing is computed on the CPU instead)"""
+    _what = ""
+
+    def __init__(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0):
+        raise NotImplementedError("ilupp_amd: %s (SURVEY section 8 f4: the pivot search makes every row wait for the permutation "
+                                  "of all rows before it) is not built on the GPU yet" % self._what)
+
+    def permutations(self):
+        raise NotImplementedError
+
+
+class ILUTPPreconditioner(_NotBuilt):
+    """ILUTP (ILUT with column pivoting; reference ilupp/__init__.py:218-236, ILUTP.hpp:13-140): not built -- raises NotImplementedError."""
+    _what = "ILUTP, the ILUT with column pivoting"
+
+
+class ILUCPPreconditioner(_NotBuilt):
+    """ILUCP (Crout ILU with pivoting; reference ilupp/__init__.py:252-270, ILUC.hpp:212-541): not built -- raises NotImplementedError."""
+    _what = "ILUCP, the Crout ILU with pivoting"
+
+
 class ILU0Preconditioner(_HipPreconditioner):
     """ILU(0): incomplete LU in the pattern of A."""
 

@@ -43,6 +43,17 @@ def test_python_surface_matches_reference_names():
     assert str(inspect.signature(ilupp.icholt)) == "(A, add_fill_in=0, threshold=0.0)"
 
 
+def test_pivoting_classes_say_that_they_are_not_built():
+    """the reference's ILUTP / ILUCP classes exist by name and refuse loudly: no CPU stand-in"""
+    import inspect
+    import ilupp_amd as ilupp
+    A = sp.eye(4, format="csr")
+    for cls in (ilupp.ILUTPPreconditioner, ilupp.ILUCPPreconditioner):
+        assert str(inspect.signature(cls.__init__)) == "(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0)"
+        with pytest.raises(NotImplementedError, match="not built"):
+            cls(A)
+
+
 def test_input_validation_types():
     """exception types/messages of ilupp/__init__.py:55-71 and binding.cpp:33-98 (no GPU needed:
     all raised before the native call)"""
