@@ -268,3 +268,18 @@ def test_bench_batch_member():
     import hashlib
     assert recs[0][1] == Q.levels() and recs[0][2] == Q.total_nnz()
     assert recs[0][3] == hashlib.sha256(Q.apply(np.ones(200000)).tobytes()).hexdigest()
+
+
+def test_degenerate_inputs_against_oracle():
+    """a matrix without entries, a 1 x 1 zero, empty rows and columns, an all-zero row with a stored zero: the reference divides by the
+    zero norms and carries NaNs and infinities through every level; the engine and the oracle do the same, bit for bit"""
+    Z = sp.csr_matrix((3, 3))
+    E = sp.csr_matrix((np.array([0.0]), np.array([0], dtype=np.int32), np.array([0, 1], dtype=np.int32)), shape=(1, 1))
+    R = sp.random(40, 40, density=0.1, random_state=np.random.default_rng(8), format="lil")
+    R[7, :] = 0; R[:, 11] = 0; R[20, :] = 0
+    R = R.tocsr(); R.eliminate_zeros()
+    S = R.copy().tolil(); S[20, 3] = 1.0; S = S.tocsr(); S.data[S.indptr[20]] = 0.0          # a stored zero in an otherwise empty row
+    for A in (Z, E, R, S, R.tocsc()):
+        for pre in (PQ, (), MWM, ("NORMALIZE_ROWS", "SPARSE_FIRST_ORDERING", "UNIT_OR_ZERO_DIAGONAL_SCALING")):
+            for thr in (0.0, 0.1):
+                _against_oracle(A, (thr, pre, {}))
