@@ -142,24 +142,6 @@ __global__ void k_ml_sorted_ties(int32_t n, const double *__restrict__ w, int32_
     if (a != a || (i + 1 < n && !(a < w[i + 1]))) *flag = 1;
 }
 
-// the greedy selection (:4608-4634) over the candidates in sorted order (W ascending, I = their rows): ip (rows) and iq (columns) are the
-// INVERSE permutations; returns the size of the leading block
-static int32_t pq_select(int32_t n, const std::vector<double> &W, const std::vector<int32_t> &I, const std::vector<int32_t> &J, double tau,
-                         std::vector<int32_t> &ip, std::vector<int32_t> &iq)
-{
-    ip.assign((size_t)n, -1); iq.assign((size_t)n, -1);
-    int32_t count = -1;
-    for (int32_t k = 0; k < n; ++k) {
-        const int32_t r = I[(size_t)k], c = J[(size_t)r];
-        if (ip[(size_t)r] == -1 && iq[(size_t)c] == -1 && -W[(size_t)k] >= tau) { count++; ip[(size_t)r] = count; iq[(size_t)c] = count; }
-    }
-    const int32_t pos = count;
-    int32_t qcount = count;
-    for (int32_t k = 0; k < n; ++k) if (ip[(size_t)k] < 0) { count++; ip[(size_t)k] = count; }
-    for (int32_t k = 0; k < n; ++k) if (iq[(size_t)k] < 0) { qcount++; iq[(size_t)k] = qcount; }
-    return pos + 1;
-}
-
 // ---------------------------------------------- applying permutations to the matrix ----------------------------------------------
 // matrix_sparse::permute(p1, p2, ip1, ip2) on a ROW matrix (:5570-5573 -> :5533-5548): new row i = old row p1[i], a column index c
 // becomes ip2[c], the rows by increasing index again.  Keys (new row, new column) sorted as 64-bit integers carry the values along.
@@ -230,27 +212,83 @@ static void upload_i32(hipStream_t st, int32_t *dst, const std::vector<int32_t> 
     if (!src.empty()) ILUPP_HIP(hipMemcpyAsync(dst, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, st));
 }
 
+// ---- permutations on the device ----
+__global__ void k_ml_gather_i32(int32_t n, const int32_t *__restrict__ a, const int32_t *__restrict__ p, int32_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[p[i]];
+}
+__global__ void k_ml_invert_i32(int32_t n, const int32_t *__restrict__ p, int32_t *__restrict__ inv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[p[i]] = i;
+}
+// P := P o p1 (index_list::compose_right, sparse_implementation.h:6165-6183), then its inverse
+static void compose_and_invert(hipStream_t st, int32_t n, int32_t *P, int32_t *invP, const int32_t *p1, int32_t *tmp)
+{
+    const int gb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_ml_gather_i32, dim3(gb), dim3(256), 0, st, n, P, p1, tmp);
+    ILUPP_HIP(hipMemcpyAsync(P, tmp, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_ml_invert_i32, dim3(gb), dim3(256), 0, st, n, P, invP);
+}
+
+// ---- the greedy selection of ddPQ (:4608-4634) on the device.  A candidate k (the row I[k], in sorted order) is taken iff its weight passes
+// tau and no EARLIER candidate took its column J[I[k]] -- every row is a candidate exactly once, so "row still free" always holds, and the
+// candidates that fail tau are a suffix of the sorted order: the winner of a column is the candidate of smallest k that wants it.
+__global__ void k_ml_pq_first(int32_t n, const double *__restrict__ W, const int32_t *__restrict__ I, const int32_t *__restrict__ J, double tau,
+                              int32_t *__restrict__ first)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && -W[k] >= tau) atomicMin(&first[J[I[k]]], k);
+}
+__global__ void k_ml_pq_sel(int32_t n, const double *__restrict__ W, const int32_t *__restrict__ I, const int32_t *__restrict__ J, double tau,
+                            const int32_t *__restrict__ first, int32_t *__restrict__ sel)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n) return;
+    sel[k] = (k < n && -W[k] >= tau && first[J[I[k]]] == k) ? 1 : 0;
+}
+__global__ void k_ml_pq_assign(int32_t n, const int32_t *__restrict__ I, const int32_t *__restrict__ J, const int32_t *__restrict__ sel,
+                               const int32_t *__restrict__ rank, int32_t *__restrict__ ip, int32_t *__restrict__ iq)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && sel[k]) { const int r = I[k]; ip[r] = rank[k]; iq[J[r]] = rank[k]; }
+}
+__global__ void k_ml_flag_free(int32_t n, const int32_t *__restrict__ ip, int32_t *__restrict__ flag)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    flag[r] = (r < n && ip[r] < 0) ? 1 : 0;
+}
+// the rows (columns) nobody took follow in index order (:4624-4634); total = rank[n] = the number taken
+__global__ void k_ml_pq_rest(int32_t n, int32_t *__restrict__ ip, const int32_t *__restrict__ flag, const int32_t *__restrict__ off,
+                             const int32_t *__restrict__ rank)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && flag[r]) ip[r] = rank[n] + off[r];
+}
+
 // matrix_sparse::preprocess (:5214-5460) for the steps this build has; A: ROW storage, replaced by the preprocessed matrix.
-// P, Q, invP, invQ: host; Drow, Dcol: device, n doubles each.
-static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::vector<int32_t> &P, std::vector<int32_t> &Q, std::vector<int32_t> &invP,
-                            std::vector<int32_t> &invQ, double *Drow, double *Dcol)
+// P, Q, invP, invQ (permutation_rows / _columns of the level and their inverses), Drow, Dcol: device arrays of n entries.
+static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32_t *P, int32_t *Q, int32_t *invP, int32_t *invQ, double *Drow, double *Dcol)
 {
     const int32_t n = A->n;
-    const int gb = (n + 255) / 256;
-    P.resize((size_t)n); Q.resize((size_t)n); invP.resize((size_t)n); invQ.resize((size_t)n);
-    for (int32_t i = 0; i < n; ++i) P[(size_t)i] = Q[(size_t)i] = invP[(size_t)i] = invQ[(size_t)i] = i;
+    const int gb = (n + 255) / 256, gb1 = (n + 1 + 255) / 256;
+    iota_i32(st, P, n); iota_i32(st, Q, n); iota_i32(st, invP, n); iota_i32(st, invQ, n);
     bool permuted_rows = false, permuted_cols = false;
     // The reference keeps ONE set of work permutations for all steps of a preprocess() call (sparse_implementation.h:5217-5218) and two
     // steps only resize them (std::vector::resize keeps existing elements): after a step that filled p1 the matching starts with every
     // column "matched", finds no augmenting path and returns the identity with unit scalings (pmwm_implementation.h:411, :460-471);
     // a second PQ step finds everything "taken" and returns the first one's permutations again (:4580-4581, :4613).  Kept as it behaves.
-    bool p1_filled = false;
-    std::vector<int32_t> pq_ip1, pq_ip2;
+    bool p1_filled = false, pq_done = false;
     hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Drow, 1.0);
     hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Dcol, 1.0);
-    PoolBlock b_D, b_inv;
+    PoolBlock b_D, b_tmpi, b_p1, b_ip1, b_p2, b_ip2, b_id, b_h, b_ih;
     ILUPP_HIP(b_D.alloc(sizeof(double) * (size_t)n));
-    ILUPP_HIP(b_inv.alloc(sizeof(int32_t) * (size_t)n));
+    for (PoolBlock *b : {&b_tmpi, &b_p1, &b_ip1, &b_p2, &b_ip2, &b_id, &b_h, &b_ih}) ILUPP_HIP(b->alloc(sizeof(int32_t) * (size_t)(n + 1)));
+    int32_t *tmpi = b_tmpi.as<int32_t>(), *p1 = b_p1.as<int32_t>(), *ip1 = b_ip1.as<int32_t>(), *p2 = b_p2.as<int32_t>(), *ip2 = b_ip2.as<int32_t>(),
+            *ident = b_id.as<int32_t>(), *hq = b_h.as<int32_t>(), *ihq = b_ih.as<int32_t>();   // p1..ip2: the PQ step's; hq, ihq: a host-made ordering
+    iota_i32(st, ident, n);
     const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
     for (int s = 0; s < IP.n_pre; ++s) {
         struct StepTimer {
@@ -265,32 +303,23 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             hipLaunchKernelGGL(k_ml_col_norms, dim3(gb), dim3(256), 0, st, n, T.ptr, T.val, b_D.as<double>());
             if (A->nnz > 0)
                 hipLaunchKernelGGL(k_ml_col_scale, dim3((unsigned)((A->nnz + 255) / 256)), dim3(256), 0, st, A->nnz, A->idx, A->val, b_D.as<double>());
-            const int32_t *inv = nullptr;
-            if (permuted_cols) { upload_i32(st, b_inv.as<int32_t>(), invQ); inv = b_inv.as<int32_t>(); }
-            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Dcol, b_D.as<double>(), inv);
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Dcol, b_D.as<double>(), permuted_cols ? (const int32_t *)invQ : (const int32_t *)nullptr);
             ILUPP_HIP(hipStreamSynchronize(st));
             T.release();
             break;
         }
-        case ML_PRE_NORMALIZE_ROWS: {                                          // :5247-5252
+        case ML_PRE_NORMALIZE_ROWS:                                            // :5247-5252
             hipLaunchKernelGGL(k_ml_row_norms_scale, dim3(gb), dim3(256), 0, st, n, A->ptr, A->val, b_D.as<double>());
-            const int32_t *inv = nullptr;
-            if (permuted_rows) { upload_i32(st, b_inv.as<int32_t>(), invP); inv = b_inv.as<int32_t>(); }
-            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), inv);
-            ILUPP_HIP(hipStreamSynchronize(st));
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), permuted_rows ? (const int32_t *)invP : (const int32_t *)nullptr);
             break;
-        }
         case ML_PRE_PQ_ORDERING: {                                             // :5264-5275
-            PoolBlock b_J, b_p1, b_ip1, b_ip2;
-            ILUPP_HIP(b_J.alloc(sizeof(int32_t) * (size_t)n));
-            hipLaunchKernelGGL(k_ml_pq_candidates, dim3(gb), dim3(256), 0, st, n, A->ptr, A->idx, A->val, b_D.as<double>(), b_J.as<int32_t>());
-            std::vector<double> W((size_t)n);
-            std::vector<int32_t> J((size_t)n), I((size_t)n), ip1, ip2, p1((size_t)n), p2((size_t)n);
-            if (pq_ip1.empty()) {
-                // The candidates by increasing weight.  With all weights distinct the order is unique: a radix sort on the device, and only the
-                // sorted rows travel.  With equal weights (every interior row of a stencil matrix has the same) the order among them is whatever the
-                // reference's unstable quicksort (sparse_implementation.h:471-505) leaves -- then that algorithm runs, on the host.
-                PoolBlock b_W2, b_I, b_I2, b_flag, b_tmp;
+            if (!pq_done) {
+                PoolBlock b_J, b_W2, b_I, b_I2, b_flag, b_tmp, b_sel, b_rank, b_off;
+                ILUPP_HIP(b_J.alloc(sizeof(int32_t) * (size_t)n));
+                hipLaunchKernelGGL(k_ml_pq_candidates, dim3(gb), dim3(256), 0, st, n, A->ptr, A->idx, A->val, b_D.as<double>(), b_J.as<int32_t>());
+                // The candidates by increasing weight.  With all weights distinct the order is unique: a radix sort on the device.  With equal
+                // weights (every interior row of a stencil matrix has the same) the order among them is whatever the reference's unstable
+                // quicksort (sparse_implementation.h:471-505) leaves -- then that algorithm runs, on the host, on the n weights.
                 ILUPP_HIP(b_W2.alloc(sizeof(double) * (size_t)n));
                 ILUPP_HIP(b_I.alloc(sizeof(int32_t) * (size_t)n));
                 ILUPP_HIP(b_I2.alloc(sizeof(int32_t) * (size_t)n));
@@ -304,36 +333,47 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
                 hipLaunchKernelGGL(k_ml_sorted_ties, dim3(gb), dim3(256), 0, st, n, b_W2.as<double>(), b_flag.as<int32_t>());
                 int32_t ties = 0;
                 ILUPP_HIP(hipMemcpyAsync(&ties, b_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                ILUPP_HIP(hipMemcpyAsync(J.data(), b_J.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
                 ILUPP_HIP(hipStreamSynchronize(st));
-                if (!ties) {
-                    ILUPP_HIP(hipMemcpyAsync(W.data(), b_W2.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-                    ILUPP_HIP(hipMemcpyAsync(I.data(), b_I2.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-                    ILUPP_HIP(hipStreamSynchronize(st));
-                } else {
+                if (ties) {
+                    std::vector<double> W((size_t)n);
+                    std::vector<int32_t> I((size_t)n);
                     ILUPP_HIP(hipMemcpyAsync(W.data(), b_D.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
                     ILUPP_HIP(hipStreamSynchronize(st));
                     for (int32_t k = 0; k < n; ++k) I[(size_t)k] = k;
                     if (n > 0) ref_quicksort(W.data(), I.data(), 0, (long)n - 1);
+                    ILUPP_HIP(hipMemcpyAsync(b_W2.p, W.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+                    ILUPP_HIP(hipMemcpyAsync(b_I2.p, I.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+                    ILUPP_HIP(hipStreamSynchronize(st));
                 }
                 if (dbg) fprintf(stderr, "[ilupp] ml: PQ candidates sorted %s\n", ties ? "on the host (equal weights)" : "on the device");
-                (void)pq_select(n, W, I, J, IP.pq_threshold, ip1, ip2);
-                pq_ip1 = ip1; pq_ip2 = ip2;
-            } else { ip1 = pq_ip1; ip2 = pq_ip2; }
+                // the greedy selection, on the device (see k_ml_pq_first)
+                ILUPP_HIP(b_sel.alloc(sizeof(int32_t) * (size_t)(n + 1)));
+                ILUPP_HIP(b_rank.alloc(sizeof(int32_t) * (size_t)(n + 1)));
+                ILUPP_HIP(b_off.alloc(sizeof(int32_t) * (size_t)(n + 1)));
+                const double *W2 = b_W2.as<double>();
+                const int32_t *I2 = b_I2.as<int32_t>(), *J = b_J.as<int32_t>();
+                ILUPP_HIP(hipMemsetAsync(tmpi, 0x7f, sizeof(int32_t) * (size_t)n, st));                  // first[c] = 0x7f7f7f7f: nobody yet
+                ILUPP_HIP(hipMemsetAsync(ip1, 0xff, sizeof(int32_t) * (size_t)n, st));
+                ILUPP_HIP(hipMemsetAsync(ip2, 0xff, sizeof(int32_t) * (size_t)n, st));
+                hipLaunchKernelGGL(k_ml_pq_first, dim3(gb), dim3(256), 0, st, n, W2, I2, J, IP.pq_threshold, tmpi);
+                hipLaunchKernelGGL(k_ml_pq_sel, dim3(gb1), dim3(256), 0, st, n, W2, I2, J, IP.pq_threshold, tmpi, b_sel.as<int32_t>());
+                { const int rc = scan_i32(st, b_sel.as<int32_t>(), b_rank.as<int32_t>(), n + 1); if (rc) return rc; }
+                hipLaunchKernelGGL(k_ml_pq_assign, dim3(gb), dim3(256), 0, st, n, I2, J, b_sel.as<int32_t>(), b_rank.as<int32_t>(), ip1, ip2);
+                for (int32_t *ip : {ip1, ip2}) {
+                    hipLaunchKernelGGL(k_ml_flag_free, dim3(gb1), dim3(256), 0, st, n, ip, b_sel.as<int32_t>());
+                    { const int rc = scan_i32(st, b_sel.as<int32_t>(), b_off.as<int32_t>(), n + 1); if (rc) return rc; }
+                    hipLaunchKernelGGL(k_ml_pq_rest, dim3(gb), dim3(256), 0, st, n, ip, b_sel.as<int32_t>(), b_off.as<int32_t>(), b_rank.as<int32_t>());
+                }
+                hipLaunchKernelGGL(k_ml_invert_i32, dim3(gb), dim3(256), 0, st, n, ip1, p1);
+                hipLaunchKernelGGL(k_ml_invert_i32, dim3(gb), dim3(256), 0, st, n, ip2, p2);
+                ILUPP_HIP(hipStreamSynchronize(st));
+                pq_done = true;
+            }
+            // (a later PQ step of the same call: ip1 / ip2 / p1 / p2 still hold the first one's permutations)
             p1_filled = true;
-            for (int32_t i = 0; i < n; ++i) { p1[(size_t)ip1[(size_t)i]] = i; p2[(size_t)ip2[(size_t)i]] = i; }
-            ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
-            ILUPP_HIP(b_ip1.alloc(sizeof(int32_t) * (size_t)n));
-            ILUPP_HIP(b_ip2.alloc(sizeof(int32_t) * (size_t)n));
-            upload_i32(st, b_p1.as<int32_t>(), p1); upload_i32(st, b_ip1.as<int32_t>(), ip1); upload_i32(st, b_ip2.as<int32_t>(), ip2);
-            { const int rc = permute_matrix(st, A, b_p1.as<int32_t>(), b_ip1.as<int32_t>(), b_ip2.as<int32_t>()); if (rc) return rc; }
-            // P.compose_right(p1): P[i] = P[p1[i]]; the same for Q; then the inverses (:5269-5272)
-            std::vector<int32_t> H((size_t)n);
-            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = P[(size_t)p1[(size_t)i]];
-            P.swap(H);
-            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = Q[(size_t)p2[(size_t)i]];
-            Q.swap(H);
-            for (int32_t i = 0; i < n; ++i) { invP[(size_t)P[(size_t)i]] = i; invQ[(size_t)Q[(size_t)i]] = i; }
+            { const int rc = permute_matrix(st, A, p1, ip1, ip2); if (rc) return rc; }
+            compose_and_invert(st, n, P, invP, p1, tmpi);                      // P.compose_right(p1); Q.compose_right(p2); the inverses (:5269-5272)
+            compose_and_invert(st, n, Q, invQ, p2, tmpi);
             permuted_rows = permuted_cols = true;
             break;
         }
@@ -341,69 +381,58 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             // the matching is a sequential augmenting-path algorithm: the level's matrix goes to the host once, a permutation and two
             // scalings come back; scaling and permuting the matrix happen on the device
             const int64_t nnz = A->nnz;
-            std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), p1, ip1((size_t)n), ident((size_t)n);
+            std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), hp1, hip1((size_t)n);
             std::vector<double> hv((size_t)(nnz > 0 ? nnz : 1)), D1, D2;
-            ILUPP_HIP(hipMemcpyAsync(hp.data(), A->ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
-            if (nnz > 0) {
-                ILUPP_HIP(hipMemcpyAsync(hi.data(), A->idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
-                ILUPP_HIP(hipMemcpyAsync(hv.data(), A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+            if (!p1_filled) {
+                ILUPP_HIP(hipMemcpyAsync(hp.data(), A->ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+                if (nnz > 0) {
+                    ILUPP_HIP(hipMemcpyAsync(hi.data(), A->idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+                    ILUPP_HIP(hipMemcpyAsync(hv.data(), A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+                }
+                ILUPP_HIP(hipStreamSynchronize(st));
+                (void)pmwm_host(n, hp.data(), hi.data(), hv.data(), hp1, D1, D2);
+            } else {
+                hp1.resize((size_t)n);
+                for (int32_t i = 0; i < n; ++i) hp1[(size_t)i] = i;
+                D1.assign((size_t)n, 1.0); D2.assign((size_t)n, 1.0);
             }
-            ILUPP_HIP(hipStreamSynchronize(st));
-            if (!p1_filled) (void)pmwm_host(n, hp.data(), hi.data(), hv.data(), p1, D1, D2);
-            else { p1.resize((size_t)n); for (int32_t i = 0; i < n; ++i) p1[(size_t)i] = i; D1.assign((size_t)n, 1.0); D2.assign((size_t)n, 1.0); }
             p1_filled = true;
-            for (int32_t i = 0; i < n; ++i) { ip1[(size_t)p1[(size_t)i]] = i; ident[(size_t)i] = i; }
-            PoolBlock b_D2, b_p1, b_ip1, b_id;
+            for (int32_t i = 0; i < n; ++i) hip1[(size_t)hp1[(size_t)i]] = i;
+            PoolBlock b_D2;
             ILUPP_HIP(b_D2.alloc(sizeof(double) * (size_t)n));
-            ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
-            ILUPP_HIP(b_ip1.alloc(sizeof(int32_t) * (size_t)n));
-            ILUPP_HIP(b_id.alloc(sizeof(int32_t) * (size_t)n));
             ILUPP_HIP(hipMemcpyAsync(b_D.p, D1.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
             ILUPP_HIP(hipMemcpyAsync(b_D2.p, D2.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-            upload_i32(st, b_p1.as<int32_t>(), p1); upload_i32(st, b_ip1.as<int32_t>(), ip1); upload_i32(st, b_id.as<int32_t>(), ident);
+            upload_i32(st, hq, hp1); upload_i32(st, ihq, hip1);
             hipLaunchKernelGGL(k_ml_row_scale, dim3(gb), dim3(256), 0, st, n, A->ptr, A->val, b_D.as<double>());           // inverse_scale(D1, ROW)
             if (nnz > 0)
                 hipLaunchKernelGGL(k_ml_col_scale, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, A->idx, A->val, b_D2.as<double>());   // (D2, COLUMN)
-            { const int rc = permute_matrix(st, A, b_p1.as<int32_t>(), b_ip1.as<int32_t>(), b_id.as<int32_t>()); if (rc) return rc; }   // permute(p1, ROW)
-            const int32_t *inv = nullptr;
-            if (permuted_rows) { upload_i32(st, b_inv.as<int32_t>(), invP); inv = b_inv.as<int32_t>(); }
-            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), inv);
+            { const int rc = permute_matrix(st, A, hq, ihq, ident); if (rc) return rc; }                                    // permute(p1, ROW)
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), permuted_rows ? (const int32_t *)invP : (const int32_t *)nullptr);
+            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Dcol, b_D2.as<double>(), permuted_cols ? (const int32_t *)invQ : (const int32_t *)nullptr);
+            compose_and_invert(st, n, P, invP, hq, tmpi);                      // P.compose_right(p1); invP.invert(P)
             ILUPP_HIP(hipStreamSynchronize(st));
-            inv = nullptr;
-            if (permuted_cols) { upload_i32(st, b_inv.as<int32_t>(), invQ); inv = b_inv.as<int32_t>(); }
-            hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Dcol, b_D2.as<double>(), inv);
-            ILUPP_HIP(hipStreamSynchronize(st));
-            std::vector<int32_t> H((size_t)n);
-            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = P[(size_t)p1[(size_t)i]];                     // P.compose_right(p1); invP.invert(P)
-            P.swap(H);
-            for (int32_t i = 0; i < n; ++i) invP[(size_t)P[(size_t)i]] = i;
             permuted_rows = true;
             break;
         }
         case ML_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING:                             // :5309-5314 (Drow.multiply(D1) without a permutation, as there)
             hipLaunchKernelGGL(k_ml_unit_diag_scale, dim3(gb), dim3(256), 0, st, n, A->ptr, A->idx, A->val, b_D.as<double>());
             hipLaunchKernelGGL(k_ml_fold_scaling, dim3(gb), dim3(256), 0, st, n, Drow, b_D.as<double>(), (const int32_t *)nullptr);
-            ILUPP_HIP(hipStreamSynchronize(st));
             break;
         case ML_PRE_SPARSE_FIRST_ORDERING: {                                   // :5293-5299
-            PoolBlock b_cnt, b_id, b_ip2;
+            PoolBlock b_cnt;
             ILUPP_HIP(b_cnt.alloc(sizeof(int32_t) * (size_t)n));
             ILUPP_HIP(hipMemsetAsync(b_cnt.p, 0, sizeof(int32_t) * (size_t)n, st));
             if (A->nnz > 0)
                 hipLaunchKernelGGL(k_ml_col_counts, dim3((unsigned)((A->nnz + 255) / 256)), dim3(256), 0, st, A->nnz, A->idx, b_cnt.as<int32_t>());
-            std::vector<int32_t> cnt((size_t)n), p2, ip2((size_t)n), ident((size_t)n);
+            std::vector<int32_t> cnt((size_t)n), hp2, hip2((size_t)n);
             ILUPP_HIP(hipMemcpyAsync(cnt.data(), b_cnt.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
             ILUPP_HIP(hipStreamSynchronize(st));
-            sparse_first_host(n, cnt, p2);
-            for (int32_t i = 0; i < n; ++i) { ip2[(size_t)p2[(size_t)i]] = i; ident[(size_t)i] = i; }
-            ILUPP_HIP(b_id.alloc(sizeof(int32_t) * (size_t)n));
-            ILUPP_HIP(b_ip2.alloc(sizeof(int32_t) * (size_t)n));
-            upload_i32(st, b_id.as<int32_t>(), ident); upload_i32(st, b_ip2.as<int32_t>(), ip2);
-            { const int rc = permute_matrix(st, A, b_id.as<int32_t>(), b_id.as<int32_t>(), b_ip2.as<int32_t>()); if (rc) return rc; }   // permute(p2, COLUMN)
-            std::vector<int32_t> H((size_t)n);
-            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = Q[(size_t)p2[(size_t)i]];
-            Q.swap(H);
-            for (int32_t i = 0; i < n; ++i) invQ[(size_t)Q[(size_t)i]] = i;
+            sparse_first_host(n, cnt, hp2);
+            for (int32_t i = 0; i < n; ++i) hip2[(size_t)hp2[(size_t)i]] = i;
+            upload_i32(st, hq, hp2); upload_i32(st, ihq, hip2);
+            { const int rc = permute_matrix(st, A, ident, ident, ihq); if (rc) return rc; }                                  // permute(p2, COLUMN)
+            compose_and_invert(st, n, Q, invQ, hq, tmpi);
+            ILUPP_HIP(hipStreamSynchronize(st));
             permuted_cols = true;
             break;
         }
@@ -411,7 +440,7 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             const int64_t nnz = A->nnz;
             DevMat T;
             transpose_storage(st, *A, &T);
-            std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), tp((size_t)n + 1), ti((size_t)(nnz > 0 ? nnz : 1)), p1, ip1((size_t)n);
+            std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), tp((size_t)n + 1), ti((size_t)(nnz > 0 ? nnz : 1)), hp1, hip1((size_t)n);
             std::vector<double> hv((size_t)(nnz > 0 ? nnz : 1)), tv((size_t)(nnz > 0 ? nnz : 1));
             ILUPP_HIP(hipMemcpyAsync(hp.data(), A->ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
             ILUPP_HIP(hipMemcpyAsync(tp.data(), T.ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
@@ -423,24 +452,18 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             }
             ILUPP_HIP(hipStreamSynchronize(st));
             T.release();
-            if (!dd_move_corner_host(n, hp.data(), hi.data(), hv.data(), tp.data(), ti.data(), tv.data(), p1)) {
+            if (!dd_move_corner_host(n, hp.data(), hi.data(), hv.data(), tp.data(), ti.data(), tv.data(), hp1)) {
                 set_error("DD_SYMM_MOVE_CORNER_ORDERING_IM: the ordering rejects an index of this matrix, and the reference's result is then undefined (it refills its "
                           "container with stale flags, sparse_implementation.h:5014 / arrays_implementation.h:55-63, and returns indices that repeat): refused");
                 return ILUPP_ERR_UNSUPPORTED;
             }
             p1_filled = true;
-            for (int32_t i = 0; i < n; ++i) ip1[(size_t)p1[(size_t)i]] = i;
-            PoolBlock b_p1, b_ip1;
-            ILUPP_HIP(b_p1.alloc(sizeof(int32_t) * (size_t)n));
-            ILUPP_HIP(b_ip1.alloc(sizeof(int32_t) * (size_t)n));
-            upload_i32(st, b_p1.as<int32_t>(), p1); upload_i32(st, b_ip1.as<int32_t>(), ip1);
-            { const int rc = permute_matrix(st, A, b_p1.as<int32_t>(), b_ip1.as<int32_t>(), b_ip1.as<int32_t>()); if (rc) return rc; }     // permute(p1, p1)
-            std::vector<int32_t> H((size_t)n);
-            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = P[(size_t)p1[(size_t)i]];
-            P.swap(H);
-            for (int32_t i = 0; i < n; ++i) H[(size_t)i] = Q[(size_t)p1[(size_t)i]];
-            Q.swap(H);
-            for (int32_t i = 0; i < n; ++i) { invP[(size_t)P[(size_t)i]] = i; invQ[(size_t)Q[(size_t)i]] = i; }
+            for (int32_t i = 0; i < n; ++i) hip1[(size_t)hp1[(size_t)i]] = i;
+            upload_i32(st, hq, hp1); upload_i32(st, ihq, hip1);
+            { const int rc = permute_matrix(st, A, hq, ihq, ihq); if (rc) return rc; }     // permute(p1, p1)
+            compose_and_invert(st, n, P, invP, hq, tmpi);
+            compose_and_invert(st, n, Q, invQ, hq, tmpi);
+            ILUPP_HIP(hipStreamSynchronize(st));
             permuted_rows = permuted_cols = true;
             break;
         }
@@ -449,6 +472,7 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, std::
             return ILUPP_ERR_UNSUPPORTED;
         }
     }
+    ILUPP_HIP(hipStreamSynchronize(st));
     return ILUPP_OK;
 }
 
@@ -492,11 +516,8 @@ int ml_build(hipStream_t st, const DevMat &A, const MlParams &IP, std::vector<Ml
         l.n = m;
         ILUPP_HIP(pool_malloc(&l.Dl, sizeof(double) * (size_t)m));
         ILUPP_HIP(pool_malloc(&l.Dr, sizeof(double) * (size_t)m));
-        std::vector<int32_t> P, Q, invP, invQ;
-        { const int rc = preprocess_level(st, &Ak, IP, P, Q, invP, invQ, l.Dl, l.Dr); if (rc) return rc; }
         for (int32_t **d : {&l.pr, &l.pc, &l.ipr, &l.ipc}) ILUPP_HIP(pool_malloc(d, sizeof(int32_t) * (size_t)m));
-        upload_i32(st, l.pr, P); upload_i32(st, l.pc, Q); upload_i32(st, l.ipr, invP); upload_i32(st, l.ipc, invQ);
-        ILUPP_HIP(hipStreamSynchronize(st));
+        { const int rc = preprocess_level(st, &Ak, IP, l.pr, l.pc, l.ipr, l.ipc, l.Dl, l.Dr); if (rc) return rc; }
         if (!in_loop && IP.use_final_threshold) tau *= IP.final_threshold;     // :1580-1581
         DevMat Anext;
         int32_t kterm = m;
