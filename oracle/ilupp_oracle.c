@@ -1758,6 +1758,247 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
     return ORC_OK;
 }
 
+
+/* index_list::quicksort_with_inverse, sparse_implementation.h:6074-6100 */
+static void perm_quicksort_with_inverse(orc_int *p, orc_int *inv, orc_int left, orc_int right)
+{
+    orc_int i, j, m, t;
+    if (left < right) {
+        m = p[left]; i = left; j = right;
+        while (i <= j) {
+            while (p[i] < m) i++;
+            while (p[j] > m) j--;
+            if (i <= j) {
+                t = inv[p[i]]; inv[p[i]] = inv[p[j]]; inv[p[j]] = t;
+                t = p[i]; p[i] = p[j]; p[j] = t;
+                i++; j--;
+            }
+        }
+        perm_quicksort_with_inverse(p, inv, left, j);
+        perm_quicksort_with_inverse(p, inv, i, right);
+    }
+}
+
+static void links_reserve(orc_int **link, orc_int **who, orc_int *have, orc_int cap)
+{
+    if (cap > *have) {
+        *link = (orc_int *)realloc(*link, sizeof(orc_int) * (size_t)cap);
+        *who = (orc_int *)realloc(*who, sizeof(orc_int) * (size_t)cap);
+        *have = cap;
+    }
+}
+
+/* matrix_sparse::partialILUCDP, ILUCDP.hpp:268-1404 -- the Crout factorisation WITH column pivoting (the largest entry of the working
+ * row, by piv_tol) and with rows taken in the order of the number of entries they have in L so far -- for the parameter sets without
+ * inverse-based / weighted dropping, DROP_TYPE 0, SCHUR_COMPLEMENT 0, EXTERNAL_FINAL_ROW off, FINAL_ROW_CRIT -1..9.
+ * L: COLUMN, U: ROW (1 first), both in the PERMUTED numbering at the end (:1150-1151); perm / permrows: column / row taken at step k. */
+static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml_params *IP, int force_finish, double threshold,
+                          orc_int bp, orc_int bpr, orc_int epr, orc_mat *L, orc_mat *U, double *Dinv, orc_mat *Anew,
+                          orc_int *perm, orc_int *permrows, orc_int *inverse_perm, orc_int *inverse_permrows, orc_int *zero_pivots)
+{
+    const orc_int n = Arow->n;
+    const orc_int nnzA = Acol->ptr[n];
+    orc_int k, i, j, h, x, p, t, capL, capU, capA = 0, haveL = 0, haveU = 0;
+    orc_int last_row_to_eliminate = n - 1, n_Anew = 0, pos_pivot = -1, selected_row;
+    orc_int max_fill_in = IP->max_fill_in > 0 ? IP->max_fill_in : n;       /* :352-355 */
+    int eliminate = 1, end_level_now = 0;
+    double pivot = 0.0, piv_tol = IP->piv_tol, val_larg_el;
+    orc_int *linkU = NULL, *rowU = NULL, *startU, *linkL = NULL, *colL = NULL, *startL, *list_L, *list_U, *numb, *pnum;
+    char *non_pivot, *unused_rows;
+    wvec z, w;
+    if (max_fill_in < 1) max_fill_in = 1;
+    if (max_fill_in > n) max_fill_in = n;
+    if (epr < 0) epr = 0;                                                      /* :372-375 */
+    if (epr >= n) epr = n - 1;
+    if (bpr < 0) bpr = 0;
+    if (bpr >= n) bpr = n - 1;
+    *zero_pivots = 0;
+    capL = capU = nnzA + n + 16;
+    mat_init(L, n, capL, 0);
+    mat_init(U, n, capU, 1);
+    mat_init(Anew, 0, 1, 1);
+    links_reserve(&linkL, &colL, &haveL, capL);
+    links_reserve(&linkU, &rowU, &haveU, capU);
+    startU = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1)); startL = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    list_L = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16)); list_U = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16));
+    numb = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int)); pnum = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 2));
+    non_pivot = (char *)malloc((size_t)n + 1); unused_rows = (char *)malloc((size_t)n + 1);
+    for (k = 0; k < n; ++k) {
+        Dinv[k] = 1.0; perm[k] = permrows[k] = inverse_perm[k] = inverse_permrows[k] = k;     /* :408-413 */
+        non_pivot[k] = 1; unused_rows[k] = 1; startU[k] = -1; startL[k] = -1;
+    }
+    for (k = 0; k < n + 2; ++k) pnum[k] = epr + 1;                              /* :417, :437 */
+    pnum[0] = 0;
+    wv_init(&z, n, 0); wv_init(&w, n, 0);
+
+    for (k = 0; k < n; ++k) {
+        orc_int nL = 0, nU;
+        double weightL, weightU;
+        if (IP->begin_total_piv && k == bp) piv_tol = 1.0;                      /* :448 */
+        selected_row = permrows[k];                                            /* (2.) :453-466 */
+        unused_rows[selected_row] = 0;
+        wv_zero_reset(&z);
+        for (i = Arow->ptr[selected_row]; i < Arow->ptr[selected_row + 1]; ++i)
+            if (non_pivot[Arow->idx[i]]) z.data[wv_slot(&z, Arow->idx[i])] = Arow->val[i];
+        for (h = startL[selected_row]; h != -1; ) {                            /* (3.) :472-487 */
+            const orc_int c = colL[h];
+            const double lv = L->val[h];
+            h = linkL[h];
+            for (j = U->ptr[c]; j < U->ptr[c + 1]; ++j)
+                if (non_pivot[U->idx[j]]) { x = wv_slot(&z, U->idx[j]); z.data[x] -= lv / Dinv[c] * U->val[j]; }
+        }
+        if (eliminate) {                                                       /* the pivot, :540-558 */
+            double mx = 0.0;
+            val_larg_el = 0.0; pos_pivot = -1;                                 /* abs_max(pos), sparse_implementation.h:1109-1120 */
+            for (i = 0; i < z.nnz; ++i)
+                if (fabs(z.data[i]) > mx) { mx = fabs(z.data[i]); val_larg_el = z.data[i]; pos_pivot = z.pointer[i]; }
+            if (non_pivot[selected_row]) {
+                x = wv_slot(&z, selected_row);
+                if (fabs(val_larg_el * piv_tol) > fabs(z.data[x]) && pos_pivot >= 0 && IP->piv_tol > 0) pivot = val_larg_el;
+                else { pos_pivot = selected_row; pivot = z.data[x]; }
+            } else {
+                if (fabs(val_larg_el) > 0.0 && pos_pivot >= 0) pivot = val_larg_el;
+                else { pos_pivot = perm[k]; pivot = z.data[wv_slot(&z, pos_pivot)]; }
+            }
+        }
+        if (eliminate && !force_finish && (double)k > IP->min_elim_factor * (double)n && IP->small_pivot_terminates
+            && fabs(pivot) < IP->min_pivot) {                                  /* :595-612 */
+            eliminate = 0;
+            end_level_now = 1;
+            threshold *= IP->threshold_shift_schur;
+            last_row_to_eliminate = k - 1;
+            n_Anew = n - k;
+            orc_free_mat(Anew);
+            capA = nnzA + 16;
+            mat_init(Anew, n_Anew, capA, 1);
+        }
+        if (eliminate) {                                                       /* :613-629 */
+            Dinv[k] = 1.0 / pivot;
+            for (j = 0; j < z.nnz; ++j) z.data[j] *= Dinv[k];
+            z.data[wv_slot(&z, pos_pivot)] = 0.0;
+            p = inverse_perm[pos_pivot];
+            t = inverse_perm[perm[k]]; inverse_perm[perm[k]] = inverse_perm[pos_pivot]; inverse_perm[pos_pivot] = t;
+            t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+            non_pivot[pos_pivot] = 0;
+        }
+        wv_zero_reset(&w);                                                     /* :633-651 */
+        if (eliminate) {
+            const orc_int c = perm[k];
+            for (i = Acol->ptr[c]; i < Acol->ptr[c + 1]; ++i)
+                if (unused_rows[Acol->idx[i]]) w.data[wv_slot(&w, Acol->idx[i])] = Acol->val[i];
+            for (h = startU[c]; h != -1; ) {
+                const orc_int r = rowU[h];
+                const double uv = U->val[h];
+                h = linkU[h];
+                for (j = L->ptr[r]; j < L->ptr[r + 1]; ++j)
+                    if (unused_rows[L->idx[j]]) { x = wv_slot(&w, L->idx[j]); w.data[x] -= uv / Dinv[r] * L->val[j]; }
+            }
+        }
+        for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* :652 */
+        if (!eliminate) nU = take_largest(&z, list_U, max_fill_in, threshold, 0, n);      /* :714-716 */
+        else {
+            weightU = ml_weight(IP, &z, &w, Dinv[k]);
+            nU = take_single_weight(&z, list_U, weightU, max_fill_in - 1, threshold, 0, n);
+        }
+        if (eliminate) {                                                       /* :761-797 (the list backwards) */
+            if (U->ptr[k] + nU + 1 > capU) { mat_reserve(U, U->ptr[k] + nU + 1, &capU); links_reserve(&linkU, &rowU, &haveU, capU); }
+            U->val[U->ptr[k]] = 1.0; U->idx[U->ptr[k]] = pos_pivot;
+            for (j = 0; j < nU; ++j) {
+                const orc_int pos = U->ptr[k] + j + 1, c = list_U[nU - 1 - j];
+                U->val[pos] = z.data[z.occupancy[c]]; U->idx[pos] = c;
+                linkU[pos] = startU[c]; startU[c] = pos; rowU[pos] = k;
+            }
+            U->ptr[k + 1] = U->ptr[k] + nU + 1;
+            if (pivot == 0.0) { (*zero_pivots)++; Dinv[k] = 1.0; }
+        } else {                                                               /* :818-847 */
+            const orc_int k_Anew = k - last_row_to_eliminate - 1;
+            if (U->ptr[k] + 1 > capU) { mat_reserve(U, U->ptr[k] + 1, &capU); links_reserve(&linkU, &rowU, &haveU, capU); }
+            mat_reserve(Anew, Anew->ptr[k_Anew] + nU, &capA);
+            U->val[U->ptr[k]] = 1.0; Dinv[k] = 1.0; U->idx[U->ptr[k]] = perm[k];
+            U->ptr[k + 1] = U->ptr[k] + 1;
+            for (j = 0; j < nU; ++j) {
+                const orc_int c = list_U[nU - 1 - j];
+                Anew->val[Anew->ptr[k_Anew] + j] = z.data[z.occupancy[c]]; Anew->idx[Anew->ptr[k_Anew] + j] = c;
+            }
+            Anew->ptr[k_Anew + 1] = Anew->ptr[k_Anew] + nU;
+        }
+        if (eliminate) {                                                       /* L, :849-1005 */
+            weightL = ml_weight(IP, &w, &z, Dinv[k]);
+            nL = take_single_weight(&w, list_L, weightL, max_fill_in, threshold, 0, n);
+            if (L->ptr[k] + nL + 1 > capL) { mat_reserve(L, L->ptr[k] + nL + 1, &capL); links_reserve(&linkL, &colL, &haveL, capL); }
+            L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = selected_row;
+            for (j = 0; j < nL; ++j) {
+                const orc_int pos = L->ptr[k] + j + 1;
+                orc_int a, b = list_L[j];
+                L->val[pos] = w.data[w.occupancy[b]]; L->idx[pos] = b;
+                linkL[pos] = startL[b]; startL[b] = pos; colL[pos] = k;
+                if (b >= bpr && b <= epr) {                                    /* the rows by their number of entries in L, :964-970 */
+                    b = inverse_permrows[b];
+                    a = --pnum[++numb[b]];
+                    t = inverse_permrows[permrows[a]]; inverse_permrows[permrows[a]] = inverse_permrows[permrows[b]]; inverse_permrows[permrows[b]] = t;
+                    t = permrows[a]; permrows[a] = permrows[b]; permrows[b] = t;
+                    t = numb[a]; numb[a] = numb[b]; numb[b] = t;
+                }
+            }
+            if (pnum[numb[k] + 1] == k + 1)                                    /* :980-981 */
+                perm_quicksort_with_inverse(permrows, inverse_permrows, pnum[numb[k] + 1], pnum[numb[k] + 2] - 1);
+            L->ptr[k + 1] = L->ptr[k] + nL + 1;
+        } else {
+            if (L->ptr[k] + 1 > capL) { mat_reserve(L, L->ptr[k] + 1, &capL); links_reserve(&linkL, &colL, &haveL, capL); }
+            L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = selected_row;
+            L->ptr[k + 1] = L->ptr[k] + 1;
+        }
+        if (eliminate && !force_finish) {                                      /* the level ends by the fill of L, :1018-1092 */
+            if ((double)k > IP->min_elim_factor * (double)n) {
+                const double dens = (double)nnzA;
+                switch (IP->final_row_crit) {
+                case -1: if ((double)numb[k] > (IP->move_level_factor * dens) / (double)n) end_level_now = 1; break;
+                case 0: if ((double)numb[k] > (0.5 * dens) / (double)n) end_level_now = 1; break;
+                case 1: if ((double)numb[k] > dens / (double)n) end_level_now = 1; break;
+                case 2: if ((double)numb[k] > (2.0 * dens) / (double)n) end_level_now = 1; break;
+                case 3: if ((double)numb[k] > (4.0 * dens) / (double)n) end_level_now = 1; break;
+                case 4: if ((double)numb[k] > (6.0 * dens) / (double)n) end_level_now = 1; break;
+                case 5: if (numb[k] > 10) end_level_now = 1; break;
+                case 6: if ((double)numb[k] > (1.5 * dens) / (double)n) end_level_now = 1; break;
+                case 7: if (wv_norm2(&z) > IP->row_u_max) end_level_now = 1; break;
+                case 8: if ((double)numb[k] > (3.0 * dens) / (double)n) end_level_now = 1; break;
+                case 9: if ((double)numb[k] > (1.2 * dens) / (double)n) end_level_now = 1; break;
+                default: break;
+                }
+            }
+            if (end_level_now) {
+                eliminate = 0;
+                threshold *= IP->threshold_shift_schur;
+                last_row_to_eliminate = k;
+                n_Anew = n - k - 1;
+                orc_free_mat(Anew);
+                capA = nnzA + 16;
+                mat_init(Anew, n_Anew, capA, 1);
+            }
+        }
+    }
+    L->nnz = L->ptr[n]; U->nnz = U->ptr[n];
+    mat_compress(L, 0.0);                                                      /* :1131-1132 */
+    mat_compress(U, 0.0);
+    if (eliminate) { orc_free_mat(Anew); mat_init(Anew, 0, 1, 1); }
+    else {
+        Anew->nnz = Anew->ptr[n_Anew];
+        if (Anew->nnz > 0) {                                                   /* :1136-1145 */
+            mat_compress(Anew, 0.0);
+            for (j = 0; j < Anew->nnz; ++j) Anew->idx[j] = inverse_perm[Anew->idx[j]] - last_row_to_eliminate - 1;
+            mat_normal_order(Anew);
+        }
+    }
+    for (j = 0; j < L->nnz; ++j) L->idx[j] = inverse_permrows[L->idx[j]];      /* permute(permrows, ROW): against the orientation, :5486-5497 */
+    mat_normal_order(L);
+    for (j = 0; j < U->nnz; ++j) U->idx[j] = inverse_perm[U->idx[j]];          /* U.permute(perm, COLUMN) */
+    mat_normal_order(U);
+    wv_free(&z); wv_free(&w);
+    free(linkU); free(rowU); free(startU); free(linkL); free(colL); free(startL); free(list_L); free(list_U); free(numb); free(pnum);
+    free(non_pivot); free(unused_rows);
+    return ORC_OK;
+}
+
 static void ml_level_free(struct orc_ml_level *l)
 {
     orc_free_mat(&l->L); orc_free_mat(&l->U);
@@ -1796,6 +2037,8 @@ void orc_ml_default_params(orc_ml_params *p)       /* default_parameters (:430-5
     p->neutral_element = 0.0;
     p->min_weight = 1.0;
     p->scale_weight_invdiag = 0;
+    p->piv_tol = 0.0; p->permute_rows = 0; p->total_piv = 0; p->begin_total_piv = 1;      /* init case 10 */
+    p->final_row_crit = -1; p->move_level_factor = 2.0; p->row_u_max = 1.5;
 }
 
 /* make_preprocessed_multilevelILUCDP, preconditioner_implementation.h:1350-1665, use_ILUC branch */
@@ -1806,6 +2049,8 @@ int orc_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
     double tau = IP->threshold;
     orc_int matrix_size, nonzeroes;
     int cap = IP->max_levels > 0 ? IP->max_levels + 1 : 1;
+    /* :1376-1382 (EXTERNAL_FINAL_ROW is off here) */
+    const int use_iluc = (IP->permute_rows == 0 || IP->permute_rows == 1) && (!IP->begin_total_piv || IP->total_piv == 0) && IP->piv_tol == 0.0;
     *out = NULL;
     view.n = n; view.nnz = ptr[n]; view.ptr = (orc_int *)ptr; view.idx = (orc_int *)idx; view.val = (double *)val; view.is_csr = is_csr;
     if (is_csr) mat_copy(&Ak, &view);
@@ -1830,7 +2075,35 @@ int orc_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
         rc = mat_preprocess(&Ak, IP, l->perm_rows, l->perm_cols, l->inv_perm_rows, l->inv_perm_cols, l->D_l, l->D_r, &bad_at);
         if (rc != ORC_OK) { P->nlevels++; orc_free_mat(&Ak); orc_ml_free(P); return rc; }
         if (!in_loop && IP->use_final_threshold) tau *= IP->final_threshold;   /* :1580-1581 */
-        rc = partial_iluc(&Ak, IP, in_loop ? 0 : 1, tau, &l->L, &l->U, l->D, &Anext, &l->zero_pivots);
+        if (use_iluc) rc = partial_iluc(&Ak, IP, in_loop ? 0 : 1, tau, &l->L, &l->U, l->D, &Anext, &l->zero_pivots);
+        else {
+            /* the windows of the pivoting and of the row reordering, :1442-1459 (a level of the loop) / :1564-1577 (the last one) */
+            const orc_int last_row_to_eliminate = in_loop ? (m - 1) / 2 : m - 1;
+            orc_int bp, bpr, epr, i;
+            orc_int *pc2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)m), *pr2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)m);
+            orc_int *ipc2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)m), *ipr2 = (orc_int *)malloc(sizeof(orc_int) * (size_t)m);
+            orc_mat Acol;
+            switch (IP->permute_rows) {
+            case 0: bpr = 0; epr = 0; break;
+            case 1: bpr = bad_at; epr = m - 1; break;
+            case 2: bpr = 0; epr = in_loop ? last_row_to_eliminate : m - 1; break;
+            default: bpr = 0; epr = m - 1; break;
+            }
+            switch (IP->total_piv) {
+            case 0: bp = m; break;
+            case 1: bp = in_loop ? last_row_to_eliminate + 1 : bad_at; break;
+            default: bp = 0; break;
+            }
+            mat_change_orientation(&Ak, &Acol);
+            rc = partial_ilucdp(&Ak, &Acol, IP, in_loop ? 0 : 1, tau, bp, bpr, epr, &l->L, &l->U, l->D, &Anext, pc2, pr2, ipc2, ipr2, &l->zero_pivots);
+            orc_free_mat(&Acol);
+            /* permutation_columns.compose(pc1, pc2), permutation_rows.compose(pr1, pr2) and their inverses, :1516-1521 */
+            for (i = 0; i < m; ++i) { ipc2[i] = l->perm_cols[pc2[i]]; ipr2[i] = l->perm_rows[pr2[i]]; }
+            for (i = 0; i < m; ++i) { l->perm_cols[i] = ipc2[i]; l->perm_rows[i] = ipr2[i]; }
+            perm_invert(l->inv_perm_cols, l->perm_cols, m);
+            perm_invert(l->inv_perm_rows, l->perm_rows, m);
+            free(pc2); free(pr2); free(ipc2); free(ipr2);
+        }
         P->nlevels++;
         if (rc != ORC_OK) { orc_free_mat(&Ak); orc_free_mat(&Anext); orc_ml_free(P); return rc; }
         orc_free_mat(&Ak);

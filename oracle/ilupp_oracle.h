@@ -122,6 +122,15 @@ typedef struct {
     int combine_factor;                  /* COMBINE_FACTOR */
     double neutral_element, min_weight;  /* NEUTRAL_ELEMENT, MIN_WEIGHT */
     int scale_weight_invdiag;            /* SCALE_WEIGHT_INVDIAG */
+    /* the factorisation WITH pivoting (partialILUCDP, ILUCDP.hpp:268-1404) is taken unless PERMUTE_ROWS is 0 (or 1), TOTAL_PIV is off
+     * and piv_tol is 0 (preconditioner_implementation.h:1376-1382) */
+    double piv_tol;                      /* piv_tol */
+    int permute_rows;                    /* PERMUTE_ROWS 0..3 */
+    int total_piv;                       /* TOTAL_PIV 0..2 */
+    int begin_total_piv;                 /* BEGIN_TOTAL_PIV */
+    int final_row_crit;                  /* FINAL_ROW_CRIT -1..9 (the ones that count the entries of a row of L) */
+    double move_level_factor;            /* MOVE_LEVEL_FACTOR */
+    double row_u_max;                    /* ROW_U_MAX */
 } orc_ml_params;
 
 typedef struct orc_ml orc_ml;

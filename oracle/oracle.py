@@ -46,7 +46,13 @@ class MLParams(ctypes.Structure):
                 ("drop_rules", ctypes.c_int), ("weight_standard_drop", ctypes.c_double), ("weight_standard_drop2", ctypes.c_double),
                 ("weight_err_prop_drop", ctypes.c_double), ("weight_err_prop_drop2", ctypes.c_double), ("weight_pivot_drop", ctypes.c_double),
                 ("combine_factor", ctypes.c_int), ("neutral_element", ctypes.c_double), ("min_weight", ctypes.c_double),
-                ("scale_weight_invdiag", ctypes.c_int)]
+                ("scale_weight_invdiag", ctypes.c_int),
+                ("piv_tol", ctypes.c_double), ("permute_rows", ctypes.c_int), ("total_piv", ctypes.c_int), ("begin_total_piv", ctypes.c_int),
+                ("final_row_crit", ctypes.c_int), ("move_level_factor", ctypes.c_double), ("row_u_max", ctypes.c_double)]
+
+
+# the reference's default-constructed parameters (precon_parameter 0: the factorisation WITH pivoting), parameters_implementation.h:430-501
+PIVOTING_DEFAULTS = dict(small_pivot_terminates=0, min_elim_factor=0.5, piv_tol=1.0, permute_rows=3, total_piv=1, begin_total_piv=1)
 
 
 class _MLView(ctypes.Structure):

@@ -293,6 +293,13 @@ int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
     param.set_WEIGHT_PIVOT_DROP(IP->weight_pivot_drop);
     param.set_COMBINE_FACTOR(IP->combine_factor); param.set_NEUTRAL_ELEMENT(IP->neutral_element); param.set_MIN_WEIGHT(IP->min_weight);
     param.set_SCALE_WEIGHT_INVDIAG(IP->scale_weight_invdiag != 0);
+    param.set_piv_tol(IP->piv_tol);
+    param.set_PERMUTE_ROWS(IP->permute_rows);
+    param.set_TOTAL_PIV(IP->total_piv);
+    param.set_BEGIN_TOTAL_PIV(IP->begin_total_piv != 0);
+    param.set_FINAL_ROW_CRIT(IP->final_row_crit);
+    param.set_MOVE_LEVEL_FACTOR(IP->move_level_factor);
+    param.set_ROW_U_MAX(IP->row_u_max);
     ref_ml *R = new ref_ml;
     R->n = n;
     try {
