@@ -1409,6 +1409,13 @@ int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
     P.pil.wgt[0] = ip->weight_standard_drop; P.pil.wgt[1] = ip->weight_standard_drop2; P.pil.wgt[2] = ip->weight_err_prop_drop;
     P.pil.wgt[3] = ip->weight_err_prop_drop2; P.pil.wgt[4] = ip->weight_pivot_drop;
     P.pil.neutral = ip->neutral_element; P.pil.min_weight = ip->min_weight;
+    P.pil.piv_tol = ip->piv_tol; P.pil.permute_rows = ip->permute_rows; P.pil.total_piv = ip->total_piv; P.pil.begin_total_piv = ip->begin_total_piv != 0;
+    P.pil.final_row_crit = ip->final_row_crit; P.pil.move_level_factor = ip->move_level_factor; P.pil.row_u_max = ip->row_u_max;
+    if (P.pil.permute_rows < 0 || P.pil.permute_rows > 3 || P.pil.total_piv < 0 || P.pil.total_piv > 2) { set_error("ILU++: PERMUTE_ROWS / TOTAL_PIV out of range"); return ILUPP_ERR_INVALID; }
+    if (P.pil.pivoting() && (P.pil.final_row_crit < -1 || P.pil.final_row_crit > 9)) {
+        set_error("ILU++: FINAL_ROW_CRIT " + std::to_string(P.pil.final_row_crit) + " (rows ordered by weights instead of counts) is not built");
+        return ILUPP_ERR_UNSUPPORTED;
+    }
     if ((P.pil.rules & ~31) != 0) { set_error("ILU++: unknown dropping rule"); return ILUPP_ERR_INVALID; }
     struct MlGuard { ilupp_ml *m; ~MlGuard() { if (m) ml_destroy(m); } } g{new ilupp_ml()};
     ilupp_ml *m = g.m;
@@ -1470,6 +1477,8 @@ void ilupp_hip_ml_default_params(ilupp_ml_params *p)
     p->drop_rules = ILUPP_DROP_ERR_PROP;
     p->weight_standard_drop = p->weight_standard_drop2 = p->weight_err_prop_drop = p->weight_err_prop_drop2 = p->weight_pivot_drop = 1.0;
     p->combine_factor = 0; p->neutral_element = 0.0; p->min_weight = 1.0; p->scale_weight_invdiag = 0;
+    p->piv_tol = 0.0; p->permute_rows = 0; p->total_piv = 0; p->begin_total_piv = 1;        // (init case 10, :927-934)
+    p->final_row_crit = -1; p->move_level_factor = 2.0; p->row_u_max = 1.5;
 }
 
 int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const ilupp_ml_params *params,

@@ -329,10 +329,24 @@ struct PilucParams {
     bool scale_invdiag = false;           // SCALE_WEIGHT_INVDIAG
     double wgt[5] = {1.0, 1.0, 1.0, 1.0, 1.0};   // WEIGHT_STANDARD_DROP, _DROP2, WEIGHT_ERR_PROP_DROP, _DROP2, WEIGHT_PIVOT_DROP
     double neutral = 0.0, min_weight = 1.0;      // NEUTRAL_ELEMENT, MIN_WEIGHT
+    // the factorisation with pivoting (pilucdp.hip)
+    double piv_tol = 0.0;                 // piv_tol
+    int32_t permute_rows = 0, total_piv = 0;     // PERMUTE_ROWS, TOTAL_PIV
+    bool begin_total_piv = true;          // BEGIN_TOTAL_PIV
+    int32_t final_row_crit = -1;          // FINAL_ROW_CRIT
+    double move_level_factor = 2.0, row_u_max = 1.5;     // MOVE_LEVEL_FACTOR, ROW_U_MAX
+    // preconditioner_implementation.h:1376-1382 (EXTERNAL_FINAL_ROW off)
+    bool pivoting() const { return !((permute_rows == 0 || permute_rows == 1) && (!begin_total_piv || total_piv == 0) && piv_tol == 0.0); }
 };
 enum { PILUC_DROP_STANDARD = 1, PILUC_DROP_STANDARD2 = 2, PILUC_DROP_ERR_PROP = 4, PILUC_DROP_ERR_PROP2 = 8, PILUC_DROP_PIVOT = 16 };   // = ILUPP_DROP_*
 int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv, DevMat *Anew,
                 int32_t *kterm, float *kernel_ms);
+
+// pilucdp.hip: one level WITH pivoting (reference partialILUCDP, ILUCDP.hpp:268-1404): a sequential algorithm -- every step picks its
+// column by the values of the step and its row by the fill so far -- run by one wave; pc2 / pr2 (device, n entries): the column / row
+// taken at step k
+int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, int32_t bp, int32_t bpr, int32_t epr,
+                  DevMat *L, DevMat *U, double **Dinv, DevMat *Anew, int32_t *pc2, int32_t *pr2, float *kernel_ms);
 
 // ml.hip: the multilevel preconditioner built from such levels (reference preconditioner_implementation.h:1350-1665, :433-488)
 enum { ML_PRE_NORMALIZE_COLUMNS = 1, ML_PRE_NORMALIZE_ROWS = 2, ML_PRE_PQ_ORDERING = 3, ML_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,

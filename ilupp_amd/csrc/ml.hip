@@ -270,7 +270,8 @@ __global__ void k_ml_pq_rest(int32_t n, int32_t *__restrict__ ip, const int32_t 
 
 // matrix_sparse::preprocess (:5214-5460) for the steps this build has; A: ROW storage, replaced by the preprocessed matrix.
 // P, Q, invP, invQ (permutation_rows / _columns of the level and their inverses), Drow, Dcol: device arrays of n entries.
-static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32_t *P, int32_t *Q, int32_t *invP, int32_t *invQ, double *Drow, double *Dcol)
+static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32_t *P, int32_t *Q, int32_t *invP, int32_t *invQ, double *Drow, double *Dcol,
+                            int32_t *bad_at)
 {
     const int32_t n = A->n;
     const int gb = (n + 255) / 256, gb1 = (n + 1 + 255) / 256;
@@ -281,6 +282,7 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
     // column "matched", finds no augmenting path and returns the identity with unit scalings (pmwm_implementation.h:411, :460-471);
     // a second PQ step finds everything "taken" and returns the first one's permutations again (:4580-4581, :4613).  Kept as it behaves.
     bool p1_filled = false, pq_done = false;
+    *bad_at = n;                                                               // preprocessing_bad_at: what the call returns (:5221, :5459)
     hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Drow, 1.0);
     hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, Dcol, 1.0);
     PoolBlock b_D, b_tmpi, b_p1, b_ip1, b_p2, b_ip2, b_id, b_h, b_ih;
@@ -296,6 +298,7 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
             ~StepTimer() { if (on) { (void)hipStreamSynchronize(st); fprintf(stderr, "[ilupp] ml: preprocessing step %d: %.2f ms\n", step,
                                                                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } }
         } timer{dbg, IP.pre[s], std::chrono::steady_clock::now(), st};
+        if (IP.pre[s] != ML_PRE_PQ_ORDERING) *bad_at = n;
         switch (IP.pre[s]) {
         case ML_PRE_NORMALIZE_COLUMNS: {                                       // :5241-5246
             DevMat T;
@@ -366,9 +369,10 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
                 }
                 hipLaunchKernelGGL(k_ml_invert_i32, dim3(gb), dim3(256), 0, st, n, ip1, p1);
                 hipLaunchKernelGGL(k_ml_invert_i32, dim3(gb), dim3(256), 0, st, n, ip2, p2);
+                ILUPP_HIP(hipMemcpyAsync(bad_at, b_rank.as<int32_t>() + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));     // the number taken (:4635)
                 ILUPP_HIP(hipStreamSynchronize(st));
                 pq_done = true;
-            }
+            } else *bad_at = 0;                                                // (the repeated call finds nothing to take: count = -1, returns pos + 1 = 0)
             // (a later PQ step of the same call: ip1 / ip2 / p1 / p2 still hold the first one's permutations)
             p1_filled = true;
             { const int rc = permute_matrix(st, A, p1, ip1, ip2); if (rc) return rc; }
@@ -517,12 +521,40 @@ int ml_build(hipStream_t st, const DevMat &A, const MlParams &IP, std::vector<Ml
         ILUPP_HIP(pool_malloc(&l.Dl, sizeof(double) * (size_t)m));
         ILUPP_HIP(pool_malloc(&l.Dr, sizeof(double) * (size_t)m));
         for (int32_t **d : {&l.pr, &l.pc, &l.ipr, &l.ipc}) ILUPP_HIP(pool_malloc(d, sizeof(int32_t) * (size_t)m));
-        { const int rc = preprocess_level(st, &Ak, IP, l.pr, l.pc, l.ipr, l.ipc, l.Dl, l.Dr); if (rc) return rc; }
+        int32_t end_PQ = m;
+        { const int rc = preprocess_level(st, &Ak, IP, l.pr, l.pc, l.ipr, l.ipc, l.Dl, l.Dr, &end_PQ); if (rc) return rc; }
         if (!in_loop && IP.use_final_threshold) tau *= IP.final_threshold;     // :1580-1581
         DevMat Anext;
         int32_t kterm = m;
         const auto tl0 = std::chrono::steady_clock::now();
-        const int rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+        int rc;
+        if (!IP.pil.pivoting()) rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+        else {
+            // the windows of the pivoting and of the row reordering, :1442-1459 (a level of the loop) / :1564-1577 (the last one)
+            const int32_t last_row_to_eliminate = in_loop ? (m - 1) / 2 : m - 1;
+            int32_t bp, bpr, epr;
+            switch (IP.pil.permute_rows) {
+            case 0: bpr = 0; epr = 0; break;
+            case 1: bpr = end_PQ; epr = m - 1; break;
+            case 2: bpr = 0; epr = in_loop ? last_row_to_eliminate : m - 1; break;
+            default: bpr = 0; epr = m - 1; break;
+            }
+            switch (IP.pil.total_piv) {
+            case 0: bp = m; break;
+            case 1: bp = in_loop ? last_row_to_eliminate + 1 : end_PQ; break;
+            default: bp = 0; break;
+            }
+            PoolBlock b_p;
+            ILUPP_HIP(b_p.alloc(sizeof(int32_t) * (size_t)m * 3));
+            int32_t *pc2 = b_p.as<int32_t>(), *pr2 = pc2 + m, *tmp = pr2 + m;
+            rc = pilucdp_level(st, Ak, IP.pil, !in_loop, tau, bp, bpr, epr, &l.L, &l.U, &l.D, &Anext, pc2, pr2, kernel_ms);
+            if (rc == ILUPP_OK) {
+                // permutation_columns.compose(pc1, pc2), permutation_rows.compose(pr1, pr2) and their inverses, :1516-1521
+                compose_and_invert(st, m, l.pc, l.ipc, pc2, tmp);
+                compose_and_invert(st, m, l.pr, l.ipr, pr2, tmp);
+                ILUPP_HIP(hipStreamSynchronize(st));
+            }
+        }
         if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ml: level %d (n %d): factorisation %.2f ms\n", nlev, m,
                                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
         if (rc) { Anext.release(); return rc; }

@@ -1,0 +1,607 @@
+// ilupp_amd/csrc/pilucdp.hip -- one level of the multilevel ILU++ preconditioner WITH pivoting (gfx950).
+//
+// Reference: matrix_sparse::partialILUCDP, ILUCDP.hpp:268-1404 (called from make_preprocessed_multilevelILUCDP,
+// preconditioner_implementation.h:1483-1494 / :1614-1625, whenever the parameters ask for row reordering, total pivoting or a
+// pivot tolerance -- the reference's default-constructed parameters do).  Crout's form of LDU: step k computes row k of U and
+// column k of L; the COLUMN eliminated in step k is the largest entry of the working row (if it beats the diagonal by piv_tol),
+// the ROW of step k + 1 is the one with the fewest entries in L so far (FINAL_ROW_CRIT -1..9), and the level ends when a row of
+// L has grown past MOVE_LEVEL_FACTOR times the mean row length of A (or at a small pivot).  Every one of these choices depends
+// on the values computed in the step before it: the algorithm is a chain of n steps, and there is nothing to run beside it --
+// no ready queue, no level schedule (piluc_df.hip has those, for the parameter family that fixes rows and columns beforehand).
+//
+// What the GPU can do is the work INSIDE a step, and that is how this kernel is laid out: ONE WAVE walks the chain; its 64 lanes
+//   * subtract a row of U from the working row z (a column of L from w): one entry per lane, new indices appended in entry order
+//     by ballot / prefix count (= the reference's insertion order, which its norms, its pivot search and its selection depend on),
+//   * search the pivot (first largest magnitude in insertion order: per-lane first maximum, then a (magnitude, slot) reduction),
+//   * scale, collect the candidates of the dropping rule in insertion order, sort the kept ones by index (bitonic, 64-bit keys),
+//   * write the row / column and thread it into the column / row lists,
+// and only what is order-dependent arithmetic stays sequential: the 1-norm / 2-norm sums (in insertion order, as the reference
+// adds them), the selection of the largest entries under a bounded fill (the reference's own partial sort, select_largest), and
+// the bucket moves that keep the rows ordered by their number of entries in L.
+// State: everything lives in HBM / L2 (dense value arrays by index + slot lists; the two factor stores with their link arrays);
+// LDS holds nothing, the kernel is bound by the latency of its dependent loads (a step is a few dozen round trips).
+// Afterwards, grid-wide kernels drop the explicit zeros (compress(), :1131-1132), renumber rows and columns by the inverse
+// permutations and sort every row / column (permute(), :1150-1151; Anew: :1136-1145) with one radix sort per matrix.
+#include <stdlib.h>
+
+#include <chrono>
+
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "piluc_dev.h"
+
+namespace ilupp {
+
+struct DpArgs {
+    int32_t n;
+    const int32_t *Ap, *Ai; const double *Av;          // the level's matrix by rows
+    const int32_t *Cp, *Ci; const double *Cv;          // ... and by columns
+    double threshold, shift_schur, min_pivot, min_elim_factor, piv_tol, move_level_factor, row_u_max;
+    int32_t small_pivot_terminates, force_finish, begin_total_piv, final_row_crit, bp, bpr, epr, max_fill;
+    int32_t rules, combine, scale_invdiag;
+    double wgt[5], neutral, min_weight;
+    int32_t *perm, *iperm, *prow, *iprow, *numb, *pnum;
+    int32_t *nonpiv, *unused;
+    double *Dinv;
+    int32_t *Uptr, *Uidx, *linkU, *rowU, *startU; double *Uval; int32_t capU;
+    int32_t *Lptr, *Lidx, *linkL, *colL, *startL; double *Lval; int32_t capL;
+    int32_t *Sptr, *Sidx; double *Sval; int32_t capS;   // the Schur complement's rows as they come (column indices of this level)
+    double *zval, *wval; int32_t *zpos, *zlist, *wpos, *wlist;
+    double *key; int32_t *cand; unsigned long long *sortk;
+    int32_t *ctrl;     // [0] status (0 ok; 1 / 2 / 3: the store of U / L / the Schur complement is full), [1] last_row_to_eliminate, [2] n_Anew,
+                       // [3] zero pivots, [4] eliminated to the end, [5] step reached
+};
+
+struct SpVec { double *val; int32_t *pos; int32_t *list; };      // value by index, index -> slot (or -1), slot -> index (insertion order)
+
+#define DP_SYNC() do { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); } while (0)
+
+// sum of |x| (mode 0) or x * x (mode 1) over the slots IN ORDER (vector_sparse_dynamic::norm1 / norm2, sparse_implementation.h:1074-1085):
+// 64 values per pass, one per lane, added one after the other
+__device__ double dp_seq_sum(const SpVec &v, int nnz, int mode, int lane)
+{
+    double acc = 0.0;
+    for (int base = 0; base < nnz; base += 64) {
+        const int s = base + lane;
+        const double x = s < nnz ? v.val[v.list[s]] : 0.0;
+        const double t = mode == 0 ? fabs(x) : x * x;
+        const int cnt = nnz - base < 64 ? nnz - base : 64;
+        for (int i = 0; i < cnt; ++i) { const double ti = __shfl(t, i); acc = acc + ti; }
+    }
+    return acc;
+}
+
+// combine() and the weight of a row of U / a column of L, ILUCDP.hpp:717-726 / :905-914 (parameters_implementation.h:526-534)
+__device__ double dp_weight(const DpArgs &A, double n2own, double n1other, double dinv)
+{
+    double w = A.neutral;
+    auto comb = [&](double x, double y) {
+        switch (A.combine) {
+        case 1: return x + y;
+        case 2: return x * y;
+        case 3: { const double m = x < y ? y : x; return A.min_weight < m ? m : A.min_weight; }
+        default: return x < y ? y : x;
+        }
+    };
+    if (A.rules & PILUC_DROP_STANDARD) { const double norm = n2own == 0.0 ? 1e-16 : n2own; w = comb(w, A.wgt[0] / norm); }
+    if (A.rules & PILUC_DROP_STANDARD2) w = comb(w, A.wgt[1]);
+    if (A.rules & PILUC_DROP_ERR_PROP) w = comb(w, A.wgt[2] * n1other);
+    if (A.rules & PILUC_DROP_ERR_PROP2) w = comb(w, A.wgt[3] * n1other / fabs(dinv));
+    if (A.rules & PILUC_DROP_PIVOT) w = comb(w, A.wgt[4] * fabs(dinv));
+    if (A.scale_invdiag) w = w * fabs(dinv);
+    return w;
+}
+
+// the entries that pass the dropping rule, in insertion order (take_single_weight_largest_elements_by_abs_value_with_threshold,
+// sparse_implementation.h:1360-1415: weight * |x| >= tau; take_largest_elements_by_abs_value_with_threshold, :1322-1357: |x| > norm * tau),
+// at most `limit` of them (the largest keys, by the reference's selection), ascending by index in cand[0 .. return)
+__device__ int dp_take(const DpArgs &A, const SpVec &v, int nnz, bool single, double weight, double thr, int limit, int lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cnt = 0;
+    for (int base = 0; base < nnz; base += 64) {
+        const int s = base + lane;
+        const bool act = s < nnz;
+        const int idx = act ? v.list[s] : 0;
+        const double x = act ? v.val[idx] : 0.0;
+        const double kx = single ? weight * fabs(x) : fabs(x);
+        const bool ok = act && (single ? kx >= thr : kx > thr);
+        const unsigned long long mask = __ballot(ok);
+        if (ok) { const int p = cnt + __popcll(mask & lt); A.cand[p] = idx; A.key[p] = kx; }
+        cnt += __popcll(mask);
+    }
+    int off = 0;
+    if (cnt > limit) {
+        DP_SYNC();
+        if (lane == 0 && limit > 0) select_largest(A.key, A.cand, 0, cnt - 1, limit);
+        off = cnt - limit;
+    }
+    DP_SYNC();
+    const int nk = cnt - off;
+    int N = 64;
+    while (N < nk) N *= 2;
+    for (int i = lane; i < N; i += 64) A.sortk[i] = i < nk ? (unsigned long long)(unsigned)A.cand[off + i] : ~0ull;
+    DP_SYNC();
+    wave_sort_u64<true>(A.sortk, N, lane);
+    for (int i = lane; i < nk; i += 64) A.cand[i] = (int)(unsigned)A.sortk[i];
+    DP_SYNC();
+    return nk;
+}
+
+// v[idx] exists afterwards (operator[] inserts a zero, sparse_implementation.h:980-994)
+__device__ __forceinline__ void dp_touch(const SpVec &v, int &nnz, int idx, int lane)
+{
+    if (v.pos[idx] < 0) {
+        if (lane == 0) { v.list[nnz] = idx; v.pos[idx] = nnz; v.val[idx] = 0.0; }
+        ++nnz;
+        DP_SYNC();
+    }
+}
+
+// v -= f * (the entries e0 .. e1 of a stored row / column) where `live` allows, new indices appended in entry order
+__device__ __forceinline__ void dp_subtract(const SpVec &v, int &nnz, double f, const int32_t *idx, const double *val, int e0, int e1, const int32_t *live, int lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = e0; base < e1; base += 64) {
+        const int e = base + lane;
+        const bool act = e < e1;
+        const int c = act ? idx[e] : 0;
+        const bool ok = act && live[c] != 0;
+        const int sl = ok ? v.pos[c] : 0;
+        const bool isnew = ok && sl < 0;
+        const unsigned long long mask = __ballot(isnew);
+        double cur = 0.0;
+        if (isnew) { const int s = nnz + __popcll(mask & lt); v.list[s] = c; v.pos[c] = s; }
+        else if (ok) cur = v.val[c];
+        if (ok) { const double prod = f * val[e]; v.val[c] = cur - prod; }
+        nnz += __popcll(mask);
+    }
+    DP_SYNC();
+}
+
+__global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
+{
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int n = A.n;
+    const SpVec z{A.zval, A.zpos, A.zlist}, w{A.wval, A.wpos, A.wlist};
+    int znnz = 0, wnnz = 0;
+    bool eliminate = true, end_level_now = false;
+    double piv_tol = A.piv_tol, threshold = A.threshold;
+    int last = n - 1, nA = 0, zero_piv = 0, pos_pivot = -1;
+    const double nnzA = (double)A.Cp[n];
+#define DP_FAIL(code) do { if (lane == 0) { A.ctrl[0] = (code); A.ctrl[5] = k; } return; } while (0)
+
+    for (int k = 0; k < n; ++k) {
+        if (A.begin_total_piv && k == A.bp) piv_tol = 1.0;                          // :448
+        const int sel = A.prow[k];                                                  // (2.) :453-466
+        for (int s = lane; s < znnz; s += 64) z.pos[z.list[s]] = -1;
+        for (int s = lane; s < wnnz; s += 64) w.pos[w.list[s]] = -1;
+        znnz = wnnz = 0;
+        if (lane == 0) A.unused[sel] = 0;
+        DP_SYNC();
+        {
+            const int r0 = A.Ap[sel], r1 = A.Ap[sel + 1];
+            for (int base = r0; base < r1; base += 64) {
+                const int e = base + lane;
+                const bool act = e < r1;
+                const int c = act ? A.Ai[e] : -1;
+                const int pc = (act && e > r0) ? A.Ai[e - 1] : -1;
+                const bool ok = act && A.nonpiv[c] != 0;
+                const bool first = ok && c != pc;
+                const unsigned long long mask = __ballot(first);
+                if (first) { const int s = znnz + __popcll(mask & lt); z.list[s] = c; z.pos[c] = s; z.val[c] = A.Av[e]; }
+                znnz += __popcll(mask);
+                unsigned long long dup = __ballot(ok && !first);                     // a column stored twice in the row: the last value stands
+                if (dup) {
+                    DP_SYNC();
+                    if (lane == 0)
+                        while (dup) { const int b = __ffsll((long long)dup) - 1; dup &= dup - 1; z.val[A.Ai[base + b]] = A.Av[base + b]; }
+                }
+            }
+            DP_SYNC();
+        }
+        for (int h = A.startL[sel]; h != -1; ) {                                    // (3.) :472-487: the rows of U this row has multipliers for
+            const int c = A.colL[h];
+            const double lv = A.Lval[h];
+            h = A.linkL[h];
+            const double f = lv / A.Dinv[c];
+            dp_subtract(z, znnz, f, A.Uidx, A.Uval, A.Uptr[c], A.Uptr[c + 1], A.nonpiv, lane);
+        }
+        double pivot = 0.0;
+        if (eliminate) {                                                            // the pivot, :540-558
+            double best = 0.0;
+            int bslot = 0x7fffffff;
+            for (int s = lane; s < znnz; s += 64) { const double v = fabs(z.val[z.list[s]]); if (v > best) { best = v; bslot = s; } }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int os = __shfl_xor(bslot, off);
+                if (ob > best || (ob == best && os < bslot)) { best = ob; bslot = os; }
+            }
+            pos_pivot = bslot == 0x7fffffff ? -1 : z.list[bslot];
+            const double val_larg_el = pos_pivot >= 0 ? z.val[pos_pivot] : 0.0;
+            if (A.nonpiv[sel] != 0) {
+                dp_touch(z, znnz, sel, lane);
+                const double zs = z.val[sel];
+                if (fabs(val_larg_el * piv_tol) > fabs(zs) && pos_pivot >= 0 && A.piv_tol > 0) pivot = val_larg_el;
+                else { pos_pivot = sel; pivot = zs; }
+            } else {
+                if (fabs(val_larg_el) > 0.0 && pos_pivot >= 0) pivot = val_larg_el;
+                else { pos_pivot = A.perm[k]; dp_touch(z, znnz, pos_pivot, lane); pivot = z.val[pos_pivot]; }
+            }
+        }
+        if (eliminate && !A.force_finish && (double)k > A.min_elim_factor * (double)n && A.small_pivot_terminates && fabs(pivot) < A.min_pivot) {   // :595-612
+            eliminate = false;
+            end_level_now = true;
+            threshold *= A.shift_schur;
+            last = k - 1;
+            nA = n - k;
+        }
+        double dinv = 1.0;
+        if (eliminate) {                                                            // :613-629
+            dinv = 1.0 / pivot;
+            for (int s = lane; s < znnz; s += 64) { const int c = z.list[s]; z.val[c] = z.val[c] * dinv; }
+            DP_SYNC();
+            if (lane == 0) {
+                z.val[pos_pivot] = 0.0;
+                const int pk = A.perm[k], p = A.iperm[pos_pivot];
+                const int t = A.iperm[pk]; A.iperm[pk] = A.iperm[pos_pivot]; A.iperm[pos_pivot] = t;
+                const int u = A.perm[k]; A.perm[k] = A.perm[p]; A.perm[p] = u;
+                A.nonpiv[pos_pivot] = 0;
+                A.Dinv[k] = dinv;
+            }
+            DP_SYNC();
+            {                                                                       // the column of L, :633-651
+                const int c = pos_pivot;                                            // = perm[k] now
+                const int c0 = A.Cp[c], c1 = A.Cp[c + 1];
+                for (int base = c0; base < c1; base += 64) {
+                    const int e = base + lane;
+                    const bool act = e < c1;
+                    const int r = act ? A.Ci[e] : -1;
+                    const int pr = (act && e > c0) ? A.Ci[e - 1] : -1;
+                    const bool ok = act && A.unused[r] != 0;
+                    const bool first = ok && r != pr;
+                    const unsigned long long mask = __ballot(first);
+                    if (first) { const int s = wnnz + __popcll(mask & lt); w.list[s] = r; w.pos[r] = s; w.val[r] = A.Cv[e]; }
+                    wnnz += __popcll(mask);
+                    unsigned long long dup = __ballot(ok && !first);
+                    if (dup) {
+                        DP_SYNC();
+                        if (lane == 0)
+                            while (dup) { const int b = __ffsll((long long)dup) - 1; dup &= dup - 1; w.val[A.Ci[base + b]] = A.Cv[base + b]; }
+                    }
+                }
+                DP_SYNC();
+                for (int h = A.startU[c]; h != -1; ) {
+                    const int r = A.rowU[h];
+                    const double uv = A.Uval[h];
+                    h = A.linkU[h];
+                    const double f = uv / A.Dinv[r];
+                    dp_subtract(w, wnnz, f, A.Lidx, A.Lval, A.Lptr[r], A.Lptr[r + 1], A.unused, lane);
+                }
+            }
+            for (int s = lane; s < wnnz; s += 64) { const int r = w.list[s]; w.val[r] = w.val[r] * dinv; }     // :652
+            DP_SYNC();
+        }
+        // ---- dropping in the row, :714-759 ----
+        int nU;
+        double n1z = 0.0;
+        if (!eliminate) {
+            const double norm = sqrt(dp_seq_sum(z, znnz, 1, lane));
+            nU = dp_take(A, z, znnz, false, 0.0, norm * threshold, A.max_fill, lane);
+        } else {
+            const double n2z = (A.rules & PILUC_DROP_STANDARD) ? sqrt(dp_seq_sum(z, znnz, 1, lane)) : 0.0;
+            const double n1w = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? dp_seq_sum(w, wnnz, 0, lane) : 0.0;
+            n1z = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? dp_seq_sum(z, znnz, 0, lane) : 0.0;
+            const double weightU = dp_weight(A, n2z, n1w, dinv);
+            nU = dp_take(A, z, znnz, true, weightU, threshold, A.max_fill - 1, lane);
+        }
+        if (eliminate) {                                                            // :761-797: the 1 at the pivot's column, then the list backwards
+            const int p0 = A.Uptr[k];
+            if ((long)p0 + nU + 1 > (long)A.capU) DP_FAIL(1);
+            for (int j = lane; j < nU; j += 64) {
+                const int pos = p0 + 1 + j, c = A.cand[nU - 1 - j];
+                A.Uval[pos] = z.val[c]; A.Uidx[pos] = c;
+                A.linkU[pos] = A.startU[c]; A.startU[c] = pos; A.rowU[pos] = k;
+            }
+            if (lane == 0) {
+                A.Uval[p0] = 1.0; A.Uidx[p0] = pos_pivot; A.Uptr[k + 1] = p0 + nU + 1;
+                if (pivot == 0.0) A.Dinv[k] = 1.0;
+            }
+            if (pivot == 0.0) { ++zero_piv; dinv = 1.0; }
+        } else {                                                                    // :818-847
+            const int kA = k - last - 1;
+            const int p0 = A.Uptr[k], q0 = A.Sptr[kA];
+            if ((long)p0 + 1 > (long)A.capU) DP_FAIL(1);
+            if ((long)q0 + nU > (long)A.capS) DP_FAIL(3);
+            for (int j = lane; j < nU; j += 64) { const int c = A.cand[nU - 1 - j]; A.Sval[q0 + j] = z.val[c]; A.Sidx[q0 + j] = c; }
+            if (lane == 0) {
+                A.Uval[p0] = 1.0; A.Uidx[p0] = A.perm[k]; A.Uptr[k + 1] = p0 + 1; A.Dinv[k] = 1.0;
+                A.Sptr[kA + 1] = q0 + nU;
+            }
+        }
+        DP_SYNC();
+        // ---- the column of L, :849-1005 ----
+        if (eliminate) {
+            const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(dp_seq_sum(w, wnnz, 1, lane)) : 0.0;
+            const double weightL = dp_weight(A, n2w, n1z, dinv);
+            const int nL = dp_take(A, w, wnnz, true, weightL, threshold, A.max_fill, lane);
+            const int p0 = A.Lptr[k];
+            if ((long)p0 + nL + 1 > (long)A.capL) DP_FAIL(2);
+            for (int j = lane; j < nL; j += 64) {
+                const int pos = p0 + 1 + j, b = A.cand[j];
+                A.Lval[pos] = w.val[b]; A.Lidx[pos] = b;
+                A.linkL[pos] = A.startL[b]; A.startL[b] = pos; A.colL[pos] = k;
+            }
+            if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + nL + 1; }
+            DP_SYNC();
+            // the rows by their number of entries in L, one move per new entry and in the order of the entries (:964-970)
+            if (lane == 0) {
+                for (int j = 0; j < nL; ++j) {
+                    const int b0 = A.cand[j];
+                    if (b0 < A.bpr || b0 > A.epr) continue;
+                    const int b = A.iprow[b0];
+                    const int cntb = A.numb[b] + 1;
+                    const int a = A.pnum[cntb] - 1;
+                    A.pnum[cntb] = a;
+                    if (a == b) { A.numb[b] = cntb; continue; }
+                    const int ra = A.prow[a], rb = A.prow[b];
+                    A.iprow[ra] = b; A.iprow[rb] = a;
+                    A.prow[a] = rb; A.prow[b] = ra;
+                    const int na = A.numb[a];
+                    A.numb[a] = cntb; A.numb[b] = na;
+                }
+            }
+            DP_SYNC();
+            // a new group of rows with equally many entries begins behind this step: by increasing row index (:980-981; the reference's
+            // quicksort_with_inverse leaves the rows -- all different -- in ascending order, and so does any sort)
+            const int nk = A.numb[k];
+            const int g0 = A.pnum[nk + 1];
+            if (g0 == k + 1) {
+                const int g1 = A.pnum[nk + 2] - 1;
+                const int len = g1 - g0 + 1;
+                if (len > 1) {
+                    int N = 64;
+                    while (N < len) N *= 2;
+                    for (int i = lane; i < N; i += 64) A.sortk[i] = i < len ? (unsigned long long)(unsigned)A.prow[g0 + i] : ~0ull;
+                    DP_SYNC();
+                    wave_sort_u64<true>(A.sortk, N, lane);
+                    for (int i = lane; i < len; i += 64) { const int r = (int)(unsigned)A.sortk[i]; A.prow[g0 + i] = r; A.iprow[r] = g0 + i; }
+                    DP_SYNC();
+                }
+            }
+            // ---- does the level end here?  :1018-1092 ----
+            if (!A.force_finish && (double)k > A.min_elim_factor * (double)n) {
+                const double cnt = (double)nk;
+                switch (A.final_row_crit) {
+                case -1: end_level_now = cnt > (A.move_level_factor * nnzA) / (double)n; break;
+                case 0: end_level_now = cnt > (0.5 * nnzA) / (double)n; break;
+                case 1: end_level_now = cnt > nnzA / (double)n; break;
+                case 2: end_level_now = cnt > (2.0 * nnzA) / (double)n; break;
+                case 3: end_level_now = cnt > (4.0 * nnzA) / (double)n; break;
+                case 4: end_level_now = cnt > (6.0 * nnzA) / (double)n; break;
+                case 5: end_level_now = nk > 10; break;
+                case 6: end_level_now = cnt > (1.5 * nnzA) / (double)n; break;
+                case 7: end_level_now = sqrt(dp_seq_sum(z, znnz, 1, lane)) > A.row_u_max; break;
+                case 8: end_level_now = cnt > (3.0 * nnzA) / (double)n; break;
+                case 9: end_level_now = cnt > (1.2 * nnzA) / (double)n; break;
+                default: break;
+                }
+                if (end_level_now) {
+                    eliminate = false;
+                    threshold *= A.shift_schur;
+                    last = k;
+                    nA = n - k - 1;
+                }
+            }
+        } else {
+            const int p0 = A.Lptr[k];
+            if ((long)p0 + 1 > (long)A.capL) DP_FAIL(2);
+            if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + 1; }
+            DP_SYNC();
+        }
+    }
+    if (lane == 0) { A.ctrl[0] = 0; A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; A.ctrl[5] = n; }
+#undef DP_FAIL
+}
+
+// ---------------------------------------------- the stores -> matrices ----------------------------------------------
+__global__ void k_dp_init(int32_t n, int32_t epr, int32_t *perm, int32_t *iperm, int32_t *prow, int32_t *iprow, int32_t *numb, int32_t *pnum,
+                          int32_t *nonpiv, int32_t *unused, int32_t *startU, int32_t *startL, int32_t *zpos, int32_t *wpos, double *Dinv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        perm[i] = iperm[i] = prow[i] = iprow[i] = i;                               // :408-413
+        numb[i] = 0; nonpiv[i] = 1; unused[i] = 1; startU[i] = -1; startL[i] = -1; zpos[i] = -1; wpos[i] = -1; Dinv[i] = 1.0;
+    }
+    if (i < n + 2) pnum[i] = i == 0 ? 0 : epr + 1;                                  // :417, :437
+}
+
+// entries of a segment that compress() keeps (|x| > 0: sparse_implementation.h:3704-3726)
+__global__ void k_dp_count(int32_t nseg, const int32_t *__restrict__ ptr, const double *__restrict__ val, int32_t *__restrict__ len)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nseg) return;
+    int c = 0;
+    if (r < nseg) for (int j = ptr[r]; j < ptr[r + 1]; ++j) c += fabs(val[j]) > 0.0 ? 1 : 0;
+    len[r] = c;
+}
+__global__ void k_dp_keys(int32_t nseg, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const double *__restrict__ val,
+                          const int32_t *__restrict__ nptr, const int32_t *__restrict__ map, int32_t shift, unsigned long long *__restrict__ keys,
+                          double *__restrict__ vals)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nseg) return;
+    int q = nptr[r];
+    for (int j = ptr[r]; j < ptr[r + 1]; ++j) {
+        if (!(fabs(val[j]) > 0.0)) continue;
+        keys[q] = ((unsigned long long)(unsigned)r << 32) | (unsigned)(map[idx[j]] - shift);
+        vals[q] = val[j];
+        ++q;
+    }
+}
+__global__ void k_dp_low(int64_t nnz, const unsigned long long *__restrict__ keys, int32_t *__restrict__ idx)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nnz) idx[j] = (int32_t)(unsigned)keys[j];
+}
+
+// compress(), then every index through `map` (minus shift), then normal_order(): one segmented sort
+static int dp_finish(hipStream_t st, int32_t nseg, const int32_t *ptr, const int32_t *idx, const double *val, const int32_t *map, int32_t shift,
+                     bool is_csr, DevMat *M)
+{
+    PoolBlock b_len, b_k0, b_k1, b_v0, b_tmp;
+    ILUPP_HIP(b_len.alloc(sizeof(int32_t) * (size_t)(nseg + 1)));
+    M->release();
+    M->n = nseg; M->is_csr = is_csr; M->owns = true;
+    ILUPP_HIP(pool_malloc(&M->ptr, sizeof(int32_t) * (size_t)(nseg + 1)));
+    hipLaunchKernelGGL(k_dp_count, dim3((nseg + 256) / 256), dim3(256), 0, st, nseg, ptr, val, b_len.as<int32_t>());
+    {
+        size_t tb = 0;
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b_len.as<int32_t>(), M->ptr, nseg + 1, st));
+        ILUPP_HIP(b_tmp.alloc(tb > 0 ? tb : 1));
+        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_len.as<int32_t>(), M->ptr, nseg + 1, st));
+    }
+    int32_t nnz = 0;
+    ILUPP_HIP(hipMemcpyAsync(&nnz, M->ptr + nseg, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    M->nnz = nnz;
+    ILUPP_HIP(pool_malloc(&M->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&M->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    if (nnz > 0) {
+        ILUPP_HIP(b_k0.alloc(sizeof(unsigned long long) * (size_t)nnz));
+        ILUPP_HIP(b_k1.alloc(sizeof(unsigned long long) * (size_t)nnz));
+        ILUPP_HIP(b_v0.alloc(sizeof(double) * (size_t)nnz));
+        hipLaunchKernelGGL(k_dp_keys, dim3((nseg + 255) / 256), dim3(256), 0, st, nseg, ptr, idx, val, M->ptr, map, shift, b_k0.as<unsigned long long>(),
+                           b_v0.as<double>());
+        size_t tb = 0;
+        ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b_k0.as<unsigned long long>(), b_k1.as<unsigned long long>(), b_v0.as<double>(), M->val,
+                                                     (int)nnz, 0, 64, st));
+        PoolBlock b_t2;
+        ILUPP_HIP(b_t2.alloc(tb > 0 ? tb : 1));
+        ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(b_t2.p, tb, b_k0.as<unsigned long long>(), b_k1.as<unsigned long long>(), b_v0.as<double>(), M->val,
+                                                     (int)nnz, 0, 64, st));
+        hipLaunchKernelGGL(k_dp_low, dim3((unsigned)(((int64_t)nnz + 255) / 256)), dim3(256), 0, st, (int64_t)nnz, b_k1.as<unsigned long long>(), M->idx);
+        ILUPP_HIP(hipStreamSynchronize(st));
+    }
+    return ILUPP_OK;
+}
+
+int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, int32_t bp, int32_t bpr, int32_t epr,
+                  DevMat *L, DevMat *U, double **Dinv_out, DevMat *Anew, int32_t *pc2, int32_t *pr2, float *kernel_ms)
+{
+    const int32_t n = Arow.n;
+    const int64_t nnz = Arow.nnz;
+    const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
+    if (epr < 0) epr = 0;                                                           // :372-375
+    if (epr >= n) epr = n - 1;
+    if (bpr < 0) bpr = 0;
+    if (bpr >= n) bpr = n - 1;
+    int32_t max_fill = P.max_fill_in > 0 ? P.max_fill_in : n;                        // :352-355
+    if (max_fill < 1) max_fill = 1;
+    if (max_fill > n) max_fill = n;
+    struct MatGuard { DevMat m; ~MatGuard() { m.release(); } } gc;
+    transpose_storage(st, Arow, &gc.m);                                             // Akcol = Akrow.change_orientation(), :1460-1461
+    const DevMat &Acol = gc.m;
+
+    int sortN = 64;
+    while (sortN < n) sortN *= 2;
+    PoolBlock b_i, b_d, b_sort, b_ctrl;
+    // int arrays of n (+2) entries: perm iperm prow iprow numb pnum nonpiv unused startU startL zpos zlist wpos wlist cand Uptr Lptr Sptr
+    const size_t slot = ((size_t)n + 64) & ~(size_t)15;
+    ILUPP_HIP(b_i.alloc(sizeof(int32_t) * slot * 18));
+    ILUPP_HIP(b_d.alloc(sizeof(double) * slot * 3));                                // zval wval key
+    ILUPP_HIP(b_sort.alloc(sizeof(unsigned long long) * (size_t)sortN));
+    ILUPP_HIP(b_ctrl.alloc(64));
+    int32_t *I = b_i.as<int32_t>();
+    auto iarr = [&](int q) { return I + slot * (size_t)q; };
+    double *Dinv = nullptr;
+    ILUPP_HIP(pool_malloc(&Dinv, sizeof(double) * (size_t)n));
+    struct DinvGuard { double **p; bool keep = false; ~DinvGuard() { if (!keep && *p) { (void)pool_free(*p); *p = nullptr; } } } gd{&Dinv};
+
+    // the stores: what the factors of this level may grow to is not known beforehand -- a full store ends the attempt, the next one has
+    // twice the room (the reference's enlarge_fields_keep_data doubles its arrays in place, :763-769)
+    int64_t cap = 4 * nnz + 16 * (int64_t)n + 1024;
+    for (int attempt = 0;; ++attempt) {
+        if (cap > 0x7ffffff0ll) cap = 0x7ffffff0ll;
+        PoolBlock b_ui, b_uv, b_li, b_lv, b_si, b_sv;
+        ILUPP_HIP(b_ui.alloc(sizeof(int32_t) * (size_t)cap * 3));                   // Uidx linkU rowU
+        ILUPP_HIP(b_uv.alloc(sizeof(double) * (size_t)cap));
+        ILUPP_HIP(b_li.alloc(sizeof(int32_t) * (size_t)cap * 3));
+        ILUPP_HIP(b_lv.alloc(sizeof(double) * (size_t)cap));
+        ILUPP_HIP(b_si.alloc(sizeof(int32_t) * (size_t)cap));
+        ILUPP_HIP(b_sv.alloc(sizeof(double) * (size_t)cap));
+        DpArgs a;
+        a.n = n;
+        a.Ap = Arow.ptr; a.Ai = Arow.idx; a.Av = Arow.val;
+        a.Cp = Acol.ptr; a.Ci = Acol.idx; a.Cv = Acol.val;
+        a.threshold = tau; a.shift_schur = P.threshold_shift_schur; a.min_pivot = P.min_pivot; a.min_elim_factor = P.min_elim_factor;
+        a.piv_tol = P.piv_tol; a.move_level_factor = P.move_level_factor; a.row_u_max = P.row_u_max;
+        a.small_pivot_terminates = P.small_pivot_terminates ? 1 : 0; a.force_finish = force_finish ? 1 : 0; a.begin_total_piv = P.begin_total_piv ? 1 : 0;
+        a.final_row_crit = P.final_row_crit; a.bp = bp; a.bpr = bpr; a.epr = epr; a.max_fill = max_fill;
+        a.rules = P.rules; a.combine = P.combine; a.scale_invdiag = P.scale_invdiag ? 1 : 0;
+        for (int q = 0; q < 5; ++q) a.wgt[q] = P.wgt[q];
+        a.neutral = P.neutral; a.min_weight = P.min_weight;
+        a.perm = iarr(0); a.iperm = iarr(1); a.prow = iarr(2); a.iprow = iarr(3); a.numb = iarr(4); a.pnum = iarr(5);
+        a.nonpiv = iarr(6); a.unused = iarr(7); a.startU = iarr(8); a.startL = iarr(9);
+        a.zpos = iarr(10); a.zlist = iarr(11); a.wpos = iarr(12); a.wlist = iarr(13); a.cand = iarr(14);
+        a.Uptr = iarr(15); a.Lptr = iarr(16); a.Sptr = iarr(17);
+        a.Dinv = Dinv;
+        a.Uidx = b_ui.as<int32_t>(); a.linkU = a.Uidx + cap; a.rowU = a.linkU + cap; a.Uval = b_uv.as<double>(); a.capU = (int32_t)cap;
+        a.Lidx = b_li.as<int32_t>(); a.linkL = a.Lidx + cap; a.colL = a.linkL + cap; a.Lval = b_lv.as<double>(); a.capL = (int32_t)cap;
+        a.Sidx = b_si.as<int32_t>(); a.Sval = b_sv.as<double>(); a.capS = (int32_t)cap;
+        a.zval = b_d.as<double>(); a.wval = a.zval + slot; a.key = a.wval + slot;
+        a.sortk = b_sort.as<unsigned long long>();
+        a.ctrl = b_ctrl.as<int32_t>();
+        ILUPP_HIP(hipMemsetAsync(a.ctrl, 0, 64, st));
+        ILUPP_HIP(hipMemsetAsync(a.Uptr, 0, sizeof(int32_t), st));
+        ILUPP_HIP(hipMemsetAsync(a.Lptr, 0, sizeof(int32_t), st));
+        ILUPP_HIP(hipMemsetAsync(a.Sptr, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_dp_init, dim3((n + 2 + 255) / 256), dim3(256), 0, st, n, epr, a.perm, a.iperm, a.prow, a.iprow, a.numb, a.pnum, a.nonpiv, a.unused,
+                           a.startU, a.startL, a.zpos, a.wpos, Dinv);
+        hipEvent_t e0, e1;
+        ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
+        ILUPP_HIP(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
+        ILUPP_HIP(hipEventRecord(e1, st));
+        int32_t ctrl[8] = {0};
+        ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (kernel_ms) *kernel_ms += ms;
+        if (dbg) fprintf(stderr, "[ilupp] pilucdp: n %d, attempt %d (stores of %lld): status %d at step %d, %.2f ms\n", n, attempt, (long long)cap, ctrl[0], ctrl[5], ms);
+        if (ctrl[0] != 0) {
+            if (cap >= 0x7ffffff0ll || attempt > 8) { set_error("ILU++ with pivoting: the factors of a level outgrow 2^31 entries"); return ILUPP_ERR_UNSUPPORTED; }
+            cap *= 2;
+            continue;
+        }
+        const int32_t last = ctrl[1], nA = ctrl[2];
+        const bool to_the_end = ctrl[4] != 0;
+        // compress(), permute(permrows, ROW) / U.permute(perm, COLUMN), :1131-1151
+        { const int rc = dp_finish(st, n, a.Lptr, a.Lidx, a.Lval, a.iprow, 0, false, L); if (rc) return rc; }
+        { const int rc = dp_finish(st, n, a.Uptr, a.Uidx, a.Uval, a.iperm, 0, true, U); if (rc) return rc; }
+        if (to_the_end) {                                                           // :1133
+            Anew->release();
+            Anew->n = 0; Anew->nnz = 0; Anew->is_csr = true; Anew->owns = true;
+            ILUPP_HIP(pool_malloc(&Anew->ptr, sizeof(int32_t)));
+            ILUPP_HIP(hipMemsetAsync(Anew->ptr, 0, sizeof(int32_t), st));
+            ILUPP_HIP(pool_malloc(&Anew->idx, sizeof(int32_t)));
+            ILUPP_HIP(pool_malloc(&Anew->val, sizeof(double)));
+        } else {
+            const int rc = dp_finish(st, nA, a.Sptr, a.Sidx, a.Sval, a.iperm, last + 1, true, Anew);      // :1136-1145
+            if (rc) return rc;
+        }
+        ILUPP_HIP(hipMemcpyAsync(pc2, a.perm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        ILUPP_HIP(hipMemcpyAsync(pr2, a.prow, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        break;
+    }
+    gd.keep = true;
+    *Dinv_out = Dinv;
+    return ILUPP_OK;
+}
+
+}  // namespace ilupp

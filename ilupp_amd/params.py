@@ -181,14 +181,15 @@ class iluplusplus_precond_parameter:
     def _to_ml_params(self):
         """the C-ABI parameter block, or NotImplementedError naming what this build lacks"""
         def refuse(what):
-            raise NotImplementedError("ilupp_amd: the multilevel ILU++ preconditioner is built for the family without pivoting "
-                                      "(PERMUTE_ROWS 0, TOTAL_PIV 0, piv_tol 0: precon_parameter 10, e.g. default_configuration(1)) "
-                                      "with error-propagation dropping; " + what + " is not built")
+            raise NotImplementedError("ilupp_amd: the multilevel ILU++ preconditioner is built with the dropping rules that need no estimates "
+                                      "carried over the steps (standard, error propagation, pivot) and the plain Schur complement; "
+                                      + what + " is not built")
         if self.PRECON_PARAMETER < 0:
             refuse("PRECON_PARAMETER < 0 (reserved for external solvers)")
-        if not self._uses_partial_iluc():
-            refuse("the pivoting factorisation partialILUCDP that these parameters select (the default-constructed "
-                   "parameters do: PERMUTE_ROWS %d, TOTAL_PIV %d, piv_tol %g)" % (self.PERMUTE_ROWS, self.TOTAL_PIV, self.piv_tol))
+        if self.PERMUTE_ROWS not in (0, 1, 2, 3) or self.TOTAL_PIV not in (0, 1, 2):
+            raise ValueError("choose permissible value for PERMUTE_ROWS / TOTAL_PIV!")
+        if not self._uses_partial_iluc() and not (-1 <= self.FINAL_ROW_CRIT <= 9):
+            refuse("FINAL_ROW_CRIT = %r with the pivoting factorisation (rows ordered by weights instead of counts)" % (self.FINAL_ROW_CRIT,))
         seq_rules = [k for k in ("USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2") if getattr(self, k)]
         if seq_rules:
             refuse("dropping by " + ", ".join(seq_rules) + " (these rules accumulate estimates over the steps in their sequential order)")
@@ -237,4 +238,8 @@ class iluplusplus_precond_parameter:
         p.combine_factor = int(self.COMBINE_FACTOR) if int(self.COMBINE_FACTOR) in (0, 1, 2, 3) else 0       # combine(): default branch = max
         p.neutral_element, p.min_weight = float(self.NEUTRAL_ELEMENT), float(self.MIN_WEIGHT)
         p.scale_weight_invdiag = 1 if self.SCALE_WEIGHT_INVDIAG else 0
+        p.piv_tol = float(self.piv_tol)
+        p.permute_rows, p.total_piv, p.begin_total_piv = int(self.PERMUTE_ROWS), int(self.TOTAL_PIV), 1 if self.BEGIN_TOTAL_PIV else 0
+        p.final_row_crit = int(self.FINAL_ROW_CRIT)
+        p.move_level_factor, p.row_u_max = float(self.MOVE_LEVEL_FACTOR), float(self.ROW_U_MAX)
         return p

@@ -198,6 +198,16 @@ typedef struct {                     /* the fields of iluplusplus_precond_parame
     int32_t combine_factor;          /* COMBINE_FACTOR */
     double neutral_element, min_weight;   /* NEUTRAL_ELEMENT, MIN_WEIGHT */
     int32_t scale_weight_invdiag;    /* SCALE_WEIGHT_INVDIAG */
+    /* the factorisation WITH pivoting (reference partialILUCDP, ILUCDP.hpp:268-1404) is taken unless PERMUTE_ROWS is 0 or 1, total pivoting
+     * is off (BEGIN_TOTAL_PIV 0 or TOTAL_PIV 0) and piv_tol is 0 (preconditioner_implementation.h:1376-1382): the reference's
+     * default-constructed parameters select it */
+    double piv_tol;                      /* piv_tol */
+    int32_t permute_rows;                /* PERMUTE_ROWS 0..3 */
+    int32_t total_piv;                   /* TOTAL_PIV 0..2 */
+    int32_t begin_total_piv;             /* BEGIN_TOTAL_PIV */
+    int32_t final_row_crit;              /* FINAL_ROW_CRIT -1..9 */
+    double move_level_factor;            /* MOVE_LEVEL_FACTOR */
+    double row_u_max;                    /* ROW_U_MAX */
 } ilupp_ml_params;
 
 /* default_configuration(1) (parameters_implementation.h:546-549: set_PQ + precon_parameter 10) with threshold 0 */

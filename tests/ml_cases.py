@@ -90,7 +90,35 @@ _ORC_FIELDS = {"MAX_LEVELS": "max_levels", "THRESHOLD_SHIFT_SCHUR": "threshold_s
                "FINAL_THRESHOLD": "final_threshold", "SMALL_PIVOT_TERMINATES": "small_pivot_terminates", "MIN_ML_SIZE": "min_ml_size",
                "fill_in": "max_fill_in", "WEIGHT_STANDARD_DROP": "weight_standard_drop", "WEIGHT_STANDARD_DROP2": "weight_standard_drop2",
                "WEIGHT_ERR_PROP_DROP": "weight_err_prop_drop", "WEIGHT_ERR_PROP_DROP2": "weight_err_prop_drop2", "WEIGHT_PIVOT_DROP": "weight_pivot_drop",
-               "COMBINE_FACTOR": "combine_factor", "NEUTRAL_ELEMENT": "neutral_element", "MIN_WEIGHT": "min_weight", "SCALE_WEIGHT_INVDIAG": "scale_weight_invdiag"}
+               "COMBINE_FACTOR": "combine_factor", "NEUTRAL_ELEMENT": "neutral_element", "MIN_WEIGHT": "min_weight", "SCALE_WEIGHT_INVDIAG": "scale_weight_invdiag",
+               "piv_tol": "piv_tol", "PERMUTE_ROWS": "permute_rows", "TOTAL_PIV": "total_piv", "BEGIN_TOTAL_PIV": "begin_total_piv",
+               "FINAL_ROW_CRIT": "final_row_crit", "MOVE_LEVEL_FACTOR": "move_level_factor", "ROW_U_MAX": "row_u_max"}
+
+# the reference's DEFAULT-constructed parameters (precon_parameter 0, parameters_implementation.h:430-501): the factorisation with pivoting
+PIVOTING = {"piv_tol": 1.0, "PERMUTE_ROWS": 3, "TOTAL_PIV": 1, "BEGIN_TOTAL_PIV": True, "SMALL_PIVOT_TERMINATES": False, "MIN_ELIM_FACTOR": 0.5}
+
+
+def pivoting(**kw):
+    d = dict(PIVOTING)
+    d.update(kw)
+    return d
+
+
+# (name, threshold, preprocessing, knobs) for the factorisation WITH pivoting (partialILUCDP)
+PIVOT_PARAMS = [
+    ("p_t1_pq", 1.0, ("PQ_ORDERING",), pivoting()),                                  # ILUppPreconditioner(A): threshold 1.0, set_PQ
+    ("p_t0_pq", 0.0, ("PQ_ORDERING",), pivoting()),                                  # ILUppPreconditioner(A, threshold=0) (test/tests.py:390, :398)
+    ("p_t0.01_pq", 1e-2, ("PQ_ORDERING",), pivoting()),                              # tests.py:346-349
+    ("p_t0.01_mwm", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING",), pivoting()),          # default_configuration(10); tests.py:355-358
+    ("p_t0.01_sf", 1e-2, ("SPARSE_FIRST_ORDERING",), pivoting()),                    # tests.py:373-376
+    ("p_t0.1_norm_pq", 0.1, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), pivoting()),
+    ("p_t0.01_tol0.1", 1e-2, ("PQ_ORDERING",), pivoting(piv_tol=0.1)),
+    ("p_t0.01_rows0_piv2", 1e-2, ("PQ_ORDERING",), pivoting(PERMUTE_ROWS=0, TOTAL_PIV=2)),
+    ("p_t0.01_rows1_crit0", 1e-2, ("PQ_ORDERING",), pivoting(PERMUTE_ROWS=1, FINAL_ROW_CRIT=0, MIN_ELIM_FACTOR=0.2)),
+    ("p_t0.01_rows2_crit7", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING",), pivoting(PERMUTE_ROWS=2, FINAL_ROW_CRIT=7, MIN_ELIM_FACTOR=0.0)),
+    ("p_t0.001_fill5_std", 1e-3, ("PQ_ORDERING",), pivoting(fill_in=5, USE_STANDARD_DROPPING=True, THRESHOLD_SHIFT_SCHUR=0.5)),
+    ("p_t0.05_smallpiv", 0.05, ("PQ_ORDERING",), pivoting(SMALL_PIVOT_TERMINATES=True, MIN_ELIM_FACTOR=0.1, MOVE_LEVEL_FACTOR=0.5)),
+]
 
 
 _RULES = (("USE_STANDARD_DROPPING", 1, False), ("USE_STANDARD_DROPPING2", 2, False), ("USE_ERR_PROP_DROPPING", 4, True), ("USE_ERR_PROP_DROPPING2", 8, False),
