@@ -129,9 +129,12 @@ class ILUppPreconditioner(_HipPreconditioner):
         fill_in: the fill_in parameter for the ILU++ preconditioner
         params: an instance of :class:`iluplusplus_precond_parameter`; if passed, overrides fill_in and threshold
 
-    The engine has the family WITHOUT pivoting (``params.default_configuration(1)``: normalisation + PQ ordering, factorisation
-    preset 10).  Default-constructed parameters select the reference's pivoting factorisation, which is not built: the call then
-    raises NotImplementedError -- nothing is replaced behind the caller's back."""
+    Default-constructed parameters select, as in the reference, the factorisation WITH pivoting (partialILUCDP: the column of a step is the
+    largest entry of its working row, the next row the one with the fewest entries in L so far) -- a chain of n steps that one wave of the
+    GPU walks (ilupp_amd/csrc/pilucdp.hip).  Parameters without row reordering, total pivoting and pivot tolerance
+    (``params.default_configuration(1)``, precon_parameter 10) fix rows and columns beforehand and run as a dataflow computation over all
+    CUs (piluc_df.hip): the fast path for large matrices.  Both are bit-identical to the reference; what is not built (inverse-based and
+    weighted dropping, the improved Schur complement, FINAL_ROW_CRIT < -1, a few preprocessing steps) raises NotImplementedError."""
 
     def __init__(self, A, threshold=1.0, fill_in=None, params=None):
         if params is None:
@@ -218,7 +221,7 @@ def solve(A, b, rtol=1e-4, atol=1e-4, max_iter=500, threshold=0.1, fill_in=None,
     The matrix, the preconditioner and every vector of the iteration live in HBM; only the residual norm comes back per iteration.
     Returns the solution (with info=True also (iterations, relative reduction reached, residual norm reached)); raises
     RuntimeError("did not converge") like the reference.  As for :class:`ILUppPreconditioner`, default-constructed parameters select the
-    pivoting factorisation, which is not built (NotImplementedError): pass ``params`` of the family without pivoting."""
+    factorisation with pivoting (sequential: one wave); parameters of the family without pivoting use the whole GPU."""
     import torch
     from . import device as _dev
     if params is None:

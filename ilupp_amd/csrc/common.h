@@ -41,6 +41,7 @@ struct PoolBlock {
     ~PoolBlock() { if (p) (void)pool_free(p); }
     hipError_t alloc(size_t bytes) { if (p) { (void)pool_free(p); p = nullptr; } return pool_malloc(&p, bytes); }
     void *release() { void *q = p; p = nullptr; return q; }                  // the caller takes the block over
+    void swap(PoolBlock &o) { void *q = p; p = o.p; o.p = q; }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 template <class T> inline hipError_t pool_malloc(T **p, size_t bytes) { return pool_malloc(reinterpret_cast<void **>(p), bytes); }

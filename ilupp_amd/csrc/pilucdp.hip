@@ -49,8 +49,10 @@ struct DpArgs {
     int32_t *Sptr, *Sidx; double *Sval; int32_t capS;   // the Schur complement's rows as they come (column indices of this level)
     double *zval, *wval; int32_t *zpos, *zlist, *wpos, *wlist;
     double *key; int32_t *cand; unsigned long long *sortk;
-    int32_t *ctrl;     // [0] status (0 ok; 1 / 2 / 3: the store of U / L / the Schur complement is full), [1] last_row_to_eliminate, [2] n_Anew,
-                       // [3] zero pivots, [4] eliminated to the end, [5] step reached
+    int32_t *ctrl;     // [0] status (0 done; 1 / 2 / 3: the store of U / L / the Schur complement has no room for another row: enlarge it and
+                       // launch again), [1] last_row_to_eliminate, [2] n_Anew, [3] zero pivots, [4] eliminating (still / to the end),
+                       // [5] the step to go on with, [6] / [7] entries of z / w to clear, [8] / [9] entries of U / L so far, [10] of the Schur complement
+    double *dctrl;     // [0] the threshold, [1] the pivot tolerance of the moment
 };
 
 struct SpVec { double *val; int32_t *pos; int32_t *list; };      // value by index, index -> slot (or -1), slot -> index (insertion order)
@@ -93,6 +95,20 @@ __device__ double dp_weight(const DpArgs &A, double n2own, double n1other, doubl
     return w;
 }
 
+// bitonic sort of 64 keys, one per lane, ascending, in registers (rows of a sparse factor rarely keep more than 64 entries: the sort in
+// memory below takes 21 passes with a barrier each)
+__device__ __forceinline__ unsigned long long dp_sort64(unsigned long long key, int lane)
+{
+    for (int k2 = 2; k2 <= 64; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, j);
+            const bool up = (lane & k2) == 0, lower = (lane & j) == 0;
+            const bool take_min = lower == up;
+            key = take_min ? (key < other ? key : other) : (key > other ? key : other);
+        }
+    return key;
+}
+
 // the entries that pass the dropping rule, in insertion order (take_single_weight_largest_elements_by_abs_value_with_threshold,
 // sparse_implementation.h:1360-1415: weight * |x| >= tau; take_largest_elements_by_abs_value_with_threshold, :1322-1357: |x| > norm * tau),
 // at most `limit` of them (the largest keys, by the reference's selection), ascending by index in cand[0 .. return)
@@ -119,6 +135,12 @@ __device__ int dp_take(const DpArgs &A, const SpVec &v, int nnz, bool single, do
     }
     DP_SYNC();
     const int nk = cnt - off;
+    if (nk <= 64) {
+        const unsigned long long sorted = dp_sort64(lane < nk ? (unsigned long long)(unsigned)A.cand[off + lane] : ~0ull, lane);
+        if (lane < nk) A.cand[lane] = (int)(unsigned)sorted;
+        DP_SYNC();
+        return nk;
+    }
     int N = 64;
     while (N < nk) N *= 2;
     for (int i = lane; i < N; i += 64) A.sortk[i] = i < nk ? (unsigned long long)(unsigned)A.cand[off + i] : ~0ull;
@@ -160,20 +182,44 @@ __device__ __forceinline__ void dp_subtract(const SpVec &v, int &nnz, double f, 
     DP_SYNC();
 }
 
+// a node of a row's / column's list (the entry `at` of the other factor's store): which row / column it belongs to, its value, the next node
+struct DpNode { int at, who, link; double v; };
+struct DpRow { double dinv; int e0, e1; };
+__device__ __forceinline__ DpNode dp_node(const int32_t *who, const double *val, const int32_t *link, int at)
+{
+    DpNode nd{at, 0, -1, 0.0};
+    if (at != -1) { nd.who = who[at]; nd.v = val[at]; nd.link = link[at]; }
+    return nd;
+}
+__device__ __forceinline__ DpRow dp_row(const double *Dinv, const int32_t *ptr, const DpNode &nd)
+{
+    DpRow r{1.0, 0, 0};
+    if (nd.at != -1) { r.dinv = Dinv[nd.who]; r.e0 = ptr[nd.who]; r.e1 = ptr[nd.who + 1]; }
+    return r;
+}
+
 __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
 {
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int n = A.n;
     const SpVec z{A.zval, A.zpos, A.zlist}, w{A.wval, A.wpos, A.wlist};
-    int znnz = 0, wnnz = 0;
-    bool eliminate = true, end_level_now = false;
-    double piv_tol = A.piv_tol, threshold = A.threshold;
-    int last = n - 1, nA = 0, zero_piv = 0, pos_pivot = -1;
+    // the state of the chain between two steps (a launch goes on where the one before it had to stop for a larger store)
+    int znnz = A.ctrl[6], wnnz = A.ctrl[7];
+    bool eliminate = A.ctrl[4] != 0, end_level_now = false;
+    double piv_tol = A.dctrl[1], threshold = A.dctrl[0];
+    int last = A.ctrl[1], nA = A.ctrl[2], zero_piv = A.ctrl[3], pos_pivot = -1;
+    int pU = A.ctrl[8], pL = A.ctrl[9], pS = A.ctrl[10];
     const double nnzA = (double)A.Cp[n];
-#define DP_FAIL(code) do { if (lane == 0) { A.ctrl[0] = (code); A.ctrl[5] = k; } return; } while (0)
+    const int row_max = (A.max_fill < n ? A.max_fill : n) + 1;                       // what one step can add to a store
+#define DP_STOP(code) do { if (lane == 0) { A.ctrl[0] = (code); A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; \
+                                            A.ctrl[5] = k; A.ctrl[6] = znnz; A.ctrl[7] = wnnz; A.ctrl[8] = pU; A.ctrl[9] = pL; A.ctrl[10] = pS; \
+                                            A.dctrl[0] = threshold; A.dctrl[1] = piv_tol; } return; } while (0)
 
-    for (int k = 0; k < n; ++k) {
+    for (int k = A.ctrl[5]; k < n; ++k) {
+        if ((long)pU + row_max > (long)A.capU) DP_STOP(1);
+        if ((long)pL + row_max > (long)A.capL) DP_STOP(2);
+        if (!eliminate && (long)pS + row_max > (long)A.capS) DP_STOP(3);
         if (A.begin_total_piv && k == A.bp) piv_tol = 1.0;                          // :448
         const int sel = A.prow[k];                                                  // (2.) :453-466
         for (int s = lane; s < znnz; s += 64) z.pos[z.list[s]] = -1;
@@ -202,12 +248,19 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             }
             DP_SYNC();
         }
-        for (int h = A.startL[sel]; h != -1; ) {                                    // (3.) :472-487: the rows of U this row has multipliers for
-            const int c = A.colL[h];
-            const double lv = A.Lval[h];
-            h = A.linkL[h];
-            const double f = lv / A.Dinv[c];
-            dp_subtract(z, znnz, f, A.Uidx, A.Uval, A.Uptr[c], A.Uptr[c + 1], A.nonpiv, lane);
+        {                                                                           // (3.) :472-487: the rows of U this row has multipliers for
+            // the list is walked two nodes ahead: a node's fields, and then the pivot and the extent of the row it names, are on their way
+            // while the row before it is subtracted (a node costs four dependent round trips instead of six)
+            DpNode n1 = dp_node(A.colL, A.Lval, A.linkL, A.startL[sel]);
+            DpRow a1 = dp_row(A.Dinv, A.Uptr, n1);
+            DpNode n2 = dp_node(A.colL, A.Lval, A.linkL, n1.link);
+            while (n1.at != -1) {
+                const DpRow a2 = dp_row(A.Dinv, A.Uptr, n2);
+                const DpNode n3 = dp_node(A.colL, A.Lval, A.linkL, n2.link);
+                const double f = n1.v / a1.dinv;
+                dp_subtract(z, znnz, f, A.Uidx, A.Uval, a1.e0, a1.e1, A.nonpiv, lane);
+                n1 = n2; a1 = a2; n2 = n3;
+            }
         }
         double pivot = 0.0;
         if (eliminate) {                                                            // the pivot, :540-558
@@ -273,12 +326,15 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                     }
                 }
                 DP_SYNC();
-                for (int h = A.startU[c]; h != -1; ) {
-                    const int r = A.rowU[h];
-                    const double uv = A.Uval[h];
-                    h = A.linkU[h];
-                    const double f = uv / A.Dinv[r];
-                    dp_subtract(w, wnnz, f, A.Lidx, A.Lval, A.Lptr[r], A.Lptr[r + 1], A.unused, lane);
+                DpNode n1 = dp_node(A.rowU, A.Uval, A.linkU, A.startU[c]);
+                DpRow a1 = dp_row(A.Dinv, A.Lptr, n1);
+                DpNode n2 = dp_node(A.rowU, A.Uval, A.linkU, n1.link);
+                while (n1.at != -1) {
+                    const DpRow a2 = dp_row(A.Dinv, A.Lptr, n2);
+                    const DpNode n3 = dp_node(A.rowU, A.Uval, A.linkU, n2.link);
+                    const double f = n1.v / a1.dinv;
+                    dp_subtract(w, wnnz, f, A.Lidx, A.Lval, a1.e0, a1.e1, A.unused, lane);
+                    n1 = n2; a1 = a2; n2 = n3;
                 }
             }
             for (int s = lane; s < wnnz; s += 64) { const int r = w.list[s]; w.val[r] = w.val[r] * dinv; }     // :652
@@ -298,8 +354,8 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             nU = dp_take(A, z, znnz, true, weightU, threshold, A.max_fill - 1, lane);
         }
         if (eliminate) {                                                            // :761-797: the 1 at the pivot's column, then the list backwards
-            const int p0 = A.Uptr[k];
-            if ((long)p0 + nU + 1 > (long)A.capU) DP_FAIL(1);
+            const int p0 = pU;
+            pU += nU + 1;
             for (int j = lane; j < nU; j += 64) {
                 const int pos = p0 + 1 + j, c = A.cand[nU - 1 - j];
                 A.Uval[pos] = z.val[c]; A.Uidx[pos] = c;
@@ -312,9 +368,8 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             if (pivot == 0.0) { ++zero_piv; dinv = 1.0; }
         } else {                                                                    // :818-847
             const int kA = k - last - 1;
-            const int p0 = A.Uptr[k], q0 = A.Sptr[kA];
-            if ((long)p0 + 1 > (long)A.capU) DP_FAIL(1);
-            if ((long)q0 + nU > (long)A.capS) DP_FAIL(3);
+            const int p0 = pU, q0 = pS;
+            pU += 1; pS += nU;
             for (int j = lane; j < nU; j += 64) { const int c = A.cand[nU - 1 - j]; A.Sval[q0 + j] = z.val[c]; A.Sidx[q0 + j] = c; }
             if (lane == 0) {
                 A.Uval[p0] = 1.0; A.Uidx[p0] = A.perm[k]; A.Uptr[k + 1] = p0 + 1; A.Dinv[k] = 1.0;
@@ -327,8 +382,8 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(dp_seq_sum(w, wnnz, 1, lane)) : 0.0;
             const double weightL = dp_weight(A, n2w, n1z, dinv);
             const int nL = dp_take(A, w, wnnz, true, weightL, threshold, A.max_fill, lane);
-            const int p0 = A.Lptr[k];
-            if ((long)p0 + nL + 1 > (long)A.capL) DP_FAIL(2);
+            const int p0 = pL;
+            pL += nL + 1;
             for (int j = lane; j < nL; j += 64) {
                 const int pos = p0 + 1 + j, b = A.cand[j];
                 A.Lval[pos] = w.val[b]; A.Lidx[pos] = b;
@@ -361,7 +416,11 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             if (g0 == k + 1) {
                 const int g1 = A.pnum[nk + 2] - 1;
                 const int len = g1 - g0 + 1;
-                if (len > 1) {
+                if (len > 1 && len <= 64) {
+                    const unsigned long long sorted = dp_sort64(lane < len ? (unsigned long long)(unsigned)A.prow[g0 + lane] : ~0ull, lane);
+                    if (lane < len) { const int r = (int)(unsigned)sorted; A.prow[g0 + lane] = r; A.iprow[r] = g0 + lane; }
+                    DP_SYNC();
+                } else if (len > 1) {
                     int N = 64;
                     while (N < len) N *= 2;
                     for (int i = lane; i < N; i += 64) A.sortk[i] = i < len ? (unsigned long long)(unsigned)A.prow[g0 + i] : ~0ull;
@@ -396,14 +455,14 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                 }
             }
         } else {
-            const int p0 = A.Lptr[k];
-            if ((long)p0 + 1 > (long)A.capL) DP_FAIL(2);
+            const int p0 = pL;
+            pL += 1;
             if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + 1; }
             DP_SYNC();
         }
     }
     if (lane == 0) { A.ctrl[0] = 0; A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; A.ctrl[5] = n; }
-#undef DP_FAIL
+#undef DP_STOP
 }
 
 // ---------------------------------------------- the stores -> matrices ----------------------------------------------
@@ -520,64 +579,98 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     ILUPP_HIP(pool_malloc(&Dinv, sizeof(double) * (size_t)n));
     struct DinvGuard { double **p; bool keep = false; ~DinvGuard() { if (!keep && *p) { (void)pool_free(*p); *p = nullptr; } } } gd{&Dinv};
 
-    // the stores: what the factors of this level may grow to is not known beforehand -- a full store ends the attempt, the next one has
-    // twice the room (the reference's enlarge_fields_keep_data doubles its arrays in place, :763-769)
-    int64_t cap = 4 * nnz + 16 * (int64_t)n + 1024;
-    for (int attempt = 0;; ++attempt) {
-        if (cap > 0x7ffffff0ll) cap = 0x7ffffff0ll;
-        PoolBlock b_ui, b_uv, b_li, b_lv, b_si, b_sv;
-        ILUPP_HIP(b_ui.alloc(sizeof(int32_t) * (size_t)cap * 3));                   // Uidx linkU rowU
-        ILUPP_HIP(b_uv.alloc(sizeof(double) * (size_t)cap));
-        ILUPP_HIP(b_li.alloc(sizeof(int32_t) * (size_t)cap * 3));
-        ILUPP_HIP(b_lv.alloc(sizeof(double) * (size_t)cap));
-        ILUPP_HIP(b_si.alloc(sizeof(int32_t) * (size_t)cap));
-        ILUPP_HIP(b_sv.alloc(sizeof(double) * (size_t)cap));
-        DpArgs a;
-        a.n = n;
-        a.Ap = Arow.ptr; a.Ai = Arow.idx; a.Av = Arow.val;
-        a.Cp = Acol.ptr; a.Ci = Acol.idx; a.Cv = Acol.val;
-        a.threshold = tau; a.shift_schur = P.threshold_shift_schur; a.min_pivot = P.min_pivot; a.min_elim_factor = P.min_elim_factor;
-        a.piv_tol = P.piv_tol; a.move_level_factor = P.move_level_factor; a.row_u_max = P.row_u_max;
-        a.small_pivot_terminates = P.small_pivot_terminates ? 1 : 0; a.force_finish = force_finish ? 1 : 0; a.begin_total_piv = P.begin_total_piv ? 1 : 0;
-        a.final_row_crit = P.final_row_crit; a.bp = bp; a.bpr = bpr; a.epr = epr; a.max_fill = max_fill;
-        a.rules = P.rules; a.combine = P.combine; a.scale_invdiag = P.scale_invdiag ? 1 : 0;
-        for (int q = 0; q < 5; ++q) a.wgt[q] = P.wgt[q];
-        a.neutral = P.neutral; a.min_weight = P.min_weight;
-        a.perm = iarr(0); a.iperm = iarr(1); a.prow = iarr(2); a.iprow = iarr(3); a.numb = iarr(4); a.pnum = iarr(5);
-        a.nonpiv = iarr(6); a.unused = iarr(7); a.startU = iarr(8); a.startL = iarr(9);
-        a.zpos = iarr(10); a.zlist = iarr(11); a.wpos = iarr(12); a.wlist = iarr(13); a.cand = iarr(14);
-        a.Uptr = iarr(15); a.Lptr = iarr(16); a.Sptr = iarr(17);
-        a.Dinv = Dinv;
-        a.Uidx = b_ui.as<int32_t>(); a.linkU = a.Uidx + cap; a.rowU = a.linkU + cap; a.Uval = b_uv.as<double>(); a.capU = (int32_t)cap;
-        a.Lidx = b_li.as<int32_t>(); a.linkL = a.Lidx + cap; a.colL = a.linkL + cap; a.Lval = b_lv.as<double>(); a.capL = (int32_t)cap;
-        a.Sidx = b_si.as<int32_t>(); a.Sval = b_sv.as<double>(); a.capS = (int32_t)cap;
-        a.zval = b_d.as<double>(); a.wval = a.zval + slot; a.key = a.wval + slot;
-        a.sortk = b_sort.as<unsigned long long>();
-        a.ctrl = b_ctrl.as<int32_t>();
-        ILUPP_HIP(hipMemsetAsync(a.ctrl, 0, 64, st));
+    // the stores: what the factors of this level may grow to is not known beforehand.  The kernel stops BETWEEN two steps when a store
+    // has no room for another row; the store is doubled (contents copied) and the kernel goes on with that step (the reference's
+    // enlarge_fields_keep_data, :763-769)
+    struct Store {
+        PoolBlock idx, link, who, val;
+        int64_t cap = 0;
+        bool lists;
+        int grow(hipStream_t st, int64_t ncap, int64_t used) {
+            PoolBlock ni, nl, nw, nv;
+            ILUPP_HIP(ni.alloc(sizeof(int32_t) * (size_t)ncap));
+            ILUPP_HIP(nv.alloc(sizeof(double) * (size_t)ncap));
+            if (lists) { ILUPP_HIP(nl.alloc(sizeof(int32_t) * (size_t)ncap)); ILUPP_HIP(nw.alloc(sizeof(int32_t) * (size_t)ncap)); }
+            if (used > 0) {
+                ILUPP_HIP(hipMemcpyAsync(ni.p, idx.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
+                ILUPP_HIP(hipMemcpyAsync(nv.p, val.p, sizeof(double) * (size_t)used, hipMemcpyDeviceToDevice, st));
+                if (lists) {
+                    ILUPP_HIP(hipMemcpyAsync(nl.p, link.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
+                    ILUPP_HIP(hipMemcpyAsync(nw.p, who.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
+                }
+                ILUPP_HIP(hipStreamSynchronize(st));
+            }
+            idx.swap(ni); val.swap(nv); link.swap(nl); who.swap(nw);
+            cap = ncap;
+            return ILUPP_OK;
+        }
+    } SU, SL, SS;
+    SU.lists = SL.lists = true; SS.lists = false;
+    int64_t cap0 = 2 * nnz + 8 * (int64_t)n + 1024, capS0 = nnz + 2 * (int64_t)n + 1024;
+    if (const char *e = getenv("ILUPP_DP_STORE")) { cap0 = capS0 = (int64_t)n + 2 + atol(e); }        // (tests: stores that fill up after a few steps)
+    { int rc = SU.grow(st, cap0, 0); if (rc) return rc; rc = SL.grow(st, cap0, 0); if (rc) return rc; rc = SS.grow(st, capS0, 0); if (rc) return rc; }
+    PoolBlock b_dctrl;
+    ILUPP_HIP(b_dctrl.alloc(64));
+    DpArgs a;
+    a.n = n;
+    a.Ap = Arow.ptr; a.Ai = Arow.idx; a.Av = Arow.val;
+    a.Cp = Acol.ptr; a.Ci = Acol.idx; a.Cv = Acol.val;
+    a.threshold = tau; a.shift_schur = P.threshold_shift_schur; a.min_pivot = P.min_pivot; a.min_elim_factor = P.min_elim_factor;
+    a.piv_tol = P.piv_tol; a.move_level_factor = P.move_level_factor; a.row_u_max = P.row_u_max;
+    a.small_pivot_terminates = P.small_pivot_terminates ? 1 : 0; a.force_finish = force_finish ? 1 : 0; a.begin_total_piv = P.begin_total_piv ? 1 : 0;
+    a.final_row_crit = P.final_row_crit; a.bp = bp; a.bpr = bpr; a.epr = epr; a.max_fill = max_fill;
+    a.rules = P.rules; a.combine = P.combine; a.scale_invdiag = P.scale_invdiag ? 1 : 0;
+    for (int q = 0; q < 5; ++q) a.wgt[q] = P.wgt[q];
+    a.neutral = P.neutral; a.min_weight = P.min_weight;
+    a.perm = iarr(0); a.iperm = iarr(1); a.prow = iarr(2); a.iprow = iarr(3); a.numb = iarr(4); a.pnum = iarr(5);
+    a.nonpiv = iarr(6); a.unused = iarr(7); a.startU = iarr(8); a.startL = iarr(9);
+    a.zpos = iarr(10); a.zlist = iarr(11); a.wpos = iarr(12); a.wlist = iarr(13); a.cand = iarr(14);
+    a.Uptr = iarr(15); a.Lptr = iarr(16); a.Sptr = iarr(17);
+    a.Dinv = Dinv;
+    a.zval = b_d.as<double>(); a.wval = a.zval + slot; a.key = a.wval + slot;
+    a.sortk = b_sort.as<unsigned long long>();
+    a.ctrl = b_ctrl.as<int32_t>();
+    a.dctrl = b_dctrl.as<double>();
+    {
+        int32_t c0[16] = {0};
+        c0[1] = n - 1; c0[4] = 1;                                                   // last_row_to_eliminate, eliminating
+        const double d0[2] = {tau, P.piv_tol};
+        ILUPP_HIP(hipMemcpyAsync(a.ctrl, c0, sizeof(c0), hipMemcpyHostToDevice, st));
+        ILUPP_HIP(hipMemcpyAsync(a.dctrl, d0, sizeof(d0), hipMemcpyHostToDevice, st));
         ILUPP_HIP(hipMemsetAsync(a.Uptr, 0, sizeof(int32_t), st));
         ILUPP_HIP(hipMemsetAsync(a.Lptr, 0, sizeof(int32_t), st));
         ILUPP_HIP(hipMemsetAsync(a.Sptr, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_dp_init, dim3((n + 2 + 255) / 256), dim3(256), 0, st, n, epr, a.perm, a.iperm, a.prow, a.iprow, a.numb, a.pnum, a.nonpiv, a.unused,
-                           a.startU, a.startL, a.zpos, a.wpos, Dinv);
+        ILUPP_HIP(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(k_dp_init, dim3((n + 2 + 255) / 256), dim3(256), 0, st, n, epr, a.perm, a.iperm, a.prow, a.iprow, a.numb, a.pnum, a.nonpiv, a.unused,
+                       a.startU, a.startL, a.zpos, a.wpos, Dinv);
+    int32_t ctrl[16] = {0};
+    for (int launch = 0;; ++launch) {
+        a.Uidx = SU.idx.as<int32_t>(); a.linkU = SU.link.as<int32_t>(); a.rowU = SU.who.as<int32_t>(); a.Uval = SU.val.as<double>(); a.capU = (int32_t)SU.cap;
+        a.Lidx = SL.idx.as<int32_t>(); a.linkL = SL.link.as<int32_t>(); a.colL = SL.who.as<int32_t>(); a.Lval = SL.val.as<double>(); a.capL = (int32_t)SL.cap;
+        a.Sidx = SS.idx.as<int32_t>(); a.Sval = SS.val.as<double>(); a.capS = (int32_t)SS.cap;
         hipEvent_t e0, e1;
         ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
         ILUPP_HIP(hipEventRecord(e0, st));
         hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
         ILUPP_HIP(hipEventRecord(e1, st));
-        int32_t ctrl[8] = {0};
         ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
         float ms = 0.f;
         ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (kernel_ms) *kernel_ms += ms;
-        if (dbg) fprintf(stderr, "[ilupp] pilucdp: n %d, attempt %d (stores of %lld): status %d at step %d, %.2f ms\n", n, attempt, (long long)cap, ctrl[0], ctrl[5], ms);
-        if (ctrl[0] != 0) {
-            if (cap >= 0x7ffffff0ll || attempt > 8) { set_error("ILU++ with pivoting: the factors of a level outgrow 2^31 entries"); return ILUPP_ERR_UNSUPPORTED; }
-            cap *= 2;
-            continue;
-        }
+        if (dbg) fprintf(stderr, "[ilupp] pilucdp: n %d, launch %d (stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", n, launch, (long long)SU.cap,
+                         (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
+        if (ctrl[0] == 0) break;
+        Store &S = ctrl[0] == 1 ? SU : ctrl[0] == 2 ? SL : SS;
+        const int64_t used = ctrl[0] == 1 ? ctrl[8] : ctrl[0] == 2 ? ctrl[9] : ctrl[10];
+        if (S.cap >= 0x7ffffff0ll || (launch > 40 && !getenv("ILUPP_DP_STORE"))) { set_error("ILU++ with pivoting: the factors of a level outgrow 2^31 entries"); return ILUPP_ERR_UNSUPPORTED; }
+        int64_t ncap = getenv("ILUPP_DP_STORE") ? S.cap + (int64_t)n + 2 + atol(getenv("ILUPP_DP_STORE")) : 2 * S.cap + (int64_t)n + 1024;
+        if (ncap > 0x7ffffff0ll) ncap = 0x7ffffff0ll;
+        { const int rc = S.grow(st, ncap, used); if (rc) return rc; }
+    }
+    {
         const int32_t last = ctrl[1], nA = ctrl[2];
         const bool to_the_end = ctrl[4] != 0;
         // compress(), permute(permrows, ROW) / U.permute(perm, COLUMN), :1131-1151
@@ -597,7 +690,6 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         ILUPP_HIP(hipMemcpyAsync(pc2, a.perm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
         ILUPP_HIP(hipMemcpyAsync(pr2, a.prow, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
         ILUPP_HIP(hipStreamSynchronize(st));
-        break;
     }
     gd.keep = true;
     *Dinv_out = Dinv;

@@ -153,3 +153,40 @@ def level_arrays(lv):
     """a level (dict from oracle.ML.level or ilupp_amd._native.MultilevelPreconditioner.level) as a flat list of arrays"""
     return [np.asarray(lv["L"][0]), np.asarray(lv["L"][1]), np.asarray(lv["L"][2]), np.asarray(lv["U"][0]), np.asarray(lv["U"][1]), np.asarray(lv["U"][2]),
             lv["D"], lv["perm_rows"], lv["perm_cols"], lv["inv_perm_rows"], lv["inv_perm_cols"], lv["D_l"], lv["D_r"]]
+
+
+def block_to_oracle(O, blk):
+    """the C-ABI parameter block of the package (ilupp_amd._native.MLParams) as the oracle's block: same fields, by name"""
+    p = O.MLParams()
+    for name, _ in O.MLParams._fields_:
+        v = getattr(blk, name)
+        if name == "preprocessing":
+            for i in range(8):
+                p.preprocessing[i] = v[i]
+        else:
+            setattr(p, name, v)
+    return p
+
+
+def ml_npz_params(ilupp, config, thr, fill):
+    """the parameters of a case of tests/golden/ml.npz (oracle/ref_shim.cpp ref_ilupp_apply: default-constructed for config -1, else
+    default_configuration(config); then set_threshold, and set_fill_in if fill >= 0)"""
+    p = ilupp.iluplusplus_precond_parameter()
+    if config >= 0:
+        p.default_configuration(config)
+    p.threshold = thr
+    if fill >= 0:
+        p.fill_in = fill
+    return p
+
+
+def ml_npz_cases(z):
+    """(key of the matrix, tag, config, threshold, fill_in) of every case of ml.npz, failed ones included"""
+    out = []
+    for k in sorted(z.files):
+        if not (k.endswith("_info") or k.endswith("_error")) or not k.startswith("ml_"):
+            continue
+        key, tag = k.rsplit("_", 1)[0].split("/")
+        c, t, f = tag.split("_")
+        out.append((key, tag, int(c[1:]), float(t[1:]), int(f[1:])))
+    return out

@@ -143,8 +143,11 @@ def test_class_api():
     assert (P @ X).shape == (n, 2) and np.array_equal((P @ X)[:, 0], want)
     with pytest.raises(RuntimeError, match="vector has wrong size for preconditioner!"):
         P.pr.apply(np.ones(n - 1))
-    with pytest.raises(NotImplementedError, match="partialILUCDP"):
-        ilupp.ILUppPreconditioner(A, threshold=0.1)
+    # default-constructed parameters: the factorisation with pivoting (tests/test_gpu_mlp.py), on a small matrix -- it is a chain of n steps
+    A2 = sp.csr_matrix(matgen.random_dd(400, k=6, diag=2.0), shape=(400, 400))
+    Pd = ilupp.ILUppPreconditioner(A2, threshold=0.1)
+    Qd = O.orc().ml((A2.data, A2.indices, A2.indptr, True), O.ml_params(0.1, (O.PRE_PQ_ORDERING,), **O.PIVOTING_DEFAULTS))
+    assert Pd.total_nnz == Qd.total_nnz() and np.array_equal(Pd @ C.rhs(400), Qd.apply(C.rhs(400)))
 
 
 def test_device_entry_points_and_bicgstab():
@@ -197,8 +200,7 @@ def test_solve_like_the_reference_tests():
     assert np.allclose(ilupp.solve(A, A @ x_exact, atol=1e-8, params=param), x_exact)
     with pytest.raises(RuntimeError, match="did not converge"):
         ilupp.solve(C.laplace2d_matrix(900), np.ones(900), atol=1e-14, rtol=1e-14, max_iter=2, params=param)
-    with pytest.raises(NotImplementedError):
-        ilupp.solve(A, A @ x_exact)                 # default-constructed parameters: the pivoting factorisation
+    assert np.allclose(ilupp.solve(A, A @ x_exact, atol=1e-8), x_exact)      # default-constructed parameters: the pivoting factorisation
 
 
 MWM = ("MAX_WEIGHTED_MATCHING_ORDERING",)

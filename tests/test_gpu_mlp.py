@@ -1,0 +1,250 @@
+"""GPU parity tests of the multilevel ILU++ preconditioner WITH pivoting (ilupp_amd/csrc/pilucdp.hip; reference partialILUCDP,
+ILUCDP.hpp:268-1404 -- what the reference's default-constructed parameters, ILUppPreconditioner(A) and solve(A, b) run on).
+
+Bit for bit, as everywhere in this package:
+* the reference's own multilevel tests (test/tests.py:344-402), as they stand there;
+* the golden vectors of the REAL reference: tests/golden/ml.npz (default-constructed parameters and default_configuration(0, 1, 10, 11) on the
+  reference's test matrices: 120 cases) and tests/golden/mlp.npz (tests/ml_cases.py PIVOT_PARAMS: windows of the row reordering and of the
+  total pivoting, pivot tolerances, every FINAL_ROW_CRIT family, bounded fill, other dropping rules; CSR and CSC; up to 100 levels);
+* the oracle on random matrices with random parameters, and on matrices of 10^4 rows.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import matgen
+import ml_cases as C
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _digest(arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+def _native_ml(a, params):
+    from ilupp_amd import _native
+    return _native.MultilevelILUCDPPreconditioner(a[0], a[1], a[2], a[3], params)
+
+
+# ---- the reference's helpers and tests (test/tests.py:9-42, :344-402) ----
+def laplace_matrix(n, format="csr"):
+    h = 1.0 / (n + 1)
+    d = np.ones(n) / (h ** 2)
+    return sp.diags((-d[:-1], 2 * d, -d[:-1]), (-1, 0, 1)).asformat(format)
+
+
+def example_laplace2d(n_total):
+    n = int(np.sqrt(n_total))
+    A1, I = laplace_matrix(n), sp.eye(n)
+    A = (sp.kron(A1, I) + sp.kron(I, A1)).asformat("csr")
+    x_exact = np.ones(A.shape[0])
+    return A, A.dot(x_exact), x_exact
+
+
+def example_random(n, format="csc", eye_factor=10.0):
+    A = (sp.random(n, n, density=min(1.0, 5 / n), random_state=39273) + eye_factor * sp.eye(n)).asformat(format)
+    x_exact = np.ones(n)
+    return A, A.dot(x_exact), x_exact
+
+
+@pytest.mark.parametrize("setter", ["set_PQ", "set_MAX_WEIGHTED_MATCHING_ORDERING", "set_SPARSE_FIRST"])
+def test_ml_solve_laplace2d(setter):
+    import ilupp_amd as ilupp
+    A, b, x_exact = example_laplace2d(900)
+    param = ilupp.iluplusplus_precond_parameter()
+    getattr(param.PREPROCESSING, setter)()
+    param.threshold = 1e-2
+    x, info = ilupp.solve(A, b, atol=1e-8, rtol=1e-8, params=param, info=True)
+    assert np.allclose(x_exact, x)
+
+
+def test_ml_solve_laplace2d_MWM_sPQ_is_refused():
+    """test/tests.py:362-369: the symmetric PQ step of this sequence has no kernel -- refused by name, nothing replaced"""
+    import ilupp_amd as ilupp
+    A, b, x_exact = example_laplace2d(900)
+    param = ilupp.iluplusplus_precond_parameter()
+    param.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ()
+    param.threshold = 1e-2
+    with pytest.raises(NotImplementedError, match="SYMM_PQ"):
+        ilupp.solve(A, b, atol=1e-8, rtol=1e-8, params=param, info=True)
+
+
+def test_ml_solve_random():
+    import ilupp_amd as ilupp
+    A, b, x_exact = example_random(50)
+    x = ilupp.solve(A, b, atol=1e-8)
+    assert np.allclose(x, x_exact)
+
+
+def test_ml_precond_laplace():
+    import ilupp_amd as ilupp
+    n = 100
+    A = laplace_matrix(n)
+    b = np.ones(n)
+    P = ilupp.ILUppPreconditioner(A, threshold=0)
+    x = P.dot(b)
+    X = np.linspace(0, 1, n + 2)[1:-1]
+    assert np.allclose(x, X * (1 - X) / 2)
+    assert P.total_nnz > 0 and P.memory == 0.0
+
+
+def test_ml_precond_random():
+    import ilupp_amd as ilupp
+    A, b, x_exact = example_random(50)
+    P = ilupp.ILUppPreconditioner(A, threshold=0)
+    x = b.copy()
+    P.apply(x)
+    assert np.allclose(x, x_exact)
+
+
+# ---- golden vectors ----
+def test_presets_of_the_reference():
+    """tests/golden/ml.npz: ILUppPreconditioner(A, threshold, fill_in) of the reference with default-constructed parameters and
+    default_configuration(0, 1, 10, 11), 120 cases: levels, total_nnz, apply, apply_trans"""
+    import ilupp_amd as ilupp
+    z = np.load(os.path.join(HERE, "golden", "ml.npz"))
+    seen = refused = 0
+    for key, tag, config, thr, fill in C.ml_npz_cases(z):
+        a = (z[key + "/A_data"], z[key + "/A_indices"], z[key + "/A_indptr"], bool(z[key + "/A_is_csr"]))
+        n = a[2].shape[0] - 1
+        name = "%s/%s" % (key, tag)
+        try:
+            P = _native_ml(a, C.ml_npz_params(ilupp, config, thr, fill))
+        except NotImplementedError as e:
+            assert config == 11 and "undefined" in str(e), name
+            refused += 1
+            continue
+        assert (P.levels(), P.total_nnz) == tuple(int(v) for v in z[name + "_info"]), name
+        b = C.rhs(n)
+        x = b.copy(); P.apply(x)
+        assert np.array_equal(x, z[name + "_apply"], equal_nan=True), name
+        x = b.copy(); P.apply_trans(x)
+        assert np.array_equal(x, z[name + "_apply_trans"], equal_nan=True), name
+        seen += 1
+    assert seen + refused == 120 and seen >= 100
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+@pytest.mark.parametrize("name", [n for n, _ in C.matrices()])
+def test_reference_vectors(name, fmt):
+    import ilupp_amd as ilupp
+    gold = np.load(os.path.join(HERE, "golden", "mlp.npz"))
+    key = "%s_%s" % (name, fmt)
+    a = (gold[key + "/data"], gold[key + "/indices"], gold[key + "/indptr"], fmt == "csr")
+    b = C.rhs(a[2].shape[0] - 1)
+    for tag, thr, pre, knobs in C.PIVOT_PARAMS:
+        k2 = "%s/%s" % (key, tag)
+        P = _native_ml(a, C.engine_params(ilupp, thr, pre, knobs))
+        info = gold[k2 + "/info"]
+        assert P.levels() == info[0] and P.total_nnz == info[1], k2
+        for k in range(P.levels()):
+            assert np.array_equal(_digest(C.level_arrays(P.level(k))), gold[k2 + "/levels_sha"][k]), (k2, k)
+        x = b.copy(); P.apply(x)
+        assert np.array_equal(x, gold[k2 + "/apply"], equal_nan=True), k2
+        x = b.copy(); P.apply_trans(x)
+        assert np.array_equal(x, gold[k2 + "/apply_trans"], equal_nan=True), k2
+
+
+# ---- the oracle ----
+def _same(P, Q, n, what):
+    assert P.levels() == Q.levels() and P.total_nnz == Q.total_nnz(), what
+    for k in range(Q.levels()):
+        for q, (x, y) in enumerate(zip(C.level_arrays(P.level(k)), C.level_arrays(Q.level(k)))):
+            assert np.array_equal(x, y, equal_nan=(np.asarray(x).dtype.kind == "f")), (what, k, q)
+    b = C.rhs(n)
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, Q.apply(b), equal_nan=True), what
+    from oracle import oracle as O
+    x = b.copy(); P.apply_trans(x)
+    assert np.array_equal(x, Q.apply(b, O.TRANSPOSE), equal_nan=True), what
+
+
+def test_fuzz_against_the_oracle():
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    names = {v: k for k, v in C.PRE.items()}
+    for it in range(60):
+        n = int(rng.integers(3, 400))
+        A = (sp.random(n, n, min(1.0, rng.uniform(2, 8) / n), random_state=rng, data_rvs=lambda k: rng.standard_normal(k))
+             + sp.eye(n) * float(rng.choice([0.0, 0.5, 3.0]))).asformat("csr" if it % 2 else "csc")
+        A.sort_indices()
+        a = (A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32), bool(it % 2))
+        knobs = C.pivoting(piv_tol=float(rng.choice([1.0, 0.5, 0.1, 0.0])), PERMUTE_ROWS=int(rng.integers(0, 4)), TOTAL_PIV=int(rng.integers(0, 3)),
+                           BEGIN_TOTAL_PIV=bool(rng.integers(0, 2)), FINAL_ROW_CRIT=int(rng.integers(-1, 10)),
+                           MIN_ELIM_FACTOR=float(rng.choice([0.0, 0.3, 0.5])), SMALL_PIVOT_TERMINATES=bool(rng.integers(0, 2)),
+                           MOVE_LEVEL_FACTOR=float(rng.choice([0.5, 2.0])))
+        if rng.integers(0, 3) == 0:
+            knobs["fill_in"] = int(rng.integers(1, 8))
+        if rng.integers(0, 3) == 0:
+            knobs.update(USE_STANDARD_DROPPING=bool(rng.integers(0, 2)), USE_PIVOT_DROPPING=bool(rng.integers(0, 2)), USE_ERR_PROP_DROPPING2=bool(rng.integers(0, 2)),
+                         COMBINE_FACTOR=int(rng.integers(0, 4)))
+        pre = [("PQ_ORDERING",), ("MAX_WEIGHTED_MATCHING_ORDERING",), ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), ("SPARSE_FIRST_ORDERING",), ()][int(rng.integers(0, 5))]
+        thr = float(rng.choice([0.0, 1e-3, 1e-2, 0.1, 1.0]))
+        ep = C.engine_params(ilupp, thr, pre, knobs)
+        if ep._uses_partial_iluc():
+            continue
+        Q = O.orc().ml(a, C.oracle_params(O, thr, pre, knobs))
+        _same(_native_ml(a, ep), Q, n, (it, n, pre, thr, knobs))
+
+
+def test_larger():
+    """10^4 rows: thousands of sequential steps, stores that are enlarged, a second level from the fill criterion"""
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    n = 10000
+    for A, thr in (((sp.random(n, n, 5.0 / n, random_state=rng) + sp.eye(n) * 2).tocsr(), 1e-2), (C.laplace2d_matrix(n), 1e-2),
+                   (sp.csr_matrix(matgen.random_dd(n, k=7, diag=1.5), shape=(n, n)), 0.1)):
+        A.sort_indices()
+        a = (A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32), True)
+        p = ilupp.iluplusplus_precond_parameter()          # default-constructed: PQ + the pivoting factorisation
+        p.threshold = thr
+        Q = O.orc().ml(a, C.block_to_oracle(O, p._to_ml_params()))
+        _same(_native_ml(a, p), Q, n, (n, thr))
+        p.default_configuration(10)                        # BASELINE config 5: maximum weighted matching + the pivoting factorisation
+        p.threshold = thr
+        Q = O.orc().ml(a, C.block_to_oracle(O, p._to_ml_params()))
+        _same(_native_ml(a, p), Q, n, (n, thr, "config 10"))
+
+
+def test_stores_that_fill_up():
+    """the kernel stops between two steps when a store has no room for another row, the store is enlarged and the kernel goes on with that
+    step: with stores of a few hundred entries (ILUPP_DP_STORE) that happens dozens of times -- same bits"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np, scipy.sparse as sp
+sys.path[:0] = [%r, %r]
+import ml_cases as C
+import ilupp_amd as ilupp
+from ilupp_amd import _native
+from oracle import oracle as O
+for name, A in C.matrices():
+    if name not in ("laplace2d_400", "weak_200", "rdd_300"):
+        continue
+    A = A.tocsr(); A.sort_indices()
+    a = (A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32), True)
+    for tag, thr, pre, knobs in C.PIVOT_PARAMS[:6]:
+        Q = O.orc().ml(a, C.oracle_params(O, thr, pre, knobs))
+        P = _native.MultilevelILUCDPPreconditioner(a[0], a[1], a[2], True, C.engine_params(ilupp, thr, pre, knobs))
+        assert P.levels() == Q.levels() and P.total_nnz == Q.total_nnz(), (name, tag)
+        for k in range(Q.levels()):
+            for x, y in zip(C.level_arrays(P.level(k)), C.level_arrays(Q.level(k))):
+                assert np.array_equal(x, y, equal_nan=(np.asarray(x).dtype.kind == "f")), (name, tag, k)
+print("ok")
+''' % (os.path.dirname(HERE), HERE)
+    env = dict(os.environ, ILUPP_DP_STORE="150", ILUPP_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stderr.count("status 1 at step") + r.stderr.count("status 2 at step") > 20 and "status 3 at step" in r.stderr

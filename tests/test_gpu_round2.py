@@ -523,11 +523,9 @@ for fmt in ("csr", "csc"):
     Qm = O.orc().ml(M, O.ml_params(0.02))
     assert ML.total_nnz == Qm.total_nnz() and ML.pr.levels() == Qm.levels()
     assert np.array_equal(ML @ b, Qm.apply(b)) and np.array_equal(ML.T @ b, Qm.apply(b, O.TRANSPOSE))
-    try:
-        ilupp.ILUppPreconditioner(A)
-        raise SystemExit("the pivoting family was not refused")
-    except NotImplementedError:
-        pass
+    MLd = ilupp.ILUppPreconditioner(A)                                  # default-constructed parameters: the factorisation with pivoting
+    Qd = O.orc().ml(M, O.ml_params(1.0, (O.PRE_PQ_ORDERING,), **O.PIVOTING_DEFAULTS))
+    assert MLd.total_nnz == Qd.total_nnz() and np.array_equal(MLd @ b, Qd.apply(b))
     x, info = spla.gmres(A, b, M=P, atol=1e-10)
     assert info == 0
 try:

@@ -154,20 +154,17 @@ def test_parameter_block_of_the_built_family():
 
 
 def test_everything_outside_the_built_family_is_refused():
-    """no silent substitution: the pivoting factorisation of the default parameters, other dropping rules, bounded fill, preprocessing
-    steps without a kernel -- each raises NotImplementedError before anything runs"""
+    """no silent substitution: dropping rules that carry estimates over the steps, the improved Schur complement, positional dropping,
+    rows ordered by weights, preprocessing steps without a kernel -- each raises NotImplementedError before anything runs"""
     import ilupp_amd as ilupp
 
-    def refused(change):
+    def refused(change, start=1):
         p = ilupp.iluplusplus_precond_parameter()
-        p.default_configuration(1)
+        if start is not None:
+            p.default_configuration(start)
         change(p)
         with pytest.raises(NotImplementedError):
             p._to_ml_params()
-    with pytest.raises(NotImplementedError, match="pivoting"):
-        ilupp.iluplusplus_precond_parameter()._to_ml_params()
-    refused(lambda p: setattr(p, "piv_tol", 0.5))
-    refused(lambda p: setattr(p, "PERMUTE_ROWS", 3))
     refused(lambda p: p.use_only_inverse_dropping())
     refused(lambda p: setattr(p, "USE_WEIGHTED_DROPPING", True))
     refused(lambda p: setattr(p, "SCALE_WGT_MAXINVDIAG", True))
@@ -176,7 +173,25 @@ def test_everything_outside_the_built_family_is_refused():
     refused(lambda p: p.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ())
     refused(lambda p: setattr(p, "EXTERNAL_FINAL_ROW", True))
     refused(lambda p: setattr(p, "PRECON_PARAMETER", -1))
-    # ... and through the class: default-constructed parameters (ilupp/__init__.py:186-190) select the pivoting factorisation
-    A = sp.eye(4, format="csr")
-    with pytest.raises(NotImplementedError, match="partialILUCDP"):
-        ilupp.ILUppPreconditioner(A)
+    refused(lambda p: setattr(p, "FINAL_ROW_CRIT", -2), start=None)       # rows by accumulated weights (a sorted container): with pivoting only
+    refused(lambda p: setattr(p, "SCHUR_COMPLEMENT", 1), start=None)
+    with pytest.raises(ValueError):
+        p = ilupp.iluplusplus_precond_parameter(); p.PERMUTE_ROWS = 4; p._to_ml_params()
+
+
+def test_parameter_block_of_the_pivoting_family():
+    """the reference's default-constructed parameters (parameters_implementation.h:430-501) select partialILUCDP
+    (preconditioner_implementation.h:1376-1382): the block carries its windows and tolerances"""
+    import ilupp_amd as ilupp
+    p = ilupp.iluplusplus_precond_parameter()
+    assert not p._uses_partial_iluc()
+    b = p._to_ml_params()
+    assert (b.piv_tol, b.permute_rows, b.total_piv, b.begin_total_piv, b.final_row_crit, b.move_level_factor, b.row_u_max) == (1.0, 3, 1, 1, -1, 2.0, 1.5)
+    assert (b.small_pivot_terminates, b.min_elim_factor, b.n_preprocessing, list(b.preprocessing)[:1], b.drop_rules) == (0, 0.5, 1, [3], 4)
+    p.default_configuration(10)                     # BASELINE config 5: maximum weighted matching + the pivoting factorisation
+    b = p._to_ml_params()
+    assert (b.permute_rows, b.total_piv, b.piv_tol, list(b.preprocessing)[:b.n_preprocessing]) == (3, 1, 1.0, [4])
+    p.default_configuration(1)
+    assert p._uses_partial_iluc()
+    p.piv_tol = 0.5
+    assert not p._uses_partial_iluc() and p._to_ml_params().piv_tol == 0.5
