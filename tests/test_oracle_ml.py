@@ -187,7 +187,7 @@ def test_parameter_block_of_the_pivoting_family():
     assert not p._uses_partial_iluc()
     b = p._to_ml_params()
     assert (b.piv_tol, b.permute_rows, b.total_piv, b.begin_total_piv, b.final_row_crit, b.move_level_factor, b.row_u_max) == (1.0, 3, 1, 1, -1, 2.0, 1.5)
-    assert (b.small_pivot_terminates, b.min_elim_factor, b.n_preprocessing, list(b.preprocessing)[:1], b.drop_rules) == (0, 0.5, 1, [3], 4)
+    assert (b.small_pivot_terminates, b.min_elim_factor, b.n_preprocessing, list(b.preprocessing)[:3], b.drop_rules) == (0, 0.5, 3, [1, 2, 3], 4)   # set_PQ: normalisation + PQ
     p.default_configuration(10)                     # BASELINE config 5: maximum weighted matching + the pivoting factorisation
     b = p._to_ml_params()
     assert (b.permute_rows, b.total_piv, b.piv_tol, list(b.preprocessing)[:b.n_preprocessing]) == (3, 1, 1.0, [4])
