@@ -171,10 +171,24 @@ def extra_config(name, dev, steps):
         prm.threshold = 1e-3
         make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
         what = "C5M: ILUppPreconditioner(MAX_WEIGHTED_MATCHING_ORDERING, preset 10 without pivoting, threshold=1e-3), random unsymmetric CSR n=1e6 (matching on one host core)"
+    elif name == "C5P":
+        # BASELINE config 5 AS NAMED: default_configuration(10) = maximum weighted matching + the factorisation WITH pivoting (partialILUCDP).
+        # The factorisation is a chain of n steps (every step picks its column by the values of the step, its row by the fill so far): one
+        # wave of the GPU walks it, ~25 us per step -- n = 1e6 takes 26.6 s (profiles/r03_c5p.txt; the reference 6.8 s on one host core),
+        # so the default run measures n = 1e5 and says so.
+        import ilupp_amd as ilupp
+        d, i, p = matgen.random_dd(100000, 8, 25.0, 12345)
+        prm = ilupp.iluplusplus_precond_parameter()
+        prm.default_configuration(10)
+        prm.threshold = 1e-3
+        make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
+        what = ("C5P: ILUppPreconditioner(default_configuration(10): MAX_WEIGHTED_MATCHING_ORDERING + the factorisation WITH pivoting, threshold=1e-3), "
+                "random unsymmetric CSR n=1e5 (a chain of n sequential steps on one wave; n=1e6: 26.6 s)")
     elif name == "C5":
         # BASELINE config 5's shape (unsymmetric CSR, n = 1e6) with the multilevel preconditioner this build has: default_configuration(1)
-        # = normalisation + PQ ordering + the factorisation WITHOUT pivoting (preset 10).  BASELINE names default_configuration(10),
-        # whose factorisation pivots (partialILUCDP): not built, and not substituted -- the line says which one ran.
+        # = normalisation + PQ ordering + the factorisation WITHOUT pivoting (preset 10): the parameter family whose rows and columns are
+        # fixed beforehand and that runs as a dataflow computation on all CUs.  BASELINE names default_configuration(10), whose factorisation
+        # pivots (partialILUCDP, a sequential chain): that one is "C5P" -- every line says which one ran.
         import ilupp_amd as ilupp
         d, i, p = matgen.random_dd(1000000, 8, 25.0, 12345)
         prm = ilupp.iluplusplus_precond_parameter()
@@ -212,7 +226,7 @@ def extra_config(name, dev, steps):
         P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
         t = P.timings()
         nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
-        if name in ("C5", "C5M"):
+        if name in ("C5", "C5M", "C5P"):
             t["numeric_kernel_ms"] = t["kernel_ms"]
             levels = P.levels()
             nnz_out = sum(sum(P.level_sizes(k)[1:]) for k in range(levels))      # both unit diagonals stored, per level
@@ -223,7 +237,7 @@ def extra_config(name, dev, steps):
     nf = 1 if name == "C4" else 2
     fbytes = (12 * nnz + 4 * (n + 1)) + (12 * nnz_out + 4 * (n + 1) * nf)
     sec = float(np.median(walls))
-    more = {"levels": int(levels)} if name in ("C5", "C5M") else {}
+    more = {"levels": int(levels)} if name in ("C5", "C5M", "C5P") else {}
     return {**more, "workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
             "numeric_kernel_ms": float(np.median(kms)), "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
@@ -239,8 +253,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "ILUC", "S27", "S9"],
-                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, C5M, ILUC)")
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "C5P", "ILUC", "S27", "S9"],
+                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, C5M, C5P, ILUC)")
     ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, C5, ILUC) and the refactor loop")
     args = ap.parse_args()
 
@@ -492,9 +506,9 @@ def main():
         extra = {}
         cfgs = list(args.config)
         if not args.no_extra and world == 1:
-            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "ILUC") if c not in cfgs] + cfgs
+            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "C5P", "ILUC") if c not in cfgs] + cfgs
         for cfg in cfgs:
-            if cfg in ("C3", "C4", "C5", "C5M", "ILUC", "S27", "S9") and world == 1:
+            if cfg in ("C3", "C4", "C5", "C5M", "C5P", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))

@@ -33,6 +33,10 @@
 
 namespace ilupp {
 
+// an entry of a working vector, by index: its value and its slot in the insertion-ordered list (-1: not in the vector; -2: dead -- a column
+// that has been a pivot / a row that has been eliminated: never touched again).  One 16-byte load answers "may I?", "where?" and "how much?".
+struct __attribute__((aligned(16))) DpRec { double val; int32_t slot; int32_t pad; };
+
 struct DpArgs {
     int32_t n;
     const int32_t *Ap, *Ai; const double *Av;          // the level's matrix by rows
@@ -47,15 +51,15 @@ struct DpArgs {
     int32_t *Uptr, *Uidx, *linkU, *rowU, *startU; double *Uval; int32_t capU;
     int32_t *Lptr, *Lidx, *linkL, *colL, *startL; double *Lval; int32_t capL;
     int32_t *Sptr, *Sidx; double *Sval; int32_t capS;   // the Schur complement's rows as they come (column indices of this level)
-    double *zval, *wval; int32_t *zpos, *zlist, *wpos, *wlist;
+    struct DpRec *zrec, *wrec; int32_t *zlist, *wlist;     // the two working vectors (below)
     double *key; int32_t *cand; unsigned long long *sortk;
     int32_t *ctrl;     // [0] status (0 done; 1 / 2 / 3: the store of U / L / the Schur complement has no room for another row: enlarge it and
                        // launch again), [1] last_row_to_eliminate, [2] n_Anew, [3] zero pivots, [4] eliminating (still / to the end),
-                       // [5] the step to go on with, [6] / [7] entries of z / w to clear, [8] / [9] entries of U / L so far, [10] of the Schur complement
+                       // [5] the step to go on with, [6] / [7] entries of z / w to clear, [8] / [9] entries of U / L so far, [10] of the Schur complement, [11] the pivot column of the step before
     double *dctrl;     // [0] the threshold, [1] the pivot tolerance of the moment
 };
 
-struct SpVec { double *val; int32_t *pos; int32_t *list; };      // value by index, index -> slot (or -1), slot -> index (insertion order)
+struct SpVec { DpRec *rec; int32_t *list; };      // by index: value and slot; slot -> index (insertion order)
 
 #define DP_SYNC() do { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); } while (0)
 
@@ -66,7 +70,7 @@ __device__ double dp_seq_sum(const SpVec &v, int nnz, int mode, int lane)
     double acc = 0.0;
     for (int base = 0; base < nnz; base += 64) {
         const int s = base + lane;
-        const double x = s < nnz ? v.val[v.list[s]] : 0.0;
+        const double x = s < nnz ? v.rec[v.list[s]].val : 0.0;
         const double t = mode == 0 ? fabs(x) : x * x;
         const int cnt = nnz - base < 64 ? nnz - base : 64;
         for (int i = 0; i < cnt; ++i) { const double ti = __shfl(t, i); acc = acc + ti; }
@@ -120,7 +124,7 @@ __device__ int dp_take(const DpArgs &A, const SpVec &v, int nnz, bool single, do
         const int s = base + lane;
         const bool act = s < nnz;
         const int idx = act ? v.list[s] : 0;
-        const double x = act ? v.val[idx] : 0.0;
+        const double x = act ? v.rec[idx].val : 0.0;
         const double kx = single ? weight * fabs(x) : fabs(x);
         const bool ok = act && (single ? kx >= thr : kx > thr);
         const unsigned long long mask = __ballot(ok);
@@ -154,29 +158,33 @@ __device__ int dp_take(const DpArgs &A, const SpVec &v, int nnz, bool single, do
 // v[idx] exists afterwards (operator[] inserts a zero, sparse_implementation.h:980-994)
 __device__ __forceinline__ void dp_touch(const SpVec &v, int &nnz, int idx, int lane)
 {
-    if (v.pos[idx] < 0) {
-        if (lane == 0) { v.list[nnz] = idx; v.pos[idx] = nnz; v.val[idx] = 0.0; }
+    if (v.rec[idx].slot < 0) {
+        if (lane == 0) { v.list[nnz] = idx; v.rec[idx] = DpRec{0.0, nnz, 0}; }
         ++nnz;
         DP_SYNC();
     }
 }
 
-// v -= f * (the entries e0 .. e1 of a stored row / column) where `live` allows, new indices appended in entry order
-__device__ __forceinline__ void dp_subtract(const SpVec &v, int &nnz, double f, const int32_t *idx, const double *val, int e0, int e1, const int32_t *live, int lane)
+// v -= f * (the entries e0 .. e1 of a stored row / column) where the entry's index is not dead, new indices appended in entry order;
+// this lane's entry of the first 64 (index c0, value v0) has been fetched ahead
+__device__ __forceinline__ void dp_subtract(const SpVec &v, int &nnz, double f, const int32_t *idx, const double *val, int e0, int e1, int c0, double v0, int lane)
 {
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int base = e0; base < e1; base += 64) {
         const int e = base + lane;
         const bool act = e < e1;
-        const int c = act ? idx[e] : 0;
-        const bool ok = act && live[c] != 0;
-        const int sl = ok ? v.pos[c] : 0;
-        const bool isnew = ok && sl < 0;
+        const int c = base == e0 ? c0 : (act ? idx[e] : 0);
+        const double ev = base == e0 ? v0 : (act ? val[e] : 0.0);
+        DpRec r{0.0, -2, 0};
+        if (act) r = v.rec[c];
+        const bool ok = act && r.slot != -2;
+        const bool isnew = ok && r.slot < 0;
         const unsigned long long mask = __ballot(isnew);
-        double cur = 0.0;
-        if (isnew) { const int s = nnz + __popcll(mask & lt); v.list[s] = c; v.pos[c] = s; }
-        else if (ok) cur = v.val[c];
-        if (ok) { const double prod = f * val[e]; v.val[c] = cur - prod; }
+        if (ok) {
+            const double prod = f * ev;
+            if (isnew) { const int s = nnz + __popcll(mask & lt); v.list[s] = c; v.rec[c] = DpRec{0.0 - prod, s, 0}; }
+            else v.rec[c].val = r.val - prod;
+        }
         nnz += __popcll(mask);
     }
     DP_SYNC();
@@ -185,6 +193,7 @@ __device__ __forceinline__ void dp_subtract(const SpVec &v, int &nnz, double f, 
 // a node of a row's / column's list (the entry `at` of the other factor's store): which row / column it belongs to, its value, the next node
 struct DpNode { int at, who, link; double v; };
 struct DpRow { double dinv; int e0, e1; };
+struct DpEnt { int c; double v; };
 __device__ __forceinline__ DpNode dp_node(const int32_t *who, const double *val, const int32_t *link, int at)
 {
     DpNode nd{at, 0, -1, 0.0};
@@ -198,22 +207,30 @@ __device__ __forceinline__ DpRow dp_row(const double *Dinv, const int32_t *ptr, 
     return r;
 }
 
+__device__ __forceinline__ DpEnt dp_ent(const int32_t *idx, const double *val, const DpRow &r, int lane)
+{
+    DpEnt t{0, 0.0};
+    if (r.e0 + lane < r.e1) { t.c = idx[r.e0 + lane]; t.v = val[r.e0 + lane]; }
+    return t;
+}
+
 __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
 {
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int n = A.n;
-    const SpVec z{A.zval, A.zpos, A.zlist}, w{A.wval, A.wpos, A.wlist};
+    const SpVec z{A.zrec, A.zlist}, w{A.wrec, A.wlist};
     // the state of the chain between two steps (a launch goes on where the one before it had to stop for a larger store)
     int znnz = A.ctrl[6], wnnz = A.ctrl[7];
     bool eliminate = A.ctrl[4] != 0, end_level_now = false;
     double piv_tol = A.dctrl[1], threshold = A.dctrl[0];
     int last = A.ctrl[1], nA = A.ctrl[2], zero_piv = A.ctrl[3], pos_pivot = -1;
     int pU = A.ctrl[8], pL = A.ctrl[9], pS = A.ctrl[10];
+    int prev_pivot = A.ctrl[11];                                                  // the column the step before took as its pivot (-1: none)
     const double nnzA = (double)A.Cp[n];
     const int row_max = (A.max_fill < n ? A.max_fill : n) + 1;                       // what one step can add to a store
 #define DP_STOP(code) do { if (lane == 0) { A.ctrl[0] = (code); A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; \
-                                            A.ctrl[5] = k; A.ctrl[6] = znnz; A.ctrl[7] = wnnz; A.ctrl[8] = pU; A.ctrl[9] = pL; A.ctrl[10] = pS; \
+                                            A.ctrl[5] = k; A.ctrl[6] = znnz; A.ctrl[7] = wnnz; A.ctrl[8] = pU; A.ctrl[9] = pL; A.ctrl[10] = pS; A.ctrl[11] = prev_pivot; \
                                             A.dctrl[0] = threshold; A.dctrl[1] = piv_tol; } return; } while (0)
 
     for (int k = A.ctrl[5]; k < n; ++k) {
@@ -222,10 +239,12 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
         if (!eliminate && (long)pS + row_max > (long)A.capS) DP_STOP(3);
         if (A.begin_total_piv && k == A.bp) piv_tol = 1.0;                          // :448
         const int sel = A.prow[k];                                                  // (2.) :453-466
-        for (int s = lane; s < znnz; s += 64) z.pos[z.list[s]] = -1;
-        for (int s = lane; s < wnnz; s += 64) w.pos[w.list[s]] = -1;
+        // the vectors of the step before are cleared -- but the column that was its pivot and the row of this step are dead from now on
+        for (int s = lane; s < znnz; s += 64) { const int c = z.list[s]; if (c != prev_pivot) z.rec[c].slot = -1; }
+        for (int s = lane; s < wnnz; s += 64) { const int r = w.list[s]; if (r != sel) w.rec[r].slot = -1; }
         znnz = wnnz = 0;
-        if (lane == 0) A.unused[sel] = 0;
+        prev_pivot = -1;
+        if (lane == 0) { A.unused[sel] = 0; w.rec[sel].slot = -2; }
         DP_SYNC();
         {
             const int r0 = A.Ap[sel], r1 = A.Ap[sel + 1];
@@ -237,51 +256,56 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                 const bool ok = act && A.nonpiv[c] != 0;
                 const bool first = ok && c != pc;
                 const unsigned long long mask = __ballot(first);
-                if (first) { const int s = znnz + __popcll(mask & lt); z.list[s] = c; z.pos[c] = s; z.val[c] = A.Av[e]; }
+                if (first) { const int s = znnz + __popcll(mask & lt); z.list[s] = c; z.rec[c] = DpRec{A.Av[e], s, 0}; }
                 znnz += __popcll(mask);
                 unsigned long long dup = __ballot(ok && !first);                     // a column stored twice in the row: the last value stands
                 if (dup) {
                     DP_SYNC();
                     if (lane == 0)
-                        while (dup) { const int b = __ffsll((long long)dup) - 1; dup &= dup - 1; z.val[A.Ai[base + b]] = A.Av[base + b]; }
+                        while (dup) { const int b = __ffsll((long long)dup) - 1; dup &= dup - 1; z.rec[A.Ai[base + b]].val = A.Av[base + b]; }
                 }
             }
             DP_SYNC();
         }
         {                                                                           // (3.) :472-487: the rows of U this row has multipliers for
-            // the list is walked two nodes ahead: a node's fields, and then the pivot and the extent of the row it names, are on their way
-            // while the row before it is subtracted (a node costs four dependent round trips instead of six)
+            // the list is walked three nodes ahead: a node's fields, then the pivot and the extent of the row it names, then the first 64 entries
+            // of that row are on their way while the rows before it are subtracted (a node costs two dependent round trips -- the records of
+            // its columns, the stores -- instead of six)
             DpNode n1 = dp_node(A.colL, A.Lval, A.linkL, A.startL[sel]);
             DpRow a1 = dp_row(A.Dinv, A.Uptr, n1);
+            DpEnt t1 = dp_ent(A.Uidx, A.Uval, a1, lane);
             DpNode n2 = dp_node(A.colL, A.Lval, A.linkL, n1.link);
+            DpRow a2 = dp_row(A.Dinv, A.Uptr, n2);
+            DpNode n3 = dp_node(A.colL, A.Lval, A.linkL, n2.link);
             while (n1.at != -1) {
-                const DpRow a2 = dp_row(A.Dinv, A.Uptr, n2);
-                const DpNode n3 = dp_node(A.colL, A.Lval, A.linkL, n2.link);
+                const DpEnt t2 = dp_ent(A.Uidx, A.Uval, a2, lane);
+                const DpRow a3 = dp_row(A.Dinv, A.Uptr, n3);
+                const DpNode n4 = dp_node(A.colL, A.Lval, A.linkL, n3.link);
                 const double f = n1.v / a1.dinv;
-                dp_subtract(z, znnz, f, A.Uidx, A.Uval, a1.e0, a1.e1, A.nonpiv, lane);
-                n1 = n2; a1 = a2; n2 = n3;
+                dp_subtract(z, znnz, f, A.Uidx, A.Uval, a1.e0, a1.e1, t1.c, t1.v, lane);
+                n1 = n2; a1 = a2; t1 = t2; n2 = n3; a2 = a3; n3 = n4;
             }
         }
         double pivot = 0.0;
         if (eliminate) {                                                            // the pivot, :540-558
             double best = 0.0;
             int bslot = 0x7fffffff;
-            for (int s = lane; s < znnz; s += 64) { const double v = fabs(z.val[z.list[s]]); if (v > best) { best = v; bslot = s; } }
+            for (int s = lane; s < znnz; s += 64) { const double v = fabs(z.rec[z.list[s]].val); if (v > best) { best = v; bslot = s; } }
             for (int off = 32; off > 0; off >>= 1) {
                 const double ob = __shfl_xor(best, off);
                 const int os = __shfl_xor(bslot, off);
                 if (ob > best || (ob == best && os < bslot)) { best = ob; bslot = os; }
             }
             pos_pivot = bslot == 0x7fffffff ? -1 : z.list[bslot];
-            const double val_larg_el = pos_pivot >= 0 ? z.val[pos_pivot] : 0.0;
+            const double val_larg_el = pos_pivot >= 0 ? z.rec[pos_pivot].val : 0.0;
             if (A.nonpiv[sel] != 0) {
                 dp_touch(z, znnz, sel, lane);
-                const double zs = z.val[sel];
+                const double zs = z.rec[sel].val;
                 if (fabs(val_larg_el * piv_tol) > fabs(zs) && pos_pivot >= 0 && A.piv_tol > 0) pivot = val_larg_el;
                 else { pos_pivot = sel; pivot = zs; }
             } else {
                 if (fabs(val_larg_el) > 0.0 && pos_pivot >= 0) pivot = val_larg_el;
-                else { pos_pivot = A.perm[k]; dp_touch(z, znnz, pos_pivot, lane); pivot = z.val[pos_pivot]; }
+                else { pos_pivot = A.perm[k]; dp_touch(z, znnz, pos_pivot, lane); pivot = z.rec[pos_pivot].val; }
             }
         }
         if (eliminate && !A.force_finish && (double)k > A.min_elim_factor * (double)n && A.small_pivot_terminates && fabs(pivot) < A.min_pivot) {   // :595-612
@@ -294,16 +318,17 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
         double dinv = 1.0;
         if (eliminate) {                                                            // :613-629
             dinv = 1.0 / pivot;
-            for (int s = lane; s < znnz; s += 64) { const int c = z.list[s]; z.val[c] = z.val[c] * dinv; }
+            for (int s = lane; s < znnz; s += 64) { const int c = z.list[s]; z.rec[c].val = z.rec[c].val * dinv; }
             DP_SYNC();
             if (lane == 0) {
-                z.val[pos_pivot] = 0.0;
+                z.rec[pos_pivot] = DpRec{0.0, -2, 0};                                // (eliminated for the sorting, :619; dead as a column from here on)
                 const int pk = A.perm[k], p = A.iperm[pos_pivot];
                 const int t = A.iperm[pk]; A.iperm[pk] = A.iperm[pos_pivot]; A.iperm[pos_pivot] = t;
                 const int u = A.perm[k]; A.perm[k] = A.perm[p]; A.perm[p] = u;
                 A.nonpiv[pos_pivot] = 0;
                 A.Dinv[k] = dinv;
             }
+            prev_pivot = pos_pivot;
             DP_SYNC();
             {                                                                       // the column of L, :633-651
                 const int c = pos_pivot;                                            // = perm[k] now
@@ -316,28 +341,32 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                     const bool ok = act && A.unused[r] != 0;
                     const bool first = ok && r != pr;
                     const unsigned long long mask = __ballot(first);
-                    if (first) { const int s = wnnz + __popcll(mask & lt); w.list[s] = r; w.pos[r] = s; w.val[r] = A.Cv[e]; }
+                    if (first) { const int s = wnnz + __popcll(mask & lt); w.list[s] = r; w.rec[r] = DpRec{A.Cv[e], s, 0}; }
                     wnnz += __popcll(mask);
                     unsigned long long dup = __ballot(ok && !first);
                     if (dup) {
                         DP_SYNC();
                         if (lane == 0)
-                            while (dup) { const int b = __ffsll((long long)dup) - 1; dup &= dup - 1; w.val[A.Ci[base + b]] = A.Cv[base + b]; }
+                            while (dup) { const int b = __ffsll((long long)dup) - 1; dup &= dup - 1; w.rec[A.Ci[base + b]].val = A.Cv[base + b]; }
                     }
                 }
                 DP_SYNC();
                 DpNode n1 = dp_node(A.rowU, A.Uval, A.linkU, A.startU[c]);
                 DpRow a1 = dp_row(A.Dinv, A.Lptr, n1);
+                DpEnt t1 = dp_ent(A.Lidx, A.Lval, a1, lane);
                 DpNode n2 = dp_node(A.rowU, A.Uval, A.linkU, n1.link);
+                DpRow a2 = dp_row(A.Dinv, A.Lptr, n2);
+                DpNode n3 = dp_node(A.rowU, A.Uval, A.linkU, n2.link);
                 while (n1.at != -1) {
-                    const DpRow a2 = dp_row(A.Dinv, A.Lptr, n2);
-                    const DpNode n3 = dp_node(A.rowU, A.Uval, A.linkU, n2.link);
+                    const DpEnt t2 = dp_ent(A.Lidx, A.Lval, a2, lane);
+                    const DpRow a3 = dp_row(A.Dinv, A.Lptr, n3);
+                    const DpNode n4 = dp_node(A.rowU, A.Uval, A.linkU, n3.link);
                     const double f = n1.v / a1.dinv;
-                    dp_subtract(w, wnnz, f, A.Lidx, A.Lval, a1.e0, a1.e1, A.unused, lane);
-                    n1 = n2; a1 = a2; n2 = n3;
+                    dp_subtract(w, wnnz, f, A.Lidx, A.Lval, a1.e0, a1.e1, t1.c, t1.v, lane);
+                    n1 = n2; a1 = a2; t1 = t2; n2 = n3; a2 = a3; n3 = n4;
                 }
             }
-            for (int s = lane; s < wnnz; s += 64) { const int r = w.list[s]; w.val[r] = w.val[r] * dinv; }     // :652
+            for (int s = lane; s < wnnz; s += 64) { const int r = w.list[s]; w.rec[r].val = w.rec[r].val * dinv; }     // :652
             DP_SYNC();
         }
         // ---- dropping in the row, :714-759 ----
@@ -358,7 +387,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             pU += nU + 1;
             for (int j = lane; j < nU; j += 64) {
                 const int pos = p0 + 1 + j, c = A.cand[nU - 1 - j];
-                A.Uval[pos] = z.val[c]; A.Uidx[pos] = c;
+                A.Uval[pos] = z.rec[c].val; A.Uidx[pos] = c;
                 A.linkU[pos] = A.startU[c]; A.startU[c] = pos; A.rowU[pos] = k;
             }
             if (lane == 0) {
@@ -370,7 +399,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             const int kA = k - last - 1;
             const int p0 = pU, q0 = pS;
             pU += 1; pS += nU;
-            for (int j = lane; j < nU; j += 64) { const int c = A.cand[nU - 1 - j]; A.Sval[q0 + j] = z.val[c]; A.Sidx[q0 + j] = c; }
+            for (int j = lane; j < nU; j += 64) { const int c = A.cand[nU - 1 - j]; A.Sval[q0 + j] = z.rec[c].val; A.Sidx[q0 + j] = c; }
             if (lane == 0) {
                 A.Uval[p0] = 1.0; A.Uidx[p0] = A.perm[k]; A.Uptr[k + 1] = p0 + 1; A.Dinv[k] = 1.0;
                 A.Sptr[kA + 1] = q0 + nU;
@@ -386,7 +415,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             pL += nL + 1;
             for (int j = lane; j < nL; j += 64) {
                 const int pos = p0 + 1 + j, b = A.cand[j];
-                A.Lval[pos] = w.val[b]; A.Lidx[pos] = b;
+                A.Lval[pos] = w.rec[b].val; A.Lidx[pos] = b;
                 A.linkL[pos] = A.startL[b]; A.startL[b] = pos; A.colL[pos] = k;
             }
             if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + nL + 1; }
@@ -467,12 +496,12 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
 
 // ---------------------------------------------- the stores -> matrices ----------------------------------------------
 __global__ void k_dp_init(int32_t n, int32_t epr, int32_t *perm, int32_t *iperm, int32_t *prow, int32_t *iprow, int32_t *numb, int32_t *pnum,
-                          int32_t *nonpiv, int32_t *unused, int32_t *startU, int32_t *startL, int32_t *zpos, int32_t *wpos, double *Dinv)
+                          int32_t *nonpiv, int32_t *unused, int32_t *startU, int32_t *startL, DpRec *zrec, DpRec *wrec, double *Dinv)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         perm[i] = iperm[i] = prow[i] = iprow[i] = i;                               // :408-413
-        numb[i] = 0; nonpiv[i] = 1; unused[i] = 1; startU[i] = -1; startL[i] = -1; zpos[i] = -1; wpos[i] = -1; Dinv[i] = 1.0;
+        numb[i] = 0; nonpiv[i] = 1; unused[i] = 1; startU[i] = -1; startL[i] = -1; zrec[i] = DpRec{0.0, -1, 0}; wrec[i] = DpRec{0.0, -1, 0}; Dinv[i] = 1.0;
     }
     if (i < n + 2) pnum[i] = i == 0 ? 0 : epr + 1;                                  // :417, :437
 }
@@ -567,10 +596,10 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     int sortN = 64;
     while (sortN < n) sortN *= 2;
     PoolBlock b_i, b_d, b_sort, b_ctrl;
-    // int arrays of n (+2) entries: perm iperm prow iprow numb pnum nonpiv unused startU startL zpos zlist wpos wlist cand Uptr Lptr Sptr
+    // int arrays of n (+2) entries: perm iperm prow iprow numb pnum nonpiv unused startU startL - zlist - wlist cand Uptr Lptr Sptr
     const size_t slot = ((size_t)n + 64) & ~(size_t)15;
     ILUPP_HIP(b_i.alloc(sizeof(int32_t) * slot * 18));
-    ILUPP_HIP(b_d.alloc(sizeof(double) * slot * 3));                                // zval wval key
+    ILUPP_HIP(b_d.alloc(sizeof(double) * slot * 5));                                // key, the records of z and of w (16 bytes each)
     ILUPP_HIP(b_sort.alloc(sizeof(unsigned long long) * (size_t)sortN));
     ILUPP_HIP(b_ctrl.alloc(64));
     int32_t *I = b_i.as<int32_t>();
@@ -624,16 +653,17 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     a.neutral = P.neutral; a.min_weight = P.min_weight;
     a.perm = iarr(0); a.iperm = iarr(1); a.prow = iarr(2); a.iprow = iarr(3); a.numb = iarr(4); a.pnum = iarr(5);
     a.nonpiv = iarr(6); a.unused = iarr(7); a.startU = iarr(8); a.startL = iarr(9);
-    a.zpos = iarr(10); a.zlist = iarr(11); a.wpos = iarr(12); a.wlist = iarr(13); a.cand = iarr(14);
+    a.zlist = iarr(11); a.wlist = iarr(13); a.cand = iarr(14);
     a.Uptr = iarr(15); a.Lptr = iarr(16); a.Sptr = iarr(17);
     a.Dinv = Dinv;
-    a.zval = b_d.as<double>(); a.wval = a.zval + slot; a.key = a.wval + slot;
+    a.key = b_d.as<double>();
+    a.zrec = reinterpret_cast<DpRec *>(a.key + slot); a.wrec = a.zrec + slot;
     a.sortk = b_sort.as<unsigned long long>();
     a.ctrl = b_ctrl.as<int32_t>();
     a.dctrl = b_dctrl.as<double>();
     {
         int32_t c0[16] = {0};
-        c0[1] = n - 1; c0[4] = 1;                                                   // last_row_to_eliminate, eliminating
+        c0[1] = n - 1; c0[4] = 1; c0[11] = -1;                                      // last_row_to_eliminate, eliminating, no pivot yet
         const double d0[2] = {tau, P.piv_tol};
         ILUPP_HIP(hipMemcpyAsync(a.ctrl, c0, sizeof(c0), hipMemcpyHostToDevice, st));
         ILUPP_HIP(hipMemcpyAsync(a.dctrl, d0, sizeof(d0), hipMemcpyHostToDevice, st));
@@ -643,7 +673,7 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         ILUPP_HIP(hipStreamSynchronize(st));
     }
     hipLaunchKernelGGL(k_dp_init, dim3((n + 2 + 255) / 256), dim3(256), 0, st, n, epr, a.perm, a.iperm, a.prow, a.iprow, a.numb, a.pnum, a.nonpiv, a.unused,
-                       a.startU, a.startL, a.zpos, a.wpos, Dinv);
+                       a.startU, a.startL, a.zrec, a.wrec, Dinv);
     int32_t ctrl[16] = {0};
     for (int launch = 0;; ++launch) {
         a.Uidx = SU.idx.as<int32_t>(); a.linkU = SU.link.as<int32_t>(); a.rowU = SU.who.as<int32_t>(); a.Uval = SU.val.as<double>(); a.capU = (int32_t)SU.cap;

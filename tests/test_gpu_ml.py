@@ -146,7 +146,7 @@ def test_class_api():
     # default-constructed parameters: the factorisation with pivoting (tests/test_gpu_mlp.py), on a small matrix -- it is a chain of n steps
     A2 = sp.csr_matrix(matgen.random_dd(400, k=6, diag=2.0), shape=(400, 400))
     Pd = ilupp.ILUppPreconditioner(A2, threshold=0.1)
-    Qd = O.orc().ml((A2.data, A2.indices, A2.indptr, True), O.ml_params(0.1, (O.PRE_PQ_ORDERING,), **O.PIVOTING_DEFAULTS))
+    Qd = O.orc().ml((A2.data, A2.indices, A2.indptr, True), O.ml_params(0.1, **O.PIVOTING_DEFAULTS))
     assert Pd.total_nnz == Qd.total_nnz() and np.array_equal(Pd @ C.rhs(400), Qd.apply(C.rhs(400)))
 
 

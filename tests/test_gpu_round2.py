@@ -524,7 +524,7 @@ for fmt in ("csr", "csc"):
     assert ML.total_nnz == Qm.total_nnz() and ML.pr.levels() == Qm.levels()
     assert np.array_equal(ML @ b, Qm.apply(b)) and np.array_equal(ML.T @ b, Qm.apply(b, O.TRANSPOSE))
     MLd = ilupp.ILUppPreconditioner(A)                                  # default-constructed parameters: the factorisation with pivoting
-    Qd = O.orc().ml(M, O.ml_params(1.0, (O.PRE_PQ_ORDERING,), **O.PIVOTING_DEFAULTS))
+    Qd = O.orc().ml(M, O.ml_params(1.0, **O.PIVOTING_DEFAULTS))
     assert MLd.total_nnz == Qd.total_nnz() and np.array_equal(MLd @ b, Qd.apply(b))
     x, info = spla.gmres(A, b, M=P, atol=1e-10)
     assert info == 0
