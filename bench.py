@@ -174,7 +174,7 @@ def extra_config(name, dev, steps):
     elif name == "C5P":
         # BASELINE config 5 AS NAMED: default_configuration(10) = maximum weighted matching + the factorisation WITH pivoting (partialILUCDP).
         # The factorisation is a chain of n steps (every step picks its column by the values of the step, its row by the fill so far): one
-        # wave of the GPU walks it, ~25 us per step -- n = 1e6 takes 26.6 s (profiles/r03_c5p.txt; the reference 6.8 s on one host core),
+        # wave of the GPU walks it, ~11-23 us per step -- n = 1e6 takes 23.4 s (profiles/r03_c5p.txt; the reference 6.8 s on one host core),
         # so the default run measures n = 1e5 and says so.
         import ilupp_amd as ilupp
         d, i, p = matgen.random_dd(100000, 8, 25.0, 12345)
@@ -183,7 +183,7 @@ def extra_config(name, dev, steps):
         prm.threshold = 1e-3
         make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
         what = ("C5P: ILUppPreconditioner(default_configuration(10): MAX_WEIGHTED_MATCHING_ORDERING + the factorisation WITH pivoting, threshold=1e-3), "
-                "random unsymmetric CSR n=1e5 (a chain of n sequential steps on one wave; n=1e6: 26.6 s)")
+                "random unsymmetric CSR n=1e5 (a chain of n sequential steps on one wave; n=1e6: 23.4 s)")
     elif name == "C5":
         # BASELINE config 5's shape (unsymmetric CSR, n = 1e6) with the multilevel preconditioner this build has: default_configuration(1)
         # = normalisation + PQ ordering + the factorisation WITHOUT pivoting (preset 10): the parameter family whose rows and columns are
