@@ -2187,3 +2187,170 @@ void orc_ml_apply(const orc_ml *P, int use, double *x)   /* apply_preconditioner
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* ILUCP: Crout ILU with column pivoting                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* vector_sparse_dynamic::take_largest_elements_by_abs_value_with_threshold_pivot_last, sparse_implementation.h:1151-1216: the entries with
+ * |x| > norm2 * tau, at most n of them (the largest, by the reference's selection), in slot order, the PIVOT last -- the largest entry if
+ * it beats piv_tol * |x[pivot_position]|, else x[pivot_position] (an empty list if that is 0) */
+static orc_int take_largest_pivot_last(const wvec *v, orc_int *list, orc_int n, double tau, orc_int pivot_position, double piv_tol)
+{
+    orc_int i, cnt = 0, t;
+    double val_larg_el = 0.0, norm = 0.0, at_pivot;
+    double *key = (double *)malloc(sizeof(double) * (size_t)(v->nnz > 0 ? v->nnz : 1));
+    for (i = 0; i < v->nnz; ++i) {
+        if (fabs(v->data[i]) > val_larg_el) val_larg_el = fabs(v->data[i]);
+        norm += v->data[i] * v->data[i];
+    }
+    at_pivot = v->occupancy[pivot_position] >= 0 ? v->data[v->occupancy[pivot_position]] : 0.0;      /* read(), :1002-1008 */
+    if (val_larg_el * piv_tol > fabs(at_pivot)) {                                 /* pivoting */
+        norm = sqrt(norm);
+        for (i = 0; i < v->nnz; ++i)
+            if (fabs(v->data[i]) > norm * tau) { key[cnt] = fabs(v->data[i]); list[cnt++] = v->pointer[i]; }
+        if (cnt > n) {
+            const orc_int offset = cnt - n;
+            vec_select_largest(key, list, 0, cnt - 1, n);
+            memmove(list, list + offset, sizeof(orc_int) * (size_t)n);
+            cnt = n;
+        } else {
+            orc_int pos = 0;
+            double mx = 0.0;
+            for (i = 0; i < cnt; ++i) if (key[i] > mx) { pos = i; mx = key[i]; }
+            if (cnt > 0) { t = list[pos]; list[pos] = list[cnt - 1]; list[cnt - 1] = t; }
+        }
+    } else {
+        if (at_pivot == 0) { free(key); return 0; }
+        norm = sqrt(norm);
+        for (i = 0; i < v->nnz; ++i)
+            if (fabs(v->data[i]) > norm * tau && v->pointer[i] != pivot_position) { key[cnt] = fabs(v->data[i]); list[cnt++] = v->pointer[i]; }
+        if (cnt > n - 1) {
+            const orc_int offset = cnt - n + 1;
+            vec_select_largest(key, list, 0, cnt - 1, n);                          /* (sorted for n, n - 1 of them taken: as there) */
+            memmove(list, list + offset, sizeof(orc_int) * (size_t)(n - 1));
+            list[n - 1] = pivot_position;
+            cnt = n;
+        } else {
+            list[cnt++] = pivot_position;
+        }
+    }
+    free(key);
+    return cnt;
+}
+
+/* ILUCP4, ILUC.hpp:212-370, on the major-order view of the arrays (for ROW input: of A^T); U by rows with the pivot FIRST and the
+ * original column indices, L by columns with its 1 first; perm[k]: the column taken at step k */
+int orc_ilucp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, orc_int max_fill_in, double threshold, double piv_tol,
+              orc_int rp, double mem_factor, orc_mat *L, orc_mat *U, orc_int *perm, orc_int *zero_pivots)
+{
+    orc_int k, i, j, h, x, p, t, reserved, nU, nL;
+    orc_int *firstL, *listL, *listA, *headA, *firstA, *linkU, *rowU, *startU, *inverse_perm, *list_L, *list_U;
+    char *non_pivot;
+    wvec z, w;
+    int rc = ORC_OK;
+    if (max_fill_in < 1) max_fill_in = 1;                                        /* :226-227 */
+    if (max_fill_in > n) max_fill_in = n;
+    {
+        long a = (long)max_fill_in * (long)n, b = (long)(mem_factor * (double)ptr[n]);
+        long r = a < b ? a : b;
+        reserved = (orc_int)(r > 0 ? r : 0);
+    }
+    *zero_pivots = 0;
+    firstL = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int)); listL = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    listA = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int)); headA = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    firstA = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));
+    linkU = (orc_int *)malloc(sizeof(orc_int) * ((size_t)reserved + 1)); rowU = (orc_int *)malloc(sizeof(orc_int) * ((size_t)reserved + 1));
+    startU = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1)); inverse_perm = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    list_L = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16)); list_U = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16));
+    non_pivot = (char *)malloc((size_t)n + 1);
+    mat_init(U, n, reserved > 0 ? reserved : 1, 1);
+    mat_init(L, n, reserved > 0 ? reserved : 1, 0);
+    wv_init(&z, n, 0); wv_init(&w, n, 0);
+    for (k = 0; k < n; ++k) { perm[k] = inverse_perm[k] = k; non_pivot[k] = 1; listL[k] = -1; startU[k] = -1; }
+    initialize_sparse_matrix_fields(n, ptr, idx, listA, headA, firstA);
+
+    for (k = 0; k < n; ++k) {
+        if (k == rp) piv_tol = 1.0;                                              /* :247-248 */
+        wv_zero_reset(&z);
+        for (h = headA[k]; h != -1; h = listA[h])                                /* row k of the matrix, through the column lists */
+            if (non_pivot[h]) z.data[wv_slot(&z, h)] = val[firstA[h]];
+        for (h = listL[k]; h != -1; h = listL[h])
+            for (j = U->ptr[h]; j < U->ptr[h + 1]; ++j)
+                if (non_pivot[U->idx[j]]) { x = wv_slot(&z, U->idx[j]); z.data[x] -= L->val[firstL[h]] * U->val[j]; }
+        nU = take_largest_pivot_last(&z, list_U, max_fill_in, threshold, perm[k], piv_tol);
+        if (nU == 0 && threshold > 0.0) nU = take_largest_pivot_last(&z, list_U, max_fill_in, 0.0, perm[k], piv_tol);
+        if (nU == 0) {                                                           /* :281-286 */
+            (*zero_pivots)++;
+            z.data[wv_slot(&z, perm[k])] = 1.0;
+            nU = 1; list_U[0] = perm[k];
+        }
+        if (U->ptr[k] + nU > reserved) { rc = ORC_ERR_MEMORY; break; }
+        U->val[U->ptr[k]] = z.data[z.occupancy[list_U[nU - 1]]];
+        U->idx[U->ptr[k]] = list_U[nU - 1];
+        for (j = 1; j < nU; ++j) {
+            const orc_int pos = U->ptr[k] + j, c = list_U[nU - 1 - j];
+            U->val[pos] = z.data[z.occupancy[c]]; U->idx[pos] = c;
+            linkU[pos] = startU[c]; startU[c] = pos; rowU[pos] = k;
+        }
+        U->ptr[k + 1] = U->ptr[k] + nU;
+        {
+            const orc_int c = U->idx[U->ptr[k]];
+            p = inverse_perm[c];
+            t = inverse_perm[perm[k]]; inverse_perm[perm[k]] = inverse_perm[c]; inverse_perm[c] = t;
+            t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+            non_pivot[c] = 0;
+        }
+        wv_zero_reset(&w);
+        for (i = ptr[perm[k]]; i < ptr[perm[k] + 1]; ++i)
+            if (idx[i] > k) w.data[wv_slot(&w, idx[i])] = val[i];
+        for (h = startU[perm[k]]; h != -1; ) {
+            const orc_int r = rowU[h];
+            const double uv = U->val[h];
+            h = linkU[h];
+            for (j = L->ptr[r]; j < L->ptr[r + 1]; ++j) { x = wv_slot(&w, L->idx[j]); w.data[x] -= uv * L->val[j]; }
+        }
+        nL = take_largest(&w, list_L, max_fill_in - 1, threshold, k + 1, n);
+        if (L->ptr[k] + nL + 1 > reserved) { rc = ORC_ERR_MEMORY; break; }
+        L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = k;
+        for (j = 0; j < nL; ++j) { L->val[L->ptr[k] + j + 1] = w.data[w.occupancy[list_L[j]]] / U->val[U->ptr[k]]; L->idx[L->ptr[k] + j + 1] = list_L[j]; }
+        L->ptr[k + 1] = L->ptr[k] + nL + 1;
+        update_sparse_matrix_fields(k, ptr, idx, listA, headA, firstA);
+        update_triangular_fields(k, L->ptr, L->idx, listL, firstL);
+    }
+    wv_free(&z); wv_free(&w);
+    free(firstL); free(listL); free(listA); free(headA); free(firstA); free(linkU); free(rowU); free(startU); free(inverse_perm);
+    free(list_L); free(list_U); free(non_pivot);
+    if (rc != ORC_OK) { orc_free_mat(L); orc_free_mat(U); return rc; }
+    L->nnz = L->ptr[n]; U->nnz = U->ptr[n];
+    mat_compress(L, 0.0); mat_compress(U, 0.0);                                  /* :365-366 */
+    return ORC_OK;
+}
+
+/* ILUCPPreconditioner (preconditioner_implementation.h:1117-1147) + apply_preconditioner_only: for COLUMN input L is the left factor
+ * (lower triangular) and U the right one (PERMUTED upper triangular, triangular_solve_perm, sparse_implementation.h:4166-4253); for ROW
+ * input the factors of A^T change sides.  L, U, perm as orc_ilucp returns them for the major-order view of the input. */
+void orc_apply_ilucp(const orc_mat *L, const orc_mat *U, const orc_int *perm, int input_is_csr, int use, double *x)
+{
+    const orc_int n = L->n;
+    orc_int k, j;
+    double *y = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    /* "forward" = the sweep with the stored rows of U as columns: y[perm[k]] /= pivot; y[rest] -= u * y[perm[k]]; x[k] = y[perm[k]] (:4196-4206);
+     * "backward" = rows of U against the unknowns already found: y[k] -= u * x[col]; x[perm[k]] = y[k] / pivot (:4209-4218) */
+#define PERM_FORWARD() do { memcpy(y, x, sizeof(double) * (size_t)n); \
+        for (k = 0; k < n; ++k) { y[perm[k]] /= U->val[U->ptr[k]]; for (j = U->ptr[k] + 1; j < U->ptr[k + 1]; ++j) y[U->idx[j]] -= U->val[j] * y[perm[k]]; } \
+        for (k = 0; k < n; ++k) x[k] = y[perm[k]]; } while (0)
+#define PERM_BACKWARD() do { memcpy(y, x, sizeof(double) * (size_t)n); \
+        for (k = n - 1; k >= 0; --k) { for (j = U->ptr[k] + 1; j < U->ptr[k + 1]; ++j) y[k] -= U->val[j] * x[U->idx[j]]; x[perm[k]] = y[k] / U->val[U->ptr[k]]; } } while (0)
+    if (!input_is_csr) {
+        if (use == ORC_ID) { orc_trisolve(n, L->ptr, L->idx, L->val, 0, ORC_LOWER, ORC_ID, x); PERM_BACKWARD(); }
+        else { PERM_FORWARD(); orc_trisolve(n, L->ptr, L->idx, L->val, 0, ORC_LOWER, ORC_TRANSPOSE, x); }
+    } else {
+        /* left = U^T (PERMUTED_LOWER_TRIANGULAR, stored by columns = the rows of U), right = L^T (upper triangular, stored by rows = the columns of L) */
+        if (use == ORC_ID) { PERM_FORWARD(); orc_trisolve(n, L->ptr, L->idx, L->val, 1, ORC_UPPER, ORC_ID, x); }
+        else { orc_trisolve(n, L->ptr, L->idx, L->val, 1, ORC_UPPER, ORC_TRANSPOSE, x); PERM_BACKWARD(); }
+    }
+#undef PERM_FORWARD
+#undef PERM_BACKWARD
+    free(y);
+}

@@ -152,6 +152,13 @@ int orc_ml_level(const orc_ml *P, int k, orc_ml_level_view *v);
 void orc_ml_apply(const orc_ml *P, int use, double *x);
 void orc_ml_free(orc_ml *P);
 
+
+/* ---- ILUCP (ILUC.hpp:212-370, preconditioner_implementation.h:1117-1147, sparse_implementation.h:4166-4253): Crout ILU with
+ * column pivoting on the major-order view of the arrays; the apply of ILUCPPreconditioner for the input's orientation ---- */
+int orc_ilucp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, orc_int max_fill_in, double threshold, double piv_tol,
+              orc_int rp, double mem_factor, orc_mat *L, orc_mat *U, orc_int *perm, orc_int *zero_pivots);
+void orc_apply_ilucp(const orc_mat *L, const orc_mat *U, const orc_int *perm, int input_is_csr, int use, double *x);
+
 #ifdef __cplusplus
 }
 #endif

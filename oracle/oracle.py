@@ -366,3 +366,47 @@ def from_scipy(A):
     A.sort_indices()
     return (A.data.astype(np.float64), A.indices.astype(np.int32), A.indptr.astype(np.int32),
             isinstance(A, sp.csr_matrix))
+
+
+class ILUCP:
+    """ILUCPPreconditioner of either library: factors for the major-order view, the permutation, apply"""
+
+    def __init__(self, lib, A, fill_in=100, threshold=0.1, piv_tol=0.1, rp=-1, mem_factor=10.0):
+        self.lib = lib
+        args, self._keep = lib._in(A)
+        n = args[0]
+        self.n, self.is_csr = n, bool(args[4])
+        L, U = _Mat(), _Mat()
+        perm = np.zeros(n, dtype=np.int32)
+        zp = ctypes.c_int32(0)
+        self.h = ctypes.c_void_p()
+        if lib.prefix == "ref_":
+            f = lib.lib.ref_ilucp
+            f.restype = ctypes.c_int
+            rc = f(args[0], args[1], args[2], args[3], args[4], ctypes.c_int32(fill_in), ctypes.c_double(threshold), ctypes.c_double(piv_tol), ctypes.c_int32(rp),
+                   ctypes.c_double(mem_factor), ctypes.byref(L), ctypes.byref(U), _p_i32(perm), ctypes.byref(zp), ctypes.byref(self.h))
+        else:
+            f = lib.lib.orc_ilucp
+            f.restype = ctypes.c_int
+            rc = f(args[0], args[1], args[2], args[3], ctypes.c_int32(fill_in), ctypes.c_double(threshold), ctypes.c_double(piv_tol), ctypes.c_int32(rp),
+                   ctypes.c_double(mem_factor), ctypes.byref(L), ctypes.byref(U), _p_i32(perm), ctypes.byref(zp))
+        if rc:
+            raise OracleError(rc)
+        self.perm, self.zero_pivots = perm, int(zp.value)
+        self._L, self._U = L, U
+        self.L = self._copy(L)
+        self.U = self._copy(U)
+
+    @staticmethod
+    def _copy(m):
+        n, nnz = m.n, m.nnz
+        return (np.ctypeslib.as_array(m.val, shape=(max(nnz, 1),))[:nnz].copy(), np.ctypeslib.as_array(m.idx, shape=(max(nnz, 1),))[:nnz].copy(),
+                np.ctypeslib.as_array(m.ptr, shape=(n + 1,)).copy())
+
+    def apply(self, x, use=ID):
+        x = np.array(x, dtype=np.float64, copy=True).ravel()
+        if self.lib.prefix == "ref_":
+            self.lib.lib.ref_ilucp_apply(self.h, ctypes.c_int32(self.n), int(use), _p_f64(x))
+        else:
+            self.lib.lib.orc_apply_ilucp(ctypes.byref(self._L), ctypes.byref(self._U), _p_i32(self.perm), int(self.is_csr), int(use), _p_f64(x))
+        return x

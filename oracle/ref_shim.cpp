@@ -361,6 +361,39 @@ void ref_ml_free(ref_ml *R)
 }
 
 /* libstdc++'s own std::sort with the comparator of dropping.hpp:25-26, to pin orc_sort_slots_by_abs_desc */
+/* ---- ILUCPPreconditioner (binding.cpp:343-356) behind the orc_ilucp / orc_apply_ilucp ABI: the factors as ILUCP4 returned them for the
+ * major-order view (for ROW input the class holds them transposed in place: the arrays are the same), the permutation, the apply ---- */
+struct ref_ilucp_obj { ILUCPPreconditioner<Real, matrix, vector> *P; };
+
+int ref_ilucp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, orc_int max_fill_in, double threshold, double piv_tol,
+              orc_int rp, double mem_factor, orc_mat *Lo, orc_mat *Uo, orc_int *perm, orc_int *zero_pivots, void **handle)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    ILUCPPreconditioner<Real, matrix, vector> *P = nullptr;
+    try {
+        P = new ILUCPPreconditioner<Real, matrix, vector>(A, max_fill_in, threshold, piv_tol, rp, mem_factor);
+    } catch (const std::runtime_error &) {
+        return ORC_ERR_MEMORY;                      // "ILUCP4: Insufficient memory reserved. Increase mem_factor"
+    }
+    if (!P->exists()) { delete P; return ORC_ERR_ZERO_PIVOT; }
+    // COLUMN input: left = L (by columns), right = U (by rows); ROW input: left = U^T (labelled COLUMN), right = L^T (labelled ROW)
+    if (!is_csr) { export_mat(P->left_matrix(), Lo); export_mat(P->right_matrix(), Uo); }
+    else { export_mat(P->right_matrix(), Lo); export_mat(P->left_matrix(), Uo); }
+    for (orc_int k = 0; k < n; ++k) perm[k] = P->extract_permutation()[k];
+    if (zero_pivots) *zero_pivots = -1;            // (private in the class)
+    if (handle) *handle = P; else delete P;
+    return ORC_OK;
+}
+
+void ref_ilucp_apply(void *handle, orc_int n, int use, double *x)
+{
+    auto *P = static_cast<ILUCPPreconditioner<Real, matrix, vector> *>(handle);
+    vector v(n, x, true);
+    P->apply_preconditioner_only(use == ORC_ID ? ID : TRANSPOSE, v);
+}
+
+void ref_ilucp_free(void *handle) { delete static_cast<ILUCPPreconditioner<Real, matrix, vector> *>(handle); }
+
 void ref_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key)
 {
     std::sort(list, list + len, [&](orc_int x, orc_int y) { return std::abs(key[x]) > std::abs(key[y]); });
