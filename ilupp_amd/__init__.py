@@ -188,9 +188,25 @@ class ILUTPPreconditioner(_NotBuilt):
     _what = "ILUTP, the ILUT with column pivoting"
 
 
-class ILUCPPreconditioner(_NotBuilt):
-    """ILUCP (Crout ILU with pivoting; reference ilupp/__init__.py:252-270, ILUC.hpp:212-541): not built -- raises NotImplementedError."""
-    _what = "ILUCP, the Crout ILU with pivoting"
+class ILUCPPreconditioner(_HipPreconditioner):
+    """An ILUCP (ILUC with pivoting) preconditioner. See (Mayer 2005).  (Reference: ilupp/__init__.py:252-270 over ILUCP4, ILUC.hpp:212-370.)
+
+    Args:
+        A: a sparse matrix in CSR or CSC format
+        fill_in: the number of nonzeros to allow per column/row of L/U
+        threshold: entries with relative magnitude less than this are dropped
+        piv_tol: pivoting tolerance; 0=only pivot when 0 encountered, 1=always pivot
+            to the largest entry, inbetween: pivot depending on relative magnitude
+
+    The pivot of a step decides which entries of all later rows are alive: a chain of n steps that one wave of the GPU walks
+    (ilupp_amd/csrc/ilucp.hip); bit-identical to the reference, not faster than it."""
+
+    def __init__(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0):
+        super().__init__(A, lambda m: _native.ILUCPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
+
+    def permutations(self):
+        """Return a pair (L,R) of permutation arrays to be applied from the left or right due to pivoting."""
+        return self.pr.permutations()
 
 
 class ILU0Preconditioner(_HipPreconditioner):

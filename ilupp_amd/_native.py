@@ -53,6 +53,7 @@ def _lib_holding_gil():
         G.ilupp_hip_apply.argtypes = [_VP, _VP, ctypes.c_int64]
         G.ilupp_hip_apply_trans.argtypes = [_VP, _VP, ctypes.c_int64]
         G.ilupp_hip_ml_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
+        G.ilupp_hip_ilucp_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
         _lib_gil = G
     return _lib_gil
 
@@ -129,6 +130,16 @@ def lib():
     L.ilupp_hip_ml_apply_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     L.ilupp_hip_ml_apply_part_device.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.ilupp_hip_ml_sync.argtypes = [_VP]
+    L.ilupp_hip_ilucp_create.argtypes = [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
+                                         ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_ilucp_destroy.argtypes = [_VP]
+    L.ilupp_hip_ilucp_destroy.restype = None
+    L.ilupp_hip_ilucp_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
+    L.ilupp_hip_ilucp_total_nnz.argtypes = [_VP]
+    L.ilupp_hip_ilucp_total_nnz.restype = ctypes.c_int64
+    L.ilupp_hip_ilucp_zero_pivots.argtypes = [_VP]
+    L.ilupp_hip_ilucp_info.argtypes = [_VP, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float)]
+    L.ilupp_hip_ilucp_copy.argtypes = [_VP] * 8
     L.ilupp_hip_ml_levels.argtypes = [_VP]
     L.ilupp_hip_ml_levels.restype = ctypes.c_int32
     L.ilupp_hip_ml_total_nnz.argtypes = [_VP]
@@ -156,6 +167,8 @@ ABI_SYMBOLS = [
     "ilupp_hip_ml_default_params", "ilupp_hip_ml_create", "ilupp_hip_ml_create_device", "ilupp_hip_ml_destroy", "ilupp_hip_ml_apply",
     "ilupp_hip_ml_apply_device", "ilupp_hip_ml_apply_part_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
     "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings",
+    "ilupp_hip_ilucp_create", "ilupp_hip_ilucp_destroy", "ilupp_hip_ilucp_apply", "ilupp_hip_ilucp_total_nnz", "ilupp_hip_ilucp_zero_pivots",
+    "ilupp_hip_ilucp_info", "ilupp_hip_ilucp_copy",
 ]
 
 
@@ -563,3 +576,93 @@ def ichol0(A_data, A_indices, A_indptr, is_csr):
 
 def icholt(A_data, A_indices, A_indptr, is_csr, add_fill_in, threshold):
     return ICholTPreconditioner(A_data, A_indices, A_indptr, is_csr, add_fill_in, threshold).factors_info()[0]
+
+
+class PivotedPreconditioner:
+    """ILUCPPreconditioner of binding.cpp:343-356: apply / apply_trans in place, total_nnz, factors_info(), permutations()"""
+    memory = 0.0
+    memory_used_calculations = 0.0
+    memory_allocated_calculations = 0.0
+    exists = True
+    special_info = ""
+
+    def __init__(self, handle, n, is_csr):
+        self._h, self._n, self._csr = handle, n, bool(is_csr)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.ilupp_hip_ilucp_destroy(h)
+
+    def _solve(self, x, transpose):
+        mv = _check_real(x, "b")
+        if mv.readonly:
+            raise RuntimeError("b must be writable")
+        a = np.frombuffer(mv, dtype=np.float64)
+        if a.shape[0] != self._n:
+            raise RuntimeError("vector has wrong size for preconditioner!")
+        rc = _lib_holding_gil().ilupp_hip_ilucp_apply(self._h, a.ctypes.data, a.shape[0], transpose)
+        if rc:
+            _raise(rc)
+
+    def apply(self, x):
+        self._solve(x, 0)
+
+    def apply_trans(self, x):
+        self._solve(x, 1)
+
+    @property
+    def total_nnz(self):
+        return int(lib().ilupp_hip_ilucp_total_nnz(self._h))
+
+    @property
+    def zero_pivots(self):
+        return int(lib().ilupp_hip_ilucp_zero_pivots(self._h))
+
+    @property
+    def kernel_ms(self):
+        ms = ctypes.c_float()
+        lib().ilupp_hip_ilucp_info(self._h, None, None, None, ctypes.byref(ms))
+        return ms.value
+
+    def raw(self):
+        """(L, U, perm) as ILUCP4 returns them for the major-order view of the input: L by columns, U by rows (pivot first, original column
+        indices), each (data, indices, indptr)"""
+        n, nl, nu = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        rc = lib().ilupp_hip_ilucp_info(self._h, ctypes.byref(n), ctypes.byref(nl), ctypes.byref(nu), None)
+        if rc:
+            _raise(rc)
+        Ld, Li, Lp = np.empty(nl.value), np.empty(nl.value, dtype=np.int32), np.empty(n.value + 1, dtype=np.int32)
+        Ud, Ui, Up = np.empty(nu.value), np.empty(nu.value, dtype=np.int32), np.empty(n.value + 1, dtype=np.int32)
+        perm = np.empty(n.value, dtype=np.int32)
+        rc = lib().ilupp_hip_ilucp_copy(self._h, Ld.ctypes.data, Li.ctypes.data, Lp.ctypes.data, Ud.ctypes.data, Ui.ctypes.data, Up.ctypes.data, perm.ctypes.data)
+        if rc:
+            _raise(rc)
+        return (Ld, Li, Lp), (Ud, Ui, Up), perm
+
+    def factors_info(self):
+        """[left, right] as the class holds them (preconditioner_implementation.h:1117-1147): COLUMN input: L by columns, U by rows; ROW input:
+        the factors of the transposed matrix change sides and labels (transpose_in_place): U's arrays as a column matrix, L's as a row matrix"""
+        L, U, _ = self.raw()
+        n = self._n
+        if not self._csr:
+            return [(L[0], L[1], L[2], False, n, n), (U[0], U[1], U[2], True, n, n)]
+        return [(U[0], U[1], U[2], False, n, n), (L[0], L[1], L[2], True, n, n)]
+
+    def permutations(self):
+        """binding.cpp:178-196: (left, right) -- the permutation belongs to the factor U came from"""
+        perm = self.raw()[2]
+        return (perm, None) if self._csr else (None, perm)
+
+    def print_info(self):
+        print("An incomplete LU factorisation with column pivoting: %d entries" % self.total_nnz)
+
+
+def ILUCPPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor):
+    """binding.cpp:343-356"""
+    args, keep = _matrix_args(A_data, A_indices, A_indptr, is_csr)
+    h = _VP()
+    rc = lib().ilupp_hip_ilucp_create(*args, int(max_fill_in), float(threshold), float(piv_tol), int(row_pos), float(mem_factor), ctypes.byref(h))
+    if rc:
+        _raise(rc)
+    return PivotedPreconditioner(h, args[3], is_csr)

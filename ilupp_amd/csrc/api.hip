@@ -1625,3 +1625,193 @@ int ilupp_hip_ml_timings(const ilupp_ml *m, float *construct_ms, float *kernel_m
 }
 
 }  // extern "C"
+
+// ===================================================================================================================
+// ILUCP: ILUCPPreconditioner, binding.cpp:343-356 -> preconditioner_implementation.h:1117-1147 -> ILUCP4 (ilucp.hip)
+// ===================================================================================================================
+// The factors come for the major-order view of the input ("Acol"): L by columns, U by rows with the pivot first and ORIGINAL column indices,
+// perm[k] = the column of step k.  With U's indices read through the inverse permutation the pair is an object of the ILUC kind (both
+// array triples upper CSR with the diagonal first), and the permuted solves of the reference (triangular_solve_perm,
+// sparse_implementation.h:4196-4218) are that object's sweeps between a gather and a scatter:
+//   COLUMN input, apply / ROW input, apply_trans:   t = (L U')^{-1} x;      x[perm[k]] = t[k]          (:4209-4218 after the plain solve with L)
+//   COLUMN input, apply_trans / ROW input, apply:   y[i] = x[perm[i]];      x = (L U')^{-T} y          (:4196-4206 before the plain solve with L^T)
+struct ilupp_ilucp {
+    int32_t n = 0;
+    bool input_csr = false;
+    ilupp_precond *obj = nullptr;          // L and U' (permuted numbering), the sweeps
+    DevMat U;                              // U as the reference stores it (original column indices): what factors() hands out
+    int32_t *perm = nullptr;               // device
+    double *tmp = nullptr, *xdev = nullptr;
+    int32_t zero_pivots = 0;
+    float kernel_ms = 0.f;
+};
+
+namespace {
+
+__global__ void k_cp_map_indices(int64_t nnz, const int32_t *__restrict__ idx, const int32_t *__restrict__ map, int32_t *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nnz) out[j] = map[idx[j]];
+}
+__global__ void k_cp_invert(int32_t n, const int32_t *__restrict__ p, int32_t *__restrict__ inv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[p[i]] = i;
+}
+__global__ void k_cp_gather(int32_t n, const double *__restrict__ x, const int32_t *__restrict__ perm, double *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[perm[i]];
+}
+__global__ void k_cp_scatter(int32_t n, const double *__restrict__ t, const int32_t *__restrict__ perm, double *__restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[perm[i]] = t[i];
+}
+
+void ilucp_destroy(ilupp_ilucp *m)
+{
+    if (!m) return;
+    if (m->obj) destroy_obj(m->obj);
+    m->U.release();
+    for (void *q : {(void *)m->perm, (void *)m->tmp, (void *)m->xdev}) if (q) (void)pool_free(q);
+    delete m;
+}
+
+int ilucp_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, double threshold, double piv_tol, int32_t row_pos, double mem_factor,
+                        ilupp_ilucp **out)
+{
+    struct Guard { ilupp_ilucp *m; ~Guard() { if (m) ilucp_destroy(m); } } g{new ilupp_ilucp};
+    ilupp_ilucp *m = g.m;
+    m->n = n; m->input_csr = is_csr != 0;
+    m->obj = new_obj(n);
+    ilupp_precond *p = m->obj;
+    hipStream_t st = p->stream;
+    ILUPP_HIP(pool_malloc(&m->perm, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&m->tmp, sizeof(double) * (size_t)n));
+    ILUPP_HIP(hipEventRecord(p->ev[0], st));
+    struct MatGuard { DevMat m; ~MatGuard() { m.release(); } } gl;
+    const int rc = ilucp_factor(st, A, max_fill_in, threshold, piv_tol, row_pos, mem_factor, &gl.m, &m->U, m->perm, &m->zero_pivots, &m->kernel_ms);
+    ILUPP_HIP(hipEventRecord(p->ev[1], st));
+    A.release();
+    if (rc) return rc;
+    // U' = U with its column indices in the permuted numbering (values and pointers shared in content, own arrays)
+    DevMat Up;
+    Up.n = n; Up.nnz = m->U.nnz; Up.is_csr = true; Up.owns = true;
+    PoolBlock b_inv;
+    ILUPP_HIP(b_inv.alloc(sizeof(int32_t) * (size_t)n));
+    hipLaunchKernelGGL(k_cp_invert, dim3((n + 255) / 256), dim3(256), 0, st, n, m->perm, b_inv.as<int32_t>());
+    ILUPP_HIP(pool_malloc(&Up.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&Up.idx, sizeof(int32_t) * (size_t)(Up.nnz > 0 ? Up.nnz : 1)));
+    ILUPP_HIP(pool_malloc(&Up.val, sizeof(double) * (size_t)(Up.nnz > 0 ? Up.nnz : 1)));
+    ILUPP_HIP(hipMemcpyAsync(Up.ptr, m->U.ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, st));
+    if (Up.nnz > 0) {
+        ILUPP_HIP(hipMemcpyAsync(Up.val, m->U.val, sizeof(double) * (size_t)Up.nnz, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_cp_map_indices, dim3((unsigned)((Up.nnz + 255) / 256)), dim3(256), 0, st, Up.nnz, m->U.idx, b_inv.as<int32_t>(), Up.idx);
+    }
+    ILUPP_HIP(stream_sync(st));
+    p->kind = KIND_UTU; p->nnz_mode = NNZ_GENERIC_LU; p->input_csc = false;
+    p->Lc = gl.m; p->Uc = Up;
+    gl.m = DevMat();                                            // (the object owns the arrays now)
+    utu_analyse(p);
+    ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
+    p->tm.numeric_kernel_ms = m->kernel_ms;
+    *out = m;
+    g.m = nullptr;
+    return ILUPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ilupp_hip_ilucp_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, int32_t max_fill_in,
+                           double threshold, double piv_tol, int32_t row_pos, double mem_factor, ilupp_ilucp **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    rc = ilucp_create_common(A, n, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor, out);
+    A.release();
+    return rc;
+    API_CATCH
+}
+
+void ilupp_hip_ilucp_destroy(ilupp_ilucp *m) { ilucp_destroy(m); }
+
+int ilupp_hip_ilucp_apply(ilupp_ilucp *m, double *x, int64_t len, int transpose)
+{
+    API_TRY
+    if (!m) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    if (len != m->n) { set_error("vector has wrong size for preconditioner!"); return ILUPP_ERR_WRONG_SIZE; }
+    const int32_t n = m->n;
+    ilupp_precond *p = m->obj;
+    hipStream_t st = p->stream;
+    if (!m->xdev) ILUPP_HIP(pool_malloc(&m->xdev, sizeof(double) * (size_t)n));
+    ILUPP_HIP(hipMemcpyAsync(m->xdev, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    const bool plain_first = (transpose != 0) == m->input_csr;            // COLUMN input + apply, ROW input + apply_trans
+    int rc;
+    if (plain_first) {
+        rc = apply_dev(p, m->xdev, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_cp_scatter, dim3((n + 255) / 256), dim3(256), 0, st, n, m->xdev, m->perm, m->tmp);
+        rc = finish_apply(p);
+        if (rc) return rc;
+        ILUPP_HIP(hipMemcpy(x, m->tmp, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    } else {
+        hipLaunchKernelGGL(k_cp_gather, dim3((n + 255) / 256), dim3(256), 0, st, n, m->xdev, m->perm, m->tmp);
+        rc = apply_dev(p, m->tmp, 1);
+        if (rc) return rc;
+        rc = finish_apply(p);
+        if (rc) return rc;
+        ILUPP_HIP(hipMemcpy(x, m->tmp, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return ILUPP_OK;
+    API_CATCH
+}
+
+int64_t ilupp_hip_ilucp_total_nnz(const ilupp_ilucp *m) { return m ? m->obj->Lc.nnz + m->U.nnz : 0; }      /* preconditioner.h:208-209 */
+int32_t ilupp_hip_ilucp_zero_pivots(const ilupp_ilucp *m) { return m ? m->zero_pivots : 0; }
+
+/* sizes, then copies: L of the view by columns (the 1 first), U by rows (the pivot first, original column indices), the permutation */
+int ilupp_hip_ilucp_info(const ilupp_ilucp *m, int32_t *n, int64_t *nnz_l, int64_t *nnz_u, float *kernel_ms)
+{
+    if (!m) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    if (n) *n = m->n;
+    if (nnz_l) *nnz_l = m->obj->Lc.nnz;
+    if (nnz_u) *nnz_u = m->U.nnz;
+    if (kernel_ms) *kernel_ms = m->kernel_ms;
+    return ILUPP_OK;
+}
+
+int ilupp_hip_ilucp_copy(const ilupp_ilucp *m, double *l_data, int32_t *l_indices, int32_t *l_indptr, double *u_data, int32_t *u_indices,
+                         int32_t *u_indptr, int32_t *perm)
+{
+    API_TRY
+    if (!m) { set_error("null preconditioner"); return ILUPP_ERR_INVALID; }
+    const ilupp_precond *p = m->obj;
+    ILUPP_HIP(stream_sync(p->stream));
+    const size_t n = (size_t)m->n;
+    auto get = [](void *dst, const void *src, size_t bytes) { if (dst && bytes) ILUPP_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); };
+    get(l_data, p->Lc.val, sizeof(double) * (size_t)p->Lc.nnz); get(l_indices, p->Lc.idx, sizeof(int32_t) * (size_t)p->Lc.nnz); get(l_indptr, p->Lc.ptr, sizeof(int32_t) * (n + 1));
+    get(u_data, m->U.val, sizeof(double) * (size_t)m->U.nnz); get(u_indices, m->U.idx, sizeof(int32_t) * (size_t)m->U.nnz); get(u_indptr, m->U.ptr, sizeof(int32_t) * (n + 1));
+    get(perm, m->perm, sizeof(int32_t) * n);
+    return ILUPP_OK;
+    API_CATCH
+}
+
+}  // extern "C"

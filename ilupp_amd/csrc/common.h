@@ -349,6 +349,10 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
 int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, int32_t bp, int32_t bpr, int32_t epr,
                   DevMat *L, DevMat *U, double **Dinv, DevMat *Anew, int32_t *pc2, int32_t *pr2, float *kernel_ms);
 
+// ilucp.hip: ILUCP4 (ILUC.hpp:212-370) on the major-order view C: L by columns, U by rows (pivot first, original column indices), perm (device)
+int ilucp_factor(hipStream_t st, const DevMat &C, int32_t max_fill_in, double threshold, double piv_tol, int32_t rp, double mem_factor,
+                 DevMat *L, DevMat *U, int32_t *perm_out, int32_t *zero_pivots, float *kernel_ms);
+
 // ml.hip: the multilevel preconditioner built from such levels (reference preconditioner_implementation.h:1350-1665, :433-488)
 enum { ML_PRE_NORMALIZE_COLUMNS = 1, ML_PRE_NORMALIZE_ROWS = 2, ML_PRE_PQ_ORDERING = 3, ML_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,
        ML_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5, ML_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6, ML_PRE_SPARSE_FIRST_ORDERING = 7 };    // = ILUPP_PRE_* of include/ilupp_hip.h

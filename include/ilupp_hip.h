@@ -238,6 +238,27 @@ int ilupp_hip_ml_level_copy(const ilupp_ml *p, int32_t level, double *l_data, in
 int ilupp_hip_ml_timings(const ilupp_ml *p, float *construct_ms, float *kernel_ms, float *last_apply_ms);
 
 /* ---------------------------------------------------------------------------------------------
+ * ILUCP: Crout ILU with column pivoting.  Replaces binding.cpp:343-356 (ILUCPPreconditioner.__init__ ->
+ * preconditioner_implementation.h:1117-1147 -> ILUCP4, ILUC.hpp:212-370) and its apply (triangular_solve_perm,
+ * sparse_implementation.h:4166-4253).  A chain of n data-dependent steps: one wave of the GPU walks it (ilucp.hip).
+ * Errors: ILUPP_ERR_MEMORY ("ILUCP4: Insufficient memory reserved. Increase mem_factor", ILUC.hpp:287-289, :344-346).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ilupp_ilucp ilupp_ilucp;
+int ilupp_hip_ilucp_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, int32_t max_fill_in,
+                           double threshold, double piv_tol, int32_t row_pos, double mem_factor, ilupp_ilucp **out);
+void ilupp_hip_ilucp_destroy(ilupp_ilucp *p);
+/* binding.cpp:237-254 apply / apply_trans, in place on a host vector */
+int ilupp_hip_ilucp_apply(ilupp_ilucp *p, double *x, int64_t len, int transpose);
+int64_t ilupp_hip_ilucp_total_nnz(const ilupp_ilucp *p);
+int32_t ilupp_hip_ilucp_zero_pivots(const ilupp_ilucp *p);
+/* the factors as ILUCP4 returns them for the major-order view of the input (L by columns with its 1 first; U by rows with the pivot first
+ * and the original column indices) and the permutation (binding.cpp:178-196 permutations(): the right one for COLUMN input, the left one
+ * for ROW input); any pointer may be NULL */
+int ilupp_hip_ilucp_info(const ilupp_ilucp *p, int32_t *n, int64_t *nnz_l, int64_t *nnz_u, float *kernel_ms);
+int ilupp_hip_ilucp_copy(const ilupp_ilucp *p, double *l_data, int32_t *l_indices, int32_t *l_indptr, double *u_data, int32_t *u_indices,
+                         int32_t *u_indptr, int32_t *perm);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hooks used by bench.py (not part of the reference's surface).
  * Times are GPU milliseconds from hipEvents recorded on the object's stream.
  * ------------------------------------------------------------------------------------------- */

@@ -43,15 +43,17 @@ def test_python_surface_matches_reference_names():
     assert str(inspect.signature(ilupp.icholt)) == "(A, add_fill_in=0, threshold=0.0)"
 
 
-def test_pivoting_classes_say_that_they_are_not_built():
-    """the reference's ILUTP / ILUCP classes exist by name and refuse loudly: no CPU stand-in"""
+def test_pivoting_classes_say_what_is_built():
+    """the reference's ILUTP / ILUCP classes exist by name with its signatures; ILUCP is built (tests/test_gpu_ilucp.py), ILUTP
+    refuses loudly: no CPU stand-in"""
     import inspect
     import ilupp_amd as ilupp
     A = sp.eye(4, format="csr")
     for cls in (ilupp.ILUTPPreconditioner, ilupp.ILUCPPreconditioner):
         assert str(inspect.signature(cls.__init__)) == "(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0)"
-        with pytest.raises(NotImplementedError, match="not built"):
-            cls(A)
+        assert callable(cls.permutations)
+    with pytest.raises(NotImplementedError, match="not built"):
+        ilupp.ILUTPPreconditioner(A)
 
 
 def test_input_validation_types():
