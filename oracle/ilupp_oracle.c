@@ -2354,3 +2354,254 @@ void orc_apply_ilucp(const orc_mat *L, const orc_mat *U, const orc_int *perm, in
 #undef PERM_BACKWARD
     free(y);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* ILUTP: ILUT with column pivoting                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* the working row of ILUTP2: vector_sparse_dynamic_enhanced (sparse.h:328-360, sparse_implementation.h:2234-2384) -- slots in insertion
+ * order, occupancy by index, and a map sorting key -> slot that is walked in ascending key order while entries are added behind the
+ * current key and removed at it.  Keys are positions of a permutation: unique.  Here: keyslot[key] and a min-heap of keys. */
+typedef struct { orc_int n, nnz, hlen, ntouched; double *data; orc_int *pointer, *occupancy, *keyslot, *heap, *touched; } evec;
+static void ev_init(evec *w, orc_int n)
+{
+    orc_int i;
+    w->n = n; w->nnz = 0; w->hlen = 0; w->ntouched = 0;
+    w->touched = (orc_int *)malloc(sizeof(orc_int) * (4 * (size_t)n + 16));
+    w->data = (double *)malloc(sizeof(double) * (4 * (size_t)n + 16)); w->pointer = (orc_int *)malloc(sizeof(orc_int) * (4 * (size_t)n + 16));
+    w->occupancy = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1)); w->keyslot = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    w->heap = (orc_int *)malloc(sizeof(orc_int) * (4 * (size_t)n + 16));
+    for (i = 0; i < n; ++i) { w->occupancy[i] = -1; w->keyslot[i] = -1; }
+}
+static void ev_free(evec *w) { free(w->data); free(w->pointer); free(w->occupancy); free(w->keyslot); free(w->heap); free(w->touched); }
+static void ev_heap_push(evec *w, orc_int key)
+{
+    orc_int i = w->hlen++, p;
+    w->heap[i] = key;
+    while (i > 0 && w->heap[p = (i - 1) / 2] > w->heap[i]) { const orc_int t = w->heap[p]; w->heap[p] = w->heap[i]; w->heap[i] = t; i = p; }
+}
+static void ev_heap_pop(evec *w)
+{
+    orc_int i = 0, c;
+    w->heap[0] = w->heap[--w->hlen];
+    for (;;) {
+        c = 2 * i + 1;
+        if (c >= w->hlen) break;
+        if (c + 1 < w->hlen && w->heap[c + 1] < w->heap[c]) c++;
+        if (w->heap[i] <= w->heap[c]) break;
+        { const orc_int t = w->heap[c]; w->heap[c] = w->heap[i]; w->heap[i] = t; }
+        i = c;
+    }
+}
+/* operator()(j, k), :2250-2271: the slot of index j (a new one with sorting key k if j is not occupied) */
+static orc_int ev_slot(evec *w, orc_int j, orc_int k)
+{
+    if (w->occupancy[j] < 0) {
+        const orc_int x = w->nnz++;
+        w->pointer[x] = j; w->data[x] = 0.0; w->occupancy[j] = x;
+        ev_heap_push(w, k);
+        w->keyslot[k] = x;
+        w->touched[w->ntouched++] = k;
+        return x;
+    }
+    return w->occupancy[j];
+}
+static void ev_reset(evec *w)       /* zero_reset, :2234-2240 */
+{
+    orc_int i;
+    for (i = 0; i < w->nnz; ++i) w->occupancy[w->pointer[i]] = -1;
+    for (i = 0; i < w->ntouched; ++i) w->keyslot[w->touched[i]] = -1;
+    w->nnz = 0; w->hlen = 0; w->ntouched = 0;
+}
+
+/* the two selections of ILUTP2 (sparse_implementation.h:1943-2033 without, :2036-2160 with the pivot tolerance): entries whose position
+ * invperm[index] lies left of `mid` go to L, the others to U, each with its own norm and threshold; at most n_L / n_U of them (the largest,
+ * by the reference's partial sort); in U the largest of the kept ones is swapped to the end (it becomes the pivot).  WITH piv_tol: unless
+ * the largest entry of the U part beats the diagonal by piv_tol, the diagonal's magnitude is replaced by the norm, which makes it the
+ * largest (:2083-2087). */
+static void ilutp_select(const evec *v, const orc_int *invperm, orc_int n_L, orc_int n_U, double tau_L, double tau_U, orc_int mid, int with_piv,
+                         double piv_tol, orc_int *list_L, orc_int *nL, orc_int *list_U, orc_int *nU)
+{
+    orc_int i, cL = 0, cU = 0, pos, t;
+    double nrmL = 0.0, nrmU = 0.0, larg = 0.0, potpiv = 0.0;
+    orc_int pos_pot = -1, keep_diag = -1;
+    double *kL = (double *)malloc(sizeof(double) * (size_t)(v->nnz > 0 ? v->nnz : 1)), *kU = (double *)malloc(sizeof(double) * (size_t)(v->nnz > 0 ? v->nnz : 1));
+    *nL = *nU = 0;
+    if (v->n == 0) { free(kL); free(kU); return; }
+    for (i = 0; i < v->nnz; ++i) {
+        const double a = fabs(v->data[i]);
+        const orc_int p = invperm[v->pointer[i]];
+        if (p < mid) nrmL += v->data[i] * v->data[i];
+        else {
+            nrmU += v->data[i] * v->data[i];
+            if (with_piv) {
+                if (a > larg) larg = a;
+                if (p == mid) { potpiv = a; pos_pot = i; }
+            }
+        }
+    }
+    nrmL = sqrt(nrmL); nrmU = sqrt(nrmU);
+    /* not pivoting (:2083-2087): the diagonal entry counts as large as the norm -- it is selected and goes to the end as the pivot */
+    if (with_piv && !((larg * piv_tol >= potpiv) || (pos_pot < 0))) keep_diag = pos_pot;
+    for (i = 0; i < v->nnz; ++i) {
+        const double a = i == keep_diag ? nrmU : fabs(v->data[i]);
+        if (invperm[v->pointer[i]] < mid) { if (a > nrmL * tau_L) { kL[cL] = a; list_L[cL++] = v->pointer[i]; } }
+        else if (a > nrmU * tau_U) { kU[cU] = a; list_U[cU++] = v->pointer[i]; }
+    }
+    if (cL > n_L) {
+        const orc_int offset = cL - n_L;
+        vec_select_largest(kL, list_L, 0, cL - 1, n_L);
+        memmove(list_L, list_L + offset, sizeof(orc_int) * (size_t)n_L);
+        cL = n_L;
+    }
+    if (cU > 0) {
+        if (cU > n_U) {
+            const orc_int offset = cU - n_U;
+            vec_select_largest(kU, list_U, 0, cU - 1, n_U);
+            pos = offset;
+            for (i = offset + 1; i < cU; ++i) if (kU[i] > kU[pos]) pos = i;
+            t = list_U[pos]; list_U[pos] = list_U[cU - 1]; list_U[cU - 1] = t;
+            memmove(list_U, list_U + offset, sizeof(orc_int) * (size_t)n_U);
+            cU = n_U;
+        } else {
+            pos = 0;
+            for (i = 1; i < cU; ++i) if (kU[i] > kU[pos]) pos = i;
+            t = list_U[pos]; list_U[pos] = list_U[cU - 1]; list_U[cU - 1] = t;
+        }
+    }
+    *nL = cL; *nU = cU;
+    free(kL); free(kU);
+}
+
+/* ILUTP2, ILUTP.hpp:13-140, on the major-order view of the arrays (for COLUMN input: of A^T): L by rows (its 1 last, columns in the
+ * PERMUTED numbering, sorted), U by rows (the pivot first, ORIGINAL column indices, ordered by their permuted position); perm[i]: the
+ * column taken at step i.  Errors: ORC_ERR_MEMORY ("ILUTP2: memory reserved was insufficient."), ORC_ERR_ZERO_PIVOT ("encountered zero pivot") */
+int orc_ilutp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, orc_int max_fill_in, double threshold, double piv_tol,
+              orc_int bp, double mem_factor, orc_mat *L, orc_mat *U, orc_int *perm, orc_int *zero_pivots)
+{
+    orc_int i, j, k, p, t, x, reserved, nL, nU;
+    orc_int *inverse_perm, *list_L, *list_U;
+    evec w;
+    int rc = ORC_OK;
+    if (max_fill_in < 1) max_fill_in = 1;
+    if (max_fill_in > n) max_fill_in = n;
+    {
+        long a = (long)max_fill_in * (long)n, b = (long)((orc_int)mem_factor) * (long)ptr[n];      /* (Integer) mem_factor * A.non_zeroes(), :37 */
+        long r = a < b ? a : b;
+        reserved = (orc_int)(r > 0 ? r : 0);
+    }
+    *zero_pivots = 0;
+    inverse_perm = (orc_int *)malloc(sizeof(orc_int) * ((size_t)n + 1));
+    list_L = (orc_int *)malloc(sizeof(orc_int) * (4 * (size_t)n + 16)); list_U = (orc_int *)malloc(sizeof(orc_int) * (4 * (size_t)n + 16));
+    mat_init(U, n, reserved > 0 ? reserved : 1, 1);
+    mat_init(L, n, reserved > 0 ? reserved : 1, 1);
+    ev_init(&w, n);
+    for (k = 0; k < n; ++k) perm[k] = inverse_perm[k] = k;
+    for (i = 0; i < n; ++i) {
+        double norm_wL = 0.0;
+        if (i == bp) piv_tol = 1.0;
+        for (k = ptr[i]; k < ptr[i + 1]; ++k) {                                  /* :46-52 */
+            j = inverse_perm[idx[k]];
+            w.data[ev_slot(&w, idx[k], j)] = val[k];
+            if (j < i) norm_wL += val[k] * val[k];
+        }
+        norm_wL = sqrt(norm_wL);
+        while (w.hlen > 0 && w.heap[0] < i) {                                    /* :54-67: the entries left of position i, by position */
+            k = w.heap[0];
+            x = w.keyslot[k];
+            if (fabs(w.data[x]) < threshold * norm_wL) {                         /* current_zero_set, :2376-2384 */
+                if (w.occupancy[w.pointer[x]] >= 0) { w.data[w.occupancy[w.pointer[x]]] = 0.0; w.occupancy[w.pointer[x]] = -1; }
+                w.keyslot[k] = -1; ev_heap_pop(&w);
+            } else {
+                double wk;
+                w.data[x] /= U->val[U->ptr[k]];
+                wk = w.data[x];
+                ev_heap_pop(&w);
+                for (j = U->ptr[k] + 1; j < U->ptr[k + 1]; ++j) {
+                    const orc_int y = ev_slot(&w, U->idx[j], inverse_perm[U->idx[j]]);
+                    w.data[y] -= wk * U->val[j];
+                }
+            }
+        }
+        ilutp_select(&w, inverse_perm, max_fill_in - 1, max_fill_in, threshold, threshold, i, 1, piv_tol, list_L, &nL, list_U, &nU);
+        if (nU == 0) {                                                           /* :72-84 */
+            if (threshold > 0.0) ilutp_select(&w, inverse_perm, max_fill_in - 1, max_fill_in, threshold, 0.0, i, 0, 0.0, list_L, &nL, list_U, &nU);
+            if (nU == 0) {
+                (*zero_pivots)++;
+                w.data[ev_slot(&w, perm[i], i)] = 1.0;
+                nU = 1; list_U[0] = perm[i];
+            }
+        }
+        if (L->ptr[i] + nL + 1 > reserved) { rc = ORC_ERR_MEMORY; break; }
+        for (j = 0; j < nL; ++j) {
+            const orc_int c = list_L[nL - 1 - j];
+            L->val[L->ptr[i] + j] = w.data[w.occupancy[c]];
+            L->idx[L->ptr[i] + j] = inverse_perm[c];
+        }
+        L->val[L->ptr[i] + nL] = 1.0; L->idx[L->ptr[i] + nL] = i;
+        L->ptr[i + 1] = L->ptr[i] + nL + 1;
+        if (U->ptr[i] + nU > reserved) { rc = ORC_ERR_MEMORY; break; }
+        for (j = 0; j < nU; ++j) {
+            const orc_int c = list_U[nU - 1 - j];
+            U->val[U->ptr[i] + j] = w.data[w.occupancy[c]];
+            U->idx[U->ptr[i] + j] = c;
+        }
+        U->ptr[i + 1] = U->ptr[i] + nU;
+        {
+            const orc_int c = U->idx[U->ptr[i]];
+            p = inverse_perm[c];
+            t = inverse_perm[perm[i]]; inverse_perm[perm[i]] = inverse_perm[c]; inverse_perm[c] = t;
+            t = perm[i]; perm[i] = perm[p]; perm[p] = t;
+        }
+        if (U->val[U->ptr[i]] == 0) { rc = ORC_ERR_ZERO_PIVOT; break; }
+        ev_reset(&w);
+    }
+    ev_free(&w);
+    free(list_L); free(list_U);
+    if (rc != ORC_OK) { free(inverse_perm); orc_free_mat(L); orc_free_mat(U); return rc; }
+    L->nnz = L->ptr[n]; U->nnz = U->ptr[n];
+    mat_compress(L, 0.0); mat_compress(U, 0.0);                                  /* :131-132 */
+    {   /* U.reorder(inverse_perm), sparse_implementation.h:3357-3379: every row by the permuted position of its columns; L.normal_order() */
+        orc_int r, maxlen = 0;
+        struct pr2 { orc_int key, pos; } *buf;
+        orc_int *ti; double *tv;
+        for (r = 0; r < n; ++r) if (U->ptr[r + 1] - U->ptr[r] > maxlen) maxlen = U->ptr[r + 1] - U->ptr[r];
+        buf = (struct pr2 *)malloc(sizeof(struct pr2) * (size_t)(maxlen > 0 ? maxlen : 1));
+        ti = (orc_int *)malloc(sizeof(orc_int) * (size_t)(maxlen > 0 ? maxlen : 1)); tv = (double *)malloc(sizeof(double) * (size_t)(maxlen > 0 ? maxlen : 1));
+        for (r = 0; r < n; ++r) {
+            const orc_int b0 = U->ptr[r], len = U->ptr[r + 1] - b0;
+            for (j = 0; j < len; ++j) { buf[j].key = inverse_perm[U->idx[b0 + j]]; buf[j].pos = j; ti[j] = U->idx[b0 + j]; tv[j] = U->val[b0 + j]; }
+            qsort(buf, (size_t)len, sizeof(struct pr2), cmp_idx_pair);
+            for (j = 0; j < len; ++j) { U->idx[b0 + j] = ti[buf[j].pos]; U->val[b0 + j] = tv[buf[j].pos]; }
+        }
+        free(buf); free(ti); free(tv);
+    }
+    mat_normal_order(L);
+    free(inverse_perm);
+    return ORC_OK;
+}
+
+/* ILUTPPreconditioner (preconditioner_implementation.h:1050-1078) + apply_preconditioner_only: for ROW input L (by rows, its 1 last) is the left
+ * factor, U (by rows, PERMUTED upper triangular) the right one; for COLUMN input the factors of A^T change sides. */
+void orc_apply_ilutp(const orc_mat *L, const orc_mat *U, const orc_int *perm, int input_is_csr, int use, double *x)
+{
+    const orc_int n = L->n;
+    orc_int k, j;
+    double *y = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+#define PERM_FORWARD() do { memcpy(y, x, sizeof(double) * (size_t)n); \
+        for (k = 0; k < n; ++k) { y[perm[k]] /= U->val[U->ptr[k]]; for (j = U->ptr[k] + 1; j < U->ptr[k + 1]; ++j) y[U->idx[j]] -= U->val[j] * y[perm[k]]; } \
+        for (k = 0; k < n; ++k) x[k] = y[perm[k]]; } while (0)
+#define PERM_BACKWARD() do { memcpy(y, x, sizeof(double) * (size_t)n); \
+        for (k = n - 1; k >= 0; --k) { for (j = U->ptr[k] + 1; j < U->ptr[k + 1]; ++j) y[k] -= U->val[j] * x[U->idx[j]]; x[perm[k]] = y[k] / U->val[U->ptr[k]]; } } while (0)
+    if (input_is_csr) {
+        if (use == ORC_ID) { orc_trisolve(n, L->ptr, L->idx, L->val, 1, ORC_LOWER, ORC_ID, x); PERM_BACKWARD(); }
+        else { PERM_FORWARD(); orc_trisolve(n, L->ptr, L->idx, L->val, 1, ORC_LOWER, ORC_TRANSPOSE, x); }
+    } else {
+        /* left = U^T (PERMUTED_LOWER_TRIANGULAR, by columns = the rows of U), right = L^T (upper triangular, by columns = the rows of L) */
+        if (use == ORC_ID) { PERM_FORWARD(); orc_trisolve(n, L->ptr, L->idx, L->val, 0, ORC_UPPER, ORC_ID, x); }
+        else { orc_trisolve(n, L->ptr, L->idx, L->val, 0, ORC_UPPER, ORC_TRANSPOSE, x); PERM_BACKWARD(); }
+    }
+#undef PERM_FORWARD
+#undef PERM_BACKWARD
+    free(y);
+}

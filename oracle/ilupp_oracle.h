@@ -159,6 +159,12 @@ int orc_ilucp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *v
               orc_int rp, double mem_factor, orc_mat *L, orc_mat *U, orc_int *perm, orc_int *zero_pivots);
 void orc_apply_ilucp(const orc_mat *L, const orc_mat *U, const orc_int *perm, int input_is_csr, int use, double *x);
 
+/* ---- ILUTP (ILUTP.hpp:13-140, preconditioner_implementation.h:1050-1078): ILUT with column pivoting on the major-order view of
+ * the arrays (rows); the apply of ILUTPPreconditioner for the input's orientation ---- */
+int orc_ilutp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, orc_int max_fill_in, double threshold, double piv_tol,
+              orc_int bp, double mem_factor, orc_mat *L, orc_mat *U, orc_int *perm, orc_int *zero_pivots);
+void orc_apply_ilutp(const orc_mat *L, const orc_mat *U, const orc_int *perm, int input_is_csr, int use, double *x);
+
 #ifdef __cplusplus
 }
 #endif

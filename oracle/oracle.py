@@ -370,6 +370,7 @@ def from_scipy(A):
 
 class ILUCP:
     """ILUCPPreconditioner of either library: factors for the major-order view, the permutation, apply"""
+    _name = "ilucp"
 
     def __init__(self, lib, A, fill_in=100, threshold=0.1, piv_tol=0.1, rp=-1, mem_factor=10.0):
         self.lib = lib
@@ -381,12 +382,12 @@ class ILUCP:
         zp = ctypes.c_int32(0)
         self.h = ctypes.c_void_p()
         if lib.prefix == "ref_":
-            f = lib.lib.ref_ilucp
+            f = getattr(lib.lib, "ref_" + self._name)
             f.restype = ctypes.c_int
             rc = f(args[0], args[1], args[2], args[3], args[4], ctypes.c_int32(fill_in), ctypes.c_double(threshold), ctypes.c_double(piv_tol), ctypes.c_int32(rp),
                    ctypes.c_double(mem_factor), ctypes.byref(L), ctypes.byref(U), _p_i32(perm), ctypes.byref(zp), ctypes.byref(self.h))
         else:
-            f = lib.lib.orc_ilucp
+            f = getattr(lib.lib, "orc_" + self._name)
             f.restype = ctypes.c_int
             rc = f(args[0], args[1], args[2], args[3], ctypes.c_int32(fill_in), ctypes.c_double(threshold), ctypes.c_double(piv_tol), ctypes.c_int32(rp),
                    ctypes.c_double(mem_factor), ctypes.byref(L), ctypes.byref(U), _p_i32(perm), ctypes.byref(zp))
@@ -406,7 +407,13 @@ class ILUCP:
     def apply(self, x, use=ID):
         x = np.array(x, dtype=np.float64, copy=True).ravel()
         if self.lib.prefix == "ref_":
-            self.lib.lib.ref_ilucp_apply(self.h, ctypes.c_int32(self.n), int(use), _p_f64(x))
+            getattr(self.lib.lib, "ref_%s_apply" % self._name)(self.h, ctypes.c_int32(self.n), int(use), _p_f64(x))
         else:
-            self.lib.lib.orc_apply_ilucp(ctypes.byref(self._L), ctypes.byref(self._U), _p_i32(self.perm), int(self.is_csr), int(use), _p_f64(x))
+            getattr(self.lib.lib, "orc_apply_" + self._name)(ctypes.byref(self._L), ctypes.byref(self._U), _p_i32(self.perm), int(self.is_csr), int(use), _p_f64(x))
         return x
+
+
+class ILUTP(ILUCP):
+    """ILUTPPreconditioner of either library: L by rows (its 1 last, permuted column numbering), U by rows (pivot first, original
+    column indices), the permutation, apply -- for the major-order view of the input"""
+    _name = "ilutp"

@@ -394,6 +394,36 @@ void ref_ilucp_apply(void *handle, orc_int n, int use, double *x)
 
 void ref_ilucp_free(void *handle) { delete static_cast<ILUCPPreconditioner<Real, matrix, vector> *>(handle); }
 
+/* ---- ILUTPPreconditioner (binding.cpp:313-326) behind the orc_ilutp / orc_apply_ilutp ABI ---- */
+int ref_ilutp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, orc_int max_fill_in, double threshold, double piv_tol,
+              orc_int bp, double mem_factor, orc_mat *Lo, orc_mat *Uo, orc_int *perm, orc_int *zero_pivots, void **handle)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    ILUTPPreconditioner<Real, matrix, vector> *P = nullptr;
+    try {
+        P = new ILUTPPreconditioner<Real, matrix, vector>(A, max_fill_in, threshold, piv_tol, bp, mem_factor);
+    } catch (const std::runtime_error &e) {
+        return std::strstr(e.what(), "zero pivot") ? ORC_ERR_ZERO_PIVOT : ORC_ERR_MEMORY;
+    }
+    if (!P->exists()) { delete P; return ORC_ERR_ZERO_PIVOT; }
+    // ROW input: left = L, right = U; COLUMN input: left = U^T (U's arrays), right = L^T (L's arrays)
+    if (is_csr) { export_mat(P->left_matrix(), Lo); export_mat(P->right_matrix(), Uo); }
+    else { export_mat(P->right_matrix(), Lo); export_mat(P->left_matrix(), Uo); }
+    for (orc_int k = 0; k < n; ++k) perm[k] = P->extract_permutation()[k];
+    if (zero_pivots) *zero_pivots = -1;
+    if (handle) *handle = P; else delete P;
+    return ORC_OK;
+}
+
+void ref_ilutp_apply(void *handle, orc_int n, int use, double *x)
+{
+    auto *P = static_cast<ILUTPPreconditioner<Real, matrix, vector> *>(handle);
+    vector v(n, x, true);
+    P->apply_preconditioner_only(use == ORC_ID ? ID : TRANSPOSE, v);
+}
+
+void ref_ilutp_free(void *handle) { delete static_cast<ILUTPPreconditioner<Real, matrix, vector> *>(handle); }
+
 void ref_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key)
 {
     std::sort(list, list + len, [&](orc_int x, orc_int y) { return std::abs(key[x]) > std::abs(key[y]); });
