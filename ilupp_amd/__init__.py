@@ -171,21 +171,26 @@ class ILUCPreconditioner(_HipPreconditioner):
         super().__init__(A, lambda m: _backend.ILUCPreconditioner(*m, fill_in, threshold))
 
 
-class _NotBuilt(_LinearOperator):
-    """a class of the reference this package has no engine for yet: constructing it says so (nothing is computed on the CPU instead)"""
-    _what = ""
+class ILUTPPreconditioner(_HipPreconditioner):
+    """An ILUTP (incomplete LU with thresholding and column pivoting) preconditioner.  (Reference: ilupp/__init__.py:218-236 over ILUTP2,
+    ILUTP.hpp:13-140.)
+
+    Args:
+        A: a sparse matrix in CSR or CSC format
+        fill_in: the number of nonzeros to allow per row of L/U
+        threshold: entries with relative magnitude less than this are dropped
+        piv_tol: pivoting tolerance; 0=only pivot when 0 encountered, 1=always pivot
+            to the largest entry, inbetween: pivot depending on relative magnitude
+
+    Every row sees the column permutation the rows before it made: a chain of n steps that one wave of the GPU walks
+    (ilupp_amd/csrc/ilutp.hip); bit-identical to the reference, not faster than it."""
 
     def __init__(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0):
-        raise NotImplementedError("ilupp_amd: %s (SURVEY section 8 f4: the pivot search makes every row wait for the permutation "
-                                  "of all rows before it) is not built on the GPU yet" % self._what)
+        super().__init__(A, lambda m: _native.ILUTPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
 
     def permutations(self):
-        raise NotImplementedError
-
-
-class ILUTPPreconditioner(_NotBuilt):
-    """ILUTP (ILUT with column pivoting; reference ilupp/__init__.py:218-236, ILUTP.hpp:13-140): not built -- raises NotImplementedError."""
-    _what = "ILUTP, the ILUT with column pivoting"
+        """Return a pair (L,R) of permutation arrays to be applied from the left or right due to pivoting."""
+        return self.pr.permutations()
 
 
 class ILUCPPreconditioner(_HipPreconditioner):

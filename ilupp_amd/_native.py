@@ -132,6 +132,7 @@ def lib():
     L.ilupp_hip_ml_sync.argtypes = [_VP]
     L.ilupp_hip_ilucp_create.argtypes = [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
                                          ctypes.c_double, ctypes.POINTER(_VP)]
+    L.ilupp_hip_ilutp_create.argtypes = L.ilupp_hip_ilucp_create.argtypes
     L.ilupp_hip_ilucp_destroy.argtypes = [_VP]
     L.ilupp_hip_ilucp_destroy.restype = None
     L.ilupp_hip_ilucp_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
@@ -168,7 +169,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_ml_apply_device", "ilupp_hip_ml_apply_part_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
     "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings",
     "ilupp_hip_ilucp_create", "ilupp_hip_ilucp_destroy", "ilupp_hip_ilucp_apply", "ilupp_hip_ilucp_total_nnz", "ilupp_hip_ilucp_zero_pivots",
-    "ilupp_hip_ilucp_info", "ilupp_hip_ilucp_copy",
+    "ilupp_hip_ilucp_info", "ilupp_hip_ilucp_copy", "ilupp_hip_ilutp_create",
 ]
 
 
@@ -586,8 +587,8 @@ class PivotedPreconditioner:
     exists = True
     special_info = ""
 
-    def __init__(self, handle, n, is_csr):
-        self._h, self._n, self._csr = handle, n, bool(is_csr)
+    def __init__(self, handle, n, is_csr, rows=False):
+        self._h, self._n, self._csr, self._rows = handle, n, bool(is_csr), bool(rows)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -645,6 +646,12 @@ class PivotedPreconditioner:
         the factors of the transposed matrix change sides and labels (transpose_in_place): U's arrays as a column matrix, L's as a row matrix"""
         L, U, _ = self.raw()
         n = self._n
+        if self._rows:
+            # ILUTP (preconditioner_implementation.h:1050-1078): ROW input: L by rows, U by rows; COLUMN input: the factors of the transposed
+            # matrix change sides and labels: U's arrays as a column matrix, L's as a column matrix
+            if self._csr:
+                return [(L[0], L[1], L[2], True, n, n), (U[0], U[1], U[2], True, n, n)]
+            return [(U[0], U[1], U[2], False, n, n), (L[0], L[1], L[2], False, n, n)]
         if not self._csr:
             return [(L[0], L[1], L[2], False, n, n), (U[0], U[1], U[2], True, n, n)]
         return [(U[0], U[1], U[2], False, n, n), (L[0], L[1], L[2], True, n, n)]
@@ -652,6 +659,8 @@ class PivotedPreconditioner:
     def permutations(self):
         """binding.cpp:178-196: (left, right) -- the permutation belongs to the factor U came from"""
         perm = self.raw()[2]
+        if self._rows:
+            return (None, perm) if self._csr else (perm, None)
         return (perm, None) if self._csr else (None, perm)
 
     def print_info(self):
@@ -666,3 +675,13 @@ def ILUCPPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, thresh
     if rc:
         _raise(rc)
     return PivotedPreconditioner(h, args[3], is_csr)
+
+
+def ILUTPPreconditioner(A_data, A_indices, A_indptr, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor):
+    """binding.cpp:313-326"""
+    args, keep = _matrix_args(A_data, A_indices, A_indptr, is_csr)
+    h = _VP()
+    rc = lib().ilupp_hip_ilutp_create(*args, int(max_fill_in), float(threshold), float(piv_tol), int(row_pos), float(mem_factor), ctypes.byref(h))
+    if rc:
+        _raise(rc)
+    return PivotedPreconditioner(h, args[3], is_csr, rows=True)

@@ -1638,6 +1638,7 @@ int ilupp_hip_ml_timings(const ilupp_ml *m, float *construct_ms, float *kernel_m
 struct ilupp_ilucp {
     int32_t n = 0;
     bool input_csr = false;
+    bool row_kind = false;                 // ILUTP: the factors belong to the ROWS of the view (L by rows, 1 last), the plain solve comes first for ROW input
     ilupp_precond *obj = nullptr;          // L and U' (permuted numbering), the sweeps
     DevMat U;                              // U as the reference stores it (original column indices): what factors() hands out
     int32_t *perm = nullptr;               // device
@@ -1763,7 +1764,8 @@ int ilupp_hip_ilucp_apply(ilupp_ilucp *m, double *x, int64_t len, int transpose)
     hipStream_t st = p->stream;
     if (!m->xdev) ILUPP_HIP(pool_malloc(&m->xdev, sizeof(double) * (size_t)n));
     ILUPP_HIP(hipMemcpyAsync(m->xdev, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-    const bool plain_first = (transpose != 0) == m->input_csr;            // COLUMN input + apply, ROW input + apply_trans
+    // ILUCP: COLUMN input + apply, ROW input + apply_trans start with the plain factor; ILUTP: ROW input + apply, COLUMN input + apply_trans
+    const bool plain_first = m->row_kind ? ((transpose == 0) == m->input_csr) : ((transpose != 0) == m->input_csr);
     int rc;
     if (plain_first) {
         rc = apply_dev(p, m->xdev, 0);
@@ -1815,3 +1817,72 @@ int ilupp_hip_ilucp_copy(const ilupp_ilucp *m, double *l_data, int32_t *l_indice
 }
 
 }  // extern "C"
+
+namespace {
+
+int ilutp_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, double threshold, double piv_tol, int32_t row_pos, double mem_factor,
+                        ilupp_ilucp **out)
+{
+    struct Guard { ilupp_ilucp *m; ~Guard() { if (m) ilucp_destroy(m); } } g{new ilupp_ilucp};
+    ilupp_ilucp *m = g.m;
+    m->n = n; m->input_csr = is_csr != 0; m->row_kind = true;
+    m->obj = new_obj(n);
+    ilupp_precond *p = m->obj;
+    hipStream_t st = p->stream;
+    ILUPP_HIP(pool_malloc(&m->perm, sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(pool_malloc(&m->tmp, sizeof(double) * (size_t)n));
+    ILUPP_HIP(hipEventRecord(p->ev[0], st));
+    const int rc = ilutp_factor(st, A, max_fill_in, threshold, piv_tol, row_pos, mem_factor, &p->Lc, &p->Uc, &m->U, m->perm, &m->zero_pivots, &m->kernel_ms);
+    ILUPP_HIP(hipEventRecord(p->ev[1], st));
+    A.release();
+    if (rc) return rc;
+    // an object of the ILUT kind: L by rows with its 1 last, U (permuted numbering) by rows with the pivot first
+    p->kind = KIND_LU; p->nnz_mode = NNZ_ILUT; p->input_csc = false;
+    int32_t m1 = 0, m2 = 0;
+    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, &p->sL, nullptr, &m1);
+    count_cuts_and_schedule(st, n, p->Uc.ptr, p->Uc.idx, p->max_lanes, nullptr, &p->sU, &m2);
+    p->max_row_len = m1 > m2 ? m1 : m2;
+    const int max_wgs = p->max_lanes / kThreads;
+    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, true, max_wgs);
+    choose_tiling(st, n, p->Uc.ptr, p->Uc.idx, &p->sU, false, max_wgs);
+    build_slot_tables(st, &p->sL, true);
+    build_slot_tables(st, &p->sU, false);
+    p->compact = schedule_is_compact(p->sL) && schedule_is_compact(p->sU);
+    if (p->compact) {
+        make_desc(st, p->Lc, p->sL, &p->dL);
+        make_desc(st, p->Uc, p->sU, &p->dU);
+    }
+    ILUPP_HIP(hipEventRecord(p->ev[2], st));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));
+    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, p->ev[1], p->ev[2]));
+    p->tm.numeric_kernel_ms = m->kernel_ms;
+    *out = m;
+    g.m = nullptr;
+    return ILUPP_OK;
+}
+
+}  // namespace
+
+extern "C" int ilupp_hip_ilutp_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, int32_t max_fill_in,
+                                      double threshold, double piv_tol, int32_t row_pos, double mem_factor, ilupp_ilucp **out)
+{
+    API_TRY
+    if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    DevMat A;
+    A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
+    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    rc = ilutp_create_common(A, n, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor, out);
+    A.release();
+    return rc;
+    API_CATCH
+}

@@ -349,6 +349,13 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
 int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, int32_t bp, int32_t bpr, int32_t epr,
                   DevMat *L, DevMat *U, double **Dinv, DevMat *Anew, int32_t *pc2, int32_t *pr2, float *kernel_ms);
 
+// pilucdp.hip: the entries with |x| > 0 of every segment (compress()), their indices through `map` minus `shift`, every segment sorted by the new index
+int seg_compress_sort(hipStream_t st, int32_t nseg, const int32_t *ptr, const int32_t *idx, const double *val, const int32_t *map, int32_t shift,
+                      bool is_csr, DevMat *M);
+// ilutp.hip: ILUTP2 (ILUTP.hpp:13-140) on the major-order view A (rows): L by rows (1 last, permuted numbering), U by rows in the permuted numbering
+// (pivot first) and the same with original column indices, perm (device)
+int ilutp_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double threshold, double piv_tol, int32_t bp, double mem_factor,
+                 DevMat *L, DevMat *Up, DevMat *Uorig, int32_t *perm_out, int32_t *zero_pivots, float *kernel_ms);
 // ilucp.hip: ILUCP4 (ILUC.hpp:212-370) on the major-order view C: L by columns, U by rows (pivot first, original column indices), perm (device)
 int ilucp_factor(hipStream_t st, const DevMat &C, int32_t max_fill_in, double threshold, double piv_tol, int32_t rp, double mem_factor,
                  DevMat *L, DevMat *U, int32_t *perm_out, int32_t *zero_pivots, float *kernel_ms);

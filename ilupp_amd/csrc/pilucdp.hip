@@ -441,8 +441,8 @@ __global__ void k_dp_low(int64_t nnz, const unsigned long long *__restrict__ key
 }
 
 // compress(), then every index through `map` (minus shift), then normal_order(): one segmented sort
-static int dp_finish(hipStream_t st, int32_t nseg, const int32_t *ptr, const int32_t *idx, const double *val, const int32_t *map, int32_t shift,
-                     bool is_csr, DevMat *M)
+int seg_compress_sort(hipStream_t st, int32_t nseg, const int32_t *ptr, const int32_t *idx, const double *val, const int32_t *map, int32_t shift,
+                      bool is_csr, DevMat *M)
 {
     PoolBlock b_len, b_k0, b_k1, b_v0, b_tmp;
     ILUPP_HIP(b_len.alloc(sizeof(int32_t) * (size_t)(nseg + 1)));
@@ -609,8 +609,8 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         const int32_t last = ctrl[1], nA = ctrl[2];
         const bool to_the_end = ctrl[4] != 0;
         // compress(), permute(permrows, ROW) / U.permute(perm, COLUMN), :1131-1151
-        { const int rc = dp_finish(st, n, a.Lptr, a.Lidx, a.Lval, a.iprow, 0, false, L); if (rc) return rc; }
-        { const int rc = dp_finish(st, n, a.Uptr, a.Uidx, a.Uval, a.iperm, 0, true, U); if (rc) return rc; }
+        { const int rc = seg_compress_sort(st, n, a.Lptr, a.Lidx, a.Lval, a.iprow, 0, false, L); if (rc) return rc; }
+        { const int rc = seg_compress_sort(st, n, a.Uptr, a.Uidx, a.Uval, a.iperm, 0, true, U); if (rc) return rc; }
         if (to_the_end) {                                                           // :1133
             Anew->release();
             Anew->n = 0; Anew->nnz = 0; Anew->is_csr = true; Anew->owns = true;
@@ -619,7 +619,7 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
             ILUPP_HIP(pool_malloc(&Anew->idx, sizeof(int32_t)));
             ILUPP_HIP(pool_malloc(&Anew->val, sizeof(double)));
         } else {
-            const int rc = dp_finish(st, nA, a.Sptr, a.Sidx, a.Sval, a.iperm, last + 1, true, Anew);      // :1136-1145
+            const int rc = seg_compress_sort(st, nA, a.Sptr, a.Sidx, a.Sval, a.iperm, last + 1, true, Anew);      // :1136-1145
             if (rc) return rc;
         }
         ILUPP_HIP(hipMemcpyAsync(pc2, a.perm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));

@@ -258,6 +258,14 @@ int ilupp_hip_ilucp_info(const ilupp_ilucp *p, int32_t *n, int64_t *nnz_l, int64
 int ilupp_hip_ilucp_copy(const ilupp_ilucp *p, double *l_data, int32_t *l_indices, int32_t *l_indptr, double *u_data, int32_t *u_indices,
                          int32_t *u_indptr, int32_t *perm);
 
+/* ILUTP: ILUT with column pivoting.  Replaces binding.cpp:313-326 (ILUTPPreconditioner.__init__ -> preconditioner_implementation.h:1050-1078 ->
+ * ILUTP2, ILUTP.hpp:13-140).  The object is of the same type as ILUCP's and shares its apply / total_nnz / info / copy / destroy entry points;
+ * its factors belong to the ROWS of the view: L by rows (its 1 last, columns in the permuted numbering), U by rows (the pivot first, original
+ * column indices, ordered by permuted position).  Errors: ILUPP_ERR_MEMORY ("ILUTP2: memory reserved was insufficient."), ILUPP_ERR_ZERO_PIVOT
+ * ("matrix_sparse::ILUTP2: encountered zero pivot in row N") */
+int ilupp_hip_ilutp_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, int32_t max_fill_in,
+                           double threshold, double piv_tol, int32_t row_pos, double mem_factor, ilupp_ilucp **out);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement hooks used by bench.py (not part of the reference's surface).
  * Times are GPU milliseconds from hipEvents recorded on the object's stream.
