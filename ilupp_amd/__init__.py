@@ -186,7 +186,7 @@ class ILUTPPreconditioner(_HipPreconditioner):
     (ilupp_amd/csrc/ilutp.hip); bit-identical to the reference, not faster than it."""
 
     def __init__(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0):
-        super().__init__(A, lambda m: _native.ILUTPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
+        super().__init__(A, lambda m: _backend.ILUTPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
 
     def permutations(self):
         """Return a pair (L,R) of permutation arrays to be applied from the left or right due to pivoting."""
@@ -207,7 +207,7 @@ class ILUCPPreconditioner(_HipPreconditioner):
     (ilupp_amd/csrc/ilucp.hip); bit-identical to the reference, not faster than it."""
 
     def __init__(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0):
-        super().__init__(A, lambda m: _native.ILUCPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
+        super().__init__(A, lambda m: _backend.ILUCPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
 
     def permutations(self):
         """Return a pair (L,R) of permutation arrays to be applied from the left or right due to pivoting."""

@@ -1,6 +1,7 @@
 // ilupp_amd/csrc/pybind_module.cpp -- the pybind11 shim over the C ABI (include/ilupp_hip.h): a compiled module with the
 // surface of the reference's `ilupp._ilupp` for the hot path (src/binding.cpp:233-264 object members, :279 index_size,
-// :299-310 ILUTPreconditioner, :366-397 the ILU0 / IChol0 / ICholT factories, :399-447 the stand-alone factor functions).
+// :299-310 ILUTPreconditioner, :313-326 ILUTPPreconditioner, :343-356 ILUCPPreconditioner with :178-196 permutations(),
+// :366-397 the ILU0 / IChol0 / ICholT factories, :399-447 the stand-alone factor functions).
 // Host code only: buffer checks, GIL handling, numpy egress; all arithmetic happens behind the C ABI on the GPU.
 //   g++ -O2 -shared -fPIC $(python3 -m pybind11 --includes) pybind_module.cpp -L.. -lilupp_hip -Wl,-rpath,'$ORIGIN'
 //       -o ../_ilupp_hip$(python3-config --extension-suffix)
@@ -156,6 +157,103 @@ void ml_solve_in_place(const Multilevel &f, const py::buffer &x, int transposed)
     ok(ilupp_hip_ml_apply(f.h, static_cast<double *>(v.ptr), v.shape[0], transposed));
 }
 
+// the two factorisations with column pivoting (binding.cpp:313-326 ILUTPPreconditioner, :343-356 ILUCPPreconditioner): one kind of object
+// behind the C ABI; `by_rows`: ILUTP2's factors belong to the rows of the view, ILUCP4's L to its columns
+struct Pivoted {
+    ilupp_ilucp *h = nullptr;
+    int32_t n = 0;
+    bool csr = true, by_rows = false;
+    Pivoted() = default;
+    Pivoted(const Pivoted &) = delete;
+    Pivoted(Pivoted &&o) noexcept : h(o.h), n(o.n), csr(o.csr), by_rows(o.by_rows) { o.h = nullptr; }
+    ~Pivoted() { if (h) ilupp_hip_ilucp_destroy(h); }
+};
+struct ILUTP : Pivoted { using Pivoted::Pivoted; };
+struct ILUCP : Pivoted { using Pivoted::Pivoted; };
+
+struct PivotedArrays { py::array_t<double> ld, ud; py::array_t<int32_t> li, lp, ui, up, perm; };
+PivotedArrays pivoted_arrays(const Pivoted &f)
+{
+    int32_t n = 0; int64_t nl = 0, nu = 0;
+    ok(ilupp_hip_ilucp_info(f.h, &n, &nl, &nu, nullptr));
+    PivotedArrays a{py::array_t<double>(nl), py::array_t<double>(nu), py::array_t<int32_t>(nl), py::array_t<int32_t>(n + 1),
+                    py::array_t<int32_t>(nu), py::array_t<int32_t>(n + 1), py::array_t<int32_t>(n)};
+    ok(ilupp_hip_ilucp_copy(f.h, a.ld.mutable_data(), a.li.mutable_data(), a.lp.mutable_data(), a.ud.mutable_data(), a.ui.mutable_data(),
+                            a.up.mutable_data(), a.perm.mutable_data()));
+    return a;
+}
+
+// [left, right] as the classes hold them (preconditioner_implementation.h:1050-1078, :1117-1147): the factors of the major-order view change
+// sides and labels when the class factorised the transposed matrix (transpose_in_place)
+py::list pivoted_factors(const Pivoted &f)
+{
+    const PivotedArrays a = pivoted_arrays(f);
+    const py::tuple L_rows = py::make_tuple(a.ld, a.li, a.lp, true, f.n, f.n), L_cols = py::make_tuple(a.ld, a.li, a.lp, false, f.n, f.n);
+    const py::tuple U_rows = py::make_tuple(a.ud, a.ui, a.up, true, f.n, f.n), U_cols = py::make_tuple(a.ud, a.ui, a.up, false, f.n, f.n);
+    py::list out;
+    if (f.by_rows) {
+        if (f.csr) { out.append(L_rows); out.append(U_rows); } else { out.append(U_cols); out.append(L_cols); }
+    } else {
+        if (!f.csr) { out.append(L_cols); out.append(U_rows); } else { out.append(U_cols); out.append(L_rows); }
+    }
+    return out;
+}
+
+// binding.cpp:178-196: (left, right) -- the permutation stands on the side of the factor U came from
+py::tuple pivoted_permutations(const Pivoted &f)
+{
+    const py::object perm = pivoted_arrays(f).perm;
+    const bool right = f.by_rows ? f.csr : !f.csr;
+    if (right) return py::make_tuple(py::none(), perm);
+    return py::make_tuple(perm, py::none());
+}
+
+template <class T, class Create>
+T make_pivoted(Create create, bool by_rows, py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t max_fill_in,
+               double threshold, double piv_tol, int32_t row_pos, double mem_factor)
+{
+    const Csr a = borrow(data, indices, indptr, is_csr);
+    T f;
+    f.n = a.n; f.csr = is_csr; f.by_rows = by_rows;
+    int rc;
+    {
+        py::gil_scoped_release release;              // binding.cpp:319-321, :349-351
+        rc = create(a.val, a.idx, a.ptr, a.n, a.row_major, max_fill_in, threshold, piv_tol, row_pos, mem_factor, &f.h);
+    }
+    ok(rc);
+    return f;
+}
+
+template <class T>
+py::class_<T> pivoted_members(py::module_ &m, const char *name)
+{
+    return py::class_<T>(m, name)
+        .def("apply", [](const T &f, py::buffer x) {
+            py::buffer_info v = reals(x, "b");
+            if (v.readonly) throw std::runtime_error("b must be writable");
+            if (v.shape[0] != f.n) throw std::runtime_error("vector has wrong size for preconditioner!");
+            ok(ilupp_hip_ilucp_apply(f.h, static_cast<double *>(v.ptr), v.shape[0], 0));
+        })
+        .def("apply_trans", [](const T &f, py::buffer x) {
+            py::buffer_info v = reals(x, "b");
+            if (v.readonly) throw std::runtime_error("b must be writable");
+            if (v.shape[0] != f.n) throw std::runtime_error("vector has wrong size for preconditioner!");
+            ok(ilupp_hip_ilucp_apply(f.h, static_cast<double *>(v.ptr), v.shape[0], 1));
+        })
+        .def_property_readonly("total_nnz", [](const T &f) { return ilupp_hip_ilucp_total_nnz(f.h); })
+        .def_property_readonly("zero_pivots", [](const T &f) { return ilupp_hip_ilucp_zero_pivots(f.h); })
+        .def("factors_info", [](const T &f) { return pivoted_factors(f); })
+        .def("permutations", [](const T &f) { return pivoted_permutations(f); })
+        .def_property_readonly("memory_used_calculations", [](const T &) { return 0.0; })
+        .def_property_readonly("memory_allocated_calculations", [](const T &) { return 0.0; })
+        .def_property_readonly("memory", [](const T &) { return 0.0; })
+        .def_property_readonly("exists", [](const T &) { return true; })
+        .def_property_readonly("special_info", [](const T &) { return std::string(); })
+        .def("print_info", [](const T &f) {
+            py::print("An incomplete LU factorisation with column pivoting:", ilupp_hip_ilucp_total_nnz(f.h), "entries");
+        });
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_ilupp_hip, m)
@@ -176,6 +274,17 @@ PYBIND11_MODULE(_ilupp_hip, m)
         .def(py::init([](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t max_fill_in, double threshold) {
             const Csr a = borrow(data, indices, indptr, is_csr);
             return adopt<ILUC>(build([&](ilupp_precond **h) { return ilupp_hip_iluc_create(a.val, a.idx, a.ptr, a.n, a.row_major, max_fill_in, threshold, h); }));
+        }));
+
+    pivoted_members<ILUTP>(m, "ILUTPPreconditioner")
+        .def(py::init([](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t max_fill_in, double threshold,
+                         double piv_tol, int32_t row_pos, double mem_factor) {
+            return make_pivoted<ILUTP>(ilupp_hip_ilutp_create, true, data, indices, indptr, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor);
+        }));
+    pivoted_members<ILUCP>(m, "ILUCPPreconditioner")
+        .def(py::init([](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, int32_t max_fill_in, double threshold,
+                         double piv_tol, int32_t row_pos, double mem_factor) {
+            return make_pivoted<ILUCP>(ilupp_hip_ilucp_create, false, data, indices, indptr, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor);
         }));
 
     py::class_<Multilevel>(m, "MultilevelILUCDPPreconditioner")

@@ -87,12 +87,16 @@ def test_pybind11_shim_surface_and_validation():
     for this path, and the buffer checks of binding.cpp:33-98 with the reference's messages (raised before any GPU call)"""
     from ilupp_amd import _ilupp_hip as m
     for name in ("index_size", "ILU0Preconditioner", "IChol0Preconditioner", "ICholTPreconditioner", "ILUTPreconditioner",
-                 "ILUCPreconditioner", "GenericLUPreconditioner", "GenericLLTPreconditioner", "ilu0", "ilut", "iluc", "ichol0", "icholt"):
+                 "ILUCPreconditioner", "ILUTPPreconditioner", "ILUCPPreconditioner", "MultilevelILUCDPPreconditioner", "GenericLUPreconditioner", "GenericLLTPreconditioner", "ilu0", "ilut", "iluc", "ichol0", "icholt"):
         assert hasattr(m, name), name
     assert m.index_size() == 4
     for member in ("apply", "apply_trans", "total_nnz", "factors_info", "memory_used_calculations",
                    "memory_allocated_calculations", "memory", "exists", "special_info", "print_info"):
         assert hasattr(m.GenericLUPreconditioner, member) and hasattr(m.ILUTPreconditioner, member) and hasattr(m.ILUCPreconditioner, member), member
+        assert hasattr(m.ILUTPPreconditioner, member) and hasattr(m.ILUCPPreconditioner, member) and hasattr(m.MultilevelILUCDPPreconditioner, member), member
+    assert hasattr(m.ILUTPPreconditioner, "permutations") and hasattr(m.ILUCPPreconditioner, "permutations")      # binding.cpp:326, :356
+    with pytest.raises(RuntimeError, match="indices and data should have the same size!"):
+        m.ILUCPPreconditioner(np.ones(3), np.arange(2, dtype=np.int32), np.arange(4, dtype=np.int32), True, 5, 0.1, 0.1, -1, 10.0)
     d, i, p = np.ones(3), np.arange(3, dtype=np.int32), np.arange(4, dtype=np.int32)
     with pytest.raises(RuntimeError, match=r"Expected d \(d\) array for A_data, got f!"):
         m.ILU0Preconditioner(d.astype(np.float32), i, p, True)

@@ -526,6 +526,22 @@ for fmt in ("csr", "csc"):
     MLd = ilupp.ILUppPreconditioner(A)                                  # default-constructed parameters: the factorisation with pivoting
     Qd = O.orc().ml(M, O.ml_params(1.0, **O.PIVOTING_DEFAULTS))
     assert MLd.total_nnz == Qd.total_nnz() and np.array_equal(MLd @ b, Qd.apply(b))
+    # the two classes with column pivoting of the shim (binding.cpp:313-326, :343-356) next to the ctypes ones and the checker
+    from ilupp_amd import _native
+    for cls, orc_cls, nat in ((ilupp.ILUCPPreconditioner, O.ILUCP, _native.ILUCPPreconditioner), (ilupp.ILUTPPreconditioner, O.ILUTP, _native.ILUTPPreconditioner)):
+        V = cls(A, fill_in=4, threshold=1e-2, piv_tol=1.0)
+        assert type(V.pr).__module__.endswith("_ilupp_hip")
+        Qv = orc_cls(O.orc(), M, fill_in=4, threshold=1e-2, piv_tol=1.0)
+        Nv = nat(*M, 4, 1e-2, 1.0, -1, 10.0)
+        pl, pr = V.permutations()
+        npl, npr = Nv.permutations()
+        assert (pl is None) == (npl is None) and (pr is None) == (npr is None)
+        assert np.array_equal(pl if pr is None else pr, Qv.perm)
+        assert V.total_nnz == len(Qv.L[0]) + len(Qv.U[0]) and V.pr.zero_pivots == Qv.zero_pivots
+        for (fa, fb) in zip(V.pr.factors_info(), Nv.factors_info()):
+            assert fa[3:] == fb[3:] and all(np.array_equal(x, y) for x, y in zip(fa[:3], fb[:3]))
+        assert np.array_equal(V @ b, Qv.apply(b)) and np.array_equal(V.T @ b, Qv.apply(b, O.TRANSPOSE))
+        assert repr(V).startswith("<%%dx%%d %%s with nnz=%%d" %% (n, n, cls.__name__, V.total_nnz))
     x, info = spla.gmres(A, b, M=P, atol=1e-10)
     assert info == 0
 try:
