@@ -1738,7 +1738,8 @@ int ilupp_hip_ilucp_create(const double *data, const int32_t *indices, const int
     int rc = validate(indptr, n);
     if (rc) return rc;
     const int64_t nnz = indptr[n];
-    DevMat A;
+    struct MatGuard { DevMat m; ~MatGuard() { m.release(); } } ga;           // (a failing copy must not leave the arrays behind)
+    DevMat &A = ga.m;
     A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
     ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
@@ -1746,9 +1747,7 @@ int ilupp_hip_ilucp_create(const double *data, const int32_t *indices, const int
     ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
-    rc = ilucp_create_common(A, n, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor, out);
-    A.release();
-    return rc;
+    return ilucp_create_common(A, n, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor, out);
     API_CATCH
 }
 
@@ -1873,7 +1872,8 @@ extern "C" int ilupp_hip_ilutp_create(const double *data, const int32_t *indices
     int rc = validate(indptr, n);
     if (rc) return rc;
     const int64_t nnz = indptr[n];
-    DevMat A;
+    struct MatGuard { DevMat m; ~MatGuard() { m.release(); } } ga;           // (a failing copy must not leave the arrays behind)
+    DevMat &A = ga.m;
     A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = true;
     ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
@@ -1881,8 +1881,6 @@ extern "C" int ilupp_hip_ilutp_create(const double *data, const int32_t *indices
     ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
-    rc = ilutp_create_common(A, n, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor, out);
-    A.release();
-    return rc;
+    return ilutp_create_common(A, n, is_csr, max_fill_in, threshold, piv_tol, row_pos, mem_factor, out);
     API_CATCH
 }
