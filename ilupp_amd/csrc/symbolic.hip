@@ -451,7 +451,8 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
     ILUPP_HIP(pool_malloc(&cutf, (size_t)n + 1));
     ILUPP_HIP(pool_malloc(&cutb, (size_t)n + 1));
     unsigned gb = (unsigned)((n + 255) / 256);
-    if (gb > 16384) gb = 16384;
+    static const unsigned gb_max = []() { const char *e = getenv("ILUPP_RCC_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16384u; }();
+    if (gb > gb_max) gb = gb_max;
     ILUPP_HIP(pool_malloc(&stats, sizeof(int32_t) * (8 + 8 * (size_t)gb)));
     hipLaunchKernelGGL(k_row_cuts_counts, dim3(gb), dim3(256), 0, st, n, A.ptr, A.idx, (int64_t)A.nnz, cutf, cutb,
                        static_cast<int32_t *>(nullptr), stats);
