@@ -47,7 +47,8 @@ def test_reference_vectors(name, fmt):
 
 def test_fuzz_against_the_oracle():
     from oracle import oracle as O
-    rng = np.random.default_rng(4242)
+    off = int(os.environ.get("ILUPP_FUZZ_OFFSET", "0"))             # other seeds: profiles/tools/fuzz_more.sh
+    rng = np.random.default_rng(4242 + off)
     failures = 0
     for it in range(70):
         n = int(rng.integers(2, 400))
@@ -76,7 +77,7 @@ def test_fuzz_against_the_oracle():
         assert np.array_equal(x, Q.apply(b), equal_nan=True), (it, kw)
         x = b.copy(); P.apply_trans(x)
         assert np.array_equal(x, Q.apply(b, O.TRANSPOSE), equal_nan=True), (it, kw)
-    assert failures >= 1
+    assert failures >= 1 or off
 
 
 def test_class_like_the_reference_tests():

@@ -244,7 +244,8 @@ def test_fuzz_against_oracle():
     """random small matrices of all kinds (missing diagonals, wild magnitudes, empty-ish rows, 1 x 1 ... 350 x 350) with random
     preprocessing sequences and knobs (tests/fuzz_ml.py): every level and both applies bit for bit, NaNs and infinities included"""
     import fuzz_ml
-    for seed in range(120):
+    off = int(os.environ.get("ILUPP_FUZZ_OFFSET", "0"))             # other seeds: profiles/tools/fuzz_more.sh
+    for seed in range(off, off + 120):
         A, params = fuzz_ml.case(seed)
         try:
             _against_oracle(A, params)

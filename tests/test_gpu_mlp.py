@@ -171,7 +171,7 @@ def _same(P, Q, n, what):
 def test_fuzz_against_the_oracle():
     import ilupp_amd as ilupp
     from oracle import oracle as O
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + int(os.environ.get("ILUPP_FUZZ_OFFSET", "0")))          # other seeds: profiles/tools/fuzz_more.sh
     names = {v: k for k, v in C.PRE.items()}
     for it in range(60):
         n = int(rng.integers(3, 400))
