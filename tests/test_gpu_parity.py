@@ -719,6 +719,28 @@ def test_icholt_config_c4_full_size():
     assert P.total_nnz == L.nnz == 66912256
 
 
+def test_icholt_fill_and_threshold_full_size():
+    """SURVEY section 8(d)'s other C4 variant at its full size: ICholT(add_fill_in=5, threshold=1e-3) on the 256^3 mesh (the largest capacity
+    class of the dataflow kernel, the level-ordered sweeps): factor and apply bit-identical to the reference's own C++ when it travelled
+    (oracle/_ref), else to the C restatement"""
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    ref = O.ref() if O.ref_available() else O.orc()
+    d, i, p = matgen.poisson3d(256)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    P = ilupp.ICholTPreconditioner(A, add_fill_in=5, threshold=1e-3)
+    L, = P.factors()
+    Lo = ref.icholt((d, i, p, True), 5, 1e-3)
+    assert G.mat_equal(_fac(L), Lo)
+    assert P.total_nnz == L.nnz == len(Lo[0])
+    b = np.ones(n)
+    x = b.copy(); P.apply(x)
+    assert np.array_equal(x, O.orc().apply_llt(Lo, b, O.ID))
+    x2 = b.copy(); P.apply(x2)                                      # (the second apply runs on the renumbered copy the first one built)
+    assert np.array_equal(x, x2)
+
+
 def test_fuzz_new_kernels():
     """60 random matrices x both orientations x random parameters (budgets 1..100, thresholds 0..0.3, equal magnitudes at the
     top-k cut, indefinite matrices with NaN columns) through ILUT and ICholT: everything bit-identical to the oracle"""

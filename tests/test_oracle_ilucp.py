@@ -43,7 +43,7 @@ def test_oracle_against_reference_vectors(name, fmt):
 
 @pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_oracle_against_reference_live():
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + int(os.environ.get("ILUPP_FUZZ_OFFSET", "0")))
     failures = 0
     for it in range(80):
         n = int(rng.integers(2, 250))

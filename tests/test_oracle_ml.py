@@ -71,7 +71,7 @@ def test_oracle_against_reference_vectors(gold, name, fmt):
 
 @pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_oracle_against_reference_live():
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(17 + int(os.environ.get("ILUPP_FUZZ_OFFSET", "0")))
     for n, dens, dg in ((80, 0.08, 0.1), (500, 0.01, 0.4), (900, 0.006, 1.5)):
         A = (sp.random(n, n, density=dens, random_state=rng, format="csr") + sp.eye(n) * dg).tocsr()
         for fmt in ("csr", "csc"):
@@ -92,7 +92,7 @@ def test_oracle_against_reference_live():
 def test_oracle_against_reference_fuzz():
     """random small matrices of all kinds with random parameter sets (tests/fuzz_ml.py): every level and both applies, bit for bit"""
     import fuzz_ml
-    for seed in range(150):
+    for seed in range(int(os.environ.get("ILUPP_FUZZ_OFFSET", "0")), int(os.environ.get("ILUPP_FUZZ_OFFSET", "0")) + 150):
         A, (thr, pre, knobs) = fuzz_ml.case(seed)
         a = O.from_scipy(A)
         p = C.oracle_params(O, thr, pre, knobs)

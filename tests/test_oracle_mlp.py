@@ -87,7 +87,7 @@ def test_oracle_against_the_presets_of_the_reference():
 
 @pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_oracle_against_reference_live():
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + int(os.environ.get("ILUPP_FUZZ_OFFSET", "0")))
     for it in range(40):
         n = int(rng.integers(5, 250))
         A = (sp.random(n, n, min(1.0, rng.uniform(2, 8) / n), random_state=rng, data_rvs=lambda k: rng.standard_normal(k))
