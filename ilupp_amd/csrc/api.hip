@@ -306,6 +306,7 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
     if (rc) return rc;
     const int max_wgs = p->max_lanes / kThreads;
     choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
+    finish_chains(&p->sA, &p->sU);                 // (the read-back ilu0_symbolic_and_schedule queued came with the tiling's wait)
     build_slot_tables(st, &p->sA, true);
     build_slot_tables(st, &p->sU, false);
     p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);

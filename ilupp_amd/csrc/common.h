@@ -78,6 +78,8 @@ struct Schedule {
     // 2-D tiling of the block grid (0 = identity placement): block b = (b % s2, b / s2), a workgroup owns ty x tz blocks
     int32_t tile_s2 = 0, tile_ty = 0, tile_tz = 0;
     bool chains = false;           // every block is exactly one chain of rows and the rows of every chain are alike (symbolic.hip: rows_alike)
+    bool chains_pre = false;       // ... as far as the first pass' counts say; `ragged` (k_block_starts' verdict) arrives with the NEXT
+    int32_t ragged = 1;            // stream_sync of the construction (ilu0_symbolic_and_schedule queues the read-back, finish_chains folds it in)
     void release();
 };
 
@@ -273,6 +275,7 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, int32_t *first_missing_diag,
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
+void finish_chains(Schedule *fwd, Schedule *bwd);
 int ilu0_csr_ptrs(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
 int csr_ptrs_from_counts(hipStream_t st, int32_t n, int32_t *counts, DevMat *M);
 int st_make_csr(hipStream_t st, int32_t n, const PackedSweep &pl, const PackedSweep &pu, DevMat *L, DevMat *U);

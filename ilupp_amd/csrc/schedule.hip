@@ -181,7 +181,7 @@ void choose_tiling_pair(hipStream_t st, const int32_t *ptr, const int32_t *idx, 
     std::vector<int32_t> hf, hb;
     int32_t *df = tiling_wanted(fwd) ? tiling_sample(st, ptr, idx, fwd, true, &hf) : nullptr;
     int32_t *db = tiling_wanted(bwd) ? tiling_sample(st, ptr, idx, bwd, false, &hb) : nullptr;
-    if (!df && !db) return;
+    // (always one wait: read-backs queued by the caller -- ilu0_symbolic_and_schedule's block verdict -- arrive with it)
     ILUPP_HIP(stream_sync(st));
     if (df) { ILUPP_HIP(pool_free(df)); tiling_decide(hf, fwd, max_wgs); }
     if (db) { ILUPP_HIP(pool_free(db)); tiling_decide(hb, bwd, max_wgs); }

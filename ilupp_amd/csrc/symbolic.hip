@@ -32,7 +32,8 @@ namespace {
 struct Staging { char *host = nullptr; char *dev = nullptr; size_t used = 0; struct Item { void *dst; size_t off, bytes; }; std::vector<Item> pending; };
 std::mutex g_stage_mu;
 std::unordered_map<hipStream_t, Staging> g_stage;
-constexpr size_t kStageBytes = 65536;
+constexpr size_t kStageBytes = 262144;        // (the two block samples of an ILU(0) analysis are 64 KiB each: beyond the stage a read-back is a
+                                              //  hipMemcpyAsync to pageable memory, which leaves the stream idle for 40 us)
 }
 __global__ void k_copy_words(const int *__restrict__ src, int *__restrict__ dst, int nwords)
 {
@@ -407,6 +408,9 @@ __global__ void k_reduce_stats(int nblocks, int32_t *stats)
     if (threadIdx.x == 0) { stats[0] = red[0]; stats[1] = red[1]; stats[2] = red[2]; stats[3] = red[3]; *reinterpret_cast<unsigned long long *>(stats + 4) = rl; stats[6] = red[4]; stats[7] = 0; }
 }
 
+// after the stream_sync that follows ilu0_symbolic_and_schedule
+void finish_chains(Schedule *fwd, Schedule *bwd) { fwd->chains = bwd->chains = fwd->chains_pre && fwd->ragged == 0; }
+
 // L/U patterns from the row pointers of L alone: Uptr[r] = Aptr[r] - (Lptr[r] - r)
 __global__ void k_ilu0_pattern2(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int64_t nnz,
                                 const int32_t *__restrict__ Lptr, int32_t *__restrict__ Uptr,
@@ -470,11 +474,12 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
     if (h[3] != 0x7fffffff) { ILUPP_HIP(pool_free(cutf)); ILUPP_HIP(pool_free(cutb)); ILUPP_HIP(pool_free(stats)); return ILUPP_ERR_NO_DIAGONAL; }
     make_schedule(st, n, cutf, h[0], max_lanes, fwd, stats + 7);
     make_schedule(st, n, cutb, h[1], max_lanes, bwd, stats + 7);
-    int32_t ragged = 1;
-    ILUPP_HIP(d2h_async(st, &ragged, stats + 7, sizeof(ragged)));
-    ILUPP_HIP(stream_sync(st));
-    // every lane one whole chain, all chains alike (st_direct.hip's premise, in its light form)
-    fwd->chains = bwd->chains = h[6] == 0 && ragged == 0 && h[0] == fwd->nb && h[1] == bwd->nb;
+    // every lane one whole chain, all chains alike (st_direct.hip's premise, in its light form).  The blocks' verdict is not waited for
+    // here (a host round trip is 10-20 us of idle stream): it arrives with the caller's next stream_sync, finish_chains() folds it in
+    fwd->chains = bwd->chains = false;
+    fwd->chains_pre = bwd->chains_pre = h[6] == 0 && h[0] == fwd->nb && h[1] == bwd->nb;
+    fwd->ragged = 1;
+    ILUPP_HIP(d2h_async(st, &fwd->ragged, stats + 7, sizeof(fwd->ragged)));
     ILUPP_HIP(pool_free(cutf));
     ILUPP_HIP(pool_free(cutb));
     ILUPP_HIP(pool_free(stats));
