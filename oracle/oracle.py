@@ -305,7 +305,7 @@ def orc():
     """The plain-C restatement (always available; built on demand)."""
     global _orc
     if _orc is None:
-        path = os.path.join(_HERE, "liborc.so")
+        path = os.environ.get("ILUPP_ORACLE_LIBRARY") or os.path.join(_HERE, "liborc.so")       # (make -C oracle asan: the sanitizer build)
         if not os.path.exists(path):
             build()
         _orc = _Lib(path, "orc_")
