@@ -362,9 +362,13 @@ void ensure_csr_values(ilupp_precond *p)
 {
     if (p->csr_vals) return;
     if (p->pkL.stat) {
+        // (the passes below read records by template position: st_wave.hip's class-aligned ones are turned back for them)
+        const int fmt = p->pkL.fmt;
+        wx_convert_records(p->stream, &p->pkL, &p->pkU, 0);
         if (!p->Lc.ptr) (void)st_make_csr(p->stream, p->n, p->pkL, p->pkU, &p->Lc, &p->Uc);      // (throws on a HIP error)
         st_unpack(p->stream, p->Lc, p->sA, p->pkL);
         st_unpack(p->stream, p->Uc, p->sU, p->pkU);
+        wx_convert_records(p->stream, &p->pkL, &p->pkU, fmt);
     } else {
         lm_unpack(p->stream, p->Lc, p->sA, p->pkL);
         lm_unpack(p->stream, p->Uc, p->sU, p->pkU);
@@ -482,7 +486,12 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
 static bool static_transposed_ready(ilupp_precond *p)
 {
     if (!(p->flm.stat && p->pkL.stat && p->pkU.stat) || p->no_static_T) return false;
-    if (st_build_transposed(p->stream, p->sA, p->n, p->flm, &p->pkL, &p->pkU, p->Lc.nnz - p->n, p->Uc.nnz - p->n)) return true;
+    if (p->pkL.pkT && p->pkU.pkT) return true;
+    const int fmt = p->pkL.fmt;
+    wx_convert_records(p->stream, &p->pkL, &p->pkU, 0);
+    const bool ok = st_build_transposed(p->stream, p->sA, p->n, p->flm, &p->pkL, &p->pkU, p->Lc.nnz - p->n, p->Uc.nnz - p->n);
+    wx_convert_records(p->stream, &p->pkL, &p->pkU, fmt);
+    if (ok) return true;
     p->no_static_T = true;
     return false;
 }

@@ -117,6 +117,8 @@ struct PackedSweep {
     // static form (st.hip): every lane's dependency structure is the same for all of its rows and sits in a lane
     // table; the records then hold values only (2 KB per chunk, absent entries = kAbsent)
     bool stat = false;
+    bool wx = false;            // every lane of the schedule fits the wave-exchange kernels (st_wave.hip; st_common.h: wx_lane_ok)
+    int fmt = 0;                // static records: 0 = by template position, kAbsent where there is no entry; 1 = class-aligned, +0.0 (st_wave.hip)
     int32_t *ltab = nullptr;    // nslots x kStTab ints
     double *dump = nullptr;     // where the stores of lanes without a row go
     double *xlm = nullptr;      // (forward sweep) the right-hand side in this sweep's level-major order, 64 per chunk
@@ -454,6 +456,12 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
 bool st_build_transposed(hipStream_t st, const Schedule &fwd, int32_t n, const FactorLM &f, PackedSweep *pl, PackedSweep *pu,
                          int64_t offdiagL, int64_t offdiagU);
 void st_drop_transposed(PackedSweep *pl, PackedSweep *pu);
+void st_vec_to_lm(hipStream_t st, const PackedSweep &ps, const double *nat, double *lm);
+void st_vec_from_lm(hipStream_t st, const PackedSweep &ps, double *nat);
+// st_wave.hip
+void wx_convert_records(hipStream_t st, PackedSweep *pl, PackedSweep *pu, int to_fmt);
+int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rhs, double *out, int32_t *d_ticket, int32_t *d_err,
+              double *ypk_out, const double *ypk_in, const int32_t *ysrc);
 int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rhs, double *out, int32_t *d_ticket, int32_t *d_err,
                 double *lml, const int32_t *ysrc);
 

@@ -59,7 +59,7 @@ void PackedSweep::release()
     if (pkT) (void)pool_free(pkT);
     pkT = nullptr; pair = false; desc = false;
     dump = nullptr; xlm = nullptr; y_chunks = 0; xe = xw = nullptr; xch = nullptr; xch_len = 0;
-    ysrc = nullptr; ybuf = nullptr; ltab = nullptr; stat = false;
+    ysrc = nullptr; ybuf = nullptr; ltab = nullptr; stat = false; wx = false; fmt = 0;
     skew = wtab = flags = uslot = nullptr; pk = nullptr; nchunks = 0; valid = false; built = false; linked = false;
 }
 

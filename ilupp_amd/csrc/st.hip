@@ -40,6 +40,13 @@
 
 namespace ilupp {
 
+// the wave-exchange kernels and the skews they need (st_common.h); ILUPP_NO_WR=1: the schedules and kernels of round 3
+static bool st_wx_on()
+{
+    static const bool on = getenv("ILUPP_NO_WR") == nullptr;
+    return on;
+}
+
 __global__ void k_lm_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, const int32_t *__restrict__ scount,
                           const int32_t *__restrict__ wtabL, const int32_t *__restrict__ skewL, int32_t *__restrict__ ysrc);   // sptrsv_lm.hip
 
@@ -151,7 +158,7 @@ k_st_template_pair(const int32_t *__restrict__ ptr, const int32_t *__restrict__ 
 template <bool FWD>
 __device__ __forceinline__ void
 st_link_body(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const int32_t *__restrict__ uslot,
-             int32_t *__restrict__ skew, int32_t *__restrict__ wtab, int32_t *__restrict__ flags, int *s)
+             int32_t *__restrict__ skew, int32_t *__restrict__ wtab, int32_t *__restrict__ flags, int *s, const bool wx, const bool bwd_sched)
 {
     const int wg = blockIdx.x, t = threadIdx.x;
     const int slot = wg * kThreads + t;
@@ -164,7 +171,8 @@ st_link_body(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, con
         const int sw = T[ST_SRC + j];
         loc[j] = j < nd && (sw & 3) == ST_LOCAL;
         cb[j] = loc[j] ? ((sw >> 2) & 255) : t;
-        cd[j] = T[ST_KAP + j] + 1;
+        // (wx: a value that does not stay in the registers of the consumer's wave is at least kWrLag steps old -- st_common.h)
+        cd[j] = T[ST_KAP + j] + wr_edge_lag(t, cb[j], wx);
     }
     s[t] = 0;
     __syncthreads();
@@ -191,6 +199,12 @@ st_link_body(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, con
             if (dt < 1 || dt > kStH - 1) bad = 1;
         }
         T[ST_DT + j] = dt;
+    }
+    // may the wave-exchange kernels run this lane?  (flags[9]: no)
+    if (wx) {
+        if (!wx_lane_ok(T, t, bwd_sched)) atomicOr(&flags[9], 1);
+    } else if (t == 0) {
+        atomicOr(&flags[9], 2);
     }
     int lo = cnt > 0 ? sk : 0x7fffffff, hi = cnt > 0 ? sk + cnt : -0x7fffffff;
     for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
@@ -242,20 +256,20 @@ st_link_body(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, con
 template <bool FWD>
 __global__ void __launch_bounds__(kThreads)
 k_st_link(int32_t *__restrict__ ltab, const int32_t *__restrict__ ltab_u, const int32_t *__restrict__ uslot,
-          int32_t *__restrict__ skew, int32_t *__restrict__ wtab, int32_t *__restrict__ flags)
+          int32_t *__restrict__ skew, int32_t *__restrict__ wtab, int32_t *__restrict__ flags, int32_t wx)
 {
     __shared__ int s[kThreads];
-    st_link_body<FWD>(ltab, ltab_u, uslot, skew, wtab, flags, s);
+    st_link_body<FWD>(ltab, ltab_u, uslot, skew, wtab, flags, s, (wx & 1) != 0, (wx & 2) != 0);
 }
 // both schedules of an ILU(0) with one launch (blockIdx.y: 0 forward with the proof about the eliminations, 1 backward)
 __global__ void __launch_bounds__(kThreads)
 k_st_link_pair(int32_t *__restrict__ ltabF, int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot, int32_t *__restrict__ skewF,
                int32_t *__restrict__ skewB, int32_t *__restrict__ wtabF, int32_t *__restrict__ wtabB, int32_t *__restrict__ flagsF,
-               int32_t *__restrict__ flagsB)
+               int32_t *__restrict__ flagsB, int32_t wx)
 {
     __shared__ int s[kThreads];
-    if (blockIdx.y == 0) st_link_body<true>(ltabF, ltabB, uslot, skewF, wtabF, flagsF, s);
-    else st_link_body<false>(ltabB, nullptr, nullptr, skewB, wtabB, flagsB, s);
+    if (blockIdx.y == 0) st_link_body<true>(ltabF, ltabB, uslot, skewF, wtabF, flagsF, s, wx != 0, false);
+    else st_link_body<false>(ltabB, nullptr, nullptr, skewB, wtabB, flagsB, s, wx != 0, true);
 }
 
 // exclusive scan of the waves' chunk counts (one block); flags[1] = total, flags[2] = longest wave
@@ -592,19 +606,6 @@ __device__ unsigned long long g_st_tl[4096 * 4];     // per workgroup of the for
 // reads and overwrites it in place, and k_st_vec takes the result back to natural order.  Natural-order stores are left
 // for the lanes other workgroups read (write-through, the data is the flag).
 // ---------------------------------------------------------------------------------------------
-struct StSArgs {
-    const v2d *pk;                            // 2 x 64 x 16 B per chunk: {v0,v1}{v2,vdiag}, dependencies in accumulation order
-    const int32_t *ltab, *wtab;
-    int32_t n, nchY;                          // nchY: first spare chunk (one per wave) of ylm
-    double *xlm;                              // level-major in the FORWARD sweep's order: the right-hand side, overwritten with the intermediate vector
-    double *ylm;                              // level-major in the backward sweep's order: the result
-    const int32_t *ysrc;                      // backward: where in xlm the lane's row 0 is (row k: - 64 k)
-    int32_t xlm_chunks;                       // chunks of xlm (and of the backward sweep's records)
-    const int32_t *xe, *xw;                   // the exchange between workgroups (PackedSweep::xe, xw, xch): all-sentinel before the sweep
-    double *xch;
-    int32_t *ticket, *err;
-};
-
 // Who does what in a workgroup of a sweep: waves 0-3 are the 256 lanes of the schedule, wave 4 is the COURIER.  Unknowns of
 // earlier workgroups ("ghosts") used to be polled, tested and selected by the lanes that need them; that code was 150 of the 200
 // instructions of a step in a wave that has such lanes (a wave64 instruction is 4 cycles: 0.2 us per step, and with the barrier
@@ -612,22 +613,6 @@ struct StSArgs {
 // the poll distance or the kind of load.  Now the courier polls (kStPF / kStPS steps ahead, one (lane, dependency) pair per courier lane,
 // at most 64 per workgroup -- the analysis checks), waits for values not there yet, and puts them into the hand-off array as the
 // values of 64 more lanes "of this step"; to the lanes of the schedule a ghost is just another LDS read at a constant address.
-#ifndef ST_CSLEEP
-#define ST_CSLEEP 1
-#endif
-#ifndef ST_SOLO
-#define ST_SOLO (48 * 1024)
-#endif
-static constexpr int kStSoloLds = ST_SOLO;      // dynamic LDS nobody uses: > 80 KB per workgroup in total
-#ifndef ST_RA
-#define ST_RA 16
-#endif
-static constexpr int kStRA = ST_RA;            // steps the streams of a sweep are read ahead (a multiple of kStH)
-static constexpr int kStRow = kThreads + 64;     // doubles per slot of the hand-off array: the lanes, then the courier's pairs
-static constexpr int kStWgThreads = kThreads + 64;
-
-struct StPair { int idx0, stride, sk, klo, khi; };   // the value of step s is xch[idx0 + s * stride]; the lane's skew; the k = s - sk that have it
-
 // EX: some lane's unknowns are read by later workgroups (a template parameter, not a branch: hipcc's waitcnt pass only counts the
 // memory operations it is sure were issued, so a store inside a branch makes every later wait of a wave that does execute it
 // stricter than meant by one)
@@ -802,64 +787,6 @@ __device__ __forceinline__ void st_courier(const unsigned long long *src, const 
     }
 #undef STC_ADDR
     if (dead && ln == 0) atomicExch(err, 1);
-}
-
-// where a lane's dependencies come from: the LDS read address of each (the value of `dt` steps ago of lane `u`, in the copy 8
-// slots up: slot index = step % 8 + 8 - dt stays inside [1, 15] with the step's immediate), and for those of earlier workgroups
-// where in the exchange the producer lane's value of step s = 0 would be and how far apart steps are
-__device__ __forceinline__ void st_lane_sources(const int32_t *T, const int t, const int32_t *ltab, const int32_t *xe, const int32_t *xw,
-                                                bool isg[3], int idx0[3], int stride[3], unsigned va[3])
-{
-    const int nd = T[ST_ND], cnt = T[ST_CNT];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int sw = T[ST_SRC + j];
-        const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
-        const int u = ty == ST_LOCAL ? ((sw >> 2) & 255) : t;
-        const int dt = ty == ST_LOCAL ? T[ST_DT + j] : 1;          // (own previous row: lane t, one step back)
-        va[j] = (unsigned)(((kStH - dt) * kStRow + u) * 8);
-        isg[j] = ty == ST_GHOST;
-        idx0[j] = 0; stride[j] = 0;
-        if (isg[j]) {
-            // the producer lane's value of ITS step s' = k' + skew' with k' = k + T[ST_KAP + j], k = s - skew
-            const int os = sw >> 2, pw = os >> 8;
-            const int E = xw[pw * 4];
-            stride[j] = E;
-            idx0[j] = xw[pw * 4 + 3] + (T[ST_KAP + j] + ltab[(size_t)os * kStTab + ST_SKEW] - T[ST_SKEW] - xw[pw * 4 + 1]) * E + xe[os];
-        }
-    }
-}
-
-// The pairs of a workgroup, numbered: lane t's ghost dependency j gets the next free index p, its descriptor goes to pairs[p],
-// and the lane reads it like any hand-off value: slot "this step", lane 256 + p.  Returns the dependency's LDS read address.
-// (called by the 256 lanes of the schedule; s_cnt[4]: scratch; *s_total: the number of pairs)
-__device__ __forceinline__ void st_number_pairs(const int32_t *T, const int t, const bool isg[3], const int idx0[3], const int stride[3],
-                                                unsigned va[3], StPair *pairs, int *s_cnt, int *s_total)
-{
-    const int wv = t >> 6;
-    unsigned long long bal[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) bal[j] = __builtin_amdgcn_ballot_w64(isg[j]);
-    const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]);
-    if ((t & 63) == 0) s_cnt[wv] = mine;
-    __syncthreads();
-    int before = 0;
-    for (int q = 0; q < wv; ++q) before += s_cnt[q];
-    if (t == 0) *s_total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (isg[j]) {
-            const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
-            if (p < 64) {
-                StPair d;
-                d.idx0 = idx0[j]; d.stride = stride[j]; d.sk = T[ST_SKEW];
-                d.klo = max(T[ST_KLO + j], 0); d.khi = max(min(T[ST_KHI + j], T[ST_CNT]), d.klo);
-                pairs[p] = d;
-            }
-            va[j] = (unsigned)((kStH * kStRow + kThreads + min(p, 63)) * 8);
-        }
-        before += __popcll(bal[j]);
-    }
 }
 
 template <int DR, bool TR>
@@ -1445,6 +1372,7 @@ k_st_xch_layout(const int32_t *__restrict__ exported, const int32_t *__restrict_
         xw[wg * 4 + 0] = E; xw[wg * 4 + 1] = tlo; xw[wg * 4 + 2] = thi - tlo; xw[wg * 4 + 3] = 0;
         xsz[wg] = E * (thi - tlo);
         if (s_pairs > 64) atomicOr(&flags[0], 32);
+        if (total > 64) atomicOr(&flags[9], 4);          // (st_wave.hip's courier exports with one store instruction per step)
     }
 }
 __global__ void k_st_xch_rows(int32_t nwg, const int32_t *__restrict__ xoff, int32_t *__restrict__ xw)
@@ -1498,7 +1426,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     pu->built = true;
     lm_link_factor(st, fwd, bwd, pu);                   // forward slot -> backward slot of the same chain (flags[3] when there is none)
     hipLaunchKernelGGL(k_st_link_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew, pu->skew,
-                       pl->wtab, pu->wtab, pl->flags, pu->flags);
+                       pl->wtab, pu->wtab, pl->flags, pu->flags, st_wx_on() ? 1 : 0);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pu->wtab, pu->flags);
     int32_t *inv = nullptr;
@@ -1520,7 +1448,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     int32_t xtot[2][2];
     int32_t *xsz = nullptr;
     void *tmp2 = nullptr;
-    int32_t hl[12], hu[4];
+    int32_t hl[12], hu[12];
     {
         ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 4));
         PackedSweep *pp[2] = {pl, pu};
@@ -1588,6 +1516,8 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     }
     pl->valid = pu->valid = true;
     pl->stat = pu->stat = true;
+    pl->wx = hl[9] == 0; pu->wx = hu[9] == 0;
+    if (dbg) fprintf(stderr, "[ilupp] static analysis: wave-exchange kernels: forward %s, backward %s\n", pl->wx ? "yes" : "no", pu->wx ? "yes" : "no");
     pu->linked = true;
     f->built = true;
     f->stat = true;
@@ -1599,7 +1529,14 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
                     int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1)
 {
     (void)fwd;
-    if (f->direct) return ilu0_numeric_sd(st, A, pl, pu, d_ctrl, kernel_ms, e0, e1);
+    pl->fmt = pu->fmt = 0;                               // (the factor kernels below write records by template position)
+    if (f->direct) {
+        const int rc = ilu0_numeric_sd(st, A, pl, pu, d_ctrl, kernel_ms, e0, e1);
+        // the sweeps of st_wave.hip read class-aligned records
+        if (rc == ILUPP_OK && pl->wx && pu->wx && st_wx_on() && (uint64_t)(pl->nchunks + 4 * (int64_t)pl->nwg) * 2048u < 0xfff00000ull)
+            wx_convert_records(st, pl, pu, 1);
+        return rc;
+    }
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
     fill_u64(st, reinterpret_cast<unsigned long long *>(pl->xch), pl->xch_len, kSentinel);
     const bool repack = !f->values_packed;
@@ -1642,12 +1579,24 @@ static void st_solo_attr_T()
 
 static inline int st_vec_groups(int max_chunks) { const int g = (max_chunks + 31) / 32; return g < 3 ? (g < 1 ? 1 : g) : 3; }
 
+void st_vec_to_lm(hipStream_t st, const PackedSweep &ps, const double *nat, double *lm)
+{
+    hipLaunchKernelGGL((k_st_vec<1, true>), dim3((unsigned)(ps.nwg * 4), (unsigned)st_vec_groups(ps.max_chunks)), dim3(512), 0, st, ps.ltab, ps.wtab,
+                       const_cast<double *>(nat), lm);
+}
+void st_vec_from_lm(hipStream_t st, const PackedSweep &ps, double *nat)
+{
+    hipLaunchKernelGGL((k_st_vec<-1, false>), dim3((unsigned)(ps.nwg * 4), (unsigned)st_vec_groups(ps.max_chunks)), dim3(512), 0, st, ps.ltab, ps.wtab,
+                       nat, ps.xlm);
+}
+
 // One sweep of an apply.  Forward: `rhs` (natural order) -> the intermediate vector in `ypk_out` (the forward sweep's ybuf, in the
 // forward sweep's level-major order); backward: `ypk_in` (the same buffer) -> the result in `out` (natural order).
 int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,
               int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
     (void)sch;
+    if (ps.fmt == 1) return sptrsv_wx(st, ps, n, rhs, out, d_ticket, d_err, ypk_out, ypk_in, ysrc);
     const bool fwd = ps.kind == (int)SWEEP_FWD_LAST_ASC;
     double *lml = fwd ? ypk_out : const_cast<double *>(ypk_in);        // level-major, forward order
     if (!lml || (!fwd && (!ysrc || !ps.xlm))) { set_error("static sweep without its level-major vector"); return ILUPP_ERR_INVALID; }
@@ -1766,9 +1715,9 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
     pu->built = true;
     lm_link_factor(st, fwd, bwd, pu);
     hipLaunchKernelGGL((k_st_link<false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, pl->ltab, static_cast<const int32_t *>(nullptr),
-                       static_cast<const int32_t *>(nullptr), pl->skew, pl->wtab, pl->flags);
+                       static_cast<const int32_t *>(nullptr), pl->skew, pl->wtab, pl->flags, st_wx_on() ? 1 : 0);
     hipLaunchKernelGGL((k_st_link<false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, pu->ltab, static_cast<const int32_t *>(nullptr),
-                       static_cast<const int32_t *>(nullptr), pu->skew, pu->wtab, pu->flags);
+                       static_cast<const int32_t *>(nullptr), pu->skew, pu->wtab, pu->flags, st_wx_on() ? 3 : 0);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pu->wtab, pu->flags);
     int32_t xtot[2][2];
@@ -1793,7 +1742,7 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
             ILUPP_HIP(d2h_async(st, &xtot[d][1], sz + (nwg - 1), sizeof(int32_t)));
         }
     }
-    int32_t hl[4], hu[4];
+    int32_t hl[12], hu[12];
     ILUPP_HIP(d2h_async(st, hl, pl->flags, sizeof(hl)));
     ILUPP_HIP(d2h_async(st, hu, pu->flags, sizeof(hu)));
     ILUPP_HIP(stream_sync(st));
@@ -1831,6 +1780,7 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
     if (gl[0]) { pl->release(); pu->release(); return false; }
     pl->valid = pu->valid = true;
     pl->stat = pu->stat = true;
+    pl->wx = hl[9] == 0; pu->wx = hu[9] == 0;
     pl->pair = pu->pair = true;
     pu->desc = bwd_desc;
     pu->linked = true;
@@ -1855,7 +1805,7 @@ bool ichol0_numeric_st(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t *
     hipLaunchKernelGGL((k_st_template<1>), dim3((unsigned)nwg), dim3(kThreads), 0, st, L->ptr, L->idx, fwd.B, fwd.nb, fwd.start,
                        fwd.blk2slot, fwd.sfirst, fwd.scount, fwd.exported, ps.ltab, ps.flags);
     hipLaunchKernelGGL((k_st_link<false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, ps.ltab, static_cast<const int32_t *>(nullptr),
-                       static_cast<const int32_t *>(nullptr), ps.skew, ps.wtab, ps.flags);
+                       static_cast<const int32_t *>(nullptr), ps.skew, ps.wtab, ps.flags, 0);
     hipLaunchKernelGGL(k_st_chol_check, dim3((unsigned)nwg), dim3(kThreads), 0, st, ps.ltab, ps.flags);
     hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, ps.wtab, ps.flags);
     int32_t *xsz = nullptr;
