@@ -14,6 +14,7 @@
 #include "pool.h"
 
 namespace ilupp {
+std::mutex g_build_mu;
 
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
@@ -640,6 +641,10 @@ int ilu0_create_common(const DevMat &A, int is_csr, ilupp_precond **out)
 }  // namespace
 
 #define API_TRY try {
+// every construction / re-factorisation of the process, one after the other: the memory pool knows nothing of streams -- a block that
+// one construction gives back may still be in use on ITS stream when another thread's construction is handed it.  (Every
+// construction synchronises its stream before it returns, so the lock costs a concurrent caller what the construction costs.)
+#define API_TRY_BUILD try { std::lock_guard<std::mutex> build_lock_(ilupp::g_build_mu);
 #define API_CATCH                                                          \
     } catch (const ilupp::HipError &e) { ilupp::d2h_cancel_all(); return ilupp::report(e); }        \
     catch (const std::bad_alloc &) { ilupp::d2h_cancel_all(); ilupp::set_error("out of host memory"); return ILUPP_ERR_MEMORY; }
@@ -668,7 +673,7 @@ int ilupp_hip_device_count(void)
 int ilupp_hip_ilu0_create(const double *data, const int32_t *indices, const int32_t *indptr,
                           int32_t n, int is_csr, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);
@@ -691,7 +696,7 @@ int ilupp_hip_ilu0_create(const double *data, const int32_t *indices, const int3
 int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
                                  int32_t n, int is_csr, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
@@ -705,7 +710,7 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
 
 int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices, const int32_t *d_indptr)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!p || p->kind != KIND_LU || p->nnz_mode != NNZ_GENERIC_LU || p->sA.nb <= 0) { set_error("not an ILU(0) object"); return ILUPP_ERR_INVALID; }
     order_after_caller(p->stream, p->sev[0]);
     {
@@ -855,7 +860,7 @@ extern "C" {
 int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int32_t *indptr,
         int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);
@@ -879,7 +884,7 @@ int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int3
 int ilupp_hip_ilut_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
         int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
@@ -895,7 +900,7 @@ int ilupp_hip_ilut_create_device(const double *d_data, const int32_t *d_indices,
 int ilupp_hip_iluc_create(const double *data, const int32_t *indices, const int32_t *indptr,
         int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);
@@ -918,7 +923,7 @@ int ilupp_hip_iluc_create(const double *data, const int32_t *indices, const int3
 int ilupp_hip_iluc_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
         int32_t n, int is_csr, int32_t max_fill_in, double threshold, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
@@ -983,7 +988,7 @@ extern "C" {
 int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const int32_t *indptr,
         int32_t n, int is_csr, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     (void)is_csr;     // IChol0 keeps idx <= major in either orientation and labels the result ROW (IChol.hpp:63-68)
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
@@ -1007,7 +1012,7 @@ int ilupp_hip_ichol0_create(const double *data, const int32_t *indices, const in
 int ilupp_hip_ichol0_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
         int32_t n, int is_csr, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
@@ -1076,7 +1081,7 @@ extern "C" {
 int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const int32_t *indptr,
         int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     (void)is_csr;     // ICholT keeps idx >= major in either orientation and labels the result COLUMN (IChol.hpp:158-164)
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
@@ -1100,7 +1105,7 @@ int ilupp_hip_icholt_create(const double *data, const int32_t *indices, const in
 int ilupp_hip_icholt_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
         int32_t n, int is_csr, int32_t add_fill_in, double threshold, ilupp_precond **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
@@ -1319,9 +1324,10 @@ int utu_half(ilupp_precond *p, bool forward, bool tr, double *rhs, double *out, 
     ensure_transposed(p);
     int32_t *err = p->ctrl;
     // small levels (the later, denser ones): one workgroup with the unknowns in LDS instead of a chain of hops through memory
-    if (p->n <= kSmallSweepMax && !getenv_small_off()) {
+    // (not for a factor with an empty row: p->degenerate objects keep the row-by-row kernel, which reports what it meets)
+    if (p->n <= kSmallSweepMax && !p->degenerate && !getenv_small_off()) {
         const DevMat &M = forward ? (tr ? p->UcT : p->LcT) : (tr ? p->Lc : p->Uc);
-        return sptrsv_small(p->stream, forward ? SWEEP_FWD_LAST_ASC : SWEEP_BWD_FIRST_ASC, M, rhs, out);
+        return sptrsv_small(p->stream, forward ? SWEEP_FWD_LAST_ASC : SWEEP_BWD_FIRST_ASC, M, rhs, out, err);
     }
     if (forward) {
         const DevMat &Mf = tr ? p->UcT : p->LcT;
@@ -1494,7 +1500,7 @@ void ilupp_hip_ml_default_params(ilupp_ml_params *p)
 int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const ilupp_ml_params *params,
                         ilupp_ml **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out || !params) { set_error("null argument"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);
@@ -1516,7 +1522,7 @@ int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_
 int ilupp_hip_ml_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr, int32_t n, int is_csr,
                                const ilupp_ml_params *params, ilupp_ml **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out || !params) { set_error("null argument"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
@@ -1742,7 +1748,7 @@ extern "C" {
 int ilupp_hip_ilucp_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, int32_t max_fill_in,
                            double threshold, double piv_tol, int32_t row_pos, double mem_factor, ilupp_ilucp **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);
@@ -1876,7 +1882,7 @@ int ilutp_create_common(DevMat &A, int32_t n, int is_csr, int32_t max_fill_in, d
 extern "C" int ilupp_hip_ilutp_create(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, int32_t max_fill_in,
                                       double threshold, double piv_tol, int32_t row_pos, double mem_factor, ilupp_ilucp **out)
 {
-    API_TRY
+    API_TRY_BUILD
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(indptr, n);

@@ -161,6 +161,7 @@ struct FactorLM {
     long long *xcount = nullptr;    // device: doubles of xch in use
     bool stat = false;              // static form (st.hip): pkA holds 4 KB chunks {a0..a6, mask}
     bool direct = false;            // static form fed from A's CSR values (st_direct.hip): no pkA at all
+    bool wxf = false;               // ... by the wave-exchange factor kernel (st_wave.hip: k_ilu0_wx), which writes format-1 records
     void release();
 };
 
@@ -410,7 +411,7 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 // sptrsv_small.hip: one workgroup, the unknowns in LDS (the small, dense levels of a multilevel preconditioner); rhs is left as it is
 static constexpr int32_t kSmallSweepMax = 1024;      // measured: 20 against 27 ms per apply for a 7-level object of n = 700; no gain from n = 3 000 on, a loss at n = 6 000
-int sptrsv_small(hipStream_t st, SweepKind kind, const DevMat &M, const double *rhs, double *out);
+int sptrsv_small(hipStream_t st, SweepKind kind, const DevMat &M, const double *rhs, double *out, int32_t *err);
 
 // sptrsv_lvl.hip
 bool lvl_order(hipStream_t st, int mode, int32_t n, int64_t nnz, const int32_t *ptr, const int32_t *idx, const Schedule &sch,

@@ -356,7 +356,7 @@ int ilucp_factor(hipStream_t st, const DevMat &C, int32_t max_fill_in, double th
     if (max_fill_in > n) max_fill_in = n;
     int64_t reserved;
     {
-        const int64_t a = (int64_t)max_fill_in * (int64_t)n, b = (int64_t)(mem_factor * (double)nnz);
+        const int64_t a = (int64_t)max_fill_in * (int64_t)n, b = (int64_t)((int32_t)mem_factor) * nnz;      // (Integer) mem_factor * Acol.non_zeroes(), ILUC.hpp:229: the factor is truncated FIRST
         reserved = a < b ? a : b;
         if (reserved < 0) reserved = 0;
         if (reserved > 0x7ffffff0ll) { set_error("ILUCP: the memory to reserve exceeds 2^31 entries"); return ILUPP_ERR_UNSUPPORTED; }

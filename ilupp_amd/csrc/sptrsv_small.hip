@@ -18,7 +18,7 @@ static constexpr int kSmallThreads = 256;      // one wave per SIMD: the chain o
 template <bool FWD>
 __global__ void __launch_bounds__(kSmallThreads)
 k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const double *__restrict__ val,
-               const double *__restrict__ rhs, double *__restrict__ out)
+               const double *__restrict__ rhs, double *__restrict__ out, int32_t *__restrict__ err)
 {
     extern __shared__ unsigned long long xs[];      // the unknowns, sentinel = not yet
     const int tid = threadIdx.x;
@@ -38,8 +38,15 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
         for (int q = 0; q < 4; ++q) if (q < have1) { c1[q] = idx[jf + q]; v1[q] = val[jf + q]; }
         jf += have1;
     };
+    // every trip of the loop below some lane consumes an entry or finishes a row unless an unknown never leaves the sentinel (an index
+    // outside the triangle, a right-hand side that carries the sentinel's bits): a bounded number of trips, then ILUPP_ERR_TIMEOUT as
+    // everywhere else in this library
+    const long long max_trips = 4ll * ((long long)ptr[n] + n) + 4096;
+    long long trips = 0;
+    bool broken = false;
     auto open_row = [&]() {
         const int b = ptr[r], e = ptr[r + 1];
+        if (e <= b) { broken = true; return; }      // (a row without its diagonal: nothing to divide by)
         if (FWD) { j = b; jend = e - 1; diag = val[e - 1]; }
         else { j = b + 1; jend = e; diag = val[b]; }
         acc = rhs[r];
@@ -53,6 +60,7 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
     };
     if (alive) open_row();
     while (__ballot(alive) != 0ull) {
+        if (__ballot(broken) != 0ull || ++trips > max_trips) { if (tid == 0 && err) atomicExch(err, 1); break; }
         if (alive) {
             if (j < jend) {
                 if (at == have0) {                  // the group is used up: the other one takes its place, the one after it is asked for
@@ -82,7 +90,7 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
 }
 
 // out = T^-1 rhs for a small triangular factor in the storage a gather sweep wants; rhs is left as it is
-int sptrsv_small(hipStream_t st, SweepKind kind, const DevMat &M, const double *rhs, double *out)
+int sptrsv_small(hipStream_t st, SweepKind kind, const DevMat &M, const double *rhs, double *out, int32_t *err)
 {
     const size_t lds = sizeof(unsigned long long) * (size_t)M.n;
     if (kind == SWEEP_FWD_LAST_ASC) {
@@ -94,7 +102,7 @@ int sptrsv_small(hipStream_t st, SweepKind kind, const DevMat &M, const double *
             ILUPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sptrsv_small<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSweepMax * 8));
             attr_dev = dev;
         }
-        hipLaunchKernelGGL(k_sptrsv_small<true>, dim3(1), dim3(kSmallThreads), lds, st, M.n, M.ptr, M.idx, M.val, rhs, out);
+        hipLaunchKernelGGL(k_sptrsv_small<true>, dim3(1), dim3(kSmallThreads), lds, st, M.n, M.ptr, M.idx, M.val, rhs, out, err);
     } else if (kind == SWEEP_BWD_FIRST_ASC) {
         static thread_local int attr_dev2 = -1;
         int dev = 0;
@@ -104,7 +112,7 @@ int sptrsv_small(hipStream_t st, SweepKind kind, const DevMat &M, const double *
             ILUPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sptrsv_small<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSweepMax * 8));
             attr_dev2 = dev;
         }
-        hipLaunchKernelGGL(k_sptrsv_small<false>, dim3(1), dim3(kSmallThreads), lds, st, M.n, M.ptr, M.idx, M.val, rhs, out);
+        hipLaunchKernelGGL(k_sptrsv_small<false>, dim3(1), dim3(kSmallThreads), lds, st, M.n, M.ptr, M.idx, M.val, rhs, out, err);
     } else {
         return ILUPP_ERR_UNSUPPORTED;
     }

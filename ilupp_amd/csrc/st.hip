@@ -313,7 +313,11 @@ __global__ void k_st_scat(int32_t nslots, int32_t *__restrict__ ltabF, const int
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nslots) return;
     // (the direct-feed factor kernel's lane fields and lane-level checks: st_direct.hip)
-    if (dflags) sd_tab_lane(f, ltabF, ltabB, uslot, Aptr, dflags);
+    if (dflags) {
+        sd_tab_lane(f, ltabF, ltabB, uslot, Aptr, dflags);
+        // (dflags + 2 = flags[10]: a lane the wave-exchange factor kernel cannot run)
+        if (!wf_lane_ok(ltabF + (size_t)f * kStTab, ltabB, uslot)) atomicOr(dflags + 2, 1);
+    }
     int32_t *T = ltabF + (size_t)f * kStTab;
     int32_t *R = rtab + (size_t)f * 32;
     const int cnt = T[ST_CNT];
@@ -1501,6 +1505,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&pl->xch, sizeof(double) * (size_t)pl->xch_len));
     ILUPP_HIP(pool_malloc(&pu->xch, sizeof(double) * (size_t)pu->xch_len));
     f->direct = try_direct && hl[8] == 0;
+    f->wxf = f->direct && hl[9] == 0 && hu[9] == 0 && hl[10] == 0 && st_wx_on() && getenv("ILUPP_NO_WXF") == nullptr;
     if (!f->direct) {
         // lanes not uniform enough for the direct feed: factor records made by the rows pass (it proves what they rely on, row by row)
         if (dbg && try_direct) fprintf(stderr, "[ilupp] static analysis: lanes not uniform (flags %d): factor records\n", hl[8]);
@@ -1530,6 +1535,8 @@ int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, Packed
 {
     (void)fwd;
     pl->fmt = pu->fmt = 0;                               // (the factor kernels below write records by template position)
+    if (f->direct && f->wxf && (uint64_t)(pl->nchunks + 4 * (int64_t)pl->nwg) * 2048u < 0xfff00000ull)
+        return ilu0_numeric_wx(st, A, pl, pu, d_ctrl, kernel_ms, e0, e1);
     if (f->direct) {
         const int rc = ilu0_numeric_sd(st, A, pl, pu, d_ctrl, kernel_ms, e0, e1);
         // the sweeps of st_wave.hip read class-aligned records

@@ -15,7 +15,10 @@ static constexpr int kStH = 8;                 // steps of hand-off history kept
 #ifndef ST_PS
 #define ST_PS 2
 #endif
-static constexpr int kStPF = 8, kStPS = ST_PS;   // steps ahead the courier polls the values of earlier workgroups: factor kernel, sweeps (measured: +-4 %)
+#ifndef ST_PF
+#define ST_PF 8
+#endif
+static constexpr int kStPF = ST_PF, kStPS = ST_PS;   // steps ahead the courier polls the values of earlier workgroups: factor kernel, sweeps (measured: +-4 %)
 static constexpr int kStMaxSkew = 30000;
 static constexpr unsigned kStSpinLimit = 1u << 21;
 static constexpr int64_t kStMaxChunks = 1 << 21;      // record offsets are 32-bit byte offsets
@@ -287,10 +290,46 @@ __device__ __forceinline__ void st_number_pairs(const int32_t *T, const int t, c
 
 #endif
 
+#if defined(__HIPCC__)
+// may the wave-exchange factor kernel (st_wave.hip: k_ilu0_wx) run this forward lane?  On top of wx_lane_ok: the transposed entry of
+// every elimination exists and is an entry its owner hands on (a'B or a'C of the pivot row; the own chain's: a'A), and what comes
+// from the workgroup is at most kSdHist - 1 steps old.  (after sd_tab_lane: ST_Q is set)
+__device__ __forceinline__ bool wf_lane_ok(const int32_t *T, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot)
+{
+    const int nd = T[ST_ND], cnt = T[ST_CNT];
+    if (cnt <= 0) return true;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < nd) {
+            const int sw = T[ST_SRC + j], ty = sw & 3, os = sw >> 2, q = T[ST_Q + j];
+            if (ty == ST_OWN) {
+                if (q != 0) ok = false;
+            } else {
+                const int pu = uslot[os];
+                if (q < 0 || pu < 0) {
+                    ok = false;
+                } else {
+                    int pc[3]; bool pr[3];
+                    (void)wr_classify(ltabB + (size_t)pu * kStTab, pu & 255, true, pc, pr);
+                    const int c = q == 0 ? pc[0] : (q == 1 ? pc[1] : pc[2]);
+                    if (c != WR_B && c != WR_C) ok = false;
+                }
+                if (ty == ST_LOCAL && (T[ST_DT + j] < 1 || T[ST_DT + j] > kSdHist - 1)) ok = false;
+            }
+        }
+    }
+    return ok;
+}
+#endif
+
 // st_direct.hip
 bool st_direct_prepare(hipStream_t st, const DevMat &A, const Schedule &fwd, int32_t *dflags);
 void st_direct_verify(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, int32_t *dflags);
 int ilu0_numeric_sd(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,
+                    hipEvent_t e0, hipEvent_t e1);
+// st_wave.hip
+int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,
                     hipEvent_t e0, hipEvent_t e1);
 
 }  // namespace ilupp

@@ -38,6 +38,8 @@ static constexpr int kWxLds = 2 * kStH * kWxRow * 8;
 #ifdef WX_STAMP
 // diagnostics build only: [0..3] forward, [4..7] backward sweep: shader cycles, 100 MHz ticks, steps of wave 0 of workgroup 0
 __device__ unsigned long long g_wx_stamp[16];
+// ... and per workgroup of the factor kernel (by ticket): entry, lane 0's first row, lane 0's last row, exit (100 MHz)
+__device__ unsigned long long g_wf_tl[4096 * 4];
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -454,8 +456,596 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
     return ILUPP_OK;
 }
 
+// =============================================================================================
+// ILU(0), wave-exchange form: the direct-feed factor kernel (st_direct.hip: producer waves stream A's values into LDS, consumer
+// waves run the pivot recurrence u_rr = a_rr - sum_k (a_rk / u_kk) a_kr, ILU0.hpp:47-62 for rows whose eliminations meet them on
+// the diagonal only) rebuilt around a lean consumer:
+//   * the PRODUCERS put every entry of a row where its class says (a canonical record of eight doubles per lane and step --
+//     {aC, aB} {aA, d} {a'A, a'B} {a'C, -}: the entries left of the diagonal by forward class, the diagonal, the entries right of it
+//     by backward class; a place no entry goes to stays +0.0): each producer thread's two 8-byte stores of a block simply go to
+//     thread-constant places.  The consumer reads its row with four 16-byte LDS loads at a lane-constant address: nothing about a
+//     row is looked up or selected, only the own-chain entries of a chain's first and last row are masked;
+//   * pivots travel as the sweeps' unknowns do (DPP / ds_bpermute inside the wave, the hand-off array two steps old otherwise, a
+//     cell of ONES for a class without an entry: 0 / 1 = +0.0); the transposed entries a(k, r) -- entries right of the diagonal of
+//     the pivot row -- are re-published by the lane that owns the pivot row when it pre-reads that row, one step before its pivot;
+//   * records leave in format 1 as they are computed: {lC, lB} {lA, 1} and {a'A, a'B} {a'C, u_rr}; no "absent" selects, stores
+//     through buffer resources (a step outside the wave's chunks is dropped);
+//   * the courier imports pivots (polled) and transposed entries (from A) of earlier workgroups two barriers early and exports.
+// Arithmetic and its order are st_direct.hip's (bit-identical results; ILUPP_NO_WR=1 runs the old kernels).
+// =============================================================================================
+static constexpr int kWfH = 4;                            // steps of hand-off history (kept twice: slot s and s + 4)
+static constexpr int kWfRow = kThreads + 64 + 16;         // doubles per slot: lanes, courier pairs, [320] a cell of ones / zeros (+ padding: 4 rows = 21 x 512 B)
+static constexpr int kWfCell = kThreads + 64;
+static constexpr int kWfArr = 2 * kWfH * kWfRow * 8;      // bytes of one hand-off array
+static constexpr int kWfPitch = 80;                       // bytes of a lane's record in the row ring: 8 doubles + 16 (a wave's 16-byte loads and the producers' 8-byte stores then spread over the banks)
+static constexpr int kWfSlot = kThreads * kWfPitch;       // bytes of a step of the row ring
+static constexpr int kWfRing = 4 * kWfSlot;               // two blocks of two steps
+static constexpr unsigned kWfX = kWfRing;                 // pivots
+static constexpr unsigned kWfTB = kWfRing + kWfArr;       // a'B of every row (and the courier's transposed entries)
+static constexpr unsigned kWfTC = kWfRing + 2 * kWfArr;   // a'C
+static constexpr int kWfLds = kWfRing + 3 * kWfArr + 64;
+static constexpr int kWfProd = 3, kWfPer = 11, kWfRA = 4; // producer waves, groups of 8 lanes per wave, blocks read ahead
+static constexpr int kWfThreads = kThreads + 64 + 64 * kWfProd;
+static_assert(kWfProd * kWfPer * 8 >= kThreads, "every lane needs a producer");
+static_assert((kWfH * kWfRow * 8) % 512 == 0, "the two copies of a hand-off value are stored with one ds_write2st64_b64");
+
+struct WfArgs {
+    const int32_t *ltab, *ltabB, *uslot, *wtab;   // forward lane table, backward lane table, forward -> backward slot, chunk table
+    const double *val;                            // A's values, the pointer rounded down to 16 bytes
+    uint32_t val_bytes;
+    int32_t val_shift;
+    unsigned char *pkL, *pkU;                     // format-1 records, both in the forward schedule's order
+    const int32_t *xe, *xw;
+    double *xch;
+    int32_t *ctrl;                                // [0] ticket, [1] error
+};
+struct WfPair { int idx0, stride, sk, cnt; unsigned at0; int atm, klast, sh, hasT; };    // (st_direct.hip: SdPair)
+
+// what a consumer lane knows
+struct WfLane {
+    unsigned xB, xC;              // pivot hand-off: stand-in of class B / C (the cell of ones without an entry)
+    unsigned tB, tC;              // transposed entries of the class B / C elimination (the cell of zeros without one)
+    bool ringC;
+    int src16;
+    bool hasB, hasC, hasUB, hasUC;   // the lane's rows have an entry of class B / C left of the diagonal; of (backward) class B / C right of it
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wf_rsrc(const WfArgs &A)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.val), 0, (int)A.val_bytes, 0x00020000);
+}
+
+// canonical place (0..7) of row position pos of forward lane `slot`: left entries by forward class, diagonal, right entries by the
+// backward lane's classes; -1: the lane has no such position
+__device__ __forceinline__ int wf_canon(const int32_t *T, const int32_t *TB, const int tl, const int tlB, const int pos)
+{
+    const int nd = T[ST_ND], ndU = T[ST_DFL] & 3;
+    if (pos < 0 || pos > nd + ndU) return -1;
+    int cls[3]; bool ring[3];
+    if (pos < nd) { (void)wr_classify(T, tl, false, cls, ring); const int c = pos == 0 ? cls[0] : (pos == 1 ? cls[1] : cls[2]); return c == WR_NONE ? -1 : wr_slot_of(c, false); }
+    if (pos == nd) return 3;
+    (void)wr_classify(TB, tlB, true, cls, ring);
+    const int q = pos - nd - 1;
+    const int c = q == 0 ? cls[0] : (q == 1 ? cls[1] : cls[2]);
+    return c == WR_NONE ? -1 : 4 + wr_slot_of(c, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the 256 lanes of the schedule
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wf_consumer(const WfArgs &A, unsigned char *lds, const int wg, const WfLane W, const int tlo, const int thi)
+{
+    typedef double v2dd __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    const int slot = wg * kThreads + t;
+    const int32_t *T = A.ltab + (size_t)slot * kStTab;
+    const int cnt = T[ST_CNT], sk = T[ST_SKEW];
+    const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
+    const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
+              nchw = __builtin_amdgcn_readfirstlane(wt[2]);
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.pkL + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(A.pkU + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
+    unsigned vout = (unsigned)(tlo - tminw) * 2048u + (unsigned)ln * 16u;          // (a step outside the wave's chunks: out of range)
+    const unsigned rowa = (unsigned)t * kWfPitch;                                  // this lane's record in a step of the row ring
+    const unsigned xown = kWfX + (unsigned)t * 8u, tbown = kWfTB + (unsigned)t * 8u, tcown = kWfTC + (unsigned)t * 8u;
+
+    // the row of a step is read during the step BEFORE (and its entries right of the diagonal handed on at once)
+#define WF_ROW(s4_, r0_, r1_, r2_, r3_)                                                                           \
+    do {                                                                                                           \
+        r0_ = *reinterpret_cast<const v2dd *>(lds + rowa + (unsigned)(s4_) * kWfSlot);                             \
+        r1_ = *reinterpret_cast<const v2dd *>(lds + rowa + (unsigned)(s4_) * kWfSlot + 16u);                       \
+        r2_ = *reinterpret_cast<const v2dd *>(lds + rowa + (unsigned)(s4_) * kWfSlot + 32u);                       \
+        r3_ = *reinterpret_cast<const v2dd *>(lds + rowa + (unsigned)(s4_) * kWfSlot + 48u);                       \
+    } while (0)
+#define WF_HAND_T(h4_, r2_, r3_)                                                                                   \
+    do {                                                                                                           \
+        *reinterpret_cast<double *>(lds + tbown + (unsigned)(h4_) * (kWfRow * 8)) = (r2_).y;                       \
+        *reinterpret_cast<double *>(lds + tbown + (unsigned)((h4_) + kWfH) * (kWfRow * 8)) = (r2_).y;              \
+        *reinterpret_cast<double *>(lds + tcown + (unsigned)(h4_) * (kWfRow * 8)) = (r3_).x;                       \
+        *reinterpret_cast<double *>(lds + tcown + (unsigned)((h4_) + kWfH) * (kWfRow * 8)) = (r3_).x;              \
+    } while (0)
+
+    // The producers place a row's entries by their distance from the row's (virtual) start.  A chain's first row has no own-chain
+    // entry left of its diagonal and its last row none right of it: there the neighbours' entries sit one place nearer to the diagonal
+    // (and the place at the far end holds an entry of another row).  Put right once per row, when the row is handed on; only the two
+    // rows at the ends of a chain need it, so the selects sit behind a branch the whole wave takes or skips.
+    const int fl = T[ST_DFL];
+    const int kF = ((fl >> 2) & 1) ? 0 : -1, kL = ((fl >> 3) & 1) ? cnt - 1 : -1;
+    // first row: the entry of template position j lies at the place of position j + 1; last row: of position q at the place of q - 1
+    const bool fCB = W.hasC && W.hasB, fCA = W.hasC && !W.hasB, fBA = W.hasB;
+    const bool lCB = W.hasUC && W.hasUB, lCA = W.hasUC && !W.hasUB, lBA = W.hasUB;
+#define WF_ENDS(kk_, r0_, r1_, r2_, r3_)                                                                          \
+    do {                                                                                                           \
+        const bool f_ = (kk_) == kF, l_ = (kk_) == kL;                                                             \
+        if (__builtin_amdgcn_ballot_w64(f_ || l_) != 0) {                                                          \
+            const double c_ = (r0_).x, b_ = (r0_).y, a_ = (r1_).x, ua_ = (r2_).x, ub_ = (r2_).y, uc_ = (r3_).x;    \
+            (r0_).x = f_ ? (fCB ? b_ : (fCA ? a_ : c_)) : c_;                                                      \
+            (r0_).y = f_ ? (fBA ? a_ : b_) : b_;                                                                   \
+            (r1_).x = f_ ? 0.0 : a_;                                                                               \
+            (r2_).x = l_ ? 0.0 : ua_;                                                                              \
+            (r2_).y = l_ ? (lBA ? ua_ : ub_) : ub_;                                                                \
+            (r3_).x = l_ ? (lCB ? ub_ : (lCA ? ua_ : uc_)) : uc_;                                                  \
+        }                                                                                                          \
+    } while (0)
+    ST_BARRIER();                                           // (the producers' first two blocks and the courier's first entries are in place)
+    v2dd c0_, c1_, c2_, c3_;                                // the row of the current step: {aC, aB} {aA, d} {a'A, a'B} {a'C, -}
+    v2dd n0_, n1_, n2_, n3_;                                // ... of the next step
+    WF_ROW(0, c0_, c1_, c2_, c3_);
+    WF_ROW(1, n0_, n1_, n2_, n3_);
+    WF_ENDS(tlo - sk, c0_, c1_, c2_, c3_);
+    WF_HAND_T(0, c2_, c3_);
+    double bB = st_lds(lds, W.xB), bC = st_lds(lds, W.xC);  // pivots of other waves / workgroups for the first step
+    ST_BARRIER();                                           // (everybody's transposed entries of the first step are handed on)
+    double tB = st_lds(lds, W.tB), tC = st_lds(lds, W.tC);
+    double w3prev = 1.0, upA = 0.0;                         // the pivot of the lane's previous row; that row's own-chain entry right of the diagonal
+    double qC = 1.0;                                        // the pivot of lane - 16 (asked for at the end of the step before)
+    int k = tlo - sk;
+    for (int tb = tlo; tb < thi; tb += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // the pivots: inside the wave from registers
+            const double pC = W.ringC ? bC : qC;
+            const double pB = wx_dpp_shr1(bB, w3prev);
+            // for the steps to come (nothing of it is used before the next barrier): the row of the step after the next, the pivots and
+            // the transposed entries of the next step that do not come through the wave's registers
+            v2dd m0_, m1_, m2_, m3_;
+            WF_ROW((u + 2) & 3, m0_, m1_, m2_, m3_);
+            const double nB = st_lds(lds, W.xB + (unsigned)((u + 1) & 3) * (kWfRow * 8));
+            const double nC = st_lds(lds, W.xC + (unsigned)((u + 1) & 3) * (kWfRow * 8));
+            const double ntB = st_lds(lds, W.tB + (unsigned)((u + 1) & 3) * (kWfRow * 8));
+            const double ntC = st_lds(lds, W.tC + (unsigned)((u + 1) & 3) * (kWfRow * 8));
+            const bool valid = (unsigned)k < (unsigned)cnt;
+#ifdef WX_STAMP
+            if (t == 0 && wg < 4096 && k == 0) g_wf_tl[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            if (t == 0 && wg < 4096 && k == cnt - 1) g_wf_tl[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+            // (the lane's previous step had no row: what it left in upA is not an entry of the matrix)
+            const double aA = c1_.x, tA = k == 0 ? 0.0 : upA;
+            const double uA = c2_.x;
+            // u_rr = a_rr - sum (a_rk / u_kk) a_kr, eliminations in ascending k: classes C, B, A
+#ifdef WF_X_NODIV
+            const double lC = c0_.x * pC, lB = c0_.y * pB, lA = aA * w3prev;
+#else
+            const double lC = c0_.x / pC, lB = c0_.y / pB, lA = aA / w3prev;
+#endif
+            double w = c1_.y;
+            w = w - lC * tC;
+            w = w - lB * tB;
+            w = w - lA * tA;
+            {
+                // (a pivot must not look like the marker of the exchange; a lane without a row hands on 1)
+                const unsigned long long wb = st_bits(w);
+                if ((wb & ~3ull) == (kSentinel & ~3ull)) w = st_dbl(kCanonNaN);
+            }
+            const double w3 = valid ? w : 1.0;
+            *reinterpret_cast<double *>(lds + xown + (unsigned)(u & 3) * (kWfRow * 8)) = w3;
+            *reinterpret_cast<double *>(lds + xown + (unsigned)((u & 3) + kWfH) * (kWfRow * 8)) = w3;
+            qC = wx_from_lane(W.src16, w3);
+            w3prev = w3; upA = c2_.x;
+            {
+                typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+                v2dd la, lb, ua, ub;
+                la.x = lC; la.y = lB; lb.x = lA; lb.y = 1.0;
+                ua.x = uA; ua.y = c2_.y; ub.x = c3_.x; ub.y = w3;
+#ifdef WF_X_NOSTORE
+                if (w3 == 1.2345e-300) {
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, la), rL, vout, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vout + 1024u, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ua), rU, vout, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ub), rU, vout + 1024u, 0, 2);
+#ifdef WF_X_NOSTORE
+                }
+#endif
+                vout += 2048u;
+            }
+            // the next row (read a step ago): its ends put right, its entries right of the diagonal handed on -- a step before its pivot
+            WF_ENDS(k + 1, n0_, n1_, n2_, n3_);
+            WF_HAND_T((u + 1) & 3, n2_, n3_);
+            c0_ = n0_; c1_ = n1_; c2_ = n2_; c3_ = n3_;
+            n0_ = m0_; n1_ = m1_; n2_ = m2_; n3_ = m3_;
+            bB = nB; bC = nC; tB = ntB; tC = ntC;
+            ++k;
+            ST_BARRIER();
+        }
+    }
+#undef WF_ROW
+#undef WF_HAND_T
+#undef WF_ENDS
+}
+
+// ---------------------------------------------------------------------------------------------
+// the courier: lane p serves pair p.  Inbound, before the barrier that ends step s - 2: the pivot of step s from the exchange (polled
+// kStPF steps ahead) and the transposed entry of step s from A.  Outbound, behind the barrier that ends step s: the pivots of the
+// exported lanes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long long *idle, unsigned char *lds, const WfPair P,
+                                           const int tlo, const int thi, const int wg, const int *s_exp)
+{
+    constexpr int NP = kStPF, SH = 2;
+    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+    const int ln = threadIdx.x & 63;
+#ifdef WF_X_NOCOURIER
+    ST_BARRIER(); ST_BARRIER();
+    for (int tb = tlo; tb < thi; ++tb) ST_BARRIER();
+    return;
+#endif
+    const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.xch);
+    const unsigned span = (unsigned)P.cnt;
+    const unsigned hoX = kWfX + (unsigned)((kWfH * kWfRow + kThreads + ln) * 8);
+    const unsigned hoT = kWfTB + (unsigned)((kWfH * kWfRow + kThreads + ln) * 8);
+    // exports (wx_courier)
+    const int E = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
+    const int xrow0 = A.xw[wg * 4 + 3] + (tlo - A.xw[wg * 4 + 1]) * E;
+    const int elane = (ln < E) ? s_exp[ln] : -1;
+    const unsigned ea = kWfX + (unsigned)((kWfH * kWfRow + (elane >= 0 ? elane : kWfCell)) * 8);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + xrow0, 0, (int)((unsigned)(thi - tlo) * (unsigned)E * 8u), 0x00020000);
+    unsigned vx = elane >= 0 ? (unsigned)ln * 8u : 0xfffffff0u;
+    const unsigned dvx = elane >= 0 ? (unsigned)E * 8u : 0u;
+    if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 1);                 // (the analysis does not let such a schedule through)
+    unsigned long long gq[NP];
+    double ga[NP];
+#define WFC_ADDR(k_) ((unsigned)(k_) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
+#define WFC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : 0xfffffff0u)
+#define WFC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, WFC_AT(k_), 0, 0))
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        gq[g] = ld_agent_u64(WFC_ADDR(tlo + g - P.sk));
+        ga[g] = WFC_LDAT(tlo + g - P.sk);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, 0.0), rx, 0xfffffff0u, 0, 16);      // (the way in looks like a pass of the loop)
+        asm volatile("" ::: "memory");
+    }
+    bool dead = false;
+#define WFC_DELIVER(i_)                                                                                              \
+    do {                                                                                                             \
+        const int k = tlo_ + (i_) - P.sk;                                                                            \
+        const bool need = (unsigned)k < span;                                                                        \
+        unsigned long long v = gq[(i_) % NP];                                                                        \
+        if (!dead) {                                                                                                 \
+            unsigned spins = 0;                                                                                      \
+            while (__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0) {                                       \
+                if (need && v == kSentinel) v = ld_agent_u64(WFC_ADDR(k));                                           \
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                                                  \
+                __builtin_amdgcn_s_sleep(1);                                                                         \
+                if ((++spins & 255u) == 0) {                                                                         \
+                    if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);                                             \
+                    const int e = ld_agent_i32(&A.ctrl[1]);                                                          \
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                                                              \
+                    if (spins > kStSpinLimit || e != 0) { dead = true; break; }                                      \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+        *reinterpret_cast<unsigned long long *>(lds + hoX + (unsigned)((i_) & 3) * (kWfRow * 8)) = v;                \
+        *reinterpret_cast<double *>(lds + hoT + (unsigned)((i_) & 3) * (kWfRow * 8)) = ga[(i_) % NP];                \
+        gq[(i_) % NP] = ld_agent_u64(WFC_ADDR(k + NP));                                                              \
+        ga[(i_) % NP] = WFC_LDAT(k + NP);                                                                            \
+    } while (0)
+    {
+        const int tlo_ = tlo;
+#pragma unroll
+        for (int i = 0; i < SH; ++i) WFC_DELIVER(i);
+    }
+    ST_BARRIER();
+    ST_BARRIER();
+    for (int tb = tlo; tb < thi; tb += 8) {
+        const int tlo_ = tb;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            WFC_DELIVER(u + SH);
+            ST_BARRIER();
+            {
+                const double v = st_lds(lds, ea + (unsigned)(u & 3) * (kWfRow * 8));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v), rx, vx, 0, 16);          // sc1: write-through
+                vx += dvx;
+            }
+        }
+    }
+#undef WFC_DELIVER
+#undef WFC_ADDR
+#undef WFC_AT
+#undef WFC_LDAT
+    if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a producer wave: 8 threads per lane, 16 bytes of A.val each per block of two steps (st_direct.hip: sd_producer); every thread's two
+// entries of a block go to the places of the canonical records they belong to
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds, const int wg, const int pw, const int tlo, const int thi)
+{
+    const int ln = threadIdx.x & 63, sub = ln & 7, lg = ln >> 3;
+#ifdef WF_X_NOPROD
+    ST_BARRIER(); ST_BARRIER();
+    for (int tb = tlo; tb < thi; ++tb) ST_BARRIER();
+    return;
+#endif
+    const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
+    unsigned g[kWfPer], S[kWfPer], d0[kWfPer], d1[kWfPer];
+    const int b0 = tlo >> 1;
+#pragma unroll
+    for (int i = 0; i < kWfPer; ++i) {
+        const int l = (pw * kWfPer + i) * 8 + lg;
+        const bool live = l < kThreads;
+        const int slot = wg * kThreads + (live ? l : 0);
+        const int32_t *T = A.ltab + (size_t)slot * kStTab;
+        const int cnt = T[ST_CNT], sk = T[ST_SKEW], fl = T[ST_DFL], p0 = T[ST_P0];
+        const int ownL = (fl >> 2) & 1, m = fl >> 4;
+        const unsigned Cu = 8u * (unsigned)(p0 - ownL - sk * m) + (unsigned)A.val_shift;
+        const bool on = live && cnt > 0 && (sub < 7 || (Cu & 15u) + 16u * (unsigned)m > 112u);
+        S[i] = on ? 16u * (unsigned)m : 0u;
+        g[i] = on ? (Cu & ~15u) + (unsigned)b0 * S[i] + 16u * (unsigned)sub : 0xfffffff0u;
+        // where the thread's two entries of a block belong
+        const int su = on ? A.uslot[slot] : -1;
+        const int32_t *TB = A.ltabB + (size_t)(su < 0 ? 0 : su) * kStTab;
+        unsigned dd[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = 2 * sub + e - (int)((Cu & 15u) >> 3);          // entry of the block's two (virtual) rows
+            int place = -1, ui = 0;
+            if (on && su >= 0 && idx >= 0 && idx < 2 * m) {
+                ui = idx >= m ? 1 : 0;
+                place = wf_canon(T, TB, l, su & 255, idx - ui * m);
+            }
+            // (a piece of no row goes to place 7 of the lane's record, which nobody reads)
+            if (place < 0) { place = 7; ui = 0; }
+            dd[e] = (unsigned)ui * kWfSlot + (unsigned)(live ? l : 0) * kWfPitch + (unsigned)place * 8u;
+        }
+        d0[i] = dd[0]; d1[i] = dd[1];
+    }
+    const unsigned lbase = (unsigned)reinterpret_cast<uintptr_t>(lds);
+    v4u ra[kWfRA][kWfPer];
+#define WFP_LOAD(rb)                                                                       \
+    do {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < kWfPer; ++i) {                               \
+            ra[rb][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, g[i], 0, 0);             \
+            g[i] += S[i];                                                                  \
+        }                                                                                  \
+    } while (0)
+#define WFP_WRITE(rb, parity)                                                              \
+    do {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < kWfPer; ++i) {                               \
+            if ((pw * kWfPer + i) * 8 < kThreads) {                                        \
+                typedef unsigned long long u64_;                                           \
+                const v4u x_ = ra[rb][i];                                                  \
+                const u64_ lo_ = ((u64_)x_.y << 32) | x_.x, hi_ = ((u64_)x_.w << 32) | x_.z; \
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(lbase + d0[i]), "v"(lo_), "n"((parity) * 2 * kWfSlot) : "memory"); \
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(lbase + d1[i]), "v"(hi_), "n"((parity) * 2 * kWfSlot) : "memory"); \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
+    // the first kWfRA blocks; blocks b0 and b0 + 1 go to the ring at once (the lanes read the row of step s during step s - 2)
+#pragma unroll
+    for (int rb = 0; rb < kWfRA; ++rb) { WFP_LOAD(rb); asm volatile("" ::: "memory"); }
+    WFP_WRITE(0, 0);
+    WFP_LOAD(0);
+    WFP_WRITE(1, 1);
+    WFP_LOAD(1);
+    ST_BARRIER();                                           // (the lanes read their first two rows behind this one)
+    ST_BARRIER();
+    for (int tb = tlo; tb < thi; tb += 8) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            // steps 2 bb and 2 bb + 1 of this trip: the lanes read the rows of steps 2 bb + 2 and 2 bb + 3 (block bb + 1); block bb + 2
+            // takes the place of block bb, whose rows were read two steps ago
+            ST_BARRIER();
+            WFP_WRITE((bb + 2) & 3, bb & 1);
+            WFP_LOAD((bb + 2) & 3);
+            ST_BARRIER();
+        }
+    }
+#undef WFP_LOAD
+#undef WFP_WRITE
+}
+
+__global__ void __launch_bounds__(kWfThreads)
+k_ilu0_wx(WfArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ WfPair s_pairs[64];
+    __shared__ int s_exp[kThreads];
+    __shared__ int s_cnt[4], s_total;
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
+    __syncthreads();
+    const int wg = (int)s_ticket;
+    const int t = threadIdx.x;
+    int tlo = 0x7fffffff, thi = -0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t *w4 = A.wtab + (size_t)(wg * 4 + q) * 4;
+        const int a = w4[1], b = w4[2];
+        if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
+    }
+    tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
+    if (thi <= tlo) return;
+    tlo &= ~7;                                                        // step % 8 = position in the unrolled loops
+    // the row ring and the hand-off arrays start all +0.0 (what no producer piece goes to stays that way); the cells of ones
+    for (int i = t; i < kWfLds / 8; i += kWfThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
+    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; s_pairs[t] = z; }
+    if (t < kThreads) s_exp[t] = -1;
+    __syncthreads();
+    if (t < 2 * kWfH) *reinterpret_cast<double *>(lds + kWfX + (unsigned)((t * kWfRow + kWfCell) * 8)) = 1.0;
+    if (t < kThreads) {
+        const int slot = wg * kThreads + t;
+        const int32_t *T = A.ltab + (size_t)slot * kStTab;
+        const int nd = T[ST_ND], cnt = T[ST_CNT];
+        int cls[3]; bool ring[3];
+        bool ok = wx_lane_ok(T, t, false) && wf_lane_ok(T, A.ltabB, A.uslot);
+        (void)wr_classify(T, t, false, cls, ring);
+        WfLane W;
+        W.xB = W.xC = kWfX + (unsigned)((kWfH * kWfRow + kWfCell) * 8);
+        W.tB = W.tC = kWfTB + (unsigned)((kWfH * kWfRow + kWfCell) * 8);
+        W.ringC = true;
+        W.src16 = ((t - 16) & 63) * 4;
+        bool isg[3];
+        WfPair gp[3];
+        unsigned xg[3], tg[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int sw = T[ST_SRC + j];
+            const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
+            const int os = sw >> 2;
+            const int q = ty != ST_NONE ? T[ST_Q + j] : -1;
+            isg[j] = ty == ST_GHOST;
+            xg[j] = 0; tg[j] = 0;
+            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0;
+            if (ty == ST_LOCAL || ty == ST_GHOST) {
+                // the transposed entry: which entry right of the diagonal of the pivot row, and where its owner hands it on
+                const int pu = A.uslot[os];
+                const int32_t *TPB = A.ltabB + (size_t)(pu < 0 ? 0 : pu) * kStTab;
+                int pc[3]; bool pr[3];
+                (void)wr_classify(TPB, pu & 255, true, pc, pr);
+                const int qs = (q >= 0 && pu >= 0) ? wr_slot_of(q == 0 ? pc[0] : (q == 1 ? pc[1] : pc[2]), true) : -1;
+                if (qs != 1 && qs != 2) ok = false;                  // (a'B or a'C of the pivot row: what the lanes hand on)
+                if (ty == ST_LOCAL) {
+                    const int lane = os & 255, dt = T[ST_DT + j];
+                    if (dt < 1 || dt > kWfH - 1) ok = false;
+                    xg[j] = kWfX + (unsigned)(((kWfH - dt) * kWfRow + lane) * 8);
+                    tg[j] = (qs == 2 ? kWfTC : kWfTB) + (unsigned)(((kWfH - dt) * kWfRow + lane) * 8);
+                } else {
+                    const int pw = os >> 8;
+                    const int32_t *TP = A.ltab + (size_t)os * kStTab;
+                    const int E = A.xw[pw * 4];
+                    const int kap = T[ST_KAP + j];
+                    d.stride = E;
+                    d.idx0 = A.xw[pw * 4 + 3] + (kap + TP[ST_SKEW] - T[ST_SKEW] - A.xw[pw * 4 + 1]) * E + A.xe[os];
+                    const int flp = TP[ST_DFL];
+                    const int mp = flp >> 4;
+                    d.hasT = q >= 0 ? 1 : 0;
+                    d.atm = 8 * mp;
+                    d.at0 = (unsigned)A.val_shift + 8u * (unsigned)(TP[ST_P0] - ((flp >> 2) & 1) + TP[ST_ND] + 1 + (q < 0 ? 0 : q) + kap * mp);
+                    d.klast = TP[ST_CNT] - 1 - kap;
+                    d.sh = 8 * ((flp >> 3) & 1);
+                }
+            } else if (ty == ST_OWN) {
+                if (q != 0) ok = false;                               // (the own chain: the pivot row's first entry right of its diagonal)
+            }
+            gp[j] = d;
+        }
+        // the pairs of the workgroup, numbered
+        {
+            const int wv = t >> 6;
+            unsigned long long bal[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bal[j] = __builtin_amdgcn_ballot_w64(isg[j]);
+            const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]);
+            if ((t & 63) == 0) s_cnt[wv] = mine;
+            __syncthreads();
+            int before = 0;
+            for (int q = 0; q < wv; ++q) before += s_cnt[q];
+            if (t == 0) s_total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (isg[j]) {
+                    const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
+                    if (p < 64) s_pairs[p] = gp[j];
+                    xg[j] = kWfX + (unsigned)((kWfH * kWfRow + kThreads + min(p, 63)) * 8);
+                    tg[j] = kWfTB + (unsigned)((kWfH * kWfRow + kThreads + min(p, 63)) * 8);
+                }
+                before += __popcll(bal[j]);
+            }
+        }
+        W.hasB = W.hasC = W.hasUB = W.hasUC = false;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (cls[j] == WR_B) { W.hasB = true; W.tB = tg[j]; if (ring[j]) W.xB = xg[j]; }
+            if (cls[j] == WR_C) { W.hasC = true; W.tC = tg[j]; if (ring[j]) W.xC = xg[j]; else W.ringC = false; }
+        }
+        {
+            const int su = cnt > 0 ? A.uslot[slot] : -1;
+            if (su >= 0) {
+                int bc[3]; bool br[3];
+                (void)wr_classify(A.ltabB + (size_t)su * kStTab, su & 255, true, bc, br);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { if (bc[q] == WR_B) W.hasUB = true; if (bc[q] == WR_C) W.hasUC = true; }
+            } else if (cnt > 0) {
+                ok = false;
+            }
+        }
+        {
+            const int xe = A.xe[slot];
+            if (cnt > 0 && xe >= 0 && xe < kThreads) s_exp[xe] = t;
+        }
+        __syncthreads();
+        if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], 1);  // (the analysis does not let such a schedule through)
+#ifdef WX_STAMP
+        if (t == 0 && wg < 4096) g_wf_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+        wf_consumer(A, lds, wg, W, tlo, thi);
+#ifdef WX_STAMP
+        if (t == 0 && wg < 4096) g_wf_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    } else if (t < kThreads + 64) {
+        __syncthreads();
+        __syncthreads();
+        const WfPair P = s_pairs[t - kThreads];
+        const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
+        wf_courier(A, idle, lds, P, tlo, thi, wg, s_exp);
+    } else {
+        __syncthreads();
+        __syncthreads();
+        wf_producer(A, lds, wg, (t - kThreads - 64) >> 6, tlo, thi);
+    }
+}
+
+int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,
+                    hipEvent_t e0, hipEvent_t e1)
+{
+    {
+        static std::once_flag once[64];      // once per device
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLds));
+        });
+    }
+    ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
+    fill_u64(st, reinterpret_cast<unsigned long long *>(pl->xch), pl->xch_len, kSentinel);
+    WfArgs a;
+    a.ltab = pl->ltab; a.ltabB = pu->ltab; a.uslot = pu->uslot; a.wtab = pl->wtab;
+    const uintptr_t vp = reinterpret_cast<uintptr_t>(A.val);
+    a.val = reinterpret_cast<const double *>(vp & ~(uintptr_t)15);
+    a.val_shift = (int32_t)(vp & 15);
+    a.val_bytes = (uint32_t)(A.nnz * 8 + a.val_shift);
+    a.pkL = reinterpret_cast<unsigned char *>(pl->pk); a.pkU = reinterpret_cast<unsigned char *>(pu->pk);
+    a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
+    ILUPP_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_ilu0_wx, dim3((unsigned)pl->nwg), dim3(kWfThreads), kWfLds, st, a);
+    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipGetLastError());
+    int32_t ctrl[4];
+    ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, 16));
+    ILUPP_HIP(stream_sync(st));
+    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
+    pl->fmt = pu->fmt = 1;
+    return ILUPP_OK;
+}
+
 #ifdef WX_STAMP
 void wx_read_stamps(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wx_stamp), sizeof(unsigned long long) * 16)); }
+void wf_read_tl(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_tl), sizeof(unsigned long long) * 4096 * 4)); }
 #endif
 
 }  // namespace ilupp
@@ -464,6 +1054,11 @@ void wx_read_stamps(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out
 extern "C" int ilupp_hip_debug_wx_stamps(unsigned long long *out)
 {
     try { ilupp::wx_read_stamps(out); } catch (...) { return -1; }
+    return 0;
+}
+extern "C" int ilupp_hip_debug_wf_timeline(unsigned long long *out)
+{
+    try { ilupp::wf_read_tl(out); } catch (...) { return -1; }
     return 0;
 }
 #endif

@@ -177,7 +177,10 @@ def bicgstab_split(A, b, M, min_iter=1, max_iter=500, rtol=1e-4, atol=1e-4):
     initial_res = float(torch.linalg.vector_norm(r))
     res = initial_res
     it = 0
-    while (((res / initial_res > rtol) or res > atol) and it < max_iter) or it < min_iter:
+    # (IEEE division as the reference's doubles do it: a zero right-hand side gives 0 / 0 = NaN, every comparison with it is false, the
+    # loop runs its min_iter iterations and the caller reports "did not converge" -- not a ZeroDivisionError)
+    rel = lambda a, b: a / b if b != 0.0 else (float("nan") if (a == 0.0 or a != a) else float("inf"))
+    while (((rel(res, initial_res) > rtol) or res > atol) and it < max_iter) or it < min_iter:
         it += 1
         Ap = pmv(p)
         dot_r_r0star = torch.dot(r, r0star)
@@ -194,4 +197,4 @@ def bicgstab_split(A, b, M, min_iter=1, max_iter=500, rtol=1e-4, atol=1e-4):
         res = float(torch.linalg.vector_norm(r))
     x = M.apply_part_(y, left=False)
     M.sync()
-    return x, it, res / initial_res, res
+    return x, it, rel(res, initial_res), res

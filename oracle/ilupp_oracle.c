@@ -2252,7 +2252,7 @@ int orc_ilucp(orc_int n, const orc_int *ptr, const orc_int *idx, const double *v
     if (max_fill_in < 1) max_fill_in = 1;                                        /* :226-227 */
     if (max_fill_in > n) max_fill_in = n;
     {
-        long a = (long)max_fill_in * (long)n, b = (long)(mem_factor * (double)ptr[n]);
+        long a = (long)max_fill_in * (long)n, b = (long)((orc_int)mem_factor) * (long)ptr[n];      /* (Integer) mem_factor * Acol.non_zeroes(), :229: truncated first */
         long r = a < b ? a : b;
         reserved = (orc_int)(r > 0 ? r : 0);
     }

@@ -201,6 +201,10 @@ def test_solve_like_the_reference_tests():
     with pytest.raises(RuntimeError, match="did not converge"):
         ilupp.solve(C.laplace2d_matrix(900), np.ones(900), atol=1e-14, rtol=1e-14, max_iter=2, params=param)
     assert np.allclose(ilupp.solve(A, A @ x_exact, atol=1e-8), x_exact)      # default-constructed parameters: the pivoting factorisation
+    # a zero right-hand side: the reference's loop divides 0 by 0 (NaN: every comparison false), runs its min_iter iterations and
+    # reports no convergence -- no ZeroDivisionError
+    with pytest.raises(RuntimeError, match="did not converge"):
+        ilupp.solve(A, np.zeros(50), params=param)
 
 
 MWM = ("MAX_WEIGHTED_MATCHING_ORDERING",)

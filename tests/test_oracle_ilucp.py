@@ -68,3 +68,36 @@ def test_oracle_against_reference_live():
         b = C.rhs(n)
         assert np.array_equal(P.apply(b), R.apply(b), equal_nan=True) and np.array_equal(P.apply(b, O.TRANSPOSE), R.apply(b, O.TRANSPOSE), equal_nan=True), it
     assert failures >= 1            # "ILUCP4: Insufficient memory reserved" (mem_factor 1) is among the cases
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_mem_factor_is_truncated_before_the_product():
+    """ILUC.hpp:229 reserves min(max_fill_in n, (Integer) mem_factor * nnz): the factor is truncated FIRST, so 1.9 reserves what 1.0
+    does (the restatement and the HIP kernel computed (Integer)(mem_factor * nnz))."""
+    rng = np.random.default_rng(4242)
+    differs = 0
+    for it in range(24):
+        n = int(rng.integers(30, 120))
+        A = (sp.random(n, n, min(1.0, 6.0 / n), random_state=rng, data_rvs=lambda k: rng.standard_normal(k)) + sp.eye(n) * 3.0).asformat("csr")
+        A.sort_indices()
+        a = (A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32), True)
+        outcome = {}
+        for mf in (1.0, 1.5, 1.9, 2.0, 2.5):
+            kw = dict(fill_in=100, threshold=0.0, piv_tol=0.1, rp=-1, mem_factor=mf)
+            res = []
+            for lib in (O.ref(), O.orc()):
+                try:
+                    P = O.ILUCP(lib, a, **kw)
+                    res.append(("ok", P))
+                except O.OracleError as e:
+                    res.append(("err", e.code))
+            assert res[0][0] == res[1][0], (it, mf, res[0][0], res[1][0])
+            if res[0][0] == "ok":
+                for x, y in zip(res[0][1].L + res[0][1].U, res[1][1].L + res[1][1].U):
+                    assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (it, mf)
+            else:
+                assert res[0][1] == res[1][1] == O.ERR_MEMORY
+            outcome[mf] = res[0][0]
+        assert outcome[1.5] == outcome[1.9] == outcome[1.0] and outcome[2.5] == outcome[2.0]
+        differs += int(outcome[1.9] != outcome[2.0])
+    assert differs >= 1          # (some matrix fits 2 nnz but not 1 nnz: there 1.9 must fail as 1.0 does)
