@@ -126,15 +126,17 @@ def batch_matrix(g, member):
     return d, i, p
 
 
-def ml_batch_member(dev, member, n=1000000):
+def ml_batch_member(dev, member, n=1000000, preset=1):
     """matrix `member` of the C5 batch (unsymmetric random CSR, seed 12345 + member) through the multilevel preconditioner
-    (default_configuration(1), threshold 1e-3) + one apply: (member, levels, total_nnz, sha256 of apply(ones), ms)"""
+    (default_configuration(preset), threshold 1e-3) + one apply: (member, levels, total_nnz, sha256 of apply(ones), ms).
+    preset 10 is BASELINE config 5 as named (maximum weighted matching + the factorisation with pivoting); preset 1 the family without
+    pivoting."""
     import torch
     import matgen
     import ilupp_amd as ilupp
     from ilupp_amd import _native
     prm = ilupp.iluplusplus_precond_parameter()
-    prm.default_configuration(1)
+    prm.default_configuration(preset)
     prm.threshold = 1e-3
     dm, im, pm = matgen.random_dd(n, 8, 25.0, 12345 + member)
     a = [torch.from_numpy(v).to(dev) for v in (dm, im, pm)]
@@ -413,22 +415,30 @@ def main():
 
     # BASELINE config 5 the same way: `world` unsymmetric matrices of n = 1e6 (seeds 12345 + member), one multilevel ILU++ preconditioner
     # (default_configuration(1), threshold 1e-3: the family without pivoting) + one apply each, sharded over the ranks
+    # ... first with the preset BASELINE names, default_configuration(10) (the factorisation WITH pivoting: a chain of n steps, so n = 1e5
+    # here -- at n = 1e6 one matrix takes tens of seconds, profiles/r03_c5p.txt), then with default_configuration(1) at n = 1e6
     batch_ml = None
+    batch_ml10 = None
     if world > 1:
-        def work_ml(member):
-            return ml_batch_member(dev, member)
-        barrier()
-        b0 = time.perf_counter()
-        recs = run_batch(world, work_ml)
-        barrier()
-        bwall = time.perf_counter() - b0
-        if rank == 0:
-            solo = [work_ml(m) for m in range(world)]
-            same = all(a[:4] == b[:4] for a, b in zip(recs, solo))
-            batch_ml = {"what": "C5 batch: ILUppPreconditioner(default_configuration(1), threshold=1e-3) + apply on %d unsymmetric matrices n=1e6, one per rank" % world,
-                        "records": [{"matrix": r[0], "levels": r[1], "total_nnz": r[2], "sha256_apply": r[3][:16], "ms": r[4]} for r in recs],
-                        "wall_s_incl_matrix_generation": bwall, "identical_to_single_rank": bool(same)}
-            assert same, "batched multilevel outputs differ from the single-rank run"
+        for preset, nml in ((10, 100000), (1, 1000000)):
+            def work_ml(member, preset=preset, nml=nml):
+                return ml_batch_member(dev, member, nml, preset)
+            barrier()
+            b0 = time.perf_counter()
+            recs = run_batch(world, work_ml)
+            barrier()
+            bwall = time.perf_counter() - b0
+            if rank == 0:
+                solo = [work_ml(m) for m in range(world)]
+                same = all(a[:4] == b[:4] for a, b in zip(recs, solo))
+                rec = {"what": "C5 batch: ILUppPreconditioner(default_configuration(%d), threshold=1e-3) + apply on %d unsymmetric matrices n=%d, one per rank" % (preset, world, nml),
+                       "records": [{"matrix": r[0], "levels": r[1], "total_nnz": r[2], "sha256_apply": r[3][:16], "ms": r[4]} for r in recs],
+                       "wall_s_incl_matrix_generation": bwall, "identical_to_single_rank": bool(same)}
+                assert same, "batched multilevel outputs (default_configuration(%d)) differ from the single-rank run" % preset
+                if preset == 10:
+                    batch_ml10 = rec
+                else:
+                    batch_ml = rec
 
     if rank == 0:
         fb, ab = algorithmic_bytes(n, nnz)
@@ -490,6 +500,8 @@ def main():
             out["refactor"] = refac
         if batch is not None:
             out["batch"] = batch
+        if batch_ml10 is not None:
+            out["batch_ml_config10"] = batch_ml10          # BASELINE config 5 as named
         if batch_ml is not None:
             out["batch_ml"] = batch_ml
         if not args.no_cpu and world == 1:

@@ -251,7 +251,7 @@ __device__ __forceinline__ void sd_consumer(const SdArgs &A, unsigned char *lds,
 __device__ __forceinline__ void sd_courier(const SdArgs &A, const unsigned long long *idle, unsigned char *lds, const SdPair P,
                                            const int tlo, const int thi)
 {
-    constexpr int NP = kStPF;
+    constexpr int NP = 8;                                 // (steps ahead: the pivots polled, the transposed entries read from A -- the latter want the distance)
     const int ln = threadIdx.x & 63;
     const __amdgpu_buffer_rsrc_t rs = sd_rsrc(A);
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.xch);

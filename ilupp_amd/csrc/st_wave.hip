@@ -484,7 +484,7 @@ static constexpr unsigned kWfX = kWfRing;                 // pivots
 static constexpr unsigned kWfTB = kWfRing + kWfArr;       // a'B of every row (and the courier's transposed entries)
 static constexpr unsigned kWfTC = kWfRing + 2 * kWfArr;   // a'C
 static constexpr int kWfLds = kWfRing + 3 * kWfArr + 64;
-static constexpr int kWfProd = 3, kWfPer = 11, kWfRA = 4; // producer waves, groups of 8 lanes per wave, blocks read ahead
+static constexpr int kWfProd = 6, kWfPer = 6, kWfRA = 4;  // producer waves, groups of 8 lanes per wave, blocks read ahead
 static constexpr int kWfThreads = kThreads + 64 + 64 * kWfProd;
 static_assert(kWfProd * kWfPer * 8 >= kThreads, "every lane needs a producer");
 static_assert((kWfH * kWfRow * 8) % 512 == 0, "the two copies of a hand-off value are stored with one ds_write2st64_b64");
@@ -513,21 +513,6 @@ struct WfLane {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wf_rsrc(const WfArgs &A)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.val), 0, (int)A.val_bytes, 0x00020000);
-}
-
-// canonical place (0..7) of row position pos of forward lane `slot`: left entries by forward class, diagonal, right entries by the
-// backward lane's classes; -1: the lane has no such position
-__device__ __forceinline__ int wf_canon(const int32_t *T, const int32_t *TB, const int tl, const int tlB, const int pos)
-{
-    const int nd = T[ST_ND], ndU = T[ST_DFL] & 3;
-    if (pos < 0 || pos > nd + ndU) return -1;
-    int cls[3]; bool ring[3];
-    if (pos < nd) { (void)wr_classify(T, tl, false, cls, ring); const int c = pos == 0 ? cls[0] : (pos == 1 ? cls[1] : cls[2]); return c == WR_NONE ? -1 : wr_slot_of(c, false); }
-    if (pos == nd) return 3;
-    (void)wr_classify(TB, tlB, true, cls, ring);
-    const int q = pos - nd - 1;
-    const int c = q == 0 ? cls[0] : (q == 1 ? cls[1] : cls[2]);
-    return c == WR_NONE ? -1 : 4 + wr_slot_of(c, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -682,7 +667,9 @@ __device__ __forceinline__ void wf_consumer(const WfArgs &A, unsigned char *lds,
 __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long long *idle, unsigned char *lds, const WfPair P,
                                            const int tlo, const int thi, const int wg, const int *s_exp)
 {
-    constexpr int NP = kStPF, SH = 2;
+    // (the pivots are polled NP steps ahead -- a tile settles that many steps further behind the one it reads from --, the transposed
+    // entries, which are A's and wait for nobody, NA steps ahead)
+    constexpr int NP = kStPF, NA = 8, SH = 2;
     typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
     const int ln = threadIdx.x & 63;
 #ifdef WF_X_NOCOURIER
@@ -705,13 +692,13 @@ __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long 
     const unsigned dvx = elane >= 0 ? (unsigned)E * 8u : 0u;
     if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 1);                 // (the analysis does not let such a schedule through)
     unsigned long long gq[NP];
-    double ga[NP];
+    double ga[NA];
 #define WFC_ADDR(k_) ((unsigned)(k_) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
 #define WFC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : 0xfffffff0u)
 #define WFC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, WFC_AT(k_), 0, 0))
 #pragma unroll
-    for (int g = 0; g < NP; ++g) {
-        gq[g] = ld_agent_u64(WFC_ADDR(tlo + g - P.sk));
+    for (int g = 0; g < NA; ++g) {
+        if (g < NP) gq[g] = ld_agent_u64(WFC_ADDR(tlo + g - P.sk));
         ga[g] = WFC_LDAT(tlo + g - P.sk);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, 0.0), rx, 0xfffffff0u, 0, 16);      // (the way in looks like a pass of the loop)
         asm volatile("" ::: "memory");
@@ -737,9 +724,9 @@ __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long 
             }                                                                                                        \
         }                                                                                                            \
         *reinterpret_cast<unsigned long long *>(lds + hoX + (unsigned)((i_) & 3) * (kWfRow * 8)) = v;                \
-        *reinterpret_cast<double *>(lds + hoT + (unsigned)((i_) & 3) * (kWfRow * 8)) = ga[(i_) % NP];                \
+        *reinterpret_cast<double *>(lds + hoT + (unsigned)((i_) & 3) * (kWfRow * 8)) = ga[(i_) % NA];                \
         gq[(i_) % NP] = ld_agent_u64(WFC_ADDR(k + NP));                                                              \
-        ga[(i_) % NP] = WFC_LDAT(k + NP);                                                                            \
+        ga[(i_) % NA] = WFC_LDAT(k + NA);                                                                            \
     } while (0)
     {
         const int tlo_ = tlo;
@@ -772,7 +759,8 @@ __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long 
 // a producer wave: 8 threads per lane, 16 bytes of A.val each per block of two steps (st_direct.hip: sd_producer); every thread's two
 // entries of a block go to the places of the canonical records they belong to
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds, const int wg, const int pw, const int tlo, const int thi)
+__device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds, const int wg, const int pw, const int tlo, const int thi,
+                                            const int4 *s_lane, const unsigned char *s_place)
 {
     const int ln = threadIdx.x & 63, sub = ln & 7, lg = ln >> 3;
 #ifdef WF_X_NOPROD
@@ -787,25 +775,24 @@ __device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds,
     for (int i = 0; i < kWfPer; ++i) {
         const int l = (pw * kWfPer + i) * 8 + lg;
         const bool live = l < kThreads;
-        const int slot = wg * kThreads + (live ? l : 0);
-        const int32_t *T = A.ltab + (size_t)slot * kStTab;
-        const int cnt = T[ST_CNT], sk = T[ST_SKEW], fl = T[ST_DFL], p0 = T[ST_P0];
+        // (the lane's fields and the canonical places of its row's positions: put into LDS by the lane itself, k_ilu0_wx)
+        const int4 lp = s_lane[live ? l : 0];                      // cnt, skew, first entry, flags (ST_DFL)
+        const int cnt = lp.x, sk = lp.y, p0 = lp.z, fl = lp.w;
         const int ownL = (fl >> 2) & 1, m = fl >> 4;
         const unsigned Cu = 8u * (unsigned)(p0 - ownL - sk * m) + (unsigned)A.val_shift;
         const bool on = live && cnt > 0 && (sub < 7 || (Cu & 15u) + 16u * (unsigned)m > 112u);
         S[i] = on ? 16u * (unsigned)m : 0u;
         g[i] = on ? (Cu & ~15u) + (unsigned)b0 * S[i] + 16u * (unsigned)sub : 0xfffffff0u;
         // where the thread's two entries of a block belong
-        const int su = on ? A.uslot[slot] : -1;
-        const int32_t *TB = A.ltabB + (size_t)(su < 0 ? 0 : su) * kStTab;
         unsigned dd[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = 2 * sub + e - (int)((Cu & 15u) >> 3);          // entry of the block's two (virtual) rows
             int place = -1, ui = 0;
-            if (on && su >= 0 && idx >= 0 && idx < 2 * m) {
+            if (on && idx >= 0 && idx < 2 * m) {
                 ui = idx >= m ? 1 : 0;
-                place = wf_canon(T, TB, l, su & 255, idx - ui * m);
+                const int pos = idx - ui * m;
+                place = pos < 8 ? (int)s_place[(live ? l : 0) * 8 + pos] - 1 : -1;
             }
             // (a piece of no row goes to place 7 of the lane's record, which nobody reads)
             if (place < 0) { place = 7; ui = 0; }
@@ -864,6 +851,8 @@ k_ilu0_wx(WfArgs A)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ WfPair s_pairs[64];
     __shared__ int s_exp[kThreads];
+    __shared__ int4 s_lane[kThreads];                     // per lane: cnt, skew, first entry of A, ST_DFL -- for the producers
+    __shared__ unsigned char s_place[kThreads * 8];       // per lane and row position: canonical place + 1 (0: the lane has no such position)
     __shared__ int s_cnt[4], s_total;
     __shared__ unsigned s_ticket;
     if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
@@ -974,13 +963,25 @@ k_ilu0_wx(WfArgs A)
         }
         {
             const int su = cnt > 0 ? A.uslot[slot] : -1;
+            int bc[3] = {WR_NONE, WR_NONE, WR_NONE};
             if (su >= 0) {
-                int bc[3]; bool br[3];
+                bool br[3];
                 (void)wr_classify(A.ltabB + (size_t)su * kStTab, su & 255, true, bc, br);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { if (bc[q] == WR_B) W.hasUB = true; if (bc[q] == WR_C) W.hasUC = true; }
             } else if (cnt > 0) {
                 ok = false;
+            }
+            // for the producers: the lane's fields, and where each position of its rows goes in the canonical record
+            const int fld = T[ST_DFL], ndU = fld & 3;
+            s_lane[t] = make_int4(cnt, T[ST_SKEW], T[ST_P0], fld);
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                int place = -1;
+                if (pos < nd) { const int c = pos == 0 ? cls[0] : (pos == 1 ? cls[1] : cls[2]); place = c == WR_NONE ? -1 : wr_slot_of(c, false); }
+                else if (pos == nd) place = 3;
+                else if (pos <= nd + ndU && pos - nd - 1 < 3) { const int q = pos - nd - 1; const int c = q == 0 ? bc[0] : (q == 1 ? bc[1] : bc[2]); place = c == WR_NONE ? -1 : 4 + wr_slot_of(c, true); }
+                s_place[t * 8 + pos] = (unsigned char)(place + 1);
             }
         }
         {
@@ -1005,7 +1006,7 @@ k_ilu0_wx(WfArgs A)
     } else {
         __syncthreads();
         __syncthreads();
-        wf_producer(A, lds, wg, (t - kThreads - 64) >> 6, tlo, thi);
+        wf_producer(A, lds, wg, (t - kThreads - 64) >> 6, tlo, thi, s_lane, s_place);
     }
 }
 

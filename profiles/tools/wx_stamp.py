@@ -24,3 +24,4 @@ for arg in sys.argv[1:]:
         cyc, rt, steps = buf[o], buf[o + 1], max(1, buf[o + 2])
         print("%s %s: kernel %.3f ms; wave 0 of workgroup 0: %d steps, %.1f cycles/step, %.1f ns/step, clock %.2f GHz" % (
             arg, nm, t[key], steps, cyc / steps, 10.0 * rt / steps, cyc / (10.0 * rt) if rt else 0))
+    print("   (last sweep) slow-path entries %d, spins %d, lanes that were not ready (bit i = count i): %s" % (buf[8], buf[9], bin(buf[10])))

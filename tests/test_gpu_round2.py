@@ -419,6 +419,10 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["batch"]["identical_to_single_rank"] and len(out["batch"]["records"]) == 2
     assert out["batch_ml"]["identical_to_single_rank"] and [x["matrix"] for x in out["batch_ml"]["records"]] == [0, 1]
     assert out["batch_ml"]["records"][0]["sha256_apply"] != out["batch_ml"]["records"][1]["sha256_apply"]
+    # BASELINE config 5 as named: default_configuration(10)
+    b10 = out["batch_ml_config10"]
+    assert "default_configuration(10)" in b10["what"] and b10["identical_to_single_rank"] and [x["matrix"] for x in b10["records"]] == [0, 1]
+    assert b10["records"][0]["sha256_apply"] != b10["records"][1]["sha256_apply"]
 
 
 def test_bench_single_gpu_line():
