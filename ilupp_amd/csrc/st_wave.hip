@@ -95,11 +95,13 @@ k_wx_convert(const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltab
             for (int j = 0; j < 3; ++j)
                 if (cls[j] != WR_NONE && !((TT[ST_SRC + j] & 3) == ST_OWN && kk == 0)) {
                     const int s = wr_slot_of(cls[j], side == 1);
-                    o[j] = s == 0 ? v[0] : (s == 1 ? v[1] : v[2]);
+                    // (a value that looks like one of the two markers of format 0 -- a NaN with that payload among A's values, or what
+                    // the arithmetic made of one -- must not read as "no entry")
+                    o[j] = st_clean(s == 0 ? v[0] : (s == 1 ? v[1] : v[2]));
                 }
         }
         v2d x; x.x = o[0]; x.y = o[1]; p[0] = x;
-        x.x = o[2]; x.y = b.y; p[64] = x;
+        x.x = o[2]; x.y = TO1 ? b.y : st_clean(b.y); p[64] = x;
     }
 }
 
