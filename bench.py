@@ -334,6 +334,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     path = P.path()
+    knames = P.kernel_names() if hasattr(P, "kernel_names") else ()
     # numeric re-factorisation with NEW values on the analysed pattern + one apply (what a time-stepping caller pays per step),
     # timed the same way: ilupp_hip_ilu0_refactor_device reads the new value array where it lies
     refac = None
@@ -446,17 +447,21 @@ def main():
         k_num = med(knum_ms)         # numeric factor kernel alone (HIP events on the library's stream)
         gpu_ms = med(fac_ms) + med(app_ms)
         kernel = FACTOR_KERNEL.get(path, path)
+        k_fwd, k_bwd = "k_sptrsv_st<1, false>", "k_sptrsv_st<-1, false>"
+        if knames:                              # (the library says which kernels the object runs: ilupp_hip_kernel_names)
+            kernel, k_fwd, k_bwd = knames
         # dominant kernel = the numeric factorisation sweep (the longest kernel of the step); its algorithmic bytes = the
         # factor bytes of SURVEY.md section 8(d): read A once + write L and U once
         step_s = wall / args.steps
+        k_traffic = measured_traffic(kernel, g)
         phases = [
-            {"name": kernel, "what": "numeric factorisation kernel", "ms": k_num, "algorithmic_bytes": fb, "traffic": measured_traffic(kernel, g)},
-            {"name": "analysis (k_row_cuts_counts + lane tables, ~20 launches)", "what": "pattern analysis and schedule, whole phase",
+            {"name": kernel, "what": "numeric factorisation kernel", "ms": k_num, "algorithmic_bytes": fb, "traffic": k_traffic},
+            {"name": "analysis (k_row_cuts_counts + lane tables, ~15 launches)", "what": "pattern analysis and schedule, whole phase",
              "ms": med(ana_ms), "algorithmic_bytes": None, "traffic": measured_traffic("k_row_cuts_counts", g)},
-            {"name": "k_st_vec<1, true> + k_sptrsv_st<1, false>", "what": "L solve, whole phase", "ms": med(ls_ms),
-             "algorithmic_bytes": ab // 2, "traffic": measured_traffic("k_sptrsv_st<1, false>", g)},
-            {"name": "k_sptrsv_st<-1, false> + k_st_vec<-1, false>", "what": "U solve, whole phase", "ms": med(us_ms),
-             "algorithmic_bytes": ab - ab // 2, "traffic": measured_traffic("k_sptrsv_st<-1, false>", g)},
+            {"name": "k_st_vec<1, true> + " + k_fwd, "what": "L solve, whole phase", "ms": med(ls_ms),
+             "algorithmic_bytes": ab // 2, "traffic": measured_traffic(k_fwd, g)},
+            {"name": k_bwd + " + k_st_vec<-1, false>", "what": "U solve, whole phase", "ms": med(us_ms),
+             "algorithmic_bytes": ab - ab // 2, "traffic": measured_traffic(k_bwd, g)},
         ]
         out = {
             "metric": "ILU(0) factor+apply nnz/s, 3-D 7-pt Poisson fp64",
@@ -483,7 +488,14 @@ def main():
                          "achieved": (fb / (k_num * 1e-3) / 1e9) if k_num > 0 else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (fb / (k_num * 1e-3) / 1e9) / HBM_PEAK_GBS if k_num > 0 else None,
-                         "traffic": measured_traffic(kernel, g),
+                         "frac_note": "achieved / frac use SURVEY 8(d)'s ALGORITHMIC factor bytes (A with its index arrays in, L and U with theirs out) over "
+                                      "the numeric kernel's time; the kernel itself reads A's values only and writes value records (the pattern is read by "
+                                      "the analysis, the factors' CSR index arrays are made on factors()): frac_bytes_moved is the fraction on the bytes it "
+                                      "moves, factor_phase_frac the whole factor phase (analysis + numeric) against the same algorithmic bytes, step_frac the "
+                                      "whole step",
+                         "frac_bytes_moved": ((k_traffic / (k_num * 1e-3) / 1e9) / HBM_PEAK_GBS) if (k_num > 0 and k_traffic) else None,
+                         "factor_phase_frac": ((fb / (med(fac_ms) * 1e-3) / 1e9) / HBM_PEAK_GBS) if med(fac_ms) > 0 else None,
+                         "traffic": k_traffic,
                          "algorithmic_bytes_per_launch": fb,
                          "avg_launch_ms": k_num,
                          # the whole step against the roofline: factor + apply bytes of section 8(d) over the wall clock of a step

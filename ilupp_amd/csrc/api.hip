@@ -1152,6 +1152,15 @@ const char *ilupp_hip_path(const ilupp_precond *p)
     return p->llt_diag_last ? (p->chol_static ? "ichol0:static-level-major" : "ichol0") : "icholt";
 }
 
+// which kernels a static ILU(0) object runs: "factor kernel;forward sweep;backward sweep" (measurement hook next to ilupp_hip_path:
+// bench.py labels its roofline phases and looks the kernels' counter traffic up by these names); "" for any other object
+const char *ilupp_hip_kernel_names(const ilupp_precond *p)
+{
+    if (!p || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU && p->flm.built && p->flm.stat)) return "";
+    if (p->pkL.fmt == 1) return p->flm.wxf ? "k_ilu0_wx;k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>" : "k_ilu0_sd;k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>";
+    return p->flm.direct ? "k_ilu0_sd;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>" : "k_ilu0_st;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>";
+}
+
 static int apply_host(ilupp_precond *p, double *x, int64_t len, int transpose)
 {
     API_TRY

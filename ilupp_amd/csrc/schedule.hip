@@ -41,10 +41,11 @@ __device__ __forceinline__ int tiled_block_of(int slot, const Tiling &t)
 
 __global__ void k_slot_tables(int32_t nb, int32_t nslots, int fwd, Tiling til, const int32_t *__restrict__ start,
                               int32_t *__restrict__ slot2blk, int32_t *__restrict__ blk2slot,
-                              int32_t *__restrict__ sfirst, int32_t *__restrict__ scount)
+                              int32_t *__restrict__ sfirst, int32_t *__restrict__ scount, int32_t *__restrict__ exported)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
+    exported[s] = 0;                             // (nobody reads this slot across a workgroup border yet; a memset of its own was one launch more)
     // block index in SWEEP order (forward: b, backward: nb-1-b)
     int bs = (til.s2 > 0) ? tiled_block_of(s, til) : (s < nb ? s : -1);
     const int b = bs < 0 ? -1 : (fwd ? bs : nb - 1 - bs);
@@ -79,11 +80,10 @@ void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
     ILUPP_HIP(pool_malloc(&sch->sfirst, bytes));
     ILUPP_HIP(pool_malloc(&sch->scount, bytes));
     ILUPP_HIP(pool_malloc(&sch->exported, bytes));
-    ILUPP_HIP(hipMemsetAsync(sch->exported, 0, bytes, st));
     const size_t gbytes = sizeof(int32_t) * (size_t)(sch->nslots / kThreads) * kGhosts;
     ILUPP_HIP(pool_malloc(&sch->gtab, gbytes));
     hipLaunchKernelGGL(k_slot_tables, dim3((unsigned)(sch->nslots / kThreads)), dim3(kThreads), 0, st,
-                       sch->nb, sch->nslots, fwd ? 1 : 0, til, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount);
+                       sch->nb, sch->nslots, fwd ? 1 : 0, til, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount, sch->exported);
 }
 
 // block-level dependency offsets of a sample of blocks (middle row of each sampled block)

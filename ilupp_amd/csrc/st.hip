@@ -273,11 +273,8 @@ k_st_link_pair(int32_t *__restrict__ ltabF, int32_t *__restrict__ ltabB, const i
 }
 
 // exclusive scan of the waves' chunk counts (one block); flags[1] = total, flags[2] = longest wave
-__global__ void __launch_bounds__(kThreads)
-k_st_scan(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ flags)
+__device__ __forceinline__ void st_scan_body(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ flags, int *part, int *pmax)
 {
-    __shared__ int part[kThreads];
-    __shared__ int pmax[kThreads];
     const int t = threadIdx.x;
     const int per = (nwaves + kThreads - 1) / kThreads;
     int sum = 0, mx = 0;
@@ -293,12 +290,43 @@ k_st_scan(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ flag
     int run = part[t];
     for (int i = t * per; i < (t + 1) * per && i < nwaves; ++i) { wtab[(size_t)i * 4] = run; run += wtab[(size_t)i * 4 + 2]; }
 }
+__global__ void __launch_bounds__(kThreads)
+k_st_scan(int32_t nwaves, int32_t *__restrict__ wtab, int32_t *__restrict__ flags)
+{
+    __shared__ int part[kThreads];
+    __shared__ int pmax[kThreads];
+    st_scan_body(nwaves, wtab, flags, part, pmax);
+}
+// both chunk scans of an ILU(0) with one launch (block 0: forward, block 1: backward)
+__global__ void __launch_bounds__(kThreads)
+k_st_scan_pair(int32_t nwaves, int32_t *__restrict__ wtabF, int32_t *__restrict__ flagsF, int32_t *__restrict__ wtabB, int32_t *__restrict__ flagsB)
+{
+    __shared__ int part[kThreads];
+    __shared__ int pmax[kThreads];
+    if (blockIdx.x == 0) st_scan_body(nwaves, wtabF, flagsF, part, pmax); else st_scan_body(nwaves, wtabB, flagsB, part, pmax);
+}
 
-__global__ void k_st_inv(int32_t nslots, const int32_t *__restrict__ uslot, int32_t *__restrict__ inv)
+// inverse of the slot map, and where the backward sweep finds its right-hand side (k_lm_ysrc, sptrsv_lm.hip) -- one launch
+__global__ void k_st_inv_ysrc(int32_t nslots, const int32_t *__restrict__ uslot, int32_t *__restrict__ inv, const int32_t *__restrict__ scount,
+                              const int32_t *__restrict__ wtabL, const int32_t *__restrict__ skewL, int32_t *__restrict__ ysrc)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < nslots && uslot[f] >= 0) inv[uslot[f]] = f;
+    if (f >= nslots) return;
+    const int su = uslot[f];
+    if (su < 0) return;
+    inv[su] = f;
+    const int w = f >> 6;
+    ysrc[su] = (wtabL[(size_t)w * 4] + (scount[f] - 1 + skewL[f] - wtabL[(size_t)w * 4 + 1])) * 64 + (f & 63);
 }
+// the arrays the analysis wants cleared, with one launch (each memset is a launch of its own: 5 us of a 450 us analysis apiece)
+struct StClearList { int32_t *p[4]; int32_t v[4]; int32_t n[4]; };
+__global__ void k_st_clear(StClearList L)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (L.p[q] && i < L.n[q]) L.p[q][i] = L.v[q];
+}
+
 
 // analysis 3 (forward lanes, after the chunk tables): where the lane's rows sit in the backward sweep's records, and
 // where each of their upper entries a(r, r+o) goes: into the record of row r+o, as the transposed entry of that row's
@@ -1379,6 +1407,69 @@ k_st_xch_layout(const int32_t *__restrict__ exported, const int32_t *__restrict_
         if (total > 64) atomicOr(&flags[9], 4);          // (st_wave.hip's courier exports with one store instruction per step)
     }
 }
+// the exchange layouts of BOTH schedules of an ILU(0) and the offsets of their rows with one launch: block (w, d) lays out workgroup w
+// of direction d (k_st_xch_layout's job); the last block of a direction to finish scans that direction's sizes (an atomic ticket;
+// sizes through agent-scope stores and loads: the blocks sit on different XCDs) and writes the row offsets and tot[2 d] = the offset
+// of the last workgroup, tot[2 d + 1] = its size.  (Before: a launch for the layout, two for the scan, one for the offsets, per direction
+// -- 5 us each in an analysis of 450.)
+struct StXchArgs { const int32_t *exported, *ltab, *wtab; int32_t *xe, *xw, *xsz, *flags; };
+__global__ void __launch_bounds__(kThreads)
+k_st_xch_pair(StXchArgs F, StXchArgs B, int32_t nwg, int32_t *__restrict__ tot)
+{
+    __shared__ int s_cnt[4], s_pairs, s_last;
+    __shared__ int part[kThreads];
+    const StXchArgs &X = blockIdx.y == 0 ? F : B;
+    const int wg = blockIdx.x, t = threadIdx.x, wv = t >> 6;
+    const int slot = wg * kThreads + t;
+    const int32_t *T = X.ltab + (size_t)slot * kStTab;
+    const bool ex = T[ST_CNT] > 0 && X.exported[slot] != 0;
+    if (t == 0) s_pairs = 0;
+    __syncthreads();
+    int ng = 0;
+    for (int j = 0; j < 3; ++j) ng += (j < T[ST_ND] && T[ST_CNT] > 0 && (T[ST_SRC + j] & 3) == ST_GHOST) ? 1 : 0;
+    if (ng) atomicAdd(&s_pairs, ng);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(ex);
+    if ((t & 63) == 0) s_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < wv; ++q) before += s_cnt[q];
+    X.xe[slot] = ex ? before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0)) : -1;
+    if (t == 0) {
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const int E = (total + 15) & ~15;
+        int tlo = 0x7fffffff, thi = -0x7fffffff;
+        for (int q = 0; q < 4; ++q) {
+            const int a = X.wtab[(size_t)(wg * 4 + q) * 4 + 1], b = X.wtab[(size_t)(wg * 4 + q) * 4 + 2];
+            if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
+        }
+        if (thi <= tlo) { tlo = 0; thi = 0; }
+        tlo &= ~(kStXAlign - 1);
+        X.xw[wg * 4 + 0] = E; X.xw[wg * 4 + 1] = tlo; X.xw[wg * 4 + 2] = thi - tlo;
+        st_agent_i32(&X.xsz[wg], E * (thi - tlo));
+        if (s_pairs > 64) atomicOr(&X.flags[0], 32);
+        if (total > 64) atomicOr(&X.flags[9], 4);          // (st_wave.hip's courier exports with one store instruction per step)
+        __threadfence();
+        s_last = atomicAdd(&X.flags[11], 1) == nwg - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // exclusive scan of this direction's sizes (one block)
+    const int per = (nwg + kThreads - 1) / kThreads;
+    int sum = 0;
+    for (int i = t * per; i < (t + 1) * per && i < nwg; ++i) sum += ld_agent_i32(&X.xsz[i]);
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) { int run = 0; for (int i = 0; i < kThreads; ++i) { const int c = part[i]; part[i] = run; run += c; } }
+    __syncthreads();
+    int run = part[t];
+    for (int i = t * per; i < (t + 1) * per && i < nwg; ++i) {
+        const int c = ld_agent_i32(&X.xsz[i]);
+        X.xw[i * 4 + 3] = run;
+        if (i == nwg - 1) { tot[2 * blockIdx.y] = run; tot[2 * blockIdx.y + 1] = c; }
+        run += c;
+    }
+}
 __global__ void k_st_xch_rows(int32_t nwg, const int32_t *__restrict__ xoff, int32_t *__restrict__ xw)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1431,53 +1522,53 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     lm_link_factor(st, fwd, bwd, pu);                   // forward slot -> backward slot of the same chain (flags[3] when there is none)
     hipLaunchKernelGGL(k_st_link_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew, pu->skew,
                        pl->wtab, pu->wtab, pl->flags, pu->flags, st_wx_on() ? 1 : 0);
-    hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags);
-    hipLaunchKernelGGL(k_st_scan, dim3(1), dim3(kThreads), 0, st, nwg * 4, pu->wtab, pu->flags);
+    hipLaunchKernelGGL(k_st_scan_pair, dim3(2), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags, pu->wtab, pu->flags);
     int32_t *inv = nullptr;
     ILUPP_HIP(pool_malloc(&inv, sizeof(int32_t) * (size_t)nslots));
-    ILUPP_HIP(hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)nslots, st));
+    ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
     const unsigned gb = (unsigned)((nslots + 255) / 256);
-    hipLaunchKernelGGL(k_st_inv, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv);
     // the rows pass' lane records (behind nslots unused ints); with them the lane fields and lane-level checks of the factor kernel
     // that reads A's values where they lie (st_direct.hip; its verdict: pl->flags[8])
     const bool try_direct = st_direct_prepare(st, A, fwd, pl->flags + 8);
+    {
+        // (what has to be cleared: one launch)
+        StClearList cl;
+        cl.p[0] = inv; cl.v[0] = -1; cl.n[0] = nslots;
+        cl.p[1] = pu->ysrc; cl.v[1] = 0; cl.n[1] = nslots;
+        cl.p[2] = nullptr; cl.v[2] = 0; cl.n[2] = 0;
+        cl.p[3] = nullptr; cl.v[3] = 0; cl.n[3] = 0;
+        hipLaunchKernelGGL(k_st_clear, dim3(gb), dim3(256), 0, st, cl);
+    }
+    hipLaunchKernelGGL(k_st_inv_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
     ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots * 33));
     hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
                        f->xbase + nslots, pl->flags, A.ptr, try_direct ? pl->flags + 8 : static_cast<int32_t *>(nullptr));
     if (try_direct) st_direct_verify(st, A, fwd, pl, pu, pl->flags + 8);
-    ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
-    ILUPP_HIP(hipMemsetAsync(pu->ysrc, 0, sizeof(int32_t) * (size_t)nslots, st));
-    hipLaunchKernelGGL(k_lm_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
     // the exchange layouts of both schedules; their sizes come back with the flags (one wait for all)
     int32_t xtot[2][2];
     int32_t *xsz = nullptr;
-    void *tmp2 = nullptr;
     int32_t hl[12], hu[12];
     {
-        ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * (size_t)nwg * 4));
+        ILUPP_HIP(pool_malloc(&xsz, sizeof(int32_t) * ((size_t)nwg * 2 + 4)));
         PackedSweep *pp[2] = {pl, pu};
         const Schedule *ss[2] = {&fwd, &bwd};
-        size_t tb2 = 0;
-        ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, xsz, xsz + nwg, nwg, st));
-        ILUPP_HIP(pool_malloc(&tmp2, tb2));
-        D2HItem items[6];
+        StXchArgs xa[2];
         for (int d = 0; d < 2; ++d) {
-            int32_t *sz = xsz + 2 * d * nwg, *off = sz + nwg;
             ILUPP_HIP(pool_malloc(&pp[d]->xe, sizeof(int32_t) * (size_t)nslots));
             ILUPP_HIP(pool_malloc(&pp[d]->xw, sizeof(int32_t) * (size_t)nwg * 4));
-            hipLaunchKernelGGL(k_st_xch_layout, dim3((unsigned)nwg), dim3(kThreads), 0, st, ss[d]->exported, pp[d]->ltab, pp[d]->wtab,
-                               pp[d]->xe, pp[d]->xw, sz, pp[d]->flags);
-            ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, sz, off, nwg, st));
-            hipLaunchKernelGGL(k_st_xch_rows, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, nwg, off, pp[d]->xw);
-            items[2 * d] = {&xtot[d][0], off + (nwg - 1), sizeof(int32_t)};
-            items[2 * d + 1] = {&xtot[d][1], sz + (nwg - 1), sizeof(int32_t)};
+            xa[d].exported = ss[d]->exported; xa[d].ltab = pp[d]->ltab; xa[d].wtab = pp[d]->wtab;
+            xa[d].xe = pp[d]->xe; xa[d].xw = pp[d]->xw; xa[d].xsz = xsz + (size_t)d * nwg; xa[d].flags = pp[d]->flags;
         }
-        items[4] = {hl, pl->flags, sizeof(hl)};
-        items[5] = {hu, pu->flags, sizeof(hu)};
-        ILUPP_HIP(d2h_async_many(st, items, 6));
+        int32_t *tot = xsz + (size_t)nwg * 2;
+        hipLaunchKernelGGL(k_st_xch_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, xa[0], xa[1], (int32_t)nwg, tot);
+        D2HItem items[3];
+        items[0] = {&xtot[0][0], tot, 4 * sizeof(int32_t)};
+        items[1] = {hl, pl->flags, sizeof(hl)};
+        items[2] = {hu, pu->flags, sizeof(hu)};
+        ILUPP_HIP(d2h_async_many(st, items, 3));
     }
     ILUPP_HIP(stream_sync(st));
-    ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(xsz)); ILUPP_HIP(pool_free(tmp2));
+    ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(xsz));
     // row slots of the chunks against rows: lines of 8 rows in a 16 x 16 patch (30 steps of skew) are 4.75 slots per row, and
     // still 400 times faster than what the other generations make of 90 000 such lines
     const int64_t lim = 6 * (int64_t)A.n + 64 * 4 * (int64_t)nwg;

@@ -291,6 +291,8 @@ int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t);
 /* which kernel family built this object ("ilu0:static-direct", "ilu0:static-level-major", "ilu0:level-major", "ilu0:level-order",
  * "ilu0:csr-program", "ilu0:csr", "ilut", "ichol0", "icholt"): bench.py names the kernel its roofline line is about */
 const char *ilupp_hip_path(const ilupp_precond *p);
+/* measurement hook: the kernels a static ILU(0) object runs, "factor;forward sweep;backward sweep" ("" otherwise); no counterpart in binding.cpp */
+const char *ilupp_hip_kernel_names(const ilupp_precond *p);
 /* redo the numeric phase on (possibly new) values with the SAME pattern (buffers reused); times it */
 int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices,
                                    const int32_t *d_indptr);
