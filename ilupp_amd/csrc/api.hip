@@ -1591,6 +1591,71 @@ int ilupp_hip_ml_apply(ilupp_ml *m, double *x, int64_t len, int transpose)
     API_CATCH
 }
 
+namespace {
+// the matrix of a solve in HBM and its preconditioner, built under the construction lock
+int solve_build(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const ilupp_ml_params *params, DevMat *A,
+                ilupp_ml **m)
+{
+    API_TRY_BUILD
+    int rc = validate(indptr, n);
+    if (rc) return rc;
+    const int64_t nnz = indptr[n];
+    A->n = n; A->nnz = nnz; A->is_csr = is_csr != 0; A->owns = true;
+    ILUPP_HIP(pool_malloc(&A->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&A->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(pool_malloc(&A->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    ILUPP_HIP(hipMemcpy(A->ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A->idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    ILUPP_HIP(hipMemcpy(A->val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    return ml_create_common(*A, params, m);
+    API_CATCH
+}
+}  // namespace
+
+int ilupp_hip_solve(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const double *rhs, int64_t rhs_len,
+                    double rtol, double atol, int32_t max_iter, const ilupp_ml_params *params, double *x, int32_t *iterations, double *rel_reached,
+                    double *abs_reached)
+{
+    if (!data || !indices || !indptr || !rhs || !params || !x) { set_error("null argument"); return ILUPP_ERR_INVALID; }
+    if (n <= 0) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+    if (rhs_len != n) { set_error("right-hand side has wrong size!"); return ILUPP_ERR_WRONG_SIZE; }            // binding.cpp:209-210
+    struct Guard {
+        DevMat A, T; ilupp_ml *m = nullptr;
+        ~Guard() { try { if (m) { (void)hipStreamSynchronize(m->obj[0]->stream); ml_destroy(m); } } catch (...) {} A.release(); T.release(); }
+    } g;
+    { const int rc = solve_build(data, indices, indptr, n, is_csr, params, &g.A, &g.m); if (rc) return rc; }
+    API_TRY
+    ilupp_ml *m = g.m;
+    hipStream_t st = m->obj[0]->stream;
+    const DevMat *R = &g.A;                                    // the rows of A, for the products
+    if (!g.A.is_csr) { transpose_storage(st, g.A, &g.T); R = &g.T; }
+    PoolBlock b_r, b_y, b_t;
+    for (PoolBlock *b : {&b_r, &b_y, &b_t}) ILUPP_HIP(b->alloc(sizeof(double) * (size_t)n));
+    struct SyncOnExit { hipStream_t st; ~SyncOnExit() { (void)hipStreamSynchronize(st); } } quiesce{st};      // (before the blocks go back)
+    double *r = b_r.as<double>(), *y = b_y.as<double>(), *tmp = b_t.as<double>();
+    ILUPP_HIP(hipMemcpyAsync(r, rhs, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    { const int rc = ml_apply_dev(m, r, 0, 1); if (rc) return rc; }                                              // r = L' b (preconditioned_rhs)
+    auto op = [&](const double *in, double *out) -> int {       // out = L'(A(R' in))
+        ILUPP_HIP(hipMemcpyAsync(tmp, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        int rc = ml_apply_dev(m, tmp, 0, 2);
+        if (rc) return rc;
+        rc = ilupp_hip_spmv_device(R->val, R->idx, R->ptr, n, R->nnz, tmp, out, st);
+        if (rc) return rc;
+        return ml_apply_dev(m, out, 0, 1);
+    };
+    int32_t it = 0; double rel = 0.0, res = 0.0;
+    { const int rc = bicgstab_split(st, n, op, r, y, 1, max_iter, rtol, atol, &it, &rel, &res); if (rc) return rc; }
+    { const int rc = ml_apply_dev(m, y, 0, 2); if (rc) return rc; }                                              // x = R' y (adapt_solution)
+    { const int rc = ml_finish_apply(m); if (rc) return rc; }
+    ILUPP_HIP(hipMemcpy(x, y, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    if (iterations) *iterations = it;
+    if (rel_reached) *rel_reached = rel;
+    if (abs_reached) *abs_reached = res;
+    if (!(rel < rtol && res < atol)) { set_error("did not converge"); return ILUPP_ERR_NOT_CONVERGED; }         // iterative_solvers_implementation.h:497
+    return ILUPP_OK;
+    API_CATCH
+}
+
 int ilupp_hip_ml_sync(ilupp_ml *m)
 {
     API_TRY

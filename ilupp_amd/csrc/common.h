@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -285,6 +286,9 @@ int st_make_csr(hipStream_t st, int32_t n, const PackedSweep &pl, const PackedSw
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
+// krylov.hip: BiCGstab with SPLIT preconditioning on device vectors (iterative_solvers_implementation.h:385-530 from the zero vector)
+int bicgstab_split(hipStream_t st, int32_t n, const std::function<int(const double *, double *)> &op, double *r, double *y, int32_t min_iter,
+                   int32_t max_iter, double rtol, double atol, int32_t *it_out, double *rel_out, double *res_out);
 void fill_u64(hipStream_t st, unsigned long long *p, int64_t count, unsigned long long v);
 int device_cu_count();
 int32_t min_row_len(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, int diag_at);
@@ -368,7 +372,7 @@ int ilucp_factor(hipStream_t st, const DevMat &C, int32_t max_fill_in, double th
 
 // ml.hip: the multilevel preconditioner built from such levels (reference preconditioner_implementation.h:1350-1665, :433-488)
 enum { ML_PRE_NORMALIZE_COLUMNS = 1, ML_PRE_NORMALIZE_ROWS = 2, ML_PRE_PQ_ORDERING = 3, ML_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,
-       ML_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5, ML_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6, ML_PRE_SPARSE_FIRST_ORDERING = 7 };    // = ILUPP_PRE_* of include/ilupp_hip.h
+       ML_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5, ML_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6, ML_PRE_SPARSE_FIRST_ORDERING = 7, ML_PRE_SYMM_PQ = 8 };    // = ILUPP_PRE_* of include/ilupp_hip.h
 struct MlParams {
     double threshold = 0.0;
     int n_pre = 0;

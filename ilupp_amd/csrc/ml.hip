@@ -111,6 +111,16 @@ __global__ void k_ml_pq_candidates(int32_t n, const int32_t *__restrict__ ptr, c
     J[k] = jk;
 }
 
+// sym_ddPQ's weight of a row (:4930-4936): the absolute row sum in storage order, times the number of stored entries
+__global__ void k_ml_sym_pq_weights(int32_t n, const int32_t *__restrict__ ptr, const double *__restrict__ val, double *__restrict__ W)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double w = 0.0;
+    for (int j = ptr[k]; j < ptr[k + 1]; ++j) w = w + fabs(val[j]);
+    W[k] = w * (double)(ptr[k + 1] - ptr[k]);
+}
+
 // vector_dense<T>::quicksort(index_list&, left, right), :471-505
 static void ref_quicksort(double *data, int32_t *list, long left, long right)
 {
@@ -268,6 +278,42 @@ __global__ void k_ml_pq_rest(int32_t n, int32_t *__restrict__ ip, const int32_t 
     if (r < n && flag[r]) ip[r] = rank[n] + off[r];
 }
 
+// Indices by increasing weight, as vector_dense::quicksort(list, 0, n-1) leaves them.  With all weights distinct the order is unique: a
+// radix sort on the device.  With equal weights (every interior row of a stencil matrix has the same) the order among them is whatever
+// the reference's unstable quicksort (sparse_implementation.h:471-505) leaves -- then that algorithm runs, on the host, on the n weights.
+// w: the weights (kept); ws / order: the sorted weights and the list that followed them, device arrays of n.
+static int sort_weights(hipStream_t st, int32_t n, const double *w, double *ws, int32_t *order, const char *what)
+{
+    if (n <= 0) return ILUPP_OK;
+    const int gb = (n + 255) / 256;
+    PoolBlock b_I, b_flag, b_tmp;
+    ILUPP_HIP(b_I.alloc(sizeof(int32_t) * (size_t)n));
+    ILUPP_HIP(b_flag.alloc(64));
+    ILUPP_HIP(hipMemsetAsync(b_flag.p, 0, 64, st));
+    iota_i32(st, b_I.as<int32_t>(), n);
+    size_t tb = 0;
+    ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, w, ws, b_I.as<int32_t>(), order, n, 0, 64, st));
+    ILUPP_HIP(b_tmp.alloc(tb > 0 ? tb : 1));
+    ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, w, ws, b_I.as<int32_t>(), order, n, 0, 64, st));
+    hipLaunchKernelGGL(k_ml_sorted_ties, dim3(gb), dim3(256), 0, st, n, ws, b_flag.as<int32_t>());
+    int32_t ties = 0;
+    ILUPP_HIP(hipMemcpyAsync(&ties, b_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ILUPP_HIP(hipStreamSynchronize(st));
+    if (ties) {
+        std::vector<double> W((size_t)n);
+        std::vector<int32_t> I((size_t)n);
+        ILUPP_HIP(hipMemcpyAsync(W.data(), w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        for (int32_t k = 0; k < n; ++k) I[(size_t)k] = k;
+        ref_quicksort(W.data(), I.data(), 0, (long)n - 1);
+        ILUPP_HIP(hipMemcpyAsync(ws, W.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+        ILUPP_HIP(hipMemcpyAsync(order, I.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+    }
+    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ml: %s sorted %s\n", what, ties ? "on the host (equal weights)" : "on the device");
+    return ILUPP_OK;
+}
+
 // matrix_sparse::preprocess (:5214-5460) for the steps this build has; A: ROW storage, replaced by the preprocessed matrix.
 // P, Q, invP, invQ (permutation_rows / _columns of the level and their inverses), Drow, Dcol: device arrays of n entries.
 static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32_t *P, int32_t *Q, int32_t *invP, int32_t *invQ, double *Drow, double *Dcol,
@@ -317,38 +363,12 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
             break;
         case ML_PRE_PQ_ORDERING: {                                             // :5264-5275
             if (!pq_done) {
-                PoolBlock b_J, b_W2, b_I, b_I2, b_flag, b_tmp, b_sel, b_rank, b_off;
+                PoolBlock b_J, b_W2, b_I2, b_sel, b_rank, b_off;
                 ILUPP_HIP(b_J.alloc(sizeof(int32_t) * (size_t)n));
                 hipLaunchKernelGGL(k_ml_pq_candidates, dim3(gb), dim3(256), 0, st, n, A->ptr, A->idx, A->val, b_D.as<double>(), b_J.as<int32_t>());
-                // The candidates by increasing weight.  With all weights distinct the order is unique: a radix sort on the device.  With equal
-                // weights (every interior row of a stencil matrix has the same) the order among them is whatever the reference's unstable
-                // quicksort (sparse_implementation.h:471-505) leaves -- then that algorithm runs, on the host, on the n weights.
                 ILUPP_HIP(b_W2.alloc(sizeof(double) * (size_t)n));
-                ILUPP_HIP(b_I.alloc(sizeof(int32_t) * (size_t)n));
                 ILUPP_HIP(b_I2.alloc(sizeof(int32_t) * (size_t)n));
-                ILUPP_HIP(b_flag.alloc(64));
-                ILUPP_HIP(hipMemsetAsync(b_flag.p, 0, 64, st));
-                iota_i32(st, b_I.as<int32_t>(), n);
-                size_t tb = 0;
-                ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b_D.as<double>(), b_W2.as<double>(), b_I.as<int32_t>(), b_I2.as<int32_t>(), n, 0, 64, st));
-                ILUPP_HIP(b_tmp.alloc(tb > 0 ? tb : 1));
-                ILUPP_HIP(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_D.as<double>(), b_W2.as<double>(), b_I.as<int32_t>(), b_I2.as<int32_t>(), n, 0, 64, st));
-                hipLaunchKernelGGL(k_ml_sorted_ties, dim3(gb), dim3(256), 0, st, n, b_W2.as<double>(), b_flag.as<int32_t>());
-                int32_t ties = 0;
-                ILUPP_HIP(hipMemcpyAsync(&ties, b_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                ILUPP_HIP(hipStreamSynchronize(st));
-                if (ties) {
-                    std::vector<double> W((size_t)n);
-                    std::vector<int32_t> I((size_t)n);
-                    ILUPP_HIP(hipMemcpyAsync(W.data(), b_D.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-                    ILUPP_HIP(hipStreamSynchronize(st));
-                    for (int32_t k = 0; k < n; ++k) I[(size_t)k] = k;
-                    if (n > 0) ref_quicksort(W.data(), I.data(), 0, (long)n - 1);
-                    ILUPP_HIP(hipMemcpyAsync(b_W2.p, W.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-                    ILUPP_HIP(hipMemcpyAsync(b_I2.p, I.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
-                    ILUPP_HIP(hipStreamSynchronize(st));
-                }
-                if (dbg) fprintf(stderr, "[ilupp] ml: PQ candidates sorted %s\n", ties ? "on the host (equal weights)" : "on the device");
+                { const int rc = sort_weights(st, n, b_D.as<double>(), b_W2.as<double>(), b_I2.as<int32_t>(), "PQ candidates"); if (rc) return rc; }
                 // the greedy selection, on the device (see k_ml_pq_first)
                 ILUPP_HIP(b_sel.alloc(sizeof(int32_t) * (size_t)(n + 1)));
                 ILUPP_HIP(b_rank.alloc(sizeof(int32_t) * (size_t)(n + 1)));
@@ -438,6 +458,21 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
             compose_and_invert(st, n, Q, invQ, hq, tmpi);
             ILUPP_HIP(hipStreamSynchronize(st));
             permuted_cols = true;
+            break;
+        }
+        case ML_PRE_SYMM_PQ: {                                                 // :5352-5360
+            // sym_ddPQ (:4926-4940): rows AND columns by increasing (sum of |a_ij|) * (entries of the row); its work list starts as the identity
+            PoolBlock b_W2;
+            ILUPP_HIP(b_W2.alloc(sizeof(double) * (size_t)(n > 0 ? n : 1)));
+            hipLaunchKernelGGL(k_ml_sym_pq_weights, dim3(gb), dim3(256), 0, st, n, A->ptr, A->val, b_D.as<double>());
+            { const int rc = sort_weights(st, n, b_D.as<double>(), b_W2.as<double>(), hq, "symmetric PQ weights"); if (rc) return rc; }
+            p1_filled = true;
+            hipLaunchKernelGGL(k_ml_invert_i32, dim3(gb), dim3(256), 0, st, n, hq, ihq);
+            { const int rc = permute_matrix(st, A, hq, ihq, ihq); if (rc) return rc; }     // permute(p1, p1)
+            compose_and_invert(st, n, P, invP, hq, tmpi);
+            compose_and_invert(st, n, Q, invQ, hq, tmpi);
+            ILUPP_HIP(hipStreamSynchronize(st));
+            permuted_rows = permuted_cols = true;
             break;
         }
         case ML_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM: {                         // :5441-5450

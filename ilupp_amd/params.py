@@ -10,7 +10,7 @@ from . import _native
 
 # preprocessing_type names (functions_implementation.h:94-127) the engine has kernels for -> ILUPP_PRE_* of include/ilupp_hip.h
 _BUILT_STEPS = {"NORMALIZE_COLUMNS": 1, "NORMALIZE_ROWS": 2, "PQ_ORDERING": 3, "MAX_WEIGHTED_MATCHING_ORDERING": 4,
-                "DD_SYMM_MOVE_CORNER_ORDERING_IM": 5, "UNIT_OR_ZERO_DIAGONAL_SCALING": 6, "SPARSE_FIRST_ORDERING": 7}
+                "DD_SYMM_MOVE_CORNER_ORDERING_IM": 5, "UNIT_OR_ZERO_DIAGONAL_SCALING": 6, "SPARSE_FIRST_ORDERING": 7, "SYMM_PQ": 8}
 
 
 class preprocessing_sequence(list):
@@ -48,6 +48,9 @@ class preprocessing_sequence(list):
 
     def set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ(self):
         self._set("MAX_WEIGHTED_MATCHING_ORDERING", "SYMM_PQ")
+
+    def set_NORM_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ(self):
+        self._set("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "MAX_WEIGHTED_MATCHING_ORDERING", "SYMM_PQ")
 
     def set_SPARSE_FIRST(self):
         self._set("SPARSE_FIRST_ORDERING")

@@ -48,6 +48,7 @@ typedef enum {
     ILUPP_ERR_NOT_SPD = -10,       /* ICholT: the pivot of a column is NaN (the matrix is not positive definite); the reference
                                       returns a NaN-filled factor for such input (IChol.hpp:115-117 has no positivity check) */
     ILUPP_ERR_INTERNAL = -12,      /* an invariant of this build does not hold (a bug here, never a property of the input) */
+    ILUPP_ERR_NOT_CONVERGED = -13, /* ilupp_hip_solve: binding.cpp:227 "did not converge" */
     ILUPP_ERR_DIAG_DROPPED = -11   /* ICholT: a finite pivot was dropped by the threshold or the top-k budget (dropping.hpp:8-34 does not
                                       protect it).  The reference keeps such a factor and solves with whatever entry comes first in
                                       the column; this build reports it instead (documented deviation) */
@@ -169,7 +170,7 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
  * parameters_implementation.h:927-934, e.g. default_configuration(1)) over matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) with
  * dropping by the combined weight of the standard / error-propagation / pivot rules (presets 10, 13, 1010, 1013; the inverse-based and
  * weighted rules accumulate over the steps in their sequential order and are not built), unbounded or bounded fill, levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
- * PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING, DD_SYMM_MOVE_CORNER_ORDERING_IM
+ * PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING, DD_SYMM_MOVE_CORNER_ORDERING_IM, SYMM_PQ
  * (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter combination -- the pivoting factorisation partialILUCDP of
  * the default-constructed parameters among them -- is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
  * ------------------------------------------------------------------------------------------- */
@@ -182,7 +183,8 @@ enum {                               /* preprocessing_type values (orderings.h) 
     ILUPP_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,     /* the matching itself runs on the host (sequential augmenting paths) */
     ILUPP_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5,    /* refused for matrices on which the reference's own result is undefined */
     ILUPP_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6,
-    ILUPP_PRE_SPARSE_FIRST_ORDERING = 7
+    ILUPP_PRE_SPARSE_FIRST_ORDERING = 7,
+    ILUPP_PRE_SYMM_PQ = 8                             /* rows and columns by sym_ddPQ's weights (sparse_implementation.h:4926-4940, :5352-5360) */
 };
 
 enum { ILUPP_DROP_STANDARD = 1, ILUPP_DROP_STANDARD2 = 2, ILUPP_DROP_ERR_PROP = 4, ILUPP_DROP_ERR_PROP2 = 8, ILUPP_DROP_PIVOT = 16 };
@@ -245,6 +247,18 @@ int ilupp_hip_ml_level_copy(const ilupp_ml *p, int32_t level, double *l_data, in
                             int32_t *inv_perm_rows, int32_t *inv_perm_cols, double *d_left, double *d_right);
 /* GPU milliseconds of the construction (whole, and the factorisation kernels alone) and of the last apply */
 int ilupp_hip_ml_timings(const ilupp_ml *p, float *construct_ms, float *kernel_ms, float *last_apply_ms);
+
+/* _ilupp.solve (binding.cpp:200-230, bound at :281): the multilevel preconditioner of `params` is built for A, then BiCGstab with SPLIT
+ * preconditioning runs from the zero vector (solve_with_multilevel_preconditioner, solving_routines_implementation.h:81 -> bicgstab,
+ * iterative_solvers_implementation.h:385-530) until res / initial_res <= rtol and res <= atol, or max_iter iterations (at least one).
+ * A, rhs and x are host arrays (x: n doubles, written in every case that reaches the iteration); the matrix, the preconditioner and
+ * every vector of the iteration live in HBM, the host sees one residual norm per iteration.  *iterations, *rel_reached (res /
+ * initial_res) and *abs_reached (res) are what the reference returns as (max_iter, 10^-rel_tol, 10^-abs_tol).
+ * Returns ILUPP_ERR_NOT_CONVERGED where the reference throws "did not converge", ILUPP_ERR_WRONG_SIZE for "right-hand side has wrong
+ * size!" (:209-210), and the errors of ilupp_hip_ml_create. */
+int ilupp_hip_solve(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const double *rhs, int64_t rhs_len,
+                    double rtol, double atol, int32_t max_iter, const ilupp_ml_params *params, double *x, int32_t *iterations, double *rel_reached,
+                    double *abs_reached);
 
 /* ---------------------------------------------------------------------------------------------
  * ILUCP: Crout ILU with column pivoting.  Replaces binding.cpp:343-356 (ILUCPPreconditioner.__init__ ->

@@ -1495,6 +1495,25 @@ static int mat_preprocess(orc_mat *A, const orc_ml_params *IP, orc_int *P, orc_i
             *bad_at = n;
             break;
         }
+        case ORC_PRE_SYMM_PQ: {                                                /* :5352-5360 */
+            /* sym_ddPQ, :4926-4940: rows by increasing (sum of |a_ij|) * (entries of the row); the reference's own quicksort orders ties */
+            for (i = 0; i < n; ++i) {
+                D[i] = 0.0;
+                for (j = A->ptr[i]; j < A->ptr[i + 1]; ++j) D[i] += fabs(A->val[j]);
+            }
+            for (i = 0; i < n; ++i) D[i] *= (double)(A->ptr[i + 1] - A->ptr[i]);
+            for (i = 0; i < n; ++i) p1[i] = i;
+            vec_quicksort(D, p1, 0, n - 1);
+            p1_filled = 1;
+            perm_invert(ip1, p1, n);
+            mat_permute_rows_cols(A, p1, ip1);                                 /* permute(p1, p1), :5564-5568 -> :5550-5561 */
+            perm_compose_right(P, p1, n);
+            perm_compose_right(Q, p1, n);
+            perm_invert(invP, P, n);
+            perm_invert(invQ, Q, n);
+            *bad_at = n;
+            break;
+        }
         default:
             rc = ORC_ERR_UNSUPPORTED;
         }

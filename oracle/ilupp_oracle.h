@@ -97,7 +97,8 @@ enum {                                   /* steps of a preprocessing_sequence (o
     ORC_PRE_MAX_WEIGHTED_MATCHING_ORDERING = 4,
     ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 5,
     ORC_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING = 6,
-    ORC_PRE_SPARSE_FIRST_ORDERING = 7
+    ORC_PRE_SPARSE_FIRST_ORDERING = 7,
+    ORC_PRE_SYMM_PQ = 8
 };
 
 enum { ORC_DROP_STANDARD = 1, ORC_DROP_STANDARD2 = 2, ORC_DROP_ERR_PROP = 4, ORC_DROP_ERR_PROP2 = 8, ORC_DROP_PIVOT = 16 };

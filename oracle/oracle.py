@@ -33,6 +33,7 @@ _F64P = ctypes.POINTER(ctypes.c_double)
 # steps of a preprocessing sequence (ilupp_oracle.h)
 DROP_STANDARD, DROP_STANDARD2, DROP_ERR_PROP, DROP_ERR_PROP2, DROP_PIVOT = 1, 2, 4, 8, 16
 PRE_NORMALIZE_COLUMNS, PRE_NORMALIZE_ROWS, PRE_PQ_ORDERING, PRE_MAX_WEIGHTED_MATCHING_ORDERING, PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 1, 2, 3, 4, 5
+PRE_UNIT_OR_ZERO_DIAGONAL_SCALING, PRE_SPARSE_FIRST_ORDERING, PRE_SYMM_PQ = 6, 7, 8
 ERR_UNSUPPORTED = 4
 
 

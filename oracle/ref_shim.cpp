@@ -266,6 +266,7 @@ int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
         case ORC_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM: seq.set(i) = DD_SYMM_MOVE_CORNER_ORDERING_IM; break;
         case ORC_PRE_UNIT_OR_ZERO_DIAGONAL_SCALING: seq.set(i) = UNIT_OR_ZERO_DIAGONAL_SCALING; break;
         case ORC_PRE_SPARSE_FIRST_ORDERING: seq.set(i) = SPARSE_FIRST_ORDERING; break;
+        case ORC_PRE_SYMM_PQ: seq.set(i) = SYMM_PQ; break;
         default: return ORC_ERR_UNSUPPORTED;
         }
     }

@@ -4,7 +4,7 @@ missing diagonals, huge and tiny values, symmetric patterns, CSR / CSC -- with r
 import numpy as np
 import scipy.sparse as sp
 
-STEPS = ["NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING", "MAX_WEIGHTED_MATCHING_ORDERING", "UNIT_OR_ZERO_DIAGONAL_SCALING", "SPARSE_FIRST_ORDERING"]
+STEPS = ["NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING", "MAX_WEIGHTED_MATCHING_ORDERING", "UNIT_OR_ZERO_DIAGONAL_SCALING", "SPARSE_FIRST_ORDERING", "SYMM_PQ"]
 
 
 def case(seed):

@@ -9,7 +9,7 @@ import scipy.sparse as sp
 import matgen
 
 PRE = {"NORMALIZE_COLUMNS": 1, "NORMALIZE_ROWS": 2, "PQ_ORDERING": 3, "MAX_WEIGHTED_MATCHING_ORDERING": 4, "DD_SYMM_MOVE_CORNER_ORDERING_IM": 5,
-       "UNIT_OR_ZERO_DIAGONAL_SCALING": 6, "SPARSE_FIRST_ORDERING": 7}
+       "UNIT_OR_ZERO_DIAGONAL_SCALING": 6, "SPARSE_FIRST_ORDERING": 7, "SYMM_PQ": 8}
 
 
 def laplace_matrix(n):
@@ -66,6 +66,10 @@ PARAMS = [
     ("t0.05_sf_mwm", 0.05, ("SPARSE_FIRST_ORDERING", "MAX_WEIGHTED_MATCHING_ORDERING"), {}),
     ("t0.05_mwm_unit", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "UNIT_OR_ZERO_DIAGONAL_SCALING"), {}),
     ("t0.05_mwm_pq", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "PQ_ORDERING"), {}),
+    # the symmetric PQ step (rows and columns by increasing row weight, orderings_implementation.h:573-584), alone and after the matching
+    ("t0.05_mwm_spq", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "SYMM_PQ"), {}),
+    ("t0.02_norm_mwm_spq", 0.02, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "MAX_WEIGHTED_MATCHING_ORDERING", "SYMM_PQ"), {}),
+    ("t0.1_spq", 0.1, ("SYMM_PQ",), {}),
     # bounded fill (presets 1000+: MAX_FILLIN_IS_INF false): at most fill_in entries per row of U / column of L, the largest by the
     # reference's own selection algorithm; THRESHOLD_SHIFT_SCHUR as in preset 1010
     ("t0_fill4", 0.0, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"fill_in": 4}),
@@ -111,6 +115,7 @@ PIVOT_PARAMS = [
     ("p_t0.01_pq", 1e-2, ("PQ_ORDERING",), pivoting()),                              # tests.py:346-349
     ("p_t0.01_mwm", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING",), pivoting()),          # default_configuration(10); tests.py:355-358
     ("p_t0.01_sf", 1e-2, ("SPARSE_FIRST_ORDERING",), pivoting()),                    # tests.py:373-376
+    ("p_t0.01_mwm_spq", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING", "SYMM_PQ"), pivoting()),   # tests.py:362-369
     ("p_t0.1_norm_pq", 0.1, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), pivoting()),
     ("p_t0.01_tol0.1", 1e-2, ("PQ_ORDERING",), pivoting(piv_tol=0.1)),
     ("p_t0.01_rows0_piv2", 1e-2, ("PQ_ORDERING",), pivoting(PERMUTE_ROWS=0, TOTAL_PIV=2)),

@@ -67,15 +67,15 @@ def test_ml_solve_laplace2d(setter):
     assert np.allclose(x_exact, x)
 
 
-def test_ml_solve_laplace2d_MWM_sPQ_is_refused():
-    """test/tests.py:362-369: the symmetric PQ step of this sequence has no kernel -- refused by name, nothing replaced"""
+def test_ml_solve_laplace2d_MWM_sPQ():
+    """test/tests.py:362-369, as written there"""
     import ilupp_amd as ilupp
     A, b, x_exact = example_laplace2d(900)
     param = ilupp.iluplusplus_precond_parameter()
     param.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ()
     param.threshold = 1e-2
-    with pytest.raises(NotImplementedError, match="SYMM_PQ"):
-        ilupp.solve(A, b, atol=1e-8, rtol=1e-8, params=param, info=True)
+    x, info = ilupp.solve(A, b, atol=1e-8, rtol=1e-8, params=param, info=True)
+    assert np.allclose(x_exact, x)
 
 
 def test_ml_solve_random():

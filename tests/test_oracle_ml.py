@@ -170,7 +170,7 @@ def test_everything_outside_the_built_family_is_refused():
     refused(lambda p: setattr(p, "SCALE_WGT_MAXINVDIAG", True))
     refused(lambda p: setattr(p, "SCHUR_COMPLEMENT", 1))
     refused(lambda p: setattr(p, "DROP_TYPE_L", 1))
-    refused(lambda p: p.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ())
+    refused(lambda p: p.PREPROCESSING.append("SYMM_MOVE_CORNER_ORDERING_IM"))
     refused(lambda p: setattr(p, "EXTERNAL_FINAL_ROW", True))
     refused(lambda p: setattr(p, "PRECON_PARAMETER", -1))
     refused(lambda p: setattr(p, "FINAL_ROW_CRIT", -2), start=None)       # rows by accumulated weights (a sorted container): with pivoting only
