@@ -239,12 +239,11 @@ def solve(A, b, rtol=1e-4, atol=1e-4, max_iter=500, threshold=0.1, fill_in=None,
     """Solve the linear system Ax=b using a multilevel ILU++ preconditioner and BiCGStab (reference: ilupp/__init__.py:85-119 over
     binding.cpp:199-231 -> solve_with_multilevel_preconditioner, BiCGstab with SPLIT preconditioning from the zero vector).
 
-    The matrix, the preconditioner and every vector of the iteration live in HBM; only the residual norm comes back per iteration.
+    The matrix, the preconditioner and every vector of the iteration live in HBM; only the residual norm comes back per iteration --
+    the loop itself runs inside the library (``ilupp_hip_solve`` of the C ABI, ilupp_amd/csrc/krylov.hip).
     Returns the solution (with info=True also (iterations, relative reduction reached, residual norm reached)); raises
     RuntimeError("did not converge") like the reference.  As for :class:`ILUppPreconditioner`, default-constructed parameters select the
     factorisation with pivoting (sequential: one wave); parameters of the family without pivoting use the whole GPU."""
-    import torch
-    from . import device as _dev
     if params is None:
         params = iluplusplus_precond_parameter()
         params.threshold = threshold
@@ -252,18 +251,9 @@ def solve(A, b, rtol=1e-4, atol=1e-4, max_iter=500, threshold=0.1, fill_in=None,
             params.fill_in = fill_in
     m = _borrow(A)
     b = np.ascontiguousarray(b, dtype=np.float64)
-    n = A.shape[0]
     if b.shape[0] != A.shape[1]:
         raise RuntimeError("right-hand side has wrong size!")
-    params._to_ml_params()                                    # (refuses before anything is copied)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    Acsr = A if m.is_csr else A.tocsr()
-    dA = _dev.DeviceCSR.from_scipy(Acsr, dev)
-    M = _dev.DevicePreconditioner("ILUpp", dA, params=params)
-    x, it, rel, res = _dev.bicgstab_split(dA, torch.from_numpy(b).to(dev), M, min_iter=1, max_iter=max_iter, rtol=rtol, atol=atol)
-    if not (rel < rtol and res < atol):
-        raise RuntimeError("did not converge")
-    sol = x.cpu().numpy()
+    sol, it, rel, res = _backend.solve(*m, b, rtol, atol, max_iter, params)
     return (sol, (it, rel, res)) if info else sol
 
 

@@ -150,6 +150,8 @@ def lib():
     L.ilupp_hip_ml_level_info.argtypes = [_VP, ctypes.c_int32, _I32P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     L.ilupp_hip_ml_level_copy.argtypes = [_VP, ctypes.c_int32] + [_VP] * 13
     L.ilupp_hip_ml_timings.argtypes = [_VP, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.ilupp_hip_solve.argtypes = mat_host + [_VP, ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(MLParams), _VP,
+                                             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
 
@@ -169,7 +171,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
     "ilupp_hip_ml_default_params", "ilupp_hip_ml_create", "ilupp_hip_ml_create_device", "ilupp_hip_ml_destroy", "ilupp_hip_ml_apply",
     "ilupp_hip_ml_apply_device", "ilupp_hip_ml_apply_part_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
-    "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings",
+    "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings", "ilupp_hip_solve",
     "ilupp_hip_ilucp_create", "ilupp_hip_ilucp_destroy", "ilupp_hip_ilucp_apply", "ilupp_hip_ilucp_total_nnz", "ilupp_hip_ilucp_zero_pivots",
     "ilupp_hip_ilucp_info", "ilupp_hip_ilucp_copy", "ilupp_hip_ilutp_create",
 ]
@@ -455,6 +457,24 @@ def MultilevelILUCDPPreconditioner(A_data, A_indices, A_indptr, is_csr, param):
     if rc:
         _raise(rc)
     return MultilevelPreconditioner(h, args[3])
+
+
+def solve(A_data, A_indices, A_indptr, is_csr, rhs, rtol, atol, max_iter, param):
+    """_ilupp.solve, binding.cpp:200-230: (x, iterations, relative reduction reached, residual norm reached); RuntimeError("did not
+    converge") as there.  The iteration runs inside the library (ilupp_hip_solve): no torch, no Python in the loop."""
+    p = param if isinstance(param, MLParams) else param._to_ml_params()
+    args, keep = _matrix_args(A_data, A_indices, A_indptr, is_csr)
+    b = _check_real(rhs, "b")
+    if b.shape[0] != args[3]:
+        raise RuntimeError("right-hand side has wrong size!")
+    ba = np.frombuffer(b, dtype=np.float64)
+    x = np.empty(args[3], dtype=np.float64)
+    it, rel, res = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc = lib().ilupp_hip_solve(*args, ba.ctypes.data, ba.shape[0], rtol, atol, max_iter, ctypes.byref(p), x.ctypes.data, ctypes.byref(it),
+                               ctypes.byref(rel), ctypes.byref(res))
+    if rc:
+        _raise(rc)
+    return x, it.value, rel.value, res.value
 
 
 def MultilevelILUCDPPreconditioner_device(d_data, d_indices, d_indptr, n, is_csr, param):

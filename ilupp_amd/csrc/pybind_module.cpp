@@ -316,6 +316,27 @@ PYBIND11_MODULE(_ilupp_hip, m)
             py::print("A multilevel incomplete LU factorisation:", ilupp_hip_ml_levels(f.h), "levels,", ilupp_hip_ml_total_nnz(f.h), "entries");
         });
 
+    // binding.cpp:200-230, bound at :281
+    m.def("solve", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, py::buffer rhs, double rtol, double atol, int32_t max_iter,
+                      py::object param) {
+        const Csr a = borrow(data, indices, indptr, is_csr);
+        py::buffer_info b = reals(rhs, "b");
+        if (b.shape[0] != a.n) throw std::runtime_error("right-hand side has wrong size!");
+        const ilupp_ml_params p = block_of(param);
+        py::array_t<double> result(a.n);
+        double *x = static_cast<double *>(result.request().ptr);
+        int32_t it = 0; double rel = 0.0, res = 0.0;
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = ilupp_hip_solve(a.val, a.idx, a.ptr, a.n, a.row_major, static_cast<const double *>(b.ptr), b.shape[0], rtol, atol, max_iter, &p, x, &it, &rel,
+                                 &res);
+        }
+        if (rc == ILUPP_ERR_UNSUPPORTED) { PyErr_SetString(PyExc_NotImplementedError, ilupp_hip_last_error()); throw py::error_already_set(); }
+        ok(rc);
+        return py::make_tuple(result, it, rel, res);
+    });
+
     m.def("ILU0Preconditioner", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr) {
         const Csr a = borrow(data, indices, indptr, is_csr);
         return adopt<LU>(build([&](ilupp_precond **h) { return ilupp_hip_ilu0_create(a.val, a.idx, a.ptr, a.n, a.row_major, h); }));

@@ -188,6 +188,23 @@ class _Lib:
         """multilevel ILU++ without pivoting: an ML object (levels, total_nnz, level(k), apply)"""
         return ML(self, A, params)
 
+    def solve(self, A, b, params, rtol=1e-4, atol=1e-4, max_iter=500):
+        """_ilupp.solve as the reference's binding runs it (binding.cpp:200-230; the real reference only): (x, converged, iterations,
+        10^-rel_tol, 10^-abs_tol)"""
+        if self.prefix != "ref_":
+            raise RuntimeError("solve: only the real reference has it (the engine's iteration is checked against its outputs)")
+        f = self.lib.ref_solve
+        f.restype = ctypes.c_int
+        args, keep = self._in(A)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros(args[0])
+        it, rel, res = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        ok = f(*args, ctypes.byref(params), _p_f64(b), ctypes.c_double(rtol), ctypes.c_double(atol), ctypes.c_int32(max_iter), _p_f64(x), ctypes.byref(it),
+               ctypes.byref(rel), ctypes.byref(res))
+        if ok < 0:
+            raise OracleError(ERR_UNSUPPORTED)
+        return x, bool(ok), it.value, rel.value, res.value
+
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)
 

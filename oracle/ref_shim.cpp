@@ -251,10 +251,9 @@ struct ref_ml {
     std::vector<std::vector<orc_int>> pr, pc, ipr, ipc;
 };
 
-int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, const orc_ml_params *IP, ref_ml **out)
+/* the parameter object of a case: default_parameters + init(sequence, 10) with the knobs of orc_ml_params set through the reference's setters */
+static int param_of(const orc_ml_params *IP, iluplusplus_precond_parameter &param)
 {
-    *out = nullptr;
-    matrix A = view(n, ptr, idx, val, is_csr);
     preprocessing_sequence seq;
     seq.resize(IP->n_preprocessing);
     for (int i = 0; i < IP->n_preprocessing; ++i) {
@@ -270,7 +269,6 @@ int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
         default: return ORC_ERR_UNSUPPORTED;
         }
     }
-    iluplusplus_precond_parameter param;
     param.init(seq, 10, "");
     param.set_threshold(IP->threshold);
     param.set_PQ_THRESHOLD(IP->pq_threshold);
@@ -301,6 +299,15 @@ int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const doubl
     param.set_FINAL_ROW_CRIT(IP->final_row_crit);
     param.set_MOVE_LEVEL_FACTOR(IP->move_level_factor);
     param.set_ROW_U_MAX(IP->row_u_max);
+    return ORC_OK;
+}
+
+int ref_ml_create(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, const orc_ml_params *IP, ref_ml **out)
+{
+    *out = nullptr;
+    matrix A = view(n, ptr, idx, val, is_csr);
+    iluplusplus_precond_parameter param;
+    { const int rc = param_of(IP, param); if (rc) return rc; }
     ref_ml *R = new ref_ml;
     R->n = n;
     try {
@@ -428,6 +435,22 @@ void ref_ilutp_free(void *handle) { delete static_cast<ILUTPPreconditioner<Real,
 void ref_sort_slots_by_abs_desc(orc_int *list, orc_int len, const double *key)
 {
     std::sort(list, list + len, [&](orc_int x, orc_int y) { return std::abs(key[x]) > std::abs(key[y]); });
+}
+
+/* _ilupp.solve as binding.cpp:200-230 runs it: solve_with_multilevel_preconditioner (solving_routines_implementation.h:193-217 -> BiCGstab,
+ * SPLIT, MIN_ITER 1, from the zero vector).  Returns 1 on success, 0 for "did not converge"; it / rel / res: what the binding returns. */
+int ref_solve(orc_int n, const orc_int *ptr, const orc_int *idx, const double *val, int is_csr, const orc_ml_params *IP, const double *rhs,
+              double rtol, double atol, orc_int max_iter, double *x_out, orc_int *it, double *rel, double *res)
+{
+    matrix A = view(n, ptr, idx, val, is_csr);
+    iluplusplus_precond_parameter param;
+    if (param_of(IP, param)) return -1;
+    vector b(n, const_cast<double *>(rhs), true), x(n, x_out, true), x_exact;
+    Real rel_tol = -std::log10(rtol), abs_tol = -std::log10(atol), abs_error = 0;
+    Integer iters = max_iter;
+    const bool ok = solve_with_multilevel_preconditioner(A, b, x_exact, x, false, rel_tol, abs_tol, iters, abs_error, "", "", param);
+    *it = iters; *rel = std::pow(10.0, -rel_tol); *res = std::pow(10.0, -abs_tol);
+    return ok ? 1 : 0;
 }
 
 }  // extern "C"

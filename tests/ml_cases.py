@@ -195,3 +195,29 @@ def ml_npz_cases(z):
         c, t, f = tag.split("_")
         out.append((key, tag, int(c[1:]), float(t[1:]), int(f[1:])))
     return out
+
+
+# ---- `solve` (binding.cpp:200-230): matrices with right-hand sides, and (tag, threshold, preprocessing, knobs, rtol, atol, max_iter) ----
+def solve_matrices():
+    A = laplace2d_matrix(900)                                                       # test/tests.py:344-383
+    yield "laplace2d_900", A, A @ np.ones(900)
+    d, i, p = matgen.poisson3d(12, 11, 10)
+    A = (sp.csr_matrix((d, i, p), shape=(1320, 1320)) + 0.5 * sp.diags([np.ones(1319)], [1], shape=(1320, 1320))).tocsr()
+    yield "p3d_shift_1320", A, rhs(1320)
+    A = sp.csr_matrix(matgen.random_dd(300, k=7, diag=3.0), shape=(300, 300))
+    yield "rdd_300", A, A @ np.linspace(1.0, 2.0, 300)
+    A = (sp.random(50, 50, density=0.1, random_state=39273) + 10.0 * sp.eye(50)).tocsr()       # tests.py:27-30 (stored as arrays in the fixture)
+    yield "random_50", A, A @ np.ones(50)
+
+
+_NPQ = ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING")
+SOLVE_PARAMS = [
+    ("t0.01_pq", 1e-2, _NPQ, {}, 1e-8, 1e-8, 500),
+    ("t0.1_pq_loose", 0.1, _NPQ, {}, 1e-4, 1e-4, 500),
+    ("t1_pq", 1.0, _NPQ, {}, 1e-8, 1e-8, 500),
+    ("t0.01_mwm", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING",), {}, 1e-8, 1e-8, 500),
+    ("t0.01_mwm_spq", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING", "SYMM_PQ"), {}, 1e-8, 1e-8, 500),
+    ("t0.01_pq_2it", 1e-2, _NPQ, {}, 1e-14, 1e-14, 2),                               # stops at max_iter: "did not converge"
+    ("p_t0.01_pq", 1e-2, ("PQ_ORDERING",), pivoting(), 1e-8, 1e-8, 500),             # the default-constructed parameters
+    ("p_t0.01_mwm_spq", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING", "SYMM_PQ"), pivoting(), 1e-8, 1e-8, 500),    # tests.py:362-369
+]

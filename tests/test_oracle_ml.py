@@ -195,3 +195,19 @@ def test_parameter_block_of_the_pivoting_family():
     assert p._uses_partial_iluc()
     p.piv_tol = 0.5
     assert not p._uses_partial_iluc() and p._to_ml_params().piv_tol == 0.5
+
+
+def test_solve_fixture_is_complete():
+    """tests/golden/solve.npz (make_golden_solve.py: the REAL reference's `_ilupp.solve`): every case of ml_cases.SOLVE_PARAMS on every
+    matrix, CSR and CSC; converging cases and the one that stops at max_iter"""
+    g = np.load(os.path.join(HERE, "golden", "solve.npz"))
+    names = [n for n, _, _ in C.solve_matrices()]
+    infos = [k for k in g.files if k.endswith("/info")]
+    assert len(infos) == len(names) * 2 * len(C.SOLVE_PARAMS)
+    ok = [bool(g[k][0]) for k in infos]
+    assert any(ok) and not all(ok)
+    for name, A, b in C.solve_matrices():
+        if name == "random_50":
+            continue                                            # (scipy's sampler is version dependent: the fixture's arrays are the case)
+        M = A.tocsr(); M.sort_indices()
+        assert np.array_equal(g[name + "_csr/data"], M.data) and np.array_equal(g[name + "_csr/b"], b)
