@@ -172,7 +172,7 @@ def extra_config(name, dev, steps):
         prm.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING()
         prm.threshold = 1e-3
         make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
-        what = "C5M: ILUppPreconditioner(MAX_WEIGHTED_MATCHING_ORDERING, preset 10 without pivoting, threshold=1e-3), random unsymmetric CSR n=1e6 (matching on one host core)"
+        what = "C5M: ILUppPreconditioner(MAX_WEIGHTED_MATCHING_ORDERING, preset 10 without pivoting, threshold=1e-3), random unsymmetric CSR n=1e6 (matching: initialisation on the device, log/exp on the host cores)"
     elif name == "C5P":
         # BASELINE config 5 AS NAMED: default_configuration(10) = maximum weighted matching + the factorisation WITH pivoting (partialILUCDP).
         # The factorisation is a chain of n steps (every step picks its column by the values of the step, its row by the fill so far): one

@@ -1273,6 +1273,7 @@ int ilupp_hip_release_cached_memory(void)
 {
     API_TRY
     pool_trim();
+    { std::lock_guard<std::mutex> build_lock_(ilupp::g_build_mu); mwm_release_stage(); }
     return ILUPP_OK;
     API_CATCH
 }

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <functional>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -286,6 +287,25 @@ int st_make_csr(hipStream_t st, int32_t n, const PackedSweep &pl, const PackedSw
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
+// The order vector_dense<T>::quicksort(index_list&, left, right) (sparse_implementation.h:471-505) leaves keys and their list in: an
+// unstable quicksort with the first element as pivot -- where keys are equal, the permutation that comes out IS the reference's answer,
+// so the same partition scheme runs here (host; the smaller part by recursion, the larger by the loop: the two parts are disjoint, the
+// order in which they are sorted does not matter, and the stack stays logarithmic).
+template <class T> void ref_quicksort(T *key, int32_t *list, long left, long right)
+{
+    while (left < right) {
+        const T pivot = key[left];
+        long i = left, j = right;
+        while (i <= j) {
+            while (key[i] < pivot) i++;
+            while (key[j] > pivot) j--;
+            if (i <= j) { std::swap(key[i], key[j]); std::swap(list[i], list[j]); i++; j--; }
+        }
+        if (j - left < right - i) { ref_quicksort(key, list, left, j); left = i; }
+        else { ref_quicksort(key, list, i, right); right = j; }
+    }
+}
+void mwm_release_stage();   // ml_order.hip: the pinned staging buffer of the matching
 // krylov.hip: BiCGstab with SPLIT preconditioning on device vectors (iterative_solvers_implementation.h:385-530 from the zero vector)
 int bicgstab_split(hipStream_t st, int32_t n, const std::function<int(const double *, double *)> &op, double *r, double *y, int32_t min_iter,
                    int32_t max_iter, double rtol, double atol, int32_t *it_out, double *rel_out, double *res_out);

@@ -22,9 +22,8 @@
 
 namespace ilupp {
 
-// ml_order.hip (host): the sequential ordering algorithms
-bool pmwm_host(int32_t n, const int32_t *ptr, const int32_t *idx, const double *val, std::vector<int32_t> &mate_col, std::vector<double> &inv_row,
-               std::vector<double> &inv_col);
+// ml_order.hip: the maximum-weight matching (device + host), and the orderings that are sequential algorithms on the host
+int mwm_order(hipStream_t st, const DevMat &A, int32_t *p1, double *D1, double *D2);
 bool dd_move_corner_host(int32_t n, const int32_t *ptr, const int32_t *idx, const double *val, const int32_t *tptr, const int32_t *tidx, const double *tval,
                          std::vector<int32_t> &P);
 void sparse_first_host(int32_t n, std::vector<int32_t> &counts, std::vector<int32_t> &p2);
@@ -119,28 +118,6 @@ __global__ void k_ml_sym_pq_weights(int32_t n, const int32_t *__restrict__ ptr, 
     double w = 0.0;
     for (int j = ptr[k]; j < ptr[k + 1]; ++j) w = w + fabs(val[j]);
     W[k] = w * (double)(ptr[k + 1] - ptr[k]);
-}
-
-// vector_dense<T>::quicksort(index_list&, left, right), :471-505
-static void ref_quicksort(double *data, int32_t *list, long left, long right)
-{
-    while (left < right) {
-        const double m = data[left];
-        long i = left, j = right;
-        while (i <= j) {
-            while (data[i] < m) i++;
-            while (data[j] > m) j--;
-            if (i <= j) {
-                const double t = data[i]; data[i] = data[j]; data[j] = t;
-                const int32_t u = list[i]; list[i] = list[j]; list[j] = u;
-                i++; j--;
-            }
-        }
-        // (the same two sub-ranges as the reference's two recursive calls; the smaller one by recursion, the larger by the loop: the
-        // ranges are disjoint, so the order in which they are sorted does not matter, and the stack stays logarithmic)
-        if (j - left < right - i) { ref_quicksort(data, list, left, j); left = i; }
-        else { ref_quicksort(data, list, i, right); right = j; }
-    }
 }
 
 // are two neighbours of the sorted weights equal (or is one a NaN)?  Then the order the reference's quicksort leaves them in is its own
@@ -402,31 +379,19 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
             break;
         }
         case ML_PRE_MAX_WEIGHTED_MATCHING_ORDERING: {                         // :5276-5292
-            // the matching is a sequential augmenting-path algorithm: the level's matrix goes to the host once, a permutation and two
-            // scalings come back; scaling and permuting the matrix happen on the device
+            // the matching: initialisation and first matching on the device, logarithms / exponentials and the augmenting-path searches
+            // for what is left on the host (ml_order.hip); the permutation and both scalings stay on the device
             const int64_t nnz = A->nnz;
-            std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), hp1, hip1((size_t)n);
-            std::vector<double> hv((size_t)(nnz > 0 ? nnz : 1)), D1, D2;
-            if (!p1_filled) {
-                ILUPP_HIP(hipMemcpyAsync(hp.data(), A->ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
-                if (nnz > 0) {
-                    ILUPP_HIP(hipMemcpyAsync(hi.data(), A->idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
-                    ILUPP_HIP(hipMemcpyAsync(hv.data(), A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
-                }
-                ILUPP_HIP(hipStreamSynchronize(st));
-                (void)pmwm_host(n, hp.data(), hi.data(), hv.data(), hp1, D1, D2);
-            } else {
-                hp1.resize((size_t)n);
-                for (int32_t i = 0; i < n; ++i) hp1[(size_t)i] = i;
-                D1.assign((size_t)n, 1.0); D2.assign((size_t)n, 1.0);
-            }
-            p1_filled = true;
-            for (int32_t i = 0; i < n; ++i) hip1[(size_t)hp1[(size_t)i]] = i;
             PoolBlock b_D2;
             ILUPP_HIP(b_D2.alloc(sizeof(double) * (size_t)n));
-            ILUPP_HIP(hipMemcpyAsync(b_D.p, D1.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-            ILUPP_HIP(hipMemcpyAsync(b_D2.p, D2.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-            upload_i32(st, hq, hp1); upload_i32(st, ihq, hip1);
+            if (!p1_filled) { const int rc = mwm_order(st, *A, hq, b_D.as<double>(), b_D2.as<double>()); if (rc) return rc; }
+            else {                                                             // (see above: the reference's search starts "all matched")
+                iota_i32(st, hq, n);
+                hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, b_D.as<double>(), 1.0);
+                hipLaunchKernelGGL(k_ml_fill_f64, dim3(gb), dim3(256), 0, st, n, b_D2.as<double>(), 1.0);
+            }
+            p1_filled = true;
+            hipLaunchKernelGGL(k_ml_invert_i32, dim3(gb), dim3(256), 0, st, n, hq, ihq);
             hipLaunchKernelGGL(k_ml_row_scale, dim3(gb), dim3(256), 0, st, n, A->ptr, A->val, b_D.as<double>());           // inverse_scale(D1, ROW)
             if (nnz > 0)
                 hipLaunchKernelGGL(k_ml_col_scale, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, A->idx, A->val, b_D2.as<double>());   // (D2, COLUMN)
