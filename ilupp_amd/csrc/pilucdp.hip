@@ -50,6 +50,9 @@ struct DpArgs {
     int32_t *Sptr, *Sidx; double *Sval; int32_t capS;   // the Schur complement's rows as they come (column indices of this level)
     struct DpRec *zrec, *wrec; int32_t *zlist, *wlist;     // the two working vectors (below)
     double *key; int32_t *cand; unsigned long long *sortk;
+#ifdef DP_PROF
+    long long *prof;   // shader-clock ticks per phase of a step, summed over the steps (diagnostic build only)
+#endif
     int32_t *ctrl;     // [0] status (0 done; 1 / 2 / 3: the store of U / L / the Schur complement has no room for another row: enlarge it and
                        // launch again), [1] last_row_to_eliminate, [2] n_Anew, [3] zero pivots, [4] eliminating (still / to the end),
                        // [5] the step to go on with, [6] / [7] entries of z / w to clear, [8] / [9] entries of U / L so far, [10] of the Schur complement, [11] the pivot column of the step before
@@ -138,6 +141,12 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                                             A.ctrl[5] = k; A.ctrl[6] = znnz; A.ctrl[7] = wnnz; A.ctrl[8] = pU; A.ctrl[9] = pL; A.ctrl[10] = pS; A.ctrl[11] = prev_pivot; \
                                             A.dctrl[0] = threshold; A.dctrl[1] = piv_tol; } return; } while (0)
 
+#ifdef DP_PROF
+    long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = (long long)__builtin_amdgcn_s_memtime();
+#define DP_T(i) do { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); pt[i] += now_ - t_last; t_last = now_; } while (0)
+#else
+#define DP_T(i) do {} while (0)
+#endif
     for (int k = A.ctrl[5]; k < n; ++k) {
         if ((long)pU + row_max > (long)A.capU) DP_STOP(1);
         if ((long)pL + row_max > (long)A.capL) DP_STOP(2);
@@ -172,6 +181,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             }
             DP_SYNC();
         }
+        DP_T(0);
         {                                                                           // (3.) :472-487: the rows of U this row has multipliers for
             // the list is walked three nodes ahead: a node's fields, then the pivot and the extent of the row it names, then the first 64 entries
             // of that row are on their way while the rows before it are subtracted (a node costs two dependent round trips -- the records of
@@ -191,6 +201,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                 n1 = n2; a1 = a2; t1 = t2; n2 = n3; a2 = a3; n3 = n4;
             }
         }
+        DP_T(1);
         double pivot = 0.0;
         if (eliminate) {                                                            // the pivot, :540-558
             double best = 0.0;
@@ -220,6 +231,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             last = k - 1;
             nA = n - k;
         }
+        DP_T(2);
         double dinv = 1.0;
         if (eliminate) {                                                            // :613-629
             dinv = 1.0 / pivot;
@@ -235,6 +247,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             }
             prev_pivot = pos_pivot;
             DP_SYNC();
+            DP_T(3);
             {                                                                       // the column of L, :633-651
                 const int c = pos_pivot;                                            // = perm[k] now
                 const int c0 = A.Cp[c], c1 = A.Cp[c + 1];
@@ -256,6 +269,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                     }
                 }
                 DP_SYNC();
+                DP_T(4);
                 DpNode n1 = dp_node(A.rowU, A.Uval, A.linkU, A.startU[c]);
                 DpRow a1 = dp_row(A.Dinv, A.Lptr, n1);
                 DpEnt t1 = dp_ent(A.Lidx, A.Lval, a1, lane);
@@ -271,8 +285,10 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                     n1 = n2; a1 = a2; t1 = t2; n2 = n3; a2 = a3; n3 = n4;
                 }
             }
+            DP_T(5);
             for (int s = lane; s < wnnz; s += 64) { const int r = w.list[s]; w.rec[r].val = w.rec[r].val * dinv; }     // :652
             DP_SYNC();
+            DP_T(6);
         }
         // ---- dropping in the row, :714-759 ----
         int nU;
@@ -287,6 +303,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             const double weightU = dp_weight(A, n2z, n1w, dinv);
             nU = dp_take(A, z, znnz, true, weightU, threshold, A.max_fill - 1, lane);
         }
+        DP_T(7);
         if (eliminate) {                                                            // :761-797: the 1 at the pivot's column, then the list backwards
             const int p0 = pU;
             pU += nU + 1;
@@ -311,6 +328,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             }
         }
         DP_SYNC();
+        DP_T(8);
         // ---- the column of L, :849-1005 ----
         if (eliminate) {
             const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(dp_seq_sum(w, wnnz, 1, lane)) : 0.0;
@@ -325,6 +343,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             }
             if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + nL + 1; }
             DP_SYNC();
+            DP_T(9);
             // the rows by their number of entries in L, one move per new entry and in the order of the entries (:964-970)
             if (lane == 0) {
                 for (int j = 0; j < nL; ++j) {
@@ -343,6 +362,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                 }
             }
             DP_SYNC();
+            DP_T(10);
             // a new group of rows with equally many entries begins behind this step: by increasing row index (:980-981; the reference's
             // quicksort_with_inverse leaves the rows -- all different -- in ascending order, and so does any sort)
             const int nk = A.numb[k];
@@ -388,6 +408,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                     nA = n - k - 1;
                 }
             }
+            DP_T(11);
         } else {
             const int p0 = pL;
             pL += 1;
@@ -395,8 +416,462 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             DP_SYNC();
         }
     }
+#ifdef DP_PROF
+    if (lane == 0) for (int i = 0; i < 12; ++i) A.prof[i] += pt[i];
+#endif
     if (lane == 0) { A.ctrl[0] = 0; A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; A.ctrl[5] = n; }
 #undef DP_STOP
+}
+
+// =====================================================================================================================================
+// The same chain with the two working vectors in LDS (k_pilucdp_lds).  The kernel above keeps z and w in HBM / L2: every phase of a step
+// (clear, subtract, pivot search, scale, norms, dropping, sort) is a handful of dependent round trips, ~100 per step.  Here a working
+// vector is a slot-ordered pair of LDS arrays (index, value: the reference's insertion order is the slot order) with an LDS hash table
+// index -> slot; all of those phases run at LDS latency, and what is left of the trips to memory is what the step really depends on:
+// the row / column of A, the walk along the list of multipliers (one trip per node, the fields of the next nodes, their rows' extents,
+// entries and liveness flags read ahead), the list heads for the new row and column, and the bucket moves of the rows whose count
+// grew -- prefetched for all new entries at once and applied in parallel when no two of them touch the same position (the usual case;
+// otherwise one lane applies them in order).  Global side effects of a step happen only after both vectors are complete: a step whose
+// vector outgrows its LDS capacity is abandoned untouched (status 4) and the chain goes on in the kernel above.
+constexpr int kLvCap = 2048;                    // entries a working vector may hold
+constexpr int kLvHash = 4096;                   // slots of its index -> slot table (linear probing, at most half full)
+constexpr int kPnL = 1024;                      // bucket boundaries (pnum) cached in LDS: counts below this
+
+struct LdsVec { int32_t *idx; double *val; int32_t *hkey; unsigned short *hslot; };
+
+#define LV_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")        // one wave: LDS operations complete in order; this orders the compiler
+
+__device__ __forceinline__ unsigned lv_hash(int c) { return ((unsigned)c * 0x9E3779B1u) >> 20; }
+__device__ __forceinline__ int lv_find(const LdsVec &v, int c)
+{
+    unsigned h = lv_hash(c);
+    for (;;) {
+        const int k = v.hkey[h];
+        if (k == c) return v.hslot[h];
+        if (k == -1) return -1;
+        h = (h + 1) & (kLvHash - 1);
+    }
+}
+// c is not in the table; other lanes may be entering other indices at the same time
+__device__ __forceinline__ void lv_enter(const LdsVec &v, int c, int slot)
+{
+    unsigned h = lv_hash(c);
+    for (;;) {
+        if (atomicCAS(&v.hkey[h], -1, c) == -1) { v.hslot[h] = (unsigned short)slot; return; }
+        h = (h + 1) & (kLvHash - 1);
+    }
+}
+__device__ __forceinline__ void lv_clear(const LdsVec &v, int lane)
+{
+    int4 *t = reinterpret_cast<int4 *>(v.hkey);
+    for (int i = lane; i < kLvHash / 4; i += 64) t[i] = make_int4(-1, -1, -1, -1);
+}
+// v[c] exists afterwards (operator[] inserts a zero); false: no room
+__device__ __forceinline__ bool lv_touch(const LdsVec &v, int &nnz, int c, int lane)
+{
+    if (lv_find(v, c) >= 0) return true;
+    if (nnz >= kLvCap) return false;
+    if (lane == 0) { v.idx[nnz] = c; v.val[nnz] = 0.0; lv_enter(v, c, nnz); }
+    ++nnz;
+    LV_SYNC();
+    return true;
+}
+// the row / column `who` of A (entries e0 .. e1 of ai / av) into an empty vector: entries whose index is alive (and is not `dead`), a
+// doubly stored index keeps its last value; false: no room
+__device__ __forceinline__ bool lv_load(const LdsVec &v, int &nnz, const int32_t *ai, const double *av, int e0, int e1, const int32_t *alive, int dead, int lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = e0; base < e1; base += 64) {
+        const int e = base + lane;
+        const bool act = e < e1;
+        const int c = act ? ai[e] : -1;
+        const int pc = (act && e > e0) ? ai[e - 1] : -1;
+        const double x = act ? av[e] : 0.0;
+        const bool ok = act && c != dead && alive[c] != 0;
+        const bool first = ok && c != pc;
+        const unsigned long long mask = __ballot(first);
+        if (nnz + __popcll(mask) > kLvCap) return false;
+        if (first) { const int s = nnz + __popcll(mask & lt); v.idx[s] = c; v.val[s] = x; lv_enter(v, c, s); }
+        nnz += __popcll(mask);
+        const unsigned long long dup = __ballot(ok && !first);
+        if (dup) {
+            LV_SYNC();
+            for (int b = 0; b < 64; ++b)
+                if ((dup >> b) & 1ull) { const int cb = __shfl(c, b); const double xb = __shfl(x, b); if (lane == 0) v.val[lv_find(v, cb)] = xb; LV_SYNC(); }
+        }
+    }
+    LV_SYNC();
+    return true;
+}
+// sum of |x| (mode 0) or x * x (mode 1) over the slots in order
+__device__ __forceinline__ double lv_seq_sum(const LdsVec &v, int nnz, int mode, int lane)
+{
+    double acc = 0.0;
+    for (int base = 0; base < nnz; base += 64) {
+        const int s = base + lane;
+        const double x = s < nnz ? v.val[s] : 0.0;
+        const double t = mode == 0 ? fabs(x) : x * x;
+        const int cnt = nnz - base < 64 ? nnz - base : 64;
+        for (int i = 0; i < cnt; ++i) { const double ti = __shfl(t, i); acc = acc + ti; }
+    }
+    return acc;
+}
+
+struct DpLive { int ok; };
+__device__ __forceinline__ DpLive dp_live(const int32_t *alive, const DpEnt &t, const DpRow &r, int lane)
+{
+    DpLive l{0};
+    if (r.e0 + lane < r.e1) l.ok = alive[t.c];
+    return l;
+}
+
+// v -= (value of the node / pivot of its row) * (row of the other factor), for every node of the list from `start`, in list order; new
+// indices are appended in entry order.  Nodes, extents, entries and liveness flags are read four nodes ahead.  false: no room.
+__device__ __forceinline__ bool lv_subtract_list(const LdsVec &v, int &nnz, int start, const int32_t *who, const double *nval, const int32_t *link,
+                                                 const double *Dinv, const int32_t *ptr, const int32_t *eidx, const double *eval, const int32_t *alive, int dead,
+                                                 int lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    DpNode n1 = dp_node(who, nval, link, start);
+    DpRow a1 = dp_row(Dinv, ptr, n1);
+    DpNode n2 = dp_node(who, nval, link, n1.link);
+    DpEnt t1 = dp_ent(eidx, eval, a1, lane);
+    DpRow a2 = dp_row(Dinv, ptr, n2);
+    DpNode n3 = dp_node(who, nval, link, n2.link);
+    DpLive l1 = dp_live(alive, t1, a1, lane);
+    DpEnt t2 = dp_ent(eidx, eval, a2, lane);
+    DpRow a3 = dp_row(Dinv, ptr, n3);
+    DpNode n4 = dp_node(who, nval, link, n3.link);
+    while (n1.at != -1) {
+        const DpLive l2 = dp_live(alive, t2, a2, lane);
+        const DpEnt t3 = dp_ent(eidx, eval, a3, lane);
+        const DpRow a4 = dp_row(Dinv, ptr, n4);
+        const DpNode n5 = dp_node(who, nval, link, n4.link);
+        const double f = n1.v / a1.dinv;
+        for (int base = a1.e0; base < a1.e1; base += 64) {
+            const int e = base + lane;
+            const bool act = e < a1.e1;
+            int c; double ev; int live;
+            if (base == a1.e0) { c = t1.c; ev = t1.v; live = l1.ok; }
+            else { c = act ? eidx[e] : 0; ev = act ? eval[e] : 0.0; live = act ? alive[c] : 0; }
+            const bool ok = act && live != 0 && c != dead;
+            const int slot = ok ? lv_find(v, c) : -1;
+            const bool isnew = ok && slot < 0;
+            const unsigned long long mask = __ballot(isnew);
+            if (nnz + __popcll(mask) > kLvCap) return false;
+            if (ok) {
+                const double prod = f * ev;
+                if (isnew) { const int s = nnz + __popcll(mask & lt); v.idx[s] = c; v.val[s] = 0.0 - prod; lv_enter(v, c, s); }
+                else v.val[slot] = v.val[slot] - prod;
+            }
+            nnz += __popcll(mask);
+            LV_SYNC();
+        }
+        n1 = n2; a1 = a2; t1 = t2; l1 = l2; n2 = n3; a2 = a3; t2 = t3; n3 = n4; a3 = a4; n4 = n5;
+    }
+    return true;
+}
+
+// the slots that pass the dropping rule, in insertion order, at most `limit` of them (the largest keys, by the reference's selection);
+// afterwards sortk[0 .. return) = (index << 32 | slot) ascending by index
+__device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, double thr, int limit, double *key, int32_t *cand, unsigned long long *sortk, int lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cnt = 0;
+    for (int base = 0; base < nnz; base += 64) {
+        const int s = base + lane;
+        const bool act = s < nnz;
+        const double x = act ? v.val[s] : 0.0;
+        const double kx = single ? weight * fabs(x) : fabs(x);
+        const bool ok = act && (single ? kx >= thr : kx > thr);
+        const unsigned long long mask = __ballot(ok);
+        if (ok) { const int p = cnt + __popcll(mask & lt); cand[p] = s; key[p] = kx; }
+        cnt += __popcll(mask);
+    }
+    int off = 0;
+    LV_SYNC();
+    if (cnt > limit) {
+        if (lane == 0 && limit > 0) select_largest(key, cand, 0, cnt - 1, limit);
+        off = cnt - limit;
+        LV_SYNC();
+    }
+    const int nk = cnt - off;
+    auto keyof = [&](int i) { const int s = cand[off + i]; return ((unsigned long long)(unsigned)v.idx[s] << 32) | (unsigned)s; };
+    if (nk <= 64) {
+        const unsigned long long sorted = dp_sort64(lane < nk ? keyof(lane) : ~0ull, lane);
+        if (lane < nk) sortk[lane] = sorted;
+        LV_SYNC();
+        return nk;
+    }
+    int N = 64;
+    while (N < nk) N *= 2;
+    for (int i = lane; i < N; i += 64) sortk[i] = i < nk ? keyof(i) : ~0ull;
+    LV_SYNC();
+    wave_sort_u64<false>(sortk, N, lane);
+    LV_SYNC();
+    return nk;
+}
+
+__global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
+{
+    __shared__ __attribute__((aligned(16))) int32_t s_zidx[kLvCap], s_widx[kLvCap], s_zh[kLvHash], s_wh[kLvHash], s_cand[kLvCap], s_pnum[kPnL];
+    __shared__ __attribute__((aligned(16))) double s_zval[kLvCap], s_wval[kLvCap], s_key[kLvCap];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_sort[kLvCap];
+    __shared__ unsigned short s_zs[kLvHash], s_ws[kLvHash];
+    const int lane = threadIdx.x;
+    const int n = A.n;
+    const LdsVec z{s_zidx, s_zval, s_zh, s_zs}, w{s_widx, s_wval, s_wh, s_ws};
+    int znnz = 0, wnnz = 0;
+    bool eliminate = A.ctrl[4] != 0, end_level_now = false;
+    double piv_tol = A.dctrl[1], threshold = A.dctrl[0];
+    int last = A.ctrl[1], nA = A.ctrl[2], zero_piv = A.ctrl[3], pos_pivot = -1;
+    int pU = A.ctrl[8], pL = A.ctrl[9], pS = A.ctrl[10];
+    const double nnzA = (double)A.Cp[n];
+    const int row_max = (A.max_fill < n ? A.max_fill : n) + 1;
+    const int npn = n + 2 < kPnL ? n + 2 : kPnL;
+    for (int i = lane; i < npn; i += 64) s_pnum[i] = A.pnum[i];
+    LV_SYNC();
+#define DPL_STOP(code) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) { A.ctrl[0] = (code); A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; \
+                                             A.ctrl[5] = k; A.ctrl[6] = 0; A.ctrl[7] = 0; A.ctrl[8] = pU; A.ctrl[9] = pL; A.ctrl[10] = pS; A.ctrl[11] = -1; \
+                                             A.dctrl[0] = threshold; A.dctrl[1] = piv_tol; } return; } while (0)
+    for (int k = A.ctrl[5]; k < n; ++k) {
+        if ((long)pU + row_max > (long)A.capU) DPL_STOP(1);
+        if ((long)pL + row_max > (long)A.capL) DPL_STOP(2);
+        if (!eliminate && (long)pS + row_max > (long)A.capS) DPL_STOP(3);
+        const double piv_tol_step = (A.begin_total_piv && k == A.bp) ? 1.0 : piv_tol;        // :448 (kept only when the step is)
+        const int sel = A.prow[k];                                                  // (2.) :453-466
+        const int nk_at_k = A.numb[k];
+        const int perm_k = A.perm[k];
+        lv_clear(z, lane); lv_clear(w, lane);
+        znnz = wnnz = 0;
+        const int r0 = A.Ap[sel], r1 = A.Ap[sel + 1], head = A.startL[sel];
+        const int sel_alive = A.nonpiv[sel];
+        LV_SYNC();
+        if (!lv_load(z, znnz, A.Ai, A.Av, r0, r1, A.nonpiv, -1, lane)) DPL_STOP(4);
+        // (3.) :472-487: the rows of U this row has multipliers for
+        if (!lv_subtract_list(z, znnz, head, A.colL, A.Lval, A.linkL, A.Dinv, A.Uptr, A.Uidx, A.Uval, A.nonpiv, -1, lane)) DPL_STOP(4);
+        double pivot = 0.0;
+        int pslot = -1;
+        bool elim_step = eliminate, end_here = false;
+        if (elim_step) {                                                            // the pivot, :540-558
+            double best = 0.0;
+            int bslot = 0x7fffffff;
+            for (int s = lane; s < znnz; s += 64) { const double v = fabs(z.val[s]); if (v > best) { best = v; bslot = s; } }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int os = __shfl_xor(bslot, off);
+                if (ob > best || (ob == best && os < bslot)) { best = ob; bslot = os; }
+            }
+            pos_pivot = bslot == 0x7fffffff ? -1 : z.idx[bslot];
+            pslot = bslot == 0x7fffffff ? -1 : bslot;
+            const double val_larg_el = pos_pivot >= 0 ? z.val[bslot] : 0.0;
+            if (sel_alive != 0) {
+                if (!lv_touch(z, znnz, sel, lane)) DPL_STOP(4);
+                const int ss = lv_find(z, sel);
+                const double zs = z.val[ss];
+                if (fabs(val_larg_el * piv_tol_step) > fabs(zs) && pos_pivot >= 0 && A.piv_tol > 0) pivot = val_larg_el;
+                else { pos_pivot = sel; pslot = ss; pivot = zs; }
+            } else {
+                if (fabs(val_larg_el) > 0.0 && pos_pivot >= 0) pivot = val_larg_el;
+                else { pos_pivot = perm_k; if (!lv_touch(z, znnz, pos_pivot, lane)) DPL_STOP(4); pslot = lv_find(z, pos_pivot); pivot = z.val[pslot]; }
+            }
+            if (!A.force_finish && (double)k > A.min_elim_factor * (double)n && A.small_pivot_terminates && fabs(pivot) < A.min_pivot) {   // :595-612
+                elim_step = false;
+                end_here = true;
+            }
+        }
+        double dinv = 1.0;
+        if (elim_step) {                                                            // :613-651, the column of L first (nothing is written before both vectors stand)
+            dinv = 1.0 / pivot;
+            const int c = pos_pivot;
+            const int c0 = A.Cp[c], c1 = A.Cp[c + 1], headU = A.startU[c];
+            if (!lv_load(w, wnnz, A.Ci, A.Cv, c0, c1, A.unused, sel, lane)) DPL_STOP(4);
+            if (!lv_subtract_list(w, wnnz, headU, A.rowU, A.Uval, A.linkU, A.Dinv, A.Lptr, A.Lidx, A.Lval, A.unused, sel, lane)) DPL_STOP(4);
+        }
+        // ---- the step stands: its effects ----
+        piv_tol = piv_tol_step;
+        if (lane == 0) { A.unused[sel] = 0; A.wrec[sel].slot = -2; }
+        if (end_here) {
+            eliminate = false;
+            end_level_now = true;
+            threshold *= A.shift_schur;
+            last = k - 1;
+            nA = n - k;
+        }
+        if (elim_step) {
+            for (int s = lane; s < znnz; s += 64) z.val[s] = z.val[s] * dinv;
+            for (int s = lane; s < wnnz; s += 64) w.val[s] = w.val[s] * dinv;       // :652
+            LV_SYNC();
+            if (lane == 0) {
+                z.val[pslot] = 0.0;                                                  // (eliminated for the sorting, :619; dead as a column from here on)
+                A.zrec[pos_pivot] = DpRec{0.0, -2, 0};
+                const int p = A.iperm[pos_pivot];
+                const int t = A.iperm[perm_k]; A.iperm[perm_k] = p; A.iperm[pos_pivot] = t;
+                const int u = A.perm[p]; A.perm[k] = u; A.perm[p] = perm_k;
+                A.nonpiv[pos_pivot] = 0;
+                A.Dinv[k] = dinv;
+            }
+            LV_SYNC();
+        }
+        // ---- dropping in the row, :714-759 ----
+        int nU;
+        double n1z = 0.0;
+        if (!elim_step) {
+            const double norm = sqrt(lv_seq_sum(z, znnz, 1, lane));
+            nU = lv_take(z, znnz, false, 0.0, norm * threshold, A.max_fill, s_key, s_cand, s_sort, lane);
+        } else {
+            const double n2z = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(z, znnz, 1, lane)) : 0.0;
+            const double n1w = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(w, wnnz, 0, lane) : 0.0;
+            n1z = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(z, znnz, 0, lane) : 0.0;
+            const double weightU = dp_weight(A, n2z, n1w, dinv);
+            nU = lv_take(z, znnz, true, weightU, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane);
+        }
+        if (elim_step) {                                                            // :761-797: the 1 at the pivot's column, then the list backwards
+            const int p0 = pU;
+            pU += nU + 1;
+            for (int j = lane; j < nU; j += 64) {
+                const unsigned long long ks = s_sort[nU - 1 - j];
+                const int pos = p0 + 1 + j, c = (int)(ks >> 32), sl = (int)(unsigned)ks;
+                A.Uval[pos] = z.val[sl]; A.Uidx[pos] = c;
+                A.linkU[pos] = A.startU[c]; A.startU[c] = pos; A.rowU[pos] = k;
+            }
+            if (lane == 0) {
+                A.Uval[p0] = 1.0; A.Uidx[p0] = pos_pivot; A.Uptr[k + 1] = p0 + nU + 1;
+                if (pivot == 0.0) A.Dinv[k] = 1.0;
+            }
+            if (pivot == 0.0) { ++zero_piv; dinv = 1.0; }
+        } else {                                                                    // :818-847
+            const int kA = k - last - 1;
+            const int p0 = pU, q0 = pS;
+            pU += 1; pS += nU;
+            for (int j = lane; j < nU; j += 64) {
+                const unsigned long long ks = s_sort[nU - 1 - j];
+                A.Sval[q0 + j] = z.val[(int)(unsigned)ks]; A.Sidx[q0 + j] = (int)(ks >> 32);
+            }
+            if (lane == 0) {
+                A.Uval[p0] = 1.0; A.Uidx[p0] = perm_k; A.Uptr[k + 1] = p0 + 1; A.Dinv[k] = 1.0;
+                A.Sptr[kA + 1] = q0 + nU;
+            }
+        }
+        LV_SYNC();
+        // ---- the column of L, :849-1005 ----
+        if (elim_step) {
+            const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(w, wnnz, 1, lane)) : 0.0;
+            const double weightL = dp_weight(A, n2w, n1z, dinv);
+            const int nL = lv_take(w, wnnz, true, weightL, threshold, A.max_fill, s_key, s_cand, s_sort, lane);
+            const int p0 = pL;
+            pL += nL + 1;
+            for (int j = lane; j < nL; j += 64) {
+                const unsigned long long ks = s_sort[j];
+                const int pos = p0 + 1 + j, b = (int)(ks >> 32);
+                A.Lval[pos] = w.val[(int)(unsigned)ks]; A.Lidx[pos] = b;
+                A.linkL[pos] = A.startL[b]; A.startL[b] = pos; A.colL[pos] = k;
+            }
+            if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + nL + 1; }
+            // the rows by their number of entries in L, one move per new entry and in the order of the entries (:964-970): what the moves
+            // read is fetched for 64 entries at once; if no move's boundary row is another move's row they do not interact and are applied
+            // at once, otherwise (or with a count beyond the cached boundaries) one lane applies them in order
+            for (int base = 0; base < nL; base += 64) {
+                const int j = base + lane;
+                const int b0 = j < nL ? (int)(s_sort[j] >> 32) : -1;
+                const bool inr = j < nL && b0 >= A.bpr && b0 <= A.epr;
+                const int b = inr ? A.iprow[b0] : -1;
+                const int cntb = inr ? A.numb[b] + 1 : 0;
+                const int cnt_chunk = nL - base < 64 ? nL - base : 64;
+                const bool far = __ballot(inr && cntb >= kPnL) != 0ull;
+                int rank = 0;
+                for (int i = 0; i < cnt_chunk; ++i) { const int ci = __shfl(cntb, i); const int ii = __shfl((int)inr, i); if (i < lane && ii && ci == cntb) ++rank; }
+                const int a = (inr && !far) ? s_pnum[cntb] - 1 - rank : -1;
+                const int ra = (inr && !far) ? A.prow[a] : -1;
+                bool clash = false;
+                for (int i = 0; i < cnt_chunk; ++i) { const int bi = __shfl(b0, i); const int ii = __shfl((int)inr, i); if (ii && i != lane && inr && ra == bi) clash = true; }
+                if (!far && __ballot(clash) == 0ull) {
+                    if (inr) {
+                        atomicSub(&s_pnum[cntb], 1);
+                        if (a != b) {
+                            A.iprow[ra] = b; A.iprow[b0] = a;
+                            A.prow[a] = b0; A.prow[b] = ra;
+                            A.numb[a] = cntb; A.numb[b] = cntb - 1;
+                        } else A.numb[b] = cntb;
+                    }
+                    LV_SYNC();
+                    if (inr) A.pnum[cntb] = s_pnum[cntb];
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    if (lane == 0) {
+                        for (int jj = base; jj < base + cnt_chunk; ++jj) {
+                            const int r = (int)(s_sort[jj] >> 32);
+                            if (r < A.bpr || r > A.epr) continue;
+                            const int bb = A.iprow[r];
+                            const int cb = A.numb[bb] + 1;
+                            const int aa = (cb < kPnL ? s_pnum[cb] : A.pnum[cb]) - 1;
+                            if (cb < kPnL) s_pnum[cb] = aa;
+                            A.pnum[cb] = aa;
+                            if (aa == bb) { A.numb[bb] = cb; continue; }
+                            const int rra = A.prow[aa], rrb = A.prow[bb];
+                            A.iprow[rra] = bb; A.iprow[rrb] = aa;
+                            A.prow[aa] = rrb; A.prow[bb] = rra;
+                            const int na = A.numb[aa];
+                            A.numb[aa] = cb; A.numb[bb] = na;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                LV_SYNC();
+            }
+            // a new group of rows with equally many entries begins behind this step: by increasing row index (:980-981)
+            const int nk = nk_at_k;
+            const int g0 = nk + 1 < kPnL ? s_pnum[nk + 1] : A.pnum[nk + 1];
+            if (g0 == k + 1) {
+                __builtin_amdgcn_s_waitcnt(0);
+                const int g1 = (nk + 2 < kPnL ? s_pnum[nk + 2] : A.pnum[nk + 2]) - 1;
+                const int len = g1 - g0 + 1;
+                if (len > 1 && len <= 64) {
+                    const unsigned long long sorted = dp_sort64(lane < len ? (unsigned long long)(unsigned)A.prow[g0 + lane] : ~0ull, lane);
+                    if (lane < len) { const int r = (int)(unsigned)sorted; A.prow[g0 + lane] = r; A.iprow[r] = g0 + lane; }
+                } else if (len > 1) {
+                    int N = 64;
+                    while (N < len) N *= 2;
+                    for (int i = lane; i < N; i += 64) A.sortk[i] = i < len ? (unsigned long long)(unsigned)A.prow[g0 + i] : ~0ull;
+                    DP_SYNC();
+                    wave_sort_u64<true>(A.sortk, N, lane);
+                    for (int i = lane; i < len; i += 64) { const int r = (int)(unsigned)A.sortk[i]; A.prow[g0 + i] = r; A.iprow[r] = g0 + i; }
+                }
+            }
+            // ---- does the level end here?  :1018-1092 ----
+            if (!A.force_finish && (double)k > A.min_elim_factor * (double)n) {
+                const double cnt = (double)nk;
+                switch (A.final_row_crit) {
+                case -1: end_level_now = cnt > (A.move_level_factor * nnzA) / (double)n; break;
+                case 0: end_level_now = cnt > (0.5 * nnzA) / (double)n; break;
+                case 1: end_level_now = cnt > nnzA / (double)n; break;
+                case 2: end_level_now = cnt > (2.0 * nnzA) / (double)n; break;
+                case 3: end_level_now = cnt > (4.0 * nnzA) / (double)n; break;
+                case 4: end_level_now = cnt > (6.0 * nnzA) / (double)n; break;
+                case 5: end_level_now = nk > 10; break;
+                case 6: end_level_now = cnt > (1.5 * nnzA) / (double)n; break;
+                case 7: end_level_now = sqrt(lv_seq_sum(z, znnz, 1, lane)) > A.row_u_max; break;
+                case 8: end_level_now = cnt > (3.0 * nnzA) / (double)n; break;
+                case 9: end_level_now = cnt > (1.2 * nnzA) / (double)n; break;
+                default: break;
+                }
+                if (end_level_now) {
+                    eliminate = false;
+                    threshold *= A.shift_schur;
+                    last = k;
+                    nA = n - k - 1;
+                }
+            }
+        } else {
+            const int p0 = pL;
+            pL += 1;
+            if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + 1; }
+        }
+        __builtin_amdgcn_s_waitcnt(0);                                              // (what this step stored is what the next one reads)
+    }
+    (void)end_level_now;
+    if (lane == 0) { A.ctrl[0] = 0; A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; A.ctrl[5] = n; }
+#undef DPL_STOP
 }
 
 // ---------------------------------------------- the stores -> matrices ----------------------------------------------
@@ -579,7 +1054,14 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     }
     hipLaunchKernelGGL(k_dp_init, dim3((n + 2 + 255) / 256), dim3(256), 0, st, n, epr, a.perm, a.iperm, a.prow, a.iprow, a.numb, a.pnum, a.nonpiv, a.unused,
                        a.startU, a.startL, a.zrec, a.wrec, Dinv);
+#ifdef DP_PROF
+    PoolBlock b_prof;
+    ILUPP_HIP(b_prof.alloc(sizeof(long long) * 16));
+    ILUPP_HIP(hipMemsetAsync(b_prof.p, 0, sizeof(long long) * 16, st));
+    a.prof = b_prof.as<long long>();
+#endif
     int32_t ctrl[16] = {0};
+    bool in_lds = getenv("ILUPP_NO_DPLDS") == nullptr;         // the working vectors in LDS while they fit (status 4: from that step on in memory)
     for (int launch = 0;; ++launch) {
         a.Uidx = SU.idx.as<int32_t>(); a.linkU = SU.link.as<int32_t>(); a.rowU = SU.who.as<int32_t>(); a.Uval = SU.val.as<double>(); a.capU = (int32_t)SU.cap;
         a.Lidx = SL.idx.as<int32_t>(); a.linkL = SL.link.as<int32_t>(); a.colL = SL.who.as<int32_t>(); a.Lval = SL.val.as<double>(); a.capL = (int32_t)SL.cap;
@@ -587,7 +1069,8 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         hipEvent_t e0, e1;
         ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
         ILUPP_HIP(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
+        if (in_lds) hipLaunchKernelGGL(k_pilucdp_lds, dim3(1), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
         ILUPP_HIP(hipEventRecord(e1, st));
         ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
@@ -595,9 +1078,10 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (kernel_ms) *kernel_ms += ms;
-        if (dbg) fprintf(stderr, "[ilupp] pilucdp: n %d, launch %d (stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", n, launch, (long long)SU.cap,
-                         (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
+        if (dbg) fprintf(stderr, "[ilupp] pilucdp: n %d, launch %d (%s; stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", n, launch,
+                         in_lds ? "vectors in LDS" : "vectors in memory", (long long)SU.cap, (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
         if (ctrl[0] == 0) break;
+        if (ctrl[0] == 4) { in_lds = false; continue; }
         Store &S = ctrl[0] == 1 ? SU : ctrl[0] == 2 ? SL : SS;
         const int64_t used = ctrl[0] == 1 ? ctrl[8] : ctrl[0] == 2 ? ctrl[9] : ctrl[10];
         if (S.cap >= 0x7ffffff0ll || (launch > 40 && !getenv("ILUPP_DP_STORE"))) { set_error("ILU++ with pivoting: the factors of a level outgrow 2^31 entries"); return ILUPP_ERR_UNSUPPORTED; }
@@ -605,6 +1089,17 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         if (ncap > 0x7ffffff0ll) ncap = 0x7ffffff0ll;
         { const int rc = S.grow(st, ncap, used); if (rc) return rc; }
     }
+#ifdef DP_PROF
+    {
+        long long hp[16];
+        ILUPP_HIP(hipMemcpy(hp, a.prof, sizeof(hp), hipMemcpyDeviceToHost));
+        static const char *names[12] = {"clear + load row", "U rows subtracted", "pivot search", "scale z + swaps", "load column", "L columns subtracted", "scale w",
+                                        "norms + take z", "write U", "take w + write L", "bucket moves", "group sort + level end"};
+        long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += hp[i];
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "[ilupp] pilucdp phase %-24s %10.3f Mticks  %5.1f %%\n", names[i], 1e-6 * (double)hp[i], 100.0 * (double)hp[i] / (double)(tot > 0 ? tot : 1));
+    }
+#endif
     {
         const int32_t last = ctrl[1], nA = ctrl[2];
         const bool to_the_end = ctrl[4] != 0;

@@ -1,9 +1,12 @@
 #!/bin/bash
-# usage: profiles/tools/mkvar.sh NAME "-DFLAGS"  -> scratch/lib_NAME.so (rebuilds the sweep/factor kernels with the flags)
+# usage: profiles/tools/mkvar.sh NAME FILE.hip "-DFLAGS"  -> profiles/tools/lib_NAME.so : FILE.hip rebuilt with the flags, the other objects as they are
+# (select it with ILUPP_HIP_LIBRARY=profiles/tools/lib_NAME.so; delete it afterwards: every gpurun call pushes it)
 set -e
 cd /root/repo/ilupp_amd/csrc
+mkdir -p scratch
 F="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -I../../include -Wall -Wno-unused-result"
-touch sptrsv.hip sptrsv_lm.hip ilu0.hip ilu0_lm.hip ilut.hip
-make -j4 CXXFLAGS="$F $2" OUT=/root/repo/profiles/tools/lib_$1.so 2>&1 | grep -E " error|Error" || true
-touch sptrsv.hip sptrsv_lm.hip ilu0.hip ilu0_lm.hip ilut.hip
+B=$(basename $2 .hip)
+/opt/rocm/bin/hipcc $F $3 -c $2 -o scratch/${B}_$1.o
+OBJS=$(ls *.o | grep -v "^${B}\.o$")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o /root/repo/profiles/tools/lib_$1.so $OBJS scratch/${B}_$1.o
 ls -la /root/repo/profiles/tools/lib_$1.so
