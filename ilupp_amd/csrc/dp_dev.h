@@ -14,6 +14,89 @@ struct SpVec { DpRec *rec; int32_t *list; };      // by index: value and slot; s
 
 #define DP_SYNC() do { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); } while (0)
 
+// ---- cross-lane operations of one wave without the LDS crossbar.  __shfl / __shfl_xor compile to ds_bpermute (an LDS-pipe round trip,
+// >100 cycles, and these kernels use them in dependent sequences: an ordered sum of 20 terms, a 6-step arg-max, a 21-stage bitonic
+// sort were 1-2 us each).  A value of a lane whose number is wave-uniform is a v_readlane (SGPR result, a few cycles); reductions run
+// on DPP row shifts / broadcasts.
+__device__ __forceinline__ int wv_i32(int x, int i) { return __builtin_amdgcn_readlane(x, i); }
+__device__ __forceinline__ unsigned long long wv_u64(unsigned long long x, int i)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, i), hi = (unsigned)__builtin_amdgcn_readlane((int)(x >> 32), i);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double wv_f64(double x, int i) { return __longlong_as_double((long long)wv_u64((unsigned long long)__double_as_longlong(x), i)); }
+
+template <int CTRL, int ROWS> __device__ __forceinline__ unsigned long long wv_dpp_u64(unsigned long long x)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)x, (int)(unsigned)x, CTRL, ROWS, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(x >> 32), (int)(x >> 32), CTRL, ROWS, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// the largest of 64 unsigned keys, in every lane (row_shr 1, 2, 4, 8, then row_bcast:15 / :31: lane 63 holds the result)
+__device__ __forceinline__ unsigned long long wv_max_u64(unsigned long long x)
+{
+    unsigned long long y;
+    y = wv_dpp_u64<0x111, 0xf>(x); x = y > x ? y : x;
+    y = wv_dpp_u64<0x112, 0xf>(x); x = y > x ? y : x;
+    y = wv_dpp_u64<0x114, 0xf>(x); x = y > x ? y : x;
+    y = wv_dpp_u64<0x118, 0xf>(x); x = y > x ? y : x;
+    y = wv_dpp_u64<0x142, 0xa>(x); x = y > x ? y : x;
+    y = wv_dpp_u64<0x143, 0xc>(x); x = y > x ? y : x;
+    return wv_u64(x, 63);
+}
+__device__ __forceinline__ int wv_min_i32(int x)
+{
+    int y;
+    y = __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false); x = y < x ? y : x;
+    y = __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false); x = y < x ? y : x;
+    y = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false); x = y < x ? y : x;
+    y = __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false); x = y < x ? y : x;
+    y = __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false); x = y < x ? y : x;
+    y = __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false); x = y < x ? y : x;
+    return wv_i32(x, 63);
+}
+// the largest of 64 doubles none of which is a NaN (their bit patterns mapped to unsigned integers of the same order)
+__device__ __forceinline__ unsigned long long wv_order_bits(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double wv_max_f64(double x)
+{
+    const unsigned long long m = wv_max_u64(wv_order_bits(x));
+    return __longlong_as_double((long long)((m >> 63) ? (m & 0x7fffffffffffffffull) : ~m));
+}
+// (value, position) pairs, position 0x7fffffff = "this lane has none": the position of the largest value, the smallest position among
+// equal values; 0x7fffffff if no lane has a pair.  Every lane gets the winner's value in `mx`.  (A NaN among the values -- which the
+// scalar comparisons treat by their own rules -- is left to the shuffle form of the same reduction.)
+__device__ __forceinline__ int wv_argmax_first(double &mx, int pos)
+{
+    if (__ballot(pos != 0x7fffffff && mx != mx)) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double om = __shfl_xor(mx, o);
+            const int op = __shfl_xor(pos, o);
+            if (op != 0x7fffffff && (pos == 0x7fffffff || om > mx || (om == mx && op < pos))) { mx = om; pos = op; }
+        }
+        return pos;
+    }
+    const unsigned long long key = pos == 0x7fffffff ? 0ull : wv_order_bits(mx);
+    const unsigned long long m = wv_max_u64(key);
+    if (m == 0ull) return 0x7fffffff;
+    const int p = wv_min_i32(key == m ? pos : 0x7fffffff);
+    mx = __longlong_as_double((long long)((m >> 63) ? (m & 0x7fffffffffffffffull) : ~m));
+    return p;
+}
+// n <= 64 DISTINCT keys in the lanes 0 .. n-1: the key of rank `lane` (ascending) for the lanes below n.  Every lane counts the keys
+// below its own (n uniform reads), then sends its key to the lane of that rank.
+__device__ __forceinline__ unsigned long long dp_sort_n(unsigned long long key, int n, int lane)
+{
+    int rank = 0;
+    for (int i = 0; i < n; ++i) rank += wv_u64(key, i) < key ? 1 : 0;
+    if (lane >= n) rank = lane;
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(unsigned)key), hi = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(key >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // sum of |x| (mode 0) or x * x (mode 1) over the slots IN ORDER (vector_sparse_dynamic::norm1 / norm2, sparse_implementation.h:1074-1085):
 // 64 values per pass, one per lane, added one after the other
 __device__ inline double dp_seq_sum(const SpVec &v, int nnz, int mode, int lane)
@@ -24,7 +107,7 @@ __device__ inline double dp_seq_sum(const SpVec &v, int nnz, int mode, int lane)
         const double x = s < nnz ? v.rec[v.list[s]].val : 0.0;
         const double t = mode == 0 ? fabs(x) : x * x;
         const int cnt = nnz - base < 64 ? nnz - base : 64;
-        for (int i = 0; i < cnt; ++i) { const double ti = __shfl(t, i); acc = acc + ti; }
+        for (int i = 0; i < cnt; ++i) acc = acc + wv_f64(t, i);
     }
     return acc;
 }

@@ -46,7 +46,7 @@ __device__ double cp_norm2_from(const SpVec &v, int nnz, int lo, int lane)
         const bool in = s < nnz && c >= lo;
         const double t = x * x;
         const int cnt = nnz - base < 64 ? nnz - base : 64;
-        for (int i = 0; i < cnt; ++i) { const double ti = __shfl(t, i); const int on = __shfl((int)in, i); if (on) acc = acc + ti; }
+        for (int i = 0; i < cnt; ++i) { const double ti = wv_f64(t, i); const int on = wv_i32((int)in, i); if (on) acc = acc + ti; }
     }
     return acc;
 }
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(64) k_ilucp(CpArgs A)
             if (pass == 1 && !(A.threshold > 0.0)) break;
             double best = 0.0;
             for (int s = lane; s < znnz; s += 64) { const double a = fabs(z.rec[z.list[s]].val); if (a > best) best = a; }
-            for (int o = 32; o > 0; o >>= 1) { const double ob = __shfl_xor(best, o); if (ob > best) best = ob; }
+            best = wv_max_f64(best);
             const double norm = sqrt(dp_seq_sum(z, znnz, 1, lane));
             const DpRec rp = z.rec[pk];
             const double at_pivot = rp.slot >= 0 ? rp.val : 0.0;
@@ -133,11 +133,7 @@ __global__ void __launch_bounds__(64) k_ilucp(CpArgs A)
                     double mx = 0.0;
                     int pos = 0x7fffffff;
                     for (int i = lane; i < cnt; i += 64) { const double a = A.key[i]; if (a > mx) { mx = a; pos = i; } }
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const double om = __shfl_xor(mx, o);
-                        const int op = __shfl_xor(pos, o);
-                        if (om > mx || (om == mx && op < pos)) { mx = om; pos = op; }
-                    }
+                    pos = wv_argmax_first(mx, pos);
                     if (pos == 0x7fffffff) pos = 0;
                     if (cnt > 0 && lane == 0) { const int t = A.cand[pos]; A.cand[pos] = A.cand[cnt - 1]; A.cand[cnt - 1] = t; }
                     DP_SYNC();
@@ -231,7 +227,7 @@ __global__ void __launch_bounds__(64) k_ilucp(CpArgs A)
             }
             nL = cnt - o2;
             if (nL <= 64) {
-                const unsigned long long sorted = dp_sort64(lane < nL ? (unsigned long long)(unsigned)A.cand[o2 + lane] : ~0ull, lane);
+                const unsigned long long sorted = dp_sort_n(lane < nL ? (unsigned long long)(unsigned)A.cand[o2 + lane] : ~0ull, nL, lane);
                 if (lane < nL) A.cand[lane] = (int)(unsigned)sorted;
                 DP_SYNC();
             } else {

@@ -45,11 +45,7 @@ __device__ int tp_first_max(const double *key, int lo, int hi, int lane)
     double mx = -1.0;
     int pos = 0x7fffffff;
     for (int i = lo + lane; i < hi; i += 64) { const double a = key[i]; if (pos == 0x7fffffff || a > mx) { if (pos == 0x7fffffff || a > mx) { mx = a; pos = i; } } }
-    for (int o = 32; o > 0; o >>= 1) {
-        const double om = __shfl_xor(mx, o);
-        const int op = __shfl_xor(pos, o);
-        if (op != 0x7fffffff && (pos == 0x7fffffff || om > mx || (om == mx && op < pos))) { mx = om; pos = op; }
-    }
+    pos = wv_argmax_first(mx, pos);
     return pos == 0x7fffffff ? lo : pos;
 }
 
@@ -70,15 +66,15 @@ __device__ void tp_select(const TpArgs &A, int ns, int n_L, int n_U, double tau_
         const double t = x * x;
         if (cls == 2) { const double a = fabs(x); if (a > larg) larg = a; }
         const unsigned long long dm = __ballot(cls == 2 && key == mid);
-        if (dm) { const int src = 63 - __builtin_clzll(dm); potpiv = fabs(__shfl(x, src)); pos_pot = base + src; }
+        if (dm) { const int src = 63 - __builtin_clzll(dm); potpiv = fabs(wv_f64(x, src)); pos_pot = base + src; }
         const int cnt = ns - base < 64 ? ns - base : 64;
         for (int i = 0; i < cnt; ++i) {
-            const double ti = __shfl(t, i);
-            const int ci = __shfl(cls, i);
+            const double ti = wv_f64(t, i);
+            const int ci = wv_i32(cls, i);
             if (ci == 1) accL = accL + ti; else if (ci == 2) accU = accU + ti;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { const double ol = __shfl_xor(larg, o); if (ol > larg) larg = ol; }
+    larg = wv_max_f64(larg);
     const double nrmL = sqrt(accL), nrmU = sqrt(accU);
     int keep_diag = -1;
     if (with_piv && !((larg * piv_tol >= potpiv) || (pos_pot < 0))) keep_diag = pos_pot;
@@ -154,7 +150,7 @@ __global__ void __launch_bounds__(64) k_ilutp(TpArgs A)
             ns += __popcll(mask);
             const double t = v * v;
             const int cnt = r1 - base < 64 ? r1 - base : 64;
-            for (int q = 0; q < cnt; ++q) { const double tq = __shfl(t, q); const int kq = __shfl(key, q); if (kq < i) acc = acc + tq; }
+            for (int q = 0; q < cnt; ++q) { const double tq = wv_f64(t, q); const int kq = wv_i32(key, q); if (kq < i) acc = acc + tq; }
         }
         const double norm_wL = sqrt(acc);
         DP_SYNC();
@@ -162,7 +158,12 @@ __global__ void __launch_bounds__(64) k_ilutp(TpArgs A)
         for (;;) {
             int kmin = 0x7fffffff, smin = -1;
             for (int s = lane; s < ns; s += 64) { const int key = A.skey[s]; if (A.sstate[s] == 0 && key < i && key < kmin) { kmin = key; smin = s; } }
-            for (int o = 32; o > 0; o >>= 1) { const int ok = __shfl_xor(kmin, o); const int os = __shfl_xor(smin, o); if (ok < kmin) { kmin = ok; smin = os; } }
+            {   // (the positions of the waiting slots are all different: the lane that holds the smallest names its slot)
+                const int km = wv_min_i32(kmin);
+                const unsigned long long who = __ballot(kmin == km && smin >= 0);
+                smin = who ? wv_i32(smin, __builtin_ctzll(who)) : -1;
+                kmin = km;
+            }
             if (smin < 0) break;
             const double cur = A.sval[smin];
             if (fabs(cur) < A.threshold * norm_wL) {                                // current_zero_set (sparse_implementation.h:2376-2384)

@@ -107,7 +107,7 @@ __device__ int dp_take(const DpArgs &A, const SpVec &v, int nnz, bool single, do
     DP_SYNC();
     const int nk = cnt - off;
     if (nk <= 64) {
-        const unsigned long long sorted = dp_sort64(lane < nk ? (unsigned long long)(unsigned)A.cand[off + lane] : ~0ull, lane);
+        const unsigned long long sorted = dp_sort_n(lane < nk ? (unsigned long long)(unsigned)A.cand[off + lane] : ~0ull, nk, lane);
         if (lane < nk) A.cand[lane] = (int)(unsigned)sorted;
         DP_SYNC();
         return nk;
@@ -207,11 +207,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             double best = 0.0;
             int bslot = 0x7fffffff;
             for (int s = lane; s < znnz; s += 64) { const double v = fabs(z.rec[z.list[s]].val); if (v > best) { best = v; bslot = s; } }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int os = __shfl_xor(bslot, off);
-                if (ob > best || (ob == best && os < bslot)) { best = ob; bslot = os; }
-            }
+            bslot = wv_argmax_first(best, bslot);
             pos_pivot = bslot == 0x7fffffff ? -1 : z.list[bslot];
             const double val_larg_el = pos_pivot >= 0 ? z.rec[pos_pivot].val : 0.0;
             if (A.nonpiv[sel] != 0) {
@@ -371,7 +367,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                 const int g1 = A.pnum[nk + 2] - 1;
                 const int len = g1 - g0 + 1;
                 if (len > 1 && len <= 64) {
-                    const unsigned long long sorted = dp_sort64(lane < len ? (unsigned long long)(unsigned)A.prow[g0 + lane] : ~0ull, lane);
+                    const unsigned long long sorted = dp_sort_n(lane < len ? (unsigned long long)(unsigned)A.prow[g0 + lane] : ~0ull, len, lane);
                     if (lane < len) { const int r = (int)(unsigned)sorted; A.prow[g0 + lane] = r; A.iprow[r] = g0 + lane; }
                     DP_SYNC();
                 } else if (len > 1) {
@@ -497,7 +493,7 @@ __device__ __forceinline__ bool lv_load(const LdsVec &v, int &nnz, const int32_t
         if (dup) {
             LV_SYNC();
             for (int b = 0; b < 64; ++b)
-                if ((dup >> b) & 1ull) { const int cb = __shfl(c, b); const double xb = __shfl(x, b); if (lane == 0) v.val[lv_find(v, cb)] = xb; LV_SYNC(); }
+                if ((dup >> b) & 1ull) { const int cb = wv_i32(c, b); const double xb = wv_f64(x, b); if (lane == 0) v.val[lv_find(v, cb)] = xb; LV_SYNC(); }
         }
     }
     LV_SYNC();
@@ -512,7 +508,7 @@ __device__ __forceinline__ double lv_seq_sum(const LdsVec &v, int nnz, int mode,
         const double x = s < nnz ? v.val[s] : 0.0;
         const double t = mode == 0 ? fabs(x) : x * x;
         const int cnt = nnz - base < 64 ? nnz - base : 64;
-        for (int i = 0; i < cnt; ++i) { const double ti = __shfl(t, i); acc = acc + ti; }
+        for (int i = 0; i < cnt; ++i) acc = acc + wv_f64(t, i);
     }
     return acc;
 }
@@ -598,7 +594,7 @@ __device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, dou
     const int nk = cnt - off;
     auto keyof = [&](int i) { const int s = cand[off + i]; return ((unsigned long long)(unsigned)v.idx[s] << 32) | (unsigned)s; };
     if (nk <= 64) {
-        const unsigned long long sorted = dp_sort64(lane < nk ? keyof(lane) : ~0ull, lane);
+        const unsigned long long sorted = dp_sort_n(lane < nk ? keyof(lane) : ~0ull, nk, lane);
         if (lane < nk) sortk[lane] = sorted;
         LV_SYNC();
         return nk;
@@ -634,6 +630,9 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
 #define DPL_STOP(code) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) { A.ctrl[0] = (code); A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; \
                                              A.ctrl[5] = k; A.ctrl[6] = 0; A.ctrl[7] = 0; A.ctrl[8] = pU; A.ctrl[9] = pL; A.ctrl[10] = pS; A.ctrl[11] = -1; \
                                              A.dctrl[0] = threshold; A.dctrl[1] = piv_tol; } return; } while (0)
+#ifdef DP_PROF
+    long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (int k = A.ctrl[5]; k < n; ++k) {
         if ((long)pU + row_max > (long)A.capU) DPL_STOP(1);
         if ((long)pL + row_max > (long)A.capL) DPL_STOP(2);
@@ -648,8 +647,10 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
         const int sel_alive = A.nonpiv[sel];
         LV_SYNC();
         if (!lv_load(z, znnz, A.Ai, A.Av, r0, r1, A.nonpiv, -1, lane)) DPL_STOP(4);
+        DP_T(0);
         // (3.) :472-487: the rows of U this row has multipliers for
         if (!lv_subtract_list(z, znnz, head, A.colL, A.Lval, A.linkL, A.Dinv, A.Uptr, A.Uidx, A.Uval, A.nonpiv, -1, lane)) DPL_STOP(4);
+        DP_T(1);
         double pivot = 0.0;
         int pslot = -1;
         bool elim_step = eliminate, end_here = false;
@@ -657,11 +658,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
             double best = 0.0;
             int bslot = 0x7fffffff;
             for (int s = lane; s < znnz; s += 64) { const double v = fabs(z.val[s]); if (v > best) { best = v; bslot = s; } }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int os = __shfl_xor(bslot, off);
-                if (ob > best || (ob == best && os < bslot)) { best = ob; bslot = os; }
-            }
+            bslot = wv_argmax_first(best, bslot);
             pos_pivot = bslot == 0x7fffffff ? -1 : z.idx[bslot];
             pslot = bslot == 0x7fffffff ? -1 : bslot;
             const double val_larg_el = pos_pivot >= 0 ? z.val[bslot] : 0.0;
@@ -680,14 +677,17 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
                 end_here = true;
             }
         }
+        DP_T(2);
         double dinv = 1.0;
         if (elim_step) {                                                            // :613-651, the column of L first (nothing is written before both vectors stand)
             dinv = 1.0 / pivot;
             const int c = pos_pivot;
             const int c0 = A.Cp[c], c1 = A.Cp[c + 1], headU = A.startU[c];
             if (!lv_load(w, wnnz, A.Ci, A.Cv, c0, c1, A.unused, sel, lane)) DPL_STOP(4);
+            DP_T(3);
             if (!lv_subtract_list(w, wnnz, headU, A.rowU, A.Uval, A.linkU, A.Dinv, A.Lptr, A.Lidx, A.Lval, A.unused, sel, lane)) DPL_STOP(4);
         }
+        DP_T(4);
         // ---- the step stands: its effects ----
         piv_tol = piv_tol_step;
         if (lane == 0) { A.unused[sel] = 0; A.wrec[sel].slot = -2; }
@@ -713,6 +713,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
             }
             LV_SYNC();
         }
+        DP_T(5);
         // ---- dropping in the row, :714-759 ----
         int nU;
         double n1z = 0.0;
@@ -726,6 +727,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
             const double weightU = dp_weight(A, n2z, n1w, dinv);
             nU = lv_take(z, znnz, true, weightU, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane);
         }
+        DP_T(6);
         if (elim_step) {                                                            // :761-797: the 1 at the pivot's column, then the list backwards
             const int p0 = pU;
             pU += nU + 1;
@@ -754,6 +756,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
             }
         }
         LV_SYNC();
+        DP_T(7);
         // ---- the column of L, :849-1005 ----
         if (elim_step) {
             const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(w, wnnz, 1, lane)) : 0.0;
@@ -768,6 +771,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
                 A.linkL[pos] = A.startL[b]; A.startL[b] = pos; A.colL[pos] = k;
             }
             if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + nL + 1; }
+            DP_T(8);
             // the rows by their number of entries in L, one move per new entry and in the order of the entries (:964-970): what the moves
             // read is fetched for 64 entries at once; if no move's boundary row is another move's row they do not interact and are applied
             // at once, otherwise (or with a count beyond the cached boundaries) one lane applies them in order
@@ -780,11 +784,11 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
                 const int cnt_chunk = nL - base < 64 ? nL - base : 64;
                 const bool far = __ballot(inr && cntb >= kPnL) != 0ull;
                 int rank = 0;
-                for (int i = 0; i < cnt_chunk; ++i) { const int ci = __shfl(cntb, i); const int ii = __shfl((int)inr, i); if (i < lane && ii && ci == cntb) ++rank; }
+                for (int i = 0; i < cnt_chunk; ++i) { const int ci = wv_i32(cntb, i); const int ii = wv_i32((int)inr, i); if (i < lane && ii && ci == cntb) ++rank; }
                 const int a = (inr && !far) ? s_pnum[cntb] - 1 - rank : -1;
                 const int ra = (inr && !far) ? A.prow[a] : -1;
                 bool clash = false;
-                for (int i = 0; i < cnt_chunk; ++i) { const int bi = __shfl(b0, i); const int ii = __shfl((int)inr, i); if (ii && i != lane && inr && ra == bi) clash = true; }
+                for (int i = 0; i < cnt_chunk; ++i) { const int bi = wv_i32(b0, i); const int ii = wv_i32((int)inr, i); if (ii && i != lane && inr && ra == bi) clash = true; }
                 if (!far && __ballot(clash) == 0ull) {
                     if (inr) {
                         atomicSub(&s_pnum[cntb], 1);
@@ -819,6 +823,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
                 __builtin_amdgcn_s_waitcnt(0);
                 LV_SYNC();
             }
+            DP_T(9);
             // a new group of rows with equally many entries begins behind this step: by increasing row index (:980-981)
             const int nk = nk_at_k;
             const int g0 = nk + 1 < kPnL ? s_pnum[nk + 1] : A.pnum[nk + 1];
@@ -827,7 +832,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
                 const int g1 = (nk + 2 < kPnL ? s_pnum[nk + 2] : A.pnum[nk + 2]) - 1;
                 const int len = g1 - g0 + 1;
                 if (len > 1 && len <= 64) {
-                    const unsigned long long sorted = dp_sort64(lane < len ? (unsigned long long)(unsigned)A.prow[g0 + lane] : ~0ull, lane);
+                    const unsigned long long sorted = dp_sort_n(lane < len ? (unsigned long long)(unsigned)A.prow[g0 + lane] : ~0ull, len, lane);
                     if (lane < len) { const int r = (int)(unsigned)sorted; A.prow[g0 + lane] = r; A.iprow[r] = g0 + lane; }
                 } else if (len > 1) {
                     int N = 64;
@@ -867,8 +872,13 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
             pL += 1;
             if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = sel; A.Lptr[k + 1] = p0 + 1; }
         }
+        DP_T(10);
         __builtin_amdgcn_s_waitcnt(0);                                              // (what this step stored is what the next one reads)
+        DP_T(11);
     }
+#ifdef DP_PROF
+    if (lane == 0) for (int i = 0; i < 12; ++i) A.prof[i] += pt[i];
+#endif
     (void)end_level_now;
     if (lane == 0) { A.ctrl[0] = 0; A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; A.ctrl[5] = n; }
 #undef DPL_STOP
@@ -1093,8 +1103,11 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     {
         long long hp[16];
         ILUPP_HIP(hipMemcpy(hp, a.prof, sizeof(hp), hipMemcpyDeviceToHost));
-        static const char *names[12] = {"clear + load row", "U rows subtracted", "pivot search", "scale z + swaps", "load column", "L columns subtracted", "scale w",
-                                        "norms + take z", "write U", "take w + write L", "bucket moves", "group sort + level end"};
+        static const char *names_mem[12] = {"clear + load row", "U rows subtracted", "pivot search", "scale z + swaps", "load column", "L columns subtracted", "scale w",
+                                            "norms + take z", "write U", "take w + write L", "bucket moves", "group sort + level end"};
+        static const char *names_lds[12] = {"start + load row", "U rows subtracted", "pivot search", "load column", "L columns subtracted", "commit + scale",
+                                            "norms + take z", "write U", "take w + write L", "bucket moves", "group sort + level end", "stores complete"};
+        const char **names = getenv("ILUPP_NO_DPLDS") ? names_mem : names_lds;
         long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += hp[i];
         for (int i = 0; i < 12; ++i) fprintf(stderr, "[ilupp] pilucdp phase %-24s %10.3f Mticks  %5.1f %%\n", names[i], 1e-6 * (double)hp[i], 100.0 * (double)hp[i] / (double)(tot > 0 ? tot : 1));
