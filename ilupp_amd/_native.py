@@ -126,6 +126,8 @@ def lib():
     L.ilupp_hip_ml_default_params.restype = None
     L.ilupp_hip_ml_create.argtypes = mat_host + [ctypes.POINTER(MLParams), ctypes.POINTER(_VP)]
     L.ilupp_hip_ml_create_device.argtypes = mat_host + [ctypes.POINTER(MLParams), ctypes.POINTER(_VP)]
+    L.ilupp_hip_ml_create_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(_VP), ctypes.POINTER(_VP), ctypes.POINTER(_VP), _I32P, ctypes.c_int,
+                                            ctypes.POINTER(MLParams), ctypes.POINTER(_VP), _I32P]
     L.ilupp_hip_ml_destroy.argtypes = [_VP]
     L.ilupp_hip_ml_destroy.restype = None
     L.ilupp_hip_ml_apply.argtypes = [_VP, _VP, ctypes.c_int64, ctypes.c_int]
@@ -171,7 +173,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
     "ilupp_hip_ml_default_params", "ilupp_hip_ml_create", "ilupp_hip_ml_create_device", "ilupp_hip_ml_destroy", "ilupp_hip_ml_apply",
     "ilupp_hip_ml_apply_device", "ilupp_hip_ml_apply_part_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
-    "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings", "ilupp_hip_solve",
+    "ilupp_hip_ml_level_copy", "ilupp_hip_ml_timings", "ilupp_hip_solve", "ilupp_hip_ml_create_batch",
     "ilupp_hip_ilucp_create", "ilupp_hip_ilucp_destroy", "ilupp_hip_ilucp_apply", "ilupp_hip_ilucp_total_nnz", "ilupp_hip_ilucp_zero_pivots",
     "ilupp_hip_ilucp_info", "ilupp_hip_ilucp_copy", "ilupp_hip_ilutp_create",
 ]
@@ -457,6 +459,32 @@ def MultilevelILUCDPPreconditioner(A_data, A_indices, A_indptr, is_csr, param):
     if rc:
         _raise(rc)
     return MultilevelPreconditioner(h, args[3])
+
+
+def MultilevelILUCDPPreconditioner_batch(matrices, is_csr, param):
+    """one multilevel preconditioner per matrix of `matrices` (a list of (data, indices, indptr)), built side by side
+    (ilupp_hip_ml_create_batch): the same objects the constructor gives one at a time"""
+    p = param if isinstance(param, MLParams) else param._to_ml_params()
+    cnt = len(matrices)
+    if cnt == 0:
+        return []
+    keep, ns = [], []
+    D, I, P = (_VP * cnt)(), (_VP * cnt)(), (_VP * cnt)()
+    for k, (d, i, ptr) in enumerate(matrices):
+        args, arrays = _matrix_args(d, i, ptr, is_csr)
+        keep.append(arrays)
+        D[k], I[k], P[k] = args[0], args[1], args[2]
+        ns.append(args[3])
+    N = (ctypes.c_int32 * cnt)(*ns)
+    out = (_VP * cnt)()
+    status = (ctypes.c_int32 * cnt)()
+    rc = lib().ilupp_hip_ml_create_batch(cnt, D, I, P, N, 1 if is_csr else 0, ctypes.byref(p), out, status)
+    if rc:
+        for k in range(cnt):
+            if out[k]:
+                lib().ilupp_hip_ml_destroy(out[k])
+        _raise(rc)
+    return [MultilevelPreconditioner(_VP(out[k]), ns[k]) for k in range(cnt)]
 
 
 def solve(A_data, A_indices, A_indptr, is_csr, rhs, rtol, atol, max_iter, param):

@@ -4,9 +4,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -71,15 +73,20 @@ BlockPool &pool()
 }
 }  // namespace
 
+// the owner lane of the calling thread (pool.h): 0 except inside a worker of a batched construction
+static thread_local int g_pool_owner = 0;
+void pool_set_owner(int owner) { g_pool_owner = owner; }
+void pool_disown(int owner) { pool().disown(owner); }
+
 hipError_t pool_malloc(void **p, size_t bytes)
 {
-    const int e = pool().acquire(p, bytes);
+    const int e = pool().acquire(p, bytes, g_pool_owner);
     return e == 0 ? hipSuccess : (hipError_t)e;
 }
 
 hipError_t pool_free(void *p)
 {
-    const int e = pool().release(p);
+    const int e = pool().release(p, g_pool_owner);
     if (e == BlockPool::kNotLive) {
         // never ignored: a block freed twice may meanwhile belong to somebody else
         set_error("internal error: a device block was released that the pool had not handed out (double release?)");
@@ -1526,6 +1533,72 @@ int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_
     ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     return ml_create_common(A, params, out);
+    API_CATCH
+}
+
+int ilupp_hip_ml_create_batch(int32_t count, const double *const *data, const int32_t *const *indices, const int32_t *const *indptr, const int32_t *n,
+                              int is_csr, const ilupp_ml_params *params, ilupp_ml **out, int32_t *status)
+{
+    API_TRY_BUILD
+    if (count < 0 || !data || !indices || !indptr || !n || !params || !out) { set_error("null argument"); return ILUPP_ERR_INVALID; }
+    for (int32_t i = 0; i < count; ++i) { out[i] = nullptr; if (status) status[i] = ILUPP_OK; }
+    if (count == 0) return ILUPP_OK;
+    int workers = 64;
+    if (const char *e = getenv("ILUPP_BATCH_WORKERS")) { const int v = atoi(e); if (v > 0) workers = v; }
+    if (workers > count) workers = count;
+    int device = 0;
+    ILUPP_HIP(hipGetDevice(&device));
+    ChainBatch *cb = chain_batch_create(workers);
+    if (!cb) { set_error("batched construction: no stream"); return ILUPP_ERR_HIP; }
+    std::vector<int> rcs((size_t)count, ILUPP_OK);
+    std::vector<std::string> msgs((size_t)count);
+    std::atomic<int32_t> next(0);
+    auto work = [&](int w) {
+        (void)hipSetDevice(device);
+        pool_set_owner(w + 1);
+        chain_batch_enter(cb);
+        for (;;) {
+            const int32_t i = next.fetch_add(1);
+            if (i >= count) break;
+            int rc;
+            try {
+                rc = validate(indptr[i], n[i]);
+                if (!rc) {
+                    const int64_t nnz = indptr[i][n[i]];
+                    struct MatGuard { DevMat m; ~MatGuard() { m.release(); } } ga;
+                    DevMat &A = ga.m;
+                    A.n = n[i]; A.nnz = nnz; A.is_csr = is_csr != 0; A.owns = true;
+                    ILUPP_HIP(pool_malloc(&A.ptr, sizeof(int32_t) * (size_t)(n[i] + 1)));
+                    ILUPP_HIP(pool_malloc(&A.idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+                    ILUPP_HIP(pool_malloc(&A.val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+                    ILUPP_HIP(hipMemcpy(A.ptr, indptr[i], sizeof(int32_t) * (size_t)(n[i] + 1), hipMemcpyHostToDevice));
+                    ILUPP_HIP(hipMemcpy(A.idx, indices[i], sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+                    ILUPP_HIP(hipMemcpy(A.val, data[i], sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+                    rc = ml_create_common(A, params, &out[i]);
+                }
+            } catch (const ilupp::HipError &e) { ilupp::d2h_cancel_all(); rc = ilupp::report(e); }
+            catch (const std::bad_alloc &) { ilupp::set_error("out of host memory"); rc = ILUPP_ERR_MEMORY; }
+            rcs[(size_t)i] = rc;
+            if (rc) msgs[(size_t)i] = ilupp::g_last_error;
+        }
+        chain_batch_leave(cb);
+        (void)hipDeviceSynchronize();                          // (everything this worker queued is done: its kept blocks are everybody's)
+        pool_disown(w + 1);
+        pool_set_owner(0);
+    };
+    {
+        std::vector<std::thread> pool_threads;
+        for (int w = 1; w < workers; ++w) pool_threads.emplace_back(work, w);
+        work(0);
+        for (std::thread &t : pool_threads) t.join();
+    }
+    chain_batch_destroy(cb);
+    int first = ILUPP_OK;
+    for (int32_t i = 0; i < count; ++i) {
+        if (status) status[i] = rcs[(size_t)i];
+        if (rcs[(size_t)i] && !first) { first = rcs[(size_t)i]; set_error("matrix " + std::to_string(i) + " of the batch: " + msgs[(size_t)i]); }
+    }
+    return first;
     API_CATCH
 }
 

@@ -30,6 +30,8 @@ struct HipError { hipError_t code; const char *what; const char *file; int line;
 hipError_t pool_malloc(void **p, size_t bytes);
 hipError_t pool_free(void *p);
 void pool_trim();
+void pool_set_owner(int owner);      // the calling thread's owner lane (pool.h): kept blocks go back only to the owner that freed them ...
+void pool_disown(int owner);         // ... until it has synchronised its stream and calls this
 void pool_set_limit(size_t bytes);
 size_t pool_cached_bytes();
 size_t pool_live_blocks();
@@ -376,6 +378,14 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
 // pilucdp.hip: one level WITH pivoting (reference partialILUCDP, ILUCDP.hpp:268-1404): a sequential algorithm -- every step picks its
 // column by the values of the step and its row by the fill so far -- run by one wave; pc2 / pr2 (device, n entries): the column / row
 // taken at step k
+// pilucdp.hip: the chains of several constructions that run side by side (one host thread and stream each) are launched TOGETHER, one
+// workgroup per chain: a thread inside a batch hands its launch to the batch and waits until every other live thread of the batch
+// has handed in its own (or has finished)
+struct ChainBatch;
+ChainBatch *chain_batch_create(int workers);
+void chain_batch_destroy(ChainBatch *b);
+void chain_batch_enter(ChainBatch *b);       // the calling thread is a worker of b from now on ...
+void chain_batch_leave(ChainBatch *b);       // ... until here (it will hand in no more launches)
 int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, int32_t bp, int32_t bpr, int32_t epr,
                   DevMat *L, DevMat *U, double **Dinv, DevMat *Anew, int32_t *pc2, int32_t *pr2, float *kernel_ms);
 

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include <map>
+#include <mutex>
 #include <queue>
 #include <thread>
 #include <vector>
@@ -59,7 +60,7 @@ template <class F> void host_parallel(size_t count, size_t grain, F f)
 
 // one pinned staging buffer for the whole process (constructions run one at a time, api.hip g_build_mu); grows, never shrinks until
 // ilupp_hip_release_cached_memory
-struct Stage { void *p = nullptr; size_t bytes = 0; } g_stage;
+struct Stage { void *p = nullptr; size_t bytes = 0; std::mutex mu; } g_stage;      // (mu: the workers of a batched construction take turns)
 
 void *stage(size_t bytes)
 {
@@ -290,6 +291,7 @@ public:
 
 void mwm_release_stage()
 {
+    std::lock_guard<std::mutex> stage_turn(g_stage.mu);
     if (g_stage.p) (void)hipHostFree(g_stage.p);
     g_stage.p = nullptr; g_stage.bytes = 0;
 }
@@ -314,6 +316,7 @@ int mwm_order(hipStream_t st, const DevMat &A, int32_t *p1, double *D1, double *
     double *cost = b_cost.as<double>(), *rowmax = b_rowmax.as<double>(), *u = b_u.as<double>(), *v = b_v.as<double>();
     unsigned long long *vbits = b_vbits.as<unsigned long long>();
     int32_t *row_mate = b_rm.as<int32_t>(), *col_mate = p1, *col_edge = b_ce.as<int32_t>(), *want = b_want.as<int32_t>(), *flag = b_flag.as<int32_t>();
+    std::lock_guard<std::mutex> stage_turn(g_stage.mu);
     // host side of the stage: costs (nnz), then u, v, rowmax (n each), then row_mate, col_mate, col_edge (n each)
     char *hs = static_cast<char *>(stage(sizeof(double) * ((size_t)nnz + 3 * (size_t)n) + sizeof(int32_t) * 3 * (size_t)n));
     double *h_cost = reinterpret_cast<double *>(hs), *h_u = h_cost + nnz, *h_v = h_u + n, *h_rowmax = h_v + n;

@@ -25,6 +25,9 @@
 #include <stdlib.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
@@ -608,7 +611,7 @@ __device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, dou
     return nk;
 }
 
-__global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
+__device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_zidx[kLvCap], s_widx[kLvCap], s_zh[kLvHash], s_wh[kLvHash], s_cand[kLvCap], s_pnum[kPnL];
     __shared__ __attribute__((aligned(16))) double s_zval[kLvCap], s_wval[kLvCap], s_key[kLvCap];
@@ -884,6 +887,108 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A)
 #undef DPL_STOP
 }
 
+__global__ void __launch_bounds__(64) k_pilucdp_lds(DpArgs A) { dp_chain_lds(A); }
+// several chains, one workgroup each (the batched construction: BASELINE config 5's "many matrices" shape)
+__global__ void __launch_bounds__(64) k_pilucdp_lds_batch(const DpArgs *__restrict__ args)
+{
+    const DpArgs A = args[blockIdx.x];
+    dp_chain_lds(A);
+}
+
+// ---- launching the chains of a batch together ----
+struct ChainBatch {
+    std::mutex mu;
+    std::condition_variable cv;
+    int live = 0;                                   // workers that may still hand in a launch
+    struct Item { const DpArgs *args; hipEvent_t before; float ms; bool done; int rc; };
+    std::vector<Item *> waiting;
+    hipStream_t stream = nullptr;
+};
+static thread_local ChainBatch *t_batch = nullptr;
+
+ChainBatch *chain_batch_create(int workers)
+{
+    ChainBatch *b = new ChainBatch();
+    b->live = workers;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; return nullptr; }
+    return b;
+}
+void chain_batch_destroy(ChainBatch *b)
+{
+    if (!b) return;
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+void chain_batch_enter(ChainBatch *b) { t_batch = b; }
+
+// (mu held) every live worker waits here: their chains as one launch
+static void chain_batch_fire(ChainBatch *b)
+{
+    const int cnt = (int)b->waiting.size();
+    int rc = ILUPP_OK;
+    float ms = 0.f;
+    try {
+        std::vector<DpArgs> host((size_t)cnt);
+        for (int i = 0; i < cnt; ++i) host[(size_t)i] = *b->waiting[(size_t)i]->args;
+        DpArgs *dev = nullptr;
+        ILUPP_HIP(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(DpArgs) * (size_t)cnt));
+        struct Free { DpArgs *p; ~Free() { (void)hipFree(p); } } guard{dev};
+        ILUPP_HIP(hipMemcpyAsync(dev, host.data(), sizeof(DpArgs) * (size_t)cnt, hipMemcpyHostToDevice, b->stream));
+        for (int i = 0; i < cnt; ++i) ILUPP_HIP(hipStreamWaitEvent(b->stream, b->waiting[(size_t)i]->before, 0));
+        hipEvent_t e0, e1;
+        ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
+        ILUPP_HIP(hipEventRecord(e0, b->stream));
+        hipLaunchKernelGGL(k_pilucdp_lds_batch, dim3((unsigned)cnt), dim3(64), 0, b->stream, (const DpArgs *)dev);
+        ILUPP_HIP(hipEventRecord(e1, b->stream));
+        ILUPP_HIP(hipStreamSynchronize(b->stream));
+        ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] pilucdp: %d chains in one launch, %.2f ms\n", cnt, ms);
+    } catch (const HipError &e) { set_error(std::string("HIP error in the batched chain launch: ") + hipGetErrorString(e.code)); rc = ILUPP_ERR_HIP; }
+    for (ChainBatch::Item *it : b->waiting) { it->ms = ms; it->rc = rc; it->done = true; }
+    b->waiting.clear();
+    b->cv.notify_all();
+}
+void chain_batch_leave(ChainBatch *b)
+{
+    t_batch = nullptr;
+    std::unique_lock<std::mutex> lk(b->mu);
+    --b->live;
+    if (b->live > 0 && (int)b->waiting.size() == b->live) chain_batch_fire(b);
+}
+
+// one chain launch: directly, or together with the other chains of the batch this thread works for
+static int chain_launch(hipStream_t st, const DpArgs &a, bool in_lds, float *ms)
+{
+    ChainBatch *b = t_batch;
+    *ms = 0.f;
+    if (!b || !in_lds) {
+        hipEvent_t e0, e1;
+        ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
+        ILUPP_HIP(hipEventRecord(e0, st));
+        if (in_lds) hipLaunchKernelGGL(k_pilucdp_lds, dim3(1), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
+        ILUPP_HIP(hipEventRecord(e1, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        ILUPP_HIP(hipEventElapsedTime(ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return ILUPP_OK;
+    }
+    ChainBatch::Item it{&a, nullptr, 0.f, false, ILUPP_OK};
+    ILUPP_HIP(hipEventCreateWithFlags(&it.before, hipEventDisableTiming));
+    ILUPP_HIP(hipEventRecord(it.before, st));                  // (what this thread queued for the chain: initialisation, enlarged stores)
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->waiting.push_back(&it);
+        if ((int)b->waiting.size() == b->live) chain_batch_fire(b);
+        else b->cv.wait(lk, [&] { return it.done; });
+    }
+    (void)hipEventDestroy(it.before);
+    *ms = it.ms;
+    return it.rc;                                              // (the batch's stream has been synchronised: the chain's results are there)
+}
+
+
 // ---------------------------------------------- the stores -> matrices ----------------------------------------------
 __global__ void k_dp_init(int32_t n, int32_t epr, int32_t *perm, int32_t *iperm, int32_t *prow, int32_t *iprow, int32_t *numb, int32_t *pnum,
                           int32_t *nonpiv, int32_t *unused, int32_t *startU, int32_t *startL, DpRec *zrec, DpRec *wrec, double *Dinv)
@@ -1076,17 +1181,10 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         a.Uidx = SU.idx.as<int32_t>(); a.linkU = SU.link.as<int32_t>(); a.rowU = SU.who.as<int32_t>(); a.Uval = SU.val.as<double>(); a.capU = (int32_t)SU.cap;
         a.Lidx = SL.idx.as<int32_t>(); a.linkL = SL.link.as<int32_t>(); a.colL = SL.who.as<int32_t>(); a.Lval = SL.val.as<double>(); a.capL = (int32_t)SL.cap;
         a.Sidx = SS.idx.as<int32_t>(); a.Sval = SS.val.as<double>(); a.capS = (int32_t)SS.cap;
-        hipEvent_t e0, e1;
-        ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
-        ILUPP_HIP(hipEventRecord(e0, st));
-        if (in_lds) hipLaunchKernelGGL(k_pilucdp_lds, dim3(1), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
-        ILUPP_HIP(hipEventRecord(e1, st));
+        float ms = 0.f;
+        { const int rc = chain_launch(st, a, in_lds, &ms); if (rc) return rc; }
         ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
-        float ms = 0.f;
-        ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (kernel_ms) *kernel_ms += ms;
         if (dbg) fprintf(stderr, "[ilupp] pilucdp: n %d, launch %d (%s; stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", n, launch,
                          in_lds ? "vectors in LDS" : "vectors in memory", (long long)SU.cap, (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);

@@ -9,7 +9,11 @@
 //     is not live is an error -- reported, never ignored (a second free of a block that has meanwhile been handed to a new owner
 //     would recycle memory in use); ILUPP_POOL_STRICT=1 aborts on it;
 //   * the kept bytes are bounded by a limit the caller can set (ilupp_hip_set_cache_limit; default 24 GiB, ILUPP_CACHE_LIMIT_MB),
-//     the oldest kept blocks go back to the back end first; a failing back-end allocation gives every kept block back and retries.
+//     the oldest kept blocks go back to the back end first; a failing back-end allocation gives every kept block back and retries;
+//   * the pool knows nothing of streams: a kept block may still be in use by kernels queued on the stream of whoever freed it.  Work on
+//     ONE stream is safe by stream order; for callers that work on several streams at once (the batched construction: one worker per
+//     matrix) every acquire / release names an OWNER: a kept block is handed out again only to the owner that freed it, until that
+//     owner has synchronised its stream and given its kept blocks to everybody (disown).  Owner 0 is "everybody".
 #pragma once
 
 #include <stddef.h>
@@ -57,13 +61,14 @@ public:
     }
 
     // a block of at least `bytes`: a kept one of the same device and bucket, else a new one
-    int acquire(void **p, size_t bytes)
+    int acquire(void **p, size_t bytes, int owner = 0)
     {
         bytes = bucket(bytes);
         const int dev = be_.device();
         {
             std::lock_guard<std::mutex> lk(mu_);
-            auto it = kept_.find(Key(dev, bytes));
+            auto it = kept_.find(Key(dev, bytes, owner));
+            if ((it == kept_.end() || it->second.empty()) && owner != 0) it = kept_.find(Key(dev, bytes, 0));
             if (it != kept_.end() && !it->second.empty()) {
                 const Kept k = it->second.back();
                 it->second.pop_back();
@@ -71,7 +76,7 @@ public:
                 age_.erase(k.age);
                 cached_ -= bytes;
                 *p = k.p;
-                live_[*p] = Key(dev, bytes);
+                live_[*p] = Key(dev, bytes, 0);
                 ++hits_;
                 return kOk;
             }
@@ -83,13 +88,13 @@ public:
         }
         if (e != 0) return e;
         std::lock_guard<std::mutex> lk(mu_);
-        live_[*p] = Key(dev, bytes);
+        live_[*p] = Key(dev, bytes, 0);
         ++misses_;
         return kOk;
     }
 
     // back to the pool (kept while the limit allows, the oldest kept blocks leave first)
-    int release(void *p)
+    int release(void *p, int owner = 0)
     {
         if (!p) return kOk;
         std::list<void *> drop;
@@ -104,13 +109,13 @@ public:
                 }
                 return kNotLive;
             }
-            const Key key = it->second;
+            const Key key(it->second.dev, it->second.bytes, owner);
             live_.erase(it);
-            if (key.second <= limit_) {
+            if (key.bytes <= limit_) {
                 age_.push_back(AgeEntry(key, p));
                 auto last = age_.end(); --last;
                 kept_[key].push_back(Kept{p, last});
-                cached_ += key.second;
+                cached_ += key.bytes;
                 // over the limit: the oldest kept blocks go
                 while (cached_ > limit_ && !age_.empty()) {
                     const AgeEntry a = age_.front();
@@ -125,6 +130,19 @@ public:
         for (void *q : drop)
             if (be_.release(q) != 0) rc = kBackend;
         return rc;
+    }
+
+    // the kept blocks of `owner` become everybody's (the owner has synchronised the stream it worked on)
+    void disown(int owner)
+    {
+        if (owner == 0) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto it = kept_.begin(); it != kept_.end();) {
+            if (it->first.owner != owner) { ++it; continue; }
+            std::list<Kept> &dst = kept_[Key(it->first.dev, it->first.bytes, 0)];
+            for (Kept &k : it->second) { k.age->first.owner = 0; dst.push_back(k); }
+            it = kept_.erase(it);
+        }
     }
 
     // every kept block back to the back end
@@ -163,7 +181,12 @@ public:
     bool is_live(void *p) const { std::lock_guard<std::mutex> lk(mu_); return live_.count(p) != 0; }
 
 private:
-    typedef std::pair<int, size_t> Key;                      // (device, bytes)
+    struct Key {                                             // (device, bytes, owner)
+        int dev; size_t bytes; int owner;
+        Key() : dev(0), bytes(0), owner(0) {}
+        Key(int d, size_t b, int o) : dev(d), bytes(b), owner(o) {}
+        bool operator<(const Key &o) const { return dev != o.dev ? dev < o.dev : bytes != o.bytes ? bytes < o.bytes : owner < o.owner; }
+    };
     typedef std::pair<Key, void *> AgeEntry;
     struct Kept { void *p; std::list<AgeEntry>::iterator age; };
 
@@ -175,7 +198,7 @@ private:
             if (k->p == p) {
                 age_.erase(k->age);
                 it->second.erase(k);
-                cached_ -= key.second;
+                cached_ -= key.bytes;
                 break;
             }
         if (it->second.empty()) kept_.erase(it);

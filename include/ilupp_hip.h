@@ -227,6 +227,14 @@ int ilupp_hip_ml_create(const double *data, const int32_t *indices, const int32_
                         const ilupp_ml_params *params, ilupp_ml **out);
 int ilupp_hip_ml_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr, int32_t n, int is_csr,
                                const ilupp_ml_params *params, ilupp_ml **out);
+/* BASELINE config 5's batched shape: `count` independent matrices (host arrays, all CSR or all CSC), one preconditioner each -- what a
+ * caller of the reference does by calling the constructor once per matrix (preconditioner_implementation.h:1483-1494 runs once per
+ * matrix).  The constructions run side by side (one host thread and HIP stream per matrix, at most ILUPP_BATCH_WORKERS = 64 at a
+ * time), and the sequential chains of the factorisation with pivoting -- one wave each -- are launched TOGETHER, one workgroup per
+ * matrix, so that a batch costs about what its slowest member costs.  out[i] / status[i] per matrix (status may be NULL); returns the
+ * first error.  Every result is identical to what ilupp_hip_ml_create gives for that matrix. */
+int ilupp_hip_ml_create_batch(int32_t count, const double *const *data, const int32_t *const *indices, const int32_t *const *indptr, const int32_t *n,
+                              int is_csr, const ilupp_ml_params *params, ilupp_ml **out, int32_t *status);
 void ilupp_hip_ml_destroy(ilupp_ml *p);
 /* binding.cpp:237-254 apply / apply_trans, in place on a host vector; the _device form on a vector in HBM (sync as above) */
 int ilupp_hip_ml_apply(ilupp_ml *p, double *x, int64_t len, int transpose);

@@ -248,3 +248,38 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stderr.count("status 1 at step") + r.stderr.count("status 2 at step") > 20 and "status 3 at step" in r.stderr
+
+
+def test_batched_construction_is_the_same_objects_and_runs_side_by_side():
+    """ILUppPreconditioner.batch (ilupp_hip_ml_create_batch: BASELINE config 5's many-matrices shape): every member identical to the
+    object built alone -- levels, total_nnz, apply, apply_trans bit for bit, with the default (pivoting) parameters, with
+    default_configuration(10) and with the family without pivoting; matrices of different sizes in one batch; and a batch of 16
+    chains costs far less than 16 times one (they share one launch, one workgroup each)"""
+    import time
+    import ilupp_amd as ilupp
+    mats = [sp.csr_matrix(matgen.random_dd(n, 8, 25.0, 100 + k), shape=(n, n)) for k, n in enumerate([3000, 2500, 4000, 3000, 1200, 3500])]
+    for cfg in (None, 10, 1):
+        p = ilupp.iluplusplus_precond_parameter()
+        if cfg is not None:
+            p.default_configuration(cfg)
+        p.threshold = 1e-2
+        B = ilupp.ILUppPreconditioner.batch(mats, params=p)
+        assert len(B) == len(mats)
+        for A, Pb in zip(mats, B):
+            P1 = ilupp.ILUppPreconditioner(A, params=p)
+            b = C.rhs(A.shape[0])
+            assert Pb.total_nnz == P1.total_nnz and Pb.pr.levels() == P1.pr.levels()
+            assert np.array_equal(Pb @ b, P1 @ b) and np.array_equal(Pb.T @ b, P1.T @ b)
+    assert ilupp.ILUppPreconditioner.batch([]) == []
+    with pytest.raises(TypeError):
+        ilupp.ILUppPreconditioner.batch([mats[0], mats[1].tocsc()])
+    # side by side: 16 chains of n = 20000
+    big = [sp.csr_matrix(matgen.random_dd(20000, 8, 25.0, 500 + k), shape=(20000, 20000)) for k in range(16)]
+    p = ilupp.iluplusplus_precond_parameter()
+    p.default_configuration(10)
+    p.threshold = 1e-3
+    ilupp.ILUppPreconditioner(big[0], params=p)                                        # (warm: pool, code objects)
+    t0 = time.perf_counter(); one = ilupp.ILUppPreconditioner(big[0], params=p); t_one = time.perf_counter() - t0
+    t0 = time.perf_counter(); B = ilupp.ILUppPreconditioner.batch(big, params=p); t_batch = time.perf_counter() - t0
+    assert B[0].total_nnz == one.total_nnz and np.array_equal(B[0] @ C.rhs(20000), one @ C.rhs(20000))
+    assert t_batch < 4.0 * t_one, (t_batch, t_one)
