@@ -149,6 +149,37 @@ def ml_batch_member(dev, member, n=1000000, preset=1):
     return (member, int(Pm.levels()), int(Pm.total_nnz), hashlib.sha256(xb.cpu().numpy().tobytes()).hexdigest(), ms)
 
 
+def batch_config(steps, members=64, n=100000):
+    """C5PB: BASELINE config 5's many-matrices shape on ONE GPU: `members` matrices (n = 1e5 each), default_configuration(10) -- the
+    factorisation with pivoting, a sequential chain per matrix -- built side by side (ilupp_hip_ml_create_batch: the chains of all
+    members in one launch, one workgroup each), against the same construction for one matrix alone"""
+    import matgen
+    import ilupp_amd as ilupp
+    from ilupp_amd import _native
+    prm = ilupp.iluplusplus_precond_parameter()
+    prm.default_configuration(10)
+    prm.threshold = 1e-3
+    mats = [matgen.random_dd(n, 8, 25.0, 12345 + m) for m in range(members)]
+    one, bat = [], []
+    nnz_f = 0
+    for rep in range(max(2, min(steps, 3))):
+        t0 = time.perf_counter()
+        P = _native.MultilevelILUCDPPreconditioner(*mats[0], True, prm)
+        t1 = time.perf_counter()
+        Ps = _native.MultilevelILUCDPPreconditioner_batch(mats, True, prm)
+        t2 = time.perf_counter()
+        assert Ps[0].total_nnz == P.total_nnz
+        nnz_f = sum(int(q.total_nnz) for q in Ps)
+        if rep:
+            one.append(t1 - t0); bat.append(t2 - t1)
+        P = Ps = None
+    s1, sb = float(np.median(one)), float(np.median(bat))
+    return {"workload": "C5PB: %d x ILUppPreconditioner(default_configuration(10), threshold=1e-3), random unsymmetric CSR n=%d each, host arrays in, "
+                        "built side by side (one launch for all chains)" % (members, n),
+            "members": members, "n": n, "construct_one_s": s1, "construct_batch_s": sb, "batch_over_one": sb / s1, "matrices_per_s": members / sb,
+            "factor_nnz_total": nnz_f}
+
+
 def extra_config(name, dev, steps):
     """C3 / C4 on device-resident inputs: seconds, factor bytes (read A + write the factors produced), GB/s"""
     import torch
@@ -255,7 +286,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "C5P", "ILUC", "S27", "S9"],
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "C5P", "C5PB", "ILUC", "S27", "S9"],
                     help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, C5M, C5P, ILUC)")
     ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, C5, ILUC) and the refactor loop")
     args = ap.parse_args()
@@ -530,12 +561,16 @@ def main():
         extra = {}
         cfgs = list(args.config)
         if not args.no_extra and world == 1:
-            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "C5P", "ILUC") if c not in cfgs] + cfgs
+            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "C5P", "C5PB", "ILUC") if c not in cfgs] + cfgs
         for cfg in cfgs:
             if cfg in ("C3", "C4", "C5", "C5M", "C5P", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))
+            elif cfg == "C5PB" and world == 1:
+                del_txs = txs[:]
+                txs.clear(); del del_txs
+                extra[cfg] = batch_config(args.steps)
         if extra:
             out["extra"] = extra
         print(json.dumps(out))
