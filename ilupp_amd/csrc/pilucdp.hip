@@ -477,16 +477,27 @@ __device__ __forceinline__ bool lv_touch(const LdsVec &v, int &nnz, int c, int l
 }
 // the row / column `who` of A (entries e0 .. e1 of ai / av) into an empty vector: entries whose index is alive (and is not `dead`), a
 // doubly stored index keeps its last value; false: no room
-__device__ __forceinline__ bool lv_load(const LdsVec &v, int &nnz, const int32_t *ai, const double *av, int e0, int e1, const int32_t *alive, int dead, int lane)
+// this lane's entry of the first 64 of a row / column of A with its liveness flag, fetched ahead
+struct OwnPipe { int c, pc, live; double x; };
+__device__ __forceinline__ void op_entries(OwnPipe &o, const int32_t *ai, const double *av, int e0, int e1, int lane)
+{
+    const int e = e0 + lane;
+    o.c = -1; o.pc = -1; o.x = 0.0; o.live = 0;
+    if (e < e1) { o.c = ai[e]; o.x = av[e]; if (e > e0) o.pc = ai[e - 1]; }
+}
+__device__ __forceinline__ void op_live(OwnPipe &o, const int32_t *alive) { if (o.c >= 0) o.live = alive[o.c]; }
+
+__device__ __forceinline__ bool lv_load(const LdsVec &v, int &nnz, const int32_t *ai, const double *av, int e0, int e1, const int32_t *alive, int dead, int lane,
+                                        const OwnPipe *pre = nullptr)
 {
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int base = e0; base < e1; base += 64) {
         const int e = base + lane;
         const bool act = e < e1;
-        const int c = act ? ai[e] : -1;
-        const int pc = (act && e > e0) ? ai[e - 1] : -1;
-        const double x = act ? av[e] : 0.0;
-        const bool ok = act && c != dead && alive[c] != 0;
+        int c, pc, live; double x;
+        if (pre && base == e0) { c = pre->c; pc = pre->pc; x = pre->x; live = pre->live; }
+        else { c = act ? ai[e] : -1; pc = (act && e > e0) ? ai[e - 1] : -1; x = act ? av[e] : 0.0; live = act ? alive[c] : 0; }
+        const bool ok = act && c != dead && live != 0;
         const bool first = ok && c != pc;
         const unsigned long long mask = __ballot(first);
         if (nnz + __popcll(mask) > kLvCap) return false;
@@ -526,21 +537,39 @@ __device__ __forceinline__ DpLive dp_live(const int32_t *alive, const DpEnt &t, 
 
 // v -= (value of the node / pivot of its row) * (row of the other factor), for every node of the list from `start`, in list order; new
 // indices are appended in entry order.  Nodes, extents, entries and liveness flags are read four nodes ahead.  false: no room.
+// the read-ahead state of a list walk: four nodes, the extents of three rows, the entries of two, the liveness flags of one
+struct ListPipe { DpNode n1, n2, n3, n4; DpRow a1, a2, a3; DpEnt t1, t2; DpLive l1; };
+struct ListSrc { const int32_t *who; const double *nval; const int32_t *link; const double *Dinv; const int32_t *ptr; const int32_t *eidx; const double *eval; const int32_t *alive; };
+// the four levels of loads that fill a pipe; each level needs what the level before it brought (the caller interleaves the levels of
+// several pipes so that their round trips overlap)
+__device__ __forceinline__ void lp_level1(ListPipe &p, const ListSrc &S, int start) { p.n1 = dp_node(S.who, S.nval, S.link, start); }
+__device__ __forceinline__ void lp_level2(ListPipe &p, const ListSrc &S) { p.a1 = dp_row(S.Dinv, S.ptr, p.n1); p.n2 = dp_node(S.who, S.nval, S.link, p.n1.link); }
+__device__ __forceinline__ void lp_level3(ListPipe &p, const ListSrc &S, int lane)
+{ p.t1 = dp_ent(S.eidx, S.eval, p.a1, lane); p.a2 = dp_row(S.Dinv, S.ptr, p.n2); p.n3 = dp_node(S.who, S.nval, S.link, p.n2.link); }
+__device__ __forceinline__ void lp_level4(ListPipe &p, const ListSrc &S, int lane)
+{ p.l1 = dp_live(S.alive, p.t1, p.a1, lane); p.t2 = dp_ent(S.eidx, S.eval, p.a2, lane); p.a3 = dp_row(S.Dinv, S.ptr, p.n3); p.n4 = dp_node(S.who, S.nval, S.link, p.n3.link); }
+
+__device__ __forceinline__ bool lv_subtract_pipe(const LdsVec &v, int &nnz, ListPipe &P, const ListSrc &S, int dead, int lane);
+
 __device__ __forceinline__ bool lv_subtract_list(const LdsVec &v, int &nnz, int start, const int32_t *who, const double *nval, const int32_t *link,
                                                  const double *Dinv, const int32_t *ptr, const int32_t *eidx, const double *eval, const int32_t *alive, int dead,
                                                  int lane)
 {
+    const ListSrc S{who, nval, link, Dinv, ptr, eidx, eval, alive};
+    ListPipe P;
+    lp_level1(P, S, start); lp_level2(P, S); lp_level3(P, S, lane); lp_level4(P, S, lane);
+    return lv_subtract_pipe(v, nnz, P, S, dead, lane);
+}
+
+__device__ __forceinline__ bool lv_subtract_pipe(const LdsVec &v, int &nnz, ListPipe &P, const ListSrc &S, int dead, int lane)
+{
     const unsigned long long lt = (1ull << lane) - 1ull;
-    DpNode n1 = dp_node(who, nval, link, start);
-    DpRow a1 = dp_row(Dinv, ptr, n1);
-    DpNode n2 = dp_node(who, nval, link, n1.link);
-    DpEnt t1 = dp_ent(eidx, eval, a1, lane);
-    DpRow a2 = dp_row(Dinv, ptr, n2);
-    DpNode n3 = dp_node(who, nval, link, n2.link);
-    DpLive l1 = dp_live(alive, t1, a1, lane);
-    DpEnt t2 = dp_ent(eidx, eval, a2, lane);
-    DpRow a3 = dp_row(Dinv, ptr, n3);
-    DpNode n4 = dp_node(who, nval, link, n3.link);
+    const int32_t *who = S.who, *link = S.link, *ptr = S.ptr, *eidx = S.eidx, *alive = S.alive;
+    const double *nval = S.nval, *Dinv = S.Dinv, *eval = S.eval;
+    DpNode n1 = P.n1, n2 = P.n2, n3 = P.n3, n4 = P.n4;
+    DpRow a1 = P.a1, a2 = P.a2, a3 = P.a3;
+    DpEnt t1 = P.t1, t2 = P.t2;
+    DpLive l1 = P.l1;
     while (n1.at != -1) {
         const DpLive l2 = dp_live(alive, t2, a2, lane);
         const DpEnt t3 = dp_ent(eidx, eval, a3, lane);
@@ -646,13 +675,25 @@ __device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
         const int perm_k = A.perm[k];
         lv_clear(z, lane); lv_clear(w, lane);
         znnz = wnnz = 0;
+        // everything the step reads about its row -- and, on the guess that the diagonal will be the pivot, about its column -- is asked for
+        // level by level for both at once: the row / column of A with liveness flags, the first four nodes of both multiplier lists
+        const ListSrc SL{A.colL, A.Lval, A.linkL, A.Dinv, A.Uptr, A.Uidx, A.Uval, A.nonpiv}, SU{A.rowU, A.Uval, A.linkU, A.Dinv, A.Lptr, A.Lidx, A.Lval, A.unused};
         const int r0 = A.Ap[sel], r1 = A.Ap[sel + 1], head = A.startL[sel];
         const int sel_alive = A.nonpiv[sel];
+        const int gc0 = A.Cp[sel], gc1 = A.Cp[sel + 1], gheadU = A.startU[sel];
+        OwnPipe zo, wo;
+        ListPipe zl, wl;
+        op_entries(zo, A.Ai, A.Av, r0, r1, lane); lp_level1(zl, SL, head);
+        op_entries(wo, A.Ci, A.Cv, gc0, gc1, lane); lp_level1(wl, SU, gheadU);
+        op_live(zo, A.nonpiv); lp_level2(zl, SL);
+        op_live(wo, A.unused); lp_level2(wl, SU);
+        lp_level3(zl, SL, lane); lp_level3(wl, SU, lane);
+        lp_level4(zl, SL, lane); lp_level4(wl, SU, lane);
         LV_SYNC();
-        if (!lv_load(z, znnz, A.Ai, A.Av, r0, r1, A.nonpiv, -1, lane)) DPL_STOP(4);
+        if (!lv_load(z, znnz, A.Ai, A.Av, r0, r1, A.nonpiv, -1, lane, &zo)) DPL_STOP(4);
         DP_T(0);
         // (3.) :472-487: the rows of U this row has multipliers for
-        if (!lv_subtract_list(z, znnz, head, A.colL, A.Lval, A.linkL, A.Dinv, A.Uptr, A.Uidx, A.Uval, A.nonpiv, -1, lane)) DPL_STOP(4);
+        if (!lv_subtract_pipe(z, znnz, zl, SL, -1, lane)) DPL_STOP(4);
         DP_T(1);
         double pivot = 0.0;
         int pslot = -1;
@@ -685,10 +726,16 @@ __device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
         if (elim_step) {                                                            // :613-651, the column of L first (nothing is written before both vectors stand)
             dinv = 1.0 / pivot;
             const int c = pos_pivot;
-            const int c0 = A.Cp[c], c1 = A.Cp[c + 1], headU = A.startU[c];
-            if (!lv_load(w, wnnz, A.Ci, A.Cv, c0, c1, A.unused, sel, lane)) DPL_STOP(4);
-            DP_T(3);
-            if (!lv_subtract_list(w, wnnz, headU, A.rowU, A.Uval, A.linkU, A.Dinv, A.Lptr, A.Lidx, A.Lval, A.unused, sel, lane)) DPL_STOP(4);
+            if (c == sel) {                                                         // the guess held: the column is here already
+                if (!lv_load(w, wnnz, A.Ci, A.Cv, gc0, gc1, A.unused, sel, lane, &wo)) DPL_STOP(4);
+                DP_T(3);
+                if (!lv_subtract_pipe(w, wnnz, wl, SU, sel, lane)) DPL_STOP(4);
+            } else {
+                const int c0 = A.Cp[c], c1 = A.Cp[c + 1], headU = A.startU[c];
+                if (!lv_load(w, wnnz, A.Ci, A.Cv, c0, c1, A.unused, sel, lane)) DPL_STOP(4);
+                DP_T(3);
+                if (!lv_subtract_list(w, wnnz, headU, A.rowU, A.Uval, A.linkU, A.Dinv, A.Lptr, A.Lidx, A.Lval, A.unused, sel, lane)) DPL_STOP(4);
+            }
         }
         DP_T(4);
         // ---- the step stands: its effects ----
