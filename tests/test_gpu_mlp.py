@@ -217,6 +217,24 @@ def test_larger():
         _same(_native_ml(a, p), Q, n, (n, thr, "config 10"))
 
 
+def test_config10_full_size():
+    """BASELINE config 5 AS NAMED at its full size: default_configuration(10) -- maximum weighted matching + the factorisation with pivoting
+    (parameters_implementation.h:547-550) -- on the n = 10^6 unsymmetric matrix of the bench, against the REAL reference where oracle/_ref
+    travelled with the snapshot (else against the oracle's restatement): levels, every level's arrays, apply and apply_trans bit for bit.
+    (A chain of 10^6 sequential steps: ~20 s on the GPU, ~7-10 s on the host core beside it.)"""
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    n = 1000000
+    d, i, p_ = matgen.random_dd(n, 8, 25.0, 12345)
+    a = (d, i, p_, True)
+    p = ilupp.iluplusplus_precond_parameter()
+    p.default_configuration(10)
+    p.threshold = 1e-3
+    lib = O.ref() if O.ref_available() else O.orc()
+    Q = lib.ml(a, C.block_to_oracle(O, p._to_ml_params()))
+    _same(_native_ml(a, p), Q, n, ("config 10, n = 1e6", "reference" if O.ref_available() else "oracle"))
+
+
 def test_stores_that_fill_up():
     """the kernel stops between two steps when a store has no room for another row, the store is enlarged and the kernel goes on with that
     step: with stores of a few hundred entries (ILUPP_DP_STORE) that happens dozens of times -- same bits"""
