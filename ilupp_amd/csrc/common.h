@@ -50,6 +50,16 @@ struct PoolBlock {
 };
 template <class T> inline hipError_t pool_malloc(T **p, size_t bytes) { return pool_malloc(reinterpret_cast<void **>(p), bytes); }
 
+// two events that bracket a kernel for its time; destroyed on every way out of the scope (ILUPP_HIP throws)
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventPair() {}
+    EventPair(const EventPair &) = delete;
+    EventPair &operator=(const EventPair &) = delete;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    hipError_t create() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+};
+
 // ---- device containers ----------------------------------------------------------------------
 // A compressed sparse matrix resident in HBM.  `is_csr` is only the LABEL handed back to the
 // caller (reference: matrix_sparse::orientation); kernels always see "major slices".

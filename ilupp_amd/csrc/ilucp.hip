@@ -398,17 +398,16 @@ int ilucp_factor(hipStream_t st, const DevMat &C, int32_t max_fill_in, double th
         ILUPP_HIP(hipcub::DeviceRadixSort::SortKeys(b_tmp.p, tb, b_k0.as<unsigned long long>(), b_k1.as<unsigned long long>(), n, 0, 64, st));
         hipLaunchKernelGGL(k_cp_chains, dim3((n + 255) / 256), dim3(256), 0, st, n, b_k1.as<unsigned long long>(), a.listA, a.headA);
     }
-    hipEvent_t e0, e1;
-    ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
-    ILUPP_HIP(hipEventRecord(e0, st));
+    EventPair ev;
+    ILUPP_HIP(ev.create());
+    ILUPP_HIP(hipEventRecord(ev.a, st));
     hipLaunchKernelGGL(k_ilucp, dim3(1), dim3(64), 0, st, a);
-    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipEventRecord(ev.b, st));
     int32_t ctrl[8] = {0};
     ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
-    ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     if (kernel_ms) *kernel_ms = ms;
     if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilucp: n %d, stores of %lld: status %d at step %d, %.2f ms\n", n, (long long)reserved, ctrl[0], ctrl[5], ms);
     if (ctrl[0] != 0) { set_error("ILUCP4: Insufficient memory reserved. Increase mem_factor"); return ILUPP_ERR_MEMORY; }

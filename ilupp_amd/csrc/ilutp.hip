@@ -282,17 +282,16 @@ int ilutp_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double th
     ILUPP_HIP(hipMemsetAsync(a.Uptr, 0, sizeof(int32_t), st));
     ILUPP_HIP(hipMemsetAsync(a.Lptr, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_tp_init, dim3((n + 255) / 256), dim3(256), 0, st, n, a.perm, a.iperm, a.occ);
-    hipEvent_t e0, e1;
-    ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
-    ILUPP_HIP(hipEventRecord(e0, st));
+    EventPair ev;
+    ILUPP_HIP(ev.create());
+    ILUPP_HIP(hipEventRecord(ev.a, st));
     hipLaunchKernelGGL(k_ilutp, dim3(1), dim3(64), 0, st, a);
-    ILUPP_HIP(hipEventRecord(e1, st));
+    ILUPP_HIP(hipEventRecord(ev.b, st));
     int32_t ctrl[8] = {0};
     ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
-    ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     if (kernel_ms) *kernel_ms = ms;
     if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilutp: n %d, stores of %lld: status %d at row %d, %.2f ms\n", n, (long long)reserved, ctrl[0], ctrl[5], ms);
     if (ctrl[0] == 3) { set_error("ILUTP2: memory reserved was insufficient."); return ILUPP_ERR_MEMORY; }

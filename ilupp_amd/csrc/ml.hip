@@ -168,12 +168,12 @@ static int permute_matrix(hipStream_t st, DevMat *A, const int32_t *d_p1, const 
 {
     const int32_t n = A->n;
     const int64_t nnz = A->nnz;
-    PoolBlock b_len, b_k0, b_k1, b_v1, b_tmp;
-    int32_t *nptr = nullptr;
+    PoolBlock b_len, b_k0, b_k1, b_v1, b_tmp, b_nptr;                          // (b_nptr: the new row pointers, handed to A at the end)
     ILUPP_HIP(b_len.alloc(sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(pool_malloc(&nptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(b_nptr.alloc(sizeof(int32_t) * (size_t)(n + 1)));
+    int32_t *nptr = b_nptr.as<int32_t>();
     hipLaunchKernelGGL(k_ml_perm_lengths, dim3((n + 256) / 256), dim3(256), 0, st, n, A->ptr, d_p1, b_len.as<int32_t>());
-    { const int rc = scan_i32(st, b_len.as<int32_t>(), nptr, n + 1); if (rc) { (void)pool_free(nptr); return rc; } }
+    { const int rc = scan_i32(st, b_len.as<int32_t>(), nptr, n + 1); if (rc) return rc; }
     if (nnz > 0) {
         ILUPP_HIP(b_k0.alloc(sizeof(unsigned long long) * (size_t)nnz));
         ILUPP_HIP(b_k1.alloc(sizeof(unsigned long long) * (size_t)nnz));
@@ -190,7 +190,7 @@ static int permute_matrix(hipStream_t st, DevMat *A, const int32_t *d_p1, const 
     }
     ILUPP_HIP(hipStreamSynchronize(st));
     (void)pool_free(A->ptr);
-    A->ptr = nptr;
+    A->ptr = static_cast<int32_t *>(b_nptr.release());
     return ILUPP_OK;
 }
 
@@ -324,7 +324,8 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
         if (IP.pre[s] != ML_PRE_PQ_ORDERING) *bad_at = n;
         switch (IP.pre[s]) {
         case ML_PRE_NORMALIZE_COLUMNS: {                                       // :5241-5246
-            DevMat T;
+            struct Temp { DevMat m; ~Temp() { m.release(); } } tmp_T;
+            DevMat &T = tmp_T.m;
             transpose_storage(st, *A, &T);                                     // (column-major copy: the entries of a column by increasing row)
             hipLaunchKernelGGL(k_ml_col_norms, dim3(gb), dim3(256), 0, st, n, T.ptr, T.val, b_D.as<double>());
             if (A->nnz > 0)
@@ -442,7 +443,8 @@ static int preprocess_level(hipStream_t st, DevMat *A, const MlParams &IP, int32
         }
         case ML_PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM: {                         // :5441-5450
             const int64_t nnz = A->nnz;
-            DevMat T;
+            struct Temp { DevMat m; ~Temp() { m.release(); } } tmp_T;
+            DevMat &T = tmp_T.m;
             transpose_storage(st, *A, &T);
             std::vector<int32_t> hp((size_t)n + 1), hi((size_t)(nnz > 0 ? nnz : 1)), tp((size_t)n + 1), ti((size_t)(nnz > 0 ? nnz : 1)), hp1, hip1((size_t)n);
             std::vector<double> hv((size_t)(nnz > 0 ? nnz : 1)), tv((size_t)(nnz > 0 ? nnz : 1));

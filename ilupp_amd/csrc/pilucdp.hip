@@ -982,14 +982,13 @@ static void chain_batch_fire(ChainBatch *b)
         struct Free { DpArgs *p; ~Free() { (void)hipFree(p); } } guard{dev};
         ILUPP_HIP(hipMemcpyAsync(dev, host.data(), sizeof(DpArgs) * (size_t)cnt, hipMemcpyHostToDevice, b->stream));
         for (int i = 0; i < cnt; ++i) ILUPP_HIP(hipStreamWaitEvent(b->stream, b->waiting[(size_t)i]->before, 0));
-        hipEvent_t e0, e1;
-        ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
-        ILUPP_HIP(hipEventRecord(e0, b->stream));
+        EventPair ev;
+        ILUPP_HIP(ev.create());
+        ILUPP_HIP(hipEventRecord(ev.a, b->stream));
         hipLaunchKernelGGL(k_pilucdp_lds_batch, dim3((unsigned)cnt), dim3(64), 0, b->stream, (const DpArgs *)dev);
-        ILUPP_HIP(hipEventRecord(e1, b->stream));
+        ILUPP_HIP(hipEventRecord(ev.b, b->stream));
         ILUPP_HIP(hipStreamSynchronize(b->stream));
-        ILUPP_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
         if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] pilucdp: %d chains in one launch, %.2f ms\n", cnt, ms);
     } catch (const HipError &e) { set_error(std::string("HIP error in the batched chain launch: ") + hipGetErrorString(e.code)); rc = ILUPP_ERR_HIP; }
     for (ChainBatch::Item *it : b->waiting) { it->ms = ms; it->rc = rc; it->done = true; }
@@ -1010,19 +1009,19 @@ static int chain_launch(hipStream_t st, const DpArgs &a, bool in_lds, float *ms)
     ChainBatch *b = t_batch;
     *ms = 0.f;
     if (!b || !in_lds) {
-        hipEvent_t e0, e1;
-        ILUPP_HIP(hipEventCreate(&e0)); ILUPP_HIP(hipEventCreate(&e1));
-        ILUPP_HIP(hipEventRecord(e0, st));
+        EventPair ev;
+        ILUPP_HIP(ev.create());
+        ILUPP_HIP(hipEventRecord(ev.a, st));
         if (in_lds) hipLaunchKernelGGL(k_pilucdp_lds, dim3(1), dim3(64), 0, st, a);
         else hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
-        ILUPP_HIP(hipEventRecord(e1, st));
+        ILUPP_HIP(hipEventRecord(ev.b, st));
         ILUPP_HIP(hipStreamSynchronize(st));
-        ILUPP_HIP(hipEventElapsedTime(ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        ILUPP_HIP(hipEventElapsedTime(ms, ev.a, ev.b));
         return ILUPP_OK;
     }
     ChainBatch::Item it{&a, nullptr, 0.f, false, ILUPP_OK};
     ILUPP_HIP(hipEventCreateWithFlags(&it.before, hipEventDisableTiming));
+    struct DropEvent { hipEvent_t e; ~DropEvent() { (void)hipEventDestroy(e); } } drop{it.before};
     ILUPP_HIP(hipEventRecord(it.before, st));                  // (what this thread queued for the chain: initialisation, enlarged stores)
     {
         std::unique_lock<std::mutex> lk(b->mu);
@@ -1030,7 +1029,6 @@ static int chain_launch(hipStream_t st, const DpArgs &a, bool in_lds, float *ms)
         if ((int)b->waiting.size() == b->live) chain_batch_fire(b);
         else b->cv.wait(lk, [&] { return it.done; });
     }
-    (void)hipEventDestroy(it.before);
     *ms = it.ms;
     return it.rc;                                              // (the batch's stream has been synchronised: the chain's results are there)
 }

@@ -571,3 +571,42 @@ def test_icholt_long_dense_tail_does_not_time_out():
     the wait itself (the factorisation used to end with "dependency wait timed out")"""
     import fuzz_util
     assert fuzz_util.run(1, first_seed=1245, verbose=False) == 0
+
+
+def test_constructions_from_two_threads():
+    """the reference lets two Python threads build preconditioners at once (the GIL is released during a factorisation, binding.cpp:292-294,
+    :371); here the constructions of a process take turns inside the library (the pool knows nothing of streams), so whatever the
+    threads do, every object is the one a lone construction gives -- several kinds of objects, many rounds, both bindings"""
+    import threading
+    import ilupp_amd as ilupp
+    import matgen
+    d, i, p = matgen.poisson3d(40, 36, 30)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    B = sp.csr_matrix(matgen.random_dd(20000, 8, 25.0, 77), shape=(20000, 20000))
+    prm = ilupp.iluplusplus_precond_parameter()
+    prm.default_configuration(1)
+    prm.threshold = 1e-2
+    makers = [lambda: ilupp.ILU0Preconditioner(A), lambda: ilupp.ILUTPreconditioner(B, 10, 1e-3), lambda: ilupp.ILUppPreconditioner(B, params=prm),
+              lambda: ilupp.ILUCPreconditioner(A, 6, 1e-2), lambda: ilupp.IChol0Preconditioner(A)]
+    rhs = {n: np.linspace(1.0, 2.0, n), 20000: np.linspace(1.0, 2.0, 20000)}
+    want = [m() @ rhs[m().shape[0]] for m in makers]
+    errors = []
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(12):
+                k = int(rng.integers(0, len(makers)))
+                P = makers[k]()
+                if not np.array_equal(P @ rhs[P.shape[0]], want[k]):
+                    errors.append((seed, k))
+        except Exception as e:          # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
