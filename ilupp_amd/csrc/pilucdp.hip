@@ -44,7 +44,8 @@ struct DpArgs {
     double threshold, shift_schur, min_pivot, min_elim_factor, piv_tol, move_level_factor, row_u_max;
     int32_t small_pivot_terminates, force_finish, begin_total_piv, final_row_crit, bp, bpr, epr, max_fill;
     int32_t rules, combine, scale_invdiag;
-    double wgt[5], neutral, min_weight;
+    double wgt[6], neutral, min_weight;
+    double *inv;       // inverse-based dropping: xU yU vxU vyU xL yL vxL vyL, n each (null without that rule)
     int32_t *perm, *iperm, *prow, *iprow, *numb, *pnum;
     int32_t *nonpiv, *unused;
     double *Dinv;
@@ -63,7 +64,7 @@ struct DpArgs {
 };
 
 // combine() and the weight of a row of U / a column of L, ILUCDP.hpp:717-726 / :905-914 (parameters_implementation.h:526-534)
-__device__ double dp_weight(const DpArgs &A, double n2own, double n1other, double dinv)
+__device__ double dp_weight(const DpArgs &A, double n2own, double n1other, double dinv, double inv)
 {
     double w = A.neutral;
     auto comb = [&](double x, double y) {
@@ -76,12 +77,56 @@ __device__ double dp_weight(const DpArgs &A, double n2own, double n1other, doubl
     };
     if (A.rules & PILUC_DROP_STANDARD) { const double norm = n2own == 0.0 ? 1e-16 : n2own; w = comb(w, A.wgt[0] / norm); }
     if (A.rules & PILUC_DROP_STANDARD2) w = comb(w, A.wgt[1]);
+    if (A.rules & PILUC_DROP_INVERSE) w = comb(w, A.wgt[5] * inv);
     if (A.rules & PILUC_DROP_ERR_PROP) w = comb(w, A.wgt[2] * n1other);
     if (A.rules & PILUC_DROP_ERR_PROP2) w = comb(w, A.wgt[3] * n1other / fabs(dinv));
     if (A.rules & PILUC_DROP_PIVOT) w = comb(w, A.wgt[4] * fabs(dinv));
     if (A.scale_invdiag) w = w * fabs(dinv);
     return w;
 }
+
+// Inverse-based dropping (ILUCDP.hpp:680-713 for the row of U, :882-916 for the column of L): two estimates x, y of the growth of the
+// inverse factor at index pk, built from running products VX, VY over the steps in their order.  v: the scaled working vector of the
+// step (its slots through acc.idx(s) / acc.val(s), in insertion order -- the two 1-norms below are summed in that order, as the
+// reference does; the counts are order-free).  Returns max(|x[pk]|, |y[pk]|), the factor of the dropping weight.
+template <class Acc>
+__device__ double dp_inverse_update(const Acc &acc, int nnz, int k, int pk, double *X, double *Y, double *VX, double *VY, int lane)
+{
+    auto smax = [](double a, double b) { return a < b ? b : a; };                // std::max
+    if (k == 0) {
+        for (int s = lane; s < nnz; s += 64) { const int c = acc.idx(s); const double x = acc.val(s); VX[c] = x; VY[c] = x; }
+        if (lane == 0) { X[pk] = 1.0; Y[pk] = 1.0; }
+        return 1.0;
+    }
+    const double vxp = VX[pk], vyp = VY[pk];
+    const double xplus = 1.0 - vxp, xminus = -1.0 - vxp, yplus = 1.0 - vyp, yminus = -1.0 - vyp;
+    double nuplus = 0.0, numinus = 0.0;
+    int nplus = 0, nminus = 0;
+    for (int base = 0; base < nnz; base += 64) {
+        const int s = base + lane;
+        const bool act = s < nnz;
+        const int c = act ? acc.idx(s) : 0;
+        const double zv = act ? acc.val(s) : 0.0;
+        const double vx = act ? VX[c] : 0.0, vi = act ? VY[c] : 0.0;
+        const double tp = act ? fabs(vx + zv * xplus) : 0.0, tm = act ? fabs(vx + zv * xminus) : 0.0;
+        const int cnt = nnz - base < 64 ? nnz - base : 64;
+        for (int i = 0; i < cnt; ++i) { nuplus = nuplus + wv_f64(tp, i); numinus = numinus + wv_f64(tm, i); }
+        const double yp = fabs(vi + zv * yplus), ym = fabs(vi + zv * yminus), lim = smax(2.0 * fabs(vi), 0.5);
+        nplus += __popcll(__ballot(act && yp > lim)) - __popcll(__ballot(act && smax(2.0 * yp, 0.5) < fabs(vi)));
+        nminus += __popcll(__ballot(act && ym > lim)) - __popcll(__ballot(act && smax(2.0 * ym, 0.5) < fabs(vi)));
+    }
+    const double xk = nuplus > numinus ? xplus : xminus, yk = nplus > nminus ? yplus : yminus;
+    for (int s = lane; s < nnz; s += 64) {
+        const int c = acc.idx(s);
+        const double zv = acc.val(s);
+        VX[c] = VX[c] + zv * xk;
+        VY[c] = VY[c] + zv * yk;
+    }
+    const double xe = smax(fabs(xplus), fabs(xminus)), ye = smax(fabs(yplus), fabs(yminus));
+    if (lane == 0) { X[pk] = xe; Y[pk] = ye; }
+    return smax(fabs(xe), fabs(ye));
+}
+struct SpAcc { SpVec v; __device__ int idx(int s) const { return v.list[s]; } __device__ double val(int s) const { return v.rec[v.list[s]].val; } };
 
 // the entries that pass the dropping rule, in insertion order (take_single_weight_largest_elements_by_abs_value_with_threshold,
 // sparse_implementation.h:1360-1415: weight * |x| >= tau; take_largest_elements_by_abs_value_with_threshold, :1322-1357: |x| > norm * tau),
@@ -299,7 +344,12 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             const double n2z = (A.rules & PILUC_DROP_STANDARD) ? sqrt(dp_seq_sum(z, znnz, 1, lane)) : 0.0;
             const double n1w = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? dp_seq_sum(w, wnnz, 0, lane) : 0.0;
             n1z = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? dp_seq_sum(z, znnz, 0, lane) : 0.0;
-            const double weightU = dp_weight(A, n2z, n1w, dinv);
+            double invU = 0.0;
+            if (A.rules & PILUC_DROP_INVERSE) {
+                invU = dp_inverse_update(SpAcc{z}, znnz, k, pos_pivot, A.inv, A.inv + n, A.inv + 2 * (size_t)n, A.inv + 3 * (size_t)n, lane);
+                DP_SYNC();
+            }
+            const double weightU = dp_weight(A, n2z, n1w, dinv, invU);
             nU = dp_take(A, z, znnz, true, weightU, threshold, A.max_fill - 1, lane);
         }
         DP_T(7);
@@ -331,7 +381,12 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
         // ---- the column of L, :849-1005 ----
         if (eliminate) {
             const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(dp_seq_sum(w, wnnz, 1, lane)) : 0.0;
-            const double weightL = dp_weight(A, n2w, n1z, dinv);
+            double invL = 0.0;
+            if (A.rules & PILUC_DROP_INVERSE) {
+                invL = dp_inverse_update(SpAcc{w}, wnnz, k, sel, A.inv + 4 * (size_t)n, A.inv + 5 * (size_t)n, A.inv + 6 * (size_t)n, A.inv + 7 * (size_t)n, lane);
+                DP_SYNC();
+            }
+            const double weightL = dp_weight(A, n2w, n1z, dinv, invL);
             const int nL = dp_take(A, w, wnnz, true, weightL, threshold, A.max_fill, lane);
             const int p0 = pL;
             pL += nL + 1;
@@ -437,6 +492,7 @@ constexpr int kLvHash = 4096;                   // slots of its index -> slot ta
 constexpr int kPnL = 1024;                      // bucket boundaries (pnum) cached in LDS: counts below this
 
 struct LdsVec { int32_t *idx; double *val; int32_t *hkey; unsigned short *hslot; };
+struct LvAcc { LdsVec v; __device__ int idx(int s) const { return v.idx[s]; } __device__ double val(int s) const { return v.val[s]; } };
 
 #define LV_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")        // one wave: LDS operations complete in order; this orders the compiler
 
@@ -774,7 +830,10 @@ __device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
             const double n2z = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(z, znnz, 1, lane)) : 0.0;
             const double n1w = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(w, wnnz, 0, lane) : 0.0;
             n1z = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(z, znnz, 0, lane) : 0.0;
-            const double weightU = dp_weight(A, n2z, n1w, dinv);
+            double invU = 0.0;
+            if (A.rules & PILUC_DROP_INVERSE)
+                invU = dp_inverse_update(LvAcc{z}, znnz, k, pos_pivot, A.inv, A.inv + n, A.inv + 2 * (size_t)n, A.inv + 3 * (size_t)n, lane);
+            const double weightU = dp_weight(A, n2z, n1w, dinv, invU);
             nU = lv_take(z, znnz, true, weightU, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane);
         }
         DP_T(6);
@@ -810,7 +869,10 @@ __device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
         // ---- the column of L, :849-1005 ----
         if (elim_step) {
             const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(w, wnnz, 1, lane)) : 0.0;
-            const double weightL = dp_weight(A, n2w, n1z, dinv);
+            double invL = 0.0;
+            if (A.rules & PILUC_DROP_INVERSE)
+                invL = dp_inverse_update(LvAcc{w}, wnnz, k, sel, A.inv + 4 * (size_t)n, A.inv + 5 * (size_t)n, A.inv + 6 * (size_t)n, A.inv + 7 * (size_t)n, lane);
+            const double weightL = dp_weight(A, n2w, n1z, dinv, invL);
             const int nL = lv_take(w, wnnz, true, weightL, threshold, A.max_fill, s_key, s_cand, s_sort, lane);
             const int p0 = pL;
             pL += nL + 1;
@@ -1189,7 +1251,14 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     a.small_pivot_terminates = P.small_pivot_terminates ? 1 : 0; a.force_finish = force_finish ? 1 : 0; a.begin_total_piv = P.begin_total_piv ? 1 : 0;
     a.final_row_crit = P.final_row_crit; a.bp = bp; a.bpr = bpr; a.epr = epr; a.max_fill = max_fill;
     a.rules = P.rules; a.combine = P.combine; a.scale_invdiag = P.scale_invdiag ? 1 : 0;
-    for (int q = 0; q < 5; ++q) a.wgt[q] = P.wgt[q];
+    for (int q = 0; q < 6; ++q) a.wgt[q] = P.wgt[q];
+    PoolBlock b_inv;
+    a.inv = nullptr;
+    if (P.rules & PILUC_DROP_INVERSE) {                                             // :423-425: eight vectors of zeros
+        ILUPP_HIP(b_inv.alloc(sizeof(double) * 8 * (size_t)n));
+        ILUPP_HIP(hipMemsetAsync(b_inv.p, 0, sizeof(double) * 8 * (size_t)n, st));
+        a.inv = b_inv.as<double>();
+    }
     a.neutral = P.neutral; a.min_weight = P.min_weight;
     a.perm = iarr(0); a.iperm = iarr(1); a.prow = iarr(2); a.iprow = iarr(3); a.numb = iarr(4); a.pnum = iarr(5);
     a.nonpiv = iarr(6); a.unused = iarr(7); a.startU = iarr(8); a.startL = iarr(9);

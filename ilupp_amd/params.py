@@ -193,12 +193,16 @@ class iluplusplus_precond_parameter:
             raise ValueError("choose permissible value for PERMUTE_ROWS / TOTAL_PIV!")
         if not self._uses_partial_iluc() and not (-1 <= self.FINAL_ROW_CRIT <= 9):
             refuse("FINAL_ROW_CRIT = %r with the pivoting factorisation (rows ordered by weights instead of counts)" % (self.FINAL_ROW_CRIT,))
-        seq_rules = [k for k in ("USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2") if getattr(self, k)]
+        # rules whose estimates accumulate over the steps in their sequential order: the inverse-based one is built where the steps are
+        # sequential anyway (the factorisation with pivoting, a chain walked by one wave); the weighted ones are not built
+        seq_rules = [k for k in ("USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2") if getattr(self, k)]
+        if self.USE_INVERSE_DROPPING and self._uses_partial_iluc():
+            seq_rules.append("USE_INVERSE_DROPPING (with the factorisation without pivoting)")
         if seq_rules:
             refuse("dropping by " + ", ".join(seq_rules) + " (these rules accumulate estimates over the steps in their sequential order)")
         rules = 0
         for bit, k in ((1, "USE_STANDARD_DROPPING"), (2, "USE_STANDARD_DROPPING2"), (4, "USE_ERR_PROP_DROPPING"), (8, "USE_ERR_PROP_DROPPING2"),
-                       (16, "USE_PIVOT_DROPPING")):
+                       (16, "USE_PIVOT_DROPPING"), (32, "USE_INVERSE_DROPPING")):
             if getattr(self, k):
                 rules |= bit
         checks = [("DROP_TYPE_L", 0), ("DROP_TYPE_U", 0), ("SCHUR_COMPLEMENT", 0), ("EXTERNAL_FINAL_ROW", False),
@@ -238,6 +242,7 @@ class iluplusplus_precond_parameter:
         p.weight_standard_drop, p.weight_standard_drop2 = float(self.WEIGHT_STANDARD_DROP), float(self.WEIGHT_STANDARD_DROP2)
         p.weight_err_prop_drop, p.weight_err_prop_drop2 = float(self.WEIGHT_ERR_PROP_DROP), float(self.WEIGHT_ERR_PROP_DROP2)
         p.weight_pivot_drop = float(self.WEIGHT_PIVOT_DROP)
+        p.weight_inverse_drop = float(self.WEIGHT_INVERSE_DROP)
         p.combine_factor = int(self.COMBINE_FACTOR) if int(self.COMBINE_FACTOR) in (0, 1, 2, 3) else 0       # combine(): default branch = max
         p.neutral_element, p.min_weight = float(self.NEUTRAL_ELEMENT), float(self.MIN_WEIGHT)
         p.scale_weight_invdiag = 1 if self.SCALE_WEIGHT_INVDIAG else 0

@@ -166,13 +166,18 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
  *   MultilevelILUCDPPreconditioner(A_data, A_indices, A_indptr, is_csr, iluplusplus_precond_parameter)
  *   -> multilevelILUCDPPreconditioner::make_preprocessed_multilevelILUCDP (preconditioner_implementation.h:1350-1665),
  *      apply :433-488, total_nnz preconditioner.h:312.
- * Built: the family WITHOUT pivoting (use_ILUC, :1385-1390: PERMUTE_ROWS 0, TOTAL_PIV 0, piv_tol 0 -- precon_parameter 10 of
- * parameters_implementation.h:927-934, e.g. default_configuration(1)) over matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) with
- * dropping by the combined weight of the standard / error-propagation / pivot rules (presets 10, 13, 1010, 1013; the inverse-based and
- * weighted rules accumulate over the steps in their sequential order and are not built), unbounded or bounded fill, levels ended by small pivots; preprocessing steps NORMALIZE_COLUMNS, NORMALIZE_ROWS,
- * PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING, DD_SYMM_MOVE_CORNER_ORDERING_IM, SYMM_PQ
- * (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter combination -- the pivoting factorisation partialILUCDP of
- * the default-constructed parameters among them -- is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
+ * Built: BOTH factorisations of make_preprocessed_multilevelILUCDP, chosen as the reference chooses (:1376-1382):
+ *   - WITHOUT pivoting (use_ILUC: PERMUTE_ROWS 0 / 1, TOTAL_PIV off, piv_tol 0 -- precon_parameter 10 of parameters_implementation.h:927-934,
+ *     e.g. default_configuration(1)): matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) as a dataflow computation over all CUs;
+ *   - WITH pivoting (the default-constructed parameters, default_configuration(0), (10)): matrix_sparse::partialILUCDP (:268-1404), a chain
+ *     of data-dependent steps walked by one wave; many matrices at once: ilupp_hip_ml_create_batch;
+ * dropping by the combined weight of the standard / error-propagation / pivot rules, and -- with pivoting -- the inverse-based rule
+ * (ILUPP_DROP_INVERSE; precon_parameter 1; its estimates accumulate over the steps in their sequential order, which the chain has anyway);
+ * unbounded or bounded fill; levels ended by small pivots or by the fill of L (FINAL_ROW_CRIT -1 .. 9); preprocessing steps
+ * NORMALIZE_COLUMNS, NORMALIZE_ROWS, PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING,
+ * DD_SYMM_MOVE_CORNER_ORDERING_IM, SYMM_PQ (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter
+ * combination (weighted dropping, the inverse-based rule without pivoting, the improved Schur complement, positional dropping, FINAL_ROW_CRIT
+ * < -1, an external final row) is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ilupp_ml ilupp_ml;
 
@@ -187,7 +192,9 @@ enum {                               /* preprocessing_type values (orderings.h) 
     ILUPP_PRE_SYMM_PQ = 8                             /* rows and columns by sym_ddPQ's weights (sparse_implementation.h:4926-4940, :5352-5360) */
 };
 
-enum { ILUPP_DROP_STANDARD = 1, ILUPP_DROP_STANDARD2 = 2, ILUPP_DROP_ERR_PROP = 4, ILUPP_DROP_ERR_PROP2 = 8, ILUPP_DROP_PIVOT = 16 };
+enum { ILUPP_DROP_STANDARD = 1, ILUPP_DROP_STANDARD2 = 2, ILUPP_DROP_ERR_PROP = 4, ILUPP_DROP_ERR_PROP2 = 8, ILUPP_DROP_PIVOT = 16,
+       ILUPP_DROP_INVERSE = 32 };   /* USE_INVERSE_DROPPING (ILUCDP.hpp:680-713, :882-916): estimates that accumulate over the steps in their order --
+                                       built for the factorisation with pivoting (a sequential chain anyway), refused for the one without */
 
 typedef struct {                     /* the fields of iluplusplus_precond_parameter (parameters.h:120-235) the built family reads */
     double threshold;                /* threshold */
@@ -219,6 +226,7 @@ typedef struct {                     /* the fields of iluplusplus_precond_parame
     int32_t final_row_crit;              /* FINAL_ROW_CRIT -1..9 */
     double move_level_factor;            /* MOVE_LEVEL_FACTOR */
     double row_u_max;                    /* ROW_U_MAX */
+    double weight_inverse_drop;          /* WEIGHT_INVERSE_DROP (with ILUPP_DROP_INVERSE; the factorisation with pivoting only) */
 } ilupp_ml_params;
 
 /* default_configuration(1) (parameters_implementation.h:546-549: set_PQ + precon_parameter 10) with threshold 0 */

@@ -1630,16 +1630,52 @@ static double ml_combine(const orc_ml_params *IP, double x, double y)
 
 /* the weight of a row of U (or column of L) for take_single_weight, ILUCDP.hpp:1719-1728 / :1896-1906: `own` is the vector that is dropped,
  * `other` the one of the other factor, dinv the Dinv[k] of that moment */
-static double ml_weight(const orc_ml_params *IP, const wvec *own, const wvec *other, double dinv)
+static double ml_weight(const orc_ml_params *IP, const wvec *own, const wvec *other, double dinv, double inv_estimate)
 {
     double w = IP->neutral_element;
     if (IP->drop_rules & ORC_DROP_STANDARD) { double norm = wv_norm2(own); if (norm == 0.0) norm = 1e-16; w = ml_combine(IP, w, IP->weight_standard_drop / norm); }
     if (IP->drop_rules & ORC_DROP_STANDARD2) w = ml_combine(IP, w, IP->weight_standard_drop2);
+    if (IP->drop_rules & ORC_DROP_INVERSE) w = ml_combine(IP, w, IP->weight_inverse_drop * inv_estimate);     /* :725 / :920, :1721 / :1894 */
     if (IP->drop_rules & ORC_DROP_ERR_PROP) w = ml_combine(IP, w, IP->weight_err_prop_drop * wv_norm1(other));
     if (IP->drop_rules & ORC_DROP_ERR_PROP2) w = ml_combine(IP, w, IP->weight_err_prop_drop2 * wv_norm1(other) / fabs(dinv));
     if (IP->drop_rules & ORC_DROP_PIVOT) w = ml_combine(IP, w, IP->weight_pivot_drop * fabs(dinv));
     if (IP->scale_weight_invdiag) w *= fabs(dinv);
     return w;
+}
+
+/* Inverse-based dropping (Bollhoefer's estimate of the growth of the inverse factors), ILUCDP.hpp:680-713 (row of U) / :882-916 (column of
+ * L); partialILUC :1676-1710 / :1856-1892: with v the scaled working vector of step k and pk the index its pivot stands for, x and y are two
+ * estimates of |e_pk^T U^-1| built from running products vx, vy over the steps IN THEIR ORDER -- x maximises the 1-norm of the updated
+ * products, y counts entries that grow / shrink by a factor of two.  Returns max(|x[pk]|, |y[pk]|), the factor of the dropping weight. */
+static double inv_update(const wvec *v, orc_int k, orc_int pk, double *x, double *y, double *vx, double *vy)
+{
+    orc_int j;
+    if (k == 0) {
+        x[pk] = 1.0; y[pk] = 1.0;
+        for (j = 0; j < v->nnz; ++j) vy[v->pointer[j]] = vx[v->pointer[j]] = v->data[j];
+    } else {
+        const double xplus = 1.0 - vx[pk], xminus = -1.0 - vx[pk], yplus = 1.0 - vy[pk], yminus = -1.0 - vy[pk];
+        double nuplus = 0.0, numinus = 0.0;
+        orc_int nplus = 0, nminus = 0;
+        for (j = 0; j < v->nnz; ++j) nuplus += fabs(vx[v->pointer[j]] + v->data[j] * xplus);
+        for (j = 0; j < v->nnz; ++j) numinus += fabs(vx[v->pointer[j]] + v->data[j] * xminus);
+        x[pk] = nuplus > numinus ? xplus : xminus;
+        for (j = 0; j < v->nnz; ++j) vx[v->pointer[j]] += v->data[j] * x[pk];
+        x[pk] = fabs(xplus) < fabs(xminus) ? fabs(xminus) : fabs(xplus);                       /* max(|xplus|, |xminus|): std::max(a, b) = a < b ? b : a */
+        for (j = 0; j < v->nnz; ++j) {
+            const double vi = vy[v->pointer[j]];
+            const double tp = fabs(vi + v->data[j] * yplus), tm = fabs(vi + v->data[j] * yminus);
+            const double lim = 2.0 * fabs(vi) < 0.5 ? 0.5 : 2.0 * fabs(vi);                   /* max(2|vi|, 0.5) */
+            if (tp > lim) nplus++;
+            if ((2.0 * tp < 0.5 ? 0.5 : 2.0 * tp) < fabs(vi)) nplus--;
+            if (tm > lim) nminus++;
+            if ((2.0 * tm < 0.5 ? 0.5 : 2.0 * tm) < fabs(vi)) nminus--;
+        }
+        y[pk] = nplus > nminus ? yplus : yminus;
+        for (j = 0; j < v->nnz; ++j) vy[v->pointer[j]] += v->data[j] * y[pk];
+        y[pk] = fabs(yplus) < fabs(yminus) ? fabs(yminus) : fabs(yplus);
+    }
+    return fabs(x[pk]) < fabs(y[pk]) ? fabs(y[pk]) : fabs(x[pk]);
 }
 
 /* matrix_sparse::partialILUC, ILUCDP.hpp:1405-2231, for the precon_parameter 10 family: err-prop dropping (weight of a row of U = the
@@ -1655,7 +1691,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
     orc_int last_row_to_eliminate = n - 1, n_Anew = 0;
     orc_int max_fill_in = IP->max_fill_in > 0 ? IP->max_fill_in : n;       /* :1440-1447: MAX_FILLIN_IS_INF => n; clamped to [1, n] */
     int eliminate = 1;
-    double pivot = 0.0;
+    double pivot = 0.0, *inv = NULL;
     orc_int *firstU, *listU, *firstL, *listL, *listA, *headA, *firstA, *list_L, *list_U;
     wvec z, w;
     if (max_fill_in < 1) max_fill_in = 1;
@@ -1672,12 +1708,13 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
     firstA = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));
     list_L = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16)); list_U = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16));
     wv_init(&z, n, 0); wv_init(&w, n, 0);
+    if (IP->drop_rules & ORC_DROP_INVERSE) inv = (double *)calloc(8 * (size_t)n + 1, sizeof(double));     /* xU yU vxU vyU xL yL vxL vyL, :1537-1546 */
     initialize_sparse_matrix_fields(n, ptr, idx, listA, headA, firstA);
     for (k = 0; k < n; ++k) { listL[k] = -1; listU[k] = -1; }
 
     for (k = 0; k < n; ++k) {
         orc_int nL = 0, nU;
-        double weightL, weightU;
+        double weightL, weightU, invU = 0.0, invL = 0.0;
         wv_zero_reset(&z);                                                     /* (2.) :1575-1583 */
         for (j = firstA[k]; j < ptr[k + 1]; ++j) z.data[wv_slot(&z, idx[j])] = val[j];
         for (h = listL[k]; h != -1; h = listL[h]) {                            /* (3.) :1589-1602 */
@@ -1715,12 +1752,13 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
                 }
             }
         }
-        for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* w.scale(Dinv[k]), :1676 */
+        for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* w.scale(Dinv[k]), :1665 */
+        if (inv && eliminate) invU = inv_update(&z, k, k, inv, inv + n, inv + 2 * (size_t)n, inv + 3 * (size_t)n);      /* :1676-1710 */
         /* dropping, :1716-1764 */
         if (!eliminate) {
             nU = take_largest(&z, list_U, max_fill_in, threshold, last_row_to_eliminate + 1, n);
         } else {
-            weightU = ml_weight(IP, &z, &w, Dinv[k]);
+            weightU = ml_weight(IP, &z, &w, Dinv[k], invU);
             nU = take_single_weight(&z, list_U, weightU, max_fill_in - 1, threshold, k + 1, n);
         }
         /* update U or Anew, :1769-1850 */
@@ -1741,7 +1779,8 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         }
         /* (12.) L, :1855-1975 */
         if (eliminate) {
-            weightL = ml_weight(IP, &w, &z, Dinv[k]);                          /* (Dinv[k] after the zero-pivot reset of :1786-1792) */
+            if (inv) invL = inv_update(&w, k, k, inv + 4 * (size_t)n, inv + 5 * (size_t)n, inv + 6 * (size_t)n, inv + 7 * (size_t)n);          /* :1856-1892 */
+            weightL = ml_weight(IP, &w, &z, Dinv[k], invL);                    /* (Dinv[k] after the zero-pivot reset of :1786-1792) */
             nL = take_single_weight(&w, list_L, weightL, max_fill_in - 1, threshold, k + 1, n);
             mat_reserve(L, L->ptr[k] + nL + 1, &capL);
             L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = k;
@@ -1773,7 +1812,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         }
     }
     wv_free(&z); wv_free(&w);
-    free(firstU); free(listU); free(firstL); free(listL); free(listA); free(headA); free(firstA); free(list_L); free(list_U);
+    free(firstU); free(listU); free(firstL); free(listL); free(listA); free(headA); free(firstA); free(list_L); free(list_U); free(inv);
     return ORC_OK;
 }
 
@@ -1821,7 +1860,7 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
     orc_int last_row_to_eliminate = n - 1, n_Anew = 0, pos_pivot = -1, selected_row;
     orc_int max_fill_in = IP->max_fill_in > 0 ? IP->max_fill_in : n;       /* :352-355 */
     int eliminate = 1, end_level_now = 0;
-    double pivot = 0.0, piv_tol = IP->piv_tol, val_larg_el;
+    double pivot = 0.0, piv_tol = IP->piv_tol, val_larg_el, *inv = NULL;
     orc_int *linkU = NULL, *rowU = NULL, *startU, *linkL = NULL, *colL = NULL, *startL, *list_L, *list_U, *numb, *pnum;
     char *non_pivot, *unused_rows;
     wvec z, w;
@@ -1849,10 +1888,11 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
     for (k = 0; k < n + 2; ++k) pnum[k] = epr + 1;                              /* :417, :437 */
     pnum[0] = 0;
     wv_init(&z, n, 0); wv_init(&w, n, 0);
+    if (IP->drop_rules & ORC_DROP_INVERSE) inv = (double *)calloc(8 * (size_t)n + 1, sizeof(double));     /* :423-425 */
 
     for (k = 0; k < n; ++k) {
         orc_int nL = 0, nU;
-        double weightL, weightU;
+        double weightL, weightU, invU = 0.0, invL = 0.0;
         if (IP->begin_total_piv && k == bp) piv_tol = 1.0;                      /* :448 */
         selected_row = permrows[k];                                            /* (2.) :453-466 */
         unused_rows[selected_row] = 0;
@@ -1914,9 +1954,10 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
             }
         }
         for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* :652 */
+        if (inv && eliminate) invU = inv_update(&z, k, perm[k], inv, inv + n, inv + 2 * (size_t)n, inv + 3 * (size_t)n);  /* :679-713 */
         if (!eliminate) nU = take_largest(&z, list_U, max_fill_in, threshold, 0, n);      /* :714-716 */
         else {
-            weightU = ml_weight(IP, &z, &w, Dinv[k]);
+            weightU = ml_weight(IP, &z, &w, Dinv[k], invU);
             nU = take_single_weight(&z, list_U, weightU, max_fill_in - 1, threshold, 0, n);
         }
         if (eliminate) {                                                       /* :761-797 (the list backwards) */
@@ -1942,7 +1983,8 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
             Anew->ptr[k_Anew + 1] = Anew->ptr[k_Anew] + nU;
         }
         if (eliminate) {                                                       /* L, :849-1005 */
-            weightL = ml_weight(IP, &w, &z, Dinv[k]);
+            if (inv) invL = inv_update(&w, k, selected_row, inv + 4 * (size_t)n, inv + 5 * (size_t)n, inv + 6 * (size_t)n, inv + 7 * (size_t)n);   /* :880-916 */
+            weightL = ml_weight(IP, &w, &z, Dinv[k], invL);
             nL = take_single_weight(&w, list_L, weightL, max_fill_in, threshold, 0, n);
             if (L->ptr[k] + nL + 1 > capL) { mat_reserve(L, L->ptr[k] + nL + 1, &capL); links_reserve(&linkL, &colL, &haveL, capL); }
             L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = selected_row;
@@ -2013,7 +2055,7 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
     for (j = 0; j < U->nnz; ++j) U->idx[j] = inverse_perm[U->idx[j]];          /* U.permute(perm, COLUMN) */
     mat_normal_order(U);
     wv_free(&z); wv_free(&w);
-    free(linkU); free(rowU); free(startU); free(linkL); free(colL); free(startL); free(list_L); free(list_U); free(numb); free(pnum);
+    free(linkU); free(rowU); free(startU); free(linkL); free(colL); free(startL); free(list_L); free(list_U); free(numb); free(pnum); free(inv);
     free(non_pivot); free(unused_rows);
     return ORC_OK;
 }
@@ -2052,6 +2094,7 @@ void orc_ml_default_params(orc_ml_params *p)       /* default_parameters (:430-5
     p->max_fill_in = 0;
     p->drop_rules = ORC_DROP_ERR_PROP;
     p->weight_standard_drop = p->weight_standard_drop2 = p->weight_err_prop_drop = p->weight_err_prop_drop2 = p->weight_pivot_drop = 1.0;
+    p->weight_inverse_drop = 1.0;
     p->combine_factor = 0;
     p->neutral_element = 0.0;
     p->min_weight = 1.0;

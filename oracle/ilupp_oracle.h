@@ -101,7 +101,7 @@ enum {                                   /* steps of a preprocessing_sequence (o
     ORC_PRE_SYMM_PQ = 8
 };
 
-enum { ORC_DROP_STANDARD = 1, ORC_DROP_STANDARD2 = 2, ORC_DROP_ERR_PROP = 4, ORC_DROP_ERR_PROP2 = 8, ORC_DROP_PIVOT = 16 };
+enum { ORC_DROP_STANDARD = 1, ORC_DROP_STANDARD2 = 2, ORC_DROP_ERR_PROP = 4, ORC_DROP_ERR_PROP2 = 8, ORC_DROP_PIVOT = 16, ORC_DROP_INVERSE = 32 };
 
 typedef struct {
     double threshold;                    /* tau of the first level */
@@ -118,7 +118,7 @@ typedef struct {
     int use_final_threshold;             /* USE_FINAL_THRESHOLD */
     double final_threshold;              /* FINAL_THRESHOLD */
     orc_int max_fill_in;                 /* 0: MAX_FILLIN_IS_INF; else fill_in (entries a row of U / a column of L may have, the 1 included) */
-    int drop_rules;                      /* ORC_DROP_*: USE_STANDARD_DROPPING, _DROPPING2, USE_ERR_PROP_DROPPING, _DROPPING2, USE_PIVOT_DROPPING */
+    int drop_rules;                      /* ORC_DROP_*: USE_STANDARD_DROPPING, _DROPPING2, USE_ERR_PROP_DROPPING, _DROPPING2, USE_PIVOT_DROPPING, USE_INVERSE_DROPPING */
     double weight_standard_drop, weight_standard_drop2, weight_err_prop_drop, weight_err_prop_drop2, weight_pivot_drop;   /* WEIGHT_* */
     int combine_factor;                  /* COMBINE_FACTOR */
     double neutral_element, min_weight;  /* NEUTRAL_ELEMENT, MIN_WEIGHT */
@@ -132,6 +132,7 @@ typedef struct {
     int final_row_crit;                  /* FINAL_ROW_CRIT -1..9 (the ones that count the entries of a row of L) */
     double move_level_factor;            /* MOVE_LEVEL_FACTOR */
     double row_u_max;                    /* ROW_U_MAX */
+    double weight_inverse_drop;          /* WEIGHT_INVERSE_DROP (with ORC_DROP_INVERSE: USE_INVERSE_DROPPING, ILUCDP.hpp:680-713, :882-916) */
 } orc_ml_params;
 
 typedef struct orc_ml orc_ml;

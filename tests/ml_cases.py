@@ -96,7 +96,8 @@ _ORC_FIELDS = {"MAX_LEVELS": "max_levels", "THRESHOLD_SHIFT_SCHUR": "threshold_s
                "WEIGHT_ERR_PROP_DROP": "weight_err_prop_drop", "WEIGHT_ERR_PROP_DROP2": "weight_err_prop_drop2", "WEIGHT_PIVOT_DROP": "weight_pivot_drop",
                "COMBINE_FACTOR": "combine_factor", "NEUTRAL_ELEMENT": "neutral_element", "MIN_WEIGHT": "min_weight", "SCALE_WEIGHT_INVDIAG": "scale_weight_invdiag",
                "piv_tol": "piv_tol", "PERMUTE_ROWS": "permute_rows", "TOTAL_PIV": "total_piv", "BEGIN_TOTAL_PIV": "begin_total_piv",
-               "FINAL_ROW_CRIT": "final_row_crit", "MOVE_LEVEL_FACTOR": "move_level_factor", "ROW_U_MAX": "row_u_max"}
+               "FINAL_ROW_CRIT": "final_row_crit", "MOVE_LEVEL_FACTOR": "move_level_factor", "ROW_U_MAX": "row_u_max",
+               "WEIGHT_INVERSE_DROP": "weight_inverse_drop"}
 
 # the reference's DEFAULT-constructed parameters (precon_parameter 0, parameters_implementation.h:430-501): the factorisation with pivoting
 PIVOTING = {"piv_tol": 1.0, "PERMUTE_ROWS": 3, "TOTAL_PIV": 1, "BEGIN_TOTAL_PIV": True, "SMALL_PIVOT_TERMINATES": False, "MIN_ELIM_FACTOR": 0.5}
@@ -123,11 +124,16 @@ PIVOT_PARAMS = [
     ("p_t0.01_rows2_crit7", 1e-2, ("MAX_WEIGHTED_MATCHING_ORDERING",), pivoting(PERMUTE_ROWS=2, FINAL_ROW_CRIT=7, MIN_ELIM_FACTOR=0.0)),
     ("p_t0.001_fill5_std", 1e-3, ("PQ_ORDERING",), pivoting(fill_in=5, USE_STANDARD_DROPPING=True, THRESHOLD_SHIFT_SCHUR=0.5)),
     ("p_t0.05_smallpiv", 0.05, ("PQ_ORDERING",), pivoting(SMALL_PIVOT_TERMINATES=True, MIN_ELIM_FACTOR=0.1, MOVE_LEVEL_FACTOR=0.5)),
+    # inverse-based dropping (precon_parameter 1 = the default-constructed parameters with USE_INVERSE_DROPPING instead of the error-propagation
+    # rule, parameters_implementation.h:872-876), alone, combined with another rule, with its weight changed
+    ("p_t0.1_inv", 0.1, ("PQ_ORDERING",), pivoting(USE_INVERSE_DROPPING=True, USE_ERR_PROP_DROPPING=False)),
+    ("p_t0.02_inv_mwm", 0.02, ("MAX_WEIGHTED_MATCHING_ORDERING",), pivoting(USE_INVERSE_DROPPING=True, USE_ERR_PROP_DROPPING=False)),
+    ("p_t0.05_inv_err_sum", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), pivoting(USE_INVERSE_DROPPING=True, COMBINE_FACTOR=1, WEIGHT_INVERSE_DROP=0.25)),
 ]
 
 
 _RULES = (("USE_STANDARD_DROPPING", 1, False), ("USE_STANDARD_DROPPING2", 2, False), ("USE_ERR_PROP_DROPPING", 4, True), ("USE_ERR_PROP_DROPPING2", 8, False),
-          ("USE_PIVOT_DROPPING", 16, False))
+          ("USE_PIVOT_DROPPING", 16, False), ("USE_INVERSE_DROPPING", 32, False))
 
 
 def oracle_params(O, thr, pre, knobs):

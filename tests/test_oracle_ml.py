@@ -76,8 +76,9 @@ def test_oracle_against_reference_live():
         A = (sp.random(n, n, density=dens, random_state=rng, format="csr") + sp.eye(n) * dg).tocsr()
         for fmt in ("csr", "csc"):
             a = O.from_scipy(A.asformat(fmt))
-            for thr in (0.0, 0.03, 0.3):
-                p = O.ml_params(thr)
+            for thr, rules in ((0.0, O.DROP_ERR_PROP), (0.03, O.DROP_ERR_PROP), (0.3, O.DROP_ERR_PROP), (0.05, O.DROP_INVERSE),
+                               (0.02, O.DROP_INVERSE | O.DROP_STANDARD)):            # (inverse-based dropping of partialILUC, ILUCDP.hpp:1676-1710, :1856-1892)
+                p = O.ml_params(thr, drop_rules=rules)
                 R, P = O.ref().ml(a, p), O.orc().ml(a, p)
                 assert R.levels() == P.levels() and R.total_nnz() == P.total_nnz()
                 for k in range(R.levels()):
@@ -177,6 +178,25 @@ def test_everything_outside_the_built_family_is_refused():
     refused(lambda p: setattr(p, "SCHUR_COMPLEMENT", 1), start=None)
     with pytest.raises(ValueError):
         p = ilupp.iluplusplus_precond_parameter(); p.PERMUTE_ROWS = 4; p._to_ml_params()
+
+
+def test_inverse_based_dropping_goes_with_the_pivoting_family():
+    """USE_INVERSE_DROPPING (precon_parameter 1: parameters_implementation.h:872-876) accumulates estimates over the steps in their order:
+    built where the steps are a sequential chain anyway (the factorisation with pivoting), refused for the dataflow factorisation"""
+    import ilupp_amd as ilupp
+    p = ilupp.iluplusplus_precond_parameter()                  # default-constructed: the pivoting family
+    p.use_only_inverse_dropping()
+    b = p._to_ml_params()
+    assert b.drop_rules == 32 and b.weight_inverse_drop == 1.0 and not p._uses_partial_iluc()
+    p.USE_ERR_PROP_DROPPING = True
+    p.WEIGHT_INVERSE_DROP = 0.5
+    b = p._to_ml_params()
+    assert b.drop_rules == 36 and b.weight_inverse_drop == 0.5
+    q = ilupp.iluplusplus_precond_parameter()
+    q.default_configuration(1)                                 # without pivoting
+    q.USE_INVERSE_DROPPING = True
+    with pytest.raises(NotImplementedError, match="USE_INVERSE_DROPPING"):
+        q._to_ml_params()
 
 
 def test_parameter_block_of_the_pivoting_family():
