@@ -37,7 +37,7 @@ class MLParams(ctypes.Structure):
                 ("scale_weight_invdiag", ctypes.c_int32),
                 ("piv_tol", ctypes.c_double), ("permute_rows", ctypes.c_int32), ("total_piv", ctypes.c_int32), ("begin_total_piv", ctypes.c_int32),
                 ("final_row_crit", ctypes.c_int32), ("move_level_factor", ctypes.c_double), ("row_u_max", ctypes.c_double),
-                ("weight_inverse_drop", ctypes.c_double)]
+                ("weight_inverse_drop", ctypes.c_double), ("weight_weighted_drop", ctypes.c_double), ("init_weights_lu", ctypes.c_double)]
 
 
 _lib = None

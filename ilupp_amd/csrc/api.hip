@@ -1441,6 +1441,7 @@ int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
     P.pil.rules = ip->drop_rules; P.pil.combine = ip->combine_factor; P.pil.scale_invdiag = ip->scale_weight_invdiag != 0;
     P.pil.wgt[0] = ip->weight_standard_drop; P.pil.wgt[1] = ip->weight_standard_drop2; P.pil.wgt[2] = ip->weight_err_prop_drop;
     P.pil.wgt[3] = ip->weight_err_prop_drop2; P.pil.wgt[4] = ip->weight_pivot_drop; P.pil.wgt[5] = ip->weight_inverse_drop;
+    P.pil.wgt[6] = ip->weight_weighted_drop; P.pil.init_weights_lu = ip->init_weights_lu;
     P.pil.neutral = ip->neutral_element; P.pil.min_weight = ip->min_weight;
     P.pil.piv_tol = ip->piv_tol; P.pil.permute_rows = ip->permute_rows; P.pil.total_piv = ip->total_piv; P.pil.begin_total_piv = ip->begin_total_piv != 0;
     P.pil.final_row_crit = ip->final_row_crit; P.pil.move_level_factor = ip->move_level_factor; P.pil.row_u_max = ip->row_u_max;
@@ -1449,10 +1450,10 @@ int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
         set_error("ILU++: FINAL_ROW_CRIT " + std::to_string(P.pil.final_row_crit) + " (rows ordered by weights instead of counts) is not built");
         return ILUPP_ERR_UNSUPPORTED;
     }
-    if ((P.pil.rules & ~63) != 0) { set_error("ILU++: unknown dropping rule"); return ILUPP_ERR_INVALID; }
-    if ((P.pil.rules & PILUC_DROP_INVERSE) && !P.pil.pivoting()) {
-        set_error("ILU++: inverse-based dropping (estimates that accumulate over the steps in their order) is built for the factorisation with "
-                  "pivoting only");
+    if ((P.pil.rules & ~255) != 0) { set_error("ILU++: unknown dropping rule"); return ILUPP_ERR_INVALID; }
+    if ((P.pil.rules & (PILUC_DROP_INVERSE | PILUC_DROP_WEIGHTED | PILUC_DROP_WEIGHTED2)) && !P.pil.pivoting()) {
+        set_error("ILU++: inverse-based and weighted dropping (estimates that accumulate over the steps in their order) are built for the "
+                  "factorisation with pivoting only");
         return ILUPP_ERR_UNSUPPORTED;
     }
     struct MlGuard { ilupp_ml *m; ~MlGuard() { if (m) ml_destroy(m); } } g{new ilupp_ml()};
@@ -1514,7 +1515,7 @@ void ilupp_hip_ml_default_params(ilupp_ml_params *p)
     p->max_fill_in = 0;
     p->drop_rules = ILUPP_DROP_ERR_PROP;
     p->weight_standard_drop = p->weight_standard_drop2 = p->weight_err_prop_drop = p->weight_err_prop_drop2 = p->weight_pivot_drop = 1.0;
-    p->weight_inverse_drop = 1.0;
+    p->weight_inverse_drop = 1.0; p->weight_weighted_drop = 1.0; p->init_weights_lu = 1.0;
     p->combine_factor = 0; p->neutral_element = 0.0; p->min_weight = 1.0; p->scale_weight_invdiag = 0;
     p->piv_tol = 0.0; p->permute_rows = 0; p->total_piv = 0; p->begin_total_piv = 1;        // (init case 10, :927-934)
     p->final_row_crit = -1; p->move_level_factor = 2.0; p->row_u_max = 1.5;

@@ -370,7 +370,8 @@ struct PilucParams {
     int32_t rules = 4;                    // PILUC_DROP_*: which rules make up the weight of a row (default: error propagation)
     int32_t combine = 0;                  // COMBINE_FACTOR
     bool scale_invdiag = false;           // SCALE_WEIGHT_INVDIAG
-    double wgt[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};   // WEIGHT_STANDARD_DROP, _DROP2, WEIGHT_ERR_PROP_DROP, _DROP2, WEIGHT_PIVOT_DROP, WEIGHT_INVERSE_DROP
+    double wgt[7] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};   // WEIGHT_STANDARD_DROP, _DROP2, WEIGHT_ERR_PROP_DROP, _DROP2, WEIGHT_PIVOT_DROP, WEIGHT_INVERSE_DROP, WEIGHT_WEIGHTED_DROP
+    double init_weights_lu = 1.0;         // INIT_WEIGHTS_LU
     double neutral = 0.0, min_weight = 1.0;      // NEUTRAL_ELEMENT, MIN_WEIGHT
     // the factorisation with pivoting (pilucdp.hip)
     double piv_tol = 0.0;                 // piv_tol
@@ -382,7 +383,7 @@ struct PilucParams {
     bool pivoting() const { return !((permute_rows == 0 || permute_rows == 1) && (!begin_total_piv || total_piv == 0) && piv_tol == 0.0); }
 };
 enum { PILUC_DROP_STANDARD = 1, PILUC_DROP_STANDARD2 = 2, PILUC_DROP_ERR_PROP = 4, PILUC_DROP_ERR_PROP2 = 8, PILUC_DROP_PIVOT = 16,
-       PILUC_DROP_INVERSE = 32 };   // = ILUPP_DROP_*
+       PILUC_DROP_INVERSE = 32, PILUC_DROP_WEIGHTED = 64, PILUC_DROP_WEIGHTED2 = 128 };   // = ILUPP_DROP_*
 int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv, DevMat *Anew,
                 int32_t *kterm, float *kernel_ms);
 

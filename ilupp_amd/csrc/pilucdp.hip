@@ -23,6 +23,7 @@
 // Afterwards, grid-wide kernels drop the explicit zeros (compress(), :1131-1132), renumber rows and columns by the inverse
 // permutations and sort every row / column (permute(), :1150-1151; Anew: :1136-1145) with one radix sort per matrix.
 #include <stdlib.h>
+#include <string.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -44,8 +45,9 @@ struct DpArgs {
     double threshold, shift_schur, min_pivot, min_elim_factor, piv_tol, move_level_factor, row_u_max;
     int32_t small_pivot_terminates, force_finish, begin_total_piv, final_row_crit, bp, bpr, epr, max_fill;
     int32_t rules, combine, scale_invdiag;
-    double wgt[6], neutral, min_weight;
+    double wgt[7], neutral, min_weight;
     double *inv;       // inverse-based dropping: xU yU vxU vyU xL yL vxL vyL, n each (null without that rule)
+    double *wts;       // weighted dropping: weightsU, weightsL, n each (null without those rules)
     int32_t *perm, *iperm, *prow, *iprow, *numb, *pnum;
     int32_t *nonpiv, *unused;
     double *Dinv;
@@ -64,7 +66,7 @@ struct DpArgs {
 };
 
 // combine() and the weight of a row of U / a column of L, ILUCDP.hpp:717-726 / :905-914 (parameters_implementation.h:526-534)
-__device__ double dp_weight(const DpArgs &A, double n2own, double n1other, double dinv, double inv)
+__device__ double dp_weight(const DpArgs &A, double n2own, double n1other, double dinv, double inv, double accumulated)
 {
     double w = A.neutral;
     auto comb = [&](double x, double y) {
@@ -78,6 +80,7 @@ __device__ double dp_weight(const DpArgs &A, double n2own, double n1other, doubl
     if (A.rules & PILUC_DROP_STANDARD) { const double norm = n2own == 0.0 ? 1e-16 : n2own; w = comb(w, A.wgt[0] / norm); }
     if (A.rules & PILUC_DROP_STANDARD2) w = comb(w, A.wgt[1]);
     if (A.rules & PILUC_DROP_INVERSE) w = comb(w, A.wgt[5] * inv);
+    if (A.rules & PILUC_DROP_WEIGHTED) w = comb(w, A.wgt[6] * accumulated);
     if (A.rules & PILUC_DROP_ERR_PROP) w = comb(w, A.wgt[2] * n1other);
     if (A.rules & PILUC_DROP_ERR_PROP2) w = comb(w, A.wgt[3] * n1other / fabs(dinv));
     if (A.rules & PILUC_DROP_PIVOT) w = comb(w, A.wgt[4] * fabs(dinv));
@@ -125,6 +128,16 @@ __device__ double dp_inverse_update(const Acc &acc, int nnz, int k, int pk, doub
     const double xe = smax(fabs(xplus), fabs(xminus)), ye = smax(fabs(yplus), fabs(yminus));
     if (lane == 0) { X[pk] = xe; Y[pk] = ye; }
     return smax(fabs(xe), fabs(ye));
+}
+// weighted dropping (ILUCDP.hpp:629-631, :670-674): every index of the step's vector collects the magnitude of its entry (one add per index
+// and step, the steps in their order).  Returns what the accumulated weight of `pk` is after it (pk_in: pk is an index of the vector --
+// the zeroed pivot of a row of U -- and gets +|0|; a column of L does not hold its own row).
+template <class Acc>
+__device__ double dp_accumulate_weights(const Acc &acc, int nnz, double *W, int pk, bool pk_in, int lane)
+{
+    const double old = W[pk];
+    for (int s = lane; s < nnz; s += 64) { const int c = acc.idx(s); W[c] = W[c] + fabs(acc.val(s)); }
+    return pk_in ? old + 0.0 : old;
 }
 struct SpAcc { SpVec v; __device__ int idx(int s) const { return v.list[s]; } __device__ double val(int s) const { return v.rec[v.list[s]].val; } };
 
@@ -292,6 +305,10 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             prev_pivot = pos_pivot;
             DP_SYNC();
             DP_T(3);
+        }
+        double wtdU = 0.0, wtdL = 0.0;
+        if (A.wts) { wtdU = dp_accumulate_weights(SpAcc{z}, znnz, A.wts, eliminate ? pos_pivot : 0, eliminate, lane); DP_SYNC(); }      // :629-631
+        if (eliminate) {
             {                                                                       // the column of L, :633-651
                 const int c = pos_pivot;                                            // = perm[k] now
                 const int c0 = A.Cp[c], c1 = A.Cp[c + 1];
@@ -333,6 +350,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
             for (int s = lane; s < wnnz; s += 64) { const int r = w.list[s]; w.rec[r].val = w.rec[r].val * dinv; }     // :652
             DP_SYNC();
             DP_T(6);
+            if (A.wts) { wtdL = dp_accumulate_weights(SpAcc{w}, wnnz, A.wts + n, sel, false, lane); DP_SYNC(); }               // :670-674
         }
         // ---- dropping in the row, :714-759 ----
         int nU;
@@ -349,7 +367,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                 invU = dp_inverse_update(SpAcc{z}, znnz, k, pos_pivot, A.inv, A.inv + n, A.inv + 2 * (size_t)n, A.inv + 3 * (size_t)n, lane);
                 DP_SYNC();
             }
-            const double weightU = dp_weight(A, n2z, n1w, dinv, invU);
+            const double weightU = dp_weight(A, n2z, n1w, dinv, invU, wtdU);
             nU = dp_take(A, z, znnz, true, weightU, threshold, A.max_fill - 1, lane);
         }
         DP_T(7);
@@ -386,7 +404,7 @@ __global__ void __launch_bounds__(64) k_pilucdp(DpArgs A)
                 invL = dp_inverse_update(SpAcc{w}, wnnz, k, sel, A.inv + 4 * (size_t)n, A.inv + 5 * (size_t)n, A.inv + 6 * (size_t)n, A.inv + 7 * (size_t)n, lane);
                 DP_SYNC();
             }
-            const double weightL = dp_weight(A, n2w, n1z, dinv, invL);
+            const double weightL = dp_weight(A, n2w, n1z, dinv, invL, wtdL);
             const int nL = dp_take(A, w, wnnz, true, weightL, threshold, A.max_fill, lane);
             const int p0 = pL;
             pL += nL + 1;
@@ -819,6 +837,11 @@ __device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
             }
             LV_SYNC();
         }
+        double wtdU = 0.0, wtdL = 0.0;
+        if (A.wts) {                                                                // weighted dropping: :629-631, :670-674
+            wtdU = dp_accumulate_weights(LvAcc{z}, znnz, A.wts, elim_step ? pos_pivot : 0, elim_step, lane);
+            if (elim_step) wtdL = dp_accumulate_weights(LvAcc{w}, wnnz, A.wts + n, sel, false, lane);
+        }
         DP_T(5);
         // ---- dropping in the row, :714-759 ----
         int nU;
@@ -833,7 +856,7 @@ __device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
             double invU = 0.0;
             if (A.rules & PILUC_DROP_INVERSE)
                 invU = dp_inverse_update(LvAcc{z}, znnz, k, pos_pivot, A.inv, A.inv + n, A.inv + 2 * (size_t)n, A.inv + 3 * (size_t)n, lane);
-            const double weightU = dp_weight(A, n2z, n1w, dinv, invU);
+            const double weightU = dp_weight(A, n2z, n1w, dinv, invU, wtdU);
             nU = lv_take(z, znnz, true, weightU, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane);
         }
         DP_T(6);
@@ -872,7 +895,7 @@ __device__ __forceinline__ void dp_chain_lds(const DpArgs &A)
             double invL = 0.0;
             if (A.rules & PILUC_DROP_INVERSE)
                 invL = dp_inverse_update(LvAcc{w}, wnnz, k, sel, A.inv + 4 * (size_t)n, A.inv + 5 * (size_t)n, A.inv + 6 * (size_t)n, A.inv + 7 * (size_t)n, lane);
-            const double weightL = dp_weight(A, n2w, n1z, dinv, invL);
+            const double weightL = dp_weight(A, n2w, n1z, dinv, invL, wtdL);
             const int nL = lv_take(w, wnnz, true, weightL, threshold, A.max_fill, s_key, s_cand, s_sort, lane);
             const int p0 = pL;
             pL += nL + 1;
@@ -1251,9 +1274,14 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     a.small_pivot_terminates = P.small_pivot_terminates ? 1 : 0; a.force_finish = force_finish ? 1 : 0; a.begin_total_piv = P.begin_total_piv ? 1 : 0;
     a.final_row_crit = P.final_row_crit; a.bp = bp; a.bpr = bpr; a.epr = epr; a.max_fill = max_fill;
     a.rules = P.rules; a.combine = P.combine; a.scale_invdiag = P.scale_invdiag ? 1 : 0;
-    for (int q = 0; q < 6; ++q) a.wgt[q] = P.wgt[q];
-    PoolBlock b_inv;
-    a.inv = nullptr;
+    for (int q = 0; q < 7; ++q) a.wgt[q] = P.wgt[q];
+    PoolBlock b_inv, b_wts;
+    a.inv = nullptr; a.wts = nullptr;
+    if (P.rules & (PILUC_DROP_WEIGHTED | PILUC_DROP_WEIGHTED2)) {                   // :426-428: weightsU, weightsL
+        ILUPP_HIP(b_wts.alloc(sizeof(double) * 2 * (size_t)n));
+        a.wts = b_wts.as<double>();
+        { unsigned long long bits; memcpy(&bits, &P.init_weights_lu, sizeof(bits)); fill_u64(st, reinterpret_cast<unsigned long long *>(a.wts), 2 * (int64_t)n, bits); }
+    }
     if (P.rules & PILUC_DROP_INVERSE) {                                             // :423-425: eight vectors of zeros
         ILUPP_HIP(b_inv.alloc(sizeof(double) * 8 * (size_t)n));
         ILUPP_HIP(hipMemsetAsync(b_inv.p, 0, sizeof(double) * 8 * (size_t)n, st));

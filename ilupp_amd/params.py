@@ -195,14 +195,13 @@ class iluplusplus_precond_parameter:
             refuse("FINAL_ROW_CRIT = %r with the pivoting factorisation (rows ordered by weights instead of counts)" % (self.FINAL_ROW_CRIT,))
         # rules whose estimates accumulate over the steps in their sequential order: the inverse-based one is built where the steps are
         # sequential anyway (the factorisation with pivoting, a chain walked by one wave); the weighted ones are not built
-        seq_rules = [k for k in ("USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2") if getattr(self, k)]
-        if self.USE_INVERSE_DROPPING and self._uses_partial_iluc():
-            seq_rules.append("USE_INVERSE_DROPPING (with the factorisation without pivoting)")
+        seq_rules = [k + " (with the factorisation without pivoting)" for k in ("USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2")
+                     if getattr(self, k) and self._uses_partial_iluc()]
         if seq_rules:
             refuse("dropping by " + ", ".join(seq_rules) + " (these rules accumulate estimates over the steps in their sequential order)")
         rules = 0
         for bit, k in ((1, "USE_STANDARD_DROPPING"), (2, "USE_STANDARD_DROPPING2"), (4, "USE_ERR_PROP_DROPPING"), (8, "USE_ERR_PROP_DROPPING2"),
-                       (16, "USE_PIVOT_DROPPING"), (32, "USE_INVERSE_DROPPING")):
+                       (16, "USE_PIVOT_DROPPING"), (32, "USE_INVERSE_DROPPING"), (64, "USE_WEIGHTED_DROPPING"), (128, "USE_WEIGHTED_DROPPING2")):
             if getattr(self, k):
                 rules |= bit
         checks = [("DROP_TYPE_L", 0), ("DROP_TYPE_U", 0), ("SCHUR_COMPLEMENT", 0), ("EXTERNAL_FINAL_ROW", False),
@@ -243,6 +242,7 @@ class iluplusplus_precond_parameter:
         p.weight_err_prop_drop, p.weight_err_prop_drop2 = float(self.WEIGHT_ERR_PROP_DROP), float(self.WEIGHT_ERR_PROP_DROP2)
         p.weight_pivot_drop = float(self.WEIGHT_PIVOT_DROP)
         p.weight_inverse_drop = float(self.WEIGHT_INVERSE_DROP)
+        p.weight_weighted_drop, p.init_weights_lu = float(self.WEIGHT_WEIGHTED_DROP), float(self.INIT_WEIGHTS_LU)
         p.combine_factor = int(self.COMBINE_FACTOR) if int(self.COMBINE_FACTOR) in (0, 1, 2, 3) else 0       # combine(): default branch = max
         p.neutral_element, p.min_weight = float(self.NEUTRAL_ELEMENT), float(self.MIN_WEIGHT)
         p.scale_weight_invdiag = 1 if self.SCALE_WEIGHT_INVDIAG else 0

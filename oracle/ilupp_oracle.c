@@ -1630,12 +1630,13 @@ static double ml_combine(const orc_ml_params *IP, double x, double y)
 
 /* the weight of a row of U (or column of L) for take_single_weight, ILUCDP.hpp:1719-1728 / :1896-1906: `own` is the vector that is dropped,
  * `other` the one of the other factor, dinv the Dinv[k] of that moment */
-static double ml_weight(const orc_ml_params *IP, const wvec *own, const wvec *other, double dinv, double inv_estimate)
+static double ml_weight(const orc_ml_params *IP, const wvec *own, const wvec *other, double dinv, double inv_estimate, double accumulated)
 {
     double w = IP->neutral_element;
     if (IP->drop_rules & ORC_DROP_STANDARD) { double norm = wv_norm2(own); if (norm == 0.0) norm = 1e-16; w = ml_combine(IP, w, IP->weight_standard_drop / norm); }
     if (IP->drop_rules & ORC_DROP_STANDARD2) w = ml_combine(IP, w, IP->weight_standard_drop2);
     if (IP->drop_rules & ORC_DROP_INVERSE) w = ml_combine(IP, w, IP->weight_inverse_drop * inv_estimate);     /* :725 / :920, :1721 / :1894 */
+    if (IP->drop_rules & ORC_DROP_WEIGHTED) w = ml_combine(IP, w, IP->weight_weighted_drop * accumulated);     /* :726 / :921, :1722 / :1895 */
     if (IP->drop_rules & ORC_DROP_ERR_PROP) w = ml_combine(IP, w, IP->weight_err_prop_drop * wv_norm1(other));
     if (IP->drop_rules & ORC_DROP_ERR_PROP2) w = ml_combine(IP, w, IP->weight_err_prop_drop2 * wv_norm1(other) / fabs(dinv));
     if (IP->drop_rules & ORC_DROP_PIVOT) w = ml_combine(IP, w, IP->weight_pivot_drop * fabs(dinv));
@@ -1691,7 +1692,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
     orc_int last_row_to_eliminate = n - 1, n_Anew = 0;
     orc_int max_fill_in = IP->max_fill_in > 0 ? IP->max_fill_in : n;       /* :1440-1447: MAX_FILLIN_IS_INF => n; clamped to [1, n] */
     int eliminate = 1;
-    double pivot = 0.0, *inv = NULL;
+    double pivot = 0.0, *inv = NULL, *wts = NULL;
     orc_int *firstU, *listU, *firstL, *listL, *listA, *headA, *firstA, *list_L, *list_U;
     wvec z, w;
     if (max_fill_in < 1) max_fill_in = 1;
@@ -1709,6 +1710,10 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
     list_L = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16)); list_U = (orc_int *)malloc(sizeof(orc_int) * (2 * (size_t)n + 16));
     wv_init(&z, n, 0); wv_init(&w, n, 0);
     if (IP->drop_rules & ORC_DROP_INVERSE) inv = (double *)calloc(8 * (size_t)n + 1, sizeof(double));     /* xU yU vxU vyU xL yL vxL vyL, :1537-1546 */
+    if (IP->drop_rules & (ORC_DROP_WEIGHTED | ORC_DROP_WEIGHTED2)) {                                       /* weightsU, weightsL, :1547-1550 */
+        wts = (double *)malloc(sizeof(double) * (2 * (size_t)n + 1));
+        for (k = 0; k < 2 * n; ++k) wts[k] = IP->init_weights_lu;
+    }
     initialize_sparse_matrix_fields(n, ptr, idx, listA, headA, firstA);
     for (k = 0; k < n; ++k) { listL[k] = -1; listU[k] = -1; }
 
@@ -1741,6 +1746,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
             for (j = 0; j < z.nnz; ++j) z.data[j] *= Dinv[k];
             z.data[wv_slot(&z, k)] = 0.0;
         }
+        if (wts) for (j = 0; j < z.nnz; ++j) wts[z.pointer[j]] += fabs(z.data[j]);         /* weightsU, :1634-1636 */
         wv_zero_reset(&w);                                                     /* (8.) :1651-1675 */
         if (eliminate) {
             for (h = headA[k]; h != -1; h = listA[h])
@@ -1753,12 +1759,13 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
             }
         }
         for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* w.scale(Dinv[k]), :1665 */
+        if (wts) for (j = 0; j < w.nnz; ++j) wts[n + w.pointer[j]] += fabs(w.data[j]);                                /* weightsL, :1670-1675 */
         if (inv && eliminate) invU = inv_update(&z, k, k, inv, inv + n, inv + 2 * (size_t)n, inv + 3 * (size_t)n);      /* :1676-1710 */
         /* dropping, :1716-1764 */
         if (!eliminate) {
             nU = take_largest(&z, list_U, max_fill_in, threshold, last_row_to_eliminate + 1, n);
         } else {
-            weightU = ml_weight(IP, &z, &w, Dinv[k], invU);
+            weightU = ml_weight(IP, &z, &w, Dinv[k], invU, wts ? wts[k] : 0.0);
             nU = take_single_weight(&z, list_U, weightU, max_fill_in - 1, threshold, k + 1, n);
         }
         /* update U or Anew, :1769-1850 */
@@ -1780,7 +1787,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         /* (12.) L, :1855-1975 */
         if (eliminate) {
             if (inv) invL = inv_update(&w, k, k, inv + 4 * (size_t)n, inv + 5 * (size_t)n, inv + 6 * (size_t)n, inv + 7 * (size_t)n);          /* :1856-1892 */
-            weightL = ml_weight(IP, &w, &z, Dinv[k], invL);                    /* (Dinv[k] after the zero-pivot reset of :1786-1792) */
+            weightL = ml_weight(IP, &w, &z, Dinv[k], invL, wts ? wts[n + k] : 0.0);   /* (Dinv[k] after the zero-pivot reset of :1786-1792) */
             nL = take_single_weight(&w, list_L, weightL, max_fill_in - 1, threshold, k + 1, n);
             mat_reserve(L, L->ptr[k] + nL + 1, &capL);
             L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = k;
@@ -1812,7 +1819,7 @@ static int partial_iluc(const orc_mat *Arow, const orc_ml_params *IP, int force_
         }
     }
     wv_free(&z); wv_free(&w);
-    free(firstU); free(listU); free(firstL); free(listL); free(listA); free(headA); free(firstA); free(list_L); free(list_U); free(inv);
+    free(firstU); free(listU); free(firstL); free(listL); free(listA); free(headA); free(firstA); free(list_L); free(list_U); free(inv); free(wts);
     return ORC_OK;
 }
 
@@ -1860,7 +1867,7 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
     orc_int last_row_to_eliminate = n - 1, n_Anew = 0, pos_pivot = -1, selected_row;
     orc_int max_fill_in = IP->max_fill_in > 0 ? IP->max_fill_in : n;       /* :352-355 */
     int eliminate = 1, end_level_now = 0;
-    double pivot = 0.0, piv_tol = IP->piv_tol, val_larg_el, *inv = NULL;
+    double pivot = 0.0, piv_tol = IP->piv_tol, val_larg_el, *inv = NULL, *wts = NULL;
     orc_int *linkU = NULL, *rowU = NULL, *startU, *linkL = NULL, *colL = NULL, *startL, *list_L, *list_U, *numb, *pnum;
     char *non_pivot, *unused_rows;
     wvec z, w;
@@ -1889,6 +1896,10 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
     pnum[0] = 0;
     wv_init(&z, n, 0); wv_init(&w, n, 0);
     if (IP->drop_rules & ORC_DROP_INVERSE) inv = (double *)calloc(8 * (size_t)n + 1, sizeof(double));     /* :423-425 */
+    if (IP->drop_rules & (ORC_DROP_WEIGHTED | ORC_DROP_WEIGHTED2)) {                                       /* :426-428 */
+        wts = (double *)malloc(sizeof(double) * (2 * (size_t)n + 1));
+        for (k = 0; k < 2 * n; ++k) wts[k] = IP->init_weights_lu;
+    }
 
     for (k = 0; k < n; ++k) {
         orc_int nL = 0, nU;
@@ -1940,6 +1951,7 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
             t = perm[k]; perm[k] = perm[p]; perm[p] = t;
             non_pivot[pos_pivot] = 0;
         }
+        if (wts) for (j = 0; j < z.nnz; ++j) wts[z.pointer[j]] += fabs(z.data[j]);         /* weightsU, :629-631 */
         wv_zero_reset(&w);                                                     /* :633-651 */
         if (eliminate) {
             const orc_int c = perm[k];
@@ -1954,10 +1966,11 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
             }
         }
         for (j = 0; j < w.nnz; ++j) w.data[j] *= Dinv[k];                      /* :652 */
+        if (wts) for (j = 0; j < w.nnz; ++j) wts[n + w.pointer[j]] += fabs(w.data[j]);                                /* weightsL, :670-674 */
         if (inv && eliminate) invU = inv_update(&z, k, perm[k], inv, inv + n, inv + 2 * (size_t)n, inv + 3 * (size_t)n);  /* :679-713 */
         if (!eliminate) nU = take_largest(&z, list_U, max_fill_in, threshold, 0, n);      /* :714-716 */
         else {
-            weightU = ml_weight(IP, &z, &w, Dinv[k], invU);
+            weightU = ml_weight(IP, &z, &w, Dinv[k], invU, wts ? wts[perm[k]] : 0.0);
             nU = take_single_weight(&z, list_U, weightU, max_fill_in - 1, threshold, 0, n);
         }
         if (eliminate) {                                                       /* :761-797 (the list backwards) */
@@ -1984,7 +1997,7 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
         }
         if (eliminate) {                                                       /* L, :849-1005 */
             if (inv) invL = inv_update(&w, k, selected_row, inv + 4 * (size_t)n, inv + 5 * (size_t)n, inv + 6 * (size_t)n, inv + 7 * (size_t)n);   /* :880-916 */
-            weightL = ml_weight(IP, &w, &z, Dinv[k], invL);
+            weightL = ml_weight(IP, &w, &z, Dinv[k], invL, wts ? wts[n + selected_row] : 0.0);
             nL = take_single_weight(&w, list_L, weightL, max_fill_in, threshold, 0, n);
             if (L->ptr[k] + nL + 1 > capL) { mat_reserve(L, L->ptr[k] + nL + 1, &capL); links_reserve(&linkL, &colL, &haveL, capL); }
             L->val[L->ptr[k]] = 1.0; L->idx[L->ptr[k]] = selected_row;
@@ -2055,7 +2068,7 @@ static int partial_ilucdp(const orc_mat *Arow, const orc_mat *Acol, const orc_ml
     for (j = 0; j < U->nnz; ++j) U->idx[j] = inverse_perm[U->idx[j]];          /* U.permute(perm, COLUMN) */
     mat_normal_order(U);
     wv_free(&z); wv_free(&w);
-    free(linkU); free(rowU); free(startU); free(linkL); free(colL); free(startL); free(list_L); free(list_U); free(numb); free(pnum); free(inv);
+    free(linkU); free(rowU); free(startU); free(linkL); free(colL); free(startL); free(list_L); free(list_U); free(numb); free(pnum); free(inv); free(wts);
     free(non_pivot); free(unused_rows);
     return ORC_OK;
 }
@@ -2094,7 +2107,7 @@ void orc_ml_default_params(orc_ml_params *p)       /* default_parameters (:430-5
     p->max_fill_in = 0;
     p->drop_rules = ORC_DROP_ERR_PROP;
     p->weight_standard_drop = p->weight_standard_drop2 = p->weight_err_prop_drop = p->weight_err_prop_drop2 = p->weight_pivot_drop = 1.0;
-    p->weight_inverse_drop = 1.0;
+    p->weight_inverse_drop = 1.0; p->weight_weighted_drop = 1.0; p->init_weights_lu = 1.0;
     p->combine_factor = 0;
     p->neutral_element = 0.0;
     p->min_weight = 1.0;

@@ -101,7 +101,8 @@ enum {                                   /* steps of a preprocessing_sequence (o
     ORC_PRE_SYMM_PQ = 8
 };
 
-enum { ORC_DROP_STANDARD = 1, ORC_DROP_STANDARD2 = 2, ORC_DROP_ERR_PROP = 4, ORC_DROP_ERR_PROP2 = 8, ORC_DROP_PIVOT = 16, ORC_DROP_INVERSE = 32 };
+enum { ORC_DROP_STANDARD = 1, ORC_DROP_STANDARD2 = 2, ORC_DROP_ERR_PROP = 4, ORC_DROP_ERR_PROP2 = 8, ORC_DROP_PIVOT = 16, ORC_DROP_INVERSE = 32,
+       ORC_DROP_WEIGHTED = 64, ORC_DROP_WEIGHTED2 = 128 };   /* USE_WEIGHTED_DROPPING (the accumulated weights enter the dropping weight), _DROPPING2 (they are only accumulated) */
 
 typedef struct {
     double threshold;                    /* tau of the first level */
@@ -133,6 +134,8 @@ typedef struct {
     double move_level_factor;            /* MOVE_LEVEL_FACTOR */
     double row_u_max;                    /* ROW_U_MAX */
     double weight_inverse_drop;          /* WEIGHT_INVERSE_DROP (with ORC_DROP_INVERSE: USE_INVERSE_DROPPING, ILUCDP.hpp:680-713, :882-916) */
+    double weight_weighted_drop;         /* WEIGHT_WEIGHTED_DROP (with ORC_DROP_WEIGHTED, :726, :921) */
+    double init_weights_lu;              /* INIT_WEIGHTS_LU: what weightsL / weightsU start from (:426-428) */
 } orc_ml_params;
 
 typedef struct orc_ml orc_ml;

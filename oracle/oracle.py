@@ -32,6 +32,7 @@ _F64P = ctypes.POINTER(ctypes.c_double)
 
 # steps of a preprocessing sequence (ilupp_oracle.h)
 DROP_STANDARD, DROP_STANDARD2, DROP_ERR_PROP, DROP_ERR_PROP2, DROP_PIVOT, DROP_INVERSE = 1, 2, 4, 8, 16, 32
+DROP_WEIGHTED, DROP_WEIGHTED2 = 64, 128
 PRE_NORMALIZE_COLUMNS, PRE_NORMALIZE_ROWS, PRE_PQ_ORDERING, PRE_MAX_WEIGHTED_MATCHING_ORDERING, PRE_DD_SYMM_MOVE_CORNER_ORDERING_IM = 1, 2, 3, 4, 5
 PRE_UNIT_OR_ZERO_DIAGONAL_SCALING, PRE_SPARSE_FIRST_ORDERING, PRE_SYMM_PQ = 6, 7, 8
 ERR_UNSUPPORTED = 4
@@ -50,7 +51,7 @@ class MLParams(ctypes.Structure):
                 ("scale_weight_invdiag", ctypes.c_int),
                 ("piv_tol", ctypes.c_double), ("permute_rows", ctypes.c_int), ("total_piv", ctypes.c_int), ("begin_total_piv", ctypes.c_int),
                 ("final_row_crit", ctypes.c_int), ("move_level_factor", ctypes.c_double), ("row_u_max", ctypes.c_double),
-                ("weight_inverse_drop", ctypes.c_double)]
+                ("weight_inverse_drop", ctypes.c_double), ("weight_weighted_drop", ctypes.c_double), ("init_weights_lu", ctypes.c_double)]
 
 
 # the reference's default-constructed parameters (precon_parameter 0: the factorisation WITH pivoting), parameters_implementation.h:430-501

@@ -289,6 +289,10 @@ static int param_of(const orc_ml_params *IP, iluplusplus_precond_parameter &para
     param.set_USE_PIVOT_DROPPING((IP->drop_rules & ORC_DROP_PIVOT) != 0);
     param.set_USE_INVERSE_DROPPING((IP->drop_rules & ORC_DROP_INVERSE) != 0);
     param.set_WEIGHT_INVERSE_DROP(IP->weight_inverse_drop);
+    param.set_USE_WEIGHTED_DROPPING((IP->drop_rules & ORC_DROP_WEIGHTED) != 0);
+    param.set_USE_WEIGHTED_DROPPING2((IP->drop_rules & ORC_DROP_WEIGHTED2) != 0);
+    param.set_WEIGHT_WEIGHTED_DROP(IP->weight_weighted_drop);
+    param.set_INIT_WEIGHTS_LU(IP->init_weights_lu);
     param.set_WEIGHT_STANDARD_DROP(IP->weight_standard_drop); param.set_WEIGHT_STANDARD_DROP2(IP->weight_standard_drop2);
     param.set_WEIGHT_ERR_PROP_DROP(IP->weight_err_prop_drop); param.set_WEIGHT_ERR_PROP_DROP2(IP->weight_err_prop_drop2);
     param.set_WEIGHT_PIVOT_DROP(IP->weight_pivot_drop);

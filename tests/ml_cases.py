@@ -97,7 +97,7 @@ _ORC_FIELDS = {"MAX_LEVELS": "max_levels", "THRESHOLD_SHIFT_SCHUR": "threshold_s
                "COMBINE_FACTOR": "combine_factor", "NEUTRAL_ELEMENT": "neutral_element", "MIN_WEIGHT": "min_weight", "SCALE_WEIGHT_INVDIAG": "scale_weight_invdiag",
                "piv_tol": "piv_tol", "PERMUTE_ROWS": "permute_rows", "TOTAL_PIV": "total_piv", "BEGIN_TOTAL_PIV": "begin_total_piv",
                "FINAL_ROW_CRIT": "final_row_crit", "MOVE_LEVEL_FACTOR": "move_level_factor", "ROW_U_MAX": "row_u_max",
-               "WEIGHT_INVERSE_DROP": "weight_inverse_drop"}
+               "WEIGHT_INVERSE_DROP": "weight_inverse_drop", "WEIGHT_WEIGHTED_DROP": "weight_weighted_drop", "INIT_WEIGHTS_LU": "init_weights_lu"}
 
 # the reference's DEFAULT-constructed parameters (precon_parameter 0, parameters_implementation.h:430-501): the factorisation with pivoting
 PIVOTING = {"piv_tol": 1.0, "PERMUTE_ROWS": 3, "TOTAL_PIV": 1, "BEGIN_TOTAL_PIV": True, "SMALL_PIVOT_TERMINATES": False, "MIN_ELIM_FACTOR": 0.5}
@@ -129,11 +129,14 @@ PIVOT_PARAMS = [
     ("p_t0.1_inv", 0.1, ("PQ_ORDERING",), pivoting(USE_INVERSE_DROPPING=True, USE_ERR_PROP_DROPPING=False)),
     ("p_t0.02_inv_mwm", 0.02, ("MAX_WEIGHTED_MATCHING_ORDERING",), pivoting(USE_INVERSE_DROPPING=True, USE_ERR_PROP_DROPPING=False)),
     ("p_t0.05_inv_err_sum", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), pivoting(USE_INVERSE_DROPPING=True, COMBINE_FACTOR=1, WEIGHT_INVERSE_DROP=0.25)),
+    # weighted dropping (precon_parameter 2, :877-881): the sums of |entries| a column of U / a row of L has collected so far weigh its step
+    ("p_t0.1_wgt", 0.1, ("PQ_ORDERING",), pivoting(USE_WEIGHTED_DROPPING=True, USE_ERR_PROP_DROPPING=False)),
+    ("p_t0.05_wgt_mwm_init", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING",), pivoting(USE_WEIGHTED_DROPPING=True, WEIGHT_WEIGHTED_DROP=0.1, INIT_WEIGHTS_LU=0.5)),
 ]
 
 
 _RULES = (("USE_STANDARD_DROPPING", 1, False), ("USE_STANDARD_DROPPING2", 2, False), ("USE_ERR_PROP_DROPPING", 4, True), ("USE_ERR_PROP_DROPPING2", 8, False),
-          ("USE_PIVOT_DROPPING", 16, False), ("USE_INVERSE_DROPPING", 32, False))
+          ("USE_PIVOT_DROPPING", 16, False), ("USE_INVERSE_DROPPING", 32, False), ("USE_WEIGHTED_DROPPING", 64, False), ("USE_WEIGHTED_DROPPING2", 128, False))
 
 
 def oracle_params(O, thr, pre, knobs):

@@ -188,6 +188,9 @@ def test_fuzz_against_the_oracle():
         if rng.integers(0, 3) == 0:
             knobs.update(USE_STANDARD_DROPPING=bool(rng.integers(0, 2)), USE_PIVOT_DROPPING=bool(rng.integers(0, 2)), USE_ERR_PROP_DROPPING2=bool(rng.integers(0, 2)),
                          COMBINE_FACTOR=int(rng.integers(0, 4)))
+        if rng.integers(0, 5) == 0:                                  # weighted dropping (accumulated weights), alone or beside the rules above
+            knobs.update(USE_WEIGHTED_DROPPING=bool(rng.integers(0, 2)), USE_WEIGHTED_DROPPING2=bool(rng.integers(0, 2)),
+                         WEIGHT_WEIGHTED_DROP=float(rng.choice([1.0, 0.2])), INIT_WEIGHTS_LU=float(rng.choice([1.0, 0.5, 2.0])))
         if rng.integers(0, 4) == 0:                                  # inverse-based dropping, alone or beside the rules above
             knobs.update(USE_INVERSE_DROPPING=True, USE_ERR_PROP_DROPPING=bool(rng.integers(0, 2)), WEIGHT_INVERSE_DROP=float(rng.choice([1.0, 0.3, 3.0])))
         pre = [("PQ_ORDERING",), ("MAX_WEIGHTED_MATCHING_ORDERING",), ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), ("SPARSE_FIRST_ORDERING",), ()][int(rng.integers(0, 5))]

@@ -192,11 +192,16 @@ def test_inverse_based_dropping_goes_with_the_pivoting_family():
     p.WEIGHT_INVERSE_DROP = 0.5
     b = p._to_ml_params()
     assert b.drop_rules == 36 and b.weight_inverse_drop == 0.5
-    q = ilupp.iluplusplus_precond_parameter()
-    q.default_configuration(1)                                 # without pivoting
-    q.USE_INVERSE_DROPPING = True
-    with pytest.raises(NotImplementedError, match="USE_INVERSE_DROPPING"):
-        q._to_ml_params()
+    p.use_only_weighted_dropping1()                            # precon_parameter 2
+    p.INIT_WEIGHTS_LU = 0.5
+    b = p._to_ml_params()
+    assert b.drop_rules == 64 and b.weight_weighted_drop == 1.0 and b.init_weights_lu == 0.5
+    for name in ("USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2"):
+        q = ilupp.iluplusplus_precond_parameter()
+        q.default_configuration(1)                             # without pivoting
+        setattr(q, name, True)
+        with pytest.raises(NotImplementedError, match=name):
+            q._to_ml_params()
 
 
 def test_parameter_block_of_the_pivoting_family():
