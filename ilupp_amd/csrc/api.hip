@@ -1555,6 +1555,16 @@ int ilupp_hip_ml_create_batch(int32_t count, const double *const *data, const in
     if (workers > count) workers = count;
     int device = 0;
     ILUPP_HIP(hipGetDevice(&device));
+    {   // as many at a time as the memory takes: a construction with pivoting holds ~116 bytes per entry + 450 per row (two stores with
+        // their link arrays, the Schur store, both orientations of the level's matrix, the tables); the pool's kept blocks count as free
+        size_t free_b = 0, total_b = 0;
+        ILUPP_HIP(hipMemGetInfo(&free_b, &total_b));
+        free_b += pool_cached_bytes();
+        double worst = 0.0;
+        for (int32_t i = 0; i < count; ++i)
+            if (indptr[i] && n[i] > 0) { const double e = 116.0 * (double)indptr[i][n[i]] + 450.0 * (double)n[i] + (double)(64 << 20); if (e > worst) worst = e; }
+        if (worst > 0.0) { const double fit = 0.6 * (double)free_b / worst; if (fit < (double)workers) workers = fit < 1.0 ? 1 : (int)fit; }
+    }
     ChainBatch *cb = chain_batch_create(workers);
     if (!cb) { set_error("batched construction: no stream"); return ILUPP_ERR_HIP; }
     std::vector<int> rcs((size_t)count, ILUPP_OK);
@@ -1673,11 +1683,11 @@ int ilupp_hip_ml_apply(ilupp_ml *m, double *x, int64_t len, int transpose)
 }
 
 namespace {
-// the matrix of a solve in HBM and its preconditioner, built under the construction lock
+// the matrix of a solve in HBM and its preconditioner (the caller holds the construction lock)
 int solve_build(const double *data, const int32_t *indices, const int32_t *indptr, int32_t n, int is_csr, const ilupp_ml_params *params, DevMat *A,
                 ilupp_ml **m)
 {
-    API_TRY_BUILD
+    API_TRY
     int rc = validate(indptr, n);
     if (rc) return rc;
     const int64_t nnz = indptr[n];
@@ -1700,6 +1710,9 @@ int ilupp_hip_solve(const double *data, const int32_t *indices, const int32_t *i
     if (!data || !indices || !indptr || !rhs || !params || !x) { set_error("null argument"); return ILUPP_ERR_INVALID; }
     if (n <= 0) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
     if (rhs_len != n) { set_error("right-hand side has wrong size!"); return ILUPP_ERR_WRONG_SIZE; }            // binding.cpp:209-210
+    // (the whole call under the construction lock: the iteration takes and returns pool blocks on its own stream, and the pool knows nothing
+    //  of streams -- see API_TRY_BUILD)
+    std::lock_guard<std::mutex> build_lock_(ilupp::g_build_mu);
     struct Guard {
         DevMat A, T; ilupp_ml *m = nullptr;
         ~Guard() { try { if (m) { (void)hipStreamSynchronize(m->obj[0]->stream); ml_destroy(m); } } catch (...) {} A.release(); T.release(); }
