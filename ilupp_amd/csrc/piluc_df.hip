@@ -1042,6 +1042,9 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
             if (cls < 4) {
                 // (class 3 has the records of many steps but no more entries or slots than class 2)
                 cls = records ? (cls < 2 ? 2 : cls + 1) : (cls < 2 ? cls + 1 : 4);
+                // (an attempt in the largest class takes seconds where the others take milliseconds, and rows that long fill the factors: it
+                //  starts with stores that a "stores too small" is unlikely to send back to the start -- 16 nnz + 8 n entries per factor)
+                if (cls == 4) { const long big = 16 * (long)Av.nnz + 8 * (long)Av.n + 1024; if (store < big) store = big; }
             } else if (records) {
                 set_error("partialILUC: a step is reached by more than 4096 stored entries");
                 rc = ILUPP_ERR_UNSUPPORTED;
@@ -1054,7 +1057,7 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
             }
         } else if (rc == 2) {
             if (store >= 0x7ffffff0L) { set_error("partialILUC: the factors of a level exceed 2^31 entries"); rc = ILUPP_ERR_MEMORY; break; }
-            store *= 2;
+            store *= cls == 4 ? 4 : 2;
         } else if (rc == ILUPP_ERR_UNSUPPORTED) {
             set_error("partialILUC: the working arrays of the largest capacity class exceed the memory set aside for them");
         }

@@ -99,6 +99,35 @@ int main(int argc, char **argv)
             CHECK(P.acquire(&z, (5 << 20) - 300000) == 0 && z == y && P.release(z) == 0);
             P.trim();
         }
+        // owner lanes (a batch of constructions on several streams): a kept block goes back only to the owner that freed it -- or, once
+        // that owner has synchronised and disowned its blocks, to everybody; everybody's kept blocks serve every owner
+        {
+            P.trim();
+            void *o1 = nullptr, *o2 = nullptr, *q = nullptr;
+            CHECK(P.acquire(&o1, 3000, 1) == 0 && P.acquire(&o2, 3000, 2) == 0 && o1 != o2);
+            CHECK(P.release(o1, 1) == 0 && P.kept_blocks() == 1);
+            CHECK(P.acquire(&q, 3000, 2) == 0 && q != o1);                 // owner 2 does not get owner 1's unsynchronised block
+            CHECK(P.release(q, 2) == 0);
+            void *r = nullptr;
+            CHECK(P.acquire(&r, 3000, 0) == 0 && r != o1 && r != q);      // nor does "everybody"
+            CHECK(P.release(r, 0) == 0);
+            void *s1 = nullptr;
+            CHECK(P.acquire(&s1, 3000, 1) == 0 && s1 == o1);               // its own owner does
+            CHECK(P.release(s1, 1) == 0);
+            void *t2 = nullptr;
+            CHECK(P.acquire(&t2, 3000, 2) == 0 && t2 == q);                // (owner 2 finds its own kept block first)
+            CHECK(P.release(t2, 2) == 0);
+            P.disown(1);
+            void *u = nullptr, *u2 = nullptr;
+            CHECK(P.acquire(&u, 3000, 3) == 0 && (u == o1 || u == r));     // disowned blocks and everybody's serve a third owner
+            CHECK(P.acquire(&u2, 3000, 3) == 0 && (u2 == o1 || u2 == r) && u2 != u);
+            CHECK(P.release(u, 3) == 0 && P.release(u2, 3) == 0 && P.release(o2, 2) == 0);
+            P.disown(2); P.disown(3);
+            const size_t kept = P.kept_blocks();
+            P.set_limit(1);                                                 // the age list still knows every block after the re-tagging
+            CHECK(P.kept_blocks() == 0 && kept == 4 && g_backend_live.empty());
+            P.set_limit(1 << 30);
+        }
         // random traffic
         std::mt19937 rng(7);
         std::vector<std::pair<void *, size_t>> held;
