@@ -1451,11 +1451,7 @@ int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
         return ILUPP_ERR_UNSUPPORTED;
     }
     if ((P.pil.rules & ~255) != 0) { set_error("ILU++: unknown dropping rule"); return ILUPP_ERR_INVALID; }
-    if ((P.pil.rules & (PILUC_DROP_INVERSE | PILUC_DROP_WEIGHTED | PILUC_DROP_WEIGHTED2)) && !P.pil.pivoting()) {
-        set_error("ILU++: inverse-based and weighted dropping (estimates that accumulate over the steps in their order) are built for the "
-                  "factorisation with pivoting only");
-        return ILUPP_ERR_UNSUPPORTED;
-    }
+    // (inverse-based and weighted dropping -- recurrences over all steps -- run as chains in both factorisations: pilucdp.hip)
     struct MlGuard { ilupp_ml *m; ~MlGuard() { if (m) ml_destroy(m); } } g{new ilupp_ml()};
     ilupp_ml *m = g.m;
     m->n = A.n;

@@ -530,8 +530,21 @@ int ml_build(hipStream_t st, const DevMat &A, const MlParams &IP, std::vector<Ml
         int32_t kterm = m;
         const auto tl0 = std::chrono::steady_clock::now();
         int rc;
-        if (!IP.pil.pivoting()) rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
-        else {
+        if (!IP.pil.pivoting()) {
+            // dataflow over all CUs -- unless the dropping rules are recurrences over all steps (inverse-based, weighted), which only a
+            // sequential walk can run: the chain kernel (pilucdp.hip: k_piluc_chain); ILUPP_PILUC_CHAIN=1 sends everything there (tests)
+            const bool sequential_rules = (IP.pil.rules & (PILUC_DROP_INVERSE | PILUC_DROP_WEIGHTED | PILUC_DROP_WEIGHTED2)) != 0;
+            if (sequential_rules || getenv("ILUPP_PILUC_CHAIN")) {
+                rc = piluc_chain_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+                if (rc == 1) {
+                    l.L.release(); l.U.release(); Anext.release();
+                    if (sequential_rules) {
+                        set_error("partialILUC with inverse-based / weighted dropping: a working row of more than 2048 entries (the chain kernel's LDS capacity)");
+                        rc = ILUPP_ERR_UNSUPPORTED;
+                    } else rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+                }
+            } else rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+        } else {
             // the windows of the pivoting and of the row reordering, :1442-1459 (a level of the loop) / :1564-1577 (the last one)
             const int32_t last_row_to_eliminate = in_loop ? (m - 1) / 2 : m - 1;
             int32_t bp, bpr, epr;

@@ -1033,9 +1033,18 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
     int rc = 1;
     int gns = 2048;
     long gne = 65536;
+    bool chain_tried = getenv("ILUPP_NO_PILUC_CHAIN") != nullptr;
     while (rc == 1 || rc == 2) {
         int which = 0;
         L->release(); U->release(); Anew->release();
+        if (cls == 4 && !chain_tried) {
+            // rows too long for the LDS classes: the steps of such a factorisation depend on one another almost one by one, and the largest
+            // class walks them through global-memory slots (700 us per step on the critical path).  The chain kernel walks them in LDS.
+            chain_tried = true;
+            const int rcc = piluc_chain_level(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms);
+            if (rcc != 1) { rc = rcc; break; }
+            L->release(); U->release(); Anew->release();
+        }
         rc = piluc_attempt(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms, cls, store, gns, gne, &which);
         if (rc == 1) {
             const bool records = which == 12 || which == 15;          // more touch records per step than the class holds

@@ -676,7 +676,8 @@ __device__ __forceinline__ bool lv_subtract_pipe(const LdsVec &v, int &nnz, List
 
 // the slots that pass the dropping rule, in insertion order, at most `limit` of them (the largest keys, by the reference's selection);
 // afterwards sortk[0 .. return) = (index << 32 | slot) ascending by index
-__device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, double thr, int limit, double *key, int32_t *cand, unsigned long long *sortk, int lane)
+__device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, double thr, int limit, double *key, int32_t *cand, unsigned long long *sortk, int lane,
+                       int skip = -1)         // skip: an index that is outside the range the candidates are taken from (partialILUC: [k + 1, n))
 {
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cnt = 0;
@@ -685,7 +686,7 @@ __device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, dou
         const bool act = s < nnz;
         const double x = act ? v.val[s] : 0.0;
         const double kx = single ? weight * fabs(x) : fabs(x);
-        const bool ok = act && (single ? kx >= thr : kx > thr);
+        const bool ok = act && (single ? kx >= thr : kx > thr) && (skip < 0 || v.idx[s] != skip);
         const unsigned long long mask = __ballot(ok);
         if (ok) { const int p = cnt + __popcll(mask & lt); cand[p] = s; key[p] = kx; }
         cnt += __popcll(mask);
@@ -1027,6 +1028,257 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds_batch(const DpArgs *__restri
     dp_chain_lds(A);
 }
 
+// =====================================================================================================================================
+// partialILUC -- the factorisation WITHOUT pivoting (ILUCDP.hpp:1405-2231) -- as a chain (k_piluc_chain).  The dataflow kernel of
+// piluc_df.hip runs its steps side by side; when the fill makes nearly every step depend on the one before it, and the working rows
+// outgrow its LDS classes, it degenerates into a sequential walk through global-memory slots (700 us per step on the critical path).
+// This kernel IS a sequential walk, with the working vectors in LDS as above: Crout's three lists (the columns of A, the rows of L, the
+// columns of U: ILUC.hpp:31-101 -- initialize / update_sparse_matrix_fields, update_triangular_fields) are kept exactly as the
+// reference keeps them, because the ORDER in which they name the contributors is the order of the subtractions.  It also serves the
+// dropping rules whose estimates are recurrences over all steps (inverse-based, weighted), which a dataflow kernel cannot run.
+// Aliases of DpArgs: perm = listA, iperm = headA, prow = firstA, iprow = listL, numb = firstL, pnum = listU, nonpiv = firstU.
+constexpr int kPcNodes = 4096;                  // contributors of one step (nodes of one list) kept in LDS for the list update
+
+// list[] / first[] of a triangular factor after step k (update_triangular_fields, ILUC.hpp:31-63): the nodes of list[k] (in `nodes`, in list
+// order) and k itself move on to the list of their next index.  One lane, in the reference's order.
+__device__ void pc_update_triangular(int k, const int32_t *ptr, const int32_t *idx, int32_t *list, int32_t *first, const int32_t *nodes, int nn, int lane)
+{
+    if (lane != 0) return;
+    for (int i = 0; i < nn; ++i) first[nodes[i]] += 1;
+    first[k] = ptr[k] + 1;
+    if (ptr[k] + 1 < ptr[k + 1]) { const int j = idx[ptr[k] + 1]; list[k] = list[j]; list[j] = k; }
+    for (int i = 0; i < nn; ++i) {
+        const int h = nodes[i];
+        const int f = first[h];
+        if (f < ptr[h + 1]) { const int j = idx[f]; list[h] = list[j]; list[j] = h; }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
+{
+    __shared__ __attribute__((aligned(16))) int32_t s_zidx[kLvCap], s_widx[kLvCap], s_zh[kLvHash], s_wh[kLvHash], s_cand[kLvCap], s_nodes[kPcNodes];
+    __shared__ __attribute__((aligned(16))) double s_zval[kLvCap], s_wval[kLvCap], s_key[kLvCap];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_sort[kLvCap];
+    __shared__ unsigned short s_zs[kLvHash], s_ws[kLvHash];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int n = A.n;
+    int32_t *const listA = A.perm, *const headA = A.iperm, *const firstA = A.prow, *const listL = A.iprow, *const firstL = A.numb, *const listU = A.pnum,
+            *const firstU = A.nonpiv;
+    const LdsVec z{s_zidx, s_zval, s_zh, s_zs}, w{s_widx, s_wval, s_wh, s_ws};
+    bool eliminate = A.ctrl[4] != 0;
+    double threshold = A.dctrl[0];
+    int last = A.ctrl[1], nA = A.ctrl[2], zero_piv = A.ctrl[3];
+    int pU = A.ctrl[8], pL = A.ctrl[9], pS = A.ctrl[10];
+    const int row_max = (A.max_fill < n ? A.max_fill : n) + 1;
+#define PC_STOP(code) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) { A.ctrl[0] = (code); A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; \
+                                            A.ctrl[5] = k; A.ctrl[8] = pU; A.ctrl[9] = pL; A.ctrl[10] = pS; A.dctrl[0] = threshold; } return; } while (0)
+    for (int k = A.ctrl[5]; k < n; ++k) {
+        if ((long)pU + row_max > (long)A.capU) PC_STOP(1);
+        if ((long)pL + row_max > (long)A.capL) PC_STOP(2);
+        if (!eliminate && (long)pS + row_max > (long)A.capS) PC_STOP(3);
+        lv_clear(z, lane); lv_clear(w, lane);
+        int znnz = 0, wnnz = 0;
+        LV_SYNC();
+        // (2.) :1575-1583: the row of A from its first entry right of the eliminated columns
+        {
+            const int e0 = firstA[k], e1 = A.Ap[k + 1];
+            for (int base = e0; base < e1; base += 64) {
+                const int e = base + lane;
+                const bool act = e < e1;
+                const int c = act ? A.Ai[e] : -1;
+                const int pc = (act && e > e0) ? A.Ai[e - 1] : -1;
+                const double x = act ? A.Av[e] : 0.0;
+                const bool first = act && c != pc;
+                const unsigned long long mask = __ballot(first);
+                if (znnz + __popcll(mask) > kLvCap) PC_STOP(4);
+                if (first) { const int s = znnz + __popcll(mask & lt); z.idx[s] = c; z.val[s] = x; lv_enter(z, c, s); }
+                znnz += __popcll(mask);
+                const unsigned long long dup = __ballot(act && !first);
+                if (dup) {
+                    LV_SYNC();
+                    for (int b = 0; b < 64; ++b)
+                        if ((dup >> b) & 1ull) { const int cb = wv_i32(c, b); const double xb = wv_f64(x, b); if (lane == 0) z.val[lv_find(z, cb)] = xb; LV_SYNC(); }
+                }
+            }
+            LV_SYNC();
+        }
+        // (3.) :1589-1602: the rows of U this row has multipliers for, in the order of the list
+        int nnL = 0;
+        for (int h = listL[k]; h != -1;) {
+            const int next = listL[h];
+            const int fl = firstL[h], e0 = firstU[h], e1 = A.Uptr[h + 1];
+            const double f = A.Lval[fl] / A.Dinv[h];
+            if (nnL >= kPcNodes) PC_STOP(4);
+            if (lane == 0) s_nodes[nnL] = h;
+            ++nnL;
+            for (int base = e0; base < e1; base += 64) {
+                const int e = base + lane;
+                const bool act = e < e1;
+                const int c = act ? A.Uidx[e] : 0;
+                const double ev = act ? A.Uval[e] : 0.0;
+                const int slot = act ? lv_find(z, c) : -1;
+                const bool isnew = act && slot < 0;
+                const unsigned long long mask = __ballot(isnew);
+                if (znnz + __popcll(mask) > kLvCap) PC_STOP(4);
+                if (act) {
+                    const double prod = f * ev;
+                    if (isnew) { const int s = znnz + __popcll(mask & lt); z.idx[s] = c; z.val[s] = 0.0 - prod; lv_enter(z, c, s); }
+                    else z.val[slot] = z.val[slot] - prod;
+                }
+                znnz += __popcll(mask);
+                LV_SYNC();
+            }
+            h = next;
+        }
+        // the level ends at a small pivot, :1619-1636 (z[k] inserts the slot if the diagonal is missing)
+        // (the reference's z[k] inserts the slot -- in the test below, which it only reaches while eliminating, or in the elimination itself)
+        if (eliminate && !lv_touch(z, znnz, k, lane)) PC_STOP(4);
+        const int kslot = eliminate ? lv_find(z, k) : -1;
+        const double zk = eliminate ? z.val[kslot] : 0.0;
+        if (eliminate && !A.force_finish && (double)k > A.min_elim_factor * (double)n && A.small_pivot_terminates && fabs(zk) < A.min_pivot) {
+            eliminate = false;
+            threshold *= A.shift_schur;
+            last = k - 1;
+            nA = n - k;
+        }
+        double pivot = 0.0, dinv = 1.0;
+        if (eliminate) {                                                            // :1637-1642
+            pivot = zk;
+            dinv = 1.0 / pivot;
+            for (int s = lane; s < znnz; s += 64) z.val[s] = z.val[s] * dinv;
+            LV_SYNC();
+            if (lane == 0) z.val[kslot] = 0.0;
+            LV_SYNC();
+        }
+        double wtdU = 0.0, wtdL = 0.0;
+        if (A.wts) wtdU = dp_accumulate_weights(LvAcc{z}, znnz, A.wts, k, true, lane);            // :1634-1636
+        // (8.) :1651-1675: the column of L
+        int nnU = 0, nnA = 0;
+        if (eliminate) {
+            // the rows of A that have an entry in column k, in the order of the list
+            for (int h = headA[k]; h != -1;) {
+                const int next = listA[h];
+                const double x = A.Av[firstA[h]];
+                if (nnA >= kLvCap) PC_STOP(4);
+                if (lane == 0) s_cand[nnA] = h;                                  // (s_cand is free until the dropping: the nodes of A's list)
+                ++nnA;
+                if (h > k) {
+                    if (wnnz >= kLvCap) PC_STOP(4);
+                    const int slot = lv_find(w, h);
+                    if (lane == 0) { if (slot < 0) { w.idx[wnnz] = h; w.val[wnnz] = x; lv_enter(w, h, wnnz); } else w.val[slot] = x; }
+                    if (slot < 0) ++wnnz;
+                    LV_SYNC();
+                }
+                h = next;
+            }
+            for (int h = listU[k]; h != -1;) {
+                const int next = listU[h];
+                const int fu = firstU[h], e0 = firstL[h], e1 = A.Lptr[h + 1];
+                const double f = A.Uval[fu] / A.Dinv[h];
+                if (nnL + nnU >= kPcNodes) PC_STOP(4);
+                if (lane == 0) s_nodes[nnL + nnU] = h;
+                ++nnU;
+                for (int base = e0; base < e1; base += 64) {
+                    const int e = base + lane;
+                    const bool act = e < e1;
+                    const int c = act ? A.Lidx[e] : 0;
+                    const double ev = act ? A.Lval[e] : 0.0;
+                    const int slot = act ? lv_find(w, c) : -1;
+                    const bool isnew = act && slot < 0;
+                    const unsigned long long mask = __ballot(isnew);
+                    if (wnnz + __popcll(mask) > kLvCap) PC_STOP(4);
+                    if (act) {
+                        const double prod = f * ev;
+                        if (isnew) { const int s = wnnz + __popcll(mask & lt); w.idx[s] = c; w.val[s] = 0.0 - prod; lv_enter(w, c, s); }
+                        else w.val[slot] = w.val[slot] - prod;
+                    }
+                    wnnz += __popcll(mask);
+                    LV_SYNC();
+                }
+                h = next;
+            }
+            for (int s = lane; s < wnnz; s += 64) w.val[s] = w.val[s] * dinv;       // w.scale(Dinv[k]), :1665
+            LV_SYNC();
+        }
+        if (A.wts && eliminate) wtdL = dp_accumulate_weights(LvAcc{w}, wnnz, A.wts + n, k, false, lane);      // :1670-1675
+        double invU = 0.0;
+        if (eliminate && (A.rules & PILUC_DROP_INVERSE))                            // :1676-1710
+            invU = dp_inverse_update(LvAcc{z}, znnz, k, k, A.inv, A.inv + n, A.inv + 2 * (size_t)n, A.inv + 3 * (size_t)n, lane);
+        // the nodes of A's list move from s_cand to the tail of s_nodes before the dropping takes s_cand
+        if (eliminate) {
+            if (nnL + nnU + nnA > kPcNodes) PC_STOP(4);
+            for (int i = lane; i < nnA; i += 64) s_nodes[nnL + nnU + i] = s_cand[i];
+            LV_SYNC();
+        }
+        // ---- dropping, :1716-1764 ----
+        int nU;
+        double n1z = 0.0;
+        if (!eliminate) {
+            const double norm = sqrt(lv_seq_sum(z, znnz, 1, lane));
+            nU = lv_take(z, znnz, false, 0.0, norm * threshold, A.max_fill, s_key, s_cand, s_sort, lane);
+        } else {
+            const double n2z = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(z, znnz, 1, lane)) : 0.0;
+            const double n1w = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(w, wnnz, 0, lane) : 0.0;
+            n1z = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(z, znnz, 0, lane) : 0.0;
+            const double weightU = dp_weight(A, n2z, n1w, dinv, invU, wtdU);
+            nU = lv_take(z, znnz, true, weightU, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane, k);
+        }
+        double dinv_store = dinv;
+        if (eliminate) {                                                            // :1769-1792
+            const int p0 = pU;
+            pU += nU + 1;
+            for (int j = lane; j < nU; j += 64) { const unsigned long long ks = s_sort[j]; A.Uval[p0 + 1 + j] = z.val[(int)(unsigned)ks]; A.Uidx[p0 + 1 + j] = (int)(ks >> 32); }
+            if (pivot == 0.0) { ++zero_piv; dinv_store = 1.0; }
+            if (lane == 0) { A.Uval[p0] = 1.0; A.Uidx[p0] = k; A.Uptr[k + 1] = p0 + nU + 1; A.Dinv[k] = dinv_store; }
+        } else {                                                                    // :1793-1850
+            const int kA = k - last - 1;
+            const int p0 = pU, q0 = pS;
+            pU += 1; pS += nU;
+            for (int j = lane; j < nU; j += 64) { const unsigned long long ks = s_sort[j]; A.Sval[q0 + j] = z.val[(int)(unsigned)ks]; A.Sidx[q0 + j] = (int)(ks >> 32); }
+            if (lane == 0) { A.Uval[p0] = 1.0; A.Uidx[p0] = k; A.Uptr[k + 1] = p0 + 1; A.Dinv[k] = 1.0; A.Sptr[kA + 1] = q0 + nU; }
+        }
+        LV_SYNC();
+        // (12.) L, :1855-1975
+        if (eliminate) {
+            double invL = 0.0;
+            if (A.rules & PILUC_DROP_INVERSE)
+                invL = dp_inverse_update(LvAcc{w}, wnnz, k, k, A.inv + 4 * (size_t)n, A.inv + 5 * (size_t)n, A.inv + 6 * (size_t)n, A.inv + 7 * (size_t)n, lane);
+            const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(w, wnnz, 1, lane)) : 0.0;
+            const double weightL = dp_weight(A, n2w, n1z, dinv_store, invL, wtdL);
+            const int nL = lv_take(w, wnnz, true, weightL, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane, k);     // (w may hold row k itself: out of [k + 1, n))
+            const int p0 = pL;
+            pL += nL + 1;
+            for (int j = lane; j < nL; j += 64) { const unsigned long long ks = s_sort[j]; A.Lval[p0 + 1 + j] = w.val[(int)(unsigned)ks]; A.Lidx[p0 + 1 + j] = (int)(ks >> 32); }
+            if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = k; A.Lptr[k + 1] = p0 + nL + 1; }
+        } else {
+            const int p0 = pL;
+            pL += 1;
+            if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = k; A.Lptr[k + 1] = p0 + 1; }
+        }
+        __builtin_amdgcn_s_waitcnt(0);                                              // (the new row and column are what the lists are moved along)
+        LV_SYNC();
+        // :1977-1983: the three lists move on
+        if (eliminate) {
+            if (lane == 0) {                                                        // update_sparse_matrix_fields, ILUC.hpp:86-101
+                const int32_t *nodesA = s_nodes + nnL + nnU;
+                for (int i = 0; i < nnA; ++i) firstA[nodesA[i]] += 1;
+                for (int i = 0; i < nnA; ++i) {
+                    const int h = nodesA[i];
+                    const int f = firstA[h];
+                    if (f < A.Ap[h + 1]) { const int c = A.Ai[f]; listA[h] = headA[c]; headA[c] = h; }
+                }
+            }
+            pc_update_triangular(k, A.Uptr, A.Uidx, listU, firstU, s_nodes + nnL, nnU, lane);
+        }
+        pc_update_triangular(k, A.Lptr, A.Lidx, listL, firstL, s_nodes, nnL, lane);
+        __builtin_amdgcn_s_waitcnt(0);
+        LV_SYNC();
+    }
+    if (lane == 0) { A.ctrl[0] = 0; A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; A.ctrl[5] = n; }
+#undef PC_STOP
+}
+
 // ---- launching the chains of a batch together ----
 struct ChainBatch {
     std::mutex mu;
@@ -1201,6 +1453,178 @@ int seg_compress_sort(hipStream_t st, int32_t nseg, const int32_t *ptr, const in
     return ILUPP_OK;
 }
 
+// a store of factor entries that grows: contents copied into a block twice as large (the reference's enlarge_fields_keep_data, :763-769)
+struct DpStore {
+    PoolBlock idx, link, who, val;
+    int64_t cap = 0;
+    bool lists;
+    int grow(hipStream_t st, int64_t ncap, int64_t used) {
+        PoolBlock ni, nl, nw, nv;
+        ILUPP_HIP(ni.alloc(sizeof(int32_t) * (size_t)ncap));
+        ILUPP_HIP(nv.alloc(sizeof(double) * (size_t)ncap));
+        if (lists) { ILUPP_HIP(nl.alloc(sizeof(int32_t) * (size_t)ncap)); ILUPP_HIP(nw.alloc(sizeof(int32_t) * (size_t)ncap)); }
+        if (used > 0) {
+            ILUPP_HIP(hipMemcpyAsync(ni.p, idx.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
+            ILUPP_HIP(hipMemcpyAsync(nv.p, val.p, sizeof(double) * (size_t)used, hipMemcpyDeviceToDevice, st));
+            if (lists) {
+                ILUPP_HIP(hipMemcpyAsync(nl.p, link.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
+                ILUPP_HIP(hipMemcpyAsync(nw.p, who.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
+            }
+            ILUPP_HIP(hipStreamSynchronize(st));
+        }
+        idx.swap(ni); val.swap(nv); link.swap(nl); who.swap(nw);
+        cap = ncap;
+        return ILUPP_OK;
+    }
+};
+
+__global__ void k_pc_first_cols(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t *__restrict__ fc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) fc[k] = ptr[k] < ptr[k + 1] ? idx[ptr[k]] : 0;
+}
+__global__ void k_pc_ones(int32_t n, double *__restrict__ d)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) d[k] = 1.0;
+}
+
+// partialILUC as a chain (k_piluc_chain): same results as piluc_level (piluc_df.hip).  +1: a working vector or a list outgrew the kernel's
+// LDS capacity -- the caller takes the dataflow kernel's largest class.
+int piluc_chain_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv_out,
+                      DevMat *Anew, int32_t *kterm, float *kernel_ms)
+{
+    const int32_t n = Arow.n;
+    const int64_t nnz = Arow.nnz;
+    const bool dbg = getenv("ILUPP_DEBUG") != nullptr;
+    int32_t max_fill = P.max_fill_in > 0 ? P.max_fill_in : n;                        // :1440-1447
+    if (max_fill < 1) max_fill = 1;
+    if (max_fill > n) max_fill = n;
+    PoolBlock b_i, b_sort, b_ctrl, b_dctrl, b_inv, b_wts, b_id;
+    const size_t slot = ((size_t)n + 64) & ~(size_t)15;
+    ILUPP_HIP(b_i.alloc(sizeof(int32_t) * slot * 10));          // listA headA firstA listL firstL listU firstU Uptr Lptr Sptr
+    ILUPP_HIP(b_sort.alloc(64));
+    ILUPP_HIP(b_ctrl.alloc(64));
+    ILUPP_HIP(b_dctrl.alloc(64));
+    ILUPP_HIP(b_id.alloc(sizeof(int32_t) * (size_t)(n + 1)));
+    int32_t *I = b_i.as<int32_t>();
+    auto iarr = [&](int q) { return I + slot * (size_t)q; };
+    double *Dinv = nullptr;
+    ILUPP_HIP(pool_malloc(&Dinv, sizeof(double) * (size_t)n));
+    struct DinvGuard { double **p; bool keep = false; ~DinvGuard() { if (!keep && *p) { (void)pool_free(*p); *p = nullptr; } } } gd{&Dinv};
+    DpStore SU, SL, SS;
+    SU.lists = SL.lists = SS.lists = false;
+    int64_t cap0 = 2 * nnz + 8 * (int64_t)n + 1024, capS0 = nnz + 2 * (int64_t)n + 1024;
+    if (const char *e = getenv("ILUPP_DP_STORE")) { cap0 = capS0 = (int64_t)n + 2 + atol(e); }
+    { int rc = SU.grow(st, cap0, 0); if (rc) return rc; rc = SL.grow(st, cap0, 0); if (rc) return rc; rc = SS.grow(st, capS0, 0); if (rc) return rc; }
+    DpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    a.Ap = Arow.ptr; a.Ai = Arow.idx; a.Av = Arow.val;
+    a.threshold = tau; a.shift_schur = P.threshold_shift_schur; a.min_pivot = P.min_pivot; a.min_elim_factor = P.min_elim_factor;
+    a.small_pivot_terminates = P.small_pivot_terminates ? 1 : 0; a.force_finish = force_finish ? 1 : 0; a.max_fill = max_fill;
+    a.rules = P.rules; a.combine = P.combine; a.scale_invdiag = P.scale_invdiag ? 1 : 0;
+    for (int q = 0; q < 7; ++q) a.wgt[q] = P.wgt[q];
+    a.neutral = P.neutral; a.min_weight = P.min_weight;
+    if (P.rules & (PILUC_DROP_WEIGHTED | PILUC_DROP_WEIGHTED2)) {
+        ILUPP_HIP(b_wts.alloc(sizeof(double) * 2 * (size_t)n));
+        a.wts = b_wts.as<double>();
+        unsigned long long bits; memcpy(&bits, &P.init_weights_lu, sizeof(bits));
+        fill_u64(st, reinterpret_cast<unsigned long long *>(a.wts), 2 * (int64_t)n, bits);
+    }
+    if (P.rules & PILUC_DROP_INVERSE) {
+        ILUPP_HIP(b_inv.alloc(sizeof(double) * 8 * (size_t)n));
+        ILUPP_HIP(hipMemsetAsync(b_inv.p, 0, sizeof(double) * 8 * (size_t)n, st));
+        a.inv = b_inv.as<double>();
+    }
+    a.perm = iarr(0); a.iperm = iarr(1); a.prow = iarr(2); a.iprow = iarr(3); a.numb = iarr(4); a.pnum = iarr(5); a.nonpiv = iarr(6);
+    a.Uptr = iarr(7); a.Lptr = iarr(8); a.Sptr = iarr(9);
+    a.Dinv = Dinv;
+    a.ctrl = b_ctrl.as<int32_t>();
+    a.dctrl = b_dctrl.as<double>();
+    {
+        // initialize_sparse_matrix_fields (ILUC.hpp:65-84): every row into the list of its first column, rows in ascending order each at the
+        // head -- a sequential statement about n integers: on the host
+        std::vector<int32_t> hp((size_t)n + 1), hc((size_t)n), lA((size_t)n, -1), hA((size_t)n, -1);
+        PoolBlock b_fc;
+        ILUPP_HIP(b_fc.alloc(sizeof(int32_t) * (size_t)n));
+        hipLaunchKernelGGL(k_pc_first_cols, dim3((n + 255) / 256), dim3(256), 0, st, n, Arow.ptr, Arow.idx, b_fc.as<int32_t>());
+        ILUPP_HIP(hipMemcpyAsync(hp.data(), Arow.ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipMemcpyAsync(hc.data(), b_fc.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        for (int32_t k = 0; k < n; ++k)
+            if (hp[(size_t)k] < hp[(size_t)k + 1]) { const int32_t c = hc[(size_t)k]; lA[(size_t)k] = hA[(size_t)c]; hA[(size_t)c] = k; }
+        ILUPP_HIP(hipMemcpyAsync(a.perm, lA.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        ILUPP_HIP(hipMemcpyAsync(a.iperm, hA.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        ILUPP_HIP(hipMemcpyAsync(a.prow, Arow.ptr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));      // firstA = pointer
+        ILUPP_HIP(hipMemsetAsync(a.iprow, 0xff, sizeof(int32_t) * (size_t)n, st));          // listL = -1
+        ILUPP_HIP(hipMemsetAsync(a.pnum, 0xff, sizeof(int32_t) * (size_t)n, st));           // listU = -1
+        ILUPP_HIP(hipMemsetAsync(a.numb, 0, sizeof(int32_t) * (size_t)n, st));
+        ILUPP_HIP(hipMemsetAsync(a.nonpiv, 0, sizeof(int32_t) * (size_t)n, st));
+        hipLaunchKernelGGL(k_pc_ones, dim3((n + 255) / 256), dim3(256), 0, st, n, Dinv);
+        iota_i32(st, b_id.as<int32_t>(), n + 1);
+        int32_t c0[16] = {0};
+        c0[1] = n - 1; c0[4] = 1;
+        const double d0[2] = {tau, 0.0};
+        ILUPP_HIP(hipMemcpyAsync(a.ctrl, c0, sizeof(c0), hipMemcpyHostToDevice, st));
+        ILUPP_HIP(hipMemcpyAsync(a.dctrl, d0, sizeof(d0), hipMemcpyHostToDevice, st));
+        ILUPP_HIP(hipMemsetAsync(a.Uptr, 0, sizeof(int32_t), st));
+        ILUPP_HIP(hipMemsetAsync(a.Lptr, 0, sizeof(int32_t), st));
+        ILUPP_HIP(hipMemsetAsync(a.Sptr, 0, sizeof(int32_t), st));
+        ILUPP_HIP(hipStreamSynchronize(st));                   // (the host vectors above are done with)
+    }
+    int32_t ctrl[16] = {0};
+    for (int launch = 0;; ++launch) {
+        a.Uidx = SU.idx.as<int32_t>(); a.Uval = SU.val.as<double>(); a.capU = (int32_t)SU.cap;
+        a.Lidx = SL.idx.as<int32_t>(); a.Lval = SL.val.as<double>(); a.capL = (int32_t)SL.cap;
+        a.Sidx = SS.idx.as<int32_t>(); a.Sval = SS.val.as<double>(); a.capS = (int32_t)SS.cap;
+        EventPair ev;
+        ILUPP_HIP(ev.create());
+        ILUPP_HIP(hipEventRecord(ev.a, st));
+        hipLaunchKernelGGL(k_piluc_chain, dim3(1), dim3(64), 0, st, a);
+        ILUPP_HIP(hipEventRecord(ev.b, st));
+        ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+        if (kernel_ms) *kernel_ms += ms;
+        if (dbg) fprintf(stderr, "[ilupp] piluc (chain): n %d, launch %d (stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", n, launch, (long long)SU.cap,
+                         (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
+        if (ctrl[0] == 0) break;
+        if (ctrl[0] == 4) return 1;
+        DpStore &S = ctrl[0] == 1 ? SU : ctrl[0] == 2 ? SL : SS;
+        const int64_t used = ctrl[0] == 1 ? ctrl[8] : ctrl[0] == 2 ? ctrl[9] : ctrl[10];
+        if (S.cap >= 0x7ffffff0ll || (launch > 40 && !getenv("ILUPP_DP_STORE"))) { set_error("partialILUC: the factors of a level outgrow 2^31 entries"); return ILUPP_ERR_MEMORY; }
+        int64_t ncap = getenv("ILUPP_DP_STORE") ? S.cap + (int64_t)n + 2 + atol(getenv("ILUPP_DP_STORE")) : 2 * S.cap + (int64_t)n + 1024;
+        if (ncap > 0x7ffffff0ll) ncap = 0x7ffffff0ll;
+        { const int rc = S.grow(st, ncap, used); if (rc) return rc; }
+    }
+    {
+        const int32_t last = ctrl[1], nA = ctrl[2];
+        const bool to_the_end = ctrl[4] != 0;
+        const int32_t *ident = b_id.as<int32_t>();
+        { const int rc = seg_compress_sort(st, n, a.Lptr, a.Lidx, a.Lval, ident, 0, false, L); if (rc) return rc; }      // compress(), :2053-2054
+        { const int rc = seg_compress_sort(st, n, a.Uptr, a.Uidx, a.Uval, ident, 0, true, U); if (rc) return rc; }
+        if (to_the_end) {                                                           // :2055
+            Anew->release();
+            Anew->n = 0; Anew->nnz = 0; Anew->is_csr = true; Anew->owns = true;
+            ILUPP_HIP(pool_malloc(&Anew->ptr, sizeof(int32_t)));
+            ILUPP_HIP(hipMemsetAsync(Anew->ptr, 0, sizeof(int32_t), st));
+            ILUPP_HIP(pool_malloc(&Anew->idx, sizeof(int32_t)));
+            ILUPP_HIP(pool_malloc(&Anew->val, sizeof(double)));
+            *kterm = n;
+        } else {
+            const int rc = seg_compress_sort(st, nA, a.Sptr, a.Sidx, a.Sval, ident, last + 1, true, Anew);       // :2057-2065
+            if (rc) return rc;
+            *kterm = last + 1;
+        }
+        ILUPP_HIP(hipStreamSynchronize(st));
+    }
+    gd.keep = true;
+    *Dinv_out = Dinv;
+    return ILUPP_OK;
+}
+
 int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, int32_t bp, int32_t bpr, int32_t epr,
                   DevMat *L, DevMat *U, double **Dinv_out, DevMat *Anew, int32_t *pc2, int32_t *pr2, float *kernel_ms)
 {
@@ -1236,29 +1660,7 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
     // the stores: what the factors of this level may grow to is not known beforehand.  The kernel stops BETWEEN two steps when a store
     // has no room for another row; the store is doubled (contents copied) and the kernel goes on with that step (the reference's
     // enlarge_fields_keep_data, :763-769)
-    struct Store {
-        PoolBlock idx, link, who, val;
-        int64_t cap = 0;
-        bool lists;
-        int grow(hipStream_t st, int64_t ncap, int64_t used) {
-            PoolBlock ni, nl, nw, nv;
-            ILUPP_HIP(ni.alloc(sizeof(int32_t) * (size_t)ncap));
-            ILUPP_HIP(nv.alloc(sizeof(double) * (size_t)ncap));
-            if (lists) { ILUPP_HIP(nl.alloc(sizeof(int32_t) * (size_t)ncap)); ILUPP_HIP(nw.alloc(sizeof(int32_t) * (size_t)ncap)); }
-            if (used > 0) {
-                ILUPP_HIP(hipMemcpyAsync(ni.p, idx.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
-                ILUPP_HIP(hipMemcpyAsync(nv.p, val.p, sizeof(double) * (size_t)used, hipMemcpyDeviceToDevice, st));
-                if (lists) {
-                    ILUPP_HIP(hipMemcpyAsync(nl.p, link.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
-                    ILUPP_HIP(hipMemcpyAsync(nw.p, who.p, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, st));
-                }
-                ILUPP_HIP(hipStreamSynchronize(st));
-            }
-            idx.swap(ni); val.swap(nv); link.swap(nl); who.swap(nw);
-            cap = ncap;
-            return ILUPP_OK;
-        }
-    } SU, SL, SS;
+    DpStore SU, SL, SS;
     SU.lists = SL.lists = true; SS.lists = false;
     int64_t cap0 = 2 * nnz + 8 * (int64_t)n + 1024, capS0 = nnz + 2 * (int64_t)n + 1024;
     if (const char *e = getenv("ILUPP_DP_STORE")) { cap0 = capS0 = (int64_t)n + 2 + atol(e); }        // (tests: stores that fill up after a few steps)
@@ -1332,7 +1734,7 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
                          in_lds ? "vectors in LDS" : "vectors in memory", (long long)SU.cap, (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
         if (ctrl[0] == 0) break;
         if (ctrl[0] == 4) { in_lds = false; continue; }
-        Store &S = ctrl[0] == 1 ? SU : ctrl[0] == 2 ? SL : SS;
+        DpStore &S = ctrl[0] == 1 ? SU : ctrl[0] == 2 ? SL : SS;
         const int64_t used = ctrl[0] == 1 ? ctrl[8] : ctrl[0] == 2 ? ctrl[9] : ctrl[10];
         if (S.cap >= 0x7ffffff0ll || (launch > 40 && !getenv("ILUPP_DP_STORE"))) { set_error("ILU++ with pivoting: the factors of a level outgrow 2^31 entries"); return ILUPP_ERR_UNSUPPORTED; }
         int64_t ncap = getenv("ILUPP_DP_STORE") ? S.cap + (int64_t)n + 2 + atol(getenv("ILUPP_DP_STORE")) : 2 * S.cap + (int64_t)n + 1024;

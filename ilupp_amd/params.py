@@ -193,12 +193,8 @@ class iluplusplus_precond_parameter:
             raise ValueError("choose permissible value for PERMUTE_ROWS / TOTAL_PIV!")
         if not self._uses_partial_iluc() and not (-1 <= self.FINAL_ROW_CRIT <= 9):
             refuse("FINAL_ROW_CRIT = %r with the pivoting factorisation (rows ordered by weights instead of counts)" % (self.FINAL_ROW_CRIT,))
-        # rules whose estimates accumulate over the steps in their sequential order: the inverse-based one is built where the steps are
-        # sequential anyway (the factorisation with pivoting, a chain walked by one wave); the weighted ones are not built
-        seq_rules = [k + " (with the factorisation without pivoting)" for k in ("USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2")
-                     if getattr(self, k) and self._uses_partial_iluc()]
-        if seq_rules:
-            refuse("dropping by " + ", ".join(seq_rules) + " (these rules accumulate estimates over the steps in their sequential order)")
+        # (the inverse-based and weighted rules accumulate estimates over the steps in their sequential order: with them both factorisations
+        #  run as chains walked by one wave, pilucdp.hip)
         rules = 0
         for bit, k in ((1, "USE_STANDARD_DROPPING"), (2, "USE_STANDARD_DROPPING2"), (4, "USE_ERR_PROP_DROPPING"), (8, "USE_ERR_PROP_DROPPING2"),
                        (16, "USE_PIVOT_DROPPING"), (32, "USE_INVERSE_DROPPING"), (64, "USE_WEIGHTED_DROPPING"), (128, "USE_WEIGHTED_DROPPING2")):
