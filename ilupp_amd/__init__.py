@@ -133,8 +133,7 @@ class ILUppPreconditioner(_HipPreconditioner):
     largest entry of its working row, the next row the one with the fewest entries in L so far) -- a chain of n steps that one wave of the
     GPU walks (ilupp_amd/csrc/pilucdp.hip).  Parameters without row reordering, total pivoting and pivot tolerance
     (``params.default_configuration(1)``, precon_parameter 10) fix rows and columns beforehand and run as a dataflow computation over all
-    CUs (piluc_df.hip): the fast path for large matrices.  Both are bit-identical to the reference; what is not built (inverse-based and weighted
-    dropping in the family without pivoting, the improved Schur complement, FINAL_ROW_CRIT < -1, a few preprocessing steps) raises
+    CUs (piluc_df.hip): the fast path for large matrices.  Both are bit-identical to the reference; what is not built (the improved Schur complement, FINAL_ROW_CRIT < -1, a few preprocessing steps) raises
     NotImplementedError."""
 
     def __init__(self, A, threshold=1.0, fill_in=None, params=None):

@@ -130,14 +130,14 @@ __device__ double dp_inverse_update(const Acc &acc, int nnz, int k, int pk, doub
     return smax(fabs(xe), fabs(ye));
 }
 // weighted dropping (ILUCDP.hpp:629-631, :670-674): every index of the step's vector collects the magnitude of its entry (one add per index
-// and step, the steps in their order).  Returns what the accumulated weight of `pk` is after it (pk_in: pk is an index of the vector --
-// the zeroed pivot of a row of U -- and gets +|0|; a column of L does not hold its own row).
+// and step, the steps in their order).  Returns what the accumulated weight of `pk` is after it (pk_in: pk is an index of the vector and
+// gets + pk_abs, the magnitude of its entry -- the zeroed pivot of a row of U: +|0|).
 template <class Acc>
-__device__ double dp_accumulate_weights(const Acc &acc, int nnz, double *W, int pk, bool pk_in, int lane)
+__device__ double dp_accumulate_weights(const Acc &acc, int nnz, double *W, int pk, bool pk_in, int lane, double pk_abs = 0.0)
 {
     const double old = W[pk];
     for (int s = lane; s < nnz; s += 64) { const int c = acc.idx(s); W[c] = W[c] + fabs(acc.val(s)); }
-    return pk_in ? old + 0.0 : old;
+    return pk_in ? old + pk_abs : old;
 }
 struct SpAcc { SpVec v; __device__ int idx(int s) const { return v.list[s]; } __device__ double val(int s) const { return v.rec[v.list[s]].val; } };
 
@@ -1201,7 +1201,10 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
             for (int s = lane; s < wnnz; s += 64) w.val[s] = w.val[s] * dinv;       // w.scale(Dinv[k]), :1665
             LV_SYNC();
         }
-        if (A.wts && eliminate) wtdL = dp_accumulate_weights(LvAcc{w}, wnnz, A.wts + n, k, false, lane);      // :1670-1675
+        if (A.wts && eliminate) {                                                   // :1670-1675 (w may hold row k itself)
+            const int ks = lv_find(w, k);
+            wtdL = dp_accumulate_weights(LvAcc{w}, wnnz, A.wts + n, k, ks >= 0, lane, ks >= 0 ? fabs(w.val[ks]) : 0.0);
+        }
         double invU = 0.0;
         if (eliminate && (A.rules & PILUC_DROP_INVERSE))                            // :1676-1710
             invU = dp_inverse_update(LvAcc{z}, znnz, k, k, A.inv, A.inv + n, A.inv + 2 * (size_t)n, A.inv + 3 * (size_t)n, lane);

@@ -171,13 +171,13 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
  *     e.g. default_configuration(1)): matrix_sparse::partialILUC (ILUCDP.hpp:1405-2231) as a dataflow computation over all CUs;
  *   - WITH pivoting (the default-constructed parameters, default_configuration(0), (10)): matrix_sparse::partialILUCDP (:268-1404), a chain
  *     of data-dependent steps walked by one wave; many matrices at once: ilupp_hip_ml_create_batch;
- * dropping by the combined weight of the standard / error-propagation / pivot rules, and -- with pivoting -- the inverse-based rule
- * (ILUPP_DROP_INVERSE; precon_parameter 1) and the weighted rule (ILUPP_DROP_WEIGHTED / _WEIGHTED2; precon_parameter 2): their estimates
- * accumulate over the steps in their sequential order, which the chain has anyway;
+ * dropping by the combined weight of the standard / error-propagation / pivot rules, the inverse-based rule (ILUPP_DROP_INVERSE;
+ * precon_parameter 1, 11) and the weighted rule (ILUPP_DROP_WEIGHTED / _WEIGHTED2; precon_parameter 2, 12) -- with the last two, whose
+ * estimates are recurrences over all steps, the factorisation without pivoting runs as a chain as well (working rows up to 2048 entries);
  * unbounded or bounded fill; levels ended by small pivots or by the fill of L (FINAL_ROW_CRIT -1 .. 9); preprocessing steps
  * NORMALIZE_COLUMNS, NORMALIZE_ROWS, PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING,
  * DD_SYMM_MOVE_CORNER_ORDERING_IM, SYMM_PQ (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter
- * combination (the inverse-based and weighted rules without pivoting, the improved Schur complement, positional dropping, FINAL_ROW_CRIT
+ * combination (the improved Schur complement, positional dropping, FINAL_ROW_CRIT
  * < -1, an external final row) is refused with ILUPP_ERR_UNSUPPORTED: nothing is silently replaced.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ilupp_ml ilupp_ml;
@@ -194,8 +194,8 @@ enum {                               /* preprocessing_type values (orderings.h) 
 };
 
 enum { ILUPP_DROP_STANDARD = 1, ILUPP_DROP_STANDARD2 = 2, ILUPP_DROP_ERR_PROP = 4, ILUPP_DROP_ERR_PROP2 = 8, ILUPP_DROP_PIVOT = 16,
-       ILUPP_DROP_INVERSE = 32, ILUPP_DROP_WEIGHTED = 64, ILUPP_DROP_WEIGHTED2 = 128 };   /* USE_INVERSE_DROPPING (ILUCDP.hpp:680-713, :882-916): estimates that accumulate over the steps in their order --
-                                       built for the factorisation with pivoting (a sequential chain anyway), refused for the one without */
+       ILUPP_DROP_INVERSE = 32, ILUPP_DROP_WEIGHTED = 64, ILUPP_DROP_WEIGHTED2 = 128 };   /* USE_INVERSE_DROPPING (ILUCDP.hpp:680-713, :882-916), USE_WEIGHTED_DROPPING[2]
+                                       (:629-631, :670-674): estimates that accumulate over the steps in their order -- the factorisation runs as a chain */
 
 typedef struct {                     /* the fields of iluplusplus_precond_parameter (parameters.h:120-235) the built family reads */
     double threshold;                /* threshold */
@@ -227,8 +227,8 @@ typedef struct {                     /* the fields of iluplusplus_precond_parame
     int32_t final_row_crit;              /* FINAL_ROW_CRIT -1..9 */
     double move_level_factor;            /* MOVE_LEVEL_FACTOR */
     double row_u_max;                    /* ROW_U_MAX */
-    double weight_inverse_drop;          /* WEIGHT_INVERSE_DROP (with ILUPP_DROP_INVERSE; the factorisation with pivoting only) */
-    double weight_weighted_drop;         /* WEIGHT_WEIGHTED_DROP (with ILUPP_DROP_WEIGHTED; the factorisation with pivoting only) */
+    double weight_inverse_drop;          /* WEIGHT_INVERSE_DROP (with ILUPP_DROP_INVERSE) */
+    double weight_weighted_drop;         /* WEIGHT_WEIGHTED_DROP (with ILUPP_DROP_WEIGHTED) */
     double init_weights_lu;              /* INIT_WEIGHTS_LU */
 } ilupp_ml_params;
 

@@ -60,4 +60,13 @@ def case(seed):
             knobs["WEIGHT_PIVOT_DROP"] = float(rng.choice([0.1, 1.0]))
         if rng.random() < 0.3:
             knobs["SCALE_WEIGHT_INVDIAG"] = True
+    if rng.random() < 0.2:                                      # the rules that are recurrences over all steps: the factorisation runs as a chain
+        if rng.random() < 0.5:
+            knobs["USE_INVERSE_DROPPING"] = True
+            knobs["WEIGHT_INVERSE_DROP"] = float(rng.choice([1.0, 0.3]))
+        else:
+            knobs["USE_WEIGHTED_DROPPING"] = True
+            knobs["INIT_WEIGHTS_LU"] = float(rng.choice([1.0, 0.5]))
+        if rng.random() < 0.5:
+            knobs["USE_ERR_PROP_DROPPING"] = False
     return A, (thr, pre, knobs)

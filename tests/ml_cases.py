@@ -84,6 +84,11 @@ PARAMS = [
                                                                           "COMBINE_FACTOR": 2, "NEUTRAL_ELEMENT": 1.0, "WEIGHT_PIVOT_DROP": 0.5}),
     ("t0.1_std2_minw_invdiag", 0.1, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"USE_STANDARD_DROPPING2": True, "COMBINE_FACTOR": 3, "MIN_WEIGHT": 0.5,
                                                                                               "SCALE_WEIGHT_INVDIAG": True}),
+    # the rules whose estimates are recurrences over all steps (presets 11, 12: inverse-based, weighted dropping; ILUCDP.hpp:1676-1710,
+    # :1856-1892, :1634-1636, :1670-1675): the factorisation runs as a chain
+    ("t0.05_inv", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"USE_INVERSE_DROPPING": True, "USE_ERR_PROP_DROPPING": False}),
+    ("t0.02_inv_err_mwm", 0.02, ("MAX_WEIGHTED_MATCHING_ORDERING",), {"USE_INVERSE_DROPPING": True, "COMBINE_FACTOR": 1, "WEIGHT_INVERSE_DROP": 0.5}),
+    ("t0.05_wgt", 0.05, ("NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"), {"USE_WEIGHTED_DROPPING": True, "USE_ERR_PROP_DROPPING": False, "INIT_WEIGHTS_LU": 0.5}),
     # default_configuration(11): where the move-to-corner ordering rejects an index the reference's result is undefined:
     # the oracle and the engine refuse, and the fixture records that
     ("t0.05_mwm_dd", 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "DD_SYMM_MOVE_CORNER_ORDERING_IM"), {}),

@@ -290,3 +290,41 @@ def test_degenerate_inputs_against_oracle():
         for pre in (PQ, (), MWM, ("NORMALIZE_ROWS", "SPARSE_FIRST_ORDERING", "UNIT_OR_ZERO_DIAGONAL_SCALING")):
             for thr in (0.0, 0.1):
                 _against_oracle(A, (thr, pre, {}))
+
+
+def test_chain_kernel_of_partial_iluc():
+    """partialILUC as a sequential chain (pilucdp.hip: k_piluc_chain -- Crout's three lists kept as the reference keeps them, the working
+    vectors in LDS): what the factorisation without pivoting runs on when its dropping rules are recurrences over all steps
+    (inverse-based, weighted: presets 11, 12) and when its rows outgrow the dataflow kernel's LDS classes.  ILUPP_PILUC_CHAIN=1 sends every
+    level there: the plain rules too, several levels, Schur complements, bounded fill, stores that fill up, n = 10^5 -- bit for bit; and the
+    two presets through the parameter object"""
+    import fuzz_ml
+    import ilupp_amd as ilupp
+    os.environ["ILUPP_PILUC_CHAIN"] = "1"
+    try:
+        A = C.weak_random(700, 0.01, 0.3, 7)
+        assert _against_oracle(A, (0.05, PQ, {})) >= 5
+        _against_oracle(A.tocsc(), (0.2, PQ, {"THRESHOLD_SHIFT_SCHUR": 1e-2, "fill_in": 6}))
+        _against_oracle(C.laplace2d_matrix(2500), (0.01, MWM, {"USE_STANDARD_DROPPING": True, "COMBINE_FACTOR": 1}))
+        _against_oracle(sp.csr_matrix(matgen.random_dd(100000, k=8), shape=(100000, 100000)), (1e-3, PQ, {}))
+        os.environ["ILUPP_DP_STORE"] = "200"
+        try:
+            _against_oracle(sp.csr_matrix(matgen.random_dd(3000, k=7, diag=2.0), shape=(3000, 3000)), (0.02, PQ, {}))
+        finally:
+            del os.environ["ILUPP_DP_STORE"]
+        for seed in range(40):
+            A, params = fuzz_ml.case(1000 + seed)
+            _against_oracle(A, params)
+    finally:
+        del os.environ["ILUPP_PILUC_CHAIN"]
+    # presets 11 and 12 (parameters_implementation.h:935-945) through the parameter object, without the switch
+    from oracle import oracle as O
+    M = sp.csr_matrix(matgen.random_dd(20000, k=7, diag=4.0), shape=(20000, 20000))
+    for preset in (11, 12):
+        p = ilupp.iluplusplus_precond_parameter()
+        p.init(ilupp.preprocessing_sequence(["NORMALIZE_COLUMNS", "NORMALIZE_ROWS", "PQ_ORDERING"]), preset)
+        p.threshold = 0.05
+        P = ilupp.ILUppPreconditioner(M, params=p)
+        Q = O.orc().ml(O.from_scipy(M), C.block_to_oracle(O, p._to_ml_params()))
+        b = C.rhs(20000)
+        assert P.total_nnz == Q.total_nnz() and np.array_equal(P @ b, Q.apply(b))

@@ -166,8 +166,6 @@ def test_everything_outside_the_built_family_is_refused():
         change(p)
         with pytest.raises(NotImplementedError):
             p._to_ml_params()
-    refused(lambda p: p.use_only_inverse_dropping())
-    refused(lambda p: setattr(p, "USE_WEIGHTED_DROPPING", True))
     refused(lambda p: setattr(p, "SCALE_WGT_MAXINVDIAG", True))
     refused(lambda p: setattr(p, "SCHUR_COMPLEMENT", 1))
     refused(lambda p: setattr(p, "DROP_TYPE_L", 1))
@@ -180,9 +178,9 @@ def test_everything_outside_the_built_family_is_refused():
         p = ilupp.iluplusplus_precond_parameter(); p.PERMUTE_ROWS = 4; p._to_ml_params()
 
 
-def test_inverse_based_dropping_goes_with_the_pivoting_family():
+def test_inverse_based_and_weighted_dropping():
     """USE_INVERSE_DROPPING (precon_parameter 1: parameters_implementation.h:872-876) accumulates estimates over the steps in their order:
-    built where the steps are a sequential chain anyway (the factorisation with pivoting), refused for the dataflow factorisation"""
+    both factorisations then run as sequential chains (pilucdp.hip: k_pilucdp_lds, k_piluc_chain)"""
     import ilupp_amd as ilupp
     p = ilupp.iluplusplus_precond_parameter()                  # default-constructed: the pivoting family
     p.use_only_inverse_dropping()
@@ -196,12 +194,12 @@ def test_inverse_based_dropping_goes_with_the_pivoting_family():
     p.INIT_WEIGHTS_LU = 0.5
     b = p._to_ml_params()
     assert b.drop_rules == 64 and b.weight_weighted_drop == 1.0 and b.init_weights_lu == 0.5
-    for name in ("USE_INVERSE_DROPPING", "USE_WEIGHTED_DROPPING", "USE_WEIGHTED_DROPPING2"):
-        q = ilupp.iluplusplus_precond_parameter()
-        q.default_configuration(1)                             # without pivoting
-        setattr(q, name, True)
-        with pytest.raises(NotImplementedError, match=name):
-            q._to_ml_params()
+    # ... and without pivoting (precon_parameter 11, 12): the factorisation then runs as a chain as well
+    q = ilupp.iluplusplus_precond_parameter()
+    q.init(ilupp.preprocessing_sequence(["PQ_ORDERING"]), 11)
+    assert q._uses_partial_iluc() and q._to_ml_params().drop_rules == 32
+    q.init(ilupp.preprocessing_sequence(["PQ_ORDERING"]), 12)
+    assert q._uses_partial_iluc() and q._to_ml_params().drop_rules == 64
 
 
 def test_parameter_block_of_the_pivoting_family():
