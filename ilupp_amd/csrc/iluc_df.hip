@@ -135,7 +135,11 @@ int iluc_column_order(hipStream_t st, int32_t m, const DevMat &Av, const int32_t
     ILUPP_HIP(hipMemcpyAsync(&cost, b_cost.p, sizeof(cost), hipMemcpyDeviceToHost, st));
     ILUPP_HIP(hipStreamSynchronize(st));
     const int64_t nnz = Av.nnz;
-    if (cost <= 64ull * (unsigned long long)(nnz > 0 ? nnz : 1) + 1000000ull || nnz > 200000000) {
+    // (the device kernels walk every chain in one thread: fine for the short chains of a large sparse matrix, hundreds of milliseconds for a
+    //  small DENSE one -- the Schur complements of a multilevel object: 212 rows, 45 000 entries, 3 million dependent steps; there the host's
+    //  O(nnz) emulation below, a millisecond, is taken)
+    const bool small_dense = nnz <= 4000000 && cost > 16ull * (unsigned long long)(nnz > 0 ? nnz : 1);
+    if (!small_dense && (cost <= 64ull * (unsigned long long)(nnz > 0 ? nnz : 1) + 1000000ull || nnz > 200000000)) {
         hipLaunchKernelGGL(k_iluc_colfill, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, colptr, fillc, colpos);
         hipLaunchKernelGGL(k_iluc_colorder, dim3(gb), dim3(256), 0, st, m, Av.ptr, Av.idx, rowof, colptr, colpos, colord);
         return ILUPP_OK;
