@@ -460,7 +460,7 @@ int sptrsv(hipStream_t st, SweepKind kind, const DevMat &M, const Schedule &sch,
 
 int sptrsv_rows(hipStream_t st, SweepKind kind, const DevMat &M, double *rhs_and_reset, double *out, int32_t *d_ticket, int32_t *d_err);
 // sptrsv_small.hip: one workgroup, the unknowns in LDS (the small, dense levels of a multilevel preconditioner); rhs is left as it is
-static constexpr int32_t kSmallSweepMax = 1024;      // measured: 20 against 27 ms per apply for a 7-level object of n = 700; no gain from n = 3 000 on, a loss at n = 6 000
+static constexpr int32_t kSmallSweepMax = 4096;      // round 3 (one entry per trip): 20 against 27 ms per apply for a 7-level object of n = 700, no gain from n = 3 000 on; round 4 (up to four entries per trip): see DESIGN 4e
 int sptrsv_small(hipStream_t st, SweepKind kind, const DevMat &M, const double *rhs, double *out, int32_t *err);
 
 // sptrsv_lvl.hip
