@@ -1344,7 +1344,7 @@ int utu_half(ilupp_precond *p, bool forward, bool tr, double *rhs, double *out, 
     // (not for a factor with an empty row: p->degenerate objects keep the row-by-row kernel, which reports what it meets)
     // (up to 1 024 rows always; up to kSmallSweepMax = 4 096 when the rows are long -- more than 32 entries on average: there the general
     //  kernels' hop through memory per link of the dependency chain costs most.  Measured, apply of a whole object: 26 levels from n = 2 000,
-    //  177 entries per row: 75 against 176 ms; 3 375 rows with 6 entries per row: 0.82 against 0.68 ms -- hence the second condition)
+    //  177 entries per row: 65 against 176 ms; 3 375 rows with 6 entries per row: 0.82 against 0.68 ms -- hence the second condition)
     const DevMat &Msmall = forward ? (tr ? p->UcT : p->LcT) : (tr ? p->Lc : p->Uc);
     if ((p->n <= 1024 || (p->n <= kSmallSweepMax && Msmall.nnz > 32 * (int64_t)p->n)) && !p->degenerate && !getenv_small_off()) {
         const DevMat &M = Msmall;

@@ -6,9 +6,9 @@
 // t + 256, ... per lane), the unknowns in an LDS array that starts all-sentinel (the data is the flag, as everywhere in this library), a lane
 // consumes its row's entries strictly in stored order as the unknowns they need appear -- the reference's arithmetic (triangular_solve,
 // sparse_implementation.h:4040-4087: x_k -= d_j x[idx_j] one entry after the other, then the division by the diagonal), hence its bits.
-// No lane ever blocks: every trip of the loop each lane either consumes up to four entries (those of its register group whose unknowns
-// are there, in order), finishes a row, or does nothing, so lanes of one wave can wait for each other.  Entries are fetched four at a
-// time into registers, the next four while the current four are consumed.
+// No lane ever blocks: every trip of the loop each lane either consumes up to eight entries (those of its register group whose unknowns
+// are there, in order), finishes a row, or does nothing, so lanes of one wave can wait for each other.  Entries are fetched eight at a
+// time into registers, the next eight while the current eight are consumed.
 #include "common.h"
 
 namespace ilupp {
@@ -16,6 +16,8 @@ namespace ilupp {
 static constexpr int kSmallThreads = 256;      // one wave per SIMD: the chain of a dense factor advances one row per two trips of the loop, and a trip is as long as the waves that share a SIMD make it
 
 // kind SWEEP_FWD_LAST_ASC: lower CSR, diagonal LAST in the row (T1);  SWEEP_BWD_FIRST_ASC: upper CSR, diagonal FIRST (T3)
+static constexpr int kG = 8;                    // entries of a row held in one register group
+
 template <bool FWD>
 __global__ void __launch_bounds__(kSmallThreads)
 k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const double *__restrict__ val,
@@ -30,13 +32,13 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
     int j = 0, jend = 0, jf = 0;                    // the off-diagonal entries of the row still to consume: [j, jend); fetched up to jf
     double acc = 0.0, diag = 1.0;
     // two groups of four entries in registers: one is consumed while the other one's loads are in flight
-    int c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
-    double v0[4] = {0.0, 0.0, 0.0, 0.0}, v1[4] = {0.0, 0.0, 0.0, 0.0};
+    int c0[kG] = {0}, c1[kG] = {0};
+    double v0[kG] = {0.0}, v1[kG] = {0.0};
     int have0 = 0, have1 = 0, at = 0;
     auto fetch1 = [&]() {                           // the next group into c1 / v1
-        have1 = jend - jf < 4 ? jend - jf : 4;
+        have1 = jend - jf < kG ? jend - jf : kG;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (q < have1) { c1[q] = idx[jf + q]; v1[q] = val[jf + q]; }
+        for (int q = 0; q < kG; ++q) if (q < have1) { c1[q] = idx[jf + q]; v1[q] = val[jf + q]; }
         jf += have1;
     };
     // every trip of the loop below some lane consumes an entry or finishes a row unless an unknown never leaves the sentinel (an index
@@ -52,9 +54,9 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
         else { j = b + 1; jend = e; diag = val[b]; }
         acc = rhs[r];
         jf = j;
-        have0 = jend - jf < 4 ? jend - jf : 4;
+        have0 = jend - jf < kG ? jend - jf : kG;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (q < have0) { c0[q] = idx[jf + q]; v0[q] = val[jf + q]; }
+        for (int q = 0; q < kG; ++q) if (q < have0) { c0[q] = idx[jf + q]; v0[q] = val[jf + q]; }
         jf += have0;
         at = 0;
         fetch1();
@@ -66,19 +68,19 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
             if (j < jend) {
                 if (at == have0) {                  // the group is used up: the other one takes its place, the one after it is asked for
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { c0[q] = c1[q]; v0[q] = v1[q]; }
+                    for (int q = 0; q < kG; ++q) { c0[q] = c1[q]; v0[q] = v1[q]; }
                     have0 = have1; at = 0;
                     fetch1();
                 }
                 // as many entries of the group as have their unknown, in stored order (a backward sweep's row waits for its FIRST entry --
                 // the unknown next to the diagonal, the last one to appear -- and then finds all the others there: one trip per entry made the
                 // backward sweep of a dense factor 70 times slower than the forward one)
-                unsigned long long xb[4];
+                unsigned long long xb[kG];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < kG; ++q)
                     xb[q] = (q >= at && q < have0) ? __hip_atomic_load(&xs[c0[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : kSentinel;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < kG; ++q)
                     if (q == at && q < have0 && xb[q] != kSentinel) {
                         const double p = v0[q] * __longlong_as_double((long long)xb[q]);
                         acc = acc - p;
