@@ -1039,18 +1039,37 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds_batch(const DpArgs *__restri
 // Aliases of DpArgs: perm = listA, iperm = headA, prow = firstA, iprow = listL, numb = firstL, pnum = listU, nonpiv = firstU.
 constexpr int kPcNodes = 4096;                  // contributors of one step (nodes of one list) kept in LDS for the list update
 
-// list[] / first[] of a triangular factor after step k (update_triangular_fields, ILUC.hpp:31-63): the nodes of list[k] (in `nodes`, in list
-// order) and k itself move on to the list of their next index.  One lane, in the reference's order.
-__device__ void pc_update_triangular(int k, const int32_t *ptr, const int32_t *idx, int32_t *list, int32_t *first, const int32_t *nodes, int nn, int lane)
+// The lists after step k (update_triangular_fields, ILUC.hpp:31-63; update_sparse_matrix_fields, :86-101): every node of list k (in `nodes`,
+// in list order) -- for a triangular factor first of all k itself -- advances its `first` and, if it has an entry left, is put at the HEAD
+// of the list of that entry's index j: list[h] = tgt[j]; tgt[j] = h (tgt = list for a triangular factor, head for the columns of A).
+// The reference does that one node after the other; what depends on the order is only what several nodes with the same j see: the
+// first one the old head, every later one the node before it, and the last one becomes the head.  64 nodes at a time, one per lane.
+__device__ void pc_relink(int k, bool with_k, const int32_t *ptr, const int32_t *idx, int32_t *list, int32_t *tgt, int32_t *first, const int32_t *nodes, int nn,
+                          int lane)
 {
-    if (lane != 0) return;
-    for (int i = 0; i < nn; ++i) first[nodes[i]] += 1;
-    first[k] = ptr[k] + 1;
-    if (ptr[k] + 1 < ptr[k + 1]) { const int j = idx[ptr[k] + 1]; list[k] = list[j]; list[j] = k; }
-    for (int i = 0; i < nn; ++i) {
-        const int h = nodes[i];
-        const int f = first[h];
-        if (f < ptr[h + 1]) { const int j = idx[f]; list[h] = list[j]; list[j] = h; }
+    const int total = nn + (with_k ? 1 : 0);
+    for (int base = 0; base < total; base += 64) {
+        const int t = base + lane;
+        const bool act = t < total;
+        const int h = !act ? -1 : (with_k ? (t == 0 ? k : nodes[t - 1]) : nodes[t]);
+        int f = 0, j = -1, old = -1;
+        if (act) {
+            f = (with_k && t == 0) ? ptr[k] + 1 : first[h] + 1;
+            first[h] = f;
+            if (f < ptr[h + 1]) { j = idx[f]; old = tgt[j]; }
+        }
+        int prev = -1;
+        bool last = j >= 0;
+        const int cnt = total - base < 64 ? total - base : 64;
+        for (int i = 0; i < cnt; ++i) {
+            const int ji = wv_i32(j, i), hi = wv_i32(h, i);
+            if (j >= 0 && ji == j) { if (i < lane) prev = hi; else if (i > lane) last = false; }
+        }
+        if (j >= 0) {
+            list[h] = prev >= 0 ? prev : old;
+            if (last) tgt[j] = h;
+        }
+        __builtin_amdgcn_s_waitcnt(0);                 // (the next 64 see these heads)
     }
 }
 
@@ -1263,18 +1282,10 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
         LV_SYNC();
         // :1977-1983: the three lists move on
         if (eliminate) {
-            if (lane == 0) {                                                        // update_sparse_matrix_fields, ILUC.hpp:86-101
-                const int32_t *nodesA = s_nodes + nnL + nnU;
-                for (int i = 0; i < nnA; ++i) firstA[nodesA[i]] += 1;
-                for (int i = 0; i < nnA; ++i) {
-                    const int h = nodesA[i];
-                    const int f = firstA[h];
-                    if (f < A.Ap[h + 1]) { const int c = A.Ai[f]; listA[h] = headA[c]; headA[c] = h; }
-                }
-            }
-            pc_update_triangular(k, A.Uptr, A.Uidx, listU, firstU, s_nodes + nnL, nnU, lane);
+            pc_relink(k, false, A.Ap, A.Ai, listA, headA, firstA, s_nodes + nnL + nnU, nnA, lane);
+            pc_relink(k, true, A.Uptr, A.Uidx, listU, listU, firstU, s_nodes + nnL, nnU, lane);
         }
-        pc_update_triangular(k, A.Lptr, A.Lidx, listL, firstL, s_nodes, nnL, lane);
+        pc_relink(k, true, A.Lptr, A.Lidx, listL, listL, firstL, s_nodes, nnL, lane);
         __builtin_amdgcn_s_waitcnt(0);
         LV_SYNC();
     }

@@ -296,6 +296,15 @@ def test_batched_construction_is_the_same_objects_and_runs_side_by_side():
     assert ilupp.ILUppPreconditioner.batch([]) == []
     with pytest.raises(TypeError):
         ilupp.ILUppPreconditioner.batch([mats[0], mats[1].tocsc()])
+    # a member the engine refuses (the move-to-corner ordering on a matrix where the reference's own result is undefined): reported by its
+    # number, the other members' objects are not handed out half-done, nothing leaks (strict pool) -- and the next batch works
+    import ml_cases
+    cases = dict(ml_cases.matrices())
+    q = ml_cases.engine_params(ilupp, 0.05, ("MAX_WEIGHTED_MATCHING_ORDERING", "DD_SYMM_MOVE_CORNER_ORDERING_IM"), {})
+    with pytest.raises(NotImplementedError, match="matrix 1 of the batch"):
+        ilupp.ILUppPreconditioner.batch([cases["laplace2d_400"], cases["rdd_300"], cases["p3d_6_7_5"]], params=q)
+    ok = ilupp.ILUppPreconditioner.batch([cases["laplace2d_400"], cases["p3d_6_7_5"]], params=q)
+    assert ok[0].total_nnz == ilupp.ILUppPreconditioner(cases["laplace2d_400"], params=q).total_nnz
     # side by side: 16 chains of n = 20000
     big = [sp.csr_matrix(matgen.random_dd(20000, 8, 25.0, 500 + k), shape=(20000, 20000)) for k in range(16)]
     p = ilupp.iluplusplus_precond_parameter()
