@@ -1073,6 +1073,61 @@ __device__ void pc_relink(int k, bool with_k, const int32_t *ptr, const int32_t 
     }
 }
 
+// v -= (mval[fmul[h]] / Dinv[h]) * (the entries [fent[h], eptr[h + 1]) of eidx / eval) for every node h of the list from `start`, in list
+// order; the nodes go to nodes[base ...].  A node costs one dependent trip (the link to the next one): its fields and the next node's are
+// asked for one node ahead, its multiplier and first 64 entries while the node before it is subtracted.  false: out of room.
+struct PcNode { int h, next, fm, e0, e1; double dinv; };
+struct PcHead { double m; int c; double ev; };
+__device__ __forceinline__ PcNode pc_node(int h, const int32_t *list, const int32_t *fmul, const int32_t *fent, const int32_t *eptr, const double *Dinv)
+{
+    PcNode n{h, -1, 0, 0, 0, 1.0};
+    if (h != -1) { n.next = list[h]; n.fm = fmul[h]; n.e0 = fent[h]; n.e1 = eptr[h + 1]; n.dinv = Dinv[h]; }
+    return n;
+}
+__device__ __forceinline__ PcHead pc_head(const PcNode &n, const double *mval, const int32_t *eidx, const double *eval, int lane)
+{
+    PcHead t{0.0, 0, 0.0};
+    if (n.h != -1) { t.m = mval[n.fm]; if (n.e0 + lane < n.e1) { t.c = eidx[n.e0 + lane]; t.ev = eval[n.e0 + lane]; } }
+    return t;
+}
+__device__ __forceinline__ bool pc_subtract_walk(const LdsVec &v, int &nnz, int start, const int32_t *list, const int32_t *fmul, const double *mval,
+                                                 const int32_t *fent, const int32_t *eptr, const int32_t *eidx, const double *eval, const double *Dinv,
+                                                 int32_t *nodes, int base_node, int &nn, int lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    PcNode a = pc_node(start, list, fmul, fent, eptr, Dinv);
+    PcNode b = pc_node(a.next, list, fmul, fent, eptr, Dinv);
+    PcHead a2 = pc_head(a, mval, eidx, eval, lane);
+    while (a.h != -1) {
+        const PcNode c = pc_node(b.next, list, fmul, fent, eptr, Dinv);
+        const PcHead b2 = pc_head(b, mval, eidx, eval, lane);
+        if (base_node + nn >= kPcNodes) return false;
+        if (lane == 0) nodes[base_node + nn] = a.h;
+        ++nn;
+        const double f = a2.m / a.dinv;
+        for (int base = a.e0; base < a.e1; base += 64) {
+            const int e = base + lane;
+            const bool act = e < a.e1;
+            int cc; double ev;
+            if (base == a.e0) { cc = a2.c; ev = a2.ev; }
+            else { cc = act ? eidx[e] : 0; ev = act ? eval[e] : 0.0; }
+            const int slot = act ? lv_find(v, cc) : -1;
+            const bool isnew = act && slot < 0;
+            const unsigned long long mask = __ballot(isnew);
+            if (nnz + __popcll(mask) > kLvCap) return false;
+            if (act) {
+                const double prod = f * ev;
+                if (isnew) { const int sl = nnz + __popcll(mask & lt); v.idx[sl] = cc; v.val[sl] = 0.0 - prod; lv_enter(v, cc, sl); }
+                else v.val[slot] = v.val[slot] - prod;
+            }
+            nnz += __popcll(mask);
+            LV_SYNC();
+        }
+        a = b; a2 = b2; b = c;
+    }
+    return true;
+}
+
 __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_zidx[kLvCap], s_widx[kLvCap], s_zh[kLvHash], s_wh[kLvHash], s_cand[kLvCap], s_nodes[kPcNodes];
@@ -1124,33 +1179,7 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
         }
         // (3.) :1589-1602: the rows of U this row has multipliers for, in the order of the list
         int nnL = 0;
-        for (int h = listL[k]; h != -1;) {
-            const int next = listL[h];
-            const int fl = firstL[h], e0 = firstU[h], e1 = A.Uptr[h + 1];
-            const double f = A.Lval[fl] / A.Dinv[h];
-            if (nnL >= kPcNodes) PC_STOP(4);
-            if (lane == 0) s_nodes[nnL] = h;
-            ++nnL;
-            for (int base = e0; base < e1; base += 64) {
-                const int e = base + lane;
-                const bool act = e < e1;
-                const int c = act ? A.Uidx[e] : 0;
-                const double ev = act ? A.Uval[e] : 0.0;
-                const int slot = act ? lv_find(z, c) : -1;
-                const bool isnew = act && slot < 0;
-                const unsigned long long mask = __ballot(isnew);
-                if (znnz + __popcll(mask) > kLvCap) PC_STOP(4);
-                if (act) {
-                    const double prod = f * ev;
-                    if (isnew) { const int s = znnz + __popcll(mask & lt); z.idx[s] = c; z.val[s] = 0.0 - prod; lv_enter(z, c, s); }
-                    else z.val[slot] = z.val[slot] - prod;
-                }
-                znnz += __popcll(mask);
-                LV_SYNC();
-            }
-            h = next;
-        }
-        // the level ends at a small pivot, :1619-1636 (z[k] inserts the slot if the diagonal is missing)
+        if (!pc_subtract_walk(z, znnz, listL[k], listL, firstL, A.Lval, firstU, A.Uptr, A.Uidx, A.Uval, A.Dinv, s_nodes, 0, nnL, lane)) PC_STOP(4);
         // (the reference's z[k] inserts the slot -- in the test below, which it only reaches while eliminating, or in the elimination itself)
         if (eliminate && !lv_touch(z, znnz, k, lane)) PC_STOP(4);
         const int kslot = eliminate ? lv_find(z, k) : -1;
@@ -1191,32 +1220,7 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
                 }
                 h = next;
             }
-            for (int h = listU[k]; h != -1;) {
-                const int next = listU[h];
-                const int fu = firstU[h], e0 = firstL[h], e1 = A.Lptr[h + 1];
-                const double f = A.Uval[fu] / A.Dinv[h];
-                if (nnL + nnU >= kPcNodes) PC_STOP(4);
-                if (lane == 0) s_nodes[nnL + nnU] = h;
-                ++nnU;
-                for (int base = e0; base < e1; base += 64) {
-                    const int e = base + lane;
-                    const bool act = e < e1;
-                    const int c = act ? A.Lidx[e] : 0;
-                    const double ev = act ? A.Lval[e] : 0.0;
-                    const int slot = act ? lv_find(w, c) : -1;
-                    const bool isnew = act && slot < 0;
-                    const unsigned long long mask = __ballot(isnew);
-                    if (wnnz + __popcll(mask) > kLvCap) PC_STOP(4);
-                    if (act) {
-                        const double prod = f * ev;
-                        if (isnew) { const int s = wnnz + __popcll(mask & lt); w.idx[s] = c; w.val[s] = 0.0 - prod; lv_enter(w, c, s); }
-                        else w.val[slot] = w.val[slot] - prod;
-                    }
-                    wnnz += __popcll(mask);
-                    LV_SYNC();
-                }
-                h = next;
-            }
+            if (!pc_subtract_walk(w, wnnz, listU[k], listU, firstU, A.Uval, firstL, A.Lptr, A.Lidx, A.Lval, A.Dinv, s_nodes, nnL, nnU, lane)) PC_STOP(4);
             for (int s = lane; s < wnnz; s += 64) w.val[s] = w.val[s] * dinv;       // w.scale(Dinv[k]), :1665
             LV_SYNC();
         }
