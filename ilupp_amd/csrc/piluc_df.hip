@@ -1037,7 +1037,7 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
     while (rc == 1 || rc == 2) {
         int which = 0;
         L->release(); U->release(); Anew->release();
-        if (cls == 4 && !chain_tried) {
+        if (cls == 4 && !chain_tried && Av.n <= (1 << 18)) {           // (a chain of more steps than that costs tens of seconds before it can find out that a row does not fit)
             // rows too long for the LDS classes: the steps of such a factorisation depend on one another almost one by one, and the largest
             // class walks them through global-memory slots (700 us per step on the critical path).  The chain kernel walks them in LDS.
             chain_tried = true;
