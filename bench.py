@@ -18,7 +18,8 @@ the max-over-ranks time and one gather of per-matrix records).  Launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU);
 run without a launcher, `--gpus N` starts that launcher itself -- before anything touches the GPU.
 
-The default run (one GPU) also measures C3, C4 and one ILUC config after the headline one (about 20 s; --no-extra skips them)
+The default run (one GPU) also measures C3, C4, one ILUC config and the multilevel configs (C5: one level, C5M: with the matching, C5L: a
+5-level object, C5P: config 5 as named, C5PB: 64 of those side by side) after the headline one (about 40 s; --no-extra skips them)
 and a re-factorisation with new values on the analysed pattern ("refactor").
 --config C3 / C4 add the other BASELINE configs as extra keys of the same JSON line ("extra"):
 ILUT(10, 1e-4) on the random diagonally dominant matrix with n = 1e6, ICholT(0, 0) on the 256^3 matrix
@@ -229,6 +230,17 @@ def extra_config(name, dev, steps):
         prm.threshold = 1e-3
         make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
         what = "C5: ILUppPreconditioner(default_configuration(1): NORMALIZE_COLUMNS+NORMALIZE_ROWS+PQ_ORDERING, preset 10 without pivoting, threshold=1e-3), random unsymmetric CSR n=1e6"
+    elif name == "C5L":
+        # a matrix whose diagonal is too weak for one level: the PQ ordering keeps a part of the rows per level and the rest goes on as a
+        # Schur complement -- the object the driver sees has several levels (construct = every level's ordering + factorisation + Schur rows;
+        # apply = the recursion of preconditioner_implementation.h:433-488 over all of them)
+        import ilupp_amd as ilupp
+        d, i, p = matgen.random_dd(1000000, 3, 0.6, 12345)
+        prm = ilupp.iluplusplus_precond_parameter()
+        prm.default_configuration(1)
+        prm.threshold = 0.3
+        make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
+        what = "C5L: ILUppPreconditioner(default_configuration(1), threshold=0.3), random unsymmetric CSR n=1e6 with a weak diagonal (0.6): a multi-level object"
     elif name in ("S27", "S9"):
         # ILU(0) beyond the 7-point rows of the headline: box stencils (eliminations meet off-diagonal entries)
         dims = (128, 128, 128) if name == "S27" else (2048, 2048)
@@ -259,7 +271,7 @@ def extra_config(name, dev, steps):
         P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
         t = P.timings()
         nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
-        if name in ("C5", "C5M", "C5P"):
+        if name in ("C5", "C5M", "C5P", "C5L"):
             t["numeric_kernel_ms"] = t["kernel_ms"]
             levels = P.levels()
             nnz_out = sum(sum(P.level_sizes(k)[1:]) for k in range(levels))      # both unit diagonals stored, per level
@@ -270,7 +282,7 @@ def extra_config(name, dev, steps):
     nf = 1 if name == "C4" else 2
     fbytes = (12 * nnz + 4 * (n + 1)) + (12 * nnz_out + 4 * (n + 1) * nf)
     sec = float(np.median(walls))
-    more = {"levels": int(levels)} if name in ("C5", "C5M", "C5P") else {}
+    more = {"levels": int(levels)} if name in ("C5", "C5M", "C5P", "C5L") else {}
     return {**more, "workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
             "numeric_kernel_ms": float(np.median(kms)), "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
@@ -286,8 +298,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "C5P", "C5PB", "ILUC", "S27", "S9"],
-                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, C5M, C5P, ILUC)")
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "C5P", "C5PB", "C5L", "ILUC", "S27", "S9"],
+                    help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, C5M, C5L, C5P, C5PB, ILUC)")
     ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, C5, ILUC) and the refactor loop")
     args = ap.parse_args()
 
@@ -561,9 +573,9 @@ def main():
         extra = {}
         cfgs = list(args.config)
         if not args.no_extra and world == 1:
-            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "C5P", "C5PB", "ILUC") if c not in cfgs] + cfgs
+            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "C5L", "C5P", "C5PB", "ILUC") if c not in cfgs] + cfgs
         for cfg in cfgs:
-            if cfg in ("C3", "C4", "C5", "C5M", "C5P", "ILUC", "S27", "S9") and world == 1:
+            if cfg in ("C3", "C4", "C5", "C5M", "C5P", "C5L", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))

@@ -277,6 +277,14 @@ def test_bench_batch_member():
     assert recs[0][3] == hashlib.sha256(Q.apply(np.ones(200000)).tobytes()).hexdigest()
 
 
+def test_bench_multilevel_object():
+    """the matrix of bench.py's "C5L" extra (random rows with a weak diagonal: several levels at n = 10^6) at n = 10^6 itself: levels, every
+    level's arrays and the apply against the oracle -- the object the driver's bench line reports is a real multilevel one"""
+    n = 1000000
+    M = sp.csr_matrix(matgen.random_dd(n, 3, 0.6, 12345), shape=(n, n))
+    assert _against_oracle(M, (0.3, PQ, {})) >= 3
+
+
 def test_degenerate_inputs_against_oracle():
     """a matrix without entries, a 1 x 1 zero, empty rows and columns, an all-zero row with a stored zero: the reference divides by the
     zero norms and carries NaNs and infinities through every level; the engine and the oracle do the same, bit for bit"""
