@@ -399,9 +399,10 @@ void chain_batch_destroy(ChainBatch *b);
 void chain_batch_enter(ChainBatch *b);       // the calling thread is a worker of b from now on ...
 void chain_batch_leave(ChainBatch *b);       // ... until here (it will hand in no more launches)
 // pilucdp.hip: partialILUC as a sequential chain with its working vectors in LDS -- for what the dataflow kernel cannot run (dropping rules
-// that are recurrences over all steps) or runs badly (long working rows: its largest class).  +1: outside the chain kernel's LDS capacity.
+// that are recurrences over all steps) or runs badly (long working rows: its largest class).  +1: outside the chain kernel's capacity (LDS: working
+// rows of 2 048 entries; with mem_ok the chain goes on with its vectors in global memory: 32 768).
 int piluc_chain_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv_out,
-                      DevMat *Anew, int32_t *kterm, float *kernel_ms);
+                      DevMat *Anew, int32_t *kterm, float *kernel_ms, bool mem_ok);
 int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, int32_t bp, int32_t bpr, int32_t epr,
                   DevMat *L, DevMat *U, double **Dinv, DevMat *Anew, int32_t *pc2, int32_t *pr2, float *kernel_ms);
 

@@ -535,11 +535,11 @@ int ml_build(hipStream_t st, const DevMat &A, const MlParams &IP, std::vector<Ml
             // sequential walk can run: the chain kernel (pilucdp.hip: k_piluc_chain); ILUPP_PILUC_CHAIN=1 sends everything there (tests)
             const bool sequential_rules = (IP.pil.rules & (PILUC_DROP_INVERSE | PILUC_DROP_WEIGHTED | PILUC_DROP_WEIGHTED2)) != 0;
             if (sequential_rules || getenv("ILUPP_PILUC_CHAIN")) {
-                rc = piluc_chain_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
+                rc = piluc_chain_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms, sequential_rules || getenv("ILUPP_PILUC_CHAIN_MEM") != nullptr);
                 if (rc == 1) {
                     l.L.release(); l.U.release(); Anext.release();
                     if (sequential_rules) {
-                        set_error("partialILUC with inverse-based / weighted dropping: a working row of more than 2048 entries (the chain kernel's LDS capacity)");
+                        set_error("partialILUC with inverse-based / weighted dropping: a working row of more than 32768 entries (the chain kernel's capacity)");
                         rc = ILUPP_ERR_UNSUPPORTED;
                     } else rc = piluc_level(st, Ak, IP.pil, !in_loop, tau, &l.L, &l.U, &l.D, &Anext, &kterm, kernel_ms);
                 }

@@ -1039,9 +1039,10 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
         L->release(); U->release(); Anew->release();
         if (cls == 4 && !chain_tried && Av.n <= (1 << 18)) {           // (a chain of more steps than that costs tens of seconds before it can find out that a row does not fit)
             // rows too long for the LDS classes: the steps of such a factorisation depend on one another almost one by one, and the largest
-            // class walks them through global-memory slots (700 us per step on the critical path).  The chain kernel walks them in LDS.
+            // class walks them through global-memory slots (700 us per step on the critical path).  The chain kernel walks them in LDS, and from
+            // the step whose vectors outgrow LDS on, in global memory (fill of 88 entries per row, n = 2e4: 5.3 s against 14.8 s in the largest class).
             chain_tried = true;
-            const int rcc = piluc_chain_level(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms);
+            const int rcc = piluc_chain_level(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms, getenv("ILUPP_NO_PILUC_MEM_CHAIN") == nullptr);
             if (rcc != 1) { rc = rcc; break; }
             L->release(); U->release(); Anew->release();
         }

@@ -56,6 +56,7 @@ struct DpArgs {
     int32_t *Sptr, *Sidx; double *Sval; int32_t capS;   // the Schur complement's rows as they come (column indices of this level)
     struct DpRec *zrec, *wrec; int32_t *zlist, *wlist;     // the two working vectors (below)
     double *key; int32_t *cand; unsigned long long *sortk;
+    char *lvmem;       // k_piluc_chain_mem: the working vectors, their tables and the node list (LvMem below), in global memory
 #ifdef DP_PROF
     long long *prof;   // shader-clock ticks per phase of a step, summed over the steps (diagnostic build only)
 #endif
@@ -509,44 +510,60 @@ constexpr int kLvCap = 2048;                    // entries a working vector may 
 constexpr int kLvHash = 4096;                   // slots of its index -> slot table (linear probing, at most half full)
 constexpr int kPnL = 1024;                      // bucket boundaries (pnum) cached in LDS: counts below this
 
+// where a chain's working vectors live.  LvLds: in LDS (the kernels below).  LvMem: the same code on global memory, for the steps of partialILUC
+// whose vectors outgrow LDS (k_piluc_chain_mem) -- the arrays are private to the wave (one CU, one L1: plain accesses are coherent once the stores
+// are acknowledged); only the table's keys are entered with an atomic (which works at L2) and therefore read past L1.
+struct LvLds {
+    static constexpr int cap = kLvCap, hash = kLvHash, hbits = 12, nodes = 4096;
+    static constexpr bool mem = false;
+    static __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+};
+struct LvMem {
+    static constexpr int cap = 32768, hash = 65536, hbits = 16, nodes = 65536;
+    static constexpr bool mem = true;
+    static __device__ __forceinline__ void sync() { __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory"); }
+};
+static_assert((1 << LvLds::hbits) == LvLds::hash && (1 << LvMem::hbits) == LvMem::hash && LvMem::cap <= 65536, "table sizes");
+
 struct LdsVec { int32_t *idx; double *val; int32_t *hkey; unsigned short *hslot; };
 struct LvAcc { LdsVec v; __device__ int idx(int s) const { return v.idx[s]; } __device__ double val(int s) const { return v.val[s]; } };
 
 #define LV_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")        // one wave: LDS operations complete in order; this orders the compiler
 
-__device__ __forceinline__ unsigned lv_hash(int c) { return ((unsigned)c * 0x9E3779B1u) >> 20; }
-__device__ __forceinline__ int lv_find(const LdsVec &v, int c)
+template <class K = LvLds> __device__ __forceinline__ unsigned lv_hash(int c) { return ((unsigned)c * 0x9E3779B1u) >> (32 - K::hbits); }
+template <class K = LvLds> __device__ __forceinline__ int lv_find(const LdsVec &v, int c)
 {
-    unsigned h = lv_hash(c);
+    unsigned h = lv_hash<K>(c);
     for (;;) {
-        const int k = v.hkey[h];
+        int k;
+        if constexpr (K::mem) k = ld_agent_i32(&v.hkey[h]); else k = v.hkey[h];
         if (k == c) return v.hslot[h];
         if (k == -1) return -1;
-        h = (h + 1) & (kLvHash - 1);
+        h = (h + 1) & (K::hash - 1);
     }
 }
 // c is not in the table; other lanes may be entering other indices at the same time
-__device__ __forceinline__ void lv_enter(const LdsVec &v, int c, int slot)
+template <class K = LvLds> __device__ __forceinline__ void lv_enter(const LdsVec &v, int c, int slot)
 {
-    unsigned h = lv_hash(c);
+    unsigned h = lv_hash<K>(c);
     for (;;) {
         if (atomicCAS(&v.hkey[h], -1, c) == -1) { v.hslot[h] = (unsigned short)slot; return; }
-        h = (h + 1) & (kLvHash - 1);
+        h = (h + 1) & (K::hash - 1);
     }
 }
-__device__ __forceinline__ void lv_clear(const LdsVec &v, int lane)
+template <class K = LvLds> __device__ __forceinline__ void lv_clear(const LdsVec &v, int lane)
 {
     int4 *t = reinterpret_cast<int4 *>(v.hkey);
-    for (int i = lane; i < kLvHash / 4; i += 64) t[i] = make_int4(-1, -1, -1, -1);
+    for (int i = lane; i < K::hash / 4; i += 64) t[i] = make_int4(-1, -1, -1, -1);
 }
 // v[c] exists afterwards (operator[] inserts a zero); false: no room
-__device__ __forceinline__ bool lv_touch(const LdsVec &v, int &nnz, int c, int lane)
+template <class K = LvLds> __device__ __forceinline__ bool lv_touch(const LdsVec &v, int &nnz, int c, int lane)
 {
-    if (lv_find(v, c) >= 0) return true;
-    if (nnz >= kLvCap) return false;
-    if (lane == 0) { v.idx[nnz] = c; v.val[nnz] = 0.0; lv_enter(v, c, nnz); }
+    if (lv_find<K>(v, c) >= 0) return true;
+    if (nnz >= K::cap) return false;
+    if (lane == 0) { v.idx[nnz] = c; v.val[nnz] = 0.0; lv_enter<K>(v, c, nnz); }
     ++nnz;
-    LV_SYNC();
+    K::sync();
     return true;
 }
 // the row / column `who` of A (entries e0 .. e1 of ai / av) into an empty vector: entries whose index is alive (and is not `dead`), a
@@ -676,7 +693,7 @@ __device__ __forceinline__ bool lv_subtract_pipe(const LdsVec &v, int &nnz, List
 
 // the slots that pass the dropping rule, in insertion order, at most `limit` of them (the largest keys, by the reference's selection);
 // afterwards sortk[0 .. return) = (index << 32 | slot) ascending by index
-__device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, double thr, int limit, double *key, int32_t *cand, unsigned long long *sortk, int lane,
+template <class K = LvLds> __device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, double thr, int limit, double *key, int32_t *cand, unsigned long long *sortk, int lane,
                        int skip = -1)         // skip: an index that is outside the range the candidates are taken from (partialILUC: [k + 1, n))
 {
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -692,26 +709,26 @@ __device__ int lv_take(const LdsVec &v, int nnz, bool single, double weight, dou
         cnt += __popcll(mask);
     }
     int off = 0;
-    LV_SYNC();
+    K::sync();
     if (cnt > limit) {
         if (lane == 0 && limit > 0) select_largest(key, cand, 0, cnt - 1, limit);
         off = cnt - limit;
-        LV_SYNC();
+        K::sync();
     }
     const int nk = cnt - off;
     auto keyof = [&](int i) { const int s = cand[off + i]; return ((unsigned long long)(unsigned)v.idx[s] << 32) | (unsigned)s; };
     if (nk <= 64) {
         const unsigned long long sorted = dp_sort_n(lane < nk ? keyof(lane) : ~0ull, nk, lane);
         if (lane < nk) sortk[lane] = sorted;
-        LV_SYNC();
+        K::sync();
         return nk;
     }
     int N = 64;
     while (N < nk) N *= 2;
     for (int i = lane; i < N; i += 64) sortk[i] = i < nk ? keyof(i) : ~0ull;
-    LV_SYNC();
-    wave_sort_u64<false>(sortk, N, lane);
-    LV_SYNC();
+    K::sync();
+    wave_sort_u64<K::mem>(sortk, N, lane);
+    K::sync();
     return nk;
 }
 
@@ -1037,7 +1054,7 @@ __global__ void __launch_bounds__(64) k_pilucdp_lds_batch(const DpArgs *__restri
 // reference keeps them, because the ORDER in which they name the contributors is the order of the subtractions.  It also serves the
 // dropping rules whose estimates are recurrences over all steps (inverse-based, weighted), which a dataflow kernel cannot run.
 // Aliases of DpArgs: perm = listA, iperm = headA, prow = firstA, iprow = listL, numb = firstL, pnum = listU, nonpiv = firstU.
-constexpr int kPcNodes = 4096;                  // contributors of one step (nodes of one list) kept in LDS for the list update
+// (LvLds::nodes / LvMem::nodes: the contributors of one step -- the nodes of its lists -- kept for the list update)
 
 // The lists after step k (update_triangular_fields, ILUC.hpp:31-63; update_sparse_matrix_fields, :86-101): every node of list k (in `nodes`,
 // in list order) -- for a triangular factor first of all k itself -- advances its `first` and, if it has an entry left, is put at the HEAD
@@ -1090,6 +1107,7 @@ __device__ __forceinline__ PcHead pc_head(const PcNode &n, const double *mval, c
     if (n.h != -1) { t.m = mval[n.fm]; if (n.e0 + lane < n.e1) { t.c = eidx[n.e0 + lane]; t.ev = eval[n.e0 + lane]; } }
     return t;
 }
+template <class K>
 __device__ __forceinline__ bool pc_subtract_walk(const LdsVec &v, int &nnz, int start, const int32_t *list, const int32_t *fmul, const double *mval,
                                                  const int32_t *fent, const int32_t *eptr, const int32_t *eidx, const double *eval, const double *Dinv,
                                                  int32_t *nodes, int base_node, int &nn, int lane)
@@ -1101,7 +1119,7 @@ __device__ __forceinline__ bool pc_subtract_walk(const LdsVec &v, int &nnz, int 
     while (a.h != -1) {
         const PcNode c = pc_node(b.next, list, fmul, fent, eptr, Dinv);
         const PcHead b2 = pc_head(b, mval, eidx, eval, lane);
-        if (base_node + nn >= kPcNodes) return false;
+        if (base_node + nn >= K::nodes) return false;
         if (lane == 0) nodes[base_node + nn] = a.h;
         ++nn;
         const double f = a2.m / a.dinv;
@@ -1111,29 +1129,46 @@ __device__ __forceinline__ bool pc_subtract_walk(const LdsVec &v, int &nnz, int 
             int cc; double ev;
             if (base == a.e0) { cc = a2.c; ev = a2.ev; }
             else { cc = act ? eidx[e] : 0; ev = act ? eval[e] : 0.0; }
-            const int slot = act ? lv_find(v, cc) : -1;
+            const int slot = act ? lv_find<K>(v, cc) : -1;
             const bool isnew = act && slot < 0;
             const unsigned long long mask = __ballot(isnew);
-            if (nnz + __popcll(mask) > kLvCap) return false;
+            if (nnz + __popcll(mask) > K::cap) return false;
             if (act) {
                 const double prod = f * ev;
-                if (isnew) { const int sl = nnz + __popcll(mask & lt); v.idx[sl] = cc; v.val[sl] = 0.0 - prod; lv_enter(v, cc, sl); }
+                if (isnew) { const int sl = nnz + __popcll(mask & lt); v.idx[sl] = cc; v.val[sl] = 0.0 - prod; lv_enter<K>(v, cc, sl); }
                 else v.val[slot] = v.val[slot] - prod;
             }
             nnz += __popcll(mask);
-            LV_SYNC();
+            K::sync();
         }
         a = b; a2 = b2; b = c;
     }
     return true;
 }
 
-__global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
+template <class K>
+__device__ __forceinline__ void pc_chain(const DpArgs &A)
 {
-    __shared__ __attribute__((aligned(16))) int32_t s_zidx[kLvCap], s_widx[kLvCap], s_zh[kLvHash], s_wh[kLvHash], s_cand[kLvCap], s_nodes[kPcNodes];
-    __shared__ __attribute__((aligned(16))) double s_zval[kLvCap], s_wval[kLvCap], s_key[kLvCap];
-    __shared__ __attribute__((aligned(16))) unsigned long long s_sort[kLvCap];
-    __shared__ unsigned short s_zs[kLvHash], s_ws[kLvHash];
+    int32_t *s_zidx, *s_widx, *s_zh, *s_wh, *s_cand, *s_nodes;
+    double *s_zval, *s_wval, *s_key;
+    unsigned long long *s_sort;
+    unsigned short *s_zs, *s_ws;
+    if constexpr (K::mem) {
+        char *q = A.lvmem;
+        auto take = [&q](size_t bytes) { char *r = q; q += (bytes + 15) & ~(size_t)15; return r; };
+        s_zidx = (int32_t *)take(4 * (size_t)K::cap); s_widx = (int32_t *)take(4 * (size_t)K::cap); s_cand = (int32_t *)take(4 * (size_t)K::cap);
+        s_zh = (int32_t *)take(4 * (size_t)K::hash); s_wh = (int32_t *)take(4 * (size_t)K::hash); s_nodes = (int32_t *)take(4 * (size_t)K::nodes);
+        s_zval = (double *)take(8 * (size_t)K::cap); s_wval = (double *)take(8 * (size_t)K::cap); s_key = (double *)take(8 * (size_t)K::cap);
+        s_sort = (unsigned long long *)take(8 * (size_t)K::cap);
+        s_zs = (unsigned short *)take(2 * (size_t)K::hash); s_ws = (unsigned short *)take(2 * (size_t)K::hash);
+    } else {
+        __shared__ __attribute__((aligned(16))) int32_t l_zidx[K::cap], l_widx[K::cap], l_zh[K::hash], l_wh[K::hash], l_cand[K::cap], l_nodes[K::nodes];
+        __shared__ __attribute__((aligned(16))) double l_zval[K::cap], l_wval[K::cap], l_key[K::cap];
+        __shared__ __attribute__((aligned(16))) unsigned long long l_sort[K::cap];
+        __shared__ unsigned short l_zs[K::hash], l_ws[K::hash];
+        s_zidx = l_zidx; s_widx = l_widx; s_zh = l_zh; s_wh = l_wh; s_cand = l_cand; s_nodes = l_nodes;
+        s_zval = l_zval; s_wval = l_wval; s_key = l_key; s_sort = l_sort; s_zs = l_zs; s_ws = l_ws;
+    }
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int n = A.n;
@@ -1151,9 +1186,9 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
         if ((long)pU + row_max > (long)A.capU) PC_STOP(1);
         if ((long)pL + row_max > (long)A.capL) PC_STOP(2);
         if (!eliminate && (long)pS + row_max > (long)A.capS) PC_STOP(3);
-        lv_clear(z, lane); lv_clear(w, lane);
+        lv_clear<K>(z, lane); lv_clear<K>(w, lane);
         int znnz = 0, wnnz = 0;
-        LV_SYNC();
+        K::sync();
         // (2.) :1575-1583: the row of A from its first entry right of the eliminated columns
         {
             const int e0 = firstA[k], e1 = A.Ap[k + 1];
@@ -1165,24 +1200,24 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
                 const double x = act ? A.Av[e] : 0.0;
                 const bool first = act && c != pc;
                 const unsigned long long mask = __ballot(first);
-                if (znnz + __popcll(mask) > kLvCap) PC_STOP(4);
-                if (first) { const int s = znnz + __popcll(mask & lt); z.idx[s] = c; z.val[s] = x; lv_enter(z, c, s); }
+                if (znnz + __popcll(mask) > K::cap) PC_STOP(4);
+                if (first) { const int s = znnz + __popcll(mask & lt); z.idx[s] = c; z.val[s] = x; lv_enter<K>(z, c, s); }
                 znnz += __popcll(mask);
                 const unsigned long long dup = __ballot(act && !first);
                 if (dup) {
-                    LV_SYNC();
+                    K::sync();
                     for (int b = 0; b < 64; ++b)
-                        if ((dup >> b) & 1ull) { const int cb = wv_i32(c, b); const double xb = wv_f64(x, b); if (lane == 0) z.val[lv_find(z, cb)] = xb; LV_SYNC(); }
+                        if ((dup >> b) & 1ull) { const int cb = wv_i32(c, b); const double xb = wv_f64(x, b); if (lane == 0) z.val[lv_find<K>(z, cb)] = xb; K::sync(); }
                 }
             }
-            LV_SYNC();
+            K::sync();
         }
         // (3.) :1589-1602: the rows of U this row has multipliers for, in the order of the list
         int nnL = 0;
-        if (!pc_subtract_walk(z, znnz, listL[k], listL, firstL, A.Lval, firstU, A.Uptr, A.Uidx, A.Uval, A.Dinv, s_nodes, 0, nnL, lane)) PC_STOP(4);
+        if (!pc_subtract_walk<K>(z, znnz, listL[k], listL, firstL, A.Lval, firstU, A.Uptr, A.Uidx, A.Uval, A.Dinv, s_nodes, 0, nnL, lane)) PC_STOP(4);
         // (the reference's z[k] inserts the slot -- in the test below, which it only reaches while eliminating, or in the elimination itself)
-        if (eliminate && !lv_touch(z, znnz, k, lane)) PC_STOP(4);
-        const int kslot = eliminate ? lv_find(z, k) : -1;
+        if (eliminate && !lv_touch<K>(z, znnz, k, lane)) PC_STOP(4);
+        const int kslot = eliminate ? lv_find<K>(z, k) : -1;
         const double zk = eliminate ? z.val[kslot] : 0.0;
         if (eliminate && !A.force_finish && (double)k > A.min_elim_factor * (double)n && A.small_pivot_terminates && fabs(zk) < A.min_pivot) {
             eliminate = false;
@@ -1195,12 +1230,11 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
             pivot = zk;
             dinv = 1.0 / pivot;
             for (int s = lane; s < znnz; s += 64) z.val[s] = z.val[s] * dinv;
-            LV_SYNC();
+            K::sync();
             if (lane == 0) z.val[kslot] = 0.0;
-            LV_SYNC();
+            K::sync();
         }
         double wtdU = 0.0, wtdL = 0.0;
-        if (A.wts) wtdU = dp_accumulate_weights(LvAcc{z}, znnz, A.wts, k, true, lane);            // :1634-1636
         // (8.) :1651-1675: the column of L
         int nnU = 0, nnA = 0;
         if (eliminate) {
@@ -1208,24 +1242,28 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
             for (int h = headA[k]; h != -1;) {
                 const int next = listA[h];
                 const double x = A.Av[firstA[h]];
-                if (nnA >= kLvCap) PC_STOP(4);
+                if (nnA >= K::cap) PC_STOP(4);
                 if (lane == 0) s_cand[nnA] = h;                                  // (s_cand is free until the dropping: the nodes of A's list)
                 ++nnA;
                 if (h > k) {
-                    if (wnnz >= kLvCap) PC_STOP(4);
-                    const int slot = lv_find(w, h);
-                    if (lane == 0) { if (slot < 0) { w.idx[wnnz] = h; w.val[wnnz] = x; lv_enter(w, h, wnnz); } else w.val[slot] = x; }
+                    if (wnnz >= K::cap) PC_STOP(4);
+                    const int slot = lv_find<K>(w, h);
+                    if (lane == 0) { if (slot < 0) { w.idx[wnnz] = h; w.val[wnnz] = x; lv_enter<K>(w, h, wnnz); } else w.val[slot] = x; }
                     if (slot < 0) ++wnnz;
-                    LV_SYNC();
+                    K::sync();
                 }
                 h = next;
             }
-            if (!pc_subtract_walk(w, wnnz, listU[k], listU, firstU, A.Uval, firstL, A.Lptr, A.Lidx, A.Lval, A.Dinv, s_nodes, nnL, nnU, lane)) PC_STOP(4);
+            if (!pc_subtract_walk<K>(w, wnnz, listU[k], listU, firstU, A.Uval, firstL, A.Lptr, A.Lidx, A.Lval, A.Dinv, s_nodes, nnL, nnU, lane)) PC_STOP(4);
             for (int s = lane; s < wnnz; s += 64) w.val[s] = w.val[s] * dinv;       // w.scale(Dinv[k]), :1665
-            LV_SYNC();
+            K::sync();
         }
+        // (status 4 -- a vector or the node list out of room -- leaves the step untouched: every side effect in memory comes after this point,
+        // so that the memory flavour can take the chain over AT this step)
+        if (eliminate && nnL + nnU + nnA > K::nodes) PC_STOP(4);
+        if (A.wts) wtdU = dp_accumulate_weights(LvAcc{z}, znnz, A.wts, k, true, lane);            // :1634-1636 (independent of the column: w)
         if (A.wts && eliminate) {                                                   // :1670-1675 (w may hold row k itself)
-            const int ks = lv_find(w, k);
+            const int ks = lv_find<K>(w, k);
             wtdL = dp_accumulate_weights(LvAcc{w}, wnnz, A.wts + n, k, ks >= 0, lane, ks >= 0 ? fabs(w.val[ks]) : 0.0);
         }
         double invU = 0.0;
@@ -1233,22 +1271,21 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
             invU = dp_inverse_update(LvAcc{z}, znnz, k, k, A.inv, A.inv + n, A.inv + 2 * (size_t)n, A.inv + 3 * (size_t)n, lane);
         // the nodes of A's list move from s_cand to the tail of s_nodes before the dropping takes s_cand
         if (eliminate) {
-            if (nnL + nnU + nnA > kPcNodes) PC_STOP(4);
             for (int i = lane; i < nnA; i += 64) s_nodes[nnL + nnU + i] = s_cand[i];
-            LV_SYNC();
+            K::sync();
         }
         // ---- dropping, :1716-1764 ----
         int nU;
         double n1z = 0.0;
         if (!eliminate) {
             const double norm = sqrt(lv_seq_sum(z, znnz, 1, lane));
-            nU = lv_take(z, znnz, false, 0.0, norm * threshold, A.max_fill, s_key, s_cand, s_sort, lane);
+            nU = lv_take<K>(z, znnz, false, 0.0, norm * threshold, A.max_fill, s_key, s_cand, s_sort, lane);
         } else {
             const double n2z = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(z, znnz, 1, lane)) : 0.0;
             const double n1w = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(w, wnnz, 0, lane) : 0.0;
             n1z = (A.rules & (PILUC_DROP_ERR_PROP | PILUC_DROP_ERR_PROP2)) ? lv_seq_sum(z, znnz, 0, lane) : 0.0;
             const double weightU = dp_weight(A, n2z, n1w, dinv, invU, wtdU);
-            nU = lv_take(z, znnz, true, weightU, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane, k);
+            nU = lv_take<K>(z, znnz, true, weightU, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane, k);
         }
         double dinv_store = dinv;
         if (eliminate) {                                                            // :1769-1792
@@ -1264,7 +1301,7 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
             for (int j = lane; j < nU; j += 64) { const unsigned long long ks = s_sort[j]; A.Sval[q0 + j] = z.val[(int)(unsigned)ks]; A.Sidx[q0 + j] = (int)(ks >> 32); }
             if (lane == 0) { A.Uval[p0] = 1.0; A.Uidx[p0] = k; A.Uptr[k + 1] = p0 + 1; A.Dinv[k] = 1.0; A.Sptr[kA + 1] = q0 + nU; }
         }
-        LV_SYNC();
+        K::sync();
         // (12.) L, :1855-1975
         if (eliminate) {
             double invL = 0.0;
@@ -1272,7 +1309,7 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
                 invL = dp_inverse_update(LvAcc{w}, wnnz, k, k, A.inv + 4 * (size_t)n, A.inv + 5 * (size_t)n, A.inv + 6 * (size_t)n, A.inv + 7 * (size_t)n, lane);
             const double n2w = (A.rules & PILUC_DROP_STANDARD) ? sqrt(lv_seq_sum(w, wnnz, 1, lane)) : 0.0;
             const double weightL = dp_weight(A, n2w, n1z, dinv_store, invL, wtdL);
-            const int nL = lv_take(w, wnnz, true, weightL, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane, k);     // (w may hold row k itself: out of [k + 1, n))
+            const int nL = lv_take<K>(w, wnnz, true, weightL, threshold, A.max_fill - 1, s_key, s_cand, s_sort, lane, k);     // (w may hold row k itself: out of [k + 1, n))
             const int p0 = pL;
             pL += nL + 1;
             for (int j = lane; j < nL; j += 64) { const unsigned long long ks = s_sort[j]; A.Lval[p0 + 1 + j] = w.val[(int)(unsigned)ks]; A.Lidx[p0 + 1 + j] = (int)(ks >> 32); }
@@ -1283,7 +1320,7 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
             if (lane == 0) { A.Lval[p0] = 1.0; A.Lidx[p0] = k; A.Lptr[k + 1] = p0 + 1; }
         }
         __builtin_amdgcn_s_waitcnt(0);                                              // (the new row and column are what the lists are moved along)
-        LV_SYNC();
+        K::sync();
         // :1977-1983: the three lists move on
         if (eliminate) {
             pc_relink(k, false, A.Ap, A.Ai, listA, headA, firstA, s_nodes + nnL + nnU, nnA, lane);
@@ -1291,11 +1328,14 @@ __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A)
         }
         pc_relink(k, true, A.Lptr, A.Lidx, listL, listL, firstL, s_nodes, nnL, lane);
         __builtin_amdgcn_s_waitcnt(0);
-        LV_SYNC();
+        K::sync();
     }
     if (lane == 0) { A.ctrl[0] = 0; A.ctrl[1] = last; A.ctrl[2] = nA; A.ctrl[3] = zero_piv; A.ctrl[4] = eliminate ? 1 : 0; A.ctrl[5] = n; }
 #undef PC_STOP
 }
+__global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A) { pc_chain<LvLds>(A); }
+__global__ void __launch_bounds__(64) k_piluc_chain_mem(DpArgs A) { pc_chain<LvMem>(A); }
+constexpr size_t kLvMemBytes = 3 * 4 * (size_t)LvMem::cap + 2 * 4 * (size_t)LvMem::hash + 4 * (size_t)LvMem::nodes + 4 * 8 * (size_t)LvMem::cap + 2 * 2 * (size_t)LvMem::hash + 256;
 
 // ---- launching the chains of a batch together ----
 struct ChainBatch {
@@ -1510,7 +1550,7 @@ __global__ void k_pc_ones(int32_t n, double *__restrict__ d)
 // partialILUC as a chain (k_piluc_chain): same results as piluc_level (piluc_df.hip).  +1: a working vector or a list outgrew the kernel's
 // LDS capacity -- the caller takes the dataflow kernel's largest class.
 int piluc_chain_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool force_finish, double tau, DevMat *L, DevMat *U, double **Dinv_out,
-                      DevMat *Anew, int32_t *kterm, float *kernel_ms)
+                      DevMat *Anew, int32_t *kterm, float *kernel_ms, bool mem_ok)
 {
     const int32_t n = Arow.n;
     const int64_t nnz = Arow.nnz;
@@ -1592,24 +1632,34 @@ int piluc_chain_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, 
         ILUPP_HIP(hipStreamSynchronize(st));                   // (the host vectors above are done with)
     }
     int32_t ctrl[16] = {0};
+    PoolBlock b_lvmem;
+    bool in_mem = mem_ok && getenv("ILUPP_PILUC_CHAIN_MEM") != nullptr;              // (tests: the memory flavour from the first step)
     for (int launch = 0;; ++launch) {
+        if (in_mem && !a.lvmem) { ILUPP_HIP(b_lvmem.alloc(kLvMemBytes)); a.lvmem = b_lvmem.as<char>(); }
         a.Uidx = SU.idx.as<int32_t>(); a.Uval = SU.val.as<double>(); a.capU = (int32_t)SU.cap;
         a.Lidx = SL.idx.as<int32_t>(); a.Lval = SL.val.as<double>(); a.capL = (int32_t)SL.cap;
         a.Sidx = SS.idx.as<int32_t>(); a.Sval = SS.val.as<double>(); a.capS = (int32_t)SS.cap;
         EventPair ev;
         ILUPP_HIP(ev.create());
         ILUPP_HIP(hipEventRecord(ev.a, st));
-        hipLaunchKernelGGL(k_piluc_chain, dim3(1), dim3(64), 0, st, a);
+        if (in_mem) hipLaunchKernelGGL(k_piluc_chain_mem, dim3(1), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_piluc_chain, dim3(1), dim3(64), 0, st, a);
         ILUPP_HIP(hipEventRecord(ev.b, st));
         ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
         float ms = 0.f;
         ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
         if (kernel_ms) *kernel_ms += ms;
-        if (dbg) fprintf(stderr, "[ilupp] piluc (chain): n %d, launch %d (stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", n, launch, (long long)SU.cap,
-                         (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
+        if (dbg) fprintf(stderr, "[ilupp] piluc (chain%s): n %d, launch %d (stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", in_mem ? ", vectors in memory" : "",
+                         n, launch, (long long)SU.cap, (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
         if (ctrl[0] == 0) break;
-        if (ctrl[0] == 4) return 1;
+        if (ctrl[0] == 4) {
+            // a working vector (or the node list) of this step does not fit: the step is untouched.  The memory flavour takes the chain over at
+            // this step (and keeps it: rows that long do not get shorter); beyond ITS capacity the level is not built
+            if (in_mem || !mem_ok) return 1;
+            in_mem = true;
+            continue;
+        }
         DpStore &S = ctrl[0] == 1 ? SU : ctrl[0] == 2 ? SL : SS;
         const int64_t used = ctrl[0] == 1 ? ctrl[8] : ctrl[0] == 2 ? ctrl[9] : ctrl[10];
         if (S.cap >= 0x7ffffff0ll || (launch > 40 && !getenv("ILUPP_DP_STORE"))) { set_error("partialILUC: the factors of a level outgrow 2^31 entries"); return ILUPP_ERR_MEMORY; }

@@ -277,6 +277,43 @@ def test_bench_batch_member():
     assert recs[0][3] == hashlib.sha256(Q.apply(np.ones(200000)).tobytes()).hexdigest()
 
 
+def test_chain_kernel_with_vectors_in_memory(capfd):
+    """working rows beyond the chain kernel's LDS capacity (2 048 entries): the same kernel body on global memory (k_piluc_chain_mem) takes the
+    chain over AT the step that does not fit.  ILUPP_PILUC_CHAIN_MEM=1 runs it from the first step (fuzz cases, several levels, the rules that
+    are recurrences); then a matrix whose rows do outgrow LDS in the middle of a level, under inverse-based dropping (which has no other path)"""
+    import fuzz_ml
+    os.environ["ILUPP_PILUC_CHAIN"] = "1"
+    os.environ["ILUPP_PILUC_CHAIN_MEM"] = "1"
+    try:
+        for seed in range(40):
+            A, params = fuzz_ml.case(2000 + seed)
+            _against_oracle(A, params)
+        assert _against_oracle(C.weak_random(700, 0.01, 0.3, 7), (0.05, PQ, {})) >= 5
+        M = sp.csr_matrix(matgen.random_dd(3000, k=7, diag=2.0), shape=(3000, 3000))
+        _against_oracle(M, (0.02, PQ, {"USE_WEIGHTED_DROPPING": True}))
+        _against_oracle(M, (0.02, PQ, {"USE_INVERSE_DROPPING": True, "USE_WEIGHTED_DROPPING2": True, "fill_in": 10}))
+    finally:
+        del os.environ["ILUPP_PILUC_CHAIN"]
+        del os.environ["ILUPP_PILUC_CHAIN_MEM"]
+    # (the case of profiles/tools/fuzz_chain.py 7000 8000 that ran into the LDS capacity: its generator, up to that matrix)
+    rng = np.random.default_rng(7000)
+    for it in range(15):
+        n = int(rng.choice([500, 1200, 2500, 4000]))
+        A = (sp.random(n, n, density=float(rng.choice([2.0, 4.0, 8.0])) / n, random_state=rng, format="csr") + sp.eye(n) * float(rng.choice([0.3, 0.6, 1.5]))).tocsr()
+        thr = float(rng.choice([0.02, 0.05, 0.2]))
+        rng.integers(0, 4)
+        if rng.random() < 0.3:
+            rng.choice([3, 10])
+    assert n == 4000 and thr == 0.2
+    capfd.readouterr()
+    os.environ["ILUPP_DEBUG"] = "1"
+    try:
+        assert _against_oracle(A, (0.2, PQ, {"USE_INVERSE_DROPPING": True, "USE_STANDARD_DROPPING": False})) >= 2
+    finally:
+        del os.environ["ILUPP_DEBUG"]
+    assert "vectors in memory" in capfd.readouterr().err           # (the log of the level that was taken over)
+
+
 def test_bench_multilevel_object():
     """the matrix of bench.py's "C5L" extra (random rows with a weak diagonal: several levels at n = 10^6) at n = 10^6 itself: levels, every
     level's arrays and the apply against the oracle -- the object the driver's bench line reports is a real multilevel one"""
