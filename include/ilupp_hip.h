@@ -173,7 +173,7 @@ int ilupp_hip_factor_device_ptrs(const ilupp_precond *p, int which, const double
  *     of data-dependent steps walked by one wave; many matrices at once: ilupp_hip_ml_create_batch;
  * dropping by the combined weight of the standard / error-propagation / pivot rules, the inverse-based rule (ILUPP_DROP_INVERSE;
  * precon_parameter 1, 11) and the weighted rule (ILUPP_DROP_WEIGHTED / _WEIGHTED2; precon_parameter 2, 12) -- with the last two, whose
- * estimates are recurrences over all steps, the factorisation without pivoting runs as a chain as well (working rows up to 2048 entries);
+ * estimates are recurrences over all steps, the factorisation without pivoting runs as a chain as well (working rows up to 2048 entries in LDS, up to 32768 in global memory);
  * unbounded or bounded fill; levels ended by small pivots or by the fill of L (FINAL_ROW_CRIT -1 .. 9); preprocessing steps
  * NORMALIZE_COLUMNS, NORMALIZE_ROWS, PQ_ORDERING, MAX_WEIGHTED_MATCHING_ORDERING, UNIT_OR_ZERO_DIAGONAL_SCALING, SPARSE_FIRST_ORDERING,
  * DD_SYMM_MOVE_CORNER_ORDERING_IM, SYMM_PQ (sparse_implementation.h:5214-5460) in any sequence of at most 8.  Every other parameter

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """More seeds for the chain form of partialILUC (k_piluc_chain) and the rules that only run there (inverse-based, weighted dropping):
-tests/fuzz_ml.py's cases FROM..TO, each built twice -- as dispatched, and with ILUPP_PILUC_CHAIN=1 -- and compared with the oracle array by
-array; then larger random matrices (n = 500 .. 4000, weak diagonals: several levels, working rows of hundreds of entries).
+tests/fuzz_ml.py's cases FROM..TO, each built three times -- as dispatched, with ILUPP_PILUC_CHAIN=1 (the chain in LDS), and with
+ILUPP_PILUC_CHAIN_MEM=1 on top (the chain with its vectors in global memory) -- and compared with the oracle array by array; then larger random matrices (n = 500 .. 4000, weak diagonals: several levels, working rows of hundreds of entries).
 usage (GPU box): fuzz_chain.py FROM TO"""
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,18 +13,21 @@ import test_gpu_ml as T
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 t0 = time.time()
-for chain in (False, True):
+for chain in (0, 1, 2):
     if chain:
         os.environ["ILUPP_PILUC_CHAIN"] = "1"
+    if chain == 2:
+        os.environ["ILUPP_PILUC_CHAIN_MEM"] = "1"
     for seed in range(lo, hi):
         A, params = fuzz_ml.case(seed)
         try:
             T._against_oracle(A, params)
         except Exception as e:       # noqa: BLE001
             bad += 1
-            print("FAIL seed %d chain %s: %r" % (seed, chain, e), flush=True)
+            print("FAIL seed %d flavour %d: %r" % (seed, chain, e), flush=True)
             traceback.print_exc(limit=2)
-print("small cases %d..%d both ways: %d failures, %.0f s" % (lo, hi, bad, time.time() - t0), flush=True)
+os.environ.pop("ILUPP_PILUC_CHAIN_MEM", None)
+print("small cases %d..%d three ways: %d failures, %.0f s" % (lo, hi, bad, time.time() - t0), flush=True)
 rng = np.random.default_rng(lo)
 for it in range(24):
     n = int(rng.choice([500, 1200, 2500, 4000]))
