@@ -1034,6 +1034,17 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
     int gns = 2048;
     long gne = 65536;
     bool chain_tried = getenv("ILUPP_NO_PILUC_CHAIN") != nullptr;
+    const bool chain_off = chain_tried;
+    // what the largest class cannot hold either goes to the chain (vectors in memory where they must: slow, but it has room for rows of 32 768
+    // entries and 65 536 contributors) before it is refused -- matrices of more than 2^18 rows, which do not try the chain first
+    auto last_resort = [&](const char *why) -> int {
+        if (chain_tried || chain_off) { set_error(why); return ILUPP_ERR_UNSUPPORTED; }
+        chain_tried = true;
+        L->release(); U->release(); Anew->release();
+        const int rcc = piluc_chain_level(st, Av, P, force_finish, tau, L, U, Dinv, Anew, kterm, kernel_ms, true);
+        if (rcc == 1) { set_error(why); return ILUPP_ERR_UNSUPPORTED; }
+        return rcc;
+    };
     while (rc == 1 || rc == 2) {
         int which = 0;
         L->release(); U->release(); Anew->release();
@@ -1056,13 +1067,12 @@ int piluc_level(hipStream_t st, const DevMat &Av, const PilucParams &P, bool for
                 //  starts with stores that a "stores too small" is unlikely to send back to the start -- 16 nnz + 8 n entries per factor)
                 if (cls == 4) { const long big = 16 * (long)Av.nnz + 8 * (long)Av.n + 1024; if (store < big) store = big; }
             } else if (records) {
-                set_error("partialILUC: a step is reached by more than 4096 stored entries");
-                rc = ILUPP_ERR_UNSUPPORTED;
+                rc = last_resort("partialILUC: a step is reached by more than 4096 stored entries");
             } else if (which == 13) {                                  // the entries of a working row: at most (contributors) x (row length)
-                if (gne >= (1L << 26)) { set_error("partialILUC: a working row gathers more than 2^26 entries"); rc = ILUPP_ERR_UNSUPPORTED; }
+                if (gne >= (1L << 26)) rc = last_resort("partialILUC: a working row gathers more than 2^26 entries");
                 else gne *= 4;
             } else {                                                   // its slots: at most n + 1
-                if (gns > 2 * (long)Av.n + 2) { set_error("partialILUC: a working row does not fit the largest capacity class"); rc = ILUPP_ERR_UNSUPPORTED; }
+                if (gns > 2 * (long)Av.n + 2) rc = last_resort("partialILUC: a working row does not fit the largest capacity class");
                 else { gns *= 4; if (gne < 8L * gns) gne = 8L * gns; }
             }
         } else if (rc == 2) {
