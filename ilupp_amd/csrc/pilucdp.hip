@@ -1335,6 +1335,8 @@ __device__ __forceinline__ void pc_chain(const DpArgs &A)
 }
 __global__ void __launch_bounds__(64) k_piluc_chain(DpArgs A) { pc_chain<LvLds>(A); }
 __global__ void __launch_bounds__(64) k_piluc_chain_mem(DpArgs A) { pc_chain<LvMem>(A); }
+__global__ void __launch_bounds__(64) k_piluc_chain_batch(const DpArgs *__restrict__ args) { pc_chain<LvLds>(args[blockIdx.x]); }
+__global__ void __launch_bounds__(64) k_piluc_chain_mem_batch(const DpArgs *__restrict__ args) { pc_chain<LvMem>(args[blockIdx.x]); }
 constexpr size_t kLvMemBytes = 3 * 4 * (size_t)LvMem::cap + 2 * 4 * (size_t)LvMem::hash + 4 * (size_t)LvMem::nodes + 4 * 8 * (size_t)LvMem::cap + 2 * 2 * (size_t)LvMem::hash + 256;
 
 // ---- launching the chains of a batch together ----
@@ -1342,7 +1344,7 @@ struct ChainBatch {
     std::mutex mu;
     std::condition_variable cv;
     int live = 0;                                   // workers that may still hand in a launch
-    struct Item { const DpArgs *args; hipEvent_t before; float ms; bool done; int rc; };
+    struct Item { const DpArgs *args; hipEvent_t before; float ms; bool done; int rc; int kind; };
     std::vector<Item *> waiting;
     hipStream_t stream = nullptr;
 };
@@ -1363,15 +1365,24 @@ void chain_batch_destroy(ChainBatch *b)
 }
 void chain_batch_enter(ChainBatch *b) { t_batch = b; }
 
-// (mu held) every live worker waits here: their chains as one launch
+// the kinds of chain a batch combines (the chain with pivoting in LDS; partialILUC in LDS / with its vectors in memory)
+enum { CHAIN_DP_LDS = 0, CHAIN_PC_LDS = 1, CHAIN_PC_MEM = 2, CHAIN_KINDS = 3 };
+
+// (mu held) every live worker waits here: their chains as one launch per kind (all launches in the queue before the one wait)
 static void chain_batch_fire(ChainBatch *b)
 {
     const int cnt = (int)b->waiting.size();
     int rc = ILUPP_OK;
     float ms = 0.f;
     try {
-        std::vector<DpArgs> host((size_t)cnt);
-        for (int i = 0; i < cnt; ++i) host[(size_t)i] = *b->waiting[(size_t)i]->args;
+        // the arguments sorted by kind; `off` = where a kind starts
+        std::vector<DpArgs> host;
+        host.reserve((size_t)cnt);
+        int off[CHAIN_KINDS + 1] = {0};
+        for (int kind = 0; kind < CHAIN_KINDS; ++kind) {
+            for (int i = 0; i < cnt; ++i) if (b->waiting[(size_t)i]->kind == kind) host.push_back(*b->waiting[(size_t)i]->args);
+            off[kind + 1] = (int)host.size();
+        }
         DpArgs *dev = nullptr;
         ILUPP_HIP(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(DpArgs) * (size_t)cnt));
         struct Free { DpArgs *p; ~Free() { (void)hipFree(p); } } guard{dev};
@@ -1380,11 +1391,13 @@ static void chain_batch_fire(ChainBatch *b)
         EventPair ev;
         ILUPP_HIP(ev.create());
         ILUPP_HIP(hipEventRecord(ev.a, b->stream));
-        hipLaunchKernelGGL(k_pilucdp_lds_batch, dim3((unsigned)cnt), dim3(64), 0, b->stream, (const DpArgs *)dev);
+        if (off[1] > off[0]) hipLaunchKernelGGL(k_pilucdp_lds_batch, dim3((unsigned)(off[1] - off[0])), dim3(64), 0, b->stream, (const DpArgs *)(dev + off[0]));
+        if (off[2] > off[1]) hipLaunchKernelGGL(k_piluc_chain_batch, dim3((unsigned)(off[2] - off[1])), dim3(64), 0, b->stream, (const DpArgs *)(dev + off[1]));
+        if (off[3] > off[2]) hipLaunchKernelGGL(k_piluc_chain_mem_batch, dim3((unsigned)(off[3] - off[2])), dim3(64), 0, b->stream, (const DpArgs *)(dev + off[2]));
         ILUPP_HIP(hipEventRecord(ev.b, b->stream));
         ILUPP_HIP(hipStreamSynchronize(b->stream));
         ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
-        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] pilucdp: %d chains in one launch, %.2f ms\n", cnt, ms);
+        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] chains of a batch: %d with pivoting, %d + %d of partialILUC (LDS / memory), %.2f ms\n", off[1] - off[0], off[2] - off[1], off[3] - off[2], ms);
     } catch (const HipError &e) { set_error(std::string("HIP error in the batched chain launch: ") + hipGetErrorString(e.code)); rc = ILUPP_ERR_HIP; }
     for (ChainBatch::Item *it : b->waiting) { it->ms = ms; it->rc = rc; it->done = true; }
     b->waiting.clear();
@@ -1399,22 +1412,24 @@ void chain_batch_leave(ChainBatch *b)
 }
 
 // one chain launch: directly, or together with the other chains of the batch this thread works for
-static int chain_launch(hipStream_t st, const DpArgs &a, bool in_lds, float *ms)
+static int chain_launch(hipStream_t st, const DpArgs &a, int kind, float *ms)         // kind: CHAIN_*, or -1: the chain with pivoting on global memory (never combined)
 {
     ChainBatch *b = t_batch;
     *ms = 0.f;
-    if (!b || !in_lds) {
+    if (!b || kind < 0) {
         EventPair ev;
         ILUPP_HIP(ev.create());
         ILUPP_HIP(hipEventRecord(ev.a, st));
-        if (in_lds) hipLaunchKernelGGL(k_pilucdp_lds, dim3(1), dim3(64), 0, st, a);
+        if (kind == CHAIN_DP_LDS) hipLaunchKernelGGL(k_pilucdp_lds, dim3(1), dim3(64), 0, st, a);
+        else if (kind == CHAIN_PC_LDS) hipLaunchKernelGGL(k_piluc_chain, dim3(1), dim3(64), 0, st, a);
+        else if (kind == CHAIN_PC_MEM) hipLaunchKernelGGL(k_piluc_chain_mem, dim3(1), dim3(64), 0, st, a);
         else hipLaunchKernelGGL(k_pilucdp, dim3(1), dim3(64), 0, st, a);
         ILUPP_HIP(hipEventRecord(ev.b, st));
         ILUPP_HIP(hipStreamSynchronize(st));
         ILUPP_HIP(hipEventElapsedTime(ms, ev.a, ev.b));
         return ILUPP_OK;
     }
-    ChainBatch::Item it{&a, nullptr, 0.f, false, ILUPP_OK};
+    ChainBatch::Item it{&a, nullptr, 0.f, false, ILUPP_OK, kind};
     ILUPP_HIP(hipEventCreateWithFlags(&it.before, hipEventDisableTiming));
     struct DropEvent { hipEvent_t e; ~DropEvent() { (void)hipEventDestroy(e); } } drop{it.before};
     ILUPP_HIP(hipEventRecord(it.before, st));                  // (what this thread queued for the chain: initialisation, enlarged stores)
@@ -1639,16 +1654,10 @@ int piluc_chain_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, 
         a.Uidx = SU.idx.as<int32_t>(); a.Uval = SU.val.as<double>(); a.capU = (int32_t)SU.cap;
         a.Lidx = SL.idx.as<int32_t>(); a.Lval = SL.val.as<double>(); a.capL = (int32_t)SL.cap;
         a.Sidx = SS.idx.as<int32_t>(); a.Sval = SS.val.as<double>(); a.capS = (int32_t)SS.cap;
-        EventPair ev;
-        ILUPP_HIP(ev.create());
-        ILUPP_HIP(hipEventRecord(ev.a, st));
-        if (in_mem) hipLaunchKernelGGL(k_piluc_chain_mem, dim3(1), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(k_piluc_chain, dim3(1), dim3(64), 0, st, a);
-        ILUPP_HIP(hipEventRecord(ev.b, st));
+        float ms = 0.f;
+        { const int rc = chain_launch(st, a, in_mem ? CHAIN_PC_MEM : CHAIN_PC_LDS, &ms); if (rc) return rc; }      // (alone, or with the other chains of a batch)
         ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
-        float ms = 0.f;
-        ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
         if (kernel_ms) *kernel_ms += ms;
         if (dbg) fprintf(stderr, "[ilupp] piluc (chain%s): n %d, launch %d (stores of %lld / %lld / %lld): status %d at step %d, %.2f ms\n", in_mem ? ", vectors in memory" : "",
                          n, launch, (long long)SU.cap, (long long)SL.cap, (long long)SS.cap, ctrl[0], ctrl[5], ms);
@@ -1794,7 +1803,7 @@ int pilucdp_level(hipStream_t st, const DevMat &Arow, const PilucParams &P, bool
         a.Lidx = SL.idx.as<int32_t>(); a.linkL = SL.link.as<int32_t>(); a.colL = SL.who.as<int32_t>(); a.Lval = SL.val.as<double>(); a.capL = (int32_t)SL.cap;
         a.Sidx = SS.idx.as<int32_t>(); a.Sval = SS.val.as<double>(); a.capS = (int32_t)SS.cap;
         float ms = 0.f;
-        { const int rc = chain_launch(st, a, in_lds, &ms); if (rc) return rc; }
+        { const int rc = chain_launch(st, a, in_lds ? CHAIN_DP_LDS : -1, &ms); if (rc) return rc; }
         ILUPP_HIP(hipMemcpyAsync(ctrl, a.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
         if (kernel_ms) *kernel_ms += ms;

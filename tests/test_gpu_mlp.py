@@ -281,7 +281,7 @@ def test_batched_construction_is_the_same_objects_and_runs_side_by_side():
     import time
     import ilupp_amd as ilupp
     mats = [sp.csr_matrix(matgen.random_dd(n, 8, 25.0, 100 + k), shape=(n, n)) for k, n in enumerate([3000, 2500, 4000, 3000, 1200, 3500])]
-    for cfg in (None, 10, 1):
+    for cfg in (None, 10, 1, 11):                       # (11: inverse-based dropping -- partialILUC as a chain, combined like the chains with pivoting)
         p = ilupp.iluplusplus_precond_parameter()
         if cfg is not None:
             p.default_configuration(cfg)
@@ -314,4 +314,13 @@ def test_batched_construction_is_the_same_objects_and_runs_side_by_side():
     t0 = time.perf_counter(); one = ilupp.ILUppPreconditioner(big[0], params=p); t_one = time.perf_counter() - t0
     t0 = time.perf_counter(); B = ilupp.ILUppPreconditioner.batch(big, params=p); t_batch = time.perf_counter() - t0
     assert B[0].total_nnz == one.total_nnz and np.array_equal(B[0] @ C.rhs(20000), one @ C.rhs(20000))
+    assert t_batch < 4.0 * t_one, (t_batch, t_one)
+    # ... and so do 16 chains of the factorisation WITHOUT pivoting under inverse-based dropping (default_configuration(11))
+    p = ilupp.iluplusplus_precond_parameter()
+    p.default_configuration(11)
+    p.threshold = 1e-3
+    ilupp.ILUppPreconditioner(big[0], params=p)
+    t0 = time.perf_counter(); one = ilupp.ILUppPreconditioner(big[0], params=p); t_one = time.perf_counter() - t0
+    t0 = time.perf_counter(); B = ilupp.ILUppPreconditioner.batch(big, params=p); t_batch = time.perf_counter() - t0
+    assert B[5].total_nnz == ilupp.ILUppPreconditioner(big[5], params=p).total_nnz and np.array_equal(B[0] @ C.rhs(20000), one @ C.rhs(20000))
     assert t_batch < 4.0 * t_one, (t_batch, t_one)
