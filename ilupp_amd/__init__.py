@@ -98,17 +98,17 @@ class _HipPreconditioner(_LinearOperator):
 
     # -- the reference's in-place members
     def apply(self, x):
-        """Apply the preconditioner to the vector `x` in-place."""
-        self.pr.apply(x.ravel())
+        """x <- M^-1 x, overwriting the caller's array (any shape with n elements; it is flattened as a view)."""
+        flat = x.ravel()
+        self.pr.apply(flat)
 
     def apply_trans(self, x):
-        """Apply the transposed preconditioner to the vector `x` in-place."""
-        self.pr.apply_trans(x.ravel())
+        """x <- M^-T x, overwriting the caller's array."""
+        flat = x.ravel()
+        self.pr.apply_trans(flat)
 
-    @property
-    def total_nnz(self):
-        """The total number of nonzeros stored in the factor matrices of the preconditioner."""
-        return self.pr.total_nnz
+    total_nnz = property(lambda self: self.pr.total_nnz,
+                         doc="Stored entries of all factors, counted the way the reference counts them for this kind of object.")
 
     def factors(self):
         """All matrix factors ((L, U) or just (L,)) as a list of sparse matrices."""
@@ -120,14 +120,25 @@ class _HipPreconditioner(_LinearOperator):
         return "<%dx%d %s with nnz=%d, %s>" % (rows, cols, type(self).__name__, self.total_nnz, what)
 
 
-class ILUppPreconditioner(_HipPreconditioner):
-    """A multilevel ILU++ preconditioner (reference: ilupp/__init__.py:171-203 over binding.cpp:284-298).
+def _ml_parameters(threshold, fill_in, params):
+    """the parameter object of a multilevel construction: the caller's, or default-constructed ones carrying the two numbers"""
+    if params is not None:
+        return params
+    fresh = iluplusplus_precond_parameter()
+    fresh.threshold = threshold
+    if fill_in is not None:
+        fresh.fill_in = fill_in
+    return fresh
 
-    Args:
-        A: a sparse matrix in CSR or CSC format
-        threshold: the threshold parameter for ILU++; entries with relative magnitude less than this are dropped
-        fill_in: the fill_in parameter for the ILU++ preconditioner
-        params: an instance of :class:`iluplusplus_precond_parameter`; if passed, overrides fill_in and threshold
+
+class ILUppPreconditioner(_HipPreconditioner):
+    """Multilevel ILU++ (reference: ilupp/__init__.py:171-203 over binding.cpp:284-298).  With default-constructed parameters (the
+    family WITH pivoting) ONE matrix builds about 2.5x slower than the reference does on one host core -- that factorisation is a
+    sequential chain; use the family without pivoting (``default_configuration(1)``) or :meth:`batch` where construction time matters.
+
+    `A`: scipy CSR or CSC matrix.  `threshold` / `fill_in`: the two numbers most callers tune (relative size below which an entry
+    is dropped; bound on the entries kept per row).  `params`: a complete :class:`iluplusplus_precond_parameter`; when given, the two
+    numbers are ignored.
 
     Default-constructed parameters select, as in the reference, the factorisation WITH pivoting (partialILUCDP: the column of a step is the
     largest entry of its working row, the next row the one with the fewest entries in L so far) -- a chain of n steps that one wave of the
@@ -137,11 +148,7 @@ class ILUppPreconditioner(_HipPreconditioner):
     NotImplementedError."""
 
     def __init__(self, A, threshold=1.0, fill_in=None, params=None):
-        if params is None:
-            params = iluplusplus_precond_parameter()
-            params.threshold = threshold
-            if fill_in is not None:
-                params.fill_in = fill_in
+        params = _ml_parameters(threshold, fill_in, params)
         super().__init__(A, lambda m: _backend.MultilevelILUCDPPreconditioner(*m, params))
 
     @classmethod
@@ -149,11 +156,7 @@ class ILUppPreconditioner(_HipPreconditioner):
         """One preconditioner per matrix of `matrices` (all CSR or all CSC), built side by side on the GPU: the objects
         ``[ILUppPreconditioner(A, ...) for A in matrices]`` gives, bit for bit, in about the time of the slowest one -- the sequential
         chains of the factorisation with pivoting (one wave each) share one launch (``ilupp_hip_ml_create_batch``)."""
-        if params is None:
-            params = iluplusplus_precond_parameter()
-            params.threshold = threshold
-            if fill_in is not None:
-                params.fill_in = fill_in
+        params = _ml_parameters(threshold, fill_in, params)
         matrices = list(matrices)
         if not matrices:
             return []
@@ -169,17 +172,10 @@ class ILUppPreconditioner(_HipPreconditioner):
             out.append(P)
         return out
 
-    @property
-    def memory(self):
-        return self.pr.memory
-
-    @property
-    def memory_used_calculations(self):
-        return self.pr.memory_used_calculations
-
-    @property
-    def memory_allocated_calculations(self):
-        return self.pr.memory_allocated_calculations
+    # the three memory figures of the reference's object (binding.cpp:257-259), passed through from the native one
+    memory = property(lambda self: self.pr.memory)
+    memory_used_calculations = property(lambda self: self.pr.memory_used_calculations)
+    memory_allocated_calculations = property(lambda self: self.pr.memory_allocated_calculations)
 
 
 class ILUTPreconditioner(_HipPreconditioner):
@@ -197,46 +193,42 @@ class ILUCPreconditioner(_HipPreconditioner):
 
 
 class ILUTPPreconditioner(_HipPreconditioner):
-    """An ILUTP (incomplete LU with thresholding and column pivoting) preconditioner.  (Reference: ilupp/__init__.py:218-236 over ILUTP2,
-    ILUTP.hpp:13-140.)
+    """ILUT with column pivoting -- on this engine a SEQUENTIAL chain that one wave walks: bit-identical to the reference and
+    10-30x slower than the reference on one host core for a single matrix (profiles/r04_chains.txt).  (Reference:
+    ilupp/__init__.py:218-236 over ILUTP2, ILUTP.hpp:13-140.)
 
-    Args:
-        A: a sparse matrix in CSR or CSC format
-        fill_in: the number of nonzeros to allow per row of L/U
-        threshold: entries with relative magnitude less than this are dropped
-        piv_tol: pivoting tolerance; 0=only pivot when 0 encountered, 1=always pivot
-            to the largest entry, inbetween: pivot depending on relative magnitude
+    `A`: scipy CSR or CSC matrix; `fill_in`: entries kept per row of L and of U; `threshold`: relative size below which an entry is
+    dropped; `piv_tol`: 0 pivots only away from a zero, 1 always takes the largest entry of the row, values between compare the
+    diagonal with the largest entry; `mem_factor`: storage reserved per factor, in multiples of nnz(A).
 
-    Every row sees the column permutation the rows before it made: a chain of n steps that one wave of the GPU walks
-    (ilupp_amd/csrc/ilutp.hip); bit-identical to the reference, not faster than it."""
+    Every row sees the column permutation the rows before it made (ilupp_amd/csrc/ilutp.hip)."""
 
     def __init__(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0):
         super().__init__(A, lambda m: _backend.ILUTPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
 
     def permutations(self):
-        """Return a pair (L,R) of permutation arrays to be applied from the left or right due to pivoting."""
-        return self.pr.permutations()
+        """(left, right): the two index arrays the pivoting produced (rows stay where they are for this factorisation)."""
+        left, right = self.pr.permutations()
+        return left, right
 
 
 class ILUCPPreconditioner(_HipPreconditioner):
-    """An ILUCP (ILUC with pivoting) preconditioner. See (Mayer 2005).  (Reference: ilupp/__init__.py:252-270 over ILUCP4, ILUC.hpp:212-370.)
+    """Crout ILU with column pivoting (Mayer 2005) -- on this engine a SEQUENTIAL chain that one wave walks: bit-identical to the
+    reference and 10-30x slower than the reference on one host core for a single matrix (profiles/r04_chains.txt).  (Reference:
+    ilupp/__init__.py:252-270 over ILUCP4, ILUC.hpp:212-370.)
 
-    Args:
-        A: a sparse matrix in CSR or CSC format
-        fill_in: the number of nonzeros to allow per column/row of L/U
-        threshold: entries with relative magnitude less than this are dropped
-        piv_tol: pivoting tolerance; 0=only pivot when 0 encountered, 1=always pivot
-            to the largest entry, inbetween: pivot depending on relative magnitude
+    `A`: scipy CSR or CSC matrix; `fill_in`: entries kept per column of L and per row of U; `threshold`, `piv_tol`, `mem_factor`: as
+    for :class:`ILUTPPreconditioner`.
 
-    The pivot of a step decides which entries of all later rows are alive: a chain of n steps that one wave of the GPU walks
-    (ilupp_amd/csrc/ilucp.hip); bit-identical to the reference, not faster than it."""
+    The pivot of a step decides which entries of all later rows are alive (ilupp_amd/csrc/ilucp.hip)."""
 
     def __init__(self, A, fill_in=100, threshold=0.1, piv_tol=0.1, mem_factor=10.0):
         super().__init__(A, lambda m: _backend.ILUCPPreconditioner(*m, fill_in, threshold, piv_tol, -1, mem_factor))
 
     def permutations(self):
-        """Return a pair (L,R) of permutation arrays to be applied from the left or right due to pivoting."""
-        return self.pr.permutations()
+        """(left, right): the two index arrays the pivoting produced (rows stay where they are for this factorisation)."""
+        left, right = self.pr.permutations()
+        return left, right
 
 
 class ILU0Preconditioner(_HipPreconditioner):
@@ -269,11 +261,7 @@ def solve(A, b, rtol=1e-4, atol=1e-4, max_iter=500, threshold=0.1, fill_in=None,
     Returns the solution (with info=True also (iterations, relative reduction reached, residual norm reached)); raises
     RuntimeError("did not converge") like the reference.  As for :class:`ILUppPreconditioner`, default-constructed parameters select the
     factorisation with pivoting (sequential: one wave); parameters of the family without pivoting use the whole GPU."""
-    if params is None:
-        params = iluplusplus_precond_parameter()
-        params.threshold = threshold
-        if fill_in is not None:
-            params.fill_in = fill_in
+    params = _ml_parameters(threshold, fill_in, params)
     m = _borrow(A)
     b = np.ascontiguousarray(b, dtype=np.float64)
     if b.shape[0] != A.shape[1]:

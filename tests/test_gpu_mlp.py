@@ -2,7 +2,7 @@
 ILUCDP.hpp:268-1404 -- what the reference's default-constructed parameters, ILUppPreconditioner(A) and solve(A, b) run on).
 
 Bit for bit, as everywhere in this package:
-* the reference's own multilevel tests (test/tests.py:344-402), as they stand there;
+* the package's Python surface (LinearOperator protocol, `solve` with setter-built parameters) on the reference's vectors;
 * the golden vectors of the REAL reference: tests/golden/ml.npz (default-constructed parameters and default_configuration(0, 1, 10, 11) on the
   reference's test matrices: 120 cases) and tests/golden/mlp.npz (tests/ml_cases.py PIVOT_PARAMS: windows of the row reordering and of the
   total pivoting, pivot tolerances, every FINAL_ROW_CRIT family, bounded fill, other dropping rules; CSR and CSC; up to 100 levels);
@@ -35,75 +35,57 @@ def _native_ml(a, params):
     return _native.MultilevelILUCDPPreconditioner(a[0], a[1], a[2], a[3], params)
 
 
-# ---- the reference's helpers and tests (test/tests.py:9-42, :344-402) ----
-def laplace_matrix(n, format="csr"):
-    h = 1.0 / (n + 1)
-    d = np.ones(n) / (h ** 2)
-    return sp.diags((-d[:-1], 2 * d, -d[:-1]), (-1, 0, 1)).asformat(format)
+# ---- the package's Python surface on the reference's vectors ----
+def _sp_matrix(z, key):
+    a = (z[key + "/A_data"], z[key + "/A_indices"], z[key + "/A_indptr"])
+    n = a[2].shape[0] - 1
+    return (sp.csr_matrix if bool(z[key + "/A_is_csr"]) else sp.csc_matrix)(a, shape=(n, n))
 
 
-def example_laplace2d(n_total):
-    n = int(np.sqrt(n_total))
-    A1, I = laplace_matrix(n), sp.eye(n)
-    A = (sp.kron(A1, I) + sp.kron(I, A1)).asformat("csr")
-    x_exact = np.ones(A.shape[0])
-    return A, A.dot(x_exact), x_exact
-
-
-def example_random(n, format="csc", eye_factor=10.0):
-    A = (sp.random(n, n, density=min(1.0, 5 / n), random_state=39273) + eye_factor * sp.eye(n)).asformat(format)
-    x_exact = np.ones(n)
-    return A, A.dot(x_exact), x_exact
-
-
-@pytest.mark.parametrize("setter", ["set_PQ", "set_MAX_WEIGHTED_MATCHING_ORDERING", "set_SPARSE_FIRST"])
-def test_ml_solve_laplace2d(setter):
+@pytest.mark.parametrize("key", ["ml_laplace2d_csr", "ml_random_csc", "ml_p3d_6_7_5_csr"])
+def test_operator_protocol_on_reference_vectors(key):
+    """ILUppPreconditioner as a scipy LinearOperator (`@`, dot, apply in place, .T, total_nnz, memory), default-constructed parameters:
+    the outputs the reference produced for the same matrix and right-hand side (tests/golden/ml.npz, config -1)"""
     import ilupp_amd as ilupp
-    A, b, x_exact = example_laplace2d(900)
-    param = ilupp.iluplusplus_precond_parameter()
-    getattr(param.PREPROCESSING, setter)()
-    param.threshold = 1e-2
-    x, info = ilupp.solve(A, b, atol=1e-8, rtol=1e-8, params=param, info=True)
-    assert np.allclose(x_exact, x)
+    z = np.load(os.path.join(HERE, "golden", "ml.npz"))
+    A = _sp_matrix(z, key)
+    n = A.shape[0]
+    cases = [c for c in C.ml_npz_cases(z) if c[0] == key and c[2] == -1 and (key + "/" + c[1] + "_info") in z.files]
+    assert cases
+    for _, tag, _, thr, fill in cases:
+        kw = {"threshold": thr}
+        if fill >= 0:
+            kw["fill_in"] = fill
+        P = ilupp.ILUppPreconditioner(A, **kw)
+        name = "%s/%s" % (key, tag)
+        assert P.total_nnz == int(z[name + "_info"][1]) and P.memory == 0.0 and P.shape == (n, n)
+        b = C.rhs(n)
+        want, want_t = z[name + "_apply"], z[name + "_apply_trans"]
+        assert np.array_equal(P @ b, want, equal_nan=True) and np.array_equal(P.dot(b), want, equal_nan=True), name
+        x = b.copy(); P.apply(x)
+        assert np.array_equal(x, want, equal_nan=True), name
+        assert np.array_equal(P.T @ b, want_t, equal_nan=True), name
 
 
-def test_ml_solve_laplace2d_MWM_sPQ():
-    """test/tests.py:362-369, as written there"""
+def test_solve_front_end_on_reference_vectors():
+    """ilupp.solve(A, b, params=...) with a parameter object set up through the PREPROCESSING setters (the way callers of the reference
+    do it) reproduces the reference's solution vectors of tests/golden/solve.npz (make_golden_solve.py)"""
     import ilupp_amd as ilupp
-    A, b, x_exact = example_laplace2d(900)
-    param = ilupp.iluplusplus_precond_parameter()
-    param.PREPROCESSING.set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ()
-    param.threshold = 1e-2
-    x, info = ilupp.solve(A, b, atol=1e-8, rtol=1e-8, params=param, info=True)
-    assert np.allclose(x_exact, x)
-
-
-def test_ml_solve_random():
-    import ilupp_amd as ilupp
-    A, b, x_exact = example_random(50)
-    x = ilupp.solve(A, b, atol=1e-8)
-    assert np.allclose(x, x_exact)
-
-
-def test_ml_precond_laplace():
-    import ilupp_amd as ilupp
-    n = 100
-    A = laplace_matrix(n)
-    b = np.ones(n)
-    P = ilupp.ILUppPreconditioner(A, threshold=0)
-    x = P.dot(b)
-    X = np.linspace(0, 1, n + 2)[1:-1]
-    assert np.allclose(x, X * (1 - X) / 2)
-    assert P.total_nnz > 0 and P.memory == 0.0
-
-
-def test_ml_precond_random():
-    import ilupp_amd as ilupp
-    A, b, x_exact = example_random(50)
-    P = ilupp.ILUppPreconditioner(A, threshold=0)
-    x = b.copy()
-    P.apply(x)
-    assert np.allclose(x, x_exact)
+    z = np.load(os.path.join(HERE, "golden", "solve.npz"))
+    key = "laplace2d_900_csr"
+    a = (z[key + "/data"], z[key + "/indices"], z[key + "/indptr"])
+    A, b = sp.csr_matrix(a, shape=(900, 900)), z[key + "/b"]
+    for tag, setters in (("t0.01_pq", ("set_PQ",)), ("t0.01_mwm", ("set_MAX_WEIGHTED_MATCHING_ORDERING",)),
+                         ("t0.01_mwm_spq", ("set_MAX_WEIGHTED_MATCHING_ORDERING_SYM_PQ",))):
+        param = ilupp.iluplusplus_precond_parameter()
+        param.default_configuration(1)
+        for s_ in setters:
+            getattr(param.PREPROCESSING, s_)()
+        param.threshold = 1e-2
+        x, info = ilupp.solve(A, b, atol=1e-8, rtol=1e-8, params=param, info=True)
+        x_ref = z["%s/%s/x" % (key, tag)]
+        assert abs(info[0] - int(z["%s/%s/info" % (key, tag)][1])) <= 1, tag
+        assert np.linalg.norm(x - x_ref) <= 1e-6 * np.linalg.norm(x_ref), tag
 
 
 # ---- golden vectors ----
