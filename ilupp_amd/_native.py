@@ -89,6 +89,8 @@ def lib():
     L.ilupp_hip_spmv_device.argtypes = [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP, _VP, _VP]
     L.ilupp_hip_path.argtypes = [_VP]
     L.ilupp_hip_path.restype = ctypes.c_char_p
+    L.ilupp_hip_analysis_path.argtypes = [_VP]
+    L.ilupp_hip_analysis_path.restype = ctypes.c_char_p
     L.ilupp_hip_kernel_names.argtypes = [_VP]
     L.ilupp_hip_kernel_names.restype = ctypes.c_char_p
     L.ilupp_hip_destroy.argtypes = [_VP]
@@ -170,7 +172,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_num_factors", "ilupp_hip_factor_info", "ilupp_hip_factor_copy",
     "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
     "ilupp_hip_sync", "ilupp_hip_release_cached_memory", "ilupp_hip_set_cache_limit", "ilupp_hip_cached_bytes", "ilupp_hip_live_blocks", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
-    "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_kernel_names", "ilupp_hip_spmv_device",
+    "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_analysis_path", "ilupp_hip_kernel_names", "ilupp_hip_spmv_device",
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
     "ilupp_hip_ml_default_params", "ilupp_hip_ml_create", "ilupp_hip_ml_create_device", "ilupp_hip_ml_destroy", "ilupp_hip_ml_apply",
     "ilupp_hip_ml_apply_device", "ilupp_hip_ml_apply_part_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",
@@ -330,6 +332,10 @@ class Preconditioner:
     def path(self):
         """which kernel family built this object (measurement hook)"""
         return lib().ilupp_hip_path(self._h).decode()
+
+    def analysis_path(self):
+        """ILU(0): "grid" when the row blocks came from the box-grid guess (proven row by row), else "general" (measurement hook)"""
+        return lib().ilupp_hip_analysis_path(self._h).decode()
 
     def kernel_names(self):
         """(factor kernel, forward sweep, backward sweep) of a static ILU(0) object, else () (measurement hook)"""

@@ -132,6 +132,34 @@ static int32_t read_device_nnz(const int32_t *d_indptr, int32_t n)
     return v;
 }
 
+// indptr[n] plus {indptr[0], indptr[1], indices[0..7]} (-1 where the matrix has no such entry) with ONE read-back
+__global__ void k_read_head(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t n, int32_t *__restrict__ out)
+{
+    const int t = threadIdx.x;
+    const int32_t nnz = ptr[n];
+    if (t == 0) out[0] = nnz;
+    if (t == 1) out[1] = ptr[0];
+    if (t == 2) out[2] = ptr[1];
+    if (t >= 3 && t < 11) out[t] = (t - 3 < nnz) ? idx[t - 3] : -1;
+}
+static int32_t read_device_head(const int32_t *d_indptr, const int32_t *d_indices, int32_t n, int32_t *head)
+{
+    static int32_t *stage = nullptr;         // pinned, mapped: the kernel writes where the host reads
+    static int32_t *stage_dev = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!stage) {
+        ILUPP_HIP(hipHostMalloc(reinterpret_cast<void **>(&stage), 64, hipHostMallocMapped | hipHostMallocPortable));
+        ILUPP_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&stage_dev), stage, 0));
+    }
+    hipStream_t s = g_caller_stream_set ? g_caller_stream : nullptr;
+    hipLaunchKernelGGL(k_read_head, dim3(1), dim3(64), 0, s, d_indptr, d_indices, n, stage_dev);
+    ILUPP_HIP(hipGetLastError());
+    ILUPP_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 10; ++i) head[i] = stage[1 + i];
+    return stage[0];
+}
+
 static int report(const HipError &e)
 {
     char buf[512];
@@ -185,16 +213,20 @@ struct ilupp_precond {
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4],[5]: around the factor kernel
     hipEvent_t sev[2] = {nullptr, nullptr};           // ordering against the caller's stream
+    hipStream_t side = nullptr;                       // a second stream for work that runs NEXT to the analysis (grid.hip's proof)
+    hipEvent_t jev[2] = {nullptr, nullptr};           // fork / join of the side stream
     int device = 0;
     ilupp_timings tm = {0, 0, 0, 0, 0, 0};
     bool apply_events_valid = false;
     int max_lanes = 65536;
+    bool grid_path = false;      // ILU(0): the row blocks came from grid.hip's guess (proven for every row)
     bool borrowed_queue = false; // stream and events belong to another object (the levels of a multilevel preconditioner share one)
 };
 
 namespace {
 
-struct QueuePack { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t sev[2] = {nullptr, nullptr}; int device = 0; };
+struct QueuePack { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t sev[2] = {nullptr, nullptr};
+                   hipStream_t side = nullptr; hipEvent_t jev[2] = {nullptr, nullptr}; int device = 0; };
 struct QueuePool { std::mutex mu; std::vector<QueuePack> free_list; } g_queues;
 
 bool schedule_is_compact(const Schedule &s) { return s.B <= 32768 && s.nslots <= kGhostBase; }
@@ -221,6 +253,7 @@ void destroy_obj(ilupp_precond *p)
         QueuePack q; q.stream = p->stream; q.device = p->device;
         for (int k = 0; k < 6; ++k) q.ev[k] = p->ev[k];
         q.sev[0] = p->sev[0]; q.sev[1] = p->sev[1];
+        q.side = p->side; q.jev[0] = p->jev[0]; q.jev[1] = p->jev[1];
         g_queues.free_list.push_back(q);
     }
     delete p;
@@ -238,6 +271,7 @@ ilupp_precond *new_obj(int32_t n)
                 p->stream = g_queues.free_list[k].stream;
                 for (int e = 0; e < 6; ++e) p->ev[e] = g_queues.free_list[k].ev[e];
                 p->sev[0] = g_queues.free_list[k].sev[0]; p->sev[1] = g_queues.free_list[k].sev[1];
+                p->side = g_queues.free_list[k].side; p->jev[0] = g_queues.free_list[k].jev[0]; p->jev[1] = g_queues.free_list[k].jev[1];
                 g_queues.free_list.erase(g_queues.free_list.begin() + (long)k);
                 break;
             }
@@ -246,6 +280,8 @@ ilupp_precond *new_obj(int32_t n)
         ILUPP_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         for (auto &e : p->ev) ILUPP_HIP(hipEventCreate(&e));
         for (auto &e : p->sev) ILUPP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ILUPP_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        for (auto &e : p->jev) ILUPP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     order_after_caller(p->stream, p->sev[0]);        // (the matrix a *_create_device call is about to read)
     ILUPP_HIP(pool_malloc(&p->work, sizeof(double) * (size_t)n));
@@ -297,32 +333,70 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
 }
 
 // ILU(0) of the row-major view held in A (device).  Fills p->Lc/Uc, schedules and timings.
-int ilu0_factor(ilupp_precond *p, const DevMat &A)
+int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
 {
     hipStream_t st = p->stream;
     hipEvent_t a0 = p->ev[0], a1 = p->ev[1], a2 = p->ev[2];
     p->nnzA = A.nnz;
     ILUPP_HIP(hipEventRecord(a0, st));
     int32_t missing = -1;
-    // one pass over A's pattern: row counts of L and U, diagonal check, and the factor-sweep schedules (L shares A's
-    // forward cuts and U its backward cuts: same strictly-lower / strictly-upper patterns)
-    int rc = ilu0_symbolic_and_schedule(st, A, &p->Lc, &p->Uc, &missing, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
-    if (rc == ILUPP_ERR_NO_DIAGONAL) {
-        set_error("ILU0: structurally missing diagonal entry in row " + std::to_string(missing));
-        return rc;
-    }
-    if (rc) return rc;
     const int max_wgs = p->max_lanes / kThreads;
-    choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
-    finish_chains(&p->sA, &p->sU);                 // (the read-back ilu0_symbolic_and_schedule queued came with the tiling's wait)
-    build_slot_tables(st, &p->sA, true);
-    build_slot_tables(st, &p->sU, false);
-    p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
+    int rc = ILUPP_OK;
+    // A matrix whose row 0 and entry count are those of a lexicographic box-grid stencil (grid.hip): the row blocks follow from the
+    // three dimensions, and ONE streaming kernel on the side stream proves the guess for every row while the lane tables are built.
+    GridDims gd = {0, 0, 0};
+    bool grid = head != nullptr && p->side != nullptr && grid_guess(A.n, A.nnz, head, &gd);
+    // where the proof runs: 0 = on the side stream next to the lane-table kernels, 1 = on the object's stream before them, 2 = on the side
+    // stream next to the factor kernel.  Its verdict comes home with the construction's last read-back in every case.
+    static const int grid_mode = []() { const char *e = getenv("ILUPP_GRID_CHECK_AT"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
+    int32_t grid_bad = 0;
+    bool lm = false;
+    for (;;) {
+        if (grid) {
+            ILUPP_HIP(hipMemsetAsync(p->ctrl + 8, 0, sizeof(int32_t), st));
+            if (grid_mode == 0) {
+                ILUPP_HIP(hipEventRecord(p->jev[0], st));
+                ILUPP_HIP(hipStreamWaitEvent(p->side, p->jev[0], 0));
+                grid_check_launch(p->side, A, gd, p->ctrl + 8);
+                ILUPP_HIP(hipEventRecord(p->jev[1], p->side));
+            } else if (grid_mode == 1) {
+                grid_check_launch(st, A, gd, p->ctrl + 8);
+            }
+            grid_schedules(st, A, gd, &p->Lc, &p->Uc, &p->sA, &p->sU, &p->max_row_len, max_wgs);
+        } else {
+            // one pass over A's pattern: row counts of L and U, diagonal check, and the factor-sweep schedules (L shares A's
+            // forward cuts and U its backward cuts: same strictly-lower / strictly-upper patterns)
+            rc = ilu0_symbolic_and_schedule(st, A, &p->Lc, &p->Uc, &missing, p->max_lanes, &p->sA, &p->sU, &p->max_row_len);
+            if (rc == ILUPP_ERR_NO_DIAGONAL) {
+                set_error("ILU0: structurally missing diagonal entry in row " + std::to_string(missing));
+                return rc;
+            }
+            if (rc) return rc;
+            choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
+            finish_chains(&p->sA, &p->sU);             // (the read-back ilu0_symbolic_and_schedule queued came with the tiling's wait)
+        }
+        build_slot_tables(st, &p->sA, true);
+        build_slot_tables(st, &p->sU, false);
+        p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
+        // static form first (lane tables, values-only records: st.hip; no descriptor words, hence no limit on block size or number
+        // of slots), then the record-decoding level-major form
+        lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
+        if (grid && !(lm && p->flm.stat && p->flm.direct)) {
+            // a grid the static direct-feed form does not take (or not the guessed grid: the lane templates of sampled rows disagree):
+            // nothing built on the guess survives; the general pass decides
+            if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] grid guess %d x %d x %d dropped (static analysis declined)\n", gd.nx, gd.ny, gd.nz);
+            if (grid_mode == 0) ILUPP_HIP(hipStreamSynchronize(p->side));
+            p->pkL.release(); p->pkU.release(); p->flm.release();
+            p->sA.release(); p->sU.release();
+            p->sA = Schedule(); p->sU = Schedule();
+            grid = false;
+            continue;
+        }
+        break;
+    }
+    p->grid_path = grid;
     bool have_prog = false;
-    // static form first (lane tables, values-only records: st.hip; no descriptor words, hence no limit on block size or number
-    // of slots), then the record-decoding level-major form
-    const bool lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm) ||
-                    (p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm));
+    lm = lm || (p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm));
     // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
     // generic transposed solves).  (Running this pass on a side stream next to the factor kernel cost the kernel more --
     // 2.0 -> 2.5 ms -- than the pass takes, 0.28 ms.)  Static form: nothing here; row pointers, column indices and values all
@@ -354,10 +428,36 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A)
         if (!(p->pkL.valid && p->pkU.valid)) { p->pkL.release(); p->pkU.release(); }
     }
     ILUPP_HIP(hipEventRecord(a1, st));
+    if (grid && grid_mode == 2) {
+        ILUPP_HIP(hipEventRecord(p->jev[0], st));
+        ILUPP_HIP(hipStreamWaitEvent(p->side, p->jev[0], 0));
+        grid_check_launch(p->side, A, gd, p->ctrl + 8);
+        ILUPP_HIP(hipEventRecord(p->jev[1], p->side));
+    }
     float kms = 0.f;
+    // (the factor kernel's own read-back waits for the proof and takes its verdict along: no round trip of its own)
+    const bool wx_numeric = p->flm.built && p->flm.stat && p->flm.direct && p->flm.wxf;
+    p->pkL.join_ev = (grid && grid_mode != 1 && wx_numeric) ? p->jev[1] : nullptr;
+    p->pkL.join_verdict = -1;                       // (-1: nobody has read the verdict yet)
     rc = ilu0_numeric_any(p, A, have_prog, &kms);
+    p->pkL.join_ev = nullptr;
     ILUPP_HIP(hipEventRecord(a2, st));
+    if (grid && p->pkL.join_verdict >= 0) {
+        grid_bad = p->pkL.join_verdict;
+    } else if (grid) {
+        if (grid_mode != 1) ILUPP_HIP(hipStreamWaitEvent(st, p->jev[1], 0));
+        ILUPP_HIP(d2h_async(st, &grid_bad, p->ctrl + 8, sizeof(int32_t)));
+    }
     ILUPP_HIP(stream_sync(st));
+    if (grid && grid_bad != 0) {
+        // the matrix only began like a grid: everything built on the guess is dropped, the general pass runs
+        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] grid guess %d x %d x %d dropped (pattern differs)\n", gd.nx, gd.ny, gd.nz);
+        p->pkL.release(); p->pkU.release(); p->flm.release();
+        p->sA.release(); p->sU.release();
+        p->sA = Schedule(); p->sU = Schedule();
+        p->grid_path = false;
+        return ilu0_factor(p, A, nullptr);
+    }
     ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
     p->tm.numeric_kernel_ms = kms;
@@ -633,13 +733,13 @@ int finish_apply(ilupp_precond *p)
     return ILUPP_OK;
 }
 
-int ilu0_create_common(const DevMat &A, int is_csr, ilupp_precond **out)
+int ilu0_create_common(const DevMat &A, int is_csr, const int32_t *head, ilupp_precond **out)
 {
     ilupp_precond *p = new_obj(A.n);
     p->kind = KIND_LU;
     p->nnz_mode = NNZ_GENERIC_LU;
     p->input_csc = !is_csr;
-    int rc = ilu0_factor(p, A);
+    int rc = ilu0_factor(p, A, head);
     if (rc) { destroy_obj(p); return rc; }
     *out = p;
     return ILUPP_OK;
@@ -694,7 +794,9 @@ int ilupp_hip_ilu0_create(const double *data, const int32_t *indices, const int3
     ILUPP_HIP(hipMemcpy(A.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     ILUPP_HIP(hipMemcpy(A.val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
-    rc = ilu0_create_common(A, is_csr, out);
+    int32_t head[10] = {indptr[0], indptr[1], -1, -1, -1, -1, -1, -1, -1, -1};
+    for (int i = 0; i < 8 && i < nnz; ++i) head[2 + i] = indices[i];
+    rc = ilu0_create_common(A, is_csr, head, out);
     A.release();
     return rc;
     API_CATCH
@@ -707,11 +809,13 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
     if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
     *out = nullptr;
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
-    const int32_t nnz32 = read_device_nnz(d_indptr, n);
+    // indptr[n], and the head of the matrix for grid.hip's guess: one read-back
+    int32_t head[10];
+    const int32_t nnz32 = read_device_head(d_indptr, d_indices, n, head);
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
-    return ilu0_create_common(A, is_csr, out);
+    return ilu0_create_common(A, is_csr, head, out);
     API_CATCH
 }
 
@@ -1159,6 +1263,12 @@ const char *ilupp_hip_path(const ilupp_precond *p)
     return p->llt_diag_last ? (p->chol_static ? "ichol0:static-level-major" : "ichol0") : "icholt";
 }
 
+const char *ilupp_hip_analysis_path(const ilupp_precond *p)
+{
+    if (!p || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU)) return "";
+    return p->grid_path ? "grid" : "general";
+}
+
 // which kernels a static ILU(0) object runs: "factor kernel;forward sweep;backward sweep" (measurement hook next to ilupp_hip_path:
 // bench.py labels its roofline phases and looks the kernels' counter traffic up by these names); "" for any other object
 const char *ilupp_hip_kernel_names(const ilupp_precond *p)
@@ -1478,8 +1588,10 @@ int ml_create_common(const DevMat &A, const ilupp_ml_params *ip, ilupp_ml **out)
                 QueuePack q; q.stream = p->stream; q.device = p->device;
                 for (int e = 0; e < 6; ++e) q.ev[e] = p->ev[e];
                 q.sev[0] = p->sev[0]; q.sev[1] = p->sev[1];
+                q.side = p->side; q.jev[0] = p->jev[0]; q.jev[1] = p->jev[1];
                 g_queues.free_list.push_back(q);
             }
+            p->side = nullptr; p->jev[0] = p->jev[1] = nullptr;
             p->stream = st;
             for (int e = 0; e < 6; ++e) p->ev[e] = p0->ev[e];
             p->sev[0] = p0->sev[0]; p->sev[1] = p0->sev[1];
@@ -1595,6 +1707,7 @@ int ilupp_hip_ml_create_batch(int32_t count, const double *const *data, const in
                 }
             } catch (const ilupp::HipError &e) { ilupp::d2h_cancel_all(); rc = ilupp::report(e); }
             catch (const std::bad_alloc &) { ilupp::set_error("out of host memory"); rc = ILUPP_ERR_MEMORY; }
+            catch (...) { ilupp::set_error("unexpected exception in a batch worker"); rc = ILUPP_ERR_HIP; }     // (a worker must reach chain_batch_leave)
             rcs[(size_t)i] = rc;
             if (rc) msgs[(size_t)i] = ilupp::g_last_error;
         }
@@ -1603,11 +1716,20 @@ int ilupp_hip_ml_create_batch(int32_t count, const double *const *data, const in
         pool_disown(w + 1);
         pool_set_owner(0);
     };
+    // Kept blocks of owner 0 may have been given back by calls on other objects' streams (apply temporaries, destroy) without a wait for
+    // those streams: nothing of that may still be queued when up to 64 fresh streams start to take such blocks (pool.h).
+    ILUPP_HIP(hipDeviceSynchronize());
     {
-        std::vector<std::thread> pool_threads;
-        for (int w = 1; w < workers; ++w) pool_threads.emplace_back(work, w);
+        // (threads that were started are joined whatever happens -- a joinable std::thread that is destroyed ends the process --, and
+        // workers that could not be started are taken out of the batch's count, or the others would wait for their launches for good)
+        struct Joiner { std::vector<std::thread> v; ~Joiner() { for (std::thread &t : v) if (t.joinable()) t.join(); } } pool_threads;
+        int started = 1;
+        try {
+            for (int w = 1; w < workers; ++w) { pool_threads.v.emplace_back(work, w); ++started; }
+        } catch (...) {
+            for (int w = started; w < workers; ++w) { chain_batch_enter(cb); chain_batch_leave(cb); }
+        }
         work(0);
-        for (std::thread &t : pool_threads) t.join();
     }
     chain_batch_destroy(cb);
     int first = ILUPP_OK;

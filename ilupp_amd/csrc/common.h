@@ -148,6 +148,10 @@ struct PackedSweep {
     // static sweeps made from a pair of stored triangular factors (st_analyse_pair): the forward sweep divides by its stored
     // diagonal; the backward sweep accumulates in descending column order when `desc` (a row-stored lower factor used transposed)
     bool pair = false, desc = false;
+    // (forward sweep of an ILU(0) whose row blocks were guessed, grid.hip) the proof's end on its side stream and its verdict word, ctrl[8]:
+    // the factor kernel's own read-back waits for the one and takes the other along
+    hipEvent_t join_ev = nullptr;
+    int32_t join_verdict = 0;
     void release();
 };
 
@@ -293,6 +297,14 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
 void finish_chains(Schedule *fwd, Schedule *bwd);
+// grid.hip: the first analysis pass for lexicographic box-grid stencil matrices (guess from row 0, proof on a side stream)
+struct GridDims { int32_t nx, ny, nz; };
+bool grid_guess(int32_t n, int64_t nnz, const int32_t *head /* ptr[0], ptr[1], idx[0..7] */, GridDims *g);
+void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
+void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
+                    int32_t *max_row_len, int max_wgs);
+// a verdict computed on another stream that a read-back of the analysis takes along: the stream waits for `ev`, then *host = *dev
+struct SideJoin { hipEvent_t ev; const int32_t *dev; int32_t *host; bool done; };
 int ilu0_csr_ptrs(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
 int csr_ptrs_from_counts(hipStream_t st, int32_t n, int32_t *counts, DevMat *M);
 int st_make_csr(hipStream_t st, int32_t n, const PackedSweep &pl, const PackedSweep &pu, DevMat *L, DevMat *U);
@@ -492,7 +504,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
 void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
 // st.hip
 bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
-                     PackedSweep *pu, FactorLM *f);
+                     PackedSweep *pu, FactorLM *f, SideJoin *join = nullptr);
 int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, FactorLM *f,
                     int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1);
 int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,

@@ -1,0 +1,165 @@
+// ilupp_amd/csrc/grid.hip -- the first analysis pass of ILU(0) for matrices whose pattern is a lexicographic box-grid stencil
+// (5-point on nx x ny, 7-point on nx x ny x nz: the matrices of BASELINE configs C1, C2, C4).
+//
+// What the general first pass (symbolic.hip: k_row_cuts_counts, k_reduce_stats, k_block_starts; schedule.hip: the tiling samples)
+// finds out about such a matrix -- rows r - 1 and r are linked inside an x-line and nowhere else, all lines are alike, every row has its
+// diagonal, the line grid has the (1, ny) dependency structure -- follows from THREE numbers.  The host reads them off row 0 (its
+// columns are 0, 1, nx, nx ny), checks the entry count against the closed form, and then
+//   * writes the two schedules' block starts (start[b] = b nx) without looking at the pattern,
+//   * lets ONE streaming kernel on a side stream prove the guess for every row: k_grid_check compares each row's pointer and columns
+//     with the closed form (0.54 GB at 256^3, no reduction, no output but one flag), next to the lane-table kernels of the static
+//     analysis, which only sample rows and need nothing from it;
+//   * takes the flag home with the read-back the static analysis makes anyway.  A matrix that merely begins like a grid fails the
+//     proof: everything built on the guess is dropped and the general pass runs (api.hip: ilu0_factor).
+// Nothing downstream changes: the lane tables, the factor kernel and the sweeps are the ones of st.hip / st_wave.hip; the reference
+// semantics are ILU0.hpp:26-66 as before (this file only replaces how the row blocks are found, ILU0.hpp has no counterpart).
+#include "common.h"
+
+namespace ilupp {
+
+// entries of a box-grid stencil matrix: n + 2 (links in x + links in y + links in z)
+static int64_t grid_links(const GridDims &g)
+{
+    const int64_t nx = g.nx, ny = g.ny, nz = g.nz;
+    return (nx - 1) * ny * nz + nx * (ny - 1) * nz + nx * ny * (nz - 1);
+}
+
+bool grid_guess(int32_t n, int64_t nnz, const int32_t *head, GridDims *g)
+{
+    static const bool off = getenv("ILUPP_NO_GRID") != nullptr;
+    if (off || n < (1 << 16)) return false;
+    // head: {ptr[0], ptr[1], idx[0..7]}
+    if (head[0] != 0) return false;
+    const int len0 = head[1];
+    const int32_t *c = head + 2;
+    int64_t nx = 0, ny = 0, nz = 0;
+    if (len0 == 4 && c[0] == 0 && c[1] == 1 && c[2] >= 2 && c[3] > c[2]) {
+        nx = c[2];
+        if (c[3] % nx != 0 || (int64_t)n % c[3] != 0) return false;
+        ny = c[3] / nx; nz = (int64_t)n / c[3];
+        if (nz < 2) return false;
+    } else if (len0 == 3 && c[0] == 0 && c[1] == 1 && c[2] >= 2) {
+        nx = c[2];
+        if ((int64_t)n % nx != 0) return false;
+        ny = (int64_t)n / nx; nz = 1;
+    } else {
+        return false;
+    }
+    // lines long enough to be lanes' chains, enough of them to fill workgroups (anything smaller: the general pass, which is quick there)
+    if (nx < 16 || ny < 4 || ny * nz < 2 * kThreads || nx > (1 << 20) || ny > (1 << 20) || nz > (1 << 20)) return false;
+    g->nx = (int32_t)nx; g->ny = (int32_t)ny; g->nz = (int32_t)nz;
+    return nnz == (int64_t)n + 2 * grid_links(*g) && nnz < (1LL << 30);        // (k_grid_check covers the index array with one buffer resource)
+}
+
+// entries before row r = (x, y, z): seven per row minus the neighbours that fall outside the box
+__device__ __forceinline__ long long grid_row_start(const int x, const int y, const int z, const GridDims &g)
+{
+    const long long nx = g.nx, ny = g.ny;
+    const long long r = x + nx * (y + ny * (long long)z);
+    const bool z0 = z == 0, z1 = z == g.nz - 1, y0 = y == 0, y1 = y == g.ny - 1;
+    long long miss = 0;
+    // whole planes below: the ends of every line, the first and the last line, and all of plane 0 (no plane below it)
+    miss += (long long)z * (2 * ny + 2 * nx) + (z > 0 ? nx * ny : 0);
+    // whole lines of this plane before line y
+    miss += 2LL * y + (y > 0 ? nx : 0) + (long long)y * nx * ((z0 ? 1 : 0) + (z1 ? 1 : 0));
+    // rows of this line before x
+    miss += (x > 0 ? 1 : 0) + (long long)x * ((y0 ? 1 : 0) + (y1 ? 1 : 0) + (z0 ? 1 : 0) + (z1 ? 1 : 0));
+    return 7 * r - miss;
+}
+
+// One row per lane.  The eight index words a row can reach from its expected start are fetched with two 16-byte loads whatever the
+// row turns out to hold (buffer loads: past the end of the array they return zeros), so nothing about a row waits for anything else
+// about it; a wave's 64 rows read one contiguous run of the index array (1.8 KB).
+__global__ void __launch_bounds__(256)
+k_grid_check(const int32_t n, const long long nnz, const GridDims g, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+             int32_t *__restrict__ bad)
+{
+    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+    bool ok = true;
+    const unsigned unx = (unsigned)g.nx, uny = (unsigned)g.ny;
+    const int sxy = g.nx * g.ny;
+    // (an index array of more than 4 GB cannot be covered by one buffer resource: the host does not take such a matrix here)
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(idx), 0, (int)((unsigned)nnz * 4u), 0x00020000);
+    for (long long r0 = (long long)blockIdx.x * 256; r0 < n; r0 += (long long)gridDim.x * 256) {
+        const long long rr = r0 + threadIdx.x;
+        if (rr >= n) break;
+        const unsigned r = (unsigned)rr;
+        const unsigned l = r / unx, x = r - l * unx;
+        const unsigned z = l / uny, y = l - z * uny;
+        const long long e = grid_row_start((int)x, (int)y, (int)z, g);
+        const unsigned eo = (unsigned)e * 4u;
+        const v4u_ c0 = __builtin_amdgcn_raw_buffer_load_b128(ri, eo, 0, 0);
+        const v4u_ c1 = __builtin_amdgcn_raw_buffer_load_b128(ri, eo + 16u, 0, 0);
+        const int p = ptr[r];
+        const int pn = rr == n - 1 ? ptr[n] : 0;
+        ok = ok && (long long)p == e && (rr != n - 1 || (long long)pn == nnz);
+        // the expected columns, in stored order, against the words that were fetched
+        const int ri_ = (int)r;
+        int want[7];
+        int m = 0;
+        if (z > 0) want[m++] = ri_ - sxy;
+        if (y > 0) want[m++] = ri_ - g.nx;
+        if (x > 0) want[m++] = ri_ - 1;
+        want[m++] = ri_;
+        if ((int)x < g.nx - 1) want[m++] = ri_ + 1;
+        if ((int)y < g.ny - 1) want[m++] = ri_ + g.nx;
+        if ((int)z < g.nz - 1) want[m++] = ri_ + sxy;
+        const int got[8] = {(int)c0.x, (int)c0.y, (int)c0.z, (int)c0.w, (int)c1.x, (int)c1.y, (int)c1.z, (int)c1.w};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) ok = ok && (j >= m || got[j] == want[j]);
+    }
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
+__global__ void k_grid_starts(const int32_t n, const int32_t nx, const int32_t nb, int32_t *__restrict__ sf, int32_t *__restrict__ sb)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    const long long s = (long long)b * nx;
+    const int32_t v = b == nb ? n : (int32_t)(s < n ? s : n);
+    sf[b] = v; sb[b] = v;
+}
+
+void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad)
+{
+    unsigned gb = (unsigned)(((int64_t)A.n + 255) / 256);
+    if (gb > (1u << 20)) gb = 1u << 20;
+    hipLaunchKernelGGL(k_grid_check, dim3(gb), dim3(256), 0, side, A.n, (long long)A.nnz, g, A.ptr, A.idx, d_bad);
+    ILUPP_HIP(hipGetLastError());
+}
+
+// What ilu0_symbolic_and_schedule + choose_tiling_pair + finish_chains leave behind, for a matrix that IS the guessed grid (the proof
+// runs next to what follows).  The placement of the lines on workgroups is the one choose_tiling makes for a (1, ny) line grid.
+void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
+                    int32_t *max_row_len, int max_wgs)
+{
+    const int32_t n = A.n;
+    const int64_t links = grid_links(g);
+    L->n = U->n = n; L->is_csr = U->is_csr = true; L->owns = U->owns = true;
+    L->nnz = (int64_t)n + links;            // strictly lower + unit diagonal (ILU0.hpp:93)
+    U->nnz = A.nnz - links;
+    if (max_row_len) *max_row_len = 1 + 2 * ((g.nx > 1 ? 1 : 0) + (g.ny > 1 ? 1 : 0) + (g.nz > 1 ? 1 : 0));
+    const int32_t nb = g.ny * g.nz;
+    for (Schedule *s : {fwd, bwd}) {
+        s->nb = nb; s->B = g.nx;
+        ILUPP_HIP(pool_malloc(&s->start, sizeof(int32_t) * (size_t)(nb + 1)));
+        s->chains = s->chains_pre = true; s->ragged = 0;
+        s->tile_s2 = s->tile_ty = s->tile_tz = 0;
+    }
+    hipLaunchKernelGGL(k_grid_starts, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st, n, g.nx, nb, fwd->start, bwd->start);
+    ILUPP_HIP(hipGetLastError());
+    // patches of 16 x 16 lines, as square as the grid allows (schedule.hip: tiling_decide)
+    if (g.nz >= 2 && getenv("ILUPP_NO_TILES") == nullptr) {
+        const int s2 = g.ny, nbz = g.nz;
+        int ty = 16, tz = 16;
+        while (ty > s2 && ty > 1) { ty >>= 1; tz <<= 1; }
+        while (tz > nbz && tz > 1) { tz >>= 1; ty <<= 1; }
+        if (ty <= s2 && ty * tz == kThreads) {
+            const int NY = (s2 + ty - 1) / ty, NZ = (nbz + tz - 1) / tz;
+            if ((long)NY * NZ <= max_wgs)
+                for (Schedule *s : {fwd, bwd}) { s->tile_s2 = s2; s->tile_ty = ty; s->tile_tz = tz; }
+        }
+    }
+}
+
+}  // namespace ilupp

@@ -1347,6 +1347,7 @@ struct ChainBatch {
     struct Item { const DpArgs *args; hipEvent_t before; float ms; bool done; int rc; int kind; };
     std::vector<Item *> waiting;
     hipStream_t stream = nullptr;
+    std::string fire_msg;                           // why the last combined launch failed (read by every worker it failed for; under `mu`)
 };
 static thread_local ChainBatch *t_batch = nullptr;
 
@@ -1398,7 +1399,10 @@ static void chain_batch_fire(ChainBatch *b)
         ILUPP_HIP(hipStreamSynchronize(b->stream));
         ILUPP_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
         if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] chains of a batch: %d with pivoting, %d + %d of partialILUC (LDS / memory), %.2f ms\n", off[1] - off[0], off[2] - off[1], off[3] - off[2], ms);
-    } catch (const HipError &e) { set_error(std::string("HIP error in the batched chain launch: ") + hipGetErrorString(e.code)); rc = ILUPP_ERR_HIP; }
+    } catch (const HipError &e) { b->fire_msg = std::string("HIP error in the batched chain launch: ") + hipGetErrorString(e.code); rc = ILUPP_ERR_HIP; }
+    catch (const std::bad_alloc &) { b->fire_msg = "out of host memory in the batched chain launch"; rc = ILUPP_ERR_MEMORY; }
+    catch (...) { b->fire_msg = "unexpected exception in the batched chain launch"; rc = ILUPP_ERR_HIP; }
+    // (every waiting worker is released whatever happened above -- one left behind would block its thread, and with it the batch, for good)
     for (ChainBatch::Item *it : b->waiting) { it->ms = ms; it->rc = rc; it->done = true; }
     b->waiting.clear();
     b->cv.notify_all();
@@ -1440,6 +1444,7 @@ static int chain_launch(hipStream_t st, const DpArgs &a, int kind, float *ms)   
         else b->cv.wait(lk, [&] { return it.done; });
     }
     *ms = it.ms;
+    if (it.rc != ILUPP_OK) set_error(b->fire_msg);             // (in THIS worker's thread: the message is thread-local, the launch may have been another worker's)
     return it.rc;                                              // (the batch's stream has been synchronised: the chain's results are there)
 }
 

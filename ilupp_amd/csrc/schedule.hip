@@ -155,6 +155,8 @@ static void tiling_decide(const std::vector<int32_t> &h, Schedule *sch, int max_
     while (ty > s2 && ty > 1) { ty >>= 1; tz <<= 1; }
     while (tz > nbz && tz > 1) { tz >>= 1; ty <<= 1; }
     if (ty > s2 || ty * tz != kThreads) return;
+    // (experiment hook: patches of fewer lines than lanes -- the lanes left over own no block)
+    if (const char *e = getenv("ILUPP_TILE_TZ")) { const int v = atoi(e); if (v >= 1 && v <= tz) tz = v; }
     const int NY = (s2 + ty - 1) / ty, NZ = (nbz + tz - 1) / tz;
     // every workgroup must be resident at once (a patch may wait on a higher-numbered patch)
     if ((long)NY * NZ > max_wgs) return;

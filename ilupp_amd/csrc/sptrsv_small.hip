@@ -41,11 +41,16 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
         for (int q = 0; q < kG; ++q) if (q < have1) { c1[q] = idx[jf + q]; v1[q] = val[jf + q]; }
         jf += have1;
     };
-    // every trip of the loop below some lane consumes an entry or finishes a row unless an unknown never leaves the sentinel (an index
-    // outside the triangle, a right-hand side that carries the sentinel's bits): a bounded number of trips, then ILUPP_ERR_TIMEOUT as
-    // everywhere else in this library
-    const long long max_trips = 4ll * ((long long)ptr[n] + n) + 4096;
-    long long trips = 0;
+    // Every trip of the loop below some lane of the WORKGROUP consumes an entry or finishes a row, unless an unknown never leaves the
+    // sentinel (an index outside the triangle, a right-hand side that carries the sentinel's bits).  A wave gives up -- ILUPP_ERR_TIMEOUT,
+    // as everywhere else in this library -- only when NO wave of the workgroup has made progress for kIdleLimit of its own trips: the
+    // trips a wave spends waiting for rows of other waves do not count against it (a chain-like factor makes a wave wait for a long time),
+    // and whichever wave gives up reports it.
+    constexpr unsigned kIdleLimit = 1u << 20;
+    __shared__ unsigned s_progress;
+    if (tid == 0) s_progress = 0;
+    __syncthreads();
+    unsigned seen = 0, idle = 0;
     bool broken = false;
     auto open_row = [&]() {
         const int b = ptr[r], e = ptr[r + 1];
@@ -63,7 +68,8 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
     };
     if (alive) open_row();
     while (__ballot(alive) != 0ull) {
-        if (__ballot(broken) != 0ull || ++trips > max_trips) { if (tid == 0 && err) atomicExch(err, 1); break; }
+        if (__ballot(broken) != 0ull || idle > kIdleLimit) { if ((tid & 63) == 0 && err) atomicExch(err, 1); break; }
+        bool did = false;
         if (alive) {
             if (j < jend) {
                 if (at == have0) {                  // the group is used up: the other one takes its place, the one after it is asked for
@@ -85,6 +91,7 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
                         const double p = v0[q] * __longlong_as_double((long long)xb[q]);
                         acc = acc - p;
                         ++at; ++j;
+                        did = true;
                     }
             } else {
                 const double x = acc / diag;
@@ -93,7 +100,15 @@ k_sptrsv_small(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__rest
                 r += FWD ? kSmallThreads : -kSmallThreads;
                 alive = FWD ? r < n : r >= 0;
                 if (alive) open_row();
+                did = true;
             }
+        }
+        if (__ballot(did) != 0ull) {
+            if ((tid & 63) == 0) atomicAdd(&s_progress, 1u);
+            idle = 0;
+        } else {
+            const unsigned now = __hip_atomic_load(&s_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (now != seen) { seen = now; idle = 0; } else ++idle;
         }
     }
 }

@@ -1499,7 +1499,7 @@ static void st_pack_values(hipStream_t st, const DevMat &A, PackedSweep *pl, Pac
 // The whole static analysis of an ILU(0): true when the factor kernel and both sweeps can run from lane tables
 // (pl, pu, f then complete, the values of A packed); false leaves the three objects released.
 bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
-                     PackedSweep *pu, FactorLM *f)
+                     PackedSweep *pu, FactorLM *f, SideJoin *join)
 {
     pl->release(); pu->release(); f->release();
     static const bool off = getenv("ILUPP_NO_PACKED") != nullptr ||
@@ -1561,11 +1561,18 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         }
         int32_t *tot = xsz + (size_t)nwg * 2;
         hipLaunchKernelGGL(k_st_xch_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, xa[0], xa[1], (int32_t)nwg, tot);
-        D2HItem items[3];
+        D2HItem items[4];
         items[0] = {&xtot[0][0], tot, 4 * sizeof(int32_t)};
         items[1] = {hl, pl->flags, sizeof(hl)};
         items[2] = {hu, pu->flags, sizeof(hu)};
-        ILUPP_HIP(d2h_async_many(st, items, 3));
+        int ni = 3;
+        if (join) {
+            // (a verdict from a side stream -- grid.hip's proof of the guessed pattern -- comes home with this read-back)
+            ILUPP_HIP(hipStreamWaitEvent(st, join->ev, 0));
+            items[ni++] = {join->host, join->dev, sizeof(int32_t)};
+            join->done = true;
+        }
+        ILUPP_HIP(d2h_async_many(st, items, ni));
     }
     ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(xsz));

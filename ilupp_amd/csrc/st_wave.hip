@@ -1037,9 +1037,11 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     hipLaunchKernelGGL(k_ilu0_wx, dim3((unsigned)pl->nwg), dim3(kWfThreads), kWfLds, st, a);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
-    int32_t ctrl[4];
-    ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, 16));
+    int32_t ctrl[12];
+    if (pl->join_ev) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));          // (grid.hip's proof, on its side stream)
+    ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, sizeof(ctrl)));
     ILUPP_HIP(stream_sync(st));
+    pl->join_verdict = ctrl[8];
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
     pl->fmt = pu->fmt = 1;

@@ -324,6 +324,10 @@ int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t);
 /* which kernel family built this object ("ilu0:static-direct", "ilu0:static-level-major", "ilu0:level-major", "ilu0:level-order",
  * "ilu0:csr-program", "ilu0:csr", "ilut", "ichol0", "icholt"): bench.py names the kernel its roofline line is about */
 const char *ilupp_hip_path(const ilupp_precond *p);
+/* how the row blocks of an ILU(0) object were found: "grid" (the pattern is a lexicographic box-grid stencil: guessed from row 0, proven
+ * for every row by one streaming pass next to the lane-table kernels, grid.hip) or "general" (the pass over the pattern that finds the
+ * chains of any matrix, symbolic.hip); "" for other objects.  Measurement / test hook, no counterpart in binding.cpp. */
+const char *ilupp_hip_analysis_path(const ilupp_precond *p);
 /* measurement hook: the kernels a static ILU(0) object runs, "factor;forward sweep;backward sweep" ("" otherwise); no counterpart in binding.cpp */
 const char *ilupp_hip_kernel_names(const ilupp_precond *p);
 /* redo the numeric phase on (possibly new) values with the SAME pattern (buffers reused); times it */
