@@ -346,9 +346,11 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     // three dimensions, and ONE streaming kernel on the side stream proves the guess for every row while the lane tables are built.
     GridDims gd = {0, 0, 0};
     bool grid = head != nullptr && p->side != nullptr && grid_guess(A.n, A.nnz, head, &gd);
-    // where the proof runs: 0 = on the side stream next to the lane-table kernels, 1 = on the object's stream before them, 2 = on the side
-    // stream next to the factor kernel.  Its verdict comes home with the construction's last read-back in every case.
-    static const int grid_mode = []() { const char *e = getenv("ILUPP_GRID_CHECK_AT"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
+    // where the proof runs: 1 (default) = on the object's stream before the lane-table kernels, 0 = on the side stream next to them, 2 = on
+    // the side stream next to the factor kernel.  Its verdict comes home with the construction's last read-back in every case.  (Measured
+    // at 256^3: the lane-table kernels are chains of dependent loads and the factor kernel lives on short hand-over latencies -- next to a
+    // 4.6 TB/s stream the former take 2x as long and the latter loses more time than the proof takes: step 2.24 / 2.26 / 2.32 ms for 1 / 0 / 2)
+    static const int grid_mode = []() { const char *e = getenv("ILUPP_GRID_CHECK_AT"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 2) ? v : 1; }();
     int32_t grid_bad = 0;
     bool lm = false;
     for (;;) {
@@ -375,12 +377,14 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
             choose_tiling_pair(st, A.ptr, A.idx, &p->sA, &p->sU, max_wgs);
             finish_chains(&p->sA, &p->sU);             // (the read-back ilu0_symbolic_and_schedule queued came with the tiling's wait)
         }
-        build_slot_tables(st, &p->sA, true);
-        build_slot_tables(st, &p->sU, false);
+        // (a grid's slot tables are filled together with its lane templates: grid.hip, k_grid_lanes; ILUPP_GRID_TABLES=0: by the general kernels)
+        static const bool grid_tables = []() { const char *e = getenv("ILUPP_GRID_TABLES"); return !(e && atoi(e) == 0); }();
+        build_slot_tables(st, &p->sA, true, !(grid && grid_tables));
+        build_slot_tables(st, &p->sU, false, !(grid && grid_tables));
         p->compact = schedule_is_compact(p->sA) && schedule_is_compact(p->sU);
         // static form first (lane tables, values-only records: st.hip; no descriptor words, hence no limit on block size or number
         // of slots), then the record-decoding level-major form
-        lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm);
+        lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm, nullptr, (grid && grid_tables) ? &gd : nullptr);
         if (grid && !(lm && p->flm.stat && p->flm.direct)) {
             // a grid the static direct-feed form does not take (or not the guessed grid: the lane templates of sampled rows disagree):
             // nothing built on the guess survives; the general pass decides

@@ -303,6 +303,10 @@ bool grid_guess(int32_t n, int64_t nnz, const int32_t *head /* ptr[0], ptr[1], i
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
 void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
                     int32_t *max_row_len, int max_wgs);
+// slot tables, lane templates and the link between the two schedules of a box grid, from its dimensions (one launch; the schedules'
+// slot arrays must be allocated: build_slot_tables(..., false))
+void grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, const Schedule &bwd, int32_t *ltabF, int32_t *ltabB,
+                      int32_t *flagsF, int32_t *flagsB, int32_t *uslot);
 // a verdict computed on another stream that a read-back of the analysis takes along: the stream waits for `ev`, then *host = *dev
 struct SideJoin { hipEvent_t ev; const int32_t *dev; int32_t *host; bool done; };
 int ilu0_csr_ptrs(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
@@ -346,7 +350,7 @@ void d2h_cancel_all();
 // schedule.hip
 void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, Schedule *sch, bool fwd, int max_wgs);
 void choose_tiling_pair(hipStream_t st, const int32_t *ptr, const int32_t *idx, Schedule *fwd, Schedule *bwd, int max_wgs);
-void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd);
+void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd, bool fill = true);      // fill = false: the arrays only (grid.hip fills them)
 void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc);
 bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, Ilu0Program *P);
 bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, int32_t **prog_out);
@@ -504,7 +508,7 @@ bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
 void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
 // st.hip
 bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
-                     PackedSweep *pu, FactorLM *f, SideJoin *join = nullptr);
+                     PackedSweep *pu, FactorLM *f, SideJoin *join = nullptr, const GridDims *grid = nullptr);
 int ilu0_numeric_st(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu, FactorLM *f,
                     int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1);
 int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_t n, const double *rhs, double *out,

@@ -120,6 +120,122 @@ __global__ void k_grid_starts(const int32_t n, const int32_t nx, const int32_t n
     sf[b] = v; sb[b] = v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The slot tables (schedule.hip: k_slot_tables), the lane templates (st.hip: st_template_body) and the link between the two
+// schedules (sptrsv_lm.hip: k_lm_uslot) of a box grid, from its dimensions: what those kernels find by following ptr -> idx -> start ->
+// blk2slot for three sampled rows of every lane is known here -- line (y, z) depends on the lines (y - 1, z) and (y, z - 1) at equal x
+// and on its own previous row.  One launch, no dependent loads; block (w, d): workgroup w of the forward (d = 0) / backward schedule.
+// ---------------------------------------------------------------------------------------------
+struct GridPlace { int32_t nx, ny, nz, nb, s2, ty, tz, NY, nslots; };
+
+// slot of the block with index bs in SWEEP order (forward: the block's own index, backward: nb - 1 - index); schedule.hip: tiled_block_of
+__device__ __forceinline__ int grid_place(const int bs, const GridPlace &g)
+{
+    if (g.s2 <= 0) return bs;
+    const int by = bs % g.s2, bz = bs / g.s2;
+    return ((bz / g.tz) * g.NY + by / g.ty) * kThreads + (bz % g.tz) * g.ty + by % g.ty;
+}
+__device__ __forceinline__ int grid_block_at(const int slot, const GridPlace &g)
+{
+    if (g.s2 <= 0) return slot < g.nb ? slot : -1;
+    const int T = slot / kThreads, lane = slot % kThreads;
+    const int by = (T % g.NY) * g.ty + lane % g.ty;
+    const int bz = (T / g.NY) * g.tz + lane / g.ty;
+    if (by >= g.s2 || lane / g.ty >= g.tz) return -1;
+    const long bs = (long)bz * g.s2 + by;
+    return bs < g.nb ? (int)bs : -1;
+}
+
+struct GridLaneArgs { int32_t *slot2blk, *blk2slot, *sfirst, *scount, *exported, *ltab, *flags; };
+
+__global__ void __launch_bounds__(kThreads)
+k_grid_lanes(const GridPlace g, const GridLaneArgs F, const GridLaneArgs Bk, int32_t *__restrict__ uslot)
+{
+    const bool fwd = blockIdx.y == 0;
+    const GridLaneArgs &X = fwd ? F : Bk;
+    const int wg = blockIdx.x, t = threadIdx.x;
+    const int slot = wg * kThreads + t;
+    if (slot >= g.nslots) return;
+    const int bs = grid_block_at(slot, g);
+    const int b = bs < 0 ? -1 : (fwd ? bs : g.nb - 1 - bs);
+    X.slot2blk[slot] = b;
+    int32_t *T = X.ltab + (size_t)slot * kStTab;
+    if (b < 0) {
+        X.sfirst[slot] = 0; X.scount[slot] = 0; X.exported[slot] = 0;
+        if (fwd) uslot[slot] = -1;
+#pragma unroll
+        for (int i = 0; i < kStTab; ++i) T[i] = 0;
+        T[ST_DT] = T[ST_DT + 1] = T[ST_DT + 2] = 1;
+        T[ST_SCAT] = T[ST_SCAT + 1] = T[ST_SCAT + 2] = -1;
+        return;
+    }
+    X.blk2slot[b] = slot;
+    const int cnt = g.nx;
+    const int first = fwd ? b * g.nx : (b + 1) * g.nx - 1;       // first row in processing order
+    X.sfirst[slot] = first; X.scount[slot] = cnt;
+    const int y = b % g.ny, z = b / g.ny;
+    // the lines this one depends on, ascending column offset (= the reference's elimination / accumulation order), and the lines that
+    // depend on it (a slot some OTHER workgroup reads is exported)
+    // (every field is stored as it is found -- the table row is the only array: an array of their own would live in scratch memory)
+    int nd = 0, bad = 0, ngh = 0;
+    const int sxy = g.nx * g.ny;
+#pragma unroll
+    for (int i = ST_OFF; i < kStTab; ++i) T[i] = 0;
+    T[ST_DT] = T[ST_DT + 1] = T[ST_DT + 2] = 1;
+    T[ST_SCAT] = T[ST_SCAT + 1] = T[ST_SCAT + 2] = -1;
+    bool ex = false;
+#define GRID_DEP(o_, bo_)                                                                              \
+    do {                                                                                               \
+        const int os_ = grid_place(fwd ? (bo_) : g.nb - 1 - (bo_), g);                                 \
+        int sw_;                                                                                       \
+        if ((os_ >> 8) == wg) sw_ = ST_LOCAL | (os_ << 2);                                             \
+        else { sw_ = ST_GHOST | (os_ << 2); ++ngh; if ((os_ >> 8) >= wg) bad = 1; }                    \
+        T[ST_OFF + nd] = (o_); T[ST_SRC + nd] = sw_; T[ST_KHI + nd] = cnt; ++nd;                       \
+    } while (0)
+#define GRID_OWN(o_)                                                                                   \
+    do {                                                                                               \
+        T[ST_OFF + nd] = (o_); T[ST_SRC + nd] = ST_OWN | (slot << 2); T[ST_KAP + nd] = -1;             \
+        T[ST_KLO + nd] = 1; T[ST_KHI + nd] = cnt; ++nd;                                                \
+    } while (0)
+#define GRID_READER(bo_) do { if ((grid_place(fwd ? (bo_) : g.nb - 1 - (bo_), g) >> 8) != wg) ex = true; } while (0)
+    if (fwd) {
+        if (z > 0) GRID_DEP(-sxy, b - g.ny);
+        if (y > 0) GRID_DEP(-g.nx, b - 1);
+        if (g.nx > 1) GRID_OWN(-1);
+        if (y < g.ny - 1) GRID_READER(b + 1);
+        if (z < g.nz - 1) GRID_READER(b + g.ny);
+    } else {
+        if (g.nx > 1) GRID_OWN(1);
+        if (y < g.ny - 1) GRID_DEP(g.nx, b + 1);
+        if (z < g.nz - 1) GRID_DEP(sxy, b + g.ny);
+        if (y > 0) GRID_READER(b - 1);
+        if (z > 0) GRID_READER(b - g.ny);
+    }
+#undef GRID_DEP
+#undef GRID_OWN
+#undef GRID_READER
+    X.exported[slot] = ex ? 1 : 0;
+    if (nd == 3 && ngh == 3) bad = 1;
+    T[ST_FIRST] = first; T[ST_CNT] = cnt; T[ST_SKEW] = 0; T[ST_ND] = nd;
+    if (bad) atomicOr(&X.flags[0], 2);
+    // the slot of the backward schedule that owns the same line
+    if (fwd) uslot[slot] = grid_place(g.nb - 1 - b, g);
+}
+
+void grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, const Schedule &bwd, int32_t *ltabF, int32_t *ltabB,
+                      int32_t *flagsF, int32_t *flagsB, int32_t *uslot)
+{
+    GridPlace g;
+    g.nx = gd.nx; g.ny = gd.ny; g.nz = gd.nz; g.nb = fwd.nb;
+    g.s2 = fwd.tile_s2; g.ty = fwd.tile_ty; g.tz = fwd.tile_tz;
+    g.NY = g.s2 > 0 ? (g.s2 + g.ty - 1) / g.ty : 0;
+    g.nslots = fwd.nslots;
+    GridLaneArgs F = {fwd.slot2blk, fwd.blk2slot, fwd.sfirst, fwd.scount, fwd.exported, ltabF, flagsF};
+    GridLaneArgs Bk = {bwd.slot2blk, bwd.blk2slot, bwd.sfirst, bwd.scount, bwd.exported, ltabB, flagsB};
+    hipLaunchKernelGGL(k_grid_lanes, dim3((unsigned)(fwd.nslots / kThreads), 2), dim3(kThreads), 0, st, g, F, Bk, uslot);
+    ILUPP_HIP(hipGetLastError());
+}
+
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad)
 {
     unsigned gb = (unsigned)(((int64_t)A.n + 255) / 256);

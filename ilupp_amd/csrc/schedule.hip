@@ -61,7 +61,7 @@ __global__ void k_slot_tables(int32_t nb, int32_t nslots, int fwd, Tiling til, c
     }
 }
 
-void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
+void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd, bool fill)
 {
     sch->fwd = fwd;
     Tiling til = {0, 0, 0, 0, sch->nb};
@@ -82,6 +82,7 @@ void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd)
     ILUPP_HIP(pool_malloc(&sch->exported, bytes));
     const size_t gbytes = sizeof(int32_t) * (size_t)(sch->nslots / kThreads) * kGhosts;
     ILUPP_HIP(pool_malloc(&sch->gtab, gbytes));
+    if (!fill) return;
     hipLaunchKernelGGL(k_slot_tables, dim3((unsigned)(sch->nslots / kThreads)), dim3(kThreads), 0, st,
                        sch->nb, sch->nslots, fwd ? 1 : 0, til, sch->start, sch->slot2blk, sch->blk2slot, sch->sfirst, sch->scount, sch->exported);
 }

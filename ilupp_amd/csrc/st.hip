@@ -1499,7 +1499,7 @@ static void st_pack_values(hipStream_t st, const DevMat &A, PackedSweep *pl, Pac
 // The whole static analysis of an ILU(0): true when the factor kernel and both sweeps can run from lane tables
 // (pl, pu, f then complete, the values of A packed); false leaves the three objects released.
 bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
-                     PackedSweep *pu, FactorLM *f, SideJoin *join)
+                     PackedSweep *pu, FactorLM *f, SideJoin *join, const GridDims *grid)
 {
     pl->release(); pu->release(); f->release();
     static const bool off = getenv("ILUPP_NO_PACKED") != nullptr ||
@@ -1510,16 +1510,21 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     const int nslots = fwd.nslots;
     st_structure(st, fwd, pl, (int)SWEEP_FWD_LAST_ASC);
     st_structure(st, bwd, pu, (int)SWEEP_BWD_FIRST_ASC);
-    {
+    if (grid) {
+        // a box grid (grid.hip): slot tables, lane templates and the link of the two schedules follow from its dimensions
+        pu->built = true;
+        ILUPP_HIP(pool_malloc(&pu->uslot, sizeof(int32_t) * (size_t)fwd.nslots));
+        grid_lane_tables(st, *grid, fwd, bwd, pl->ltab, pu->ltab, pl->flags, pu->flags, pu->uslot);
+    } else {
         StTplArgs tf, tb;
         tf.B = fwd.B; tf.nb = fwd.nb; tf.start = fwd.start; tf.blk2slot = fwd.blk2slot; tf.sfirst = fwd.sfirst; tf.scount = fwd.scount;
         tf.exported = fwd.exported; tf.ltab = pl->ltab; tf.flags = pl->flags;
         tb.B = bwd.B; tb.nb = bwd.nb; tb.start = bwd.start; tb.blk2slot = bwd.blk2slot; tb.sfirst = bwd.sfirst; tb.scount = bwd.scount;
         tb.exported = bwd.exported; tb.ltab = pu->ltab; tb.flags = pu->flags;
         hipLaunchKernelGGL(k_st_template_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, A.ptr, A.idx, tf, tb);
+        pu->built = true;
+        lm_link_factor(st, fwd, bwd, pu);               // forward slot -> backward slot of the same chain (flags[3] when there is none)
     }
-    pu->built = true;
-    lm_link_factor(st, fwd, bwd, pu);                   // forward slot -> backward slot of the same chain (flags[3] when there is none)
     hipLaunchKernelGGL(k_st_link_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew, pu->skew,
                        pl->wtab, pu->wtab, pl->flags, pu->flags, st_wx_on() ? 1 : 0);
     hipLaunchKernelGGL(k_st_scan_pair, dim3(2), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags, pu->wtab, pu->flags);

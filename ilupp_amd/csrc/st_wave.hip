@@ -40,6 +40,12 @@ static constexpr int kWxLds = 2 * kStH * kWxRow * 8;
 __device__ unsigned long long g_wx_stamp[16];
 // ... and per workgroup of the factor kernel (by ticket): entry, lane 0's first row, lane 0's last row, exit (100 MHz)
 __device__ unsigned long long g_wf_tl[4096 * 4];
+// ... and per workgroup and wave (16 slots): cycles spent waiting at the barriers of the main loop, [12..15]: loop cycles of wave 0, the
+// courier's spin cycles, the producers' cycles between barriers (wave 5), steps
+__device__ unsigned long long g_wf_wait[4096 * 16];
+#define WF_BARRIER(acc_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long b0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_barrier" ::: "memory"); (acc_) += __builtin_amdgcn_s_memtime() - b0_; } while (0)
+#else
+#define WF_BARRIER(acc_) ST_BARRIER()
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -476,19 +482,30 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
 // Arithmetic and its order are st_direct.hip's (bit-identical results; ILUPP_NO_WR=1 runs the old kernels).
 // =============================================================================================
 static constexpr int kWfH = 4;                            // steps of hand-off history (kept twice: slot s and s + 4)
-static constexpr int kWfRow = kThreads + 64 + 16;         // doubles per slot: lanes, courier pairs, [320] a cell of ones / zeros (+ padding: 4 rows = 21 x 512 B)
-static constexpr int kWfCell = kThreads + 64;
+#ifdef WF_HALF
+// experiment: a workgroup runs the first 128 lanes of its slots only (schedules made with ILUPP_TILE_TZ=8: patches of 16 x 8 lines), with
+// half the LDS, so that two workgroups share a CU
+static constexpr int kWfLanes = 128, kWfPairs = 32;
+#else
+static constexpr int kWfLanes = kThreads, kWfPairs = 64;
+#endif
+static constexpr int kWfRow = kWfLanes + kWfPairs + 16;   // doubles per slot: lanes, courier pairs, [320] a cell of ones / zeros (+ padding: 4 rows = 21 x 512 B)
+static constexpr int kWfCell = kWfLanes + kWfPairs;
 static constexpr int kWfArr = 2 * kWfH * kWfRow * 8;      // bytes of one hand-off array
 static constexpr int kWfPitch = 80;                       // bytes of a lane's record in the row ring: 8 doubles + 16 (a wave's 16-byte loads and the producers' 8-byte stores then spread over the banks)
-static constexpr int kWfSlot = kThreads * kWfPitch;       // bytes of a step of the row ring
+static constexpr int kWfSlot = kWfLanes * kWfPitch;       // bytes of a step of the row ring
 static constexpr int kWfRing = 4 * kWfSlot;               // two blocks of two steps
 static constexpr unsigned kWfX = kWfRing;                 // pivots
 static constexpr unsigned kWfTB = kWfRing + kWfArr;       // a'B of every row (and the courier's transposed entries)
 static constexpr unsigned kWfTC = kWfRing + 2 * kWfArr;   // a'C
 static constexpr int kWfLds = kWfRing + 3 * kWfArr + 64;
+#ifdef WF_HALF
+static constexpr int kWfProd = 3, kWfPer = 6, kWfRA = 4;
+#else
 static constexpr int kWfProd = 6, kWfPer = 6, kWfRA = 4;  // producer waves, groups of 8 lanes per wave, blocks read ahead
-static constexpr int kWfThreads = kThreads + 64 + 64 * kWfProd;
-static_assert(kWfProd * kWfPer * 8 >= kThreads, "every lane needs a producer");
+#endif
+static constexpr int kWfThreads = kWfLanes + 64 + 64 * kWfProd;
+static_assert(kWfProd * kWfPer * 8 >= kWfLanes, "every lane needs a producer");
 static_assert((kWfH * kWfRow * 8) % 512 == 0, "the two copies of a hand-off value are stored with one ds_write2st64_b64");
 
 struct WfArgs {
@@ -587,6 +604,11 @@ __device__ __forceinline__ void wf_consumer(const WfArgs &A, unsigned char *lds,
     double w3prev = 1.0, upA = 0.0;                         // the pivot of the lane's previous row; that row's own-chain entry right of the diagonal
     double qC = 1.0;                                        // the pivot of lane - 16 (asked for at the end of the step before)
     int k = tlo - sk;
+    unsigned long long wacc_ = 0;
+#ifdef WX_STAMP
+    const unsigned long long wt0_ = __builtin_amdgcn_s_memtime();
+#endif
+    (void)wacc_;
     for (int tb = tlo; tb < thi; tb += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -653,9 +675,12 @@ __device__ __forceinline__ void wf_consumer(const WfArgs &A, unsigned char *lds,
             n0_ = m0_; n1_ = m1_; n2_ = m2_; n3_ = m3_;
             bB = nB; bC = nC; tB = ntB; tC = ntC;
             ++k;
-            ST_BARRIER();
+            WF_BARRIER(wacc_);
         }
     }
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + wv] = wacc_; if (wv == 0) { g_wf_wait[wg * 16 + 12] = __builtin_amdgcn_s_memtime() - wt0_; g_wf_wait[wg * 16 + 15] = (unsigned long long)(thi - tlo); } }
+#endif
 #undef WF_ROW
 #undef WF_HAND_T
 #undef WF_ENDS
@@ -682,8 +707,9 @@ __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long 
     const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.xch);
     const unsigned span = (unsigned)P.cnt;
-    const unsigned hoX = kWfX + (unsigned)((kWfH * kWfRow + kThreads + ln) * 8);
-    const unsigned hoT = kWfTB + (unsigned)((kWfH * kWfRow + kThreads + ln) * 8);
+    // (a courier lane beyond the pair slots delivers to a place of the padding nobody reads)
+    const unsigned hoX = kWfX + (unsigned)((kWfH * kWfRow + (ln < kWfPairs ? kWfLanes + ln : kWfCell + 8)) * 8);
+    const unsigned hoT = kWfTB + (unsigned)((kWfH * kWfRow + (ln < kWfPairs ? kWfLanes + ln : kWfCell + 8)) * 8);
     // exports (wx_courier)
     const int E = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
     const int xrow0 = A.xw[wg * 4 + 3] + (tlo - A.xw[wg * 4 + 1]) * E;
@@ -737,12 +763,20 @@ __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long 
     }
     ST_BARRIER();
     ST_BARRIER();
+    unsigned long long wacc_ = 0, sacc_ = 0;
+    (void)wacc_; (void)sacc_;
     for (int tb = tlo; tb < thi; tb += 8) {
         const int tlo_ = tb;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+#ifdef WX_STAMP
+            const unsigned long long d0_ = __builtin_amdgcn_s_memtime();
+#endif
             WFC_DELIVER(u + SH);
-            ST_BARRIER();
+#ifdef WX_STAMP
+            sacc_ += __builtin_amdgcn_s_memtime() - d0_;
+#endif
+            WF_BARRIER(wacc_);
             {
                 const double v = st_lds(lds, ea + (unsigned)(u & 3) * (kWfRow * 8));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v), rx, vx, 0, 16);          // sc1: write-through
@@ -754,6 +788,9 @@ __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long 
 #undef WFC_ADDR
 #undef WFC_AT
 #undef WFC_LDAT
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 4] = wacc_; g_wf_wait[wg * 16 + 13] = sacc_; }
+#endif
     if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
 }
 
@@ -776,7 +813,7 @@ __device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds,
 #pragma unroll
     for (int i = 0; i < kWfPer; ++i) {
         const int l = (pw * kWfPer + i) * 8 + lg;
-        const bool live = l < kThreads;
+        const bool live = l < kWfLanes;
         // (the lane's fields and the canonical places of its row's positions: put into LDS by the lane itself, k_ilu0_wx)
         const int4 lp = s_lane[live ? l : 0];                      // cnt, skew, first entry, flags (ST_DFL)
         const int cnt = lp.x, sk = lp.y, p0 = lp.z, fl = lp.w;
@@ -814,7 +851,7 @@ __device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds,
 #define WFP_WRITE(rb, parity)                                                              \
     do {                                                                                   \
         _Pragma("unroll") for (int i = 0; i < kWfPer; ++i) {                               \
-            if ((pw * kWfPer + i) * 8 < kThreads) {                                        \
+            if ((pw * kWfPer + i) * 8 < kWfLanes) {                                        \
                 typedef unsigned long long u64_;                                           \
                 const v4u x_ = ra[rb][i];                                                  \
                 const u64_ lo_ = ((u64_)x_.y << 32) | x_.x, hi_ = ((u64_)x_.w << 32) | x_.z; \
@@ -832,17 +869,29 @@ __device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds,
     WFP_LOAD(1);
     ST_BARRIER();                                           // (the lanes read their first two rows behind this one)
     ST_BARRIER();
+    unsigned long long wacc_ = 0, pacc_ = 0;
+    (void)wacc_; (void)pacc_;
     for (int tb = tlo; tb < thi; tb += 8) {
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
             // steps 2 bb and 2 bb + 1 of this trip: the lanes read the rows of steps 2 bb + 2 and 2 bb + 3 (block bb + 1); block bb + 2
             // takes the place of block bb, whose rows were read two steps ago
-            ST_BARRIER();
+            WF_BARRIER(wacc_);
+#ifdef WX_STAMP
+            const unsigned long long p0_ = __builtin_amdgcn_s_memtime();
+#endif
             WFP_WRITE((bb + 2) & 3, bb & 1);
             WFP_LOAD((bb + 2) & 3);
-            ST_BARRIER();
+#ifdef WX_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pacc_ += __builtin_amdgcn_s_memtime() - p0_;
+#endif
+            WF_BARRIER(wacc_);
         }
     }
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 5 + pw] = wacc_; if (pw == 0) g_wf_wait[wg * 16 + 14] = pacc_; }
+#endif
 #undef WFP_LOAD
 #undef WFP_WRITE
 }
@@ -852,9 +901,9 @@ k_ilu0_wx(WfArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ WfPair s_pairs[64];
-    __shared__ int s_exp[kThreads];
-    __shared__ int4 s_lane[kThreads];                     // per lane: cnt, skew, first entry of A, ST_DFL -- for the producers
-    __shared__ unsigned char s_place[kThreads * 8];       // per lane and row position: canonical place + 1 (0: the lane has no such position)
+    __shared__ int s_exp[kWfLanes];
+    __shared__ int4 s_lane[kWfLanes];                     // per lane: cnt, skew, first entry of A, ST_DFL -- for the producers
+    __shared__ unsigned char s_place[kWfLanes * 8];       // per lane and row position: canonical place + 1 (0: the lane has no such position)
     __shared__ int s_cnt[4], s_total;
     __shared__ unsigned s_ticket;
     if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
@@ -874,10 +923,11 @@ k_ilu0_wx(WfArgs A)
     // the row ring and the hand-off arrays start all +0.0 (what no producer piece goes to stays that way); the cells of ones
     for (int i = t; i < kWfLds / 8; i += kWfThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
     if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; s_pairs[t] = z; }
-    if (t < kThreads) s_exp[t] = -1;
+    if (t < kWfLanes) s_exp[t] = -1;
+    if (t < 4) s_cnt[t] = 0;
     __syncthreads();
     if (t < 2 * kWfH) *reinterpret_cast<double *>(lds + kWfX + (unsigned)((t * kWfRow + kWfCell) * 8)) = 1.0;
-    if (t < kThreads) {
+    if (t < kWfLanes) {
         const int slot = wg * kThreads + t;
         const int32_t *T = A.ltab + (size_t)slot * kStTab;
         const int nd = T[ST_ND], cnt = T[ST_CNT];
@@ -950,9 +1000,9 @@ k_ilu0_wx(WfArgs A)
             for (int j = 0; j < 3; ++j) {
                 if (isg[j]) {
                     const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
-                    if (p < 64) s_pairs[p] = gp[j];
-                    xg[j] = kWfX + (unsigned)((kWfH * kWfRow + kThreads + min(p, 63)) * 8);
-                    tg[j] = kWfTB + (unsigned)((kWfH * kWfRow + kThreads + min(p, 63)) * 8);
+                    if (p < kWfPairs) s_pairs[p] = gp[j];
+                    xg[j] = kWfX + (unsigned)((kWfH * kWfRow + kWfLanes + min(p, kWfPairs - 1)) * 8);
+                    tg[j] = kWfTB + (unsigned)((kWfH * kWfRow + kWfLanes + min(p, kWfPairs - 1)) * 8);
                 }
                 before += __popcll(bal[j]);
             }
@@ -988,10 +1038,10 @@ k_ilu0_wx(WfArgs A)
         }
         {
             const int xe = A.xe[slot];
-            if (cnt > 0 && xe >= 0 && xe < kThreads) s_exp[xe] = t;
+            if (cnt > 0 && xe >= 0 && xe < kWfLanes) s_exp[xe] = t;
         }
         __syncthreads();
-        if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], 1);  // (the analysis does not let such a schedule through)
+        if ((t == 0 && s_total > kWfPairs) || !ok) atomicExch(&A.ctrl[1], 1);  // (the analysis does not let such a schedule through)
 #ifdef WX_STAMP
         if (t == 0 && wg < 4096) g_wf_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -999,16 +1049,16 @@ k_ilu0_wx(WfArgs A)
 #ifdef WX_STAMP
         if (t == 0 && wg < 4096) g_wf_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
-    } else if (t < kThreads + 64) {
+    } else if (t < kWfLanes + 64) {
         __syncthreads();
         __syncthreads();
-        const WfPair P = s_pairs[t - kThreads];
+        const WfPair P = s_pairs[t - kWfLanes];
         const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
         wf_courier(A, idle, lds, P, tlo, thi, wg, s_exp);
     } else {
         __syncthreads();
         __syncthreads();
-        wf_producer(A, lds, wg, (t - kThreads - 64) >> 6, tlo, thi, s_lane, s_place);
+        wf_producer(A, lds, wg, (t - kWfLanes - 64) >> 6, tlo, thi, s_lane, s_place);
     }
 }
 
@@ -1051,6 +1101,7 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
 #ifdef WX_STAMP
 void wx_read_stamps(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wx_stamp), sizeof(unsigned long long) * 16)); }
 void wf_read_tl(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_tl), sizeof(unsigned long long) * 4096 * 4)); }
+void wf_read_wait(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_wait), sizeof(unsigned long long) * 4096 * 16)); }
 #endif
 
 }  // namespace ilupp
@@ -1059,6 +1110,11 @@ void wf_read_tl(unsigned long long *out) { ILUPP_HIP(hipMemcpyFromSymbol(out, HI
 extern "C" int ilupp_hip_debug_wx_stamps(unsigned long long *out)
 {
     try { ilupp::wx_read_stamps(out); } catch (...) { return -1; }
+    return 0;
+}
+extern "C" int ilupp_hip_debug_wf_wait(unsigned long long *out)
+{
+    try { ilupp::wf_read_wait(out); } catch (...) { return -1; }
     return 0;
 }
 extern "C" int ilupp_hip_debug_wf_timeline(unsigned long long *out)
