@@ -346,11 +346,11 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     // three dimensions, and ONE streaming kernel on the side stream proves the guess for every row while the lane tables are built.
     GridDims gd = {0, 0, 0};
     bool grid = head != nullptr && p->side != nullptr && grid_guess(A.n, A.nnz, head, &gd);
-    // where the proof runs: 1 (default) = on the object's stream before the lane-table kernels, 0 = on the side stream next to them, 2 = on
+    // where the proof runs: 0 (default) = on the side stream next to the lane-table kernels, 1 = on the object's stream before them, 2 = on
     // the side stream next to the factor kernel.  Its verdict comes home with the construction's last read-back in every case.  (Measured
-    // at 256^3: the lane-table kernels are chains of dependent loads and the factor kernel lives on short hand-over latencies -- next to a
-    // 4.6 TB/s stream the former take 2x as long and the latter loses more time than the proof takes: step 2.24 / 2.26 / 2.32 ms for 1 / 0 / 2)
-    static const int grid_mode = []() { const char *e = getenv("ILUPP_GRID_CHECK_AT"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 2) ? v : 1; }();
+    // at 256^3: k_grid_lanes only stores and the skew fixpoint lives in LDS, so they lose little next to the 4.6 TB/s stream of the proof --
+    // analysis 0.23 ms for 0, 0.26 for 1; the factor kernel lives on short hand-over latencies and loses more than the proof takes: 2)
+    static const int grid_mode = []() { const char *e = getenv("ILUPP_GRID_CHECK_AT"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
     int32_t grid_bad = 0;
     bool lm = false;
     for (;;) {

@@ -224,6 +224,9 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
     for (int u = 0; u < kStRA; ++u) { WXS_LOAD(u); asm volatile("" ::: "memory"); }
     // (the courier's values of the first two steps are in place)
     ST_BARRIER();
+#ifdef WX_PRIO
+    __builtin_amdgcn_s_setprio(WX_PRIO);
+#endif
     double xprev = 0.0;
     double bB = st_lds(xh, W.aB), bC = st_lds(xh, W.aC);               // the hand-off values of the first step
     int k = tlo - sk;
@@ -592,6 +595,9 @@ __device__ __forceinline__ void wf_consumer(const WfArgs &A, unsigned char *lds,
         }                                                                                                          \
     } while (0)
     ST_BARRIER();                                           // (the producers' first two blocks and the courier's first entries are in place)
+#ifdef WF_PRIO
+    __builtin_amdgcn_s_setprio(WF_PRIO);                    // (experiment: the waves on the chain before the couriers and producers that share their SIMDs)
+#endif
     v2dd c0_, c1_, c2_, c3_;                                // the row of the current step: {aC, aB} {aA, d} {a'A, a'B} {a'C, -}
     v2dd n0_, n1_, n2_, n3_;                                // ... of the next step
     WF_ROW(0, c0_, c1_, c2_, c3_);
