@@ -1278,6 +1278,8 @@ const char *ilupp_hip_analysis_path(const ilupp_precond *p)
 const char *ilupp_hip_kernel_names(const ilupp_precond *p)
 {
     if (!p || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU && p->flm.built && p->flm.stat)) return "";
+    if (p->pkL.fmt == 1 && wx_vec_on() && p->pkL.vec_ok && p->pkU.vec_ok)
+        return p->flm.wxf ? "k_ilu0_wx;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>" : "k_ilu0_sd;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>";
     if (p->pkL.fmt == 1) return p->flm.wxf ? "k_ilu0_wx;k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>" : "k_ilu0_sd;k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>";
     return p->flm.direct ? "k_ilu0_sd;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>" : "k_ilu0_st;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>";
 }

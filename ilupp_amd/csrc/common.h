@@ -132,6 +132,7 @@ struct PackedSweep {
     // table; the records then hold values only (2 KB per chunk, absent entries = kAbsent)
     bool stat = false;
     bool wx = false;            // every lane of the schedule fits the wave-exchange kernels (st_wave.hip; st_common.h: wx_lane_ok)
+    bool vec_ok = false;        // ... and no more than 16 lanes of a workgroup share a skew modulo 16 (st_wave.hip: the vector wave serves two instructions of 8 lanes per step)
     int fmt = 0;                // static records: 0 = by template position, kAbsent where there is no entry; 1 = class-aligned, +0.0 (st_wave.hip)
     int32_t *ltab = nullptr;    // nslots x kStTab ints
     double *dump = nullptr;     // where the stores of lanes without a row go
@@ -297,6 +298,7 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
 void finish_chains(Schedule *fwd, Schedule *bwd);
+bool wx_vec_on();            // st_wave.hip: the sweeps move the caller's vector through their vector wave (no level-major copies, no k_st_vec)
 // grid.hip: the first analysis pass for lexicographic box-grid stencil matrices (guess from row 0, proof on a side stream)
 struct GridDims { int32_t nx, ny, nz; };
 bool grid_guess(int32_t n, int64_t nnz, const int32_t *head /* ptr[0], ptr[1], idx[0..7] */, GridDims *g);

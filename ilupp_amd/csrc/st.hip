@@ -1423,8 +1423,13 @@ k_st_xch_pair(StXchArgs F, StXchArgs B, int32_t nwg, int32_t *__restrict__ tot)
     const int slot = wg * kThreads + t;
     const int32_t *T = X.ltab + (size_t)slot * kStTab;
     const bool ex = T[ST_CNT] > 0 && X.exported[slot] != 0;
+    __shared__ int s_phase[16];
     if (t == 0) s_pairs = 0;
+    if (t < 16) s_phase[t] = 0;
     __syncthreads();
+    // (st_wave.hip's vector wave serves the lanes whose skew is congruent to the step modulo 16 with two instructions of 8 lanes: flags[9] & 8
+    // when a workgroup has more than 16 such lanes)
+    if (T[ST_CNT] > 0 && atomicAdd(&s_phase[T[ST_SKEW] & 15], 1) >= 16) atomicOr(&X.flags[9], 8);
     int ng = 0;
     for (int j = 0; j < 3; ++j) ng += (j < T[ST_ND] && T[ST_CNT] > 0 && (T[ST_SRC + j] & 3) == ST_GHOST) ? 1 : 0;
     if (ng) atomicAdd(&s_pairs, ng);
@@ -1608,7 +1613,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     ILUPP_HIP(pool_malloc(&pl->xch, sizeof(double) * (size_t)pl->xch_len));
     ILUPP_HIP(pool_malloc(&pu->xch, sizeof(double) * (size_t)pu->xch_len));
     f->direct = try_direct && hl[8] == 0;
-    f->wxf = f->direct && hl[9] == 0 && hu[9] == 0 && hl[10] == 0 && st_wx_on() && getenv("ILUPP_NO_WXF") == nullptr;
+    f->wxf = f->direct && (hl[9] & ~8) == 0 && (hu[9] & ~8) == 0 && hl[10] == 0 && st_wx_on() && getenv("ILUPP_NO_WXF") == nullptr;
     if (!f->direct) {
         // lanes not uniform enough for the direct feed: factor records made by the rows pass (it proves what they rely on, row by row)
         if (dbg && try_direct) fprintf(stderr, "[ilupp] static analysis: lanes not uniform (flags %d): factor records\n", hl[8]);
@@ -1624,7 +1629,8 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     }
     pl->valid = pu->valid = true;
     pl->stat = pu->stat = true;
-    pl->wx = hl[9] == 0; pu->wx = hu[9] == 0;
+    pl->wx = (hl[9] & ~8) == 0; pu->wx = (hu[9] & ~8) == 0;
+    pl->vec_ok = pl->wx && (hl[9] & 8) == 0; pu->vec_ok = pu->wx && (hu[9] & 8) == 0;
     if (dbg) fprintf(stderr, "[ilupp] static analysis: wave-exchange kernels: forward %s, backward %s\n", pl->wx ? "yes" : "no", pu->wx ? "yes" : "no");
     pu->linked = true;
     f->built = true;

@@ -213,6 +213,7 @@ struct StSArgs {
     const int32_t *xe, *xw;                   // the exchange between workgroups (PackedSweep::xe, xw, xch): all-sentinel before the sweep
     double *xch;
     int32_t *ticket, *err;
+    double *nat;                              // (st_wave.hip, vector wave) the caller's vector in natural order: read by the forward sweep, written by the backward one
 };
 
 #ifndef ST_CSLEEP

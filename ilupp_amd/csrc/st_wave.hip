@@ -170,8 +170,15 @@ __device__ __forceinline__ bool wx_lane_setup(const int32_t *T, const int t, con
 // ---------------------------------------------------------------------------------------------
 // the 256 lanes of the schedule.  DR = +1 forward, -1 backward; DIV: divide by the record's diagonal
 // ---------------------------------------------------------------------------------------------
-template <int DR, bool DIV>
-__device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *xh, const int wg, const WxLane W, const int tlo, const int thi)
+// VEC: the caller's vector (natural order) travels through a ring in LDS that a sixth wave of the workgroup fills (forward: the
+// right-hand side) or drains (backward: the result) in whole 128-byte lines -- wx_vector below: no level-major copy of the vector, no
+// conversion kernels, one vector-memory instruction less per step in the waves on the chain.
+static constexpr int kVecPitch = 34 * 8;                  // bytes of a lane's 32 ring entries (+ 2: the lanes of a wave spread over the banks)
+static constexpr int kVecRing = kThreads * kVecPitch;
+
+template <int DR, bool DIV, bool VEC>
+__device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *xh, const int wg, const WxLane W, const int tlo, const int thi,
+                                              unsigned char *vr)
 {
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
     const int slot = wg * kThreads + t;
@@ -213,7 +220,7 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
     do {                                                                                               \
         ra[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rrec, vrec, 0, 0);                            \
         ra[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rrec, vrec + 1024u, 0, 0);                    \
-        rr[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rrhs, vrhs, 0, 0));    \
+        if (!(VEC && DR > 0)) rr[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rrhs, vrhs, 0, 0)); \
         vrec += dRec; vrhs += dRhs;                                                                    \
     } while (0)
 #endif
@@ -230,6 +237,8 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
     double xprev = 0.0;
     double bB = st_lds(xh, W.aB), bC = st_lds(xh, W.aC);               // the hand-off values of the first step
     int k = tlo - sk;
+    const unsigned vbase = (unsigned)t * kVecPitch;                    // (VEC) this lane's ring
+    double bR = (VEC && DR > 0) ? st_lds(vr, vbase + (((unsigned)k & 31u) << 3)) : 0.0;
 #ifdef WX_STAMP
     const unsigned long long st0_ = __builtin_amdgcn_s_memtime(), sr0_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -239,6 +248,8 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
             // the hand-off values of the NEXT step: stored before the barrier this wave has just passed
             const double nB = st_lds(xh, W.aB + (unsigned)((u + 1) % kStH) * (kWxRow * 8));
             const double nC = st_lds(xh, W.aC + (unsigned)((u + 1) % kStH) * (kWxRow * 8));
+            // (VEC, forward) the right-hand side of the next step: in the ring since at least kVecLead steps
+            const double nR = (VEC && DR > 0) ? st_lds(vr, vbase + (((unsigned)(k + 1) & 31u) << 3)) : 0.0;
             const bool valid = (unsigned)k < (unsigned)cnt;
             const double alt = valid ? st_dbl(kCanonNaN) : 0.0;
             const v2dd c01 = __builtin_bit_cast(v2dd, ra[u][0]), c2d = __builtin_bit_cast(v2dd, ra[u][1]);
@@ -251,7 +262,7 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
 #endif
             const double sC = W.ringC ? bC : pC;
             const double xs0 = DR > 0 ? sC : xprev, xs2 = DR > 0 ? xprev : sC;
-            double acc = rr[u];
+            double acc = (VEC && DR > 0) ? bR : rr[u];
             acc = acc - c01.x * xs0;
             acc = acc - c01.y * sB;
             acc = acc - c2d.x * xs2;
@@ -266,11 +277,12 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
 #endif
             xprev = x;
 #ifndef WX_X_NOMEM
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, x), rout, DR > 0 ? vrhs - (unsigned)kStRA * 512u : vout, 0, 2);
+            if (VEC && DR < 0) *reinterpret_cast<double *>(vr + vbase + (((unsigned)k & 31u) << 3)) = x;      // (the vector wave takes it from there)
+            else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, x), rout, vout, 0, 2);
 #endif
             vout += 512u;
             WXS_LOAD(u);
-            bB = nB; bC = nC;
+            bB = nB; bC = nC; bR = nR;
             ++k;
 #ifdef WX_X_NOBAR
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -373,11 +385,159 @@ __device__ __forceinline__ void wx_courier(const unsigned long long *src, const 
     if (dead && ln == 0) atomicExch(err, 1);
 }
 
-template <int DR, bool DIV>
-__global__ void __launch_bounds__(kStWgThreads)
-k_sptrsv_wx(StSArgs A)
+// ---------------------------------------------------------------------------------------------
+// the vector wave (VEC).  A lane's rows 16 g .. 16 g + 15 (group g) are ONE 128-byte line of the caller's vector: eight threads move it,
+// 16 bytes each, as whole lines.  The ring holds two groups per lane (entry k mod 32).  Lane t reaches group g at step 16 g + skew(t), so
+// the lanes whose skew is congruent to the step modulo 16 are served at that step ("phase"; 16 lanes of a 16 x 16 patch per phase = two
+// instructions of 8 lanes):
+//   forward:  load group g + 1 (its half of the ring was read for the last time two steps ago), store it into the ring kVecLead steps
+//             later -- 8 steps before the lane reads its first entry;
+//   backward: group g - 1 has just been completed: read it from the ring, store it (descending rows: the pairs swapped).
+// Per step: 2 loads + 2 LDS stores (forward), 2 LDS loads + 2 stores (backward; + 2 for chains of odd length).
+// ---------------------------------------------------------------------------------------------
+static constexpr int kVecSlots = 2;                       // instructions of 8 lanes per phase
+struct VecLds { int first[kThreads], cnt[kThreads], sk[kThreads]; int plist[kThreads]; int pstart[17]; int pcnt[16]; int odd; };
+
+static constexpr int kVecRecs = 16 * kVecSlots * 64;                // one 16-byte record per (phase, instruction, thread) ...
+static constexpr int kVecDyn = kVecRing + 64 + kVecRecs * 16;       // ... behind the ring (and its dump place) in the dynamic LDS
+
+template <int DR>
+__device__ __forceinline__ void wx_vector(const StSArgs &A, unsigned char *vr, VecLds *V, const int tlo, const int thi)
+{
+    typedef double v2dd __attribute__((ext_vector_type(2)));
+    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+    const int ln = threadIdx.x & 63, j = ln & 7, grp = ln >> 3;
+    // the phases' lane lists (this wave alone: LDS operations of one wave are in order)
+    if (ln < 16) V->pcnt[ln] = 0;
+    if (ln == 0) V->odd = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int myp[4], mypos[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tt = ln + 64 * i;
+        myp[i] = V->cnt[tt] > 0 ? (V->sk[tt] & 15) : -1;
+        mypos[i] = myp[i] >= 0 ? atomicAdd(&V->pcnt[myp[i]], 1) : 0;
+        if (V->cnt[tt] > 0 && (V->cnt[tt] & 1)) V->odd = 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ln == 0) { int run = 0; for (int p = 0; p < 16; ++p) { V->pstart[p] = run; run += V->pcnt[p]; } V->pstart[16] = run; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (myp[i] >= 0) {
+            if (mypos[i] >= 8 * kVecSlots) over = true; else V->plist[V->pstart[myp[i]] + mypos[i]] = ln + 64 * i;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (__builtin_amdgcn_ballot_w64(over) != 0 && ln == 0) atomicExch(A.err, 1);      // (the analysis does not let such a schedule through: flags[9] & 8)
+    const bool odd = __builtin_amdgcn_readfirstlane(V->odd) != 0;
+    const int thiR = tlo + ((thi - tlo + kStRA - 1) & ~(kStRA - 1));      // (the other waves run whole trips of kStRA steps: as many barriers here)
+    const __amdgpu_buffer_rsrc_t rnat = __builtin_amdgcn_make_buffer_rsrc(A.nat, 0, (int)((unsigned)A.n * 8u), 0x00020000);
+    // What this thread does for instruction q of a step of phase p, as ONE record {c1, c2, cnt, c3} (a step then costs this wave one
+    // 16-byte LDS load per instruction, not a chain of table look-ups).  With lane tt of the phase, its skew sk and this thread's pair j:
+    //   forward (phase of step s: (s + 8) mod 16; the lane starts group m = (s + 8 - sk) / 16 eight steps later and group m + 1 is asked
+    //     for): first row of the pair k0 = s + c2, c2 = 24 + 2 j - sk; vector offset c1 + 8 s, c1 = 8 (first + c2); ring place
+    //     c3 + 8 (k0 mod 32), c3 = tt * pitch;
+    //   backward (phase s mod 16; group (s - sk) / 16 - 1 is complete): lower row of the pair kk = s + c2, c2 = -sk - 2 - 2 j; vector
+    //     offset c1 - 8 s, c1 = 8 (first - 1 - c2); ring place as above.
+    int4 *rec = reinterpret_cast<int4 *>(vr + kVecRing + 64);
+    for (int pq = 0; pq < 16 * kVecSlots; ++pq) {
+        const int p = pq / kVecSlots, q = pq % kVecSlots;
+        int4 r = make_int4(0, 0, 0, 0);
+        if (8 * q + grp < V->pcnt[p]) {
+            const int tt = V->plist[V->pstart[p] + 8 * q + grp];
+            const int sk = V->sk[tt], c2 = DR > 0 ? 24 + 2 * j - sk : -sk - 2 - 2 * j;
+            r.x = DR > 0 ? 8 * (V->first[tt] + c2) : 8 * (V->first[tt] - 1 - c2);
+            r.y = c2; r.z = V->cnt[tt]; r.w = tt * kVecPitch;
+        }
+        rec[pq * 64 + ln] = r;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (DR > 0) {
+        // groups 0 and 1 of every lane before the first step (what the steps before tlo would have asked for)
+#pragma unroll 1
+        for (int b0 = 0; b0 < kThreads / 8; b0 += 4) {
+            v4u hold[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int tt = (b0 + (i & 3)) * 8 + grp;
+                const int k0 = 2 * j + 16 * (i >> 2);
+                unsigned off = (V->cnt[tt] > 0 && k0 < V->cnt[tt]) ? (unsigned)(V->first[tt] + k0) * 8u : 0xfffffff0u;
+                asm volatile("" : "+v"(off));
+                hold[i] = __builtin_amdgcn_raw_buffer_load_b128(rnat, off, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int tt = (b0 + (i & 3)) * 8 + grp;
+                *reinterpret_cast<v4u *>(vr + (unsigned)tt * kVecPitch + (unsigned)(2 * j + 16 * (i >> 2)) * 8u) = hold[i];
+            }
+        }
+        ST_BARRIER();
+        v4u ring[kStRA][kVecSlots];
+        unsigned dst[kStRA][kVecSlots];
+#pragma unroll
+        for (int u = 0; u < kStRA; ++u)
+#pragma unroll
+            for (int q = 0; q < kVecSlots; ++q) { ring[u][q] = v4u{0, 0, 0, 0}; dst[u][q] = (unsigned)kVecRing; }     // (the dump place behind the ring)
+        static_assert(kStRA == 16, "a request goes into the ring one trip of the unrolled loop (16 steps) after it was made");
+        for (int tb = tlo; tb < thiR; tb += kStRA) {
+#pragma unroll
+            for (int u = 0; u < kStRA; ++u) {
+                const int s = tb + u;
+                int4 r[kVecSlots];
+#pragma unroll
+                for (int q = 0; q < kVecSlots; ++q) r[q] = rec[(((u + 8) & 15) * kVecSlots + q) * 64 + ln];
+#pragma unroll
+                for (int q = 0; q < kVecSlots; ++q) {
+                    // what was asked for 16 steps ago goes into the ring (its half was read for the last time 9 steps ago, its first entry
+                    // is read in 7), the next request takes its place
+                    *reinterpret_cast<v4u *>(vr + dst[u][q]) = ring[u][q];
+                    const int k0 = s + r[q].y;
+                    const bool ok = (unsigned)k0 < (unsigned)r[q].z;
+                    // (ONE load instruction whatever `ok` says: as two loads in two branches the compiler can no longer count what is in
+                    // flight and waits for everything, every step -- the offsets are pinned as values before the instruction)
+                    unsigned lo_ = ok ? (unsigned)(r[q].x + 8 * s) : 0xfffffff0u;
+                    unsigned ds_ = ok ? (unsigned)r[q].w + (((unsigned)k0 & 31u) << 3) : (unsigned)kVecRing;
+                    asm volatile("" : "+v"(lo_), "+v"(ds_));
+                    ring[u][q] = __builtin_amdgcn_raw_buffer_load_b128(rnat, lo_, 0, 0);
+                    dst[u][q] = ds_;
+                }
+                ST_BARRIER();
+            }
+        }
+    } else {
+        ST_BARRIER();
+        // at step s the groups completed by step s - 1 leave; after the last step the rest (no more barriers: everything is in the ring)
+        const int tend = thiR + 16;
+        for (int tb = tlo; tb < tend; tb += kStRA) {
+#pragma unroll
+            for (int u = 0; u < kStRA; ++u) {
+                const int s = tb + u;
+#pragma unroll
+                for (int q = 0; q < kVecSlots; ++q) {
+                    const int4 r = rec[((u & 15) * kVecSlots + q) * 64 + ln];
+                    const int kk = s + r.y;                               // the pair's rows: kk (higher address), kk + 1 (lower address)
+                    const bool hi_ok = (unsigned)kk < (unsigned)r.z, lo_ok = hi_ok && kk + 1 < r.z;
+                    const v2dd pr = *reinterpret_cast<const v2dd *>(vr + (unsigned)r.w + (((unsigned)kk & 31u) << 3));
+                    v2dd sw; sw.x = pr.y; sw.y = pr.x;                    // {x(kk + 1), x(kk)}: ascending addresses
+                    const unsigned fo = (unsigned)(r.x - 8 * s);
+                    unsigned o2_ = lo_ok ? fo : 0xfffffff0u, o1_ = (hi_ok && !lo_ok) ? fo + 8u : 0xfffffff0u;
+                    asm volatile("" : "+v"(o2_), "+v"(o1_));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, sw), rnat, o2_, 0, 2);
+                    if (odd) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, pr.x), rnat, o1_, 0, 2);
+                }
+                if (s < thiR) ST_BARRIER();
+            }
+        }
+    }
+}
+
+template <int DR, bool DIV, bool VEC>
+__device__ __forceinline__ void wx_sweep_body(const StSArgs &A, unsigned char *vr)
 {
     __shared__ __attribute__((aligned(16))) unsigned char xh[kWxLds];
+    __shared__ VecLds s_vec;
     __shared__ StPair s_pairs[64];
     __shared__ int s_exp[kThreads];
     __shared__ int s_cnt[4], s_total;
@@ -403,6 +563,7 @@ k_sptrsv_wx(StSArgs A)
         bool isg[3]; int idx0[3], stride[3]; unsigned va[3];
         st_lane_sources(T, t, A.ltab, A.xe, A.xw, isg, idx0, stride, va, kWxRow);
         s_exp[t] = -1;
+        if (VEC) { s_vec.first[t] = T[ST_FIRST]; s_vec.cnt[t] = T[ST_CNT]; s_vec.sk[t] = T[ST_SKEW]; }
         __syncthreads();                                              // (s_pairs zeroed, s_exp cleared)
         st_number_pairs(T, t, isg, idx0, stride, va, s_pairs, s_cnt, &s_total, kWxRow);
         WxLane W;
@@ -416,7 +577,12 @@ k_sptrsv_wx(StSArgs A)
         for (int i = t; i < 2 * kStH * kWxRow; i += kThreads) reinterpret_cast<double *>(xh)[i] = 0.0;
         __syncthreads();
         if ((t == 0 && s_total > 64) || !ok) atomicExch(A.err, 1);    // (the analysis does not let such a schedule through)
-        wx_sweep_wave<DR, DIV>(A, xh, wg, W, tlo, thi);
+        wx_sweep_wave<DR, DIV, VEC>(A, xh, wg, W, tlo, thi, vr);
+    } else if (VEC && t >= kThreads + 64) {
+        __syncthreads();                                              // (the lanes' fields are in s_vec)
+        __syncthreads();
+        __syncthreads();
+        wx_vector<DR>(A, vr, &s_vec, tlo, thi);
     } else {
         __syncthreads();
         __syncthreads();                                              // (the one inside st_number_pairs)
@@ -432,6 +598,27 @@ k_sptrsv_wx(StSArgs A)
     }
 }
 
+template <int DR, bool DIV>
+__global__ void __launch_bounds__(kStWgThreads)
+k_sptrsv_wx(StSArgs A)
+{
+    wx_sweep_body<DR, DIV, false>(A, nullptr);
+}
+// ... with the vector wave: the caller's vector where it lies (A.nat)
+template <int DR, bool DIV>
+__global__ void __launch_bounds__(kStWgThreads + 64)
+k_sptrsv_wv(StSArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wv_ring[];
+    wx_sweep_body<DR, DIV, true>(A, wv_ring);
+}
+
+bool wx_vec_on()
+{
+    static const bool on = getenv("ILUPP_NO_VECWAVE") == nullptr;
+    return on;
+}
+
 // One sweep of an apply on format-1 records (sptrsv_st's interface)
 int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rhs, double *out, int32_t *d_ticket, int32_t *d_err,
               double *ypk_out, const double *ypk_in, const int32_t *ysrc)
@@ -445,6 +632,10 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
     a.xlm = lml; a.ylm = fwd ? nullptr : ps.xlm;
     a.ysrc = ysrc; a.xlm_chunks = (int32_t)(fwd ? ps.nchunks : ps.y_chunks);
     a.xe = ps.xe; a.xw = ps.xw; a.xch = ps.xch; a.ticket = d_ticket; a.err = d_err;
+    // the caller's vector where it lies, through the vector wave (the forward sweep reads `rhs`, the backward sweep writes `out`);
+    // ILUPP_NO_VECWAVE=1, or a schedule with more than 16 lanes in a phase: through the level-major copies that k_st_vec makes (round 4)
+    const bool vec = wx_vec_on() && ps.vec_ok;
+    a.nat = fwd ? const_cast<double *>(rhs) : out;
     fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
     {
         static std::once_flag once[64];      // once per device
@@ -453,10 +644,15 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
         std::call_once(once[dev & 63], [] {
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
         });
     }
     const dim3 grid((unsigned)ps.nwg);
-    if (fwd) {
+    if (vec) {
+        if (fwd) hipLaunchKernelGGL((k_sptrsv_wv<1, false>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
+        else hipLaunchKernelGGL((k_sptrsv_wv<-1, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
+    } else if (fwd) {
         st_vec_to_lm(st, ps, rhs, lml);
         hipLaunchKernelGGL((k_sptrsv_wx<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
