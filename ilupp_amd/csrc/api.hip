@@ -220,6 +220,7 @@ struct ilupp_precond {
     bool apply_events_valid = false;
     int max_lanes = 65536;
     bool grid_path = false;      // ILU(0): the row blocks came from grid.hip's guess (proven for every row)
+    bool ctrl_armed = false;     // the control words are zero and both exchange buffers all-sentinel already (arm_apply): the next plain apply starts with its first sweep
     bool borrowed_queue = false; // stream and events belong to another object (the levels of a multilevel preconditioner share one)
 };
 
@@ -302,10 +303,33 @@ int validate(const int32_t *indptr, int32_t n)
     return ILUPP_OK;
 }
 
+// What a plain apply of a static ILU(0) object needs before its first sweep -- control words zero, both exchange buffers all-sentinel --
+// as ONE launch BEHIND the last wait of the call before (construction, apply): it runs while the host is on its way back to the caller,
+// and the next apply is two launches, the sweeps.  (Before: a memset, two fills and their launch gaps inside every apply, 30 us of a 0.7 ms apply.)
+__global__ void k_arm_apply(int32_t *__restrict__ ctrl, unsigned long long *__restrict__ a, long long na, unsigned long long *__restrict__ b,
+                            long long nb, unsigned long long v)
+{
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (i0 < 16) ctrl[i0] = 0;
+    for (long long i = i0; i < na; i += stride) a[i] = v;
+    for (long long i = i0; i < nb; i += stride) b[i] = v;
+}
+static void arm_apply(ilupp_precond *p)
+{
+    static const bool off = getenv("ILUPP_NO_ARM") != nullptr;
+    if (off || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU && p->flm.built && p->flm.stat && p->pkL.valid && p->pkU.valid &&
+                 p->pkL.fmt == 1 && p->pkU.fmt == 1 && p->pkL.xch && p->pkU.xch && !p->degenerate)) return;
+    hipLaunchKernelGGL(k_arm_apply, dim3(1024), dim3(256), 0, p->stream, p->ctrl, reinterpret_cast<unsigned long long *>(p->pkL.xch),
+                       (long long)p->pkL.xch_len, reinterpret_cast<unsigned long long *>(p->pkU.xch), (long long)p->pkU.xch_len, kSentinel);
+    if (hipGetLastError() != hipSuccess) return;
+    p->ctrl_armed = true; p->pkL.xch_armed = p->pkU.xch_armed = true;
+}
+
 // numeric phase with whatever machinery the analysis could set up; leaves the sweep records' values in place
 static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, float *kms)
 {
     hipStream_t st = p->stream;
+    p->ctrl_armed = false; p->pkL.xch_armed = p->pkU.xch_armed = false;      // (the factor kernels use the control words and the forward exchange)
     int rc = ILUPP_ERR_UNSUPPORTED;
     if (p->flm.built) {
         rc = p->flm.stat ? ilu0_numeric_st(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5])
@@ -453,9 +477,23 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
         ILUPP_HIP(d2h_async(st, &grid_bad, p->ctrl + 8, sizeof(int32_t)));
     }
     ILUPP_HIP(stream_sync(st));
+    if (grid && p->flm.spec && grid_bad == 0) {
+        // the sizes the lane-table kernels were launched with were predicted (st.hip: st_analyse_ilu0); what the device found is here now
+        const FactorLM &f = p->flm;
+        bool same = f.chk_hl[0] == 0 && f.chk_hu[0] == 0 && f.chk_hu[3] == 0 && f.chk_hl[8] == 0 && f.chk_hl[9] == 0 && f.chk_hu[9] == 0 && f.chk_hl[10] == 0;
+        same = same && f.chk_hl[1] == f.pred[0] && f.chk_hu[1] == f.pred[0] && f.chk_hl[2] == f.pred[1] && f.chk_hu[2] == f.pred[1];
+        same = same && f.chk_xtot[0] == f.pred[2] && f.chk_xtot[2] == f.pred[2] && f.chk_xtot[1] == f.pred[3] && f.chk_xtot[3] == f.pred[3];
+        if (!same) {
+            if (getenv("ILUPP_DEBUG"))
+                fprintf(stderr, "[ilupp] grid %d x %d x %d: predicted sizes %d %d %d %d, found %d/%d %d/%d %d/%d %d/%d, flags %d %d %d %d %d %d %d: redone\n", gd.nx, gd.ny, gd.nz,
+                        f.pred[0], f.pred[1], f.pred[2], f.pred[3], f.chk_hl[1], f.chk_hu[1], f.chk_hl[2], f.chk_hu[2], f.chk_xtot[0], f.chk_xtot[2], f.chk_xtot[1], f.chk_xtot[3],
+                        f.chk_hl[0], f.chk_hu[0], f.chk_hu[3], f.chk_hl[8], f.chk_hl[9], f.chk_hu[9], f.chk_hl[10]);
+            grid_bad = 2;
+        }
+    }
     if (grid && grid_bad != 0) {
-        // the matrix only began like a grid: everything built on the guess is dropped, the general pass runs
-        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] grid guess %d x %d x %d dropped (pattern differs)\n", gd.nx, gd.ny, gd.nz);
+        // the matrix only began like a grid (or a size was mispredicted): everything built on the guess is dropped, the general pass runs
+        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] grid guess %d x %d x %d dropped (%s)\n", gd.nx, gd.ny, gd.nz, grid_bad == 2 ? "sizes mispredicted" : "pattern differs");
         p->pkL.release(); p->pkU.release(); p->flm.release();
         p->sA.release(); p->sU.release();
         p->sA = Schedule(); p->sU = Schedule();
@@ -466,6 +504,7 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
     p->tm.numeric_kernel_ms = kms;
     if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out (invalid structure?)");
+    if (rc == ILUPP_OK) arm_apply(p);
     return rc;
 }
 
@@ -614,7 +653,8 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
 {
     hipStream_t st = p->stream;
     order_after_caller(st, p->sev[0]);
-    ILUPP_HIP(hipMemsetAsync(p->ctrl, 0, 64, st));
+    if (p->ctrl_armed) p->ctrl_armed = false;            // (zero already: arm_apply)
+    else ILUPP_HIP(hipMemsetAsync(p->ctrl, 0, 64, st));
     int32_t *err = p->ctrl, *t1 = p->ctrl + 4, *t2 = p->ctrl + 5;
     double *y = p->work;
     if (p->kind == KIND_LU) {
@@ -636,7 +676,7 @@ int apply_dev(ilupp_precond *p, double *x, int transpose)
             SWEEP_OR_RETURN(p, SWEEP_BWD_FIRST_ASC, p->Uc, p->sU, p->dU, MAXLEN_OF(p->Uc), p2, y, x, t2, err, nullptr,
                   ylm ? p->pkL.ybuf : nullptr, ylm ? p->pkU.ysrc : nullptr);
             ILUPP_HIP(hipEventRecord(p->ev[2], st));
-        } else if (static_transposed_ready(p)) {
+        } else if ((p->pkL.xch_armed = p->pkU.xch_armed = false, static_transposed_ready(p))) {
             // static form: the same two sweep kernels on records of U^T and L^T
             ILUPP_HIP(hipEventRecord(p->ev[0], st));
             { const int rc_ = sptrsv_st_T(st, p->pkL, p->n, x, y, t1, err, p->pkL.ybuf, nullptr); if (rc_) return rc_; }
@@ -734,6 +774,7 @@ int finish_apply(ilupp_precond *p)
         set_error("triangular solve: dependency wait timed out (factor not triangular?)");
         return ILUPP_ERR_TIMEOUT;
     }
+    arm_apply(p);
     return ILUPP_OK;
 }
 
@@ -856,6 +897,7 @@ int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const
         p->dUT = p->dLT = nullptr; p->haveT = false;
         p->pkUT.release(); p->pkLT.release(); p->pack_tried[2] = p->pack_tried[3] = false;
     }
+    if (rc == ILUPP_OK) arm_apply(p);
     if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out");
     return rc;
     API_CATCH

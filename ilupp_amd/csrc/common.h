@@ -153,6 +153,7 @@ struct PackedSweep {
     // the factor kernel's own read-back waits for the one and takes the other along
     hipEvent_t join_ev = nullptr;
     int32_t join_verdict = 0;
+    mutable bool xch_armed = false;     // the exchange buffer is all-sentinel already (api.hip: arm_apply, behind the previous call's last wait): the sweep need not fill it
     void release();
 };
 
@@ -181,6 +182,11 @@ struct FactorLM {
     bool stat = false;              // static form (st.hip): pkA holds 4 KB chunks {a0..a6, mask}
     bool direct = false;            // static form fed from A's CSR values (st_direct.hip): no pkA at all
     bool wxf = false;               // ... by the wave-exchange factor kernel (st_wave.hip: k_ilu0_wx), which writes format-1 records
+    // (box grids, grid.hip) the sizes the analysis used to wait for were PREDICTED from the dimensions and everything behind them launched
+    // at once; what the device found (flags of both schedules, exchange totals) lands here with the construction's last read-back and
+    // must equal the prediction, or the construction is redone the waiting way (api.hip: ilu0_factor)
+    bool spec = false;
+    int32_t chk_hl[12] = {0}, chk_hu[12] = {0}, chk_xtot[4] = {0}, pred[4] = {0};      // pred: chunks, longest wave, exchange offset of the last workgroup, its size
     void release();
 };
 
@@ -309,6 +315,9 @@ void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *
 // slot arrays must be allocated: build_slot_tables(..., false))
 void grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, const Schedule &bwd, int32_t *ltabF, int32_t *ltabB,
                       int32_t *flagsF, int32_t *flagsB, int32_t *uslot);
+// chunks of a schedule (all waves), chunks of its longest wave, exchange entries before the last workgroup and of the last workgroup, for
+// a box grid placed in 16 x 16 patches with the wave-exchange skews (what k_st_link / k_st_scan / k_st_xch_pair find); false: not predictable
+bool grid_predict_sizes(const GridDims &g, int ty, int tz, int64_t *nchunks, int32_t *maxch, int64_t *xoff_last, int32_t *xsz_last);
 // a verdict computed on another stream that a read-back of the analysis takes along: the stream waits for `ev`, then *host = *dev
 struct SideJoin { hipEvent_t ev; const int32_t *dev; int32_t *host; bool done; };
 int ilu0_csr_ptrs(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);

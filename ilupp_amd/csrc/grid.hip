@@ -236,6 +236,41 @@ void grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, c
     ILUPP_HIP(hipGetLastError());
 }
 
+// Host: what the lane-table kernels will find for a box grid in 16 x 16 patches (st.hip: st_link_body -- skew of lane (y, z) of a patch =
+// y + z + (z / 4)(kWrLag - 1): one step per neighbour, one more across a wave's border --, st_scan_body, k_st_xch_pair).  Both
+// schedules have the same numbers (the backward one is the mirror image).
+bool grid_predict_sizes(const GridDims &g, int ty, int tz, int64_t *nchunks, int32_t *maxch, int64_t *xoff_last, int32_t *xsz_last)
+{
+    if (ty != 16 || tz != 16 || g.nz < 2) return false;
+    const int lagx = 1;                      // kWrLag - 1 (st_common.h)
+    const int NY = (g.ny + 15) / 16, NZ = (g.nz + 15) / 16;
+    int64_t total = 0, xrun = 0;
+    int32_t mx = 0, xlast = 0;
+    for (int Z = 0; Z < NZ; ++Z) {
+        for (int Y = 0; Y < NY; ++Y) {
+            const int nyt = g.ny - 16 * Y < 16 ? g.ny - 16 * Y : 16, nzt = g.nz - 16 * Z < 16 ? g.nz - 16 * Z : 16;
+            int thi = 0;
+            for (int w = 0; 4 * w < nzt; ++w) {
+                const int zmax = 4 * w + 3 < nzt - 1 ? 4 * w + 3 : nzt - 1;
+                const int tmin = 4 * w + w * lagx;
+                const int smax = nyt - 1 + zmax + (zmax / 4) * lagx;
+                const int nch = smax + g.nx - tmin;
+                total += nch;
+                if (nch > mx) mx = nch;
+                if (tmin + nch > thi) thi = tmin + nch;
+            }
+            const bool ey = Y < NY - 1, ez = Z < NZ - 1;
+            const int ex = (ey ? nzt : 0) + (ez ? nyt : 0) - ((ey && ez) ? 1 : 0);
+            const int E = (ex + 15) & ~15;
+            const int64_t xsz = (int64_t)E * thi;            // (first step of a patch: 0)
+            if (xrun + xsz > 0x7fffffffLL) return false;
+            if (Z == NZ - 1 && Y == NY - 1) xlast = (int32_t)xsz; else xrun += xsz;
+        }
+    }
+    *nchunks = total; *maxch = mx; *xoff_last = xrun; *xsz_last = xlast;
+    return total > 0 && total < 0x7fffffffLL;
+}
+
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad)
 {
     unsigned gb = (unsigned)(((int64_t)A.n + 255) / 256);

@@ -43,7 +43,7 @@ void FactorLM::release()
     if (xbase) (void)pool_free(xbase);
     if (xch) (void)pool_free(xch);
     if (xcount) (void)pool_free(xcount);
-    pkA = nullptr; xbase = nullptr; xch = nullptr; xcount = nullptr; built = false; values_packed = false; stat = false; direct = false; wxf = false;
+    pkA = nullptr; xbase = nullptr; xch = nullptr; xcount = nullptr; built = false; values_packed = false; stat = false; direct = false; wxf = false; spec = false;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1572,19 +1572,37 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         int32_t *tot = xsz + (size_t)nwg * 2;
         hipLaunchKernelGGL(k_st_xch_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, xa[0], xa[1], (int32_t)nwg, tot);
         D2HItem items[4];
-        items[0] = {&xtot[0][0], tot, 4 * sizeof(int32_t)};
-        items[1] = {hl, pl->flags, sizeof(hl)};
-        items[2] = {hu, pu->flags, sizeof(hu)};
+        items[0] = {f->chk_xtot, tot, 4 * sizeof(int32_t)};
+        items[1] = {f->chk_hl, pl->flags, sizeof(f->chk_hl)};
+        items[2] = {f->chk_hu, pu->flags, sizeof(f->chk_hu)};
         int ni = 3;
         if (join) {
-            // (a verdict from a side stream -- grid.hip's proof of the guessed pattern -- comes home with this read-back)
+            // (a verdict from a side stream comes home with this read-back)
             ILUPP_HIP(hipStreamWaitEvent(st, join->ev, 0));
             items[ni++] = {join->host, join->dev, sizeof(int32_t)};
             join->done = true;
         }
         ILUPP_HIP(d2h_async_many(st, items, ni));
     }
-    ILUPP_HIP(stream_sync(st));
+    // A box grid in 16 x 16 patches: the sizes are known from the dimensions (grid.hip: grid_predict_sizes), so nothing is waited for
+    // here -- the factor kernel follows the lane-table kernels at once, and what the device found is compared with the prediction when
+    // the construction's last read-back has arrived (f->spec; api.hip).  ILUPP_NO_SPEC=1: wait as for any other matrix.
+    {
+        static const bool nospec = getenv("ILUPP_NO_SPEC") != nullptr;
+        int64_t pn = 0, px = 0; int32_t pm = 0, pxl = 0;
+        f->spec = grid && !nospec && !join && st_wx_on() && try_direct && getenv("ILUPP_NO_WXF") == nullptr &&
+                  grid_predict_sizes(*grid, fwd.tile_ty, fwd.tile_tz, &pn, &pm, &px, &pxl);
+        if (f->spec) {
+            for (int i = 0; i < 12; ++i) hl[i] = hu[i] = 0;
+            hl[1] = hu[1] = (int32_t)pn; hl[2] = hu[2] = pm;
+            xtot[0][0] = xtot[1][0] = (int32_t)px; xtot[0][1] = xtot[1][1] = pxl;
+            f->pred[0] = (int32_t)pn; f->pred[1] = pm; f->pred[2] = (int32_t)px; f->pred[3] = pxl;
+        } else {
+            ILUPP_HIP(stream_sync(st));
+            for (int i = 0; i < 12; ++i) { hl[i] = f->chk_hl[i]; hu[i] = f->chk_hu[i]; }
+            for (int i = 0; i < 4; ++i) (&xtot[0][0])[i] = f->chk_xtot[i];
+        }
+    }
     ILUPP_HIP(pool_free(inv)); ILUPP_HIP(pool_free(xsz));
     // row slots of the chunks against rows: lines of 8 rows in a 16 x 16 patch (30 steps of skew) are 4.75 slots per row, and
     // still 400 times faster than what the other generations make of 90 000 such lines

@@ -636,7 +636,8 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
     // ILUPP_NO_VECWAVE=1, or a schedule with more than 16 lanes in a phase: through the level-major copies that k_st_vec makes (round 4)
     const bool vec = wx_vec_on() && ps.vec_ok;
     a.nat = fwd ? const_cast<double *>(rhs) : out;
-    fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
+    if (ps.xch_armed) ps.xch_armed = false;
+    else fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
     {
         static std::once_flag once[64];      // once per device
         int dev = 0;
