@@ -313,8 +313,9 @@ void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *
                     int32_t *max_row_len, int max_wgs);
 // slot tables, lane templates and the link between the two schedules of a box grid, from its dimensions (one launch; the schedules'
 // slot arrays must be allocated: build_slot_tables(..., false))
-void grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, const Schedule &bwd, int32_t *ltabF, int32_t *ltabB,
-                      int32_t *flagsF, int32_t *flagsB, int32_t *uslot);
+// (true: skews, hand-off ages and the waves' chunk ranges are made too -- k_st_link_pair's job)
+bool grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, const Schedule &bwd, int32_t *ltabF, int32_t *ltabB,
+                      int32_t *flagsF, int32_t *flagsB, int32_t *uslot, int32_t *skewF, int32_t *skewB, int32_t *wtabF, int32_t *wtabB, bool wx);
 // chunks of a schedule (all waves), chunks of its longest wave, exchange entries before the last workgroup and of the last workgroup, for
 // a box grid placed in 16 x 16 patches with the wave-exchange skews (what k_st_link / k_st_scan / k_st_xch_pair find); false: not predictable
 bool grid_predict_sizes(const GridDims &g, int ty, int tz, int64_t *nchunks, int32_t *maxch, int64_t *xoff_last, int32_t *xsz_last);

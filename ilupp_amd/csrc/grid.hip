@@ -13,7 +13,7 @@
 //     proof: everything built on the guess is dropped and the general pass runs (api.hip: ilu0_factor).
 // Nothing downstream changes: the lane tables, the factor kernel and the sweeps are the ones of st.hip / st_wave.hip; the reference
 // semantics are ILU0.hpp:26-66 as before (this file only replaces how the row blocks are found, ILU0.hpp has no counterpart).
-#include "common.h"
+#include "st_common.h"
 
 namespace ilupp {
 
@@ -146,10 +146,10 @@ __device__ __forceinline__ int grid_block_at(const int slot, const GridPlace &g)
     return bs < g.nb ? (int)bs : -1;
 }
 
-struct GridLaneArgs { int32_t *slot2blk, *blk2slot, *sfirst, *scount, *exported, *ltab, *flags; };
+struct GridLaneArgs { int32_t *slot2blk, *blk2slot, *sfirst, *scount, *exported, *ltab, *flags, *skew, *wtab; };
 
 __global__ void __launch_bounds__(kThreads)
-k_grid_lanes(const GridPlace g, const GridLaneArgs F, const GridLaneArgs Bk, int32_t *__restrict__ uslot)
+k_grid_lanes(const GridPlace g, const GridLaneArgs F, const GridLaneArgs Bk, int32_t *__restrict__ uslot, const int link)
 {
     const bool fwd = blockIdx.y == 0;
     const GridLaneArgs &X = fwd ? F : Bk;
@@ -158,82 +158,119 @@ k_grid_lanes(const GridPlace g, const GridLaneArgs F, const GridLaneArgs Bk, int
     if (slot >= g.nslots) return;
     const int bs = grid_block_at(slot, g);
     const int b = bs < 0 ? -1 : (fwd ? bs : g.nb - 1 - bs);
-    X.slot2blk[slot] = b;
-    int32_t *T = X.ltab + (size_t)slot * kStTab;
-    if (b < 0) {
-        X.sfirst[slot] = 0; X.scount[slot] = 0; X.exported[slot] = 0;
-        if (fwd) uslot[slot] = -1;
-#pragma unroll
-        for (int i = 0; i < kStTab; ++i) T[i] = 0;
-        T[ST_DT] = T[ST_DT + 1] = T[ST_DT + 2] = 1;
-        T[ST_SCAT] = T[ST_SCAT + 1] = T[ST_SCAT + 2] = -1;
-        return;
-    }
-    X.blk2slot[b] = slot;
-    const int cnt = g.nx;
-    const int first = fwd ? b * g.nx : (b + 1) * g.nx - 1;       // first row in processing order
-    X.sfirst[slot] = first; X.scount[slot] = cnt;
-    const int y = b % g.ny, z = b / g.ny;
-    // the lines this one depends on, ascending column offset (= the reference's elimination / accumulation order), and the lines that
-    // depend on it (a slot some OTHER workgroup reads is exported)
-    // (every field is stored as it is found -- the table row is the only array: an array of their own would live in scratch memory)
-    int nd = 0, bad = 0, ngh = 0;
+    const bool has = b >= 0;
+    const int cnt = has ? g.nx : 0;
+    const int first = has ? (fwd ? b * g.nx : (b + 1) * g.nx - 1) : 0;        // first row in processing order
+    const int y = has ? b % g.ny : 0, z = has ? b / g.ny : 0;
     const int sxy = g.nx * g.ny;
-#pragma unroll
-    for (int i = ST_OFF; i < kStTab; ++i) T[i] = 0;
-    T[ST_DT] = T[ST_DT + 1] = T[ST_DT + 2] = 1;
-    T[ST_SCAT] = T[ST_SCAT + 1] = T[ST_SCAT + 2] = -1;
-    bool ex = false;
-#define GRID_DEP(o_, bo_)                                                                              \
-    do {                                                                                               \
-        const int os_ = grid_place(fwd ? (bo_) : g.nb - 1 - (bo_), g);                                 \
-        int sw_;                                                                                       \
-        if ((os_ >> 8) == wg) sw_ = ST_LOCAL | (os_ << 2);                                             \
-        else { sw_ = ST_GHOST | (os_ << 2); ++ngh; if ((os_ >> 8) >= wg) bad = 1; }                    \
-        T[ST_OFF + nd] = (o_); T[ST_SRC + nd] = sw_; T[ST_KHI + nd] = cnt; ++nd;                       \
-    } while (0)
-#define GRID_OWN(o_)                                                                                   \
-    do {                                                                                               \
-        T[ST_OFF + nd] = (o_); T[ST_SRC + nd] = ST_OWN | (slot << 2); T[ST_KAP + nd] = -1;             \
-        T[ST_KLO + nd] = 1; T[ST_KHI + nd] = cnt; ++nd;                                                \
-    } while (0)
-#define GRID_READER(bo_) do { if ((grid_place(fwd ? (bo_) : g.nb - 1 - (bo_), g) >> 8) != wg) ex = true; } while (0)
-    if (fwd) {
-        if (z > 0) GRID_DEP(-sxy, b - g.ny);
-        if (y > 0) GRID_DEP(-g.nx, b - 1);
-        if (g.nx > 1) GRID_OWN(-1);
-        if (y < g.ny - 1) GRID_READER(b + 1);
-        if (z < g.nz - 1) GRID_READER(b + g.ny);
-    } else {
-        if (g.nx > 1) GRID_OWN(1);
-        if (y < g.ny - 1) GRID_DEP(g.nx, b + 1);
-        if (z < g.nz - 1) GRID_DEP(sxy, b + g.ny);
-        if (y > 0) GRID_READER(b - 1);
-        if (z > 0) GRID_READER(b - g.ny);
-    }
-#undef GRID_DEP
-#undef GRID_OWN
-#undef GRID_READER
-    X.exported[slot] = ex ? 1 : 0;
+    // The (at most three) lines this one depends on as CANDIDATES in ascending column offset (= the reference's elimination /
+    // accumulation order) -- forward: the line below (z - 1), the line before (y - 1), the own chain; backward: the own chain, the line
+    // after (y + 1), the line above (z + 1) -- then the ones that exist moved up to the front of the template.  Everything stays in
+    // registers (no array is indexed with a run-time value) and the row of the table leaves as eight 16-byte stores.
+    const bool p0 = has && (fwd ? z > 0 : g.nx > 1), p1 = has && (fwd ? y > 0 : y < g.ny - 1), p2 = has && (fwd ? g.nx > 1 : z < g.nz - 1);
+    const int cb0 = fwd ? b - g.ny : b, cb1 = fwd ? b - 1 : b + 1, cb2 = fwd ? b : b + g.ny;      // candidate lines
+    const int co0 = fwd ? -sxy : 1, co1 = fwd ? -g.nx : g.nx, co2 = fwd ? -1 : sxy;               // their column offsets
+    const bool own0 = !fwd, own2 = fwd;                                                           // which candidate is the own chain
+    int bad = 0, ngh = 0;
+    auto source = [&](const bool present, const bool own, const int bo) -> int {
+        if (!present) return 0;
+        if (own) return ST_OWN | (slot << 2);
+        const int os = grid_place(fwd ? bo : g.nb - 1 - bo, g);
+        if ((os >> 8) == wg) return ST_LOCAL | (os << 2);
+        ++ngh; if ((os >> 8) >= wg) bad = 1;
+        return ST_GHOST | (os << 2);
+    };
+    const int cs0 = source(p0, own0, cb0), cs1 = source(p1, false, cb1), cs2 = source(p2, own2, cb2);
+    // j-th present candidate
+    const int i0 = p0 ? 0 : (p1 ? 1 : (p2 ? 2 : -1));
+    const int i1 = p0 ? (p1 ? 1 : (p2 ? 2 : -1)) : ((p1 && p2) ? 2 : -1);
+    const int i2 = (p0 && p1 && p2) ? 2 : -1;
+    const int nd = (p0 ? 1 : 0) + (p1 ? 1 : 0) + (p2 ? 1 : 0);
+#define GRID_PICK(i_, a0_, a1_, a2_) ((i_) == 0 ? (a0_) : ((i_) == 1 ? (a1_) : ((i_) == 2 ? (a2_) : 0)))
+    const int of0 = GRID_PICK(i0, co0, co1, co2), of1 = GRID_PICK(i1, co0, co1, co2), of2 = GRID_PICK(i2, co0, co1, co2);
+    const int sr0 = GRID_PICK(i0, cs0, cs1, cs2), sr1 = GRID_PICK(i1, cs0, cs1, cs2), sr2 = GRID_PICK(i2, cs0, cs1, cs2);
+#undef GRID_PICK
+    const bool o0 = (sr0 & 3) == ST_OWN, o1 = (sr1 & 3) == ST_OWN, o2 = (sr2 & 3) == ST_OWN;
+    // (own chain: every row but the first has the entry, from the row before; the other lines: every row, from the row at the same place)
+    const int ka0 = o0 ? -1 : 0, ka1 = o1 ? -1 : 0, ka2 = o2 ? -1 : 0;
+    const int kl0 = o0 ? 1 : 0, kl1 = o1 ? 1 : 0, kl2 = o2 ? 1 : 0;
+    const int kh0 = i0 >= 0 ? cnt : 0, kh1 = i1 >= 0 ? cnt : 0, kh2 = i2 >= 0 ? cnt : 0;
     if (nd == 3 && ngh == 3) bad = 1;
-    T[ST_FIRST] = first; T[ST_CNT] = cnt; T[ST_SKEW] = 0; T[ST_ND] = nd;
+    // the lines that depend on this one: a slot some OTHER workgroup reads is exported
+    bool ex = false;
+    if (has) {
+        const int r0 = fwd ? b + 1 : b - 1, r1 = fwd ? b + g.ny : b - g.ny;
+        const bool q0 = fwd ? y < g.ny - 1 : y > 0, q1 = fwd ? z < g.nz - 1 : z > 0;
+        if (q0 && (grid_place(fwd ? r0 : g.nb - 1 - r0, g) >> 8) != wg) ex = true;
+        if (q1 && (grid_place(fwd ? r1 : g.nb - 1 - r1, g) >> 8) != wg) ex = true;
+    }
+    // (16 x 16 patches, wave-exchange skews: `link`) what k_st_link's fixpoint arrives at: a step per neighbour inside the patch, kWrLag
+    // steps where the neighbour below sits in another wave; its proof about the eliminations (they meet the eliminated row on its
+    // diagonal only) holds for every box stencil with nx >= 3, ny >= 3 (grid_guess asks for more)
+    const int sk = (link && has) ? (t & 15) + (t >> 4) + (t >> 6) * (kWrLag - 1) : 0;
+    int dt0 = 1, dt1 = 1, dt2 = 1;
+    if (link) {
+        if ((sr0 & 3) == ST_LOCAL) dt0 = wr_edge_lag(t, (sr0 >> 2) & 255, true);
+        if ((sr1 & 3) == ST_LOCAL) dt1 = wr_edge_lag(t, (sr1 >> 2) & 255, true);
+        if ((sr2 & 3) == ST_LOCAL) dt2 = wr_edge_lag(t, (sr2 >> 2) & 255, true);
+    }
+    // the row: {FIRST, CNT, SKEW, ND} {OFF x3, SRC0} {SRC1, SRC2, KLO0, KLO1} {KLO2, KAP x3} {UP0, DT x3} {KHI x3, SCAT0} {SCAT1, SCAT2, -, -} {- x4}
+    static_assert(ST_FIRST == 0 && ST_CNT == 1 && ST_SKEW == 2 && ST_ND == 3 && ST_OFF == 4 && ST_SRC == 7 && ST_KLO == 10 && ST_KAP == 13 &&
+                  ST_UP0 == 16 && ST_DT == 17 && ST_KHI == 20 && ST_SCAT == 23 && kStTab == 32, "layout of a lane table row");
+    int4 *T4 = reinterpret_cast<int4 *>(X.ltab + (size_t)slot * kStTab);
+    T4[0] = make_int4(first, cnt, sk, nd);
+    T4[1] = make_int4(of0, of1, of2, sr0);
+    T4[2] = make_int4(sr1, sr2, kl0, kl1);
+    T4[3] = make_int4(kl2, ka0, ka1, ka2);
+    T4[4] = make_int4(0, dt0, dt1, dt2);
+    T4[5] = make_int4(kh0, kh1, kh2, -1);
+    T4[6] = make_int4(-1, -1, 0, 0);
+    T4[7] = make_int4(0, 0, 0, 0);
+    X.slot2blk[slot] = b;
+    X.sfirst[slot] = first; X.scount[slot] = cnt; X.exported[slot] = ex ? 1 : 0;
+    if (has) X.blk2slot[b] = slot;
+    if (fwd) uslot[slot] = has ? grid_place(g.nb - 1 - b, g) : -1;       // the slot of the backward schedule that owns the same line
     if (bad) atomicOr(&X.flags[0], 2);
-    // the slot of the backward schedule that owns the same line
-    if (fwd) uslot[slot] = grid_place(g.nb - 1 - b, g);
+    if (link) {
+        X.skew[slot] = sk;
+        // may the wave-exchange kernels run this lane?  (st_common.h: wx_lane_ok, on the row as it stands in registers)
+        if (has) {
+            int32_t row[kStTab];
+#pragma unroll
+            for (int i = 0; i < kStTab; ++i) row[i] = 0;
+            row[ST_FIRST] = first; row[ST_CNT] = cnt; row[ST_SKEW] = sk; row[ST_ND] = nd;
+            row[ST_OFF] = of0; row[ST_OFF + 1] = of1; row[ST_OFF + 2] = of2; row[ST_SRC] = sr0; row[ST_SRC + 1] = sr1; row[ST_SRC + 2] = sr2;
+            row[ST_KLO] = kl0; row[ST_KLO + 1] = kl1; row[ST_KLO + 2] = kl2; row[ST_KAP] = ka0; row[ST_KAP + 1] = ka1; row[ST_KAP + 2] = ka2;
+            row[ST_DT] = dt0; row[ST_DT + 1] = dt1; row[ST_DT + 2] = dt2; row[ST_KHI] = kh0; row[ST_KHI + 1] = kh1; row[ST_KHI + 2] = kh2;
+            if (!wx_lane_ok(row, t, !fwd)) atomicOr(&X.flags[9], 1);
+        }
+        // the wave's chunk range
+        int w_lo = has ? sk : 0x7fffffff, w_hi = has ? sk + cnt : -0x7fffffff;
+        for (int off = 32; off > 0; off >>= 1) { w_lo = min(w_lo, __shfl_xor(w_lo, off)); w_hi = max(w_hi, __shfl_xor(w_hi, off)); }
+        if ((t & 63) == 0) {
+            const int nch = w_hi > w_lo ? w_hi - w_lo : 0;
+            *reinterpret_cast<int4 *>(X.wtab + (size_t)(wg * 4 + (t >> 6)) * 4) = make_int4(0, nch > 0 ? w_lo : 0, nch, 0);
+        }
+    }
 }
 
-void grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, const Schedule &bwd, int32_t *ltabF, int32_t *ltabB,
-                      int32_t *flagsF, int32_t *flagsB, int32_t *uslot)
+bool grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, const Schedule &bwd, int32_t *ltabF, int32_t *ltabB,
+                      int32_t *flagsF, int32_t *flagsB, int32_t *uslot, int32_t *skewF, int32_t *skewB, int32_t *wtabF, int32_t *wtabB, bool wx)
 {
     GridPlace g;
     g.nx = gd.nx; g.ny = gd.ny; g.nz = gd.nz; g.nb = fwd.nb;
     g.s2 = fwd.tile_s2; g.ty = fwd.tile_ty; g.tz = fwd.tile_tz;
     g.NY = g.s2 > 0 ? (g.s2 + g.ty - 1) / g.ty : 0;
     g.nslots = fwd.nslots;
-    GridLaneArgs F = {fwd.slot2blk, fwd.blk2slot, fwd.sfirst, fwd.scount, fwd.exported, ltabF, flagsF};
-    GridLaneArgs Bk = {bwd.slot2blk, bwd.blk2slot, bwd.sfirst, bwd.scount, bwd.exported, ltabB, flagsB};
-    hipLaunchKernelGGL(k_grid_lanes, dim3((unsigned)(fwd.nslots / kThreads), 2), dim3(kThreads), 0, st, g, F, Bk, uslot);
+    GridLaneArgs F = {fwd.slot2blk, fwd.blk2slot, fwd.sfirst, fwd.scount, fwd.exported, ltabF, flagsF, skewF, wtabF};
+    GridLaneArgs Bk = {bwd.slot2blk, bwd.blk2slot, bwd.sfirst, bwd.scount, bwd.exported, ltabB, flagsB, skewB, wtabB};
+    // skews, ages of the hand-off values and the waves' chunk ranges too (what k_st_link_pair makes) where the patches are 16 x 16 and
+    // the wave-exchange skews are wanted; ILUPP_GRID_LINK=0: by the general kernel
+    static const bool link_on = []() { const char *e = getenv("ILUPP_GRID_LINK"); return !(e && atoi(e) == 0); }();
+    const bool link = link_on && wx && g.s2 > 0 && g.ty == 16 && g.tz == 16 && gd.nx >= 3 && gd.ny >= 3;
+    hipLaunchKernelGGL(k_grid_lanes, dim3((unsigned)(fwd.nslots / kThreads), 2), dim3(kThreads), 0, st, g, F, Bk, uslot, link ? 1 : 0);
     ILUPP_HIP(hipGetLastError());
+    return link;
 }
 
 // Host: what the lane-table kernels will find for a box grid in 16 x 16 patches (st.hip: st_link_body -- skew of lane (y, z) of a patch =

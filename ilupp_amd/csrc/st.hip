@@ -1515,11 +1515,13 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     const int nslots = fwd.nslots;
     st_structure(st, fwd, pl, (int)SWEEP_FWD_LAST_ASC);
     st_structure(st, bwd, pu, (int)SWEEP_BWD_FIRST_ASC);
+    bool linked_by_grid = false;
     if (grid) {
         // a box grid (grid.hip): slot tables, lane templates and the link of the two schedules follow from its dimensions
         pu->built = true;
         ILUPP_HIP(pool_malloc(&pu->uslot, sizeof(int32_t) * (size_t)fwd.nslots));
-        grid_lane_tables(st, *grid, fwd, bwd, pl->ltab, pu->ltab, pl->flags, pu->flags, pu->uslot);
+        linked_by_grid = grid_lane_tables(st, *grid, fwd, bwd, pl->ltab, pu->ltab, pl->flags, pu->flags, pu->uslot, pl->skew, pu->skew,
+                                          pl->wtab, pu->wtab, st_wx_on());
     } else {
         StTplArgs tf, tb;
         tf.B = fwd.B; tf.nb = fwd.nb; tf.start = fwd.start; tf.blk2slot = fwd.blk2slot; tf.sfirst = fwd.sfirst; tf.scount = fwd.scount;
@@ -1530,8 +1532,9 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         pu->built = true;
         lm_link_factor(st, fwd, bwd, pu);               // forward slot -> backward slot of the same chain (flags[3] when there is none)
     }
-    hipLaunchKernelGGL(k_st_link_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew, pu->skew,
-                       pl->wtab, pu->wtab, pl->flags, pu->flags, st_wx_on() ? 1 : 0);
+    if (!linked_by_grid)
+        hipLaunchKernelGGL(k_st_link_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew, pu->skew,
+                           pl->wtab, pu->wtab, pl->flags, pu->flags, st_wx_on() ? 1 : 0);
     hipLaunchKernelGGL(k_st_scan_pair, dim3(2), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags, pu->wtab, pu->flags);
     int32_t *inv = nullptr;
     ILUPP_HIP(pool_malloc(&inv, sizeof(int32_t) * (size_t)nslots));
