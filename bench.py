@@ -68,11 +68,61 @@ def measured_traffic(kernel, g):
         try:
             ks = json.load(open(f))["kernels"]
             for name, k in ks.items():
-                if name.replace("ilupp::", "") == kernel:
+                if name.replace("ilupp::", "").replace("void ", "") == kernel:
+                    TRAFFIC_SOURCE.add(os.path.relpath(f, ROOT))
                     return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
         except Exception:
             continue
     return None
+
+
+TRAFFIC_SOURCE = set()      # the committed counter files the traffic figures of this line come from (they are NOT measured in this run)
+
+
+def cpu_extra(name, d, i, p):
+    """The reference's own C++ (oracle/_ref, one host core) on an extra config's workload, construction only -- beside the GPU's construct_s.
+    C3 (102 s on one core) is quoted from BASELINE.md, not run."""
+    n, nnz = p.shape[0] - 1, int(p[-1])
+    if name == "C3":
+        return {"value": nnz / 102.1, "unit": "nnz/s", "cores": 1, "kind": "quoted", "seconds": 102.1,
+                "sample": "BASELINE.md section 3, row C3: ILUT_heap on one core of the survey container (not run here: 102 s)"}
+    try:
+        import ctypes
+        from oracle import oracle as O
+        if not O.ref_available():
+            return None
+        ref = O.ref()
+        A = (d, i, p, True)
+        t0 = time.perf_counter()
+        if name == "C4":
+            ref.icholt(A, 0, 0.0)
+        elif name == "ILUC":
+            ref.iluc(A, 8, 1e-2)
+        elif name in ("C5", "C5P", "C5L"):
+            I32P, F64P = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)
+            f = ref.lib.ref_ilupp_apply
+            f.argtypes = [ctypes.c_int32, I32P, I32P, F64P, ctypes.c_int, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int, F64P, I32P, I32P]
+            f.restype = ctypes.c_int
+            x = np.ones(n)
+            lev, tn = ctypes.c_int32(0), ctypes.c_int32(0)
+            dd, ii, pp = (np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(i, dtype=np.int32), np.ascontiguousarray(p, dtype=np.int32))
+            rc = f(ctypes.c_int32(n), pp.ctypes.data_as(I32P), ii.ctypes.data_as(I32P), dd.ctypes.data_as(F64P), ctypes.c_int(1),
+                   ctypes.c_int32(10 if name == "C5P" else 1), ctypes.c_double(0.3 if name == "C5L" else 1e-3), ctypes.c_int32(-1), ctypes.c_int(0),
+                   x.ctypes.data_as(F64P), ctypes.byref(lev), ctypes.byref(tn))
+            if rc:
+                return None
+        else:
+            return None
+        sec = time.perf_counter() - t0
+        return {"value": nnz / sec, "unit": "nnz/s", "cores": 1, "kind": "reference", "seconds": sec,
+                "sample": "the same matrix once through oracle/_ref (the reference's C++ compiled from /root/reference), construction" +
+                          (" + one apply" if name in ("C5", "C5P", "C5L") else "") + ", one host core"}
+    except Exception as e:                     # the CPU leg never takes the line down
+        return {"value": None, "kind": "failed", "sample": repr(e)}
+
+
+EXTRA_KERNEL = {"C3": "k_ilut_rows_wp", "C4": "k_icholt_df", "ILUC": "k_iluc_df", "C5": "k_piluc_df", "C5M": "k_piluc_df", "C5L": "k_piluc_df",
+                "C5P": "k_pilucdp_lds", "S27": "k_ilu0_lvl", "S9": "k_ilu0_lvl"}
 
 
 def cpu_baseline(g, want_ref=True):
@@ -150,6 +200,32 @@ def ml_batch_member(dev, member, n=1000000, preset=1):
     return (member, int(Pm.levels()), int(Pm.total_nnz), hashlib.sha256(xb.cpu().numpy().tobytes()).hexdigest(), ms)
 
 
+def _cpu_batch_one(a):
+    member, n, preset = a
+    import matgen
+    dm, im, pm = matgen.random_dd(n, 8, 25.0, 12345 + member)
+    t0 = time.perf_counter()
+    r = cpu_extra("C5P" if preset == 10 else "C5", dm, im, pm)
+    return (time.perf_counter() - t0) if (r and r.get("value")) else None
+
+
+def cpu_batch(world, n, preset):
+    """BASELINE.md section 4.3's CPU figure for the batch: `world` single-thread instances of the reference (oracle/_ref), one matrix each, on
+    `world` host cores at once"""
+    try:
+        import multiprocessing as mp
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(world) as pool:
+            secs = pool.map(_cpu_batch_one, [(m, n, preset) for m in range(world)])
+        wall = time.perf_counter() - t0
+        if any(v is None for v in secs):
+            return None
+        return {"kind": "reference", "cores": world, "wall_s": wall, "per_matrix_s": secs, "matrices_per_s": world / wall,
+                "sample": "%d processes, one matrix (n=%d, default_configuration(%d)) each: construction + one apply through oracle/_ref" % (world, n, preset)}
+    except Exception as e:
+        return {"kind": "failed", "sample": repr(e)}
+
+
 def batch_config(steps, members=64, n=100000):
     """C5PB: BASELINE config 5's many-matrices shape on ONE GPU: `members` matrices (n = 1e5 each), default_configuration(10) -- the
     factorisation with pivoting, a sequential chain per matrix -- built side by side (ilupp_hip_ml_create_batch: the chains of all
@@ -181,7 +257,7 @@ def batch_config(steps, members=64, n=100000):
             "factor_nnz_total": nnz_f}
 
 
-def extra_config(name, dev, steps):
+def extra_config(name, dev, steps, with_cpu=True):
     """C3 / C4 on device-resident inputs: seconds, factor bytes (read A + write the factors produced), GB/s"""
     import torch
     import matgen
@@ -282,11 +358,21 @@ def extra_config(name, dev, steps):
     nf = 1 if name == "C4" else 2
     fbytes = (12 * nnz + 4 * (n + 1)) + (12 * nnz_out + 4 * (n + 1) * nf)
     sec = float(np.median(walls))
+    kms_med = float(np.median(kms))
     more = {"levels": int(levels)} if name in ("C5", "C5M", "C5P", "C5L") else {}
+    del td, ti, tp, x
+    torch.cuda.empty_cache()
+    cpu = cpu_extra(name, d, i, p) if with_cpu else None
     return {**more, "workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
-            "numeric_kernel_ms": float(np.median(kms)), "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
+            "numeric_kernel_ms": kms_med, "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
-            "hbm_fraction": fbytes / sec / 1e9 / HBM_PEAK_GBS}
+            "hbm_fraction": fbytes / sec / 1e9 / HBM_PEAK_GBS,
+            # the dominant kernel of the construction against the HBM roofline: SURVEY 8(d)'s bytes for these configs (read A + write the
+            # factors actually produced) over the kernel's own time; no counter traffic was collected for these kernels
+            "roofline": {"bound": "hbm", "kernel": EXTRA_KERNEL.get(name), "algorithmic_bytes": fbytes, "avg_launch_ms": kms_med,
+                         "achieved": (fbytes / (kms_med * 1e-3) / 1e9) if kms_med > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (fbytes / (kms_med * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms_med > 0 else None, "traffic": None},
+            "cpu_baseline": cpu}
 
 
 def main():
@@ -377,6 +463,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     path = P.path()
+    analysis_path = P.analysis_path() if hasattr(P, "analysis_path") else "general"
     knames = P.kernel_names() if hasattr(P, "kernel_names") else ()
     # numeric re-factorisation with NEW values on the analysed pattern + one apply (what a time-stepping caller pays per step),
     # timed the same way: ilupp_hip_ilu0_refactor_device reads the new value array where it lies
@@ -464,7 +551,7 @@ def main():
     batch_ml = None
     batch_ml10 = None
     if world > 1:
-        for preset, nml in ((10, 100000), (1, 1000000)):
+        for preset, nml in ((10, int(os.environ.get("BENCH_C5_N", "1000000"))), (1, int(os.environ.get("BENCH_C5_N", "1000000")))):
             def work_ml(member, preset=preset, nml=nml):
                 return ml_batch_member(dev, member, nml, preset)
             barrier()
@@ -476,6 +563,8 @@ def main():
                 solo = [work_ml(m) for m in range(world)]
                 same = all(a[:4] == b[:4] for a, b in zip(recs, solo))
                 rec = {"what": "C5 batch: ILUppPreconditioner(default_configuration(%d), threshold=1e-3) + apply on %d unsymmetric matrices n=%d, one per rank" % (preset, world, nml),
+                       "n": nml, "preset": preset,
+                       "cpu_baseline": cpu_batch(world, nml, preset) if not args.no_cpu else None,
                        "records": [{"matrix": r[0], "levels": r[1], "total_nnz": r[2], "sha256_apply": r[3][:16], "ms": r[4]} for r in recs],
                        "wall_s_incl_matrix_generation": bwall, "identical_to_single_rank": bool(same)}
                 assert same, "batched multilevel outputs (default_configuration(%d)) differ from the single-rank run" % preset
@@ -499,13 +588,16 @@ def main():
         k_traffic = measured_traffic(kernel, g)
         phases = [
             {"name": kernel, "what": "numeric factorisation kernel", "ms": k_num, "algorithmic_bytes": fb, "traffic": k_traffic},
-            {"name": "analysis (k_row_cuts_counts + lane tables, ~15 launches)", "what": "pattern analysis and schedule, whole phase",
-             "ms": med(ana_ms), "algorithmic_bytes": None, "traffic": measured_traffic("k_row_cuts_counts", g)},
-            {"name": "k_st_vec<1, true> + " + k_fwd, "what": "L solve, whole phase", "ms": med(ls_ms),
+            {"name": ("analysis (k_grid_check next to k_grid_lanes + the lane-table kernels)" if analysis_path == "grid"
+                      else "analysis (k_row_cuts_counts + lane tables)"), "what": "pattern analysis and schedule, whole phase",
+             "ms": med(ana_ms), "algorithmic_bytes": None,
+             "traffic": measured_traffic("k_grid_check" if analysis_path == "grid" else "k_row_cuts_counts", g)},
+            {"name": k_fwd, "what": "L solve, whole phase", "ms": med(ls_ms),
              "algorithmic_bytes": ab // 2, "traffic": measured_traffic(k_fwd, g)},
-            {"name": k_bwd + " + k_st_vec<-1, false>", "what": "U solve, whole phase", "ms": med(us_ms),
+            {"name": k_bwd, "what": "U solve, whole phase", "ms": med(us_ms),
              "algorithmic_bytes": ab - ab // 2, "traffic": measured_traffic(k_bwd, g)},
         ]
+        step_frac = ((fb + ab) / step_s / 1e9) / HBM_PEAK_GBS
         out = {
             "metric": "ILU(0) factor+apply nnz/s, 3-D 7-pt Poisson fp64",
             "value": world * nnz / (wall / args.steps),
@@ -521,12 +613,16 @@ def main():
                        "parallelism": "1 matrix per GPU, no data-path collective" if world > 1 else "single GPU",
                        "step": "full ILU0Preconditioner construction (pattern analysis + row scheduling + numeric factorisation) "
                                "+ one apply, A and x resident in HBM; wall clock over all steps",
-                       "path": path},
+                       "path": path, "analysis": analysis_path},
+            # THE fraction of this line: the whole step (factor + apply bytes of SURVEY 8d) over the wall clock of a step, against the
+            # 8 TB/s HBM peak -- the number BASELINE.json's 0.40 target is about.  roofline.frac below is the dominant KERNEL's.
+            "headline_fraction": step_frac,
+            "headline_fraction_what": "(factor + apply algorithmic bytes of SURVEY 8d) / (wall clock of a step) / 8 TB/s: the whole step, host gaps and analysis included",
             "gpu_ms": {"analysis": med(ana_ms), "numeric": med(num_ms), "factor": med(fac_ms), "apply": med(app_ms),
                        "lsolve": med(ls_ms), "usolve": med(us_ms), "factor_plus_apply": gpu_ms,
                        "numeric_kernel": k_num},
             "gpu_event_value_nnz_per_s": nnz / (gpu_ms * 1e-3) if gpu_ms > 0 else None,
-            "hbm_fraction_factor_plus_apply": ((fb + ab) / (gpu_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gpu_ms > 0 else None,
+            "hbm_fraction_factor_plus_apply": step_frac,      # (wall clock, = headline_fraction; the sum of the GPU events is gpu_ms.factor_plus_apply)
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": (fb / (k_num * 1e-3) / 1e9) if k_num > 0 else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -539,10 +635,11 @@ def main():
                          "frac_bytes_moved": ((k_traffic / (k_num * 1e-3) / 1e9) / HBM_PEAK_GBS) if (k_num > 0 and k_traffic) else None,
                          "factor_phase_frac": ((fb / (med(fac_ms) * 1e-3) / 1e9) / HBM_PEAK_GBS) if med(fac_ms) > 0 else None,
                          "traffic": k_traffic,
+                         "traffic_source": (", ".join(sorted(TRAFFIC_SOURCE)) + " (committed PMC passes of this command, not collected in this run)") if TRAFFIC_SOURCE else None,
                          "algorithmic_bytes_per_launch": fb,
                          "avg_launch_ms": k_num,
                          # the whole step against the roofline: factor + apply bytes of section 8(d) over the wall clock of a step
-                         "step_frac": ((fb + ab) / step_s / 1e9) / HBM_PEAK_GBS,
+                         "step_frac": step_frac,
                          "step_algorithmic_bytes": fb + ab,
                          "phases": phases,
                          "copy_GBs_measured": copy_gbs,
@@ -578,7 +675,7 @@ def main():
             if cfg in ("C3", "C4", "C5", "C5M", "C5P", "C5L", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
-                extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)))
+                extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)), with_cpu=not args.no_cpu)
             elif cfg == "C5PB" and world == 1:
                 del_txs = txs[:]
                 txs.clear(); del del_txs

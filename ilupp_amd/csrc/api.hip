@@ -1309,6 +1309,39 @@ const char *ilupp_hip_path(const ilupp_precond *p)
     return p->llt_diag_last ? (p->chol_static ? "ichol0:static-level-major" : "ichol0") : "icholt";
 }
 
+/* diagnostics: table `which` of a static ILU(0) object as 32-bit words (0 / 1: lane tables of the forward / backward schedule, 2 / 3: chunk
+ * tables, 4: backward right-hand-side map, 5: rows-pass records, 6 / 7: export ordinals, 8 / 9: exchange layout, 10: forward -> backward
+ * slots, 11 / 12: skews); returns the number of words copied (at most cap), -1 for an object without such a table */
+long long ilupp_hip_debug_static_table(ilupp_precond *p, int which, int32_t *out, long long cap)
+{
+    try {
+        if (!p || !(p->flm.built && p->flm.stat) || !out) return -1;
+        const long long ns = p->sA.nslots, nwg = ns / kThreads;
+        const int32_t *src = nullptr; long long cnt = 0;
+        switch (which) {
+            case 0: src = p->pkL.ltab; cnt = ns * kStTab; break;
+            case 1: src = p->pkU.ltab; cnt = ns * kStTab; break;
+            case 2: src = p->pkL.wtab; cnt = nwg * 16; break;
+            case 3: src = p->pkU.wtab; cnt = nwg * 16; break;
+            case 4: src = p->pkU.ysrc; cnt = ns; break;
+            case 5: src = p->flm.xbase ? p->flm.xbase + ns : nullptr; cnt = ns * 32; break;
+            case 6: src = p->pkL.xe; cnt = ns; break;
+            case 7: src = p->pkU.xe; cnt = ns; break;
+            case 8: src = p->pkL.xw; cnt = nwg * 4; break;
+            case 9: src = p->pkU.xw; cnt = nwg * 4; break;
+            case 10: src = p->pkU.uslot; cnt = ns; break;
+            case 11: src = p->pkL.skew; cnt = ns; break;
+            case 12: src = p->pkU.skew; cnt = ns; break;
+            default: return -1;
+        }
+        if (!src) return -1;
+        if (cnt > cap) cnt = cap;
+        ILUPP_HIP(stream_sync(p->stream));
+        ILUPP_HIP(hipMemcpy(out, src, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+        return cnt;
+    } catch (...) { return -1; }
+}
+
 const char *ilupp_hip_analysis_path(const ilupp_precond *p)
 {
     if (!p || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU)) return "";

@@ -319,6 +319,12 @@ bool grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, c
 // chunks of a schedule (all waves), chunks of its longest wave, exchange entries before the last workgroup and of the last workgroup, for
 // a box grid placed in 16 x 16 patches with the wave-exchange skews (what k_st_link / k_st_scan / k_st_xch_pair find); false: not predictable
 bool grid_predict_sizes(const GridDims &g, int ty, int tz, int64_t *nchunks, int32_t *maxch, int64_t *xoff_last, int32_t *xsz_last);
+// ... and everything the static analysis makes from them (first chunks of the waves, positions in the other schedule's records, direct-feed
+// fields, backward right-hand-side map, exchange layout) for 16 x 16 patches, in closed form: one launch instead of k_st_scan_pair,
+// k_st_clear, k_st_inv_ysrc, k_st_scat and k_st_xch_pair
+void grid_scat_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, int32_t *ltabF, int32_t *ltabB, int32_t *wtabF, int32_t *wtabB,
+                      int32_t *ysrc, int32_t *rtab, int32_t *xeF, int32_t *xeB, int32_t *xwF, int32_t *xwB, int32_t *flagsF, int32_t *flagsB,
+                      int32_t *tot);
 // a verdict computed on another stream that a read-back of the analysis takes along: the stream waits for `ev`, then *host = *dev
 struct SideJoin { hipEvent_t ev; const int32_t *dev; int32_t *host; bool done; };
 int ilu0_csr_ptrs(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);

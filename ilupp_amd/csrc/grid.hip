@@ -273,6 +273,206 @@ bool grid_lane_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, c
     return link;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Everything else the static analysis makes from the lane tables of a box grid in 16 x 16 patches -- the waves' first chunks (st.hip:
+// st_scan_body), where a lane's rows sit in the other schedule's records and where their upper entries go as transposed entries
+// (k_st_scat), the direct-feed fields (st_common.h: sd_tab_lane), the forward <-> backward slot maps (k_st_inv_ysrc) and the exchange
+// layout (k_st_xch_pair) -- in closed form from the lane's place: no table of another lane is read, nothing is scanned.  One launch,
+// block (w, d): workgroup w of the forward (d = 0) / backward (d = 1) schedule.  Both schedules place their blocks the same way (the
+// backward one on the mirrored grid), so one set of formulas serves both.
+// ---------------------------------------------------------------------------------------------
+struct GridGeom { int32_t nx, ny, nz, nb, NY, NZ, nyl, nzl; };                  // nyl / nzl: lines of the last patch in y / z
+
+__device__ __forceinline__ int gt_skew(const int t) { return (t & 15) + (t >> 4) + (t >> 6) * (kWrLag - 1); }
+__device__ __forceinline__ int gt_wave_nch(const GridGeom &g, const int nyt, const int nzt, const int w)
+{
+    if (4 * w >= nzt) return 0;
+    const int zmax = min(4 * w + 3, nzt - 1);
+    return g.nx + nyt - 1 + zmax + (zmax >> 2) * (kWrLag - 1) - (4 * w + w * (kWrLag - 1));
+}
+__device__ __forceinline__ int gt_tile_chunks(const GridGeom &g, const int nyt, const int nzt)
+{
+    return gt_wave_nch(g, nyt, nzt, 0) + gt_wave_nch(g, nyt, nzt, 1) + gt_wave_nch(g, nyt, nzt, 2) + gt_wave_nch(g, nyt, nzt, 3);
+}
+// first chunk of wave w of workgroup T (row-major over the NY x NZ patches; only the last row / column of patches is partial)
+__device__ __forceinline__ int gt_wave_base(const GridGeom &g, const int T, const int w)
+{
+    const int Y = T % g.NY, Z = T / g.NY;
+    const int nyt = Y == g.NY - 1 ? g.nyl : 16, nzt = Z == g.NZ - 1 ? g.nzl : 16;
+    const long row_full = (long)(g.NY - 1) * gt_tile_chunks(g, 16, 16) + gt_tile_chunks(g, g.nyl, 16);
+    long base = (long)Z * row_full + (long)Y * gt_tile_chunks(g, 16, nzt);
+    for (int q = 0; q < w; ++q) base += gt_wave_nch(g, nyt, nzt, q);
+    return (int)base;
+}
+__device__ __forceinline__ int gt_wave_tmin(const int w) { return 4 * w + w * (kWrLag - 1); }
+// exchange of workgroup T: exported lanes rounded up to 16, steps (first step 0), entries
+__device__ __forceinline__ void gt_xch(const GridGeom &g, const int Y, const int Z, int *E, int *steps)
+{
+    const int nyt = Y == g.NY - 1 ? g.nyl : 16, nzt = Z == g.NZ - 1 ? g.nzl : 16;
+    const bool ey = Y < g.NY - 1, ez = Z < g.NZ - 1;
+    const int ex = (ey ? nzt : 0) + (ez ? nyt : 0) - ((ey && ez) ? 1 : 0);
+    int thi = 0;
+    for (int w = 0; 4 * w < nzt; ++w) thi = max(thi, gt_wave_tmin(w) + gt_wave_nch(g, nyt, nzt, w));
+    *E = (ex + 15) & ~15; *steps = thi;
+}
+__device__ __forceinline__ long gt_xch_offset(const GridGeom &g, const int T)
+{
+    const int Y = T % g.NY, Z = T / g.NY;
+    int E, st;
+    long row_full = 0;
+    gt_xch(g, 0, 0, &E, &st);                      // (a patch that is last in neither direction: only counted when there is one)
+    if (g.NY > 1 && g.NZ > 1) row_full += (long)(g.NY - 1) * E * st;
+    if (g.NZ > 1) { gt_xch(g, g.NY - 1, 0, &E, &st); row_full += (long)E * st; }
+    long off = (long)Z * row_full;
+    if (Y > 0) { gt_xch(g, 0, Z, &E, &st); off += (long)Y * E * st; }
+    return off;
+}
+
+struct GridScatArgs { int32_t *ltabF, *ltabB, *wtabF, *wtabB, *ysrc, *rtab, *xeF, *xeB, *xwF, *xwB, *flagsF, *flagsB, *tot; };
+
+__global__ void __launch_bounds__(kThreads)
+k_grid_scat(const GridPlace gp, const GridGeom g, const GridScatArgs X)
+{
+    const bool fwd = blockIdx.y == 0;
+    const int wg = blockIdx.x, t = threadIdx.x, w = t >> 6;
+    const int slot = wg * kThreads + t;
+    const int bs = grid_block_at(slot, gp);
+    const int b = bs < 0 ? -1 : (fwd ? bs : g.nb - 1 - bs);
+    const bool has = b >= 0;
+    const int Y = wg % g.NY, Z = wg / g.NY;
+    // the waves' chunk tables get their first chunks (scan), the totals go to the flags
+    if ((t & 63) == 0) (fwd ? X.wtabF : X.wtabB)[(size_t)(wg * 4 + w) * 4] = gt_wave_base(g, wg, w);
+    if (wg == 0 && t == 0) {
+        int32_t *fl = fwd ? X.flagsF : X.flagsB;
+        const int last = g.NY * g.NZ - 1;
+        const int nyt = g.nyl, nzt = g.nzl;
+        fl[1] = gt_wave_base(g, last, 0) + gt_tile_chunks(g, nyt, nzt);
+        int mx = 0;
+        for (int cy = 0; cy < 2; ++cy)
+            for (int cz = 0; cz < 2; ++cz) {
+                if ((cy == 0 && g.NY < 2) || (cz == 0 && g.NZ < 2)) continue;          // (no patch of that class)
+                for (int q = 0; q < 4; ++q) mx = max(mx, gt_wave_nch(g, cy ? g.nyl : 16, cz ? g.nzl : 16, q));
+            }
+        fl[2] = mx;
+    }
+    // the exchange: ordinal of an exported lane, {exported lanes rounded up to 16, first step, steps, first entry} of the workgroup
+    {
+        const bool ey = Y < g.NY - 1, ez = Z < g.NZ - 1;
+        const int yl = t & 15, zl = t >> 4;
+        const bool ex = has && ((ey && yl == 15) || (ez && zl == 15));
+        (fwd ? X.xeF : X.xeB)[slot] = ex ? zl * (ey ? 1 : 0) + ((ez && zl == 15) ? yl : 0) : -1;
+        if (t == 0) {
+            int E, st;
+            gt_xch(g, Y, Z, &E, &st);
+            const int off = (int)gt_xch_offset(g, wg);
+            *reinterpret_cast<int4 *>((fwd ? X.xwF : X.xwB) + (size_t)wg * 4) = make_int4(E, 0, st, off);
+            // (what k_st_xch_pair reports to the host: first entry and size of the last workgroup)
+            if (wg == g.NY * g.NZ - 1) { X.tot[fwd ? 0 : 2] = off; X.tot[fwd ? 1 : 3] = E * st; }
+        }
+    }
+    if (!fwd) {
+        if (!has) X.ysrc[slot] = 0;                  // (a lane without rows: the entry the forward lanes never write)
+        return;
+    }
+    // ---- forward lanes: k_st_scat + sd_tab_lane + k_st_inv_ysrc
+    int32_t *T = X.ltabF + (size_t)slot * kStTab;
+    int32_t *R = X.rtab + (size_t)slot * 32;
+    if (!has) {
+        *reinterpret_cast<int4 *>(R) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int4 *>(T + 24) = make_int4(-1, -1, 0, 0);
+        *reinterpret_cast<int4 *>(T + 28) = make_int4(-1, -1, -1, 0);
+        return;
+    }
+    const int y = b % g.ny, z = b / g.ny;
+    const int cnt = g.nx, first = b * g.nx, sk = gt_skew(t);
+    const bool own = g.nx > 1;
+    // this line in the backward schedule
+    const int su = grid_place(g.nb - 1 - b, gp), tu = su & 255, wgu = su >> 8, wu = su >> 6;
+    const int skB = gt_skew(tu);
+    const int baseF = gt_wave_base(g, wg, w), baseU = gt_wave_base(g, wgu, (su >> 6) & 3);
+    X.ysrc[su] = (baseF + (cnt - 1 + sk - gt_wave_tmin(w))) * 64 + (t & 63);
+    const int up0 = (baseU + (cnt - 1 + skB - gt_wave_tmin(wu & 3))) * 128 + (su & 63);
+    // forward template (ascending offset: line below, line before, own chain) and backward template (own chain, line after, line above)
+    const bool f0 = z > 0, f1 = y > 0, f2 = own, b0 = own, b1 = y < g.ny - 1, b2 = z < g.nz - 1;
+    const int sxy = g.nx * g.ny;
+    const int nd = (f0 ? 1 : 0) + (f1 ? 1 : 0) + (f2 ? 1 : 0), nu = (b0 ? 1 : 0) + (b1 ? 1 : 0) + (b2 ? 1 : 0);
+    // where the upper entries of this lane's rows go: into the record of row r + o, as the transposed entry of its elimination with row r
+    // (candidate c of the backward template -> chain cs, its dependency index jc with offset -o, the index kc of row r + o in that chain)
+    auto scat_of = [&](const int c) -> int {
+        int cs, jc, kc;
+        if (c == 0) { cs = slot; jc = nd - 1; kc = 1; }                                  // own chain: column r + 1
+        else if (c == 1) { cs = grid_place(b + 1, gp); jc = f0 ? 1 : 0; kc = 0; }        // line (y + 1, z): its dependency "line before"
+        else { cs = grid_place(b + g.ny, gp); jc = 0; kc = 0; }                         // line (y, z + 1): its dependency "line below"
+        const int cw = cs >> 6;
+        const int chunk0 = gt_wave_base(g, cs >> 8, cw & 3) + (kc + gt_skew(cs & 255) - gt_wave_tmin(cw & 3));
+        return (chunk0 * 256 + (2 + (jc >> 1)) * 64 + (cs & 63)) * 2 + (jc & 1);
+    };
+    const int j0 = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : -1));
+    const int j1 = b0 ? (b1 ? 1 : (b2 ? 2 : -1)) : ((b1 && b2) ? 2 : -1);
+    const int j2 = (b0 && b1 && b2) ? 2 : -1;
+    const int sc0 = j0 >= 0 ? scat_of(j0) : -1, sc1 = j1 >= 0 ? scat_of(j1) : -1, sc2 = j2 >= 0 ? scat_of(j2) : -1;
+    // which entry right of the pivot row's diagonal is the transposed entry of forward dependency j (sd_tab_lane: ST_Q)
+    const int qz = (own ? 1 : 0) + (y < g.ny - 1 ? 1 : 0);       // line (y, z - 1): its entry + sxy comes after + 1 and + nx
+    const int qy = own ? 1 : 0;                                   // line (y - 1, z): its entry + nx comes after + 1
+    const int i0 = f0 ? 0 : (f1 ? 1 : (f2 ? 2 : -1));
+    const int i1 = f0 ? (f1 ? 1 : (f2 ? 2 : -1)) : ((f1 && f2) ? 2 : -1);
+    const int i2 = (f0 && f1 && f2) ? 2 : -1;
+#define GS_Q(i_) ((i_) == 0 ? qz : ((i_) == 1 ? qy : ((i_) == 2 ? 0 : -1)))
+    const int q0 = GS_Q(i0), q1 = GS_Q(i1), q2 = GS_Q(i2);
+#undef GS_Q
+    const int p0 = (int)grid_row_start(0, y, z, GridDims{g.nx, g.ny, g.nz});
+    const int dfl = nu | ((own ? 1 : 0) << 2) | ((own ? 1 : 0) << 3) | ((nd + 1 + nu) << 4);
+    // lane table: UP0, SCAT, P0, DFL, Q (the rest stands since k_grid_lanes)
+    T[ST_UP0] = up0;
+    T[ST_SCAT] = sc0;
+    *reinterpret_cast<int4 *>(T + 24) = make_int4(sc1, sc2, p0, dfl);
+    *reinterpret_cast<int4 *>(T + 28) = make_int4(q0, q1, q2, 0);
+    // the rows pass' / transposed records' view of the lane (k_st_scat: rtab)
+#define GS_OFF_F(i_) ((i_) == 0 ? -sxy : ((i_) == 1 ? -g.nx : ((i_) == 2 ? -1 : 0)))
+#define GS_OFF_B(i_) ((i_) == 0 ? 1 : ((i_) == 1 ? g.nx : ((i_) == 2 ? sxy : 0)))
+    const int oF0 = GS_OFF_F(i0), oF1 = GS_OFF_F(i1), oF2 = GS_OFF_F(i2), oB0 = GS_OFF_B(j0), oB1 = GS_OFF_B(j1), oB2 = GS_OFF_B(j2);
+#undef GS_OFF_F
+#undef GS_OFF_B
+    const int klF0 = i0 == 2 ? 1 : 0, klF1 = i1 == 2 ? 1 : 0, klF2 = i2 == 2 ? 1 : 0;       // (own chain: every row but the first)
+    const int klB0 = j0 == 0 ? 1 : 0, klB1 = 0, klB2 = 0;
+    const int khF0 = i0 >= 0 ? cnt : 0, khF1 = i1 >= 0 ? cnt : 0, khF2 = i2 >= 0 ? cnt : 0;
+    const int khB0 = j0 >= 0 ? cnt : 0, khB1 = j1 >= 0 ? cnt : 0, khB2 = j2 >= 0 ? cnt : 0;
+    // the forward dependency's producer lane when it is one of the 64 lanes of the same wave: lane | (k' - k + 128) << 8
+    auto samewave = [&](const int i) -> int {
+        if (i < 0) return -1;
+        if (i == 2) return (t & 63) | ((-1 + 128) << 8);
+        const int os = grid_place(i == 0 ? b - g.ny : b - 1, gp);
+        return ((os >> 6) == (slot >> 6)) ? ((os & 63) | (128 << 8)) : -1;
+    };
+    int4 *R4 = reinterpret_cast<int4 *>(R);
+    R4[0] = make_int4(first, cnt, sk, nd);
+    R4[1] = make_int4(oF0, oF1, oF2, nu);
+    R4[2] = make_int4(oB0, oB1, oB2, up0);
+    R4[3] = make_int4(klF0, klF1, klF2, 0);
+    R4[4] = make_int4(khF0, khF1, khF2, 0);
+    R4[5] = make_int4(klB0, klB1, klB2, 0);
+    R4[6] = make_int4(khB0, khB1, khB2, 0);
+    R4[7] = make_int4(samewave(i0), samewave(i1), samewave(i2), 0);
+}
+
+void grid_scat_tables(hipStream_t st, const GridDims &gd, const Schedule &fwd, int32_t *ltabF, int32_t *ltabB, int32_t *wtabF, int32_t *wtabB,
+                      int32_t *ysrc, int32_t *rtab, int32_t *xeF, int32_t *xeB, int32_t *xwF, int32_t *xwB, int32_t *flagsF, int32_t *flagsB,
+                      int32_t *tot)
+{
+    GridPlace gp;
+    gp.nx = gd.nx; gp.ny = gd.ny; gp.nz = gd.nz; gp.nb = fwd.nb;
+    gp.s2 = fwd.tile_s2; gp.ty = fwd.tile_ty; gp.tz = fwd.tile_tz;
+    gp.NY = (gp.s2 + gp.ty - 1) / gp.ty;
+    gp.nslots = fwd.nslots;
+    GridGeom g;
+    g.nx = gd.nx; g.ny = gd.ny; g.nz = gd.nz; g.nb = fwd.nb;
+    g.NY = (gd.ny + 15) / 16; g.NZ = (gd.nz + 15) / 16;
+    g.nyl = gd.ny - 16 * (g.NY - 1); g.nzl = gd.nz - 16 * (g.NZ - 1);
+    GridScatArgs X = {ltabF, ltabB, wtabF, wtabB, ysrc, rtab, xeF, xeB, xwF, xwB, flagsF, flagsB, tot};
+    hipLaunchKernelGGL(k_grid_scat, dim3((unsigned)(fwd.nslots / kThreads), 2), dim3(kThreads), 0, st, gp, g, X);
+    ILUPP_HIP(hipGetLastError());
+}
+
 // Host: what the lane-table kernels will find for a box grid in 16 x 16 patches (st.hip: st_link_body -- skew of lane (y, z) of a patch =
 // y + z + (z / 4)(kWrLag - 1): one step per neighbour, one more across a wave's border --, st_scan_body, k_st_xch_pair).  Both
 // schedules have the same numbers (the backward one is the mirror image).

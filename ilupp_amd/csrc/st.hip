@@ -1535,7 +1535,11 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     if (!linked_by_grid)
         hipLaunchKernelGGL(k_st_link_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->skew, pu->skew,
                            pl->wtab, pu->wtab, pl->flags, pu->flags, st_wx_on() ? 1 : 0);
-    hipLaunchKernelGGL(k_st_scan_pair, dim3(2), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags, pu->wtab, pu->flags);
+    // (a box grid in 16 x 16 patches: one closed-form launch below instead of the scan, the clears, the slot maps, k_st_scat and the
+    // exchange layout -- grid.hip: k_grid_scat; ILUPP_GRID_SCAT=0: the general kernels on the grid's lane tables)
+    static const bool grid_scat_on = []() { const char *e = getenv("ILUPP_GRID_SCAT"); return !(e && atoi(e) == 0); }();
+    const bool scat_by_grid = linked_by_grid && grid_scat_on && getenv("ILUPP_SD_VERIFY") == nullptr;
+    if (!scat_by_grid) hipLaunchKernelGGL(k_st_scan_pair, dim3(2), dim3(kThreads), 0, st, nwg * 4, pl->wtab, pl->flags, pu->wtab, pu->flags);
     int32_t *inv = nullptr;
     ILUPP_HIP(pool_malloc(&inv, sizeof(int32_t) * (size_t)nslots));
     ILUPP_HIP(pool_malloc(&pu->ysrc, sizeof(int32_t) * (size_t)nslots));
@@ -1543,7 +1547,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
     // the rows pass' lane records (behind nslots unused ints); with them the lane fields and lane-level checks of the factor kernel
     // that reads A's values where they lie (st_direct.hip; its verdict: pl->flags[8])
     const bool try_direct = st_direct_prepare(st, A, fwd, pl->flags + 8);
-    {
+    if (!scat_by_grid) {
         // (what has to be cleared: one launch)
         StClearList cl;
         cl.p[0] = inv; cl.v[0] = -1; cl.n[0] = nslots;
@@ -1551,12 +1555,14 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         cl.p[2] = nullptr; cl.v[2] = 0; cl.n[2] = 0;
         cl.p[3] = nullptr; cl.v[3] = 0; cl.n[3] = 0;
         hipLaunchKernelGGL(k_st_clear, dim3(gb), dim3(256), 0, st, cl);
+        hipLaunchKernelGGL(k_st_inv_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
     }
-    hipLaunchKernelGGL(k_st_inv_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
     ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots * 33));
-    hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
-                       f->xbase + nslots, pl->flags, A.ptr, try_direct ? pl->flags + 8 : static_cast<int32_t *>(nullptr));
-    if (try_direct) st_direct_verify(st, A, fwd, pl, pu, pl->flags + 8);
+    if (!scat_by_grid) {
+        hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
+                           f->xbase + nslots, pl->flags, A.ptr, try_direct ? pl->flags + 8 : static_cast<int32_t *>(nullptr));
+        if (try_direct) st_direct_verify(st, A, fwd, pl, pu, pl->flags + 8);
+    }
     // the exchange layouts of both schedules; their sizes come back with the flags (one wait for all)
     int32_t xtot[2][2];
     int32_t *xsz = nullptr;
@@ -1573,7 +1579,11 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
             xa[d].xe = pp[d]->xe; xa[d].xw = pp[d]->xw; xa[d].xsz = xsz + (size_t)d * nwg; xa[d].flags = pp[d]->flags;
         }
         int32_t *tot = xsz + (size_t)nwg * 2;
-        hipLaunchKernelGGL(k_st_xch_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, xa[0], xa[1], (int32_t)nwg, tot);
+        if (scat_by_grid)
+            grid_scat_tables(st, *grid, fwd, pl->ltab, pu->ltab, pl->wtab, pu->wtab, pu->ysrc, f->xbase + nslots, pl->xe, pu->xe, pl->xw, pu->xw,
+                             pl->flags, pu->flags, tot);
+        else
+            hipLaunchKernelGGL(k_st_xch_pair, dim3((unsigned)nwg, 2), dim3(kThreads), 0, st, xa[0], xa[1], (int32_t)nwg, tot);
         D2HItem items[4];
         items[0] = {f->chk_xtot, tot, 4 * sizeof(int32_t)};
         items[1] = {f->chk_hl, pl->flags, sizeof(f->chk_hl)};

@@ -702,7 +702,11 @@ static constexpr int kWfLds = kWfRing + 3 * kWfArr + 64;
 #ifdef WF_HALF
 static constexpr int kWfProd = 3, kWfPer = 6, kWfRA = 4;
 #else
-static constexpr int kWfProd = 6, kWfPer = 6, kWfRA = 4;  // producer waves, groups of 8 lanes per wave, blocks read ahead
+#ifndef WF_RA
+#define WF_RA 4
+#endif
+static constexpr int kWfProd = 6, kWfPer = 6, kWfRA = WF_RA;  // producer waves, groups of 8 lanes per wave, blocks read ahead (1, 2 or 4)
+static_assert(WF_RA == 1 || WF_RA == 2 || WF_RA == 4, "the producers' ring of registers is walked with (bb + 2) % kWfRA inside trips of four blocks");
 #endif
 static constexpr int kWfThreads = kWfLanes + 64 + 64 * kWfProd;
 static_assert(kWfProd * kWfPer * 8 >= kWfLanes, "every lane needs a producer");
@@ -1083,8 +1087,8 @@ __device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds,
 #ifdef WX_STAMP
             const unsigned long long p0_ = __builtin_amdgcn_s_memtime();
 #endif
-            WFP_WRITE((bb + 2) & 3, bb & 1);
-            WFP_LOAD((bb + 2) & 3);
+            WFP_WRITE((bb + 2) % kWfRA, bb & 1);
+            WFP_LOAD((bb + 2) % kWfRA);
 #ifdef WX_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             pacc_ += __builtin_amdgcn_s_memtime() - p0_;

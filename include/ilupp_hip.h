@@ -328,6 +328,11 @@ const char *ilupp_hip_path(const ilupp_precond *p);
  * for every row by one streaming pass next to the lane-table kernels, grid.hip) or "general" (the pass over the pattern that finds the
  * chains of any matrix, symbolic.hip); "" for other objects.  Measurement / test hook, no counterpart in binding.cpp. */
 const char *ilupp_hip_analysis_path(const ilupp_precond *p);
+/* diagnostics (tests compare the closed-form tables of grid.hip with the ones the general kernels make): table `which` of a static ILU(0)
+ * object as 32-bit words -- 0 / 1 lane tables (forward / backward schedule), 2 / 3 chunk tables, 4 backward right-hand-side map, 5 rows-pass
+ * records, 6 / 7 export ordinals, 8 / 9 exchange layout, 10 forward -> backward slots, 11 / 12 skews; returns the words copied (<= cap), -1
+ * where there is no such table.  No counterpart in binding.cpp. */
+long long ilupp_hip_debug_static_table(ilupp_precond *p, int which, int32_t *out, long long cap);
 /* measurement hook: the kernels a static ILU(0) object runs, "factor;forward sweep;backward sweep" ("" otherwise); no counterpart in binding.cpp */
 const char *ilupp_hip_kernel_names(const ilupp_precond *p);
 /* redo the numeric phase on (possibly new) values with the SAME pattern (buffers reused); times it */

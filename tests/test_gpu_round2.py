@@ -423,6 +423,8 @@ def test_bench_two_ranks_on_one_gpu():
     b10 = out["batch_ml_config10"]
     assert "default_configuration(10)" in b10["what"] and b10["identical_to_single_rank"] and [x["matrix"] for x in b10["records"]] == [0, 1]
     assert b10["records"][0]["sha256_apply"] != b10["records"][1]["sha256_apply"]
+    # ... at the size BASELINE.json names: n = 10^6 for both presets
+    assert b10["n"] == 1000000 and b10["preset"] == 10 and out["batch_ml"]["n"] == 1000000
 
 
 def test_bench_single_gpu_line():
@@ -435,6 +437,7 @@ def test_bench_single_gpu_line():
     out = json.loads(line[-1])
     assert out["n_gpus"] == 1 and out["parity"]["apply_ones_equal"] is True
     assert out["roofline"]["kernel"] in ("k_ilu0_wx", "k_ilu0_sd") and out["roofline"]["frac"] > 0 and out["roofline"]["step_frac"] > 0
+    assert out["headline_fraction"] == out["roofline"]["step_frac"] == out["hbm_fraction_factor_plus_apply"]
     assert [ph["name"] for ph in out["roofline"]["phases"]][0] in ("k_ilu0_wx", "k_ilu0_sd")
     assert out["cpu_baseline"]["kind"] in ("reference", "port") and out["cpu_baseline"]["apply_paths_agree"]
 
