@@ -133,16 +133,18 @@ static int32_t read_device_nnz(const int32_t *d_indptr, int32_t n)
 }
 
 // indptr[n] plus {indptr[0], indptr[1], indices[0..7]} (-1 where the matrix has no such entry) with ONE read-back
-__global__ void k_read_head(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t n, int32_t *__restrict__ out)
+__global__ void k_read_head(const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t n, int32_t *__restrict__ out,
+                            int32_t *__restrict__ zero)
 {
     const int t = threadIdx.x;
     const int32_t nnz = ptr[n];
+    if (t == 63 && zero) *zero = 0;               // (the verdict word of grid.hip's proof: clean before anything is launched)
     if (t == 0) out[0] = nnz;
     if (t == 1) out[1] = ptr[0];
     if (t == 2) out[2] = ptr[1];
     if (t >= 3 && t < 11) out[t] = (t - 3 < nnz) ? idx[t - 3] : -1;
 }
-static int32_t read_device_head(const int32_t *d_indptr, const int32_t *d_indices, int32_t n, int32_t *head)
+static int32_t read_device_head(const int32_t *d_indptr, const int32_t *d_indices, int32_t n, int32_t *head, int32_t *d_zero = nullptr)
 {
     static int32_t *stage = nullptr;         // pinned, mapped: the kernel writes where the host reads
     static int32_t *stage_dev = nullptr;
@@ -153,7 +155,7 @@ static int32_t read_device_head(const int32_t *d_indptr, const int32_t *d_indice
         ILUPP_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&stage_dev), stage, 0));
     }
     hipStream_t s = g_caller_stream_set ? g_caller_stream : nullptr;
-    hipLaunchKernelGGL(k_read_head, dim3(1), dim3(64), 0, s, d_indptr, d_indices, n, stage_dev);
+    hipLaunchKernelGGL(k_read_head, dim3(1), dim3(64), 0, s, d_indptr, d_indices, n, stage_dev, d_zero);
     ILUPP_HIP(hipGetLastError());
     ILUPP_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < 10; ++i) head[i] = stage[1 + i];
@@ -220,6 +222,7 @@ struct ilupp_precond {
     bool apply_events_valid = false;
     int max_lanes = 65536;
     bool grid_path = false;      // ILU(0): the row blocks came from grid.hip's guess (proven for every row)
+    bool verdict_clean = false;  // ctrl[8] (the verdict word of grid.hip's proof) is zero already
     bool ctrl_armed = false;     // the control words are zero and both exchange buffers all-sentinel already (arm_apply): the next plain apply starts with its first sweep
     bool borrowed_queue = false; // stream and events belong to another object (the levels of a multilevel preconditioner share one)
 };
@@ -379,7 +382,8 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     bool lm = false;
     for (;;) {
         if (grid) {
-            ILUPP_HIP(hipMemsetAsync(p->ctrl + 8, 0, sizeof(int32_t), st));
+            if (p->verdict_clean) p->verdict_clean = false;
+            else ILUPP_HIP(hipMemsetAsync(p->ctrl + 8, 0, sizeof(int32_t), st));
             if (grid_mode == 0) {
                 ILUPP_HIP(hipEventRecord(p->jev[0], st));
                 ILUPP_HIP(hipStreamWaitEvent(p->side, p->jev[0], 0));
@@ -455,6 +459,8 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
         }
         if (!(p->pkL.valid && p->pkU.valid)) { p->pkL.release(); p->pkU.release(); }
     }
+    // (the factor kernel lives on short hand-over latencies: next to the proof's 4.6 TB/s stream it loses more than waiting for the proof
+    // costs -- with the lane tables in closed form the proof is what the analysis phase lasts)
     ILUPP_HIP(hipEventRecord(a1, st));
     if (grid && grid_mode == 2) {
         ILUPP_HIP(hipEventRecord(p->jev[0], st));
@@ -465,7 +471,11 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     float kms = 0.f;
     // (the factor kernel's own read-back waits for the proof and takes its verdict along: no round trip of its own)
     const bool wx_numeric = p->flm.built && p->flm.stat && p->flm.direct && p->flm.wxf;
+    // (mode 0: the factor kernel waits for the proof -- it lives on short hand-over latencies and loses more next to the proof's 4.6 TB/s
+    // stream than the wait costs --, but what is queued in front of it, the clearing of its control words and exchange, does not)
     p->pkL.join_ev = (grid && grid_mode != 1 && wx_numeric) ? p->jev[1] : nullptr;
+    p->pkL.join_before = grid && grid_mode == 0 && wx_numeric;
+    if (grid && grid_mode == 0 && !wx_numeric) ILUPP_HIP(hipStreamWaitEvent(st, p->jev[1], 0));
     p->pkL.join_verdict = -1;                       // (-1: nobody has read the verdict yet)
     rc = ilu0_numeric_any(p, A, have_prog, &kms);
     p->pkL.join_ev = nullptr;
@@ -500,8 +510,15 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
         p->grid_path = false;
         return ilu0_factor(p, A, nullptr);
     }
-    ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
-    ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
+    if (grid && grid_mode == 0 && wx_numeric && rc == ILUPP_OK) {
+        // (the proof ends in front of the factor kernel, behind the launches that clear its control words: the analysis phase lasts until
+        // the event in front of that kernel, ev[4], not until a1)
+        ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, p->ev[4]));
+        ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[4], a2));
+    } else {
+        ILUPP_HIP(hipEventElapsedTime(&p->tm.analysis_ms, a0, a1));
+        ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, a1, a2));
+    }
     p->tm.numeric_kernel_ms = kms;
     if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out (invalid structure?)");
     if (rc == ILUPP_OK) arm_apply(p);
@@ -778,9 +795,9 @@ int finish_apply(ilupp_precond *p)
     return ILUPP_OK;
 }
 
-int ilu0_create_common(const DevMat &A, int is_csr, const int32_t *head, ilupp_precond **out)
+int ilu0_create_common(const DevMat &A, int is_csr, const int32_t *head, ilupp_precond **out, ilupp_precond *made = nullptr)
 {
-    ilupp_precond *p = new_obj(A.n);
+    ilupp_precond *p = made ? made : new_obj(A.n);
     p->kind = KIND_LU;
     p->nnz_mode = NNZ_GENERIC_LU;
     p->input_csc = !is_csr;
@@ -856,11 +873,14 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
     if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
     // indptr[n], and the head of the matrix for grid.hip's guess: one read-back
     int32_t head[10];
-    const int32_t nnz32 = read_device_head(d_indptr, d_indices, n, head);
+    ilupp_precond *p = new_obj(n);                 // (first: the read-back below also cleans the object's verdict word)
+    int32_t nnz32 = 0;
+    try { nnz32 = read_device_head(d_indptr, d_indices, n, head, p->ctrl + 8); } catch (...) { destroy_obj(p); throw; }
+    p->verdict_clean = true;
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
-    return ilu0_create_common(A, is_csr, head, out);
+    return ilu0_create_common(A, is_csr, head, out, p);
     API_CATCH
 }
 

@@ -152,6 +152,7 @@ struct PackedSweep {
     // (forward sweep of an ILU(0) whose row blocks were guessed, grid.hip) the proof's end on its side stream and its verdict word, ctrl[8]:
     // the factor kernel's own read-back waits for the one and takes the other along
     hipEvent_t join_ev = nullptr;
+    bool join_before = false;           // wait for join_ev in front of the factor kernel (behind the launches that prepare it), not behind it
     int32_t join_verdict = 0;
     mutable bool xch_armed = false;     // the exchange buffer is all-sentinel already (api.hip: arm_apply, behind the previous call's last wait): the sweep need not fill it
     void release();

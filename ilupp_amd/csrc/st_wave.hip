@@ -1290,12 +1290,13 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     a.val_bytes = (uint32_t)(A.nnz * 8 + a.val_shift);
     a.pkL = reinterpret_cast<unsigned char *>(pl->pk); a.pkU = reinterpret_cast<unsigned char *>(pu->pk);
     a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
+    if (pl->join_ev && pl->join_before) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));       // (grid.hip's proof, on its side stream)
     ILUPP_HIP(hipEventRecord(e0, st));
     hipLaunchKernelGGL(k_ilu0_wx, dim3((unsigned)pl->nwg), dim3(kWfThreads), kWfLds, st, a);
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t ctrl[12];
-    if (pl->join_ev) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));          // (grid.hip's proof, on its side stream)
+    if (pl->join_ev && !pl->join_before) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));
     ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, sizeof(ctrl)));
     ILUPP_HIP(stream_sync(st));
     pl->join_verdict = ctrl[8];
