@@ -444,7 +444,7 @@ def main():
     def step(record):
         nonlocal P, nstep
         P = None      # release the previous factorisation first (its buffers go back to the allocator)
-        P = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True)
+        P = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True, nnz=nnz)
         tx = txs[nstep % nrhs]
         nstep += 1
         P.apply_device(tx.data_ptr(), n, transpose=False, sync=True)
@@ -612,7 +612,8 @@ def main():
             "config": {"workload": "C2: ILU(0) factor + one L/U apply, 3-D 7-point Poisson %d^3 CSR (n=%d, nnz=%d), fp64/int32" % (g, n, nnz),
                        "parallelism": "1 matrix per GPU, no data-path collective" if world > 1 else "single GPU",
                        "step": "full ILU0Preconditioner construction (pattern analysis + row scheduling + numeric factorisation) "
-                               "+ one apply, A and x resident in HBM; wall clock over all steps",
+                               "+ one apply, A and x resident in HBM, the caller hands in len(indices) as nnz (ilupp_hip_ilu0_create_device_nnz: "
+                               "no read-back before the construction starts); wall clock over all steps",
                        "path": path, "analysis": analysis_path},
             # THE fraction of this line: the whole step (factor + apply bytes of SURVEY 8d) over the wall clock of a step, against the
             # 8 TB/s HBM peak -- the number BASELINE.json's 0.40 target is about.  roofline.frac below is the dominant KERNEL's.

@@ -76,6 +76,7 @@ def lib():
     mat_host = [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int]
     L.ilupp_hip_ilu0_create.argtypes = mat_host + [ctypes.POINTER(_VP)]
     L.ilupp_hip_ilu0_create_device.argtypes = mat_host + [ctypes.POINTER(_VP)]
+    L.ilupp_hip_ilu0_create_device_nnz.argtypes = [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(_VP)]
     L.ilupp_hip_ilu0_refactor_device.argtypes = [_VP, _VP, _VP, _VP]
     L.ilupp_hip_ilut_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
     L.ilupp_hip_iluc_create.argtypes = mat_host + [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(_VP)]
@@ -164,7 +165,7 @@ def lib():
 # names every symbol include/ilupp_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "ilupp_hip_index_size", "ilupp_hip_last_error", "ilupp_hip_set_device", "ilupp_hip_device_count",
-    "ilupp_hip_ilu0_create", "ilupp_hip_ilu0_create_device", "ilupp_hip_ilut_create",
+    "ilupp_hip_ilu0_create", "ilupp_hip_ilu0_create_device", "ilupp_hip_ilu0_create_device_nnz", "ilupp_hip_ilut_create",
     "ilupp_hip_ichol0_create", "ilupp_hip_icholt_create", "ilupp_hip_destroy",
     "ilupp_hip_apply", "ilupp_hip_apply_trans", "ilupp_hip_apply_device", "ilupp_hip_total_nnz",
     "ilupp_hip_memory_used_calculations", "ilupp_hip_memory_allocated_calculations", "ilupp_hip_memory",
@@ -535,10 +536,14 @@ def ILU0Preconditioner(A_data, A_indices, A_indptr, is_csr):
     return _create(lib().ilupp_hip_ilu0_create, A_data, A_indices, A_indptr, is_csr)
 
 
-def ILU0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr):
-    """ILU(0) of a matrix already resident in HBM (device pointers as ints)."""
+def ILU0Preconditioner_device(d_data, d_indices, d_indptr, n, is_csr, nnz=None):
+    """ILU(0) of a matrix already resident in HBM (device pointers as ints).  nnz: the number of stored entries when the caller knows it
+    (the length of its arrays): the construction then need not read indptr[n] back (ilupp_hip_ilu0_create_device_nnz)."""
     h = _VP()
-    rc = lib().ilupp_hip_ilu0_create_device(d_data, d_indices, d_indptr, n, 1 if is_csr else 0, ctypes.byref(h))
+    if nnz is not None:
+        rc = lib().ilupp_hip_ilu0_create_device_nnz(d_data, d_indices, d_indptr, n, int(nnz), 1 if is_csr else 0, ctypes.byref(h))
+    else:
+        rc = lib().ilupp_hip_ilu0_create_device(d_data, d_indices, d_indptr, n, 1 if is_csr else 0, ctypes.byref(h))
     if rc:
         _raise(rc)
     return Preconditioner(h)

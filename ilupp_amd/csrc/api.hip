@@ -222,6 +222,7 @@ struct ilupp_precond {
     bool apply_events_valid = false;
     int max_lanes = 65536;
     bool grid_path = false;      // ILU(0): the row blocks came from grid.hip's guess (proven for every row)
+    bool no_general_retry = false;   // (ilupp_hip_ilu0_create_device_nnz) a grid guess that fails ends the attempt: the caller reads the head and starts over
     bool verdict_clean = false;  // ctrl[8] (the verdict word of grid.hip's proof) is zero already
     bool ctrl_armed = false;     // the control words are zero and both exchange buffers all-sentinel already (arm_apply): the next plain apply starts with its first sweep
     bool borrowed_queue = false; // stream and events belong to another object (the levels of a multilevel preconditioner share one)
@@ -413,6 +414,10 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
         // static form first (lane tables, values-only records: st.hip; no descriptor words, hence no limit on block size or number
         // of slots), then the record-decoding level-major form
         lm = st_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm, nullptr, (grid && grid_tables) ? &gd : nullptr);
+        if (grid && !(lm && p->flm.stat && p->flm.direct) && p->no_general_retry) {
+            if (grid_mode == 0) ILUPP_HIP(hipStreamSynchronize(p->side));
+            return ILUPP_ERR_UNSUPPORTED;
+        }
         if (grid && !(lm && p->flm.stat && p->flm.direct)) {
             // a grid the static direct-feed form does not take (or not the guessed grid: the lane templates of sampled rows disagree):
             // nothing built on the guess survives; the general pass decides
@@ -477,16 +482,24 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     p->pkL.join_before = grid && grid_mode == 0 && wx_numeric;
     if (grid && grid_mode == 0 && !wx_numeric) ILUPP_HIP(hipStreamWaitEvent(st, p->jev[1], 0));
     p->pkL.join_verdict = -1;                       // (-1: nobody has read the verdict yet)
+    // (... and queues the arming of the first apply behind that read-back; the speculation's leftovers -- pending read-backs of the lane
+    // tables' flags -- lie in front of it too)
+    if (wx_numeric && p->jev[0]) { p->pkL.arm = [](void *c) { arm_apply(static_cast<ilupp_precond *>(c)); }; p->pkL.arm_ctx = p; p->pkL.arm_ev = p->jev[0]; }
     rc = ilu0_numeric_any(p, A, have_prog, &kms);
+    p->pkL.arm = nullptr; p->pkL.arm_ctx = nullptr; p->pkL.arm_ev = nullptr;
     p->pkL.join_ev = nullptr;
-    ILUPP_HIP(hipEventRecord(a2, st));
+    // (the wave-exchange factor kernel's own read-back has been waited for -- through an event, so that what it queued behind it, the
+    // arming of the first apply, runs on: no wait for the whole stream here then)
+    const bool waited = wx_numeric && p->pkL.join_verdict >= 0;
+    if (!waited) ILUPP_HIP(hipEventRecord(a2, st));
     if (grid && p->pkL.join_verdict >= 0) {
         grid_bad = p->pkL.join_verdict;
     } else if (grid) {
         if (grid_mode != 1) ILUPP_HIP(hipStreamWaitEvent(st, p->jev[1], 0));
         ILUPP_HIP(d2h_async(st, &grid_bad, p->ctrl + 8, sizeof(int32_t)));
     }
-    ILUPP_HIP(stream_sync(st));
+    if (!waited) ILUPP_HIP(stream_sync(st));
+    if (waited) a2 = p->ev[5];                        // (recorded behind the factor kernel)
     if (grid && p->flm.spec && grid_bad == 0) {
         // the sizes the lane-table kernels were launched with were predicted (st.hip: st_analyse_ilu0); what the device found is here now
         const FactorLM &f = p->flm;
@@ -508,8 +521,11 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
         p->sA.release(); p->sU.release();
         p->sA = Schedule(); p->sU = Schedule();
         p->grid_path = false;
+        grid_shape_forget(A.n, A.nnz);
+        if (p->no_general_retry) return ILUPP_ERR_UNSUPPORTED;
         return ilu0_factor(p, A, nullptr);
     }
+    if (grid && rc == ILUPP_OK) grid_shape_remember(A.n, A.nnz, gd);
     if (grid && grid_mode == 0 && wx_numeric && rc == ILUPP_OK) {
         // (the proof ends in front of the factor kernel, behind the launches that clear its control words: the analysis phase lasts until
         // the event in front of that kernel, ev[4], not until a1)
@@ -521,7 +537,7 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     }
     p->tm.numeric_kernel_ms = kms;
     if (rc == ILUPP_ERR_TIMEOUT) set_error("ILU0: dependency wait timed out (invalid structure?)");
-    if (rc == ILUPP_OK) arm_apply(p);
+    if (rc == ILUPP_OK && !p->ctrl_armed) arm_apply(p);
     return rc;
 }
 
@@ -778,7 +794,16 @@ int finish_apply(ilupp_precond *p)
 {
     int32_t err = 0;
     ILUPP_HIP(d2h_async(p->stream, &err, p->ctrl, sizeof(int32_t)));
-    ILUPP_HIP(stream_sync(p->stream));
+    bool armed_here = false;
+    if (p->jev[0] && !p->borrowed_queue) {
+        // (the next apply is armed behind this read-back and in front of the wait for it)
+        ILUPP_HIP(hipEventRecord(p->jev[0], p->stream));
+        arm_apply(p);
+        armed_here = true;
+        ILUPP_HIP(event_sync(p->stream, p->jev[0]));
+    } else {
+        ILUPP_HIP(stream_sync(p->stream));
+    }
     if (p->apply_events_valid) {
         ILUPP_HIP(hipEventElapsedTime(&p->tm.lsolve_kernel_ms, p->ev[0], p->ev[1]));
         ILUPP_HIP(hipEventElapsedTime(&p->tm.usolve_kernel_ms, p->ev[1], p->ev[2]));
@@ -791,7 +816,7 @@ int finish_apply(ilupp_precond *p)
         set_error("triangular solve: dependency wait timed out (factor not triangular?)");
         return ILUPP_ERR_TIMEOUT;
     }
-    arm_apply(p);
+    if (!armed_here) arm_apply(p);
     return ILUPP_OK;
 }
 
@@ -882,6 +907,41 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
     return ilu0_create_common(A, is_csr, head, out, p);
     API_CATCH
+}
+
+int ilupp_hip_ilu0_create_device_nnz(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                     int32_t n, int64_t nnz, int is_csr, ilupp_precond **out)
+{
+    {
+        API_TRY_BUILD
+        if (!out) { set_error("null output"); return ILUPP_ERR_INVALID; }
+        *out = nullptr;
+        if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
+        // the dimensions a matrix of this size had when it last was a box grid: the head a grid of those dimensions has (nothing is read)
+        GridDims gd = {0, 0, 0};
+        if (nnz > 0 && nnz < (1LL << 31) && grid_shape_recall(n, nnz, &gd)) {
+            int32_t head[10] = {0, gd.nz > 1 ? 4 : 3, 0, 1, gd.nx, gd.nz > 1 ? gd.nx * gd.ny : -1, -1, -1, -1, -1};
+            DevMat A;
+            A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = false;
+            A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
+            ilupp_precond *p = new_obj(n);
+            p->kind = KIND_LU; p->nnz_mode = NNZ_GENERIC_LU; p->input_csc = !is_csr;
+            p->no_general_retry = true;            // (a failed proof must not run the general pass with an nnz nobody has checked)
+            const int rc = ilu0_factor(p, A, head);
+            if (rc == ILUPP_OK) { *out = p; return ILUPP_OK; }
+            destroy_obj(p);
+            if (rc != ILUPP_ERR_UNSUPPORTED) return rc;
+        }
+        API_CATCH
+    }
+    // the reading way; the caller's nnz is checked against indptr[n]
+    const int rc = ilupp_hip_ilu0_create_device(d_data, d_indices, d_indptr, n, is_csr, out);
+    if (rc == ILUPP_OK && *out && (*out)->nnzA != nnz) {
+        ilupp_hip_destroy(*out); *out = nullptr;
+        set_error("ILU0: the number of stored entries handed in is not indptr[n]");
+        return ILUPP_ERR_INVALID;
+    }
+    return rc;
 }
 
 int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices, const int32_t *d_indptr)

@@ -154,6 +154,11 @@ struct PackedSweep {
     hipEvent_t join_ev = nullptr;
     bool join_before = false;           // wait for join_ev in front of the factor kernel (behind the launches that prepare it), not behind it
     int32_t join_verdict = 0;
+    // (forward sweep of a static ILU(0)) what the factor kernel's launch is followed by, behind its read-back and in front of the wait for
+    // it: the arming of the first apply (api.hip: arm_apply) -- `arm` runs with `arm_ctx`, the wait is for `arm_ev` instead of the stream
+    void (*arm)(void *) = nullptr;
+    void *arm_ctx = nullptr;
+    hipEvent_t arm_ev = nullptr;
     mutable bool xch_armed = false;     // the exchange buffer is all-sentinel already (api.hip: arm_apply, behind the previous call's last wait): the sweep need not fill it
     void release();
 };
@@ -309,6 +314,9 @@ bool wx_vec_on();            // st_wave.hip: the sweeps move the caller's vector
 // grid.hip: the first analysis pass for lexicographic box-grid stencil matrices (guess from row 0, proof on a side stream)
 struct GridDims { int32_t nx, ny, nz; };
 bool grid_guess(int32_t n, int64_t nnz, const int32_t *head /* ptr[0], ptr[1], idx[0..7] */, GridDims *g);
+bool grid_shape_recall(int32_t n, int64_t nnz, GridDims *g);
+void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g);
+void grid_shape_forget(int32_t n, int64_t nnz);
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
 void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
                     int32_t *max_row_len, int max_wgs);
@@ -364,6 +372,7 @@ hipError_t d2h_async(hipStream_t st, void *host_dst, const void *dev_src, size_t
 struct D2HItem { void *dst; const void *src; size_t bytes; };
 hipError_t d2h_async_many(hipStream_t st, const D2HItem *items, int n);   // up to 8 read-backs with one launch
 hipError_t stream_sync(hipStream_t st);
+hipError_t event_sync(hipStream_t st, hipEvent_t ev);      // ... for an event behind all pending read-backs of st (what is queued behind it runs on)
 void d2h_cancel_all();
 
 // schedule.hip

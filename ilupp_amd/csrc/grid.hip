@@ -13,6 +13,10 @@
 //     proof: everything built on the guess is dropped and the general pass runs (api.hip: ilu0_factor).
 // Nothing downstream changes: the lane tables, the factor kernel and the sweeps are the ones of st.hip / st_wave.hip; the reference
 // semantics are ILU0.hpp:26-66 as before (this file only replaces how the row blocks are found, ILU0.hpp has no counterpart).
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "st_common.h"
 
 namespace ilupp {
@@ -49,6 +53,31 @@ bool grid_guess(int32_t n, int64_t nnz, const int32_t *head, GridDims *g)
     if (nx < 16 || ny < 4 || ny * nz < 2 * kThreads || nx > (1 << 20) || ny > (1 << 20) || nz > (1 << 20)) return false;
     g->nx = (int32_t)nx; g->ny = (int32_t)ny; g->nz = (int32_t)nz;
     return nnz == (int64_t)n + 2 * grid_links(*g) && nnz < (1LL << 30);        // (k_grid_check covers the index array with one buffer resource)
+}
+
+// the dimensions of the box grids this process has factored, by (n, nnz): ilupp_hip_ilu0_create_device_nnz guesses them again without
+// reading the matrix' head back (a guess, nothing more: the proof runs every time)
+namespace {
+struct ShapeMemo { std::mutex mu; std::vector<std::pair<std::pair<int64_t, int64_t>, GridDims>> seen; } g_shapes;
+}
+bool grid_shape_recall(int32_t n, int64_t nnz, GridDims *g)
+{
+    std::lock_guard<std::mutex> lk(g_shapes.mu);
+    for (const auto &e : g_shapes.seen) if (e.first.first == n && e.first.second == nnz) { *g = e.second; return true; }
+    return false;
+}
+void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g)
+{
+    std::lock_guard<std::mutex> lk(g_shapes.mu);
+    for (auto &e : g_shapes.seen) if (e.first.first == n && e.first.second == nnz) { e.second = g; return; }
+    if (g_shapes.seen.size() >= 64) g_shapes.seen.erase(g_shapes.seen.begin());
+    g_shapes.seen.push_back({{n, nnz}, g});
+}
+void grid_shape_forget(int32_t n, int64_t nnz)
+{
+    std::lock_guard<std::mutex> lk(g_shapes.mu);
+    for (size_t i = 0; i < g_shapes.seen.size(); ++i)
+        if (g_shapes.seen[i].first.first == n && g_shapes.seen[i].first.second == nnz) { g_shapes.seen.erase(g_shapes.seen.begin() + (long)i); return; }
 }
 
 // entries before row r = (x, y, z): seven per row minus the neighbours that fall outside the box

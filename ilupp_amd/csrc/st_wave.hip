@@ -1298,7 +1298,15 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     int32_t ctrl[12];
     if (pl->join_ev && !pl->join_before) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));
     ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, sizeof(ctrl)));
-    ILUPP_HIP(stream_sync(st));
+    if (pl->arm && pl->arm_ev) {
+        // (the first apply's control words and exchange buffers are made ready behind the read-back, while the host is on its way back)
+        pl->fmt = pu->fmt = 1;                       // (what the kernel in flight writes)
+        ILUPP_HIP(hipEventRecord(pl->arm_ev, st));
+        pl->arm(pl->arm_ctx);
+        ILUPP_HIP(event_sync(st, pl->arm_ev));
+    } else {
+        ILUPP_HIP(stream_sync(st));
+    }
     pl->join_verdict = ctrl[8];
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;

@@ -118,6 +118,22 @@ hipError_t stream_sync(hipStream_t st)
     return e;
 }
 
+// wait for an event recorded on `st` BEHIND its read-backs instead of for the whole stream: what was queued behind the event (the arming
+// of the next apply, api.hip) runs on while the host goes back to its caller.  Every pending read-back of `st` must lie before `ev`.
+hipError_t event_sync(hipStream_t st, hipEvent_t ev)
+{
+    const hipError_t e = hipEventSynchronize(ev);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    auto it = g_stage.find(st);
+    if (it != g_stage.end()) {
+        Staging &s = it->second;
+        if (e == hipSuccess) for (const auto &p : s.pending) memcpy(p.dst, s.host + p.off, p.bytes);
+        s.pending.clear();
+        s.used = 0;
+    }
+    return e;
+}
+
 __global__ void k_iota_i32(int32_t *p, int64_t count)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

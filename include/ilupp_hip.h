@@ -76,6 +76,12 @@ int ilupp_hip_ilu0_create(const double *data, const int32_t *indices, const int3
                           int32_t n, int is_csr, ilupp_precond **out);
 int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
                                  int32_t n, int is_csr, ilupp_precond **out);
+/* ... for a caller that KNOWS the number of stored entries (the length of the arrays it holds -- what the reference reads as pointer[last],
+ * sparse_implementation.h:3076-3089): nothing is read back before the construction starts when a matrix of this (n, nnz) was a box grid
+ * before in this process (the dimensions are guessed again, grid.hip; the proof on the device covers indptr[n] == nnz and every row, and a
+ * failed proof, or an (n, nnz) not seen before, takes the reading way of ilupp_hip_ilu0_create_device).  A wrong nnz is an error. */
+int ilupp_hip_ilu0_create_device_nnz(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
+                                     int32_t n, int64_t nnz, int is_csr, ilupp_precond **out);
 
 /* binding.cpp:299-310  ILUTPreconditioner.__init__(..., max_fill_in, threshold)  (ILUT.hpp:199-278) */
 int ilupp_hip_ilut_create(const double *data, const int32_t *indices, const int32_t *indptr,
