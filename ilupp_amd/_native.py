@@ -92,6 +92,8 @@ def lib():
     L.ilupp_hip_path.restype = ctypes.c_char_p
     L.ilupp_hip_analysis_path.argtypes = [_VP]
     L.ilupp_hip_analysis_path.restype = ctypes.c_char_p
+    L.ilupp_hip_debug_static_table.argtypes = [_VP, ctypes.c_int, _VP, ctypes.c_longlong]
+    L.ilupp_hip_debug_static_table.restype = ctypes.c_longlong
     L.ilupp_hip_kernel_names.argtypes = [_VP]
     L.ilupp_hip_kernel_names.restype = ctypes.c_char_p
     L.ilupp_hip_destroy.argtypes = [_VP]
@@ -173,7 +175,7 @@ ABI_SYMBOLS = [
     "ilupp_hip_num_factors", "ilupp_hip_factor_info", "ilupp_hip_factor_copy",
     "ilupp_hip_factor_device_ptrs", "ilupp_hip_get_timings", "ilupp_hip_ilu0_refactor_device",
     "ilupp_hip_sync", "ilupp_hip_release_cached_memory", "ilupp_hip_set_cache_limit", "ilupp_hip_cached_bytes", "ilupp_hip_live_blocks", "ilupp_hip_ilut_create_device", "ilupp_hip_ichol0_create_device",
-    "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_analysis_path", "ilupp_hip_kernel_names", "ilupp_hip_spmv_device",
+    "ilupp_hip_icholt_create_device", "ilupp_hip_set_caller_stream", "ilupp_hip_path", "ilupp_hip_analysis_path", "ilupp_hip_debug_static_table", "ilupp_hip_kernel_names", "ilupp_hip_spmv_device",
     "ilupp_hip_iluc_create", "ilupp_hip_iluc_create_device",
     "ilupp_hip_ml_default_params", "ilupp_hip_ml_create", "ilupp_hip_ml_create_device", "ilupp_hip_ml_destroy", "ilupp_hip_ml_apply",
     "ilupp_hip_ml_apply_device", "ilupp_hip_ml_apply_part_device", "ilupp_hip_ml_sync", "ilupp_hip_ml_levels", "ilupp_hip_ml_total_nnz", "ilupp_hip_ml_level_info",

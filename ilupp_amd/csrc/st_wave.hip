@@ -689,6 +689,10 @@ static constexpr int kWfLanes = 128, kWfPairs = 32;
 #else
 static constexpr int kWfLanes = kThreads, kWfPairs = 64;
 #endif
+#ifndef WF_PSLEEP
+#define WF_PSLEEP 4
+#endif
+static constexpr int kWfProdNap = WF_PSLEEP;              // s_sleep units (64 cycles) a producer waits behind each barrier before it issues loads
 static constexpr int kWfRow = kWfLanes + kWfPairs + 16;   // doubles per slot: lanes, courier pairs, [320] a cell of ones / zeros (+ padding: 4 rows = 21 x 512 B)
 static constexpr int kWfCell = kWfLanes + kWfPairs;
 static constexpr int kWfArr = 2 * kWfH * kWfRow * 8;      // bytes of one hand-off array
@@ -1088,6 +1092,9 @@ __device__ __forceinline__ void wf_producer(const WfArgs &A, unsigned char *lds,
             const unsigned long long p0_ = __builtin_amdgcn_s_memtime();
 #endif
             WFP_WRITE((bb + 2) % kWfRA, bb & 1);
+            // (the producers, who have eight steps of slack, let the courier's export and poll of this step into the CU's memory queue first:
+            // measured -2 % on the kernel at 256^3 with 2..6, nothing with 8, +5 % with 16)
+            __builtin_amdgcn_s_sleep(kWfProdNap);
             WFP_LOAD((bb + 2) % kWfRA);
 #ifdef WX_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -164,3 +164,48 @@ def test_device_resident_construction_and_the_head_read():
     Pd.apply_device(x.data_ptr(), n, transpose=False, sync=True)
     y = xb.copy(); P2.apply(y)
     assert np.array_equal(x.cpu().numpy(), y)
+
+
+def test_construction_with_the_number_of_entries_handed_in():
+    """ilupp_hip_ilu0_create_device_nnz: a shape remembered from an earlier proven grid is guessed again without reading the head (the proof
+    still covers every row and the last row pointer); a matrix of the same size that is no grid falls back to the reading way; a wrong
+    count is refused"""
+    import torch
+    from ilupp_amd import _native
+    d, i, p = matgen.poisson3d(80, 64, 32)
+    d = _unsym(d, 13)
+    n, nnz = p.shape[0] - 1, int(p[-1])
+    dev = torch.device("cuda", 0)
+    td, ti, tp = (torch.from_numpy(a).to(dev) for a in (d, i, p))
+    torch.cuda.synchronize()
+    Ph = _native.ILU0Preconditioner(d, i, p, True)                     # (remembers the shape)
+    assert Ph.analysis_path() == "grid"
+    b = np.random.default_rng(8).random(n)
+    want = b.copy(); Ph.apply(want)
+    for rep in range(2):
+        Pd = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True, nnz=nnz)
+        assert Pd.analysis_path() == "grid" and Pd.total_nnz == Ph.total_nnz
+        x = torch.from_numpy(b).to(dev)
+        Pd.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+        assert np.array_equal(x.cpu().numpy(), want)
+        for f, g in zip(Pd.factors_info(), Ph.factors_info()):
+            assert all(np.array_equal(a, c) for a, c in zip(f[:3], g[:3]))
+    # same n and nnz, one interior row with a column moved: the recalled guess fails its proof, the reading way takes the general pass
+    i2 = i.copy()
+    r = 10 * 80 * 64 + 20 * 80 + 40
+    i2[p[r] + 1] += 1
+    ti2 = torch.from_numpy(i2).to(dev)
+    torch.cuda.synchronize()
+    P2 = _native.ILU0Preconditioner_device(td.data_ptr(), ti2.data_ptr(), tp.data_ptr(), n, True, nnz=nnz)
+    Pg = _native.ILU0Preconditioner(d, i2, p, True)
+    assert P2.analysis_path() == Pg.analysis_path() == "general"
+    x = torch.from_numpy(b).to(dev)
+    P2.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+    y = b.copy(); Pg.apply(y)
+    assert np.array_equal(x.cpu().numpy(), y)
+    # (the failed proof dropped the remembered shape; the grid itself is taken for a grid again, the reading way)
+    P3 = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True, nnz=nnz)
+    assert P3.analysis_path() == "grid"
+    # a count that is not indptr[n]
+    with pytest.raises(RuntimeError, match="number of stored entries"):
+        _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True, nnz=nnz - 7)
