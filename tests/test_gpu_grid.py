@@ -47,7 +47,7 @@ def _check_against_oracle(a, want_analysis):
     return P
 
 
-@pytest.mark.parametrize("dims", [(64, 48, 40), (100, 37, 19), (33, 50, 40), (17, 64, 64), (1024, 700), (301, 300)])
+@pytest.mark.parametrize("dims", [(64, 48, 40), (100, 37, 19), (33, 50, 40), (17, 64, 64), (1024, 700), (129, 520)])
 def test_box_grids_take_the_grid_analysis(dims):
     """full and partial 16 x 16 patches, odd line lengths (the vector wave's 8-byte tail stores), 2-D grids (identity placement)"""
     d, i, p = matgen.poisson3d(*dims) if len(dims) == 3 else matgen.poisson2d(*dims)
@@ -56,7 +56,7 @@ def test_box_grids_take_the_grid_analysis(dims):
 
 def test_small_and_thin_grids_keep_the_general_analysis():
     """below 2^16 rows, lines shorter than 16 rows or fewer than 512 lines: the general pass (grid_guess declines)"""
-    for dims in ((33, 20, 30), (8, 100, 100), (300, 300)):
+    for dims in ((33, 20, 30), (8, 100, 100), (300, 300), (301, 300)):
         d, i, p = matgen.poisson3d(*dims) if len(dims) == 3 else matgen.poisson2d(*dims)
         _check_against_oracle((_unsym(d, 3), i, p), "general")
 
