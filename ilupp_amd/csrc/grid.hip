@@ -80,22 +80,6 @@ void grid_shape_forget(int32_t n, int64_t nnz)
         if (g_shapes.seen[i].first.first == n && g_shapes.seen[i].first.second == nnz) { g_shapes.seen.erase(g_shapes.seen.begin() + (long)i); return; }
 }
 
-// entries before row r = (x, y, z): seven per row minus the neighbours that fall outside the box
-__device__ __forceinline__ long long grid_row_start(const int x, const int y, const int z, const GridDims &g)
-{
-    const long long nx = g.nx, ny = g.ny;
-    const long long r = x + nx * (y + ny * (long long)z);
-    const bool z0 = z == 0, z1 = z == g.nz - 1, y0 = y == 0, y1 = y == g.ny - 1;
-    long long miss = 0;
-    // whole planes below: the ends of every line, the first and the last line, and all of plane 0 (no plane below it)
-    miss += (long long)z * (2 * ny + 2 * nx) + (z > 0 ? nx * ny : 0);
-    // whole lines of this plane before line y
-    miss += 2LL * y + (y > 0 ? nx : 0) + (long long)y * nx * ((z0 ? 1 : 0) + (z1 ? 1 : 0));
-    // rows of this line before x
-    miss += (x > 0 ? 1 : 0) + (long long)x * ((y0 ? 1 : 0) + (y1 ? 1 : 0) + (z0 ? 1 : 0) + (z1 ? 1 : 0));
-    return 7 * r - miss;
-}
-
 // One row per lane.  The eight index words a row can reach from its expected start are fetched with two 16-byte loads whatever the
 // row turns out to hold (buffer loads: past the end of the array they return zeros), so nothing about a row waits for anything else
 // about it; a wave's 64 rows read one contiguous run of the index array (1.8 KB).

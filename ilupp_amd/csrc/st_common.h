@@ -44,6 +44,26 @@ __device__ __forceinline__ double st_lds(const unsigned char *base, unsigned off
 __device__ __forceinline__ int st_med3(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 #endif
 
+#if defined(__HIPCC__)
+// ---- box grids (grid.hip, icholt_grid.hip) ----
+// entries before row r = (x, y, z): seven per row minus the neighbours that fall outside the box
+__device__ __forceinline__ long long grid_row_start(const int x, const int y, const int z, const GridDims &g)
+{
+    const long long nx = g.nx, ny = g.ny;
+    const long long r = x + nx * (y + ny * (long long)z);
+    const bool z0 = z == 0, z1 = z == g.nz - 1, y0 = y == 0, y1 = y == g.ny - 1;
+    long long miss = 0;
+    // whole planes below: the ends of every line, the first and the last line, and all of plane 0 (no plane below it)
+    miss += (long long)z * (2 * ny + 2 * nx) + (z > 0 ? nx * ny : 0);
+    // whole lines of this plane before line y
+    miss += 2LL * y + (y > 0 ? nx : 0) + (long long)y * nx * ((z0 ? 1 : 0) + (z1 ? 1 : 0));
+    // rows of this line before x
+    miss += (x > 0 ? 1 : 0) + (long long)x * ((y0 ? 1 : 0) + (y1 ? 1 : 0) + (z0 ? 1 : 0) + (z1 ? 1 : 0));
+    return 7 * r - miss;
+}
+
+#endif
+
 // ---- the wave-exchange kernels (st_wave.hip) -------------------------------------------------------------------------
 // The lanes of a workgroup are a 16 x 16 patch of chains, lane = 16 z + y, a wave = 16 x 4 of them.  A dependency on the
 // chain one to the left (lane - 1, same row of 16 lanes) or one below (lane - 16, same wave) whose value is ONE step old never
