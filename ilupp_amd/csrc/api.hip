@@ -1276,11 +1276,35 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
     hipStream_t st = p->stream;
     ILUPP_HIP(hipEventRecord(p->ev[0], st));
     float kms = 0.f;
+    // the schedule of the sweeps: Lc = CSC lower, diagonal first; its arrays read as CSR are L^T (upper, diagonal first): backward sweep
+    auto sweep_schedule = [&](hipStream_t q) {
+        p->degenerate = min_row_len(q, n, p->Lc.ptr, p->Lc.idx, 1) == 0;      // (column-major lower: diagonal first)
+        int32_t m1 = 0;
+        count_cuts_and_schedule(q, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);
+        p->max_row_len = m1;
+        choose_tiling(q, n, p->Lc.ptr, p->Lc.idx, &p->sL, false, p->max_lanes / kThreads);
+        build_slot_tables(q, &p->sL, false);
+        p->compact = schedule_is_compact(p->sL);
+        if (p->compact) make_desc(q, p->Lc, p->sL, &p->dL);
+    };
     // no fill allowed, nothing dropped by size, on a box grid: every column keeps A's entries if they all outweigh the one-step fill --
-    // assumed, computed on the wavefront x + 2y + 3z, verified column by column (icholt_grid.hip); anything else: the general way
+    // assumed, computed on the wavefront x + 2y + 3z, verified column by column (icholt_grid.hip); anything else: the general way.
+    // L's pattern is A's then: the sweeps' schedule is made on the side stream while the kernel runs.
     GridDims gd = {0, 0, 0};
-    if (add_fill_in == 0 && threshold == 0.0 && head && grid_guess(A.n, A.nnz, head, &gd))
-        p->icholt_grid = icholt_grid_factor(st, A, gd, p->ctrl, &p->Lc, &kms);
+    if (add_fill_in == 0 && threshold == 0.0 && head && grid_guess(A.n, A.nnz, head, &gd)) {
+        IcholtGridJob job;
+        if (icholt_grid_launch(st, A, gd, p->ctrl, &p->Lc, &job)) {
+            hipStream_t q = p->side ? p->side : st;
+            if (p->side) ILUPP_HIP(hipStreamWaitEvent(p->side, job.pattern_done, 0));
+            sweep_schedule(q);
+            ILUPP_HIP(stream_sync(q));
+            p->icholt_grid = icholt_grid_finish(st, &job, &kms);
+            if (!p->icholt_grid) {
+                p->Lc.release(); p->sL.release();
+                if (p->dL) { (void)pool_free(p->dL); p->dL = nullptr; }
+            }
+        }
+    }
     if (!p->icholt_grid) {
         DevMat T;
         int32_t missing = -1;
@@ -1306,15 +1330,7 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
         destroy_obj(p);
         return rc;
     }
-    p->degenerate = min_row_len(st, n, p->Lc.ptr, p->Lc.idx, 1) == 0;      // (column-major lower: diagonal first)
-    // Lc = CSC lower, diagonal first.  Its arrays read as CSR are L^T (upper, diagonal first): backward sweep.
-    int32_t m1 = 0;
-    count_cuts_and_schedule(st, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &p->sL, &m1);
-    p->max_row_len = m1;
-    choose_tiling(st, n, p->Lc.ptr, p->Lc.idx, &p->sL, false, p->max_lanes / kThreads);
-    build_slot_tables(st, &p->sL, false);
-    p->compact = schedule_is_compact(p->sL);
-    if (p->compact) make_desc(st, p->Lc, p->sL, &p->dL);
+    if (!p->icholt_grid) sweep_schedule(st);
     ILUPP_HIP(hipEventRecord(p->ev[2], st));
     ILUPP_HIP(stream_sync(st));
     ILUPP_HIP(hipEventElapsedTime(&p->tm.numeric_ms, p->ev[0], p->ev[1]));

@@ -399,8 +399,21 @@ int ichol0_numeric(hipStream_t st, DevMat *L, const Schedule &fwd, int32_t max_r
 
 int icholt_factor(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms);
 // icholt_df.hip (returns 1 when the matrix is outside its capacities: the caller runs the sequential kernel)
-// ICholT(0, 0.0) of a box grid as a speculative static computation (icholt_grid.hip); false: not built, take the general way
-bool icholt_grid_factor(hipStream_t st, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, float *kernel_ms);
+// ICholT(0, 0.0) of a box grid as a speculative static computation (icholt_grid.hip): launch queues everything and hands L's index
+// arrays over at once (event pattern_done), finish waits and says whether the premise held
+struct IcholtGridJob {
+    PoolBlock xch;
+    EventPair ev;
+    hipEvent_t pattern_done = nullptr;
+    GridDims g = {0, 0, 0};
+    int32_t h[16] = {0};
+    IcholtGridJob() {}
+    IcholtGridJob(const IcholtGridJob &) = delete;
+    IcholtGridJob &operator=(const IcholtGridJob &) = delete;
+    ~IcholtGridJob();
+};
+bool icholt_grid_launch(hipStream_t st, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job);
+bool icholt_grid_finish(hipStream_t st, IcholtGridJob *job, float *kernel_ms);
 int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms);
 // iluc_df.hip: Crout ILU on the major-order view; L by columns (arrays = CSR of L^T, 1 first), U by rows (pivot first)
 int iluc_factor(hipStream_t st, const DevMat &Av, int32_t max_fill_in, double threshold, DevMat *L, DevMat *U, int32_t *err_row,

@@ -36,9 +36,9 @@ constexpr unsigned kIgLds = kIgWords * kIgWordB;          // 125 952 bytes
 constexpr int kIgExp = 32;                                // exported lanes of a patch: y' = 15 (16), z' = 15 (15 more)
 constexpr int kIgThreads = 320;                           // four consumer waves + the courier
 #ifndef IG_NP
-#define IG_NP 3
+#define IG_NP 0
 #endif
-constexpr int kIgNP = IG_NP;                              // steps ahead the courier polls (+ 1)
+constexpr int kIgNP = IG_NP;                              // the imports of a step are polled for kIgNP + 1 steps ahead (256^3: 3.7-3.85 ms with 0, 3.85 with 1, 4.0 with 3, 4.2 with 5)
 constexpr int kIgRA = 4;                                  // steps ahead a lane reads A
 constexpr int kIgMaxSkew = 2 * 15 + 15;
 // words of a published record (column m of a lane): what the lanes (y+1, z), (y, z+1), (y-1, z+1) subtract from their diagonals
@@ -120,10 +120,16 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(A.lval, 0, (int)A.lbytes, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
 
+#ifdef IG_X_NOLOAD
+#define IG_NOLOAD_(o) (o) = OOB
+#else
+#define IG_NOLOAD_(o) (void)0
+#endif
     double ring[kIgRA][4];
 #define IG_LOAD(slot_, k_)                                                                                   \
     do {                                                                                                     \
         unsigned o_ = (active && (unsigned)(k_) < (unsigned)nx) ? ua0 + (unsigned)(k_) * lenb : OOB;         \
+        IG_NOLOAD_(o_);                                                                                      \
         asm volatile("" : "+v"(o_));                                                                         \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
             ring[slot_][j_] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, o_ + 8u * (unsigned)j_, 0, 0)); \
@@ -185,6 +191,9 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
                 unsigned o2 = (valid && has2) ? pos + 8u + (has1 ? 8u : 0u) : OOB;
                 unsigned o3 = (valid && has3) ? pos + 8u + (has1 ? 8u : 0u) + (has2 ? 8u : 0u) : OOB;
                 asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+#ifdef IG_X_NOSTORE
+                o0 = o1 = o2 = o3 = OOB;
+#endif
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, p), rl, o0, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, e1), rl, o1, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, e2), rl, o2, 0, 0);
@@ -224,6 +233,9 @@ __device__ __forceinline__ void ig_courier(const IgArgs &A, unsigned char *lds, 
     }
     {
         const int y = ty * 16 + cy - cz, z = tz * 16 + cz;
+#ifdef IG_X_NOCOURIER
+        exists = false;
+#endif
         exists = exists && y >= 0 && y < A.g.ny && z < A.g.nz && sty >= 0 && sty < A.nty && (p >= 16 || y > 0) && (!wantC || y + 1 < A.g.ny);
     }
     const int skc = 2 * cy + cz;
@@ -329,9 +341,15 @@ k_icholt_grid(IgArgs A)
 
 }  // namespace
 
-// true: *L is ICholT(0, 0.0) of A (a box grid, proven; every column kept A's pattern, verified).  false: nothing was built (no grid, a
-// grid outside the kernel's limits, a violated premise, a time-out): the caller takes the general way.
-bool icholt_grid_factor(hipStream_t st, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, float *kernel_ms)
+IcholtGridJob::~IcholtGridJob()
+{
+    if (pattern_done) (void)hipEventDestroy(pattern_done);
+}
+
+// Queues everything on st and returns: L's index arrays (closed form; `pattern_done` is recorded behind them -- the caller's sweep
+// analysis needs nothing else and can run beside the kernel), the proof of the grid (k_grid_check), the exchange buffer's sentinels,
+// the kernel, the read-back of its verdict.  *L owns the arrays at once.  false: a grid outside the kernel's limits, nothing was queued.
+bool icholt_grid_launch(hipStream_t st, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job)
 {
     static const bool off = getenv("ILUPP_NO_ICHOLT_GRID") != nullptr;
     if (off) return false;
@@ -346,42 +364,49 @@ bool icholt_grid_factor(hipStream_t st, const DevMat &A, const GridDims &g, int3
         attr = true;
     }
     const int64_t xwords = (int64_t)nty * ntz * kIgExp * (g.nx + 1) * 8;
-    PoolBlock xchb;
-    ILUPP_HIP(xchb.alloc(sizeof(unsigned long long) * (size_t)(xwords + 8)));
-    unsigned long long *xp = xchb.as<unsigned long long>();
-    DevMat T;
-    struct MatGuard { DevMat *m; ~MatGuard() { if (m) m->release(); } } guard{&T};
-    T.n = A.n; T.nnz = nnzL; T.is_csr = false; T.owns = true;
-    ILUPP_HIP(pool_malloc(&T.ptr, sizeof(int32_t) * (size_t)(n + 1)));
-    ILUPP_HIP(pool_malloc(&T.idx, sizeof(int32_t) * (size_t)nnzL));
-    ILUPP_HIP(pool_malloc(&T.val, sizeof(double) * (size_t)nnzL));
+    ILUPP_HIP(job->xch.alloc(sizeof(unsigned long long) * (size_t)(xwords + 8)));
+    unsigned long long *xp = job->xch.as<unsigned long long>();
+    ILUPP_HIP(job->ev.create());
+    ILUPP_HIP(hipEventCreateWithFlags(&job->pattern_done, hipEventDisableTiming));
+    job->g = g;
+    L->release();
+    L->n = A.n; L->nnz = nnzL; L->is_csr = false; L->owns = true;
+    ILUPP_HIP(pool_malloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
+    ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)nnzL));
+    ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)nnzL));
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, sizeof(int32_t) * 16, st));
+    hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, st, A.n, g, L->ptr, L->idx, (long long)nnzL);
+    ILUPP_HIP(hipEventRecord(job->pattern_done, st));
     grid_check_launch(st, A, g, ctrl + 8);
     fill_u64(st, xp, xwords, kSentinel);
     ILUPP_HIP(hipMemsetAsync(xp + xwords, 0, 64, st));
-    hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, st, A.n, g, T.ptr, T.idx, (long long)nnzL);
     IgArgs a;
     a.g = g; a.nty = nty; a.ntz = ntz;
     a.S = ((g.nx + kIgMaxSkew + 3) + 7) & ~7;
     a.aval = A.val; a.abytes = (unsigned)(A.nnz * 8);
-    a.lval = T.val; a.lbytes = (unsigned)(nnzL * 8);
+    a.lval = L->val; a.lbytes = (unsigned)(nnzL * 8);
     a.xch = xp; a.idle = xp + xwords; a.ctrl = ctrl;
-    EventPair ev;
-    ILUPP_HIP(ev.create());
-    ILUPP_HIP(hipEventRecord(ev.a, st));
+    ILUPP_HIP(hipEventRecord(job->ev.a, st));
     hipLaunchKernelGGL(k_icholt_grid, dim3((unsigned)(nty * ntz)), dim3(kIgThreads), kIgLds, st, a);
     ILUPP_HIP(hipGetLastError());
-    ILUPP_HIP(hipEventRecord(ev.b, st));
-    int32_t h[16];
-    ILUPP_HIP(d2h_async(st, h, ctrl, sizeof(h)));
-    ILUPP_HIP(stream_sync(st));
-    if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, ev.a, ev.b));
+    ILUPP_HIP(hipEventRecord(job->ev.b, st));
+    ILUPP_HIP(d2h_async(st, job->h, ctrl, sizeof(job->h)));
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, sizeof(int32_t) * 16, st));
-    if (getenv("ILUPP_IG_DEBUG")) fprintf(stderr, "icholt_grid: %d x %d x %d tickets %d timeout %d premise %d grid %d kernel %.3f ms\n", g.nx, g.ny, g.nz, h[0], h[1], h[2], h[8], kernel_ms ? *kernel_ms : 0.f);
-    if (h[1] != 0 || h[2] != 0 || h[8] != 0) return false;
-    *L = T;
-    guard.m = nullptr;
     return true;
+}
+
+// waits for st.  true: L (icholt_grid_launch) is ICholT(0, 0.0) of A -- a box grid, proven; every column kept A's pattern, verified.
+// false: a violated premise, no grid after all, or a time-out: the caller drops L and takes the general way.
+bool icholt_grid_finish(hipStream_t st, IcholtGridJob *job, float *kernel_ms)
+{
+    ILUPP_HIP(stream_sync(st));
+    float ms = 0.f;
+    ILUPP_HIP(hipEventElapsedTime(&ms, job->ev.a, job->ev.b));
+    if (kernel_ms) *kernel_ms = ms;
+    const int32_t *h = job->h;
+    if (getenv("ILUPP_IG_DEBUG"))
+        fprintf(stderr, "icholt_grid: %d x %d x %d tickets %d timeout %d premise %d grid %d kernel %.3f ms\n", job->g.nx, job->g.ny, job->g.nz, h[0], h[1], h[2], h[8], ms);
+    return h[1] == 0 && h[2] == 0 && h[8] == 0;
 }
 
 }  // namespace ilupp
