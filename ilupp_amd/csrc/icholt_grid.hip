@@ -29,12 +29,16 @@ namespace {
 constexpr int kIgLanes = 256, kIgPairs = 64;
 constexpr int kIgZero = kIgLanes + kIgPairs;              // a cell nobody writes: the source of a lane without that neighbour
 constexpr int kIgRow = kIgLanes + kIgPairs + 8;           // doubles per (word, slot)
-constexpr int kIgSlots = 8, kIgWords = 6;
+constexpr int kIgSlots = 4, kIgWords = 6;                 // a record is read at most two steps after it was written, an import lands one step early
 constexpr unsigned kIgSlotB = kIgRow * 8u;
 constexpr unsigned kIgWordB = kIgSlots * kIgSlotB;
-constexpr unsigned kIgLds = kIgWords * kIgWordB;          // 125 952 bytes
+constexpr unsigned kIgHand = kIgWords * kIgWordB;         // 62 976 bytes of hand-off records
+constexpr unsigned kIgAst = kIgHand;                      // A's values of a step, staged by the loader waves: [4 slots][256 lanes][4]
+constexpr unsigned kIgAstSlot = kIgLanes * 32u;
+constexpr unsigned kIgSst = kIgAst + 4u * kIgAstSlot;     // L's values of a step, staged for the storer waves: [2 slots][256 lanes][4]
+constexpr unsigned kIgLds = kIgSst + 2u * kIgAstSlot;     // 112 128 bytes
 constexpr int kIgExp = 32;                                // exported lanes of a patch: y' = 15 (16), z' = 15 (15 more)
-constexpr int kIgThreads = 320;                           // four consumer waves + the courier
+constexpr int kIgThreads = 576;                           // four consumer waves, the courier, two loader waves, two storer waves
 #ifndef IG_NP
 #define IG_NP 0
 #endif
@@ -84,21 +88,46 @@ k_icholt_grid_pattern(const int32_t n, const GridDims g, int32_t *__restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
-// a consumer lane: the x-line (y, z)
+// what a lane (the x-line (y, z)) is, for the waves that work on it: the consumer, its loader, its storer
+// ---------------------------------------------------------------------------------------------
+struct IgLane {
+    int yl, zl, y, z, sk;
+    bool active, has2, has3;
+    unsigned ua0, lenb;       // A: byte offset of the diagonal of row 0, bytes per inner row
+    unsigned ul0, cub;        // L: byte offset of column 0, bytes per inner column
+};
+// a patch is SHEARED: its lane (y', z') is the line y = 16 ty + y' - z', z = 16 tz + z' -- the line (y+1, z-1) is the lane below, and
+// every line a patch needs from another patch belongs to one with a smaller ticket (ty - 1 or tz - 1): with upright patches the
+// neighbours in y would wait for each other column by column
+__device__ __forceinline__ IgLane ig_lane(const IgArgs &A, const int ty, const int tz, const int t)
+{
+    IgLane l;
+    l.yl = t & 15; l.zl = t >> 4;
+    l.y = ty * 16 + l.yl - l.zl; l.z = tz * 16 + l.zl;
+    l.active = l.y >= 0 && l.y < A.g.ny && l.z < A.g.nz;
+    l.sk = 2 * l.yl + l.zl;
+    l.has2 = l.active && l.y < A.g.ny - 1; l.has3 = l.active && l.z < A.g.nz - 1;
+    // A: the upper part of row (x, y, z) starts at line start + entries left of the diagonal of row 0 + x * (entries of an inner row)
+    const int edge = l.active ? ((l.y == 0) + (l.y == A.g.ny - 1) + (l.z == 0) + (l.z == A.g.nz - 1)) : 0;
+    l.lenb = (unsigned)(7 - edge) * 8u;
+    const long long ls = l.active ? grid_row_start(0, l.y, l.z, A.g) + (l.y > 0 ? 1 : 0) + (l.z > 0 ? 1 : 0) : 0;
+    l.ua0 = (unsigned)ls * 8u;
+    l.cub = (unsigned)(2 + (l.has2 ? 1 : 0) + (l.has3 ? 1 : 0)) * 8u;
+    l.ul0 = l.active ? (unsigned)ig_col_start(0, l.y, l.z, A.g) * 8u : 0u;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a consumer lane: the recurrence.  Its row of A comes from LDS (loader waves), its column of L goes to LDS (storer waves): the
+// scattered 8-byte memory operations of a step -- eight per lane -- are issued by waves that have nothing else to do
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds, const int ty, const int tz)
 {
-    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
     const int t = threadIdx.x;
-    // a patch is SHEARED: its lane (y', z') is the line y = 16 ty + y' - z', z = 16 tz + z' -- the line (y+1, z-1) is the lane below, and
-    // every line a patch needs from another patch belongs to one with a smaller ticket (ty - 1 or tz - 1): with upright patches the
-    // neighbours in y would wait for each other column by column
-    const int yl = t & 15, zl = t >> 4;
-    const int y = ty * 16 + yl - zl, z = tz * 16 + zl;
+    const IgLane l = ig_lane(A, ty, tz, t);
+    const int yl = l.yl, zl = l.zl, y = l.y, z = l.z, sk = l.sk;
+    const bool active = l.active, has2 = l.has2, has3 = l.has3;
     const int nx = A.g.nx;
-    const bool active = y >= 0 && y < A.g.ny && z < A.g.nz;
-    const int sk = 2 * yl + zl;
-    const bool has2 = active && y < A.g.ny - 1, has3 = active && z < A.g.nz - 1;
     // where the three neighbours' records are read: a lane of this patch (d steps back), a pair of the courier (this step's slot), nobody
     unsigned srcA = kIgZero, srcB = kIgZero, srcC = kIgZero;
     int dA = 0, dB = 0, dC = 0;
@@ -109,33 +138,7 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
     }
     if (active && z > 0 && y + 1 < A.g.ny) { if (zl > 0) { srcC = (unsigned)(t - 16); dC = 1; } else srcC = (unsigned)(kIgLanes + 48 + yl); }
     const unsigned aA = srcA * 8u, aB = srcB * 8u, aC = srcC * 8u, aMe = (unsigned)t * 8u;
-    // A: the upper part of row (x, y, z) starts at line start + entries left of the diagonal of row 0 + x * (entries of an inner row)
-    const int edge = active ? ((y == 0) + (y == A.g.ny - 1) + (z == 0) + (z == A.g.nz - 1)) : 0;
-    const unsigned lenb = (unsigned)(7 - edge) * 8u;
-    const long long ls = active ? grid_row_start(0, y, z, A.g) + (y > 0 ? 1 : 0) + (z > 0 ? 1 : 0) : 0;
-    const unsigned ua0 = (unsigned)ls * 8u;
-    const unsigned cub = (unsigned)(2 + (has2 ? 1 : 0) + (has3 ? 1 : 0)) * 8u;
-    const unsigned ul0 = active ? (unsigned)ig_col_start(0, y, z, A.g) * 8u : 0u;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.aval), 0, (int)A.abytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(A.lval, 0, (int)A.lbytes, 0x00020000);
-    constexpr unsigned OOB = 0xfffffff0u;
-
-#ifdef IG_X_NOLOAD
-#define IG_NOLOAD_(o) (o) = OOB
-#else
-#define IG_NOLOAD_(o) (void)0
-#endif
-    double ring[kIgRA][4];
-#define IG_LOAD(slot_, k_)                                                                                   \
-    do {                                                                                                     \
-        unsigned o_ = (active && (unsigned)(k_) < (unsigned)nx) ? ua0 + (unsigned)(k_) * lenb : OOB;         \
-        IG_NOLOAD_(o_);                                                                                      \
-        asm volatile("" : "+v"(o_));                                                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
-            ring[slot_][j_] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, o_ + 8u * (unsigned)j_, 0, 0)); \
-    } while (0)
-#pragma unroll
-    for (int u = 0; u < kIgRA; ++u) IG_LOAD(u, u - sk);
+    const unsigned aSt = (unsigned)t * 32u;
 
     double e1p = 0.0, e2p = 0.0, e3p = 0.0, e1sqp = 0.0, e2sqp = 0.0, e3sqp = 0.0, qp = 0.0;
     bool bad = false;
@@ -146,19 +149,21 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
             const int k = s - sk;
             const bool valid = active && (unsigned)k < (unsigned)nx;
             const bool has1 = valid && k < nx - 1;
-            const double w0 = ring[u % kIgRA][0], w1 = ring[u % kIgRA][1], w2 = ring[u % kIgRA][2], w3 = ring[u % kIgRA][3];
+            ST_BARRIER();
+            const v2d wa = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 3) * kIgAstSlot + aSt);
+            const v2d wb = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 3) * kIgAstSlot + aSt + 16u);
+            const unsigned oA = (unsigned)((u - dA) & (kIgSlots - 1)) * kIgSlotB + aA;
+            const unsigned oB = (unsigned)((u - dB) & (kIgSlots - 1)) * kIgSlotB + aB;
+            const unsigned oC = (unsigned)((u - dC) & (kIgSlots - 1)) * kIgSlotB + aC;
+            const double inE2 = st_lds(lds, IG_E2P * kIgWordB + oA), inQ = st_lds(lds, IG_QP * kIgWordB + oA), inF1 = st_lds(lds, IG_F1 * kIgWordB + oA);
+            const double inE3 = st_lds(lds, IG_E3P * kIgWordB + oB), inF2 = st_lds(lds, IG_F2 * kIgWordB + oB);
+            const double inF3 = st_lds(lds, IG_F3 * kIgWordB + oC);
+            const double w0 = wa.x, w1 = wa.y, w2 = wb.x, w3 = wb.y;
             const double a0 = w0;
             const double a1 = has1 ? w1 : 0.0;
             const double a2 = has2 ? (has1 ? w2 : w1) : 0.0;
             const double a3m = has2 ? (has1 ? w3 : w2) : (has1 ? w2 : w1);
             const double a3 = has3 ? a3m : 0.0;
-            ST_BARRIER();
-            const unsigned oA = (unsigned)((u - dA) & 7) * kIgSlotB + aA;
-            const unsigned oB = (unsigned)((u - dB) & 7) * kIgSlotB + aB;
-            const unsigned oC = (unsigned)((u - dC) & 7) * kIgSlotB + aC;
-            const double inE2 = st_lds(lds, IG_E2P * kIgWordB + oA), inQ = st_lds(lds, IG_QP * kIgWordB + oA), inF1 = st_lds(lds, IG_F1 * kIgWordB + oA);
-            const double inE3 = st_lds(lds, IG_E3P * kIgWordB + oB), inF2 = st_lds(lds, IG_F2 * kIgWordB + oB);
-            const double inF3 = st_lds(lds, IG_F3 * kIgWordB + oC);
             // D[j] over the columns that touched it, ascending (IChol.hpp:139), then the diagonal (IChol.hpp:112-113)
             double D = 0.0;
             D -= inE3; D -= inF2; D -= inF3; D -= inE2; D -= inF1; D -= e1sqp;
@@ -175,7 +180,7 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
             const bool keep = p > vmax && (!has1 || fabs(e1) > vmax) && (!has2 || fabs(e2) > vmax) && (!has3 || fabs(e3) > vmax);
             bad = bad || (valid && !keep);
             const double e1sq = e1 * e1, e2sq = e2 * e2, e3sq = e3 * e3, q = e3 * e2;
-            const unsigned oM = (unsigned)u * kIgSlotB + aMe;
+            const unsigned oM = (unsigned)(u & (kIgSlots - 1)) * kIgSlotB + aMe;
             *reinterpret_cast<double *>(lds + IG_E2P * kIgWordB + oM) = e2sqp;
             *reinterpret_cast<double *>(lds + IG_QP * kIgWordB + oM) = qp;
             *reinterpret_cast<double *>(lds + IG_F1 * kIgWordB + oM) = f1 * f1;
@@ -183,27 +188,113 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
             *reinterpret_cast<double *>(lds + IG_E3P * kIgWordB + oM) = e3sqp;
             *reinterpret_cast<double *>(lds + IG_F2 * kIgWordB + oM) = f2 * f2;
             e1p = e1; e2p = e2; e3p = e3; e1sqp = e1sq; e2sqp = e2sq; e3sqp = e3sq; qp = q;
-            // column j of L: the diagonal and A's entries, by ascending row
+            // column j of L, for the storer waves
             {
-                const unsigned pos = ul0 + (unsigned)k * cub;
-                unsigned o0 = valid ? pos : OOB;
-                unsigned o1 = has1 ? pos + 8u : OOB;
-                unsigned o2 = (valid && has2) ? pos + 8u + (has1 ? 8u : 0u) : OOB;
-                unsigned o3 = (valid && has3) ? pos + 8u + (has1 ? 8u : 0u) + (has2 ? 8u : 0u) : OOB;
-                asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
-#ifdef IG_X_NOSTORE
-                o0 = o1 = o2 = o3 = OOB;
-#endif
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, p), rl, o0, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, e1), rl, o1, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, e2), rl, o2, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, e3), rl, o3, 0, 0);
+                v2d sa, sb2;
+                sa.x = p; sa.y = e1; sb2.x = e2; sb2.y = e3;
+                *reinterpret_cast<v2d *>(lds + kIgSst + (unsigned)(u & 1) * kIgAstSlot + aSt) = sa;
+                *reinterpret_cast<v2d *>(lds + kIgSst + (unsigned)(u & 1) * kIgAstSlot + aSt + 16u) = sb2;
             }
-            IG_LOAD(u % kIgRA, k + kIgRA);
         }
     }
-#undef IG_LOAD
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && (t & 63) == 0) atomicOr(&A.ctrl[2], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a loader wave: the rows of A of two consumer waves, kIgRA steps ahead in registers, one step ahead in LDS
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ig_loader(const IgArgs &A, unsigned char *lds, const int ty, const int tz, const int lw)
+{
+    const int ln = threadIdx.x & 63;
+    const int nx = A.g.nx;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.aval), 0, (int)A.abytes, 0x00020000);
+    const IgLane l0 = ig_lane(A, ty, tz, (2 * lw) * 64 + ln), l1 = ig_lane(A, ty, tz, (2 * lw + 1) * 64 + ln);
+    const unsigned st0 = (unsigned)((2 * lw) * 64 + ln) * 32u, st1 = (unsigned)((2 * lw + 1) * 64 + ln) * 32u;
+    double r0[kIgRA][4], r1[kIgRA][4];
+#define IGL_LOAD(r_, l_, slot_, s_)                                                                          \
+    do {                                                                                                     \
+        const int k_ = (s_) - (l_).sk;                                                                       \
+        unsigned o_ = ((l_).active && (unsigned)k_ < (unsigned)nx) ? (l_).ua0 + (unsigned)k_ * (l_).lenb : OOB; \
+        IGL_NOLOAD_(o_);                                                                                     \
+        asm volatile("" : "+v"(o_));                                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
+            r_[slot_][j_] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, o_ + 8u * (unsigned)j_, 0, 0)); \
+    } while (0)
+#ifdef IG_X_NOLOAD
+#define IGL_NOLOAD_(o) (o) = OOB
+#else
+#define IGL_NOLOAD_(o) (void)0
+#endif
+#define IGL_WRITE(r_, st_, slot_, s_)                                                                        \
+    do {                                                                                                     \
+        v2d a_, b_;                                                                                          \
+        a_.x = r_[slot_][0]; a_.y = r_[slot_][1]; b_.x = r_[slot_][2]; b_.y = r_[slot_][3];                  \
+        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 3) * kIgAstSlot + (st_)) = a_;             \
+        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 3) * kIgAstSlot + (st_) + 16u) = b_;       \
+    } while (0)
+#pragma unroll
+    for (int r = 0; r < kIgRA; ++r) { IGL_LOAD(r0, l0, r, r); IGL_LOAD(r1, l1, r, r); }
+    IGL_WRITE(r0, st0, 0, 0); IGL_WRITE(r1, st1, 0, 0);
+    IGL_LOAD(r0, l0, 0, kIgRA); IGL_LOAD(r1, l1, 0, kIgRA);
+    for (int ib = 0; ib < A.S; ib += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = ib + u;
+            ST_BARRIER();
+            IGL_WRITE(r0, st0, (u + 1) % kIgRA, i + 1); IGL_WRITE(r1, st1, (u + 1) % kIgRA, i + 1);
+            IGL_LOAD(r0, l0, (u + 1) % kIgRA, i + 1 + kIgRA); IGL_LOAD(r1, l1, (u + 1) % kIgRA, i + 1 + kIgRA);
+        }
+    }
+#undef IGL_LOAD
+#undef IGL_WRITE
+#undef IGL_NOLOAD_
+}
+
+// ---------------------------------------------------------------------------------------------
+// a storer wave: the columns of L two consumer waves finished in the previous step: the diagonal and A's entries, by ascending row
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ig_storer(const IgArgs &A, unsigned char *lds, const int ty, const int tz, const int sw)
+{
+    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+    const int ln = threadIdx.x & 63;
+    const int nx = A.g.nx;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(A.lval, 0, (int)A.lbytes, 0x00020000);
+    const IgLane l0 = ig_lane(A, ty, tz, (2 * sw) * 64 + ln), l1 = ig_lane(A, ty, tz, (2 * sw + 1) * 64 + ln);
+    const unsigned st0 = (unsigned)((2 * sw) * 64 + ln) * 32u, st1 = (unsigned)((2 * sw + 1) * 64 + ln) * 32u;
+#define IGS_STORE(l_, st_, s_)                                                                               \
+    do {                                                                                                     \
+        const int k_ = (s_) - (l_).sk;                                                                       \
+        const bool valid_ = (l_).active && (unsigned)k_ < (unsigned)nx;                                      \
+        const bool has1_ = valid_ && k_ < nx - 1;                                                            \
+        const v2d a_ = *reinterpret_cast<const v2d *>(lds + kIgSst + (unsigned)((s_) & 1) * kIgAstSlot + (st_)); \
+        const v2d b_ = *reinterpret_cast<const v2d *>(lds + kIgSst + (unsigned)((s_) & 1) * kIgAstSlot + (st_) + 16u); \
+        const unsigned pos_ = (l_).ul0 + (unsigned)k_ * (l_).cub;                                            \
+        unsigned o0_ = valid_ ? pos_ : OOB;                                                                  \
+        unsigned o1_ = has1_ ? pos_ + 8u : OOB;                                                              \
+        unsigned o2_ = (valid_ && (l_).has2) ? pos_ + 8u + (has1_ ? 8u : 0u) : OOB;                          \
+        unsigned o3_ = (valid_ && (l_).has3) ? pos_ + 8u + (has1_ ? 8u : 0u) + ((l_).has2 ? 8u : 0u) : OOB; \
+        IGS_NOSTORE_(o0_, o1_, o2_, o3_);                                                                    \
+        asm volatile("" : "+v"(o0_), "+v"(o1_), "+v"(o2_), "+v"(o3_));                                       \
+        /* (scalars first: __builtin_bit_cast of a vector ELEMENT expression takes the vector's first element whichever is named) */ \
+        const double v0_ = a_.x, v1_ = a_.y, v2_ = b_.x, v3_ = b_.y;                                         \
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v0_), rl, o0_, 0, 0);                 \
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v1_), rl, o1_, 0, 0);                 \
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v2_), rl, o2_, 0, 0);                 \
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v3_), rl, o3_, 0, 0);                 \
+    } while (0)
+#ifdef IG_X_NOSTORE
+#define IGS_NOSTORE_(a, b, c, d) (a) = (b) = (c) = (d) = OOB
+#else
+#define IGS_NOSTORE_(a, b, c, d) (void)0
+#endif
+    for (int i = 0; i < A.S; ++i) {
+        ST_BARRIER();
+        if (i >= 1) { IGS_STORE(l0, st0, i - 1); IGS_STORE(l1, st1, i - 1); }
+    }
+#undef IGS_STORE
+#undef IGS_NOSTORE_
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -282,7 +373,7 @@ __device__ __forceinline__ void ig_courier(const IgArgs &A, unsigned char *lds, 
             }                                                                                                \
         }                                                                                                    \
         if (!need) { v0 = 0; v1 = 0; v2 = 0; }                                                               \
-        const unsigned o_ = (unsigned)((s_) & 7) * kIgSlotB + dst;                                           \
+        const unsigned o_ = (unsigned)((s_) & (kIgSlots - 1)) * kIgSlotB + dst;                                           \
         *reinterpret_cast<unsigned long long *>(lds + (unsigned)w0 * kIgWordB + o_) = v0;                    \
         *reinterpret_cast<unsigned long long *>(lds + (unsigned)w1 * kIgWordB + o_) = v1;                    \
         *reinterpret_cast<unsigned long long *>(lds + (unsigned)w2 * kIgWordB + o_) = v2;                    \
@@ -301,7 +392,7 @@ __device__ __forceinline__ void ig_courier(const IgArgs &A, unsigned char *lds, 
                 // the records of step i - 1 of the exported lanes
                 const int m = i - 1 - ske;
                 if (et >= 0 && i >= 1 && (unsigned)m <= (unsigned)nx) {
-                    const unsigned o = (unsigned)((i - 1) & 7) * kIgSlotB + (unsigned)et * 8u;
+                    const unsigned o = (unsigned)((i - 1) & (kIgSlots - 1)) * kIgSlotB + (unsigned)et * 8u;
                     unsigned long long w[6];
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
@@ -335,8 +426,11 @@ k_icholt_grid(IgArgs A)
     __syncthreads();
     const int wg = s_wg;
     const int ty = wg % A.nty, tz = wg / A.nty;
-    if (threadIdx.x < kIgLanes) ig_consumer(A, lds, ty, tz);
-    else ig_courier(A, lds, ty, tz, wg);
+    const int wv = threadIdx.x >> 6;
+    if (wv < 4) ig_consumer(A, lds, ty, tz);
+    else if (wv == 4) ig_courier(A, lds, ty, tz, wg);
+    else if (wv < 7) ig_loader(A, lds, ty, tz, wv - 5);
+    else ig_storer(A, lds, ty, tz, wv - 7);
 }
 
 }  // namespace
