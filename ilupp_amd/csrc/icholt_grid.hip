@@ -33,10 +33,10 @@ constexpr int kIgSlots = 4, kIgWords = 6;                 // a record is read at
 constexpr unsigned kIgSlotB = kIgRow * 8u;
 constexpr unsigned kIgWordB = kIgSlots * kIgSlotB;
 constexpr unsigned kIgHand = kIgWords * kIgWordB;         // 62 976 bytes of hand-off records
-constexpr unsigned kIgAst = kIgHand;                      // A's values of a step, staged by the loader waves: [4 slots][256 lanes][4]
+constexpr unsigned kIgAst = kIgHand;                      // A's values of a step, staged by the loader waves: [2 slots][256 lanes][4]
 constexpr unsigned kIgAstSlot = kIgLanes * 32u;
-constexpr unsigned kIgSst = kIgAst + 4u * kIgAstSlot;     // L's values of a step, staged for the storer waves: [2 slots][256 lanes][4]
-constexpr unsigned kIgLds = kIgSst + 2u * kIgAstSlot;     // 112 128 bytes
+constexpr unsigned kIgSst = kIgAst + 2u * kIgAstSlot;     // L's values of a step, staged for the storer waves: [8 slots][256 lanes][4]
+constexpr unsigned kIgLds = kIgSst + 8u * kIgAstSlot;     // 144 896 bytes
 constexpr int kIgExp = 32;                                // exported lanes of a patch: y' = 15 (16), z' = 15 (15 more)
 constexpr int kIgThreads = 576;                           // four consumer waves, the courier, two loader waves, two storer waves
 #ifndef IG_NP
@@ -150,8 +150,8 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
             const bool valid = active && (unsigned)k < (unsigned)nx;
             const bool has1 = valid && k < nx - 1;
             ST_BARRIER();
-            const v2d wa = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 3) * kIgAstSlot + aSt);
-            const v2d wb = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 3) * kIgAstSlot + aSt + 16u);
+            const v2d wa = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 1) * kIgAstSlot + aSt);
+            const v2d wb = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 1) * kIgAstSlot + aSt + 16u);
             const unsigned oA = (unsigned)((u - dA) & (kIgSlots - 1)) * kIgSlotB + aA;
             const unsigned oB = (unsigned)((u - dB) & (kIgSlots - 1)) * kIgSlotB + aB;
             const unsigned oC = (unsigned)((u - dC) & (kIgSlots - 1)) * kIgSlotB + aC;
@@ -192,8 +192,8 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
             {
                 v2d sa, sb2;
                 sa.x = p; sa.y = e1; sb2.x = e2; sb2.y = e3;
-                *reinterpret_cast<v2d *>(lds + kIgSst + (unsigned)(u & 1) * kIgAstSlot + aSt) = sa;
-                *reinterpret_cast<v2d *>(lds + kIgSst + (unsigned)(u & 1) * kIgAstSlot + aSt + 16u) = sb2;
+                *reinterpret_cast<v2d *>(lds + kIgSst + (unsigned)(u & 7) * kIgAstSlot + aSt) = sa;
+                *reinterpret_cast<v2d *>(lds + kIgSst + (unsigned)(u & 7) * kIgAstSlot + aSt + 16u) = sb2;
             }
         }
     }
@@ -230,8 +230,8 @@ __device__ __forceinline__ void ig_loader(const IgArgs &A, unsigned char *lds, c
     do {                                                                                                     \
         v2d a_, b_;                                                                                          \
         a_.x = r_[slot_][0]; a_.y = r_[slot_][1]; b_.x = r_[slot_][2]; b_.y = r_[slot_][3];                  \
-        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 3) * kIgAstSlot + (st_)) = a_;             \
-        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 3) * kIgAstSlot + (st_) + 16u) = b_;       \
+        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 1) * kIgAstSlot + (st_)) = a_;             \
+        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 1) * kIgAstSlot + (st_) + 16u) = b_;       \
     } while (0)
 #pragma unroll
     for (int r = 0; r < kIgRA; ++r) { IGL_LOAD(r0, l0, r, r); IGL_LOAD(r1, l1, r, r); }
@@ -252,7 +252,11 @@ __device__ __forceinline__ void ig_loader(const IgArgs &A, unsigned char *lds, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// a storer wave: the columns of L two consumer waves finished in the previous step: the diagonal and A's entries, by ascending row
+// a storer wave.  A lane's columns are contiguous in L (four entries each for a lane inside the box): four finished columns are one
+// 128-byte run, written as eight 16-byte pieces by eight threads -- an instruction covers 8 lanes x 128 bytes instead of 64 lanes x 8.
+// The lanes whose column k = 3 (mod 4) was finished in the previous step form one of four classes of 64 lanes (skew mod 4); the two
+// storer waves take eight of them per instruction.  What the groups do not cover -- lanes on the box' faces (shorter columns), the
+// last columns of every lane (the final one has no entry below the diagonal in x) -- goes out entry by entry as before.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ig_storer(const IgArgs &A, unsigned char *lds, const int ty, const int tz, const int sw)
 {
@@ -263,36 +267,80 @@ __device__ __forceinline__ void ig_storer(const IgArgs &A, unsigned char *lds, c
     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(A.lval, 0, (int)A.lbytes, 0x00020000);
     const IgLane l0 = ig_lane(A, ty, tz, (2 * sw) * 64 + ln), l1 = ig_lane(A, ty, tz, (2 * sw + 1) * 64 + ln);
     const unsigned st0 = (unsigned)((2 * sw) * 64 + ln) * 32u, st1 = (unsigned)((2 * sw + 1) * 64 + ln) * 32u;
+    const int kcut = ((nx - 1) / 4) * 4;                 // columns from here on are not part of a full group of four
+    // the grouped path: for class c (= step & 3) and instruction j, this thread's lane and piece
+    const int piece = ln & 7;
+    unsigned gul[16], gst[16];
+    int gsk[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = (sw * 4 + j) * 8 + (ln >> 3);
+            const int zl = 2 * (q >> 3) + (c & 1);
+            const int yl = 2 * (q & 7) + (((c - zl) & 3) >> 1);
+            const IgLane g = ig_lane(A, ty, tz, 16 * zl + yl);
+            const bool grouped = g.active && g.has2 && g.has3;
+            gul[c * 4 + j] = g.ul0 + 16u * (unsigned)piece;
+            gst[c * 4 + j] = (unsigned)(16 * zl + yl) * 32u + (unsigned)(piece & 1) * 16u;
+            gsk[c * 4 + j] = grouped ? g.sk : (1 << 28);             // (a lane outside the grouped path never has a column to store here)
+        }
+    }
+#ifdef IG_X_NOSTORE
+#define IGS_NOSTORE_(o) (o) = OOB
+#else
+#define IGS_NOSTORE_(o) (void)0
+#endif
+    // the columns k-3 .. k of the lanes of class c_ whose column k (= 3 mod 4) was written in step s_
+#define IGS_GROUP(c_, j_, s_)                                                                                \
+    do {                                                                                                     \
+        const int k_ = (s_) - gsk[(c_) * 4 + (j_)];                                                          \
+        const bool ok_ = k_ >= 3 && k_ < nx - 1;                                                             \
+        const int kk_ = k_ - 3 + (piece >> 1);                                                               \
+        const unsigned slot_ = (unsigned)((kk_ + gsk[(c_) * 4 + (j_)]) & 7);                                 \
+        const v4u v_ = *reinterpret_cast<const v4u *>(lds + kIgSst + slot_ * kIgAstSlot + gst[(c_) * 4 + (j_)]); \
+        unsigned o_ = ok_ ? gul[(c_) * 4 + (j_)] + (unsigned)(k_ - 3) * 32u : OOB;                           \
+        IGS_NOSTORE_(o_);                                                                                    \
+        asm volatile("" : "+v"(o_));                                                                         \
+        __builtin_amdgcn_raw_buffer_store_b128(v_, rl, o_, 0, 0);                                            \
+    } while (0)
+    // entry by entry: the column written in step s_ of a lane the groups do not serve, or beyond the last full group
 #define IGS_STORE(l_, st_, s_)                                                                               \
     do {                                                                                                     \
         const int k_ = (s_) - (l_).sk;                                                                       \
-        const bool valid_ = (l_).active && (unsigned)k_ < (unsigned)nx;                                      \
-        const bool has1_ = valid_ && k_ < nx - 1;                                                            \
-        const v2d a_ = *reinterpret_cast<const v2d *>(lds + kIgSst + (unsigned)((s_) & 1) * kIgAstSlot + (st_)); \
-        const v2d b_ = *reinterpret_cast<const v2d *>(lds + kIgSst + (unsigned)((s_) & 1) * kIgAstSlot + (st_) + 16u); \
-        const unsigned pos_ = (l_).ul0 + (unsigned)k_ * (l_).cub;                                            \
-        unsigned o0_ = valid_ ? pos_ : OOB;                                                                  \
-        unsigned o1_ = has1_ ? pos_ + 8u : OOB;                                                              \
-        unsigned o2_ = (valid_ && (l_).has2) ? pos_ + 8u + (has1_ ? 8u : 0u) : OOB;                          \
-        unsigned o3_ = (valid_ && (l_).has3) ? pos_ + 8u + (has1_ ? 8u : 0u) + ((l_).has2 ? 8u : 0u) : OOB; \
-        IGS_NOSTORE_(o0_, o1_, o2_, o3_);                                                                    \
-        asm volatile("" : "+v"(o0_), "+v"(o1_), "+v"(o2_), "+v"(o3_));                                       \
-        /* (scalars first: __builtin_bit_cast of a vector ELEMENT expression takes the vector's first element whichever is named) */ \
-        const double v0_ = a_.x, v1_ = a_.y, v2_ = b_.x, v3_ = b_.y;                                         \
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v0_), rl, o0_, 0, 0);                 \
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v1_), rl, o1_, 0, 0);                 \
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v2_), rl, o2_, 0, 0);                 \
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v3_), rl, o3_, 0, 0);                 \
+        const bool valid_ = (l_).active && (unsigned)k_ < (unsigned)nx && (!((l_).has2 && (l_).has3) || k_ >= kcut); \
+        if (__builtin_amdgcn_ballot_w64(valid_) != 0) {                                                      \
+            const bool has1_ = valid_ && k_ < nx - 1;                                                        \
+            const v2d a_ = *reinterpret_cast<const v2d *>(lds + kIgSst + (unsigned)((s_) & 7) * kIgAstSlot + (st_)); \
+            const v2d b_ = *reinterpret_cast<const v2d *>(lds + kIgSst + (unsigned)((s_) & 7) * kIgAstSlot + (st_) + 16u); \
+            const unsigned pos_ = (l_).ul0 + (unsigned)k_ * (l_).cub;                                        \
+            unsigned o0_ = valid_ ? pos_ : OOB;                                                              \
+            unsigned o1_ = has1_ ? pos_ + 8u : OOB;                                                          \
+            unsigned o2_ = (valid_ && (l_).has2) ? pos_ + 8u + (has1_ ? 8u : 0u) : OOB;                      \
+            unsigned o3_ = (valid_ && (l_).has3) ? pos_ + 8u + (has1_ ? 8u : 0u) + ((l_).has2 ? 8u : 0u) : OOB; \
+            IGS_NOSTORE_(o0_); IGS_NOSTORE_(o1_); IGS_NOSTORE_(o2_); IGS_NOSTORE_(o3_);                      \
+            asm volatile("" : "+v"(o0_), "+v"(o1_), "+v"(o2_), "+v"(o3_));                                   \
+            /* (scalars first: __builtin_bit_cast of a vector ELEMENT expression takes the vector's first element whichever is named) */ \
+            const double v0_ = a_.x, v1_ = a_.y, v2_ = b_.x, v3_ = b_.y;                                     \
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v0_), rl, o0_, 0, 0);             \
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v1_), rl, o1_, 0, 0);             \
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v2_), rl, o2_, 0, 0);             \
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v3_), rl, o3_, 0, 0);             \
+        }                                                                                                    \
     } while (0)
-#ifdef IG_X_NOSTORE
-#define IGS_NOSTORE_(a, b, c, d) (a) = (b) = (c) = (d) = OOB
-#else
-#define IGS_NOSTORE_(a, b, c, d) (void)0
-#endif
-    for (int i = 0; i < A.S; ++i) {
-        ST_BARRIER();
-        if (i >= 1) { IGS_STORE(l0, st0, i - 1); IGS_STORE(l1, st1, i - 1); }
+    for (int ib = 0; ib < A.S; ib += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = ib + u;
+            ST_BARRIER();
+            if (i >= 1) {
+                // the step before: i - 1; its class (skew = step - 3 mod 4) is (u + 4 - 1 - 3) & 3 = u
+                IGS_GROUP(u, 0, i - 1); IGS_GROUP(u, 1, i - 1); IGS_GROUP(u, 2, i - 1); IGS_GROUP(u, 3, i - 1);
+                IGS_STORE(l0, st0, i - 1); IGS_STORE(l1, st1, i - 1);
+            }
+        }
     }
+#undef IGS_GROUP
 #undef IGS_STORE
 #undef IGS_NOSTORE_
 }
