@@ -33,17 +33,16 @@ constexpr int kIgSlots = 4, kIgWords = 6;                 // a record is read at
 constexpr unsigned kIgSlotB = kIgRow * 8u;
 constexpr unsigned kIgWordB = kIgSlots * kIgSlotB;
 constexpr unsigned kIgHand = kIgWords * kIgWordB;         // 62 976 bytes of hand-off records
-constexpr unsigned kIgAst = kIgHand;                      // A's values of a step, staged by the loader waves: [2 slots][256 lanes][4]
+constexpr unsigned kIgAst = kIgHand;                      // A's values of a step, staged by the loader waves: [4 slots][256 lanes][4]
 constexpr unsigned kIgAstSlot = kIgLanes * 32u;
-constexpr unsigned kIgSst = kIgAst + 2u * kIgAstSlot;     // L's values of a step, staged for the storer waves: [8 slots][256 lanes][4]
-constexpr unsigned kIgLds = kIgSst + 8u * kIgAstSlot;     // 144 896 bytes
+constexpr unsigned kIgSst = kIgAst + 4u * kIgAstSlot;     // L's values of a step, staged for the storer waves: [8 slots][256 lanes][4]
+constexpr unsigned kIgLds = kIgSst + 8u * kIgAstSlot;     // 161 280 bytes (of the 163 840 a workgroup can have)
 constexpr int kIgExp = 32;                                // exported lanes of a patch: y' = 15 (16), z' = 15 (15 more)
 constexpr int kIgThreads = 576;                           // four consumer waves, the courier, two loader waves, two storer waves
 #ifndef IG_NP
 #define IG_NP 0
 #endif
 constexpr int kIgNP = IG_NP;                              // the imports of a step are polled for kIgNP + 1 steps ahead (256^3: 3.7-3.85 ms with 0, 3.85 with 1, 4.0 with 3, 4.2 with 5)
-constexpr int kIgRA = 4;                                  // steps ahead a lane reads A
 constexpr int kIgMaxSkew = 2 * 15 + 15;
 // words of a published record (column m of a lane): what the lanes (y+1, z), (y, z+1), (y-1, z+1) subtract from their diagonals
 enum { IG_E2P = 0, IG_QP = 1, IG_F1 = 2, IG_F3 = 3, IG_E3P = 4, IG_F2 = 5 };   // e2^2, e3 e2 of column m-1; f1^2, f3^2 of m; e3^2 of m-1; f2^2 of m
@@ -150,8 +149,8 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
             const bool valid = active && (unsigned)k < (unsigned)nx;
             const bool has1 = valid && k < nx - 1;
             ST_BARRIER();
-            const v2d wa = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 1) * kIgAstSlot + aSt);
-            const v2d wb = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 1) * kIgAstSlot + aSt + 16u);
+            const v2d wa = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 3) * kIgAstSlot + aSt);
+            const v2d wb = *reinterpret_cast<const v2d *>(lds + kIgAst + (unsigned)(u & 3) * kIgAstSlot + aSt + 16u);
             const unsigned oA = (unsigned)((u - dA) & (kIgSlots - 1)) * kIgSlotB + aA;
             const unsigned oB = (unsigned)((u - dB) & (kIgSlots - 1)) * kIgSlotB + aB;
             const unsigned oC = (unsigned)((u - dC) & (kIgSlots - 1)) * kIgSlotB + aC;
@@ -201,7 +200,11 @@ __device__ __forceinline__ void ig_consumer(const IgArgs &A, unsigned char *lds,
 }
 
 // ---------------------------------------------------------------------------------------------
-// a loader wave: the rows of A of two consumer waves, kIgRA steps ahead in registers, one step ahead in LDS
+// a loader wave.  The upper part of a lane's row is a 32-byte window of A.val, 56 bytes (a row) after the one before: two rows of a lane
+// are fetched as four 16-byte pieces by four threads -- an instruction covers 16 lanes x (2 windows in 88 bytes) instead of 64 lanes x
+// 8 bytes.  The lanes whose skew has the parity of the step take their turn together (128 lanes = eight instructions over the two
+// loader waves); a pair of rows is requested four steps before its first row is due, waits in registers, and lands in the stage one
+// step early.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ig_loader(const IgArgs &A, unsigned char *lds, const int ty, const int tz, const int lw)
 {
@@ -209,43 +212,60 @@ __device__ __forceinline__ void ig_loader(const IgArgs &A, unsigned char *lds, c
     const int nx = A.g.nx;
     constexpr unsigned OOB = 0xfffffff0u;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.aval), 0, (int)A.abytes, 0x00020000);
-    const IgLane l0 = ig_lane(A, ty, tz, (2 * lw) * 64 + ln), l1 = ig_lane(A, ty, tz, (2 * lw + 1) * 64 + ln);
-    const unsigned st0 = (unsigned)((2 * lw) * 64 + ln) * 32u, st1 = (unsigned)((2 * lw + 1) * 64 + ln) * 32u;
-    double r0[kIgRA][4], r1[kIgRA][4];
-#define IGL_LOAD(r_, l_, slot_, s_)                                                                          \
-    do {                                                                                                     \
-        const int k_ = (s_) - (l_).sk;                                                                       \
-        unsigned o_ = ((l_).active && (unsigned)k_ < (unsigned)nx) ? (l_).ua0 + (unsigned)k_ * (l_).lenb : OOB; \
-        IGL_NOLOAD_(o_);                                                                                     \
-        asm volatile("" : "+v"(o_));                                                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
-            r_[slot_][j_] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, o_ + 8u * (unsigned)j_, 0, 0)); \
-    } while (0)
+    const int piece = ln & 3;
+    unsigned gua[8], glen[8], gst[8];
+    int gsk[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = (lw * 4 + j) * 16 + (ln >> 2);
+            const int zl = 2 * (q >> 4) + c, yl = q & 15;
+            const IgLane g = ig_lane(A, ty, tz, 16 * zl + yl);
+            gua[c * 4 + j] = g.ua0 + 16u * (unsigned)(piece & 1);
+            glen[c * 4 + j] = g.lenb;
+            gst[c * 4 + j] = (unsigned)(16 * zl + yl) * 32u + 16u * (unsigned)(piece & 1);
+            gsk[c * 4 + j] = g.active ? g.sk : (1 << 28);          // (an idle lane never has a row)
+        }
+    }
 #ifdef IG_X_NOLOAD
 #define IGL_NOLOAD_(o) (o) = OOB
 #else
 #define IGL_NOLOAD_(o) (void)0
 #endif
-#define IGL_WRITE(r_, st_, slot_, s_)                                                                        \
+    v4u R[8][2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { R[e][0] = v4u{0u, 0u, 0u, 0u}; R[e][1] = v4u{0u, 0u, 0u, 0u}; }
+    // rows 2m, 2m+1 (m = (i_ + 1 - skew) / 2 + 2) of the lanes of class c_: requested in iteration i_
+#define IGL_LOAD(c_, j_, gen_, i_)                                                                           \
     do {                                                                                                     \
-        v2d a_, b_;                                                                                          \
-        a_.x = r_[slot_][0]; a_.y = r_[slot_][1]; b_.x = r_[slot_][2]; b_.y = r_[slot_][3];                  \
-        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 1) * kIgAstSlot + (st_)) = a_;             \
-        *reinterpret_cast<v2d *>(lds + kIgAst + (unsigned)((s_) & 1) * kIgAstSlot + (st_) + 16u) = b_;       \
+        const int kk_ = (i_) + 5 - gsk[(c_) * 4 + (j_)] + (piece >> 1);                                      \
+        unsigned o_ = (unsigned)kk_ < (unsigned)nx ? gua[(c_) * 4 + (j_)] + (unsigned)kk_ * glen[(c_) * 4 + (j_)] : OOB; \
+        IGL_NOLOAD_(o_);                                                                                     \
+        asm volatile("" : "+v"(o_));                                                                         \
+        R[(c_) * 4 + (j_)][gen_] = __builtin_amdgcn_raw_buffer_load_b128(ra, o_, 0, 0);                      \
     } while (0)
-#pragma unroll
-    for (int r = 0; r < kIgRA; ++r) { IGL_LOAD(r0, l0, r, r); IGL_LOAD(r1, l1, r, r); }
-    IGL_WRITE(r0, st0, 0, 0); IGL_WRITE(r1, st1, 0, 0);
-    IGL_LOAD(r0, l0, 0, kIgRA); IGL_LOAD(r1, l1, 0, kIgRA);
-    for (int ib = 0; ib < A.S; ib += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = ib + u;
-            ST_BARRIER();
-            IGL_WRITE(r0, st0, (u + 1) % kIgRA, i + 1); IGL_WRITE(r1, st1, (u + 1) % kIgRA, i + 1);
-            IGL_LOAD(r0, l0, (u + 1) % kIgRA, i + 1 + kIgRA); IGL_LOAD(r1, l1, (u + 1) % kIgRA, i + 1 + kIgRA);
-        }
+    // ... and put where the consumers read them in the steps i_ + 1, i_ + 2 (rows (i_ + 1 - skew) + {0, 1})
+#define IGL_WRITE(c_, j_, gen_, i_)                                                                          \
+    do {                                                                                                     \
+        const unsigned slot_ = (unsigned)(((i_) + 1 + (piece >> 1)) & 3);                                    \
+        *reinterpret_cast<v4u *>(lds + kIgAst + slot_ * kIgAstSlot + gst[(c_) * 4 + (j_)]) = R[(c_) * 4 + (j_)][gen_]; \
+    } while (0)
+#define IGL_EVENT(c_, gen_, i_, wr_)                                                                         \
+    do {                                                                                                     \
+        if (wr_) { IGL_WRITE(c_, 0, gen_, i_); IGL_WRITE(c_, 1, gen_, i_); IGL_WRITE(c_, 2, gen_, i_); IGL_WRITE(c_, 3, gen_, i_); } \
+        IGL_LOAD(c_, 0, gen_, i_); IGL_LOAD(c_, 1, gen_, i_); IGL_LOAD(c_, 2, gen_, i_); IGL_LOAD(c_, 3, gen_, i_); \
+    } while (0)
+    // iteration i serves the class (i + 1) & 1; its register generation alternates: ((i + 1 - class) / 2) & 1
+    IGL_EVENT(0, 0, -5, false); IGL_EVENT(1, 0, -4, false); IGL_EVENT(0, 1, -3, false); IGL_EVENT(1, 1, -2, false);
+    IGL_EVENT(0, 0, -1, true);
+    for (int ib = 0; ib < A.S; ib += 4) {
+        ST_BARRIER(); IGL_EVENT(1, 0, ib, true);
+        ST_BARRIER(); IGL_EVENT(0, 1, ib + 1, true);
+        ST_BARRIER(); IGL_EVENT(1, 1, ib + 2, true);
+        ST_BARRIER(); IGL_EVENT(0, 0, ib + 3, true);
     }
+#undef IGL_EVENT
 #undef IGL_LOAD
 #undef IGL_WRITE
 #undef IGL_NOLOAD_
