@@ -1293,9 +1293,8 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
     GridDims gd = {0, 0, 0};
     if (add_fill_in == 0 && threshold == 0.0 && head && grid_guess(A.n, A.nnz, head, &gd)) {
         IcholtGridJob job;
-        if (icholt_grid_launch(st, A, gd, p->ctrl, &p->Lc, &job)) {
+        if (icholt_grid_launch(st, p->side, A, gd, p->ctrl, &p->Lc, &job)) {
             hipStream_t q = p->side ? p->side : st;
-            if (p->side) ILUPP_HIP(hipStreamWaitEvent(p->side, job.pattern_done, 0));
             sweep_schedule(q);
             ILUPP_HIP(stream_sync(q));
             p->icholt_grid = icholt_grid_finish(st, &job, &kms);

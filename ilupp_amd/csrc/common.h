@@ -412,7 +412,7 @@ struct IcholtGridJob {
     IcholtGridJob &operator=(const IcholtGridJob &) = delete;
     ~IcholtGridJob();
 };
-bool icholt_grid_launch(hipStream_t st, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job);
+bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job);
 bool icholt_grid_finish(hipStream_t st, IcholtGridJob *job, float *kernel_ms);
 int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms);
 // iluc_df.hip: Crout ILU on the major-order view; L by columns (arrays = CSR of L^T, 1 first), U by rows (pivot first)

@@ -511,7 +511,7 @@ IcholtGridJob::~IcholtGridJob()
 // Queues everything on st and returns: L's index arrays (closed form; `pattern_done` is recorded behind them -- the caller's sweep
 // analysis needs nothing else and can run beside the kernel), the proof of the grid (k_grid_check), the exchange buffer's sentinels,
 // the kernel, the read-back of its verdict.  *L owns the arrays at once.  false: a grid outside the kernel's limits, nothing was queued.
-bool icholt_grid_launch(hipStream_t st, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job)
+bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job)
 {
     static const bool off = getenv("ILUPP_NO_ICHOLT_GRID") != nullptr;
     if (off) return false;
@@ -537,9 +537,17 @@ bool icholt_grid_launch(hipStream_t st, const DevMat &A, const GridDims &g, int3
     ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)nnzL));
     ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)nnzL));
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, sizeof(int32_t) * 16, st));
-    hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, st, A.n, g, L->ptr, L->idx, (long long)nnzL);
-    ILUPP_HIP(hipEventRecord(job->pattern_done, st));
-    grid_check_launch(st, A, g, ctrl + 8);
+    // L's index arrays and the proof of the grid need nothing from the kernel and the kernel nothing from them: on the side stream,
+    // beside the kernel's first steps (few patches are at work then)
+    hipStream_t q = side ? side : st;
+    if (side) {
+        ILUPP_HIP(hipEventRecord(job->pattern_done, st));
+        ILUPP_HIP(hipStreamWaitEvent(side, job->pattern_done, 0));
+    }
+    hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, q, A.n, g, L->ptr, L->idx, (long long)nnzL);
+    ILUPP_HIP(hipEventRecord(job->pattern_done, q));
+    grid_check_launch(q, A, g, ctrl + 8);
+    if (side) ILUPP_HIP(hipEventRecord(job->ev.b, side));
     fill_u64(st, xp, xwords, kSentinel);
     ILUPP_HIP(hipMemsetAsync(xp + xwords, 0, 64, st));
     IgArgs a;
@@ -551,6 +559,7 @@ bool icholt_grid_launch(hipStream_t st, const DevMat &A, const GridDims &g, int3
     ILUPP_HIP(hipEventRecord(job->ev.a, st));
     hipLaunchKernelGGL(k_icholt_grid, dim3((unsigned)(nty * ntz)), dim3(kIgThreads), kIgLds, st, a);
     ILUPP_HIP(hipGetLastError());
+    if (side) ILUPP_HIP(hipStreamWaitEvent(st, job->ev.b, 0));          // (the proof's verdict word)
     ILUPP_HIP(hipEventRecord(job->ev.b, st));
     ILUPP_HIP(d2h_async(st, job->h, ctrl, sizeof(job->h)));
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, sizeof(int32_t) * 16, st));
