@@ -346,6 +346,7 @@ def extra_config(name, dev, steps, with_cpu=True):
         x.fill_(1.0)
         P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
         t = P.timings()
+        path = P.path()
         nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
         if name in ("C5", "C5M", "C5P", "C5L"):
             t["numeric_kernel_ms"] = t["kernel_ms"]
@@ -363,15 +364,22 @@ def extra_config(name, dev, steps, with_cpu=True):
     del td, ti, tp, x
     torch.cuda.empty_cache()
     cpu = cpu_extra(name, d, i, p) if with_cpu else None
-    return {**more, "workload": what, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
+    kernel = EXTRA_KERNEL.get(name)
+    if path == "icholt:grid-static":
+        # ICholT(0, 0) of a box grid: the speculative static kernel (icholt_grid.hip) -- A's pattern assumed for every column, verified
+        kernel = "k_icholt_grid"
+    ktraffic = measured_traffic(kernel, 256) if kernel == "k_icholt_grid" else None
+    return {**more, "workload": what, "path": path, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
             "numeric_kernel_ms": kms_med, "first_apply_ms": float(np.median(firsts)), "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
             "hbm_fraction": fbytes / sec / 1e9 / HBM_PEAK_GBS,
             # the dominant kernel of the construction against the HBM roofline: SURVEY 8(d)'s bytes for these configs (read A + write the
             # factors actually produced) over the kernel's own time; no counter traffic was collected for these kernels
-            "roofline": {"bound": "hbm", "kernel": EXTRA_KERNEL.get(name), "algorithmic_bytes": fbytes, "avg_launch_ms": kms_med,
+            "roofline": {"bound": "hbm", "kernel": kernel, "algorithmic_bytes": fbytes, "avg_launch_ms": kms_med,
                          "achieved": (fbytes / (kms_med * 1e-3) / 1e9) if kms_med > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (fbytes / (kms_med * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms_med > 0 else None, "traffic": None},
+                         "frac": (fbytes / (kms_med * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms_med > 0 else None,
+                         "traffic": ktraffic,
+                         "traffic_source": (", ".join(sorted(TRAFFIC_SOURCE)) + " (committed counter passes, not this run)") if ktraffic else None},
             "cpu_baseline": cpu}
 
 

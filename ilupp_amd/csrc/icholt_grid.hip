@@ -1,7 +1,7 @@
 // ilupp_amd/csrc/icholt_grid.hip -- ICholT(add_fill_in = 0, threshold = 0) of a box-grid stencil matrix (BASELINE config C4) as a
 // SPECULATIVE static computation.
 //
-// The reference (IChol.hpp:78-155, restated in oracle/ilupp_oracle.c: orc_icholt) builds column j of L from a working column w:
+// The reference (IChol.hpp:78-155) builds column j of L from a working column w:
 //   w = A(j:, j);  D[j] += a_jj;  L_jj = sqrt(D[j]);  for every column k < j with L(j, k) != 0:  w(i) -= L(i, k) L(j, k)  (i > j);
 //   w(i) /= L_jj and D[i] -= w(i)^2 for EVERY i > j of w (IChol.hpp:135-141: before anything is dropped);
 //   keep the col_len = nnz(A(j:, j)) entries of largest magnitude, the diagonal competing (dropping.hpp:8-34), sorted by row.
