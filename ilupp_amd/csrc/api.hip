@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1293,11 +1294,50 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
     GridDims gd = {0, 0, 0};
     if (add_fill_in == 0 && threshold == 0.0 && head && grid_guess(A.n, A.nnz, head, &gd)) {
         IcholtGridJob job;
-        if (icholt_grid_launch(st, p->side, A, gd, p->ctrl, &p->Lc, &job)) {
+        const auto w0 = std::chrono::steady_clock::now();
+        // L's pattern is the grid's: blocks and patches of the sweeps' schedule from the dimensions, no pass over the pattern (env
+        // ILUPP_IG_SCHED=general: the general pass; =verify: both, compared)
+        auto schedule_on = [&](hipStream_t q) {
+            static const char *sched_mode = getenv("ILUPP_IG_SCHED");
+            const bool want_general = sched_mode && !strcmp(sched_mode, "general");
+            if (!want_general && grid_llt_schedule(q, n, gd, p->max_lanes, &p->sL)) {
+                p->degenerate = false;                              // (every column has its diagonal)
+                p->max_row_len = 1 + (gd.nx > 1) + (gd.ny > 1) + (gd.nz > 1);
+                if (sched_mode && !strcmp(sched_mode, "verify")) {
+                    Schedule ref;
+                    int32_t m1 = 0;
+                    count_cuts_and_schedule(q, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &ref, &m1);
+                    choose_tiling(q, n, p->Lc.ptr, p->Lc.idx, &ref, false, p->max_lanes / kThreads);
+                    bool same = ref.nb == p->sL.nb && ref.B == p->sL.B && ref.tile_s2 == p->sL.tile_s2 && ref.tile_ty == p->sL.tile_ty &&
+                                ref.tile_tz == p->sL.tile_tz && m1 == p->max_row_len && min_row_len(q, n, p->Lc.ptr, p->Lc.idx, 1) != 0;
+                    if (same) {
+                        std::vector<int32_t> a((size_t)ref.nb + 1), b((size_t)ref.nb + 1);
+                        ILUPP_HIP(hipMemcpyAsync(a.data(), ref.start, sizeof(int32_t) * a.size(), hipMemcpyDeviceToHost, q));
+                        ILUPP_HIP(hipMemcpyAsync(b.data(), p->sL.start, sizeof(int32_t) * b.size(), hipMemcpyDeviceToHost, q));
+                        ILUPP_HIP(hipStreamSynchronize(q));
+                        same = a == b;
+                    }
+                    ref.release();
+                    if (!same) { set_error("ICholT grid path: the schedule from the dimensions differs from the general pass'"); throw HipError{hipErrorUnknown, "ILUPP_IG_SCHED=verify", __FILE__, __LINE__}; }
+                }
+                build_slot_tables(q, &p->sL, false);
+                p->compact = schedule_is_compact(p->sL);
+                if (p->compact) make_desc(q, p->Lc, p->sL, &p->dL);
+            } else {
+                sweep_schedule(q);
+            }
+        };
+        if (icholt_grid_launch(st, p->side, A, gd, p->ctrl, &p->Lc, &job, schedule_on)) {
             hipStream_t q = p->side ? p->side : st;
-            sweep_schedule(q);
+            const auto w1 = std::chrono::steady_clock::now();
             ILUPP_HIP(stream_sync(q));
+            const auto w2 = std::chrono::steady_clock::now();
             p->icholt_grid = icholt_grid_finish(st, &job, &kms);
+            if (getenv("ILUPP_IG_DEBUG")) {
+                const auto w3 = std::chrono::steady_clock::now();
+                fprintf(stderr, "icholt_grid host: launch %.3f ms, sweep schedule %.3f ms, wait %.3f ms\n", std::chrono::duration<double, std::milli>(w1 - w0).count(),
+                        std::chrono::duration<double, std::milli>(w2 - w1).count(), std::chrono::duration<double, std::milli>(w3 - w2).count());
+            }
             if (!p->icholt_grid) {
                 p->Lc.release(); p->sL.release();
                 if (p->dL) { (void)pool_free(p->dL); p->dL = nullptr; }

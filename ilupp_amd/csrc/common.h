@@ -318,6 +318,7 @@ bool grid_shape_recall(int32_t n, int64_t nnz, GridDims *g);
 void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g);
 void grid_shape_forget(int32_t n, int64_t nnz);
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
+bool grid_llt_schedule(hipStream_t st, int32_t n, const GridDims &g, int max_lanes, Schedule *bwd);
 void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
                     int32_t *max_row_len, int max_wgs);
 // slot tables, lane templates and the link between the two schedules of a box grid, from its dimensions (one launch; the schedules'
@@ -412,7 +413,8 @@ struct IcholtGridJob {
     IcholtGridJob &operator=(const IcholtGridJob &) = delete;
     ~IcholtGridJob();
 };
-bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job);
+bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job,
+                        const std::function<void(hipStream_t)> &after_pattern);
 bool icholt_grid_finish(hipStream_t st, IcholtGridJob *job, float *kernel_ms);
 int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms);
 // iluc_df.hip: Crout ILU on the major-order view; L by columns (arrays = CSR of L^T, 1 first), U by rows (pivot first)

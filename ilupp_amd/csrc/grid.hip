@@ -563,4 +563,30 @@ void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *
     }
 }
 
+// The backward schedule of L^T of an LL^T object on a box grid (icholt_grid.hip): what count_cuts_and_schedule + choose_tiling find in
+// the pattern -- one block per x-line, patches of 16 x 16 lines -- from the dimensions.  false: the general pass would cut differently
+// (more rows than lanes x line length), nothing was made.
+bool grid_llt_schedule(hipStream_t st, int32_t n, const GridDims &g, int max_lanes, Schedule *bwd)
+{
+    if (((int64_t)n + max_lanes - 1) / max_lanes > g.nx || g.nx <= 4) return false;
+    const int32_t nb = g.ny * g.nz;
+    bwd->nb = nb; bwd->B = g.nx;
+    ILUPP_HIP(pool_malloc(&bwd->start, sizeof(int32_t) * (size_t)(nb + 1)));
+    bwd->tile_s2 = bwd->tile_ty = bwd->tile_tz = 0;
+    hipLaunchKernelGGL(k_grid_starts, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st, n, g.nx, nb, bwd->start, bwd->start);
+    ILUPP_HIP(hipGetLastError());
+    // patches of 16 x 16 lines, as square as the grid allows (schedule.hip: tiling_decide; grid_schedules above)
+    if (g.nz >= 2 && getenv("ILUPP_NO_TILES") == nullptr) {
+        const int s2 = g.ny, nbz = g.nz;
+        int ty = 16, tz = 16;
+        while (ty > s2 && ty > 1) { ty >>= 1; tz <<= 1; }
+        while (tz > nbz && tz > 1) { tz >>= 1; ty <<= 1; }
+        if (ty <= s2 && ty * tz == kThreads) {
+            const int NY = (s2 + ty - 1) / ty, NZ = (nbz + tz - 1) / tz;
+            if ((long)NY * NZ <= max_lanes / kThreads) { bwd->tile_s2 = s2; bwd->tile_ty = ty; bwd->tile_tz = tz; }
+        }
+    }
+    return true;
+}
+
 }  // namespace ilupp

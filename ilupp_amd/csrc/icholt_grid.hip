@@ -511,7 +511,8 @@ IcholtGridJob::~IcholtGridJob()
 // Queues everything on st and returns: L's index arrays (closed form; `pattern_done` is recorded behind them -- the caller's sweep
 // analysis needs nothing else and can run beside the kernel), the proof of the grid (k_grid_check), the exchange buffer's sentinels,
 // the kernel, the read-back of its verdict.  *L owns the arrays at once.  false: a grid outside the kernel's limits, nothing was queued.
-bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job)
+bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job,
+                        const std::function<void(hipStream_t)> &after_pattern)
 {
     static const bool off = getenv("ILUPP_NO_ICHOLT_GRID") != nullptr;
     if (off) return false;
@@ -537,19 +538,18 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
     ILUPP_HIP(pool_malloc(&L->idx, sizeof(int32_t) * (size_t)nnzL));
     ILUPP_HIP(pool_malloc(&L->val, sizeof(double) * (size_t)nnzL));
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, sizeof(int32_t) * 16, st));
-    // L's index arrays and the proof of the grid need nothing from the kernel and the kernel nothing from them: on the side stream,
-    // beside the kernel's first steps (few patches are at work then)
+    // Before the kernel, on two streams: L's index arrays and what the caller makes of them (the sweeps' schedule) on the side stream;
+    // the proof of the grid and the exchange buffer's sentinels on this one.  The kernel starts when both are through: anything that
+    // streams beside it costs several times its own duration (the patches of the kernel hold every CU; measured: the schedule's
+    // 0.15 ms became 0.9 ms, the proof's 0.12 ms 0.5 ms, and the kernel 0.2 ms longer).
     hipStream_t q = side ? side : st;
-    if (side) {
-        ILUPP_HIP(hipEventRecord(job->pattern_done, st));
-        ILUPP_HIP(hipStreamWaitEvent(side, job->pattern_done, 0));
-    }
     hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, q, A.n, g, L->ptr, L->idx, (long long)nnzL);
+    if (after_pattern) after_pattern(q);
     ILUPP_HIP(hipEventRecord(job->pattern_done, q));
-    grid_check_launch(q, A, g, ctrl + 8);
-    if (side) ILUPP_HIP(hipEventRecord(job->ev.b, side));
+    grid_check_launch(st, A, g, ctrl + 8);
     fill_u64(st, xp, xwords, kSentinel);
     ILUPP_HIP(hipMemsetAsync(xp + xwords, 0, 64, st));
+    if (side) ILUPP_HIP(hipStreamWaitEvent(st, job->pattern_done, 0));
     IgArgs a;
     a.g = g; a.nty = nty; a.ntz = ntz;
     a.S = ((g.nx + kIgMaxSkew + 3) + 7) & ~7;
@@ -559,7 +559,6 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
     ILUPP_HIP(hipEventRecord(job->ev.a, st));
     hipLaunchKernelGGL(k_icholt_grid, dim3((unsigned)(nty * ntz)), dim3(kIgThreads), kIgLds, st, a);
     ILUPP_HIP(hipGetLastError());
-    if (side) ILUPP_HIP(hipStreamWaitEvent(st, job->ev.b, 0));          // (the proof's verdict word)
     ILUPP_HIP(hipEventRecord(job->ev.b, st));
     ILUPP_HIP(d2h_async(st, job->h, ctrl, sizeof(job->h)));
     ILUPP_HIP(hipMemsetAsync(ctrl, 0, sizeof(int32_t) * 16, st));

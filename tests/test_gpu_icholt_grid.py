@@ -153,3 +153,12 @@ def test_the_static_and_the_general_path_give_the_same_bits():
     assert info == ["icholt:grid-static"] * 2
     info2, dig = _run_with({"ILUPP_NO_ICHOLT_GRID": "1"})
     assert info2 == ["icholt"] * 2 and dig == ref
+
+
+def test_the_schedule_from_the_dimensions_is_the_general_one():
+    """ILUPP_IG_SCHED=verify builds the sweeps' schedule both ways (from the grid's dimensions; by the pass over L's pattern) and
+    compares blocks, starts, patches, the longest row; =general uses the pass.  Same factor, same applies either way."""
+    info, ref = _run_with({})
+    for mode in ("verify", "general"):
+        info2, dig = _run_with({"ILUPP_IG_SCHED": mode})
+        assert info2 == info and dig == ref, mode
