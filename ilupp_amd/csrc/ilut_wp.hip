@@ -27,6 +27,8 @@
 // entries, private to the wave); a row that outgrows those, or a fill budget beyond the LDS selection queue, makes the host run
 // the whole factorisation in the largest capacity class (k_ilut_rows_wp_big: pieces as long as the matrix is wide, on fewer waves).
 #include <stdio.h>
+#include <algorithm>
+#include <vector>
 #include <stdlib.h>
 
 #include "common.h"
@@ -48,8 +50,16 @@ static constexpr int kWpHashG = 1 << 17;
 #endif
 
 #ifdef ILUT_PROFILE
-#define WP_T(var) const long long var = clock64()
-#define WP_ACC(slot, t0, t1) do { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + (slot), (unsigned long long)((t1) - (t0))); } while (0)
+// Profile build (profiles/tools/ilut_profile.sh): cycles per phase summed over the waves (ctrl + 8: [0] pops and stage-1 drops, [1] waiting
+// for / fetching a U row, [2] the update with it ([6] of that: appending fill), [3] dropping and storing the row, [7] scatter of A's row;
+// [4] fetch retries, [5] fetches), and per row: its dependency level, the row it last had to WAIT for, its start and finish times --
+// the host walks the chain of last-awaited rows back from the row that finished last: the realised critical path.
+#define WP_T(var) const long long var = wall_clock64()
+// (per wave in registers, added to ctrl + 8 once when the wave has no more rows: an atomic per phase and fetch on one address from
+// 5 120 waves made the kernel eight times slower)
+#define WP_ACC(slot, t0, t1) do { prof[slot] += (unsigned long long)((t1) - (t0)); } while (0)
+__device__ int *g_wp_lvl, *g_wp_parent;
+__device__ long long *g_wp_tfin, *g_wp_tstart, *g_wp_wait;
 #else
 #define WP_T(var)
 #define WP_ACC(slot, t0, t1)
@@ -249,12 +259,19 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                                       const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                                       int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
                                       int32_t *Urow_idx, double *Urow_val, int32_t *Ulen,
-                                      const WpArraysT<IdT> w, int *bcol, double *bpr, int *bfound, int *selq, int *gscratch, int32_t *ctrl)
+                                      const WpArraysT<IdT> w, int *bcol, double *bpr, int *bfound, int *selq, int *gscratch, int32_t *ctrl,
+                                      unsigned long long *prof = nullptr)
 {
     using A = WpAcc<G>;
+    (void)prof;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nL = 0, nU = 0, nK = 0, seq = 0;
     double wdiag = 0.0;
+#ifdef ILUT_PROFILE
+    int prof_lvl = 0, prof_parent = -1;
+    long long prof_wait = 0;
+    const long long prof_t0 = wall_clock64();
+#endif
     // the U-slot hash starts empty
     {
         unsigned long long *t64 = reinterpret_cast<unsigned long long *>(w.uh);
@@ -286,28 +303,50 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         for (int q = 0; q < nL; ++q) { const double v = A::ldd(&w.lval[q]); const double sq = v * v; z = z + sq; }
         thr1 = tau * sqrt(z);
     }
+    WP_ACC(7, prof_t0, wall_clock64());
     // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
     for (;;) {
         WP_T(tp0);
+        // The next column that is ELIMINATED: the smallest one whose entry is neither zero (ILUT.hpp:239-240) nor below the stage-1
+        // threshold (:244-245).  The reference pops every column in ascending order and forgets those; a forgotten entry has no
+        // effect on anything, and an entry's value only changes when a smaller column is eliminated -- so every entry left of the
+        // next eliminated column has, now, the value it would have when popped: all of them go at once (on C3 78 % of the pops,
+        // each a pass over the pool, end this way: 600 passes per row became 134).
         unsigned best = 0x7fffffffu;
         int bq = -1;
-        for (int q = lane; q < nL; q += 64) { const unsigned c = (unsigned)A::ldi(&w.lcol[q]); if (c < best) { best = c; bq = q; } }
+        for (int q = lane; q < nL; q += 64) {
+            const unsigned c = (unsigned)A::ldi(&w.lcol[q]);
+            const double v = A::ldd(&w.lval[q]);
+            const bool live = v != 0.0 && !(fabs(v) < thr1);
+            if (live && c < best) { best = c; bq = q; }
+        }
         const unsigned g = wave_min_u32(best);
-        if (g == 0x7fffffffu) break;
+        if (g == 0x7fffffffu) break;                                         // (what is left would be popped and forgotten)
         const unsigned long long who = __ballot(best == g);
         const int qs = __builtin_amdgcn_readlane(bq, __ffsll((long long)who) - 1);
         const int k = (int)g;
         const double wkv = A::ldd(&w.lval[qs]);
         const int sk = A::ldi(&w.lseq[qs]);
-        const int last = nL - 1;
-        int mc = 0, ms = 0; double mv = 0.0;
-        if (qs != last) { mc = A::ldi(&w.lcol[last]); mv = A::ldd(&w.lval[last]); ms = A::ldi(&w.lseq[last]); }
         A::sync();
-        if (lane == 0 && qs != last) { A::sti(&w.lcol[qs], mc); A::std_(&w.lval[qs], mv); A::sti(&w.lseq[qs], ms); }
-        nL = last;
-        A::sync();
-        if (wkv == 0.0) continue;                                            // ILUT.hpp:239-240
-        if (fabs(wkv) < thr1) continue;                                      // stage-1 drop, :244-245
+        // the pool keeps the entries right of column k (in place: a chunk's entries are in registers before any of them is written,
+        // and they move to positions at or before their own)
+        {
+            int kept = 0;
+            for (int base = 0; base < nL; base += 64) {
+                const int q = base + lane;
+                const bool valid = q < nL;
+                const int c = valid ? A::ldi(&w.lcol[q]) : 0;
+                const double v = valid ? A::ldd(&w.lval[q]) : 0.0;
+                const int sq = valid ? A::ldi(&w.lseq[q]) : 0;
+                const bool keep = valid && c > k;
+                const unsigned long long mk = __ballot(keep);
+                A::sync();
+                if (keep) { const int pos = kept + __popcll(mk & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], sq); }
+                kept += __popcll(mk);
+                A::sync();
+            }
+            nL = kept;
+        }
         // row k of U, validated against the sentinels
         WP_T(tp1); WP_ACC(0, tp0, tp1);
         const size_t ub = (size_t)k * p;
@@ -325,10 +364,17 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             __builtin_amdgcn_s_sleep(1);
         }
 #ifdef ILUT_PROFILE
-        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + 4, (unsigned long long)spins); atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + 5, 1ull); }
+        prof[4] += spins; prof[5] += 1ull;
 #endif
         ul = __builtin_amdgcn_readfirstlane(ul);
         WP_T(tp2); WP_ACC(1, tp1, tp2);
+#ifdef ILUT_PROFILE
+        {
+            const int lk = ld_agent_i32(&g_wp_lvl[k]);
+            prof_lvl = lk > prof_lvl ? lk : prof_lvl;
+            if (spins > 0) { prof_parent = k; prof_wait += tp2 - tp1; }
+        }
+#endif
         const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
         const double m = wkv / ud;                                           // :249
         if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); return 1; }
@@ -439,6 +485,11 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         if ((unsigned long long)__double_as_longlong(piv) == kSentinel) piv = __longlong_as_double((long long)kCanonNaN);
         st_agent_f64(&Urow_val[lb], piv);
         st_agent_i32(&Urow_idx[lb], i);
+#ifdef ILUT_PROFILE
+        st_agent_i32(&g_wp_lvl[i], prof_lvl + 1);
+        g_wp_parent[i] = prof_parent; g_wp_tstart[i] = prof_t0; g_wp_wait[i] = prof_wait; g_wp_tfin[i] = wall_clock64();
+        __threadfence();
+#endif
         st_agent_i32(&Ulen[i], nUk + 1);
     }
     A::sync();
@@ -470,18 +521,23 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
     g.kcol += wv * (size_t)gw.capK; g.kval += wv * (size_t)gw.capK; g.kseq += wv * (size_t)gw.capK;
     int *gscratch = gscratch_all + wv * (size_t)gw.capU;
     const WpArrays lw = {s_uh, kWpHashLds - 1, s_ucol, s_uval, kWpCapU, s_lcol, s_lval, s_lseq, kWpCapL, g.kcol, g.kval, g.kseq, gw.capK};
+#ifdef ILUT_PROFILE
+    unsigned long long prof[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#else
+    unsigned long long *prof = nullptr;
+#endif
     for (;;) {
         int i = 0;
         if (lane == 0) i = atomicAdd(&ctrl[0], 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= n) break;
         int rc = wp_row<false>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                               lw, bcol, bpr, bfound, s_selq, gscratch, ctrl);
+                               lw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc == 1) {
             if (lane == 0) atomicAdd(&ctrl[3], 1);          // statistics: rows that went to the global-memory pieces
             rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                              g, bcol, bpr, bfound, s_selq, gscratch, ctrl);
+                              g, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
             rc = __builtin_amdgcn_readfirstlane(rc);
         }
         if (rc != 0) {
@@ -495,6 +551,10 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
             }
         }
     }
+#ifdef ILUT_PROFILE
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + q, prof[q]);
+#endif
 }
 
 // the largest capacity class: every piece as long as the matrix is wide, 32-bit slot ids and sequence numbers, the selection
@@ -515,6 +575,11 @@ k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *_
     g.lcol += wv * (size_t)gw.capL; g.lval += wv * (size_t)gw.capL; g.lseq += wv * (size_t)gw.capL;
     g.kcol += wv * (size_t)gw.capK; g.kval += wv * (size_t)gw.capK; g.kseq += wv * (size_t)gw.capK;
     int *gscratch = gscratch_all + wv * (size_t)gw.capU;
+#ifdef ILUT_PROFILE
+    unsigned long long prof[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#else
+    unsigned long long *prof = nullptr;
+#endif
     int *selq = selq_all + wv * (size_t)(p + 1);
     for (;;) {
         int i = 0;
@@ -522,7 +587,7 @@ k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *_
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= n) break;
         int rc = wp_row<true, unsigned int, true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                                                  g, bcol, bpr, bfound, selq, gscratch, ctrl);
+                                                  g, bcol, bpr, bfound, selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc != 0) {
             // give up: publish a poisoned row so that nobody waits for it, and report
@@ -627,6 +692,20 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         g.kcol = b_kcol.as<int>(); g.kval = b_kval.as<double>(); g.kseq = b_kseq.as<unsigned short>();
         int *gscratch = b_scr.as<int>();
         wp_init_slabs(st, n, slab, Uri, Urv, Ulen, ctrl);
+#ifdef ILUT_PROFILE
+        PoolBlock pb_lvl, pb_par, pb_fin, pb_start, pb_wait;
+        ILUPP_HIP(pb_lvl.alloc(sizeof(int) * (size_t)n)); ILUPP_HIP(pb_par.alloc(sizeof(int) * (size_t)n));
+        ILUPP_HIP(pb_fin.alloc(sizeof(long long) * (size_t)n)); ILUPP_HIP(pb_start.alloc(sizeof(long long) * (size_t)n)); ILUPP_HIP(pb_wait.alloc(sizeof(long long) * (size_t)n));
+        ILUPP_HIP(hipMemsetAsync(pb_lvl.p, 0, sizeof(int) * (size_t)n, st));
+        {
+            int *a = pb_lvl.as<int>(), *b = pb_par.as<int>();
+            long long *c = pb_fin.as<long long>(), *d = pb_start.as<long long>(), *e = pb_wait.as<long long>();
+            ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_lvl), &a, sizeof(a))); ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_parent), &b, sizeof(b)));
+            ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_tfin), &c, sizeof(c))); ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_tstart), &d, sizeof(d)));
+            ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_wait), &e, sizeof(e)));
+        }
+        ILUPP_HIP(hipMemsetAsync(ctrl + 8, 0, 64, st));
+#endif
         WpEvents ev;
         ILUPP_HIP(hipEventCreate(&ev.a));
         ILUPP_HIP(hipEventCreate(&ev.b));
@@ -642,15 +721,61 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         ILUPP_HIP(hipMemcpyAsync(h, ctrl, 32, hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
         if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, ev.a, ev.b));
-    }
 #ifdef ILUT_PROFILE
-    {
-        unsigned long long t[8];
-        ILUPP_HIP(hipMemcpy(t, ctrl + 8, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ilupp] ilut_wp cycles (sum over waves, M): pops+drops %.1f  fetch %.1f  update %.1f (of which append %.1f)  dropping %.1f;  %llu fetches, %llu retries\n",
-                t[0] * 1e-6, t[1] * 1e-6, t[2] * 1e-6, t[6] * 1e-6, t[3] * 1e-6, t[5], t[4]);
-    }
+        if (h[1] == 0) {
+            unsigned long long t[8];
+            ILUPP_HIP(hipMemcpy(t, ctrl + 8, 64, hipMemcpyDeviceToHost));
+            float kms = 0.f;
+            ILUPP_HIP(hipEventElapsedTime(&kms, ev.a, ev.b));
+            const double tick = 1e-8;            // wall_clock64: 100 MHz
+            const double wave_s = (double)workers * kms * 1e-3;
+            fprintf(stderr, "[ilut profile] n %d, p %d, %d waves (%d per CU), kernel %.3f ms: wave-seconds %.2f\n", n, p, workers, workers / device_cu_count(), kms, wave_s);
+            const char *nm[8] = {"pop the next column (minimum over the pool) + stage-1 drops", "wait for / fetch the U row", "update with the U row", "drop, sort, store the row",
+                                 "", "", "  (of the update: append fill, hash)", "scatter A's row, clear the hash"};
+            for (int q : {7, 0, 1, 2, 6, 3}) fprintf(stderr, "[ilut profile]   %-62s %9.3f wave-s  %5.1f %%\n", nm[q], t[q] * tick, 100.0 * t[q] * tick / wave_s);
+            fprintf(stderr, "[ilut profile]   U rows fetched %llu (%.1f per row), retries while waiting %llu\n", t[5], (double)t[5] / n, t[4]);
+            std::vector<int> lvl((size_t)n), par((size_t)n);
+            std::vector<long long> fin((size_t)n), sta((size_t)n), wai((size_t)n);
+            ILUPP_HIP(hipMemcpy(lvl.data(), pb_lvl.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+            ILUPP_HIP(hipMemcpy(par.data(), pb_par.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+            ILUPP_HIP(hipMemcpy(fin.data(), pb_fin.p, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+            ILUPP_HIP(hipMemcpy(sta.data(), pb_start.p, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+            ILUPP_HIP(hipMemcpy(wai.data(), pb_wait.p, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+            int depth = 0, last = 0;
+            long long tmin = sta[0], tmax = fin[0];
+            double busy = 0.0, waited = 0.0;
+            size_t nwait = 0;
+            for (int r = 0; r < n; ++r) {
+                depth = lvl[r] > depth ? lvl[r] : depth;
+                if (fin[r] > tmax) { tmax = fin[r]; last = r; }
+                if (sta[r] < tmin) tmin = sta[r];
+                busy += (double)(fin[r] - sta[r]); waited += (double)wai[r];
+                nwait += par[r] >= 0 ? 1 : 0;
+            }
+            fprintf(stderr, "[ilut profile]   dependency depth of the factor (levels) %d; first start -> last finish %.3f ms\n", depth, (tmax - tmin) * tick * 1e3);
+            fprintf(stderr, "[ilut profile]   a row is in its wave %.1f us on average, %.1f us of that waiting for rows not finished yet (%.1f %% of the rows wait at all)\n",
+                    busy / n * tick * 1e6, waited / n * tick * 1e6, 100.0 * nwait / n);
+            // the chain of last-awaited rows back from the row that finished last
+            int links = 0; double chain_wait = 0.0, chain_own = 0.0;
+            std::vector<double> link_us;
+            for (int r = last; r >= 0;) {
+                const int q = par[r];
+                if (q < 0) { chain_own += (double)(fin[r] - sta[r]); break; }
+                const double d = (double)(fin[r] - fin[q]);             // from the awaited row's publication to this row's
+                link_us.push_back(d * tick * 1e6);
+                chain_own += d; chain_wait += (double)wai[r];
+                ++links; r = q;
+            }
+            std::sort(link_us.begin(), link_us.end());
+            fprintf(stderr, "[ilut profile]   critical chain (row %d back through the rows it last waited for): %d links, %.3f ms = %.1f %% of the kernel; a link (awaited row published -> this row published) "
+                            "median %.1f us, mean %.1f us, p90 %.1f us; its rows waited %.3f ms in all\n", last, links, chain_own * tick * 1e3, 100.0 * chain_own * tick * 1e3 / kms,
+                    link_us.empty() ? 0.0 : link_us[link_us.size() / 2], links ? chain_own * tick * 1e6 / links : 0.0, link_us.empty() ? 0.0 : link_us[link_us.size() * 9 / 10],
+                    chain_wait * tick * 1e3);
+            fprintf(stderr, "[ilut profile]   throughput bound: %.2f wave-s of non-waiting work / %d waves = %.1f ms; latency bound: the chain above\n",
+                    (busy - waited) * tick, workers, (busy - waited) * tick / workers * 1e3);
+        }
 #endif
+    }
     if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: %d of %d rows outgrew LDS (pool %d, U slots %d, kept %d), status %d, kernel %.3f ms\n", h[3], n, h[4], h[5], h[6], h[1], kernel_ms ? *kernel_ms : 0.f);
     // a row that outgrew the 64 K pieces: the whole factorisation once more in the largest class
     if (h[1] == 3) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
