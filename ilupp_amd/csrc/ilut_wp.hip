@@ -58,7 +58,7 @@ static constexpr int kWpHashG = 1 << 17;
 // (per wave in registers, added to ctrl + 8 once when the wave has no more rows: an atomic per phase and fetch on one address from
 // 5 120 waves made the kernel eight times slower)
 #define WP_ACC(slot, t0, t1) do { prof[slot] += (unsigned long long)((t1) - (t0)); } while (0)
-__device__ int *g_wp_lvl, *g_wp_parent;
+__device__ int *g_wp_lvl, *g_wp_parent, *g_wp_lparent;
 __device__ long long *g_wp_tfin, *g_wp_tstart, *g_wp_wait;
 #else
 #define WP_T(var)
@@ -268,12 +268,14 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     int nL = 0, nU = 0, nK = 0, seq = 0;
     double wdiag = 0.0;
 #ifdef ILUT_PROFILE
-    int prof_lvl = 0, prof_parent = -1;
+    int prof_lvl = 0, prof_parent = -1, prof_lparent = -1;
     long long prof_wait = 0;
     const long long prof_t0 = wall_clock64();
 #endif
-    // the U-slot hash starts empty
-    {
+    // the U-slot hash starts empty: the LDS table is cleared here; the wave's table in global memory (256 KB and more) is empty between
+    // rows -- the host clears it once, every row takes its own cells out again when it is done (clearing all of it per row wrote
+    // 190 GB on C3: three rows of four work there)
+    if (!G) {
         unsigned long long *t64 = reinterpret_cast<unsigned long long *>(w.uh);
         for (int q = lane; q < (int)((size_t)(w.hmask + 1) * sizeof(IdT) / 8); q += 64) t64[q] = 0ull;
         A::sync();
@@ -371,7 +373,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
 #ifdef ILUT_PROFILE
         {
             const int lk = ld_agent_i32(&g_wp_lvl[k]);
-            prof_lvl = lk > prof_lvl ? lk : prof_lvl;
+            if (lk > prof_lvl) { prof_lvl = lk; prof_lparent = k; }
             if (spins > 0) { prof_parent = k; prof_wait += tp2 - tp1; }
         }
 #endif
@@ -487,12 +489,23 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         st_agent_i32(&Urow_idx[lb], i);
 #ifdef ILUT_PROFILE
         st_agent_i32(&g_wp_lvl[i], prof_lvl + 1);
-        g_wp_parent[i] = prof_parent; g_wp_tstart[i] = prof_t0; g_wp_wait[i] = prof_wait; g_wp_tfin[i] = wall_clock64();
+        g_wp_parent[i] = prof_parent; g_wp_lparent[i] = prof_lparent; g_wp_tstart[i] = prof_t0; g_wp_wait[i] = prof_wait; g_wp_tfin[i] = wall_clock64();
         __threadfence();
 #endif
         st_agent_i32(&Ulen[i], nUk + 1);
     }
     A::sync();
+    if (G) {
+        // this row's cells of the table: found first (nothing is removed while anybody still walks), then emptied
+        for (int q = lane; q < nU; q += 64) {
+            unsigned h = wp_hash(A::ldi(&w.ucol[q]), w.hmask);
+            while (w.uh[h] != (IdT)(q + 1)) h = (h + 1) & (unsigned)w.hmask;
+            gscratch[q] = (int)h;
+        }
+        A::sync();
+        for (int q = lane; q < nU; q += 64) w.uh[gscratch[q]] = (IdT)0;
+        A::sync();
+    }
     WP_T(tq1); WP_ACC(3, tq0, tq1);
     return 0;
 }
@@ -549,6 +562,9 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
                 st_agent_i32(&Ulen[i], 1);
                 Llen[i] = 0;
             }
+            // (the row left its cells in the wave's table: the rows this wave still takes start from an empty one)
+            for (size_t q = lane; q < (size_t)kWpHashG * sizeof(unsigned short) / 8; q += 64) reinterpret_cast<unsigned long long *>(g.uh)[q] = 0ull;
+            __builtin_amdgcn_s_waitcnt(0);
         }
     }
 #ifdef ILUT_PROFILE
@@ -598,6 +614,8 @@ k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *_
                 st_agent_i32(&Ulen[i], 1);
                 Llen[i] = 0;
             }
+            for (size_t q = lane; q < (size_t)(gw.hmask + 1) * sizeof(unsigned int) / 8; q += 64) reinterpret_cast<unsigned long long *>(g.uh)[q] = 0ull;
+            __builtin_amdgcn_s_waitcnt(0);
         }
     }
 }
@@ -640,6 +658,7 @@ static int ilut_rows_wp_big(hipStream_t st, const DevMat &A, int32_t p, double t
     ILUPP_HIP(b_scr.alloc(sizeof(int) * (size_t)workers * cap));
     ILUPP_HIP(b_selq.alloc(sizeof(int) * (size_t)workers * (size_t)(p + 1)));
     g.uh = b_uh.as<unsigned int>(); g.ucol = b_ucol.as<int>(); g.uval = b_uval.as<double>();
+    ILUPP_HIP(hipMemsetAsync(g.uh, 0, sizeof(unsigned int) * (size_t)workers * hashN, st));
     g.lcol = b_lcol.as<int>(); g.lval = b_lval.as<double>(); g.lseq = b_lseq.as<unsigned int>();
     g.kcol = b_kcol.as<int>(); g.kval = b_kval.as<double>(); g.kseq = b_kseq.as<unsigned int>();
     wp_init_slabs(st, n, slab, Uri, Urv, Ulen, ctrl);
@@ -671,7 +690,8 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     if (p - 1 >= kWpSel || force_big) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
     const size_t slab = (size_t)n * p;
     const bool small_pieces = p <= 32;
-    int workers = device_cu_count() * (small_pieces ? 20 : 14);
+    static const int waves_env = getenv("ILUPP_ILUT_WAVES") ? atoi(getenv("ILUPP_ILUT_WAVES")) : 0;     // (experiments: waves per CU)
+    int workers = device_cu_count() * (waves_env > 0 ? waves_env : (small_pieces ? 20 : 14));
     if (workers > n) workers = n;
     WpArrays g = {nullptr, kWpHashG - 1, nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
     int32_t h[8];
@@ -688,12 +708,15 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         ILUPP_HIP(b_kseq.alloc(sizeof(unsigned short) * (size_t)workers * g.capK));
         ILUPP_HIP(b_scr.alloc(sizeof(int) * (size_t)workers * g.capU));
         g.uh = b_uh.as<unsigned short>(); g.ucol = b_ucol.as<int>(); g.uval = b_uval.as<double>();
+        ILUPP_HIP(hipMemsetAsync(g.uh, 0, sizeof(unsigned short) * (size_t)workers * kWpHashG, st));
         g.lcol = b_lcol.as<int>(); g.lval = b_lval.as<double>(); g.lseq = b_lseq.as<unsigned short>();
         g.kcol = b_kcol.as<int>(); g.kval = b_kval.as<double>(); g.kseq = b_kseq.as<unsigned short>();
         int *gscratch = b_scr.as<int>();
         wp_init_slabs(st, n, slab, Uri, Urv, Ulen, ctrl);
 #ifdef ILUT_PROFILE
-        PoolBlock pb_lvl, pb_par, pb_fin, pb_start, pb_wait;
+        PoolBlock pb_lvl, pb_par, pb_fin, pb_start, pb_wait, pb_lpar;
+        ILUPP_HIP(pb_lpar.alloc(sizeof(int) * (size_t)n));
+        { int *f = pb_lpar.as<int>(); ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_lparent), &f, sizeof(f))); }
         ILUPP_HIP(pb_lvl.alloc(sizeof(int) * (size_t)n)); ILUPP_HIP(pb_par.alloc(sizeof(int) * (size_t)n));
         ILUPP_HIP(pb_fin.alloc(sizeof(long long) * (size_t)n)); ILUPP_HIP(pb_start.alloc(sizeof(long long) * (size_t)n)); ILUPP_HIP(pb_wait.alloc(sizeof(long long) * (size_t)n));
         ILUPP_HIP(hipMemsetAsync(pb_lvl.p, 0, sizeof(int) * (size_t)n, st));
@@ -710,7 +733,14 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         ILUPP_HIP(hipEventCreate(&ev.a));
         ILUPP_HIP(hipEventCreate(&ev.b));
         ILUPP_HIP(hipEventRecord(ev.a, st));
-        if (small_pieces)
+        static const int cap_env = getenv("ILUPP_ILUT_CAP") ? atoi(getenv("ILUPP_ILUT_CAP")) : 0;           // (experiments: entries per LDS piece)
+        if (cap_env == 512)
+            hipLaunchKernelGGL((k_ilut_rows_wp<512, 2048>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+        else if (cap_env == 1024)
+            hipLaunchKernelGGL((k_ilut_rows_wp<1024, 4096>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+        else if (small_pieces && cap_env != 256)
             hipLaunchKernelGGL((k_ilut_rows_wp<128, 512>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
                                Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
         else
@@ -771,6 +801,28 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
                             "median %.1f us, mean %.1f us, p90 %.1f us; its rows waited %.3f ms in all\n", last, links, chain_own * tick * 1e3, 100.0 * chain_own * tick * 1e3 / kms,
                     link_us.empty() ? 0.0 : link_us[link_us.size() / 2], links ? chain_own * tick * 1e6 / links : 0.0, link_us.empty() ? 0.0 : link_us[link_us.size() * 9 / 10],
                     chain_wait * tick * 1e3);
+            {
+                // the chain of DEEPEST dependencies back from a row of the last level: one row per level
+                std::vector<int> lpar((size_t)n);
+                ILUPP_HIP(hipMemcpy(lpar.data(), pb_lpar.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+                int deepest = 0;
+                for (int r = 0; r < n; ++r) if (lvl[r] > lvl[deepest] || (lvl[r] == lvl[deepest] && fin[r] > fin[deepest])) deepest = r;
+                std::vector<double> gap, own, wt;
+                int cnt = 0, root = deepest;
+                for (int r = deepest; r >= 0 && lpar[r] >= 0; r = lpar[r]) {
+                    const int q = lpar[r];
+                    gap.push_back((double)(fin[r] - fin[q]) * tick * 1e6);
+                    own.push_back((double)(fin[r] - sta[r]) * tick * 1e6);
+                    wt.push_back((double)wai[r] * tick * 1e6);
+                    ++cnt; root = q;
+                }
+                auto mean = [](const std::vector<double> &v) { double z = 0; for (double x : v) z += x; return v.empty() ? 0.0 : z / v.size(); };
+                std::vector<double> g2 = gap; std::sort(g2.begin(), g2.end());
+                fprintf(stderr, "[ilut profile]   chain of deepest dependencies: row %d (level %d) back to row %d: %d links; from the first row's publication to the last's %.3f ms = %.1f %% of the kernel\n",
+                        deepest, lvl[deepest], root, cnt, (double)(fin[deepest] - fin[root]) * tick * 1e3, 100.0 * (double)(fin[deepest] - fin[root]) * tick * 1e3 / kms);
+                fprintf(stderr, "[ilut profile]     a link (the deepest dependency published -> this row published): mean %.1f us, median %.1f us, p90 %.1f us; the rows of the chain are %.1f us in their waves, %.1f us of that waiting\n",
+                        mean(gap), g2.empty() ? 0.0 : g2[g2.size() / 2], g2.empty() ? 0.0 : g2[g2.size() * 9 / 10], mean(own), mean(wt));
+            }
             fprintf(stderr, "[ilut profile]   throughput bound: %.2f wave-s of non-waiting work / %d waves = %.1f ms; latency bound: the chain above\n",
                     (busy - waited) * tick, workers, (busy - waited) * tick / workers * 1e3);
         }
