@@ -46,6 +46,23 @@ void ilu0_unit_diagonal(hipStream_t st, DevMat *L)
 // numeric: persistent dataflow kernel
 // ---------------------------------------------------------------------------------------------
 static constexpr unsigned kSpinLimit = 1u << 22;
+// The limit counts idle trips of a wave during which NO wave of the grid made progress: a wave that progresses bumps ctrl[2] at most once
+// per millisecond, a wave that idles looks at it every 8 192 trips (a long chain elsewhere is not a hang).
+__device__ __forceinline__ void ilu0_heartbeat(int32_t *ctrl, long long &beat_at)
+{
+    const long long now = wall_clock64();
+    if (now - beat_at > 100000) {
+        beat_at = now;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&ctrl[2], 1);
+    }
+}
+__device__ __forceinline__ bool ilu0_progress_elsewhere(const int32_t *ctrl, int &beat_seen)
+{
+    const int f = ld_agent_i32(&ctrl[2]);
+    const bool moved = f != beat_seen;
+    beat_seen = f;
+    return moved;
+}
 
 // ctrl[0] = workgroup ticket, ctrl[1] = error word
 template <int MAXLEN, bool GLOBAL_W>
@@ -71,6 +88,8 @@ k_ilu0_numeric(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aid
     bool need_init = true;
     int a0 = 0, len = 0, cl = 0, p = 0;
     unsigned spins = 0;
+    long long beat_at = 0;
+    int beat_seen = 0;
 
     for (;;) {
         if (!__any(active)) break;
@@ -125,9 +144,11 @@ k_ilu0_numeric(const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aid
         }
         if (__any(progressed)) {
             spins = 0;
+            ilu0_heartbeat(ctrl, beat_at);
         } else {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSpinLimit) {
+            if ((++spins & 8191u) == 0u && ilu0_progress_elsewhere(ctrl, beat_seen)) spins = 0;
+            if (spins > kSpinLimit) {
                 if ((tid & 63) == 0) atomicExch(&ctrl[1], 1);
                 break;
             }
@@ -181,6 +202,8 @@ k_ilu0_numeric_prog(const double *__restrict__ Aval, const int32_t *__restrict__
     bool need_init = true;
     int len = 0, cl = 0, e = 0, pe = 0;
     unsigned spins = 0;
+    long long beat_at = 0;
+    int beat_seen = 0;
 
 #define W(q) w[(q) * kThreads + tid]
     for (;;) {
@@ -276,9 +299,11 @@ k_ilu0_numeric_prog(const double *__restrict__ Aval, const int32_t *__restrict__
         }
         if (__any(progressed)) {
             spins = 0;
+            ilu0_heartbeat(ctrl, beat_at);
         } else {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) {
+            if ((++spins & 8191u) == 0u && ilu0_progress_elsewhere(ctrl, beat_seen)) spins = 0;
+            if (spins > kSpinLimit) {
                 if ((tid & 63) == 0) atomicExch(&ctrl[1], 1);
                 break;
             }
@@ -507,6 +532,8 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
     for (int k = 0; k < 8; ++k) pw[k] = 0;
     int len = 0, cl = 0, nmt = 0;
     unsigned spins = 0;
+    long long beat_at = 0;
+    int beat_seen = 0;
 
     for (;;) {
         if (!__any(active)) break;
@@ -674,9 +701,11 @@ k_ilu0_numeric_lc(const double *__restrict__ Aval, long nnzA, const int32_t *__r
         }
         if (__any(progressed)) {
             spins = 0;
+            ilu0_heartbeat(ctrl, beat_at);
         } else {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) {
+            if ((++spins & 8191u) == 0u && ilu0_progress_elsewhere(ctrl, beat_seen)) spins = 0;
+            if (spins > kSpinLimit) {
                 if ((tid & 63) == 0) atomicExch(&ctrl[1], 1);
                 fin[tid] = 1;
                 break;

@@ -266,6 +266,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     (void)prof;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nL = 0, nU = 0, nK = 0, seq = 0;
+    int seen_done = -1;
     double wdiag = 0.0;
 #ifdef ILUT_PROFILE
     int prof_lvl = 0, prof_parent = -1, prof_lparent = -1;
@@ -354,7 +355,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const size_t ub = (size_t)k * p;
         int ul, c0;
         unsigned long long v0;
-        unsigned spins = 0;
+        unsigned spins = 0, idle = 0;
+        (void)spins;
         for (;;) {
             ul = ld_agent_i32(&Ulen[k]);
             const bool mine = lane < p;
@@ -362,7 +364,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             v0 = mine ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
             const bool bad = ul <= 0 || (lane < ul && (c0 < 0 || v0 == kSentinel));
             if (__ballot(bad) == 0ull) break;
-            if (++spins > ILUT_SPIN) return 2;
+            ++spins;
+            // the limit counts polls during which NO row was finished anywhere (ctrl[7]): a long chain elsewhere is not a hang
+            if (++idle > ILUT_SPIN) return 2;
+            if ((idle & 4095u) == 0u) { const int f = ld_agent_i32(&ctrl[7]); if (f != seen_done) { seen_done = f; idle = 0; } }
             __builtin_amdgcn_s_sleep(1);
         }
 #ifdef ILUT_PROFILE
@@ -394,6 +399,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                     const bool bad = j < ul && (c < 0 || vb == kSentinel);
                     if (__ballot(bad) == 0ull) break;
                     if (++sp2 > ILUT_SPIN) return 2;
+                    if ((sp2 & 4095u) == 0u) { const int f = ld_agent_i32(&ctrl[7]); if (f != seen_done) { seen_done = f; sp2 = 0; } }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
@@ -493,6 +499,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         __threadfence();
 #endif
         st_agent_i32(&Ulen[i], nUk + 1);
+        atomicAdd(&ctrl[7], 1);                                                  // rows finished (what a waiting wave watches)
     }
     A::sync();
     if (G) {
@@ -510,7 +517,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     return 0;
 }
 
-// ctrl: [0] next row, [1] error (1 timeout, 3 capacity -> the host runs the largest capacity class), [2] smallest row with a zero pivot
+// ctrl: [0] next row, [1] error (1 timeout, 3 capacity -> the host runs the largest capacity class), [2] smallest row with a zero pivot,
+// [3..6] statistics, [7] rows finished
 template <int kWpCapU, int kWpHashLds>
 __global__ void __launch_bounds__(64)
 k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
