@@ -163,7 +163,7 @@ class ILUppPreconditioner(_HipPreconditioner):
         ms = [_borrow(A) for A in matrices]
         if any(m.is_csr != ms[0].is_csr for m in ms):
             raise TypeError("a batch holds matrices of one format")
-        natives = _native.MultilevelILUCDPPreconditioner_batch([(m.data, m.indices, m.indptr) for m in ms], ms[0].is_csr, params)
+        natives = _backend.MultilevelILUCDPPreconditioner_batch([(m.data, m.indices, m.indptr) for m in ms], ms[0].is_csr, params)
         out = []
         for A, pr in zip(matrices, natives):
             P = cls.__new__(cls)

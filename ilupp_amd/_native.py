@@ -490,10 +490,14 @@ def MultilevelILUCDPPreconditioner_batch(matrices, is_csr, param):
     status = (ctypes.c_int32 * cnt)()
     rc = lib().ilupp_hip_ml_create_batch(cnt, D, I, P, N, 1 if is_csr else 0, ctypes.byref(p), out, status)
     if rc:
+        first = next((k for k in range(cnt) if status[k] != 0), -1)
         for k in range(cnt):
             if out[k]:
                 lib().ilupp_hip_ml_destroy(out[k])
-        _raise(rc)
+        msg = lib().ilupp_hip_last_error().decode() + " (matrix %d of the batch, status %d)" % (first, status[first] if first >= 0 else rc)
+        if rc == -8:
+            raise NotImplementedError(msg)
+        raise RuntimeError(msg)
     return [MultilevelPreconditioner(_VP(out[k]), ns[k]) for k in range(cnt)]
 
 

@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/ilupp_hip.h"
 
@@ -315,6 +316,42 @@ PYBIND11_MODULE(_ilupp_hip, m)
         .def("print_info", [](const Multilevel &f) {
             py::print("A multilevel incomplete LU factorisation:", ilupp_hip_ml_levels(f.h), "levels,", ilupp_hip_ml_total_nnz(f.h), "entries");
         });
+
+    // many matrices side by side (include/ilupp_hip.h: ilupp_hip_ml_create_batch): the objects the constructor gives one at a time.  On an
+    // error every object already built is destroyed; the message names the first failing matrix and its status.
+    m.def("MultilevelILUCDPPreconditioner_batch", [](py::list matrices, bool is_csr, py::object param) {
+        const ilupp_ml_params p = block_of(param);
+        const int32_t cnt = (int32_t)matrices.size();
+        std::vector<Csr> as;
+        std::vector<const double *> D; std::vector<const int32_t *> I, P; std::vector<int32_t> N;
+        for (py::handle h : matrices) {
+            py::tuple t = py::reinterpret_borrow<py::tuple>(h);
+            as.push_back(borrow(py::reinterpret_borrow<py::buffer>(t[0]), py::reinterpret_borrow<py::buffer>(t[1]), py::reinterpret_borrow<py::buffer>(t[2]), is_csr));
+        }
+        for (const Csr &a : as) { D.push_back(a.val); I.push_back(a.idx); P.push_back(a.ptr); N.push_back(a.n); }
+        std::vector<ilupp_ml *> out((size_t)cnt, nullptr);
+        std::vector<int32_t> status((size_t)cnt, 0);
+        int rc = ILUPP_OK;
+        if (cnt > 0) {
+            py::gil_scoped_release release;
+            rc = ilupp_hip_ml_create_batch(cnt, D.data(), I.data(), P.data(), N.data(), is_csr ? 1 : 0, &p, out.data(), status.data());
+        }
+        if (rc != ILUPP_OK) {
+            const std::string msg = ilupp_hip_last_error();
+            int first = -1;
+            for (int32_t k = 0; k < cnt; ++k) { if (status[(size_t)k] != 0 && first < 0) first = k; if (out[(size_t)k]) ilupp_hip_ml_destroy(out[(size_t)k]); }
+            const std::string full = msg + " (matrix " + std::to_string(first) + " of the batch, status " + std::to_string(first >= 0 ? status[(size_t)first] : rc) + ")";
+            if (rc == ILUPP_ERR_UNSUPPORTED) { PyErr_SetString(PyExc_NotImplementedError, full.c_str()); throw py::error_already_set(); }
+            throw std::runtime_error(full);
+        }
+        py::list res;
+        for (int32_t k = 0; k < cnt; ++k) {
+            Multilevel f;
+            f.h = out[(size_t)k]; f.n = N[(size_t)k];
+            res.append(py::cast(std::move(f)));
+        }
+        return res;
+    });
 
     // binding.cpp:200-230, bound at :281
     m.def("solve", [](py::buffer data, py::buffer indices, py::buffer indptr, bool is_csr, py::buffer rhs, double rtol, double atol, int32_t max_iter,

@@ -556,6 +556,18 @@ try:
     raise SystemExit("no size check")
 except RuntimeError as e:
     assert "wrong size" in str(e)
+# a batch through the compiled shim: the objects the constructor gives one at a time (its own native class, not the ctypes one)
+mats = [sp.csr_matrix(matgen.random_dd(3000 + 100 * k, 6, 25.0, 500 + k), shape=(3000 + 100 * k, 3000 + 100 * k)) for k in range(3)]
+prm = ilupp.iluplusplus_precond_parameter()
+prm.default_configuration(10)
+Ps = ilupp.ILUppPreconditioner.batch(mats, params=prm)
+for M, Pb in zip(mats, Ps):
+    P1 = ilupp.ILUppPreconditioner(M, params=prm)
+    assert type(Pb.pr) is type(P1.pr) and type(Pb.pr).__module__.endswith("_ilupp_hip"), type(Pb.pr)
+    v = np.random.default_rng(3).random(M.shape[0])
+    a1 = v.copy(); P1.pr.apply(a1)
+    a2 = v.copy(); Pb.pr.apply(a2)
+    assert np.array_equal(a1, a2) and Pb.pr.total_nnz == P1.pr.total_nnz
 print("pybind ok")
 '''
 
