@@ -1297,13 +1297,27 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
         const auto w0 = std::chrono::steady_clock::now();
         // L's pattern is the grid's: blocks and patches of the sweeps' schedule from the dimensions, no pass over the pattern (env
         // ILUPP_IG_SCHED=general: the general pass; =verify: both, compared)
+        static const char *sched_mode = getenv("ILUPP_IG_SCHED");
+        const bool sched_verify = sched_mode && !strcmp(sched_mode, "verify");
+        bool sched_done = false;
+        // (nothing of the closed-form schedule reads L's arrays: it is queued ahead of the kernel that writes them)
+        auto schedule_early = [&](hipStream_t q) {
+            if (sched_mode) return;
+            if (!grid_llt_schedule(q, n, gd, p->max_lanes, &p->sL)) return;
+            p->degenerate = false;
+            p->max_row_len = 1 + (gd.nx > 1) + (gd.ny > 1) + (gd.nz > 1);
+            build_slot_tables(q, &p->sL, false);
+            p->compact = schedule_is_compact(p->sL);
+            if (p->compact) make_desc_llt_grid(q, p->Lc, p->sL, gd, &p->dL);
+            sched_done = true;
+        };
         auto schedule_on = [&](hipStream_t q) {
-            static const char *sched_mode = getenv("ILUPP_IG_SCHED");
+            if (sched_done) return;
             const bool want_general = sched_mode && !strcmp(sched_mode, "general");
             if (!want_general && grid_llt_schedule(q, n, gd, p->max_lanes, &p->sL)) {
                 p->degenerate = false;                              // (every column has its diagonal)
                 p->max_row_len = 1 + (gd.nx > 1) + (gd.ny > 1) + (gd.nz > 1);
-                if (sched_mode && !strcmp(sched_mode, "verify")) {
+                if (sched_verify) {
                     Schedule ref;
                     int32_t m1 = 0;
                     count_cuts_and_schedule(q, n, p->Lc.ptr, p->Lc.idx, p->max_lanes, nullptr, &ref, &m1);
@@ -1322,12 +1336,29 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
                 }
                 build_slot_tables(q, &p->sL, false);
                 p->compact = schedule_is_compact(p->sL);
-                if (p->compact) make_desc(q, p->Lc, p->sL, &p->dL);
+                if (p->compact) {
+                    make_desc_llt_grid(q, p->Lc, p->sL, gd, &p->dL);
+                    if (sched_verify) {
+                        // ... and the descriptors: the general kernel's, word for word (the export marks too)
+                        std::vector<int32_t> d1((size_t)p->Lc.nnz), d2((size_t)p->Lc.nnz), e1((size_t)p->sL.nslots), e2((size_t)p->sL.nslots);
+                        ILUPP_HIP(hipMemcpyAsync(d1.data(), p->dL, sizeof(int32_t) * d1.size(), hipMemcpyDeviceToHost, q));
+                        ILUPP_HIP(hipMemcpyAsync(e1.data(), p->sL.exported, sizeof(int32_t) * e1.size(), hipMemcpyDeviceToHost, q));
+                        ILUPP_HIP(hipStreamSynchronize(q));
+                        ILUPP_HIP(hipMemsetAsync(p->sL.exported, 0, sizeof(int32_t) * e1.size(), q));
+                        int32_t *ref = nullptr;
+                        make_desc(q, p->Lc, p->sL, &ref, false);
+                        ILUPP_HIP(hipMemcpyAsync(d2.data(), ref, sizeof(int32_t) * d2.size(), hipMemcpyDeviceToHost, q));
+                        ILUPP_HIP(hipMemcpyAsync(e2.data(), p->sL.exported, sizeof(int32_t) * e2.size(), hipMemcpyDeviceToHost, q));
+                        ILUPP_HIP(hipStreamSynchronize(q));
+                        (void)pool_free(ref);
+                        if (d1 != d2 || e1 != e2) { set_error("ICholT grid path: the descriptors from the dimensions differ from the general kernel's"); throw HipError{hipErrorUnknown, "ILUPP_IG_SCHED=verify", __FILE__, __LINE__}; }
+                    }
+                }
             } else {
                 sweep_schedule(q);
             }
         };
-        if (icholt_grid_launch(st, p->side, A, gd, p->ctrl, &p->Lc, &job, schedule_on)) {
+        if (icholt_grid_launch(st, p->side, A, gd, p->ctrl, &p->Lc, &job, schedule_early, schedule_on)) {
             hipStream_t q = p->side ? p->side : st;
             const auto w1 = std::chrono::steady_clock::now();
             ILUPP_HIP(stream_sync(q));

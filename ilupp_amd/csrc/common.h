@@ -319,6 +319,7 @@ void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g);
 void grid_shape_forget(int32_t n, int64_t nnz);
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
 bool grid_llt_schedule(hipStream_t st, int32_t n, const GridDims &g, int max_lanes, Schedule *bwd);
+void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc);
 void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
                     int32_t *max_row_len, int max_wgs);
 // slot tables, lane templates and the link between the two schedules of a box grid, from its dimensions (one launch; the schedules'
@@ -380,7 +381,7 @@ void d2h_cancel_all();
 void choose_tiling(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx, Schedule *sch, bool fwd, int max_wgs);
 void choose_tiling_pair(hipStream_t st, const int32_t *ptr, const int32_t *idx, Schedule *fwd, Schedule *bwd, int max_wgs);
 void build_slot_tables(hipStream_t st, Schedule *sch, bool fwd, bool fill = true);      // fill = false: the arrays only (grid.hip fills them)
-void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc);
+void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc, bool fill_import_table = true);
 bool build_ilu0_program(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, Ilu0Program *P);
 bool build_ilu0_program_f3(hipStream_t st, const DevMat &A, const DevMat &U, const Schedule &sch, int32_t **prog_out);
 int ilu0_numeric_lc(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U, const Schedule &fwd, const int32_t *prog_f3,
@@ -414,7 +415,7 @@ struct IcholtGridJob {
     ~IcholtGridJob();
 };
 bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job,
-                        const std::function<void(hipStream_t)> &after_pattern);
+                        const std::function<void(hipStream_t)> &pattern_free, const std::function<void(hipStream_t)> &after_pattern);
 bool icholt_grid_finish(hipStream_t st, IcholtGridJob *job, float *kernel_ms);
 int icholt_factor_df(hipStream_t st, const DevMat &Atri, int32_t add_fill_in, double threshold, DevMat *L, float *kernel_ms);
 // iluc_df.hip: Crout ILU on the major-order view; L by columns (arrays = CSR of L^T, 1 first), U by rows (pivot first)

@@ -57,17 +57,6 @@ struct IgArgs {
     int32_t *ctrl;                    // [0] ticket, [1] time-out / error, [2] a column that does not keep A's pattern
 };
 
-// entries of L before column r = (x, y, z): four per column minus the neighbours beyond the box
-__device__ __forceinline__ long long ig_col_start(const int x, const int y, const int z, const GridDims &g)
-{
-    const long long nx = g.nx, ny = g.ny;
-    const long long r = x + nx * (y + ny * (long long)z);
-    long long miss = r / nx;                                              // ends of the lines before
-    miss += (long long)z * nx + (y == g.ny - 1 ? x : 0);                  // last lines of the planes before, of this plane
-    miss += z == g.nz - 1 ? r - (long long)z * nx * ny : 0;               // the last plane
-    return 4 * r - miss;
-}
-
 __global__ void __launch_bounds__(256)
 k_icholt_grid_pattern(const int32_t n, const GridDims g, int32_t *__restrict__ ptr, int32_t *__restrict__ idx, const long long nnzL)
 {
@@ -508,11 +497,11 @@ IcholtGridJob::~IcholtGridJob()
     if (pattern_done) (void)hipEventDestroy(pattern_done);
 }
 
-// Queues everything on st and returns: L's index arrays (closed form; `pattern_done` is recorded behind them -- the caller's sweep
-// analysis needs nothing else and can run beside the kernel), the proof of the grid (k_grid_check), the exchange buffer's sentinels,
+// Queues everything on st and returns: the caller's work that needs nothing of L (`pattern_free`: the sweeps' schedule from the grid's
+// dimensions), L's index arrays (closed form), the caller's work on them (`after_pattern`: the general schedule pass), the proof of the grid (k_grid_check), the exchange buffer's sentinels,
 // the kernel, the read-back of its verdict.  *L owns the arrays at once.  false: a grid outside the kernel's limits, nothing was queued.
 bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const GridDims &g, int32_t *ctrl, DevMat *L, IcholtGridJob *job,
-                        const std::function<void(hipStream_t)> &after_pattern)
+                        const std::function<void(hipStream_t)> &pattern_free, const std::function<void(hipStream_t)> &after_pattern)
 {
     static const bool off = getenv("ILUPP_NO_ICHOLT_GRID") != nullptr;
     if (off) return false;
@@ -543,6 +532,7 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
     // streams beside it costs several times its own duration (the patches of the kernel hold every CU; measured: the schedule's
     // 0.15 ms became 0.9 ms, the proof's 0.12 ms 0.5 ms, and the kernel 0.2 ms longer).
     hipStream_t q = side ? side : st;
+    if (pattern_free) pattern_free(q);
     hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, q, A.n, g, L->ptr, L->idx, (long long)nnzL);
     if (after_pattern) after_pattern(q);
     ILUPP_HIP(hipEventRecord(job->pattern_done, q));

@@ -17,7 +17,7 @@
 
 #include <hipcub/hipcub.hpp>
 
-#include "common.h"
+#include "st_common.h"
 
 namespace ilupp {
 
@@ -260,14 +260,95 @@ __global__ void k_make_desc(int32_t n, const int32_t *__restrict__ ptr, const in
     }
 }
 
-void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc)
+void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **desc, bool fill_import_table)
 {
     ILUPP_HIP(pool_malloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
-    if (sch.gtab)
+    // (fill_import_table = false: the table stands as somebody made it -- which producer gets which cell depends on the order of the
+    // insertions, so descriptors are only comparable on ONE table)
+    if (sch.gtab && fill_import_table)
         hipLaunchKernelGGL(k_ghost_table, dim3((unsigned)(sch.nslots / kThreads)), dim3(kThreads), 0, st, M.ptr, M.idx,
                            sch.B, sch.nb, sch.start, sch.blk2slot, sch.fwd ? 1 : 0, sch.sfirst, sch.scount, sch.gtab);
     hipLaunchKernelGGL(k_make_desc, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, st, M.n, M.ptr, M.idx,
                        sch.B, sch.nb, sch.fwd ? 1 : 0, sch.start, sch.blk2slot, *desc, sch.exported, sch.gtab);
+}
+
+// The descriptors of L^T of an LL^T object on a box grid (icholt_grid.hip: columns of four entries -- diagonal, +1, +nx, +nx ny --, one block
+// per x-line, backward schedule): what k_make_desc finds by ptr -> idx -> block_of -> start for every entry follows from (x, y, z).
+__global__ void __launch_bounds__(256)
+k_make_desc_llt_grid(const int32_t n, const GridDims g, const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc,
+                     int32_t *__restrict__ exported, const int32_t *__restrict__ gtab)
+{
+    const unsigned unx = (unsigned)g.nx, uny = (unsigned)g.ny;
+    for (long long rr = (long long)blockIdx.x * 256 + threadIdx.x; rr < n; rr += (long long)gridDim.x * 256) {
+        const unsigned r = (unsigned)rr;
+        const unsigned l = r / unx, x = r - l * unx;
+        const unsigned z = l / uny, y = l - z * uny;
+        long long q = ig_col_start((int)x, (int)y, (int)z, g);
+        const int my = blk2slot[l];
+        const int mywg = my >> 8;
+        desc[q++] = -1;
+        // (backward schedule: a row's place in its line counts from the line's end)
+        if ((int)x < g.nx - 1) desc[q++] = (my << 15) | (g.nx - 2 - (int)x);
+        const int kloc = g.nx - 1 - (int)x;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const bool has = d == 0 ? (int)y < g.ny - 1 : (int)z < g.nz - 1;
+            if (!has) continue;
+            int oslot = blk2slot[l + (d == 0 ? 1u : uny)];
+            if ((oslot >> 8) != mywg) {
+                exported[oslot] = 1;
+                if (gtab && kloc < 0x7fff) {
+                    const int32_t *tab = gtab + (size_t)mywg * kGhosts;
+                    unsigned h = ((unsigned)oslot * 0x9E3779B1u) >> 26;
+                    for (int probe = 0; probe < kGhosts; ++probe, h = (h + 1) & (kGhosts - 1)) {
+                        const int cur = tab[h];
+                        if (cur == oslot) { oslot = kGhostBase + (int)h; break; }
+                        if (cur == -1) break;
+                    }
+                }
+            }
+            desc[q++] = (oslot << 15) | kloc;
+        }
+    }
+}
+
+// ... and the import table of such an object: a lane's foreign producers are the lines y + 1 and z + 1 of its own line, where those lie
+// in another workgroup (k_ghost_table finds the same set on three sampled rows of every lane; which cell a producer gets depends on the
+// order of the insertions there as here)
+__global__ void __launch_bounds__(kThreads)
+k_ghost_table_llt_grid(const GridDims g, const int32_t *__restrict__ slot2blk, const int32_t *__restrict__ blk2slot, int32_t *__restrict__ gtab)
+{
+    __shared__ int tab[kGhosts];
+    const int wg = blockIdx.x, t = threadIdx.x;
+    if (t < kGhosts) tab[t] = -1;
+    __syncthreads();
+    const int l = slot2blk[wg * kThreads + t];
+    if (l >= 0 && g.nx > 1) {
+        const int z = l / g.ny, y = l - z * g.ny;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const bool has = d == 0 ? y < g.ny - 1 : z < g.nz - 1;
+            if (!has) continue;
+            const int oslot = blk2slot[l + (d == 0 ? 1 : g.ny)];
+            if ((oslot >> 8) == wg) continue;
+            unsigned h = ((unsigned)oslot * 0x9E3779B1u) >> 26;
+            for (int probe = 0; probe < kGhosts; ++probe, h = (h + 1) & (kGhosts - 1)) {
+                const int cur = atomicCAS(&tab[h], -1, oslot);
+                if (cur == -1 || cur == oslot) break;
+            }
+        }
+    }
+    __syncthreads();
+    if (t < kGhosts) gtab[(size_t)wg * kGhosts + t] = tab[t];
+}
+
+void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc)
+{
+    ILUPP_HIP(pool_malloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
+    if (sch.gtab)
+        hipLaunchKernelGGL(k_ghost_table_llt_grid, dim3((unsigned)(sch.nslots / kThreads)), dim3(kThreads), 0, st, g, sch.slot2blk, sch.blk2slot, sch.gtab);
+    hipLaunchKernelGGL(k_make_desc_llt_grid, dim3(2048), dim3(256), 0, st, M.n, g, sch.blk2slot, *desc, sch.exported, sch.gtab);
+    ILUPP_HIP(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------------------

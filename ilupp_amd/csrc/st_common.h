@@ -62,6 +62,17 @@ __device__ __forceinline__ long long grid_row_start(const int x, const int y, co
     return 7 * r - miss;
 }
 
+// entries of L before column r = (x, y, z): four per column minus the neighbours beyond the box
+__device__ __forceinline__ long long ig_col_start(const int x, const int y, const int z, const GridDims &g)
+{
+    const long long nx = g.nx, ny = g.ny;
+    const long long r = x + nx * (y + ny * (long long)z);
+    long long miss = r / nx;                                              // ends of the lines before
+    miss += (long long)z * nx + (y == g.ny - 1 ? x : 0);                  // last lines of the planes before, of this plane
+    miss += z == g.nz - 1 ? r - (long long)z * nx * ny : 0;               // the last plane
+    return 4 * r - miss;
+}
+
 #endif
 
 // ---- the wave-exchange kernels (st_wave.hip) -------------------------------------------------------------------------
