@@ -23,7 +23,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")            # (template arguments kept: the L and the U sweep are two kernels)
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")   # (template arguments kept: the L and the U sweep are two kernels)
         key = (k, r["Dispatch_Id"])
         disp[key] += float(r["Counter_Value"])
         name[key] = k
