@@ -442,6 +442,20 @@ def test_bench_single_gpu_line():
     assert out["cpu_baseline"]["kind"] in ("reference", "port") and out["cpu_baseline"]["apply_paths_agree"]
 
 
+def test_bench_extras_of_every_kind_of_object():
+    """the default run's extra configs build three kinds of objects (single-level ones with a path word, multilevel ones without, the
+    speculative ICholT path): one of each through bench.py, with their roofline and path fields"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "48", "--no-extra", "--no-cpu",
+                        "--config", "C4", "--config", "C5", "--config", "ILUC"], capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout + r.stderr
+    ex = json.loads(line[-1])["extra"]
+    assert ex["C4"]["path"] == "icholt:grid-static" and ex["C4"]["roofline"]["kernel"] == "k_icholt_grid" and ex["C4"]["construct_s"] < 0.02
+    assert ex["C5"]["path"] is None and ex["C5"]["levels"] >= 1 and ex["C5"]["roofline"]["kernel"] == "k_piluc_df"
+    assert ex["ILUC"]["path"] == "iluc" and ex["ILUC"]["roofline"]["frac"] > 0
+
+
 def test_spmv_device_bit_exact():
     """the CSR product on device tensors = scipy's csr_matvec bit for bit (one lane per row, stored order, from 0;
     reference: sparse_implementation.h:2733-2760), short rows and long ones"""
