@@ -45,7 +45,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 # kernel that dominates the numeric factorisation, per construction path (ilupp_hip_path)
-FACTOR_KERNEL = {"ilu0:static-direct": "k_ilu0_sd", "ilu0:static-level-major": "k_ilu0_st", "ilu0:level-order": "k_ilu0_lvl", "ilu0:level-major": "k_ilu0_lm",
+FACTOR_KERNEL = {"ilu0:static-direct": "k_ilu0_sd", "ilu0:static-level-major": "k_ilu0_st", "ilu0:level-order": "k_ilu0_lvl",
                  "ilu0:csr-program": "k_ilu0_numeric_lc", "ilu0:csr": "k_ilu0_numeric"}
 
 

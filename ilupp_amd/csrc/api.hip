@@ -338,8 +338,9 @@ static int ilu0_numeric_any(ilupp_precond *p, const DevMat &A, bool have_prog, f
     p->ctrl_armed = false; p->pkL.xch_armed = p->pkU.xch_armed = false;      // (the factor kernels use the control words and the forward exchange)
     int rc = ILUPP_ERR_UNSUPPORTED;
     if (p->flm.built) {
-        rc = p->flm.stat ? ilu0_numeric_st(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5])
-                         : ilu0_numeric_lm(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5]);
+        // (flm.built means the static form: round 1's record-decoding level-major FACTOR kernel, which only matrices the static form takes
+        // ever reached -- and then only under ILUPP_NO_STATIC --, was removed in round 5)
+        rc = ilu0_numeric_st(st, A, p->sA, &p->pkL, &p->pkU, &p->flm, p->ctrl, kms, p->ev[4], p->ev[5]);
         p->csr_vals = false;
         return rc;
     }
@@ -435,7 +436,6 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     }
     p->grid_path = grid;
     bool have_prog = false;
-    lm = lm || (p->compact && lm_analyse_ilu0(st, A, p->sA, p->sU, &p->pkL, &p->pkU, &p->flm));
     // CSR patterns of L and U (ILU0.hpp:85-98).  The level-major kernels never read them (they are for factors() and the
     // generic transposed solves).  (Running this pass on a side stream next to the factor kernel cost the kernel more --
     // 2.0 -> 2.5 ms -- than the pass takes, 0.28 ms.)  Static form: nothing here; row pointers, column indices and values all
@@ -555,9 +555,6 @@ void ensure_csr_values(ilupp_precond *p)
         st_unpack(p->stream, p->Lc, p->sA, p->pkL);
         st_unpack(p->stream, p->Uc, p->sU, p->pkU);
         wx_convert_records(p->stream, &p->pkL, &p->pkU, fmt);
-    } else {
-        lm_unpack(p->stream, p->Lc, p->sA, p->pkL);
-        lm_unpack(p->stream, p->Uc, p->sU, p->pkU);
     }
     ILUPP_HIP(stream_sync(p->stream));
     p->csr_vals = true;
@@ -1480,7 +1477,7 @@ const char *ilupp_hip_path(const ilupp_precond *p)
 {
     if (!p) return "";
     if (p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU) {
-        if (p->flm.built) return p->flm.stat ? (p->flm.direct ? "ilu0:static-direct" : "ilu0:static-level-major") : "ilu0:level-major";
+        if (p->flm.built) return p->flm.direct ? "ilu0:static-direct" : "ilu0:static-level-major";
         if (p->fperm) return "ilu0:level-order";
         return p->prog_f3 ? "ilu0:csr-program" : "ilu0:csr";
     }

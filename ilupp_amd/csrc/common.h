@@ -545,13 +545,6 @@ int sptrsv_lm(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               const int32_t *ysrc = nullptr);
 void lm_link_y(hipStream_t st, const Schedule &fwd, PackedSweep *pl, PackedSweep *pu);
 
-// ilu0_lm.hip
-int ilu0_numeric_lm(hipStream_t st, const DevMat &A, const Schedule &fwd, PackedSweep *pl,
-                    PackedSweep *pu, FactorLM *f, int32_t *d_ctrl, float *kernel_ms, hipEvent_t e0, hipEvent_t e1);
-// records_lm.hip
-bool lm_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
-                     PackedSweep *pu, FactorLM *f);
-void lm_unpack(hipStream_t st, const DevMat &M, const Schedule &sch, const PackedSweep &ps);
 // st.hip
 bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const Schedule &bwd, PackedSweep *pl,
                      PackedSweep *pu, FactorLM *f, SideJoin *join = nullptr, const GridDims *grid = nullptr);

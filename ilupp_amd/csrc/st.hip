@@ -40,6 +40,15 @@
 
 namespace ilupp {
 
+void FactorLM::release()
+{
+    if (pkA) (void)pool_free(pkA);
+    if (xbase) (void)pool_free(xbase);
+    if (xch) (void)pool_free(xch);
+    if (xcount) (void)pool_free(xcount);
+    pkA = nullptr; xbase = nullptr; xch = nullptr; xcount = nullptr; built = false; values_packed = false; stat = false; direct = false; wxf = false; spec = false;
+}
+
 // the wave-exchange kernels and the skews they need (st_common.h); ILUPP_NO_WR=1: the schedules and kernels of round 3
 static bool st_wx_on()
 {

@@ -336,7 +336,7 @@ print("refactor ok")
 
 
 @pytest.mark.parametrize("env", [{}, {"ILUPP_NO_DIRECT": "1"}, {"ILUPP_NO_STATIC": "1"}, {"ILUPP_CLASSIC_ANALYSIS": "1"}, {"ILUPP_NO_PACKED": "1"}],
-                         ids=["static_direct", "static_records", "level_major_records", "csr_program_packed_sweeps", "csr_only"])
+                         ids=["static_direct", "static_records", "no_static_form", "csr_program_packed_sweeps", "csr_only"])
 def test_refactor_on_every_generation(env):
     """numeric re-factorisation (same pattern, new values) followed by apply / apply_trans / factors() on every kernel
     generation, incl. an object of which only one sweep has a level-major form (stale packed values)"""
