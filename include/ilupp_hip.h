@@ -17,11 +17,12 @@
  * Threads: the reference has no internal threads and no global state on this path ("Threading /
  * reentrancy"); its Python callers are single-threaded.  Here every object owns one HIP stream and its entry points are
  * serialised by the caller per object; applies of DISTINCT finished objects may run from distinct host threads.  CONSTRUCTIONS
- * (the *_create*, *_refactor* entry points) must not run concurrently with each other in one process: their work arrays come
- * from one process-wide pool of device blocks that is guarded by a mutex but knows nothing of streams -- a block released while
- * the releasing object's stream still uses it is only safe to hand to work queued on that same stream or after that stream has
- * been waited for, which every construction does before it returns.  One process per GPU (bench.py --gpus N, batched.py) is
- * the supported way to build several factorisations at once.
+ * (the *_create*, *_refactor* entry points) may be CALLED from several threads, but the library runs them one at a time: one
+ * process-wide mutex, also across devices -- a process that drives two GPUs gets no overlap of its constructions.  The reason: their
+ * work arrays come from one process-wide pool of device blocks that knows nothing of streams -- a block released while the releasing
+ * object's stream still uses it is only safe to hand to work queued on that same stream or after that stream has been waited for,
+ * which every construction does before it returns.  The ways to build several factorisations at once: ilupp_hip_ml_create_batch (one
+ * call, many matrices, the pool's blocks partitioned per worker), or one process per GPU (bench.py --gpus N, batched.py).
  */
 #ifndef ILUPP_HIP_H
 #define ILUPP_HIP_H
