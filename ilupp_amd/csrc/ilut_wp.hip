@@ -58,7 +58,7 @@ static constexpr int kWpHashG = 1 << 17;
 // (per wave in registers, added to ctrl + 8 once when the wave has no more rows: an atomic per phase and fetch on one address from
 // 5 120 waves made the kernel eight times slower)
 #define WP_ACC(slot, t0, t1) do { prof[slot] += (unsigned long long)((t1) - (t0)); } while (0)
-__device__ int *g_wp_lvl, *g_wp_parent, *g_wp_lparent;
+__device__ int *g_wp_lvl, *g_wp_parent, *g_wp_lparent, *g_wp_size;      // size: max pool | U slots << 12 | eliminations << 22 | global pieces << 31
 __device__ long long *g_wp_tfin, *g_wp_tstart, *g_wp_wait;
 #else
 #define WP_T(var)
@@ -254,6 +254,22 @@ __device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool m
 }
 
 // one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout
+// this row's cells of the wave's table in global memory: found first (nothing is removed while anybody still walks), then emptied
+template <bool G, typename IdT>
+__device__ __forceinline__ void wp_uh_clear(const WpArraysT<IdT> &w, const int lane, const int nU, int *gscratch)
+{
+    if (!G) return;
+    WpAcc<G>::sync();
+    for (int q = lane; q < nU; q += 64) {
+        unsigned h = wp_hash(WpAcc<G>::ldi(&w.ucol[q]), w.hmask);
+        while (w.uh[h] != (IdT)(q + 1)) h = (h + 1) & (unsigned)w.hmask;
+        gscratch[q] = (int)h;
+    }
+    WpAcc<G>::sync();
+    for (int q = lane; q < nU; q += 64) w.uh[gscratch[q]] = (IdT)0;
+    WpAcc<G>::sync();
+}
+
 template <bool G, typename IdT = unsigned short, bool SELG = false>
 __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, const int p, const double tau,
                                       const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
@@ -269,7 +285,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     int seen_done = -1;
     double wdiag = 0.0;
 #ifdef ILUT_PROFILE
-    int prof_lvl = 0, prof_parent = -1, prof_lparent = -1;
+    int prof_lvl = 0, prof_parent = -1, prof_lparent = -1, prof_maxl = 0;
     long long prof_wait = 0;
     const long long prof_t0 = wall_clock64();
 #endif
@@ -290,8 +306,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double v = valid ? Aval[q] : 0.0;
         const bool isL = valid && c < i, isU = valid && c > i, isD = valid && c == i;
         const unsigned long long mL = __ballot(isL), mU = __ballot(isU), mD = __ballot(isD);
-        if (seq + __popcll(mL) > WpIdMax<IdT>::value) return 1;
-        if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
+        if (seq + __popcll(mL) > WpIdMax<IdT>::value) { wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
+        if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
         if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
         if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], v); }
         A::sync();
@@ -310,6 +326,9 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
     for (;;) {
         WP_T(tp0);
+#ifdef ILUT_PROFILE
+        prof_maxl = nL > prof_maxl ? nL : prof_maxl;
+#endif
         // The next column that is ELIMINATED: the smallest one whose entry is neither zero (ILUT.hpp:239-240) nor below the stage-1
         // threshold (:244-245).  The reference pops every column in ascending order and forgets those; a forgotten entry has no
         // effect on anything, and an entry's value only changes when a smaller column is eliminated -- so every entry left of the
@@ -384,7 +403,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
 #endif
         const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
         const double m = wkv / ud;                                           // :249
-        if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); return 1; }
+        if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
         if (lane == 0) { w.kcol[nK] = k; w.kval[nK] = m; w.kseq[nK] = (IdT)sk; }
         ++nK;
         for (int base = 0; base < ul; base += 64) {                          // w -= m * U[k, j>k]  (:252-253)
@@ -453,8 +472,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             const bool nf = valid && c != i && (c < i ? bfound[lane] == 0 : !ufound);
             const bool isL = nf && c < i, isU = nf && c > i;
             const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
-            if (seq + __popcll(mL) > WpIdMax<IdT>::value) return 1;
-            if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); return 1; }
+            if (seq + __popcll(mL) > WpIdMax<IdT>::value) { wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
+            if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
             if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], 0.0 - pr); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
             A::sync();
@@ -468,7 +487,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     WP_T(tq0);
     // (10.) dropping (ILUT.hpp:259,261): the multipliers back in insertion order (the pool is empty now: its arrays take
     // them), then both pieces
-    if (nK > w.capL) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); return 1; }
+    if (nK > w.capL) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
     __builtin_amdgcn_s_waitcnt(0);
     for (int q = lane; q < nK; q += 64) A::sti(&w.lseq[q], (int)w.kseq[q]);
     A::sync();
@@ -495,24 +514,15 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         st_agent_i32(&Urow_idx[lb], i);
 #ifdef ILUT_PROFILE
         st_agent_i32(&g_wp_lvl[i], prof_lvl + 1);
-        g_wp_parent[i] = prof_parent; g_wp_lparent[i] = prof_lparent; g_wp_tstart[i] = prof_t0; g_wp_wait[i] = prof_wait; g_wp_tfin[i] = wall_clock64();
+        g_wp_parent[i] = prof_parent; g_wp_lparent[i] = prof_lparent; g_wp_tstart[i] = prof_t0;
+        g_wp_size[i] = (prof_maxl > 4095 ? 4095 : prof_maxl) | ((nU > 1023 ? 1023 : nU) << 12) | ((nK > 511 ? 511 : nK) << 22) | (G ? (1 << 31) : 0); g_wp_wait[i] = prof_wait; g_wp_tfin[i] = wall_clock64();
         __threadfence();
 #endif
         st_agent_i32(&Ulen[i], nUk + 1);
         atomicAdd(&ctrl[7], 1);                                                  // rows finished (what a waiting wave watches)
     }
     A::sync();
-    if (G) {
-        // this row's cells of the table: found first (nothing is removed while anybody still walks), then emptied
-        for (int q = lane; q < nU; q += 64) {
-            unsigned h = wp_hash(A::ldi(&w.ucol[q]), w.hmask);
-            while (w.uh[h] != (IdT)(q + 1)) h = (h + 1) & (unsigned)w.hmask;
-            gscratch[q] = (int)h;
-        }
-        A::sync();
-        for (int q = lane; q < nU; q += 64) w.uh[gscratch[q]] = (IdT)0;
-        A::sync();
-    }
+    wp_uh_clear<G, IdT>(w, lane, nU, gscratch);
     WP_T(tq1); WP_ACC(3, tq0, tq1);
     return 0;
 }
@@ -524,15 +534,26 @@ __global__ void __launch_bounds__(64)
 k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                int32_t p, double tau, WpArrays gw, int *gscratch_all,
                int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
-               int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl)
+               int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl, int tier2)
 {
     constexpr int kWpCapL = kWpCapU;
-    __shared__ int s_ucol[kWpCapU], s_lcol[kWpCapL], s_selq[kWpSel];
-    __shared__ unsigned short s_lseq[kWpCapL];
-    __shared__ double s_uval[kWpCapU], s_lval[kWpCapL];
+    // One block of LDS per wave, carved twice.  Tier 1: pool, U slots and hash, kWpCapU entries each.  Tier 2 (a row that outgrew tier 1:
+    // three of four on C3, mostly by their U part -- 508 U slots on average against a pool of at most 202): the whole block is the POOL,
+    // which every elimination passes over several times, and the U slots, their hash and the kept list live in the wave's global arrays,
+    // touched once per entry of a fetched row.  Tier 3: everything in global memory.
+    constexpr int kRaw = kWpCapU == 128 ? 7168 : 14336;
+    constexpr int kCap2 = kRaw / 14;                                         // 512 / 1024 pool entries (8 + 4 + 2 bytes each)
+    static_assert(kWpCapU * 26 + kWpHashLds * 2 <= kRaw, "tier 1 does not fit the block");
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRaw];
+    __shared__ int s_selq[kWpSel];
     __shared__ int bcol[64], bfound[64];
     __shared__ double bpr[64];
-    __shared__ __attribute__((aligned(16))) unsigned short s_uh[kWpHashLds];
+    double *s_uval = reinterpret_cast<double *>(s_raw), *s_lval = s_uval + kWpCapU;
+    int *s_ucol = reinterpret_cast<int *>(s_lval + kWpCapL), *s_lcol = s_ucol + kWpCapU;
+    unsigned short *s_lseq = reinterpret_cast<unsigned short *>(s_lcol + kWpCapL), *s_uh = s_lseq + kWpCapL;
+    double *t_lval = reinterpret_cast<double *>(s_raw);
+    int *t_lcol = reinterpret_cast<int *>(t_lval + kCap2);
+    unsigned short *t_lseq = reinterpret_cast<unsigned short *>(t_lcol + kCap2);
     const int lane = threadIdx.x;
     const size_t wv = blockIdx.x;
     WpArrays g = gw;
@@ -542,6 +563,8 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
     g.kcol += wv * (size_t)gw.capK; g.kval += wv * (size_t)gw.capK; g.kseq += wv * (size_t)gw.capK;
     int *gscratch = gscratch_all + wv * (size_t)gw.capU;
     const WpArrays lw = {s_uh, kWpHashLds - 1, s_ucol, s_uval, kWpCapU, s_lcol, s_lval, s_lseq, kWpCapL, g.kcol, g.kval, g.kseq, gw.capK};
+    const WpArrays hw = {g.uh, kWpHashG - 1, g.ucol, g.uval, gw.capU, t_lcol, t_lval, t_lseq, kCap2, g.kcol, g.kval, g.kseq, gw.capK};
+    static_assert(kWpHashLds * 2 % 8 == 0 && (kWpCapU * 26) % 8 == 0, "the LDS hash is cleared in 8-byte words");
 #ifdef ILUT_PROFILE
     unsigned long long prof[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #else
@@ -552,11 +575,20 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
         if (lane == 0) i = atomicAdd(&ctrl[0], 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= n) break;
+        // (starting every row in tier 2 costs the same as trying tier 1 first: 494 against 496 ms on C3)
         int rc = wp_row<false>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
                                lw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
+        if (rc == 1 && tier2) {
+            if (lane == 0) atomicAdd(&ctrl[3], 1);          // statistics: rows that outgrew tier 1
+            rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+                              hw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
+            rc = __builtin_amdgcn_readfirstlane(rc);
+            if (rc == 1 && lane == 0) atomicAdd(&ctrl[24], 1);      // ... and tier 2
+        } else if (rc == 1) {
+            if (lane == 0) atomicAdd(&ctrl[3], 1);
+        }
         if (rc == 1) {
-            if (lane == 0) atomicAdd(&ctrl[3], 1);          // statistics: rows that went to the global-memory pieces
             rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
                               g, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
             rc = __builtin_amdgcn_readfirstlane(rc);
@@ -699,10 +731,10 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     const size_t slab = (size_t)n * p;
     const bool small_pieces = p <= 32;
     static const int waves_env = getenv("ILUPP_ILUT_WAVES") ? atoi(getenv("ILUPP_ILUT_WAVES")) : 0;     // (experiments: waves per CU)
-    int workers = device_cu_count() * (waves_env > 0 ? waves_env : (small_pieces ? 20 : 14));
+    int workers = device_cu_count() * (waves_env > 0 ? waves_env : (small_pieces ? 16 : 8));          // (what the LDS block of a wave lets a CU hold)
     if (workers > n) workers = n;
     WpArrays g = {nullptr, kWpHashG - 1, nullptr, nullptr, kWpGCapU, nullptr, nullptr, nullptr, kWpGCapL, nullptr, nullptr, nullptr, kWpGCapK};
-    int32_t h[8];
+    int32_t h[32];
     {
         PoolBlock b_uh, b_ucol, b_uval, b_lcol, b_lval, b_lseq, b_kcol, b_kval, b_kseq, b_scr;
         ILUPP_HIP(b_uh.alloc(sizeof(unsigned short) * (size_t)workers * kWpHashG));
@@ -725,6 +757,9 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         PoolBlock pb_lvl, pb_par, pb_fin, pb_start, pb_wait, pb_lpar;
         ILUPP_HIP(pb_lpar.alloc(sizeof(int) * (size_t)n));
         { int *f = pb_lpar.as<int>(); ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_lparent), &f, sizeof(f))); }
+        PoolBlock pb_size;
+        ILUPP_HIP(pb_size.alloc(sizeof(int) * (size_t)n));
+        { int *f = pb_size.as<int>(); ILUPP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_size), &f, sizeof(f))); }
         ILUPP_HIP(pb_lvl.alloc(sizeof(int) * (size_t)n)); ILUPP_HIP(pb_par.alloc(sizeof(int) * (size_t)n));
         ILUPP_HIP(pb_fin.alloc(sizeof(long long) * (size_t)n)); ILUPP_HIP(pb_start.alloc(sizeof(long long) * (size_t)n)); ILUPP_HIP(pb_wait.alloc(sizeof(long long) * (size_t)n));
         ILUPP_HIP(hipMemsetAsync(pb_lvl.p, 0, sizeof(int) * (size_t)n, st));
@@ -741,22 +776,17 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         ILUPP_HIP(hipEventCreate(&ev.a));
         ILUPP_HIP(hipEventCreate(&ev.b));
         ILUPP_HIP(hipEventRecord(ev.a, st));
-        static const int cap_env = getenv("ILUPP_ILUT_CAP") ? atoi(getenv("ILUPP_ILUT_CAP")) : 0;           // (experiments: entries per LDS piece)
-        if (cap_env == 512)
-            hipLaunchKernelGGL((k_ilut_rows_wp<512, 2048>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
-        else if (cap_env == 1024)
-            hipLaunchKernelGGL((k_ilut_rows_wp<1024, 4096>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
-        else if (small_pieces && cap_env != 256)
+        static const int cap_env = getenv("ILUPP_ILUT_CAP") ? atoi(getenv("ILUPP_ILUT_CAP")) : 0;           // (experiments: 256 = the larger LDS class for every budget)
+        static const int tier2 = getenv("ILUPP_ILUT_NO_TIER2") ? 0 : 1;                                     // (tests, A/B: rows that outgrow LDS go to global memory at once)
+        if (small_pieces && cap_env != 256)
             hipLaunchKernelGGL((k_ilut_rows_wp<128, 512>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, tier2);
         else
             hipLaunchKernelGGL((k_ilut_rows_wp<256, 1024>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, tier2);
         ILUPP_HIP(hipEventRecord(ev.b, st));
         ILUPP_HIP(hipGetLastError());
-        ILUPP_HIP(hipMemcpyAsync(h, ctrl, 32, hipMemcpyDeviceToHost, st));
+        ILUPP_HIP(hipMemcpyAsync(h, ctrl, 128, hipMemcpyDeviceToHost, st));
         ILUPP_HIP(hipStreamSynchronize(st));
         if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, ev.a, ev.b));
 #ifdef ILUT_PROFILE
@@ -825,6 +855,29 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
                     ++cnt; root = q;
                 }
                 auto mean = [](const std::vector<double> &v) { double z = 0; for (double x : v) z += x; return v.empty() ? 0.0 : z / v.size(); };
+                {
+                    // the working rows' sizes: all rows / the rows of the chain
+                    std::vector<int> sz((size_t)n);
+                    ILUPP_HIP(hipMemcpy(sz.data(), pb_size.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+                    auto stats = [&](const char *what, const std::vector<int> &rows) {
+                        double pl = 0, us = 0, el = 0, gl = 0; int pmax = 0, umax = 0, p128 = 0, p512 = 0, u128 = 0;
+                        for (int r : rows) {
+                            const unsigned v = (unsigned)sz[(size_t)r];
+                            const int a = v & 4095, b = (v >> 12) & 1023, c = (v >> 22) & 511;
+                            pl += a; us += b; el += c; gl += v >> 31;
+                            pmax = a > pmax ? a : pmax; umax = b > umax ? b : umax;
+                            p128 += a > 128; p512 += a > 512; u128 += b > 128;
+                        }
+                        const double m = rows.empty() ? 1.0 : (double)rows.size();
+                        fprintf(stderr, "[ilut profile]     %-18s %8zu rows: pool max %.0f on average (largest %d; > 128: %.1f %%, > 512: %.1f %%), U slots %.0f (largest >= %d; > 128: %.1f %%), eliminations %.0f, in the global pieces %.1f %%\n",
+                                what, rows.size(), pl / m, pmax, 100.0 * p128 / m, 100.0 * p512 / m, us / m, umax, 100.0 * u128 / m, el / m, 100.0 * gl / m);
+                    };
+                    std::vector<int> all((size_t)n), ch;
+                    for (int r = 0; r < n; ++r) all[(size_t)r] = r;
+                    for (int r = deepest; r >= 0 && lpar[r] >= 0; r = lpar[r]) ch.push_back(r);
+                    stats("all rows", all);
+                    stats("rows of the chain", ch);
+                }
                 std::vector<double> g2 = gap; std::sort(g2.begin(), g2.end());
                 fprintf(stderr, "[ilut profile]   chain of deepest dependencies: row %d (level %d) back to row %d: %d links; from the first row's publication to the last's %.3f ms = %.1f %% of the kernel\n",
                         deepest, lvl[deepest], root, cnt, (double)(fin[deepest] - fin[root]) * tick * 1e3, 100.0 * (double)(fin[deepest] - fin[root]) * tick * 1e3 / kms);
@@ -836,7 +889,7 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         }
 #endif
     }
-    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: %d of %d rows outgrew LDS (pool %d, U slots %d, kept %d), status %d, kernel %.3f ms\n", h[3], n, h[4], h[5], h[6], h[1], kernel_ms ? *kernel_ms : 0.f);
+    if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: %d of %d rows outgrew LDS (pool %d, U slots %d, kept %d), %d of them the pool-in-LDS tier too, status %d, kernel %.3f ms\n", h[3], n, h[4], h[5], h[6], h[24], h[1], kernel_ms ? *kernel_ms : 0.f);
     // a row that outgrew the 64 K pieces: the whole factorisation once more in the largest class
     if (h[1] == 3) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
     if (h[1] == 1) return ILUPP_ERR_TIMEOUT;

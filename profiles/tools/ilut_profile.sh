@@ -12,6 +12,6 @@ if [ "$1" = build ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o /root/repo/profiles/tools/lib_ilutprof.so $OBJS scratch/ilut_prof.o
     ls -la /root/repo/profiles/tools/lib_ilutprof.so
 else
-    ILUPP_HIP_LIBRARY=profiles/tools/lib_ilutprof.so python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extra --config C3 2>&1 | grep "ilut profile" | tail -16 > "$2"
+    ILUPP_HIP_LIBRARY=profiles/tools/lib_ilutprof.so python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extra --config C3 2>&1 | grep "ilut profile" | tail -18 > "$2"
     cat "$2"
 fi

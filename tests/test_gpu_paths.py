@@ -40,7 +40,7 @@ def _tridiagonal_blocks():
 
 
 def _arrow():
-    n = 50000
+    n = 4000
     A = sp.lil_matrix((n, n)); A.setdiag(4.0); A[n - 1, :] = -0.001; A[:, n - 1] = -0.001; A[n - 1, n - 1] = 4.0
     return _csr(A)
 

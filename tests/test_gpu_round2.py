@@ -90,6 +90,46 @@ def test_ilut_config_c3_full_size():
     assert np.array_equal(x.cpu().numpy(), O.orc().apply_lu(Lo, Uo, b, O.ID))
 
 
+_ILUT_TIERS = r"""
+import sys, hashlib
+sys.path[:0] = [%r, %r]
+import numpy as np, matgen
+from ilupp_amd import _native
+from oracle import oracle as O
+d, i, p = matgen.random_dd(60000, 19, 25.0, 4711)
+P = _native.ILUTPreconditioner(d, i, p, True, 10, 1e-4)
+L, U = P.factors_info()
+Lo, Uo = O.orc().ilut((d, i, p, True), 10, 1e-4)
+assert np.array_equal(L[0], Lo[0]) and np.array_equal(L[1], Lo[1]) and np.array_equal(L[2], Lo[2])
+assert np.array_equal(U[0], Uo[0]) and np.array_equal(U[1], Uo[1]) and np.array_equal(U[2], Uo[2])
+h = hashlib.sha256()
+for f in (L, U):
+    for a in f[:3]:
+        h.update(np.ascontiguousarray(a).tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_ilut_rows_of_every_tier():
+    """a C3-shaped matrix (19 entries per row, ILUT(10, 1e-4)): most working rows outgrow the LDS pieces (tier 1) by their U part and go
+    on with the pool in LDS and the U part in global memory (tier 2), some outgrow that too (tier 3: ILUPP_DEBUG=1 prints the counts);
+    ILUPP_ILUT_NO_TIER2=1 sends them to global memory at once.  Array-equal to the oracle, and the same bits, either way"""
+    code = _ILUT_TIERS % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for env in ({"ILUPP_DEBUG": "1"}, {"ILUPP_DEBUG": "1", "ILUPP_ILUT_NO_TIER2": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(r.stdout.strip().splitlines()[-1])
+        import re
+        m = re.search(r"ilut_wp: (\d+) of (\d+) rows outgrew LDS .*?, (\d+) of them the pool-in-LDS tier too", r.stderr)
+        assert m and int(m.group(1)) > 1000, r.stderr[-400:]
+        if "ILUPP_ILUT_NO_TIER2" in env:
+            assert int(m.group(3)) == 0
+        else:
+            assert 0 < int(m.group(3)) < int(m.group(1))
+    assert outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("shape", [(40, 40, 40), (64, 24, 16), (17, 33, 65), (300, 300)])
 @pytest.mark.parametrize("fmt", ["csr", "csc"])
 def test_static_path_meshes(shape, fmt):
@@ -571,7 +611,7 @@ try:
 except RuntimeError as e:
     assert "wrong size" in str(e)
 # a batch through the compiled shim: the objects the constructor gives one at a time (its own native class, not the ctypes one)
-mats = [sp.csr_matrix(matgen.random_dd(3000 + 100 * k, 6, 25.0, 500 + k), shape=(3000 + 100 * k, 3000 + 100 * k)) for k in range(3)]
+mats = [sp.csr_matrix(matgen.random_dd(600 + 50 * k, 6, 25.0, 500 + k), shape=(600 + 50 * k, 600 + 50 * k)) for k in range(3)]
 prm = ilupp.iluplusplus_precond_parameter()
 prm.default_configuration(10)
 Ps = ilupp.ILUppPreconditioner.batch(mats, params=prm)
