@@ -541,7 +541,10 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
     // three of four on C3, mostly by their U part -- 508 U slots on average against a pool of at most 202): the whole block is the POOL,
     // which every elimination passes over several times, and the U slots, their hash and the kept list live in the wave's global arrays,
     // touched once per entry of a fetched row.  Tier 3: everything in global memory.
-    constexpr int kRaw = kWpCapU == 128 ? 7168 : 14336;
+#ifndef ILUT_RAW
+#define ILUT_RAW 7168
+#endif
+    constexpr int kRaw = kWpCapU == 128 ? ILUT_RAW : 14336;
     constexpr int kCap2 = kRaw / 14;                                         // 512 / 1024 pool entries (8 + 4 + 2 bytes each)
     static_assert(kWpCapU * 26 + kWpHashLds * 2 <= kRaw, "tier 1 does not fit the block");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRaw];
