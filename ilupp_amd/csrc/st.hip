@@ -1389,8 +1389,12 @@ k_st_xch_layout(const int32_t *__restrict__ exported, const int32_t *__restrict_
     const int32_t *T = ltab + (size_t)slot * kStTab;
     const bool ex = T[ST_CNT] > 0 && exported[slot] != 0;
     // the courier wave of the kernels serves at most 64 (lane, dependency) pairs that come from earlier workgroups
+    __shared__ int s_phase[16];
     if (t == 0) s_pairs = 0;
+    if (t < 16) s_phase[t] = 0;
     __syncthreads();
+    // (the vector wave of st_wave.hip serves at most 16 lanes per skew modulo 16: flags[9] & 8, as in k_st_xch_pair)
+    if (T[ST_CNT] > 0 && atomicAdd(&s_phase[T[ST_SKEW] & 15], 1) >= 16) atomicOr(&flags[9], 8);
     int ng = 0;
     for (int j = 0; j < 3; ++j) ng += (j < T[ST_ND] && T[ST_CNT] > 0 && (T[ST_SRC + j] & 3) == ST_GHOST) ? 1 : 0;
     if (ng) atomicAdd(&s_pairs, ng);
@@ -1936,10 +1940,15 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
     if (gl[0]) { pl->release(); pu->release(); return false; }
     pl->valid = pu->valid = true;
     pl->stat = pu->stat = true;
-    pl->wx = hl[9] == 0; pu->wx = hu[9] == 0;
+    pl->wx = (hl[9] & ~8) == 0; pu->wx = (hu[9] & ~8) == 0;
+    pl->vec_ok = pl->wx && (hl[9] & 8) == 0; pu->vec_ok = pu->wx && (hu[9] & 8) == 0;
     pl->pair = pu->pair = true;
     pu->desc = bwd_desc;
     pu->linked = true;
+    // a pair whose lanes fit the wave-exchange classes and whose backward sweep accumulates in ascending order (ICholT: T3): class-aligned
+    // records, round 4's sweep kernels (neighbours in registers); IChol0's descending backward sweep (T4) keeps round 2's (env
+    // ILUPP_NO_WR: every pair does)
+    if (pl->wx && pu->wx && !bwd_desc && st_wx_on()) wx_convert_records(st, pl, pu, 1);
     return true;
 }
 

@@ -645,17 +645,22 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
         std::call_once(once[dev & 63], [] {
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
         });
     }
     const dim3 grid((unsigned)ps.nwg);
     if (vec) {
-        if (fwd) hipLaunchKernelGGL((k_sptrsv_wv<1, false>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
+        if (fwd && ps.pair) hipLaunchKernelGGL((k_sptrsv_wv<1, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
+        else if (fwd) hipLaunchKernelGGL((k_sptrsv_wv<1, false>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
         else hipLaunchKernelGGL((k_sptrsv_wv<-1, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
     } else if (fwd) {
         st_vec_to_lm(st, ps, rhs, lml);
-        hipLaunchKernelGGL((k_sptrsv_wx<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        // (a pair of stored factors -- an LL^T object -- has a diagonal of its own in the forward factor)
+        if (ps.pair) hipLaunchKernelGGL((k_sptrsv_wx<1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        else hipLaunchKernelGGL((k_sptrsv_wx<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
         hipLaunchKernelGGL((k_sptrsv_wx<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
         st_vec_from_lm(st, ps, out);
