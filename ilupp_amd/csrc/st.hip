@@ -1945,10 +1945,10 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
     pl->pair = pu->pair = true;
     pu->desc = bwd_desc;
     pu->linked = true;
-    // a pair whose lanes fit the wave-exchange classes and whose backward sweep accumulates in ascending order (ICholT: T3): class-aligned
-    // records, round 4's sweep kernels (neighbours in registers); IChol0's descending backward sweep (T4) keeps round 2's (env
-    // ILUPP_NO_WR: every pair does)
-    if (pl->wx && pu->wx && !bwd_desc && st_wx_on()) wx_convert_records(st, pl, pu, 1);
+    // a pair whose lanes fit the wave-exchange classes: class-aligned records, round 4's sweep kernels (neighbours in registers) with round
+    // 5's vector wave; a backward sweep that accumulates in descending order (IChol0: T4) has its own instantiation (env ILUPP_NO_WR:
+    // round 2's sweeps for every pair)
+    if (pl->wx && pu->wx && st_wx_on()) wx_convert_records(st, pl, pu, 1);
     return true;
 }
 

@@ -57,7 +57,7 @@ __device__ unsigned long long g_wf_wait[4096 * 16];
 template <bool TO1>
 __global__ void __launch_bounds__(512)
 k_wx_convert(const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot,
-             const int32_t *__restrict__ wtab, v2d *__restrict__ pkL, v2d *__restrict__ pkU)
+             const int32_t *__restrict__ wtab, v2d *__restrict__ pkL, v2d *__restrict__ pkU, const int descB)
 {
     const int w = blockIdx.x;
     const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
@@ -92,7 +92,9 @@ k_wx_convert(const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltab
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 if (cls[j] != WR_NONE && st_bits(v[j]) != kAbsent) {
-                    const int s = wr_slot_of(cls[j], side == 1);
+                    // (descB: a backward sweep that accumulates in DESCENDING column order -- IChol0's T4 -- takes its coefficients in the
+                    // forward sweeps' slot order C, B, A)
+                    const int s = wr_slot_of(cls[j], side == 1 && !descB);
                     if (s == 0) o[0] = v[j]; else if (s == 1) o[1] = v[j]; else o[2] = v[j];
                 }
         } else {
@@ -100,7 +102,7 @@ k_wx_convert(const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltab
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 if (cls[j] != WR_NONE && !((TT[ST_SRC + j] & 3) == ST_OWN && kk == 0)) {
-                    const int s = wr_slot_of(cls[j], side == 1);
+                    const int s = wr_slot_of(cls[j], side == 1 && !descB);
                     // (a value that looks like one of the two markers of format 0 -- a NaN with that payload among A's values, or what
                     // the arithmetic made of one -- must not read as "no entry")
                     o[j] = st_clean(s == 0 ? v[0] : (s == 1 ? v[1] : v[2]));
@@ -117,10 +119,10 @@ void wx_convert_records(hipStream_t st, PackedSweep *pl, PackedSweep *pu, int to
     const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
     if (to_fmt == 1)
         hipLaunchKernelGGL((k_wx_convert<true>), grid, dim3(512), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->wtab, reinterpret_cast<v2d *>(pl->pk),
-                           reinterpret_cast<v2d *>(pu->pk));
+                           reinterpret_cast<v2d *>(pu->pk), (pu->pair && pu->desc) ? 1 : 0);
     else
         hipLaunchKernelGGL((k_wx_convert<false>), grid, dim3(512), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->wtab, reinterpret_cast<v2d *>(pl->pk),
-                           reinterpret_cast<v2d *>(pu->pk));
+                           reinterpret_cast<v2d *>(pu->pk), (pu->pair && pu->desc) ? 1 : 0);
     ILUPP_HIP(hipGetLastError());
     pl->fmt = pu->fmt = to_fmt;
 }
@@ -176,7 +178,7 @@ __device__ __forceinline__ bool wx_lane_setup(const int32_t *T, const int t, con
 static constexpr int kVecPitch = 34 * 8;                  // bytes of a lane's 32 ring entries (+ 2: the lanes of a wave spread over the banks)
 static constexpr int kVecRing = kThreads * kVecPitch;
 
-template <int DR, bool DIV, bool VEC>
+template <int DR, bool DIV, bool VEC, bool DESC = false>
 __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *xh, const int wg, const WxLane W, const int tlo, const int thi,
                                               unsigned char *vr)
 {
@@ -261,7 +263,8 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
             const double pC = wx_from_lane(W.src16, xprev);
 #endif
             const double sC = W.ringC ? bC : pC;
-            const double xs0 = DR > 0 ? sC : xprev, xs2 = DR > 0 ? xprev : sC;
+            // (accumulation in ascending column order: C, B, A forward, A, B, C backward; DESC: a backward sweep in descending order)
+            const double xs0 = (DR > 0 || DESC) ? sC : xprev, xs2 = (DR > 0 || DESC) ? xprev : sC;
             double acc = (VEC && DR > 0) ? bR : rr[u];
             acc = acc - c01.x * xs0;
             acc = acc - c01.y * sB;
@@ -533,7 +536,7 @@ __device__ __forceinline__ void wx_vector(const StSArgs &A, unsigned char *vr, V
     }
 }
 
-template <int DR, bool DIV, bool VEC>
+template <int DR, bool DIV, bool VEC, bool DESC = false>
 __device__ __forceinline__ void wx_sweep_body(const StSArgs &A, unsigned char *vr)
 {
     __shared__ __attribute__((aligned(16))) unsigned char xh[kWxLds];
@@ -577,7 +580,7 @@ __device__ __forceinline__ void wx_sweep_body(const StSArgs &A, unsigned char *v
         for (int i = t; i < 2 * kStH * kWxRow; i += kThreads) reinterpret_cast<double *>(xh)[i] = 0.0;
         __syncthreads();
         if ((t == 0 && s_total > 64) || !ok) atomicExch(A.err, 1);    // (the analysis does not let such a schedule through)
-        wx_sweep_wave<DR, DIV, VEC>(A, xh, wg, W, tlo, thi, vr);
+        wx_sweep_wave<DR, DIV, VEC, DESC>(A, xh, wg, W, tlo, thi, vr);
     } else if (VEC && t >= kThreads + 64) {
         __syncthreads();                                              // (the lanes' fields are in s_vec)
         __syncthreads();
@@ -598,19 +601,19 @@ __device__ __forceinline__ void wx_sweep_body(const StSArgs &A, unsigned char *v
     }
 }
 
-template <int DR, bool DIV>
+template <int DR, bool DIV, bool DESC = false>
 __global__ void __launch_bounds__(kStWgThreads)
 k_sptrsv_wx(StSArgs A)
 {
-    wx_sweep_body<DR, DIV, false>(A, nullptr);
+    wx_sweep_body<DR, DIV, false, DESC>(A, nullptr);
 }
 // ... with the vector wave: the caller's vector where it lies (A.nat)
-template <int DR, bool DIV>
+template <int DR, bool DIV, bool DESC = false>
 __global__ void __launch_bounds__(kStWgThreads + 64)
 k_sptrsv_wv(StSArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wv_ring[];
-    wx_sweep_body<DR, DIV, true>(A, wv_ring);
+    wx_sweep_body<DR, DIV, true, DESC>(A, wv_ring);
 }
 
 bool wx_vec_on()
@@ -647,6 +650,8 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<-1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<-1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
         });
@@ -655,6 +660,7 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
     if (vec) {
         if (fwd && ps.pair) hipLaunchKernelGGL((k_sptrsv_wv<1, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
         else if (fwd) hipLaunchKernelGGL((k_sptrsv_wv<1, false>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
+        else if (ps.pair && ps.desc) hipLaunchKernelGGL((k_sptrsv_wv<-1, true, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
         else hipLaunchKernelGGL((k_sptrsv_wv<-1, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
     } else if (fwd) {
         st_vec_to_lm(st, ps, rhs, lml);
@@ -662,7 +668,8 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
         if (ps.pair) hipLaunchKernelGGL((k_sptrsv_wx<1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
         else hipLaunchKernelGGL((k_sptrsv_wx<1, false>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
     } else {
-        hipLaunchKernelGGL((k_sptrsv_wx<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        if (ps.pair && ps.desc) hipLaunchKernelGGL((k_sptrsv_wx<-1, true, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
+        else hipLaunchKernelGGL((k_sptrsv_wx<-1, true>), grid, dim3(kStWgThreads), kStSoloLds, st, a);
         st_vec_from_lm(st, ps, out);
     }
     ILUPP_HIP(hipGetLastError());
