@@ -341,7 +341,7 @@ class Preconditioner:
         return lib().ilupp_hip_analysis_path(self._h).decode()
 
     def kernel_names(self):
-        """(factor kernel, forward sweep, backward sweep) of a static ILU(0) object, else () (measurement hook)"""
+        """(factor kernel, forward sweep, backward sweep) of a static ILU(0) object or of an LL^T object (its sweeps once an apply has built them), else () (measurement hook)"""
         s = lib().ilupp_hip_kernel_names(self._h).decode()
         return tuple(s.split(";")) if s else ()
 

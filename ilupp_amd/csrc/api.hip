@@ -1529,6 +1529,19 @@ const char *ilupp_hip_analysis_path(const ilupp_precond *p)
 // bench.py labels its roofline phases and looks the kernels' counter traffic up by these names); "" for any other object
 const char *ilupp_hip_kernel_names(const ilupp_precond *p)
 {
+    if (p && p->kind == KIND_LLT) {
+        // an LL^T object: the factor kernel of its construction and -- once an apply has built them -- the sweeps of its factor pair
+        const PackedSweep &pf = p->llt_diag_last ? p->pkL : p->pkLT, &pb = p->llt_diag_last ? p->pkLT : p->pkL;
+        const char *fk = p->llt_diag_last ? (p->chol_static ? "k_ichol0_st" : "k_ichol0") : (p->icholt_grid ? "k_icholt_grid" : "k_icholt_df");
+        static thread_local std::string names;
+        names = fk;
+        if (pf.valid && pf.pair && pb.valid && pb.pair) {
+            const bool vec = pf.fmt == 1 && wx_vec_on() && pf.vec_ok && pb.vec_ok;
+            if (pf.fmt == 1) names += std::string(vec ? ";k_sptrsv_wv<1, true>;k_sptrsv_wv" : ";k_sptrsv_wx<1, true>;k_sptrsv_wx") + (pb.desc ? "<-1, true, true>" : "<-1, true>");
+            else names += std::string(";k_sptrsv_st<1, true>;k_sptrsv_st") + (pb.desc ? "<-1, true>" : "<-1, false>");
+        }
+        return names.c_str();
+    }
     if (!p || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU && p->flm.built && p->flm.stat)) return "";
     if (p->pkL.fmt == 1 && wx_vec_on() && p->pkL.vec_ok && p->pkU.vec_ok)
         return p->flm.wxf ? "k_ilu0_wx;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>" : "k_ilu0_sd;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>";

@@ -340,7 +340,8 @@ const char *ilupp_hip_analysis_path(const ilupp_precond *p);
  * records, 6 / 7 export ordinals, 8 / 9 exchange layout, 10 forward -> backward slots, 11 / 12 skews; returns the words copied (<= cap), -1
  * where there is no such table.  No counterpart in binding.cpp. */
 long long ilupp_hip_debug_static_table(ilupp_precond *p, int which, int32_t *out, long long cap);
-/* measurement hook: the kernels a static ILU(0) object runs, "factor;forward sweep;backward sweep" ("" otherwise); no counterpart in binding.cpp */
+/* measurement hook: the kernels a static ILU(0) object runs, "factor;forward sweep;backward sweep"; for an LL^T object (IChol0, ICholT) its
+ * factor kernel and, once an apply has built them, the sweeps of its factor pair; "" otherwise.  No counterpart in binding.cpp */
 const char *ilupp_hip_kernel_names(const ilupp_precond *p);
 /* redo the numeric phase on (possibly new) values with the SAME pattern (buffers reused); times it */
 int ilupp_hip_ilu0_refactor_device(ilupp_precond *p, const double *d_data, const int32_t *d_indices,

@@ -33,6 +33,12 @@ def _check(A, expect_static):
         assert np.array_equal(x, want)
         xt = b.copy(); P.apply_trans(xt)
         assert np.array_equal(xt, want)
+    if expect_static:
+        # (the pair's sweeps: round 4's wave-exchange kernels where every lane fits their classes -- the backward one accumulating in
+        # descending column order --, round 2's otherwise)
+        names = P.pr.kernel_names()
+        assert names[0] == "k_ichol0_st" and names[1:] in ((("k_sptrsv_wv<1, true>", "k_sptrsv_wv<-1, true, true>")), ("k_sptrsv_wx<1, true>", "k_sptrsv_wx<-1, true, true>"),
+                                                             ("k_sptrsv_st<1, true>", "k_sptrsv_st<-1, true>")), names
 
 
 @pytest.mark.parametrize("shape", [(40, 40, 40), (64, 24, 16), (17, 33, 65), (300, 300), (128, 128, 128)])

@@ -717,6 +717,13 @@ def test_icholt_config_c4_full_size():
     Lo = ref.icholt((d, i, p, True), 0, 0.0)
     assert G.mat_equal(_fac(L), Lo)
     assert P.total_nnz == L.nnz == 66912256
+    # ... by the speculative static kernel for box grids (round 5), and its apply by the wave-exchange sweeps with the vector wave: the two
+    # triangular solves at full size against the oracle's (sparse_implementation.h:4040-4087: T2 / T3 on the column-stored factor)
+    assert P.pr.path() == "icholt:grid-static"
+    b = G.rhs(n)
+    x = b.copy(); P.pr.apply(x)
+    assert np.array_equal(x, O.orc().apply_llt(Lo, b))
+    assert P.pr.kernel_names() == ("k_icholt_grid", "k_sptrsv_wv<1, true>", "k_sptrsv_wv<-1, true>"), P.pr.kernel_names()
 
 
 def test_icholt_fill_and_threshold_full_size():
