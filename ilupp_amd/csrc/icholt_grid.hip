@@ -40,9 +40,9 @@ constexpr unsigned kIgLds = kIgSst + 8u * kIgAstSlot;     // 161 280 bytes (of t
 constexpr int kIgExp = 32;                                // exported lanes of a patch: y' = 15 (16), z' = 15 (15 more)
 constexpr int kIgThreads = 576;                           // four consumer waves, the courier, two loader waves, two storer waves
 #ifndef IG_NP
-#define IG_NP 0
+#define IG_NP 2
 #endif
-constexpr int kIgNP = IG_NP;                              // the imports of a step are polled for kIgNP + 1 steps ahead (256^3: 3.7-3.85 ms with 0, 3.85 with 1, 4.0 with 3, 4.2 with 5)
+constexpr int kIgNP = IG_NP;                              // the imports of a step are polled for kIgNP + 1 steps ahead (256^3, final kernel: 2.60 ms with 0, 2.59 with 1, 2.55 with 2, 2.72 with 3, 2.84 with 5)
 constexpr int kIgMaxSkew = 2 * 15 + 15;
 // words of a published record (column m of a lane): what the lanes (y+1, z), (y, z+1), (y-1, z+1) subtract from their diagonals
 enum { IG_E2P = 0, IG_QP = 1, IG_F1 = 2, IG_F3 = 3, IG_E3P = 4, IG_F2 = 5 };   // e2^2, e3 e2 of column m-1; f1^2, f3^2 of m; e3^2 of m-1; f2^2 of m
