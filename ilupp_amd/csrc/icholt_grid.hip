@@ -408,27 +408,29 @@ __device__ __forceinline__ void ig_courier(const IgArgs &A, unsigned char *lds, 
 #define IGC_POLL(s_, slot_)                                                                                  \
     do { gq[slot_][0] = ld_agent_u64(IGC_ADDR(s_, w0)); gq[slot_][1] = ld_agent_u64(IGC_ADDR(s_, w1)); gq[slot_][2] = ld_agent_u64(IGC_ADDR(s_, w2)); } while (0)
     bool dead = false;
+    unsigned spins = 0;
+#define IGC_WAIT(v_, w_, s_)                                                                                 \
+    do {                                                                                                     \
+        while (!dead && __builtin_amdgcn_ballot_w64(need && v_ == kSentinel) != 0) {                         \
+            if (need && v_ == kSentinel) v_ = ld_agent_u64(IGC_ADDR(s_, w_));                                \
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                              \
+            __builtin_amdgcn_s_sleep(1);                                                                     \
+            if ((++spins & 255u) == 0) {                                                                     \
+                if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);                                         \
+                const int e = ld_agent_i32(&A.ctrl[1]);                                                      \
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                                          \
+                if (spins > kStSpinLimit || e != 0) { dead = true; break; }                                  \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
     // deliver what the lanes read at step s_ (slot s_ & 7), then poll for step s_ + kIgNP + 1
 #define IGC_DELIVER(s_, i_)                                                                                  \
     do {                                                                                                     \
         const bool need = exists && (unsigned)((s_) - skc) < (unsigned)nx;                                   \
         unsigned long long v0 = gq[(i_) % (kIgNP + 1)][0], v1 = gq[(i_) % (kIgNP + 1)][1], v2 = gq[(i_) % (kIgNP + 1)][2]; \
-        if (!dead) {                                                                                         \
-            unsigned spins = 0;                                                                              \
-            while (__builtin_amdgcn_ballot_w64(need && (v0 == kSentinel || v1 == kSentinel || v2 == kSentinel)) != 0) { \
-                if (need && v0 == kSentinel) v0 = ld_agent_u64(IGC_ADDR(s_, w0));                            \
-                if (need && v1 == kSentinel) v1 = ld_agent_u64(IGC_ADDR(s_, w1));                            \
-                if (need && v2 == kSentinel) v2 = ld_agent_u64(IGC_ADDR(s_, w2));                            \
-                __builtin_amdgcn_s_waitcnt(0x0F70);                                                          \
-                __builtin_amdgcn_s_sleep(1);                                                                 \
-                if ((++spins & 255u) == 0) {                                                                 \
-                    if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);                                     \
-                    const int e = ld_agent_i32(&A.ctrl[1]);                                                  \
-                    __builtin_amdgcn_s_waitcnt(0x0F70);                                                      \
-                    if (spins > kStSpinLimit || e != 0) { dead = true; break; }                              \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
+        /* (one loop per word: with the three words in ONE loop hipcc waits for every outstanding memory operation at the loop's  \
+           header -- the exports just issued, the polls of the steps ahead --, i.e. once per step: 1.82 -> ... ms without memory ops) */ \
+        IGC_WAIT(v0, w0, s_); IGC_WAIT(v1, w1, s_); IGC_WAIT(v2, w2, s_);                                    \
         if (!need) { v0 = 0; v1 = 0; v2 = 0; }                                                               \
         const unsigned o_ = (unsigned)((s_) & (kIgSlots - 1)) * kIgSlotB + dst;                                           \
         *reinterpret_cast<unsigned long long *>(lds + (unsigned)w0 * kIgWordB + o_) = v0;                    \
@@ -444,30 +446,33 @@ __device__ __forceinline__ void ig_courier(const IgArgs &A, unsigned char *lds, 
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = ib + u;
-            if (i < A.S) {
+            {
                 ST_BARRIER();
-                // the records of step i - 1 of the exported lanes
+                // the records of step i - 1 of the exported lanes.  UNCONDITIONAL stores (a lane or step without an export stores beyond
+                // the buffer's end, which drops it): hipcc's wait for a poll of three steps ago counts the memory operations issued since, and
+                // takes the smallest count over all paths -- with the exports under a branch it waited for the exports of the step before
                 const int m = i - 1 - ske;
-                if (et >= 0 && i >= 1 && (unsigned)m <= (unsigned)nx) {
-                    const unsigned o = (unsigned)((i - 1) & (kIgSlots - 1)) * kIgSlotB + (unsigned)et * 8u;
-                    unsigned long long w[6];
+                const bool ex = et >= 0 && i >= 1 && (unsigned)m <= (unsigned)nx;
+                const unsigned o = (unsigned)((i - 1) & (kIgSlots - 1)) * kIgSlotB + (unsigned)(et >= 0 ? et : 0) * 8u;
+                unsigned long long w[6];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        w[j] = *reinterpret_cast<const unsigned long long *>(lds + (unsigned)j * kIgWordB + o);
-                        w[j] = w[j] == kSentinel ? kCanonNaN : w[j];
-                    }
-                    // (buffer stores, sc1 = write-through: an inline-asm store would be a memory operation hipcc's wait counts do not know of --
-                    // the polls behind it were then taken for complete one operation early)
-                    const unsigned qo = eoff + (unsigned)m * 64u;
-                    __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32)}, rx, qo, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32)}, rx, qo + 16u, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)w[4], (unsigned)(w[4] >> 32), (unsigned)w[5], (unsigned)(w[5] >> 32)}, rx, qo + 32u, 0, 16);
+                for (int j = 0; j < 6; ++j) {
+                    w[j] = *reinterpret_cast<const unsigned long long *>(lds + (unsigned)j * kIgWordB + o);
+                    w[j] = w[j] == kSentinel ? kCanonNaN : w[j];
                 }
+                // (buffer stores, sc1 = write-through: an inline-asm store would be a memory operation hipcc's wait counts do not know of --
+                // the polls behind it were then taken for complete one operation early)
+                unsigned qo = ex ? eoff + (unsigned)m * 64u : 0xffffff00u;
+                asm volatile("" : "+v"(qo));
+                __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32)}, rx, qo, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32)}, rx, qo + 16u, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)w[4], (unsigned)(w[4] >> 32), (unsigned)w[5], (unsigned)(w[5] >> 32)}, rx, qo + 32u, 0, 16);
                 IGC_DELIVER(i + 1, u + 1);
             }
         }
     }
 #undef IGC_DELIVER
+#undef IGC_WAIT
 #undef IGC_POLL
 #undef IGC_ADDR
     if (dead && p == 0) atomicExch(&A.ctrl[1], 1);
@@ -542,7 +547,8 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
     if (side) ILUPP_HIP(hipStreamWaitEvent(st, job->pattern_done, 0));
     IgArgs a;
     a.g = g; a.nty = nty; a.ntz = ntz;
-    a.S = ((g.nx + kIgMaxSkew + 3) + 7) & ~7;
+    a.S = ((g.nx + kIgMaxSkew + 3) + 23) / 24 * 24;        // (a multiple of the consumers' 8 and of the courier's 4 (kIgNP + 1) unrolled steps)
+    static_assert(24 % (4 * (kIgNP + 1)) == 0, "the courier's unrolled loop must divide the step count");
     a.aval = A.val; a.abytes = (unsigned)(A.nnz * 8);
     a.lval = L->val; a.lbytes = (unsigned)(nnzL * 8);
     a.xch = xp; a.idle = xp + xwords; a.ctrl = ctrl;
