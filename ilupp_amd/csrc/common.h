@@ -407,6 +407,8 @@ struct IcholtGridJob {
     PoolBlock xch;
     EventPair ev;
     hipEvent_t pattern_done = nullptr;
+    hipStream_t launched_on = nullptr, side_stream = nullptr;
+    bool finished = false;
     GridDims g = {0, 0, 0};
     int32_t h[16] = {0};
     IcholtGridJob() {}

@@ -21,6 +21,8 @@
 // (then the cut of dropping.hpp keeps exactly them, whatever it does with ties), nothing is NaN.  One violated column, or a matrix
 // that is no box grid (grid.hip: k_grid_check), and the result is thrown away: the dataflow kernel (icholt_df.hip) builds the object.
 // Values: the same operations in the same order as the reference, so the factor is bit-identical (tests/test_gpu_icholt_grid.py).
+#include <mutex>
+
 #include "st_common.h"
 
 namespace ilupp {
@@ -499,6 +501,8 @@ k_icholt_grid(IgArgs A)
 
 IcholtGridJob::~IcholtGridJob()
 {
+    // (a construction that unwinds between launch and finish: the kernel may still run on what this object gives back to the pool)
+    if (launched_on && !finished) { (void)hipStreamSynchronize(launched_on); if (side_stream) (void)hipStreamSynchronize(side_stream); }
     if (pattern_done) (void)hipEventDestroy(pattern_done);
 }
 
@@ -515,10 +519,13 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
     const int nty = (g.ny + 15 + 15) / 16, ntz = (g.nz + 15) / 16;        // (sheared patches: y + z' runs to ny - 1 + 15)
     // buffer resources cover the value arrays
     if (A.nnz * 8 >= (1LL << 32) || nnzL >= (1LL << 31) || (int64_t)nty * ntz > (1 << 20)) return false;
-    static bool attr = false;
-    if (!attr) {
-        ILUPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_icholt_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIgLds));
-        attr = true;
+    {
+        static std::once_flag once[64];      // once per device
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        std::call_once(once[dev & 63], [] {
+            ILUPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_icholt_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIgLds));
+        });
     }
     const int64_t xwords = (int64_t)nty * ntz * kIgExp * (g.nx + 1) * 8;
     ILUPP_HIP(job->xch.alloc(sizeof(unsigned long long) * (size_t)(xwords + 8)));
@@ -526,6 +533,7 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
     ILUPP_HIP(job->ev.create());
     ILUPP_HIP(hipEventCreateWithFlags(&job->pattern_done, hipEventDisableTiming));
     job->g = g;
+    job->launched_on = st; job->side_stream = side;
     L->release();
     L->n = A.n; L->nnz = nnzL; L->is_csr = false; L->owns = true;
     ILUPP_HIP(pool_malloc(&L->ptr, sizeof(int32_t) * (size_t)(n + 1)));
@@ -566,6 +574,7 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
 bool icholt_grid_finish(hipStream_t st, IcholtGridJob *job, float *kernel_ms)
 {
     ILUPP_HIP(stream_sync(st));
+    job->finished = true;
     float ms = 0.f;
     ILUPP_HIP(hipEventElapsedTime(&ms, job->ev.a, job->ev.b));
     if (kernel_ms) *kernel_ms = ms;
