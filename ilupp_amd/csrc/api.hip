@@ -1305,7 +1305,8 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
             p->max_row_len = 1 + (gd.nx > 1) + (gd.ny > 1) + (gd.nz > 1);
             build_slot_tables(q, &p->sL, false);
             p->compact = schedule_is_compact(p->sL);
-            if (p->compact) make_desc_llt_grid(q, p->Lc, p->sL, gd, &p->dL);
+            // (the descriptors and the factor's own index arrays in one pass over the columns)
+            if (p->compact) { make_desc_llt_grid(q, p->Lc, p->sL, gd, &p->dL, true); job.pattern_written = true; }
             sched_done = true;
         };
         auto schedule_on = [&](hipStream_t q) {

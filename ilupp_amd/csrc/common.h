@@ -319,7 +319,7 @@ void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g);
 void grid_shape_forget(int32_t n, int64_t nnz);
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
 bool grid_llt_schedule(hipStream_t st, int32_t n, const GridDims &g, int max_lanes, Schedule *bwd);
-void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc);
+void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc, bool with_pattern = false);
 void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
                     int32_t *max_row_len, int max_wgs);
 // slot tables, lane templates and the link between the two schedules of a box grid, from its dimensions (one launch; the schedules'
@@ -409,6 +409,7 @@ struct IcholtGridJob {
     hipEvent_t pattern_done = nullptr;
     hipStream_t launched_on = nullptr, side_stream = nullptr;
     bool finished = false;
+    bool pattern_written = false;      // the caller's pattern_free work wrote L's index arrays too (make_desc_llt_grid)
     GridDims g = {0, 0, 0};
     int32_t h[16] = {0};
     IcholtGridJob() {}

@@ -546,7 +546,8 @@ bool icholt_grid_launch(hipStream_t st, hipStream_t side, const DevMat &A, const
     // 0.15 ms became 0.9 ms, the proof's 0.12 ms 0.5 ms, and the kernel 0.2 ms longer).
     hipStream_t q = side ? side : st;
     if (pattern_free) pattern_free(q);
-    hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, q, A.n, g, L->ptr, L->idx, (long long)nnzL);
+    if (!job->pattern_written)
+        hipLaunchKernelGGL(k_icholt_grid_pattern, dim3(2048), dim3(256), 0, q, A.n, g, L->ptr, L->idx, (long long)nnzL);
     if (after_pattern) after_pattern(q);
     ILUPP_HIP(hipEventRecord(job->pattern_done, q));
     grid_check_launch(st, A, g, ctrl + 8);

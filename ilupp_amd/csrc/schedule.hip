@@ -276,7 +276,8 @@ void make_desc(hipStream_t st, const DevMat &M, const Schedule &sch, int32_t **d
 // per x-line, backward schedule): what k_make_desc finds by ptr -> idx -> block_of -> start for every entry follows from (x, y, z).
 __global__ void __launch_bounds__(256)
 k_make_desc_llt_grid(const int32_t n, const GridDims g, const int32_t *__restrict__ blk2slot, int32_t *__restrict__ desc,
-                     int32_t *__restrict__ exported, const int32_t *__restrict__ gtab)
+                     int32_t *__restrict__ exported, const int32_t *__restrict__ gtab, int32_t *__restrict__ Lptr, int32_t *__restrict__ Lidx,
+                     const long long nnzL)
 {
     const unsigned unx = (unsigned)g.nx, uny = (unsigned)g.ny;
     for (long long rr = (long long)blockIdx.x * 256 + threadIdx.x; rr < n; rr += (long long)gridDim.x * 256) {
@@ -284,6 +285,16 @@ k_make_desc_llt_grid(const int32_t n, const GridDims g, const int32_t *__restric
         const unsigned l = r / unx, x = r - l * unx;
         const unsigned z = l / uny, y = l - z * uny;
         long long q = ig_col_start((int)x, (int)y, (int)z, g);
+        if (Lptr) {
+            // (the factor's own index arrays in the same pass: icholt_grid.hip's k_icholt_grid_pattern writes nothing else)
+            long long w = q;
+            Lptr[r] = (int32_t)q;
+            Lidx[w++] = (int32_t)r;
+            if ((int)x < g.nx - 1) Lidx[w++] = (int32_t)r + 1;
+            if ((int)y < g.ny - 1) Lidx[w++] = (int32_t)r + g.nx;
+            if ((int)z < g.nz - 1) Lidx[w++] = (int32_t)r + g.nx * g.ny;
+            if (rr == n - 1) Lptr[n] = (int32_t)nnzL;
+        }
         const int my = blk2slot[l];
         const int mywg = my >> 8;
         desc[q++] = -1;
@@ -342,12 +353,13 @@ k_ghost_table_llt_grid(const GridDims g, const int32_t *__restrict__ slot2blk, c
     if (t < kGhosts) gtab[(size_t)wg * kGhosts + t] = tab[t];
 }
 
-void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc)
+void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc, bool with_pattern)
 {
     ILUPP_HIP(pool_malloc(desc, sizeof(int32_t) * (size_t)(M.nnz > 0 ? M.nnz : 1)));
     if (sch.gtab)
         hipLaunchKernelGGL(k_ghost_table_llt_grid, dim3((unsigned)(sch.nslots / kThreads)), dim3(kThreads), 0, st, g, sch.slot2blk, sch.blk2slot, sch.gtab);
-    hipLaunchKernelGGL(k_make_desc_llt_grid, dim3(2048), dim3(256), 0, st, M.n, g, sch.blk2slot, *desc, sch.exported, sch.gtab);
+    hipLaunchKernelGGL(k_make_desc_llt_grid, dim3(2048), dim3(256), 0, st, M.n, g, sch.blk2slot, *desc, sch.exported, sch.gtab,
+                       with_pattern ? M.ptr : nullptr, with_pattern ? M.idx : nullptr, (long long)M.nnz);
     ILUPP_HIP(hipGetLastError());
 }
 
