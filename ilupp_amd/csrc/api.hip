@@ -674,6 +674,8 @@ static bool static_transposed_ready(ilupp_precond *p)
     wx_convert_records(p->stream, &p->pkL, &p->pkU, 0);
     const bool ok = st_build_transposed(p->stream, p->sA, p->n, p->flm, &p->pkL, &p->pkU, p->Lc.nnz - p->n, p->Uc.nnz - p->n);
     wx_convert_records(p->stream, &p->pkL, &p->pkU, fmt);
+    // (an object whose own sweeps are the wave-exchange ones gets them for the transposed apply as well)
+    if (ok && fmt == 1) wx_convert_transposed(p->stream, &p->pkL, &p->pkU);
     if (ok) return true;
     p->no_static_T = true;
     return false;

@@ -146,6 +146,7 @@ struct PackedSweep {
     // records of the TRANSPOSED factor for this sweep's schedule (static form; built on the first transposed apply, dropped
     // by a re-factorisation): forward schedule: U^T (diagonal u_rr), backward schedule: L^T (diagonal 1)
     unsigned char *pkT = nullptr;
+    int fmtT = 0;               // format of the transposed records (0 / 1 as `fmt`)
     // static sweeps made from a pair of stored triangular factors (st_analyse_pair): the forward sweep divides by its stored
     // diagonal; the backward sweep accumulates in descending column order when `desc` (a row-stored lower factor used transposed)
     bool pair = false, desc = false;
@@ -570,6 +571,7 @@ void st_vec_to_lm(hipStream_t st, const PackedSweep &ps, const double *nat, doub
 void st_vec_from_lm(hipStream_t st, const PackedSweep &ps, double *nat);
 // st_wave.hip
 void wx_convert_records(hipStream_t st, PackedSweep *pl, PackedSweep *pu, int to_fmt);
+void wx_convert_transposed(hipStream_t st, PackedSweep *pl, PackedSweep *pu);      // pkT of both: format 0 -> 1 (U^T forward, L^T backward in descending order)
 int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rhs, double *out, int32_t *d_ticket, int32_t *d_err,
               double *ypk_out, const double *ypk_in, const int32_t *ysrc);
 int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rhs, double *out, int32_t *d_ticket, int32_t *d_err,

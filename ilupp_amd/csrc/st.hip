@@ -2123,6 +2123,7 @@ void st_drop_transposed(PackedSweep *pl, PackedSweep *pu)
 {
     if (pl->pkT) { (void)pool_free(pl->pkT); pl->pkT = nullptr; }
     if (pu->pkT) { (void)pool_free(pu->pkT); pu->pkT = nullptr; }
+    pl->fmtT = pu->fmtT = 0;
 }
 
 bool st_build_transposed(hipStream_t st, const Schedule &fwd, int32_t n, const FactorLM &f, PackedSweep *pl, PackedSweep *pu,
@@ -2157,6 +2158,13 @@ int sptrsv_st_T(hipStream_t st, const PackedSweep &ps, int32_t n, const double *
 {
     const bool fwd = ps.kind == (int)SWEEP_FWD_LAST_ASC;
     if (!lml || !ps.pkT || (!fwd && (!ysrc || !ps.xlm))) { set_error("static transposed sweep without its records"); return ILUPP_ERR_INVALID; }
+    if (ps.fmtT == 1) {
+        // class-aligned transposed records: the wave-exchange sweeps (U^T: forward with a diagonal of its own; L^T: backward, unit
+        // diagonal, descending accumulation) -- the object's own schedule, tables and exchange, the transposed records for `pk`
+        PackedSweep q = ps;
+        q.pk = ps.pkT; q.fmt = 1; q.pair = true; q.desc = !fwd; q.xch_armed = false;
+        return sptrsv_wx(st, q, n, rhs, out, d_ticket, d_err, fwd ? lml : nullptr, fwd ? nullptr : lml, ysrc);
+    }
     StSArgs a;
     a.pk = reinterpret_cast<const v2d *>(ps.pkT); a.ltab = ps.ltab; a.wtab = ps.wtab; a.n = n;
     a.nchY = (int32_t)ps.nchunks;

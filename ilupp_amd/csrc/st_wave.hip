@@ -127,6 +127,18 @@ void wx_convert_records(hipStream_t st, PackedSweep *pl, PackedSweep *pu, int to
     pl->fmt = pu->fmt = to_fmt;
 }
 
+// the records of the transposed apply (st.hip: k_st_transpose writes them by template position): class-aligned, the backward ones --
+// L^T, accumulated in descending column order -- in the forward sweeps' slot order
+void wx_convert_transposed(hipStream_t st, PackedSweep *pl, PackedSweep *pu)
+{
+    if (!pl->pkT || !pu->pkT || (pl->fmtT == 1 && pu->fmtT == 1)) return;
+    const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
+    hipLaunchKernelGGL((k_wx_convert<true>), grid, dim3(512), 0, st, pl->ltab, pu->ltab, pu->uslot, pl->wtab, reinterpret_cast<v2d *>(pl->pkT),
+                       reinterpret_cast<v2d *>(pu->pkT), 1);
+    ILUPP_HIP(hipGetLastError());
+    pl->fmtT = pu->fmtT = 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the exchange inside a wave
 // ---------------------------------------------------------------------------------------------
