@@ -1188,39 +1188,67 @@ k_st_chol_check(const int32_t *__restrict__ ltab, int32_t *__restrict__ flags)
     if (bad) atomicOr(&flags[0], 4);
 }
 
-// lower rows (diagonal last) -> records {a0,a1}{a2,a_ii}, every entry matched against its lane's template and range of rows
+// lower rows (diagonal last) -> records {a0,a1}{a2,a_ii}, every entry matched against its lane's template and range of rows.  The CSR
+// side is read as in k_st_unpack it is written: a lane's eight rows of a group of eight chunks are one contiguous run, fetched by eight
+// threads per lane into LDS (256^3: 1.35 ms with a row per lane and instruction)
 __global__ void __launch_bounds__(512)
 k_st_pack_lower(const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lidx, const double *__restrict__ Lval,
                 const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, v2d *__restrict__ pk, int32_t *__restrict__ flags)
 {
+    __shared__ double s_val[64][33];
+    __shared__ int s_idx[64][33];
+    __shared__ int s_lo[64], s_hi[64];
     const int w = blockIdx.x;
     const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
     const int L = threadIdx.x & 63;
     const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
-    if (c >= nch) return;
+    if (threadIdx.x < 64) { s_lo[threadIdx.x] = 0x7fffffff; s_hi[threadIdx.x] = -1; }
+    __syncthreads();
     const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
     const int32_t *T = ltab + (size_t)slot * kStTab;
     const int k = tmin + c - T[ST_SKEW];
     const int cnt = T[ST_CNT];
+    const bool inchunk = c < nch;
+    const bool live = inchunk && k >= 0 && k < cnt;
+    const int r = live ? T[ST_FIRST] + k : 0;
+    const int q0 = live ? Lptr[r] : 0, q1 = live ? Lptr[r + 1] : 0;
+    const bool shape_ok = q1 - q0 >= 1 && q1 - q0 <= 4;
+    if (live && shape_ok) { atomicMin(&s_lo[L], q0); atomicMax(&s_hi[L], q1); }
+    __syncthreads();
+    {
+        const int L2 = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int lo2 = s_lo[L2], len = s_hi[L2] - lo2;
+        if (len > 0 && len <= 32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * j + e < len) { s_val[L2][4 * j + e] = Lval[lo2 + 4 * j + e]; s_idx[L2][4 * j + e] = Lidx[lo2 + 4 * j + e]; }
+        }
+    }
+    __syncthreads();
+    if (!inchunk) return;
     const double absent = st_dbl(kAbsent);
     v2d *o = pk + ((size_t)base + c) * 128 + L;
     v2d x;
-    if (k < 0 || k >= cnt) { x.x = absent; x.y = absent; o[0] = x; o[64] = x; return; }
-    const int r = T[ST_FIRST] + k;
+    if (!live) { x.x = absent; x.y = absent; o[0] = x; o[64] = x; return; }
+    const int lo = s_lo[L];
+    const bool staged = shape_ok && s_hi[L] - lo <= 32;
     double lv[3] = {absent, absent, absent};
     int bad = 0;
-    const int q0 = Lptr[r], q1 = Lptr[r + 1];
-    if (q1 - q0 < 1 || q1 - q0 > 4 || Lidx[q1 - 1] != r) bad = 1;
+    const int dcol = !shape_ok ? -1 : (staged ? s_idx[L][q1 - 1 - lo] : Lidx[q1 - 1]);
+    if (!shape_ok || dcol != r) bad = 1;
     for (int q = q0; q < q1 - 1 && !bad; ++q) {
-        const int off = Lidx[q] - r;
+        const int col = staged ? s_idx[L][q - lo] : Lidx[q];
+        const int off = col - r;
         int hit = -1;
 #pragma unroll
         for (int j = 0; j < 3; ++j) if (j < T[ST_ND] && T[ST_OFF + j] == off) hit = j;
-        if (hit < 0 || k < T[ST_KLO + hit] || k >= T[ST_KHI + hit]) bad = 1; else lv[hit] = st_clean(Lval[q]);
+        const double vq = staged ? s_val[L][q - lo] : Lval[q];
+        if (hit < 0 || k < T[ST_KLO + hit] || k >= T[ST_KHI + hit]) bad = 1;
+        else { const double cv = st_clean(vq); if (hit == 0) lv[0] = cv; else if (hit == 1) lv[1] = cv; else lv[2] = cv; }
     }
     if (bad) { atomicOr(&flags[0], 8); return; }
     x.x = lv[0]; x.y = lv[1]; o[0] = x;
-    x.x = lv[2]; x.y = st_clean(Lval[q1 - 1]); o[64] = x;
+    x.x = lv[2]; x.y = st_clean(staged ? s_val[L][q1 - 1 - lo] : Lval[q1 - 1]); o[64] = x;
 }
 
 // natural order <-> level-major order of a sweep (64 per chunk), both sides coalesced through an LDS tile of 32 chunks x 64 lanes:
@@ -1286,6 +1314,10 @@ k_st_vec(const int32_t *__restrict__ ltab, const int32_t *__restrict__ wtab, dou
 #undef STV_LOAD
 }
 
+// CSR values AND column indices of a factor from its records.  The eight rows a lane contributes to a group of eight chunks are
+// consecutive rows, i.e. ONE contiguous run of at most 32 entries of val / idx: a thread per (chunk, lane) puts its row's entries into the
+// lane's run in LDS (the records side: 64 lanes x 16 bytes per instruction), then eight threads per lane write the run out in
+// 32-byte pieces -- an instruction covers 8 lanes' runs instead of 64 rows that lie 14 KB apart (256^3, IChol0's L: 1.33 ms before).
 template <int KIND>
 __global__ void __launch_bounds__(512)
 k_st_unpack(const int32_t *__restrict__ ptr, int32_t *__restrict__ idx, double *__restrict__ val, const int32_t *__restrict__ wtab,
@@ -1293,28 +1325,51 @@ k_st_unpack(const int32_t *__restrict__ ptr, int32_t *__restrict__ idx, double *
 {
     constexpr bool FWD = (KIND == SWEEP_FWD_LAST_ASC);
     constexpr int DR = FWD ? 1 : -1;
+    __shared__ double s_val[64][33];
+    __shared__ int s_idx[64][33];
+    __shared__ int s_lo[64], s_hi[64];
     const int w = blockIdx.x;
     const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
     const int L = threadIdx.x & 63;
     const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
-    if (c >= nch) return;
+    if (threadIdx.x < 64) { s_lo[threadIdx.x] = 0x7fffffff; s_hi[threadIdx.x] = -1; }
+    __syncthreads();
     const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
     const int32_t *T = ltab + (size_t)slot * kStTab;
     const int k = tmin + c - T[ST_SKEW];
-    if (k < 0 || k >= T[ST_CNT]) return;
-    const int r = T[ST_FIRST] + DR * k;
-    const int q0 = ptr[r], q1 = ptr[r + 1];
-    // (the backward sweep's records are stored in the forward schedule's order: ysrc = chunk * 64 + lane of the lane's row 0)
-    const int pos = FWD ? 0 : ysrc[slot] - 64 * k;
-    const v2d *p = FWD ? pk + ((size_t)base + c) * 128 + L : pk + (size_t)(pos >> 6) * 128 + (pos & 63);
-    const v2d a = p[0], b = p[64];
-    const double v[3] = {a.x, a.y, b.x};
-    val[FWD ? q1 - 1 : q0] = b.y;
-    idx[FWD ? q1 - 1 : q0] = r;
-    int q = FWD ? q0 : q0 + 1;
+    const bool live = c < nch && k >= 0 && k < T[ST_CNT];
+    const int r = live ? T[ST_FIRST] + DR * k : 0;
+    const int q0 = live ? ptr[r] : 0, q1 = live ? ptr[r + 1] : 0;
+    if (live) { atomicMin(&s_lo[L], q0); atomicMax(&s_hi[L], q1); }
+    __syncthreads();
+    const int lo = s_lo[L];
+    const bool staged = s_hi[L] - lo <= 32;                              // (rows as long as the static form has them: always)
+    if (live) {
+        // (the backward sweep's records are stored in the forward schedule's order: ysrc = chunk * 64 + lane of the lane's row 0)
+        const int pos = FWD ? 0 : ysrc[slot] - 64 * k;
+        const v2d *p = FWD ? pk + ((size_t)base + c) * 128 + L : pk + (size_t)(pos >> 6) * 128 + (pos & 63);
+        const v2d a = p[0], b = p[64];
+        const double v[3] = {a.x, a.y, b.x};
+        const int qd = FWD ? q1 - 1 : q0;                               // the diagonal: last (forward) / first (backward) of the row
+        if (staged) { s_val[L][qd - lo] = b.y; s_idx[L][qd - lo] = r; } else { val[qd] = b.y; idx[qd] = r; }
+        int q = FWD ? q0 : q0 + 1;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (st_bits(v[j]) != kAbsent && q < (FWD ? q1 - 1 : q1)) { val[q] = v[j]; idx[q] = r + T[ST_OFF + j]; ++q; }
+        for (int j = 0; j < 3; ++j)
+            if (st_bits(v[j]) != kAbsent && q < (FWD ? q1 - 1 : q1)) {
+                if (staged) { s_val[L][q - lo] = v[j]; s_idx[L][q - lo] = r + T[ST_OFF + j]; } else { val[q] = v[j]; idx[q] = r + T[ST_OFF + j]; }
+                ++q;
+            }
+    }
+    __syncthreads();
+    {
+        const int L2 = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int lo2 = s_lo[L2], len = s_hi[L2] - lo2;
+        if (len > 0 && len <= 32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * j + e < len) { val[lo2 + 4 * j + e] = s_val[L2][4 * j + e]; idx[lo2 + 4 * j + e] = s_idx[L2][4 * j + e]; }
+        }
+    }
 }
 
 // entries per row of a factor, from its records (the CSR row pointers of the static form are made when somebody asks for them)
