@@ -1858,56 +1858,93 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
 // records are the factors' values.  One thread per (forward lane, row): the row of the forward factor (diagonal last) and the row
 // of the backward factor (diagonal first), each entry matched against the lane's template and its range of rows.
 // ---------------------------------------------------------------------------------------------
+// the runs of eight consecutive rows of 64 lanes (at most 32 entries each) of a CSR matrix into LDS, eight threads per lane (the pass of
+// k_st_pack_lower): q0, q1 = this thread's row; use = the row counts for its lane's run; false for a lane whose run does not fit
+struct StRuns { double val[64][33]; int idx[64][33]; int lo[64], hi[64]; };
+__device__ __forceinline__ void st_stage_runs(StRuns &S, const int32_t *__restrict__ idx, const double *__restrict__ val, const int L,
+                                              const bool use, const int q0, const int q1)
+{
+    if (threadIdx.x < 64) { S.lo[threadIdx.x] = 0x7fffffff; S.hi[threadIdx.x] = -1; }
+    __syncthreads();
+    if (use) { atomicMin(&S.lo[L], q0); atomicMax(&S.hi[L], q1); }
+    __syncthreads();
+    const int L2 = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int lo2 = S.lo[L2], len = S.hi[L2] - lo2;
+    if (len > 0 && len <= 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * j + e < len) { S.val[L2][4 * j + e] = val[lo2 + 4 * j + e]; S.idx[L2][4 * j + e] = idx[lo2 + 4 * j + e]; }
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(512)
 k_st_pack_pair(const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lidx, const double *__restrict__ Lval,
                const int32_t *__restrict__ Uptr, const int32_t *__restrict__ Uidx, const double *__restrict__ Uval,
                const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot,
                const int32_t *__restrict__ wtab, v2d *__restrict__ pkL, v2d *__restrict__ pkU, int32_t *__restrict__ flags)
 {
+    __shared__ StRuns SL, SU;
     const int w = blockIdx.x;
     const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
     const int L = threadIdx.x & 63;
     const int base = wtab[(size_t)w * 4], tmin = wtab[(size_t)w * 4 + 1], nch = wtab[(size_t)w * 4 + 2];
-    if (c >= nch) return;
     const int slot = (w >> 2) * kThreads + (w & 3) * 64 + L;
     const int32_t *T = ltabF + (size_t)slot * kStTab;
     const int k = tmin + c - T[ST_SKEW];
     const int cnt = T[ST_CNT];
-    if (k < 0 || k >= cnt) return;
-    const int su = uslot[slot];
+    const bool live = c < nch && k >= 0 && k < cnt;
+    const int su = live ? uslot[slot] : 0;
+    const int r = live ? T[ST_FIRST] + k : 0;
+    const int q0 = live ? Lptr[r] : 0, q1 = live ? Lptr[r + 1] : 0;
+    const int p0 = live ? Uptr[r] : 0, p1 = live ? Uptr[r + 1] : 0;
+    const bool okL = q1 - q0 >= 1 && q1 - q0 <= 4, okU = p1 - p0 >= 1 && p1 - p0 <= 4;
+    // (the rows of a lane's eight steps are consecutive rows of both factors: one run each)
+    st_stage_runs(SL, Lidx, Lval, L, live && okL, q0, q1);
+    st_stage_runs(SU, Uidx, Uval, L, live && okU, p0, p1);
+    if (!live) return;
     if (su < 0) { atomicOr(&flags[0], 64); return; }
     const int32_t *TB = ltabB + (size_t)su * kStTab;
-    const int r = T[ST_FIRST] + k;
     const double absent = st_dbl(kAbsent);
     double lv[3] = {absent, absent, absent}, uv[3] = {absent, absent, absent};
     int bad = 0;
-    const int q0 = Lptr[r], q1 = Lptr[r + 1];
-    if (q1 - q0 < 1 || q1 - q0 > 4 || Lidx[q1 - 1] != r) bad = 1;
+    const int loL = SL.lo[L], loU = SU.lo[L];
+    const bool stL = okL && SL.hi[L] - loL <= 32, stU = okU && SU.hi[L] - loU <= 32;
+#define LI(q) (stL ? SL.idx[L][(q) - loL] : Lidx[q])
+#define LV(q) (stL ? SL.val[L][(q) - loL] : Lval[q])
+#define UI(q) (stU ? SU.idx[L][(q) - loU] : Uidx[q])
+#define UV(q) (stU ? SU.val[L][(q) - loU] : Uval[q])
+    if (!okL || LI(q1 - 1) != r) bad = 1;
     for (int q = q0; q < q1 - 1 && !bad; ++q) {
-        const int o = Lidx[q] - r;
+        const int o = LI(q) - r;
         int hit = -1;
 #pragma unroll
         for (int j = 0; j < 3; ++j) if (j < T[ST_ND] && T[ST_OFF + j] == o) hit = j;
-        if (hit < 0 || k < T[ST_KLO + hit] || k >= T[ST_KHI + hit]) bad = 1; else lv[hit] = st_clean(Lval[q]);
+        if (hit < 0 || k < T[ST_KLO + hit] || k >= T[ST_KHI + hit]) bad = 1;
+        else { const double cv = st_clean(LV(q)); if (hit == 0) lv[0] = cv; else if (hit == 1) lv[1] = cv; else lv[2] = cv; }
     }
-    const int p0 = Uptr[r], p1 = Uptr[r + 1];
     const int kb = cnt - 1 - k;
-    if (p1 - p0 < 1 || p1 - p0 > 4 || Uidx[p0] != r) bad = 1;
+    if (!okU || UI(p0) != r) bad = 1;
     for (int q = p0 + 1; q < p1 && !bad; ++q) {
-        const int o = Uidx[q] - r;
+        const int o = UI(q) - r;
         int hit = -1;
 #pragma unroll
         for (int j = 0; j < 3; ++j) if (j < TB[ST_ND] && TB[ST_OFF + j] == o) hit = j;
-        if (hit < 0 || kb < TB[ST_KLO + hit] || kb >= TB[ST_KHI + hit]) bad = 1; else uv[hit] = st_clean(Uval[q]);
+        if (hit < 0 || kb < TB[ST_KLO + hit] || kb >= TB[ST_KHI + hit]) bad = 1;
+        else { const double cv = st_clean(UV(q)); if (hit == 0) uv[0] = cv; else if (hit == 1) uv[1] = cv; else uv[2] = cv; }
     }
     if (bad) { atomicOr(&flags[0], 8); return; }
     v2d x;
     v2d *pl_ = pkL + ((size_t)base + c) * 128 + L;
     x.x = lv[0]; x.y = lv[1]; pl_[0] = x;
-    x.x = lv[2]; x.y = st_clean(Lval[q1 - 1]); pl_[64] = x;
+    x.x = lv[2]; x.y = st_clean(LV(q1 - 1)); pl_[64] = x;
     v2d *pu_ = pkU + ((size_t)base + c) * 128 + L;
     x.x = uv[0]; x.y = uv[1]; pu_[0] = x;
-    x.x = uv[2]; x.y = st_clean(Uval[p0]); pu_[64] = x;
+    x.x = uv[2]; x.y = st_clean(UV(p0)); pu_[64] = x;
+#undef LI
+#undef LV
+#undef UI
+#undef UV
 }
 
 bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat &Urow, const Schedule &fwd, const Schedule &bwd,
