@@ -282,7 +282,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     (void)prof;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nL = 0, nU = 0, nK = 0, seq = 0;
-    int seen_done = -1;
+    int seen_done = -1, klast = -1;
     double wdiag = 0.0;
 #ifdef ILUT_PROFILE
     int prof_lvl = 0, prof_parent = -1, prof_lparent = -1, prof_maxl = 0;
@@ -334,13 +334,25 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         // effect on anything, and an entry's value only changes when a smaller column is eliminated -- so every entry left of the
         // next eliminated column has, now, the value it would have when popped: all of them go at once (on C3 78 % of the pops,
         // each a pass over the pool, end this way: 600 passes per row became 134).
+        // ONE pass over the pool per elimination: the minimum over the live entries, and the places of the entries that went with the
+        // previous elimination (column <= klast: popped or forgotten).  Nothing depends on an entry's place in the pool (its order of
+        // insertion is lseq), so those places are filled from the pool's tail instead of moving everything up -- a rewrite of the whole
+        // pool, with two hand-overs per 64 entries, was the larger half of this phase.
         unsigned best = 0x7fffffffu;
-        int bq = -1;
-        for (int q = lane; q < nL; q += 64) {
-            const unsigned c = (unsigned)A::ldi(&w.lcol[q]);
-            const double v = A::ldd(&w.lval[q]);
-            const bool live = v != 0.0 && !(fabs(v) < thr1);
-            if (live && c < best) { best = c; bq = q; }
+        int bq = -1, nd = 0;
+        for (int base = 0; base < nL; base += 64) {
+            const int q = base + lane;
+            const bool valid = q < nL;
+            const int c = valid ? A::ldi(&w.lcol[q]) : 0x7fffffff;
+            const double v = valid ? A::ldd(&w.lval[q]) : 0.0;
+            const bool dead = valid && c <= klast;
+            const unsigned long long md = __ballot(dead);
+            if (md != 0ull) {
+                if (dead) { const int pos = nd + __popcll(md & lt); if (pos < 63) bcol[pos] = q; }
+                nd += __popcll(md);
+            }
+            const bool live = valid && !dead && v != 0.0 && !(fabs(v) < thr1);
+            if (live && (unsigned)c < best) { best = (unsigned)c; bq = q; }
         }
         const unsigned g = wave_min_u32(best);
         if (g == 0x7fffffffu) break;                                         // (what is left would be popped and forgotten)
@@ -350,9 +362,31 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double wkv = A::ldd(&w.lval[qs]);
         const int sk = A::ldi(&w.lseq[qs]);
         A::sync();
-        // the pool keeps the entries right of column k (in place: a chunk's entries are in registers before any of them is written,
-        // and they move to positions at or before their own)
-        {
+        if (nd < 63) {
+            // (the popped entry goes too) the r-th free place below the new end takes the r-th surviving entry behind it
+            if (lane == 0) bcol[nd] = qs;
+            ++nd;
+            const int nLn = nL - nd;
+            __builtin_amdgcn_wave_barrier();
+            const int hq = lane < nd ? bcol[lane] : 0x7fffffff;
+            const bool is_hole = lane < nd && hq < nLn;
+            const int mq = nLn + lane;
+            const int mc = lane < nd ? A::ldi(&w.lcol[mq]) : 0;
+            const bool is_mover = lane < nd && mc > klast && mq != qs;
+            const unsigned long long mh = __ballot(is_hole), mm = __ballot(is_mover);
+            if (is_hole) bfound[__popcll(mh & lt)] = hq;
+            __builtin_amdgcn_wave_barrier();
+            if (is_mover) {
+                const int dst = bfound[__popcll(mm & lt)];
+                const double v = A::ldd(&w.lval[mq]);
+                const int sq = A::ldi(&w.lseq[mq]);
+                A::sti(&w.lcol[dst], mc); A::std_(&w.lval[dst], v); A::sti(&w.lseq[dst], sq);
+            }
+            nL = nLn;
+            A::sync();
+        } else {
+            // (more went than the list holds: the pool keeps the entries right of column k, in place -- a chunk's entries are in
+            // registers before any of them is written, and they move to positions at or before their own)
             int kept = 0;
             for (int base = 0; base < nL; base += 64) {
                 const int q = base + lane;
@@ -369,6 +403,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             }
             nL = kept;
         }
+        klast = k;
         // row k of U, validated against the sentinels
         WP_T(tp1); WP_ACC(0, tp0, tp1);
         const size_t ub = (size_t)k * p;
