@@ -58,11 +58,18 @@ static constexpr int kWpHashG = 1 << 17;
 // (per wave in registers, added to ctrl + 8 once when the wave has no more rows: an atomic per phase and fetch on one address from
 // 5 120 waves made the kernel eight times slower)
 #define WP_ACC(slot, t0, t1) do { prof[slot] += (unsigned long long)((t1) - (t0)); } while (0)
+#ifdef ILUT_PROFILE_SUB
+// (experiments: slots 4 and 5 -- normally the fetch counters -- take the clock of two sub-phases of the update instead)
+#define WP_SUB(which, slot, t0, t1) do { if (ILUT_PROFILE_SUB == (which)) prof[slot] += (unsigned long long)((t1) - (t0)); } while (0)
+#else
+#define WP_SUB(which, slot, t0, t1)
+#endif
 __device__ int *g_wp_lvl, *g_wp_parent, *g_wp_lparent, *g_wp_size;      // size: max pool | U slots << 12 | eliminations << 22 | global pieces << 31
 __device__ long long *g_wp_tfin, *g_wp_tstart, *g_wp_wait;
 #else
 #define WP_T(var)
 #define WP_ACC(slot, t0, t1)
+#define WP_SUB(which, slot, t0, t1)
 #endif
 
 // IdT: the type of a U-slot id and of a left-part sequence number: 16 bits for the LDS pieces and the 64 K global pieces, 32 bits
@@ -140,63 +147,148 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
     using A = WpAcc<G>;
     if (nkeep <= 0) return 0;                                                 // dropping.hpp:11-12
     const unsigned long long lt = (1ull << lane) - 1ull;
-    double z = 0.0;
-#pragma unroll 4
-    for (int q = 0; q < cnt; ++q) { const double v = A::ldd(&vals[q]); const double sq = v * v; z = z + sq; }
-    const double thr = sqrt(z) * tau;
-    int ncand = 0;
-    for (int base = 0; base < cnt; base += 64) {
-        const int q = base + lane;
-        const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
-        ncand += __popcll(__ballot(is));
-    }
     int nsel;
-    if (ncand <= nkeep) {
-        nsel = 0;
+    constexpr int kRC = 16;
+    if (cnt <= 64 * kRC) {
+        // Pieces of up to 1 024 entries (all but a handful of rows) are read ONCE, lane t holding entries t, t + 64, ...: the norm's
+        // ordered sum takes the squares out of the registers lane by lane (same operands, same order as one lane adding them up),
+        // the candidate test and every selection round work on the registers.  Reading the piece again per round -- a trip per 64
+        // entries, a dozen rounds, and the norm a trip per four entries -- was 160 us per row, all of it between a row's last
+        // elimination and its publication.
+        double vr[kRC];
+#pragma unroll
+        for (int u = 0; u < kRC; ++u) { const int q = 64 * u + lane; vr[u] = q < cnt ? A::ldd(&vals[q]) : 0.0; }
+        double z = 0.0;
+#pragma unroll
+        for (int u = 0; u < kRC; ++u) {
+            if (64 * u < cnt) {
+                const double sq = vr[u] * vr[u];
+                const long long sb = __double_as_longlong(sq);
+                const int rem = cnt - 64 * u < 64 ? cnt - 64 * u : 64;
+                for (int l = 0; l < rem; ++l) {
+                    const int lo = __builtin_amdgcn_readlane((int)sb, l), hi = __builtin_amdgcn_readlane((int)(sb >> 32), l);
+                    z = z + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+                }
+            }
+        }
+        const double thr = sqrt(z) * tau;
+        unsigned long long mbr[kRC];
+        int ncand = 0;
+#pragma unroll
+        for (int u = 0; u < kRC; ++u) {
+            const double a = fabs(vr[u]);
+            const bool is = 64 * u + lane < cnt && a > thr;
+            mbr[u] = is ? (unsigned long long)__double_as_longlong(a) : 0ull;
+            if (64 * u < cnt) ncand += __popcll(__ballot(is));
+        }
+        if (ncand <= nkeep) {
+            nsel = 0;
+#pragma unroll
+            for (int u = 0; u < kRC; ++u) {
+                if (64 * u < cnt) {
+                    const bool is = mbr[u] != 0ull;
+                    const unsigned long long m = __ballot(is);
+                    if (is) selq[nsel + __popcll(m & lt)] = 64 * u + lane;
+                    nsel += __popcll(m);
+                }
+            }
+        } else {
+            unsigned long long pm = ~0ull;
+            int pp = -1;
+            bool tie = false;
+            for (int t = 0; t <= nkeep; ++t) {          // the extra round finds the first entry NOT kept (tie test)
+                unsigned long long bm = 0ull;
+                unsigned bq = 0x7fffffffu;
+#pragma unroll
+                for (int u = 0; u < kRC; ++u) {
+                    const unsigned long long mb = mbr[u];
+                    const int q = 64 * u + lane;
+                    const bool after = mb < pm || (mb == pm && q > pp);
+                    if (mb != 0ull && after && mb > bm) { bm = mb; bq = (unsigned)q; }
+                }
+                const unsigned long long gm = wave_max_u64(bm);
+                const unsigned gq = wave_min_u32(bm == gm ? bq : 0x7fffffffu);
+                if (t < nkeep) { if (lane == 0) selq[t] = (int)gq; }
+                else tie = gm == pm;
+                pm = gm; pp = (int)gq;
+            }
+            nsel = nkeep;
+            if (tie && ncand > 16) {
+                // equal magnitudes across the cut: the kept set is what libstdc++'s introsort leaves in front (stdsort.h)
+                int c = 0;
+                for (int base = 0; base < cnt; base += 64) {
+                    const int q = base + lane;
+                    const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
+                    const unsigned long long m = __ballot(is);
+                    if (is) gscratch[c + __popcll(m & lt)] = q;
+                    c += __popcll(m);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane == 0) {
+                    c_sort_slots_by_abs_desc(gscratch, ncand, vals);
+                    for (int t = 0; t < nkeep; ++t) selq[t] = gscratch[t];
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+        }
+    } else {
+        double z = 0.0;
+    #pragma unroll 4
+        for (int q = 0; q < cnt; ++q) { const double v = A::ldd(&vals[q]); const double sq = v * v; z = z + sq; }
+        const double thr = sqrt(z) * tau;
+        int ncand = 0;
         for (int base = 0; base < cnt; base += 64) {
             const int q = base + lane;
             const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
-            const unsigned long long m = __ballot(is);
-            if (is) selq[nsel + __popcll(m & lt)] = q;
-            nsel += __popcll(m);
+            ncand += __popcll(__ballot(is));
         }
-    } else {
-        unsigned long long pm = ~0ull;
-        int pp = -1;
-        bool tie = false;
-        for (int t = 0; t <= nkeep; ++t) {          // the extra round finds the first entry NOT kept (tie test)
-            unsigned long long bm = 0ull;
-            unsigned bq = 0x7fffffffu;
-            for (int q = lane; q < cnt; q += 64) {
-                const double a = fabs(A::ldd(&vals[q]));
-                if (!(a > thr)) continue;
-                const unsigned long long mb = (unsigned long long)__double_as_longlong(a);
-                const bool after = mb < pm || (mb == pm && q > pp);
-                if (after && mb > bm) { bm = mb; bq = (unsigned)q; }
-            }
-            const unsigned long long gm = wave_max_u64(bm);
-            const unsigned gq = wave_min_u32(bm == gm ? bq : 0x7fffffffu);
-            if (t < nkeep) { if (lane == 0) selq[t] = (int)gq; }
-            else tie = gm == pm;
-            pm = gm; pp = (int)gq;
-        }
-        nsel = nkeep;
-        if (tie && ncand > 16) {
-            // equal magnitudes across the cut: the kept set is what libstdc++'s introsort leaves in front (stdsort.h)
-            int c = 0;
+        if (ncand <= nkeep) {
+            nsel = 0;
             for (int base = 0; base < cnt; base += 64) {
                 const int q = base + lane;
                 const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
                 const unsigned long long m = __ballot(is);
-                if (is) gscratch[c + __popcll(m & lt)] = q;
-                c += __popcll(m);
+                if (is) selq[nsel + __popcll(m & lt)] = q;
+                nsel += __popcll(m);
             }
-            __builtin_amdgcn_s_waitcnt(0);
-            if (lane == 0) {
-                c_sort_slots_by_abs_desc(gscratch, ncand, vals);
-                for (int t = 0; t < nkeep; ++t) selq[t] = gscratch[t];
+        } else {
+            unsigned long long pm = ~0ull;
+            int pp = -1;
+            bool tie = false;
+            for (int t = 0; t <= nkeep; ++t) {          // the extra round finds the first entry NOT kept (tie test)
+                unsigned long long bm = 0ull;
+                unsigned bq = 0x7fffffffu;
+                for (int q = lane; q < cnt; q += 64) {
+                    const double a = fabs(A::ldd(&vals[q]));
+                    if (!(a > thr)) continue;
+                    const unsigned long long mb = (unsigned long long)__double_as_longlong(a);
+                    const bool after = mb < pm || (mb == pm && q > pp);
+                    if (after && mb > bm) { bm = mb; bq = (unsigned)q; }
+                }
+                const unsigned long long gm = wave_max_u64(bm);
+                const unsigned gq = wave_min_u32(bm == gm ? bq : 0x7fffffffu);
+                if (t < nkeep) { if (lane == 0) selq[t] = (int)gq; }
+                else tie = gm == pm;
+                pm = gm; pp = (int)gq;
             }
-            __builtin_amdgcn_s_waitcnt(0);
+            nsel = nkeep;
+            if (tie && ncand > 16) {
+                // equal magnitudes across the cut: the kept set is what libstdc++'s introsort leaves in front (stdsort.h)
+                int c = 0;
+                for (int base = 0; base < cnt; base += 64) {
+                    const int q = base + lane;
+                    const bool is = q < cnt && fabs(A::ldd(&vals[q])) > thr;
+                    const unsigned long long m = __ballot(is);
+                    if (is) gscratch[c + __popcll(m & lt)] = q;
+                    c += __popcll(m);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane == 0) {
+                    c_sort_slots_by_abs_desc(gscratch, ncand, vals);
+                    for (int t = 0; t < nkeep; ++t) selq[t] = gscratch[t];
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+            }
         }
     }
     if constexpr (SELG) __builtin_amdgcn_s_waitcnt(0);
@@ -233,23 +325,41 @@ __device__ __forceinline__ int wp_uh_find(const WpArraysT<IdT> &w, int c)
         h = (h + 1) & (unsigned)w.hmask;
     }
 }
-// all lanes with `mine` insert their (distinct) columns at once: everybody walks to an empty cell and writes; where two
-// lanes picked the same cell one of the writes survives, the other lane sees a foreign value and walks on
+// the same walk that also brings the slot's value (asked for together with its column: one trip instead of two)
+template <bool G, typename IdT>
+__device__ __forceinline__ int wp_uh_find_val(const WpArraysT<IdT> &w, int c, double &val)
+{
+    unsigned h = wp_hash(c, w.hmask);
+    for (;;) {
+        const unsigned e = w.uh[h];
+        if (e == 0u) return -1;
+        const int cc = WpAcc<G>::ldi(&w.ucol[e - 1]);
+        const double v = WpAcc<G>::ldd(&w.uval[e - 1]);
+        if (cc == c) { val = v; return (int)e - 1; }
+        h = (h + 1) & (unsigned)w.hmask;
+    }
+}
+// all lanes with `mine` insert their (distinct) columns at once: everybody walks to an empty cell; where two lanes stand at the same
+// cell the lower lane takes it (found by comparing the cells inside the wave -- reading the cell back was two more trips to the
+// table) and the other walks on once the winners' writes have landed
 template <bool G, typename IdT>
 __device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool mine, int c, int slot)
 {
     unsigned h = wp_hash(c, w.hmask);
     bool pending = mine;
-    while (__ballot(pending) != 0ull) {
-        if (pending) {
-            while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask;
-            w.uh[h] = (IdT)(slot + 1);
+    unsigned long long pm;
+    while ((pm = __ballot(pending)) != 0ull) {
+        if (pending) { while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask; }
+        bool lose = false;
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        for (unsigned long long m = pm; m != 0ull; m &= m - 1ull) {
+            const int l = __ffsll((long long)m) - 1;
+            const unsigned hh = (unsigned)__builtin_amdgcn_readlane((int)h, l);
+            lose = lose || (l < lane && hh == h);
         }
+        if (pending && !lose) { w.uh[h] = (IdT)(slot + 1); pending = false; }
         WpAcc<G>::sync();
-        if (pending) {
-            if (w.uh[h] == (IdT)(slot + 1)) pending = false;
-            else h = (h + 1) & (unsigned)w.hmask;
-        }
+        if (pending) h = (h + 1) & (unsigned)w.hmask;
     }
 }
 
@@ -340,20 +450,34 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         // pool, with two hand-overs per 64 entries, was the larger half of this phase.
         unsigned best = 0x7fffffffu;
         int bq = -1, nd = 0;
-        for (int base = 0; base < nL; base += 64) {
-            const int q = base + lane;
-            const bool valid = q < nL;
-            const int c = valid ? A::ldi(&w.lcol[q]) : 0x7fffffff;
-            const double v = valid ? A::ldd(&w.lval[q]) : 0.0;
-            const bool dead = valid && c <= klast;
-            const unsigned long long md = __ballot(dead);
-            if (md != 0ull) {
-                if (dead) { const int pos = nd + __popcll(md & lt); if (pos < 63) bcol[pos] = q; }
-                nd += __popcll(md);
+        // (four chunks of 64 entries are asked for together: a chunk per trip was most of this pass -- the pool is reached by flat
+        // or global loads, 200 cycles and more each)
+        for (int base = 0; base < nL; base += 256) {
+            int c4[4];
+            double v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = base + 64 * u + lane;
+                c4[u] = q < nL ? A::ldi(&w.lcol[q]) : 0x7fffffff;
+                v4[u] = q < nL ? A::ldd(&w.lval[q]) : 0.0;
             }
-            const bool live = valid && !dead && v != 0.0 && !(fabs(v) < thr1);
-            if (live && (unsigned)c < best) { best = (unsigned)c; bq = q; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = base + 64 * u + lane;
+                const bool valid = q < nL;
+                const int c = c4[u];
+                const double v = v4[u];
+                const bool dead = valid && c <= klast;
+                const unsigned long long md = __ballot(dead);
+                if (md != 0ull) {
+                    if (dead) { const int pos = nd + __popcll(md & lt); if (pos < 63) bcol[pos] = q; }
+                    nd += __popcll(md);
+                }
+                const bool live = valid && !dead && v != 0.0 && !(fabs(v) < thr1);
+                if (live && (unsigned)c < best) { best = (unsigned)c; bq = q; }
+            }
         }
+        WP_T(tpa); WP_SUB(2, 5, tp0, tpa);
         const unsigned g = wave_min_u32(best);
         if (g == 0x7fffffffu) break;                                         // (what is left would be popped and forgotten)
         const unsigned long long who = __ballot(best == g);
@@ -425,7 +549,9 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             __builtin_amdgcn_s_sleep(1);
         }
 #ifdef ILUT_PROFILE
+#ifndef ILUT_PROFILE_SUB
         prof[4] += spins; prof[5] += 1ull;
+#endif
 #endif
         ul = __builtin_amdgcn_readfirstlane(ul);
         WP_T(tp2); WP_ACC(1, tp1, tp2);
@@ -442,6 +568,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         if (lane == 0) { w.kcol[nK] = k; w.kval[nK] = m; w.kseq[nK] = (IdT)sk; }
         ++nK;
         for (int base = 0; base < ul; base += 64) {                          // w -= m * U[k, j>k]  (:252-253)
+            WP_T(tu0);
             const int j = base + lane;
             int c = c0;
             unsigned long long vb = v0;
@@ -465,6 +592,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             bfound[lane] = 0;
             __builtin_amdgcn_wave_barrier();
             const int bmin = bcol[0], bmax = bcol[cnt - 1];
+            WP_T(tu1); WP_SUB(1, 4, tu0, tu1);
             if (cnt <= 16) {
                 // the usual case (p <= 16): the U row's columns sit in 16 scalars and every slot is compared against all of
                 // them -- a binary search per slot is a chain of dependent LDS reads that the whole wave pays for as soon
@@ -473,15 +601,16 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) bc[jj] = __builtin_amdgcn_readfirstlane(jj < cnt ? bcol[jj] : -1);
 #define WP_MATCH(c2, m) do { _Pragma("unroll") for (int jj = 0; jj < 16; ++jj) m = (c2) == bc[jj] ? jj : m; } while (0)
-                for (int q = lane; q < nL; q += 128) {
-                    const int q1 = q + 64;
-                    const int ca = A::ldi(&w.lcol[q]);
-                    const int cb = q1 < nL ? A::ldi(&w.lcol[q1]) : -2;
-                    int ma = -1, mb = -1;
-                    WP_MATCH(ca, ma);
-                    WP_MATCH(cb, mb);
-                    if (ma >= 0) { const double o = A::ldd(&w.lval[q]); A::std_(&w.lval[q], o - bpr[ma]); bfound[ma] = 1; }
-                    if (mb >= 0) { const double o = A::ldd(&w.lval[q1]); A::std_(&w.lval[q1], o - bpr[mb]); bfound[mb] = 1; }
+                for (int q0 = lane; q0 < nL; q0 += 256) {
+                    int cq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cq[u] = q0 + 64 * u < nL ? A::ldi(&w.lcol[q0 + 64 * u]) : -2;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int ma = -1;
+                        WP_MATCH(cq[u], ma);
+                        if (ma >= 0) { const int q = q0 + 64 * u; const double o = A::ldd(&w.lval[q]); A::std_(&w.lval[q], o - bpr[ma]); bfound[ma] = 1; }
+                    }
                 }
 #undef WP_MATCH
             } else {
@@ -495,12 +624,14 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             }
             }
             // right of the diagonal: the entry's own lane looks its column up in the hash (the reference's occupancy[] access)
+            WP_T(tu2); WP_SUB(1, 5, tu1, tu2);
             bool ufound = false;
             if (valid && c > i) {
-                const int us = wp_uh_find<G, IdT>(w, c);
-                if (us >= 0) { const double o = A::ldd(&w.uval[us]); A::std_(&w.uval[us], o - pr); ufound = true; }
+                double o;
+                const int us = wp_uh_find_val<G, IdT>(w, c, o);
+                if (us >= 0) { A::std_(&w.uval[us], o - pr); ufound = true; }
             }
-            WP_T(ts1);
+            WP_T(ts1); WP_SUB(2, 4, tu2, ts1);
             const unsigned long long md = __ballot(valid && c == i);
             if (md != 0ull) wdiag = wdiag - wave_bcast_f64(pr, __ffsll((long long)md) - 1);
             A::sync();
@@ -520,25 +651,11 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         WP_T(tp3); WP_ACC(2, tp2, tp3);
     }
     WP_T(tq0);
-    // (10.) dropping (ILUT.hpp:259,261): the multipliers back in insertion order (the pool is empty now: its arrays take
-    // them), then both pieces
+    // (10.-12.) dropping (ILUT.hpp:259,261).  The U row FIRST: it is what other rows wait for; the L row is nobody's dependency and is
+    // selected behind the publication (the capacity test of its staging comes before anything is published)
     if (nK > w.capL) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int q = lane; q < nK; q += 64) A::sti(&w.lseq[q], (int)w.kseq[q]);
-    A::sync();
-    for (int q = lane; q < nK; q += 64) {
-        const int s = A::ldi(&w.lseq[q]);
-        int r = 0;
-        for (int q2 = 0; q2 < nK; ++q2) r += (A::ldi(&w.lseq[q2]) < s) ? 1 : 0;
-        A::sti(&w.lcol[r], w.kcol[q]);
-        A::std_(&w.lval[r], w.kval[q]);
-    }
-    A::sync();
     const size_t lb = (size_t)i * p;
-    // (11.) L row = kept entries then (i, 1.0)
-    const int nLk = wp_select<G, false, SELG>(lane, w.lcol, w.lval, nK, p - 1, tau, selq, gscratch, Lrow_idx + lb, Lrow_val + lb);
-    if (lane == 0) { Lrow_idx[lb + nLk] = i; Lrow_val[lb + nLk] = 1.0; Llen[i] = nLk + 1; }
-    A::sync();
+    __builtin_amdgcn_s_waitcnt(0);
     // (12.) U row = (i, w[i]) then kept entries; every datum write-through, the length last is not required
     const int nUk = wp_select<G, true, SELG>(lane, w.ucol, w.uval, nU, p - 1, tau, selq, gscratch, Urow_idx + lb + 1, Urow_val + lb + 1);
     if (lane == 0) {
@@ -556,6 +673,21 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         st_agent_i32(&Ulen[i], nUk + 1);
         atomicAdd(&ctrl[7], 1);                                                  // rows finished (what a waiting wave watches)
     }
+    A::sync();
+    // (10.) the multipliers back in insertion order (the pool is empty now: its arrays take them)
+    for (int q = lane; q < nK; q += 64) A::sti(&w.lseq[q], (int)w.kseq[q]);
+    A::sync();
+    for (int q = lane; q < nK; q += 64) {
+        const int s = A::ldi(&w.lseq[q]);
+        int r = 0;
+        for (int q2 = 0; q2 < nK; ++q2) r += (A::ldi(&w.lseq[q2]) < s) ? 1 : 0;
+        A::sti(&w.lcol[r], w.kcol[q]);
+        A::std_(&w.lval[r], w.kval[q]);
+    }
+    A::sync();
+    // (11.) L row = kept entries then (i, 1.0)
+    const int nLk = wp_select<G, false, SELG>(lane, w.lcol, w.lval, nK, p - 1, tau, selq, gscratch, Lrow_idx + lb, Lrow_val + lb);
+    if (lane == 0) { Lrow_idx[lb + nLk] = i; Lrow_val[lb + nLk] = 1.0; Llen[i] = nLk + 1; }
     A::sync();
     wp_uh_clear<G, IdT>(w, lane, nU, gscratch);
     WP_T(tq1); WP_ACC(3, tq0, tq1);
