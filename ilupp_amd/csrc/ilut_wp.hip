@@ -363,7 +363,17 @@ __device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool m
     }
 }
 
-// one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout
+// a row between two eliminations (wp_row's alt_*: returned with 3, taken up again by the next call)
+struct WpResume {
+    int active, nL, nU, nK, seq, klast;
+    double wdiag, thr1;
+#ifdef ILUT_PROFILE
+    int lvl, parent, lparent, maxl;
+    long long wait, t0;
+#endif
+};
+
+// one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout, 3 = the pool moved (see alt_*)
 // this row's cells of the wave's table in global memory: found first (nothing is removed while anybody still walks), then emptied
 template <bool G, typename IdT>
 __device__ __forceinline__ void wp_uh_clear(const WpArraysT<IdT> &w, const int lane, const int nU, int *gscratch)
@@ -386,19 +396,50 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                                       int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
                                       int32_t *Urow_idx, double *Urow_val, int32_t *Ulen,
                                       const WpArraysT<IdT> w, int *bcol, double *bpr, int *bfound, int *selq, int *gscratch, int32_t *ctrl,
-                                      unsigned long long *prof = nullptr)
+                                      unsigned long long *prof = nullptr, WpResume *rs = nullptr, int *alt_lcol = nullptr,
+                                      double *alt_lval = nullptr, IdT *alt_lseq = nullptr, int alt_capL = 0)
 {
     using A = WpAcc<G>;
     (void)prof;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nL = 0, nU = 0, nK = 0, seq = 0;
     int seen_done = -1, klast = -1;
-    double wdiag = 0.0;
+    double wdiag = 0.0, thr1 = 0.0;
 #ifdef ILUT_PROFILE
     int prof_lvl = 0, prof_parent = -1, prof_lparent = -1, prof_maxl = 0;
     long long prof_wait = 0;
-    const long long prof_t0 = wall_clock64();
+    long long prof_t0 = wall_clock64();
 #endif
+    // alt_*: a second, larger home for the pool (the wave's global arrays, for the tier with the pool in LDS: the U part, its hash and
+    // the kept list are the same arrays in both).  A row whose pool is about to outgrow its home copies it there BETWEEN two
+    // eliminations and returns 3; the caller goes on with the row (rs) on the other arrays instead of starting again from A's row --
+    // such a row is a long one, and on the chain of deepest dependencies its second start was the longest link of all.
+    const bool resume = rs != nullptr && rs->active != 0;
+    if (resume) {
+        nL = rs->nL; nU = rs->nU; nK = rs->nK; seq = rs->seq; klast = rs->klast; wdiag = rs->wdiag; thr1 = rs->thr1;
+#ifdef ILUT_PROFILE
+        prof_lvl = rs->lvl; prof_parent = rs->parent; prof_lparent = rs->lparent; prof_maxl = rs->maxl; prof_wait = rs->wait; prof_t0 = rs->t0;
+#endif
+    }
+#define WP_MOVE_POOL()                                                                                                  \
+    do {                                                                                                                \
+        for (int q = lane; q < nL; q += 64) {                                                                           \
+            const int c2 = A::ldi(&w.lcol[q]);                                                                          \
+            const double v2 = A::ldd(&w.lval[q]);                                                                       \
+            const int s2 = A::ldi(&w.lseq[q]);                                                                          \
+            alt_lcol[q] = c2; alt_lval[q] = v2; A::sti(&alt_lseq[q], s2);                                               \
+        }                                                                                                               \
+        A::sync();                                                                                                      \
+        rs->active = 1; rs->nL = nL; rs->nU = nU; rs->nK = nK; rs->seq = seq; rs->klast = klast; rs->wdiag = wdiag; rs->thr1 = thr1; \
+        WP_MOVE_PROF();                                                                                                 \
+        return 3;                                                                                                       \
+    } while (0)
+#ifdef ILUT_PROFILE
+#define WP_MOVE_PROF() do { rs->lvl = prof_lvl; rs->parent = prof_parent; rs->lparent = prof_lparent; rs->maxl = prof_maxl; rs->wait = prof_wait; rs->t0 = prof_t0; } while (0)
+#else
+#define WP_MOVE_PROF() do { } while (0)
+#endif
+    if (!resume) {
     // the U-slot hash starts empty: the LDS table is cleared here; the wave's table in global memory (256 KB and more) is empty between
     // rows -- the host clears it once, every row takes its own cells out again when it is done (clearing all of it per row wrote
     // 190 GB on C3: three rows of four work there)
@@ -426,19 +467,21 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
     }
     A::sync();
-    double thr1;
     {
         double z = 0.0;
         for (int q = 0; q < nL; ++q) { const double v = A::ldd(&w.lval[q]); const double sq = v * v; z = z + sq; }
         thr1 = tau * sqrt(z);
     }
     WP_ACC(7, prof_t0, wall_clock64());
+    }
     // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
     for (;;) {
         WP_T(tp0);
 #ifdef ILUT_PROFILE
         prof_maxl = nL > prof_maxl ? nL : prof_maxl;
 #endif
+        // (an elimination appends at most p - 1 entries -- a U row has p at most)
+        if (G && alt_lcol != nullptr && nL + p > w.capL && nL + p <= alt_capL) WP_MOVE_POOL();
         // The next column that is ELIMINATED: the smallest one whose entry is neither zero (ILUT.hpp:239-240) nor below the stage-1
         // threshold (:244-245).  The reference pops every column in ascending order and forgets those; a forgotten entry has no
         // effect on anything, and an entry's value only changes when a smaller column is eliminated -- so every entry left of the
@@ -653,6 +696,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     WP_T(tq0);
     // (10.-12.) dropping (ILUT.hpp:259,261).  The U row FIRST: it is what other rows wait for; the L row is nobody's dependency and is
     // selected behind the publication (the capacity test of its staging comes before anything is published)
+    if (G && alt_lcol != nullptr && nK > w.capL && nK <= alt_capL) { nL = 0; WP_MOVE_POOL(); }      // (the pool is empty: only its home changes)
     if (nK > w.capL) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
     const size_t lb = (size_t)i * p;
     __builtin_amdgcn_s_waitcnt(0);
@@ -696,8 +740,13 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
 
 // ctrl: [0] next row, [1] error (1 timeout, 3 capacity -> the host runs the largest capacity class), [2] smallest row with a zero pivot,
 // [3..6] statistics, [7] rows finished
+// (four waves per SIMD -- 128 VGPRs -- is what the launch of 16 waves per CU counts on; left alone the compiler took 156-169 registers for the
+// scalars it spills into vector registers and three or two waves were resident: 370 -> 309 ms on C3.  The class with 16 KB of LDS per wave
+// holds 10 waves per CU anyway and keeps its registers: that is the remark silenced here)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
 template <int kWpCapU, int kWpHashLds>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                int32_t p, double tau, WpArrays gw, int *gscratch_all,
                int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
@@ -746,21 +795,25 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= n) break;
         // (starting every row in tier 2 costs the same as trying tier 1 first: 494 against 496 ms on C3)
+        WpResume rs;
+        rs.active = 0;
         int rc = wp_row<false>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
                                lw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc == 1 && tier2) {
             if (lane == 0) atomicAdd(&ctrl[3], 1);          // statistics: rows that outgrew tier 1
             rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                              hw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
+                              hw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof, &rs, g.lcol, g.lval, g.lseq, gw.capL);
             rc = __builtin_amdgcn_readfirstlane(rc);
-            if (rc == 1 && lane == 0) atomicAdd(&ctrl[24], 1);      // ... and tier 2
+            if ((rc == 1 || rc == 3) && lane == 0) atomicAdd(&ctrl[24], 1);      // ... and tier 2
         } else if (rc == 1) {
             if (lane == 0) atomicAdd(&ctrl[3], 1);
         }
-        if (rc == 1) {
+        if (rc == 1 || rc == 3) {
+            // (3: the row goes on where it was, its pool in the global arrays now)
+            if (rc == 1) rs.active = 0;
             rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                              g, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
+                              g, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof, &rs);
             rc = __builtin_amdgcn_readfirstlane(rc);
         }
         if (rc != 0) {
@@ -782,6 +835,8 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
         for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 8) + q, prof[q]);
 #endif
 }
+
+#pragma clang diagnostic pop
 
 // the largest capacity class: every piece as long as the matrix is wide, 32-bit slot ids and sequence numbers, the selection
 // queue in global memory too (budgets beyond kWpSel) -- rows of any length and any fill budget, on a few waves
