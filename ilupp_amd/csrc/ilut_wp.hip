@@ -395,7 +395,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                                       const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                                       int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
                                       int32_t *Urow_idx, double *Urow_val, int32_t *Ulen,
-                                      const WpArraysT<IdT> w, int *bcol, double *bpr, int *bfound, int *selq, int *gscratch, int32_t *ctrl,
+                                      const WpArraysT<IdT> w, int *bcol, double *bpr, int *bfound, int *dlist, int *selq, int *gscratch, int32_t *ctrl,
                                       unsigned long long *prof = nullptr, WpResume *rs = nullptr, int *alt_lcol = nullptr,
                                       double *alt_lval = nullptr, IdT *alt_lseq = nullptr, int alt_capL = 0)
 {
@@ -475,6 +475,44 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     WP_ACC(7, prof_t0, wall_clock64());
     }
     // (3.-9.) eliminate in ascending column order (ILUT.hpp:234-255)
+    unsigned best = 0x7fffffffu;
+    int bq = -1, nd = 0;
+    bool have = false;
+    int bc[16];
+    // one pass over the pool: every lane's smallest live column (best, at bq), the places of the entries that went with the last
+    // elimination (column <= klast: dlist, nd of them) and, for N > 0, the update with the U row at hand (columns bc[1..N), products bpr).
+    // Four chunks of 64 entries are asked for together: a chunk per trip was most of such a pass -- the pool is reached by flat or
+    // global loads, 200 cycles and more each.
+#define WP_SCAN(N)                                                                                                      \
+    best = 0x7fffffffu; bq = -1; nd = 0;                                                                                \
+    for (int base_ = 0; base_ < nL; base_ += 256) {                                                                     \
+        int c4[4];                                                                                                      \
+        double v4[4];                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                 \
+            const int q = base_ + 64 * u + lane;                                                                        \
+            c4[u] = q < nL ? A::ldi(&w.lcol[q]) : 0x7fffffff;                                                           \
+            v4[u] = q < nL ? A::ldd(&w.lval[q]) : 0.0;                                                                  \
+        }                                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                 \
+            const int q = base_ + 64 * u + lane;                                                                        \
+            const bool valid = q < nL;                                                                                  \
+            const int c_ = c4[u];                                                                                       \
+            double v_ = v4[u];                                                                                          \
+            if ((N) > 0) {                                                                                              \
+                int ma = -1;                                                                                            \
+                _Pragma("unroll") for (int jj = 1; jj < ((N) > 0 ? (N) : 1); ++jj) ma = c_ == bc[jj] ? jj : ma;         \
+                if (ma >= 0) { v_ = v_ - bpr[ma]; A::std_(&w.lval[q], v_); bfound[ma] = 1; }                           \
+            }                                                                                                           \
+            const bool dead = valid && c_ <= klast;                                                                     \
+            const unsigned long long md = __ballot(dead);                                                               \
+            if (md != 0ull) {                                                                                           \
+                if (dead) { const int pos = nd + __popcll(md & lt); if (pos < 63) dlist[pos] = q; }                     \
+                nd += __popcll(md);                                                                                     \
+            }                                                                                                           \
+            const bool live = valid && !dead && v_ != 0.0 && !(fabs(v_) < thr1);                                        \
+            if (live && (unsigned)c_ < best) { best = (unsigned)c_; bq = q; }                                           \
+        }                                                                                                               \
+    }
     for (;;) {
         WP_T(tp0);
 #ifdef ILUT_PROFILE
@@ -491,35 +529,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         // previous elimination (column <= klast: popped or forgotten).  Nothing depends on an entry's place in the pool (its order of
         // insertion is lseq), so those places are filled from the pool's tail instead of moving everything up -- a rewrite of the whole
         // pool, with two hand-overs per 64 entries, was the larger half of this phase.
-        unsigned best = 0x7fffffffu;
-        int bq = -1, nd = 0;
-        // (four chunks of 64 entries are asked for together: a chunk per trip was most of this pass -- the pool is reached by flat
-        // or global loads, 200 cycles and more each)
-        for (int base = 0; base < nL; base += 256) {
-            int c4[4];
-            double v4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = base + 64 * u + lane;
-                c4[u] = q < nL ? A::ldi(&w.lcol[q]) : 0x7fffffff;
-                v4[u] = q < nL ? A::ldd(&w.lval[q]) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = base + 64 * u + lane;
-                const bool valid = q < nL;
-                const int c = c4[u];
-                const double v = v4[u];
-                const bool dead = valid && c <= klast;
-                const unsigned long long md = __ballot(dead);
-                if (md != 0ull) {
-                    if (dead) { const int pos = nd + __popcll(md & lt); if (pos < 63) bcol[pos] = q; }
-                    nd += __popcll(md);
-                }
-                const bool live = valid && !dead && v != 0.0 && !(fabs(v) < thr1);
-                if (live && (unsigned)c < best) { best = (unsigned)c; bq = q; }
-            }
-        }
+        // The pass that updates the pool with a U row (WP_SCAN(N > 0), below) does this pass's work for the NEXT elimination on the way
+        // -- it has every entry's column and new value in hand -- and the entries appended behind it join in: `have`.
+        if (!have) { WP_SCAN(0) }
+        have = false;
         WP_T(tpa); WP_SUB(2, 5, tp0, tpa);
         const unsigned g = wave_min_u32(best);
         if (g == 0x7fffffffu) break;                                         // (what is left would be popped and forgotten)
@@ -531,11 +544,11 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         A::sync();
         if (nd < 63) {
             // (the popped entry goes too) the r-th free place below the new end takes the r-th surviving entry behind it
-            if (lane == 0) bcol[nd] = qs;
+            if (lane == 0) dlist[nd] = qs;
             ++nd;
             const int nLn = nL - nd;
             __builtin_amdgcn_wave_barrier();
-            const int hq = lane < nd ? bcol[lane] : 0x7fffffff;
+            const int hq = lane < nd ? dlist[lane] : 0x7fffffff;
             const bool is_hole = lane < nd && hq < nLn;
             const int mq = nLn + lane;
             const int mc = lane < nd ? A::ldi(&w.lcol[mq]) : 0;
@@ -636,26 +649,19 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             __builtin_amdgcn_wave_barrier();
             const int bmin = bcol[0], bmax = bcol[cnt - 1];
             WP_T(tu1); WP_SUB(1, 4, tu0, tu1);
-            if (cnt <= 16) {
-                // the usual case (p <= 16): the U row's columns sit in 16 scalars and every slot is compared against all of
-                // them -- a binary search per slot is a chain of dependent LDS reads that the whole wave pays for as soon
-                // as one lane's slot lies in [bmin, bmax], i.e. always (it was 5-6 us per U row, 3/4 of a row's time)
-                int bc[16];
+            if (cnt <= 16 && base == 0) {
+                // the usual case (p <= 16): the U row's columns sit in scalars and every slot is compared against them -- a binary
+                // search per slot is a chain of dependent LDS reads that the whole wave pays for as soon as one lane's slot lies in
+                // [bmin, bmax], i.e. always (it was 5-6 us per U row, 3/4 of a row's time).  Only the columns LEFT of the diagonal
+                // can be in the pool -- the first cntL of the ascending row, its own diagonal entry (column k, popped) aside: rows
+                // eliminated late have few of those or none, and the pass over the pool is as long as that number asks for.
+                const int cntL = __popcll(__ballot(j < ul && c < i));
+                if (cntL > 1) {
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) bc[jj] = __builtin_amdgcn_readfirstlane(jj < cnt ? bcol[jj] : -1);
-#define WP_MATCH(c2, m) do { _Pragma("unroll") for (int jj = 0; jj < 16; ++jj) m = (c2) == bc[jj] ? jj : m; } while (0)
-                for (int q0 = lane; q0 < nL; q0 += 256) {
-                    int cq[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) cq[u] = q0 + 64 * u < nL ? A::ldi(&w.lcol[q0 + 64 * u]) : -2;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int ma = -1;
-                        WP_MATCH(cq[u], ma);
-                        if (ma >= 0) { const int q = q0 + 64 * u; const double o = A::ldd(&w.lval[q]); A::std_(&w.lval[q], o - bpr[ma]); bfound[ma] = 1; }
-                    }
+                    for (int jj = 1; jj < 16; ++jj) bc[jj] = __builtin_amdgcn_readfirstlane(jj < cntL ? bcol[jj] : -1);
+                    if (cntL <= 4) { WP_SCAN(4) } else if (cntL <= 8) { WP_SCAN(8) } else { WP_SCAN(16) }
+                    have = true;
                 }
-#undef WP_MATCH
             } else {
             for (int q = lane; q < nL; q += 64) {
                 const int c2 = A::ldi(&w.lcol[q]);
@@ -683,7 +689,12 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
             if (seq + __popcll(mL) > WpIdMax<IdT>::value) { wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
             if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
-            if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], 0.0 - pr); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
+            if (isL) {
+                const int pos = nL + __popcll(mL & lt);
+                const double fv = 0.0 - pr;
+                A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], fv); A::sti(&w.lseq[pos], seq + __popcll(mL & lt));
+                if (have && fv != 0.0 && !(fabs(fv) < thr1) && (unsigned)c < best) { best = (unsigned)c; bq = pos; }
+            }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
             A::sync();
             wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt));
@@ -765,7 +776,7 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
     static_assert(kWpCapU * 26 + kWpHashLds * 2 <= kRaw, "tier 1 does not fit the block");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRaw];
     __shared__ int s_selq[kWpSel];
-    __shared__ int bcol[64], bfound[64];
+    __shared__ int bcol[64], bfound[64], s_dlist[64];
     __shared__ double bpr[64];
     double *s_uval = reinterpret_cast<double *>(s_raw), *s_lval = s_uval + kWpCapU;
     int *s_ucol = reinterpret_cast<int *>(s_lval + kWpCapL), *s_lcol = s_ucol + kWpCapU;
@@ -798,12 +809,12 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
         WpResume rs;
         rs.active = 0;
         int rc = wp_row<false>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                               lw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof);
+                               lw, bcol, bpr, bfound, s_dlist, s_selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc == 1 && tier2) {
             if (lane == 0) atomicAdd(&ctrl[3], 1);          // statistics: rows that outgrew tier 1
             rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                              hw, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof, &rs, g.lcol, g.lval, g.lseq, gw.capL);
+                              hw, bcol, bpr, bfound, s_dlist, s_selq, gscratch, ctrl, prof, &rs, g.lcol, g.lval, g.lseq, gw.capL);
             rc = __builtin_amdgcn_readfirstlane(rc);
             if ((rc == 1 || rc == 3) && lane == 0) atomicAdd(&ctrl[24], 1);      // ... and tier 2
         } else if (rc == 1) {
@@ -813,7 +824,7 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
             // (3: the row goes on where it was, its pool in the global arrays now)
             if (rc == 1) rs.active = 0;
             rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                              g, bcol, bpr, bfound, s_selq, gscratch, ctrl, prof, &rs);
+                              g, bcol, bpr, bfound, s_dlist, s_selq, gscratch, ctrl, prof, &rs);
             rc = __builtin_amdgcn_readfirstlane(rc);
         }
         if (rc != 0) {
@@ -846,7 +857,7 @@ k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *_
                    int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
                    int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl)
 {
-    __shared__ int bcol[64], bfound[64];
+    __shared__ int bcol[64], bfound[64], s_dlist[64];
     __shared__ double bpr[64];
     const int lane = threadIdx.x;
     const size_t wv = blockIdx.x;
@@ -868,7 +879,7 @@ k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *_
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= n) break;
         int rc = wp_row<true, unsigned int, true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
-                                                  g, bcol, bpr, bfound, selq, gscratch, ctrl, prof);
+                                                  g, bcol, bpr, bfound, s_dlist, selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc != 0) {
             // give up: publish a poisoned row so that nobody waits for it, and report
