@@ -165,10 +165,12 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
                 const double sq = vr[u] * vr[u];
                 const long long sb = __double_as_longlong(sq);
                 const int rem = cnt - 64 * u < 64 ? cnt - 64 * u : 64;
-                for (int l = 0; l < rem; ++l) {
-                    const int lo = __builtin_amdgcn_readlane((int)sb, l), hi = __builtin_amdgcn_readlane((int)(sb >> 32), l);
-                    z = z + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-                }
+#define WP_ZADD(l_) do { const int lo = __builtin_amdgcn_readlane((int)sb, (l_)), hi = __builtin_amdgcn_readlane((int)(sb >> 32), (l_)); \
+                         z = z + __longlong_as_double(((long long)hi << 32) | (unsigned)lo); } while (0)
+                int l = 0;
+                for (; l + 4 <= rem; l += 4) { WP_ZADD(l); WP_ZADD(l + 1); WP_ZADD(l + 2); WP_ZADD(l + 3); }
+                for (; l < rem; ++l) WP_ZADD(l);
+#undef WP_ZADD
             }
         }
         const double thr = sqrt(z) * tau;
@@ -294,11 +296,17 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
     if constexpr (SELG) __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     // by increasing column (dropping.hpp:32-33; unique keys)
-    for (int t = lane; t < nsel; t += 64) {
-        const int q = selq[t];
-        const int c = A::ldi(&cols[q]);
+    for (int t = lane; t - lane < nsel; t += 64) {
+        const int q = t < nsel ? selq[t] : 0;
+        const int c = t < nsel ? A::ldi(&cols[q]) : 0x7fffffff;
         int r = 0;
-        for (int t2 = 0; t2 < nsel; ++t2) r += (A::ldi(&cols[selq[t2]]) < c) ? 1 : 0;
+        if (nsel <= 64) {
+            // (the kept columns are in the lanes: their ranks without another trip per column)
+            for (int t2 = 0; t2 < nsel; ++t2) r += (__builtin_amdgcn_readlane(c, t2) < c) ? 1 : 0;
+        } else {
+            for (int t2 = 0; t2 < nsel; ++t2) r += (A::ldi(&cols[selq[t2]]) < c) ? 1 : 0;
+        }
+        if (t >= nsel) continue;
         double v = A::ldd(&vals[q]);
         if constexpr (STORE_AGENT) {
             if ((unsigned long long)__double_as_longlong(v) == kSentinel) v = __longlong_as_double((long long)kCanonNaN);
@@ -712,7 +720,9 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     const size_t lb = (size_t)i * p;
     __builtin_amdgcn_s_waitcnt(0);
     // (12.) U row = (i, w[i]) then kept entries; every datum write-through, the length last is not required
+    WP_T(tq0a);
     const int nUk = wp_select<G, true, SELG>(lane, w.ucol, w.uval, nU, p - 1, tau, selq, gscratch, Urow_idx + lb + 1, Urow_val + lb + 1);
+    WP_T(tq0b); WP_SUB(3, 4, tq0a, tq0b);
     if (lane == 0) {
         double piv = wdiag;
         if (piv == 0.0) atomicMin(&ctrl[2], i);                                  // ILUT.hpp:269-270 (reported after the sweep)
@@ -730,22 +740,32 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     }
     A::sync();
     // (10.) the multipliers back in insertion order (the pool is empty now: its arrays take them)
-    for (int q = lane; q < nK; q += 64) A::sti(&w.lseq[q], (int)w.kseq[q]);
-    A::sync();
-    for (int q = lane; q < nK; q += 64) {
-        const int s = A::ldi(&w.lseq[q]);
+    WP_T(tq0c);
+    // (an entry's rank among the sequence numbers: those are read 64 at a time and compared out of the registers -- a load per
+    // comparison was 68 us per row on C3)
+    for (int q0 = 0; q0 < nK; q0 += 64) {
+        const int q = q0 + lane;
+        const int s = q < nK ? (int)w.kseq[q] : 0;
         int r = 0;
-        for (int q2 = 0; q2 < nK; ++q2) r += (A::ldi(&w.lseq[q2]) < s) ? 1 : 0;
-        A::sti(&w.lcol[r], w.kcol[q]);
-        A::std_(&w.lval[r], w.kval[q]);
+        for (int b2 = 0; b2 < nK; b2 += 64) {
+            const int t = b2 + lane < nK ? (int)w.kseq[b2 + lane] : 0x7fffffff;
+            const int rem = nK - b2 < 64 ? nK - b2 : 64;
+            for (int l = 0; l < rem; ++l) r += (__builtin_amdgcn_readlane(t, l) < s) ? 1 : 0;
+        }
+        if (q < nK) {
+            A::sti(&w.lcol[r], w.kcol[q]);
+            A::std_(&w.lval[r], w.kval[q]);
+        }
     }
     A::sync();
+    WP_T(tq0d); WP_SUB(3, 5, tq0c, tq0d);
     // (11.) L row = kept entries then (i, 1.0)
     const int nLk = wp_select<G, false, SELG>(lane, w.lcol, w.lval, nK, p - 1, tau, selq, gscratch, Lrow_idx + lb, Lrow_val + lb);
     if (lane == 0) { Lrow_idx[lb + nLk] = i; Lrow_val[lb + nLk] = 1.0; Llen[i] = nLk + 1; }
     A::sync();
+    WP_T(tq0e); WP_SUB(4, 4, tq0d, tq0e);
     wp_uh_clear<G, IdT>(w, lane, nU, gscratch);
-    WP_T(tq1); WP_ACC(3, tq0, tq1);
+    WP_T(tq1); WP_ACC(3, tq0, tq1); WP_SUB(4, 5, tq0e, tq1);
     return 0;
 }
 
