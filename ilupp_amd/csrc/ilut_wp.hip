@@ -366,6 +366,7 @@ __device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool m
             lose = lose || (l < lane && hh == h);
         }
         if (pending && !lose) { w.uh[h] = (IdT)(slot + 1); pending = false; }
+        if (__ballot(pending) == 0ull) break;                       // (the caller's hand-over covers the writes)
         WpAcc<G>::sync();
         if (pending) h = (h + 1) & (unsigned)w.hmask;
     }
@@ -691,7 +692,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             WP_T(ts1); WP_SUB(2, 4, tu2, ts1);
             const unsigned long long md = __ballot(valid && c == i);
             if (md != 0ull) wdiag = wdiag - wave_bcast_f64(pr, __ffsll((long long)md) - 1);
-            A::sync();
+            // (bfound is LDS, in order per wave.  Waiting here for the stores of the update to be acknowledged, and again before and
+            // inside the hash insertion, was three trips per elimination for nothing: what is appended below goes to new places, and
+            // the one hand-over through memory -- a lane walking on from a cell another lane has just taken -- waits by itself)
+            __builtin_amdgcn_wave_barrier();
             const bool nf = valid && c != i && (c < i ? bfound[lane] == 0 : !ufound);
             const bool isL = nf && c < i, isU = nf && c > i;
             const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
@@ -704,7 +708,6 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                 if (have && fv != 0.0 && !(fabs(fv) < thr1) && (unsigned)c < best) { best = (unsigned)c; bq = pos; }
             }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
-            A::sync();
             wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt));
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
