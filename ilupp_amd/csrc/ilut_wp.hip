@@ -548,31 +548,40 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const unsigned long long who = __ballot(best == g);
         const int qs = __builtin_amdgcn_readlane(bq, __ffsll((long long)who) - 1);
         const int k = (int)g;
+        // Everything the top of an elimination reads is asked for TOGETHER: row k of U (the first attempt of the fetch below), the popped
+        // entry, and the tail entries that may have to move into freed places -- one trip where there were five in a row.
+        const size_t ub = (size_t)k * p;
+        int ul = ld_agent_i32(&Ulen[k]);
+        int c0 = lane < p ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
+        unsigned long long v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
         const double wkv = A::ldd(&w.lval[qs]);
         const int sk = A::ldi(&w.lseq[qs]);
+        const bool fill_holes = nd < 63;
+        const int nLn = nL - (nd + 1);
+        const int mq = nLn + lane;
+        const bool mvalid = fill_holes && lane <= nd;
+        const int mc = mvalid ? A::ldi(&w.lcol[mq]) : 0;
+        const double mval = mvalid ? A::ldd(&w.lval[mq]) : 0.0;
+        const int msq = mvalid ? A::ldi(&w.lseq[mq]) : 0;
         A::sync();
-        if (nd < 63) {
+        if (fill_holes) {
             // (the popped entry goes too) the r-th free place below the new end takes the r-th surviving entry behind it
             if (lane == 0) dlist[nd] = qs;
             ++nd;
-            const int nLn = nL - nd;
             __builtin_amdgcn_wave_barrier();
             const int hq = lane < nd ? dlist[lane] : 0x7fffffff;
             const bool is_hole = lane < nd && hq < nLn;
-            const int mq = nLn + lane;
-            const int mc = lane < nd ? A::ldi(&w.lcol[mq]) : 0;
             const bool is_mover = lane < nd && mc > klast && mq != qs;
             const unsigned long long mh = __ballot(is_hole), mm = __ballot(is_mover);
             if (is_hole) bfound[__popcll(mh & lt)] = hq;
             __builtin_amdgcn_wave_barrier();
             if (is_mover) {
                 const int dst = bfound[__popcll(mm & lt)];
-                const double v = A::ldd(&w.lval[mq]);
-                const int sq = A::ldi(&w.lseq[mq]);
-                A::sti(&w.lcol[dst], mc); A::std_(&w.lval[dst], v); A::sti(&w.lseq[dst], sq);
+                A::sti(&w.lcol[dst], mc); A::std_(&w.lval[dst], mval); A::sti(&w.lseq[dst], msq);
             }
             nL = nLn;
-            A::sync();
+            // (the moved entries are read again behind the fetch below, whose wait covers these stores)
+            __builtin_amdgcn_wave_barrier();
         } else {
             // (more went than the list holds: the pool keeps the entries right of column k, in place -- a chunk's entries are in
             // registers before any of them is written, and they move to positions at or before their own)
@@ -595,16 +604,9 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         klast = k;
         // row k of U, validated against the sentinels
         WP_T(tp1); WP_ACC(0, tp0, tp1);
-        const size_t ub = (size_t)k * p;
-        int ul, c0;
-        unsigned long long v0;
         unsigned spins = 0, idle = 0;
         (void)spins;
         for (;;) {
-            ul = ld_agent_i32(&Ulen[k]);
-            const bool mine = lane < p;
-            c0 = mine ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
-            v0 = mine ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
             const bool bad = ul <= 0 || (lane < ul && (c0 < 0 || v0 == kSentinel));
             if (__ballot(bad) == 0ull) break;
             ++spins;
@@ -612,6 +614,9 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             if (++idle > ILUT_SPIN) return 2;
             if ((idle & 4095u) == 0u) { const int f = ld_agent_i32(&ctrl[7]); if (f != seen_done) { seen_done = f; idle = 0; } }
             __builtin_amdgcn_s_sleep(1);
+            ul = ld_agent_i32(&Ulen[k]);
+            c0 = lane < p ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
+            v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
         }
 #ifdef ILUT_PROFILE
 #ifndef ILUT_PROFILE_SUB
