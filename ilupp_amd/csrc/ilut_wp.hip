@@ -351,13 +351,16 @@ __device__ __forceinline__ int wp_uh_find_val(const WpArraysT<IdT> &w, int c, do
 // cell the lower lane takes it (found by comparing the cells inside the wave -- reading the cell back was two more trips to the
 // table) and the other walks on once the winners' writes have landed
 template <bool G, typename IdT>
-__device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool mine, int c, int slot)
+__device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool mine, int c, int slot, unsigned at = ~0u)
 {
-    unsigned h = wp_hash(c, w.hmask);
+    // (at: a cell the caller's own walk for column c has just found empty -- no second walk to it)
+    bool known = at != ~0u;
+    unsigned h = known ? at : wp_hash(c, w.hmask);
     bool pending = mine;
     unsigned long long pm;
     while ((pm = __ballot(pending)) != 0ull) {
-        if (pending) { while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask; }
+        if (pending && !known) { while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask; }
+        known = false;
         bool lose = false;
         const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         for (unsigned long long m = pm; m != 0ull; m &= m - 1ull) {
@@ -662,6 +665,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             bfound[lane] = 0;
             __builtin_amdgcn_wave_barrier();
             const int bmin = bcol[0], bmax = bcol[cnt - 1];
+            // (the first probe of the U-slot hash is asked for before the pass over the pool, whose trip it shares)
+            const bool uside = valid && c > i;
+            unsigned hU = wp_hash(c, w.hmask);
+            unsigned eU = uside ? (unsigned)w.uh[hU] : 0u;
             WP_T(tu1); WP_SUB(1, 4, tu0, tu1);
             if (cnt <= 16 && base == 0) {
                 // the usual case (p <= 16): the U row's columns sit in scalars and every slot is compared against them -- a binary
@@ -689,10 +696,15 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             // right of the diagonal: the entry's own lane looks its column up in the hash (the reference's occupancy[] access)
             WP_T(tu2); WP_SUB(1, 5, tu1, tu2);
             bool ufound = false;
-            if (valid && c > i) {
-                double o;
-                const int us = wp_uh_find_val<G, IdT>(w, c, o);
-                if (us >= 0) { A::std_(&w.uval[us], o - pr); ufound = true; }
+            if (uside) {
+                // (the walk ends at the slot of column c or at an empty cell -- hU: where the column goes if it is appended below)
+                while (eU != 0u) {
+                    const int cc = A::ldi(&w.ucol[eU - 1]);
+                    const double o = A::ldd(&w.uval[eU - 1]);
+                    if (cc == c) { A::std_(&w.uval[eU - 1], o - pr); ufound = true; break; }
+                    hU = (hU + 1) & (unsigned)w.hmask;
+                    eU = (unsigned)w.uh[hU];
+                }
             }
             WP_T(ts1); WP_SUB(2, 4, tu2, ts1);
             const unsigned long long md = __ballot(valid && c == i);
@@ -713,7 +725,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                 if (have && fv != 0.0 && !(fabs(fv) < thr1) && (unsigned)c < best) { best = (unsigned)c; bq = pos; }
             }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
-            wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt));
+            wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt), hU);
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
             WP_T(ts2); WP_ACC(6, ts1, ts2);
