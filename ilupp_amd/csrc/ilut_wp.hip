@@ -322,31 +322,8 @@ __device__ __forceinline__ int wp_select(const int lane, const int *cols, const 
 
 // U-slot hash: what the reference does with its n-long occupancy array (sparse_implementation.h:987-993)
 __device__ __forceinline__ unsigned wp_hash(int c, int hmask) { return (((unsigned)c * 0x9E3779B1u) >> 12) & (unsigned)hmask; }
-template <bool G, typename IdT>
-__device__ __forceinline__ int wp_uh_find(const WpArraysT<IdT> &w, int c)
-{
-    unsigned h = wp_hash(c, w.hmask);
-    for (;;) {
-        const unsigned e = w.uh[h];
-        if (e == 0u) return -1;
-        if (WpAcc<G>::ldi(&w.ucol[e - 1]) == c) return (int)e - 1;
-        h = (h + 1) & (unsigned)w.hmask;
-    }
-}
-// the same walk that also brings the slot's value (asked for together with its column: one trip instead of two)
-template <bool G, typename IdT>
-__device__ __forceinline__ int wp_uh_find_val(const WpArraysT<IdT> &w, int c, double &val)
-{
-    unsigned h = wp_hash(c, w.hmask);
-    for (;;) {
-        const unsigned e = w.uh[h];
-        if (e == 0u) return -1;
-        const int cc = WpAcc<G>::ldi(&w.ucol[e - 1]);
-        const double v = WpAcc<G>::ldd(&w.uval[e - 1]);
-        if (cc == c) { val = v; return (int)e - 1; }
-        h = (h + 1) & (unsigned)w.hmask;
-    }
-}
+// (the walk for a column -- to its slot or to the empty cell where it goes -- is written out in wp_row: its first probe is asked for before
+// the pass over the pool, and the slot's value comes with its key)
 // all lanes with `mine` insert their (distinct) columns at once: everybody walks to an empty cell; where two lanes stand at the same
 // cell the lower lane takes it (found by comparing the cells inside the wave -- reading the cell back was two more trips to the
 // table) and the other walks on once the winners' writes have landed
@@ -797,7 +774,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"
 template <int kWpCapU, int kWpHashLds>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef ILUT_WPE
+#define ILUT_WPE 4
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ILUT_WPE, ILUT_WPE)))
 k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                int32_t p, double tau, WpArrays gw, int *gscratch_all,
                int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
