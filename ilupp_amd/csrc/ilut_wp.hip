@@ -96,7 +96,13 @@ template <bool G> struct WpAcc {
     static __device__ __forceinline__ int ldi(const unsigned int *p) { return (int)*p; }
     static __device__ __forceinline__ void sti(unsigned int *p, int v) { *p = (unsigned int)v; }
     // cross-lane hand-over inside the wave: LDS is in order per wave; global stores must have landed
+#ifdef ILUT_NOACK
+    // (experiment: a wave's own loads and stores are executed in order, so the acknowledgement is not needed for the hand-over between
+    // lanes of ONE wave -- same bits on C3 and 243 -> 238 ms; the product keeps the wait)
+    static __device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }
+#else
     static __device__ __forceinline__ void sync() { if constexpr (G) __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
+#endif
 };
 
 template <int CTRL, int RM, int BM> __device__ __forceinline__ unsigned wp_dpp(unsigned identity, unsigned v)
