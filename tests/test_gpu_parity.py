@@ -635,7 +635,7 @@ def test_icholt_dataflow_vs_oracle_seeded(case):
                 assert G.mat_equal(_fac(Ls), Lo), (case, "largest capacity class", a, t)
 
 
-@pytest.mark.parametrize("case", ["grid_24", "rand_20k", "rand_long_rows", "wide_budget", "huge_budget", "budget_one"])
+@pytest.mark.parametrize("case", ["grid_24", "rand_20k", "rand_long_rows", "wide_budget", "huge_budget", "budget_one", "long_pieces", "mass_forget"])
 def test_ilut_wave_kernel_vs_oracle_seeded(case):
     """pool/kept/U-slot working row, validated U-row fetches, top-k with ties, rows that outgrow LDS, U rows longer than one
     wave (fill_in > 64), fill budgets beyond the LDS selection queue (fill_in > 256: the largest capacity class): bit-exact
@@ -658,6 +658,16 @@ def test_ilut_wave_kernel_vs_oracle_seeded(case):
     elif case == "huge_budget":
         d, i, p = matgen.poisson3d(9)
         params = ((300, 0.0), (729, 0.0))                    # budgets beyond kWpSel: exact LU in the largest capacity class
+    elif case == "long_pieces":
+        # working rows with more than 1 024 U slots (the dropping step's path for pieces that do not fit its registers) and pools that
+        # outgrow LDS in the middle of a row (the pool moves and the row goes on)
+        d, i, p = matgen.random_dd(2200, 30, 40.0, 5)
+        params = ((40, 0.0),)
+    elif case == "mass_forget":
+        # long left parts with a high threshold: dozens of entries are forgotten with one elimination (more than the list of freed
+        # places holds: the pool is rewritten in place instead)
+        d, i, p = matgen.random_dd(1500, 160, 200.0, 6)
+        params = ((10, 0.3), (10, 0.05))
     else:
         d, i, p = matgen.poisson3d(10)
         params = ((1, 0.1), (2, 0.0))
