@@ -358,6 +358,10 @@ __device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool m
     }
 }
 
+#ifndef ILUT_POLL_NAP
+#define ILUT_POLL_NAP 8
+#endif
+
 // a row between two eliminations (wp_row's alt_*: returned with 3, taken up again by the next call)
 struct WpResume {
     int active, nL, nU, nK, seq, klast;
@@ -599,10 +603,14 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             // the limit counts polls during which NO row was finished anywhere (ctrl[7]): a long chain elsewhere is not a hang
             if (++idle > ILUT_SPIN) return 2;
             if ((idle & 4095u) == 0u) { const int f = ld_agent_i32(&ctrl[7]); if (f != seen_done) { seen_done = f; idle = 0; } }
-            __builtin_amdgcn_s_sleep(1);
-            ul = ld_agent_i32(&Ulen[k]);
-            c0 = lane < p ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
-            v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
+            // (a row that is not there yet is asked for by its length word alone -- one request instead of three per poll, and not
+            // more often than a trip takes: the pollers share the L2 with the waves that work)
+            __builtin_amdgcn_s_sleep(ILUT_POLL_NAP);
+            ul = __builtin_amdgcn_readfirstlane(ld_agent_i32(&Ulen[k]));
+            if (ul > 0) {
+                c0 = lane < p ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
+                v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
+            }
         }
 #ifdef ILUT_PROFILE
 #ifndef ILUT_PROFILE_SUB
