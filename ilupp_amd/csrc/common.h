@@ -517,8 +517,11 @@ int ilut_factor(hipStream_t st, const DevMat &A, int32_t max_fill_in, double thr
                 int32_t *err_row, float *kernel_ms);
 
 // ilut_wp.hip (returns 1 when a row fits no capacity class, not even the largest: the matrix is too wide for the memory budget)
+// (the U rows are RECORDS while the kernel runs: a row's length word, columns and values lie together -- 124 bytes for a budget of 10: one
+// 128-byte line per fetched row instead of three or four; Uri / Urv / Ulen point into that slab, a row apart by si ints / sv doubles / sl ints)
+struct UrowLayout { int32_t si, sv, sl; };
 int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
-                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms);
+                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, UrowLayout ul, int32_t *ctrl, float *kernel_ms);
 
 // sptrsv.hip
 enum SweepKind { SWEEP_FWD_LAST_ASC = 0, SWEEP_BWD_FIRST_ASC = 1, SWEEP_BWD_FIRST_DESC = 2 };

@@ -393,7 +393,7 @@ template <bool G, typename IdT = unsigned short, bool SELG = false>
 __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, const int p, const double tau,
                                       const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                                       int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
-                                      int32_t *Urow_idx, double *Urow_val, int32_t *Ulen,
+                                      int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, const UrowLayout ul_,
                                       const WpArraysT<IdT> w, int *bcol, double *bpr, int *bfound, int *dlist, int *selq, int *gscratch, int32_t *ctrl,
                                       unsigned long long *prof = nullptr, WpResume *rs = nullptr, int *alt_lcol = nullptr,
                                       double *alt_lval = nullptr, IdT *alt_lseq = nullptr, int alt_capL = 0)
@@ -540,10 +540,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const int k = (int)g;
         // Everything the top of an elimination reads is asked for TOGETHER: row k of U (the first attempt of the fetch below), the popped
         // entry, and the tail entries that may have to move into freed places -- one trip where there were five in a row.
-        const size_t ub = (size_t)k * p;
-        int ul = ld_agent_i32(&Ulen[k]);
-        int c0 = lane < p ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
-        unsigned long long v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
+        const size_t ubi = (size_t)k * ul_.si, ubv = (size_t)k * ul_.sv, ubl = (size_t)k * ul_.sl;      // (row k's record: common.h, UrowLayout)
+        int ul = ld_agent_i32(&Ulen[ubl]);
+        int c0 = lane < p ? ld_agent_i32(&Urow_idx[ubi + lane]) : -1;
+        unsigned long long v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ubv + lane])) : 0ull;
         const double wkv = A::ldd(&w.lval[qs]);
         const int sk = A::ldi(&w.lseq[qs]);
         const bool fill_holes = nd < 63;
@@ -606,10 +606,10 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             // (a row that is not there yet is asked for by its length word alone -- one request instead of three per poll, and not
             // more often than a trip takes: the pollers share the L2 with the waves that work)
             __builtin_amdgcn_s_sleep(ILUT_POLL_NAP);
-            ul = __builtin_amdgcn_readfirstlane(ld_agent_i32(&Ulen[k]));
+            ul = __builtin_amdgcn_readfirstlane(ld_agent_i32(&Ulen[ubl]));
             if (ul > 0) {
-                c0 = lane < p ? ld_agent_i32(&Urow_idx[ub + lane]) : -1;
-                v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + lane])) : 0ull;
+                c0 = lane < p ? ld_agent_i32(&Urow_idx[ubi + lane]) : -1;
+                v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ubv + lane])) : 0ull;
             }
         }
 #ifdef ILUT_PROFILE
@@ -639,8 +639,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             if (base > 0) {
                 unsigned sp2 = 0;
                 for (;;) {
-                    c = j < ul ? ld_agent_i32(&Urow_idx[ub + j]) : 0;
-                    vb = j < ul ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ub + j])) : 0ull;
+                    c = j < ul ? ld_agent_i32(&Urow_idx[ubi + j]) : 0;
+                    vb = j < ul ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ubv + j])) : 0ull;
                     const bool bad = j < ul && (c < 0 || vb == kSentinel);
                     if (__ballot(bad) == 0ull) break;
                     if (++sp2 > ILUT_SPIN) return 2;
@@ -732,21 +732,22 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     __builtin_amdgcn_s_waitcnt(0);
     // (12.) U row = (i, w[i]) then kept entries; every datum write-through, the length last is not required
     WP_T(tq0a);
-    const int nUk = wp_select<G, true, SELG>(lane, w.ucol, w.uval, nU, p - 1, tau, selq, gscratch, Urow_idx + lb + 1, Urow_val + lb + 1);
+    const size_t lbi = (size_t)i * ul_.si, lbv = (size_t)i * ul_.sv;
+    const int nUk = wp_select<G, true, SELG>(lane, w.ucol, w.uval, nU, p - 1, tau, selq, gscratch, Urow_idx + lbi + 1, Urow_val + lbv + 1);
     WP_T(tq0b); WP_SUB(3, 4, tq0a, tq0b);
     if (lane == 0) {
         double piv = wdiag;
         if (piv == 0.0) atomicMin(&ctrl[2], i);                                  // ILUT.hpp:269-270 (reported after the sweep)
         if ((unsigned long long)__double_as_longlong(piv) == kSentinel) piv = __longlong_as_double((long long)kCanonNaN);
-        st_agent_f64(&Urow_val[lb], piv);
-        st_agent_i32(&Urow_idx[lb], i);
+        st_agent_f64(&Urow_val[lbv], piv);
+        st_agent_i32(&Urow_idx[lbi], i);
 #ifdef ILUT_PROFILE
         st_agent_i32(&g_wp_lvl[i], prof_lvl + 1);
         g_wp_parent[i] = prof_parent; g_wp_lparent[i] = prof_lparent; g_wp_tstart[i] = prof_t0;
         g_wp_size[i] = (prof_maxl > 4095 ? 4095 : prof_maxl) | ((nU > 1023 ? 1023 : nU) << 12) | ((nK > 511 ? 511 : nK) << 22) | (G ? (1 << 31) : 0); g_wp_wait[i] = prof_wait; g_wp_tfin[i] = wall_clock64();
         __threadfence();
 #endif
-        st_agent_i32(&Ulen[i], nUk + 1);
+        st_agent_i32(&Ulen[(size_t)i * ul_.sl], nUk + 1);
         atomicAdd(&ctrl[7], 1);                                                  // rows finished (what a waiting wave watches)
     }
     A::sync();
@@ -795,7 +796,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ILUT_WP
 k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                int32_t p, double tau, WpArrays gw, int *gscratch_all,
                int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
-               int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl, int tier2)
+               int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, UrowLayout ul_, int32_t *ctrl, int tier2)
 {
     constexpr int kWpCapL = kWpCapU;
     // One block of LDS per wave, carved twice.  Tier 1: pool, U slots and hash, kWpCapU entries each.  Tier 2 (a row that outgrew tier 1:
@@ -842,12 +843,12 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
         // (starting every row in tier 2 costs the same as trying tier 1 first: 494 against 496 ms on C3)
         WpResume rs;
         rs.active = 0;
-        int rc = wp_row<false>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+        int rc = wp_row<false>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen, ul_,
                                lw, bcol, bpr, bfound, s_dlist, s_selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc == 1 && tier2) {
             if (lane == 0) atomicAdd(&ctrl[3], 1);          // statistics: rows that outgrew tier 1
-            rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+            rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen, ul_,
                               hw, bcol, bpr, bfound, s_dlist, s_selq, gscratch, ctrl, prof, &rs, g.lcol, g.lval, g.lseq, gw.capL);
             rc = __builtin_amdgcn_readfirstlane(rc);
             if ((rc == 1 || rc == 3) && lane == 0) atomicAdd(&ctrl[24], 1);      // ... and tier 2
@@ -857,7 +858,7 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
         if (rc == 1 || rc == 3) {
             // (3: the row goes on where it was, its pool in the global arrays now)
             if (rc == 1) rs.active = 0;
-            rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+            rc = wp_row<true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen, ul_,
                               g, bcol, bpr, bfound, s_dlist, s_selq, gscratch, ctrl, prof, &rs);
             rc = __builtin_amdgcn_readfirstlane(rc);
         }
@@ -865,9 +866,9 @@ k_ilut_rows_wp(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__res
             // give up: publish a poisoned row so that nobody waits for it, and report
             if (lane == 0) {
                 atomicMax(&ctrl[1], rc == 1 ? 3 : 1);
-                st_agent_f64(&Urow_val[(size_t)i * p], 1.0);
-                st_agent_i32(&Urow_idx[(size_t)i * p], i);
-                st_agent_i32(&Ulen[i], 1);
+                st_agent_f64(&Urow_val[(size_t)i * ul_.sv], 1.0);
+                st_agent_i32(&Urow_idx[(size_t)i * ul_.si], i);
+                st_agent_i32(&Ulen[(size_t)i * ul_.sl], 1);
                 Llen[i] = 0;
             }
             // (the row left its cells in the wave's table: the rows this wave still takes start from an empty one)
@@ -889,7 +890,7 @@ __global__ void __launch_bounds__(64)
 k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *__restrict__ Aidx, const double *__restrict__ Aval,
                    int32_t p, double tau, WpArraysT<unsigned int> gw, int *gscratch_all, int *selq_all,
                    int32_t *Lrow_idx, double *Lrow_val, int32_t *Llen,
-                   int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, int32_t *ctrl)
+                   int32_t *Urow_idx, double *Urow_val, int32_t *Ulen, UrowLayout ul_, int32_t *ctrl)
 {
     __shared__ int bcol[64], bfound[64], s_dlist[64];
     __shared__ double bpr[64];
@@ -912,16 +913,16 @@ k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *_
         if (lane == 0) i = atomicAdd(&ctrl[0], 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= n) break;
-        int rc = wp_row<true, unsigned int, true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen,
+        int rc = wp_row<true, unsigned int, true>(lane, i, n, p, tau, Aptr, Aidx, Aval, Lrow_idx, Lrow_val, Llen, Urow_idx, Urow_val, Ulen, ul_,
                                                   g, bcol, bpr, bfound, s_dlist, selq, gscratch, ctrl, prof);
         rc = __builtin_amdgcn_readfirstlane(rc);
         if (rc != 0) {
             // give up: publish a poisoned row so that nobody waits for it, and report
             if (lane == 0) {
                 atomicMax(&ctrl[1], rc == 1 ? 3 : 1);
-                st_agent_f64(&Urow_val[(size_t)i * p], 1.0);
-                st_agent_i32(&Urow_idx[(size_t)i * p], i);
-                st_agent_i32(&Ulen[i], 1);
+                st_agent_f64(&Urow_val[(size_t)i * ul_.sv], 1.0);
+                st_agent_i32(&Urow_idx[(size_t)i * ul_.si], i);
+                st_agent_i32(&Ulen[(size_t)i * ul_.sl], 1);
                 Llen[i] = 0;
             }
             for (size_t q = lane; q < (size_t)(gw.hmask + 1) * sizeof(unsigned int) / 8; q += 64) reinterpret_cast<unsigned long long *>(g.uh)[q] = 0ull;
@@ -930,11 +931,21 @@ k_ilut_rows_wp_big(int32_t n, const int32_t *__restrict__ Aptr, const int32_t *_
     }
 }
 
-static void wp_init_slabs(hipStream_t st, int32_t n, size_t slab, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl)
+// every record starts as "not there": length 0, columns -1, values the sentinel
+__global__ void k_urec_init(const long long words, const int rw, const int vw, const int p, unsigned long long *__restrict__ rec)
 {
-    ILUPP_HIP(hipMemsetAsync(Uri, 0xff, sizeof(int32_t) * slab, st));
-    fill_u64(st, reinterpret_cast<unsigned long long *>(Urv), (int64_t)slab, kSentinel);
-    ILUPP_HIP(hipMemsetAsync(Ulen, 0, sizeof(int32_t) * (size_t)n, st));
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    const int o = (int)(w % rw);                                  // 8-byte word of its record
+    rec[w] = o == 0 ? 0xffffffff00000000ull : o < vw ? ~0ull : o < vw + p ? kSentinel : 0ull;
+}
+static void wp_init_slabs(hipStream_t st, int32_t n, int32_t p, double *Urv, int32_t *Ulen, UrowLayout ul_, int32_t *ctrl)
+{
+    const long long words = (long long)n * ul_.sv;
+    const int vw = (int)(Urv - reinterpret_cast<double *>(Ulen));
+    hipLaunchKernelGGL(k_urec_init, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, words, ul_.sv, vw, p,
+                       reinterpret_cast<unsigned long long *>(Ulen));
+    ILUPP_HIP(hipGetLastError());
     const int32_t init[32] = {0, 0, 0x7fffffff};
     ILUPP_HIP(hipMemcpyAsync(ctrl, init, 128, hipMemcpyHostToDevice, st));
 }
@@ -942,10 +953,9 @@ struct WpEvents { hipEvent_t a = nullptr, b = nullptr; ~WpEvents() { if (a) (voi
 
 // 0 = rows computed, 1 = not even this class has room (a matrix too wide for the memory budget), ILUPP_ERR_TIMEOUT
 static int ilut_rows_wp_big(hipStream_t st, const DevMat &A, int32_t p, double threshold,
-                            int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms)
+                            int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, UrowLayout ul_, int32_t *ctrl, float *kernel_ms)
 {
     const int32_t n = A.n;
-    const size_t slab = (size_t)n * p;
     const int cap = n + 64;
     size_t hashN = 1024;
     while (hashN < 2 * (size_t)cap) hashN *= 2;
@@ -971,13 +981,13 @@ static int ilut_rows_wp_big(hipStream_t st, const DevMat &A, int32_t p, double t
     ILUPP_HIP(hipMemsetAsync(g.uh, 0, sizeof(unsigned int) * (size_t)workers * hashN, st));
     g.lcol = b_lcol.as<int>(); g.lval = b_lval.as<double>(); g.lseq = b_lseq.as<unsigned int>();
     g.kcol = b_kcol.as<int>(); g.kval = b_kval.as<double>(); g.kseq = b_kseq.as<unsigned int>();
-    wp_init_slabs(st, n, slab, Uri, Urv, Ulen, ctrl);
+    wp_init_slabs(st, n, p, Urv, Ulen, ul_, ctrl);
     WpEvents ev;
     ILUPP_HIP(hipEventCreate(&ev.a));
     ILUPP_HIP(hipEventCreate(&ev.b));
     ILUPP_HIP(hipEventRecord(ev.a, st));
     hipLaunchKernelGGL(k_ilut_rows_wp_big, dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, b_scr.as<int>(),
-                       b_selq.as<int>(), Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl);
+                       b_selq.as<int>(), Lri, Lrv, Llen, Uri, Urv, Ulen, ul_, ctrl);
     ILUPP_HIP(hipEventRecord(ev.b, st));
     ILUPP_HIP(hipGetLastError());
     int32_t h[8];
@@ -992,13 +1002,12 @@ static int ilut_rows_wp_big(hipStream_t st, const DevMat &A, int32_t p, double t
 
 // returns 0 = rows computed (ctrl holds zero-pivot info), 1 = a row that fits no capacity class, ILUPP_ERR_TIMEOUT
 int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
-                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, int32_t *ctrl, float *kernel_ms)
+                 int32_t *Lri, double *Lrv, int32_t *Llen, int32_t *Uri, double *Urv, int32_t *Ulen, UrowLayout ul_, int32_t *ctrl, float *kernel_ms)
 {
     const int32_t n = A.n;
     const bool force_big = getenv("ILUPP_ILUT_BIG") != nullptr;                // (tests: A/B of the capacity classes)
     // fill budgets beyond the LDS selection queue: the largest class at once
-    if (p - 1 >= kWpSel || force_big) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
-    const size_t slab = (size_t)n * p;
+    if (p - 1 >= kWpSel || force_big) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ul_, ctrl, kernel_ms);
     const bool small_pieces = p <= 32;
     static const int waves_env = getenv("ILUPP_ILUT_WAVES") ? atoi(getenv("ILUPP_ILUT_WAVES")) : 0;     // (experiments: waves per CU)
     int workers = device_cu_count() * (waves_env > 0 ? waves_env : (small_pieces ? 16 : 8));          // (what the LDS block of a wave lets a CU hold)
@@ -1022,7 +1031,7 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         g.lcol = b_lcol.as<int>(); g.lval = b_lval.as<double>(); g.lseq = b_lseq.as<unsigned short>();
         g.kcol = b_kcol.as<int>(); g.kval = b_kval.as<double>(); g.kseq = b_kseq.as<unsigned short>();
         int *gscratch = b_scr.as<int>();
-        wp_init_slabs(st, n, slab, Uri, Urv, Ulen, ctrl);
+        wp_init_slabs(st, n, p, Urv, Ulen, ul_, ctrl);
 #ifdef ILUT_PROFILE
         PoolBlock pb_lvl, pb_par, pb_fin, pb_start, pb_wait, pb_lpar;
         ILUPP_HIP(pb_lpar.alloc(sizeof(int) * (size_t)n));
@@ -1050,10 +1059,10 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
         static const int tier2 = getenv("ILUPP_ILUT_NO_TIER2") ? 0 : 1;                                     // (tests, A/B: rows that outgrow LDS go to global memory at once)
         if (small_pieces && cap_env != 256)
             hipLaunchKernelGGL((k_ilut_rows_wp<128, 512>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, tier2);
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ul_, ctrl, tier2);
         else
             hipLaunchKernelGGL((k_ilut_rows_wp<256, 1024>), dim3((unsigned)workers), dim3(64), 0, st, n, A.ptr, A.idx, A.val, p, threshold, g, gscratch,
-                               Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, tier2);
+                               Lri, Lrv, Llen, Uri, Urv, Ulen, ul_, ctrl, tier2);
         ILUPP_HIP(hipEventRecord(ev.b, st));
         ILUPP_HIP(hipGetLastError());
         ILUPP_HIP(hipMemcpyAsync(h, ctrl, 128, hipMemcpyDeviceToHost, st));
@@ -1161,7 +1170,7 @@ int ilut_rows_wp(hipStream_t st, const DevMat &A, int32_t p, double threshold,
     }
     if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] ilut_wp: %d of %d rows outgrew LDS (pool %d, U slots %d, kept %d), %d of them the pool-in-LDS tier too, status %d, kernel %.3f ms\n", h[3], n, h[4], h[5], h[6], h[24], h[1], kernel_ms ? *kernel_ms : 0.f);
     // a row that outgrew the 64 K pieces: the whole factorisation once more in the largest class
-    if (h[1] == 3) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ctrl, kernel_ms);
+    if (h[1] == 3) return ilut_rows_wp_big(st, A, p, threshold, Lri, Lrv, Llen, Uri, Urv, Ulen, ul_, ctrl, kernel_ms);
     if (h[1] == 1) return ILUPP_ERR_TIMEOUT;
     return 0;
 }
