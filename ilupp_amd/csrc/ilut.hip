@@ -7,8 +7,9 @@
 // The sparsity pattern of L and U depends on the VALUES (thresholds, top-k by magnitude), so nothing can be scheduled ahead:
 // the rows are computed by a row-wise dataflow kernel, one wave per row (ilut_wp.hip: the working row as three
 // insertion-ordered pieces in LDS, in 64 K global pieces, or -- the largest capacity class -- in pieces as long as the matrix is
-// wide).  Rows go to fixed-pitch slabs (p entries per row); the compaction pass here drops exact zeros like compress(0.0) and
-// makes the CSR arrays of L (unit diagonal last) and U (pivot first).
+// wide).  Rows go to fixed-pitch slabs (L: p entries per row in plain arrays; U: one record of whole 128-byte lines per row -- length,
+// columns, values -- because other rows fetch it while the kernel runs); the compaction pass here drops exact zeros like compress(0.0)
+// and makes the CSR arrays of L (unit diagonal last) and U (pivot first).
 #include <stdio.h>
 #include <stdlib.h>
 
