@@ -12,20 +12,30 @@
 //   * U slots: the entries right of the diagonal in insertion order (they are never removed) with a hash table
 //     column -> slot, the stand-in for the reference's n-long occupancy array; the diagonal is a scalar.
 // What the reference does with a binary heap -- "next column in ascending order" -- is a wave-wide minimum over the
-// pool (DPP reduction).  Subtracting a U row: its (<= 16) columns go into scalars and every pool entry is compared against
-// all of them (a binary search per entry is a chain of dependent LDS reads that the whole wave pays for as soon as one
-// lane needs it: it was 3/4 of a row's time); the entries right of the diagonal look their column up in the hash, each on
-// its own lane; the misses are appended in row order (= the reference's insertion order) by ballot/prefix-sum and enter
-// the hash all at once.
-// A finished U row is fetched in ONE memory round trip: rows live in fixed-pitch slabs initialised to sentinels
-// (index -1, value kSentinel, length 0); the writer stores every datum write-through, the reader validates every
-// datum it needs and retries otherwise (write-once data: a set of individually fresh values is consistent).
+// pool (DPP reduction) of the LIVE entries: the columns the reference pops and forgets (zero, or below the stage-1 threshold) go
+// with the next elimination.  One elimination (round 5: about four dependent trips to memory instead of ten):
+//   * top: the wave-wide minimum of what the last pass found; ONE batch of loads -- row k of U, the popped entry, the pool's tail
+//     entries that may have to move; the places freed by the last elimination are filled from the tail (nothing depends on an
+//     entry's place in the pool: its insertion order is seq);
+//   * subtracting the U row: its (<= 16) columns go into scalars and every pool entry is compared against those LEFT of the
+//     diagonal (a binary search per entry is a chain of dependent LDS reads that the whole wave pays for as soon as one lane
+//     needs it); that same pass finds the next column to eliminate and the places that fall free (WP_SCAN); the entries right of
+//     the diagonal look their column up in the hash, each on its own lane, the first probe asked for before the pass; the misses
+//     are appended in row order (= the reference's insertion order) by ballot/prefix-sum and enter the hash at the empty cells
+//     their walks ended at.
+// A finished U row is fetched in ONE memory round trip and, for a budget of 10, one 128-byte line: rows are records (length,
+// columns, values: common.h, UrowLayout) initialised to sentinels (index -1, value kSentinel, length 0); the writer stores every
+// datum write-through, the reader validates every datum it needs and retries otherwise (write-once data: a set of individually
+// fresh values is consistent) -- by the length word alone while the row is not there.
 // Dropping: norm in insertion order, candidates by strict >, the p-1 largest by repeated wave-wide maximum with
 // (magnitude desc, position asc) order -- equal to std::sort's result unless the cut falls between equal magnitudes
-// among more than 16 candidates; then one lane runs libstdc++'s algorithm (stdsort.h) on the candidate list.
-// The pieces live in LDS; a row that outgrows them is started over with the wave's global-memory arrays (64 K
-// entries, private to the wave); a row that outgrows those, or a fill budget beyond the LDS selection queue, makes the host run
-// the whole factorisation in the largest capacity class (k_ilut_rows_wp_big: pieces as long as the matrix is wide, on fewer waves).
+// among more than 16 candidates; then one lane runs libstdc++'s algorithm (stdsort.h) on the candidate list.  Pieces of up to
+// 1 024 entries are read once into registers for all of that; the U row is selected and published before the L row is touched.
+// The pieces live in LDS (tier 1); a row that outgrows them is started over with its U part in the wave's global-memory arrays
+// (64 K entries, private to the wave) and the whole LDS block as its pool (tier 2); a pool that outgrows that MOVES to the global
+// arrays between two eliminations and the row goes on (WpResume); a row that outgrows those, or a fill budget beyond the LDS
+// selection queue, makes the host run the whole factorisation in the largest capacity class (k_ilut_rows_wp_big: pieces as long
+// as the matrix is wide, on fewer waves).
 #include <stdio.h>
 #include <algorithm>
 #include <vector>
@@ -37,7 +47,8 @@
 namespace ilupp {
 
 // LDS pieces of a wave (pool, U slots, hash cells) in two sizes.  What decides the kernel's time is how many waves a CU holds: it is
-// bound by the chains of dependent memory operations of each row, and the time goes like 1 / waves up to about 20 waves per CU.
+// bound by the chains of dependent memory operations of each row, and the time goes like 1 / waves up to 16 waves per CU -- what the
+// kernel's 128 VGPRs (amdgpu_waves_per_eu below) and its LDS block allow; DESIGN.md section 4b has the history of that number.
 // With pieces of 1 536 entries (49 KB, 3 waves per CU) C3 took 1.12 s and 1 % of its rows started over in global memory; with 128
 // entries (6 KB, 20 waves per CU) 74 % of the rows start over (early: the pieces fill within the first eliminations) and it takes
 // 0.63 s.  Rows of a factorisation with a large fill budget (p > 32; 48^3 mesh, ILUT(100, 1e-3): ~110 entries per row) get
