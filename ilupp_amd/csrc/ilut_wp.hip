@@ -552,9 +552,17 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         // Everything the top of an elimination reads is asked for TOGETHER: row k of U (the first attempt of the fetch below), the popped
         // entry, and the tail entries that may have to move into freed places -- one trip where there were five in a row.
         const size_t ubi = (size_t)k * ul_.si, ubv = (size_t)k * ul_.sv, ubl = (size_t)k * ul_.sl;      // (row k's record: common.h, UrowLayout)
+#ifdef ILUT_FIRST_PLAIN
+        // (experiment: the first attempt with loads that may be served by this XCD's L2 -- a record is written once, so whatever a stale
+        // line holds is either "not there" or final; the retries below go past the L2)
+        int ul = __hip_atomic_load(&Ulen[ubl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        int c0 = lane < p ? __hip_atomic_load(&Urow_idx[ubi + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
+        unsigned long long v0 = lane < p ? __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&Urow_val[ubv + lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0ull;
+#else
         int ul = ld_agent_i32(&Ulen[ubl]);
         int c0 = lane < p ? ld_agent_i32(&Urow_idx[ubi + lane]) : -1;
         unsigned long long v0 = lane < p ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(&Urow_val[ubv + lane])) : 0ull;
+#endif
         const double wkv = A::ldd(&w.lval[qs]);
         const int sk = A::ldi(&w.lseq[qs]);
         const bool fill_holes = nd < 63;
