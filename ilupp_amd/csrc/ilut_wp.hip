@@ -56,6 +56,7 @@ namespace ilupp {
 static constexpr int kWpSel = 256;      // (the KEPT list is append-only until the end: it lives in global memory)
 static constexpr int kWpGCapU = 65534, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;      // (U slot ids + 1 fit the table's 16-bit cells)
 static constexpr int kWpHashG = 1 << 17;
+static constexpr int kWpHashSmall = 1 << 12;            // cells a row's U-slot hash starts on in a global table (wp_row: hm)
 #ifndef ILUT_SPIN
 #define ILUT_SPIN (1u << 24)
 #endif
@@ -345,15 +346,15 @@ __device__ __forceinline__ unsigned wp_hash(int c, int hmask) { return (((unsign
 // cell the lower lane takes it (found by comparing the cells inside the wave -- reading the cell back was two more trips to the
 // table) and the other walks on once the winners' writes have landed
 template <bool G, typename IdT>
-__device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool mine, int c, int slot, unsigned at = ~0u)
+__device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, const int hmask, bool mine, int c, int slot, unsigned at = ~0u)
 {
     // (at: a cell the caller's own walk for column c has just found empty -- no second walk to it)
     bool known = at != ~0u;
-    unsigned h = known ? at : wp_hash(c, w.hmask);
+    unsigned h = known ? at : wp_hash(c, hmask);
     bool pending = mine;
     unsigned long long pm;
     while ((pm = __ballot(pending)) != 0ull) {
-        if (pending && !known) { while (w.uh[h] != 0u) h = (h + 1) & (unsigned)w.hmask; }
+        if (pending && !known) { while (w.uh[h] != 0u) h = (h + 1) & (unsigned)hmask; }
         known = false;
         bool lose = false;
         const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -365,7 +366,7 @@ __device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool m
         if (pending && !lose) { w.uh[h] = (IdT)(slot + 1); pending = false; }
         if (__ballot(pending) == 0ull) break;                       // (the caller's hand-over covers the writes)
         WpAcc<G>::sync();
-        if (pending) h = (h + 1) & (unsigned)w.hmask;
+        if (pending) h = (h + 1) & (unsigned)hmask;
     }
 }
 
@@ -375,7 +376,7 @@ __device__ __forceinline__ void wp_uh_insert_all(const WpArraysT<IdT> &w, bool m
 
 // a row between two eliminations (wp_row's alt_*: returned with 3, taken up again by the next call)
 struct WpResume {
-    int active, nL, nU, nK, seq, klast;
+    int active, nL, nU, nK, seq, klast, hm;
     double wdiag, thr1;
 #ifdef ILUT_PROFILE
     int lvl, parent, lparent, maxl;
@@ -386,13 +387,13 @@ struct WpResume {
 // one row; returns 0 = done, 1 = a piece outgrew its capacity (nothing was published), 2 = timeout, 3 = the pool moved (see alt_*)
 // this row's cells of the wave's table in global memory: found first (nothing is removed while anybody still walks), then emptied
 template <bool G, typename IdT>
-__device__ __forceinline__ void wp_uh_clear(const WpArraysT<IdT> &w, const int lane, const int nU, int *gscratch)
+__device__ __forceinline__ void wp_uh_clear(const WpArraysT<IdT> &w, const int hmask, const int lane, const int nU, int *gscratch)
 {
     if (!G) return;
     WpAcc<G>::sync();
     for (int q = lane; q < nU; q += 64) {
-        unsigned h = wp_hash(WpAcc<G>::ldi(&w.ucol[q]), w.hmask);
-        while (w.uh[h] != (IdT)(q + 1)) h = (h + 1) & (unsigned)w.hmask;
+        unsigned h = wp_hash(WpAcc<G>::ldi(&w.ucol[q]), hmask);
+        while (w.uh[h] != (IdT)(q + 1)) h = (h + 1) & (unsigned)hmask;
         gscratch[q] = (int)h;
     }
     WpAcc<G>::sync();
@@ -415,6 +416,12 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     int nL = 0, nU = 0, nK = 0, seq = 0;
     int seen_done = -1, klast = -1;
     double wdiag = 0.0, thr1 = 0.0;
+    // The U-slot hash of a row in the wave's GLOBAL table starts on the table's first 4 096 cells (8 KB: 64 lines that stay in the
+    // L2 / the MALL between two probes) and moves to the whole table (256 KB and more, every probe a line from HBM: 120 of the
+    // kernel's 150 GiB of fetches on C3) only when the row has more than 2 048 - p U slots: the cells of a table are all 0 between rows
+    // whatever mask the last row used.  (A row of A with more than 1 024 entries starts on the whole table.)
+    int hm = w.hmask;
+    if (G && w.hmask > kWpHashSmall - 1 && Aptr[i + 1] - Aptr[i] <= kWpHashSmall / 4) hm = kWpHashSmall - 1;
 #ifdef ILUT_PROFILE
     int prof_lvl = 0, prof_parent = -1, prof_lparent = -1, prof_maxl = 0;
     long long prof_wait = 0;
@@ -426,7 +433,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     // such a row is a long one, and on the chain of deepest dependencies its second start was the longest link of all.
     const bool resume = rs != nullptr && rs->active != 0;
     if (resume) {
-        nL = rs->nL; nU = rs->nU; nK = rs->nK; seq = rs->seq; klast = rs->klast; wdiag = rs->wdiag; thr1 = rs->thr1;
+        nL = rs->nL; nU = rs->nU; nK = rs->nK; seq = rs->seq; klast = rs->klast; wdiag = rs->wdiag; thr1 = rs->thr1; hm = rs->hm;
 #ifdef ILUT_PROFILE
         prof_lvl = rs->lvl; prof_parent = rs->parent; prof_lparent = rs->lparent; prof_maxl = rs->maxl; prof_wait = rs->wait; prof_t0 = rs->t0;
 #endif
@@ -440,7 +447,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             alt_lcol[q] = c2; alt_lval[q] = v2; A::sti(&alt_lseq[q], s2);                                               \
         }                                                                                                               \
         A::sync();                                                                                                      \
-        rs->active = 1; rs->nL = nL; rs->nU = nU; rs->nK = nK; rs->seq = seq; rs->klast = klast; rs->wdiag = wdiag; rs->thr1 = thr1; \
+        rs->active = 1; rs->nL = nL; rs->nU = nU; rs->nK = nK; rs->seq = seq; rs->klast = klast; rs->wdiag = wdiag; rs->thr1 = thr1; rs->hm = hm; \
         WP_MOVE_PROF();                                                                                                 \
         return 3;                                                                                                       \
     } while (0)
@@ -467,12 +474,12 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         const double v = valid ? Aval[q] : 0.0;
         const bool isL = valid && c < i, isU = valid && c > i, isD = valid && c == i;
         const unsigned long long mL = __ballot(isL), mU = __ballot(isU), mD = __ballot(isD);
-        if (seq + __popcll(mL) > WpIdMax<IdT>::value) { wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
-        if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
+        if (seq + __popcll(mL) > WpIdMax<IdT>::value) { wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch); return 1; }
+        if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch); return 1; }
         if (isL) { const int pos = nL + __popcll(mL & lt); A::sti(&w.lcol[pos], c); A::std_(&w.lval[pos], v); A::sti(&w.lseq[pos], seq + __popcll(mL & lt)); }
         if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], v); }
         A::sync();
-        wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt));
+        wp_uh_insert_all<G, IdT>(w, hm, isU, c, nU + __popcll(mU & lt));
         if (mD != 0ull) wdiag = wave_bcast_f64(v, __ffsll((long long)mD) - 1);
         nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
     }
@@ -529,6 +536,17 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
         prof_maxl = nL > prof_maxl ? nL : prof_maxl;
 #endif
         // (an elimination appends at most p - 1 entries -- a U row has p at most)
+        if (G && hm != w.hmask && nU + p > (hm + 1) / 2) {
+            // the U-slot hash moves to the whole table: its cells out of the small one, the slots in again
+            wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch);
+            hm = w.hmask;
+            for (int base = 0; base < nU; base += 64) {
+                const int q = base + lane;
+                const int c2 = q < nU ? A::ldi(&w.ucol[q]) : 0;
+                wp_uh_insert_all<G, IdT>(w, hm, q < nU, c2, q);
+                A::sync();
+            }
+        }
         if (G && alt_lcol != nullptr && nL + p > w.capL && nL + p <= alt_capL) WP_MOVE_POOL();
         // The next column that is ELIMINATED: the smallest one whose entry is neither zero (ILUT.hpp:239-240) nor below the stage-1
         // threshold (:244-245).  The reference pops every column in ascending order and forgets those; a forgotten entry has no
@@ -647,7 +665,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
 #endif
         const double ud = wave_bcast_f64(__longlong_as_double((long long)v0), 0);
         const double m = wkv / ud;                                           // :249
-        if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
+        if (nK >= w.capK) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch); return 1; }
         if (lane == 0) { w.kcol[nK] = k; w.kval[nK] = m; w.kseq[nK] = (IdT)sk; }
         ++nK;
         for (int base = 0; base < ul; base += 64) {                          // w -= m * U[k, j>k]  (:252-253)
@@ -677,7 +695,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             const int bmin = bcol[0], bmax = bcol[cnt - 1];
             // (the first probe of the U-slot hash is asked for before the pass over the pool, whose trip it shares)
             const bool uside = valid && c > i;
-            unsigned hU = wp_hash(c, w.hmask);
+            unsigned hU = wp_hash(c, hm);
             unsigned eU = uside ? (unsigned)w.uh[hU] : 0u;
             WP_T(tu1); WP_SUB(1, 4, tu0, tu1);
             if (cnt <= 16 && base == 0) {
@@ -712,7 +730,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                     const int cc = A::ldi(&w.ucol[eU - 1]);
                     const double o = A::ldd(&w.uval[eU - 1]);
                     if (cc == c) { A::std_(&w.uval[eU - 1], o - pr); ufound = true; break; }
-                    hU = (hU + 1) & (unsigned)w.hmask;
+                    hU = (hU + 1) & (unsigned)hm;
                     eU = (unsigned)w.uh[hU];
                 }
             }
@@ -726,8 +744,8 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
             const bool nf = valid && c != i && (c < i ? bfound[lane] == 0 : !ufound);
             const bool isL = nf && c < i, isU = nf && c > i;
             const unsigned long long mL = __ballot(isL), mU = __ballot(isU);
-            if (seq + __popcll(mL) > WpIdMax<IdT>::value) { wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
-            if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
+            if (seq + __popcll(mL) > WpIdMax<IdT>::value) { wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch); return 1; }
+            if (nL + __popcll(mL) > w.capL || nU + __popcll(mU) > w.capU) { if (!G && lane == 0) atomicAdd(&ctrl[nL + __popcll(mL) > w.capL ? 4 : 5], 1); wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch); return 1; }
             if (isL) {
                 const int pos = nL + __popcll(mL & lt);
                 const double fv = 0.0 - pr;
@@ -735,7 +753,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
                 if (have && fv != 0.0 && !(fabs(fv) < thr1) && (unsigned)c < best) { best = (unsigned)c; bq = pos; }
             }
             if (isU) { const int pos = nU + __popcll(mU & lt); A::sti(&w.ucol[pos], c); A::std_(&w.uval[pos], 0.0 - pr); }
-            wp_uh_insert_all<G, IdT>(w, isU, c, nU + __popcll(mU & lt), hU);
+            wp_uh_insert_all<G, IdT>(w, hm, isU, c, nU + __popcll(mU & lt), hU);
             nL += __popcll(mL); seq += __popcll(mL); nU += __popcll(mU);
             A::sync();
             WP_T(ts2); WP_ACC(6, ts1, ts2);
@@ -746,7 +764,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     // (10.-12.) dropping (ILUT.hpp:259,261).  The U row FIRST: it is what other rows wait for; the L row is nobody's dependency and is
     // selected behind the publication (the capacity test of its staging comes before anything is published)
     if (G && alt_lcol != nullptr && nK > w.capL && nK <= alt_capL) { nL = 0; WP_MOVE_POOL(); }      // (the pool is empty: only its home changes)
-    if (nK > w.capL) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, lane, nU, gscratch); return 1; }
+    if (nK > w.capL) { if (!G && lane == 0) atomicAdd(&ctrl[6], 1); wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch); return 1; }
     const size_t lb = (size_t)i * p;
     __builtin_amdgcn_s_waitcnt(0);
     // (12.) U row = (i, w[i]) then kept entries; every datum write-through, the length last is not required
@@ -795,7 +813,7 @@ __device__ __forceinline__ int wp_row(const int lane, const int i, const int n, 
     if (lane == 0) { Lrow_idx[lb + nLk] = i; Lrow_val[lb + nLk] = 1.0; Llen[i] = nLk + 1; }
     A::sync();
     WP_T(tq0e); WP_SUB(4, 4, tq0d, tq0e);
-    wp_uh_clear<G, IdT>(w, lane, nU, gscratch);
+    wp_uh_clear<G, IdT>(w, hm, lane, nU, gscratch);
     WP_T(tq1); WP_ACC(3, tq0, tq1); WP_SUB(4, 5, tq0e, tq1);
     return 0;
 }
