@@ -56,7 +56,10 @@ namespace ilupp {
 static constexpr int kWpSel = 256;      // (the KEPT list is append-only until the end: it lives in global memory)
 static constexpr int kWpGCapU = 65534, kWpGCapL = 1 << 15, kWpGCapK = 1 << 15;      // (U slot ids + 1 fit the table's 16-bit cells)
 static constexpr int kWpHashG = 1 << 17;
-static constexpr int kWpHashSmall = 1 << 12;            // cells a row's U-slot hash starts on in a global table (wp_row: hm)
+#ifndef ILUT_HASH_SMALL
+#define ILUT_HASH_SMALL 4096
+#endif
+static constexpr int kWpHashSmall = ILUT_HASH_SMALL;    // cells a row's U-slot hash starts on in a global table (wp_row: hm)
 #ifndef ILUT_SPIN
 #define ILUT_SPIN (1u << 24)
 #endif
