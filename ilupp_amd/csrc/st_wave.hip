@@ -716,6 +716,9 @@ static constexpr int kWfLanes = kThreads, kWfPairs = 64;
 #ifndef WF_PSLEEP
 #define WF_PSLEEP 4
 #endif
+#ifndef WD_PSLEEP
+#define WD_PSLEEP 16
+#endif
 static constexpr int kWfProdNap = WF_PSLEEP;              // s_sleep units (64 cycles) a producer waits behind each barrier before it issues loads
 static constexpr int kWfRow = kWfLanes + kWfPairs + 16;   // doubles per slot: lanes, courier pairs, [320] a cell of ones / zeros (+ padding: 4 rows = 21 x 512 B)
 static constexpr int kWfCell = kWfLanes + kWfPairs;
@@ -1300,6 +1303,633 @@ k_ilu0_wx(WfArgs A)
     }
 }
 
+
+// =============================================================================================
+// ILU(0), wave-exchange form fed by LDS-DMA (round 6): k_ilu0_wd.
+//
+// What k_ilu0_wx spends a step on beyond its chain, measured with its knock-outs (profiles/README.md: -DWF_X_NOPROD takes 0.17 of the
+// 0.57 us a lone tile needs per step): six producer waves that load A's values into registers, wait for them, and scatter them into
+// canonical rows with 36 ds_write_b64 per step -- on the SIMDs, the LDS port and at the barrier of the four waves that walk the chain.
+// Here nobody touches the values on their way in:
+//   * four LOADER waves (one per consumer wave) issue buffer_load_dwordx4 ... lds: A's values go from HBM into LDS as they lie, a
+//     128-byte window per lane and block of two steps (eight threads x 16 bytes = one memory burst per lane; the window of block b
+//     starts at the lane's row of step 2 b rounded down to 16 bytes and advances by the lane's two rows), no register, no ds_write,
+//     no wait for data in any wave but a counted vmcnt in the loader.  A ring of four blocks per lane: six steps of read-ahead;
+//   * a window's eight 16-byte pieces are ROTATED by the lane ((lane >> 1) & 7; the source address of a DMA thread is per thread, its
+//     LDS destination is not: thread order), so that the 16 lanes the LDS serves at a time read 16 different bank groups;
+//   * the consumers read their row's seven entries where the window holds them: seven ds_read_b64 at lane-constant addresses (by step
+//     parity; an entry the lane's rows do not have is read from a cell of zeros) straight into the canonical order {aC, aB} {aA, d}
+//     {a'A, a'B} {a'C} -- from there on a step is k_ilu0_wx's, bit for bit;
+//   * the hand-off arrays are kept once (a lane's source of `dt` steps ago is one of four precomputed addresses), which is what
+//     lets 128 KB of ring fit beside them.
+// MODE 1 (experiment, ILUPP_WD_MODE=1): the pivot recurrence alone -- the records are not stored (results are wrong by design; what
+// VERDICT r5 asked to be measured: the chain without the record stream).
+// =============================================================================================
+static constexpr int kWdD = 4;                             // blocks of two steps in a lane's ring
+static constexpr int kWdWaveBlk = 64 * 128 + 16;           // a wave's windows of one block, and 16 bytes of zeros (what a row position the lane does not have reads)
+static constexpr int kWdWaveRing = kWdD * kWdWaveBlk;
+static constexpr unsigned kWdRingBytes = 4u * kWdWaveRing;
+static constexpr int kWdRowX = kThreads + 64 + 8;          // doubles per slot of the pivot and a'B arrays: lanes, courier pairs, [320] the cell of ones / zeros
+static constexpr int kWdRowC = kThreads + 8;               // ... of the a'C array: lanes, [256] the cell of zeros
+static constexpr int kWdCellX = kThreads + 64, kWdCellC = kThreads;
+static constexpr unsigned kWdX = kWdRingBytes;
+static constexpr unsigned kWdTB = kWdX + 4u * kWdRowX * 8u;
+static constexpr unsigned kWdTC = kWdTB + 4u * kWdRowX * 8u;
+static constexpr int kWdLds = (int)(kWdTC + 4u * kWdRowC * 8u) + 64;
+static constexpr int kWdThreads = kThreads + 2 * 64 + 4 * 64;      // consumers, poller, exporter, loaders
+static_assert(kWdLds <= 160 * 1024 - 256, "one workgroup per CU: the LDS of a CU");
+
+struct WdLane {
+    unsigned xB[4], xC[4];        // pivot hand-off: where the stand-in of class B / C FOR a step = v (mod 4) is read (the cell of ones without an entry)
+    unsigned tB[4], tC[4];        // transposed entries of the class B / C elimination (a cell of zeros without one)
+    unsigned ra[2][7];            // the row's seven canonical places in the lane's window, by step parity (relative to the ring slot)
+    bool ringC;
+    int src16;
+    bool hasB, hasC, hasUB, hasUC;
+};
+// the value of step (v - dt) of `src` in a hand-off array whose slots are `row` doubles long, as read for step v (mod 4)
+__device__ __forceinline__ void wd_addr4(unsigned a[4], const unsigned base, const int row, const int src, const int dt)
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = base + (unsigned)((((v - dt) & 3) * row + src) * 8);
+}
+
+template <int MODE>
+__device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds, const int wg, const WdLane W, const int tlo, const int thi)
+{
+    typedef double v2dd __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    const int slot = wg * kThreads + t;
+    const int32_t *T = A.ltab + (size_t)slot * kStTab;
+    const int cnt = T[ST_CNT], sk = T[ST_SKEW];
+    const int32_t *wt = A.wtab + (size_t)(wg * 4 + wv) * 4;
+    const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
+              nchw = __builtin_amdgcn_readfirstlane(wt[2]);
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.pkL + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(A.pkU + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
+    unsigned vout = (unsigned)(tlo - tminw) * 2048u + (unsigned)ln * 16u;          // (a step outside the wave's chunks: out of range)
+    const unsigned xown = kWdX + (unsigned)t * 8u, tbown = kWdTB + (unsigned)t * 8u, tcown = kWdTC + (unsigned)t * 8u;
+
+    // the row of step s (ring slot (s >> 1) & 3, parity s & 1): seven 8-byte reads at lane-constant places
+#define WD_ROW(blk_, par_, r0_, r1_, r2_, r3_)                                                                     \
+    do {                                                                                                           \
+        const unsigned o_ = (unsigned)(blk_) * kWdWaveBlk;                                                         \
+        (r0_).x = st_lds(lds, W.ra[par_][0] + o_); (r0_).y = st_lds(lds, W.ra[par_][1] + o_);                      \
+        (r1_).x = st_lds(lds, W.ra[par_][2] + o_); (r1_).y = st_lds(lds, W.ra[par_][3] + o_);                      \
+        (r2_).x = st_lds(lds, W.ra[par_][4] + o_); (r2_).y = st_lds(lds, W.ra[par_][5] + o_);                      \
+        (r3_).x = st_lds(lds, W.ra[par_][6] + o_); (r3_).y = 0.0;                                                  \
+    } while (0)
+#define WD_HAND_T(h4_, r2_, r3_)                                                                                   \
+    do {                                                                                                           \
+        *reinterpret_cast<double *>(lds + tbown + (unsigned)(h4_) * (kWdRowX * 8)) = (r2_).y;                      \
+        *reinterpret_cast<double *>(lds + tcown + (unsigned)(h4_) * (kWdRowC * 8)) = (r3_).x;                      \
+    } while (0)
+    // (k_ilu0_wx: the entries of a chain's first and last row sit one place nearer to the diagonal)
+    const int fl = T[ST_DFL];
+    const int kF = ((fl >> 2) & 1) ? 0 : -1, kL = ((fl >> 3) & 1) ? cnt - 1 : -1;
+    const bool fCB = W.hasC && W.hasB, fCA = W.hasC && !W.hasB, fBA = W.hasB;
+    const bool lCB = W.hasUC && W.hasUB, lCA = W.hasUC && !W.hasUB, lBA = W.hasUB;
+#define WD_ENDS(kk_, r0_, r1_, r2_, r3_)                                                                          \
+    do {                                                                                                           \
+        const bool f_ = (kk_) == kF, l_ = (kk_) == kL;                                                             \
+        if (__builtin_amdgcn_ballot_w64(f_ || l_) != 0) {                                                          \
+            const double c_ = (r0_).x, b_ = (r0_).y, a_ = (r1_).x, ua_ = (r2_).x, ub_ = (r2_).y, uc_ = (r3_).x;    \
+            (r0_).x = f_ ? (fCB ? b_ : (fCA ? a_ : c_)) : c_;                                                      \
+            (r0_).y = f_ ? (fBA ? a_ : b_) : b_;                                                                   \
+            (r1_).x = f_ ? 0.0 : a_;                                                                               \
+            (r2_).x = l_ ? 0.0 : ua_;                                                                              \
+            (r2_).y = l_ ? (lBA ? ua_ : ub_) : ub_;                                                                \
+            (r3_).x = l_ ? (lCB ? ub_ : (lCA ? ua_ : uc_)) : uc_;                                                  \
+        }                                                                                                          \
+    } while (0)
+    ST_BARRIER();                                           // (the loaders' first two blocks have landed, the courier's first entries are in place)
+    v2dd c0_, c1_, c2_, c3_;                                // the row of the current step: {aC, aB} {aA, d} {a'A, a'B} {a'C, -}
+    v2dd n0_, n1_, n2_, n3_;                                // ... of the next step
+    WD_ROW(0, 0, c0_, c1_, c2_, c3_);
+    WD_ROW(0, 1, n0_, n1_, n2_, n3_);
+    WD_ENDS(tlo - sk, c0_, c1_, c2_, c3_);
+    WD_HAND_T(0, c2_, c3_);
+    double bB = st_lds(lds, W.xB[0]), bC = st_lds(lds, W.xC[0]);  // pivots of other waves / workgroups for the first step
+    ST_BARRIER();                                           // (everybody's transposed entries of the first step are handed on)
+    double tB = st_lds(lds, W.tB[0]), tC = st_lds(lds, W.tC[0]);
+    double w3prev = 1.0, upA = 0.0;
+    double qC = 1.0;
+    int k = tlo - sk;
+    unsigned long long wacc_ = 0;
+    (void)wacc_;
+    for (int tb = tlo; tb < thi; tb += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double pC = W.ringC ? bC : qC;
+            const double pB = wx_dpp_shr1(bB, w3prev);
+            // for the steps to come: the row of the step after the next (block ((u + 2) >> 1) & 3 of the ring), the pivots and the
+            // transposed entries of the next step that do not come through the wave's registers
+            v2dd m0_, m1_, m2_, m3_;
+            WD_ROW(((u + 2) >> 1) & 3, u & 1, m0_, m1_, m2_, m3_);
+            const double nB = st_lds(lds, W.xB[(u + 1) & 3]);
+            const double nC = st_lds(lds, W.xC[(u + 1) & 3]);
+            const double ntB = st_lds(lds, W.tB[(u + 1) & 3]);
+            const double ntC = st_lds(lds, W.tC[(u + 1) & 3]);
+            const bool valid = (unsigned)k < (unsigned)cnt;
+#ifdef WX_STAMP
+            if (t == 0 && wg < 4096 && k == 0) g_wf_tl[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            if (t == 0 && wg < 4096 && k == cnt - 1) g_wf_tl[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+            const double aA = c1_.x, tA = k == 0 ? 0.0 : upA;
+            const double uA = c2_.x;
+            // u_rr = a_rr - sum (a_rk / u_kk) a_kr, eliminations in ascending k: classes C, B, A (ILU0.hpp:47-62)
+            const double lC = c0_.x / pC, lB = c0_.y / pB, lA = aA / w3prev;
+            double w = c1_.y;
+            w = w - lC * tC;
+            w = w - lB * tB;
+            w = w - lA * tA;
+            {
+                const unsigned long long wb = st_bits(w);
+                if ((wb & ~3ull) == (kSentinel & ~3ull)) w = st_dbl(kCanonNaN);
+            }
+            const double w3 = valid ? w : 1.0;
+            *reinterpret_cast<double *>(lds + xown + (unsigned)(u & 3) * (kWdRowX * 8)) = w3;
+            qC = wx_from_lane(W.src16, w3);
+            w3prev = w3; upA = c2_.x;
+            {
+                typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+                v2dd la, lb, ua, ub;
+                la.x = lC; la.y = lB; lb.x = lA; lb.y = 1.0;
+                ua.x = uA; ua.y = c2_.y; ub.x = c3_.x; ub.y = w3;
+                if (MODE == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, la), rL, vout, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vout + 1024u, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ua), rU, vout, 0, 2);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ub), rU, vout + 1024u, 0, 2);
+                vout += 2048u;
+            }
+            WD_ENDS(k + 1, n0_, n1_, n2_, n3_);
+            WD_HAND_T((u + 1) & 3, n2_, n3_);
+            c0_ = n0_; c1_ = n1_; c2_ = n2_; c3_ = n3_;
+            n0_ = m0_; n1_ = m1_; n2_ = m2_; n3_ = m3_;
+            bB = nB; bC = nC; tB = ntB; tC = ntC;
+            ++k;
+            WF_BARRIER(wacc_);
+        }
+    }
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) g_wf_wait[wg * 16 + wv] = wacc_;
+#endif
+#undef WD_ROW
+#undef WD_HAND_T
+#undef WD_ENDS
+}
+
+// The courier of k_ilu0_wx did three things in ONE wave -- polled the pivots of earlier workgroups, fetched their transposed entries
+// from A, exported this workgroup's border pivots with write-through stores -- and a wave's vector-memory operations retire in issue
+// order: to look at a poll of two steps ago it waited for everything older, the write-through store of three steps ago (acknowledged
+// by memory, not by L2) and a load of A (HBM) included.  On an idle chip those come back within two steps; with 60 tiles at work they
+// do not, and the whole workgroup stood at its barrier for them every step (stamped build, 256^3: the courier of a tile WITHOUT imports
+// spent 0.7 of its time there, and a step took 0.62 us against 0.46 us on a chip with 16 tiles).  So: one wave per kind of traffic.
+//   * the POLLER only polls (kWdNP steps ahead): what it waits for is the hand-over itself;
+//   * the EXPORTER stores the border pivots right behind the barrier and never waits for a store; it also brings the transposed
+//     entries, asked for kWdNA steps ahead, so that the only thing it waits for is a load (and the stores in front of it) of long ago.
+#ifndef WD_NP
+#define WD_NP 2
+#endif
+static constexpr int kWdNP = WD_NP, kWdNA = 8, kWdSH = 2;
+static_assert(8 % kWdNP == 0, "the poller's ring of registers is walked with u % kWdNP inside trips of eight steps");
+
+__device__ __forceinline__ void wd_poller(const WfArgs &A, const unsigned long long *idle, unsigned char *lds, const WfPair P,
+                                          const int tlo, const int thi, const int wg)
+{
+    constexpr int NP = kWdNP, SH = kWdSH;
+    const int ln = threadIdx.x & 63;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.xch);
+    const unsigned span = (unsigned)P.cnt;
+    const unsigned hoX = kWdX + (unsigned)((kThreads + ln) * 8);
+    unsigned long long gq[NP];
+#define WDC_ADDR(k_) ((unsigned)(k_) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
+#pragma unroll
+    for (int g = 0; g < NP; ++g) { gq[g] = ld_agent_u64(WDC_ADDR(tlo + g - P.sk)); asm volatile("" ::: "memory"); }
+    bool dead = false;
+#ifdef WX_STAMP
+    unsigned long long nmiss_ = 0, nspin_ = 0;
+#define WDC_COUNT(c_) do { if (c_) ++nmiss_; } while (0)
+#define WDC_SPIN() do { ++nspin_; } while (0)
+#else
+#define WDC_COUNT(c_) do { } while (0)
+#define WDC_SPIN() do { } while (0)
+#endif
+#define WDC_DELIVER(i_)                                                                                              \
+    do {                                                                                                             \
+        const int k = tlo_ + (i_) - P.sk;                                                                            \
+        const bool need = (unsigned)k < span;                                                                        \
+        unsigned long long v = gq[(i_) % NP];                                                                        \
+        if (!dead) {                                                                                                 \
+            unsigned spins = 0;                                                                                      \
+            WDC_COUNT(__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0);                                     \
+            while (__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0) {                                       \
+                WDC_SPIN();                                                                                          \
+                if (need && v == kSentinel) v = ld_agent_u64(WDC_ADDR(k));                                           \
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                                                  \
+                __builtin_amdgcn_s_sleep(1);                                                                         \
+                if ((++spins & 255u) == 0) {                                                                         \
+                    if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);                                             \
+                    const int e = ld_agent_i32(&A.ctrl[1]);                                                          \
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                                                              \
+                    if (spins > kStSpinLimit || e != 0) { dead = true; break; }                                      \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+        *reinterpret_cast<unsigned long long *>(lds + hoX + (unsigned)((i_) & 3) * (kWdRowX * 8)) = v;               \
+        gq[(i_) % NP] = ld_agent_u64(WDC_ADDR(k + NP));                                                              \
+    } while (0)
+    {
+        const int tlo_ = tlo;
+#pragma unroll
+        for (int i = 0; i < SH; ++i) WDC_DELIVER(i);
+    }
+    ST_BARRIER();
+    ST_BARRIER();
+    unsigned long long cwacc_ = 0, dacc_ = 0;
+    (void)cwacc_; (void)dacc_;
+    for (int tb = tlo; tb < thi; tb += 8) {
+        const int tlo_ = tb;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#ifdef WX_STAMP
+            const unsigned long long d0_ = __builtin_amdgcn_s_memtime();
+#endif
+            WDC_DELIVER(u + SH);
+#ifdef WX_STAMP
+            dacc_ += __builtin_amdgcn_s_memtime() - d0_;
+#endif
+            WF_BARRIER(cwacc_);
+        }
+    }
+#undef WDC_DELIVER
+#undef WDC_COUNT
+#undef WDC_SPIN
+#undef WDC_ADDR
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 4] = nspin_; g_wf_wait[wg * 16 + 13] = nmiss_; g_wf_wait[wg * 16 + 15] = (unsigned long long)(thi - tlo);
+                                g_wf_wait[wg * 16 + 11] = cwacc_; g_wf_wait[wg * 16 + 14] = dacc_; }
+#endif
+    if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
+}
+
+__device__ __forceinline__ void wd_exporter(const WfArgs &A, unsigned char *lds, const WfPair P, const int tlo, const int thi, const int wg,
+                                            const int elane)
+{
+    constexpr int NA = kWdNA, SH = kWdSH;
+    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+    const int ln = threadIdx.x & 63;
+    const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
+    const unsigned span = (unsigned)P.cnt;
+    const unsigned hoT = kWdTB + (unsigned)((kThreads + ln) * 8);
+    const int E = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
+    const int xrow0 = A.xw[wg * 4 + 3] + (tlo - A.xw[wg * 4 + 1]) * E;
+    const unsigned ea = kWdX + (unsigned)((elane >= 0 ? elane : kWdCellX) * 8);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + xrow0, 0, (int)((unsigned)(thi - tlo) * (unsigned)E * 8u), 0x00020000);
+    unsigned vx = elane >= 0 ? (unsigned)ln * 8u : 0xfffffff0u;
+    const unsigned dvx = elane >= 0 ? (unsigned)E * 8u : 0u;
+    if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 1);                 // (the analysis does not let such a schedule through)
+    double ga[NA];
+#define WDC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : 0xfffffff0u)
+#define WDC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, WDC_AT(k_), 0, 0))
+#pragma unroll
+    for (int g = 0; g < NA; ++g) {
+        ga[g] = WDC_LDAT(tlo + g - P.sk);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, 0.0), rx, 0xfffffff0u, 0, 16);      // (the way in looks like a pass of the loop)
+        asm volatile("" ::: "memory");
+    }
+#define WDC_DELIVER(i_)                                                                                              \
+    do {                                                                                                             \
+        const int k = tlo_ + (i_) - P.sk;                                                                            \
+        *reinterpret_cast<double *>(lds + hoT + (unsigned)((i_) & 3) * (kWdRowX * 8)) = ga[(i_) % NA];               \
+        ga[(i_) % NA] = WDC_LDAT(k + NA);                                                                            \
+    } while (0)
+    {
+        const int tlo_ = tlo;
+#pragma unroll
+        for (int i = 0; i < SH; ++i) {
+            WDC_DELIVER(i);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, 0.0), rx, 0xfffffff0u, 0, 16);
+        }
+    }
+    ST_BARRIER();
+    ST_BARRIER();
+    unsigned long long ewacc_ = 0, edacc_ = 0;
+    (void)ewacc_; (void)edacc_;
+    for (int tb = tlo; tb < thi; tb += 8) {
+        const int tlo_ = tb;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#ifdef WX_STAMP
+            const unsigned long long d0_ = __builtin_amdgcn_s_memtime();
+#endif
+            WDC_DELIVER(u + SH);
+#ifdef WX_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            edacc_ += __builtin_amdgcn_s_memtime() - d0_;
+#endif
+            WF_BARRIER(ewacc_);
+            {
+                const double v = st_lds(lds, ea + (unsigned)(u & 3) * (kWdRowX * 8));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v), rx, vx, 0, 16);          // sc1: write-through
+                vx += dvx;
+            }
+        }
+    }
+#undef WDC_DELIVER
+#undef WDC_AT
+#undef WDC_LDAT
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 9] = ewacc_; g_wf_wait[wg * 16 + 10] = edacc_; }
+#endif
+}
+
+// a loader wave: the windows of consumer wave `lw`.  Thread (g, j) of instruction q: piece (j + rot) & 7 of the window of lane 8 q + g
+__device__ __forceinline__ void wd_loader(const WfArgs &A, unsigned char *lds, const int wg, const int lw, const int tlo, const int thi)
+{
+    const int ln = threadIdx.x & 63, j = ln & 7, gi = ln >> 3;
+    const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
+    unsigned g[8], S[8];
+    const int b0 = tlo >> 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int w = 8 * q + gi;
+        const int32_t *T = A.ltab + (size_t)(wg * kThreads + lw * 64 + w) * kStTab;
+        const int cnt = T[ST_CNT], sk = T[ST_SKEW], p0 = T[ST_P0], fl = T[ST_DFL];
+        const int ownL = (fl >> 2) & 1, m = fl >> 4;
+        const unsigned Cu = 8u * (unsigned)(p0 - ownL - sk * m) + (unsigned)A.val_shift;
+        const int piece = (j + ((w >> 1) & 7)) & 7;
+        const bool on = cnt > 0 && (piece < 7 || (Cu & 15u) + 16u * (unsigned)m > 112u);
+        S[q] = on ? 16u * (unsigned)m : 0u;
+        g[q] = on ? (Cu & ~15u) + (unsigned)b0 * S[q] + 16u * (unsigned)piece : 0xfffffff0u;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+#define WDL_ISSUE(slot_)                                                                                             \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(lds + lw * kWdWaveRing + (slot_) * kWdWaveBlk + q * 1024), 16, g[q], 0, 0, 0); \
+            g[q] += S[q];                                                                                            \
+        }                                                                                                            \
+        asm volatile("" ::: "memory");                                                                               \
+    } while (0)
+    // blocks b0 .. b0 + 3; b0 and b0 + 1 have landed before the consumers' first reads
+    WDL_ISSUE(0); WDL_ISSUE(1); WDL_ISSUE(2); WDL_ISSUE(3);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    ST_BARRIER();
+    ST_BARRIER();
+    unsigned long long wacc_ = 0, vacc_ = 0, iacc_ = 0;
+    (void)wacc_; (void)vacc_; (void)iacc_;
+    for (int tb = tlo; tb < thi; tb += 8) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            // steps 2 bb, 2 bb + 1 of this trip (block b): the consumers read the rows of block b + 1; block b's slot was read for the
+            // last time a step ago and takes block b + 4; block b + 2 has to be there behind the second barrier (b + 3, b + 4 may be
+            // on their way: sixteen instructions)
+#ifdef WX_STAMP
+            const unsigned long long i0_ = __builtin_amdgcn_s_memtime();
+#endif
+            WDL_ISSUE(bb);
+#ifdef WX_STAMP
+            iacc_ += __builtin_amdgcn_s_memtime() - i0_;
+#endif
+            WF_BARRIER(wacc_);
+#ifdef WX_STAMP
+            const unsigned long long v0_ = __builtin_amdgcn_s_memtime();
+#endif
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#ifdef WX_STAMP
+            vacc_ += __builtin_amdgcn_s_memtime() - v0_;
+#endif
+            WF_BARRIER(wacc_);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 5 + lw] = wacc_; if (lw == 0) g_wf_wait[wg * 16 + 5] = vacc_ << 32 | (wacc_ & 0xffffffffull); if (lw == 1) g_wf_wait[wg * 16 + 6] = iacc_ << 32 | (wacc_ & 0xffffffffull); }
+#endif
+#undef WDL_ISSUE
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kWdThreads)
+k_ilu0_wd(WfArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int s_cnt[4], s_total;
+    __shared__ unsigned s_ticket;
+    // (set-up only, inside the ring: read into registers before the first window lands)
+    WfPair *s_pairs = reinterpret_cast<WfPair *>(lds);
+    int *s_exp = reinterpret_cast<int *>(lds + 64 * sizeof(WfPair));
+    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
+    __syncthreads();
+    const int wg = (int)s_ticket;
+    const int t = threadIdx.x;
+    int tlo = 0x7fffffff, thi = -0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t *w4 = A.wtab + (size_t)(wg * 4 + q) * 4;
+        const int a = w4[1], b = w4[2];
+        if (b > 0) { tlo = min(tlo, a); thi = max(thi, a + b); }
+    }
+    tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
+    if (thi <= tlo) return;
+    tlo &= ~7;                                                        // step % 8 = position in the unrolled loops
+    for (int i = t; i < kWdLds / 8; i += kWdThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
+    if (t < 4) s_cnt[t] = 0;
+    __syncthreads();
+    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; s_pairs[t] = z; }
+    if (t < kThreads) s_exp[t] = -1;
+    if (t < 4) *reinterpret_cast<double *>(lds + kWdX + (unsigned)((t * kWdRowX + kWdCellX) * 8)) = 1.0;
+    __syncthreads();
+    if (t < kThreads) {
+        const int slot = wg * kThreads + t;
+        const int32_t *T = A.ltab + (size_t)slot * kStTab;
+        const int nd = T[ST_ND], cnt = T[ST_CNT];
+        int cls[3]; bool ring[3];
+        bool ok = wx_lane_ok(T, t, false) && wf_lane_ok(T, A.ltabB, A.uslot);
+        (void)wr_classify(T, t, false, cls, ring);
+        WdLane W;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            W.xB[v] = W.xC[v] = kWdX + (unsigned)(kWdCellX * 8);
+            W.tB[v] = W.tC[v] = kWdTB + (unsigned)(kWdCellX * 8);
+        }
+        W.ringC = true;
+        W.src16 = ((t - 16) & 63) * 4;
+        bool isg[3];
+        WfPair gp[3];
+        unsigned xg[3][4], tg[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int sw = T[ST_SRC + j];
+            const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
+            const int os = sw >> 2;
+            const int q = ty != ST_NONE ? T[ST_Q + j] : -1;
+            isg[j] = ty == ST_GHOST;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { xg[j][v] = 0; tg[j][v] = 0; }
+            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0;
+            if (ty == ST_LOCAL || ty == ST_GHOST) {
+                const int pu = A.uslot[os];
+                const int32_t *TPB = A.ltabB + (size_t)(pu < 0 ? 0 : pu) * kStTab;
+                int pc[3]; bool pr[3];
+                (void)wr_classify(TPB, pu & 255, true, pc, pr);
+                const int qs = (q >= 0 && pu >= 0) ? wr_slot_of(q == 0 ? pc[0] : (q == 1 ? pc[1] : pc[2]), true) : -1;
+                if (qs != 1 && qs != 2) ok = false;                  // (a'B or a'C of the pivot row: what the lanes hand on)
+                if (ty == ST_LOCAL) {
+                    const int lane = os & 255, dt = T[ST_DT + j];
+                    if (dt < 1 || dt > 3) ok = false;
+                    wd_addr4(xg[j], kWdX, kWdRowX, lane, dt);
+                    if (qs == 2) wd_addr4(tg[j], kWdTC, kWdRowC, lane, dt); else wd_addr4(tg[j], kWdTB, kWdRowX, lane, dt);
+                } else {
+                    const int pw = os >> 8;
+                    const int32_t *TP = A.ltab + (size_t)os * kStTab;
+                    const int E = A.xw[pw * 4];
+                    const int kap = T[ST_KAP + j];
+                    d.stride = E;
+                    d.idx0 = A.xw[pw * 4 + 3] + (kap + TP[ST_SKEW] - T[ST_SKEW] - A.xw[pw * 4 + 1]) * E + A.xe[os];
+                    const int flp = TP[ST_DFL];
+                    const int mp = flp >> 4;
+                    d.hasT = q >= 0 ? 1 : 0;
+                    d.atm = 8 * mp;
+                    d.at0 = (unsigned)A.val_shift + 8u * (unsigned)(TP[ST_P0] - ((flp >> 2) & 1) + TP[ST_ND] + 1 + (q < 0 ? 0 : q) + kap * mp);
+                    d.klast = TP[ST_CNT] - 1 - kap;
+                    d.sh = 8 * ((flp >> 3) & 1);
+                }
+            } else if (ty == ST_OWN) {
+                if (q != 0) ok = false;
+            }
+            gp[j] = d;
+        }
+        // the pairs of the workgroup, numbered
+        {
+            const int wv = t >> 6;
+            unsigned long long bal[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bal[j] = __builtin_amdgcn_ballot_w64(isg[j]);
+            const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]);
+            if ((t & 63) == 0) s_cnt[wv] = mine;
+            __syncthreads();
+            int before = 0;
+            for (int q = 0; q < wv; ++q) before += s_cnt[q];
+            if (t == 0) s_total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (isg[j]) {
+                    const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
+                    if (p < 64) s_pairs[p] = gp[j];
+                    wd_addr4(xg[j], kWdX, kWdRowX, kThreads + min(p, 63), 0);
+                    wd_addr4(tg[j], kWdTB, kWdRowX, kThreads + min(p, 63), 0);
+                }
+                before += __popcll(bal[j]);
+            }
+        }
+        W.hasB = W.hasC = W.hasUB = W.hasUC = false;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (cls[j] == WR_B) {
+                W.hasB = true;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { W.tB[v] = tg[j][v]; if (ring[j]) W.xB[v] = xg[j][v]; }
+            }
+            if (cls[j] == WR_C) {
+                W.hasC = true;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { W.tC[v] = tg[j][v]; if (ring[j]) W.xC[v] = xg[j][v]; }
+                if (!ring[j]) W.ringC = false;
+            }
+        }
+        {
+            const int su = cnt > 0 ? A.uslot[slot] : -1;
+            int bc[3] = {WR_NONE, WR_NONE, WR_NONE};
+            if (su >= 0) {
+                bool br[3];
+                (void)wr_classify(A.ltabB + (size_t)su * kStTab, su & 255, true, bc, br);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { if (bc[q] == WR_B) W.hasUB = true; if (bc[q] == WR_C) W.hasUC = true; }
+            } else if (cnt > 0) {
+                ok = false;
+            }
+            // where the seven canonical places of a row lie in the lane's window (k_ilu0_wx: s_place), by step parity
+            const int fld = T[ST_DFL], ndU = fld & 3, ownL = (fld >> 2) & 1, m = fld >> 4;
+            const unsigned Cu = 8u * (unsigned)(T[ST_P0] - ownL - T[ST_SKEW] * m) + (unsigned)A.val_shift;
+            const int ln = t & 63, wv = t >> 6;
+            const int rot = (ln >> 1) & 7;
+            int posOf[7] = {-1, -1, -1, -1, -1, -1, -1};
+#pragma unroll
+            for (int pos = 0; pos < 7; ++pos) {
+                int place = -1;
+                if (pos < nd) { const int c = pos == 0 ? cls[0] : (pos == 1 ? cls[1] : cls[2]); place = c == WR_NONE ? -1 : wr_slot_of(c, false); }
+                else if (pos == nd) place = 3;
+                else if (pos <= nd + ndU && pos - nd - 1 < 3) { const int q = pos - nd - 1; const int c = q == 0 ? bc[0] : (q == 1 ? bc[1] : bc[2]); place = c == WR_NONE ? -1 : 4 + wr_slot_of(c, true); }
+#pragma unroll
+                for (int pl_ = 0; pl_ < 7; ++pl_) if (place == pl_) posOf[pl_] = pos;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int pl_ = 0; pl_ < 7; ++pl_) {
+                    const unsigned B = (Cu & 15u) + (unsigned)(e * 8 * m) + 8u * (unsigned)(posOf[pl_] < 0 ? 0 : posOf[pl_]);
+                    const unsigned a = (unsigned)(wv * kWdWaveRing + ln * 128) + ((((B >> 4) - (unsigned)rot) & 7u) << 4) + (B & 8u);
+                    // (the zeros behind the wave's windows of every ring slot: the slot's offset is added to it as to any place)
+                    W.ra[e][pl_] = (cnt > 0 && posOf[pl_] >= 0 && B < 128u) ? a : (unsigned)(wv * kWdWaveRing + 64 * 128);
+                    if (cnt > 0 && posOf[pl_] >= 0 && B >= 128u) ok = false;
+                }
+        }
+        {
+            const int xe = A.xe[slot];
+            if (cnt > 0 && xe >= 0 && xe < kThreads) s_exp[xe] = t;
+        }
+        __syncthreads();
+        if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], 1);  // (the analysis does not let such a schedule through)
+        __syncthreads();                                              // (the courier has read its pair and its exported lane)
+        for (int i = t; i < 64 * (int)sizeof(WfPair) / 8 + kThreads / 2; i += kThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
+        __syncthreads();
+#ifdef WX_STAMP
+        const unsigned long long cy0_ = __builtin_amdgcn_s_memtime();
+        if (t == 0 && wg < 4096) g_wf_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+        wd_consumer<MODE>(A, lds, wg, W, tlo, thi);
+#ifdef WX_STAMP
+        if (t == 0 && wg < 4096) { g_wf_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime(); g_wf_wait[wg * 16 + 12] = __builtin_amdgcn_s_memtime() - cy0_; }
+#endif
+    } else if (t < kThreads + 128) {
+        __syncthreads();
+        __syncthreads();
+        const WfPair P = s_pairs[t & 63];
+        const int E = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
+        const int elane = ((t & 63) < E) ? s_exp[t & 63] : -1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        __syncthreads();
+        if (t < kThreads + 64) {
+            const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
+            wd_poller(A, idle, lds, P, tlo, thi, wg);
+        } else {
+            wd_exporter(A, lds, P, tlo, thi, wg, elane);
+        }
+    } else {
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        wd_loader(A, lds, wg, (t - kThreads - 128) >> 6, tlo, thi);
+    }
+}
+
+static int wd_mode()
+{
+    static const int m = [] { const char *e = getenv("ILUPP_WD_MODE"); return e ? atoi(e) : 0; }();
+    return m;
+}
+bool wd_on()
+{
+    static const bool on = getenv("ILUPP_NO_WD") == nullptr;
+    return on;
+}
+
 int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,
                     hipEvent_t e0, hipEvent_t e1)
 {
@@ -1309,6 +1939,8 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
         ILUPP_HIP(hipGetDevice(&dev));
         std::call_once(once[dev & 63], [] {
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWdLds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWdLds));
         });
     }
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
@@ -1323,7 +1955,12 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
     if (pl->join_ev && pl->join_before) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));       // (grid.hip's proof, on its side stream)
     ILUPP_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(k_ilu0_wx, dim3((unsigned)pl->nwg), dim3(kWfThreads), kWfLds, st, a);
+    if (wd_on()) {
+        if (wd_mode() == 1) hipLaunchKernelGGL((k_ilu0_wd<1>), dim3((unsigned)pl->nwg), dim3(kWdThreads), kWdLds, st, a);
+        else hipLaunchKernelGGL((k_ilu0_wd<0>), dim3((unsigned)pl->nwg), dim3(kWdThreads), kWdLds, st, a);
+    } else {
+        hipLaunchKernelGGL(k_ilu0_wx, dim3((unsigned)pl->nwg), dim3(kWfThreads), kWfLds, st, a);
+    }
     ILUPP_HIP(hipEventRecord(e1, st));
     ILUPP_HIP(hipGetLastError());
     int32_t ctrl[12];
