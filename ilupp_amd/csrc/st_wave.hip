@@ -716,9 +716,6 @@ static constexpr int kWfLanes = kThreads, kWfPairs = 64;
 #ifndef WF_PSLEEP
 #define WF_PSLEEP 4
 #endif
-#ifndef WD_PSLEEP
-#define WD_PSLEEP 16
-#endif
 static constexpr int kWfProdNap = WF_PSLEEP;              // s_sleep units (64 cycles) a producer waits behind each barrier before it issues loads
 static constexpr int kWfRow = kWfLanes + kWfPairs + 16;   // doubles per slot: lanes, courier pairs, [320] a cell of ones / zeros (+ padding: 4 rows = 21 x 512 B)
 static constexpr int kWfCell = kWfLanes + kWfPairs;
@@ -751,9 +748,11 @@ struct WfArgs {
     unsigned char *pkL, *pkU;                     // format-1 records, both in the forward schedule's order
     const int32_t *xe, *xw;
     double *xch;
-    int32_t *ctrl;                                // [0] ticket, [1] error
+    int32_t *ctrl;                                // [0] ticket, [1] error; k_ilu0_wa: [2], [3], [9] .. [14] tickets by XCD
+    int32_t flags;                                // k_ilu0_wa: 2 = every workgroup of the launch is resident at once; 1 = ... and tiles are handed out by XCD
+    int32_t *prog;                                // k_ilu0_wa: [tile] steps done, [nwg + tile] blocks of eight steps somebody has asked for (or null)
 };
-struct WfPair { int idx0, stride, sk, cnt; unsigned at0; int atm, klast, sh, hasT; };    // (st_direct.hip: SdPair)
+struct WfPair { int idx0, stride, sk, cnt; unsigned at0; int atm, klast, sh, hasT; int astart; };    // (st_direct.hip: SdPair; astart, k_ilu0_wa: where the producer's workgroup exports its first step)
 
 // what a consumer lane knows
 struct WfLane {
@@ -1163,7 +1162,7 @@ k_ilu0_wx(WfArgs A)
     tlo &= ~7;                                                        // step % 8 = position in the unrolled loops
     // the row ring and the hand-off arrays start all +0.0 (what no producer piece goes to stays that way); the cells of ones
     for (int i = t; i < kWfLds / 8; i += kWfThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
-    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; s_pairs[t] = z; }
+    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; s_pairs[t] = z; }
     if (t < kWfLanes) s_exp[t] = -1;
     if (t < 4) s_cnt[t] = 0;
     __syncthreads();
@@ -1191,7 +1190,7 @@ k_ilu0_wx(WfArgs A)
             const int q = ty != ST_NONE ? T[ST_Q + j] : -1;
             isg[j] = ty == ST_GHOST;
             xg[j] = 0; tg[j] = 0;
-            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0;
+            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0; d.astart = -1;
             if (ty == ST_LOCAL || ty == ST_GHOST) {
                 // the transposed entry: which entry right of the diagonal of the pivot row, and where its owner hands it on
                 const int pu = A.uslot[os];
@@ -1305,48 +1304,56 @@ k_ilu0_wx(WfArgs A)
 
 
 // =============================================================================================
-// ILU(0), wave-exchange form fed by LDS-DMA (round 6): k_ilu0_wd.
+// ILU(0), wave-exchange form, round 6: k_ilu0_wa -- fed by LDS-DMA, no barrier in its loop, other workgroups reading ahead for it.
 //
-// What k_ilu0_wx spends a step on beyond its chain, measured with its knock-outs (profiles/README.md: -DWF_X_NOPROD takes 0.17 of the
-// 0.57 us a lone tile needs per step): six producer waves that load A's values into registers, wait for them, and scatter them into
-// canonical rows with 36 ds_write_b64 per step -- on the SIMDs, the LDS port and at the barrier of the four waves that walk the chain.
-// Here nobody touches the values on their way in:
+// k_ilu0_wx (above) took 1.0 ms at 256^3 for three rounds.  What this round's stamps and experiments found about it:
+//   (1) a tile at work is bounded by what ONE CU can have in flight at HBM latency: 25-30 GB/s of loads + stores, whether 4 tiles
+//       work on an otherwise idle chip or 120 (4096 x 32 x 32: four tiles, 0.73 us per step; 8192 x 16 x 16, one tile whose data the
+//       Infinity Cache still holds from the run before: 0.44).  A tile moves 30 KB per step, so a step takes about 1.1 us, and the
+//       path through the launch is 30 hand-overs x 21 steps + 289 steps.  Neither the XCD a tile runs on, nor polling by the
+//       waiting tiles, nor the shader clock (2.35 GHz throughout) matter;
+//   (2) the same tile reads A at nearly twice that pace when A's values come from the Infinity Cache (256 x 96 x 96, A touched just
+//       before: 0.49 -> 0.31 ms) -- and at any time most CUs are idle: their tile has not begun or has ended;
+//   (3) s_barrier counts every wave of the workgroup: with helper waves that touch memory at the step's barrier, the waves on the
+//       chain stood there for whichever of them was late (0.2 of 0.6 us per step).
+// So:
 //   * four LOADER waves (one per consumer wave) issue buffer_load_dwordx4 ... lds: A's values go from HBM into LDS as they lie, a
 //     128-byte window per lane and block of two steps (eight threads x 16 bytes = one memory burst per lane; the window of block b
-//     starts at the lane's row of step 2 b rounded down to 16 bytes and advances by the lane's two rows), no register, no ds_write,
-//     no wait for data in any wave but a counted vmcnt in the loader.  A ring of four blocks per lane: six steps of read-ahead;
+//     starts at the lane's row of step 2 b rounded down to 16 bytes and advances by the lane's two rows): no register, no
+//     ds_write, no wait for data in any wave but a counted vmcnt in the loader.  A ring of four blocks per lane;
 //   * a window's eight 16-byte pieces are ROTATED by the lane ((lane >> 1) & 7; the source address of a DMA thread is per thread, its
 //     LDS destination is not: thread order), so that the 16 lanes the LDS serves at a time read 16 different bank groups;
 //   * the consumers read their row's seven entries where the window holds them: seven ds_read_b64 at lane-constant addresses (by step
 //     parity; an entry the lane's rows do not have is read from a cell of zeros) straight into the canonical order {aC, aB} {aA, d}
 //     {a'A, a'B} {a'C} -- from there on a step is k_ilu0_wx's, bit for bit;
+//   * the courier is three waves, one per kind of traffic (a wave's memory operations retire in issue order: behind a write-through
+//     store or a load of A, a poll is late): the POLLER only polls, the EXPORTER stores the border pivots and fetches the imports'
+//     transposed entries eight steps ahead, the PREFETCHER (below) reads ahead for other tiles;
+//   * NO BARRIER in the loop: every wave runs freely and waits only for what it really needs, through counters in LDS (all in
+//     STEPS: "everything up to and including this step is done"):
+//         cprog[w]  consumer wave w has finished the step (its LDS writes included)
+//         lfull[w]  the rows up to this step are in wave w's ring (loader w, behind its counted vmcnt)
+//         ipub      the poller has put the imported pivots up to this step into the import ring
+//         tpub      the exporter has put the imports' transposed entries up to this step into their slots
+//         eprog     the exporter has read (and stored) the border pivots of this step
+//     A consumer wave checks all it depends on with ONE ds_read_b32 and one compare per step: lane i reads counter i and compares
+//     it with the step plus the lane's margin (wave w - 1 one step ahead: its hand-over values are two steps old; wave w + 1 and
+//     the exporter not more than the history of the hand-off arrays behind; rows two steps ahead, imports one).  The counters are
+//     read half a step early: what is checked is a little stale, which only matters when a producer is less than that ahead --
+//     then the wave reads again until it is;
 //   * the hand-off arrays are kept once (a lane's source of `dt` steps ago is one of four precomputed addresses), which is what
 //     lets 128 KB of ring fit beside them.
-// MODE 1 (experiment, ILUPP_WD_MODE=1): the pivot recurrence alone -- the records are not stored (results are wrong by design; what
-// VERDICT r5 asked to be measured: the chain without the record stream).
+// MODE 1 (experiment, ILUPP_WD_MODE=1): the pivot recurrence alone -- of the records only {a'C, u_rr} is stored (results are wrong by
+// design; what VERDICT r5 asked to be measured: the chain without the record stream).
 // =============================================================================================
-static constexpr int kWdD = 4;                             // blocks of two steps in a lane's ring
+#ifndef WD_NP
+#define WD_NP 2
+#endif
+#ifndef WA_DMA_AUX
+#define WA_DMA_AUX 0
+#endif
+static constexpr int kWdSH = 2;                            // steps a delivery is ahead of the step that uses it
 static constexpr int kWdWaveBlk = 64 * 128 + 16;           // a wave's windows of one block, and 16 bytes of zeros (what a row position the lane does not have reads)
-static constexpr int kWdWaveRing = kWdD * kWdWaveBlk;
-static constexpr unsigned kWdRingBytes = 4u * kWdWaveRing;
-static constexpr int kWdRowX = kThreads + 64 + 8;          // doubles per slot of the pivot and a'B arrays: lanes, courier pairs, [320] the cell of ones / zeros
-static constexpr int kWdRowC = kThreads + 8;               // ... of the a'C array: lanes, [256] the cell of zeros
-static constexpr int kWdCellX = kThreads + 64, kWdCellC = kThreads;
-static constexpr unsigned kWdX = kWdRingBytes;
-static constexpr unsigned kWdTB = kWdX + 4u * kWdRowX * 8u;
-static constexpr unsigned kWdTC = kWdTB + 4u * kWdRowX * 8u;
-static constexpr int kWdLds = (int)(kWdTC + 4u * kWdRowC * 8u) + 64;
-static constexpr int kWdThreads = kThreads + 2 * 64 + 4 * 64;      // consumers, poller, exporter, loaders
-static_assert(kWdLds <= 160 * 1024 - 256, "one workgroup per CU: the LDS of a CU");
-
-struct WdLane {
-    unsigned xB[4], xC[4];        // pivot hand-off: where the stand-in of class B / C FOR a step = v (mod 4) is read (the cell of ones without an entry)
-    unsigned tB[4], tC[4];        // transposed entries of the class B / C elimination (a cell of zeros without one)
-    unsigned ra[2][7];            // the row's seven canonical places in the lane's window, by step parity (relative to the ring slot)
-    bool ringC;
-    int src16;
-    bool hasB, hasC, hasUB, hasUC;
-};
 // the value of step (v - dt) of `src` in a hand-off array whose slots are `row` doubles long, as read for step v (mod 4)
 __device__ __forceinline__ void wd_addr4(unsigned a[4], const unsigned base, const int row, const int src, const int dt)
 {
@@ -1354,9 +1361,82 @@ __device__ __forceinline__ void wd_addr4(unsigned a[4], const unsigned base, con
     for (int v = 0; v < 4; ++v) a[v] = base + (unsigned)((((v - dt) & 3) * row + src) * 8);
 }
 
-template <int MODE>
-__device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds, const int wg, const WdLane W, const int tlo, const int thi)
+// NCW consumer waves (4: a 16 x 16 patch of lines, one workgroup per CU), D ring blocks of two steps per lane (4).  The loops are
+// unrolled over U steps, a multiple of the ring (2 D steps) and of the hand-off arrays and the import ring (4 steps).
+// (NCW = 2, D = 3 is an experiment -- ILUPP_WA_HALF=1 on schedules of 16 x 8 patches, ILUPP_NO_GRID=1 ILUPP_TILE_TZ=8: two workgroups
+// per CU, to spread the tiles at work over more CUs.  Measured at 256^3: 1.2 ms against 1.0 -- two tiles that work at the same time
+// on one CU share what it can have in flight, and a path through the launch has 46 hand-overs instead of 30.)
+template <int NCW, int D>
+struct WaCfg {
+    static constexpr int NL = NCW * 64;                        // lanes
+    static constexpr int U = D == 4 ? 8 : 12;
+    static constexpr int R = 4;                                // steps of the import ring
+    static constexpr int NP = D == 4 ? 8 : 6;                  // steps the poller asks ahead / the exporter loads A's transposed entries ahead
+    static constexpr int WaveRing = D * kWdWaveBlk;
+    static constexpr int RowL = NL + 8;                        // doubles per slot of the pivot and a'C arrays: lanes, [NL] the cell of ones / zeros
+    static constexpr int RowX = NL + 64 + 8;                   // ... of the a'B array: lanes, the imports' transposed entries, [NL + 64] zeros
+    static constexpr unsigned X = (unsigned)(NCW * WaveRing);
+    static constexpr unsigned XI = X + 4u * RowL * 8u;
+    static constexpr unsigned TB = XI + (unsigned)R * 64u * 8u;
+    static constexpr unsigned TC = TB + 4u * RowX * 8u;
+    static constexpr unsigned Cnt = TC + 4u * RowL * 8u;
+    static constexpr int Lds = (int)Cnt + 128;
+    static constexpr int Threads = NL + 128 + NCW * 64 + 64;   // consumers, poller, exporter, loaders, prefetcher
+    static_assert(U % (2 * D) == 0 && U % 4 == 0 && U % NP == 0, "slots are immediates of the unrolled loops");
+    static_assert(Lds * (4 / NCW) <= 160 * 1024 - 256 * (4 / NCW), "the LDS of a CU");
+};
+enum { WA_CP = 0, WA_LF = 4, WA_IP = 8, WA_TP = 9, WA_EP = 10, WA_DEAD = 11, WA_BIG = 12, WA_WARM = 13 };
+static constexpr unsigned kWaSpinLimit = 1u << 24;
+
+// (LDS words other waves write: ordered with compiler barriers -- `volatile` would turn them into flat, system-scope accesses)
+__device__ __forceinline__ int wa_ld32(const unsigned char *lds, const unsigned off)
 {
+    asm volatile("" ::: "memory");
+    const int v = *reinterpret_cast<const int *>(lds + off);
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void wa_st32(unsigned char *lds, const unsigned off, const int v)
+{
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<int *>(lds + off) = v;
+    asm volatile("" ::: "memory");
+}
+template <class C> __device__ __forceinline__ int wa_cnt(const unsigned char *lds, const int i) { return wa_ld32(lds, C::Cnt + 4u * (unsigned)i); }
+template <class C> __device__ __forceinline__ void wa_set(unsigned char *lds, const int i, const int v) { wa_st32(lds, C::Cnt + 4u * (unsigned)i, v); }
+// a helper wave waits until the slowest consumer wave has finished step `s` (lanes 0..NCW-1 read one counter each)
+template <class C, int NCW>
+__device__ __forceinline__ bool wa_wait_consumers(unsigned char *lds, const int s, int32_t *ctrl)
+{
+    const int ln = threadIdx.x & 63;
+    unsigned spins = 0;
+    for (;;) {
+        const int c = wa_cnt<C>(lds, ln < NCW ? WA_CP + ln : WA_BIG);
+        if (__builtin_amdgcn_ballot_w64(c < s) == 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+            if (spins > kWaSpinLimit) { atomicExch(&ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
+            if (wa_cnt<C>(lds, WA_DEAD) != 0) return false;
+        }
+    }
+}
+
+template <int U>
+struct WaLane {
+    unsigned xB[4], xC[4];        // pivot hand-off: where the stand-in of class B / C FOR a step = v (mod 4) is read (the cell of ones without an entry)
+    unsigned tB[4], tC[4];        // transposed entries of the class B / C elimination FOR a step = v (mod 4) (a cell of zeros without one)
+    unsigned ra[2][7];
+    unsigned ca; int coff;        // the counter this lane checks and its margin: counter - coff >= step
+    bool ringC;
+    int src16;
+    bool hasB, hasC, hasUB, hasUC;
+};
+
+template <int MODE, int NCW, int D>
+__device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds, const int wg, const WaLane<WaCfg<NCW, D>::U> W, const int tlo, const int thi)
+{
+    typedef WaCfg<NCW, D> C;
+    constexpr int U = C::U;
     typedef double v2dd __attribute__((ext_vector_type(2)));
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
     const int slot = wg * kThreads + t;
@@ -1367,11 +1447,9 @@ __device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds,
               nchw = __builtin_amdgcn_readfirstlane(wt[2]);
     const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.pkL + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(A.pkU + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
-    unsigned vout = (unsigned)(tlo - tminw) * 2048u + (unsigned)ln * 16u;          // (a step outside the wave's chunks: out of range)
-    const unsigned xown = kWdX + (unsigned)t * 8u, tbown = kWdTB + (unsigned)t * 8u, tcown = kWdTC + (unsigned)t * 8u;
-
-    // the row of step s (ring slot (s >> 1) & 3, parity s & 1): seven 8-byte reads at lane-constant places
-#define WD_ROW(blk_, par_, r0_, r1_, r2_, r3_)                                                                     \
+    unsigned vout = (unsigned)(tlo - tminw) * 2048u + (unsigned)ln * 16u;
+    const unsigned xown = C::X + (unsigned)t * 8u, tbown = C::TB + (unsigned)t * 8u, tcown = C::TC + (unsigned)t * 8u;
+#define WA_ROW(blk_, par_, r0_, r1_, r2_, r3_)                                                                     \
     do {                                                                                                           \
         const unsigned o_ = (unsigned)(blk_) * kWdWaveBlk;                                                         \
         (r0_).x = st_lds(lds, W.ra[par_][0] + o_); (r0_).y = st_lds(lds, W.ra[par_][1] + o_);                      \
@@ -1379,17 +1457,16 @@ __device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds,
         (r2_).x = st_lds(lds, W.ra[par_][4] + o_); (r2_).y = st_lds(lds, W.ra[par_][5] + o_);                      \
         (r3_).x = st_lds(lds, W.ra[par_][6] + o_); (r3_).y = 0.0;                                                  \
     } while (0)
-#define WD_HAND_T(h4_, r2_, r3_)                                                                                   \
+#define WA_HAND_T(h4_, r2_, r3_)                                                                                   \
     do {                                                                                                           \
-        *reinterpret_cast<double *>(lds + tbown + (unsigned)(h4_) * (kWdRowX * 8)) = (r2_).y;                      \
-        *reinterpret_cast<double *>(lds + tcown + (unsigned)(h4_) * (kWdRowC * 8)) = (r3_).x;                      \
+        *reinterpret_cast<double *>(lds + tbown + (unsigned)(h4_) * (C::RowX * 8)) = (r2_).y;                      \
+        *reinterpret_cast<double *>(lds + tcown + (unsigned)(h4_) * (C::RowL * 8)) = (r3_).x;                      \
     } while (0)
-    // (k_ilu0_wx: the entries of a chain's first and last row sit one place nearer to the diagonal)
     const int fl = T[ST_DFL];
     const int kF = ((fl >> 2) & 1) ? 0 : -1, kL = ((fl >> 3) & 1) ? cnt - 1 : -1;
     const bool fCB = W.hasC && W.hasB, fCA = W.hasC && !W.hasB, fBA = W.hasB;
     const bool lCB = W.hasUC && W.hasUB, lCA = W.hasUC && !W.hasUB, lBA = W.hasUB;
-#define WD_ENDS(kk_, r0_, r1_, r2_, r3_)                                                                          \
+#define WA_ENDS(kk_, r0_, r1_, r2_, r3_)                                                                          \
     do {                                                                                                           \
         const bool f_ = (kk_) == kF, l_ = (kk_) == kL;                                                             \
         if (__builtin_amdgcn_ballot_w64(f_ || l_) != 0) {                                                          \
@@ -1402,30 +1479,69 @@ __device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds,
             (r3_).x = l_ ? (lCB ? ub_ : (lCA ? ua_ : uc_)) : uc_;                                                  \
         }                                                                                                          \
     } while (0)
-    ST_BARRIER();                                           // (the loaders' first two blocks have landed, the courier's first entries are in place)
-    v2dd c0_, c1_, c2_, c3_;                                // the row of the current step: {aC, aB} {aA, d} {a'A, a'B} {a'C, -}
-    v2dd n0_, n1_, n2_, n3_;                                // ... of the next step
-    WD_ROW(0, 0, c0_, c1_, c2_, c3_);
-    WD_ROW(0, 1, n0_, n1_, n2_, n3_);
-    WD_ENDS(tlo - sk, c0_, c1_, c2_, c3_);
-    WD_HAND_T(0, c2_, c3_);
-    double bB = st_lds(lds, W.xB[0]), bC = st_lds(lds, W.xC[0]);  // pivots of other waves / workgroups for the first step
-    ST_BARRIER();                                           // (everybody's transposed entries of the first step are handed on)
+    // (no barrier from here on: the loaders' first two blocks, the first imports and their transposed entries are waited for as
+    // every later one is -- the check of a step "tlo - 1")
+    bool dead = false;
+    {
+        unsigned spins = 0;
+        for (;;) {
+            const int c0 = wa_ld32(lds, W.ca);
+            if (__builtin_amdgcn_ballot_w64(c0 - W.coff < tlo - 1) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0) {
+                if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
+                if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    v2dd c0_, c1_, c2_, c3_;
+    v2dd n0_, n1_, n2_, n3_;
+    WA_ROW(0, 0, c0_, c1_, c2_, c3_);
+    WA_ROW(0, 1, n0_, n1_, n2_, n3_);
+    WA_ENDS(tlo - sk, c0_, c1_, c2_, c3_);
+    WA_HAND_T(0, c2_, c3_);
+    double bB = st_lds(lds, W.xB[0]), bC = st_lds(lds, W.xC[0]);
+    // (the transposed entries of the first step: the wave's own lanes' -- written just above, a wave's LDS operations stay in order --,
+    // the imports' behind tpub; what another wave would hand on for it is two steps old: before the first step, zeros)
     double tB = st_lds(lds, W.tB[0]), tC = st_lds(lds, W.tC[0]);
+    asm volatile("" ::: "memory");
+    if (ln == 0) wa_set<C>(lds, WA_CP + wv, tlo - 1);
     double w3prev = 1.0, upA = 0.0;
     double qC = 1.0;
     int k = tlo - sk;
-    unsigned long long wacc_ = 0;
-    (void)wacc_;
-    for (int tb = tlo; tb < thi; tb += 8) {
+    int cv = wa_ld32(lds, W.ca);
+#ifdef WX_STAMP
+    unsigned long long nslow_ = 0, cslow_ = 0;
+#endif
+    for (int tb = tlo; tb < thi; tb += U) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
+            const int s = tb + u;
+            // everything this step reads from or writes to LDS is there / free (counters read in the middle of the step before)
+            if (!dead && __builtin_amdgcn_ballot_w64(cv - W.coff < s) != 0) {
+#ifdef WX_STAMP
+                const unsigned long long q0_ = __builtin_amdgcn_s_memtime();
+                ++nslow_;
+#endif
+                unsigned spins = 0;
+                for (;;) {
+                    cv = wa_ld32(lds, W.ca);
+                    if (__builtin_amdgcn_ballot_w64(cv - W.coff < s) == 0) break;
+                    if ((++spins & 1023u) == 0) {
+                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
+                        if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
+                    }
+                }
+#ifdef WX_STAMP
+                cslow_ += __builtin_amdgcn_s_memtime() - q0_;
+#endif
+            }
+            asm volatile("" ::: "memory");                  // (no LDS access of the step in front of its check)
             const double pC = W.ringC ? bC : qC;
             const double pB = wx_dpp_shr1(bB, w3prev);
-            // for the steps to come: the row of the step after the next (block ((u + 2) >> 1) & 3 of the ring), the pivots and the
-            // transposed entries of the next step that do not come through the wave's registers
             v2dd m0_, m1_, m2_, m3_;
-            WD_ROW(((u + 2) >> 1) & 3, u & 1, m0_, m1_, m2_, m3_);
+            WA_ROW(((u + 2) >> 1) % D, u & 1, m0_, m1_, m2_, m3_);
             const double nB = st_lds(lds, W.xB[(u + 1) & 3]);
             const double nC = st_lds(lds, W.xC[(u + 1) & 3]);
             const double ntB = st_lds(lds, W.tB[(u + 1) & 3]);
@@ -1438,7 +1554,10 @@ __device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds,
             const double aA = c1_.x, tA = k == 0 ? 0.0 : upA;
             const double uA = c2_.x;
             // u_rr = a_rr - sum (a_rk / u_kk) a_kr, eliminations in ascending k: classes C, B, A (ILU0.hpp:47-62)
-            const double lC = c0_.x / pC, lB = c0_.y / pB, lA = aA / w3prev;
+            const double lC = c0_.x / pC, lB = c0_.y / pB;
+            // (the counters for the next step's check: asked for here, half a step before they are looked at)
+            cv = wa_ld32(lds, W.ca);
+            const double lA = aA / w3prev;
             double w = c1_.y;
             w = w - lC * tC;
             w = w - lB * tB;
@@ -1448,7 +1567,7 @@ __device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds,
                 if ((wb & ~3ull) == (kSentinel & ~3ull)) w = st_dbl(kCanonNaN);
             }
             const double w3 = valid ? w : 1.0;
-            *reinterpret_cast<double *>(lds + xown + (unsigned)(u & 3) * (kWdRowX * 8)) = w3;
+            *reinterpret_cast<double *>(lds + xown + (unsigned)(u & 3) * (C::RowL * 8)) = w3;
             qC = wx_from_lane(W.src16, w3);
             w3prev = w3; upA = c2_.x;
             {
@@ -1464,191 +1583,189 @@ __device__ __forceinline__ void wd_consumer(const WfArgs &A, unsigned char *lds,
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ub), rU, vout + 1024u, 0, 2);
                 vout += 2048u;
             }
-            WD_ENDS(k + 1, n0_, n1_, n2_, n3_);
-            WD_HAND_T((u + 1) & 3, n2_, n3_);
+            WA_ENDS(k + 1, n0_, n1_, n2_, n3_);
+            WA_HAND_T((u + 1) & 3, n2_, n3_);
+            // this wave's step is done: its LDS writes are in front of the counter's (a wave's LDS operations stay in order)
+            asm volatile("" ::: "memory");
+            if (ln == 0) wa_set<C>(lds, WA_CP + wv, s);
             c0_ = n0_; c1_ = n1_; c2_ = n2_; c3_ = n3_;
             n0_ = m0_; n1_ = m1_; n2_ = m2_; n3_ = m3_;
             bB = nB; bC = nC; tB = ntB; tC = ntC;
             ++k;
-            WF_BARRIER(wacc_);
         }
     }
 #ifdef WX_STAMP
-    if (ln == 0 && wg < 4096) g_wf_wait[wg * 16 + wv] = wacc_;
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + wv] = cslow_; if (wv == 0) g_wf_wait[wg * 16 + 13] = nslow_; }
 #endif
-#undef WD_ROW
-#undef WD_HAND_T
-#undef WD_ENDS
+#undef WA_ROW
+#undef WA_HAND_T
+#undef WA_ENDS
 }
 
-// The courier of k_ilu0_wx did three things in ONE wave -- polled the pivots of earlier workgroups, fetched their transposed entries
-// from A, exported this workgroup's border pivots with write-through stores -- and a wave's vector-memory operations retire in issue
-// order: to look at a poll of two steps ago it waited for everything older, the write-through store of three steps ago (acknowledged
-// by memory, not by L2) and a load of A (HBM) included.  On an idle chip those come back within two steps; with 60 tiles at work they
-// do not, and the whole workgroup stood at its barrier for them every step (stamped build, 256^3: the courier of a tile WITHOUT imports
-// spent 0.7 of its time there, and a step took 0.62 us against 0.46 us on a chip with 16 tiles).  So: one wave per kind of traffic.
-//   * the POLLER only polls (kWdNP steps ahead): what it waits for is the hand-over itself;
-//   * the EXPORTER stores the border pivots right behind the barrier and never waits for a store; it also brings the transposed
-//     entries, asked for kWdNA steps ahead, so that the only thing it waits for is a load (and the stores in front of it) of long ago.
-#ifndef WD_NP
-#define WD_NP 2
-#endif
-static constexpr int kWdNP = WD_NP, kWdNA = 8, kWdSH = 2;
-static_assert(8 % kWdNP == 0, "the poller's ring of registers is walked with u % kWdNP inside trips of eight steps");
-
-__device__ __forceinline__ void wd_poller(const WfArgs &A, const unsigned long long *idle, unsigned char *lds, const WfPair P,
+// the poller: the imported pivots of step j into slot j mod 8 of the import ring, as far ahead of the consumers as the earlier
+// workgroups (and the ring) allow
+template <int NCW, int D>
+__device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long long *idle, unsigned char *lds, const WfPair P,
                                           const int tlo, const int thi, const int wg)
 {
-    constexpr int NP = kWdNP, SH = kWdSH;
+    typedef WaCfg<NCW, D> C;
+    constexpr int NP = C::NP, SH = kWdSH, U = C::U;
     const int ln = threadIdx.x & 63;
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.xch);
     const unsigned span = (unsigned)P.cnt;
-    const unsigned hoX = kWdX + (unsigned)((kThreads + ln) * 8);
+    const unsigned hoX = C::XI + (unsigned)(ln * 8);
     unsigned long long gq[NP];
-#define WDC_ADDR(k_) ((unsigned)(k_) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
+#define WAC_ADDR(k_) ((unsigned)(k_) < span ? src + (P.idx0 + ((k_) + P.sk) * P.stride) : idle)
 #pragma unroll
-    for (int g = 0; g < NP; ++g) { gq[g] = ld_agent_u64(WDC_ADDR(tlo + g - P.sk)); asm volatile("" ::: "memory"); }
+    for (int g = 0; g < NP; ++g) { gq[g] = ld_agent_u64(WAC_ADDR(tlo + g - P.sk)); asm volatile("" ::: "memory"); }
     bool dead = false;
 #ifdef WX_STAMP
     unsigned long long nmiss_ = 0, nspin_ = 0;
-#define WDC_COUNT(c_) do { if (c_) ++nmiss_; } while (0)
-#define WDC_SPIN() do { ++nspin_; } while (0)
-#else
-#define WDC_COUNT(c_) do { } while (0)
-#define WDC_SPIN() do { } while (0)
 #endif
-#define WDC_DELIVER(i_)                                                                                              \
+    // Warm start.  Every workgroup this one reads from has begun (its first export is there): this one begins in some twenty steps.
+    // A wave of its own (wa_prefetcher) takes that time to ask for the rows behind the ring's -- a tile's first steps are the ones the
+    // next tile waits for, and what one CU has in flight at HBM latency feeds them at half their pace.
+    {
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned long long v = P.astart >= 0 ? ld_agent_u64(src + P.astart) : 0ull;
+            if (__builtin_amdgcn_ballot_w64(v == kSentinel) == 0) break;
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 255u) == 0) {
+                if (spins > kStSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
+                const int e = ld_agent_i32(&A.ctrl[1]);
+                if (spins > kStSpinLimit || e != 0) { dead = true; break; }
+            }
+        }
+        if (ln == 0) { wa_set<C>(lds, WA_WARM, 1); if (A.prog) st_agent_i32(&A.prog[wg], 0); }
+    }
+    // the value of step tlo_ + i_: wait for it, put it into the ring, ask for the one eight steps on; a value that was not there at the
+    // first look means this workgroup has caught up with the one it reads from: everything asked for meanwhile was asked too early,
+    // so the whole window is asked for again (one trip for all of it, not one per step)
+#define WAC_DELIVER(i_)                                                                                              \
     do {                                                                                                             \
         const int k = tlo_ + (i_) - P.sk;                                                                            \
         const bool need = (unsigned)k < span;                                                                        \
         unsigned long long v = gq[(i_) % NP];                                                                        \
+        bool late_ = false;                                                                                          \
         if (!dead) {                                                                                                 \
             unsigned spins = 0;                                                                                      \
-            WDC_COUNT(__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0);                                     \
             while (__builtin_amdgcn_ballot_w64(need && v == kSentinel) != 0) {                                       \
-                WDC_SPIN();                                                                                          \
-                if (need && v == kSentinel) v = ld_agent_u64(WDC_ADDR(k));                                           \
+                late_ = true;                                                                                        \
+                WAC_STAT();                                                                                          \
+                if (need && v == kSentinel) v = ld_agent_u64(WAC_ADDR(k));                                           \
                 __builtin_amdgcn_s_waitcnt(0x0F70);                                                                  \
                 __builtin_amdgcn_s_sleep(1);                                                                         \
                 if ((++spins & 255u) == 0) {                                                                         \
-                    if (spins > kStSpinLimit) atomicExch(&A.ctrl[1], 1);                                             \
+                    if (spins > kStSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }                \
                     const int e = ld_agent_i32(&A.ctrl[1]);                                                          \
                     __builtin_amdgcn_s_waitcnt(0x0F70);                                                              \
-                    if (spins > kStSpinLimit || e != 0) { dead = true; break; }                                      \
+                    if (spins > kStSpinLimit || e != 0 || wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }         \
                 }                                                                                                    \
             }                                                                                                        \
         }                                                                                                            \
-        *reinterpret_cast<unsigned long long *>(lds + hoX + (unsigned)((i_) & 3) * (kWdRowX * 8)) = v;               \
-        gq[(i_) % NP] = ld_agent_u64(WDC_ADDR(k + NP));                                                              \
+        *reinterpret_cast<unsigned long long *>(lds + hoX + (unsigned)((i_) & 3) * 512u) = v;                        \
+        if (ln == 0) wa_set<C>(lds, WA_IP, tlo_ + (i_));                                                                \
+        if (late_) {                                                                                                 \
+            _Pragma("unroll") for (int g_ = 1; g_ < NP; ++g_) gq[((i_) + g_) % NP] = ld_agent_u64(WAC_ADDR(k + g_)); \
+        }                                                                                                            \
+        gq[(i_) % NP] = ld_agent_u64(WAC_ADDR(k + NP));                                                              \
     } while (0)
+#ifdef WX_STAMP
+#define WAC_STAT() do { ++nspin_; if (spins == 0) ++nmiss_; } while (0)
+#else
+#define WAC_STAT() do { } while (0)
+#endif
     {
         const int tlo_ = tlo;
 #pragma unroll
-        for (int i = 0; i < SH; ++i) WDC_DELIVER(i);
+        for (int i = 0; i < SH; ++i) WAC_DELIVER(i);
     }
-    ST_BARRIER();
-    ST_BARRIER();
-    unsigned long long cwacc_ = 0, dacc_ = 0;
-    (void)cwacc_; (void)dacc_;
-    for (int tb = tlo; tb < thi; tb += 8) {
+    const int thiR = tlo + (thi - tlo + U - 1) / U * U;
+    for (int tb = tlo; tb < thiR; tb += U) {
         const int tlo_ = tb;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-#ifdef WX_STAMP
-            const unsigned long long d0_ = __builtin_amdgcn_s_memtime();
-#endif
-            WDC_DELIVER(u + SH);
-#ifdef WX_STAMP
-            dacc_ += __builtin_amdgcn_s_memtime() - d0_;
-#endif
-            WF_BARRIER(cwacc_);
+        for (int u = 0; u < U; ++u) {
+            // the slot of step j held step j - 4, which the consumers read during step j - 5
+            if (!dead && !wa_wait_consumers<C, NCW>(lds, tb + u + SH - 5, A.ctrl)) dead = true;
+            WAC_DELIVER(u + SH);
         }
     }
-#undef WDC_DELIVER
-#undef WDC_COUNT
-#undef WDC_SPIN
-#undef WDC_ADDR
+#undef WAC_DELIVER
+#undef WAC_STAT
+#undef WAC_ADDR
 #ifdef WX_STAMP
-    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 4] = nspin_; g_wf_wait[wg * 16 + 13] = nmiss_; g_wf_wait[wg * 16 + 15] = (unsigned long long)(thi - tlo);
-                                g_wf_wait[wg * 16 + 11] = cwacc_; g_wf_wait[wg * 16 + 14] = dacc_; }
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 4] = nspin_; g_wf_wait[wg * 16 + 14] = nmiss_; g_wf_wait[wg * 16 + 15] = (unsigned long long)(thi - tlo); }
 #endif
     if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
 }
 
-__device__ __forceinline__ void wd_exporter(const WfArgs &A, unsigned char *lds, const WfPair P, const int tlo, const int thi, const int wg,
+// the exporter: the border pivots of step s behind the consumers' step s; the imports' transposed entries four steps ahead
+template <int NCW, int D>
+__device__ __forceinline__ void wa_exporter(const WfArgs &A, unsigned char *lds, const WfPair P, const int tlo, const int thi, const int wg,
                                             const int elane)
 {
-    constexpr int NA = kWdNA, SH = kWdSH;
+    typedef WaCfg<NCW, D> C;
+    constexpr int NA = C::NP, U = C::U;
     typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
     const int ln = threadIdx.x & 63;
     const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
     const unsigned span = (unsigned)P.cnt;
-    const unsigned hoT = kWdTB + (unsigned)((kThreads + ln) * 8);
+    const unsigned hoT = C::TB + (unsigned)((C::NL + ln) * 8);
     const int E = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
     const int xrow0 = A.xw[wg * 4 + 3] + (tlo - A.xw[wg * 4 + 1]) * E;
-    const unsigned ea = kWdX + (unsigned)((elane >= 0 ? elane : kWdCellX) * 8);
+    const unsigned ea = C::X + (unsigned)((elane >= 0 ? elane : C::NL) * 8);
+    const int thiR = tlo + (thi - tlo + U - 1) / U * U;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + xrow0, 0, (int)((unsigned)(thi - tlo) * (unsigned)E * 8u), 0x00020000);
     unsigned vx = elane >= 0 ? (unsigned)ln * 8u : 0xfffffff0u;
     const unsigned dvx = elane >= 0 ? (unsigned)E * 8u : 0u;
     if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 1);                 // (the analysis does not let such a schedule through)
     double ga[NA];
-#define WDC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : 0xfffffff0u)
-#define WDC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, WDC_AT(k_), 0, 0))
+#define WAC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : 0xfffffff0u)
+#define WAC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, WAC_AT(k_), 0, 0))
+    // steps tlo .. tlo + 3 before the consumers start, then one step per pass, four steps ahead
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const double v = WAC_LDAT(tlo + g - P.sk);
+        *reinterpret_cast<double *>(lds + hoT + (unsigned)g * (C::RowX * 8)) = v;
+    }
 #pragma unroll
     for (int g = 0; g < NA; ++g) {
-        ga[g] = WDC_LDAT(tlo + g - P.sk);
+        ga[g] = WAC_LDAT(tlo + 4 + g - P.sk);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, 0.0), rx, 0xfffffff0u, 0, 16);      // (the way in looks like a pass of the loop)
         asm volatile("" ::: "memory");
     }
-#define WDC_DELIVER(i_)                                                                                              \
-    do {                                                                                                             \
-        const int k = tlo_ + (i_) - P.sk;                                                                            \
-        *reinterpret_cast<double *>(lds + hoT + (unsigned)((i_) & 3) * (kWdRowX * 8)) = ga[(i_) % NA];               \
-        ga[(i_) % NA] = WDC_LDAT(k + NA);                                                                            \
-    } while (0)
-    {
-        const int tlo_ = tlo;
+    if (ln == 0) { wa_set<C>(lds, WA_TP, tlo + 3); }
+    bool dead = false;
+    for (int tb = tlo; tb < thiR; tb += U) {
 #pragma unroll
-        for (int i = 0; i < SH; ++i) {
-            WDC_DELIVER(i);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, 0.0), rx, 0xfffffff0u, 0, 16);
-        }
-    }
-    ST_BARRIER();
-    ST_BARRIER();
-    unsigned long long ewacc_ = 0, edacc_ = 0;
-    (void)ewacc_; (void)edacc_;
-    for (int tb = tlo; tb < thi; tb += 8) {
-        const int tlo_ = tb;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-#ifdef WX_STAMP
-            const unsigned long long d0_ = __builtin_amdgcn_s_memtime();
-#endif
-            WDC_DELIVER(u + SH);
-#ifdef WX_STAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            edacc_ += __builtin_amdgcn_s_memtime() - d0_;
-#endif
-            WF_BARRIER(ewacc_);
+        for (int u = 0; u < U; ++u) {
+            const int s = tb + u;
+            if (!dead && !wa_wait_consumers<C, NCW>(lds, s, A.ctrl)) dead = true;
             {
-                const double v = st_lds(lds, ea + (unsigned)(u & 3) * (kWdRowX * 8));
+                const double v = st_lds(lds, ea + (unsigned)(u & 3) * (C::RowL * 8));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, v), rx, vx, 0, 16);          // sc1: write-through
                 vx += dvx;
             }
+            // the transposed entries of step s + 4 take the slot of step s (read during step s - 1)
+            *reinterpret_cast<double *>(lds + hoT + (unsigned)(u & 3) * (C::RowX * 8)) = ga[u % NA];
+            ga[u % NA] = WAC_LDAT(s + 4 + NA - P.sk);
+            if (ln == 0) { wa_set<C>(lds, WA_EP, s); wa_set<C>(lds, WA_TP, s + 4); }
+            // (for the prefetchers of other workgroups: how far this tile is, in steps from its first)
+            if ((u & 7) == 0 && ln == 0 && A.prog) st_agent_i32(&A.prog[wg], s - tlo);
         }
     }
-#undef WDC_DELIVER
-#undef WDC_AT
-#undef WDC_LDAT
-#ifdef WX_STAMP
-    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 9] = ewacc_; g_wf_wait[wg * 16 + 10] = edacc_; }
-#endif
+    if (ln == 0 && A.prog) st_agent_i32(&A.prog[wg], 0x3fffffff);
+#undef WAC_AT
+#undef WAC_LDAT
 }
 
-// a loader wave: the windows of consumer wave `lw`.  Thread (g, j) of instruction q: piece (j + rot) & 7 of the window of lane 8 q + g
-__device__ __forceinline__ void wd_loader(const WfArgs &A, unsigned char *lds, const int wg, const int lw, const int tlo, const int thi)
+// a loader wave (wd_loader's windows), paced by its consumer wave's progress instead of the barrier
+template <int NCW, int D>
+__device__ __forceinline__ void wa_loader(const WfArgs &A, unsigned char *lds, const int wg, const int lw, const int tlo, const int thi)
 {
+    typedef WaCfg<NCW, D> C;
+    constexpr int U = C::U;
     const int ln = threadIdx.x & 63, j = ln & 7, gi = ln >> 3;
     const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
     unsigned g[8], S[8];
@@ -1666,65 +1783,219 @@ __device__ __forceinline__ void wd_loader(const WfArgs &A, unsigned char *lds, c
         g[q] = on ? (Cu & ~15u) + (unsigned)b0 * S[q] + 16u * (unsigned)piece : 0xfffffff0u;
     }
     typedef __attribute__((address_space(3))) void lds_void;
-#define WDL_ISSUE(slot_)                                                                                             \
+#define WAL_ISSUE(slot_)                                                                                             \
     do {                                                                                                             \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                              \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(lds + lw * kWdWaveRing + (slot_) * kWdWaveBlk + q * 1024), 16, g[q], 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(lds + lw * C::WaveRing + (slot_) * kWdWaveBlk + q * 1024), 16, g[q], 0, 0, WA_DMA_AUX); \
             g[q] += S[q];                                                                                            \
         }                                                                                                            \
         asm volatile("" ::: "memory");                                                                               \
     } while (0)
-    // blocks b0 .. b0 + 3; b0 and b0 + 1 have landed before the consumers' first reads
-    WDL_ISSUE(0); WDL_ISSUE(1); WDL_ISSUE(2); WDL_ISSUE(3);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    ST_BARRIER();
-    ST_BARRIER();
-    unsigned long long wacc_ = 0, vacc_ = 0, iacc_ = 0;
-    (void)wacc_; (void)vacc_; (void)iacc_;
-    for (int tb = tlo; tb < thi; tb += 8) {
+    // (blocks b0 .. b0 + D - 1; the first two have landed before the consumers' first reads)
+    WAL_ISSUE(0); WAL_ISSUE(1); WAL_ISSUE(2); if (D == 4) WAL_ISSUE(3);
+    if (D == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (ln == 0) wa_set<C>(lds, WA_LF + lw, tlo + 3);
+    const int thiR = tlo + (thi - tlo + U - 1) / U * U;
+    bool dead = false;
+#ifdef WX_STAMP
+    unsigned long long iacc_ = 0, vacc_ = 0, sacc_ = 0;
+#endif
+    for (int tb = tlo; tb < thiR; tb += U) {
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            // steps 2 bb, 2 bb + 1 of this trip (block b): the consumers read the rows of block b + 1; block b's slot was read for the
-            // last time a step ago and takes block b + 4; block b + 2 has to be there behind the second barrier (b + 3, b + 4 may be
-            // on their way: sixteen instructions)
+        for (int bb = 0; bb < U / 2; ++bb) {
+            // block b (steps tb + 2 bb, + 1): its slot takes block b + D once the wave has read its rows (during the two steps before);
+            // block b + 2 is published when it has landed (the D - 2 blocks behind it may be on their way: eight instructions each)
+            const int need = tb + 2 * bb - 1;
+#ifdef WX_STAMP
+            const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
+#endif
+            if (!dead) {
+                unsigned spins = 0;
+                while (wa_cnt<C>(lds, WA_CP + lw) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0) {
+                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
+                        if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
+                    }
+                }
+            }
 #ifdef WX_STAMP
             const unsigned long long i0_ = __builtin_amdgcn_s_memtime();
+            sacc_ += i0_ - s0_;
 #endif
-            WDL_ISSUE(bb);
-#ifdef WX_STAMP
-            iacc_ += __builtin_amdgcn_s_memtime() - i0_;
-#endif
-            WF_BARRIER(wacc_);
+            WAL_ISSUE(bb % D);
 #ifdef WX_STAMP
             const unsigned long long v0_ = __builtin_amdgcn_s_memtime();
+            iacc_ += v0_ - i0_;
 #endif
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (D == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #ifdef WX_STAMP
             vacc_ += __builtin_amdgcn_s_memtime() - v0_;
 #endif
-            WF_BARRIER(wacc_);
+            if (ln == 0) wa_set<C>(lds, WA_LF + lw, tb + 2 * bb + 5);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef WX_STAMP
-    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 5 + lw] = wacc_; if (lw == 0) g_wf_wait[wg * 16 + 5] = vacc_ << 32 | (wacc_ & 0xffffffffull); if (lw == 1) g_wf_wait[wg * 16 + 6] = iacc_ << 32 | (wacc_ & 0xffffffffull); }
+    if (ln == 0 && wg < 4096 && lw == 0) { g_wf_wait[wg * 16 + 5] = sacc_; g_wf_wait[wg * 16 + 6] = iacc_; g_wf_wait[wg * 16 + 7] = vacc_; }
 #endif
-#undef WDL_ISSUE
+#undef WAL_ISSUE
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(kWdThreads)
-k_ilu0_wd(WfArgs A)
+// The prefetcher.  What bounds a tile at work is what ONE CU can have in flight at HBM latency (25-30 GB/s: measured with 4 tiles on an
+// idle chip as with 256); the same tile reads A at twice that pace when A's values come from the Infinity Cache (256 x 96 x 96, A
+// touched just before: 0.49 -> 0.31 ms).  Most CUs are idle at any time -- their tile has not begun or has ended --, so one wave per
+// workgroup spends that time reading ahead FOR THE TILES AT WORK: one 4-byte load per 128-byte line of the rows a tile needs in the
+// next kPfLead steps brings the lines into the memory-side cache, where the tile's own loads find them.  Who asks for what: every
+// tile publishes its progress (prog[tile], by its exporter, every eight steps); a block of eight steps of a tile is claimed with an
+// atomic add on claim[tile] (from -1; block 0 is what the tile's loaders bring before its first step); a tile counts as begun, for
+// this purpose, when its poller says that every workgroup it reads from has begun -- some twenty steps before its first.  While
+// its own tile works the wave sleeps (it would take from what its CU can have in flight).
+#ifndef WA_PF_LEAD
+#define WA_PF_LEAD 32
+#endif
+static constexpr int kPfLead = WA_PF_LEAD;                   // steps ahead of a tile's published progress that are asked for
+
+template <int NCW, int D>
+__device__ __forceinline__ unsigned wa_pf_block(const WfArgs &A, const __amdgpu_buffer_rsrc_t rs, const int tile, const int blk)
 {
+    const int ln = threadIdx.x & 63;
+    // the tile's first step (as its own workgroup computes it)
+    int tl = 0x7fffffff, th = -0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t *w4 = A.wtab + (size_t)(tile * 4 + q) * 4;
+        const int a = w4[1], b = w4[2];
+        if (b > 0) { tl = min(tl, a); th = max(th, a + b); }
+    }
+    tl &= WaCfg<NCW, D>::U == 8 ? ~7 : ~3;
+    const int s0 = tl + 8 * blk;
+    if (th <= tl || s0 >= th + 2) return 0u;
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+        const int32_t *T = A.ltab + (size_t)(tile * kThreads + 64 * i + ln) * kStTab;
+        const int cnt = T[ST_CNT], fl = T[ST_DFL], m = fl >> 4;
+        const unsigned Cu = 8u * (unsigned)(T[ST_P0] - ((fl >> 2) & 1) - T[ST_SKEW] * m) + (unsigned)A.val_shift;
+        const unsigned lo = Cu + 8u * (unsigned)m * (unsigned)s0, hi = lo + 64u * (unsigned)m;      // eight rows
+        unsigned o = cnt > 0 ? (lo & ~127u) : 0xfffffff0u;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const unsigned oo = (cnt > 0 && o < hi) ? o : 0xfffffff0u;
+            acc ^= __builtin_amdgcn_raw_buffer_load_b32(rs, oo, 0, 0);
+            o += 128u;
+        }
+    }
+    return acc;
+}
+
+template <int NCW, int D>
+__device__ __forceinline__ void wa_prefetcher(const WfArgs &A, unsigned char *lds, const int wg, const int tlo, const int thi)
+{
+    typedef WaCfg<NCW, D> C;
+    const int ln = threadIdx.x & 63;
+    if (!A.prog) return;
+    const int nwg = (int)gridDim.x;
+    int32_t *prog = A.prog, *claim = A.prog + nwg;
+    const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
+    unsigned acc = 0;
+    bool own_done = false, own_warm = false;
+    unsigned idle = 0;
+#ifdef WX_STAMP
+    unsigned long long npf_ = 0, nscan_ = 0; long long lead_ = 0;
+#endif
+    for (;;) {
+#ifdef WX_STAMP
+        ++nscan_;
+#endif
+        // this workgroup's own tile: its first blocks at the warm start; hands off while it works
+        if (!own_warm) {
+            if (wa_cnt<C>(lds, WA_WARM) != 0) { own_warm = true; continue; }
+        } else if (!own_done) {
+            if (wa_cnt<C>(lds, WA_DEAD) != 0) break;
+            int cmin = 0x7fffffff;
+            for (int q = 0; q < NCW; ++q) cmin = min(cmin, wa_cnt<C>(lds, WA_CP + q));
+            if (cmin < thi - 1) { __builtin_amdgcn_s_sleep(127); continue; }
+            own_done = true;
+            // (a launch of more workgroups than the chip holds: this one's CU is wanted by the next)
+            if (!(A.flags & 2)) break;
+        }
+        // THREE other tiles, fixed: half the launch away, an eighth of a line of tiles away, and both (on a box grid in 16 x 16
+        // patches: eight patches on in z, in y, in both -- eight or sixteen hand-overs earlier or later: they work mostly while this
+        // one does not, and between them every tile has somebody idle at every time of its life).  The next block inside a mate's
+        // window is claimed with a compare-and-swap on claim[mate] (at most three waves ask for a tile: no crowd)
+        bool did = false, allfin = true;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int off = j == 0 ? nwg / 2 : (j == 1 ? nwg / 32 : nwg / 2 + nwg / 32);
+            const int mate = (wg + off) % nwg;
+            if (mate == wg || (j == 1 && nwg < 64)) continue;
+            const int pr = ld_agent_i32(&prog[mate]);
+            if (pr < 0x3fffffff) allfin = false;
+            if (pr < 0 || pr >= 0x3fffffff) continue;
+            int cl = ld_agent_i32(&claim[mate]);
+            // (blocks the tile has passed already are not asked for)
+            if (8 * (cl + 2) <= pr) cl = pr / 8 - 1;
+            if (8 * (cl + 2) > pr + kPfLead) continue;
+            int got = 0;
+            if (ln == 0) { const int old = ld_agent_i32(&claim[mate]); got = (old <= cl && atomicCAS(&claim[mate], old, cl + 1) == old) ? 1 : 0; }
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (!got) continue;
+            acc ^= wa_pf_block<NCW, D>(A, rs, mate, cl + 2);
+            did = true;
+#ifdef WX_STAMP
+            ++npf_;
+            lead_ += (long long)(8 * (cl + 2) - pr);
+#endif
+        }
+        if (allfin && own_done) break;
+        if (!did) {
+            __builtin_amdgcn_s_sleep(64);
+            if (own_done && ++idle > (1u << 18)) break;
+            if (!own_warm && wa_cnt<C>(lds, WA_DEAD) != 0) break;
+        }
+    }
+#ifdef WX_STAMP
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 9] = npf_; g_wf_wait[wg * 16 + 10] = nscan_; g_wf_wait[wg * 16 + 11] = (unsigned long long)lead_; }
+#endif
+    if (acc == 0x9e3779b9u && A.val_bytes == 0xfffffff3u) atomicExch(&A.ctrl[1], (int)acc);        // (the loads above are not dead code)
+}
+
+// (per-XCD ticket counters in the control words: [2], [3], [9] .. [14])
+__device__ __forceinline__ int wa_xcd_word(const int x) { return x < 2 ? 2 + x : 7 + x; }
+
+template <int MODE, int NCW, int D>
+__global__ void __launch_bounds__((WaCfg<NCW, D>::Threads), (NCW == 2 ? 4 : 3))
+k_ilu0_wa(WfArgs A)
+{
+    typedef WaCfg<NCW, D> C;
+    constexpr int U = C::U, NL = C::NL;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ int s_cnt[4], s_total;
     __shared__ unsigned s_ticket;
-    // (set-up only, inside the ring: read into registers before the first window lands)
     WfPair *s_pairs = reinterpret_cast<WfPair *>(lds);
     int *s_exp = reinterpret_cast<int *>(lds + 64 * sizeof(WfPair));
-    if (threadIdx.x == 0) s_ticket = (unsigned)atomicAdd(&A.ctrl[0], 1);
+    if (threadIdx.x == 0) {
+        // Which tile: the next ticket -- or (experiment, flags bit 0; only when every workgroup of the launch is resident at once) the
+        // next tile of THIS XCD's class (tile mod 8 = XCD).  The hardware starts the workgroups of one XCD in a row, so plain tickets
+        // put a whole line of 16 neighbouring tiles -- which work at the same time -- behind one XCD's L2 and fabric port; by class
+        // every band of the wavefront is spread over all eight.  Measured at 256^3: no difference (1.005 ms either way).
+        int tile = -1;
+        if (A.flags & 1) {
+            const int x = (int)(__builtin_amdgcn_s_getreg(0x1814) & 7u);
+            for (int i = 0; i < 8 && tile < 0; ++i) {
+                const int xx = (x + i) & 7;
+                const int c = atomicAdd(&A.ctrl[wa_xcd_word(xx)], 1);
+                if (c * 8 + xx < (int)gridDim.x) tile = c * 8 + xx;
+            }
+        } else {
+            tile = atomicAdd(&A.ctrl[0], 1);
+        }
+        s_ticket = (unsigned)tile;
+    }
     __syncthreads();
     const int wg = (int)s_ticket;
+    if (wg < 0) return;
     const int t = threadIdx.x;
     int tlo = 0x7fffffff, thi = -0x7fffffff;
 #pragma unroll
@@ -1735,27 +2006,30 @@ k_ilu0_wd(WfArgs A)
     }
     tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
     if (thi <= tlo) return;
-    tlo &= ~7;                                                        // step % 8 = position in the unrolled loops
-    for (int i = t; i < kWdLds / 8; i += kWdThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
+    tlo &= U == 8 ? ~7 : ~3;                                          // step % 4 (% 8) = position in the unrolled loops
+    for (int i = t; i < C::Lds / 8; i += C::Threads) reinterpret_cast<double *>(lds)[i] = 0.0;
     if (t < 4) s_cnt[t] = 0;
     __syncthreads();
-    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; s_pairs[t] = z; }
-    if (t < kThreads) s_exp[t] = -1;
-    if (t < 4) *reinterpret_cast<double *>(lds + kWdX + (unsigned)((t * kWdRowX + kWdCellX) * 8)) = 1.0;
+    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; s_pairs[t] = z; }
+    if (t < NL) s_exp[t] = -1;
+    if (t < 4) *reinterpret_cast<double *>(lds + C::X + (unsigned)((t * C::RowL + NL) * 8)) = 1.0;
+    // (a consumer wave has "done step tlo - 1" when it has read what its first step starts from)
+    if (t < 16) wa_set<C>(lds, t, t == WA_BIG ? 0x7fffffff : ((t == WA_DEAD || t == WA_WARM) ? 0 : (t < WA_LF ? tlo - 2 : tlo - 1)));
     __syncthreads();
-    if (t < kThreads) {
+    if (t < NL) {
         const int slot = wg * kThreads + t;
         const int32_t *T = A.ltab + (size_t)slot * kStTab;
         const int nd = T[ST_ND], cnt = T[ST_CNT];
         int cls[3]; bool ring[3];
         bool ok = wx_lane_ok(T, t, false) && wf_lane_ok(T, A.ltabB, A.uslot);
         (void)wr_classify(T, t, false, cls, ring);
-        WdLane W;
+        // (a workgroup of fewer lanes than the schedule's slots: the slots left over own no rows)
+        for (int l2 = t + NL; l2 < kThreads; l2 += NL) if (A.ltab[(size_t)(wg * kThreads + l2) * kStTab + ST_CNT] > 0) ok = false;
+        WaLane<U> W;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            W.xB[v] = W.xC[v] = kWdX + (unsigned)(kWdCellX * 8);
-            W.tB[v] = W.tC[v] = kWdTB + (unsigned)(kWdCellX * 8);
-        }
+        for (int v = 0; v < 4; ++v) W.xB[v] = W.xC[v] = C::X + (unsigned)(NL * 8);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) W.tB[v] = W.tC[v] = C::TB + (unsigned)((NL + 64) * 8);
         W.ringC = true;
         W.src16 = ((t - 16) & 63) * 4;
         bool isg[3];
@@ -1769,20 +2043,26 @@ k_ilu0_wd(WfArgs A)
             const int q = ty != ST_NONE ? T[ST_Q + j] : -1;
             isg[j] = ty == ST_GHOST;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) { xg[j][v] = 0; tg[j][v] = 0; }
-            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0;
+            for (int v = 0; v < 4; ++v) xg[j][v] = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tg[j][v] = 0;
+            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0; d.astart = -1;
             if (ty == ST_LOCAL || ty == ST_GHOST) {
                 const int pu = A.uslot[os];
                 const int32_t *TPB = A.ltabB + (size_t)(pu < 0 ? 0 : pu) * kStTab;
                 int pc[3]; bool pr[3];
                 (void)wr_classify(TPB, pu & 255, true, pc, pr);
                 const int qs = (q >= 0 && pu >= 0) ? wr_slot_of(q == 0 ? pc[0] : (q == 1 ? pc[1] : pc[2]), true) : -1;
-                if (qs != 1 && qs != 2) ok = false;                  // (a'B or a'C of the pivot row: what the lanes hand on)
+                if (qs != 1 && qs != 2) ok = false;
                 if (ty == ST_LOCAL) {
                     const int lane = os & 255, dt = T[ST_DT + j];
-                    if (dt < 1 || dt > 3) ok = false;
-                    wd_addr4(xg[j], kWdX, kWdRowX, lane, dt);
-                    if (qs == 2) wd_addr4(tg[j], kWdTC, kWdRowC, lane, dt); else wd_addr4(tg[j], kWdTB, kWdRowX, lane, dt);
+                    // (what crosses a wave is two steps old, not more, and comes from the wave below: the margins of the counters are
+                    // made for that)
+                    if (dt < 1 || dt > 2) ok = false;
+                    if ((lane >> 6) != (t >> 6) && (lane >> 6) != (t >> 6) - 1) ok = false;
+                    if (lane >= NL) ok = false;
+                    wd_addr4(xg[j], C::X, C::RowL, lane, dt);
+                    if (qs == 2) wd_addr4(tg[j], C::TC, C::RowL, lane, dt); else wd_addr4(tg[j], C::TB, C::RowX, lane, dt);
                 } else {
                     const int pw = os >> 8;
                     const int32_t *TP = A.ltab + (size_t)os * kStTab;
@@ -1797,13 +2077,20 @@ k_ilu0_wd(WfArgs A)
                     d.at0 = (unsigned)A.val_shift + 8u * (unsigned)(TP[ST_P0] - ((flp >> 2) & 1) + TP[ST_ND] + 1 + (q < 0 ? 0 : q) + kap * mp);
                     d.klast = TP[ST_CNT] - 1 - kap;
                     d.sh = 8 * ((flp >> 3) & 1);
+                    {
+                        // the producer's workgroup stores its border pivots from its first step on (whether its lanes have rows yet or not)
+                        int tl = 0x7fffffff;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) { const int32_t *w4 = A.wtab + (size_t)(pw * 4 + q4) * 4; if (w4[2] > 0) tl = min(tl, w4[1]); }
+                        tl &= U == 8 ? ~7 : ~3;
+                        d.astart = A.xw[pw * 4 + 3] + (tl - A.xw[pw * 4 + 1]) * E + A.xe[os];
+                    }
                 }
             } else if (ty == ST_OWN) {
                 if (q != 0) ok = false;
             }
             gp[j] = d;
         }
-        // the pairs of the workgroup, numbered
         {
             const int wv = t >> 6;
             unsigned long long bal[3];
@@ -1820,8 +2107,9 @@ k_ilu0_wd(WfArgs A)
                 if (isg[j]) {
                     const int p = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0));
                     if (p < 64) s_pairs[p] = gp[j];
-                    wd_addr4(xg[j], kWdX, kWdRowX, kThreads + min(p, 63), 0);
-                    wd_addr4(tg[j], kWdTB, kWdRowX, kThreads + min(p, 63), 0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) xg[j][v] = C::XI + (unsigned)(v * 512 + min(p, 63) * 8);
+                    wd_addr4(tg[j], C::TB, C::RowX, NL + min(p, 63), 0);
                 }
                 before += __popcll(bal[j]);
             }
@@ -1832,13 +2120,22 @@ k_ilu0_wd(WfArgs A)
             if (cls[j] == WR_B) {
                 W.hasB = true;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) { W.tB[v] = tg[j][v]; if (ring[j]) W.xB[v] = xg[j][v]; }
+                for (int v = 0; v < 4; ++v) W.tB[v] = tg[j][v];
+                if (ring[j]) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) W.xB[v] = xg[j][v];
+                }
             }
             if (cls[j] == WR_C) {
                 W.hasC = true;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) { W.tC[v] = tg[j][v]; if (ring[j]) W.xC[v] = xg[j][v]; }
-                if (!ring[j]) W.ringC = false;
+                for (int v = 0; v < 4; ++v) W.tC[v] = tg[j][v];
+                if (ring[j]) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) W.xC[v] = xg[j][v];
+                } else {
+                    W.ringC = false;
+                }
             }
         }
         {
@@ -1852,7 +2149,6 @@ k_ilu0_wd(WfArgs A)
             } else if (cnt > 0) {
                 ok = false;
             }
-            // where the seven canonical places of a row lie in the lane's window (k_ilu0_wx: s_place), by step parity
             const int fld = T[ST_DFL], ndU = fld & 3, ownL = (fld >> 2) & 1, m = fld >> 4;
             const unsigned Cu = 8u * (unsigned)(T[ST_P0] - ownL - T[ST_SKEW] * m) + (unsigned)A.val_shift;
             const int ln = t & 63, wv = t >> 6;
@@ -1872,30 +2168,42 @@ k_ilu0_wd(WfArgs A)
 #pragma unroll
                 for (int pl_ = 0; pl_ < 7; ++pl_) {
                     const unsigned B = (Cu & 15u) + (unsigned)(e * 8 * m) + 8u * (unsigned)(posOf[pl_] < 0 ? 0 : posOf[pl_]);
-                    const unsigned a = (unsigned)(wv * kWdWaveRing + ln * 128) + ((((B >> 4) - (unsigned)rot) & 7u) << 4) + (B & 8u);
-                    // (the zeros behind the wave's windows of every ring slot: the slot's offset is added to it as to any place)
-                    W.ra[e][pl_] = (cnt > 0 && posOf[pl_] >= 0 && B < 128u) ? a : (unsigned)(wv * kWdWaveRing + 64 * 128);
+                    const unsigned a = (unsigned)(wv * C::WaveRing + ln * 128) + ((((B >> 4) - (unsigned)rot) & 7u) << 4) + (B & 8u);
+                    W.ra[e][pl_] = (cnt > 0 && posOf[pl_] >= 0 && B < 128u) ? a : (unsigned)(wv * C::WaveRing + 64 * 128);
                     if (cnt > 0 && posOf[pl_] >= 0 && B >= 128u) ok = false;
                 }
+            // the counter this lane looks at, and its margin (counter - margin >= step)
+            int ci = WA_BIG, co = 0;
+            if (ln == 0 && wv > 0) { ci = WA_CP + wv - 1; co = -1; }       // hand-over values of wave w - 1: two steps old, read a step early
+            if (ln == 1 && wv < NCW - 1) { ci = WA_CP + wv + 1; co = -2; }       // wave w + 1 still reads what this step overwrites (four slots, two steps old)
+            if (ln == 2) { ci = WA_LF + wv; co = 2; }                      // the row of step s + 2
+            if (ln == 3) { ci = WA_IP; co = 1; }                           // the imports of step s + 1
+            if (ln == 4) { ci = WA_TP; co = 1; }
+            if (ln == 5) { ci = WA_EP; co = -4; }                          // the exporter has read the pivots this step overwrites
+            W.ca = C::Cnt + 4u * (unsigned)ci; W.coff = co;
         }
         {
             const int xe = A.xe[slot];
-            if (cnt > 0 && xe >= 0 && xe < kThreads) s_exp[xe] = t;
+            if (cnt > 0 && xe >= 0 && xe < NL) s_exp[xe] = t;
         }
         __syncthreads();
-        if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], 1);  // (the analysis does not let such a schedule through)
-        __syncthreads();                                              // (the courier has read its pair and its exported lane)
-        for (int i = t; i < 64 * (int)sizeof(WfPair) / 8 + kThreads / 2; i += kThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
+        if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], 1);
+        __syncthreads();
+        for (int i = t; i < 64 * (int)sizeof(WfPair) / 8 + kThreads / 2; i += NL) reinterpret_cast<double *>(lds)[i] = 0.0;
         __syncthreads();
 #ifdef WX_STAMP
         const unsigned long long cy0_ = __builtin_amdgcn_s_memtime();
         if (t == 0 && wg < 4096) g_wf_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
 #endif
-        wd_consumer<MODE>(A, lds, wg, W, tlo, thi);
+        wa_consumer<MODE, NCW, D>(A, lds, wg, W, tlo, thi);
 #ifdef WX_STAMP
-        if (t == 0 && wg < 4096) { g_wf_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime(); g_wf_wait[wg * 16 + 12] = __builtin_amdgcn_s_memtime() - cy0_; }
+        if (t == 0 && wg < 4096) {
+            g_wf_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime(); g_wf_wait[wg * 16 + 12] = __builtin_amdgcn_s_memtime() - cy0_;
+            // where the workgroup ran: HW_ID (wave, SIMD, pipe, CU, SH, SE ...) and XCC_ID
+            g_wf_wait[wg * 16 + 8] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0x1814) << 32);
+        }
 #endif
-    } else if (t < kThreads + 128) {
+    } else if (t < NL + 128) {
         __syncthreads();
         __syncthreads();
         const WfPair P = s_pairs[t & 63];
@@ -1904,18 +2212,24 @@ k_ilu0_wd(WfArgs A)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         __syncthreads();
-        if (t < kThreads + 64) {
+        if (t < NL + 64) {
             const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
-            wd_poller(A, idle, lds, P, tlo, thi, wg);
+            wa_poller<NCW, D>(A, idle, lds, P, tlo, thi, wg);
         } else {
-            wd_exporter(A, lds, P, tlo, thi, wg, elane);
+            wa_exporter<NCW, D>(A, lds, P, tlo, thi, wg, elane);
         }
+    } else if (t < NL + 128 + NCW * 64) {
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        wa_loader<NCW, D>(A, lds, wg, (t - NL - 128) >> 6, tlo, thi);
     } else {
         __syncthreads();
         __syncthreads();
         __syncthreads();
         __syncthreads();
-        wd_loader(A, lds, wg, (t - kThreads - 128) >> 6, tlo, thi);
+        wa_prefetcher<NCW, D>(A, lds, wg, tlo, thi);
     }
 }
 
@@ -1924,9 +2238,14 @@ static int wd_mode()
     static const int m = [] { const char *e = getenv("ILUPP_WD_MODE"); return e ? atoi(e) : 0; }();
     return m;
 }
-bool wd_on()
+bool wa_on()
 {
-    static const bool on = getenv("ILUPP_NO_WD") == nullptr;
+    static const bool on = getenv("ILUPP_NO_WA") == nullptr;
+    return on;
+}
+static bool wa_half()
+{
+    static const bool on = getenv("ILUPP_WA_HALF") != nullptr;
     return on;
 }
 
@@ -1939,8 +2258,12 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
         ILUPP_HIP(hipGetDevice(&dev));
         std::call_once(once[dev & 63], [] {
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLds));
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWdLds));
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWdLds));
+            typedef WaCfg<4, 4> C44;
+            typedef WaCfg<2, 3> C23;
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<0, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<0, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C23::Lds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C23::Lds));
         });
     }
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
@@ -1953,11 +2276,50 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     a.val_bytes = (uint32_t)(A.nnz * 8 + a.val_shift);
     a.pkL = reinterpret_cast<unsigned char *>(pl->pk); a.pkU = reinterpret_cast<unsigned char *>(pu->pk);
     a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
+    a.flags = 0;
+    a.prog = nullptr;
+    if (wa_on() && getenv("ILUPP_NO_PREFETCH") == nullptr) {
+        // progress and claim words of the tiles, all -1 (one buffer per device, kept)
+        static int32_t *buf[64];
+        static int64_t cap[64];
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        const int d = dev & 63;
+        if (cap[d] < 2 * (int64_t)pl->nwg) {
+            if (buf[d]) ILUPP_HIP(pool_free(buf[d]));
+            buf[d] = nullptr; cap[d] = 0;
+            ILUPP_HIP(pool_malloc(&buf[d], sizeof(int32_t) * 2 * (size_t)pl->nwg));
+            cap[d] = 2 * (int64_t)pl->nwg;
+        }
+        a.prog = buf[d];
+        ILUPP_HIP(hipMemsetAsync(a.prog, 0xff, sizeof(int32_t) * 2 * (size_t)pl->nwg, st));
+    }
+    {
+        // does the chip hold every workgroup of the launch at once?  (Then the prefetchers stay behind their own tile's end, for the
+        // tiles that still work; and, an experiment that changed nothing -- ILUPP_XCD_TICKETS=1 --, tiles are handed out by XCD.)
+        static int ncu[64];
+        int dev = 0;
+        ILUPP_HIP(hipGetDevice(&dev));
+        if (ncu[dev & 63] == 0) { int v = 0; ILUPP_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev)); ncu[dev & 63] = v > 0 ? v : -1; }
+        if (ncu[dev & 63] > 0 && (int64_t)pl->nwg <= (int64_t)ncu[dev & 63] * (wa_half() ? 2 : 1)) {
+            a.flags |= 2;
+            if (getenv("ILUPP_XCD_TICKETS") != nullptr) {
+                a.flags |= 1;
+                ILUPP_HIP(hipMemsetAsync(d_ctrl + 9, 0, 6 * sizeof(int32_t), st));
+            }
+        }
+    }
     if (pl->join_ev && pl->join_before) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));       // (grid.hip's proof, on its side stream)
     ILUPP_HIP(hipEventRecord(e0, st));
-    if (wd_on()) {
-        if (wd_mode() == 1) hipLaunchKernelGGL((k_ilu0_wd<1>), dim3((unsigned)pl->nwg), dim3(kWdThreads), kWdLds, st, a);
-        else hipLaunchKernelGGL((k_ilu0_wd<0>), dim3((unsigned)pl->nwg), dim3(kWdThreads), kWdLds, st, a);
+    if (wa_on() && wa_half()) {
+        // (experiment, ILUPP_WA_HALF=1 with schedules of 16 x 8 patches -- ILUPP_NO_GRID=1 ILUPP_TILE_TZ=8: two workgroups per CU)
+        typedef WaCfg<2, 3> C;
+        if (wd_mode() == 1) hipLaunchKernelGGL((k_ilu0_wa<1, 2, 3>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
+        else hipLaunchKernelGGL((k_ilu0_wa<0, 2, 3>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
+    } else if (wa_on()) {
+        typedef WaCfg<4, 4> C;
+        if (wd_mode() == 1) hipLaunchKernelGGL((k_ilu0_wa<1, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
+        else hipLaunchKernelGGL((k_ilu0_wa<0, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
     } else {
         hipLaunchKernelGGL(k_ilu0_wx, dim3((unsigned)pl->nwg), dim3(kWfThreads), kWfLds, st, a);
     }
