@@ -750,9 +750,9 @@ struct WfArgs {
     double *xch;
     int32_t *ctrl;                                // [0] ticket, [1] error; k_ilu0_wa: [2], [3], [9] .. [14] tickets by XCD
     int32_t flags;                                // k_ilu0_wa: 2 = every workgroup of the launch is resident at once; 1 = ... and tiles are handed out by XCD
-    int32_t *prog;                                // k_ilu0_wa: [tile] steps done, [nwg + tile] blocks of eight steps somebody has asked for (or null)
+    int32_t *prog;                                // k_ilu0_wa: [tile] steps done, [nwg + tile] blocks of eight steps somebody has asked for, [2 nwg + tile] blocks somebody finishes (or null)
 };
-struct WfPair { int idx0, stride, sk, cnt; unsigned at0; int atm, klast, sh, hasT; int astart; };    // (st_direct.hip: SdPair; astart, k_ilu0_wa: where the producer's workgroup exports its first step)
+struct WfPair { int idx0, stride, sk, cnt; unsigned at0; int atm, klast, sh, hasT; int astart, pw; };    // (st_direct.hip: SdPair; k_ilu0_wa: astart, where the producer's workgroup exports its first step; pw, that workgroup)
 
 // what a consumer lane knows
 struct WfLane {
@@ -1162,7 +1162,7 @@ k_ilu0_wx(WfArgs A)
     tlo &= ~7;                                                        // step % 8 = position in the unrolled loops
     // the row ring and the hand-off arrays start all +0.0 (what no producer piece goes to stays that way); the cells of ones
     for (int i = t; i < kWfLds / 8; i += kWfThreads) reinterpret_cast<double *>(lds)[i] = 0.0;
-    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; s_pairs[t] = z; }
+    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; z.pw = -1; s_pairs[t] = z; }
     if (t < kWfLanes) s_exp[t] = -1;
     if (t < 4) s_cnt[t] = 0;
     __syncthreads();
@@ -1190,7 +1190,7 @@ k_ilu0_wx(WfArgs A)
             const int q = ty != ST_NONE ? T[ST_Q + j] : -1;
             isg[j] = ty == ST_GHOST;
             xg[j] = 0; tg[j] = 0;
-            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0; d.astart = -1;
+            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0; d.astart = -1; d.pw = -1;
             if (ty == ST_LOCAL || ty == ST_GHOST) {
                 // the transposed entry: which entry right of the diagonal of the pivot row, and where its owner hands it on
                 const int pu = A.uslot[os];
@@ -1580,7 +1580,13 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vout + 1024u, 0, 2);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ua), rU, vout, 0, 2);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ub), rU, vout + 1024u, 0, 2);
+                if (MODE == 2) {
+                    // (write-through: the finishers on other CUs read it; at most 15 of this wave's stores are ever on their way)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ub), rU, vout + 1024u, 0, 16);
+                    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ub), rU, vout + 1024u, 0, 2);
+                }
                 vout += 2048u;
             }
             WA_ENDS(k + 1, n0_, n1_, n2_, n3_);
@@ -1597,6 +1603,9 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
 #ifdef WX_STAMP
     if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + wv] = cslow_; if (wv == 0) g_wf_wait[wg * 16 + 13] = nslow_; }
 #endif
+    // (every store of this wave has arrived: the word the exporter's last progress and the finishers of this tile's leftovers wait for)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ln == 0) wa_set<C>(lds, WA_CP + wv, 0x7ffffff8);
 #undef WA_ROW
 #undef WA_HAND_T
 #undef WA_ENDS
@@ -1623,7 +1632,7 @@ __device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long l
     unsigned long long nmiss_ = 0, nspin_ = 0;
 #endif
     // Warm start.  Every workgroup this one reads from has begun (its first export is there): this one begins in some twenty steps.
-    // A wave of its own (wa_prefetcher) takes that time to ask for the rows behind the ring's -- a tile's first steps are the ones the
+    // A wave of its own (wa_helper) takes that time to ask for the rows behind the ring's -- a tile's first steps are the ones the
     // next tile waits for, and what one CU has in flight at HBM latency feeds them at half their pace.
     {
         unsigned spins = 0;
@@ -1755,7 +1764,7 @@ __device__ __forceinline__ void wa_exporter(const WfArgs &A, unsigned char *lds,
             if ((u & 7) == 0 && ln == 0 && A.prog) st_agent_i32(&A.prog[wg], s - tlo);
         }
     }
-    if (ln == 0 && A.prog) st_agent_i32(&A.prog[wg], 0x3fffffff);
+    if (A.prog) { (void)wa_wait_consumers<C, NCW>(lds, 0x7ffffff0, A.ctrl); if (ln == 0) st_agent_i32(&A.prog[wg], 0x3fffffff); }
 #undef WAC_AT
 #undef WAC_LDAT
 }
@@ -1889,74 +1898,348 @@ __device__ __forceinline__ unsigned wa_pf_block(const WfArgs &A, const __amdgpu_
     return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MODE 2: the records are FINISHED by idle waves.  The waves on the chain store {a'C, u_rr} only (write-through: other CUs read it);
+// everything else of a row's records follows from A and the pivots without any recurrence -- l = a / u_kk, the strict upper part of
+// U is A's (ILU0.hpp:47-62 for rows whose eliminations meet them on the diagonal only) -- and is written, a block of eight steps of a
+// tile at a time, by whoever has nothing else to do: the prefetcher of a workgroup whose tile has not begun, every wave of a
+// workgroup whose tile has ended.  That takes 48 of the 64 record bytes per row off the CU that is bounded by what it can have
+// in flight.  A block of a tile is finished when the tile is kFinMargin steps past it (the chain waves keep at most 15 of their
+// stores unacknowledged, so what the finisher reads has arrived); a tile's own workgroup finishes what nobody else has claimed.
+// The arithmetic is the chain's: the same divisions, on the same operands, in the same order of evaluation per entry.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kFinMargin = 16;
+
+// what a lane of a tile knows (wa kernel prologue), for somebody who is not that lane
+struct WaFin {
+    int cnt, sk, kF, kL;
+    unsigned rowb, m8;            // byte offset (val_shift included) of the virtual start of the row of step 0; bytes per row
+    unsigned off[7];              // byte offset of each canonical place in the row (0xffffff00: the lane's rows have no such entry)
+    bool hasB, hasC, hasUB, hasUC, ringC;
+    int bKind, cKind;             // where the pivot of class B / C comes from when not from the wave's registers: 0 nobody (one), 1 a lane of the tile `dt` steps ago, 2 the exchange
+    int bLane, bDt, bIdx0, bStride, cLane, cDt, cIdx0, cStride;
+    bool ok;
+};
+__device__ __forceinline__ void wa_fin_decode(const WfArgs &A, const int tile, const int t, WaFin *F)
+{
+    const int slot = tile * kThreads + t;
+    const int32_t *T = A.ltab + (size_t)slot * kStTab;
+    const int nd = T[ST_ND], cnt = T[ST_CNT];
+    int cls[3]; bool ring[3];
+    bool ok = wr_classify(T, t, false, cls, ring);
+    F->cnt = cnt; F->sk = T[ST_SKEW];
+    const int fl = T[ST_DFL], ndU = fl & 3, ownL = (fl >> 2) & 1, m = fl >> 4;
+    F->kF = ownL ? 0 : -1; F->kL = ((fl >> 3) & 1) ? cnt - 1 : -1;
+    F->rowb = 8u * (unsigned)(T[ST_P0] - ownL - T[ST_SKEW] * m) + (unsigned)A.val_shift;
+    F->m8 = 8u * (unsigned)m;
+    F->hasB = F->hasC = F->hasUB = F->hasUC = false; F->ringC = true;
+    F->bKind = F->cKind = 0; F->bLane = F->cLane = 0; F->bDt = F->cDt = 0; F->bIdx0 = F->cIdx0 = 0; F->bStride = F->cStride = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int sw = T[ST_SRC + j];
+        const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
+        const int os = sw >> 2;
+        int kind = 0, lane = 0, dt = 0, idx0 = 0, stride = 0;
+        if (ty == ST_LOCAL) { kind = 1; lane = os & 255; dt = T[ST_DT + j]; }
+        else if (ty == ST_GHOST) {
+            const int pw = os >> 8;
+            const int32_t *TP = A.ltab + (size_t)os * kStTab;
+            const int E = A.xw[pw * 4];
+            kind = 2; stride = E;
+            idx0 = A.xw[pw * 4 + 3] + (T[ST_KAP + j] + TP[ST_SKEW] - T[ST_SKEW] - A.xw[pw * 4 + 1]) * E + A.xe[os];
+        }
+        if (cls[j] == WR_B) { F->hasB = true; if (ring[j]) { F->bKind = kind; F->bLane = lane; F->bDt = dt; F->bIdx0 = idx0; F->bStride = stride; } }
+        if (cls[j] == WR_C) {
+            F->hasC = true;
+            if (ring[j]) { F->cKind = kind; F->cLane = lane; F->cDt = dt; F->cIdx0 = idx0; F->cStride = stride; } else F->ringC = false;
+        }
+    }
+    int bc[3] = {WR_NONE, WR_NONE, WR_NONE};
+    {
+        const int su = cnt > 0 ? A.uslot[slot] : -1;
+        if (su >= 0) {
+            bool br[3];
+            (void)wr_classify(A.ltabB + (size_t)su * kStTab, su & 255, true, bc, br);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { if (bc[q] == WR_B) F->hasUB = true; if (bc[q] == WR_C) F->hasUC = true; }
+        } else if (cnt > 0) ok = false;
+    }
+    int posOf[7] = {-1, -1, -1, -1, -1, -1, -1};
+#pragma unroll
+    for (int pos = 0; pos < 7; ++pos) {
+        int place = -1;
+        if (pos < nd) { const int c = pos == 0 ? cls[0] : (pos == 1 ? cls[1] : cls[2]); place = c == WR_NONE ? -1 : wr_slot_of(c, false); }
+        else if (pos == nd) place = 3;
+        else if (pos <= nd + ndU && pos - nd - 1 < 3) { const int q = pos - nd - 1; const int c = q == 0 ? bc[0] : (q == 1 ? bc[1] : bc[2]); place = c == WR_NONE ? -1 : 4 + wr_slot_of(c, true); }
+#pragma unroll
+        for (int pl_ = 0; pl_ < 7; ++pl_) if (place == pl_) posOf[pl_] = pos;
+    }
+#pragma unroll
+    for (int pl_ = 0; pl_ < 7; ++pl_) F->off[pl_] = (cnt > 0 && posOf[pl_] >= 0) ? 8u * (unsigned)posOf[pl_] : 0xffffff00u;
+    F->ok = ok;
+}
+
+// the first step of a tile and the number of its blocks of eight steps (as its own workgroup computes them)
 template <int NCW, int D>
-__device__ __forceinline__ void wa_prefetcher(const WfArgs &A, unsigned char *lds, const int wg, const int tlo, const int thi)
+__device__ __forceinline__ void wa_tile_span(const WfArgs &A, const int tile, int *tl_out, int *nblk_out)
+{
+    int tl = 0x7fffffff, th = -0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t *w4 = A.wtab + (size_t)(tile * 4 + q) * 4;
+        const int a = w4[1], b = w4[2];
+        if (b > 0) { tl = min(tl, a); th = max(th, a + b); }
+    }
+    constexpr int U = WaCfg<NCW, D>::U;
+    tl &= U == 8 ? ~7 : ~3;
+    *tl_out = tl;
+    *nblk_out = th > tl ? ((th - tl + U - 1) / U * U) / 8 : 0;
+}
+
+// one block of eight steps of a tile: {lC, lB} {lA, 1} and {a'A, a'B} of every lane's row (one wave; the lanes of a consumer wave at a time)
+template <int NCW, int D>
+__device__ __forceinline__ void wa_finish_block(const WfArgs &A, const int tile, const int blk)
+{
+    typedef double v2dd __attribute__((ext_vector_type(2)));
+    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+    const int ln = threadIdx.x & 63;
+    int tl, nblk;
+    wa_tile_span<NCW, D>(A, tile, &tl, &nblk);
+    if (blk >= nblk) return;
+    const int s0 = tl + 8 * blk;
+    const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
+    const __amdgpu_buffer_rsrc_t rxch = __builtin_amdgcn_make_buffer_rsrc(A.xch, 0, 0x7ffffff0, 0x00020000);
+#pragma unroll 1
+    for (int w = 0; w < NCW; ++w) {
+        const int t = 64 * w + ln;
+        WaFin F;
+        wa_fin_decode(A, tile, t, &F);
+        const int32_t *wt = A.wtab + (size_t)(tile * 4 + w) * 4;
+        const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
+                  nchw = __builtin_amdgcn_readfirstlane(wt[2]);
+        if (nchw <= 0) continue;
+        const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.pkL + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(A.pkU + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
+        // (the pivots of a lane of ANOTHER wave of the tile: that wave's chunks)
+        const int wB = F.bKind == 1 ? (F.bLane >> 6) : w, wC = F.cKind == 1 ? (F.cLane >> 6) : w;
+        const int32_t *wtB = A.wtab + (size_t)(tile * 4 + wB) * 4, *wtC = A.wtab + (size_t)(tile * 4 + wC) * 4;
+        const int baseB = wtB[0], tminB = wtB[1], nchB = wtB[2], baseC = wtC[0], tminC = wtC[1], nchC = wtC[2];
+        const __amdgpu_buffer_rsrc_t rUall = __builtin_amdgcn_make_buffer_rsrc(A.pkU, 0, 0x7ffffff0, 0x00020000);
+        const bool fCB = F.hasC && F.hasB, fCA = F.hasC && !F.hasB, fBA = F.hasB;
+        const bool lCB = F.hasUC && F.hasUB, lCA = F.hasUC && !F.hasUB, lBA = F.hasUB;
+        const int src16 = ((t - 16) & 63) * 4;
+        // the lane's pivot of the step before the block's first (one where the lane had no row, or a step before its wave's chunks)
+        double wprev;
+        {
+            const int c = s0 - 1 - tminw;
+            const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rU, (unsigned)c * 2048u + 1024u + (unsigned)ln * 16u, 0, 16);
+            wprev = ((unsigned)c < (unsigned)nchw) ? __builtin_bit_cast(v2dd, r).y : 1.0;
+        }
+#pragma unroll 2
+        for (int j = 0; j < 8; ++j) {
+            const int s = s0 + j, k = s - F.sk;
+            const bool valid = (unsigned)k < (unsigned)F.cnt;
+            // the row, place by place (a place the lane's rows do not have: out of range, zero)
+            const unsigned rb = F.rowb + F.m8 * (unsigned)s;
+            double v[7];
+#pragma unroll
+            for (int p_ = 0; p_ < 7; ++p_) {
+                unsigned o_ = F.off[p_] < 0x1000u ? rb + F.off[p_] : 0xfffffff0u;
+                asm volatile("" : "+v"(o_));
+                v[p_] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, o_, 0, 0));
+            }
+            // this step's own pivot (the next step's `wprev`) and what comes from outside the wave's registers
+            const int c = s - tminw;
+            const v4u_ rw = __builtin_amdgcn_raw_buffer_load_b128(rU, (unsigned)c * 2048u + 1024u + (unsigned)ln * 16u, 0, 16);
+            double bB = 1.0, bC = 1.0;
+            if (F.bKind == 1) {
+                const int cb = s - F.bDt - tminB;
+                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rUall, (unsigned)(baseB + cb) * 2048u + 1024u + (unsigned)(F.bLane & 63) * 16u + 8u, 0, 16);
+                bB = ((unsigned)cb < (unsigned)nchB) ? __builtin_bit_cast(double, r) : 1.0;
+            } else if (F.bKind == 2) {
+                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rxch, (unsigned)(F.bIdx0 + s * F.bStride) * 8u, 0, 16);
+                bB = __builtin_bit_cast(double, r);
+            }
+            if (F.cKind == 1) {
+                const int cc = s - F.cDt - tminC;
+                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rUall, (unsigned)(baseC + cc) * 2048u + 1024u + (unsigned)(F.cLane & 63) * 16u + 8u, 0, 16);
+                bC = ((unsigned)cc < (unsigned)nchC) ? __builtin_bit_cast(double, r) : 1.0;
+            } else if (F.cKind == 2) {
+                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rxch, (unsigned)(F.cIdx0 + s * F.cStride) * 8u, 0, 16);
+                bC = __builtin_bit_cast(double, r);
+            }
+            // (k_ilu0_wa: the entries of a chain's first and last row sit one place nearer to the diagonal)
+            {
+                const bool f_ = k == F.kF, l_ = k == F.kL;
+                const double c_ = v[0], b_ = v[1], a_ = v[2], ua_ = v[4], ub_ = v[5], uc_ = v[6];
+                v[0] = f_ ? (fCB ? b_ : (fCA ? a_ : c_)) : c_;
+                v[1] = f_ ? (fBA ? a_ : b_) : b_;
+                v[2] = f_ ? 0.0 : a_;
+                v[4] = l_ ? 0.0 : ua_;
+                v[5] = l_ ? (lBA ? ua_ : ub_) : ub_;
+                v[6] = l_ ? (lCB ? ub_ : (lCA ? ua_ : uc_)) : uc_;
+            }
+            const double pB = wx_dpp_shr1(bB, wprev);
+            const double qC = wx_from_lane(src16, wprev);
+            const double pC = F.ringC ? bC : qC;
+            v2dd la, lb, ua;
+            la.x = v[0] / pC; la.y = v[1] / pB; lb.x = v[2] / wprev; lb.y = 1.0;
+            ua.x = v[4]; ua.y = v[5];
+            if (!valid) { la.x = 0.0; la.y = 0.0; lb.x = 0.0; ua.x = 0.0; ua.y = 0.0; }
+            const unsigned vo = (unsigned)c * 2048u + (unsigned)ln * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, la), rL, vo, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vo + 1024u, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ua), rU, vo, 0, 2);
+            wprev = ((unsigned)c < (unsigned)nchw) ? __builtin_bit_cast(v2dd, rw).y : 1.0;
+        }
+    }
+}
+
+// What a wave does when its own tile does not need it: read ahead for the tiles at work and (MODE 2) finish their records.
+//   PF: the prefetcher wave of a workgroup (from the launch on: before its tile begins, asleep while it works, after it has ended);
+//   else: any other wave, once its tile has ended.
+template <int MODE, int NCW, int D, bool PF>
+__device__ __forceinline__ void wa_helper(const WfArgs &A, unsigned char *lds, const int wg, const int tlo, const int thi, const int my_pw)
 {
     typedef WaCfg<NCW, D> C;
     const int ln = threadIdx.x & 63;
     if (!A.prog) return;
     const int nwg = (int)gridDim.x;
-    int32_t *prog = A.prog, *claim = A.prog + nwg;
+    int32_t *prog = A.prog, *claim = A.prog + nwg, *claimF = A.prog + 2 * nwg;
     const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
     unsigned acc = 0;
-    bool own_done = false, own_warm = false;
+    bool own_done = !PF, own_warm = !PF;
     unsigned idle = 0;
+    // the (first two) workgroups this one imports from: they work right before it does, and until it begins it has nothing else to do
+    int up1 = -1, up2 = -1;
+    if (PF) {
+        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(my_pw >= 0);
+        if (b1 != 0) {
+            up1 = __builtin_amdgcn_readlane(my_pw, __builtin_ctzll(b1));
+            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(my_pw >= 0 && my_pw != up1);
+            if (b2 != 0) up2 = __builtin_amdgcn_readlane(my_pw, __builtin_ctzll(b2));
+        }
+    }
+    int own_nblk = 0;
+    { int tl_; wa_tile_span<NCW, D>(A, wg, &tl_, &own_nblk); }
+    if (!PF) {
+        // (a wave whose own job is done: the tile's last stores first)
+        unsigned spins = 0;
+        for (;;) {
+            int cmin = 0x7fffffff;
+            for (int q = 0; q < NCW; ++q) cmin = min(cmin, wa_cnt<C>(lds, WA_CP + q));
+            if (cmin >= 0x7ffffff0 || wa_cnt<C>(lds, WA_DEAD) != 0) break;
+            __builtin_amdgcn_s_sleep(127);
+            if (++spins > kWaSpinLimit) return;
+        }
+    }
 #ifdef WX_STAMP
-    unsigned long long npf_ = 0, nscan_ = 0; long long lead_ = 0;
+    unsigned long long npf_ = 0, nscan_ = 0, nfin_ = 0; long long lead_ = 0;
 #endif
     for (;;) {
 #ifdef WX_STAMP
         ++nscan_;
 #endif
-        // this workgroup's own tile: its first blocks at the warm start; hands off while it works
-        if (!own_warm) {
-            if (wa_cnt<C>(lds, WA_WARM) != 0) { own_warm = true; continue; }
-        } else if (!own_done) {
-            if (wa_cnt<C>(lds, WA_DEAD) != 0) break;
-            int cmin = 0x7fffffff;
-            for (int q = 0; q < NCW; ++q) cmin = min(cmin, wa_cnt<C>(lds, WA_CP + q));
-            if (cmin < thi - 1) { __builtin_amdgcn_s_sleep(127); continue; }
-            own_done = true;
-            // (a launch of more workgroups than the chip holds: this one's CU is wanted by the next)
-            if (!(A.flags & 2)) break;
+        if (PF) {
+            // this workgroup's own tile: hands off while it works
+            if (!own_warm) {
+                if (wa_cnt<C>(lds, WA_WARM) != 0) { own_warm = true; continue; }
+            } else if (!own_done) {
+                if (wa_cnt<C>(lds, WA_DEAD) != 0) break;
+                int cmin = 0x7fffffff;
+                for (int q = 0; q < NCW; ++q) cmin = min(cmin, wa_cnt<C>(lds, WA_CP + q));
+                if (cmin < 0x7ffffff0) { __builtin_amdgcn_s_sleep(127); continue; }       // (the chain waves' stores have all arrived)
+                own_done = true;
+            }
         }
-        // THREE other tiles, fixed: half the launch away, an eighth of a line of tiles away, and both (on a box grid in 16 x 16
-        // patches: eight patches on in z, in y, in both -- eight or sixteen hand-overs earlier or later: they work mostly while this
-        // one does not, and between them every tile has somebody idle at every time of its life).  The next block inside a mate's
-        // window is claimed with a compare-and-swap on claim[mate] (at most three waves ask for a tile: no crowd)
+        // (a launch of more workgroups than the chip holds: this one's CU is wanted by the next; what is left of its own tile first)
+        const bool stay = (A.flags & 2) != 0;
+        // FIVE other tiles, fixed.  The (two) tiles this one imports from: they begin some twenty steps before it and it is idle till
+        // then -- a tile's first steps, which the next tile waits for, always have somebody.  And three far ones: half the launch
+        // away, an eighth of a line of tiles away, and both (on a box grid in 16 x 16 patches: eight patches on in z, in y, in both --
+        // eight or sixteen hand-overs earlier or later: they work mostly while this one does not).  The next block inside a mate's
+        // window is claimed with a compare-and-swap on claim[mate] (few waves ask for a tile: no crowd)
         bool did = false, allfin = true;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int off = j == 0 ? nwg / 2 : (j == 1 ? nwg / 32 : nwg / 2 + nwg / 32);
-            const int mate = (wg + off) % nwg;
-            if (mate == wg || (j == 1 && nwg < 64)) continue;
-            const int pr = ld_agent_i32(&prog[mate]);
-            if (pr < 0x3fffffff) allfin = false;
-            if (pr < 0 || pr >= 0x3fffffff) continue;
-            int cl = ld_agent_i32(&claim[mate]);
-            // (blocks the tile has passed already are not asked for)
-            if (8 * (cl + 2) <= pr) cl = pr / 8 - 1;
-            if (8 * (cl + 2) > pr + kPfLead) continue;
-            int got = 0;
-            if (ln == 0) { const int old = ld_agent_i32(&claim[mate]); got = (old <= cl && atomicCAS(&claim[mate], old, cl + 1) == old) ? 1 : 0; }
-            got = __builtin_amdgcn_readfirstlane(got);
-            if (!got) continue;
-            acc ^= wa_pf_block<NCW, D>(A, rs, mate, cl + 2);
-            did = true;
+        if (stay || !own_done) {
+#pragma unroll 1
+            for (int j = 0; j < 5; ++j) {
+                const int off = j == 2 ? nwg / 2 : (j == 3 ? nwg / 32 : nwg / 2 + nwg / 32);
+                const int mate = j == 0 ? up1 : (j == 1 ? up2 : (wg + off) % nwg);
+                if (mate < 0 || mate == wg || (j == 3 && nwg < 64) || (j < 2 && own_done)) continue;
+                const int pr = ld_agent_i32(&prog[mate]);
+                if (pr < 0) { allfin = false; continue; }
+                if (pr < 0x3fffffff) {
+                    allfin = false;
+                    int cl = ld_agent_i32(&claim[mate]);
+                    // (blocks the tile has passed already are not asked for)
+                    if (8 * (cl + 2) <= pr) cl = pr / 8 - 1;
+                    if (8 * (cl + 2) <= pr + kPfLead) {
+                        int got = 0;
+                        if (ln == 0) { const int old = ld_agent_i32(&claim[mate]); got = (old <= cl && atomicCAS(&claim[mate], old, cl + 1) == old) ? 1 : 0; }
+                        got = __builtin_amdgcn_readfirstlane(got);
+                        if (got) {
+                            acc ^= wa_pf_block<NCW, D>(A, rs, mate, cl + 2);
+                            did = true;
 #ifdef WX_STAMP
-            ++npf_;
-            lead_ += (long long)(8 * (cl + 2) - pr);
+                            ++npf_;
+                            lead_ += (long long)(8 * (cl + 2) - pr);
 #endif
+                            continue;
+                        }
+                    }
+                }
+                if (MODE == 2) {
+                    // the mate's next unfinished block, once the mate is far enough past it
+                    int tlm, nbm;
+                    wa_tile_span<NCW, D>(A, mate, &tlm, &nbm);
+                    const int cf = ld_agent_i32(&claimF[mate]);
+                    if (cf + 1 < nbm) {
+                        allfin = false;
+                        if (8 * (cf + 2) + kFinMargin <= pr) {
+                            int got = 0;
+                            if (ln == 0) got = atomicCAS(&claimF[mate], cf, cf + 1) == cf ? 1 : 0;
+                            got = __builtin_amdgcn_readfirstlane(got);
+                            if (got) {
+                                wa_finish_block<NCW, D>(A, mate, cf + 1);
+                                did = true;
+#ifdef WX_STAMP
+                                ++nfin_;
+#endif
+                            }
+                        }
+                    }
+                }
+            }
         }
-        if (allfin && own_done) break;
+        if (MODE == 2 && own_done) {
+            // what nobody has claimed of this workgroup's own tile
+            const int cf = ld_agent_i32(&claimF[wg]);
+            if (cf + 1 < own_nblk) {
+                allfin = false;
+                int got = 0;
+                if (ln == 0) got = atomicCAS(&claimF[wg], cf, cf + 1) == cf ? 1 : 0;
+                got = __builtin_amdgcn_readfirstlane(got);
+                if (got) {
+                    wa_finish_block<NCW, D>(A, wg, cf + 1);
+                    did = true;
+#ifdef WX_STAMP
+                    ++nfin_;
+#endif
+                }
+            }
+        }
+        if (own_done && (allfin || !stay) && !did) break;
         if (!did) {
             __builtin_amdgcn_s_sleep(64);
             if (own_done && ++idle > (1u << 18)) break;
             if (!own_warm && wa_cnt<C>(lds, WA_DEAD) != 0) break;
+        } else {
+            idle = 0;
         }
     }
 #ifdef WX_STAMP
-    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 9] = npf_; g_wf_wait[wg * 16 + 10] = nscan_; g_wf_wait[wg * 16 + 11] = (unsigned long long)lead_; }
+    if (PF && ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 9] = npf_; g_wf_wait[wg * 16 + 10] = nscan_ | (nfin_ << 32); g_wf_wait[wg * 16 + 11] = (unsigned long long)lead_; }
 #endif
     if (acc == 0x9e3779b9u && A.val_bytes == 0xfffffff3u) atomicExch(&A.ctrl[1], (int)acc);        // (the loads above are not dead code)
 }
@@ -2010,7 +2293,7 @@ k_ilu0_wa(WfArgs A)
     for (int i = t; i < C::Lds / 8; i += C::Threads) reinterpret_cast<double *>(lds)[i] = 0.0;
     if (t < 4) s_cnt[t] = 0;
     __syncthreads();
-    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; s_pairs[t] = z; }
+    if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; z.pw = -1; s_pairs[t] = z; }
     if (t < NL) s_exp[t] = -1;
     if (t < 4) *reinterpret_cast<double *>(lds + C::X + (unsigned)((t * C::RowL + NL) * 8)) = 1.0;
     // (a consumer wave has "done step tlo - 1" when it has read what its first step starts from)
@@ -2046,7 +2329,7 @@ k_ilu0_wa(WfArgs A)
             for (int v = 0; v < 4; ++v) xg[j][v] = 0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) tg[j][v] = 0;
-            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0; d.astart = -1;
+            WfPair d; d.idx0 = 0; d.stride = 0; d.sk = T[ST_SKEW]; d.cnt = cnt > 0 ? cnt : 0; d.at0 = 0; d.atm = 0; d.klast = -1; d.sh = 0; d.hasT = 0; d.astart = -1; d.pw = -1;
             if (ty == ST_LOCAL || ty == ST_GHOST) {
                 const int pu = A.uslot[os];
                 const int32_t *TPB = A.ltabB + (size_t)(pu < 0 ? 0 : pu) * kStTab;
@@ -2084,6 +2367,7 @@ k_ilu0_wa(WfArgs A)
                         for (int q4 = 0; q4 < 4; ++q4) { const int32_t *w4 = A.wtab + (size_t)(pw * 4 + q4) * 4; if (w4[2] > 0) tl = min(tl, w4[1]); }
                         tl &= U == 8 ? ~7 : ~3;
                         d.astart = A.xw[pw * 4 + 3] + (tl - A.xw[pw * 4 + 1]) * E + A.xe[os];
+                        d.pw = pw;
                     }
                 }
             } else if (ty == ST_OWN) {
@@ -2196,6 +2480,7 @@ k_ilu0_wa(WfArgs A)
         if (t == 0 && wg < 4096) g_wf_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
 #endif
         wa_consumer<MODE, NCW, D>(A, lds, wg, W, tlo, thi);
+        if (MODE == 2) wa_helper<MODE, NCW, D, false>(A, lds, wg, tlo, thi, -1);
 #ifdef WX_STAMP
         if (t == 0 && wg < 4096) {
             g_wf_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime(); g_wf_wait[wg * 16 + 12] = __builtin_amdgcn_s_memtime() - cy0_;
@@ -2218,18 +2503,22 @@ k_ilu0_wa(WfArgs A)
         } else {
             wa_exporter<NCW, D>(A, lds, P, tlo, thi, wg, elane);
         }
+        if (MODE == 2) wa_helper<MODE, NCW, D, false>(A, lds, wg, tlo, thi, -1);
     } else if (t < NL + 128 + NCW * 64) {
         __syncthreads();
         __syncthreads();
         __syncthreads();
         __syncthreads();
         wa_loader<NCW, D>(A, lds, wg, (t - NL - 128) >> 6, tlo, thi);
+        if (MODE == 2) wa_helper<MODE, NCW, D, false>(A, lds, wg, tlo, thi, -1);
     } else {
         __syncthreads();
         __syncthreads();
+        const int my_pw = s_pairs[t & 63].pw;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         __syncthreads();
-        wa_prefetcher<NCW, D>(A, lds, wg, tlo, thi);
+        wa_helper<MODE, NCW, D, true>(A, lds, wg, tlo, thi, my_pw);
     }
 }
 
@@ -2262,6 +2551,7 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
             typedef WaCfg<2, 3> C23;
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<0, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<0, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C23::Lds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C23::Lds));
         });
@@ -2285,14 +2575,14 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
         int dev = 0;
         ILUPP_HIP(hipGetDevice(&dev));
         const int d = dev & 63;
-        if (cap[d] < 2 * (int64_t)pl->nwg) {
+        if (cap[d] < 3 * (int64_t)pl->nwg) {
             if (buf[d]) ILUPP_HIP(pool_free(buf[d]));
             buf[d] = nullptr; cap[d] = 0;
-            ILUPP_HIP(pool_malloc(&buf[d], sizeof(int32_t) * 2 * (size_t)pl->nwg));
-            cap[d] = 2 * (int64_t)pl->nwg;
+            ILUPP_HIP(pool_malloc(&buf[d], sizeof(int32_t) * 3 * (size_t)pl->nwg));
+            cap[d] = 3 * (int64_t)pl->nwg;
         }
         a.prog = buf[d];
-        ILUPP_HIP(hipMemsetAsync(a.prog, 0xff, sizeof(int32_t) * 2 * (size_t)pl->nwg, st));
+        ILUPP_HIP(hipMemsetAsync(a.prog, 0xff, sizeof(int32_t) * 3 * (size_t)pl->nwg, st));
     }
     {
         // does the chip hold every workgroup of the launch at once?  (Then the prefetchers stay behind their own tile's end, for the
@@ -2318,7 +2608,10 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
         else hipLaunchKernelGGL((k_ilu0_wa<0, 2, 3>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
     } else if (wa_on()) {
         typedef WaCfg<4, 4> C;
+        // (the records finished by idle waves -- MODE 2 -- where every workgroup is resident and the progress words exist)
+        static const bool nofin = getenv("ILUPP_NO_FINISHERS") != nullptr;
         if (wd_mode() == 1) hipLaunchKernelGGL((k_ilu0_wa<1, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
+        else if ((a.flags & 2) && a.prog && !nofin) hipLaunchKernelGGL((k_ilu0_wa<2, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
         else hipLaunchKernelGGL((k_ilu0_wa<0, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
     } else {
         hipLaunchKernelGGL(k_ilu0_wx, dim3((unsigned)pl->nwg), dim3(kWfThreads), kWfLds, st, a);

@@ -44,7 +44,8 @@ dur = a[:, 2] - a[:, 1]
 if not os.environ.get("ILUPP_NO_WA"):
     npf = w[:, 9]; lead = np.array(wbuf[:nt * 16], dtype=np.uint64).reshape(nt, 16)[:, 11].astype(np.int64)
     print("prefetchers: %d blocks of eight steps asked for in all (%.1f per tile; a tile has %d), %d scans; a block was asked for %.1f steps ahead of its tile's progress on average" %
-          (npf.sum(), npf.sum() / nt, (dims[0] + 30) // 8, w[:, 10].sum(), lead.sum() / max(1.0, npf.sum())))
+          (npf.sum(), npf.sum() / nt, (dims[0] + 30) // 8, (np.array(wbuf[:nt * 16], dtype=np.uint64).reshape(nt, 16)[:, 10] & np.uint64(0xffffffff)).sum(), lead.sum() / max(1.0, npf.sum())))
+    print("blocks finished by the prefetcher waves: %d" % (np.array(wbuf[:nt * 16], dtype=np.uint64).reshape(nt, 16)[:, 10] >> np.uint64(32)).sum())
     print("blocks asked for by the prefetcher of each workgroup:")
     for z in range(Tz):
         print(" ".join("%4d" % npf[z * Ty + y] for y in range(Ty)))
