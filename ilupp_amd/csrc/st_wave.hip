@@ -1385,7 +1385,8 @@ struct WaCfg {
     static_assert(U % (2 * D) == 0 && U % 4 == 0 && U % NP == 0, "slots are immediates of the unrolled loops");
     static_assert(Lds * (4 / NCW) <= 160 * 1024 - 256 * (4 / NCW), "the LDS of a CU");
 };
-enum { WA_CP = 0, WA_LF = 4, WA_IP = 8, WA_TP = 9, WA_EP = 10, WA_DEAD = 11, WA_BIG = 12, WA_WARM = 13 };
+enum { WA_CP = 0, WA_LF = 4, WA_IP = 8, WA_TP = 9, WA_EP = 10, WA_DEAD = 11, WA_BIG = 12, WA_WARM = 13,          // (set anew for every unit)
+       WA_CHAIN = 14, WA_UM = 16, WA_UA = 17, WA_UB = 18, WA_BARC = 20, WA_BARG = 21 };
 static constexpr unsigned kWaSpinLimit = 1u << 24;
 
 // (LDS words other waves write: ordered with compiler barriers -- `volatile` would turn them into flat, system-scope accesses)
@@ -1404,6 +1405,24 @@ __device__ __forceinline__ void wa_st32(unsigned char *lds, const unsigned off, 
 }
 template <class C> __device__ __forceinline__ int wa_cnt(const unsigned char *lds, const int i) { return wa_ld32(lds, C::Cnt + 4u * (unsigned)i); }
 template <class C> __device__ __forceinline__ void wa_set(unsigned char *lds, const int i, const int v) { wa_st32(lds, C::Cnt + 4u * (unsigned)i, v); }
+// the waves of the roles meet (s_barrier would count the prefetcher's wave too, which is somewhere else): a count and a generation in LDS
+template <class C>
+__device__ __forceinline__ void wa_bar(unsigned char *lds, const int nwaves)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) {
+        int *cnt = reinterpret_cast<int *>(lds + C::Cnt + 4u * WA_BARC);
+        const int g = wa_cnt<C>(lds, WA_BARG);
+        if (atomicAdd(cnt, 1) == nwaves - 1) {
+            wa_set<C>(lds, WA_BARC, 0);
+            wa_set<C>(lds, WA_BARG, g + 1);
+        } else {
+            unsigned spins = 0;
+            while (wa_cnt<C>(lds, WA_BARG) == g && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 // a helper wave waits until the slowest consumer wave has finished step `s` (lanes 0..NCW-1 read one counter each)
 template <class C, int NCW>
 __device__ __forceinline__ bool wa_wait_consumers(unsigned char *lds, const int s, int32_t *ctrl)
@@ -1432,7 +1451,9 @@ struct WaLane {
     bool hasB, hasC, hasUB, hasUC;
 };
 
-template <int MODE, int NCW, int D>
+// RP: a REPLAY of steps [tlo, thi) of tile `wg` (MODE 2): the pivots are read, not computed -- the chain has stored them --, and the
+// three quarters of the records the chain left out are written: {lC, lB} {lA, 1} and {a'A, a'B}
+template <int MODE, int NCW, int D, bool RP>
 __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds, const int wg, const WaLane<WaCfg<NCW, D>::U> W, const int tlo, const int thi)
 {
     typedef WaCfg<NCW, D> C;
@@ -1449,6 +1470,10 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(A.pkU + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
     unsigned vout = (unsigned)(tlo - tminw) * 2048u + (unsigned)ln * 16u;
     const unsigned xown = C::X + (unsigned)t * 8u, tbown = C::TB + (unsigned)t * 8u, tcown = C::TC + (unsigned)t * 8u;
+    // (RP) the lane's stored pivot of step s_: write-through by the chain, 1 where the lane had no row or the wave no chunk
+    typedef unsigned int v4w_ __attribute__((ext_vector_type(4)));
+#define WA_LDW(s_) __builtin_amdgcn_raw_buffer_load_b128(rU, (unsigned)((s_) - tminw) * 2048u + 1024u + (unsigned)ln * 16u, 0, 16)
+#define WA_W(r_, s_) (((unsigned)((s_) - tminw) < (unsigned)nchw) ? __builtin_bit_cast(v2dd, r_).y : 1.0)
 #define WA_ROW(blk_, par_, r0_, r1_, r2_, r3_)                                                                     \
     do {                                                                                                           \
         const unsigned o_ = (unsigned)(blk_) * kWdWaveBlk;                                                         \
@@ -1505,10 +1530,40 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
     // (the transposed entries of the first step: the wave's own lanes' -- written just above, a wave's LDS operations stay in order --,
     // the imports' behind tpub; what another wave would hand on for it is two steps old: before the first step, zeros)
     double tB = st_lds(lds, W.tB[0]), tC = st_lds(lds, W.tC[0]);
-    asm volatile("" ::: "memory");
-    if (ln == 0) wa_set<C>(lds, WA_CP + wv, tlo - 1);
     double w3prev = 1.0, upA = 0.0;
     double qC = 1.0;
+    v4w_ wq[2];                                             // (RP) the stored pivots of the next two steps
+    if (RP) {
+        // the two steps before: what the other waves' lanes read of them (two steps old), this lane's own last pivot
+        const v4w_ r1 = WA_LDW(tlo - 1), r2 = WA_LDW(tlo - 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wq[i] = WA_LDW(tlo + i);
+        const double w1 = WA_W(r1, tlo - 1), w2 = WA_W(r2, tlo - 2);
+        *reinterpret_cast<double *>(lds + xown + (unsigned)((tlo - 1) & 3) * (C::RowL * 8)) = w1;
+        *reinterpret_cast<double *>(lds + xown + (unsigned)((tlo - 2) & 3) * (C::RowL * 8)) = w2;
+        w3prev = w1;
+        qC = wx_from_lane(W.src16, w1);
+    }
+    asm volatile("" ::: "memory");
+    if (ln == 0) wa_set<C>(lds, WA_CP + wv, tlo - 1);
+    if (RP) {
+        // (bB, bC above were read before the wave below had put its two steps in: again, behind the first step's check)
+        unsigned spins = 0;
+        for (;;) {
+            const int c0 = wa_ld32(lds, W.ca);
+            if (__builtin_amdgcn_ballot_w64(c0 - W.coff < tlo) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0) {
+                if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
+                if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
+            }
+        }
+        asm volatile("" ::: "memory");
+        // (only what another wave of the tile has put there: an import was read above, before this wave said so -- the poller takes
+        // the slot back once every wave has)
+        if (W.xB[0] < C::XI) bB = st_lds(lds, W.xB[0]);
+        if (W.xC[0] < C::XI) bC = st_lds(lds, W.xC[0]);
+    }
     int k = tlo - sk;
     int cv = wa_ld32(lds, W.ca);
 #ifdef WX_STAMP
@@ -1544,12 +1599,12 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
             WA_ROW(((u + 2) >> 1) % D, u & 1, m0_, m1_, m2_, m3_);
             const double nB = st_lds(lds, W.xB[(u + 1) & 3]);
             const double nC = st_lds(lds, W.xC[(u + 1) & 3]);
-            const double ntB = st_lds(lds, W.tB[(u + 1) & 3]);
-            const double ntC = st_lds(lds, W.tC[(u + 1) & 3]);
+            const double ntB = RP ? 0.0 : st_lds(lds, W.tB[(u + 1) & 3]);
+            const double ntC = RP ? 0.0 : st_lds(lds, W.tC[(u + 1) & 3]);
             const bool valid = (unsigned)k < (unsigned)cnt;
 #ifdef WX_STAMP
-            if (t == 0 && wg < 4096 && k == 0) g_wf_tl[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-            if (t == 0 && wg < 4096 && k == cnt - 1) g_wf_tl[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+            if (!RP && t == 0 && wg < 4096 && k == 0) g_wf_tl[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            if (!RP && t == 0 && wg < 4096 && k == cnt - 1) g_wf_tl[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
             const double aA = c1_.x, tA = k == 0 ? 0.0 : upA;
             const double uA = c2_.x;
@@ -1559,14 +1614,18 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
             cv = wa_ld32(lds, W.ca);
             const double lA = aA / w3prev;
             double w = c1_.y;
-            w = w - lC * tC;
-            w = w - lB * tB;
-            w = w - lA * tA;
-            {
+            if (!RP) {
+                w = w - lC * tC;
+                w = w - lB * tB;
+                w = w - lA * tA;
                 const unsigned long long wb = st_bits(w);
                 if ((wb & ~3ull) == (kSentinel & ~3ull)) w = st_dbl(kCanonNaN);
             }
-            const double w3 = valid ? w : 1.0;
+            double w3 = valid ? w : 1.0;
+            if (RP) {
+                w3 = WA_W(wq[u & 1], s);
+                wq[u & 1] = WA_LDW(s + 2);
+            }
             *reinterpret_cast<double *>(lds + xown + (unsigned)(u & 3) * (C::RowL * 8)) = w3;
             qC = wx_from_lane(W.src16, w3);
             w3prev = w3; upA = c2_.x;
@@ -1575,12 +1634,13 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
                 v2dd la, lb, ua, ub;
                 la.x = lC; la.y = lB; lb.x = lA; lb.y = 1.0;
                 ua.x = uA; ua.y = c2_.y; ub.x = c3_.x; ub.y = w3;
-                if (MODE == 0) {
+                if (MODE == 0 || RP) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, la), rL, vout, 0, 2);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vout + 1024u, 0, 2);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ua), rU, vout, 0, 2);
                 }
-                if (MODE == 2) {
+                if (RP) {
+                } else if (MODE == 2) {
                     // (write-through: the finishers on other CUs read it; at most 15 of this wave's stores are ever on their way)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ub), rU, vout + 1024u, 0, 16);
                     asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
@@ -1590,7 +1650,7 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
                 vout += 2048u;
             }
             WA_ENDS(k + 1, n0_, n1_, n2_, n3_);
-            WA_HAND_T((u + 1) & 3, n2_, n3_);
+            if (!RP) WA_HAND_T((u + 1) & 3, n2_, n3_);
             // this wave's step is done: its LDS writes are in front of the counter's (a wave's LDS operations stay in order)
             asm volatile("" ::: "memory");
             if (ln == 0) wa_set<C>(lds, WA_CP + wv, s);
@@ -1601,7 +1661,7 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
         }
     }
 #ifdef WX_STAMP
-    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + wv] = cslow_; if (wv == 0) g_wf_wait[wg * 16 + 13] = nslow_; }
+    if (!RP && ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + wv] = cslow_; if (wv == 0) g_wf_wait[wg * 16 + 13] = nslow_; }
 #endif
     // (every store of this wave has arrived: the word the exporter's last progress and the finishers of this tile's leftovers wait for)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1609,13 +1669,15 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
 #undef WA_ROW
 #undef WA_HAND_T
 #undef WA_ENDS
+#undef WA_LDW
+#undef WA_W
 }
 
 // the poller: the imported pivots of step j into slot j mod 8 of the import ring, as far ahead of the consumers as the earlier
 // workgroups (and the ring) allow
 template <int NCW, int D>
 __device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long long *idle, unsigned char *lds, const WfPair P,
-                                          const int tlo, const int thi, const int wg)
+                                          const int tlo, const int thi, const int wg, const bool publish)
 {
     typedef WaCfg<NCW, D> C;
     constexpr int NP = C::NP, SH = kWdSH, U = C::U;
@@ -1646,7 +1708,7 @@ __device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long l
                 if (spins > kStSpinLimit || e != 0) { dead = true; break; }
             }
         }
-        if (ln == 0) { wa_set<C>(lds, WA_WARM, 1); if (A.prog) st_agent_i32(&A.prog[wg], 0); }
+        if (ln == 0) { wa_set<C>(lds, WA_WARM, 1); if (A.prog && publish) st_agent_i32(&A.prog[wg], 0); }
     }
     // the value of step tlo_ + i_: wait for it, put it into the ring, ask for the one eight steps on; a value that was not there at the
     // first look means this workgroup has caught up with the one it reads from: everything asked for meanwhile was asked too early,
@@ -1712,7 +1774,7 @@ __device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long l
 // the exporter: the border pivots of step s behind the consumers' step s; the imports' transposed entries four steps ahead
 template <int NCW, int D>
 __device__ __forceinline__ void wa_exporter(const WfArgs &A, unsigned char *lds, const WfPair P, const int tlo, const int thi, const int wg,
-                                            const int elane)
+                                            const int elane, const bool publish)
 {
     typedef WaCfg<NCW, D> C;
     constexpr int NA = C::NP, U = C::U;
@@ -1761,10 +1823,10 @@ __device__ __forceinline__ void wa_exporter(const WfArgs &A, unsigned char *lds,
             ga[u % NA] = WAC_LDAT(s + 4 + NA - P.sk);
             if (ln == 0) { wa_set<C>(lds, WA_EP, s); wa_set<C>(lds, WA_TP, s + 4); }
             // (for the prefetchers of other workgroups: how far this tile is, in steps from its first)
-            if ((u & 7) == 0 && ln == 0 && A.prog) st_agent_i32(&A.prog[wg], s - tlo);
+            if ((u & 7) == 0 && ln == 0 && A.prog && publish) st_agent_i32(&A.prog[wg], s - tlo);
         }
     }
-    if (A.prog) { (void)wa_wait_consumers<C, NCW>(lds, 0x7ffffff0, A.ctrl); if (ln == 0) st_agent_i32(&A.prog[wg], 0x3fffffff); }
+    if (A.prog && publish) { (void)wa_wait_consumers<C, NCW>(lds, 0x7ffffff0, A.ctrl); if (ln == 0) st_agent_i32(&A.prog[wg], 0x3fffffff); }
 #undef WAC_AT
 #undef WAC_LDAT
 }
@@ -1899,85 +1961,21 @@ __device__ __forceinline__ unsigned wa_pf_block(const WfArgs &A, const __amdgpu_
 }
 
 // ---------------------------------------------------------------------------------------------
-// MODE 2: the records are FINISHED by idle waves.  The waves on the chain store {a'C, u_rr} only (write-through: other CUs read it);
-// everything else of a row's records follows from A and the pivots without any recurrence -- l = a / u_kk, the strict upper part of
-// U is A's (ILU0.hpp:47-62 for rows whose eliminations meet them on the diagonal only) -- and is written, a block of eight steps of a
-// tile at a time, by whoever has nothing else to do: the prefetcher of a workgroup whose tile has not begun, every wave of a
-// workgroup whose tile has ended.  That takes 48 of the 64 record bytes per row off the CU that is bounded by what it can have
-// in flight.  A block of a tile is finished when the tile is kFinMargin steps past it (the chain waves keep at most 15 of their
-// stores unacknowledged, so what the finisher reads has arrived); a tile's own workgroup finishes what nobody else has claimed.
-// The arithmetic is the chain's: the same divisions, on the same operands, in the same order of evaluation per entry.
+// MODE 2: the chains store a quarter of the records, REPLAYS write the rest.  The waves on the chain of a tile store {a'C, u_rr} only
+// (write-through: other CUs read it); everything else of a row's records follows from A and the pivots without any recurrence --
+// l = a / u_kk, the strict upper part of U is A's (ILU0.hpp:47-62 for rows whose eliminations meet them on the diagonal only) -- and
+// is written by a workgroup whose own tile has ended: it takes a unit of kRpSteps steps of any tile that is kFinMargin steps past
+// them and runs the same waves over it once more (wa_unit<RP>) -- loaders, poller, the four waves -- with the pivots read instead
+// of computed: no hand-over to wait for, the rows mostly still in the Infinity Cache.  That takes 48 of the 64 record bytes per row
+// off the CU that is bounded by what it can have in flight while it is on the critical path, and puts them on CUs that would idle.
+// (The chain waves keep at most 15 of their stores unacknowledged: what a replay reads has arrived.  The arithmetic of a replay is
+// the chain's, the same divisions on the same operands: bit-identical records.)
 // ---------------------------------------------------------------------------------------------
 static constexpr int kFinMargin = 16;
-
-// what a lane of a tile knows (wa kernel prologue), for somebody who is not that lane
-struct WaFin {
-    int cnt, sk, kF, kL;
-    unsigned rowb, m8;            // byte offset (val_shift included) of the virtual start of the row of step 0; bytes per row
-    unsigned off[7];              // byte offset of each canonical place in the row (0xffffff00: the lane's rows have no such entry)
-    bool hasB, hasC, hasUB, hasUC, ringC;
-    int bKind, cKind;             // where the pivot of class B / C comes from when not from the wave's registers: 0 nobody (one), 1 a lane of the tile `dt` steps ago, 2 the exchange
-    int bLane, bDt, bIdx0, bStride, cLane, cDt, cIdx0, cStride;
-    bool ok;
-};
-__device__ __forceinline__ void wa_fin_decode(const WfArgs &A, const int tile, const int t, WaFin *F)
-{
-    const int slot = tile * kThreads + t;
-    const int32_t *T = A.ltab + (size_t)slot * kStTab;
-    const int nd = T[ST_ND], cnt = T[ST_CNT];
-    int cls[3]; bool ring[3];
-    bool ok = wr_classify(T, t, false, cls, ring);
-    F->cnt = cnt; F->sk = T[ST_SKEW];
-    const int fl = T[ST_DFL], ndU = fl & 3, ownL = (fl >> 2) & 1, m = fl >> 4;
-    F->kF = ownL ? 0 : -1; F->kL = ((fl >> 3) & 1) ? cnt - 1 : -1;
-    F->rowb = 8u * (unsigned)(T[ST_P0] - ownL - T[ST_SKEW] * m) + (unsigned)A.val_shift;
-    F->m8 = 8u * (unsigned)m;
-    F->hasB = F->hasC = F->hasUB = F->hasUC = false; F->ringC = true;
-    F->bKind = F->cKind = 0; F->bLane = F->cLane = 0; F->bDt = F->cDt = 0; F->bIdx0 = F->cIdx0 = 0; F->bStride = F->cStride = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int sw = T[ST_SRC + j];
-        const int ty = (j < nd && cnt > 0) ? (sw & 3) : ST_NONE;
-        const int os = sw >> 2;
-        int kind = 0, lane = 0, dt = 0, idx0 = 0, stride = 0;
-        if (ty == ST_LOCAL) { kind = 1; lane = os & 255; dt = T[ST_DT + j]; }
-        else if (ty == ST_GHOST) {
-            const int pw = os >> 8;
-            const int32_t *TP = A.ltab + (size_t)os * kStTab;
-            const int E = A.xw[pw * 4];
-            kind = 2; stride = E;
-            idx0 = A.xw[pw * 4 + 3] + (T[ST_KAP + j] + TP[ST_SKEW] - T[ST_SKEW] - A.xw[pw * 4 + 1]) * E + A.xe[os];
-        }
-        if (cls[j] == WR_B) { F->hasB = true; if (ring[j]) { F->bKind = kind; F->bLane = lane; F->bDt = dt; F->bIdx0 = idx0; F->bStride = stride; } }
-        if (cls[j] == WR_C) {
-            F->hasC = true;
-            if (ring[j]) { F->cKind = kind; F->cLane = lane; F->cDt = dt; F->cIdx0 = idx0; F->cStride = stride; } else F->ringC = false;
-        }
-    }
-    int bc[3] = {WR_NONE, WR_NONE, WR_NONE};
-    {
-        const int su = cnt > 0 ? A.uslot[slot] : -1;
-        if (su >= 0) {
-            bool br[3];
-            (void)wr_classify(A.ltabB + (size_t)su * kStTab, su & 255, true, bc, br);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { if (bc[q] == WR_B) F->hasUB = true; if (bc[q] == WR_C) F->hasUC = true; }
-        } else if (cnt > 0) ok = false;
-    }
-    int posOf[7] = {-1, -1, -1, -1, -1, -1, -1};
-#pragma unroll
-    for (int pos = 0; pos < 7; ++pos) {
-        int place = -1;
-        if (pos < nd) { const int c = pos == 0 ? cls[0] : (pos == 1 ? cls[1] : cls[2]); place = c == WR_NONE ? -1 : wr_slot_of(c, false); }
-        else if (pos == nd) place = 3;
-        else if (pos <= nd + ndU && pos - nd - 1 < 3) { const int q = pos - nd - 1; const int c = q == 0 ? bc[0] : (q == 1 ? bc[1] : bc[2]); place = c == WR_NONE ? -1 : 4 + wr_slot_of(c, true); }
-#pragma unroll
-        for (int pl_ = 0; pl_ < 7; ++pl_) if (place == pl_) posOf[pl_] = pos;
-    }
-#pragma unroll
-    for (int pl_ = 0; pl_ < 7; ++pl_) F->off[pl_] = (cnt > 0 && posOf[pl_] >= 0) ? 8u * (unsigned)posOf[pl_] : 0xffffff00u;
-    F->ok = ok;
-}
+#ifndef WA_RP_STEPS
+#define WA_RP_STEPS 32
+#endif
+static constexpr int kRpSteps = WA_RP_STEPS;
 
 // the first step of a tile and the number of its blocks of eight steps (as its own workgroup computes them)
 template <int NCW, int D>
@@ -1996,124 +1994,79 @@ __device__ __forceinline__ void wa_tile_span(const WfArgs &A, const int tile, in
     *nblk_out = th > tl ? ((th - tl + U - 1) / U * U) / 8 : 0;
 }
 
-// one block of eight steps of a tile: {lC, lB} {lA, 1} and {a'A, a'B} of every lane's row (one wave; the lanes of a consumer wave at a time)
+// (wave 0 of a workgroup between units) the next unit to replay -> WA_UM (the tile; -1: none is left anywhere), WA_UA, WA_UB
 template <int NCW, int D>
-__device__ __forceinline__ void wa_finish_block(const WfArgs &A, const int tile, const int blk)
+__device__ __forceinline__ void wa_claim_unit(const WfArgs &A, unsigned char *lds, const int wg)
 {
-    typedef double v2dd __attribute__((ext_vector_type(2)));
-    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
-    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+    typedef WaCfg<NCW, D> C;
     const int ln = threadIdx.x & 63;
-    int tl, nblk;
-    wa_tile_span<NCW, D>(A, tile, &tl, &nblk);
-    if (blk >= nblk) return;
-    const int s0 = tl + 8 * blk;
-    const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
-    const __amdgpu_buffer_rsrc_t rxch = __builtin_amdgcn_make_buffer_rsrc(A.xch, 0, 0x7ffffff0, 0x00020000);
-#pragma unroll 1
-    for (int w = 0; w < NCW; ++w) {
-        const int t = 64 * w + ln;
-        WaFin F;
-        wa_fin_decode(A, tile, t, &F);
-        const int32_t *wt = A.wtab + (size_t)(tile * 4 + w) * 4;
-        const int base = __builtin_amdgcn_readfirstlane(wt[0]), tminw = __builtin_amdgcn_readfirstlane(wt[1]),
-                  nchw = __builtin_amdgcn_readfirstlane(wt[2]);
-        if (nchw <= 0) continue;
-        const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.pkL + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(A.pkU + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
-        // (the pivots of a lane of ANOTHER wave of the tile: that wave's chunks)
-        const int wB = F.bKind == 1 ? (F.bLane >> 6) : w, wC = F.cKind == 1 ? (F.cLane >> 6) : w;
-        const int32_t *wtB = A.wtab + (size_t)(tile * 4 + wB) * 4, *wtC = A.wtab + (size_t)(tile * 4 + wC) * 4;
-        const int baseB = wtB[0], tminB = wtB[1], nchB = wtB[2], baseC = wtC[0], tminC = wtC[1], nchC = wtC[2];
-        const __amdgpu_buffer_rsrc_t rUall = __builtin_amdgcn_make_buffer_rsrc(A.pkU, 0, 0x7ffffff0, 0x00020000);
-        const bool fCB = F.hasC && F.hasB, fCA = F.hasC && !F.hasB, fBA = F.hasB;
-        const bool lCB = F.hasUC && F.hasUB, lCA = F.hasUC && !F.hasUB, lBA = F.hasUB;
-        const int src16 = ((t - 16) & 63) * 4;
-        // the lane's pivot of the step before the block's first (one where the lane had no row, or a step before its wave's chunks)
-        double wprev;
-        {
-            const int c = s0 - 1 - tminw;
-            const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rU, (unsigned)c * 2048u + 1024u + (unsigned)ln * 16u, 0, 16);
-            wprev = ((unsigned)c < (unsigned)nchw) ? __builtin_bit_cast(v2dd, r).y : 1.0;
+    const int nwg = (int)gridDim.x;
+    int32_t *prog = A.prog, *claimR = A.prog + 2 * nwg;
+    unsigned spins = 0;
+    for (;;) {
+        bool open = false;
+        for (int t0 = 0; t0 < nwg; t0 += 64) {
+            const int tt = t0 + ((ln + wg) & 63);
+            bool ready = false;
+            int cr = 0, tl = 0, nb = 0;
+            if (tt < nwg) {
+                const int pr = ld_agent_i32(&prog[tt]);
+                cr = ld_agent_i32(&claimR[tt]);
+                wa_tile_span<NCW, D>(A, tt, &tl, &nb);
+                const int nunits = (nb * 8 + kRpSteps - 1) / kRpSteps;
+                if (cr + 1 < nunits) {
+                    open = true;
+                    ready = pr >= 0x3fffffff || pr >= kRpSteps * (cr + 2) + kFinMargin;
+                }
+            }
+            const unsigned long long bw = __builtin_amdgcn_ballot_w64(ready);
+            if (bw != 0) {
+                const int L = __builtin_ctzll(bw);
+                int got = 0;
+                if (ln == L) got = atomicCAS(&claimR[tt], cr, cr + 1) == cr ? 1 : 0;
+                got = __builtin_amdgcn_readlane(got, L);
+                if (got) {
+                    if (ln == L) {
+                        const int ua = tl + kRpSteps * (cr + 1);
+                        wa_set<C>(lds, WA_UM, tt); wa_set<C>(lds, WA_UA, ua); wa_set<C>(lds, WA_UB, min(ua + kRpSteps, tl + 8 * nb));
+                    }
+                    return;
+                }
+                open = true;
+            }
         }
-#pragma unroll 2
-        for (int j = 0; j < 8; ++j) {
-            const int s = s0 + j, k = s - F.sk;
-            const bool valid = (unsigned)k < (unsigned)F.cnt;
-            // the row, place by place (a place the lane's rows do not have: out of range, zero)
-            const unsigned rb = F.rowb + F.m8 * (unsigned)s;
-            double v[7];
-#pragma unroll
-            for (int p_ = 0; p_ < 7; ++p_) {
-                unsigned o_ = F.off[p_] < 0x1000u ? rb + F.off[p_] : 0xfffffff0u;
-                asm volatile("" : "+v"(o_));
-                v[p_] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, o_, 0, 0));
-            }
-            // this step's own pivot (the next step's `wprev`) and what comes from outside the wave's registers
-            const int c = s - tminw;
-            const v4u_ rw = __builtin_amdgcn_raw_buffer_load_b128(rU, (unsigned)c * 2048u + 1024u + (unsigned)ln * 16u, 0, 16);
-            double bB = 1.0, bC = 1.0;
-            if (F.bKind == 1) {
-                const int cb = s - F.bDt - tminB;
-                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rUall, (unsigned)(baseB + cb) * 2048u + 1024u + (unsigned)(F.bLane & 63) * 16u + 8u, 0, 16);
-                bB = ((unsigned)cb < (unsigned)nchB) ? __builtin_bit_cast(double, r) : 1.0;
-            } else if (F.bKind == 2) {
-                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rxch, (unsigned)(F.bIdx0 + s * F.bStride) * 8u, 0, 16);
-                bB = __builtin_bit_cast(double, r);
-            }
-            if (F.cKind == 1) {
-                const int cc = s - F.cDt - tminC;
-                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rUall, (unsigned)(baseC + cc) * 2048u + 1024u + (unsigned)(F.cLane & 63) * 16u + 8u, 0, 16);
-                bC = ((unsigned)cc < (unsigned)nchC) ? __builtin_bit_cast(double, r) : 1.0;
-            } else if (F.cKind == 2) {
-                const v2u_ r = __builtin_amdgcn_raw_buffer_load_b64(rxch, (unsigned)(F.cIdx0 + s * F.cStride) * 8u, 0, 16);
-                bC = __builtin_bit_cast(double, r);
-            }
-            // (k_ilu0_wa: the entries of a chain's first and last row sit one place nearer to the diagonal)
-            {
-                const bool f_ = k == F.kF, l_ = k == F.kL;
-                const double c_ = v[0], b_ = v[1], a_ = v[2], ua_ = v[4], ub_ = v[5], uc_ = v[6];
-                v[0] = f_ ? (fCB ? b_ : (fCA ? a_ : c_)) : c_;
-                v[1] = f_ ? (fBA ? a_ : b_) : b_;
-                v[2] = f_ ? 0.0 : a_;
-                v[4] = l_ ? 0.0 : ua_;
-                v[5] = l_ ? (lBA ? ua_ : ub_) : ub_;
-                v[6] = l_ ? (lCB ? ub_ : (lCA ? ua_ : uc_)) : uc_;
-            }
-            const double pB = wx_dpp_shr1(bB, wprev);
-            const double qC = wx_from_lane(src16, wprev);
-            const double pC = F.ringC ? bC : qC;
-            v2dd la, lb, ua;
-            la.x = v[0] / pC; la.y = v[1] / pB; lb.x = v[2] / wprev; lb.y = 1.0;
-            ua.x = v[4]; ua.y = v[5];
-            if (!valid) { la.x = 0.0; la.y = 0.0; lb.x = 0.0; ua.x = 0.0; ua.y = 0.0; }
-            const unsigned vo = (unsigned)c * 2048u + (unsigned)ln * 16u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, la), rL, vo, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vo + 1024u, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ua), rU, vo, 0, 2);
-            wprev = ((unsigned)c < (unsigned)nchw) ? __builtin_bit_cast(v2dd, rw).y : 1.0;
-        }
+        if (__builtin_amdgcn_ballot_w64(open) == 0 || wa_cnt<C>(lds, WA_DEAD) != 0 || ++spins > (1u << 20)) { if (ln == 0) wa_set<C>(lds, WA_UM, -1); return; }
+        __builtin_amdgcn_s_sleep(64);
     }
 }
 
-// What a wave does when its own tile does not need it: read ahead for the tiles at work and (MODE 2) finish their records.
-//   PF: the prefetcher wave of a workgroup (from the launch on: before its tile begins, asleep while it works, after it has ended);
-//   else: any other wave, once its tile has ended.
+// The prefetcher: one wave of a workgroup, on its own from the launch on.  Before its tile begins and after its chain has ended it reads
+// ahead for the tiles at work (asleep in between: it would take from what its CU can have in flight while that is on the critical path).
 template <int MODE, int NCW, int D, bool PF>
-__device__ __forceinline__ void wa_helper(const WfArgs &A, unsigned char *lds, const int wg, const int tlo, const int thi, const int my_pw)
+__device__ __forceinline__ void wa_helper(const WfArgs &A, unsigned char *lds, const int wg)
 {
     typedef WaCfg<NCW, D> C;
     const int ln = threadIdx.x & 63;
     if (!A.prog) return;
     const int nwg = (int)gridDim.x;
-    int32_t *prog = A.prog, *claim = A.prog + nwg, *claimF = A.prog + 2 * nwg;
+    int32_t *prog = A.prog, *claim = A.prog + nwg;
     const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
     unsigned acc = 0;
-    bool own_done = !PF, own_warm = !PF;
+    bool own_done = false, own_warm = false;
     unsigned idle = 0;
     // the (first two) workgroups this one imports from: they work right before it does, and until it begins it has nothing else to do
     int up1 = -1, up2 = -1;
-    if (PF) {
+    {
+        int my_pw = -1;
+        for (int i = 0; i < NCW && my_pw < 0; ++i) {
+            const int32_t *T = A.ltab + (size_t)(wg * kThreads + 64 * i + ln) * kStTab;
+            const int nd = T[ST_ND], cnt = T[ST_CNT];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sw = T[ST_SRC + j];
+                if (j < nd && cnt > 0 && (sw & 3) == ST_GHOST && my_pw < 0) my_pw = (sw >> 2) >> 8;
+            }
+        }
         const unsigned long long b1 = __builtin_amdgcn_ballot_w64(my_pw >= 0);
         if (b1 != 0) {
             up1 = __builtin_amdgcn_readlane(my_pw, __builtin_ctzll(b1));
@@ -2121,125 +2074,61 @@ __device__ __forceinline__ void wa_helper(const WfArgs &A, unsigned char *lds, c
             if (b2 != 0) up2 = __builtin_amdgcn_readlane(my_pw, __builtin_ctzll(b2));
         }
     }
-    int own_nblk = 0;
-    { int tl_; wa_tile_span<NCW, D>(A, wg, &tl_, &own_nblk); }
-    if (!PF) {
-        // (a wave whose own job is done: the tile's last stores first)
-        unsigned spins = 0;
-        for (;;) {
-            int cmin = 0x7fffffff;
-            for (int q = 0; q < NCW; ++q) cmin = min(cmin, wa_cnt<C>(lds, WA_CP + q));
-            if (cmin >= 0x7ffffff0 || wa_cnt<C>(lds, WA_DEAD) != 0) break;
-            __builtin_amdgcn_s_sleep(127);
-            if (++spins > kWaSpinLimit) return;
-        }
-    }
 #ifdef WX_STAMP
-    unsigned long long npf_ = 0, nscan_ = 0, nfin_ = 0; long long lead_ = 0;
+    unsigned long long npf_ = 0, nscan_ = 0; long long lead_ = 0;
 #endif
     for (;;) {
 #ifdef WX_STAMP
         ++nscan_;
 #endif
-        if (PF) {
-            // this workgroup's own tile: hands off while it works
-            if (!own_warm) {
-                if (wa_cnt<C>(lds, WA_WARM) != 0) { own_warm = true; continue; }
-            } else if (!own_done) {
-                if (wa_cnt<C>(lds, WA_DEAD) != 0) break;
-                int cmin = 0x7fffffff;
-                for (int q = 0; q < NCW; ++q) cmin = min(cmin, wa_cnt<C>(lds, WA_CP + q));
-                if (cmin < 0x7ffffff0) { __builtin_amdgcn_s_sleep(127); continue; }       // (the chain waves' stores have all arrived)
-                own_done = true;
-            }
+        // this workgroup's own tile: hands off while its chain works
+        if (!own_warm) {
+            if (wa_cnt<C>(lds, WA_WARM) != 0) { own_warm = true; continue; }
+        } else if (!own_done) {
+            if (wa_cnt<C>(lds, WA_DEAD) != 0) break;
+            if (wa_cnt<C>(lds, WA_CHAIN) != 2 && !(MODE != 2 && wa_cnt<C>(lds, WA_CP) >= 0x7ffffff0)) { __builtin_amdgcn_s_sleep(127); continue; }
+            own_done = true;
+            // (a launch of more workgroups than the chip holds: this one's CU is wanted by the next)
+            if (!(A.flags & 2)) break;
         }
-        // (a launch of more workgroups than the chip holds: this one's CU is wanted by the next; what is left of its own tile first)
-        const bool stay = (A.flags & 2) != 0;
         // FIVE other tiles, fixed.  The (two) tiles this one imports from: they begin some twenty steps before it and it is idle till
         // then -- a tile's first steps, which the next tile waits for, always have somebody.  And three far ones: half the launch
         // away, an eighth of a line of tiles away, and both (on a box grid in 16 x 16 patches: eight patches on in z, in y, in both --
         // eight or sixteen hand-overs earlier or later: they work mostly while this one does not).  The next block inside a mate's
         // window is claimed with a compare-and-swap on claim[mate] (few waves ask for a tile: no crowd)
         bool did = false, allfin = true;
-        if (stay || !own_done) {
 #pragma unroll 1
-            for (int j = 0; j < 5; ++j) {
-                const int off = j == 2 ? nwg / 2 : (j == 3 ? nwg / 32 : nwg / 2 + nwg / 32);
-                const int mate = j == 0 ? up1 : (j == 1 ? up2 : (wg + off) % nwg);
-                if (mate < 0 || mate == wg || (j == 3 && nwg < 64) || (j < 2 && own_done)) continue;
-                const int pr = ld_agent_i32(&prog[mate]);
-                if (pr < 0) { allfin = false; continue; }
-                if (pr < 0x3fffffff) {
-                    allfin = false;
-                    int cl = ld_agent_i32(&claim[mate]);
-                    // (blocks the tile has passed already are not asked for)
-                    if (8 * (cl + 2) <= pr) cl = pr / 8 - 1;
-                    if (8 * (cl + 2) <= pr + kPfLead) {
-                        int got = 0;
-                        if (ln == 0) { const int old = ld_agent_i32(&claim[mate]); got = (old <= cl && atomicCAS(&claim[mate], old, cl + 1) == old) ? 1 : 0; }
-                        got = __builtin_amdgcn_readfirstlane(got);
-                        if (got) {
-                            acc ^= wa_pf_block<NCW, D>(A, rs, mate, cl + 2);
-                            did = true;
+        for (int j = 0; j < 5; ++j) {
+            const int off = j == 2 ? nwg / 2 : (j == 3 ? nwg / 32 : nwg / 2 + nwg / 32);
+            const int mate = j == 0 ? up1 : (j == 1 ? up2 : (wg + off) % nwg);
+            if (mate < 0 || mate == wg || (j == 3 && nwg < 64) || (j < 2 && own_done)) continue;
+            const int pr = ld_agent_i32(&prog[mate]);
+            if (pr < 0x3fffffff) allfin = false;
+            if (pr < 0 || pr >= 0x3fffffff) continue;
+            int cl = ld_agent_i32(&claim[mate]);
+            // (blocks the tile has passed already are not asked for)
+            if (8 * (cl + 2) <= pr) cl = pr / 8 - 1;
+            if (8 * (cl + 2) > pr + kPfLead) continue;
+            int got = 0;
+            if (ln == 0) { const int old = ld_agent_i32(&claim[mate]); got = (old <= cl && atomicCAS(&claim[mate], old, cl + 1) == old) ? 1 : 0; }
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (!got) continue;
+            acc ^= wa_pf_block<NCW, D>(A, rs, mate, cl + 2);
+            did = true;
 #ifdef WX_STAMP
-                            ++npf_;
-                            lead_ += (long long)(8 * (cl + 2) - pr);
+            ++npf_;
+            lead_ += (long long)(8 * (cl + 2) - pr);
 #endif
-                            continue;
-                        }
-                    }
-                }
-                if (MODE == 2) {
-                    // the mate's next unfinished block, once the mate is far enough past it
-                    int tlm, nbm;
-                    wa_tile_span<NCW, D>(A, mate, &tlm, &nbm);
-                    const int cf = ld_agent_i32(&claimF[mate]);
-                    if (cf + 1 < nbm) {
-                        allfin = false;
-                        if (8 * (cf + 2) + kFinMargin <= pr) {
-                            int got = 0;
-                            if (ln == 0) got = atomicCAS(&claimF[mate], cf, cf + 1) == cf ? 1 : 0;
-                            got = __builtin_amdgcn_readfirstlane(got);
-                            if (got) {
-                                wa_finish_block<NCW, D>(A, mate, cf + 1);
-                                did = true;
-#ifdef WX_STAMP
-                                ++nfin_;
-#endif
-                            }
-                        }
-                    }
-                }
-            }
         }
-        if (MODE == 2 && own_done) {
-            // what nobody has claimed of this workgroup's own tile
-            const int cf = ld_agent_i32(&claimF[wg]);
-            if (cf + 1 < own_nblk) {
-                allfin = false;
-                int got = 0;
-                if (ln == 0) got = atomicCAS(&claimF[wg], cf, cf + 1) == cf ? 1 : 0;
-                got = __builtin_amdgcn_readfirstlane(got);
-                if (got) {
-                    wa_finish_block<NCW, D>(A, wg, cf + 1);
-                    did = true;
-#ifdef WX_STAMP
-                    ++nfin_;
-#endif
-                }
-            }
-        }
-        if (own_done && (allfin || !stay) && !did) break;
+        if (allfin && own_done) break;
         if (!did) {
             __builtin_amdgcn_s_sleep(64);
             if (own_done && ++idle > (1u << 18)) break;
             if (!own_warm && wa_cnt<C>(lds, WA_DEAD) != 0) break;
-        } else {
-            idle = 0;
         }
     }
 #ifdef WX_STAMP
-    if (PF && ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 9] = npf_; g_wf_wait[wg * 16 + 10] = nscan_ | (nfin_ << 32); g_wf_wait[wg * 16 + 11] = (unsigned long long)lead_; }
+    if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 9] = npf_; g_wf_wait[wg * 16 + 10] = nscan_; g_wf_wait[wg * 16 + 11] = (unsigned long long)lead_; }
 #endif
     if (acc == 0x9e3779b9u && A.val_bytes == 0xfffffff3u) atomicExch(&A.ctrl[1], (int)acc);        // (the loads above are not dead code)
 }
@@ -2247,38 +2136,17 @@ __device__ __forceinline__ void wa_helper(const WfArgs &A, unsigned char *lds, c
 // (per-XCD ticket counters in the control words: [2], [3], [9] .. [14])
 __device__ __forceinline__ int wa_xcd_word(const int x) { return x < 2 ? 2 + x : 7 + x; }
 
-template <int MODE, int NCW, int D>
-__global__ void __launch_bounds__((WaCfg<NCW, D>::Threads), (NCW == 2 ? 4 : 3))
-k_ilu0_wa(WfArgs A)
+// one UNIT of a workgroup's work: the chain of its own tile (RP false: tile `wg`, all of its steps), or (RP, MODE 2) the replay of steps
+// [ua, ub) of some tile whose chain is past them.  The waves of the roles only (the prefetcher goes its own way): they meet at
+// wa_bar, not at s_barrier.
+template <int MODE, int NCW, int D, bool RP>
+__device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int *s_cnt, int &s_total, const int wg, const int ua, const int ub)
 {
     typedef WaCfg<NCW, D> C;
     constexpr int U = C::U, NL = C::NL;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ int s_cnt[4], s_total;
-    __shared__ unsigned s_ticket;
+    constexpr int NROLE = NL + 128 + NCW * 64;
     WfPair *s_pairs = reinterpret_cast<WfPair *>(lds);
     int *s_exp = reinterpret_cast<int *>(lds + 64 * sizeof(WfPair));
-    if (threadIdx.x == 0) {
-        // Which tile: the next ticket -- or (experiment, flags bit 0; only when every workgroup of the launch is resident at once) the
-        // next tile of THIS XCD's class (tile mod 8 = XCD).  The hardware starts the workgroups of one XCD in a row, so plain tickets
-        // put a whole line of 16 neighbouring tiles -- which work at the same time -- behind one XCD's L2 and fabric port; by class
-        // every band of the wavefront is spread over all eight.  Measured at 256^3: no difference (1.005 ms either way).
-        int tile = -1;
-        if (A.flags & 1) {
-            const int x = (int)(__builtin_amdgcn_s_getreg(0x1814) & 7u);
-            for (int i = 0; i < 8 && tile < 0; ++i) {
-                const int xx = (x + i) & 7;
-                const int c = atomicAdd(&A.ctrl[wa_xcd_word(xx)], 1);
-                if (c * 8 + xx < (int)gridDim.x) tile = c * 8 + xx;
-            }
-        } else {
-            tile = atomicAdd(&A.ctrl[0], 1);
-        }
-        s_ticket = (unsigned)tile;
-    }
-    __syncthreads();
-    const int wg = (int)s_ticket;
-    if (wg < 0) return;
     const int t = threadIdx.x;
     int tlo = 0x7fffffff, thi = -0x7fffffff;
 #pragma unroll
@@ -2290,15 +2158,18 @@ k_ilu0_wa(WfArgs A)
     tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
     if (thi <= tlo) return;
     tlo &= U == 8 ? ~7 : ~3;                                          // step % 4 (% 8) = position in the unrolled loops
-    for (int i = t; i < C::Lds / 8; i += C::Threads) reinterpret_cast<double *>(lds)[i] = 0.0;
+    if (RP) { tlo = ua; thi = min(thi, ub); }
+    // the hand-off arrays start all +0.0 (the windows are whatever they are: a lane reads its own rows or the cells of zeros behind
+    // them, which no DMA touches), the scratch at the ring's start is the set-up's
+    for (int i = (int)(C::X / 8) + t; i < (int)(C::Cnt / 8); i += NROLE) reinterpret_cast<double *>(lds)[i] = 0.0;
     if (t < 4) s_cnt[t] = 0;
-    __syncthreads();
+    wa_bar<C>(lds, NROLE / 64);
     if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; z.pw = -1; s_pairs[t] = z; }
     if (t < NL) s_exp[t] = -1;
     if (t < 4) *reinterpret_cast<double *>(lds + C::X + (unsigned)((t * C::RowL + NL) * 8)) = 1.0;
     // (a consumer wave has "done step tlo - 1" when it has read what its first step starts from)
-    if (t < 16) wa_set<C>(lds, t, t == WA_BIG ? 0x7fffffff : ((t == WA_DEAD || t == WA_WARM) ? 0 : (t < WA_LF ? tlo - 2 : tlo - 1)));
-    __syncthreads();
+    if (t < 14) wa_set<C>(lds, t, t == WA_BIG ? 0x7fffffff : ((t == WA_DEAD || t == WA_WARM) ? 0 : (t < WA_LF ? tlo - 2 : ((RP && (t == WA_TP || t == WA_EP)) ? 0x7ffffff0 : tlo - 1))));
+    wa_bar<C>(lds, NROLE / 64);
     if (t < NL) {
         const int slot = wg * kThreads + t;
         const int32_t *T = A.ltab + (size_t)slot * kStTab;
@@ -2382,7 +2253,7 @@ k_ilu0_wa(WfArgs A)
             for (int j = 0; j < 3; ++j) bal[j] = __builtin_amdgcn_ballot_w64(isg[j]);
             const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]);
             if ((t & 63) == 0) s_cnt[wv] = mine;
-            __syncthreads();
+            wa_bar<C>(lds, NROLE / 64);
             int before = 0;
             for (int q = 0; q < wv; ++q) before += s_cnt[q];
             if (t == 0) s_total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
@@ -2470,55 +2341,101 @@ k_ilu0_wa(WfArgs A)
             const int xe = A.xe[slot];
             if (cnt > 0 && xe >= 0 && xe < NL) s_exp[xe] = t;
         }
-        __syncthreads();
+        wa_bar<C>(lds, NROLE / 64);
         if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], 1);
-        __syncthreads();
+        wa_bar<C>(lds, NROLE / 64);
         for (int i = t; i < 64 * (int)sizeof(WfPair) / 8 + kThreads / 2; i += NL) reinterpret_cast<double *>(lds)[i] = 0.0;
-        __syncthreads();
+        wa_bar<C>(lds, NROLE / 64);
 #ifdef WX_STAMP
         const unsigned long long cy0_ = __builtin_amdgcn_s_memtime();
-        if (t == 0 && wg < 4096) g_wf_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
+        if (!RP && t == 0 && wg < 4096) g_wf_tl[wg * 4] = __builtin_amdgcn_s_memrealtime();
 #endif
-        wa_consumer<MODE, NCW, D>(A, lds, wg, W, tlo, thi);
-        if (MODE == 2) wa_helper<MODE, NCW, D, false>(A, lds, wg, tlo, thi, -1);
+        wa_consumer<MODE, NCW, D, RP>(A, lds, wg, W, tlo, thi);
 #ifdef WX_STAMP
-        if (t == 0 && wg < 4096) {
+        if (!RP && t == 0 && wg < 4096) {
             g_wf_tl[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime(); g_wf_wait[wg * 16 + 12] = __builtin_amdgcn_s_memtime() - cy0_;
             // where the workgroup ran: HW_ID (wave, SIMD, pipe, CU, SH, SE ...) and XCC_ID
             g_wf_wait[wg * 16 + 8] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0x1814) << 32);
         }
 #endif
     } else if (t < NL + 128) {
-        __syncthreads();
-        __syncthreads();
+        wa_bar<C>(lds, NROLE / 64);
+        wa_bar<C>(lds, NROLE / 64);
         const WfPair P = s_pairs[t & 63];
         const int E = __builtin_amdgcn_readfirstlane(A.xw[wg * 4]);
         const int elane = ((t & 63) < E) ? s_exp[t & 63] : -1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        __syncthreads();
+        wa_bar<C>(lds, NROLE / 64);
+        wa_bar<C>(lds, NROLE / 64);
         if (t < NL + 64) {
             const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
-            wa_poller<NCW, D>(A, idle, lds, P, tlo, thi, wg);
-        } else {
-            wa_exporter<NCW, D>(A, lds, P, tlo, thi, wg, elane);
+            wa_poller<NCW, D>(A, idle, lds, P, tlo, thi, wg, !RP);
+        } else if (!RP) {
+            wa_exporter<NCW, D>(A, lds, P, tlo, thi, wg, elane, true);
         }
-        if (MODE == 2) wa_helper<MODE, NCW, D, false>(A, lds, wg, tlo, thi, -1);
     } else if (t < NL + 128 + NCW * 64) {
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
+        wa_bar<C>(lds, NROLE / 64);
+        wa_bar<C>(lds, NROLE / 64);
+        wa_bar<C>(lds, NROLE / 64);
+        wa_bar<C>(lds, NROLE / 64);
         wa_loader<NCW, D>(A, lds, wg, (t - NL - 128) >> 6, tlo, thi);
-        if (MODE == 2) wa_helper<MODE, NCW, D, false>(A, lds, wg, tlo, thi, -1);
-    } else {
-        __syncthreads();
-        __syncthreads();
-        const int my_pw = s_pairs[t & 63].pw;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        __syncthreads();
-        wa_helper<MODE, NCW, D, true>(A, lds, wg, tlo, thi, my_pw);
+    }
+}
+
+template <int MODE, int NCW, int D>
+__global__ void __launch_bounds__((WaCfg<NCW, D>::Threads), (NCW == 2 ? 4 : 3))
+k_ilu0_wa(WfArgs A)
+{
+    typedef WaCfg<NCW, D> C;
+    constexpr int U = C::U, NL = C::NL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int s_cnt[4], s_total;
+    __shared__ unsigned s_ticket;
+    WfPair *s_pairs = reinterpret_cast<WfPair *>(lds);
+    int *s_exp = reinterpret_cast<int *>(lds + 64 * sizeof(WfPair));
+    if (threadIdx.x == 0) {
+        // Which tile: the next ticket -- or (experiment, flags bit 0; only when every workgroup of the launch is resident at once) the
+        // next tile of THIS XCD's class (tile mod 8 = XCD).  The hardware starts the workgroups of one XCD in a row, so plain tickets
+        // put a whole line of 16 neighbouring tiles -- which work at the same time -- behind one XCD's L2 and fabric port; by class
+        // every band of the wavefront is spread over all eight.  Measured at 256^3: no difference (1.005 ms either way).
+        int tile = -1;
+        if (A.flags & 1) {
+            const int x = (int)(__builtin_amdgcn_s_getreg(0x1814) & 7u);
+            for (int i = 0; i < 8 && tile < 0; ++i) {
+                const int xx = (x + i) & 7;
+                const int c = atomicAdd(&A.ctrl[wa_xcd_word(xx)], 1);
+                if (c * 8 + xx < (int)gridDim.x) tile = c * 8 + xx;
+            }
+        } else {
+            tile = atomicAdd(&A.ctrl[0], 1);
+        }
+        s_ticket = (unsigned)tile;
+    }
+    __syncthreads();
+    const int wg = (int)s_ticket;
+    if (wg < 0) return;
+    const int t = threadIdx.x;
+    // all of LDS +0.0 once (the cells of zeros behind every wave's windows stay that way)
+    for (int i = t; i < C::Lds / 8; i += C::Threads) reinterpret_cast<double *>(lds)[i] = 0.0;
+    __syncthreads();
+    constexpr int NROLE = NL + 128 + NCW * 64;
+    if (t >= NROLE) {
+        // the prefetcher: on its own from here
+        wa_helper<MODE, NCW, D, true>(A, lds, wg);
+        return;
+    }
+    wa_unit<MODE, NCW, D, false>(A, lds, s_cnt, s_total, wg, 0, 0);
+    if (MODE != 2 || !(A.flags & 2) || !A.prog) return;
+    // Replays: what the chains leave of the records, in units of kRpSteps steps of any tile that is far enough past them
+    wa_bar<C>(lds, NROLE / 64);
+    if (t == 0) wa_set<C>(lds, WA_CHAIN, 2);
+    for (;;) {
+        if (t < 64) wa_claim_unit<NCW, D>(A, lds, wg);
+        wa_bar<C>(lds, NROLE / 64);
+        const int um = wa_cnt<C>(lds, WA_UM), ua = wa_cnt<C>(lds, WA_UA), ub = wa_cnt<C>(lds, WA_UB);
+        if (um < 0) break;
+        wa_unit<MODE, NCW, D, true>(A, lds, s_cnt, s_total, um, ua, ub);
+        wa_bar<C>(lds, NROLE / 64);
     }
 }
 
@@ -2608,8 +2525,10 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
         else hipLaunchKernelGGL((k_ilu0_wa<0, 2, 3>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
     } else if (wa_on()) {
         typedef WaCfg<4, 4> C;
-        // (the records finished by idle waves -- MODE 2 -- where every workgroup is resident and the progress words exist)
-        static const bool nofin = getenv("ILUPP_NO_FINISHERS") != nullptr;
+        // (MODE 2 -- the chains store a quarter of the records, replays by the workgroups whose tile has ended write the rest -- is an
+        // experiment, ILUPP_REPLAY=1, where every workgroup is resident and the progress words exist: bit-identical, and slower at
+        // 256^3 -- 1.07 ms against 0.93: a replay unit's set-up and its 30 KB per step cost the idle CUs more time than they have)
+        static const bool nofin = getenv("ILUPP_REPLAY") == nullptr;
         if (wd_mode() == 1) hipLaunchKernelGGL((k_ilu0_wa<1, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
         else if ((a.flags & 2) && a.prog && !nofin) hipLaunchKernelGGL((k_ilu0_wa<2, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
         else hipLaunchKernelGGL((k_ilu0_wa<0, 4, 4>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
