@@ -190,9 +190,12 @@ def index_size():
     return lib().ilupp_hip_index_size()
 
 
+ILUPP_ERR_UNSUPPORTED = -8          # include/ilupp_hip.h
+
+
 def _raise(rc):
     msg = lib().ilupp_hip_last_error().decode()
-    if rc == -8:
+    if rc == ILUPP_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
     raise RuntimeError(msg)          # pybind11 maps std::exception -> RuntimeError
 
@@ -495,7 +498,7 @@ def MultilevelILUCDPPreconditioner_batch(matrices, is_csr, param):
             if out[k]:
                 lib().ilupp_hip_ml_destroy(out[k])
         msg = lib().ilupp_hip_last_error().decode() + " (matrix %d of the batch, status %d)" % (first, status[first] if first >= 0 else rc)
-        if rc == -8:
+        if rc == ILUPP_ERR_UNSUPPORTED:
             raise NotImplementedError(msg)
         raise RuntimeError(msg)
     return [MultilevelPreconditioner(_VP(out[k]), ns[k]) for k in range(cnt)]

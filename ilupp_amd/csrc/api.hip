@@ -821,15 +821,27 @@ int finish_apply(ilupp_precond *p)
     return ILUPP_OK;
 }
 
+// an object under construction: destroyed (its side stream synchronised, its pool blocks given back) when the construction unwinds --
+// a HIP error thrown from the middle of ilu0_factor leaves nothing behind
+struct ObjGuard {
+    ilupp_precond *p;
+    explicit ObjGuard(ilupp_precond *q) : p(q) {}
+    ~ObjGuard() { if (p) { if (p->side) (void)stream_sync(p->side); destroy_obj(p); } }
+    ilupp_precond *release() { ilupp_precond *q = p; p = nullptr; return q; }
+    ObjGuard(const ObjGuard &) = delete;
+    ObjGuard &operator=(const ObjGuard &) = delete;
+};
+
 int ilu0_create_common(const DevMat &A, int is_csr, const int32_t *head, ilupp_precond **out, ilupp_precond *made = nullptr)
 {
-    ilupp_precond *p = made ? made : new_obj(A.n);
+    ObjGuard g(made ? made : new_obj(A.n));
+    ilupp_precond *p = g.p;
     p->kind = KIND_LU;
     p->nnz_mode = NNZ_GENERIC_LU;
     p->input_csc = !is_csr;
-    int rc = ilu0_factor(p, A, head);
-    if (rc) { destroy_obj(p); return rc; }
-    *out = p;
+    const int rc = ilu0_factor(p, A, head);
+    if (rc) return rc;
+    *out = g.release();
     return ILUPP_OK;
 }
 
@@ -906,7 +918,7 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
     DevMat A;
     A.n = n; A.nnz = nnz32; A.is_csr = true; A.owns = false;
     A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
-    return ilu0_create_common(A, is_csr, head, out, p);
+    return ilu0_create_common(A, is_csr, head, out, p);           // (owns p from here: ObjGuard)
     API_CATCH
 }
 
@@ -925,12 +937,12 @@ int ilupp_hip_ilu0_create_device_nnz(const double *d_data, const int32_t *d_indi
             DevMat A;
             A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = false;
             A.ptr = const_cast<int32_t *>(d_indptr); A.idx = const_cast<int32_t *>(d_indices); A.val = const_cast<double *>(d_data);
-            ilupp_precond *p = new_obj(n);
+            ObjGuard g(new_obj(n));
+            ilupp_precond *p = g.p;
             p->kind = KIND_LU; p->nnz_mode = NNZ_GENERIC_LU; p->input_csc = !is_csr;
             p->no_general_retry = true;            // (a failed proof must not run the general pass with an nnz nobody has checked)
             const int rc = ilu0_factor(p, A, head);
-            if (rc == ILUPP_OK) { *out = p; return ILUPP_OK; }
-            destroy_obj(p);
+            if (rc == ILUPP_OK) { *out = g.release(); return ILUPP_OK; }
             if (rc != ILUPP_ERR_UNSUPPORTED) return rc;
         }
         API_CATCH
@@ -1504,7 +1516,7 @@ long long ilupp_hip_debug_static_table(ilupp_precond *p, int which, int32_t *out
             case 2: src = p->pkL.wtab; cnt = nwg * 16; break;
             case 3: src = p->pkU.wtab; cnt = nwg * 16; break;
             case 4: src = p->pkU.ysrc; cnt = ns; break;
-            case 5: src = p->flm.xbase ? p->flm.xbase + ns : nullptr; cnt = ns * 32; break;
+            case 5: src = (p->flm.xbase && p->flm.xbase_len >= (int64_t)ns * 33) ? p->flm.xbase + ns : nullptr; cnt = ns * 32; break;
             case 6: src = p->pkL.xe; cnt = ns; break;
             case 7: src = p->pkU.xe; cnt = ns; break;
             case 8: src = p->pkL.xw; cnt = nwg * 4; break;
@@ -1953,6 +1965,8 @@ int ilupp_hip_ml_create_batch(int32_t count, const double *const *data, const in
     }
     ChainBatch *cb = chain_batch_create(workers);
     if (!cb) { set_error("batched construction: no stream"); return ILUPP_ERR_HIP; }
+    // (the batch and its stream go when this call unwinds, whatever throws below)
+    struct BatchGuard { ChainBatch *b; ~BatchGuard() { if (b) chain_batch_destroy(b); } } cbg{cb};
     std::vector<int> rcs((size_t)count, ILUPP_OK);
     std::vector<std::string> msgs((size_t)count);
     std::atomic<int32_t> next(0);
@@ -2005,7 +2019,7 @@ int ilupp_hip_ml_create_batch(int32_t count, const double *const *data, const in
         }
         work(0);
     }
-    chain_batch_destroy(cb);
+    chain_batch_destroy(cbg.b); cbg.b = nullptr;
     int first = ILUPP_OK;
     for (int32_t i = 0; i < count; ++i) {
         if (status) status[i] = rcs[(size_t)i];

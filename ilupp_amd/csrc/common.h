@@ -183,7 +183,8 @@ struct FactorLM {
     bool built = false;
     bool values_packed = false;     // the factor records already hold the values of the matrix about to be factored
     void *pkA = nullptr;            // chunks x 5120 bytes: rows of A (diagonal-aligned), program header, decoded dependencies
-    int32_t *xbase = nullptr;       // nslots: first exchange row of a slot whose U rows other workgroups read, else -1
+    int32_t *xbase = nullptr;       // nslots: first exchange row of a slot whose U rows other workgroups read, else -1 (+ the rows pass' records behind it)
+    int64_t xbase_len = 0;          // ints of that allocation
     double *xch = nullptr;          // exchange rows x 4 doubles (write-through, sentinel = not yet)
     long long *xcount = nullptr;    // device: doubles of xch in use
     bool stat = false;              // static form (st.hip): pkA holds 4 KB chunks {a0..a6, mask}

@@ -46,7 +46,7 @@ void FactorLM::release()
     if (xbase) (void)pool_free(xbase);
     if (xch) (void)pool_free(xch);
     if (xcount) (void)pool_free(xcount);
-    pkA = nullptr; xbase = nullptr; xch = nullptr; xcount = nullptr; built = false; values_packed = false; stat = false; direct = false; wxf = false; spec = false;
+    pkA = nullptr; xbase = nullptr; xbase_len = 0; xch = nullptr; xcount = nullptr; built = false; values_packed = false; stat = false; direct = false; wxf = false; spec = false;
 }
 
 // the wave-exchange kernels and the skews they need (st_common.h); ILUPP_NO_WR=1: the schedules and kernels of round 3
@@ -1626,6 +1626,7 @@ bool st_analyse_ilu0(hipStream_t st, const DevMat &A, const Schedule &fwd, const
         hipLaunchKernelGGL(k_st_inv_ysrc, dim3(gb), dim3(256), 0, st, nslots, pu->uslot, inv, fwd.scount, pl->wtab, pl->skew, pu->ysrc);
     }
     ILUPP_HIP(pool_malloc(&f->xbase, sizeof(int32_t) * (size_t)nslots * 33));
+    f->xbase_len = (int64_t)nslots * 33;
     if (!scat_by_grid) {
         hipLaunchKernelGGL(k_st_scat, dim3(gb), dim3(256), 0, st, nslots, pl->ltab, pu->ltab, pu->uslot, inv, pl->wtab, pu->wtab,
                            f->xbase + nslots, pl->flags, A.ptr, try_direct ? pl->flags + 8 : static_cast<int32_t *>(nullptr));

@@ -748,6 +748,7 @@ struct WfArgs {
     unsigned char *pkL, *pkU;                     // format-1 records, both in the forward schedule's order
     const int32_t *xe, *xw;
     double *xch;
+    int64_t xch_len;                              // doubles of the exchange: a workgroup's export window never reaches past it
     int32_t *ctrl;                                // [0] ticket, [1] error; k_ilu0_wa: [2], [3], [9] .. [14] tickets by XCD
     int32_t flags;                                // k_ilu0_wa: 2 = every workgroup of the launch is resident at once; 1 = ... and tiles are handed out by XCD
     int32_t *prog;                                // k_ilu0_wa: [tile] steps done, [nwg + tile] blocks of eight steps somebody has asked for, [2 nwg + tile] blocks somebody finishes (or null)
@@ -952,7 +953,11 @@ __device__ __forceinline__ void wf_courier(const WfArgs &A, const unsigned long 
     const int xrow0 = A.xw[wg * 4 + 3] + (tlo - A.xw[wg * 4 + 1]) * E;
     const int elane = (ln < E) ? s_exp[ln] : -1;
     const unsigned ea = kWfX + (unsigned)((kWfH * kWfRow + (elane >= 0 ? elane : kWfCell)) * 8);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + xrow0, 0, (int)((unsigned)(thi - tlo) * (unsigned)E * 8u), 0x00020000);
+    // (the window is clamped to the allocation: sizes predicted from a box grid's dimensions are only compared with what the device
+    // found after this kernel has run)
+    const long long xroom = (long long)A.xch_len - (long long)xrow0;
+    const long long xwant = (long long)(thi - tlo) * (long long)E;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + (xroom > 0 ? xrow0 : 0), 0, (int)(8 * (xroom > 0 ? (xwant < xroom ? xwant : xroom) : 0)), 0x00020000);
     unsigned vx = elane >= 0 ? (unsigned)ln * 8u : 0xfffffff0u;
     const unsigned dvx = elane >= 0 ? (unsigned)E * 8u : 0u;
     if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 1);                 // (the analysis does not let such a schedule through)
@@ -1787,7 +1792,10 @@ __device__ __forceinline__ void wa_exporter(const WfArgs &A, unsigned char *lds,
     const int xrow0 = A.xw[wg * 4 + 3] + (tlo - A.xw[wg * 4 + 1]) * E;
     const unsigned ea = C::X + (unsigned)((elane >= 0 ? elane : C::NL) * 8);
     const int thiR = tlo + (thi - tlo + U - 1) / U * U;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + xrow0, 0, (int)((unsigned)(thi - tlo) * (unsigned)E * 8u), 0x00020000);
+    // (clamped to the allocation, as wf_courier's)
+    const long long xroom = (long long)A.xch_len - (long long)xrow0;
+    const long long xwant = (long long)(thi - tlo) * (long long)E;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + (xroom > 0 ? xrow0 : 0), 0, (int)(8 * (xroom > 0 ? (xwant < xroom ? xwant : xroom) : 0)), 0x00020000);
     unsigned vx = elane >= 0 ? (unsigned)ln * 8u : 0xfffffff0u;
     const unsigned dvx = elane >= 0 ? (unsigned)E * 8u : 0u;
     if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 1);                 // (the analysis does not let such a schedule through)
@@ -2482,7 +2490,7 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     a.val_shift = (int32_t)(vp & 15);
     a.val_bytes = (uint32_t)(A.nnz * 8 + a.val_shift);
     a.pkL = reinterpret_cast<unsigned char *>(pl->pk); a.pkU = reinterpret_cast<unsigned char *>(pu->pk);
-    a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.ctrl = d_ctrl;
+    a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.xch_len = pl->xch_len; a.ctrl = d_ctrl;
     a.flags = 0;
     a.prog = nullptr;
     if (wa_on() && getenv("ILUPP_NO_PREFETCH") == nullptr) {

@@ -80,7 +80,9 @@ int ilupp_hip_ilu0_create_device(const double *d_data, const int32_t *d_indices,
 /* ... for a caller that KNOWS the number of stored entries (the length of the arrays it holds -- what the reference reads as pointer[last],
  * sparse_implementation.h:3076-3089): nothing is read back before the construction starts when a matrix of this (n, nnz) was a box grid
  * before in this process (the dimensions are guessed again, grid.hip; the proof on the device covers indptr[n] == nnz and every row, and a
- * failed proof, or an (n, nnz) not seen before, takes the reading way of ilupp_hip_ilu0_create_device).  A wrong nnz is an error. */
+ * failed proof, or an (n, nnz) not seen before, takes the reading way of ilupp_hip_ilu0_create_device).  A wrong nnz is an error;
+ * d_indices and d_data MUST hold at least nnz entries (the proof and the factor kernel address them with nnz as their bound before
+ * indptr[n] has been compared with it). */
 int ilupp_hip_ilu0_create_device_nnz(const double *d_data, const int32_t *d_indices, const int32_t *d_indptr,
                                      int32_t n, int64_t nnz, int is_csr, ilupp_precond **out);
 
@@ -328,7 +330,7 @@ typedef struct {
     float usolve_kernel_ms;   /* backward-solve kernel of the last apply */
 } ilupp_timings;
 int ilupp_hip_get_timings(const ilupp_precond *p, ilupp_timings *t);
-/* which kernel family built this object ("ilu0:static-direct", "ilu0:static-level-major", "ilu0:level-major", "ilu0:level-order",
+/* which kernel family built this object ("ilu0:static-direct", "ilu0:static-level-major", "ilu0:level-order",
  * "ilu0:csr-program", "ilu0:csr", "ilut", "ichol0", "icholt"): bench.py names the kernel its roofline line is about */
 const char *ilupp_hip_path(const ilupp_precond *p);
 /* how the row blocks of an ILU(0) object were found: "grid" (the pattern is a lexicographic box-grid stencil: guessed from row 0, proven

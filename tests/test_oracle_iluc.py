@@ -58,54 +58,6 @@ def test_edges():
     check(z, "edge_ties", (d, i, p, True), ((2, 0.0), (3, 0.0), (4, 0.0)))
 
 
-def _drop(v, max_entries, threshold):
-    """the dropping rule as the reference's tests state it (test/tests.py:58-65): relative to the 2-norm, then the largest"""
-    v = v.copy()
-    v[np.abs(v) < threshold * np.linalg.norm(v)] = 0.0
-    nz = np.flatnonzero(v)
-    if len(nz) > max_entries:
-        keep = nz[np.argsort(-np.abs(v[nz]), kind="stable")[:max_entries]]
-        w = np.zeros_like(v); w[keep] = v[keep]; v = w
-    return v
-
-
-def _iluc_dense(A, fill_in, threshold):
-    A = A.toarray()
-    n = A.shape[0]
-    L, U = np.zeros_like(A), np.zeros_like(A)
-    for k in range(n):
-        z = A[k, :].copy(); z[:k] = 0
-        for i in range(k):
-            if L[k, i] != 0:
-                z[k:] -= L[k, i] * U[i, k:]
-        w = A[:, k].copy(); w[:k + 1] = 0
-        for i in range(k):
-            if U[i, k] != 0:
-                w[k + 1:] -= U[i, k] * L[k + 1:, i]
-        z[k + 1:] = _drop(z[k + 1:], fill_in - 1, threshold)
-        w[k + 1:] = _drop(w[k + 1:], fill_in - 1, threshold)
-        U[k, :] = z
-        L[:, k] = w / U[k, k]
-        L[k, k] = 1
-    return L, U
-
-
-@pytest.mark.parametrize("fmt", ["csr", "csc"])
-def test_against_the_dense_statement_of_the_algorithm(fmt):
-    """no ties in these matrices, so the dense statement (any order of accumulation) and the sparse one agree to rounding"""
-    for (d, i, p) in (matgen.random_dd(60, k=7, diag=4.0), matgen.random_dd(120, k=5, diag=2.5, seed=5)):
-        n = p.shape[0] - 1
-        A = sp.csr_matrix((d, i, p), shape=(n, n))
-        M = A if fmt == "csr" else A.tocsc()
-        L, U = O.orc().iluc((M.data, M.indices, M.indptr, fmt == "csr"), 5, 0.1)
-        Ld, Ud = _iluc_dense(A if fmt == "csr" else A.T.tocsr(), 5, 0.1)
-        if fmt == "csc":
-            Ld, Ud = Ud.T, Ld.T
-        Ls = (sp.csr_matrix if L[3] else sp.csc_matrix)((L[0], L[1], L[2]), shape=(n, n)).toarray()
-        Us = (sp.csr_matrix if U[3] else sp.csc_matrix)((U[0], U[1], U[2]), shape=(n, n)).toarray()
-        assert np.allclose(Ls, Ld, rtol=1e-12, atol=0) and np.allclose(Us, Ud, rtol=1e-12, atol=0)
-
-
 def test_restatement_vs_reference_live():
     if not O.ref_available():
         pytest.skip("oracle/_ref not built (no reference in this environment)")
