@@ -56,6 +56,21 @@ def algorithmic_bytes(n, nnz):
     return factor, apply_
 
 
+def _same_kernel(profiled, wanted):
+    """a profiler's name of a kernel ('ilupp::k_sptrsv_wv<1, false, false>': namespace, defaulted template arguments spelled out)
+    against the library's ('k_sptrsv_wv<1, false>')"""
+    a = profiled.replace("ilupp::", "").replace("void ", "").split("(")[0].strip()
+    if a == wanted:
+        return True
+    if "<" not in a or "<" not in wanted:
+        return False
+    an, aa = a.split("<", 1)
+    wn, wa = wanted.split("<", 1)
+    aa = [x.strip() for x in aa.rstrip(">").split(",")]
+    wa = [x.strip() for x in wa.rstrip(">").split(",")]
+    return an == wn and aa[:len(wa)] == wa and all(x in ("false", "0") for x in aa[len(wa):])
+
+
 def measured_traffic(kernel, g):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*_pmc_hbm.json, collected with
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs of this same command).  gfx950
@@ -68,7 +83,7 @@ def measured_traffic(kernel, g):
         try:
             ks = json.load(open(f))["kernels"]
             for name, k in ks.items():
-                if name.replace("ilupp::", "").replace("void ", "") == kernel:
+                if _same_kernel(name, kernel):
                     TRAFFIC_SOURCE.add(os.path.relpath(f, ROOT))
                     return (2.0 * k["FETCH_SIZE_KiB_avg_per_launch"] + k["WRITE_SIZE_KiB_avg_per_launch"]) * 1024.0
         except Exception:

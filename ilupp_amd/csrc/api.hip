@@ -1558,9 +1558,13 @@ const char *ilupp_hip_kernel_names(const ilupp_precond *p)
         return names.c_str();
     }
     if (!p || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU && p->flm.built && p->flm.stat)) return "";
-    if (p->pkL.fmt == 1 && wx_vec_on() && p->pkL.vec_ok && p->pkU.vec_ok)
-        return p->flm.wxf ? "k_ilu0_wx;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>" : "k_ilu0_sd;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>";
-    if (p->pkL.fmt == 1) return p->flm.wxf ? "k_ilu0_wx;k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>" : "k_ilu0_sd;k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>";
+    static thread_local std::string lu_names;
+    if (p->pkL.fmt == 1) {
+        const bool vec = wx_vec_on() && p->pkL.vec_ok && p->pkU.vec_ok;
+        lu_names = std::string(p->flm.wxf ? wx_factor_kernel_name() : "k_ilu0_sd") +
+                   (vec ? ";k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>" : ";k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>");
+        return lu_names.c_str();
+    }
     return p->flm.direct ? "k_ilu0_sd;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>" : "k_ilu0_st;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>";
 }
 

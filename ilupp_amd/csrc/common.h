@@ -312,6 +312,7 @@ int ilu0_symbolic_and_schedule(hipStream_t st, const DevMat &A, DevMat *L, DevMa
                                int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
 void ilu0_write_patterns(hipStream_t st, const DevMat &A, DevMat *L, DevMat *U);
 void finish_chains(Schedule *fwd, Schedule *bwd);
+const char *wx_factor_kernel_name();     // st_wave.hip: the factor kernel ilu0_numeric_wx launches, as a profiler names it
 bool wx_vec_on();            // st_wave.hip: the sweeps move the caller's vector through their vector wave (no level-major copies, no k_st_vec)
 // grid.hip: the first analysis pass for lexicographic box-grid stencil matrices (guess from row 0, proof on a side stream)
 struct GridDims { int32_t nx, ny, nz; };

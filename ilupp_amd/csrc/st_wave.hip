@@ -1368,9 +1368,10 @@ __device__ __forceinline__ void wd_addr4(unsigned a[4], const unsigned base, con
 
 // NCW consumer waves (4: a 16 x 16 patch of lines, one workgroup per CU), D ring blocks of two steps per lane (4).  The loops are
 // unrolled over U steps, a multiple of the ring (2 D steps) and of the hand-off arrays and the import ring (4 steps).
-// (NCW = 2, D = 3 is an experiment -- ILUPP_WA_HALF=1 on schedules of 16 x 8 patches, ILUPP_NO_GRID=1 ILUPP_TILE_TZ=8: two workgroups
-// per CU, to spread the tiles at work over more CUs.  Measured at 256^3: 1.2 ms against 1.0 -- two tiles that work at the same time
-// on one CU share what it can have in flight, and a path through the launch has 46 hand-overs instead of 30.)
+// (NCW = 2, D = 3 -- half the lanes per workgroup, two workgroups per CU, on schedules of 16 x 8 patches, to spread the tiles at work
+// over more CUs -- was built, ran bit-exact on 3-D grids and was measured at 256^3: 1.2 ms against 1.0.  Two tiles that work at the
+// same time on one CU share what it can have in flight, and a path through the launch has 46 hand-overs instead of 30.  The
+// launch path for it is gone; the configuration stays a template parameter.)
 template <int NCW, int D>
 struct WaCfg {
     static constexpr int NL = NCW * 64;                        // lanes
@@ -2457,10 +2458,12 @@ bool wa_on()
     static const bool on = getenv("ILUPP_NO_WA") == nullptr;
     return on;
 }
-static bool wa_half()
+// the factor kernel ilu0_numeric_wx launches, as a profiler names it (ilupp_hip_kernel_names)
+const char *wx_factor_kernel_name()
 {
-    static const bool on = getenv("ILUPP_WA_HALF") != nullptr;
-    return on;
+    if (!wa_on()) return "k_ilu0_wx";
+    if (wd_mode() == 1) return "k_ilu0_wa<1, 4, 4>";
+    return getenv("ILUPP_REPLAY") != nullptr ? "k_ilu0_wa<2, 4, 4>" : "k_ilu0_wa<0, 4, 4>";
 }
 
 int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,
@@ -2473,12 +2476,9 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
         std::call_once(once[dev & 63], [] {
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLds));
             typedef WaCfg<4, 4> C44;
-            typedef WaCfg<2, 3> C23;
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<0, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<0, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C23::Lds));
-            ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C23::Lds));
         });
     }
     ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
@@ -2516,7 +2516,7 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
         int dev = 0;
         ILUPP_HIP(hipGetDevice(&dev));
         if (ncu[dev & 63] == 0) { int v = 0; ILUPP_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev)); ncu[dev & 63] = v > 0 ? v : -1; }
-        if (ncu[dev & 63] > 0 && (int64_t)pl->nwg <= (int64_t)ncu[dev & 63] * (wa_half() ? 2 : 1)) {
+        if (ncu[dev & 63] > 0 && (int64_t)pl->nwg <= (int64_t)ncu[dev & 63]) {
             a.flags |= 2;
             if (getenv("ILUPP_XCD_TICKETS") != nullptr) {
                 a.flags |= 1;
@@ -2526,12 +2526,7 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     }
     if (pl->join_ev && pl->join_before) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));       // (grid.hip's proof, on its side stream)
     ILUPP_HIP(hipEventRecord(e0, st));
-    if (wa_on() && wa_half()) {
-        // (experiment, ILUPP_WA_HALF=1 with schedules of 16 x 8 patches -- ILUPP_NO_GRID=1 ILUPP_TILE_TZ=8: two workgroups per CU)
-        typedef WaCfg<2, 3> C;
-        if (wd_mode() == 1) hipLaunchKernelGGL((k_ilu0_wa<1, 2, 3>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
-        else hipLaunchKernelGGL((k_ilu0_wa<0, 2, 3>), dim3((unsigned)pl->nwg), dim3(C::Threads), C::Lds, st, a);
-    } else if (wa_on()) {
+    if (wa_on()) {
         typedef WaCfg<4, 4> C;
         // (MODE 2 -- the chains store a quarter of the records, replays by the workgroups whose tile has ended write the rest -- is an
         // experiment, ILUPP_REPLAY=1, where every workgroup is resident and the progress words exist: bit-identical, and slower at

@@ -476,9 +476,9 @@ def test_bench_single_gpu_line():
     assert r.returncode == 0 and line, r.stdout + r.stderr
     out = json.loads(line[-1])
     assert out["n_gpus"] == 1 and out["parity"]["apply_ones_equal"] is True
-    assert out["roofline"]["kernel"] in ("k_ilu0_wx", "k_ilu0_sd") and out["roofline"]["frac"] > 0 and out["roofline"]["step_frac"] > 0
+    assert out["roofline"]["kernel"] in ("k_ilu0_wa<0, 4, 4>", "k_ilu0_wx", "k_ilu0_sd") and out["roofline"]["frac"] > 0 and out["roofline"]["step_frac"] > 0
     assert out["headline_fraction"] == out["roofline"]["step_frac"] == out["hbm_fraction_factor_plus_apply"]
-    assert [ph["name"] for ph in out["roofline"]["phases"]][0] in ("k_ilu0_wx", "k_ilu0_sd")
+    assert [ph["name"] for ph in out["roofline"]["phases"]][0] in ("k_ilu0_wa<0, 4, 4>", "k_ilu0_wx", "k_ilu0_sd")
     assert out["cpu_baseline"]["kind"] in ("reference", "port") and out["cpu_baseline"]["apply_paths_agree"]
 
 
