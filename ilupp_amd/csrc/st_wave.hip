@@ -1388,14 +1388,15 @@ struct WaCfg {
     static constexpr unsigned TB = XI + (unsigned)R * 64u * 8u;
     static constexpr unsigned TC = TB + 4u * RowX * 8u;
     static constexpr unsigned Cnt = TC + 4u * RowL * 8u;
-    static constexpr int Lds = (int)Cnt + 128;
+    static constexpr int Lds = (int)Cnt + 256;
     static constexpr int Threads = NL + 128 + NCW * 64 + 64;   // consumers, poller, exporter, loaders, prefetcher
     static_assert(U % (2 * D) == 0 && U % 4 == 0 && U % NP == 0, "slots are immediates of the unrolled loops");
     static_assert(NCW == 4 && D == 4, "the line ring: four slots of 8 KB per wave, 32 KB per wave");
     static_assert(Lds * (4 / NCW) <= 160 * 1024 - 256 * (4 / NCW), "the LDS of a CU");
 };
 enum { WA_CP = 0, WA_LF = 4, WA_IP = 8, WA_TP = 9, WA_EP = 10, WA_DEAD = 11, WA_BIG = 12, WA_WARM = 13,          // (set anew for every unit)
-       WA_CHAIN = 14, WA_UM = 16, WA_UA = 17, WA_UB = 18, WA_BARC = 20, WA_BARG = 21 };
+       WA_CHAIN = 14, WA_UM = 16, WA_UA = 17, WA_UB = 18, WA_BARC = 20, WA_BARG = 21,
+       WA_LH = 32 };                                              // lfull of quarters 1 .. 3 of a wave's lanes: WA_LH + 4 (h - 1) + wave (quarter 0: WA_LF + wave)
 static constexpr unsigned kWaSpinLimit = 1u << 24;
 
 // (LDS words other waves write: ordered with compiler barriers -- `volatile` would turn them into flat, system-scope accesses)
@@ -1896,140 +1897,198 @@ __device__ __forceinline__ void wa_loader(const WfArgs &A, unsigned char *lds, c
         on[q] = grp[q].x != WA_K_GATHER;
         g[q] = grp[q].x == WA_K_DMA ? ((unsigned)grp[q].y & ~127u) + 16u * (unsigned)(pp ^ gi ^ (q & 1)) : 0xffffff00u;
     }
-    // this thread's own lane (the gather)
+    // the gathered lanes: the first `ns` places of the wave (they sort first).  Their lines are put together by ALL the wave's threads:
+    // entry i (of 16) of the line of place L is thread (L, i)'s of instruction L / 4 -- four full instructions per quarter of places
+    // (an instruction costs what it costs whether 16 or 64 of its threads load).
     const bool slow = own.x == WA_K_GATHER;
-    const bool anyslow = __builtin_amdgcn_ballot_w64(slow) != 0;
-    unsigned rowaddr = (unsigned)own.y;
-    const unsigned m8own = (unsigned)own.z, srcpk = (unsigned)own.w;
-    int vp = 0;
-    const unsigned wbase = (unsigned)(lw * C::WaveRing + ln * 128), xsown = (unsigned)(((ln & 7) ^ ((ln >> 3) & 1)) << 4);
-    int fmin, fmax;
+    const int ns = __popcll(__builtin_amdgcn_ballot_w64(slow));
+    // the quarter h of the wave's places (16 lanes in the order of their rows' offsets, instructions 2 h and 2 h + 1): where its rows
+    // begin (fmn[h] .. fmx[h]), its instructions, whether it gathers
+    int fmn[4], fmx[4], nd[4];
+    bool gq[4];
     {
         const int f = own.x == WA_K_DMA ? (int)(((unsigned)own.y & 127u) >> 3) : 0;
         int lo = own.x == WA_K_EMPTY ? 15 : f, hi = own.x == WA_K_EMPTY ? 0 : f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-        fmin = __builtin_amdgcn_readfirstlane(min(lo, hi)); fmax = __builtin_amdgcn_readfirstlane(hi);
-    }
-    // DMA instructions per round: a group of eight lanes that are all gathered has none (its threads are masked out, the instruction
-    // is skipped) -- the counted waits below are in instructions
-    int ndma = 0;
+        for (int o = 8; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        lo = min(lo, hi);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ndma += __builtin_amdgcn_ballot_w64(on[q]) != 0 ? 1 : 0;
-    ndma = __builtin_amdgcn_readfirstlane(ndma);
-    // everything but this round's DMA instructions has arrived (the round before; this round's gathered entries)
-#define WAL_WAIT_PREV()                                                                                              \
-    do {                                                                                                             \
-        switch (ndma) {                                                                                              \
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;                                              \
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;                                              \
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                                              \
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;                                              \
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                              \
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;                                              \
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;                                              \
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;                                              \
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                                             \
-        }                                                                                                            \
-    } while (0)
+        for (int h = 0; h < 4; ++h) {
+            fmn[h] = __builtin_amdgcn_readlane(lo, 16 * h); fmx[h] = __builtin_amdgcn_readlane(hi, 16 * h);
+            nd[h] = (__builtin_amdgcn_ballot_w64(on[2 * h]) != 0 ? 1 : 0) + (__builtin_amdgcn_ballot_w64(on[2 * h + 1]) != 0 ? 1 : 0);
+            gq[h] = ns > 16 * h;
+        }
+    }
     typedef __attribute__((address_space(3))) void lds_void;
     typedef unsigned int v2w_ __attribute__((ext_vector_type(2)));
     v2w_ sv[16];
-#define WAL_GATHER_LOAD()                                                                                            \
+#define WAL_VM(n_)                                                                                                   \
     do {                                                                                                             \
-        if (slow) {                                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                         \
-                const unsigned j_ = (srcpk >> (4 * vp)) & 15u;                                                       \
-                sv[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, j_ == 15u ? 0xfffffff0u : rowaddr + 8u * j_, 0, 0); \
-                if (++vp == M) { vp = 0; rowaddr += m8own; }                                                         \
-            }                                                                                                        \
+        switch (n_) {                                                                                                \
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;                                        \
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;                                        \
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;                                        \
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;                                        \
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;                                        \
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;                                        \
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;                                        \
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;                                        \
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;                                        \
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;                                        \
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;                                        \
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;                                        \
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;                                        \
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;                                        \
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;                                        \
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;                                          \
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;                                          \
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;                                          \
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                                          \
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;                                          \
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                          \
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;                                          \
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;                                          \
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;                                          \
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                                             \
         }                                                                                                            \
     } while (0)
-#define WAL_GATHER_STORE(r_)                                                                                         \
+#define WAL_GATHER_LOAD(h_, r_)                                                                                      \
     do {                                                                                                             \
-        if (slow) {                                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                           \
-                *reinterpret_cast<v2w_ *>(lds + (wbase + (unsigned)((r_) & 3) * kWaSlot + ((8u * (unsigned)i) ^ xsown))) = sv[i]; \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                           \
+            const int L_ = 16 * (h_) + 4 * kk + (ln >> 4);                                                           \
+            const unsigned a0_ = (unsigned)__shfl(own.y, L_), m8_ = (unsigned)__shfl(own.z, L_), pk_ = (unsigned)__shfl(own.w, L_); \
+            const int E_ = 16 * (r_) + (ln & 15);                                                                    \
+            const int n_ = wa_div(E_, rm), vp_ = E_ - n_ * M;                                                        \
+            const unsigned j_ = (pk_ >> (4 * vp_)) & 15u;                                                            \
+            sv[4 * (h_) + kk] = __builtin_amdgcn_raw_buffer_load_b64(rs, (L_ < ns && j_ != 15u) ? a0_ + m8_ * (unsigned)n_ + 8u * j_ : 0xfffffff0u, 0, 0); \
+        }                                                                                                            \
+    } while (0)
+#define WAL_GATHER_STORE(h_, r_)                                                                                     \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                           \
+            const int L_ = 16 * (h_) + 4 * kk + (ln >> 4);                                                           \
+            const unsigned xs_ = (unsigned)(((L_ & 7) ^ ((L_ >> 3) & 1)) << 4);                                      \
+            if (L_ < ns)                                                                                             \
+                *reinterpret_cast<v2w_ *>(lds + ((unsigned)(lw * C::WaveRing + L_ * 128) + (unsigned)((r_) & 3) * kWaSlot + ((8u * (unsigned)(ln & 15)) ^ xs_))) = sv[4 * (h_) + kk]; \
         }                                                                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
     } while (0)
-#define WAL_ISSUE(r_)                                                                                                \
+#define WAL_ISSUE(h_, r_)                                                                                            \
     do {                                                                                                             \
         unsigned char *dst_ = lds + lw * C::WaveRing + ((r_) & 3) * kWaSlot;                                         \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                              \
+        _Pragma("unroll") for (int q = 2 * (h_); q < 2 * (h_) + 2; ++q) {                                            \
             if (on[q]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst_ + q * 1024), 16, g[q], 0, 0, WA_DMA_AUX); \
             g[q] += grp[q].x == WA_K_DMA ? 128u : 0u;                                                                \
         }                                                                                                            \
         asm volatile("" ::: "memory");                                                                               \
     } while (0)
-    // rows there after round r_ has landed; the step the consumers must have finished before round r_ is issued
-#define WAL_FULL(r_) (tlo + wa_div(16 * ((r_) + 1) - fmax - M, rm))
-// (not before they have read the row they begin with: their counter starts at tlo - 2 without having read anything)
-#define WAL_GATE(r_) max(tlo - 1, tlo + wa_div(16 * ((r_) - 4) + 15 - fmin, rm) - 1)
-    // rounds 0 .. 3 fill the ring (rounds 0 and 1 hold the rows of steps tlo and tlo + 1, what the consumers begin with)
+    // rows of quarter h_ there once its lines up to r_ have landed; the step the consumers must have finished before its line r_ is
+    // asked for (line r_ - 4 read to its end -- and not before they have read the row they begin with: their counter starts at
+    // tlo - 2 without their having read anything)
+#define WAL_FULL(h_, r_) (tlo + wa_div(16 * ((r_) + 1) - fmx[h_] - M, rm))
+#define WAL_GATE(h_, r_) max(tlo - 1, tlo + wa_div(16 * ((r_) - 4) + 15 - fmn[h_], rm) - 1)
+#define WAL_PUBLISH(h_, v_) do { if (ln == 0) wa_set<C>(lds, (h_) == 0 ? WA_LF + lw : WA_LH + 4 * ((h_) - 1) + lw, (v_)); } while (0)
+    // lines 0 .. 3 fill the ring
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
-        if (anyslow) WAL_GATHER_LOAD();
-        WAL_ISSUE(r);
-        if (anyslow) { WAL_WAIT_PREV(); WAL_GATHER_STORE(r); }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (gq[h]) WAL_GATHER_LOAD(h, r);
+            WAL_ISSUE(h, r);
+            if (gq[h]) { WAL_VM(nd[h]); WAL_GATHER_STORE(h, r); }
+        }
     }
-    WAL_WAIT_PREV();
-    if (ln == 0) wa_set<C>(lds, WA_LF + lw, WAL_FULL(2));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 4; ++h) WAL_PUBLISH(h, WAL_FULL(h, 3));
+    // (a gathered lane's entries of the NEXT line wait in its thread's registers: asked for when the line before was put into the ring)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) if (gq[h]) WAL_GATHER_LOAD(h, 4);
     const int thiR = tlo + (thi - tlo + U - 1) / U * U;
     bool dead = false;
 #ifdef WX_STAMP
     unsigned long long iacc_ = 0, vacc_ = 0, sacc_ = 0;
 #endif
     // (the consumers ask for the rows up to thiR)
+    // The quarters are in the order of their rows' offsets, so they need line r in the order 3, 2, 1, 0 and quarter 3 needs line r + 1
+    // after quarter 0 line r: one sequence of gates.  Behind the instructions of (quarter h, line r) everything but the last four
+    // quarters' instructions has arrived: (h, r - 1) is there.  When the next gate is still closed, the wave waits for all it has
+    // asked for and says so at once (a line is needed less than a step after the one behind it may be asked for).
+    // (vector-memory instructions of a quarter per line: its DMA instructions, and the four loads of its gathered lanes' entries)
+    int vq[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) vq[h] = nd[h] + (gq[h] ? 4 : 0);
+    const int ndtot = vq[0] + vq[1] + vq[2] + vq[3];
 #pragma unroll 1
-    for (int r = 4; WAL_FULL(r - 2) < thiR + 1; ++r) {
-        const int need = WAL_GATE(r);
+    for (int r = 4;; ++r) {
+        bool act[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) act[h] = WAL_FULL(h, r - 1) < thiR;
+        if (!(act[0] || act[1] || act[2] || act[3])) break;
+        const bool allfour = act[0] && act[1] && act[2] && act[3];
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const int h = 3 - hh;
+            if (!act[h]) continue;
+            const int need = WAL_GATE(h, r);
 #ifdef WX_STAMP
-        const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
+            const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
 #endif
-        if (!dead && wa_cnt<C>(lds, WA_CP + lw) < need) {
-            // nothing to issue yet: the round before is said to be there as soon as it is (not only behind the next round's
-            // instructions -- its rows are needed less than a step after that round may be issued)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (ln == 0) wa_set<C>(lds, WA_LF + lw, WAL_FULL(r - 1));
-            unsigned spins = 0;
-            while (wa_cnt<C>(lds, WA_CP + lw) < need) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0) {
-                    if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 6); wa_set<C>(lds, WA_DEAD, 1); }
-                    if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
+            if (!dead && wa_cnt<C>(lds, WA_CP + lw) < need) {
+                // nothing to ask for yet: first what is behind the quarter asked for last (it has had a quarter's time to arrive), then --
+                // if the gate is still closed -- that one too (the consumers may be waiting for exactly it)
+                const int hl = (h + 1) & 3;                              // (the quarter before this one in the sequence; it was active if all four are)
+                if (allfour) {
+                    WAL_VM(vq[hl]);
+#pragma unroll
+                    for (int h2 = 0; h2 < 4; ++h2) if (h2 != hl) WAL_PUBLISH(h2, WAL_FULL(h2, h2 > h ? r : r - 1));
+                }
+                if (!allfour || wa_cnt<C>(lds, WA_CP + lw) < need) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int h2 = 0; h2 < 4; ++h2) WAL_PUBLISH(h2, WAL_FULL(h2, (h2 > h && act[h2]) ? r : r - 1));
+                }
+                unsigned spins = 0;
+                while (wa_cnt<C>(lds, WA_CP + lw) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0) {
+                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 6); wa_set<C>(lds, WA_DEAD, 1); }
+                        if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
+                    }
                 }
             }
+#ifdef WX_STAMP
+            const unsigned long long i0_ = __builtin_amdgcn_s_memtime();
+            sacc_ += i0_ - s0_;
+#endif
+            // (the gathered entries of this line were asked for a line ago: behind them, the other three quarters' instructions)
+            if (gq[h]) { WAL_VM(ndtot - vq[h]); WAL_GATHER_STORE(h, r); }
+            WAL_ISSUE(h, r);
+            if (gq[h]) WAL_GATHER_LOAD(h, r + 1);
+#ifdef WX_STAMP
+            const unsigned long long v0_ = __builtin_amdgcn_s_memtime();
+            iacc_ += v0_ - i0_;
+#endif
+            if (allfour) WAL_VM(ndtot); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WX_STAMP
+            vacc_ += __builtin_amdgcn_s_memtime() - v0_;
+#endif
+            WAL_PUBLISH(h, WAL_FULL(h, allfour ? r - 1 : r));
         }
-#ifdef WX_STAMP
-        const unsigned long long i0_ = __builtin_amdgcn_s_memtime();
-        sacc_ += i0_ - s0_;
-#endif
-        if (anyslow) WAL_GATHER_LOAD();
-        WAL_ISSUE(r);
-#ifdef WX_STAMP
-        const unsigned long long v0_ = __builtin_amdgcn_s_memtime();
-        iacc_ += v0_ - i0_;
-#endif
-        // round r - 1 has landed (and this round's gathered entries: they were asked for before its DMA)
-        WAL_WAIT_PREV();
-        if (anyslow) WAL_GATHER_STORE(r);
-#ifdef WX_STAMP
-        vacc_ += __builtin_amdgcn_s_memtime() - v0_;
-#endif
-        if (ln == 0) wa_set<C>(lds, WA_LF + lw, WAL_FULL(r - 1));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ln == 0) wa_set<C>(lds, WA_LF + lw, 0x7ffffff0);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) WAL_PUBLISH(h, 0x7ffffff0);
 #ifdef WX_STAMP
     if (ln == 0 && wg < 4096 && lw == 0) { g_wf_wait[wg * 16 + 5] = sacc_; g_wf_wait[wg * 16 + 6] = iacc_; g_wf_wait[wg * 16 + 7] = vacc_; }
 #endif
 #undef WAL_ISSUE
-#undef WAL_WAIT_PREV
+#undef WAL_VM
 #undef WAL_GATHER_LOAD
 #undef WAL_GATHER_STORE
 #undef WAL_FULL
 #undef WAL_GATE
+#undef WAL_PUBLISH
 }
 
 // The prefetcher.  What bounds a tile at work is what ONE CU can have in flight at HBM latency (25-30 GB/s: measured with 4 tiles on an
@@ -2290,6 +2349,7 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
     if (t < NL) s_exp[t] = -1;
     if (t < 4) *reinterpret_cast<double *>(lds + C::X + (unsigned)((t * C::RowL + NL) * 8)) = 1.0;
     // (a consumer wave has "done step tlo - 1" when it has read what its first step starts from)
+    if (t >= WA_LH && t < WA_LH + 12) wa_set<C>(lds, t, tlo - 1);
     if (t < 14) wa_set<C>(lds, t, t == WA_BIG ? 0x7fffffff : ((t == WA_DEAD || t == WA_WARM) ? 0 : (t < WA_LF ? tlo - 2 : ((RP && (t == WA_TP || t == WA_EP)) ? 0x7ffffff0 : tlo - 1))));
     wa_bar<C>(lds, NROLE / 64);
     if (t < NL) {
@@ -2462,7 +2522,8 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
             int ci = WA_BIG, co = 0;
             if (ln == 0 && wv > 0) { ci = WA_CP + wv - 1; co = -1; }       // hand-over values of wave w - 1: two steps old, read a step early
             if (ln == 1 && wv < NCW - 1) { ci = WA_CP + wv + 1; co = -2; }       // wave w + 1 still reads what this step overwrites (four slots, two steps old)
-            if (ln == 2) { ci = WA_LF + wv; co = 1; }                      // the row of step s + 1
+            if (ln == 2) { ci = WA_LF + wv; co = 1; }                      // the row of step s + 1: of the lanes of each quarter of the wave's ring
+            if (ln >= 6 && ln <= 8) { ci = WA_LH + 4 * (ln - 6) + wv; co = 1; }
             if (ln == 3) { ci = WA_IP; co = 1; }                           // the imports of step s + 1
             if (ln == 4) { ci = WA_TP; co = 1; }
             if (ln == 5) { ci = WA_EP; co = -4; }                          // the exporter has read the pivots this step overwrites
@@ -2504,11 +2565,26 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
                 }
             }
             const unsigned a0 = CuOwn + 8u * (unsigned)mOwn * (unsigned)tlo;   // the lane's "row" of step tlo (mod 2^32: before the array is out of it)
+            // The lane's PLACE in the slots of its wave's ring: the wave's lanes in the order of where their rows begin in a memory line
+            // (gathered lanes first, lanes without rows last).  The loader fetches the lines of each quarter of the places (16 lanes,
+            // two instructions) when THEY need them: lanes whose rows begin at the same offset need a new line at the same step,
+            // lanes at different offsets up to two steps apart -- steps of lead that the ring of four lines does not have to spare.
+            const int fkey = kind == WA_K_DMA ? 1 + (int)((a0 & 127u) >> 3) : (kind == WA_K_GATHER ? 0 : 17);
+            int pos = 0;
+            {
+                int before = 0;
+#pragma unroll 1
+                for (int v = 0; v <= 17; ++v) {
+                    const unsigned long long b = __builtin_amdgcn_ballot_w64(fkey == v);
+                    if (fkey == v) pos = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
+                    before += __popcll(b);
+                }
+            }
             int4 rec; rec.x = kind; rec.y = (int)a0; rec.z = 8 * mOwn; rec.w = srcpk;
-            *reinterpret_cast<int4 *>(lds + kWaScrRec + 16u * (unsigned)t) = rec;
+            *reinterpret_cast<int4 *>(lds + kWaScrRec + 16u * (unsigned)((t & ~63) + pos)) = rec;
             W.e0 = kind == WA_K_DMA ? (a0 & 127u) : 0u;
-            W.lb = (unsigned)((t >> 6) * C::WaveRing + (t & 63) * 128);
-            W.xs = (unsigned)(((t & 7) ^ ((t >> 3) & 1)) << 4);
+            W.lb = (unsigned)((t >> 6) * C::WaveRing + pos * 128);
+            W.xs = (unsigned)(((pos & 7) ^ ((pos >> 3) & 1)) << 4);
             W.cpk = cpkU; W.m8 = 8 * M;
         }
         if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], okShape ? (ok ? 9 : 8) : 5);
