@@ -1358,9 +1358,7 @@ k_ilu0_wx(WfArgs A)
 #define WA_DMA_AUX 0
 #endif
 static constexpr int kWdSH = 2;                            // steps a delivery is ahead of the step that uses it
-static constexpr int kWaSlot = 64 * 128;                   // a wave's lines of one ring slot: 64 x-lines x 128 bytes
-static constexpr unsigned kWaScrM = 6144, kWaScrRec = 8192; // set-up scratch inside the (not yet filled) ring: the tile's row shape; a record per lane
-enum { WA_K_EMPTY = 0, WA_K_DMA = 1, WA_K_GATHER = 2 };     // how a lane's rows get into its ring
+static constexpr int kWdWaveBlk = 64 * 128 + 16;           // a wave's windows of one block, and 16 bytes of zeros (what a row position the lane does not have reads)
 // the value of step (v - dt) of `src` in a hand-off array whose slots are `row` doubles long, as read for step v (mod 4)
 __device__ __forceinline__ void wd_addr4(unsigned a[4], const unsigned base, const int row, const int src, const int dt)
 {
@@ -1380,7 +1378,7 @@ struct WaCfg {
     static constexpr int U = D == 4 ? 8 : 12;
     static constexpr int R = 4;                                // steps of the import ring
     static constexpr int NP = D == 4 ? 8 : 6;                  // steps the poller asks ahead / the exporter loads A's transposed entries ahead
-    static constexpr int WaveRing = 4 * kWaSlot;              // (a power of two: slot and wave are bit fields of a ring address)
+    static constexpr int WaveRing = D * kWdWaveBlk;
     static constexpr int RowL = NL + 8;                        // doubles per slot of the pivot and a'C arrays: lanes, [NL] the cell of ones / zeros
     static constexpr int RowX = NL + 64 + 8;                   // ... of the a'B array: lanes, the imports' transposed entries, [NL + 64] zeros
     static constexpr unsigned X = (unsigned)(NCW * WaveRing);
@@ -1388,15 +1386,13 @@ struct WaCfg {
     static constexpr unsigned TB = XI + (unsigned)R * 64u * 8u;
     static constexpr unsigned TC = TB + 4u * RowX * 8u;
     static constexpr unsigned Cnt = TC + 4u * RowL * 8u;
-    static constexpr int Lds = (int)Cnt + 256;
+    static constexpr int Lds = (int)Cnt + 128;
     static constexpr int Threads = NL + 128 + NCW * 64 + 64;   // consumers, poller, exporter, loaders, prefetcher
     static_assert(U % (2 * D) == 0 && U % 4 == 0 && U % NP == 0, "slots are immediates of the unrolled loops");
-    static_assert(NCW == 4 && D == 4, "the line ring: four slots of 8 KB per wave, 32 KB per wave");
     static_assert(Lds * (4 / NCW) <= 160 * 1024 - 256 * (4 / NCW), "the LDS of a CU");
 };
 enum { WA_CP = 0, WA_LF = 4, WA_IP = 8, WA_TP = 9, WA_EP = 10, WA_DEAD = 11, WA_BIG = 12, WA_WARM = 13,          // (set anew for every unit)
-       WA_CHAIN = 14, WA_UM = 16, WA_UA = 17, WA_UB = 18, WA_BARC = 20, WA_BARG = 21,
-       WA_LH = 32 };                                              // lfull of quarters 1 .. 3 of a wave's lanes: WA_LH + 4 (h - 1) + wave (quarter 0: WA_LF + wave)
+       WA_CHAIN = 14, WA_UM = 16, WA_UA = 17, WA_UB = 18, WA_BARC = 20, WA_BARG = 21 };
 static constexpr unsigned kWaSpinLimit = 1u << 24;
 
 // (LDS words other waves write: ordered with compiler barriers -- `volatile` would turn them into flat, system-scope accesses)
@@ -1444,36 +1440,17 @@ __device__ __forceinline__ bool wa_wait_consumers(unsigned char *lds, const int 
         if (__builtin_amdgcn_ballot_w64(c < s) == 0) return true;
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023u) == 0) {
-            if (spins > kWaSpinLimit) { atomicExch(&ctrl[1], 4); wa_set<C>(lds, WA_DEAD, 1); }
+            if (spins > kWaSpinLimit) { atomicExch(&ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
             if (wa_cnt<C>(lds, WA_DEAD) != 0) return false;
         }
     }
-}
-
-// A lane's ring: four lines of 128 bytes as they lie in memory (aligned), line j in slot j % 4; a slot is the wave's 64 lines one after
-// the other (what eight DMA instructions write), a wave's four slots 32 KB.  Byte `e` of the lane's ring (0 .. 511, more is cut off) is
-// at  wave | slot (bits 13, 14) | x-line (bits 7 .. 12) | byte in the line (bits 3 .. 6, the 16-byte pieces swizzled by `xs`: the 16
-// lanes the LDS serves at a time then read 16 different bank groups whatever their rows' offsets are).
-__device__ __forceinline__ unsigned wa_ring_addr(const unsigned e, const unsigned xs, const unsigned lb)
-{
-    const unsigned tx = e ^ xs;
-    return (((tx << 6) | tx) & 0x6078u) | lb;
-}
-__device__ __forceinline__ double wa_entry(const unsigned char *lds, const unsigned er, const int cpk, const int pl, const unsigned xs, const unsigned lb)
-{
-    const int c = (cpk >> (4 * pl)) & 15;                   // (the same for every lane: a scalar)
-    if (c == 15) return 0.0;
-    return st_lds(lds, wa_ring_addr(er + 8u * (unsigned)c, xs, lb));
 }
 
 template <int U>
 struct WaLane {
     unsigned xB[4], xC[4];        // pivot hand-off: where the stand-in of class B / C FOR a step = v (mod 4) is read (the cell of ones without an entry)
     unsigned tB[4], tC[4];        // transposed entries of the class B / C elimination FOR a step = v (mod 4) (a cell of zeros without one)
-    unsigned e0;                  // byte offset of the lane's row of step tlo in its ring (0 .. 127: inside line 0)
-    unsigned lb, xs;              // the lane's place in a slot (wave, x-line); the swizzle of the 16-byte pieces of its lines
-    int cpk;                      // (the tile's, the same for every lane) position of each of the 7 places in a row, 4 bits each, 15 = none
-    int m8;                       // (the tile's) bytes per row: 8 M
+    unsigned ra[2][7];
     unsigned ca; int coff;        // the counter this lane checks and its margin: counter - coff >= step
     bool ringC;
     int src16;
@@ -1503,18 +1480,13 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
     typedef unsigned int v4w_ __attribute__((ext_vector_type(4)));
 #define WA_LDW(s_) __builtin_amdgcn_raw_buffer_load_b128(rU, (unsigned)((s_) - tminw) * 2048u + 1024u + (unsigned)ln * 16u, 0, 16)
 #define WA_W(r_, s_) (((unsigned)((s_) - tminw) < (unsigned)nchw) ? __builtin_bit_cast(v2dd, r_).y : 1.0)
-    // the next row of the lane: its seven places, from where the ring holds them (`er`: the row's byte offset in the lane's ring of
-    // 512 bytes); a place the tile's rows do not have is +0.0
-    const int cpk = __builtin_amdgcn_readfirstlane(W.cpk);
-    const unsigned m8 = (unsigned)__builtin_amdgcn_readfirstlane(W.m8);
-    unsigned er = W.e0;
-#define WA_ROW(r0_, r1_, r2_, r3_)                                                                                 \
+#define WA_ROW(blk_, par_, r0_, r1_, r2_, r3_)                                                                     \
     do {                                                                                                           \
-        (r0_).x = wa_entry(lds, er, cpk, 0, W.xs, W.lb); (r0_).y = wa_entry(lds, er, cpk, 1, W.xs, W.lb);          \
-        (r1_).x = wa_entry(lds, er, cpk, 2, W.xs, W.lb); (r1_).y = wa_entry(lds, er, cpk, 3, W.xs, W.lb);          \
-        (r2_).x = wa_entry(lds, er, cpk, 4, W.xs, W.lb); (r2_).y = wa_entry(lds, er, cpk, 5, W.xs, W.lb);          \
-        (r3_).x = wa_entry(lds, er, cpk, 6, W.xs, W.lb); (r3_).y = 0.0;                                            \
-        er = (er + m8) & 511u;                                                                                     \
+        const unsigned o_ = (unsigned)(blk_) * kWdWaveBlk;                                                         \
+        (r0_).x = st_lds(lds, W.ra[par_][0] + o_); (r0_).y = st_lds(lds, W.ra[par_][1] + o_);                      \
+        (r1_).x = st_lds(lds, W.ra[par_][2] + o_); (r1_).y = st_lds(lds, W.ra[par_][3] + o_);                      \
+        (r2_).x = st_lds(lds, W.ra[par_][4] + o_); (r2_).y = st_lds(lds, W.ra[par_][5] + o_);                      \
+        (r3_).x = st_lds(lds, W.ra[par_][6] + o_); (r3_).y = 0.0;                                                  \
     } while (0)
 #define WA_HAND_T(h4_, r2_, r3_)                                                                                   \
     do {                                                                                                           \
@@ -1548,7 +1520,7 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
             if (__builtin_amdgcn_ballot_w64(c0 - W.coff < tlo - 1) == 0) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0) {
-                if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 7); wa_set<C>(lds, WA_DEAD, 1); }
+                if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
                 if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
             }
         }
@@ -1556,7 +1528,8 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
     asm volatile("" ::: "memory");
     v2dd c0_, c1_, c2_, c3_;
     v2dd n0_, n1_, n2_, n3_;
-    WA_ROW(c0_, c1_, c2_, c3_);
+    WA_ROW(0, 0, c0_, c1_, c2_, c3_);
+    WA_ROW(0, 1, n0_, n1_, n2_, n3_);
     WA_ENDS(tlo - sk, c0_, c1_, c2_, c3_);
     WA_HAND_T(0, c2_, c3_);
     double bB = st_lds(lds, W.xB[0]), bC = st_lds(lds, W.xC[0]);
@@ -1587,7 +1560,7 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
             if (__builtin_amdgcn_ballot_w64(c0 - W.coff < tlo) == 0) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0) {
-                if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 7); wa_set<C>(lds, WA_DEAD, 1); }
+                if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
                 if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
             }
         }
@@ -1617,7 +1590,7 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
                     cv = wa_ld32(lds, W.ca);
                     if (__builtin_amdgcn_ballot_w64(cv - W.coff < s) == 0) break;
                     if ((++spins & 1023u) == 0) {
-                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 7); wa_set<C>(lds, WA_DEAD, 1); }
+                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
                         if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
                     }
                 }
@@ -1628,8 +1601,8 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
             asm volatile("" ::: "memory");                  // (no LDS access of the step in front of its check)
             const double pC = W.ringC ? bC : qC;
             const double pB = wx_dpp_shr1(bB, w3prev);
-            // (the next step's row: asked for here, used at the end of this step)
-            WA_ROW(n0_, n1_, n2_, n3_);
+            v2dd m0_, m1_, m2_, m3_;
+            WA_ROW(((u + 2) >> 1) % D, u & 1, m0_, m1_, m2_, m3_);
             const double nB = st_lds(lds, W.xB[(u + 1) & 3]);
             const double nC = st_lds(lds, W.xC[(u + 1) & 3]);
             const double ntB = RP ? 0.0 : st_lds(lds, W.tB[(u + 1) & 3]);
@@ -1688,6 +1661,7 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
             asm volatile("" ::: "memory");
             if (ln == 0) wa_set<C>(lds, WA_CP + wv, s);
             c0_ = n0_; c1_ = n1_; c2_ = n2_; c3_ = n3_;
+            n0_ = m0_; n1_ = m1_; n2_ = m2_; n3_ = m3_;
             bB = nB; bC = nC; tB = ntB; tC = ntC;
             ++k;
         }
@@ -1735,7 +1709,7 @@ __device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long l
             if (__builtin_amdgcn_ballot_w64(v == kSentinel) == 0) break;
             __builtin_amdgcn_s_sleep(8);
             if ((++spins & 255u) == 0) {
-                if (spins > kStSpinLimit) { atomicExch(&A.ctrl[1], 2); wa_set<C>(lds, WA_DEAD, 1); }
+                if (spins > kStSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
                 const int e = ld_agent_i32(&A.ctrl[1]);
                 if (spins > kStSpinLimit || e != 0) { dead = true; break; }
             }
@@ -1760,7 +1734,7 @@ __device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long l
                 __builtin_amdgcn_s_waitcnt(0x0F70);                                                                  \
                 __builtin_amdgcn_s_sleep(1);                                                                         \
                 if ((++spins & 255u) == 0) {                                                                         \
-                    if (spins > kStSpinLimit) { atomicExch(&A.ctrl[1], 2); wa_set<C>(lds, WA_DEAD, 1); }                \
+                    if (spins > kStSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }                \
                     const int e = ld_agent_i32(&A.ctrl[1]);                                                          \
                     __builtin_amdgcn_s_waitcnt(0x0F70);                                                              \
                     if (spins > kStSpinLimit || e != 0 || wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }         \
@@ -1800,7 +1774,7 @@ __device__ __forceinline__ void wa_poller(const WfArgs &A, const unsigned long l
 #ifdef WX_STAMP
     if (ln == 0 && wg < 4096) { g_wf_wait[wg * 16 + 4] = nspin_; g_wf_wait[wg * 16 + 14] = nmiss_; g_wf_wait[wg * 16 + 15] = (unsigned long long)(thi - tlo); }
 #endif
-    if (dead && ln == 0) atomicExch(&A.ctrl[1], 2);
+    if (dead && ln == 0) atomicExch(&A.ctrl[1], 1);
 }
 
 // the exporter: the border pivots of step s behind the consumers' step s; the imports' transposed entries four steps ahead
@@ -1825,7 +1799,7 @@ __device__ __forceinline__ void wa_exporter(const WfArgs &A, unsigned char *lds,
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(A.xch + (xroom > 0 ? xrow0 : 0), 0, (int)(8 * (xroom > 0 ? (xwant < xroom ? xwant : xroom) : 0)), 0x00020000);
     unsigned vx = elane >= 0 ? (unsigned)ln * 8u : 0xfffffff0u;
     const unsigned dvx = elane >= 0 ? (unsigned)E * 8u : 0u;
-    if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 3);                 // (the analysis does not let such a schedule through)
+    if (E > 64 && ln == 0) atomicExch(&A.ctrl[1], 1);                 // (the analysis does not let such a schedule through)
     double ga[NA];
 #define WAC_AT(k_) (((unsigned)(k_) < span && P.hasT) ? P.at0 + (unsigned)((k_) * P.atm) - ((k_) == P.klast ? (unsigned)P.sh : 0u) : 0xfffffff0u)
 #define WAC_LDAT(k_) __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, WAC_AT(k_), 0, 0))
@@ -1867,192 +1841,60 @@ __device__ __forceinline__ void wa_exporter(const WfArgs &A, unsigned char *lds,
 }
 
 // a loader wave (wd_loader's windows), paced by its consumer wave's progress instead of the barrier
-// x / m for small non-negative x (the float quotient of x + 1/2 is never within rounding of an integer)
-__device__ __forceinline__ int wa_div(const int x, const float rm) { return (int)(((float)x + 0.5f) * rm); }
-
-// A loader wave: the rows of consumer wave lw's 64 lanes, from memory into their rings, one LINE (128 bytes as they lie in memory,
-// aligned) per lane and round: eight DMA instructions of 8 lanes' lines each (a thread = one 16-byte piece; the pieces of a line
-// swizzled as wa_ring_addr reads them), round r into slot r % 4.  Every byte is fetched once -- the 128-byte windows per two steps this
-// replaces started wherever the rows did, and each memory line was fetched twice, which is what bounded a tile: profiles/r06_cu_stream.txt.
-//   * With f the offset (in entries) of a lane's row of step tlo in its line 0 and M entries per row, the row of step tlo + n is
-//     entries f + M n .. f + M n + M - 1 of the lane's ring, line j entries 16 j .. 16 j + 15.  The wave's lanes start at different
-//     f (fmin .. fmax): after round r the rows up to tlo + (16 (r + 1) - fmax - M) / M are there for all of them (lfull), and round
-//     r + 4 may overwrite line r once the consumers have READ (a step ahead of their step) row tlo + (16 r + 15 - fmin) / M.
-//   * A lane whose rows have fewer entries than the tile's shape (WA_K_GATHER: on the domain's boundary) gets its lines from this
-//     wave's thread of the same number: sixteen 8-byte loads per round, put into the ring in the tile's shape (zeros where the lane has
-//     no entry); its DMA threads are masked out.  A lane without rows (WA_K_EMPTY) fetches from beyond the array: zeros.
 template <int NCW, int D>
-__device__ __forceinline__ void wa_loader(const WfArgs &A, unsigned char *lds, const int wg, const int lw, const int tlo, const int thi,
-                                          const int M, const int4 own, const int4 (&grp)[8])
+__device__ __forceinline__ void wa_loader(const WfArgs &A, unsigned char *lds, const int wg, const int lw, const int tlo, const int thi)
 {
     typedef WaCfg<NCW, D> C;
     constexpr int U = C::U;
-    const int ln = threadIdx.x & 63, pp = ln & 7, gi = ln >> 3;
+    const int ln = threadIdx.x & 63, j = ln & 7, gi = ln >> 3;
     const __amdgpu_buffer_rsrc_t rs = wf_rsrc(A);
-    const float rm = 1.0f / (float)(M > 0 ? M : 1);
-    unsigned g[8];
-    bool on[8];
+    unsigned g[8], S[8];
+    const int b0 = tlo >> 1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        on[q] = grp[q].x != WA_K_GATHER;
-        g[q] = grp[q].x == WA_K_DMA ? ((unsigned)grp[q].y & ~127u) + 16u * (unsigned)(pp ^ gi ^ (q & 1)) : 0xffffff00u;
-    }
-    // the gathered lanes: the first `ns` places of the wave (they sort first).  Their lines are put together by ALL the wave's threads:
-    // entry i (of 16) of the line of place L is thread (L, i)'s of instruction L / 4 -- four full instructions per quarter of places
-    // (an instruction costs what it costs whether 16 or 64 of its threads load).
-    const bool slow = own.x == WA_K_GATHER;
-    const int ns = __popcll(__builtin_amdgcn_ballot_w64(slow));
-    // the quarter h of the wave's places (16 lanes in the order of their rows' offsets, instructions 2 h and 2 h + 1): where its rows
-    // begin (fmn[h] .. fmx[h]), its instructions, whether it gathers
-    int fmn[4], fmx[4], nd[4];
-    bool gq[4];
-    {
-        const int f = own.x == WA_K_DMA ? (int)(((unsigned)own.y & 127u) >> 3) : 0;
-        int lo = own.x == WA_K_EMPTY ? 15 : f, hi = own.x == WA_K_EMPTY ? 0 : f;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-        lo = min(lo, hi);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            fmn[h] = __builtin_amdgcn_readlane(lo, 16 * h); fmx[h] = __builtin_amdgcn_readlane(hi, 16 * h);
-            nd[h] = (__builtin_amdgcn_ballot_w64(on[2 * h]) != 0 ? 1 : 0) + (__builtin_amdgcn_ballot_w64(on[2 * h + 1]) != 0 ? 1 : 0);
-            gq[h] = ns > 16 * h;
-        }
+        const int w = 8 * q + gi;
+        const int32_t *T = A.ltab + (size_t)(wg * kThreads + lw * 64 + w) * kStTab;
+        const int cnt = T[ST_CNT], sk = T[ST_SKEW], p0 = T[ST_P0], fl = T[ST_DFL];
+        const int ownL = (fl >> 2) & 1, m = fl >> 4;
+        const unsigned Cu = 8u * (unsigned)(p0 - ownL - sk * m) + (unsigned)A.val_shift;
+        const int piece = (j + ((w >> 1) & 7)) & 7;
+        const bool on = cnt > 0 && (piece < 7 || (Cu & 15u) + 16u * (unsigned)m > 112u);
+        S[q] = on ? 16u * (unsigned)m : 0u;
+        g[q] = on ? (Cu & ~15u) + (unsigned)b0 * S[q] + 16u * (unsigned)piece : 0xfffffff0u;
     }
     typedef __attribute__((address_space(3))) void lds_void;
-    typedef unsigned int v2w_ __attribute__((ext_vector_type(2)));
-    v2w_ sv[16];
-#define WAL_VM(n_)                                                                                                   \
+#define WAL_ISSUE(slot_)                                                                                             \
     do {                                                                                                             \
-        switch (n_) {                                                                                                \
-        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;                                        \
-        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;                                        \
-        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;                                        \
-        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;                                        \
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;                                        \
-        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;                                        \
-        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;                                        \
-        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;                                        \
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;                                        \
-        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;                                        \
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;                                        \
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;                                        \
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;                                        \
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;                                        \
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;                                        \
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;                                          \
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;                                          \
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;                                          \
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                                          \
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;                                          \
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                          \
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;                                          \
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;                                          \
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;                                          \
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                                             \
-        }                                                                                                            \
-    } while (0)
-#define WAL_GATHER_LOAD(h_, r_)                                                                                      \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                           \
-            const int L_ = 16 * (h_) + 4 * kk + (ln >> 4);                                                           \
-            const unsigned a0_ = (unsigned)__shfl(own.y, L_), m8_ = (unsigned)__shfl(own.z, L_), pk_ = (unsigned)__shfl(own.w, L_); \
-            const int E_ = 16 * (r_) + (ln & 15);                                                                    \
-            const int n_ = wa_div(E_, rm), vp_ = E_ - n_ * M;                                                        \
-            const unsigned j_ = (pk_ >> (4 * vp_)) & 15u;                                                            \
-            sv[4 * (h_) + kk] = __builtin_amdgcn_raw_buffer_load_b64(rs, (L_ < ns && j_ != 15u) ? a0_ + m8_ * (unsigned)n_ + 8u * j_ : 0xfffffff0u, 0, 0); \
-        }                                                                                                            \
-    } while (0)
-#define WAL_GATHER_STORE(h_, r_)                                                                                     \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                           \
-            const int L_ = 16 * (h_) + 4 * kk + (ln >> 4);                                                           \
-            const unsigned xs_ = (unsigned)(((L_ & 7) ^ ((L_ >> 3) & 1)) << 4);                                      \
-            if (L_ < ns)                                                                                             \
-                *reinterpret_cast<v2w_ *>(lds + ((unsigned)(lw * C::WaveRing + L_ * 128) + (unsigned)((r_) & 3) * kWaSlot + ((8u * (unsigned)(ln & 15)) ^ xs_))) = sv[4 * (h_) + kk]; \
-        }                                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
-    } while (0)
-#define WAL_ISSUE(h_, r_)                                                                                            \
-    do {                                                                                                             \
-        unsigned char *dst_ = lds + lw * C::WaveRing + ((r_) & 3) * kWaSlot;                                         \
-        _Pragma("unroll") for (int q = 2 * (h_); q < 2 * (h_) + 2; ++q) {                                            \
-            if (on[q]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst_ + q * 1024), 16, g[q], 0, 0, WA_DMA_AUX); \
-            g[q] += grp[q].x == WA_K_DMA ? 128u : 0u;                                                                \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(lds + lw * C::WaveRing + (slot_) * kWdWaveBlk + q * 1024), 16, g[q], 0, 0, WA_DMA_AUX); \
+            g[q] += S[q];                                                                                            \
         }                                                                                                            \
         asm volatile("" ::: "memory");                                                                               \
     } while (0)
-    // rows of quarter h_ there once its lines up to r_ have landed; the step the consumers must have finished before its line r_ is
-    // asked for (line r_ - 4 read to its end -- and not before they have read the row they begin with: their counter starts at
-    // tlo - 2 without their having read anything)
-#define WAL_FULL(h_, r_) (tlo + wa_div(16 * ((r_) + 1) - fmx[h_] - M, rm))
-#define WAL_GATE(h_, r_) max(tlo - 1, tlo + wa_div(16 * ((r_) - 4) + 15 - fmn[h_], rm) - 1)
-#define WAL_PUBLISH(h_, v_) do { if (ln == 0) wa_set<C>(lds, (h_) == 0 ? WA_LF + lw : WA_LH + 4 * ((h_) - 1) + lw, (v_)); } while (0)
-    // lines 0 .. 3 fill the ring
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            if (gq[h]) WAL_GATHER_LOAD(h, r);
-            WAL_ISSUE(h, r);
-            if (gq[h]) { WAL_VM(nd[h]); WAL_GATHER_STORE(h, r); }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int h = 0; h < 4; ++h) WAL_PUBLISH(h, WAL_FULL(h, 3));
-    // (a gathered lane's entries of the NEXT line wait in its thread's registers: asked for when the line before was put into the ring)
-#pragma unroll
-    for (int h = 0; h < 4; ++h) if (gq[h]) WAL_GATHER_LOAD(h, 4);
+    // (blocks b0 .. b0 + D - 1; the first two have landed before the consumers' first reads)
+    WAL_ISSUE(0); WAL_ISSUE(1); WAL_ISSUE(2); if (D == 4) WAL_ISSUE(3);
+    if (D == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (ln == 0) wa_set<C>(lds, WA_LF + lw, tlo + 3);
     const int thiR = tlo + (thi - tlo + U - 1) / U * U;
     bool dead = false;
 #ifdef WX_STAMP
     unsigned long long iacc_ = 0, vacc_ = 0, sacc_ = 0;
 #endif
-    // (the consumers ask for the rows up to thiR)
-    // The quarters are in the order of their rows' offsets, so they need line r in the order 3, 2, 1, 0 and quarter 3 needs line r + 1
-    // after quarter 0 line r: one sequence of gates.  Behind the instructions of (quarter h, line r) everything but the last four
-    // quarters' instructions has arrived: (h, r - 1) is there.  When the next gate is still closed, the wave waits for all it has
-    // asked for and says so at once (a line is needed less than a step after the one behind it may be asked for).
-    // (vector-memory instructions of a quarter per line: its DMA instructions, and the four loads of its gathered lanes' entries)
-    int vq[4];
+    for (int tb = tlo; tb < thiR; tb += U) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) vq[h] = nd[h] + (gq[h] ? 4 : 0);
-    const int ndtot = vq[0] + vq[1] + vq[2] + vq[3];
-#pragma unroll 1
-    for (int r = 4;; ++r) {
-        bool act[4];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) act[h] = WAL_FULL(h, r - 1) < thiR;
-        if (!(act[0] || act[1] || act[2] || act[3])) break;
-        const bool allfour = act[0] && act[1] && act[2] && act[3];
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            const int h = 3 - hh;
-            if (!act[h]) continue;
-            const int need = WAL_GATE(h, r);
+        for (int bb = 0; bb < U / 2; ++bb) {
+            // block b (steps tb + 2 bb, + 1): its slot takes block b + D once the wave has read its rows (during the two steps before);
+            // block b + 2 is published when it has landed (the D - 2 blocks behind it may be on their way: eight instructions each)
+            const int need = tb + 2 * bb - 1;
 #ifdef WX_STAMP
             const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
 #endif
-            if (!dead && wa_cnt<C>(lds, WA_CP + lw) < need) {
-                // nothing to ask for yet: first what is behind the quarter asked for last (it has had a quarter's time to arrive), then --
-                // if the gate is still closed -- that one too (the consumers may be waiting for exactly it)
-                const int hl = (h + 1) & 3;                              // (the quarter before this one in the sequence; it was active if all four are)
-                if (allfour) {
-                    WAL_VM(vq[hl]);
-#pragma unroll
-                    for (int h2 = 0; h2 < 4; ++h2) if (h2 != hl) WAL_PUBLISH(h2, WAL_FULL(h2, h2 > h ? r : r - 1));
-                }
-                if (!allfour || wa_cnt<C>(lds, WA_CP + lw) < need) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int h2 = 0; h2 < 4; ++h2) WAL_PUBLISH(h2, WAL_FULL(h2, (h2 > h && act[h2]) ? r : r - 1));
-                }
+            if (!dead) {
                 unsigned spins = 0;
                 while (wa_cnt<C>(lds, WA_CP + lw) < need) {
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 1023u) == 0) {
-                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 6); wa_set<C>(lds, WA_DEAD, 1); }
+                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
                         if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
                     }
                 }
@@ -2061,34 +1903,23 @@ __device__ __forceinline__ void wa_loader(const WfArgs &A, unsigned char *lds, c
             const unsigned long long i0_ = __builtin_amdgcn_s_memtime();
             sacc_ += i0_ - s0_;
 #endif
-            // (the gathered entries of this line were asked for a line ago: behind them, the other three quarters' instructions)
-            if (gq[h]) { WAL_VM(ndtot - vq[h]); WAL_GATHER_STORE(h, r); }
-            WAL_ISSUE(h, r);
-            if (gq[h]) WAL_GATHER_LOAD(h, r + 1);
+            WAL_ISSUE(bb % D);
 #ifdef WX_STAMP
             const unsigned long long v0_ = __builtin_amdgcn_s_memtime();
             iacc_ += v0_ - i0_;
 #endif
-            if (allfour) WAL_VM(ndtot); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (D == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #ifdef WX_STAMP
             vacc_ += __builtin_amdgcn_s_memtime() - v0_;
 #endif
-            WAL_PUBLISH(h, WAL_FULL(h, allfour ? r - 1 : r));
+            if (ln == 0) wa_set<C>(lds, WA_LF + lw, tb + 2 * bb + 5);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int h = 0; h < 4; ++h) WAL_PUBLISH(h, 0x7ffffff0);
 #ifdef WX_STAMP
     if (ln == 0 && wg < 4096 && lw == 0) { g_wf_wait[wg * 16 + 5] = sacc_; g_wf_wait[wg * 16 + 6] = iacc_; g_wf_wait[wg * 16 + 7] = vacc_; }
 #endif
 #undef WAL_ISSUE
-#undef WAL_VM
-#undef WAL_GATHER_LOAD
-#undef WAL_GATHER_STORE
-#undef WAL_FULL
-#undef WAL_GATE
-#undef WAL_PUBLISH
 }
 
 // The prefetcher.  What bounds a tile at work is what ONE CU can have in flight at HBM latency (25-30 GB/s: measured with 4 tiles on an
@@ -2325,8 +2156,6 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
     constexpr int NROLE = NL + 128 + NCW * 64;
     WfPair *s_pairs = reinterpret_cast<WfPair *>(lds);
     int *s_exp = reinterpret_cast<int *>(lds + 64 * sizeof(WfPair));
-    int *s_m = reinterpret_cast<int *>(lds + kWaScrM), *s_vp = s_m + 4;
-    int M = 0;
     const int t = threadIdx.x;
     int tlo = 0x7fffffff, thi = -0x7fffffff;
 #pragma unroll
@@ -2344,12 +2173,10 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
     for (int i = (int)(C::X / 8) + t; i < (int)(C::Cnt / 8); i += NROLE) reinterpret_cast<double *>(lds)[i] = 0.0;
     if (t < 4) s_cnt[t] = 0;
     wa_bar<C>(lds, NROLE / 64);
-    if (t == 0) s_vp[4] = 0;
     if (t < 64) { WfPair z; z.idx0 = 0; z.stride = 0; z.sk = 0; z.cnt = 0; z.at0 = 0; z.atm = 0; z.klast = -1; z.sh = 0; z.hasT = 0; z.astart = -1; z.pw = -1; s_pairs[t] = z; }
     if (t < NL) s_exp[t] = -1;
     if (t < 4) *reinterpret_cast<double *>(lds + C::X + (unsigned)((t * C::RowL + NL) * 8)) = 1.0;
     // (a consumer wave has "done step tlo - 1" when it has read what its first step starts from)
-    if (t >= WA_LH && t < WA_LH + 12) wa_set<C>(lds, t, tlo - 1);
     if (t < 14) wa_set<C>(lds, t, t == WA_BIG ? 0x7fffffff : ((t == WA_DEAD || t == WA_WARM) ? 0 : (t < WA_LF ? tlo - 2 : ((RP && (t == WA_TP || t == WA_EP)) ? 0x7ffffff0 : tlo - 1))));
     wa_bar<C>(lds, NROLE / 64);
     if (t < NL) {
@@ -2435,13 +2262,7 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
             for (int j = 0; j < 3; ++j) bal[j] = __builtin_amdgcn_ballot_w64(isg[j]);
             const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]);
             if ((t & 63) == 0) s_cnt[wv] = mine;
-            // (the most entries a row of the tile has: the shape of the rows in the rings)
-            int mw = cnt > 0 ? (T[ST_DFL] >> 4) : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mw = max(mw, __shfl_xor(mw, o));
-            if ((t & 63) == 0) s_m[wv] = mw;
             wa_bar<C>(lds, NROLE / 64);
-            M = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
             int before = 0;
             for (int q = 0; q < wv; ++q) before += s_cnt[q];
             if (t == 0) s_total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
@@ -2457,9 +2278,6 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
                 before += __popcll(bal[j]);
             }
         }
-        int pkOwn = 0, mOwn = 0;
-        bool okShape = true;
-        unsigned CuOwn = 0;
         W.hasB = W.hasC = W.hasUB = W.hasUC = false;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -2498,6 +2316,7 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
             const int fld = T[ST_DFL], ndU = fld & 3, ownL = (fld >> 2) & 1, m = fld >> 4;
             const unsigned Cu = 8u * (unsigned)(T[ST_P0] - ownL - T[ST_SKEW] * m) + (unsigned)A.val_shift;
             const int ln = t & 63, wv = t >> 6;
+            const int rot = (ln >> 1) & 7;
             int posOf[7] = {-1, -1, -1, -1, -1, -1, -1};
 #pragma unroll
             for (int pos = 0; pos < 7; ++pos) {
@@ -2508,22 +2327,20 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
 #pragma unroll
                 for (int pl_ = 0; pl_ < 7; ++pl_) if (place == pl_) posOf[pl_] = pos;
             }
-            // where each of the seven places is in the lane's rows (4 bits each, 15: not there); the wave's proposal for the shape of the
-            // tile's rows: that of its first lane with the most entries
 #pragma unroll
-            for (int pl_ = 0; pl_ < 7; ++pl_) pkOwn |= (posOf[pl_] < 0 ? 15 : posOf[pl_]) << (4 * pl_);
-            mOwn = m; CuOwn = Cu;
-            {
-                const unsigned long long fb = __builtin_amdgcn_ballot_w64(cnt > 0 && m == M);
-                const int cand = fb != 0 ? __builtin_amdgcn_readlane(pkOwn, __builtin_ctzll(fb)) : -1;
-                if (ln == 0) s_vp[wv] = cand;
-            }
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int pl_ = 0; pl_ < 7; ++pl_) {
+                    const unsigned B = (Cu & 15u) + (unsigned)(e * 8 * m) + 8u * (unsigned)(posOf[pl_] < 0 ? 0 : posOf[pl_]);
+                    const unsigned a = (unsigned)(wv * C::WaveRing + ln * 128) + ((((B >> 4) - (unsigned)rot) & 7u) << 4) + (B & 8u);
+                    W.ra[e][pl_] = (cnt > 0 && posOf[pl_] >= 0 && B < 128u) ? a : (unsigned)(wv * C::WaveRing + 64 * 128);
+                    if (cnt > 0 && posOf[pl_] >= 0 && B >= 128u) ok = false;
+                }
             // the counter this lane looks at, and its margin (counter - margin >= step)
             int ci = WA_BIG, co = 0;
             if (ln == 0 && wv > 0) { ci = WA_CP + wv - 1; co = -1; }       // hand-over values of wave w - 1: two steps old, read a step early
             if (ln == 1 && wv < NCW - 1) { ci = WA_CP + wv + 1; co = -2; }       // wave w + 1 still reads what this step overwrites (four slots, two steps old)
-            if (ln == 2) { ci = WA_LF + wv; co = 1; }                      // the row of step s + 1: of the lanes of each quarter of the wave's ring
-            if (ln >= 6 && ln <= 8) { ci = WA_LH + 4 * (ln - 6) + wv; co = 1; }
+            if (ln == 2) { ci = WA_LF + wv; co = 2; }                      // the row of step s + 2
             if (ln == 3) { ci = WA_IP; co = 1; }                           // the imports of step s + 1
             if (ln == 4) { ci = WA_TP; co = 1; }
             if (ln == 5) { ci = WA_EP; co = -4; }                          // the exporter has read the pivots this step overwrites
@@ -2534,60 +2351,7 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
             if (cnt > 0 && xe >= 0 && xe < NL) s_exp[xe] = t;
         }
         wa_bar<C>(lds, NROLE / 64);
-        {
-            // The rows in the rings have the tile's shape: M entries, the seven places where the lanes with M entries have them (they
-            // must agree).  Such a lane's rows go from memory into its ring as they lie (DMA); a lane with fewer entries has its rows
-            // PUT into that shape by its loader (a gather: per position of the shape, which of the lane's entries, or none).  Either
-            // way the lane reads the lattice it read before: entry `posOf` of "row" k at P0 - ownL + k m + posOf.
-            // (Lanes with M entries that disagree, or a lane with an entry the shape has no place for -- tiles without an inner lane,
-            // at an edge of the domain: then the shape is all seven places in their order, and every lane is gathered.)
-            int cpkU = -1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (cpkU < 0) cpkU = s_vp[q];
-            if (cpkU < 0) cpkU = 0x0fffffff;
-            {
-                bool fits = true;
-#pragma unroll
-                for (int pl_ = 0; pl_ < 7; ++pl_) if (cnt > 0 && ((pkOwn >> (4 * pl_)) & 15) != 15 && ((cpkU >> (4 * pl_)) & 15) == 15) fits = false;
-                if ((__builtin_amdgcn_ballot_w64(!fits) != 0 || (A.flags & 4)) && (t & 63) == 0) s_vp[4] = 1;
-            }
-            wa_bar<C>(lds, NROLE / 64);
-            const bool allg = s_vp[4] != 0;
-            if (allg) { cpkU = 0x6543210; M = 7; }
-            const int kind = cnt <= 0 ? WA_K_EMPTY : ((!allg && mOwn == M && pkOwn == cpkU) ? WA_K_DMA : WA_K_GATHER);
-            int srcpk = 0x0fffffff;
-            if (kind == WA_K_GATHER) {
-#pragma unroll
-                for (int pl_ = 0; pl_ < 7; ++pl_) {
-                    const int own = (pkOwn >> (4 * pl_)) & 15, vp = (cpkU >> (4 * pl_)) & 15;
-                    if (own != 15 && vp == 15) { ok = false; okShape = false; }  // (cannot be)
-                    if (own != 15 && vp != 15) srcpk = (srcpk & ~(15 << (4 * vp))) | (own << (4 * vp));
-                }
-            }
-            const unsigned a0 = CuOwn + 8u * (unsigned)mOwn * (unsigned)tlo;   // the lane's "row" of step tlo (mod 2^32: before the array is out of it)
-            // The lane's PLACE in the slots of its wave's ring: the wave's lanes in the order of where their rows begin in a memory line
-            // (gathered lanes first, lanes without rows last).  The loader fetches the lines of each quarter of the places (16 lanes,
-            // two instructions) when THEY need them: lanes whose rows begin at the same offset need a new line at the same step,
-            // lanes at different offsets up to two steps apart -- steps of lead that the ring of four lines does not have to spare.
-            const int fkey = kind == WA_K_DMA ? 1 + (int)((a0 & 127u) >> 3) : (kind == WA_K_GATHER ? 0 : 17);
-            int pos = 0;
-            {
-                int before = 0;
-#pragma unroll 1
-                for (int v = 0; v <= 17; ++v) {
-                    const unsigned long long b = __builtin_amdgcn_ballot_w64(fkey == v);
-                    if (fkey == v) pos = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
-                    before += __popcll(b);
-                }
-            }
-            int4 rec; rec.x = kind; rec.y = (int)a0; rec.z = 8 * mOwn; rec.w = srcpk;
-            *reinterpret_cast<int4 *>(lds + kWaScrRec + 16u * (unsigned)((t & ~63) + pos)) = rec;
-            W.e0 = kind == WA_K_DMA ? (a0 & 127u) : 0u;
-            W.lb = (unsigned)((t >> 6) * C::WaveRing + pos * 128);
-            W.xs = (unsigned)(((pos & 7) ^ ((pos >> 3) & 1)) << 4);
-            W.cpk = cpkU; W.m8 = 8 * M;
-        }
-        if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], okShape ? (ok ? 9 : 8) : 5);
+        if ((t == 0 && s_total > 64) || !ok) atomicExch(&A.ctrl[1], 1);
         wa_bar<C>(lds, NROLE / 64);
         for (int i = t; i < 64 * (int)sizeof(WfPair) / 8 + kThreads / 2; i += NL) reinterpret_cast<double *>(lds)[i] = 0.0;
         wa_bar<C>(lds, NROLE / 64);
@@ -2612,7 +2376,6 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wa_bar<C>(lds, NROLE / 64);
         wa_bar<C>(lds, NROLE / 64);
-        wa_bar<C>(lds, NROLE / 64);
         if (t < NL + 64) {
             const unsigned long long *idle = reinterpret_cast<const unsigned long long *>(A.ltab + (size_t)wg * kThreads * kStTab);
             wa_poller<NCW, D>(A, idle, lds, P, tlo, thi, wg, !RP);
@@ -2624,17 +2387,7 @@ __device__ __forceinline__ void wa_unit(const WfArgs &A, unsigned char *lds, int
         wa_bar<C>(lds, NROLE / 64);
         wa_bar<C>(lds, NROLE / 64);
         wa_bar<C>(lds, NROLE / 64);
-        // (the lanes' records and the rows' shape are there; they lie where the first lines will land: read by every loader before any
-        // of them begins)
-        const int lw = (t - NL - 128) >> 6, ln = t & 63;
-        const int Mt = s_vp[4] != 0 ? 7 : max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
-        const int4 own = *reinterpret_cast<const int4 *>(lds + kWaScrRec + 16u * (unsigned)(lw * 64 + ln));
-        int4 grp[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) grp[q] = *reinterpret_cast<const int4 *>(lds + kWaScrRec + 16u * (unsigned)(lw * 64 + 8 * q + (ln >> 3)));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wa_bar<C>(lds, NROLE / 64);
-        wa_loader<NCW, D>(A, lds, wg, lw, tlo, thi, Mt, own, grp);
+        wa_loader<NCW, D>(A, lds, wg, (t - NL - 128) >> 6, tlo, thi);
     }
 }
 
@@ -2739,7 +2492,6 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     a.pkL = reinterpret_cast<unsigned char *>(pl->pk); a.pkU = reinterpret_cast<unsigned char *>(pu->pk);
     a.xe = pl->xe; a.xw = pl->xw; a.xch = pl->xch; a.xch_len = pl->xch_len; a.ctrl = d_ctrl;
     a.flags = 0;
-    { static const bool allg = getenv("ILUPP_WA_GATHER") != nullptr; if (allg) a.flags |= 4; }   // (test switch: every lane's rows gathered)
     a.prog = nullptr;
     if (wa_on() && getenv("ILUPP_NO_PREFETCH") == nullptr) {
         // progress and claim words of the tiles, all -1 (one buffer per device, kept)
@@ -2802,7 +2554,6 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     }
     pl->join_verdict = ctrl[8];
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
-    if (ctrl[1] != 0 && getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] wave-exchange factor kernel gave up: code %d\n", ctrl[1]);
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
     pl->fmt = pu->fmt = 1;
     return ILUPP_OK;
