@@ -62,6 +62,8 @@ def _same_kernel(profiled, wanted):
     a = profiled.replace("ilupp::", "").replace("void ", "").split("(")[0].strip()
     if a == wanted:
         return True
+    if "<" in a and "<" not in wanted:
+        return a.split("<", 1)[0] == wanted          # (a kernel named without its template arguments: any instance)
     if "<" not in a or "<" not in wanted:
         return False
     an, aa = a.split("<", 1)
@@ -109,7 +111,12 @@ def cpu_extra(name, d, i, p):
         ref = O.ref()
         A = (d, i, p, True)
         t0 = time.perf_counter()
-        if name == "C4":
+        if name in ("C2H", "C2HP", "S27", "S9"):
+            L, U = ref.ilu0(A)
+            x = np.ones(n)
+            x = ref.trisolve(L, O.LOWER, O.ID, x)
+            x = ref.trisolve(U, O.UPPER, O.ID, x)
+        elif name == "C4":
             ref.icholt(A, 0, 0.0)
         elif name == "ILUC":
             ref.iluc(A, 8, 1e-2)
@@ -131,12 +138,12 @@ def cpu_extra(name, d, i, p):
         sec = time.perf_counter() - t0
         return {"value": nnz / sec, "unit": "nnz/s", "cores": 1, "kind": "reference", "seconds": sec,
                 "sample": "the same matrix once through oracle/_ref (the reference's C++ compiled from /root/reference), construction" +
-                          (" + one apply" if name in ("C5", "C5P", "C5L") else "") + ", one host core"}
+                          (" + one apply" if name in ("C5", "C5P", "C5L", "C2H", "C2HP", "S27", "S9") else "") + ", one host core"}
     except Exception as e:                     # the CPU leg never takes the line down
         return {"value": None, "kind": "failed", "sample": repr(e)}
 
 
-EXTRA_KERNEL = {"C3": "k_ilut_rows_wp", "C4": "k_icholt_df", "ILUC": "k_iluc_df", "C5": "k_piluc_df", "C5M": "k_piluc_df", "C5L": "k_piluc_df",
+EXTRA_KERNEL = {"C2H": None, "C2HP": None, "C3": "k_ilut_rows_wp", "C4": "k_icholt_df", "ILUC": "k_iluc_df", "C5": "k_piluc_df", "C5M": "k_piluc_df", "C5L": "k_piluc_df",
                 "C5P": "k_pilucdp_lds", "S27": "k_ilu0_lvl", "S9": "k_ilu0_lvl"}
 
 
@@ -272,6 +279,50 @@ def batch_config(steps, members=64, n=100000):
             "factor_nnz_total": nnz_f}
 
 
+_COLD = r"""
+import sys, time, json
+sys.path[:0] = [%r, %r]
+import numpy as np, torch
+import matgen
+from ilupp_amd import _native
+g = int(sys.argv[1])
+d, i, p = matgen.poisson3d(g)
+n, nnz = p.shape[0] - 1, int(p[-1])
+dev = torch.device("cuda", 0)
+td, ti, tp = (torch.from_numpy(a).to(dev) for a in (d, i, p))
+x = torch.ones(n, dtype=torch.float64, device=dev)
+y = torch.ones(1 << 20, device=dev).sum().item()          # (the runtime and its first kernel are up)
+torch.cuda.synchronize()
+out = []
+for rep in range(3):
+    t0 = time.perf_counter()
+    P = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True)
+    P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+    out.append(1e3 * (time.perf_counter() - t0))
+    path = P.path(); P = None
+print("COLD " + json.dumps({"ms": out, "path": path, "n": n, "nnz": nnz}))
+"""
+
+
+def cold_config(g):
+    """C2 in a FRESH process through the plain entry (ilupp_hip_ilu0_create_device, no nnz handed in, no shape remembered): the first
+    construction + apply of the process (code objects loaded, pools grown, the pattern proven before anything is assumed), then the second
+    and third -- what the headline's warm loop does not show."""
+    try:
+        r = subprocess.run([sys.executable, "-c", _COLD % (ROOT, os.path.join(ROOT, "tests")), str(g)], capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("COLD ")]
+        if r.returncode != 0 or not line:
+            return {"failed": (r.stderr or r.stdout)[-400:]}
+        rec = json.loads(line[0][5:])
+        fb, ab = algorithmic_bytes(rec["n"], rec["nnz"])
+        ms = rec["ms"]
+        return {"workload": "C2COLD: the headline step (ILU0Preconditioner_device without nnz + one apply, %d^3) in a fresh process: first, second, third call" % g,
+                "path": rec["path"], "first_ms": ms[0], "second_ms": ms[1], "third_ms": ms[2],
+                "first_fraction": (fb + ab) / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, "third_fraction": (fb + ab) / (ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    except Exception as e:
+        return {"failed": repr(e)}
+
+
 def extra_config(name, dev, steps, with_cpu=True):
     """C3 / C4 on device-resident inputs: seconds, factor bytes (read A + write the factors produced), GB/s"""
     import torch
@@ -332,6 +383,14 @@ def extra_config(name, dev, steps, with_cpu=True):
         prm.threshold = 0.3
         make = lambda a: _native.MultilevelILUCDPPreconditioner_device(*a, True, prm)
         what = "C5L: ILUppPreconditioner(default_configuration(1), threshold=0.3), random unsymmetric CSR n=1e6 with a weak diagonal (0.6): a multi-level object"
+    elif name in ("C2H", "C2HP"):
+        # what a matrix that is NOT the benchmark's box gets: the 256^3 7-point mesh with 3 % of its points removed (x-lines of irregular
+        # length: the box-grid templates do not hold, the general analysis decides), and the same matrix under a random symmetric
+        # permutation (no line structure left at all)
+        d, i, p = matgen.mesh_with_holes(256, 5, 0.03, permute=(name == "C2HP"))
+        make = lambda a: _native.ILU0Preconditioner_device(*a, True)
+        what = ("%s: ILU0Preconditioner, 7-point mesh 256^3 with 3 %% of its points removed%s" %
+                (name, ", rows and columns in a random symmetric permutation" if name == "C2HP" else ""))
     elif name in ("S27", "S9"):
         # ILU(0) beyond the 7-point rows of the headline: box stencils (eliminations meet off-diagonal entries)
         dims = (128, 128, 128) if name == "S27" else (2048, 2048)
@@ -364,6 +423,7 @@ def extra_config(name, dev, steps, with_cpu=True):
         P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
         t = P.timings()
         path = P.path() if hasattr(P, "path") else None          # (the multilevel object has no such word: its levels differ)
+        knames = P.kernel_names() if hasattr(P, "kernel_names") else ()
         nnz_out = P.total_nnz + (n if name == "C3" else 0)       # stored entries of the factors (ILUT's total_nnz leaves the unit diagonal out)
         if name in ("C5", "C5M", "C5P", "C5L"):
             t["numeric_kernel_ms"] = t["kernel_ms"]
@@ -382,12 +442,18 @@ def extra_config(name, dev, steps, with_cpu=True):
     torch.cuda.empty_cache()
     cpu = cpu_extra(name, d, i, p) if with_cpu else None
     kernel = EXTRA_KERNEL.get(name)
+    if name in ("C2H", "C2HP", "S27", "S9") and knames:
+        kernel = knames[0]                     # (the library says which kernel factored: ilupp_hip_kernel_names)
     if path == "icholt:grid-static":
         # ICholT(0, 0) of a box grid: the speculative static kernel (icholt_grid.hip) -- A's pattern assumed for every column, verified
         kernel = "k_icholt_grid"
-    ktraffic = measured_traffic(kernel, 256) if kernel == "k_icholt_grid" else None
+    ktraffic = measured_traffic(kernel, 256) if kernel in ("k_icholt_grid", "k_ilut_rows_wp") else None
     return {**more, "workload": what, "path": path, "n": n, "nnz": nnz, "factor_nnz": int(nnz_out), "construct_s": sec,
             "numeric_kernel_ms": kms_med, "first_apply_ms": float(np.median(firsts)), "first_apply_wall_ms": float(np.median(first_walls)),
+            # what a caller waits for before the first preconditioned iteration can start, and its share of the roofline (factor bytes +
+            # one apply's: read the factors, read and write x per solve)
+            "construct_plus_first_apply_s": sec + 1e-3 * float(np.median(first_walls)),
+            "construct_plus_first_apply_fraction": (fbytes + 12 * nnz_out + 8 * (n + 1) + 32 * n) / (sec + 1e-3 * float(np.median(first_walls))) / 1e9 / HBM_PEAK_GBS,
             "first_apply_note": "first_apply_ms / apply_ms are the sweeps' kernel time (GPU events); first_apply_wall_ms is the wall clock of the FIRST apply call, which also builds what the sweeps need (level order of long-row factors, the static records of an LL^T object's factor pair)",
             "apply_ms": float(np.median(apps)),
             "nnz_per_s": nnz / sec, "factor_bytes": fbytes, "achieved_GBs": fbytes / sec / 1e9,
@@ -398,6 +464,7 @@ def extra_config(name, dev, steps, with_cpu=True):
                          "achieved": (fbytes / (kms_med * 1e-3) / 1e9) if kms_med > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (fbytes / (kms_med * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms_med > 0 else None,
                          "traffic": ktraffic,
+                         "traffic_over_algorithmic": (ktraffic / fbytes) if ktraffic else None,
                          "traffic_source": (", ".join(sorted(TRAFFIC_SOURCE)) + " (committed counter passes, not this run)") if ktraffic else None},
             "cpu_baseline": cpu}
 
@@ -411,7 +478,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nrhs", type=int, default=0, help="right-hand sides kept resident (default: one per step, at most 16)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU baseline sample (default: same as --grid)")
-    ap.add_argument("--config", action="append", default=[], choices=["C2", "C3", "C4", "C5", "C5M", "C5P", "C5PB", "C5L", "ILUC", "S27", "S9"],
+    ap.add_argument("--config", action="append", default=[], choices=["C2", "C2COLD", "C2H", "C2HP", "C3", "C4", "C5", "C5M", "C5P", "C5PB", "C5L", "ILUC", "S27", "S9"],
                     help="extra configs measured after the headline one (C2 is always the bench line; default: C3, C4, C5, C5M, C5L, C5P, C5PB, ILUC)")
     ap.add_argument("--no-extra", action="store_true", help="skip the default extra configs (C3, C4, C5, ILUC) and the refactor loop")
     args = ap.parse_args()
@@ -517,6 +584,23 @@ def main():
         # leave the object with the original values (the checksum below is of A itself)
         P.refactor_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr())
         del td2
+    # the same step through the entry the reference's constructor maps to (ilupp_hip_ilu0_create_device: no nnz handed in, so the
+    # construction reads indptr[n] back before it starts), beside the headline's
+    plain = None
+    if world == 1:
+        k = max(3, min(args.steps, 10))
+        for it in range(k + 2):
+            if it == 2:
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+            Pp = None
+            Pp = _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True)
+            Pp.apply_device(txs[it % nrhs].data_ptr(), n, transpose=False, sync=True)
+        torch.cuda.synchronize()
+        pwall = (time.perf_counter() - q0) / k
+        Pp = None
+        plain = {"ms_per_step": 1e3 * pwall, "steps": k,
+                 "what": "ILU0Preconditioner_device without nnz (ilupp_hip_ilu0_create_device, what ILU0Preconditioner(A) on device arrays maps to) + one apply, wall clock per step"}
     # apply(ones) with the last factorisation (untimed): compared, as an array, with the CPU leg's
     tx = txs[0]
     tx.fill_(1.0)
@@ -674,6 +758,10 @@ def main():
                          "frac_of_measured_copy": ((fb / (k_num * 1e-3) / 1e9) / copy_gbs) if (k_num > 0 and copy_gbs) else None},
             "checksum": checksum,
         }
+        if plain is not None:
+            plain["hbm_fraction"] = ((fb + ab) / (plain["ms_per_step"] * 1e-3) / 1e9) / HBM_PEAK_GBS
+            plain["value_nnz_per_s"] = nnz / (plain["ms_per_step"] * 1e-3)
+            out["plain_entry"] = plain
         if refac is not None:
             refac["hbm_fraction"] = ((fb + ab) / (refac["ms_per_step"] * 1e-3) / 1e9) / HBM_PEAK_GBS
             refac["value_nnz_per_s"] = nnz / (refac["ms_per_step"] * 1e-3)
@@ -698,9 +786,11 @@ def main():
         extra = {}
         cfgs = list(args.config)
         if not args.no_extra and world == 1:
-            cfgs = [c for c in ("C3", "C4", "C5", "C5M", "C5L", "C5P", "C5PB", "ILUC") if c not in cfgs] + cfgs
+            cfgs = [c for c in ("C2COLD", "C2H", "C2HP", "C3", "C4", "C5", "C5M", "C5L", "C5P", "C5PB", "ILUC") if c not in cfgs] + cfgs
         for cfg in cfgs:
-            if cfg in ("C3", "C4", "C5", "C5M", "C5P", "C5L", "ILUC", "S27", "S9") and world == 1:
+            if cfg == "C2COLD" and world == 1:
+                extra[cfg] = cold_config(g)
+            elif cfg in ("C2H", "C2HP", "C3", "C4", "C5", "C5M", "C5P", "C5L", "ILUC", "S27", "S9") and world == 1:
                 del_txs = txs[:]        # free the headline workload first
                 txs.clear(); del del_txs
                 extra[cfg] = extra_config(cfg, dev, max(2, min(args.steps, 3)), with_cpu=not args.no_cpu)

@@ -448,8 +448,20 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
     if (!lm) ilu0_unit_diagonal(st, &p->Lc);        // the CSR-streaming factor kernels write the eliminations only
     // rows too long for the level-major forms (9-point, 27-point stencils ...): one wave per row, rows in level order (ilu0_lvl.hip);
     // the sweeps of such factors are the level-ordered ones as well (sptrsv_lvl.hip), nothing below is needed
-    const bool by_level = !lm && A.nnz > 8 * (int64_t)A.n && p->max_row_len <= 64 && A.n >= 1024 &&
-                          lvl_order(st, 2, A.n, A.nnz, A.ptr, A.idx, p->sA, &p->fperm, &p->fperm_levels);
+    // ... and SHORT rows that the static form did not take (a mesh with holes, lines of irregular length): in natural order the
+    // CSR-streaming kernels and the generic sweeps run such a matrix's chains one row after the other behind a window of resident rows
+    // (the 256^3 mesh with 3 % of its points removed: 111 s, and the sweeps ran into their time limit) -- by level it is hundreds of wide
+    // levels.  A matrix whose levels are few and wide anyway (the same mesh randomly permuted: about 30) stays on the streaming kernels.
+    static const bool lvl_never = getenv("ILUPP_NO_LVL_SHORT") != nullptr;
+    bool by_level = false;
+    if (!lm && p->max_row_len <= 64 && A.n >= 1024) {
+        const bool longrows = A.nnz > 8 * (int64_t)A.n;
+        if ((longrows || !lvl_never) && lvl_order(st, 2, A.n, A.nnz, A.ptr, A.idx, p->sA, &p->fperm, &p->fperm_levels)) {
+            // (deep AND wide: a 1-D chain has n levels of one row -- nothing to run side by side, natural order is as good as any)
+            by_level = longrows || (p->fperm_levels > 64 && A.n / p->fperm_levels >= 256);
+            if (!by_level) { (void)pool_free(p->fperm); p->fperm = nullptr; p->fperm_levels = 0; }
+        }
+    }
     if (p->compact && !lm && !by_level) {
         // not a short-row matrix (or an irregular one): descriptors, update program and the CSR-streaming kernels
         if (!(A.nnz >= 16 && build_ilu0_program_f3(st, A, p->Uc, p->sA, &p->prog_f3)))
@@ -651,7 +663,7 @@ static int sweep(ilupp_precond *p, SweepKind kind, const DevMat &M, const Schedu
     // block of consecutive rows.  With blocks, a row waits for everything its lane has to do before it, and the factors of
     // a random matrix have no chains that would make blocks pay: BASELINE config C3's apply took 70 + 186 ms, more than the
     // reference needs on one core.
-    if (M.nnz > 4 * (int64_t)M.n && M.n >= 1024) {
+    if ((M.nnz > 4 * (int64_t)M.n || (p->kind == KIND_LU && p->fperm != nullptr)) && M.n >= 1024) {
         // ... and the rows in level order (sptrsv_lvl.hip; renumbered copy of the factor, built at the first sweep): in natural
         // order only the rows inside the window of resident tickets can run, on a mesh a few grid lines
         LevelSweep *ls = &M == &p->Lc ? &p->lvl[0] : &M == &p->Uc ? &p->lvl[1] : &M == &p->UcT ? &p->lvl[2] : &M == &p->LcT ? &p->lvl[3] : nullptr;

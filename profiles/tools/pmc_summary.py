@@ -42,7 +42,7 @@ def main():
             continue
         kernels[k] = {"FETCH_SIZE_KiB_avg_per_launch": fe.get(k, (0.0, 0))[0], "WRITE_SIZE_KiB_avg_per_launch": wr.get(k, (0.0, 0))[0],
                       "launches_fetch": fe.get(k, (0.0, 0))[1], "launches_write": wr.get(k, (0.0, 0))[1]}
-    json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extra --config C4",
+    json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extra --config C4 --config C3",
                "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in kernels.items():
         print("%-52s fetch %10.1f MiB  write %10.1f MiB  (hbm bytes %.3f GB)" % (

@@ -152,3 +152,20 @@ def box_stencil(dims, diag=None):
     base = np.where(np.asarray(offs) == 0, w, -1.0 + 0.1 * np.sin(np.arange(len(offs))))
     vals = np.broadcast_to(base[None, :], valid.shape)[valid]
     return np.ascontiguousarray(vals, dtype=np.float64), cols.astype(np.int32), indptr.astype(np.int32)
+
+
+def mesh_with_holes(g, seed=5, frac=0.03, permute=False):
+    """The 7-point matrix of a g^3 grid with a fraction of its points removed (their rows and columns deleted): x-lines of irregular
+    length, what a mesh that is not a box looks like to the kernels.  permute: the same matrix under a random symmetric permutation
+    (no ordering left for a schedule to find).  Returns (data, indices, indptr) with int32 indices, columns sorted."""
+    import scipy.sparse as sp
+    d, i, p = poisson3d(g)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    rng = np.random.default_rng(seed)
+    idx = np.flatnonzero(rng.random(n) > frac)
+    if permute:
+        idx = idx[rng.permutation(idx.shape[0])]
+    B = A[idx][:, idx].tocsr()
+    B.sort_indices()
+    return np.ascontiguousarray(B.data, dtype=np.float64), B.indices.astype(np.int32), B.indptr.astype(np.int32)

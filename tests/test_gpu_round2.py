@@ -272,6 +272,29 @@ def test_static_path_rejects_and_falls_back(case):
     assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, O.ID))
 
 
+@pytest.mark.parametrize("permute", [False, True])
+def test_mesh_with_holes_takes_the_level_order_when_its_chains_are_deep(permute):
+    """A box mesh with 3 % of its points removed is no box grid: the static form rejects it.  Its dependency levels are as deep as the
+    box's (64^3: 190), so the factorisation and both sweeps run by level (round 6: in natural order the same matrix at 256^3 took
+    111 s and its sweeps ran into their time limit); the same matrix randomly permuted has few, wide levels and stays on the
+    CSR-streaming kernels.  Both bit-identical to the reference's C++ (`ILU0.hpp:26-106`), factors and apply."""
+    import ilupp_amd as ilupp
+    O, ref = _oracle()
+    d, i, p = matgen.mesh_with_holes(64, 5, 0.03, permute=permute)
+    n = p.shape[0] - 1
+    A = sp.csr_matrix((d, i, p), shape=(n, n))
+    P = ilupp.ILU0Preconditioner(A)
+    assert P.pr.path() == ("ilu0:csr" if permute else "ilu0:level-order"), P.pr.path()
+    Lo, Uo = ref.ilu0((d, i, p, True))
+    L, U = P.factors()
+    assert G.mat_equal((L.data, L.indices, L.indptr, True), Lo) and G.mat_equal((U.data, U.indices, U.indptr, True), Uo)
+    b = G.rhs(n)
+    want = O.orc().apply_lu(Lo, Uo, b, O.ID)
+    for _ in range(2):                      # (the first apply builds the sweeps' level order, the second runs on it)
+        x = b.copy(); P.apply(x)
+        assert np.array_equal(x, want)
+
+
 def test_device_constructors_match_host_constructors():
     """ILUT / IChol0 / ICholT from device-resident inputs (include/ilupp_hip.h *_create_device) = the host-pointer ones"""
     import torch
