@@ -194,6 +194,30 @@ k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restri
 }
 
 // position of every row, length of every row in position order
+// The levels by relaxation (round 6): lev[r] = max over the rows r depends on of lev + 1, every row at once, again and again until
+// nothing changes -- in place, so that within a pass a value travels as far as the order in which the hardware happens to run the rows
+// lets it (rows are walked in the direction of the dependencies).  Any order of updates ends at the same numbers (the operator is
+// monotone and starts from zero).  For patterns with SHORT rows whose levels are deep (a mesh that is no box: 766 levels at 256^3) the
+// pass above walks the chains behind a window of resident blocks: 2.3 s, where this takes the passes' count times 0.1 ms.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_lvl_relax(const int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t *lev, int32_t *__restrict__ changed)
+{
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const int r = MODE == 1 ? n - 1 - (int)g : (int)g;
+    int j0 = ptr[r], j1 = ptr[r + 1];
+    if (j1 > j0) { if (MODE == 1) ++j0; if (MODE == 0) --j1; }
+    int mx = 0;
+    for (int j = j0; j < j1; ++j) {
+        const int c = idx[j];
+        if (MODE == 2 && c >= r) break;
+        const int v = ld_agent_i32(lev + c) + 1;
+        mx = v > mx ? v : mx;
+    }
+    if (mx > lev[r]) { st_agent_i32(lev + r, mx); *changed = 1; }
+}
+
 __global__ void k_lvl_pos(int32_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ ptr, int32_t *__restrict__ pos,
                           int32_t *__restrict__ plen)
 {
@@ -359,7 +383,31 @@ bool lvl_order(hipStream_t st, int mode, int32_t n, int64_t nnz, const int32_t *
 #define LV_LAUNCH(M, WW)                                                                                                        \
     hipLaunchKernelGGL((k_lvl_levels<M, WW>), dim3(grid), dim3(kLvBlock), kLvLds, st, n, ptr, idx, sch.nb, sch.start, sch.B, lev, ctl, ctl + 1)
 #define LV_LAUNCH_W(M) do { if (w == 4) LV_LAUNCH(M, 4); else if (w == 8) LV_LAUNCH(M, 8); else LV_LAUNCH(M, 16); } while (0)
-    if (mode == 0) LV_LAUNCH_W(0); else if (mode == 1) LV_LAUNCH_W(1); else LV_LAUNCH_W(2);
+    static const bool no_relax = getenv("ILUPP_LVL_NO_RELAX") != nullptr;
+    bool relaxed = false;
+    if (per_row <= 4.5 && n >= 65536 && !no_relax) {
+        // short rows: by relaxation, 32 passes between two looks at the flags (one per pass; the last one clear = nothing changed any more)
+        int32_t *flags = nullptr;
+        ILUPP_HIP(pool_malloc(&flags, 32 * sizeof(int32_t)));
+        ILUPP_HIP(hipMemsetAsync(lev, 0, sizeof(int32_t) * (size_t)n, st));
+        const dim3 rg((unsigned)(((int64_t)n + 255) / 256)), rb(256);
+        int32_t hf[32];
+        for (int batch = 0; batch < (1 << 16) && !relaxed; ++batch) {
+            ILUPP_HIP(hipMemsetAsync(flags, 0, 32 * sizeof(int32_t), st));
+            for (int k = 0; k < 32; ++k) {
+                if (mode == 0) hipLaunchKernelGGL((k_lvl_relax<0>), rg, rb, 0, st, n, ptr, idx, lev, flags + k);
+                else if (mode == 1) hipLaunchKernelGGL((k_lvl_relax<1>), rg, rb, 0, st, n, ptr, idx, lev, flags + k);
+                else hipLaunchKernelGGL((k_lvl_relax<2>), rg, rb, 0, st, n, ptr, idx, lev, flags + k);
+            }
+            ILUPP_HIP(d2h_async(st, hf, flags, sizeof(hf)));
+            ILUPP_HIP(stream_sync(st));
+            relaxed = hf[31] == 0;
+        }
+        (void)pool_free(flags);
+        if (!relaxed) ILUPP_HIP(hipMemsetAsync(lev, 0xff, sizeof(int32_t) * (size_t)n, st));     // (65536 x 32 passes were not enough: the pass below)
+    }
+    if (relaxed) { }
+    else if (mode == 0) LV_LAUNCH_W(0); else if (mode == 1) LV_LAUNCH_W(1); else LV_LAUNCH_W(2);
 #undef LV_LAUNCH_W
 #undef LV_LAUNCH
     size_t b1 = 0, b2 = 0;
