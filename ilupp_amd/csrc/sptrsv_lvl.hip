@@ -199,6 +199,22 @@ k_lvl_levels(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restri
 // lets it (rows are walked in the direction of the dependencies).  Any order of updates ends at the same numbers (the operator is
 // monotone and starts from zero).  For patterns with SHORT rows whose levels are deep (a mesh that is no box: 766 levels at 256^3) the
 // pass above walks the chains behind a window of resident blocks: 2.3 s, where this takes the passes' count times 0.1 ms.
+// the farthest dependency of any row (rows sorted by column: the first entry of a lower part, the last of an upper one)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_lvl_reach(const int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t *__restrict__ reach)
+{
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    int d = 0;
+    if (g < n) {
+        const int r = (int)g, j0 = ptr[r], j1 = ptr[r + 1];
+        if (j1 > j0) d = MODE == 1 ? idx[j1 - 1] - r : r - idx[j0];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(reach, d);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_lvl_relax(const int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, int32_t *lev, int32_t *__restrict__ changed)
@@ -385,14 +401,33 @@ bool lvl_order(hipStream_t st, int mode, int32_t n, int64_t nnz, const int32_t *
 #define LV_LAUNCH_W(M) do { if (w == 4) LV_LAUNCH(M, 4); else if (w == 8) LV_LAUNCH(M, 8); else LV_LAUNCH(M, 16); } while (0)
     static const bool no_relax = getenv("ILUPP_LVL_NO_RELAX") != nullptr;
     bool relaxed = false;
-    if (per_row <= 4.5 && n >= 65536 && !no_relax) {
+    static const bool relax_all = getenv("ILUPP_LVL_RELAX_ALL") != nullptr;
+    // The relaxation takes about as many passes as there are levels (measured: 672 for 766 levels, 5 500 for 6 141), the pass above a
+    // time per row that depends on how far a row's dependencies reach (9 ns per row on a 9-point 2048^2 matrix, reach 2 049; 140 ns on
+    // the 3-D mesh with holes, reach 63 000, at every size).  For mesh-like patterns the number of levels is about 3 n / reach
+    // (2-D: reach = sqrt n, 3 sqrt n levels; 3-D: n^(2/3), 3 n^(1/3)): the relaxation where that estimate is at most 1 024.
+    bool relax_ok = false;
+    if ((per_row <= 4.5 || relax_all) && n >= 65536 && !no_relax) {
+        const dim3 rg((unsigned)(((int64_t)n + 255) / 256)), rb(256);
+        if (mode == 1) hipLaunchKernelGGL((k_lvl_reach<1>), rg, rb, 0, st, n, ptr, idx, ctl + 4);
+        else hipLaunchKernelGGL((k_lvl_reach<0>), rg, rb, 0, st, n, ptr, idx, ctl + 4);
+        int32_t reach = 0;
+        ILUPP_HIP(d2h_async(st, &reach, ctl + 4, sizeof(reach)));
+        ILUPP_HIP(stream_sync(st));
+        relax_ok = relax_all || (reach > 0 && 3.0 * (double)n / (double)reach <= 1024.0);
+        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] level numbering (mode %d, n %d): dependencies reach %d rows: %s\n", mode, n, reach, relax_ok ? "by relaxation" : "in natural order");
+    }
+    if (relax_ok) {
         // short rows: by relaxation, 32 passes between two looks at the flags (one per pass; the last one clear = nothing changed any more)
         int32_t *flags = nullptr;
         ILUPP_HIP(pool_malloc(&flags, 32 * sizeof(int32_t)));
         ILUPP_HIP(hipMemsetAsync(lev, 0, sizeof(int32_t) * (size_t)n, st));
         const dim3 rg((unsigned)(((int64_t)n + 255) / 256)), rb(256);
         int32_t hf[32];
-        for (int batch = 0; batch < (1 << 16) && !relaxed; ++batch) {
+        static const int max_batches = getenv("ILUPP_LVL_RELAX_BATCHES") ? atoi(getenv("ILUPP_LVL_RELAX_BATCHES")) : 64;
+        int batches = 0;
+        for (int batch = 0; batch < max_batches && !relaxed; ++batch) {
+            ++batches;
             ILUPP_HIP(hipMemsetAsync(flags, 0, 32 * sizeof(int32_t), st));
             for (int k = 0; k < 32; ++k) {
                 if (mode == 0) hipLaunchKernelGGL((k_lvl_relax<0>), rg, rb, 0, st, n, ptr, idx, lev, flags + k);
@@ -404,7 +439,8 @@ bool lvl_order(hipStream_t st, int mode, int32_t n, int64_t nnz, const int32_t *
             relaxed = hf[31] == 0;
         }
         (void)pool_free(flags);
-        if (!relaxed) ILUPP_HIP(hipMemsetAsync(lev, 0xff, sizeof(int32_t) * (size_t)n, st));     // (65536 x 32 passes were not enough: the pass below)
+        if (getenv("ILUPP_DEBUG")) fprintf(stderr, "[ilupp] level numbering by relaxation (mode %d, n %d): %d batches of 32 passes, %s\n", mode, n, batches, relaxed ? "converged" : "given up");
+        if (!relaxed) ILUPP_HIP(hipMemsetAsync(lev, 0xff, sizeof(int32_t) * (size_t)n, st));     // (2 048 passes were not enough: the pass below)
     }
     if (relaxed) { }
     else if (mode == 0) LV_LAUNCH_W(0); else if (mode == 1) LV_LAUNCH_W(1); else LV_LAUNCH_W(2);
