@@ -36,7 +36,8 @@
 // the gathered entries (up to 262144 per column) and the touch records of a row (up to 65536) in global memory; beyond that
 // the factorisation is refused.
 // A column that loses its diagonal (indefinite input: the pivot's square root is NaN; a negative add_fill_in that leaves a
-// budget below 1) is an error here ("not positive definite"), where the reference silently returns a NaN-filled factor.
+// budget below 1) is an error here ("not positive definite"), where the reference silently returns a factor with EMPTY columns
+// (a NaN pivot makes every entry of its column NaN and none of them passes the threshold test); ILUPP_REFERENCE_NANS=1 gives that factor.
 #include <stdlib.h>
 
 #include <mutex>
@@ -104,7 +105,7 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
             int32_t add, double tau, int32_t T, int32_t nq, const int32_t *__restrict__ Loff,
             int32_t *Lidx, double *Lval, int32_t *Llen,
             int32_t *cnt, unsigned long long *rec, int32_t *pending, int32_t *rq, int32_t *ctrl,
-            unsigned char *gws, int32_t gNE, int32_t gNS, int32_t gTM)
+            unsigned char *gws, int32_t gNE, int32_t gNS, int32_t gTM, int32_t refnans)
 {
     __shared__ int s_erow[kLdsNE], s_eslot[kLdsNE];
     __shared__ double s_eval[kLdsNE];
@@ -373,7 +374,10 @@ k_icholt_df(int32_t m, const int32_t *__restrict__ Aptr, const int32_t *__restri
         //   3: the pivot is NaN (the matrix is not positive definite); 4: a finite pivot that the threshold or the top-k budget dropped
         if (nk < 1 || __builtin_amdgcn_readfirstlane(srank[0]) != 0) {
             const double piv = sval[0];
-            CT_FAIL(piv != piv ? 3 : 4);
+            // (ILUPP_REFERENCE_NANS=1: what the reference does with a NaN pivot -- every entry of the column is NaN, none passes
+            // `|w| > norm * tau`, the column is stored EMPTY, and its NaNs reach the diagonals of the rows it touches through the
+            // records below, whose columns end the same way: IChol.hpp:115-141, dropping.hpp:15-21)
+            if (!(refnans != 0 && piv != piv && nk == 0)) CT_FAIL(piv != piv ? 3 : 4);
         }
 
         // ---- append  (sparse_implementation.h:3170-3186) ----
@@ -523,7 +527,8 @@ static int icholt_attempt(hipStream_t st, const DevMat &Atri, int32_t add_fill_i
     ILUPP_HIP(hipEventCreate(&e0));
     ILUPP_HIP(hipEventCreate(&e1));
     ILUPP_HIP(hipEventRecord(e0, st));
-#define ICT_ARGS m, Atri.ptr, Atri.idx, Atri.val, add_fill_in, threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl, gws, gNE, gNS, gTM
+    static const int refnans = getenv("ILUPP_REFERENCE_NANS") != nullptr ? 1 : 0;
+#define ICT_ARGS m, Atri.ptr, Atri.idx, Atri.val, add_fill_in, threshold, T, nq, Loff, Lidx, Lval, Llen, cnt, rec, pending, rq, ctrl, gws, gNE, gNS, gTM, refnans
     if (cls == 0)
         hipLaunchKernelGGL((k_icholt_df<128, 64, kCtTtiny, false>), dim3(waves), dim3(64), 0, st, ICT_ARGS);
     else if (small)

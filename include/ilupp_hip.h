@@ -46,8 +46,10 @@ typedef enum {
     ILUPP_ERR_TIMEOUT = -7,        /* dependency wait exceeded its bound (cyclic/invalid structure) */
     ILUPP_ERR_UNSUPPORTED = -8,    /* path not built yet in this round */
     ILUPP_ERR_MEMORY = -9,         /* sparse_implementation.h:3178-3179 "insufficient memory reserved" */
-    ILUPP_ERR_NOT_SPD = -10,       /* ICholT: the pivot of a column is NaN (the matrix is not positive definite); the reference
-                                      returns a NaN-filled factor for such input (IChol.hpp:115-117 has no positivity check) */
+    ILUPP_ERR_NOT_SPD = -10,       /* ICholT: the pivot of a column is NaN (the matrix is not positive definite).  The reference has no
+                                      positivity check (IChol.hpp:115-117): such a column's entries are all NaN, none passes the threshold
+                                      test, the column is stored empty and its NaNs spread through the diagonals it touched.  With
+                                      ILUPP_REFERENCE_NANS=1 in the environment this library returns exactly that factor instead */
     ILUPP_ERR_INTERNAL = -12,      /* an invariant of this build does not hold (a bug here, never a property of the input) */
     ILUPP_ERR_NOT_CONVERGED = -13, /* ilupp_hip_solve: binding.cpp:227 "did not converge" */
     ILUPP_ERR_DIAG_DROPPED = -11   /* ICholT: a finite pivot was dropped by the threshold or the top-k budget (dropping.hpp:8-34 does not
