@@ -2396,12 +2396,10 @@ __global__ void __launch_bounds__((WaCfg<NCW, D>::Threads), (NCW == 2 ? 4 : 3))
 k_ilu0_wa(WfArgs A)
 {
     typedef WaCfg<NCW, D> C;
-    constexpr int U = C::U, NL = C::NL;
+    constexpr int NL = C::NL;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ int s_cnt[4], s_total;
     __shared__ unsigned s_ticket;
-    WfPair *s_pairs = reinterpret_cast<WfPair *>(lds);
-    int *s_exp = reinterpret_cast<int *>(lds + 64 * sizeof(WfPair));
     if (threadIdx.x == 0) {
         // Which tile: the next ticket -- or (experiment, flags bit 0; only when every workgroup of the launch is resident at once) the
         // next tile of THIS XCD's class (tile mod 8 = XCD).  The hardware starts the workgroups of one XCD in a row, so plain tickets
