@@ -118,3 +118,37 @@ def test_old_kernel_is_named_when_it_runs(reference_run):
 def test_medium_grid_default_against_old():
     a, b = _run("default", "big"), _run("old", "big")
     assert {k: v[0] for k, v in a.items()} == {k: v[0] for k, v in b.items()}
+
+
+def test_random_box_shapes_predicted_sizes_and_edge_tiles():
+    """Box grids of random dimensions (patches cut by the domain in y and z, lines of 16 .. 90 rows, more or fewer tiles than the chip
+    has workgroups): the closed-form analysis' predicted sizes must be what the device finds (a mismatch redoes the construction the
+    general way and shows as another path), and factors + apply are the oracle's bits.  ILUPP_FUZZ_OFFSET shifts the seed."""
+    import numpy as np
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import matgen
+    import scipy.sparse as sp
+    import ilupp_amd as ilupp
+    from oracle import oracle as O
+    rng = np.random.default_rng(4242 + int(os.environ.get("ILUPP_FUZZ_OFFSET", "0")))
+    done = 0
+    while done < 10:
+        nx, ny, nz = int(rng.integers(16, 91)), int(rng.integers(8, 71)), int(rng.integers(8, 71))
+        if nx * ny * nz < (1 << 16) or ny * nz < 512:
+            continue
+        done += 1
+        d, i, p = matgen.poisson3d(nx, ny, nz)
+        d = d * (1.0 + 0.3 * rng.random(d.shape[0]))
+        n = p.shape[0] - 1
+        A = sp.csr_matrix((d, i, p), shape=(n, n))
+        P = ilupp.ILU0Preconditioner(A)
+        assert P.pr.path() == "ilu0:static-direct", ((nx, ny, nz), P.pr.path())
+        assert P.pr.analysis_path() == "grid", ((nx, ny, nz), P.pr.analysis_path())
+        assert "k_ilu0_wa<0, 4, 4>" in P.pr.kernel_names()[0]
+        Lo, Uo = O.orc().ilu0((d, i, p, True))
+        L, U = P.factors()
+        assert np.array_equal(L.indptr, Lo[2]) and np.array_equal(L.indices, Lo[1]) and np.array_equal(U.indptr, Uo[2]) and np.array_equal(U.indices, Uo[1]), (nx, ny, nz)
+        assert np.array_equal(L.data, Lo[0]) and np.array_equal(U.data, Uo[0]), (nx, ny, nz)
+        b = rng.random(n)
+        x = b.copy(); P.apply(x)
+        assert np.array_equal(x, O.orc().apply_lu(Lo, Uo, b, O.ID)), (nx, ny, nz)
