@@ -535,11 +535,11 @@ int ilu0_factor(ilupp_precond *p, const DevMat &A, const int32_t *head)
         p->sA.release(); p->sU.release();
         p->sA = Schedule(); p->sU = Schedule();
         p->grid_path = false;
-        grid_shape_forget(A.n, A.nnz);
+        grid_shape_forget(A.n, A.nnz, A.idx);
         if (p->no_general_retry) return ILUPP_ERR_UNSUPPORTED;
         return ilu0_factor(p, A, nullptr);
     }
-    if (grid && rc == ILUPP_OK) grid_shape_remember(A.n, A.nnz, gd);
+    if (grid && rc == ILUPP_OK) grid_shape_remember(A.n, A.nnz, gd, A.idx);
     if (grid && grid_mode == 0 && wx_numeric && rc == ILUPP_OK) {
         // (the proof ends in front of the factor kernel, behind the launches that clear its control words: the analysis phase lasts until
         // the event in front of that kernel, ev[4], not until a1)
@@ -944,7 +944,7 @@ int ilupp_hip_ilu0_create_device_nnz(const double *d_data, const int32_t *d_indi
         if (n <= 0 || !d_indptr) { set_error("matrix has size 0!"); return ILUPP_ERR_INVALID; }
         // the dimensions a matrix of this size had when it last was a box grid: the head a grid of those dimensions has (nothing is read)
         GridDims gd = {0, 0, 0};
-        if (nnz > 0 && nnz < (1LL << 31) && grid_shape_recall(n, nnz, &gd)) {
+        if (nnz > 0 && nnz < (1LL << 31) && grid_shape_recall(n, nnz, &gd, d_indices)) {
             int32_t head[10] = {0, gd.nz > 1 ? 4 : 3, 0, 1, gd.nx, gd.nz > 1 ? gd.nx * gd.ny : -1, -1, -1, -1, -1};
             DevMat A;
             A.n = n; A.nnz = nnz; A.is_csr = true; A.owns = false;

@@ -317,9 +317,9 @@ bool wx_vec_on();            // st_wave.hip: the sweeps move the caller's vector
 // grid.hip: the first analysis pass for lexicographic box-grid stencil matrices (guess from row 0, proof on a side stream)
 struct GridDims { int32_t nx, ny, nz; };
 bool grid_guess(int32_t n, int64_t nnz, const int32_t *head /* ptr[0], ptr[1], idx[0..7] */, GridDims *g);
-bool grid_shape_recall(int32_t n, int64_t nnz, GridDims *g);
-void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g);
-void grid_shape_forget(int32_t n, int64_t nnz);
+bool grid_shape_recall(int32_t n, int64_t nnz, GridDims *g, const void *idx);
+void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g, const void *idx);
+void grid_shape_forget(int32_t n, int64_t nnz, const void *idx);
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
 bool grid_llt_schedule(hipStream_t st, int32_t n, const GridDims &g, int max_lanes, Schedule *bwd);
 void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc, bool with_pattern = false);

@@ -58,26 +58,52 @@ bool grid_guess(int32_t n, int64_t nnz, const int32_t *head, GridDims *g)
 // the dimensions of the box grids this process has factored, by (n, nnz): ilupp_hip_ilu0_create_device_nnz guesses them again without
 // reading the matrix' head back (a guess, nothing more: the proof runs every time)
 namespace {
-struct ShapeMemo { std::mutex mu; std::vector<std::pair<std::pair<int64_t, int64_t>, GridDims>> seen; } g_shapes;
+// (n, nnz) -> dimensions, with the index array's address as a hint: two matrices of equal size and entry count but other dimensions
+// (64 x 128 x 256 and 128 x 64 x 256) live in different arrays and keep an entry each; a lookup prefers the entry of the same array
+struct ShapeEntry { int64_t n, nnz; const void *idx; GridDims g; };
+struct ShapeMemo { std::mutex mu; std::vector<ShapeEntry> seen; } g_shapes;
 }
-bool grid_shape_recall(int32_t n, int64_t nnz, GridDims *g)
+bool grid_shape_recall(int32_t n, int64_t nnz, GridDims *g, const void *idx)
 {
     std::lock_guard<std::mutex> lk(g_shapes.mu);
-    for (const auto &e : g_shapes.seen) if (e.first.first == n && e.first.second == nnz) { *g = e.second; return true; }
+    const ShapeEntry *any = nullptr;
+    for (const auto &e : g_shapes.seen) {
+        if (e.n != n || e.nnz != nnz) continue;
+        if (e.idx == idx) { *g = e.g; return true; }
+        any = &e;                                       // (the most recent one of that size)
+    }
+    if (any) { *g = any->g; return true; }
     return false;
 }
-void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g)
+void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g, const void *idx)
 {
     std::lock_guard<std::mutex> lk(g_shapes.mu);
-    for (auto &e : g_shapes.seen) if (e.first.first == n && e.first.second == nnz) { e.second = g; return; }
+    for (size_t i = 0; i < g_shapes.seen.size(); ++i) {
+        auto &e = g_shapes.seen[i];
+        if (e.n == n && e.nnz == nnz && e.idx == idx) {
+            // (moved to the back: the most recent entry of a size is what a lookup from another array gets)
+            ShapeEntry m = e; m.g = g;
+            g_shapes.seen.erase(g_shapes.seen.begin() + (long)i);
+            g_shapes.seen.push_back(m);
+            return;
+        }
+    }
     if (g_shapes.seen.size() >= 64) g_shapes.seen.erase(g_shapes.seen.begin());
-    g_shapes.seen.push_back({{n, nnz}, g});
+    g_shapes.seen.push_back({n, nnz, idx, g});
 }
-void grid_shape_forget(int32_t n, int64_t nnz)
+void grid_shape_forget(int32_t n, int64_t nnz, const void *idx)
 {
     std::lock_guard<std::mutex> lk(g_shapes.mu);
-    for (size_t i = 0; i < g_shapes.seen.size(); ++i)
-        if (g_shapes.seen[i].first.first == n && g_shapes.seen[i].first.second == nnz) { g_shapes.seen.erase(g_shapes.seen.begin() + (long)i); return; }
+    // the entry of this array if there is one, else the one a lookup from this array got (the most recent of that size)
+    long hit = -1, last = -1;
+    for (size_t i = 0; i < g_shapes.seen.size(); ++i) {
+        const auto &e = g_shapes.seen[i];
+        if (e.n != n || e.nnz != nnz) continue;
+        last = (long)i;
+        if (e.idx == idx) hit = (long)i;
+    }
+    const long victim = hit >= 0 ? hit : last;
+    if (victim >= 0) g_shapes.seen.erase(g_shapes.seen.begin() + victim);
 }
 
 // One row per lane.  The eight index words a row can reach from its expected start are fetched with two 16-byte loads whatever the

@@ -209,3 +209,30 @@ def test_construction_with_the_number_of_entries_handed_in():
     # a count that is not indptr[n]
     with pytest.raises(RuntimeError, match="number of stored entries"):
         _native.ILU0Preconditioner_device(td.data_ptr(), ti.data_ptr(), tp.data_ptr(), n, True, nnz=nnz - 7)
+
+
+def test_two_grids_of_equal_size_and_entry_count_keep_their_shapes():
+    """64 x 32 x 40 and 32 x 64 x 40 have the same n and nnz: the remembered shapes are kept per index array, so that
+    alternating between the two neither evicts the other's shape nor ends anywhere but on the grid analysis with the right bits"""
+    import torch
+    from ilupp_amd import _native
+    dev = torch.device("cuda", 0)
+    mats = []
+    for dims in ((64, 32, 40), (32, 64, 40)):
+        d, i, p = matgen.poisson3d(*dims)
+        d = _unsym(d, 3)
+        n, nnz = p.shape[0] - 1, int(p[-1])
+        t = tuple(torch.from_numpy(a).to(dev) for a in (d, i, p))
+        Ph = _native.ILU0Preconditioner(d, i, p, True)
+        b = np.random.default_rng(2).random(n)
+        want = b.copy(); Ph.apply(want)
+        mats.append((t, n, nnz, b, want))
+    assert mats[0][1] == mats[1][1] and mats[0][2] == mats[1][2]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for (t, n, nnz, b, want) in mats:
+            P = _native.ILU0Preconditioner_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, True, nnz=nnz)
+            assert P.analysis_path() == "grid"
+            x = torch.from_numpy(b).to(dev)
+            P.apply_device(x.data_ptr(), n, transpose=False, sync=True)
+            assert np.array_equal(x.cpu().numpy(), want)
