@@ -1880,6 +1880,45 @@ __device__ __forceinline__ void wa_loader(const WfArgs &A, unsigned char *lds, c
 #ifdef WX_STAMP
     unsigned long long iacc_ = 0, vacc_ = 0, sacc_ = 0;
 #endif
+#ifndef WA_NO_PAIR
+    // Two blocks at a time, the two windows of a lane right behind each other: the memory line they share is asked for once (the
+    // windows start where the rows start, so consecutive windows of a lane overlap in a line; profiles/r06_cu_stream.txt: 37 against
+    // 30 GB/s of new bytes per CU).  The ring then has two blocks in flight and four steps of lead for the first of a pair instead of
+    // three and six -- and the kernel takes 0.84 ms instead of 0.90 at 256^3 (-DWA_NO_PAIR: one block every two steps).
+#define WAL_ISSUE2(s0_, s1_)                                                                                         \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(lds + lw * C::WaveRing + (s0_) * kWdWaveBlk + q * 1024), 16, g[q], 0, 0, WA_DMA_AUX); \
+            g[q] += S[q];                                                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(lds + lw * C::WaveRing + (s1_) * kWdWaveBlk + q * 1024), 16, g[q], 0, 0, WA_DMA_AUX); \
+            g[q] += S[q];                                                                                            \
+        }                                                                                                            \
+        asm volatile("" ::: "memory");                                                                               \
+    } while (0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ln == 0) wa_set<C>(lds, WA_LF + lw, tlo + 7);
+    for (int tb = tlo; tb < thiR; tb += U) {
+#pragma unroll
+        for (int bb = 1; bb < U / 2; bb += 2) {
+            const int need = tb + 2 * bb - 1;                       // blocks bb - 1 and bb have been read: their slots take blocks + D
+            if (!dead) {
+                unsigned spins = 0;
+                while (wa_cnt<C>(lds, WA_CP + lw) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0) {
+                        if (spins > kWaSpinLimit) { atomicExch(&A.ctrl[1], 1); wa_set<C>(lds, WA_DEAD, 1); }
+                        if (wa_cnt<C>(lds, WA_DEAD) != 0) { dead = true; break; }
+                    }
+                }
+            }
+            // the pair before has landed (asked for four steps ago): said so before this pair's sixteen instructions go out
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ln == 0) wa_set<C>(lds, WA_LF + lw, tb + 2 * bb + 5);
+            WAL_ISSUE2((bb - 1) % D, bb % D);
+        }
+    }
+#undef WAL_ISSUE2
+#else
     for (int tb = tlo; tb < thiR; tb += U) {
 #pragma unroll
         for (int bb = 0; bb < U / 2; ++bb) {
@@ -1915,6 +1954,7 @@ __device__ __forceinline__ void wa_loader(const WfArgs &A, unsigned char *lds, c
             if (ln == 0) wa_set<C>(lds, WA_LF + lw, tb + 2 * bb + 5);
         }
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef WX_STAMP
     if (ln == 0 && wg < 4096 && lw == 0) { g_wf_wait[wg * 16 + 5] = sacc_; g_wf_wait[wg * 16 + 6] = iacc_; g_wf_wait[wg * 16 + 7] = vacc_; }
