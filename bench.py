@@ -10,7 +10,7 @@ A "step" = one complete ILU(0) factorisation of the device-resident CSR matrix (
 i.e. exactly what `P = ilupp.ILU0Preconditioner(A); P.apply(x)` does, with A and x already in HBM
 when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu] [--no-extra] [--config C3|C4|ILUC|S27|S9]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu] [--no-extra] [--config C2COLD|C2H|C2HP|C3|C4|ILUC|S27|S9]
 
 N > 1: the path does not shard (a single factorisation is one dependency chain), so every rank
 factors its own matrix of a batch (weak scaling, no data-path collective; RCCL only for the barrier,
@@ -18,9 +18,12 @@ the max-over-ranks time and one gather of per-matrix records).  Launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU);
 run without a launcher, `--gpus N` starts that launcher itself -- before anything touches the GPU.
 
-The default run (one GPU) also measures C3, C4, one ILUC config and the multilevel configs (C5: one level, C5M: with the matching, C5L: a
-5-level object, C5P: config 5 as named, C5PB: 64 of those side by side) after the headline one (about 40 s; --no-extra skips them)
-and a re-factorisation with new values on the analysed pattern ("refactor").
+The default run (one GPU) also measures what a matrix that is NOT the benchmark's box gets (C2COLD: the headline step in a fresh process
+through the plain entry; C2H: the 256^3 mesh with 3 % of its points removed; C2HP: the same under a random symmetric permutation), C3, C4,
+one ILUC config and the multilevel configs (C5: one level, C5M: with the matching, C5L: a 5-level object, C5P: config 5 as named, C5PB: 64
+of those side by side) after the headline one (about a minute; --no-extra skips them), the same step through the entry without the
+entry count ("plain_entry") and a re-factorisation with new values on the analysed pattern ("refactor").  Every extra carries path, roofline,
+the reference's CPU figure and construct_plus_first_apply_s.
 --config C3 / C4 add the other BASELINE configs as extra keys of the same JSON line ("extra"):
 ILUT(10, 1e-4) on the random diagonally dominant matrix with n = 1e6, ICholT(0, 0) on the 256^3 matrix
 (bytes = read A + write the factors actually produced).  --config S27 / S9: ILU(0) beyond 7-point rows (27-point box
