@@ -614,6 +614,75 @@ __global__ void k_ptr_from_sorted(int32_t n, int64_t nnz, const int32_t *__restr
     tptr[c] = (int32_t)lo;
 }
 
+// Short slices (stencil-like factors: the first apply of an LL^T object, the transposed apply of an ILU(0) object): count, scan, scatter
+// with one atomic per entry, then every new slice sorts its few entries in registers -- the same arrays as the sort by column below
+// (a (row, column) pair occurs once: the order inside a slice is determined), without three radix passes over all entries
+// (256^3, ICholT(0, 0): 2.8 -> 0.6 ms of the first apply).  A slice of more than kTrMax entries sends the matrix the other way.
+static constexpr int kTrMax = 8;
+__global__ void k_tr_count(int64_t nnz, const int32_t *__restrict__ idx, int32_t *__restrict__ cnt)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < nnz; e += stride) atomicAdd(&cnt[idx[e]], 1);
+}
+__global__ void k_tr_scatter(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, const double *__restrict__ val,
+                             const int32_t *__restrict__ tptr, int32_t *__restrict__ fill, int32_t *__restrict__ tidx, double *__restrict__ tval)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int q = ptr[r]; q < ptr[r + 1]; ++q) {
+        const int c = idx[q];
+        const int pos = tptr[c] + atomicAdd(&fill[c], 1);
+        tidx[pos] = r; tval[pos] = val[q];
+    }
+}
+__global__ void k_tr_sort(int32_t n, const int32_t *__restrict__ tptr, int32_t *__restrict__ tidx, double *__restrict__ tval, int32_t *__restrict__ toolong)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int p0 = tptr[c], len = tptr[c + 1] - p0;
+    if (len > kTrMax) { atomicOr(toolong, 1); return; }
+    int ki[kTrMax]; double kv[kTrMax];
+#pragma unroll
+    for (int a = 0; a < kTrMax; ++a) { ki[a] = a < len ? tidx[p0 + a] : 0x7fffffff; kv[a] = a < len ? tval[p0 + a] : 0.0; }
+    // (a fixed network of compare-exchanges: the arrays stay in registers)
+#pragma unroll
+    for (int a = 0; a < kTrMax; ++a)
+#pragma unroll
+        for (int b = 0; b + 1 < kTrMax - a; ++b)
+            if (ki[b] > ki[b + 1]) { const int ti = ki[b]; ki[b] = ki[b + 1]; ki[b + 1] = ti; const double tv = kv[b]; kv[b] = kv[b + 1]; kv[b + 1] = tv; }
+#pragma unroll
+    for (int a = 0; a < kTrMax; ++a) if (a < len) { tidx[p0 + a] = ki[a]; tval[p0 + a] = kv[a]; }
+}
+static bool transpose_short(hipStream_t st, const DevMat &A, DevMat *T)
+{
+    const int32_t n = A.n;
+    const int64_t nnz = A.nnz;
+    int32_t *cnt = nullptr, *flag = nullptr;
+    void *tmp = nullptr;
+    ILUPP_HIP(pool_malloc(&cnt, sizeof(int32_t) * ((size_t)n + 1)));
+    ILUPP_HIP(pool_malloc(&flag, 16));
+    ILUPP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n + 1), st));
+    ILUPP_HIP(hipMemsetAsync(flag, 0, 16, st));
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_tr_count, dim3((unsigned)blocks), dim3(256), 0, st, nnz, A.idx, cnt);
+    size_t tb = 0;
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, T->ptr, n + 1, st));
+    ILUPP_HIP(pool_malloc(&tmp, tb > 0 ? tb : 16));
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, T->ptr, n + 1, st));
+    ILUPP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)n, st));
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_tr_scatter, g, b, 0, st, n, A.ptr, A.idx, A.val, T->ptr, cnt, T->idx, T->val);
+    hipLaunchKernelGGL(k_tr_sort, g, b, 0, st, n, T->ptr, T->idx, T->val, flag);
+    int32_t h = 0;
+    ILUPP_HIP(d2h_async(st, &h, flag, sizeof(h)));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(tmp)); ILUPP_HIP(pool_free(cnt)); ILUPP_HIP(pool_free(flag));
+    return h == 0;
+}
+
 void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
 {
     const int32_t n = A.n;
@@ -622,6 +691,8 @@ void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
     ILUPP_HIP(pool_malloc(&T->ptr, sizeof(int32_t) * (size_t)(n + 1)));
     ILUPP_HIP(pool_malloc(&T->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
     ILUPP_HIP(pool_malloc(&T->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
+    static const bool no_short = getenv("ILUPP_NO_SHORT_TRANSPOSE") != nullptr;
+    if (!no_short && n >= 4096 && nnz > 0 && nnz <= 8 * (int64_t)n && transpose_short(st, A, T)) return;
     int32_t *rowid, *seq, *keys_out, *perm;
     const size_t eb = sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1);
     ILUPP_HIP(pool_malloc(&rowid, eb));
