@@ -223,6 +223,7 @@ struct ilupp_precond {
     bool apply_events_valid = false;
     int max_lanes = 65536;
     bool icholt_grid = false;    // ICholT(0, 0.0): built by the speculative static kernel for box grids (icholt_grid.hip)
+    GridDims llt_gd = {0, 0, 0};  // ... and the grid it was (the row-major copy for the sweeps follows from it)
     bool grid_path = false;      // ILU(0): the row blocks came from grid.hip's guess (proven for every row)
     bool no_general_retry = false;   // (ilupp_hip_ilu0_create_device_nnz) a grid guess that fails ends the attempt: the caller reads the head and starts over
     bool verdict_clean = false;  // ctrl[8] (the verdict word of grid.hip's proof) is zero already
@@ -607,7 +608,7 @@ void ensure_transposed(ilupp_precond *p)
         if (schedule_is_compact(p->sLT)) make_desc(st, p->LcT, p->sLT, &p->dLT);
         if (schedule_is_compact(p->sUT)) make_desc(st, p->UcT, p->sUT, &p->dUT);
     } else {
-        transpose_storage(st, p->Lc, &p->LcT);
+        transpose_storage(st, p->Lc, &p->LcT, (p->icholt_grid && !p->llt_diag_last && p->llt_gd.nx > 0) ? &p->llt_gd : nullptr);
         if (min_row_len(st, p->n, p->LcT.ptr, p->LcT.idx, p->llt_diag_last ? 1 : 2) == 0) p->degenerate = true;
         // Lc row-major lower (IChol0): LcT is upper with the diagonal first -> backward sweep;
         // Lc column-major lower (ICholT): LcT is its row-major form with the diagonal last -> forward sweep
@@ -1388,6 +1389,7 @@ static int icholt_create_common(DevMat &A, int32_t n, int is_csr, int32_t add_fi
             ILUPP_HIP(stream_sync(q));
             const auto w2 = std::chrono::steady_clock::now();
             p->icholt_grid = icholt_grid_finish(st, &job, &kms);
+            if (p->icholt_grid) p->llt_gd = gd;
             if (getenv("ILUPP_IG_DEBUG")) {
                 const auto w3 = std::chrono::steady_clock::now();
                 fprintf(stderr, "icholt_grid host: launch %.3f ms, sweep schedule %.3f ms, wait %.3f ms\n", std::chrono::duration<double, std::milli>(w1 - w0).count(),

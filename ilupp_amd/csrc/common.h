@@ -322,6 +322,7 @@ void grid_shape_remember(int32_t n, int64_t nnz, const GridDims &g, const void *
 void grid_shape_forget(int32_t n, int64_t nnz, const void *idx);
 void grid_check_launch(hipStream_t side, const DevMat &A, const GridDims &g, int32_t *d_bad);
 bool grid_llt_schedule(hipStream_t st, int32_t n, const GridDims &g, int max_lanes, Schedule *bwd);
+bool llt_grid_rows(hipStream_t st, const DevMat &Lc, const GridDims &g, DevMat *T);      // row-major copy of a column-major factor with the grid's lower pattern
 void make_desc_llt_grid(hipStream_t st, const DevMat &M, const Schedule &sch, const GridDims &g, int32_t **desc, bool with_pattern = false);
 void grid_schedules(hipStream_t st, const DevMat &A, const GridDims &g, DevMat *L, DevMat *U, Schedule *fwd, Schedule *bwd,
                     int32_t *max_row_len, int max_wgs);
@@ -346,7 +347,7 @@ int csr_ptrs_from_counts(hipStream_t st, int32_t n, int32_t *counts, DevMat *M);
 int st_make_csr(hipStream_t st, int32_t n, const PackedSweep &pl, const PackedSweep &pu, DevMat *L, DevMat *U);
 int count_cuts_and_schedule(hipStream_t st, int32_t n, const int32_t *ptr, const int32_t *idx,
                             int max_lanes, Schedule *fwd, Schedule *bwd, int32_t *max_row_len);
-void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T);
+void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T, const GridDims *llt_grid = nullptr);
 // The order vector_dense<T>::quicksort(index_list&, left, right) (sparse_implementation.h:471-505) leaves keys and their list in: an
 // unstable quicksort with the first element as pivot -- where keys are equal, the permutation that comes out IS the reference's answer,
 // so the same partition scheme runs here (host; the smaller part by recursion, the larger by the loop: the two parts are disjoint, the

@@ -17,6 +17,8 @@
 #include <utility>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "st_common.h"
 
 namespace ilupp {
@@ -613,6 +615,80 @@ bool grid_llt_schedule(hipStream_t st, int32_t n, const GridDims &g, int max_lan
         }
     }
     return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The row-major copy of an LL^T factor whose pattern is the grid's lower triangle, stored by columns (ICholT(0, 0) on the speculative
+// static path, api.hip): row i of the copy is l(i, i - nx ny), l(i, i - nx), l(i, i - 1), l(i, i) -- column j holds l(j, j), then the
+// entries below it in the order + 1, + nx, + nx ny as far as the grid has them, so where l(i, j) sits in column j follows from j's
+// coordinates.  No sort, no atomics; every fetched index is compared with the row it must be (a factor whose pattern is not the
+// grid's raises the flag and the general transposition runs).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_llt_grid_rowcount(const int32_t n, const GridDims g, int32_t *__restrict__ cnt)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { cnt[n] = 0; return; }
+    const unsigned r = (unsigned)i, l = r / (unsigned)g.nx, x = r - l * (unsigned)g.nx, z = l / (unsigned)g.ny, y = l - z * (unsigned)g.ny;
+    cnt[i] = 1 + (x > 0) + (y > 0) + (z > 0);
+}
+__global__ void k_llt_grid_rows(const int32_t n, const GridDims g, const int32_t *__restrict__ cptr, const int32_t *__restrict__ cidx,
+                                const double *__restrict__ cval, const int32_t *__restrict__ rptr, int32_t *__restrict__ ridx,
+                                double *__restrict__ rval, int32_t *__restrict__ bad)
+{
+    const long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ii >= n) return;
+    const int i = (int)ii;
+    const unsigned r = (unsigned)i, l = r / (unsigned)g.nx, x = r - l * (unsigned)g.nx, z = l / (unsigned)g.ny, y = l - z * (unsigned)g.ny;
+    const int sxy = g.nx * g.ny;
+    int out = rptr[i];
+    bool ok = true;
+    if (z > 0) {                                   // column j = (x, y, z - 1): behind its + 1 and + nx entries
+        const int j = i - sxy, q = cptr[j] + 1 + ((int)x < g.nx - 1) + ((int)y < g.ny - 1);
+        ok = ok && cidx[q] == i;
+        ridx[out] = j; rval[out] = cval[q]; ++out;
+    }
+    if (y > 0) {                                   // column j = (x, y - 1, z): behind its + 1 entry
+        const int j = i - g.nx, q = cptr[j] + 1 + ((int)x < g.nx - 1);
+        ok = ok && cidx[q] == i;
+        ridx[out] = j; rval[out] = cval[q]; ++out;
+    }
+    if (x > 0) {
+        const int j = i - 1, q = cptr[j] + 1;
+        ok = ok && cidx[q] == i;
+        ridx[out] = j; rval[out] = cval[q]; ++out;
+    }
+    {
+        const int q = cptr[i];
+        ok = ok && cidx[q] == i && cptr[i + 1] - q == 1 + ((int)x < g.nx - 1) + ((int)y < g.ny - 1) + ((int)z < g.nz - 1);
+        ridx[out] = i; rval[out] = cval[q];
+    }
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+// T's arrays are allocated by the caller (transpose_storage's sizes); false: the factor's pattern is not the grid's
+bool llt_grid_rows(hipStream_t st, const DevMat &Lc, const GridDims &g, DevMat *T)
+{
+    const int32_t n = Lc.n;
+    if ((int64_t)g.nx * g.ny * g.nz != n || n < 2) return false;
+    int32_t *cnt = nullptr, *flag = nullptr;
+    void *tmp = nullptr;
+    ILUPP_HIP(pool_malloc(&cnt, sizeof(int32_t) * ((size_t)n + 1)));
+    ILUPP_HIP(pool_malloc(&flag, 16));
+    ILUPP_HIP(hipMemsetAsync(flag, 0, 16, st));
+    hipLaunchKernelGGL(k_llt_grid_rowcount, dim3((unsigned)(((int64_t)n + 1 + 255) / 256)), dim3(256), 0, st, n, g, cnt);
+    size_t tb = 0;
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, T->ptr, n + 1, st));
+    ILUPP_HIP(pool_malloc(&tmp, tb > 0 ? tb : 16));
+    ILUPP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, T->ptr, n + 1, st));
+    hipLaunchKernelGGL(k_llt_grid_rows, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, st, n, g, Lc.ptr, Lc.idx, Lc.val, T->ptr, T->idx,
+                       T->val, flag);
+    int32_t h[2] = {1, 0};
+    ILUPP_HIP(d2h_async(st, h, flag, sizeof(int32_t)));
+    ILUPP_HIP(d2h_async(st, h + 1, T->ptr + n, sizeof(int32_t)));
+    ILUPP_HIP(stream_sync(st));
+    ILUPP_HIP(pool_free(tmp)); ILUPP_HIP(pool_free(cnt)); ILUPP_HIP(pool_free(flag));
+    return h[0] == 0 && (int64_t)h[1] == Lc.nnz;
 }
 
 }  // namespace ilupp

@@ -683,7 +683,7 @@ static bool transpose_short(hipStream_t st, const DevMat &A, DevMat *T)
     return h == 0;
 }
 
-void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
+void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T, const GridDims *llt_grid)
 {
     const int32_t n = A.n;
     const int64_t nnz = A.nnz;
@@ -692,6 +692,8 @@ void transpose_storage(hipStream_t st, const DevMat &A, DevMat *T)
     ILUPP_HIP(pool_malloc(&T->idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
     ILUPP_HIP(pool_malloc(&T->val, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)));
     static const bool no_short = getenv("ILUPP_NO_SHORT_TRANSPOSE") != nullptr;
+    // (a column-major LL^T factor with the grid's lower pattern: where every entry sits follows from the dimensions, grid.hip)
+    if (llt_grid && getenv("ILUPP_NO_LLT_GRID_ROWS") == nullptr && llt_grid_rows(st, A, *llt_grid, T)) return;
     if (!no_short && n >= 4096 && nnz > 0 && nnz <= 8 * (int64_t)n && transpose_short(st, A, T)) return;
     int32_t *rowid, *seq, *keys_out, *perm;
     const size_t eb = sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1);
