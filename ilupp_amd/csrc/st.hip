@@ -1883,7 +1883,8 @@ __global__ void __launch_bounds__(512)
 k_st_pack_pair(const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lidx, const double *__restrict__ Lval,
                const int32_t *__restrict__ Uptr, const int32_t *__restrict__ Uidx, const double *__restrict__ Uval,
                const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltabB, const int32_t *__restrict__ uslot,
-               const int32_t *__restrict__ wtab, v2d *__restrict__ pkL, v2d *__restrict__ pkU, int32_t *__restrict__ flags)
+               const int32_t *__restrict__ wtab, v2d *__restrict__ pkL, v2d *__restrict__ pkU, int32_t *__restrict__ flags,
+               const int fmt1, const int descB)
 {
     __shared__ StRuns SL, SU;
     const int w = blockIdx.x;
@@ -1903,7 +1904,15 @@ k_st_pack_pair(const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lid
     // (the rows of a lane's eight steps are consecutive rows of both factors: one run each)
     st_stage_runs(SL, Lidx, Lval, L, live && okL, q0, q1);
     st_stage_runs(SU, Uidx, Uval, L, live && okU, p0, p1);
-    if (!live) return;
+    if (!live) {
+        // (class-aligned records, st_wave.hip's format 1: the zero record wherever a lane has no row at a step of its wave)
+        if (fmt1 && c < nch) {
+            v2d z0, z1; z0.x = 0.0; z0.y = 0.0; z1.x = 0.0; z1.y = 1.0;
+            v2d *pz = pkL + ((size_t)base + c) * 128 + L; pz[0] = z0; pz[64] = z1;
+            pz = pkU + ((size_t)base + c) * 128 + L; pz[0] = z0; pz[64] = z1;
+        }
+        return;
+    }
     if (su < 0) { atomicOr(&flags[0], 64); return; }
     const int32_t *TB = ltabB + (size_t)su * kStTab;
     const double absent = st_dbl(kAbsent);
@@ -1935,6 +1944,24 @@ k_st_pack_pair(const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lid
         else { const double cv = st_clean(UV(q)); if (hit == 0) uv[0] = cv; else if (hit == 1) uv[1] = cv; else uv[2] = cv; }
     }
     if (bad) { atomicOr(&flags[0], 8); return; }
+    if (fmt1) {
+        // straight into the class-aligned form (what k_wx_convert<true> makes of the records by template position: a missing
+        // coefficient is +0.0, the coefficients sit where their dependency class puts them)
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            double *v = side == 0 ? lv : uv;
+            int cls[3]; bool ring[3];
+            (void)wr_classify(side == 0 ? T : TB, side == 0 ? (slot & 255) : (su & 255), side == 1, cls, ring);
+            double o[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (cls[j] != WR_NONE && st_bits(v[j]) != kAbsent) {
+                    const int sl = wr_slot_of(cls[j], side == 1 && !descB);
+                    if (sl == 0) o[0] = v[j]; else if (sl == 1) o[1] = v[j]; else o[2] = v[j];
+                }
+            v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
+        }
+    }
     v2d x;
     v2d *pl_ = pkL + ((size_t)base + c) * 128 + L;
     x.x = lv[0]; x.y = lv[1]; pl_[0] = x;
@@ -2013,9 +2040,11 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
     ILUPP_HIP(pool_malloc(&pl->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));
     ILUPP_HIP(pool_malloc(&pu->pk, (size_t)(pl->nchunks + 4 * nwg) * 2048));      // (both in the forward schedule's order)
     pl->built = true;
+    // (a pair whose lanes fit the wave-exchange classes gets its records class-aligned at once: no second pass over 2 GB)
+    const bool fmt1 = (hl[9] & ~8) == 0 && (hu[9] & ~8) == 0 && st_wx_on() && getenv("ILUPP_PACK_FMT0") == nullptr;
     hipLaunchKernelGGL(k_st_pack_pair, dim3((unsigned)(nwg * 4), (unsigned)((pl->max_chunks + 7) / 8)), dim3(512), 0, st, Lrow.ptr, Lrow.idx,
                        Lrow.val, Urow.ptr, Urow.idx, Urow.val, pl->ltab, pu->ltab, pu->uslot, pl->wtab, reinterpret_cast<v2d *>(pl->pk),
-                       reinterpret_cast<v2d *>(pu->pk), pl->flags);
+                       reinterpret_cast<v2d *>(pu->pk), pl->flags, fmt1 ? 1 : 0, bwd_desc ? 1 : 0);
     ILUPP_HIP(pool_malloc(&pl->ybuf, sizeof(double) * 64 * (size_t)(pl->nchunks + 4 * nwg)));
     ILUPP_HIP(pool_malloc(&pu->xlm, sizeof(double) * 64 * (size_t)(pu->nchunks + 4 * nwg)));
     pu->y_chunks = pl->nchunks + 4 * nwg;
@@ -2041,6 +2070,7 @@ bool st_analyse_pair(hipStream_t st, int32_t n, const DevMat &Lrow, const DevMat
     // a pair whose lanes fit the wave-exchange classes: class-aligned records, round 4's sweep kernels (neighbours in registers) with round
     // 5's vector wave; a backward sweep that accumulates in descending order (IChol0: T4) has its own instantiation (env ILUPP_NO_WR:
     // round 2's sweeps for every pair)
+    if (fmt1) pl->fmt = pu->fmt = 1;
     if (pl->wx && pu->wx && st_wx_on()) wx_convert_records(st, pl, pu, 1);
     return true;
 }
