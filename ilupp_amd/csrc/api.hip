@@ -325,7 +325,7 @@ static void arm_apply(ilupp_precond *p)
 {
     static const bool off = getenv("ILUPP_NO_ARM") != nullptr;
     if (off || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU && p->flm.built && p->flm.stat && p->pkL.valid && p->pkU.valid &&
-                 p->pkL.fmt == 1 && p->pkU.fmt == 1 && p->pkL.xch && p->pkU.xch && !p->degenerate)) return;
+                 p->pkL.fmt >= 1 && p->pkU.fmt == 1 && p->pkL.xch && p->pkU.xch && !p->degenerate)) return;
     hipLaunchKernelGGL(k_arm_apply, dim3(1024), dim3(256), 0, p->stream, p->ctrl, reinterpret_cast<unsigned long long *>(p->pkL.xch),
                        (long long)p->pkL.xch_len, reinterpret_cast<unsigned long long *>(p->pkU.xch), (long long)p->pkU.xch_len, kSentinel);
     if (hipGetLastError() != hipSuccess) return;
@@ -688,7 +688,7 @@ static bool static_transposed_ready(ilupp_precond *p)
     const bool ok = st_build_transposed(p->stream, p->sA, p->n, p->flm, &p->pkL, &p->pkU, p->Lc.nnz - p->n, p->Uc.nnz - p->n);
     wx_convert_records(p->stream, &p->pkL, &p->pkU, fmt);
     // (an object whose own sweeps are the wave-exchange ones gets them for the transposed apply as well)
-    if (ok && fmt == 1) wx_convert_transposed(p->stream, &p->pkL, &p->pkU);
+    if (ok && fmt >= 1) wx_convert_transposed(p->stream, &p->pkL, &p->pkU);
     if (ok) return true;
     p->no_static_T = true;
     return false;
@@ -1573,10 +1573,11 @@ const char *ilupp_hip_kernel_names(const ilupp_precond *p)
     }
     if (!p || !(p->kind == KIND_LU && p->nnz_mode == NNZ_GENERIC_LU && p->flm.built && p->flm.stat)) return "";
     static thread_local std::string lu_names;
-    if (p->pkL.fmt == 1) {
+    if (p->pkL.fmt >= 1) {
         const bool vec = wx_vec_on() && p->pkL.vec_ok && p->pkU.vec_ok;
         lu_names = std::string(p->flm.wxf ? wx_factor_kernel_name() : "k_ilu0_sd") +
-                   (vec ? ";k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>" : ";k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>");
+                   (p->pkL.fmt == 2 ? ";k_sptrsv_wv<1, false, false, true>;k_sptrsv_wv<-1, true>"
+                    : vec ? ";k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>" : ";k_sptrsv_wx<1, false>;k_sptrsv_wx<-1, true>");
         return lu_names.c_str();
     }
     return p->flm.direct ? "k_ilu0_sd;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>" : "k_ilu0_st;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>";

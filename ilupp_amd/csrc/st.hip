@@ -1812,7 +1812,7 @@ int sptrsv_st(hipStream_t st, const PackedSweep &ps, const Schedule &sch, int32_
               int32_t *d_ticket, int32_t *d_err, double *ypk_out, const double *ypk_in, const int32_t *ysrc)
 {
     (void)sch;
-    if (ps.fmt == 1) return sptrsv_wx(st, ps, n, rhs, out, d_ticket, d_err, ypk_out, ypk_in, ysrc);
+    if (ps.fmt >= 1) return sptrsv_wx(st, ps, n, rhs, out, d_ticket, d_err, ypk_out, ypk_in, ysrc);
     const bool fwd = ps.kind == (int)SWEEP_FWD_LAST_ASC;
     double *lml = fwd ? ypk_out : const_cast<double *>(ypk_in);        // level-major, forward order
     if (!lml || (!fwd && (!ysrc || !ps.xlm))) { set_error("static sweep without its level-major vector"); return ILUPP_ERR_INVALID; }

@@ -113,8 +113,32 @@ k_wx_convert(const int32_t *__restrict__ ltabF, const int32_t *__restrict__ ltab
     }
 }
 
+// format 2 -> format 1 for the L records: a wave per chunk, {lA} at 1024 + 8 lane becomes {lA, 1} at 1024 + 16 lane (every lane has read
+// before any lane writes: the loads of a wave's instruction are issued before its next instruction's stores, which need their data)
+__global__ void __launch_bounds__(512)
+k_wx_expand_l(const int32_t *__restrict__ wtab, unsigned char *__restrict__ pkL)
+{
+    const int w = blockIdx.x;
+    const int c = blockIdx.y * 8 + (threadIdx.x >> 6);
+    const int L = threadIdx.x & 63;
+    const int base = wtab[(size_t)w * 4], nch = wtab[(size_t)w * 4 + 2];
+    if (c >= nch) return;
+    unsigned char *ch = pkL + ((size_t)base + c) * 2048 + 1024;
+    const double lA = *reinterpret_cast<const double *>(ch + 8 * L);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    v2d x; x.x = lA; x.y = 1.0;
+    *reinterpret_cast<v2d *>(ch + 16 * L) = x;
+}
+
 void wx_convert_records(hipStream_t st, PackedSweep *pl, PackedSweep *pu, int to_fmt)
 {
+    if (to_fmt == 2) to_fmt = 1;                     // (nobody but the factor kernel makes compact records: an object that left them stays on format 1)
+    if (pl->fmt == 2) {
+        const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
+        hipLaunchKernelGGL(k_wx_expand_l, grid, dim3(512), 0, st, pl->wtab, reinterpret_cast<unsigned char *>(pl->pk));
+        ILUPP_HIP(hipGetLastError());
+        pl->fmt = 1;
+    }
     if (pl->fmt == to_fmt && pu->fmt == to_fmt) return;
     const dim3 grid((unsigned)(pl->nwg * 4), (unsigned)((pl->max_chunks + 7) / 8));
     if (to_fmt == 1)
@@ -190,7 +214,10 @@ __device__ __forceinline__ bool wx_lane_setup(const int32_t *T, const int t, con
 static constexpr int kVecPitch = 34 * 8;                  // bytes of a lane's 32 ring entries (+ 2: the lanes of a wave spread over the banks)
 static constexpr int kVecRing = kThreads * kVecPitch;
 
-template <int DR, bool DIV, bool VEC, bool DESC = false>
+// CL: the forward sweep of a unit lower factor on COMPACT records (format 2: the second piece of a record is the one coefficient lA, 8 bytes
+// per lane at 1024 + 8 lane of the chunk; the constant 1 of format 1's {lA, 1} is neither stored nor fetched: 12 memory lines per chunk
+// instead of 16)
+template <int DR, bool DIV, bool VEC, bool DESC = false, bool CL = false>
 __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *xh, const int wg, const WxLane W, const int tlo, const int thi,
                                               unsigned char *vr)
 {
@@ -222,6 +249,8 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
                            : (unsigned)((ysrc_ >> 6) + sk - tlo) * 512u + (unsigned)(ysrc_ & 63) * 8u;
     unsigned vout = (unsigned)(tlo - tminw) * 512u + (unsigned)ln * 8u;
     constexpr unsigned dRec = DR > 0 ? 2048u : 0u - 2048u, dRhs = DR > 0 ? 512u : 0u - 512u;
+    static_assert(!CL || (DR > 0 && !DIV), "compact records: the forward sweep of a unit lower factor");
+    const unsigned cl2 = 1024u - (unsigned)ln * 8u;                       // (CL) from a lane's first piece to its second
 
     typedef double v2dd __attribute__((ext_vector_type(2)));
     typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
@@ -233,7 +262,8 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
 #define WXS_LOAD(u)                                                                                    \
     do {                                                                                               \
         ra[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rrec, vrec, 0, 0);                            \
-        ra[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rrec, vrec + 1024u, 0, 0);                    \
+        if (CL) { const v2u_ c_ = __builtin_amdgcn_raw_buffer_load_b64(rrec, vrec + cl2, 0, 0); ra[u][1].x = c_.x; ra[u][1].y = c_.y; } \
+        else ra[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rrec, vrec + 1024u, 0, 0);               \
         if (!(VEC && DR > 0)) rr[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rrhs, vrhs, 0, 0)); \
         vrec += dRec; vrhs += dRhs;                                                                    \
     } while (0)
@@ -284,7 +314,7 @@ __device__ __forceinline__ void wx_sweep_wave(const StSArgs &A, unsigned char *x
             double x = DIV ? acc / c2d.y : acc;
             // (the forward sweep does not divide: the register of the diagonal stays taken until here all the same -- a dead quarter of a
             // 16-byte load is a free register to the allocator, and what it puts there has to wait for that load, a load of a later step)
-            if (!DIV) asm volatile("" :: "v"(c2d.y));
+            if (!DIV && !CL) asm volatile("" :: "v"(c2d.y));
             x = (valid && x == x) ? x : alt;
 #ifndef WX_X_NOLDSW
             *reinterpret_cast<double *>(xh + (unsigned)t * 8 + (unsigned)(u % kStH) * (kWxRow * 8)) = x;
@@ -548,7 +578,7 @@ __device__ __forceinline__ void wx_vector(const StSArgs &A, unsigned char *vr, V
     }
 }
 
-template <int DR, bool DIV, bool VEC, bool DESC = false>
+template <int DR, bool DIV, bool VEC, bool DESC = false, bool CL = false>
 __device__ __forceinline__ void wx_sweep_body(const StSArgs &A, unsigned char *vr)
 {
     __shared__ __attribute__((aligned(16))) unsigned char xh[kWxLds];
@@ -592,7 +622,7 @@ __device__ __forceinline__ void wx_sweep_body(const StSArgs &A, unsigned char *v
         for (int i = t; i < 2 * kStH * kWxRow; i += kThreads) reinterpret_cast<double *>(xh)[i] = 0.0;
         __syncthreads();
         if ((t == 0 && s_total > 64) || !ok) atomicExch(A.err, 1);    // (the analysis does not let such a schedule through)
-        wx_sweep_wave<DR, DIV, VEC, DESC>(A, xh, wg, W, tlo, thi, vr);
+        wx_sweep_wave<DR, DIV, VEC, DESC, CL>(A, xh, wg, W, tlo, thi, vr);
     } else if (VEC && t >= kThreads + 64) {
         __syncthreads();                                              // (the lanes' fields are in s_vec)
         __syncthreads();
@@ -620,12 +650,12 @@ k_sptrsv_wx(StSArgs A)
     wx_sweep_body<DR, DIV, false, DESC>(A, nullptr);
 }
 // ... with the vector wave: the caller's vector where it lies (A.nat)
-template <int DR, bool DIV, bool DESC = false>
+template <int DR, bool DIV, bool DESC = false, bool CL = false>
 __global__ void __launch_bounds__(kStWgThreads + 64)
 k_sptrsv_wv(StSArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wv_ring[];
-    wx_sweep_body<DR, DIV, true, DESC>(A, wv_ring);
+    wx_sweep_body<DR, DIV, true, DESC, CL>(A, wv_ring);
 }
 
 bool wx_vec_on()
@@ -650,6 +680,7 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
     // the caller's vector where it lies, through the vector wave (the forward sweep reads `rhs`, the backward sweep writes `out`);
     // ILUPP_NO_VECWAVE=1, or a schedule with more than 16 lanes in a phase: through the level-major copies that k_st_vec makes (round 4)
     const bool vec = wx_vec_on() && ps.vec_ok;
+    if (ps.fmt == 2 && !(vec && fwd && !ps.pair)) { set_error("compact records without their sweep"); return ILUPP_ERR_INTERNAL; }
     a.nat = fwd ? const_cast<double *>(rhs) : out;
     if (ps.xch_armed) ps.xch_armed = false;
     else fill_u64(st, reinterpret_cast<unsigned long long *>(ps.xch), ps.xch_len, kSentinel);
@@ -665,12 +696,14 @@ int sptrsv_wx(hipStream_t st, const PackedSweep &ps, int32_t n, const double *rh
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wx<-1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStSoloLds));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<-1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
+            ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_sptrsv_wv<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVecDyn));
         });
     }
     const dim3 grid((unsigned)ps.nwg);
     if (vec) {
         if (fwd && ps.pair) hipLaunchKernelGGL((k_sptrsv_wv<1, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
+        else if (fwd && ps.fmt == 2) hipLaunchKernelGGL((k_sptrsv_wv<1, false, false, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
         else if (fwd) hipLaunchKernelGGL((k_sptrsv_wv<1, false>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
         else if (ps.pair && ps.desc) hipLaunchKernelGGL((k_sptrsv_wv<-1, true, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
         else hipLaunchKernelGGL((k_sptrsv_wv<-1, true>), grid, dim3(kStWgThreads + 64), kVecDyn, st, a);
@@ -1475,6 +1508,9 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
     const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.pkL + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(A.pkU + (size_t)base * 2048, 0, nchw * 2048, 0x00020000);
     unsigned vout = (unsigned)(tlo - tminw) * 2048u + (unsigned)ln * 16u;
+    const bool compactL = (A.flags & 8) != 0;
+    const unsigned cl2 = 1024u - (unsigned)ln * 8u;
+    typedef unsigned int v2w2_ __attribute__((ext_vector_type(2)));
     const unsigned xown = C::X + (unsigned)t * 8u, tbown = C::TB + (unsigned)t * 8u, tcown = C::TC + (unsigned)t * 8u;
     // (RP) the lane's stored pivot of step s_: write-through by the chain, 1 where the lane had no row or the wave no chunk
     typedef unsigned int v4w_ __attribute__((ext_vector_type(4)));
@@ -1642,7 +1678,9 @@ __device__ __forceinline__ void wa_consumer(const WfArgs &A, unsigned char *lds,
                 ua.x = uA; ua.y = c2_.y; ub.x = c3_.x; ub.y = w3;
                 if (MODE == 0 || RP) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, la), rL, vout, 0, 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vout + 1024u, 0, 2);
+                    // (flags bit 3: compact L records -- lA alone, 8 bytes per lane: four memory lines of a step's sixteen less)
+                    if (compactL) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2w2_, lA), rL, vout + cl2, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, lb), rL, vout + 1024u, 0, 2);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, ua), rU, vout, 0, 2);
                 }
                 if (RP) {
@@ -2564,6 +2602,10 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     }
     if (pl->join_ev && pl->join_before) ILUPP_HIP(hipStreamWaitEvent(st, pl->join_ev, 0));       // (grid.hip's proof, on its side stream)
     ILUPP_HIP(hipEventRecord(e0, st));
+    // compact L records when the L sweep that reads them will run (the vector-wave sweep: ILUPP_NO_COMPACT_L=1 for format 1)
+    static const bool no_compact = getenv("ILUPP_NO_COMPACT_L") != nullptr;
+    const bool compact = wa_on() && wd_mode() != 1 && !no_compact && wx_vec_on() && pl->vec_ok && pu->vec_ok;
+    if (compact) a.flags |= 8;
     if (wa_on()) {
         typedef WaCfg<4, 4> C;
         // (MODE 2 -- the chains store a quarter of the records, replays by the workgroups whose tile has ended write the rest -- is an
@@ -2583,7 +2625,7 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     ILUPP_HIP(d2h_async(st, ctrl, d_ctrl, sizeof(ctrl)));
     if (pl->arm && pl->arm_ev) {
         // (the first apply's control words and exchange buffers are made ready behind the read-back, while the host is on its way back)
-        pl->fmt = pu->fmt = 1;                       // (what the kernel in flight writes)
+        pl->fmt = compact ? 2 : 1; pu->fmt = 1;      // (what the kernel in flight writes)
         ILUPP_HIP(hipEventRecord(pl->arm_ev, st));
         pl->arm(pl->arm_ctx);
         ILUPP_HIP(event_sync(st, pl->arm_ev));
@@ -2593,7 +2635,7 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
     pl->join_verdict = ctrl[8];
     if (kernel_ms) ILUPP_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
     if (ctrl[1] != 0) return ILUPP_ERR_TIMEOUT;
-    pl->fmt = pu->fmt = 1;
+    pl->fmt = compact ? 2 : 1; pu->fmt = 1;
     return ILUPP_OK;
 }
 

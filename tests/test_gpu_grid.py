@@ -127,7 +127,7 @@ def test_every_switch_of_the_grid_path_gives_the_same_bits():
     info, ref = _run_with({})
     assert all(l.startswith("grid") and "k_sptrsv_wv<1, false>" in l for l in info), info
     for env in ({"ILUPP_NO_GRID": "1"}, {"ILUPP_GRID_TABLES": "0"}, {"ILUPP_GRID_LINK": "0"}, {"ILUPP_NO_SPEC": "1"}, {"ILUPP_GRID_CHECK_AT": "1"},
-                {"ILUPP_GRID_CHECK_AT": "2"}, {"ILUPP_NO_VECWAVE": "1"}, {"ILUPP_NO_ARM": "1"}):
+                {"ILUPP_GRID_CHECK_AT": "2"}, {"ILUPP_NO_VECWAVE": "1"}, {"ILUPP_NO_ARM": "1"}, {"ILUPP_NO_COMPACT_L": "1"}):
         info2, dig = _run_with(env)
         assert dig == ref, (env, info2)
         if "ILUPP_NO_GRID" in env:

@@ -46,8 +46,8 @@ def _arrow():
 
 
 CASES = [
-    ("box grid 64x48x40", lambda: matgen.poisson3d(64, 48, 40), "ilu0:static-direct", "k_ilu0_wa<0, 4, 4>;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>"),
-    ("2-D grid below the grid analysis' size", lambda: matgen.poisson2d(300, 300), "ilu0:static-direct", "k_ilu0_wa<0, 4, 4>;k_sptrsv_wv<1, false>;k_sptrsv_wv<-1, true>"),
+    ("box grid 64x48x40", lambda: matgen.poisson3d(64, 48, 40), "ilu0:static-direct", "k_ilu0_wa<0, 4, 4>;k_sptrsv_wv<1, false, false, true>;k_sptrsv_wv<-1, true>"),
+    ("2-D grid below the grid analysis' size", lambda: matgen.poisson2d(300, 300), "ilu0:static-direct", "k_ilu0_wa<0, 4, 4>;k_sptrsv_wv<1, false, false, true>;k_sptrsv_wv<-1, true>"),
     ("chains without side neighbours", _tridiagonal_blocks, "ilu0:static-direct", "k_ilu0_sd;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>"),
     ("mesh with missing transposed entries", _mesh_missing_upper, "ilu0:static-level-major", "k_ilu0_st;k_sptrsv_st<1, false>;k_sptrsv_st<-1, false>"),
     ("mesh with holes", _mesh_with_holes, "ilu0:level-order", ""),          # (round 6: short rows, but 94 levels of 340 rows)

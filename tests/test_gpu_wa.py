@@ -76,6 +76,7 @@ _VARIANTS = {
     "no-prefetch": {"ILUPP_NO_PREFETCH": "1"},
     "replay": {"ILUPP_REPLAY": "1"},
     "xcd": {"ILUPP_XCD_TICKETS": "1"},
+    "format1": {"ILUPP_NO_COMPACT_L": "1"},      # L's records as {lA, 1} pairs (round 6's default leaves the constant out: format 2)
 }
 
 
@@ -98,7 +99,7 @@ def reference_run():
     return _run("old")
 
 
-@pytest.mark.parametrize("variant", ["default", "no-prefetch", "replay", "xcd"])
+@pytest.mark.parametrize("variant", ["default", "no-prefetch", "replay", "xcd", "format1"])
 def test_every_variant_gives_the_old_kernels_bits(variant, reference_run):
     got = _run(variant)
     assert set(got) == set(reference_run)
@@ -107,7 +108,7 @@ def test_every_variant_gives_the_old_kernels_bits(variant, reference_run):
         assert "oracle=False" not in line, line
     # the kernel the objects name is the variant's
     some = next(v[1] for k, v in got.items() if k.startswith("7pt"))
-    want = {"default": "k_ilu0_wa<0, 4, 4>", "no-prefetch": "k_ilu0_wa<0, 4, 4>", "xcd": "k_ilu0_wa<0, 4, 4>", "replay": "k_ilu0_wa<2, 4, 4>"}[variant]
+    want = {"default": "k_ilu0_wa<0, 4, 4>", "no-prefetch": "k_ilu0_wa<0, 4, 4>", "xcd": "k_ilu0_wa<0, 4, 4>", "replay": "k_ilu0_wa<2, 4, 4>", "format1": "k_ilu0_wa<0, 4, 4>"}[variant]
     assert want in some, some
 
 
