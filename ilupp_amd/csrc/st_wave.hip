@@ -2542,6 +2542,18 @@ const char *wx_factor_kernel_name()
     return getenv("ILUPP_REPLAY") != nullptr ? "k_ilu0_wa<2, 4, 4>" : "k_ilu0_wa<0, 4, 4>";
 }
 
+// what the factor kernel finds prepared, in ONE launch (three small launches in a row cost their dispatch gaps, and this chain -- not the
+// proof beside it -- is what the analysis phase of a box grid lasts): the control words zero, the tiles' progress and claim words -1,
+// the exchange buffer all-sentinel
+__global__ void k_wa_prepare(int32_t *__restrict__ ctrl, int32_t *__restrict__ prog, const int nprog, unsigned long long *__restrict__ xch,
+                             const long long nx)
+{
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (i0 < 4) ctrl[i0] = 0;
+    for (long long i = i0; i < nprog; i += stride) prog[i] = -1;
+    for (long long i = i0; i < nx; i += stride) xch[i] = kSentinel;
+}
+
 int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSweep *pu, int32_t *d_ctrl, float *kernel_ms,
                     hipEvent_t e0, hipEvent_t e1)
 {
@@ -2557,8 +2569,6 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
             ILUPP_HIP(hipFuncSetAttribute((const void *)k_ilu0_wa<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C44::Lds));
         });
     }
-    ILUPP_HIP(hipMemsetAsync(d_ctrl, 0, 16, st));
-    fill_u64(st, reinterpret_cast<unsigned long long *>(pl->xch), pl->xch_len, kSentinel);
     WfArgs a;
     a.ltab = pl->ltab; a.ltabB = pu->ltab; a.uslot = pu->uslot; a.wtab = pl->wtab;
     const uintptr_t vp = reinterpret_cast<uintptr_t>(A.val);
@@ -2583,7 +2593,13 @@ int ilu0_numeric_wx(hipStream_t st, const DevMat &A, PackedSweep *pl, PackedSwee
             cap[d] = 3 * (int64_t)pl->nwg;
         }
         a.prog = buf[d];
-        ILUPP_HIP(hipMemsetAsync(a.prog, 0xff, sizeof(int32_t) * 3 * (size_t)pl->nwg, st));
+    }
+    {
+        long long blocks = ((long long)pl->xch_len + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_wa_prepare, dim3((unsigned)blocks), dim3(256), 0, st, d_ctrl, a.prog, a.prog ? 3 * (int)pl->nwg : 0,
+                           reinterpret_cast<unsigned long long *>(pl->xch), (long long)pl->xch_len);
     }
     {
         // does the chip hold every workgroup of the launch at once?  (Then the prefetchers stay behind their own tile's end, for the
